@@ -1,0 +1,160 @@
+/*
+ * sd-mi355x.h — C ABI of the MI355X denoise + VAE-decode engine (libsdcpp-host.so).
+ *
+ * This is the host-facing slice of the reference's public C API (include/stable-diffusion.h) that the
+ * hot path touches, with the same names / argument meaning / error behaviour where a counterpart
+ * exists, and plain pointers + sizes everywhere (no C++ / torch types).  What differs, and why:
+ *   - text encoders are out of scope ("synthetic prompts"), so conditioning enters
+ *     as tensors (`sd_condition_t`) instead of prompt strings — the SDCondition struct of
+ *     src/conditioning/conditioner.hpp:18-34;
+ *   - weights are synthetic (random-init of the named architecture) unless the caller overwrites
+ *     tensors by name with sd_set_tensor (checkpoint readers are a "next" row).
+ *
+ * All compute goes through ggml's backend plug-in interface (include/ggml-abi.h).  The engine loads
+ * libggml-mi355x.so and FAILS (returns NULL) if it or a gfx950 device is missing — there is no CPU
+ * fallback in the product.  Tests may register another backend plug-in (the CPU oracle) explicitly
+ * through sd_load_backend() and select it by name.
+ *
+ * reference counterpart                          -> this header
+ *   sd_ctx_params_t   stable-diffusion.h:192-238 -> sd_ctx_params_t (fields the hot path reads)
+ *   sd_sample_params_t                 :276-287  -> sd_sample_params_t
+ *   new_sd_ctx / free_sd_ctx           :482-485  -> new_sd_ctx / free_sd_ctx
+ *   generate_image                     :493-496  -> generate_image (batch_count images, seeds seed+b)
+ *   free_sd_images                     :595-597  -> free_sd_images
+ *   sd_image_t                         :258-263  -> sd_image_t
+ *   sd_set_backend_eval_callback       :442-447  -> (sub-graph views are honoured by the backend)
+ */
+#ifndef SD_MI355X_H
+#define SD_MI355X_H
+
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SD_API __attribute__((visibility("default")))
+
+enum sd_model_family_t {
+    SD_MODEL_SD15       = 0, /* UNetConfig defaults, unet.hpp:16-35; VAE 4ch scale 0.18215 */
+    SD_MODEL_SDXL       = 1, /* unet.hpp:47-57; VAE scale 0.13025 */
+    SD_MODEL_SD15_TINY  = 2, /* same topology, model_channels 32 — CPU-sized parity tests */
+    SD_MODEL_SDXL_TINY  = 3,
+};
+
+/* numeric values = enum ggml_type (stable-diffusion.h:98-143) */
+enum sd_type_t {
+    SD_TYPE_F32  = 0,
+    SD_TYPE_F16  = 1,
+    SD_TYPE_Q4_0 = 2,
+    SD_TYPE_Q8_0 = 8,
+    SD_TYPE_BF16 = 30,
+};
+
+enum sample_method_t { EULER_SAMPLE_METHOD = 0, EULER_A_SAMPLE_METHOD = 1 };
+enum scheduler_t { DISCRETE_SCHEDULER = 0 };
+
+typedef struct {
+    const char* backend;        /* ggml device name, case-insensitive; NULL -> "MI355X0" (stable-diffusion.h:232) */
+    enum sd_model_family_t model;
+    enum sd_type_t wtype;       /* Linear weight type (conv stays f16, norms/bias f32 — SURVEY.md F9) */
+    bool diffusion_flash_attn;  /* stable-diffusion.h:223 */
+    bool diffusion_conv_direct; /* stable-diffusion.h:225 */
+    bool vae_decode_only;       /* always true here */
+    uint64_t weight_seed;       /* synthetic-weight seed (1234) */
+    int n_threads;              /* only reaches CPU backends (ggml_extend.hpp:2838-2843) */
+} sd_ctx_params_t;
+
+typedef struct {
+    float txt_cfg;              /* cfg scale (7.0 default, stable-diffusion.cpp:3650-3667) */
+    enum scheduler_t scheduler;
+    enum sample_method_t sample_method;
+    int sample_steps;
+    float eta;                  /* INFINITY -> 1.0 for Euler-A (stable-diffusion.cpp:4024-4049) */
+} sd_sample_params_t;
+
+/* SDCondition (conditioner.hpp:18-34): c_crossattn [ctx_dim, n_tokens], c_vector [adm] (SDXL) */
+typedef struct {
+    const float* c_crossattn;
+    int64_t ctx_dim, n_tokens;
+    const float* c_vector; /* NULL for SD1.x */
+    int64_t vector_dim;
+} sd_condition_t;
+
+typedef struct {
+    sd_condition_t cond;
+    sd_condition_t uncond;      /* used iff txt_cfg != 1 (stable-diffusion.cpp:4249) */
+    int width, height;          /* pixels; latent = /8 */
+    sd_sample_params_t sample_params;
+    int64_t seed;
+    int batch_count;            /* images seed .. seed+batch_count-1 (stable-diffusion.cpp:5664-5683) */
+    int device_batch;           /* OUR extension: images denoised together per graph; 0 -> batch_count */
+    bool decode;                /* run the VAE and return pixels; false -> latents only */
+} sd_img_gen_params_t;
+
+typedef struct {
+    uint32_t width, height, channel;
+    uint8_t* data;
+} sd_image_t;
+
+typedef struct sd_ctx_t sd_ctx_t;
+
+/* ---- backend discovery (GGML_BACKEND_DL) ---- */
+SD_API bool sd_load_backend(const char* path); /* dlopen a libggml-<name>.so and register its devices */
+SD_API int sd_device_count(void);
+SD_API const char* sd_device_name(int i);
+SD_API const char* sd_device_description(int i);
+
+/* ---- context ---- */
+SD_API void sd_ctx_params_init(sd_ctx_params_t* p);
+SD_API void sd_sample_params_init(sd_sample_params_t* p);
+SD_API void sd_img_gen_params_init(sd_img_gen_params_t* p);
+SD_API sd_ctx_t* new_sd_ctx(const sd_ctx_params_t* params); /* NULL on failure (no device, alloc failure) */
+SD_API void free_sd_ctx(sd_ctx_t* ctx);
+SD_API const char* sd_last_error(void);
+
+/* ---- weights by name ("model.diffusion_model.<...>", "first_stage_model.<...>") ---- */
+SD_API int64_t sd_tensor_count(sd_ctx_t* ctx);
+SD_API const char* sd_tensor_name(sd_ctx_t* ctx, int64_t i);
+/* ne[4], ggml type; returns false if unknown */
+SD_API bool sd_tensor_info(sd_ctx_t* ctx, const char* name, int64_t* ne, int* type, size_t* nbytes);
+SD_API bool sd_get_tensor(sd_ctx_t* ctx, const char* name, void* dst, size_t nbytes);       /* raw bytes (device -> host) */
+SD_API bool sd_get_tensor_f32(sd_ctx_t* ctx, const char* name, float* dst, int64_t nelem);  /* dequantised */
+SD_API bool sd_set_tensor_f32(sd_ctx_t* ctx, const char* name, const float* src, int64_t nelem); /* converts per stored type */
+
+/* ---- the hot path ---- */
+/* one diffusion-model forward (DiffusionModelRunner::compute, unet.hpp:818-858): x [W,H,C,N] f32,
+ * timesteps [N], context [ctx_dim,n_tokens,N or 1], y [adm,N or 1] or NULL -> out [W,H,C,N] */
+SD_API bool sd_unet_forward(sd_ctx_t* ctx, const float* x, int w, int h, int c, int n, const float* timesteps,
+                            const float* context, int64_t ctx_dim, int64_t n_tokens, int64_t ctx_n,
+                            const float* y, int64_t y_dim, int64_t y_n, float* out);
+/* VAE decode_first_stage (stable-diffusion.cpp:3062-3078): latents [w,h,zc,n] (diffusion scale) -> rgb f32 [8w,8h,3,n] in [0,1] */
+SD_API bool sd_vae_decode(sd_ctx_t* ctx, const float* latents, int w, int h, int c, int n, float* out_rgb);
+/* sample(): init noise (Philox seed+b) -> Euler(-A) loop with CFG -> final latents [w,h,c,batch_count] */
+SD_API bool sd_sample_latents(sd_ctx_t* ctx, const sd_img_gen_params_t* p, float* out_latents);
+/* generate_image: sample + decode + uint8 RGB.  Caller frees with free_sd_images (library callocs). */
+SD_API bool generate_image(sd_ctx_t* ctx, const sd_img_gen_params_t* p, sd_image_t** images_out, int* num_images_out);
+SD_API void free_sd_images(sd_image_t* images, int num_images);
+
+/* ---- host-side sampler pieces exposed for known-answer tests ---- */
+SD_API void sd_philox_randn(uint64_t seed, uint32_t offset, uint32_t n, float* out); /* rng_philox.hpp:101-122 */
+SD_API int sd_get_sigmas(int steps, float* out /* steps+1 */);                       /* denoiser.hpp:32-54 + stable-diffusion.cpp:173-186 */
+SD_API float sd_sigma_to_t(float sigma);                                             /* denoiser.hpp:1140-1165 */
+
+/* ---- timing / introspection ---- */
+typedef struct {
+    double last_sample_ms;  /* denoise loop wall time of the last sd_sample_latents / generate_image */
+    double last_decode_ms;  /* VAE decode wall time */
+    int64_t unet_calls;     /* graph computes issued */
+    int64_t graph_nodes;    /* nodes in the last UNet graph */
+    size_t compute_buffer_bytes;
+    size_t weight_bytes;
+} sd_stats_t;
+SD_API void sd_get_stats(sd_ctx_t* ctx, sd_stats_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

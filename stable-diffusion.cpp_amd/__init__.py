@@ -1,0 +1,441 @@
+"""stable-diffusion.cpp_amd — ctypes binding of the MI355X denoise + VAE-decode engine.
+
+The product is native: libsdcpp-host.so (C++ host: graph front-end, UNet/VAE graph builders, sampler,
+the C ABI of include/sd-mi355x.h) and libggml-mi355x.so (the hand-written HIP ggml backend for gfx950).
+This module only marshals numpy buffers across that C ABI; it performs no arithmetic.
+
+The directory name contains a '.', so import it through `sdcpp_amd_loader.load()` (repo root) or
+importlib (see __graft_entry__.py); inside Python it is registered as module `sdcpp_amd`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+PKG_DIR = Path(__file__).resolve().parent
+ROOT = PKG_DIR.parent
+LIB_DIR = PKG_DIR / "lib"
+HOST_LIB = LIB_DIR / "libsdcpp-host.so"
+BACKEND_LIB = LIB_DIR / "libggml-mi355x.so"
+
+# ggml_type numeric values (include/ggml-abi.h)
+F32, F16, Q4_0, Q8_0, I32, BF16 = 0, 1, 2, 8, 26, 30
+TYPE_SIZE = {F32: 4, F16: 2, BF16: 2, I32: 4}
+
+# sd_model_family_t
+SD15, SDXL, SD15_TINY, SDXL_TINY = 0, 1, 2, 3
+EULER, EULER_A = 0, 1
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+class GgmlTensor(C.Structure):
+    """struct ggml_tensor (include/ggml-abi.h) — read-only view for tests."""
+    _fields_ = [
+        ("type", C.c_int),
+        ("buffer", C.c_void_p),
+        ("ne", C.c_int64 * 4),
+        ("nb", C.c_size_t * 4),
+        ("op", C.c_int),
+        ("op_params", C.c_int32 * 16),
+        ("flags", C.c_int32),
+        ("src", C.c_void_p * 10),
+        ("view_src", C.c_void_p),
+        ("view_offs", C.c_size_t),
+        ("data", C.c_void_p),
+        ("name", C.c_char * 160),
+        ("extra", C.c_void_p),
+        ("padding", C.c_char * 8),
+    ]
+
+
+class GgmlInitParams(C.Structure):
+    _fields_ = [("mem_size", C.c_size_t), ("mem_buffer", C.c_void_p), ("no_alloc", C.c_bool)]
+
+
+class SdCtxParams(C.Structure):
+    _fields_ = [
+        ("backend", C.c_char_p),
+        ("model", C.c_int),
+        ("wtype", C.c_int),
+        ("diffusion_flash_attn", C.c_bool),
+        ("diffusion_conv_direct", C.c_bool),
+        ("vae_decode_only", C.c_bool),
+        ("weight_seed", C.c_uint64),
+        ("n_threads", C.c_int),
+    ]
+
+
+class SdSampleParams(C.Structure):
+    _fields_ = [("txt_cfg", C.c_float), ("scheduler", C.c_int), ("sample_method", C.c_int),
+                ("sample_steps", C.c_int), ("eta", C.c_float)]
+
+
+class SdCondition(C.Structure):
+    _fields_ = [("c_crossattn", C.POINTER(C.c_float)), ("ctx_dim", C.c_int64), ("n_tokens", C.c_int64),
+                ("c_vector", C.POINTER(C.c_float)), ("vector_dim", C.c_int64)]
+
+
+class SdImgGenParams(C.Structure):
+    _fields_ = [("cond", SdCondition), ("uncond", SdCondition), ("width", C.c_int), ("height", C.c_int),
+                ("sample_params", SdSampleParams), ("seed", C.c_int64), ("batch_count", C.c_int),
+                ("device_batch", C.c_int), ("decode", C.c_bool)]
+
+
+class SdImage(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("channel", C.c_uint32), ("data", C.POINTER(C.c_uint8))]
+
+
+class SdStats(C.Structure):
+    _fields_ = [("last_sample_ms", C.c_double), ("last_decode_ms", C.c_double), ("unet_calls", C.c_int64),
+                ("graph_nodes", C.c_int64), ("compute_buffer_bytes", C.c_size_t), ("weight_bytes", C.c_size_t)]
+
+
+_lib = None
+
+_PTR_FUNCS = """ggml_init ggml_new_tensor_1d ggml_new_tensor_2d ggml_new_tensor_3d ggml_new_tensor_4d ggml_dup_tensor
+ggml_add ggml_add_inplace ggml_sub ggml_mul ggml_mul_inplace ggml_div ggml_scale ggml_scale_inplace ggml_silu
+ggml_silu_inplace ggml_gelu ggml_gelu_inplace ggml_gelu_quick ggml_sigmoid ggml_tanh ggml_relu ggml_norm ggml_rms_norm
+ggml_group_norm ggml_mul_mat ggml_cpy ggml_cast ggml_cont ggml_reshape_1d ggml_reshape_2d ggml_reshape_3d ggml_reshape_4d
+ggml_view_1d ggml_view_2d ggml_view_3d ggml_view_4d ggml_permute ggml_transpose ggml_repeat ggml_concat ggml_soft_max
+ggml_soft_max_inplace ggml_soft_max_ext ggml_im2col ggml_conv_2d ggml_conv_2d_direct ggml_upscale ggml_pad
+ggml_timestep_embedding ggml_flash_attn_ext ggml_new_graph ggml_new_graph_custom ggml_graph_node ggml_set_name
+ggml_gallocr_new ggml_backend_load ggml_backend_dev_get ggml_backend_dev_by_name ggml_backend_dev_init
+ggml_backend_get_default_buffer_type ggml_backend_alloc_ctx_tensors ggml_backend_dev_buffer_type ggml_unary
+ggml_unary_inplace ggml_get_rows ggml_dup new_sd_ctx""".split()
+
+
+def lib() -> C.CDLL:
+    """Load libsdcpp-host.so (builds nothing; call build.build_all() first)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not HOST_LIB.exists():
+        raise EngineError(f"{HOST_LIB} missing — run `python -c 'import __graft_entry__ as g; g.build()'`")
+    L = C.CDLL(str(HOST_LIB), mode=C.RTLD_GLOBAL)
+    for name in _PTR_FUNCS:
+        getattr(L, name).restype = C.c_void_p
+    L.ggml_init.argtypes = [GgmlInitParams]
+    L.ggml_free.argtypes = [C.c_void_p]
+    for n, k in (("ggml_new_tensor_1d", 1), ("ggml_new_tensor_2d", 2), ("ggml_new_tensor_3d", 3), ("ggml_new_tensor_4d", 4)):
+        getattr(L, n).argtypes = [C.c_void_p, C.c_int] + [C.c_int64] * k
+    for n, k in (("ggml_reshape_1d", 1), ("ggml_reshape_2d", 2), ("ggml_reshape_3d", 3), ("ggml_reshape_4d", 4)):
+        getattr(L, n).argtypes = [C.c_void_p, C.c_void_p] + [C.c_int64] * k
+    L.ggml_view_4d.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int64] * 4 + [C.c_size_t] * 4
+    L.ggml_view_3d.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int64] * 3 + [C.c_size_t] * 3
+    L.ggml_view_2d.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int64] * 2 + [C.c_size_t] * 2
+    for n in ("ggml_add", "ggml_add_inplace", "ggml_sub", "ggml_mul", "ggml_mul_inplace", "ggml_div", "ggml_mul_mat",
+              "ggml_cpy", "ggml_repeat", "ggml_get_rows"):
+        getattr(L, n).argtypes = [C.c_void_p] * 3
+    for n in ("ggml_silu", "ggml_silu_inplace", "ggml_gelu", "ggml_gelu_inplace", "ggml_gelu_quick", "ggml_sigmoid",
+              "ggml_tanh", "ggml_relu", "ggml_cont", "ggml_transpose", "ggml_soft_max", "ggml_soft_max_inplace", "ggml_dup"):
+        getattr(L, n).argtypes = [C.c_void_p] * 2
+    L.ggml_scale.argtypes = [C.c_void_p, C.c_void_p, C.c_float]
+    L.ggml_scale_inplace.argtypes = [C.c_void_p, C.c_void_p, C.c_float]
+    L.ggml_norm.argtypes = [C.c_void_p, C.c_void_p, C.c_float]
+    L.ggml_rms_norm.argtypes = [C.c_void_p, C.c_void_p, C.c_float]
+    L.ggml_group_norm.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float]
+    L.ggml_cast.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.ggml_permute.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 4
+    L.ggml_concat.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.ggml_soft_max_ext.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float]
+    L.ggml_im2col.argtypes = [C.c_void_p] * 3 + [C.c_int] * 6 + [C.c_bool, C.c_int]
+    L.ggml_conv_2d.argtypes = [C.c_void_p] * 3 + [C.c_int] * 6
+    L.ggml_conv_2d_direct.argtypes = [C.c_void_p] * 3 + [C.c_int] * 6
+    L.ggml_upscale.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    L.ggml_pad.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 4
+    L.ggml_timestep_embedding.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    L.ggml_flash_attn_ext.argtypes = [C.c_void_p] * 5 + [C.c_float] * 3
+    L.ggml_flash_attn_ext_set_prec.argtypes = [C.c_void_p, C.c_int]
+    L.ggml_unary.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.ggml_unary_inplace.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.ggml_new_graph.argtypes = [C.c_void_p]
+    L.ggml_new_graph_custom.argtypes = [C.c_void_p, C.c_size_t, C.c_bool]
+    L.ggml_build_forward_expand.argtypes = [C.c_void_p, C.c_void_p]
+    L.ggml_graph_n_nodes.argtypes = [C.c_void_p]
+    L.ggml_graph_node.argtypes = [C.c_void_p, C.c_int]
+    L.ggml_set_name.argtypes = [C.c_void_p, C.c_char_p]
+    L.ggml_set_input.argtypes = [C.c_void_p]
+    L.ggml_set_output.argtypes = [C.c_void_p]
+    L.ggml_nbytes.argtypes = [C.c_void_p]
+    L.ggml_nbytes.restype = C.c_size_t
+    L.ggml_nelements.argtypes = [C.c_void_p]
+    L.ggml_nelements.restype = C.c_int64
+    L.ggml_gallocr_new.argtypes = [C.c_void_p]
+    L.ggml_gallocr_free.argtypes = [C.c_void_p]
+    L.ggml_gallocr_alloc_graph.argtypes = [C.c_void_p, C.c_void_p]
+    L.ggml_gallocr_alloc_graph.restype = C.c_bool
+    L.ggml_gallocr_get_buffer_size.argtypes = [C.c_void_p, C.c_int]
+    L.ggml_gallocr_get_buffer_size.restype = C.c_size_t
+    L.ggml_backend_load.argtypes = [C.c_char_p]
+    L.ggml_backend_dev_count.restype = C.c_size_t
+    L.ggml_backend_dev_get.argtypes = [C.c_size_t]
+    L.ggml_backend_dev_by_name.argtypes = [C.c_char_p]
+    L.ggml_backend_dev_name.argtypes = [C.c_void_p]
+    L.ggml_backend_dev_name.restype = C.c_char_p
+    L.ggml_backend_dev_description.argtypes = [C.c_void_p]
+    L.ggml_backend_dev_description.restype = C.c_char_p
+    L.ggml_backend_dev_init.argtypes = [C.c_void_p, C.c_char_p]
+    L.ggml_backend_dev_supports_op.argtypes = [C.c_void_p, C.c_void_p]
+    L.ggml_backend_dev_supports_op.restype = C.c_bool
+    L.ggml_backend_dev_memory.argtypes = [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    L.ggml_backend_free.argtypes = [C.c_void_p]
+    L.ggml_backend_name.argtypes = [C.c_void_p]
+    L.ggml_backend_name.restype = C.c_char_p
+    L.ggml_backend_get_default_buffer_type.argtypes = [C.c_void_p]
+    L.ggml_backend_alloc_ctx_tensors.argtypes = [C.c_void_p, C.c_void_p]
+    L.ggml_backend_buffer_free.argtypes = [C.c_void_p]
+    L.ggml_backend_buffer_set_usage.argtypes = [C.c_void_p, C.c_int]
+    L.ggml_backend_tensor_set.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]
+    L.ggml_backend_tensor_get.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]
+    L.ggml_backend_graph_compute.argtypes = [C.c_void_p, C.c_void_p]
+    L.ggml_backend_graph_compute.restype = C.c_int
+    L.ggml_backend_supports_op.argtypes = [C.c_void_p, C.c_void_p]
+    L.ggml_backend_supports_op.restype = C.c_bool
+    L.ggml_backend_synchronize.argtypes = [C.c_void_p]
+    L.ggml_quantize_chunk.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]
+    L.ggml_quantize_chunk.restype = C.c_size_t
+    L.ggml_dequantize_row.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int64]
+    L.ggml_row_size.argtypes = [C.c_int, C.c_int64]
+    L.ggml_row_size.restype = C.c_size_t
+    # engine API
+    L.sd_load_backend.argtypes = [C.c_char_p]
+    L.sd_load_backend.restype = C.c_bool
+    L.sd_device_name.argtypes = [C.c_int]
+    L.sd_device_name.restype = C.c_char_p
+    L.sd_device_description.argtypes = [C.c_int]
+    L.sd_device_description.restype = C.c_char_p
+    L.sd_last_error.restype = C.c_char_p
+    L.sd_ctx_params_init.argtypes = [C.POINTER(SdCtxParams)]
+    L.sd_sample_params_init.argtypes = [C.POINTER(SdSampleParams)]
+    L.sd_img_gen_params_init.argtypes = [C.POINTER(SdImgGenParams)]
+    L.new_sd_ctx.argtypes = [C.POINTER(SdCtxParams)]
+    L.free_sd_ctx.argtypes = [C.c_void_p]
+    L.sd_tensor_count.argtypes = [C.c_void_p]
+    L.sd_tensor_count.restype = C.c_int64
+    L.sd_tensor_name.argtypes = [C.c_void_p, C.c_int64]
+    L.sd_tensor_name.restype = C.c_char_p
+    L.sd_tensor_info.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_size_t)]
+    L.sd_tensor_info.restype = C.c_bool
+    L.sd_get_tensor_f32.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]
+    L.sd_get_tensor_f32.restype = C.c_bool
+    L.sd_set_tensor_f32.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]
+    L.sd_set_tensor_f32.restype = C.c_bool
+    L.sd_unet_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                  C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
+    L.sd_unet_forward.restype = C.c_bool
+    L.sd_vae_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.sd_vae_decode.restype = C.c_bool
+    L.sd_sample_latents.argtypes = [C.c_void_p, C.POINTER(SdImgGenParams), C.c_void_p]
+    L.sd_sample_latents.restype = C.c_bool
+    L.generate_image.argtypes = [C.c_void_p, C.POINTER(SdImgGenParams), C.POINTER(C.POINTER(SdImage)), C.POINTER(C.c_int)]
+    L.generate_image.restype = C.c_bool
+    L.free_sd_images.argtypes = [C.POINTER(SdImage), C.c_int]
+    L.sd_philox_randn.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p]
+    L.sd_get_sigmas.argtypes = [C.c_int, C.c_void_p]
+    L.sd_sigma_to_t.argtypes = [C.c_float]
+    L.sd_sigma_to_t.restype = C.c_float
+    L.sd_get_stats.argtypes = [C.c_void_p, C.POINTER(SdStats)]
+    _lib = L
+    return L
+
+
+_loaded_plugins: set[str] = set()
+
+
+def load_backend(path: os.PathLike | str) -> None:
+    """Register a ggml backend plug-in (.so exporting ggml_backend_init)."""
+    p = str(Path(path).resolve())
+    if p in _loaded_plugins:
+        return
+    if not lib().sd_load_backend(p.encode()):
+        raise EngineError(f"failed to load backend plug-in {p}")
+    _loaded_plugins.add(p)
+
+
+def load_mi355x_backend() -> None:
+    """Load the product backend.  Raises (never falls back) when the .so or a gfx950 GPU is missing."""
+    if not BACKEND_LIB.exists():
+        raise EngineError(f"{BACKEND_LIB} missing — the HIP backend was not built")
+    load_backend(BACKEND_LIB)
+    names = devices()
+    if not any(n.upper().startswith("MI355X") for n in names):
+        raise EngineError(f"libggml-mi355x.so loaded but exposes no MI355X device (devices: {names}); is a gfx950 GPU visible?")
+
+
+def devices() -> list[str]:
+    L = lib()
+    return [L.sd_device_name(i).decode() for i in range(L.sd_device_count())]
+
+
+def _fptr(a: np.ndarray | None):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class Engine:
+    """RAII wrapper over sd_ctx_t.  Array layouts are ggml's: ne0 fastest == numpy C-order reversed, i.e. a latent
+    batch is a numpy array of shape [N, C, H, W]."""
+
+    def __init__(self, model: int = SD15, backend: str | None = None, wtype: int = F16, flash_attn: bool = False,
+                 conv_direct: bool = False, weight_seed: int = 1234):
+        L = lib()
+        p = SdCtxParams()
+        L.sd_ctx_params_init(C.byref(p))
+        if backend is None:
+            load_mi355x_backend()
+            backend = "MI355X0"
+        self._backend_name = backend.encode()
+        p.backend = self._backend_name
+        p.model = model
+        p.wtype = wtype
+        p.diffusion_flash_attn = flash_attn
+        p.diffusion_conv_direct = conv_direct
+        p.weight_seed = weight_seed
+        self._ctx = L.new_sd_ctx(C.byref(p))
+        if not self._ctx:
+            raise EngineError("new_sd_ctx failed: " + L.sd_last_error().decode())
+        self.model = model
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            lib().free_sd_ctx(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- weights ----
+    def tensor_names(self) -> list[str]:
+        L = lib()
+        return [L.sd_tensor_name(self._ctx, i).decode() for i in range(L.sd_tensor_count(self._ctx))]
+
+    def tensor_info(self, name: str):
+        ne = (C.c_int64 * 4)()
+        ty = C.c_int()
+        nb = C.c_size_t()
+        if not lib().sd_tensor_info(self._ctx, name.encode(), ne, C.byref(ty), C.byref(nb)):
+            raise KeyError(name)
+        return list(ne), ty.value, nb.value
+
+    def get_tensor(self, name: str) -> np.ndarray:
+        """Dequantised f32 copy, numpy shape = reversed ggml ne (trailing 1s dropped)."""
+        ne, _, _ = self.tensor_info(name)
+        n = int(np.prod(ne))
+        out = np.empty(n, dtype=np.float32)
+        if not lib().sd_get_tensor_f32(self._ctx, name.encode(), _fptr(out), n):
+            raise EngineError("sd_get_tensor_f32 failed")
+        shape = [d for d in reversed(ne)]
+        while len(shape) > 1 and shape[0] == 1:
+            shape = shape[1:]
+        return out.reshape(shape)
+
+    def set_tensor(self, name: str, value: np.ndarray) -> None:
+        v = _f32(value).ravel()
+        if not lib().sd_set_tensor_f32(self._ctx, name.encode(), _fptr(v), v.size):
+            raise EngineError(f"sd_set_tensor_f32({name}) failed")
+
+    # ---- hot path ----
+    def unet_forward(self, x: np.ndarray, timesteps: np.ndarray, context: np.ndarray, y: np.ndarray | None = None) -> np.ndarray:
+        """x [N,C,H,W]; timesteps [N]; context [Nc,77,ctx_dim] (Nc in {1,N}); y [Ny,adm] or None."""
+        x = _f32(x)
+        t = _f32(timesteps)
+        ctxt = _f32(context)
+        n, c, h, w = x.shape
+        out = np.empty_like(x)
+        yy = None if y is None else _f32(y)
+        ok = lib().sd_unet_forward(self._ctx, _fptr(x), w, h, c, n, _fptr(t), _fptr(ctxt), ctxt.shape[2], ctxt.shape[1],
+                                   ctxt.shape[0], _fptr(yy), 0 if yy is None else yy.shape[1], 0 if yy is None else yy.shape[0],
+                                   _fptr(out))
+        if not ok:
+            raise EngineError("sd_unet_forward failed: " + lib().sd_last_error().decode())
+        return out
+
+    def vae_decode(self, latents: np.ndarray) -> np.ndarray:
+        """latents [N,C,h,w] (diffusion scale) -> rgb [N,3,8h,8w] in [0,1]."""
+        z = _f32(latents)
+        n, c, h, w = z.shape
+        out = np.empty((n, 3, h * 8, w * 8), dtype=np.float32)
+        if not lib().sd_vae_decode(self._ctx, _fptr(z), w, h, c, n, _fptr(out)):
+            raise EngineError("sd_vae_decode failed: " + lib().sd_last_error().decode())
+        return out
+
+    def _gen_params(self, cond, uncond, width, height, steps, cfg, seed, batch, device_batch, method, eta, cond_y=None, uncond_y=None):
+        p = SdImgGenParams()
+        lib().sd_img_gen_params_init(C.byref(p))
+        keep = []
+
+        def fill(dst, ctx_arr, vec):
+            a = _f32(ctx_arr)
+            keep.append(a)
+            dst.c_crossattn = a.ctypes.data_as(C.POINTER(C.c_float))
+            dst.n_tokens, dst.ctx_dim = a.shape[-2], a.shape[-1]
+            if vec is not None:
+                v = _f32(vec)
+                keep.append(v)
+                dst.c_vector = v.ctypes.data_as(C.POINTER(C.c_float))
+                dst.vector_dim = v.shape[-1]
+
+        fill(p.cond, cond, cond_y)
+        if uncond is not None:
+            fill(p.uncond, uncond, uncond_y)
+        p.width, p.height = width, height
+        p.sample_params.txt_cfg = cfg
+        p.sample_params.sample_steps = steps
+        p.sample_params.sample_method = method
+        p.sample_params.eta = eta
+        p.seed = seed
+        p.batch_count = batch
+        p.device_batch = device_batch
+        return p, keep
+
+    def sample_latents(self, cond, uncond=None, width=512, height=512, steps=20, cfg=7.0, seed=42, batch=1, device_batch=0,
+                       method=EULER_A, eta=float("inf"), cond_y=None, uncond_y=None) -> np.ndarray:
+        p, keep = self._gen_params(cond, uncond, width, height, steps, cfg, seed, batch, device_batch, method, eta, cond_y, uncond_y)
+        ch = 4
+        out = np.empty((batch, ch, height // 8, width // 8), dtype=np.float32)
+        if not lib().sd_sample_latents(self._ctx, C.byref(p), _fptr(out)):
+            raise EngineError("sd_sample_latents failed: " + lib().sd_last_error().decode())
+        return out
+
+    def generate_image(self, cond, uncond=None, width=512, height=512, steps=20, cfg=7.0, seed=42, batch=1, device_batch=0,
+                       method=EULER_A, eta=float("inf"), cond_y=None, uncond_y=None) -> np.ndarray:
+        """-> uint8 [batch, H, W, 3]"""
+        p, keep = self._gen_params(cond, uncond, width, height, steps, cfg, seed, batch, device_batch, method, eta, cond_y, uncond_y)
+        imgs = C.POINTER(SdImage)()
+        n = C.c_int()
+        if not lib().generate_image(self._ctx, C.byref(p), C.byref(imgs), C.byref(n)):
+            raise EngineError("generate_image failed: " + lib().sd_last_error().decode())
+        out = np.empty((n.value, height, width, 3), dtype=np.uint8)
+        for i in range(n.value):
+            out[i] = np.ctypeslib.as_array(imgs[i].data, shape=(height, width, 3))
+        lib().free_sd_images(imgs, n.value)
+        return out
+
+    def stats(self) -> dict:
+        s = SdStats()
+        lib().sd_get_stats(self._ctx, C.byref(s))
+        return {f[0]: getattr(s, f[0]) for f in SdStats._fields_}
+
+
+def philox_randn(seed: int, offset: int, n: int) -> np.ndarray:
+    out = np.empty(n, dtype=np.float32)
+    lib().sd_philox_randn(seed, offset, n, _fptr(out))
+    return out
+
+
+def get_sigmas(steps: int) -> np.ndarray:
+    out = np.empty(steps + 1, dtype=np.float32)
+    lib().sd_get_sigmas(steps, _fptr(out))
+    return out

@@ -1,0 +1,551 @@
+// engine.cpp — host driver of the hot path + the C ABI declared in include/sd-mi355x.h.
+//
+// Mirrors (re-designed, not transcribed):
+//   GGMLRunner::compute / execute_graph      src/core/ggml_extend.hpp:3151-3210, 2767-2930
+//   StableDiffusionGGML::sample + denoise    src/stable-diffusion.cpp:2509-2926
+//   sample_euler_ancestral / sample_euler    src/runtime/denoiser.hpp:1513-1546, 1582-1597
+//   ClassifierFreeGuidance::forward          src/runtime/guidance.cpp:149-179
+//   decode_first_stage / VAE::decode         src/stable-diffusion.cpp:3062-3078, src/model/vae/vae.hpp:170-222
+//   generate_image batch loop                src/stable-diffusion.cpp:5664-5721
+//
+// Like the reference, the graph is rebuilt for every model call; unlike it, `device_batch`
+// images are denoised together in ONE graph (N>1 is our extension, F6) — per-image results are defined
+// as those of independent batch-1 runs with seeds seed+b.
+#include <dlfcn.h>
+
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "ggml.h"
+#include "models.hpp"
+#include "sampler.hpp"
+#include "sd-mi355x.h"
+
+using namespace sdmi;
+
+static thread_local std::string g_last_error;
+static void set_error(const std::string& e) {
+    g_last_error = e;
+    fprintf(stderr, "[sd-mi355x] error: %s\n", e.c_str());
+}
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// ---------------------------------------------------------------------------------------------------
+// synthetic weights: deterministic per tensor name, N(0, 1/sqrt(fan_in)) weights, small biases,
+// norm scales around 1
+// ---------------------------------------------------------------------------------------------------
+static inline uint64_t splitmix64(uint64_t& s) {
+    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+    z          = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z          = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+static uint64_t hash_name(const std::string& s, uint64_t seed) {
+    uint64_t h = 1469598103934665603ull ^ seed;
+    for (unsigned char c : s) h = (h ^ c) * 1099511628211ull;
+    return h;
+}
+static void fill_normal(float* dst, int64_t n, uint64_t seed, float mean, float std) {
+    const int nthreads = (int)std::max<int64_t>(1, std::min<int64_t>(std::thread::hardware_concurrency(), n / 65536));
+    auto work          = [&](int tid) {
+        const int64_t chunk = (n + nthreads - 1) / nthreads;
+        const int64_t i0 = tid * chunk, i1 = std::min<int64_t>(n, i0 + chunk);
+        // counter-based: value i depends only on (seed, i/2) so the result is thread-count independent
+        for (int64_t i = i0 & ~1ll; i < i1; i += 2) {
+            uint64_t s  = seed + (uint64_t)(i / 2) * 0x632BE59BD9B4E019ull;
+            uint64_t r1 = splitmix64(s), r2 = splitmix64(s);
+            const float u1 = ((float)(r1 >> 40) + 0.5f) * (1.0f / 16777216.0f);
+            const float u2 = ((float)(r2 >> 40) + 0.5f) * (1.0f / 16777216.0f);
+            const float m  = sqrtf(-2.0f * logf(u1));
+            const float a = m * cosf(6.2831853f * u2), b = m * sinf(6.2831853f * u2);
+            if (i >= i0 && i < i1) dst[i] = mean + std * a;
+            if (i + 1 >= i0 && i + 1 < i1) dst[i + 1] = mean + std * b;
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nthreads; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto& t : th) t.join();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Runner: weights residency + per-call graph lifecycle
+// ---------------------------------------------------------------------------------------------------
+struct HostInput {
+    ggml_tensor* t;
+    const void* data;
+    size_t nbytes;
+};
+
+struct Runner {
+    ggml_backend_t backend        = nullptr;
+    ParamStore ps;
+    ggml_backend_buffer_t weights = nullptr;
+    ggml_gallocr_t galloc         = nullptr;
+    size_t graph_size             = 102400;  // UNET_GRAPH_SIZE (unet.hpp:14)
+    int64_t calls                 = 0;
+    int64_t last_nodes            = 0;
+
+    ~Runner() {
+        if (galloc) ggml_gallocr_free(galloc);
+        if (weights) ggml_backend_buffer_free(weights);
+    }
+
+    bool alloc_weights(uint64_t seed) {
+        weights = ggml_backend_alloc_ctx_tensors(ps.ctx, backend);
+        if (!weights) return false;
+        ggml_backend_buffer_set_usage(weights, GGML_BACKEND_BUFFER_USAGE_WEIGHTS);
+        std::vector<float> tmp;
+        std::vector<uint8_t> conv;
+        for (auto& sp : ps.specs) {
+            const int64_t n = ggml_nelements(sp.tensor);
+            tmp.resize(n);
+            const uint64_t s = hash_name(sp.name, seed);
+            switch (sp.kind) {
+                case InitKind::WEIGHT: fill_normal(tmp.data(), n, s, 0.f, 1.0f / sqrtf((float)sp.fan_in)); break;
+                case InitKind::BIAS: fill_normal(tmp.data(), n, s, 0.f, 0.02f); break;
+                case InitKind::NORM_SCALE: fill_normal(tmp.data(), n, s, 1.f, 0.05f); break;
+                case InitKind::ZERO: std::fill(tmp.begin(), tmp.end(), 0.f); break;
+            }
+            upload_f32(sp.tensor, tmp.data(), conv);
+        }
+        return true;
+    }
+
+    void upload_f32(ggml_tensor* t, const float* src, std::vector<uint8_t>& scratch) {
+        const int64_t n = ggml_nelements(t);
+        if (t->type == GGML_TYPE_F32) {
+            ggml_backend_tensor_set(t, src, 0, n * 4);
+            return;
+        }
+        scratch.resize(ggml_nbytes(t));
+        ggml_quantize_chunk(t->type, src, scratch.data(), 0, n / t->ne[0], t->ne[0], nullptr);  // model_loader.cpp:168-202
+        ggml_backend_tensor_set(t, scratch.data(), 0, scratch.size());
+    }
+
+    // build -> alloc -> upload inputs -> compute -> download   (ggml_extend.hpp:2767-2930)
+    template <typename BuildFn>
+    bool compute(BuildFn&& build, float* out, size_t out_bytes) {
+        ggml_init_params ip{0, nullptr, true};
+        ggml_context* cctx = ggml_init(ip);
+        ggml_cgraph* gf    = ggml_new_graph_custom(cctx, graph_size, false);
+        std::vector<HostInput> inputs;
+        GraphCtx g;
+        g.ctx            = cctx;
+        g.backend        = backend;
+        ggml_tensor* res = build(g, inputs);
+        ggml_set_name(res, "ggml_runner_final_result_tensor");  // ggml_extend.hpp:2048-2051
+        ggml_set_output(res);
+        ggml_build_forward_expand(gf, res);
+        if (!galloc) galloc = ggml_gallocr_new(ggml_backend_get_default_buffer_type(backend));
+        bool ok = ggml_gallocr_alloc_graph(galloc, gf);
+        if (!ok) {
+            set_error("compute buffer allocation failed");
+            ggml_free(cctx);
+            return false;
+        }
+        for (auto& in : inputs) ggml_backend_tensor_set(in.t, in.data, 0, in.nbytes);
+        const enum ggml_status st = ggml_backend_graph_compute(backend, gf);
+        if (st != GGML_STATUS_SUCCESS) {
+            set_error(std::string("graph compute failed: ") + ggml_status_to_string(st));
+            ggml_free(cctx);
+            return false;
+        }
+        if (ggml_nbytes(res) != out_bytes) {
+            set_error("output size mismatch");
+            ggml_free(cctx);
+            return false;
+        }
+        ggml_backend_tensor_get(res, out, 0, out_bytes);
+        last_nodes = gf->n_nodes;
+        ++calls;
+        ggml_free(cctx);
+        return true;
+    }
+};
+
+struct sd_ctx_t {
+    sd_ctx_params_t params;
+    ggml_backend_t backend = nullptr;
+    Runner unet_runner, vae_runner;
+    UNetModel unet;
+    VaeDecoder vae;
+    CompVisDenoiser denoiser;
+    sd_stats_t stats{};
+    std::vector<std::pair<std::string, ggml_tensor*>> all_tensors;
+    ~sd_ctx_t() {
+        // runners free their buffers in their destructors; the backend must outlive them
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* sd_last_error(void) { return g_last_error.c_str(); }
+
+bool sd_load_backend(const char* path) { return ggml_backend_load(path) != nullptr; }
+int sd_device_count(void) { return (int)ggml_backend_dev_count(); }
+const char* sd_device_name(int i) {
+    ggml_backend_dev_t d = ggml_backend_dev_get(i);
+    return d ? ggml_backend_dev_name(d) : nullptr;
+}
+const char* sd_device_description(int i) {
+    ggml_backend_dev_t d = ggml_backend_dev_get(i);
+    return d ? ggml_backend_dev_description(d) : nullptr;
+}
+
+void sd_ctx_params_init(sd_ctx_params_t* p) {
+    memset(p, 0, sizeof(*p));
+    p->backend              = nullptr;
+    p->model                = SD_MODEL_SD15;
+    p->wtype                = SD_TYPE_F16;
+    p->diffusion_flash_attn = false;
+    p->vae_decode_only      = true;
+    p->weight_seed          = 1234;
+    p->n_threads            = -1;
+}
+void sd_sample_params_init(sd_sample_params_t* p) {  // stable-diffusion.cpp:3650-3667
+    memset(p, 0, sizeof(*p));
+    p->txt_cfg       = 7.0f;
+    p->scheduler     = DISCRETE_SCHEDULER;
+    p->sample_method = EULER_A_SAMPLE_METHOD;
+    p->sample_steps  = 20;
+    p->eta           = INFINITY;
+}
+void sd_img_gen_params_init(sd_img_gen_params_t* p) {  // stable-diffusion.cpp:3710-3731
+    memset(p, 0, sizeof(*p));
+    sd_sample_params_init(&p->sample_params);
+    p->width       = 512;
+    p->height      = 512;
+    p->seed        = 42;
+    p->batch_count = 1;
+    p->decode      = true;
+}
+
+// locate libggml-mi355x.so next to this library (the GGML_BACKEND_DL convention:
+// "a shared object libggml-<name>.so next to the binary", SURVEY.md §8(b) Discovery)
+static std::string self_dir() {
+    Dl_info info;
+    if (dladdr((void*)&self_dir, &info) && info.dli_fname) {
+        std::string p = info.dli_fname;
+        size_t s      = p.find_last_of('/');
+        return s == std::string::npos ? "." : p.substr(0, s);
+    }
+    return ".";
+}
+
+sd_ctx_t* new_sd_ctx(const sd_ctx_params_t* params) {
+    const char* dev_name = params->backend ? params->backend : "MI355X0";
+    ggml_backend_dev_t dev = ggml_backend_dev_by_name(dev_name);
+    if (!dev && !params->backend) {
+        // default device: load the product backend plug-in; no CPU fallback exists in the product
+        const std::string path = self_dir() + "/libggml-mi355x.so";
+        if (!ggml_backend_load(path.c_str())) {
+            set_error("MI355X backend plug-in missing or failed to load: " + path);
+            return nullptr;
+        }
+        dev = ggml_backend_dev_by_name(dev_name);
+    }
+    if (!dev) {
+        set_error(std::string("no ggml device named '") + dev_name + "' (is a gfx950 GPU visible?)");
+        return nullptr;
+    }
+    ggml_backend_t backend = ggml_backend_dev_init(dev, nullptr);
+    if (!backend) {
+        set_error("ggml_backend_dev_init failed");
+        return nullptr;
+    }
+    sd_ctx_t* ctx = new sd_ctx_t();
+    ctx->params   = *params;
+    ctx->backend  = backend;
+
+    const bool xl   = params->model == SD_MODEL_SDXL || params->model == SD_MODEL_SDXL_TINY;
+    const bool tiny = params->model == SD_MODEL_SD15_TINY || params->model == SD_MODEL_SDXL_TINY;
+    UNetConfig ucfg = tiny ? UNetConfig::tiny(xl) : (xl ? UNetConfig::sdxl_base() : UNetConfig::sd15());
+    VaeConfig vcfg  = tiny ? VaeConfig::tiny() : (xl ? VaeConfig::sdxl() : VaeConfig::sd15());
+    if (tiny && xl) vcfg.scale_factor = 0.13025f;
+
+    ctx->unet_runner.backend        = backend;
+    ctx->unet_runner.ps.linear_type = (ggml_type)params->wtype;
+    ctx->unet.init(ctx->unet_runner.ps, "model.diffusion_model.", ucfg);  // prefix: stable-diffusion.cpp:1337
+    ctx->vae_runner.backend        = backend;
+    ctx->vae_runner.ps.linear_type = GGML_TYPE_F16;
+    ctx->vae_runner.graph_size     = 20480;
+    ctx->vae.init(ctx->vae_runner.ps, "first_stage_model.", vcfg);  // prefix: stable-diffusion.cpp:1472
+
+    if (!ctx->unet_runner.alloc_weights(params->weight_seed) || !ctx->vae_runner.alloc_weights(params->weight_seed)) {
+        set_error("weight buffer allocation failed");
+        free_sd_ctx(ctx);
+        return nullptr;
+    }
+    for (auto* r : {&ctx->unet_runner, &ctx->vae_runner})
+        for (auto& sp : r->ps.specs) ctx->all_tensors.push_back({sp.name, sp.tensor});
+    ctx->stats.weight_bytes = ggml_backend_buffer_get_size(ctx->unet_runner.weights) + ggml_backend_buffer_get_size(ctx->vae_runner.weights);
+    return ctx;
+}
+
+void free_sd_ctx(sd_ctx_t* ctx) {
+    if (!ctx) return;
+    ggml_backend_t b = ctx->backend;
+    delete ctx;
+    ggml_backend_free(b);
+}
+
+int64_t sd_tensor_count(sd_ctx_t* ctx) { return (int64_t)ctx->all_tensors.size(); }
+const char* sd_tensor_name(sd_ctx_t* ctx, int64_t i) { return ctx->all_tensors[i].first.c_str(); }
+static ggml_tensor* find_tensor(sd_ctx_t* ctx, const char* name) {
+    for (auto* r : {&ctx->unet_runner, &ctx->vae_runner}) {
+        auto it = r->ps.by_name.find(name);
+        if (it != r->ps.by_name.end()) return it->second;
+    }
+    return nullptr;
+}
+bool sd_tensor_info(sd_ctx_t* ctx, const char* name, int64_t* ne, int* type, size_t* nbytes) {
+    ggml_tensor* t = find_tensor(ctx, name);
+    if (!t) return false;
+    for (int i = 0; i < 4; ++i) ne[i] = t->ne[i];
+    *type   = (int)t->type;
+    *nbytes = ggml_nbytes(t);
+    return true;
+}
+bool sd_get_tensor(sd_ctx_t* ctx, const char* name, void* dst, size_t nbytes) {
+    ggml_tensor* t = find_tensor(ctx, name);
+    if (!t || nbytes != ggml_nbytes(t)) return false;
+    ggml_backend_tensor_get(t, dst, 0, nbytes);
+    return true;
+}
+bool sd_get_tensor_f32(sd_ctx_t* ctx, const char* name, float* dst, int64_t nelem) {
+    ggml_tensor* t = find_tensor(ctx, name);
+    if (!t || nelem != ggml_nelements(t)) return false;
+    std::vector<uint8_t> raw(ggml_nbytes(t));
+    ggml_backend_tensor_get(t, raw.data(), 0, raw.size());
+    const int64_t rows = nelem / t->ne[0];
+    const size_t rs    = ggml_row_size(t->type, t->ne[0]);
+    for (int64_t r = 0; r < rows; ++r) ggml_dequantize_row(t->type, raw.data() + r * rs, dst + r * t->ne[0], t->ne[0]);
+    return true;
+}
+bool sd_set_tensor_f32(sd_ctx_t* ctx, const char* name, const float* src, int64_t nelem) {
+    ggml_tensor* t = find_tensor(ctx, name);
+    if (!t || nelem != ggml_nelements(t)) return false;
+    std::vector<uint8_t> scratch;
+    ctx->unet_runner.upload_f32(t, src, scratch);
+    return true;
+}
+
+// ---- one UNet forward ---------------------------------------------------------------------------
+bool sd_unet_forward(sd_ctx_t* ctx, const float* x, int w, int h, int c, int n, const float* timesteps, const float* context,
+                     int64_t ctx_dim, int64_t n_tokens, int64_t ctx_n, const float* y, int64_t y_dim, int64_t y_n, float* out) {
+    Runner& r = ctx->unet_runner;
+    auto build = [&](GraphCtx& g, std::vector<HostInput>& in) {
+        g.flash_attn   = ctx->params.diffusion_flash_attn;
+        g.conv_direct  = ctx->params.diffusion_conv_direct;
+        ggml_tensor* tx = ggml_new_tensor_4d(g.ctx, GGML_TYPE_F32, w, h, c, n);
+        ggml_set_input(tx);
+        in.push_back({tx, x, ggml_nbytes(tx)});
+        ggml_tensor* tt = ggml_new_tensor_1d(g.ctx, GGML_TYPE_F32, n);
+        ggml_set_input(tt);
+        in.push_back({tt, timesteps, ggml_nbytes(tt)});
+        ggml_tensor* tc = ggml_new_tensor_3d(g.ctx, GGML_TYPE_F32, ctx_dim, n_tokens, ctx_n);
+        ggml_set_input(tc);
+        in.push_back({tc, context, ggml_nbytes(tc)});
+        ggml_tensor* ty = nullptr;
+        if (y != nullptr) {
+            ty = ggml_new_tensor_2d(g.ctx, GGML_TYPE_F32, y_dim, y_n);
+            ggml_set_input(ty);
+            in.push_back({ty, y, ggml_nbytes(ty)});
+        }
+        return ctx->unet.forward(g, tx, tt, tc, ty);
+    };
+    const bool ok = r.compute(build, out, (size_t)w * h * ctx->unet.cfg.out_channels * n * sizeof(float));
+    ctx->stats.unet_calls  = r.calls;
+    ctx->stats.graph_nodes = r.last_nodes;
+    if (r.galloc) ctx->stats.compute_buffer_bytes = ggml_gallocr_get_buffer_size(r.galloc, 0);
+    return ok;
+}
+
+// ---- VAE decode ---------------------------------------------------------------------------------
+bool sd_vae_decode(sd_ctx_t* ctx, const float* latents, int w, int h, int c, int n, float* out_rgb) {
+    Runner& r       = ctx->vae_runner;
+    const float sf  = ctx->vae.cfg.scale_factor, sh = ctx->vae.cfg.shift_factor;
+    const size_t ne = (size_t)w * h * c * n;
+    std::vector<float> z(ne);
+    for (size_t i = 0; i < ne; ++i) z[i] = latents[i] / sf + sh;  // diffusion_to_vae_latents, auto_encoder_kl.hpp:818-826
+    auto build = [&](GraphCtx& g, std::vector<HostInput>& in) {
+        g.flash_attn    = ctx->params.diffusion_flash_attn;
+        g.conv_direct   = ctx->params.diffusion_conv_direct;
+        ggml_tensor* tz = ggml_new_tensor_4d(g.ctx, GGML_TYPE_F32, w, h, c, n);
+        ggml_set_input(tz);
+        in.push_back({tz, z.data(), ggml_nbytes(tz)});
+        return ctx->vae.forward(g, tz);
+    };
+    const size_t on = (size_t)w * 8 * h * 8 * 3 * n;
+    const double t0 = now_ms();
+    if (!r.compute(build, out_rgb, on * sizeof(float))) return false;
+    for (size_t i = 0; i < on; ++i) {  // scale_tensor_to_0_1, vae.hpp:24-30
+        const float v = (out_rgb[i] + 1.0f) * 0.5f;
+        out_rgb[i]    = std::max(0.0f, std::min(1.0f, v));
+    }
+    ctx->stats.last_decode_ms = now_ms() - t0;
+    return true;
+}
+
+// ---- sample(): the denoise loop -------------------------------------------------------------------
+static bool sample_group(sd_ctx_t* ctx, const sd_img_gen_params_t* p, int b0, int nb, float* out) {
+    const int W = p->width / 8, H = p->height / 8, C = ctx->unet.cfg.in_channels;
+    const size_t per = (size_t)W * H * C;
+    const sd_sample_params_t& sp = p->sample_params;
+    float eta = sp.eta;
+    if (eta == INFINITY) eta = sp.sample_method == EULER_A_SAMPLE_METHOD ? 1.0f : 0.0f;  // resolve_eta, stable-diffusion.cpp:4024-4049
+    const std::vector<float> sigmas = ctx->denoiser.get_sigmas(sp.sample_steps);
+    const int steps                 = (int)sigmas.size() - 1;
+
+    // per-image RNG: seed+b; initial noise consumes offset 0 (stable-diffusion.cpp:5678-5683; rng == sampler_rng :886-889)
+    std::vector<PhiloxRNG> rngs;
+    std::vector<float> x(per * nb);
+    for (int b = 0; b < nb; ++b) {
+        rngs.emplace_back((uint64_t)(p->seed + b0 + b));
+        std::vector<float> noise = rngs[b].randn((uint32_t)per);
+        for (size_t i = 0; i < per; ++i) x[b * per + i] = 0.0f + noise[i] * sigmas[0];  // noise_scaling, denoiser.hpp:1174-1179
+    }
+    const bool use_cfg = sp.txt_cfg != 1.0f && p->uncond.c_crossattn != nullptr;
+    std::vector<float> noised(per * nb), cond_out(per * nb), uncond_out(per * nb), denoised(per * nb), ts(nb);
+
+    for (int i = 0; i < steps; ++i) {
+        const float sigma = sigmas[i], sigma_to = sigmas[i + 1];
+        float c_skip, c_out, c_in;
+        ctx->denoiser.scalings(sigma, c_skip, c_out, c_in);
+        const float t = ctx->denoiser.sigma_to_t(sigma);
+        for (int b = 0; b < nb; ++b) ts[b] = t;
+        for (size_t k = 0; k < x.size(); ++k) noised[k] = x[k] * c_in;  // stable-diffusion.cpp:2662
+        auto run = [&](const sd_condition_t& cd, float* dst) {
+            return sd_unet_forward(ctx, noised.data(), W, H, C, nb, ts.data(), cd.c_crossattn, cd.ctx_dim, cd.n_tokens, 1,
+                                   cd.c_vector, cd.vector_dim, 1, dst);
+        };
+        if (!run(p->cond, cond_out.data())) return false;
+        if (use_cfg) {
+            if (!run(p->uncond, uncond_out.data())) return false;
+            for (size_t k = 0; k < x.size(); ++k) {  // guidance.cpp:171 ; stable-diffusion.cpp:2876
+                const float guided = uncond_out[k] + sp.txt_cfg * (cond_out[k] - uncond_out[k]);
+                denoised[k]        = guided * c_out + x[k] * c_skip;
+            }
+        } else {
+            for (size_t k = 0; k < x.size(); ++k) denoised[k] = cond_out[k] * c_out + x[k] * c_skip;
+        }
+        if (sp.sample_method == EULER_A_SAMPLE_METHOD) {  // denoiser.hpp:1513-1546
+            if (sigma_to == 0.f) {
+                x = denoised;
+            } else if (eta == 0.f) {
+                const float ratio = sigma_to / sigma;
+                for (size_t k = 0; k < x.size(); ++k) x[k] = ratio * x[k] + (float)((1.0 - ratio) * denoised[k]);
+            } else {
+                float sigma_down, sigma_up;
+                ancestral_step(sigma, sigma_to, eta, sigma_down, sigma_up);
+                const float ratio = sigma_down / sigma;
+                for (size_t k = 0; k < x.size(); ++k) x[k] = ratio * x[k] + (1.0f - ratio) * denoised[k];
+                if (sigma_up > 0.f) {
+                    for (int b = 0; b < nb; ++b) {
+                        std::vector<float> nz = rngs[b].randn((uint32_t)per);
+                        for (size_t k = 0; k < per; ++k) x[b * per + k] += nz[k] * sigma_up;
+                    }
+                }
+            }
+        } else {  // sample_euler, denoiser.hpp:1582-1597
+            for (size_t k = 0; k < x.size(); ++k) {
+                const float d = (x[k] - denoised[k]) / sigma;
+                x[k] += d * (sigma_to - sigma);
+            }
+        }
+    }
+    memcpy(out, x.data(), x.size() * sizeof(float));
+    return true;
+}
+
+bool sd_sample_latents(sd_ctx_t* ctx, const sd_img_gen_params_t* p, float* out_latents) {
+    const int W = p->width / 8, H = p->height / 8, C = ctx->unet.cfg.in_channels;
+    const size_t per = (size_t)W * H * C;
+    const int group  = p->device_batch > 0 ? p->device_batch : p->batch_count;
+    const double t0  = now_ms();
+    for (int b0 = 0; b0 < p->batch_count; b0 += group) {
+        const int nb = std::min(group, p->batch_count - b0);
+        if (!sample_group(ctx, p, b0, nb, out_latents + b0 * per)) return false;
+    }
+    ctx->stats.last_sample_ms = now_ms() - t0;
+    return true;
+}
+
+static inline uint8_t float_to_u8(float v) {  // preprocessing.hpp:27-35
+    if (v <= 0.0f) return 0;
+    if (v >= 1.0f) return 255;
+    return (uint8_t)(v * 255.0f + 0.5f);
+}
+
+bool generate_image(sd_ctx_t* ctx, const sd_img_gen_params_t* p, sd_image_t** images_out, int* num_images_out) {
+    const int W = p->width / 8, H = p->height / 8, C = ctx->unet.cfg.in_channels;
+    const size_t per = (size_t)W * H * C;
+    std::vector<float> latents(per * p->batch_count);
+    if (!sd_sample_latents(ctx, p, latents.data())) return false;
+    const int PW = W * 8, PH = H * 8;
+    const size_t pix = (size_t)PW * PH;
+    sd_image_t* imgs = (sd_image_t*)calloc(p->batch_count, sizeof(sd_image_t));  // stable-diffusion.cpp:5398-5410
+    std::vector<float> rgb(pix * 3 * p->batch_count);
+    const int group = p->device_batch > 0 ? p->device_batch : p->batch_count;
+    double dec_ms   = 0;
+    for (int b0 = 0; b0 < p->batch_count; b0 += group) {
+        const int nb = std::min(group, p->batch_count - b0);
+        if (!sd_vae_decode(ctx, latents.data() + b0 * per, W, H, C, nb, rgb.data() + (size_t)b0 * pix * 3)) {
+            free_sd_images(imgs, p->batch_count);
+            return false;
+        }
+        dec_ms += ctx->stats.last_decode_ms;
+    }
+    ctx->stats.last_decode_ms = dec_ms;
+    for (int b = 0; b < p->batch_count; ++b) {
+        imgs[b].width   = PW;
+        imgs[b].height  = PH;
+        imgs[b].channel = 3;
+        imgs[b].data    = (uint8_t*)malloc(pix * 3);
+        const float* f  = rgb.data() + (size_t)b * pix * 3;
+        for (size_t i = 0; i < pix; ++i) {  // planar CHW -> interleaved RGB (preprocessing.hpp:52-60)
+            imgs[b].data[i * 3 + 0] = float_to_u8(f[i]);
+            imgs[b].data[i * 3 + 1] = float_to_u8(f[pix + i]);
+            imgs[b].data[i * 3 + 2] = float_to_u8(f[2 * pix + i]);
+        }
+    }
+    *images_out     = imgs;
+    *num_images_out = p->batch_count;
+    return true;
+}
+
+void free_sd_images(sd_image_t* images, int num_images) {
+    if (!images) return;
+    for (int i = 0; i < num_images; ++i) free(images[i].data);
+    free(images);
+}
+
+void sd_philox_randn(uint64_t seed, uint32_t offset, uint32_t n, float* out) {
+    PhiloxRNG r(seed);
+    r.offset = offset;
+    std::vector<float> v = r.randn(n);
+    memcpy(out, v.data(), n * sizeof(float));
+}
+int sd_get_sigmas(int steps, float* out) {
+    static CompVisDenoiser d;
+    std::vector<float> s = d.get_sigmas(steps);
+    memcpy(out, s.data(), s.size() * sizeof(float));
+    return (int)s.size();
+}
+float sd_sigma_to_t(float sigma) {
+    static CompVisDenoiser d;
+    return d.sigma_to_t(sigma);
+}
+void sd_get_stats(sd_ctx_t* ctx, sd_stats_t* out) { *out = ctx->stats; }
+
+}  // extern "C"

@@ -1,0 +1,362 @@
+// models.hpp — UNet (SD1.x / SDXL) and KL-VAE decoder graph builders.
+// Topology restated from the reference (cited per struct); emits the reference's node sequences via nn.hpp.
+#pragma once
+#include <algorithm>
+
+#include "nn.hpp"
+
+namespace sdmi {
+
+// UNetConfig — src/model/diffusion/unet.hpp:16-57
+struct UNetConfig {
+    bool sdxl                              = false;
+    int in_channels                        = 4;
+    int out_channels                       = 4;
+    int num_res_blocks                     = 2;
+    std::vector<int> attention_resolutions = {4, 2, 1};
+    std::vector<int> channel_mult          = {1, 2, 4, 4};
+    std::vector<int> transformer_depth     = {1, 1, 1, 1};
+    int time_embed_dim                     = 1280;
+    int num_heads                          = 8;
+    int num_head_channels                  = -1;
+    int context_dim                        = 768;
+    bool use_linear_projection             = false;
+    int model_channels                     = 320;
+    int adm_in_channels                    = 2816;
+
+    static UNetConfig sd15() { return UNetConfig(); }
+    static UNetConfig sdxl_base() {  // unet.hpp:47-57
+        UNetConfig c;
+        c.sdxl                  = true;
+        c.context_dim           = 2048;
+        c.attention_resolutions = {4, 2};
+        c.channel_mult          = {1, 2, 4};
+        c.transformer_depth     = {1, 2, 10};
+        c.num_head_channels     = 64;
+        c.num_heads             = -1;
+        c.use_linear_projection = true;
+        return c;
+    }
+    // reduced-width variant with the SAME topology, for CPU-sized parity tests
+    static UNetConfig tiny(bool xl = false) {
+        UNetConfig c     = xl ? sdxl_base() : sd15();
+        c.model_channels = 32;
+        c.time_embed_dim = 128;
+        c.context_dim    = 64;
+        c.adm_in_channels = 96;
+        if (xl) {
+            c.num_head_channels = 16;
+            c.transformer_depth = {1, 1, 2};
+        } else {
+            c.num_heads = 2;
+        }
+        return c;
+    }
+};
+
+// UnetModelBlock — src/model/diffusion/unet.hpp:298-745
+struct UNetModel {
+    UNetConfig cfg;
+    Linear time_embed_0, time_embed_2, label_emb_0, label_emb_2;
+    Conv2d input_conv, out_conv;
+    GroupNorm32 out_norm;
+    struct Level {
+        std::unique_ptr<ResBlock> res;
+        std::unique_ptr<SpatialTransformer> attn;
+        std::unique_ptr<Conv2d> down;   // DownSampleBlock "op" (block.hpp:8-41)
+        std::unique_ptr<Conv2d> up;     // UpSampleBlock "conv" (block.hpp:44-64)
+    };
+    std::vector<Level> input_blocks;   // index 1.. (0 is input_conv)
+    Level mid0, mid1, mid2;
+    std::vector<Level> output_blocks;
+
+    bool has_attn(int ds) const { return std::find(cfg.attention_resolutions.begin(), cfg.attention_resolutions.end(), ds) != cfg.attention_resolutions.end(); }
+    void heads(int ch, int& n_head, int& d_head) const {
+        n_head = cfg.num_heads;
+        d_head = ch / std::max(cfg.num_heads, 1);
+        if (cfg.num_head_channels != -1) {
+            d_head = cfg.num_head_channels;
+            n_head = ch / d_head;
+        }
+    }
+
+    void init(ParamStore& ps, const std::string& prefix, const UNetConfig& c) {
+        cfg = c;
+        const int mc = cfg.model_channels, ted = cfg.time_embed_dim;
+        time_embed_0.init(ps, prefix + "time_embed.0.", mc, ted, true, true);
+        time_embed_2.init(ps, prefix + "time_embed.2.", ted, ted, true, true);
+        if (cfg.sdxl) {
+            label_emb_0.init(ps, prefix + "label_emb.0.0.", cfg.adm_in_channels, ted, true, true);
+            label_emb_2.init(ps, prefix + "label_emb.0.2.", ted, ted, true, true);
+        }
+        input_conv.init(ps, prefix + "input_blocks.0.0.", cfg.in_channels, mc, 3, 1, 1);
+
+        std::vector<int> chans{mc};
+        int ch = mc, idx = 0, ds = 1;
+        const int L = (int)cfg.channel_mult.size();
+        for (int i = 0; i < L; ++i) {
+            const int mult = cfg.channel_mult[i];
+            for (int j = 0; j < cfg.num_res_blocks; ++j) {
+                ++idx;
+                Level lv;
+                lv.res = std::make_unique<ResBlock>();
+                lv.res->init(ps, prefix + "input_blocks." + std::to_string(idx) + ".0.", ch, ted, mult * mc);
+                ch = mult * mc;
+                if (has_attn(ds)) {
+                    int nh, dh;
+                    heads(ch, nh, dh);
+                    lv.attn = std::make_unique<SpatialTransformer>();
+                    lv.attn->init(ps, prefix + "input_blocks." + std::to_string(idx) + ".1.", ch, nh, dh, cfg.transformer_depth[i], cfg.context_dim, cfg.use_linear_projection);
+                }
+                input_blocks.push_back(std::move(lv));
+                chans.push_back(ch);
+            }
+            if (i != L - 1) {
+                ++idx;
+                Level lv;
+                lv.down = std::make_unique<Conv2d>();
+                lv.down->init(ps, prefix + "input_blocks." + std::to_string(idx) + ".0.op.", ch, ch, 3, 2, 1);
+                input_blocks.push_back(std::move(lv));
+                chans.push_back(ch);
+                ds *= 2;
+            }
+        }
+        {
+            int nh, dh;
+            heads(ch, nh, dh);
+            mid0.res = std::make_unique<ResBlock>();
+            mid0.res->init(ps, prefix + "middle_block.0.", ch, ted, ch);
+            mid1.attn = std::make_unique<SpatialTransformer>();
+            mid1.attn->init(ps, prefix + "middle_block.1.", ch, nh, dh, cfg.transformer_depth.back(), cfg.context_dim, cfg.use_linear_projection);
+            mid2.res = std::make_unique<ResBlock>();
+            mid2.res->init(ps, prefix + "middle_block.2.", ch, ted, ch);
+        }
+        int oidx = 0;
+        for (int i = L - 1; i >= 0; --i) {
+            const int mult = cfg.channel_mult[i];
+            for (int j = 0; j < cfg.num_res_blocks + 1; ++j) {
+                const int ich = chans.back();
+                chans.pop_back();
+                Level lv;
+                lv.res = std::make_unique<ResBlock>();
+                lv.res->init(ps, prefix + "output_blocks." + std::to_string(oidx) + ".0.", ch + ich, ted, mult * mc);
+                ch         = mult * mc;
+                int up_idx = 1;
+                if (has_attn(ds)) {
+                    int nh, dh;
+                    heads(ch, nh, dh);
+                    lv.attn = std::make_unique<SpatialTransformer>();
+                    lv.attn->init(ps, prefix + "output_blocks." + std::to_string(oidx) + ".1.", ch, nh, dh, cfg.transformer_depth[i], cfg.context_dim, cfg.use_linear_projection);
+                    ++up_idx;
+                }
+                if (i > 0 && j == cfg.num_res_blocks) {
+                    lv.up = std::make_unique<Conv2d>();
+                    lv.up->init(ps, prefix + "output_blocks." + std::to_string(oidx) + "." + std::to_string(up_idx) + ".conv.", ch, ch, 3, 1, 1);
+                    ds /= 2;
+                }
+                output_blocks.push_back(std::move(lv));
+                ++oidx;
+            }
+        }
+        out_norm.init(ps, prefix + "out.0.", ch);
+        out_conv.init(ps, prefix + "out.2.", mc, cfg.out_channels, 3, 1, 1);
+    }
+
+    // forward — unet.hpp:526-745.  x [W,H,C,N]; timesteps [N]; context [ctx_dim,77,N|1]; y [adm,N|1]
+    ggml_tensor* forward(GraphCtx& g, ggml_tensor* x, ggml_tensor* timesteps, ggml_tensor* context, ggml_tensor* y) const {
+        ggml_context* c = g.ctx;
+        if (context != nullptr && context->ne[2] != x->ne[3]) {
+            context = ggml_repeat(c, context, ggml_new_tensor_3d(c, GGML_TYPE_F32, context->ne[0], context->ne[1], x->ne[3]));
+        }
+        if (y != nullptr && y->ne[1] != x->ne[3]) {
+            y = ggml_repeat(c, y, ggml_new_tensor_2d(c, GGML_TYPE_F32, y->ne[0], x->ne[3]));
+        }
+        // ggml_ext_timestep_embedding (ggml_extend.hpp:1644-1652): scale by time_factor 1.0, then embed
+        ggml_tensor* t_emb = ggml_timestep_embedding(c, ext_scale(c, timesteps, 1.0f), cfg.model_channels, 10000);
+        ggml_tensor* emb   = time_embed_0.forward(g, t_emb);
+        emb                = ggml_silu_inplace(c, emb);
+        emb                = time_embed_2.forward(g, emb);
+        if (y != nullptr) {
+            ggml_tensor* le = label_emb_0.forward(g, y);
+            le              = ggml_silu_inplace(c, le);
+            le              = label_emb_2.forward(g, le);
+            emb             = ggml_add(c, emb, le);
+        }
+        std::vector<ggml_tensor*> hs;
+        ggml_tensor* h = input_conv.forward(g, x);
+        ggml_set_name(h, "bench-start");
+        hs.push_back(h);
+        for (auto& lv : input_blocks) {
+            if (lv.down) {
+                h = lv.down->forward(g, h);
+            } else {
+                h = lv.res->forward(g, h, emb);
+                if (lv.attn) h = lv.attn->forward(g, h, context);
+            }
+            hs.push_back(h);
+        }
+        h = mid0.res->forward(g, h, emb);
+        h = mid1.attn->forward(g, h, context);
+        h = mid2.res->forward(g, h, emb);
+        for (auto& lv : output_blocks) {
+            ggml_tensor* skip = hs.back();
+            hs.pop_back();
+            h = ggml_concat(c, h, skip, 2);
+            h = lv.res->forward(g, h, emb);
+            if (lv.attn) h = lv.attn->forward(g, h, context);
+            if (lv.up) {
+                h = ggml_upscale(c, h, 2, GGML_SCALE_MODE_NEAREST);
+                h = lv.up->forward(g, h);
+            }
+        }
+        h = out_norm.forward(g, h);
+        h = ggml_silu_inplace(c, h);
+        h = out_conv.forward(g, h);
+        ggml_set_name(h, "bench-end");
+        return h;
+    }
+};
+
+// ---- KL-VAE decoder — src/model/vae/auto_encoder_kl.hpp:10-160 (ResnetBlock, AttnBlock), :360-492 (Decoder), :589-620
+struct VaeResnetBlock {
+    int64_t in_ch = 0, out_ch = 0;
+    GroupNorm32 norm1, norm2;
+    Conv2d conv1, conv2, nin;
+    void init(ParamStore& ps, const std::string& prefix, int64_t ic, int64_t oc) {
+        in_ch  = ic;
+        out_ch = oc;
+        norm1.init(ps, prefix + "norm1.", ic);
+        conv1.init(ps, prefix + "conv1.", ic, oc, 3, 1, 1);
+        norm2.init(ps, prefix + "norm2.", oc);
+        conv2.init(ps, prefix + "conv2.", oc, oc, 3, 1, 1);
+        if (ic != oc) nin.init(ps, prefix + "nin_shortcut.", ic, oc, 1, 1, 0);
+    }
+    ggml_tensor* forward(GraphCtx& g, ggml_tensor* x) const {
+        ggml_context* c = g.ctx;
+        ggml_tensor* h  = norm1.forward(g, x);
+        h               = ggml_silu_inplace(c, h);
+        h               = conv1.forward(g, h);
+        h               = norm2.forward(g, h);
+        h               = ggml_silu_inplace(c, h);
+        h               = conv2.forward(g, h);
+        if (in_ch != out_ch) x = nin.forward(g, x);
+        return ggml_add(c, h, x);
+    }
+};
+
+struct VaeAttnBlock {  // conv (1x1) projections, as SD1.x/SDXL checkpoints store them (auto_encoder_kl.hpp:62-159)
+    GroupNorm32 norm;
+    Conv2d q, k, v, proj_out;
+    void init(ParamStore& ps, const std::string& prefix, int64_t ch) {
+        norm.init(ps, prefix + "norm.", ch);
+        q.init(ps, prefix + "q.", ch, ch, 1);
+        k.init(ps, prefix + "k.", ch, ch, 1);
+        v.init(ps, prefix + "v.", ch, ch, 1);
+        proj_out.init(ps, prefix + "proj_out.", ch, ch, 1);
+    }
+    ggml_tensor* forward(GraphCtx& g, ggml_tensor* x) const {
+        ggml_context* cx = g.ctx;
+        ggml_tensor* h_  = norm.forward(g, x);
+        const int64_t n = h_->ne[3], c = h_->ne[2], h = h_->ne[1], w = h_->ne[0];
+        auto tok = [&](const Conv2d& proj) {
+            ggml_tensor* t = proj.forward(g, h_);
+            t              = ggml_cont(cx, ggml_permute(cx, t, 1, 2, 0, 3));
+            return ggml_reshape_3d(cx, t, c, h * w, n);
+        };
+        ggml_tensor* qq = tok(q);
+        ggml_tensor* kk = tok(k);
+        ggml_tensor* vv = tok(v);
+        h_              = ext_attention(g, qq, kk, vv, 1);
+        h_              = ggml_cont(cx, ggml_permute(cx, h_, 1, 0, 2, 3));
+        h_              = ggml_reshape_4d(cx, h_, w, h, c, n);
+        h_              = proj_out.forward(g, h_);
+        return ggml_add(cx, h_, x);
+    }
+};
+
+struct VaeConfig {
+    int ch                   = 128;
+    int out_ch               = 3;
+    std::vector<int> ch_mult = {1, 2, 4, 4};
+    int num_res_blocks       = 2;
+    int z_channels           = 4;
+    bool use_quant           = true;   // post_quant_conv present (SD1/SDXL; auto_encoder_kl.hpp:609-612)
+    float scale_factor       = 0.18215f;  // auto_encoder_kl.hpp:676-687
+    float shift_factor       = 0.f;
+    static VaeConfig sd15() { return VaeConfig(); }
+    static VaeConfig sdxl() {
+        VaeConfig c;
+        c.scale_factor = 0.13025f;
+        return c;
+    }
+    static VaeConfig tiny() {
+        VaeConfig c;
+        c.ch = 32;
+        return c;
+    }
+};
+
+struct VaeDecoder {
+    VaeConfig cfg;
+    Conv2d post_quant, conv_in, conv_out;
+    VaeResnetBlock mid1, mid2;
+    VaeAttnBlock mid_attn;
+    struct Up {
+        std::vector<VaeResnetBlock> blocks;
+        std::unique_ptr<Conv2d> upsample;
+    };
+    std::vector<Up> ups;  // indexed by resolution i (processed from last to first)
+    GroupNorm32 norm_out;
+
+    void init(ParamStore& ps, const std::string& prefix, const VaeConfig& c) {
+        cfg           = c;
+        const int nr  = (int)cfg.ch_mult.size();
+        int block_in  = cfg.ch * cfg.ch_mult[nr - 1];
+        if (cfg.use_quant) post_quant.init(ps, prefix + "post_quant_conv.", cfg.z_channels, cfg.z_channels, 1);
+        const std::string d = prefix + "decoder.";
+        conv_in.init(ps, d + "conv_in.", cfg.z_channels, block_in, 3, 1, 1);
+        mid1.init(ps, d + "mid.block_1.", block_in, block_in);
+        mid_attn.init(ps, d + "mid.attn_1.", block_in);
+        mid2.init(ps, d + "mid.block_2.", block_in, block_in);
+        ups.resize(nr);
+        for (int i = nr - 1; i >= 0; --i) {
+            const int block_out = cfg.ch * cfg.ch_mult[i];
+            ups[i].blocks.resize(cfg.num_res_blocks + 1);
+            for (int j = 0; j < cfg.num_res_blocks + 1; ++j) {
+                ups[i].blocks[j].init(ps, d + "up." + std::to_string(i) + ".block." + std::to_string(j) + ".", block_in, block_out);
+                block_in = block_out;
+            }
+            if (i != 0) {
+                ups[i].upsample = std::make_unique<Conv2d>();
+                ups[i].upsample->init(ps, d + "up." + std::to_string(i) + ".upsample.conv.", block_in, block_in, 3, 1, 1);
+            }
+        }
+        norm_out.init(ps, d + "norm_out.", block_in);
+        conv_out.init(ps, d + "conv_out.", block_in, cfg.out_ch, 3, 1, 1);
+    }
+
+    // AutoEncoderKLModel::decode + Decoder::forward
+    ggml_tensor* forward(GraphCtx& g, ggml_tensor* z) const {
+        ggml_context* c = g.ctx;
+        if (cfg.use_quant) z = post_quant.forward(g, z);
+        ggml_set_name(z, "bench-start");
+        ggml_tensor* h = conv_in.forward(g, z);
+        h              = mid1.forward(g, h);
+        h              = mid_attn.forward(g, h);
+        h              = mid2.forward(g, h);
+        for (int i = (int)ups.size() - 1; i >= 0; --i) {
+            for (auto& b : ups[i].blocks) h = b.forward(g, h);
+            if (ups[i].upsample) {
+                h = ggml_upscale(c, h, 2, GGML_SCALE_MODE_NEAREST);
+                h = ups[i].upsample->forward(g, h);
+            }
+        }
+        h = norm_out.forward(g, h);
+        h = ggml_silu_inplace(c, h);
+        h = conv_out.forward(g, h);
+        ggml_set_name(h, "bench-end");
+        return h;
+    }
+};
+
+}  // namespace sdmi

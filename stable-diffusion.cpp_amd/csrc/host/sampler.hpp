@@ -1,0 +1,127 @@
+// sampler.hpp — host-side fp32 sampler math of the denoise loop.
+// Everything here is cheap scalar / elementwise work the reference also keeps on the host.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+namespace sdmi {
+
+constexpr int TIMESTEPS = 1000;
+
+// Philox4x32-10 + Box-Muller, counter = (offset, 0, i, 0), key = seed — bit-compatible with
+// PhiloxRNG::randn (src/core/rng_philox.hpp:101-122), which imitates torch-CUDA randn.
+struct PhiloxRNG {
+    uint64_t seed   = 0;
+    uint32_t offset = 0;
+    explicit PhiloxRNG(uint64_t s = 0) : seed(s) {}
+    void manual_seed(uint64_t s) {
+        seed   = s;
+        offset = 0;
+    }
+    static inline void round(uint32_t c[4], const uint32_t k[2]) {
+        const uint64_t p0 = (uint64_t)c[0] * 0xD2511F53u;
+        const uint64_t p1 = (uint64_t)c[2] * 0xCD9E8D57u;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k[0];
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k[1];
+        const uint32_t n3 = (uint32_t)p0;
+        c[0] = n0;
+        c[1] = n1;
+        c[2] = n2;
+        c[3] = n3;
+    }
+    std::vector<float> randn(uint32_t n) {
+        std::vector<float> out(n);
+        const float two_pow32_inv     = 2.3283064e-10f;
+        const float two_pow32_inv_2pi = 2.3283064e-10f * 6.2831855f;
+        for (uint32_t i = 0; i < n; ++i) {
+            uint32_t c[4] = {offset, 0, i, 0};
+            uint32_t k[2] = {(uint32_t)(seed & 0xFFFFFFFFu), (uint32_t)(seed >> 32)};
+            for (int r = 0; r < 9; ++r) {
+                round(c, k);
+                k[0] += 0x9E3779B9u;
+                k[1] += 0xBB67AE85u;
+            }
+            round(c, k);
+            const float u = (float)c[0] * two_pow32_inv + two_pow32_inv / 2;
+            const float v = (float)c[1] * two_pow32_inv_2pi + two_pow32_inv_2pi / 2;
+            const float s = sqrtf(-2.0f * logf(u));
+            out[i]        = s * sinf(v);
+        }
+        offset += 1;
+        return out;
+    }
+};
+
+// CompVisDenoiser (src/runtime/denoiser.hpp:1126-1196) with the SD1/SDXL scaled-linear beta table
+// (calculate_alphas_cumprod, src/stable-diffusion.cpp:173-186; refresh :666-681)
+struct CompVisDenoiser {
+    float sigmas[TIMESTEPS];
+    float log_sigmas[TIMESTEPS];
+    CompVisDenoiser() {
+        const float ls_sqrt = sqrtf(0.00085f), le_sqrt = sqrtf(0.0120f);
+        const float amount = le_sqrt - ls_sqrt;
+        float product      = 1.0f;
+        for (int i = 0; i < TIMESTEPS; ++i) {
+            const float beta = ls_sqrt + amount * ((float)i / (TIMESTEPS - 1));
+            product *= 1.0f - powf(beta, 2.0f);
+            sigmas[i]     = std::sqrt((1 - product) / product);
+            log_sigmas[i] = std::log(sigmas[i]);
+        }
+    }
+    float sigma_to_t(float sigma) const {
+        const float log_sigma = std::log(sigma);
+        int low_idx           = 0;
+        for (int i = 0; i < TIMESTEPS; ++i)
+            if (log_sigma - log_sigmas[i] >= 0) low_idx++;
+        low_idx        = std::min(std::max(low_idx - 1, 0), TIMESTEPS - 2);
+        const int high = low_idx + 1;
+        const float lo = log_sigmas[low_idx], hi = log_sigmas[high];
+        float w = (lo - log_sigma) / (lo - hi);
+        w       = std::max(0.f, std::min(1.f, w));
+        return (1.0f - w) * low_idx + w * high;
+    }
+    float t_to_sigma(float t) const {
+        const int lo = (int)std::floor(t), hi = (int)std::ceil(t);
+        const float w = t - (float)lo;
+        return std::exp((1.0f - w) * log_sigmas[lo] + w * log_sigmas[hi]);
+    }
+    // DiscreteScheduler::get_sigmas — denoiser.hpp:32-54
+    std::vector<float> get_sigmas(uint32_t n) const {
+        std::vector<float> r;
+        const int t_max = TIMESTEPS - 1;
+        if (n == 0) return r;
+        if (n == 1) {
+            r.push_back(t_to_sigma((float)t_max));
+            r.push_back(0);
+            return r;
+        }
+        const float step = (float)t_max / (float)(n - 1);
+        for (uint32_t i = 0; i < n; ++i) r.push_back(t_to_sigma(t_max - step * i));
+        r.push_back(0);
+        return r;
+    }
+    // get_scalings — denoiser.hpp:1167-1172: {c_skip, c_out, c_in}
+    void scalings(float sigma, float& c_skip, float& c_out, float& c_in) const {
+        c_skip = 1.0f;
+        c_out  = -sigma;
+        c_in   = 1.0f / std::sqrt(sigma * sigma + 1.0f);
+    }
+};
+
+// get_ancestral_step — denoiser.hpp:1447-1467
+inline void ancestral_step(float sigma_from, float sigma_to, float eta, float& sigma_down, float& sigma_up) {
+    sigma_up   = 0.0f;
+    sigma_down = sigma_to;
+    if (eta <= 0.0f) return;
+    const float from_sq = sigma_from * sigma_from, to_sq = sigma_to * sigma_to;
+    if (from_sq > 0.0f) {
+        const float term = to_sq * (from_sq - to_sq) / from_sq;
+        sigma_up         = std::min(sigma_to, eta * std::sqrt(std::max(term, 0.0f)));
+    }
+    const float down_sq = to_sq - sigma_up * sigma_up;
+    sigma_down          = down_sq > 0.0f ? std::sqrt(down_sq) : 0.0f;
+}
+
+}  // namespace sdmi
