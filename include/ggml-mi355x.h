@@ -1,0 +1,74 @@
+/*
+ * ggml-mi355x.h — C ABI exported by libggml-mi355x.so, the MI355X (gfx950) ggml backend plug-in.
+ *
+ * The library is a drop-in for the reference's ggml-backend compute path: a host that was built with
+ * GGML_BACKEND_DL (the reference's CI does exactly this: .github/workflows/build.yml:88,686) discovers
+ * it with ggml_backend_load_all(), enumerates its devices and drives it ONLY through the vtables of
+ * include/ggml-abi.h.  Each entry point below cites the reference interface it plugs into.
+ *
+ *   ggml_backend_init()            <- dlsym'd by ggml_backend_load()/load_all()
+ *                                     (src/core/ggml_extend_backend.cpp:302-320 -> ggml_backend_load_all)
+ *   ggml_backend_score()           <- optional ranking among several libggml-*.so variants
+ *   ggml_backend_mi355x_reg()      <- static-registration form (what ggml-backend-reg.cpp would call if
+ *                                     the backend were compiled into ggml: `register_backend(ggml_backend_mi355x_reg())`)
+ *
+ * Reached through the returned registry (struct ggml_backend_reg, include/ggml-abi.h):
+ *   reg.get_device(i)              <- ggml_backend_dev_get / dev_by_name (ggml_extend_backend.cpp:334-418)
+ *   dev.supports_op(node)          <- probed at graph BUILD time (ggml_extend.hpp:1425, :2198-2210)
+ *   dev.get_buffer_type / buft.alloc_buffer / buffer.set_tensor,get_tensor
+ *                                  <- gallocr + weight staging (ggml_extend.hpp:2227-2245, 2347-2435;
+ *                                     model_manager.cpp:470-477, 735-750)
+ *   dev.init_backend -> backend.graph_compute(cgraph)
+ *                                  <- THE hot-path call, src/core/ggml_extend_backend.cpp:471 (sync form)
+ *                                     and :489 (async on a sub-graph VIEW: n_nodes slice, leafs == NULL)
+ *   backend.synchronize            <- ggml_extend_backend.cpp:494,504; ggml_extend.hpp:1526,2330
+ *   reg.get_proc_address(name)     <- "ggml_backend_split_buffer_type" / "ggml_backend_set_n_threads" /
+ *                                     "ggml_backend_get_features" -> NULL (host handles absence,
+ *                                     ggml_extend_backend.cpp:801-804,440-446,519-528);
+ *                                     "ggml_backend_mi355x_get_stats" / "_set_option" -> the functions below
+ *
+ * Error behaviour (SURVEY.md §8(b) Errors): graph_compute returns GGML_STATUS_FAILED for an unsupported
+ * node or a HIP launch error and GGML_STATUS_ALLOC_FAILED when an internal workspace cannot be
+ * allocated — it never aborts; alloc_buffer returns NULL on hipMalloc failure.
+ */
+#ifndef GGML_MI355X_H
+#define GGML_MI355X_H
+
+#include "ggml-abi.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GGML_MI355X_API __attribute__((visibility("default")))
+
+GGML_MI355X_API ggml_backend_reg_t ggml_backend_init(void);
+GGML_MI355X_API int ggml_backend_score(void);
+GGML_MI355X_API ggml_backend_reg_t ggml_backend_mi355x_reg(void);
+GGML_MI355X_API int ggml_backend_mi355x_get_device_count(void);
+
+/* execution statistics of the graph planner (process-wide, monotonically increasing) */
+struct ggml_backend_mi355x_stats {
+    int64_t graphs_computed;     /* graph_compute calls */
+    int64_t plans_built;         /* plan-cache misses (topology seen for the first time) */
+    int64_t nodes_seen;          /* ggml nodes in the graphs of plans built */
+    int64_t kernels_planned;     /* kernel launches in plans built (after fusion) */
+    int64_t kernels_launched;    /* kernel launches issued */
+    int64_t fused_conv;          /* IM2COL+MUL_MAT+CONT(+ADD...) chains replaced by the implicit-GEMM conv */
+    int64_t fused_conv_bounced;  /* ... of which had to bounce through scratch because dst aliased the input */
+    int64_t fused_linear;        /* MUL_MAT(+bias)(+residual) on the MFMA weight GEMM */
+    int64_t fused_norm;          /* GROUP_NORM/NORM + affine (+SiLU) */
+    int64_t fused_geglu;
+    int64_t fused_attention;     /* attention sub-graphs routed to the flash kernel */
+    int64_t generic_matmul;      /* MUL_MAT on the generic exact-f32 path */
+    int64_t swizzled_weight_bytes;
+    int64_t graph_replays;       /* hipGraph replays (when graph capture is enabled) */
+};
+GGML_MI355X_API void ggml_backend_mi355x_get_stats(struct ggml_backend_mi355x_stats* out);
+/* options: "fusion" (1), "mfma_gemm" (1), "hip_graph" (0/1), "flash_pattern" (1) */
+GGML_MI355X_API void ggml_backend_mi355x_set_option(const char* key, int value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,291 @@
+// backend.cpp — libggml-mi355x.so: a ggml backend plug-in for AMD Instinct MI355X (gfx950 / CDNA4).
+//
+// This file is the DROP-IN BOUNDARY of the repo: it implements the ggml backend vtables declared in
+// include/ggml-abi.h (registry -> device -> buffer type -> buffer -> backend/stream) and exports the
+// dynamic-loading entry points `ggml_backend_init` / `ggml_backend_score` that a GGML_BACKEND_DL host finds
+// via ggml_backend_load_all() (reference: src/core/ggml_extend_backend.cpp:302-320).  The host-visible
+// contract per vtable slot is documented in include/ggml-mi355x.h; graph execution (fusion planner + plan
+// cache) lives in planner.cpp, kernels in ../kernels/*.hip.
+//
+// Device naming: "MI355X<i>".  The name deliberately contains none of "ROCm"/"CUDA"/"Vulkan"/"SYCL": the
+// reference string-matches device names to flip graph-build decisions and we want the
+// DEFAULT graph (no force_prec_f32 special case — accumulation is always f32 here).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "ggml-abi.h"
+#include "ggml-mi355x.h"
+#include "planner.h"
+
+namespace mi355x {
+
+#define HIP_OK(expr)                                                                                          \
+    do {                                                                                                      \
+        hipError_t _e = (expr);                                                                               \
+        if (_e != hipSuccess) {                                                                               \
+            fprintf(stderr, "[ggml-mi355x] %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+        }                                                                                                     \
+    } while (0)
+
+struct DeviceCtx {
+    int id;
+    std::string name, desc;
+    ggml_backend_device dev;
+    ggml_backend_buffer_type buft;
+};
+struct BufferCtx {
+    int device;
+    void* base;
+};
+
+static std::vector<DeviceCtx*> g_devices;
+static ggml_backend_reg g_reg;
+static ggml_guid g_guid = {{0x35, 0x5a, 0x0d, 0xcd, 0x4a, 0x09, 0x50, 0x11, 0xa1, 0xb2, 0xc3, 0xd4, 0xe5, 0xf6, 0x07, 0x18}};
+
+// ---------------------------------------------------------------- buffers
+static const char* buft_get_name(ggml_backend_buffer_type_t t) { return ((DeviceCtx*)t->context)->name.c_str(); }
+static void buf_free(ggml_backend_buffer_t b) {
+    BufferCtx* c = (BufferCtx*)b->context;
+    HIP_OK(hipSetDevice(c->device));
+    HIP_OK(hipDeviceSynchronize());
+    planner_forget_range(c->base, b->size);
+    HIP_OK(hipFree(c->base));
+    delete c;
+}
+static void* buf_get_base(ggml_backend_buffer_t b) { return ((BufferCtx*)b->context)->base; }
+static enum ggml_status buf_init_tensor(ggml_backend_buffer_t, ggml_tensor*) { return GGML_STATUS_SUCCESS; }
+static void buf_memset(ggml_backend_buffer_t b, ggml_tensor* t, uint8_t v, size_t off, size_t sz) {
+    HIP_OK(hipSetDevice(((BufferCtx*)b->context)->device));
+    HIP_OK(hipMemset((char*)t->data + off, v, sz));
+}
+static void buf_set(ggml_backend_buffer_t b, ggml_tensor* t, const void* d, size_t off, size_t sz) {
+    HIP_OK(hipSetDevice(((BufferCtx*)b->context)->device));
+    if (b->usage == GGML_BACKEND_BUFFER_USAGE_WEIGHTS) planner_forget_range((char*)t->data + off, sz);  // swizzled copies are stale now
+    HIP_OK(hipMemcpy((char*)t->data + off, d, sz, hipMemcpyHostToDevice));
+}
+static void buf_get(ggml_backend_buffer_t b, const ggml_tensor* t, void* d, size_t off, size_t sz) {
+    HIP_OK(hipSetDevice(((BufferCtx*)b->context)->device));
+    HIP_OK(hipMemcpy(d, (const char*)t->data + off, sz, hipMemcpyDeviceToHost));
+}
+static bool buf_cpy(ggml_backend_buffer_t b, const ggml_tensor* src, ggml_tensor* dst) {
+    ggml_backend_buffer_t sb = src->view_src ? src->view_src->buffer : src->buffer;
+    if (!sb || sb->iface.get_base != buf_get_base) return false;  // not one of ours
+    if (!ggml_abi_is_contiguous(src) || !ggml_abi_is_contiguous(dst)) return false;
+    HIP_OK(hipSetDevice(((BufferCtx*)b->context)->device));
+    HIP_OK(hipMemcpy(dst->data, src->data, ggml_abi_nbytes(src), hipMemcpyDeviceToDevice));
+    return true;
+}
+static void buf_clear(ggml_backend_buffer_t b, uint8_t v) {
+    BufferCtx* c = (BufferCtx*)b->context;
+    HIP_OK(hipSetDevice(c->device));
+    HIP_OK(hipMemset(c->base, v, b->size));
+}
+static ggml_backend_buffer_t buft_alloc(ggml_backend_buffer_type_t t, size_t size) {
+    DeviceCtx* d = (DeviceCtx*)t->context;
+    HIP_OK(hipSetDevice(d->id));
+    void* p = nullptr;
+    if (hipMalloc(&p, size > 0 ? size : 256) != hipSuccess) {
+        fprintf(stderr, "[ggml-mi355x] hipMalloc(%zu) failed\n", size);
+        (void)hipGetLastError();
+        return nullptr;  // host turns this into "alloc failed" (ggml_extend.hpp:2232-2236)
+    }
+    ggml_backend_buffer* b = new ggml_backend_buffer();
+    memset(b, 0, sizeof(*b));
+    b->iface.free_buffer   = buf_free;
+    b->iface.get_base      = buf_get_base;
+    b->iface.init_tensor   = buf_init_tensor;
+    b->iface.memset_tensor = buf_memset;
+    b->iface.set_tensor    = buf_set;
+    b->iface.get_tensor    = buf_get;
+    b->iface.cpy_tensor    = buf_cpy;
+    b->iface.clear         = buf_clear;
+    b->buft                = t;
+    b->context             = new BufferCtx{d->id, p};
+    b->size                = size;
+    b->usage               = GGML_BACKEND_BUFFER_USAGE_ANY;
+    return b;
+}
+static size_t buft_alignment(ggml_backend_buffer_type_t) { return 256; }
+static size_t buft_max_size(ggml_backend_buffer_type_t t) {
+    size_t fr = 0, tot = 0;
+    HIP_OK(hipSetDevice(((DeviceCtx*)t->context)->id));
+    HIP_OK(hipMemGetInfo(&fr, &tot));
+    return tot;
+}
+static size_t buft_alloc_size(ggml_backend_buffer_type_t, const ggml_tensor* t) { return ggml_abi_nbytes(t); }
+static bool buft_is_host(ggml_backend_buffer_type_t) { return false; }
+
+// ---------------------------------------------------------------- backend (one HIP stream)
+struct BackendCtx {
+    DeviceCtx* dev;
+    hipStream_t stream;
+    Planner* planner;
+};
+static const char* be_get_name(ggml_backend_t b) { return ((BackendCtx*)b->context)->dev->name.c_str(); }
+static void be_free(ggml_backend_t b) {
+    BackendCtx* c = (BackendCtx*)b->context;
+    HIP_OK(hipSetDevice(c->dev->id));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    planner_destroy(c->planner);
+    HIP_OK(hipStreamDestroy(c->stream));
+    delete c;
+    delete b;
+}
+static void be_set_async(ggml_backend_t b, ggml_tensor* t, const void* d, size_t off, size_t sz) {
+    BackendCtx* c = (BackendCtx*)b->context;
+    HIP_OK(hipSetDevice(c->dev->id));
+    HIP_OK(hipMemcpyAsync((char*)t->data + off, d, sz, hipMemcpyHostToDevice, c->stream));
+}
+static void be_get_async(ggml_backend_t b, const ggml_tensor* t, void* d, size_t off, size_t sz) {
+    BackendCtx* c = (BackendCtx*)b->context;
+    HIP_OK(hipSetDevice(c->dev->id));
+    HIP_OK(hipMemcpyAsync(d, (const char*)t->data + off, sz, hipMemcpyDeviceToHost, c->stream));
+}
+static void be_synchronize(ggml_backend_t b) {
+    BackendCtx* c = (BackendCtx*)b->context;
+    HIP_OK(hipSetDevice(c->dev->id));
+    HIP_OK(hipStreamSynchronize(c->stream));
+}
+static enum ggml_status be_graph_compute(ggml_backend_t b, ggml_cgraph* g) {
+    BackendCtx* c = (BackendCtx*)b->context;
+    if (hipSetDevice(c->dev->id) != hipSuccess) return GGML_STATUS_FAILED;
+    return planner_compute(c->planner, g, c->stream);
+}
+
+// ---------------------------------------------------------------- device
+static const char* dev_get_name(ggml_backend_dev_t d) { return ((DeviceCtx*)d->context)->name.c_str(); }
+static const char* dev_get_desc(ggml_backend_dev_t d) { return ((DeviceCtx*)d->context)->desc.c_str(); }
+static void dev_get_memory(ggml_backend_dev_t d, size_t* fr, size_t* tot) {
+    HIP_OK(hipSetDevice(((DeviceCtx*)d->context)->id));
+    HIP_OK(hipMemGetInfo(fr, tot));
+}
+static enum ggml_backend_dev_type dev_get_type(ggml_backend_dev_t) { return GGML_BACKEND_DEVICE_TYPE_GPU; }
+static void dev_get_props(ggml_backend_dev_t d, ggml_backend_dev_props* p) {
+    memset(p, 0, sizeof(*p));
+    p->name        = dev_get_name(d);
+    p->description = dev_get_desc(d);
+    dev_get_memory(d, &p->memory_free, &p->memory_total);
+    p->type                      = GGML_BACKEND_DEVICE_TYPE_GPU;
+    p->caps.async                = true;
+    p->caps.host_buffer          = false;
+    p->caps.buffer_from_host_ptr = false;  // probed at ggml_extend_backend.cpp:759-761
+    p->caps.events               = false;
+}
+static ggml_backend_t dev_init_backend(ggml_backend_dev_t d, const char*) {
+    DeviceCtx* dc = (DeviceCtx*)d->context;
+    if (hipSetDevice(dc->id) != hipSuccess) return nullptr;
+    BackendCtx* c = new BackendCtx();
+    c->dev        = dc;
+    if (hipStreamCreate(&c->stream) != hipSuccess) {
+        delete c;
+        return nullptr;
+    }
+    c->planner       = planner_create(dc->id);
+    ggml_backend* b  = new ggml_backend();
+    memset(b, 0, sizeof(*b));
+    b->guid                   = &g_guid;
+    b->iface.get_name         = be_get_name;
+    b->iface.free             = be_free;
+    b->iface.set_tensor_async = be_set_async;
+    b->iface.get_tensor_async = be_get_async;
+    b->iface.synchronize      = be_synchronize;
+    b->iface.graph_compute    = be_graph_compute;
+    b->device                 = d;
+    b->context                = c;
+    return b;
+}
+static ggml_backend_buffer_type_t dev_get_buft(ggml_backend_dev_t d) { return &((DeviceCtx*)d->context)->buft; }
+static bool dev_supports_op(ggml_backend_dev_t, const ggml_tensor* op) { return planner_supports_op(op); }
+static bool dev_supports_buft(ggml_backend_dev_t d, ggml_backend_buffer_type_t t) { return t == &((DeviceCtx*)d->context)->buft; }
+static bool dev_offload_op(ggml_backend_dev_t, const ggml_tensor*) { return false; }
+
+// ---------------------------------------------------------------- registry
+static const char* reg_get_name(ggml_backend_reg_t) { return "MI355X"; }
+static size_t reg_dev_count(ggml_backend_reg_t) { return g_devices.size(); }
+static ggml_backend_dev_t reg_get_dev(ggml_backend_reg_t, size_t i) { return i < g_devices.size() ? &g_devices[i]->dev : nullptr; }
+static void* reg_get_proc(ggml_backend_reg_t, const char* name) {
+    // optional proc addresses the host probes: split buffer type, set_n_threads, get_features -> absent
+    // (ggml_extend_backend.cpp:801-804, 440-446, 519-528).  Ours: planner statistics for tests / bench.
+    if (strcmp(name, "ggml_backend_mi355x_get_stats") == 0) return (void*)ggml_backend_mi355x_get_stats;
+    if (strcmp(name, "ggml_backend_mi355x_set_option") == 0) return (void*)ggml_backend_mi355x_set_option;
+    return nullptr;
+}
+
+static void init_once() {
+    static std::once_flag once;
+    std::call_once(once, [] {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess) {
+            (void)hipGetLastError();
+            n = 0;
+        }
+        for (int i = 0; i < n; ++i) {
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, i) != hipSuccess) continue;
+            // gfx950 only: this library contains no code object for anything else
+            if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+                fprintf(stderr, "[ggml-mi355x] skipping device %d (%s): not gfx950\n", i, prop.gcnArchName);
+                continue;
+            }
+            DeviceCtx* d = new DeviceCtx();
+            d->id        = i;
+            d->name      = "MI355X" + std::to_string((int)g_devices.size());
+            d->desc      = std::string(prop.name) + " (" + prop.gcnArchName + ", " + std::to_string(prop.multiProcessorCount) + " CUs)";
+            memset(&d->dev, 0, sizeof(d->dev));
+            d->dev.iface.get_name        = dev_get_name;
+            d->dev.iface.get_description = dev_get_desc;
+            d->dev.iface.get_memory      = dev_get_memory;
+            d->dev.iface.get_type        = dev_get_type;
+            d->dev.iface.get_props       = dev_get_props;
+            d->dev.iface.init_backend    = dev_init_backend;
+            d->dev.iface.get_buffer_type = dev_get_buft;
+            d->dev.iface.supports_op     = dev_supports_op;
+            d->dev.iface.supports_buft   = dev_supports_buft;
+            d->dev.iface.offload_op      = dev_offload_op;
+            d->dev.reg                   = &g_reg;
+            d->dev.context               = d;
+            memset(&d->buft, 0, sizeof(d->buft));
+            d->buft.iface.get_name       = buft_get_name;
+            d->buft.iface.alloc_buffer   = buft_alloc;
+            d->buft.iface.get_alignment  = buft_alignment;
+            d->buft.iface.get_max_size   = buft_max_size;
+            d->buft.iface.get_alloc_size = buft_alloc_size;
+            d->buft.iface.is_host        = buft_is_host;
+            d->buft.device               = &d->dev;
+            d->buft.context              = d;
+            g_devices.push_back(d);
+        }
+        memset(&g_reg, 0, sizeof(g_reg));
+        g_reg.api_version            = GGML_BACKEND_API_VERSION;
+        g_reg.iface.get_name         = reg_get_name;
+        g_reg.iface.get_device_count = reg_dev_count;
+        g_reg.iface.get_device       = reg_get_dev;
+        g_reg.iface.get_proc_address = reg_get_proc;
+    });
+}
+
+}  // namespace mi355x
+
+extern "C" {
+GGML_MI355X_API ggml_backend_reg_t ggml_backend_mi355x_reg(void) {
+    mi355x::init_once();
+    return &mi355x::g_reg;
+}
+GGML_MI355X_API ggml_backend_reg_t ggml_backend_init(void) { return ggml_backend_mi355x_reg(); }
+GGML_MI355X_API int ggml_backend_score(void) {
+    mi355x::init_once();
+    return mi355x::g_devices.empty() ? 0 : 100;
+}
+GGML_MI355X_API int ggml_backend_mi355x_get_device_count(void) {
+    mi355x::init_once();
+    return (int)mi355x::g_devices.size();
+}
+GGML_MI355X_API void ggml_backend_mi355x_get_stats(struct ggml_backend_mi355x_stats* out) { mi355x::planner_get_stats(out); }
+GGML_MI355X_API void ggml_backend_mi355x_set_option(const char* key, int value) { mi355x::planner_set_option(key, value); }
+}

@@ -1,0 +1,969 @@
+// planner.cpp — turns a ggml_cgraph into a list of fused gfx950 kernel launches and caches it.
+//
+// The reference rebuilds, re-allocates and re-submits the SAME graph topology for every model call
+//  and expresses each layer as a chain of primitive nodes (Appendix G).  Both facts are
+// turned into advantages here:
+//   * the first time a topology is seen it is pattern-matched into fused launches
+//       IM2COL -> RESHAPE -> MUL_MAT -> RESHAPE -> PERMUTE -> CONT [-> ADD bias] [-> ADD residual]   => implicit-GEMM conv
+//       MUL_MAT(static weight) [-> RESHAPE] [-> ADD bias] [-> ADD residual]                           => MFMA weight GEMM
+//       GROUP_NORM -> MUL -> ADD [-> SILU]   /   NORM|RMS_NORM -> MUL [-> ADD]                         => one norm kernel
+//       VIEW,VIEW -> CONT(gate) -> GELU -> MUL                                                         => GEGLU
+//       CONT(permute q/k/v) [-> CPY f16] -> FLASH_ATTN_EXT -> VIEW -> CONT      (flash flag on)        => flash attention
+//       CONT(permute v) -> MUL_MAT(k,q) -> SCALE -> SOFT_MAX -> MUL_MAT(v,kq) -> PERMUTE -> CONT      => flash attention
+//     and every remaining node gets its single-op kernel; view ops (RESHAPE/VIEW/PERMUTE/TRANSPOSE) cost nothing;
+//   * the resulting plan is keyed by a hash of the topology INCLUDING the device addresses the (deterministic)
+//     graph allocator handed out, so later calls replay the launch list without looking at the graph again.
+//
+// Fusing a chain moves its output to the LAST node's buffer, which the graph allocator may have placed on
+// top of a tensor that died inside the chain (e.g. the conv input once IM2COL has consumed it).  Every fusion
+// therefore checks the chosen output range against the kernel's inputs and, on overlap, either bounces through a
+// dead intermediate buffer of the chain (im2col / mul_mat output) or stops absorbing nodes.
+#include "planner.h"
+
+#include <atomic>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "kernels.h"
+
+namespace mi355x {
+
+namespace {
+
+struct Stats {
+    std::atomic<int64_t> graphs_computed{0}, plans_built{0}, nodes_seen{0}, kernels_planned{0}, kernels_launched{0}, fused_conv{0},
+        fused_conv_bounced{0}, fused_linear{0}, fused_norm{0}, fused_geglu{0}, fused_attention{0}, generic_matmul{0}, swizzled_weight_bytes{0},
+        graph_replays{0};
+} g_stats;
+
+struct Options {
+    std::atomic<int> fusion{1}, mfma_gemm{1}, hip_graph{0}, flash_pattern{1};
+} g_opt;
+
+using Step = std::function<void(hipStream_t)>;
+
+struct Plan {
+    int n_nodes = 0;
+    std::vector<Step> steps;
+    hipGraphExec_t graph_exec = nullptr;
+    bool graph_failed         = false;
+};
+
+struct SwzEntry {
+    void* swz;
+    size_t bytes;
+    const void* src;
+    size_t src_bytes;
+};
+
+std::mutex g_mu;
+std::vector<Planner*> g_planners;
+
+}  // namespace
+
+struct Planner {
+    int device;
+    std::unordered_map<uint64_t, std::unique_ptr<Plan>> plans;
+    std::unordered_map<uint64_t, SwzEntry> swz;  // key: hash(src ptr, kind)
+    void* scratch        = nullptr;              // small workspace for bounced outputs
+    size_t scratch_bytes = 0;
+};
+
+namespace {
+
+inline bool overlaps(const void* a, size_t an, const void* b, size_t bn) {
+    const char* pa = (const char*)a;
+    const char* pb = (const char*)b;
+    return pa < pb + bn && pb < pa + an;
+}
+
+View4 view_of(const ggml_tensor* t) {
+    View4 v;
+    v.data = t->data;
+    for (int i = 0; i < 4; ++i) {
+        v.ne[i] = t->ne[i];
+        v.nb[i] = (int64_t)t->nb[i];
+    }
+    v.type = (int)t->type;
+    return v;
+}
+inline bool is_f32(const ggml_tensor* t) { return t->type == GGML_TYPE_F32; }
+inline bool contig(const ggml_tensor* t) { return ggml_abi_is_contiguous(t); }
+inline const ggml_tensor* root_of(const ggml_tensor* t) { return t->view_src ? t->view_src : t; }
+inline bool is_static_weight(const ggml_tensor* t) {
+    const ggml_backend_buffer* b = t->view_src ? t->view_src->buffer : t->buffer;
+    return b != nullptr && b->usage == GGML_BACKEND_BUFFER_USAGE_WEIGHTS;
+}
+inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+uint64_t fnv(uint64_t h, const void* p, size_t n) {
+    const unsigned char* c = (const unsigned char*)p;
+    for (size_t i = 0; i < n; ++i) h = (h ^ c[i]) * 1099511628211ull;
+    return h;
+}
+
+uint64_t graph_key(const ggml_cgraph* g) {
+    uint64_t h = 1469598103934665603ull;
+    h          = fnv(h, &g->n_nodes, sizeof(g->n_nodes));
+    for (int i = 0; i < g->n_nodes; ++i) {
+        const ggml_tensor* n = g->nodes[i];
+        h = fnv(h, &n->op, sizeof(n->op));
+        h = fnv(h, &n->type, sizeof(n->type));
+        h = fnv(h, n->ne, sizeof(n->ne));
+        h = fnv(h, n->nb, sizeof(n->nb));
+        h = fnv(h, n->op_params, sizeof(n->op_params));
+        h = fnv(h, &n->data, sizeof(n->data));
+        const int32_t fl = n->flags & GGML_TENSOR_FLAG_OUTPUT;
+        h = fnv(h, &fl, sizeof(fl));
+        for (int j = 0; j < GGML_MAX_SRC; ++j) {
+            const ggml_tensor* s = n->src[j];
+            if (!s) break;
+            h = fnv(h, &s->data, sizeof(s->data));
+            h = fnv(h, s->ne, sizeof(s->ne));
+            h = fnv(h, s->nb, sizeof(s->nb));
+            h = fnv(h, &s->type, sizeof(s->type));
+        }
+    }
+    return h;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// graph analysis
+// ---------------------------------------------------------------------------------------------------
+struct GInfo {
+    const ggml_cgraph* g;
+    std::unordered_map<const ggml_tensor*, int> index;
+    std::vector<std::vector<int>> consumers;
+    std::vector<char> done;
+
+    explicit GInfo(const ggml_cgraph* gr) : g(gr), consumers(gr->n_nodes), done(gr->n_nodes, 0) {
+        for (int i = 0; i < g->n_nodes; ++i) index[g->nodes[i]] = i;
+        for (int i = 0; i < g->n_nodes; ++i) {
+            const ggml_tensor* n = g->nodes[i];
+            for (int j = 0; j < GGML_MAX_SRC; ++j) {
+                if (!n->src[j]) continue;
+                auto it = index.find(n->src[j]);
+                if (it != index.end()) consumers[it->second].push_back(i);
+            }
+        }
+    }
+    const ggml_tensor* node(int i) const { return g->nodes[i]; }
+    int idx(const ggml_tensor* t) const {
+        auto it = index.find(t);
+        return it == index.end() ? -1 : it->second;
+    }
+    // the only consumer of node i, provided i is not a graph output; -1 otherwise
+    int sole(int i) const {
+        if (i < 0 || consumers[i].size() != 1) return -1;
+        if (node(i)->flags & GGML_TENSOR_FLAG_OUTPUT) return -1;
+        if (i == g->n_nodes - 1) return -1;
+        return consumers[i][0];
+    }
+    // true when every node strictly between a and b is a view op or already claimed by the current chain
+    bool only_noops_between(int a, int b, const std::vector<int>& chain) const {
+        for (int k = a + 1; k < b; ++k) {
+            if (ggml_abi_op_is_noop(node(k)->op)) continue;
+            bool in_chain = false;
+            for (int c : chain) in_chain = in_chain || (c == k);
+            if (!in_chain) return false;
+        }
+        return true;
+    }
+};
+
+struct Builder {
+    Planner* P;
+    Plan* plan;
+    GInfo gi;
+    Builder(Planner* p, Plan* pl, const ggml_cgraph* g) : P(p), plan(pl), gi(g) {}
+    void emit(Step s) { plan->steps.push_back(std::move(s)); }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// swizzled weights
+// ---------------------------------------------------------------------------------------------------
+const void* get_swz_linear(Planner* P, const ggml_tensor* w, hipStream_t s) {
+    uint64_t key = fnv(fnv(1469598103934665603ull, &w->data, sizeof(w->data)), "L", 1);
+    auto it      = P->swz.find(key);
+    if (it != P->swz.end()) return it->second.swz;
+    const int64_t K = w->ne[0], R = w->ne[1];
+    const size_t bytes = wswz_bytes(R, K);
+    void* d            = nullptr;
+    if (hipMalloc(&d, bytes) != hipSuccess) return nullptr;
+    launch_wswz_linear(s, d, w->data, (int)w->type, K, R, (int64_t)w->nb[1]);
+    P->swz[key] = {d, bytes, w->data, ggml_abi_nbytes(w)};
+    g_stats.swizzled_weight_bytes += (int64_t)bytes;
+    return d;
+}
+const void* get_swz_conv(Planner* P, const ggml_tensor* w, hipStream_t s) {
+    uint64_t key = fnv(fnv(1469598103934665603ull, &w->data, sizeof(w->data)), "C", 1);
+    auto it      = P->swz.find(key);
+    if (it != P->swz.end()) return it->second.swz;
+    const int64_t KW = w->ne[0], KH = w->ne[1], IC = w->ne[2], OC = w->ne[3];
+    const int64_t ICp  = (IC + 31) / 32 * 32;
+    const size_t bytes = wswz_bytes(OC, ICp * KW * KH);
+    void* d            = nullptr;
+    if (hipMalloc(&d, bytes) != hipSuccess) return nullptr;
+    launch_wswz_conv(s, d, w->data, KW, KH, IC, OC);
+    P->swz[key] = {d, bytes, w->data, ggml_abi_nbytes(w)};
+    g_stats.swizzled_weight_bytes += (int64_t)bytes;
+    return d;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// single-node kernels
+// ---------------------------------------------------------------------------------------------------
+bool plan_single(Builder& B, int i, hipStream_t s);
+
+bool bias_like_chan(const ggml_tensor* b, int64_t C) {  // [1,1,C,1] f32 contiguous
+    return b && is_f32(b) && b->ne[0] == 1 && b->ne[1] == 1 && b->ne[2] == C && b->ne[3] == 1;
+}
+bool bias_like_row(const ggml_tensor* b, int64_t M) {  // [M] f32
+    return b && is_f32(b) && b->ne[0] == M && b->ne[1] == 1 && b->ne[2] == 1 && b->ne[3] == 1 && b->nb[0] == 4;
+}
+
+// MUL_MAT with a static weight on the MFMA path?  tokens = product of src1 dims 1..3 (must be collapsible)
+bool linear_fast_ok(const ggml_tensor* n) {
+    const ggml_tensor* w = n->src[0];
+    const ggml_tensor* x = n->src[1];
+    if (!g_opt.mfma_gemm) return false;
+    if (!is_static_weight(w) || !is_f32(x) || !is_f32(n)) return false;
+    if (!(w->type == GGML_TYPE_F16 || w->type == GGML_TYPE_F32 || w->type == GGML_TYPE_BF16 || w->type == GGML_TYPE_Q8_0 || w->type == GGML_TYPE_Q4_0)) return false;
+    if (w->ne[2] != 1 || w->ne[3] != 1 || !contig(w)) return false;
+    if (x->nb[0] != 4 || x->ne[0] % 4 != 0 || x->nb[1] % 16 != 0 || !aligned16(x->data)) return false;
+    if (x->ne[2] > 1 && x->nb[2] != x->nb[1] * (size_t)x->ne[1]) return false;
+    if (x->ne[3] > 1 && x->nb[3] != x->nb[2] * (size_t)x->ne[2]) return false;
+    if (!contig(n)) return false;
+    return true;
+}
+
+void plan_linear(Builder& B, int i, hipStream_t s, std::vector<int>& chain) {
+    GInfo& gi            = B.gi;
+    const ggml_tensor* n = gi.node(i);
+    const ggml_tensor* w = n->src[0];
+    const ggml_tensor* x = n->src[1];
+    const int64_t K = w->ne[0], M = w->ne[1], tokens = x->ne[1] * x->ne[2] * x->ne[3];
+    Epilogue ep;
+    int last = i;
+    chain.push_back(i);
+    if (g_opt.fusion) {
+        // [RESHAPE] -> ADD bias
+        int j = gi.sole(last);
+        int via = last;
+        while (j >= 0 && gi.node(j)->op == GGML_OP_RESHAPE) {
+            via = j;
+            j   = gi.sole(j);
+        }
+        if (j >= 0 && gi.node(j)->op == GGML_OP_ADD && gi.node(j)->src[0] == gi.node(via) && bias_like_row(gi.node(j)->src[1], M) &&
+            gi.node(j)->data == n->data && gi.only_noops_between(i, j, chain)) {
+            ep.bias = (const float*)gi.node(j)->src[1]->data;
+            chain.push_back(j);
+            last = j;
+            // -> ADD residual (either operand order), same shape, contiguous
+            int r = gi.sole(last);
+            if (r >= 0 && gi.node(r)->op == GGML_OP_ADD && gi.only_noops_between(last, r, chain)) {
+                const ggml_tensor* a = gi.node(r);
+                const ggml_tensor* other = a->src[0] == gi.node(last) ? a->src[1] : (a->src[1] == gi.node(last) ? a->src[0] : nullptr);
+                if (other && is_f32(other) && contig(other) && contig(a) && ggml_abi_same_shape(other, a) && ggml_abi_same_shape(gi.node(last), a) &&
+                    gi.idx(other) < i) {
+                    const size_t ob = ggml_abi_nbytes(a);
+                    // dst must not land on the activation tile the other workgroups are still reading
+                    if (!overlaps(a->data, ob, x->data, ggml_abi_nbytes(x)) && (other->data == a->data || !overlaps(a->data, ob, other->data, ob))) {
+                        ep.residual = (const float*)other->data;
+                        chain.push_back(r);
+                        last = r;
+                    }
+                }
+            }
+        }
+    }
+    const void* swz = get_swz_linear(B.P, w, s);
+    float* dst      = (float*)gi.node(last)->data;
+    const float* xp = (const float*)x->data;
+    const int64_t xs = (int64_t)x->nb[1] / 4;
+    B.emit([=](hipStream_t st) { launch_linear_mfma(st, dst, xp, swz, tokens, K, M, xs, M, ep); });
+    g_stats.fused_linear++;
+}
+
+// IM2COL chain -> implicit GEMM conv.  Returns false if the pattern does not match.
+bool plan_conv_chain(Builder& B, int i, hipStream_t s, std::vector<int>& chain) {
+    GInfo& gi              = B.gi;
+    const ggml_tensor* im  = gi.node(i);
+    const ggml_tensor* ker = im->src[0];
+    const ggml_tensor* x   = im->src[1];
+    const int32_t* p       = im->op_params;
+    if (!g_opt.mfma_gemm || !g_opt.fusion) return false;
+    if (p[6] != 1 || p[4] != 1 || p[5] != 1) return false;                       // 2-D, no dilation
+    if (ker->type != GGML_TYPE_F16 || !is_static_weight(ker) || !contig(ker)) return false;
+    if (!is_f32(x) || !contig(x)) return false;
+    const int KW = (int)ker->ne[0], KH = (int)ker->ne[1];
+    const int s0 = p[0], s1 = p[1], p0 = p[2], p1 = p[3];
+    if (KW != KH || s0 != s1 || p0 != p1) return false;
+    if (!((KW == 3 && p0 == 1 && (s0 == 1 || s0 == 2)) || (KW == 1 && p0 == 0 && s0 == 1))) return false;
+    const int64_t IC = ker->ne[2], OC = ker->ne[3], N = x->ne[3];
+    // RESHAPE -> MUL_MAT -> RESHAPE -> PERMUTE -> CONT
+    int j1 = gi.sole(i);
+    if (j1 < 0 || gi.node(j1)->op != GGML_OP_RESHAPE) return false;
+    int j2 = gi.sole(j1);
+    if (j2 < 0 || gi.node(j2)->op != GGML_OP_MUL_MAT || gi.node(j2)->src[0] != gi.node(j1)) return false;
+    if (root_of(gi.node(j2)->src[1]) != root_of(ker)) return false;
+    int j3 = gi.sole(j2);
+    if (j3 < 0 || gi.node(j3)->op != GGML_OP_RESHAPE) return false;
+    int j4 = gi.sole(j3);
+    if (j4 < 0 || gi.node(j4)->op != GGML_OP_PERMUTE) return false;
+    const int32_t* ax = gi.node(j4)->op_params;
+    if (!(ax[0] == 0 && ax[1] == 1 && ax[2] == 3 && ax[3] == 2)) return false;
+    int j5 = gi.sole(j4);
+    if (j5 < 0 || gi.node(j5)->op != GGML_OP_CONT) return false;
+    chain = {i, j1, j2, j3, j4, j5};
+    if (!gi.only_noops_between(i, j5, chain)) return false;
+    const ggml_tensor* out = gi.node(j5);  // [OW,OH,OC,N]
+    if (!contig(out) || out->ne[2] != OC || out->ne[3] != N) return false;
+
+    Epilogue ep;
+    int last = j5;
+    // -> ADD bias [1,1,OC,1]
+    int j6 = gi.sole(last);
+    if (j6 >= 0 && gi.node(j6)->op == GGML_OP_ADD && gi.node(j6)->src[0] == gi.node(last) && bias_like_chan(gi.node(j6)->src[1], OC) &&
+        gi.node(j6)->data == out->data && gi.only_noops_between(last, j6, chain)) {
+        ep.bias = (const float*)gi.node(j6)->src[1]->data;
+        chain.push_back(j6);
+        last = j6;
+    }
+    // -> ADD residual (same shape, either operand order), only when it directly follows
+    const size_t ob = ggml_abi_nbytes(out);
+    {
+        int r = gi.sole(last);
+        if (r >= 0 && gi.node(r)->op == GGML_OP_ADD && gi.only_noops_between(last, r, chain)) {
+            const ggml_tensor* a     = gi.node(r);
+            const ggml_tensor* other = a->src[0] == gi.node(last) ? a->src[1] : (a->src[1] == gi.node(last) ? a->src[0] : nullptr);
+            if (other && is_f32(other) && contig(other) && contig(a) && ggml_abi_same_shape(other, a) && ggml_abi_same_shape(out, a) && gi.idx(other) < i &&
+                (other->data == a->data || !overlaps(a->data, ob, other->data, ob))) {
+                ep.residual = (const float*)other->data;
+                chain.push_back(r);
+                last = r;
+            }
+        }
+    }
+    const void* swz = get_swz_conv(B.P, ker, s);
+    if (!swz) return false;
+    float* final_dst = (float*)gi.node(last)->data;
+    const float* xp  = (const float*)x->data;
+    const size_t xb  = ggml_abi_nbytes(x);
+    const int64_t W = x->ne[0], H = x->ne[1];
+    float* kdst = final_dst;
+    if (overlaps(final_dst, ob, xp, xb)) {
+        // the allocator recycled the conv input for the chain's output: bounce through a dead intermediate
+        float* cand1 = (float*)gi.node(j2)->data;                                  // MUL_MAT output, same byte size
+        float* cand2 = ggml_abi_nbytes(im) >= ob ? (float*)im->data : nullptr;     // im2col buffer (never written by us)
+        auto clean   = [&](float* c) {
+            return c && !overlaps(c, ob, xp, xb) && !overlaps(c, ob, final_dst, ob) && (!ep.residual || !overlaps(c, ob, ep.residual, ob));
+        };
+        if (clean(cand1))
+            kdst = cand1;
+        else if (clean(cand2))
+            kdst = cand2;
+        else
+            return false;  // fall back to the unfused path
+        g_stats.fused_conv_bounced++;
+    }
+    const int ks = KW, st_ = s0, pd = p0;
+    if (kdst == final_dst) {
+        B.emit([=](hipStream_t st) { launch_conv2d_mfma(st, final_dst, xp, swz, W, H, IC, N, OC, ks, st_, pd, false, ep); });
+    } else {
+        const int64_t nel = ggml_abi_nelements(out);
+        B.emit([=](hipStream_t st) {
+            launch_conv2d_mfma(st, kdst, xp, swz, W, H, IC, N, OC, ks, st_, pd, false, ep);
+            View4 d, sv;
+            d.data = final_dst;
+            sv.data = kdst;
+            d.type = sv.type = 0;
+            d.ne[0] = sv.ne[0] = nel;
+            d.nb[0] = sv.nb[0] = 4;
+            for (int q = 1; q < 4; ++q) {
+                d.ne[q] = sv.ne[q] = 1;
+                d.nb[q] = sv.nb[q] = nel * 4;
+            }
+            launch_copy(st, d, sv);
+        });
+        g_stats.kernels_planned++;
+    }
+    g_stats.fused_conv++;
+    return true;
+}
+
+// GROUP_NORM -> MUL -> ADD [-> SILU]
+bool plan_group_norm(Builder& B, int i, hipStream_t, std::vector<int>& chain) {
+    GInfo& gi            = B.gi;
+    const ggml_tensor* n = gi.node(i);
+    const ggml_tensor* x = n->src[0];
+    if (!is_f32(x) || !contig(x) || !contig(n)) return false;
+    const int groups = n->op_params[0];
+    const float eps  = ggml_abi_op_param_f32(n, 1);
+    const int64_t hw = x->ne[0] * x->ne[1], C = x->ne[2], N = x->ne[3];
+    const float *w = nullptr, *b = nullptr;
+    bool silu = false;
+    chain.push_back(i);
+    int last = i;
+    if (g_opt.fusion) {
+        int j1 = gi.sole(i);
+        if (j1 >= 0 && gi.node(j1)->op == GGML_OP_MUL && gi.node(j1)->src[0] == n && bias_like_chan(gi.node(j1)->src[1], C) && gi.node(j1)->data == n->data &&
+            gi.only_noops_between(i, j1, chain)) {
+            int j2 = gi.sole(j1);
+            if (j2 >= 0 && gi.node(j2)->op == GGML_OP_ADD && gi.node(j2)->src[0] == gi.node(j1) && bias_like_chan(gi.node(j2)->src[1], C) &&
+                gi.node(j2)->data == n->data && gi.only_noops_between(j1, j2, chain)) {
+                w = (const float*)gi.node(j1)->src[1]->data;
+                b = (const float*)gi.node(j2)->src[1]->data;
+                chain.push_back(j1);
+                chain.push_back(j2);
+                last   = j2;
+                int j3 = gi.sole(j2);
+                if (j3 >= 0 && gi.node(j3)->op == GGML_OP_UNARY && ggml_abi_get_unary_op(gi.node(j3)) == GGML_UNARY_OP_SILU && gi.node(j3)->data == n->data &&
+                    gi.only_noops_between(j2, j3, chain)) {
+                    silu = true;
+                    chain.push_back(j3);
+                    last = j3;
+                }
+            }
+        }
+    }
+    float* dst      = (float*)n->data;
+    const float* xp = (const float*)x->data;
+    B.emit([=](hipStream_t st) { launch_group_norm(st, dst, xp, hw, C, N, groups, eps, w, b, silu); });
+    if (last != i) g_stats.fused_norm++;
+    return true;
+}
+
+// NORM / RMS_NORM -> MUL(w[C]) [-> ADD(b[C])]
+bool plan_layer_norm(Builder& B, int i, hipStream_t, std::vector<int>& chain) {
+    GInfo& gi            = B.gi;
+    const ggml_tensor* n = gi.node(i);
+    const ggml_tensor* x = n->src[0];
+    if (!is_f32(x) || x->nb[0] != 4 || n->nb[0] != 4) return false;
+    // rows must be uniformly strided: collapse dims 1..3
+    if ((x->ne[2] > 1 && x->nb[2] != x->nb[1] * (size_t)x->ne[1]) || (x->ne[3] > 1 && x->nb[3] != x->nb[2] * (size_t)x->ne[2])) return false;
+    if ((n->ne[2] > 1 && n->nb[2] != n->nb[1] * (size_t)n->ne[1]) || (n->ne[3] > 1 && n->nb[3] != n->nb[2] * (size_t)n->ne[2])) return false;
+    const bool rms   = n->op == GGML_OP_RMS_NORM;
+    const float eps  = ggml_abi_op_param_f32(n, 0);
+    const int64_t C = x->ne[0], rows = x->ne[1] * x->ne[2] * x->ne[3];
+    const float *w = nullptr, *b = nullptr;
+    chain.push_back(i);
+    int last = i;
+    if (g_opt.fusion) {
+        int j1 = gi.sole(i);
+        if (j1 >= 0 && gi.node(j1)->op == GGML_OP_MUL && gi.node(j1)->src[0] == n && bias_like_row(gi.node(j1)->src[1], C) && gi.node(j1)->data == n->data &&
+            gi.only_noops_between(i, j1, chain)) {
+            w = (const float*)gi.node(j1)->src[1]->data;
+            chain.push_back(j1);
+            last   = j1;
+            int j2 = gi.sole(j1);
+            if (j2 >= 0 && gi.node(j2)->op == GGML_OP_ADD && gi.node(j2)->src[0] == gi.node(j1) && bias_like_row(gi.node(j2)->src[1], C) &&
+                gi.node(j2)->data == n->data && gi.only_noops_between(j1, j2, chain)) {
+                b = (const float*)gi.node(j2)->src[1]->data;
+                chain.push_back(j2);
+                last = j2;
+            }
+        }
+    }
+    float* dst      = (float*)n->data;
+    const float* xp = (const float*)x->data;
+    const int64_t xs = (int64_t)x->nb[1] / 4, ds = (int64_t)n->nb[1] / 4;
+    B.emit([=](hipStream_t st) { launch_layer_norm(st, dst, xp, C, rows, xs, ds, eps, w, b, rms); });
+    if (last != i) g_stats.fused_norm++;
+    return true;
+}
+
+// CONT(view hi half) -> GELU -> MUL(view lo half, .)   (block.hpp:193-210)
+bool plan_geglu(Builder& B, int i, hipStream_t, std::vector<int>& chain) {
+    GInfo& gi            = B.gi;
+    const ggml_tensor* c = gi.node(i);
+    if (!g_opt.fusion || c->op != GGML_OP_CONT) return false;
+    const ggml_tensor* vhi = c->src[0];
+    if (!vhi || vhi->op != GGML_OP_VIEW || !vhi->view_src || !is_f32(c)) return false;
+    const ggml_tensor* X = vhi->view_src;
+    const int64_t inner  = vhi->ne[0];
+    if (!is_f32(X) || !contig(X) || X->ne[0] != 2 * inner || inner % 4 != 0) return false;
+    if ((const char*)vhi->data != (const char*)X->data + inner * 4) return false;
+    if (vhi->nb[1] != X->nb[1] || vhi->nb[2] != X->nb[2] || vhi->nb[3] != X->nb[3]) return false;
+    int j1 = gi.sole(i);
+    if (j1 < 0 || gi.node(j1)->op != GGML_OP_UNARY || ggml_abi_get_unary_op(gi.node(j1)) != GGML_UNARY_OP_GELU || gi.node(j1)->src[0] != c) return false;
+    int j2 = gi.sole(j1);
+    if (j2 < 0 || gi.node(j2)->op != GGML_OP_MUL || gi.node(j2)->src[1] != gi.node(j1)) return false;
+    const ggml_tensor* vlo = gi.node(j2)->src[0];
+    if (!vlo || vlo->view_src != X || vlo->data != X->data || vlo->ne[0] != inner || vlo->nb[1] != X->nb[1]) return false;
+    chain = {i, j1, j2};
+    if (!gi.only_noops_between(i, j2, chain)) return false;
+    const ggml_tensor* out = gi.node(j2);
+    if (!contig(out) || !aligned16(out->data) || !aligned16(X->data)) return false;
+    const int64_t tokens = X->ne[1] * X->ne[2] * X->ne[3];
+    if (overlaps(out->data, ggml_abi_nbytes(out), X->data, ggml_abi_nbytes(X))) return false;
+    float* dst      = (float*)out->data;
+    const float* xp = (const float*)X->data;
+    const int64_t xs = (int64_t)X->nb[1] / 4;
+    B.emit([=](hipStream_t st) { launch_geglu(st, dst, xp, tokens, inner, xs); });
+    g_stats.fused_geglu++;
+    return true;
+}
+
+// manual attention (flash flag off): MUL_MAT(k,q) -> SCALE -> SOFT_MAX -> MUL_MAT(vT, kq)  (ggml_extend.hpp:1460-1479)
+// => one flash kernel; the [Lk,Lq,H] score tensor is never written.
+bool plan_manual_attention(Builder& B, int i, hipStream_t, std::vector<int>& chain) {
+    GInfo& gi             = B.gi;
+    const ggml_tensor* kq = gi.node(i);
+    if (!g_opt.fusion || !g_opt.flash_pattern) return false;
+    const ggml_tensor* k = kq->src[0];
+    const ggml_tensor* q = kq->src[1];
+    if (!is_f32(k) || !is_f32(q) || is_static_weight(k) || k->nb[0] != 4 || q->nb[0] != 4) return false;
+    if (k->ne[3] != 1 || q->ne[3] != 1 || k->ne[2] != q->ne[2]) return false;
+    int j1 = gi.sole(i);
+    if (j1 < 0 || gi.node(j1)->op != GGML_OP_SCALE || gi.node(j1)->src[0] != kq || ggml_abi_op_param_f32(gi.node(j1), 1) != 0.f) return false;
+    int j2 = gi.sole(j1);
+    if (j2 < 0 || gi.node(j2)->op != GGML_OP_SOFT_MAX || gi.node(j2)->src[0] != gi.node(j1) || gi.node(j2)->src[1] != nullptr) return false;
+    if (ggml_abi_op_param_f32(gi.node(j2), 0) != 1.0f || ggml_abi_op_param_f32(gi.node(j2), 1) != 0.0f) return false;
+    int j3 = gi.sole(j2);
+    if (j3 < 0 || gi.node(j3)->op != GGML_OP_MUL_MAT || gi.node(j3)->src[1] != gi.node(j2)) return false;
+    const ggml_tensor* vt  = gi.node(j3)->src[0];  // [Lk, dv, HN]
+    const ggml_tensor* out = gi.node(j3);          // [dv, Lq, HN]
+    if (!is_f32(vt) || is_static_weight(vt) || vt->nb[0] != 4 || vt->ne[3] != 1 || vt->ne[2] != q->ne[2] || vt->ne[0] != k->ne[1]) return false;
+    if (!flash_attn_supported(q->ne[0], vt->ne[1]) || !contig(out)) return false;
+    chain = {i, j1, j2, j3};
+    if (!gi.only_noops_between(i, j3, chain)) return false;
+    const float scale = ggml_abi_op_param_f32(gi.node(j1), 0);
+    const size_t ob   = ggml_abi_nbytes(out);
+    float* dst        = (float*)out->data;
+    auto clean        = [&](const void* c) {
+        return !overlaps(c, ob, q->data, ggml_abi_nbytes(q)) && !overlaps(c, ob, k->data, ggml_abi_nbytes(k)) && !overlaps(c, ob, vt->data, ggml_abi_nbytes(vt));
+    };
+    float* kdst = dst;
+    if (!clean(dst)) {
+        if (ggml_abi_nbytes(kq) >= ob && clean(kq->data) && !overlaps(kq->data, ob, dst, ob))
+            kdst = (float*)kq->data;  // the (never written) score buffer doubles as bounce space
+        else
+            return false;
+    }
+    View4 qv = view_of(q), kv = view_of(k), vv;
+    // present vT [Lk, dv, HN] as v [dv, Lk, HN] with swapped strides
+    vv.data  = vt->data;
+    vv.type  = (int)vt->type;
+    vv.ne[0] = vt->ne[1];
+    vv.ne[1] = vt->ne[0];
+    vv.ne[2] = vt->ne[2];
+    vv.ne[3] = 1;
+    vv.nb[0] = (int64_t)vt->nb[1];
+    vv.nb[1] = (int64_t)vt->nb[0];
+    vv.nb[2] = (int64_t)vt->nb[2];
+    vv.nb[3] = (int64_t)vt->nb[3];
+    const int64_t nbq = (int64_t)out->nb[1], nbh = (int64_t)out->nb[2];
+    const int64_t nel = ggml_abi_nelements(out);
+    B.emit([=](hipStream_t st) {
+        launch_flash_attn(st, kdst, nbq, nbh, qv, kv, vv, scale);
+        if (kdst != dst) (void)hipMemcpyAsync(dst, kdst, nel * 4, hipMemcpyDeviceToDevice, st);
+    });
+    g_stats.fused_attention++;
+    return true;
+}
+
+bool plan_single(Builder& B, int i, hipStream_t s) {
+    GInfo& gi            = B.gi;
+    const ggml_tensor* n = gi.node(i);
+    switch (n->op) {
+        case GGML_OP_DUP:
+        case GGML_OP_CONT:
+        case GGML_OP_CPY: {
+            View4 d = view_of(n), sv = view_of(n->src[0]);
+            B.emit([=](hipStream_t st) { launch_copy(st, d, sv); });
+            return true;
+        }
+        case GGML_OP_ADD:
+        case GGML_OP_SUB:
+        case GGML_OP_MUL:
+        case GGML_OP_DIV: {
+            const BinOp op = n->op == GGML_OP_ADD ? BIN_ADD : n->op == GGML_OP_SUB ? BIN_SUB : n->op == GGML_OP_MUL ? BIN_MUL : BIN_DIV;
+            View4 a = view_of(n->src[0]), b = view_of(n->src[1]);
+            View4 d = view_of(n);
+            B.emit([=](hipStream_t st) { launch_binary(st, op, (void*)d.data, d.nb, a, b); });
+            return true;
+        }
+        case GGML_OP_SCALE: {
+            const float sc = ggml_abi_op_param_f32(n, 0), bias = ggml_abi_op_param_f32(n, 1);
+            const int64_t nel = ggml_abi_nelements(n);
+            float* dst        = (float*)n->data;
+            const float* src  = (const float*)n->src[0]->data;
+            B.emit([=](hipStream_t st) { launch_scale(st, dst, src, nel, sc, bias); });
+            return true;
+        }
+        case GGML_OP_UNARY: {
+            UnOp u;
+            switch (ggml_abi_get_unary_op(n)) {
+                case GGML_UNARY_OP_SILU: u = UN_SILU; break;
+                case GGML_UNARY_OP_GELU: u = UN_GELU; break;
+                case GGML_UNARY_OP_GELU_QUICK: u = UN_GELU_QUICK; break;
+                case GGML_UNARY_OP_SIGMOID: u = UN_SIGMOID; break;
+                case GGML_UNARY_OP_TANH: u = UN_TANH; break;
+                case GGML_UNARY_OP_RELU: u = UN_RELU; break;
+                case GGML_UNARY_OP_NEG: u = UN_NEG; break;
+                case GGML_UNARY_OP_EXP: u = UN_EXP; break;
+                default: return false;
+            }
+            const int64_t nel = ggml_abi_nelements(n);
+            float* dst        = (float*)n->data;
+            const float* src  = (const float*)n->src[0]->data;
+            B.emit([=](hipStream_t st) { launch_unary(st, u, dst, src, nel); });
+            return true;
+        }
+        case GGML_OP_SOFT_MAX: {
+            const float sc    = ggml_abi_op_param_f32(n, 0);
+            const int64_t nc = n->ne[0], nr = ggml_abi_nrows(n);
+            float* dst        = (float*)n->data;
+            const float* src  = (const float*)n->src[0]->data;
+            const bool has_m  = n->src[1] != nullptr;
+            View4 mv{};
+            if (has_m) mv = view_of(n->src[1]);
+            const int64_t rpm = n->ne[1];
+            B.emit([=](hipStream_t st) { launch_soft_max(st, dst, src, nc, nr, sc, has_m ? &mv : nullptr, rpm); });
+            return true;
+        }
+        case GGML_OP_MUL_MAT: {
+            View4 a = view_of(n->src[0]), b = view_of(n->src[1]);
+            View4 d = view_of(n);
+            B.emit([=](hipStream_t st) { launch_mul_mat_generic(st, (float*)d.data, d.ne, d.nb, a, b); });
+            g_stats.generic_matmul++;
+            return true;
+        }
+        case GGML_OP_IM2COL: {
+            const int32_t* p = n->op_params;
+            View4 x          = view_of(n->src[1]);
+            const int64_t KW = n->src[0]->ne[0], KH = p[6] ? n->src[0]->ne[1] : 1;
+            const int64_t OW = n->ne[1], OH = p[6] ? n->ne[2] : 1;
+            void* dst        = n->data;
+            const int dt     = (int)n->type;
+            const int s0 = p[0], s1 = p[1], p0 = p[2], p1 = p[3], d0 = p[4], d1 = p[5];
+            B.emit([=](hipStream_t st) { launch_im2col_f16(st, dst, dt, x, KW, KH, OW, OH, s0, s1, p0, p1, d0, d1); });
+            return true;
+        }
+        case GGML_OP_CONV_2D: {
+            const ggml_tensor* ker = n->src[0];
+            const ggml_tensor* x   = n->src[1];
+            const int32_t* p       = n->op_params;
+            const void* swz        = get_swz_conv(B.P, ker, s);
+            if (!swz) return false;
+            float* dst      = (float*)n->data;
+            const float* xp = (const float*)x->data;
+            const int64_t W = x->ne[0], H = x->ne[1], IC = x->ne[2], N = x->ne[3], OC = ker->ne[3];
+            const int ks = (int)ker->ne[0], st_ = p[0], pd = p[2];
+            Epilogue ep;
+            B.emit([=](hipStream_t st) { launch_conv2d_mfma(st, dst, xp, swz, W, H, IC, N, OC, ks, st_, pd, false, ep); });
+            return true;
+        }
+        case GGML_OP_CONCAT: {
+            View4 d = view_of(n), a = view_of(n->src[0]), b = view_of(n->src[1]);
+            const int dim = n->op_params[0];
+            B.emit([=](hipStream_t st) { launch_concat(st, d, a, b, dim); });
+            return true;
+        }
+        case GGML_OP_REPEAT: {
+            View4 d = view_of(n), a = view_of(n->src[0]);
+            B.emit([=](hipStream_t st) { launch_repeat(st, d, a); });
+            return true;
+        }
+        case GGML_OP_UPSCALE: {
+            View4 d = view_of(n), a = view_of(n->src[0]);
+            B.emit([=](hipStream_t st) { launch_upscale_nearest(st, d, a); });
+            return true;
+        }
+        case GGML_OP_PAD: {
+            View4 d = view_of(n), a = view_of(n->src[0]);
+            int32_t pads[8];
+            memcpy(pads, n->op_params, sizeof(pads));
+            B.emit([=](hipStream_t st) { launch_pad(st, d, a, pads); });
+            return true;
+        }
+        case GGML_OP_TIMESTEP_EMBEDDING: {
+            float* dst       = (float*)n->data;
+            const float* t   = (const float*)n->src[0]->data;
+            const int cnt = (int)n->src[0]->ne[0], dim = n->op_params[0], mp = n->op_params[1];
+            const int64_t rs = (int64_t)n->nb[1] / 4;
+            B.emit([=](hipStream_t st) { launch_timestep_embedding(st, dst, t, cnt, dim, mp, rs); });
+            return true;
+        }
+        case GGML_OP_FLASH_ATTN_EXT: {
+            View4 q = view_of(n->src[0]), k = view_of(n->src[1]), v = view_of(n->src[2]);
+            float* dst       = (float*)n->data;
+            const float sc   = ggml_abi_op_param_f32(n, 0);
+            // dst.ne = [dv, H, Lq, B]: element (d, q, h) at h*nb1 + q*nb2
+            const int64_t nbq = (int64_t)n->nb[2], nbh = (int64_t)n->nb[1];
+            B.emit([=](hipStream_t st) { launch_flash_attn(st, dst, nbq, nbh, q, k, v, sc); });
+            g_stats.fused_attention++;
+            return true;
+        }
+        default:
+            return false;
+    }
+}
+
+bool build_plan(Planner* P, Plan* plan, const ggml_cgraph* g, hipStream_t s) {
+    Builder B(P, plan, g);
+    GInfo& gi = B.gi;
+    for (int i = 0; i < g->n_nodes; ++i) {
+        if (gi.done[i]) continue;
+        const ggml_tensor* n = gi.node(i);
+        if (ggml_abi_op_is_noop(n->op)) continue;
+        if (ggml_abi_nelements(n) == 0) continue;
+        std::vector<int> chain;
+        bool ok = false;
+        switch (n->op) {
+            case GGML_OP_IM2COL: ok = plan_conv_chain(B, i, s, chain); break;
+            case GGML_OP_MUL_MAT:
+                if (linear_fast_ok(n)) {
+                    plan_linear(B, i, s, chain);
+                    ok = true;
+                } else {
+                    ok = plan_manual_attention(B, i, s, chain);
+                }
+                break;
+            case GGML_OP_GROUP_NORM: ok = plan_group_norm(B, i, s, chain); break;
+            case GGML_OP_NORM:
+            case GGML_OP_RMS_NORM: ok = plan_layer_norm(B, i, s, chain); break;
+            case GGML_OP_CONT: ok = plan_geglu(B, i, s, chain); break;
+            default: break;
+        }
+        if (ok) {
+            for (int c : chain) gi.done[c] = 1;
+            continue;
+        }
+        if (!planner_supports_op(n) || !plan_single(B, i, s)) {
+            fprintf(stderr, "[ggml-mi355x] unsupported node %d: op=%d type=%d name=%s\n", i, (int)n->op, (int)n->type, n->name);
+            return false;
+        }
+        gi.done[i] = 1;
+    }
+    plan->n_nodes = g->n_nodes;
+    g_stats.plans_built++;
+    g_stats.nodes_seen += g->n_nodes;
+    g_stats.kernels_planned += (int64_t)plan->steps.size();
+    return true;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------
+Planner* planner_create(int device) {
+    Planner* p = new Planner();
+    p->device  = device;
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_planners.push_back(p);
+    return p;
+}
+
+static void planner_clear_locked(Planner* p) {
+    for (auto& kv : p->plans)
+        if (kv.second->graph_exec) (void)hipGraphExecDestroy(kv.second->graph_exec);
+    p->plans.clear();
+}
+
+void planner_destroy(Planner* p) {
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        for (size_t i = 0; i < g_planners.size(); ++i)
+            if (g_planners[i] == p) {
+                g_planners.erase(g_planners.begin() + i);
+                break;
+            }
+        planner_clear_locked(p);
+    }
+    for (auto& kv : p->swz) (void)hipFree(kv.second.swz);
+    if (p->scratch) (void)hipFree(p->scratch);
+    delete p;
+}
+
+void planner_forget_range(const void* ptr, size_t size) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (Planner* p : g_planners) {
+        if (p->plans.empty() && p->swz.empty()) continue;
+        (void)hipDeviceSynchronize();
+        planner_clear_locked(p);  // plans hold raw device addresses: drop them all (rare: buffer free / weight rewrite)
+        for (auto it = p->swz.begin(); it != p->swz.end();) {
+            if (overlaps(it->second.src, it->second.src_bytes, ptr, size)) {
+                (void)hipFree(it->second.swz);
+                it = p->swz.erase(it);
+            } else {
+                ++it;
+            }
+        }
+    }
+}
+
+enum ggml_status planner_compute(Planner* p, ggml_cgraph* g, hipStream_t stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_stats.graphs_computed++;
+    const uint64_t key = graph_key(g);
+    Plan* plan         = nullptr;
+    auto it            = p->plans.find(key);
+    if (it != p->plans.end() && it->second->n_nodes == g->n_nodes) {
+        plan = it->second.get();
+    } else {
+        std::unique_ptr<Plan> np(new Plan());
+        if (!build_plan(p, np.get(), g, stream)) return GGML_STATUS_FAILED;
+        plan         = np.get();
+        p->plans[key] = std::move(np);
+    }
+    if (g_opt.hip_graph && !plan->graph_failed) {
+        if (!plan->graph_exec) {
+            hipGraph_t hg = nullptr;
+            if (hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                for (auto& st : plan->steps) st(stream);
+                if (hipStreamEndCapture(stream, &hg) == hipSuccess && hg && hipGraphInstantiate(&plan->graph_exec, hg, nullptr, nullptr, 0) == hipSuccess) {
+                    (void)hipGraphDestroy(hg);
+                } else {
+                    plan->graph_failed = true;
+                    plan->graph_exec   = nullptr;
+                    (void)hipGetLastError();
+                }
+            } else {
+                plan->graph_failed = true;
+                (void)hipGetLastError();
+            }
+        }
+        if (plan->graph_exec) {
+            if (hipGraphLaunch(plan->graph_exec, stream) == hipSuccess) {
+                g_stats.graph_replays++;
+                g_stats.kernels_launched += (int64_t)plan->steps.size();
+                return GGML_STATUS_SUCCESS;
+            }
+            plan->graph_failed = true;
+            (void)hipGetLastError();
+        }
+    }
+    for (auto& st : plan->steps) st(stream);
+    g_stats.kernels_launched += (int64_t)plan->steps.size();
+    if (hipPeekAtLastError() != hipSuccess) {
+        fprintf(stderr, "[ggml-mi355x] kernel launch error: %s\n", hipGetErrorString(hipGetLastError()));
+        return GGML_STATUS_FAILED;
+    }
+    return GGML_STATUS_SUCCESS;
+}
+
+bool planner_supports_op(const ggml_tensor* n) {
+    auto f32c = [](const ggml_tensor* t) { return t && t->type == GGML_TYPE_F32; };
+    switch (n->op) {
+        case GGML_OP_NONE:
+        case GGML_OP_RESHAPE:
+        case GGML_OP_VIEW:
+        case GGML_OP_PERMUTE:
+        case GGML_OP_TRANSPOSE:
+            return true;
+        case GGML_OP_DUP:
+        case GGML_OP_CONT:
+        case GGML_OP_CPY: {
+            auto okt = [](int t) { return t == GGML_TYPE_F32 || t == GGML_TYPE_F16 || t == GGML_TYPE_BF16; };
+            const ggml_tensor* s = n->src[0];
+            if (!s || !okt(s->type) || !okt(n->type)) return false;
+            if (s->type == GGML_TYPE_BF16 && n->type != GGML_TYPE_F32) return false;
+            if (n->type == GGML_TYPE_BF16 && s->type != GGML_TYPE_F32) return false;
+            return true;
+        }
+        case GGML_OP_ADD:
+        case GGML_OP_SUB:
+        case GGML_OP_MUL:
+        case GGML_OP_DIV:
+            return f32c(n) && f32c(n->src[0]) && f32c(n->src[1]);
+        case GGML_OP_SCALE:
+            return f32c(n) && f32c(n->src[0]) && ggml_abi_is_contiguous(n) && ggml_abi_is_contiguous(n->src[0]);
+        case GGML_OP_UNARY:
+            switch (ggml_abi_get_unary_op(n)) {
+                case GGML_UNARY_OP_SILU:
+                case GGML_UNARY_OP_GELU:
+                case GGML_UNARY_OP_GELU_QUICK:
+                case GGML_UNARY_OP_SIGMOID:
+                case GGML_UNARY_OP_TANH:
+                case GGML_UNARY_OP_RELU:
+                case GGML_UNARY_OP_NEG:
+                case GGML_UNARY_OP_EXP:
+                    return f32c(n) && f32c(n->src[0]) && ggml_abi_is_contiguous(n) && ggml_abi_is_contiguous(n->src[0]);
+                default:
+                    return false;
+            }
+        case GGML_OP_NORM:
+        case GGML_OP_RMS_NORM:
+            return f32c(n) && f32c(n->src[0]) && n->src[0]->nb[0] == 4;
+        case GGML_OP_GROUP_NORM:
+            return f32c(n) && f32c(n->src[0]) && ggml_abi_is_contiguous(n->src[0]) && ggml_abi_is_contiguous(n);
+        case GGML_OP_SOFT_MAX:
+            return f32c(n) && f32c(n->src[0]) && ggml_abi_is_contiguous(n->src[0]) && ggml_abi_op_param_f32(n, 1) == 0.0f &&
+                   (!n->src[1] || ((n->src[1]->type == GGML_TYPE_F16 || n->src[1]->type == GGML_TYPE_F32) && n->src[1]->ne[2] == 1 && n->src[1]->ne[3] == 1));
+        case GGML_OP_MUL_MAT: {
+            const ggml_tensor *a = n->src[0], *b = n->src[1];
+            if (!a || !b || n->type != GGML_TYPE_F32) return false;
+            const bool at = a->type == GGML_TYPE_F32 || a->type == GGML_TYPE_F16 || a->type == GGML_TYPE_BF16 || a->type == GGML_TYPE_Q8_0 || a->type == GGML_TYPE_Q4_0;
+            const bool bt = b->type == GGML_TYPE_F32 || b->type == GGML_TYPE_F16;
+            return at && bt && a->nb[0] == ggml_abi_type_size(a->type) && b->nb[0] == ggml_abi_type_size(b->type);
+        }
+        case GGML_OP_IM2COL:
+            return f32c(n->src[1]) && (n->type == GGML_TYPE_F16 || n->type == GGML_TYPE_F32);
+        case GGML_OP_CONV_2D: {
+            const ggml_tensor *k = n->src[0], *x = n->src[1];
+            if (!k || !x || k->type != GGML_TYPE_F16 || !f32c(x) || !ggml_abi_is_contiguous(x) || !ggml_abi_is_contiguous(k)) return false;
+            const int32_t* p = n->op_params;
+            const int ks     = (int)k->ne[0];
+            if (k->ne[1] != ks || p[0] != p[1] || p[2] != p[3] || p[4] != 1 || p[5] != 1) return false;
+            return (ks == 3 && p[2] == 1 && (p[0] == 1 || p[0] == 2)) || (ks == 1 && p[2] == 0 && p[0] == 1);
+        }
+        case GGML_OP_CONCAT:
+        case GGML_OP_REPEAT:
+        case GGML_OP_UPSCALE:
+        case GGML_OP_PAD:
+            if (n->op == GGML_OP_UPSCALE && n->op_params[0] != GGML_SCALE_MODE_NEAREST) return false;
+            return f32c(n) && f32c(n->src[0]);
+        case GGML_OP_TIMESTEP_EMBEDDING:
+            return f32c(n) && f32c(n->src[0]);
+        case GGML_OP_FLASH_ATTN_EXT: {
+            const ggml_tensor *q = n->src[0], *k = n->src[1], *v = n->src[2];
+            if (!q || !k || !v || n->src[3] != nullptr) return false;  // no mask on the hot path
+            if (!f32c(q) || !(k->type == GGML_TYPE_F16 || k->type == GGML_TYPE_F32) || v->type != k->type) return false;
+            if (ggml_abi_op_param_f32(n, 1) != 0.0f || ggml_abi_op_param_f32(n, 2) != 0.0f) return false;
+            if (q->nb[0] != 4 || k->nb[0] != ggml_abi_type_size(k->type) || v->nb[0] != ggml_abi_type_size(v->type)) return false;
+            if (q->ne[3] != 1 || k->ne[2] != q->ne[2]) return false;
+            return flash_attn_supported(q->ne[0], v->ne[0]);
+        }
+        default:
+            return false;
+    }
+}
+
+void planner_get_stats(ggml_backend_mi355x_stats* o) {
+    o->graphs_computed       = g_stats.graphs_computed;
+    o->plans_built           = g_stats.plans_built;
+    o->nodes_seen            = g_stats.nodes_seen;
+    o->kernels_planned       = g_stats.kernels_planned;
+    o->kernels_launched      = g_stats.kernels_launched;
+    o->fused_conv            = g_stats.fused_conv;
+    o->fused_conv_bounced    = g_stats.fused_conv_bounced;
+    o->fused_linear          = g_stats.fused_linear;
+    o->fused_norm            = g_stats.fused_norm;
+    o->fused_geglu           = g_stats.fused_geglu;
+    o->fused_attention       = g_stats.fused_attention;
+    o->generic_matmul        = g_stats.generic_matmul;
+    o->swizzled_weight_bytes = g_stats.swizzled_weight_bytes;
+    o->graph_replays         = g_stats.graph_replays;
+}
+
+void planner_set_option(const char* key, int value) {
+    if (!strcmp(key, "fusion")) g_opt.fusion = value;
+    else if (!strcmp(key, "mfma_gemm")) g_opt.mfma_gemm = value;
+    else if (!strcmp(key, "hip_graph")) g_opt.hip_graph = value;
+    else if (!strcmp(key, "flash_pattern")) g_opt.flash_pattern = value;
+    // options change what a plan contains: drop cached plans
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (Planner* p : g_planners) {
+        (void)hipDeviceSynchronize();
+        planner_clear_locked(p);
+    }
+}
+
+}  // namespace mi355x

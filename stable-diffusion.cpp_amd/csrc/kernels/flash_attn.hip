@@ -1,0 +1,237 @@
+// flash_attn.hip — fused scaled-dot-product attention forward for gfx950 (no mask, no GQA broadcast needed on
+// the UNet / VAE path): softmax(scale * Q K^T) V with online softmax, never materialising the [Lk, Lq] scores.
+// Serves both encodings the reference emits (ggml_ext_attention_ext, src/core/ggml_extend.hpp:1349-1485):
+//   * the FLASH_ATTN_EXT node (flash flag on; K/V arrive as f16), and
+//   * the manual MUL_MAT -> SCALE -> SOFT_MAX -> MUL_MAT chain (flag off; K/V f32), pattern-matched by the planner.
+// Numerics: Q, K, P and V enter v_mfma_f32_32x32x16_f16 as f16, all sums and the softmax are f32 — tighter than
+// ggml-cpu's flash path (which accumulates V in f16).
+//
+// Mapping (wave64): a workgroup = 4 waves x 32 query rows for one (head, image); K/V tiles of 64 keys are staged
+// in LDS (K row-major [key][d], V TRANSPOSED [d][key] so the PV B-fragments are k-contiguous 8-byte reads).
+// S^T = K.Q^T is computed "swapped" (MFMA A = K rows, B = Q rows): every lane then holds the scores of ONE query
+// (its MFMA column) for 32 keys, its partner lane (l ^ 32) the other 32, so the row max / row sum need a single
+// cross-lane exchange.  P is fed back as the A operand WITHOUT any data movement by letting the MFMA k-slots
+// follow the accumulator's own key order (lane half h owns keys {4h..4h+3, 8+4h..8+4h+3} of each 16-key group)
+// and reading V with the same permutation.
+#include "device_utils.h"
+#include "kernels.h"
+
+namespace mi355x {
+
+constexpr int FA_KT   = 64;  // keys per tile
+constexpr int FA_VTS  = 68;  // Vt row stride in halfs (136 B: conflict-free ds_read_b64 over 32 rows)
+
+struct FAArgs {
+    const char *q, *k, *v;
+    float* dst;
+    int64_t q_nb1, q_nb2, k_nb1, k_nb2, v_nb0, v_nb1, v_nb2, dst_nb_q, dst_nb_h;
+    int Lq, Lk, D, DV;
+    int kv_f16;
+    float scale_log2e;
+};
+
+template <int DKP, int NDV>
+__global__ __launch_bounds__(256) void k_flash_attn(FAArgs g) {
+    constexpr int KS   = DKP / 16;   // MFMA k-steps over the head dim
+    constexpr int KROW = DKP + 8;    // K tile row stride (halfs)
+    __shared__ __attribute__((aligned(16))) _Float16 Ks[FA_KT * KROW];
+    __shared__ __attribute__((aligned(16))) _Float16 Vt[NDV * 32 * FA_VTS];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int hi   = lane >> 5;
+    const int hn   = blockIdx.y;
+    const int q0   = blockIdx.x * 128 + wave * 32;
+    const int qi   = q0 + (lane & 31);
+
+    // ---- Q fragments (B operand of S^T): lane holds Q[qi][ks*16 + hi*8 .. +8] as f16
+    half8_t qf[KS];
+    {
+        const float* qrow = (const float*)(g.q + (int64_t)min(qi, g.Lq - 1) * g.q_nb1 + (int64_t)hn * g.q_nb2);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int d = ks * 16 + hi * 8 + j;
+                qf[ks][j]   = (_Float16)((d < g.D && qi < g.Lq) ? qrow[d] : 0.f);
+            }
+        }
+    }
+
+    float16_t o[NDV];
+#pragma unroll
+    for (int nb = 0; nb < NDV; ++nb) o[nb] = (float16_t){0};
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const char* kbase = g.k + (int64_t)hn * g.k_nb2;
+    const char* vbase = g.v + (int64_t)hn * g.v_nb2;
+
+    for (int kt = 0; kt < g.Lk; kt += FA_KT) {
+        __syncthreads();
+        // ---- stage K tile [64][DKP] (zero padded) : one 8-wide chunk per thread-iteration, lanes along d
+        for (int e = threadIdx.x; e < FA_KT * (DKP / 8); e += 256) {
+            const int key = e / (DKP / 8), ch = e % (DKP / 8);
+            half8_t h;
+            const int kk = kt + key;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int d = ch * 8 + j;
+                float v     = 0.f;
+                if (kk < g.Lk && d < g.D) {
+                    const char* p = kbase + (int64_t)kk * g.k_nb1;
+                    v             = g.kv_f16 ? __half2float(((const __half*)p)[d]) : ((const float*)p)[d];
+                }
+                h[j] = (_Float16)v;
+            }
+            *(half8_t*)&Ks[key * KROW + ch * 8] = h;
+        }
+        // ---- stage V tile transposed Vt[dv][key] : lanes along keys (conflict-free 2-byte LDS writes)
+        for (int e = threadIdx.x; e < FA_KT * (NDV * 4); e += 256) {
+            const int key = e & (FA_KT - 1), ch = e >> 6;  // ch: 8-wide dv chunk
+            const int kk  = kt + key;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int d = ch * 8 + j;
+                float v     = 0.f;
+                if (kk < g.Lk && d < g.DV) {
+                    const char* p = vbase + (int64_t)kk * g.v_nb1 + (int64_t)d * g.v_nb0;
+                    v             = g.kv_f16 ? __half2float(*(const __half*)p) : *(const float*)p;
+                }
+                Vt[d * FA_VTS + key] = (_Float16)v;
+            }
+        }
+        __syncthreads();
+
+        // ---- S^T = K Q^T  (rows i = key, cols j = query)
+        float16_t s[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            s[kb] = (float16_t){0};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const half8_t kf = *(const half8_t*)&Ks[(kb * 32 + (lane & 31)) * KROW + ks * 16 + hi * 8];
+                s[kb]            = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[kb], 0, 0, 0);
+            }
+        }
+        // ---- online softmax for query (lane & 31); this lane holds keys kb*32 + (r&3)+8*(r>>2)+4*hi
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                float v       = s[kb][r] * g.scale_log2e;
+                if (key >= g.Lk) v = -INFINITY;
+                s[kb][r] = v;
+                tmax     = fmaxf(tmax, v);
+            }
+        }
+        tmax              = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = exp2f(m_run - m_new);  // m_run = -inf on the first tile -> 0
+        float psum        = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = exp2f(s[kb][r] - m_new);
+                s[kb][r]      = p;
+                psum += p;
+            }
+        }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+        // ---- rescale O rows: row i of the accumulator belongs to query lane i -> fetch its alpha
+        if (!__all(alpha == 1.0f)) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row  = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const float ar = __shfl(alpha, row, 64);
+#pragma unroll
+                for (int nb = 0; nb < NDV; ++nb) o[nb][r] *= ar;
+            }
+        }
+        // ---- O += P V : 4 k-steps of 16 keys; k-slot order = accumulator key order (see header)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int kb = t >> 1, rb = (t & 1) * 8;
+            half8_t pa;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pa[j] = (_Float16)s[kb][rb + j];
+#pragma unroll
+            for (int nb = 0; nb < NDV; ++nb) {
+                const _Float16* vrow = &Vt[(nb * 32 + (lane & 31)) * FA_VTS + t * 16 + 4 * hi];
+                const half4_t v0 = *(const half4_t*)vrow, v1 = *(const half4_t*)(vrow + 8);
+                half8_t vf;
+                vf[0] = v0[0];
+                vf[1] = v0[1];
+                vf[2] = v0[2];
+                vf[3] = v0[3];
+                vf[4] = v1[0];
+                vf[5] = v1[1];
+                vf[6] = v1[2];
+                vf[7] = v1[3];
+                o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa, vf, o[nb], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- finalise: divide by the row sum (both lane halves), write [d] contiguous
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv   = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row  = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const float ir = __shfl(inv, row, 64);
+        const int q    = q0 + row;
+        if (q < g.Lq) {
+            float* orow = (float*)((char*)g.dst + (int64_t)q * g.dst_nb_q + (int64_t)hn * g.dst_nb_h);
+#pragma unroll
+            for (int nb = 0; nb < NDV; ++nb) {
+                const int d = nb * 32 + (lane & 31);
+                if (d < g.DV) orow[d] = o[nb][r] * ir;
+            }
+        }
+    }
+}
+
+bool flash_attn_supported(int64_t D, int64_t DV) { return D == DV && D >= 8 && D <= 160; }
+
+void launch_flash_attn(hipStream_t s, float* dst, int64_t dst_nb_q, int64_t dst_nb_h, const View4& q, const View4& k, const View4& v, float scale) {
+    FAArgs g;
+    g.q = (const char*)q.data;
+    g.k = (const char*)k.data;
+    g.v = (const char*)v.data;
+    g.dst = dst;
+    g.q_nb1 = q.nb[1];
+    g.q_nb2 = q.nb[2];
+    g.k_nb1 = k.nb[1];
+    g.k_nb2 = k.nb[2];
+    g.v_nb0 = v.nb[0];
+    g.v_nb1 = v.nb[1];
+    g.v_nb2 = v.nb[2];
+    g.dst_nb_q = dst_nb_q;
+    g.dst_nb_h = dst_nb_h;
+    g.Lq = (int)q.ne[1];
+    g.Lk = (int)k.ne[1];
+    g.D  = (int)q.ne[0];
+    g.DV = (int)v.ne[0];
+    g.kv_f16      = k.type == 1;
+    g.scale_log2e = scale * 1.44269504088896340736f;
+    dim3 grid((unsigned)((g.Lq + 127) / 128), (unsigned)q.ne[2]);
+    const int D = g.D;
+    if (D <= 48)
+        k_flash_attn<48, 2><<<grid, 256, 0, s>>>(g);
+    else if (D <= 64)
+        k_flash_attn<64, 2><<<grid, 256, 0, s>>>(g);
+    else if (D <= 80)
+        k_flash_attn<80, 3><<<grid, 256, 0, s>>>(g);
+    else if (D <= 96)
+        k_flash_attn<96, 3><<<grid, 256, 0, s>>>(g);
+    else if (D <= 128)
+        k_flash_attn<128, 4><<<grid, 256, 0, s>>>(g);
+    else
+        k_flash_attn<160, 5><<<grid, 256, 0, s>>>(g);
+}
+
+}  // namespace mi355x

@@ -1,0 +1,81 @@
+// kernels.h — host-callable launchers of the hand-written gfx950 kernels.  Every launcher enqueues on the
+// given HIP stream and returns immediately.  Shapes use ggml's ne order (ne0 contiguous).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace mi355x {
+
+// 4-D strided view of a tensor (element strides are in BYTES like ggml's nb[])
+struct View4 {
+    const void* data;
+    int64_t ne[4];
+    int64_t nb[4];
+    int type;  // ggml_type
+};
+
+enum BinOp { BIN_ADD = 0, BIN_SUB = 1, BIN_MUL = 2, BIN_DIV = 3 };
+enum UnOp { UN_SILU = 0, UN_GELU = 1, UN_GELU_QUICK = 2, UN_SIGMOID = 3, UN_TANH = 4, UN_RELU = 5, UN_NEG = 6, UN_EXP = 7 };
+
+// ---- elementwise.hip --------------------------------------------------------------------------------
+// dst = a (op) broadcast(b); a/dst f32 with arbitrary strides, b f32 broadcast by modulo on every dim
+void launch_binary(hipStream_t s, BinOp op, void* dst, const int64_t dnb[4], const View4& a, const View4& b);
+void launch_unary(hipStream_t s, UnOp op, float* dst, const float* src, int64_t n);
+void launch_scale(hipStream_t s, float* dst, const float* src, int64_t n, float scale, float bias);
+// generic strided copy with conversion between f32/f16/bf16 (logical element order preserved)
+void launch_copy(hipStream_t s, const View4& dst, const View4& src);
+void launch_concat(hipStream_t s, const View4& dst, const View4& a, const View4& b, int dim);
+void launch_repeat(hipStream_t s, const View4& dst, const View4& src);
+void launch_upscale_nearest(hipStream_t s, const View4& dst, const View4& src);
+void launch_pad(hipStream_t s, const View4& dst, const View4& src, const int32_t pads[8]);
+void launch_timestep_embedding(hipStream_t s, float* dst, const float* t, int n, int dim, int max_period, int64_t dst_row_stride);
+// GEGLU: dst[t][i] = x[t][i] * gelu(x[t][inner + i]); x row stride given in floats
+void launch_geglu(hipStream_t s, float* dst, const float* x, int64_t tokens, int64_t inner, int64_t x_stride);
+
+// ---- norm.hip ---------------------------------------------------------------------------------------
+// GROUP_NORM over [W*H, C, N] contiguous f32; optional fused affine (w,b per channel) and SiLU
+void launch_group_norm(hipStream_t s, float* dst, const float* x, int64_t hw, int64_t C, int64_t N, int groups, float eps,
+                       const float* w, const float* b, bool silu);
+// NORM / RMS_NORM over rows of ne0 contiguous f32 (row strides in floats); optional fused affine
+void launch_layer_norm(hipStream_t s, float* dst, const float* x, int64_t ne0, int64_t nrows, int64_t x_stride, int64_t d_stride,
+                       float eps, const float* w, const float* b, bool rms);
+void launch_soft_max(hipStream_t s, float* dst, const float* x, int64_t ncols, int64_t nrows, float scale, const View4* mask,
+                     int64_t rows_per_mat);
+
+// ---- gemm_generic.hip: any-operand matmul (exact f32 MFMA), ggml MUL_MAT semantics ------------------
+// dst[m + n*ldd] = sum_k A[m][k]*B[n][k];  A type in {f32,f16,bf16,q8_0,q4_0} rows K-contiguous, B f32/f16
+void launch_mul_mat_generic(hipStream_t s, float* dst, const int64_t dne[4], const int64_t dnb[4], const View4& a, const View4& b);
+void launch_im2col_f16(hipStream_t s, void* dst, int dst_type, const View4& x, int64_t KW, int64_t KH, int64_t OW, int64_t OH,
+                       int s0, int s1, int p0, int p1, int d0, int d1);
+
+// ---- wgemm.hip: static-weight GEMMs on f16 MFMA (32x32x16), weights pre-swizzled into fragment order ----
+// pre-swizzle: rows R (padded to 32) x K (padded to 16) -> [R/32][K/16][64 lanes][8 halfs]
+size_t wswz_bytes(int64_t R, int64_t K);
+void launch_wswz_linear(hipStream_t s, void* dst, const void* src, int src_type, int64_t K, int64_t R, int64_t src_row_bytes);
+// conv weight [KW,KH,IC,OC] f16 -> rows OC, K index = tap*ICp + ic (ICp = IC padded to 32)
+void launch_wswz_conv(hipStream_t s, void* dst, const void* src, int64_t KW, int64_t KH, int64_t IC, int64_t OC);
+
+struct Epilogue {
+    const float* bias     = nullptr;  // per output feature / channel
+    const float* residual = nullptr;  // same layout as dst (added after bias)
+    const float* chan_add = nullptr;  // conv only: per (oc, n) value added (time-embedding broadcast), [OC, N]
+    float scale           = 1.0f;     // applied to the accumulator before bias
+    int act               = -1;       // UnOp applied last, or -1
+};
+// Linear: dst[tok][m] = sum_k x[tok][k] * W[m][k]   x f32 rows (row stride x_stride floats), dst row stride M
+void launch_linear_mfma(hipStream_t s, float* dst, const float* x, const void* wswz, int64_t tokens, int64_t K, int64_t M,
+                        int64_t x_stride, int64_t d_stride, const Epilogue& ep);
+// Implicit-GEMM conv2d: x [W,H,IC,N] f32 NCHW, dst [OW,OH,OC,N]; 3x3 (pad 1, stride 1|2) or 1x1; optional nearest x2 upscale of x fused
+void launch_conv2d_mfma(hipStream_t s, float* dst, const float* x, const void* wswz, int64_t W, int64_t H, int64_t IC, int64_t N,
+                        int64_t OC, int ksize, int stride, int pad, bool upscale2x, const Epilogue& ep);
+
+// ---- flash_attn.hip ---------------------------------------------------------------------------------
+// q [D,Lq,HN] (f32, strides in bytes), k [D,Lk,HN], v [DV,Lk,HN] (f16 or f32; v may be a transposed view,
+// any nb[0]) -> dst f32 written with strides
+// (dst_nb_d=4 implied) dst element (d, q, hn) at dst + q*dst_nb_q + hn*dst_nb_h
+bool flash_attn_supported(int64_t D, int64_t DV);
+void launch_flash_attn(hipStream_t s, float* dst, int64_t dst_nb_q, int64_t dst_nb_h, const View4& q, const View4& k, const View4& v,
+                       float scale);
+
+}  // namespace mi355x

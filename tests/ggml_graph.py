@@ -130,7 +130,8 @@ class Graph:
         self._galloc = L.ggml_gallocr_new(L.ggml_backend_get_default_buffer_type(self.backend))
         assert L.ggml_gallocr_alloc_graph(self._galloc, gf)
         for t, raw in self._inputs:
-            L.ggml_backend_tensor_set(t, raw, 0, len(raw))
+            if tensor_struct(t).data:  # tensors used only as shape templates (ggml_repeat) are never allocated
+                L.ggml_backend_tensor_set(t, raw, 0, len(raw))
         st = L.ggml_backend_graph_compute(self.backend, gf)
         assert st == 0, f"graph_compute status {st}"
         self.n_nodes = L.ggml_graph_n_nodes(gf)

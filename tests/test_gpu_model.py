@@ -1,0 +1,66 @@
+"""Whole-graph parity on the GPU: tiny-width UNet / VAE (same topology as SD1.5 / SDXL) through the C ABI,
+MI355X backend vs the CPU oracle backend, same synthetic weights (seed 1234) and seeded inputs.
+
+Tolerance: every contraction on both sides rounds activations to f16 and accumulates in f32, so single
+layers agree to ~1e-4; through the ~60 layer deep UNet the summation-order noise compounds to ~1e-3 rel-L2.
+Stated bar: rel-L2 <= 5e-3 per forward (f16), PSNR >= 35 dB on decoded pixels (SURVEY.md section 7 hard parts).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_l2(a, b):
+    a = np.asarray(a, np.float64).ravel()
+    b = np.asarray(b, np.float64).ravel()
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
+@pytest.mark.parametrize("model_name,flash", [("SD15_TINY", False), ("SD15_TINY", True), ("SDXL_TINY", False)])
+def test_unet_forward_parity(sd, oracle, gpu, model_name, flash):
+    model = getattr(sd, model_name)
+    rng = np.random.default_rng(7)
+    n = 2
+    x = rng.standard_normal((n, 4, 32, 32)).astype(np.float32)
+    t = np.array([731.0] * n, dtype=np.float32)
+    ctx_dim = 64
+    ctx = rng.standard_normal((1, 77, ctx_dim)).astype(np.float32)
+    y = rng.standard_normal((1, 96)).astype(np.float32) if "XL" in model_name else None
+    ref_e = sd.Engine(model=model, backend=oracle, flash_attn=flash)
+    gpu_e = sd.Engine(model=model, backend=gpu, flash_attn=flash)
+    ref = ref_e.unet_forward(x, t, ctx, y)
+    out = gpu_e.unet_forward(x, t, ctx, y)
+    assert np.isfinite(out).all()
+    err = rel_l2(out, ref)
+    print(f"{model_name} flash={flash}: rel-L2 {err:.3e}, nodes {gpu_e.stats()['graph_nodes']}")
+    assert err < 5e-3
+    # second call hits the plan cache and must give the same answer bit-for-bit
+    out2 = gpu_e.unet_forward(x, t, ctx, y)
+    np.testing.assert_array_equal(out, out2)
+
+
+def test_vae_decode_parity(sd, oracle, gpu):
+    rng = np.random.default_rng(8)
+    z = rng.standard_normal((1, 4, 16, 16)).astype(np.float32) * 0.18215 * 3
+    ref = sd.Engine(model=sd.SD15_TINY, backend=oracle).vae_decode(z)
+    out = sd.Engine(model=sd.SD15_TINY, backend=gpu).vae_decode(z)
+    mse = float(np.mean((out.astype(np.float64) - ref) ** 2))
+    psnr = 10 * np.log10(1.0 / max(mse, 1e-20))
+    print(f"VAE decode PSNR {psnr:.1f} dB")
+    assert psnr > 35.0
+
+
+def test_sampler_trajectory_parity(sd, oracle, gpu):
+    """4-step Euler-A with CFG 7, two images in one device batch vs the oracle's independent batch-1 runs."""
+    rng = np.random.default_rng(9)
+    cond = rng.standard_normal((1, 77, 64)).astype(np.float32)
+    uncond = rng.standard_normal((1, 77, 64)).astype(np.float32)
+    ref_e = sd.Engine(model=sd.SD15_TINY, backend=oracle)
+    gpu_e = sd.Engine(model=sd.SD15_TINY, backend=gpu)
+    kw = dict(width=128, height=128, steps=4, cfg=7.0, seed=42)
+    out = gpu_e.sample_latents(cond, uncond, batch=2, device_batch=2, **kw)
+    ref = np.concatenate([ref_e.sample_latents(cond, uncond, batch=1, seed=42 + b, width=128, height=128, steps=4, cfg=7.0) for b in range(2)])
+    err = rel_l2(out, ref)
+    print(f"trajectory rel-L2 {err:.3e}")
+    assert err < 2e-2
