@@ -31,6 +31,8 @@ import numpy as np
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
+if (os.cpu_count() or 1) > 32:
+    os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")  # cpu_baseline leg (OpenMP oracle) on a big shared host
 
 # algorithmic work per unit: 2*M*N*K per Linear / conv, 4*Lq*Lk*H*d per attention
 UNET_FWD_TFLOP = {"sd15": 0.803, "sdxl": 6.761}

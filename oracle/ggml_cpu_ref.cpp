@@ -35,6 +35,7 @@
 // =================================================================================================
 #include <immintrin.h>
 #include <omp.h>
+#include <sched.h>
 
 #include <algorithm>
 #include <cmath>
@@ -70,9 +71,32 @@ const float SQRT_2_OVER_PI  = 0.79788456080286535587989211986876f;
 const float GELU_QUICK_COEF = -1.702f;
 inline float gelu_f32(float x) { return 0.5f * x * (1.0f + tanhf(SQRT_2_OVER_PI * x * (1.0f + GELU_COEF_A * x * x))); }
 inline float gelu_quick_f32(float x) { return x * (1.0f / (1.0f + expf(GELU_QUICK_COEF * x))); }
+// Threads the oracle uses: the CPUs this process may actually run on (affinity mask and cgroup CPU quota), capped at 16
+// — GPU boxes report hundreds of hardware threads to a container that may only schedule a few of them, and an
+// oversubscribed OpenMP team spin-waiting at every one of the ~3k per-graph parallel regions is pathologically slow.
+int usable_cpus() {
+    int n = omp_get_num_procs();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = std::min(n, CPU_COUNT(&set));
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char quota[64];
+        long period = 0;
+        if (fscanf(f, "%63s %ld", quota, &period) == 2 && strcmp(quota, "max") != 0 && period > 0) {
+            const long q = atol(quota);
+            if (q > 0) n = std::min<int>(n, (int)std::max<long>(1, (q + period - 1) / period));
+        }
+        fclose(f);
+    }
+    if (const char* e = getenv("ORACLE_THREADS")) n = std::max(1, atoi(e));
+    else n = std::min(n, 16);
+    return std::max(1, n);
+}
+
 void init_tables() {
     static bool done = false;
     if (done) return;
+    omp_set_dynamic(0);
+    omp_set_num_threads(usable_cpus());
     for (int i = 0; i < 65536; ++i) {
         const float f         = h2f((ggml_fp16_t)i);
         g_gelu_table[i]       = f2h(gelu_f32(f));

@@ -54,7 +54,7 @@ static uint64_t hash_name(const std::string& s, uint64_t seed) {
     return h;
 }
 static void fill_normal(float* dst, int64_t n, uint64_t seed, float mean, float std) {
-    const int nthreads = (int)std::max<int64_t>(1, std::min<int64_t>(std::thread::hardware_concurrency(), n / 65536));
+    const int nthreads = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<unsigned>(std::thread::hardware_concurrency(), 16u), n / 65536));
     auto work          = [&](int tid) {
         const int64_t chunk = (n + nthreads - 1) / nthreads;
         const int64_t i0 = tid * chunk, i1 = std::min<int64_t>(n, i0 + chunk);

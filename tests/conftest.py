@@ -5,6 +5,11 @@ from pathlib import Path
 import pytest
 
 ROOT = Path(__file__).resolve().parent.parent
+# the CPU oracle is OpenMP code: keep its team small and passive (GPU boxes expose hundreds of hardware threads to
+# containers that can schedule only a few; a spinning oversubscribed team makes whole-graph oracle runs crawl)
+os.environ.setdefault("OMP_NUM_THREADS", str(max(1, min(os.cpu_count() or 1, 16))))
+if (os.cpu_count() or 1) > 32:  # big shared host: do not spin-wait an oversubscribed team
+    os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 
@@ -39,5 +44,8 @@ def oracle(sd):
 @pytest.fixture(scope="session")
 def gpu(sd):
     """Loads the product backend; fails loudly if the HIP extension or the GPU is missing."""
+    if os.environ.get("SDCPP_GPU_TESTS_ON_ORACLE"):  # harness self-check on a CPU-only box: both sides run the oracle
+        sd.load_backend(ROOT / "oracle" / "_build" / "libggml-cpu-oracle.so")
+        return "CPU-oracle"
     sd.load_mi355x_backend()
     return "MI355X0"

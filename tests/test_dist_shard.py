@@ -1,0 +1,68 @@
+"""CPU suite: the N > 1 path (image sharding + result gather) with world_size 2 over gloo on 127.0.0.1, using the CPU
+oracle backend on the tiny model.  Sharded results must equal the single-process results image by image."""
+import os
+import socket
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+
+WORKER = r'''
+import os, sys, pickle
+import numpy as np
+import torch, torch.distributed as dist
+sys.path.insert(0, os.environ["SD_ROOT"])
+import sdcpp_amd as sd
+from sdcpp_amd import shard
+dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{os.environ['MASTER_PORT']}", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank, world = dist.get_rank(), dist.get_world_size()
+sd.load_backend(os.path.join(os.environ["SD_ROOT"], "oracle/_build/libggml-cpu-oracle.so"))
+eng = sd.Engine(model=sd.SD15_TINY, backend="CPU-oracle")
+rng = np.random.default_rng(11)
+cond = rng.standard_normal((1, 77, 64)).astype(np.float32)
+uncond = rng.standard_normal((1, 77, 64)).astype(np.float32)
+def gather(local):
+    objs = [None] * world
+    dist.all_gather_object(objs, local)
+    merged = {}
+    for o in objs: merged.update(o)
+    return merged
+res = shard.generate_sharded(eng, cond, uncond, batch_count=5, seed=100, rank=rank, world=world, gather=gather,
+                             width=64, height=64, steps=2, cfg=7.0)
+dist.barrier()
+if rank == 0:
+    with open(os.environ["SD_OUT"], "wb") as f: pickle.dump(res, f)
+dist.destroy_process_group()
+'''
+
+
+def test_world_size_2_sharding_matches_single_process(sd, oracle, tmp_path):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = tmp_path / "res.pkl"
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SD_ROOT=str(ROOT), SD_OUT=str(out),
+                   OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, "-c", WORKER], env=env))
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    import pickle
+
+    res = pickle.loads(out.read_bytes())
+    assert sorted(res) == [0, 1, 2, 3, 4]
+    from sdcpp_amd import shard
+
+    assert shard.shard_indices(5, 0, 2) == [0, 2, 4] and shard.shard_indices(5, 1, 2) == [1, 3]
+    eng = sd.Engine(model=sd.SD15_TINY, backend=oracle)
+    rng = np.random.default_rng(11)
+    cond = rng.standard_normal((1, 77, 64)).astype(np.float32)
+    uncond = rng.standard_normal((1, 77, 64)).astype(np.float32)
+    ref = eng.sample_latents(cond, uncond, width=64, height=64, steps=2, cfg=7.0, seed=100, batch=5, device_batch=5)
+    for b in range(5):
+        np.testing.assert_allclose(res[b], ref[b], rtol=1e-4, atol=1e-5)
