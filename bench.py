@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=8, help="images per GPU (device batch)")
     ap.add_argument("--no-flash", action="store_true")
     ap.add_argument("--hip-graph", type=int, default=0)
+    ap.add_argument("--g16-variant", type=int, default=-1, help="gemm16 pipeline variant (A/B measurements)")
+    ap.add_argument("--no-fuse-cfg", action="store_true", help="run cond and uncond as two graph computes (the reference's way)")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--e2e", action="store_true", help="also time one full image (20 steps + VAE decode) per GPU batch")
@@ -82,6 +84,8 @@ def main():
         blib = C.CDLL(str(sd.BACKEND_LIB))
         blib.ggml_backend_mi355x_set_option.argtypes = [C.c_char_p, C.c_int]
         blib.ggml_backend_mi355x_set_option(b"hip_graph", args.hip_graph)
+        if args.g16_variant >= 0:
+            blib.ggml_backend_mi355x_set_option(b"gemm16_variant", args.g16_variant)
     except OSError:
         blib = None
 
@@ -96,11 +100,20 @@ def main():
     x = rng.standard_normal((B, 4, lat, lat)).astype(np.float32)
     t = np.full((B,), 500.0, dtype=np.float32)
 
+    fuse = not args.no_fuse_cfg
+    x2 = np.repeat(x, 2, axis=0)            # (b cond, b uncond, ...) interleaved
+    t2 = np.repeat(t, 2)
+    c2 = np.concatenate([cond, uncond], 0)  # [2,77,D]: tiled over the 2B images by the graph's ggml_repeat
+    y2 = None if y is None else np.concatenate([y, y], 0)
+
     def step():
         # one sampler iteration's model work: cond + uncond forward over the device batch (host CFG/Euler math is included
         # in the e2e number; here the H2D/D2H crossings of the reference boundary are part of the step, as in the reference)
-        eng.unet_forward(x, t, cond, y)
-        eng.unet_forward(x, t, uncond, y)
+        if fuse:
+            eng.unet_forward(x2, t2, c2, y2)
+        else:
+            eng.unet_forward(x, t, cond, y)
+            eng.unet_forward(x, t, uncond, y)
 
     def barrier():
         torch.cuda.synchronize()
@@ -139,7 +152,8 @@ def main():
         "dtype": "f16",
         "data": "synthetic",
         "config": {"workload": f"{args.model} UNet {lat*8}x{lat*8}, cfg 7 (cond+uncond), f16 weights, batch {B}/GPU, Euler-A step",
-                   "global_batch": B * world, "flash_attn": not args.no_flash, "hip_graph": args.hip_graph},
+                   "global_batch": B * world, "flash_attn": not args.no_flash, "hip_graph": args.hip_graph,
+                   "cfg_pair_in_one_graph": fuse},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
                      "note": "whole UNet step (algorithmic 2*B*%.3f TFLOP per step / wall step time incl. host graph build + H2D/D2H)" % fwd_tflop},
@@ -147,7 +161,7 @@ def main():
     if args.e2e and rank == 0:
         t0 = time.perf_counter()
         eng.generate_image(cond, uncond, width=lat * 8, height=lat * 8, steps=20, cfg=7.0, seed=42, batch=B, device_batch=B,
-                           cond_y=y, uncond_y=y)
+                           cond_y=y, uncond_y=y, fuse_cfg=fuse)
         e2e = time.perf_counter() - t0
         st = eng.stats()
         out["e2e"] = {"sec_per_image": round(e2e / B, 4), "batch": B, "steps": 20, "sample_ms": round(st["last_sample_ms"], 1),

@@ -92,6 +92,8 @@ typedef struct {
     int batch_count;            /* images seed .. seed+batch_count-1 (stable-diffusion.cpp:5664-5683) */
     int device_batch;           /* OUR extension: images denoised together per graph; 0 -> batch_count */
     bool decode;                /* run the VAE and return pixels; false -> latents only */
+    bool fuse_cfg_pair;         /* OUR extension: cond and uncond of every image run in ONE graph (N = 2*batch, context [.,.,2]
+                                   tiled by the graph's own ggml_repeat, unet.hpp:548-552) instead of two computes per step */
 } sd_img_gen_params_t;
 
 typedef struct {

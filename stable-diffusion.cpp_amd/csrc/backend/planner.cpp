@@ -43,13 +43,14 @@ struct Stats {
 } g_stats;
 
 struct Options {
-    std::atomic<int> fusion{1}, mfma_gemm{1}, hip_graph{0}, flash_pattern{1};
+    std::atomic<int> fusion{1}, mfma_gemm{1}, hip_graph{0}, flash_pattern{1}, gemm16{1};
 } g_opt;
 
 using Step = std::function<void(hipStream_t)>;
 
 struct Plan {
     int n_nodes = 0;
+    size_t arena_needed = 0;
     std::vector<Step> steps;
     hipGraphExec_t graph_exec = nullptr;
     bool graph_failed         = false;
@@ -71,8 +72,10 @@ struct Planner {
     int device;
     std::unordered_map<uint64_t, std::unique_ptr<Plan>> plans;
     std::unordered_map<uint64_t, SwzEntry> swz;  // key: hash(src ptr, kind)
-    void* scratch        = nullptr;              // small workspace for bounced outputs
-    size_t scratch_bytes = 0;
+    // private operand arena: f16 activation images + GroupNorm affine tables of the plan being executed.  Plans hold
+    // OFFSETS; the base is read at launch time, so growing the arena never invalidates a cached plan.
+    char* arena       = nullptr;
+    size_t arena_cap  = 0;
 };
 
 namespace {
@@ -177,13 +180,33 @@ struct GInfo {
     }
 };
 
+struct Packed {
+    size_t off;     // arena offset of the f16 image
+    int64_t ld;     // row stride in halfs (K or C rounded up to 64)
+    bool nhwc;      // [N][H*W][Cp] image of an NCHW tensor (else [rows][Kp] of a row-major tensor)
+};
+
 struct Builder {
     Planner* P;
     Plan* plan;
     GInfo gi;
+    size_t arena_off = 0;
+    std::unordered_map<const ggml_tensor*, Packed> packed;           // graph tensor -> f16 operand image
+    std::unordered_map<const ggml_tensor*, const ggml_tensor*> ups;  // deferred nearest-x2 UPSCALE node -> its source
     Builder(Planner* p, Plan* pl, const ggml_cgraph* g) : P(p), plan(pl), gi(g) {}
     void emit(Step s) { plan->steps.push_back(std::move(s)); }
+    size_t alloc(size_t bytes) {
+        const size_t off = (arena_off + 255) & ~(size_t)255;
+        arena_off        = off + bytes;
+        return off;
+    }
 };
+
+inline int64_t rup64(int64_t a) { return (a + 63) / 64 * 64; }
+inline const ggml_tensor* strip_reshape(const ggml_tensor* t) {
+    while (t && t->op == GGML_OP_RESHAPE && t->src[0]) t = t->src[0];
+    return t;
+}
 
 // ---------------------------------------------------------------------------------------------------
 // swizzled weights
@@ -206,7 +229,7 @@ const void* get_swz_conv(Planner* P, const ggml_tensor* w, hipStream_t s) {
     auto it      = P->swz.find(key);
     if (it != P->swz.end()) return it->second.swz;
     const int64_t KW = w->ne[0], KH = w->ne[1], IC = w->ne[2], OC = w->ne[3];
-    const int64_t ICp  = (IC + 31) / 32 * 32;
+    const int64_t ICp  = (IC + 63) / 64 * 64;
     const size_t bytes = wswz_bytes(OC, ICp * KW * KH);
     void* d            = nullptr;
     if (hipMalloc(&d, bytes) != hipSuccess) return nullptr;
@@ -229,6 +252,62 @@ bool bias_like_row(const ggml_tensor* b, int64_t M) {  // [M] f32
 }
 
 // MUL_MAT with a static weight on the MFMA path?  tokens = product of src1 dims 1..3 (must be collapsible)
+
+// ---- gen-2 (gemm16) helpers -------------------------------------------------------------------------
+// is node i an IM2COL that plan_conv_chain will turn into an MFMA implicit-GEMM conv?
+bool conv_im2col_fast_ok(const GInfo& gi, int i) {
+    const ggml_tensor* im = gi.node(i);
+    if (im->op != GGML_OP_IM2COL || !g_opt.mfma_gemm || !g_opt.fusion) return false;
+    const ggml_tensor* ker = im->src[0];
+    const ggml_tensor* x   = im->src[1];
+    const int32_t* p       = im->op_params;
+    if (p[6] != 1 || p[4] != 1 || p[5] != 1) return false;
+    if (ker->type != GGML_TYPE_F16 || !is_static_weight(ker) || !contig(ker)) return false;
+    if (!is_f32(x) || !contig(x)) return false;
+    const int KW = (int)ker->ne[0], KH = (int)ker->ne[1];
+    if (KW != KH || p[0] != p[1] || p[2] != p[3]) return false;
+    if (!((KW == 3 && p[2] == 1 && (p[0] == 1 || p[0] == 2)) || (KW == 1 && p[2] == 0 && p[0] == 1))) return false;
+    int j1 = gi.sole(i);
+    if (j1 < 0 || gi.node(j1)->op != GGML_OP_RESHAPE) return false;
+    int j2 = gi.sole(j1);
+    if (j2 < 0 || gi.node(j2)->op != GGML_OP_MUL_MAT || gi.node(j2)->src[0] != gi.node(j1)) return false;
+    int j3 = gi.sole(j2);
+    if (j3 < 0 || gi.node(j3)->op != GGML_OP_RESHAPE) return false;
+    int j4 = gi.sole(j3);
+    if (j4 < 0 || gi.node(j4)->op != GGML_OP_PERMUTE) return false;
+    int j5 = gi.sole(j4);
+    return j5 >= 0 && gi.node(j5)->op == GGML_OP_CONT;
+}
+bool linear_fast_ok(const ggml_tensor* n);
+// every consumer of node i (looking through RESHAPE views) is a gen-2 GEMM that reads the f16 image
+bool all_consumers_gemm16(const GInfo& gi, int i, bool want_conv) {
+    if (!g_opt.gemm16 || !g_opt.mfma_gemm || !g_opt.fusion) return false;
+    const ggml_tensor* t = gi.node(i);
+    if ((t->flags & GGML_TENSOR_FLAG_OUTPUT) || i == gi.g->n_nodes - 1) return false;
+    std::vector<int> work{i};
+    int n_real = 0;
+    while (!work.empty()) {
+        const int k = work.back();
+        work.pop_back();
+        if (gi.consumers[k].empty() && k != i) return false;
+        for (int c : gi.consumers[k]) {
+            const ggml_tensor* cn = gi.node(c);
+            if (cn->op == GGML_OP_RESHAPE) {
+                if ((cn->flags & GGML_TENSOR_FLAG_OUTPUT)) return false;
+                work.push_back(c);
+                continue;
+            }
+            if (want_conv) {
+                if (!(cn->op == GGML_OP_IM2COL && cn->src[1] == gi.node(k) && conv_im2col_fast_ok(gi, c))) return false;
+            } else {
+                if (!(cn->op == GGML_OP_MUL_MAT && strip_reshape(cn->src[1]) == t && linear_fast_ok(cn))) return false;
+            }
+            ++n_real;
+        }
+    }
+    return n_real > 0;
+}
+
 bool linear_fast_ok(const ggml_tensor* n) {
     const ggml_tensor* w = n->src[0];
     const ggml_tensor* x = n->src[1];
@@ -252,7 +331,40 @@ void plan_linear(Builder& B, int i, hipStream_t s, std::vector<int>& chain) {
     Epilogue ep;
     int last = i;
     chain.push_back(i);
-    if (g_opt.fusion) {
+    // attention operand chain: MUL_MAT -> RESHAPE [d,H,L,N] -> PERMUTE(0,2,1,3) -> CONT [-> RESHAPE -> CPY f16]  (ggml_extend.hpp:1373-1406):
+    // the projection GEMM stores straight into the CONT (f32) or CPY (f16) buffer in head-major order
+    int hm_d = 0, hm_H = 0, hm_L = 0;
+    bool hm_f16 = false;
+    if (g_opt.fusion && g_opt.gemm16) {
+        const int j1 = gi.sole(i);
+        const int j2 = (j1 >= 0 && gi.node(j1)->op == GGML_OP_RESHAPE) ? gi.sole(j1) : -1;
+        const int j3 = (j2 >= 0 && gi.node(j2)->op == GGML_OP_PERMUTE) ? gi.sole(j2) : -1;
+        if (j3 >= 0 && gi.node(j3)->op == GGML_OP_CONT && is_f32(gi.node(j3)) && contig(gi.node(j3))) {
+            const ggml_tensor* r4 = gi.node(j1);
+            const int32_t* ax    = gi.node(j2)->op_params;
+            const int64_t d = r4->ne[0], H = r4->ne[1], L = r4->ne[2], Nimg = r4->ne[3];
+            if (ax[0] == 0 && ax[1] == 2 && ax[2] == 1 && ax[3] == 3 && d * H == M && L * Nimg == tokens && x->ne[1] == L && d < 32768 && H < 32768) {
+                std::vector<int> c2{i, j1, j2, j3};
+                int lastn = j3;
+                const int j4 = gi.sole(j3);
+                const int j5 = (j4 >= 0 && gi.node(j4)->op == GGML_OP_RESHAPE) ? gi.sole(j4) : -1;
+                if (j5 >= 0 && gi.node(j5)->op == GGML_OP_CPY && gi.node(j5)->type == GGML_TYPE_F16 && gi.node(j5)->src[0] == gi.node(j4) && contig(gi.node(j5))) {
+                    c2.push_back(j4);
+                    c2.push_back(j5);
+                    lastn  = j5;
+                    hm_f16 = true;
+                }
+                if (gi.only_noops_between(i, lastn, c2)) {
+                    hm_d  = (int)d;
+                    hm_H  = (int)H;
+                    hm_L  = (int)L;
+                    chain = c2;
+                    last  = lastn;
+                }
+            }
+        }
+    }
+    if (g_opt.fusion && hm_d == 0) {
         // [RESHAPE] -> ADD bias
         int j = gi.sole(last);
         int via = last;
@@ -287,7 +399,34 @@ void plan_linear(Builder& B, int i, hipStream_t s, std::vector<int>& chain) {
     float* dst      = (float*)gi.node(last)->data;
     const float* xp = (const float*)x->data;
     const int64_t xs = (int64_t)x->nb[1] / 4;
-    B.emit([=](hipStream_t st) { launch_linear_mfma(st, dst, xp, swz, tokens, K, M, xs, M, ep); });
+    if (g_opt.gemm16) {
+        // gen-2: A operand = f16 image in the private arena (written by the producer, or packed here once per tensor)
+        const ggml_tensor* key = strip_reshape(x);
+        auto it = B.packed.find(key);
+        if (it == B.packed.end() || it->second.nhwc) {
+            Packed pk{B.alloc((size_t)tokens * rup64(K) * 2), rup64(K), false};
+            Planner* P = B.P;
+            const size_t off = pk.off;
+            B.emit([=](hipStream_t st) { launch_pack_rows_f16(st, P->arena + off, xp, tokens, K, xs); });
+            it = B.packed.emplace(key, pk).first;
+            if (it->second.nhwc) it->second = pk;
+        }
+        Planner* P       = B.P;
+        const size_t off = it->second.off;
+        const int64_t ld = it->second.ld;
+        if (hm_d > 0) {
+            void* hdst = gi.node(last)->data;
+            const bool f16o = hm_f16;
+            const int hd = hm_d, hH = hm_H, hL = hm_L;
+            B.emit([=](hipStream_t st) {
+                launch_gemm16_linear(st, f16o ? nullptr : (float*)hdst, f16o ? hdst : nullptr, 0, P->arena + off, ld, swz, tokens, K, M, M, ep, hd, hH, hL);
+            });
+        } else {
+            B.emit([=](hipStream_t st) { launch_gemm16_linear(st, dst, nullptr, 0, P->arena + off, ld, swz, tokens, K, M, M, ep); });
+        }
+    } else {
+        B.emit([=](hipStream_t st) { launch_linear_mfma(st, dst, xp, swz, tokens, K, M, xs, M, ep); });
+    }
     g_stats.fused_linear++;
 }
 
@@ -354,6 +493,34 @@ bool plan_conv_chain(Builder& B, int i, hipStream_t s, std::vector<int>& chain) 
     const void* swz = get_swz_conv(B.P, ker, s);
     if (!swz) return false;
     float* final_dst = (float*)gi.node(last)->data;
+    const int ks = KW, st_ = s0, pd = p0;
+    if (g_opt.gemm16) {
+        // gen-2: the conv reads an f16 NHWC image from the private arena, so the graph allocator's recycling of the
+        // conv input for the chain output is harmless (no bounce).  A deferred nearest-x2 UPSCALE becomes an index shift.
+        const ggml_tensor* src = x;
+        bool upscale           = false;
+        auto ui                = B.ups.find(x);
+        if (ui != B.ups.end()) {
+            src     = ui->second;
+            upscale = true;
+        }
+        const int64_t SW = src->ne[0], SH = src->ne[1];
+        auto it = B.packed.find(src);
+        if (it == B.packed.end() || !it->second.nhwc) {
+            Packed pk{B.alloc((size_t)N * SW * SH * rup64(IC) * 2), rup64(IC), true};
+            Planner* P       = B.P;
+            const size_t off = pk.off;
+            const float* sp  = (const float*)src->data;
+            B.emit([=](hipStream_t st) { launch_nchw_to_nhwc_f16(st, P->arena + off, sp, SW * SH, IC, N, nullptr, nullptr, false); });
+            B.packed[src] = pk;
+            it            = B.packed.find(src);
+        }
+        Planner* P       = B.P;
+        const size_t off = it->second.off;
+        B.emit([=](hipStream_t st) { launch_gemm16_conv(st, final_dst, P->arena + off, swz, SW, SH, IC, N, OC, ks, st_, pd, upscale, ep); });
+        g_stats.fused_conv++;
+        return true;
+    }
     const float* xp  = (const float*)x->data;
     const size_t xb  = ggml_abi_nbytes(x);
     const int64_t W = x->ne[0], H = x->ne[1];
@@ -373,7 +540,6 @@ bool plan_conv_chain(Builder& B, int i, hipStream_t s, std::vector<int>& chain) 
             return false;  // fall back to the unfused path
         g_stats.fused_conv_bounced++;
     }
-    const int ks = KW, st_ = s0, pd = p0;
     if (kdst == final_dst) {
         B.emit([=](hipStream_t st) { launch_conv2d_mfma(st, final_dst, xp, swz, W, H, IC, N, OC, ks, st_, pd, false, ep); });
     } else {
@@ -435,6 +601,23 @@ bool plan_group_norm(Builder& B, int i, hipStream_t, std::vector<int>& chain) {
     }
     float* dst      = (float*)n->data;
     const float* xp = (const float*)x->data;
+    if (w && all_consumers_gemm16(gi, last, true)) {
+        // gen-2: every reader is an implicit-GEMM conv -> statistics kernel + one transposing apply kernel that writes the
+        // f16 NHWC operand image straight into the arena; the f32 NCHW result is never materialised.
+        Planner* P          = B.P;
+        const size_t so     = B.alloc((size_t)N * C * 4 * 2);
+        const size_t off    = B.alloc((size_t)N * hw * rup64(C) * 2);
+        B.emit([=](hipStream_t st) {
+            float* sc = (float*)(P->arena + so);
+            float* sh = sc + N * C;
+            launch_gn_stats(st, sc, sh, xp, hw, C, N, groups, eps, w, b);
+            launch_nchw_to_nhwc_f16(st, P->arena + off, xp, hw, C, N, sc, sh, silu);
+        });
+        g_stats.kernels_planned++;
+        B.packed[gi.node(last)] = Packed{off, rup64(C), true};
+        g_stats.fused_norm++;
+        return true;
+    }
     B.emit([=](hipStream_t st) { launch_group_norm(st, dst, xp, hw, C, N, groups, eps, w, b, silu); });
     if (last != i) g_stats.fused_norm++;
     return true;
@@ -474,6 +657,15 @@ bool plan_layer_norm(Builder& B, int i, hipStream_t, std::vector<int>& chain) {
     float* dst      = (float*)n->data;
     const float* xp = (const float*)x->data;
     const int64_t xs = (int64_t)x->nb[1] / 4, ds = (int64_t)n->nb[1] / 4;
+    if (C % 4 == 0 && xs % 4 == 0 && aligned16(xp) && (!w || aligned16(w)) && (!b || aligned16(b)) && all_consumers_gemm16(gi, last, false)) {
+        // gen-2: all readers are weight GEMMs (q/k/v or FF projections) -> write the f16 operand image only
+        Planner* P       = B.P;
+        const size_t off = B.alloc((size_t)rows * rup64(C) * 2);
+        B.emit([=](hipStream_t st) { launch_layer_norm_f16(st, P->arena + off, xp, C, rows, xs, eps, w, b, rms); });
+        B.packed[gi.node(last)] = Packed{off, rup64(C), false};
+        g_stats.fused_norm++;
+        return true;
+    }
     B.emit([=](hipStream_t st) { launch_layer_norm(st, dst, xp, C, rows, xs, ds, eps, w, b, rms); });
     if (last != i) g_stats.fused_norm++;
     return true;
@@ -506,6 +698,14 @@ bool plan_geglu(Builder& B, int i, hipStream_t, std::vector<int>& chain) {
     float* dst      = (float*)out->data;
     const float* xp = (const float*)X->data;
     const int64_t xs = (int64_t)X->nb[1] / 4;
+    if (all_consumers_gemm16(gi, j2, false)) {
+        Planner* P       = B.P;
+        const size_t off = B.alloc((size_t)tokens * rup64(inner) * 2);
+        B.emit([=](hipStream_t st) { launch_geglu_f16(st, P->arena + off, xp, tokens, inner, xs); });
+        B.packed[out] = Packed{off, rup64(inner), false};
+        g_stats.fused_geglu++;
+        return true;
+    }
     B.emit([=](hipStream_t st) { launch_geglu(st, dst, xp, tokens, inner, xs); });
     g_stats.fused_geglu++;
     return true;
@@ -562,7 +762,11 @@ bool plan_manual_attention(Builder& B, int i, hipStream_t, std::vector<int>& cha
     const int64_t nbq = (int64_t)out->nb[1], nbh = (int64_t)out->nb[2];
     const int64_t nel = ggml_abi_nelements(out);
     B.emit([=](hipStream_t st) {
-        launch_flash_attn(st, kdst, nbq, nbh, qv, kv, vv, scale);
+        FlashOut fo;
+        fo.dst  = kdst;
+        fo.nb_q = nbq;
+        fo.nb_h = nbh;
+        launch_flash_attn(st, fo, qv, kv, vv, scale);
         if (kdst != dst) (void)hipMemcpyAsync(dst, kdst, nel * 4, hipMemcpyDeviceToDevice, st);
     });
     g_stats.fused_attention++;
@@ -658,6 +862,21 @@ bool plan_single(Builder& B, int i, hipStream_t s) {
             const int64_t W = x->ne[0], H = x->ne[1], IC = x->ne[2], N = x->ne[3], OC = ker->ne[3];
             const int ks = (int)ker->ne[0], st_ = p[0], pd = p[2];
             Epilogue ep;
+            if (g_opt.gemm16) {
+                auto it = B.packed.find(x);
+                if (it == B.packed.end() || !it->second.nhwc) {
+                    Packed pk{B.alloc((size_t)N * W * H * rup64(IC) * 2), rup64(IC), true};
+                    Planner* P       = B.P;
+                    const size_t off = pk.off;
+                    B.emit([=](hipStream_t st) { launch_nchw_to_nhwc_f16(st, P->arena + off, xp, W * H, IC, N, nullptr, nullptr, false); });
+                    B.packed[x] = pk;
+                    it          = B.packed.find(x);
+                }
+                Planner* P       = B.P;
+                const size_t off = it->second.off;
+                B.emit([=](hipStream_t st) { launch_gemm16_conv(st, dst, P->arena + off, swz, W, H, IC, N, OC, ks, st_, pd, false, ep); });
+                return true;
+            }
             B.emit([=](hipStream_t st) { launch_conv2d_mfma(st, dst, xp, swz, W, H, IC, N, OC, ks, st_, pd, false, ep); });
             return true;
         }
@@ -698,7 +917,58 @@ bool plan_single(Builder& B, int i, hipStream_t s) {
             const float sc   = ggml_abi_op_param_f32(n, 0);
             // dst.ne = [dv, H, Lq, B]: element (d, q, h) at h*nb1 + q*nb2
             const int64_t nbq = (int64_t)n->nb[2], nbh = (int64_t)n->nb[1];
-            B.emit([=](hipStream_t st) { launch_flash_attn(st, dst, nbq, nbh, q, k, v, sc); });
+            FlashOut fo;
+            fo.dst  = dst;
+            fo.nb_q = nbq;
+            fo.nb_h = nbh;
+            // -> VIEW [d,H,Lq,N] -> CONT [C,Lq,N] (ggml_extend.hpp:1446-1455, 1481-1482): write the final layout directly
+            if (g_opt.fusion) {
+                const int j1 = gi.sole(i);
+                const int j2 = (j1 >= 0 && gi.node(j1)->op == GGML_OP_VIEW) ? gi.sole(j1) : -1;
+                if (j2 >= 0 && gi.node(j2)->op == GGML_OP_CONT && gi.node(j2)->src[0] == gi.node(j1) && is_f32(gi.node(j2)) && contig(gi.node(j2))) {
+                    const ggml_tensor* vw = gi.node(j1);   // ne = [d, H, Lq, N]
+                    const ggml_tensor* ct = gi.node(j2);
+                    std::vector<int> chain{i, j1, j2};
+                    const int64_t d = vw->ne[0], H = vw->ne[1], Lq = vw->ne[2], Nimg = vw->ne[3];
+                    if (d == n->ne[0] && H * Nimg == n->ne[1] && Lq == n->ne[2] && (const char*)vw->data == (const char*)n->data &&
+                        (int64_t)vw->nb[1] == (int64_t)n->nb[1] && (int64_t)vw->nb[2] == (int64_t)n->nb[2] && (int64_t)vw->nb[3] == (int64_t)n->nb[1] * H &&
+                        gi.only_noops_between(i, j2, chain)) {
+                        const int64_t C = d * H;
+                        if (all_consumers_gemm16(gi, j2, false)) {
+                            // every reader is a weight GEMM (to_out): emit only the f16 operand image [tok][C]
+                            Planner* P       = B.P;
+                            const size_t off = B.alloc((size_t)Nimg * Lq * rup64(C) * 2);
+                            const int64_t ld = rup64(C);
+                            if (ld != C) {  // zero the K padding once per launch
+                                B.emit([=](hipStream_t st) { (void)hipMemsetAsync(P->arena + off, 0, (size_t)Nimg * Lq * ld * 2, st); });
+                            }
+                            B.emit([=](hipStream_t st) {
+                                FlashOut f2;
+                                f2.H     = (int)H;
+                                f2.dst16 = P->arena + off;
+                                f2.ld16  = ld;
+                                launch_flash_attn(st, f2, q, k, v, sc);
+                            });
+                            B.packed[ct] = Packed{off, ld, false};
+                        } else {
+                            float* cdst = (float*)ct->data;
+                            B.emit([=](hipStream_t st) {
+                                FlashOut f2;
+                                f2.dst  = cdst;
+                                f2.H    = (int)H;
+                                f2.nb_q = C * 4;
+                                f2.nb_h = d * 4;
+                                f2.nb_n = Lq * C * 4;
+                                launch_flash_attn(st, f2, q, k, v, sc);
+                            });
+                        }
+                        gi.done[j1] = gi.done[j2] = 1;
+                        g_stats.fused_attention++;
+                        return true;
+                    }
+                }
+            }
+            B.emit([=](hipStream_t st) { launch_flash_attn(st, fo, q, k, v, sc); });
             g_stats.fused_attention++;
             return true;
         }
@@ -731,6 +1001,19 @@ bool build_plan(Planner* P, Plan* plan, const ggml_cgraph* g, hipStream_t s) {
             case GGML_OP_NORM:
             case GGML_OP_RMS_NORM: ok = plan_layer_norm(B, i, s, chain); break;
             case GGML_OP_CONT: ok = plan_geglu(B, i, s, chain); break;
+            case GGML_OP_UPSCALE: {
+                // nearest x2 feeding only an implicit-GEMM conv (UpSampleBlock, block.hpp:57-64): fold into the conv's gather
+                const ggml_tensor* src = n->src[0];
+                const int c            = gi.sole(i);
+                if (g_opt.gemm16 && n->op_params[0] == GGML_SCALE_MODE_NEAREST && is_f32(src) && contig(src) && n->ne[0] == 2 * src->ne[0] &&
+                    n->ne[1] == 2 * src->ne[1] && n->ne[2] == src->ne[2] && n->ne[3] == src->ne[3] && c >= 0 && gi.node(c)->op == GGML_OP_IM2COL &&
+                    gi.node(c)->src[1] == n && conv_im2col_fast_ok(gi, c) && gi.node(c)->src[0]->ne[0] == 3 && gi.node(c)->op_params[0] == 1) {
+                    B.ups[n] = src;
+                    chain    = {i};
+                    ok       = true;
+                }
+                break;
+            }
             default: break;
         }
         if (ok) {
@@ -743,7 +1026,8 @@ bool build_plan(Planner* P, Plan* plan, const ggml_cgraph* g, hipStream_t s) {
         }
         gi.done[i] = 1;
     }
-    plan->n_nodes = g->n_nodes;
+    plan->n_nodes      = g->n_nodes;
+    plan->arena_needed = B.arena_off;
     g_stats.plans_built++;
     g_stats.nodes_seen += g->n_nodes;
     g_stats.kernels_planned += (int64_t)plan->steps.size();
@@ -756,6 +1040,7 @@ bool build_plan(Planner* P, Plan* plan, const ggml_cgraph* g, hipStream_t s) {
 Planner* planner_create(int device) {
     Planner* p = new Planner();
     p->device  = device;
+    gemm16_init();
     std::lock_guard<std::mutex> lk(g_mu);
     g_planners.push_back(p);
     return p;
@@ -778,7 +1063,7 @@ void planner_destroy(Planner* p) {
         planner_clear_locked(p);
     }
     for (auto& kv : p->swz) (void)hipFree(kv.second.swz);
-    if (p->scratch) (void)hipFree(p->scratch);
+    if (p->arena) (void)hipFree(p->arena);
     delete p;
 }
 
@@ -812,6 +1097,26 @@ enum ggml_status planner_compute(Planner* p, ggml_cgraph* g, hipStream_t stream)
         if (!build_plan(p, np.get(), g, stream)) return GGML_STATUS_FAILED;
         plan         = np.get();
         p->plans[key] = std::move(np);
+    }
+    if (plan->arena_needed > p->arena_cap) {
+        // grow the operand arena (plans keep offsets, so only captured hipGraphs must be dropped)
+        (void)hipStreamSynchronize(stream);
+        if (p->arena) (void)hipFree(p->arena);
+        const size_t want = plan->arena_needed + plan->arena_needed / 4 + (64u << 20);
+        void* np          = nullptr;
+        if (hipMalloc(&np, want) != hipSuccess) {
+            p->arena     = nullptr;
+            p->arena_cap = 0;
+            (void)hipGetLastError();
+            return GGML_STATUS_ALLOC_FAILED;
+        }
+        p->arena     = (char*)np;
+        p->arena_cap = want;
+        for (auto& kv : p->plans)
+            if (kv.second->graph_exec) {
+                (void)hipGraphExecDestroy(kv.second->graph_exec);
+                kv.second->graph_exec = nullptr;
+            }
     }
     if (g_opt.hip_graph && !plan->graph_failed) {
         if (!plan->graph_exec) {
@@ -958,6 +1263,8 @@ void planner_set_option(const char* key, int value) {
     else if (!strcmp(key, "mfma_gemm")) g_opt.mfma_gemm = value;
     else if (!strcmp(key, "hip_graph")) g_opt.hip_graph = value;
     else if (!strcmp(key, "flash_pattern")) g_opt.flash_pattern = value;
+    else if (!strcmp(key, "gemm16")) g_opt.gemm16 = value;
+    else if (!strcmp(key, "gemm16_variant")) gemm16_set_variant(value);
     // options change what a plan contains: drop cached plans
     std::lock_guard<std::mutex> lk(g_mu);
     for (Planner* p : g_planners) {

@@ -429,8 +429,37 @@ static bool sample_group(sd_ctx_t* ctx, const sd_img_gen_params_t* p, int b0, in
             return sd_unet_forward(ctx, noised.data(), W, H, C, nb, ts.data(), cd.c_crossattn, cd.ctx_dim, cd.n_tokens, 1,
                                    cd.c_vector, cd.vector_dim, 1, dst);
         };
-        if (!run(p->cond, cond_out.data())) return false;
-        if (use_cfg) {
+        if (use_cfg && p->fuse_cfg_pair && p->cond.ctx_dim == p->uncond.ctx_dim && p->cond.n_tokens == p->uncond.n_tokens) {
+            // one graph for the cond/uncond pair: images interleaved (b cond, b uncond, ...); context/y have batch 2 and are
+            // tiled over the 2*nb images by the graph's ggml_repeat (dst[i] = src[i % 2])
+            const size_t cn = (size_t)p->cond.ctx_dim * p->cond.n_tokens;
+            std::vector<float> x2(2 * per * nb), o2(2 * per * nb), t2(2 * nb, t), c2(2 * cn), y2;
+            for (int b = 0; b < nb; ++b) {
+                memcpy(&x2[(2 * b) * per], &noised[b * per], per * sizeof(float));
+                memcpy(&x2[(2 * b + 1) * per], &noised[b * per], per * sizeof(float));
+            }
+            memcpy(&c2[0], p->cond.c_crossattn, cn * sizeof(float));
+            memcpy(&c2[cn], p->uncond.c_crossattn, cn * sizeof(float));
+            const bool has_y = p->cond.c_vector && p->uncond.c_vector;
+            if (has_y) {
+                y2.resize(2 * p->cond.vector_dim);
+                memcpy(&y2[0], p->cond.c_vector, p->cond.vector_dim * sizeof(float));
+                memcpy(&y2[p->cond.vector_dim], p->uncond.c_vector, p->cond.vector_dim * sizeof(float));
+            }
+            if (!sd_unet_forward(ctx, x2.data(), W, H, C, 2 * nb, t2.data(), c2.data(), p->cond.ctx_dim, p->cond.n_tokens, 2,
+                                 has_y ? y2.data() : nullptr, p->cond.vector_dim, 2, o2.data()))
+                return false;
+            for (int b = 0; b < nb; ++b) {
+                memcpy(&cond_out[b * per], &o2[(2 * b) * per], per * sizeof(float));
+                memcpy(&uncond_out[b * per], &o2[(2 * b + 1) * per], per * sizeof(float));
+            }
+            for (size_t k = 0; k < x.size(); ++k) {
+                const float guided = uncond_out[k] + sp.txt_cfg * (cond_out[k] - uncond_out[k]);
+                denoised[k]        = guided * c_out + x[k] * c_skip;
+            }
+        } else if (!run(p->cond, cond_out.data())) {
+            return false;
+        } else if (use_cfg) {
             if (!run(p->uncond, uncond_out.data())) return false;
             for (size_t k = 0; k < x.size(); ++k) {  // guidance.cpp:171 ; stable-diffusion.cpp:2876
                 const float guided = uncond_out[k] + sp.txt_cfg * (cond_out[k] - uncond_out[k]);

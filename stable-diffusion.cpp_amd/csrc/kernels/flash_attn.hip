@@ -13,29 +13,39 @@
 // cross-lane exchange.  P is fed back as the A operand WITHOUT any data movement by letting the MFMA k-slots
 // follow the accumulator's own key order (lane half h owns keys {4h..4h+3, 8+4h..8+4h+3} of each 16-key group)
 // and reading V with the same permutation.
+// Staging is split (cdna_hip_programming.md T14): the 16-byte global loads of tile t+1 are issued into registers
+// BEFORE the MFMAs of tile t and written to LDS after the next barrier, so HBM/L2 latency hides under compute.
 #include "device_utils.h"
 #include "kernels.h"
 
 namespace mi355x {
 
-constexpr int FA_KT   = 64;  // keys per tile
-constexpr int FA_VTS  = 68;  // Vt row stride in halfs (136 B: conflict-free ds_read_b64 over 32 rows)
+constexpr int FA_KT  = 64;  // keys per tile
+constexpr int FA_VTS = 68;  // Vt row stride in halfs (136 B: conflict-free ds_read_b64 over 32 rows)
 
 struct FAArgs {
     const char *q, *k, *v;
     float* dst;
-    int64_t q_nb1, q_nb2, k_nb1, k_nb2, v_nb0, v_nb1, v_nb2, dst_nb_q, dst_nb_h;
+    _Float16* dst16;
+    int64_t q_nb1, q_nb2, k_nb1, k_nb2, v_nb0, v_nb1, v_nb2, dst_nb_q, dst_nb_h, dst_nb_n, ld16;
+    int H;
     int Lq, Lk, D, DV;
     int kv_f16;
+    int vec_ok;  // K and V rows are d-contiguous, 16-byte aligned, D % 8 == 0 -> 128-bit staging loads
     float scale_log2e;
 };
 
-template <int DKP, int NDV>
-__global__ __launch_bounds__(256) void k_flash_attn(FAArgs g) {
-    constexpr int KS   = DKP / 16;   // MFMA k-steps over the head dim
-    constexpr int KROW = DKP + 8;    // K tile row stride (halfs)
-    __shared__ __attribute__((aligned(16))) _Float16 Ks[FA_KT * KROW];
-    __shared__ __attribute__((aligned(16))) _Float16 Vt[NDV * 32 * FA_VTS];
+// FAST: K and V are f16, d-contiguous and 16-byte aligned (the FLASH_ATTN_EXT node as the reference builds it) -> 128-bit
+// loads, register-prefetched one tile ahead.  !FAST: any strides / f32 sources (manual-attention chain), staged directly.
+template <int DKP, int NDV, bool FAST>
+__global__ __launch_bounds__(256, 2) void k_flash_attn(FAArgs g) {
+    constexpr int KS   = DKP / 16;                       // MFMA k-steps over the head dim
+    constexpr int KROW = DKP + 8;                        // K tile row stride (halfs)
+    constexpr int DCH  = DKP / 8;                        // 8-wide d chunks per key
+    constexpr int NCH  = FAST ? (FA_KT * DCH + 255) / 256 : 1;  // prefetched chunks per thread (K and V each)
+    __shared__ __attribute__((aligned(16))) _Float16 smem[FA_KT * KROW + NDV * 32 * FA_VTS];
+    _Float16* Ks = smem;
+    _Float16* Vt = smem + FA_KT * KROW;
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -66,13 +76,41 @@ __global__ __launch_bounds__(256) void k_flash_attn(FAArgs g) {
     const char* kbase = g.k + (int64_t)hn * g.k_nb2;
     const char* vbase = g.v + (int64_t)hn * g.v_nb2;
 
-    for (int kt = 0; kt < g.Lk; kt += FA_KT) {
-        __syncthreads();
-        // ---- stage K tile [64][DKP] (zero padded) : one 8-wide chunk per thread-iteration, lanes along d
-        for (int e = threadIdx.x; e < FA_KT * (DKP / 8); e += 256) {
-            const int key = e / (DKP / 8), ch = e % (DKP / 8);
+    // ---- FAST: split staging (T14): registers hold the next tile's K and V chunks (8 halfs = 16 B each)
+    half8_t kreg[NCH], vreg[NCH];
+    const int nd8 = g.D / 8;  // valid 8-wide chunks per row
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int e   = threadIdx.x + c * 256;
+            const int key = e / DCH, ch = e - key * DCH;
+            half8_t zk = {0, 0, 0, 0, 0, 0, 0, 0};
+            kreg[c] = zk;
+            vreg[c] = zk;
+            if (e < FA_KT * DCH && kt + key < g.Lk && ch < nd8) {
+                kreg[c] = *(const half8_t*)(kbase + (int64_t)(kt + key) * g.k_nb1 + ch * 16);
+                vreg[c] = *(const half8_t*)(vbase + (int64_t)(kt + key) * g.v_nb1 + ch * 16);
+            }
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int e = threadIdx.x + c * 256;
+            if (e < FA_KT * DCH) {
+                const int key = e / DCH, ch = e - key * DCH;
+                *(half8_t*)&Ks[key * KROW + ch * 8] = kreg[c];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) Vt[(ch * 8 + j) * FA_VTS + key] = vreg[c][j];
+            }
+        }
+    };
+    // ---- generic staging (any strides, f16 or f32 sources): straight to LDS
+    auto stage_generic = [&](int kt) {
+        for (int e = threadIdx.x; e < FA_KT * DCH; e += 256) {
+            const int key = e / DCH, ch = e - key * DCH;
+            const int kk  = kt + key;
             half8_t h;
-            const int kk = kt + key;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int d = ch * 8 + j;
@@ -85,9 +123,9 @@ __global__ __launch_bounds__(256) void k_flash_attn(FAArgs g) {
             }
             *(half8_t*)&Ks[key * KROW + ch * 8] = h;
         }
-        // ---- stage V tile transposed Vt[dv][key] : lanes along keys (conflict-free 2-byte LDS writes)
-        for (int e = threadIdx.x; e < FA_KT * (NDV * 4); e += 256) {
-            const int key = e & (FA_KT - 1), ch = e >> 6;  // ch: 8-wide dv chunk
+        // V: lanes along keys (coalesced for the key-contiguous vT of the manual chain, conflict-free 2-byte LDS writes)
+        for (int e = threadIdx.x; e < FA_KT * DCH; e += 256) {
+            const int key = e & (FA_KT - 1), ch = e >> 6;
             const int kk  = kt + key;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -100,7 +138,19 @@ __global__ __launch_bounds__(256) void k_flash_attn(FAArgs g) {
                 Vt[d * FA_VTS + key] = (_Float16)v;
             }
         }
+    };
+
+    // padded V^T rows (d >= DKP) are never staged: clear them once so the masked output columns stay finite
+    for (int e = threadIdx.x; e < NDV * 32 * FA_VTS / 2; e += 256) ((uint32_t*)Vt)[e] = 0u;
+    if (FAST) gload(0);
+    for (int kt = 0; kt < g.Lk; kt += FA_KT) {
+        __syncthreads();  // every wave finished reading the previous tile
+        if (FAST)
+            lstore();
+        else
+            stage_generic(kt);
         __syncthreads();
+        if (FAST && kt + FA_KT < g.Lk) gload(kt + FA_KT);  // in flight during this tile's MFMAs
 
         // ---- S^T = K Q^T  (rows i = key, cols j = query)
         float16_t s[2];
@@ -115,13 +165,16 @@ __global__ __launch_bounds__(256) void k_flash_attn(FAArgs g) {
         }
         // ---- online softmax for query (lane & 31); this lane holds keys kb*32 + (r&3)+8*(r>>2)+4*hi
         float tmax = -INFINITY;
+        const bool tail = kt + FA_KT > g.Lk;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int key = kt + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                float v       = s[kb][r] * g.scale_log2e;
-                if (key >= g.Lk) v = -INFINITY;
+                float v = s[kb][r] * g.scale_log2e;
+                if (tail) {
+                    const int key = kt + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (key >= g.Lk) v = -INFINITY;
+                }
                 s[kb][r] = v;
                 tmax     = fmaxf(tmax, v);
             }
@@ -185,11 +238,17 @@ __global__ __launch_bounds__(256) void k_flash_attn(FAArgs g) {
         const float ir = __shfl(inv, row, 64);
         const int q    = q0 + row;
         if (q < g.Lq) {
-            float* orow = (float*)((char*)g.dst + (int64_t)q * g.dst_nb_q + (int64_t)hn * g.dst_nb_h);
+            const int hh = g.H > 0 ? hn % g.H : hn, nn = g.H > 0 ? hn / g.H : 0;
+            float* orow     = g.dst ? (float*)((char*)g.dst + (int64_t)q * g.dst_nb_q + (int64_t)hh * g.dst_nb_h + (int64_t)nn * g.dst_nb_n) : nullptr;
+            _Float16* orow16 = g.dst16 ? g.dst16 + ((int64_t)nn * g.Lq + q) * g.ld16 + (int64_t)hh * g.DV : nullptr;
 #pragma unroll
             for (int nb = 0; nb < NDV; ++nb) {
                 const int d = nb * 32 + (lane & 31);
-                if (d < g.DV) orow[d] = o[nb][r] * ir;
+                if (d < g.DV) {
+                    const float val = o[nb][r] * ir;
+                    if (orow) orow[d] = val;
+                    if (orow16) orow16[d] = (_Float16)val;
+                }
             }
         }
     }
@@ -197,12 +256,17 @@ __global__ __launch_bounds__(256) void k_flash_attn(FAArgs g) {
 
 bool flash_attn_supported(int64_t D, int64_t DV) { return D == DV && D >= 8 && D <= 160; }
 
-void launch_flash_attn(hipStream_t s, float* dst, int64_t dst_nb_q, int64_t dst_nb_h, const View4& q, const View4& k, const View4& v, float scale) {
+void launch_flash_attn(hipStream_t s, const FlashOut& out, const View4& q, const View4& k, const View4& v, float scale) {
     FAArgs g;
     g.q = (const char*)q.data;
     g.k = (const char*)k.data;
     g.v = (const char*)v.data;
-    g.dst = dst;
+    g.dst      = out.dst;
+    g.dst16    = (_Float16*)out.dst16;
+    g.ld16     = out.ld16;
+    g.H        = out.H;
+    g.dst_nb_n = out.nb_n;
+    const int64_t dst_nb_q = out.nb_q, dst_nb_h = out.nb_h;
     g.q_nb1 = q.nb[1];
     g.q_nb2 = q.nb[2];
     g.k_nb1 = k.nb[1];
@@ -218,20 +282,31 @@ void launch_flash_attn(hipStream_t s, float* dst, int64_t dst_nb_q, int64_t dst_
     g.DV = (int)v.ne[0];
     g.kv_f16      = k.type == 1;
     g.scale_log2e = scale * 1.44269504088896340736f;
+    auto al16 = [](const void* p, int64_t a, int64_t b) { return ((((uintptr_t)p) | (uintptr_t)a | (uintptr_t)b) & 15) == 0; };
+    g.vec_ok = (g.D % 8 == 0) && al16(k.data, k.nb[1], k.nb[2]) && al16(v.data, v.nb[1], v.nb[2]);
     dim3 grid((unsigned)((g.Lq + 127) / 128), (unsigned)q.ne[2]);
-    const int D = g.D;
+    const int D     = g.D;
+    const bool fast = g.vec_ok && g.kv_f16 && v.nb[0] == 2 && k.nb[0] == 2 && g.D == g.DV;
+#define FA_CASE(DKP_, NDV_)                                           \
+    do {                                                              \
+        if (fast)                                                     \
+            k_flash_attn<DKP_, NDV_, true><<<grid, 256, 0, s>>>(g);   \
+        else                                                          \
+            k_flash_attn<DKP_, NDV_, false><<<grid, 256, 0, s>>>(g);  \
+    } while (0)
     if (D <= 48)
-        k_flash_attn<48, 2><<<grid, 256, 0, s>>>(g);
+        FA_CASE(48, 2);
     else if (D <= 64)
-        k_flash_attn<64, 2><<<grid, 256, 0, s>>>(g);
+        FA_CASE(64, 2);
     else if (D <= 80)
-        k_flash_attn<80, 3><<<grid, 256, 0, s>>>(g);
+        FA_CASE(80, 3);
     else if (D <= 96)
-        k_flash_attn<96, 3><<<grid, 256, 0, s>>>(g);
+        FA_CASE(96, 3);
     else if (D <= 128)
-        k_flash_attn<128, 4><<<grid, 256, 0, s>>>(g);
+        FA_CASE(128, 4);
     else
-        k_flash_attn<160, 5><<<grid, 256, 0, s>>>(g);
+        k_flash_attn<160, 5, false><<<grid, 256, 0, s>>>(g);  // 80 accumulator + 40 Q registers leave no room for the prefetch set
+#undef FA_CASE
 }
 
 }  // namespace mi355x

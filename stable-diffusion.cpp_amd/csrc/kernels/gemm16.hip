@@ -1,0 +1,603 @@
+// gemm16.hip — second-generation dense contraction for gfx950: BOTH operands arrive as f16 images and are
+// streamed HBM/L2 -> LDS by the LDS-DMA engine (global_load_lds_dwordx4), so the main loop contains nothing but
+// DMA issue, ds_read_b128 fragment reads and v_mfma_f32_32x32x16_f16.  No f32->f16 conversion, no address math
+// per element, no VGPR staging — the first-generation kernels in wgemm.hip were bound by exactly those
+// (profiles/r01a_*: 3 % of the MFMA peak).
+//
+//   A  activations, f16 row-major [rows][Kp] (K contiguous, Kp % 64 == 0), written once by the PRODUCER of the
+//      tensor (norm / GEGLU / pack kernels below) into the backend's private operand arena;
+//      linear: rows = tokens;  conv: rows = output positions, the A-tile of K-tile (tap, ic-block) is gathered
+//      straight from the NHWC image at (oh*S+kh-pad, ow*S+kw-pad) — implicit GEMM with K = KS*KS*ICp, padding
+//      taps read a zero page, the nearest-x2 upsample is an index shift.  No im2col, no halo patch.
+//   W  static weights in MFMA fragment order [col/32][Kp/16][64 lanes][8 halfs] (wgemm.hip: launch_wswz_*).
+//
+// Tile 128 rows x BN cols x 64 k per stage, 2 LDS stages (32 KB A + 32 KB W at BN=128), 4 waves (2x2, 64x64 each).
+// LDS image of A: row r holds its 8 16-byte k-slots XOR-permuted by ((r>>1)&7); the permutation is applied on the
+// DMA SOURCE address (the LDS destination of an LDS-DMA is always lane-linear) and again on the fragment read, which
+// makes every ds_read_b128 of 16 consecutive rows hit 16 distinct 4-bank slots (cdna_hip_programming.md rule 21).
+// One __syncthreads per K-tile: the barrier's implicit vmcnt(0) retires this tile's DMA, the next tile's DMA is
+// issued right after it and overlaps the 32 MFMAs of the current tile; 2 workgroups per CU hide the rest.
+#include "device_utils.h"
+#include "kernels.h"
+
+namespace mi355x {
+
+struct G16Epi {
+    const float* bias;
+    const float* residual;
+    float scale;
+    int act;
+};
+
+struct G16Args {
+    const _Float16* A;
+    int64_t lda;       // halfs (rows mode)
+    const half8_t* W;
+    int64_t kfr;       // fragments per 32-col block = Kp/16
+    float* dst;
+    _Float16* dst16;   // optional f16 row-major copy of the output (rows mode), row stride ldd16 halfs
+    int64_t ldd, ldd16;
+    int hm_d, hm_H, hm_L;  // head-major store (rows mode): element (row = n*L + l, col = h*d + dd) -> ((n*H + h)*L + l)*d + dd
+    int64_t R, C;
+    int nt;            // K tiles (64 each)
+    int ncol_tiles;
+    // conv gather
+    int H, Wd, ICp, OH, OW, S, pad, UPS, KS, icb_per_tap;
+    int64_t OHOW;
+    const _Float16* zero;
+    G16Epi ep;
+};
+
+#define GLDS16(gptr, ldsptr) \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr), (__attribute__((address_space(3))) void*)(ldsptr), 16, 0, 0)
+
+template <int BN, bool CONV, int BK, int NST, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void k_gemm16(G16Args g) {
+    constexpr int WC  = 2;             // waves along columns
+    constexpr int WR  = NW / 2;        // waves along rows
+    constexpr int BM  = WR * 64;       // rows per workgroup (128 or 256)
+    constexpr int RB  = 2;             // 32-row blocks per wave
+    constexpr int CB  = BN / WC / 32;  // 32-col blocks per wave (2 or 1)
+    constexpr int ROWB   = BK * 2;     // bytes per A row in a stage (128 or 64)
+    constexpr int SLOTS  = ROWB / 16;  // 16-byte k-slots per row (8 or 4)
+    constexpr int RPP    = 1024 / ROWB;  // rows per 1-KiB DMA piece (8 or 16)
+    constexpr int ABYTES = BM * ROWB;
+    constexpr int BBYTES = BN * ROWB;  // W stage (fragment order)
+    constexpr int KSTEPS = BK / 16;
+    constexpr int APW    = (ABYTES / 1024) / NW;       // A pieces per wave per stage
+    constexpr int WPW    = (BN / 32) * KSTEPS / NW;    // W fragments per wave per stage
+    constexpr int NPT    = APW + WPW;                  // LDS-DMA instructions per wave per stage
+    static_assert(WPW >= 1, "tile too small");
+    __shared__ __attribute__((aligned(1024))) char smem[NST * (ABYTES + BBYTES)];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave % WR, wc = wave / WR;
+
+    // XCD-aware tile order: consecutive ids on one XCD share the A row tile (all column tiles of a row tile)
+    int bid = blockIdx.x;
+    {
+        const int nb = gridDim.x;
+        if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);
+    }
+    const int row_tile = bid / g.ncol_tiles, col_tile = bid - row_tile * g.ncol_tiles;
+    const int64_t row0 = (int64_t)row_tile * BM;
+    const int col0     = col_tile * BN;
+
+    // XOR permutation of the k-slots of LDS row r (conflict-free ds_read_b128 over 16 consecutive rows)
+    auto rowswz = [](int r) { return SLOTS == 8 ? ((r >> 1) & 7) : ((r >> 2) & 3); };
+
+    // ---- per-lane DMA sources.  A: wave w issues pieces i = w*APW+q: rows RPP*i + lane/SLOTS, physical slot lane%SLOTS
+    const _Float16* asrc[APW];   // rows mode: row pointer (+slot); conv: pointer of the tap-(0,0) pixel (+slot), may be out of range
+    unsigned a_mask[APW];        // conv: bit t set <=> tap t of this output position reads a real pixel (else the zero page)
+    int a_slot[APW];
+#pragma unroll
+    for (int q = 0; q < APW; ++q) {
+        const int r  = (wave * APW + q) * RPP + lane / SLOTS;
+        const int ls = (lane % SLOTS) ^ rowswz(r);  // logical k-slot fetched into physical slot lane%SLOTS
+        a_slot[q]    = ls * 8;
+        int64_t row  = row0 + r;
+        if (!CONV) {
+            if (row >= g.R) row = g.R - 1;
+            asrc[q] = g.A + row * g.lda + ls * 8;
+        } else {
+            // all per-position address work happens ONCE here; the K loop only adds a wave-uniform tap offset
+            const bool ok = row < g.R;
+            if (!ok) row = g.R - 1;
+            const int img = (int)(row / g.OHOW);
+            const int p   = (int)(row - (int64_t)img * g.OHOW);
+            const int oh = p / g.OW, ow = p - oh * g.OW;
+            const int CH = g.UPS ? g.H * 2 : g.H, CW = g.UPS ? g.Wd * 2 : g.Wd;
+            unsigned m = 0;
+            for (int t = 0; t < g.KS * g.KS; ++t) {
+                const int ih = oh * g.S + t / g.KS - g.pad, iw = ow * g.S + t % g.KS - g.pad;
+                if (ok && ih >= 0 && ih < CH && iw >= 0 && iw < CW) m |= 1u << t;
+            }
+            a_mask[q] = m;
+            if (!g.UPS) {
+                // tap (kh,kw) pixel = base + ((kh*Wd + kw) * ICp) halfs  (no upsample: source index is affine in the tap)
+                asrc[q] = g.A + (((int64_t)img * g.H + (oh * g.S - g.pad)) * g.Wd + (ow * g.S - g.pad)) * g.ICp + ls * 8;
+            } else {
+                // nearest x2: keep (img, oh, ow) packed; resolved per tap (3 taps map to 2 source pixels)
+                asrc[q] = g.A + ((int64_t)img * g.H * g.Wd) * g.ICp + ls * 8;
+                a_slot[q] |= (oh << 8) | (ow << 20);  // oh, ow < 4096
+            }
+        }
+    }
+    const half8_t* wsrc[WPW];
+    int wdst[WPW];
+#pragma unroll
+    for (int q = 0; q < WPW; ++q) {
+        const int f  = wave * WPW + q;
+        const int cb = f / KSTEPS, ks = f % KSTEPS;
+        wsrc[q]      = g.W + ((int64_t)(col0 / 32 + cb) * g.kfr + ks) * 64 + lane;
+        wdst[q]      = f * 1024;
+    }
+    const int ktiles_per_icb = 64 / BK;  // conv: K tiles per 64-channel block (1 or 2)
+
+    auto stage = [&](int kt, int buf) {
+        char* sa = smem + buf * (ABYTES + BBYTES);
+        char* sb = sa + ABYTES;
+        if (!CONV) {
+#pragma unroll
+            for (int q = 0; q < APW; ++q) GLDS16(asrc[q] + (int64_t)kt * BK, sa + (wave * APW + q) * 1024);
+        } else {
+            const int kb  = kt / ktiles_per_icb, sub = kt - kb * ktiles_per_icb;  // kb: (tap, 64-channel block)
+            const int tap = kb / g.icb_per_tap, icb = kb - tap * g.icb_per_tap;
+            const int kh = tap / g.KS, kw = tap - kh * g.KS;
+            const int64_t koff = (int64_t)icb * 64 + sub * BK;  // wave-uniform (SALU)
+            if (!g.UPS) {
+                const int64_t toff = ((int64_t)kh * g.Wd + kw) * g.ICp + koff;
+#pragma unroll
+                for (int q = 0; q < APW; ++q) {
+                    const _Float16* p = ((a_mask[q] >> tap) & 1u) ? asrc[q] + toff : g.zero + (a_slot[q] & 63);
+                    GLDS16(p, sa + (wave * APW + q) * 1024);
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < APW; ++q) {
+                    const int oh = (a_slot[q] >> 8) & 4095, ow = (a_slot[q] >> 20) & 4095;
+                    const int sy = (oh * g.S + kh - g.pad) >> 1, sx = (ow * g.S + kw - g.pad) >> 1;
+                    const _Float16* p = ((a_mask[q] >> tap) & 1u) ? asrc[q] + ((int64_t)sy * g.Wd + sx) * g.ICp + koff : g.zero + (a_slot[q] & 63);
+                    GLDS16(p, sa + (wave * APW + q) * 1024);
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < WPW; ++q) GLDS16(wsrc[q] + (int64_t)kt * KSTEPS * 64, sb + wdst[q]);
+    };
+
+    float16_t acc[RB][CB];
+#pragma unroll
+    for (int a = 0; a < RB; ++a)
+#pragma unroll
+        for (int b = 0; b < CB; ++b) acc[a][b] = (float16_t){0};
+
+    // fragment read offsets (bytes) inside a stage
+    int aoff[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) aoff[rb] = (wr * (RB * 32) + rb * 32 + (lane & 31)) * ROWB;
+    const int aswz = rowswz(lane & 31);  // row blocks start at multiples of 32 rows -> the permutation depends on the lane only
+    const int hi   = lane >> 5;
+
+    auto compute = [&](int buf) {
+        const char* sa = smem + buf * (ABYTES + BBYTES);
+        const char* sb = sa + ABYTES;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            half8_t af[RB], bf[CB];
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) af[rb] = *(const half8_t*)(sa + aoff[rb] + (((ks * 2 + hi) ^ aswz) << 4));
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) bf[cb] = *(const half8_t*)(sb + (((wc * CB + cb) * KSTEPS + ks) * 64 + lane) * 16);
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) {
+                    if (CONV)
+                        acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[cb], af[rb], acc[rb][cb], 0, 0, 0);  // D[oc][pos]
+                    else
+                        acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[rb], bf[cb], acc[rb][cb], 0, 0, 0);  // D[row][col]
+                }
+        }
+    };
+
+    if (NST == 2) {
+        // one barrier per K tile: its implicit vmcnt(0) retires this tile's DMA, the next tile's DMA overlaps the MFMAs
+        stage(0, 0);
+        for (int kt = 0; kt < g.nt; ++kt) {
+            __syncthreads();
+            if (kt + 1 < g.nt) stage(kt + 1, (kt + 1) & 1);
+            compute(kt & 1);
+        }
+    } else {
+        // 3-deep ring, COUNTED waits: two tiles of DMA stay in flight across the barrier (cdna_hip_programming.md T3+T4):
+        // vmcnt(NPT) retires tile kt while tile kt+1 is still streaming; tile kt+2 is issued right after the barrier.
+        stage(0, 0);
+        if (g.nt > 1) stage(1, 1);
+        int buf = 0;
+        for (int kt = 0; kt < g.nt; ++kt) {
+            if (kt + 1 < g.nt)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPT) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (kt + 2 < g.nt) stage(kt + 2, buf >= 1 ? buf - 1 : 2);  // (kt+2)%3
+            compute(buf);
+            buf = buf == 2 ? 0 : buf + 1;
+        }
+    }
+
+    // ---- epilogue
+    if (!CONV) {
+        if (g.hm_d > 0) {
+            // attention operand layout [d, L, H, N]: the q/k/v projections write what CONT(permute(0,2,1,3)) (+CPY f16) would:
+            // element (row = n*L + l, col = h*d + dd) -> n*(H*L*d) + h*(L*d) + l*d + dd.  All divisions are hoisted: per column
+            // block (lane-constant) and per 32-row block (wave-uniform); rows inside a block advance by carry.
+            const int64_t Ld = (int64_t)g.hm_L * g.hm_d, HLd = Ld * g.hm_H;
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                const int64_t base_row = row0 + wr * (RB * 32) + rb * 32;
+                const int64_t n0       = base_row / g.hm_L;
+                const int l0           = (int)(base_row - n0 * g.hm_L);
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) {
+                    const int col = col0 + (wc * CB + cb) * 32 + (lane & 31);
+                    if (col >= g.C) continue;
+                    const int h = col / g.hm_d, dd = col - h * g.hm_d;
+                    const int64_t colpart = (int64_t)h * Ld + dd;
+                    const float bias      = g.ep.bias ? g.ep.bias[col] : 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int o = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        if (base_row + o >= g.R) continue;
+                        int l     = l0 + o;
+                        int64_t n = n0;
+                        while (l >= g.hm_L) {
+                            l -= g.hm_L;
+                            ++n;
+                        }
+                        const int64_t idx = n * HLd + (int64_t)l * g.hm_d + colpart;
+                        const float v     = acc[rb][cb][r] * g.ep.scale + bias;
+                        if (g.dst) g.dst[idx] = v;
+                        if (g.dst16) g.dst16[idx] = (_Float16)v;
+                    }
+                }
+            }
+            return;
+        }
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+            const int col = col0 + (wc * CB + cb) * 32 + (lane & 31);
+            if (col >= g.C) continue;
+            const float bias = g.ep.bias ? g.ep.bias[col] : 0.f;
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t row = row0 + wr * (RB * 32) + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (row < g.R) {
+                        float v = acc[rb][cb][r] * g.ep.scale + bias;
+                        if (g.ep.residual) v += g.ep.residual[row * g.ldd + col];
+                        if (g.ep.act >= 0) v = act_dyn(g.ep.act, v);
+                        if (g.dst) g.dst[row * g.ldd + col] = v;
+                        if (g.dst16) g.dst16[row * g.ldd16 + col] = (_Float16)v;
+                    }
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            const int64_t pos = row0 + wr * (RB * 32) + rb * 32 + (lane & 31);
+            if (pos >= g.R) continue;
+            const int64_t img = pos / g.OHOW, p = pos - img * g.OHOW;
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int oc = col0 + (wc * CB + cb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (oc < g.C) {
+                        const int64_t o = (img * g.C + oc) * g.OHOW + p;
+                        float v         = acc[rb][cb][r] * g.ep.scale;
+                        if (g.ep.bias) v += g.ep.bias[oc];
+                        if (g.ep.residual) v += g.ep.residual[o];
+                        if (g.ep.act >= 0) v = act_dyn(g.ep.act, v);
+                        g.dst[o] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+static inline int64_t rup64(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
+
+// pipeline / tile variant (tunable at run time for A/B measurements):
+//   0 = BK 64 x 2 stages (__syncthreads), 1 = BK 32 x 3 stages (counted vmcnt), 2 = BK 64 x 3 stages; all 128-row tiles
+//   3 (default) = variant 1 plus 256-row x 128-col tiles (8 waves) whenever they still fill the chip — the LDS-DMA engine
+//   delivers ~20 B/clk/CU, so FLOP per DMA byte (tile area / perimeter) is what bounds these kernels.
+static int g_g16_variant = 3;
+void gemm16_set_variant(int v) { g_g16_variant = v; }
+template <int BN_, bool CONV_>
+static void g16_launch(hipStream_t s, G16Args& g, int64_t rows) {
+    const int64_t col_tiles = g.ncol_tiles;
+    if (g_g16_variant == 3 && BN_ == 128) {
+        const int64_t rt256 = (rows + 255) / 256;
+        if (rt256 * col_tiles >= 256) {
+            k_gemm16<128, CONV_, 32, 3, 8><<<(unsigned)(rt256 * col_tiles), 512, 0, s>>>(g);
+            return;
+        }
+    }
+    const unsigned grid = (unsigned)(((rows + 127) / 128) * col_tiles);
+    if (g_g16_variant == 0)
+        k_gemm16<BN_, CONV_, 64, 2, 4><<<grid, 256, 0, s>>>(g);
+    else if (g_g16_variant == 2)
+        k_gemm16<BN_, CONV_, 64, 3, 4><<<grid, 256, 0, s>>>(g);
+    else
+        k_gemm16<BN_, CONV_, 32, 3, 4><<<grid, 256, 0, s>>>(g);
+}
+static inline bool g16_bk32() { return g_g16_variant == 1 || g_g16_variant == 3; }
+
+// a 256-byte zero page per device for the padding taps
+static const _Float16* zero_page() {
+    static thread_local const _Float16* z[16] = {nullptr};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!z[dev & 15]) {
+        void* p = nullptr;
+        (void)hipMalloc(&p, 256);
+        (void)hipMemset(p, 0, 256);
+        z[dev & 15] = (const _Float16*)p;
+    }
+    return z[dev & 15];
+}
+
+void gemm16_init() { (void)zero_page(); }
+
+void launch_gemm16_linear(hipStream_t s, float* dst, void* dst16, int64_t ldd16, const void* a16, int64_t lda, const void* wswz, int64_t rows, int64_t K,
+                          int64_t M, int64_t ldd, const Epilogue& e, int hm_d, int hm_H, int hm_L) {
+    G16Args g{};
+    g.A     = (const _Float16*)a16;
+    g.lda   = lda;
+    g.W     = (const half8_t*)wswz;
+    const int64_t Kp = rup64(K, 64);
+    g.kfr   = Kp / 16;
+    g.dst   = dst;
+    g.dst16 = (_Float16*)dst16;
+    g.ldd   = ldd;
+    g.ldd16 = ldd16;
+    g.hm_d  = hm_d;
+    g.hm_H  = hm_H;
+    g.hm_L  = hm_L;
+    g.R     = rows;
+    g.C     = M;
+    g.nt    = (int)(Kp / (g16_bk32() ? 32 : 64));
+    g.ep    = {e.bias, e.residual, e.scale, e.act};
+    // narrow outputs (M = 320: 2.5 tiles of 128) waste less with 64-wide column tiles
+    const bool bn64 = M <= 64;
+    if (bn64) {
+        g.ncol_tiles = (int)((M + 63) / 64);
+        g16_launch<64, false>(s, g, rows);
+    } else {
+        g.ncol_tiles = (int)((M + 127) / 128);
+        g16_launch<128, false>(s, g, rows);
+    }
+}
+
+void launch_gemm16_conv(hipStream_t s, float* dst, const void* x16_nhwc, const void* wswz, int64_t W, int64_t H, int64_t IC, int64_t N, int64_t OC, int ksize,
+                        int stride, int pad, bool upscale2x, const Epilogue& e) {
+    G16Args g{};
+    g.A   = (const _Float16*)x16_nhwc;
+    g.W   = (const half8_t*)wswz;
+    g.ICp = (int)rup64(IC, 64);
+    g.kfr = (int64_t)g.ICp * ksize * ksize / 16;
+    g.dst = dst;
+    g.H   = (int)H;
+    g.Wd  = (int)W;
+    const int CW = upscale2x ? (int)W * 2 : (int)W, CH = upscale2x ? (int)H * 2 : (int)H;
+    g.OW   = (CW + 2 * pad - ksize) / stride + 1;
+    g.OH   = (CH + 2 * pad - ksize) / stride + 1;
+    g.OHOW = (int64_t)g.OW * g.OH;
+    g.S    = stride;
+    g.pad  = pad;
+    g.UPS  = upscale2x ? 1 : 0;
+    g.KS   = ksize;
+    g.icb_per_tap = g.ICp / 64;
+    g.nt   = ksize * ksize * g.icb_per_tap * (g16_bk32() ? 2 : 1);
+    g.R    = g.OHOW * N;
+    g.C    = OC;
+    g.zero = zero_page();
+    g.ep   = {e.bias, e.residual, e.scale, e.act};
+    const bool bn64 = OC <= 64;
+    if (bn64) {
+        g.ncol_tiles = (int)((OC + 63) / 64);
+        g16_launch<64, true>(s, g, g.R);
+    } else {
+        g.ncol_tiles = (int)((OC + 127) / 128);
+        g16_launch<128, true>(s, g, g.R);
+    }
+}
+
+// =====================================================================================================
+// producers of the f16 operand images
+// =====================================================================================================
+// f32 rows [R][K] (row stride xs floats) -> f16 [R][Kp], zero padded
+__global__ void k_pack_rows_f16(_Float16* __restrict__ dst, const float* __restrict__ x, int64_t R, int K, int Kp, int64_t xs) {
+    const int64_t n8 = R * (Kp / 8);
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / (Kp / 8);
+        const int k0    = (int)(i - r * (Kp / 8)) * 8;
+        half8_t h;
+        if (k0 + 8 <= K) {
+            const float4 a = *(const float4*)(x + r * xs + k0), b = *(const float4*)(x + r * xs + k0 + 4);
+            h[0] = (_Float16)a.x; h[1] = (_Float16)a.y; h[2] = (_Float16)a.z; h[3] = (_Float16)a.w;
+            h[4] = (_Float16)b.x; h[5] = (_Float16)b.y; h[6] = (_Float16)b.z; h[7] = (_Float16)b.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) h[j] = (_Float16)(k0 + j < K ? x[r * xs + k0 + j] : 0.f);
+        }
+        *(half8_t*)(dst + r * Kp + k0) = h;
+    }
+}
+void launch_pack_rows_f16(hipStream_t s, void* dst, const float* x, int64_t R, int64_t K, int64_t xs) {
+    const int Kp = (int)rup64(K, 64);
+    const int64_t n8 = R * (Kp / 8);
+    int64_t blocks   = (n8 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    k_pack_rows_f16<<<(unsigned)blocks, 256, 0, s>>>((_Float16*)dst, x, R, (int)K, Kp, xs);
+}
+
+// LayerNorm / RMSNorm (+affine) writing the f16 operand image: one wave per row
+__global__ __launch_bounds__(256) void k_layer_norm_f16(_Float16* __restrict__ dst, const float* __restrict__ x, int ne0, int Kp, int64_t nrows, int64_t xs,
+                                                        float eps, const float* __restrict__ w, const float* __restrict__ b, int rms) {
+    const int lane    = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= nrows) return;
+    const float* xr = x + row * xs;
+    _Float16* yr    = dst + row * Kp;
+    const int n4    = ne0 / 4;  // callers guarantee ne0 % 4 == 0 and 16-byte alignment
+    float mean = 0.f;
+    if (!rms) {
+        float s = 0.f;
+        for (int i = lane; i < n4; i += 64) {
+            const float4 v = ((const float4*)xr)[i];
+            s += (v.x + v.y) + (v.z + v.w);
+        }
+        mean = wave_sum(s) / (float)ne0;
+    }
+    float q = 0.f;
+    for (int i = lane; i < n4; i += 64) {
+        const float4 v = ((const float4*)xr)[i];
+        const float a = v.x - mean, bb = v.y - mean, c = v.z - mean, d = v.w - mean;
+        q += (a * a + bb * bb) + (c * c + d * d);
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)ne0 + eps);
+    for (int i = lane; i < Kp / 4; i += 64) {
+        half4_t h = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+        if (i < n4) {
+            float4 v = ((const float4*)xr)[i];
+            v.x = (v.x - mean) * rstd; v.y = (v.y - mean) * rstd; v.z = (v.z - mean) * rstd; v.w = (v.w - mean) * rstd;
+            if (w) { const float4 ww = ((const float4*)w)[i]; v.x *= ww.x; v.y *= ww.y; v.z *= ww.z; v.w *= ww.w; }
+            if (b) { const float4 bb = ((const float4*)b)[i]; v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w; }
+            h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
+        }
+        *(half4_t*)(yr + i * 4) = h;
+    }
+}
+void launch_layer_norm_f16(hipStream_t s, void* dst, const float* x, int64_t ne0, int64_t nrows, int64_t xs, float eps, const float* w, const float* b, bool rms) {
+    const int Kp = (int)rup64(ne0, 64);
+    k_layer_norm_f16<<<(unsigned)((nrows + 3) / 4), 256, 0, s>>>((_Float16*)dst, x, (int)ne0, Kp, nrows, xs, eps, w, b, rms ? 1 : 0);
+}
+
+// GEGLU writing the f16 operand image: dst[t][i] = x[t][i] * gelu(x[t][inner+i])
+__global__ void k_geglu_f16(_Float16* __restrict__ dst, const float* __restrict__ x, int64_t tokens, int inner, int Kp, int64_t xs) {
+    const int64_t n4 = tokens * (Kp / 4);
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t t = i / (Kp / 4);
+        const int c     = (int)(i - t * (Kp / 4)) * 4;
+        half4_t h = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+        if (c < inner) {
+            const float4 a = *(const float4*)(x + t * xs + c), gt = *(const float4*)(x + t * xs + inner + c);
+            h[0] = (_Float16)(a.x * act_apply<UN_GELU>(gt.x));
+            h[1] = (_Float16)(a.y * act_apply<UN_GELU>(gt.y));
+            h[2] = (_Float16)(a.z * act_apply<UN_GELU>(gt.z));
+            h[3] = (_Float16)(a.w * act_apply<UN_GELU>(gt.w));
+        }
+        *(half4_t*)(dst + t * Kp + c) = h;
+    }
+}
+void launch_geglu_f16(hipStream_t s, void* dst, const float* x, int64_t tokens, int64_t inner, int64_t xs) {
+    const int Kp = (int)rup64(inner, 64);
+    const int64_t n4 = tokens * (Kp / 4);
+    int64_t blocks   = (n4 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    k_geglu_f16<<<(unsigned)blocks, 256, 0, s>>>((_Float16*)dst, x, tokens, (int)inner, Kp, xs);
+}
+
+// GroupNorm statistics -> per-(image, channel) affine:  y = x * scale[n][c] + shift[n][c]
+template <int NT>
+__global__ __launch_bounds__(NT) void k_gn_stats(float* __restrict__ scale, float* __restrict__ shift, const float* __restrict__ x, int64_t hw, int C, int groups,
+                                                 int cpg, float eps, const float* __restrict__ w, const float* __restrict__ b) {
+    __shared__ float scratch[2 * (NT / 64)];
+    const int gidx = blockIdx.x % groups, n = blockIdx.x / groups;
+    const int c0 = gidx * cpg, c1 = min(c0 + cpg, C);
+    if (c0 >= c1) return;
+    const int64_t cnt = (int64_t)(c1 - c0) * hw;
+    const float* xs   = x + ((int64_t)n * C + c0) * hw;
+    const bool v4     = (hw % 4 == 0) && ((((uintptr_t)xs) & 15) == 0);
+    float s = 0.f, dummy = 0.f;
+    if (v4) {
+        for (int64_t i = threadIdx.x; i < cnt / 4; i += NT) {
+            const float4 v = ((const float4*)xs)[i];
+            s += (v.x + v.y) + (v.z + v.w);
+        }
+    } else {
+        for (int64_t i = threadIdx.x; i < cnt; i += NT) s += xs[i];
+    }
+    block_sum2<NT / 64>(s, dummy, scratch);
+    const float mean = s / (float)cnt;
+    float q = 0.f;
+    if (v4) {
+        for (int64_t i = threadIdx.x; i < cnt / 4; i += NT) {
+            const float4 v = ((const float4*)xs)[i];
+            const float a = v.x - mean, bb = v.y - mean, c = v.z - mean, d = v.w - mean;
+            q += (a * a + bb * bb) + (c * c + d * d);
+        }
+    } else {
+        for (int64_t i = threadIdx.x; i < cnt; i += NT) {
+            const float a = xs[i] - mean;
+            q += a * a;
+        }
+    }
+    dummy = 0.f;
+    block_sum2<NT / 64>(q, dummy, scratch);
+    const float rstd = rsqrtf(q / (float)cnt + eps);
+    for (int c = c0 + threadIdx.x; c < c1; c += NT) {
+        const float sc           = (w ? w[c] : 1.f) * rstd;
+        scale[(int64_t)n * C + c] = sc;
+        shift[(int64_t)n * C + c] = (b ? b[c] : 0.f) - mean * sc;
+    }
+}
+void launch_gn_stats(hipStream_t s, float* scale, float* shift, const float* x, int64_t hw, int64_t C, int64_t N, int groups, float eps, const float* w,
+                     const float* b) {
+    const int cpg = (int)((C + groups - 1) / groups);
+    if (cpg * hw >= 16384)
+        k_gn_stats<1024><<<(unsigned)(N * groups), 1024, 0, s>>>(scale, shift, x, hw, (int)C, groups, cpg, eps, w, b);
+    else
+        k_gn_stats<256><<<(unsigned)(N * groups), 256, 0, s>>>(scale, shift, x, hw, (int)C, groups, cpg, eps, w, b);
+}
+
+// f32 NCHW [hw][C][N] -> f16 NHWC [N][hw][Cp] with optional per-(n,c) affine (GroupNorm apply) and SiLU.
+// 64 channels x 64 positions per workgroup through an LDS transpose: coalesced 256-B reads along hw, 128-B writes along c.
+__global__ __launch_bounds__(256) void k_nchw_to_nhwc_f16(_Float16* __restrict__ dst, const float* __restrict__ x, int64_t hw, int C, int Cp,
+                                                          const float* __restrict__ scale, const float* __restrict__ shift, int silu) {
+    __shared__ float tile[64][65];
+    const int n  = blockIdx.z;
+    const int p0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const float* xn = x + (int64_t)n * C * hw;
+    for (int j = ty; j < 64; j += 4) {
+        const int c = c0 + j, p = p0 + tx;
+        float v = 0.f;
+        if (c < C && p < hw) {
+            v = xn[(int64_t)c * hw + p];
+            if (scale) v = v * scale[(int64_t)n * C + c] + shift[(int64_t)n * C + c];
+            if (silu) v = act_apply<UN_SILU>(v);
+        }
+        tile[j][tx] = v;
+    }
+    __syncthreads();
+    _Float16* dn = dst + (int64_t)n * hw * Cp;
+    for (int j = ty; j < 64; j += 4) {
+        const int p = p0 + j, c = c0 + tx;
+        if (p < hw && c < Cp) dn[(int64_t)p * Cp + c] = (_Float16)tile[tx][j];
+    }
+}
+void launch_nchw_to_nhwc_f16(hipStream_t s, void* dst, const float* x, int64_t hw, int64_t C, int64_t N, const float* scale, const float* shift, bool silu) {
+    const int Cp = (int)rup64(C, 64);
+    dim3 grid((unsigned)((hw + 63) / 64), (unsigned)(Cp / 64), (unsigned)N);
+    k_nchw_to_nhwc_f16<<<grid, 256, 0, s>>>((_Float16*)dst, x, hw, (int)C, Cp, scale, shift, silu ? 1 : 0);
+}
+
+}  // namespace mi355x

@@ -70,12 +70,40 @@ void launch_linear_mfma(hipStream_t s, float* dst, const float* x, const void* w
 void launch_conv2d_mfma(hipStream_t s, float* dst, const float* x, const void* wswz, int64_t W, int64_t H, int64_t IC, int64_t N,
                         int64_t OC, int ksize, int stride, int pad, bool upscale2x, const Epilogue& ep);
 
+// ---- gemm16.hip: second-generation contraction, both operands f16 via LDS-DMA -------------------------------
+// a16: f16 row-major [rows][lda] (K contiguous, padded to 64); output f32 [rows][ldd] and/or f16 [rows][ldd16]
+void gemm16_init();
+void gemm16_set_variant(int v);  // 0: BK64x2 stages, 1: BK32x3 stages (default), 2: BK64x3 stages
+// hm_d > 0: head-major store — element (row = n*hm_L + l, col = h*hm_d + dd) goes to ((n*hm_H + h)*hm_L + l)*hm_d + dd of dst (f32) / dst16 (f16)
+void launch_gemm16_linear(hipStream_t s, float* dst, void* dst16, int64_t ldd16, const void* a16, int64_t lda, const void* wswz, int64_t rows,
+                          int64_t K, int64_t M, int64_t ldd, const Epilogue& ep, int hm_d = 0, int hm_H = 0, int hm_L = 0);
+// x16: f16 NHWC [N][H][W][ICp]; dst f32 NCHW [OW,OH,OC,N]
+void launch_gemm16_conv(hipStream_t s, float* dst, const void* x16_nhwc, const void* wswz, int64_t W, int64_t H, int64_t IC, int64_t N, int64_t OC,
+                        int ksize, int stride, int pad, bool upscale2x, const Epilogue& ep);
+// producers of f16 operand images (row stride = K rounded up to 64, zero padded)
+void launch_pack_rows_f16(hipStream_t s, void* dst, const float* x, int64_t R, int64_t K, int64_t x_stride);
+void launch_layer_norm_f16(hipStream_t s, void* dst, const float* x, int64_t ne0, int64_t nrows, int64_t x_stride, float eps, const float* w,
+                           const float* b, bool rms);
+void launch_geglu_f16(hipStream_t s, void* dst, const float* x, int64_t tokens, int64_t inner, int64_t x_stride);
+void launch_gn_stats(hipStream_t s, float* scale, float* shift, const float* x, int64_t hw, int64_t C, int64_t N, int groups, float eps,
+                     const float* w, const float* b);
+void launch_nchw_to_nhwc_f16(hipStream_t s, void* dst, const float* x, int64_t hw, int64_t C, int64_t N, const float* scale, const float* shift,
+                             bool silu);
+
 // ---- flash_attn.hip ---------------------------------------------------------------------------------
 // q [D,Lq,HN] (f32, strides in bytes), k [D,Lk,HN], v [DV,Lk,HN] (f16 or f32; v may be a transposed view,
 // any nb[0]) -> dst f32 written with strides
 // (dst_nb_d=4 implied) dst element (d, q, hn) at dst + q*dst_nb_q + hn*dst_nb_h
 bool flash_attn_supported(int64_t D, int64_t DV);
-void launch_flash_attn(hipStream_t s, float* dst, int64_t dst_nb_q, int64_t dst_nb_h, const View4& q, const View4& k, const View4& v,
-                       float scale);
+// output: f32 element (d, q, hn) at dst + q*dst_nb_q + (hn % H)*dst_nb_h + (hn / H)*dst_nb_n   (H = 0: flat head index),
+// and/or f16 operand image dst16[(n*Lq + q)*ld16 + h*D + d] (the packed [tok][C] input of the to_out projection)
+struct FlashOut {
+    float* dst       = nullptr;
+    int64_t nb_q = 0, nb_h = 0, nb_n = 0;
+    int H            = 0;
+    void* dst16      = nullptr;
+    int64_t ld16     = 0;
+};
+void launch_flash_attn(hipStream_t s, const FlashOut& out, const View4& q, const View4& k, const View4& v, float scale);
 
 }  // namespace mi355x

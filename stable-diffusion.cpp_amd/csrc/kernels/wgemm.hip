@@ -32,7 +32,7 @@ enum { WT_F32 = 0, WT_F16 = 1, WT_Q4_0 = 2, WT_Q8_0 = 8, WT_BF16 = 30 };
 
 static inline int64_t rup(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 
-size_t wswz_bytes(int64_t R, int64_t K) { return (size_t)rup(R, 64) * (size_t)rup(K, 32) * 2; }
+size_t wswz_bytes(int64_t R, int64_t K) { return (size_t)rup(R, 128) * (size_t)rup(K, 64) * 2; }
 
 __device__ __forceinline__ float wload(const char* row, int type, int64_t k) {
     if (type == WT_F16) return __half2float(((const __half*)row)[k]);
@@ -69,7 +69,7 @@ __global__ void k_wswz_linear(half8_t* __restrict__ dst, const char* __restrict_
     dst[i] = v;
 }
 void launch_wswz_linear(hipStream_t s, void* dst, const void* src, int src_type, int64_t K, int64_t R, int64_t src_row_bytes) {
-    const int64_t Kp = rup(K, 32), Rp = rup(R, 64);
+    const int64_t Kp = rup(K, 64), Rp = rup(R, 128);
     const int64_t total = (Rp / 32) * (Kp / 16) * 64;
     k_wswz_linear<<<(unsigned)((total + 255) / 256), 256, 0, s>>>((half8_t*)dst, (const char*)src, src_type, K, R, src_row_bytes, Kp, total);
 }
@@ -99,7 +99,7 @@ __global__ void k_wswz_conv(half8_t* __restrict__ dst, const __half* __restrict_
     dst[i] = v;
 }
 void launch_wswz_conv(hipStream_t s, void* dst, const void* src, int64_t KW, int64_t KH, int64_t IC, int64_t OC) {
-    const int64_t ICp = rup(IC, 32), Kp = ICp * KW * KH, Rp = rup(OC, 64);
+    const int64_t ICp = rup(IC, 64), Kp = ICp * KW * KH, Rp = rup(OC, 128);
     const int64_t total = (Rp / 32) * (Kp / 16) * 64;
     k_wswz_conv<<<(unsigned)((total + 255) / 256), 256, 0, s>>>((half8_t*)dst, (const __half*)src, (int)KW, (int)KH, IC, OC, ICp, Kp, total);
 }
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void k_linear_mfma(float* __restrict__ dst, co
 void launch_linear_mfma(hipStream_t s, float* dst, const float* x, const void* wswz, int64_t tokens, int64_t K, int64_t M, int64_t x_stride,
                         int64_t d_stride, const Epilogue& e) {
     EpiDev ep{e.bias, e.residual, e.chan_add, e.scale, e.act};
-    const int64_t Kp = rup(K, 32);
+    const int64_t Kp = rup(K, 64);
     // pick the workgroup shape: wide-m tiles for wide outputs (activation tile re-read M/tile_m times),
     // tall-token tiles for narrow outputs.  All variants share the (128 tok x 64 m) wave tile.
     const int64_t mt64 = (M + 63) / 64;
@@ -377,7 +377,7 @@ void launch_conv2d_mfma(hipStream_t s, float* dst, const float* x, const void* w
     const int CW = upscale2x ? (int)W * 2 : (int)W, CH = upscale2x ? (int)H * 2 : (int)H;
     g.OW  = (CW + 2 * pad - ksize) / stride + 1;
     g.OH  = (CH + 2 * pad - ksize) / stride + 1;
-    g.ICp = (int)rup(IC, 32);
+    g.ICp = (int)rup(IC, 64);
     g.pad = pad;
     g.kfr = (int64_t)g.ICp * ksize * ksize / 16;
 

@@ -115,3 +115,14 @@ def test_generate_image_end_to_end(sd, oracle, eng15):
     assert img.std() > 1.0 and not np.array_equal(img[0], img[1])   # different seeds -> different images
     again = eng15.generate_image(cond, cond * 0.0, width=64, height=64, steps=2, cfg=7.0, seed=7, batch=2, device_batch=1)
     assert np.abs(img.astype(int) - again.astype(int)).max() <= 1     # device batching does not change the images
+
+
+def test_fused_cfg_pair_equals_two_computes(sd, oracle, eng15):
+    """cond+uncond in one N=2B graph (context batch 2 tiled by ggml_repeat) == two separate computes per step."""
+    rng = np.random.default_rng(6)
+    cond = rng.standard_normal((1, 77, 64)).astype(np.float32)
+    uncond = rng.standard_normal((1, 77, 64)).astype(np.float32)
+    kw = dict(width=64, height=64, steps=2, cfg=7.0, seed=5, batch=2, device_batch=2)
+    a = eng15.sample_latents(cond, uncond, fuse_cfg=False, **kw)
+    b = eng15.sample_latents(cond, uncond, fuse_cfg=True, **kw)
+    assert rel_l2(b, a) < 1e-5
