@@ -17,16 +17,17 @@
 // makes every ds_read_b128 of 16 consecutive rows hit 16 distinct 4-bank slots (cdna_hip_programming.md rule 21).
 // One __syncthreads per K-tile: the barrier's implicit vmcnt(0) retires this tile's DMA, the next tile's DMA is
 // issued right after it and overlaps the 32 MFMAs of the current tile; 2 workgroups per CU hide the rest.
+#include <cstdio>
+#include <cstdlib>
 #include "device_utils.h"
 #include "kernels.h"
 
 namespace mi355x {
 
-struct G16Epi {
+struct G16Epi {  // dst = acc * scale + bias (+ residual); the planner fuses no activation into these kernels
     const float* bias;
     const float* residual;
     float scale;
-    int act;
 };
 
 struct G16Args {
@@ -50,6 +51,147 @@ struct G16Args {
 
 #define GLDS16(gptr, ldsptr) \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr), (__attribute__((address_space(3))) void*)(ldsptr), 16, 0, 0)
+
+
+// =====================================================================================================
+// epilogue.  The accumulators of one 32x32 block live in 16 registers per lane.  The stores used to be one 64-way unrolled loop
+// with the activation switch and every optional pointer tested per element: ~16k instructions per kernel of which a wave
+// executed a sparse ~5 %, every step an instruction-cache miss (+50 us per workgroup, profiles/r01b).  Now the launch-/workgroup-
+// uniform case analysis happens ONCE and selects a compact straight-line variant: per element one v_fma and one global_store
+// with an SGPR base (uniform 64-bit tile pointer + register row) and a single 32-bit per-lane byte offset.
+// =====================================================================================================
+template <typename T>
+__device__ __forceinline__ void st_u(T* ubase, uint32_t lane_bytes, T v) { *(T*)((char*)ubase + lane_bytes) = v; }
+template <typename T>
+__device__ __forceinline__ T ld_u(const T* ubase, uint32_t lane_bytes) { return *(const T*)((const char*)ubase + lane_bytes); }
+
+enum { EPI_F32 = 0, EPI_F32_RES = 1, EPI_F16 = 2, EPI_HM_F32 = 3, EPI_HM_F16 = 4, EPI_GENERIC = 5 };
+
+// linear (D[row][col]): register r holds row ro(r) + 4*hi of the block, lanes run along columns.  Fast variants need a full row tile.
+template <int MODE, int RB, int CB>
+__device__ __forceinline__ void epi_linear(const float16_t (&acc)[RB][CB], const G16Args& g, int64_t row0, int col0, int wr, int wc, int lane) {
+    const int hi = lane >> 5, lc = lane & 31;
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        const int64_t base_row = row0 + wr * (RB * 32) + rb * 32;  // wave-uniform
+        if (MODE == EPI_GENERIC && base_row >= g.R) continue;
+        uint32_t hm_n0 = 0, hm_l0 = 0;
+        if (MODE == EPI_HM_F32 || MODE == EPI_HM_F16) {
+            hm_n0 = (uint32_t)base_row / (uint32_t)g.hm_L;
+            hm_l0 = (uint32_t)base_row - hm_n0 * (uint32_t)g.hm_L;
+        }
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+            const int cblk = col0 + (wc * CB + cb) * 32;
+            const int col  = cblk + lc;
+            if (col >= g.C) continue;
+            const float bias = g.ep.bias ? g.ep.bias[col] : 0.f;
+            if (MODE == EPI_F32 || MODE == EPI_F32_RES) {
+                float* ub         = g.dst + base_row * g.ldd + cblk;
+                const float* ur   = MODE == EPI_F32_RES ? g.ep.residual + base_row * g.ldd + cblk : nullptr;
+                const uint32_t lb = (uint32_t)(lc + 4 * hi * (int)g.ldd) * 4u;
+                // all residual loads are issued before the first store (dst may BE the residual: the loads cannot be hoisted by the compiler)
+#pragma unroll
+                for (int r0 = 0; r0 < 16; r0 += 8) {
+                    float rv[8];
+#pragma unroll
+                    for (int r = r0; r < r0 + 8; ++r) rv[r - r0] = MODE == EPI_F32_RES ? ld_u(ur + (int64_t)((r & 3) + 8 * (r >> 2)) * g.ldd, lb) : 0.f;
+#pragma unroll
+                    for (int r = r0; r < r0 + 8; ++r)
+                        st_u(ub + (int64_t)((r & 3) + 8 * (r >> 2)) * g.ldd, lb, acc[rb][cb][r] * g.ep.scale + bias + rv[r - r0]);
+                }
+            } else if (MODE == EPI_F16) {
+                _Float16* ub      = g.dst16 + base_row * g.ldd16 + cblk;
+                const uint32_t lb = (uint32_t)(lc + 4 * hi * (int)g.ldd16) * 2u;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st_u(ub + (int64_t)((r & 3) + 8 * (r >> 2)) * g.ldd16, lb, (_Float16)(acc[rb][cb][r] * g.ep.scale + bias));
+            } else if (MODE == EPI_HM_F32 || MODE == EPI_HM_F16) {
+                // attention operand layout [d, L, H, N] — what CONT(permute(0,2,1,3)) (+CPY f16) of the projection would hold:
+                // element (row = n*L + l, col = h*d + dd) -> n*(H*L*d) + h*(L*d) + l*d + dd.  hm_L % 32 == 0: a block stays in one image.
+                const int64_t Ld  = (int64_t)g.hm_L * g.hm_d;
+                const int64_t ub  = (int64_t)hm_n0 * Ld * g.hm_H + (int64_t)hm_l0 * g.hm_d;  // uniform
+                const uint32_t h  = (uint32_t)col / (uint32_t)g.hm_d, dd = (uint32_t)col - h * (uint32_t)g.hm_d;
+                const uint32_t le = h * (uint32_t)Ld + dd + 4u * hi * (uint32_t)g.hm_d;  // per-lane elements (< one image of the operand)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t ro = ub + (int64_t)((r & 3) + 8 * (r >> 2)) * g.hm_d;
+                    const float v    = acc[rb][cb][r] * g.ep.scale + bias;
+                    if (MODE == EPI_HM_F32)
+                        st_u(g.dst + ro, le * 4u, v);
+                    else
+                        st_u(g.dst16 + ro, le * 2u, (_Float16)v);
+                }
+            } else {
+                // everything else (ragged last row tile, f32+f16 double output, head-major with L % 32 != 0)
+                const int64_t Ld = (int64_t)g.hm_L * g.hm_d, HLd = Ld * g.hm_H;
+                const int64_t n0 = g.hm_d > 0 ? base_row / g.hm_L : 0;
+                const int l0     = g.hm_d > 0 ? (int)(base_row - n0 * g.hm_L) : 0;
+                const int h = g.hm_d > 0 ? col / g.hm_d : 0, dd = g.hm_d > 0 ? col - h * g.hm_d : 0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int o       = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    const int64_t row = base_row + o;
+                    if (row >= g.R) continue;
+                    float v = acc[rb][cb][r] * g.ep.scale + bias;
+                    int64_t idx = row * g.ldd + col, idx16 = row * g.ldd16 + col;
+                    if (g.hm_d > 0) {
+                        const int q = (l0 + o) / g.hm_L, l = (l0 + o) - q * g.hm_L;
+                        idx = idx16 = (n0 + q) * HLd + (int64_t)h * Ld + (int64_t)l * g.hm_d + dd;
+                    }
+                    if (g.ep.residual) v += g.ep.residual[idx];
+                    if (g.dst) g.dst[idx] = v;
+                    if (g.dst16) g.dst16[idx16] = (_Float16)v;
+                }
+            }
+        }
+    }
+}
+
+// conv (D[oc][pos]): register r holds output channel ro(r) + 4*hi of the block, lanes run along output positions.
+// MODE 0: bias only, 1: + residual, 2: generic (ragged channel block)
+template <int MODE, int RB, int CB>
+__device__ __forceinline__ void epi_conv(const float16_t (&acc)[RB][CB], const G16Args& g, int64_t row0, int col0, int wr, int wc, int lane) {
+    const int hi = lane >> 5, lc = lane & 31;
+    const uint32_t ohow = (uint32_t)g.OHOW;
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        const int64_t pos_base = row0 + wr * (RB * 32) + rb * 32;  // wave-uniform
+        if (pos_base >= g.R) continue;
+        const uint32_t img0 = (uint32_t)pos_base / ohow, p0 = (uint32_t)pos_base - img0 * ohow;
+        uint32_t pl = p0 + lc, dimg = 0;
+        while (pl >= ohow) {  // a 32-position block may straddle images when OH*OW % 32 != 0
+            pl -= ohow;
+            ++dimg;
+        }
+        if (pos_base + lc >= g.R) continue;
+        const uint32_t le = dimg * (uint32_t)g.C * ohow + pl + 4u * hi * ohow;  // per-lane elements relative to (img0, cblk)
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+            const int cblk = col0 + (wc * CB + cb) * 32;
+            if (cblk >= g.C) continue;
+            const int64_t ub = ((int64_t)img0 * g.C + cblk) * g.OHOW;  // uniform
+            const float* pb  = g.ep.bias ? g.ep.bias + cblk : nullptr;
+            // loads first (bias, residual), then the stores: dst may BE the residual, so the compiler cannot batch them itself
+#pragma unroll
+            for (int r0 = 0; r0 < 16; r0 += 8) {
+                float bv[8], rv[8];
+#pragma unroll
+                for (int r = r0; r < r0 + 8; ++r) {
+                    const int ro  = (r & 3) + 8 * (r >> 2);
+                    const bool ok = MODE != 2 || cblk + ro + 4 * hi < g.C;
+                    bv[r - r0]    = (pb && ok) ? ld_u(pb + ro, 16u * hi) : 0.f;
+                    rv[r - r0]    = ((MODE == 1 || (MODE == 2 && g.ep.residual)) && ok) ? ld_u(g.ep.residual + ub + (int64_t)ro * g.OHOW, le * 4u) : 0.f;
+                }
+#pragma unroll
+                for (int r = r0; r < r0 + 8; ++r) {
+                    const int ro = (r & 3) + 8 * (r >> 2);
+                    if (MODE == 2 && cblk + ro + 4 * hi >= g.C) continue;
+                    st_u(g.dst + ub + (int64_t)ro * g.OHOW, le * 4u, acc[rb][cb][r] * g.ep.scale + bv[r - r0] + rv[r - r0]);
+                }
+            }
+        }
+    }
+}
 
 template <int BN, bool CONV, int BK, int NST, int NW>
 __global__ __launch_bounds__(NW * 64, 2) void k_gemm16(G16Args g) {
@@ -228,85 +370,34 @@ __global__ __launch_bounds__(NW * 64, 2) void k_gemm16(G16Args g) {
         }
     }
 
-    // ---- epilogue
+    // ---- epilogue: one compact variant per workgroup (all conditions are launch- or workgroup-uniform)
     if (!CONV) {
-        if (g.hm_d > 0) {
-            // attention operand layout [d, L, H, N]: the q/k/v projections write what CONT(permute(0,2,1,3)) (+CPY f16) would:
-            // element (row = n*L + l, col = h*d + dd) -> n*(H*L*d) + h*(L*d) + l*d + dd.  All divisions are hoisted: per column
-            // block (lane-constant) and per 32-row block (wave-uniform); rows inside a block advance by carry.
-            const int64_t Ld = (int64_t)g.hm_L * g.hm_d, HLd = Ld * g.hm_H;
-#pragma unroll
-            for (int rb = 0; rb < RB; ++rb) {
-                const int64_t base_row = row0 + wr * (RB * 32) + rb * 32;
-                const int64_t n0       = base_row / g.hm_L;
-                const int l0           = (int)(base_row - n0 * g.hm_L);
-#pragma unroll
-                for (int cb = 0; cb < CB; ++cb) {
-                    const int col = col0 + (wc * CB + cb) * 32 + (lane & 31);
-                    if (col >= g.C) continue;
-                    const int h = col / g.hm_d, dd = col - h * g.hm_d;
-                    const int64_t colpart = (int64_t)h * Ld + dd;
-                    const float bias      = g.ep.bias ? g.ep.bias[col] : 0.f;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int o = (r & 3) + 8 * (r >> 2) + 4 * hi;
-                        if (base_row + o >= g.R) continue;
-                        int l     = l0 + o;
-                        int64_t n = n0;
-                        while (l >= g.hm_L) {
-                            l -= g.hm_L;
-                            ++n;
-                        }
-                        const int64_t idx = n * HLd + (int64_t)l * g.hm_d + colpart;
-                        const float v     = acc[rb][cb][r] * g.ep.scale + bias;
-                        if (g.dst) g.dst[idx] = v;
-                        if (g.dst16) g.dst16[idx] = (_Float16)v;
-                    }
-                }
-            }
-            return;
-        }
-#pragma unroll
-        for (int cb = 0; cb < CB; ++cb) {
-            const int col = col0 + (wc * CB + cb) * 32 + (lane & 31);
-            if (col >= g.C) continue;
-            const float bias = g.ep.bias ? g.ep.bias[col] : 0.f;
-#pragma unroll
-            for (int rb = 0; rb < RB; ++rb) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int64_t row = row0 + wr * (RB * 32) + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (row < g.R) {
-                        float v = acc[rb][cb][r] * g.ep.scale + bias;
-                        if (g.ep.residual) v += g.ep.residual[row * g.ldd + col];
-                        if (g.ep.act >= 0) v = act_dyn(g.ep.act, v);
-                        if (g.dst) g.dst[row * g.ldd + col] = v;
-                        if (g.dst16) g.dst16[row * g.ldd16 + col] = (_Float16)v;
-                    }
-                }
-            }
+        const bool full  = row0 + BM <= g.R;
+        const bool plain = full;
+        if (plain && g.hm_d > 0 && (g.hm_L & 31) == 0 && !g.ep.residual && (g.dst != nullptr) != (g.dst16 != nullptr)) {
+            if (g.dst16)
+                epi_linear<EPI_HM_F16>(acc, g, row0, col0, wr, wc, lane);
+            else
+                epi_linear<EPI_HM_F32>(acc, g, row0, col0, wr, wc, lane);
+        } else if (plain && g.hm_d == 0 && g.dst && !g.dst16) {
+            if (g.ep.residual)
+                epi_linear<EPI_F32_RES>(acc, g, row0, col0, wr, wc, lane);
+            else
+                epi_linear<EPI_F32>(acc, g, row0, col0, wr, wc, lane);
+        } else if (plain && g.hm_d == 0 && g.dst16 && !g.dst && !g.ep.residual) {
+            epi_linear<EPI_F16>(acc, g, row0, col0, wr, wc, lane);
+        } else {
+            epi_linear<EPI_GENERIC>(acc, g, row0, col0, wr, wc, lane);
         }
     } else {
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb) {
-            const int64_t pos = row0 + wr * (RB * 32) + rb * 32 + (lane & 31);
-            if (pos >= g.R) continue;
-            const int64_t img = pos / g.OHOW, p = pos - img * g.OHOW;
-#pragma unroll
-            for (int cb = 0; cb < CB; ++cb) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int oc = col0 + (wc * CB + cb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (oc < g.C) {
-                        const int64_t o = (img * g.C + oc) * g.OHOW + p;
-                        float v         = acc[rb][cb][r] * g.ep.scale;
-                        if (g.ep.bias) v += g.ep.bias[oc];
-                        if (g.ep.residual) v += g.ep.residual[o];
-                        if (g.ep.act >= 0) v = act_dyn(g.ep.act, v);
-                        g.dst[o] = v;
-                    }
-                }
-            }
+        const bool fullc = col0 + BN <= g.C;
+        if (fullc) {
+            if (g.ep.residual)
+                epi_conv<1>(acc, g, row0, col0, wr, wc, lane);
+            else
+                epi_conv<0>(acc, g, row0, col0, wr, wc, lane);
+        } else {
+            epi_conv<2>(acc, g, row0, col0, wr, wc, lane);
         }
     }
 }
@@ -355,6 +446,13 @@ static const _Float16* zero_page() {
 
 void gemm16_init() { (void)zero_page(); }
 
+static void g16_check_epi(const Epilogue& e) {
+    if (e.act >= 0) {
+        fprintf(stderr, "ggml-mi355x: gemm16 kernels have no fused activation (act=%d requested)\n", e.act);
+        abort();
+    }
+}
+
 void launch_gemm16_linear(hipStream_t s, float* dst, void* dst16, int64_t ldd16, const void* a16, int64_t lda, const void* wswz, int64_t rows, int64_t K,
                           int64_t M, int64_t ldd, const Epilogue& e, int hm_d, int hm_H, int hm_L) {
     G16Args g{};
@@ -373,7 +471,8 @@ void launch_gemm16_linear(hipStream_t s, float* dst, void* dst16, int64_t ldd16,
     g.R     = rows;
     g.C     = M;
     g.nt    = (int)(Kp / (g16_bk32() ? 32 : 64));
-    g.ep    = {e.bias, e.residual, e.scale, e.act};
+    g16_check_epi(e);
+    g.ep    = {e.bias, e.residual, e.scale};
     // narrow outputs (M = 320: 2.5 tiles of 128) waste less with 64-wide column tiles
     const bool bn64 = M <= 64;
     if (bn64) {
@@ -408,7 +507,8 @@ void launch_gemm16_conv(hipStream_t s, float* dst, const void* x16_nhwc, const v
     g.R    = g.OHOW * N;
     g.C    = OC;
     g.zero = zero_page();
-    g.ep   = {e.bias, e.residual, e.scale, e.act};
+    g16_check_epi(e);
+    g.ep   = {e.bias, e.residual, e.scale};
     const bool bn64 = OC <= 64;
     if (bn64) {
         g.ncol_tiles = (int)((OC + 63) / 64);
