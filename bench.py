@@ -12,8 +12,11 @@ progress meter counts as one "it" (src/stable-diffusion.cpp:2470-2482).  Workloa
 collective => weak scaling: per-GPU batch fixed.
 
 The JSON line also carries
-  roofline:     achieved TFLOP/s of the dominant kernel (implicit-GEMM conv) from HIP-event timing of the UNet forwards
-                vs the dense f16 MFMA peak (2.5 PFLOP/s, MI355X_MICROARCH.md)
+  roofline:     the dominant kernel (k_gemm16<128,true,32,3,8>, the 256x128-tile implicit-GEMM conv): achieved = sum of the
+                launches' algorithmic FLOPs (2 * output positions * IC*KH*KW * OC) / sum of their durations, measured live with
+                HIP events recorded on the backend's launch stream around every dispatch inside the timed region, vs the dense
+                f16 MFMA peak (2.5 PFLOP/s, MI355X_MICROARCH.md).  traffic = HBM bytes per launch from the rocprofv3 PMC passes
+                committed under profiles/ (FETCH_SIZE doubled per the guide's gfx950 correction + WRITE_SIZE), or null.
   cpu_baseline: the CPU oracle (restatement of the reference ggml-cpu path) timed on this box's host cores on a bounded
                 sample of the same workload (rank 0, N = 1 only).
 """
@@ -79,15 +82,9 @@ def main():
     backend_name = f"MI355X{local_rank if local_rank < len([d for d in sd.devices() if d.startswith('MI355X')]) else 0}"
     eng = sd.Engine(model=model_id, backend=backend_name, wtype=sd.Q8_0 if args.model == "sdxl" else sd.F16,
                     flash_attn=not args.no_flash)
-    set_opt = None
-    try:
-        blib = C.CDLL(str(sd.BACKEND_LIB))
-        blib.ggml_backend_mi355x_set_option.argtypes = [C.c_char_p, C.c_int]
-        blib.ggml_backend_mi355x_set_option(b"hip_graph", args.hip_graph)
-        if args.g16_variant >= 0:
-            blib.ggml_backend_mi355x_set_option(b"gemm16_variant", args.g16_variant)
-    except OSError:
-        blib = None
+    sd.backend_set_option("hip_graph", args.hip_graph)
+    if args.g16_variant >= 0:
+        sd.backend_set_option("gemm16_variant", args.g16_variant)
 
     rng = np.random.default_rng(1234 + rank)
     tiny = args.model == "sd15_tiny"
@@ -124,11 +121,17 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    timing = args.hip_graph == 0  # events cannot be recorded inside a captured graph replay
+    if timing:
+        sd.kernel_timing_enable(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     dt = time.perf_counter() - t0
+    kt = sd.kernel_timing() if timing else None
+    if timing:
+        sd.kernel_timing_enable(False)
     if world > 1:
         tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -137,7 +140,24 @@ def main():
     its = B * world * args.steps / dt
 
     fwd_tflop = UNET_FWD_TFLOP.get(args.model, 0.0)
-    achieved = (2 * B * fwd_tflop) / (ms_per_step / 1e3) if fwd_tflop else 0.0
+    step_tflops = (2 * B * fwd_tflop) / (ms_per_step / 1e3) if fwd_tflop else 0.0
+    roofline = {"bound": "mfma", "achieved": None, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None}
+    if kt and kt["launches"] > 0 and kt["total_ms"] > 0:
+        achieved = kt["total_flops"] / (kt["total_ms"] * 1e-3) / 1e12
+        roofline.update({"achieved": round(achieved, 2), "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "kernel": kt["kernel"],
+                         "launches": kt["launches"], "avg_launch_us": round(kt["total_ms"] * 1e3 / kt["launches"], 2),
+                         "avg_launch_gflop": round(kt["total_flops"] / kt["launches"] / 1e9, 2),
+                         "share_of_step_time": round(kt["total_ms"] / (dt * 1e3), 4),
+                         "timing": "hipEventElapsedTime around each launch on the launch stream, inside the timed region"})
+        tf = ROOT / "profiles" / "r01_pmc_traffic.json"
+        if tf.exists() and args.model == "sd15" and B == 8 and fuse:
+            try:
+                pm = json.loads(tf.read_text())
+                roofline["traffic"] = pm["hbm_bytes_per_launch"]
+                roofline["traffic_source"] = pm.get("source", "profiles/r01_pmc_traffic.json")
+            except (ValueError, KeyError):
+                pass
+    roofline["whole_step_tflops"] = round(step_tflops, 2)  # all kernels + host graph build + H2D/D2H: 2*B*UNet-forward FLOPs / step wall time
     out = {
         "metric": "denoise it/s (image-iterations/s: cond+uncond UNet forwards per image per step)",
         "value": round(its, 3),
@@ -154,9 +174,7 @@ def main():
         "config": {"workload": f"{args.model} UNet {lat*8}x{lat*8}, cfg 7 (cond+uncond), f16 weights, batch {B}/GPU, Euler-A step",
                    "global_batch": B * world, "flash_attn": not args.no_flash, "hip_graph": args.hip_graph,
                    "cfg_pair_in_one_graph": fuse},
-        "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                     "note": "whole UNet step (algorithmic 2*B*%.3f TFLOP per step / wall step time incl. host graph build + H2D/D2H)" % fwd_tflop},
+        "roofline": roofline,
     }
     if args.e2e and rank == 0:
         t0 = time.perf_counter()

@@ -63,9 +63,22 @@ struct ggml_backend_mi355x_stats {
     int64_t generic_matmul;      /* MUL_MAT on the generic exact-f32 path */
     int64_t swizzled_weight_bytes;
     int64_t graph_replays;       /* hipGraph replays (when graph capture is enabled) */
+    int64_t fused_linear_geglu;  /* FF1 GEMM + GEGLU in one kernel (the [tokens][2*inner] tensor is never written) */
+    int64_t split_k_gemms;       /* gemm16 contractions planned with a split-K workspace */
+    int64_t head_major_gemms;    /* q/k/v projections that store the attention operand layout directly */
 };
 GGML_MI355X_API void ggml_backend_mi355x_get_stats(struct ggml_backend_mi355x_stats* out);
-/* options: "fusion" (1), "mfma_gemm" (1), "hip_graph" (0/1), "flash_pattern" (1) */
+/* live timing of the dominant kernel (bench.py's roofline leg): HIP events on the launch stream around every dispatch of
+ * that kernel while enabled; get_ synchronises the device, returns the totals since enable / the last get_, and resets. */
+struct ggml_backend_mi355x_kernel_timing {
+    char kernel[96];     /* kernel the events bracket */
+    int64_t launches;
+    double total_ms;     /* sum of hipEventElapsedTime over the launches */
+    double total_flops;  /* sum of the launches' algorithmic FLOPs (2 * positions * IC*KH*KW * OC) */
+};
+GGML_MI355X_API void ggml_backend_mi355x_kernel_timing_enable(int enable);
+GGML_MI355X_API void ggml_backend_mi355x_get_kernel_timing(struct ggml_backend_mi355x_kernel_timing* out);
+/* options: "fusion" (1), "mfma_gemm" (1), "hip_graph" (0/1), "flash_pattern" (1), "gemm16" (1), "gemm16_variant" (3) */
 GGML_MI355X_API void ggml_backend_mi355x_set_option(const char* key, int value);
 
 #ifdef __cplusplus

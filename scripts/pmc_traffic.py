@@ -1,0 +1,35 @@
+#!/usr/bin/env python
+"""HBM traffic per launch of the dominant kernel from two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE cannot share a pass:
+MI355X_MICROARCH.md 'rocprofv3 PMC slots').  Units/corrections per that guide's HBM section: the counters are reported in KiB-like
+units of 1024 B (rocprofv3 FETCH_SIZE/WRITE_SIZE = request count * 64 B / 1024), and on gfx950 FETCH_SIZE tallies the 128-B
+requests of wide coalesced streaming reads (16 B/lane, global_load and LDS-DMA alike — exactly this kernel's loads) at 64 B, so it
+is DOUBLED; WRITE_SIZE is uncalibrated and reported as is.
+usage: pmc_traffic.py <fetch.db> <write.db> <kernel substring> <out.json>"""
+import json
+import sqlite3
+import sys
+
+
+def per_launch(db, counter, pat):
+    con = sqlite3.connect(db)
+    rows = list(con.execute("select dispatch_id, sum(counter_value) from pmc_events where counter_name = ? and name like ? group by dispatch_id", (counter, f"%{pat}%")))
+    vals = [v for _, v in rows]
+    return (sum(vals) / len(vals) if vals else None), len(vals)
+
+
+fetch_db, write_db, pat, out = sys.argv[1:5]
+f, nf = per_launch(fetch_db, "FETCH_SIZE", pat)
+w, nw = per_launch(write_db, "WRITE_SIZE", pat)
+res = {
+    "kernel": pat,
+    "launches_fetch_pass": nf,
+    "launches_write_pass": nw,
+    "fetch_size_raw_per_launch": f,
+    "write_size_raw_per_launch": w,
+    "fetch_bytes_per_launch": None if f is None else f * 1024 * 2,
+    "write_bytes_per_launch": None if w is None else w * 1024,
+    "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on bench.py --steps 2 --warmup 1; FETCH_SIZE doubled (gfx950 wide-read correction), units of 1024 B",
+}
+res["hbm_bytes_per_launch"] = None if f is None or w is None else round(res["fetch_bytes_per_launch"] + res["write_bytes_per_launch"])
+json.dump(res, open(out, "w"), indent=1)
+print(json.dumps(res, indent=1))

@@ -268,6 +268,60 @@ def load_mi355x_backend() -> None:
         raise EngineError(f"libggml-mi355x.so loaded but exposes no MI355X device (devices: {names}); is a gfx950 GPU visible?")
 
 
+_BACKEND_STAT_FIELDS = ("graphs_computed plans_built nodes_seen kernels_planned kernels_launched fused_conv fused_conv_bounced fused_linear "
+                        "fused_norm fused_geglu fused_attention generic_matmul swizzled_weight_bytes graph_replays fused_linear_geglu "
+                        "split_k_gemms head_major_gemms").split()
+
+
+class BackendStats(C.Structure):
+    """struct ggml_backend_mi355x_stats (include/ggml-mi355x.h)"""
+    _fields_ = [(n, C.c_int64) for n in _BACKEND_STAT_FIELDS]
+
+
+_backend_cdll = None
+
+
+def _backend() -> C.CDLL:
+    global _backend_cdll
+    if _backend_cdll is None:
+        load_mi355x_backend()
+        _backend_cdll = C.CDLL(str(BACKEND_LIB))  # same handle the plug-in loader dlopen()ed
+        _backend_cdll.ggml_backend_mi355x_get_stats.argtypes = [C.POINTER(BackendStats)]
+        _backend_cdll.ggml_backend_mi355x_set_option.argtypes = [C.c_char_p, C.c_int]
+    return _backend_cdll
+
+
+def backend_stats() -> dict:
+    """Process-wide planner counters of the MI355X backend (plans built, fusions taken, kernels launched)."""
+    st = BackendStats()
+    _backend().ggml_backend_mi355x_get_stats(C.byref(st))
+    return {n: int(getattr(st, n)) for n in _BACKEND_STAT_FIELDS}
+
+
+class KernelTiming(C.Structure):
+    """struct ggml_backend_mi355x_kernel_timing (include/ggml-mi355x.h)"""
+    _fields_ = [("kernel", C.c_char * 96), ("launches", C.c_int64), ("total_ms", C.c_double), ("total_flops", C.c_double)]
+
+
+def kernel_timing_enable(on: bool) -> None:
+    """HIP events on the launch stream around every dispatch of the dominant kernel (resets the accumulators)."""
+    _backend().ggml_backend_mi355x_kernel_timing_enable(1 if on else 0)
+
+
+def kernel_timing() -> dict:
+    """Totals since enable / the previous call (synchronises the device and resets)."""
+    kt = KernelTiming()
+    b = _backend()
+    b.ggml_backend_mi355x_get_kernel_timing.argtypes = [C.POINTER(KernelTiming)]
+    b.ggml_backend_mi355x_get_kernel_timing(C.byref(kt))
+    return {"kernel": kt.kernel.decode(), "launches": int(kt.launches), "total_ms": float(kt.total_ms), "total_flops": float(kt.total_flops)}
+
+
+def backend_set_option(key: str, value: int) -> None:
+    """ggml_backend_mi355x_set_option: fusion / mfma_gemm / hip_graph / flash_pattern / gemm16 / gemm16_variant"""
+    _backend().ggml_backend_mi355x_set_option(key.encode(), int(value))
+
+
 def devices() -> list[str]:
     L = lib()
     return [L.sd_device_name(i).decode() for i in range(L.sd_device_count())]

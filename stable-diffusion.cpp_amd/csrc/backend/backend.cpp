@@ -23,6 +23,12 @@
 #include "ggml-mi355x.h"
 #include "planner.h"
 
+namespace mi355x {  // kernels/gemm16.hip
+void gemm16_timing_enable(bool on);
+void gemm16_timing_read(int64_t* launches, double* ms, double* flops);
+const char* gemm16_timing_kernel_name();
+}  // namespace mi355x
+
 namespace mi355x {
 
 #define HIP_OK(expr)                                                                                          \
@@ -214,6 +220,8 @@ static void* reg_get_proc(ggml_backend_reg_t, const char* name) {
     // (ggml_extend_backend.cpp:801-804, 440-446, 519-528).  Ours: planner statistics for tests / bench.
     if (strcmp(name, "ggml_backend_mi355x_get_stats") == 0) return (void*)ggml_backend_mi355x_get_stats;
     if (strcmp(name, "ggml_backend_mi355x_set_option") == 0) return (void*)ggml_backend_mi355x_set_option;
+    if (strcmp(name, "ggml_backend_mi355x_kernel_timing_enable") == 0) return (void*)ggml_backend_mi355x_kernel_timing_enable;
+    if (strcmp(name, "ggml_backend_mi355x_get_kernel_timing") == 0) return (void*)ggml_backend_mi355x_get_kernel_timing;
     return nullptr;
 }
 
@@ -288,4 +296,10 @@ GGML_MI355X_API int ggml_backend_mi355x_get_device_count(void) {
 }
 GGML_MI355X_API void ggml_backend_mi355x_get_stats(struct ggml_backend_mi355x_stats* out) { mi355x::planner_get_stats(out); }
 GGML_MI355X_API void ggml_backend_mi355x_set_option(const char* key, int value) { mi355x::planner_set_option(key, value); }
+GGML_MI355X_API void ggml_backend_mi355x_kernel_timing_enable(int enable) { mi355x::gemm16_timing_enable(enable != 0); }
+GGML_MI355X_API void ggml_backend_mi355x_get_kernel_timing(struct ggml_backend_mi355x_kernel_timing* out) {
+    memset(out, 0, sizeof(*out));
+    snprintf(out->kernel, sizeof(out->kernel), "%s", mi355x::gemm16_timing_kernel_name());
+    mi355x::gemm16_timing_read(&out->launches, &out->total_ms, &out->total_flops);
+}
 }

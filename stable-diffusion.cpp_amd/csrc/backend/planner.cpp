@@ -38,7 +38,7 @@ namespace {
 
 struct Stats {
     std::atomic<int64_t> graphs_computed{0}, plans_built{0}, nodes_seen{0}, kernels_planned{0}, kernels_launched{0}, fused_conv{0},
-        fused_conv_bounced{0}, fused_linear{0}, fused_norm{0}, fused_geglu{0}, fused_attention{0}, generic_matmul{0}, swizzled_weight_bytes{0},
+        fused_conv_bounced{0}, fused_linear{0}, fused_norm{0}, fused_geglu{0}, fused_attention{0}, generic_matmul{0}, swizzled_weight_bytes{0}, fused_linear_geglu{0}, split_k_gemms{0}, head_major_gemms{0},
         graph_replays{0};
 } g_stats;
 
@@ -211,21 +211,22 @@ inline const ggml_tensor* strip_reshape(const ggml_tensor* t) {
 // ---------------------------------------------------------------------------------------------------
 // swizzled weights
 // ---------------------------------------------------------------------------------------------------
-const void* get_swz_linear(Planner* P, const ggml_tensor* w, hipStream_t s) {
-    uint64_t key = fnv(fnv(1469598103934665603ull, &w->data, sizeof(w->data)), "L", 1);
+const void* get_swz_linear(Planner* P, const ggml_tensor* w, hipStream_t s, bool geglu_pairs = false) {
+    uint64_t key = fnv(fnv(1469598103934665603ull, &w->data, sizeof(w->data)), geglu_pairs ? "G" : "L", 1);
     auto it      = P->swz.find(key);
     if (it != P->swz.end()) return it->second.swz;
     const int64_t K = w->ne[0], R = w->ne[1];
     const size_t bytes = wswz_bytes(R, K);
     void* d            = nullptr;
     if (hipMalloc(&d, bytes) != hipSuccess) return nullptr;
-    launch_wswz_linear(s, d, w->data, (int)w->type, K, R, (int64_t)w->nb[1]);
+    launch_wswz_linear(s, d, w->data, (int)w->type, K, R, (int64_t)w->nb[1], geglu_pairs ? R / 2 : 0);
     P->swz[key] = {d, bytes, w->data, ggml_abi_nbytes(w)};
     g_stats.swizzled_weight_bytes += (int64_t)bytes;
     return d;
 }
 const void* get_swz_conv(Planner* P, const ggml_tensor* w, hipStream_t s) {
-    uint64_t key = fnv(fnv(1469598103934665603ull, &w->data, sizeof(w->data)), "C", 1);
+    const bool icb_major = g_opt.gemm16 != 0 && !gemm16_tap_major();
+    uint64_t key = fnv(fnv(1469598103934665603ull, &w->data, sizeof(w->data)), icb_major ? "D" : "C", 1);
     auto it      = P->swz.find(key);
     if (it != P->swz.end()) return it->second.swz;
     const int64_t KW = w->ne[0], KH = w->ne[1], IC = w->ne[2], OC = w->ne[3];
@@ -233,7 +234,7 @@ const void* get_swz_conv(Planner* P, const ggml_tensor* w, hipStream_t s) {
     const size_t bytes = wswz_bytes(OC, ICp * KW * KH);
     void* d            = nullptr;
     if (hipMalloc(&d, bytes) != hipSuccess) return nullptr;
-    launch_wswz_conv(s, d, w->data, KW, KH, IC, OC);
+    launch_wswz_conv(s, d, w->data, KW, KH, IC, OC, icb_major);
     P->swz[key] = {d, bytes, w->data, ggml_abi_nbytes(w)};
     g_stats.swizzled_weight_bytes += (int64_t)bytes;
     return d;
@@ -343,7 +344,8 @@ void plan_linear(Builder& B, int i, hipStream_t s, std::vector<int>& chain) {
             const ggml_tensor* r4 = gi.node(j1);
             const int32_t* ax    = gi.node(j2)->op_params;
             const int64_t d = r4->ne[0], H = r4->ne[1], L = r4->ne[2], Nimg = r4->ne[3];
-            if (ax[0] == 0 && ax[1] == 2 && ax[2] == 1 && ax[3] == 3 && d * H == M && L * Nimg == tokens && x->ne[1] == L && d < 32768 && H < 32768) {
+            if (ax[0] == 0 && ax[1] == 2 && ax[2] == 1 && ax[3] == 3 && d * H == M && L * Nimg == tokens && x->ne[1] == L && d < 32768 && H < 32768 && L >= 32 &&
+                tokens < (1ll << 31)) {
                 std::vector<int> c2{i, j1, j2, j3};
                 int lastn = j3;
                 const int j4 = gi.sole(j3);
@@ -395,7 +397,36 @@ void plan_linear(Builder& B, int i, hipStream_t s, std::vector<int>& chain) {
             }
         }
     }
-    const void* swz = get_swz_linear(B.P, w, s);
+    // FF1 -> GEGLU (block.hpp:193-210): [bias ADD] -> {VIEW lo, VIEW hi} ; CONT(hi) -> GELU -> MUL(lo, .) feeding only gemm16 GEMMs (FF2):
+    // one kernel computes value and gate columns side by side and writes the f16 operand image of FF2
+    int geglu_out = -1;
+    if (g_opt.fusion && g_opt.gemm16 && hm_d == 0 && !ep.residual && M % 128 == 0 && gi.consumers[last].size() == 2) {
+        const ggml_tensor* X = gi.node(last);
+        const int64_t inner  = M / 2;
+        int vlo = -1, vhi = -1;
+        for (int c : gi.consumers[last]) {
+            const ggml_tensor* v = gi.node(c);
+            const ggml_tensor* root = X->view_src ? X->view_src : X;  // the in-place bias ADD is itself a view of the MUL_MAT output
+            if (v->op != GGML_OP_VIEW || (v->view_src != X && v->view_src != root) || v->ne[0] != inner || v->nb[1] != X->nb[1] || v->nb[2] != X->nb[2] || v->nb[3] != X->nb[3] ||
+                v->ne[1] != X->ne[1] || v->ne[2] != X->ne[2] || v->ne[3] != X->ne[3])
+                continue;
+            if (v->data == X->data) vlo = c;
+            if ((const char*)v->data == (const char*)X->data + inner * 4) vhi = c;
+        }
+        const int jc = vhi >= 0 ? gi.sole(vhi) : -1;
+        const int jg = (jc >= 0 && gi.node(jc)->op == GGML_OP_CONT && gi.node(jc)->src[0] == gi.node(vhi)) ? gi.sole(jc) : -1;
+        const int jm = (jg >= 0 && gi.node(jg)->op == GGML_OP_UNARY && ggml_abi_get_unary_op(gi.node(jg)) == GGML_UNARY_OP_GELU) ? gi.sole(jg) : -1;
+        if (vlo >= 0 && jm >= 0 && gi.node(jm)->op == GGML_OP_MUL && gi.node(jm)->src[0] == gi.node(vlo) && gi.node(jm)->src[1] == gi.node(jg) &&
+            gi.sole(vlo) == jm && !(X->flags & GGML_TENSOR_FLAG_OUTPUT) && all_consumers_gemm16(gi, jm, false)) {
+            std::vector<int> c2 = chain;
+            for (int c : {vlo, vhi, jc, jg, jm}) c2.push_back(c);
+            if (gi.only_noops_between(i, jm, c2)) {
+                chain     = c2;
+                geglu_out = jm;
+            }
+        }
+    }
+    const void* swz = get_swz_linear(B.P, w, s, geglu_out >= 0);
     float* dst      = (float*)gi.node(last)->data;
     const float* xp = (const float*)x->data;
     const int64_t xs = (int64_t)x->nb[1] / 4;
@@ -414,15 +445,28 @@ void plan_linear(Builder& B, int i, hipStream_t s, std::vector<int>& chain) {
         Planner* P       = B.P;
         const size_t off = it->second.off;
         const int64_t ld = it->second.ld;
-        if (hm_d > 0) {
+        if (geglu_out >= 0) {
+            const size_t ooff  = B.alloc((size_t)tokens * (M / 2) * 2);
+            const float* biasp = ep.bias;
+            B.emit([=](hipStream_t st) { launch_gemm16_linear_geglu(st, P->arena + ooff, P->arena + off, ld, swz, tokens, K, M, biasp); });
+            B.packed[gi.node(geglu_out)] = Packed{ooff, M / 2, false};
+            g_stats.fused_geglu++;
+            g_stats.fused_linear_geglu++;
+        } else if (hm_d > 0) {
             void* hdst = gi.node(last)->data;
+            g_stats.head_major_gemms++;
             const bool f16o = hm_f16;
             const int hd = hm_d, hH = hm_H, hL = hm_L;
             B.emit([=](hipStream_t st) {
                 launch_gemm16_linear(st, f16o ? nullptr : (float*)hdst, f16o ? hdst : nullptr, 0, P->arena + off, ld, swz, tokens, K, M, M, ep, hd, hH, hL);
             });
         } else {
-            B.emit([=](hipStream_t st) { launch_gemm16_linear(st, dst, nullptr, 0, P->arena + off, ld, swz, tokens, K, M, M, ep); });
+            const int S       = gemm16_split_k(tokens, M, K);
+            const size_t wsoff = S > 1 ? B.alloc((size_t)S * tokens * M * 4) : 0;
+            if (S > 1) g_stats.split_k_gemms++;
+            B.emit([=](hipStream_t st) {
+                launch_gemm16_linear(st, dst, nullptr, 0, P->arena + off, ld, swz, tokens, K, M, M, ep, 0, 0, 0, S > 1 ? (float*)(P->arena + wsoff) : nullptr);
+            });
         }
     } else {
         B.emit([=](hipStream_t st) { launch_linear_mfma(st, dst, xp, swz, tokens, K, M, xs, M, ep); });
@@ -517,7 +561,14 @@ bool plan_conv_chain(Builder& B, int i, hipStream_t s, std::vector<int>& chain) 
         }
         Planner* P       = B.P;
         const size_t off = it->second.off;
-        B.emit([=](hipStream_t st) { launch_gemm16_conv(st, final_dst, P->arena + off, swz, SW, SH, IC, N, OC, ks, st_, pd, upscale, ep); });
+        const int64_t CW_ = upscale ? SW * 2 : SW, CH_ = upscale ? SH * 2 : SH;
+        const int64_t opos = ((CW_ + 2 * pd - ks) / st_ + 1) * ((CH_ + 2 * pd - ks) / st_ + 1) * N;
+        const int S        = gemm16_split_k(opos, OC, rup64(IC) * ks * ks);
+        const size_t wsoff = S > 1 ? B.alloc((size_t)S * opos * OC * 4) : 0;
+        if (S > 1) g_stats.split_k_gemms++;
+        B.emit([=](hipStream_t st) {
+            launch_gemm16_conv(st, final_dst, P->arena + off, swz, SW, SH, IC, N, OC, ks, st_, pd, upscale, ep, S > 1 ? (float*)(P->arena + wsoff) : nullptr);
+        });
         g_stats.fused_conv++;
         return true;
     }
@@ -1252,6 +1303,9 @@ void planner_get_stats(ggml_backend_mi355x_stats* o) {
     o->fused_linear          = g_stats.fused_linear;
     o->fused_norm            = g_stats.fused_norm;
     o->fused_geglu           = g_stats.fused_geglu;
+    o->fused_linear_geglu    = g_stats.fused_linear_geglu;
+    o->split_k_gemms         = g_stats.split_k_gemms;
+    o->head_major_gemms      = g_stats.head_major_gemms;
     o->fused_attention       = g_stats.fused_attention;
     o->generic_matmul        = g_stats.generic_matmul;
     o->swizzled_weight_bytes = g_stats.swizzled_weight_bytes;
@@ -1265,6 +1319,8 @@ void planner_set_option(const char* key, int value) {
     else if (!strcmp(key, "flash_pattern")) g_opt.flash_pattern = value;
     else if (!strcmp(key, "gemm16")) g_opt.gemm16 = value;
     else if (!strcmp(key, "gemm16_variant")) gemm16_set_variant(value);
+    else if (!strcmp(key, "conv_tap_major")) gemm16_set_tap_major(value);
+    else if (!strcmp(key, "gemm16_tile")) gemm16_set_tile(value);
     // options change what a plan contains: drop cached plans
     std::lock_guard<std::mutex> lk(g_mu);
     for (Planner* p : g_planners) {

@@ -57,17 +57,18 @@ __device__ __forceinline__ float to_f32(bf16_t v) { return cvt<float, bf16_t>(v)
 
 // activations.  GELU is the tanh approximation evaluated in f32 (ggml-cpu goes through an f16 table,
 // i.e. the reference result carries an extra f16 rounding of input and output — covered by the tolerance).
+// Reciprocals are v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division: the GEGLU / SiLU epilogues are VALU-bound.
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 template <int OP>
 __device__ __forceinline__ float act_apply(float x) {
-    if (OP == UN_SILU) return x / (1.0f + __expf(-x));
+    if (OP == UN_SILU) return x * fast_rcp(1.0f + __expf(-x));
     if (OP == UN_GELU) {
+        // 0.5 x (1 + tanh(u)) with tanh(u) = 1 - 2/(exp(2u)+1)  ==  x * (1 - 1/(exp(2u)+1));  exp -> inf gives x, exp -> 0 gives 0
         const float u = 0.79788456080286535588f * x * (1.0f + 0.044715f * x * x);
-        // tanh(u) = 1 - 2/(exp(2u)+1); stable for large |u|
-        const float t = 1.0f - 2.0f / (__expf(2.0f * u) + 1.0f);
-        return 0.5f * x * (1.0f + t);
+        return x * (1.0f - fast_rcp(__expf(2.0f * u) + 1.0f));
     }
-    if (OP == UN_GELU_QUICK) return x / (1.0f + __expf(-1.702f * x));
-    if (OP == UN_SIGMOID) return 1.0f / (1.0f + __expf(-x));
+    if (OP == UN_GELU_QUICK) return x * fast_rcp(1.0f + __expf(-1.702f * x));
+    if (OP == UN_SIGMOID) return fast_rcp(1.0f + __expf(-x));
     if (OP == UN_TANH) return tanhf(x);
     if (OP == UN_RELU) return x > 0.f ? x : 0.f;
     if (OP == UN_NEG) return -x;

@@ -6,8 +6,8 @@
 //
 //   A  activations, f16 row-major [rows][Kp] (K contiguous, Kp % 64 == 0), written once by the PRODUCER of the
 //      tensor (norm / GEGLU / pack kernels below) into the backend's private operand arena;
-//      linear: rows = tokens;  conv: rows = output positions, the A-tile of K-tile (tap, ic-block) is gathered
-//      straight from the NHWC image at (oh*S+kh-pad, ow*S+kw-pad) — implicit GEMM with K = KS*KS*ICp, padding
+//      linear: rows = tokens;  conv: rows = output positions, the A-tile of K-tile (ic-block, tap) is gathered
+//      straight from the NHWC image at (oh*S+kh-pad, ow*S+kw-pad) — implicit GEMM with K = ICp*KS*KS ordered (ic-block, tap, ic), padding
 //      taps read a zero page, the nearest-x2 upsample is an index shift.  No im2col, no halo patch.
 //   W  static weights in MFMA fragment order [col/32][Kp/16][64 lanes][8 halfs] (wgemm.hip: launch_wswz_*).
 //
@@ -19,6 +19,9 @@
 // issued right after it and overlaps the 32 MFMAs of the current tile; 2 workgroups per CU hide the rest.
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
+#include <utility>
+#include <vector>
 #include "device_utils.h"
 #include "kernels.h"
 
@@ -38,12 +41,16 @@ struct G16Args {
     float* dst;
     _Float16* dst16;   // optional f16 row-major copy of the output (rows mode), row stride ldd16 halfs
     int64_t ldd, ldd16;
+    int geglu_inner;       // > 0: GEGLU epilogue (weights in the paired order of k_wswz_linear), f16 output [rows][geglu_inner]
     int hm_d, hm_H, hm_L;  // head-major store (rows mode): element (row = n*L + l, col = h*d + dd) -> ((n*H + h)*L + l)*d + dd
     int64_t R, C;
-    int nt;            // K tiles (64 each)
+    int nt;            // K tiles (BK each)
     int ncol_tiles;
+    int split_k;       // > 1: blockIdx.y = K slice; slice s accumulates K tiles [s*nt_slice, ...) into dst + s*slab (raw partial sums)
+    int nt_slice;
+    int64_t slab;      // elements between the partial-sum slabs
     // conv gather
-    int H, Wd, ICp, OH, OW, S, pad, UPS, KS, icb_per_tap;
+    int H, Wd, ICp, OH, OW, S, pad, UPS, KS, icb_per_tap, tap_major;
     int64_t OHOW;
     const _Float16* zero;
     G16Epi ep;
@@ -67,6 +74,31 @@ __device__ __forceinline__ T ld_u(const T* ubase, uint32_t lane_bytes) { return 
 
 enum { EPI_F32 = 0, EPI_F32_RES = 1, EPI_F16 = 2, EPI_HM_F32 = 3, EPI_HM_F16 = 4, EPI_GENERIC = 5 };
 
+// FF1 + GEGLU: the wave's column block cb = 0 holds 32 value columns, cb = 1 the matching gate columns
+template <int RB, int CB>
+__device__ __forceinline__ void epi_geglu(const float16_t (&acc)[RB][CB], const G16Args& g, int64_t row0, int col0, int wr, int wc, int lane) {
+    static_assert(CB == 2, "GEGLU pairing needs two column blocks per wave");
+    const int hi = lane >> 5, lc = lane & 31;
+    const int oc0 = (col0 / 128 * 2 + wc) * 32;  // first output column of this wave
+    if (oc0 >= g.geglu_inner) return;
+    const float bx = g.ep.bias ? g.ep.bias[oc0 + lc] : 0.f, bg = g.ep.bias ? g.ep.bias[g.geglu_inner + oc0 + lc] : 0.f;
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        const int64_t base_row = row0 + wr * (RB * 32) + rb * 32;
+        if (base_row >= g.R) continue;
+        const int nvl     = (int)(g.R - base_row < 32 ? g.R - base_row : 32) - 4 * hi;
+        _Float16* ub      = g.dst16 + base_row * g.ldd16 + oc0;
+        const uint32_t lb = (uint32_t)(lc + 4 * hi * (int)g.ldd16) * 2u;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ro = (r & 3) + 8 * (r >> 2);
+            if (ro >= nvl) continue;
+            const float xv = acc[rb][0][r] * g.ep.scale + bx, gv = acc[rb][1][r] * g.ep.scale + bg;
+            st_u(ub + (int64_t)ro * g.ldd16, lb, (_Float16)(xv * act_apply<UN_GELU>(gv)));
+        }
+    }
+}
+
 // linear (D[row][col]): register r holds row ro(r) + 4*hi of the block, lanes run along columns.  Fast variants need a full row tile.
 template <int MODE, int RB, int CB>
 __device__ __forceinline__ void epi_linear(const float16_t (&acc)[RB][CB], const G16Args& g, int64_t row0, int col0, int wr, int wc, int lane) {
@@ -77,6 +109,7 @@ __device__ __forceinline__ void epi_linear(const float16_t (&acc)[RB][CB], const
         if (MODE == EPI_GENERIC && base_row >= g.R) continue;
         uint32_t hm_n0 = 0, hm_l0 = 0;
         if (MODE == EPI_HM_F32 || MODE == EPI_HM_F16) {
+            if (base_row >= g.R) continue;
             hm_n0 = (uint32_t)base_row / (uint32_t)g.hm_L;
             hm_l0 = (uint32_t)base_row - hm_n0 * (uint32_t)g.hm_L;
         }
@@ -107,40 +140,38 @@ __device__ __forceinline__ void epi_linear(const float16_t (&acc)[RB][CB], const
                 for (int r = 0; r < 16; ++r) st_u(ub + (int64_t)((r & 3) + 8 * (r >> 2)) * g.ldd16, lb, (_Float16)(acc[rb][cb][r] * g.ep.scale + bias));
             } else if (MODE == EPI_HM_F32 || MODE == EPI_HM_F16) {
                 // attention operand layout [d, L, H, N] — what CONT(permute(0,2,1,3)) (+CPY f16) of the projection would hold:
-                // element (row = n*L + l, col = h*d + dd) -> n*(H*L*d) + h*(L*d) + l*d + dd.  hm_L % 32 == 0: a block stays in one image.
-                const int64_t Ld  = (int64_t)g.hm_L * g.hm_d;
-                const int64_t ub  = (int64_t)hm_n0 * Ld * g.hm_H + (int64_t)hm_l0 * g.hm_d;  // uniform
-                const uint32_t h  = (uint32_t)col / (uint32_t)g.hm_d, dd = (uint32_t)col - h * (uint32_t)g.hm_d;
-                const uint32_t le = h * (uint32_t)Ld + dd + 4u * hi * (uint32_t)g.hm_d;  // per-lane elements (< one image of the operand)
+                // element (row = n*L + l, col = h*d + dd) -> n*(H*L*d) + h*(L*d) + l*d + dd.  L >= 32: the 32 rows of a block cross at
+                // most ONE image boundary; rows past it move by (H-1)*L*d elements.  Ragged last row tiles are masked per register.
+                const int64_t Ld   = (int64_t)g.hm_L * g.hm_d;
+                const int64_t ub   = (int64_t)hm_n0 * Ld * g.hm_H + (int64_t)hm_l0 * g.hm_d;  // uniform
+                const uint32_t h   = (uint32_t)col / (uint32_t)g.hm_d, dd = (uint32_t)col - h * (uint32_t)g.hm_d;
+                const uint32_t le  = h * (uint32_t)Ld + dd + 4u * hi * (uint32_t)g.hm_d;  // per-lane elements (< one image of the operand)
+                const uint32_t adj = (uint32_t)(Ld * (g.hm_H - 1));
+                const int wrap_at  = g.hm_L - (int)hm_l0 - 4 * hi;  // register rows ro >= wrap_at belong to the next image
+                const int nvl      = (int)(g.R - base_row < 32 ? g.R - base_row : 32) - 4 * hi;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int64_t ro = ub + (int64_t)((r & 3) + 8 * (r >> 2)) * g.hm_d;
-                    const float v    = acc[rb][cb][r] * g.ep.scale + bias;
+                    const int ro = (r & 3) + 8 * (r >> 2);
+                    if (ro >= nvl) continue;
+                    const int64_t uo  = ub + (int64_t)ro * g.hm_d;
+                    const uint32_t lo = le + (ro >= wrap_at ? adj : 0u);
+                    const float v     = acc[rb][cb][r] * g.ep.scale + bias;
                     if (MODE == EPI_HM_F32)
-                        st_u(g.dst + ro, le * 4u, v);
+                        st_u(g.dst + uo, lo * 4u, v);
                     else
-                        st_u(g.dst16 + ro, le * 2u, (_Float16)v);
+                        st_u(g.dst16 + uo, lo * 2u, (_Float16)v);
                 }
             } else {
-                // everything else (ragged last row tile, f32+f16 double output, head-major with L % 32 != 0)
-                const int64_t Ld = (int64_t)g.hm_L * g.hm_d, HLd = Ld * g.hm_H;
-                const int64_t n0 = g.hm_d > 0 ? base_row / g.hm_L : 0;
-                const int l0     = g.hm_d > 0 ? (int)(base_row - n0 * g.hm_L) : 0;
-                const int h = g.hm_d > 0 ? col / g.hm_d : 0, dd = g.hm_d > 0 ? col - h * g.hm_d : 0;
+                // everything else (ragged last row tile, f32+f16 double output); head-major stores never come here (L >= 32 is a
+                // launch precondition and their variant masks ragged rows itself)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int o       = (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    const int64_t row = base_row + o;
+                    const int64_t row = base_row + (r & 3) + 8 * (r >> 2) + 4 * hi;
                     if (row >= g.R) continue;
                     float v = acc[rb][cb][r] * g.ep.scale + bias;
-                    int64_t idx = row * g.ldd + col, idx16 = row * g.ldd16 + col;
-                    if (g.hm_d > 0) {
-                        const int q = (l0 + o) / g.hm_L, l = (l0 + o) - q * g.hm_L;
-                        idx = idx16 = (n0 + q) * HLd + (int64_t)h * Ld + (int64_t)l * g.hm_d + dd;
-                    }
-                    if (g.ep.residual) v += g.ep.residual[idx];
-                    if (g.dst) g.dst[idx] = v;
-                    if (g.dst16) g.dst16[idx16] = (_Float16)v;
+                    if (g.ep.residual) v += g.ep.residual[row * g.ldd + col];
+                    if (g.dst) g.dst[row * g.ldd + col] = v;
+                    if (g.dst16) g.dst16[row * g.ldd16 + col] = (_Float16)v;
                 }
             }
         }
@@ -193,23 +224,25 @@ __device__ __forceinline__ void epi_conv(const float16_t (&acc)[RB][CB], const G
     }
 }
 
-template <int BN, bool CONV, int BK, int NST, int NW>
-__global__ __launch_bounds__(NW * 64, 2) void k_gemm16(G16Args g) {
-    constexpr int WC  = 2;             // waves along columns
-    constexpr int WR  = NW / 2;        // waves along rows
-    constexpr int BM  = WR * 64;       // rows per workgroup (128 or 256)
-    constexpr int RB  = 2;             // 32-row blocks per wave
-    constexpr int CB  = BN / WC / 32;  // 32-col blocks per wave (2 or 1)
+// geometry: workgroup tile BM x BN, WR x WC waves, each wave owns (BM/WR) x (BN/WC) outputs = RB x CB blocks of 32x32
+template <int BM, int BN, bool CONV, int BK, int NST, int WR, int WC>
+__global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm16(G16Args g) {
+    constexpr int NW  = WR * WC;
+    constexpr int RB  = BM / WR / 32;  // 32-row blocks per wave
+    constexpr int CB  = BN / WC / 32;  // 32-col blocks per wave
+    static_assert(RB * WR * 32 == BM && CB * WC * 32 == BN, "tile must split into 32x32 blocks per wave");
     constexpr int ROWB   = BK * 2;     // bytes per A row in a stage (128 or 64)
     constexpr int SLOTS  = ROWB / 16;  // 16-byte k-slots per row (8 or 4)
     constexpr int RPP    = 1024 / ROWB;  // rows per 1-KiB DMA piece (8 or 16)
     constexpr int ABYTES = BM * ROWB;
-    constexpr int BBYTES = BN * ROWB;  // W stage (fragment order)
     constexpr int KSTEPS = BK / 16;
+    constexpr int NF     = (BN / 32) * KSTEPS;         // W fragments (1 KiB each) per stage
     constexpr int APW    = (ABYTES / 1024) / NW;       // A pieces per wave per stage
-    constexpr int WPW    = (BN / 32) * KSTEPS / NW;    // W fragments per wave per stage
-    constexpr int NPT    = APW + WPW;                  // LDS-DMA instructions per wave per stage
-    static_assert(WPW >= 1, "tile too small");
+    constexpr int WPW    = (NF + NW - 1) / NW;         // W fragments per wave per stage (wave w fetches fragments w, w + NW, ...)
+    constexpr int WEXTRA = NF % NW;                    // != 0: only waves < WEXTRA fetch WPW fragments, the others WPW - 1
+    constexpr int BBYTES = NF * 1024;
+    constexpr int NPT    = APW + WPW;                  // LDS-DMA instructions per wave per stage (waves >= WEXTRA: one fewer when WEXTRA != 0)
+    static_assert(APW * NW * 1024 == ABYTES && APW >= 1, "A stage must split evenly over the waves");
     __shared__ __attribute__((aligned(1024))) char smem[NST * (ABYTES + BBYTES)];
 
     const int lane = threadIdx.x & 63;
@@ -221,6 +254,13 @@ __global__ __launch_bounds__(NW * 64, 2) void k_gemm16(G16Args g) {
     {
         const int nb = gridDim.x;
         if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);
+    }
+    // split-K: this workgroup accumulates K tiles [kt0, kt0 + nt) and stores raw partial sums into its slab
+    int kt0 = 0, nt = g.nt;
+    if (g.split_k > 1) {
+        kt0 = blockIdx.y * g.nt_slice;
+        nt  = min(g.nt_slice, g.nt - kt0);
+        g.dst += (int64_t)blockIdx.y * g.slab;
     }
     const int row_tile = bid / g.ncol_tiles, col_tile = bid - row_tile * g.ncol_tiles;
     const int64_t row0 = (int64_t)row_tile * BM;
@@ -270,11 +310,13 @@ __global__ __launch_bounds__(NW * 64, 2) void k_gemm16(G16Args g) {
     int wdst[WPW];
 #pragma unroll
     for (int q = 0; q < WPW; ++q) {
-        const int f  = wave * WPW + q;
-        const int cb = f / KSTEPS, ks = f % KSTEPS;
+        const int f  = q * NW + wave;
+        const int fs = f < NF ? f : NF - 1;
+        const int cb = fs / KSTEPS, ks = fs % KSTEPS;
         wsrc[q]      = g.W + ((int64_t)(col0 / 32 + cb) * g.kfr + ks) * 64 + lane;
-        wdst[q]      = f * 1024;
+        wdst[q]      = fs * 1024;
     }
+    const bool w_short = WEXTRA != 0 && wave >= WEXTRA;  // this wave issues one W fragment fewer per stage
     const int ktiles_per_icb = 64 / BK;  // conv: K tiles per 64-channel block (1 or 2)
 
     auto stage = [&](int kt, int buf) {
@@ -284,8 +326,19 @@ __global__ __launch_bounds__(NW * 64, 2) void k_gemm16(G16Args g) {
 #pragma unroll
             for (int q = 0; q < APW; ++q) GLDS16(asrc[q] + (int64_t)kt * BK, sa + (wave * APW + q) * 1024);
         } else {
-            const int kb  = kt / ktiles_per_icb, sub = kt - kb * ktiles_per_icb;  // kb: (tap, 64-channel block)
-            const int tap = kb / g.icb_per_tap, icb = kb - tap * g.icb_per_tap;
+            // K order = (64-channel block, tap, channel): the KS*KS taps of one channel block are consecutive K tiles, so a workgroup
+            // re-reads the same small input window (rows +-1, 128 B per pixel) back to back and the re-reads hit L2 (tap-major
+            // order re-read the whole tile 9 times, one full K sweep apart: 3x the algorithmic HBM/MALL fetch, profiles/r01c)
+            const int kb  = kt / ktiles_per_icb, sub = kt - kb * ktiles_per_icb;  // kb: (64-channel block, tap)
+            const int ntaps = g.KS * g.KS;
+            int icb, tap;
+            if (g.tap_major) {  // A/B switch (option "conv_tap_major"): the old (tap, channel block) order
+                tap = kb / g.icb_per_tap;
+                icb = kb - tap * g.icb_per_tap;
+            } else {
+                icb = kb / ntaps;
+                tap = kb - icb * ntaps;
+            }
             const int kh = tap / g.KS, kw = tap - kh * g.KS;
             const int64_t koff = (int64_t)icb * 64 + sub * BK;  // wave-uniform (SALU)
             if (!g.UPS) {
@@ -306,7 +359,8 @@ __global__ __launch_bounds__(NW * 64, 2) void k_gemm16(G16Args g) {
             }
         }
 #pragma unroll
-        for (int q = 0; q < WPW; ++q) GLDS16(wsrc[q] + (int64_t)kt * KSTEPS * 64, sb + wdst[q]);
+        for (int q = 0; q < WPW; ++q)
+            if (q + 1 < WPW || !w_short) GLDS16(wsrc[q] + (int64_t)kt * KSTEPS * 64, sb + wdst[q]);
     };
 
     float16_t acc[RB][CB];
@@ -346,25 +400,27 @@ __global__ __launch_bounds__(NW * 64, 2) void k_gemm16(G16Args g) {
 
     if (NST == 2) {
         // one barrier per K tile: its implicit vmcnt(0) retires this tile's DMA, the next tile's DMA overlaps the MFMAs
-        stage(0, 0);
-        for (int kt = 0; kt < g.nt; ++kt) {
+        stage(kt0, 0);
+        for (int kt = 0; kt < nt; ++kt) {
             __syncthreads();
-            if (kt + 1 < g.nt) stage(kt + 1, (kt + 1) & 1);
+            if (kt + 1 < nt) stage(kt0 + kt + 1, (kt + 1) & 1);
             compute(kt & 1);
         }
     } else {
         // 3-deep ring, COUNTED waits: two tiles of DMA stay in flight across the barrier (cdna_hip_programming.md T3+T4):
         // vmcnt(NPT) retires tile kt while tile kt+1 is still streaming; tile kt+2 is issued right after the barrier.
-        stage(0, 0);
-        if (g.nt > 1) stage(1, 1);
+        stage(kt0, 0);
+        if (nt > 1) stage(kt0 + 1, 1);
         int buf = 0;
-        for (int kt = 0; kt < g.nt; ++kt) {
-            if (kt + 1 < g.nt)
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPT) : "memory");
-            else
+        for (int kt = 0; kt < nt; ++kt) {
+            if (kt + 1 >= nt)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (w_short)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPT - 1) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPT) : "memory");
             __builtin_amdgcn_s_barrier();
-            if (kt + 2 < g.nt) stage(kt + 2, buf >= 1 ? buf - 1 : 2);  // (kt+2)%3
+            if (kt + 2 < nt) stage(kt0 + kt + 2, buf >= 1 ? buf - 1 : 2);  // (kt+2)%3
             compute(buf);
             buf = buf == 2 ? 0 : buf + 1;
         }
@@ -374,7 +430,9 @@ __global__ __launch_bounds__(NW * 64, 2) void k_gemm16(G16Args g) {
     if (!CONV) {
         const bool full  = row0 + BM <= g.R;
         const bool plain = full;
-        if (plain && g.hm_d > 0 && (g.hm_L & 31) == 0 && !g.ep.residual && (g.dst != nullptr) != (g.dst16 != nullptr)) {
+        if (CB == 2 && g.geglu_inner > 0) {
+            if constexpr (CB == 2) epi_geglu(acc, g, row0, col0, wr, wc, lane);
+        } else if (g.hm_d > 0 && g.hm_L >= 32 && !g.ep.residual && (g.dst != nullptr) != (g.dst16 != nullptr)) {
             if (g.dst16)
                 epi_linear<EPI_HM_F16>(acc, g, row0, col0, wr, wc, lane);
             else
@@ -409,26 +467,184 @@ static inline int64_t rup64(int64_t a, int64_t b) { return (a + b - 1) / b * b; 
 //   3 (default) = variant 1 plus 256-row x 128-col tiles (8 waves) whenever they still fill the chip — the LDS-DMA engine
 //   delivers ~20 B/clk/CU, so FLOP per DMA byte (tile area / perimeter) is what bounds these kernels.
 static int g_g16_variant = 3;
+static int g_g16_tap_major = 0;
+void gemm16_set_tap_major(int v) { g_g16_tap_major = v; }
+int gemm16_tap_major() { return g_g16_tap_major; }
 void gemm16_set_variant(int v) { g_g16_variant = v; }
+static inline bool g16_bk32() { return g_g16_variant == 1 || g_g16_variant == 3; }
+
+// ---- live timing of the dominant kernel (bench.py's roofline leg): HIP events recorded on the launch stream around every
+// k_gemm16<128, true, 32, 3, 8> dispatch (the 256x128-tile implicit-GEMM conv), with the launch's algorithmic FLOPs.
+namespace {
+struct G16Timing {
+    std::mutex mu;
+    bool on = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+    std::vector<double> flops;
+    size_t used = 0;
+} g_timing;
+}  // namespace
+void gemm16_timing_enable(bool on) {
+    std::lock_guard<std::mutex> lk(g_timing.mu);
+    g_timing.on   = on;
+    g_timing.used = 0;
+    g_timing.flops.clear();
+}
+void gemm16_timing_read(int64_t* launches, double* ms, double* flops) {
+    std::lock_guard<std::mutex> lk(g_timing.mu);
+    (void)hipDeviceSynchronize();
+    double t = 0, f = 0;
+    for (size_t i = 0; i < g_timing.used; ++i) {
+        float e = 0.f;
+        if (hipEventElapsedTime(&e, g_timing.pool[i].first, g_timing.pool[i].second) == hipSuccess) t += e;
+        f += g_timing.flops[i];
+    }
+    *launches     = (int64_t)g_timing.used;
+    *ms           = t;
+    *flops        = f;
+    g_timing.used = 0;
+    g_timing.flops.clear();
+}
+const char* gemm16_timing_kernel_name() { return "k_gemm16<256, *, true, 32, 3, *, *> (implicit-GEMM conv, 256-row tiles)"; }
+
+// tile configurations (all BK 32 x 3 stages, counted vmcnt):
+//   T128   128x128, 4 waves of 64x64   (48 KB LDS, 3 workgroups/CU)  — small outputs, finest granularity
+//   T256   256x128, 8 waves of 64x64   (72 KB, 2/CU)                 — large outputs, 1.33x the per-round area of T128
+//   T256W  256x128, 4 waves of 128x64  (72 KB, 2/CU)                 — same tile, fatter waves: 25 % fewer LDS fragment reads per MFMA
+//   T160   256x160, 4 waves of 64x160  (78 KB, 2/CU)                 — outputs that are multiples of 160 but not of 128 (SD1.5's 320):
+//                                                                       no padded columns, 2 column tiles instead of 3
+//   T160N  256x160, 8 waves of 32x160  (78 KB, 2/CU)                 — T160 with twice the waves in flight (experiment)
+enum { G16_T128 = 0, G16_T256 = 1, G16_T256W = 2, G16_T160 = 3, G16_T160N = 4 };
+static int g_g16_force_tile = -1;  // option "gemm16_tile": force one configuration (A/B measurements); -1 = choose per shape
+void gemm16_set_tile(int t) { g_g16_force_tile = t; }
+
+// Per-shape choice.  Measured on SD1.5 batch 16 (profiles/r01e_tile_configs.txt): a launch takes ceil(workgroups / resident slots)
+// rounds; a full round of T128 (768 slots) and of T256 (512 slots, twice the area per workgroup) take about the same time, a T160
+// round 1.5x that (4 waves per workgroup hide less latency) but covers 1.25x T256's area with no padded columns.  256-row tiles
+// only pay when they fill every CU twice (>= 512 workgroups); otherwise the finer T128 quantises better.
+static int g16_pick_tile(int64_t rows, int64_t M, bool geglu, bool conv) {
+    if (g_g16_variant != 3) return G16_T128;
+    const bool can160 = M % 160 == 0 && !geglu;
+    if (g_g16_force_tile >= 0) {
+        if ((g_g16_force_tile == G16_T160 || g_g16_force_tile == G16_T160N) && !can160) return G16_T256;
+        return g_g16_force_tile;
+    }
+    const int64_t rt256 = (rows + 255) / 256, c128 = ((rows + 127) / 128) * ((M + 127) / 128), c256 = rt256 * ((M + 127) / 128);
+    const int64_t c160 = can160 ? rt256 * (M / 160) : 0;
+    double best = (double)((c128 + 767) / 768) * 1.0;
+    int tile    = G16_T128;
+    if (c256 >= 512 && (double)((c256 + 511) / 512) * 0.98 < best) {
+        best = (double)((c256 + 511) / 512) * 0.98;
+        tile = G16_T256;
+    }
+    if (c160 >= 512 && (double)((c160 + 511) / 512) * 1.52 < best) tile = conv ? G16_T160 : G16_T160N;  // short-K linears: 8 thin waves hide more latency
+    else if (tile == G16_T128 && c160 >= 256 && c160 < 512 && c128 <= 768) tile = G16_T160N;             // one workgroup per CU, 8 waves each: ~4 % over T128
+    return tile;
+}
+
 template <int BN_, bool CONV_>
-static void g16_launch(hipStream_t s, G16Args& g, int64_t rows) {
-    const int64_t col_tiles = g.ncol_tiles;
-    if (g_g16_variant == 3 && BN_ == 128) {
-        const int64_t rt256 = (rows + 255) / 256;
-        if (rt256 * col_tiles >= 256) {
-            k_gemm16<128, CONV_, 32, 3, 8><<<(unsigned)(rt256 * col_tiles), 512, 0, s>>>(g);
+static void g16_launch(hipStream_t s, G16Args& g, int64_t rows, double flops) {
+    const unsigned ny = g.split_k > 1 ? (unsigned)g.split_k : 1u;
+    if (BN_ == 128 && g_g16_variant == 3) {
+        const int tile = g16_pick_tile(rows, g.C, g.geglu_inner > 0, CONV_);  // the GEGLU pairing is laid out for 128-column tiles
+        if (tile != G16_T128) {
+            const int64_t rt256 = (rows + 255) / 256;
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (CONV_ && g_timing.on) {
+                std::lock_guard<std::mutex> lk(g_timing.mu);
+                if (g_timing.used == g_timing.pool.size()) {
+                    hipEvent_t a, b;
+                    (void)hipEventCreate(&a);
+                    (void)hipEventCreate(&b);
+                    g_timing.pool.emplace_back(a, b);
+                }
+                e0 = g_timing.pool[g_timing.used].first;
+                e1 = g_timing.pool[g_timing.used].second;
+                g_timing.flops.push_back(flops);
+                ++g_timing.used;
+                (void)hipEventRecord(e0, s);
+            }
+            if (tile == G16_T160) {
+                g.ncol_tiles = (int)(g.C / 160);
+                k_gemm16<256, 160, CONV_, 32, 3, 4, 1><<<dim3((unsigned)(rt256 * g.ncol_tiles), ny), 256, 0, s>>>(g);
+            } else if (tile == G16_T160N) {
+                g.ncol_tiles = (int)(g.C / 160);
+                k_gemm16<256, 160, CONV_, 32, 3, 8, 1><<<dim3((unsigned)(rt256 * g.ncol_tiles), ny), 512, 0, s>>>(g);
+            } else if (tile == G16_T256W) {
+                k_gemm16<256, 128, CONV_, 32, 3, 2, 2><<<dim3((unsigned)(rt256 * g.ncol_tiles), ny), 256, 0, s>>>(g);
+            } else {
+                k_gemm16<256, 128, CONV_, 32, 3, 4, 2><<<dim3((unsigned)(rt256 * g.ncol_tiles), ny), 512, 0, s>>>(g);
+            }
+            if (e1) (void)hipEventRecord(e1, s);
             return;
         }
     }
-    const unsigned grid = (unsigned)(((rows + 127) / 128) * col_tiles);
+    const dim3 grid((unsigned)(((rows + 127) / 128) * g.ncol_tiles), ny);
     if (g_g16_variant == 0)
-        k_gemm16<BN_, CONV_, 64, 2, 4><<<grid, 256, 0, s>>>(g);
+        k_gemm16<128, BN_, CONV_, 64, 2, 2, 2><<<grid, 256, 0, s>>>(g);
     else if (g_g16_variant == 2)
-        k_gemm16<BN_, CONV_, 64, 3, 4><<<grid, 256, 0, s>>>(g);
+        k_gemm16<128, BN_, CONV_, 64, 3, 2, 2><<<grid, 256, 0, s>>>(g);
     else
-        k_gemm16<BN_, CONV_, 32, 3, 4><<<grid, 256, 0, s>>>(g);
+        k_gemm16<128, BN_, CONV_, 32, 3, 2, 2><<<grid, 256, 0, s>>>(g);
 }
-static inline bool g16_bk32() { return g_g16_variant == 1 || g_g16_variant == 3; }
+
+// ---- split-K.  Deep-K contractions over few output tiles (the 8x8 UNet level: 80 tiles on 256 CUs; the 16-row time-embedding
+// projections: 10 tiles) leave most of the chip idle.  K is cut into S slices, slice s writes raw partial sums to slab s of a
+// workspace in the operand arena (same indexing as dst), and k_splitk_reduce sums the slabs in a fixed order (deterministic,
+// unlike float atomics) and applies bias + residual.
+int gemm16_split_k(int64_t rows, int64_t M, int64_t K) {
+    if (!g16_bk32()) return 1;
+    const int64_t wgs = ((rows + 127) / 128) * ((M + 127) / 128);
+    const int64_t nt  = rup64(K, 64) / 32;
+    if (wgs >= 128) return 1;
+    int64_t S = 384 / wgs;
+    if (S > 8) S = 8;
+    if (S > nt / 8) S = nt / 8;
+    return S < 2 ? 1 : (int)S;
+}
+
+// dst[i] = sum_s slab_s[i] + bias[(i / inner) % C] + residual[i];  4 elements per thread (n % 4 == 0, and inner % 4 == 0 or inner == 1 with C % 4 == 0)
+template <bool V4>
+__global__ void k_splitk_reduce(float* __restrict__ dst, const float* __restrict__ ws, int S, int64_t slab, int64_t n, const float* __restrict__ bias,
+                                int64_t inner, int C, const float* residual) {
+    constexpr int W   = V4 ? 4 : 1;
+    const int64_t i   = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * W;
+    if (i >= n) return;
+    float v[W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) v[j] = 0.f;
+    for (int s = 0; s < S; ++s) {
+        if (V4) {
+            const float4 t = *(const float4*)(ws + s * slab + i);
+            v[0] += t.x; v[W > 1 ? 1 : 0] += t.y; v[W > 2 ? 2 : 0] += t.z; v[W > 3 ? 3 : 0] += t.w;
+        } else {
+            v[0] += ws[s * slab + i];
+        }
+    }
+    if (bias) {
+        if (inner == 1) {
+#pragma unroll
+            for (int j = 0; j < W; ++j) v[j] += bias[(i + j) % C];
+        } else {
+            const float b = bias[(i / inner) % C];
+#pragma unroll
+            for (int j = 0; j < W; ++j) v[j] += b;
+        }
+    }
+    if (residual) {
+#pragma unroll
+        for (int j = 0; j < W; ++j) v[j] += residual[i + j];
+    }
+#pragma unroll
+    for (int j = 0; j < W; ++j) dst[i + j] = v[j];
+}
+static void launch_splitk_reduce(hipStream_t s, float* dst, const float* ws, int S, int64_t n, const float* bias, int64_t inner, int64_t C, const float* residual) {
+    const bool v4 = n % 4 == 0 && (inner % 4 == 0 || (inner == 1 && C % 4 == 0)) && (((uintptr_t)dst | (uintptr_t)ws | (uintptr_t)residual) & 15) == 0;
+    if (v4)
+        k_splitk_reduce<true><<<(unsigned)((n / 4 + 255) / 256), 256, 0, s>>>(dst, ws, S, n, n, bias, inner, (int)C, residual);
+    else
+        k_splitk_reduce<false><<<(unsigned)((n + 255) / 256), 256, 0, s>>>(dst, ws, S, n, n, bias, inner, (int)C, residual);
+}
 
 // a 256-byte zero page per device for the padding taps
 static const _Float16* zero_page() {
@@ -446,6 +662,11 @@ static const _Float16* zero_page() {
 
 void gemm16_init() { (void)zero_page(); }
 
+// GGML_MI355X_TRACE=1: one stderr line per launch (shape), in launch order — joined with a rocprofv3 kernel trace by scripts/shape_stats.py
+static bool g16_trace() {
+    static const bool on = getenv("GGML_MI355X_TRACE") != nullptr;
+    return on;
+}
 static void g16_check_epi(const Epilogue& e) {
     if (e.act >= 0) {
         fprintf(stderr, "ggml-mi355x: gemm16 kernels have no fused activation (act=%d requested)\n", e.act);
@@ -454,7 +675,7 @@ static void g16_check_epi(const Epilogue& e) {
 }
 
 void launch_gemm16_linear(hipStream_t s, float* dst, void* dst16, int64_t ldd16, const void* a16, int64_t lda, const void* wswz, int64_t rows, int64_t K,
-                          int64_t M, int64_t ldd, const Epilogue& e, int hm_d, int hm_H, int hm_L) {
+                          int64_t M, int64_t ldd, const Epilogue& e, int hm_d, int hm_H, int hm_L, float* splitk_ws) {
     G16Args g{};
     g.A     = (const _Float16*)a16;
     g.lda   = lda;
@@ -465,6 +686,10 @@ void launch_gemm16_linear(hipStream_t s, float* dst, void* dst16, int64_t ldd16,
     g.dst16 = (_Float16*)dst16;
     g.ldd   = ldd;
     g.ldd16 = ldd16;
+    if (hm_d > 0 && (hm_L < 32 || e.residual || (dst != nullptr) == (dst16 != nullptr) || rows >= (1ll << 31))) {
+        fprintf(stderr, "ggml-mi355x: head-major gemm16 store needs L >= 32, exactly one output and no residual\n");
+        abort();
+    }
     g.hm_d  = hm_d;
     g.hm_H  = hm_H;
     g.hm_L  = hm_L;
@@ -473,19 +698,49 @@ void launch_gemm16_linear(hipStream_t s, float* dst, void* dst16, int64_t ldd16,
     g.nt    = (int)(Kp / (g16_bk32() ? 32 : 64));
     g16_check_epi(e);
     g.ep    = {e.bias, e.residual, e.scale};
+    const int S = (splitk_ws && dst && !dst16 && hm_d == 0 && ldd == M) ? gemm16_split_k(rows, M, K) : 1;
+    if (S > 1) {
+        g.split_k  = S;
+        g.nt_slice = (g.nt + S - 1) / S;
+        g.slab     = rows * M;
+        g.dst      = splitk_ws;
+        g.ep       = {nullptr, nullptr, e.scale};
+    }
     // narrow outputs (M = 320: 2.5 tiles of 128) waste less with 64-wide column tiles
     const bool bn64 = M <= 64;
+    if (g16_trace()) fprintf(stderr, "G16 linear rows=%lld K=%lld M=%lld res=%d hm=%d f16out=%d\n", (long long)rows, (long long)K, (long long)M, e.residual ? 1 : 0, hm_d, dst16 ? 1 : 0);
     if (bn64) {
         g.ncol_tiles = (int)((M + 63) / 64);
-        g16_launch<64, false>(s, g, rows);
+        g16_launch<64, false>(s, g, rows, 2.0 * rows * K * M);
     } else {
         g.ncol_tiles = (int)((M + 127) / 128);
-        g16_launch<128, false>(s, g, rows);
+        g16_launch<128, false>(s, g, rows, 2.0 * rows * K * M);
     }
+    if (S > 1) launch_splitk_reduce(s, dst, splitk_ws, S, rows * M, e.bias, 1, M, e.residual);
+}
+
+void launch_gemm16_linear_geglu(hipStream_t s, void* dst16, const void* a16, int64_t lda, const void* wswz_geglu, int64_t rows, int64_t K, int64_t M,
+                                const float* bias) {
+    G16Args g{};
+    g.A           = (const _Float16*)a16;
+    g.lda         = lda;
+    g.W           = (const half8_t*)wswz_geglu;
+    const int64_t Kp = rup64(K, 64);
+    g.kfr         = Kp / 16;
+    g.dst16       = (_Float16*)dst16;
+    g.geglu_inner = (int)(M / 2);
+    g.ldd16       = M / 2;
+    g.R           = rows;
+    g.C           = M;
+    g.nt          = (int)(Kp / (g16_bk32() ? 32 : 64));
+    g.ep          = {bias, nullptr, 1.f};
+    g.ncol_tiles  = (int)((M + 127) / 128);
+    if (g16_trace()) fprintf(stderr, "G16 linear rows=%lld K=%lld M=%lld res=0 hm=0 f16out=1 geglu=1\n", (long long)rows, (long long)K, (long long)M);
+    g16_launch<128, false>(s, g, rows, 2.0 * rows * K * M);
 }
 
 void launch_gemm16_conv(hipStream_t s, float* dst, const void* x16_nhwc, const void* wswz, int64_t W, int64_t H, int64_t IC, int64_t N, int64_t OC, int ksize,
-                        int stride, int pad, bool upscale2x, const Epilogue& e) {
+                        int stride, int pad, bool upscale2x, const Epilogue& e, float* splitk_ws) {
     G16Args g{};
     g.A   = (const _Float16*)x16_nhwc;
     g.W   = (const half8_t*)wswz;
@@ -503,20 +758,33 @@ void launch_gemm16_conv(hipStream_t s, float* dst, const void* x16_nhwc, const v
     g.UPS  = upscale2x ? 1 : 0;
     g.KS   = ksize;
     g.icb_per_tap = g.ICp / 64;
+    g.tap_major   = g_g16_tap_major;
     g.nt   = ksize * ksize * g.icb_per_tap * (g16_bk32() ? 2 : 1);
     g.R    = g.OHOW * N;
     g.C    = OC;
     g.zero = zero_page();
     g16_check_epi(e);
     g.ep   = {e.bias, e.residual, e.scale};
+    const int S = splitk_ws ? gemm16_split_k(g.R, OC, (int64_t)g.ICp * ksize * ksize) : 1;
+    if (S > 1) {
+        g.split_k  = S;
+        g.nt_slice = (g.nt + S - 1) / S;
+        g.slab     = g.R * OC;
+        g.dst      = splitk_ws;
+        g.ep       = {nullptr, nullptr, e.scale};
+    }
     const bool bn64 = OC <= 64;
+    if (g16_trace())
+        fprintf(stderr, "G16 conv rows=%lld K=%lld M=%lld res=%d ks=%d s=%d ups=%d hw=%lldx%lld ic=%lld\n", (long long)g.R, (long long)g.ICp * ksize * ksize, (long long)OC,
+                e.residual ? 1 : 0, ksize, stride, g.UPS, (long long)W, (long long)H, (long long)IC);
     if (bn64) {
         g.ncol_tiles = (int)((OC + 63) / 64);
-        g16_launch<64, true>(s, g, g.R);
+        g16_launch<64, true>(s, g, g.R, 2.0 * g.R * IC * ksize * ksize * OC);
     } else {
         g.ncol_tiles = (int)((OC + 127) / 128);
-        g16_launch<128, true>(s, g, g.R);
+        g16_launch<128, true>(s, g, g.R, 2.0 * g.R * IC * ksize * ksize * OC);
     }
+    if (S > 1) launch_splitk_reduce(s, dst, splitk_ws, S, g.R * OC, e.bias, g.OHOW, OC, e.residual);
 }
 
 // =====================================================================================================

@@ -52,9 +52,11 @@ void launch_im2col_f16(hipStream_t s, void* dst, int dst_type, const View4& x, i
 // ---- wgemm.hip: static-weight GEMMs on f16 MFMA (32x32x16), weights pre-swizzled into fragment order ----
 // pre-swizzle: rows R (padded to 32) x K (padded to 16) -> [R/32][K/16][64 lanes][8 halfs]
 size_t wswz_bytes(int64_t R, int64_t K);
-void launch_wswz_linear(hipStream_t s, void* dst, const void* src, int src_type, int64_t K, int64_t R, int64_t src_row_bytes);
+// geglu_inner > 0: rows permuted so that every wave of a gemm16 column tile owns matching value / gate blocks (GEGLU epilogue)
+void launch_wswz_linear(hipStream_t s, void* dst, const void* src, int src_type, int64_t K, int64_t R, int64_t src_row_bytes, int64_t geglu_inner = 0);
 // conv weight [KW,KH,IC,OC] f16 -> rows OC, K index = tap*ICp + ic (ICp = IC padded to 32)
-void launch_wswz_conv(hipStream_t s, void* dst, const void* src, int64_t KW, int64_t KH, int64_t IC, int64_t OC);
+void launch_wswz_conv(hipStream_t s, void* dst, const void* src, int64_t KW, int64_t KH, int64_t IC, int64_t OC, bool icb_major = false);
+// icb_major: K ordered (64-channel block, tap, channel) for gemm16.hip; false: (tap, channel) for the first-generation kernels
 
 struct Epilogue {
     const float* bias     = nullptr;  // per output feature / channel
@@ -73,13 +75,26 @@ void launch_conv2d_mfma(hipStream_t s, float* dst, const float* x, const void* w
 // ---- gemm16.hip: second-generation contraction, both operands f16 via LDS-DMA -------------------------------
 // a16: f16 row-major [rows][lda] (K contiguous, padded to 64); output f32 [rows][ldd] and/or f16 [rows][ldd16]
 void gemm16_init();
+void gemm16_set_tap_major(int v);  // A/B: conv K order (tap, channel block) instead of (channel block, tap)
+int gemm16_tap_major();
+void gemm16_set_tile(int t);     // -1: per-shape choice; 0..3: force T128 / T256 / T256W / T160 (A/B measurements)
 void gemm16_set_variant(int v);  // 0: BK64x2 stages, 1: BK32x3 stages (default), 2: BK64x3 stages
 // hm_d > 0: head-major store — element (row = n*hm_L + l, col = h*hm_d + dd) goes to ((n*hm_H + h)*hm_L + l)*hm_d + dd of dst (f32) / dst16 (f16)
 void launch_gemm16_linear(hipStream_t s, float* dst, void* dst16, int64_t ldd16, const void* a16, int64_t lda, const void* wswz, int64_t rows,
-                          int64_t K, int64_t M, int64_t ldd, const Epilogue& ep, int hm_d = 0, int hm_H = 0, int hm_L = 0);
+                          int64_t K, int64_t M, int64_t ldd, const Epilogue& ep, int hm_d = 0, int hm_H = 0, int hm_L = 0, float* splitk_ws = nullptr);
+// FF1 + GEGLU in one kernel (block.hpp:193-210): wswz built with geglu_inner = M/2; dst16[t][c] = (y[t][c] + b[c]) * gelu(y[t][inner + c] + b[inner + c]),
+// f16 row-major with row stride inner (inner % 64 == 0) — the operand image of the FF2 GEMM.  The [tokens][2*inner] f32 tensor is never written.
+void launch_gemm16_linear_geglu(hipStream_t s, void* dst16, const void* a16, int64_t lda, const void* wswz_geglu, int64_t rows, int64_t K, int64_t M,
+                                const float* bias);
+// live HIP-event timing of the dominant kernel (the 256x128-tile implicit-GEMM conv): enable resets, read synchronises + resets
+void gemm16_timing_enable(bool on);
+void gemm16_timing_read(int64_t* launches, double* ms, double* flops);
+const char* gemm16_timing_kernel_name();
+// split-K factor the launchers will use when given a workspace of factor * rows * M floats (1 = no split)
+int gemm16_split_k(int64_t rows, int64_t M, int64_t K);
 // x16: f16 NHWC [N][H][W][ICp]; dst f32 NCHW [OW,OH,OC,N]
 void launch_gemm16_conv(hipStream_t s, float* dst, const void* x16_nhwc, const void* wswz, int64_t W, int64_t H, int64_t IC, int64_t N, int64_t OC,
-                        int ksize, int stride, int pad, bool upscale2x, const Epilogue& ep);
+                        int ksize, int stride, int pad, bool upscale2x, const Epilogue& ep, float* splitk_ws = nullptr);
 // producers of f16 operand images (row stride = K rounded up to 64, zero padded)
 void launch_pack_rows_f16(hipStream_t s, void* dst, const float* x, int64_t R, int64_t K, int64_t x_stride);
 void launch_layer_norm_f16(hipStream_t s, void* dst, const float* x, int64_t ne0, int64_t nrows, int64_t x_stride, float eps, const float* w,

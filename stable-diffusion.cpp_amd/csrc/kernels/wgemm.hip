@@ -50,14 +50,22 @@ __device__ __forceinline__ float wload(const char* row, int type, int64_t k) {
 }
 
 // one thread per (fragment, lane): writes 8 halfs
+// geglu_inner > 0: GEGLU pairing (gemm16.hip EPI_GEGLU) — 32-row block rb of the image holds, for column tile t = rb/4 and q = rb%4
+// (wave column wc = q/2, block cb = q%2), rows cb*inner + (2t + wc)*32 + r of the source: each wave then owns a value block (cb = 0)
+// and the gate block of the same 32 output columns (cb = 1).
 __global__ void k_wswz_linear(half8_t* __restrict__ dst, const char* __restrict__ src, int type, int64_t K, int64_t R, int64_t row_bytes, int64_t Kp,
-                              int64_t total) {
+                              int64_t total, int64_t geglu_inner) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int lane     = (int)(i & 63);
     const int64_t frag = i >> 6;
     const int64_t kb = frag % (Kp / 16), rb = frag / (Kp / 16);
-    const int64_t row = rb * 32 + (lane & 31);
+    int64_t row = rb * 32 + (lane & 31);
+    if (geglu_inner > 0) {
+        const int64_t t = rb >> 2, q = rb & 3;
+        row = (q & 1) * geglu_inner + (2 * t + (q >> 1)) * 32 + (lane & 31);
+        if ((2 * t + (q >> 1)) * 32 >= geglu_inner) row = R;  // beyond the last pair: zero rows
+    }
     const int64_t k0  = kb * 16 + (lane >> 5) * 8;
     half8_t v;
 #pragma unroll
@@ -68,15 +76,15 @@ __global__ void k_wswz_linear(half8_t* __restrict__ dst, const char* __restrict_
     }
     dst[i] = v;
 }
-void launch_wswz_linear(hipStream_t s, void* dst, const void* src, int src_type, int64_t K, int64_t R, int64_t src_row_bytes) {
+void launch_wswz_linear(hipStream_t s, void* dst, const void* src, int src_type, int64_t K, int64_t R, int64_t src_row_bytes, int64_t geglu_inner) {
     const int64_t Kp = rup(K, 64), Rp = rup(R, 128);
     const int64_t total = (Rp / 32) * (Kp / 16) * 64;
-    k_wswz_linear<<<(unsigned)((total + 255) / 256), 256, 0, s>>>((half8_t*)dst, (const char*)src, src_type, K, R, src_row_bytes, Kp, total);
+    k_wswz_linear<<<(unsigned)((total + 255) / 256), 256, 0, s>>>((half8_t*)dst, (const char*)src, src_type, K, R, src_row_bytes, Kp, total, geglu_inner);
 }
 
 // conv weight [KW,KH,IC,OC] f16 -> rows OC, k = tap*ICp + ic
 __global__ void k_wswz_conv(half8_t* __restrict__ dst, const __half* __restrict__ src, int KW, int KH, int64_t IC, int64_t OC, int64_t ICp, int64_t Kp,
-                            int64_t total) {
+                            int64_t total, int icb_major) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int lane     = (int)(i & 63);
@@ -88,7 +96,15 @@ __global__ void k_wswz_conv(half8_t* __restrict__ dst, const __half* __restrict_
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int64_t k = k0 + j;
-        const int64_t tap = k / ICp, ic = k % ICp;
+        int64_t tap, ic;
+        if (icb_major) {  // gemm16: k = (icb * taps + tap) * 64 + ic % 64
+            const int64_t taps = (int64_t)KH * KW, kb = k / 64;
+            tap = kb % taps;
+            ic  = (kb / taps) * 64 + k % 64;
+        } else {  // first-generation kernels: k = tap * ICp + ic
+            tap = k / ICp;
+            ic  = k % ICp;
+        }
         _Float16 f = (_Float16)0.f;
         if (oc < OC && ic < IC) {
             const __half h = src[(oc * IC + ic) * (KH * KW) + tap];
@@ -98,10 +114,10 @@ __global__ void k_wswz_conv(half8_t* __restrict__ dst, const __half* __restrict_
     }
     dst[i] = v;
 }
-void launch_wswz_conv(hipStream_t s, void* dst, const void* src, int64_t KW, int64_t KH, int64_t IC, int64_t OC) {
+void launch_wswz_conv(hipStream_t s, void* dst, const void* src, int64_t KW, int64_t KH, int64_t IC, int64_t OC, bool icb_major) {
     const int64_t ICp = rup(IC, 64), Kp = ICp * KW * KH, Rp = rup(OC, 128);
     const int64_t total = (Rp / 32) * (Kp / 16) * 64;
-    k_wswz_conv<<<(unsigned)((total + 255) / 256), 256, 0, s>>>((half8_t*)dst, (const __half*)src, (int)KW, (int)KH, IC, OC, ICp, Kp, total);
+    k_wswz_conv<<<(unsigned)((total + 255) / 256), 256, 0, s>>>((half8_t*)dst, (const __half*)src, (int)KW, (int)KH, IC, OC, ICp, Kp, total, icb_major ? 1 : 0);
 }
 
 struct EpiDev {

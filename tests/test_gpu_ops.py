@@ -15,6 +15,12 @@ from ggml_graph import BF16, F16, F32, Q4_0, Q8_0, Graph, dequant
 pytestmark = pytest.mark.gpu
 
 
+def _on_gpu():
+    """False in the harness self-check mode (SDCPP_GPU_TESTS_ON_ORACLE=1: the 'gpu' fixture is the CPU oracle)"""
+    import os
+    return os.environ.get("SDCPP_GPU_TESTS_ON_ORACLE") != "1"
+
+
 def rel_l2(a, b):
     a = np.asarray(a, np.float64).ravel()
     b = np.asarray(b, np.float64).ravel()
@@ -306,3 +312,101 @@ def test_manual_attention_chain(sd, oracle, gpu, rng, d, Lq, Lk, HN):
 
     ref, out = run_both(sd, oracle, gpu, build)
     assert rel_l2(out, ref) < 2e-3
+
+
+@pytest.mark.parametrize("tokens,K,M", [(16, 1280, 1280), (1000, 5120, 200), (130, 2560, 96)])
+def test_linear_split_k(sd, oracle, gpu, rng, tokens, K, M):
+    """deep-K GEMMs over few output tiles run split-K (slabs + fixed-order reduce with bias + residual)"""
+    x = rng.standard_normal((tokens, K)).astype(np.float32)
+    w = (rng.standard_normal((M, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(M).astype(np.float32)
+    r = rng.standard_normal((tokens, M)).astype(np.float32)
+
+    def build(g, L):
+        y = L.ggml_mul_mat(g.ctx, g.weight(w, F16), g.input(x))
+        y = L.ggml_add_inplace(g.ctx, y, g.weight(b, F32))
+        return L.ggml_add(g.ctx, y, g.input(r))
+
+    before = sd.backend_stats() if _on_gpu() else None
+    ref, out = run_both(sd, oracle, gpu, build)
+    assert rel_l2(out, ref) < 2e-4
+    if before is not None:
+        assert sd.backend_stats()["split_k_gemms"] == before["split_k_gemms"] + 1
+
+
+@pytest.mark.parametrize("N,IC,OC,H,W,ks,stride", [(2, 256, 256, 8, 8, 3, 1), (1, 640, 320, 8, 8, 3, 1), (2, 128, 192, 16, 16, 3, 2), (1, 1280, 130, 6, 10, 1, 1)])
+def test_conv2d_split_k(sd, oracle, gpu, rng, N, IC, OC, H, W, ks, stride):
+    x = rng.standard_normal((N, IC, H, W)).astype(np.float32)
+    w = (rng.standard_normal((OC, IC, ks, ks)) / np.sqrt(IC * ks * ks)).astype(np.float32)
+    b = rng.standard_normal(OC).astype(np.float32)
+    pad = ks // 2
+
+    def build(g, L):
+        y = L.ggml_conv_2d(g.ctx, g.weight(w, F16), g.input(x), stride, stride, pad, pad, 1, 1)
+        return L.ggml_add_inplace(g.ctx, y, L.ggml_reshape_4d(g.ctx, g.weight(b, F32), 1, 1, OC, 1))
+
+    before = sd.backend_stats() if _on_gpu() else None
+    ref, out = run_both(sd, oracle, gpu, build)
+    assert out.shape == ref.shape
+    assert rel_l2(out, ref) < 2e-4
+    if before is not None:
+        assert sd.backend_stats()["split_k_gemms"] == before["split_k_gemms"] + 1
+
+
+@pytest.mark.parametrize("d,H,L_,N,K,f16", [(40, 8, 77, 3, 768, True), (40, 8, 77, 3, 768, False), (80, 4, 200, 2, 320, True), (64, 2, 24, 5, 128, False),
+                                            (160, 2, 64, 2, 320, True), (40, 2, 300, 1, 64, False)])
+def test_projection_head_major_chain(sd, oracle, gpu, rng, d, H, L_, N, K, f16):
+    """q/k/v projection + reshape/permute/cont (+ f16 cast): the GEMM epilogue writes the attention operand layout directly
+    (ggml_extend.hpp:1349-1400); rows = N*L is ragged against the 128-row tile and L is not a multiple of 32."""
+    C = d * H
+    x = rng.standard_normal((N, L_, K)).astype(np.float32)
+    w = (rng.standard_normal((C, K)) / np.sqrt(K)).astype(np.float32)
+
+    def build(g, L):
+        y = L.ggml_mul_mat(g.ctx, g.weight(w, F16), g.input(x))          # [C, L, N]
+        y = L.ggml_reshape_4d(g.ctx, y, d, H, L_, N)
+        y = L.ggml_cont(g.ctx, L.ggml_permute(g.ctx, y, 0, 2, 1, 3))     # [d, L, H, N]
+        y = L.ggml_reshape_3d(g.ctx, y, d, L_, H * N)
+        if f16:
+            y = L.ggml_cast(g.ctx, y, F16)
+            y = L.ggml_cast(g.ctx, y, F32)
+        return y
+
+    before = sd.backend_stats() if _on_gpu() else None
+    ref, out = run_both(sd, oracle, gpu, build)
+    assert out.shape == ref.shape
+    assert rel_l2(out, ref) < (1e-3 if f16 else 2e-4)
+    if before is not None:
+        assert sd.backend_stats()["head_major_gemms"] == before["head_major_gemms"] + (1 if L_ >= 32 else 0)
+
+
+@pytest.mark.parametrize("tokens,dim,inner", [(100, 64, 128), (300, 320, 1280), (77, 128, 192)])
+def test_feed_forward_geglu_fused(sd, oracle, gpu, rng, tokens, dim, inner):
+    """FeedForward (block.hpp:193-247): Linear(dim, 2*inner) -> GEGLU -> Linear(inner, dim) + residual.  When 2*inner % 128 == 0 the
+    first GEMM computes value and gate columns side by side and writes the f16 operand of the second one (no [tokens][2*inner]
+    tensor); inner = 192 exercises the unfused fallback."""
+    x = rng.standard_normal((1, tokens, dim)).astype(np.float32)
+    w1 = (rng.standard_normal((2 * inner, dim)) / np.sqrt(dim)).astype(np.float32)
+    b1 = rng.standard_normal(2 * inner).astype(np.float32)
+    w2 = (rng.standard_normal((dim, inner)) / np.sqrt(inner)).astype(np.float32)
+    b2 = rng.standard_normal(dim).astype(np.float32)
+
+    def build(g, L):
+        xin = g.input(x)
+        h = L.ggml_mul_mat(g.ctx, g.weight(w1, F16), xin)
+        h = L.ggml_add_inplace(g.ctx, h, g.weight(b1, F32))
+        ts = sd_tensor_nb(h)
+        lo = L.ggml_view_4d(g.ctx, h, inner, tokens, 1, 1, ts[1], ts[2], ts[3], 0)
+        hi = L.ggml_view_4d(g.ctx, h, inner, tokens, 1, 1, ts[1], ts[2], ts[3], inner * 4)
+        gate = L.ggml_gelu_inplace(g.ctx, L.ggml_cont(g.ctx, hi))
+        h = L.ggml_mul(g.ctx, lo, gate)
+        y = L.ggml_mul_mat(g.ctx, g.weight(w2, F16), h)
+        y = L.ggml_add_inplace(g.ctx, y, g.weight(b2, F32))
+        return L.ggml_add(g.ctx, y, xin)
+
+    before = sd.backend_stats() if _on_gpu() else None
+    ref, out = run_both(sd, oracle, gpu, build)
+    assert rel_l2(out, ref) < 1e-3   # oracle GELU goes through the f16 table
+    if before is not None:
+        fused = sd.backend_stats()["fused_linear_geglu"] - before["fused_linear_geglu"]
+        assert fused == (1 if (2 * inner) % 128 == 0 else 0)
