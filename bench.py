@@ -171,7 +171,7 @@ def main():
         "vs_baseline": None,
         "dtype": "f16",
         "data": "synthetic",
-        "config": {"workload": f"{args.model} UNet {lat*8}x{lat*8}, cfg 7 (cond+uncond), f16 weights, batch {B}/GPU, Euler-A step",
+        "config": {"workload": f"{args.model} UNet {lat*8}x{lat*8}, cfg 7 (cond+uncond), {'q8_0 Linear + f16 conv' if args.model == 'sdxl' else 'f16'} weights, batch {B}/GPU, Euler-A step",
                    "global_batch": B * world, "flash_attn": not args.no_flash, "hip_graph": args.hip_graph,
                    "cfg_pair_in_one_graph": fuse},
         "roofline": roofline,

@@ -21,6 +21,9 @@
 namespace mi355x {
 
 constexpr int FA_KT  = 64;  // keys per tile
+constexpr float FA_THR = 8.0f;  // deferred-max threshold, log2 units
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef float float2_t __attribute__((ext_vector_type(2)));
 constexpr int FA_VTS = 68;  // Vt row stride in halfs (136 B: conflict-free ds_read_b64 over 32 rows)
 
 struct FAArgs {
@@ -38,7 +41,7 @@ struct FAArgs {
 // FAST: K and V are f16, d-contiguous and 16-byte aligned (the FLASH_ATTN_EXT node as the reference builds it) -> 128-bit
 // loads, register-prefetched one tile ahead.  !FAST: any strides / f32 sources (manual-attention chain), staged directly.
 template <int DKP, int NDV, bool FAST>
-__global__ __launch_bounds__(256, 2) void k_flash_attn(FAArgs g) {
+__global__ __launch_bounds__(256, DKP <= 64 ? 3 : 2) void k_flash_attn(FAArgs g) {
     constexpr int KS   = DKP / 16;                       // MFMA k-steps over the head dim
     constexpr int KROW = DKP + 8;                        // K tile row stride (halfs)
     constexpr int DCH  = DKP / 8;                        // 8-wide d chunks per key
@@ -63,7 +66,7 @@ __global__ __launch_bounds__(256, 2) void k_flash_attn(FAArgs g) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int d = ks * 16 + hi * 8 + j;
-                qf[ks][j]   = (_Float16)((d < g.D && qi < g.Lq) ? qrow[d] : 0.f);
+                qf[ks][j]   = (_Float16)((d < g.D && qi < g.Lq) ? qrow[d] * g.scale_log2e : 0.f);  // scores come out of the MFMA in log2 units
             }
         }
     }
@@ -163,39 +166,28 @@ __global__ __launch_bounds__(256, 2) void k_flash_attn(FAArgs g) {
                 s[kb]            = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[kb], 0, 0, 0);
             }
         }
-        // ---- online softmax for query (lane & 31); this lane holds keys kb*32 + (r&3)+8*(r>>2)+4*hi
-        float tmax = -INFINITY;
-        const bool tail = kt + FA_KT > g.Lk;
+        // ---- online softmax for query (lane & 31); this lane holds keys kb*32 + (r&3)+8*(r>>2)+4*hi.  The loop is VALU-bound at
+        // d = 40 (32 exps per lane per tile vs 14 MFMAs), so every instruction counts: scores arrive pre-scaled (Q carries
+        // scale*log2e), exp is the bare v_exp_f32, and the running max is DEFERRED — it only moves when a query's tile max exceeds
+        // it by more than FA_THR (2^8: P <= 256 stays exact enough in f16 and far from its range), which makes the accumulator
+        // rescale (16 cross-lane fetches + 16*NDV multiplies) rare instead of per tile.
+        if (kt + FA_KT > g.Lk) {  // tail tile: mask keys >= Lk
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = s[kb][r] * g.scale_log2e;
-                if (tail) {
-                    const int key = kt + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (key >= g.Lk) v = -INFINITY;
-                }
-                s[kb][r] = v;
-                tmax     = fmaxf(tmax, v);
-            }
+                for (int r = 0; r < 16; ++r)
+                    if (kt + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= g.Lk) s[kb][r] = -INFINITY;
         }
-        tmax              = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float m_new = fmaxf(m_run, tmax);
-        const float alpha = exp2f(m_run - m_new);  // m_run = -inf on the first tile -> 0
-        float psum        = 0.f;
+        float tmax = fmaxf(s[0][0], s[1][0]);
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = exp2f(s[kb][r] - m_new);
-                s[kb][r]      = p;
-                psum += p;
-            }
-        }
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
-        // ---- rescale O rows: row i of the accumulator belongs to query lane i -> fetch its alpha
-        if (!__all(alpha == 1.0f)) {
+        for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, fmaxf(s[0][r], s[1][r]));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        if (__any(tmax > m_run + FA_THR)) {
+            const float m_new = fmaxf(m_run, tmax);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // m_run = -inf on the first tile -> 0
+            l_run *= alpha;
+            m_run = m_new;
+            // rescale O rows: row i of the accumulator belongs to query lane i -> fetch its alpha
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row  = (r & 3) + 8 * (r >> 2) + 4 * hi;
@@ -204,13 +196,28 @@ __global__ __launch_bounds__(256, 2) void k_flash_attn(FAArgs g) {
                 for (int nb = 0; nb < NDV; ++nb) o[nb][r] *= ar;
             }
         }
+        float psum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(s[kb][r] - m_run);
+                s[kb][r]      = p;
+                psum += p;
+            }
+        }
+        l_run += psum;
         // ---- O += P V : 4 k-steps of 16 keys; k-slot order = accumulator key order (see header)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int kb = t >> 1, rb = (t & 1) * 8;
             half8_t pa;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) pa[j] = (_Float16)s[kb][rb + j];
+            for (int j = 0; j < 8; j += 2) {  // v_cvt_pk_f16_f32
+                const half2_t h2 = __builtin_convertvector((float2_t){s[kb][rb + j], s[kb][rb + j + 1]}, half2_t);
+                pa[j]     = h2[0];
+                pa[j + 1] = h2[1];
+            }
 #pragma unroll
             for (int nb = 0; nb < NDV; ++nb) {
                 const _Float16* vrow = &Vt[(nb * 32 + (lane & 31)) * FA_VTS + t * 16 + 4 * hi];
@@ -232,24 +239,22 @@ __global__ __launch_bounds__(256, 2) void k_flash_attn(FAArgs g) {
     // ---- finalise: divide by the row sum (both lane halves), write [d] contiguous
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv   = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    const int hh = g.H > 0 ? hn % g.H : hn, nn = g.H > 0 ? hn / g.H : 0;  // wave-uniform
+    char* obase          = g.dst ? (char*)g.dst + (int64_t)hh * g.dst_nb_h + (int64_t)nn * g.dst_nb_n : nullptr;
+    _Float16* obase16    = g.dst16 ? g.dst16 + (int64_t)nn * g.Lq * g.ld16 + (int64_t)hh * g.DV : nullptr;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row  = (r & 3) + 8 * (r >> 2) + 4 * hi;
         const float ir = __shfl(inv, row, 64);
         const int q    = q0 + row;
-        if (q < g.Lq) {
-            const int hh = g.H > 0 ? hn % g.H : hn, nn = g.H > 0 ? hn / g.H : 0;
-            float* orow     = g.dst ? (float*)((char*)g.dst + (int64_t)q * g.dst_nb_q + (int64_t)hh * g.dst_nb_h + (int64_t)nn * g.dst_nb_n) : nullptr;
-            _Float16* orow16 = g.dst16 ? g.dst16 + ((int64_t)nn * g.Lq + q) * g.ld16 + (int64_t)hh * g.DV : nullptr;
+        if (q >= g.Lq) continue;
 #pragma unroll
-            for (int nb = 0; nb < NDV; ++nb) {
-                const int d = nb * 32 + (lane & 31);
-                if (d < g.DV) {
-                    const float val = o[nb][r] * ir;
-                    if (orow) orow[d] = val;
-                    if (orow16) orow16[d] = (_Float16)val;
-                }
-            }
+        for (int nb = 0; nb < NDV; ++nb) {
+            const int d = nb * 32 + (lane & 31);
+            if (d >= g.DV) continue;
+            const float val = o[nb][r] * ir;
+            if (obase) *(float*)(obase + (int64_t)q * g.dst_nb_q + d * 4) = val;
+            if (obase16) obase16[(int64_t)q * g.ld16 + d] = (_Float16)val;
         }
     }
 }

@@ -592,12 +592,14 @@ static void g16_launch(hipStream_t s, G16Args& g, int64_t rows, double flops) {
 // projections: 10 tiles) leave most of the chip idle.  K is cut into S slices, slice s writes raw partial sums to slab s of a
 // workspace in the operand arena (same indexing as dst), and k_splitk_reduce sums the slabs in a fixed order (deterministic,
 // unlike float atomics) and applies bias + residual.
+static int g_g16_splitk_target = 384;  // option "splitk_target": workgroups a split launch should reach
+void gemm16_set_splitk_target(int v) { g_g16_splitk_target = v; }
 int gemm16_split_k(int64_t rows, int64_t M, int64_t K) {
     if (!g16_bk32()) return 1;
     const int64_t wgs = ((rows + 127) / 128) * ((M + 127) / 128);
     const int64_t nt  = rup64(K, 64) / 32;
-    if (wgs >= 128) return 1;
-    int64_t S = 384 / wgs;
+    if (wgs > g_g16_splitk_target / 2) return 1;
+    int64_t S = g_g16_splitk_target / wgs;
     if (S > 8) S = 8;
     if (S > nt / 8) S = nt / 8;
     return S < 2 ? 1 : (int)S;
