@@ -88,7 +88,12 @@ int usable_cpus() {
         fclose(f);
     }
     if (const char* e = getenv("ORACLE_THREADS")) n = std::max(1, atoi(e));
-    else n = std::min(n, 16);
+    else {
+        n = std::min(n, 16);
+        // an explicit OMP_NUM_THREADS is a ceiling (several oracle processes sharing a box: tests/test_dist_shard.py)
+        if (const char* o = getenv("OMP_NUM_THREADS"))
+            if (atoi(o) > 0) n = std::min(n, atoi(o));
+    }
     return std::max(1, n);
 }
 

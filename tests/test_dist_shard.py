@@ -48,7 +48,7 @@ def test_world_size_2_sharding_matches_single_process(sd, oracle, tmp_path):
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SD_ROOT=str(ROOT), SD_OUT=str(out),
-                   OMP_NUM_THREADS="2")
+                   OMP_NUM_THREADS="2", OMP_WAIT_POLICY="PASSIVE")
         procs.append(subprocess.Popen([sys.executable, "-c", WORKER], env=env))
     for p in procs:
         assert p.wait(timeout=300) == 0
