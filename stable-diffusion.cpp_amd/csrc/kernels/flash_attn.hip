@@ -46,7 +46,11 @@ __global__ __launch_bounds__(256, DKP <= 64 ? 3 : 2) void k_flash_attn(FAArgs g)
     constexpr int KROW = DKP + 8;                        // K tile row stride (halfs)
     constexpr int DCH  = DKP / 8;                        // 8-wide d chunks per key
     constexpr int NCH  = FAST ? (FA_KT * DCH + 255) / 256 : 1;  // prefetched chunks per thread (K and V each)
-    __shared__ __attribute__((aligned(16))) _Float16 smem[FA_KT * KROW + NDV * 32 * FA_VTS];
+    // FAST: two K/V tile buffers — tile t+1 is written while tile t is read, ONE barrier per tile (waves were parked at the two
+    // barriers of the single-buffer loop 47 % of their cycles, profiles/r01g_pmc_flash.txt)
+    constexpr int TILE_H = FA_KT * KROW + NDV * 32 * FA_VTS;  // halfs per tile buffer
+    constexpr int NBUF   = FAST ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) _Float16 smem[NBUF * TILE_H];
     _Float16* Ks = smem;
     _Float16* Vt = smem + FA_KT * KROW;
 
@@ -82,29 +86,53 @@ __global__ __launch_bounds__(256, DKP <= 64 ? 3 : 2) void k_flash_attn(FAArgs g)
     // ---- FAST: split staging (T14): registers hold the next tile's K and V chunks (8 halfs = 16 B each)
     half8_t kreg[NCH], vreg[NCH];
     const int nd8 = g.D / 8;  // valid 8-wide chunks per row
+    // Row sums for free: when the head dim leaves a padded output column (DV < NDV*32; d = 40, 80: yes, d = 64, 128, 160: no), row DV
+    // of V^T is set to ones and column DV of the PV accumulator becomes sum_k P[q][k] — in the same f16-rounded P the numerator
+    // uses — instead of 32 VALU adds per lane per tile.  (FAST staging needs D % 8 == 0 for the row to sit at a chunk start.)
+    const bool has_ones     = g.DV < NDV * 32 && g.D == g.DV && (!FAST || g.D % 8 == 0);
+    const bool ones_in_tile = has_ones && g.DV < DKP;  // the row is (re)written by the per-tile staging; else set once below
+    // K chunks: thread e -> (key = e / DCH, chunk = e % DCH): row-major 16-byte LDS writes.  V chunks: (key = e % 64, chunk = e / 64):
+    // lanes run along keys so the 8 transposing 2-byte LDS writes of a chunk are bank-contiguous (the (e / DCH, e % DCH) mapping
+    // put a wave's 64 lanes on ~12 banks: 31 % of all LDS cycles were conflict cycles).
+    // per-thread chunk coordinates are tile-invariant: 32-bit byte offsets against a wave-uniform tile base (SGPR base + VGPR offset loads)
+    uint32_t koff[NCH], voff[NCH];
+    int kkey[NCH], vkey_[NCH];  // key index inside the tile, or FA_KT (never valid) for chunks this thread does not fetch
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int e   = threadIdx.x + c * 256;
+        const int key = e / DCH, ch = e - key * DCH;
+        const int vkey = e & (FA_KT - 1), vch = e >> 6;
+        koff[c]  = (uint32_t)key * (uint32_t)g.k_nb1 + (uint32_t)ch * 16u;
+        voff[c]  = (uint32_t)vkey * (uint32_t)g.v_nb1 + (uint32_t)vch * 16u;
+        kkey[c]  = (e < FA_KT * DCH && ch < nd8) ? key : FA_KT;
+        vkey_[c] = (e < FA_KT * DCH && vch < nd8) ? vkey : FA_KT;
+    }
     auto gload = [&](int kt) {
+        const char* kb = kbase + (int64_t)kt * g.k_nb1;  // wave-uniform
+        const char* vb = vbase + (int64_t)kt * g.v_nb1;
+        const int left = min(g.Lk - kt, FA_KT);           // valid keys in this tile
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
-            const int e   = threadIdx.x + c * 256;
-            const int key = e / DCH, ch = e - key * DCH;
             half8_t zk = {0, 0, 0, 0, 0, 0, 0, 0};
             kreg[c] = zk;
             vreg[c] = zk;
-            if (e < FA_KT * DCH && kt + key < g.Lk && ch < nd8) {
-                kreg[c] = *(const half8_t*)(kbase + (int64_t)(kt + key) * g.k_nb1 + ch * 16);
-                vreg[c] = *(const half8_t*)(vbase + (int64_t)(kt + key) * g.v_nb1 + ch * 16);
-            }
+            if (kkey[c] < left) kreg[c] = *(const half8_t*)(kb + koff[c]);
+            if (vkey_[c] < left) vreg[c] = *(const half8_t*)(vb + voff[c]);
+            if (ones_in_tile && ((threadIdx.x + c * 256) >> 6) == nd8) vreg[c][0] = (_Float16)1.0f;  // V^T row DV = 1: PV accumulates the row sums
         }
     };
-    auto lstore = [&]() {
+    auto lstore = [&](int buf) {
+        _Float16* ks = Ks + buf * TILE_H;
+        _Float16* vt = Vt + buf * TILE_H;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int e = threadIdx.x + c * 256;
             if (e < FA_KT * DCH) {
                 const int key = e / DCH, ch = e - key * DCH;
-                *(half8_t*)&Ks[key * KROW + ch * 8] = kreg[c];
+                const int vkey = e & (FA_KT - 1), vch = e >> 6;
+                *(half8_t*)&ks[key * KROW + ch * 8] = kreg[c];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) Vt[(ch * 8 + j) * FA_VTS + key] = vreg[c][j];
+                for (int j = 0; j < 8; ++j) vt[(vch * 8 + j) * FA_VTS + vkey] = vreg[c][j];
             }
         }
     };
@@ -138,22 +166,41 @@ __global__ __launch_bounds__(256, DKP <= 64 ? 3 : 2) void k_flash_attn(FAArgs g)
                     const char* p = vbase + (int64_t)kk * g.v_nb1 + (int64_t)d * g.v_nb0;
                     v             = g.kv_f16 ? __half2float(*(const __half*)p) : *(const float*)p;
                 }
+                if (ones_in_tile && d == g.DV) v = 1.0f;
                 Vt[d * FA_VTS + key] = (_Float16)v;
             }
         }
     };
 
     // padded V^T rows (d >= DKP) are never staged: clear them once so the masked output columns stay finite
-    for (int e = threadIdx.x; e < NDV * 32 * FA_VTS / 2; e += 256) ((uint32_t*)Vt)[e] = 0u;
-    if (FAST) gload(0);
-    for (int kt = 0; kt < g.Lk; kt += FA_KT) {
-        __syncthreads();  // every wave finished reading the previous tile
-        if (FAST)
-            lstore();
-        else
-            stage_generic(kt);
+#pragma unroll
+    for (int b = 0; b < NBUF; ++b)
+        for (int e = threadIdx.x; e < NDV * 32 * FA_VTS / 2; e += 256) ((uint32_t*)(Vt + b * TILE_H))[e] = 0u;
+    if (has_ones && !ones_in_tile) {
         __syncthreads();
-        if (FAST && kt + FA_KT < g.Lk) gload(kt + FA_KT);  // in flight during this tile's MFMAs
+        if (threadIdx.x < FA_KT * NBUF) Vt[(threadIdx.x >> 6) * TILE_H + g.DV * FA_VTS + (threadIdx.x & 63)] = (_Float16)1.0f;
+    }
+    if (FAST) {
+        gload(0);
+        __syncthreads();  // the clears above
+        lstore(0);
+        if (FA_KT < g.Lk) gload(FA_KT);
+        __syncthreads();
+    }
+    int buf = 0;
+    for (int kt = 0; kt < g.Lk; kt += FA_KT) {
+        if (FAST) {
+            // tile kt sits in buffer buf (visible since the barrier that ended the previous iteration); the registers hold tile
+            // kt+64: park it in the other buffer now, then fetch kt+128 — both overlap this tile's MFMAs
+            if (kt + FA_KT < g.Lk) lstore(buf ^ 1);
+            if (kt + 2 * FA_KT < g.Lk) gload(kt + 2 * FA_KT);
+        } else {
+            __syncthreads();  // every wave finished reading the previous tile
+            stage_generic(kt);
+            __syncthreads();
+        }
+        const _Float16* Kc = Ks + (FAST ? buf * TILE_H : 0);
+        const _Float16* Vc = Vt + (FAST ? buf * TILE_H : 0);
 
         // ---- S^T = K Q^T  (rows i = key, cols j = query)
         float16_t s[2];
@@ -162,7 +209,7 @@ __global__ __launch_bounds__(256, DKP <= 64 ? 3 : 2) void k_flash_attn(FAArgs g)
             s[kb] = (float16_t){0};
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const half8_t kf = *(const half8_t*)&Ks[(kb * 32 + (lane & 31)) * KROW + ks * 16 + hi * 8];
+                const half8_t kf = *(const half8_t*)&Kc[(kb * 32 + (lane & 31)) * KROW + ks * 16 + hi * 8];
                 s[kb]            = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[kb], 0, 0, 0);
             }
         }
@@ -178,9 +225,9 @@ __global__ __launch_bounds__(256, DKP <= 64 ? 3 : 2) void k_flash_attn(FAArgs g)
                 for (int r = 0; r < 16; ++r)
                     if (kt + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= g.Lk) s[kb][r] = -INFINITY;
         }
-        float tmax = fmaxf(s[0][0], s[1][0]);
+        float tmax = s[0][0];
 #pragma unroll
-        for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, fmaxf(s[0][r], s[1][r]));
+        for (int r = 0; r < 16; ++r) tmax = __builtin_fmaxf(__builtin_fmaxf(tmax, s[0][r]), s[1][r]);  // v_max3_f32
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
         if (__any(tmax > m_run + FA_THR)) {
             const float m_new = fmaxf(m_run, tmax);
@@ -196,17 +243,18 @@ __global__ __launch_bounds__(256, DKP <= 64 ? 3 : 2) void k_flash_attn(FAArgs g)
                 for (int nb = 0; nb < NDV; ++nb) o[nb][r] *= ar;
             }
         }
-        float psum = 0.f;
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(s[kb][r] - m_run);
-                s[kb][r]      = p;
-                psum += p;
-            }
+            for (int r = 0; r < 16; ++r) s[kb][r] = __builtin_amdgcn_exp2f(s[kb][r] - m_run);
+        if (!has_ones) {
+            float psum = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) psum += s[kb][r];
+            l_run += psum;
         }
-        l_run += psum;
         // ---- O += P V : 4 k-steps of 16 keys; k-slot order = accumulator key order (see header)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -220,7 +268,7 @@ __global__ __launch_bounds__(256, DKP <= 64 ? 3 : 2) void k_flash_attn(FAArgs g)
             }
 #pragma unroll
             for (int nb = 0; nb < NDV; ++nb) {
-                const _Float16* vrow = &Vt[(nb * 32 + (lane & 31)) * FA_VTS + t * 16 + 4 * hi];
+                const _Float16* vrow = &Vc[(nb * 32 + (lane & 31)) * FA_VTS + t * 16 + 4 * hi];
                 const half4_t v0 = *(const half4_t*)vrow, v1 = *(const half4_t*)(vrow + 8);
                 half8_t vf;
                 vf[0] = v0[0];
@@ -234,19 +282,32 @@ __global__ __launch_bounds__(256, DKP <= 64 ? 3 : 2) void k_flash_attn(FAArgs g)
                 o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa, vf, o[nb], 0, 0, 0);
             }
         }
+        if (FAST) {
+            __syncthreads();  // tile kt+64 is complete in the other buffer; everybody is done reading this one
+            buf ^= 1;
+        }
     }
 
     // ---- finalise: divide by the row sum (both lane halves), write [d] contiguous
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv   = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    const int nb_l = g.DV >> 5, lane_l = (g.DV & 31) + 32 * hi;  // has_ones: accumulator column DV holds the row sums
     const int hh = g.H > 0 ? hn % g.H : hn, nn = g.H > 0 ? hn / g.H : 0;  // wave-uniform
     char* obase          = g.dst ? (char*)g.dst + (int64_t)hh * g.dst_nb_h + (int64_t)nn * g.dst_nb_n : nullptr;
     _Float16* obase16    = g.dst16 ? g.dst16 + (int64_t)nn * g.Lq * g.ld16 + (int64_t)hh * g.DV : nullptr;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row  = (r & 3) + 8 * (r >> 2) + 4 * hi;
-        const float ir = __shfl(inv, row, 64);
-        const int q    = q0 + row;
+        float ir = __shfl(inv, row, 64);
+        if (has_ones) {
+            float lsum = 0.f;
+#pragma unroll
+            for (int nb = 0; nb < NDV; ++nb)
+                if (nb == nb_l) lsum = o[nb][r];
+            lsum = __shfl(lsum, lane_l, 64);
+            ir   = lsum > 0.f ? 1.0f / lsum : 0.f;
+        }
+        const int q = q0 + row;
         if (q >= g.Lq) continue;
 #pragma unroll
         for (int nb = 0; nb < NDV; ++nb) {
