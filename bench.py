@@ -38,7 +38,7 @@ if (os.cpu_count() or 1) > 32:
     os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")  # cpu_baseline leg (OpenMP oracle) on a big shared host
 
 # algorithmic work per unit: 2*M*N*K per Linear / conv, 4*Lq*Lk*H*d per attention
-UNET_FWD_TFLOP = {"sd15": 0.803, "sdxl": 6.761}
+UNET_FWD_TFLOP = {"sd15": 0.803, "sdxl": 6.761, "sd35": 29.60}
 MFMA_PEAK_TFLOPS = 2500.0
 
 
@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--model", default="sd15", choices=["sd15", "sdxl", "sd15_tiny"])
+    ap.add_argument("--model", default="sd15", choices=["sd15", "sdxl", "sd15_tiny", "sd35", "sd35_tiny"])
     ap.add_argument("--batch", type=int, default=8, help="images per GPU (device batch)")
     ap.add_argument("--no-flash", action="store_true")
     ap.add_argument("--hip-graph", type=int, default=0)
@@ -78,23 +78,26 @@ def main():
 
     sd.load_mi355x_backend()
     L = sd.lib()
-    model_id = {"sd15": sd.SD15, "sdxl": sd.SDXL, "sd15_tiny": sd.SD15_TINY}[args.model]
+    model_id = {"sd15": sd.SD15, "sdxl": sd.SDXL, "sd15_tiny": sd.SD15_TINY, "sd35": sd.SD35_LARGE, "sd35_tiny": sd.SD35_TINY}[args.model]
     backend_name = f"MI355X{local_rank if local_rank < len([d for d in sd.devices() if d.startswith('MI355X')]) else 0}"
-    eng = sd.Engine(model=model_id, backend=backend_name, wtype=sd.Q8_0 if args.model == "sdxl" else sd.F16,
-                    flash_attn=not args.no_flash)
+    dit = args.model.startswith("sd35")
+    wtype = sd.Q8_0 if args.model == "sdxl" else (sd.BF16 if dit else sd.F16)   # BASELINE.json configs 3 / 5
+    eng = sd.Engine(model=model_id, backend=backend_name, wtype=wtype, flash_attn=not args.no_flash)
     sd.backend_set_option("hip_graph", args.hip_graph)
     if args.g16_variant >= 0:
         sd.backend_set_option("gemm16_variant", args.g16_variant)
 
     rng = np.random.default_rng(1234 + rank)
     tiny = args.model == "sd15_tiny"
-    lat = 128 if args.model == "sdxl" else (16 if tiny else 64)
-    ctx_dim = 2048 if args.model == "sdxl" else (64 if tiny else 768)
+    lat = 128 if args.model in ("sdxl", "sd35") else (16 if tiny or args.model == "sd35_tiny" else 64)
+    ctx_dim = {"sdxl": 2048, "sd35": 4096, "sd35_tiny": 96}.get(args.model, 64 if tiny else 768)
+    n_tok = 154 if dit else 77
+    y_dim = {"sdxl": 2816, "sd35": 2048, "sd35_tiny": 64}.get(args.model)
     B = args.batch
-    cond = rng.standard_normal((1, 77, ctx_dim)).astype(np.float32)
-    uncond = np.random.default_rng(1235).standard_normal((1, 77, ctx_dim)).astype(np.float32)
-    y = rng.standard_normal((1, 2816)).astype(np.float32) if args.model == "sdxl" else None
-    x = rng.standard_normal((B, 4, lat, lat)).astype(np.float32)
+    cond = rng.standard_normal((1, n_tok, ctx_dim)).astype(np.float32)
+    uncond = np.random.default_rng(1235).standard_normal((1, n_tok, ctx_dim)).astype(np.float32)
+    y = rng.standard_normal((1, y_dim)).astype(np.float32) if y_dim else None
+    x = rng.standard_normal((B, 16 if dit else 4, lat, lat)).astype(np.float32)
     t = np.full((B,), 500.0, dtype=np.float32)
 
     fuse = not args.no_fuse_cfg
@@ -171,7 +174,7 @@ def main():
         "vs_baseline": None,
         "dtype": "f16",
         "data": "synthetic",
-        "config": {"workload": f"{args.model} UNet {lat*8}x{lat*8}, cfg 7 (cond+uncond), {'q8_0 Linear + f16 conv' if args.model == 'sdxl' else 'f16'} weights, batch {B}/GPU, Euler-A step",
+        "config": {"workload": f"{args.model} {'MMDiT' if dit else 'UNet'} {lat*8}x{lat*8}, cfg 7 (cond+uncond), {'q8_0 Linear + f16 conv' if args.model == 'sdxl' else ('bf16' if dit else 'f16')} weights, batch {B}/GPU, Euler-A step",
                    "global_batch": B * world, "flash_attn": not args.no_flash, "hip_graph": args.hip_graph,
                    "cfg_pair_in_one_graph": fuse},
         "roofline": roofline,
@@ -184,7 +187,7 @@ def main():
         st = eng.stats()
         out["e2e"] = {"sec_per_image": round(e2e / B, 4), "batch": B, "steps": 20, "sample_ms": round(st["last_sample_ms"], 1),
                       "vae_decode_ms": round(st["last_decode_ms"], 1)}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not dit:  # the CPU leg is defined for the headline UNet workloads
         out["cpu_baseline"] = cpu_baseline(sd, args, lat, ctx_dim)
     if rank == 0:
         print(json.dumps(out), flush=True)
@@ -201,7 +204,7 @@ def cpu_baseline(sd, args, lat, ctx_dim):
     sd.load_backend(oracle_so)
     olib = C.CDLL(str(oracle_so))
     cores = int(olib.oracle_num_threads())
-    model_id = {"sd15": sd.SD15, "sdxl": sd.SDXL, "sd15_tiny": sd.SD15_TINY}[args.model]
+    model_id = {"sd15": sd.SD15, "sdxl": sd.SDXL, "sd15_tiny": sd.SD15_TINY, "sd35": sd.SD35_LARGE, "sd35_tiny": sd.SD35_TINY}[args.model]
     eng = sd.Engine(model=model_id, backend="CPU-oracle", wtype=sd.Q8_0 if args.model == "sdxl" else sd.F16, flash_attn=False)
     rng = np.random.default_rng(7)
     x = rng.standard_normal((1, 4, lat, lat)).astype(np.float32)

@@ -42,6 +42,9 @@ enum sd_model_family_t {
     SD_MODEL_SDXL       = 1, /* unet.hpp:47-57; VAE scale 0.13025 */
     SD_MODEL_SD15_TINY  = 2, /* same topology, model_channels 32 — CPU-sized parity tests */
     SD_MODEL_SDXL_TINY  = 3,
+    SD_MODEL_SD35_LARGE = 4, /* MMDiT, 38 joint blocks, hidden 2432, rms qk-norm (mmdit.hpp); 16-ch VAE scale 1.5305 shift 0.0609;
+                                discrete-flow denoiser, shift 3.0 (denoiser.hpp:1239-1283) */
+    SD_MODEL_SD35_TINY  = 5, /* same topology at 3 blocks / hidden 192, with one MMDiT-X self-attention block */
 };
 
 /* numeric values = enum ggml_type (stable-diffusion.h:98-143) */
@@ -143,6 +146,7 @@ SD_API void free_sd_images(sd_image_t* images, int num_images);
 /* ---- host-side sampler pieces exposed for known-answer tests ---- */
 SD_API void sd_philox_randn(uint64_t seed, uint32_t offset, uint32_t n, float* out); /* rng_philox.hpp:101-122 */
 SD_API int sd_get_sigmas(int steps, float* out /* steps+1 */);                       /* denoiser.hpp:32-54 + stable-diffusion.cpp:173-186 */
+SD_API int sd_get_flow_sigmas(int steps, float shift, float* out /* steps+1 */);    /* DiscreteFlowDenoiser, denoiser.hpp:1239-1283 (t = 1000*sigma) */
 SD_API float sd_sigma_to_t(float sigma);                                             /* denoiser.hpp:1140-1165 */
 
 /* ---- timing / introspection ---- */

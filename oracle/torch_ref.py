@@ -239,3 +239,103 @@ def vae_decode(engine, latents, scale_factor=0.18215, ch_mult=(1, 2, 4, 4)):
             h = conv(d.sub(f"up.{i}.upsample.conv."), h, padding=1)
     h = conv(d.sub("conv_out."), F.silu(group_norm(d.sub("norm_out."), h)), padding=1)
     return ((h + 1.0) * 0.5).clamp(0.0, 1.0).numpy()  # vae.hpp:24-30
+
+
+# =====================================================================================================
+# MMDiT (SD3 / SD3.5) — src/model/diffusion/mmdit.hpp, written from the model's mathematical definition
+# =====================================================================================================
+MMDIT_CFG = {
+    # name: (depth, hidden, patch, in_ch, out_ch, pos_embed_max_size, d_self, qk_rms)
+    "SD35_LARGE": (38, 2432, 2, 16, 16, 192, -1, True),
+    "SD35_TINY": (3, 192, 2, 16, 16, 24, 0, True),
+}
+
+
+def _rms(w: Weights, x, eps=1e-6):
+    # RMSNorm over the head dim, ggml_extend.hpp:3996-4023
+    return x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + eps) * w("weight")
+
+
+def _ln_plain(x, eps=1e-6):
+    return F.layer_norm(x, (x.shape[-1],), None, None, eps=eps)
+
+
+def _dit_qkv(w: Weights, x, heads, qk_rms):
+    # SelfAttention::pre_attention, mmdit.hpp:326-350: fused qkv projection, per-head RMS norm of q and k
+    B, L, C = x.shape
+    q, k, v = linear(w.sub("qkv."), x).view(B, L, 3, C).unbind(2)
+    if qk_rms:
+        q = _rms(w.sub("ln_q."), q.reshape(B, L, heads, C // heads)).reshape(B, L, C)
+        k = _rms(w.sub("ln_k."), k.reshape(B, L, heads, C // heads)).reshape(B, L, C)
+    return q, k, v
+
+
+def _modulate(x, shift, scale):
+    # mmdit.hpp:368-380
+    return x * (1 + scale[:, None, :]) + shift[:, None, :]
+
+
+def _dit_block_pre(w: Weights, x, c, heads, qk_rms, pre_only, self_attn):
+    n_mods = 9 if self_attn else (2 if pre_only else 6)
+    m = linear(w.sub("adaLN_modulation.1."), F.silu(c)).chunk(n_mods, dim=-1)
+    xn = _ln_plain(x)
+    qkv = _dit_qkv(w.sub("attn."), _modulate(xn, m[0], m[1]), heads, qk_rms)
+    qkv2 = _dit_qkv(w.sub("attn2."), _modulate(xn, m[6], m[7]), heads, qk_rms) if self_attn else None
+    return qkv, qkv2, m
+
+
+def _dit_block_post(w: Weights, x, attn_out, attn2_out, m, self_attn):
+    # DismantledBlock::post_attention(_x), mmdit.hpp:491-556
+    x = x + linear(w.sub("attn.proj."), attn_out) * m[2][:, None, :]
+    if self_attn:
+        x = x + linear(w.sub("attn2.proj."), attn2_out) * m[8][:, None, :]
+    h = _modulate(_ln_plain(x), m[3], m[4])
+    h = linear(w.sub("mlp.fc2."), F.gelu(linear(w.sub("mlp.fc1."), h), approximate="tanh"))
+    return x + h * m[5][:, None, :]
+
+
+def mmdit_forward(engine, model: str, x, timesteps, context, y=None):
+    """x [N,16,H,W], timesteps [N], context [N,L,context_size], y [N,adm] -> [N,16,H,W]  (MMDiT::forward, mmdit.hpp:881-927)"""
+    depth, hidden, ps, in_ch, out_ch, pmax, d_self, qk_rms = MMDIT_CFG[model]
+    w = Weights(engine, "model.diffusion_model.")
+    x = torch.from_numpy(x).float()
+    t = torch.from_numpy(timesteps).float()
+    context = torch.from_numpy(context).float()
+    N, _, H, W = x.shape
+    if context.shape[0] != N:
+        context = context.repeat(N // context.shape[0], 1, 1)
+    pad_h, pad_w = (ps - H % ps) % ps, (ps - W % ps) % ps
+    xp = F.pad(x, (0, pad_w, 0, pad_h))
+    tok = F.conv2d(xp, w("x_embedder.proj.weight"), w("x_embedder.proj.bias"), stride=ps)  # [N, hidden, h, w]
+    h_, w_ = tok.shape[2], tok.shape[3]
+    tok = tok.flatten(2).transpose(1, 2)  # [N, h*w, hidden]
+    # cropped_pos_embed, mmdit.hpp:808-847: centre crop of the [pmax, pmax] table
+    pe = w("pos_embed").reshape(pmax, pmax, hidden)
+    hh, ww = (H + 1) // ps, (W + 1) // ps
+    top, left = (pmax - hh) // 2, (pmax - ww) // 2
+    pe = pe[top:top + hh, left:left + ww].reshape(1, hh * ww, hidden)
+    xt = tok + pe
+    c = linear(w.sub("t_embedder.mlp.2."), F.silu(linear(w.sub("t_embedder.mlp.0."), timestep_embedding(t, 256))))
+    if y is not None:
+        yy = torch.from_numpy(y).float()
+        if yy.shape[0] != N:
+            yy = yy.repeat(N // yy.shape[0], 1)
+        c = c + linear(w.sub("y_embedder.mlp.2."), F.silu(linear(w.sub("y_embedder.mlp.0."), yy)))
+    ctx = linear(w.sub("context_embedder."), context)
+    heads = depth
+    for i in range(depth):
+        wb = w.sub(f"joint_blocks.{i}.")
+        pre_only = i == depth - 1
+        self_attn = i <= d_self
+        cq, _, cm = _dit_block_pre(wb.sub("context_block."), ctx, c, heads, qk_rms, pre_only, False)
+        xq, xq2, xm = _dit_block_pre(wb.sub("x_block."), xt, c, heads, qk_rms, False, self_attn)
+        Lc = ctx.shape[1]
+        joint = attention(torch.cat([cq[0], xq[0]], 1), torch.cat([cq[1], xq[1]], 1), torch.cat([cq[2], xq[2]], 1), heads)
+        attn2 = attention(*xq2, heads) if self_attn else None
+        new_ctx = None if pre_only else _dit_block_post(wb.sub("context_block."), ctx, joint[:, :Lc], None, cm, False)
+        xt = _dit_block_post(wb.sub("x_block."), xt, joint[:, Lc:], attn2, xm, self_attn)
+        ctx = new_ctx
+    shift, scale = linear(w.sub("final_layer.adaLN_modulation.1."), F.silu(c)).chunk(2, dim=-1)
+    out = linear(w.sub("final_layer.linear."), _modulate(_ln_plain(xt), shift, scale))  # [N, h*w, ps*ps*C] with C fastest
+    out = out.view(N, h_, w_, ps, ps, out_ch).permute(0, 5, 1, 3, 2, 4).reshape(N, out_ch, h_ * ps, w_ * ps)
+    return out[:, :, :H, :W].contiguous().numpy()

@@ -26,7 +26,7 @@ F32, F16, Q4_0, Q8_0, I32, BF16 = 0, 1, 2, 8, 26, 30
 TYPE_SIZE = {F32: 4, F16: 2, BF16: 2, I32: 4}
 
 # sd_model_family_t
-SD15, SDXL, SD15_TINY, SDXL_TINY = 0, 1, 2, 3
+SD15, SDXL, SD15_TINY, SDXL_TINY, SD35_LARGE, SD35_TINY = 0, 1, 2, 3, 4, 5
 EULER, EULER_A = 0, 1
 
 
@@ -238,6 +238,7 @@ def lib() -> C.CDLL:
     L.free_sd_images.argtypes = [C.POINTER(SdImage), C.c_int]
     L.sd_philox_randn.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p]
     L.sd_get_sigmas.argtypes = [C.c_int, C.c_void_p]
+    L.sd_get_flow_sigmas.argtypes = [C.c_int, C.c_float, C.c_void_p]
     L.sd_sigma_to_t.argtypes = [C.c_float]
     L.sd_sigma_to_t.restype = C.c_float
     L.sd_get_stats.argtypes = [C.c_void_p, C.POINTER(SdStats)]
@@ -459,7 +460,7 @@ class Engine:
     def sample_latents(self, cond, uncond=None, width=512, height=512, steps=20, cfg=7.0, seed=42, batch=1, device_batch=0,
                        method=EULER_A, eta=float("inf"), cond_y=None, uncond_y=None, fuse_cfg=False) -> np.ndarray:
         p, keep = self._gen_params(cond, uncond, width, height, steps, cfg, seed, batch, device_batch, method, eta, cond_y, uncond_y, fuse_cfg)
-        ch = 4
+        ch = 16 if self.model in (SD35_LARGE, SD35_TINY) else 4
         out = np.empty((batch, ch, height // 8, width // 8), dtype=np.float32)
         if not lib().sd_sample_latents(self._ctx, C.byref(p), _fptr(out)):
             raise EngineError("sd_sample_latents failed: " + lib().sd_last_error().decode())
@@ -494,4 +495,11 @@ def philox_randn(seed: int, offset: int, n: int) -> np.ndarray:
 def get_sigmas(steps: int) -> np.ndarray:
     out = np.empty(steps + 1, dtype=np.float32)
     lib().sd_get_sigmas(steps, _fptr(out))
+    return out
+
+
+def get_flow_sigmas(steps: int, shift: float = 3.0) -> np.ndarray:
+    """DiscreteFlowDenoiser sigma ladder (SD3 / SD3.5), src/runtime/denoiser.hpp:1239-1283"""
+    out = np.empty(steps + 1, dtype=np.float32)
+    lib().sd_get_flow_sigmas(steps, shift, _fptr(out))
     return out

@@ -317,7 +317,11 @@ bool linear_fast_ok(const ggml_tensor* n) {
     if (!(w->type == GGML_TYPE_F16 || w->type == GGML_TYPE_F32 || w->type == GGML_TYPE_BF16 || w->type == GGML_TYPE_Q8_0 || w->type == GGML_TYPE_Q4_0)) return false;
     if (w->ne[2] != 1 || w->ne[3] != 1 || !contig(w)) return false;
     if (x->nb[0] != 4 || x->ne[0] % 4 != 0 || x->nb[1] % 16 != 0 || !aligned16(x->data)) return false;
-    if (x->ne[2] > 1 && x->nb[2] != x->nb[1] * (size_t)x->ne[1]) return false;
+    if (x->ne[2] > 1 && x->nb[2] != x->nb[1] * (size_t)x->ne[1]) {
+        // a token slice of a [C, L, N] tensor (MMDiT block_mixing, mmdit.hpp:651-667): rows are N runs with the parent's batch stride — the
+        // gemm16 pack kernel takes that stride; the first-generation path does not
+        if (!g_opt.gemm16 || x->ne[3] != 1 || x->nb[2] % 16 != 0) return false;
+    }
     if (x->ne[3] > 1 && x->nb[3] != x->nb[2] * (size_t)x->ne[2]) return false;
     if (!contig(n)) return false;
     return true;
@@ -438,7 +442,9 @@ void plan_linear(Builder& B, int i, hipStream_t s, std::vector<int>& chain) {
             Packed pk{B.alloc((size_t)tokens * rup64(K) * 2), rup64(K), false};
             Planner* P = B.P;
             const size_t off = pk.off;
-            B.emit([=](hipStream_t st) { launch_pack_rows_f16(st, P->arena + off, xp, tokens, K, xs); });
+            const bool runs  = x->ne[2] > 1 && x->nb[2] != x->nb[1] * (size_t)x->ne[1];
+            const int64_t pL = runs ? x->ne[1] : 0, pbs = runs ? (int64_t)x->nb[2] / 4 : 0;
+            B.emit([=](hipStream_t st) { launch_pack_rows_f16(st, P->arena + off, xp, tokens, K, xs, pL, pbs); });
             it = B.packed.emplace(key, pk).first;
             if (it->second.nhwc) it->second = pk;
         }

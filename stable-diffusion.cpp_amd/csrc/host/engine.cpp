@@ -177,8 +177,21 @@ struct sd_ctx_t {
     ggml_backend_t backend = nullptr;
     Runner unet_runner, vae_runner;
     UNetModel unet;
+    MMDiTModel mmdit;
+    bool is_dit = false;
     VaeDecoder vae;
     CompVisDenoiser denoiser;
+    DiscreteFlowDenoiser flow_denoiser;
+    int in_channels() const { return is_dit ? (int)mmdit.cfg.in_channels : unet.cfg.in_channels; }
+    int out_channels() const { return is_dit ? (int)mmdit.cfg.out_channels : unet.cfg.out_channels; }
+    std::vector<float> get_sigmas(uint32_t n) const { return is_dit ? flow_denoiser.get_sigmas(n) : denoiser.get_sigmas(n); }
+    void scalings(float sigma, float& c_skip, float& c_out, float& c_in) const {
+        if (is_dit)
+            flow_denoiser.scalings(sigma, c_skip, c_out, c_in);
+        else
+            denoiser.scalings(sigma, c_skip, c_out, c_in);
+    }
+    float sigma_to_t(float sigma) const { return is_dit ? flow_denoiser.sigma_to_t(sigma) : denoiser.sigma_to_t(sigma); }
     sd_stats_t stats{};
     std::vector<std::pair<std::string, ggml_tensor*>> all_tensors;
     ~sd_ctx_t() {
@@ -269,13 +282,26 @@ sd_ctx_t* new_sd_ctx(const sd_ctx_params_t* params) {
 
     const bool xl   = params->model == SD_MODEL_SDXL || params->model == SD_MODEL_SDXL_TINY;
     const bool tiny = params->model == SD_MODEL_SD15_TINY || params->model == SD_MODEL_SDXL_TINY;
+    const bool dit      = params->model == SD_MODEL_SD35_LARGE || params->model == SD_MODEL_SD35_TINY;
+    const bool dit_tiny = params->model == SD_MODEL_SD35_TINY;
     UNetConfig ucfg = tiny ? UNetConfig::tiny(xl) : (xl ? UNetConfig::sdxl_base() : UNetConfig::sd15());
-    VaeConfig vcfg  = tiny ? VaeConfig::tiny() : (xl ? VaeConfig::sdxl() : VaeConfig::sd15());
+    VaeConfig vcfg  = (tiny || dit_tiny) ? VaeConfig::tiny() : (xl ? VaeConfig::sdxl() : VaeConfig::sd15());
     if (tiny && xl) vcfg.scale_factor = 0.13025f;
+    if (dit) {  // SD3 VAE: 16 latent channels, no post_quant_conv (auto_encoder_kl.hpp:548-556, 682-684)
+        vcfg.z_channels   = 16;
+        vcfg.use_quant    = false;
+        vcfg.scale_factor = 1.5305f;
+        vcfg.shift_factor = 0.0609f;
+    }
 
     ctx->unet_runner.backend        = backend;
     ctx->unet_runner.ps.linear_type = (ggml_type)params->wtype;
-    ctx->unet.init(ctx->unet_runner.ps, "model.diffusion_model.", ucfg);  // prefix: stable-diffusion.cpp:1337
+    ctx->is_dit                     = dit;
+    if (dit) {
+        ctx->unet_runner.graph_size = 10240 * 8;  // MMDIT_GRAPH_SIZE (mmdit.hpp:14) x our batch headroom
+        ctx->mmdit.init(ctx->unet_runner.ps, "model.diffusion_model.", dit_tiny ? MMDiTConfig::tiny() : MMDiTConfig::sd35_large());
+    } else
+        ctx->unet.init(ctx->unet_runner.ps, "model.diffusion_model.", ucfg);  // prefix: stable-diffusion.cpp:1337
     ctx->vae_runner.backend        = backend;
     ctx->vae_runner.ps.linear_type = GGML_TYPE_F16;
     ctx->vae_runner.graph_size     = 20480;
@@ -362,9 +388,9 @@ bool sd_unet_forward(sd_ctx_t* ctx, const float* x, int w, int h, int c, int n, 
             ggml_set_input(ty);
             in.push_back({ty, y, ggml_nbytes(ty)});
         }
-        return ctx->unet.forward(g, tx, tt, tc, ty);
+        return ctx->is_dit ? ctx->mmdit.forward(g, tx, tt, tc, ty) : ctx->unet.forward(g, tx, tt, tc, ty);
     };
-    const bool ok = r.compute(build, out, (size_t)w * h * ctx->unet.cfg.out_channels * n * sizeof(float));
+    const bool ok = r.compute(build, out, (size_t)w * h * ctx->out_channels() * n * sizeof(float));
     ctx->stats.unet_calls  = r.calls;
     ctx->stats.graph_nodes = r.last_nodes;
     if (r.galloc) ctx->stats.compute_buffer_bytes = ggml_gallocr_get_buffer_size(r.galloc, 0);
@@ -399,12 +425,12 @@ bool sd_vae_decode(sd_ctx_t* ctx, const float* latents, int w, int h, int c, int
 
 // ---- sample(): the denoise loop -------------------------------------------------------------------
 static bool sample_group(sd_ctx_t* ctx, const sd_img_gen_params_t* p, int b0, int nb, float* out) {
-    const int W = p->width / 8, H = p->height / 8, C = ctx->unet.cfg.in_channels;
+    const int W = p->width / 8, H = p->height / 8, C = ctx->in_channels();
     const size_t per = (size_t)W * H * C;
     const sd_sample_params_t& sp = p->sample_params;
     float eta = sp.eta;
     if (eta == INFINITY) eta = sp.sample_method == EULER_A_SAMPLE_METHOD ? 1.0f : 0.0f;  // resolve_eta, stable-diffusion.cpp:4024-4049
-    const std::vector<float> sigmas = ctx->denoiser.get_sigmas(sp.sample_steps);
+    const std::vector<float> sigmas = ctx->get_sigmas(sp.sample_steps);
     const int steps                 = (int)sigmas.size() - 1;
 
     // per-image RNG: seed+b; initial noise consumes offset 0 (stable-diffusion.cpp:5678-5683; rng == sampler_rng :886-889)
@@ -421,8 +447,8 @@ static bool sample_group(sd_ctx_t* ctx, const sd_img_gen_params_t* p, int b0, in
     for (int i = 0; i < steps; ++i) {
         const float sigma = sigmas[i], sigma_to = sigmas[i + 1];
         float c_skip, c_out, c_in;
-        ctx->denoiser.scalings(sigma, c_skip, c_out, c_in);
-        const float t = ctx->denoiser.sigma_to_t(sigma);
+        ctx->scalings(sigma, c_skip, c_out, c_in);
+        const float t = ctx->sigma_to_t(sigma);
         for (int b = 0; b < nb; ++b) ts[b] = t;
         for (size_t k = 0; k < x.size(); ++k) noised[k] = x[k] * c_in;  // stable-diffusion.cpp:2662
         auto run = [&](const sd_condition_t& cd, float* dst) {
@@ -498,7 +524,7 @@ static bool sample_group(sd_ctx_t* ctx, const sd_img_gen_params_t* p, int b0, in
 }
 
 bool sd_sample_latents(sd_ctx_t* ctx, const sd_img_gen_params_t* p, float* out_latents) {
-    const int W = p->width / 8, H = p->height / 8, C = ctx->unet.cfg.in_channels;
+    const int W = p->width / 8, H = p->height / 8, C = ctx->in_channels();
     const size_t per = (size_t)W * H * C;
     const int group  = p->device_batch > 0 ? p->device_batch : p->batch_count;
     const double t0  = now_ms();
@@ -517,7 +543,7 @@ static inline uint8_t float_to_u8(float v) {  // preprocessing.hpp:27-35
 }
 
 bool generate_image(sd_ctx_t* ctx, const sd_img_gen_params_t* p, sd_image_t** images_out, int* num_images_out) {
-    const int W = p->width / 8, H = p->height / 8, C = ctx->unet.cfg.in_channels;
+    const int W = p->width / 8, H = p->height / 8, C = ctx->in_channels();
     const size_t per = (size_t)W * H * C;
     std::vector<float> latents(per * p->batch_count);
     if (!sd_sample_latents(ctx, p, latents.data())) return false;
@@ -567,6 +593,13 @@ void sd_philox_randn(uint64_t seed, uint32_t offset, uint32_t n, float* out) {
 }
 int sd_get_sigmas(int steps, float* out) {
     static CompVisDenoiser d;
+    std::vector<float> s = d.get_sigmas(steps);
+    memcpy(out, s.data(), s.size() * sizeof(float));
+    return (int)s.size();
+}
+int sd_get_flow_sigmas(int steps, float shift, float* out) {
+    DiscreteFlowDenoiser d;
+    d.shift              = shift;
     std::vector<float> s = d.get_sigmas(steps);
     memcpy(out, s.data(), s.size() * sizeof(float));
     return (int)s.size();

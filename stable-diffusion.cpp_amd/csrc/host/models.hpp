@@ -359,4 +359,244 @@ struct VaeDecoder {
     }
 };
 
+// =====================================================================================================
+// MMDiT (SD3 / SD3.5) — src/model/diffusion/mmdit.hpp
+// =====================================================================================================
+// MMDiTConfig — mmdit.hpp:16-136 (what detect_from_weights derives for SD3.5-large: 38 joint blocks, hidden 64*depth = 2432,
+// heads = depth, rms qk-norm, no MMDiT-X self-attention blocks)
+struct MMDiTConfig {
+    int patch_size             = 2;
+    int64_t in_channels        = 16;
+    int64_t d_self             = -1;  // >= 0 for MMDiT-X (SD3.5-medium)
+    int64_t depth              = 24;
+    float mlp_ratio            = 4.0f;
+    int64_t adm_in_channels    = 2048;
+    int64_t out_channels       = 16;
+    int64_t pos_embed_max_size = 192;
+    int64_t context_size       = 4096;
+    int64_t hidden_size        = 1536;
+    bool qk_rms                = false;
+
+    static MMDiTConfig sd35_large() {
+        MMDiTConfig c;
+        c.depth       = 38;
+        c.hidden_size = 64 * 38;
+        c.qk_rms      = true;
+        return c;
+    }
+    // same topology at CPU-test size (last block pre_only, rms qk-norm, one MMDiT-X block to cover that path)
+    static MMDiTConfig tiny() {
+        MMDiTConfig c;
+        c.depth              = 3;
+        c.hidden_size        = 64 * 3;
+        c.qk_rms             = true;
+        c.adm_in_channels    = 64;
+        c.context_size       = 96;
+        c.pos_embed_max_size = 24;
+        c.d_self             = 0;
+        return c;
+    }
+};
+
+// mmdit.hpp:299-366
+struct DitSelfAttention {
+    int64_t num_heads = 0;
+    bool pre_only     = false, qk_rms = false;
+    Linear qkv, proj;
+    RMSNorm ln_q, ln_k;
+    void init(ParamStore& ps, const std::string& prefix, int64_t dim, int64_t heads, bool rms, bool pre_only_) {
+        num_heads = heads;
+        pre_only  = pre_only_;
+        qk_rms    = rms;
+        qkv.init(ps, prefix + "qkv.", dim, dim * 3, true);
+        if (!pre_only) proj.init(ps, prefix + "proj.", dim, dim);
+        if (rms) {
+            ln_q.init(ps, prefix + "ln_q.", dim / heads);
+            ln_k.init(ps, prefix + "ln_k.", dim / heads);
+        }
+    }
+    std::vector<ggml_tensor*> pre_attention(GraphCtx& g, ggml_tensor* x) const {
+        ggml_context* c = g.ctx;
+        auto v3         = split_qkv(c, qkv.forward(g, x));
+        const int64_t hd = v3[0]->ne[0] / num_heads;
+        ggml_tensor* q  = ggml_reshape_4d(c, v3[0], hd, num_heads, v3[0]->ne[1], v3[0]->ne[2]);
+        ggml_tensor* k  = ggml_reshape_4d(c, v3[1], hd, num_heads, v3[1]->ne[1], v3[1]->ne[2]);
+        if (qk_rms) {
+            q = ln_q.forward(g, q);
+            k = ln_k.forward(g, k);
+        }
+        q = ggml_reshape_3d(c, q, q->ne[0] * q->ne[1], q->ne[2], q->ne[3]);
+        k = ggml_reshape_3d(c, k, k->ne[0] * k->ne[1], k->ne[2], k->ne[3]);
+        return {q, k, v3[2]};
+    }
+};
+
+// DismantledBlock — mmdit.hpp:382-612
+struct DismantledBlock {
+    int64_t num_heads = 0;
+    bool pre_only = false, self_attn = false;
+    PlainLayerNorm norm1, norm2;
+    DitSelfAttention attn, attn2;
+    Mlp mlp;
+    Linear adaLN;
+    void init(ParamStore& ps, const std::string& prefix, int64_t hidden, int64_t heads, float mlp_ratio, bool rms, bool pre_only_, bool self_attn_) {
+        num_heads = heads;
+        pre_only  = pre_only_;
+        self_attn = self_attn_;
+        attn.init(ps, prefix + "attn.", hidden, heads, rms, pre_only);
+        if (self_attn) attn2.init(ps, prefix + "attn2.", hidden, heads, rms, false);
+        if (!pre_only) mlp.init(ps, prefix + "mlp.", hidden, (int64_t)(hidden * mlp_ratio));
+        const int64_t n_mods = self_attn ? 9 : (pre_only ? 2 : 6);
+        adaLN.init(ps, prefix + "adaLN_modulation.1.", hidden, n_mods * hidden);
+    }
+    struct Pre {
+        std::vector<ggml_tensor*> qkv, qkv2, inter;  // inter: x, gate_msa, shift_mlp, scale_mlp, gate_mlp[, gate_msa2]
+    };
+    Pre pre_attention(GraphCtx& g, ggml_tensor* x, ggml_tensor* cvec) const {
+        ggml_context* c = g.ctx;
+        const int n_mods = self_attn ? 9 : (pre_only ? 2 : 6);
+        ggml_tensor* m   = adaLN.forward(g, ggml_silu(c, cvec));
+        auto mv          = ext_chunk(c, m, n_mods, 0, true);
+        Pre r;
+        if (self_attn) {  // pre_attention_x, mmdit.hpp:424-457
+            ggml_tensor* xn = norm1.forward(g, x);
+            r.qkv           = attn.pre_attention(g, modulate(c, xn, mv[0], mv[1]));
+            r.qkv2          = attn2.pre_attention(g, modulate(c, xn, mv[6], mv[7]));
+            r.inter         = {x, mv[2], mv[3], mv[4], mv[5], mv[8]};
+        } else {
+            r.qkv = attn.pre_attention(g, modulate(c, norm1.forward(g, x), mv[0], mv[1]));
+            if (!pre_only) r.inter = {x, mv[2], mv[3], mv[4], mv[5]};
+        }
+        return r;
+    }
+    ggml_tensor* post_attention(GraphCtx& g, ggml_tensor* attn_out, ggml_tensor* attn2_out, const std::vector<ggml_tensor*>& it) const {
+        ggml_context* c = g.ctx;
+        ggml_tensor* x  = it[0];
+        auto gate3      = [&](ggml_tensor* t) { return ggml_reshape_3d(c, t, t->ne[0], 1, t->ne[1]); };
+        ggml_tensor *gate_msa = gate3(it[1]), *gate_mlp = gate3(it[4]);
+        attn_out = attn.proj.forward(g, attn_out);
+        if (self_attn) {
+            ggml_tensor* gate_msa2 = gate3(it[5]);
+            attn2_out              = attn2.proj.forward(g, attn2_out);
+            x                      = ggml_add(c, x, ggml_mul(c, attn_out, gate_msa));
+            x                      = ggml_add(c, x, ggml_mul(c, attn2_out, gate_msa2));
+        } else {
+            x = ggml_add(c, x, ggml_mul(c, attn_out, gate_msa));
+        }
+        ggml_tensor* mlp_out = mlp.forward(g, modulate(c, norm2.forward(g, x), it[2], it[3]));
+        return ggml_add(c, x, ggml_mul(c, mlp_out, gate_mlp));
+    }
+};
+
+struct MMDiTModel {
+    MMDiTConfig cfg;
+    Conv2d x_embedder;
+    Linear t_mlp0, t_mlp2, y_mlp0, y_mlp2, context_embedder, final_linear, final_adaLN;
+    PlainLayerNorm norm_final;
+    ggml_tensor* pos_embed = nullptr;
+    struct Joint {
+        DismantledBlock context_block, x_block;
+    };
+    std::vector<Joint> blocks;
+
+    void init(ParamStore& ps, const std::string& prefix, const MMDiTConfig& c) {
+        cfg = c;
+        x_embedder.init(ps, prefix + "x_embedder.proj.", cfg.in_channels, cfg.hidden_size, cfg.patch_size, cfg.patch_size, 0);
+        pos_embed = ps.add(prefix + "pos_embed", GGML_TYPE_F32, {cfg.hidden_size, cfg.pos_embed_max_size * cfg.pos_embed_max_size, 1}, InitKind::BIAS, cfg.hidden_size);
+        t_mlp0.init(ps, prefix + "t_embedder.mlp.0.", 256, cfg.hidden_size, true, false, true);
+        t_mlp2.init(ps, prefix + "t_embedder.mlp.2.", cfg.hidden_size, cfg.hidden_size, true, false, true);
+        y_mlp0.init(ps, prefix + "y_embedder.mlp.0.", cfg.adm_in_channels, cfg.hidden_size, true, false, true);
+        y_mlp2.init(ps, prefix + "y_embedder.mlp.2.", cfg.hidden_size, cfg.hidden_size, true, false, true);
+        context_embedder.init(ps, prefix + "context_embedder.", cfg.context_size, cfg.hidden_size, true, false, true);
+        blocks.resize(cfg.depth);
+        for (int64_t i = 0; i < cfg.depth; ++i) {  // heads = depth (mmdit.hpp:799), qkv_bias true, last context block pre_only
+            const std::string p = prefix + "joint_blocks." + std::to_string(i) + ".";
+            blocks[i].context_block.init(ps, p + "context_block.", cfg.hidden_size, cfg.depth, cfg.mlp_ratio, cfg.qk_rms, i == cfg.depth - 1, false);
+            blocks[i].x_block.init(ps, p + "x_block.", cfg.hidden_size, cfg.depth, cfg.mlp_ratio, cfg.qk_rms, false, i <= cfg.d_self);
+        }
+        final_linear.init(ps, prefix + "final_layer.linear.", cfg.hidden_size, cfg.patch_size * cfg.patch_size * cfg.out_channels, true, false, true);
+        final_adaLN.init(ps, prefix + "final_layer.adaLN_modulation.1.", cfg.hidden_size, 2 * cfg.hidden_size);
+    }
+
+    // cropped_pos_embed — mmdit.hpp:808-847
+    ggml_tensor* cropped_pos_embed(ggml_context* c, int64_t h, int64_t w) const {
+        h = (h + 1) / cfg.patch_size;
+        w = (w + 1) / cfg.patch_size;
+        const int64_t top = (cfg.pos_embed_max_size - h) / 2, left = (cfg.pos_embed_max_size - w) / 2;
+        ggml_tensor* sp = ggml_reshape_3d(c, pos_embed, cfg.hidden_size, cfg.pos_embed_max_size, cfg.pos_embed_max_size);
+        sp = ggml_view_3d(c, sp, cfg.hidden_size, cfg.pos_embed_max_size, h, sp->nb[1], sp->nb[2], sp->nb[2] * top);
+        sp = ggml_cont(c, ggml_permute(c, sp, 0, 2, 1, 3));
+        sp = ggml_view_3d(c, sp, cfg.hidden_size, h, w, sp->nb[1], sp->nb[2], sp->nb[2] * left);
+        sp = ggml_cont(c, ggml_permute(c, sp, 0, 2, 1, 3));
+        return ggml_reshape_3d(c, sp, cfg.hidden_size, h * w, 1);
+    }
+
+    // block_mixing — mmdit.hpp:614-699
+    void block_mixing(GraphCtx& g, const Joint& jb, ggml_tensor*& context, ggml_tensor*& x, ggml_tensor* cvec) const {
+        ggml_context* c = g.ctx;
+        auto cp         = jb.context_block.pre_attention(g, context, cvec);
+        auto xp         = jb.x_block.pre_attention(g, x, cvec);
+        std::vector<ggml_tensor*> qkv;
+        for (int i = 0; i < 3; ++i) qkv.push_back(ggml_concat(c, cp.qkv[i], xp.qkv[i], 1));
+        ggml_tensor* attn = ext_attention(g, qkv[0], qkv[1], qkv[2], jb.x_block.num_heads);  // [hidden, n_context + n_token, N]
+        ggml_tensor* context_attn = ggml_view_3d(c, attn, attn->ne[0], context->ne[1], attn->ne[2], attn->nb[1], attn->nb[2], 0);
+        ggml_tensor* x_attn       = ggml_view_3d(c, attn, attn->ne[0], x->ne[1], attn->ne[2], attn->nb[1], attn->nb[2], context->ne[1] * attn->nb[1]);
+        ggml_tensor* new_context  = jb.context_block.pre_only ? nullptr : jb.context_block.post_attention(g, context_attn, nullptr, cp.inter);
+        if (jb.x_block.self_attn) {
+            ggml_tensor* attn2 = ext_attention(g, xp.qkv2[0], xp.qkv2[1], xp.qkv2[2], jb.x_block.num_heads);
+            x                  = jb.x_block.post_attention(g, x_attn, attn2, xp.inter);
+        } else {
+            x = jb.x_block.post_attention(g, x_attn, nullptr, xp.inter);
+        }
+        context = new_context;
+    }
+
+    // forward — mmdit.hpp:881-927.  x [W,H,C,N]; timesteps [N]; context [context_size, L, N|1|2]; y [adm, N|1|2] -> [W,H,C,N]
+    ggml_tensor* forward(GraphCtx& g, ggml_tensor* x, ggml_tensor* timesteps, ggml_tensor* context, ggml_tensor* y) const {
+        ggml_context* c = g.ctx;
+        const int64_t W = x->ne[0], H = x->ne[1], N = x->ne[3];
+        // OUR extension (batch > 1 per graph): conditioning given once (or once per cfg branch) is tiled over the images
+        if (context != nullptr && context->ne[2] != N) context = ggml_repeat(c, context, ggml_new_tensor_3d(c, GGML_TYPE_F32, context->ne[0], context->ne[1], N));
+        if (y != nullptr && y->ne[1] != N) y = ggml_repeat(c, y, ggml_new_tensor_2d(c, GGML_TYPE_F32, y->ne[0], N));
+
+        // PatchEmbed (mmdit.hpp:216-243): pad to the patch grid, stride-p conv, flatten to tokens
+        const int ps_ = cfg.patch_size;
+        const int pad_h = (ps_ - (int)(H % ps_)) % ps_, pad_w = (ps_ - (int)(W % ps_)) % ps_;
+        ggml_tensor* pe = ggml_pad(c, x, pad_w, pad_h, 0, 0);
+        pe              = x_embedder.forward(g, pe);
+        pe              = ggml_reshape_3d(c, pe, pe->ne[0] * pe->ne[1], pe->ne[2], pe->ne[3]);
+        pe              = ggml_cont(c, ggml_permute(c, pe, 1, 0, 2, 3));  // [hidden, h*w, N]
+        x               = ggml_add(c, pe, cropped_pos_embed(c, H, W));
+
+        ggml_tensor* cv = ggml_timestep_embedding(c, ext_scale(c, timesteps, 1.0f), 256, 10000);  // TimestepEmbedder, mmdit.hpp:245-272
+        cv              = t_mlp0.forward(g, cv);
+        cv              = ggml_silu_inplace(c, cv);
+        cv              = t_mlp2.forward(g, cv);
+        if (y != nullptr) {  // VectorEmbedder, mmdit.hpp:274-297
+            ggml_tensor* ye = y_mlp0.forward(g, y);
+            ye              = ggml_silu_inplace(c, ye);
+            ye              = y_mlp2.forward(g, ye);
+            cv              = ggml_add(c, cv, ye);
+        }
+        if (context != nullptr) context = context_embedder.forward(g, context);
+        for (auto& jb : blocks) block_mixing(g, jb, context, x, cv);
+
+        // FinalLayer — mmdit.hpp:725-757
+        auto mv = ext_chunk(c, final_adaLN.forward(g, ggml_silu(c, cv)), 2, 0, true);
+        x       = modulate(c, norm_final.forward(g, x), mv[0], mv[1]);
+        x       = final_linear.forward(g, x);
+
+        // DiT::unpatchify_and_crop(patch_last = false) — dit.hpp:36-104
+        const int64_t h = (H + pad_h) / ps_, w = (W + pad_w) / ps_, C = cfg.out_channels;
+        x = ggml_reshape_4d(c, x, C, ps_ * ps_, w * h, N);
+        x = ggml_cont(c, ggml_permute(c, x, 2, 0, 1, 3));  // [ph*pw, h*w, C, N]
+        x = ggml_reshape_4d(c, x, ps_, ps_, w, h * C * N);
+        x = ggml_cont(c, ggml_permute(c, x, 0, 2, 1, 3));
+        x = ggml_reshape_4d(c, x, w * ps_, h * ps_, C, N);
+        x = ext_slice(c, x, 1, 0, H);
+        x = ext_slice(c, x, 0, 0, W);
+        return x;
+    }
+};
+
 }  // namespace sdmi

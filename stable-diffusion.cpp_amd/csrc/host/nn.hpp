@@ -191,10 +191,10 @@ struct Linear {
     ggml_tensor *w = nullptr, *b = nullptr;
     bool force_prec_f32 = false;
     float scale         = 1.f;
-    void init(ParamStore& ps, const std::string& prefix, int64_t in, int64_t out, bool bias = true, bool never_quant = false) {
+    void init(ParamStore& ps, const std::string& prefix, int64_t in, int64_t out, bool bias = true, bool never_quant = false, bool force_f32 = false) {
         ggml_type t = ps.linear_type;
         if (never_quant && ggml_is_quantized(t)) t = GGML_TYPE_F16;  // model_loader.cpp:1517-1539
-        if (in % ggml_blck_size(t) != 0) t = GGML_TYPE_F32;
+        if (in % ggml_blck_size(t) != 0 || force_f32) t = GGML_TYPE_F32;  // ggml_extend.hpp:3422-3425
         w = ps.add(prefix + "weight", t, {in, out}, InitKind::WEIGHT, in);
         if (bias) b = ps.add(prefix + "bias", GGML_TYPE_F32, {out}, InitKind::BIAS, in);
     }
@@ -393,6 +393,69 @@ struct SpatialTransformer {
             x = proj_out_c.forward(g, x);
         }
         return ggml_add(c, x, x_in);
+    }
+};
+
+// ---- DiT building blocks -------------------------------------------------------------------------
+// ggml_ext_slice — ggml_extend.hpp:605-638
+inline ggml_tensor* ext_slice(ggml_context* c, ggml_tensor* x, int dim, int64_t start, int64_t end, bool cont = true) {
+    if (x->ne[dim] == 1) return x;
+    while (start < 0) start = x->ne[dim] + start;
+    while (end < 0) end = x->ne[dim] + end;
+    int64_t ne[4] = {x->ne[0], x->ne[1], x->ne[2], x->ne[3]};
+    ne[dim]       = end - start;
+    x             = ggml_view_4d(c, x, ne[0], ne[1], ne[2], ne[3], x->nb[1], x->nb[2], x->nb[3], start * x->nb[dim]);
+    if (cont) x = ggml_cont(c, x);
+    return x;
+}
+
+// split_qkv — ggml_extend.hpp:1253-1263: [3C, L, N] -> 3 x [C, L, N] through one permuted copy
+inline std::vector<ggml_tensor*> split_qkv(ggml_context* c, ggml_tensor* qkv) {
+    qkv = ggml_reshape_4d(c, qkv, qkv->ne[0] / 3, 3, qkv->ne[1], qkv->ne[2]);
+    qkv = ggml_cont(c, ggml_permute(c, qkv, 0, 3, 1, 2));
+    const size_t off = qkv->nb[2] * qkv->ne[2];
+    std::vector<ggml_tensor*> r;
+    for (int i = 0; i < 3; ++i) r.push_back(ggml_view_3d(c, qkv, qkv->ne[0], qkv->ne[1], qkv->ne[2], qkv->nb[1], qkv->nb[2], off * i));
+    return r;
+}
+
+// modulate — src/model/diffusion/mmdit.hpp:368-380: x * (1 + scale) + shift with [C, N] modulation vectors
+inline ggml_tensor* modulate(ggml_context* c, ggml_tensor* x, ggml_tensor* shift, ggml_tensor* scale) {
+    scale = ggml_reshape_3d(c, scale, scale->ne[0], 1, scale->ne[1]);
+    shift = ggml_reshape_3d(c, shift, shift->ne[0], 1, shift->ne[1]);
+    x     = ggml_add(c, x, ggml_mul(c, x, scale));
+    x     = ggml_add(c, x, shift);
+    return x;
+}
+
+// RMSNorm — ggml_extend.hpp:3996-4023
+struct RMSNorm {
+    ggml_tensor* w = nullptr;
+    float eps      = 1e-6f;
+    void init(ParamStore& ps, const std::string& prefix, int64_t dim, float eps_ = 1e-6f) {
+        eps = eps_;
+        w   = ps.add(prefix + "weight", GGML_TYPE_F32, {dim}, InitKind::NORM_SCALE, dim);
+    }
+    ggml_tensor* forward(GraphCtx& g, ggml_tensor* x) const { return ggml_mul_inplace(g.ctx, ggml_rms_norm(g.ctx, x, eps), w); }
+};
+
+// LayerNorm(elementwise_affine = false) — ggml_extend.hpp:3897-3944
+struct PlainLayerNorm {
+    float eps = 1e-6f;
+    ggml_tensor* forward(GraphCtx& g, ggml_tensor* x) const { return ext_layer_norm(g.ctx, x, nullptr, nullptr, eps); }
+};
+
+// Mlp — src/model/common/block.hpp:230-259 (GELU tanh)
+struct Mlp {
+    Linear fc1, fc2;
+    void init(ParamStore& ps, const std::string& prefix, int64_t in, int64_t hidden) {
+        fc1.init(ps, prefix + "fc1.", in, hidden);
+        fc2.init(ps, prefix + "fc2.", hidden, in);
+    }
+    ggml_tensor* forward(GraphCtx& g, ggml_tensor* x) const {
+        x = fc1.forward(g, x);
+        x = ext_gelu(g.ctx, x, true);
+        return fc2.forward(g, x);
     }
 };
 

@@ -110,6 +110,33 @@ struct CompVisDenoiser {
     }
 };
 
+// DiscreteFlowDenoiser (src/runtime/denoiser.hpp:1232-1283): SD3 / SD3.5 rectified flow, sigma = shifted t/1000
+struct DiscreteFlowDenoiser {
+    float shift = 3.0f;
+    static float time_snr_shift(float alpha, float t) { return alpha == 1.0f ? t : alpha * t / (1 + (alpha - 1) * t); }
+    float sigma_to_t(float sigma) const { return sigma * 1000.f; }
+    float t_to_sigma(float t) const { return time_snr_shift(shift, (t + 1) / 1000.f); }
+    std::vector<float> get_sigmas(uint32_t n) const {  // DiscreteScheduler::get_sigmas — denoiser.hpp:32-54
+        std::vector<float> r;
+        const int t_max = TIMESTEPS - 1;
+        if (n == 0) return r;
+        if (n == 1) {
+            r.push_back(t_to_sigma((float)t_max));
+            r.push_back(0);
+            return r;
+        }
+        const float step = (float)t_max / (float)(n - 1);
+        for (uint32_t i = 0; i < n; ++i) r.push_back(t_to_sigma(t_max - step * i));
+        r.push_back(0);
+        return r;
+    }
+    void scalings(float sigma, float& c_skip, float& c_out, float& c_in) const {
+        c_skip = 1.0f;
+        c_out  = -sigma;
+        c_in   = 1.0f;
+    }
+};
+
 // get_ancestral_step — denoiser.hpp:1447-1467
 inline void ancestral_step(float sigma_from, float sigma_to, float eta, float& sigma_down, float& sigma_up) {
     sigma_up   = 0.0f;

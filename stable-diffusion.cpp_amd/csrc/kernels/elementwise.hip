@@ -49,6 +49,18 @@ __global__ void k_bin_rowvec(float* __restrict__ dst, const float* __restrict__ 
         ((float4*)dst)[i] = r;
     }
 }
+// b is one vector along ne0 PER IMAGE: a [C, L, N] contiguous, b [C, 1, N]
+template <int OP>
+__global__ void k_bin_tokvec(float* __restrict__ dst, const float* __restrict__ a, const float* __restrict__ b, int64_t n4, int ne0_4, int64_t img4) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 x = ((const float4*)a)[i], y = ((const float4*)b)[(i / img4) * ne0_4 + i % ne0_4], r;
+        r.x = bin_apply<OP>(x.x, y.x);
+        r.y = bin_apply<OP>(x.y, y.y);
+        r.z = bin_apply<OP>(x.z, y.z);
+        r.w = bin_apply<OP>(x.w, y.w);
+        ((float4*)dst)[i] = r;
+    }
+}
 // b indexed by (i / inner) % bC + ((i / (inner*C)) % bN) * bC : per-channel (and per-image) scalar; inner % 4 == 0
 template <int OP>
 __global__ void k_bin_chan(float* __restrict__ dst, const float* __restrict__ a, const float* __restrict__ b, int64_t n4, int64_t inner4, int C,
@@ -105,6 +117,12 @@ static void binary_dispatch(hipStream_t s, void* dst, const int64_t dnb[4], cons
         }
         if (b.ne[0] == a.ne[0] && b.ne[1] == 1 && b.ne[2] == 1 && b.ne[3] == 1 && a.ne[0] % 4 == 0) {
             k_bin_rowvec<OP><<<grid_for(n / 4, block), block, 0, s>>>((float*)dst, (const float*)a.data, (const float*)b.data, n / 4, (int)(a.ne[0] / 4));
+            return;
+        }
+        // [C,1,N] broadcast over the tokens of [C,L,N] (adaLN modulate / gate of the DiT blocks, mmdit.hpp:368-380)
+        if (b.ne[0] == a.ne[0] && b.ne[1] == 1 && a.ne[1] > 1 && b.ne[2] == a.ne[2] && b.ne[3] == 1 && a.ne[3] == 1 && a.ne[0] % 4 == 0) {
+            k_bin_tokvec<OP><<<grid_for(n / 4, block), block, 0, s>>>((float*)dst, (const float*)a.data, (const float*)b.data, n / 4, (int)(a.ne[0] / 4),
+                                                                     a.ne[0] / 4 * a.ne[1]);
             return;
         }
         // [1,1,C,N'] broadcast over [W,H,C,N] (conv bias, group-norm affine, time-embedding add)
@@ -179,6 +197,21 @@ __global__ void k_copy_generic(char* __restrict__ dst, const char* __restrict__ 
         const int64_t b0 = i % g.dne[0], b1 = (i / g.dne[0]) % g.dne[1], b2 = (i / (g.dne[0] * g.dne[1])) % g.dne[2], b3 = i / (g.dne[0] * g.dne[1] * g.dne[2]);
         const TS v = *(const TS*)(src + a0 * g.snb[0] + a1 * g.snb[1] + a2 * g.snb[2] + a3 * g.snb[3]);
         *(TD*)(dst + b0 * g.dnb[0] + b1 * g.dnb[1] + b2 * g.dnb[2] + b3 * g.dnb[3]) = cvt<TD>(v);
+    }
+}
+// same logical shape, ne0 contiguous on both sides (permuted / sliced rows: split_qkv, head permutes, chunk, slice): 4 elements per thread
+template <typename TS, typename TD>
+__global__ void k_copy_rows(char* __restrict__ dst, const char* __restrict__ src, CopyArgs g, int64_t n4) {
+    const int64_t r0 = g.sne[0] / 4;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t c = i % r0, row = i / r0;
+        const int64_t i1 = row % g.sne[1], t = row / g.sne[1], i2 = t % g.sne[2], i3 = t / g.sne[2];
+        TS v[4];
+        *(vec_t<TS, 4>*)v = *(const vec_t<TS, 4>*)(src + i1 * g.snb[1] + i2 * g.snb[2] + i3 * g.snb[3] + c * 4 * (int64_t)sizeof(TS));
+        TD r[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = cvt<TD>(v[j]);
+        *(vec_t<TD, 4>*)(dst + i1 * g.dnb[1] + i2 * g.dnb[2] + i3 * g.dnb[3] + c * 4 * (int64_t)sizeof(TD)) = *(vec_t<TD, 4>*)r;
     }
 }
 // contiguous -> contiguous with conversion, 4 elements per thread
@@ -262,6 +295,16 @@ static void copy_typed(hipStream_t s, const View4& dst, const View4& src) {
         g.snb[i] = src.nb[i];
         g.dne[i] = dst.ne[i];
         g.dnb[i] = dst.nb[i];
+    }
+    {
+        const int64_t sa = 4 * sizeof(TS), da = 4 * sizeof(TD);  // vector alignment in bytes
+        bool rows = same && src.nb[0] == (int64_t)sizeof(TS) && dst.nb[0] == (int64_t)sizeof(TD) && src.ne[0] % 4 == 0 && ((uintptr_t)src.data % sa) == 0 &&
+                    ((uintptr_t)dst.data % da) == 0;
+        for (int i = 1; i < 4; ++i) rows = rows && src.nb[i] % sa == 0 && dst.nb[i] % da == 0;
+        if (rows) {
+            k_copy_rows<TS, TD><<<grid_for(n / 4, 256), 256, 0, s>>>((char*)dst.data, (const char*)src.data, g, n / 4);
+            return;
+        }
     }
     k_copy_generic<TS, TD><<<grid_for(n, 256), 256, 0, s>>>((char*)dst.data, (const char*)src.data, g, n);
 }

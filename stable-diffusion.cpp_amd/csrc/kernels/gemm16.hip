@@ -793,11 +793,13 @@ void launch_gemm16_conv(hipStream_t s, float* dst, const void* x16_nhwc, const v
 // producers of the f16 operand images
 // =====================================================================================================
 // f32 rows [R][K] (row stride xs floats) -> f16 [R][Kp], zero padded
-__global__ void k_pack_rows_f16(_Float16* __restrict__ dst, const float* __restrict__ x, int64_t R, int K, int Kp, int64_t xs) {
+// rows r = (n, l): n = r / L images with element stride bs, l = r % L rows with stride xs (a sliced token range keeps its parent's batch stride)
+__global__ void k_pack_rows_f16(_Float16* __restrict__ dst, const float* __restrict__ xin, int64_t R, int K, int Kp, int64_t xs, int64_t L, int64_t bs) {
     const int64_t n8 = R * (Kp / 8);
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = i / (Kp / 8);
         const int k0    = (int)(i - r * (Kp / 8)) * 8;
+        const float* x  = xin + (r / L) * bs + (r % L) * xs - r * xs;  // so that x + r * xs addresses row r
         half8_t h;
         if (k0 + 8 <= K) {
             const float4 a = *(const float4*)(x + r * xs + k0), b = *(const float4*)(x + r * xs + k0 + 4);
@@ -810,12 +812,16 @@ __global__ void k_pack_rows_f16(_Float16* __restrict__ dst, const float* __restr
         *(half8_t*)(dst + r * Kp + k0) = h;
     }
 }
-void launch_pack_rows_f16(hipStream_t s, void* dst, const float* x, int64_t R, int64_t K, int64_t xs) {
+void launch_pack_rows_f16(hipStream_t s, void* dst, const float* x, int64_t R, int64_t K, int64_t xs, int64_t L, int64_t bs) {
     const int Kp = (int)rup64(K, 64);
     const int64_t n8 = R * (Kp / 8);
     int64_t blocks   = (n8 + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    k_pack_rows_f16<<<(unsigned)blocks, 256, 0, s>>>((_Float16*)dst, x, R, (int)K, Kp, xs);
+    if (L <= 0) {  // one run of rows
+        L  = R;
+        bs = 0;
+    }
+    k_pack_rows_f16<<<(unsigned)blocks, 256, 0, s>>>((_Float16*)dst, x, R, (int)K, Kp, xs, L, bs);
 }
 
 // LayerNorm / RMSNorm (+affine) writing the f16 operand image: one wave per row

@@ -97,7 +97,8 @@ int gemm16_split_k(int64_t rows, int64_t M, int64_t K);
 void launch_gemm16_conv(hipStream_t s, float* dst, const void* x16_nhwc, const void* wswz, int64_t W, int64_t H, int64_t IC, int64_t N, int64_t OC,
                         int ksize, int stride, int pad, bool upscale2x, const Epilogue& ep, float* splitk_ws = nullptr);
 // producers of f16 operand images (row stride = K rounded up to 64, zero padded)
-void launch_pack_rows_f16(hipStream_t s, void* dst, const float* x, int64_t R, int64_t K, int64_t x_stride);
+// L > 0: rows are N runs of L rows, run n starting bs elements after run n-1 (a token slice of a [C, Lfull, N] tensor)
+void launch_pack_rows_f16(hipStream_t s, void* dst, const float* x, int64_t R, int64_t K, int64_t xs, int64_t L = 0, int64_t bs = 0);
 void launch_layer_norm_f16(hipStream_t s, void* dst, const float* x, int64_t ne0, int64_t nrows, int64_t x_stride, float eps, const float* w,
                            const float* b, bool rms);
 void launch_geglu_f16(hipStream_t s, void* dst, const float* x, int64_t tokens, int64_t inner, int64_t x_stride);

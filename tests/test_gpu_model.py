@@ -64,3 +64,44 @@ def test_sampler_trajectory_parity(sd, oracle, gpu):
     err = rel_l2(out, ref)
     print(f"trajectory rel-L2 {err:.3e}")
     assert err < 2e-2
+
+
+@pytest.mark.parametrize("flash,wtype", [(False, "F16"), (True, "F16"), (True, "BF16")])
+def test_mmdit_forward_parity(sd, oracle, gpu, flash, wtype):
+    """SD3.5 MMDiT (tiny width, same topology incl. one MMDiT-X block; odd latent size exercises pad + crop) — SURVEY.md row a11.
+    bf16 Linear weights (config 5) are decoded once into the f16 MFMA weight image; the oracle keeps them bf16 x f32-rounded-to-bf16
+    like ggml-cpu, so that leg gets the looser bar."""
+    rng = np.random.default_rng(17)
+    n = 2
+    x = rng.standard_normal((n, 16, 18, 15)).astype(np.float32)
+    t = np.array([731.0, 210.0], dtype=np.float32)
+    ctx = rng.standard_normal((1, 154, 96)).astype(np.float32)
+    y = rng.standard_normal((1, 64)).astype(np.float32)
+    wt = getattr(sd, wtype)
+    ref = sd.Engine(model=sd.SD35_TINY, backend=oracle, flash_attn=flash, wtype=wt).unet_forward(x, t, ctx, y)
+    gpu_e = sd.Engine(model=sd.SD35_TINY, backend=gpu, flash_attn=flash, wtype=wt)
+    out = gpu_e.unet_forward(x, t, ctx, y)
+    assert np.isfinite(out).all()
+    err = rel_l2(out, ref)
+    print(f"SD35_TINY flash={flash} {wtype}: rel-L2 {err:.3e}, nodes {gpu_e.stats()['graph_nodes']}")
+    assert err < (2e-2 if wtype == "BF16" else 5e-3)
+    np.testing.assert_array_equal(out, gpu_e.unet_forward(x, t, ctx, y))
+
+
+def test_mmdit_flow_trajectory_and_vae_parity(sd, oracle, gpu):
+    rng = np.random.default_rng(18)
+    cond, uncond = (rng.standard_normal((1, 40, 96)).astype(np.float32) for _ in range(2))
+    cy, uy = (rng.standard_normal((1, 64)).astype(np.float32) for _ in range(2))
+    kw = dict(width=128, height=128, steps=4, cfg=4.5, method=sd.EULER, cond_y=cy, uncond_y=uy)
+    gpu_e = sd.Engine(model=sd.SD35_TINY, backend=gpu, flash_attn=True)
+    ref_e = sd.Engine(model=sd.SD35_TINY, backend=oracle, flash_attn=True)
+    out = gpu_e.sample_latents(cond, uncond, batch=2, device_batch=2, seed=42, fuse_cfg=True, **kw)
+    ref = np.concatenate([ref_e.sample_latents(cond, uncond, batch=1, seed=42 + b, **kw) for b in range(2)])
+    err = rel_l2(out, ref)
+    print(f"SD3.5 flow trajectory rel-L2 {err:.3e}")
+    assert err < 2e-2
+    z = ref[:1]
+    a, b = gpu_e.vae_decode(z), ref_e.vae_decode(z)
+    psnr = 10 * np.log10(1.0 / max(float(np.mean((a.astype(np.float64) - b) ** 2)), 1e-20))
+    print(f"16-channel VAE decode PSNR {psnr:.1f} dB")
+    assert psnr > 35.0
