@@ -66,6 +66,9 @@ struct ggml_backend_mi355x_stats {
     int64_t fused_linear_geglu;  /* FF1 GEMM + GEGLU in one kernel (the [tokens][2*inner] tensor is never written) */
     int64_t split_k_gemms;       /* gemm16 contractions planned with a split-K workspace */
     int64_t head_major_gemms;    /* q/k/v projections that store the attention operand layout directly */
+    int64_t fused_modulate;      /* LayerNorm + adaLN modulate written straight to the next GEMM's f16 operand image (DiT) */
+    int64_t fused_gate;          /* Linear -> * gate -> + x folded into the GEMM epilogue (DiT) */
+    int64_t fused_gelu;          /* fc1 -> GELU written as fc2's f16 operand image */
 };
 GGML_MI355X_API void ggml_backend_mi355x_get_stats(struct ggml_backend_mi355x_stats* out);
 /* live timing of the dominant kernel (bench.py's roofline leg): HIP events on the launch stream around every dispatch of

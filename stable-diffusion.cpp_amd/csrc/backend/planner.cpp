@@ -27,6 +27,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <map>
 #include <unordered_map>
 #include <vector>
 
@@ -38,12 +39,12 @@ namespace {
 
 struct Stats {
     std::atomic<int64_t> graphs_computed{0}, plans_built{0}, nodes_seen{0}, kernels_planned{0}, kernels_launched{0}, fused_conv{0},
-        fused_conv_bounced{0}, fused_linear{0}, fused_norm{0}, fused_geglu{0}, fused_attention{0}, generic_matmul{0}, swizzled_weight_bytes{0}, fused_linear_geglu{0}, split_k_gemms{0}, head_major_gemms{0},
+        fused_conv_bounced{0}, fused_linear{0}, fused_norm{0}, fused_geglu{0}, fused_attention{0}, generic_matmul{0}, swizzled_weight_bytes{0}, fused_linear_geglu{0}, split_k_gemms{0}, head_major_gemms{0}, fused_modulate{0}, fused_gate{0}, fused_gelu{0},
         graph_replays{0};
 } g_stats;
 
 struct Options {
-    std::atomic<int> fusion{1}, mfma_gemm{1}, hip_graph{0}, flash_pattern{1}, gemm16{1};
+    std::atomic<int> fusion{1}, mfma_gemm{1}, hip_graph{0}, flash_pattern{1}, gemm16{1}, fuse_modulate{1}, fuse_gate{1}, fuse_gelu{1};
 } g_opt;
 
 using Step = std::function<void(hipStream_t)>;
@@ -193,8 +194,31 @@ struct Builder {
     size_t arena_off = 0;
     std::unordered_map<const ggml_tensor*, Packed> packed;           // graph tensor -> f16 operand image
     std::unordered_map<const ggml_tensor*, const ggml_tensor*> ups;  // deferred nearest-x2 UPSCALE node -> its source
+    std::map<int, std::vector<Step>> deferred;                       // steps to run once the walk reaches graph node <key>
     Builder(Planner* p, Plan* pl, const ggml_cgraph* g) : P(p), plan(pl), gi(g) {}
     void emit(Step s) { plan->steps.push_back(std::move(s)); }
+    // A fused chain normally runs at the position of its FIRST node.  When one of its operands is produced by a node that sits between
+    // the chain's nodes in graph order (the adaLN chunk CONTs of a DiT block are reached by the DFS through the gate / scale operand),
+    // the kernel is emitted at the position of the chain's LAST node instead.
+    void emit_at(int node, int cur, Step s) {
+        if (node <= cur)
+            emit(std::move(s));
+        else
+            deferred[node].push_back(std::move(s));
+    }
+    // would executing at node `b` instead of node `a` read a clobbered operand?  true if a node in (a, b] outside the chain writes into [p, p+n)
+    bool clobbered_between(int a, int b, const void* p, size_t n, const std::vector<int>& chain) const {
+        for (int k = a + 1; k <= b; ++k) {
+            const ggml_tensor* t = gi.node(k);
+            if (ggml_abi_op_is_noop(t->op)) continue;
+            bool in_chain = false;
+            for (int c : chain) in_chain = in_chain || (c == k);
+            if (in_chain) continue;
+            const char *a0 = (const char*)t->data, *b0 = (const char*)p;
+            if (a0 < b0 + n && b0 < a0 + ggml_abi_nbytes(t)) return true;
+        }
+        return false;
+    }
     size_t alloc(size_t bytes) {
         const size_t off = (arena_off + 255) & ~(size_t)255;
         arena_off        = off + bytes;
@@ -401,10 +425,57 @@ void plan_linear(Builder& B, int i, hipStream_t s, std::vector<int>& chain) {
             }
         }
     }
+    int emit_node = i;  // graph position at which the GEMM itself is launched (operand packing always happens at i)
+    // DiT gate (mmdit.hpp:540-551): Linear -> MUL(., gate[M,1,N]) -> ADD(x, .): dst = x + (acc + bias) * gate
+    if (g_opt.fusion && g_opt.gemm16 && g_opt.fuse_gate && hm_d == 0 && !ep.residual && x->ne[3] == 1 && x->ne[1] >= 32 && tokens < (1ll << 31) &&
+        gemm16_split_k(tokens, M, K) == 1) {  // split-K launches keep the plain epilogue (the slab reduce applies bias only)
+        const int jm = gi.sole(last);
+        const ggml_tensor* mt = jm >= 0 ? gi.node(jm) : nullptr;
+        if (mt && mt->op == GGML_OP_MUL && mt->src[0] == gi.node(last)) {
+            const ggml_tensor* gv = mt->src[1];
+            const int jr          = gi.sole(jm);
+            const ggml_tensor* a  = jr >= 0 ? gi.node(jr) : nullptr;
+            if (is_f32(gv) && contig(gv) && gv->ne[0] == M && gv->ne[1] == 1 && gv->ne[2] == x->ne[2] && gv->ne[3] == 1 && a && a->op == GGML_OP_ADD) {
+                const ggml_tensor* other = a->src[1] == mt ? a->src[0] : (a->src[0] == mt ? a->src[1] : nullptr);
+                const size_t ob          = ggml_abi_nbytes(a);
+                std::vector<int> c2 = chain;
+                c2.push_back(jm);
+                c2.push_back(jr);
+                if (other && is_f32(other) && contig(other) && contig(a) && contig(mt) && ggml_abi_same_shape(other, a) && ggml_abi_same_shape(mt, a) &&
+                    gi.idx(other) < i && !overlaps(a->data, ob, x->data, ggml_abi_nbytes(x)) &&
+                    (other->data == a->data || !overlaps(a->data, ob, other->data, ob)) && !overlaps(a->data, ob, gv->data, ggml_abi_nbytes(gv)) &&
+                    !B.clobbered_between(jm, jr, gv->data, ggml_abi_nbytes(gv), c2) && !B.clobbered_between(i, jr, other->data, ob, c2)) {
+                    // the GEMM runs at jr (the gate chunk's CONT sits between the projection and the MUL in graph order)
+                    ep.residual = (const float*)other->data;
+                    ep.gate     = (const float*)gv->data;
+                    ep.gate_L   = (int)x->ne[1];
+                    chain       = c2;
+                    last        = jr;
+                    emit_node   = jr;
+                    g_stats.fused_gate++;
+                }
+            }
+        }
+    }
+    // Mlp (block.hpp:249-258): fc1 -> GELU feeding only fc2: the GEMM writes gelu(acc + bias) as fc2's f16 operand image
+    int gelu_out = -1;
+    if (g_opt.fusion && g_opt.gemm16 && g_opt.fuse_gelu && hm_d == 0 && !ep.residual && !ep.gate) {
+        const int ju = gi.sole(last);
+        if (ju >= 0 && gi.node(ju)->op == GGML_OP_UNARY && ggml_abi_get_unary_op(gi.node(ju)) == GGML_UNARY_OP_GELU && gi.node(ju)->src[0] == gi.node(last) &&
+            contig(gi.node(ju)) && M % 64 == 0 && all_consumers_gemm16(gi, ju, false)) {
+            std::vector<int> c2 = chain;
+            c2.push_back(ju);
+            if (gi.only_noops_between(i, ju, c2)) {
+                chain    = c2;
+                gelu_out = ju;
+                ep.gelu  = 1;
+            }
+        }
+    }
     // FF1 -> GEGLU (block.hpp:193-210): [bias ADD] -> {VIEW lo, VIEW hi} ; CONT(hi) -> GELU -> MUL(lo, .) feeding only gemm16 GEMMs (FF2):
     // one kernel computes value and gate columns side by side and writes the f16 operand image of FF2
     int geglu_out = -1;
-    if (g_opt.fusion && g_opt.gemm16 && hm_d == 0 && !ep.residual && M % 128 == 0 && gi.consumers[last].size() == 2) {
+    if (g_opt.fusion && g_opt.gemm16 && hm_d == 0 && !ep.residual && gelu_out < 0 && M % 128 == 0 && gi.consumers[last].size() == 2) {
         const ggml_tensor* X = gi.node(last);
         const int64_t inner  = M / 2;
         int vlo = -1, vhi = -1;
@@ -458,6 +529,11 @@ void plan_linear(Builder& B, int i, hipStream_t s, std::vector<int>& chain) {
             B.packed[gi.node(geglu_out)] = Packed{ooff, M / 2, false};
             g_stats.fused_geglu++;
             g_stats.fused_linear_geglu++;
+        } else if (gelu_out >= 0) {
+            const size_t ooff = B.alloc((size_t)tokens * M * 2);
+            B.emit([=](hipStream_t st) { launch_gemm16_linear(st, nullptr, P->arena + ooff, M, P->arena + off, ld, swz, tokens, K, M, M, ep); });
+            B.packed[gi.node(gelu_out)] = Packed{ooff, M, false};
+            g_stats.fused_gelu++;
         } else if (hm_d > 0) {
             void* hdst = gi.node(last)->data;
             g_stats.head_major_gemms++;
@@ -470,7 +546,7 @@ void plan_linear(Builder& B, int i, hipStream_t s, std::vector<int>& chain) {
             const int S       = gemm16_split_k(tokens, M, K);
             const size_t wsoff = S > 1 ? B.alloc((size_t)S * tokens * M * 4) : 0;
             if (S > 1) g_stats.split_k_gemms++;
-            B.emit([=](hipStream_t st) {
+            B.emit_at(emit_node, i, [=](hipStream_t st) {
                 launch_gemm16_linear(st, dst, nullptr, 0, P->arena + off, ld, swz, tokens, K, M, M, ep, 0, 0, 0, S > 1 ? (float*)(P->arena + wsoff) : nullptr);
             });
         }
@@ -714,6 +790,47 @@ bool plan_layer_norm(Builder& B, int i, hipStream_t, std::vector<int>& chain) {
     float* dst      = (float*)n->data;
     const float* xp = (const float*)x->data;
     const int64_t xs = (int64_t)x->nb[1] / 4, ds = (int64_t)n->nb[1] / 4;
+    // adaLN modulate (mmdit.hpp:368-380): NORM -> {MUL(xn, scale[C,1,N]), ADD(xn, mul)} -> ADD(., shift[C,1,N]) feeding only weight GEMMs:
+    // one kernel writes norm * (1 + scale) + shift as the f16 operand image (the four f32 tensors are never materialised)
+    if (g_opt.fusion && g_opt.gemm16 && g_opt.fuse_modulate && !w && !rms && gi.consumers[i].size() == 2 && n->ne[3] == 1 && contig(n) && C % 4 == 0 && xs % 4 == 0 && aligned16(xp)) {
+        int jm = -1, ja = -1;
+        for (int c : gi.consumers[i]) {
+            const ggml_tensor* t = gi.node(c);
+            if (t->op == GGML_OP_MUL && t->src[0] == n) jm = c;
+            if (t->op == GGML_OP_ADD && t->src[0] == n) ja = c;
+        }
+        auto mod_vec = [&](const ggml_tensor* v) {  // [C, 1, N] contiguous f32
+            return v && is_f32(v) && contig(v) && v->ne[0] == C && v->ne[1] == 1 && v->ne[2] == n->ne[2] && v->ne[3] == 1 && aligned16(v->data);
+        };
+        const int js = (jm >= 0 && ja >= 0 && gi.node(ja)->src[1] == gi.node(jm) && gi.sole(jm) == ja) ? gi.sole(ja) : -1;
+        if (js >= 0 && gi.node(js)->op == GGML_OP_ADD && gi.node(js)->src[0] == gi.node(ja) && mod_vec(gi.node(jm)->src[1]) && mod_vec(gi.node(js)->src[1]) &&
+            all_consumers_gemm16(gi, js, false)) {
+            std::vector<int> c2{i, jm, ja, js};
+            const ggml_tensor* sc_t = gi.node(jm)->src[1];
+            // the kernel runs at js (the shift vector's CONT sits between the chain's nodes): x and scale must still be intact there
+            if (!B.clobbered_between(i, js, x->data, ggml_abi_nbytes(x), c2)) {
+                chain               = c2;
+                Planner* P          = B.P;
+                const size_t off    = B.alloc((size_t)rows * rup64(C) * 2);
+                const float* scalep = (const float*)sc_t->data;
+                const float* shiftp = (const float*)gi.node(js)->src[1]->data;
+                const int64_t L     = n->ne[1];
+                // scale dies at jm: the graph allocator typically hands its block to the shift chunk's CONT (same size, runs before js) —
+                // keep a private copy taken at jm
+                const bool sc_clob  = B.clobbered_between(jm, js, sc_t->data, ggml_abi_nbytes(sc_t), c2);
+                const size_t sc_n   = ggml_abi_nbytes(sc_t);
+                const size_t sc_off = sc_clob ? B.alloc(sc_n) : 0;
+                if (sc_clob) B.emit_at(jm, i, [=](hipStream_t st) { (void)hipMemcpyAsync(P->arena + sc_off, scalep, sc_n, hipMemcpyDeviceToDevice, st); });
+                B.emit_at(js, i, [=](hipStream_t st) {
+                    launch_layer_norm_f16(st, P->arena + off, xp, C, rows, xs, eps, sc_clob ? (const float*)(P->arena + sc_off) : scalep, shiftp, false, L);
+                });
+                B.packed[gi.node(js)] = Packed{off, rup64(C), false};
+                g_stats.fused_norm++;
+                g_stats.fused_modulate++;
+                return true;
+            }
+        }
+    }
     if (C % 4 == 0 && xs % 4 == 0 && aligned16(xp) && (!w || aligned16(w)) && (!b || aligned16(b)) && all_consumers_gemm16(gi, last, false)) {
         // gen-2: all readers are weight GEMMs (q/k/v or FF projections) -> write the f16 operand image only
         Planner* P       = B.P;
@@ -1038,6 +1155,13 @@ bool build_plan(Planner* P, Plan* plan, const ggml_cgraph* g, hipStream_t s) {
     Builder B(P, plan, g);
     GInfo& gi = B.gi;
     for (int i = 0; i < g->n_nodes; ++i) {
+        {
+            auto it = B.deferred.find(i);
+            if (it != B.deferred.end()) {
+                for (auto& st : it->second) B.emit(std::move(st));
+                B.deferred.erase(it);
+            }
+        }
         if (gi.done[i]) continue;
         const ggml_tensor* n = gi.node(i);
         if (ggml_abi_op_is_noop(n->op)) continue;
@@ -1312,6 +1436,9 @@ void planner_get_stats(ggml_backend_mi355x_stats* o) {
     o->fused_linear_geglu    = g_stats.fused_linear_geglu;
     o->split_k_gemms         = g_stats.split_k_gemms;
     o->head_major_gemms      = g_stats.head_major_gemms;
+    o->fused_modulate        = g_stats.fused_modulate;
+    o->fused_gate            = g_stats.fused_gate;
+    o->fused_gelu            = g_stats.fused_gelu;
     o->fused_attention       = g_stats.fused_attention;
     o->generic_matmul        = g_stats.generic_matmul;
     o->swizzled_weight_bytes = g_stats.swizzled_weight_bytes;
@@ -1324,6 +1451,9 @@ void planner_set_option(const char* key, int value) {
     else if (!strcmp(key, "hip_graph")) g_opt.hip_graph = value;
     else if (!strcmp(key, "flash_pattern")) g_opt.flash_pattern = value;
     else if (!strcmp(key, "gemm16")) g_opt.gemm16 = value;
+    else if (!strcmp(key, "fuse_modulate")) g_opt.fuse_modulate = value;
+    else if (!strcmp(key, "fuse_gate")) g_opt.fuse_gate = value;
+    else if (!strcmp(key, "fuse_gelu")) g_opt.fuse_gelu = value;
     else if (!strcmp(key, "gemm16_variant")) gemm16_set_variant(value);
     else if (!strcmp(key, "conv_tap_major")) gemm16_set_tap_major(value);
     else if (!strcmp(key, "gemm16_tile")) gemm16_set_tile(value);

@@ -27,10 +27,13 @@
 
 namespace mi355x {
 
-struct G16Epi {  // dst = acc * scale + bias (+ residual); the planner fuses no activation into these kernels
+struct G16Epi {  // dst = acc * scale + bias (+ residual); DiT variants: (acc*scale + bias) * gate[image][col] + residual, and gelu -> f16
     const float* bias;
     const float* residual;
     float scale;
+    const float* gate = nullptr;  // [images][C] per-image per-column gate (adaLN gate_msa / gate_mlp, mmdit.hpp:540-551); needs residual
+    int gate_L        = 0;        // rows per image (>= 32)
+    int gelu          = 0;        // f16-only output: tanh-GELU before rounding (Mlp fc1 -> fc2, block.hpp:249-258)
 };
 
 struct G16Args {
@@ -72,7 +75,7 @@ __device__ __forceinline__ void st_u(T* ubase, uint32_t lane_bytes, T v) { *(T*)
 template <typename T>
 __device__ __forceinline__ T ld_u(const T* ubase, uint32_t lane_bytes) { return *(const T*)((const char*)ubase + lane_bytes); }
 
-enum { EPI_F32 = 0, EPI_F32_RES = 1, EPI_F16 = 2, EPI_HM_F32 = 3, EPI_HM_F16 = 4, EPI_GENERIC = 5 };
+enum { EPI_F32 = 0, EPI_F32_RES = 1, EPI_F16 = 2, EPI_HM_F32 = 3, EPI_HM_F16 = 4, EPI_GENERIC = 5, EPI_F16_GELU = 6, EPI_F32_GATE = 7 };
 
 // FF1 + GEGLU: the wave's column block cb = 0 holds 32 value columns, cb = 1 the matching gate columns
 template <int RB, int CB>
@@ -106,7 +109,7 @@ __device__ __forceinline__ void epi_linear(const float16_t (&acc)[RB][CB], const
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
         const int64_t base_row = row0 + wr * (RB * 32) + rb * 32;  // wave-uniform
-        if (MODE == EPI_GENERIC && base_row >= g.R) continue;
+        if ((MODE == EPI_GENERIC || MODE == EPI_F16 || MODE == EPI_F16_GELU || MODE == EPI_F32_GATE) && base_row >= g.R) continue;
         uint32_t hm_n0 = 0, hm_l0 = 0;
         if (MODE == EPI_HM_F32 || MODE == EPI_HM_F16) {
             if (base_row >= g.R) continue;
@@ -133,11 +136,43 @@ __device__ __forceinline__ void epi_linear(const float16_t (&acc)[RB][CB], const
                     for (int r = r0; r < r0 + 8; ++r)
                         st_u(ub + (int64_t)((r & 3) + 8 * (r >> 2)) * g.ldd, lb, acc[rb][cb][r] * g.ep.scale + bias + rv[r - r0]);
                 }
-            } else if (MODE == EPI_F16) {
+            } else if (MODE == EPI_F16 || MODE == EPI_F16_GELU) {
                 _Float16* ub      = g.dst16 + base_row * g.ldd16 + cblk;
                 const uint32_t lb = (uint32_t)(lc + 4 * hi * (int)g.ldd16) * 2u;
+                const int nvl     = (int)(g.R - base_row < 32 ? g.R - base_row : 32) - 4 * hi;  // ragged last row tile: masked per register
 #pragma unroll
-                for (int r = 0; r < 16; ++r) st_u(ub + (int64_t)((r & 3) + 8 * (r >> 2)) * g.ldd16, lb, (_Float16)(acc[rb][cb][r] * g.ep.scale + bias));
+                for (int r = 0; r < 16; ++r) {
+                    const int ro = (r & 3) + 8 * (r >> 2);
+                    if (ro >= nvl) continue;
+                    float v = acc[rb][cb][r] * g.ep.scale + bias;
+                    if (MODE == EPI_F16_GELU) v = act_apply<UN_GELU>(v);
+                    st_u(ub + (int64_t)ro * g.ldd16, lb, (_Float16)v);
+                }
+            } else if (MODE == EPI_F32_GATE) {
+                // x + (acc + bias) * gate[image][col]: the 32 rows of a block cross at most one image boundary (gate_L >= 32)
+                float* ub         = g.dst + base_row * g.ldd + cblk;
+                const float* ur   = g.ep.residual + base_row * g.ldd + cblk;
+                const uint32_t lb = (uint32_t)(lc + 4 * hi * (int)g.ldd) * 4u;
+                const uint32_t n0 = (uint32_t)base_row / (uint32_t)g.ep.gate_L, l0 = (uint32_t)base_row - n0 * (uint32_t)g.ep.gate_L;
+                const int wrap_at = g.ep.gate_L - (int)l0 - 4 * hi;
+                const int nvl     = (int)(g.R - base_row < 32 ? g.R - base_row : 32) - 4 * hi;
+                const float g0 = g.ep.gate[(int64_t)n0 * g.C + col];
+                const float g1 = (int64_t)(n0 + 1) * g.ep.gate_L < g.R ? g.ep.gate[(int64_t)(n0 + 1) * g.C + col] : 0.f;
+#pragma unroll
+                for (int r0 = 0; r0 < 16; r0 += 8) {
+                    float rv[8];
+#pragma unroll
+                    for (int r = r0; r < r0 + 8; ++r) {
+                        const int ro = (r & 3) + 8 * (r >> 2);
+                        rv[r - r0]   = ro < nvl ? ld_u(ur + (int64_t)ro * g.ldd, lb) : 0.f;
+                    }
+#pragma unroll
+                    for (int r = r0; r < r0 + 8; ++r) {
+                        const int ro = (r & 3) + 8 * (r >> 2);
+                        if (ro >= nvl) continue;
+                        st_u(ub + (int64_t)ro * g.ldd, lb, (acc[rb][cb][r] * g.ep.scale + bias) * (ro >= wrap_at ? g1 : g0) + rv[r - r0]);
+                    }
+                }
             } else if (MODE == EPI_HM_F32 || MODE == EPI_HM_F16) {
                 // attention operand layout [d, L, H, N] — what CONT(permute(0,2,1,3)) (+CPY f16) of the projection would hold:
                 // element (row = n*L + l, col = h*d + dd) -> n*(H*L*d) + h*(L*d) + l*d + dd.  L >= 32: the 32 rows of a block cross at
@@ -437,13 +472,18 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm16(G16Args g) {
                 epi_linear<EPI_HM_F16>(acc, g, row0, col0, wr, wc, lane);
             else
                 epi_linear<EPI_HM_F32>(acc, g, row0, col0, wr, wc, lane);
+        } else if (g.ep.gate) {
+            epi_linear<EPI_F32_GATE>(acc, g, row0, col0, wr, wc, lane);
         } else if (plain && g.hm_d == 0 && g.dst && !g.dst16) {
             if (g.ep.residual)
                 epi_linear<EPI_F32_RES>(acc, g, row0, col0, wr, wc, lane);
             else
                 epi_linear<EPI_F32>(acc, g, row0, col0, wr, wc, lane);
-        } else if (plain && g.hm_d == 0 && g.dst16 && !g.dst && !g.ep.residual) {
-            epi_linear<EPI_F16>(acc, g, row0, col0, wr, wc, lane);
+        } else if (g.hm_d == 0 && g.dst16 && !g.dst && !g.ep.residual) {
+            if (g.ep.gelu)
+                epi_linear<EPI_F16_GELU>(acc, g, row0, col0, wr, wc, lane);
+            else
+                epi_linear<EPI_F16>(acc, g, row0, col0, wr, wc, lane);
         } else {
             epi_linear<EPI_GENERIC>(acc, g, row0, col0, wr, wc, lane);
         }
@@ -699,14 +739,18 @@ void launch_gemm16_linear(hipStream_t s, float* dst, void* dst16, int64_t ldd16,
     g.C     = M;
     g.nt    = (int)(Kp / (g16_bk32() ? 32 : 64));
     g16_check_epi(e);
-    g.ep    = {e.bias, e.residual, e.scale};
-    const int S = (splitk_ws && dst && !dst16 && hm_d == 0 && ldd == M) ? gemm16_split_k(rows, M, K) : 1;
+    g.ep    = {e.bias, e.residual, e.scale, e.gate, e.gate_L, e.gelu};
+    if ((e.gate && (!e.residual || e.gate_L < 32 || !dst || dst16 || hm_d > 0 || rows >= (1ll << 31))) || (e.gelu && (dst || !dst16 || e.residual || hm_d > 0))) {
+        fprintf(stderr, "ggml-mi355x: invalid gated / gelu gemm16 epilogue request\n");
+        abort();
+    }
+    const int S = (splitk_ws && dst && !dst16 && hm_d == 0 && ldd == M && !e.gate) ? gemm16_split_k(rows, M, K) : 1;
     if (S > 1) {
         g.split_k  = S;
         g.nt_slice = (g.nt + S - 1) / S;
         g.slab     = rows * M;
         g.dst      = splitk_ws;
-        g.ep       = {nullptr, nullptr, e.scale};
+        g.ep       = G16Epi{nullptr, nullptr, e.scale};
     }
     // narrow outputs (M = 320: 2.5 tiles of 128) waste less with 64-wide column tiles
     const bool bn64 = M <= 64;
@@ -735,7 +779,7 @@ void launch_gemm16_linear_geglu(hipStream_t s, void* dst16, const void* a16, int
     g.R           = rows;
     g.C           = M;
     g.nt          = (int)(Kp / (g16_bk32() ? 32 : 64));
-    g.ep          = {bias, nullptr, 1.f};
+    g.ep          = G16Epi{bias, nullptr, 1.f};
     g.ncol_tiles  = (int)((M + 127) / 128);
     if (g16_trace()) fprintf(stderr, "G16 linear rows=%lld K=%lld M=%lld res=0 hm=0 f16out=1 geglu=1\n", (long long)rows, (long long)K, (long long)M);
     g16_launch<128, false>(s, g, rows, 2.0 * rows * K * M);
@@ -766,14 +810,14 @@ void launch_gemm16_conv(hipStream_t s, float* dst, const void* x16_nhwc, const v
     g.C    = OC;
     g.zero = zero_page();
     g16_check_epi(e);
-    g.ep   = {e.bias, e.residual, e.scale};
+    g.ep   = G16Epi{e.bias, e.residual, e.scale};
     const int S = splitk_ws ? gemm16_split_k(g.R, OC, (int64_t)g.ICp * ksize * ksize) : 1;
     if (S > 1) {
         g.split_k  = S;
         g.nt_slice = (g.nt + S - 1) / S;
         g.slab     = g.R * OC;
         g.dst      = splitk_ws;
-        g.ep       = {nullptr, nullptr, e.scale};
+        g.ep       = G16Epi{nullptr, nullptr, e.scale};
     }
     const bool bn64 = OC <= 64;
     if (g16_trace())
@@ -825,11 +869,17 @@ void launch_pack_rows_f16(hipStream_t s, void* dst, const float* x, int64_t R, i
 }
 
 // LayerNorm / RMSNorm (+affine) writing the f16 operand image: one wave per row
+// mod_L > 0: adaLN modulate (mmdit.hpp:368-380) — w and b are per-image [images][ne0] tables and the affine is norm * (1 + w) + b
 __global__ __launch_bounds__(256) void k_layer_norm_f16(_Float16* __restrict__ dst, const float* __restrict__ x, int ne0, int Kp, int64_t nrows, int64_t xs,
-                                                        float eps, const float* __restrict__ w, const float* __restrict__ b, int rms) {
+                                                        float eps, const float* __restrict__ w, const float* __restrict__ b, int rms, int64_t mod_L) {
     const int lane    = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= nrows) return;
+    const float wadd = mod_L > 0 ? 1.f : 0.f;
+    if (mod_L > 0) {
+        w += (row / mod_L) * ne0;
+        b += (row / mod_L) * ne0;
+    }
     const float* xr = x + row * xs;
     _Float16* yr    = dst + row * Kp;
     const int n4    = ne0 / 4;  // callers guarantee ne0 % 4 == 0 and 16-byte alignment
@@ -854,16 +904,17 @@ __global__ __launch_bounds__(256) void k_layer_norm_f16(_Float16* __restrict__ d
         if (i < n4) {
             float4 v = ((const float4*)xr)[i];
             v.x = (v.x - mean) * rstd; v.y = (v.y - mean) * rstd; v.z = (v.z - mean) * rstd; v.w = (v.w - mean) * rstd;
-            if (w) { const float4 ww = ((const float4*)w)[i]; v.x *= ww.x; v.y *= ww.y; v.z *= ww.z; v.w *= ww.w; }
+            if (w) { const float4 ww = ((const float4*)w)[i]; v.x *= ww.x + wadd; v.y *= ww.y + wadd; v.z *= ww.z + wadd; v.w *= ww.w + wadd; }
             if (b) { const float4 bb = ((const float4*)b)[i]; v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w; }
             h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
         }
         *(half4_t*)(yr + i * 4) = h;
     }
 }
-void launch_layer_norm_f16(hipStream_t s, void* dst, const float* x, int64_t ne0, int64_t nrows, int64_t xs, float eps, const float* w, const float* b, bool rms) {
+void launch_layer_norm_f16(hipStream_t s, void* dst, const float* x, int64_t ne0, int64_t nrows, int64_t xs, float eps, const float* w, const float* b, bool rms,
+                           int64_t mod_L) {
     const int Kp = (int)rup64(ne0, 64);
-    k_layer_norm_f16<<<(unsigned)((nrows + 3) / 4), 256, 0, s>>>((_Float16*)dst, x, (int)ne0, Kp, nrows, xs, eps, w, b, rms ? 1 : 0);
+    k_layer_norm_f16<<<(unsigned)((nrows + 3) / 4), 256, 0, s>>>((_Float16*)dst, x, (int)ne0, Kp, nrows, xs, eps, w, b, rms ? 1 : 0, mod_L);
 }
 
 // GEGLU writing the f16 operand image: dst[t][i] = x[t][i] * gelu(x[t][inner+i])

@@ -64,6 +64,10 @@ struct Epilogue {
     const float* chan_add = nullptr;  // conv only: per (oc, n) value added (time-embedding broadcast), [OC, N]
     float scale           = 1.0f;     // applied to the accumulator before bias
     int act               = -1;       // UnOp applied last, or -1
+    // gemm16 linear only (DiT blocks):
+    const float* gate     = nullptr;  // [images][M]: dst = (acc*scale + bias) * gate[row / gate_L][col] + residual
+    int gate_L            = 0;        // rows per image
+    int gelu              = 0;        // f16-only output: tanh-GELU applied before rounding
 };
 // Linear: dst[tok][m] = sum_k x[tok][k] * W[m][k]   x f32 rows (row stride x_stride floats), dst row stride M
 void launch_linear_mfma(hipStream_t s, float* dst, const float* x, const void* wswz, int64_t tokens, int64_t K, int64_t M,
@@ -99,8 +103,9 @@ void launch_gemm16_conv(hipStream_t s, float* dst, const void* x16_nhwc, const v
 // producers of f16 operand images (row stride = K rounded up to 64, zero padded)
 // L > 0: rows are N runs of L rows, run n starting bs elements after run n-1 (a token slice of a [C, Lfull, N] tensor)
 void launch_pack_rows_f16(hipStream_t s, void* dst, const float* x, int64_t R, int64_t K, int64_t xs, int64_t L = 0, int64_t bs = 0);
+// mod_L > 0: w, b are per-image [rows / mod_L][ne0] adaLN tables and the affine is norm * (1 + w) + b (DiT modulate)
 void launch_layer_norm_f16(hipStream_t s, void* dst, const float* x, int64_t ne0, int64_t nrows, int64_t x_stride, float eps, const float* w,
-                           const float* b, bool rms);
+                           const float* b, bool rms, int64_t mod_L = 0);
 void launch_geglu_f16(hipStream_t s, void* dst, const float* x, int64_t tokens, int64_t inner, int64_t x_stride);
 void launch_gn_stats(hipStream_t s, float* scale, float* shift, const float* x, int64_t hw, int64_t C, int64_t N, int groups, float eps,
                      const float* w, const float* b);

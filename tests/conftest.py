@@ -48,4 +48,8 @@ def gpu(sd):
         sd.load_backend(ROOT / "oracle" / "_build" / "libggml-cpu-oracle.so")
         return "CPU-oracle"
     sd.load_mi355x_backend()
+    # debugging aid: SDCPP_BACKEND_OPTS="fuse_gate=0,gemm16_tile=1" applies planner options for the whole session
+    for kv in filter(None, os.environ.get("SDCPP_BACKEND_OPTS", "").split(",")):
+        k, v = kv.split("=")
+        sd.backend_set_option(k.strip(), int(v))
     return "MI355X0"
