@@ -38,7 +38,7 @@ if (os.cpu_count() or 1) > 32:
     os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")  # cpu_baseline leg (OpenMP oracle) on a big shared host
 
 # algorithmic work per unit: 2*M*N*K per Linear / conv, 4*Lq*Lk*H*d per attention
-UNET_FWD_TFLOP = {"sd15": 0.803, "sdxl": 6.761, "sd35": 29.60}
+UNET_FWD_TFLOP = {"sd15": 0.803, "sdxl": 6.761, "sd35": 29.60, "flux": 69.47}
 MFMA_PEAK_TFLOPS = 2500.0
 
 
@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--model", default="sd15", choices=["sd15", "sdxl", "sd15_tiny", "sd35", "sd35_tiny"])
+    ap.add_argument("--model", default="sd15", choices=["sd15", "sdxl", "sd15_tiny", "sd35", "sd35_tiny", "flux", "flux_tiny"])
     ap.add_argument("--batch", type=int, default=8, help="images per GPU (device batch)")
     ap.add_argument("--no-flash", action="store_true")
     ap.add_argument("--hip-graph", type=int, default=0)
@@ -78,10 +78,12 @@ def main():
 
     sd.load_mi355x_backend()
     L = sd.lib()
-    model_id = {"sd15": sd.SD15, "sdxl": sd.SDXL, "sd15_tiny": sd.SD15_TINY, "sd35": sd.SD35_LARGE, "sd35_tiny": sd.SD35_TINY}[args.model]
+    model_id = {"sd15": sd.SD15, "sdxl": sd.SDXL, "sd15_tiny": sd.SD15_TINY, "sd35": sd.SD35_LARGE, "sd35_tiny": sd.SD35_TINY,
+                "flux": sd.FLUX_DEV, "flux_tiny": sd.FLUX_TINY}[args.model]
     backend_name = f"MI355X{local_rank if local_rank < len([d for d in sd.devices() if d.startswith('MI355X')]) else 0}"
-    dit = args.model.startswith("sd35")
-    wtype = sd.Q8_0 if args.model == "sdxl" else (sd.BF16 if dit else sd.F16)   # BASELINE.json configs 3 / 5
+    flux = args.model.startswith("flux")
+    dit = args.model.startswith("sd35") or flux
+    wtype = sd.Q8_0 if args.model == "sdxl" else (sd.Q4_0 if flux else (sd.BF16 if dit else sd.F16))   # BASELINE.json configs 3 / 4 / 5
     eng = sd.Engine(model=model_id, backend=backend_name, wtype=wtype, flash_attn=not args.no_flash)
     sd.backend_set_option("hip_graph", args.hip_graph)
     if args.g16_variant >= 0:
@@ -89,10 +91,10 @@ def main():
 
     rng = np.random.default_rng(1234 + rank)
     tiny = args.model == "sd15_tiny"
-    lat = 128 if args.model in ("sdxl", "sd35") else (16 if tiny or args.model == "sd35_tiny" else 64)
-    ctx_dim = {"sdxl": 2048, "sd35": 4096, "sd35_tiny": 96}.get(args.model, 64 if tiny else 768)
-    n_tok = 154 if dit else 77
-    y_dim = {"sdxl": 2816, "sd35": 2048, "sd35_tiny": 64}.get(args.model)
+    lat = 128 if args.model in ("sdxl", "sd35", "flux") else (16 if tiny or args.model in ("sd35_tiny", "flux_tiny") else 64)
+    ctx_dim = {"sdxl": 2048, "sd35": 4096, "sd35_tiny": 96, "flux": 4096, "flux_tiny": 96}.get(args.model, 64 if tiny else 768)
+    n_tok = 256 if flux else (154 if dit else 77)
+    y_dim = {"sdxl": 2816, "sd35": 2048, "sd35_tiny": 64, "flux": 768, "flux_tiny": 64}.get(args.model)
     B = args.batch
     cond = rng.standard_normal((1, n_tok, ctx_dim)).astype(np.float32)
     uncond = np.random.default_rng(1235).standard_normal((1, n_tok, ctx_dim)).astype(np.float32)
@@ -100,7 +102,7 @@ def main():
     x = rng.standard_normal((B, 16 if dit else 4, lat, lat)).astype(np.float32)
     t = np.full((B,), 500.0, dtype=np.float32)
 
-    fuse = not args.no_fuse_cfg
+    fuse = not args.no_fuse_cfg and not flux   # FLUX.1-dev is guidance-distilled: cfg 1, ONE model call per step
     x2 = np.repeat(x, 2, axis=0)            # (b cond, b uncond, ...) interleaved
     t2 = np.repeat(t, 2)
     c2 = np.concatenate([cond, uncond], 0)  # [2,77,D]: tiled over the 2B images by the graph's ggml_repeat
@@ -109,7 +111,9 @@ def main():
     def step():
         # one sampler iteration's model work: cond + uncond forward over the device batch (host CFG/Euler math is included
         # in the e2e number; here the H2D/D2H crossings of the reference boundary are part of the step, as in the reference)
-        if fuse:
+        if flux:
+            eng.unet_forward(x, t * 0.0 + 0.5, cond, y)
+        elif fuse:
             eng.unet_forward(x2, t2, c2, y2)
         else:
             eng.unet_forward(x, t, cond, y)
@@ -143,7 +147,7 @@ def main():
     its = B * world * args.steps / dt
 
     fwd_tflop = UNET_FWD_TFLOP.get(args.model, 0.0)
-    step_tflops = (2 * B * fwd_tflop) / (ms_per_step / 1e3) if fwd_tflop else 0.0
+    step_tflops = ((1 if flux else 2) * B * fwd_tflop) / (ms_per_step / 1e3) if fwd_tflop else 0.0
     roofline = {"bound": "mfma", "achieved": None, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None}
     if kt and kt["launches"] > 0 and kt["total_ms"] > 0:
         achieved = kt["total_flops"] / (kt["total_ms"] * 1e-3) / 1e12
@@ -174,7 +178,7 @@ def main():
         "vs_baseline": None,
         "dtype": "f16",
         "data": "synthetic",
-        "config": {"workload": f"{args.model} {'MMDiT' if dit else 'UNet'} {lat*8}x{lat*8}, cfg 7 (cond+uncond), {'q8_0 Linear + f16 conv' if args.model == 'sdxl' else ('bf16' if dit else 'f16')} weights, batch {B}/GPU, Euler-A step",
+        "config": {"workload": f"{args.model} {'MMDiT' if dit else 'UNet'} {lat*8}x{lat*8}, {'cfg 1 (distilled guidance 3.5, one forward per step)' if flux else 'cfg 7 (cond+uncond)'}, {'q8_0 Linear + f16 conv' if args.model == 'sdxl' else ('q4_0' if flux else ('bf16' if dit else 'f16'))} weights, batch {B}/GPU, Euler-A step",
                    "global_batch": B * world, "flash_attn": not args.no_flash, "hip_graph": args.hip_graph,
                    "cfg_pair_in_one_graph": fuse},
         "roofline": roofline,

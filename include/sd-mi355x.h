@@ -45,6 +45,9 @@ enum sd_model_family_t {
     SD_MODEL_SD35_LARGE = 4, /* MMDiT, 38 joint blocks, hidden 2432, rms qk-norm (mmdit.hpp); 16-ch VAE scale 1.5305 shift 0.0609;
                                 discrete-flow denoiser, shift 3.0 (denoiser.hpp:1239-1283) */
     SD_MODEL_SD35_TINY  = 5, /* same topology at 3 blocks / hidden 192, with one MMDiT-X self-attention block */
+    SD_MODEL_FLUX_DEV   = 6, /* FLUX.1-dev: 19 double + 38 single stream blocks, hidden 3072, 24 heads, RoPE axes 16/56/56, distilled
+                                guidance input (flux.hpp); 16-ch VAE scale 0.3611 shift 0.1159; FluxFlowDenoiser + Flux scheduler */
+    SD_MODEL_FLUX_TINY  = 7, /* same topology: 2 + 2 blocks, hidden 128, 4 heads, axes 8/12/12 */
 };
 
 /* numeric values = enum ggml_type (stable-diffusion.h:98-143) */
@@ -146,6 +149,9 @@ SD_API void free_sd_images(sd_image_t* images, int num_images);
 /* ---- host-side sampler pieces exposed for known-answer tests ---- */
 SD_API void sd_philox_randn(uint64_t seed, uint32_t offset, uint32_t n, float* out); /* rng_philox.hpp:101-122 */
 SD_API int sd_get_sigmas(int steps, float* out /* steps+1 */);                       /* denoiser.hpp:32-54 + stable-diffusion.cpp:173-186 */
+SD_API void sd_set_guidance(sd_ctx_t* ctx, float guidance); /* FLUX distilled-guidance input (default 3.5, stable-diffusion.h guidance.distilled_guidance) */
+SD_API int sd_get_flux_sigmas(int steps, int image_seq_len, float* out /* steps+1 */); /* FluxScheduler, denoiser.hpp:726-782 */
+SD_API int sd_gen_flux_pe(int h, int w, int patch_size, int context_len, const int* axes_dim, int n_axes, float theta, float* out); /* Rope::gen_flux_pe; returns floats written */
 SD_API int sd_get_flow_sigmas(int steps, float shift, float* out /* steps+1 */);    /* DiscreteFlowDenoiser, denoiser.hpp:1239-1283 (t = 1000*sigma) */
 SD_API float sd_sigma_to_t(float sigma);                                             /* denoiser.hpp:1140-1165 */
 

@@ -339,3 +339,122 @@ def mmdit_forward(engine, model: str, x, timesteps, context, y=None):
     out = linear(w.sub("final_layer.linear."), _modulate(_ln_plain(xt), shift, scale))  # [N, h*w, ps*ps*C] with C fastest
     out = out.view(N, h_, w_, ps, ps, out_ch).permute(0, 5, 1, 3, 2, 4).reshape(N, out_ch, h_ * ps, w_ * ps)
     return out[:, :, :H, :W].contiguous().numpy()
+
+
+# =====================================================================================================
+# FLUX.1 — src/model/diffusion/flux.hpp, written from the model's mathematical definition (BFL reference semantics)
+# =====================================================================================================
+FLUX_CFG = {
+    # name: (hidden, heads, depth, single_depth, axes_dim, theta, guidance_embed)
+    "FLUX_DEV": (3072, 24, 19, 38, (16, 56, 56), 10000.0, True),
+    "FLUX_TINY": (128, 4, 2, 2, (8, 12, 12), 10000.0, True),
+}
+
+
+def flux_rope_table(h_len, w_len, n_txt, axes_dim, theta):
+    """cos / sin per token and rotary pair: ids (0, row, col) for image patches, zeros for text (text first) — rope.hpp:55-106, 398-490"""
+    ids = torch.zeros(n_txt + h_len * w_len, 3)
+    rr, cc = torch.meshgrid(torch.arange(h_len, dtype=torch.float32), torch.arange(w_len, dtype=torch.float32), indexing="ij")
+    ids[n_txt:, 1] = rr.reshape(-1)
+    ids[n_txt:, 2] = cc.reshape(-1)
+    cos, sin = [], []
+    for a, dim in enumerate(axes_dim):
+        half = dim // 2
+        scale = torch.linspace(0.0, (dim - 2) / dim, half) if half > 1 else torch.zeros(1)
+        omega = 1.0 / (theta ** scale)
+        ang = ids[:, a:a + 1] * omega[None]
+        cos.append(torch.cos(ang))
+        sin.append(torch.sin(ang))
+    return torch.cat(cos, -1), torch.cat(sin, -1)  # [L, d_head/2]
+
+
+def _apply_rope(x, cos, sin):
+    # x [B, heads, L, d]; interleaved pairs (x0, x1) -> (x0 cos - x1 sin, x0 sin + x1 cos)  (rope.hpp:966-1004)
+    x0, x1 = x[..., 0::2], x[..., 1::2]
+    out = torch.stack([x0 * cos - x1 * sin, x0 * sin + x1 * cos], dim=-1)
+    return out.flatten(-2)
+
+
+def _flux_qkv(qkv, heads):
+    B, L, C3 = qkv.shape
+    C = C3 // 3
+    q, k, v = qkv.split(C, dim=-1)
+    return [t.view(B, L, heads, C // heads).transpose(1, 2) for t in (q, k, v)]  # [B, heads, L, d]
+
+
+def _flux_rms(w: Weights, x, eps=1e-6):
+    return x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + eps) * w("scale")
+
+
+def _flux_attn(q, k, v, cos, sin):
+    q, k = _apply_rope(q, cos, sin), _apply_rope(k, cos, sin)
+    o = F.scaled_dot_product_attention(q, k, v)
+    B, Hh, L, d = o.shape
+    return o.transpose(1, 2).reshape(B, L, Hh * d)
+
+
+def flux_forward(engine, model: str, x, timesteps, context, y, guidance=3.5):
+    """x [N,16,H,W], timesteps [N] (sigma in (0,1]), context [N|1,L,ctx], y [N|1,vec] -> [N,16,H,W]  (flux.hpp:1008-1337)"""
+    hidden, heads, depth, sdepth, axes, theta, gemb = FLUX_CFG[model]
+    w = Weights(engine, "model.diffusion_model.")
+    x = torch.from_numpy(x).float()
+    N, C, H, W = x.shape
+    t = torch.from_numpy(timesteps).float()
+    ctx = torch.from_numpy(context).float()
+    yy = torch.from_numpy(y).float()
+    if ctx.shape[0] != N:
+        ctx = ctx.repeat(N // ctx.shape[0], 1, 1)
+    if yy.shape[0] != N:
+        yy = yy.repeat(N // yy.shape[0], 1)
+    ps = 2
+    xp = F.pad(x, (0, (ps - W % ps) % ps, 0, (ps - H % ps) % ps))
+    hh, ww = xp.shape[2] // ps, xp.shape[3] // ps
+    # patchify, channel-major then (ph, pw) ("patch_last"): [N, h*w, C*ps*ps]
+    img = xp.view(N, C, hh, ps, ww, ps).permute(0, 2, 4, 1, 3, 5).reshape(N, hh * ww, C * ps * ps)
+    img = linear(w.sub("img_in."), img)
+
+    def embed(wm, v):
+        return linear(wm.sub("out_layer."), F.silu(linear(wm.sub("in_layer."), v)))
+
+    vec = embed(w.sub("time_in."), timestep_embedding(t * 1000.0, 256))
+    if gemb:
+        vec = vec + embed(w.sub("guidance_in."), timestep_embedding(torch.full((N,), float(guidance)) * 1000.0, 256))
+    vec = vec + embed(w.sub("vector_in."), yy)
+    txt = linear(w.sub("txt_in."), ctx)
+    n_txt = txt.shape[1]
+    cos, sin = flux_rope_table(hh, ww, n_txt, axes, theta)
+
+    def mods(wm, n):
+        return linear(wm.sub("lin."), F.silu(vec)).chunk(n, dim=-1)
+
+    def mlp(wm, v):
+        return linear(wm.sub("2."), F.gelu(linear(wm.sub("0."), v), approximate="tanh"))
+
+    for i in range(depth):
+        wb = w.sub(f"double_blocks.{i}.")
+        im, tm = mods(wb.sub("img_mod."), 6), mods(wb.sub("txt_mod."), 6)
+        iq = _flux_qkv(linear(wb.sub("img_attn.qkv."), _modulate(_ln_plain(img), im[0], im[1])), heads)
+        tq = _flux_qkv(linear(wb.sub("txt_attn.qkv."), _modulate(_ln_plain(txt), tm[0], tm[1])), heads)
+        iq[0], iq[1] = _flux_rms(wb.sub("img_attn.norm.query_norm."), iq[0]), _flux_rms(wb.sub("img_attn.norm.key_norm."), iq[1])
+        tq[0], tq[1] = _flux_rms(wb.sub("txt_attn.norm.query_norm."), tq[0]), _flux_rms(wb.sub("txt_attn.norm.key_norm."), tq[1])
+        attn = _flux_attn(*(torch.cat([a, b], dim=2) for a, b in zip(tq, iq)), cos, sin)
+        ta, ia = attn[:, :n_txt], attn[:, n_txt:]
+        img = img + linear(wb.sub("img_attn.proj."), ia) * im[2][:, None]
+        img = img + mlp(wb.sub("img_mlp."), _modulate(_ln_plain(img), im[3], im[4])) * im[5][:, None]
+        txt = txt + linear(wb.sub("txt_attn.proj."), ta) * tm[2][:, None]
+        txt = txt + mlp(wb.sub("txt_mlp."), _modulate(_ln_plain(txt), tm[3], tm[4])) * tm[5][:, None]
+    xs = torch.cat([txt, img], dim=1)
+    for i in range(sdepth):
+        wb = w.sub(f"single_blocks.{i}.")
+        m = mods(wb.sub("modulation."), 3)
+        l1 = linear(wb.sub("linear1."), _modulate(_ln_plain(xs), m[0], m[1]))
+        q, k, v = _flux_qkv(l1[..., :3 * hidden], heads)
+        q, k = _flux_rms(wb.sub("norm.query_norm."), q), _flux_rms(wb.sub("norm.key_norm."), k)
+        attn = _flux_attn(q, k, v, cos, sin)
+        out = linear(wb.sub("linear2."), torch.cat([attn, F.gelu(l1[..., 3 * hidden:], approximate="tanh")], dim=-1))
+        xs = xs + out * m[2][:, None]
+    img = xs[:, n_txt:]
+    shift, scale = linear(w.sub("final_layer.adaLN_modulation.1."), F.silu(vec)).chunk(2, dim=-1)
+    out = linear(w.sub("final_layer.linear."), _modulate(_ln_plain(img), shift, scale))  # [N, h*w, C*ps*ps]
+    out = out.view(N, hh, ww, C, ps, ps).permute(0, 3, 1, 4, 2, 5).reshape(N, C, hh * ps, ww * ps)
+    return out[:, :, :H, :W].contiguous().numpy()

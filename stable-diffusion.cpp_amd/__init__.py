@@ -26,7 +26,7 @@ F32, F16, Q4_0, Q8_0, I32, BF16 = 0, 1, 2, 8, 26, 30
 TYPE_SIZE = {F32: 4, F16: 2, BF16: 2, I32: 4}
 
 # sd_model_family_t
-SD15, SDXL, SD15_TINY, SDXL_TINY, SD35_LARGE, SD35_TINY = 0, 1, 2, 3, 4, 5
+SD15, SDXL, SD15_TINY, SDXL_TINY, SD35_LARGE, SD35_TINY, FLUX_DEV, FLUX_TINY = 0, 1, 2, 3, 4, 5, 6, 7
 EULER, EULER_A = 0, 1
 
 
@@ -239,6 +239,10 @@ def lib() -> C.CDLL:
     L.sd_philox_randn.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p]
     L.sd_get_sigmas.argtypes = [C.c_int, C.c_void_p]
     L.sd_get_flow_sigmas.argtypes = [C.c_int, C.c_float, C.c_void_p]
+    L.sd_get_flux_sigmas.argtypes = [C.c_int, C.c_int, C.c_void_p]
+    L.sd_set_guidance.argtypes = [C.c_void_p, C.c_float]
+    L.sd_set_guidance.restype = None
+    L.sd_gen_flux_pe.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_float, C.c_void_p]
     L.sd_sigma_to_t.argtypes = [C.c_float]
     L.sd_sigma_to_t.restype = C.c_float
     L.sd_get_stats.argtypes = [C.c_void_p, C.POINTER(SdStats)]
@@ -396,6 +400,10 @@ class Engine:
             shape = shape[1:]
         return out.reshape(shape)
 
+    def set_guidance(self, guidance: float) -> None:
+        """FLUX distilled-guidance input (default 3.5)"""
+        lib().sd_set_guidance(self._ctx, float(guidance))
+
     def set_tensor(self, name: str, value: np.ndarray) -> None:
         v = _f32(value).ravel()
         if not lib().sd_set_tensor_f32(self._ctx, name.encode(), _fptr(v), v.size):
@@ -460,7 +468,7 @@ class Engine:
     def sample_latents(self, cond, uncond=None, width=512, height=512, steps=20, cfg=7.0, seed=42, batch=1, device_batch=0,
                        method=EULER_A, eta=float("inf"), cond_y=None, uncond_y=None, fuse_cfg=False) -> np.ndarray:
         p, keep = self._gen_params(cond, uncond, width, height, steps, cfg, seed, batch, device_batch, method, eta, cond_y, uncond_y, fuse_cfg)
-        ch = 16 if self.model in (SD35_LARGE, SD35_TINY) else 4
+        ch = 16 if self.model in (SD35_LARGE, SD35_TINY, FLUX_DEV, FLUX_TINY) else 4
         out = np.empty((batch, ch, height // 8, width // 8), dtype=np.float32)
         if not lib().sd_sample_latents(self._ctx, C.byref(p), _fptr(out)):
             raise EngineError("sd_sample_latents failed: " + lib().sd_last_error().decode())
@@ -495,6 +503,24 @@ def philox_randn(seed: int, offset: int, n: int) -> np.ndarray:
 def get_sigmas(steps: int) -> np.ndarray:
     out = np.empty(steps + 1, dtype=np.float32)
     lib().sd_get_sigmas(steps, _fptr(out))
+    return out
+
+
+def get_flux_sigmas(steps: int, image_seq_len: int) -> np.ndarray:
+    """FluxScheduler sigma ladder, src/runtime/denoiser.hpp:721-782"""
+    out = np.empty(steps + 1, dtype=np.float32)
+    lib().sd_get_flux_sigmas(steps, image_seq_len, _fptr(out))
+    return out
+
+
+def gen_flux_pe(h: int, w: int, patch_size: int, context_len: int, axes_dim, theta: float = 10000.0) -> np.ndarray:
+    """Rope::gen_flux_pe (src/model/common/rope.hpp:424): -> [L, d_head/2, 2, 2] rotation matrices, text tokens first"""
+    ax = (C.c_int * len(axes_dim))(*axes_dim)
+    half = sum(a // 2 for a in axes_dim)
+    L = context_len + ((h + patch_size // 2) // patch_size) * ((w + patch_size // 2) // patch_size)
+    out = np.empty((L, half, 2, 2), dtype=np.float32)
+    n = lib().sd_gen_flux_pe(h, w, patch_size, context_len, ax, len(axes_dim), theta, _fptr(out))
+    assert n == out.size
     return out
 
 

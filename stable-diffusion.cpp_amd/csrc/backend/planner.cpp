@@ -762,9 +762,19 @@ bool plan_layer_norm(Builder& B, int i, hipStream_t, std::vector<int>& chain) {
     const ggml_tensor* n = gi.node(i);
     const ggml_tensor* x = n->src[0];
     if (!is_f32(x) || x->nb[0] != 4 || n->nb[0] != 4) return false;
-    // rows must be uniformly strided: collapse dims 1..3
-    if ((x->ne[2] > 1 && x->nb[2] != x->nb[1] * (size_t)x->ne[1]) || (x->ne[3] > 1 && x->nb[3] != x->nb[2] * (size_t)x->ne[2])) return false;
-    if ((n->ne[2] > 1 && n->nb[2] != n->nb[1] * (size_t)n->ne[1]) || (n->ne[3] > 1 && n->nb[3] != n->nb[2] * (size_t)n->ne[2])) return false;
+    // rows uniformly strided (dims 1..3 collapse) -> fused paths below; anything else (per-head slices of a fused qkv projection) runs the
+    // plain norm through the 3-level row map
+    if ((x->ne[2] > 1 && x->nb[2] != x->nb[1] * (size_t)x->ne[1]) || (x->ne[3] > 1 && x->nb[3] != x->nb[2] * (size_t)x->ne[2]) ||
+        (n->ne[2] > 1 && n->nb[2] != n->nb[1] * (size_t)n->ne[1]) || (n->ne[3] > 1 && n->nb[3] != n->nb[2] * (size_t)n->ne[2])) {
+        for (int d = 1; d < 4; ++d)
+            if (x->nb[d] % 4 != 0 || n->nb[d] % 4 != 0) return false;
+        View4 xv = view_of(x), dv = view_of(n);
+        const float eps4 = ggml_abi_op_param_f32(n, 0);
+        const bool rms4  = n->op == GGML_OP_RMS_NORM;
+        B.emit([=](hipStream_t st) { launch_layer_norm_4d(st, (float*)dv.data, (const float*)xv.data, xv.ne, xv.nb, dv.nb, eps4, nullptr, nullptr, rms4); });
+        chain.push_back(i);
+        return true;
+    }
     const bool rms   = n->op == GGML_OP_RMS_NORM;
     const float eps  = ggml_abi_op_param_f32(n, 0);
     const int64_t C = x->ne[0], rows = x->ne[1] * x->ne[2] * x->ne[3];

@@ -178,20 +178,27 @@ struct sd_ctx_t {
     Runner unet_runner, vae_runner;
     UNetModel unet;
     MMDiTModel mmdit;
-    bool is_dit = false;
+    FluxModel flux;
+    bool is_dit = false, is_flux = false;
+    float guidance = 3.5f;
+    FluxFlowDenoiser flux_denoiser;
     VaeDecoder vae;
     CompVisDenoiser denoiser;
     DiscreteFlowDenoiser flow_denoiser;
-    int in_channels() const { return is_dit ? (int)mmdit.cfg.in_channels : unet.cfg.in_channels; }
-    int out_channels() const { return is_dit ? (int)mmdit.cfg.out_channels : unet.cfg.out_channels; }
-    std::vector<float> get_sigmas(uint32_t n) const { return is_dit ? flow_denoiser.get_sigmas(n) : denoiser.get_sigmas(n); }
+    int in_channels() const { return is_flux ? 16 : (is_dit ? (int)mmdit.cfg.in_channels : unet.cfg.in_channels); }
+    int out_channels() const { return is_flux ? 16 : (is_dit ? (int)mmdit.cfg.out_channels : unet.cfg.out_channels); }
+    std::vector<float> get_sigmas(uint32_t n, int image_seq_len) const {
+        return is_flux ? flux_denoiser.get_sigmas(n, image_seq_len) : (is_dit ? flow_denoiser.get_sigmas(n) : denoiser.get_sigmas(n));
+    }
     void scalings(float sigma, float& c_skip, float& c_out, float& c_in) const {
-        if (is_dit)
+        if (is_flux)
+            flux_denoiser.scalings(sigma, c_skip, c_out, c_in);
+        else if (is_dit)
             flow_denoiser.scalings(sigma, c_skip, c_out, c_in);
         else
             denoiser.scalings(sigma, c_skip, c_out, c_in);
     }
-    float sigma_to_t(float sigma) const { return is_dit ? flow_denoiser.sigma_to_t(sigma) : denoiser.sigma_to_t(sigma); }
+    float sigma_to_t(float sigma) const { return is_flux ? sigma : (is_dit ? flow_denoiser.sigma_to_t(sigma) : denoiser.sigma_to_t(sigma)); }
     sd_stats_t stats{};
     std::vector<std::pair<std::string, ggml_tensor*>> all_tensors;
     ~sd_ctx_t() {
@@ -282,22 +289,27 @@ sd_ctx_t* new_sd_ctx(const sd_ctx_params_t* params) {
 
     const bool xl   = params->model == SD_MODEL_SDXL || params->model == SD_MODEL_SDXL_TINY;
     const bool tiny = params->model == SD_MODEL_SD15_TINY || params->model == SD_MODEL_SDXL_TINY;
-    const bool dit      = params->model == SD_MODEL_SD35_LARGE || params->model == SD_MODEL_SD35_TINY;
-    const bool dit_tiny = params->model == SD_MODEL_SD35_TINY;
+    const bool flux     = params->model == SD_MODEL_FLUX_DEV || params->model == SD_MODEL_FLUX_TINY;
+    const bool dit      = params->model == SD_MODEL_SD35_LARGE || params->model == SD_MODEL_SD35_TINY || flux;
+    const bool dit_tiny = params->model == SD_MODEL_SD35_TINY || params->model == SD_MODEL_FLUX_TINY;
     UNetConfig ucfg = tiny ? UNetConfig::tiny(xl) : (xl ? UNetConfig::sdxl_base() : UNetConfig::sd15());
     VaeConfig vcfg  = (tiny || dit_tiny) ? VaeConfig::tiny() : (xl ? VaeConfig::sdxl() : VaeConfig::sd15());
     if (tiny && xl) vcfg.scale_factor = 0.13025f;
     if (dit) {  // SD3 VAE: 16 latent channels, no post_quant_conv (auto_encoder_kl.hpp:548-556, 682-684)
         vcfg.z_channels   = 16;
         vcfg.use_quant    = false;
-        vcfg.scale_factor = 1.5305f;
-        vcfg.shift_factor = 0.0609f;
+        vcfg.scale_factor = flux ? 0.3611f : 1.5305f;  // auto_encoder_kl.hpp:682-687
+        vcfg.shift_factor = flux ? 0.1159f : 0.0609f;
     }
 
     ctx->unet_runner.backend        = backend;
     ctx->unet_runner.ps.linear_type = (ggml_type)params->wtype;
     ctx->is_dit                     = dit;
-    if (dit) {
+    ctx->is_flux                    = flux;
+    if (flux) {
+        ctx->unet_runner.graph_size = 32768 * 4;  // FLUX_GRAPH_SIZE headroom
+        ctx->flux.init(ctx->unet_runner.ps, "model.diffusion_model.", dit_tiny ? FluxConfig::tiny() : FluxConfig::flux_dev());
+    } else if (dit) {
         ctx->unet_runner.graph_size = 10240 * 8;  // MMDIT_GRAPH_SIZE (mmdit.hpp:14) x our batch headroom
         ctx->mmdit.init(ctx->unet_runner.ps, "model.diffusion_model.", dit_tiny ? MMDiTConfig::tiny() : MMDiTConfig::sd35_large());
     } else
@@ -370,6 +382,15 @@ bool sd_set_tensor_f32(sd_ctx_t* ctx, const char* name, const float* src, int64_
 bool sd_unet_forward(sd_ctx_t* ctx, const float* x, int w, int h, int c, int n, const float* timesteps, const float* context,
                      int64_t ctx_dim, int64_t n_tokens, int64_t ctx_n, const float* y, int64_t y_dim, int64_t y_n, float* out) {
     Runner& r = ctx->unet_runner;
+    std::vector<float> guidance_vec, pe_vec;
+    if (ctx->is_flux) {
+        if (y == nullptr) {
+            set_error("FLUX needs the pooled text vector y");
+            return false;
+        }
+        guidance_vec.assign(n, ctx->guidance);
+        pe_vec = gen_flux_pe(h, w, ctx->flux.cfg.patch_size, (int)n_tokens, ctx->flux.cfg.axes_dim, (float)ctx->flux.cfg.theta);
+    }
     auto build = [&](GraphCtx& g, std::vector<HostInput>& in) {
         g.flash_attn   = ctx->params.diffusion_flash_attn;
         g.conv_direct  = ctx->params.diffusion_conv_direct;
@@ -387,6 +408,17 @@ bool sd_unet_forward(sd_ctx_t* ctx, const float* x, int w, int h, int c, int n, 
             ty = ggml_new_tensor_2d(g.ctx, GGML_TYPE_F32, y_dim, y_n);
             ggml_set_input(ty);
             in.push_back({ty, y, ggml_nbytes(ty)});
+        }
+        if (ctx->is_flux) {
+            // guidance [N] and the rotary table are host-built inputs of every call (flux.hpp:1457-1500: pe_vec generated on the CPU and uploaded)
+            ggml_tensor* tg = ggml_new_tensor_1d(g.ctx, GGML_TYPE_F32, n);
+            ggml_set_input(tg);
+            in.push_back({tg, guidance_vec.data(), ggml_nbytes(tg)});
+            const FluxConfig& fc = ctx->flux.cfg;
+            ggml_tensor* tp      = ggml_new_tensor_4d(g.ctx, GGML_TYPE_F32, 2, 2, fc.hidden_size / fc.num_heads / 2, (int64_t)pe_vec.size() / (2 * (fc.hidden_size / fc.num_heads)));
+            ggml_set_input(tp);
+            in.push_back({tp, pe_vec.data(), ggml_nbytes(tp)});
+            return ctx->flux.forward(g, tx, tt, tc, ty, tg, tp);
         }
         return ctx->is_dit ? ctx->mmdit.forward(g, tx, tt, tc, ty) : ctx->unet.forward(g, tx, tt, tc, ty);
     };
@@ -430,7 +462,7 @@ static bool sample_group(sd_ctx_t* ctx, const sd_img_gen_params_t* p, int b0, in
     const sd_sample_params_t& sp = p->sample_params;
     float eta = sp.eta;
     if (eta == INFINITY) eta = sp.sample_method == EULER_A_SAMPLE_METHOD ? 1.0f : 0.0f;  // resolve_eta, stable-diffusion.cpp:4024-4049
-    const std::vector<float> sigmas = ctx->get_sigmas(sp.sample_steps);
+    const std::vector<float> sigmas = ctx->get_sigmas(sp.sample_steps, W * H);  // image_seq_len = latent pixels (stable-diffusion.cpp:2983-2986)
     const int steps                 = (int)sigmas.size() - 1;
 
     // per-image RNG: seed+b; initial noise consumes offset 0 (stable-diffusion.cpp:5678-5683; rng == sampler_rng :886-889)
@@ -596,6 +628,18 @@ int sd_get_sigmas(int steps, float* out) {
     std::vector<float> s = d.get_sigmas(steps);
     memcpy(out, s.data(), s.size() * sizeof(float));
     return (int)s.size();
+}
+void sd_set_guidance(sd_ctx_t* ctx, float guidance) { ctx->guidance = guidance; }
+int sd_get_flux_sigmas(int steps, int image_seq_len, float* out) {
+    FluxFlowDenoiser d;
+    std::vector<float> s = d.get_sigmas(steps, image_seq_len);
+    memcpy(out, s.data(), s.size() * sizeof(float));
+    return (int)s.size();
+}
+int sd_gen_flux_pe(int h, int w, int patch_size, int context_len, const int* axes_dim, int n_axes, float theta, float* out) {
+    std::vector<float> pe = gen_flux_pe(h, w, patch_size, context_len, std::vector<int>(axes_dim, axes_dim + n_axes), theta);
+    memcpy(out, pe.data(), pe.size() * sizeof(float));
+    return (int)pe.size();
 }
 int sd_get_flow_sigmas(int steps, float shift, float* out) {
     DiscreteFlowDenoiser d;

@@ -143,18 +143,25 @@ inline ggml_tensor* ext_group_norm(ggml_context* c, ggml_tensor* x, ggml_tensor*
 }
 
 // ggml_ext_attention_ext — ggml_extend.hpp:1349-1485 (no mask, kv_scale = 1, skip_reshape = false)
-inline ggml_tensor* ext_attention(GraphCtx& g, ggml_tensor* q, ggml_tensor* k, ggml_tensor* v, int64_t n_head) {
+// skip_reshape (ggml_extend.hpp:1383-1390): q, k arrive as [d_head, L, n_head*N] and v as [d_head, n_head, L, N] (Rope::attention)
+inline ggml_tensor* ext_attention(GraphCtx& g, ggml_tensor* q, ggml_tensor* k, ggml_tensor* v, int64_t n_head, bool skip_reshape = false) {
     ggml_context* c = g.ctx;
-    const int64_t L_q = q->ne[1], L_k = k->ne[1], C = q->ne[0], N = q->ne[2];
-    const int64_t d_head = C / n_head, n_kv_head = k->ne[0] / d_head;
-
-    q = ggml_reshape_4d(c, q, d_head, n_head, L_q, N);
-    q = ext_cont(c, ggml_permute(c, q, 0, 2, 1, 3));
-    q = ggml_reshape_3d(c, q, d_head, L_q, n_head * N);
-    k = ggml_reshape_4d(c, k, d_head, n_kv_head, L_k, N);
-    k = ext_cont(c, ggml_permute(c, k, 0, 2, 1, 3));
-    k = ggml_reshape_3d(c, k, d_head, L_k, n_kv_head * N);
-    v = ggml_reshape_4d(c, v, d_head, n_kv_head, L_k, N);
+    int64_t L_q = q->ne[1], L_k = k->ne[1], C = q->ne[0], N = q->ne[2];
+    int64_t d_head = C / n_head, n_kv_head = k->ne[0] / d_head;
+    if (!skip_reshape) {
+        q = ggml_reshape_4d(c, q, d_head, n_head, L_q, N);
+        q = ext_cont(c, ggml_permute(c, q, 0, 2, 1, 3));
+        q = ggml_reshape_3d(c, q, d_head, L_q, n_head * N);
+        k = ggml_reshape_4d(c, k, d_head, n_kv_head, L_k, N);
+        k = ext_cont(c, ggml_permute(c, k, 0, 2, 1, 3));
+        k = ggml_reshape_3d(c, k, d_head, L_k, n_kv_head * N);
+        v = ggml_reshape_4d(c, v, d_head, n_kv_head, L_k, N);
+    } else {
+        d_head    = v->ne[0];
+        N         = v->ne[3];
+        n_kv_head = k->ne[2] / N;
+        C         = d_head * n_head;
+    }
 
     const float scale = 1.0f / sqrtf((float)d_head);
     ggml_tensor* kqv  = nullptr;
@@ -444,6 +451,35 @@ struct PlainLayerNorm {
     float eps = 1e-6f;
     ggml_tensor* forward(GraphCtx& g, ggml_tensor* x) const { return ext_layer_norm(g.ctx, x, nullptr, nullptr, eps); }
 };
+
+// Rope::apply_rope (interleaved) — src/model/common/rope.hpp:966-1004.  x [d_head, n_head, L, N], pe [2, 2, d_head/2, L] -> [d_head, L, n_head*N]
+inline ggml_tensor* apply_rope(ggml_context* c, ggml_tensor* x, ggml_tensor* pe) {
+    const int64_t d_head = x->ne[0], n_head = x->ne[1], L = x->ne[2], N = x->ne[3];
+    x = ggml_cont(c, ggml_permute(c, x, 0, 2, 1, 3));            // [d_head, L, n_head, N]
+    x = ggml_reshape_4d(c, x, 2, d_head / 2, L, n_head * N);
+    x = ggml_cont(c, ggml_permute(c, x, 3, 0, 1, 2));            // [d_head/2, L, n_head*N, 2]
+    size_t off       = x->nb[2] * x->ne[2];
+    ggml_tensor* x_0 = ggml_view_3d(c, x, x->ne[0], x->ne[1], x->ne[2], x->nb[1], x->nb[2], 0);
+    ggml_tensor* x_1 = ggml_view_3d(c, x, x->ne[0], x->ne[1], x->ne[2], x->nb[1], x->nb[2], off);
+    x_0              = ggml_reshape_4d(c, x_0, 1, x_0->ne[0], x_0->ne[1], x_0->ne[2]);
+    x_1              = ggml_reshape_4d(c, x_1, 1, x_1->ne[0], x_1->ne[1], x_1->ne[2]);
+    ggml_tensor* tmp = ggml_new_tensor_4d(c, x_0->type, 2, x_0->ne[1], x_0->ne[2], x_0->ne[3]);
+    x_0              = ggml_repeat(c, x_0, tmp);
+    x_1              = ggml_repeat(c, x_1, tmp);
+    pe               = ggml_cont(c, ggml_permute(c, pe, 3, 0, 1, 2));  // [2, d_head/2, L, 2]
+    off              = pe->nb[2] * pe->ne[2];
+    ggml_tensor* pe_0 = ggml_view_3d(c, pe, pe->ne[0], pe->ne[1], pe->ne[2], pe->nb[1], pe->nb[2], 0);
+    ggml_tensor* pe_1 = ggml_view_3d(c, pe, pe->ne[0], pe->ne[1], pe->ne[2], pe->nb[1], pe->nb[2], off);
+    ggml_tensor* out  = ggml_add_inplace(c, ggml_mul(c, x_0, pe_0), ggml_mul(c, x_1, pe_1));
+    return ggml_reshape_3d(c, out, d_head, L, n_head * N);
+}
+// Rope::attention — rope.hpp:1006-1025
+inline ggml_tensor* rope_attention(GraphCtx& g, ggml_tensor* q, ggml_tensor* k, ggml_tensor* v, ggml_tensor* pe) {
+    const int64_t n_head = q->ne[1];
+    q = apply_rope(g.ctx, q, pe);
+    k = apply_rope(g.ctx, k, pe);
+    return ext_attention(g, q, k, v, n_head, true);
+}
 
 // Mlp — src/model/common/block.hpp:230-259 (GELU tanh)
 struct Mlp {

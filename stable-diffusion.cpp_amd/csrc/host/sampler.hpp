@@ -137,6 +137,34 @@ struct DiscreteFlowDenoiser {
     }
 };
 
+// FluxFlowDenoiser (denoiser.hpp:1285-1300) with the Flux scheduler (denoiser.hpp:721-782): sigma(t) = e^mu / (e^mu + (1/t - 1)), the
+// shift mu interpolated linearly in the image sequence length between (256, 0.5) and (4096, 1.15); the model sees t = sigma
+struct FluxFlowDenoiser {
+    float base_shift = 0.5f, max_shift = 1.15f;
+    static float time_shift(float mu, float sigma, float t) { return ::expf(mu) / (::expf(mu) + ::powf(1.0f / t - 1.0f, sigma)); }
+    float sigma_to_t(float sigma) const { return sigma; }
+    std::vector<float> get_sigmas(uint32_t n, int image_seq_len) const {
+        const float m  = (max_shift - base_shift) / (4096.0f - 256.0f), b = base_shift - m * 256.0f;
+        const float mu = (float)image_seq_len * m + b;
+        std::vector<float> s;
+        if (n == 0) {
+            s.push_back(1.0f);
+            return s;
+        }
+        for (uint32_t i = 0; i <= n; ++i) {
+            const float t = 1.0f - (float)i / (float)n;
+            s.push_back(t <= 0.0f ? 0.0f : time_shift(mu, 1.0f, t));
+        }
+        s[n] = 0.0f;
+        return s;
+    }
+    void scalings(float sigma, float& c_skip, float& c_out, float& c_in) const {
+        c_skip = 1.0f;
+        c_out  = -sigma;
+        c_in   = 1.0f;
+    }
+};
+
 // get_ancestral_step — denoiser.hpp:1447-1467
 inline void ancestral_step(float sigma_from, float sigma_to, float eta, float& sigma_down, float& sigma_up) {
     sigma_up   = 0.0f;

@@ -40,6 +40,9 @@ void launch_group_norm(hipStream_t s, float* dst, const float* x, int64_t hw, in
 // NORM / RMS_NORM over rows of ne0 contiguous f32 (row strides in floats); optional fused affine
 void launch_layer_norm(hipStream_t s, float* dst, const float* x, int64_t ne0, int64_t nrows, int64_t x_stride, int64_t d_stride,
                        float eps, const float* w, const float* b, bool rms);
+// rows addressed by (i1, i2, i3) with byte strides xnb / dnb (strided views: per-head slices of a fused qkv projection)
+void launch_layer_norm_4d(hipStream_t s, float* dst, const float* x, const int64_t ne[4], const int64_t xnb[4], const int64_t dnb[4], float eps, const float* w,
+                          const float* b, bool rms);
 void launch_soft_max(hipStream_t s, float* dst, const float* x, int64_t ncols, int64_t nrows, float scale, const View4* mask,
                      int64_t rows_per_mat);
 

@@ -94,13 +94,28 @@ void launch_group_norm(hipStream_t s, float* dst, const float* x, int64_t hw, in
 }
 
 // one wave per row
-__global__ __launch_bounds__(256) void k_layer_norm(float* __restrict__ dst, const float* __restrict__ x, int ne0, int64_t nrows, int64_t x_stride,
-                                                    int64_t d_stride, float eps, const float* __restrict__ w, const float* __restrict__ b, int rms) {
+// rows are addressed through RowMap: uniform stride, or a 3-level (i1, i2, i3) decomposition for strided views (the per-head q / k
+// slices of a fused qkv projection, flux.hpp:283-296)
+struct RowMap {
+    int64_t ne1, ne2;          // 0: uniform
+    int64_t s1, s2, s3;        // source strides (elements) of dims 1..3 (s1 = the uniform stride)
+    int64_t d1, d2, d3;        // destination strides
+};
+__global__ __launch_bounds__(256) void k_layer_norm(float* __restrict__ dst, const float* __restrict__ x, int ne0, int64_t nrows, RowMap m, float eps,
+                                                    const float* __restrict__ w, const float* __restrict__ b, int rms) {
     const int lane    = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= nrows) return;
-    const float* xr = x + row * x_stride;
-    float* yr       = dst + row * d_stride;
+    const float* xr;
+    float* yr;
+    if (m.ne1 == 0) {
+        xr = x + row * m.s1;
+        yr = dst + row * m.d1;
+    } else {
+        const int64_t i1 = row % m.ne1, t = row / m.ne1, i2 = t % m.ne2, i3 = t / m.ne2;
+        xr = x + i1 * m.s1 + i2 * m.s2 + i3 * m.s3;
+        yr = dst + i1 * m.d1 + i2 * m.d2 + i3 * m.d3;
+    }
     const bool v4   = (ne0 % 4 == 0) && ((((uintptr_t)xr | (uintptr_t)yr) & 15) == 0) && (!w || (((uintptr_t)w & 15) == 0)) && (!b || (((uintptr_t)b & 15) == 0));
     float mean = 0.f, rstd;
     if (v4) {
@@ -166,7 +181,14 @@ __global__ __launch_bounds__(256) void k_layer_norm(float* __restrict__ dst, con
 void launch_layer_norm(hipStream_t s, float* dst, const float* x, int64_t ne0, int64_t nrows, int64_t x_stride, int64_t d_stride, float eps,
                        const float* w, const float* b, bool rms) {
     const int blocks = (int)((nrows + 3) / 4);
-    k_layer_norm<<<blocks, 256, 0, s>>>(dst, x, (int)ne0, nrows, x_stride, d_stride, eps, w, b, rms ? 1 : 0);
+    RowMap m{0, 0, x_stride, 0, 0, d_stride, 0, 0};
+    k_layer_norm<<<blocks, 256, 0, s>>>(dst, x, (int)ne0, nrows, m, eps, w, b, rms ? 1 : 0);
+}
+void launch_layer_norm_4d(hipStream_t s, float* dst, const float* x, const int64_t ne[4], const int64_t xnb[4], const int64_t dnb[4], float eps, const float* w,
+                          const float* b, bool rms) {
+    const int64_t nrows = ne[1] * ne[2] * ne[3];
+    RowMap m{ne[1], ne[2], xnb[1] / 4, xnb[2] / 4, xnb[3] / 4, dnb[1] / 4, dnb[2] / 4, dnb[3] / 4};
+    k_layer_norm<<<(int)((nrows + 3) / 4), 256, 0, s>>>(dst, x, (int)ne[0], nrows, m, eps, w, b, rms ? 1 : 0);
 }
 
 // one block per row; mask (f16 or f32) row selected as row % rows_per_mat (broadcast over batch)

@@ -117,3 +117,37 @@ def test_mmdit_flow_trajectory_and_vae_parity(sd, oracle, gpu):
     psnr = 10 * np.log10(1.0 / max(float(np.mean((a.astype(np.float64) - b) ** 2)), 1e-20))
     print(f"16-channel VAE decode PSNR {psnr:.1f} dB")
     assert psnr > 35.0
+
+
+@pytest.mark.parametrize("flash,wtype", [(True, "F16"), (False, "F16"), (True, "Q4_0")])
+def test_flux_forward_parity(sd, oracle, gpu, flash, wtype):
+    """FLUX (tiny width, same topology: double + single stream blocks, RoPE node chain, fused qkv+mlp linear1) — SURVEY.md row a12.
+    q4_0 Linear weights (config 4): the GPU multiplies f16-rounded activations with the exactly dequantised weights, the oracle
+    (like ggml-cpu) quantises activations to q8_0 first — the looser bar covers that."""
+    rng = np.random.default_rng(27)
+    x = rng.standard_normal((2, 16, 18, 15)).astype(np.float32)
+    t = np.array([0.81, 0.27], dtype=np.float32)
+    ctx = rng.standard_normal((1, 40, 96)).astype(np.float32)
+    y = rng.standard_normal((1, 64)).astype(np.float32)
+    wt = getattr(sd, wtype)
+    ref = sd.Engine(model=sd.FLUX_TINY, backend=oracle, flash_attn=flash, wtype=wt).unet_forward(x, t, ctx, y)
+    gpu_e = sd.Engine(model=sd.FLUX_TINY, backend=gpu, flash_attn=flash, wtype=wt)
+    out = gpu_e.unet_forward(x, t, ctx, y)
+    assert np.isfinite(out).all()
+    err = rel_l2(out, ref)
+    print(f"FLUX_TINY flash={flash} {wtype}: rel-L2 {err:.3e}, nodes {gpu_e.stats()['graph_nodes']}")
+    assert err < (6e-2 if wtype == "Q4_0" else 5e-3)
+    np.testing.assert_array_equal(out, gpu_e.unet_forward(x, t, ctx, y))
+
+
+def test_flux_trajectory_parity(sd, oracle, gpu):
+    rng = np.random.default_rng(28)
+    cond = rng.standard_normal((1, 24, 96)).astype(np.float32)
+    cy = rng.standard_normal((1, 64)).astype(np.float32)
+    kw = dict(width=128, height=128, steps=4, cfg=1.0, method=sd.EULER, cond_y=cy)
+    out = sd.Engine(model=sd.FLUX_TINY, backend=gpu, flash_attn=True).sample_latents(cond, None, batch=2, device_batch=2, seed=42, **kw)
+    ref_e = sd.Engine(model=sd.FLUX_TINY, backend=oracle, flash_attn=True)
+    ref = np.concatenate([ref_e.sample_latents(cond, None, batch=1, seed=42 + b, **kw) for b in range(2)])
+    err = rel_l2(out, ref)
+    print(f"FLUX flow trajectory rel-L2 {err:.3e}")
+    assert err < 2e-2

@@ -208,3 +208,71 @@ def test_sd35_generate_image_16ch_vae(sd, oracle, eng35):
     two = eng35.generate_image(cond, cond * 0.0, width=64, height=64, steps=2, cfg=4.0, seed=3, batch=2, device_batch=1, method=sd.EULER,
                                cond_y=cy, uncond_y=cy * 0.0, fuse_cfg=False)
     assert np.abs(img.astype(int) - two.astype(int)).max() <= 1
+
+
+# ---------------------------------------------------------------------------------------------------
+# FLUX.1 — SURVEY.md section 8 row a12
+# ---------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def engflux(sd, oracle):
+    return sd.Engine(model=sd.FLUX_TINY, backend=oracle)
+
+
+@pytest.mark.parametrize("H,W", [(10, 12), (9, 7)])
+def test_flux_graph_vs_torch(sd, oracle, engflux, H, W):
+    """Flux graph builder (patchify, double/single stream blocks, RoPE as the reference's cont/repeat/mul/add node chain, fused
+    qkv+mlp linear1, distilled-guidance embedder, last layer, unpatchify+crop) vs the torch restatement with complex-free RoPE."""
+    rng = np.random.default_rng(20)
+    x = rng.standard_normal((2, 16, H, W)).astype(np.float32)
+    t = np.array([0.7, 0.3], dtype=np.float32)
+    ctx = rng.standard_normal((2, 20, 96)).astype(np.float32)
+    y = rng.standard_normal((2, 64)).astype(np.float32)
+    a = engflux.unet_forward(x, t, ctx, y)
+    b = torch_ref.flux_forward(engflux, "FLUX_TINY", x, t, ctx, y)
+    assert a.shape == b.shape == (2, 16, H, W)
+    assert rel_l2(a, b) < 3e-3
+    ef = sd.Engine(model=sd.FLUX_TINY, backend=oracle, flash_attn=True)
+    assert rel_l2(ef.unet_forward(x, t, ctx, y), b) < 5e-3
+    engflux.set_guidance(1.0)
+    assert rel_l2(engflux.unet_forward(x, t, ctx, y), torch_ref.flux_forward(engflux, "FLUX_TINY", x, t, ctx, y, guidance=1.0)) < 3e-3
+    engflux.set_guidance(3.5)
+
+
+def test_flux_rope_table_and_sigmas_known_answers(sd):
+    import torch
+
+    pe = sd.gen_flux_pe(6, 8, 2, 5, (8, 12, 12))        # [L, 16, 2, 2], L = 5 + 3*4
+    cos, sin = torch_ref.flux_rope_table(3, 4, 5, (8, 12, 12), 10000.0)
+    assert pe.shape == (17, 16, 2, 2)
+    np.testing.assert_allclose(pe[:, :, 0, 0], cos.numpy(), atol=1e-6)
+    np.testing.assert_allclose(pe[:, :, 0, 1], -sin.numpy(), atol=1e-6)
+    np.testing.assert_allclose(pe[:, :, 1, 0], sin.numpy(), atol=1e-6)
+    np.testing.assert_allclose(pe[:, :, 1, 1], cos.numpy(), atol=1e-6)
+    assert np.all(pe[:5, :, 0, 0] == 1.0)               # text tokens: position 0 on every axis
+    # FluxScheduler (denoiser.hpp:721-782): mu linear in the sequence length through (256, 0.5), (4096, 1.15)
+    s = sd.get_flux_sigmas(4, 4096)
+    tt = np.array([1.0, 0.75, 0.5, 0.25])
+    ref = np.exp(1.15) / (np.exp(1.15) + (1.0 / tt - 1.0))
+    np.testing.assert_allclose(s[:4], ref, rtol=1e-5)
+    assert s[0] == pytest.approx(1.0) and s[4] == 0.0
+    assert sd.get_flux_sigmas(2, 256)[1] == pytest.approx(np.exp(0.5) / (np.exp(0.5) + 1.0), rel=1e-5)
+
+
+def test_flux_euler_trajectory_vs_numpy_restatement(sd, oracle, engflux):
+    """cfg 1 (distilled guidance): one model call per step, t = sigma, c_out = -sigma; Flux scheduler ladder"""
+    from test_host_logic import philox_randn_np
+
+    rng = np.random.default_rng(21)
+    cond = rng.standard_normal((1, 12, 96)).astype(np.float32)
+    cy = rng.standard_normal((1, 64)).astype(np.float32)
+    steps, seed = 3, 5
+    out = engflux.sample_latents(cond, None, width=64, height=64, steps=steps, cfg=1.0, seed=seed, batch=1, method=sd.EULER, cond_y=cy)
+    sig = sd.get_flux_sigmas(steps, 8 * 8)
+    x = (philox_randn_np(seed, 0, 16 * 64) * sig[0]).astype(np.float32).reshape(1, 16, 8, 8)
+    for i in range(steps):
+        s, s_to = np.float32(sig[i]), np.float32(sig[i + 1])
+        den = engflux.unet_forward(x, np.array([s], np.float32), cond, cy) * (-s) + x
+        x = x + (x - den) / s * (s_to - s)
+    assert rel_l2(out, x) < 1e-4
+    img = engflux.generate_image(cond, None, width=64, height=64, steps=2, cfg=1.0, seed=3, batch=2, device_batch=2, method=sd.EULER, cond_y=cy)
+    assert img.shape == (2, 64, 64, 3) and img.std() > 1.0
