@@ -27,6 +27,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <algorithm>
 #include <map>
 #include <unordered_map>
 #include <vector>
@@ -39,12 +40,12 @@ namespace {
 
 struct Stats {
     std::atomic<int64_t> graphs_computed{0}, plans_built{0}, nodes_seen{0}, kernels_planned{0}, kernels_launched{0}, fused_conv{0},
-        fused_conv_bounced{0}, fused_linear{0}, fused_norm{0}, fused_geglu{0}, fused_attention{0}, generic_matmul{0}, swizzled_weight_bytes{0}, fused_linear_geglu{0}, split_k_gemms{0}, head_major_gemms{0}, fused_modulate{0}, fused_gate{0}, fused_gelu{0},
+        fused_conv_bounced{0}, fused_linear{0}, fused_norm{0}, fused_geglu{0}, fused_attention{0}, generic_matmul{0}, swizzled_weight_bytes{0}, fused_linear_geglu{0}, split_k_gemms{0}, head_major_gemms{0}, fused_modulate{0}, fused_gate{0}, fused_gelu{0}, fused_rope{0},
         graph_replays{0};
 } g_stats;
 
 struct Options {
-    std::atomic<int> fusion{1}, mfma_gemm{1}, hip_graph{0}, flash_pattern{1}, gemm16{1}, fuse_modulate{1}, fuse_gate{1}, fuse_gelu{1};
+    std::atomic<int> fusion{1}, mfma_gemm{1}, hip_graph{0}, flash_pattern{1}, gemm16{1}, fuse_modulate{1}, fuse_gate{1}, fuse_gelu{1}, fuse_rope{1};
 } g_opt;
 
 using Step = std::function<void(hipStream_t)>;
@@ -855,6 +856,89 @@ bool plan_layer_norm(Builder& B, int i, hipStream_t, std::vector<int>& chain) {
     return true;
 }
 
+// Rope::apply_rope, interleaved (rope.hpp:966-1004):
+//   c1 = CONT(PERMUTE(x,0,2,1,3)) -> RESHAPE [2,d/2,L,HN] -> xc = CONT(PERMUTE(.,3,0,1,2)) -> {VIEW half 0, VIEW half 1} -> RESHAPE [1,..] -> REPEAT [2,..]
+//   pec = CONT(PERMUTE(pe,3,0,1,2)) -> {VIEW 0, VIEW 1};  out = ADD_inplace(MUL(rep0, pe0), MUL(rep1, pe1)) [-> RESHAPE [d, L, HN]]
+// => one kernel reading x and the ORIGINAL pe.  It runs at the ADD's position (its output buffer only exists from there on); x must be intact.
+bool plan_rope(Builder& B, int i, hipStream_t, std::vector<int>& chain) {
+    GInfo& gi             = B.gi;
+    const ggml_tensor* c1 = gi.node(i);
+    if (!g_opt.fusion || !g_opt.fuse_rope || c1->op != GGML_OP_CONT || !is_f32(c1) || !contig(c1)) return false;
+    const ggml_tensor* p1 = c1->src[0];
+    if (!p1 || p1->op != GGML_OP_PERMUTE) return false;
+    const int32_t* a1 = p1->op_params;
+    if (!(a1[0] == 0 && a1[1] == 2 && a1[2] == 1 && a1[3] == 3)) return false;
+    const ggml_tensor* x = p1->src[0];
+    if (!x || !is_f32(x) || x->nb[0] != 4 || x->ne[0] % 2 != 0 || x->nb[1] % 8 != 0 || x->nb[2] % 8 != 0 || x->nb[3] % 8 != 0 || ((uintptr_t)x->data & 7)) return false;
+    const int64_t d = x->ne[0], H = x->ne[1], L = x->ne[2], N = x->ne[3];
+    auto sole_op = [&](int k, int op) {
+        const int j = k >= 0 ? gi.sole(k) : -1;
+        return (j >= 0 && (int)gi.node(j)->op == op) ? j : -1;
+    };
+    const int r1 = sole_op(i, GGML_OP_RESHAPE);
+    const int p2 = sole_op(r1, GGML_OP_PERMUTE);
+    const int xc = sole_op(p2, GGML_OP_CONT);
+    if (xc < 0) return false;
+    const ggml_tensor* r1t = gi.node(r1);
+    const int32_t* a2      = gi.node(p2)->op_params;
+    if (!(r1t->ne[0] == 2 && r1t->ne[1] == d / 2 && r1t->ne[2] == L && r1t->ne[3] == H * N) || !(a2[0] == 3 && a2[1] == 0 && a2[2] == 1 && a2[3] == 2)) return false;
+    if (gi.consumers[xc].size() != 2) return false;
+    const ggml_tensor* xct = gi.node(xc);  // [d/2, L, HN, 2]
+    int mul[2] = {-1, -1};
+    std::vector<int> c2{i, r1, p2, xc};
+    const ggml_tensor* pec = nullptr;
+    for (int v : gi.consumers[xc]) {
+        const ggml_tensor* vt = gi.node(v);
+        if (vt->op != GGML_OP_VIEW || vt->view_src != xct) return false;
+        const size_t half = xct->nb[2] * xct->ne[2];
+        const int which   = (const char*)vt->data == (const char*)xct->data ? 0 : ((const char*)vt->data == (const char*)xct->data + half ? 1 : -1);
+        if (which < 0 || vt->ne[0] != d / 2 || vt->ne[1] != L || vt->ne[2] != H * N) return false;
+        const int rs = sole_op(v, GGML_OP_RESHAPE);
+        const int rp = sole_op(rs, GGML_OP_REPEAT);
+        const int m  = sole_op(rp, GGML_OP_MUL);
+        if (m < 0 || gi.node(m)->src[0] != gi.node(rp)) return false;
+        const ggml_tensor* rpt = gi.node(rp);
+        if (!(rpt->ne[0] == 2 && rpt->ne[1] == d / 2 && rpt->ne[2] == L && rpt->ne[3] == H * N)) return false;
+        // pe operand: VIEW (half `which`) of CONT(PERMUTE(pe, 3,0,1,2))
+        const ggml_tensor* pv = gi.node(m)->src[1];
+        if (!pv || pv->op != GGML_OP_VIEW || !pv->view_src || pv->view_src->op != GGML_OP_CONT) return false;
+        const ggml_tensor* pc = pv->view_src;
+        if (pec && pec != pc) return false;
+        pec               = pc;
+        const size_t phalf = pc->nb[2] * pc->ne[2];
+        if ((const char*)pv->data != (const char*)pc->data + phalf * which) return false;
+        mul[which] = m;
+        for (int k : {v, rs, rp, m, gi.idx(pv)}) c2.push_back(k);
+    }
+    if (mul[0] < 0 || mul[1] < 0 || !pec) return false;
+    const ggml_tensor* pp = pec->src[0];
+    if (!pp || pp->op != GGML_OP_PERMUTE) return false;
+    const int32_t* a3     = pp->op_params;
+    const ggml_tensor* pe = pp->src[0];
+    if (!(a3[0] == 3 && a3[1] == 0 && a3[2] == 1 && a3[3] == 2) || !pe || !is_f32(pe) || !contig(pe) || pe->ne[0] != 2 || pe->ne[1] != 2 || pe->ne[2] != d / 2 ||
+        pe->ne[3] != L || ((uintptr_t)pe->data & 15))
+        return false;
+    const int ipec = gi.idx(pec);
+    if (ipec < 0 || gi.consumers[ipec].size() != 2) return false;  // only this chain's two views read the permuted table
+    c2.push_back(ipec);
+    const int add = gi.sole(mul[0]);
+    if (add < 0 || add != gi.sole(mul[1]) || gi.node(add)->op != GGML_OP_ADD || !contig(gi.node(add)) || (gi.node(add)->flags & GGML_TENSOR_FLAG_OUTPUT)) return false;
+    c2.push_back(add);
+    // nothing outside the chain may run between its first and last node that overwrites x (it is read at the ADD's position)
+    const int first = *std::min_element(c2.begin(), c2.end());
+    if (B.clobbered_between(first, add, x->data, ggml_abi_nbytes(x), c2)) return false;
+    // every chain node except the ADD must be consumed inside the chain only (checked through sole()/size above), and none may be a graph output
+    for (int k : c2)
+        if (k != add && (gi.node(k)->flags & GGML_TENSOR_FLAG_OUTPUT)) return false;
+    chain        = c2;
+    View4 xv     = view_of(x);
+    float* out   = (float*)gi.node(add)->data;
+    const float* pep = (const float*)pe->data;
+    B.emit_at(add, i, [=](hipStream_t st) { launch_rope_pairs(st, out, xv, pep); });
+    g_stats.fused_rope++;
+    return true;
+}
+
 // CONT(view hi half) -> GELU -> MUL(view lo half, .)   (block.hpp:193-210)
 bool plan_geglu(Builder& B, int i, hipStream_t, std::vector<int>& chain) {
     GInfo& gi            = B.gi;
@@ -1191,7 +1275,10 @@ bool build_plan(Planner* P, Plan* plan, const ggml_cgraph* g, hipStream_t s) {
             case GGML_OP_GROUP_NORM: ok = plan_group_norm(B, i, s, chain); break;
             case GGML_OP_NORM:
             case GGML_OP_RMS_NORM: ok = plan_layer_norm(B, i, s, chain); break;
-            case GGML_OP_CONT: ok = plan_geglu(B, i, s, chain); break;
+            case GGML_OP_CONT:
+                ok = plan_geglu(B, i, s, chain);
+                if (!ok) ok = plan_rope(B, i, s, chain);
+                break;
             case GGML_OP_UPSCALE: {
                 // nearest x2 feeding only an implicit-GEMM conv (UpSampleBlock, block.hpp:57-64): fold into the conv's gather
                 const ggml_tensor* src = n->src[0];
@@ -1449,6 +1536,7 @@ void planner_get_stats(ggml_backend_mi355x_stats* o) {
     o->fused_modulate        = g_stats.fused_modulate;
     o->fused_gate            = g_stats.fused_gate;
     o->fused_gelu            = g_stats.fused_gelu;
+    o->fused_rope            = g_stats.fused_rope;
     o->fused_attention       = g_stats.fused_attention;
     o->generic_matmul        = g_stats.generic_matmul;
     o->swizzled_weight_bytes = g_stats.swizzled_weight_bytes;
@@ -1464,6 +1552,7 @@ void planner_set_option(const char* key, int value) {
     else if (!strcmp(key, "fuse_modulate")) g_opt.fuse_modulate = value;
     else if (!strcmp(key, "fuse_gate")) g_opt.fuse_gate = value;
     else if (!strcmp(key, "fuse_gelu")) g_opt.fuse_gelu = value;
+    else if (!strcmp(key, "fuse_rope")) g_opt.fuse_rope = value;
     else if (!strcmp(key, "gemm16_variant")) gemm16_set_variant(value);
     else if (!strcmp(key, "conv_tap_major")) gemm16_set_tap_major(value);
     else if (!strcmp(key, "gemm16_tile")) gemm16_set_tile(value);

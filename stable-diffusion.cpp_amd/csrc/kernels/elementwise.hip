@@ -319,6 +319,31 @@ void launch_copy(hipStream_t s, const View4& dst, const View4& src) {
     if (src.type == BF16 && dst.type == F32) return copy_typed<bf16_t, float>(s, dst, src);
 }
 
+// ---------------------------------------------------------------------------------------- rotary embedding (interleaved pairs)
+// Rope::apply_rope (src/model/common/rope.hpp:966-1004) as ONE kernel instead of its 8-node cont/repeat/mul/add chain:
+//   x   [d, H, L, N] f32, any strides with d contiguous (a slice of a fused qkv projection, or a concat result)
+//   pe  [2, 2, d/2, L] f32 contiguous: per token and pair the matrix [[cos, -sin], [sin, cos]]
+//   out [d, L, H*N] f32 contiguous:  out[2j] = x[2j]*pe[0][0] + x[2j+1]*pe[0][1],  out[2j+1] = x[2j]*pe[1][0] + x[2j+1]*pe[1][1]
+__global__ void k_rope_pairs(float* __restrict__ out, const char* __restrict__ x, const float* __restrict__ pe, int d2, int H, int64_t L, int64_t N, int64_t xnb1,
+                             int64_t xnb2, int64_t xnb3, int64_t npairs) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < npairs; i += (int64_t)gridDim.x * blockDim.x) {
+        const int j     = (int)(i % d2);
+        const int64_t t = i / d2, l = t % L, hn = t / L;
+        const int64_t h = hn % H, n = hn / H;
+        const float2 v  = *(const float2*)(x + h * xnb1 + l * xnb2 + n * xnb3 + (int64_t)j * 8);
+        const float4 m  = *(const float4*)(pe + (l * d2 + j) * 4);  // (m00, m01, m10, m11) = (cos, -sin, sin, cos)
+        float2 r;
+        r.x = v.x * m.x + v.y * m.y;
+        r.y = v.x * m.z + v.y * m.w;
+        *(float2*)(out + ((hn * L + l) * d2 + j) * 2) = r;
+    }
+}
+void launch_rope_pairs(hipStream_t s, float* out, const View4& x, const float* pe) {
+    const int d2 = (int)(x.ne[0] / 2);
+    const int64_t npairs = (int64_t)d2 * x.ne[1] * x.ne[2] * x.ne[3];
+    k_rope_pairs<<<grid_for(npairs, 256), 256, 0, s>>>(out, (const char*)x.data, pe, d2, (int)x.ne[1], x.ne[2], x.ne[3], x.nb[1], x.nb[2], x.nb[3], npairs);
+}
+
 // ---------------------------------------------------------------------------------------- concat / repeat / upscale / pad
 struct Idx4 {
     int64_t ne[4], nb[4];

@@ -573,8 +573,10 @@ static int g16_pick_tile(int64_t rows, int64_t M, bool geglu, bool conv) {
     const int64_t c160 = can160 ? rt256 * (M / 160) : 0;
     double best = (double)((c128 + 767) / 768) * 1.0;
     int tile    = G16_T128;
-    if (c256 >= 512 && (double)((c256 + 511) / 512) * 0.98 < best) {
-        best = (double)((c256 + 511) / 512) * 0.98;
+    // a partially filled T256 round (256..511 workgroups: some CUs host two, most one) runs ~1.2x a full round's time per workgroup
+    const double cost256 = (double)((c256 + 511) / 512) * 0.98 * (c256 < 512 ? 1.2 : 1.0);
+    if (c256 >= 256 && cost256 < best) {
+        best = cost256;
         tile = G16_T256;
     }
     if (c160 >= 512 && (double)((c160 + 511) / 512) * 1.52 < best) tile = conv ? G16_T160 : G16_T160N;  // short-K linears: 8 thin waves hide more latency

@@ -27,6 +27,8 @@ void launch_scale(hipStream_t s, float* dst, const float* src, int64_t n, float 
 void launch_copy(hipStream_t s, const View4& dst, const View4& src);
 void launch_concat(hipStream_t s, const View4& dst, const View4& a, const View4& b, int dim);
 void launch_repeat(hipStream_t s, const View4& dst, const View4& src);
+// interleaved rotary embedding: x [d, H, L, N] (d contiguous, other dims strided), pe [2,2,d/2,L] -> out [d, L, H*N] contiguous
+void launch_rope_pairs(hipStream_t s, float* out, const View4& x, const float* pe);
 void launch_upscale_nearest(hipStream_t s, const View4& dst, const View4& src);
 void launch_pad(hipStream_t s, const View4& dst, const View4& src, const int32_t pads[8]);
 void launch_timestep_embedding(hipStream_t s, float* dst, const float* t, int n, int dim, int max_period, int64_t dst_row_stride);

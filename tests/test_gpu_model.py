@@ -132,8 +132,12 @@ def test_flux_forward_parity(sd, oracle, gpu, flash, wtype):
     wt = getattr(sd, wtype)
     ref = sd.Engine(model=sd.FLUX_TINY, backend=oracle, flash_attn=flash, wtype=wt).unet_forward(x, t, ctx, y)
     gpu_e = sd.Engine(model=sd.FLUX_TINY, backend=gpu, flash_attn=flash, wtype=wt)
+    before = sd.backend_stats() if gpu != oracle else None
     out = gpu_e.unet_forward(x, t, ctx, y)
     assert np.isfinite(out).all()
+    if before is not None and not os.environ.get("SDCPP_BACKEND_OPTS"):
+        # every apply_rope node chain (q and k of 2 double + 2 single blocks) must have been replaced by the rotary kernel
+        assert sd.backend_stats()["fused_rope"] - before["fused_rope"] == 8
     err = rel_l2(out, ref)
     print(f"FLUX_TINY flash={flash} {wtype}: rel-L2 {err:.3e}, nodes {gpu_e.stats()['graph_nodes']}")
     assert err < (6e-2 if wtype == "Q4_0" else 5e-3)
