@@ -70,6 +70,7 @@ struct ggml_backend_mi355x_stats {
     int64_t fused_gate;          /* Linear -> * gate -> + x folded into the GEMM epilogue (DiT) */
     int64_t fused_gelu;          /* fc1 -> GELU written as fc2's f16 operand image */
     int64_t fused_rope;          /* Rope::apply_rope node chains (cont/repeat/mul/add) replaced by one rotary kernel */
+    int64_t fused_concat_heads;  /* token concat + head-major permute (+ f16 cast) of the MMDiT joint-attention operands in one pass */
 };
 GGML_MI355X_API void ggml_backend_mi355x_get_stats(struct ggml_backend_mi355x_stats* out);
 /* live timing of the dominant kernel (bench.py's roofline leg): HIP events on the launch stream around every dispatch of

@@ -40,12 +40,12 @@ namespace {
 
 struct Stats {
     std::atomic<int64_t> graphs_computed{0}, plans_built{0}, nodes_seen{0}, kernels_planned{0}, kernels_launched{0}, fused_conv{0},
-        fused_conv_bounced{0}, fused_linear{0}, fused_norm{0}, fused_geglu{0}, fused_attention{0}, generic_matmul{0}, swizzled_weight_bytes{0}, fused_linear_geglu{0}, split_k_gemms{0}, head_major_gemms{0}, fused_modulate{0}, fused_gate{0}, fused_gelu{0}, fused_rope{0},
+        fused_conv_bounced{0}, fused_linear{0}, fused_norm{0}, fused_geglu{0}, fused_attention{0}, generic_matmul{0}, swizzled_weight_bytes{0}, fused_linear_geglu{0}, split_k_gemms{0}, head_major_gemms{0}, fused_modulate{0}, fused_gate{0}, fused_gelu{0}, fused_rope{0}, fused_concat_heads{0},
         graph_replays{0};
 } g_stats;
 
 struct Options {
-    std::atomic<int> fusion{1}, mfma_gemm{1}, hip_graph{0}, flash_pattern{1}, gemm16{1}, fuse_modulate{1}, fuse_gate{1}, fuse_gelu{1}, fuse_rope{1};
+    std::atomic<int> fusion{1}, mfma_gemm{1}, hip_graph{0}, flash_pattern{1}, gemm16{1}, fuse_modulate{1}, fuse_gate{1}, fuse_gelu{1}, fuse_rope{1}, fuse_concat_heads{1};
 } g_opt;
 
 using Step = std::function<void(hipStream_t)>;
@@ -856,6 +856,47 @@ bool plan_layer_norm(Builder& B, int i, hipStream_t, std::vector<int>& chain) {
     return true;
 }
 
+// MMDiT joint attention inputs: CONCAT(ctx, x; tokens) -> RESHAPE [d,H,Lt,N] -> PERMUTE(0,2,1,3) -> CONT [-> RESHAPE -> CPY f16]
+// (mmdit.hpp:640-646 + ggml_extend.hpp:1366-1412) => one gather pass writing the attention operand; runs at the chain's last node.
+bool plan_concat_heads(Builder& B, int i, hipStream_t, std::vector<int>& chain) {
+    GInfo& gi            = B.gi;
+    const ggml_tensor* n = gi.node(i);
+    if (!g_opt.fusion || !g_opt.fuse_concat_heads || n->op != GGML_OP_CONCAT || n->op_params[0] != 1 || !is_f32(n) || n->ne[3] != 1) return false;
+    const ggml_tensor *a = n->src[0], *b = n->src[1];
+    if (!is_f32(a) || !is_f32(b) || !contig(a) || !contig(b) || ((uintptr_t)a->data & 15) || ((uintptr_t)b->data & 15)) return false;
+    const int64_t C = n->ne[0], Lt = n->ne[1], N = n->ne[2];
+    const int j1 = gi.sole(i);
+    const int j2 = (j1 >= 0 && gi.node(j1)->op == GGML_OP_RESHAPE) ? gi.sole(j1) : -1;
+    const int j3 = (j2 >= 0 && gi.node(j2)->op == GGML_OP_PERMUTE) ? gi.sole(j2) : -1;
+    if (j3 < 0 || gi.node(j3)->op != GGML_OP_CONT || !is_f32(gi.node(j3)) || !contig(gi.node(j3))) return false;
+    const ggml_tensor* r4 = gi.node(j1);
+    const int32_t* ax     = gi.node(j2)->op_params;
+    const int64_t d = r4->ne[0], H = r4->ne[1];
+    if (!(ax[0] == 0 && ax[1] == 2 && ax[2] == 1 && ax[3] == 3) || d * H != C || r4->ne[2] != Lt || r4->ne[3] != N || d % 4 != 0) return false;
+    std::vector<int> c2{i, j1, j2, j3};
+    int last = j3;
+    bool f16 = false;
+    const int j4 = gi.sole(j3);
+    const int j5 = (j4 >= 0 && gi.node(j4)->op == GGML_OP_RESHAPE) ? gi.sole(j4) : -1;
+    if (j5 >= 0 && gi.node(j5)->op == GGML_OP_CPY && gi.node(j5)->type == GGML_TYPE_F16 && gi.node(j5)->src[0] == gi.node(j4) && contig(gi.node(j5))) {
+        c2.push_back(j4);
+        c2.push_back(j5);
+        last = j5;
+        f16  = true;
+    }
+    if ((gi.node(last)->flags & GGML_TENSOR_FLAG_OUTPUT) || ((uintptr_t)gi.node(last)->data & 15)) return false;
+    if (B.clobbered_between(i, last, a->data, ggml_abi_nbytes(a), c2) || B.clobbered_between(i, last, b->data, ggml_abi_nbytes(b), c2)) return false;
+    const void* outp = gi.node(last)->data;
+    if (overlaps(outp, ggml_abi_nbytes(gi.node(last)), a->data, ggml_abi_nbytes(a)) || overlaps(outp, ggml_abi_nbytes(gi.node(last)), b->data, ggml_abi_nbytes(b))) return false;
+    chain = c2;
+    const float *ap = (const float*)a->data, *bp = (const float*)b->data;
+    const int64_t La = a->ne[1], Lb = b->ne[1];
+    void* op = gi.node(last)->data;
+    B.emit_at(last, i, [=](hipStream_t st) { launch_concat_heads(st, op, f16, ap, bp, d, H, La, Lb, N); });
+    g_stats.fused_concat_heads++;
+    return true;
+}
+
 // Rope::apply_rope, interleaved (rope.hpp:966-1004):
 //   c1 = CONT(PERMUTE(x,0,2,1,3)) -> RESHAPE [2,d/2,L,HN] -> xc = CONT(PERMUTE(.,3,0,1,2)) -> {VIEW half 0, VIEW half 1} -> RESHAPE [1,..] -> REPEAT [2,..]
 //   pec = CONT(PERMUTE(pe,3,0,1,2)) -> {VIEW 0, VIEW 1};  out = ADD_inplace(MUL(rep0, pe0), MUL(rep1, pe1)) [-> RESHAPE [d, L, HN]]
@@ -1275,6 +1316,7 @@ bool build_plan(Planner* P, Plan* plan, const ggml_cgraph* g, hipStream_t s) {
             case GGML_OP_GROUP_NORM: ok = plan_group_norm(B, i, s, chain); break;
             case GGML_OP_NORM:
             case GGML_OP_RMS_NORM: ok = plan_layer_norm(B, i, s, chain); break;
+            case GGML_OP_CONCAT: ok = plan_concat_heads(B, i, s, chain); break;
             case GGML_OP_CONT:
                 ok = plan_geglu(B, i, s, chain);
                 if (!ok) ok = plan_rope(B, i, s, chain);
@@ -1537,6 +1579,7 @@ void planner_get_stats(ggml_backend_mi355x_stats* o) {
     o->fused_gate            = g_stats.fused_gate;
     o->fused_gelu            = g_stats.fused_gelu;
     o->fused_rope            = g_stats.fused_rope;
+    o->fused_concat_heads    = g_stats.fused_concat_heads;
     o->fused_attention       = g_stats.fused_attention;
     o->generic_matmul        = g_stats.generic_matmul;
     o->swizzled_weight_bytes = g_stats.swizzled_weight_bytes;
@@ -1553,6 +1596,7 @@ void planner_set_option(const char* key, int value) {
     else if (!strcmp(key, "fuse_gate")) g_opt.fuse_gate = value;
     else if (!strcmp(key, "fuse_gelu")) g_opt.fuse_gelu = value;
     else if (!strcmp(key, "fuse_rope")) g_opt.fuse_rope = value;
+    else if (!strcmp(key, "fuse_concat_heads")) g_opt.fuse_concat_heads = value;
     else if (!strcmp(key, "gemm16_variant")) gemm16_set_variant(value);
     else if (!strcmp(key, "conv_tap_major")) gemm16_set_tap_major(value);
     else if (!strcmp(key, "gemm16_tile")) gemm16_set_tile(value);

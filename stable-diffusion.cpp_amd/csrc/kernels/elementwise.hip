@@ -344,6 +344,29 @@ void launch_rope_pairs(hipStream_t s, float* out, const View4& x, const float* p
     k_rope_pairs<<<grid_for(npairs, 256), 256, 0, s>>>(out, (const char*)x.data, pe, d2, (int)x.ne[1], x.ne[2], x.ne[3], x.nb[1], x.nb[2], x.nb[3], npairs);
 }
 
+// ---------------------------------------------------------------------------------------- token concat straight into the attention operand
+// MMDiT block_mixing (mmdit.hpp:640-646) + ggml_ext_attention_ext (ggml_extend.hpp:1366-1412): concat(ctx, x) along tokens -> reshape
+// [d,H,Lt,N] -> permute(0,2,1,3) -> cont (-> cast f16) as ONE pass: out[dd, l, h, n] = (l < La ? a : b)[h*d + dd, l', n]
+template <typename TD>
+__global__ void k_concat_heads(TD* __restrict__ out, const float* __restrict__ a, const float* __restrict__ b, int d4, int H, int64_t La, int64_t Lb, int64_t N,
+                               int64_t n4) {
+    const int64_t Lt = La + Lb, C4 = (int64_t)d4 * H;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int j      = (int)(i % d4);
+        const int64_t t1 = i / d4, l = t1 % Lt, t2 = t1 / Lt, h = t2 % H, n = t2 / H;
+        const float4 v   = l < La ? ((const float4*)a)[(n * La + l) * C4 + h * d4 + j] : ((const float4*)b)[(n * Lb + (l - La)) * C4 + h * d4 + j];
+        TD r[4] = {cvt<TD>(v.x), cvt<TD>(v.y), cvt<TD>(v.z), cvt<TD>(v.w)};
+        ((vec_t<TD, 4>*)out)[i] = *(vec_t<TD, 4>*)r;
+    }
+}
+void launch_concat_heads(hipStream_t s, void* out, bool out_f16, const float* a, const float* b, int64_t d, int64_t H, int64_t La, int64_t Lb, int64_t N) {
+    const int64_t n4 = d / 4 * H * (La + Lb) * N;
+    if (out_f16)
+        k_concat_heads<__half><<<grid_for(n4, 256), 256, 0, s>>>((__half*)out, a, b, (int)(d / 4), (int)H, La, Lb, N, n4);
+    else
+        k_concat_heads<float><<<grid_for(n4, 256), 256, 0, s>>>((float*)out, a, b, (int)(d / 4), (int)H, La, Lb, N, n4);
+}
+
 // ---------------------------------------------------------------------------------------- concat / repeat / upscale / pad
 struct Idx4 {
     int64_t ne[4], nb[4];

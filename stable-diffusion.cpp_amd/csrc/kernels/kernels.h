@@ -27,6 +27,8 @@ void launch_scale(hipStream_t s, float* dst, const float* src, int64_t n, float 
 void launch_copy(hipStream_t s, const View4& dst, const View4& src);
 void launch_concat(hipStream_t s, const View4& dst, const View4& a, const View4& b, int dim);
 void launch_repeat(hipStream_t s, const View4& dst, const View4& src);
+// a [d*H, La, N], b [d*H, Lb, N] f32 contiguous -> out [d, La+Lb, H, N] (f32 or f16): token concat + head-major permute (+ cast) in one pass
+void launch_concat_heads(hipStream_t s, void* out, bool out_f16, const float* a, const float* b, int64_t d, int64_t H, int64_t La, int64_t Lb, int64_t N);
 // interleaved rotary embedding: x [d, H, L, N] (d contiguous, other dims strided), pe [2,2,d/2,L] -> out [d, L, H*N] contiguous
 void launch_rope_pairs(hipStream_t s, float* out, const View4& x, const float* pe);
 void launch_upscale_nearest(hipStream_t s, const View4& dst, const View4& src);

@@ -92,11 +92,12 @@ def test_mmdit_forward_parity(sd, oracle, gpu, flash, wtype):
     if on_gpu and not os.environ.get("SDCPP_BACKEND_OPTS"):
         # the DiT fusions must actually be taken: LN+modulate -> operand image, gate+residual and GELU in the GEMM epilogue
         st = sd.backend_stats()
-        d = {k: st[k] - before[k] for k in ("fused_modulate", "fused_gate", "fused_gelu")}
+        d = {k: st[k] - before[k] for k in ("fused_modulate", "fused_gate", "fused_gelu", "fused_concat_heads")}
         print("DiT fusions taken:", d)
         assert d["fused_modulate"] >= 6   # LN+modulate in front of qkv / fc1 of both streams (the MMDiT-X block shares its LN: unfused)
         assert d["fused_gate"] >= 3       # attention projections (the tiny model's deep-K fc2 runs split-K and keeps the plain epilogue)
         assert d["fused_gelu"] >= 3
+        assert d["fused_concat_heads"] >= 3   # joint-attention operands (a chain is left unfused when the address analysis cannot prove its inputs intact)
     np.testing.assert_array_equal(out, gpu_e.unet_forward(x, t, ctx, y))
 
 
