@@ -36,3 +36,52 @@ def generate_sharded(engine, cond, uncond, *, batch_count: int, seed: int, rank:
     if gather is not None:
         out = gather(out)
     return out
+
+
+def sample_cfg_pair_split(engine, cond, uncond, *, width: int, height: int, steps: int, cfg: float, seed: int, dist, group=None, rank_in_pair: int,
+                          batch: int = 1, eta: float = 1.0, ancestral: bool = True, cond_y=None, uncond_y=None) -> np.ndarray:
+    """CFG-pair split (the one real exchange step on this path): when there are fewer images than GPUs, the cond
+    branch runs on one rank of a pair and the uncond branch on the other; per step the pair all-reduces (SUM) its PRE-SCALED eps —
+    s*cond on the cond rank, (1-s)*uncond on the other — so the sum is uncond + s*(cond - uncond) (src/runtime/guidance.cpp:171).
+    One [N,C,H,W] f32 all-reduce per step (64 KB per SD1.5 image) over a single xGMI link with RCCL (`dist` = torch.distributed with
+    backend "nccl"; "gloo" in the CPU tests).  Both ranks then take the same Euler(-A) update (src/runtime/denoiser.hpp:1513-1546,
+    1582-1597) with the same Philox noise, so their latents stay bit-identical and nothing else is exchanged.
+
+    rank_in_pair: 0 = cond branch, 1 = uncond branch.  Returns the final latents [batch, C, H/8, W/8] (identical on both ranks)."""
+    import torch
+
+    from . import get_sigmas, lib, philox_randn
+
+    h, w = height // 8, width // 8
+    C = 4
+    per = C * h * w
+    sig = get_sigmas(steps)
+    x = np.stack([philox_randn(seed + b, 0, per).reshape(C, h, w) * sig[0] for b in range(batch)]).astype(np.float32)
+    offs = [1] * batch
+    mine, my_y = (cond, cond_y) if rank_in_pair == 0 else (uncond, uncond_y)
+    weight = np.float32(cfg) if rank_in_pair == 0 else np.float32(1.0 - cfg)
+    for i in range(steps):
+        s, s_to = np.float32(sig[i]), np.float32(sig[i + 1])
+        c_in = np.float32(1.0) / np.sqrt(s * s + np.float32(1.0))   # CompVisDenoiser::get_scalings, denoiser.hpp:1167-1172
+        t = np.full((batch,), lib().sd_sigma_to_t(float(s)), dtype=np.float32)
+        eps = engine.unet_forward(x * c_in, t, mine, my_y) * weight
+        buf = torch.from_numpy(np.ascontiguousarray(eps))
+        if dist.get_backend(group) == "nccl":
+            dev = buf.cuda()
+            dist.all_reduce(dev, op=dist.ReduceOp.SUM, group=group)
+            guided = dev.cpu().numpy()
+        else:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+            guided = buf.numpy()
+        den = guided * (-s) + x
+        if not ancestral or s_to == 0:
+            x = den if s_to == 0 else x + (x - den) / s * (s_to - s)
+            continue
+        up = np.float32(min(float(s_to), eta * float(np.sqrt(max(float(s_to) ** 2 * (float(s) ** 2 - float(s_to) ** 2) / float(s) ** 2, 0.0)))))
+        down = np.float32(np.sqrt(max(float(s_to) ** 2 - float(up) ** 2, 0.0)))
+        r = np.float32(down / s)
+        x = r * x + (np.float32(1) - r) * den
+        for b in range(batch):
+            x[b] = x[b] + philox_randn(seed + b, offs[b], per).reshape(C, h, w) * up
+            offs[b] += 1
+    return x.astype(np.float32)

@@ -66,3 +66,51 @@ def test_world_size_2_sharding_matches_single_process(sd, oracle, tmp_path):
     ref = eng.sample_latents(cond, uncond, width=64, height=64, steps=2, cfg=7.0, seed=100, batch=5, device_batch=5)
     for b in range(5):
         np.testing.assert_allclose(res[b], ref[b], rtol=1e-4, atol=1e-5)
+
+
+PAIR_WORKER = r'''
+import os, sys, pickle
+import numpy as np
+import torch, torch.distributed as dist
+sys.path.insert(0, os.environ["SD_ROOT"])
+import sdcpp_amd as sd
+from sdcpp_amd import shard
+dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{os.environ['MASTER_PORT']}", rank=int(os.environ["RANK"]), world_size=2)
+sd.load_backend(os.path.join(os.environ["SD_ROOT"], "oracle/_build/libggml-cpu-oracle.so"))
+eng = sd.Engine(model=sd.SD15_TINY, backend="CPU-oracle")
+rng = np.random.default_rng(12)
+cond = rng.standard_normal((1, 77, 64)).astype(np.float32)
+uncond = rng.standard_normal((1, 77, 64)).astype(np.float32)
+out = shard.sample_cfg_pair_split(eng, cond, uncond, width=64, height=64, steps=3, cfg=7.0, seed=77, dist=dist, rank_in_pair=dist.get_rank(), batch=2)
+with open(os.environ["SD_OUT"] + str(dist.get_rank()), "wb") as f: pickle.dump(out, f)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_cfg_pair_split_all_reduce_matches_single_process(sd, oracle, tmp_path):
+    """cond on rank 0, uncond on rank 1, one all-reduce of the pre-scaled eps per step (the CFG-pair reduction of SURVEY.md 8(e)):
+    both ranks end with the same latents, equal to the single-process Euler-A + CFG trajectory."""
+    import pickle
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = tmp_path / "pair.pkl"
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SD_ROOT=str(ROOT), SD_OUT=str(out),
+                   OMP_NUM_THREADS="2", OMP_WAIT_POLICY="PASSIVE")
+        procs.append(subprocess.Popen([sys.executable, "-c", PAIR_WORKER], env=env))
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    a = pickle.loads((tmp_path / "pair.pkl0").read_bytes())
+    b = pickle.loads((tmp_path / "pair.pkl1").read_bytes())
+    np.testing.assert_array_equal(a, b)
+    eng = sd.Engine(model=sd.SD15_TINY, backend=oracle)
+    rng = np.random.default_rng(12)
+    cond = rng.standard_normal((1, 77, 64)).astype(np.float32)
+    uncond = rng.standard_normal((1, 77, 64)).astype(np.float32)
+    ref = eng.sample_latents(cond, uncond, width=64, height=64, steps=3, cfg=7.0, seed=77, batch=2, device_batch=2)
+    assert float(np.linalg.norm(a - ref) / np.linalg.norm(ref)) < 1e-4
