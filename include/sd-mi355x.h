@@ -132,6 +132,12 @@ SD_API bool sd_get_tensor(sd_ctx_t* ctx, const char* name, void* dst, size_t nby
 SD_API bool sd_get_tensor_f32(sd_ctx_t* ctx, const char* name, float* dst, int64_t nelem);  /* dequantised */
 SD_API bool sd_set_tensor_f32(sd_ctx_t* ctx, const char* name, const float* src, int64_t nelem); /* converts per stored type */
 
+/* ---- checkpoint files: safetensors (F32/F16/BF16) and GGUF v2/v3 (F32/F16/BF16/Q8_0/Q4_0) ----
+ * Every parameter the model declares that the file names (original-LDM / sd.cpp GGUF names, e.g. "model.diffusion_model.input_blocks.0.0.weight")
+ * is converted file dtype -> f32 -> the parameter's type (ModelLoader convert_tensor, src/model_loader.cpp:155-205) and uploaded.
+ * Returns the number of parameters loaded, -1 on error (sd_last_error); *n_missing = declared but absent, *n_unused = in the file but unknown. */
+SD_API int64_t sd_load_weights(sd_ctx_t* ctx, const char* path, int64_t* n_missing, int64_t* n_unused);
+
 /* ---- the hot path ---- */
 /* one diffusion-model forward (DiffusionModelRunner::compute, unet.hpp:818-858): x [W,H,C,N] f32,
  * timesteps [N], context [ctx_dim,n_tokens,N or 1], y [adm,N or 1] or NULL -> out [W,H,C,N] */

@@ -400,6 +400,17 @@ class Engine:
             shape = shape[1:]
         return out.reshape(shape)
 
+    def load_weights(self, path) -> dict:
+        """Load a safetensors / GGUF checkpoint into the declared parameters (names must be the original-LDM / sd.cpp GGUF names)."""
+        miss, unused = C.c_int64(0), C.c_int64(0)
+        L = lib()
+        L.sd_load_weights.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.sd_load_weights.restype = C.c_int64
+        n = L.sd_load_weights(self._ctx, str(path).encode(), C.byref(miss), C.byref(unused))
+        if n < 0:
+            raise EngineError("sd_load_weights failed: " + L.sd_last_error().decode())
+        return {"loaded": int(n), "missing": int(miss.value), "unused": int(unused.value)}
+
     def set_guidance(self, guidance: float) -> None:
         """FLUX distilled-guidance input (default 3.5)"""
         lib().sd_set_guidance(self._ctx, float(guidance))

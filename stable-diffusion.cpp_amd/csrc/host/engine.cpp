@@ -27,6 +27,7 @@
 #include "ggml.h"
 #include "models.hpp"
 #include "sampler.hpp"
+#include "model_io.hpp"
 #include "sd-mi355x.h"
 
 using namespace sdmi;
@@ -376,6 +377,71 @@ bool sd_set_tensor_f32(sd_ctx_t* ctx, const char* name, const float* src, int64_
     std::vector<uint8_t> scratch;
     ctx->unet_runner.upload_f32(t, src, scratch);
     return true;
+}
+
+// ---- checkpoint files -> weight buffers ---------------------------------------------
+// ModelLoader::load_tensors (src/model_loader.cpp:1180-1260): for every tensor the model declares that the file holds, convert
+// file dtype -> f32 -> the parameter's ggml type (convert_tensor, model_loader.cpp:155-205) and ggml_backend_tensor_set it.
+// Returns the number of parameters loaded, or -1 on a file / shape error; tensors the file does not name keep their current values.
+int64_t sd_load_weights(sd_ctx_t* ctx, const char* path, int64_t* n_missing, int64_t* n_unused) {
+    ModelFile mf;
+    if (!read_model_file(path, mf)) {
+        set_error(mf.error);
+        return -1;
+    }
+    std::map<std::string, const FileTensor*> dir;
+    for (auto& t : mf.tensors) dir[t.name] = &t;
+    FILE* f = fopen(path, "rb");
+    if (!f) {
+        set_error(std::string("cannot open ") + path);
+        return -1;
+    }
+    int64_t loaded = 0, missing = 0;
+    std::vector<uint8_t> raw, conv;
+    std::vector<float> f32;
+    std::map<std::string, bool> used;
+    for (auto& nt : ctx->all_tensors) {
+        auto it = dir.find(nt.first);
+        if (it == dir.end()) {
+            ++missing;
+            continue;
+        }
+        const FileTensor& ft = *it->second;
+        ggml_tensor* t       = nt.second;
+        const int64_t n      = ggml_nelements(t);
+        int64_t fn           = 1;
+        for (int d = 0; d < 4; ++d) fn *= ft.ne[d];
+        // shapes must agree up to trailing 1s; Linear / conv weights additionally dim by dim (torch [out,in,kh,kw] == ggml [kw,kh,in,out])
+        bool same = fn == n;
+        for (int d = 0; same && d < 4; ++d) same = ft.ne[d] == t->ne[d] || (ft.n_dims <= 2 && ggml_n_dims(t) <= 2);
+        if (same && ft.n_dims <= 2 && ggml_n_dims(t) <= 2) same = ft.ne[0] == t->ne[0];
+        if (!same) {
+            set_error("shape mismatch for " + nt.first);
+            fclose(f);
+            return -1;
+        }
+        raw.resize(ft.nbytes);
+        if (fseek(f, (long)ft.offset, SEEK_SET) != 0 || fread(raw.data(), 1, ft.nbytes, f) != ft.nbytes) {
+            set_error("short read for " + nt.first);
+            fclose(f);
+            return -1;
+        }
+        if (ft.type == t->type) {
+            ggml_backend_tensor_set(t, raw.data(), 0, ggml_nbytes(t));
+        } else {
+            f32.resize(n);
+            const int64_t rows = n / ft.ne[0];
+            const size_t rs    = ggml_row_size(ft.type, ft.ne[0]);
+            for (int64_t r = 0; r < rows; ++r) ggml_dequantize_row(ft.type, raw.data() + r * rs, f32.data() + r * ft.ne[0], ft.ne[0]);
+            ctx->unet_runner.upload_f32(t, f32.data(), conv);
+        }
+        used[nt.first] = true;
+        ++loaded;
+    }
+    fclose(f);
+    if (n_missing) *n_missing = missing;
+    if (n_unused) *n_unused = (int64_t)mf.tensors.size() - (int64_t)used.size();
+    return loaded;
 }
 
 // ---- one UNet forward ---------------------------------------------------------------------------

@@ -1,0 +1,341 @@
+// model_io.hpp — on-disk checkpoint formats -> tensor directory: safetensors and GGUF.
+//
+// What the reference does (src/model_io/safetensors_io.cpp, gguf_io.cpp, src/model_loader.cpp:160-205, 1252): build a name -> TensorStorage
+// map (dtype, shape, file offset) per file, then stream every tensor the model declares through convert_tensor() (file dtype -> f32 ->
+// the parameter's ggml type) into the backend buffer with ggml_backend_tensor_set.  This header restates the two container formats
+// from their public specifications (no reference code): the engine (engine.cpp sd_load_weights) does the convert-and-upload part with
+// the same rule.  Name conversion between checkpoint dialects (src/name_conversion.cpp) is NOT done here: names must already be the
+// original-LDM / sd.cpp GGUF names the graph builders register ("model.diffusion_model.…", "first_stage_model.…").
+#pragma once
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "ggml.h"
+
+namespace sdmi {
+
+struct FileTensor {
+    std::string name;
+    ggml_type type = GGML_TYPE_F32;
+    int64_t ne[4]  = {1, 1, 1, 1};  // ggml order (ne0 fastest)
+    int n_dims     = 0;
+    uint64_t offset = 0;            // absolute file offset of the data
+    uint64_t nbytes = 0;
+};
+
+struct ModelFile {
+    std::string path, error;
+    std::vector<FileTensor> tensors;
+    std::map<std::string, std::string> metadata;  // safetensors __metadata__ / GGUF string KVs
+};
+
+// ---- minimal JSON (the safetensors header is a flat object of objects) --------------------------------------
+struct JsonCursor {
+    const char* p;
+    const char* end;
+    bool ok = true;
+    void ws() {
+        while (p < end && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) ++p;
+    }
+    bool eat(char c) {
+        ws();
+        if (p < end && *p == c) {
+            ++p;
+            return true;
+        }
+        return false;
+    }
+    std::string str() {
+        ws();
+        std::string s;
+        if (p >= end || *p != '"') {
+            ok = false;
+            return s;
+        }
+        ++p;
+        while (p < end && *p != '"') {
+            if (*p == '\\' && p + 1 < end) {
+                ++p;
+                switch (*p) {
+                    case 'n': s += '\n'; break;
+                    case 't': s += '\t'; break;
+                    case 'u':  // keep \uXXXX escapes verbatim (tensor names are ASCII)
+                        s += "\\u";
+                        break;
+                    default: s += *p;
+                }
+                ++p;
+            } else {
+                s += *p++;
+            }
+        }
+        if (p < end) ++p;
+        return s;
+    }
+    int64_t integer() {
+        ws();
+        int64_t v = 0;
+        bool neg  = false;
+        if (p < end && *p == '-') {
+            neg = true;
+            ++p;
+        }
+        if (p >= end || *p < '0' || *p > '9') ok = false;
+        while (p < end && *p >= '0' && *p <= '9') v = v * 10 + (*p++ - '0');
+        return neg ? -v : v;
+    }
+    // skip any value (used for unknown keys)
+    void skip() {
+        ws();
+        if (p >= end) {
+            ok = false;
+            return;
+        }
+        if (*p == '"') {
+            (void)str();
+        } else if (*p == '{' || *p == '[') {
+            const char open = *p, close = (*p == '{') ? '}' : ']';
+            int depth = 0;
+            while (p < end) {
+                if (*p == '"') {
+                    (void)str();
+                    continue;
+                }
+                if (*p == open) ++depth;
+                if (*p == close && --depth == 0) {
+                    ++p;
+                    return;
+                }
+                ++p;
+            }
+            ok = false;
+        } else {
+            while (p < end && *p != ',' && *p != '}' && *p != ']') ++p;
+        }
+    }
+};
+
+inline bool st_dtype(const std::string& s, ggml_type& t) {
+    if (s == "F32") t = GGML_TYPE_F32;
+    else if (s == "F16") t = GGML_TYPE_F16;
+    else if (s == "BF16") t = GGML_TYPE_BF16;
+    else return false;  // F64 / I64 / F8 tensors are not parameters of the hot-path models
+    return true;
+}
+
+// safetensors: u64 LE header length N, N bytes of JSON {"name": {"dtype": "F16", "shape": [..torch order..], "data_offsets": [b, e]}, ...,
+// "__metadata__": {...}}, then the byte buffer the offsets index.
+inline bool read_safetensors(const std::string& path, ModelFile& mf) {
+    mf.path  = path;
+    FILE* f  = fopen(path.c_str(), "rb");
+    if (!f) {
+        mf.error = "cannot open " + path;
+        return false;
+    }
+    uint64_t hlen = 0;
+    if (fread(&hlen, 8, 1, f) != 1 || hlen < 2 || hlen > (1ull << 31)) {
+        mf.error = "not a safetensors file (bad header length)";
+        fclose(f);
+        return false;
+    }
+    std::string hdr(hlen, '\0');
+    if (fread(&hdr[0], 1, hlen, f) != hlen) {
+        mf.error = "truncated safetensors header";
+        fclose(f);
+        return false;
+    }
+    fseek(f, 0, SEEK_END);
+    const uint64_t fsize = (uint64_t)ftell(f);
+    fclose(f);
+    const uint64_t base = 8 + hlen;
+    JsonCursor c{hdr.data(), hdr.data() + hdr.size()};
+    if (!c.eat('{')) {
+        mf.error = "safetensors header is not a JSON object";
+        return false;
+    }
+    while (c.ok) {
+        c.ws();
+        if (c.eat('}')) break;
+        const std::string key = c.str();
+        if (!c.eat(':')) break;
+        if (key == "__metadata__") {
+            if (c.eat('{')) {
+                while (c.ok && !c.eat('}')) {
+                    const std::string k = c.str();
+                    (void)c.eat(':');
+                    c.ws();
+                    if (c.p < c.end && *c.p == '"')
+                        mf.metadata[k] = c.str();
+                    else
+                        c.skip();
+                    (void)c.eat(',');
+                }
+            } else {
+                c.skip();
+            }
+        } else {
+            FileTensor t;
+            t.name = key;
+            std::vector<int64_t> shape;
+            int64_t b = -1, e = -1;
+            bool known = true;
+            if (!c.eat('{')) break;
+            while (c.ok && !c.eat('}')) {
+                const std::string k = c.str();
+                (void)c.eat(':');
+                if (k == "dtype") {
+                    known = st_dtype(c.str(), t.type);
+                } else if (k == "shape") {
+                    (void)c.eat('[');
+                    while (c.ok && !c.eat(']')) {
+                        shape.push_back(c.integer());
+                        (void)c.eat(',');
+                    }
+                } else if (k == "data_offsets") {
+                    (void)c.eat('[');
+                    b = c.integer();
+                    (void)c.eat(',');
+                    e = c.integer();
+                    (void)c.eat(']');
+                } else {
+                    c.skip();
+                }
+                (void)c.eat(',');
+            }
+            if (known && shape.size() <= 4 && b >= 0 && e >= b && base + (uint64_t)e <= fsize) {
+                t.n_dims = (int)shape.size();
+                for (size_t i = 0; i < shape.size(); ++i) t.ne[i] = shape[shape.size() - 1 - i];  // torch order -> ggml order
+                t.offset = base + (uint64_t)b;
+                t.nbytes = (uint64_t)(e - b);
+                mf.tensors.push_back(t);
+            }
+        }
+        (void)c.eat(',');
+    }
+    if (!c.ok) {
+        mf.error = "malformed safetensors header";
+        return false;
+    }
+    return true;
+}
+
+// GGUF v2/v3: "GGUF", u32 version, u64 n_tensors, u64 n_kv, KV pairs (string key, u32 type, value), tensor infos (string name, u32 n_dims,
+// u64 dims[], u32 ggml_type, u64 offset relative to the data section), padding to general.alignment (default 32), data.
+inline bool read_gguf(const std::string& path, ModelFile& mf) {
+    mf.path = path;
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) {
+        mf.error = "cannot open " + path;
+        return false;
+    }
+    bool ok    = true;
+    auto rd    = [&](void* dst, size_t n) { ok = ok && fread(dst, 1, n, f) == n; };
+    auto rstr  = [&]() {
+        uint64_t n = 0;
+        rd(&n, 8);
+        std::string s;
+        if (ok && n < (1u << 20)) {
+            s.resize(n);
+            if (n) rd(&s[0], n);
+        } else {
+            ok = false;
+        }
+        return s;
+    };
+    char magic[4];
+    uint32_t version = 0;
+    uint64_t nt = 0, nkv = 0;
+    rd(magic, 4);
+    rd(&version, 4);
+    rd(&nt, 8);
+    rd(&nkv, 8);
+    if (!ok || memcmp(magic, "GGUF", 4) != 0 || version < 2 || version > 3 || nt > (1u << 24) || nkv > (1u << 20)) {
+        mf.error = "not a GGUF v2/v3 file";
+        fclose(f);
+        return false;
+    }
+    uint64_t alignment = 32;
+    static const size_t scalar_size[] = {1, 1, 2, 2, 4, 4, 4, 1, 0, 0, 8, 8, 8};  // gguf_type 0..12 (8 = string, 9 = array)
+    std::function<void(uint32_t, const std::string&)> skip_value = [&](uint32_t ty, const std::string& key) {
+        if (ty == 8) {
+            const std::string v = rstr();
+            mf.metadata[key]    = v;
+        } else if (ty == 9) {
+            uint32_t et = 0;
+            uint64_t n  = 0;
+            rd(&et, 4);
+            rd(&n, 8);
+            for (uint64_t i = 0; ok && i < n; ++i) skip_value(et, std::string());
+        } else if (ty < 13 && scalar_size[ty]) {
+            uint64_t v = 0;
+            rd(&v, scalar_size[ty]);
+            if (key == "general.alignment" && ty == 4) alignment = (uint32_t)v;
+        } else {
+            ok = false;
+        }
+    };
+    for (uint64_t i = 0; ok && i < nkv; ++i) {
+        const std::string key = rstr();
+        uint32_t ty           = 0;
+        rd(&ty, 4);
+        skip_value(ty, key);
+    }
+    for (uint64_t i = 0; ok && i < nt; ++i) {
+        FileTensor t;
+        t.name     = rstr();
+        uint32_t nd = 0, ty = 0;
+        rd(&nd, 4);
+        if (nd > 4) ok = false;
+        for (uint32_t d = 0; ok && d < nd; ++d) {
+            uint64_t v = 0;
+            rd(&v, 8);
+            t.ne[d] = (int64_t)v;
+        }
+        rd(&ty, 4);
+        rd(&t.offset, 8);
+        t.n_dims = (int)nd;
+        t.type   = (ggml_type)ty;
+        mf.tensors.push_back(t);
+    }
+    if (!ok) {
+        mf.error = "truncated or malformed GGUF header";
+        fclose(f);
+        return false;
+    }
+    uint64_t data0 = (uint64_t)ftell(f);
+    data0          = (data0 + alignment - 1) / alignment * alignment;
+    fseek(f, 0, SEEK_END);
+    const uint64_t fsize = (uint64_t)ftell(f);
+    fclose(f);
+    std::vector<FileTensor> keep;
+    for (auto& t : mf.tensors) {
+        const bool known = t.type == GGML_TYPE_F32 || t.type == GGML_TYPE_F16 || t.type == GGML_TYPE_BF16 || t.type == GGML_TYPE_Q8_0 || t.type == GGML_TYPE_Q4_0;
+        if (!known) continue;  // other quantisations: not decodable by this build (the reference accepts any ggml type)
+        const int64_t rows = t.ne[1] * t.ne[2] * t.ne[3];
+        t.nbytes           = ggml_row_size(t.type, t.ne[0]) * (uint64_t)rows;
+        t.offset += data0;
+        if (t.offset + t.nbytes <= fsize) keep.push_back(t);
+    }
+    mf.tensors.swap(keep);
+    return true;
+}
+
+inline bool read_model_file(const std::string& path, ModelFile& mf) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) {
+        mf.error = "cannot open " + path;
+        return false;
+    }
+    char magic[4] = {0, 0, 0, 0};
+    const size_t n = fread(magic, 1, 4, f);
+    fclose(f);
+    if (n == 4 && memcmp(magic, "GGUF", 4) == 0) return read_gguf(path, mf);
+    return read_safetensors(path, mf);
+}
+
+}  // namespace sdmi

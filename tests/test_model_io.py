@@ -1,0 +1,159 @@
+"""CPU suite: checkpoint readers — safetensors and GGUF files written here from the formats' public
+specifications, loaded through sd_load_weights into the tiny SD1.5 engine, and checked tensor by tensor and through a UNet forward."""
+import json
+import struct
+
+import numpy as np
+import pytest
+
+
+def _names(e):
+    L = __import__("sdcpp_amd").lib()
+    return [L.sd_tensor_name(e._ctx, i).decode() for i in range(L.sd_tensor_count(e._ctx))]
+
+
+def _write_safetensors(path, tensors, metadata=None):
+    """tensors: {name: (dtype_str, np array in torch order)}; BF16 arrays are passed as uint16 bit patterns."""
+    header, blobs, off = {}, [], 0
+    if metadata:
+        header["__metadata__"] = metadata
+    for name, (dt, arr) in tensors.items():
+        raw = np.ascontiguousarray(arr).tobytes()
+        header[name] = {"dtype": dt, "shape": list(arr.shape), "data_offsets": [off, off + len(raw)]}
+        blobs.append(raw)
+        off += len(raw)
+    hj = json.dumps(header).encode()
+    hj += b" " * ((8 - len(hj) % 8) % 8)
+    with open(path, "wb") as f:
+        f.write(struct.pack("<Q", len(hj)))
+        f.write(hj)
+        for b in blobs:
+            f.write(b)
+
+
+def _f32_to_bf16_bits(a):
+    u = a.astype(np.float32).view(np.uint32)
+    return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+
+
+def _q8_0_blocks(a):
+    """ggml block_q8_0: f16 d + 32 int8, d = amax / 127 (Appendix D of SURVEY.md)"""
+    a = a.astype(np.float32).reshape(-1, 32)
+    d = np.abs(a).max(axis=1) / 127.0
+    idd = np.where(d > 0, 1.0 / np.where(d > 0, d, 1), 0.0)
+    q = np.round(a * idd[:, None]).astype(np.int8)
+    out = bytearray()
+    for i in range(a.shape[0]):
+        out += np.float16(d[i]).tobytes() + q[i].tobytes()
+    return bytes(out), (q.astype(np.float32) * np.float16(d).astype(np.float32)[:, None]).reshape(-1)
+
+
+def _write_gguf(path, tensors, alignment=32):
+    """tensors: [(name, ggml_type, ne (ggml order), raw bytes)] — GGUF v3"""
+    def s(x):
+        b = x.encode()
+        return struct.pack("<Q", len(b)) + b
+
+    kv = s("general.architecture") + struct.pack("<I", 8) + s("sd") + s("general.alignment") + struct.pack("<II", 4, alignment)
+    infos, data, off = b"", b"", 0
+    for name, ty, ne, raw in tensors:
+        infos += s(name) + struct.pack("<I", len(ne)) + b"".join(struct.pack("<Q", int(d)) for d in ne) + struct.pack("<IQ", ty, off)
+        pad = (alignment - len(raw) % alignment) % alignment
+        data += raw + b"\0" * pad
+        off += len(raw) + pad
+    head = b"GGUF" + struct.pack("<IQQ", 3, len(tensors), 2) + kv + infos
+    head += b"\0" * ((alignment - len(head) % alignment) % alignment)
+    with open(path, "wb") as f:
+        f.write(head + data)
+
+
+def test_safetensors_load_converts_and_runs(sd, oracle, tmp_path):
+    e = sd.Engine(model=sd.SD15_TINY, backend=oracle)
+    names = _names(e)
+    rng = np.random.default_rng(3)
+    tensors, want = {}, {}
+    for i, n in enumerate(names):
+        ne, ty, _ = e.tensor_info(n)
+        shape = tuple(int(d) for d in reversed(ne))
+        while len(shape) > 1 and shape[0] == 1:
+            shape = shape[1:]
+        a = (rng.standard_normal(shape) * 0.05).astype(np.float32)
+        kind = i % 3
+        if kind == 0:
+            tensors[n] = ("F32", a)
+            want[n] = a
+        elif kind == 1:
+            tensors[n] = ("F16", a.astype(np.float16))
+            want[n] = a.astype(np.float16).astype(np.float32)
+        else:
+            bits = _f32_to_bf16_bits(a)
+            tensors[n] = ("BF16", bits)
+            want[n] = (bits.astype(np.uint32) << 16).view(np.float32)
+    tensors["some.unrelated.tensor"] = ("F32", np.zeros((3,), np.float32))
+    p = tmp_path / "tiny.safetensors"
+    _write_safetensors(p, tensors, {"format": "pt"})
+    r = e.load_weights(p)
+    assert r == {"loaded": len(names), "missing": 0, "unused": 1}
+    for n in names[:40] + names[-40:]:
+        _, ty, _ = e.tensor_info(n)
+        got = e.get_tensor(n).ravel()
+        ref = want[n].ravel()
+        if ty == sd.F16:
+            ref = ref.astype(np.float16).astype(np.float32)   # file dtype -> f32 -> parameter type (model_loader.cpp:155-205)
+        np.testing.assert_array_equal(got, ref, err_msg=n)
+    # the loaded model runs and depends on the loaded values
+    x = rng.standard_normal((1, 4, 8, 8)).astype(np.float32)
+    ctx = rng.standard_normal((1, 77, 64)).astype(np.float32)
+    y1 = e.unet_forward(x, np.array([100.0], np.float32), ctx)
+    assert np.isfinite(y1).all()
+    e2 = sd.Engine(model=sd.SD15_TINY, backend=oracle)
+    assert np.abs(e2.unet_forward(x, np.array([100.0], np.float32), ctx) - y1).max() > 1e-3
+
+
+def test_gguf_load_f16_f32_q8_0(sd, oracle, tmp_path):
+    e = sd.Engine(model=sd.SD15_TINY, backend=oracle, wtype=sd.Q8_0)
+    rng = np.random.default_rng(4)
+    picks = {
+        "model.diffusion_model.input_blocks.0.0.weight": sd.F16,                                    # conv weight [3,3,4,32] f16
+        "model.diffusion_model.input_blocks.0.0.bias": sd.F32,
+        "model.diffusion_model.input_blocks.1.1.transformer_blocks.0.attn1.to_q.weight": sd.Q8_0,   # quantised Linear, stays q8_0 bit for bit
+        "model.diffusion_model.time_embed.0.weight": sd.Q8_0,                                       # file q8_0 -> parameter f16 (never quantised)
+    }
+    tensors, want = [], {}
+    for n, fty in picks.items():
+        ne, pty, _ = e.tensor_info(n)
+        ne = [int(d) for d in ne]
+        while len(ne) > 1 and ne[-1] == 1:
+            ne = ne[:-1]
+        a = (rng.standard_normal(int(np.prod(ne))) * 0.1).astype(np.float32)
+        if fty == sd.F32:
+            raw, val = a.tobytes(), a
+        elif fty == sd.F16:
+            raw, val = a.astype(np.float16).tobytes(), a.astype(np.float16).astype(np.float32)
+        else:
+            raw, val = _q8_0_blocks(a)
+        tensors.append((n, fty, ne, raw))
+        want[n] = (val, pty, raw)
+    p = tmp_path / "tiny.gguf"
+    _write_gguf(p, tensors)
+    r = e.load_weights(p)
+    assert r["loaded"] == 4 and r["unused"] == 0 and r["missing"] > 100
+    for n, (val, pty, raw) in want.items():
+        got = e.get_tensor(n).ravel()
+        if pty == sd.F16:
+            val = val.astype(np.float16).astype(np.float32)
+        np.testing.assert_allclose(got, val, rtol=0, atol=1e-7, err_msg=n)
+
+
+def test_bad_files_are_rejected(sd, oracle, tmp_path):
+    e = sd.Engine(model=sd.SD15_TINY, backend=oracle)
+    p = tmp_path / "junk.bin"
+    p.write_bytes(b"\x05\x00\x00\x00\x00\x00\x00\x00hello")
+    with pytest.raises(sd.EngineError):
+        e.load_weights(p)
+    with pytest.raises(sd.EngineError):
+        e.load_weights(tmp_path / "missing.safetensors")
+    # right name, wrong shape
+    _write_safetensors(tmp_path / "bad.safetensors", {"model.diffusion_model.input_blocks.0.0.bias": ("F32", np.zeros((7,), np.float32))})
+    with pytest.raises(sd.EngineError):
+        e.load_weights(tmp_path / "bad.safetensors")
