@@ -393,6 +393,17 @@ __global__ void k_concat_dim2(float4* __restrict__ dst, const float4* __restrict
         dst[i] = r < sa4 ? a[img * sa4 + r] : b[img * sb4 + (r - sa4)];
     }
 }
+// concat along dim 2 of [ne0, ne1, L, N] tensors whose (ne0, ne1) plane is contiguous in a, b and dst (per-head q/k/v of the txt and img
+// streams, flux.hpp:540-544: v is a strided slice of the fused qkv projection): whole planes are copied as float4 runs
+__global__ void k_concat_planes(float4* __restrict__ dst, const char* __restrict__ a, const char* __restrict__ b, int64_t plane4, int64_t La, int64_t Lb,
+                                int64_t a_nb2, int64_t a_nb3, int64_t b_nb2, int64_t b_nb3, int64_t n4) {
+    const int64_t Lt = La + Lb;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t c = i % plane4, t = i / plane4, l = t % Lt, n = t / Lt;
+        const char* src = l < La ? a + l * a_nb2 + n * a_nb3 : b + (l - La) * b_nb2 + n * b_nb3;
+        dst[i]          = ((const float4*)src)[c];
+    }
+}
 static Idx4 mk(const View4& v) {
     Idx4 r;
     for (int i = 0; i < 4; ++i) {
@@ -407,6 +418,17 @@ void launch_concat(hipStream_t s, const View4& dst, const View4& a, const View4&
         const int64_t sa = a.ne[0] * a.ne[1] * a.ne[2], sb = b.ne[0] * b.ne[1] * b.ne[2];
         if (sa % 4 == 0 && sb % 4 == 0 && (((uintptr_t)a.data | (uintptr_t)b.data | (uintptr_t)dst.data) & 15) == 0) {
             k_concat_dim2<<<grid_for(n / 4, 256), 256, 0, s>>>((float4*)dst.data, (const float4*)a.data, (const float4*)b.data, sa / 4, sb / 4, n / 4);
+            return;
+        }
+    }
+    if (dim == 2 && contig_f32(dst.ne, dst.nb)) {
+        const int64_t plane = dst.ne[0] * dst.ne[1];
+        auto plane_ok = [&](const View4& v) {
+            return v.nb[0] == 4 && (v.ne[1] == 1 || v.nb[1] == v.ne[0] * 4) && v.nb[2] % 16 == 0 && v.nb[3] % 16 == 0 && (((uintptr_t)v.data) & 15) == 0;
+        };
+        if (plane % 4 == 0 && plane_ok(a) && plane_ok(b) && (((uintptr_t)dst.data) & 15) == 0) {
+            k_concat_planes<<<grid_for(n / 4, 256), 256, 0, s>>>((float4*)dst.data, (const char*)a.data, (const char*)b.data, plane / 4, a.ne[2], b.ne[2], a.nb[2], a.nb[3],
+                                                                b.nb[2], b.nb[3], n / 4);
             return;
         }
     }

@@ -410,3 +410,26 @@ def test_feed_forward_geglu_fused(sd, oracle, gpu, rng, tokens, dim, inner):
     if before is not None:
         fused = sd.backend_stats()["fused_linear_geglu"] - before["fused_linear_geglu"]
         assert fused == (1 if (2 * inner) % 128 == 0 else 0)
+
+
+@pytest.mark.parametrize("dim", [0, 1, 2])
+def test_concat_of_strided_head_views(sd, oracle, gpu, rng, dim):
+    """concat over per-head views of a fused projection (flux.hpp:283-296, 540-544): inputs are strided [d, H, L, N] slices whose
+    (d, H) plane is contiguous; dim 2 takes the plane-copy path, dims 0 / 1 the generic one."""
+    d, H, N = 16, 3, 2
+    La, Lb = 5, 9
+    qa = rng.standard_normal((N, La, 3 * d * H)).astype(np.float32)
+    qb = rng.standard_normal((N, Lb if dim == 2 else La, 3 * d * H)).astype(np.float32)
+
+    def build(g, L):
+        ta, tb = g.input(qa), g.input(qb)
+        na, nb_ = sd_tensor_nb(ta), sd_tensor_nb(tb)
+        va = L.ggml_view_4d(g.ctx, ta, d, H, qa.shape[1], N, 4 * d, na[1], na[2], 4 * d * H)       # the "k" third of a fused qkv
+        vb = L.ggml_view_4d(g.ctx, tb, d, H, qb.shape[1], N, 4 * d, nb_[1], nb_[2], 4 * d * H)
+        return L.ggml_concat(g.ctx, va, vb, dim)
+
+    ref, out = run_both(sd, oracle, gpu, build)
+    np.testing.assert_array_equal(out, ref)
+    ka = qa[:, :, d * H:2 * d * H].reshape(N, qa.shape[1], H, d)
+    kb = qb[:, :, d * H:2 * d * H].reshape(N, qb.shape[1], H, d)
+    np.testing.assert_array_equal(out, np.concatenate([ka, kb], axis=3 - dim))
