@@ -276,3 +276,21 @@ def test_flux_euler_trajectory_vs_numpy_restatement(sd, oracle, engflux):
     assert rel_l2(out, x) < 1e-4
     img = engflux.generate_image(cond, None, width=64, height=64, steps=2, cfg=1.0, seed=3, batch=2, device_batch=2, method=sd.EULER, cond_y=cy)
     assert img.shape == (2, 64, 64, 3) and img.std() > 1.0
+
+
+# ---------------------------------------------------------------------------------------------------
+# committed model-level golden vectors (tests/golden/models_torch_fp32.npz, written by tests/golden/make_model_golden.py)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["SD15_TINY", "SDXL_TINY", "SD35_TINY", "FLUX_TINY"])
+def test_model_outputs_match_committed_golden(sd, oracle, name):
+    """The oracle path (graph builders + CPU oracle + synthetic weights, a pure function of (seed 1234, tensor name)) against the committed
+    PyTorch-fp32 outputs: pins builders, oracle and weight generator at once, without needing torch at test time."""
+    from pathlib import Path
+
+    G = np.load(Path(__file__).resolve().parent / "golden" / "models_torch_fp32.npz")
+    e = sd.Engine(model=getattr(sd, name), backend=oracle)
+    y = G[f"{name}_y"] if f"{name}_y" in G.files else None
+    out = e.unet_forward(G[f"{name}_x"], G[f"{name}_t"], G[f"{name}_ctx"], y)
+    assert rel_l2(out, G[f"{name}_out"]) < 3e-3
+    if name == "SD15_TINY":
+        assert np.abs(e.vae_decode(G["VAE_TINY_z"]) - G["VAE_TINY_rgb"]).max() < 5e-3
