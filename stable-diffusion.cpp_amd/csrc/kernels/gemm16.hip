@@ -354,7 +354,51 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm16(G16Args g) {
     const bool w_short = WEXTRA != 0 && wave >= WEXTRA;  // this wave issues one W fragment fewer per stage
     const int ktiles_per_icb = 64 / BK;  // conv: K tiles per 64-channel block (1 or 2)
 
-    auto stage = [&](int kt, int buf) {
+    // conv tile cursor: K tile -> (64-channel block icb, tap = (kh, kw), half sub).  Tiles are staged strictly in order, so the cursor
+    // advances by carries — the per-tile integer divisions this replaces were ~60 scalar instructions in front of every DMA issue.
+    int c_sub = 0, c_tap = 0, c_icb = 0, c_kh = 0, c_kw = 0;
+    if (CONV) {
+        const int kb = kt0 / ktiles_per_icb, ntaps = g.KS * g.KS;
+        c_sub        = kt0 - kb * ktiles_per_icb;
+        if (g.tap_major) {
+            c_tap = kb / g.icb_per_tap;
+            c_icb = kb - c_tap * g.icb_per_tap;
+        } else {
+            c_icb = kb / ntaps;
+            c_tap = kb - c_icb * ntaps;
+        }
+        c_kh = c_tap / g.KS;
+        c_kw = c_tap - c_kh * g.KS;
+    }
+// advance the cursor by one K tile (plain statements on locals, NOT a lambda: a mutating by-reference capture made the compiler keep the
+// cursor in scratch memory and in VGPRs)
+#define G16_ADVANCE()                                  \
+    do {                                               \
+        if (CONV && ++c_sub >= ktiles_per_icb) {       \
+            c_sub = 0;                                 \
+            if (g.tap_major) {                         \
+                if (++c_icb >= g.icb_per_tap) {        \
+                    c_icb = 0;                         \
+                    ++c_tap;                           \
+                    if (++c_kw == g.KS) {              \
+                        c_kw = 0;                      \
+                        ++c_kh;                        \
+                    }                                  \
+                }                                      \
+            } else {                                   \
+                ++c_tap;                               \
+                if (++c_kw == g.KS) {                  \
+                    c_kw = 0;                          \
+                    ++c_kh;                            \
+                }                                      \
+                if (c_tap == g.KS * g.KS) {            \
+                    c_tap = c_kh = c_kw = 0;           \
+                    ++c_icb;                           \
+                }                                      \
+            }                                          \
+        }                                              \
+    } while (0)
+    auto stage = [&](int kt, int buf, int tap, int kh, int kw, int icb, int sub) {
         char* sa = smem + buf * (ABYTES + BBYTES);
         char* sb = sa + ABYTES;
         if (!CONV) {
@@ -364,17 +408,7 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm16(G16Args g) {
             // K order = (64-channel block, tap, channel): the KS*KS taps of one channel block are consecutive K tiles, so a workgroup
             // re-reads the same small input window (rows +-1, 128 B per pixel) back to back and the re-reads hit L2 (tap-major
             // order re-read the whole tile 9 times, one full K sweep apart: 3x the algorithmic HBM/MALL fetch, profiles/r01c)
-            const int kb  = kt / ktiles_per_icb, sub = kt - kb * ktiles_per_icb;  // kb: (64-channel block, tap)
-            const int ntaps = g.KS * g.KS;
-            int icb, tap;
-            if (g.tap_major) {  // A/B switch (option "conv_tap_major"): the old (tap, channel block) order
-                tap = kb / g.icb_per_tap;
-                icb = kb - tap * g.icb_per_tap;
-            } else {
-                icb = kb / ntaps;
-                tap = kb - icb * ntaps;
-            }
-            const int kh = tap / g.KS, kw = tap - kh * g.KS;
+            // (option "conv_tap_major" keeps the old (tap, channel block) order for A/B runs)
             const int64_t koff = (int64_t)icb * 64 + sub * BK;  // wave-uniform (SALU)
             if (!g.UPS) {
                 const int64_t toff = ((int64_t)kh * g.Wd + kw) * g.ICp + koff;
@@ -435,17 +469,25 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm16(G16Args g) {
 
     if (NST == 2) {
         // one barrier per K tile: its implicit vmcnt(0) retires this tile's DMA, the next tile's DMA overlaps the MFMAs
-        stage(kt0, 0);
+        stage(kt0, 0, c_tap, c_kh, c_kw, c_icb, c_sub);
+        G16_ADVANCE();
         for (int kt = 0; kt < nt; ++kt) {
             __syncthreads();
-            if (kt + 1 < nt) stage(kt0 + kt + 1, (kt + 1) & 1);
+            if (kt + 1 < nt) {
+                stage(kt0 + kt + 1, (kt + 1) & 1, c_tap, c_kh, c_kw, c_icb, c_sub);
+                G16_ADVANCE();
+            }
             compute(kt & 1);
         }
     } else {
         // 3-deep ring, COUNTED waits: two tiles of DMA stay in flight across the barrier (cdna_hip_programming.md T3+T4):
         // vmcnt(NPT) retires tile kt while tile kt+1 is still streaming; tile kt+2 is issued right after the barrier.
-        stage(kt0, 0);
-        if (nt > 1) stage(kt0 + 1, 1);
+        stage(kt0, 0, c_tap, c_kh, c_kw, c_icb, c_sub);
+        G16_ADVANCE();
+        if (nt > 1) {
+            stage(kt0 + 1, 1, c_tap, c_kh, c_kw, c_icb, c_sub);
+            G16_ADVANCE();
+        }
         int buf = 0;
         for (int kt = 0; kt < nt; ++kt) {
             if (kt + 1 >= nt)
@@ -455,7 +497,10 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm16(G16Args g) {
             else
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPT) : "memory");
             __builtin_amdgcn_s_barrier();
-            if (kt + 2 < nt) stage(kt0 + kt + 2, buf >= 1 ? buf - 1 : 2);  // (kt+2)%3
+            if (kt + 2 < nt) {
+                stage(kt0 + kt + 2, buf >= 1 ? buf - 1 : 2, c_tap, c_kh, c_kw, c_icb, c_sub);  // (kt+2)%3
+                G16_ADVANCE();
+            }
             compute(buf);
             buf = buf == 2 ? 0 : buf + 1;
         }
