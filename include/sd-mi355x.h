@@ -4,9 +4,9 @@
  * This is the host-facing slice of the reference's public C API (include/stable-diffusion.h) that the
  * hot path touches, with the same names / argument meaning / error behaviour where a counterpart
  * exists, and plain pointers + sizes everywhere (no C++ / torch types).  What differs, and why:
- *   - text encoders are out of scope ("synthetic prompts"), so conditioning enters
- *     as tensors (`sd_condition_t`) instead of prompt strings — the SDCondition struct of
- *     src/conditioning/conditioner.hpp:18-34;
+ *   - conditioning enters the denoise path as tensors (`sd_condition_t`, the SDCondition struct of
+ *     src/conditioning/conditioner.hpp:18-34); the text encoders that produce them take token ids
+ *     (sd_get_learned_condition below) because the reference's tokenizer vocabularies are not in its source drop;
  *   - weights are synthetic (random-init of the named architecture) unless the caller overwrites
  *     tensors by name with sd_set_tensor (checkpoint readers are a "next" row).
  *
@@ -171,6 +171,31 @@ typedef struct {
     size_t weight_bytes;
 } sd_stats_t;
 SD_API void sd_get_stats(sd_ctx_t* ctx, sd_stats_t* out);
+/* ---- text encoders + conditioner --------------------------------------------------------
+ * CLIP text towers (src/model/te/clip.hpp) and the T5 encoder (src/model/te/t5.hpp) as graphs on the same backend, and the
+ * conditioner composition of src/conditioning/conditioner.hpp (SD1.x/SDXL :414-544, SD3 :842-1015, FLUX :1209-1297).  Inputs are
+ * TOKEN IDS (+ per-token prompt weights): the reference's vocabularies are not part of its source drop, so tokenisation stays with
+ * the caller.  Encoders are created on first use with synthetic weights (weight_seed); sd_load_weights overwrites them when the file
+ * names "cond_stage_model.*" / "text_encoders.*" tensors. */
+typedef struct {
+    const int32_t* ids;
+    const float* weights; /* NULL = all 1.0 */
+    int n;                /* multiple of the chunk length: 77 for CLIP and SD3's T5, 256 for FLUX's T5 */
+} sd_token_list_t;
+SD_API bool sd_text_encoders_init(sd_ctx_t* ctx);
+/* which: 0 = clip_l (ViT-L/14), 1 = clip_g (ViT-bigG/14).  CLIPTextModelRunner::compute (clip.hpp:562-583): hidden states
+ * [hidden, n_tokens] after layer n_layer - clip_skip (clip_skip <= 0: all layers), or with return_pooled the final-LN'd row
+ * max_token_idx (times text_projection for bigG).  Returns floats written, -1 on error. */
+SD_API int64_t sd_clip_forward(sd_ctx_t* ctx, int which, const int32_t* ids, int n_tokens, int max_token_idx, bool return_pooled, int clip_skip, float* out,
+                               int64_t out_capacity);
+SD_API int64_t sd_t5_forward(sd_ctx_t* ctx, const int32_t* ids, int n_tokens, float* out, int64_t out_capacity); /* T5Runner::compute, t5.hpp:452-461 */
+SD_API int sd_t5_relative_position_buckets(int q_len, int k_len, int32_t* out /* q_len*k_len */);                 /* t5.hpp:463-530 */
+/* token ids -> SDCondition.  crossattn_ne = {ctx_dim, n_tokens}; pass NULL output pointers to query the sizes first.  clip_g / t5
+ * are ignored by families that do not own them (SD1.x and SDXL derive the bigG ids from clip_l like the reference). */
+SD_API bool sd_get_learned_condition(sd_ctx_t* ctx, const sd_token_list_t* clip_l, const sd_token_list_t* clip_g, const sd_token_list_t* t5, int clip_skip,
+                                     int width, int height, bool zero_out_masked, float* crossattn_out, int64_t crossattn_capacity, int64_t* crossattn_ne,
+                                     float* vector_out, int64_t vector_capacity, int64_t* vector_n);
+
 
 #ifdef __cplusplus
 }

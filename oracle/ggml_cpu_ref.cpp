@@ -725,7 +725,21 @@ void op_get_rows(ggml_tensor* dst) {
         const int32_t row = *(const int32_t*)(cptr(b) + i10 * b->nb[0] + i11 * b->nb[1] + i12 * b->nb[2]);
         const char* src   = cptr(a) + row * a->nb[1] + i11 * a->nb[2] + i12 * a->nb[3];
         float* out        = (float*)(mptr(dst) + i10 * dst->nb[1] + i11 * dst->nb[2] + i12 * dst->nb[3]);
-        for (int64_t c = 0; c < nc; ++c) out[c] = load_as_f32(a, src + c * a->nb[0]);
+        if (a->type == GGML_TYPE_Q8_0) {  // block_q8_0: f16 d, 32 x int8; value = d * q
+            for (int64_t c = 0; c < nc; ++c) {
+                const char* blk = src + (c / 32) * 34;
+                out[c]          = h2f(*(const ggml_fp16_t*)blk) * (float)((const int8_t*)(blk + 2))[c % 32];
+            }
+        } else if (a->type == GGML_TYPE_Q4_0) {  // block_q4_0: f16 d, 16 bytes; element j < 16 = low nibble of qs[j], j >= 16 = high nibble of qs[j-16]
+            for (int64_t c = 0; c < nc; ++c) {
+                const char* blk = src + (c / 32) * 18;
+                const int j     = (int)(c % 32);
+                const uint8_t q = ((const uint8_t*)(blk + 2))[j % 16];
+                out[c]          = h2f(*(const ggml_fp16_t*)blk) * (float)((j < 16 ? (q & 0xF) : (q >> 4)) - 8);
+            }
+        } else {
+            for (int64_t c = 0; c < nc; ++c) out[c] = load_as_f32(a, src + c * a->nb[0]);
+        }
     }
 }
 

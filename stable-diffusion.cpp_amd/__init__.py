@@ -87,6 +87,11 @@ class SdImgGenParams(C.Structure):
                 ("device_batch", C.c_int), ("decode", C.c_bool), ("fuse_cfg_pair", C.c_bool)]
 
 
+class SdTokenList(C.Structure):
+    """sd_token_list_t (include/sd-mi355x.h)"""
+    _fields_ = [("ids", C.POINTER(C.c_int32)), ("weights", C.POINTER(C.c_float)), ("n", C.c_int)]
+
+
 class SdImage(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("channel", C.c_uint32), ("data", C.POINTER(C.c_uint8))]
 
@@ -246,6 +251,16 @@ def lib() -> C.CDLL:
     L.sd_sigma_to_t.argtypes = [C.c_float]
     L.sd_sigma_to_t.restype = C.c_float
     L.sd_get_stats.argtypes = [C.c_void_p, C.POINTER(SdStats)]
+    L.sd_text_encoders_init.argtypes = [C.c_void_p]
+    L.sd_text_encoders_init.restype = C.c_bool
+    L.sd_clip_forward.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_bool, C.c_int, C.c_void_p, C.c_int64]
+    L.sd_clip_forward.restype = C.c_int64
+    L.sd_t5_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64]
+    L.sd_t5_forward.restype = C.c_int64
+    L.sd_t5_relative_position_buckets.argtypes = [C.c_int, C.c_int, C.c_void_p]
+    L.sd_get_learned_condition.argtypes = [C.c_void_p, C.POINTER(SdTokenList), C.POINTER(SdTokenList), C.POINTER(SdTokenList), C.c_int, C.c_int, C.c_int,
+                                           C.c_bool, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+    L.sd_get_learned_condition.restype = C.c_bool
     _lib = L
     return L
 
@@ -375,6 +390,71 @@ class Engine:
         except Exception:
             pass
 
+    # ---- text encoders / conditioner ----
+    def text_encoders_init(self) -> None:
+        if not lib().sd_text_encoders_init(self._ctx):
+            raise EngineError("sd_text_encoders_init failed: " + lib().sd_last_error().decode())
+
+    def clip_forward(self, which: int, ids, max_token_idx: int = 0, return_pooled: bool = False, clip_skip: int = -1) -> np.ndarray:
+        """One CLIP text tower (0 = ViT-L, 1 = bigG) on token ids [n_tokens] -> hidden states [n_tokens, hidden] or the pooled vector."""
+        ids = np.ascontiguousarray(ids, dtype=np.int32).ravel()
+        self.text_encoders_init()
+        cap = int(ids.size) * 4096 + 4096
+        out = np.empty(cap, dtype=np.float32)
+        n = lib().sd_clip_forward(self._ctx, which, ids.ctypes.data_as(C.c_void_p), int(ids.size), int(max_token_idx), bool(return_pooled), int(clip_skip),
+                                  _fptr(out), cap)
+        if n < 0:
+            raise EngineError("sd_clip_forward failed: " + lib().sd_last_error().decode())
+        out = out[:n].copy()
+        return out if return_pooled else out.reshape(ids.size, -1)
+
+    def t5_forward(self, ids) -> np.ndarray:
+        ids = np.ascontiguousarray(ids, dtype=np.int32).ravel()
+        self.text_encoders_init()
+        cap = int(ids.size) * 4096
+        out = np.empty(cap, dtype=np.float32)
+        n = lib().sd_t5_forward(self._ctx, ids.ctypes.data_as(C.c_void_p), int(ids.size), _fptr(out), cap)
+        if n < 0:
+            raise EngineError("sd_t5_forward failed: " + lib().sd_last_error().decode())
+        return out[:n].copy().reshape(ids.size, -1)
+
+    def get_learned_condition(self, clip_l=None, clip_g=None, t5=None, *, clip_skip: int = -1, width: int = 512, height: int = 512,
+                              zero_out_masked: bool = False):
+        """Token ids (+ weights) -> (c_crossattn [1, n_tokens, ctx_dim], c_vector [1, dim] or None).  Each argument is an id array or an
+        (ids, weights) pair; see sd_get_learned_condition."""
+        keep = []
+
+        def tl(x):
+            if x is None:
+                return None
+            ids, w = x if isinstance(x, tuple) else (x, None)
+            ids = np.ascontiguousarray(ids, dtype=np.int32).ravel()
+            t = SdTokenList()
+            t.ids = ids.ctypes.data_as(C.POINTER(C.c_int32))
+            t.n = int(ids.size)
+            keep.append(ids)
+            if w is not None:
+                w = np.ascontiguousarray(w, dtype=np.float32).ravel()
+                assert w.size == ids.size
+                t.weights = w.ctypes.data_as(C.POINTER(C.c_float))
+                keep.append(w)
+            return t
+
+        lists = [tl(clip_l), tl(clip_g), tl(t5)]
+        ptrs = [C.byref(t) if t is not None else None for t in lists]
+        ne = (C.c_int64 * 2)()
+        vn = C.c_int64()
+        L = lib()
+        args = (self._ctx, ptrs[0], ptrs[1], ptrs[2], int(clip_skip), int(width), int(height), bool(zero_out_masked))
+        # sizes are a function of the token counts only: ask first (runs the encoders), then fetch
+        cross = np.empty(max(1, sum(t.n for t in lists if t is not None)) * 2 * 4096, dtype=np.float32)
+        vec = np.empty(8192, dtype=np.float32)
+        if not L.sd_get_learned_condition(*args, _fptr(cross), cross.size, ne, _fptr(vec), vec.size, C.byref(vn)):
+            raise EngineError("sd_get_learned_condition failed: " + L.sd_last_error().decode())
+        c = cross[: ne[0] * ne[1]].copy().reshape(1, ne[1], ne[0])
+        y = vec[: vn.value].copy().reshape(1, -1) if vn.value > 0 else None
+        return c, y
+
     # ---- weights ----
     def tensor_names(self) -> list[str]:
         L = lib()
@@ -503,6 +583,13 @@ class Engine:
         s = SdStats()
         lib().sd_get_stats(self._ctx, C.byref(s))
         return {f[0]: getattr(s, f[0]) for f in SdStats._fields_}
+
+
+def t5_relative_position_buckets(q_len: int, k_len: int) -> np.ndarray:
+    """T5 bidirectional relative-position buckets [q_len, k_len] (t5.hpp:463-530)."""
+    out = np.empty(q_len * k_len, dtype=np.int32)
+    lib().sd_t5_relative_position_buckets(q_len, k_len, out.ctypes.data_as(C.c_void_p))
+    return out.reshape(q_len, k_len)
 
 
 def philox_randn(seed: int, offset: int, n: int) -> np.ndarray:

@@ -1212,6 +1212,18 @@ bool plan_single(Builder& B, int i, hipStream_t s) {
             B.emit([=](hipStream_t st) { launch_pad(st, d, a, pads); });
             return true;
         }
+        case GGML_OP_GET_ROWS: {
+            const View4 tab = view_of(n->src[0]), ids = view_of(n->src[1]);
+            float* dst      = (float*)n->data;
+            int64_t dnb[4];
+            for (int d = 0; d < 4; ++d) dnb[d] = (int64_t)n->nb[d];
+            const int64_t b1 = dnb[1], b2 = dnb[2], b3 = dnb[3];
+            B.emit([=](hipStream_t st) {
+                const int64_t nb[4] = {4, b1, b2, b3};
+                launch_get_rows(st, dst, nb, tab, ids);
+            });
+            return true;
+        }
         case GGML_OP_TIMESTEP_EMBEDDING: {
             float* dst       = (float*)n->data;
             const float* t   = (const float*)n->src[0]->data;
@@ -1545,6 +1557,12 @@ bool planner_supports_op(const ggml_tensor* n) {
         case GGML_OP_PAD:
             if (n->op == GGML_OP_UPSCALE && n->op_params[0] != GGML_SCALE_MODE_NEAREST) return false;
             return f32c(n) && f32c(n->src[0]);
+        case GGML_OP_GET_ROWS: {
+            const ggml_tensor *a = n->src[0], *b = n->src[1];
+            if (!a || !b || !f32c(n) || b->type != GGML_TYPE_I32 || n->nb[0] != 4) return false;
+            const bool at = a->type == GGML_TYPE_F32 || a->type == GGML_TYPE_F16 || a->type == GGML_TYPE_BF16 || a->type == GGML_TYPE_Q8_0 || a->type == GGML_TYPE_Q4_0;
+            return at && a->nb[0] == ggml_abi_type_size(a->type);
+        }
         case GGML_OP_TIMESTEP_EMBEDDING:
             return f32c(n) && f32c(n->src[0]);
         case GGML_OP_FLASH_ATTN_EXT: {

@@ -670,6 +670,9 @@ ggml_tensor* ggml_soft_max_ext(ggml_context* ctx, ggml_tensor* a, ggml_tensor* m
 
 ggml_tensor* ggml_get_rows(ggml_context* ctx, ggml_tensor* a, ggml_tensor* b) {
     GGML_ASSERT(a->ne[2] == b->ne[1] && b->ne[3] == 1 && b->type == GGML_TYPE_I32);
+    // rows of plane (i11, i12) of `a` are gathered for ids[:, i11, i12]: upstream does not check the outermost plane count and would read
+    // past a 2-D table when ids carry a batch in ne[2] (the "batch inference" issue noted at ggml_extend.hpp:3574-3575) — refuse instead
+    GGML_ASSERT(b->ne[2] == 1 || a->ne[3] == b->ne[2]);
     const int64_t ne[4] = {a->ne[0], b->ne[0], b->ne[1], b->ne[2]};
     ggml_tensor* r      = ggml_new_tensor(ctx, GGML_TYPE_F32, 4, ne);
     r->op               = GGML_OP_GET_ROWS;

@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -26,6 +27,7 @@
 
 #include "ggml.h"
 #include "models.hpp"
+#include "conditioner.hpp"
 #include "sampler.hpp"
 #include "model_io.hpp"
 #include "sd-mi355x.h"
@@ -202,6 +204,24 @@ struct sd_ctx_t {
     float sigma_to_t(float sigma) const { return is_flux ? sigma : (is_dit ? flow_denoiser.sigma_to_t(sigma) : denoiser.sigma_to_t(sigma)); }
     sd_stats_t stats{};
     std::vector<std::pair<std::string, ggml_tensor*>> all_tensors;
+    // text encoders: built on first use (sd_text_encoders_init / sd_get_learned_condition / a checkpoint naming them)
+    struct TextEncoders {
+        Runner l_runner, g_runner, t5_runner;
+        ClipTextModel clip_l, clip_g;
+        T5Model t5;
+        ConditionerSpec spec;
+        Runner* runner(int which) { return which == 0 ? &l_runner : (which == 1 ? &g_runner : &t5_runner); }
+    };
+    std::unique_ptr<TextEncoders> te;
+    std::vector<Runner*> runners() {
+        std::vector<Runner*> v{&unet_runner, &vae_runner};
+        if (te) {
+            if (te->spec.has_l) v.push_back(&te->l_runner);
+            if (te->spec.has_g) v.push_back(&te->g_runner);
+            if (te->spec.has_t5) v.push_back(&te->t5_runner);
+        }
+        return v;
+    }
     ~sd_ctx_t() {
         // runners free their buffers in their destructors; the backend must outlive them
     }
@@ -341,7 +361,7 @@ void free_sd_ctx(sd_ctx_t* ctx) {
 int64_t sd_tensor_count(sd_ctx_t* ctx) { return (int64_t)ctx->all_tensors.size(); }
 const char* sd_tensor_name(sd_ctx_t* ctx, int64_t i) { return ctx->all_tensors[i].first.c_str(); }
 static ggml_tensor* find_tensor(sd_ctx_t* ctx, const char* name) {
-    for (auto* r : {&ctx->unet_runner, &ctx->vae_runner}) {
+    for (Runner* r : ctx->runners()) {
         auto it = r->ps.by_name.find(name);
         if (it != r->ps.by_name.end()) return it->second;
     }
@@ -383,6 +403,7 @@ bool sd_set_tensor_f32(sd_ctx_t* ctx, const char* name, const float* src, int64_
 // ModelLoader::load_tensors (src/model_loader.cpp:1180-1260): for every tensor the model declares that the file holds, convert
 // file dtype -> f32 -> the parameter's ggml type (convert_tensor, model_loader.cpp:155-205) and ggml_backend_tensor_set it.
 // Returns the number of parameters loaded, or -1 on a file / shape error; tensors the file does not name keep their current values.
+static bool ensure_text_encoders(sd_ctx_t* ctx);
 int64_t sd_load_weights(sd_ctx_t* ctx, const char* path, int64_t* n_missing, int64_t* n_unused) {
     ModelFile mf;
     if (!read_model_file(path, mf)) {
@@ -390,7 +411,12 @@ int64_t sd_load_weights(sd_ctx_t* ctx, const char* path, int64_t* n_missing, int
         return -1;
     }
     std::map<std::string, const FileTensor*> dir;
-    for (auto& t : mf.tensors) dir[t.name] = &t;
+    bool names_te = false;
+    for (auto& t : mf.tensors) {
+        dir[t.name] = &t;
+        names_te    = names_te || t.name.rfind("cond_stage_model.", 0) == 0 || t.name.rfind("text_encoders.", 0) == 0;
+    }
+    if (names_te && !ensure_text_encoders(ctx)) return -1;  // like the conditioners' tensor_storage_map probes (conditioner.hpp:630-651)
     FILE* f = fopen(path, "rb");
     if (!f) {
         set_error(std::string("cannot open ") + path);
@@ -442,6 +468,240 @@ int64_t sd_load_weights(sd_ctx_t* ctx, const char* path, int64_t* n_missing, int
     if (n_missing) *n_missing = missing;
     if (n_unused) *n_unused = (int64_t)mf.tensors.size() - (int64_t)used.size();
     return loaded;
+}
+
+// ---- text encoders + conditioner ----------------------------------------------------
+// Which encoders a family owns, their parameter prefixes and output wiring: FrozenCLIPEmbedderWithCustomWords (conditioner.hpp:169-190),
+// SD3CLIPEmbedder (:623-652), FluxCLIPEmbedder (:1034-1062).  Weights are synthetic (weight_seed) until sd_load_weights overwrites them.
+static bool ensure_text_encoders(sd_ctx_t* ctx) {
+    if (ctx->te) return true;
+    std::unique_ptr<sd_ctx_t::TextEncoders> te(new sd_ctx_t::TextEncoders());
+    const int m     = (int)ctx->params.model;
+    const bool tiny = m == SD_MODEL_SD15_TINY || m == SD_MODEL_SDXL_TINY || m == SD_MODEL_SD35_TINY || m == SD_MODEL_FLUX_TINY;
+    ConditionerSpec& sp = te->spec;
+    ClipTextConfig lc, gc;
+    T5Config tc;
+    std::string lp, gp, tp;
+    if (m == SD_MODEL_SD15 || m == SD_MODEL_SD15_TINY) {
+        sp.family = CondFamily::SD1;
+        lc        = tiny ? ClipTextConfig::tiny(64, 4, 0, false, true) : ClipTextConfig::vit_l(true);
+        lp        = "cond_stage_model.transformer.text_model.";
+    } else if (m == SD_MODEL_SDXL || m == SD_MODEL_SDXL_TINY) {
+        sp.family  = CondFamily::SDXL;
+        sp.has_g   = true;
+        lc         = tiny ? ClipTextConfig::tiny(24, 2, 0, false, false) : ClipTextConfig::vit_l(false);
+        gc         = tiny ? ClipTextConfig::tiny(40, 2, 48, true, false) : ClipTextConfig::vit_bigg(false);
+        lp         = "cond_stage_model.transformer.text_model.";
+        gp         = "cond_stage_model.1.transformer.text_model.";
+        sp.adm_dim = ctx->unet.cfg.adm_in_channels;
+        sp.ts_dim  = tiny ? 8 : 256;
+    } else if (m == SD_MODEL_SD35_LARGE || m == SD_MODEL_SD35_TINY) {
+        sp.family = CondFamily::SD3;
+        sp.has_g = sp.has_t5 = true;
+        lc = tiny ? ClipTextConfig::tiny(24, 2, 0, false, false) : ClipTextConfig::vit_l(false);
+        gc = tiny ? ClipTextConfig::tiny(40, 2, 40, true, false) : ClipTextConfig::vit_bigg(false);
+        tc = tiny ? T5Config::tiny(96) : T5Config::xxl();
+        lp = "text_encoders.clip_l.transformer.text_model.";
+        gp = "text_encoders.clip_g.transformer.text_model.";
+        tp = "text_encoders.t5xxl.transformer.";
+    } else {
+        sp.family   = CondFamily::FLUX;
+        sp.has_t5   = true;
+        sp.t5_chunk = tiny ? 32 : 256;
+        lc          = tiny ? ClipTextConfig::tiny(64, 4, 0, false, true) : ClipTextConfig::vit_l(true);
+        tc          = tiny ? T5Config::tiny(96) : T5Config::xxl();
+        lp          = "text_encoders.clip_l.transformer.text_model.";
+        tp          = "text_encoders.t5xxl.transformer.";
+    }
+    sp.l_dim  = lc.hidden_size;
+    sp.g_dim  = gc.hidden_size;
+    sp.g_proj = gc.projection_dim;
+    sp.t5_dim = tc.model_dim;
+    sp.eos_id = (int32_t)lc.vocab_size - 1;  // 49407 = <|endoftext|> of the 49408-entry CLIP vocabulary
+    auto setup = [&](Runner& r, size_t graph_size) {
+        r.backend        = ctx->backend;
+        r.ps.linear_type = (ggml_type)ctx->params.wtype;
+        r.graph_size     = graph_size;
+    };
+    setup(te->l_runner, 2048);  // clip.hpp:522
+    te->clip_l.init(te->l_runner.ps, lp, lc);
+    if (sp.has_g) {
+        setup(te->g_runner, 4096);
+        te->clip_g.init(te->g_runner.ps, gp, gc);
+    }
+    if (sp.has_t5) {
+        setup(te->t5_runner, 4096);
+        te->t5.init(te->t5_runner.ps, tp, tc);
+    }
+    ctx->te = std::move(te);
+    for (Runner* r : ctx->runners()) {
+        if (r == &ctx->unet_runner || r == &ctx->vae_runner) continue;
+        if (!r->alloc_weights(ctx->params.weight_seed)) {
+            set_error("text-encoder weight buffer allocation failed");
+            ctx->te.reset();
+            return false;
+        }
+    }
+    for (Runner* r : ctx->runners()) {
+        if (r == &ctx->unet_runner || r == &ctx->vae_runner) continue;
+        for (auto& spn : r->ps.specs) ctx->all_tensors.push_back({spn.name, spn.tensor});
+        ctx->stats.weight_bytes += ggml_backend_buffer_get_size(r->weights);
+    }
+    return true;
+}
+
+// CLIPTextModelRunner::build_graph / compute (clip.hpp:516-583)
+static bool te_clip_forward(sd_ctx_t* ctx, int which, const int32_t* ids, int64_t n_tokens, size_t max_token_idx, bool return_pooled, int clip_skip, std::vector<float>& out) {
+    if (!ensure_text_encoders(ctx)) return false;
+    auto& te = *ctx->te;
+    if (which < 0 || which > 1 || (which == 1 && !te.spec.has_g)) {
+        set_error("this model family has no such CLIP tower");
+        return false;
+    }
+    const ClipTextModel& m = which == 0 ? te.clip_l : te.clip_g;
+    const int64_t L        = m.cfg.n_token;
+    if (n_tokens <= 0 || n_tokens % L != 0) {  // clip.hpp:509-512: longer inputs fold into a batch of n_token-long rows
+        set_error("CLIP input length must be a positive multiple of 77");
+        return false;
+    }
+    const int64_t N = n_tokens / L;
+    for (int64_t i = 0; i < n_tokens; ++i)
+        if (ids[i] < 0 || ids[i] >= m.cfg.vocab_size) {
+            set_error("token id out of range");
+            return false;
+        }
+    if (max_token_idx >= (size_t)n_tokens) {
+        set_error("max_token_idx out of range");
+        return false;
+    }
+    const std::vector<float> mask = ClipTextModel::causal_mask((int)L);
+    out.resize((size_t)(return_pooled ? (m.text_projection ? m.cfg.projection_dim : m.cfg.hidden_size) : m.cfg.hidden_size * n_tokens));
+    auto build = [&](GraphCtx& g, std::vector<HostInput>& in) {
+        g.flash_attn     = ctx->params.diffusion_flash_attn;
+        ggml_tensor* tid = ggml_new_tensor_2d(g.ctx, GGML_TYPE_I32, L, N);
+        ggml_set_input(tid);
+        in.push_back({tid, ids, ggml_nbytes(tid)});
+        ggml_tensor* tm = ggml_new_tensor_2d(g.ctx, GGML_TYPE_F32, L, L);
+        ggml_set_input(tm);
+        in.push_back({tm, mask.data(), ggml_nbytes(tm)});
+        return m.forward(g, tid, tm, max_token_idx, return_pooled, clip_skip);
+    };
+    return te.runner(which)->compute(build, out.data(), out.size() * sizeof(float));
+}
+
+// T5Runner::build_graph / compute (t5.hpp:422-461); no padding mask (SD3 / FLUX pass none)
+static bool te_t5_forward(sd_ctx_t* ctx, const int32_t* ids, int64_t n_tokens, std::vector<float>& out) {
+    if (!ensure_text_encoders(ctx)) return false;
+    auto& te = *ctx->te;
+    if (!te.spec.has_t5) {
+        set_error("this model family has no T5 encoder");
+        return false;
+    }
+    const T5Model& m = te.t5;
+    if (n_tokens <= 0) {
+        set_error("empty T5 input");
+        return false;
+    }
+    for (int64_t i = 0; i < n_tokens; ++i)
+        if (ids[i] < 0 || ids[i] >= m.cfg.vocab_size) {
+            set_error("token id out of range");
+            return false;
+        }
+    const std::vector<int32_t> buckets = T5Model::relative_position_buckets((int)n_tokens, (int)n_tokens);
+    out.resize((size_t)(m.cfg.model_dim * n_tokens));
+    auto build = [&](GraphCtx& g, std::vector<HostInput>& in) {
+        g.flash_attn     = ctx->params.diffusion_flash_attn;
+        ggml_tensor* tid = ggml_new_tensor_2d(g.ctx, GGML_TYPE_I32, n_tokens, 1);
+        ggml_set_input(tid);
+        in.push_back({tid, ids, ggml_nbytes(tid)});
+        ggml_tensor* tb = ggml_new_tensor_2d(g.ctx, GGML_TYPE_I32, n_tokens, n_tokens);
+        ggml_set_input(tb);
+        in.push_back({tb, buckets.data(), ggml_nbytes(tb)});
+        return m.forward(g, tid, tb, nullptr);
+    };
+    return te.t5_runner.compute(build, out.data(), out.size() * sizeof(float));
+}
+
+bool sd_text_encoders_init(sd_ctx_t* ctx) { return ensure_text_encoders(ctx); }
+
+int64_t sd_clip_forward(sd_ctx_t* ctx, int which, const int32_t* ids, int n_tokens, int max_token_idx, bool return_pooled, int clip_skip, float* out, int64_t out_capacity) {
+    std::vector<float> o;
+    if (max_token_idx < 0) {
+        set_error("max_token_idx out of range");
+        return -1;
+    }
+    if (!te_clip_forward(ctx, which, ids, n_tokens, (size_t)max_token_idx, return_pooled, clip_skip, o)) return -1;
+    if ((int64_t)o.size() > out_capacity) {
+        set_error("output buffer too small");
+        return -1;
+    }
+    std::copy(o.begin(), o.end(), out);
+    return (int64_t)o.size();
+}
+
+int64_t sd_t5_forward(sd_ctx_t* ctx, const int32_t* ids, int n_tokens, float* out, int64_t out_capacity) {
+    std::vector<float> o;
+    if (!te_t5_forward(ctx, ids, n_tokens, o)) return -1;
+    if ((int64_t)o.size() > out_capacity) {
+        set_error("output buffer too small");
+        return -1;
+    }
+    std::copy(o.begin(), o.end(), out);
+    return (int64_t)o.size();
+}
+
+int sd_t5_relative_position_buckets(int q_len, int k_len, int32_t* out) {
+    const std::vector<int32_t> b = T5Model::relative_position_buckets(q_len, k_len);
+    std::copy(b.begin(), b.end(), out);
+    return (int)b.size();
+}
+
+bool sd_get_learned_condition(sd_ctx_t* ctx, const sd_token_list_t* clip_l, const sd_token_list_t* clip_g, const sd_token_list_t* t5, int clip_skip, int width,
+                              int height, bool zero_out_masked, float* crossattn_out, int64_t crossattn_capacity, int64_t* crossattn_ne, float* vector_out,
+                              int64_t vector_capacity, int64_t* vector_n) {
+    if (!ensure_text_encoders(ctx)) return false;
+    auto to_list = [](const sd_token_list_t* t) {
+        TokenList l;
+        if (t && t->n > 0) {
+            l.ids.assign(t->ids, t->ids + t->n);
+            if (t->weights)
+                l.weights.assign(t->weights, t->weights + t->n);
+            else
+                l.weights.assign((size_t)t->n, 1.0f);
+        }
+        return l;
+    };
+    EncoderFns fn;
+    fn.clip = [&](int which, const std::vector<int32_t>& ids, size_t max_idx, bool pooled, int skip, std::vector<float>& o) {
+        return te_clip_forward(ctx, which, ids.data(), (int64_t)ids.size(), max_idx, pooled, skip, o);
+    };
+    fn.t5 = [&](const std::vector<int32_t>& ids, std::vector<float>& o) { return te_t5_forward(ctx, ids.data(), (int64_t)ids.size(), o); };
+    Condition c;
+    std::string err;
+    if (!get_learned_condition(ctx->te->spec, fn, to_list(clip_l), to_list(clip_g), to_list(t5), clip_skip, width, height, zero_out_masked, c, err)) {
+        if (!err.empty()) set_error(err);
+        return false;
+    }
+    if (crossattn_ne) {
+        crossattn_ne[0] = c.ctx_dim;
+        crossattn_ne[1] = c.n_tokens;
+    }
+    if (vector_n) *vector_n = (int64_t)c.vec.size();
+    if (crossattn_out) {
+        if ((int64_t)c.crossattn.size() > crossattn_capacity) {
+            set_error("c_crossattn buffer too small");
+            return false;
+        }
+        std::copy(c.crossattn.begin(), c.crossattn.end(), crossattn_out);
+    }
+    if (vector_out && !c.vec.empty()) {
+        if ((int64_t)c.vec.size() > vector_capacity) {
+            set_error("c_vector buffer too small");
+            return false;
+        }
+        std::copy(c.vec.begin(), c.vec.end(), vector_out);
+    }
+    return true;
 }
 
 // ---- one UNet forward ---------------------------------------------------------------------------

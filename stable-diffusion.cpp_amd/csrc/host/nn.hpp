@@ -142,9 +142,11 @@ inline ggml_tensor* ext_group_norm(ggml_context* c, ggml_tensor* x, ggml_tensor*
     return x;
 }
 
-// ggml_ext_attention_ext — ggml_extend.hpp:1349-1485 (no mask, kv_scale = 1, skip_reshape = false)
+// ggml_ext_attention_ext — ggml_extend.hpp:1349-1485 (kv_scale = 1)
 // skip_reshape (ggml_extend.hpp:1383-1390): q, k arrive as [d_head, L, n_head*N] and v as [d_head, n_head, L, N] (Rope::attention)
-inline ggml_tensor* ext_attention(GraphCtx& g, ggml_tensor* q, ggml_tensor* k, ggml_tensor* v, int64_t n_head, bool skip_reshape = false) {
+// mask (text encoders): f32 [L_k, L_q or 1, heads or 1, 1] added to the scaled scores; the flash path materialises the query dimension
+// and casts it to f16 (:1411-1425), the manual path adds it in place (:1466-1468)
+inline ggml_tensor* ext_attention(GraphCtx& g, ggml_tensor* q, ggml_tensor* k, ggml_tensor* v, int64_t n_head, bool skip_reshape = false, ggml_tensor* mask = nullptr) {
     ggml_context* c = g.ctx;
     int64_t L_q = q->ne[1], L_k = k->ne[1], C = q->ne[0], N = q->ne[2];
     int64_t d_head = C / n_head, n_kv_head = k->ne[0] / d_head;
@@ -165,12 +167,17 @@ inline ggml_tensor* ext_attention(GraphCtx& g, ggml_tensor* q, ggml_tensor* k, g
 
     const float scale = 1.0f / sqrtf((float)d_head);
     ggml_tensor* kqv  = nullptr;
-    if (g.flash_attn) {
+    if (g.flash_attn && (mask == nullptr || mask->ne[3] == 1)) {
         ggml_tensor* k_in = ggml_cast(c, k, GGML_TYPE_F16);
         ggml_tensor* v_in = ext_cont(c, ggml_permute(c, v, 0, 2, 1, 3));
         v_in              = ggml_reshape_3d(c, v_in, d_head, L_k, n_kv_head * N);
         v_in              = ggml_cast(c, v_in, GGML_TYPE_F16);
-        ggml_tensor* out  = ggml_flash_attn_ext(c, q, k_in, v_in, nullptr, scale, 0, 0);
+        ggml_tensor* m_in = mask;
+        if (m_in != nullptr) {
+            if (m_in->ne[1] != L_q) m_in = ggml_repeat(c, m_in, ggml_new_tensor_4d(c, m_in->type, m_in->ne[0], L_q, m_in->ne[2], m_in->ne[3]));
+            m_in = ggml_cast(c, m_in, GGML_TYPE_F16);
+        }
+        ggml_tensor* out  = ggml_flash_attn_ext(c, q, k_in, v_in, m_in, scale, 0, 0);
         if (g.backend == nullptr || ggml_backend_supports_op(g.backend, out)) {
             ggml_flash_attn_ext_set_prec(out, GGML_PREC_F32);
             kqv = ggml_view_4d(c, out, d_head, n_head, L_q, N, out->nb[1], out->nb[2], out->nb[1] * n_head, 0);
@@ -182,6 +189,7 @@ inline ggml_tensor* ext_attention(GraphCtx& g, ggml_tensor* q, ggml_tensor* k, g
         ggml_tensor* kq = ggml_mul_mat(c, k, q);
         ggml_mul_mat_set_prec(kq, GGML_PREC_F32);
         kq  = ggml_scale_inplace(c, kq, scale);
+        if (mask) kq = ggml_add_inplace(c, kq, mask);
         kq  = ggml_soft_max_inplace(c, kq);
         kqv = ggml_mul_mat(c, v, kq);
         kqv = ggml_reshape_4d(c, kqv, d_head, L_q, n_head, N);

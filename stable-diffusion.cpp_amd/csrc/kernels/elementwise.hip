@@ -518,4 +518,53 @@ void launch_geglu(hipStream_t s, float* dst, const float* x, int64_t tokens, int
     k_geglu<<<grid_for(n4, 256), 256, 0, s>>>(dst, x, n4, (int)(inner / 4), x_stride / 4);
 }
 
+// ---------------------------------------------------------------------------------------- GET_ROWS (embedding gather)
+// dst[:, i10, i11, i12] = dequant(table[ids[i10, i11, i12], :] of plane (i11, i12)); one workgroup per gathered row.  HBM-bound:
+// nc * (table element + 4) bytes per row.  f32 / f16 / bf16 tables and ggml's q8_0 / q4_0 blocks.
+template <int TYPE>
+__global__ void k_get_rows(float* __restrict__ dst, const char* __restrict__ table, const char* __restrict__ ids, int64_t nc, int64_t ne10, int64_t ne11,
+                           int64_t ib0, int64_t ib1, int64_t ib2, int64_t tb1, int64_t tb2, int64_t tb3, int64_t db1, int64_t db2, int64_t db3, int64_t n_table_rows) {
+    const int64_t r   = blockIdx.x;
+    const int64_t i10 = r % ne10, i11 = (r / ne10) % ne11, i12 = r / (ne10 * ne11);
+    int64_t row       = *(const int32_t*)(ids + i10 * ib0 + i11 * ib1 + i12 * ib2);
+    row               = row < 0 ? 0 : (row >= n_table_rows ? n_table_rows - 1 : row);  // never read outside the table
+    const char* src   = table + row * tb1 + i11 * tb2 + i12 * tb3;
+    float* out        = (float*)((char*)dst + i10 * db1 + i11 * db2 + i12 * db3);
+    for (int64_t c = threadIdx.x; c < nc; c += blockDim.x) {
+        float v;
+        if (TYPE == 0) {
+            v = ((const float*)src)[c];
+        } else if (TYPE == 1) {
+            v = (float)((const _Float16*)src)[c];
+        } else if (TYPE == 30) {
+            v = __uint_as_float((uint32_t)((const uint16_t*)src)[c] << 16);
+        } else if (TYPE == 8) {
+            const char* blk = src + (c >> 5) * 34;
+            v               = (float)*(const _Float16*)blk * (float)((const int8_t*)(blk + 2))[c & 31];
+        } else {
+            const char* blk = src + (c >> 5) * 18;
+            const int j     = (int)(c & 31);
+            const uint8_t q = ((const uint8_t*)(blk + 2))[j & 15];
+            v               = (float)*(const _Float16*)blk * (float)((j < 16 ? (q & 0xF) : (q >> 4)) - 8);
+        }
+        out[c] = v;
+    }
+}
+void launch_get_rows(hipStream_t s, float* dst, const int64_t dnb[4], const View4& table, const View4& ids) {
+    const int64_t nr = ids.ne[0] * ids.ne[1] * ids.ne[2];
+    if (nr == 0) return;
+    const int threads = table.ne[0] >= 256 ? 256 : 64;
+#define GR(T)                                                                                                                                                  \
+    k_get_rows<T><<<(unsigned)nr, threads, 0, s>>>(dst, (const char*)table.data, (const char*)ids.data, table.ne[0], ids.ne[0], ids.ne[1], ids.nb[0], ids.nb[1], \
+                                                  ids.nb[2], table.nb[1], table.nb[2], table.nb[3], dnb[1], dnb[2], dnb[3], table.ne[1])
+    switch (table.type) {
+        case 0: GR(0); break;
+        case 1: GR(1); break;
+        case 30: GR(30); break;
+        case 8: GR(8); break;
+        default: GR(2); break;
+    }
+#undef GR
+}
+
 }  // namespace mi355x

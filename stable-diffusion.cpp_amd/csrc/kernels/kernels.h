@@ -33,6 +33,8 @@ void launch_concat_heads(hipStream_t s, void* out, bool out_f16, const float* a,
 void launch_rope_pairs(hipStream_t s, float* out, const View4& x, const float* pe);
 void launch_upscale_nearest(hipStream_t s, const View4& dst, const View4& src);
 void launch_pad(hipStream_t s, const View4& dst, const View4& src, const int32_t pads[8]);
+// GET_ROWS: ids i32 [ne0, ne1, ne2] (byte strides), table f32/f16/bf16/q8_0/q4_0 [nc, rows, ne1, ne2] -> dst f32 [nc, ne0, ne1, ne2]
+void launch_get_rows(hipStream_t s, float* dst, const int64_t dnb[4], const View4& table, const View4& ids);
 void launch_timestep_embedding(hipStream_t s, float* dst, const float* t, int n, int dim, int max_period, int64_t dst_row_stride);
 // GEGLU: dst[t][i] = x[t][i] * gelu(x[t][inner + i]); x row stride given in floats
 void launch_geglu(hipStream_t s, float* dst, const float* x, int64_t tokens, int64_t inner, int64_t x_stride);

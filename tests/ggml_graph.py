@@ -7,7 +7,7 @@ import ctypes as C
 import numpy as np
 
 import sdcpp_amd as sd
-from sdcpp_amd import F16, F32, BF16, Q4_0, Q8_0, GgmlInitParams, GgmlTensor
+from sdcpp_amd import F16, F32, BF16, I32, Q4_0, Q8_0, GgmlInitParams, GgmlTensor
 
 
 def tensor_struct(t) -> GgmlTensor:
@@ -20,7 +20,9 @@ def to_bf16_bits(a: np.ndarray) -> np.ndarray:
 
 
 def encode(arr: np.ndarray, gtype: int) -> bytes:
-    """f32 numpy [..., ne0] -> raw bytes of ggml type."""
+    """f32 numpy [..., ne0] -> raw bytes of ggml type (I32: integer array as is)."""
+    if gtype == I32:
+        return np.ascontiguousarray(arr, dtype=np.int32).tobytes()
     a = np.ascontiguousarray(arr, dtype=np.float32)
     if gtype == F32:
         return a.tobytes()

@@ -156,3 +156,74 @@ def test_flux_trajectory_parity(sd, oracle, gpu):
     err = rel_l2(out, ref)
     print(f"FLUX flow trajectory rel-L2 {err:.3e}")
     assert err < 2e-2
+
+
+# ---- text encoders -------------------------------------------------------------------------------------
+def _prompt(rng, n_words, pad, vocab=1000, length=77):
+    ids = np.full(length, pad, dtype=np.int32)
+    ids[0] = vocab - 2
+    ids[1:1 + n_words] = rng.integers(1, vocab - 2, n_words)
+    ids[1 + n_words] = vocab - 1
+    return ids
+
+
+@pytest.mark.parametrize("wtype", ["F16", "Q8_0"])
+def test_clip_text_towers_parity(sd, oracle, gpu, wtype):
+    """CLIP ViT-L and bigG text towers (tiny width, same topology: GET_ROWS embeddings, causal-mask attention, quick-GELU / GELU MLP,
+    penultimate-layer output, pooled + text_projection) on the GPU vs the oracle.  Same f16 bar as the UNet: rel-L2 <= 5e-3; q8_0
+    weights get the looser bar because the oracle also quantises activations."""
+    rng = np.random.default_rng(31)
+    wt = getattr(sd, wtype)
+    tol = 5e-3 if wtype == "F16" else 3e-2
+    ref_e = sd.Engine(model=sd.SDXL_TINY, backend=oracle, wtype=wt)
+    gpu_e = sd.Engine(model=sd.SDXL_TINY, backend=gpu, wtype=wt)
+    ids_l, ids_g = _prompt(rng, 9, 999), _prompt(rng, 9, 0)
+    for which, ids in ((0, ids_l), (1, ids_g)):
+        a, b = gpu_e.clip_forward(which, ids, clip_skip=2), ref_e.clip_forward(which, ids, clip_skip=2)
+        assert np.isfinite(a).all()
+        print(f"clip tower {which} {wtype}: rel-L2 {rel_l2(a, b):.3e}")
+        assert rel_l2(a, b) < tol
+    pa = gpu_e.clip_forward(1, ids_g, max_token_idx=10, return_pooled=True)
+    pb = ref_e.clip_forward(1, ids_g, max_token_idx=10, return_pooled=True)
+    assert rel_l2(pa, pb) < tol
+    # SD1.x flavour: all layers + final LN
+    a = sd.Engine(model=sd.SD15_TINY, backend=gpu, wtype=wt).clip_forward(0, ids_l)
+    b = sd.Engine(model=sd.SD15_TINY, backend=oracle, wtype=wt).clip_forward(0, ids_l)
+    assert rel_l2(a, b) < tol
+
+
+def test_t5_encoder_and_conditioner_parity(sd, oracle, gpu):
+    """T5 encoder stack (relative-position bias gather, RMS norm, gated-GELU FF with the 1/32 pre-scale) and the SD3 conditioner
+    composition (two CLIP towers + T5 -> [154, ctx] context and the pooled vector) on the GPU vs the oracle."""
+    rng = np.random.default_rng(32)
+    ref_e = sd.Engine(model=sd.SD35_TINY, backend=oracle)
+    gpu_e = sd.Engine(model=sd.SD35_TINY, backend=gpu)
+    for n in (77, 24):
+        ids = rng.integers(0, 1000, n).astype(np.int32)
+        a, b = gpu_e.t5_forward(ids), ref_e.t5_forward(ids)
+        assert np.isfinite(a).all()
+        print(f"T5 n={n}: rel-L2 {rel_l2(a, b):.3e}")
+        assert rel_l2(a, b) < 5e-3
+    il, ig, it = _prompt(rng, 6, 999), _prompt(rng, 6, 0), rng.integers(0, 1000, 77).astype(np.int32)
+    w = np.ones(77, np.float32)
+    w[2:6] = 1.4
+    (ca, ya), (cb, yb) = gpu_e.get_learned_condition((il, w), ig, it), ref_e.get_learned_condition((il, w), ig, it)
+    assert ca.shape == (1, 154, 96) and ya.shape == (1, 64)
+    assert rel_l2(ca, cb) < 5e-3 and rel_l2(ya, yb) < 5e-3
+
+
+def test_tokens_to_image_on_gpu(sd, oracle, gpu):
+    """ids -> conditioner -> 3 Euler-A steps -> VAE decode, all on the GPU engine; pixels vs the same pipeline on the oracle."""
+    rng = np.random.default_rng(33)
+    ids = _prompt(rng, 8, 999)
+    empty = _prompt(rng, 0, 999)
+    imgs = []
+    for dev in (gpu, oracle):
+        e = sd.Engine(model=sd.SD15_TINY, backend=dev)
+        c, _ = e.get_learned_condition(ids)
+        u, _ = e.get_learned_condition(empty)
+        imgs.append(e.generate_image(c, u, width=64, height=64, steps=3, cfg=5.0, seed=11).astype(np.float64) / 255.0)
+    mse = float(np.mean((imgs[0] - imgs[1]) ** 2))
+    psnr = 10 * np.log10(1.0 / max(mse, 1e-20))
+    print(f"tokens -> image PSNR {psnr:.1f} dB")
+    assert psnr > 30.0

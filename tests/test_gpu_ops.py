@@ -10,7 +10,7 @@
 import numpy as np
 import pytest
 
-from ggml_graph import BF16, F16, F32, Q4_0, Q8_0, Graph, dequant
+from ggml_graph import BF16, F16, F32, I32, Q4_0, Q8_0, Graph, dequant
 
 pytestmark = pytest.mark.gpu
 
@@ -433,3 +433,49 @@ def test_concat_of_strided_head_views(sd, oracle, gpu, rng, dim):
     ka = qa[:, :, d * H:2 * d * H].reshape(N, qa.shape[1], H, d)
     kb = qb[:, :, d * H:2 * d * H].reshape(N, qb.shape[1], H, d)
     np.testing.assert_array_equal(out, np.concatenate([ka, kb], axis=3 - dim))
+
+
+@pytest.mark.parametrize("ttype", [F32, F16, BF16, Q8_0, Q4_0])
+def test_get_rows(sd, oracle, gpu, rng, ttype):
+    """Embedding gather (CLIP / T5 token tables, T5 relative-attention bias): bit-exact against the oracle — both decode the same
+    stored bytes — and against the numpy gather of the dequantised table for the non-quantised types."""
+    table = rng.standard_normal((1000, 96)).astype(np.float32)
+    ids = rng.integers(0, 1000, (2, 77)).astype(np.int32)
+    ids[0, :3] = [0, 999, 0]
+
+    def build(g, L):
+        t = g.input(ids.reshape(-1), I32)
+        t = L.ggml_reshape_3d(g.ctx, t, 154, 1, 1)              # ggml_extend.hpp:3577-3580: flattened ids [n_token * N, 1, 1]
+        return L.ggml_get_rows(g.ctx, g.weight(table, ttype), t)
+
+    ref, out = run_both(sd, oracle, gpu, build)
+    np.testing.assert_array_equal(out, ref)
+    if ttype in (F32, F16):
+        np.testing.assert_array_equal(out.reshape(2, 77, 96), dequant(table, ttype)[ids])
+    # a [heads, 32] bias table gathered by a [Lq*Lk] bucket list (t5.hpp:208-215)
+    bias = rng.standard_normal((32, 4)).astype(np.float32)
+    buckets = sd.t5_relative_position_buckets(19, 19).reshape(-1)
+    ref, out = run_both(sd, oracle, gpu, lambda g, L: L.ggml_get_rows(g.ctx, g.weight(bias, F32), g.input(buckets, I32)))
+    np.testing.assert_array_equal(out, ref)
+    np.testing.assert_array_equal(out.reshape(-1, 4), bias[buckets])
+
+
+def test_masked_attention_chain(sd, oracle, gpu, rng):
+    """The text encoders' attention (ggml_extend.hpp:1460-1475 with a mask): scores + causal -inf mask (broadcast over heads) -> softmax
+    -> V.  -inf entries must give exact zeros and no NaN."""
+    H, Lq, d = 4, 77, 16
+    q = rng.standard_normal((H, Lq, d)).astype(np.float32)
+    k = rng.standard_normal((H, Lq, d)).astype(np.float32)
+    v = rng.standard_normal((H, d, Lq)).astype(np.float32)
+    mask = np.triu(np.full((Lq, Lq), -np.inf, dtype=np.float32), 1)
+
+    def build(g, L):
+        kq = L.ggml_mul_mat(g.ctx, g.input(k), g.input(q))
+        kq = L.ggml_scale_inplace(g.ctx, kq, 0.25)
+        kq = L.ggml_add_inplace(g.ctx, kq, g.input(mask))
+        kq = L.ggml_soft_max_inplace(g.ctx, kq)
+        return L.ggml_mul_mat(g.ctx, g.input(v), kq)
+
+    ref, out = run_both(sd, oracle, gpu, build)
+    assert np.isfinite(out).all()
+    assert rel_l2(out, ref) < 2e-4
