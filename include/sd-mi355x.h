@@ -137,6 +137,12 @@ SD_API bool sd_set_tensor_f32(sd_ctx_t* ctx, const char* name, const float* src,
  * is converted file dtype -> f32 -> the parameter's type (ModelLoader convert_tensor, src/model_loader.cpp:155-205) and uploaded.
  * Returns the number of parameters loaded, -1 on error (sd_last_error); *n_missing = declared but absent, *n_unused = in the file but unknown. */
 SD_API int64_t sd_load_weights(sd_ctx_t* ctx, const char* path, int64_t* n_missing, int64_t* n_unused);
+/* Same, with `prefix` prepended to every file name first — diffusers keeps one file per sub-model whose names carry no component prefix
+ * ("unet." / "vae." / "text_encoder." / "text_encoder_2.", model_loader.cpp init_from_diffusers_file).  File names are rewritten to the
+ * engine's canonical dialect before matching (src/name_conversion.cpp): diffusers UNet / VAE names, OpenCLIP text-tower names (fused
+ * in_proj rows are split into q/k/v), "conditioner.embedders.N.", "te1." … component aliases, llama.cpp-style T5 GGUF names. */
+SD_API int64_t sd_load_weights_prefixed(sd_ctx_t* ctx, const char* path, const char* prefix, int64_t* n_missing, int64_t* n_unused);
+SD_API bool sd_convert_tensor_name(sd_ctx_t* ctx, const char* name, char* out, size_t out_capacity); /* convert_tensor_name, name_conversion.cpp:1346 */
 
 /* ---- the hot path ---- */
 /* one diffusion-model forward (DiffusionModelRunner::compute, unet.hpp:818-858): x [W,H,C,N] f32,

@@ -251,6 +251,10 @@ def lib() -> C.CDLL:
     L.sd_sigma_to_t.argtypes = [C.c_float]
     L.sd_sigma_to_t.restype = C.c_float
     L.sd_get_stats.argtypes = [C.c_void_p, C.POINTER(SdStats)]
+    L.sd_load_weights_prefixed.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.sd_load_weights_prefixed.restype = C.c_int64
+    L.sd_convert_tensor_name.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_size_t]
+    L.sd_convert_tensor_name.restype = C.c_bool
     L.sd_text_encoders_init.argtypes = [C.c_void_p]
     L.sd_text_encoders_init.restype = C.c_bool
     L.sd_clip_forward.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_bool, C.c_int, C.c_void_p, C.c_int64]
@@ -480,16 +484,23 @@ class Engine:
             shape = shape[1:]
         return out.reshape(shape)
 
-    def load_weights(self, path) -> dict:
-        """Load a safetensors / GGUF checkpoint into the declared parameters (names must be the original-LDM / sd.cpp GGUF names)."""
+    def load_weights(self, path, prefix: str | None = None) -> dict:
+        """Load a safetensors / GGUF checkpoint into the declared parameters.  File names are converted to the engine's canonical
+        dialect first (diffusers UNet / VAE, OpenCLIP, component aliases); `prefix` is prepended to every file name before that
+        (diffusers keeps one un-prefixed file per sub-model: "unet.", "vae.", "text_encoder.", "text_encoder_2.")."""
         miss, unused = C.c_int64(0), C.c_int64(0)
         L = lib()
-        L.sd_load_weights.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
-        L.sd_load_weights.restype = C.c_int64
-        n = L.sd_load_weights(self._ctx, str(path).encode(), C.byref(miss), C.byref(unused))
+        n = L.sd_load_weights_prefixed(self._ctx, str(path).encode(), prefix.encode() if prefix else None, C.byref(miss), C.byref(unused))
         if n < 0:
             raise EngineError("sd_load_weights failed: " + L.sd_last_error().decode())
         return {"loaded": int(n), "missing": int(miss.value), "unused": int(unused.value)}
+
+    def convert_tensor_name(self, name: str) -> str:
+        """A checkpoint tensor name in the engine's canonical dialect (convert_tensor_name, src/name_conversion.cpp:1346)."""
+        buf = C.create_string_buffer(512)
+        if not lib().sd_convert_tensor_name(self._ctx, name.encode(), buf, 512):
+            raise EngineError("sd_convert_tensor_name: name too long")
+        return buf.value.decode()
 
     def set_guidance(self, guidance: float) -> None:
         """FLUX distilled-guidance input (default 3.5)"""

@@ -30,6 +30,7 @@
 #include "conditioner.hpp"
 #include "sampler.hpp"
 #include "model_io.hpp"
+#include "name_conversion.hpp"
 #include "sd-mi355x.h"
 
 using namespace sdmi;
@@ -404,18 +405,67 @@ bool sd_set_tensor_f32(sd_ctx_t* ctx, const char* name, const float* src, int64_
 // file dtype -> f32 -> the parameter's ggml type (convert_tensor, model_loader.cpp:155-205) and ggml_backend_tensor_set it.
 // Returns the number of parameters loaded, or -1 on a file / shape error; tensors the file does not name keep their current values.
 static bool ensure_text_encoders(sd_ctx_t* ctx);
-int64_t sd_load_weights(sd_ctx_t* ctx, const char* path, int64_t* n_missing, int64_t* n_unused) {
+
+static NameDialect name_dialect(const sd_ctx_t* ctx) {
+    NameDialect d;
+    d.unet_family = !ctx->is_dit;
+    d.flux        = ctx->is_flux;
+    if (!ctx->is_dit) {
+        const UNetConfig& c = ctx->unet.cfg;
+        d.unet_levels       = (int)c.channel_mult.size();
+        d.unet_res_blocks   = c.num_res_blocks;
+        d.unet_attn_levels.clear();
+        int ds = 1;
+        for (int l = 0; l < d.unet_levels; ++l, ds *= 2)
+            if (std::find(c.attention_resolutions.begin(), c.attention_resolutions.end(), ds) != c.attention_resolutions.end()) d.unet_attn_levels.push_back(l);
+    }
+    d.vae_levels = (int)ctx->vae.cfg.ch_mult.size();
+    return d;
+}
+
+bool sd_convert_tensor_name(sd_ctx_t* ctx, const char* name, char* out, size_t out_capacity) {
+    const std::string r = canonical_tensor_name(name, name_dialect(ctx));
+    if (r.size() + 1 > out_capacity) return false;
+    memcpy(out, r.c_str(), r.size() + 1);
+    return true;
+}
+
+int64_t sd_load_weights(sd_ctx_t* ctx, const char* path, int64_t* n_missing, int64_t* n_unused) { return sd_load_weights_prefixed(ctx, path, nullptr, n_missing, n_unused); }
+
+int64_t sd_load_weights_prefixed(sd_ctx_t* ctx, const char* path, const char* prefix, int64_t* n_missing, int64_t* n_unused) {
     ModelFile mf;
     if (!read_model_file(path, mf)) {
         set_error(mf.error);
         return -1;
     }
-    std::map<std::string, const FileTensor*> dir;
+    // file names -> canonical names (init_from_file_and_convert_name, model_loader.cpp); OpenCLIP's fused in_proj rows are split into the
+    // q / k / v projections the graph registers: rows [0,E) [E,2E) [2E,3E) of the [3E, E] weight (the reference keeps it fused and
+    // chunks the activation instead, ggml_extend.hpp:4074-4081 — the same dot products)
+    const NameDialect dialect = name_dialect(ctx);
+    std::vector<FileTensor> expanded;
+    expanded.reserve(mf.tensors.size());
     bool names_te = false;
-    for (auto& t : mf.tensors) {
-        dir[t.name] = &t;
-        names_te    = names_te || t.name.rfind("cond_stage_model.", 0) == 0 || t.name.rfind("text_encoders.", 0) == 0;
+    for (const FileTensor& t : mf.tensors) {
+        FileTensor c = t;
+        c.name       = canonical_tensor_name(prefix ? std::string(prefix) + t.name : t.name, dialect);
+        names_te     = names_te || c.name.rfind("cond_stage_model.", 0) == 0 || c.name.rfind("text_encoders.", 0) == 0;
+        const std::vector<std::string> qkv = split_in_proj_names(c.name);
+        const int outer                    = c.n_dims >= 2 ? 1 : 0;  // the fused dimension: rows of the weight, elements of the bias
+        if (!qkv.empty() && c.ne[outer] % 3 == 0 && (outer == 1 || !ggml_is_quantized(c.type))) {
+            for (int k = 0; k < 3; ++k) {
+                FileTensor part = c;
+                part.name       = qkv[k];
+                part.ne[outer]  = c.ne[outer] / 3;
+                part.nbytes     = c.nbytes / 3;
+                part.offset     = c.offset + (uint64_t)k * part.nbytes;
+                expanded.push_back(part);
+            }
+        } else {
+            expanded.push_back(c);
+        }
     }
+    std::map<std::string, const FileTensor*> dir;
+    for (auto& t : expanded) dir[t.name] = &t;
     if (names_te && !ensure_text_encoders(ctx)) return -1;  // like the conditioners' tensor_storage_map probes (conditioner.hpp:630-651)
     FILE* f = fopen(path, "rb");
     if (!f) {
@@ -437,10 +487,12 @@ int64_t sd_load_weights(sd_ctx_t* ctx, const char* path, int64_t* n_missing, int
         const int64_t n      = ggml_nelements(t);
         int64_t fn           = 1;
         for (int d = 0; d < 4; ++d) fn *= ft.ne[d];
-        // shapes must agree up to trailing 1s; Linear / conv weights additionally dim by dim (torch [out,in,kh,kw] == ggml [kw,kh,in,out])
+        // shapes must agree up to trailing 1s; Linear / conv weights additionally dim by dim (torch [out,in,kh,kw] == ggml [kw,kh,in,out]);
+        // a [out, in] matrix may fill a 1x1 conv kernel [1,1,in,out] (diffusers stores the VAE attention projections as Linear)
         bool same = fn == n;
-        for (int d = 0; same && d < 4; ++d) same = ft.ne[d] == t->ne[d] || (ft.n_dims <= 2 && ggml_n_dims(t) <= 2);
-        if (same && ft.n_dims <= 2 && ggml_n_dims(t) <= 2) same = ft.ne[0] == t->ne[0];
+        const bool lin_as_conv1x1 = ft.n_dims == 2 && t->ne[0] == 1 && t->ne[1] == 1 && ft.ne[0] == t->ne[2] && ft.ne[1] == t->ne[3];
+        for (int d = 0; same && !lin_as_conv1x1 && d < 4; ++d) same = ft.ne[d] == t->ne[d] || (ft.n_dims <= 2 && ggml_n_dims(t) <= 2);
+        if (same && !lin_as_conv1x1 && ft.n_dims <= 2 && ggml_n_dims(t) <= 2) same = ft.ne[0] == t->ne[0];
         if (!same) {
             set_error("shape mismatch for " + nt.first);
             fclose(f);
@@ -466,7 +518,7 @@ int64_t sd_load_weights(sd_ctx_t* ctx, const char* path, int64_t* n_missing, int
     }
     fclose(f);
     if (n_missing) *n_missing = missing;
-    if (n_unused) *n_unused = (int64_t)mf.tensors.size() - (int64_t)used.size();
+    if (n_unused) *n_unused = (int64_t)expanded.size() - (int64_t)used.size();
     return loaded;
 }
 

@@ -1,0 +1,280 @@
+"""CPU suite: checkpoint name dialects -> the engine's canonical names (src/name_conversion.cpp).
+
+Expected names are taken from the PUBLIC conversion tables the reference itself cites (diffusers' convert_diffusers_to_original_
+stable_diffusion.py / ..._sdxl.py, OpenCLIP <-> HF CLIP layouts), written out by hand below or produced by an independent Python
+inverse (LDM -> diffusers) in this file — never by the C++ under test.  The last tests write whole checkpoints in the foreign
+dialects and require a bit-identical engine after loading."""
+import re
+
+import numpy as np
+import pytest
+
+MDM, FSM = "model.diffusion_model.", "first_stage_model."
+
+
+@pytest.fixture(scope="module")
+def e15(sd, oracle):
+    return sd.Engine(model=sd.SD15_TINY, backend=oracle)   # same level / res-block / attention layout as SD1.5
+
+
+@pytest.fixture(scope="module")
+def exl(sd, oracle):
+    return sd.Engine(model=sd.SDXL_TINY, backend=oracle)
+
+
+SD1_CASES = [
+    ("unet.conv_in.weight", MDM + "input_blocks.0.0.weight"),
+    ("unet.time_embedding.linear_2.bias", MDM + "time_embed.2.bias"),
+    ("unet.down_blocks.0.resnets.1.norm1.weight", MDM + "input_blocks.2.0.in_layers.0.weight"),
+    ("unet.down_blocks.1.resnets.0.conv_shortcut.weight", MDM + "input_blocks.4.0.skip_connection.weight"),
+    ("unet.down_blocks.2.attentions.0.transformer_blocks.0.attn1.to_q.weight", MDM + "input_blocks.7.1.transformer_blocks.0.attn1.to_q.weight"),
+    ("unet.down_blocks.2.attentions.1.transformer_blocks.0.attn2.to_out.0.bias", MDM + "input_blocks.8.1.transformer_blocks.0.attn2.to_out.0.bias"),
+    ("unet.down_blocks.0.attentions.1.transformer_blocks.0.attn1.to_out.weight", MDM + "input_blocks.2.1.transformer_blocks.0.attn1.to_out.0.weight"),
+    ("unet.down_blocks.1.downsamplers.0.conv.bias", MDM + "input_blocks.6.0.op.bias"),
+    ("unet.down_blocks.3.resnets.1.time_emb_proj.weight", MDM + "input_blocks.11.0.emb_layers.1.weight"),
+    ("unet.mid_block.resnets.1.conv2.bias", MDM + "middle_block.2.out_layers.3.bias"),
+    ("unet.mid_block.attentions.0.proj_in.weight", MDM + "middle_block.1.proj_in.weight"),
+    ("unet.up_blocks.0.resnets.2.norm2.bias", MDM + "output_blocks.2.0.out_layers.0.bias"),
+    ("unet.up_blocks.0.upsamplers.0.conv.weight", MDM + "output_blocks.2.1.conv.weight"),       # deepest SD1.x level has no attention
+    ("unet.up_blocks.1.upsamplers.0.conv.weight", MDM + "output_blocks.5.2.conv.weight"),
+    ("unet.up_blocks.3.attentions.2.norm.weight", MDM + "output_blocks.11.1.norm.weight"),
+    ("unet.conv_norm_out.bias", MDM + "out.0.bias"),
+    ("unet.conv_out.weight", MDM + "out.2.weight"),
+    ("diffusion_model.input_blocks.1.0.in_layers.0.weight", MDM + "input_blocks.1.0.in_layers.0.weight"),
+    (MDM + "out.2.bias", MDM + "out.2.bias"),
+    ("vae.decoder.conv_in.weight", FSM + "decoder.conv_in.weight"),
+    ("vae.decoder.conv_norm_out.weight", FSM + "decoder.norm_out.weight"),
+    ("vae.decoder.up_blocks.0.resnets.2.conv1.weight", FSM + "decoder.up.3.block.2.conv1.weight"),
+    ("vae.decoder.up_blocks.2.resnets.0.conv_shortcut.weight", FSM + "decoder.up.1.block.0.nin_shortcut.weight"),
+    ("vae.decoder.up_blocks.1.upsamplers.0.conv.bias", FSM + "decoder.up.2.upsample.conv.bias"),
+    ("vae.decoder.mid_block.resnets.1.norm2.weight", FSM + "decoder.mid.block_2.norm2.weight"),
+    ("vae.decoder.mid_block.attentions.0.group_norm.weight", FSM + "decoder.mid.attn_1.norm.weight"),
+    ("vae.decoder.mid_block.attentions.0.to_q.weight", FSM + "decoder.mid.attn_1.q.weight"),
+    ("vae.decoder.mid_block.attentions.0.to_out.0.bias", FSM + "decoder.mid.attn_1.proj_out.bias"),
+    ("vae.decoder.mid_block.attentions.0.proj_attn.weight", FSM + "decoder.mid.attn_1.proj_out.weight"),
+    ("vae.decoder.mid_block.attentions.0.value.bias", FSM + "decoder.mid.attn_1.v.bias"),
+    ("vae.encoder.down_blocks.1.downsamplers.0.conv.weight", FSM + "encoder.down.1.downsample.conv.weight"),
+    ("vae.post_quant_conv.weight", FSM + "post_quant_conv.weight"),
+    ("text_encoder.text_model.final_layer_norm.weight", "cond_stage_model.transformer.text_model.final_layer_norm.weight"),
+    ("te.text_model.encoder.layers.3.mlp.fc1.bias", "cond_stage_model.transformer.text_model.encoder.layers.3.mlp.fc1.bias"),
+    ("cond_stage_model.transformer.text_model.embeddings.token_embedding.weight", "cond_stage_model.transformer.text_model.embeddings.token_embedding.weight"),
+    ("cond_stage_model.model.transformer.resblocks.5.mlp.c_fc.weight", "cond_stage_model.transformer.text_model.encoder.layers.5.mlp.fc1.weight"),
+    ("cond_stage_model.model.ln_final.bias", "cond_stage_model.transformer.text_model.final_layer_norm.bias"),
+    ("cond_stage_model.model.positional_embedding", "cond_stage_model.transformer.text_model.embeddings.position_embedding.weight"),
+    ("some.unrelated.tensor", "some.unrelated.tensor"),
+]
+
+SDXL_CASES = [
+    ("unet.add_embedding.linear_1.weight", MDM + "label_emb.0.0.weight"),
+    ("unet.down_blocks.0.resnets.1.conv1.weight", MDM + "input_blocks.2.0.in_layers.2.weight"),
+    ("unet.down_blocks.1.attentions.1.transformer_blocks.1.ff.net.0.proj.weight", MDM + "input_blocks.5.1.transformer_blocks.1.ff.net.0.proj.weight"),
+    ("unet.down_blocks.1.downsamplers.0.conv.weight", MDM + "input_blocks.6.0.op.weight"),
+    ("unet.up_blocks.0.upsamplers.0.conv.weight", MDM + "output_blocks.2.2.conv.weight"),       # deepest SDXL level carries attention
+    ("unet.up_blocks.1.upsamplers.0.conv.bias", MDM + "output_blocks.5.2.conv.bias"),
+    ("unet.up_blocks.2.resnets.2.conv2.weight", MDM + "output_blocks.8.0.out_layers.3.weight"),
+    ("conditioner.embedders.0.transformer.text_model.embeddings.position_embedding.weight", "cond_stage_model.transformer.text_model.embeddings.position_embedding.weight"),
+    ("conditioner.embedders.1.model.transformer.resblocks.31.attn.in_proj_weight", "cond_stage_model.1.transformer.text_model.encoder.layers.31.self_attn.in_proj.weight"),
+    ("conditioner.embedders.1.model.transformer.resblocks.0.attn.out_proj.bias", "cond_stage_model.1.transformer.text_model.encoder.layers.0.self_attn.out_proj.bias"),
+    ("conditioner.embedders.1.model.transformer.resblocks.7.ln_2.weight", "cond_stage_model.1.transformer.text_model.encoder.layers.7.layer_norm2.weight"),
+    ("conditioner.embedders.1.model.transformer.resblocks.7.mlp.c_proj.bias", "cond_stage_model.1.transformer.text_model.encoder.layers.7.mlp.fc2.bias"),
+    ("conditioner.embedders.1.model.token_embedding.weight", "cond_stage_model.1.transformer.text_model.embeddings.token_embedding.weight"),
+    ("conditioner.embedders.1.model.text_projection", "cond_stage_model.1.transformer.text_model.text_projection"),
+    ("text_encoder_2.text_model.encoder.layers.2.self_attn.k_proj.weight", "cond_stage_model.1.transformer.text_model.encoder.layers.2.self_attn.k_proj.weight"),
+    ("text_encoder_2.text_projection.weight", "cond_stage_model.1.transformer.text_model.text_projection"),
+    ("te2.text_model.final_layer_norm.bias", "cond_stage_model.1.transformer.text_model.final_layer_norm.bias"),
+]
+
+DIT_CASES = [
+    ("model.diffusion_model.joint_blocks.0.x_block.attn.qkv.weight", "model.diffusion_model.joint_blocks.0.x_block.attn.qkv.weight"),
+    ("clip_l.text_model.final_layer_norm.weight", "text_encoders.clip_l.transformer.text_model.final_layer_norm.weight"),
+    ("text_encoders.clip_g.transformer.text_model.text_projection", "text_encoders.clip_g.transformer.text_model.text_projection"),
+    ("text_encoders.t5xxl.transformer.encoder.block.3.layer.1.DenseReluDense.wi_0.weight", "text_encoders.t5xxl.transformer.encoder.block.3.layer.1.DenseReluDense.wi_0.weight"),
+    ("text_encoders.t5xxl.transformer.enc.blk.3.ffn_gate.weight", "text_encoders.t5xxl.transformer.encoder.block.3.layer.1.DenseReluDense.wi_0.weight"),
+    ("text_encoders.t5xxl.transformer.enc.blk.0.attn_rel_b.weight", "text_encoders.t5xxl.transformer.encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight"),
+    ("text_encoders.t5xxl.transformer.enc.output_norm.weight", "text_encoders.t5xxl.transformer.encoder.final_layer_norm.weight"),
+    ("text_encoders.t5xxl.transformer.token_embd.weight", "text_encoders.t5xxl.transformer.shared.weight"),
+    ("te3.encoder.block.0.layer.0.SelfAttention.q.weight", "text_encoders.t5xxl.transformer.encoder.block.0.layer.0.SelfAttention.q.weight"),
+    ("vae.decoder.up_blocks.3.resnets.0.norm1.bias", FSM + "decoder.up.0.block.0.norm1.bias"),
+]
+
+
+@pytest.mark.parametrize("raw,want", SD1_CASES)
+def test_sd1_names(e15, raw, want):
+    assert e15.convert_tensor_name(raw) == want
+
+
+@pytest.mark.parametrize("raw,want", SDXL_CASES)
+def test_sdxl_names(exl, raw, want):
+    assert exl.convert_tensor_name(raw) == want
+
+
+@pytest.mark.parametrize("raw,want", DIT_CASES)
+def test_dit_names(sd, oracle, raw, want):
+    e = sd.Engine(model=sd.SD35_TINY, backend=oracle)
+    assert e.convert_tensor_name(raw) == want
+
+
+# ---- independent inverse: LDM -> diffusers (the direction of diffusers' own convert_original_stable_diffusion_to_diffusers) ----------
+RES_INV = {"in_layers.0": "norm1", "in_layers.2": "conv1", "out_layers.0": "norm2", "out_layers.3": "conv2", "emb_layers.1": "time_emb_proj",
+           "skip_connection": "conv_shortcut"}
+
+
+def _res_inv(rest):
+    for k, v in RES_INV.items():
+        if rest.startswith(k + "."):
+            return v + rest[len(k):]
+    raise AssertionError(rest)
+
+
+def ldm_unet_to_diffusers(name, R=2):
+    top = {"time_embed.0.": "time_embedding.linear_1.", "time_embed.2.": "time_embedding.linear_2.", "label_emb.0.0.": "add_embedding.linear_1.",
+           "label_emb.0.2.": "add_embedding.linear_2.", "input_blocks.0.0.": "conv_in.", "out.0.": "conv_norm_out.", "out.2.": "conv_out."}
+    for k, v in top.items():
+        if name.startswith(k):
+            return v + name[len(k):]
+    m = re.match(r"(input_blocks|output_blocks)\.(\d+)\.(\d+)\.(.*)", name)
+    if m:
+        kind, n, sub, rest = m.group(1), int(m.group(2)), int(m.group(3)), m.group(4)
+        if kind == "input_blocks":
+            i, j = (n - 1) // (R + 1), (n - 1) % (R + 1)
+            if j == R:
+                assert rest.startswith("op.")
+                return f"down_blocks.{i}.downsamplers.0.conv.{rest[3:]}"
+            return f"down_blocks.{i}.resnets.{j}.{_res_inv(rest)}" if sub == 0 else f"down_blocks.{i}.attentions.{j}.{rest}"
+        i, j = n // (R + 1), n % (R + 1)
+        if sub == 0:
+            return f"up_blocks.{i}.resnets.{j}.{_res_inv(rest)}"
+        if rest.startswith("conv."):
+            return f"up_blocks.{i}.upsamplers.0.{rest}"
+        return f"up_blocks.{i}.attentions.{j}.{rest}"
+    m = re.match(r"middle_block\.(\d)\.(.*)", name)
+    assert m, name
+    k, rest = int(m.group(1)), m.group(2)
+    return f"mid_block.attentions.0.{rest}" if k == 1 else f"mid_block.resnets.{k // 2}.{_res_inv(rest)}"
+
+
+def ldm_vae_to_diffusers(name, levels=4):
+    m = re.match(r"(encoder|decoder)\.(.*)", name)
+    if not m:
+        return name
+    side, rest = m.group(1), m.group(2)
+    if rest.startswith("norm_out."):
+        return f"{side}.conv_norm_out.{rest[9:]}"
+    mm = re.match(r"mid\.block_(\d)\.(.*)", rest)
+    if mm:
+        return f"{side}.mid_block.resnets.{int(mm.group(1)) - 1}." + mm.group(2).replace("nin_shortcut", "conv_shortcut")
+    mm = re.match(r"mid\.attn_1\.(\w+)\.(.*)", rest)
+    if mm:
+        member = {"norm": "group_norm", "q": "to_q", "k": "to_k", "v": "to_v", "proj_out": "to_out.0"}[mm.group(1)]
+        return f"{side}.mid_block.attentions.0.{member}.{mm.group(2)}"
+    mm = re.match(r"(up|down)\.(\d)\.(block\.(\d)|upsample|downsample)\.(.*)", rest)
+    if mm:
+        up, lvl = mm.group(1) == "up", int(mm.group(2))
+        blk = f"{side}.{'up' if up else 'down'}_blocks.{levels - 1 - lvl if up else lvl}"
+        if mm.group(3).startswith("block"):
+            return f"{blk}.resnets.{mm.group(4)}." + mm.group(5).replace("nin_shortcut", "conv_shortcut")
+        return f"{blk}.{'upsamplers' if up else 'downsamplers'}.0.{mm.group(5)}"
+    return name
+
+
+@pytest.mark.parametrize("which", ["SD15_TINY", "SDXL_TINY"])
+def test_every_unet_and_vae_name_round_trips(sd, oracle, which):
+    e = sd.Engine(model=getattr(sd, which), backend=oracle)
+    n_unet = n_vae = 0
+    for name in e.tensor_names():
+        if name.startswith(MDM):
+            foreign = "unet." + ldm_unet_to_diffusers(name[len(MDM):])
+            n_unet += 1
+        elif name.startswith(FSM):
+            foreign = "vae." + ldm_vae_to_diffusers(name[len(FSM):])
+            n_vae += 1
+        else:
+            continue
+        assert foreign.split(".", 1)[1] != name.split(".", 2)[-1] or "post_quant" in name or "conv_in" in name or "conv_out" in name
+        assert e.convert_tensor_name(foreign) == name, foreign
+    assert n_unet > 300 and n_vae > 60
+
+
+def test_foreign_dialect_checkpoint_loads_bit_identically(sd, oracle, tmp_path):
+    """One checkpoint, three dialects: LDM names; diffusers names for UNet + VAE (VAE attention projections as 2-D Linear weights, the
+    way diffusers stores them); OpenCLIP names with the fused in_proj for the text tower.  All must give the same engine."""
+    from safetensors.numpy import save_file
+
+    src = sd.Engine(model=sd.SD15_TINY, backend=oracle, weight_seed=5)
+    src.text_encoders_init()
+    native, foreign = {}, {}
+    qkv = {}
+    for name in src.tensor_names():
+        arr = src.get_tensor(name)
+        arr = arr.astype(np.float16 if src.tensor_info(name)[1] == sd.F16 else np.float32)
+        native[name] = arr
+        if name.startswith(MDM):
+            foreign["unet." + ldm_unet_to_diffusers(name[len(MDM):])] = arr
+        elif name.startswith(FSM):
+            f = "vae." + ldm_vae_to_diffusers(name[len(FSM):])
+            if ".attentions.0.to_" in f and f.endswith("weight"):
+                arr = arr.reshape(arr.shape[0], arr.shape[1])          # conv 1x1 [O, I, 1, 1] -> Linear [O, I]
+            foreign[f] = arr
+        else:  # cond_stage_model.transformer.text_model.* -> OpenCLIP layout under cond_stage_model.model.*
+            t = name[len("cond_stage_model.transformer.text_model."):]
+            m = re.match(r"encoder\.layers\.(\d+)\.(.*)", t)
+            if m:
+                i, rest = m.group(1), m.group(2)
+                mm = re.match(r"self_attn\.([qkv])_proj\.(weight|bias)", rest)
+                if mm:
+                    qkv.setdefault((i, mm.group(2)), {})[mm.group(1)] = arr
+                    continue
+                rest = (rest.replace("self_attn.out_proj", "attn.out_proj").replace("layer_norm1", "ln_1").replace("layer_norm2", "ln_2")
+                        .replace("mlp.fc1", "mlp.c_fc").replace("mlp.fc2", "mlp.c_proj"))
+                foreign[f"cond_stage_model.model.transformer.resblocks.{i}.{rest}"] = arr
+            else:
+                t = {"embeddings.token_embedding.weight": "token_embedding.weight", "embeddings.position_embedding.weight": "positional_embedding",
+                     "final_layer_norm.weight": "ln_final.weight", "final_layer_norm.bias": "ln_final.bias"}[t]
+                foreign["cond_stage_model.model." + t] = arr
+    for (i, leaf), parts in qkv.items():
+        foreign[f"cond_stage_model.model.transformer.resblocks.{i}.attn.in_proj_{leaf}"] = np.concatenate([parts["q"], parts["k"], parts["v"]], axis=0)
+    save_file(native, str(tmp_path / "native.safetensors"))
+    save_file(foreign, str(tmp_path / "foreign.safetensors"))
+    assert not (set(native) & set(foreign) - {n for n in native if "conv_in" in n or "conv_out" in n or "quant_conv" in n})
+
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((1, 4, 16, 16)).astype(np.float32)
+    ctx = rng.standard_normal((1, 77, 64)).astype(np.float32)
+    t = np.array([321.0], np.float32)
+    ids = np.full(77, 999, np.int32)
+    ids[:6] = [998, 4, 8, 15, 16, 23]
+    outs = []
+    for fname in ("native.safetensors", "foreign.safetensors"):
+        e = sd.Engine(model=sd.SD15_TINY, backend=oracle, weight_seed=99)
+        r = e.load_weights(tmp_path / fname)
+        assert r["loaded"] == len(native) and r["missing"] == 0 and r["unused"] == 0, (fname, r)
+        outs.append((e.unet_forward(x, t, ctx), e.vae_decode(x), e.clip_forward(0, ids)))
+    ref = (src.unet_forward(x, t, ctx), src.vae_decode(x), src.clip_forward(0, ids))
+    for o in outs:
+        for a, b in zip(o, ref):
+            np.testing.assert_array_equal(a, b)
+
+
+def test_component_file_with_prefix(sd, oracle, tmp_path):
+    """diffusers layout: one un-prefixed file per sub-model (unet/diffusion_pytorch_model.safetensors) loaded with prefix='unet.'"""
+    from safetensors.numpy import save_file
+
+    src = sd.Engine(model=sd.SDXL_TINY, backend=oracle, weight_seed=6)
+    unet = {}
+    for name in src.tensor_names():
+        if name.startswith(MDM):
+            arr = src.get_tensor(name)
+            unet[ldm_unet_to_diffusers(name[len(MDM):])] = arr.astype(np.float16 if src.tensor_info(name)[1] == sd.F16 else np.float32)
+    save_file(unet, str(tmp_path / "diffusion_pytorch_model.safetensors"))
+    e = sd.Engine(model=sd.SDXL_TINY, backend=oracle, weight_seed=7)
+    r = e.load_weights(tmp_path / "diffusion_pytorch_model.safetensors", prefix="unet.")
+    assert r["loaded"] == len(unet) and r["unused"] == 0
+    # without the prefix nothing matches (bare diffusers names are not guessed)
+    r0 = sd.Engine(model=sd.SDXL_TINY, backend=oracle, weight_seed=7).load_weights(tmp_path / "diffusion_pytorch_model.safetensors")
+    assert r0["loaded"] == 0
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((1, 4, 16, 16)).astype(np.float32)
+    ctx = rng.standard_normal((1, 77, 64)).astype(np.float32)
+    y = rng.standard_normal((1, 96)).astype(np.float32)
+    t = np.array([111.0], np.float32)
+    np.testing.assert_array_equal(e.unet_forward(x, t, ctx, y), src.unet_forward(x, t, ctx, y))
