@@ -664,11 +664,11 @@ inline std::vector<float> gen_flux_pe(int h, int w, int patch_size, int context_
     return pe;
 }
 
-struct FluxMLPEmbedder {  // flux.hpp:193-211
+struct FluxMLPEmbedder {  // flux.hpp:193-211; time_in / vector_in / guidance_in are never quantised (model_loader.cpp:1523-1529)
     Linear in_layer, out_layer;
     void init(ParamStore& ps, const std::string& prefix, int64_t in, int64_t hidden) {
-        in_layer.init(ps, prefix + "in_layer.", in, hidden);
-        out_layer.init(ps, prefix + "out_layer.", hidden, hidden);
+        in_layer.init(ps, prefix + "in_layer.", in, hidden, true, true);
+        out_layer.init(ps, prefix + "out_layer.", hidden, hidden, true, true);
     }
     ggml_tensor* forward(GraphCtx& g, ggml_tensor* x) const {
         x = in_layer.forward(g, x);
@@ -817,17 +817,18 @@ struct FluxModel {
 
     void init(ParamStore& ps, const std::string& prefix, const FluxConfig& c) {
         cfg = c;
-        img_in.init(ps, prefix + "img_in.", cfg.in_channels, cfg.hidden_size);
+        // img_in / txt_in / final_layer keep f16 under a quantised wtype (tensor_should_be_converted, model_loader.cpp:1523-1529)
+        img_in.init(ps, prefix + "img_in.", cfg.in_channels, cfg.hidden_size, true, true);
         time_in.init(ps, prefix + "time_in.", 256, cfg.hidden_size);
         vector_in.init(ps, prefix + "vector_in.", cfg.vec_in_dim, cfg.hidden_size);
         if (cfg.guidance_embed) guidance_in.init(ps, prefix + "guidance_in.", 256, cfg.hidden_size);
-        txt_in.init(ps, prefix + "txt_in.", cfg.context_in_dim, cfg.hidden_size);
+        txt_in.init(ps, prefix + "txt_in.", cfg.context_in_dim, cfg.hidden_size, true, true);
         double_blocks.resize(cfg.depth);
         for (int i = 0; i < cfg.depth; ++i) double_blocks[i].init(ps, prefix + "double_blocks." + std::to_string(i) + ".", cfg);
         single_blocks.resize(cfg.depth_single_blocks);
         for (int i = 0; i < cfg.depth_single_blocks; ++i) single_blocks[i].init(ps, prefix + "single_blocks." + std::to_string(i) + ".", cfg);
-        final_linear.init(ps, prefix + "final_layer.linear.", cfg.hidden_size, cfg.out_channels);
-        final_adaLN.init(ps, prefix + "final_layer.adaLN_modulation.1.", cfg.hidden_size, 2 * cfg.hidden_size);
+        final_linear.init(ps, prefix + "final_layer.linear.", cfg.hidden_size, cfg.out_channels, true, true);
+        final_adaLN.init(ps, prefix + "final_layer.adaLN_modulation.1.", cfg.hidden_size, 2 * cfg.hidden_size, true, true);
     }
 
     // forward_flux_chroma + forward_orig — flux.hpp:1267-1337, 1008-1182.  x [W,H,16,N]; timestep [N] (= sigma); context [ctx, L, N|1|2];

@@ -294,3 +294,17 @@ def test_model_outputs_match_committed_golden(sd, oracle, name):
     assert rel_l2(out, G[f"{name}_out"]) < 3e-3
     if name == "SD15_TINY":
         assert np.abs(e.vae_decode(G["VAE_TINY_z"]) - G["VAE_TINY_rgb"]).max() < 5e-3
+
+
+def test_flux_never_quantised_tensors(sd, oracle):
+    """tensor_should_be_converted (model_loader.cpp:1509-1545): under a quantised wtype the FLUX input / embedder / final layers keep
+    f16, biases and norm scales f32, and the block Linears take the block type."""
+    e = sd.Engine(model=sd.FLUX_TINY, backend=oracle, wtype=sd.Q4_0)
+    P = "model.diffusion_model."
+    for n in ("img_in.weight", "txt_in.weight", "time_in.in_layer.weight", "time_in.out_layer.weight", "vector_in.in_layer.weight", "guidance_in.out_layer.weight",
+              "final_layer.linear.weight", "final_layer.adaLN_modulation.1.weight"):
+        assert e.tensor_info(P + n)[1] == sd.F16, n
+    for n in ("double_blocks.0.img_attn.qkv.weight", "double_blocks.1.txt_mlp.0.weight", "single_blocks.0.linear1.weight", "double_blocks.0.img_mod.lin.weight"):
+        assert e.tensor_info(P + n)[1] == sd.Q4_0, n
+    for n in ("img_in.bias", "double_blocks.0.img_attn.norm.query_norm.scale", "single_blocks.1.linear2.bias"):
+        assert e.tensor_info(P + n)[1] == sd.F32, n
