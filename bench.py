@@ -56,6 +56,9 @@ def parse():
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--e2e", action="store_true", help="also time one full image (20 steps + VAE decode) per GPU batch")
+    ap.add_argument("--device-sampler", action="store_true",
+                    help="time the K steps as ONE device-resident Euler-A trajectory (SURVEY.md section 8 f4: latents stay in HBM, one graph per "
+                         "step queued without host synchronisation) instead of K host-driven cond+uncond forwards")
     return ap.parse_args()
 
 
@@ -125,15 +128,27 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    def trajectory(k):
+        # k sampler iterations on the device batch: x*c_in, cond+uncond forward, CFG, Euler(-A) update per step, no host crossing in between
+        eng.sample_latents(cond, None if flux else uncond, width=lat * 8, height=lat * 8, steps=k, cfg=1.0 if flux else 7.0, seed=42, batch=B,
+                           device_batch=B, method=sd.EULER if dit else sd.EULER_A, cond_y=y, uncond_y=y, fuse_cfg=True, device_sampler=True)
+
+    if args.device_sampler:
+        if args.warmup > 0:
+            trajectory(args.warmup)
+    else:
+        for _ in range(args.warmup):
+            step()
     barrier()
     timing = args.hip_graph == 0  # events cannot be recorded inside a captured graph replay
     if timing:
         sd.kernel_timing_enable(True)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    if args.device_sampler:
+        trajectory(args.steps)
+    else:
+        for _ in range(args.steps):
+            step()
     barrier()
     dt = time.perf_counter() - t0
     kt = sd.kernel_timing() if timing else None
@@ -180,13 +195,13 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"{args.model} {'MMDiT' if dit else 'UNet'} {lat*8}x{lat*8}, {'cfg 1 (distilled guidance 3.5, one forward per step)' if flux else 'cfg 7 (cond+uncond)'}, {'q8_0 Linear + f16 conv' if args.model == 'sdxl' else ('q4_0' if flux else ('bf16' if dit else 'f16'))} weights, batch {B}/GPU, Euler-A step",
                    "global_batch": B * world, "flash_attn": not args.no_flash, "hip_graph": args.hip_graph,
-                   "cfg_pair_in_one_graph": fuse},
+                   "cfg_pair_in_one_graph": fuse, "device_resident_sampler": bool(args.device_sampler)},
         "roofline": roofline,
     }
     if args.e2e and rank == 0:
         t0 = time.perf_counter()
         eng.generate_image(cond, uncond, width=lat * 8, height=lat * 8, steps=20, cfg=7.0, seed=42, batch=B, device_batch=B,
-                           cond_y=y, uncond_y=y, fuse_cfg=fuse)
+                           cond_y=y, uncond_y=y, fuse_cfg=fuse, device_sampler=args.device_sampler)
         e2e = time.perf_counter() - t0
         st = eng.stats()
         out["e2e"] = {"sec_per_image": round(e2e / B, 4), "batch": B, "steps": 20, "sample_ms": round(st["last_sample_ms"], 1),

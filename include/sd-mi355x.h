@@ -100,6 +100,9 @@ typedef struct {
     bool decode;                /* run the VAE and return pixels; false -> latents only */
     bool fuse_cfg_pair;         /* OUR extension: cond and uncond of every image run in ONE graph (N = 2*batch, context [.,.,2]
                                    tiled by the graph's own ggml_repeat, unet.hpp:548-552) instead of two computes per step */
+    bool device_sampler;        /* OUR extension: the whole iteration — x*c_in, model pair, CFG combine, Euler(-A) update —
+                                   is one graph per step on latents that stay in a backend buffer; nothing crosses back to the host until
+                                   the last step (the reference's three crossings per model call: stable-diffusion.cpp:2636-2664, 2855-2896) */
 } sd_img_gen_params_t;
 
 typedef struct {

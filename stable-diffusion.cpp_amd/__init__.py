@@ -84,7 +84,7 @@ class SdCondition(C.Structure):
 class SdImgGenParams(C.Structure):
     _fields_ = [("cond", SdCondition), ("uncond", SdCondition), ("width", C.c_int), ("height", C.c_int),
                 ("sample_params", SdSampleParams), ("seed", C.c_int64), ("batch_count", C.c_int),
-                ("device_batch", C.c_int), ("decode", C.c_bool), ("fuse_cfg_pair", C.c_bool)]
+                ("device_batch", C.c_int), ("decode", C.c_bool), ("fuse_cfg_pair", C.c_bool), ("device_sampler", C.c_bool)]
 
 
 class SdTokenList(C.Structure):
@@ -537,7 +537,7 @@ class Engine:
         return out
 
     def _gen_params(self, cond, uncond, width, height, steps, cfg, seed, batch, device_batch, method, eta, cond_y=None, uncond_y=None,
-                    fuse_cfg=False):
+                    fuse_cfg=False, device_sampler=False):
         p = SdImgGenParams()
         lib().sd_img_gen_params_init(C.byref(p))
         keep = []
@@ -565,11 +565,13 @@ class Engine:
         p.batch_count = batch
         p.device_batch = device_batch
         p.fuse_cfg_pair = fuse_cfg
+        p.device_sampler = device_sampler
         return p, keep
 
     def sample_latents(self, cond, uncond=None, width=512, height=512, steps=20, cfg=7.0, seed=42, batch=1, device_batch=0,
-                       method=EULER_A, eta=float("inf"), cond_y=None, uncond_y=None, fuse_cfg=False) -> np.ndarray:
-        p, keep = self._gen_params(cond, uncond, width, height, steps, cfg, seed, batch, device_batch, method, eta, cond_y, uncond_y, fuse_cfg)
+                       method=EULER_A, eta=float("inf"), cond_y=None, uncond_y=None, fuse_cfg=False, device_sampler=False) -> np.ndarray:
+        p, keep = self._gen_params(cond, uncond, width, height, steps, cfg, seed, batch, device_batch, method, eta, cond_y, uncond_y, fuse_cfg,
+                                   device_sampler)
         ch = 16 if self.model in (SD35_LARGE, SD35_TINY, FLUX_DEV, FLUX_TINY) else 4
         out = np.empty((batch, ch, height // 8, width // 8), dtype=np.float32)
         if not lib().sd_sample_latents(self._ctx, C.byref(p), _fptr(out)):
@@ -577,9 +579,10 @@ class Engine:
         return out
 
     def generate_image(self, cond, uncond=None, width=512, height=512, steps=20, cfg=7.0, seed=42, batch=1, device_batch=0,
-                       method=EULER_A, eta=float("inf"), cond_y=None, uncond_y=None, fuse_cfg=False) -> np.ndarray:
+                       method=EULER_A, eta=float("inf"), cond_y=None, uncond_y=None, fuse_cfg=False, device_sampler=False) -> np.ndarray:
         """-> uint8 [batch, H, W, 3]"""
-        p, keep = self._gen_params(cond, uncond, width, height, steps, cfg, seed, batch, device_batch, method, eta, cond_y, uncond_y, fuse_cfg)
+        p, keep = self._gen_params(cond, uncond, width, height, steps, cfg, seed, batch, device_batch, method, eta, cond_y, uncond_y, fuse_cfg,
+                                   device_sampler)
         imgs = C.POINTER(SdImage)()
         n = C.c_int()
         if not lib().generate_image(self._ctx, C.byref(p), C.byref(imgs), C.byref(n)):

@@ -136,6 +136,8 @@ struct Runner {
     }
 
     // build -> alloc -> upload inputs -> compute -> download   (ggml_extend.hpp:2767-2930)
+    // out == nullptr: nothing is downloaded and nothing waits — inputs go through set_tensor_async and the graph through
+    // graph_compute_async on the backend's stream, so the host can build the next graph while this one runs (device-resident sampler)
     template <typename BuildFn>
     bool compute(BuildFn&& build, float* out, size_t out_bytes) {
         ggml_init_params ip{0, nullptr, true};
@@ -156,19 +158,27 @@ struct Runner {
             ggml_free(cctx);
             return false;
         }
-        for (auto& in : inputs) ggml_backend_tensor_set(in.t, in.data, 0, in.nbytes);
-        const enum ggml_status st = ggml_backend_graph_compute(backend, gf);
+        const bool async = out == nullptr;
+        for (auto& in : inputs) {
+            if (async)
+                ggml_backend_tensor_set_async(backend, in.t, in.data, 0, in.nbytes);
+            else
+                ggml_backend_tensor_set(in.t, in.data, 0, in.nbytes);
+        }
+        const enum ggml_status st = async ? ggml_backend_graph_compute_async(backend, gf) : ggml_backend_graph_compute(backend, gf);
         if (st != GGML_STATUS_SUCCESS) {
             set_error(std::string("graph compute failed: ") + ggml_status_to_string(st));
             ggml_free(cctx);
             return false;
         }
-        if (ggml_nbytes(res) != out_bytes) {
-            set_error("output size mismatch");
-            ggml_free(cctx);
-            return false;
+        if (!async) {
+            if (ggml_nbytes(res) != out_bytes) {
+                set_error("output size mismatch");
+                ggml_free(cctx);
+                return false;
+            }
+            ggml_backend_tensor_get(res, out, 0, out_bytes);
         }
-        ggml_backend_tensor_get(res, out, 0, out_bytes);
         last_nodes = gf->n_nodes;
         ++calls;
         ggml_free(cctx);
@@ -214,6 +224,18 @@ struct sd_ctx_t {
         Runner* runner(int which) { return which == 0 ? &l_runner : (which == 1 ? &g_runner : &t5_runner); }
     };
     std::unique_ptr<TextEncoders> te;
+    // device-resident sampler state: the latent batch and the current step's noise live in one persistent buffer
+    struct SamplerState {
+        ggml_context* sctx        = nullptr;
+        ggml_backend_buffer_t buf = nullptr;
+        ggml_tensor *x = nullptr, *noise = nullptr;
+        int64_t W = 0, H = 0, C = 0, N = 0;
+        ~SamplerState() {
+            if (buf) ggml_backend_buffer_free(buf);
+            if (sctx) ggml_free(sctx);
+        }
+    };
+    std::unique_ptr<SamplerState> sstate;
     std::vector<Runner*> runners() {
         std::vector<Runner*> v{&unet_runner, &vae_runner};
         if (te) {
@@ -757,48 +779,61 @@ bool sd_get_learned_condition(sd_ctx_t* ctx, const sd_token_list_t* clip_l, cons
 }
 
 // ---- one UNet forward ---------------------------------------------------------------------------
+// host-built side inputs of one model call (FLUX: guidance vector and rotary table, flux.hpp:1457-1500)
+struct ModelSideInputs {
+    std::vector<float> guidance, pe;
+};
+static bool prepare_side_inputs(sd_ctx_t* ctx, int w, int h, int n, int64_t n_tokens, bool has_y, ModelSideInputs& si) {
+    if (!ctx->is_flux) return true;
+    if (!has_y) {
+        set_error("FLUX needs the pooled text vector y");
+        return false;
+    }
+    si.guidance.assign(n, ctx->guidance);
+    si.pe = gen_flux_pe(h, w, ctx->flux.cfg.patch_size, (int)n_tokens, ctx->flux.cfg.axes_dim, (float)ctx->flux.cfg.theta);
+    return true;
+}
+// the denoiser network on an existing latent tensor tx [w,h,c,n]: declares the remaining graph inputs and calls the family's forward
+static ggml_tensor* build_model_call(sd_ctx_t* ctx, GraphCtx& g, std::vector<HostInput>& in, ggml_tensor* tx, int n, const float* timesteps, const float* context,
+                                     int64_t ctx_dim, int64_t n_tokens, int64_t ctx_n, const float* y, int64_t y_dim, int64_t y_n, const ModelSideInputs& si) {
+    g.flash_attn    = ctx->params.diffusion_flash_attn;
+    g.conv_direct   = ctx->params.diffusion_conv_direct;
+    ggml_tensor* tt = ggml_new_tensor_1d(g.ctx, GGML_TYPE_F32, n);
+    ggml_set_input(tt);
+    in.push_back({tt, timesteps, ggml_nbytes(tt)});
+    ggml_tensor* tc = ggml_new_tensor_3d(g.ctx, GGML_TYPE_F32, ctx_dim, n_tokens, ctx_n);
+    ggml_set_input(tc);
+    in.push_back({tc, context, ggml_nbytes(tc)});
+    ggml_tensor* ty = nullptr;
+    if (y != nullptr) {
+        ty = ggml_new_tensor_2d(g.ctx, GGML_TYPE_F32, y_dim, y_n);
+        ggml_set_input(ty);
+        in.push_back({ty, y, ggml_nbytes(ty)});
+    }
+    if (ctx->is_flux) {
+        // guidance [N] and the rotary table are host-built inputs of every call (flux.hpp:1457-1500: pe_vec generated on the CPU and uploaded)
+        ggml_tensor* tg = ggml_new_tensor_1d(g.ctx, GGML_TYPE_F32, n);
+        ggml_set_input(tg);
+        in.push_back({tg, si.guidance.data(), ggml_nbytes(tg)});
+        const FluxConfig& fc = ctx->flux.cfg;
+        ggml_tensor* tp      = ggml_new_tensor_4d(g.ctx, GGML_TYPE_F32, 2, 2, fc.hidden_size / fc.num_heads / 2, (int64_t)si.pe.size() / (2 * (fc.hidden_size / fc.num_heads)));
+        ggml_set_input(tp);
+        in.push_back({tp, si.pe.data(), ggml_nbytes(tp)});
+        return ctx->flux.forward(g, tx, tt, tc, ty, tg, tp);
+    }
+    return ctx->is_dit ? ctx->mmdit.forward(g, tx, tt, tc, ty) : ctx->unet.forward(g, tx, tt, tc, ty);
+}
+
 bool sd_unet_forward(sd_ctx_t* ctx, const float* x, int w, int h, int c, int n, const float* timesteps, const float* context,
                      int64_t ctx_dim, int64_t n_tokens, int64_t ctx_n, const float* y, int64_t y_dim, int64_t y_n, float* out) {
     Runner& r = ctx->unet_runner;
-    std::vector<float> guidance_vec, pe_vec;
-    if (ctx->is_flux) {
-        if (y == nullptr) {
-            set_error("FLUX needs the pooled text vector y");
-            return false;
-        }
-        guidance_vec.assign(n, ctx->guidance);
-        pe_vec = gen_flux_pe(h, w, ctx->flux.cfg.patch_size, (int)n_tokens, ctx->flux.cfg.axes_dim, (float)ctx->flux.cfg.theta);
-    }
+    ModelSideInputs si;
+    if (!prepare_side_inputs(ctx, w, h, n, n_tokens, y != nullptr, si)) return false;
     auto build = [&](GraphCtx& g, std::vector<HostInput>& in) {
-        g.flash_attn   = ctx->params.diffusion_flash_attn;
-        g.conv_direct  = ctx->params.diffusion_conv_direct;
         ggml_tensor* tx = ggml_new_tensor_4d(g.ctx, GGML_TYPE_F32, w, h, c, n);
         ggml_set_input(tx);
         in.push_back({tx, x, ggml_nbytes(tx)});
-        ggml_tensor* tt = ggml_new_tensor_1d(g.ctx, GGML_TYPE_F32, n);
-        ggml_set_input(tt);
-        in.push_back({tt, timesteps, ggml_nbytes(tt)});
-        ggml_tensor* tc = ggml_new_tensor_3d(g.ctx, GGML_TYPE_F32, ctx_dim, n_tokens, ctx_n);
-        ggml_set_input(tc);
-        in.push_back({tc, context, ggml_nbytes(tc)});
-        ggml_tensor* ty = nullptr;
-        if (y != nullptr) {
-            ty = ggml_new_tensor_2d(g.ctx, GGML_TYPE_F32, y_dim, y_n);
-            ggml_set_input(ty);
-            in.push_back({ty, y, ggml_nbytes(ty)});
-        }
-        if (ctx->is_flux) {
-            // guidance [N] and the rotary table are host-built inputs of every call (flux.hpp:1457-1500: pe_vec generated on the CPU and uploaded)
-            ggml_tensor* tg = ggml_new_tensor_1d(g.ctx, GGML_TYPE_F32, n);
-            ggml_set_input(tg);
-            in.push_back({tg, guidance_vec.data(), ggml_nbytes(tg)});
-            const FluxConfig& fc = ctx->flux.cfg;
-            ggml_tensor* tp      = ggml_new_tensor_4d(g.ctx, GGML_TYPE_F32, 2, 2, fc.hidden_size / fc.num_heads / 2, (int64_t)pe_vec.size() / (2 * (fc.hidden_size / fc.num_heads)));
-            ggml_set_input(tp);
-            in.push_back({tp, pe_vec.data(), ggml_nbytes(tp)});
-            return ctx->flux.forward(g, tx, tt, tc, ty, tg, tp);
-        }
-        return ctx->is_dit ? ctx->mmdit.forward(g, tx, tt, tc, ty) : ctx->unet.forward(g, tx, tt, tc, ty);
+        return build_model_call(ctx, g, in, tx, n, timesteps, context, ctx_dim, n_tokens, ctx_n, y, y_dim, y_n, si);
     };
     const bool ok = r.compute(build, out, (size_t)w * h * ctx->out_channels() * n * sizeof(float));
     ctx->stats.unet_calls  = r.calls;
@@ -933,6 +968,156 @@ static bool sample_group(sd_ctx_t* ctx, const sd_img_gen_params_t* p, int b0, in
     return true;
 }
 
+// ---- device-resident sampler -----------------------------------------------------------------------
+// The reference crosses the host boundary three times per model call (x*c_in up, eps down, CFG / Euler on the host:
+// stable-diffusion.cpp:2636-2664, 2855-2896; denoiser.hpp:1513-1546).  Here one graph per step carries the whole iteration —
+//   x*c_in -> (cond, uncond interleaved) model call -> uncond + s*(cond - uncond) -> *c_out + x*c_skip -> Euler(-A) update (+ noise*sigma_up)
+//   -> CPY back into the persistent latent tensor
+// — on nodes the backend already runs (MUL / SUB / ADD / DIV with a 1-element broadcast operand, REPEAT, CPY), and every step's
+// scalars arrive as ONE 8-float input, so all steps share one cached plan.  Nothing is read back until the last step: uploads and
+// graphs are queued on the backend stream (set_tensor_async / graph_compute_async) and the host builds step k+1 while step k runs.
+// Ancestral noise stays the host Philox stream (bit-reproducible, rng_philox.hpp:101-122), uploaded per step (64 KB per SD1.5 image).
+static bool sample_group_device(sd_ctx_t* ctx, const sd_img_gen_params_t* p, int b0, int nb, float* out, bool* handled) {
+    *handled = false;
+    const int W = p->width / 8, H = p->height / 8, C = ctx->in_channels();
+    const sd_sample_params_t& sp = p->sample_params;
+    const bool use_cfg = sp.txt_cfg != 1.0f && p->uncond.c_crossattn != nullptr;
+    const bool has_y   = p->cond.c_vector != nullptr;
+    if (use_cfg && (p->cond.ctx_dim != p->uncond.ctx_dim || p->cond.n_tokens != p->uncond.n_tokens || has_y != (p->uncond.c_vector != nullptr))) return true;
+    if (ctx->out_channels() != C) return true;  // learned-sigma heads are not sampled this way
+    *handled = true;
+    const size_t per = (size_t)W * H * C;
+    float eta        = sp.eta;
+    if (eta == INFINITY) eta = sp.sample_method == EULER_A_SAMPLE_METHOD ? 1.0f : 0.0f;
+    const std::vector<float> sigmas = ctx->get_sigmas(sp.sample_steps, W * H);
+    const int steps                 = (int)sigmas.size() - 1;
+    const bool euler_a              = sp.sample_method == EULER_A_SAMPLE_METHOD;
+
+    if (!ctx->sstate || ctx->sstate->W != W || ctx->sstate->H != H || ctx->sstate->C != C || ctx->sstate->N != nb) {
+        ctx->sstate.reset(new sd_ctx_t::SamplerState());
+        auto& st = *ctx->sstate;
+        ggml_init_params ip{0, nullptr, true};
+        st.sctx  = ggml_init(ip);
+        st.x     = ggml_new_tensor_4d(st.sctx, GGML_TYPE_F32, W, H, C, nb);
+        st.noise = ggml_new_tensor_4d(st.sctx, GGML_TYPE_F32, W, H, C, nb);
+        ggml_set_name(st.x, "sampler.x");
+        ggml_set_name(st.noise, "sampler.noise");
+        st.buf = ggml_backend_alloc_ctx_tensors(st.sctx, ctx->backend);
+        if (!st.buf) {
+            ctx->sstate.reset();
+            set_error("sampler state allocation failed");
+            return false;
+        }
+        st.W = W, st.H = H, st.C = C, st.N = nb;
+    }
+    auto& st = *ctx->sstate;
+
+    std::vector<PhiloxRNG> rngs;
+    std::vector<float> x(per * nb), noise(per * nb, 0.f);
+    for (int b = 0; b < nb; ++b) {
+        rngs.emplace_back((uint64_t)(p->seed + b0 + b));
+        std::vector<float> nz = rngs[b].randn((uint32_t)per);
+        for (size_t i = 0; i < per; ++i) x[b * per + i] = 0.0f + nz[i] * sigmas[0];
+    }
+    ggml_backend_tensor_set_async(ctx->backend, st.x, x.data(), 0, x.size() * sizeof(float));
+    ggml_backend_tensor_set_async(ctx->backend, st.noise, noise.data(), 0, noise.size() * sizeof(float));
+
+    // conditioning of the (cond, uncond) pair, tiled over the images by the model graph's own ggml_repeat
+    const int n_model = use_cfg ? 2 * nb : nb;
+    const int ctx_n   = use_cfg ? 2 : 1;
+    const size_t cn   = (size_t)p->cond.ctx_dim * p->cond.n_tokens;
+    std::vector<float> c2(cn * ctx_n), y2;
+    memcpy(&c2[0], p->cond.c_crossattn, cn * sizeof(float));
+    if (use_cfg) memcpy(&c2[cn], p->uncond.c_crossattn, cn * sizeof(float));
+    if (has_y) {
+        y2.resize((size_t)p->cond.vector_dim * ctx_n);
+        memcpy(&y2[0], p->cond.c_vector, p->cond.vector_dim * sizeof(float));
+        if (use_cfg) memcpy(&y2[p->cond.vector_dim], p->uncond.c_vector, p->cond.vector_dim * sizeof(float));
+    }
+    ModelSideInputs si;
+    if (!prepare_side_inputs(ctx, W, H, n_model, p->cond.n_tokens, has_y, si)) return false;
+    std::vector<float> ts(n_model);
+    Runner& r = ctx->unet_runner;
+
+    for (int i = 0; i < steps; ++i) {
+        const float sigma = sigmas[i], sigma_to = sigmas[i + 1];
+        float c_skip, c_out, c_in;
+        ctx->scalings(sigma, c_skip, c_out, c_in);
+        std::fill(ts.begin(), ts.end(), ctx->sigma_to_t(sigma));
+        // scalars of this step: {c_in, cfg scale, c_out, c_skip, a, b, noise gain, 0}; Euler-A: x' = a*x + b*denoised + gain*noise;
+        // Euler: x' = x + ((x - denoised) / a) * b with a = sigma, b = sigma_to - sigma
+        float sc[8] = {c_in, sp.txt_cfg, c_out, c_skip, 0.f, 0.f, 0.f, 0.f};
+        bool fresh_noise = false;
+        if (euler_a) {
+            if (sigma_to == 0.f) {
+                sc[4] = 0.f, sc[5] = 1.f;
+            } else if (eta == 0.f) {
+                const float ratio = sigma_to / sigma;
+                sc[4] = ratio, sc[5] = (float)(1.0 - ratio);
+            } else {
+                float sigma_down, sigma_up;
+                ancestral_step(sigma, sigma_to, eta, sigma_down, sigma_up);
+                const float ratio = sigma_down / sigma;
+                sc[4] = ratio, sc[5] = 1.0f - ratio;
+                if (sigma_up > 0.f) {
+                    sc[6]       = sigma_up;
+                    fresh_noise = true;
+                }
+            }
+        } else {
+            sc[4] = sigma, sc[5] = sigma_to - sigma;
+        }
+        if (fresh_noise) {
+            for (int b = 0; b < nb; ++b) {
+                std::vector<float> nz = rngs[b].randn((uint32_t)per);
+                memcpy(&noise[b * per], nz.data(), per * sizeof(float));
+            }
+            ggml_backend_tensor_set_async(ctx->backend, st.noise, noise.data(), 0, noise.size() * sizeof(float));
+        }
+        auto build = [&](GraphCtx& g, std::vector<HostInput>& in) {
+            ggml_context* c  = g.ctx;
+            ggml_tensor* tsc = ggml_new_tensor_1d(c, GGML_TYPE_F32, 8);
+            ggml_set_input(tsc);
+            in.push_back({tsc, sc, sizeof(sc)});
+            auto S = [&](int k) { return ggml_view_1d(c, tsc, 1, (size_t)k * sizeof(float)); };
+            ggml_tensor* xs     = st.x;
+            ggml_tensor* noised = ggml_mul(c, xs, S(0));
+            ggml_tensor* xin    = noised;
+            if (use_cfg) {  // every image twice, (cond, uncond) adjacent: [per, 1, nb] -> [per, 2, nb]
+                ggml_tensor* flat = ggml_reshape_3d(c, noised, (int64_t)per, 1, nb);
+                ggml_tensor* rep  = ggml_repeat(c, flat, ggml_new_tensor_3d(c, GGML_TYPE_F32, (int64_t)per, 2, nb));
+                xin               = ggml_reshape_4d(c, rep, W, H, C, 2 * nb);
+            }
+            ggml_tensor* eps = build_model_call(ctx, g, in, xin, n_model, ts.data(), c2.data(), p->cond.ctx_dim, p->cond.n_tokens, ctx_n,
+                                                has_y ? y2.data() : nullptr, p->cond.vector_dim, ctx_n, si);
+            ggml_tensor* guided = eps;
+            if (use_cfg) {  // uncond + s*(cond - uncond), guidance.cpp:171
+                ggml_tensor* e3 = ggml_reshape_3d(c, ggml_cont(c, eps), (int64_t)per, 2, nb);
+                ggml_tensor* ec = ggml_view_3d(c, e3, (int64_t)per, 1, nb, e3->nb[1], e3->nb[2], 0);
+                ggml_tensor* eu = ggml_view_3d(c, e3, (int64_t)per, 1, nb, e3->nb[1], e3->nb[2], e3->nb[1]);
+                ggml_tensor* d  = ggml_mul(c, ggml_sub(c, ec, eu), S(1));
+                guided          = ggml_reshape_4d(c, ggml_add(c, eu, d), W, H, C, nb);
+            }
+            ggml_tensor* den = ggml_add(c, ggml_mul(c, guided, S(2)), ggml_mul(c, xs, S(3)));  // stable-diffusion.cpp:2876
+            ggml_tensor* xn;
+            if (euler_a) {  // denoiser.hpp:1513-1546
+                xn = ggml_add(c, ggml_mul(c, xs, S(4)), ggml_mul(c, den, S(5)));
+                xn = ggml_add(c, xn, ggml_mul(c, st.noise, S(6)));
+            } else {  // denoiser.hpp:1582-1597
+                ggml_tensor* d = ggml_div(c, ggml_sub(c, xs, den), S(4));
+                xn             = ggml_add(c, xs, ggml_mul(c, d, S(5)));
+            }
+            return ggml_cpy(c, xn, xs);
+        };
+        if (!r.compute(build, nullptr, 0)) return false;
+    }
+    ggml_backend_tensor_get(st.x, out, 0, per * nb * sizeof(float));  // synchronises the stream
+    ctx->stats.unet_calls  = r.calls;
+    ctx->stats.graph_nodes = r.last_nodes;
+    if (r.galloc) ctx->stats.compute_buffer_bytes = ggml_gallocr_get_buffer_size(r.galloc, 0);
+    return true;
+}
+
 bool sd_sample_latents(sd_ctx_t* ctx, const sd_img_gen_params_t* p, float* out_latents) {
     const int W = p->width / 8, H = p->height / 8, C = ctx->in_channels();
     const size_t per = (size_t)W * H * C;
@@ -940,6 +1125,11 @@ bool sd_sample_latents(sd_ctx_t* ctx, const sd_img_gen_params_t* p, float* out_l
     const double t0  = now_ms();
     for (int b0 = 0; b0 < p->batch_count; b0 += group) {
         const int nb = std::min(group, p->batch_count - b0);
+        if (p->device_sampler) {
+            bool handled = false;
+            if (!sample_group_device(ctx, p, b0, nb, out_latents + b0 * per, &handled)) return false;
+            if (handled) continue;  // otherwise (cond / uncond shapes differ): the host loop below
+        }
         if (!sample_group(ctx, p, b0, nb, out_latents + b0 * per)) return false;
     }
     ctx->stats.last_sample_ms = now_ms() - t0;

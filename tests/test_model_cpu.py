@@ -308,3 +308,50 @@ def test_flux_never_quantised_tensors(sd, oracle):
         assert e.tensor_info(P + n)[1] == sd.Q4_0, n
     for n in ("img_in.bias", "double_blocks.0.img_attn.norm.query_norm.scale", "single_blocks.1.linear2.bias"):
         assert e.tensor_info(P + n)[1] == sd.F32, n
+
+
+# ---- device-resident sampler ----------------------------------------------------------------------------
+@pytest.mark.parametrize("name,method,cfg", [("SD15_TINY", "EULER_A", 7.0), ("SDXL_TINY", "EULER_A", 5.0), ("SD35_TINY", "EULER", 4.5), ("FLUX_TINY", "EULER", 1.0)])
+def test_device_resident_sampler_is_bit_identical_to_host_loop(sd, oracle, name, method, cfg):
+    """One graph per step (x*c_in -> model pair -> CFG -> Euler(-A) -> CPY into the persistent latent tensor) performs the same f32
+    operations in the same order as the host loop, so on the oracle backend the trajectories must be bit-identical."""
+    e = sd.Engine(model=getattr(sd, name), backend=oracle)
+    rng = np.random.default_rng(50)
+    dit = name in ("SD35_TINY", "FLUX_TINY")
+    cond = rng.standard_normal((1, 40 if dit else 77, 96 if dit else 64)).astype(np.float32)
+    uncond = rng.standard_normal(cond.shape).astype(np.float32)
+    ydim = {"SDXL_TINY": 96, "SD35_TINY": 64, "FLUX_TINY": 64}.get(name)
+    cy, uy = ((rng.standard_normal((1, ydim)).astype(np.float32) for _ in range(2)) if ydim else (None, None))
+    kw = dict(width=128, height=128, steps=5, cfg=cfg, seed=11, batch=3, device_batch=3, fuse_cfg=True, method=getattr(sd, method), cond_y=cy, uncond_y=uy)
+    host = e.sample_latents(cond, uncond, **kw)
+    calls0 = e.stats()["unet_calls"]
+    dev = e.sample_latents(cond, uncond, device_sampler=True, **kw)
+    assert e.stats()["unet_calls"] - calls0 == 5           # one graph per step, cond + uncond inside it
+    np.testing.assert_array_equal(dev, host)
+    # a second batch shape re-creates the state tensors; device groups smaller than the batch iterate
+    kw2 = dict(kw, batch=3, device_batch=2)
+    np.testing.assert_array_equal(e.sample_latents(cond, uncond, device_sampler=True, **kw2), e.sample_latents(cond, uncond, **kw2))
+
+
+def test_device_resident_sampler_variants(sd, oracle):
+    e = sd.Engine(model=sd.SD15_TINY, backend=oracle)
+    rng = np.random.default_rng(51)
+    cond = rng.standard_normal((1, 77, 64)).astype(np.float32)
+    uncond = rng.standard_normal((1, 77, 64)).astype(np.float32)
+    base = dict(width=64, height=64, steps=4, seed=2, batch=1)
+    # cfg 1: a single model call per step, no uncond branch
+    a = e.sample_latents(cond, None, cfg=1.0, **base)
+    np.testing.assert_array_equal(e.sample_latents(cond, None, cfg=1.0, device_sampler=True, **base), a)
+    # plain Euler on the eps-prediction denoiser; eta = 0 Euler-A (deterministic branch, one double-precision product on the host: 1 ulp)
+    b = e.sample_latents(cond, uncond, cfg=6.0, method=sd.EULER, fuse_cfg=True, **base)
+    np.testing.assert_array_equal(e.sample_latents(cond, uncond, cfg=6.0, method=sd.EULER, fuse_cfg=True, device_sampler=True, **base), b)
+    c = e.sample_latents(cond, uncond, cfg=6.0, eta=0.0, fuse_cfg=True, **base)
+    np.testing.assert_allclose(e.sample_latents(cond, uncond, cfg=6.0, eta=0.0, fuse_cfg=True, device_sampler=True, **base), c, rtol=1e-6, atol=1e-6)
+    # cond / uncond of different length cannot share one graph: the call falls back to the host loop and still answers
+    short = rng.standard_normal((1, 40, 64)).astype(np.float32)
+    d = e.sample_latents(cond, short, cfg=6.0, **base)
+    np.testing.assert_array_equal(e.sample_latents(cond, short, cfg=6.0, device_sampler=True, **base), d)
+    # through generate_image (sampler + VAE decode)
+    img_h = e.generate_image(cond, uncond, width=64, height=64, steps=3, cfg=6.0, seed=4, fuse_cfg=True)
+    img_d = e.generate_image(cond, uncond, width=64, height=64, steps=3, cfg=6.0, seed=4, fuse_cfg=True, device_sampler=True)
+    np.testing.assert_array_equal(img_d, img_h)
