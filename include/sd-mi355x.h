@@ -178,6 +178,9 @@ typedef struct {
     int64_t graph_nodes;    /* nodes in the last UNet graph */
     size_t compute_buffer_bytes;
     size_t weight_bytes;
+    /* cumulative HOST time of the denoiser runner since context creation (ms): graph construction, gallocr allocation, and
+     * uploads + graph_compute (which contains the device time on the synchronous path, only the enqueue cost on the device-resident path) */
+    double host_build_ms, host_alloc_ms, host_submit_ms;
 } sd_stats_t;
 SD_API void sd_get_stats(sd_ctx_t* ctx, sd_stats_t* out);
 /* ---- text encoders + conditioner --------------------------------------------------------

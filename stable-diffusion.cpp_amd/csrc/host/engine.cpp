@@ -97,6 +97,7 @@ struct Runner {
     size_t graph_size             = 102400;  // UNET_GRAPH_SIZE (unet.hpp:14)
     int64_t calls                 = 0;
     int64_t last_nodes            = 0;
+    double build_ms = 0, alloc_ms = 0, submit_ms = 0;  // cumulative host time: graph construction, gallocr, uploads + graph_compute call
 
     ~Runner() {
         if (galloc) ggml_gallocr_free(galloc);
@@ -147,12 +148,17 @@ struct Runner {
         GraphCtx g;
         g.ctx            = cctx;
         g.backend        = backend;
+        const double t_b = now_ms();
         ggml_tensor* res = build(g, inputs);
         ggml_set_name(res, "ggml_runner_final_result_tensor");  // ggml_extend.hpp:2048-2051
         ggml_set_output(res);
         ggml_build_forward_expand(gf, res);
+        const double t_a = now_ms();
+        build_ms += t_a - t_b;
         if (!galloc) galloc = ggml_gallocr_new(ggml_backend_get_default_buffer_type(backend));
         bool ok = ggml_gallocr_alloc_graph(galloc, gf);
+        const double t_s = now_ms();
+        alloc_ms += t_s - t_a;
         if (!ok) {
             set_error("compute buffer allocation failed");
             ggml_free(cctx);
@@ -171,6 +177,7 @@ struct Runner {
             ggml_free(cctx);
             return false;
         }
+        submit_ms += now_ms() - t_s;  // synchronous path: includes the device time of the graph
         if (!async) {
             if (ggml_nbytes(res) != out_bytes) {
                 set_error("output size mismatch");
@@ -1220,6 +1227,11 @@ float sd_sigma_to_t(float sigma) {
     static CompVisDenoiser d;
     return d.sigma_to_t(sigma);
 }
-void sd_get_stats(sd_ctx_t* ctx, sd_stats_t* out) { *out = ctx->stats; }
+void sd_get_stats(sd_ctx_t* ctx, sd_stats_t* out) {
+    ctx->stats.host_build_ms  = ctx->unet_runner.build_ms;
+    ctx->stats.host_alloc_ms  = ctx->unet_runner.alloc_ms;
+    ctx->stats.host_submit_ms = ctx->unet_runner.submit_ms;
+    *out                      = ctx->stats;
+}
 
 }  // extern "C"
