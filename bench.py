@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--e2e", action="store_true", help="also time one full image (20 steps + VAE decode) per GPU batch")
+    ap.add_argument("--backend-opt", action="append", default=[], metavar="KEY=INT",
+                    help="planner / kernel option for A/B measurements, e.g. gemm16_sched=1 (ggml_backend_mi355x_set_option)")
     ap.add_argument("--device-sampler", action="store_true",
                     help="time the K steps as ONE device-resident Euler-A trajectory (SURVEY.md section 8 f4: latents stay in HBM, one graph per "
                          "step queued without host synchronisation) instead of K host-driven cond+uncond forwards")
@@ -91,6 +93,9 @@ def main():
     sd.backend_set_option("hip_graph", args.hip_graph)
     if args.g16_variant >= 0:
         sd.backend_set_option("gemm16_variant", args.g16_variant)
+    for kv in args.backend_opt:
+        k, v = kv.split("=")
+        sd.backend_set_option(k.strip(), int(v))
 
     rng = np.random.default_rng(1234 + rank)
     tiny = args.model == "sd15_tiny"
@@ -195,7 +200,8 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"{args.model} {'MMDiT' if dit else 'UNet'} {lat*8}x{lat*8}, {'cfg 1 (distilled guidance 3.5, one forward per step)' if flux else 'cfg 7 (cond+uncond)'}, {'q8_0 Linear + f16 conv' if args.model == 'sdxl' else ('q4_0' if flux else ('bf16' if dit else 'f16'))} weights, batch {B}/GPU, Euler-A step",
                    "global_batch": B * world, "flash_attn": not args.no_flash, "hip_graph": args.hip_graph,
-                   "cfg_pair_in_one_graph": fuse, "device_resident_sampler": bool(args.device_sampler)},
+                   "cfg_pair_in_one_graph": fuse, "device_resident_sampler": bool(args.device_sampler),
+                   **({"backend_opts": args.backend_opt} if args.backend_opt else {})},
         "roofline": roofline,
     }
     if args.e2e and rank == 0:

@@ -9,3 +9,6 @@ timeout 300 python bench.py --steps 20 --warmup 2 --no-cpu-baseline --device-sam
 timeout 300 python bench.py --steps 5 --warmup 1 --no-cpu-baseline --e2e              | tee $D/e2e_host_loop.jsonl | cut -c1-400
 timeout 300 python bench.py --steps 5 --warmup 1 --no-cpu-baseline --e2e --device-sampler | tee $D/e2e_device_sampler.jsonl | cut -c1-400
 timeout 300 python scripts/te_bench.py sd15 sdxl | tee $D/te_bench.jsonl
+#   4. explicit LDS-read / MFMA interleave in the 256-row gemm16 tiles (built blind at the end of round 1: parity first, then time)
+SDCPP_BACKEND_OPTS=gemm16_sched=3 timeout 300 python -m pytest tests/test_gpu_ops.py tests/test_gpu_model.py -m gpu -x -q 2>&1 | tail -3
+for v in 1 2 3; do timeout 300 python bench.py --steps 20 --warmup 2 --no-cpu-baseline --backend-opt gemm16_sched=$v | tee $D/bench_sched$v.jsonl | cut -c1-400; done

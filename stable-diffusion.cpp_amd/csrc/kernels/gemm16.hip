@@ -260,7 +260,9 @@ __device__ __forceinline__ void epi_conv(const float16_t (&acc)[RB][CB], const G
 }
 
 // geometry: workgroup tile BM x BN, WR x WC waves, each wave owns (BM/WR) x (BN/WC) outputs = RB x CB blocks of 32x32
-template <int BM, int BN, bool CONV, int BK, int NST, int WR, int WC>
+// SCHED = 1 (option "gemm16_sched", A/B experiment): the fragment reads of k-step 1 are interleaved with the MFMAs of k-step 0 by an
+// explicit sched_group_barrier pipeline, so the first MFMA of a tile waits for (RB + CB) LDS reads instead of for all of them.
+template <int BM, int BN, bool CONV, int BK, int NST, int WR, int WC, int SCHED = 0>
 __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm16(G16Args g) {
     constexpr int NW  = WR * WC;
     constexpr int RB  = BM / WR / 32;  // 32-row blocks per wave
@@ -448,6 +450,37 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm16(G16Args g) {
     auto compute = [&](int buf) {
         const char* sa = smem + buf * (ABYTES + BBYTES);
         const char* sb = sa + ABYTES;
+        if constexpr (SCHED == 1 && KSTEPS == 2) {
+            half8_t af[2][RB], bf[2][CB];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) af[ks][rb] = *(const half8_t*)(sa + aoff[rb] + (((ks * 2 + hi) ^ aswz) << 4));
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) bf[ks][cb] = *(const half8_t*)(sb + (((wc * CB + cb) * KSTEPS + ks) * 64 + lane) * 16);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                    for (int cb = 0; cb < CB; ++cb) {
+                        if (CONV)
+                            acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[ks][cb], af[ks][rb], acc[rb][cb], 0, 0, 0);
+                        else
+                            acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][rb], bf[ks][cb], acc[rb][cb], 0, 0, 0);
+                    }
+            // schedule: [k-step 0 reads] then {1 MFMA, 1 read} until the k-step 1 reads are issued, then the remaining MFMAs
+            constexpr int NR = RB + CB, NM = 2 * RB * CB;
+            __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, NM - NR, 0);
+            return;
+        }
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
             half8_t af[RB], bf[CB];
@@ -602,6 +635,8 @@ const char* gemm16_timing_kernel_name() { return "k_gemm16<256, *, true, 32, 3, 
 enum { G16_T128 = 0, G16_T256 = 1, G16_T256W = 2, G16_T160 = 3, G16_T160N = 4 };
 static int g_g16_force_tile = -1;  // option "gemm16_tile": force one configuration (A/B measurements); -1 = choose per shape
 void gemm16_set_tile(int t) { g_g16_force_tile = t; }
+static int g_g16_sched = 0;  // option "gemm16_sched" (experiment, default 0): explicit LDS-read / MFMA interleave — bit 0: 256-row tiles, bit 1: 128-row tiles
+void gemm16_set_sched(int v) { g_g16_sched = v; }
 
 // Per-shape choice.  Measured on SD1.5 batch 16 (profiles/r01e_tile_configs.txt): a launch takes ceil(workgroups / resident slots)
 // rounds; a full round of T128 (768 slots) and of T256 (512 slots, twice the area per workgroup) take about the same time, a T160
@@ -651,16 +686,29 @@ static void g16_launch(hipStream_t s, G16Args& g, int64_t rows, double flops) {
                 ++g_timing.used;
                 (void)hipEventRecord(e0, s);
             }
+            const bool sched = (g_g16_sched & 1) != 0;
             if (tile == G16_T160) {
                 g.ncol_tiles = (int)(g.C / 160);
-                k_gemm16<256, 160, CONV_, 32, 3, 4, 1><<<dim3((unsigned)(rt256 * g.ncol_tiles), ny), 256, 0, s>>>(g);
+                const dim3 grid((unsigned)(rt256 * g.ncol_tiles), ny);
+                if (sched)
+                    k_gemm16<256, 160, CONV_, 32, 3, 4, 1, 1><<<grid, 256, 0, s>>>(g);
+                else
+                    k_gemm16<256, 160, CONV_, 32, 3, 4, 1><<<grid, 256, 0, s>>>(g);
             } else if (tile == G16_T160N) {
                 g.ncol_tiles = (int)(g.C / 160);
-                k_gemm16<256, 160, CONV_, 32, 3, 8, 1><<<dim3((unsigned)(rt256 * g.ncol_tiles), ny), 512, 0, s>>>(g);
+                const dim3 grid((unsigned)(rt256 * g.ncol_tiles), ny);
+                if (sched)
+                    k_gemm16<256, 160, CONV_, 32, 3, 8, 1, 1><<<grid, 512, 0, s>>>(g);
+                else
+                    k_gemm16<256, 160, CONV_, 32, 3, 8, 1><<<grid, 512, 0, s>>>(g);
             } else if (tile == G16_T256W) {
                 k_gemm16<256, 128, CONV_, 32, 3, 2, 2><<<dim3((unsigned)(rt256 * g.ncol_tiles), ny), 256, 0, s>>>(g);
             } else {
-                k_gemm16<256, 128, CONV_, 32, 3, 4, 2><<<dim3((unsigned)(rt256 * g.ncol_tiles), ny), 512, 0, s>>>(g);
+                const dim3 grid((unsigned)(rt256 * g.ncol_tiles), ny);
+                if (sched)
+                    k_gemm16<256, 128, CONV_, 32, 3, 4, 2, 1><<<grid, 512, 0, s>>>(g);
+                else
+                    k_gemm16<256, 128, CONV_, 32, 3, 4, 2><<<grid, 512, 0, s>>>(g);
             }
             if (e1) (void)hipEventRecord(e1, s);
             return;
@@ -671,6 +719,8 @@ static void g16_launch(hipStream_t s, G16Args& g, int64_t rows, double flops) {
         k_gemm16<128, BN_, CONV_, 64, 2, 2, 2><<<grid, 256, 0, s>>>(g);
     else if (g_g16_variant == 2)
         k_gemm16<128, BN_, CONV_, 64, 3, 2, 2><<<grid, 256, 0, s>>>(g);
+    else if (g_g16_sched & 2)
+        k_gemm16<128, BN_, CONV_, 32, 3, 2, 2, 1><<<grid, 256, 0, s>>>(g);
     else
         k_gemm16<128, BN_, CONV_, 32, 3, 2, 2><<<grid, 256, 0, s>>>(g);
 }
