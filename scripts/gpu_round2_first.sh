@@ -6,6 +6,8 @@ D=gpurun_out/r02a
 mkdir -p $D
 timeout 300 python bench.py --steps 20 --warmup 2 --no-cpu-baseline                   | tee $D/bench_host_loop.jsonl | cut -c1-400
 timeout 300 python bench.py --steps 20 --warmup 2 --no-cpu-baseline --device-sampler  | tee $D/bench_device_sampler.jsonl | cut -c1-400
+timeout 300 python bench.py --steps 20 --warmup 2 --no-cpu-baseline --device-sampler --backend-opt pinned_uploads=1 | tee $D/bench_device_sampler_pinned.jsonl | cut -c1-400
+SDCPP_BACKEND_OPTS=pinned_uploads=1 timeout 300 python -m pytest tests/test_gpu_model.py -m gpu -x -q 2>&1 | tail -3
 timeout 300 python bench.py --steps 5 --warmup 1 --no-cpu-baseline --e2e              | tee $D/e2e_host_loop.jsonl | cut -c1-400
 timeout 300 python bench.py --steps 5 --warmup 1 --no-cpu-baseline --e2e --device-sampler | tee $D/e2e_device_sampler.jsonl | cut -c1-400
 timeout 300 python scripts/te_bench.py sd15 sdxl | tee $D/te_bench.jsonl

@@ -12,6 +12,7 @@
 // DEFAULT graph (no force_prec_f32 special case — accumulation is always f32 here).
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -128,10 +129,26 @@ static size_t buft_alloc_size(ggml_backend_buffer_type_t, const ggml_tensor* t) 
 static bool buft_is_host(ggml_backend_buffer_type_t) { return false; }
 
 // ---------------------------------------------------------------- backend (one HIP stream)
+// Pinned upload staging (option "pinned_uploads", default 0 until timed on hardware).  hipMemcpyAsync from PAGEABLE host memory is
+// host-synchronous in ROCm: the call returns only when the copy — ordered behind everything already queued on the stream — has
+// finished, so a host that uploads the next step's inputs stalls until the GPU has drained the previous graph.  With the option on,
+// set_tensor_async copies the caller's bytes into a pinned double buffer and queues the DMA from there: the call returns at once, the
+// caller may reuse its buffer, and a half is only rewritten after the event recorded behind its last DMA has completed.
+struct UploadStaging {
+    static constexpr size_t HALF = 16u << 20;
+    char* base        = nullptr;  // 2 * HALF bytes of hipHostMalloc memory
+    size_t used       = 0;        // bytes handed out in the current half
+    int cur           = 0;
+    hipEvent_t done[2] = {nullptr, nullptr};
+    bool pending[2]   = {false, false};
+};
+static std::atomic<int> g_pinned_uploads{0};
+
 struct BackendCtx {
     DeviceCtx* dev;
     hipStream_t stream;
     Planner* planner;
+    UploadStaging up;
 };
 static const char* be_get_name(ggml_backend_t b) { return ((BackendCtx*)b->context)->dev->name.c_str(); }
 static void be_free(ggml_backend_t b) {
@@ -139,6 +156,11 @@ static void be_free(ggml_backend_t b) {
     HIP_OK(hipSetDevice(c->dev->id));
     HIP_OK(hipStreamSynchronize(c->stream));
     planner_destroy(c->planner);
+    if (c->up.base) {
+        (void)hipEventDestroy(c->up.done[0]);
+        (void)hipEventDestroy(c->up.done[1]);
+        (void)hipHostFree(c->up.base);
+    }
     HIP_OK(hipStreamDestroy(c->stream));
     delete c;
     delete b;
@@ -146,6 +168,37 @@ static void be_free(ggml_backend_t b) {
 static void be_set_async(ggml_backend_t b, ggml_tensor* t, const void* d, size_t off, size_t sz) {
     BackendCtx* c = (BackendCtx*)b->context;
     HIP_OK(hipSetDevice(c->dev->id));
+    UploadStaging& u   = c->up;
+    const size_t need  = (sz + 255) & ~(size_t)255;
+    if (g_pinned_uploads.load() && sz > 0 && need <= UploadStaging::HALF) {
+        if (!u.base) {
+            if (hipHostMalloc((void**)&u.base, 2 * UploadStaging::HALF, hipHostMallocDefault) != hipSuccess) {
+                (void)hipGetLastError();
+                u.base = nullptr;
+            } else {
+                HIP_OK(hipEventCreateWithFlags(&u.done[0], hipEventDisableTiming));
+                HIP_OK(hipEventCreateWithFlags(&u.done[1], hipEventDisableTiming));
+            }
+        }
+        if (u.base) {
+            if (u.used + need > UploadStaging::HALF) {
+                // this half is full: mark the end of its DMAs and move to the other half once ITS DMAs have completed
+                HIP_OK(hipEventRecord(u.done[u.cur], c->stream));
+                u.pending[u.cur] = true;
+                u.cur ^= 1;
+                u.used = 0;
+                if (u.pending[u.cur]) {
+                    HIP_OK(hipEventSynchronize(u.done[u.cur]));
+                    u.pending[u.cur] = false;
+                }
+            }
+            char* slot = u.base + (size_t)u.cur * UploadStaging::HALF + u.used;
+            memcpy(slot, d, sz);
+            u.used += need;
+            HIP_OK(hipMemcpyAsync((char*)t->data + off, slot, sz, hipMemcpyHostToDevice, c->stream));
+            return;
+        }
+    }
     HIP_OK(hipMemcpyAsync((char*)t->data + off, d, sz, hipMemcpyHostToDevice, c->stream));
 }
 static void be_get_async(ggml_backend_t b, const ggml_tensor* t, void* d, size_t off, size_t sz) {
@@ -295,7 +348,13 @@ GGML_MI355X_API int ggml_backend_mi355x_get_device_count(void) {
     return (int)mi355x::g_devices.size();
 }
 GGML_MI355X_API void ggml_backend_mi355x_get_stats(struct ggml_backend_mi355x_stats* out) { mi355x::planner_get_stats(out); }
-GGML_MI355X_API void ggml_backend_mi355x_set_option(const char* key, int value) { mi355x::planner_set_option(key, value); }
+GGML_MI355X_API void ggml_backend_mi355x_set_option(const char* key, int value) {
+    if (strcmp(key, "pinned_uploads") == 0) {
+        mi355x::g_pinned_uploads.store(value);
+        return;
+    }
+    mi355x::planner_set_option(key, value);
+}
 GGML_MI355X_API void ggml_backend_mi355x_kernel_timing_enable(int enable) { mi355x::gemm16_timing_enable(enable != 0); }
 GGML_MI355X_API void ggml_backend_mi355x_get_kernel_timing(struct ggml_backend_mi355x_kernel_timing* out) {
     memset(out, 0, sizeof(*out));
