@@ -190,7 +190,6 @@ def test_every_unet_and_vae_name_round_trips(sd, oracle, which):
             n_vae += 1
         else:
             continue
-        assert foreign.split(".", 1)[1] != name.split(".", 2)[-1] or "post_quant" in name or "conv_in" in name or "conv_out" in name
         assert e.convert_tensor_name(foreign) == name, foreign
     assert n_unet > 300 and n_vae > 60
 
@@ -235,7 +234,7 @@ def test_foreign_dialect_checkpoint_loads_bit_identically(sd, oracle, tmp_path):
         foreign[f"cond_stage_model.model.transformer.resblocks.{i}.attn.in_proj_{leaf}"] = np.concatenate([parts["q"], parts["k"], parts["v"]], axis=0)
     save_file(native, str(tmp_path / "native.safetensors"))
     save_file(foreign, str(tmp_path / "foreign.safetensors"))
-    assert not (set(native) & set(foreign) - {n for n in native if "conv_in" in n or "conv_out" in n or "quant_conv" in n})
+    assert not set(native) & set(foreign)   # every name of the foreign file really is in another dialect
 
     rng = np.random.default_rng(0)
     x = rng.standard_normal((1, 4, 16, 16)).astype(np.float32)
