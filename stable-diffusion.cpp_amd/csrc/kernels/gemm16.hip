@@ -262,6 +262,9 @@ __device__ __forceinline__ void epi_conv(const float16_t (&acc)[RB][CB], const G
 // geometry: workgroup tile BM x BN, WR x WC waves, each wave owns (BM/WR) x (BN/WC) outputs = RB x CB blocks of 32x32
 // SCHED = 1 (option "gemm16_sched", A/B experiment): the fragment reads of k-step 1 are interleaved with the MFMAs of k-step 0 by an
 // explicit sched_group_barrier pipeline, so the first MFMA of a tile waits for (RB + CB) LDS reads instead of for all of them.
+// SCHED = 2 / 3 are TIMING ABLATIONS with wrong results (microbenchmarks only, never selected by the planner's defaults): 2 keeps the
+// LDS-DMA stream, waits and barriers but skips the fragment reads and MFMAs; 3 keeps reads + MFMAs but stages only the first two
+// K tiles — together they say which of the two pipelines bounds the loop.
 template <int BM, int BN, bool CONV, int BK, int NST, int WR, int WC, int SCHED = 0>
 __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm16(G16Args g) {
     constexpr int NW  = WR * WC;
@@ -401,6 +404,9 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm16(G16Args g) {
         }                                              \
     } while (0)
     auto stage = [&](int kt, int buf, int tap, int kh, int kw, int icb, int sub) {
+        if constexpr (SCHED == 3) {
+            if (kt >= kt0 + 2) return;
+        }
         char* sa = smem + buf * (ABYTES + BBYTES);
         char* sb = sa + ABYTES;
         if (!CONV) {
@@ -448,6 +454,7 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm16(G16Args g) {
     const int hi   = lane >> 5;
 
     auto compute = [&](int buf) {
+        if constexpr (SCHED == 2) return;
         const char* sa = smem + buf * (ABYTES + BBYTES);
         const char* sb = sa + ABYTES;
         if constexpr (SCHED == 1 && KSTEPS == 2) {
@@ -635,7 +642,8 @@ const char* gemm16_timing_kernel_name() { return "k_gemm16<256, *, true, 32, 3, 
 enum { G16_T128 = 0, G16_T256 = 1, G16_T256W = 2, G16_T160 = 3, G16_T160N = 4 };
 static int g_g16_force_tile = -1;  // option "gemm16_tile": force one configuration (A/B measurements); -1 = choose per shape
 void gemm16_set_tile(int t) { g_g16_force_tile = t; }
-static int g_g16_sched = 0;  // option "gemm16_sched" (experiment, default 0): explicit LDS-read / MFMA interleave — bit 0: 256-row tiles, bit 1: 128-row tiles
+static int g_g16_sched = 0;  // option "gemm16_sched" (experiment, default 0): explicit LDS-read / MFMA interleave — bit 0: 256-row tiles, bit 1: 128-row tiles;
+                             // 16 / 32: timing ablations of the T160 conv kernel (DMA-only / compute-only; WRONG RESULTS, scripts/gemm_ablation.sh)
 void gemm16_set_sched(int v) { g_g16_sched = v; }
 
 // Per-shape choice.  Measured on SD1.5 batch 16 (profiles/r01e_tile_configs.txt): a launch takes ceil(workgroups / resident slots)
@@ -690,7 +698,11 @@ static void g16_launch(hipStream_t s, G16Args& g, int64_t rows, double flops) {
             if (tile == G16_T160) {
                 g.ncol_tiles = (int)(g.C / 160);
                 const dim3 grid((unsigned)(rt256 * g.ncol_tiles), ny);
-                if (sched)
+                if (CONV_ && g_g16_sched == 16)
+                    k_gemm16<256, 160, CONV_, 32, 3, 4, 1, 2><<<grid, 256, 0, s>>>(g);
+                else if (CONV_ && g_g16_sched == 32)
+                    k_gemm16<256, 160, CONV_, 32, 3, 4, 1, 3><<<grid, 256, 0, s>>>(g);
+                else if (sched)
                     k_gemm16<256, 160, CONV_, 32, 3, 4, 1, 1><<<grid, 256, 0, s>>>(g);
                 else
                     k_gemm16<256, 160, CONV_, 32, 3, 4, 1><<<grid, 256, 0, s>>>(g);
