@@ -1,0 +1,198 @@
+"""Parity at BASELINE.json's FULL sizes (SD1.5 512x512, cond+uncond batch 16 per step) through properties that do not need the CPU
+oracle to finish a whole graph:
+
+  * sampled exact products — random output elements of the full-size conv / linear / attention recomputed in float64 from the same
+    f16-rounded operands the MFMA path consumes (tolerance 1e-3 relative to the output scale: f32 accumulation over K <= 11520);
+  * tile-configuration agreement — the per-shape choice (256x160 / 256x128 tiles, the kernels bench.py's roofline is quoted on)
+    against the 128x128 tile the small-shape oracle tests validate: same f16 operands, f32 accumulation, so the outputs agree to
+    f32 summation-order noise (rel-L2 <= 2e-5, an order of magnitude under the f16-operand bar of the oracle tests);
+  * determinism — the same graph twice gives the same bits;
+  * batch consistency of the whole full-width UNet — a (cond, uncond) pair in one graph equals the two single forwards.
+
+The same file runs against the oracle in the harness self-check mode (SDCPP_GPU_TESTS_ON_ORACLE=1) at reduced sizes, which is how
+the NumPy references below were validated on a machine without a GPU.  (The file name sorts last on purpose: these are the
+longest GPU tests, and `pytest -x` should reach them after the oracle-parity suites.)
+"""
+import os
+
+import numpy as np
+import pytest
+
+from ggml_graph import F16, F32, Graph
+
+pytestmark = pytest.mark.gpu
+
+ON_GPU = os.environ.get("SDCPP_GPU_TESTS_ON_ORACLE") != "1"
+T128, T256, T256W, T160, T160N = 0, 1, 2, 3, 4
+
+
+def rel_l2(a, b):
+    a = np.asarray(a, np.float64).ravel()
+    b = np.asarray(b, np.float64).ravel()
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
+def f16r(a):
+    return a.astype(np.float16).astype(np.float64)
+
+
+class tile_config:
+    """Force one gemm16 tile configuration for the duration of a block (no-op in the oracle self-check mode)."""
+
+    def __init__(self, sd, tile):
+        self.sd, self.tile = sd, tile
+
+    def __enter__(self):
+        if ON_GPU:
+            self.sd.backend_set_option("gemm16_tile", self.tile)
+
+    def __exit__(self, *a):
+        if ON_GPU:
+            self.sd.backend_set_option("gemm16_tile", -1)
+
+
+def run(dev, build):
+    with Graph(dev) as g:
+        return g.run(build(g, g.L))
+
+
+# N, IC, OC, HW, ks, stride — the UNet levels of SD1.5 at 512x512 with the cond+uncond pair of 8 images in one graph
+CONV_CASES = [
+    (16, 320, 320, 64, 3, 1),     # level 0 ResBlock conv: 512 workgroups of 256x160 — THE dominant kernel of the bench
+    (16, 640, 640, 32, 3, 1),     # level 1
+    (16, 1280, 1280, 16, 3, 1),   # level 2 (K = 11520)
+    (16, 960, 320, 64, 3, 1),     # output-block conv on a concatenated skip
+    (16, 320, 640, 64, 3, 2),     # stride-2 downsample
+    (16, 320, 320, 64, 1, 1),     # 1x1 projection
+]
+if not ON_GPU:
+    CONV_CASES = [(2, 320, 320, 16, 3, 1), (2, 64, 320, 16, 3, 2), (2, 320, 320, 16, 1, 1)]
+
+
+@pytest.mark.parametrize("N,IC,OC,HW,ks,stride", CONV_CASES)
+def test_full_size_conv(sd, gpu, N, IC, OC, HW, ks, stride):
+    rng = np.random.default_rng(100 + IC + OC + HW)
+    x = rng.standard_normal((N, IC, HW, HW)).astype(np.float32)
+    w = (rng.standard_normal((OC, IC, ks, ks)) / np.sqrt(IC * ks * ks)).astype(np.float32)
+    b = rng.standard_normal(OC).astype(np.float32)
+    pad = ks // 2
+
+    def build(g, L):
+        y = L.ggml_conv_2d(g.ctx, g.weight(w, F16), g.input(x), stride, stride, pad, pad, 1, 1)
+        return L.ggml_add_inplace(g.ctx, y, L.ggml_reshape_4d(g.ctx, g.weight(b, F32), 1, 1, OC, 1))
+
+    out = run(gpu, build)
+    O = (HW + 2 * pad - ks) // stride + 1
+    assert out.shape == (N, OC, O, O) and np.isfinite(out).all()
+    # sampled exact products on the f16-rounded operands
+    xp = np.pad(x.astype(np.float16), ((0, 0), (0, 0), (pad, pad), (pad, pad)))   # stays f16: the level-0 skip conv input is 250 MB in f32
+    w16 = f16r(w)
+    scale = float(np.abs(out).mean())
+    for _ in range(96):
+        n, oc, oh, ow = rng.integers(N), rng.integers(OC), rng.integers(O), rng.integers(O)
+        ref = float((xp[n, :, oh * stride:oh * stride + ks, ow * stride:ow * stride + ks].astype(np.float64) * w16[oc]).sum() + b[oc])
+        assert abs(out[n, oc, oh, ow] - ref) < 1e-3 * max(scale, abs(ref)), (n, oc, oh, ow, out[n, oc, oh, ow], ref)
+    # borders exercise the zero-page taps
+    for (oh, ow) in ((0, 0), (0, O - 1), (O - 1, 0), (O - 1, O - 1)):
+        ref = float((xp[0, :, oh * stride:oh * stride + ks, ow * stride:ow * stride + ks].astype(np.float64) * w16[1]).sum() + b[1])
+        assert abs(out[0, 1, oh, ow] - ref) < 1e-3 * max(scale, abs(ref))
+    np.testing.assert_array_equal(out, run(gpu, build))  # determinism
+    if ON_GPU:
+        with tile_config(sd, T128):
+            base = run(gpu, build)
+        assert rel_l2(out, base) < 2e-5
+        for tile in (T256, T160, T160N):
+            with tile_config(sd, tile):
+                assert rel_l2(run(gpu, build), base) < 2e-5, f"tile configuration {tile}"
+
+
+LINEAR_CASES = [
+    (65536, 320, 320),     # attention projections at level 0
+    (65536, 320, 2560),    # GEGLU FF1 is 320 -> 2560 (value | gate)
+    (65536, 1280, 320),    # FF2
+    (16384, 640, 5120),
+    (4096, 1280, 10240),
+    (1232, 768, 320),      # cross-attention K/V of 16 x 77 tokens
+]
+if not ON_GPU:
+    LINEAR_CASES = [(1024, 320, 320), (77, 768, 320)]
+
+
+@pytest.mark.parametrize("tokens,K,M", LINEAR_CASES)
+def test_full_size_linear(sd, gpu, tokens, K, M):
+    rng = np.random.default_rng(200 + K + M)
+    x = rng.standard_normal((tokens, K)).astype(np.float32)
+    w = (rng.standard_normal((M, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(M).astype(np.float32)
+
+    def build(g, L):
+        return L.ggml_add_inplace(g.ctx, L.ggml_mul_mat(g.ctx, g.weight(w, F16), g.input(x)), g.weight(b, F32))
+
+    out = run(gpu, build)
+    assert out.shape == (1, 1, tokens, M) and np.isfinite(out).all()
+    out = out.reshape(tokens, M)
+    rows = rng.integers(0, tokens, 48)
+    ref = f16r(x[rows]) @ f16r(w).T + b
+    assert np.abs(out[rows] - ref).max() < 1e-3 * max(1.0, float(np.abs(ref).max()))
+    ref_tail = f16r(x[-1:]) @ f16r(w).T + b   # last (possibly ragged) row tile
+    assert np.abs(out[-1:] - ref_tail).max() < 1e-3 * max(1.0, float(np.abs(ref_tail).max()))
+    np.testing.assert_array_equal(out, run(gpu, build).reshape(tokens, M))
+    if ON_GPU:
+        with tile_config(sd, T128):
+            base = run(gpu, build)
+        assert rel_l2(out, base) < 2e-5
+        for tile in (T256, T160, T160N):   # T256W is a timing experiment the per-shape choice never selects
+            with tile_config(sd, tile):
+                assert rel_l2(run(gpu, build), base) < 2e-5, f"tile configuration {tile}"
+
+
+FLASH_CASES = [(40, 4096, 4096, 16), (80, 1024, 1024, 16), (160, 256, 256, 16), (40, 4096, 77, 16)]
+if not ON_GPU:
+    FLASH_CASES = [(40, 256, 256, 2), (40, 256, 77, 2)]
+
+
+@pytest.mark.parametrize("d,Lq,Lk,HN", FLASH_CASES)
+def test_full_size_flash_attention(sd, gpu, d, Lq, Lk, HN):
+    """Self-attention at 64x64 / 32x32 / 16x16 tokens and cross-attention onto 77 text tokens: sampled query rows against the exact
+    softmax(QK^T / sqrt(d)) V on the f16-rounded K and V (tolerance 3e-3: P and Q enter the MFMA as f16)."""
+    rng = np.random.default_rng(300 + d + Lk)
+    q = rng.standard_normal((HN, Lq, d)).astype(np.float32)
+    k = rng.standard_normal((HN, Lk, d)).astype(np.float32)
+    v = rng.standard_normal((HN, Lk, d)).astype(np.float32)
+    sc = 1.0 / np.sqrt(d)
+
+    def build(g, L):
+        return L.ggml_flash_attn_ext(g.ctx, g.input(q), g.input(k, F16), g.input(v, F16), None, sc, 0.0, 0.0)
+
+    out = run(gpu, build)            # [1, Lq, HN, d]
+    assert out.shape == (1, Lq, HN, d) and np.isfinite(out).all()
+    k16, v16 = f16r(k), f16r(v)
+    for _ in range(24):
+        h, i = rng.integers(HN), rng.integers(Lq)
+        s = (k16[h] @ q[h, i].astype(np.float64)) * sc
+        p = np.exp(s - s.max())
+        ref = (p / p.sum()) @ v16[h]
+        assert np.abs(out[0, i, h] - ref).max() < 3e-3 * max(1.0, float(np.abs(ref).max())), (h, i)
+    np.testing.assert_array_equal(out, run(gpu, build))
+
+
+@pytest.mark.skipif(not ON_GPU, reason="full-width UNet: minutes per forward on the CPU oracle")
+def test_full_width_unet_pair_equals_single_forwards(sd, gpu):
+    """SD1.5 UNet at 512x512: the (cond, uncond) pair of one image in ONE graph (batch 2, context tiled by the graph) against the two
+    batch-1 forwards — different row counts select different tile configurations and split-K factors, so agreement within f16-operand
+    noise (rel-L2 <= 2e-3, as between any two summation orders of this depth) checks them against each other at full width."""
+    rng = np.random.default_rng(400)
+    e = sd.Engine(model=sd.SD15, backend=gpu, flash_attn=True)
+    x = rng.standard_normal((1, 4, 64, 64)).astype(np.float32)
+    t = np.array([500.0], np.float32)
+    cond = rng.standard_normal((1, 77, 768)).astype(np.float32)
+    uncond = rng.standard_normal((1, 77, 768)).astype(np.float32)
+    a, b = e.unet_forward(x, t, cond), e.unet_forward(x, t, uncond)
+    pair = e.unet_forward(np.repeat(x, 2, axis=0), np.repeat(t, 2), np.concatenate([cond, uncond]))
+    assert np.isfinite(pair).all()
+    assert rel_l2(pair[0], a[0]) < 2e-3 and rel_l2(pair[1], b[0]) < 2e-3
+    np.testing.assert_array_equal(pair, e.unet_forward(np.repeat(x, 2, axis=0), np.repeat(t, 2), np.concatenate([cond, uncond])))
+    # the bench configuration: 8 images x (cond, uncond) — image 0 of the batch equals the single-image pair
+    x8 = np.concatenate([np.repeat(x, 2, axis=0), rng.standard_normal((14, 4, 64, 64)).astype(np.float32)])
+    out8 = e.unet_forward(x8, np.full(16, 500.0, np.float32), np.concatenate([cond, uncond]))
+    assert rel_l2(out8[0], a[0]) < 2e-3 and rel_l2(out8[1], b[0]) < 2e-3
