@@ -1619,6 +1619,7 @@ void planner_set_option(const char* key, int value) {
     else if (!strcmp(key, "conv_tap_major")) gemm16_set_tap_major(value);
     else if (!strcmp(key, "gemm16_tile")) gemm16_set_tile(value);
     else if (!strcmp(key, "gemm16_sched")) gemm16_set_sched(value);
+    else if (!strcmp(key, "gemm16_adirect")) gemm16_set_adirect(value);
     else if (!strcmp(key, "splitk_target")) gemm16_set_splitk_target(value);
     // options change what a plan contains: drop cached plans
     std::lock_guard<std::mutex> lk(g_mu);

@@ -585,6 +585,186 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm16(G16Args g) {
     }
 }
 
+// =====================================================================================================
+// k_conv16d — EXPERIMENT (option "gemm16_adirect", default 0; written after round 1's GPU budget was spent: NOT yet run on hardware).
+// The 256x160 implicit-GEMM conv tile with the A operand (activations) loaded global -> VGPR in MFMA operand layout instead of through
+// the LDS-DMA engine.  Why: per K tile the T160 tile moves 16 KB of A + 10 KB of W through global_load_lds; if that engine (~20 B/clk/CU
+// measured) bounds the loop — scripts/gemm_ablation.py decides — taking A off it cuts its traffic 2.6x and frees 48 KB of LDS.
+// 8 waves x (32 positions x 160 channels): every wave owns its 32 output positions, so an A fragment is needed by exactly one wave and never
+// has to be shared through LDS; lane l loads the 16 bytes (position l % 32, k-slot l / 32) of each of the tile's two k-steps with one
+// global_load_dwordx4, three tiles deep in registers (the register slots rotate with the 3-stage W ring).  No nearest-x2 upsample gather.
+__global__ __launch_bounds__(512, 2) void k_conv16d(G16Args g) {
+    constexpr bool CONV = true;
+    constexpr int BM = 256, BN = 160, BK = 32, NST = 3, NW = 8, CB = BN / 32, KSTEPS = BK / 16;
+    constexpr int NF     = CB * KSTEPS;            // W fragments (1 KiB each) per stage
+    constexpr int WPW    = (NF + NW - 1) / NW;     // W fragments per wave per stage
+    constexpr int WEXTRA = NF % NW;                // only waves < WEXTRA fetch WPW fragments, the others WPW - 1
+    constexpr int BBYTES = NF * 1024;
+    constexpr int NA     = KSTEPS;                 // register loads of A per lane per stage
+    __shared__ __attribute__((aligned(1024))) char smem[NST * BBYTES];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int hi   = lane >> 5;
+    int bid = blockIdx.x;
+    {
+        const int nb = gridDim.x;
+        if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);
+    }
+    int kt0 = 0, nt = g.nt;
+    if (g.split_k > 1) {
+        kt0 = blockIdx.y * g.nt_slice;
+        nt  = min(g.nt_slice, g.nt - kt0);
+        g.dst += (int64_t)blockIdx.y * g.slab;
+    }
+    const int row_tile = bid / g.ncol_tiles, col_tile = bid - row_tile * g.ncol_tiles;
+    const int64_t row0 = (int64_t)row_tile * BM;
+    const int col0     = col_tile * BN;
+
+    // ---- this lane's output position and its tap mask (all per-position address work happens once)
+    const _Float16* abase;
+    unsigned amask = 0;
+    {
+        int64_t row   = row0 + wave * 32 + (lane & 31);
+        const bool ok = row < g.R;
+        if (!ok) row = g.R - 1;
+        const int img = (int)(row / g.OHOW);
+        const int p   = (int)(row - (int64_t)img * g.OHOW);
+        const int oh = p / g.OW, ow = p - oh * g.OW;
+        for (int t = 0; t < g.KS * g.KS; ++t) {
+            const int ih = oh * g.S + t / g.KS - g.pad, iw = ow * g.S + t % g.KS - g.pad;
+            if (ok && ih >= 0 && ih < g.H && iw >= 0 && iw < g.Wd) amask |= 1u << t;
+        }
+        abase = g.A + (((int64_t)img * g.H + (oh * g.S - g.pad)) * g.Wd + (ow * g.S - g.pad)) * g.ICp + hi * 8;
+    }
+    const _Float16* zsrc = g.zero + hi * 8;
+
+    const half8_t* wsrc[WPW];
+    int wdst[WPW];
+#pragma unroll
+    for (int q = 0; q < WPW; ++q) {
+        const int f  = q * NW + wave;
+        const int fs = f < NF ? f : NF - 1;
+        const int cb = fs / KSTEPS, ks = fs % KSTEPS;
+        wsrc[q]      = g.W + ((int64_t)(col0 / 32 + cb) * g.kfr + ks) * 64 + lane;
+        wdst[q]      = fs * 1024;
+    }
+    const bool w_short = WEXTRA != 0 && wave >= WEXTRA;
+    const int ktiles_per_icb = 64 / BK;
+
+    int c_sub = 0, c_tap = 0, c_icb = 0, c_kh = 0, c_kw = 0;
+    {
+        const int kb = kt0 / ktiles_per_icb, ntaps = g.KS * g.KS;
+        c_sub        = kt0 - kb * ktiles_per_icb;
+        if (g.tap_major) {
+            c_tap = kb / g.icb_per_tap;
+            c_icb = kb - c_tap * g.icb_per_tap;
+        } else {
+            c_icb = kb / ntaps;
+            c_tap = kb - c_icb * ntaps;
+        }
+        c_kh = c_tap / g.KS;
+        c_kw = c_tap - c_kh * g.KS;
+    }
+
+    half8_t areg[NST][KSTEPS];
+    // one stage = this lane's two A fragments (registers) + this wave's share of the W fragments (LDS-DMA), issued in that order.
+    // The A loads are inline asm: as ordinary C++ loads the compiler guarded the first use of a slot with its own s_waitcnt vmcnt(0)
+    // once per trip of the 3-tile loop, draining the prefetch of the next two tiles.  The counted waits in front of the barriers
+    // below are what guarantees a slot has landed before its MFMAs (loads retire in order).  NW_ is the compile-time number of W
+    // pieces this wave issues; the loop exists once per value so that the count in those waits is a constant.
+#define C16D_STAGE(SLOT, KT, NW_)                                                                                        \
+    do {                                                                                                                \
+        const int64_t toff_ = ((int64_t)c_kh * g.Wd + c_kw) * g.ICp + (int64_t)c_icb * 64 + c_sub * BK;                 \
+        const _Float16* p_  = ((amask >> c_tap) & 1u) ? abase + toff_ : zsrc;                                           \
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(areg[SLOT][0]) : "v"(p_) : "memory");                    \
+        asm volatile("global_load_dwordx4 %0, %1, off offset:32" : "=v"(areg[SLOT][1]) : "v"(p_) : "memory");          \
+        char* sb_           = smem + (SLOT) * BBYTES;                                                                   \
+        _Pragma("unroll") for (int q = 0; q < (NW_); ++q) GLDS16(wsrc[q] + (int64_t)(KT) * KSTEPS * 64, sb_ + wdst[q]); \
+        G16_ADVANCE();                                                                                                  \
+    } while (0)
+
+    float16_t acc[1][CB];
+#pragma unroll
+    for (int b = 0; b < CB; ++b) acc[0][b] = (float16_t){0};
+
+    // fragment reads + MFMAs of the tile in slot S: k-step 0 reads, then {1 MFMA, 1 read of k-step 1} x CB, then the k-step 1 MFMAs
+#define C16D_COMPUTE(S)                                                                                                 \
+    do {                                                                                                                \
+        const char* sbc_ = smem + (S) * BBYTES;                                                                         \
+        half8_t bf_[KSTEPS][CB];                                                                                        \
+        _Pragma("unroll") for (int ks = 0; ks < KSTEPS; ++ks)                                                           \
+            _Pragma("unroll") for (int cb = 0; cb < CB; ++cb) bf_[ks][cb] = *(const half8_t*)(sbc_ + ((cb * KSTEPS + ks) * 64 + lane) * 16); \
+        _Pragma("unroll") for (int ks = 0; ks < KSTEPS; ++ks)                                                           \
+            _Pragma("unroll") for (int cb = 0; cb < CB; ++cb)                                                           \
+                acc[0][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf_[ks][cb], areg[S][ks], acc[0][cb], 0, 0, 0);   \
+        __builtin_amdgcn_sched_group_barrier(0x100, CB, 0);                                                             \
+        _Pragma("unroll") for (int i = 0; i < CB; ++i) {                                                                \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                          \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                          \
+        }                                                                                                               \
+        __builtin_amdgcn_sched_group_barrier(0x008, CB, 0);                                                             \
+    } while (0)
+
+    // tile KT lives in slot S = KT % 3.  Loads are issued per stage as [NA register loads][W DMA pieces] and retire in order, so
+    // vmcnt(NA + pieces) retires all of tile KT (its own A fragments AND its W pieces) while tile KT+1 stays in flight.
+    // steady state: tiles KT+1 and KT+2 exist, nothing is conditional
+#define C16D_BODY_STEADY(S, KT, NW_)                                                                                    \
+    do {                                                                                                                \
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + (NW_)) : "memory");                                             \
+        __builtin_amdgcn_s_barrier();                                                                                   \
+        C16D_STAGE(((S) + 2) % 3, kt0 + (KT) + 2, NW_);                                                                 \
+        C16D_COMPUTE(S);                                                                                                \
+    } while (0)
+    // tail: the last tiles of the K range
+#define C16D_BODY_TAIL(S, KT, NW_)                                                                                      \
+    do {                                                                                                                \
+        if ((KT) + 1 >= nt)                                                                                             \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                           \
+        else                                                                                                            \
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + (NW_)) : "memory");                                         \
+        __builtin_amdgcn_s_barrier();                                                                                   \
+        if ((KT) + 2 < nt) C16D_STAGE(((S) + 2) % 3, kt0 + (KT) + 2, NW_);                                              \
+        C16D_COMPUTE(S);                                                                                                \
+    } while (0)
+#define C16D_LOOP(NW_)                                                                                                  \
+    do {                                                                                                                \
+        C16D_STAGE(0, kt0, NW_);                                                                                        \
+        if (nt > 1) C16D_STAGE(1, kt0 + 1, NW_);                                                                        \
+        int kt = 0;                                                                                                     \
+        for (; kt + 4 < nt; kt += 3) {                                                                                  \
+            C16D_BODY_STEADY(0, kt, NW_);                                                                               \
+            C16D_BODY_STEADY(1, kt + 1, NW_);                                                                           \
+            C16D_BODY_STEADY(2, kt + 2, NW_);                                                                           \
+        }                                                                                                               \
+        for (; kt < nt; kt += 3) {                                                                                      \
+            C16D_BODY_TAIL(0, kt, NW_);                                                                                 \
+            if (kt + 1 < nt) C16D_BODY_TAIL(1, kt + 1, NW_);                                                            \
+            if (kt + 2 < nt) C16D_BODY_TAIL(2, kt + 2, NW_);                                                            \
+        }                                                                                                               \
+    } while (0)
+
+    if (w_short)
+        C16D_LOOP(WPW - 1);
+    else
+        C16D_LOOP(WPW);
+#undef C16D_LOOP
+#undef C16D_BODY_TAIL
+#undef C16D_BODY_STEADY
+#undef C16D_COMPUTE
+#undef C16D_STAGE
+
+    const bool fullc = col0 + BN <= g.C;
+    if (fullc) {
+        if (g.ep.residual)
+            epi_conv<1>(acc, g, row0, col0, wave, 0, lane);
+        else
+            epi_conv<0>(acc, g, row0, col0, wave, 0, lane);
+    } else {
+        epi_conv<2>(acc, g, row0, col0, wave, 0, lane);
+    }
+}
+
 static inline int64_t rup64(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 
 // pipeline / tile variant (tunable at run time for A/B measurements):
@@ -645,6 +825,8 @@ void gemm16_set_tile(int t) { g_g16_force_tile = t; }
 static int g_g16_sched = 0;  // option "gemm16_sched" (experiment, default 0): explicit LDS-read / MFMA interleave — bit 0: 256-row tiles, bit 1: 128-row tiles;
                              // 16 / 32: timing ablations of the T160 conv kernel (DMA-only / compute-only; WRONG RESULTS, scripts/gemm_ablation.sh)
 void gemm16_set_sched(int v) { g_g16_sched = v; }
+static int g_g16_adirect = 0;  // option "gemm16_adirect" (experiment, default 0): 256x160 conv tiles run k_conv16d (A operand global -> VGPR)
+void gemm16_set_adirect(int v) { g_g16_adirect = v; }
 
 // Per-shape choice.  Measured on SD1.5 batch 16 (profiles/r01e_tile_configs.txt): a launch takes ceil(workgroups / resident slots)
 // rounds; a full round of T128 (768 slots) and of T256 (512 slots, twice the area per workgroup) take about the same time, a T160
@@ -695,7 +877,10 @@ static void g16_launch(hipStream_t s, G16Args& g, int64_t rows, double flops) {
                 (void)hipEventRecord(e0, s);
             }
             const bool sched = (g_g16_sched & 1) != 0;
-            if (tile == G16_T160) {
+            if (CONV_ && g_g16_adirect && !g.UPS && (tile == G16_T160 || tile == G16_T160N)) {
+                g.ncol_tiles = (int)(g.C / 160);
+                k_conv16d<<<dim3((unsigned)(rt256 * g.ncol_tiles), ny), 512, 0, s>>>(g);
+            } else if (tile == G16_T160) {
                 g.ncol_tiles = (int)(g.C / 160);
                 const dim3 grid((unsigned)(rt256 * g.ncol_tiles), ny);
                 if (CONV_ && g_g16_sched == 16)
