@@ -586,15 +586,15 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm16(G16Args g) {
 }
 
 // =====================================================================================================
-// k_conv16d — EXPERIMENT (option "gemm16_adirect", default 0; written after round 1's GPU budget was spent: NOT yet run on hardware).
-// The 256x160 implicit-GEMM conv tile with the A operand (activations) loaded global -> VGPR in MFMA operand layout instead of through
+// k_conv16d<CONV> — EXPERIMENT (option "gemm16_adirect", default 0; written after round 1's GPU budget was spent: NOT yet run on hardware).
+// The 256x160 tile (implicit-GEMM conv, and the same for Linear with CONV = false) with the A operand (activations) loaded global -> VGPR in MFMA operand layout instead of through
 // the LDS-DMA engine.  Why: per K tile the T160 tile moves 16 KB of A + 10 KB of W through global_load_lds; if that engine (~20 B/clk/CU
 // measured) bounds the loop — scripts/gemm_ablation.py decides — taking A off it cuts its traffic 2.6x and frees 48 KB of LDS.
 // 8 waves x (32 positions x 160 channels): every wave owns its 32 output positions, so an A fragment is needed by exactly one wave and never
 // has to be shared through LDS; lane l loads the 16 bytes (position l % 32, k-slot l / 32) of each of the tile's two k-steps with one
 // global_load_dwordx4, three tiles deep in registers (the register slots rotate with the 3-stage W ring).  No nearest-x2 upsample gather.
+template <bool CONV>
 __global__ __launch_bounds__(512, 2) void k_conv16d(G16Args g) {
-    constexpr bool CONV = true;
     constexpr int BM = 256, BN = 160, BK = 32, NST = 3, NW = 8, CB = BN / 32, KSTEPS = BK / 16;
     constexpr int NF     = CB * KSTEPS;            // W fragments (1 KiB each) per stage
     constexpr int WPW    = (NF + NW - 1) / NW;     // W fragments per wave per stage
@@ -621,23 +621,27 @@ __global__ __launch_bounds__(512, 2) void k_conv16d(G16Args g) {
     const int64_t row0 = (int64_t)row_tile * BM;
     const int col0     = col_tile * BN;
 
-    // ---- this lane's output position and its tap mask (all per-position address work happens once)
+    // ---- this lane's A row: conv = its output position and tap mask (all per-position address work happens once); linear = its token row
     const _Float16* abase;
     unsigned amask = 0;
     {
         int64_t row   = row0 + wave * 32 + (lane & 31);
         const bool ok = row < g.R;
         if (!ok) row = g.R - 1;
-        const int img = (int)(row / g.OHOW);
-        const int p   = (int)(row - (int64_t)img * g.OHOW);
-        const int oh = p / g.OW, ow = p - oh * g.OW;
-        for (int t = 0; t < g.KS * g.KS; ++t) {
-            const int ih = oh * g.S + t / g.KS - g.pad, iw = ow * g.S + t % g.KS - g.pad;
-            if (ok && ih >= 0 && ih < g.H && iw >= 0 && iw < g.Wd) amask |= 1u << t;
+        if (CONV) {
+            const int img = (int)(row / g.OHOW);
+            const int p   = (int)(row - (int64_t)img * g.OHOW);
+            const int oh = p / g.OW, ow = p - oh * g.OW;
+            for (int t = 0; t < g.KS * g.KS; ++t) {
+                const int ih = oh * g.S + t / g.KS - g.pad, iw = ow * g.S + t % g.KS - g.pad;
+                if (ok && ih >= 0 && ih < g.H && iw >= 0 && iw < g.Wd) amask |= 1u << t;
+            }
+            abase = g.A + (((int64_t)img * g.H + (oh * g.S - g.pad)) * g.Wd + (ow * g.S - g.pad)) * g.ICp + hi * 8;
+        } else {
+            abase = g.A + row * g.lda + hi * 8;  // rows past R re-read the last row; their outputs are never stored
         }
-        abase = g.A + (((int64_t)img * g.H + (oh * g.S - g.pad)) * g.Wd + (ow * g.S - g.pad)) * g.ICp + hi * 8;
     }
-    const _Float16* zsrc = g.zero + hi * 8;
+    const _Float16* zsrc = CONV ? g.zero + hi * 8 : abase;
 
     const half8_t* wsrc[WPW];
     int wdst[WPW];
@@ -653,7 +657,7 @@ __global__ __launch_bounds__(512, 2) void k_conv16d(G16Args g) {
     const int ktiles_per_icb = 64 / BK;
 
     int c_sub = 0, c_tap = 0, c_icb = 0, c_kh = 0, c_kw = 0;
-    {
+    if (CONV) {
         const int kb = kt0 / ktiles_per_icb, ntaps = g.KS * g.KS;
         c_sub        = kt0 - kb * ktiles_per_icb;
         if (g.tap_major) {
@@ -675,8 +679,8 @@ __global__ __launch_bounds__(512, 2) void k_conv16d(G16Args g) {
     // pieces this wave issues; the loop exists once per value so that the count in those waits is a constant.
 #define C16D_STAGE(SLOT, KT, NW_)                                                                                        \
     do {                                                                                                                \
-        const int64_t toff_ = ((int64_t)c_kh * g.Wd + c_kw) * g.ICp + (int64_t)c_icb * 64 + c_sub * BK;                 \
-        const _Float16* p_  = ((amask >> c_tap) & 1u) ? abase + toff_ : zsrc;                                           \
+        const int64_t toff_ = CONV ? ((int64_t)c_kh * g.Wd + c_kw) * g.ICp + (int64_t)c_icb * 64 + c_sub * BK : (int64_t)(KT) * BK; \
+        const _Float16* p_  = (!CONV || ((amask >> c_tap) & 1u)) ? abase + toff_ : zsrc;                                \
         asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(areg[SLOT][0]) : "v"(p_) : "memory");                    \
         asm volatile("global_load_dwordx4 %0, %1, off offset:32" : "=v"(areg[SLOT][1]) : "v"(p_) : "memory");          \
         char* sb_           = smem + (SLOT) * BBYTES;                                                                   \
@@ -754,6 +758,30 @@ __global__ __launch_bounds__(512, 2) void k_conv16d(G16Args g) {
 #undef C16D_COMPUTE
 #undef C16D_STAGE
 
+    if (!CONV) {  // the workgroup-uniform epilogue choice of k_gemm16
+        const bool full = row0 + BM <= g.R;
+        if (g.hm_d > 0 && g.hm_L >= 32 && !g.ep.residual && (g.dst != nullptr) != (g.dst16 != nullptr)) {
+            if (g.dst16)
+                epi_linear<EPI_HM_F16>(acc, g, row0, col0, wave, 0, lane);
+            else
+                epi_linear<EPI_HM_F32>(acc, g, row0, col0, wave, 0, lane);
+        } else if (g.ep.gate) {
+            epi_linear<EPI_F32_GATE>(acc, g, row0, col0, wave, 0, lane);
+        } else if (full && g.hm_d == 0 && g.dst && !g.dst16) {
+            if (g.ep.residual)
+                epi_linear<EPI_F32_RES>(acc, g, row0, col0, wave, 0, lane);
+            else
+                epi_linear<EPI_F32>(acc, g, row0, col0, wave, 0, lane);
+        } else if (g.hm_d == 0 && g.dst16 && !g.dst && !g.ep.residual) {
+            if (g.ep.gelu)
+                epi_linear<EPI_F16_GELU>(acc, g, row0, col0, wave, 0, lane);
+            else
+                epi_linear<EPI_F16>(acc, g, row0, col0, wave, 0, lane);
+        } else {
+            epi_linear<EPI_GENERIC>(acc, g, row0, col0, wave, 0, lane);
+        }
+        return;
+    }
     const bool fullc = col0 + BN <= g.C;
     if (fullc) {
         if (g.ep.residual)
@@ -877,9 +905,9 @@ static void g16_launch(hipStream_t s, G16Args& g, int64_t rows, double flops) {
                 (void)hipEventRecord(e0, s);
             }
             const bool sched = (g_g16_sched & 1) != 0;
-            if (CONV_ && g_g16_adirect && !g.UPS && (tile == G16_T160 || tile == G16_T160N)) {
+            if (g_g16_adirect && (!CONV_ || !g.UPS) && g.geglu_inner == 0 && (tile == G16_T160 || tile == G16_T160N)) {
                 g.ncol_tiles = (int)(g.C / 160);
-                k_conv16d<<<dim3((unsigned)(rt256 * g.ncol_tiles), ny), 512, 0, s>>>(g);
+                k_conv16d<CONV_><<<dim3((unsigned)(rt256 * g.ncol_tiles), ny), 512, 0, s>>>(g);
             } else if (tile == G16_T160) {
                 g.ncol_tiles = (int)(g.C / 160);
                 const dim3 grid((unsigned)(rt256 * g.ncol_tiles), ny);
