@@ -87,7 +87,7 @@ GGML_MI355X_API void ggml_backend_mi355x_get_kernel_timing(struct ggml_backend_m
  * "splitk_target" (384), "conv_tap_major" (0), "fuse_modulate" / "fuse_gate" / "fuse_gelu" / "fuse_rope" / "fuse_concat_heads" (1);
  * experiments that are off until timed on hardware: "gemm16_sched" (0: explicit LDS-read / MFMA interleave, bit 0 = 256-row tiles, bit 1 =
  * 128-row tiles; 16 / 32 = wrong-result timing ablations), "gemm16_adirect" (0: 256x160 conv tiles load the A operand global -> VGPR),
- * "pinned_uploads" (0: set_tensor_async stages through pinned host memory so the call does not wait for the stream) */
+ * "splitk_mid" (0: two K slices for launches of 193..384 workgroups), "pinned_uploads" (0: set_tensor_async stages through pinned host memory so the call does not wait for the stream) */
 GGML_MI355X_API void ggml_backend_mi355x_set_option(const char* key, int value);
 
 #ifdef __cplusplus

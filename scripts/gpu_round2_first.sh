@@ -20,3 +20,6 @@ python scripts/rocpd_stats.py $D/ablation_results.db $D/ablation_kernel_stats.cs
 #   6. A operand global -> VGPR for the 256x160 conv tiles (k_conv16d, built blind at the end of round 1): parity first, then time
 SDCPP_BACKEND_OPTS=gemm16_adirect=1 timeout 300 python -m pytest tests/test_gpu_ops.py tests/test_gpu_model.py tests/test_zz_gpu_fullsize.py -m gpu -x -q 2>&1 | tail -3
 timeout 300 python bench.py --steps 20 --warmup 2 --no-cpu-baseline --backend-opt gemm16_adirect=1 | tee $D/bench_adirect.jsonl | cut -c1-400
+#   7. two K slices for the 193..384-workgroup launches (16x16 UNet level)
+SDCPP_BACKEND_OPTS=splitk_mid=1 timeout 300 python -m pytest tests/test_gpu_ops.py tests/test_zz_gpu_fullsize.py -m gpu -x -q 2>&1 | tail -3
+timeout 300 python bench.py --steps 20 --warmup 2 --no-cpu-baseline --backend-opt splitk_mid=1 | tee $D/bench_splitk_mid.jsonl | cut -c1-400

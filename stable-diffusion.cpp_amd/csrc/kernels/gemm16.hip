@@ -956,11 +956,18 @@ static void g16_launch(hipStream_t s, G16Args& g, int64_t rows, double flops) {
 // unlike float atomics) and applies bias + residual.
 static int g_g16_splitk_target = 384;  // option "splitk_target": workgroups a split launch should reach
 void gemm16_set_splitk_target(int v) { g_g16_splitk_target = v; }
+static int g_g16_splitk_mid = 0;
+void gemm16_set_splitk_mid(int v) { g_g16_splitk_mid = v; }
 int gemm16_split_k(int64_t rows, int64_t M, int64_t K) {
     if (!g16_bk32()) return 1;
     const int64_t wgs = ((rows + 127) / 128) * ((M + 127) / 128);
     const int64_t nt  = rup64(K, 64) / 32;
-    if (wgs > g_g16_splitk_target / 2) return 1;
+    if (wgs > g_g16_splitk_target / 2) {
+        // option "splitk_mid" (experiment, default 0): 193..384 workgroups over 768 resident slots leave most CUs with one or two
+        // workgroups (the 16x16 UNet level: 320 tiles, K = 11520..23040 at ~520 TFLOP/s); two K slices double the workgroups in flight
+        if (g_g16_splitk_mid && wgs <= g_g16_splitk_target && nt >= 128) return 2;
+        return 1;
+    }
     int64_t S = g_g16_splitk_target / wgs;
     if (S > 8) S = 8;
     if (S > nt / 8) S = nt / 8;
