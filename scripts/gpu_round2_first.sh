@@ -17,7 +17,7 @@ for v in 1 2 3; do timeout 300 python bench.py --steps 20 --warmup 2 --no-cpu-ba
 #   5. which pipeline bounds the dominant kernel: DMA-only / compute-only ablations (wrong results by design, timing only)
 ( cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$D -o ablation -- python $GRAFT_REPO_ROOT/scripts/gemm_ablation.py > $GRAFT_REPO_ROOT/$D/ablation_wall.txt 2> $GRAFT_REPO_ROOT/$D/ablation.log )
 python scripts/rocpd_stats.py $D/ablation_results.db $D/ablation_kernel_stats.csv | grep k_gemm16 | cut -c1-160
-#   6. A operand global -> VGPR for the 256x160 conv tiles (k_conv16d, built blind at the end of round 1): parity first, then time
+#   6. A operand global -> VGPR (k_gemm16d, all tile shapes; built blind at the end of round 1): parity first, then time
 SDCPP_BACKEND_OPTS=gemm16_adirect=1 timeout 300 python -m pytest tests/test_gpu_ops.py tests/test_gpu_model.py tests/test_zz_gpu_fullsize.py -m gpu -x -q 2>&1 | tail -3
 timeout 300 python bench.py --steps 20 --warmup 2 --no-cpu-baseline --backend-opt gemm16_adirect=1 | tee $D/bench_adirect.jsonl | cut -c1-400
 #   7. two K slices for the 193..384-workgroup launches (16x16 UNet level)
