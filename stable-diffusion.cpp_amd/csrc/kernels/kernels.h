@@ -93,7 +93,7 @@ int gemm16_tap_major();
 void gemm16_set_splitk_target(int v);
 void gemm16_set_sched(int v);    // explicit LDS-read / MFMA interleave (experiment; default 0): bit 0 = 256-row tiles, bit 1 = 128-row tiles
 void gemm16_set_splitk_mid(int v);  // 1: two K slices for launches of 193..384 workgroups with >= 128 K tiles (experiment, default 0)
-void gemm16_set_adirect(int v);  // 1: 256x160 conv tiles load the A operand global -> VGPR (k_conv16d; experiment, default 0)
+void gemm16_set_adirect(int v);  // 1: tiles without upsample gather / GEGLU pairing load the A operand global -> VGPR (k_gemm16d; experiment, default 0)
 void gemm16_set_tile(int t);     // -1: per-shape choice; 0..3: force T128 / T256 / T256W / T160 (A/B measurements)
 void gemm16_set_variant(int v);  // 0: BK64x2 stages, 1: BK32x3 stages (default), 2: BK64x3 stages
 // hm_d > 0: head-major store — element (row = n*hm_L + l, col = h*hm_d + dd) goes to ((n*hm_H + h)*hm_L + l)*hm_d + dd of dst (f32) / dst16 (f16)
