@@ -181,6 +181,7 @@ typedef struct {
     /* cumulative HOST time of the denoiser runner since context creation (ms): graph construction, gallocr allocation, and
      * uploads + graph_compute (which contains the device time on the synchronous path, only the enqueue cost on the device-resident path) */
     double host_build_ms, host_alloc_ms, host_submit_ms;
+    int64_t graph_cache_hits; /* denoiser calls that replayed the cached graph (same shapes as the previous call) instead of rebuilding it */
 } sd_stats_t;
 SD_API void sd_get_stats(sd_ctx_t* ctx, sd_stats_t* out);
 /* ---- text encoders + conditioner --------------------------------------------------------

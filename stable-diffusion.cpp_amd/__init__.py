@@ -99,7 +99,8 @@ class SdImage(C.Structure):
 class SdStats(C.Structure):
     _fields_ = [("last_sample_ms", C.c_double), ("last_decode_ms", C.c_double), ("unet_calls", C.c_int64),
                 ("graph_nodes", C.c_int64), ("compute_buffer_bytes", C.c_size_t), ("weight_bytes", C.c_size_t),
-                ("host_build_ms", C.c_double), ("host_alloc_ms", C.c_double), ("host_submit_ms", C.c_double)]
+                ("host_build_ms", C.c_double), ("host_alloc_ms", C.c_double), ("host_submit_ms", C.c_double),
+                ("graph_cache_hits", C.c_int64)]
 
 
 _lib = None

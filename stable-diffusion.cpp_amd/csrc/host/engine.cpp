@@ -100,6 +100,7 @@ struct Runner {
     double build_ms = 0, alloc_ms = 0, submit_ms = 0;  // cumulative host time: graph construction, gallocr, uploads + graph_compute call
 
     ~Runner() {
+        drop_cache();
         if (galloc) ggml_gallocr_free(galloc);
         if (weights) ggml_backend_buffer_free(weights);
     }
@@ -136,36 +137,85 @@ struct Runner {
         ggml_backend_tensor_set(t, scratch.data(), 0, scratch.size());
     }
 
+    // ---- one cached graph (OUR host-side optimisation; the reference rebuilds and re-allocates per call, ggml_extend.hpp:2767-2930):
+    // consecutive calls with the same signature (shapes + flags) reuse the built graph and its gallocr placement — only the inputs are
+    // uploaded again.  Building the 2570-node SD1.5 UNet graph and placing it costs 1.5–2.3 ms of host time per step, which on the
+    // synchronous path sits between two device steps.  Any other graph allocated from this runner's gallocr invalidates the entry.
+    std::string cache_sig;
+    ggml_context* cache_ctx = nullptr;
+    ggml_cgraph* cache_gf   = nullptr;
+    ggml_tensor* cache_res  = nullptr;
+    std::vector<HostInput> cache_inputs;
+    int64_t cache_hits = 0;
+    void drop_cache() {
+        if (cache_ctx) ggml_free(cache_ctx);
+        cache_ctx = nullptr;
+        cache_gf  = nullptr;
+        cache_res = nullptr;
+        cache_inputs.clear();
+        cache_sig.clear();
+    }
+
     // build -> alloc -> upload inputs -> compute -> download   (ggml_extend.hpp:2767-2930)
     // out == nullptr: nothing is downloaded and nothing waits — inputs go through set_tensor_async and the graph through
     // graph_compute_async on the backend's stream, so the host can build the next graph while this one runs (device-resident sampler)
+    // sig / ptrs: non-empty sig enables the cached graph; ptrs are this call's host buffers in the order `build` declares its inputs
     template <typename BuildFn>
-    bool compute(BuildFn&& build, float* out, size_t out_bytes) {
-        ggml_init_params ip{0, nullptr, true};
-        ggml_context* cctx = ggml_init(ip);
-        ggml_cgraph* gf    = ggml_new_graph_custom(cctx, graph_size, false);
-        std::vector<HostInput> inputs;
-        GraphCtx g;
-        g.ctx            = cctx;
-        g.backend        = backend;
-        const double t_b = now_ms();
-        ggml_tensor* res = build(g, inputs);
-        ggml_set_name(res, "ggml_runner_final_result_tensor");  // ggml_extend.hpp:2048-2051
-        ggml_set_output(res);
-        ggml_build_forward_expand(gf, res);
-        const double t_a = now_ms();
-        build_ms += t_a - t_b;
-        if (!galloc) galloc = ggml_gallocr_new(ggml_backend_get_default_buffer_type(backend));
-        bool ok = ggml_gallocr_alloc_graph(galloc, gf);
-        const double t_s = now_ms();
-        alloc_ms += t_s - t_a;
-        if (!ok) {
-            set_error("compute buffer allocation failed");
-            ggml_free(cctx);
-            return false;
+    bool compute(BuildFn&& build, float* out, size_t out_bytes, const std::string& sig = std::string(), const std::vector<const void*>& ptrs = {}) {
+        ggml_context* cctx = nullptr;
+        ggml_cgraph* gf    = nullptr;
+        ggml_tensor* res   = nullptr;
+        std::vector<HostInput> local_inputs;
+        std::vector<HostInput>* inputs = &local_inputs;
+        const bool cacheable = !sig.empty();
+        double t_s = now_ms();
+        if (cacheable && cache_ctx && cache_sig == sig && cache_inputs.size() == ptrs.size()) {
+            cctx = cache_ctx;
+            gf   = cache_gf;
+            res  = cache_res;
+            for (size_t i = 0; i < ptrs.size(); ++i) cache_inputs[i].data = ptrs[i];
+            inputs = &cache_inputs;
+            ++cache_hits;
+        } else {
+            drop_cache();  // whatever is placed next reuses the gallocr buffer
+            ggml_init_params ip{0, nullptr, true};
+            cctx = ggml_init(ip);
+            gf   = ggml_new_graph_custom(cctx, graph_size, false);
+            GraphCtx g;
+            g.ctx            = cctx;
+            g.backend        = backend;
+            const double t_b = now_ms();
+            res              = build(g, local_inputs);
+            ggml_set_name(res, "ggml_runner_final_result_tensor");  // ggml_extend.hpp:2048-2051
+            ggml_set_output(res);
+            ggml_build_forward_expand(gf, res);
+            const double t_a = now_ms();
+            build_ms += t_a - t_b;
+            if (!galloc) galloc = ggml_gallocr_new(ggml_backend_get_default_buffer_type(backend));
+            const bool ok = ggml_gallocr_alloc_graph(galloc, gf);
+            t_s           = now_ms();
+            alloc_ms += t_s - t_a;
+            if (!ok) {
+                set_error("compute buffer allocation failed");
+                ggml_free(cctx);
+                return false;
+            }
+            if (cacheable) {
+                bool same = ptrs.size() == local_inputs.size();
+                for (size_t i = 0; same && i < ptrs.size(); ++i) same = ptrs[i] == local_inputs[i].data;
+                if (same) {  // the caller's pointer list matches what the builder declared: safe to replay with new pointers
+                    cache_sig    = sig;
+                    cache_ctx    = cctx;
+                    cache_gf     = gf;
+                    cache_res    = res;
+                    cache_inputs = local_inputs;
+                    inputs       = &cache_inputs;
+                }
+            }
         }
+        const bool keep  = cctx == cache_ctx;
         const bool async = out == nullptr;
-        for (auto& in : inputs) {
+        for (auto& in : *inputs) {
             if (async)
                 ggml_backend_tensor_set_async(backend, in.t, in.data, 0, in.nbytes);
             else
@@ -174,21 +224,27 @@ struct Runner {
         const enum ggml_status st = async ? ggml_backend_graph_compute_async(backend, gf) : ggml_backend_graph_compute(backend, gf);
         if (st != GGML_STATUS_SUCCESS) {
             set_error(std::string("graph compute failed: ") + ggml_status_to_string(st));
-            ggml_free(cctx);
+            if (keep)
+                drop_cache();
+            else
+                ggml_free(cctx);
             return false;
         }
         submit_ms += now_ms() - t_s;  // synchronous path: includes the device time of the graph
         if (!async) {
             if (ggml_nbytes(res) != out_bytes) {
                 set_error("output size mismatch");
-                ggml_free(cctx);
+                if (keep)
+                    drop_cache();
+                else
+                    ggml_free(cctx);
                 return false;
             }
             ggml_backend_tensor_get(res, out, 0, out_bytes);
         }
         last_nodes = gf->n_nodes;
         ++calls;
-        ggml_free(cctx);
+        if (!keep) ggml_free(cctx);
         return true;
     }
 };
@@ -842,7 +898,16 @@ bool sd_unet_forward(sd_ctx_t* ctx, const float* x, int w, int h, int c, int n, 
         in.push_back({tx, x, ggml_nbytes(tx)});
         return build_model_call(ctx, g, in, tx, n, timesteps, context, ctx_dim, n_tokens, ctx_n, y, y_dim, y_n, si);
     };
-    const bool ok = r.compute(build, out, (size_t)w * h * ctx->out_channels() * n * sizeof(float));
+    char sig[160];
+    snprintf(sig, sizeof(sig), "fwd %d %d %d %d %lld %lld %lld %lld %lld %d", w, h, c, n, (long long)ctx_dim, (long long)n_tokens, (long long)ctx_n,
+             (long long)(y ? y_dim : -1), (long long)y_n, (int)ctx->is_flux);
+    std::vector<const void*> ptrs{x, timesteps, context};
+    if (y) ptrs.push_back(y);
+    if (ctx->is_flux) {
+        ptrs.push_back(si.guidance.data());
+        ptrs.push_back(si.pe.data());
+    }
+    const bool ok = r.compute(build, out, (size_t)w * h * ctx->out_channels() * n * sizeof(float), sig, ptrs);
     ctx->stats.unet_calls  = r.calls;
     ctx->stats.graph_nodes = r.last_nodes;
     if (r.galloc) ctx->stats.compute_buffer_bytes = ggml_gallocr_get_buffer_size(r.galloc, 0);
@@ -866,7 +931,9 @@ bool sd_vae_decode(sd_ctx_t* ctx, const float* latents, int w, int h, int c, int
     };
     const size_t on = (size_t)w * 8 * h * 8 * 3 * n;
     const double t0 = now_ms();
-    if (!r.compute(build, out_rgb, on * sizeof(float))) return false;
+    char sig[64];
+    snprintf(sig, sizeof(sig), "vae %d %d %d %d", w, h, c, n);
+    if (!r.compute(build, out_rgb, on * sizeof(float), sig, {z.data()})) return false;
     for (size_t i = 0; i < on; ++i) {  // scale_tensor_to_0_1, vae.hpp:24-30
         const float v = (out_rgb[i] + 1.0f) * 0.5f;
         out_rgb[i]    = std::max(0.0f, std::min(1.0f, v));
@@ -1045,6 +1112,9 @@ static bool sample_group_device(sd_ctx_t* ctx, const sd_img_gen_params_t* p, int
     if (!prepare_side_inputs(ctx, W, H, n_model, p->cond.n_tokens, has_y, si)) return false;
     std::vector<float> ts(n_model);
     Runner& r = ctx->unet_runner;
+    char step_sig[200];  // every step of the trajectory replays ONE cached graph: only the 8 scalars, the timesteps and the conditioning are re-uploaded
+    snprintf(step_sig, sizeof(step_sig), "step %d %d %d %d cfg%d ea%d %lld %lld y%lld %p", W, H, C, nb, (int)use_cfg, (int)euler_a, (long long)p->cond.ctx_dim,
+             (long long)p->cond.n_tokens, (long long)(has_y ? p->cond.vector_dim : -1), (void*)st.x);
 
     for (int i = 0; i < steps; ++i) {
         const float sigma = sigmas[i], sigma_to = sigmas[i + 1];
@@ -1116,7 +1186,13 @@ static bool sample_group_device(sd_ctx_t* ctx, const sd_img_gen_params_t* p, int
             }
             return ggml_cpy(c, xn, xs);
         };
-        if (!r.compute(build, nullptr, 0)) return false;
+        std::vector<const void*> ptrs{sc, ts.data(), c2.data()};
+        if (has_y) ptrs.push_back(y2.data());
+        if (ctx->is_flux) {
+            ptrs.push_back(si.guidance.data());
+            ptrs.push_back(si.pe.data());
+        }
+        if (!r.compute(build, nullptr, 0, step_sig, ptrs)) return false;
     }
     ggml_backend_tensor_get(st.x, out, 0, per * nb * sizeof(float));  // synchronises the stream
     ctx->stats.unet_calls  = r.calls;
@@ -1231,6 +1307,7 @@ void sd_get_stats(sd_ctx_t* ctx, sd_stats_t* out) {
     ctx->stats.host_build_ms  = ctx->unet_runner.build_ms;
     ctx->stats.host_alloc_ms  = ctx->unet_runner.alloc_ms;
     ctx->stats.host_submit_ms = ctx->unet_runner.submit_ms;
+    ctx->stats.graph_cache_hits = ctx->unet_runner.cache_hits;
     *out                      = ctx->stats;
 }
 

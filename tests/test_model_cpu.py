@@ -355,3 +355,32 @@ def test_device_resident_sampler_variants(sd, oracle):
     img_h = e.generate_image(cond, uncond, width=64, height=64, steps=3, cfg=6.0, seed=4, fuse_cfg=True)
     img_d = e.generate_image(cond, uncond, width=64, height=64, steps=3, cfg=6.0, seed=4, fuse_cfg=True, device_sampler=True)
     np.testing.assert_array_equal(img_d, img_h)
+
+
+def test_graph_cache_replays_same_shapes_and_rebuilds_on_change(sd, oracle):
+    """Host-side graph cache (engine.cpp Runner::compute): consecutive denoiser calls with the same shapes replay one built + placed
+    graph with fresh inputs; results must be what a fresh engine (fresh graph every time) computes, and a shape change must rebuild."""
+    rng = np.random.default_rng(60)
+    e = sd.Engine(model=sd.SDXL_TINY, backend=oracle)
+    ctx = rng.standard_normal((1, 77, 64)).astype(np.float32)
+    y = rng.standard_normal((1, 96)).astype(np.float32)
+    xs = [rng.standard_normal((2, 4, 16, 16)).astype(np.float32) for _ in range(3)]
+    ts = [np.array([900.0, 10.0], np.float32), np.array([500.0, 500.0], np.float32), np.array([1.0, 999.0], np.float32)]
+    h0 = e.stats()["graph_cache_hits"]
+    outs = [e.unet_forward(x, t, ctx, y) for x, t in zip(xs, ts)]
+    assert e.stats()["graph_cache_hits"] - h0 == 2
+    for x, t, o in zip(xs, ts, outs):
+        np.testing.assert_array_equal(o, sd.Engine(model=sd.SDXL_TINY, backend=oracle).unet_forward(x, t, ctx, y))
+    # another batch size: miss, then hits again; going back to the first shape is a miss too (single-entry cache)
+    x1 = xs[0][:1]
+    h1 = e.stats()["graph_cache_hits"]
+    a = e.unet_forward(x1, ts[0][:1], ctx, y)
+    b = e.unet_forward(x1, ts[0][:1], ctx, y)
+    c = e.unet_forward(xs[0], ts[0], ctx, y)
+    assert e.stats()["graph_cache_hits"] - h1 == 1
+    np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(c, outs[0])
+    # the VAE runner and the sampler share nothing with the denoiser's entry
+    z = rng.standard_normal((1, 4, 8, 8)).astype(np.float32)
+    np.testing.assert_array_equal(e.vae_decode(z), e.vae_decode(z))
+    np.testing.assert_array_equal(e.unet_forward(xs[1], ts[1], ctx, y), outs[1])
