@@ -299,6 +299,9 @@ struct sd_ctx_t {
         }
     };
     std::unique_ptr<SamplerState> sstate;
+    std::vector<float> pe_cache;  // FLUX rotary table of the last (h, w, n_tokens)
+    int pe_h = 0, pe_w = 0;
+    int64_t pe_tokens = 0;
     std::vector<Runner*> runners() {
         std::vector<Runner*> v{&unet_runner, &vae_runner};
         if (te) {
@@ -844,7 +847,9 @@ bool sd_get_learned_condition(sd_ctx_t* ctx, const sd_token_list_t* clip_l, cons
 // ---- one UNet forward ---------------------------------------------------------------------------
 // host-built side inputs of one model call (FLUX: guidance vector and rotary table, flux.hpp:1457-1500)
 struct ModelSideInputs {
-    std::vector<float> guidance, pe;
+    std::vector<float> guidance;
+    const std::vector<float>* pe_table = nullptr;
+    const std::vector<float>& pe() const { return *pe_table; }
 };
 static bool prepare_side_inputs(sd_ctx_t* ctx, int w, int h, int n, int64_t n_tokens, bool has_y, ModelSideInputs& si) {
     if (!ctx->is_flux) return true;
@@ -853,7 +858,15 @@ static bool prepare_side_inputs(sd_ctx_t* ctx, int w, int h, int n, int64_t n_to
         return false;
     }
     si.guidance.assign(n, ctx->guidance);
-    si.pe = gen_flux_pe(h, w, ctx->flux.cfg.patch_size, (int)n_tokens, ctx->flux.cfg.axes_dim, (float)ctx->flux.cfg.theta);
+    // the rotary table depends on the latent size and the text length only: 12 ms of sin/cos per call at 1024x1024 + 256 tokens if rebuilt
+    // every forward like the reference does (flux.hpp:1457-1500) — kept per context instead
+    if (ctx->pe_cache.empty() || ctx->pe_h != h || ctx->pe_w != w || ctx->pe_tokens != n_tokens) {
+        ctx->pe_cache  = gen_flux_pe(h, w, ctx->flux.cfg.patch_size, (int)n_tokens, ctx->flux.cfg.axes_dim, (float)ctx->flux.cfg.theta);
+        ctx->pe_h      = h;
+        ctx->pe_w      = w;
+        ctx->pe_tokens = n_tokens;
+    }
+    si.pe_table = &ctx->pe_cache;
     return true;
 }
 // the denoiser network on an existing latent tensor tx [w,h,c,n]: declares the remaining graph inputs and calls the family's forward
@@ -879,9 +892,9 @@ static ggml_tensor* build_model_call(sd_ctx_t* ctx, GraphCtx& g, std::vector<Hos
         ggml_set_input(tg);
         in.push_back({tg, si.guidance.data(), ggml_nbytes(tg)});
         const FluxConfig& fc = ctx->flux.cfg;
-        ggml_tensor* tp      = ggml_new_tensor_4d(g.ctx, GGML_TYPE_F32, 2, 2, fc.hidden_size / fc.num_heads / 2, (int64_t)si.pe.size() / (2 * (fc.hidden_size / fc.num_heads)));
+        ggml_tensor* tp      = ggml_new_tensor_4d(g.ctx, GGML_TYPE_F32, 2, 2, fc.hidden_size / fc.num_heads / 2, (int64_t)si.pe().size() / (2 * (fc.hidden_size / fc.num_heads)));
         ggml_set_input(tp);
-        in.push_back({tp, si.pe.data(), ggml_nbytes(tp)});
+        in.push_back({tp, si.pe().data(), ggml_nbytes(tp)});
         return ctx->flux.forward(g, tx, tt, tc, ty, tg, tp);
     }
     return ctx->is_dit ? ctx->mmdit.forward(g, tx, tt, tc, ty) : ctx->unet.forward(g, tx, tt, tc, ty);
@@ -905,7 +918,7 @@ bool sd_unet_forward(sd_ctx_t* ctx, const float* x, int w, int h, int c, int n, 
     if (y) ptrs.push_back(y);
     if (ctx->is_flux) {
         ptrs.push_back(si.guidance.data());
-        ptrs.push_back(si.pe.data());
+        ptrs.push_back(si.pe().data());
     }
     const bool ok = r.compute(build, out, (size_t)w * h * ctx->out_channels() * n * sizeof(float), sig, ptrs);
     ctx->stats.unet_calls  = r.calls;
@@ -1190,7 +1203,7 @@ static bool sample_group_device(sd_ctx_t* ctx, const sd_img_gen_params_t* p, int
         if (has_y) ptrs.push_back(y2.data());
         if (ctx->is_flux) {
             ptrs.push_back(si.guidance.data());
-            ptrs.push_back(si.pe.data());
+            ptrs.push_back(si.pe().data());
         }
         if (!r.compute(build, nullptr, 0, step_sig, ptrs)) return false;
     }
