@@ -997,6 +997,7 @@ static bool sample_group(sd_ctx_t* ctx, const sd_img_gen_params_t* p, int b0, in
     const bool use_cfg = sp.txt_cfg != 1.0f && p->uncond.c_crossattn != nullptr;
     std::vector<float> noised(per * nb), cond_out(per * nb), uncond_out(per * nb), denoised(per * nb), ts(nb);
     std::vector<std::vector<float>> step_noise(nb);
+    std::vector<float> x2, o2, t2, c2, y2;  // staging of the fused (cond, uncond) pair
 
     for (int i = 0; i < steps; ++i) {
         const float sigma = sigmas[i], sigma_to = sigmas[i + 1];
@@ -1029,19 +1030,25 @@ static bool sample_group(sd_ctx_t* ctx, const sd_img_gen_params_t* p, int b0, in
         if (use_cfg && p->fuse_cfg_pair && p->cond.ctx_dim == p->uncond.ctx_dim && p->cond.n_tokens == p->uncond.n_tokens) {
             // one graph for the cond/uncond pair: images interleaved (b cond, b uncond, ...); context/y have batch 2 and are
             // tiled over the 2*nb images by the graph's ggml_repeat (dst[i] = src[i % 2])
-            const size_t cn = (size_t)p->cond.ctx_dim * p->cond.n_tokens;
-            std::vector<float> x2(2 * per * nb), o2(2 * per * nb), t2(2 * nb, t), c2(2 * cn), y2;
+            const size_t cn  = (size_t)p->cond.ctx_dim * p->cond.n_tokens;
+            const bool has_y = p->cond.c_vector && p->uncond.c_vector;
+            if (x2.empty()) {  // first step: the pair's conditioning is the same for every step, the staging buffers are reused
+                x2.resize(2 * per * nb);
+                o2.resize(2 * per * nb);
+                t2.resize(2 * nb);
+                c2.resize(2 * cn);
+                memcpy(&c2[0], p->cond.c_crossattn, cn * sizeof(float));
+                memcpy(&c2[cn], p->uncond.c_crossattn, cn * sizeof(float));
+                if (has_y) {
+                    y2.resize(2 * p->cond.vector_dim);
+                    memcpy(&y2[0], p->cond.c_vector, p->cond.vector_dim * sizeof(float));
+                    memcpy(&y2[p->cond.vector_dim], p->uncond.c_vector, p->cond.vector_dim * sizeof(float));
+                }
+            }
+            std::fill(t2.begin(), t2.end(), t);
             for (int b = 0; b < nb; ++b) {
                 memcpy(&x2[(2 * b) * per], &noised[b * per], per * sizeof(float));
                 memcpy(&x2[(2 * b + 1) * per], &noised[b * per], per * sizeof(float));
-            }
-            memcpy(&c2[0], p->cond.c_crossattn, cn * sizeof(float));
-            memcpy(&c2[cn], p->uncond.c_crossattn, cn * sizeof(float));
-            const bool has_y = p->cond.c_vector && p->uncond.c_vector;
-            if (has_y) {
-                y2.resize(2 * p->cond.vector_dim);
-                memcpy(&y2[0], p->cond.c_vector, p->cond.vector_dim * sizeof(float));
-                memcpy(&y2[p->cond.vector_dim], p->uncond.c_vector, p->cond.vector_dim * sizeof(float));
             }
             if (!sd_unet_forward(ctx, x2.data(), W, H, C, 2 * nb, t2.data(), c2.data(), p->cond.ctx_dim, p->cond.n_tokens, 2,
                                  has_y ? y2.data() : nullptr, p->cond.vector_dim, 2, o2.data()))
