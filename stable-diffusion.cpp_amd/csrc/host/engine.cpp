@@ -45,9 +45,9 @@ static double now_ms() { return std::chrono::duration<double, std::milli>(std::c
 
 // host post-processing of whole image batches (clamp / uint8 conversion of 6.3 M floats for 8 x 512x512) on a few threads
 template <typename Fn>
-static void parallel_chunks(size_t n, Fn&& fn) {
+static void parallel_chunks(size_t n, Fn&& fn, size_t min_parallel = (1u << 16)) {
     const unsigned hw = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
-    const size_t T    = n < (1u << 16) ? 1 : hw;
+    const size_t T    = n < min_parallel ? 1 : std::min<size_t>(hw, n);
     if (T == 1) {
         fn((size_t)0, n);
         return;
@@ -130,18 +130,24 @@ struct Runner {
         ggml_backend_buffer_set_usage(weights, GGML_BACKEND_BUFFER_USAGE_WEIGHTS);
         std::vector<float> tmp;
         std::vector<uint8_t> conv;
+        double t_fill = 0, t_up = 0;
         for (auto& sp : ps.specs) {
             const int64_t n = ggml_nelements(sp.tensor);
-            tmp.resize(n);
+            if ((int64_t)tmp.size() < n) tmp.resize(n);  // grow only: every element is overwritten below
             const uint64_t s = hash_name(sp.name, seed);
+            const double t0  = now_ms();
             switch (sp.kind) {
                 case InitKind::WEIGHT: fill_normal(tmp.data(), n, s, 0.f, 1.0f / sqrtf((float)sp.fan_in)); break;
                 case InitKind::BIAS: fill_normal(tmp.data(), n, s, 0.f, 0.02f); break;
                 case InitKind::NORM_SCALE: fill_normal(tmp.data(), n, s, 1.f, 0.05f); break;
-                case InitKind::ZERO: std::fill(tmp.begin(), tmp.end(), 0.f); break;
+                case InitKind::ZERO: std::fill(tmp.begin(), tmp.begin() + n, 0.f); break;
             }
+            const double t1 = now_ms();
             upload_f32(sp.tensor, tmp.data(), conv);
+            t_fill += t1 - t0;
+            t_up += now_ms() - t1;
         }
+        if (getenv("SDCPP_INIT_TIMING")) fprintf(stderr, "[sd-mi355x] synthetic init: %zu tensors, fill %.0f ms, convert + upload %.0f ms\n", ps.specs.size(), t_fill, t_up);
         return true;
     }
 
@@ -152,7 +158,24 @@ struct Runner {
             return;
         }
         scratch.resize(ggml_nbytes(t));
-        ggml_quantize_chunk(t->type, src, scratch.data(), 0, n / t->ne[0], t->ne[0], nullptr);  // model_loader.cpp:168-202
+        // model_loader.cpp:168-202; rows are independent, so big tensors convert on a few threads (the software f32 -> f16 / q8_0 / q4_0
+        // row encoders run at a few ns per element: 4 s of a 7 s SD1.5 context creation, minutes for a 12 B-parameter FLUX)
+        const int64_t rows = n / t->ne[0], per_row = t->ne[0];
+        const ggml_type ty = t->type;
+        uint8_t* dst       = scratch.data();
+        if (ty == GGML_TYPE_F16 || ty == GGML_TYPE_BF16) {
+            // elementwise encodings: convert flat ranges (conv kernels have ne0 = 3, a row-wise walk would pay one call per 3 elements)
+            parallel_chunks((size_t)n, [&](size_t i0, size_t i1) {
+                if (ty == GGML_TYPE_F16)
+                    ggml_fp32_to_fp16_row(src + i0, (ggml_fp16_t*)dst + i0, (int64_t)(i1 - i0));
+                else
+                    ggml_fp32_to_bf16_row(src + i0, (ggml_bf16_t*)dst + i0, (int64_t)(i1 - i0));
+            }, 1 << 20);
+        } else if (n < (1 << 20)) {
+            ggml_quantize_chunk(ty, src, dst, 0, rows, per_row, nullptr);
+        } else {
+            parallel_chunks((size_t)rows, [&](size_t r0, size_t r1) { ggml_quantize_chunk(ty, src, dst, (int64_t)r0 * per_row, (int64_t)(r1 - r0), per_row, nullptr); }, 2);
+        }
         ggml_backend_tensor_set(t, scratch.data(), 0, scratch.size());
     }
 
