@@ -23,3 +23,6 @@ timeout 300 python bench.py --steps 20 --warmup 2 --no-cpu-baseline --backend-op
 #   7. two K slices for the 193..384-workgroup launches (16x16 UNet level)
 SDCPP_BACKEND_OPTS=splitk_mid=1 timeout 300 python -m pytest tests/test_gpu_ops.py tests/test_zz_gpu_fullsize.py -m gpu -x -q 2>&1 | tail -3
 timeout 300 python bench.py --steps 20 --warmup 2 --no-cpu-baseline --backend-opt splitk_mid=1 | tee $D/bench_splitk_mid.jsonl | cut -c1-400
+#   8. flash attention d = 40: where the 380 us go (wrong-result ablations, timing only)
+( cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$D -o flash_ablation -- python $GRAFT_REPO_ROOT/scripts/flash_ablation.py > $GRAFT_REPO_ROOT/$D/flash_ablation_wall.txt 2> $GRAFT_REPO_ROOT/$D/flash_ablation.log )
+python scripts/rocpd_stats.py $D/flash_ablation_results.db $D/flash_ablation_kernel_stats.csv | grep k_flash | cut -c1-160

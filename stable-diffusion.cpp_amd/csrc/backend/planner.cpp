@@ -1639,6 +1639,7 @@ void planner_set_option(const char* key, int value) {
     else if (!strcmp(key, "gemm16_sched")) gemm16_set_sched(value);
     else if (!strcmp(key, "gemm16_adirect")) gemm16_set_adirect(value);
     else if (!strcmp(key, "splitk_mid")) gemm16_set_splitk_mid(value);
+    else if (!strcmp(key, "flash_ablate")) flash_attn_set_ablate(value);
     else if (!strcmp(key, "splitk_target")) gemm16_set_splitk_target(value);
     // options change what a plan contains: drop cached plans
     std::lock_guard<std::mutex> lk(g_mu);

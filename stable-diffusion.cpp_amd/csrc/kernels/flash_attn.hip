@@ -40,7 +40,9 @@ struct FAArgs {
 
 // FAST: K and V are f16, d-contiguous and 16-byte aligned (the FLASH_ATTN_EXT node as the reference builds it) -> 128-bit
 // loads, register-prefetched one tile ahead.  !FAST: any strides / f32 sources (manual-attention chain), staged directly.
-template <int DKP, int NDV, bool FAST>
+// ABL != 0: TIMING ABLATIONS with wrong results (option "flash_ablate", scripts/flash_ablation.py only): 1 = no softmax VALU work (the raw
+// scores go into the PV product), 2 = K/V tiles are staged once and reused (no global loads / LDS stores in the loop)
+template <int DKP, int NDV, bool FAST, int ABL = 0>
 __global__ __launch_bounds__(256, DKP <= 64 ? 3 : 2) void k_flash_attn(FAArgs g) {
     constexpr int KS   = DKP / 16;                       // MFMA k-steps over the head dim
     constexpr int KROW = DKP + 8;                        // K tile row stride (halfs)
@@ -192,8 +194,10 @@ __global__ __launch_bounds__(256, DKP <= 64 ? 3 : 2) void k_flash_attn(FAArgs g)
         if (FAST) {
             // tile kt sits in buffer buf (visible since the barrier that ended the previous iteration); the registers hold tile
             // kt+64: park it in the other buffer now, then fetch kt+128 — both overlap this tile's MFMAs
-            if (kt + FA_KT < g.Lk) lstore(buf ^ 1);
-            if (kt + 2 * FA_KT < g.Lk) gload(kt + 2 * FA_KT);
+            if (ABL != 2) {
+                if (kt + FA_KT < g.Lk) lstore(buf ^ 1);
+                if (kt + 2 * FA_KT < g.Lk) gload(kt + 2 * FA_KT);
+            }
         } else {
             __syncthreads();  // every wave finished reading the previous tile
             stage_generic(kt);
@@ -226,10 +230,12 @@ __global__ __launch_bounds__(256, DKP <= 64 ? 3 : 2) void k_flash_attn(FAArgs g)
                     if (kt + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= g.Lk) s[kb][r] = -INFINITY;
         }
         float tmax = s[0][0];
+        if (ABL != 1) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) tmax = __builtin_fmaxf(__builtin_fmaxf(tmax, s[0][r]), s[1][r]);  // v_max3_f32
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        if (__any(tmax > m_run + FA_THR)) {
+            for (int r = 0; r < 16; ++r) tmax = __builtin_fmaxf(__builtin_fmaxf(tmax, s[0][r]), s[1][r]);  // v_max3_f32
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        }
+        if (ABL != 1 && __any(tmax > m_run + FA_THR)) {
             const float m_new = fmaxf(m_run, tmax);
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // m_run = -inf on the first tile -> 0
             l_run *= alpha;
@@ -243,10 +249,12 @@ __global__ __launch_bounds__(256, DKP <= 64 ? 3 : 2) void k_flash_attn(FAArgs g)
                 for (int nb = 0; nb < NDV; ++nb) o[nb][r] *= ar;
             }
         }
+        if (ABL != 1) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[kb][r] = __builtin_amdgcn_exp2f(s[kb][r] - m_run);
+                for (int r = 0; r < 16; ++r) s[kb][r] = __builtin_amdgcn_exp2f(s[kb][r] - m_run);
+        }
         if (!has_ones) {
             float psum = 0.f;
 #pragma unroll
@@ -284,7 +292,7 @@ __global__ __launch_bounds__(256, DKP <= 64 ? 3 : 2) void k_flash_attn(FAArgs g)
         }
         if (FAST) {
             __syncthreads();  // tile kt+64 is complete in the other buffer; everybody is done reading this one
-            buf ^= 1;
+            if (ABL != 2) buf ^= 1;
         }
     }
 
@@ -321,6 +329,9 @@ __global__ __launch_bounds__(256, DKP <= 64 ? 3 : 2) void k_flash_attn(FAArgs g)
 }
 
 bool flash_attn_supported(int64_t D, int64_t DV) { return D == DV && D >= 8 && D <= 160; }
+
+static int g_flash_ablate = 0;  // option "flash_ablate": 1 / 2 select the wrong-result timing ablations of the d <= 48 kernel
+void flash_attn_set_ablate(int v) { g_flash_ablate = v; }
 
 void launch_flash_attn(hipStream_t s, const FlashOut& out, const View4& q, const View4& k, const View4& v, float scale) {
     FAArgs g;
@@ -360,7 +371,11 @@ void launch_flash_attn(hipStream_t s, const FlashOut& out, const View4& q, const
         else                                                          \
             k_flash_attn<DKP_, NDV_, false><<<grid, 256, 0, s>>>(g);  \
     } while (0)
-    if (D <= 48)
+    if (D <= 48 && fast && g_flash_ablate == 1)
+        k_flash_attn<48, 2, true, 1><<<grid, 256, 0, s>>>(g);
+    else if (D <= 48 && fast && g_flash_ablate == 2)
+        k_flash_attn<48, 2, true, 2><<<grid, 256, 0, s>>>(g);
+    else if (D <= 48)
         FA_CASE(48, 2);
     else if (D <= 64)
         FA_CASE(64, 2);

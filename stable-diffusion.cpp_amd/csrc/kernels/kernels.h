@@ -138,6 +138,7 @@ struct FlashOut {
     void* dst16      = nullptr;
     int64_t ld16     = 0;
 };
+void flash_attn_set_ablate(int v);  // timing ablations of the d <= 48 kernel (wrong results; microbenchmarks only)
 void launch_flash_attn(hipStream_t s, const FlashOut& out, const View4& q, const View4& k, const View4& v, float scale);
 
 }  // namespace mi355x
