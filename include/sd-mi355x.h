@@ -48,6 +48,8 @@ enum sd_model_family_t {
     SD_MODEL_FLUX_DEV   = 6, /* FLUX.1-dev: 19 double + 38 single stream blocks, hidden 3072, 24 heads, RoPE axes 16/56/56, distilled
                                 guidance input (flux.hpp); 16-ch VAE scale 0.3611 shift 0.1159; FluxFlowDenoiser + Flux scheduler */
     SD_MODEL_FLUX_TINY  = 7, /* same topology: 2 + 2 blocks, hidden 128, 4 heads, axes 8/12/12 */
+    SD_MODEL_SD35_WIDE2 = 8, /* SD3.5-large's real width (hidden 2432, 38 heads x 64), 2 joint blocks — full-width block parity tests */
+    SD_MODEL_FLUX_WIDE1 = 9, /* FLUX.1-dev's real width (hidden 3072, 24 heads x 128), 1 double + 1 single block — same purpose */
 };
 
 /* numeric values = enum ggml_type (stable-diffusion.h:98-143) */
@@ -163,6 +165,7 @@ SD_API void free_sd_images(sd_image_t* images, int num_images);
 
 /* ---- host-side sampler pieces exposed for known-answer tests ---- */
 SD_API void sd_philox_randn(uint64_t seed, uint32_t offset, uint32_t n, float* out); /* rng_philox.hpp:101-122 */
+SD_API void sd_philox_uint32(uint64_t seed, uint32_t offset, uint32_t n, uint32_t* out /* 4*n words */); /* the integer stage alone: philox4_32, rng_philox.hpp:63-77 */
 SD_API int sd_get_sigmas(int steps, float* out /* steps+1 */);                       /* denoiser.hpp:32-54 + stable-diffusion.cpp:173-186 */
 SD_API void sd_set_guidance(sd_ctx_t* ctx, float guidance); /* FLUX distilled-guidance input (default 3.5, stable-diffusion.h guidance.distilled_guidance) */
 SD_API int sd_get_flux_sigmas(int steps, int image_seq_len, float* out /* steps+1 */); /* FluxScheduler, denoiser.hpp:726-782 */

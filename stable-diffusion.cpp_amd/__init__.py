@@ -26,7 +26,7 @@ F32, F16, Q4_0, Q8_0, I32, BF16 = 0, 1, 2, 8, 26, 30
 TYPE_SIZE = {F32: 4, F16: 2, BF16: 2, I32: 4}
 
 # sd_model_family_t
-SD15, SDXL, SD15_TINY, SDXL_TINY, SD35_LARGE, SD35_TINY, FLUX_DEV, FLUX_TINY = 0, 1, 2, 3, 4, 5, 6, 7
+SD15, SDXL, SD15_TINY, SDXL_TINY, SD35_LARGE, SD35_TINY, FLUX_DEV, FLUX_TINY, SD35_WIDE2, FLUX_WIDE1 = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
 EULER, EULER_A = 0, 1
 
 
@@ -244,6 +244,7 @@ def lib() -> C.CDLL:
     L.generate_image.restype = C.c_bool
     L.free_sd_images.argtypes = [C.POINTER(SdImage), C.c_int]
     L.sd_philox_randn.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p]
+    L.sd_philox_uint32.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p]
     L.sd_get_sigmas.argtypes = [C.c_int, C.c_void_p]
     L.sd_get_flow_sigmas.argtypes = [C.c_int, C.c_float, C.c_void_p]
     L.sd_get_flux_sigmas.argtypes = [C.c_int, C.c_int, C.c_void_p]
@@ -574,7 +575,7 @@ class Engine:
                        method=EULER_A, eta=float("inf"), cond_y=None, uncond_y=None, fuse_cfg=False, device_sampler=False) -> np.ndarray:
         p, keep = self._gen_params(cond, uncond, width, height, steps, cfg, seed, batch, device_batch, method, eta, cond_y, uncond_y, fuse_cfg,
                                    device_sampler)
-        ch = 16 if self.model in (SD35_LARGE, SD35_TINY, FLUX_DEV, FLUX_TINY) else 4
+        ch = 16 if self.model in (SD35_LARGE, SD35_TINY, FLUX_DEV, FLUX_TINY, SD35_WIDE2, FLUX_WIDE1) else 4
         out = np.empty((batch, ch, height // 8, width // 8), dtype=np.float32)
         if not lib().sd_sample_latents(self._ctx, C.byref(p), _fptr(out)):
             raise EngineError("sd_sample_latents failed: " + lib().sd_last_error().decode())
@@ -611,6 +612,13 @@ def t5_relative_position_buckets(q_len: int, k_len: int) -> np.ndarray:
 def philox_randn(seed: int, offset: int, n: int) -> np.ndarray:
     out = np.empty(n, dtype=np.float32)
     lib().sd_philox_randn(seed, offset, n, _fptr(out))
+    return out
+
+
+def philox_uint32(seed: int, offset: int, n: int) -> np.ndarray:
+    """The four Philox4x32-10 output words of counters (offset, 0, i, 0), i < n -> uint32 [n, 4]."""
+    out = np.empty((n, 4), dtype=np.uint32)
+    lib().sd_philox_uint32(seed, offset, n, out.ctypes.data_as(C.c_void_p))
     return out
 
 

@@ -441,8 +441,8 @@ sd_ctx_t* new_sd_ctx(const sd_ctx_params_t* params) {
 
     const bool xl   = params->model == SD_MODEL_SDXL || params->model == SD_MODEL_SDXL_TINY;
     const bool tiny = params->model == SD_MODEL_SD15_TINY || params->model == SD_MODEL_SDXL_TINY;
-    const bool flux     = params->model == SD_MODEL_FLUX_DEV || params->model == SD_MODEL_FLUX_TINY;
-    const bool dit      = params->model == SD_MODEL_SD35_LARGE || params->model == SD_MODEL_SD35_TINY || flux;
+    const bool flux     = params->model == SD_MODEL_FLUX_DEV || params->model == SD_MODEL_FLUX_TINY || params->model == SD_MODEL_FLUX_WIDE1;
+    const bool dit      = params->model == SD_MODEL_SD35_LARGE || params->model == SD_MODEL_SD35_TINY || params->model == SD_MODEL_SD35_WIDE2 || flux;
     const bool dit_tiny = params->model == SD_MODEL_SD35_TINY || params->model == SD_MODEL_FLUX_TINY;
     UNetConfig ucfg = tiny ? UNetConfig::tiny(xl) : (xl ? UNetConfig::sdxl_base() : UNetConfig::sd15());
     VaeConfig vcfg  = (tiny || dit_tiny) ? VaeConfig::tiny() : (xl ? VaeConfig::sdxl() : VaeConfig::sd15());
@@ -460,10 +460,10 @@ sd_ctx_t* new_sd_ctx(const sd_ctx_params_t* params) {
     ctx->is_flux                    = flux;
     if (flux) {
         ctx->unet_runner.graph_size = 32768 * 4;  // FLUX_GRAPH_SIZE headroom
-        ctx->flux.init(ctx->unet_runner.ps, "model.diffusion_model.", dit_tiny ? FluxConfig::tiny() : FluxConfig::flux_dev());
+        ctx->flux.init(ctx->unet_runner.ps, "model.diffusion_model.", dit_tiny ? FluxConfig::tiny() : (params->model == SD_MODEL_FLUX_WIDE1 ? FluxConfig::flux_wide1() : FluxConfig::flux_dev()));
     } else if (dit) {
         ctx->unet_runner.graph_size = 10240 * 8;  // MMDIT_GRAPH_SIZE (mmdit.hpp:14) x our batch headroom
-        ctx->mmdit.init(ctx->unet_runner.ps, "model.diffusion_model.", dit_tiny ? MMDiTConfig::tiny() : MMDiTConfig::sd35_large());
+        ctx->mmdit.init(ctx->unet_runner.ps, "model.diffusion_model.", dit_tiny ? MMDiTConfig::tiny() : (params->model == SD_MODEL_SD35_WIDE2 ? MMDiTConfig::sd35_wide2() : MMDiTConfig::sd35_large()));
     } else
         ctx->unet.init(ctx->unet_runner.ps, "model.diffusion_model.", ucfg);  // prefix: stable-diffusion.cpp:1337
     ctx->vae_runner.backend        = backend;
@@ -677,7 +677,7 @@ static bool ensure_text_encoders(sd_ctx_t* ctx) {
         gp         = "cond_stage_model.1.transformer.text_model.";
         sp.adm_dim = ctx->unet.cfg.adm_in_channels;
         sp.ts_dim  = tiny ? 8 : 256;
-    } else if (m == SD_MODEL_SD35_LARGE || m == SD_MODEL_SD35_TINY) {
+    } else if (m == SD_MODEL_SD35_LARGE || m == SD_MODEL_SD35_TINY || m == SD_MODEL_SD35_WIDE2) {
         sp.family = CondFamily::SD3;
         sp.has_g = sp.has_t5 = true;
         lc = tiny ? ClipTextConfig::tiny(24, 2, 0, false, false) : ClipTextConfig::vit_l(false);
@@ -1357,6 +1357,9 @@ void sd_philox_randn(uint64_t seed, uint32_t offset, uint32_t n, float* out) {
     r.offset = offset;
     std::vector<float> v = r.randn(n);
     memcpy(out, v.data(), n * sizeof(float));
+}
+void sd_philox_uint32(uint64_t seed, uint32_t offset, uint32_t n, uint32_t* out) {
+    for (uint32_t i = 0; i < n; ++i) PhiloxRNG::words(seed, offset, i, out + 4 * (size_t)i);
 }
 int sd_get_sigmas(int steps, float* out) {
     static CompVisDenoiser d;

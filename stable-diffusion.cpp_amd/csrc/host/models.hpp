@@ -376,12 +376,21 @@ struct MMDiTConfig {
     int64_t context_size       = 4096;
     int64_t hidden_size        = 1536;
     bool qk_rms                = false;
+    int64_t num_heads          = 0;  // 0: heads = depth, as the reference wires it (mmdit.hpp:798-799)
 
     static MMDiTConfig sd35_large() {
         MMDiTConfig c;
         c.depth       = 38;
         c.hidden_size = 64 * 38;
         c.qk_rms      = true;
+        return c;
+    }
+    // SD3.5-large's real width (hidden 2432, 38 heads x 64) with TWO joint blocks (one full, one whose context stream is pre_only):
+    // full-width block parity against the CPU oracle in seconds (tests/test_zz_gpu_fullsize.py)
+    static MMDiTConfig sd35_wide2() {
+        MMDiTConfig c = sd35_large();
+        c.depth       = 2;
+        c.num_heads   = 38;
         return c;
     }
     // same topology at CPU-test size (last block pre_only, rms qk-norm, one MMDiT-X block to cover that path)
@@ -509,10 +518,11 @@ struct MMDiTModel {
         y_mlp2.init(ps, prefix + "y_embedder.mlp.2.", cfg.hidden_size, cfg.hidden_size, true, false, true);
         context_embedder.init(ps, prefix + "context_embedder.", cfg.context_size, cfg.hidden_size, true, false, true);
         blocks.resize(cfg.depth);
+        const int64_t heads = cfg.num_heads > 0 ? cfg.num_heads : cfg.depth;
         for (int64_t i = 0; i < cfg.depth; ++i) {  // heads = depth (mmdit.hpp:799), qkv_bias true, last context block pre_only
             const std::string p = prefix + "joint_blocks." + std::to_string(i) + ".";
-            blocks[i].context_block.init(ps, p + "context_block.", cfg.hidden_size, cfg.depth, cfg.mlp_ratio, cfg.qk_rms, i == cfg.depth - 1, false);
-            blocks[i].x_block.init(ps, p + "x_block.", cfg.hidden_size, cfg.depth, cfg.mlp_ratio, cfg.qk_rms, false, i <= cfg.d_self);
+            blocks[i].context_block.init(ps, p + "context_block.", cfg.hidden_size, heads, cfg.mlp_ratio, cfg.qk_rms, i == cfg.depth - 1, false);
+            blocks[i].x_block.init(ps, p + "x_block.", cfg.hidden_size, heads, cfg.mlp_ratio, cfg.qk_rms, false, i <= cfg.d_self);
         }
         final_linear.init(ps, prefix + "final_layer.linear.", cfg.hidden_size, cfg.patch_size * cfg.patch_size * cfg.out_channels, true, false, true);
         final_adaLN.init(ps, prefix + "final_layer.adaLN_modulation.1.", cfg.hidden_size, 2 * cfg.hidden_size);
@@ -617,6 +627,13 @@ struct FluxConfig {  // flux.hpp:28-60
     int theta                 = 10000;
     bool guidance_embed       = true;
     static FluxConfig flux_dev() { return FluxConfig(); }
+    // FLUX.1-dev's real width (hidden 3072, 24 heads x 128, RoPE 16/56/56) with ONE double and ONE single stream block
+    static FluxConfig flux_wide1() {
+        FluxConfig c;
+        c.depth               = 1;
+        c.depth_single_blocks = 1;
+        return c;
+    }
     static FluxConfig tiny() {
         FluxConfig c;
         c.vec_in_dim          = 64;

@@ -31,23 +31,35 @@ struct PhiloxRNG {
         c[2] = n2;
         c[3] = n3;
     }
+    // the integer stage: Philox4x32-10 of counter (offset, 0, i, 0) under key = seed -> 4 words (philox4_32, rng_philox.hpp:63-77)
+    static inline void words(uint64_t seed, uint32_t offset, uint32_t i, uint32_t c[4]) {
+        c[0] = offset;
+        c[1] = 0;
+        c[2] = i;
+        c[3] = 0;
+        uint32_t k[2] = {(uint32_t)(seed & 0xFFFFFFFFu), (uint32_t)(seed >> 32)};
+        for (int r = 0; r < 9; ++r) {
+            round(c, k);
+            k[0] += 0x9E3779B9u;
+            k[1] += 0xBB67AE85u;
+        }
+        round(c, k);
+    }
     std::vector<float> randn(uint32_t n) {
         std::vector<float> out(n);
         const float two_pow32_inv     = 2.3283064e-10f;
         const float two_pow32_inv_2pi = 2.3283064e-10f * 6.2831855f;
         for (uint32_t i = 0; i < n; ++i) {
-            uint32_t c[4] = {offset, 0, i, 0};
-            uint32_t k[2] = {(uint32_t)(seed & 0xFFFFFFFFu), (uint32_t)(seed >> 32)};
-            for (int r = 0; r < 9; ++r) {
-                round(c, k);
-                k[0] += 0x9E3779B9u;
-                k[1] += 0xBB67AE85u;
-            }
-            round(c, k);
+            uint32_t c[4];
+            words(seed, offset, i, c);
             const float u = (float)c[0] * two_pow32_inv + two_pow32_inv / 2;
             const float v = (float)c[1] * two_pow32_inv_2pi + two_pow32_inv_2pi / 2;
-            const float s = sqrtf(-2.0f * logf(u));
-            out[i]        = s * sinf(v);
+            // box_muller (rng_philox.hpp:79-87) calls the UNQUALIFIED log / sqrt / sin with only <cmath> included: under GCC + libstdc++ those
+            // are the C double functions (the float overloads live in std::), so the float operands are promoted, the products are
+            // formed in double and each statement rounds to float once.  Verified bit-for-bit against the reference's own header
+            // compiled from /root/reference (oracle/Makefile -> oracle/_ref/libref_philox.so; tests/golden/philox_ref.npz).
+            const float s = (float)std::sqrt((double)-2.0f * std::log((double)u));
+            out[i]        = (float)((double)s * std::sin((double)v));
         }
         offset += 1;
         return out;

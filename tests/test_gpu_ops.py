@@ -272,7 +272,9 @@ def _attn_exact(q, k, v, scale):
     return np.einsum("hqk,hkd->hqd", p, v.astype(np.float64))
 
 
-@pytest.mark.parametrize("d,Lq,Lk,HN", [(40, 200, 200, 4), (40, 130, 77, 8), (64, 256, 256, 3), (80, 64, 77, 2), (160, 64, 64, 2), (16, 70, 70, 4)])
+@pytest.mark.parametrize("d,Lq,Lk,HN", [(40, 200, 200, 4), (40, 130, 77, 8), (64, 256, 256, 3), (80, 64, 77, 2), (160, 64, 64, 2), (16, 70, 70, 4),
+                                        # d = 96 / 128 instantiations (FLUX: 24 heads x 128, L = 4096 + 256) with ragged key counts
+                                        (96, 200, 333, 2), (96, 130, 4352, 1), (128, 333, 333, 3), (128, 512, 4352, 2), (128, 77, 77, 2)])
 def test_flash_attn_ext(sd, oracle, gpu, rng, d, Lq, Lk, HN):
     """FLASH_ATTN_EXT node (f16 K/V).  The oracle reproduces ggml-cpu's F16 accumulation of V (Appendix E.3), which is
     LESS accurate than the MFMA kernel (f32 accumulation): tolerance vs oracle 1e-2 rel-L2, vs exact math 2e-3."""

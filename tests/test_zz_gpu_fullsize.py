@@ -7,7 +7,10 @@ oracle to finish a whole graph:
     against the 128x128 tile the small-shape oracle tests validate: same f16 operands, f32 accumulation, so the outputs agree to
     f32 summation-order noise (rel-L2 <= 2e-5, an order of magnitude under the f16-operand bar of the oracle tests);
   * determinism — the same graph twice gives the same bits;
-  * batch consistency of the whole full-width UNet — a (cond, uncond) pair in one graph equals the two single forwards.
+  * batch consistency of the whole full-width UNet — a (cond, uncond) pair in one graph equals the two single forwards;
+  * and, where the CPU oracle finishes in seconds, the oracle itself at FULL width: the SD1.5 UNet forward of a (cond, uncond) pair
+    (the graph bench.py times, at batch 2), the 64x64 -> 512x512 VAE decode, the SDXL UNet with q8_0 Linear weights, and real-width
+    SD3.5-large / FLUX.1-dev transformer blocks (hidden 2432 / 3072, d_head 64 / 128).
 
 The same file runs against the oracle in the harness self-check mode (SDCPP_GPU_TESTS_ON_ORACLE=1) at reduced sizes, which is how
 the NumPy references below were validated on a machine without a GPU.  (The file name sorts last on purpose: these are the
@@ -196,3 +199,114 @@ def test_full_width_unet_pair_equals_single_forwards(sd, gpu):
     x8 = np.concatenate([np.repeat(x, 2, axis=0), rng.standard_normal((14, 4, 64, 64)).astype(np.float32)])
     out8 = e.unet_forward(x8, np.full(16, 500.0, np.float32), np.concatenate([cond, uncond]))
     assert rel_l2(out8[0], a[0]) < 2e-3 and rel_l2(out8[1], b[0]) < 2e-3
+
+
+# ---- FULL-WIDTH graphs against the CPU oracle (same synthetic weights, seed 1234; same seeded inputs) ---------------------------
+# Every planner decision (fusion chains, tile configurations, split-K, head-major stores, aliasing analysis) is taken on the shapes
+# bench.py runs; the bars are the ones of the tiny-width tests in test_gpu_model.py (rel-L2 <= 5e-3 per forward at f16, PSNR >= 35 dB).
+full = pytest.mark.skipif(not ON_GPU, reason="full-width model on both sides: the self-check mode would run the oracle twice")
+
+
+def psnr(a, b):
+    return 10 * np.log10(1.0 / max(float(np.mean((np.asarray(a, np.float64) - b) ** 2)), 1e-20))
+
+
+@full
+def test_full_width_sd15_unet_vs_oracle(sd, oracle, gpu):
+    """SD1.5 UNet at 512x512 (src/model/diffusion/unet.hpp:526-745), flash attention on: the (cond, uncond) pair of one image in one graph."""
+    rng = np.random.default_rng(500)
+    x = np.repeat(rng.standard_normal((1, 4, 64, 64)).astype(np.float32), 2, axis=0)
+    t = np.array([731.0, 731.0], np.float32)
+    c2 = rng.standard_normal((2, 77, 768)).astype(np.float32)
+    ref = sd.Engine(model=sd.SD15, backend=oracle, flash_attn=True).unet_forward(x, t, c2)
+    e = sd.Engine(model=sd.SD15, backend=gpu, flash_attn=True)
+    out = e.unet_forward(x, t, c2)
+    assert np.isfinite(out).all()
+    err = rel_l2(out, ref)
+    print(f"full-width SD1.5 UNet (pair, flash): rel-L2 vs oracle {err:.3e}")
+    assert err < 5e-3
+    # the bench graph: 8 images x (cond, uncond); images 0 / 1 carry the pair above
+    x16 = np.concatenate([x, rng.standard_normal((14, 4, 64, 64)).astype(np.float32)])
+    out16 = e.unet_forward(x16, np.full(16, 731.0, np.float32), c2)
+    assert rel_l2(out16[:2], ref) < 5e-3
+
+
+@full
+def test_full_width_sd15_unet_manual_attention_vs_oracle(sd, oracle, gpu):
+    """the same forward with the flash flag off (MUL_MAT / SOFT_MAX attention chain, ggml_extend.hpp:1460-1479)"""
+    rng = np.random.default_rng(501)
+    x = rng.standard_normal((1, 4, 64, 64)).astype(np.float32)
+    t = np.array([210.0], np.float32)
+    c = rng.standard_normal((1, 77, 768)).astype(np.float32)
+    ref = sd.Engine(model=sd.SD15, backend=oracle, flash_attn=False).unet_forward(x, t, c)
+    out = sd.Engine(model=sd.SD15, backend=gpu, flash_attn=False).unet_forward(x, t, c)
+    err = rel_l2(out, ref)
+    print(f"full-width SD1.5 UNet (manual attention): rel-L2 vs oracle {err:.3e}")
+    assert np.isfinite(out).all() and err < 5e-3
+
+
+@full
+def test_full_size_vae_decode_vs_oracle(sd, oracle, gpu):
+    """KL-VAE decode 64x64 -> 512x512 (auto_encoder_kl.hpp:444-492; mid attention 1 head x d 512 over 4096 positions)"""
+    rng = np.random.default_rng(502)
+    z = rng.standard_normal((1, 4, 64, 64)).astype(np.float32) * 0.18215 * 3
+    ref = sd.Engine(model=sd.SD15, backend=oracle).vae_decode(z)
+    out = sd.Engine(model=sd.SD15, backend=gpu).vae_decode(z)
+    assert out.shape == (1, 3, 512, 512) and np.isfinite(out).all()
+    p = psnr(out, ref)
+    print(f"full-size VAE decode: PSNR vs oracle {p:.1f} dB, max abs diff {np.abs(out - ref).max():.2e}")
+    assert p > 35.0
+
+
+@full
+@pytest.mark.parametrize("flash", [True, False])
+def test_full_width_sdxl_unet_q8_0_vs_oracle(sd, oracle, gpu, flash):
+    """SDXL UNet (unet.hpp:47-57: depth-2 / depth-10 transformers, Linear proj_in / proj_out, label_emb), q8_0 Linear weights + f16 conv
+    (BASELINE.json config 3), latent 64x64 (the oracle needs ~4x longer at 128x128; widths and depths are the real ones).  The oracle
+    quantises the ACTIVATIONS of a q8_0 Linear to q8_0 as ggml-cpu does; the GPU keeps them f16 — hence 1e-2."""
+    rng = np.random.default_rng(503)
+    x = rng.standard_normal((1, 4, 64, 64)).astype(np.float32)
+    t = np.array([500.0], np.float32)
+    c = rng.standard_normal((1, 77, 2048)).astype(np.float32)
+    y = rng.standard_normal((1, 2816)).astype(np.float32)
+    ref = sd.Engine(model=sd.SDXL, backend=oracle, wtype=sd.Q8_0, flash_attn=flash).unet_forward(x, t, c, y)
+    out = sd.Engine(model=sd.SDXL, backend=gpu, wtype=sd.Q8_0, flash_attn=flash).unet_forward(x, t, c, y)
+    err = rel_l2(out, ref)
+    print(f"full-width SDXL UNet q8_0 flash={flash}: rel-L2 vs oracle {err:.3e}")
+    assert np.isfinite(out).all() and err < 1e-2
+
+
+@full
+@pytest.mark.parametrize("wtype,tol", [("F16", 5e-3), ("BF16", 2e-2)])
+def test_real_width_sd35_joint_blocks_vs_oracle(sd, oracle, gpu, wtype, tol):
+    """Two SD3.5-large joint blocks at the real width (hidden 2432, 38 heads x 64, rms qk-norm; the second block's context stream is
+    pre_only — mmdit.hpp:614-699, 803) between the real embedders and final layer: 1024 image + 154 context tokens."""
+    rng = np.random.default_rng(504)
+    x = rng.standard_normal((1, 16, 64, 64)).astype(np.float32)
+    t = np.array([600.0], np.float32)
+    c = rng.standard_normal((1, 154, 4096)).astype(np.float32)
+    y = rng.standard_normal((1, 2048)).astype(np.float32)
+    wt = getattr(sd, wtype)
+    ref = sd.Engine(model=sd.SD35_WIDE2, backend=oracle, wtype=wt, flash_attn=True).unet_forward(x, t, c, y)
+    out = sd.Engine(model=sd.SD35_WIDE2, backend=gpu, wtype=wt, flash_attn=True).unet_forward(x, t, c, y)
+    err = rel_l2(out, ref)
+    print(f"real-width SD3.5 joint blocks {wtype}: rel-L2 vs oracle {err:.3e}")
+    assert np.isfinite(out).all() and err < tol
+
+
+@full
+@pytest.mark.parametrize("wtype,tol", [("F16", 5e-3), ("Q4_0", 6e-2)])
+def test_real_width_flux_blocks_vs_oracle(sd, oracle, gpu, wtype, tol):
+    """One FLUX.1-dev double-stream and one single-stream block at the real width (hidden 3072, 24 heads x 128, RoPE axes 16/56/56,
+    fused qkv+mlp linear1 3072 -> 21504; flux.hpp:430-700): 1024 image + 77 text tokens (a ragged key count for the d = 128 attention)."""
+    rng = np.random.default_rng(505)
+    x = rng.standard_normal((1, 16, 64, 64)).astype(np.float32)
+    t = np.array([0.62], np.float32)
+    c = rng.standard_normal((1, 77, 4096)).astype(np.float32)
+    y = rng.standard_normal((1, 768)).astype(np.float32)
+    wt = getattr(sd, wtype)
+    ref = sd.Engine(model=sd.FLUX_WIDE1, backend=oracle, wtype=wt, flash_attn=True).unet_forward(x, t, c, y)
+    out = sd.Engine(model=sd.FLUX_WIDE1, backend=gpu, wtype=wt, flash_attn=True).unet_forward(x, t, c, y)
+    err = rel_l2(out, ref)
+    print(f"real-width FLUX blocks {wtype}: rel-L2 vs oracle {err:.3e}")
+    assert np.isfinite(out).all() and err < tol
