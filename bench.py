@@ -205,7 +205,7 @@ def main():
                    **({"backend_opts": args.backend_opt} if args.backend_opt else {})},
         "roofline": roofline,
     }
-    # BASELINE.json's metric is "denoise it/s + sec/image": the second half is one whole generate_image call (noise -> 20 sampler steps ->
+    # BASELINE.json's metric is "denoise it/s + sec/image": the second half is one whole sdm_generate_image call (noise -> 20 sampler steps ->
     # VAE decode -> uint8 pixels) on the same device batch, run AFTER the timed region.  Default on one GPU; --e2e forces it on rank 0.
     if rank == 0 and not args.no_e2e and (args.e2e or world == 1):
         try:

@@ -15,14 +15,25 @@
  * fallback in the product.  Tests may register another backend plug-in (the CPU oracle) explicitly
  * through sd_load_backend() and select it by name.
  *
- * reference counterpart                          -> this header
- *   sd_ctx_params_t   stable-diffusion.h:192-238 -> sd_ctx_params_t (fields the hot path reads)
- *   sd_sample_params_t                 :276-287  -> sd_sample_params_t
- *   new_sd_ctx / free_sd_ctx           :482-485  -> new_sd_ctx / free_sd_ctx
- *   generate_image                     :493-496  -> generate_image (batch_count images, seeds seed+b)
- *   free_sd_images                     :595-597  -> free_sd_images
- *   sd_image_t                         :258-263  -> sd_image_t
- *   sd_set_backend_eval_callback       :442-447  -> (sub-graph views are honoured by the backend)
+ * NAMING.  The reference's public API takes model paths and prompt strings and its parameter structs carry ~50 fields the hot path never
+ * reads (include/stable-diffusion.h:192-287); this slice takes tensors and token ids, so its structs CANNOT be layout-compatible.  Every
+ * type, enumerator and function whose name exists in the reference header therefore carries the prefix `sdm_` / `SDM_` here: a program
+ * may include both headers and link both libraries, and a reference-side caller can never bind one of these entry points by accident
+ * (round-1 review: same names + different layouts = silent memory corruption).  The pairs:
+ *
+ * reference (stable-diffusion.h)                  -> this header
+ *   sd_ctx_params_t                     :192-238 -> sdm_ctx_params_t (only the fields the hot path reads; + model family, weight seed)
+ *   sd_sample_params_t                  :276-287 -> sdm_sample_params_t
+ *   sd_img_gen_params_t                          -> sdm_img_gen_params_t (conditioning as tensors instead of prompt strings)
+ *   sd_image_t                          :258-263 -> sdm_image_t (same four fields, same order)
+ *   enum sample_method_t / scheduler_t  :38-83   -> sdm_sample_method_t / sdm_scheduler_t (same numeric values for the members kept)
+ *   enum sd_type_t                      :99-143  -> sdm_type_t (same numeric values = enum ggml_type)
+ *   new_sd_ctx / free_sd_ctx            :482-485 -> sdm_new_ctx / sdm_free_ctx
+ *   generate_image                      :493-496 -> sdm_generate_image (batch_count images, seeds seed+b)
+ *   free_sd_images                      :595-597 -> sdm_free_images
+ *   sd_*_params_init                             -> sdm_*_params_init
+ *   sd_set_backend_eval_callback        :442-447 -> (sub-graph views are honoured by the backend)
+ * Names without a reference counterpart (sd_unet_forward, sd_vae_decode, sd_load_backend, ...) keep the plain `sd_` prefix.
  */
 #ifndef SD_MI355X_H
 #define SD_MI355X_H
@@ -53,35 +64,37 @@ enum sd_model_family_t {
 };
 
 /* numeric values = enum ggml_type (stable-diffusion.h:98-143) */
-enum sd_type_t {
-    SD_TYPE_F32  = 0,
-    SD_TYPE_F16  = 1,
-    SD_TYPE_Q4_0 = 2,
-    SD_TYPE_Q8_0 = 8,
-    SD_TYPE_BF16 = 30,
+enum sdm_type_t {
+    SDM_TYPE_F32  = 0,
+    SDM_TYPE_F16  = 1,
+    SDM_TYPE_Q4_0 = 2,
+    SDM_TYPE_Q8_0 = 8,
+    SDM_TYPE_BF16 = 30,
 };
 
-enum sample_method_t { EULER_SAMPLE_METHOD = 0, EULER_A_SAMPLE_METHOD = 1 };
-enum scheduler_t { DISCRETE_SCHEDULER = 0 };
+/* SDM_SAMPLE_METHOD_COUNT = "the family's default" like the reference's SAMPLE_METHOD_COUNT (sd_get_default_sample_method,
+ * stable-diffusion.cpp:3965-3975): Euler for the DiT families (SD3.5, FLUX), Euler-A otherwise */
+enum sdm_sample_method_t { SDM_EULER_SAMPLE_METHOD = 0, SDM_EULER_A_SAMPLE_METHOD = 1, SDM_SAMPLE_METHOD_COUNT = 2 };
+enum sdm_scheduler_t { SDM_DISCRETE_SCHEDULER = 0 };
 
 typedef struct {
     const char* backend;        /* ggml device name, case-insensitive; NULL -> "MI355X0" (stable-diffusion.h:232) */
     enum sd_model_family_t model;
-    enum sd_type_t wtype;       /* Linear weight type (conv stays f16, norms/bias f32 — SURVEY.md F9) */
+    enum sdm_type_t wtype;       /* Linear weight type (conv stays f16, norms/bias f32 — SURVEY.md F9) */
     bool diffusion_flash_attn;  /* stable-diffusion.h:223 */
     bool diffusion_conv_direct; /* stable-diffusion.h:225 */
     bool vae_decode_only;       /* always true here */
     uint64_t weight_seed;       /* synthetic-weight seed (1234) */
     int n_threads;              /* only reaches CPU backends (ggml_extend.hpp:2838-2843) */
-} sd_ctx_params_t;
+} sdm_ctx_params_t;
 
 typedef struct {
     float txt_cfg;              /* cfg scale (7.0 default, stable-diffusion.cpp:3650-3667) */
-    enum scheduler_t scheduler;
-    enum sample_method_t sample_method;
+    enum sdm_scheduler_t scheduler;
+    enum sdm_sample_method_t sample_method;
     int sample_steps;
     float eta;                  /* INFINITY -> 1.0 for Euler-A (stable-diffusion.cpp:4024-4049) */
-} sd_sample_params_t;
+} sdm_sample_params_t;
 
 /* SDCondition (conditioner.hpp:18-34): c_crossattn [ctx_dim, n_tokens], c_vector [adm] (SDXL) */
 typedef struct {
@@ -95,7 +108,7 @@ typedef struct {
     sd_condition_t cond;
     sd_condition_t uncond;      /* used iff txt_cfg != 1 (stable-diffusion.cpp:4249) */
     int width, height;          /* pixels; latent = /8 */
-    sd_sample_params_t sample_params;
+    sdm_sample_params_t sample_params;
     int64_t seed;
     int batch_count;            /* images seed .. seed+batch_count-1 (stable-diffusion.cpp:5664-5683) */
     int device_batch;           /* OUR extension: images denoised together per graph; 0 -> batch_count */
@@ -105,14 +118,14 @@ typedef struct {
     bool device_sampler;        /* OUR extension: the whole iteration — x*c_in, model pair, CFG combine, Euler(-A) update —
                                    is one graph per step on latents that stay in a backend buffer; nothing crosses back to the host until
                                    the last step (the reference's three crossings per model call: stable-diffusion.cpp:2636-2664, 2855-2896) */
-} sd_img_gen_params_t;
+} sdm_img_gen_params_t;
 
 typedef struct {
     uint32_t width, height, channel;
     uint8_t* data;
-} sd_image_t;
+} sdm_image_t;
 
-typedef struct sd_ctx_t sd_ctx_t;
+typedef struct sdm_ctx_t sdm_ctx_t;
 
 /* ---- backend discovery (GGML_BACKEND_DL) ---- */
 SD_API bool sd_load_backend(const char* path); /* dlopen a libggml-<name>.so and register its devices */
@@ -121,53 +134,53 @@ SD_API const char* sd_device_name(int i);
 SD_API const char* sd_device_description(int i);
 
 /* ---- context ---- */
-SD_API void sd_ctx_params_init(sd_ctx_params_t* p);
-SD_API void sd_sample_params_init(sd_sample_params_t* p);
-SD_API void sd_img_gen_params_init(sd_img_gen_params_t* p);
-SD_API sd_ctx_t* new_sd_ctx(const sd_ctx_params_t* params); /* NULL on failure (no device, alloc failure) */
-SD_API void free_sd_ctx(sd_ctx_t* ctx);
+SD_API void sdm_ctx_params_init(sdm_ctx_params_t* p);
+SD_API void sdm_sample_params_init(sdm_sample_params_t* p);
+SD_API void sdm_img_gen_params_init(sdm_img_gen_params_t* p);
+SD_API sdm_ctx_t* sdm_new_ctx(const sdm_ctx_params_t* params); /* NULL on failure (no device, alloc failure) */
+SD_API void sdm_free_ctx(sdm_ctx_t* ctx);
 SD_API const char* sd_last_error(void);
 
 /* ---- weights by name ("model.diffusion_model.<...>", "first_stage_model.<...>") ---- */
-SD_API int64_t sd_tensor_count(sd_ctx_t* ctx);
-SD_API const char* sd_tensor_name(sd_ctx_t* ctx, int64_t i);
+SD_API int64_t sd_tensor_count(sdm_ctx_t* ctx);
+SD_API const char* sd_tensor_name(sdm_ctx_t* ctx, int64_t i);
 /* ne[4], ggml type; returns false if unknown */
-SD_API bool sd_tensor_info(sd_ctx_t* ctx, const char* name, int64_t* ne, int* type, size_t* nbytes);
-SD_API bool sd_get_tensor(sd_ctx_t* ctx, const char* name, void* dst, size_t nbytes);       /* raw bytes (device -> host) */
-SD_API bool sd_get_tensor_f32(sd_ctx_t* ctx, const char* name, float* dst, int64_t nelem);  /* dequantised */
-SD_API bool sd_set_tensor_f32(sd_ctx_t* ctx, const char* name, const float* src, int64_t nelem); /* converts per stored type */
+SD_API bool sd_tensor_info(sdm_ctx_t* ctx, const char* name, int64_t* ne, int* type, size_t* nbytes);
+SD_API bool sd_get_tensor(sdm_ctx_t* ctx, const char* name, void* dst, size_t nbytes);       /* raw bytes (device -> host) */
+SD_API bool sd_get_tensor_f32(sdm_ctx_t* ctx, const char* name, float* dst, int64_t nelem);  /* dequantised */
+SD_API bool sd_set_tensor_f32(sdm_ctx_t* ctx, const char* name, const float* src, int64_t nelem); /* converts per stored type */
 
 /* ---- checkpoint files: safetensors (F32/F16/BF16) and GGUF v2/v3 (F32/F16/BF16/Q8_0/Q4_0) ----
  * Every parameter the model declares that the file names (original-LDM / sd.cpp GGUF names, e.g. "model.diffusion_model.input_blocks.0.0.weight")
  * is converted file dtype -> f32 -> the parameter's type (ModelLoader convert_tensor, src/model_loader.cpp:155-205) and uploaded.
  * Returns the number of parameters loaded, -1 on error (sd_last_error); *n_missing = declared but absent, *n_unused = in the file but unknown. */
-SD_API int64_t sd_load_weights(sd_ctx_t* ctx, const char* path, int64_t* n_missing, int64_t* n_unused);
+SD_API int64_t sd_load_weights(sdm_ctx_t* ctx, const char* path, int64_t* n_missing, int64_t* n_unused);
 /* Same, with `prefix` prepended to every file name first — diffusers keeps one file per sub-model whose names carry no component prefix
  * ("unet." / "vae." / "text_encoder." / "text_encoder_2.", model_loader.cpp init_from_diffusers_file).  File names are rewritten to the
  * engine's canonical dialect before matching (src/name_conversion.cpp): diffusers UNet / VAE names, OpenCLIP text-tower names (fused
  * in_proj rows are split into q/k/v), "conditioner.embedders.N.", "te1." … component aliases, llama.cpp-style T5 GGUF names. */
-SD_API int64_t sd_load_weights_prefixed(sd_ctx_t* ctx, const char* path, const char* prefix, int64_t* n_missing, int64_t* n_unused);
-SD_API bool sd_convert_tensor_name(sd_ctx_t* ctx, const char* name, char* out, size_t out_capacity); /* convert_tensor_name, name_conversion.cpp:1346 */
+SD_API int64_t sd_load_weights_prefixed(sdm_ctx_t* ctx, const char* path, const char* prefix, int64_t* n_missing, int64_t* n_unused);
+SD_API bool sd_convert_tensor_name(sdm_ctx_t* ctx, const char* name, char* out, size_t out_capacity); /* convert_tensor_name, name_conversion.cpp:1346 */
 
 /* ---- the hot path ---- */
 /* one diffusion-model forward (DiffusionModelRunner::compute, unet.hpp:818-858): x [W,H,C,N] f32,
  * timesteps [N], context [ctx_dim,n_tokens,N or 1], y [adm,N or 1] or NULL -> out [W,H,C,N] */
-SD_API bool sd_unet_forward(sd_ctx_t* ctx, const float* x, int w, int h, int c, int n, const float* timesteps,
+SD_API bool sd_unet_forward(sdm_ctx_t* ctx, const float* x, int w, int h, int c, int n, const float* timesteps,
                             const float* context, int64_t ctx_dim, int64_t n_tokens, int64_t ctx_n,
                             const float* y, int64_t y_dim, int64_t y_n, float* out);
 /* VAE decode_first_stage (stable-diffusion.cpp:3062-3078): latents [w,h,zc,n] (diffusion scale) -> rgb f32 [8w,8h,3,n] in [0,1] */
-SD_API bool sd_vae_decode(sd_ctx_t* ctx, const float* latents, int w, int h, int c, int n, float* out_rgb);
+SD_API bool sd_vae_decode(sdm_ctx_t* ctx, const float* latents, int w, int h, int c, int n, float* out_rgb);
 /* sample(): init noise (Philox seed+b) -> Euler(-A) loop with CFG -> final latents [w,h,c,batch_count] */
-SD_API bool sd_sample_latents(sd_ctx_t* ctx, const sd_img_gen_params_t* p, float* out_latents);
-/* generate_image: sample + decode + uint8 RGB.  Caller frees with free_sd_images (library callocs). */
-SD_API bool generate_image(sd_ctx_t* ctx, const sd_img_gen_params_t* p, sd_image_t** images_out, int* num_images_out);
-SD_API void free_sd_images(sd_image_t* images, int num_images);
+SD_API bool sd_sample_latents(sdm_ctx_t* ctx, const sdm_img_gen_params_t* p, float* out_latents);
+/* sdm_generate_image: sample + decode + uint8 RGB.  Caller frees with sdm_free_images (library callocs). */
+SD_API bool sdm_generate_image(sdm_ctx_t* ctx, const sdm_img_gen_params_t* p, sdm_image_t** images_out, int* num_images_out);
+SD_API void sdm_free_images(sdm_image_t* images, int num_images);
 
 /* ---- host-side sampler pieces exposed for known-answer tests ---- */
 SD_API void sd_philox_randn(uint64_t seed, uint32_t offset, uint32_t n, float* out); /* rng_philox.hpp:101-122 */
 SD_API void sd_philox_uint32(uint64_t seed, uint32_t offset, uint32_t n, uint32_t* out /* 4*n words */); /* the integer stage alone: philox4_32, rng_philox.hpp:63-77 */
 SD_API int sd_get_sigmas(int steps, float* out /* steps+1 */);                       /* denoiser.hpp:32-54 + stable-diffusion.cpp:173-186 */
-SD_API void sd_set_guidance(sd_ctx_t* ctx, float guidance); /* FLUX distilled-guidance input (default 3.5, stable-diffusion.h guidance.distilled_guidance) */
+SD_API void sd_set_guidance(sdm_ctx_t* ctx, float guidance); /* FLUX distilled-guidance input (default 3.5, stable-diffusion.h guidance.distilled_guidance) */
 SD_API int sd_get_flux_sigmas(int steps, int image_seq_len, float* out /* steps+1 */); /* FluxScheduler, denoiser.hpp:726-782 */
 SD_API int sd_gen_flux_pe(int h, int w, int patch_size, int context_len, const int* axes_dim, int n_axes, float theta, float* out); /* Rope::gen_flux_pe; returns floats written */
 SD_API int sd_get_flow_sigmas(int steps, float shift, float* out /* steps+1 */);    /* DiscreteFlowDenoiser, denoiser.hpp:1239-1283 (t = 1000*sigma) */
@@ -175,7 +188,7 @@ SD_API float sd_sigma_to_t(float sigma);                                        
 
 /* ---- timing / introspection ---- */
 typedef struct {
-    double last_sample_ms;  /* denoise loop wall time of the last sd_sample_latents / generate_image */
+    double last_sample_ms;  /* denoise loop wall time of the last sd_sample_latents / sdm_generate_image */
     double last_decode_ms;  /* VAE decode wall time */
     int64_t unet_calls;     /* graph computes issued */
     int64_t graph_nodes;    /* nodes in the last UNet graph */
@@ -186,7 +199,7 @@ typedef struct {
     double host_build_ms, host_alloc_ms, host_submit_ms;
     int64_t graph_cache_hits; /* denoiser calls that replayed the cached graph (same shapes as the previous call) instead of rebuilding it */
 } sd_stats_t;
-SD_API void sd_get_stats(sd_ctx_t* ctx, sd_stats_t* out);
+SD_API void sd_get_stats(sdm_ctx_t* ctx, sd_stats_t* out);
 /* ---- text encoders + conditioner --------------------------------------------------------
  * CLIP text towers (src/model/te/clip.hpp) and the T5 encoder (src/model/te/t5.hpp) as graphs on the same backend, and the
  * conditioner composition of src/conditioning/conditioner.hpp (SD1.x/SDXL :414-544, SD3 :842-1015, FLUX :1209-1297).  Inputs are
@@ -198,17 +211,17 @@ typedef struct {
     const float* weights; /* NULL = all 1.0 */
     int n;                /* multiple of the chunk length: 77 for CLIP and SD3's T5, 256 for FLUX's T5 */
 } sd_token_list_t;
-SD_API bool sd_text_encoders_init(sd_ctx_t* ctx);
+SD_API bool sd_text_encoders_init(sdm_ctx_t* ctx);
 /* which: 0 = clip_l (ViT-L/14), 1 = clip_g (ViT-bigG/14).  CLIPTextModelRunner::compute (clip.hpp:562-583): hidden states
  * [hidden, n_tokens] after layer n_layer - clip_skip (clip_skip <= 0: all layers), or with return_pooled the final-LN'd row
  * max_token_idx (times text_projection for bigG).  Returns floats written, -1 on error. */
-SD_API int64_t sd_clip_forward(sd_ctx_t* ctx, int which, const int32_t* ids, int n_tokens, int max_token_idx, bool return_pooled, int clip_skip, float* out,
+SD_API int64_t sd_clip_forward(sdm_ctx_t* ctx, int which, const int32_t* ids, int n_tokens, int max_token_idx, bool return_pooled, int clip_skip, float* out,
                                int64_t out_capacity);
-SD_API int64_t sd_t5_forward(sd_ctx_t* ctx, const int32_t* ids, int n_tokens, float* out, int64_t out_capacity); /* T5Runner::compute, t5.hpp:452-461 */
+SD_API int64_t sd_t5_forward(sdm_ctx_t* ctx, const int32_t* ids, int n_tokens, float* out, int64_t out_capacity); /* T5Runner::compute, t5.hpp:452-461 */
 SD_API int sd_t5_relative_position_buckets(int q_len, int k_len, int32_t* out /* q_len*k_len */);                 /* t5.hpp:463-530 */
 /* token ids -> SDCondition.  crossattn_ne = {ctx_dim, n_tokens}; pass NULL output pointers to query the sizes first.  clip_g / t5
  * are ignored by families that do not own them (SD1.x and SDXL derive the bigG ids from clip_l like the reference). */
-SD_API bool sd_get_learned_condition(sd_ctx_t* ctx, const sd_token_list_t* clip_l, const sd_token_list_t* clip_g, const sd_token_list_t* t5, int clip_skip,
+SD_API bool sd_get_learned_condition(sdm_ctx_t* ctx, const sd_token_list_t* clip_l, const sd_token_list_t* clip_g, const sd_token_list_t* t5, int clip_skip,
                                      int width, int height, bool zero_out_masked, float* crossattn_out, int64_t crossattn_capacity, int64_t* crossattn_ne,
                                      float* vector_out, int64_t vector_capacity, int64_t* vector_n);
 

@@ -27,7 +27,7 @@ TYPE_SIZE = {F32: 4, F16: 2, BF16: 2, I32: 4}
 
 # sd_model_family_t
 SD15, SDXL, SD15_TINY, SDXL_TINY, SD35_LARGE, SD35_TINY, FLUX_DEV, FLUX_TINY, SD35_WIDE2, FLUX_WIDE1 = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
-EULER, EULER_A = 0, 1
+EULER, EULER_A, SAMPLE_METHOD_DEFAULT = 0, 1, 2   # DEFAULT: Euler for the DiT families, Euler-A otherwise (sd_get_default_sample_method)
 
 
 class EngineError(RuntimeError):
@@ -114,7 +114,7 @@ ggml_soft_max_inplace ggml_soft_max_ext ggml_im2col ggml_conv_2d ggml_conv_2d_di
 ggml_timestep_embedding ggml_flash_attn_ext ggml_new_graph ggml_new_graph_custom ggml_graph_node ggml_set_name
 ggml_gallocr_new ggml_backend_load ggml_backend_dev_get ggml_backend_dev_by_name ggml_backend_dev_init
 ggml_backend_get_default_buffer_type ggml_backend_alloc_ctx_tensors ggml_backend_dev_buffer_type ggml_unary
-ggml_unary_inplace ggml_get_rows ggml_dup new_sd_ctx""".split()
+ggml_unary_inplace ggml_get_rows ggml_dup sdm_new_ctx""".split()
 
 
 def lib() -> C.CDLL:
@@ -218,11 +218,11 @@ def lib() -> C.CDLL:
     L.sd_device_description.argtypes = [C.c_int]
     L.sd_device_description.restype = C.c_char_p
     L.sd_last_error.restype = C.c_char_p
-    L.sd_ctx_params_init.argtypes = [C.POINTER(SdCtxParams)]
-    L.sd_sample_params_init.argtypes = [C.POINTER(SdSampleParams)]
-    L.sd_img_gen_params_init.argtypes = [C.POINTER(SdImgGenParams)]
-    L.new_sd_ctx.argtypes = [C.POINTER(SdCtxParams)]
-    L.free_sd_ctx.argtypes = [C.c_void_p]
+    L.sdm_ctx_params_init.argtypes = [C.POINTER(SdCtxParams)]
+    L.sdm_sample_params_init.argtypes = [C.POINTER(SdSampleParams)]
+    L.sdm_img_gen_params_init.argtypes = [C.POINTER(SdImgGenParams)]
+    L.sdm_new_ctx.argtypes = [C.POINTER(SdCtxParams)]
+    L.sdm_free_ctx.argtypes = [C.c_void_p]
     L.sd_tensor_count.argtypes = [C.c_void_p]
     L.sd_tensor_count.restype = C.c_int64
     L.sd_tensor_name.argtypes = [C.c_void_p, C.c_int64]
@@ -240,9 +240,9 @@ def lib() -> C.CDLL:
     L.sd_vae_decode.restype = C.c_bool
     L.sd_sample_latents.argtypes = [C.c_void_p, C.POINTER(SdImgGenParams), C.c_void_p]
     L.sd_sample_latents.restype = C.c_bool
-    L.generate_image.argtypes = [C.c_void_p, C.POINTER(SdImgGenParams), C.POINTER(C.POINTER(SdImage)), C.POINTER(C.c_int)]
-    L.generate_image.restype = C.c_bool
-    L.free_sd_images.argtypes = [C.POINTER(SdImage), C.c_int]
+    L.sdm_generate_image.argtypes = [C.c_void_p, C.POINTER(SdImgGenParams), C.POINTER(C.POINTER(SdImage)), C.POINTER(C.c_int)]
+    L.sdm_generate_image.restype = C.c_bool
+    L.sdm_free_images.argtypes = [C.POINTER(SdImage), C.c_int]
     L.sd_philox_randn.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p]
     L.sd_philox_uint32.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p]
     L.sd_get_sigmas.argtypes = [C.c_int, C.c_void_p]
@@ -363,14 +363,14 @@ def _f32(a) -> np.ndarray:
 
 
 class Engine:
-    """RAII wrapper over sd_ctx_t.  Array layouts are ggml's: ne0 fastest == numpy C-order reversed, i.e. a latent
+    """RAII wrapper over sdm_ctx_t.  Array layouts are ggml's: ne0 fastest == numpy C-order reversed, i.e. a latent
     batch is a numpy array of shape [N, C, H, W]."""
 
     def __init__(self, model: int = SD15, backend: str | None = None, wtype: int = F16, flash_attn: bool = False,
                  conv_direct: bool = False, weight_seed: int = 1234):
         L = lib()
         p = SdCtxParams()
-        L.sd_ctx_params_init(C.byref(p))
+        L.sdm_ctx_params_init(C.byref(p))
         if backend is None:
             load_mi355x_backend()
             backend = "MI355X0"
@@ -381,14 +381,14 @@ class Engine:
         p.diffusion_flash_attn = flash_attn
         p.diffusion_conv_direct = conv_direct
         p.weight_seed = weight_seed
-        self._ctx = L.new_sd_ctx(C.byref(p))
+        self._ctx = L.sdm_new_ctx(C.byref(p))
         if not self._ctx:
-            raise EngineError("new_sd_ctx failed: " + L.sd_last_error().decode())
+            raise EngineError("sdm_new_ctx failed: " + L.sd_last_error().decode())
         self.model = model
 
     def close(self):
         if getattr(self, "_ctx", None):
-            lib().free_sd_ctx(self._ctx)
+            lib().sdm_free_ctx(self._ctx)
             self._ctx = None
 
     def __del__(self):
@@ -542,7 +542,7 @@ class Engine:
     def _gen_params(self, cond, uncond, width, height, steps, cfg, seed, batch, device_batch, method, eta, cond_y=None, uncond_y=None,
                     fuse_cfg=False, device_sampler=False):
         p = SdImgGenParams()
-        lib().sd_img_gen_params_init(C.byref(p))
+        lib().sdm_img_gen_params_init(C.byref(p))
         keep = []
 
         def fill(dst, ctx_arr, vec):
@@ -572,7 +572,7 @@ class Engine:
         return p, keep
 
     def sample_latents(self, cond, uncond=None, width=512, height=512, steps=20, cfg=7.0, seed=42, batch=1, device_batch=0,
-                       method=EULER_A, eta=float("inf"), cond_y=None, uncond_y=None, fuse_cfg=False, device_sampler=False) -> np.ndarray:
+                       method=SAMPLE_METHOD_DEFAULT, eta=float("inf"), cond_y=None, uncond_y=None, fuse_cfg=False, device_sampler=False) -> np.ndarray:
         p, keep = self._gen_params(cond, uncond, width, height, steps, cfg, seed, batch, device_batch, method, eta, cond_y, uncond_y, fuse_cfg,
                                    device_sampler)
         ch = 16 if self.model in (SD35_LARGE, SD35_TINY, FLUX_DEV, FLUX_TINY, SD35_WIDE2, FLUX_WIDE1) else 4
@@ -582,18 +582,18 @@ class Engine:
         return out
 
     def generate_image(self, cond, uncond=None, width=512, height=512, steps=20, cfg=7.0, seed=42, batch=1, device_batch=0,
-                       method=EULER_A, eta=float("inf"), cond_y=None, uncond_y=None, fuse_cfg=False, device_sampler=False) -> np.ndarray:
+                       method=SAMPLE_METHOD_DEFAULT, eta=float("inf"), cond_y=None, uncond_y=None, fuse_cfg=False, device_sampler=False) -> np.ndarray:
         """-> uint8 [batch, H, W, 3]"""
         p, keep = self._gen_params(cond, uncond, width, height, steps, cfg, seed, batch, device_batch, method, eta, cond_y, uncond_y, fuse_cfg,
                                    device_sampler)
         imgs = C.POINTER(SdImage)()
         n = C.c_int()
-        if not lib().generate_image(self._ctx, C.byref(p), C.byref(imgs), C.byref(n)):
-            raise EngineError("generate_image failed: " + lib().sd_last_error().decode())
+        if not lib().sdm_generate_image(self._ctx, C.byref(p), C.byref(imgs), C.byref(n)):
+            raise EngineError("sdm_generate_image failed: " + lib().sd_last_error().decode())
         out = np.empty((n.value, height, width, 3), dtype=np.uint8)
         for i in range(n.value):
             out[i] = np.ctypeslib.as_array(imgs[i].data, shape=(height, width, 3))
-        lib().free_sd_images(imgs, n.value)
+        lib().sdm_free_images(imgs, n.value)
         return out
 
     def stats(self) -> dict:

@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "ggml-abi.h"
+#include "ggml-abi-check.h"  // static_asserts: every layout fact of ggml's headers this backend was written against
 #include "ggml-mi355x.h"
 #include "planner.h"
 

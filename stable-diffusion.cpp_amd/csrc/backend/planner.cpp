@@ -52,6 +52,7 @@ using Step = std::function<void(hipStream_t)>;
 
 struct Plan {
     int n_nodes = 0;
+    uint64_t check = 0;  // second, independently mixed hash of the graph: verified on every cache hit (a 64-bit key alone could collide)
     size_t arena_needed = 0;
     std::vector<Step> steps;
     hipGraphExec_t graph_exec = nullptr;
@@ -133,27 +134,52 @@ static inline uint64_t mix_words(uint64_t h, const void* p, size_t n) {
     return h;
 }
 
-uint64_t graph_key(const ggml_cgraph* g) {
-    uint64_t h = 1469598103934665603ull;
-    h          = mix_words(h, &g->n_nodes, sizeof(g->n_nodes));
+// Two independently mixed 64-bit hashes in one pass: `key` indexes the plan cache, `check` is stored in the plan and compared on a hit
+// (round-1 advice: a cached launch list holds raw device addresses — replaying the wrong one corrupts results silently).  Everything a
+// fusion decision reads is hashed: per node op / type / flags / shape / strides / params / address, per source its address, type,
+// shape, strides, OP, view offset and whether it lives in a WEIGHTS buffer.
+struct GraphKey {
+    uint64_t key, check;
+};
+static inline void mix2(uint64_t& a, uint64_t& b, const void* p, size_t n) {
+    a = mix_words(a, p, n);
+    const unsigned char* c = (const unsigned char*)p;
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        uint64_t w;
+        memcpy(&w, c + i, 8);
+        b = ((b << 27) | (b >> 37)) + w * 0xC2B2AE3D27D4EB4Full;
+        b ^= b >> 33;
+    }
+    if (i < n) {
+        uint64_t w = 0;
+        memcpy(&w, c + i, n - i);
+        b = ((b << 27) | (b >> 37)) + (w ^ ((uint64_t)(n - i) << 56)) * 0xC2B2AE3D27D4EB4Full;
+        b ^= b >> 33;
+    }
+}
+GraphKey graph_key(const ggml_cgraph* g) {
+    uint64_t h = 1469598103934665603ull, k = 0x165667B19E3779F9ull;
+    mix2(h, k, &g->n_nodes, sizeof(g->n_nodes));
     for (int i = 0; i < g->n_nodes; ++i) {
         const ggml_tensor* n = g->nodes[i];
         const int32_t head[4] = {(int32_t)n->op, (int32_t)n->type, n->flags & GGML_TENSOR_FLAG_OUTPUT, i};
-        h = mix_words(h, head, sizeof(head));
-        h = mix_words(h, n->ne, sizeof(n->ne));
-        h = mix_words(h, n->nb, sizeof(n->nb));
-        h = mix_words(h, n->op_params, sizeof(n->op_params));
-        h = mix_words(h, &n->data, sizeof(n->data));
+        mix2(h, k, head, sizeof(head));
+        mix2(h, k, n->ne, sizeof(n->ne));
+        mix2(h, k, n->nb, sizeof(n->nb));
+        mix2(h, k, n->op_params, sizeof(n->op_params));
+        mix2(h, k, &n->data, sizeof(n->data));
         for (int j = 0; j < GGML_MAX_SRC; ++j) {
             const ggml_tensor* s = n->src[j];
             if (!s) break;
-            const uint64_t sh[2] = {(uint64_t)(uintptr_t)s->data, ((uint64_t)(uint32_t)s->type << 32) | (uint32_t)j};
-            h = mix_words(h, sh, sizeof(sh));
-            h = mix_words(h, s->ne, sizeof(s->ne));
-            h = mix_words(h, s->nb, sizeof(s->nb));
+            const uint64_t sh[4] = {(uint64_t)(uintptr_t)s->data, ((uint64_t)(uint32_t)s->type << 32) | (uint32_t)j,
+                                    ((uint64_t)(uint32_t)s->op << 32) | (is_static_weight(s) ? 1u : 0u), (uint64_t)s->view_offs};
+            mix2(h, k, sh, sizeof(sh));
+            mix2(h, k, s->ne, sizeof(s->ne));
+            mix2(h, k, s->nb, sizeof(s->nb));
         }
     }
-    return h;
+    return {h, k};
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -569,8 +595,6 @@ void plan_linear(Builder& B, int i, hipStream_t s, std::vector<int>& chain) {
                 launch_gemm16_linear(st, dst, nullptr, 0, P->arena + off, ld, swz, tokens, K, M, M, ep, 0, 0, 0, S > 1 ? (float*)(P->arena + wsoff) : nullptr);
             });
         }
-    } else {
-        B.emit([=](hipStream_t st) { launch_linear_mfma(st, dst, xp, swz, tokens, K, M, xs, M, ep); });
     }
     g_stats.fused_linear++;
 }
@@ -673,47 +697,7 @@ bool plan_conv_chain(Builder& B, int i, hipStream_t s, std::vector<int>& chain) 
         g_stats.fused_conv++;
         return true;
     }
-    const float* xp  = (const float*)x->data;
-    const size_t xb  = ggml_abi_nbytes(x);
-    const int64_t W = x->ne[0], H = x->ne[1];
-    float* kdst = final_dst;
-    if (overlaps(final_dst, ob, xp, xb)) {
-        // the allocator recycled the conv input for the chain's output: bounce through a dead intermediate
-        float* cand1 = (float*)gi.node(j2)->data;                                  // MUL_MAT output, same byte size
-        float* cand2 = ggml_abi_nbytes(im) >= ob ? (float*)im->data : nullptr;     // im2col buffer (never written by us)
-        auto clean   = [&](float* c) {
-            return c && !overlaps(c, ob, xp, xb) && !overlaps(c, ob, final_dst, ob) && (!ep.residual || !overlaps(c, ob, ep.residual, ob));
-        };
-        if (clean(cand1))
-            kdst = cand1;
-        else if (clean(cand2))
-            kdst = cand2;
-        else
-            return false;  // fall back to the unfused path
-        g_stats.fused_conv_bounced++;
-    }
-    if (kdst == final_dst) {
-        B.emit([=](hipStream_t st) { launch_conv2d_mfma(st, final_dst, xp, swz, W, H, IC, N, OC, ks, st_, pd, false, ep); });
-    } else {
-        const int64_t nel = ggml_abi_nelements(out);
-        B.emit([=](hipStream_t st) {
-            launch_conv2d_mfma(st, kdst, xp, swz, W, H, IC, N, OC, ks, st_, pd, false, ep);
-            View4 d, sv;
-            d.data = final_dst;
-            sv.data = kdst;
-            d.type = sv.type = 0;
-            d.ne[0] = sv.ne[0] = nel;
-            d.nb[0] = sv.nb[0] = 4;
-            for (int q = 1; q < 4; ++q) {
-                d.ne[q] = sv.ne[q] = 1;
-                d.nb[q] = sv.nb[q] = nel * 4;
-            }
-            launch_copy(st, d, sv);
-        });
-        g_stats.kernels_planned++;
-    }
-    g_stats.fused_conv++;
-    return true;
+    return false;  // unreachable: option "gemm16" is always on (the first-generation kernels behind gemm16=0 were removed in round 2)
 }
 
 // GROUP_NORM -> MUL -> ADD [-> SILU]
@@ -1204,8 +1188,7 @@ bool plan_single(Builder& B, int i, hipStream_t s) {
                 B.emit([=](hipStream_t st) { launch_gemm16_conv(st, dst, P->arena + off, swz, W, H, IC, N, OC, ks, st_, pd, false, ep); });
                 return true;
             }
-            B.emit([=](hipStream_t st) { launch_conv2d_mfma(st, dst, xp, swz, W, H, IC, N, OC, ks, st_, pd, false, ep); });
-            return true;
+            return false;  // unreachable (gemm16 is always on)
         }
         case GGML_OP_CONCAT: {
             View4 d = view_of(n), a = view_of(n->src[0]), b = view_of(n->src[1]);
@@ -1437,15 +1420,22 @@ void planner_forget_range(const void* ptr, size_t size) {
 enum ggml_status planner_compute(Planner* p, ggml_cgraph* g, hipStream_t stream) {
     std::lock_guard<std::mutex> lk(g_mu);
     g_stats.graphs_computed++;
-    const uint64_t key = graph_key(g);
+    const GraphKey gk  = graph_key(g);
+    const uint64_t key = gk.key;
     Plan* plan         = nullptr;
     auto it            = p->plans.find(key);
-    if (it != p->plans.end() && it->second->n_nodes == g->n_nodes) {
+    if (it != p->plans.end() && it->second->n_nodes == g->n_nodes && it->second->check == gk.check) {
         plan = it->second.get();
     } else {
+        if (it != p->plans.end()) {  // same key, different graph: the old launch list must never be replayed for this one
+            (void)hipStreamSynchronize(stream);
+            if (it->second->graph_exec) (void)hipGraphExecDestroy(it->second->graph_exec);
+            p->plans.erase(it);
+        }
         std::unique_ptr<Plan> np(new Plan());
         if (!build_plan(p, np.get(), g, stream)) return GGML_STATUS_FAILED;
-        plan         = np.get();
+        np->check     = gk.check;
+        plan          = np.get();
         p->plans[key] = std::move(np);
     }
     if (plan->arena_needed > p->arena_cap) {
@@ -1627,7 +1617,10 @@ void planner_set_option(const char* key, int value) {
     else if (!strcmp(key, "mfma_gemm")) g_opt.mfma_gemm = value;
     else if (!strcmp(key, "hip_graph")) g_opt.hip_graph = value;
     else if (!strcmp(key, "flash_pattern")) g_opt.flash_pattern = value;
-    else if (!strcmp(key, "gemm16")) g_opt.gemm16 = value;
+#ifdef MI355X_EXPERIMENTS
+    else if (!strcmp(key, "flash_ablate")) flash_attn_set_ablate(value);
+#endif
+    else if (!strcmp(key, "gemm16")) (void)value;  // kept for old scripts: the gemm16 path is the only one (first-generation kernels removed)
     else if (!strcmp(key, "fuse_modulate")) g_opt.fuse_modulate = value;
     else if (!strcmp(key, "fuse_gate")) g_opt.fuse_gate = value;
     else if (!strcmp(key, "fuse_gelu")) g_opt.fuse_gelu = value;
@@ -1636,10 +1629,7 @@ void planner_set_option(const char* key, int value) {
     else if (!strcmp(key, "gemm16_variant")) gemm16_set_variant(value);
     else if (!strcmp(key, "conv_tap_major")) gemm16_set_tap_major(value);
     else if (!strcmp(key, "gemm16_tile")) gemm16_set_tile(value);
-    else if (!strcmp(key, "gemm16_sched")) gemm16_set_sched(value);
-    else if (!strcmp(key, "gemm16_adirect")) gemm16_set_adirect(value);
     else if (!strcmp(key, "splitk_mid")) gemm16_set_splitk_mid(value);
-    else if (!strcmp(key, "flash_ablate")) flash_attn_set_ablate(value);
     else if (!strcmp(key, "splitk_target")) gemm16_set_splitk_target(value);
     // options change what a plan contains: drop cached plans
     std::lock_guard<std::mutex> lk(g_mu);

@@ -6,7 +6,7 @@
 //   sample_euler_ancestral / sample_euler    src/runtime/denoiser.hpp:1513-1546, 1582-1597
 //   ClassifierFreeGuidance::forward          src/runtime/guidance.cpp:149-179
 //   decode_first_stage / VAE::decode         src/stable-diffusion.cpp:3062-3078, src/model/vae/vae.hpp:170-222
-//   generate_image batch loop                src/stable-diffusion.cpp:5664-5721
+//   sdm_generate_image batch loop                src/stable-diffusion.cpp:5664-5721
 //
 // Like the reference, the graph is rebuilt for every model call; unlike it, `device_batch`
 // images are denoised together in ONE graph (N>1 is our extension, F6) — per-image results are defined
@@ -291,8 +291,8 @@ struct Runner {
     }
 };
 
-struct sd_ctx_t {
-    sd_ctx_params_t params;
+struct sdm_ctx_t {
+    sdm_ctx_params_t params;
     ggml_backend_t backend = nullptr;
     Runner unet_runner, vae_runner;
     UNetModel unet;
@@ -353,7 +353,7 @@ struct sd_ctx_t {
         }
         return v;
     }
-    ~sd_ctx_t() {
+    ~sdm_ctx_t() {
         // runners free their buffers in their destructors; the backend must outlive them
     }
 };
@@ -374,27 +374,27 @@ const char* sd_device_description(int i) {
     return d ? ggml_backend_dev_description(d) : nullptr;
 }
 
-void sd_ctx_params_init(sd_ctx_params_t* p) {
+void sdm_ctx_params_init(sdm_ctx_params_t* p) {
     memset(p, 0, sizeof(*p));
     p->backend              = nullptr;
     p->model                = SD_MODEL_SD15;
-    p->wtype                = SD_TYPE_F16;
+    p->wtype                = SDM_TYPE_F16;
     p->diffusion_flash_attn = false;
     p->vae_decode_only      = true;
     p->weight_seed          = 1234;
     p->n_threads            = -1;
 }
-void sd_sample_params_init(sd_sample_params_t* p) {  // stable-diffusion.cpp:3650-3667
+void sdm_sample_params_init(sdm_sample_params_t* p) {  // stable-diffusion.cpp:3650-3667
     memset(p, 0, sizeof(*p));
     p->txt_cfg       = 7.0f;
-    p->scheduler     = DISCRETE_SCHEDULER;
-    p->sample_method = EULER_A_SAMPLE_METHOD;
+    p->scheduler     = SDM_DISCRETE_SCHEDULER;
+    p->sample_method = SDM_SAMPLE_METHOD_COUNT;  // resolved per family at sampling time (sd_get_default_sample_method)
     p->sample_steps  = 20;
     p->eta           = INFINITY;
 }
-void sd_img_gen_params_init(sd_img_gen_params_t* p) {  // stable-diffusion.cpp:3710-3731
+void sdm_img_gen_params_init(sdm_img_gen_params_t* p) {  // stable-diffusion.cpp:3710-3731
     memset(p, 0, sizeof(*p));
-    sd_sample_params_init(&p->sample_params);
+    sdm_sample_params_init(&p->sample_params);
     p->width       = 512;
     p->height      = 512;
     p->seed        = 42;
@@ -414,7 +414,7 @@ static std::string self_dir() {
     return ".";
 }
 
-sd_ctx_t* new_sd_ctx(const sd_ctx_params_t* params) {
+sdm_ctx_t* sdm_new_ctx(const sdm_ctx_params_t* params) {
     const char* dev_name = params->backend ? params->backend : "MI355X0";
     ggml_backend_dev_t dev = ggml_backend_dev_by_name(dev_name);
     if (!dev && !params->backend) {
@@ -435,7 +435,7 @@ sd_ctx_t* new_sd_ctx(const sd_ctx_params_t* params) {
         set_error("ggml_backend_dev_init failed");
         return nullptr;
     }
-    sd_ctx_t* ctx = new sd_ctx_t();
+    sdm_ctx_t* ctx = new sdm_ctx_t();
     ctx->params   = *params;
     ctx->backend  = backend;
 
@@ -473,7 +473,7 @@ sd_ctx_t* new_sd_ctx(const sd_ctx_params_t* params) {
 
     if (!ctx->unet_runner.alloc_weights(params->weight_seed) || !ctx->vae_runner.alloc_weights(params->weight_seed)) {
         set_error("weight buffer allocation failed");
-        free_sd_ctx(ctx);
+        sdm_free_ctx(ctx);
         return nullptr;
     }
     for (auto* r : {&ctx->unet_runner, &ctx->vae_runner})
@@ -482,23 +482,23 @@ sd_ctx_t* new_sd_ctx(const sd_ctx_params_t* params) {
     return ctx;
 }
 
-void free_sd_ctx(sd_ctx_t* ctx) {
+void sdm_free_ctx(sdm_ctx_t* ctx) {
     if (!ctx) return;
     ggml_backend_t b = ctx->backend;
     delete ctx;
     ggml_backend_free(b);
 }
 
-int64_t sd_tensor_count(sd_ctx_t* ctx) { return (int64_t)ctx->all_tensors.size(); }
-const char* sd_tensor_name(sd_ctx_t* ctx, int64_t i) { return ctx->all_tensors[i].first.c_str(); }
-static ggml_tensor* find_tensor(sd_ctx_t* ctx, const char* name) {
+int64_t sd_tensor_count(sdm_ctx_t* ctx) { return (int64_t)ctx->all_tensors.size(); }
+const char* sd_tensor_name(sdm_ctx_t* ctx, int64_t i) { return ctx->all_tensors[i].first.c_str(); }
+static ggml_tensor* find_tensor(sdm_ctx_t* ctx, const char* name) {
     for (Runner* r : ctx->runners()) {
         auto it = r->ps.by_name.find(name);
         if (it != r->ps.by_name.end()) return it->second;
     }
     return nullptr;
 }
-bool sd_tensor_info(sd_ctx_t* ctx, const char* name, int64_t* ne, int* type, size_t* nbytes) {
+bool sd_tensor_info(sdm_ctx_t* ctx, const char* name, int64_t* ne, int* type, size_t* nbytes) {
     ggml_tensor* t = find_tensor(ctx, name);
     if (!t) return false;
     for (int i = 0; i < 4; ++i) ne[i] = t->ne[i];
@@ -506,13 +506,13 @@ bool sd_tensor_info(sd_ctx_t* ctx, const char* name, int64_t* ne, int* type, siz
     *nbytes = ggml_nbytes(t);
     return true;
 }
-bool sd_get_tensor(sd_ctx_t* ctx, const char* name, void* dst, size_t nbytes) {
+bool sd_get_tensor(sdm_ctx_t* ctx, const char* name, void* dst, size_t nbytes) {
     ggml_tensor* t = find_tensor(ctx, name);
     if (!t || nbytes != ggml_nbytes(t)) return false;
     ggml_backend_tensor_get(t, dst, 0, nbytes);
     return true;
 }
-bool sd_get_tensor_f32(sd_ctx_t* ctx, const char* name, float* dst, int64_t nelem) {
+bool sd_get_tensor_f32(sdm_ctx_t* ctx, const char* name, float* dst, int64_t nelem) {
     ggml_tensor* t = find_tensor(ctx, name);
     if (!t || nelem != ggml_nelements(t)) return false;
     std::vector<uint8_t> raw(ggml_nbytes(t));
@@ -522,7 +522,7 @@ bool sd_get_tensor_f32(sd_ctx_t* ctx, const char* name, float* dst, int64_t nele
     for (int64_t r = 0; r < rows; ++r) ggml_dequantize_row(t->type, raw.data() + r * rs, dst + r * t->ne[0], t->ne[0]);
     return true;
 }
-bool sd_set_tensor_f32(sd_ctx_t* ctx, const char* name, const float* src, int64_t nelem) {
+bool sd_set_tensor_f32(sdm_ctx_t* ctx, const char* name, const float* src, int64_t nelem) {
     ggml_tensor* t = find_tensor(ctx, name);
     if (!t || nelem != ggml_nelements(t)) return false;
     std::vector<uint8_t> scratch;
@@ -534,9 +534,9 @@ bool sd_set_tensor_f32(sd_ctx_t* ctx, const char* name, const float* src, int64_
 // ModelLoader::load_tensors (src/model_loader.cpp:1180-1260): for every tensor the model declares that the file holds, convert
 // file dtype -> f32 -> the parameter's ggml type (convert_tensor, model_loader.cpp:155-205) and ggml_backend_tensor_set it.
 // Returns the number of parameters loaded, or -1 on a file / shape error; tensors the file does not name keep their current values.
-static bool ensure_text_encoders(sd_ctx_t* ctx);
+static bool ensure_text_encoders(sdm_ctx_t* ctx);
 
-static NameDialect name_dialect(const sd_ctx_t* ctx) {
+static NameDialect name_dialect(const sdm_ctx_t* ctx) {
     NameDialect d;
     d.unet_family = !ctx->is_dit;
     d.flux        = ctx->is_flux;
@@ -553,16 +553,16 @@ static NameDialect name_dialect(const sd_ctx_t* ctx) {
     return d;
 }
 
-bool sd_convert_tensor_name(sd_ctx_t* ctx, const char* name, char* out, size_t out_capacity) {
+bool sd_convert_tensor_name(sdm_ctx_t* ctx, const char* name, char* out, size_t out_capacity) {
     const std::string r = canonical_tensor_name(name, name_dialect(ctx));
     if (r.size() + 1 > out_capacity) return false;
     memcpy(out, r.c_str(), r.size() + 1);
     return true;
 }
 
-int64_t sd_load_weights(sd_ctx_t* ctx, const char* path, int64_t* n_missing, int64_t* n_unused) { return sd_load_weights_prefixed(ctx, path, nullptr, n_missing, n_unused); }
+int64_t sd_load_weights(sdm_ctx_t* ctx, const char* path, int64_t* n_missing, int64_t* n_unused) { return sd_load_weights_prefixed(ctx, path, nullptr, n_missing, n_unused); }
 
-int64_t sd_load_weights_prefixed(sd_ctx_t* ctx, const char* path, const char* prefix, int64_t* n_missing, int64_t* n_unused) {
+int64_t sd_load_weights_prefixed(sdm_ctx_t* ctx, const char* path, const char* prefix, int64_t* n_missing, int64_t* n_unused) {
     ModelFile mf;
     if (!read_model_file(path, mf)) {
         set_error(mf.error);
@@ -596,6 +596,8 @@ int64_t sd_load_weights_prefixed(sd_ctx_t* ctx, const char* path, const char* pr
     }
     std::map<std::string, const FileTensor*> dir;
     for (auto& t : expanded) dir[t.name] = &t;
+    std::map<std::string, std::string> undecodable;  // canonical name -> dtype the readers could not decode
+    for (auto& kv : mf.undecodable) undecodable[canonical_tensor_name(prefix ? std::string(prefix) + kv.first : kv.first, dialect)] = kv.second;
     if (names_te && !ensure_text_encoders(ctx)) return -1;  // like the conditioners' tensor_storage_map probes (conditioner.hpp:630-651)
     FILE* f = fopen(path, "rb");
     if (!f) {
@@ -609,6 +611,12 @@ int64_t sd_load_weights_prefixed(sd_ctx_t* ctx, const char* path, const char* pr
     for (auto& nt : ctx->all_tensors) {
         auto it = dir.find(nt.first);
         if (it == dir.end()) {
+            auto ud = undecodable.find(nt.first);
+            if (ud != undecodable.end()) {  // the file HAS this parameter, in a dtype we cannot read: leaving the synthetic weights in place would be silent garbage
+                set_error("tensor '" + nt.first + "' is stored as " + ud->second + ", which this build cannot decode");
+                fclose(f);
+                return -1;
+            }
             ++missing;
             continue;
         }
@@ -628,13 +636,24 @@ int64_t sd_load_weights_prefixed(sd_ctx_t* ctx, const char* path, const char* pr
             fclose(f);
             return -1;
         }
+        // the readers validated nbytes against the file's own shape; here against what the copies below will touch
+        const uint64_t want = ft.kind != SrcKind::NATIVE ? ft.nbytes : (uint64_t)ggml_row_size(ft.type, ft.ne[0]) * (uint64_t)(n / ft.ne[0]);
+        if (ft.nbytes != want || (ft.type == t->type && ft.kind == SrcKind::NATIVE && ft.nbytes != ggml_nbytes(t))) {
+            set_error("size mismatch for tensor '" + nt.first + "'");
+            fclose(f);
+            return -1;
+        }
         raw.resize(ft.nbytes);
         if (fseek(f, (long)ft.offset, SEEK_SET) != 0 || fread(raw.data(), 1, ft.nbytes, f) != ft.nbytes) {
             set_error("short read for " + nt.first);
             fclose(f);
             return -1;
         }
-        if (ft.type == t->type) {
+        if (ft.kind != SrcKind::NATIVE) {
+            f32.resize(n);
+            decode_src_kind(ft.kind, raw.data(), n, f32.data());
+            ctx->unet_runner.upload_f32(t, f32.data(), conv);
+        } else if (ft.type == t->type) {
             ggml_backend_tensor_set(t, raw.data(), 0, ggml_nbytes(t));
         } else {
             f32.resize(n);
@@ -655,9 +674,9 @@ int64_t sd_load_weights_prefixed(sd_ctx_t* ctx, const char* path, const char* pr
 // ---- text encoders + conditioner ----------------------------------------------------
 // Which encoders a family owns, their parameter prefixes and output wiring: FrozenCLIPEmbedderWithCustomWords (conditioner.hpp:169-190),
 // SD3CLIPEmbedder (:623-652), FluxCLIPEmbedder (:1034-1062).  Weights are synthetic (weight_seed) until sd_load_weights overwrites them.
-static bool ensure_text_encoders(sd_ctx_t* ctx) {
+static bool ensure_text_encoders(sdm_ctx_t* ctx) {
     if (ctx->te) return true;
-    std::unique_ptr<sd_ctx_t::TextEncoders> te(new sd_ctx_t::TextEncoders());
+    std::unique_ptr<sdm_ctx_t::TextEncoders> te(new sdm_ctx_t::TextEncoders());
     const int m     = (int)ctx->params.model;
     const bool tiny = m == SD_MODEL_SD15_TINY || m == SD_MODEL_SDXL_TINY || m == SD_MODEL_SD35_TINY || m == SD_MODEL_FLUX_TINY;
     ConditionerSpec& sp = te->spec;
@@ -733,7 +752,7 @@ static bool ensure_text_encoders(sd_ctx_t* ctx) {
 }
 
 // CLIPTextModelRunner::build_graph / compute (clip.hpp:516-583)
-static bool te_clip_forward(sd_ctx_t* ctx, int which, const int32_t* ids, int64_t n_tokens, size_t max_token_idx, bool return_pooled, int clip_skip, std::vector<float>& out) {
+static bool te_clip_forward(sdm_ctx_t* ctx, int which, const int32_t* ids, int64_t n_tokens, size_t max_token_idx, bool return_pooled, int clip_skip, std::vector<float>& out) {
     if (!ensure_text_encoders(ctx)) return false;
     auto& te = *ctx->te;
     if (which < 0 || which > 1 || (which == 1 && !te.spec.has_g)) {
@@ -772,7 +791,7 @@ static bool te_clip_forward(sd_ctx_t* ctx, int which, const int32_t* ids, int64_
 }
 
 // T5Runner::build_graph / compute (t5.hpp:422-461); no padding mask (SD3 / FLUX pass none)
-static bool te_t5_forward(sd_ctx_t* ctx, const int32_t* ids, int64_t n_tokens, std::vector<float>& out) {
+static bool te_t5_forward(sdm_ctx_t* ctx, const int32_t* ids, int64_t n_tokens, std::vector<float>& out) {
     if (!ensure_text_encoders(ctx)) return false;
     auto& te = *ctx->te;
     if (!te.spec.has_t5) {
@@ -804,9 +823,9 @@ static bool te_t5_forward(sd_ctx_t* ctx, const int32_t* ids, int64_t n_tokens, s
     return te.t5_runner.compute(build, out.data(), out.size() * sizeof(float));
 }
 
-bool sd_text_encoders_init(sd_ctx_t* ctx) { return ensure_text_encoders(ctx); }
+bool sd_text_encoders_init(sdm_ctx_t* ctx) { return ensure_text_encoders(ctx); }
 
-int64_t sd_clip_forward(sd_ctx_t* ctx, int which, const int32_t* ids, int n_tokens, int max_token_idx, bool return_pooled, int clip_skip, float* out, int64_t out_capacity) {
+int64_t sd_clip_forward(sdm_ctx_t* ctx, int which, const int32_t* ids, int n_tokens, int max_token_idx, bool return_pooled, int clip_skip, float* out, int64_t out_capacity) {
     std::vector<float> o;
     if (max_token_idx < 0) {
         set_error("max_token_idx out of range");
@@ -821,7 +840,7 @@ int64_t sd_clip_forward(sd_ctx_t* ctx, int which, const int32_t* ids, int n_toke
     return (int64_t)o.size();
 }
 
-int64_t sd_t5_forward(sd_ctx_t* ctx, const int32_t* ids, int n_tokens, float* out, int64_t out_capacity) {
+int64_t sd_t5_forward(sdm_ctx_t* ctx, const int32_t* ids, int n_tokens, float* out, int64_t out_capacity) {
     std::vector<float> o;
     if (!te_t5_forward(ctx, ids, n_tokens, o)) return -1;
     if ((int64_t)o.size() > out_capacity) {
@@ -838,7 +857,7 @@ int sd_t5_relative_position_buckets(int q_len, int k_len, int32_t* out) {
     return (int)b.size();
 }
 
-bool sd_get_learned_condition(sd_ctx_t* ctx, const sd_token_list_t* clip_l, const sd_token_list_t* clip_g, const sd_token_list_t* t5, int clip_skip, int width,
+bool sd_get_learned_condition(sdm_ctx_t* ctx, const sd_token_list_t* clip_l, const sd_token_list_t* clip_g, const sd_token_list_t* t5, int clip_skip, int width,
                               int height, bool zero_out_masked, float* crossattn_out, int64_t crossattn_capacity, int64_t* crossattn_ne, float* vector_out,
                               int64_t vector_capacity, int64_t* vector_n) {
     if (!ensure_text_encoders(ctx)) return false;
@@ -893,7 +912,7 @@ struct ModelSideInputs {
     const std::vector<float>* pe_table = nullptr;
     const std::vector<float>& pe() const { return *pe_table; }
 };
-static bool prepare_side_inputs(sd_ctx_t* ctx, int w, int h, int n, int64_t n_tokens, bool has_y, ModelSideInputs& si) {
+static bool prepare_side_inputs(sdm_ctx_t* ctx, int w, int h, int n, int64_t n_tokens, bool has_y, ModelSideInputs& si) {
     if (!ctx->is_flux) return true;
     if (!has_y) {
         set_error("FLUX needs the pooled text vector y");
@@ -912,7 +931,7 @@ static bool prepare_side_inputs(sd_ctx_t* ctx, int w, int h, int n, int64_t n_to
     return true;
 }
 // the denoiser network on an existing latent tensor tx [w,h,c,n]: declares the remaining graph inputs and calls the family's forward
-static ggml_tensor* build_model_call(sd_ctx_t* ctx, GraphCtx& g, std::vector<HostInput>& in, ggml_tensor* tx, int n, const float* timesteps, const float* context,
+static ggml_tensor* build_model_call(sdm_ctx_t* ctx, GraphCtx& g, std::vector<HostInput>& in, ggml_tensor* tx, int n, const float* timesteps, const float* context,
                                      int64_t ctx_dim, int64_t n_tokens, int64_t ctx_n, const float* y, int64_t y_dim, int64_t y_n, const ModelSideInputs& si) {
     g.flash_attn    = ctx->params.diffusion_flash_attn;
     g.conv_direct   = ctx->params.diffusion_conv_direct;
@@ -942,7 +961,7 @@ static ggml_tensor* build_model_call(sd_ctx_t* ctx, GraphCtx& g, std::vector<Hos
     return ctx->is_dit ? ctx->mmdit.forward(g, tx, tt, tc, ty) : ctx->unet.forward(g, tx, tt, tc, ty);
 }
 
-bool sd_unet_forward(sd_ctx_t* ctx, const float* x, int w, int h, int c, int n, const float* timesteps, const float* context,
+bool sd_unet_forward(sdm_ctx_t* ctx, const float* x, int w, int h, int c, int n, const float* timesteps, const float* context,
                      int64_t ctx_dim, int64_t n_tokens, int64_t ctx_n, const float* y, int64_t y_dim, int64_t y_n, float* out) {
     Runner& r = ctx->unet_runner;
     ModelSideInputs si;
@@ -970,7 +989,7 @@ bool sd_unet_forward(sd_ctx_t* ctx, const float* x, int w, int h, int c, int n, 
 }
 
 // ---- VAE decode ---------------------------------------------------------------------------------
-bool sd_vae_decode(sd_ctx_t* ctx, const float* latents, int w, int h, int c, int n, float* out_rgb) {
+bool sd_vae_decode(sdm_ctx_t* ctx, const float* latents, int w, int h, int c, int n, float* out_rgb) {
     Runner& r       = ctx->vae_runner;
     const float sf  = ctx->vae.cfg.scale_factor, sh = ctx->vae.cfg.shift_factor;
     const size_t ne = (size_t)w * h * c * n;
@@ -1000,12 +1019,18 @@ bool sd_vae_decode(sd_ctx_t* ctx, const float* latents, int w, int h, int c, int
 }
 
 // ---- sample(): the denoise loop -------------------------------------------------------------------
-static bool sample_group(sd_ctx_t* ctx, const sd_img_gen_params_t* p, int b0, int nb, float* out) {
+// resolve_sample_method / sd_get_default_sample_method (stable-diffusion.cpp:3965-3975, 4006-4013): DiT families default to plain Euler
+static int resolve_sample_method(const sdm_ctx_t* ctx, int m) {
+    if (m == SDM_SAMPLE_METHOD_COUNT) return ctx->is_dit ? SDM_EULER_SAMPLE_METHOD : SDM_EULER_A_SAMPLE_METHOD;
+    return m;
+}
+static bool sample_group(sdm_ctx_t* ctx, const sdm_img_gen_params_t* p, int b0, int nb, float* out) {
     const int W = p->width / 8, H = p->height / 8, C = ctx->in_channels();
     const size_t per = (size_t)W * H * C;
-    const sd_sample_params_t& sp = p->sample_params;
-    float eta = sp.eta;
-    if (eta == INFINITY) eta = sp.sample_method == EULER_A_SAMPLE_METHOD ? 1.0f : 0.0f;  // resolve_eta, stable-diffusion.cpp:4024-4049
+    const sdm_sample_params_t& sp = p->sample_params;
+    const int method = resolve_sample_method(ctx, sp.sample_method);
+    float eta        = sp.eta;
+    if (eta == INFINITY) eta = method == SDM_EULER_A_SAMPLE_METHOD ? 1.0f : 0.0f;  // resolve_eta, stable-diffusion.cpp:4024-4049
     const std::vector<float> sigmas = ctx->get_sigmas(sp.sample_steps, W * H);  // image_seq_len = latent pixels (stable-diffusion.cpp:2983-2986)
     const int steps                 = (int)sigmas.size() - 1;
 
@@ -1031,10 +1056,13 @@ static bool sample_group(sd_ctx_t* ctx, const sd_img_gen_params_t* p, int b0, in
         for (size_t k = 0; k < x.size(); ++k) noised[k] = x[k] * c_in;  // stable-diffusion.cpp:2662
         // The ancestral noise of this step depends on the sigma ladder only, not on the model output: draw it (host Philox, 0.7 ms per
         // SD1.5 image) on a helper thread WHILE the device runs the forward, instead of after it.  Same per-image streams, same order.
-        float sigma_down = 0.f, sigma_up = 0.f;
+        float sigma_down = 0.f, sigma_up = 0.f, alpha_scale = 1.f;
         std::future<void> noise_job;
-        if (sp.sample_method == EULER_A_SAMPLE_METHOD && sigma_to != 0.f && eta != 0.f) {
-            ancestral_step(sigma, sigma_to, eta, sigma_down, sigma_up);
+        if (method == SDM_EULER_A_SAMPLE_METHOD && sigma_to != 0.f && eta != 0.f) {
+            if (ctx->is_dit)  // flow denoisers (SD3.5, FLUX): get_ancestral_step(..., is_flow_denoiser), denoiser.hpp:1501-1511
+                ancestral_step_flow(sigma, sigma_to, eta, sigma_down, sigma_up, alpha_scale);
+            else
+                ancestral_step(sigma, sigma_to, eta, sigma_down, sigma_up);
             if (sigma_up > 0.f)
                 noise_job = std::async(std::launch::async, [&]() {
                     for (int b = 0; b < nb; ++b) step_noise[b] = rngs[b].randn((uint32_t)per);
@@ -1095,7 +1123,7 @@ static bool sample_group(sd_ctx_t* ctx, const sd_img_gen_params_t* p, int b0, in
         } else {
             for (size_t k = 0; k < x.size(); ++k) denoised[k] = cond_out[k] * c_out + x[k] * c_skip;
         }
-        if (sp.sample_method == EULER_A_SAMPLE_METHOD) {  // denoiser.hpp:1513-1546
+        if (method == SDM_EULER_A_SAMPLE_METHOD) {  // denoiser.hpp:1513-1546
             if (sigma_to == 0.f) {
                 x = denoised;
             } else if (eta == 0.f) {
@@ -1106,6 +1134,8 @@ static bool sample_group(sd_ctx_t* ctx, const sd_img_gen_params_t* p, int b0, in
                 for (size_t k = 0; k < x.size(); ++k) x[k] = ratio * x[k] + (1.0f - ratio) * denoised[k];
                 if (sigma_up > 0.f) {
                     noise_job.get();
+                    if (ctx->is_dit)
+                        for (size_t k = 0; k < x.size(); ++k) x[k] *= alpha_scale;  // denoiser.hpp:1537-1539
                     for (int b = 0; b < nb; ++b) {
                         const std::vector<float>& nz = step_noise[b];
                         for (size_t k = 0; k < per; ++k) x[b * per + k] += nz[k] * sigma_up;
@@ -1132,24 +1162,26 @@ static bool sample_group(sd_ctx_t* ctx, const sd_img_gen_params_t* p, int b0, in
 // scalars arrive as ONE 8-float input, so all steps share one cached plan.  Nothing is read back until the last step: uploads and
 // graphs are queued on the backend stream (set_tensor_async / graph_compute_async) and the host builds step k+1 while step k runs.
 // Ancestral noise stays the host Philox stream (bit-reproducible, rng_philox.hpp:101-122), uploaded per step (64 KB per SD1.5 image).
-static bool sample_group_device(sd_ctx_t* ctx, const sd_img_gen_params_t* p, int b0, int nb, float* out, bool* handled) {
+static bool sample_group_device(sdm_ctx_t* ctx, const sdm_img_gen_params_t* p, int b0, int nb, float* out, bool* handled) {
     *handled = false;
     const int W = p->width / 8, H = p->height / 8, C = ctx->in_channels();
-    const sd_sample_params_t& sp = p->sample_params;
+    const sdm_sample_params_t& sp = p->sample_params;
     const bool use_cfg = sp.txt_cfg != 1.0f && p->uncond.c_crossattn != nullptr;
     const bool has_y   = p->cond.c_vector != nullptr;
     if (use_cfg && (p->cond.ctx_dim != p->uncond.ctx_dim || p->cond.n_tokens != p->uncond.n_tokens || has_y != (p->uncond.c_vector != nullptr))) return true;
     if (ctx->out_channels() != C) return true;  // learned-sigma heads are not sampled this way
     *handled = true;
     const size_t per = (size_t)W * H * C;
+    const int method = resolve_sample_method(ctx, sp.sample_method);
     float eta        = sp.eta;
-    if (eta == INFINITY) eta = sp.sample_method == EULER_A_SAMPLE_METHOD ? 1.0f : 0.0f;
+    if (eta == INFINITY) eta = method == SDM_EULER_A_SAMPLE_METHOD ? 1.0f : 0.0f;
     const std::vector<float> sigmas = ctx->get_sigmas(sp.sample_steps, W * H);
     const int steps                 = (int)sigmas.size() - 1;
-    const bool euler_a              = sp.sample_method == EULER_A_SAMPLE_METHOD;
+    const bool euler_a              = method == SDM_EULER_A_SAMPLE_METHOD;
+    const bool flow                 = ctx->is_dit;  // flow denoiser: ancestral steps rescale x by alpha_scale before the noise (denoiser.hpp:1536-1541)
 
     if (!ctx->sstate || ctx->sstate->W != W || ctx->sstate->H != H || ctx->sstate->C != C || ctx->sstate->N != nb) {
-        ctx->sstate.reset(new sd_ctx_t::SamplerState());
+        ctx->sstate.reset(new sdm_ctx_t::SamplerState());
         auto& st = *ctx->sstate;
         ggml_init_params ip{0, nullptr, true};
         st.sctx  = ggml_init(ip);
@@ -1194,7 +1226,7 @@ static bool sample_group_device(sd_ctx_t* ctx, const sd_img_gen_params_t* p, int
     std::vector<float> ts(n_model);
     Runner& r = ctx->unet_runner;
     char step_sig[200];  // every step of the trajectory replays ONE cached graph: only the 8 scalars, the timesteps and the conditioning are re-uploaded
-    snprintf(step_sig, sizeof(step_sig), "step %d %d %d %d cfg%d ea%d %lld %lld y%lld %p", W, H, C, nb, (int)use_cfg, (int)euler_a, (long long)p->cond.ctx_dim,
+    snprintf(step_sig, sizeof(step_sig), "step %d %d %d %d cfg%d ea%d %lld %lld y%lld %p", W, H, C, nb, (int)use_cfg, (int)euler_a + 2 * (int)flow, (long long)p->cond.ctx_dim,
              (long long)p->cond.n_tokens, (long long)(has_y ? p->cond.vector_dim : -1), (void*)st.x);
 
     for (int i = 0; i < steps; ++i) {
@@ -1202,9 +1234,9 @@ static bool sample_group_device(sd_ctx_t* ctx, const sd_img_gen_params_t* p, int
         float c_skip, c_out, c_in;
         ctx->scalings(sigma, c_skip, c_out, c_in);
         std::fill(ts.begin(), ts.end(), ctx->sigma_to_t(sigma));
-        // scalars of this step: {c_in, cfg scale, c_out, c_skip, a, b, noise gain, 0}; Euler-A: x' = a*x + b*denoised + gain*noise;
+        // scalars of this step: {c_in, cfg scale, c_out, c_skip, a, b, noise gain, alpha}; Euler-A: x' = (a*x + b*denoised) [* alpha on flow models] + gain*noise;
         // Euler: x' = x + ((x - denoised) / a) * b with a = sigma, b = sigma_to - sigma
-        float sc[8] = {c_in, sp.txt_cfg, c_out, c_skip, 0.f, 0.f, 0.f, 0.f};
+        float sc[8] = {c_in, sp.txt_cfg, c_out, c_skip, 0.f, 0.f, 0.f, 1.f};
         bool fresh_noise = false;
         if (euler_a) {
             if (sigma_to == 0.f) {
@@ -1213,12 +1245,16 @@ static bool sample_group_device(sd_ctx_t* ctx, const sd_img_gen_params_t* p, int
                 const float ratio = sigma_to / sigma;
                 sc[4] = ratio, sc[5] = (float)(1.0 - ratio);
             } else {
-                float sigma_down, sigma_up;
-                ancestral_step(sigma, sigma_to, eta, sigma_down, sigma_up);
+                float sigma_down, sigma_up, alpha_scale = 1.f;
+                if (flow)
+                    ancestral_step_flow(sigma, sigma_to, eta, sigma_down, sigma_up, alpha_scale);
+                else
+                    ancestral_step(sigma, sigma_to, eta, sigma_down, sigma_up);
                 const float ratio = sigma_down / sigma;
                 sc[4] = ratio, sc[5] = 1.0f - ratio;
                 if (sigma_up > 0.f) {
                     sc[6]       = sigma_up;
+                    sc[7]       = alpha_scale;
                     fresh_noise = true;
                 }
             }
@@ -1260,6 +1296,7 @@ static bool sample_group_device(sd_ctx_t* ctx, const sd_img_gen_params_t* p, int
             ggml_tensor* xn;
             if (euler_a) {  // denoiser.hpp:1513-1546
                 xn = ggml_add(c, ggml_mul(c, xs, S(4)), ggml_mul(c, den, S(5)));
+                if (flow) xn = ggml_mul(c, xn, S(7));
                 xn = ggml_add(c, xn, ggml_mul(c, st.noise, S(6)));
             } else {  // denoiser.hpp:1582-1597
                 ggml_tensor* d = ggml_div(c, ggml_sub(c, xs, den), S(4));
@@ -1282,7 +1319,7 @@ static bool sample_group_device(sd_ctx_t* ctx, const sd_img_gen_params_t* p, int
     return true;
 }
 
-bool sd_sample_latents(sd_ctx_t* ctx, const sd_img_gen_params_t* p, float* out_latents) {
+bool sd_sample_latents(sdm_ctx_t* ctx, const sdm_img_gen_params_t* p, float* out_latents) {
     const int W = p->width / 8, H = p->height / 8, C = ctx->in_channels();
     const size_t per = (size_t)W * H * C;
     const int group  = p->device_batch > 0 ? p->device_batch : p->batch_count;
@@ -1306,21 +1343,21 @@ static inline uint8_t float_to_u8(float v) {  // preprocessing.hpp:27-35
     return (uint8_t)(v * 255.0f + 0.5f);
 }
 
-bool generate_image(sd_ctx_t* ctx, const sd_img_gen_params_t* p, sd_image_t** images_out, int* num_images_out) {
+bool sdm_generate_image(sdm_ctx_t* ctx, const sdm_img_gen_params_t* p, sdm_image_t** images_out, int* num_images_out) {
     const int W = p->width / 8, H = p->height / 8, C = ctx->in_channels();
     const size_t per = (size_t)W * H * C;
     std::vector<float> latents(per * p->batch_count);
     if (!sd_sample_latents(ctx, p, latents.data())) return false;
     const int PW = W * 8, PH = H * 8;
     const size_t pix = (size_t)PW * PH;
-    sd_image_t* imgs = (sd_image_t*)calloc(p->batch_count, sizeof(sd_image_t));  // stable-diffusion.cpp:5398-5410
+    sdm_image_t* imgs = (sdm_image_t*)calloc(p->batch_count, sizeof(sdm_image_t));  // stable-diffusion.cpp:5398-5410
     std::vector<float> rgb(pix * 3 * p->batch_count);
     const int group = p->device_batch > 0 ? p->device_batch : p->batch_count;
     double dec_ms   = 0;
     for (int b0 = 0; b0 < p->batch_count; b0 += group) {
         const int nb = std::min(group, p->batch_count - b0);
         if (!sd_vae_decode(ctx, latents.data() + b0 * per, W, H, C, nb, rgb.data() + (size_t)b0 * pix * 3)) {
-            free_sd_images(imgs, p->batch_count);
+            sdm_free_images(imgs, p->batch_count);
             return false;
         }
         dec_ms += ctx->stats.last_decode_ms;
@@ -1346,7 +1383,7 @@ bool generate_image(sd_ctx_t* ctx, const sd_img_gen_params_t* p, sd_image_t** im
     return true;
 }
 
-void free_sd_images(sd_image_t* images, int num_images) {
+void sdm_free_images(sdm_image_t* images, int num_images) {
     if (!images) return;
     for (int i = 0; i < num_images; ++i) free(images[i].data);
     free(images);
@@ -1367,7 +1404,7 @@ int sd_get_sigmas(int steps, float* out) {
     memcpy(out, s.data(), s.size() * sizeof(float));
     return (int)s.size();
 }
-void sd_set_guidance(sd_ctx_t* ctx, float guidance) { ctx->guidance = guidance; }
+void sd_set_guidance(sdm_ctx_t* ctx, float guidance) { ctx->guidance = guidance; }
 int sd_get_flux_sigmas(int steps, int image_seq_len, float* out) {
     FluxFlowDenoiser d;
     std::vector<float> s = d.get_sigmas(steps, image_seq_len);
@@ -1390,7 +1427,7 @@ float sd_sigma_to_t(float sigma) {
     static CompVisDenoiser d;
     return d.sigma_to_t(sigma);
 }
-void sd_get_stats(sd_ctx_t* ctx, sd_stats_t* out) {
+void sd_get_stats(sdm_ctx_t* ctx, sd_stats_t* out) {
     ctx->stats.host_build_ms  = ctx->unet_runner.build_ms;
     ctx->stats.host_alloc_ms  = ctx->unet_runner.alloc_ms;
     ctx->stats.host_submit_ms = ctx->unet_runner.submit_ms;

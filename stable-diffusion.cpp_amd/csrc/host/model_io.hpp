@@ -7,6 +7,8 @@
 // the same rule.  Name conversion between checkpoint dialects (src/name_conversion.cpp) is NOT done here: names must already be the
 // original-LDM / sd.cpp GGUF names the graph builders register ("model.diffusion_model.…", "first_stage_model.…").
 #pragma once
+#include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -19,9 +21,14 @@
 
 namespace sdmi {
 
+// dtypes the safetensors format names that ggml has no element type for: decoded to f32 at load time (the reference widens them the
+// same way before its own convert step — F8 -> F16, F64 -> F32, I64 -> I32: src/model_io/safetensors_io.cpp:79-99, src/model_loader.cpp:81-153)
+enum class SrcKind { NATIVE, F64, I64, F8_E4M3, F8_E5M2 };
+
 struct FileTensor {
     std::string name;
     ggml_type type = GGML_TYPE_F32;
+    SrcKind kind   = SrcKind::NATIVE;
     int64_t ne[4]  = {1, 1, 1, 1};  // ggml order (ne0 fastest)
     int n_dims     = 0;
     uint64_t offset = 0;            // absolute file offset of the data
@@ -31,6 +38,7 @@ struct FileTensor {
 struct ModelFile {
     std::string path, error;
     std::vector<FileTensor> tensors;
+    std::map<std::string, std::string> undecodable;  // tensor name -> dtype this build cannot decode (K-quants, I8, BOOL ...): an error if a declared parameter needs one
     std::map<std::string, std::string> metadata;  // safetensors __metadata__ / GGUF string KVs
 };
 
@@ -120,12 +128,55 @@ struct JsonCursor {
     }
 };
 
-inline bool st_dtype(const std::string& s, ggml_type& t) {
-    if (s == "F32") t = GGML_TYPE_F32;
-    else if (s == "F16") t = GGML_TYPE_F16;
-    else if (s == "BF16") t = GGML_TYPE_BF16;
-    else return false;  // F64 / I64 / F8 tensors are not parameters of the hot-path models
+inline bool st_dtype(const std::string& s, ggml_type& t, SrcKind& kind, size_t& elem_bytes) {
+    kind = SrcKind::NATIVE;
+    if (s == "F32") t = GGML_TYPE_F32, elem_bytes = 4;
+    else if (s == "F16") t = GGML_TYPE_F16, elem_bytes = 2;
+    else if (s == "BF16") t = GGML_TYPE_BF16, elem_bytes = 2;
+    else if (s == "F64") t = GGML_TYPE_F32, kind = SrcKind::F64, elem_bytes = 8;
+    else if (s == "I64") t = GGML_TYPE_F32, kind = SrcKind::I64, elem_bytes = 8;
+    else if (s == "F8_E4M3") t = GGML_TYPE_F32, kind = SrcKind::F8_E4M3, elem_bytes = 1;
+    else if (s == "F8_E5M2") t = GGML_TYPE_F32, kind = SrcKind::F8_E5M2, elem_bytes = 1;
+    else return false;  // I8 / I16 / I32 / U8 / BOOL: no parameter of the hot-path models has these
     return true;
+}
+
+// OCP 8-bit floats -> f32.  E4M3 ("fn": bias 7, no infinities, S.1111.111 = NaN, subnormals m/8 * 2^-6); E5M2 is the high byte of an IEEE half.
+inline float f8_e4m3_to_f32(uint8_t v) {
+    const int sign = v >> 7, e = (v >> 3) & 15, m = v & 7;
+    float r;
+    if (e == 15 && m == 7) r = NAN;
+    else if (e == 0) r = std::ldexp((float)m, -9);
+    else r = std::ldexp(1.0f + (float)m / 8.0f, e - 7);
+    return sign ? -r : r;
+}
+inline float f8_e5m2_to_f32(uint8_t v) { return ggml_fp16_to_fp32((ggml_fp16_t)((uint16_t)v << 8)); }
+
+// widen a non-native safetensors payload to f32 (n elements)
+inline void decode_src_kind(SrcKind kind, const uint8_t* raw, int64_t n, float* dst) {
+    switch (kind) {
+        case SrcKind::F64:
+            for (int64_t i = 0; i < n; ++i) {
+                double d;
+                memcpy(&d, raw + 8 * i, 8);
+                dst[i] = (float)d;
+            }
+            break;
+        case SrcKind::I64:
+            for (int64_t i = 0; i < n; ++i) {
+                int64_t d;
+                memcpy(&d, raw + 8 * i, 8);
+                dst[i] = (float)(int32_t)d;  // i64 -> i32 like the reference, then the parameter's float type
+            }
+            break;
+        case SrcKind::F8_E4M3:
+            for (int64_t i = 0; i < n; ++i) dst[i] = f8_e4m3_to_f32(raw[i]);
+            break;
+        case SrcKind::F8_E5M2:
+            for (int64_t i = 0; i < n; ++i) dst[i] = f8_e5m2_to_f32(raw[i]);
+            break;
+        default: break;
+    }
 }
 
 // safetensors: u64 LE header length N, N bytes of JSON {"name": {"dtype": "F16", "shape": [..torch order..], "data_offsets": [b, e]}, ...,
@@ -184,12 +235,15 @@ inline bool read_safetensors(const std::string& path, ModelFile& mf) {
             std::vector<int64_t> shape;
             int64_t b = -1, e = -1;
             bool known = true;
+            size_t elem_bytes = 0;
+            std::string dtype;
             if (!c.eat('{')) break;
             while (c.ok && !c.eat('}')) {
                 const std::string k = c.str();
                 (void)c.eat(':');
                 if (k == "dtype") {
-                    known = st_dtype(c.str(), t.type);
+                    dtype = c.str();
+                    known = st_dtype(dtype, t.type, t.kind, elem_bytes);
                 } else if (k == "shape") {
                     (void)c.eat('[');
                     while (c.ok && !c.eat(']')) {
@@ -207,12 +261,30 @@ inline bool read_safetensors(const std::string& path, ModelFile& mf) {
                 }
                 (void)c.eat(',');
             }
-            if (known && shape.size() <= 4 && b >= 0 && e >= b && base + (uint64_t)e <= fsize) {
+            if (!known) {
+                mf.undecodable[key] = dtype;
+            } else if (shape.size() <= 4 && b >= 0 && e >= b && base + (uint64_t)e <= fsize) {
                 t.n_dims = (int)shape.size();
-                for (size_t i = 0; i < shape.size(); ++i) t.ne[i] = shape[shape.size() - 1 - i];  // torch order -> ggml order
+                // the byte range must hold exactly prod(shape) elements ("size mismatch for tensor", safetensors_io.cpp:326-351): the loader
+                // later reads nelements * type_size bytes out of a buffer of (e - b) bytes
+                uint64_t nel = 1;
+                bool shape_ok = true;
+                for (size_t i = 0; i < shape.size(); ++i) {
+                    const int64_t d = shape[i];
+                    if (d < 0 || (d > 0 && nel > (1ull << 40) / (uint64_t)d)) shape_ok = false;
+                    nel *= (uint64_t)std::max<int64_t>(d, 0);
+                    t.ne[shape.size() - 1 - i] = d;  // torch order -> ggml order
+                }
+                if (!shape_ok || nel * elem_bytes != (uint64_t)(e - b)) {
+                    mf.error = "size mismatch for tensor '" + key + "' (" + dtype + ")";
+                    return false;
+                }
                 t.offset = base + (uint64_t)b;
                 t.nbytes = (uint64_t)(e - b);
-                mf.tensors.push_back(t);
+                if (nel > 0) mf.tensors.push_back(t);
+            } else {
+                mf.error = "bad shape / data_offsets for tensor '" + key + "'";
+                return false;
             }
         }
         (void)c.eat(',');
@@ -315,11 +387,26 @@ inline bool read_gguf(const std::string& path, ModelFile& mf) {
     std::vector<FileTensor> keep;
     for (auto& t : mf.tensors) {
         const bool known = t.type == GGML_TYPE_F32 || t.type == GGML_TYPE_F16 || t.type == GGML_TYPE_BF16 || t.type == GGML_TYPE_Q8_0 || t.type == GGML_TYPE_Q4_0;
-        if (!known) continue;  // other quantisations: not decodable by this build (the reference accepts any ggml type)
-        const int64_t rows = t.ne[1] * t.ne[2] * t.ne[3];
-        t.nbytes           = ggml_row_size(t.type, t.ne[0]) * (uint64_t)rows;
+        if (!known) {  // other quantisations (Q4_1, Q5_x, K-quants ...): not decodable by this build — an ERROR if a declared parameter needs one
+            mf.undecodable[t.name] = "ggml type " + std::to_string((int)t.type);
+            continue;
+        }
+        // dims come from the file: positive, ne0 a whole number of blocks, and every product / offset checked for overflow before it is trusted
+        const int64_t blck = ggml_blck_size(t.type);
+        uint64_t rows      = 1;
+        bool dims_ok       = t.ne[0] > 0 && t.ne[0] % blck == 0 && t.ne[0] < (1ll << 40);
+        for (int d = 1; d < 4 && dims_ok; ++d) {
+            dims_ok = t.ne[d] > 0 && rows <= (1ull << 40) / (uint64_t)t.ne[d];
+            rows *= (uint64_t)t.ne[d];
+        }
+        const uint64_t rs = dims_ok ? (uint64_t)ggml_row_size(t.type, t.ne[0]) : 0;
+        if (!dims_ok || rs == 0 || rows > (1ull << 46) / rs || t.offset > fsize || data0 > fsize - t.offset || rs * rows > fsize - t.offset - data0) {
+            mf.error = "tensor '" + t.name + "' has invalid dimensions or lies outside the file";
+            return false;
+        }
+        t.nbytes = rs * rows;
         t.offset += data0;
-        if (t.offset + t.nbytes <= fsize) keep.push_back(t);
+        keep.push_back(t);
     }
     mf.tensors.swap(keep);
     return true;

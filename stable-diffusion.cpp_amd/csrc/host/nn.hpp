@@ -35,7 +35,7 @@ struct ParamStore {
     ggml_context* ctx = nullptr;
     std::vector<ParamSpec> specs;
     std::map<std::string, ggml_tensor*> by_name;
-    ggml_type linear_type = GGML_TYPE_F16;  // sd_ctx_params_t.wtype analogue for Linear weights
+    ggml_type linear_type = GGML_TYPE_F16;  // sdm_ctx_params_t.wtype analogue for Linear weights
 
     ParamStore() {
         ggml_init_params p{0, nullptr, true};
@@ -57,8 +57,8 @@ struct ParamStore {
 struct GraphCtx {
     ggml_context* ctx      = nullptr;
     ggml_backend_t backend = nullptr;
-    bool flash_attn        = false;  // sd_ctx_params_t.diffusion_flash_attn
-    bool conv_direct       = false;  // sd_ctx_params_t.diffusion_conv_direct
+    bool flash_attn        = false;  // sdm_ctx_params_t.diffusion_flash_attn
+    bool conv_direct       = false;  // sdm_ctx_params_t.diffusion_conv_direct
 };
 
 // ---- ggml_ext_* wrappers (node-for-node) --------------------------------------------------------

@@ -191,4 +191,26 @@ inline void ancestral_step(float sigma_from, float sigma_to, float eta, float& s
     sigma_down          = down_sq > 0.0f ? std::sqrt(down_sq) : 0.0f;
 }
 
+// get_ancestral_step_flow — denoiser.hpp:1468-1499 (rectified-flow denoisers: SD3 / SD3.5 / FLUX).  eta is clamped to 1; the caller scales x by
+// alpha_scale before adding sigma_up * noise (sample_euler_ancestral, denoiser.hpp:1536-1541)
+inline void ancestral_step_flow(float sigma_from, float sigma_to, float eta, float& sigma_down, float& sigma_up, float& alpha_scale) {
+    sigma_down  = sigma_to;
+    sigma_up    = 0.0f;
+    alpha_scale = 1.0f;
+    if (eta <= 0.0f || sigma_from <= 0.0f || sigma_to <= 0.0f) return;
+    eta                     = std::min(eta, 1.0f);
+    const float sigma_ratio = sigma_to / sigma_from;
+    sigma_down              = sigma_to * (1.0f + (sigma_ratio - 1.0f) * eta);
+    sigma_down              = std::max(0.0f, std::min(sigma_to, sigma_down));
+    const float denom       = 1.0f - sigma_down;
+    if (denom <= 0.0f) {
+        sigma_down = sigma_to;
+        return;
+    }
+    alpha_scale = (1.0f - sigma_to) / denom;
+    float term  = (sigma_down / sigma_to) * alpha_scale;
+    term        = std::max(-1.0f, std::min(1.0f, term));
+    sigma_up    = sigma_to * std::sqrt(std::max(1.0f - term * term, 0.0f));
+}
+
 }  // namespace sdmi

@@ -330,8 +330,10 @@ __global__ __launch_bounds__(256, DKP <= 64 ? 3 : 2) void k_flash_attn(FAArgs g)
 
 bool flash_attn_supported(int64_t D, int64_t DV) { return D == DV && D >= 8 && D <= 160; }
 
-static int g_flash_ablate = 0;  // option "flash_ablate": 1 / 2 select the wrong-result timing ablations of the d <= 48 kernel
+#ifdef MI355X_EXPERIMENTS  // wrong-result timing ablations: never part of the shipped library (build with -DMI355X_EXPERIMENTS)
+static int g_flash_ablate = 0;
 void flash_attn_set_ablate(int v) { g_flash_ablate = v; }
+#endif
 
 void launch_flash_attn(hipStream_t s, const FlashOut& out, const View4& q, const View4& k, const View4& v, float scale) {
     FAArgs g;
@@ -371,11 +373,17 @@ void launch_flash_attn(hipStream_t s, const FlashOut& out, const View4& q, const
         else                                                          \
             k_flash_attn<DKP_, NDV_, false><<<grid, 256, 0, s>>>(g);  \
     } while (0)
-    if (D <= 48 && fast && g_flash_ablate == 1)
+#ifdef MI355X_EXPERIMENTS
+    if (D <= 48 && fast && g_flash_ablate == 1) {
         k_flash_attn<48, 2, true, 1><<<grid, 256, 0, s>>>(g);
-    else if (D <= 48 && fast && g_flash_ablate == 2)
+        return;
+    }
+    if (D <= 48 && fast && g_flash_ablate == 2) {
         k_flash_attn<48, 2, true, 2><<<grid, 256, 0, s>>>(g);
-    else if (D <= 48)
+        return;
+    }
+#endif
+    if (D <= 48)
         FA_CASE(48, 2);
     else if (D <= 64)
         FA_CASE(64, 2);

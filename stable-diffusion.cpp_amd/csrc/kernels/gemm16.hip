@@ -260,12 +260,7 @@ __device__ __forceinline__ void epi_conv(const float16_t (&acc)[RB][CB], const G
 }
 
 // geometry: workgroup tile BM x BN, WR x WC waves, each wave owns (BM/WR) x (BN/WC) outputs = RB x CB blocks of 32x32
-// SCHED = 1 (option "gemm16_sched", A/B experiment): the fragment reads of k-step 1 are interleaved with the MFMAs of k-step 0 by an
-// explicit sched_group_barrier pipeline, so the first MFMA of a tile waits for (RB + CB) LDS reads instead of for all of them.
-// SCHED = 2 / 3 are TIMING ABLATIONS with wrong results (microbenchmarks only, never selected by the planner's defaults): 2 keeps the
-// LDS-DMA stream, waits and barriers but skips the fragment reads and MFMAs; 3 keeps reads + MFMAs but stages only the first two
-// K tiles — together they say which of the two pipelines bounds the loop.
-template <int BM, int BN, bool CONV, int BK, int NST, int WR, int WC, int SCHED = 0>
+template <int BM, int BN, bool CONV, int BK, int NST, int WR, int WC>
 __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm16(G16Args g) {
     constexpr int NW  = WR * WC;
     constexpr int RB  = BM / WR / 32;  // 32-row blocks per wave
@@ -404,9 +399,6 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm16(G16Args g) {
         }                                              \
     } while (0)
     auto stage = [&](int kt, int buf, int tap, int kh, int kw, int icb, int sub) {
-        if constexpr (SCHED == 3) {
-            if (kt >= kt0 + 2) return;
-        }
         char* sa = smem + buf * (ABYTES + BBYTES);
         char* sb = sa + ABYTES;
         if (!CONV) {
@@ -454,40 +446,8 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm16(G16Args g) {
     const int hi   = lane >> 5;
 
     auto compute = [&](int buf) {
-        if constexpr (SCHED == 2) return;
         const char* sa = smem + buf * (ABYTES + BBYTES);
         const char* sb = sa + ABYTES;
-        if constexpr (SCHED == 1 && KSTEPS == 2) {
-            half8_t af[2][RB], bf[2][CB];
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-                for (int rb = 0; rb < RB; ++rb) af[ks][rb] = *(const half8_t*)(sa + aoff[rb] + (((ks * 2 + hi) ^ aswz) << 4));
-#pragma unroll
-                for (int cb = 0; cb < CB; ++cb) bf[ks][cb] = *(const half8_t*)(sb + (((wc * CB + cb) * KSTEPS + ks) * 64 + lane) * 16);
-            }
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-                    for (int cb = 0; cb < CB; ++cb) {
-                        if (CONV)
-                            acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[ks][cb], af[ks][rb], acc[rb][cb], 0, 0, 0);
-                        else
-                            acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][rb], bf[ks][cb], acc[rb][cb], 0, 0, 0);
-                    }
-            // schedule: [k-step 0 reads] then {1 MFMA, 1 read} until the k-step 1 reads are issued, then the remaining MFMAs
-            constexpr int NR = RB + CB, NM = 2 * RB * CB;
-            __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
-#pragma unroll
-            for (int i = 0; i < NR; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, NM - NR, 0);
-            return;
-        }
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
             half8_t af[RB], bf[CB];
@@ -585,237 +545,6 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm16(G16Args g) {
     }
 }
 
-// =====================================================================================================
-// k_gemm16d<BM, BN, CONV, WR, WC> — EXPERIMENT (option "gemm16_adirect", default 0; written after round 1's GPU budget was spent: NOT yet
-// run on hardware).  The k_gemm16 tiles with the A operand (activations) loaded global -> VGPR in MFMA operand layout instead of through
-// the LDS-DMA engine.  Why: per K tile the 256x160 tile moves 16 KB of A + 10 KB of W through global_load_lds; if that engine (~20 B/clk/CU
-// measured) bounds the loop — scripts/gemm_ablation.py decides — taking A off it cuts its traffic 2.6x (2x for the 128-column tiles) and
-// frees the A share of LDS.  A wave owns RB blocks of 32 rows: lane l loads the 16 bytes (row l % 32, k-slot l / 32) of each block and k-step
-// with one global_load_dwordx4, three tiles deep in registers (the register slots rotate with the 3-stage W ring).  With WC = 1
-// (256x160: 8 waves x 32 rows) every A fragment is needed by exactly one wave; with WC = 2 the two waves of a row block both load it (the
-// second hits L1/L2).  No nearest-x2 upsample gather, no GEGLU pairing.
-template <int BM, int BN, bool CONV, int WR, int WC>
-__global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm16d(G16Args g) {
-    constexpr int BK = 32, NST = 3, NW = WR * WC, KSTEPS = BK / 16;
-    constexpr int RB = BM / WR / 32, CB = BN / WC / 32;
-    static_assert(RB * WR * 32 == BM && CB * WC * 32 == BN, "tile must split into 32x32 blocks per wave");
-    constexpr int NF     = (BN / 32) * KSTEPS;     // W fragments (1 KiB each) per stage
-    constexpr int WPW    = (NF + NW - 1) / NW;     // W fragments per wave per stage
-    constexpr int WEXTRA = NF % NW;                // != 0: only waves < WEXTRA fetch WPW fragments, the others WPW - 1
-    constexpr int BBYTES = NF * 1024;
-    constexpr int NA     = RB * KSTEPS;            // register loads of A per lane per stage
-    __shared__ __attribute__((aligned(1024))) char smem[NST * BBYTES];
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wr = wave % WR, wc = wave / WR;
-    const int hi = lane >> 5;
-    int bid = blockIdx.x;
-    {
-        const int nb = gridDim.x;
-        if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);
-    }
-    int kt0 = 0, nt = g.nt;
-    if (g.split_k > 1) {
-        kt0 = blockIdx.y * g.nt_slice;
-        nt  = min(g.nt_slice, g.nt - kt0);
-        g.dst += (int64_t)blockIdx.y * g.slab;
-    }
-    const int row_tile = bid / g.ncol_tiles, col_tile = bid - row_tile * g.ncol_tiles;
-    const int64_t row0 = (int64_t)row_tile * BM;
-    const int col0     = col_tile * BN;
-
-    // ---- this lane's A rows: conv = output positions and their tap masks (all per-position address work happens once); linear = token rows
-    const _Float16* abase[RB];
-    unsigned amask[RB];
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb) {
-        int64_t row   = row0 + wr * (RB * 32) + rb * 32 + (lane & 31);
-        const bool ok = row < g.R;
-        if (!ok) row = g.R - 1;
-        amask[rb] = 0;
-        if (CONV) {
-            const int img = (int)(row / g.OHOW);
-            const int p   = (int)(row - (int64_t)img * g.OHOW);
-            const int oh = p / g.OW, ow = p - oh * g.OW;
-            for (int t = 0; t < g.KS * g.KS; ++t) {
-                const int ih = oh * g.S + t / g.KS - g.pad, iw = ow * g.S + t % g.KS - g.pad;
-                if (ok && ih >= 0 && ih < g.H && iw >= 0 && iw < g.Wd) amask[rb] |= 1u << t;
-            }
-            abase[rb] = g.A + (((int64_t)img * g.H + (oh * g.S - g.pad)) * g.Wd + (ow * g.S - g.pad)) * g.ICp + hi * 8;
-        } else {
-            abase[rb] = g.A + row * g.lda + hi * 8;  // rows past R re-read the last row; their outputs are never stored
-        }
-    }
-    const _Float16* zsrc = CONV ? g.zero + hi * 8 : abase[0];
-
-    const half8_t* wsrc[WPW];
-    int wdst[WPW];
-#pragma unroll
-    for (int q = 0; q < WPW; ++q) {
-        const int f  = q * NW + wave;
-        const int fs = f < NF ? f : NF - 1;
-        const int cb = fs / KSTEPS, ks = fs % KSTEPS;
-        wsrc[q]      = g.W + ((int64_t)(col0 / 32 + cb) * g.kfr + ks) * 64 + lane;
-        wdst[q]      = fs * 1024;
-    }
-    const bool w_short = WEXTRA != 0 && wave >= WEXTRA;
-    const int ktiles_per_icb = 64 / BK;
-
-    int c_sub = 0, c_tap = 0, c_icb = 0, c_kh = 0, c_kw = 0;
-    if (CONV) {
-        const int kb = kt0 / ktiles_per_icb, ntaps = g.KS * g.KS;
-        c_sub        = kt0 - kb * ktiles_per_icb;
-        if (g.tap_major) {
-            c_tap = kb / g.icb_per_tap;
-            c_icb = kb - c_tap * g.icb_per_tap;
-        } else {
-            c_icb = kb / ntaps;
-            c_tap = kb - c_icb * ntaps;
-        }
-        c_kh = c_tap / g.KS;
-        c_kw = c_tap - c_kh * g.KS;
-    }
-
-    half8_t areg[NST][RB][KSTEPS];
-    // one stage = this lane's A fragments (registers) + this wave's share of the W fragments (LDS-DMA), issued in that order.
-    // The A loads are inline asm: as ordinary C++ loads the compiler guarded the first use of a slot with its own s_waitcnt vmcnt(0)
-    // once per trip of the 3-tile loop, draining the prefetch of the next two tiles.  The counted waits in front of the barriers
-    // below are what guarantees a slot has landed before its MFMAs (loads retire in order).  NW_ is the compile-time number of W
-    // pieces this wave issues; the loop exists once per value so that the count in those waits is a constant.
-#define C16D_STAGE(SLOT, KT, NW_)                                                                                        \
-    do {                                                                                                                \
-        const int64_t toff_ = CONV ? ((int64_t)c_kh * g.Wd + c_kw) * g.ICp + (int64_t)c_icb * 64 + c_sub * BK : (int64_t)(KT) * BK; \
-        _Pragma("unroll") for (int rb = 0; rb < RB; ++rb) {                                                             \
-            const _Float16* p_ = (!CONV || ((amask[rb] >> c_tap) & 1u)) ? abase[rb] + toff_ : zsrc;                     \
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(areg[SLOT][rb][0]) : "v"(p_) : "memory");            \
-            asm volatile("global_load_dwordx4 %0, %1, off offset:32" : "=v"(areg[SLOT][rb][1]) : "v"(p_) : "memory");  \
-        }                                                                                                               \
-        char* sb_ = smem + (SLOT) * BBYTES;                                                                             \
-        _Pragma("unroll") for (int q = 0; q < (NW_); ++q) GLDS16(wsrc[q] + (int64_t)(KT) * KSTEPS * 64, sb_ + wdst[q]); \
-        G16_ADVANCE();                                                                                                  \
-    } while (0)
-
-    float16_t acc[RB][CB];
-#pragma unroll
-    for (int a = 0; a < RB; ++a)
-#pragma unroll
-        for (int b = 0; b < CB; ++b) acc[a][b] = (float16_t){0};
-
-    // fragment reads + MFMAs of the tile in slot S: k-step 0 reads, then {1 MFMA, 1 read of k-step 1} x CB, then the remaining MFMAs
-#define C16D_COMPUTE(S)                                                                                                 \
-    do {                                                                                                                \
-        const char* sbc_ = smem + (S) * BBYTES;                                                                         \
-        half8_t bf_[KSTEPS][CB];                                                                                        \
-        _Pragma("unroll") for (int ks = 0; ks < KSTEPS; ++ks)                                                           \
-            _Pragma("unroll") for (int cb = 0; cb < CB; ++cb)                                                           \
-                bf_[ks][cb] = *(const half8_t*)(sbc_ + (((wc * CB + cb) * KSTEPS + ks) * 64 + lane) * 16);             \
-        _Pragma("unroll") for (int ks = 0; ks < KSTEPS; ++ks)                                                           \
-            _Pragma("unroll") for (int rb = 0; rb < RB; ++rb)                                                           \
-                _Pragma("unroll") for (int cb = 0; cb < CB; ++cb) {                                                     \
-                    if (CONV)                                                                                           \
-                        acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf_[ks][cb], areg[S][rb][ks], acc[rb][cb], 0, 0, 0); \
-                    else                                                                                                \
-                        acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(areg[S][rb][ks], bf_[ks][cb], acc[rb][cb], 0, 0, 0); \
-                }                                                                                                       \
-        __builtin_amdgcn_sched_group_barrier(0x100, CB, 0);                                                             \
-        _Pragma("unroll") for (int i = 0; i < CB; ++i) {                                                                \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                          \
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                          \
-        }                                                                                                               \
-        __builtin_amdgcn_sched_group_barrier(0x008, 2 * RB * CB - CB, 0);                                               \
-    } while (0)
-
-    // tile KT lives in slot S = KT % 3.  Loads are issued per stage as [NA register loads][W DMA pieces] and retire in order, so
-    // vmcnt(NA + pieces) retires all of tile KT (its own A fragments AND its W pieces) while tile KT+1 stays in flight.  The wait also
-    // drains this wave's LDS reads (lgkmcnt(0)): the loop is unrolled three tiles deep and the scheduler hoists the barrier above the
-    // trailing MFMAs of the previous tile — without it the fragment reads of slot S could still be in flight when another wave, past
-    // the barrier, starts the DMA that refills slot S.
-    // steady state: tiles KT+1 and KT+2 exist, nothing is conditional
-#define C16D_BODY_STEADY(S, KT, NW_)                                                                                    \
-    do {                                                                                                                \
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NA + (NW_)) : "memory");                                  \
-        __builtin_amdgcn_s_barrier();                                                                                   \
-        C16D_STAGE(((S) + 2) % 3, kt0 + (KT) + 2, NW_);                                                                 \
-        C16D_COMPUTE(S);                                                                                                \
-    } while (0)
-    // tail: the last tiles of the K range
-#define C16D_BODY_TAIL(S, KT, NW_)                                                                                      \
-    do {                                                                                                                \
-        if ((KT) + 1 >= nt)                                                                                             \
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                \
-        else                                                                                                            \
-            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NA + (NW_)) : "memory");                              \
-        __builtin_amdgcn_s_barrier();                                                                                   \
-        if ((KT) + 2 < nt) C16D_STAGE(((S) + 2) % 3, kt0 + (KT) + 2, NW_);                                              \
-        C16D_COMPUTE(S);                                                                                                \
-    } while (0)
-#define C16D_LOOP(NW_)                                                                                                  \
-    do {                                                                                                                \
-        C16D_STAGE(0, kt0, NW_);                                                                                        \
-        if (nt > 1) C16D_STAGE(1, kt0 + 1, NW_);                                                                        \
-        int kt = 0;                                                                                                     \
-        for (; kt + 4 < nt; kt += 3) {                                                                                  \
-            C16D_BODY_STEADY(0, kt, NW_);                                                                               \
-            C16D_BODY_STEADY(1, kt + 1, NW_);                                                                           \
-            C16D_BODY_STEADY(2, kt + 2, NW_);                                                                           \
-        }                                                                                                               \
-        for (; kt < nt; kt += 3) {                                                                                      \
-            C16D_BODY_TAIL(0, kt, NW_);                                                                                 \
-            if (kt + 1 < nt) C16D_BODY_TAIL(1, kt + 1, NW_);                                                            \
-            if (kt + 2 < nt) C16D_BODY_TAIL(2, kt + 2, NW_);                                                            \
-        }                                                                                                               \
-    } while (0)
-
-    if constexpr (WEXTRA != 0) {
-        if (w_short)
-            C16D_LOOP(WPW - 1);
-        else
-            C16D_LOOP(WPW);
-    } else {
-        C16D_LOOP(WPW);
-    }
-#undef C16D_LOOP
-#undef C16D_BODY_TAIL
-#undef C16D_BODY_STEADY
-#undef C16D_COMPUTE
-#undef C16D_STAGE
-
-    if (!CONV) {  // the workgroup-uniform epilogue choice of k_gemm16 (no GEGLU pairing here)
-        const bool full = row0 + BM <= g.R;
-        if (g.hm_d > 0 && g.hm_L >= 32 && !g.ep.residual && (g.dst != nullptr) != (g.dst16 != nullptr)) {
-            if (g.dst16)
-                epi_linear<EPI_HM_F16>(acc, g, row0, col0, wr, wc, lane);
-            else
-                epi_linear<EPI_HM_F32>(acc, g, row0, col0, wr, wc, lane);
-        } else if (g.ep.gate) {
-            epi_linear<EPI_F32_GATE>(acc, g, row0, col0, wr, wc, lane);
-        } else if (full && g.hm_d == 0 && g.dst && !g.dst16) {
-            if (g.ep.residual)
-                epi_linear<EPI_F32_RES>(acc, g, row0, col0, wr, wc, lane);
-            else
-                epi_linear<EPI_F32>(acc, g, row0, col0, wr, wc, lane);
-        } else if (g.hm_d == 0 && g.dst16 && !g.dst && !g.ep.residual) {
-            if (g.ep.gelu)
-                epi_linear<EPI_F16_GELU>(acc, g, row0, col0, wr, wc, lane);
-            else
-                epi_linear<EPI_F16>(acc, g, row0, col0, wr, wc, lane);
-        } else {
-            epi_linear<EPI_GENERIC>(acc, g, row0, col0, wr, wc, lane);
-        }
-        return;
-    }
-    const bool fullc = col0 + BN <= g.C;
-    if (fullc) {
-        if (g.ep.residual)
-            epi_conv<1>(acc, g, row0, col0, wr, wc, lane);
-        else
-            epi_conv<0>(acc, g, row0, col0, wr, wc, lane);
-    } else {
-        epi_conv<2>(acc, g, row0, col0, wr, wc, lane);
-    }
-}
-
 static inline int64_t rup64(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 
 // pipeline / tile variant (tunable at run time for A/B measurements):
@@ -873,12 +602,6 @@ const char* gemm16_timing_kernel_name() { return "k_gemm16<256, *, true, 32, 3, 
 enum { G16_T128 = 0, G16_T256 = 1, G16_T256W = 2, G16_T160 = 3, G16_T160N = 4 };
 static int g_g16_force_tile = -1;  // option "gemm16_tile": force one configuration (A/B measurements); -1 = choose per shape
 void gemm16_set_tile(int t) { g_g16_force_tile = t; }
-static int g_g16_sched = 0;  // option "gemm16_sched" (experiment, default 0): explicit LDS-read / MFMA interleave — bit 0: 256-row tiles, bit 1: 128-row tiles;
-                             // 16 / 32: timing ablations of the T160 conv kernel (DMA-only / compute-only; WRONG RESULTS, scripts/gemm_ablation.sh)
-void gemm16_set_sched(int v) { g_g16_sched = v; }
-static int g_g16_adirect = 0;  // option "gemm16_adirect" (experiment, default 0): tiles without upsample gather / GEGLU pairing run k_gemm16d (A operand global -> VGPR)
-void gemm16_set_adirect(int v) { g_g16_adirect = v; }
-
 // Per-shape choice.  Measured on SD1.5 batch 16 (profiles/r01e_tile_configs.txt): a launch takes ceil(workgroups / resident slots)
 // rounds; a full round of T128 (768 slots) and of T256 (512 slots, twice the area per workgroup) take about the same time, a T160
 // round 1.5x that (4 waves per workgroup hide less latency) but covers 1.25x T256's area with no padded columns.  256-row tiles
@@ -927,39 +650,16 @@ static void g16_launch(hipStream_t s, G16Args& g, int64_t rows, double flops) {
                 ++g_timing.used;
                 (void)hipEventRecord(e0, s);
             }
-            const bool sched = (g_g16_sched & 1) != 0;
-            const bool adirect = g_g16_adirect && (!CONV_ || !g.UPS) && g.geglu_inner == 0;
-            if (adirect && (tile == G16_T160 || tile == G16_T160N)) {
+            if (tile == G16_T160) {
                 g.ncol_tiles = (int)(g.C / 160);
-                k_gemm16d<256, 160, CONV_, 8, 1><<<dim3((unsigned)(rt256 * g.ncol_tiles), ny), 512, 0, s>>>(g);
-            } else if (adirect && tile == G16_T256) {
-                k_gemm16d<256, 128, CONV_, 4, 2><<<dim3((unsigned)(rt256 * g.ncol_tiles), ny), 512, 0, s>>>(g);
-            } else if (tile == G16_T160) {
-                g.ncol_tiles = (int)(g.C / 160);
-                const dim3 grid((unsigned)(rt256 * g.ncol_tiles), ny);
-                if (CONV_ && g_g16_sched == 16)
-                    k_gemm16<256, 160, CONV_, 32, 3, 4, 1, 2><<<grid, 256, 0, s>>>(g);
-                else if (CONV_ && g_g16_sched == 32)
-                    k_gemm16<256, 160, CONV_, 32, 3, 4, 1, 3><<<grid, 256, 0, s>>>(g);
-                else if (sched)
-                    k_gemm16<256, 160, CONV_, 32, 3, 4, 1, 1><<<grid, 256, 0, s>>>(g);
-                else
-                    k_gemm16<256, 160, CONV_, 32, 3, 4, 1><<<grid, 256, 0, s>>>(g);
+                k_gemm16<256, 160, CONV_, 32, 3, 4, 1><<<dim3((unsigned)(rt256 * g.ncol_tiles), ny), 256, 0, s>>>(g);
             } else if (tile == G16_T160N) {
                 g.ncol_tiles = (int)(g.C / 160);
-                const dim3 grid((unsigned)(rt256 * g.ncol_tiles), ny);
-                if (sched)
-                    k_gemm16<256, 160, CONV_, 32, 3, 8, 1, 1><<<grid, 512, 0, s>>>(g);
-                else
-                    k_gemm16<256, 160, CONV_, 32, 3, 8, 1><<<grid, 512, 0, s>>>(g);
+                k_gemm16<256, 160, CONV_, 32, 3, 8, 1><<<dim3((unsigned)(rt256 * g.ncol_tiles), ny), 512, 0, s>>>(g);
             } else if (tile == G16_T256W) {
                 k_gemm16<256, 128, CONV_, 32, 3, 2, 2><<<dim3((unsigned)(rt256 * g.ncol_tiles), ny), 256, 0, s>>>(g);
             } else {
-                const dim3 grid((unsigned)(rt256 * g.ncol_tiles), ny);
-                if (sched)
-                    k_gemm16<256, 128, CONV_, 32, 3, 4, 2, 1><<<grid, 512, 0, s>>>(g);
-                else
-                    k_gemm16<256, 128, CONV_, 32, 3, 4, 2><<<grid, 512, 0, s>>>(g);
+                k_gemm16<256, 128, CONV_, 32, 3, 4, 2><<<dim3((unsigned)(rt256 * g.ncol_tiles), ny), 512, 0, s>>>(g);
             }
             if (e1) (void)hipEventRecord(e1, s);
             return;
@@ -970,10 +670,6 @@ static void g16_launch(hipStream_t s, G16Args& g, int64_t rows, double flops) {
         k_gemm16<128, BN_, CONV_, 64, 2, 2, 2><<<grid, 256, 0, s>>>(g);
     else if (g_g16_variant == 2)
         k_gemm16<128, BN_, CONV_, 64, 3, 2, 2><<<grid, 256, 0, s>>>(g);
-    else if (BN_ == 128 && g_g16_adirect && g_g16_variant == 3 && (!CONV_ || !g.UPS) && g.geglu_inner == 0)
-        k_gemm16d<128, 128, CONV_, 2, 2><<<grid, 256, 0, s>>>(g);
-    else if (g_g16_sched & 2)
-        k_gemm16<128, BN_, CONV_, 32, 3, 2, 2, 1><<<grid, 256, 0, s>>>(g);
     else
         k_gemm16<128, BN_, CONV_, 32, 3, 2, 2><<<grid, 256, 0, s>>>(g);
 }

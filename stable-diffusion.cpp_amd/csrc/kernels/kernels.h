@@ -78,22 +78,13 @@ struct Epilogue {
     int gate_L            = 0;        // rows per image
     int gelu              = 0;        // f16-only output: tanh-GELU applied before rounding
 };
-// Linear: dst[tok][m] = sum_k x[tok][k] * W[m][k]   x f32 rows (row stride x_stride floats), dst row stride M
-void launch_linear_mfma(hipStream_t s, float* dst, const float* x, const void* wswz, int64_t tokens, int64_t K, int64_t M,
-                        int64_t x_stride, int64_t d_stride, const Epilogue& ep);
-// Implicit-GEMM conv2d: x [W,H,IC,N] f32 NCHW, dst [OW,OH,OC,N]; 3x3 (pad 1, stride 1|2) or 1x1; optional nearest x2 upscale of x fused
-void launch_conv2d_mfma(hipStream_t s, float* dst, const float* x, const void* wswz, int64_t W, int64_t H, int64_t IC, int64_t N,
-                        int64_t OC, int ksize, int stride, int pad, bool upscale2x, const Epilogue& ep);
-
 // ---- gemm16.hip: second-generation contraction, both operands f16 via LDS-DMA -------------------------------
 // a16: f16 row-major [rows][lda] (K contiguous, padded to 64); output f32 [rows][ldd] and/or f16 [rows][ldd16]
 void gemm16_init();
 void gemm16_set_tap_major(int v);  // A/B: conv K order (tap, channel block) instead of (channel block, tap)
 int gemm16_tap_major();
 void gemm16_set_splitk_target(int v);
-void gemm16_set_sched(int v);    // explicit LDS-read / MFMA interleave (experiment; default 0): bit 0 = 256-row tiles, bit 1 = 128-row tiles
 void gemm16_set_splitk_mid(int v);  // 1: two K slices for launches of 193..384 workgroups with >= 128 K tiles (experiment, default 0)
-void gemm16_set_adirect(int v);  // 1: tiles without upsample gather / GEGLU pairing load the A operand global -> VGPR (k_gemm16d; experiment, default 0)
 void gemm16_set_tile(int t);     // -1: per-shape choice; 0..3: force T128 / T256 / T256W / T160 (A/B measurements)
 void gemm16_set_variant(int v);  // 0: BK64x2 stages, 1: BK32x3 stages (default), 2: BK64x3 stages
 // hm_d > 0: head-major store — element (row = n*hm_L + l, col = h*hm_d + dd) goes to ((n*hm_H + h)*hm_L + l)*hm_d + dd of dst (f32) / dst16 (f16)
@@ -138,7 +129,9 @@ struct FlashOut {
     void* dst16      = nullptr;
     int64_t ld16     = 0;
 };
-void flash_attn_set_ablate(int v);  // timing ablations of the d <= 48 kernel (wrong results; microbenchmarks only)
+#ifdef MI355X_EXPERIMENTS
+void flash_attn_set_ablate(int v);
+#endif
 void launch_flash_attn(hipStream_t s, const FlashOut& out, const View4& q, const View4& k, const View4& v, float scale);
 
 }  // namespace mi355x

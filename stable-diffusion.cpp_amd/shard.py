@@ -1,7 +1,9 @@
 """Image sharding across the GPUs of one node.
 
-Each image (seed + b) is an independent denoise trajectory, so ranks never exchange data on the hot path: rank r owns
-images {b : b % world == r}.  The only collective is the optional gather of finished results to rank 0
+Each image (seed + b) is an independent denoise trajectory, so ranks never exchange data on the hot path: rank r owns the CONTIGUOUS
+block of images [r * ceil(B / world), (r + 1) * ceil(B / world)) — contiguous seeds are what the engine batches into one device graph
+(seeds seed+b0 .. seed+b0+n-1), so every rank runs its whole share as ONE device batch (a round-robin b % world assignment would leave
+each rank with n sequential batch-1 trajectories).  The only collective is the optional gather of finished results
 (torch.distributed: backend "nccl" == RCCL over xGMI on MI355X, "gloo" in the CPU tests) — payload <= a few MB."""
 from __future__ import annotations
 
@@ -9,7 +11,8 @@ import numpy as np
 
 
 def shard_indices(batch_count: int, rank: int, world: int) -> list[int]:
-    return [b for b in range(batch_count) if b % world == rank]
+    per = -(-batch_count // world)
+    return list(range(min(rank * per, batch_count), min((rank + 1) * per, batch_count)))
 
 
 def generate_sharded(engine, cond, uncond, *, batch_count: int, seed: int, rank: int, world: int, gather=None, decode=False, **kw):

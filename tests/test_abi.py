@@ -40,7 +40,7 @@ def test_backend_plugin_loads_without_gpu_and_reports_no_device(sd):
 
 def test_host_library_exports(sd):
     want = declared(ROOT / "include" / "sd-mi355x.h", "SD_API")
-    assert {"new_sd_ctx", "generate_image", "free_sd_images", "sd_unet_forward", "sd_vae_decode"} <= want
+    assert {"sdm_new_ctx", "sdm_generate_image", "sdm_free_images", "sd_unet_forward", "sd_vae_decode"} <= want
     missing = want - exported(sd.HOST_LIB)
     assert not missing, missing
 

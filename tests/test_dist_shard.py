@@ -58,7 +58,7 @@ def test_world_size_2_sharding_matches_single_process(sd, oracle, tmp_path):
     assert sorted(res) == [0, 1, 2, 3, 4]
     from sdcpp_amd import shard
 
-    assert shard.shard_indices(5, 0, 2) == [0, 2, 4] and shard.shard_indices(5, 1, 2) == [1, 3]
+    assert shard.shard_indices(5, 0, 2) == [0, 1, 2] and shard.shard_indices(5, 1, 2) == [3, 4] and shard.shard_indices(2, 3, 4) == []
     eng = sd.Engine(model=sd.SD15_TINY, backend=oracle)
     rng = np.random.default_rng(11)
     cond = rng.standard_normal((1, 77, 64)).astype(np.float32)

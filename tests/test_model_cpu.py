@@ -198,6 +198,50 @@ def test_mmdit_euler_flow_trajectory_vs_numpy_restatement(sd, oracle, eng35):
     assert rel_l2(out, x) < 1e-4
 
 
+def test_sd35_flow_euler_a_trajectory_and_family_default(sd, oracle, eng35):
+    """Euler-A on a rectified-flow model takes get_ancestral_step_flow (denoiser.hpp:1468-1499): sigma_down = sigma_to * (1 + (ratio - 1) * eta),
+    x scaled by alpha_scale = (1 - sigma_to) / (1 - sigma_down) before the noise (:1536-1541).  numpy restatement calling the same model;
+    host loop and device-resident sampler agree; and the family default (no method given) is plain Euler (stable-diffusion.cpp:3965-3975)."""
+    from test_host_logic import philox_randn_np
+
+    rng = np.random.default_rng(14)
+    cond, uncond = (rng.standard_normal((1, 12, 96)).astype(np.float32) for _ in range(2))
+    cy, uy = (rng.standard_normal((1, 64)).astype(np.float32) for _ in range(2))
+    steps, cfg, seed = 3, 4.0, 21
+    kw = dict(width=64, height=64, steps=steps, cfg=cfg, seed=seed, batch=1, cond_y=cy, uncond_y=uy)
+    out = eng35.sample_latents(cond, uncond, method=sd.EULER_A, **kw)
+    sig = sd.get_flow_sigmas(steps, 3.0)
+    n = 16 * 64
+    x = (philox_randn_np(seed, 0, n) * sig[0]).astype(np.float32).reshape(1, 16, 8, 8)
+    off = 1
+    f32 = np.float32
+    for i in range(steps):
+        s, s_to = f32(sig[i]), f32(sig[i + 1])
+        t = np.array([s * f32(1000.0)], dtype=np.float32)
+        ec = eng35.unet_forward(x, t, cond, cy)
+        eu = eng35.unet_forward(x, t, uncond, uy)
+        den = (eu + f32(cfg) * (ec - eu)) * (-s) + x
+        if s_to == 0:
+            x = den
+            continue
+        ratio = s_to / s
+        down = min(s_to, max(f32(0), s_to * (f32(1) + (ratio - f32(1)) * f32(1.0))))
+        alpha = (f32(1) - s_to) / (f32(1) - down)
+        term = min(f32(1), max(f32(-1), (down / s_to) * alpha))
+        up = s_to * np.sqrt(max(f32(1) - term * term, f32(0)))
+        r = f32(down / s)
+        x = r * x + (f32(1) - r) * den
+        if up > 0:
+            x = x * f32(alpha) + philox_randn_np(seed, off, n).reshape(x.shape) * f32(up)
+            off += 1
+    assert np.isfinite(out).all() and rel_l2(out, x) < 1e-4
+    dev = eng35.sample_latents(cond, uncond, method=sd.EULER_A, fuse_cfg=True, device_sampler=True, **kw)
+    assert rel_l2(dev, out) < 1e-5
+    # family default = Euler for DiT models, and it differs from Euler-A
+    np.testing.assert_array_equal(eng35.sample_latents(cond, uncond, **kw), eng35.sample_latents(cond, uncond, method=sd.EULER, **kw))
+    assert rel_l2(eng35.sample_latents(cond, uncond, **kw), out) > 1e-2
+
+
 def test_sd35_generate_image_16ch_vae(sd, oracle, eng35):
     rng = np.random.default_rng(13)
     cond = rng.standard_normal((1, 12, 96)).astype(np.float32)
@@ -351,7 +395,7 @@ def test_device_resident_sampler_variants(sd, oracle):
     short = rng.standard_normal((1, 40, 64)).astype(np.float32)
     d = e.sample_latents(cond, short, cfg=6.0, **base)
     np.testing.assert_array_equal(e.sample_latents(cond, short, cfg=6.0, device_sampler=True, **base), d)
-    # through generate_image (sampler + VAE decode)
+    # through sdm_generate_image (sampler + VAE decode)
     img_h = e.generate_image(cond, uncond, width=64, height=64, steps=3, cfg=6.0, seed=4, fuse_cfg=True)
     img_d = e.generate_image(cond, uncond, width=64, height=64, steps=3, cfg=6.0, seed=4, fuse_cfg=True, device_sampler=True)
     np.testing.assert_array_equal(img_d, img_h)

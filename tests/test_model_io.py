@@ -157,3 +157,64 @@ def test_bad_files_are_rejected(sd, oracle, tmp_path):
     _write_safetensors(tmp_path / "bad.safetensors", {"model.diffusion_model.input_blocks.0.0.bias": ("F32", np.zeros((7,), np.float32))})
     with pytest.raises(sd.EngineError):
         e.load_weights(tmp_path / "bad.safetensors")
+
+
+def _e4m3_decode_np(b):
+    """OCP FP8 E4M3 ("fn") from the format definition: bias 7, no infinities, S.1111.111 = NaN"""
+    b = b.astype(np.int32)
+    s, e, m = b >> 7, (b >> 3) & 15, b & 7
+    v = np.where(e == 0, m / 8.0 * 2.0**-6, (1 + m / 8.0) * 2.0 ** (e - 7.0))
+    v = np.where((e == 15) & (m == 7), np.nan, v)
+    return np.where(s == 1, -v, v).astype(np.float32)
+
+
+def test_safetensors_wide_and_8bit_dtypes_are_converted(sd, oracle, tmp_path):
+    """F64 / I64 / F8_E4M3 / F8_E5M2 payloads are widened to f32 and then converted to the parameter's type, as the reference does
+    (safetensors_io.cpp:79-99, model_loader.cpp:81-153) — round-1 advice: they used to be dropped silently."""
+    e = sd.Engine(model=sd.SD15_TINY, backend=oracle)
+    rng = np.random.default_rng(5)
+    nb, nw = "model.diffusion_model.input_blocks.0.0.bias", "model.diffusion_model.out.2.bias"
+    n8, n52 = "model.diffusion_model.time_embed.0.bias", "model.diffusion_model.time_embed.2.bias"
+    shp = lambda n: tuple(int(d) for d in reversed(e.tensor_info(n)[0]) if d != 1) or (1,)
+    a64 = rng.standard_normal(shp(nb))
+    i64 = rng.integers(-5, 5, shp(nw)).astype(np.int64)
+    b8 = rng.integers(0, 256, shp(n8)).astype(np.uint8)
+    b8[(b8 & 0x7F) == 0x7F] = 0x3C   # keep NaNs out of the weights
+    b52 = rng.integers(0, 0x7B, shp(n52)).astype(np.uint8)   # below the E5M2 inf / NaN codes
+    _write_safetensors(tmp_path / "wide.safetensors", {nb: ("F64", a64), nw: ("I64", i64), n8: ("F8_E4M3", b8), n52: ("F8_E5M2", b52)})
+    r = e.load_weights(tmp_path / "wide.safetensors")
+    assert r["loaded"] == 4 and r["unused"] == 0
+    np.testing.assert_array_equal(e.get_tensor(nb).ravel(), a64.astype(np.float32).ravel())
+    np.testing.assert_array_equal(e.get_tensor(nw).ravel(), i64.astype(np.float32).ravel())
+    np.testing.assert_array_equal(e.get_tensor(n8).ravel(), _e4m3_decode_np(b8).ravel())
+    np.testing.assert_array_equal(e.get_tensor(n52).ravel(), (b52.astype(np.uint16) << 8).view(np.float16).astype(np.float32).ravel())
+
+
+def test_malformed_headers_are_rejected_not_overread(sd, oracle, tmp_path):
+    """Round-1 advice: a byte range shorter than prod(shape) * type_size, an undecodable dtype of a declared parameter, and GGUF dims that are
+    negative / not whole blocks / overflowing must be errors (they used to become heap over-reads or silent synthetic weights)."""
+    e = sd.Engine(model=sd.SD15_TINY, backend=oracle)
+    name = "model.diffusion_model.input_blocks.0.0.bias"
+    n = int(np.prod(e.tensor_info(name)[0]))
+    # 1. data_offsets shorter than the shape needs
+    hdr = json.dumps({name: {"dtype": "F32", "shape": [n], "data_offsets": [0, 4 * n - 8]}}).encode()
+    (tmp_path / "short.safetensors").write_bytes(struct.pack("<Q", len(hdr)) + hdr + b"\0" * (4 * n))
+    with pytest.raises(sd.EngineError, match="size mismatch"):
+        e.load_weights(tmp_path / "short.safetensors")
+    # 2. a dtype no reader decodes, on a tensor the model declares
+    _write_safetensors(tmp_path / "i8.safetensors", {name: ("I8", np.zeros((n,), np.int8))})
+    with pytest.raises(sd.EngineError, match="cannot decode"):
+        e.load_weights(tmp_path / "i8.safetensors")
+    # ... while an undecodable tensor the model does NOT declare is just unused
+    _write_safetensors(tmp_path / "i8b.safetensors", {"unrelated.flag": ("BOOL", np.zeros((3,), np.uint8)), name: ("F32", np.ones((n,), np.float32))})
+    assert e.load_weights(tmp_path / "i8b.safetensors")["loaded"] == 1
+    # 3. GGUF: K-quant type on a declared tensor; ne0 not a whole number of blocks; a dimension that overflows; data past the end of the file
+    wname = "model.diffusion_model.time_embed.0.weight"
+    ne = [int(d) for d in e.tensor_info(wname)[0][:2]]
+    _write_gguf(tmp_path / "q4k.gguf", [(wname, 12, ne, b"\0" * 64)])
+    with pytest.raises(sd.EngineError, match="cannot decode"):
+        e.load_weights(tmp_path / "q4k.gguf")
+    for bad_ne, raw in (([33, 4], b"\0" * 34 * 8), ([32, 2**62], b"\0" * 34), ([32, 2**20], b"\0" * 34)):
+        _write_gguf(tmp_path / "bad.gguf", [(wname, sd.Q8_0, bad_ne, raw)])
+        with pytest.raises(sd.EngineError, match="invalid dimensions|outside the file"):
+            e.load_weights(tmp_path / "bad.gguf")
