@@ -4,19 +4,28 @@
   python bench.py --gpus N --steps K --warmup W
   (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
 
-A "step" is one sampler iteration of the hot path over one batch of synthetic input: for every image of the per-GPU
-batch, the cond AND uncond UNet forwards (cfg 7), CFG combine and the Euler-A update — exactly what the reference's
-progress meter counts as one "it" (src/stable-diffusion.cpp:2470-2482).  Workload at N = 1: BASELINE.json configs[1]
-(SD1.5 UNet, 512x512, f16, batch 8 on one MI355X).  value = image-iterations per second over the whole job
-(batch * steps / time, summed over ranks; max time over ranks).  Images shard across ranks with no data-path
+A "step" is one sampler iteration of the hot path over one batch of synthetic input.  Default (device-resident trajectory, SURVEY.md
+section 8 f4): the latents stay in HBM for the whole timed region and every step is ONE graph — x*c_in, the cond AND uncond UNet forwards
+of every image of the per-GPU batch (cfg 7), the CFG combine and the Euler-A update — exactly what the reference's progress meter counts
+as one "it" (src/stable-diffusion.cpp:2470-2482); per step only 8 scalars and the ancestral noise cross PCIe.  With --host-loop a step
+is the cond+uncond forward pair driven from host buffers (x up, eps down each step: the reference's boundary; the CFG / Euler host math
+is then NOT in the step) — that PCIe-inclusive rate is reported beside the headline as `host_loop`, never as `value`.
+Workload at N = 1: BASELINE.json configs[1] (SD1.5 UNet, 512x512, f16, batch 8 on one MI355X).  value = image-iterations per second
+over the whole job (batch * steps / time, summed over ranks; max time over ranks).  Images shard across ranks with no data-path
 collective => weak scaling: per-GPU batch fixed.
 
 The JSON line also carries
-  roofline:     the dominant kernel (k_gemm16<128,true,32,3,8>, the 256x128-tile implicit-GEMM conv): achieved = sum of the
-                launches' algorithmic FLOPs (2 * output positions * IC*KH*KW * OC) / sum of their durations, measured live with
-                HIP events recorded on the backend's launch stream around every dispatch inside the timed region, vs the dense
-                f16 MFMA peak (2.5 PFLOP/s, MI355X_MICROARCH.md).  traffic = HBM bytes per launch from the rocprofv3 PMC passes
-                committed under profiles/ (FETCH_SIZE doubled per the guide's gfx950 correction + WRITE_SIZE), or null.
+  roofline:     headline = the dominant kernel family (implicit-GEMM conv, 256-row tiles): achieved = sum of the launches' algorithmic
+                FLOPs (2 * output positions * IC*KH*KW * OC) / sum of their durations, measured live with HIP events recorded on the
+                backend's launch stream around every dispatch INSIDE the timed region, vs the dense f16 MFMA peak (2.5 PFLOP/s,
+                MI355X_MICROARCH.md).  traffic = HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/
+                (FETCH_SIZE doubled per the guide's gfx950 correction + WRITE_SIZE), or null.
+                roofline.kernels[] = EVERY kernel family of the step, timed the same way in a short extra pass after the timed region
+                (events around ~800 launches per step would perturb the headline): contraction families against the MFMA peak,
+                layout / norm / elementwise families as algorithmic bytes (one read + one write of the activation) / time against
+                8 TB/s, each with its share of the step's kernel time.
+  sdxl:         the other model the metric names — SDXL UNet 1024x1024, q8_0 Linear + f16 conv, batch 1 per GPU (config 3's per-GPU
+                share), a few steps after the timed region: ms/step, it/s, whole-step fraction of the MFMA peak.
   cpu_baseline: the CPU oracle (restatement of the reference ggml-cpu path) timed on this box's host cores on a bounded
                 sample of the same workload (rank 0, N = 1 only).
 """
@@ -40,6 +49,7 @@ if (os.cpu_count() or 1) > 32:
 # algorithmic work per unit: 2*M*N*K per Linear / conv, 4*Lq*Lk*H*d per attention
 UNET_FWD_TFLOP = {"sd15": 0.803, "sdxl": 6.761, "sd35": 29.60, "flux": 69.47}
 MFMA_PEAK_TFLOPS = 2500.0
+HBM_PEAK_GBS = 8000.0
 
 
 def parse():
@@ -59,14 +69,18 @@ def parse():
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end sec/image leg")
     ap.add_argument("--backend-opt", action="append", default=[], metavar="KEY=INT",
                     help="planner / kernel option for A/B measurements, e.g. gemm16_sched=1 (ggml_backend_mi355x_set_option)")
-    ap.add_argument("--device-sampler", action="store_true",
-                    help="time the K steps as ONE device-resident Euler-A trajectory (SURVEY.md section 8 f4: latents stay in HBM, one graph per "
-                         "step queued without host synchronisation) instead of K host-driven cond+uncond forwards")
+    ap.add_argument("--device-sampler", action="store_true", help="(default; kept for old command lines)")
+    ap.add_argument("--host-loop", action="store_true",
+                    help="time K host-driven cond+uncond forward pairs (x up / eps down per step, the reference's boundary) instead of the "
+                         "device-resident trajectory")
+    ap.add_argument("--no-sdxl", action="store_true", help="skip the SDXL 1024x1024 sub-record")
+    ap.add_argument("--no-kernels", action="store_true", help="skip the per-kernel-family pass")
     return ap.parse_args()
 
 
 def main():
     args = parse()
+    args.device_sampler = not args.host_loop
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -160,10 +174,13 @@ def main():
     kt = sd.kernel_timing() if timing else None
     if timing:
         sd.kernel_timing_enable(False)
+    per_rank_ms = [round(dt / args.steps * 1e3, 3)]
     if world > 1:
-        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        tt = torch.zeros(world, device="cuda", dtype=torch.float64)
+        tt[rank] = dt
+        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+        per_rank_ms = [round(float(v) / args.steps * 1e3, 3) for v in tt.tolist()]   # stragglers show up here
+        dt = float(tt.max().item())
     ms_per_step = dt / args.steps * 1e3
     its = B * world * args.steps / dt
 
@@ -185,7 +202,10 @@ def main():
                 roofline["traffic_source"] = pm.get("source", "profiles/r01_pmc_traffic.json")
             except (ValueError, KeyError):
                 pass
-    roofline["whole_step_tflops"] = round(step_tflops, 2)  # all kernels + host graph build + H2D/D2H: 2*B*UNet-forward FLOPs / step wall time
+    roofline["whole_step_tflops"] = round(step_tflops, 2)  # all kernels + host graph build + uploads: 2*B*UNet-forward FLOPs / step wall time
+    roofline["whole_step_frac"] = round(step_tflops / MFMA_PEAK_TFLOPS, 4)
+    if timing and rank == 0 and not args.no_kernels:
+        roofline["kernels"] = kernel_families(sd, trajectory if args.device_sampler else None, step)
     out = {
         "metric": "denoise it/s (image-iterations/s: cond+uncond UNet forwards per image per step)",
         "value": round(its, 3),
@@ -194,6 +214,7 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3),
+        "ms_per_step_per_rank": per_rank_ms,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -220,12 +241,86 @@ def main():
                           "vae_decode_ms": round(st["last_decode_ms"], 1)}
         except Exception as exc:  # the headline line must survive a failure of the extra leg
             out["e2e"] = {"error": str(exc)[:200]}
+    if rank == 0 and world == 1 and args.device_sampler:
+        # the PCIe-inclusive rate of the reference's boundary (host buffers in and out every step), for DESIGN.md — never the headline
+        step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize()
+        hl = (time.perf_counter() - t0) / 5
+        out["host_loop"] = {"ms_per_step": round(hl * 1e3, 3), "it_per_s": round(B / hl, 2),
+                            "note": "cond+uncond forward pair per step from host buffers (x H2D, eps D2H each step); CFG / Euler math on the host is outside this step"}
+    if rank == 0 and world == 1 and args.model == "sd15" and not args.no_sdxl:
+        try:
+            out["sdxl"] = sdxl_leg(sd, backend_name, args)
+        except Exception as exc:
+            out["sdxl"] = {"error": str(exc)[:200]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not dit:  # the CPU leg is defined for the headline UNet workloads
         out["cpu_baseline"] = cpu_baseline(sd, args, lat, ctx_dim)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def kernel_families(sd, trajectory, step):
+    """Every kernel family of one step, timed with HIP events around each dispatch in a SEPARATE short pass (2 steps)."""
+    if trajectory is not None:
+        trajectory(1)
+    else:
+        step()
+    sd.kernel_timing_enable(sd.KF_ALL)
+    n = 2
+    if trajectory is not None:
+        trajectory(n)
+    else:
+        for _ in range(n):
+            step()
+    fams = sd.kernel_timings()
+    sd.kernel_timing_enable(0)
+    tot = sum(f["total_ms"] for f in fams) or 1.0
+    rows = []
+    for f in sorted(fams, key=lambda f: -f["total_ms"]):
+        sec = f["total_ms"] * 1e-3
+        if f["bound"] == "mfma":
+            ach, peak, unit = f["total_flops"] / sec / 1e12, MFMA_PEAK_TFLOPS, "TFLOP/s"
+        else:
+            ach, peak, unit = f["total_bytes"] / sec / 1e9, HBM_PEAK_GBS, "GB/s"
+        rows.append({"name": f["kernel"], "bound": f["bound"], "launches_per_step": round(f["launches"] / n, 1), "ms_per_step": round(f["total_ms"] / n, 3),
+                     "share_of_step_time": round(f["total_ms"] / tot, 4), "achieved": round(ach, 1), "peak": peak, "unit": unit, "frac": round(ach / peak, 4)})
+    return rows
+
+
+def sdxl_leg(sd, backend_name, args):
+    """SDXL UNet 1024x1024 (latent 128x128), q8_0 Linear + f16 conv weights, batch 1 per GPU, cond+uncond in one graph, device-resident
+    Euler-A steps (the 30-step convention of BASELINE.json config 3; a few steps are timed).  6.761 TFLOP per forward."""
+    import torch
+
+    t_init = time.perf_counter()
+    eng = sd.Engine(model=sd.SDXL, backend=backend_name, wtype=sd.Q8_0, flash_attn=not args.no_flash)
+    init_s = time.perf_counter() - t_init
+    rng = np.random.default_rng(99)
+    cond = rng.standard_normal((1, 77, 2048)).astype(np.float32)
+    uncond = rng.standard_normal((1, 77, 2048)).astype(np.float32)
+    y = rng.standard_normal((1, 2816)).astype(np.float32)
+    kw = dict(width=1024, height=1024, cfg=7.0, seed=42, batch=1, device_batch=1, method=sd.EULER_A, cond_y=y, uncond_y=y, fuse_cfg=True, device_sampler=True)
+    eng.sample_latents(cond, uncond, steps=2, **kw)   # builds weight images + plan
+    torch.cuda.synchronize()
+    k = 6
+    t0 = time.perf_counter()
+    eng.sample_latents(cond, uncond, steps=k, **kw)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / k * 1e3
+    tfl = 2 * UNET_FWD_TFLOP["sdxl"] / (ms / 1e3)
+    st = sd.backend_stats()
+    res = {"workload": "sdxl UNet 1024x1024, cfg 7 (cond+uncond in one graph), q8_0 Linear + f16 conv weights, batch 1/GPU, Euler-A step, device-resident",
+           "steps_timed": k, "ms_per_step": round(ms, 2), "it_per_s": round(1e3 / ms, 3), "sec_per_image_30_steps_denoise": round(30 * ms / 1e3, 3),
+           "whole_step_tflops": round(tfl, 1), "whole_step_frac": round(tfl / MFMA_PEAK_TFLOPS, 4), "engine_init_s": round(init_s, 1),
+           "swizzled_weight_bytes_total": st.get("swizzled_weight_bytes")}
+    del eng
+    return res
 
 
 def cpu_baseline(sd, args, lat, ctx_dim):

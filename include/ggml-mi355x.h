@@ -73,21 +73,28 @@ struct ggml_backend_mi355x_stats {
     int64_t fused_concat_heads;  /* token concat + head-major permute (+ f16 cast) of the MMDiT joint-attention operands in one pass */
 };
 GGML_MI355X_API void ggml_backend_mi355x_get_stats(struct ggml_backend_mi355x_stats* out);
-/* live timing of the dominant kernel (bench.py's roofline leg): HIP events on the launch stream around every dispatch of
- * that kernel while enabled; get_ synchronises the device, returns the totals since enable / the last get_, and resets. */
+/* live per-kernel-family timing (bench.py's roofline legs): while a family's bit is enabled, every dispatch of that family is bracketed by
+ * HIP events recorded on the launch stream.  get_* synchronise the device, return the totals since enable / the last get_, and reset.
+ * Family indices (bit positions of `family_mask`): 0 conv 256-row tiles, 1 conv 128-row tiles, 2 Linear GEMM, 3 flash attention,
+ * 4 q8_0/q4_0 in-register dequant GEMM, 5 f32 MFMA matmul, 6 k_nchw_to_nhwc_f16, 7 k_layer_norm_f16, 8 k_gn_stats, 9 f16 pack,
+ * 10 copies / transposes, 11 binary elementwise, 12 concat, 13 unary / scale, 14 split-K reduce, 15 f32 norms, 16 softmax, 17 other. */
 struct ggml_backend_mi355x_kernel_timing {
-    char kernel[96];     /* kernel the events bracket */
+    char kernel[96];     /* kernel family the events bracket */
     int64_t launches;
     double total_ms;     /* sum of hipEventElapsedTime over the launches */
-    double total_flops;  /* sum of the launches' algorithmic FLOPs (2 * positions * IC*KH*KW * OC) */
+    double total_flops;  /* sum of the launches' algorithmic FLOPs (conv: 2 * positions * IC*KH*KW * OC; attention: 4 * Lq * Lk * heads * d) */
+    double total_bytes;  /* sum of the launches' algorithmic HBM bytes (bandwidth-bound families: one read + one write of the activation) */
+    int32_t bound;       /* 0 = judged against the MFMA peak, 1 = against HBM bandwidth */
+    int32_t family;
 };
-GGML_MI355X_API void ggml_backend_mi355x_kernel_timing_enable(int enable);
-GGML_MI355X_API void ggml_backend_mi355x_get_kernel_timing(struct ggml_backend_mi355x_kernel_timing* out);
+GGML_MI355X_API void ggml_backend_mi355x_kernel_timing_enable(int enable);           /* != 0: family 0 only (the dominant kernel; cheap enough for the timed region) */
+GGML_MI355X_API void ggml_backend_mi355x_kernel_timing_enable_mask(uint32_t family_mask);
+GGML_MI355X_API void ggml_backend_mi355x_get_kernel_timing(struct ggml_backend_mi355x_kernel_timing* out);  /* the first timed family */
+GGML_MI355X_API int ggml_backend_mi355x_get_kernel_timings(struct ggml_backend_mi355x_kernel_timing* out, int capacity);  /* every family with launches; returns the count */
 /* options (default): "fusion" (1), "mfma_gemm" (1), "hip_graph" (0), "flash_pattern" (1), "gemm16" (1), "gemm16_variant" (3), "gemm16_tile" (-1),
  * "splitk_target" (384), "conv_tap_major" (0), "fuse_modulate" / "fuse_gate" / "fuse_gelu" / "fuse_rope" / "fuse_concat_heads" (1);
- * experiments that are off until timed on hardware: "gemm16_sched" (0: explicit LDS-read / MFMA interleave, bit 0 = 256-row tiles, bit 1 =
- * 128-row tiles; 16 / 32 = wrong-result timing ablations), "gemm16_adirect" (0: 256x160 conv tiles load the A operand global -> VGPR),
- * "splitk_mid" (0: two K slices for launches of 193..384 workgroups), "pinned_uploads" (0: set_tensor_async stages through pinned host memory so the call does not wait for the stream) */
+ * "splitk_mid" (0: two K slices for launches of 193..384 workgroups), "pinned_uploads" (0: set_tensor_async stages through pinned host memory so the call does
+ * not wait for the stream).  Wrong-result timing ablations exist only in builds with -DMI355X_EXPERIMENTS ("flash_ablate"). */
 GGML_MI355X_API void ggml_backend_mi355x_set_option(const char* key, int value);
 
 #ifdef __cplusplus

@@ -327,21 +327,41 @@ def backend_stats() -> dict:
 
 class KernelTiming(C.Structure):
     """struct ggml_backend_mi355x_kernel_timing (include/ggml-mi355x.h)"""
-    _fields_ = [("kernel", C.c_char * 96), ("launches", C.c_int64), ("total_ms", C.c_double), ("total_flops", C.c_double)]
+    _fields_ = [("kernel", C.c_char * 96), ("launches", C.c_int64), ("total_ms", C.c_double), ("total_flops", C.c_double),
+                ("total_bytes", C.c_double), ("bound", C.c_int32), ("family", C.c_int32)]
 
 
-def kernel_timing_enable(on: bool) -> None:
-    """HIP events on the launch stream around every dispatch of the dominant kernel (resets the accumulators)."""
-    _backend().ggml_backend_mi355x_kernel_timing_enable(1 if on else 0)
+KF_ALL = 0x3FFFF  # every kernel family (include/ggml-mi355x.h lists the bit positions)
+
+
+def kernel_timing_enable(on) -> None:
+    """HIP events on the launch stream around the dispatches of the enabled kernel families (resets the accumulators).
+    True / 1: the dominant family only (256-row conv tiles — cheap enough for a timed region); an int > 1 is a family bit mask; 0 / False: off."""
+    b = _backend()
+    b.ggml_backend_mi355x_kernel_timing_enable_mask.argtypes = [C.c_uint32]
+    mask = 1 if on is True else int(on or 0)
+    b.ggml_backend_mi355x_kernel_timing_enable_mask(mask)
+
+
+def _timing_dict(kt) -> dict:
+    return {"kernel": kt.kernel.decode(), "family": int(kt.family), "bound": "hbm" if kt.bound else "mfma", "launches": int(kt.launches),
+            "total_ms": float(kt.total_ms), "total_flops": float(kt.total_flops), "total_bytes": float(kt.total_bytes)}
+
+
+def kernel_timings() -> list:
+    """Per-family totals since enable / the previous call (synchronises the device and resets)."""
+    arr = (KernelTiming * 32)()
+    b = _backend()
+    b.ggml_backend_mi355x_get_kernel_timings.argtypes = [C.POINTER(KernelTiming), C.c_int]
+    b.ggml_backend_mi355x_get_kernel_timings.restype = C.c_int
+    n = b.ggml_backend_mi355x_get_kernel_timings(arr, 32)
+    return [_timing_dict(arr[i]) for i in range(n)]
 
 
 def kernel_timing() -> dict:
-    """Totals since enable / the previous call (synchronises the device and resets)."""
-    kt = KernelTiming()
-    b = _backend()
-    b.ggml_backend_mi355x_get_kernel_timing.argtypes = [C.POINTER(KernelTiming)]
-    b.ggml_backend_mi355x_get_kernel_timing(C.byref(kt))
-    return {"kernel": kt.kernel.decode(), "launches": int(kt.launches), "total_ms": float(kt.total_ms), "total_flops": float(kt.total_flops)}
+    """The first timed family (the dominant kernel when only that one is enabled)."""
+    t = kernel_timings()
+    return t[0] if t else {"kernel": "(no timed launches)", "family": -1, "bound": "mfma", "launches": 0, "total_ms": 0.0, "total_flops": 0.0, "total_bytes": 0.0}
 
 
 def backend_set_option(key: str, value: int) -> None:

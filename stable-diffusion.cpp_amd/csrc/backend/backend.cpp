@@ -23,6 +23,7 @@
 #include "ggml-abi.h"
 #include "ggml-abi-check.h"  // static_asserts: every layout fact of ggml's headers this backend was written against
 #include "ggml-mi355x.h"
+#include "ktime.h"
 #include "planner.h"
 
 namespace mi355x {  // kernels/gemm16.hip
@@ -276,6 +277,8 @@ static void* reg_get_proc(ggml_backend_reg_t, const char* name) {
     if (strcmp(name, "ggml_backend_mi355x_set_option") == 0) return (void*)ggml_backend_mi355x_set_option;
     if (strcmp(name, "ggml_backend_mi355x_kernel_timing_enable") == 0) return (void*)ggml_backend_mi355x_kernel_timing_enable;
     if (strcmp(name, "ggml_backend_mi355x_get_kernel_timing") == 0) return (void*)ggml_backend_mi355x_get_kernel_timing;
+    if (strcmp(name, "ggml_backend_mi355x_get_kernel_timings") == 0) return (void*)ggml_backend_mi355x_get_kernel_timings;
+    if (strcmp(name, "ggml_backend_mi355x_kernel_timing_enable_mask") == 0) return (void*)ggml_backend_mi355x_kernel_timing_enable_mask;
     return nullptr;
 }
 
@@ -356,10 +359,34 @@ GGML_MI355X_API void ggml_backend_mi355x_set_option(const char* key, int value) 
     }
     mi355x::planner_set_option(key, value);
 }
-GGML_MI355X_API void ggml_backend_mi355x_kernel_timing_enable(int enable) { mi355x::gemm16_timing_enable(enable != 0); }
+static void fill_timing(struct ggml_backend_mi355x_kernel_timing* o, const mi355x::KFamTiming& t, int family) {
+    memset(o, 0, sizeof(*o));
+    snprintf(o->kernel, sizeof(o->kernel), "%s", t.name);
+    o->launches    = t.launches;
+    o->total_ms    = t.total_ms;
+    o->total_flops = t.total_flops;
+    o->total_bytes = t.total_bytes;
+    o->bound       = t.bound;
+    o->family      = family;
+}
+GGML_MI355X_API void ggml_backend_mi355x_kernel_timing_enable(int enable) { mi355x::ktime_enable(enable ? 1u : 0u); }
+GGML_MI355X_API void ggml_backend_mi355x_kernel_timing_enable_mask(uint32_t family_mask) { mi355x::ktime_enable(family_mask); }
+GGML_MI355X_API int ggml_backend_mi355x_get_kernel_timings(struct ggml_backend_mi355x_kernel_timing* out, int capacity) {
+    mi355x::KFamTiming t[mi355x::KF_COUNT];
+    int fam[mi355x::KF_COUNT];
+    const int n = mi355x::ktime_read(t, mi355x::KF_COUNT, fam);
+    int m       = 0;
+    for (int i = 0; i < n && m < capacity; ++i) fill_timing(&out[m++], t[i], fam[i]);
+    return m;
+}
 GGML_MI355X_API void ggml_backend_mi355x_get_kernel_timing(struct ggml_backend_mi355x_kernel_timing* out) {
-    memset(out, 0, sizeof(*out));
-    snprintf(out->kernel, sizeof(out->kernel), "%s", mi355x::gemm16_timing_kernel_name());
-    mi355x::gemm16_timing_read(&out->launches, &out->total_ms, &out->total_flops);
+    struct ggml_backend_mi355x_kernel_timing all[mi355x::KF_COUNT];
+    const int n = ggml_backend_mi355x_get_kernel_timings(all, mi355x::KF_COUNT);
+    if (n > 0) {
+        *out = all[0];
+    } else {
+        memset(out, 0, sizeof(*out));
+        snprintf(out->kernel, sizeof(out->kernel), "(no timed launches)");
+    }
 }
 }

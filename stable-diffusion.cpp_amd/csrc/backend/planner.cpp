@@ -1620,6 +1620,7 @@ void planner_set_option(const char* key, int value) {
 #ifdef MI355X_EXPERIMENTS
     else if (!strcmp(key, "flash_ablate")) flash_attn_set_ablate(value);
 #endif
+    else if (!strcmp(key, "gemm16_t320")) gemm16_set_t320(value);
     else if (!strcmp(key, "gemm16")) (void)value;  // kept for old scripts: the gemm16 path is the only one (first-generation kernels removed)
     else if (!strcmp(key, "fuse_modulate")) g_opt.fuse_modulate = value;
     else if (!strcmp(key, "fuse_gate")) g_opt.fuse_gate = value;

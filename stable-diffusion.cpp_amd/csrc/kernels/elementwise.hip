@@ -3,9 +3,14 @@
 // timestep embedding, GEGLU.  All are judged against the HBM roofline: algorithmic bytes = one read of
 // each input + one write of the output.  128-bit accesses wherever the layout allows.
 #include "kernels.h"
+#include "ktime.h"
 #include "device_utils.h"
 
 namespace mi355x {
+
+static inline double v4_elems(const View4& v) { return (double)v.ne[0] * (double)v.ne[1] * (double)v.ne[2] * (double)v.ne[3]; }
+static inline double v4_esize(const View4& v) { return v.type == 0 ? 4.0 : (v.type == 1 || v.type == 30 ? 2.0 : 4.0); }
+
 
 static inline int grid_for(int64_t n, int block, int cap = 256 * 16) {
     int64_t g = (n + block - 1) / block;
@@ -145,6 +150,7 @@ static void binary_dispatch(hipStream_t s, void* dst, const int64_t dnb[4], cons
 }
 
 void launch_binary(hipStream_t s, BinOp op, void* dst, const int64_t dnb[4], const View4& a, const View4& b) {
+    KScope ks_(s, KF_BINARY, 0.0, v4_elems(a) * 8.0 + v4_elems(b) * 4.0);  // read a (+ broadcast b), write dst
     switch (op) {
         case BIN_ADD: binary_dispatch<BIN_ADD>(s, dst, dnb, a, b); break;
         case BIN_SUB: binary_dispatch<BIN_SUB>(s, dst, dnb, a, b); break;
@@ -171,6 +177,7 @@ __global__ void k_unary(float* __restrict__ dst, const float* __restrict__ src, 
     }
 }
 void launch_unary(hipStream_t s, UnOp op, float* dst, const float* src, int64_t n) {
+    KScope ks_(s, KF_UNARY, 0.0, (double)n * 8.0);
     const int block = 256, grid = grid_for(n / 4 + 1, block);
 #define U(OPV) case OPV: k_unary<OPV><<<grid, block, 0, s>>>(dst, src, n); break;
     switch (op) {
@@ -183,6 +190,7 @@ __global__ void k_scale(float* __restrict__ dst, const float* __restrict__ src, 
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i] * sc + bias;
 }
 void launch_scale(hipStream_t s, float* dst, const float* src, int64_t n, float scale, float bias) {
+    KScope ks_(s, KF_UNARY, 0.0, (double)n * 8.0);
     k_scale<<<grid_for(n, 256), 256, 0, s>>>(dst, src, n, scale, bias);
 }
 
@@ -310,6 +318,7 @@ static void copy_typed(hipStream_t s, const View4& dst, const View4& src) {
 }
 
 void launch_copy(hipStream_t s, const View4& dst, const View4& src) {
+    KScope ks_(s, KF_COPY, 0.0, v4_elems(src) * (v4_esize(src) + v4_esize(dst)));
     const int F32 = 0, F16 = 1, BF16 = 30;
     if (src.type == F32 && dst.type == F32) return copy_typed<float, float>(s, dst, src);
     if (src.type == F32 && dst.type == F16) return copy_typed<float, __half>(s, dst, src);
@@ -339,6 +348,7 @@ __global__ void k_rope_pairs(float* __restrict__ out, const char* __restrict__ x
     }
 }
 void launch_rope_pairs(hipStream_t s, float* out, const View4& x, const float* pe) {
+    KScope ks_(s, KF_OTHER, 0.0, v4_elems(x) * 8.0);
     const int d2 = (int)(x.ne[0] / 2);
     const int64_t npairs = (int64_t)d2 * x.ne[1] * x.ne[2] * x.ne[3];
     k_rope_pairs<<<grid_for(npairs, 256), 256, 0, s>>>(out, (const char*)x.data, pe, d2, (int)x.ne[1], x.ne[2], x.ne[3], x.nb[1], x.nb[2], x.nb[3], npairs);
@@ -360,6 +370,7 @@ __global__ void k_concat_heads(TD* __restrict__ out, const float* __restrict__ a
     }
 }
 void launch_concat_heads(hipStream_t s, void* out, bool out_f16, const float* a, const float* b, int64_t d, int64_t H, int64_t La, int64_t Lb, int64_t N) {
+    KScope ks_(s, KF_CONCAT, 0.0, (double)d * H * (La + Lb) * N * (4.0 + (out_f16 ? 2.0 : 4.0)));
     const int64_t n4 = d / 4 * H * (La + Lb) * N;
     if (out_f16)
         k_concat_heads<__half><<<grid_for(n4, 256), 256, 0, s>>>((__half*)out, a, b, (int)(d / 4), (int)H, La, Lb, N, n4);
@@ -413,6 +424,7 @@ static Idx4 mk(const View4& v) {
     return r;
 }
 void launch_concat(hipStream_t s, const View4& dst, const View4& a, const View4& b, int dim) {
+    KScope ks_(s, KF_CONCAT, 0.0, v4_elems(dst) * 8.0);
     const int64_t n = dst.ne[0] * dst.ne[1] * dst.ne[2] * dst.ne[3];
     if (dim == 2 && contig_f32(a.ne, a.nb) && contig_f32(b.ne, b.nb) && contig_f32(dst.ne, dst.nb)) {
         const int64_t sa = a.ne[0] * a.ne[1] * a.ne[2], sb = b.ne[0] * b.ne[1] * b.ne[2];
@@ -443,6 +455,7 @@ __global__ void k_repeat(char* __restrict__ dst, const char* __restrict__ src, I
     }
 }
 void launch_repeat(hipStream_t s, const View4& dst, const View4& src) {
+    KScope ks_(s, KF_COPY, 0.0, v4_elems(dst) * 4.0 + v4_elems(src) * 4.0);
     const int64_t n = dst.ne[0] * dst.ne[1] * dst.ne[2] * dst.ne[3];
     k_repeat<<<grid_for(n, 256), 256, 0, s>>>((char*)dst.data, (const char*)src.data, mk(dst), mk(src), n);
 }
@@ -455,6 +468,7 @@ __global__ void k_upscale(char* __restrict__ dst, const char* __restrict__ src, 
     }
 }
 void launch_upscale_nearest(hipStream_t s, const View4& dst, const View4& src) {
+    KScope ks_(s, KF_COPY, 0.0, v4_elems(dst) * 4.0 + v4_elems(src) * 4.0);
     const int64_t n = dst.ne[0] * dst.ne[1] * dst.ne[2] * dst.ne[3];
     k_upscale<<<grid_for(n, 256), 256, 0, s>>>((char*)dst.data, (const char*)src.data, mk(dst), mk(src), (float)dst.ne[0] / src.ne[0],
                                               (float)dst.ne[1] / src.ne[1], (float)dst.ne[2] / src.ne[2], (float)dst.ne[3] / src.ne[3], n);
@@ -514,6 +528,7 @@ __global__ void k_geglu(float* __restrict__ dst, const float* __restrict__ x, in
     }
 }
 void launch_geglu(hipStream_t s, float* dst, const float* x, int64_t tokens, int64_t inner, int64_t x_stride) {
+    KScope ks_(s, KF_OTHER, 0.0, (double)tokens * inner * 12.0);
     const int64_t n4 = tokens * inner / 4;
     k_geglu<<<grid_for(n4, 256), 256, 0, s>>>(dst, x, n4, (int)(inner / 4), x_stride / 4);
 }

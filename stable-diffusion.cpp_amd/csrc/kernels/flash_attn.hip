@@ -17,6 +17,7 @@
 // BEFORE the MFMAs of tile t and written to LDS after the next barrier, so HBM/L2 latency hides under compute.
 #include "device_utils.h"
 #include "kernels.h"
+#include "ktime.h"
 
 namespace mi355x {
 
@@ -336,6 +337,7 @@ void flash_attn_set_ablate(int v) { g_flash_ablate = v; }
 #endif
 
 void launch_flash_attn(hipStream_t s, const FlashOut& out, const View4& q, const View4& k, const View4& v, float scale) {
+    KScope ks_(s, KF_FLASH, 4.0 * (double)q.ne[1] * (double)k.ne[1] * (double)q.ne[2] * (double)q.ne[0], 0.0);  // 4 * Lq * Lk * (H*N) * d
     FAArgs g;
     g.q = (const char*)q.data;
     g.k = (const char*)k.data;

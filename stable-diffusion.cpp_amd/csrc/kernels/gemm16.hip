@@ -20,10 +20,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <mutex>
+#include <type_traits>
 #include <utility>
 #include <vector>
 #include "device_utils.h"
 #include "kernels.h"
+#include "ktime.h"
 
 namespace mi355x {
 
@@ -260,8 +262,15 @@ __device__ __forceinline__ void epi_conv(const float16_t (&acc)[RB][CB], const G
 }
 
 // geometry: workgroup tile BM x BN, WR x WC waves, each wave owns (BM/WR) x (BN/WC) outputs = RB x CB blocks of 32x32
-template <int BM, int BN, bool CONV, int BK, int NST, int WR, int WC>
-__global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm16(G16Args g) {
+// PIPE = 1 (tile configuration T320: 256 x 320, 8 waves of 64 x 160, BK 32, FOUR stages = 144 KB of LDS, one workgroup per CU):
+// the software-pipelined main loop.  The fragment reads of the NEXT k-step are issued before the MFMAs of the current one (A fragments
+// double-buffered, each B fragment re-loaded in place right behind its last use), so the matrix pipe never waits for LDS; the one
+// barrier per stage sits at the head of the stage's LAST k-step — every wave has its fragments of that k-step in registers by then, so
+// the barrier both publishes stage kt+1 (each wave waited for its own DMA pieces first) and frees slot kt for the DMA of stage kt+4,
+// with two further stages (72 KB) in flight across it.  FLOP per DMA byte is 1.45x the 256x160 tile's (the LDS-DMA stream, ~23 B/clk/CU,
+// is what bounds these kernels: profiles/r02a_gemm_ablation_kernel_stats.csv).
+template <int BM, int BN, bool CONV, int BK, int NST, int WR, int WC, int PIPE = 0>
+__global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g) {
     constexpr int NW  = WR * WC;
     constexpr int RB  = BM / WR / 32;  // 32-row blocks per wave
     constexpr int CB  = BN / WC / 32;  // 32-col blocks per wave
@@ -467,7 +476,147 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm16(G16Args g) {
         }
     };
 
-    if (NST == 2) {
+    if constexpr (PIPE) {
+        // ---- hand-scheduled software pipeline (see the header comment of this kernel).  Fragment reads and waits are inline asm: left to
+        // the compiler, every k-step opened with s_waitcnt lgkmcnt(0) behind freshly issued reads and the reads were sunk below the MFMAs.
+        // Ordering rules used here: asm volatile statements keep their program order; an MFMA is tied behind a wait by passing its operand
+        // registers through an empty asm ("+v") placed after the wait; sched_barrier(0) keeps the {MFMA group, read} interleave as written.
+        static_assert(KSTEPS == 2 && NST == 4 && RB == 2 && ROWB == 64 && CB >= 3, "the pipelined loop is written for BK 32 x 4 stages, 64-row waves");
+        constexpr int STAGE = ABYTES + BBYTES;
+        const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+        const uint32_t aad0 = lds0 + (uint32_t)aoff[0] + (uint32_t)(((0 + hi) ^ aswz) << 4);  // row block 0, k-step 0 (row block 1: + 32 rows = + 2048 B)
+        const uint32_t aad1 = lds0 + (uint32_t)aoff[0] + (uint32_t)(((2 + hi) ^ aswz) << 4);  // k-step 1
+        const uint32_t bad  = lds0 + (uint32_t)(ABYTES + (wc * CB * KSTEPS) * 1024 + lane * 16);
+        // fragment registers: two A sets (current / next k-step); column blocks 0 .. CB-3 are re-read in place right behind their MFMAs;
+        // the LAST two column blocks are double-buffered (BH0 / BH1) and read at the head of a k-step, so that no read is issued during
+        // the last two MFMA groups (128 cycles) in front of the wait that needs every fragment of the next k-step
+        constexpr int CL = CB - 2;
+        half8_t A0[RB], A1[RB], BL[CL], BH0[2], BH1[2];
+        auto mma = [&](int rb, int cb, const half8_t& a, const half8_t& b) {
+            if (CONV)
+                acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b, a, acc[rb][cb], 0, 0, 0);  // D[oc][pos]
+            else
+                acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[rb][cb], 0, 0, 0);  // D[row][col]
+        };
+#define G16_RD(DST_, ADDR_, OFF_) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST_) : "v"(ADDR_), "n"(OFF_))
+#define G16_TIE(X_) asm volatile("" : "+v"(X_))
+        // One k-step.  ACUR / ANXT, HCUR / HNXT: current and next fragment sets; an_ / bn_: LDS addresses of this lane's A row (row block 0)
+        // and of this wave's first B fragment for the NEXT k-step (KSN_ = its index inside its stage)
+#define G16_KSTEP(ACUR, ANXT, HCUR, HNXT, an_, bn_, KSN_)                                                            \
+    do {                                                                                                             \
+        G16_RD(ANXT[0], an_, 0);                                                                                     \
+        G16_RD(ANXT[1], an_, 2048);                                                                                  \
+        G16_RD(HNXT[0], bn_, ((CB - 2) * KSTEPS + (KSN_)) * 1024);                                                   \
+        G16_RD(HNXT[1], bn_, ((CB - 1) * KSTEPS + (KSN_)) * 1024);                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        mma(0, 0, ACUR[0], BL[0]);                                                                                   \
+        mma(1, 0, ACUR[1], BL[0]);                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        G16_RD(BL[0], bn_, (0 * KSTEPS + (KSN_)) * 1024);                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        mma(0, 1, ACUR[0], BL[1]);                                                                                   \
+        mma(1, 1, ACUR[1], BL[1]);                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        G16_RD(BL[1], bn_, (1 * KSTEPS + (KSN_)) * 1024);                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        if constexpr (CL > 2) {                                                                                      \
+            mma(0, 2, ACUR[0], BL[CL - 1]);                                                                          \
+            mma(1, 2, ACUR[1], BL[CL - 1]);                                                                          \
+            __builtin_amdgcn_sched_barrier(0);                                                                       \
+            G16_RD(BL[CL - 1], bn_, (2 * KSTEPS + (KSN_)) * 1024);                                                   \
+            __builtin_amdgcn_sched_barrier(0);                                                                       \
+        }                                                                                                            \
+        mma(0, CB - 2, ACUR[0], HCUR[0]);                                                                            \
+        mma(1, CB - 2, ACUR[1], HCUR[0]);                                                                            \
+        mma(0, CB - 1, ACUR[0], HCUR[1]);                                                                            \
+        mma(1, CB - 1, ACUR[1], HCUR[1]);                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+    } while (0)
+        // tie every fragment the next MFMAs use behind the s_waitcnt issued just before (asm volatile statements keep their order)
+#define G16_TIE_FRAGS(AS_, HS_)                                                                                      \
+    do {                                                                                                             \
+        G16_TIE(AS_[0]);                                                                                             \
+        G16_TIE(AS_[1]);                                                                                             \
+        _Pragma("unroll") for (int cb = 0; cb < CL; ++cb) G16_TIE(BL[cb]);                                           \
+        G16_TIE(HS_[0]);                                                                                             \
+        G16_TIE(HS_[1]);                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+    } while (0)
+#define G16_PIPE_LOOP(NP_)                                                                                                         \
+    do {                                                                                                                           \
+        const int npro = nt < NST ? nt : NST;                                                                                      \
+        for (int i = 0; i < npro; ++i) {                                                                                           \
+            stage(kt0 + i, i, c_tap, c_kh, c_kw, c_icb, c_sub);                                                                    \
+            G16_ADVANCE();                                                                                                         \
+        }                                                                                                                          \
+        /* stage 0 landed (later stages stay in flight), published by the barrier */                                              \
+        if (npro >= 4)                                                                                                             \
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (NP_)) : "memory");                                                       \
+        else if (npro == 3)                                                                                                        \
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NP_)) : "memory");                                                       \
+        else if (npro == 2)                                                                                                        \
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP_) : "memory");                                                             \
+        else                                                                                                                       \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                       \
+        asm volatile("s_barrier" ::: "memory");                                                                                    \
+        G16_RD(A0[0], aad0, 0);                                                                                                    \
+        G16_RD(A0[1], aad0, 2048);                                                                                                 \
+        G16_RD(BL[0], bad, (0 * KSTEPS) * 1024);                                                                                   \
+        G16_RD(BL[1], bad, (1 * KSTEPS) * 1024);                                                                                   \
+        if constexpr (CL > 2) G16_RD(BL[CL - 1], bad, (2 * KSTEPS) * 1024);                                                        \
+        G16_RD(BH0[0], bad, ((CB - 2) * KSTEPS) * 1024);                                                                           \
+        G16_RD(BH0[1], bad, ((CB - 1) * KSTEPS) * 1024);                                                                           \
+        int buf = 0, kt = 0;                                                                                                       \
+        /* steady state: stages kt+1 .. kt+3 exist and stage kt+4 is issued — nothing in the body is conditional */               \
+        for (; kt + NST < nt; ++kt) {                                                                                              \
+            const uint32_t so = (uint32_t)buf * STAGE;                                                                             \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                     \
+            G16_TIE_FRAGS(A0, BH0);                                                                                                \
+            G16_KSTEP(A0, A1, BH0, BH1, aad1 + so, bad + so, 1);                                                                   \
+            /* this wave's pieces of stage kt+1 have landed (two younger stages stay in flight) and all its fragment reads of       \
+               stage kt are complete; the barrier then makes stage kt+1 readable and this slot refillable for everyone */           \
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * (NP_)) : "memory");                                            \
+            G16_TIE_FRAGS(A1, BH1);                                                                                                \
+            asm volatile("s_barrier" ::: "memory");                                                                                \
+            stage(kt0 + kt + NST, buf, c_tap, c_kh, c_kw, c_icb, c_sub);                                                           \
+            G16_ADVANCE();                                                                                                         \
+            buf               = buf == NST - 1 ? 0 : buf + 1;                                                                      \
+            const uint32_t sn = (uint32_t)buf * STAGE;                                                                             \
+            __builtin_amdgcn_sched_barrier(0);                                                                                     \
+            G16_KSTEP(A1, A0, BH1, BH0, aad0 + sn, bad + sn, 0);                                                                   \
+        }                                                                                                                          \
+        /* drain: the last (up to NST) stages, nothing left to issue */                                                           \
+        for (; kt < nt; ++kt) {                                                                                                    \
+            const uint32_t so = (uint32_t)buf * STAGE;                                                                             \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                     \
+            G16_TIE_FRAGS(A0, BH0);                                                                                                \
+            G16_KSTEP(A0, A1, BH0, BH1, aad1 + so, bad + so, 1);                                                                   \
+            if (kt + 3 < nt)                                                                                                       \
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * (NP_)) : "memory");                                        \
+            else if (kt + 2 < nt)                                                                                                  \
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NP_) : "memory");                                              \
+            else                                                                                                                   \
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                        \
+            G16_TIE_FRAGS(A1, BH1);                                                                                                \
+            asm volatile("s_barrier" ::: "memory");                                                                                \
+            buf               = buf == NST - 1 ? 0 : buf + 1;                                                                      \
+            const uint32_t sn = (uint32_t)buf * STAGE;                                                                             \
+            /* after the last stage the "next" fragment reads fetch stale bytes of the following slot: harmless, never used —      \
+               keeping the body unconditional keeps the accumulators in place (a branch here made the compiler copy and spill them) */ \
+            G16_KSTEP(A1, A0, BH1, BH0, aad0 + sn, bad + sn, 0);                                                                   \
+        }                                                                                                                          \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                         \
+    } while (0)
+        if (WEXTRA != 0 && w_short)
+            G16_PIPE_LOOP(NPT - 1);
+        else
+            G16_PIPE_LOOP(NPT);
+#undef G16_PIPE_LOOP
+#undef G16_TIE_FRAGS
+#undef G16_KSTEP
+#undef G16_TIE
+#undef G16_RD
+    } else if (NST == 2) {
         // one barrier per K tile: its implicit vmcnt(0) retires this tile's DMA, the next tile's DMA overlaps the MFMAs
         stage(kt0, 0, c_tap, c_kh, c_kw, c_icb, c_sub);
         G16_ADVANCE();
@@ -558,40 +707,6 @@ int gemm16_tap_major() { return g_g16_tap_major; }
 void gemm16_set_variant(int v) { g_g16_variant = v; }
 static inline bool g16_bk32() { return g_g16_variant == 1 || g_g16_variant == 3; }
 
-// ---- live timing of the dominant kernel (bench.py's roofline leg): HIP events recorded on the launch stream around every
-// k_gemm16<128, true, 32, 3, 8> dispatch (the 256x128-tile implicit-GEMM conv), with the launch's algorithmic FLOPs.
-namespace {
-struct G16Timing {
-    std::mutex mu;
-    bool on = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
-    std::vector<double> flops;
-    size_t used = 0;
-} g_timing;
-}  // namespace
-void gemm16_timing_enable(bool on) {
-    std::lock_guard<std::mutex> lk(g_timing.mu);
-    g_timing.on   = on;
-    g_timing.used = 0;
-    g_timing.flops.clear();
-}
-void gemm16_timing_read(int64_t* launches, double* ms, double* flops) {
-    std::lock_guard<std::mutex> lk(g_timing.mu);
-    (void)hipDeviceSynchronize();
-    double t = 0, f = 0;
-    for (size_t i = 0; i < g_timing.used; ++i) {
-        float e = 0.f;
-        if (hipEventElapsedTime(&e, g_timing.pool[i].first, g_timing.pool[i].second) == hipSuccess) t += e;
-        f += g_timing.flops[i];
-    }
-    *launches     = (int64_t)g_timing.used;
-    *ms           = t;
-    *flops        = f;
-    g_timing.used = 0;
-    g_timing.flops.clear();
-}
-const char* gemm16_timing_kernel_name() { return "k_gemm16<256, *, true, 32, 3, *, *> (implicit-GEMM conv, 256-row tiles)"; }
-
 // tile configurations (all BK 32 x 3 stages, counted vmcnt):
 //   T128   128x128, 4 waves of 64x64   (48 KB LDS, 3 workgroups/CU)  — small outputs, finest granularity
 //   T256   256x128, 8 waves of 64x64   (72 KB, 2/CU)                 — large outputs, 1.33x the per-round area of T128
@@ -599,21 +714,32 @@ const char* gemm16_timing_kernel_name() { return "k_gemm16<256, *, true, 32, 3, 
 //   T160   256x160, 4 waves of 64x160  (78 KB, 2/CU)                 — outputs that are multiples of 160 but not of 128 (SD1.5's 320):
 //                                                                       no padded columns, 2 column tiles instead of 3
 //   T160N  256x160, 8 waves of 32x160  (78 KB, 2/CU)                 — T160 with twice the waves in flight (experiment)
-enum { G16_T128 = 0, G16_T256 = 1, G16_T256W = 2, G16_T160 = 3, G16_T160N = 4 };
+enum { G16_T128 = 0, G16_T256 = 1, G16_T256W = 2, G16_T160 = 3, G16_T160N = 4, G16_T320 = 5 };
 static int g_g16_force_tile = -1;  // option "gemm16_tile": force one configuration (A/B measurements); -1 = choose per shape
 void gemm16_set_tile(int t) { g_g16_force_tile = t; }
 // Per-shape choice.  Measured on SD1.5 batch 16 (profiles/r01e_tile_configs.txt): a launch takes ceil(workgroups / resident slots)
 // rounds; a full round of T128 (768 slots) and of T256 (512 slots, twice the area per workgroup) take about the same time, a T160
 // round 1.5x that (4 waves per workgroup hide less latency) but covers 1.25x T256's area with no padded columns.  256-row tiles
 // only pay when they fill every CU twice (>= 512 workgroups); otherwise the finer T128 quantises better.
-static int g16_pick_tile(int64_t rows, int64_t M, bool geglu, bool conv) {
+static int g_g16_t320 = 1;  // option "gemm16_t320": 0 disables the pipelined 256x320 tile in the per-shape choice (A/B measurements)
+void gemm16_set_t320(int v) { g_g16_t320 = v; }
+static int g16_pick_tile(int64_t rows, int64_t M, bool geglu, bool conv, bool split) {
     if (g_g16_variant != 3) return G16_T128;
     const bool can160 = M % 160 == 0 && !geglu;
+    // T320 (256x320, one workgroup per CU): the weight image is padded to 128 columns only, so M must be a multiple of 320; the GEGLU
+    // pairing is laid out for 128-column tiles
+    const bool can320 = M % 320 == 0 && !geglu;
     if (g_g16_force_tile >= 0) {
+        if (g_g16_force_tile == G16_T320) return can320 ? G16_T320 : G16_T256;
         if ((g_g16_force_tile == G16_T160 || g_g16_force_tile == G16_T160N) && !can160) return G16_T256;
         return g_g16_force_tile;
     }
     const int64_t rt256 = (rows + 255) / 256, c128 = ((rows + 127) / 128) * ((M + 127) / 128), c256 = rt256 * ((M + 127) / 128);
+    if (g_g16_t320 && can320 && !split) {
+        // one workgroup per CU and 256 CUs: take it when the launch fills >= 75 % of its rounds
+        const int64_t c320 = rt256 * (M / 320), rounds = (c320 + 255) / 256;
+        if (c320 >= 192 && c320 * 4 >= rounds * 256 * 3) return G16_T320;
+    }
     const int64_t c160 = can160 ? rt256 * (M / 160) : 0;
     double best = (double)((c128 + 767) / 768) * 1.0;
     int tile    = G16_T128;
@@ -632,25 +758,14 @@ template <int BN_, bool CONV_>
 static void g16_launch(hipStream_t s, G16Args& g, int64_t rows, double flops) {
     const unsigned ny = g.split_k > 1 ? (unsigned)g.split_k : 1u;
     if (BN_ == 128 && g_g16_variant == 3) {
-        const int tile = g16_pick_tile(rows, g.C, g.geglu_inner > 0, CONV_);  // the GEGLU pairing is laid out for 128-column tiles
+        const int tile = g16_pick_tile(rows, g.C, g.geglu_inner > 0, CONV_, g.split_k > 1);  // the GEGLU pairing is laid out for 128-column tiles
         if (tile != G16_T128) {
             const int64_t rt256 = (rows + 255) / 256;
-            hipEvent_t e0 = nullptr, e1 = nullptr;
-            if (CONV_ && g_timing.on) {
-                std::lock_guard<std::mutex> lk(g_timing.mu);
-                if (g_timing.used == g_timing.pool.size()) {
-                    hipEvent_t a, b;
-                    (void)hipEventCreate(&a);
-                    (void)hipEventCreate(&b);
-                    g_timing.pool.emplace_back(a, b);
-                }
-                e0 = g_timing.pool[g_timing.used].first;
-                e1 = g_timing.pool[g_timing.used].second;
-                g_timing.flops.push_back(flops);
-                ++g_timing.used;
-                (void)hipEventRecord(e0, s);
-            }
-            if (tile == G16_T160) {
+            KScope ks_(s, CONV_ ? KF_CONV_T256 : KF_LINEAR, flops, 0.0);
+            if (tile == G16_T320) {
+                g.ncol_tiles = (int)((g.C + 319) / 320);
+                k_gemm16<256, 320, CONV_, 32, 4, 4, 2, 1><<<dim3((unsigned)(rt256 * g.ncol_tiles), ny), 512, 0, s>>>(g);
+            } else if (tile == G16_T160) {
                 g.ncol_tiles = (int)(g.C / 160);
                 k_gemm16<256, 160, CONV_, 32, 3, 4, 1><<<dim3((unsigned)(rt256 * g.ncol_tiles), ny), 256, 0, s>>>(g);
             } else if (tile == G16_T160N) {
@@ -661,11 +776,11 @@ static void g16_launch(hipStream_t s, G16Args& g, int64_t rows, double flops) {
             } else {
                 k_gemm16<256, 128, CONV_, 32, 3, 4, 2><<<dim3((unsigned)(rt256 * g.ncol_tiles), ny), 512, 0, s>>>(g);
             }
-            if (e1) (void)hipEventRecord(e1, s);
             return;
         }
     }
     const dim3 grid((unsigned)(((rows + 127) / 128) * g.ncol_tiles), ny);
+    KScope ks_(s, CONV_ ? KF_CONV_T128 : KF_LINEAR, flops, 0.0);
     if (g_g16_variant == 0)
         k_gemm16<128, BN_, CONV_, 64, 2, 2, 2><<<grid, 256, 0, s>>>(g);
     else if (g_g16_variant == 2)
@@ -734,6 +849,7 @@ __global__ void k_splitk_reduce(float* __restrict__ dst, const float* __restrict
     for (int j = 0; j < W; ++j) dst[i + j] = v[j];
 }
 static void launch_splitk_reduce(hipStream_t s, float* dst, const float* ws, int S, int64_t n, const float* bias, int64_t inner, int64_t C, const float* residual) {
+    KScope ks_(s, KF_SPLITK, 0.0, (double)n * 4.0 * (S + 1));
     const bool v4 = n % 4 == 0 && (inner % 4 == 0 || (inner == 1 && C % 4 == 0)) && (((uintptr_t)dst | (uintptr_t)ws | (uintptr_t)residual) & 15) == 0;
     if (v4)
         k_splitk_reduce<true><<<(unsigned)((n / 4 + 255) / 256), 256, 0, s>>>(dst, ws, S, n, n, bias, inner, (int)C, residual);
@@ -910,6 +1026,7 @@ __global__ void k_pack_rows_f16(_Float16* __restrict__ dst, const float* __restr
     }
 }
 void launch_pack_rows_f16(hipStream_t s, void* dst, const float* x, int64_t R, int64_t K, int64_t xs, int64_t L, int64_t bs) {
+    KScope ks_(s, KF_PACK_F16, 0.0, (double)R * K * 4.0 + (double)R * rup64(K, 64) * 2.0);
     const int Kp = (int)rup64(K, 64);
     const int64_t n8 = R * (Kp / 8);
     int64_t blocks   = (n8 + 255) / 256;
@@ -966,6 +1083,7 @@ __global__ __launch_bounds__(256) void k_layer_norm_f16(_Float16* __restrict__ d
 }
 void launch_layer_norm_f16(hipStream_t s, void* dst, const float* x, int64_t ne0, int64_t nrows, int64_t xs, float eps, const float* w, const float* b, bool rms,
                            int64_t mod_L) {
+    KScope ks_(s, KF_LN_F16, 0.0, (double)nrows * ne0 * 4.0 + (double)nrows * rup64(ne0, 64) * 2.0);
     const int Kp = (int)rup64(ne0, 64);
     k_layer_norm_f16<<<(unsigned)((nrows + 3) / 4), 256, 0, s>>>((_Float16*)dst, x, (int)ne0, Kp, nrows, xs, eps, w, b, rms ? 1 : 0, mod_L);
 }
@@ -988,6 +1106,7 @@ __global__ void k_geglu_f16(_Float16* __restrict__ dst, const float* __restrict_
     }
 }
 void launch_geglu_f16(hipStream_t s, void* dst, const float* x, int64_t tokens, int64_t inner, int64_t xs) {
+    KScope ks_(s, KF_PACK_F16, 0.0, (double)tokens * inner * 8.0 + (double)tokens * rup64(inner, 64) * 2.0);
     const int Kp = (int)rup64(inner, 64);
     const int64_t n4 = tokens * (Kp / 4);
     int64_t blocks   = (n4 + 255) / 256;
@@ -1041,6 +1160,7 @@ __global__ __launch_bounds__(NT) void k_gn_stats(float* __restrict__ scale, floa
 }
 void launch_gn_stats(hipStream_t s, float* scale, float* shift, const float* x, int64_t hw, int64_t C, int64_t N, int groups, float eps, const float* w,
                      const float* b) {
+    KScope ks_(s, KF_GN_STATS, 0.0, (double)hw * C * N * 4.0);  // algorithmic: ONE read of the activation (the kernel reads it twice)
     const int cpg = (int)((C + groups - 1) / groups);
     if (cpg * hw >= 16384)
         k_gn_stats<1024><<<(unsigned)(N * groups), 1024, 0, s>>>(scale, shift, x, hw, (int)C, groups, cpg, eps, w, b);
@@ -1075,6 +1195,7 @@ __global__ __launch_bounds__(256) void k_nchw_to_nhwc_f16(_Float16* __restrict__
     }
 }
 void launch_nchw_to_nhwc_f16(hipStream_t s, void* dst, const float* x, int64_t hw, int64_t C, int64_t N, const float* scale, const float* shift, bool silu) {
+    KScope ks_(s, KF_NCHW_NHWC, 0.0, (double)hw * C * N * 4.0 + (double)hw * rup64(C, 64) * N * 2.0);
     const int Cp = (int)rup64(C, 64);
     dim3 grid((unsigned)((hw + 63) / 64), (unsigned)(Cp / 64), (unsigned)N);
     k_nchw_to_nhwc_f16<<<grid, 256, 0, s>>>((_Float16*)dst, x, hw, (int)C, Cp, scale, shift, silu ? 1 : 0);

@@ -4,6 +4,7 @@
 // Also: IM2COL (F16/F32 dst) for the unfused conv path.
 #include "device_utils.h"
 #include "kernels.h"
+#include "ktime.h"
 
 namespace mi355x {
 
@@ -112,6 +113,7 @@ __global__ __launch_bounds__(256) void k_mul_mat_generic(float* __restrict__ dst
 }
 
 void launch_mul_mat_generic(hipStream_t s, float* dst, const int64_t dne[4], const int64_t dnb[4], const View4& a, const View4& b) {
+    KScope ks_(s, KF_GEMM_F32, 2.0 * (double)dne[0] * dne[1] * dne[2] * dne[3] * (double)a.ne[0], 0.0);
     MMArgs g;
     g.K = a.ne[0];
     g.M = a.ne[1];

@@ -85,7 +85,8 @@ void gemm16_set_tap_major(int v);  // A/B: conv K order (tap, channel block) ins
 int gemm16_tap_major();
 void gemm16_set_splitk_target(int v);
 void gemm16_set_splitk_mid(int v);  // 1: two K slices for launches of 193..384 workgroups with >= 128 K tiles (experiment, default 0)
-void gemm16_set_tile(int t);     // -1: per-shape choice; 0..3: force T128 / T256 / T256W / T160 (A/B measurements)
+void gemm16_set_tile(int t);     // -1: per-shape choice; 0..5: force T128 / T256 / T256W / T160 / T160N / T320 (A/B measurements)
+void gemm16_set_t320(int v);     // 0: never choose the pipelined 256x320 tile
 void gemm16_set_variant(int v);  // 0: BK64x2 stages, 1: BK32x3 stages (default), 2: BK64x3 stages
 // hm_d > 0: head-major store — element (row = n*hm_L + l, col = h*hm_d + dd) goes to ((n*hm_H + h)*hm_L + l)*hm_d + dd of dst (f32) / dst16 (f16)
 void launch_gemm16_linear(hipStream_t s, float* dst, void* dst16, int64_t ldd16, const void* a16, int64_t lda, const void* wswz, int64_t rows,
@@ -94,10 +95,6 @@ void launch_gemm16_linear(hipStream_t s, float* dst, void* dst16, int64_t ldd16,
 // f16 row-major with row stride inner (inner % 64 == 0) — the operand image of the FF2 GEMM.  The [tokens][2*inner] f32 tensor is never written.
 void launch_gemm16_linear_geglu(hipStream_t s, void* dst16, const void* a16, int64_t lda, const void* wswz_geglu, int64_t rows, int64_t K, int64_t M,
                                 const float* bias);
-// live HIP-event timing of the dominant kernel (the 256x128-tile implicit-GEMM conv): enable resets, read synchronises + resets
-void gemm16_timing_enable(bool on);
-void gemm16_timing_read(int64_t* launches, double* ms, double* flops);
-const char* gemm16_timing_kernel_name();
 // split-K factor the launchers will use when given a workspace of factor * rows * M floats (1 = no split)
 int gemm16_split_k(int64_t rows, int64_t M, int64_t K);
 // x16: f16 NHWC [N][H][W][ICp]; dst f32 NCHW [OW,OH,OC,N]

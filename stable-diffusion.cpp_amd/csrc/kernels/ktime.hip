@@ -1,0 +1,89 @@
+// ktime.hip — see ktime.h
+#include "ktime.h"
+
+#include <atomic>
+#include <mutex>
+#include <utility>
+#include <vector>
+
+namespace mi355x {
+namespace {
+const char* const kNames[KF_COUNT] = {
+    "conv implicit-GEMM, 256-row tiles (k_gemm16<256,*,true,...>)",
+    "conv implicit-GEMM, 128-row tiles (k_gemm16<128,*,true,...>)",
+    "Linear MFMA GEMM (k_gemm16<*,*,false,...>)",
+    "flash attention (k_flash_attn)",
+    "q8_0/q4_0 in-register dequant GEMM (k_qgemm)",
+    "f32 MFMA matmul (k_mul_mat_generic)",
+    "GroupNorm apply + SiLU + NCHW->NHWC f16 (k_nchw_to_nhwc_f16)",
+    "LayerNorm -> f16 operand image (k_layer_norm_f16)",
+    "GroupNorm statistics (k_gn_stats)",
+    "f32 rows -> f16 operand image (k_pack_rows_f16 / k_geglu_f16)",
+    "copies / transposes (k_copy_*, k_transpose)",
+    "binary elementwise (k_bin_*)",
+    "concat (k_concat*)",
+    "unary / scale (k_unary, k_scale)",
+    "split-K slab reduce (k_splitk_reduce)",
+    "f32 norms (k_group_norm, k_layer_norm)",
+    "softmax (k_soft_max)",
+    "other",
+};
+const int kBound[KF_COUNT] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
+
+struct Rec {
+    hipEvent_t e0, e1;
+    int fam;
+    double flops, bytes;
+};
+std::atomic<uint32_t> g_mask{0};
+std::mutex g_mu;
+std::vector<std::pair<hipEvent_t, hipEvent_t>> g_pool;
+std::vector<Rec> g_recs;
+}  // namespace
+
+void ktime_enable(uint32_t fam_mask) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    (void)hipDeviceSynchronize();
+    g_recs.clear();
+    g_mask.store(fam_mask, std::memory_order_relaxed);
+}
+bool ktime_on(int fam) { return (g_mask.load(std::memory_order_relaxed) >> fam) & 1u; }
+
+KScope::KScope(hipStream_t stream, int fam, double flops, double bytes) : s(stream) {
+    if (!ktime_on(fam)) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_recs.size() == g_pool.size()) {
+        hipEvent_t a = nullptr, b = nullptr;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+        g_pool.emplace_back(a, b);
+    }
+    const auto& ev = g_pool[g_recs.size()];
+    g_recs.push_back({ev.first, ev.second, fam, flops, bytes});
+    (void)hipEventRecord(ev.first, s);
+    e1 = ev.second;
+}
+
+int ktime_read(KFamTiming* out, int cap, int* fam_index) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    (void)hipDeviceSynchronize();
+    KFamTiming acc[KF_COUNT];
+    for (int f = 0; f < KF_COUNT; ++f) acc[f] = {kNames[f], kBound[f], 0, 0.0, 0.0, 0.0};
+    for (const Rec& r : g_recs) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) continue;
+        acc[r.fam].launches++;
+        acc[r.fam].total_ms += ms;
+        acc[r.fam].total_flops += r.flops;
+        acc[r.fam].total_bytes += r.bytes;
+    }
+    g_recs.clear();
+    int n = 0;
+    for (int f = 0; f < KF_COUNT && n < cap; ++f)
+        if (acc[f].launches > 0) {
+            if (fam_index) fam_index[n] = f;
+            out[n++] = acc[f];
+        }
+    return n;
+}
+
+}  // namespace mi355x

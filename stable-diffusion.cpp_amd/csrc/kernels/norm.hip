@@ -5,6 +5,7 @@
 // Reductions: wavefront shuffles, then LDS across the waves of the block.
 #include "device_utils.h"
 #include "kernels.h"
+#include "ktime.h"
 
 namespace mi355x {
 
@@ -84,6 +85,7 @@ __global__ __launch_bounds__(NT) void k_group_norm(float* __restrict__ dst, cons
 
 void launch_group_norm(hipStream_t s, float* dst, const float* x, int64_t hw, int64_t C, int64_t N, int groups, float eps, const float* w,
                        const float* b, bool silu) {
+    KScope ks_(s, KF_NORM_F32, 0.0, (double)hw * C * N * 8.0);
     const int cpg      = (int)((C + groups - 1) / groups);
     const int64_t cnt  = cpg * hw;
     const int blocks   = (int)(N * groups);
@@ -180,12 +182,14 @@ __global__ __launch_bounds__(256) void k_layer_norm(float* __restrict__ dst, con
 
 void launch_layer_norm(hipStream_t s, float* dst, const float* x, int64_t ne0, int64_t nrows, int64_t x_stride, int64_t d_stride, float eps,
                        const float* w, const float* b, bool rms) {
+    KScope ks_(s, KF_NORM_F32, 0.0, (double)ne0 * nrows * 8.0);
     const int blocks = (int)((nrows + 3) / 4);
     RowMap m{0, 0, x_stride, 0, 0, d_stride, 0, 0};
     k_layer_norm<<<blocks, 256, 0, s>>>(dst, x, (int)ne0, nrows, m, eps, w, b, rms ? 1 : 0);
 }
 void launch_layer_norm_4d(hipStream_t s, float* dst, const float* x, const int64_t ne[4], const int64_t xnb[4], const int64_t dnb[4], float eps, const float* w,
                           const float* b, bool rms) {
+    KScope ks_(s, KF_NORM_F32, 0.0, (double)ne[0] * ne[1] * ne[2] * ne[3] * 8.0);
     const int64_t nrows = ne[1] * ne[2] * ne[3];
     RowMap m{ne[1], ne[2], xnb[1] / 4, xnb[2] / 4, xnb[3] / 4, dnb[1] / 4, dnb[2] / 4, dnb[3] / 4};
     k_layer_norm<<<(int)((nrows + 3) / 4), 256, 0, s>>>(dst, x, (int)ne[0], nrows, m, eps, w, b, rms ? 1 : 0);
@@ -227,6 +231,7 @@ __global__ __launch_bounds__(256) void k_soft_max(float* __restrict__ dst, const
 }
 
 void launch_soft_max(hipStream_t s, float* dst, const float* x, int64_t ncols, int64_t nrows, float scale, const View4* mask, int64_t rows_per_mat) {
+    KScope ks_(s, KF_SOFTMAX, 0.0, (double)ncols * nrows * 8.0);
     k_soft_max<<<(unsigned)nrows, 256, 0, s>>>(dst, x, (int)ncols, scale, mask ? (const char*)mask->data : nullptr, mask ? mask->type : 0,
                                              mask ? mask->nb[1] : 0, rows_per_mat);
 }

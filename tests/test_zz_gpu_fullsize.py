@@ -213,36 +213,35 @@ def psnr(a, b):
 
 @full
 def test_full_width_sd15_unet_vs_oracle(sd, oracle, gpu):
-    """SD1.5 UNet at 512x512 (src/model/diffusion/unet.hpp:526-745), flash attention on: the (cond, uncond) pair of one image in one graph."""
+    """SD1.5 UNet at 512x512 (src/model/diffusion/unet.hpp:526-745): the (cond, uncond) pair of one image in one graph, both attention
+    paths of the GPU against the oracle.
+
+    Which oracle output is the bar?  ggml-cpu's FLASH_ATTN_EXT accumulates V in F16.  Over 4096 keys that
+    rounding is NOT small: the oracle's own two attention paths (flash node vs MUL_MAT / SOFT_MAX chain, the same math) differ by
+    rel-L2 1.3e-2 on this very forward (measured oracle vs oracle, profiles/r02c_fullwidth_parity.txt), an order of magnitude above
+    every other rounding point.  The MFMA flash kernel accumulates P.V in f32, so it sits next to the exact chain, not next to the
+    f16-accumulating CPU kernel.  Hence: both GPU paths within 5e-3 of the oracle's exact-softmax chain (the tiny-width bar), and the
+    GPU flash path no farther from the oracle's flash path than that path is from the exact chain (+ the 5e-3 bar)."""
     rng = np.random.default_rng(500)
     x = np.repeat(rng.standard_normal((1, 4, 64, 64)).astype(np.float32), 2, axis=0)
     t = np.array([731.0, 731.0], np.float32)
     c2 = rng.standard_normal((2, 77, 768)).astype(np.float32)
-    ref = sd.Engine(model=sd.SD15, backend=oracle, flash_attn=True).unet_forward(x, t, c2)
+    ref = sd.Engine(model=sd.SD15, backend=oracle, flash_attn=False).unet_forward(x, t, c2)        # exact f32 softmax chain
+    ref_flash = sd.Engine(model=sd.SD15, backend=oracle, flash_attn=True).unet_forward(x, t, c2)   # f16 V accumulation (ggml-cpu)
+    spread = rel_l2(ref_flash, ref)
     e = sd.Engine(model=sd.SD15, backend=gpu, flash_attn=True)
     out = e.unet_forward(x, t, c2)
-    assert np.isfinite(out).all()
-    err = rel_l2(out, ref)
-    print(f"full-width SD1.5 UNet (pair, flash): rel-L2 vs oracle {err:.3e}")
-    assert err < 5e-3
+    out_manual = sd.Engine(model=sd.SD15, backend=gpu, flash_attn=False).unet_forward(x, t, c2)
+    assert np.isfinite(out).all() and np.isfinite(out_manual).all()
+    e_f, e_m, e_ff = rel_l2(out, ref), rel_l2(out_manual, ref), rel_l2(out, ref_flash)
+    print(f"full-width SD1.5 UNet (pair): GPU flash vs oracle chain {e_f:.3e}, GPU chain vs oracle chain {e_m:.3e}, "
+          f"GPU flash vs oracle flash {e_ff:.3e}, oracle flash vs oracle chain {spread:.3e}")
+    assert e_f < 5e-3 and e_m < 5e-3
+    assert e_ff < spread + 5e-3
     # the bench graph: 8 images x (cond, uncond); images 0 / 1 carry the pair above
     x16 = np.concatenate([x, rng.standard_normal((14, 4, 64, 64)).astype(np.float32)])
     out16 = e.unet_forward(x16, np.full(16, 731.0, np.float32), c2)
     assert rel_l2(out16[:2], ref) < 5e-3
-
-
-@full
-def test_full_width_sd15_unet_manual_attention_vs_oracle(sd, oracle, gpu):
-    """the same forward with the flash flag off (MUL_MAT / SOFT_MAX attention chain, ggml_extend.hpp:1460-1479)"""
-    rng = np.random.default_rng(501)
-    x = rng.standard_normal((1, 4, 64, 64)).astype(np.float32)
-    t = np.array([210.0], np.float32)
-    c = rng.standard_normal((1, 77, 768)).astype(np.float32)
-    ref = sd.Engine(model=sd.SD15, backend=oracle, flash_attn=False).unet_forward(x, t, c)
-    out = sd.Engine(model=sd.SD15, backend=gpu, flash_attn=False).unet_forward(x, t, c)
-    err = rel_l2(out, ref)
-    print(f"full-width SD1.5 UNet (manual attention): rel-L2 vs oracle {err:.3e}")
-    assert np.isfinite(out).all() and err < 5e-3
 
 
 @full
@@ -258,22 +257,42 @@ def test_full_size_vae_decode_vs_oracle(sd, oracle, gpu):
     assert p > 35.0
 
 
+
 @full
-@pytest.mark.parametrize("flash", [True, False])
-def test_full_width_sdxl_unet_q8_0_vs_oracle(sd, oracle, gpu, flash):
+def test_full_width_sdxl_unet_q8_0_vs_oracle(sd, oracle, gpu):
     """SDXL UNet (unet.hpp:47-57: depth-2 / depth-10 transformers, Linear proj_in / proj_out, label_emb), q8_0 Linear weights + f16 conv
-    (BASELINE.json config 3), latent 64x64 (the oracle needs ~4x longer at 128x128; widths and depths are the real ones).  The oracle
-    quantises the ACTIVATIONS of a q8_0 Linear to q8_0 as ggml-cpu does; the GPU keeps them f16 — hence 1e-2."""
+    (BASELINE.json config 3), latent 64x64 (the oracle needs ~4x longer at 128x128; widths and depths are the real ones).
+
+    The oracle quantises the ACTIVATIONS of a q8_0 Linear to q8_0 blocks as ggml-cpu does; the GPU multiplies
+    f16-rounded activations with the exactly dequantised weights.  Through 70 transformer blocks that activation-quantisation noise is
+    the dominant term (oracle q8_0 vs the same network with the dequantised weights held in f32: ~1.3e-2), so the test pins BOTH
+    sides: the GPU within 5e-3 of the oracle running the identical (dequantised) weights without activation quantisation, and no
+    farther from the oracle's q8_0 path than that path is from the exact-weight one (+ 5e-3).  Attention reference = the oracle's
+    exact-softmax chain (see the SD1.5 test)."""
     rng = np.random.default_rng(503)
     x = rng.standard_normal((1, 4, 64, 64)).astype(np.float32)
     t = np.array([500.0], np.float32)
     c = rng.standard_normal((1, 77, 2048)).astype(np.float32)
     y = rng.standard_normal((1, 2816)).astype(np.float32)
-    ref = sd.Engine(model=sd.SDXL, backend=oracle, wtype=sd.Q8_0, flash_attn=flash).unet_forward(x, t, c, y)
-    out = sd.Engine(model=sd.SDXL, backend=gpu, wtype=sd.Q8_0, flash_attn=flash).unet_forward(x, t, c, y)
-    err = rel_l2(out, ref)
-    print(f"full-width SDXL UNet q8_0 flash={flash}: rel-L2 vs oracle {err:.3e}")
-    assert np.isfinite(out).all() and err < 1e-2
+    ref_q = sd.Engine(model=sd.SDXL, backend=oracle, wtype=sd.Q8_0, flash_attn=False)
+    ref_q8 = ref_q.unet_forward(x, t, c, y)
+    # the same network with every q8_0 tensor replaced by its dequantised values in f32 (no activation quantisation on that path)
+    ref_x = sd.Engine(model=sd.SDXL, backend=oracle, wtype=sd.F32, flash_attn=False)
+    n_q = 0
+    for name in ref_q.tensor_names():
+        if name.startswith("model.diffusion_model.") and ref_q.tensor_info(name)[1] == sd.Q8_0:
+            ref_x.set_tensor(name, ref_q.get_tensor(name))
+            n_q += 1
+    assert n_q > 500
+    ref = ref_x.unet_forward(x, t, c, y)
+    spread = rel_l2(ref_q8, ref)
+    del ref_x, ref_q
+    for flash in (True, False):
+        out = sd.Engine(model=sd.SDXL, backend=gpu, wtype=sd.Q8_0, flash_attn=flash).unet_forward(x, t, c, y)
+        e_x, e_q = rel_l2(out, ref), rel_l2(out, ref_q8)
+        print(f"full-width SDXL UNet q8_0 flash={flash}: GPU vs oracle(dequantised weights) {e_x:.3e}, GPU vs oracle(q8_0 activations) {e_q:.3e}, "
+              f"oracle q8_0 vs oracle dequantised {spread:.3e}")
+        assert np.isfinite(out).all() and e_x < 5e-3 and e_q < spread + 5e-3
 
 
 @full
@@ -287,7 +306,7 @@ def test_real_width_sd35_joint_blocks_vs_oracle(sd, oracle, gpu, wtype, tol):
     c = rng.standard_normal((1, 154, 4096)).astype(np.float32)
     y = rng.standard_normal((1, 2048)).astype(np.float32)
     wt = getattr(sd, wtype)
-    ref = sd.Engine(model=sd.SD35_WIDE2, backend=oracle, wtype=wt, flash_attn=True).unet_forward(x, t, c, y)
+    ref = sd.Engine(model=sd.SD35_WIDE2, backend=oracle, wtype=wt, flash_attn=False).unet_forward(x, t, c, y)   # exact-softmax chain
     out = sd.Engine(model=sd.SD35_WIDE2, backend=gpu, wtype=wt, flash_attn=True).unet_forward(x, t, c, y)
     err = rel_l2(out, ref)
     print(f"real-width SD3.5 joint blocks {wtype}: rel-L2 vs oracle {err:.3e}")
@@ -305,7 +324,7 @@ def test_real_width_flux_blocks_vs_oracle(sd, oracle, gpu, wtype, tol):
     c = rng.standard_normal((1, 77, 4096)).astype(np.float32)
     y = rng.standard_normal((1, 768)).astype(np.float32)
     wt = getattr(sd, wtype)
-    ref = sd.Engine(model=sd.FLUX_WIDE1, backend=oracle, wtype=wt, flash_attn=True).unet_forward(x, t, c, y)
+    ref = sd.Engine(model=sd.FLUX_WIDE1, backend=oracle, wtype=wt, flash_attn=False).unet_forward(x, t, c, y)   # exact-softmax chain
     out = sd.Engine(model=sd.FLUX_WIDE1, backend=gpu, wtype=wt, flash_attn=True).unet_forward(x, t, c, y)
     err = rel_l2(out, ref)
     print(f"real-width FLUX blocks {wtype}: rel-L2 vs oracle {err:.3e}")
