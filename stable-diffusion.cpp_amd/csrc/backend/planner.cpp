@@ -41,11 +41,11 @@ namespace {
 struct Stats {
     std::atomic<int64_t> graphs_computed{0}, plans_built{0}, nodes_seen{0}, kernels_planned{0}, kernels_launched{0}, fused_conv{0},
         fused_conv_bounced{0}, fused_linear{0}, fused_norm{0}, fused_geglu{0}, fused_attention{0}, generic_matmul{0}, swizzled_weight_bytes{0}, fused_linear_geglu{0}, split_k_gemms{0}, head_major_gemms{0}, fused_modulate{0}, fused_gate{0}, fused_gelu{0}, fused_rope{0}, fused_concat_heads{0},
-        graph_replays{0};
+        graph_replays{0}, qgemv_linears{0};
 } g_stats;
 
 struct Options {
-    std::atomic<int> fusion{1}, mfma_gemm{1}, hip_graph{0}, flash_pattern{1}, gemm16{1}, fuse_modulate{1}, fuse_gate{1}, fuse_gelu{1}, fuse_rope{1}, fuse_concat_heads{1};
+    std::atomic<int> fusion{1}, mfma_gemm{1}, hip_graph{0}, flash_pattern{1}, gemm16{1}, fuse_modulate{1}, fuse_gate{1}, fuse_gelu{1}, fuse_rope{1}, fuse_concat_heads{1}, qgemv{1};
 } g_opt;
 
 using Step = std::function<void(hipStream_t)>;
@@ -545,6 +545,23 @@ void plan_linear(Builder& B, int i, hipStream_t s, std::vector<int>& chain) {
                 geglu_out = jm;
             }
         }
+    }
+    // q8_0 / q4_0 weights under a few activation rows (adaLN / modulation vectors): stream the RAW quantised blocks once, dequantise in
+    // registers (qgemm.hip) — no f16 weight image is ever built for these tensors
+    if (g_opt.qgemv && hm_d == 0 && !ep.gate && gelu_out < 0 && geglu_out < 0 && qgemv_supported((int)w->type, tokens, K) && x->nb[0] == 4 &&
+        (x->ne[2] == 1 || x->nb[2] == x->nb[1] * (size_t)x->ne[1]) && (x->ne[3] == 1 || x->nb[3] == x->nb[2] * (size_t)x->ne[2]) && aligned16(x->data) &&
+        x->nb[1] % 16 == 0) {
+        const size_t wsoff = B.alloc(qgemv_workspace_bytes(tokens, K));
+        Planner* P         = B.P;
+        float* qdst        = (float*)gi.node(last)->data;
+        const float* qx    = (const float*)x->data;
+        const int64_t qxs  = (int64_t)x->nb[1] / 4;
+        const void* wraw   = w->data;
+        const int wt       = (int)w->type;
+        B.emit_at(emit_node, i, [=](hipStream_t st) { launch_qgemv(st, qdst, M, qx, qxs, tokens, wraw, wt, K, M, P->arena + wsoff, ep, 1.0f); });
+        g_stats.qgemv_linears++;
+        g_stats.fused_linear++;
+        return;
     }
     const void* swz = get_swz_linear(B.P, w, s, geglu_out >= 0);
     float* dst      = (float*)gi.node(last)->data;
@@ -1606,6 +1623,7 @@ void planner_get_stats(ggml_backend_mi355x_stats* o) {
     o->fused_gelu            = g_stats.fused_gelu;
     o->fused_rope            = g_stats.fused_rope;
     o->fused_concat_heads    = g_stats.fused_concat_heads;
+    o->qgemv_linears         = g_stats.qgemv_linears;
     o->fused_attention       = g_stats.fused_attention;
     o->generic_matmul        = g_stats.generic_matmul;
     o->swizzled_weight_bytes = g_stats.swizzled_weight_bytes;
@@ -1621,6 +1639,7 @@ void planner_set_option(const char* key, int value) {
     else if (!strcmp(key, "flash_ablate")) flash_attn_set_ablate(value);
 #endif
     else if (!strcmp(key, "gemm16_t320")) gemm16_set_t320(value);
+    else if (!strcmp(key, "qgemv")) g_opt.qgemv = value;
     else if (!strcmp(key, "gemm16")) (void)value;  // kept for old scripts: the gemm16 path is the only one (first-generation kernels removed)
     else if (!strcmp(key, "fuse_modulate")) g_opt.fuse_modulate = value;
     else if (!strcmp(key, "fuse_gate")) g_opt.fuse_gate = value;

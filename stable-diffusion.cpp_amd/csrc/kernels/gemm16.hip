@@ -79,27 +79,32 @@ __device__ __forceinline__ T ld_u(const T* ubase, uint32_t lane_bytes) { return 
 
 enum { EPI_F32 = 0, EPI_F32_RES = 1, EPI_F16 = 2, EPI_HM_F32 = 3, EPI_HM_F16 = 4, EPI_GENERIC = 5, EPI_F16_GELU = 6, EPI_F32_GATE = 7 };
 
-// FF1 + GEGLU: the wave's column block cb = 0 holds 32 value columns, cb = 1 the matching gate columns
+// FF1 + GEGLU: the weight image is laid out (k_wswz_linear, geglu_inner > 0) so that inside every 128-column tile the 32-column blocks
+// are [value w0 | gate w0 | value w1 | gate w1]: a wave's even column block holds 32 value columns, the next odd one the matching gates
 template <int RB, int CB>
 __device__ __forceinline__ void epi_geglu(const float16_t (&acc)[RB][CB], const G16Args& g, int64_t row0, int col0, int wr, int wc, int lane) {
-    static_assert(CB == 2, "GEGLU pairing needs two column blocks per wave");
+    static_assert(CB % 2 == 0, "GEGLU pairing needs an even number of column blocks per wave");
     const int hi = lane >> 5, lc = lane & 31;
-    const int oc0 = (col0 / 128 * 2 + wc) * 32;  // first output column of this wave
-    if (oc0 >= g.geglu_inner) return;
-    const float bx = g.ep.bias ? g.ep.bias[oc0 + lc] : 0.f, bg = g.ep.bias ? g.ep.bias[g.geglu_inner + oc0 + lc] : 0.f;
 #pragma unroll
-    for (int rb = 0; rb < RB; ++rb) {
-        const int64_t base_row = row0 + wr * (RB * 32) + rb * 32;
-        if (base_row >= g.R) continue;
-        const int nvl     = (int)(g.R - base_row < 32 ? g.R - base_row : 32) - 4 * hi;
-        _Float16* ub      = g.dst16 + base_row * g.ldd16 + oc0;
-        const uint32_t lb = (uint32_t)(lc + 4 * hi * (int)g.ldd16) * 2u;
+    for (int p = 0; p < CB / 2; ++p) {
+        const int gb  = col0 / 32 + wc * CB + 2 * p;  // global 32-column block of the value half
+        const int oc0 = ((gb >> 2) * 2 + ((gb & 3) >> 1)) * 32;  // first output column of this pair
+        if (oc0 >= g.geglu_inner) continue;
+        const float bx = g.ep.bias ? g.ep.bias[oc0 + lc] : 0.f, bg = g.ep.bias ? g.ep.bias[g.geglu_inner + oc0 + lc] : 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int ro = (r & 3) + 8 * (r >> 2);
-            if (ro >= nvl) continue;
-            const float xv = acc[rb][0][r] * g.ep.scale + bx, gv = acc[rb][1][r] * g.ep.scale + bg;
-            st_u(ub + (int64_t)ro * g.ldd16, lb, (_Float16)(xv * act_apply<UN_GELU>(gv)));
+        for (int rb = 0; rb < RB; ++rb) {
+            const int64_t base_row = row0 + wr * (RB * 32) + rb * 32;
+            if (base_row >= g.R) continue;
+            const int nvl     = (int)(g.R - base_row < 32 ? g.R - base_row : 32) - 4 * hi;
+            _Float16* ub      = g.dst16 + base_row * g.ldd16 + oc0;
+            const uint32_t lb = (uint32_t)(lc + 4 * hi * (int)g.ldd16) * 2u;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ro = (r & 3) + 8 * (r >> 2);
+                if (ro >= nvl) continue;
+                const float xv = acc[rb][2 * p][r] * g.ep.scale + bx, gv = acc[rb][2 * p + 1][r] * g.ep.scale + bg;
+                st_u(ub + (int64_t)ro * g.ldd16, lb, (_Float16)(xv * act_apply<UN_GELU>(gv)));
+            }
         }
     }
 }
@@ -659,8 +664,8 @@ __global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g
     if (!CONV) {
         const bool full  = row0 + BM <= g.R;
         const bool plain = full;
-        if (CB == 2 && g.geglu_inner > 0) {
-            if constexpr (CB == 2) epi_geglu(acc, g, row0, col0, wr, wc, lane);
+        if (CB % 2 == 0 && g.geglu_inner > 0) {
+            if constexpr (CB % 2 == 0) epi_geglu(acc, g, row0, col0, wr, wc, lane);
         } else if (g.hm_d > 0 && g.hm_L >= 32 && !g.ep.residual && (g.dst != nullptr) != (g.dst16 != nullptr)) {
             if (g.dst16)
                 epi_linear<EPI_HM_F16>(acc, g, row0, col0, wr, wc, lane);
@@ -714,7 +719,7 @@ static inline bool g16_bk32() { return g_g16_variant == 1 || g_g16_variant == 3;
 //   T160   256x160, 4 waves of 64x160  (78 KB, 2/CU)                 — outputs that are multiples of 160 but not of 128 (SD1.5's 320):
 //                                                                       no padded columns, 2 column tiles instead of 3
 //   T160N  256x160, 8 waves of 32x160  (78 KB, 2/CU)                 — T160 with twice the waves in flight (experiment)
-enum { G16_T128 = 0, G16_T256 = 1, G16_T256W = 2, G16_T160 = 3, G16_T160N = 4, G16_T320 = 5 };
+enum { G16_T128 = 0, G16_T256 = 1, G16_T256W = 2, G16_T160 = 3, G16_T160N = 4, G16_T320 = 5, G16_T256P = 6 };
 static int g_g16_force_tile = -1;  // option "gemm16_tile": force one configuration (A/B measurements); -1 = choose per shape
 void gemm16_set_tile(int t) { g_g16_force_tile = t; }
 // Per-shape choice.  Measured on SD1.5 batch 16 (profiles/r01e_tile_configs.txt): a launch takes ceil(workgroups / resident slots)
@@ -723,7 +728,8 @@ void gemm16_set_tile(int t) { g_g16_force_tile = t; }
 // only pay when they fill every CU twice (>= 512 workgroups); otherwise the finer T128 quantises better.
 static int g_g16_t320 = 1;  // option "gemm16_t320": 0 disables the pipelined 256x320 tile in the per-shape choice (A/B measurements)
 void gemm16_set_t320(int v) { g_g16_t320 = v; }
-static int g16_pick_tile(int64_t rows, int64_t M, bool geglu, bool conv, bool split) {
+static int g16_t320_split(int64_t rows, int64_t M, int64_t nt);
+static int g16_pick_tile(int64_t rows, int64_t M, bool geglu, bool conv, int split, int64_t nt) {
     if (g_g16_variant != 3) return G16_T128;
     const bool can160 = M % 160 == 0 && !geglu;
     // T320 (256x320, one workgroup per CU): the weight image is padded to 128 columns only, so M must be a multiple of 320; the GEGLU
@@ -731,14 +737,24 @@ static int g16_pick_tile(int64_t rows, int64_t M, bool geglu, bool conv, bool sp
     const bool can320 = M % 320 == 0 && !geglu;
     if (g_g16_force_tile >= 0) {
         if (g_g16_force_tile == G16_T320) return can320 ? G16_T320 : G16_T256;
+        if (g_g16_force_tile == G16_T256P) return (!conv && M % 256 == 0) ? G16_T256P : G16_T256;
         if ((g_g16_force_tile == G16_T160 || g_g16_force_tile == G16_T160N) && !can160) return G16_T256;
         return g_g16_force_tile;
     }
     const int64_t rt256 = (rows + 255) / 256, c128 = ((rows + 127) / 128) * ((M + 127) / 128), c256 = rt256 * ((M + 127) / 128);
-    if (g_g16_t320 && can320 && !split) {
+    if (g_g16_force_tile < 0 && !split && !conv && g_g16_t320 && !can320 && M % 256 == 0) {
+        // T256P: the same pipelined loop on 256x256 tiles (Linear only: GEGLU FF1, N a multiple of 256)
+        // one workgroup per CU: pipeline fill, drain and epilogue of a workgroup overlap with nothing, so short-K GEMMs (SD1.5's GEGLU FF1,
+        // K = 320 .. 1280: 10-40 stages) stay on the 2-workgroups-per-CU tiles (r02d: 264 -> 318 us); long-K Linears (DiT) take it
+        const int64_t c256p = rt256 * (M / 256), rounds = (c256p + 255) / 256;
+        if (nt >= 64 && c256p >= 192 && c256p * 4 >= rounds * 256 * 3) return G16_T256P;
+    }
+    if (split) {
+        if (can320 && g16_t320_split(rows, M, nt) == split) return G16_T320;
+    } else if (g_g16_t320 && can320) {
         // one workgroup per CU and 256 CUs: take it when the launch fills >= 75 % of its rounds
         const int64_t c320 = rt256 * (M / 320), rounds = (c320 + 255) / 256;
-        if (c320 >= 192 && c320 * 4 >= rounds * 256 * 3) return G16_T320;
+        if (nt >= (conv ? 16 : 32) && c320 >= 192 && c320 * 4 >= rounds * 256 * 3) return G16_T320;
     }
     const int64_t c160 = can160 ? rt256 * (M / 160) : 0;
     double best = (double)((c128 + 767) / 768) * 1.0;
@@ -758,13 +774,16 @@ template <int BN_, bool CONV_>
 static void g16_launch(hipStream_t s, G16Args& g, int64_t rows, double flops) {
     const unsigned ny = g.split_k > 1 ? (unsigned)g.split_k : 1u;
     if (BN_ == 128 && g_g16_variant == 3) {
-        const int tile = g16_pick_tile(rows, g.C, g.geglu_inner > 0, CONV_, g.split_k > 1);  // the GEGLU pairing is laid out for 128-column tiles
+        const int tile = g16_pick_tile(rows, g.C, g.geglu_inner > 0, CONV_, g.split_k > 1 ? g.split_k : 0, g.nt);  // the GEGLU pairing is laid out for 128-column tiles
         if (tile != G16_T128) {
             const int64_t rt256 = (rows + 255) / 256;
             KScope ks_(s, CONV_ ? KF_CONV_T256 : KF_LINEAR, flops, 0.0);
             if (tile == G16_T320) {
                 g.ncol_tiles = (int)((g.C + 319) / 320);
                 k_gemm16<256, 320, CONV_, 32, 4, 4, 2, 1><<<dim3((unsigned)(rt256 * g.ncol_tiles), ny), 512, 0, s>>>(g);
+            } else if (tile == G16_T256P) {
+                g.ncol_tiles = (int)((g.C + 255) / 256);
+                if constexpr (!CONV_) k_gemm16<256, 256, false, 32, 4, 4, 2, 1><<<dim3((unsigned)(rt256 * g.ncol_tiles), ny), 512, 0, s>>>(g);
             } else if (tile == G16_T160) {
                 g.ncol_tiles = (int)(g.C / 160);
                 k_gemm16<256, 160, CONV_, 32, 3, 4, 1><<<dim3((unsigned)(rt256 * g.ncol_tiles), ny), 256, 0, s>>>(g);
@@ -797,10 +816,26 @@ static int g_g16_splitk_target = 384;  // option "splitk_target": workgroups a s
 void gemm16_set_splitk_target(int v) { g_g16_splitk_target = v; }
 static int g_g16_splitk_mid = 0;
 void gemm16_set_splitk_mid(int v) { g_g16_splitk_mid = v; }
+// K slices for the pipelined 256x320 tile when the output alone does not fill the chip (one workgroup per CU: 256 slots): the 32x32 and
+// 16x16 UNet levels give 128 / 64 tiles.  0 = not applicable.  At least 20 stages per slice (4 of them are pipeline fill).
+static int g16_t320_split(int64_t rows, int64_t M, int64_t nt) {
+    if (!g_g16_t320 || g_g16_variant != 3 || M % 320 != 0 || (g_g16_force_tile >= 0 && g_g16_force_tile != G16_T320)) return 0;
+    const int64_t c320 = ((rows + 255) / 256) * (M / 320);
+    if (c320 >= 192 || c320 < 8) return 0;
+    int64_t S = 256 / c320;
+    if (S > 16) S = 16;
+    // every slice writes a whole f32 slab and the reduce pass reads them all: worth it only when a slice still carries real work
+    // (profiles/r02d_t320_tile_check.txt: K/S = 2880 wins 10-45 %, K/S = 1280 loses 25 %); the 8x8 level (<= 2048 rows) has no good
+    // alternative and takes shorter slices
+    const int64_t min_stages = rows <= 2048 ? 20 : 48;
+    while (S > 1 && nt / S < min_stages) --S;
+    return (S >= 2 && c320 * S >= 128) ? (int)S : 0;
+}
 int gemm16_split_k(int64_t rows, int64_t M, int64_t K) {
     if (!g16_bk32()) return 1;
     const int64_t wgs = ((rows + 127) / 128) * ((M + 127) / 128);
     const int64_t nt  = rup64(K, 64) / 32;
+    if (const int s320 = g16_t320_split(rows, M, nt)) return s320;
     if (wgs > g_g16_splitk_target / 2) {
         // option "splitk_mid" (experiment, default 0): 193..384 workgroups over 768 resident slots leave most CUs with one or two
         // workgroups (the 16x16 UNet level: 320 tiles, K = 11520..23040 at ~520 TFLOP/s); two K slices double the workgroups in flight
@@ -1081,11 +1116,74 @@ __global__ __launch_bounds__(256) void k_layer_norm_f16(_Float16* __restrict__ d
         *(half4_t*)(yr + i * 4) = h;
     }
 }
+// register-resident variant: a wave keeps its row in NV float4 registers per lane (ne0 <= 256 * NV), so the row is read from memory ONCE
+// (the generic kernel above walks it three times: mean, variance, write); same summation order per lane, same wave reductions
+template <int NV>
+__global__ __launch_bounds__(256) void k_layer_norm_f16_reg(_Float16* __restrict__ dst, const float* __restrict__ x, int ne0, int Kp, int64_t nrows, int64_t xs,
+                                                            float eps, const float* __restrict__ w, const float* __restrict__ b, int rms, int64_t mod_L) {
+    const int lane    = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= nrows) return;
+    const float wadd = mod_L > 0 ? 1.f : 0.f;
+    if (mod_L > 0) {
+        w += (row / mod_L) * ne0;
+        b += (row / mod_L) * ne0;
+    }
+    const float4* xr = (const float4*)(x + row * xs);
+    _Float16* yr     = dst + row * Kp;
+    const int n4     = ne0 / 4;
+    float4 v[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int i = lane + 64 * j;
+        v[j]        = i < n4 ? xr[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float mean = 0.f;
+    if (!rms) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+        mean = wave_sum(s) / (float)ne0;
+    }
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        if (lane + 64 * j < n4) {
+            const float a = v[j].x - mean, bb = v[j].y - mean, c = v[j].z - mean, d = v[j].w - mean;
+            q += (a * a + bb * bb) + (c * c + d * d);
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)ne0 + eps);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int i = lane + 64 * j;
+        if (i >= Kp / 4) continue;
+        half4_t h = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+        if (i < n4) {
+            float4 t = v[j];
+            t.x = (t.x - mean) * rstd; t.y = (t.y - mean) * rstd; t.z = (t.z - mean) * rstd; t.w = (t.w - mean) * rstd;
+            if (w) { const float4 ww = ((const float4*)w)[i]; t.x *= ww.x + wadd; t.y *= ww.y + wadd; t.z *= ww.z + wadd; t.w *= ww.w + wadd; }
+            if (b) { const float4 bb = ((const float4*)b)[i]; t.x += bb.x; t.y += bb.y; t.z += bb.z; t.w += bb.w; }
+            h[0] = (_Float16)t.x; h[1] = (_Float16)t.y; h[2] = (_Float16)t.z; h[3] = (_Float16)t.w;
+        }
+        *(half4_t*)(yr + i * 4) = h;
+    }
+}
 void launch_layer_norm_f16(hipStream_t s, void* dst, const float* x, int64_t ne0, int64_t nrows, int64_t xs, float eps, const float* w, const float* b, bool rms,
                            int64_t mod_L) {
     KScope ks_(s, KF_LN_F16, 0.0, (double)nrows * ne0 * 4.0 + (double)nrows * rup64(ne0, 64) * 2.0);
     const int Kp = (int)rup64(ne0, 64);
-    k_layer_norm_f16<<<(unsigned)((nrows + 3) / 4), 256, 0, s>>>((_Float16*)dst, x, (int)ne0, Kp, nrows, xs, eps, w, b, rms ? 1 : 0, mod_L);
+    const unsigned grid = (unsigned)((nrows + 3) / 4);
+#define LN16_ARGS (_Float16*)dst, x, (int)ne0, Kp, nrows, xs, eps, w, b, rms ? 1 : 0, mod_L
+    if (Kp <= 256 * 2)
+        k_layer_norm_f16_reg<2><<<grid, 256, 0, s>>>(LN16_ARGS);
+    else if (Kp <= 256 * 5)
+        k_layer_norm_f16_reg<5><<<grid, 256, 0, s>>>(LN16_ARGS);
+    else if (Kp <= 256 * 12)
+        k_layer_norm_f16_reg<12><<<grid, 256, 0, s>>>(LN16_ARGS);
+    else
+        k_layer_norm_f16<<<grid, 256, 0, s>>>(LN16_ARGS);
+#undef LN16_ARGS
 }
 
 // GEGLU writing the f16 operand image: dst[t][i] = x[t][i] * gelu(x[t][inner+i])
@@ -1158,14 +1256,63 @@ __global__ __launch_bounds__(NT) void k_gn_stats(float* __restrict__ scale, floa
         shift[(int64_t)n * C + c] = (b ? b[c] : 0.f) - mean * sc;
     }
 }
+// register-resident variant: one (image, group) slab of up to 4 * NT * NV floats is read ONCE into NV float4 registers per thread
+// (the kernel above reads it twice: mean, then centred sum of squares); same per-thread order, same block reductions
+template <int NT, int NV>
+__global__ __launch_bounds__(NT) void k_gn_stats_reg(float* __restrict__ scale, float* __restrict__ shift, const float* __restrict__ x, int64_t hw, int C, int groups,
+                                                     int cpg, float eps, const float* __restrict__ w, const float* __restrict__ b) {
+    __shared__ float scratch[2 * (NT / 64)];
+    const int gidx = blockIdx.x % groups, n = blockIdx.x / groups;
+    const int c0 = gidx * cpg, c1 = min(c0 + cpg, C);
+    if (c0 >= c1) return;
+    const int64_t cnt = (int64_t)(c1 - c0) * hw;
+    const float4* xs  = (const float4*)(x + ((int64_t)n * C + c0) * hw);
+    const int64_t n4  = cnt / 4;
+    float4 v[NV];
+    float s = 0.f, dummy = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int64_t i = threadIdx.x + (int64_t)NT * j;
+        v[j]            = i < n4 ? xs[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+    }
+    block_sum2<NT / 64>(s, dummy, scratch);
+    const float mean = s / (float)cnt;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        if (threadIdx.x + (int64_t)NT * j < n4) {
+            const float a = v[j].x - mean, bb = v[j].y - mean, c = v[j].z - mean, d = v[j].w - mean;
+            q += (a * a + bb * bb) + (c * c + d * d);
+        }
+    }
+    dummy = 0.f;
+    block_sum2<NT / 64>(q, dummy, scratch);
+    const float rstd = rsqrtf(q / (float)cnt + eps);
+    for (int c = c0 + threadIdx.x; c < c1; c += NT) {
+        const float sc            = (w ? w[c] : 1.f) * rstd;
+        scale[(int64_t)n * C + c] = sc;
+        shift[(int64_t)n * C + c] = (b ? b[c] : 0.f) - mean * sc;
+    }
+}
 void launch_gn_stats(hipStream_t s, float* scale, float* shift, const float* x, int64_t hw, int64_t C, int64_t N, int groups, float eps, const float* w,
                      const float* b) {
-    KScope ks_(s, KF_GN_STATS, 0.0, (double)hw * C * N * 4.0);  // algorithmic: ONE read of the activation (the kernel reads it twice)
-    const int cpg = (int)((C + groups - 1) / groups);
-    if (cpg * hw >= 16384)
-        k_gn_stats<1024><<<(unsigned)(N * groups), 1024, 0, s>>>(scale, shift, x, hw, (int)C, groups, cpg, eps, w, b);
+    KScope ks_(s, KF_GN_STATS, 0.0, (double)hw * C * N * 4.0);  // algorithmic: ONE read of the activation
+    const int cpg       = (int)((C + groups - 1) / groups);
+    const int64_t cnt   = (int64_t)cpg * hw;
+    const bool full_grp = C % groups == 0 || true;  // the last group may be short: the kernels bound it by c1
+    const bool v4       = hw % 4 == 0 && (((uintptr_t)x) & 15) == 0 && full_grp;
+    const unsigned grid = (unsigned)(N * groups);
+    if (v4 && cnt <= 4 * 256 * 4)
+        k_gn_stats_reg<256, 4><<<grid, 256, 0, s>>>(scale, shift, x, hw, (int)C, groups, cpg, eps, w, b);
+    else if (v4 && cnt <= 4 * 1024 * 4)
+        k_gn_stats_reg<1024, 4><<<grid, 1024, 0, s>>>(scale, shift, x, hw, (int)C, groups, cpg, eps, w, b);
+    else if (v4 && cnt <= 4 * 1024 * 16)
+        k_gn_stats_reg<1024, 16><<<grid, 1024, 0, s>>>(scale, shift, x, hw, (int)C, groups, cpg, eps, w, b);
+    else if (cnt >= 16384)
+        k_gn_stats<1024><<<grid, 1024, 0, s>>>(scale, shift, x, hw, (int)C, groups, cpg, eps, w, b);
     else
-        k_gn_stats<256><<<(unsigned)(N * groups), 256, 0, s>>>(scale, shift, x, hw, (int)C, groups, cpg, eps, w, b);
+        k_gn_stats<256><<<grid, 256, 0, s>>>(scale, shift, x, hw, (int)C, groups, cpg, eps, w, b);
 }
 
 // f32 NCHW [hw][C][N] -> f16 NHWC [N][hw][Cp] with optional per-(n,c) affine (GroupNorm apply) and SiLU.
@@ -1194,11 +1341,73 @@ __global__ __launch_bounds__(256) void k_nchw_to_nhwc_f16(_Float16* __restrict__
         if (p < hw && c < Cp) dn[(int64_t)p * Cp + c] = (_Float16)tile[tx][j];
     }
 }
+// 16-byte variant (hw % 4 == 0, 16-byte aligned rows): 64 channels x 64 positions per workgroup.  Load: a thread owns a channel PAIR x 4
+// consecutive positions — two float4 loads (256-byte row segments per 16 lanes), affine + SiLU, four half2 LDS stores (row stride 33
+// dwords: 2-way conflicts at most).  Store: a thread owns one position x 8 channels — one 16-byte store (128-byte rows per 8 lanes).
+__global__ __launch_bounds__(256) void k_nchw_to_nhwc_f16_v4(_Float16* __restrict__ dst, const float* __restrict__ x, int64_t hw, int C, int Cp,
+                                                             const float* __restrict__ scale, const float* __restrict__ shift, int silu) {
+    __shared__ uint32_t tile[64][33];  // [position][channel pair] half2
+    const int n  = blockIdx.z;
+    const int p0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const float* xn = x + (int64_t)n * C * hw;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int item = threadIdx.x + 256 * k;  // 32 channel pairs x 16 position quads
+        const int cp = item >> 4, pq = (item & 15) * 4;
+        const int c = c0 + 2 * cp, p = p0 + pq;
+        float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
+        if (p < hw) {
+            if (c < C) va = *(const float4*)(xn + (int64_t)c * hw + p);
+            if (c + 1 < C) vb = *(const float4*)(xn + (int64_t)(c + 1) * hw + p);
+        }
+        float a[4] = {va.x, va.y, va.z, va.w}, bq[4] = {vb.x, vb.y, vb.z, vb.w};
+        if (scale) {
+            const float sa = c < C ? scale[(int64_t)n * C + c] : 0.f, ha = c < C ? shift[(int64_t)n * C + c] : 0.f;
+            const float sb = c + 1 < C ? scale[(int64_t)n * C + c + 1] : 0.f, hb = c + 1 < C ? shift[(int64_t)n * C + c + 1] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a[i]  = a[i] * sa + ha;
+                bq[i] = bq[i] * sb + hb;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float u = a[i], v = bq[i];
+            if (silu) {
+                u = act_apply<UN_SILU>(u);
+                v = act_apply<UN_SILU>(v);
+            }
+            if (c >= C) u = 0.f;       // padded channels of the operand image are zeros
+            if (c + 1 >= C) v = 0.f;
+            const _Float16 hu = (_Float16)u, hv = (_Float16)v;
+            tile[pq + i][cp] = (uint32_t)__builtin_bit_cast(uint16_t, hu) | ((uint32_t)__builtin_bit_cast(uint16_t, hv) << 16);
+        }
+    }
+    __syncthreads();
+    _Float16* dn = dst + (int64_t)n * hw * Cp;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int item = threadIdx.x + 256 * k;  // 64 positions x 8 channel octets
+        const int pos = item >> 3, cg = (item & 7) * 4;  // cg: first channel pair of the octet
+        const int p = p0 + pos, c = c0 + 2 * cg;
+        if (p < hw && c < Cp) {
+            uint4 o;
+            o.x = tile[pos][cg];
+            o.y = tile[pos][cg + 1];
+            o.z = tile[pos][cg + 2];
+            o.w = tile[pos][cg + 3];
+            *(uint4*)(dn + (int64_t)p * Cp + c) = o;
+        }
+    }
+}
 void launch_nchw_to_nhwc_f16(hipStream_t s, void* dst, const float* x, int64_t hw, int64_t C, int64_t N, const float* scale, const float* shift, bool silu) {
     KScope ks_(s, KF_NCHW_NHWC, 0.0, (double)hw * C * N * 4.0 + (double)hw * rup64(C, 64) * N * 2.0);
     const int Cp = (int)rup64(C, 64);
     dim3 grid((unsigned)((hw + 63) / 64), (unsigned)(Cp / 64), (unsigned)N);
-    k_nchw_to_nhwc_f16<<<grid, 256, 0, s>>>((_Float16*)dst, x, hw, (int)C, Cp, scale, shift, silu ? 1 : 0);
+    if (hw % 4 == 0 && ((((uintptr_t)x) | ((uintptr_t)dst)) & 15) == 0)
+        k_nchw_to_nhwc_f16_v4<<<grid, 256, 0, s>>>((_Float16*)dst, x, hw, (int)C, Cp, scale, shift, silu ? 1 : 0);
+    else
+        k_nchw_to_nhwc_f16<<<grid, 256, 0, s>>>((_Float16*)dst, x, hw, (int)C, Cp, scale, shift, silu ? 1 : 0);
 }
 
 }  // namespace mi355x

@@ -112,6 +112,12 @@ void launch_gn_stats(hipStream_t s, float* scale, float* shift, const float* x, 
 void launch_nchw_to_nhwc_f16(hipStream_t s, void* dst, const float* x, int64_t hw, int64_t C, int64_t N, const float* scale, const float* shift,
                              bool silu);
 
+// ---- qgemm.hip: q8_0 / q4_0 Linear with <= 4 activation rows: raw quantised blocks streamed once, in-register dequant ----------------
+bool qgemv_supported(int wtype, int64_t rows, int64_t K);
+size_t qgemv_workspace_bytes(int64_t rows, int64_t K);
+void launch_qgemv(hipStream_t s, float* dst, int64_t ldd, const float* x, int64_t xs, int64_t rows, const void* wraw, int wtype, int64_t K, int64_t M, void* ws,
+                  const Epilogue& ep, float pre_scale);
+
 // ---- flash_attn.hip ---------------------------------------------------------------------------------
 // q [D,Lq,HN] (f32, strides in bytes), k [D,Lk,HN], v [DV,Lk,HN] (f16 or f32; v may be a transposed view,
 // any nb[0]) -> dst f32 written with strides

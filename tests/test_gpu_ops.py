@@ -7,6 +7,8 @@
     => GPU is closer to the exact product; rel-L2 vs oracle <= 1e-2 (q8_0) / 3e-2 (q4_0) as SURVEY.md suggests,
     and rel-L2 vs the exact dequantised-weight product <= 2e-3.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -139,6 +141,34 @@ def test_linear_weight_gemm(sd, oracle, gpu, rng, wtype, tol, tokens, K, M):
     exact = x.astype(np.float64) @ dequant(w, wtype).astype(np.float64).T + b
     if _on_gpu() or wtype in (F16, F32, BF16):   # the oracle itself (q8_0-quantised activations) is outside this bar for q8_0 / q4_0 weights
         assert rel_l2(out.reshape(tokens, M), exact) < (2e-3 if _on_gpu() or wtype != BF16 else 1e-2)
+
+
+@pytest.mark.parametrize("wtype", [Q8_0, Q4_0])
+@pytest.mark.parametrize("tokens,K,M,res", [(1, 3072, 18432 // 8, False), (2, 256, 100, True), (4, 1024, 33, False), (1, 4096, 640, True), (3, 768, 96, False)])
+def test_quantised_gemv_raw_blocks(sd, oracle, gpu, rng, wtype, tokens, K, M, res):
+    """q8_0 / q4_0 Linear under <= 4 activation rows (the DiT adaLN / modulation vectors): k_qgemv streams the RAW GGUF blocks and
+    dequantises in registers — no f16 weight image.  Its arithmetic is ggml-cpu's (activations quantised to q8_0 blocks, integer dot
+    products scaled by d_w * d_x — SURVEY.md Appendix E.1), i.e. exactly what the oracle computes: rel-L2 <= 1e-5 vs the oracle
+    (f32 summation order only), and the usual quantisation bars vs the exact dequantised product."""
+    x = rng.standard_normal((tokens, K)).astype(np.float32)
+    w = (rng.standard_normal((M, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(M).astype(np.float32)
+    r = rng.standard_normal((tokens, M)).astype(np.float32)
+
+    def build(g, L):
+        y = L.ggml_add_inplace(g.ctx, L.ggml_mul_mat(g.ctx, g.weight(w, wtype), g.input(x)), g.weight(b, F32))
+        return L.ggml_add(g.ctx, y, g.input(r)) if res else y
+
+    before = sd.backend_stats() if _on_gpu() else None
+    ref, out = run_both(sd, oracle, gpu, build)
+    assert np.isfinite(out).all()
+    assert rel_l2(out, ref) < 1e-5
+    exact = x.astype(np.float64) @ dequant(w, wtype).astype(np.float64).T + b + (r if res else 0)
+    assert rel_l2(out.reshape(tokens, M), exact) < 1e-2    # q8_0 quantisation of the activations (both sides of the comparison above share it)
+    if before is not None and not os.environ.get("SDCPP_BACKEND_OPTS"):
+        st = sd.backend_stats()
+        assert st["qgemv_linears"] - before["qgemv_linears"] == 1
+        assert st["swizzled_weight_bytes"] == before["swizzled_weight_bytes"]   # no f16 image was built for this weight
 
 
 def test_linear_residual_fusion_and_batch_dims(sd, oracle, gpu, rng):
