@@ -260,6 +260,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not dit:  # the CPU leg is defined for the headline UNet workloads
         out["cpu_baseline"] = cpu_baseline(sd, args, lat, ctx_dim)
     if rank == 0:
+        st = sd.backend_stats()
+        out["backend"] = {k: st[k] for k in ("swizzled_weight_bytes", "qgemv_linears", "split_k_gemms", "fused_attention", "generic_matmul", "plans_built", "graph_replays")}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

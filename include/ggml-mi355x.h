@@ -72,6 +72,8 @@ struct ggml_backend_mi355x_stats {
     int64_t fused_rope;          /* Rope::apply_rope node chains (cont/repeat/mul/add) replaced by one rotary kernel */
     int64_t fused_concat_heads;  /* token concat + head-major permute (+ f16 cast) of the MMDiT joint-attention operands in one pass */
     int64_t qgemv_linears;       /* q8_0 / q4_0 Linears planned on the in-register dequant kernel (raw blocks streamed, no f16 weight image) */
+    int64_t fused_chan_add;      /* conv + ADD(time-embedding [1,1,C,N]) folded into the conv epilogue (ResBlock) */
+    int64_t fused_proj_tokens;   /* SpatialTransformer 1x1 proj_in / proj_out run as token GEMMs (the NCHW <-> token transposes are not executed) */
 };
 GGML_MI355X_API void ggml_backend_mi355x_get_stats(struct ggml_backend_mi355x_stats* out);
 /* live per-kernel-family timing (bench.py's roofline legs): while a family's bit is enabled, every dispatch of that family is bracketed by

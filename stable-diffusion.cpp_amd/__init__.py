@@ -19,7 +19,7 @@ PKG_DIR = Path(__file__).resolve().parent
 ROOT = PKG_DIR.parent
 LIB_DIR = PKG_DIR / "lib"
 HOST_LIB = LIB_DIR / "libsdcpp-host.so"
-BACKEND_LIB = LIB_DIR / "libggml-mi355x.so"
+BACKEND_LIB = Path(os.environ.get("SDCPP_BACKEND_LIB", str(LIB_DIR / "libggml-mi355x.so")))  # override: experiment builds (build.py SDCPP_BUILD_VARIANT)
 
 # ggml_type numeric values (include/ggml-abi.h)
 F32, F16, Q4_0, Q8_0, I32, BF16 = 0, 1, 2, 8, 26, 30
@@ -297,7 +297,7 @@ def load_mi355x_backend() -> None:
 
 _BACKEND_STAT_FIELDS = ("graphs_computed plans_built nodes_seen kernels_planned kernels_launched fused_conv fused_conv_bounced fused_linear "
                         "fused_norm fused_geglu fused_attention generic_matmul swizzled_weight_bytes graph_replays fused_linear_geglu "
-                        "split_k_gemms head_major_gemms fused_modulate fused_gate fused_gelu fused_rope fused_concat_heads qgemv_linears").split()
+                        "split_k_gemms head_major_gemms fused_modulate fused_gate fused_gelu fused_rope fused_concat_heads qgemv_linears fused_chan_add fused_proj_tokens").split()
 
 
 class BackendStats(C.Structure):

@@ -19,8 +19,11 @@ from pathlib import Path
 PKG = Path(__file__).resolve().parent
 ROOT = PKG.parent
 CSRC = PKG / "csrc"
-LIB = PKG / "lib"
-OBJ = PKG / "build"
+# SDCPP_BUILD_VARIANT=exp builds a second copy of the backend with -DMI355X_EXPERIMENTS (wrong-result timing ablations for
+# scripts/*_ablation.py) into lib_exp/ — never loaded unless SDCPP_BACKEND_LIB points at it
+VARIANT = os.environ.get("SDCPP_BUILD_VARIANT", "")
+LIB = PKG / ("lib_" + VARIANT if VARIANT else "lib")
+OBJ = PKG / ("build_" + VARIANT if VARIANT else "build")
 ORACLE = ROOT / "oracle"
 INCLUDE = ROOT / "include"
 
@@ -33,6 +36,8 @@ HOST_FLAGS = ["-std=c++17", "-O2", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wn
 HIP_FLAGS = ["-std=c++17", "-O3", "-fPIC", "-fvisibility=hidden", f"--offload-arch={ARCH}", "-Wall",
              "-Wno-unused-function", "-Wno-unused-result", "-Wno-pass-failed", f"-I{INCLUDE}", f"-I{CSRC}",
              f"-I{CSRC / 'backend'}", f"-I{CSRC / 'kernels'}", "-D__HIP_PLATFORM_AMD__"]
+if VARIANT == "exp":
+    HIP_FLAGS.append("-DMI355X_EXPERIMENTS")
 ORACLE_FLAGS = ["-std=c++17", "-O3", "-fPIC", "-fvisibility=hidden", "-fopenmp", "-mavx2", "-mfma", "-mf16c",
                 "-Wall", f"-I{INCLUDE}"]
 

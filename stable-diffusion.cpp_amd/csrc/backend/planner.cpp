@@ -41,11 +41,11 @@ namespace {
 struct Stats {
     std::atomic<int64_t> graphs_computed{0}, plans_built{0}, nodes_seen{0}, kernels_planned{0}, kernels_launched{0}, fused_conv{0},
         fused_conv_bounced{0}, fused_linear{0}, fused_norm{0}, fused_geglu{0}, fused_attention{0}, generic_matmul{0}, swizzled_weight_bytes{0}, fused_linear_geglu{0}, split_k_gemms{0}, head_major_gemms{0}, fused_modulate{0}, fused_gate{0}, fused_gelu{0}, fused_rope{0}, fused_concat_heads{0},
-        graph_replays{0}, qgemv_linears{0};
+        graph_replays{0}, qgemv_linears{0}, fused_chan_add{0}, fused_proj_tokens{0};
 } g_stats;
 
 struct Options {
-    std::atomic<int> fusion{1}, mfma_gemm{1}, hip_graph{0}, flash_pattern{1}, gemm16{1}, fuse_modulate{1}, fuse_gate{1}, fuse_gelu{1}, fuse_rope{1}, fuse_concat_heads{1}, qgemv{1};
+    std::atomic<int> fusion{1}, mfma_gemm{1}, hip_graph{0}, flash_pattern{1}, gemm16{1}, fuse_modulate{1}, fuse_gate{1}, fuse_gelu{1}, fuse_rope{1}, fuse_concat_heads{1}, qgemv{1}, fuse_chan_add{1}, fuse_proj_tokens{1};
 } g_opt;
 
 using Step = std::function<void(hipStream_t)>;
@@ -661,9 +661,57 @@ bool plan_conv_chain(Builder& B, int i, hipStream_t s, std::vector<int>& chain) 
         chain.push_back(j6);
         last = j6;
     }
-    // -> ADD residual (same shape, either operand order), only when it directly follows
+    // SpatialTransformer proj_in (block.hpp:548-556, SD1.x keeps it a 1x1 conv): conv -> PERMUTE(1,2,0,3) -> CONT turns [W,H,OC,N] into the
+    // token-major [OC, W*H, N] the transformer blocks read.  A 1x1 conv IS a token GEMM: rows = positions of the NHWC operand image,
+    // columns = output channels — run it in Linear mode and write the CONT's layout directly (no NCHW tensor, no transpose pass).
+    int token_major_out = -1;
+    if (g_opt.fuse_proj_tokens && g_opt.gemm16 && KW == 1 && s0 == 1 && B.ups.find(x) == B.ups.end()) {
+        const int jp = gi.sole(last);
+        const int jc = (jp >= 0 && gi.node(jp)->op == GGML_OP_PERMUTE && gi.node(jp)->src[0] == gi.node(last)) ? gi.sole(jp) : -1;
+        if (jc >= 0 && gi.node(jc)->op == GGML_OP_CONT && gi.node(jc)->src[0] == gi.node(jp) && is_f32(gi.node(jc)) && contig(gi.node(jc))) {
+            const int32_t* pa = gi.node(jp)->op_params;
+            std::vector<int> c2 = chain;
+            c2.push_back(jp);
+            c2.push_back(jc);
+            if (pa[0] == 1 && pa[1] == 2 && pa[2] == 0 && pa[3] == 3 && gi.node(jc)->ne[0] == OC && gi.only_noops_between(last, jc, c2) &&
+                !(gi.node(last)->flags & GGML_TENSOR_FLAG_OUTPUT)) {
+                chain           = c2;
+                last            = jc;
+                token_major_out = jc;
+            }
+        }
+    }
+    // -> ADD(., emb [1,1,OC,N]): the ResBlock's time-embedding add (block.hpp:150-160).  The embedding branch (SILU -> Linear -> RESHAPE) is
+    // reached by the graph's DFS AFTER the conv chain, so its nodes sit between the chain and this ADD: the conv kernel is emitted at the
+    // ADD's position instead (its input is the private f16 image in the arena, which no graph node can overwrite in between)
     const size_t ob = ggml_abi_nbytes(out);
-    {
+    int emit_node = i;
+    if (g_opt.fuse_chan_add && g_opt.gemm16 && token_major_out < 0) {
+        const int r = gi.sole(last);
+        if (r >= 0 && gi.node(r)->op == GGML_OP_ADD && gi.node(r)->src[0] == gi.node(last)) {
+            const ggml_tensor* a = gi.node(r);
+            const ggml_tensor* e = a->src[1];
+            if (is_f32(e) && contig(e) && contig(a) && e->ne[0] == 1 && e->ne[1] == 1 && e->ne[2] == OC && e->ne[3] == N && N > 0 && ggml_abi_same_shape(out, a) &&
+                gi.idx(strip_reshape(e)) < r && !(gi.node(last)->flags & GGML_TENSOR_FLAG_OUTPUT)) {
+                bool ok = true;  // nothing between the chain and the ADD may touch the ADD's output range
+                for (int k = last + 1; k < r && ok; ++k) {
+                    const ggml_tensor* t = gi.node(k);
+                    if (ggml_abi_op_is_noop(t->op)) continue;
+                    for (int q = 0; q < GGML_MAX_SRC && t->src[q]; ++q)
+                        for (int c : chain) ok = ok && t->src[q] != gi.node(c);
+                }
+                if (ok) {
+                    ep.chan_add = (const float*)e->data;
+                    chain.push_back(r);
+                    last      = r;
+                    emit_node = r;
+                    g_stats.fused_chan_add++;
+                }
+            }
+        }
+    }
+    // -> ADD residual (same shape, either operand order), only when it directly follows
+    if (!ep.chan_add && token_major_out < 0) {
         int r = gi.sole(last);
         if (r >= 0 && gi.node(r)->op == GGML_OP_ADD && gi.only_noops_between(last, r, chain)) {
             const ggml_tensor* a     = gi.node(r);
@@ -705,16 +753,62 @@ bool plan_conv_chain(Builder& B, int i, hipStream_t s, std::vector<int>& chain) 
         const size_t off = it->second.off;
         const int64_t CW_ = upscale ? SW * 2 : SW, CH_ = upscale ? SH * 2 : SH;
         const int64_t opos = ((CW_ + 2 * pd - ks) / st_ + 1) * ((CH_ + 2 * pd - ks) / st_ + 1) * N;
+        if (token_major_out >= 0) {
+            float* tdst          = (float*)gi.node(token_major_out)->data;
+            const int64_t tokens = SW * SH * N;
+            const int64_t lda    = it->second.ld;
+            B.emit([=](hipStream_t st) { launch_gemm16_linear(st, tdst, nullptr, 0, P->arena + off, lda, swz, tokens, IC, OC, OC, ep); });
+            g_stats.fused_conv++;
+            g_stats.fused_proj_tokens++;
+            return true;
+        }
         const int S        = gemm16_split_k(opos, OC, rup64(IC) * ks * ks);
         const size_t wsoff = S > 1 ? B.alloc((size_t)S * opos * OC * 4) : 0;
         if (S > 1) g_stats.split_k_gemms++;
-        B.emit([=](hipStream_t st) {
+        B.emit_at(emit_node, i, [=](hipStream_t st) {
             launch_gemm16_conv(st, final_dst, P->arena + off, swz, SW, SH, IC, N, OC, ks, st_, pd, upscale, ep, S > 1 ? (float*)(P->arena + wsoff) : nullptr);
         });
         g_stats.fused_conv++;
         return true;
     }
     return false;  // unreachable: option "gemm16" is always on (the first-generation kernels behind gemm16=0 were removed in round 2)
+}
+
+// SpatialTransformer proj_out (block.hpp:566-572): tokens [C, HW, N] -> CONT(PERMUTE(1,0,2,3)) -> RESHAPE [W,H,C,N] -> 1x1 conv.  The conv's
+// NHWC f16 operand image [N][HW][Cp] is exactly the token rows rounded to f16: pack it straight from the token tensor and drop the
+// transposing copy (its f32 output is read by nothing else).
+bool plan_tokens_to_conv(Builder& B, int i, hipStream_t, std::vector<int>& chain) {
+    GInfo& gi            = B.gi;
+    const ggml_tensor* n = gi.node(i);
+    if (!g_opt.fuse_proj_tokens || !g_opt.gemm16 || !g_opt.fusion || !is_f32(n) || !contig(n) || (n->flags & GGML_TENSOR_FLAG_OUTPUT)) return false;
+    const ggml_tensor* pm = n->src[0];
+    if (!pm || pm->op != GGML_OP_PERMUTE) return false;
+    const int32_t* pa = pm->op_params;
+    if (!(pa[0] == 1 && pa[1] == 0 && pa[2] == 2 && pa[3] == 3)) return false;
+    const ggml_tensor* t = pm->src[0];  // [C, HW, N(, 1)] token-major
+    if (!t || !is_f32(t) || !contig(t) || t->ne[3] != 1 || t->ne[0] % 4 != 0 || !aligned16(t->data)) return false;
+    const int64_t C = t->ne[0], HW = t->ne[1], N = t->ne[2];
+    // sole consumer chain: RESHAPE [W,H,C,N] -> IM2COL of a fusable 1x1 conv
+    int j = gi.sole(i);
+    int rs = -1;
+    while (j >= 0 && gi.node(j)->op == GGML_OP_RESHAPE) {
+        rs = j;
+        j  = gi.sole(j);
+    }
+    if (rs < 0 || j < 0 || gi.node(j)->op != GGML_OP_IM2COL || gi.node(j)->src[1] != gi.node(rs) || !conv_im2col_fast_ok(gi, j)) return false;
+    const ggml_tensor* xr  = gi.node(rs);
+    const ggml_tensor* ker = gi.node(j)->src[0];
+    if (ker->ne[0] != 1 || ker->ne[1] != 1 || ker->ne[2] != C || xr->ne[2] != C || xr->ne[3] != N || xr->ne[0] * xr->ne[1] != HW) return false;
+    if (!gi.only_noops_between(i, j, {i})) return false;
+    Packed pk{B.alloc((size_t)N * HW * rup64(C) * 2), rup64(C), true};
+    Planner* P       = B.P;
+    const size_t off = pk.off;
+    const float* tp  = (const float*)t->data;
+    B.emit([=](hipStream_t st) { launch_pack_rows_f16(st, P->arena + off, tp, N * HW, C, C); });
+    B.packed[xr] = pk;
+    chain        = {i};
+    g_stats.fused_proj_tokens++;
+    return true;
 }
 
 // GROUP_NORM -> MUL -> ADD [-> SILU]
@@ -1350,6 +1444,7 @@ bool build_plan(Planner* P, Plan* plan, const ggml_cgraph* g, hipStream_t s) {
             case GGML_OP_CONT:
                 ok = plan_geglu(B, i, s, chain);
                 if (!ok) ok = plan_rope(B, i, s, chain);
+                if (!ok) ok = plan_tokens_to_conv(B, i, s, chain);
                 break;
             case GGML_OP_UPSCALE: {
                 // nearest x2 feeding only an implicit-GEMM conv (UpSampleBlock, block.hpp:57-64): fold into the conv's gather
@@ -1624,6 +1719,8 @@ void planner_get_stats(ggml_backend_mi355x_stats* o) {
     o->fused_rope            = g_stats.fused_rope;
     o->fused_concat_heads    = g_stats.fused_concat_heads;
     o->qgemv_linears         = g_stats.qgemv_linears;
+    o->fused_chan_add        = g_stats.fused_chan_add;
+    o->fused_proj_tokens     = g_stats.fused_proj_tokens;
     o->fused_attention       = g_stats.fused_attention;
     o->generic_matmul        = g_stats.generic_matmul;
     o->swizzled_weight_bytes = g_stats.swizzled_weight_bytes;
@@ -1637,9 +1734,12 @@ void planner_set_option(const char* key, int value) {
     else if (!strcmp(key, "flash_pattern")) g_opt.flash_pattern = value;
 #ifdef MI355X_EXPERIMENTS
     else if (!strcmp(key, "flash_ablate")) flash_attn_set_ablate(value);
+    else if (!strcmp(key, "gemm16_abl")) gemm16_set_abl(value);
 #endif
     else if (!strcmp(key, "gemm16_t320")) gemm16_set_t320(value);
     else if (!strcmp(key, "qgemv")) g_opt.qgemv = value;
+    else if (!strcmp(key, "fuse_chan_add")) g_opt.fuse_chan_add = value;
+    else if (!strcmp(key, "fuse_proj_tokens")) g_opt.fuse_proj_tokens = value;
     else if (!strcmp(key, "gemm16")) (void)value;  // kept for old scripts: the gemm16 path is the only one (first-generation kernels removed)
     else if (!strcmp(key, "fuse_modulate")) g_opt.fuse_modulate = value;
     else if (!strcmp(key, "fuse_gate")) g_opt.fuse_gate = value;

@@ -1037,11 +1037,13 @@ static bool sample_group(sdm_ctx_t* ctx, const sdm_img_gen_params_t* p, int b0, 
     // per-image RNG: seed+b; initial noise consumes offset 0 (stable-diffusion.cpp:5678-5683; rng == sampler_rng :886-889)
     std::vector<PhiloxRNG> rngs;
     std::vector<float> x(per * nb);
-    for (int b = 0; b < nb; ++b) {
-        rngs.emplace_back((uint64_t)(p->seed + b0 + b));
-        std::vector<float> noise = rngs[b].randn((uint32_t)per);
-        for (size_t i = 0; i < per; ++i) x[b * per + i] = 0.0f + noise[i] * sigmas[0];  // noise_scaling, denoiser.hpp:1174-1179
-    }
+    for (int b = 0; b < nb; ++b) rngs.emplace_back((uint64_t)(p->seed + b0 + b));
+    parallel_chunks((size_t)nb, [&](size_t i0, size_t i1) {
+        for (size_t b = i0; b < i1; ++b) {
+            std::vector<float> noise = rngs[b].randn((uint32_t)per);
+            for (size_t i = 0; i < per; ++i) x[b * per + i] = 0.0f + noise[i] * sigmas[0];  // noise_scaling, denoiser.hpp:1174-1179
+        }
+    }, 2);
     const bool use_cfg = sp.txt_cfg != 1.0f && p->uncond.c_crossattn != nullptr;
     std::vector<float> noised(per * nb), cond_out(per * nb), uncond_out(per * nb), denoised(per * nb), ts(nb);
     std::vector<std::vector<float>> step_noise(nb);
@@ -1201,11 +1203,14 @@ static bool sample_group_device(sdm_ctx_t* ctx, const sdm_img_gen_params_t* p, i
 
     std::vector<PhiloxRNG> rngs;
     std::vector<float> x(per * nb), noise(per * nb, 0.f);
-    for (int b = 0; b < nb; ++b) {
-        rngs.emplace_back((uint64_t)(p->seed + b0 + b));
-        std::vector<float> nz = rngs[b].randn((uint32_t)per);
-        for (size_t i = 0; i < per; ++i) x[b * per + i] = 0.0f + nz[i] * sigmas[0];
-    }
+    for (int b = 0; b < nb; ++b) rngs.emplace_back((uint64_t)(p->seed + b0 + b));
+    // one independent Philox stream per image (seed + b): the images' draws run on separate host threads (0.7 ms per SD1.5 image each)
+    parallel_chunks((size_t)nb, [&](size_t i0, size_t i1) {
+        for (size_t b = i0; b < i1; ++b) {
+            std::vector<float> nz = rngs[b].randn((uint32_t)per);
+            for (size_t i = 0; i < per; ++i) x[b * per + i] = 0.0f + nz[i] * sigmas[0];
+        }
+    }, 2);
     ggml_backend_tensor_set_async(ctx->backend, st.x, x.data(), 0, x.size() * sizeof(float));
     ggml_backend_tensor_set_async(ctx->backend, st.noise, noise.data(), 0, noise.size() * sizeof(float));
 
@@ -1262,10 +1267,12 @@ static bool sample_group_device(sdm_ctx_t* ctx, const sdm_img_gen_params_t* p, i
             sc[4] = sigma, sc[5] = sigma_to - sigma;
         }
         if (fresh_noise) {
-            for (int b = 0; b < nb; ++b) {
-                std::vector<float> nz = rngs[b].randn((uint32_t)per);
-                memcpy(&noise[b * per], nz.data(), per * sizeof(float));
-            }
+            parallel_chunks((size_t)nb, [&](size_t i0, size_t i1) {
+                for (size_t b = i0; b < i1; ++b) {
+                    std::vector<float> nz = rngs[b].randn((uint32_t)per);
+                    memcpy(&noise[b * per], nz.data(), per * sizeof(float));
+                }
+            }, 2);
             ggml_backend_tensor_set_async(ctx->backend, st.noise, noise.data(), 0, noise.size() * sizeof(float));
         }
         auto build = [&](GraphCtx& g, std::vector<HostInput>& in) {

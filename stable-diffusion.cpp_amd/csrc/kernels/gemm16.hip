@@ -36,6 +36,7 @@ struct G16Epi {  // dst = acc * scale + bias (+ residual); DiT variants: (acc*sc
     const float* gate = nullptr;  // [images][C] per-image per-column gate (adaLN gate_msa / gate_mlp, mmdit.hpp:540-551); needs residual
     int gate_L        = 0;        // rows per image (>= 32)
     int gelu          = 0;        // f16-only output: tanh-GELU before rounding (Mlp fc1 -> fc2, block.hpp:249-258)
+    const float* chan_add = nullptr;  // conv only: [N][OC] value added per (image, channel) — the ResBlock's time-embedding ADD (block.hpp:150-160)
 };
 
 struct G16Args {
@@ -244,6 +245,7 @@ __device__ __forceinline__ void epi_conv(const float16_t (&acc)[RB][CB], const G
             if (cblk >= g.C) continue;
             const int64_t ub = ((int64_t)img0 * g.C + cblk) * g.OHOW;  // uniform
             const float* pb  = g.ep.bias ? g.ep.bias + cblk : nullptr;
+            const float* pc  = g.ep.chan_add ? g.ep.chan_add + (int64_t)img0 * g.C + cblk : nullptr;  // + dimg * C per lane
             // loads first (bias, residual), then the stores: dst may BE the residual, so the compiler cannot batch them itself
 #pragma unroll
             for (int r0 = 0; r0 < 16; r0 += 8) {
@@ -253,6 +255,7 @@ __device__ __forceinline__ void epi_conv(const float16_t (&acc)[RB][CB], const G
                     const int ro  = (r & 3) + 8 * (r >> 2);
                     const bool ok = MODE != 2 || cblk + ro + 4 * hi < g.C;
                     bv[r - r0]    = (pb && ok) ? ld_u(pb + ro, 16u * hi) : 0.f;
+                    if (pc && ok) bv[r - r0] += ld_u(pc + ro, (4u * hi + dimg * (uint32_t)g.C) * 4u);
                     rv[r - r0]    = ((MODE == 1 || (MODE == 2 && g.ep.residual)) && ok) ? ld_u(g.ep.residual + ub + (int64_t)ro * g.OHOW, le * 4u) : 0.f;
                 }
 #pragma unroll
@@ -446,6 +449,34 @@ __global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g
             if (q + 1 < WPW || !w_short) GLDS16(wsrc[q] + (int64_t)kt * KSTEPS * 64, sb + wdst[q]);
     };
 
+    // the same, ONE LDS-DMA piece at a time (idx < APW: A piece idx, else W fragment idx - APW; same issue order as stage()) — the pipelined loop
+    // interleaves the pieces with its MFMA groups so that the address arithmetic issues in the shadow of the wave's own MFMAs
+    auto stage_piece = [&](int idx, int kt, int buf, int tap, int kh, int kw, int icb, int sub) {
+        char* sa = smem + buf * (ABYTES + BBYTES);
+        char* sb = sa + ABYTES;
+        if (idx < APW) {
+            const int q = idx;
+            if (!CONV) {
+                GLDS16(asrc[q] + (int64_t)kt * BK, sa + (wave * APW + q) * 1024);
+            } else {
+                const int64_t koff = (int64_t)icb * 64 + sub * BK;
+                if (!g.UPS) {
+                    const int64_t toff = ((int64_t)kh * g.Wd + kw) * g.ICp + koff;
+                    const _Float16* p  = ((a_mask[q] >> tap) & 1u) ? asrc[q] + toff : g.zero + (a_slot[q] & 63);
+                    GLDS16(p, sa + (wave * APW + q) * 1024);
+                } else {
+                    const int oh = (a_slot[q] >> 8) & 4095, ow = (a_slot[q] >> 20) & 4095;
+                    const int sy = (oh * g.S + kh - g.pad) >> 1, sx = (ow * g.S + kw - g.pad) >> 1;
+                    const _Float16* p = ((a_mask[q] >> tap) & 1u) ? asrc[q] + ((int64_t)sy * g.Wd + sx) * g.ICp + koff : g.zero + (a_slot[q] & 63);
+                    GLDS16(p, sa + (wave * APW + q) * 1024);
+                }
+            }
+        } else {
+            const int q = idx - APW;
+            if (q < WPW && (q + 1 < WPW || !w_short)) GLDS16(wsrc[q] + (int64_t)kt * KSTEPS * 64, sb + wdst[q]);
+        }
+    };
+
     float16_t acc[RB][CB];
 #pragma unroll
     for (int a = 0; a < RB; ++a)
@@ -497,7 +528,13 @@ __global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g
         // the last two MFMA groups (128 cycles) in front of the wait that needs every fragment of the next k-step
         constexpr int CL = CB - 2;
         half8_t A0[RB], A1[RB], BL[CL], BH0[2], BH1[2];
+        // PIPE == 2 / 3 exist only in -DMI355X_EXPERIMENTS builds (scripts/gemm_ablation.py): wrong-result TIMING ablations — 2 keeps the
+        // DMA stream, reads, waits and barriers but issues no MFMA; 3 keeps reads + MFMAs but stages nothing after the pipeline fill
         auto mma = [&](int rb, int cb, const half8_t& a, const half8_t& b) {
+            if constexpr (PIPE == 2) {
+                asm volatile("" ::"v"(a), "v"(b));
+                return;
+            }
             if (CONV)
                 acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b, a, acc[rb][cb], 0, 0, 0);  // D[oc][pos]
             else
@@ -507,7 +544,10 @@ __global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g
 #define G16_TIE(X_) asm volatile("" : "+v"(X_))
         // One k-step.  ACUR / ANXT, HCUR / HNXT: current and next fragment sets; an_ / bn_: LDS addresses of this lane's A row (row block 0)
         // and of this wave's first B fragment for the NEXT k-step (KSN_ = its index inside its stage)
-#define G16_KSTEP(ACUR, ANXT, HCUR, HNXT, an_, bn_, KSN_)                                                            \
+#define G16_NOHOOK(I_) ((void)0)
+#define G16_KSTEP(ACUR, ANXT, HCUR, HNXT, an_, bn_, KSN_) G16_KSTEP_H(ACUR, ANXT, HCUR, HNXT, an_, bn_, KSN_, G16_NOHOOK)
+        // HOOK_(i), i = 0 .. 4: a statement issued behind MFMA group i (the steady-state loop issues one LDS-DMA piece of stage kt+4 there)
+#define G16_KSTEP_H(ACUR, ANXT, HCUR, HNXT, an_, bn_, KSN_, HOOK_)                                                   \
     do {                                                                                                             \
         G16_RD(ANXT[0], an_, 0);                                                                                     \
         G16_RD(ANXT[1], an_, 2048);                                                                                  \
@@ -518,11 +558,13 @@ __global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g
         mma(1, 0, ACUR[1], BL[0]);                                                                                   \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
         G16_RD(BL[0], bn_, (0 * KSTEPS + (KSN_)) * 1024);                                                            \
+        HOOK_(0);                                                                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
         mma(0, 1, ACUR[0], BL[1]);                                                                                   \
         mma(1, 1, ACUR[1], BL[1]);                                                                                   \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
         G16_RD(BL[1], bn_, (1 * KSTEPS + (KSN_)) * 1024);                                                            \
+        HOOK_(1);                                                                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
         if constexpr (CL > 2) {                                                                                      \
             mma(0, 2, ACUR[0], BL[CL - 1]);                                                                          \
@@ -531,10 +573,17 @@ __global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g
             G16_RD(BL[CL - 1], bn_, (2 * KSTEPS + (KSN_)) * 1024);                                                   \
             __builtin_amdgcn_sched_barrier(0);                                                                       \
         }                                                                                                            \
+        HOOK_(2);                                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
         mma(0, CB - 2, ACUR[0], HCUR[0]);                                                                            \
         mma(1, CB - 2, ACUR[1], HCUR[0]);                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        HOOK_(3);                                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
         mma(0, CB - 1, ACUR[0], HCUR[1]);                                                                            \
         mma(1, CB - 1, ACUR[1], HCUR[1]);                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        HOOK_(4);                                                                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
     } while (0)
         // tie every fragment the next MFMAs use behind the s_waitcnt issued just before (asm volatile statements keep their order)
@@ -546,6 +595,13 @@ __global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g
         G16_TIE(HS_[0]);                                                                                             \
         G16_TIE(HS_[1]);                                                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
+    } while (0)
+#define G16_DMA_HOOK(I_)                                                                                             \
+    do {                                                                                                             \
+        if (PIPE != 3 && (I_) < NPT) stage_piece((I_), kt0 + kt + NST, fbuf, c_tap, c_kh, c_kw, c_icb, c_sub);      \
+        if (PIPE != 3 && (I_) == 4 && NPT > 5) {                                                                     \
+            _Pragma("unroll") for (int e_ = 5; e_ < NPT; ++e_) stage_piece(e_, kt0 + kt + NST, fbuf, c_tap, c_kh, c_kw, c_icb, c_sub); \
+        }                                                                                                            \
     } while (0)
 #define G16_PIPE_LOOP(NP_)                                                                                                         \
     do {                                                                                                                           \
@@ -583,12 +639,13 @@ __global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g
             asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * (NP_)) : "memory");                                            \
             G16_TIE_FRAGS(A1, BH1);                                                                                                \
             asm volatile("s_barrier" ::: "memory");                                                                                \
-            stage(kt0 + kt + NST, buf, c_tap, c_kh, c_kw, c_icb, c_sub);                                                           \
-            G16_ADVANCE();                                                                                                         \
+            /* the slot just freed takes stage kt+4: its NPT LDS-DMA pieces are issued one per MFMA group of this k-step */         \
+            const int fbuf    = buf;                                                                                               \
             buf               = buf == NST - 1 ? 0 : buf + 1;                                                                      \
             const uint32_t sn = (uint32_t)buf * STAGE;                                                                             \
             __builtin_amdgcn_sched_barrier(0);                                                                                     \
-            G16_KSTEP(A1, A0, BH1, BH0, aad0 + sn, bad + sn, 0);                                                                   \
+            G16_KSTEP_H(A1, A0, BH1, BH0, aad0 + sn, bad + sn, 0, G16_DMA_HOOK);                                                   \
+            G16_ADVANCE();                                                                                                         \
         }                                                                                                                          \
         /* drain: the last (up to NST) stages, nothing left to issue */                                                           \
         for (; kt < nt; ++kt) {                                                                                                    \
@@ -617,8 +674,11 @@ __global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g
         else
             G16_PIPE_LOOP(NPT);
 #undef G16_PIPE_LOOP
+#undef G16_DMA_HOOK
 #undef G16_TIE_FRAGS
+#undef G16_KSTEP_H
 #undef G16_KSTEP
+#undef G16_NOHOOK
 #undef G16_TIE
 #undef G16_RD
     } else if (NST == 2) {
@@ -726,6 +786,10 @@ void gemm16_set_tile(int t) { g_g16_force_tile = t; }
 // rounds; a full round of T128 (768 slots) and of T256 (512 slots, twice the area per workgroup) take about the same time, a T160
 // round 1.5x that (4 waves per workgroup hide less latency) but covers 1.25x T256's area with no padded columns.  256-row tiles
 // only pay when they fill every CU twice (>= 512 workgroups); otherwise the finer T128 quantises better.
+#ifdef MI355X_EXPERIMENTS
+static int g_g16_abl = 0;  // option "gemm16_abl": 1 = no MFMAs, 2 = no DMA after the fill (T320 only; wrong results, timing)
+void gemm16_set_abl(int v) { g_g16_abl = v; }
+#endif
 static int g_g16_t320 = 1;  // option "gemm16_t320": 0 disables the pipelined 256x320 tile in the per-shape choice (A/B measurements)
 void gemm16_set_t320(int v) { g_g16_t320 = v; }
 static int g16_t320_split(int64_t rows, int64_t M, int64_t nt);
@@ -780,6 +844,16 @@ static void g16_launch(hipStream_t s, G16Args& g, int64_t rows, double flops) {
             KScope ks_(s, CONV_ ? KF_CONV_T256 : KF_LINEAR, flops, 0.0);
             if (tile == G16_T320) {
                 g.ncol_tiles = (int)((g.C + 319) / 320);
+#ifdef MI355X_EXPERIMENTS
+                if (g_g16_abl == 1) {
+                    k_gemm16<256, 320, CONV_, 32, 4, 4, 2, 2><<<dim3((unsigned)(rt256 * g.ncol_tiles), ny), 512, 0, s>>>(g);
+                    return;
+                }
+                if (g_g16_abl == 2) {
+                    k_gemm16<256, 320, CONV_, 32, 4, 4, 2, 3><<<dim3((unsigned)(rt256 * g.ncol_tiles), ny), 512, 0, s>>>(g);
+                    return;
+                }
+#endif
                 k_gemm16<256, 320, CONV_, 32, 4, 4, 2, 1><<<dim3((unsigned)(rt256 * g.ncol_tiles), ny), 512, 0, s>>>(g);
             } else if (tile == G16_T256P) {
                 g.ncol_tiles = (int)((g.C + 255) / 256);
@@ -851,7 +925,7 @@ int gemm16_split_k(int64_t rows, int64_t M, int64_t K) {
 // dst[i] = sum_s slab_s[i] + bias[(i / inner) % C] + residual[i];  4 elements per thread (n % 4 == 0, and inner % 4 == 0 or inner == 1 with C % 4 == 0)
 template <bool V4>
 __global__ void k_splitk_reduce(float* __restrict__ dst, const float* __restrict__ ws, int S, int64_t slab, int64_t n, const float* __restrict__ bias,
-                                int64_t inner, int C, const float* residual) {
+                                int64_t inner, int C, const float* residual, const float* __restrict__ chan_add) {
     constexpr int W   = V4 ? 4 : 1;
     const int64_t i   = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * W;
     if (i >= n) return;
@@ -876,6 +950,16 @@ __global__ void k_splitk_reduce(float* __restrict__ dst, const float* __restrict
             for (int j = 0; j < W; ++j) v[j] += b;
         }
     }
+    if (chan_add) {  // conv output [OHOW][C][N]: element i belongs to (image, channel) pair i / OHOW
+        if (inner == 1) {  // 1x1 feature maps: consecutive elements are consecutive channels
+#pragma unroll
+            for (int j = 0; j < W; ++j) v[j] += chan_add[i + j];
+        } else {
+            const float b = chan_add[i / inner];
+#pragma unroll
+            for (int j = 0; j < W; ++j) v[j] += b;
+        }
+    }
     if (residual) {
 #pragma unroll
         for (int j = 0; j < W; ++j) v[j] += residual[i + j];
@@ -883,13 +967,14 @@ __global__ void k_splitk_reduce(float* __restrict__ dst, const float* __restrict
 #pragma unroll
     for (int j = 0; j < W; ++j) dst[i + j] = v[j];
 }
-static void launch_splitk_reduce(hipStream_t s, float* dst, const float* ws, int S, int64_t n, const float* bias, int64_t inner, int64_t C, const float* residual) {
+static void launch_splitk_reduce(hipStream_t s, float* dst, const float* ws, int S, int64_t n, const float* bias, int64_t inner, int64_t C, const float* residual,
+                                 const float* chan_add = nullptr) {
     KScope ks_(s, KF_SPLITK, 0.0, (double)n * 4.0 * (S + 1));
     const bool v4 = n % 4 == 0 && (inner % 4 == 0 || (inner == 1 && C % 4 == 0)) && (((uintptr_t)dst | (uintptr_t)ws | (uintptr_t)residual) & 15) == 0;
     if (v4)
-        k_splitk_reduce<true><<<(unsigned)((n / 4 + 255) / 256), 256, 0, s>>>(dst, ws, S, n, n, bias, inner, (int)C, residual);
+        k_splitk_reduce<true><<<(unsigned)((n / 4 + 255) / 256), 256, 0, s>>>(dst, ws, S, n, n, bias, inner, (int)C, residual, chan_add);
     else
-        k_splitk_reduce<false><<<(unsigned)((n + 255) / 256), 256, 0, s>>>(dst, ws, S, n, n, bias, inner, (int)C, residual);
+        k_splitk_reduce<false><<<(unsigned)((n + 255) / 256), 256, 0, s>>>(dst, ws, S, n, n, bias, inner, (int)C, residual, chan_add);
 }
 
 // a 256-byte zero page per device for the padding taps
@@ -1015,6 +1100,7 @@ void launch_gemm16_conv(hipStream_t s, float* dst, const void* x16_nhwc, const v
     g.zero = zero_page();
     g16_check_epi(e);
     g.ep   = G16Epi{e.bias, e.residual, e.scale};
+    g.ep.chan_add = e.chan_add;
     const int S = splitk_ws ? gemm16_split_k(g.R, OC, (int64_t)g.ICp * ksize * ksize) : 1;
     if (S > 1) {
         g.split_k  = S;
@@ -1034,7 +1120,7 @@ void launch_gemm16_conv(hipStream_t s, float* dst, const void* x16_nhwc, const v
         g.ncol_tiles = (int)((OC + 127) / 128);
         g16_launch<128, true>(s, g, g.R, 2.0 * g.R * IC * ksize * ksize * OC);
     }
-    if (S > 1) launch_splitk_reduce(s, dst, splitk_ws, S, g.R * OC, e.bias, g.OHOW, OC, e.residual);
+    if (S > 1) launch_splitk_reduce(s, dst, splitk_ws, S, g.R * OC, e.bias, g.OHOW, OC, e.residual, e.chan_add);
 }
 
 // =====================================================================================================

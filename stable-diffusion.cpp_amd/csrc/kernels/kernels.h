@@ -86,6 +86,9 @@ int gemm16_tap_major();
 void gemm16_set_splitk_target(int v);
 void gemm16_set_splitk_mid(int v);  // 1: two K slices for launches of 193..384 workgroups with >= 128 K tiles (experiment, default 0)
 void gemm16_set_tile(int t);     // -1: per-shape choice; 0..5: force T128 / T256 / T256W / T160 / T160N / T320 (A/B measurements)
+#ifdef MI355X_EXPERIMENTS
+void gemm16_set_abl(int v);
+#endif
 void gemm16_set_t320(int v);     // 0: never choose the pipelined 256x320 tile
 void gemm16_set_variant(int v);  // 0: BK64x2 stages, 1: BK32x3 stages (default), 2: BK64x3 stages
 // hm_d > 0: head-major store — element (row = n*hm_L + l, col = h*hm_d + dd) goes to ((n*hm_H + h)*hm_L + l)*hm_d + dd of dst (f32) / dst16 (f16)

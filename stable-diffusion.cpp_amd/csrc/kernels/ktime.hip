@@ -28,7 +28,7 @@ const char* const kNames[KF_COUNT] = {
     "softmax (k_soft_max)",
     "other",
 };
-const int kBound[KF_COUNT] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
+const int kBound[KF_COUNT] = {0, 0, 0, 0, 1, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
 
 struct Rec {
     hipEvent_t e0, e1;

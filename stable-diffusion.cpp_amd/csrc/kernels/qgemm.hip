@@ -124,24 +124,29 @@ __global__ __launch_bounds__(256) void k_qgemv(QGArgs g) {
             }
         }
         const int64_t seg_byte = (int64_t)seg * SEGB;
+        // ---- coalesced 16-byte loads of the contiguous segment of ALL CPW rows first (independent loads: CPW x 1-2 KB in flight per wave —
+        // issued one row at a time behind the LDS round trip of the previous row they serialised on the full HBM latency: 740 GB/s)
+        uint4 gl[CPW][NLD];
+#pragma unroll
+        for (int c = 0; c < CPW; ++c) {
+            const int col    = min(col0 + c, g.M - 1);
+            const char* rowp = g.W + (int64_t)col * g.row_bytes + seg_byte;
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                const int gidx = i * 64 + lane;
+                gl[c][i]       = gidx < seg_ng ? *(const uint4*)(rowp + (int64_t)gidx * 16) : make_uint4(0, 0, 0, 0);
+            }
+        }
 #pragma unroll
         for (int c = 0; c < CPW; ++c) {
             const int col = col0 + c;
             if (col >= g.M) break;  // wave-uniform
-            const char* rowp = g.W + (int64_t)col * g.row_bytes + seg_byte;
-            // ---- coalesced 16-byte loads of the contiguous segment into the wave's LDS strip
-            uint4 gl[NLD];
-#pragma unroll
-            for (int i = 0; i < NLD; ++i) {
-                const int gidx = i * 64 + lane;
-                gl[i]          = gidx < seg_ng ? *(const uint4*)(rowp + (int64_t)gidx * 16) : make_uint4(0, 0, 0, 0);
-            }
             // the strip is private to this wave and LDS operations of one wave execute in order: a wavefront-scope fence (no instruction, it
             // only stops the compiler from moving the block reads above other lanes' stores) is all the synchronisation needed
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int i = 0; i < NLD; ++i) *(uint4*)(my + (i * 64 + lane) * 16) = gl[i];
+            for (int i = 0; i < NLD; ++i) *(uint4*)(my + (i * 64 + lane) * 16) = gl[c][i];
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             // ---- this lane's block: NDW aligned dwords, funnel-shifted to the block's 2-byte phase
@@ -221,7 +226,7 @@ void launch_qgemv(hipStream_t s, float* dst, int64_t ldd, const float* x, int64_
     g.dst = dst; g.ldd = ldd;
     g.bias = ep.bias; g.residual = ep.residual; g.scale = ep.scale;
     g.K = (int)K; g.M = (int)M; g.rows = (int)rows;
-    constexpr int CPW = 8;
+    constexpr int CPW = 4;
     const unsigned grid = (unsigned)((M + 4 * CPW - 1) / (4 * CPW));
 #define QG_LAUNCH(QT_, R_) k_qgemv<QT_, R_, CPW><<<grid, 256, 0, s>>>(g)
     if (wtype == 8) {

@@ -143,6 +143,70 @@ def test_linear_weight_gemm(sd, oracle, gpu, rng, wtype, tol, tokens, K, M):
         assert rel_l2(out.reshape(tokens, M), exact) < (2e-3 if _on_gpu() or wtype != BF16 else 1e-2)
 
 
+@pytest.mark.parametrize("N,C,inner,H,W", [(2, 320, 320, 16, 16), (1, 64, 96, 5, 7), (3, 128, 64, 8, 8)])
+def test_spatial_transformer_projections_as_token_gemms(sd, oracle, gpu, rng, N, C, inner, H, W):
+    """SpatialTransformer shell with conv projections (SD1.x, block.hpp:548-577): proj_in conv1x1 -> PERMUTE(1,2,0,3) -> CONT -> tokens,
+    [a Linear on the tokens], tokens -> CONT(PERMUTE(1,0,2,3)) -> RESHAPE -> proj_out conv1x1 -> + x.  Both 1x1 convs run as token GEMMs and
+    neither transposing copy is executed."""
+    x = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    w_in = (rng.standard_normal((inner, C, 1, 1)) / np.sqrt(C)).astype(np.float32)
+    b_in = rng.standard_normal(inner).astype(np.float32)
+    w_mid = (rng.standard_normal((inner, inner)) / np.sqrt(inner)).astype(np.float32)
+    w_out = (rng.standard_normal((C, inner, 1, 1)) / np.sqrt(inner)).astype(np.float32)
+    b_out = rng.standard_normal(C).astype(np.float32)
+
+    def build(g, L):
+        xin = g.input(x)
+        h = L.ggml_conv_2d(g.ctx, g.weight(w_in, F16), xin, 1, 1, 0, 0, 1, 1)
+        h = L.ggml_add_inplace(g.ctx, h, L.ggml_reshape_4d(g.ctx, g.weight(b_in, F32), 1, 1, inner, 1))
+        t = L.ggml_cont(g.ctx, L.ggml_permute(g.ctx, h, 1, 2, 0, 3))          # [inner, W, H, N]
+        t = L.ggml_reshape_3d(g.ctx, t, inner, W * H, N)
+        t = L.ggml_mul_mat(g.ctx, g.weight(w_mid, F16), t)                      # stands in for the transformer blocks
+        y = L.ggml_cont(g.ctx, L.ggml_permute(g.ctx, t, 1, 0, 2, 3))            # [W*H, inner, N]
+        y = L.ggml_reshape_4d(g.ctx, y, W, H, inner, N)
+        y = L.ggml_conv_2d(g.ctx, g.weight(w_out, F16), y, 1, 1, 0, 0, 1, 1)
+        y = L.ggml_add_inplace(g.ctx, y, L.ggml_reshape_4d(g.ctx, g.weight(b_out, F32), 1, 1, C, 1))
+        return L.ggml_add(g.ctx, y, xin)
+
+    before = sd.backend_stats() if _on_gpu() else None
+    ref, out = run_both(sd, oracle, gpu, build)
+    assert out.shape == (N, C, H, W) and np.isfinite(out).all()
+    assert rel_l2(out, ref) < 3e-4
+    if before is not None and not os.environ.get("SDCPP_BACKEND_OPTS"):
+        assert sd.backend_stats()["fused_proj_tokens"] - before["fused_proj_tokens"] == 2
+
+
+@pytest.mark.parametrize("N,C,OC,HW,split", [(2, 64, 320, 16, False), (3, 320, 96, 12, False), (2, 1280, 1280, 8, True), (2, 128, 128, 1, True), (1, 128, 64, 2, True),
+                                              (5, 32, 32, 3, False)])
+def test_conv_time_embedding_add_fused(sd, oracle, gpu, rng, N, C, OC, HW, split):
+    """ResBlock (block.hpp:126-179): conv3x3 (+bias) -> ADD(h, Linear(SiLU(emb)) reshaped [1,1,OC,N]).  The embedding branch sits BETWEEN the
+    conv chain and the ADD in graph order (DFS), so the fused conv kernel is emitted at the ADD's position and adds the per-(image, channel)
+    value in its epilogue (also through the split-K reduce pass)."""
+    x = rng.standard_normal((N, C, HW, HW)).astype(np.float32)
+    w = (rng.standard_normal((OC, C, 3, 3)) / np.sqrt(C * 9)).astype(np.float32)
+    b = rng.standard_normal(OC).astype(np.float32)
+    emb = rng.standard_normal((N, 128)).astype(np.float32)
+    we = (rng.standard_normal((OC, 128)) / np.sqrt(128)).astype(np.float32)
+    be = rng.standard_normal(OC).astype(np.float32)
+
+    def build(g, L):
+        h = L.ggml_conv_2d(g.ctx, g.weight(w, F16), g.input(x), 1, 1, 1, 1, 1, 1)
+        h = L.ggml_add_inplace(g.ctx, h, L.ggml_reshape_4d(g.ctx, g.weight(b, F32), 1, 1, OC, 1))
+        e = L.ggml_mul_mat(g.ctx, g.weight(we, F16), L.ggml_silu(g.ctx, g.input(emb)))
+        e = L.ggml_add_inplace(g.ctx, e, g.weight(be, F32))
+        return L.ggml_add(g.ctx, h, L.ggml_reshape_4d(g.ctx, e, 1, 1, OC, N))
+
+    before = sd.backend_stats() if _on_gpu() else None
+    ref, out = run_both(sd, oracle, gpu, build)
+    assert out.shape == (N, OC, HW, HW) and np.isfinite(out).all()
+    assert rel_l2(out, ref) < 2e-4
+    if before is not None and not os.environ.get("SDCPP_BACKEND_OPTS"):
+        st = sd.backend_stats()
+        assert st["fused_chan_add"] - before["fused_chan_add"] == 1
+        if split:
+            assert st["split_k_gemms"] - before["split_k_gemms"] >= 1
+
+
 @pytest.mark.parametrize("wtype", [Q8_0, Q4_0])
 @pytest.mark.parametrize("tokens,K,M,res", [(1, 3072, 18432 // 8, False), (2, 256, 100, True), (4, 1024, 33, False), (1, 4096, 640, True), (3, 768, 96, False)])
 def test_quantised_gemv_raw_blocks(sd, oracle, gpu, rng, wtype, tokens, K, M, res):
@@ -323,7 +387,9 @@ def test_flash_attn_ext(sd, oracle, gpu, rng, d, Lq, Lk, HN):
         assert g.supports(node)
     ref, out = run_both(sd, oracle, gpu, build)          # [1, Lq, HN, d]
     assert out.shape == ref.shape == (1, Lq, HN, d)
-    assert rel_l2(out, ref) < 1e-2
+    # the oracle's F16 V accumulation loses ~sqrt(Lk) * 2^-11: over 4352 keys it sits ~1e-2 from the exact result by itself (the bar against
+    # the exact softmax below is the one that pins the kernel; r02g: 1.01e-2 here on a passing kernel)
+    assert rel_l2(out, ref) < (1e-2 if Lk <= 1024 else 3e-2)
     exact = _attn_exact(q, k.astype(np.float16).astype(np.float32), v.astype(np.float16).astype(np.float32), scale)  # [HN, Lq, d]
     assert rel_l2(out[0].transpose(1, 0, 2), exact) < (2e-3 if _on_gpu() else 1e-2)   # self-check mode: the oracle's f16 V accumulation
 
