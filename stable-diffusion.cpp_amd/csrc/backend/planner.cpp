@@ -454,7 +454,7 @@ void plan_linear(Builder& B, int i, hipStream_t s, std::vector<int>& chain) {
             last = j;
             // -> ADD residual (either operand order), same shape, contiguous
             int r = gi.sole(last);
-            if (r >= 0 && gi.node(r)->op == GGML_OP_ADD && gi.only_noops_between(last, r, chain)) {
+            if (r >= 0 && !gi.done[r] && gi.node(r)->op == GGML_OP_ADD && gi.only_noops_between(last, r, chain)) {
                 const ggml_tensor* a = gi.node(r);
                 const ggml_tensor* other = a->src[0] == gi.node(last) ? a->src[1] : (a->src[1] == gi.node(last) ? a->src[0] : nullptr);
                 if (other && is_f32(other) && contig(other) && contig(a) && ggml_abi_same_shape(other, a) && ggml_abi_same_shape(gi.node(last), a) &&
@@ -691,8 +691,12 @@ bool plan_conv_chain(Builder& B, int i, hipStream_t s, std::vector<int>& chain) 
         if (r >= 0 && gi.node(r)->op == GGML_OP_ADD && gi.node(r)->src[0] == gi.node(last)) {
             const ggml_tensor* a = gi.node(r);
             const ggml_tensor* e = a->src[1];
-            if (is_f32(e) && contig(e) && contig(a) && e->ne[0] == 1 && e->ne[1] == 1 && e->ne[2] == OC && e->ne[3] == N && N > 0 && ggml_abi_same_shape(out, a) &&
-                gi.idx(strip_reshape(e)) < r && !(gi.node(last)->flags & GGML_TENSOR_FLAG_OUTPUT)) {
+            // only the embedding Linear's output (MUL_MAT [+ bias ADD]) qualifies: on 1x1 feature maps EVERY [1,1,OC,N] tensor has this shape —
+            // e.g. the ResBlock's skip operand, which the skip conv's own chain claims as its residual (two chains claiming one ADD)
+            const ggml_tensor* eroot = strip_reshape(e);
+            const bool from_linear   = eroot->op == GGML_OP_MUL_MAT || (eroot->op == GGML_OP_ADD && eroot->src[0] && strip_reshape(eroot->src[0])->op == GGML_OP_MUL_MAT);
+            if (!gi.done[r] && from_linear && is_f32(e) && contig(e) && contig(a) && e->ne[0] == 1 && e->ne[1] == 1 && e->ne[2] == OC && e->ne[3] == N && N > 0 &&
+                ggml_abi_same_shape(out, a) && gi.idx(eroot) < r && !(gi.node(last)->flags & GGML_TENSOR_FLAG_OUTPUT)) {
                 bool ok = true;  // nothing between the chain and the ADD may touch the ADD's output range
                 for (int k = last + 1; k < r && ok; ++k) {
                     const ggml_tensor* t = gi.node(k);
@@ -713,7 +717,7 @@ bool plan_conv_chain(Builder& B, int i, hipStream_t s, std::vector<int>& chain) 
     // -> ADD residual (same shape, either operand order), only when it directly follows
     if (!ep.chan_add && token_major_out < 0) {
         int r = gi.sole(last);
-        if (r >= 0 && gi.node(r)->op == GGML_OP_ADD && gi.only_noops_between(last, r, chain)) {
+        if (r >= 0 && !gi.done[r] && gi.node(r)->op == GGML_OP_ADD && gi.only_noops_between(last, r, chain)) {
             const ggml_tensor* a     = gi.node(r);
             const ggml_tensor* other = a->src[0] == gi.node(last) ? a->src[1] : (a->src[1] == gi.node(last) ? a->src[0] : nullptr);
             if (other && is_f32(other) && contig(other) && contig(a) && ggml_abi_same_shape(other, a) && ggml_abi_same_shape(out, a) && gi.idx(other) < i &&

@@ -1,15 +1,19 @@
-// qgemm.hip — Linear layers whose weights are q8_0 / q4_0 GGUF blocks and whose activation has only a few rows (adaLN / modulation
-// vectors of the DiTs: 1 row per image).  Such a contraction is a pure WEIGHT STREAM: the
-// kernel reads the RAW quantised blocks from HBM exactly once (34 B / 18 B per 32 weights, coalesced 16-byte loads of whole row
-// segments), dequantises in registers and never builds the f16 weight image the MFMA GEMMs use (that image is 3.5x the bytes of q4_0).
+// qgemm.hip — Linear layers whose weights are q8_0 / q4_0 GGUF blocks and whose activation has only one or two rows (adaLN / modulation
+// vectors of the DiTs and the ResBlock embedding projections: 1 row per image).  Such a
+// contraction is a pure WEIGHT STREAM: the kernel reads the RAW quantised blocks from HBM exactly once (34 B / 18 B per 32 weights,
+// coalesced 16-byte loads of whole row segments), dequantises in registers and never builds the f16 weight image the MFMA GEMMs use
+// (that image is 3.5x the bytes of q4_0).
 //
-// Arithmetic = ggml-cpu's for a quantised src0 (upstream vec_dot_q8_0_q8_0 / vec_dot_q4_0_q8_0): the activation
-// row is quantised to q8_0 blocks first (d = amax / 127 stored as f16, q = round(x / d)), every weight block contributes
-// d_w * d_x * sum_i(q_w[i] * q_x[i]) with the integer sum on v_dot4_i32_i8; q4_0 weights are (nibble - 8): the "- 8" is applied as
-// - 8 * d_w * d_x * sum_i q_x[i], precomputed per activation block.
+// Arithmetic = the MFMA path's rounding points, so that a Linear gives the same values (to f32 summation order and the f16 rounding of
+// the dequantised weight, ~1e-4) whichever kernel its row count selects — a batch of 1 and a batch of 8 must agree: activations are
+// rounded to f16, weights are d * q exactly, products and sums are f32.  (ggml-cpu quantises the activations to q8_0 instead, SURVEY.md
+// Appendix E.1; the first version of this kernel did the same on v_dot4_i32_i8 and moved the full-width SDXL forward from 1.5e-3 to 7e-3
+// of the exact-weight oracle — r02, profiles/r02e_fullwidth_parity.txt vs the failing run — so it was replaced.)
+//   q8_0:  sum_i q_i x_i           = sum_i u_i x_i - 128 * sum_i x_i     with u = q ^ 0x80 (unsigned bytes -> v_cvt_f32_ubyteN)
+//   q4_0:  sum_i (n_i - 8) x_i     = sum_i n_i x_i -   8 * sum_i x_i     with the nibbles n spread to bytes by two AND / shift pairs
 //
 // Mapping: a wave owns CPW consecutive weight rows (= output features) and walks K in segments of 64 blocks — lane l of the wave owns
-// block l of the segment for every row, so the activation blocks of the segment sit in registers (R rows x 10 registers) and are reused
+// block l of the segment for every row, so the activation values of the segment sit in registers (R rows x 32 floats) and are reused
 // by all CPW weight rows.  A weight row segment (64 x 34 B = 2176 B, or 64 x 18 B = 1152 B) is fetched with 16-byte loads of the whole
 // contiguous range into a per-wave LDS strip and re-read block-wise with aligned 4-byte LDS loads + v_alignbit (the blocks are only
 // 2-byte aligned).  Cross-lane sums at the end, bias / residual in the store.
@@ -19,56 +23,16 @@
 
 namespace mi355x {
 
-// ---- activation rows -> private q8 blocks: q [rows][K] int8, d [rows][K/32] f32 (the f16-rounded scale), s8 [rows][K/32] = 8 * d * sum(q)
-__global__ void k_quant_q8_rows(int8_t* __restrict__ q, float* __restrict__ d, float* __restrict__ s8, const float* __restrict__ x, int64_t xs, int rows, int K,
-                                float pre_scale) {
-    const int nblk = K / 32;
-    const int i    = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows * nblk) return;
-    const int r = i / nblk, b = i - r * nblk;
-    const float4* xp = (const float4*)(x + (int64_t)r * xs + b * 32);
-    float v[32];
-    float amax = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float4 t = xp[j];
-        v[4 * j] = t.x * pre_scale; v[4 * j + 1] = t.y * pre_scale; v[4 * j + 2] = t.z * pre_scale; v[4 * j + 3] = t.w * pre_scale;
-        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[4 * j]), fabsf(v[4 * j + 1])), fmaxf(fabsf(v[4 * j + 2]), fabsf(v[4 * j + 3]))));
-    }
-    const float dd = amax / 127.f;
-    const float id = dd != 0.f ? 1.f / dd : 0.f;
-    int sum = 0;
-    uint32_t packed[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        uint32_t w = 0;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int qi = (int)roundf(v[4 * j + e] * id);
-            sum += qi;
-            w |= ((uint32_t)(qi & 0xFF)) << (8 * e);
-        }
-        packed[j] = w;
-    }
-    uint4* qp = (uint4*)(q + (int64_t)r * K + b * 32);
-    qp[0] = make_uint4(packed[0], packed[1], packed[2], packed[3]);
-    qp[1] = make_uint4(packed[4], packed[5], packed[6], packed[7]);
-    const float df = (float)(_Float16)dd;  // block_q8_0.d is an f16
-    d[i]  = df;
-    s8[i] = 8.f * df * (float)sum;
-}
-
 struct QGArgs {
     const char* W;       // raw quantised rows
     int64_t row_bytes;
-    const int8_t* xq;    // [R][K]
-    const float* xd;     // [R][nblk]
-    const float* xs8;    // [R][nblk]
+    const float* x;      // activation rows, f32 (rounded to f16 in the kernel)
+    int64_t xs;          // row stride in floats
     float* dst;
     int64_t ldd;
     const float* bias;
     const float* residual;  // same layout as dst
-    float scale;
+    float scale, pre_scale;
     int K, M, rows;
 };
 
@@ -104,23 +68,26 @@ __global__ __launch_bounds__(256) void k_qgemv(QGArgs g) {
         const bool have    = blk < nblk;
         const int seg_blks = min(64, nblk - seg * 64);
         const int seg_ng   = (seg_blks * BLK + 15) / 16;  // granules that hold real bytes of this row
-        // activation blocks of this segment: registers, shared by all CPW weight rows
-        uint32_t xq[R][8];
-        float xd[R], xs8[R];
+        // activation values of this lane's block: registers, shared by all CPW weight rows; rounded to f16 like every MFMA operand
+        float xf[R][32], xsum[R];
 #pragma unroll
         for (int t = 0; t < R; ++t) {
             const int tt = t < g.rows ? t : 0;
-            if (have) {
-                const uint4* p = (const uint4*)(g.xq + (int64_t)tt * g.K + (int64_t)blk * 32);
-                const uint4 a = p[0], b = p[1];
-                xq[t][0] = a.x; xq[t][1] = a.y; xq[t][2] = a.z; xq[t][3] = a.w;
-                xq[t][4] = b.x; xq[t][5] = b.y; xq[t][6] = b.z; xq[t][7] = b.w;
-                xd[t]  = t < g.rows ? g.xd[(int64_t)tt * nblk + blk] : 0.f;
-                xs8[t] = t < g.rows ? g.xs8[(int64_t)tt * nblk + blk] : 0.f;
+            xsum[t]      = 0.f;
+            if (have && t < g.rows) {
+                const float4* p = (const float4*)(g.x + (int64_t)tt * g.xs + (int64_t)blk * 32);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float4 v = p[j];
+                    xf[t][4 * j]     = (float)(_Float16)(v.x * g.pre_scale);
+                    xf[t][4 * j + 1] = (float)(_Float16)(v.y * g.pre_scale);
+                    xf[t][4 * j + 2] = (float)(_Float16)(v.z * g.pre_scale);
+                    xf[t][4 * j + 3] = (float)(_Float16)(v.w * g.pre_scale);
+                    xsum[t] += (xf[t][4 * j] + xf[t][4 * j + 1]) + (xf[t][4 * j + 2] + xf[t][4 * j + 3]);
+                }
             } else {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) xq[t][j] = 0;
-                xd[t] = xs8[t] = 0.f;
+                for (int j = 0; j < 32; ++j) xf[t][j] = 0.f;
             }
         }
         const int64_t seg_byte = (int64_t)seg * SEGB;
@@ -168,18 +135,31 @@ __global__ __launch_bounds__(256) void k_qgemv(QGArgs g) {
             if (have) {
 #pragma unroll
                 for (int t = 0; t < R; ++t) {
-                    int isum = 0;
+                    float sa = 0.f, sb = 0.f;  // two chains: the 32 FMAs of a block are dependent otherwise
                     if (QT == 8) {
 #pragma unroll
-                        for (int m = 0; m < 8; ++m) isum = __builtin_amdgcn_sdot4((int)qd[m], (int)xq[t][m], isum, false);
-                        acc[c][t] += dw * xd[t] * (float)isum;
+                        for (int m = 0; m < 8; ++m) {
+                            const uint32_t u = qd[m] ^ 0x80808080u;
+                            sa = fmaf((float)(u & 0xFFu), xf[t][4 * m], sa);
+                            sb = fmaf((float)((u >> 8) & 0xFFu), xf[t][4 * m + 1], sb);
+                            sa = fmaf((float)((u >> 16) & 0xFFu), xf[t][4 * m + 2], sa);
+                            sb = fmaf((float)(u >> 24), xf[t][4 * m + 3], sb);
+                        }
+                        acc[c][t] += dw * ((sa + sb) - 128.f * xsum[t]);
                     } else {
 #pragma unroll
                         for (int m = 0; m < 4; ++m) {
-                            isum = __builtin_amdgcn_sdot4((int)(qd[m] & 0x0F0F0F0Fu), (int)xq[t][m], isum, false);
-                            isum = __builtin_amdgcn_sdot4((int)((qd[m] >> 4) & 0x0F0F0F0Fu), (int)xq[t][m + 4], isum, false);
+                            const uint32_t lo = qd[m] & 0x0F0F0F0Fu, hi = (qd[m] >> 4) & 0x0F0F0F0Fu;  // elements 4m.. and 16 + 4m..
+                            sa = fmaf((float)(lo & 0xFFu), xf[t][4 * m], sa);
+                            sb = fmaf((float)((lo >> 8) & 0xFFu), xf[t][4 * m + 1], sb);
+                            sa = fmaf((float)((lo >> 16) & 0xFFu), xf[t][4 * m + 2], sa);
+                            sb = fmaf((float)(lo >> 24), xf[t][4 * m + 3], sb);
+                            sa = fmaf((float)(hi & 0xFFu), xf[t][16 + 4 * m], sa);
+                            sb = fmaf((float)((hi >> 8) & 0xFFu), xf[t][16 + 4 * m + 1], sb);
+                            sa = fmaf((float)((hi >> 16) & 0xFFu), xf[t][16 + 4 * m + 2], sa);
+                            sb = fmaf((float)(hi >> 24), xf[t][16 + 4 * m + 3], sb);
                         }
-                        acc[c][t] += dw * (xd[t] * (float)isum - xs8[t]);
+                        acc[c][t] += dw * ((sa + sb) - 8.f * xsum[t]);
                     }
                 }
             }
@@ -202,41 +182,37 @@ __global__ __launch_bounds__(256) void k_qgemv(QGArgs g) {
     }
 }
 
-size_t qgemv_workspace_bytes(int64_t rows, int64_t K) { return (size_t)rows * K + 2 * (size_t)rows * (K / 32) * sizeof(float) + 64; }
+size_t qgemv_workspace_bytes(int64_t, int64_t) { return 0; }  // (the first version quantised the activations into a workspace)
 
 bool qgemv_supported(int wtype, int64_t rows, int64_t K) {
-    // whole row segments are fetched with 16-byte loads: every row must start 16-byte aligned (34 * K/32 and 18 * K/32 are multiples of 16 iff K % 256 == 0)
-    return (wtype == 8 || wtype == 2) && rows >= 1 && rows <= 4 && K % 256 == 0 && K >= 256;
+    // whole row segments are fetched with 16-byte loads: every row must start 16-byte aligned (34 * K/32 and 18 * K/32 are multiples of 16 iff
+    // K % 256 == 0).  Rows: the activation values of a block live in registers (32 per row) — one or two rows.  Above that the f16 weight
+    // image + MFMA GEMM take over: from ~32 rows on the contraction stops being a pure weight stream anyway.
+    return (wtype == 8 || wtype == 2) && rows >= 1 && rows <= 2 && K % 256 == 0 && K >= 256;
 }
 
-// x: f32 rows (row stride xs floats), pre-multiplied by pre_scale before quantisation (ggml_ext_linear's scale); ws: qgemv_workspace_bytes(rows, K)
-void launch_qgemv(hipStream_t s, float* dst, int64_t ldd, const float* x, int64_t xs, int64_t rows, const void* wraw, int wtype, int64_t K, int64_t M, void* ws,
+// x: f32 rows (row stride xs floats, 16-byte aligned), multiplied by pre_scale before the f16 rounding (ggml_ext_linear's scale)
+void launch_qgemv(hipStream_t s, float* dst, int64_t ldd, const float* x, int64_t xs, int64_t rows, const void* wraw, int wtype, int64_t K, int64_t M, void*,
                   const Epilogue& ep, float pre_scale) {
-    const int64_t nblk = K / 32;
-    int8_t* xq = (int8_t*)ws;
-    float* xd  = (float*)((char*)ws + (((size_t)rows * K + 15) & ~(size_t)15));
-    float* xs8 = xd + rows * nblk;
+    const int64_t nblk  = K / 32;
     const size_t wbytes = (size_t)M * (size_t)nblk * (wtype == 8 ? 34 : 18);
     KScope ks_(s, KF_QGEMM, 2.0 * rows * K * M, (double)wbytes + (double)rows * K * 4.0 + (double)rows * M * 4.0);
-    k_quant_q8_rows<<<(unsigned)((rows * nblk + 127) / 128), 128, 0, s>>>(xq, xd, xs8, x, xs, (int)rows, (int)K, pre_scale);
     QGArgs g;
     g.W         = (const char*)wraw;
     g.row_bytes = nblk * (wtype == 8 ? 34 : 18);
-    g.xq = xq; g.xd = xd; g.xs8 = xs8;
+    g.x = x; g.xs = xs;
     g.dst = dst; g.ldd = ldd;
-    g.bias = ep.bias; g.residual = ep.residual; g.scale = ep.scale;
+    g.bias = ep.bias; g.residual = ep.residual; g.scale = ep.scale; g.pre_scale = pre_scale;
     g.K = (int)K; g.M = (int)M; g.rows = (int)rows;
     constexpr int CPW = 4;
     const unsigned grid = (unsigned)((M + 4 * CPW - 1) / (4 * CPW));
 #define QG_LAUNCH(QT_, R_) k_qgemv<QT_, R_, CPW><<<grid, 256, 0, s>>>(g)
     if (wtype == 8) {
         if (rows == 1) QG_LAUNCH(8, 1);
-        else if (rows == 2) QG_LAUNCH(8, 2);
-        else QG_LAUNCH(8, 4);
+        else QG_LAUNCH(8, 2);
     } else {
         if (rows == 1) QG_LAUNCH(4, 1);
-        else if (rows == 2) QG_LAUNCH(4, 2);
-        else QG_LAUNCH(4, 4);
+        else QG_LAUNCH(4, 2);
     }
 #undef QG_LAUNCH
 }

@@ -42,6 +42,19 @@ def test_unet_forward_parity(sd, oracle, gpu, model_name, flash):
     np.testing.assert_array_equal(out, out2)
 
 
+@pytest.mark.parametrize("n", [1, 3])
+def test_unet_forward_parity_down_to_1x1_feature_maps(sd, oracle, gpu, n):
+    """An 8x8 latent reaches 1x1 feature maps at the deepest UNet level, where every activation has the shape [1,1,C,N] of a bias / embedding
+    operand: pattern matches keyed on shapes must not confuse them (round 2: the ResBlock skip ADD was claimed by two fused chains)."""
+    rng = np.random.default_rng(70 + n)
+    x = rng.standard_normal((n, 4, 8, 8)).astype(np.float32)
+    t = np.full(n, 500.0, np.float32)
+    ctx = rng.standard_normal((1, 77, 64)).astype(np.float32)
+    ref = sd.Engine(model=sd.SD15_TINY, backend=oracle).unet_forward(x, t, ctx)
+    out = sd.Engine(model=sd.SD15_TINY, backend=gpu).unet_forward(x, t, ctx)
+    assert np.isfinite(out).all() and rel_l2(out, ref) < 5e-3
+
+
 def test_vae_decode_parity(sd, oracle, gpu):
     rng = np.random.default_rng(8)
     z = rng.standard_normal((1, 4, 16, 16)).astype(np.float32) * 0.18215 * 3

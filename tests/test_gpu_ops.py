@@ -207,13 +207,13 @@ def test_conv_time_embedding_add_fused(sd, oracle, gpu, rng, N, C, OC, HW, split
             assert st["split_k_gemms"] - before["split_k_gemms"] >= 1
 
 
-@pytest.mark.parametrize("wtype", [Q8_0, Q4_0])
-@pytest.mark.parametrize("tokens,K,M,res", [(1, 3072, 18432 // 8, False), (2, 256, 100, True), (4, 1024, 33, False), (1, 4096, 640, True), (3, 768, 96, False)])
-def test_quantised_gemv_raw_blocks(sd, oracle, gpu, rng, wtype, tokens, K, M, res):
-    """q8_0 / q4_0 Linear under <= 4 activation rows (the DiT adaLN / modulation vectors): k_qgemv streams the RAW GGUF blocks and
-    dequantises in registers — no f16 weight image.  Its arithmetic is ggml-cpu's (activations quantised to q8_0 blocks, integer dot
-    products scaled by d_w * d_x — SURVEY.md Appendix E.1), i.e. exactly what the oracle computes: rel-L2 <= 1e-5 vs the oracle
-    (f32 summation order only), and the usual quantisation bars vs the exact dequantised product."""
+@pytest.mark.parametrize("wtype,tol", [(Q8_0, 1e-2), (Q4_0, 3e-2)])
+@pytest.mark.parametrize("tokens,K,M,res", [(1, 3072, 18432 // 8, False), (2, 256, 100, True), (2, 1024, 33, False), (1, 4096, 640, True), (1, 768, 96, False), (3, 768, 96, False)])
+def test_quantised_gemv_raw_blocks(sd, oracle, gpu, rng, wtype, tol, tokens, K, M, res):
+    """q8_0 / q4_0 Linear under one or two activation rows (DiT adaLN / modulation vectors, ResBlock embedding projections): k_qgemv streams
+    the RAW GGUF blocks and dequantises in registers — no f16 weight image is built.  Rounding points = the MFMA path's (f16 activations,
+    exact d * q weights, f32 accumulation), so the bars are those of test_linear_weight_gemm: <= 2e-3 vs the exact dequantised product,
+    1e-2 / 3e-2 vs the oracle (which quantises the activations to q8_0 like ggml-cpu).  3 rows: stays on the MFMA GEMM."""
     x = rng.standard_normal((tokens, K)).astype(np.float32)
     w = (rng.standard_normal((M, K)) / np.sqrt(K)).astype(np.float32)
     b = rng.standard_normal(M).astype(np.float32)
@@ -226,13 +226,24 @@ def test_quantised_gemv_raw_blocks(sd, oracle, gpu, rng, wtype, tokens, K, M, re
     before = sd.backend_stats() if _on_gpu() else None
     ref, out = run_both(sd, oracle, gpu, build)
     assert np.isfinite(out).all()
-    assert rel_l2(out, ref) < 1e-5
+    assert rel_l2(out, ref) < tol
     exact = x.astype(np.float64) @ dequant(w, wtype).astype(np.float64).T + b + (r if res else 0)
-    assert rel_l2(out.reshape(tokens, M), exact) < 1e-2    # q8_0 quantisation of the activations (both sides of the comparison above share it)
+    if _on_gpu():
+        assert rel_l2(out.reshape(tokens, M), exact) < 2e-3
     if before is not None and not os.environ.get("SDCPP_BACKEND_OPTS"):
         st = sd.backend_stats()
-        assert st["qgemv_linears"] - before["qgemv_linears"] == 1
-        assert st["swizzled_weight_bytes"] == before["swizzled_weight_bytes"]   # no f16 image was built for this weight
+        taken = st["qgemv_linears"] - before["qgemv_linears"]
+        assert taken == (1 if tokens <= 2 else 0)
+        if taken:
+            assert st["swizzled_weight_bytes"] == before["swizzled_weight_bytes"]   # no f16 image was built for this weight
+            # same Linear through the MFMA GEMM (f16 weight image): the two kernels must agree far inside the quantisation bars
+            sd.backend_set_option("qgemv", 0)
+            try:
+                with Graph(gpu) as g2:
+                    alt = g2.run(build(g2, sd.lib()))
+            finally:
+                sd.backend_set_option("qgemv", 1)
+            assert rel_l2(out, alt) < 5e-4
 
 
 def test_linear_residual_fusion_and_batch_dims(sd, oracle, gpu, rng):
