@@ -194,12 +194,12 @@ def main():
                          "avg_launch_gflop": round(kt["total_flops"] / kt["launches"] / 1e9, 2),
                          "share_of_step_time": round(kt["total_ms"] / (dt * 1e3), 4),
                          "timing": "hipEventElapsedTime around each launch on the launch stream, inside the timed region"})
-        tf = ROOT / "profiles" / "r01_pmc_traffic.json"
+        tf = ROOT / "profiles" / "r02_pmc_traffic.json"
         if tf.exists() and args.model == "sd15" and B == 8 and fuse:
             try:
                 pm = json.loads(tf.read_text())
                 roofline["traffic"] = pm["hbm_bytes_per_launch"]
-                roofline["traffic_source"] = pm.get("source", "profiles/r01_pmc_traffic.json")
+                roofline["traffic_source"] = "profiles/r02_pmc_traffic.json (k_gemm16<256, 320, true, ...>, the 256x320 pipelined conv tile): " + pm.get("source", "")
             except (ValueError, KeyError):
                 pass
     roofline["whole_step_tflops"] = round(step_tflops, 2)  # all kernels + host graph build + uploads: 2*B*UNet-forward FLOPs / step wall time

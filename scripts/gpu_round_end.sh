@@ -1,15 +1,20 @@
+# end-of-round measurement sequence (round 2): GPU suite, smoke, default bench line, rocprofv3 kernel summary of the same command,
+# PMC traffic passes (FETCH_SIZE / WRITE_SIZE, separate runs) for the dominant conv kernel and for the bandwidth-bound producers
 run() { echo "=== $*"; timeout $T "$@" 2>&1 | tail -${TAILN:-12}; echo "rc=$?"; }
-D=gpurun_out/r01h
+D=${D:-gpurun_out/r02m}
 mkdir -p $D
-T=400 TAILN=4 run python -m pytest tests -m gpu -x -q
+T=1500 TAILN=4 run python -m pytest tests -m gpu -x -q
 T=200 TAILN=2 run python -c "import __graft_entry__ as g; g.smoke()"
-T=400 TAILN=1 run python bench.py --gpus 1 --steps 10 --warmup 2
-python bench.py --gpus 1 --steps 10 --warmup 2 --no-cpu-baseline > $D/bench_default_nocpu.jsonl 2>/dev/null
+timeout 600 python bench.py --gpus 1 --steps 20 --warmup 3 > $D/bench_default.jsonl 2> $D/bench_default.err; tail -c 1500 $D/bench_default.jsonl
 export TMPDIR=/tmp
-( cd /tmp && timeout 500 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$D -o stats -- python $GRAFT_REPO_ROOT/bench.py --gpus 1 --steps 10 --warmup 2 > $GRAFT_REPO_ROOT/$D/bench_under_rocprof.jsonl 2> $GRAFT_REPO_ROOT/$D/stderr.log )
-tail -1 $D/bench_under_rocprof.jsonl | cut -c1-1200
-python scripts/rocpd_stats.py $D/stats_results.db $D/kernel_stats.csv | head -12 | cut -c1-150
-( cd /tmp && timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --kernel-include-regex "k_gemm16" -d $GRAFT_REPO_ROOT/$D -o pmc_fetch -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $GRAFT_REPO_ROOT/$D/pmc_fetch.log )
-( cd /tmp && timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --kernel-include-regex "k_gemm16" -d $GRAFT_REPO_ROOT/$D -o pmc_write -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $GRAFT_REPO_ROOT/$D/pmc_write.log )
-python scripts/pmc_traffic.py $D/pmc_fetch_results.db $D/pmc_write_results.db "k_gemm16<256, 160, true" $D/pmc_traffic_t160.json | head -12
-python scripts/pmc_traffic.py $D/pmc_fetch_results.db $D/pmc_write_results.db "k_gemm16<256, 1" $D/pmc_traffic_256rows.json | grep hbm_bytes
+R=$GRAFT_REPO_ROOT
+( cd /tmp && timeout 500 rocprofv3 --kernel-trace --stats -d $R/$D -o stats -- python $R/bench.py --gpus 1 --steps 10 --warmup 2 --no-cpu-baseline --no-sdxl > $R/$D/bench_under_rocprof.jsonl 2> $R/$D/stderr.log )
+python scripts/rocpd_stats.py $D/stats_results.db $D/kernel_stats.csv | head -16 | cut -c1-170
+for c in FETCH_SIZE WRITE_SIZE; do
+  ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --pmc $c --kernel-include-regex "k_gemm16|k_nchw_to_nhwc|k_layer_norm_f16|k_gn_stats" -d $R/$D -o pmc_$c -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-sdxl --no-e2e --no-kernels > /dev/null 2> $R/$D/pmc_$c.log )
+done
+python scripts/pmc_traffic.py $D/pmc_FETCH_SIZE_results.db $D/pmc_WRITE_SIZE_results.db "k_gemm16<256, 320, true" $D/pmc_traffic_t320_conv.json | grep -E "hbm_bytes|launches"
+python scripts/pmc_traffic.py $D/pmc_FETCH_SIZE_results.db $D/pmc_WRITE_SIZE_results.db "k_nchw_to_nhwc_f16" $D/pmc_traffic_nchw_to_nhwc.json | grep -E "hbm_bytes|launches"
+python scripts/pmc_traffic.py $D/pmc_FETCH_SIZE_results.db $D/pmc_WRITE_SIZE_results.db "k_layer_norm_f16" $D/pmc_traffic_layer_norm_f16.json | grep -E "hbm_bytes|launches"
+python scripts/pmc_traffic.py $D/pmc_FETCH_SIZE_results.db $D/pmc_WRITE_SIZE_results.db "k_gn_stats" $D/pmc_traffic_gn_stats.json | grep -E "hbm_bytes|launches"
+rm -f $D/*_results.db

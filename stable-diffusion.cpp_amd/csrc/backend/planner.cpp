@@ -41,7 +41,7 @@ namespace {
 struct Stats {
     std::atomic<int64_t> graphs_computed{0}, plans_built{0}, nodes_seen{0}, kernels_planned{0}, kernels_launched{0}, fused_conv{0},
         fused_conv_bounced{0}, fused_linear{0}, fused_norm{0}, fused_geglu{0}, fused_attention{0}, generic_matmul{0}, swizzled_weight_bytes{0}, fused_linear_geglu{0}, split_k_gemms{0}, head_major_gemms{0}, fused_modulate{0}, fused_gate{0}, fused_gelu{0}, fused_rope{0}, fused_concat_heads{0},
-        graph_replays{0}, qgemv_linears{0}, fused_chan_add{0}, fused_proj_tokens{0};
+        graph_replays{0}, qgemv_linears{0}, fused_chan_add{0}, fused_proj_tokens{0}, gemm_attention{0};
 } g_stats;
 
 struct Options {
@@ -1157,7 +1157,48 @@ bool plan_manual_attention(Builder& B, int i, hipStream_t, std::vector<int>& cha
     const ggml_tensor* vt  = gi.node(j3)->src[0];  // [Lk, dv, HN]
     const ggml_tensor* out = gi.node(j3);          // [dv, Lq, HN]
     if (!is_f32(vt) || is_static_weight(vt) || vt->nb[0] != 4 || vt->ne[3] != 1 || vt->ne[2] != q->ne[2] || vt->ne[0] != k->ne[1]) return false;
-    if (!flash_attn_supported(q->ne[0], vt->ne[1]) || !contig(out)) return false;
+    if (!contig(out)) return false;
+    if (!flash_attn_supported(q->ne[0], vt->ne[1])) {
+        // head dims beyond the flash kernel (the KL-VAE mid-block attention: 1 head x d = 512 over 4096 / 16384 positions, auto_encoder_kl.hpp:104-159):
+        // composed from the MFMA GEMM instead of the exact-f32 generic matmul (38 TFLOP/s) — per head: Q rows -> f16 image, K rows -> weight
+        // image on the fly, S = scale * Q K^T (f32), row softmax written as the f16 operand image, V^T -> weight image, O = P V.
+        const int64_t d = q->ne[0], Lq = q->ne[1], Lk = k->ne[1], dv = vt->ne[1], HN = q->ne[2];
+        if (!g_opt.gemm16 || d % 8 != 0 || Lk % 4 != 0 || k->ne[0] != d || Lq < 64 || Lk < 64 || !aligned16(q->data) || !aligned16(k->data) || !aligned16(vt->data) ||
+            q->nb[1] % 16 != 0 || k->nb[1] % 16 != 0 || vt->nb[1] % 16 != 0 || out->ne[0] != dv || out->ne[1] != Lq)
+            return false;
+        chain = {i, j1, j2, j3};
+        if (!gi.only_noops_between(i, j3, chain)) return false;
+        const float scale  = ggml_abi_op_param_f32(gi.node(j1), 0);
+        const int64_t dp   = rup64(d), Lkp = rup64(Lk);
+        const size_t o_q   = B.alloc((size_t)Lq * dp * 2);
+        const size_t o_k   = B.alloc(wswz_bytes(Lk, d));
+        const size_t o_s   = B.alloc((size_t)Lq * Lk * 4);
+        const size_t o_p   = B.alloc((size_t)Lq * Lkp * 2);
+        const size_t o_v   = B.alloc(wswz_bytes(dv, Lk));
+        Planner* P         = B.P;
+        const char* qd     = (const char*)q->data;
+        const char* kd     = (const char*)k->data;
+        const char* vd     = (const char*)vt->data;
+        char* od           = (char*)out->data;
+        const int64_t qnb1 = (int64_t)q->nb[1], qnb2 = (int64_t)q->nb[2], knb1 = (int64_t)k->nb[1], knb2 = (int64_t)k->nb[2];
+        const int64_t vnb1 = (int64_t)vt->nb[1], vnb2 = (int64_t)vt->nb[2], onb1 = (int64_t)out->nb[1], onb2 = (int64_t)out->nb[2];
+        B.emit([=](hipStream_t st) {
+            for (int64_t h = 0; h < HN; ++h) {  // the heads reuse one set of scratch images (stream order)
+                launch_pack_rows_f16(st, P->arena + o_q, (const float*)(qd + h * qnb2), Lq, d, qnb1 / 4);
+                launch_wswz_linear(st, P->arena + o_k, kd + h * knb2, 0 /* f32 rows */, d, Lk, knb1);
+                Epilogue e1;
+                e1.scale = scale;
+                launch_gemm16_linear(st, (float*)(P->arena + o_s), nullptr, 0, P->arena + o_q, dp, P->arena + o_k, Lq, d, Lk, Lk, e1);
+                launch_soft_max_rows_f16(st, P->arena + o_p, (const float*)(P->arena + o_s), Lk, Lq);
+                launch_wswz_linear(st, P->arena + o_v, vd + h * vnb2, 0, Lk, dv, vnb1);
+                Epilogue e2;
+                launch_gemm16_linear(st, (float*)(od + h * onb2), nullptr, 0, P->arena + o_p, Lkp, P->arena + o_v, Lq, Lk, dv, onb1 / 4, e2);
+            }
+        });
+        g_stats.fused_attention++;
+        g_stats.gemm_attention++;
+        return true;
+    }
     chain = {i, j1, j2, j3};
     if (!gi.only_noops_between(i, j3, chain)) return false;
     const float scale = ggml_abi_op_param_f32(gi.node(j1), 0);
@@ -1725,6 +1766,7 @@ void planner_get_stats(ggml_backend_mi355x_stats* o) {
     o->qgemv_linears         = g_stats.qgemv_linears;
     o->fused_chan_add        = g_stats.fused_chan_add;
     o->fused_proj_tokens     = g_stats.fused_proj_tokens;
+    o->gemm_attention        = g_stats.gemm_attention;
     o->fused_attention       = g_stats.fused_attention;
     o->generic_matmul        = g_stats.generic_matmul;
     o->swizzled_weight_bytes = g_stats.swizzled_weight_bytes;

@@ -51,6 +51,8 @@ void launch_layer_norm_4d(hipStream_t s, float* dst, const float* x, const int64
                           const float* b, bool rms);
 void launch_soft_max(hipStream_t s, float* dst, const float* x, int64_t ncols, int64_t nrows, float scale, const View4* mask,
                      int64_t rows_per_mat);
+// softmax over contiguous f32 rows (ncols % 4 == 0) -> f16 operand image [nrows][ncols rounded up to 64]
+void launch_soft_max_rows_f16(hipStream_t s, void* dst16, const float* x, int64_t ncols, int64_t nrows);
 
 // ---- gemm_generic.hip: any-operand matmul (exact f32 MFMA), ggml MUL_MAT semantics ------------------
 // dst[m + n*ldd] = sum_k A[m][k]*B[n][k];  A type in {f32,f16,bf16,q8_0,q4_0} rows K-contiguous, B f32/f16

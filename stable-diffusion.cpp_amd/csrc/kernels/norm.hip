@@ -230,6 +230,51 @@ __global__ __launch_bounds__(256) void k_soft_max(float* __restrict__ dst, const
     for (int i = threadIdx.x; i < ncols; i += 256) yr[i] *= inv;
 }
 
+// row softmax of f32 scores written as the f16 operand image of the following P.V GEMM ([rows][Kp], zero padded): one block per row,
+// float4 reads (the row is re-read from L2 for the sum and the write), 8-byte stores
+__global__ __launch_bounds__(256) void k_soft_max_rows_f16(_Float16* __restrict__ dst, const float* __restrict__ x, int ncols, int Kp) {
+    __shared__ float scratch[8];
+    const int64_t row = blockIdx.x;
+    const float4* xr  = (const float4*)(x + row * ncols);
+    _Float16* yr      = dst + row * Kp;
+    const int n4 = ncols / 4;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float mx = -INFINITY;
+    for (int i = threadIdx.x; i < n4; i += 256) {
+        const float4 v = xr[i];
+        mx = fmaxf(fmaxf(mx, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+    }
+    mx = wave_max(mx);
+    if (lane == 0) scratch[wv] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(scratch[0], scratch[1]), fmaxf(scratch[2], scratch[3]));
+    float sum = 0.f;
+    for (int i = threadIdx.x; i < n4; i += 256) {
+        const float4 v = xr[i];
+        sum += (__expf(v.x - mx) + __expf(v.y - mx)) + (__expf(v.z - mx) + __expf(v.w - mx));
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) scratch[4 + wv] = sum;
+    __syncthreads();
+    const float inv = 1.0f / (scratch[4] + scratch[5] + scratch[6] + scratch[7]);
+    for (int i = threadIdx.x; i < Kp / 4; i += 256) {
+        half4_t h = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+        if (i < n4) {
+            const float4 v = xr[i];
+            h[0] = (_Float16)(__expf(v.x - mx) * inv);
+            h[1] = (_Float16)(__expf(v.y - mx) * inv);
+            h[2] = (_Float16)(__expf(v.z - mx) * inv);
+            h[3] = (_Float16)(__expf(v.w - mx) * inv);
+        }
+        *(half4_t*)(yr + i * 4) = h;
+    }
+}
+void launch_soft_max_rows_f16(hipStream_t s, void* dst16, const float* x, int64_t ncols, int64_t nrows) {
+    KScope ks_(s, KF_SOFTMAX, 0.0, (double)ncols * nrows * 6.0);
+    const int Kp = (int)((ncols + 63) / 64 * 64);
+    k_soft_max_rows_f16<<<(unsigned)nrows, 256, 0, s>>>((_Float16*)dst16, x, (int)ncols, Kp);
+}
+
 void launch_soft_max(hipStream_t s, float* dst, const float* x, int64_t ncols, int64_t nrows, float scale, const View4* mask, int64_t rows_per_mat) {
     KScope ks_(s, KF_SOFTMAX, 0.0, (double)ncols * nrows * 8.0);
     k_soft_max<<<(unsigned)nrows, 256, 0, s>>>(dst, x, (int)ncols, scale, mask ? (const char*)mask->data : nullptr, mask ? mask->type : 0,

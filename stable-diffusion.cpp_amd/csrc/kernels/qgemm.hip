@@ -45,12 +45,29 @@ __global__ __launch_bounds__(256) void k_qgemv(QGArgs g) {
     constexpr int NLD  = (NG + 63) / 64;         // loads per lane per segment (3 / 2)
     constexpr int NDW  = QT == 8 ? 9 : 5;        // aligned dwords covering one block at any 2-byte phase
     __shared__ __attribute__((aligned(16))) char strip[4][NLD * 64 * 16 + 16];
+    // activation rows as f16, staged ONCE per workgroup with coalesced loads (16-byte chunk c of block b sits at chunk slot c ^ (b & 3): a
+    // lane's four chunk reads then spread over the banks).  Every wave re-reading its blocks straight from global memory — 8 loads of one
+    // 128-byte line per lane — was 7x the address-path work of the weight stream itself.
+    extern __shared__ __attribute__((aligned(16))) char xlds[];  // [R][K] halfs
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     char* my       = strip[wave];
     const int nblk = g.K / 32;
     const int nseg = (nblk + 63) / 64;
     const int col0 = (blockIdx.x * 4 + wave) * CPW;
+    for (int t = 0; t < R; ++t) {
+        const int tt    = t < g.rows ? t : 0;
+        const float* xr = g.x + (int64_t)tt * g.xs;
+        for (int c8 = threadIdx.x; c8 < g.K / 8; c8 += 256) {  // 8 values = one 16-byte f16 chunk
+            const float4 a = *(const float4*)(xr + c8 * 8), b = *(const float4*)(xr + c8 * 8 + 4);
+            half8_t h;
+            h[0] = (_Float16)(a.x * g.pre_scale); h[1] = (_Float16)(a.y * g.pre_scale); h[2] = (_Float16)(a.z * g.pre_scale); h[3] = (_Float16)(a.w * g.pre_scale);
+            h[4] = (_Float16)(b.x * g.pre_scale); h[5] = (_Float16)(b.y * g.pre_scale); h[6] = (_Float16)(b.z * g.pre_scale); h[7] = (_Float16)(b.w * g.pre_scale);
+            const int blk = c8 >> 2, ch = c8 & 3;
+            *(half8_t*)(xlds + ((size_t)t * g.K + (size_t)blk * 32) * 2 + ((ch ^ (blk & 3)) << 4)) = h;
+        }
+    }
+    __syncthreads();
     if (col0 >= g.M) return;
 
     float acc[CPW][R];
@@ -75,15 +92,15 @@ __global__ __launch_bounds__(256) void k_qgemv(QGArgs g) {
             const int tt = t < g.rows ? t : 0;
             xsum[t]      = 0.f;
             if (have && t < g.rows) {
-                const float4* p = (const float4*)(g.x + (int64_t)tt * g.xs + (int64_t)blk * 32);
+                const char* xb = xlds + ((size_t)tt * g.K + (size_t)blk * 32) * 2;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float4 v = p[j];
-                    xf[t][4 * j]     = (float)(_Float16)(v.x * g.pre_scale);
-                    xf[t][4 * j + 1] = (float)(_Float16)(v.y * g.pre_scale);
-                    xf[t][4 * j + 2] = (float)(_Float16)(v.z * g.pre_scale);
-                    xf[t][4 * j + 3] = (float)(_Float16)(v.w * g.pre_scale);
-                    xsum[t] += (xf[t][4 * j] + xf[t][4 * j + 1]) + (xf[t][4 * j + 2] + xf[t][4 * j + 3]);
+                for (int ch = 0; ch < 4; ++ch) {
+                    const half8_t h = *(const half8_t*)(xb + ((ch ^ (blk & 3)) << 4));
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        xf[t][8 * ch + j] = (float)h[j];
+                        xsum[t] += xf[t][8 * ch + j];
+                    }
                 }
             } else {
 #pragma unroll
@@ -188,7 +205,7 @@ bool qgemv_supported(int wtype, int64_t rows, int64_t K) {
     // whole row segments are fetched with 16-byte loads: every row must start 16-byte aligned (34 * K/32 and 18 * K/32 are multiples of 16 iff
     // K % 256 == 0).  Rows: the activation values of a block live in registers (32 per row) — one or two rows.  Above that the f16 weight
     // image + MFMA GEMM take over: from ~32 rows on the contraction stops being a pure weight stream anyway.
-    return (wtype == 8 || wtype == 2) && rows >= 1 && rows <= 2 && K % 256 == 0 && K >= 256;
+    return (wtype == 8 || wtype == 2) && rows >= 1 && rows <= 2 && K % 256 == 0 && K >= 256 && K <= 12288;  // activations staged as f16 in LDS: 2 rows x 12288 halfs = 48 KB
 }
 
 // x: f32 rows (row stride xs floats, 16-byte aligned), multiplied by pre_scale before the f16 rounding (ggml_ext_linear's scale)
@@ -206,7 +223,7 @@ void launch_qgemv(hipStream_t s, float* dst, int64_t ldd, const float* x, int64_
     g.K = (int)K; g.M = (int)M; g.rows = (int)rows;
     constexpr int CPW = 4;
     const unsigned grid = (unsigned)((M + 4 * CPW - 1) / (4 * CPW));
-#define QG_LAUNCH(QT_, R_) k_qgemv<QT_, R_, CPW><<<grid, 256, 0, s>>>(g)
+#define QG_LAUNCH(QT_, R_) k_qgemv<QT_, R_, CPW><<<grid, 256, (size_t)(R_) * K * 2, s>>>(g)
     if (wtype == 8) {
         if (rows == 1) QG_LAUNCH(8, 1);
         else QG_LAUNCH(8, 2);

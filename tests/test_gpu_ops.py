@@ -405,7 +405,9 @@ def test_flash_attn_ext(sd, oracle, gpu, rng, d, Lq, Lk, HN):
     assert rel_l2(out[0].transpose(1, 0, 2), exact) < (2e-3 if _on_gpu() else 1e-2)   # self-check mode: the oracle's f16 V accumulation
 
 
-@pytest.mark.parametrize("d,Lq,Lk,HN", [(40, 200, 200, 4), (80, 100, 77, 2), (160, 64, 64, 2)])
+@pytest.mark.parametrize("d,Lq,Lk,HN", [(40, 200, 200, 4), (80, 100, 77, 2), (160, 64, 64, 2),
+                                        # head dims beyond the flash kernel (KL-VAE mid attention: 1 head x 512): composed from MFMA GEMMs + f16 row softmax
+                                        (512, 256, 256, 1), (192, 100, 80, 2), (512, 1024, 1024, 2)])
 def test_manual_attention_chain(sd, oracle, gpu, rng, d, Lq, Lk, HN):
     """flash flag off: MUL_MAT(k,q) -> SCALE -> SOFT_MAX -> MUL_MAT(vT,kq) is routed to the flash kernel (f16 MFMA operands);
     the oracle computes this chain in exact f32, so the tolerance is the f16-operand one: 2e-3 rel-L2."""
@@ -420,8 +422,11 @@ def test_manual_attention_chain(sd, oracle, gpu, rng, d, Lq, Lk, HN):
         kq = L.ggml_soft_max_inplace(g.ctx, kq)
         return L.ggml_mul_mat(g.ctx, g.input(vt), kq)
 
+    before = sd.backend_stats() if _on_gpu() else None
     ref, out = run_both(sd, oracle, gpu, build)
-    assert rel_l2(out, ref) < 2e-3
+    assert np.isfinite(out).all() and rel_l2(out, ref) < (2e-3 if d <= 160 else 4e-3)   # d > 160: Q, K, P and V all enter the MFMA as f16
+    if before is not None and d > 160 and not os.environ.get("SDCPP_BACKEND_OPTS"):
+        assert sd.backend_stats()["gemm_attention"] - before["gemm_attention"] == 1
 
 
 @pytest.mark.parametrize("tokens,K,M", [(16, 1280, 1280), (1000, 5120, 200), (130, 2560, 96)])
