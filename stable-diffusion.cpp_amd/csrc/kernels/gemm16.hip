@@ -792,6 +792,7 @@ void gemm16_set_abl(int v) { g_g16_abl = v; }
 #endif
 static int g_g16_t320 = 1;  // option "gemm16_t320": 0 disables the pipelined 256x320 tile in the per-shape choice (A/B measurements)
 void gemm16_set_t320(int v) { g_g16_t320 = v; }
+int gemm16_split_k(int64_t rows, int64_t M, int64_t K);
 static int g16_t320_split(int64_t rows, int64_t M, int64_t nt);
 static int g16_pick_tile(int64_t rows, int64_t M, bool geglu, bool conv, int split, int64_t nt) {
     if (g_g16_variant != 3) return G16_T128;
@@ -801,13 +802,13 @@ static int g16_pick_tile(int64_t rows, int64_t M, bool geglu, bool conv, int spl
     const bool can320 = M % 320 == 0 && !geglu;
     if (g_g16_force_tile >= 0) {
         if (g_g16_force_tile == G16_T320) return can320 ? G16_T320 : G16_T256;
-        if (g_g16_force_tile == G16_T256P) return (!conv && M % 256 == 0) ? G16_T256P : G16_T256;
+        if (g_g16_force_tile == G16_T256P) return M % 256 == 0 ? G16_T256P : G16_T256;
         if ((g_g16_force_tile == G16_T160 || g_g16_force_tile == G16_T160N) && !can160) return G16_T256;
         return g_g16_force_tile;
     }
     const int64_t rt256 = (rows + 255) / 256, c128 = ((rows + 127) / 128) * ((M + 127) / 128), c256 = rt256 * ((M + 127) / 128);
-    if (g_g16_force_tile < 0 && !split && !conv && g_g16_t320 && !can320 && M % 256 == 0) {
-        // T256P: the same pipelined loop on 256x256 tiles (Linear only: GEGLU FF1, N a multiple of 256)
+    if (g_g16_force_tile < 0 && !split && g_g16_t320 && !can320 && M % 256 == 0) {
+        // T256P: the same pipelined loop on 256x256 tiles (N a multiple of 256 but not of 320: DiT Linears, the KL-VAE's 512 / 256-channel convs)
         // one workgroup per CU: pipeline fill, drain and epilogue of a workgroup overlap with nothing, so short-K GEMMs (SD1.5's GEGLU FF1,
         // K = 320 .. 1280: 10-40 stages) stay on the 2-workgroups-per-CU tiles (r02d: 264 -> 318 us); long-K Linears (DiT) take it
         const int64_t c256p = rt256 * (M / 256), rounds = (c256p + 255) / 256;
@@ -857,7 +858,7 @@ static void g16_launch(hipStream_t s, G16Args& g, int64_t rows, double flops) {
                 k_gemm16<256, 320, CONV_, 32, 4, 4, 2, 1><<<dim3((unsigned)(rt256 * g.ncol_tiles), ny), 512, 0, s>>>(g);
             } else if (tile == G16_T256P) {
                 g.ncol_tiles = (int)((g.C + 255) / 256);
-                if constexpr (!CONV_) k_gemm16<256, 256, false, 32, 4, 4, 2, 1><<<dim3((unsigned)(rt256 * g.ncol_tiles), ny), 512, 0, s>>>(g);
+                k_gemm16<256, 256, CONV_, 32, 4, 4, 2, 1><<<dim3((unsigned)(rt256 * g.ncol_tiles), ny), 512, 0, s>>>(g);
             } else if (tile == G16_T160) {
                 g.ncol_tiles = (int)(g.C / 160);
                 k_gemm16<256, 160, CONV_, 32, 3, 4, 1><<<dim3((unsigned)(rt256 * g.ncol_tiles), ny), 256, 0, s>>>(g);
@@ -1381,6 +1382,37 @@ __global__ __launch_bounds__(NT) void k_gn_stats_reg(float* __restrict__ scale, 
         shift[(int64_t)n * C + c] = (b ? b[c] : 0.f) - mean * sc;
     }
 }
+// groups too large for registers (the KL-VAE's 128-channel 512x512 maps: 4 channels x 262144 pixels per group): ONE pass with sums
+// taken relative to the group's first element (shifted data: var = E[(x-K)^2] - E[x-K]^2 stays well conditioned because K is a sample of
+// the group; the two-pass kernel reads every byte twice and ran at 2.7 TB/s algorithmic)
+template <int NT>
+__global__ __launch_bounds__(NT) void k_gn_stats_1pass(float* __restrict__ scale, float* __restrict__ shift, const float* __restrict__ x, int64_t hw, int C, int groups,
+                                                       int cpg, float eps, const float* __restrict__ w, const float* __restrict__ b) {
+    __shared__ float scratch[2 * (NT / 64)];
+    const int gidx = blockIdx.x % groups, n = blockIdx.x / groups;
+    const int c0 = gidx * cpg, c1 = min(c0 + cpg, C);
+    if (c0 >= c1) return;
+    const int64_t cnt = (int64_t)(c1 - c0) * hw;
+    const float* xs   = x + ((int64_t)n * C + c0) * hw;
+    const float K     = xs[0];
+    float s1 = 0.f, s2 = 0.f;
+    for (int64_t i = threadIdx.x; i < cnt / 4; i += NT) {
+        const float4 v = ((const float4*)xs)[i];
+        const float a = v.x - K, bb = v.y - K, c = v.z - K, d = v.w - K;
+        s1 += (a + bb) + (c + d);
+        s2 += (a * a + bb * bb) + (c * c + d * d);
+    }
+    block_sum2<NT / 64>(s1, s2, scratch);
+    const float m1   = s1 / (float)cnt;
+    const float mean = K + m1;
+    const float var  = fmaxf(s2 / (float)cnt - m1 * m1, 0.f);
+    const float rstd = rsqrtf(var + eps);
+    for (int c = c0 + threadIdx.x; c < c1; c += NT) {
+        const float sc            = (w ? w[c] : 1.f) * rstd;
+        scale[(int64_t)n * C + c] = sc;
+        shift[(int64_t)n * C + c] = (b ? b[c] : 0.f) - mean * sc;
+    }
+}
 void launch_gn_stats(hipStream_t s, float* scale, float* shift, const float* x, int64_t hw, int64_t C, int64_t N, int groups, float eps, const float* w,
                      const float* b) {
     KScope ks_(s, KF_GN_STATS, 0.0, (double)hw * C * N * 4.0);  // algorithmic: ONE read of the activation
@@ -1395,6 +1427,8 @@ void launch_gn_stats(hipStream_t s, float* scale, float* shift, const float* x, 
         k_gn_stats_reg<1024, 4><<<grid, 1024, 0, s>>>(scale, shift, x, hw, (int)C, groups, cpg, eps, w, b);
     else if (v4 && cnt <= 4 * 1024 * 16)
         k_gn_stats_reg<1024, 16><<<grid, 1024, 0, s>>>(scale, shift, x, hw, (int)C, groups, cpg, eps, w, b);
+    else if (v4 && cnt >= 16384)
+        k_gn_stats_1pass<1024><<<grid, 1024, 0, s>>>(scale, shift, x, hw, (int)C, groups, cpg, eps, w, b);
     else if (cnt >= 16384)
         k_gn_stats<1024><<<grid, 1024, 0, s>>>(scale, shift, x, hw, (int)C, groups, cpg, eps, w, b);
     else

@@ -101,6 +101,28 @@ def test_group_norm_chain(sd, oracle, gpu, rng, shape):
     assert np.abs(out - ref).max() < 3e-5
 
 
+@pytest.mark.parametrize("shape,mean", [((1, 64, 256, 256), 5.0), ((2, 64, 64, 64), -2.0), ((1, 32, 300, 260), 0.3)])
+def test_group_norm_into_conv_large_groups(sd, oracle, gpu, rng, shape, mean):
+    """GN -> affine -> SiLU feeding a conv: statistics kernel + apply-and-pack kernel (no f32 normalised tensor).  Groups of 131072 / 8192 /
+    78000 values with a mean far from zero: the one-pass statistics (sums relative to the group's first element) must match the oracle's
+    double-precision two-pass mean / variance."""
+    N, C, H, W = shape
+    x = (rng.standard_normal(shape) * 1.5 + mean).astype(np.float32)
+    w = (1 + 0.1 * rng.standard_normal(C)).astype(np.float32)
+    b = rng.standard_normal(C).astype(np.float32)
+    wc = (rng.standard_normal((32, C, 3, 3)) / np.sqrt(C * 9)).astype(np.float32)
+
+    def build(g, L):
+        t = L.ggml_group_norm(g.ctx, g.input(x), 32, 1e-6)
+        t = L.ggml_mul_inplace(g.ctx, t, L.ggml_reshape_4d(g.ctx, g.weight(w, F32), 1, 1, C, 1))
+        t = L.ggml_add_inplace(g.ctx, t, L.ggml_reshape_4d(g.ctx, g.weight(b, F32), 1, 1, C, 1))
+        t = L.ggml_silu_inplace(g.ctx, t)
+        return L.ggml_conv_2d(g.ctx, g.weight(wc, F16), t, 1, 1, 1, 1, 1, 1)
+
+    ref, out = run_both(sd, oracle, gpu, build)
+    assert np.isfinite(out).all() and rel_l2(out, ref) < 3e-4
+
+
 @pytest.mark.parametrize("C,rows", [(320, 64), (1280, 17), (77, 5), (3072, 8)])
 def test_layer_norm_chain(sd, oracle, gpu, rng, C, rows):
     x = (rng.standard_normal((rows, C)) * 2 + 1).astype(np.float32)
