@@ -1,6 +1,7 @@
 #!/usr/bin/env python
-"""Per-kernel-family time (HIP events around every dispatch) of one hot-path call: `vae` = KL-VAE decode 64x64 -> 512x512 of 8 images,
-`sdxl` = SDXL UNet 1024x1024 cond+uncond pair (q8_0), `sd35` / `flux` = one DiT forward.  usage: family_times.py vae [sdxl ...]"""
+"""Per-kernel-family time (HIP events around every dispatch) of one hot-path call: `sd15` = the bench forward; `vae` = KL-VAE decode 64x64 -> 512x512 of 8 images,
+`sdxl` = SDXL UNet 1024x1024 cond+uncond pair (q8_0), `sd35` / `flux` = one DiT forward.  usage: family_times.py vae [sdxl ...]
+MI355X_KTIME_DUMP=<file> additionally appends one line per distinct launch shape (by flops / bytes)."""
 import sys
 from pathlib import Path
 
@@ -29,11 +30,20 @@ def report(label, fn, reps=2):
         print(f"   {f['kernel'][:62]:62s} {f['launches'] / reps:6.1f} launches {f['total_ms'] / reps:8.3f} ms {100 * f['total_ms'] / tot:5.1f} %  {rate}", flush=True)
 
 
-for what in sys.argv[1:] or ["vae"]:
+args = [a for a in sys.argv[1:] if "=" not in a]
+for kv in (a for a in sys.argv[1:] if "=" in a):  # backend options: key=int
+    sd.backend_set_option(kv.split("=")[0], int(kv.split("=")[1]))
+for what in args or ["vae"]:
     if what == "vae":
         e = sd.Engine(model=sd.SD15, flash_attn=True)
         z = rng.standard_normal((8, 4, 64, 64)).astype(np.float32) * 0.5
         report("KL-VAE decode 64x64 -> 512x512, 8 images", lambda: e.vae_decode(z))
+    elif what == "sd15":  # the bench workload's forward: 8 images x (cond, uncond) at 512x512
+        e = sd.Engine(model=sd.SD15, flash_attn=True)
+        x = rng.standard_normal((16, 4, 64, 64)).astype(np.float32)
+        t = np.full(16, 500.0, np.float32)
+        c = rng.standard_normal((16, 77, 768)).astype(np.float32)
+        report("SD1.5 UNet 512x512, 8 images x cond+uncond", lambda: e.unet_forward(x, t, c, None))
     elif what == "sdxl":
         e = sd.Engine(model=sd.SDXL, wtype=sd.Q8_0, flash_attn=True)
         x = rng.standard_normal((2, 4, 128, 128)).astype(np.float32)

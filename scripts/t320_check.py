@@ -55,7 +55,7 @@ def run_case(label, build, flops, tiles=MODES, fams=0b100000000000111):
     return all(rel_l2(outs[t][0], base) < 3e-5 and np.array_equal(outs[t][0], outs[t][1]) and np.isfinite(outs[t][0]).all() for t in tiles)
 
 
-def conv(N, IC, OC, HW, ks=3, stride=1, res=False, ups=False):
+def conv(N, IC, OC, HW, ks=3, stride=1, res=False, ups=False, tiles=MODES):
     x = rng.standard_normal((N, IC, HW, HW)).astype(np.float32)
     w = (rng.standard_normal((OC, IC, ks, ks)) / np.sqrt(IC * ks * ks)).astype(np.float32)
     b = rng.standard_normal(OC).astype(np.float32)
@@ -72,10 +72,10 @@ def conv(N, IC, OC, HW, ks=3, stride=1, res=False, ups=False):
             y = L.ggml_add(g.ctx, y, g.input(r))
         return y
 
-    return run_case(f"conv{ks}x{ks} N{N} {IC}->{OC} @{HW} s{stride}{' +res' if res else ''}{' ups' if ups else ''}", build, 2.0 * N * o * o * OC * IC * ks * ks)
+    return run_case(f"conv{ks}x{ks} N{N} {IC}->{OC} @{HW} s{stride}{' +res' if res else ''}{' ups' if ups else ''}", build, 2.0 * N * o * o * OC * IC * ks * ks, tiles=tiles)
 
 
-def linear(tokens, K, M, res=False):
+def linear(tokens, K, M, res=False, tiles=MODES):
     x = rng.standard_normal((tokens, K)).astype(np.float32)
     w = (rng.standard_normal((M, K)) / np.sqrt(K)).astype(np.float32)
     b = rng.standard_normal(M).astype(np.float32)
@@ -87,7 +87,7 @@ def linear(tokens, K, M, res=False):
             y = L.ggml_add(g.ctx, y, g.input(r))
         return y
 
-    return run_case(f"linear {tokens}x{K}->{M}{' +res' if res else ''}", build, 2.0 * tokens * K * M)
+    return run_case(f"linear {tokens}x{K}->{M}{' +res' if res else ''}", build, 2.0 * tokens * K * M, tiles=tiles)
 
 
 def geglu_ff(tokens, dim, inner):
@@ -114,44 +114,49 @@ def geglu_ff(tokens, dim, inner):
     return run_case(f"GEGLU FF {tokens} x {dim} -> 2x{inner} -> {dim}", build, 2.0 * tokens * dim * inner * 3)
 
 
-ok = True
-# small / ragged shapes first (short K: prologue + drain paths; ragged rows; K not a multiple of 128)
-ok &= linear(300, 64, 320)
-ok &= linear(256, 96, 320)
-ok &= linear(1000, 160, 640, res=True)
-ok &= linear(77, 768, 320)
-ok &= conv(1, 64, 320, 16)
-ok &= conv(2, 320, 320, 16, res=True)
-ok &= conv(1, 32, 320, 24, ks=1)
-ok &= conv(1, 320, 320, 8, ups=True)
-# the SD1.5 batch-16 shapes of the 64x64 level
-ok &= conv(16, 320, 320, 64)
-ok &= conv(16, 320, 320, 64, res=True)
-ok &= conv(16, 640, 320, 64)
-ok &= conv(16, 960, 320, 64)
-ok &= conv(16, 320, 320, 64, ks=1, res=True)
-ok &= conv(16, 4, 320, 64)
-ok &= conv(16, 320, 320, 32, ups=True)
-ok &= linear(65536, 320, 320)
-ok &= linear(65536, 320, 320, res=True)
-ok &= linear(65536, 1280, 320, res=True)
-ok &= conv(16, 640, 640, 32)
-ok &= conv(16, 1280, 1280, 16)
-ok &= linear(16384, 640, 640)
-ok &= linear(16384, 2560, 640, res=True)
-# under-filled outputs: 256x320 tiles with K slices (32x32, 16x16 and 8x8 UNet levels)
-ok &= conv(16, 1280, 640, 32)
-ok &= conv(16, 2560, 1280, 16)
-ok &= conv(16, 1280, 1280, 16, res=True)
-ok &= conv(16, 1280, 1280, 8)
-ok &= conv(16, 2560, 1280, 8)
-ok &= conv(2, 1280, 1280, 16)
-ok &= linear(4096, 5120, 1280, res=True)
-ok &= linear(1232, 768, 1280)
-# GEGLU feed-forwards (FF1 on the pipelined 256x256 tile)
-ok &= geglu_ff(300, 320, 1280)
-ok &= geglu_ff(65536, 320, 1280)
-ok &= geglu_ff(16384, 640, 2560)
-ok &= geglu_ff(4096, 1280, 5120)
-print("ALL OK" if ok else "MISMATCH", flush=True)
-sys.exit(0 if ok else 1)
+def main():
+    ok = True
+    # small / ragged shapes first (short K: prologue + drain paths; ragged rows; K not a multiple of 128)
+    ok &= linear(300, 64, 320)
+    ok &= linear(256, 96, 320)
+    ok &= linear(1000, 160, 640, res=True)
+    ok &= linear(77, 768, 320)
+    ok &= conv(1, 64, 320, 16)
+    ok &= conv(2, 320, 320, 16, res=True)
+    ok &= conv(1, 32, 320, 24, ks=1)
+    ok &= conv(1, 320, 320, 8, ups=True)
+    # the SD1.5 batch-16 shapes of the 64x64 level
+    ok &= conv(16, 320, 320, 64)
+    ok &= conv(16, 320, 320, 64, res=True)
+    ok &= conv(16, 640, 320, 64)
+    ok &= conv(16, 960, 320, 64)
+    ok &= conv(16, 320, 320, 64, ks=1, res=True)
+    ok &= conv(16, 4, 320, 64)
+    ok &= conv(16, 320, 320, 32, ups=True)
+    ok &= linear(65536, 320, 320)
+    ok &= linear(65536, 320, 320, res=True)
+    ok &= linear(65536, 1280, 320, res=True)
+    ok &= conv(16, 640, 640, 32)
+    ok &= conv(16, 1280, 1280, 16)
+    ok &= linear(16384, 640, 640)
+    ok &= linear(16384, 2560, 640, res=True)
+    # under-filled outputs: 256x320 tiles with K slices (32x32, 16x16 and 8x8 UNet levels)
+    ok &= conv(16, 1280, 640, 32)
+    ok &= conv(16, 2560, 1280, 16)
+    ok &= conv(16, 1280, 1280, 16, res=True)
+    ok &= conv(16, 1280, 1280, 8)
+    ok &= conv(16, 2560, 1280, 8)
+    ok &= conv(2, 1280, 1280, 16)
+    ok &= linear(4096, 5120, 1280, res=True)
+    ok &= linear(1232, 768, 1280)
+    # GEGLU feed-forwards (FF1 on the pipelined 256x256 tile)
+    ok &= geglu_ff(300, 320, 1280)
+    ok &= geglu_ff(65536, 320, 1280)
+    ok &= geglu_ff(16384, 640, 2560)
+    ok &= geglu_ff(4096, 1280, 5120)
+    print("ALL OK" if ok else "MISMATCH", flush=True)
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == "__main__":
+    main()

@@ -35,6 +35,8 @@ struct FAArgs {
     int H;
     int Lq, Lk, D, DV;
     int kv_f16;
+    int grp, units;  // XCD-grouped 1-D grid (see the kernel): heads per unit, (image, query block) units
+    int q_vec;   // Q rows are f32 d-contiguous, 16-byte aligned, D % 4 == 0 -> coalesced float4 staging through LDS
     int vec_ok;  // K and V rows are d-contiguous, 16-byte aligned, D % 8 == 0 -> 128-bit staging loads
     float scale_log2e;
 };
@@ -44,7 +46,7 @@ struct FAArgs {
 // ABL != 0: TIMING ABLATIONS with wrong results (option "flash_ablate", scripts/flash_ablation.py only): 1 = no softmax VALU work (the raw
 // scores go into the PV product), 2 = K/V tiles are staged once and reused (no global loads / LDS stores in the loop)
 template <int DKP, int NDV, bool FAST, int ABL = 0>
-__global__ __launch_bounds__(256, DKP <= 64 ? 3 : 2) void k_flash_attn(FAArgs g) {
+__global__ __launch_bounds__(256, DKP <= 64 ? 3 : (DKP <= 128 ? 2 : 1)) void k_flash_attn(FAArgs g) {
     constexpr int KS   = DKP / 16;                       // MFMA k-steps over the head dim
     constexpr int KROW = DKP + 8;                        // K tile row stride (halfs)
     constexpr int DCH  = DKP / 8;                        // 8-wide d chunks per key
@@ -60,20 +62,63 @@ __global__ __launch_bounds__(256, DKP <= 64 ? 3 : 2) void k_flash_attn(FAArgs g)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int hi   = lane >> 5;
-    const int hn   = blockIdx.y;
-    const int q0   = blockIdx.x * 128 + wave * 32;
+    // workgroup id -> (head-image hn, query block): consecutive ids go round-robin over the 8 XCDs, so with the plain (query block, hn) grid the
+    // heads of one token row land on different L2s at different times — the head-interleaved f16 output (80-byte pieces of a 640-byte
+    // token row at d = 40) is then written as 8 partial lines from up to 8 L2s.  grp > 0: the grp heads of one (image, query block) unit run
+    // back to back on ONE XCD (id = (unit / 8 * grp + head) * 8 + unit % 8), so an output line is completed inside one L2 and a K/V
+    // stream is shared by 3x more of the XCD's resident workgroups.
+    int hn, qb;
+    if (g.grp > 0) {
+        const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
+        const int h = j % g.grp, unit = (j / g.grp) * 8 + xcd;
+        if (unit >= g.units) return;
+        const int nrb = (g.Lq + 127) >> 7;
+        hn = (unit / nrb) * g.grp + h;
+        qb = unit % nrb;
+    } else {
+        hn = blockIdx.y;
+        qb = blockIdx.x;
+    }
+    const int q0   = qb * 128 + wave * 32;
     const int qi   = q0 + (lane & 31);
 
-    // ---- Q fragments (B operand of S^T): lane holds Q[qi][ks*16 + hi*8 .. +8] as f16
+    // ---- Q fragments (B operand of S^T): lane holds Q[qi][ks*16 + hi*8 .. +8] as f16.
+    // q_vec (rows d-contiguous f32, 16-byte aligned, D % 4 == 0 — the head-major projection output): the workgroup's 128 rows are fetched with
+    // coalesced float4 loads and handed to the lanes through LDS (the region aliases the K/V tiles, which are staged afterwards).  Per-lane
+    // row reads (32 rows x 2 halves per instruction, 4 useful bytes of every 64-byte segment) cost ~1500 TA cycles per wave: at Lk = 77
+    // (cross-attention, 2 tiles per workgroup) that was most of the kernel.
     half8_t qf[KS];
-    {
+    if (g.q_vec) {
+        constexpr int QROW = DKP + 4, C4 = DKP / 4;  // +4 halfs: 8-byte aligned rows, 2-way conflicts at worst on the one-time fragment reads
+        static_assert(128 * QROW <= NBUF * TILE_H, "Q staging must fit the K/V tile buffers");
+        const char* qblk = g.q + (int64_t)hn * g.q_nb2 + (int64_t)(qb * 128) * g.q_nb1;
+        for (int e = threadIdx.x; e < 128 * C4; e += 256) {
+            const int row = e / C4, c4 = e - row * C4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (qb * 128 + row < g.Lq && c4 * 4 < g.D) v = *(const float4*)(qblk + (int64_t)row * g.q_nb1 + c4 * 16);
+            half4_t h;
+            h[0] = (_Float16)(v.x * g.scale_log2e);  // scores come out of the MFMA in log2 units
+            h[1] = (_Float16)(v.y * g.scale_log2e);
+            h[2] = (_Float16)(v.z * g.scale_log2e);
+            h[3] = (_Float16)(v.w * g.scale_log2e);
+            *(half4_t*)&smem[row * QROW + c4 * 4] = h;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const _Float16* p = &smem[(wave * 32 + (lane & 31)) * QROW + ks * 16 + hi * 8];
+            const half4_t a = *(const half4_t*)p, b = *(const half4_t*)(p + 4);
+            qf[ks] = (half8_t){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+        }
+        __syncthreads();
+    } else {
         const float* qrow = (const float*)(g.q + (int64_t)min(qi, g.Lq - 1) * g.q_nb1 + (int64_t)hn * g.q_nb2);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int d = ks * 16 + hi * 8 + j;
-                qf[ks][j]   = (_Float16)((d < g.D && qi < g.Lq) ? qrow[d] * g.scale_log2e : 0.f);  // scores come out of the MFMA in log2 units
+                qf[ks][j]   = (_Float16)((d < g.D && qi < g.Lq) ? qrow[d] * g.scale_log2e : 0.f);
             }
         }
     }
@@ -336,6 +381,9 @@ static int g_flash_ablate = 0;
 void flash_attn_set_ablate(int v) { g_flash_ablate = v; }
 #endif
 
+static int g_flash_grid = 1;  // option "flash_grid": 0 = plain (query block, head) grid (A/B measurements)
+void flash_attn_set_grid(int v) { g_flash_grid = v; }
+
 void launch_flash_attn(hipStream_t s, const FlashOut& out, const View4& q, const View4& k, const View4& v, float scale) {
     KScope ks_(s, KF_FLASH, 4.0 * (double)q.ne[1] * (double)k.ne[1] * (double)q.ne[2] * (double)q.ne[0], 0.0);  // 4 * Lq * Lk * (H*N) * d
     FAArgs g;
@@ -365,7 +413,14 @@ void launch_flash_attn(hipStream_t s, const FlashOut& out, const View4& q, const
     g.scale_log2e = scale * 1.44269504088896340736f;
     auto al16 = [](const void* p, int64_t a, int64_t b) { return ((((uintptr_t)p) | (uintptr_t)a | (uintptr_t)b) & 15) == 0; };
     g.vec_ok = (g.D % 8 == 0) && al16(k.data, k.nb[1], k.nb[2]) && al16(v.data, v.nb[1], v.nb[2]);
+    g.q_vec = (g.D % 4 == 0) && q.nb[0] == 4 && al16(q.data, q.nb[1], q.nb[2]);
     dim3 grid((unsigned)((g.Lq + 127) / 128), (unsigned)q.ne[2]);
+    g.grp = g.units = 0;
+    if (g_flash_grid && out.H > 0 && q.ne[2] % out.H == 0) {
+        g.grp   = out.H;
+        g.units = (int)(q.ne[2] / out.H) * (int)grid.x;
+        grid    = dim3((unsigned)(((g.units + 7) / 8) * 8 * g.grp), 1u);
+    }
     const int D     = g.D;
     const bool fast = g.vec_ok && g.kv_f16 && v.nb[0] == 2 && k.nb[0] == 2 && g.D == g.DV;
 #define FA_CASE(DKP_, NDV_)                                           \
@@ -396,7 +451,7 @@ void launch_flash_attn(hipStream_t s, const FlashOut& out, const View4& q, const
     else if (D <= 128)
         FA_CASE(128, 4);
     else
-        k_flash_attn<160, 5, false><<<grid, 256, 0, s>>>(g);  // 80 accumulator + 40 Q registers leave no room for the prefetch set
+        FA_CASE(160, 5);  // one workgroup per CU (80 accumulator + 40 Q + 40 prefetch registers; 86 KB of tiles)
 #undef FA_CASE
 }
 

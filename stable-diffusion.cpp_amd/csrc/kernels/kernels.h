@@ -140,6 +140,7 @@ struct FlashOut {
 #ifdef MI355X_EXPERIMENTS
 void flash_attn_set_ablate(int v);
 #endif
+void flash_attn_set_grid(int v);  // option "flash_grid"
 void launch_flash_attn(hipStream_t s, const FlashOut& out, const View4& q, const View4& k, const View4& v, float scale);
 
 }  // namespace mi355x

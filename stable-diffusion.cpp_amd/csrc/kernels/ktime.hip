@@ -2,7 +2,11 @@
 #include "ktime.h"
 
 #include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
 #include <mutex>
+#include <tuple>
 #include <utility>
 #include <vector>
 
@@ -75,6 +79,27 @@ int ktime_read(KFamTiming* out, int cap, int* fam_index) {
         acc[r.fam].total_ms += ms;
         acc[r.fam].total_flops += r.flops;
         acc[r.fam].total_bytes += r.bytes;
+    }
+    // MI355X_KTIME_DUMP=<file>: append one line per distinct (family, flops, bytes) launch shape — which shapes a family's time sits in
+    if (const char* path = getenv("MI355X_KTIME_DUMP")) {
+        std::map<std::tuple<int, double, double>, std::pair<int64_t, double>> shapes;
+        for (const Rec& r : g_recs) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) continue;
+            auto& a = shapes[{r.fam, r.flops, r.bytes}];
+            a.first++;
+            a.second += ms;
+        }
+        if (FILE* fp = fopen(path, "a")) {
+            fprintf(fp, "# family | launches | us/launch | total ms | GFLOP/launch | MB/launch | TFLOP/s | GB/s\n");
+            for (const auto& kv : shapes) {
+                const double us = kv.second.second * 1e3 / (double)kv.second.first;
+                fprintf(fp, "%-28.28s | %5lld | %9.1f | %8.3f | %10.3f | %9.2f | %7.1f | %7.1f\n", kNames[std::get<0>(kv.first)],
+                        (long long)kv.second.first, us, kv.second.second, std::get<1>(kv.first) * 1e-9, std::get<2>(kv.first) * 1e-6,
+                        std::get<1>(kv.first) / us * 1e-6, std::get<2>(kv.first) / us * 1e-3);
+            }
+            fclose(fp);
+        }
     }
     g_recs.clear();
     int n = 0;
