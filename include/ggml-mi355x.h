@@ -75,6 +75,7 @@ struct ggml_backend_mi355x_stats {
     int64_t fused_chan_add;      /* conv + ADD(time-embedding [1,1,C,N]) folded into the conv epilogue (ResBlock) */
     int64_t fused_proj_tokens;   /* SpatialTransformer 1x1 proj_in / proj_out run as token GEMMs (the NCHW <-> token transposes are not executed) */
     int64_t gemm_attention;      /* attention chains with head dims beyond the flash kernel (VAE d = 512) composed from MFMA GEMMs + f16 row softmax */
+    int64_t fused_q16;           /* Q projections stored as the flash kernel's f16 head-major operand (the f32 CONT buffer is never written) */
 };
 GGML_MI355X_API void ggml_backend_mi355x_get_stats(struct ggml_backend_mi355x_stats* out);
 /* live per-kernel-family timing (bench.py's roofline legs): while a family's bit is enabled, every dispatch of that family is bracketed by

@@ -1,13 +1,15 @@
 #!/usr/bin/env python
-"""Every gemm16 tile configuration forced in turn on the short-K d -> d GEMMs of the SD1.5 transformer blocks (q/k/v/out projections, proj_out
-1x1 convs): which tile the per-shape choice should take.  Columns = gemm16_tile 0..6 (T128, T256, T256W, T160, T160N, T320, T256P)."""
+"""Every gemm16 tile configuration forced in turn on the short-K d -> d GEMMs of the SD1.5 / SDXL transformer blocks (q/k/v/out projections,
+proj_out 1x1 convs): which tile the per-shape choice should take.  Columns = gemm16_tile 0..7 (T128, T256, T256W, T160, T160N, T320, T256P,
+128x64)."""
+import sys
+
 import t320_check as T
 
-TILES = tuple((t, 1) for t in range(7))
+TILES = tuple((t, 1) for t in range(8))
 ok = True
-for rows, d in ((65536, 320), (16384, 640), (4096, 1280)):
+cases = ((65536, 320), (16384, 640), (4096, 1280), (2048, 1280), (8192, 640)) if len(sys.argv) < 2 else [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]]
+for rows, d in cases:
     ok &= T.linear(rows, d, d, tiles=TILES)
     ok &= T.linear(rows, d, d, res=True, tiles=TILES)
-    hw = {65536: 64, 16384: 32, 4096: 16}[rows]
-    ok &= T.conv(16, d, d, hw, ks=1, res=True, tiles=TILES)
 print("ALL OK" if ok else "MISMATCH")

@@ -41,11 +41,11 @@ namespace {
 struct Stats {
     std::atomic<int64_t> graphs_computed{0}, plans_built{0}, nodes_seen{0}, kernels_planned{0}, kernels_launched{0}, fused_conv{0},
         fused_conv_bounced{0}, fused_linear{0}, fused_norm{0}, fused_geglu{0}, fused_attention{0}, generic_matmul{0}, swizzled_weight_bytes{0}, fused_linear_geglu{0}, split_k_gemms{0}, head_major_gemms{0}, fused_modulate{0}, fused_gate{0}, fused_gelu{0}, fused_rope{0}, fused_concat_heads{0},
-        graph_replays{0}, qgemv_linears{0}, fused_chan_add{0}, fused_proj_tokens{0}, gemm_attention{0};
+        graph_replays{0}, qgemv_linears{0}, fused_chan_add{0}, fused_proj_tokens{0}, gemm_attention{0}, fused_q16{0};
 } g_stats;
 
 struct Options {
-    std::atomic<int> fusion{1}, mfma_gemm{1}, hip_graph{0}, flash_pattern{1}, gemm16{1}, fuse_modulate{1}, fuse_gate{1}, fuse_gelu{1}, fuse_rope{1}, fuse_concat_heads{1}, qgemv{1}, fuse_chan_add{1}, fuse_proj_tokens{1};
+    std::atomic<int> fusion{1}, mfma_gemm{1}, hip_graph{0}, flash_pattern{1}, gemm16{1}, fuse_modulate{1}, fuse_gate{1}, fuse_gelu{1}, fuse_rope{1}, fuse_concat_heads{1}, qgemv{1}, fuse_chan_add{1}, fuse_proj_tokens{1}, fuse_q16{1};
 } g_opt;
 
 using Step = std::function<void(hipStream_t)>;
@@ -238,6 +238,7 @@ struct Builder {
     GInfo gi;
     size_t arena_off = 0;
     std::unordered_map<const ggml_tensor*, Packed> packed;           // graph tensor -> f16 operand image
+    std::unordered_map<const ggml_tensor*, size_t> q16;              // flash Q operand (the RESHAPE the node reads) -> f16 head-major image in the arena
     std::unordered_map<const ggml_tensor*, const ggml_tensor*> ups;  // deferred nearest-x2 UPSCALE node -> its source
     std::map<int, std::vector<Step>> deferred;                       // steps to run once the walk reaches graph node <key>
     Builder(Planner* p, Plan* pl, const ggml_cgraph* g) : P(p), plan(pl), gi(g) {}
@@ -601,9 +602,28 @@ void plan_linear(Builder& B, int i, hipStream_t s, std::vector<int>& chain) {
             g_stats.head_major_gemms++;
             const bool f16o = hm_f16;
             const int hd = hm_d, hH = hm_H, hL = hm_L;
-            B.emit([=](hipStream_t st) {
-                launch_gemm16_linear(st, f16o ? nullptr : (float*)hdst, f16o ? hdst : nullptr, 0, P->arena + off, ld, swz, tokens, K, M, M, ep, hd, hH, hL);
-            });
+            // the f32 CONT is the Q operand of a FLASH_ATTN_EXT node and nothing else reads it (ggml_extend.hpp:1373-1376, 1437): store it as an
+            // f16 head-major image in the arena instead — the kernel rounds Q to f16 anyway; half the bytes written here and read there
+            int qflash = -1, qview = -1;
+            if (!f16o && g_opt.fuse_q16 && hd % 8 == 0) {
+                const int c1 = gi.sole(last);
+                const int c2 = (c1 >= 0 && gi.node(c1)->op == GGML_OP_RESHAPE) ? gi.sole(c1) : -1;
+                if (c2 >= 0 && gi.node(c2)->op == GGML_OP_FLASH_ATTN_EXT && gi.node(c2)->src[0] == gi.node(c1) && !gi.node(c2)->src[3] && contig(gi.node(c1)) &&
+                    gi.node(c1)->ne[0] == hd && flash_attn_supported(hd, gi.node(c2)->src[2]->ne[0])) {
+                    qflash = c2;
+                    qview  = c1;
+                }
+            }
+            if (qflash >= 0) {
+                const size_t qoff        = B.alloc((size_t)tokens * M * 2);
+                B.q16[gi.node(qview)]    = qoff;
+                g_stats.fused_q16++;
+                B.emit([=](hipStream_t st) { launch_gemm16_linear(st, nullptr, P->arena + qoff, 0, P->arena + off, ld, swz, tokens, K, M, M, ep, hd, hH, hL); });
+            } else {
+                B.emit([=](hipStream_t st) {
+                    launch_gemm16_linear(st, f16o ? nullptr : (float*)hdst, f16o ? hdst : nullptr, 0, P->arena + off, ld, swz, tokens, K, M, M, ep, hd, hH, hL);
+                });
+            }
         } else {
             const int S       = gemm16_split_k(tokens, M, K);
             const size_t wsoff = S > 1 ? B.alloc((size_t)S * tokens * M * 4) : 0;
@@ -1393,6 +1413,19 @@ bool plan_single(Builder& B, int i, hipStream_t s) {
             View4 q = view_of(n->src[0]), k = view_of(n->src[1]), v = view_of(n->src[2]);
             float* dst       = (float*)n->data;
             const float sc   = ggml_abi_op_param_f32(n, 0);
+            const auto q16it = B.q16.find(n->src[0]);
+            const bool q16   = q16it != B.q16.end();
+            const size_t q16off = q16 ? q16it->second : 0;
+            if (q16) {  // same [d, L, H*N] shape, f16 elements; the address is resolved at launch (the arena may still grow while planning)
+                q.type = GGML_TYPE_F16;
+                q.data = nullptr;
+                for (int a = 0; a < 4; ++a) q.nb[a] /= 2;
+            }
+            Planner* PP = B.P;
+            auto qfix = [=](View4 qq) {
+                if (q16) qq.data = PP->arena + q16off;
+                return qq;
+            };
             // dst.ne = [dv, H, Lq, B]: element (d, q, h) at h*nb1 + q*nb2
             const int64_t nbq = (int64_t)n->nb[2], nbh = (int64_t)n->nb[1];
             FlashOut fo;
@@ -1425,7 +1458,7 @@ bool plan_single(Builder& B, int i, hipStream_t s) {
                                 f2.H     = (int)H;
                                 f2.dst16 = P->arena + off;
                                 f2.ld16  = ld;
-                                launch_flash_attn(st, f2, q, k, v, sc);
+                                launch_flash_attn(st, f2, qfix(q), k, v, sc);
                             });
                             B.packed[ct] = Packed{off, ld, false};
                         } else {
@@ -1437,7 +1470,7 @@ bool plan_single(Builder& B, int i, hipStream_t s) {
                                 f2.nb_q = C * 4;
                                 f2.nb_h = d * 4;
                                 f2.nb_n = Lq * C * 4;
-                                launch_flash_attn(st, f2, q, k, v, sc);
+                                launch_flash_attn(st, f2, qfix(q), k, v, sc);
                             });
                         }
                         gi.done[j1] = gi.done[j2] = 1;
@@ -1446,7 +1479,7 @@ bool plan_single(Builder& B, int i, hipStream_t s) {
                     }
                 }
             }
-            B.emit([=](hipStream_t st) { launch_flash_attn(st, fo, q, k, v, sc); });
+            B.emit([=](hipStream_t st) { launch_flash_attn(st, fo, qfix(q), k, v, sc); });
             g_stats.fused_attention++;
             return true;
         }
@@ -1767,6 +1800,7 @@ void planner_get_stats(ggml_backend_mi355x_stats* o) {
     o->fused_chan_add        = g_stats.fused_chan_add;
     o->fused_proj_tokens     = g_stats.fused_proj_tokens;
     o->gemm_attention        = g_stats.gemm_attention;
+    o->fused_q16             = g_stats.fused_q16;
     o->fused_attention       = g_stats.fused_attention;
     o->generic_matmul        = g_stats.generic_matmul;
     o->swizzled_weight_bytes = g_stats.swizzled_weight_bytes;
@@ -1784,6 +1818,7 @@ void planner_set_option(const char* key, int value) {
 #endif
     else if (!strcmp(key, "gemm16_t320")) gemm16_set_t320(value);
     else if (!strcmp(key, "qgemv")) g_opt.qgemv = value;
+    else if (!strcmp(key, "fuse_q16")) g_opt.fuse_q16 = value;
     else if (!strcmp(key, "flash_grid")) flash_attn_set_grid(value);
     else if (!strcmp(key, "fuse_chan_add")) g_opt.fuse_chan_add = value;
     else if (!strcmp(key, "fuse_proj_tokens")) g_opt.fuse_proj_tokens = value;

@@ -15,6 +15,9 @@
 // and reading V with the same permutation.
 // Staging is split (cdna_hip_programming.md T14): the 16-byte global loads of tile t+1 are issued into registers
 // BEFORE the MFMAs of tile t and written to LDS after the next barrier, so HBM/L2 latency hides under compute.
+#include <cstdio>
+#include <cstdlib>
+
 #include "device_utils.h"
 #include "kernels.h"
 #include "ktime.h"
@@ -36,6 +39,7 @@ struct FAArgs {
     int Lq, Lk, D, DV;
     int kv_f16;
     int grp, units;  // XCD-grouped 1-D grid (see the kernel): heads per unit, (image, query block) units
+    int q_f16;   // Q is an f16 image (planner: the projection GEMM's head-major output feeds only this launch)
     int q_vec;   // Q rows are f32 d-contiguous, 16-byte aligned, D % 4 == 0 -> coalesced float4 staging through LDS
     int vec_ok;  // K and V rows are d-contiguous, 16-byte aligned, D % 8 == 0 -> 128-bit staging loads
     float scale_log2e;
@@ -88,7 +92,31 @@ __global__ __launch_bounds__(256, DKP <= 64 ? 3 : (DKP <= 128 ? 2 : 1)) void k_f
     // row reads (32 rows x 2 halves per instruction, 4 useful bytes of every 64-byte segment) cost ~1500 TA cycles per wave: at Lk = 77
     // (cross-attention, 2 tiles per workgroup) that was most of the kernel.
     half8_t qf[KS];
-    if (g.q_vec) {
+    if (g.q_f16) {  // f16 head-major Q written by the projection GEMM for this launch (rows d-contiguous, 16-byte aligned, D % 8 == 0)
+        constexpr int QROW = DKP + 4, C8 = DKP / 8;
+        const char* qblk = g.q + (int64_t)hn * g.q_nb2 + (int64_t)(qb * 128) * g.q_nb1;
+        for (int e = threadIdx.x; e < 128 * C8; e += 256) {
+            const int row = e / C8, c8 = e - row * C8;
+            half8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (qb * 128 + row < g.Lq && c8 * 8 < g.D) v = *(const half8_t*)(qblk + (int64_t)row * g.q_nb1 + c8 * 16);
+            half4_t a, b;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a[j] = (_Float16)((float)v[j] * g.scale_log2e);
+                b[j] = (_Float16)((float)v[4 + j] * g.scale_log2e);
+            }
+            *(half4_t*)&smem[row * QROW + c8 * 8]     = a;
+            *(half4_t*)&smem[row * QROW + c8 * 8 + 4] = b;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const _Float16* p = &smem[(wave * 32 + (lane & 31)) * QROW + ks * 16 + hi * 8];
+            const half4_t a = *(const half4_t*)p, b = *(const half4_t*)(p + 4);
+            qf[ks] = (half8_t){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+        }
+        __syncthreads();
+    } else if (g.q_vec) {
         constexpr int QROW = DKP + 4, C4 = DKP / 4;  // +4 halfs: 8-byte aligned rows, 2-way conflicts at worst on the one-time fragment reads
         static_assert(128 * QROW <= NBUF * TILE_H, "Q staging must fit the K/V tile buffers");
         const char* qblk = g.q + (int64_t)hn * g.q_nb2 + (int64_t)(qb * 128) * g.q_nb1;
@@ -413,7 +441,12 @@ void launch_flash_attn(hipStream_t s, const FlashOut& out, const View4& q, const
     g.scale_log2e = scale * 1.44269504088896340736f;
     auto al16 = [](const void* p, int64_t a, int64_t b) { return ((((uintptr_t)p) | (uintptr_t)a | (uintptr_t)b) & 15) == 0; };
     g.vec_ok = (g.D % 8 == 0) && al16(k.data, k.nb[1], k.nb[2]) && al16(v.data, v.nb[1], v.nb[2]);
-    g.q_vec = (g.D % 4 == 0) && q.nb[0] == 4 && al16(q.data, q.nb[1], q.nb[2]);
+    g.q_vec = q.type == 0 && (g.D % 4 == 0) && q.nb[0] == 4 && al16(q.data, q.nb[1], q.nb[2]);
+    g.q_f16 = q.type == 1;
+    if (g.q_f16 && !(g.D % 8 == 0 && q.nb[0] == 2 && al16(q.data, q.nb[1], q.nb[2]))) {
+        fprintf(stderr, "mi355x: flash attention: f16 Q must be d-contiguous, 16-byte aligned, d %% 8 == 0\n");
+        abort();
+    }
     dim3 grid((unsigned)((g.Lq + 127) / 128), (unsigned)q.ne[2]);
     g.grp = g.units = 0;
     if (g_flash_grid && out.H > 0 && q.ne[2] % out.H == 0) {

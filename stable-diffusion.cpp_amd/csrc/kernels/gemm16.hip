@@ -804,7 +804,7 @@ static int g16_pick_tile(int64_t rows, int64_t M, bool geglu, bool conv, int spl
         if (g_g16_force_tile == G16_T320) return can320 ? G16_T320 : G16_T256;
         if (g_g16_force_tile == G16_T256P) return M % 256 == 0 ? G16_T256P : G16_T256;
         if ((g_g16_force_tile == G16_T160 || g_g16_force_tile == G16_T160N) && !can160) return G16_T256;
-        return g_g16_force_tile;
+        return g_g16_force_tile > G16_T256P ? G16_T128 : g_g16_force_tile;
     }
     const int64_t rt256 = (rows + 255) / 256, c128 = ((rows + 127) / 128) * ((M + 127) / 128), c256 = rt256 * ((M + 127) / 128);
     if (g_g16_force_tile < 0 && !split && g_g16_t320 && !can320 && M % 256 == 0) {
@@ -1043,7 +1043,7 @@ void launch_gemm16_linear(hipStream_t s, float* dst, void* dst16, int64_t ldd16,
         g.ep       = G16Epi{nullptr, nullptr, e.scale};
     }
     // narrow outputs (M = 320: 2.5 tiles of 128) waste less with 64-wide column tiles
-    const bool bn64 = M <= 64;
+    const bool bn64 = M <= 64 || (g_g16_force_tile == 7 && M % 64 == 0 && !hm_d);
     if (g16_trace()) fprintf(stderr, "G16 linear rows=%lld K=%lld M=%lld res=%d hm=%d f16out=%d\n", (long long)rows, (long long)K, (long long)M, e.residual ? 1 : 0, hm_d, dst16 ? 1 : 0);
     if (bn64) {
         g.ncol_tiles = (int)((M + 63) / 64);

@@ -427,6 +427,62 @@ def test_flash_attn_ext(sd, oracle, gpu, rng, d, Lq, Lk, HN):
     assert rel_l2(out[0].transpose(1, 0, 2), exact) < (2e-3 if _on_gpu() else 1e-2)   # self-check mode: the oracle's f16 V accumulation
 
 
+@pytest.mark.parametrize("d,H,Lq,Lk,N,ctx", [(40, 8, 300, 300, 2, 320), (40, 8, 130, 77, 3, 768), (80, 4, 256, 77, 1, 768), (160, 2, 64, 64, 2, 320), (64, 5, 96, 96, 1, 320)])
+def test_attention_block_flash_operands_from_projections(sd, oracle, gpu, rng, d, H, Lq, Lk, N, ctx):
+    """CrossAttention as the reference builds it with the flash flag on (ggml_extend.hpp:1349-1485): q/k/v Linears -> reshape / permute / cont
+    (-> f16 cast for k, v) -> FLASH_ATTN_EXT -> view / cont -> to_out Linear.  The projections write the flash kernel's operand layouts
+    directly: K/V as f16 head-major, and Q — read by nothing else — as an f16 head-major image too (stat fused_q16)."""
+    C = d * H
+    x = rng.standard_normal((N, Lq, C)).astype(np.float32)
+    c = x if ctx == C and Lk == Lq else rng.standard_normal((N, Lk, ctx)).astype(np.float32)
+    wq = (rng.standard_normal((C, C)) / np.sqrt(C)).astype(np.float32)
+    wk = (rng.standard_normal((C, ctx)) / np.sqrt(ctx)).astype(np.float32)
+    wv = (rng.standard_normal((C, ctx)) / np.sqrt(ctx)).astype(np.float32)
+    wo = (rng.standard_normal((C, C)) / np.sqrt(C)).astype(np.float32)
+    bo = rng.standard_normal(C).astype(np.float32)
+    scale = 1.0 / np.sqrt(d)
+
+    def build(g, L):
+        xi = g.input(x)
+        ci = xi if c is x else g.input(c)
+
+        def heads(t, Lt, f16):
+            t = L.ggml_reshape_4d(g.ctx, t, d, H, Lt, N)
+            t = L.ggml_cont(g.ctx, L.ggml_permute(g.ctx, t, 0, 2, 1, 3))   # [d, L, H, N]
+            t = L.ggml_reshape_3d(g.ctx, t, d, Lt, H * N)
+            return L.ggml_cast(g.ctx, t, F16) if f16 else t
+
+        q = heads(L.ggml_mul_mat(g.ctx, g.weight(wq, F16), xi), Lq, False)
+        k = heads(L.ggml_mul_mat(g.ctx, g.weight(wk, F16), ci), Lk, True)
+        v = heads(L.ggml_mul_mat(g.ctx, g.weight(wv, F16), ci), Lk, True)
+        a = L.ggml_flash_attn_ext(g.ctx, q, k, v, None, scale, 0.0, 0.0)      # [d, H*N, Lq, 1]
+        L.ggml_flash_attn_ext_set_prec(a, 10)
+        nb = sd_tensor_nb(a)
+        a = L.ggml_view_4d(g.ctx, a, d, H, Lq, N, nb[1], nb[2], nb[1] * H, 0)
+        a = L.ggml_cont(g.ctx, L.ggml_permute(g.ctx, a, 0, 1, 2, 3))
+        a = L.ggml_reshape_3d(g.ctx, a, C, Lq, N)
+        y = L.ggml_mul_mat(g.ctx, g.weight(wo, F16), a)
+        return L.ggml_add_inplace(g.ctx, y, g.weight(bo, F32))
+
+    before = sd.backend_stats() if _on_gpu() else None
+    ref, out = run_both(sd, oracle, gpu, build)
+    assert out.shape == ref.shape == (1, N, Lq, C)
+    out, ref = out[0], ref[0]
+    assert rel_l2(out, ref) < 1e-2      # the oracle's flash path accumulates V in f16
+    # exact chain in float64 on the f16-rounded weights
+    f = lambda w: w.astype(np.float16).astype(np.float64)
+    qe = (x.astype(np.float64) @ f(wq).T).reshape(N, Lq, H, d).transpose(0, 2, 1, 3).reshape(N * H, Lq, d)
+    ke = (c.astype(np.float64) @ f(wk).T).reshape(N, Lk, H, d).transpose(0, 2, 1, 3).reshape(N * H, Lk, d)
+    ve = (c.astype(np.float64) @ f(wv).T).reshape(N, Lk, H, d).transpose(0, 2, 1, 3).reshape(N * H, Lk, d)
+    ae = _attn_exact(qe, ke, ve, scale).reshape(N, H, Lq, d).transpose(0, 2, 1, 3).reshape(N, Lq, C)
+    exact = ae @ f(wo).T + bo
+    assert rel_l2(out, exact) < (4e-3 if _on_gpu() else 1e-2)
+    if before is not None and Lq >= 32:
+        after = sd.backend_stats()
+        assert after["fused_q16"] - before["fused_q16"] == (1 if d % 8 == 0 else 0)
+        assert after["fused_attention"] - before["fused_attention"] == 1
+
+
 @pytest.mark.parametrize("d,Lq,Lk,HN", [(40, 200, 200, 4), (80, 100, 77, 2), (160, 64, 64, 2),
                                         # head dims beyond the flash kernel (KL-VAE mid attention: 1 head x 512): composed from MFMA GEMMs + f16 row softmax
                                         (512, 256, 256, 1), (192, 100, 80, 2), (512, 1024, 1024, 2)])
