@@ -3,7 +3,8 @@
     SDCPP_BUILD_VARIANT=exp python -c "from sdcpp_amd import build; build.build_all()"
     SDCPP_BACKEND_LIB=stable-diffusion.cpp_amd/lib_exp/libggml-mi355x.so python scripts/gemm_ablation.py
 Times the SD1.5 64x64-level convs three ways (HIP events per dispatch): product kernel, DMA + reads + barriers without MFMAs (option
-gemm16_abl = 1), reads + MFMAs without DMA after the pipeline fill (2).  The ablations compute WRONG results on purpose."""
+gemm16_abl = 1), reads + MFMAs without DMA after the pipeline fill (2), input tiles
+fetched for one tap of nine (3: the DMA volume of a kernel that keeps the input window resident in LDS).  The ablations compute WRONG results on purpose."""
 import sys
 from pathlib import Path
 
@@ -38,8 +39,9 @@ def conv_time(N, IC, OC, HW, abl):
     return sum(f["total_ms"] for f in t) / 5 * 1e3
 
 
-for (N, IC, OC, HW) in ((16, 320, 320, 64), (16, 960, 320, 64)):
-    full, nomfma, nodma = (conv_time(N, IC, OC, HW, a) for a in (0, 1, 2))
+for (N, IC, OC, HW) in ((16, 320, 320, 64), (16, 960, 320, 64), (16, 640, 640, 32)):
+    full, nomfma, nodma, areuse = (conv_time(N, IC, OC, HW, a) for a in (0, 1, 2, 3))
     stages = IC // 32 * 9 if IC % 64 == 0 else (IC + 63) // 64 * 2 * 9
     print(f"conv3x3 N{N} {IC}->{OC} @{HW}: product {full:7.1f} us | DMA + reads + barriers, no MFMA {nomfma:7.1f} us | reads + MFMA, no DMA {nodma:7.1f} us "
-          f"| per stage ({stages} stages): {full / stages * 1e3:.0f} / {nomfma / stages * 1e3:.0f} / {nodma / stages * 1e3:.0f} ns", flush=True)
+          f"| input tile fetched for tap 0 only (A traffic / 9) {areuse:7.1f} us "
+          f"| per stage ({stages} stages): {full / stages * 1e3:.0f} / {nomfma / stages * 1e3:.0f} / {nodma / stages * 1e3:.0f} / {areuse / stages * 1e3:.0f} ns", flush=True)

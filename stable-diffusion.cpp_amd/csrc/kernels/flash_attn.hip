@@ -49,7 +49,10 @@ struct FAArgs {
 // loads, register-prefetched one tile ahead.  !FAST: any strides / f32 sources (manual-attention chain), staged directly.
 // ABL != 0: TIMING ABLATIONS with wrong results (option "flash_ablate", scripts/flash_ablation.py only): 1 = no softmax VALU work (the raw
 // scores go into the PV product), 2 = K/V tiles are staged once and reused (no global loads / LDS stores in the loop)
-template <int DKP, int NDV, bool FAST, int ABL = 0>
+// MSLOT (d = 40 on the 48-wide tile, FAST): the running max rides in the first padded k-slot — Q[q][40] = -m_run[q], K[key][40] = 1 — so the MFMA
+// delivers scores already relative to the max and the 32 v_sub per lane per tile disappear from the VALU-bound loop (m_run is kept
+// f16-representable; any consistent offset is a valid softmax shift because numerator and row sum use the same P)
+template <int DKP, int NDV, bool FAST, int ABL = 0, bool MSLOT = false>
 __global__ __launch_bounds__(256, DKP <= 64 ? 3 : (DKP <= 128 ? 2 : 1)) void k_flash_attn(FAArgs g) {
     constexpr int KS   = DKP / 16;                       // MFMA k-steps over the head dim
     constexpr int KROW = DKP + 8;                        // K tile row stride (halfs)
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(256, DKP <= 64 ? 3 : (DKP <= 128 ? 2 : 1)) void k_f
     float16_t o[NDV];
 #pragma unroll
     for (int nb = 0; nb < NDV; ++nb) o[nb] = (float16_t){0};
-    float m_run = -INFINITY, l_run = 0.f;
+    float m_run = MSLOT ? 0.f : -INFINITY, l_run = 0.f;  // MSLOT: Q's max slot starts at 0 and the first tile always moves the max
 
     const char* kbase = g.k + (int64_t)hn * g.k_nb2;
     const char* vbase = g.v + (int64_t)hn * g.v_nb2;
@@ -172,6 +175,7 @@ __global__ __launch_bounds__(256, DKP <= 64 ? 3 : (DKP <= 128 ? 2 : 1)) void k_f
     // put a wave's 64 lanes on ~12 banks: 31 % of all LDS cycles were conflict cycles).
     // per-thread chunk coordinates are tile-invariant: 32-bit byte offsets against a wave-uniform tile base (SGPR base + VGPR offset loads)
     uint32_t koff[NCH], voff[NCH];
+    bool kone[NCH];             // MSLOT: this chunk starts at d = D (the max slot)
     int kkey[NCH], vkey_[NCH];  // key index inside the tile, or FA_KT (never valid) for chunks this thread does not fetch
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
@@ -181,6 +185,7 @@ __global__ __launch_bounds__(256, DKP <= 64 ? 3 : (DKP <= 128 ? 2 : 1)) void k_f
         koff[c]  = (uint32_t)key * (uint32_t)g.k_nb1 + (uint32_t)ch * 16u;
         voff[c]  = (uint32_t)vkey * (uint32_t)g.v_nb1 + (uint32_t)vch * 16u;
         kkey[c]  = (e < FA_KT * DCH && ch < nd8) ? key : FA_KT;
+        kone[c]  = e < FA_KT * DCH && ch == nd8;
         vkey_[c] = (e < FA_KT * DCH && vch < nd8) ? vkey : FA_KT;
     }
     auto gload = [&](int kt) {
@@ -193,6 +198,7 @@ __global__ __launch_bounds__(256, DKP <= 64 ? 3 : (DKP <= 128 ? 2 : 1)) void k_f
             kreg[c] = zk;
             vreg[c] = zk;
             if (kkey[c] < left) kreg[c] = *(const half8_t*)(kb + koff[c]);
+            if (MSLOT && kone[c]) kreg[c][0] = (_Float16)1.0f;  // K[key][D] = 1 (keys beyond Lk are masked after the MFMA)
             if (vkey_[c] < left) vreg[c] = *(const half8_t*)(vb + voff[c]);
             if (ones_in_tile && ((threadIdx.x + c * 256) >> 6) == nd8) vreg[c][0] = (_Float16)1.0f;  // V^T row DV = 1: PV accumulates the row sums
         }
@@ -309,11 +315,25 @@ __global__ __launch_bounds__(256, DKP <= 64 ? 3 : (DKP <= 128 ? 2 : 1)) void k_f
             for (int r = 0; r < 16; ++r) tmax = __builtin_fmaxf(__builtin_fmaxf(tmax, s[0][r]), s[1][r]);  // v_max3_f32
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
         }
-        if (ABL != 1 && __any(tmax > m_run + FA_THR)) {
-            const float m_new = fmaxf(m_run, tmax);
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // m_run = -inf on the first tile -> 0
+        if (MSLOT ? (kt == 0 || __any(tmax > FA_THR)) : (ABL != 1 && __any(tmax > m_run + FA_THR))) {
+            float alpha;
+            if constexpr (MSLOT) {
+                // the scores are relative to m_run already: move the max by delta (rounded so that the new max is an f16 value), re-base this tile
+                const float m_new = (float)(_Float16)(m_run + (kt == 0 ? tmax : fmaxf(tmax, 0.f)));
+                const float delta = m_new - m_run;
+                alpha             = __builtin_amdgcn_exp2f(-delta);
+                m_run             = m_new;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[kb][r] -= delta;
+                if (hi) qf[KS - 1][0] = (_Float16)(-m_new);  // d = 40: k-step 2, upper lane half, element 0
+            } else {
+                const float m_new = fmaxf(m_run, tmax);
+                alpha             = __builtin_amdgcn_exp2f(m_run - m_new);  // m_run = -inf on the first tile -> 0
+                m_run             = m_new;
+            }
             l_run *= alpha;
-            m_run = m_new;
             // rescale O rows: row i of the accumulator belongs to query lane i -> fetch its alpha
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -327,7 +347,7 @@ __global__ __launch_bounds__(256, DKP <= 64 ? 3 : (DKP <= 128 ? 2 : 1)) void k_f
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) s[kb][r] = __builtin_amdgcn_exp2f(s[kb][r] - m_run);
+                for (int r = 0; r < 16; ++r) s[kb][r] = __builtin_amdgcn_exp2f(MSLOT ? s[kb][r] : s[kb][r] - m_run);
         }
         if (!has_ones) {
             float psum = 0.f;
@@ -409,6 +429,8 @@ static int g_flash_ablate = 0;
 void flash_attn_set_ablate(int v) { g_flash_ablate = v; }
 #endif
 
+static int g_flash_mslot = 1;  // option "flash_mslot": 0 = subtract the running max on the VALU (A/B measurements)
+void flash_attn_set_mslot(int v) { g_flash_mslot = v; }
 static int g_flash_grid = 1;  // option "flash_grid": 0 = plain (query block, head) grid (A/B measurements)
 void flash_attn_set_grid(int v) { g_flash_grid = v; }
 
@@ -473,7 +495,9 @@ void launch_flash_attn(hipStream_t s, const FlashOut& out, const View4& q, const
         return;
     }
 #endif
-    if (D <= 48)
+    if (D == 40 && fast && g_flash_mslot)
+        k_flash_attn<48, 2, true, 0, true><<<grid, 256, 0, s>>>(g);
+    else if (D <= 48)
         FA_CASE(48, 2);
     else if (D <= 64)
         FA_CASE(64, 2);

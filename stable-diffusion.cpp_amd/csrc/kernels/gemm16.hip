@@ -431,7 +431,7 @@ __global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g
                 const int64_t toff = ((int64_t)kh * g.Wd + kw) * g.ICp + koff;
 #pragma unroll
                 for (int q = 0; q < APW; ++q) {
-                    const _Float16* p = ((a_mask[q] >> tap) & 1u) ? asrc[q] + toff : g.zero + (a_slot[q] & 63);
+                    const _Float16* p = (((a_mask[q] >> tap) & 1u) && !(PIPE == 4 && tap != 0)) ? asrc[q] + toff : g.zero + (a_slot[q] & 63);
                     GLDS16(p, sa + (wave * APW + q) * 1024);
                 }
             } else {
@@ -462,7 +462,7 @@ __global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g
                 const int64_t koff = (int64_t)icb * 64 + sub * BK;
                 if (!g.UPS) {
                     const int64_t toff = ((int64_t)kh * g.Wd + kw) * g.ICp + koff;
-                    const _Float16* p  = ((a_mask[q] >> tap) & 1u) ? asrc[q] + toff : g.zero + (a_slot[q] & 63);
+                    const _Float16* p  = (((a_mask[q] >> tap) & 1u) && !(PIPE == 4 && tap != 0)) ? asrc[q] + toff : g.zero + (a_slot[q] & 63);  // PIPE 4: ablation
                     GLDS16(p, sa + (wave * APW + q) * 1024);
                 } else {
                     const int oh = (a_slot[q] >> 8) & 4095, ow = (a_slot[q] >> 20) & 4095;
@@ -787,7 +787,7 @@ void gemm16_set_tile(int t) { g_g16_force_tile = t; }
 // round 1.5x that (4 waves per workgroup hide less latency) but covers 1.25x T256's area with no padded columns.  256-row tiles
 // only pay when they fill every CU twice (>= 512 workgroups); otherwise the finer T128 quantises better.
 #ifdef MI355X_EXPERIMENTS
-static int g_g16_abl = 0;  // option "gemm16_abl": 1 = no MFMAs, 2 = no DMA after the fill (T320 only; wrong results, timing)
+static int g_g16_abl = 0;  // option "gemm16_abl": 1 = no MFMAs, 2 = no DMA after the fill, 3 = conv input tiles fetched for tap 0 only (T320 only; wrong results, timing)
 void gemm16_set_abl(int v) { g_g16_abl = v; }
 #endif
 static int g_g16_t320 = 1;  // option "gemm16_t320": 0 disables the pipelined 256x320 tile in the per-shape choice (A/B measurements)
@@ -852,6 +852,10 @@ static void g16_launch(hipStream_t s, G16Args& g, int64_t rows, double flops) {
                 }
                 if (g_g16_abl == 2) {
                     k_gemm16<256, 320, CONV_, 32, 4, 4, 2, 3><<<dim3((unsigned)(rt256 * g.ncol_tiles), ny), 512, 0, s>>>(g);
+                    return;
+                }
+                if (g_g16_abl == 3) {  // A tiles fetched for tap 0 only (other taps: the zero page): the DMA volume of a kernel that keeps the input window in LDS
+                    k_gemm16<256, 320, CONV_, 32, 4, 4, 2, 4><<<dim3((unsigned)(rt256 * g.ncol_tiles), ny), 512, 0, s>>>(g);
                     return;
                 }
 #endif

@@ -140,7 +140,8 @@ struct FlashOut {
 #ifdef MI355X_EXPERIMENTS
 void flash_attn_set_ablate(int v);
 #endif
-void flash_attn_set_grid(int v);  // option "flash_grid"
+void flash_attn_set_grid(int v);   // option "flash_grid"
+void flash_attn_set_mslot(int v);  // option "flash_mslot"
 void launch_flash_attn(hipStream_t s, const FlashOut& out, const View4& q, const View4& k, const View4& v, float scale);
 
 }  // namespace mi355x
