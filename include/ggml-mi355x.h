@@ -101,6 +101,9 @@ GGML_MI355X_API int ggml_backend_mi355x_get_kernel_timings(struct ggml_backend_m
  * "splitk_mid" (0: two K slices for launches of 193..384 workgroups), "pinned_uploads" (0: set_tensor_async stages through pinned host memory so the call does
  * not wait for the stream).  Wrong-result timing ablations exist only in builds with -DMI355X_EXPERIMENTS ("flash_ablate"). */
 GGML_MI355X_API void ggml_backend_mi355x_set_option(const char* key, int value);
+/* the hipStream_t every graph of this backend instance is enqueued on (graph_compute_async, set/get_tensor_async): a caller that touches a
+ * tensor's device memory between two graphs (the CFG-pair all-reduce, sd_set_pair_exchange) orders its work on this stream */
+GGML_MI355X_API void* ggml_backend_mi355x_get_stream(ggml_backend_t backend);
 
 #ifdef __cplusplus
 }

@@ -180,6 +180,14 @@ SD_API void sdm_free_images(sdm_image_t* images, int num_images);
 SD_API void sd_philox_randn(uint64_t seed, uint32_t offset, uint32_t n, float* out); /* rng_philox.hpp:101-122 */
 SD_API void sd_philox_uint32(uint64_t seed, uint32_t offset, uint32_t n, uint32_t* out /* 4*n words */); /* the integer stage alone: philox4_32, rng_philox.hpp:63-77 */
 SD_API int sd_get_sigmas(int steps, float* out /* steps+1 */);                       /* denoiser.hpp:32-54 + stable-diffusion.cpp:173-186 */
+/* CFG-pair split across two GPUs (the cond / uncond evaluations of src/runtime/guidance.cpp:149-179 on two devices):
+ * with an exchange installed, the device-resident trajectory (device_sampler) evaluates ONE branch per step on this context — branch 0 = cond,
+ * 1 = uncond — writes weight * eps (weight = cfg on branch 0, 1 - cfg on branch 1) to a device buffer and calls `exchange` once per step with
+ * that buffer's DEVICE address, its f32 element count and the hipStream_t the producer graph was enqueued on (NULL on host backends).  The
+ * callee sums the two ranks' buffers in place (one all-reduce, e.g. RCCL over one xGMI link) ordered on that stream, and returns false on
+ * failure.  Nothing is copied to the host.  fn = NULL restores the single-device CFG pair. */
+typedef bool (*sd_pair_exchange_fn)(void* device_eps, int64_t count, void* stream, void* user);
+SD_API void sd_set_pair_exchange(sdm_ctx_t* ctx, sd_pair_exchange_fn fn, void* user, int branch);
 SD_API void sd_set_guidance(sdm_ctx_t* ctx, float guidance); /* FLUX distilled-guidance input (default 3.5, stable-diffusion.h guidance.distilled_guidance) */
 SD_API int sd_get_flux_sigmas(int steps, int image_seq_len, float* out /* steps+1 */); /* FluxScheduler, denoiser.hpp:726-782 */
 SD_API int sd_gen_flux_pe(int h, int w, int patch_size, int context_len, const int* axes_dim, int n_axes, float theta, float* out); /* Rope::gen_flux_pe; returns floats written */

@@ -27,6 +27,8 @@ TYPE_SIZE = {F32: 4, F16: 2, BF16: 2, I32: 4}
 
 # sd_model_family_t
 SD15, SDXL, SD15_TINY, SDXL_TINY, SD35_LARGE, SD35_TINY, FLUX_DEV, FLUX_TINY, SD35_WIDE2, FLUX_WIDE1 = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
+# sd_pair_exchange_fn (include/sd-mi355x.h): (device address of the f32 eps buffer, element count, hipStream_t, user) -> ok
+PAIR_EXCHANGE_FN = C.CFUNCTYPE(C.c_bool, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p)
 EULER, EULER_A, SAMPLE_METHOD_DEFAULT = 0, 1, 2   # DEFAULT: Euler for the DiT families, Euler-A otherwise (sd_get_default_sample_method)
 
 
@@ -250,6 +252,8 @@ def lib() -> C.CDLL:
     L.sd_get_flux_sigmas.argtypes = [C.c_int, C.c_int, C.c_void_p]
     L.sd_set_guidance.argtypes = [C.c_void_p, C.c_float]
     L.sd_set_guidance.restype = None
+    L.sd_set_pair_exchange.argtypes = [C.c_void_p, PAIR_EXCHANGE_FN, C.c_void_p, C.c_int]
+    L.sd_set_pair_exchange.restype = None
     L.sd_gen_flux_pe.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_float, C.c_void_p]
     L.sd_sigma_to_t.argtypes = [C.c_float]
     L.sd_sigma_to_t.restype = C.c_float
@@ -528,6 +532,22 @@ class Engine:
     def set_guidance(self, guidance: float) -> None:
         """FLUX distilled-guidance input (default 3.5)"""
         lib().sd_set_guidance(self._ctx, float(guidance))
+
+    def set_pair_exchange(self, fn, branch: int = 0) -> None:
+        """CFG-pair split (sd_set_pair_exchange): `fn(device_ptr, count, stream) -> bool` sums this rank's weighted eps with its partner's in
+        place, in device memory, once per step of the device-resident trajectory; branch 0 = cond, 1 = uncond.  fn = None removes it."""
+        if fn is None:
+            self._pair_cb = PAIR_EXCHANGE_FN(0)
+        else:
+            def cb(ptr, count, stream, _user, _fn=fn):
+                try:
+                    return bool(_fn(ptr, int(count), stream))
+                except Exception:  # never unwind through the C frames
+                    import traceback
+                    traceback.print_exc()
+                    return False
+            self._pair_cb = PAIR_EXCHANGE_FN(cb)   # kept alive as long as it is installed
+        lib().sd_set_pair_exchange(self._ctx, self._pair_cb, None, int(branch))
 
     def set_tensor(self, name: str, value: np.ndarray) -> None:
         v = _f32(value).ravel()

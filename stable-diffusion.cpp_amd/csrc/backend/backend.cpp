@@ -279,6 +279,7 @@ static void* reg_get_proc(ggml_backend_reg_t, const char* name) {
     if (strcmp(name, "ggml_backend_mi355x_get_kernel_timing") == 0) return (void*)ggml_backend_mi355x_get_kernel_timing;
     if (strcmp(name, "ggml_backend_mi355x_get_kernel_timings") == 0) return (void*)ggml_backend_mi355x_get_kernel_timings;
     if (strcmp(name, "ggml_backend_mi355x_kernel_timing_enable_mask") == 0) return (void*)ggml_backend_mi355x_kernel_timing_enable_mask;
+    if (strcmp(name, "ggml_backend_mi355x_get_stream") == 0) return (void*)ggml_backend_mi355x_get_stream;
     return nullptr;
 }
 
@@ -371,6 +372,9 @@ static void fill_timing(struct ggml_backend_mi355x_kernel_timing* o, const mi355
 }
 GGML_MI355X_API void ggml_backend_mi355x_kernel_timing_enable(int enable) { mi355x::ktime_enable(enable ? 1u : 0u); }
 GGML_MI355X_API void ggml_backend_mi355x_kernel_timing_enable_mask(uint32_t family_mask) { mi355x::ktime_enable(family_mask); }
+GGML_MI355X_API void* ggml_backend_mi355x_get_stream(ggml_backend_t backend) {
+    return backend ? (void*)((mi355x::BackendCtx*)backend->context)->stream : nullptr;
+}
 GGML_MI355X_API int ggml_backend_mi355x_get_kernel_timings(struct ggml_backend_mi355x_kernel_timing* out, int capacity) {
     mi355x::KFamTiming t[mi355x::KF_COUNT];
     int fam[mi355x::KF_COUNT];

@@ -333,7 +333,7 @@ struct sdm_ctx_t {
     struct SamplerState {
         ggml_context* sctx        = nullptr;
         ggml_backend_buffer_t buf = nullptr;
-        ggml_tensor *x = nullptr, *noise = nullptr;
+        ggml_tensor *x = nullptr, *noise = nullptr, *eps = nullptr;
         int64_t W = 0, H = 0, C = 0, N = 0;
         ~SamplerState() {
             if (buf) ggml_backend_buffer_free(buf);
@@ -341,6 +341,11 @@ struct sdm_ctx_t {
         }
     };
     std::unique_ptr<SamplerState> sstate;
+    // CFG-pair split (sd_set_pair_exchange): this context computes one branch; the per-step sum with the partner is the caller's collective
+    sd_pair_exchange_fn pair_fn = nullptr;
+    void* pair_user             = nullptr;
+    int pair_branch             = 0;
+    Runner pair_runner;  // the sampler-update graph behind the exchange keeps its own cached graph + compute buffer
     std::vector<float> pe_cache;  // FLUX rotary table of the last (h, w, n_tokens)
     int pe_h = 0, pe_w = 0;
     int64_t pe_tokens = 0;
@@ -466,6 +471,8 @@ sdm_ctx_t* sdm_new_ctx(const sdm_ctx_params_t* params) {
         ctx->mmdit.init(ctx->unet_runner.ps, "model.diffusion_model.", dit_tiny ? MMDiTConfig::tiny() : (params->model == SD_MODEL_SD35_WIDE2 ? MMDiTConfig::sd35_wide2() : MMDiTConfig::sd35_large()));
     } else
         ctx->unet.init(ctx->unet_runner.ps, "model.diffusion_model.", ucfg);  // prefix: stable-diffusion.cpp:1337
+    ctx->pair_runner.backend       = backend;
+    ctx->pair_runner.graph_size    = 256;
     ctx->vae_runner.backend        = backend;
     ctx->vae_runner.ps.linear_type = GGML_TYPE_F16;
     ctx->vae_runner.graph_size     = 20480;
@@ -1189,6 +1196,8 @@ static bool sample_group_device(sdm_ctx_t* ctx, const sdm_img_gen_params_t* p, i
         st.sctx  = ggml_init(ip);
         st.x     = ggml_new_tensor_4d(st.sctx, GGML_TYPE_F32, W, H, C, nb);
         st.noise = ggml_new_tensor_4d(st.sctx, GGML_TYPE_F32, W, H, C, nb);
+        st.eps   = ggml_new_tensor_4d(st.sctx, GGML_TYPE_F32, W, H, C, nb);  // CFG-pair split: this rank's weighted eps, summed in place by the exchange
+        ggml_set_name(st.eps, "sampler.eps");
         ggml_set_name(st.x, "sampler.x");
         ggml_set_name(st.noise, "sampler.noise");
         st.buf = ggml_backend_alloc_ctx_tensors(st.sctx, ctx->backend);
@@ -1214,25 +1223,41 @@ static bool sample_group_device(sdm_ctx_t* ctx, const sdm_img_gen_params_t* p, i
     ggml_backend_tensor_set_async(ctx->backend, st.x, x.data(), 0, x.size() * sizeof(float));
     ggml_backend_tensor_set_async(ctx->backend, st.noise, noise.data(), 0, noise.size() * sizeof(float));
 
+    // CFG-pair split (guidance.cpp:149-179 computed on two GPUs): this context runs ONE branch per step and writes
+    // weight * eps (weight = s on the cond rank, 1 - s on the uncond rank) to st.eps; the caller's exchange sums the two ranks' buffers in
+    // place, in HBM, ordered on the backend stream; a second small graph takes the Euler(-A) update from the sum.  Both ranks then hold the
+    // same latents (same Philox streams), so nothing else is exchanged.
+    const bool pair = ctx->pair_fn != nullptr && use_cfg;
     // conditioning of the (cond, uncond) pair, tiled over the images by the model graph's own ggml_repeat
-    const int n_model = use_cfg ? 2 * nb : nb;
-    const int ctx_n   = use_cfg ? 2 : 1;
+    const bool both   = use_cfg && !pair;
+    const int n_model = both ? 2 * nb : nb;
+    const int ctx_n   = both ? 2 : 1;
     const size_t cn   = (size_t)p->cond.ctx_dim * p->cond.n_tokens;
+    const sd_condition_t& first = (pair && ctx->pair_branch == 1) ? p->uncond : p->cond;
     std::vector<float> c2(cn * ctx_n), y2;
-    memcpy(&c2[0], p->cond.c_crossattn, cn * sizeof(float));
-    if (use_cfg) memcpy(&c2[cn], p->uncond.c_crossattn, cn * sizeof(float));
+    memcpy(&c2[0], first.c_crossattn, cn * sizeof(float));
+    if (both) memcpy(&c2[cn], p->uncond.c_crossattn, cn * sizeof(float));
     if (has_y) {
         y2.resize((size_t)p->cond.vector_dim * ctx_n);
-        memcpy(&y2[0], p->cond.c_vector, p->cond.vector_dim * sizeof(float));
-        if (use_cfg) memcpy(&y2[p->cond.vector_dim], p->uncond.c_vector, p->cond.vector_dim * sizeof(float));
+        memcpy(&y2[0], first.c_vector, p->cond.vector_dim * sizeof(float));
+        if (both) memcpy(&y2[p->cond.vector_dim], p->uncond.c_vector, p->cond.vector_dim * sizeof(float));
+    }
+    void* pair_stream = nullptr;
+    if (pair) {
+        typedef void* (*get_stream_fn)(ggml_backend_t);
+        ggml_backend_dev_t dev = ggml_backend_get_device(ctx->backend);
+        ggml_backend_reg_t reg = dev ? ggml_backend_dev_backend_reg(dev) : nullptr;
+        get_stream_fn gs       = reg ? (get_stream_fn)ggml_backend_reg_get_proc_address(reg, "ggml_backend_mi355x_get_stream") : nullptr;
+        pair_stream            = gs ? gs(ctx->backend) : nullptr;  // host backends (the CPU oracle in the tests): no stream, calls are synchronous
     }
     ModelSideInputs si;
     if (!prepare_side_inputs(ctx, W, H, n_model, p->cond.n_tokens, has_y, si)) return false;
     std::vector<float> ts(n_model);
     Runner& r = ctx->unet_runner;
     char step_sig[200];  // every step of the trajectory replays ONE cached graph: only the 8 scalars, the timesteps and the conditioning are re-uploaded
-    snprintf(step_sig, sizeof(step_sig), "step %d %d %d %d cfg%d ea%d %lld %lld y%lld %p", W, H, C, nb, (int)use_cfg, (int)euler_a + 2 * (int)flow, (long long)p->cond.ctx_dim,
-             (long long)p->cond.n_tokens, (long long)(has_y ? p->cond.vector_dim : -1), (void*)st.x);
+    snprintf(step_sig, sizeof(step_sig), "step %d %d %d %d cfg%d ea%d %lld %lld y%lld %p pair%d", W, H, C, nb, (int)use_cfg, (int)euler_a + 2 * (int)flow, (long long)p->cond.ctx_dim,
+             (long long)p->cond.n_tokens, (long long)(has_y ? p->cond.vector_dim : -1), (void*)st.x, (int)pair);
+    const std::string update_sig = std::string("update ") + step_sig;
 
     for (int i = 0; i < steps; ++i) {
         const float sigma = sigmas[i], sigma_to = sigmas[i + 1];
@@ -1241,7 +1266,7 @@ static bool sample_group_device(sdm_ctx_t* ctx, const sdm_img_gen_params_t* p, i
         std::fill(ts.begin(), ts.end(), ctx->sigma_to_t(sigma));
         // scalars of this step: {c_in, cfg scale, c_out, c_skip, a, b, noise gain, alpha}; Euler-A: x' = (a*x + b*denoised) [* alpha on flow models] + gain*noise;
         // Euler: x' = x + ((x - denoised) / a) * b with a = sigma, b = sigma_to - sigma
-        float sc[8] = {c_in, sp.txt_cfg, c_out, c_skip, 0.f, 0.f, 0.f, 1.f};
+        float sc[8] = {c_in, pair ? (ctx->pair_branch == 0 ? sp.txt_cfg : 1.0f - sp.txt_cfg) : sp.txt_cfg, c_out, c_skip, 0.f, 0.f, 0.f, 1.f};
         bool fresh_noise = false;
         if (euler_a) {
             if (sigma_to == 0.f) {
@@ -1284,15 +1309,16 @@ static bool sample_group_device(sdm_ctx_t* ctx, const sdm_img_gen_params_t* p, i
             ggml_tensor* xs     = st.x;
             ggml_tensor* noised = ggml_mul(c, xs, S(0));
             ggml_tensor* xin    = noised;
-            if (use_cfg) {  // every image twice, (cond, uncond) adjacent: [per, 1, nb] -> [per, 2, nb]
+            if (both) {  // every image twice, (cond, uncond) adjacent: [per, 1, nb] -> [per, 2, nb]
                 ggml_tensor* flat = ggml_reshape_3d(c, noised, (int64_t)per, 1, nb);
                 ggml_tensor* rep  = ggml_repeat(c, flat, ggml_new_tensor_3d(c, GGML_TYPE_F32, (int64_t)per, 2, nb));
                 xin               = ggml_reshape_4d(c, rep, W, H, C, 2 * nb);
             }
             ggml_tensor* eps = build_model_call(ctx, g, in, xin, n_model, ts.data(), c2.data(), p->cond.ctx_dim, p->cond.n_tokens, ctx_n,
                                                 has_y ? y2.data() : nullptr, p->cond.vector_dim, ctx_n, si);
+            if (pair) return ggml_cpy(c, ggml_mul(c, eps, S(1)), st.eps);  // weight * eps of this rank's branch; the update follows the exchange
             ggml_tensor* guided = eps;
-            if (use_cfg) {  // uncond + s*(cond - uncond), guidance.cpp:171
+            if (both) {  // uncond + s*(cond - uncond), guidance.cpp:171
                 ggml_tensor* e3 = ggml_reshape_3d(c, ggml_cont(c, eps), (int64_t)per, 2, nb);
                 ggml_tensor* ec = ggml_view_3d(c, e3, (int64_t)per, 1, nb, e3->nb[1], e3->nb[2], 0);
                 ggml_tensor* eu = ggml_view_3d(c, e3, (int64_t)per, 1, nb, e3->nb[1], e3->nb[2], e3->nb[1]);
@@ -1318,6 +1344,32 @@ static bool sample_group_device(sdm_ctx_t* ctx, const sdm_img_gen_params_t* p, i
             ptrs.push_back(si.pe().data());
         }
         if (!r.compute(build, nullptr, 0, step_sig, ptrs)) return false;
+        if (pair) {
+            if (!ctx->pair_fn(st.eps->data, (int64_t)(per * nb), pair_stream, ctx->pair_user)) {
+                set_error("CFG-pair exchange failed");
+                return false;
+            }
+            auto update = [&](GraphCtx& g, std::vector<HostInput>& in) {  // s*cond + (1-s)*uncond = uncond + s*(cond - uncond) is in st.eps
+                ggml_context* c  = g.ctx;
+                ggml_tensor* tsc = ggml_new_tensor_1d(c, GGML_TYPE_F32, 8);
+                ggml_set_input(tsc);
+                in.push_back({tsc, sc, sizeof(sc)});
+                auto S = [&](int k) { return ggml_view_1d(c, tsc, 1, (size_t)k * sizeof(float)); };
+                ggml_tensor* xs  = st.x;
+                ggml_tensor* den = ggml_add(c, ggml_mul(c, st.eps, S(2)), ggml_mul(c, xs, S(3)));
+                ggml_tensor* xn;
+                if (euler_a) {
+                    xn = ggml_add(c, ggml_mul(c, xs, S(4)), ggml_mul(c, den, S(5)));
+                    if (flow) xn = ggml_mul(c, xn, S(7));
+                    xn = ggml_add(c, xn, ggml_mul(c, st.noise, S(6)));
+                } else {
+                    ggml_tensor* d = ggml_div(c, ggml_sub(c, xs, den), S(4));
+                    xn             = ggml_add(c, xs, ggml_mul(c, d, S(5)));
+                }
+                return ggml_cpy(c, xn, xs);
+            };
+            if (!ctx->pair_runner.compute(update, nullptr, 0, update_sig, {sc})) return false;
+        }
     }
     ggml_backend_tensor_get(st.x, out, 0, per * nb * sizeof(float));  // synchronises the stream
     ctx->stats.unet_calls  = r.calls;
@@ -1412,6 +1464,11 @@ int sd_get_sigmas(int steps, float* out) {
     return (int)s.size();
 }
 void sd_set_guidance(sdm_ctx_t* ctx, float guidance) { ctx->guidance = guidance; }
+void sd_set_pair_exchange(sdm_ctx_t* ctx, sd_pair_exchange_fn fn, void* user, int branch) {
+    ctx->pair_fn     = fn;
+    ctx->pair_user   = user;
+    ctx->pair_branch = branch != 0;
+}
 int sd_get_flux_sigmas(int steps, int image_seq_len, float* out) {
     FluxFlowDenoiser d;
     std::vector<float> s = d.get_sigmas(steps, image_seq_len);

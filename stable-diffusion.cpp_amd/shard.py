@@ -41,50 +41,87 @@ def generate_sharded(engine, cond, uncond, *, batch_count: int, seed: int, rank:
     return out
 
 
+class _DeviceF32:
+    """A flat f32 device buffer exposed through __cuda_array_interface__ (torch.as_tensor wraps it without a copy)."""
+
+    def __init__(self, ptr: int, count: int):
+        self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f4", "data": (int(ptr), False), "version": 3, "strides": None}
+
+
+def make_pair_exchange(dist, group=None):
+    """The per-step exchange of the CFG-pair split as a torch.distributed all-reduce (SUM) on the engine's own eps buffer.
+
+    backend "nccl" (= RCCL on ROCm): the buffer is wrapped as a CUDA tensor in place and the collective is ordered on the engine's HIP stream
+    (torch.cuda.ExternalStream) — no host copy, no host synchronisation; one [N,C,H,W] f32 all-reduce per step (64 KB per SD1.5 image) over a
+    single xGMI link.  backend "gloo" (CPU tests, host backends): the buffer is host memory and is reduced in place."""
+    import ctypes
+
+    import torch
+
+    def exchange(ptr: int, count: int, stream) -> bool:
+        if dist.get_backend(group) == "nccl":
+            dev = torch.device("cuda", torch.cuda.current_device())
+            t = torch.as_tensor(_DeviceF32(ptr, count), device=dev)
+            if stream:
+                with torch.cuda.stream(torch.cuda.ExternalStream(int(stream), device=dev)):
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+                torch.cuda.synchronize()
+        else:
+            a = np.ctypeslib.as_array((ctypes.c_float * count).from_address(ptr))
+            dist.all_reduce(torch.from_numpy(a), op=dist.ReduceOp.SUM, group=group)
+        return True
+
+    return exchange
+
+
 def sample_cfg_pair_split(engine, cond, uncond, *, width: int, height: int, steps: int, cfg: float, seed: int, dist, group=None, rank_in_pair: int,
-                          batch: int = 1, eta: float = 1.0, ancestral: bool = True, cond_y=None, uncond_y=None) -> np.ndarray:
+                          batch: int = 1, eta: float = float("inf"), ancestral: bool = True, cond_y=None, uncond_y=None, exchange=None) -> np.ndarray:
     """CFG-pair split (the one real exchange step on this path): when there are fewer images than GPUs, the cond
     branch runs on one rank of a pair and the uncond branch on the other; per step the pair all-reduces (SUM) its PRE-SCALED eps —
     s*cond on the cond rank, (1-s)*uncond on the other — so the sum is uncond + s*(cond - uncond) (src/runtime/guidance.cpp:171).
-    One [N,C,H,W] f32 all-reduce per step (64 KB per SD1.5 image) over a single xGMI link with RCCL (`dist` = torch.distributed with
-    backend "nccl"; "gloo" in the CPU tests).  Both ranks then take the same Euler(-A) update (src/runtime/denoiser.hpp:1513-1546,
-    1582-1597) with the same Philox noise, so their latents stay bit-identical and nothing else is exchanged.
+    The whole trajectory stays in the engine and in HBM (sd_set_pair_exchange + the device-resident sampler): the engine hands the exchange the
+    device address of its eps buffer and the stream it was produced on, `make_pair_exchange` runs the all-reduce there.  Both ranks then take
+    the same Euler(-A) update (src/runtime/denoiser.hpp:1513-1546, 1582-1597) with the same Philox noise, so their latents stay bit-identical
+    and nothing else is exchanged.
 
     rank_in_pair: 0 = cond branch, 1 = uncond branch.  Returns the final latents [batch, C, H/8, W/8] (identical on both ranks)."""
-    import torch
+    from . import EULER, EULER_A
 
-    from . import get_sigmas, lib, philox_randn
+    engine.set_pair_exchange(exchange or make_pair_exchange(dist, group), rank_in_pair)
+    try:
+        return engine.sample_latents(cond, uncond, width=width, height=height, steps=steps, cfg=cfg, seed=seed, batch=batch, device_batch=batch,
+                                     method=EULER_A if ancestral else EULER, eta=eta, cond_y=cond_y, uncond_y=uncond_y, device_sampler=True)
+    finally:
+        engine.set_pair_exchange(None)
 
-    h, w = height // 8, width // 8
-    C = 4
-    per = C * h * w
-    sig = get_sigmas(steps)
-    x = np.stack([philox_randn(seed + b, 0, per).reshape(C, h, w) * sig[0] for b in range(batch)]).astype(np.float32)
-    offs = [1] * batch
-    mine, my_y = (cond, cond_y) if rank_in_pair == 0 else (uncond, uncond_y)
-    weight = np.float32(cfg) if rank_in_pair == 0 else np.float32(1.0 - cfg)
-    for i in range(steps):
-        s, s_to = np.float32(sig[i]), np.float32(sig[i + 1])
-        c_in = np.float32(1.0) / np.sqrt(s * s + np.float32(1.0))   # CompVisDenoiser::get_scalings, denoiser.hpp:1167-1172
-        t = np.full((batch,), lib().sd_sigma_to_t(float(s)), dtype=np.float32)
-        eps = engine.unet_forward(x * c_in, t, mine, my_y) * weight
-        buf = torch.from_numpy(np.ascontiguousarray(eps))
-        if dist.get_backend(group) == "nccl":
-            dev = buf.cuda()
-            dist.all_reduce(dev, op=dist.ReduceOp.SUM, group=group)
-            guided = dev.cpu().numpy()
-        else:
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
-            guided = buf.numpy()
-        den = guided * (-s) + x
-        if not ancestral or s_to == 0:
-            x = den if s_to == 0 else x + (x - den) / s * (s_to - s)
-            continue
-        up = np.float32(min(float(s_to), eta * float(np.sqrt(max(float(s_to) ** 2 * (float(s) ** 2 - float(s_to) ** 2) / float(s) ** 2, 0.0)))))
-        down = np.float32(np.sqrt(max(float(s_to) ** 2 - float(up) ** 2, 0.0)))
-        r = np.float32(down / s)
-        x = r * x + (np.float32(1) - r) * den
-        for b in range(batch):
-            x[b] = x[b] + philox_randn(seed + b, offs[b], per).reshape(C, h, w) * up
-            offs[b] += 1
-    return x.astype(np.float32)
+
+def generate_multi_device(engines, cond, uncond, *, batch_count: int, seed: int, decode=False, **kw) -> dict:
+    """One process x N devices: `engines` are contexts created on different devices (Engine(backend="MI355X<i>")); every engine runs its
+    contiguous share of the images (shard_indices) on its own host thread — each backend instance owns its device stream, plan cache and
+    arena, and ctypes releases the GIL for the duration of a call, so the N trajectories run concurrently.  The alternative to one process per
+    GPU (torchrun) when the caller is a single server process.  Returns {image index: result}."""
+    import threading
+
+    world = len(engines)
+    results, errors = [None] * world, [None] * world
+
+    def run(r):
+        try:
+            results[r] = generate_sharded(engines[r], cond, uncond, batch_count=batch_count, seed=seed, rank=r, world=world, decode=decode, **kw)
+        except BaseException as e:  # surfaced on the caller's thread
+            errors[r] = e
+
+    threads = [threading.Thread(target=run, args=(r,), name=f"sd-device-{r}") for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for e in errors:
+        if e is not None:
+            raise e
+    out = {}
+    for r in results:
+        out.update(r)
+    return out
