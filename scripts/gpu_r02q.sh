@@ -1,6 +1,9 @@
 D=gpurun_out/r02q
-timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_model.py -m gpu -x -q -k "flash or attention or unet" 2>&1 | grep -E "^E|assert|passed|failed" | head -20
+mkdir -p $D
+timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_model.py -m gpu -x -q 2>&1 | tail -3
 for v in 0 1 0 1; do
-MI355X_KTIME_DUMP=$D/shapes_mslot$v.txt timeout 500 python scripts/family_times.py sd15 flash_mslot=$v 2>&1 | grep -E "==|flash"
+timeout 500 python scripts/family_times.py sd15 gemm16_bn64=$v 2>&1 | grep -E "==|Linear"
 done
-grep "343.597" $D/shapes_mslot*.txt
+for v in 0 1; do
+timeout 500 python scripts/family_times.py sdxl gemm16_bn64=$v 2>&1 | grep -E "==|Linear"
+done

@@ -1820,6 +1820,7 @@ void planner_set_option(const char* key, int value) {
     else if (!strcmp(key, "qgemv")) g_opt.qgemv = value;
     else if (!strcmp(key, "fuse_q16")) g_opt.fuse_q16 = value;
     else if (!strcmp(key, "flash_grid")) flash_attn_set_grid(value);
+    else if (!strcmp(key, "gemm16_bn64")) gemm16_set_bn64(value);
     else if (!strcmp(key, "flash_mslot")) flash_attn_set_mslot(value);
     else if (!strcmp(key, "fuse_chan_add")) g_opt.fuse_chan_add = value;
     else if (!strcmp(key, "fuse_proj_tokens")) g_opt.fuse_proj_tokens = value;

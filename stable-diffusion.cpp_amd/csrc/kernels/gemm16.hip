@@ -694,29 +694,45 @@ __global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g
             compute(kt & 1);
         }
     } else {
-        // 3-deep ring, COUNTED waits: two tiles of DMA stay in flight across the barrier (cdna_hip_programming.md T3+T4):
-        // vmcnt(NPT) retires tile kt while tile kt+1 is still streaming; tile kt+2 is issued right after the barrier.
-        stage(kt0, 0, c_tap, c_kh, c_kw, c_icb, c_sub);
-        G16_ADVANCE();
-        if (nt > 1) {
-            stage(kt0 + 1, 1, c_tap, c_kh, c_kw, c_icb, c_sub);
+        // NST-deep ring, COUNTED waits: NST-1 tiles of DMA are issued ahead and up to NST-2 stay in flight across the barrier
+        // (cdna_hip_programming.md T3+T4): the wait retires tile kt while the younger tiles keep streaming; tile kt+NST-1 is issued right
+        // after the barrier into the slot tile kt-1 just left.  (Deeper rings were measured for launches that leave one workgroup per CU —
+        // 5 and 6 stages on the 128x128 tile, profiles/r02q_tile_sweep.txt — and change nothing: those k-steps are not bound by the
+        // prefetch distance.)
+        constexpr int PD = NST - 1;
+        static_assert(PD * NPT <= 63, "vmcnt is a 6-bit counter");
+        for (int i = 0; i < PD && i < nt; ++i) {
+            stage(kt0 + i, i, c_tap, c_kh, c_kw, c_icb, c_sub);
             G16_ADVANCE();
         }
-        int buf = 0;
+        int buf = 0, fill = PD % NST;  // fill = slot of the next tile to stage
         for (int kt = 0; kt < nt; ++kt) {
-            if (kt + 1 >= nt)
+            const int ahead = min(PD - 1, nt - 1 - kt);  // younger tiles that may stay in flight
+            if (ahead <= 0) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else if (w_short)
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPT - 1) : "memory");
-            else
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPT) : "memory");
+            } else if (w_short) {
+                switch (ahead) {
+                    case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * (NPT - 1)) : "memory"); break;
+                    case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NPT - 1)) : "memory"); break;
+                    case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (NPT - 1)) : "memory"); break;
+                    default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PD - 1) * (NPT - 1)) : "memory"); break;
+                }
+            } else {
+                switch (ahead) {
+                    case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * NPT) : "memory"); break;
+                    case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPT > 63 ? 63 : 2 * NPT) : "memory"); break;
+                    case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NPT > 63 ? 63 : 3 * NPT) : "memory"); break;
+                    default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PD - 1) * NPT) : "memory"); break;
+                }
+            }
             __builtin_amdgcn_s_barrier();
-            if (kt + 2 < nt) {
-                stage(kt0 + kt + 2, buf >= 1 ? buf - 1 : 2, c_tap, c_kh, c_kw, c_icb, c_sub);  // (kt+2)%3
+            if (kt + PD < nt) {
+                stage(kt0 + kt + PD, fill, c_tap, c_kh, c_kw, c_icb, c_sub);
                 G16_ADVANCE();
+                fill = fill == NST - 1 ? 0 : fill + 1;
             }
             compute(buf);
-            buf = buf == 2 ? 0 : buf + 1;
+            buf = buf == NST - 1 ? 0 : buf + 1;
         }
     }
 
@@ -779,7 +795,7 @@ static inline bool g16_bk32() { return g_g16_variant == 1 || g_g16_variant == 3;
 //   T160   256x160, 4 waves of 64x160  (78 KB, 2/CU)                 — outputs that are multiples of 160 but not of 128 (SD1.5's 320):
 //                                                                       no padded columns, 2 column tiles instead of 3
 //   T160N  256x160, 8 waves of 32x160  (78 KB, 2/CU)                 — T160 with twice the waves in flight (experiment)
-enum { G16_T128 = 0, G16_T256 = 1, G16_T256W = 2, G16_T160 = 3, G16_T160N = 4, G16_T320 = 5, G16_T256P = 6 };
+enum { G16_T128 = 0, G16_T256 = 1, G16_T256W = 2, G16_T160 = 3, G16_T160N = 4, G16_T320 = 5, G16_T256P = 6, G16_T128N64 = 7 };
 static int g_g16_force_tile = -1;  // option "gemm16_tile": force one configuration (A/B measurements); -1 = choose per shape
 void gemm16_set_tile(int t) { g_g16_force_tile = t; }
 // Per-shape choice.  Measured on SD1.5 batch 16 (profiles/r01e_tile_configs.txt): a launch takes ceil(workgroups / resident slots)
@@ -790,6 +806,8 @@ void gemm16_set_tile(int t) { g_g16_force_tile = t; }
 static int g_g16_abl = 0;  // option "gemm16_abl": 1 = no MFMAs, 2 = no DMA after the fill, 3 = conv input tiles fetched for tap 0 only (T320 only; wrong results, timing)
 void gemm16_set_abl(int v) { g_g16_abl = v; }
 #endif
+static int g_g16_bn64 = 1;  // option "gemm16_bn64": 0 = 64-column tiles only for M <= 64 (A/B measurements)
+void gemm16_set_bn64(int v) { g_g16_bn64 = v; }
 static int g_g16_t320 = 1;  // option "gemm16_t320": 0 disables the pipelined 256x320 tile in the per-shape choice (A/B measurements)
 void gemm16_set_t320(int v) { g_g16_t320 = v; }
 int gemm16_split_k(int64_t rows, int64_t M, int64_t K);
@@ -1046,8 +1064,10 @@ void launch_gemm16_linear(hipStream_t s, float* dst, void* dst16, int64_t ldd16,
         g.dst      = splitk_ws;
         g.ep       = G16Epi{nullptr, nullptr, e.scale};
     }
-    // narrow outputs (M = 320: 2.5 tiles of 128) waste less with 64-wide column tiles
-    const bool bn64 = M <= 64 || (g_g16_force_tile == 7 && M % 64 == 0 && !hm_d);
+    // 64-column tiles: narrow outputs, and small grids (<= 128 tiles of 128x128 on 256 CUs: the cross-attention K/V projections of the 77-token
+    // context, the time-embedding Linears) where twice the workgroups matter more than the tile's arithmetic intensity (r02q: 1232x768->768 36 -> 21 us)
+    const int64_t c128_ = ((rows + 127) / 128) * ((M + 127) / 128);
+    const bool bn64 = M <= 64 || (M % 64 == 0 && g16_bk32() && (g_g16_force_tile == G16_T128N64 || (g_g16_force_tile < 0 && g_g16_bn64 && c128_ <= 128)));
     if (g16_trace()) fprintf(stderr, "G16 linear rows=%lld K=%lld M=%lld res=%d hm=%d f16out=%d\n", (long long)rows, (long long)K, (long long)M, e.residual ? 1 : 0, hm_d, dst16 ? 1 : 0);
     if (bn64) {
         g.ncol_tiles = (int)((M + 63) / 64);
