@@ -41,11 +41,11 @@ namespace {
 struct Stats {
     std::atomic<int64_t> graphs_computed{0}, plans_built{0}, nodes_seen{0}, kernels_planned{0}, kernels_launched{0}, fused_conv{0},
         fused_conv_bounced{0}, fused_linear{0}, fused_norm{0}, fused_geglu{0}, fused_attention{0}, generic_matmul{0}, swizzled_weight_bytes{0}, fused_linear_geglu{0}, split_k_gemms{0}, head_major_gemms{0}, fused_modulate{0}, fused_gate{0}, fused_gelu{0}, fused_rope{0}, fused_concat_heads{0},
-        graph_replays{0}, qgemv_linears{0}, fused_chan_add{0}, fused_proj_tokens{0}, gemm_attention{0}, fused_q16{0};
+        graph_replays{0}, qgemv_linears{0}, fused_chan_add{0}, fused_proj_tokens{0}, gemm_attention{0}, fused_q16{0}, split_k_inlaunch{0}, qgemm16_linears{0}, fgemv_linears{0}, fused_presilu{0};
 } g_stats;
 
 struct Options {
-    std::atomic<int> fusion{1}, mfma_gemm{1}, hip_graph{0}, flash_pattern{1}, gemm16{1}, fuse_modulate{1}, fuse_gate{1}, fuse_gelu{1}, fuse_rope{1}, fuse_concat_heads{1}, qgemv{1}, fuse_chan_add{1}, fuse_proj_tokens{1}, fuse_q16{1};
+    std::atomic<int> fusion{1}, mfma_gemm{1}, hip_graph{0}, flash_pattern{1}, gemm16{1}, fuse_modulate{1}, fuse_gate{1}, fuse_gelu{1}, fuse_rope{1}, fuse_concat_heads{1}, qgemv{1}, fuse_chan_add{1}, fuse_proj_tokens{1}, fuse_q16{1}, qgemm16{1}, fgemv{1};
 } g_opt;
 
 using Step = std::function<void(hipStream_t)>;
@@ -240,6 +240,7 @@ struct Builder {
     std::unordered_map<const ggml_tensor*, Packed> packed;           // graph tensor -> f16 operand image
     std::unordered_map<const ggml_tensor*, size_t> q16;              // flash Q operand (the RESHAPE the node reads) -> f16 head-major image in the arena
     std::unordered_map<const ggml_tensor*, const ggml_tensor*> ups;  // deferred nearest-x2 UPSCALE node -> its source
+    std::unordered_map<const ggml_tensor*, const ggml_tensor*> presilu;  // deferred SiLU node in front of a few-row Linear -> its source (applied by k_fgemv / k_qgemv on load)
     std::map<int, std::vector<Step>> deferred;                       // steps to run once the walk reaches graph node <key>
     Builder(Planner* p, Plan* pl, const ggml_cgraph* g) : P(p), plan(pl), gi(g) {}
     void emit(Step s) { plan->steps.push_back(std::move(s)); }
@@ -269,6 +270,43 @@ struct Builder {
         const size_t off = (arena_off + 255) & ~(size_t)255;
         arena_off        = off + bytes;
         return off;
+    }
+    // ---- split-K of one GEMM launch (kernels.h: gemm16_split_plan).  In-launch combines take their tile counters from one block of this plan's
+    // arena share; the plan zeroes the used part with a single memset ahead of its first launch (build_plan).
+    static constexpr size_t CNT_CAP = 1u << 18;
+    size_t cnt_off = 0, cnt_used = 0;
+    bool cnt_alloc = false;
+    struct Split {
+        int S          = 1;
+        bool inkernel  = false;
+        size_t wsoff   = 0, cnt_rel = 0, cnt_base = 0;
+        float* ws(const Planner* p) const { return S > 1 ? (float*)(p->arena + wsoff) : nullptr; }  // resolved at launch: the arena may have grown
+        int* cnt(const Planner* p) const { return inkernel ? (int*)(p->arena + cnt_base) + cnt_rel : nullptr; }
+    };
+    Split plan_split(int64_t rows, int64_t M, int64_t K, bool conv, bool plain_out) {
+        Split r;
+        G16SplitPlan sp = gemm16_split_plan(rows, M, K, conv, plain_out);
+        if (sp.S > 1 && sp.inkernel && cnt_used + (size_t)sp.tiles > CNT_CAP) {  // counter block full: the slab + reduce pass where it applies
+            sp.inkernel = false;
+            sp.S        = plain_out ? gemm16_split_k(rows, M, K) : 1;
+            sp.ws_bytes = (size_t)sp.S * rows * M * 4;
+        }
+        if (sp.S <= 1) return r;
+        if (sp.inkernel) {
+            if (!cnt_alloc) {
+                cnt_off   = alloc(CNT_CAP * sizeof(int));
+                cnt_alloc = true;
+            }
+            r.cnt_base = cnt_off;
+            r.cnt_rel  = cnt_used;
+            cnt_used += (size_t)sp.tiles;
+            g_stats.split_k_inlaunch++;
+        }
+        r.S        = sp.S;
+        r.inkernel = sp.inkernel;
+        r.wsoff    = alloc(sp.ws_bytes);
+        g_stats.split_k_gemms++;
+        return r;
     }
 };
 
@@ -547,24 +585,58 @@ void plan_linear(Builder& B, int i, hipStream_t s, std::vector<int>& chain) {
             }
         }
     }
-    // q8_0 / q4_0 weights under a few activation rows (adaLN / modulation vectors): stream the RAW quantised blocks once, dequantise in
-    // registers (qgemm.hip) — no f16 weight image is ever built for these tensors
-    if (g_opt.qgemv && hm_d == 0 && !ep.gate && gelu_out < 0 && geglu_out < 0 && qgemv_supported((int)w->type, tokens, K) && x->nb[0] == 4 &&
-        (x->ne[2] == 1 || x->nb[2] == x->nb[1] * (size_t)x->ne[1]) && (x->ne[3] == 1 || x->nb[3] == x->nb[2] * (size_t)x->ne[2]) && aligned16(x->data) &&
-        x->nb[1] % 16 == 0) {
+    // few activation rows (adaLN / modulation vectors, time-embedding MLP, ResBlock embedding projections): one weight-streaming launch.
+    // A SiLU node in front of such a Linear was deferred (build_plan): the kernels apply it while staging the rows.
+    const auto psi             = B.presilu.find(x);
+    const ggml_tensor* xsrc    = psi != B.presilu.end() ? psi->second : x;
+    const bool simple_rows     = x->nb[0] == 4 && (x->ne[2] == 1 || x->nb[2] == x->nb[1] * (size_t)x->ne[1]) && (x->ne[3] == 1 || x->nb[3] == x->nb[2] * (size_t)x->ne[2]) &&
+                             aligned16(xsrc->data) && x->nb[1] % 16 == 0 && xsrc->nb[1] == x->nb[1];
+    const bool plain_epi       = hm_d == 0 && !ep.gate && gelu_out < 0 && geglu_out < 0;
+    // the chain's output must not land on rows the kernel is still reading (the deferred SiLU's source may have been released by the allocator)
+    const ggml_tensor* lastt   = gi.node(last);
+    const bool src_safe        = xsrc == x || !overlaps(lastt->data, ggml_abi_nbytes(lastt), xsrc->data, ggml_abi_nbytes(xsrc));
+    // q8_0 / q4_0 weights under one or two rows: stream the RAW quantised blocks once, dequantise in registers (qgemm.hip) — no f16 weight image is ever built for these tensors
+    if (g_opt.qgemv && plain_epi && simple_rows && src_safe && qgemv_supported((int)w->type, tokens, K)) {
         const size_t wsoff = B.alloc(qgemv_workspace_bytes(tokens, K));
         Planner* P         = B.P;
         float* qdst        = (float*)gi.node(last)->data;
-        const float* qx    = (const float*)x->data;
+        const float* qx    = (const float*)xsrc->data;
         const int64_t qxs  = (int64_t)x->nb[1] / 4;
         const void* wraw   = w->data;
         const int wt       = (int)w->type;
-        B.emit_at(emit_node, i, [=](hipStream_t st) { launch_qgemv(st, qdst, M, qx, qxs, tokens, wraw, wt, K, M, P->arena + wsoff, ep, 1.0f); });
+        const bool silu    = xsrc != x;
+        B.emit_at(emit_node, i, [=](hipStream_t st) { launch_qgemv(st, qdst, M, qx, qxs, tokens, wraw, wt, K, M, P->arena + wsoff, ep, 1.0f, silu); });
         g_stats.qgemv_linears++;
         g_stats.fused_linear++;
+        if (silu) g_stats.fused_presilu++;
         return;
     }
-    const void* swz = get_swz_linear(B.P, w, s, geglu_out >= 0);
+    // f16 / f32 weights under <= 16 rows: k_fgemv (f32 weights keep f32 x f32 like ggml-cpu; the MFMA image would round them to f16)
+    if (g_opt.fgemv && plain_epi && simple_rows && src_safe && emit_node == i && fgemv_supported((int)w->type, tokens, K) && aligned16(w->data)) {
+        float* fdst       = (float*)gi.node(last)->data;
+        const float* fx   = (const float*)xsrc->data;
+        const int64_t fxs = (int64_t)x->nb[1] / 4;
+        const void* wp    = w->data;
+        const int wt      = (int)w->type;
+        const bool silu   = xsrc != x;
+        B.emit([=](hipStream_t st) { launch_fgemv(st, fdst, M, fx, fxs, tokens, wp, wt, K, M, ep, silu); });
+        g_stats.fgemv_linears++;
+        g_stats.fused_linear++;
+        if (silu) g_stats.fused_presilu++;
+        return;
+    }
+    if (xsrc != x) {  // the Linear goes to a GEMM after all: run the deferred SiLU now
+        float* ud       = (float*)x->data;
+        const float* us = (const float*)xsrc->data;
+        const int64_t un = ggml_abi_nelements(x);
+        B.emit([=](hipStream_t st) { launch_unary(st, UN_SILU, ud, us, un); });
+    }
+    // ... and under a few hundred rows (text-stream Linears, text encoders): the raw blocks again, dequantised in registers on the way into the
+    // MFMA units (k_qgemm16) — below ~300 rows a GEMM is bound by its weight stream, and the quantised stream is 1.9x / 3.6x smaller
+    const bool useq  = g_opt.gemm16 && g_opt.qgemm16 && hm_d == 0 && geglu_out < 0 && qgemm16_supported((int)w->type, tokens, K, M);
+    const void* wraw = w->data;
+    const int wt     = (int)w->type;
+    const void* swz = useq ? nullptr : get_swz_linear(B.P, w, s, geglu_out >= 0);
     float* dst      = (float*)gi.node(last)->data;
     const float* xp = (const float*)x->data;
     const int64_t xs = (int64_t)x->nb[1] / 4;
@@ -594,7 +666,13 @@ void plan_linear(Builder& B, int i, hipStream_t s, std::vector<int>& chain) {
             g_stats.fused_linear_geglu++;
         } else if (gelu_out >= 0) {
             const size_t ooff = B.alloc((size_t)tokens * M * 2);
-            B.emit([=](hipStream_t st) { launch_gemm16_linear(st, nullptr, P->arena + ooff, M, P->arena + off, ld, swz, tokens, K, M, M, ep); });
+            if (useq) {
+                B.emit([=](hipStream_t st) { launch_qgemm16(st, nullptr, P->arena + ooff, M, P->arena + off, ld, tokens, wraw, wt, K, M, ep); });
+                g_stats.qgemm16_linears++;
+            } else {
+                const Builder::Split sk = B.plan_split(tokens, M, K, false, false);
+                B.emit([=](hipStream_t st) { launch_gemm16_linear(st, nullptr, P->arena + ooff, M, P->arena + off, ld, swz, tokens, K, M, M, ep, 0, 0, 0, sk.ws(P), sk.cnt(P), sk.S); });
+            }
             B.packed[gi.node(gelu_out)] = Packed{ooff, M, false};
             g_stats.fused_gelu++;
         } else if (hm_d > 0) {
@@ -618,19 +696,24 @@ void plan_linear(Builder& B, int i, hipStream_t s, std::vector<int>& chain) {
                 const size_t qoff        = B.alloc((size_t)tokens * M * 2);
                 B.q16[gi.node(qview)]    = qoff;
                 g_stats.fused_q16++;
-                B.emit([=](hipStream_t st) { launch_gemm16_linear(st, nullptr, P->arena + qoff, 0, P->arena + off, ld, swz, tokens, K, M, M, ep, hd, hH, hL); });
+                const Builder::Split sk = B.plan_split(tokens, M, K, false, false);
+                B.emit([=](hipStream_t st) { launch_gemm16_linear(st, nullptr, P->arena + qoff, 0, P->arena + off, ld, swz, tokens, K, M, M, ep, hd, hH, hL, sk.ws(P), sk.cnt(P), sk.S); });
             } else {
+                const Builder::Split sk = hL >= 32 ? B.plan_split(tokens, M, K, false, false) : Builder::Split();
                 B.emit([=](hipStream_t st) {
-                    launch_gemm16_linear(st, f16o ? nullptr : (float*)hdst, f16o ? hdst : nullptr, 0, P->arena + off, ld, swz, tokens, K, M, M, ep, hd, hH, hL);
+                    launch_gemm16_linear(st, f16o ? nullptr : (float*)hdst, f16o ? hdst : nullptr, 0, P->arena + off, ld, swz, tokens, K, M, M, ep, hd, hH, hL, sk.ws(P), sk.cnt(P), sk.S);
                 });
             }
-        } else {
-            const int S       = gemm16_split_k(tokens, M, K);
+        } else if (useq) {
+            const int S        = ep.gate ? 1 : qgemm16_split_k(tokens, K, M);
             const size_t wsoff = S > 1 ? B.alloc((size_t)S * tokens * M * 4) : 0;
-            if (S > 1) g_stats.split_k_gemms++;
             B.emit_at(emit_node, i, [=](hipStream_t st) {
-                launch_gemm16_linear(st, dst, nullptr, 0, P->arena + off, ld, swz, tokens, K, M, M, ep, 0, 0, 0, S > 1 ? (float*)(P->arena + wsoff) : nullptr);
+                launch_qgemm16(st, dst, nullptr, 0, P->arena + off, ld, tokens, wraw, wt, K, M, ep, S > 1 ? (float*)(P->arena + wsoff) : nullptr, S);
             });
+            g_stats.qgemm16_linears++;
+        } else {
+            const Builder::Split sk = B.plan_split(tokens, M, K, false, !ep.gate);
+            B.emit_at(emit_node, i, [=](hipStream_t st) { launch_gemm16_linear(st, dst, nullptr, 0, P->arena + off, ld, swz, tokens, K, M, M, ep, 0, 0, 0, sk.ws(P), sk.cnt(P), sk.S); });
         }
     }
     g_stats.fused_linear++;
@@ -786,12 +869,8 @@ bool plan_conv_chain(Builder& B, int i, hipStream_t s, std::vector<int>& chain) 
             g_stats.fused_proj_tokens++;
             return true;
         }
-        const int S        = gemm16_split_k(opos, OC, rup64(IC) * ks * ks);
-        const size_t wsoff = S > 1 ? B.alloc((size_t)S * opos * OC * 4) : 0;
-        if (S > 1) g_stats.split_k_gemms++;
-        B.emit_at(emit_node, i, [=](hipStream_t st) {
-            launch_gemm16_conv(st, final_dst, P->arena + off, swz, SW, SH, IC, N, OC, ks, st_, pd, upscale, ep, S > 1 ? (float*)(P->arena + wsoff) : nullptr);
-        });
+        const Builder::Split sk = B.plan_split(opos, OC, rup64(IC) * ks * ks, true, true);
+        B.emit_at(emit_node, i, [=](hipStream_t st) { launch_gemm16_conv(st, final_dst, P->arena + off, swz, SW, SH, IC, N, OC, ks, st_, pd, upscale, ep, sk.ws(P), sk.cnt(P), sk.S); });
         g_stats.fused_conv++;
         return true;
     }
@@ -1524,6 +1603,23 @@ bool build_plan(Planner* P, Plan* plan, const ggml_cgraph* g, hipStream_t s) {
                 if (!ok) ok = plan_rope(B, i, s, chain);
                 if (!ok) ok = plan_tokens_to_conv(B, i, s, chain);
                 break;
+            case GGML_OP_UNARY: {
+                // SiLU feeding only the NEXT node, a Linear with a handful of rows (ResBlock emb_layers, time_embed.2, the DiT vector embedders):
+                // applied by the weight-streaming kernel while it stages the rows (plan_linear); adjacency keeps the source rows alive
+                const ggml_tensor* src = n->src[0];
+                const int c            = gi.sole(i);
+                if (g_opt.fusion && (g_opt.fgemv || g_opt.qgemv) && ggml_abi_get_unary_op(n) == GGML_UNARY_OP_SILU && c == i + 1 && is_f32(src) && contig(src) && contig(n) &&
+                    !(n->flags & GGML_TENSOR_FLAG_OUTPUT) && gi.node(c)->op == GGML_OP_MUL_MAT && gi.node(c)->src[1] == n && linear_fast_ok(gi.node(c))) {
+                    const ggml_tensor* w = gi.node(c)->src[0];
+                    const int64_t rows   = n->ne[1] * n->ne[2] * n->ne[3];
+                    if ((g_opt.fgemv && fgemv_supported((int)w->type, rows, w->ne[0])) || (g_opt.qgemv && qgemv_supported((int)w->type, rows, w->ne[0]))) {
+                        B.presilu[n] = src;
+                        chain        = {i};
+                        ok           = true;
+                    }
+                }
+                break;
+            }
             case GGML_OP_UPSCALE: {
                 // nearest x2 feeding only an implicit-GEMM conv (UpSampleBlock, block.hpp:57-64): fold into the conv's gather
                 const ggml_tensor* src = n->src[0];
@@ -1548,6 +1644,11 @@ bool build_plan(Planner* P, Plan* plan, const ggml_cgraph* g, hipStream_t s) {
             return false;
         }
         gi.done[i] = 1;
+    }
+    if (B.cnt_used > 0) {  // tile counters of the in-launch split-K combines: zero before the first launch of every run
+        Planner* PP          = P;
+        const size_t coff    = B.cnt_off, cbytes = B.cnt_used * sizeof(int);
+        plan->steps.insert(plan->steps.begin(), [=](hipStream_t st) { (void)hipMemsetAsync(PP->arena + coff, 0, cbytes, st); });
     }
     plan->n_nodes      = g->n_nodes;
     plan->arena_needed = B.arena_off;
@@ -1801,6 +1902,10 @@ void planner_get_stats(ggml_backend_mi355x_stats* o) {
     o->fused_proj_tokens     = g_stats.fused_proj_tokens;
     o->gemm_attention        = g_stats.gemm_attention;
     o->fused_q16             = g_stats.fused_q16;
+    o->split_k_inlaunch      = g_stats.split_k_inlaunch;
+    o->qgemm16_linears       = g_stats.qgemm16_linears;
+    o->fgemv_linears         = g_stats.fgemv_linears;
+    o->fused_presilu         = g_stats.fused_presilu;
     o->fused_attention       = g_stats.fused_attention;
     o->generic_matmul        = g_stats.generic_matmul;
     o->swizzled_weight_bytes = g_stats.swizzled_weight_bytes;
@@ -1821,6 +1926,12 @@ void planner_set_option(const char* key, int value) {
     else if (!strcmp(key, "fuse_q16")) g_opt.fuse_q16 = value;
     else if (!strcmp(key, "flash_grid")) flash_attn_set_grid(value);
     else if (!strcmp(key, "gemm16_bn64")) gemm16_set_bn64(value);
+    else if (!strcmp(key, "qgemm16")) g_opt.qgemm16 = value;
+    else if (!strcmp(key, "fgemv")) g_opt.fgemv = value;
+    else if (!strcmp(key, "fgemv_max_rows")) fgemv_set_max_rows(value);
+    else if (!strcmp(key, "qgemm16_max_rows")) qgemm16_set_max_rows(value);
+    else if (!strcmp(key, "splitk_inkernel")) gemm16_set_splitk_inkernel(value);
+    else if (!strcmp(key, "splitk_in_target")) gemm16_set_splitk_in_target(value);
     else if (!strcmp(key, "flash_mslot")) flash_attn_set_mslot(value);
     else if (!strcmp(key, "fuse_chan_add")) g_opt.fuse_chan_add = value;
     else if (!strcmp(key, "fuse_proj_tokens")) g_opt.fuse_proj_tokens = value;

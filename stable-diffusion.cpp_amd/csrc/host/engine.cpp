@@ -627,9 +627,63 @@ int64_t sd_load_weights_prefixed(sdm_ctx_t* ctx, const char* path, const char* p
             ++missing;
             continue;
         }
-        const FileTensor& ft = *it->second;
         ggml_tensor* t       = nt.second;
         const int64_t n      = ggml_nelements(t);
+        // a fused parameter the file keeps as separate tensors (diffusers DiT q / k / v [/ proj_mlp], name_conversion.hpp: "<name>", "<name>.1",
+        // "<name>.2", ...): stack the parts along the output dimension (rows of a weight, elements of a bias)
+        if (dir.count(nt.first + ".1")) {
+            std::vector<const FileTensor*> parts{it->second};
+            for (int k = 1;; ++k) {
+                auto pk = dir.find(nt.first + "." + std::to_string(k));
+                if (pk == dir.end()) break;
+                parts.push_back(pk->second);
+            }
+            const int64_t inner = ggml_n_dims(t) >= 2 ? t->ne[0] : 1, outer_total = n / inner;
+            int64_t outer_sum = 0;
+            bool ok = ggml_n_dims(t) <= 2, native_same = true;
+            for (const FileTensor* pt : parts) {
+                int64_t pn = 1;
+                for (int d = 0; d < 4; ++d) pn *= pt->ne[d];
+                ok = ok && pn % inner == 0 && (inner == 1 || pt->ne[0] == inner) && pt->n_dims <= 2;
+                const uint64_t want = pt->kind != SrcKind::NATIVE ? pt->nbytes : (uint64_t)ggml_row_size(pt->type, pt->ne[0]) * (uint64_t)(pn / pt->ne[0]);
+                ok = ok && pt->nbytes == want;
+                outer_sum += pn / inner;
+                native_same = native_same && pt->kind == SrcKind::NATIVE && pt->type == t->type;
+            }
+            if (!ok || outer_sum != outer_total) {
+                set_error("fused parts do not add up to the shape of " + nt.first);
+                fclose(f);
+                return -1;
+            }
+            if (!native_same) f32.assign((size_t)n, 0.f);
+            int64_t o0 = 0;  // first output row of the current part
+            for (size_t k = 0; k < parts.size(); ++k) {
+                const FileTensor& pt = *parts[k];
+                int64_t pn = 1;
+                for (int d = 0; d < 4; ++d) pn *= pt.ne[d];
+                raw.resize(pt.nbytes);
+                if (fseek(f, (long)pt.offset, SEEK_SET) != 0 || fread(raw.data(), 1, pt.nbytes, f) != pt.nbytes) {
+                    set_error("short read for " + nt.first);
+                    fclose(f);
+                    return -1;
+                }
+                if (native_same) {
+                    ggml_backend_tensor_set(t, raw.data(), (size_t)o0 * ggml_row_size(t->type, inner), pt.nbytes);
+                } else if (pt.kind != SrcKind::NATIVE) {
+                    decode_src_kind(pt.kind, raw.data(), pn, f32.data() + o0 * inner);
+                } else {
+                    const int64_t rows = pn / pt.ne[0];
+                    const size_t rs    = ggml_row_size(pt.type, pt.ne[0]);
+                    for (int64_t r = 0; r < rows; ++r) ggml_dequantize_row(pt.type, raw.data() + r * rs, f32.data() + o0 * inner + r * pt.ne[0], pt.ne[0]);
+                }
+                o0 += pn / inner;
+                used[nt.first + (k ? "." + std::to_string(k) : std::string())] = true;
+            }
+            if (!native_same) ctx->unet_runner.upload_f32(t, f32.data(), conv);
+            ++loaded;
+            continue;
+        }
+        const FileTensor& ft = *it->second;
         int64_t fn           = 1;
         for (int d = 0; d < 4; ++d) fn *= ft.ne[d];
         // shapes must agree up to trailing 1s; Linear / conv weights additionally dim by dim (torch [out,in,kh,kw] == ggml [kw,kh,in,out]);

@@ -193,6 +193,88 @@ inline std::string t5_to_hf(const std::string& name) {
     return name;
 }
 
+// ---- diffusers SD3Transformer2DModel / FluxTransformer2DModel -> original MMDiT / Flux names ------------------------------------------
+// (name_conversion.cpp:452-556 convert_diffusers_dit_to_original_sd3, :558-683 convert_diffusers_dit_to_original_flux).  diffusers keeps
+// q / k / v (and FLUX's single-block proj_mlp) as separate Linears; the original models own ONE fused Linear whose output rows are the
+// parts in order.  Like the reference, a part other than the first is named "<fused name>.<part index>" ("...attn.qkv.weight.1"): the
+// loader (engine.cpp sd_load_weights) stacks "<name>", "<name>.1", "<name>.2", ... along the output dimension.  Names that are already in
+// the original dialect pass through unchanged.
+inline std::string part_suffix(int part) { return part > 0 ? "." + std::to_string(part) : std::string(); }
+
+inline std::string dit_attn_member(const std::vector<std::string>& p, size_t i, bool flux, bool single, const std::string& attn) {
+    // p[i] = to_q | to_k | to_v | add_q_proj | ... | norm_q | norm_k | norm_added_q | norm_added_k | to_out | to_add_out;  attn = "attn" | "attn2"
+    const std::string& m = p[i];
+    const std::string leaf = join_from(p, i + 1);
+    const std::string xs = flux ? (single ? "" : "img_" + attn + ".") : "x_block." + attn + ".";
+    const std::string cs = flux ? "txt_" + attn + "." : "context_block." + attn + ".";
+    const std::string fused = single ? "linear1." : "qkv.";
+    static const char* qkv[3] = {"q", "k", "v"};
+    for (int k = 0; k < 3; ++k) {
+        if (m == std::string("to_") + qkv[k]) return xs + fused + leaf + part_suffix(k);
+        if (m == std::string("add_") + qkv[k] + "_proj") return cs + "qkv." + leaf + part_suffix(k);
+    }
+    if (m == "norm_q" || m == "norm_k" || m == "norm_added_q" || m == "norm_added_k") {
+        const bool added = m.compare(0, 10, "norm_added") == 0, q = m.back() == 'q';
+        if (flux) return (added ? cs : xs) + (q ? "norm.query_norm." : "norm.key_norm.") + (leaf == "weight" ? "scale" : leaf);
+        return (added ? cs : xs) + (q ? "ln_q." : "ln_k.") + leaf;
+    }
+    if (m == "to_out" && i + 1 < p.size() && p[i + 1] == "0") return xs + "proj." + join_from(p, i + 2);
+    if (m == "to_add_out") return cs + "proj." + leaf;
+    return std::string();
+}
+
+inline std::string dit_diffusers_to_original(const std::string& name, bool flux) {
+    const std::vector<std::string> p = split_dots(name);
+    if (p.size() < 2) return name;
+    const std::string leaf2 = p.size() >= 2 ? p[p.size() - 1] : std::string();
+    if ((p[0] == "time_text_embed" || p[0] == "time_embed") && p.size() == 4) {
+        const int which = p[2] == "linear_1" ? 0 : (p[2] == "linear_2" ? 1 : -1);
+        if (which < 0) return name;
+        if (flux) {
+            const std::string tgt = p[1] == "timestep_embedder" ? "time_in." : p[1] == "text_embedder" ? "vector_in." : p[1] == "guidance_embedder" ? "guidance_in." : "";
+            return tgt.empty() ? name : tgt + (which ? "out_layer." : "in_layer.") + p[3];
+        }
+        const std::string tgt = p[1] == "timestep_embedder" ? "t_embedder." : p[1] == "text_embedder" ? "y_embedder." : "";
+        return tgt.empty() ? name : tgt + (which ? "mlp.2." : "mlp.0.") + p[3];
+    }
+    if (!flux && p[0] == "pos_embed" && p.size() >= 2) {
+        if (p[1] == "pos_embed") return "pos_embed";
+        if (p[1] == "proj") return "x_embedder.proj." + join_from(p, 2);
+        return name;
+    }
+    if (flux && p[0] == "context_embedder") return "txt_in." + join_from(p, 1);
+    if (flux && p[0] == "x_embedder") return "img_in." + join_from(p, 1);
+    if (p[0] == "proj_out" && p.size() == 2) return "final_layer.linear." + p[1];
+    if (p[0] == "norm_out" && p.size() == 3 && p[1] == "linear") return "final_layer.adaLN_modulation.1." + p[2];
+    const bool dbl = p[0] == "transformer_blocks", sgl = flux && p[0] == "single_transformer_blocks";
+    if ((dbl || sgl) && p.size() >= 4 && is_index(p[1])) {
+        const std::string dst = (sgl ? "single_blocks." : flux ? "double_blocks." : "joint_blocks.") + p[1] + ".";
+        const std::string& m = p[2];
+        std::string r;
+        if (sgl) {
+            if (m == "norm" && p[3] == "linear") r = "modulation.lin." + join_from(p, 4);
+            else if (m == "attn") r = dit_attn_member(p, 3, true, true, "attn");
+            else if (m == "proj_mlp") r = "linear1." + join_from(p, 3) + part_suffix(3);
+            else if (m == "proj_out") r = "linear2." + join_from(p, 3);
+        } else {
+            const std::string xb = flux ? "img_" : "x_block.", cb = flux ? "txt_" : "context_block.";
+            if ((m == "norm1" || m == "norm1_context") && p[3] == "linear")
+                r = (m == "norm1" ? xb : cb) + (flux ? "mod.lin." : "adaLN_modulation.1.") + join_from(p, 4);
+            else if (m == "attn" || (m == "attn2" && !flux)) r = dit_attn_member(p, 3, flux, false, m);
+            else if ((m == "ff" || m == "ff_context") && p.size() >= 5 && p[3] == "net") {
+                const std::string blk = m == "ff" ? xb : cb;
+                if (p[4] == "0" && p.size() >= 7 && p[5] == "proj") r = blk + (flux ? "mlp.0." : "mlp.fc1.") + join_from(p, 6);
+                else if (p[4] == "2") r = blk + (flux ? "mlp.2." : "mlp.fc2.") + join_from(p, 5);
+            }
+        }
+        return r.empty() ? name : dst + r;
+    }
+    // original-dialect FLUX files that store the RMSNorm scale as "weight" (name_conversion.cpp:632-636, 668-670)
+    if (flux && p.size() >= 3 && p[p.size() - 1] == "weight" && (p[p.size() - 2] == "query_norm" || p[p.size() - 2] == "key_norm") && p[p.size() - 3] == "norm")
+        return name.substr(0, name.size() - 6) + "scale";
+    return name;
+}
+
 }  // namespace nameconv
 
 // file name -> canonical engine name (unchanged when already canonical or not recognised)
@@ -239,10 +321,10 @@ inline std::string canonical_tensor_name(const std::string& raw, const NameDiale
         }
     if (prefix.empty()) {
         // bare component files (diffusers keeps one file per sub-model): recognise the UNet / DiT by its top-level members
-        if (starts_with(raw, "transformer.") && !d.unet_family) return MDM + raw.substr(12);
+        if (starts_with(raw, "transformer.") && !d.unet_family) return MDM + dit_diffusers_to_original(raw.substr(12), d.flux);
         return raw;
     }
-    if (prefix == MDM) return prefix + (d.unet_family ? unet_diffusers_to_ldm(rest, d) : rest);
+    if (prefix == MDM) return prefix + (d.unet_family ? unet_diffusers_to_ldm(rest, d) : dit_diffusers_to_original(rest, d.flux));
     if (prefix == FSM) return prefix + vae_diffusers_to_ldm(rest, d);
     if (prefix == T || prefix == "text_encoders.t5xxl.") {
         if (prefix != T && starts_with(rest, "transformer.")) rest = rest.substr(12);

@@ -55,6 +55,10 @@ struct G16Args {
     int split_k;       // > 1: blockIdx.y = K slice; slice s accumulates K tiles [s*nt_slice, ...) into dst + s*slab (raw partial sums)
     int nt_slice;
     int64_t slab;      // elements between the partial-sum slabs
+    // in-kernel reduction (sk_cnt != nullptr): every K slice dumps its accumulators to sk_slab[(tile * split_k + slice)] (BM x BN floats, register
+    // order), takes a ticket on sk_cnt[tile], and the LAST arriver sums all slices in slice order and runs the regular epilogue
+    float* sk_slab;
+    int* sk_cnt;
     // conv gather
     int H, Wd, ICp, OH, OW, S, pad, UPS, KS, icb_per_tap, tap_major;
     int64_t OHOW;
@@ -312,7 +316,7 @@ __global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g
     if (g.split_k > 1) {
         kt0 = blockIdx.y * g.nt_slice;
         nt  = min(g.nt_slice, g.nt - kt0);
-        g.dst += (int64_t)blockIdx.y * g.slab;
+        if (!g.sk_cnt) g.dst += (int64_t)blockIdx.y * g.slab;
     }
     const int row_tile = bid / g.ncol_tiles, col_tile = bid - row_tile * g.ncol_tiles;
     const int64_t row0 = (int64_t)row_tile * BM;
@@ -736,6 +740,60 @@ __global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g
         }
     }
 
+    // ---- split-K, reduced in the launch: slab dump -> ticket; the last arriver sums the slices in slice order (bitwise deterministic whoever
+    // arrives last) and falls through to the epilogue.  Protocol = cdna_hip_programming.md section 5 "in-launch split-K reduction", write-through
+    // form: 16-byte sc1 stores, every storing wave drains vmcnt, barrier, ONE lane takes a relaxed agent-scope ticket; the reducer reads with
+    // sc1 loads.  Nobody ever waits for another workgroup, so residency does not matter.  The plan zeroes all its tile counters with one hipMemsetAsync ahead of its first launch.
+    // Only the 128-row tiles take this path (64 / 32 KB per slice: a few slices are a few microseconds of reading for the last arriver; the
+    // 320 KB slabs of the 256x320 tile were measured 40-70 % slower than slabs + a chip-wide reduce pass, profiles/r02o_*).
+    if (BM == 128 && g.split_k > 1 && g.sk_cnt) {
+        // slabs are stored WRITE-THROUGH (sc1, aux = 16) and read back with sc1 loads, so the hand-off needs no release / acquire fence: a
+        // buffer_wbl2 per workgroup writes back every dirty line of the XCD's L2 — with all workgroups dumping slabs at once that cost
+        // ~20 us per launch (r02q: SDXL Linears 23 -> 36 ms with fences)
+        typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+        constexpr int TILE_B = BM * BN * 4;
+        char* slab0          = (char*)g.sk_slab + (int64_t)bid * g.split_k * TILE_B;  // wave-uniform
+        const auto rs        = __builtin_amdgcn_make_buffer_rsrc((void*)slab0, 0, g.split_k * TILE_B, 0x00020000);
+        const int mine       = (int)blockIdx.y * TILE_B;
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                for (int i4 = 0; i4 < 4; ++i4) {
+                    u32x4_t v;
+                    v[0] = __float_as_uint(acc[rb][cb][4 * i4]);
+                    v[1] = __float_as_uint(acc[rb][cb][4 * i4 + 1]);
+                    v[2] = __float_as_uint(acc[rb][cb][4 * i4 + 2]);
+                    v[3] = __float_as_uint(acc[rb][cb][4 * i4 + 3]);
+                    __builtin_amdgcn_raw_buffer_store_b128(v, rs, mine + ((((wave * RB + rb) * CB + cb) * 4 + i4) * 64 + lane) * 16, 0, 16);
+                }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains
+        __syncthreads();
+        int* flag = (int*)smem;  // the staging ring is dead: every wave is past its last fragment read
+        if (threadIdx.x == 0) *flag = __hip_atomic_fetch_add(&g.sk_cnt[bid], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == g.split_k - 1;
+        __syncthreads();
+        if (!*flag) return;
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) acc[rb][cb] = (float16_t){0};
+        for (int sl = 0; sl < g.split_k; ++sl) {  // slice order: the sum does not depend on who arrives last
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                    for (int i4 = 0; i4 < 4; ++i4) {
+                        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, sl * TILE_B + ((((wave * RB + rb) * CB + cb) * 4 + i4) * 64 + lane) * 16, 0, 16);
+                        acc[rb][cb][4 * i4] += __uint_as_float(v[0]);
+                        acc[rb][cb][4 * i4 + 1] += __uint_as_float(v[1]);
+                        acc[rb][cb][4 * i4 + 2] += __uint_as_float(v[2]);
+                        acc[rb][cb][4 * i4 + 3] += __uint_as_float(v[3]);
+                    }
+        }
+    }
+
     // ---- epilogue: one compact variant per workgroup (all conditions are launch- or workgroup-uniform)
     if (!CONV) {
         const bool full  = row0 + BM <= g.R;
@@ -856,7 +914,7 @@ static int g16_pick_tile(int64_t rows, int64_t M, bool geglu, bool conv, int spl
 template <int BN_, bool CONV_>
 static void g16_launch(hipStream_t s, G16Args& g, int64_t rows, double flops) {
     const unsigned ny = g.split_k > 1 ? (unsigned)g.split_k : 1u;
-    if (BN_ == 128 && g_g16_variant == 3) {
+    if (BN_ == 128 && g_g16_variant == 3 && !g.sk_cnt) {
         const int tile = g16_pick_tile(rows, g.C, g.geglu_inner > 0, CONV_, g.split_k > 1 ? g.split_k : 0, g.nt);  // the GEGLU pairing is laid out for 128-column tiles
         if (tile != G16_T128) {
             const int64_t rt256 = (rows + 255) / 256;
@@ -945,6 +1003,49 @@ int gemm16_split_k(int64_t rows, int64_t M, int64_t K) {
     return S < 2 ? 1 : (int)S;
 }
 
+// ---- split-K policy.  Two mechanisms:
+//   * slabs + k_splitk_reduce (above): the 256x320 tile's K slices (g16_t320_split) and any plain-f32-output launch with a tiny grid;
+//   * in-launch combine (k_gemm16, BM = 128): launches that leave the chip one 128-row tile per CU or less.  Such a workgroup runs its k-steps
+//     as a bare LDS-read -> MFMA chain with nothing to overlap (0.7 us per 128x128x32 step whatever the ring depth, wave count or tile width,
+//     profiles/r02q_tile_sweep.txt), so the launch takes nt x 0.7 us; S slices cut the chain to nt / S steps and bring S x the workgroups.
+//     The last arriver applies the launch's full epilogue, so every output mode (head-major, f16 image, gate, residual) can split.
+static int g_g16_sk_inkernel = 1;  // option "splitk_inkernel": 0 = never combine in the launch
+void gemm16_set_splitk_inkernel(int v) { g_g16_sk_inkernel = v; }
+static int g_g16_sk_in_target = 640;  // option "splitk_in_target": workgroups an in-launch split aims for
+void gemm16_set_splitk_in_target(int v) { g_g16_sk_in_target = v; }
+static bool g16_use_bn64(int64_t rows, int64_t M) {
+    const int64_t c128 = ((rows + 127) / 128) * ((M + 127) / 128);
+    return M <= 64 || (M % 64 == 0 && g16_bk32() && (g_g16_force_tile == G16_T128N64 || (g_g16_force_tile < 0 && g_g16_bn64 && c128 <= 128)));
+}
+G16SplitPlan gemm16_split_plan(int64_t rows, int64_t M, int64_t K, bool conv, bool plain_out) {
+    G16SplitPlan r{1, false, 0, 0};
+    const int64_t nt = rup64(K, 64) / (g16_bk32() ? 32 : 64);
+    if (!g16_bk32()) return r;
+    if (g16_t320_split(rows, M, nt) == 0 && g_g16_sk_inkernel && g_g16_variant == 3 && g_g16_force_tile < 0) {
+        const int bn        = (conv ? M <= 64 : g16_use_bn64(rows, M)) ? 64 : 128;
+        const int64_t tiles = ((rows + 127) / 128) * ((M + bn - 1) / bn);
+        // only grids the 128-row tile would get anyway (g16_pick_tile moves to 256-row tiles from 256 of them on)
+        const int64_t c256 = ((rows + 255) / 256) * ((M + 127) / 128);
+        if (tiles <= 384 && c256 < 256 && nt >= 16 && tiles < (1 << 20)) {
+            int64_t S = (g_g16_sk_in_target + tiles / 2) / tiles;
+            if (S > 4) S = 4;
+            while (S > 1 && nt / S < 8) --S;
+            if (S >= 2) {
+                r.S        = (int)S;
+                r.inkernel = true;
+                r.tiles    = (int)tiles;
+                r.ws_bytes = (size_t)tiles * S * 128 * bn * 4;
+                return r;
+            }
+        }
+    }
+    if (plain_out) {
+        r.S = gemm16_split_k(rows, M, K);
+        if (r.S > 1) r.ws_bytes = (size_t)r.S * rows * M * 4;
+    }
+    return r;
+}
+
 // dst[i] = sum_s slab_s[i] + bias[(i / inner) % C] + residual[i];  4 elements per thread (n % 4 == 0, and inner % 4 == 0 or inner == 1 with C % 4 == 0)
 template <bool V4>
 __global__ void k_splitk_reduce(float* __restrict__ dst, const float* __restrict__ ws, int S, int64_t slab, int64_t n, const float* __restrict__ bias,
@@ -1000,6 +1101,10 @@ static void launch_splitk_reduce(hipStream_t s, float* dst, const float* ws, int
         k_splitk_reduce<false><<<(unsigned)((n + 255) / 256), 256, 0, s>>>(dst, ws, S, n, n, bias, inner, (int)C, residual, chan_add);
 }
 
+void splitk_reduce_rows(hipStream_t s, float* dst, const float* ws, int S, int64_t n, const float* bias, int64_t C, const float* residual) {
+    launch_splitk_reduce(s, dst, ws, S, n, bias, 1, C, residual);
+}
+
 // a 256-byte zero page per device for the padding taps
 static const _Float16* zero_page() {
     static thread_local const _Float16* z[16] = {nullptr};
@@ -1029,7 +1134,7 @@ static void g16_check_epi(const Epilogue& e) {
 }
 
 void launch_gemm16_linear(hipStream_t s, float* dst, void* dst16, int64_t ldd16, const void* a16, int64_t lda, const void* wswz, int64_t rows, int64_t K,
-                          int64_t M, int64_t ldd, const Epilogue& e, int hm_d, int hm_H, int hm_L, float* splitk_ws) {
+                          int64_t M, int64_t ldd, const Epilogue& e, int hm_d, int hm_H, int hm_L, float* splitk_ws, int* splitk_cnt, int splitk_S) {
     G16Args g{};
     g.A     = (const _Float16*)a16;
     g.lda   = lda;
@@ -1056,18 +1161,23 @@ void launch_gemm16_linear(hipStream_t s, float* dst, void* dst16, int64_t ldd16,
         fprintf(stderr, "ggml-mi355x: invalid gated / gelu gemm16 epilogue request\n");
         abort();
     }
-    const int S = (splitk_ws && dst && !dst16 && hm_d == 0 && ldd == M && !e.gate) ? gemm16_split_k(rows, M, K) : 1;
+    const bool inker = splitk_ws && splitk_cnt != nullptr && splitk_S > 1;
+    const int S      = inker ? splitk_S : ((splitk_ws && dst && !dst16 && hm_d == 0 && ldd == M && !e.gate) ? gemm16_split_k(rows, M, K) : 1);
     if (S > 1) {
         g.split_k  = S;
         g.nt_slice = (g.nt + S - 1) / S;
-        g.slab     = rows * M;
-        g.dst      = splitk_ws;
-        g.ep       = G16Epi{nullptr, nullptr, e.scale};
+        if (inker) {  // the last arriver of every tile applies the epilogue itself
+            g.sk_slab = splitk_ws;
+            g.sk_cnt  = splitk_cnt;
+        } else {
+            g.slab = rows * M;
+            g.dst  = splitk_ws;
+            g.ep   = G16Epi{nullptr, nullptr, e.scale};
+        }
     }
     // 64-column tiles: narrow outputs, and small grids (<= 128 tiles of 128x128 on 256 CUs: the cross-attention K/V projections of the 77-token
     // context, the time-embedding Linears) where twice the workgroups matter more than the tile's arithmetic intensity (r02q: 1232x768->768 36 -> 21 us)
-    const int64_t c128_ = ((rows + 127) / 128) * ((M + 127) / 128);
-    const bool bn64 = M <= 64 || (M % 64 == 0 && g16_bk32() && (g_g16_force_tile == G16_T128N64 || (g_g16_force_tile < 0 && g_g16_bn64 && c128_ <= 128)));
+    const bool bn64 = g16_use_bn64(rows, M);
     if (g16_trace()) fprintf(stderr, "G16 linear rows=%lld K=%lld M=%lld res=%d hm=%d f16out=%d\n", (long long)rows, (long long)K, (long long)M, e.residual ? 1 : 0, hm_d, dst16 ? 1 : 0);
     if (bn64) {
         g.ncol_tiles = (int)((M + 63) / 64);
@@ -1076,7 +1186,7 @@ void launch_gemm16_linear(hipStream_t s, float* dst, void* dst16, int64_t ldd16,
         g.ncol_tiles = (int)((M + 127) / 128);
         g16_launch<128, false>(s, g, rows, 2.0 * rows * K * M);
     }
-    if (S > 1) launch_splitk_reduce(s, dst, splitk_ws, S, rows * M, e.bias, 1, M, e.residual);
+    if (S > 1 && !inker) launch_splitk_reduce(s, dst, splitk_ws, S, rows * M, e.bias, 1, M, e.residual);
 }
 
 void launch_gemm16_linear_geglu(hipStream_t s, void* dst16, const void* a16, int64_t lda, const void* wswz_geglu, int64_t rows, int64_t K, int64_t M,
@@ -1100,7 +1210,7 @@ void launch_gemm16_linear_geglu(hipStream_t s, void* dst16, const void* a16, int
 }
 
 void launch_gemm16_conv(hipStream_t s, float* dst, const void* x16_nhwc, const void* wswz, int64_t W, int64_t H, int64_t IC, int64_t N, int64_t OC, int ksize,
-                        int stride, int pad, bool upscale2x, const Epilogue& e, float* splitk_ws) {
+                        int stride, int pad, bool upscale2x, const Epilogue& e, float* splitk_ws, int* splitk_cnt, int splitk_S) {
     G16Args g{};
     g.A   = (const _Float16*)x16_nhwc;
     g.W   = (const half8_t*)wswz;
@@ -1126,13 +1236,19 @@ void launch_gemm16_conv(hipStream_t s, float* dst, const void* x16_nhwc, const v
     g16_check_epi(e);
     g.ep   = G16Epi{e.bias, e.residual, e.scale};
     g.ep.chan_add = e.chan_add;
-    const int S = splitk_ws ? gemm16_split_k(g.R, OC, (int64_t)g.ICp * ksize * ksize) : 1;
+    const bool inker = splitk_ws && splitk_cnt != nullptr && splitk_S > 1;
+    const int S      = inker ? splitk_S : (splitk_ws ? gemm16_split_k(g.R, OC, (int64_t)g.ICp * ksize * ksize) : 1);
     if (S > 1) {
         g.split_k  = S;
         g.nt_slice = (g.nt + S - 1) / S;
-        g.slab     = g.R * OC;
-        g.dst      = splitk_ws;
-        g.ep       = G16Epi{nullptr, nullptr, e.scale};
+        if (inker) {
+            g.sk_slab = splitk_ws;
+            g.sk_cnt  = splitk_cnt;
+        } else {
+            g.slab = g.R * OC;
+            g.dst  = splitk_ws;
+            g.ep   = G16Epi{nullptr, nullptr, e.scale};
+        }
     }
     const bool bn64 = OC <= 64;
     if (g16_trace())
@@ -1145,7 +1261,7 @@ void launch_gemm16_conv(hipStream_t s, float* dst, const void* x16_nhwc, const v
         g.ncol_tiles = (int)((OC + 127) / 128);
         g16_launch<128, true>(s, g, g.R, 2.0 * g.R * IC * ksize * ksize * OC);
     }
-    if (S > 1) launch_splitk_reduce(s, dst, splitk_ws, S, g.R * OC, e.bias, g.OHOW, OC, e.residual, e.chan_add);
+    if (S > 1 && !inker) launch_splitk_reduce(s, dst, splitk_ws, S, g.R * OC, e.bias, g.OHOW, OC, e.residual, e.chan_add);
 }
 
 // =====================================================================================================

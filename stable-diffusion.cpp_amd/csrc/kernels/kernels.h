@@ -96,16 +96,28 @@ void gemm16_set_bn64(int v);     // 0: never choose the pipelined 256x320 tile
 void gemm16_set_variant(int v);  // 0: BK64x2 stages, 1: BK32x3 stages (default), 2: BK64x3 stages
 // hm_d > 0: head-major store — element (row = n*hm_L + l, col = h*hm_d + dd) goes to ((n*hm_H + h)*hm_L + l)*hm_d + dd of dst (f32) / dst16 (f16)
 void launch_gemm16_linear(hipStream_t s, float* dst, void* dst16, int64_t ldd16, const void* a16, int64_t lda, const void* wswz, int64_t rows,
-                          int64_t K, int64_t M, int64_t ldd, const Epilogue& ep, int hm_d = 0, int hm_H = 0, int hm_L = 0, float* splitk_ws = nullptr);
+                          int64_t K, int64_t M, int64_t ldd, const Epilogue& ep, int hm_d = 0, int hm_H = 0, int hm_L = 0, float* splitk_ws = nullptr, int* splitk_cnt = nullptr, int splitk_S = 0);
 // FF1 + GEGLU in one kernel (block.hpp:193-210): wswz built with geglu_inner = M/2; dst16[t][c] = (y[t][c] + b[c]) * gelu(y[t][inner + c] + b[inner + c]),
 // f16 row-major with row stride inner (inner % 64 == 0) — the operand image of the FF2 GEMM.  The [tokens][2*inner] f32 tensor is never written.
 void launch_gemm16_linear_geglu(hipStream_t s, void* dst16, const void* a16, int64_t lda, const void* wswz_geglu, int64_t rows, int64_t K, int64_t M,
                                 const float* bias);
 // split-K factor the launchers will use when given a workspace of factor * rows * M floats (1 = no split)
 int gemm16_split_k(int64_t rows, int64_t M, int64_t K);
+// the split a launch of this shape should take: S slices; inkernel = combined by the last-arriving workgroup of every output tile (the launcher
+// then needs `tiles` zeroed int counters and ws_bytes of slab space, and applies the full epilogue itself), else slabs + k_splitk_reduce (only
+// for plain f32 outputs: plain_out).  S = 1: no split.
+struct G16SplitPlan {
+    int S;
+    bool inkernel;
+    size_t ws_bytes;
+    int tiles;
+};
+G16SplitPlan gemm16_split_plan(int64_t rows, int64_t M, int64_t K, bool conv, bool plain_out);
+void gemm16_set_splitk_inkernel(int v);
+void gemm16_set_splitk_in_target(int v);
 // x16: f16 NHWC [N][H][W][ICp]; dst f32 NCHW [OW,OH,OC,N]
 void launch_gemm16_conv(hipStream_t s, float* dst, const void* x16_nhwc, const void* wswz, int64_t W, int64_t H, int64_t IC, int64_t N, int64_t OC,
-                        int ksize, int stride, int pad, bool upscale2x, const Epilogue& ep, float* splitk_ws = nullptr);
+                        int ksize, int stride, int pad, bool upscale2x, const Epilogue& ep, float* splitk_ws = nullptr, int* splitk_cnt = nullptr, int splitk_S = 0);
 // producers of f16 operand images (row stride = K rounded up to 64, zero padded)
 // L > 0: rows are N runs of L rows, run n starting bs elements after run n-1 (a token slice of a [C, Lfull, N] tensor)
 void launch_pack_rows_f16(hipStream_t s, void* dst, const float* x, int64_t R, int64_t K, int64_t xs, int64_t L = 0, int64_t bs = 0);
@@ -122,7 +134,24 @@ void launch_nchw_to_nhwc_f16(hipStream_t s, void* dst, const float* x, int64_t h
 bool qgemv_supported(int wtype, int64_t rows, int64_t K);
 size_t qgemv_workspace_bytes(int64_t rows, int64_t K);
 void launch_qgemv(hipStream_t s, float* dst, int64_t ldd, const float* x, int64_t xs, int64_t rows, const void* wraw, int wtype, int64_t K, int64_t M, void* ws,
-                  const Epilogue& ep, float pre_scale);
+                  const Epilogue& ep, float pre_scale, bool pre_silu = false);
+
+// k_fgemv: f16 / f32 weights under <= 16 activation rows (time-embedding MLP, ResBlock embedding projections): one launch, optional SiLU on the
+// activation rows (the UNARY node in front of the Linear is not executed), f32 x f32 for f32 weights
+bool fgemv_supported(int wtype, int64_t rows, int64_t K);
+void fgemv_set_max_rows(int v);
+void launch_fgemv(hipStream_t s, float* dst, int64_t ldd, const float* x, int64_t xs, int64_t rows, const void* w, int wtype, int64_t K, int64_t M, const Epilogue& ep,
+                  bool pre_silu);
+// k_qgemm16: the same raw-block stream on the MFMA units for 3 .. qgemm16_max_rows activation rows.  a16 = the f16 operand image [rows][lda]
+// (lda >= K); plain f32 output [rows][M] (+ bias, residual, gate) or, with ep.gelu, the f16 rows dst16 (row stride ldd16).  Split-K (S slices,
+// workspace of S * rows * M floats) only for plain outputs.
+bool qgemm16_supported(int wtype, int64_t rows, int64_t K, int64_t M);
+int qgemm16_split_k(int64_t rows, int64_t K, int64_t M);
+void qgemm16_set_max_rows(int v);
+void launch_qgemm16(hipStream_t s, float* dst, void* dst16, int64_t ldd16, const void* a16, int64_t lda, int64_t rows, const void* wraw, int wtype, int64_t K,
+                    int64_t M, const Epilogue& ep, float* splitk_ws = nullptr, int splitk_S = 1);
+// dst[i] = sum_s ws[s * n + i] + bias[i % C] + residual[i] (gemm16.hip's k_splitk_reduce on a row-major [rows][C] output)
+void splitk_reduce_rows(hipStream_t s, float* dst, const float* ws, int S, int64_t n, const float* bias, int64_t C, const float* residual);
 
 // ---- flash_attn.hip ---------------------------------------------------------------------------------
 // q [D,Lq,HN] (f32, strides in bytes), k [D,Lk,HN], v [DV,Lk,HN] (f16 or f32; v may be a transposed view,

@@ -17,7 +17,7 @@ const char* const kNames[KF_COUNT] = {
     "conv implicit-GEMM, 128-row tiles (k_gemm16<128,*,true,...>)",
     "Linear MFMA GEMM (k_gemm16<*,*,false,...>)",
     "flash attention (k_flash_attn)",
-    "q8_0/q4_0 in-register dequant GEMM (k_qgemm)",
+    "weight-streaming few-row Linears (k_qgemv / k_qgemm16: raw q8_0 / q4_0 blocks, in-register dequant; k_fgemv: f16 / f32)",
     "f32 MFMA matmul (k_mul_mat_generic)",
     "GroupNorm apply + SiLU + NCHW->NHWC f16 (k_nchw_to_nhwc_f16)",
     "LayerNorm -> f16 operand image (k_layer_norm_f16)",

@@ -17,6 +17,9 @@
 // by all CPW weight rows.  A weight row segment (64 x 34 B = 2176 B, or 64 x 18 B = 1152 B) is fetched with 16-byte loads of the whole
 // contiguous range into a per-wave LDS strip and re-read block-wise with aligned 4-byte LDS loads + v_alignbit (the blocks are only
 // 2-byte aligned).  Cross-lane sums at the end, bias / residual in the store.
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
 #include "device_utils.h"
 #include "kernels.h"
 #include "ktime.h"
@@ -33,7 +36,7 @@ struct QGArgs {
     const float* bias;
     const float* residual;  // same layout as dst
     float scale, pre_scale;
-    int K, M, rows;
+    int K, M, rows, pre_silu;
 };
 
 // QT: 8 = q8_0 (34-byte blocks), 4 = q4_0 (18-byte blocks).  R = activation rows held in registers (rows <= R), CPW = weight rows per wave.
@@ -59,7 +62,11 @@ __global__ __launch_bounds__(256) void k_qgemv(QGArgs g) {
         const int tt    = t < g.rows ? t : 0;
         const float* xr = g.x + (int64_t)tt * g.xs;
         for (int c8 = threadIdx.x; c8 < g.K / 8; c8 += 256) {  // 8 values = one 16-byte f16 chunk
-            const float4 a = *(const float4*)(xr + c8 * 8), b = *(const float4*)(xr + c8 * 8 + 4);
+            float4 a = *(const float4*)(xr + c8 * 8), b = *(const float4*)(xr + c8 * 8 + 4);
+            if (g.pre_silu) {  // the SiLU node in front of this Linear was deferred to here (planner: presilu)
+                a.x = act_apply<UN_SILU>(a.x); a.y = act_apply<UN_SILU>(a.y); a.z = act_apply<UN_SILU>(a.z); a.w = act_apply<UN_SILU>(a.w);
+                b.x = act_apply<UN_SILU>(b.x); b.y = act_apply<UN_SILU>(b.y); b.z = act_apply<UN_SILU>(b.z); b.w = act_apply<UN_SILU>(b.w);
+            }
             half8_t h;
             h[0] = (_Float16)(a.x * g.pre_scale); h[1] = (_Float16)(a.y * g.pre_scale); h[2] = (_Float16)(a.z * g.pre_scale); h[3] = (_Float16)(a.w * g.pre_scale);
             h[4] = (_Float16)(b.x * g.pre_scale); h[5] = (_Float16)(b.y * g.pre_scale); h[6] = (_Float16)(b.z * g.pre_scale); h[7] = (_Float16)(b.w * g.pre_scale);
@@ -210,7 +217,7 @@ bool qgemv_supported(int wtype, int64_t rows, int64_t K) {
 
 // x: f32 rows (row stride xs floats, 16-byte aligned), multiplied by pre_scale before the f16 rounding (ggml_ext_linear's scale)
 void launch_qgemv(hipStream_t s, float* dst, int64_t ldd, const float* x, int64_t xs, int64_t rows, const void* wraw, int wtype, int64_t K, int64_t M, void*,
-                  const Epilogue& ep, float pre_scale) {
+                  const Epilogue& ep, float pre_scale, bool pre_silu) {
     const int64_t nblk  = K / 32;
     const size_t wbytes = (size_t)M * (size_t)nblk * (wtype == 8 ? 34 : 18);
     KScope ks_(s, KF_QGEMM, 2.0 * rows * K * M, (double)wbytes + (double)rows * K * 4.0 + (double)rows * M * 4.0);
@@ -220,7 +227,7 @@ void launch_qgemv(hipStream_t s, float* dst, int64_t ldd, const float* x, int64_
     g.x = x; g.xs = xs;
     g.dst = dst; g.ldd = ldd;
     g.bias = ep.bias; g.residual = ep.residual; g.scale = ep.scale; g.pre_scale = pre_scale;
-    g.K = (int)K; g.M = (int)M; g.rows = (int)rows;
+    g.K = (int)K; g.M = (int)M; g.rows = (int)rows; g.pre_silu = pre_silu ? 1 : 0;
     constexpr int CPW = 4;
     const unsigned grid = (unsigned)((M + 4 * CPW - 1) / (4 * CPW));
 #define QG_LAUNCH(QT_, R_) k_qgemv<QT_, R_, CPW><<<grid, 256, (size_t)(R_) * K * 2, s>>>(g)
@@ -232,6 +239,420 @@ void launch_qgemv(hipStream_t s, float* dst, int64_t ldd, const float* x, int64_
         else QG_LAUNCH(4, 2);
     }
 #undef QG_LAUNCH
+}
+
+
+// =====================================================================================================
+// k_qgemm16 — the same raw-block weight stream on the MATRIX CORES, for Linears with a few hundred activation rows (text-stream Linears of the
+// DiTs, the text encoders' 77..512 tokens, small latents): below ~300 rows (2.5 PFLOP/s / 8 TB/s) a GEMM against the f16 weight image is
+// bound by the 2 B/weight it streams; the raw blocks are 1.06 B (q8_0) / 0.56 B (q4_0) per weight and no image is ever built or kept.
+//
+//   W   raw GGUF rows.  Per K segment of 8 blocks (256 weights) a wave fetches the contiguous 272 B / 144 B piece of each of ITS 32 columns with
+//       coalesced 16-byte loads (17 / 9 consecutive lanes per column piece) into a per-wave LDS strip; every lane then picks the bytes of its
+//       MFMA B fragment out of the strip with aligned dword reads (+ v_alignbit: blocks are 2-byte aligned) and dequantises in registers:
+//       byte u -> f16 (1024 + u) by a v_perm with the exponent byte 0x64, minus 1152 (q8_0: u = q ^ 0x80) / 1032 (q4_0 nibbles) = the exact
+//       integer, times the block scale d with v_pk_mul_f16 = f16(d * q) round-to-nearest: bit-identical to the value the f16 image holds
+//       (wgemm.hip wload), so this kernel and k_gemm16 differ by f32 summation order only.
+//   A   the f16 operand image [rows][K] every gemm16 Linear uses (written by the producing kernel), staged per segment into LDS by the whole
+//       workgroup (16-byte loads, 512-byte runs), rows padded by 16 B so a ds_read_b128 of 16 consecutive rows covers all banks.
+//   k order inside a block follows the quantised bytes, not 0..31: lane group kg (= lane / 32) of v_mfma_f32_32x32x16_f16 step s multiplies
+//       q8_0: weights 16 kg + 8 s + i (one contiguous 16-byte run per lane and block);  q4_0: 16 s + 8 kg + i (low nibbles of bytes
+//       8 kg .. 8 kg + 7 are elements 8 kg + i, the high nibbles elements 16 + 8 kg + i);  the A fragment is read at the same offsets.
+//   Tile: 32 RB rows x 128 columns (4 waves x 32 columns, every wave all rows), next segment's global loads in flight (registers) during the
+//   MFMAs of the current one.  Optional split-K over gridDim.z into f32 slabs (combined by k_splitk_reduce) for shapes with few tiles.
+// =====================================================================================================
+struct QG16Args {
+    const char* W;
+    int64_t row_bytes;
+    const _Float16* A;
+    int64_t lda;  // halfs
+    float* dst;
+    int64_t ldd;
+    _Float16* dst16;  // gelu != 0: f16 output rows (operand image of the next Linear), row stride ldd16
+    int64_t ldd16;
+    const float* bias;
+    const float* residual;
+    const float* gate;
+    int gate_L, gelu;
+    float scale;
+    int R, M;
+    int nseg, nseg_slice;
+    int64_t slab;  // > 0: split-K, slice z writes acc * scale to dst + z * slab (bias / residual are added by the reduce pass)
+};
+
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+
+// four bytes of u -> two half2 {1024 + byte0, 1024 + byte1}, {1024 + byte2, 1024 + byte3}, minus off, times d
+__device__ __forceinline__ void qg_deq4(uint32_t u, half2_t off, half2_t d2, uint32_t& o01, uint32_t& o23) {
+    const uint32_t p01 = __builtin_amdgcn_perm(0x64646464u, u, 0x04010400u);
+    const uint32_t p23 = __builtin_amdgcn_perm(0x64646464u, u, 0x04030402u);
+    const half2_t h01  = (__builtin_bit_cast(half2_t, p01) - off) * d2;
+    const half2_t h23  = (__builtin_bit_cast(half2_t, p23) - off) * d2;
+    o01                = __builtin_bit_cast(uint32_t, h01);
+    o23                = __builtin_bit_cast(uint32_t, h23);
+}
+
+template <int QT, int RB>
+__global__ __launch_bounds__(256) void k_qgemm16(QG16Args g) {
+    constexpr int BLK = QT == 8 ? 34 : 18;
+    constexpr int SEG = 8;               // blocks per K segment (256 weights)
+    constexpr int CS  = SEG * BLK;       // bytes of one column piece: 272 / 144 (multiples of 16)
+    constexpr int NGC = CS / 16;         // 16-byte granules per column piece: 17 / 9
+    constexpr int NGW = 32 * NGC;        // granules of a wave's strip: 544 / 288
+    constexpr int NLW = (NGW + 63) / 64; // loads per lane: 9 / 5
+    constexpr int RT  = RB * 32;
+    constexpr int AS  = 256 * 2 + 16;    // bytes between A rows in LDS
+    constexpr int NLA = RT * 32 / 256;   // A granules per thread
+    constexpr int NB  = QT == 8 ? 16 : 8;  // quant bytes per lane and block
+    __shared__ __attribute__((aligned(16))) char As[RT * AS];
+    __shared__ __attribute__((aligned(16))) char Wsm[4][32 * CS];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = lane & 31, kg = lane >> 5;
+    char* Ws             = Wsm[wave];
+    const int64_t row0   = (int64_t)blockIdx.x * RT;
+    const int colw       = (int)blockIdx.y * 128 + wave * 32;  // first column of this wave
+    const int seg0       = (int)blockIdx.z * g.nseg_slice;
+    const int seg1       = min(g.nseg, seg0 + g.nseg_slice);
+
+    float16_t acc[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[rb][i] = 0.f;
+
+    u32x4_t wreg[NLW], areg[NLA];
+    auto fetch = [&](int seg) {
+#pragma unroll
+        for (int i = 0; i < NLW; ++i) {
+            const int idx = i * 64 + lane;
+            const int col = idx / NGC, gr = idx - col * NGC;
+            const int cc  = min(colw + col, g.M - 1);
+            wreg[i]       = (u32x4_t){0, 0, 0, 0};
+            if (idx < NGW) wreg[i] = *(const u32x4_t*)(g.W + (int64_t)cc * g.row_bytes + (int64_t)seg * CS + gr * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < NLA; ++i) {
+            const int idx     = i * 256 + (int)threadIdx.x;
+            const int row     = idx >> 5, gr = idx & 31;
+            const int64_t grw = row0 + row;
+            areg[i]           = (u32x4_t){0, 0, 0, 0};
+            if (grw < g.R) areg[i] = *(const u32x4_t*)(g.A + grw * g.lda + (int64_t)seg * 256 + gr * 8);
+        }
+    };
+    if (seg0 < seg1) fetch(seg0);
+    for (int seg = seg0; seg < seg1; ++seg) {
+        __syncthreads();  // every wave is done reading the previous segment
+#pragma unroll
+        for (int i = 0; i < NLW; ++i) {
+            const int idx = i * 64 + lane;
+            if (idx < NGW) *(u32x4_t*)(Ws + idx * 16) = wreg[i];  // strip = [column][piece bytes]: idx * 16 = col * CS + gr * 16
+        }
+#pragma unroll
+        for (int i = 0; i < NLA; ++i) {
+            const int idx = i * 256 + (int)threadIdx.x;
+            *(u32x4_t*)(As + (idx >> 5) * AS + (idx & 31) * 16) = areg[i];
+        }
+        __syncthreads();
+        if (seg + 1 < seg1) fetch(seg + 1);  // in flight during the MFMAs below
+#pragma unroll
+        for (int b = 0; b < SEG; ++b) {
+            const char* blk  = Ws + n * CS + BLK * b;
+            const _Float16 d = *(const _Float16*)blk;
+            const half2_t d2 = {d, d};
+            const int ph = (BLK * b + 2) & 2;  // compile-time after unrolling: phase of this lane's quant bytes inside a dword (CS, NB * kg are multiples of 4)
+            const char* qp = blk + 2 + NB * kg;
+            uint32_t q[NB / 4];
+            if (ph == 0) {
+#pragma unroll
+                for (int j = 0; j < NB / 4; ++j) q[j] = *(const uint32_t*)(qp + 4 * j);
+            } else {
+                uint32_t raw[NB / 4 + 1];
+#pragma unroll
+                for (int j = 0; j <= NB / 4; ++j) raw[j] = *(const uint32_t*)(qp - 2 + 4 * j);
+#pragma unroll
+                for (int j = 0; j < NB / 4; ++j) q[j] = __builtin_amdgcn_alignbit(raw[j + 1], raw[j], 16);
+            }
+            uint32_t f0[4], f1[4];  // B fragments of MFMA steps 0 and 1 (8 halfs each)
+            if constexpr (QT == 8) {
+                const half2_t off = {(_Float16)1152.f, (_Float16)1152.f};
+                qg_deq4(q[0] ^ 0x80808080u, off, d2, f0[0], f0[1]);
+                qg_deq4(q[1] ^ 0x80808080u, off, d2, f0[2], f0[3]);
+                qg_deq4(q[2] ^ 0x80808080u, off, d2, f1[0], f1[1]);
+                qg_deq4(q[3] ^ 0x80808080u, off, d2, f1[2], f1[3]);
+            } else {
+                const half2_t off = {(_Float16)1032.f, (_Float16)1032.f};
+                qg_deq4(q[0] & 0x0F0F0F0Fu, off, d2, f0[0], f0[1]);
+                qg_deq4(q[1] & 0x0F0F0F0Fu, off, d2, f0[2], f0[3]);
+                qg_deq4((q[0] >> 4) & 0x0F0F0F0Fu, off, d2, f1[0], f1[1]);
+                qg_deq4((q[1] >> 4) & 0x0F0F0F0Fu, off, d2, f1[2], f1[3]);
+            }
+            const half8_t bf0 = __builtin_bit_cast(half8_t, (u32x4_t){f0[0], f0[1], f0[2], f0[3]}), bf1 = __builtin_bit_cast(half8_t, (u32x4_t){f1[0], f1[1], f1[2], f1[3]});
+            const int k0 = 32 * b + (QT == 8 ? 16 * kg : 8 * kg);      // step 0
+            const int k1 = 32 * b + (QT == 8 ? 16 * kg + 8 : 16 + 8 * kg);  // step 1
+            half8_t af0[RB], af1[RB];
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                const char* ar = As + (rb * 32 + n) * AS;
+                af0[rb]        = *(const half8_t*)(ar + k0 * 2);
+                af1[rb]        = *(const half8_t*)(ar + k1 * 2);
+            }
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af0[rb], bf0, acc[rb], 0, 0, 0);
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af1[rb], bf1, acc[rb], 0, 0, 0);
+        }
+    }
+    // ---- store: register r of a 32x32 block holds row (r & 3) + 8 (r >> 2) + 4 kg, lanes run along columns
+    const int col = colw + n;
+    if (col >= g.M) return;
+    const float bias = (g.bias && g.slab == 0) ? g.bias[col] : 0.f;
+    float* dst       = g.dst + (g.slab > 0 ? (int64_t)blockIdx.z * g.slab : 0);
+    const int mode   = g.slab > 0 ? 0 : g.gelu ? 1 : g.gate ? 2 : g.residual ? 3 : 0;  // workgroup-uniform
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        const int rbase = (int)row0 + rb * 32 + 4 * kg;
+        if ((int)row0 + rb * 32 >= g.R) break;
+        if (mode == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rbase + (r & 3) + 8 * (r >> 2);
+                if (row < g.R) dst[(int64_t)row * g.ldd + col] = acc[rb][r] * g.scale + bias;
+            }
+        } else if (mode == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rbase + (r & 3) + 8 * (r >> 2);
+                if (row < g.R) g.dst16[(int64_t)row * g.ldd16 + col] = (_Float16)act_apply<UN_GELU>(acc[rb][r] * g.scale + bias);
+            }
+        } else if (mode == 2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rbase + (r & 3) + 8 * (r >> 2);
+                if (row < g.R) {
+                    const uint32_t img = (uint32_t)row / (uint32_t)g.gate_L;
+                    const int64_t o    = (int64_t)row * g.ldd + col;
+                    dst[o]             = (acc[rb][r] * g.scale + bias) * g.gate[(int64_t)img * g.M + col] + g.residual[o];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rbase + (r & 3) + 8 * (r >> 2);
+                if (row < g.R) {
+                    const int64_t o = (int64_t)row * g.ldd + col;
+                    dst[o]          = acc[rb][r] * g.scale + bias + g.residual[o];
+                }
+            }
+        }
+    }
+}
+
+static int g_qg16_max_rows = 512;  // option "qgemm16_max_rows": Linears with more activation rows go to the f16 weight image + k_gemm16 (0 = never use k_qgemm16)
+void qgemm16_set_max_rows(int v) { g_qg16_max_rows = v; }
+
+bool qgemm16_supported(int wtype, int64_t rows, int64_t K, int64_t M) {
+    // column pieces are fetched with 16-byte loads: rows of the weight must start 16-byte aligned (K % 256 == 0); 1-2 rows belong to k_qgemv
+    return (wtype == 8 || wtype == 2) && rows >= 3 && rows <= g_qg16_max_rows && K % 256 == 0 && K >= 256 && M >= 1 && M < (1ll << 30);
+}
+
+// split-K slices for a launch (1 = none): plain outputs only (the reduce pass adds bias and residual)
+int qgemm16_split_k(int64_t rows, int64_t K, int64_t M) {
+    const int64_t rt    = rows <= 32 ? 32 : rows <= 64 ? 64 : 128;
+    const int64_t tiles = ((rows + rt - 1) / rt) * ((M + 127) / 128);
+    const int64_t nseg  = K / 256;
+    int64_t S           = 512 / tiles;  // aim for two workgroups per CU
+    if (S > nseg / 2) S = nseg / 2;     // at least two segments per slice
+    if (S > 16) S = 16;
+    return S < 2 ? 1 : (int)S;
+}
+
+void launch_qgemm16(hipStream_t s, float* dst, void* dst16, int64_t ldd16, const void* a16, int64_t lda, int64_t rows, const void* wraw, int wtype, int64_t K,
+                    int64_t M, const Epilogue& ep, float* splitk_ws, int splitk_S) {
+    const int64_t nblk  = K / 32;
+    const size_t wbytes = (size_t)M * (size_t)nblk * (wtype == 8 ? 34 : 18);
+    KScope ks_(s, KF_QGEMM, 2.0 * rows * K * M, (double)wbytes + (double)rows * K * 2.0 + (double)rows * M * 4.0);
+    QG16Args g{};
+    g.W = (const char*)wraw;
+    g.row_bytes = nblk * (wtype == 8 ? 34 : 18);
+    g.A = (const _Float16*)a16; g.lda = lda;
+    g.dst = dst; g.ldd = M; g.dst16 = (_Float16*)dst16; g.ldd16 = ldd16;
+    g.bias = ep.bias; g.residual = ep.residual; g.gate = ep.gate; g.gate_L = ep.gate_L > 0 ? ep.gate_L : 1; g.gelu = ep.gelu; g.scale = ep.scale;
+    g.R = (int)rows; g.M = (int)M;
+    g.nseg = (int)(K / 256);
+    const int S = (splitk_ws && splitk_S > 1 && !ep.gate && !ep.gelu && dst) ? splitk_S : 1;
+    g.nseg_slice = (g.nseg + S - 1) / S;
+    if (S > 1) {
+        g.slab = rows * M;
+        g.dst  = splitk_ws;
+    }
+    if ((ep.gelu && !dst16) || (!ep.gelu && !dst) || (ep.gate && !ep.residual)) {
+        fprintf(stderr, "ggml-mi355x: invalid k_qgemm16 epilogue request\n");
+        abort();
+    }
+    const int rb    = rows <= 32 ? 1 : rows <= 64 ? 2 : 4;
+    const dim3 grid((unsigned)((rows + rb * 32 - 1) / (rb * 32)), (unsigned)((M + 127) / 128), (unsigned)S);
+#define QG16_LAUNCH(QT_, RB_) k_qgemm16<QT_, RB_><<<grid, 256, 0, s>>>(g)
+    if (wtype == 8) {
+        if (rb == 1) QG16_LAUNCH(8, 1);
+        else if (rb == 2) QG16_LAUNCH(8, 2);
+        else QG16_LAUNCH(8, 4);
+    } else {
+        if (rb == 1) QG16_LAUNCH(4, 1);
+        else if (rb == 2) QG16_LAUNCH(4, 2);
+        else QG16_LAUNCH(4, 4);
+    }
+#undef QG16_LAUNCH
+    if (S > 1) splitk_reduce_rows(s, dst, splitk_ws, S, rows * M, ep.bias, M, ep.residual);
+}
+
+
+// =====================================================================================================
+// k_fgemv — Linear with f16 / f32 weights under a handful of activation rows: the time-embedding MLP and the per-ResBlock embedding projections
+// (SiLU(emb) -> Linear 1280 -> C on one row per image, block.hpp:126-160 / unet.hpp time_embed) and the DiTs' vector embedders.  On the MFMA
+// GEMM such a Linear is four launches (SiLU, f16 pack, a one-workgroup-per-tile GEMM whose K loop is a pure latency chain, split-K reduce)
+// of ~6-20 us each for ~3 MB of weights.  Here: ONE launch; the workgroup stages the (optionally SiLU-activated) rows in LDS once, every wave
+// streams its weight rows with coalesced 16-byte loads exactly once and keeps R x CPW f32 accumulators.
+// Rounding points = the MFMA path's for f16 weights (activation -> f16, f32 products and sums), so a batch that crosses the row limit agrees up
+// to summation order; f32 weights keep f32 x f32 like ggml-cpu's vec_dot_f32 (the MFMA path rounds both to f16).
+// =====================================================================================================
+struct FGArgs {
+    const char* W;  // [M][K] rows of f16 or f32
+    const float* x;
+    int64_t xs;     // floats between activation rows
+    float* dst;
+    int64_t ldd;
+    const float* bias;
+    const float* residual;
+    float scale;
+    int K, M, rows, pre_silu;
+};
+
+template <bool W16, int R, int CPW>
+__global__ __launch_bounds__(256) void k_fgemv(FGArgs g) {
+    using XT = typename std::conditional<W16, _Float16, float>::type;
+    extern __shared__ __attribute__((aligned(16))) char fg_smem[];  // [R][K] XT
+    XT* xl         = (XT*)fg_smem;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int t = 0; t < R; ++t) {
+        const int tt    = t < g.rows ? t : 0;
+        const float* xr = g.x + (int64_t)tt * g.xs;
+        for (int c4 = threadIdx.x; c4 < g.K / 4; c4 += 256) {
+            float4 a = *(const float4*)(xr + c4 * 4);
+            if (g.pre_silu) {
+                a.x = act_apply<UN_SILU>(a.x); a.y = act_apply<UN_SILU>(a.y); a.z = act_apply<UN_SILU>(a.z); a.w = act_apply<UN_SILU>(a.w);
+            }
+            XT* d = xl + (size_t)t * g.K + c4 * 4;
+            d[0] = (XT)a.x; d[1] = (XT)a.y; d[2] = (XT)a.z; d[3] = (XT)a.w;
+        }
+    }
+    __syncthreads();
+    const int col0 = (blockIdx.x * 4 + wave) * CPW;
+    if (col0 >= g.M) return;
+    float acc[CPW][R];
+#pragma unroll
+    for (int c = 0; c < CPW; ++c)
+#pragma unroll
+        for (int t = 0; t < R; ++t) acc[c][t] = 0.f;
+    const int64_t row_bytes = (int64_t)g.K * (W16 ? 2 : 4);
+    for (int k = lane * 8; k < g.K; k += 512) {  // 8 weights per lane and step: 16 B (f16) / 32 B (f32), a wave covers 512 consecutive k
+        float w[CPW][8];
+#pragma unroll
+        for (int c = 0; c < CPW; ++c) {
+            const int col    = min(col0 + c, g.M - 1);
+            const char* rowp = g.W + (int64_t)col * row_bytes;
+            if (W16) {
+                const half8_t h = *(const half8_t*)(rowp + (size_t)k * 2);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) w[c][j] = (float)h[j];
+            } else {
+                const float4 a = *(const float4*)(rowp + (size_t)k * 4), b = *(const float4*)(rowp + (size_t)k * 4 + 16);
+                w[c][0] = a.x; w[c][1] = a.y; w[c][2] = a.z; w[c][3] = a.w; w[c][4] = b.x; w[c][5] = b.y; w[c][6] = b.z; w[c][7] = b.w;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < R; ++t) {
+            float xv[8];
+            if (W16) {
+                const half8_t h = *(const half8_t*)((const _Float16*)xl + (size_t)t * g.K + k);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xv[j] = (float)h[j];
+            } else {
+                const float4 a = *(const float4*)((const float*)xl + (size_t)t * g.K + k), b = *(const float4*)((const float*)xl + (size_t)t * g.K + k + 4);
+                xv[0] = a.x; xv[1] = a.y; xv[2] = a.z; xv[3] = a.w; xv[4] = b.x; xv[5] = b.y; xv[6] = b.z; xv[7] = b.w;
+            }
+#pragma unroll
+            for (int c = 0; c < CPW; ++c)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[c][t] = fmaf(w[c][j], xv[j], acc[c][t]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) {
+        const int col = col0 + c;
+        if (col >= g.M) break;  // wave-uniform
+        float mine = 0.f;
+#pragma unroll
+        for (int t = 0; t < R; ++t) {
+            const float v = wave_sum(acc[c][t]);
+            if (lane == t) mine = v;
+        }
+        if (lane < g.rows && lane < R) {
+            float o = mine * g.scale + (g.bias ? g.bias[col] : 0.f);
+            if (g.residual) o += g.residual[(int64_t)lane * g.ldd + col];
+            g.dst[(int64_t)lane * g.ldd + col] = o;
+        }
+    }
+}
+
+static int g_fgemv_max_rows = 16;  // option "fgemv_max_rows" (0 = never)
+void fgemv_set_max_rows(int v) { g_fgemv_max_rows = v > 16 ? 16 : v; }
+
+// wtype: 0 = f32, 1 = f16 (ggml type ids)
+bool fgemv_supported(int wtype, int64_t rows, int64_t K) {
+    if (!(wtype == 0 || wtype == 1) || rows < 1 || rows > g_fgemv_max_rows || K % 8 != 0 || K < 8) return false;
+    const int64_t r = rows <= 2 ? 2 : rows <= 4 ? 4 : rows <= 8 ? 8 : 16;
+    return r * K * (wtype == 1 ? 2 : 4) <= 96 * 1024;  // the staged rows live in LDS
+}
+
+void launch_fgemv(hipStream_t s, float* dst, int64_t ldd, const float* x, int64_t xs, int64_t rows, const void* w, int wtype, int64_t K, int64_t M, const Epilogue& ep,
+                  bool pre_silu) {
+    const int esz = wtype == 1 ? 2 : 4;
+    KScope ks_(s, KF_QGEMM, 2.0 * rows * K * M, (double)M * K * esz + (double)rows * K * 4.0 + (double)rows * M * 4.0);
+    FGArgs g;
+    g.W = (const char*)w; g.x = x; g.xs = xs; g.dst = dst; g.ldd = ldd;
+    g.bias = ep.bias; g.residual = ep.residual; g.scale = ep.scale;
+    g.K = (int)K; g.M = (int)M; g.rows = (int)rows; g.pre_silu = pre_silu ? 1 : 0;
+    constexpr int CPW = 2;
+    const unsigned grid = (unsigned)((M + 4 * CPW - 1) / (4 * CPW));
+    const int r         = rows <= 2 ? 2 : rows <= 4 ? 4 : rows <= 8 ? 8 : 16;
+    const size_t lds    = (size_t)r * K * esz;
+#define FG_LAUNCH(W16_, R_)                                                                                        \
+    do {                                                                                                           \
+        static bool attr_dev_[64] = {false};                                                                       \
+        int dev_ = 0;                                                                                              \
+        (void)hipGetDevice(&dev_);                                                                                 \
+        bool& attr_ = attr_dev_[dev_ & 63];                                                                        \
+        if (!attr_) {                                                                                              \
+            (void)hipFuncSetAttribute((const void*)k_fgemv<W16_, R_, CPW>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
+            attr_ = true;                                                                                          \
+        }                                                                                                          \
+        k_fgemv<W16_, R_, CPW><<<grid, 256, lds, s>>>(g);                                                          \
+    } while (0)
+    if (wtype == 1) {
+        if (r == 2) FG_LAUNCH(true, 2);
+        else if (r == 4) FG_LAUNCH(true, 4);
+        else if (r == 8) FG_LAUNCH(true, 8);
+        else FG_LAUNCH(true, 16);
+    } else {
+        if (r == 2) FG_LAUNCH(false, 2);
+        else if (r == 4) FG_LAUNCH(false, 4);
+        else if (r == 8) FG_LAUNCH(false, 8);
+        else FG_LAUNCH(false, 16);
+    }
+#undef FG_LAUNCH
 }
 
 }  // namespace mi355x

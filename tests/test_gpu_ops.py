@@ -268,6 +268,149 @@ def test_quantised_gemv_raw_blocks(sd, oracle, gpu, rng, wtype, tol, tokens, K, 
             assert rel_l2(out, alt) < 5e-4
 
 
+@pytest.mark.parametrize("wtype,tol", [(Q8_0, 1e-2), (Q4_0, 3e-2)])
+@pytest.mark.parametrize("tokens,K,M,res", [(3, 768, 96, False), (33, 256, 100, True), (77, 768, 320, False), (64, 1024, 640, True), (130, 3072, 1152, True),
+                                            (300, 1280, 320, False), (512, 4096, 200, False), (257, 12288, 128, True), (600, 768, 96, False)])
+def test_quantised_mfma_gemm_raw_blocks(sd, oracle, gpu, rng, wtype, tol, tokens, K, M, res):
+    """q8_0 / q4_0 Linear under 3 .. 512 activation rows (text-stream Linears of the DiTs, text encoders): k_qgemm16 streams the RAW GGUF blocks,
+    dequantises them in registers into MFMA B fragments (f16(d * q), bit-identical to what the f16 weight image would hold) and never builds
+    that image.  Bars as for test_linear_weight_gemm; against the same Linear on the f16-image GEMM only the f32 summation order differs.
+    600 rows: above qgemm16_max_rows, stays on the image path."""
+    x = rng.standard_normal((tokens, K)).astype(np.float32)
+    w = (rng.standard_normal((M, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(M).astype(np.float32)
+    r = rng.standard_normal((tokens, M)).astype(np.float32)
+
+    def build(g, L):
+        y = L.ggml_add_inplace(g.ctx, L.ggml_mul_mat(g.ctx, g.weight(w, wtype), g.input(x)), g.weight(b, F32))
+        return L.ggml_add(g.ctx, y, g.input(r)) if res else y
+
+    before = sd.backend_stats() if _on_gpu() else None
+    ref, out = run_both(sd, oracle, gpu, build)
+    assert np.isfinite(out).all()
+    assert rel_l2(out, ref) < tol
+    exact = x.astype(np.float64) @ dequant(w, wtype).astype(np.float64).T + b + (r if res else 0)
+    if _on_gpu():
+        assert rel_l2(out.reshape(tokens, M), exact) < 2e-3
+    if before is not None and not os.environ.get("SDCPP_BACKEND_OPTS"):
+        st = sd.backend_stats()
+        taken = st["qgemm16_linears"] - before["qgemm16_linears"]
+        assert taken == (1 if tokens <= 512 else 0)
+        if taken:
+            assert st["swizzled_weight_bytes"] == before["swizzled_weight_bytes"]   # no f16 image was built for this weight
+            sd.backend_set_option("qgemm16", 0)
+            try:
+                with Graph(gpu) as g2:
+                    alt = g2.run(build(g2, sd.lib()))
+            finally:
+                sd.backend_set_option("qgemm16", 1)
+            assert sd.backend_stats()["swizzled_weight_bytes"] > st["swizzled_weight_bytes"]
+            assert rel_l2(out, alt) < 2e-5   # same f16 weights, same f16 activations: f32 summation order only
+
+
+@pytest.mark.parametrize("wtype", [F16, F32])
+@pytest.mark.parametrize("rows,K,M,res,silu", [(16, 1280, 320, False, True), (16, 1280, 1280, False, True), (16, 320, 1280, False, False), (1, 320, 1280, False, False),
+                                                (5, 768, 100, True, False), (2, 2816, 1280, False, True), (9, 1280, 644, True, True), (16, 24, 8, False, True),
+                                                (17, 1280, 320, False, True)])
+def test_few_row_linear_weight_stream(sd, oracle, gpu, rng, wtype, rows, K, M, res, silu):
+    """Linear with f16 / f32 weights under <= 16 activation rows (time_embed, ResBlock emb_layers: SiLU(emb) -> Linear, block.hpp:126-160): ONE
+    k_fgemv launch; the SiLU node in front of it is not executed (applied while the rows are staged).  f16 weights: the MFMA path's rounding
+    points (summation order only vs the GEMM); f32 weights: f32 x f32 like the oracle (the GEMM image rounds both to f16).  17 rows: GEMM."""
+    x = rng.standard_normal((rows, K)).astype(np.float32)
+    w = (rng.standard_normal((M, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(M).astype(np.float32)
+    r = rng.standard_normal((rows, M)).astype(np.float32)
+
+    def build(g, L):
+        h = g.input(x)
+        if silu:
+            h = L.ggml_silu(g.ctx, h)
+        y = L.ggml_add_inplace(g.ctx, L.ggml_mul_mat(g.ctx, g.weight(w, wtype), h), g.weight(b, F32))
+        return L.ggml_add(g.ctx, y, g.input(r)) if res else y
+
+    before = sd.backend_stats() if _on_gpu() else None
+    ref, out = run_both(sd, oracle, gpu, build)
+    assert np.isfinite(out).all()
+    taken = rows <= 16
+    on_stream = _on_gpu() and not os.environ.get("SDCPP_BACKEND_OPTS")
+    assert rel_l2(out, ref) < (2e-4 if wtype == F16 else (1e-5 if taken and on_stream else 2e-3))
+    if before is not None and not os.environ.get("SDCPP_BACKEND_OPTS"):
+        st = sd.backend_stats()
+        assert st["fgemv_linears"] - before["fgemv_linears"] == (1 if taken else 0)
+        assert st["fused_presilu"] - before["fused_presilu"] == (1 if taken and silu else 0)
+        if taken:
+            assert st["swizzled_weight_bytes"] == before["swizzled_weight_bytes"]   # no weight image, no pack, no split-K pass
+            assert st["kernels_planned"] - before["kernels_planned"] == 1
+            sd.backend_set_option("fgemv", 0)
+            try:
+                with Graph(gpu) as g2:
+                    alt = g2.run(build(g2, sd.lib()))
+            finally:
+                sd.backend_set_option("fgemv", 1)
+            assert rel_l2(out, alt) < (2e-5 if wtype == F16 else 2e-3)
+
+
+@pytest.mark.parametrize("wtype", [Q8_0, Q4_0])
+def test_quantised_gemv_with_deferred_silu(sd, oracle, gpu, rng, wtype):
+    """adaLN modulation with quantised weights (mmdit.hpp / flux.hpp: Linear(SiLU(vec)) on one row per image): the SiLU is applied by k_qgemv
+    while it stages the rows."""
+    rows, K, M = 2, 1024, 600
+    x = rng.standard_normal((rows, K)).astype(np.float32)
+    w = (rng.standard_normal((M, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(M).astype(np.float32)
+
+    def build(g, L):
+        return L.ggml_add_inplace(g.ctx, L.ggml_mul_mat(g.ctx, g.weight(w, wtype), L.ggml_silu(g.ctx, g.input(x))), g.weight(b, F32))
+
+    before = sd.backend_stats() if _on_gpu() else None
+    ref, out = run_both(sd, oracle, gpu, build)
+    assert rel_l2(out, ref) < (1e-2 if wtype == Q8_0 else 3e-2)
+    xs = x / (1 + np.exp(-x.astype(np.float64)))
+    exact = xs @ dequant(w, wtype).astype(np.float64).T + b
+    if _on_gpu():
+        assert rel_l2(out.reshape(rows, M), exact) < 2e-3
+    if before is not None and not os.environ.get("SDCPP_BACKEND_OPTS"):
+        st = sd.backend_stats()
+        assert st["qgemv_linears"] - before["qgemv_linears"] == 1 and st["fused_presilu"] - before["fused_presilu"] == 1
+        assert st["kernels_planned"] - before["kernels_planned"] == 1
+
+
+@pytest.mark.parametrize("wtype", [Q8_0, Q4_0])
+def test_quantised_mlp_gelu_chain_raw_blocks(sd, oracle, gpu, rng, wtype):
+    """Mlp (block.hpp:249-258) with quantised weights on a short token run: fc1 -> GELU is written by k_qgemm16 as the f16 operand image of
+    fc2, fc2 (+bias, +residual) reads it — both Linears on raw blocks."""
+    tokens, C, Hd = 154, 256, 1024
+    x = rng.standard_normal((tokens, C)).astype(np.float32)
+    w1 = (rng.standard_normal((Hd, C)) / np.sqrt(C)).astype(np.float32)
+    b1 = rng.standard_normal(Hd).astype(np.float32) * 0.1
+    w2 = (rng.standard_normal((C, Hd)) / np.sqrt(Hd)).astype(np.float32)
+    b2 = rng.standard_normal(C).astype(np.float32) * 0.1
+
+    def build(g, L):
+        xin = g.input(x)
+        h = L.ggml_add_inplace(g.ctx, L.ggml_mul_mat(g.ctx, g.weight(w1, wtype), xin), g.weight(b1, F32))
+        h = L.ggml_gelu_inplace(g.ctx, h)
+        y = L.ggml_add_inplace(g.ctx, L.ggml_mul_mat(g.ctx, g.weight(w2, wtype), h), g.weight(b2, F32))
+        return L.ggml_add(g.ctx, y, xin)
+
+    before = sd.backend_stats() if _on_gpu() else None
+    ref, out = run_both(sd, oracle, gpu, build)
+    assert np.isfinite(out).all()
+    assert rel_l2(out, ref) < (1e-2 if wtype == Q8_0 else 3e-2)
+    if before is not None and not os.environ.get("SDCPP_BACKEND_OPTS"):
+        st = sd.backend_stats()
+        assert st["qgemm16_linears"] - before["qgemm16_linears"] == 2
+        assert st["fused_gelu"] - before["fused_gelu"] == 1
+        assert st["swizzled_weight_bytes"] == before["swizzled_weight_bytes"]
+        sd.backend_set_option("qgemm16", 0)
+        try:
+            with Graph(gpu) as g2:
+                alt = g2.run(build(g2, sd.lib()))
+        finally:
+            sd.backend_set_option("qgemm16", 1)
+        assert rel_l2(out, alt) < 1e-4   # the f16 rounding of gelu(fc1) can flip on summation-order differences
+
+
 def test_linear_residual_fusion_and_batch_dims(sd, oracle, gpu, rng):
     # [C, L, N] activations, bias + residual: the BasicTransformerBlock tail (block.hpp:450-466)
     x = rng.standard_normal((2, 64, 320)).astype(np.float32)

@@ -98,6 +98,193 @@ DIT_CASES = [
 ]
 
 
+# diffusers SD3Transformer2DModel names (public diffusers layout) -> original MMDiT names; parts of fused parameters carry ".<index>"
+SD3_DIFFUSERS_CASES = [
+    ("transformer.time_text_embed.timestep_embedder.linear_1.weight", MDM + "t_embedder.mlp.0.weight"),
+    ("transformer.time_text_embed.timestep_embedder.linear_2.bias", MDM + "t_embedder.mlp.2.bias"),
+    ("transformer.time_text_embed.text_embedder.linear_1.weight", MDM + "y_embedder.mlp.0.weight"),
+    ("transformer.pos_embed.pos_embed", MDM + "pos_embed"),
+    ("transformer.pos_embed.proj.weight", MDM + "x_embedder.proj.weight"),
+    ("transformer.context_embedder.bias", MDM + "context_embedder.bias"),
+    ("transformer.transformer_blocks.3.norm1.linear.weight", MDM + "joint_blocks.3.x_block.adaLN_modulation.1.weight"),
+    ("transformer.transformer_blocks.3.norm1_context.linear.bias", MDM + "joint_blocks.3.context_block.adaLN_modulation.1.bias"),
+    ("transformer.transformer_blocks.0.attn.to_q.weight", MDM + "joint_blocks.0.x_block.attn.qkv.weight"),
+    ("transformer.transformer_blocks.0.attn.to_k.weight", MDM + "joint_blocks.0.x_block.attn.qkv.weight.1"),
+    ("transformer.transformer_blocks.0.attn.to_v.bias", MDM + "joint_blocks.0.x_block.attn.qkv.bias.2"),
+    ("transformer.transformer_blocks.11.attn.add_k_proj.weight", MDM + "joint_blocks.11.context_block.attn.qkv.weight.1"),
+    ("transformer.transformer_blocks.2.attn2.to_v.weight", MDM + "joint_blocks.2.x_block.attn2.qkv.weight.2"),
+    ("transformer.transformer_blocks.2.attn.norm_q.weight", MDM + "joint_blocks.2.x_block.attn.ln_q.weight"),
+    ("transformer.transformer_blocks.2.attn.norm_added_k.weight", MDM + "joint_blocks.2.context_block.attn.ln_k.weight"),
+    ("transformer.transformer_blocks.2.attn2.norm_k.weight", MDM + "joint_blocks.2.x_block.attn2.ln_k.weight"),
+    ("transformer.transformer_blocks.5.ff.net.0.proj.weight", MDM + "joint_blocks.5.x_block.mlp.fc1.weight"),
+    ("transformer.transformer_blocks.5.ff.net.2.bias", MDM + "joint_blocks.5.x_block.mlp.fc2.bias"),
+    ("transformer.transformer_blocks.5.ff_context.net.0.proj.bias", MDM + "joint_blocks.5.context_block.mlp.fc1.bias"),
+    ("transformer.transformer_blocks.5.attn.to_out.0.weight", MDM + "joint_blocks.5.x_block.attn.proj.weight"),
+    ("transformer.transformer_blocks.5.attn.to_add_out.bias", MDM + "joint_blocks.5.context_block.attn.proj.bias"),
+    ("transformer.transformer_blocks.5.attn2.to_out.0.bias", MDM + "joint_blocks.5.x_block.attn2.proj.bias"),
+    ("transformer.proj_out.weight", MDM + "final_layer.linear.weight"),
+    ("transformer.norm_out.linear.bias", MDM + "final_layer.adaLN_modulation.1.bias"),
+    ("model.diffusion_model.transformer_blocks.1.attn.to_k.bias", MDM + "joint_blocks.1.x_block.attn.qkv.bias.1"),
+    ("model.diffusion_model.x_embedder.proj.weight", MDM + "x_embedder.proj.weight"),   # already original
+]
+
+FLUX_DIFFUSERS_CASES = [
+    ("transformer.time_text_embed.timestep_embedder.linear_1.weight", MDM + "time_in.in_layer.weight"),
+    ("transformer.time_text_embed.text_embedder.linear_2.bias", MDM + "vector_in.out_layer.bias"),
+    ("transformer.time_text_embed.guidance_embedder.linear_1.weight", MDM + "guidance_in.in_layer.weight"),
+    ("transformer.context_embedder.weight", MDM + "txt_in.weight"),
+    ("transformer.x_embedder.bias", MDM + "img_in.bias"),
+    ("transformer.transformer_blocks.7.norm1.linear.weight", MDM + "double_blocks.7.img_mod.lin.weight"),
+    ("transformer.transformer_blocks.7.norm1_context.linear.bias", MDM + "double_blocks.7.txt_mod.lin.bias"),
+    ("transformer.transformer_blocks.7.attn.to_q.weight", MDM + "double_blocks.7.img_attn.qkv.weight"),
+    ("transformer.transformer_blocks.7.attn.to_v.weight", MDM + "double_blocks.7.img_attn.qkv.weight.2"),
+    ("transformer.transformer_blocks.7.attn.add_k_proj.bias", MDM + "double_blocks.7.txt_attn.qkv.bias.1"),
+    ("transformer.transformer_blocks.7.attn.norm_q.weight", MDM + "double_blocks.7.img_attn.norm.query_norm.scale"),
+    ("transformer.transformer_blocks.7.attn.norm_added_k.weight", MDM + "double_blocks.7.txt_attn.norm.key_norm.scale"),
+    ("transformer.transformer_blocks.7.ff.net.0.proj.weight", MDM + "double_blocks.7.img_mlp.0.weight"),
+    ("transformer.transformer_blocks.7.ff_context.net.2.bias", MDM + "double_blocks.7.txt_mlp.2.bias"),
+    ("transformer.transformer_blocks.7.attn.to_out.0.weight", MDM + "double_blocks.7.img_attn.proj.weight"),
+    ("transformer.transformer_blocks.7.attn.to_add_out.weight", MDM + "double_blocks.7.txt_attn.proj.weight"),
+    ("transformer.single_transformer_blocks.30.norm.linear.weight", MDM + "single_blocks.30.modulation.lin.weight"),
+    ("transformer.single_transformer_blocks.30.attn.to_q.weight", MDM + "single_blocks.30.linear1.weight"),
+    ("transformer.single_transformer_blocks.30.attn.to_k.bias", MDM + "single_blocks.30.linear1.bias.1"),
+    ("transformer.single_transformer_blocks.30.attn.to_v.weight", MDM + "single_blocks.30.linear1.weight.2"),
+    ("transformer.single_transformer_blocks.30.proj_mlp.weight", MDM + "single_blocks.30.linear1.weight.3"),
+    ("transformer.single_transformer_blocks.30.attn.norm_q.weight", MDM + "single_blocks.30.norm.query_norm.scale"),
+    ("transformer.single_transformer_blocks.30.attn.norm_k.weight", MDM + "single_blocks.30.norm.key_norm.scale"),
+    ("transformer.single_transformer_blocks.30.proj_out.bias", MDM + "single_blocks.30.linear2.bias"),
+    ("transformer.proj_out.weight", MDM + "final_layer.linear.weight"),
+    ("transformer.norm_out.linear.weight", MDM + "final_layer.adaLN_modulation.1.weight"),
+    ("model.diffusion_model.double_blocks.0.img_attn.norm.query_norm.weight", MDM + "double_blocks.0.img_attn.norm.query_norm.scale"),
+    ("model.diffusion_model.single_blocks.4.norm.key_norm.weight", MDM + "single_blocks.4.norm.key_norm.scale"),
+    ("model.diffusion_model.double_blocks.0.img_attn.qkv.weight", MDM + "double_blocks.0.img_attn.qkv.weight"),   # already original
+]
+
+
+@pytest.mark.parametrize("raw,want", SD3_DIFFUSERS_CASES)
+def test_sd3_diffusers_names(sd, oracle, raw, want):
+    e = sd.Engine(model=sd.SD35_TINY, backend=oracle)
+    assert e.convert_tensor_name(raw) == want
+
+
+@pytest.mark.parametrize("raw,want", FLUX_DIFFUSERS_CASES)
+def test_flux_diffusers_names(sd, oracle, raw, want):
+    e = sd.Engine(model=sd.FLUX_TINY, backend=oracle)
+    assert e.convert_tensor_name(raw) == want
+
+
+# ---- independent inverse: original MMDiT / Flux names -> diffusers (the direction of diffusers' convert_sd3_to_diffusers / convert_flux_to_diffusers),
+# splitting every fused parameter into the separate Linears diffusers stores
+def mmdit_to_diffusers(name, arr):
+    """-> list of (diffusers name, array)"""
+    top = {"t_embedder.mlp.0": "time_text_embed.timestep_embedder.linear_1", "t_embedder.mlp.2": "time_text_embed.timestep_embedder.linear_2",
+           "y_embedder.mlp.0": "time_text_embed.text_embedder.linear_1", "y_embedder.mlp.2": "time_text_embed.text_embedder.linear_2",
+           "x_embedder.proj": "pos_embed.proj", "final_layer.linear": "proj_out", "final_layer.adaLN_modulation.1": "norm_out.linear",
+           "context_embedder": "context_embedder"}
+    if name == "pos_embed":
+        return [("pos_embed.pos_embed", arr)]
+    stem, leaf = name.rsplit(".", 1)
+    if stem in top:
+        return [(f"{top[stem]}.{leaf}", arr)]
+    m = re.match(r"joint_blocks\.(\d+)\.(x_block|context_block)\.(.*)\.(weight|bias)$", name)
+    assert m, name
+    i, blk, member, leaf = m.groups()
+    x = blk == "x_block"
+    pre = f"transformer_blocks.{i}."
+    if member == "adaLN_modulation.1":
+        return [(pre + ("norm1" if x else "norm1_context") + f".linear.{leaf}", arr)]
+    mm = re.match(r"(attn2?)\.(qkv|proj|ln_q|ln_k)$", member)
+    if mm:
+        a, what = mm.groups()
+        if what == "qkv":
+            names = ["to_q", "to_k", "to_v"] if x else ["add_q_proj", "add_k_proj", "add_v_proj"]
+            return [(pre + f"{a}.{n}.{leaf}", part) for n, part in zip(names, np.split(arr, 3, axis=0))]
+        if what == "proj":
+            return [(pre + f"{a}." + ("to_out.0" if x else "to_add_out") + f".{leaf}", arr)]
+        return [(pre + f"{a}.norm_" + ("" if x else "added_") + what[-1] + f".{leaf}", arr)]
+    ff = "ff" if x else "ff_context"
+    if member == "mlp.fc1":
+        return [(pre + f"{ff}.net.0.proj.{leaf}", arr)]
+    assert member == "mlp.fc2", name
+    return [(pre + f"{ff}.net.2.{leaf}", arr)]
+
+
+def flux_to_diffusers(name, arr, hidden):
+    top = {"time_in.in_layer": "time_text_embed.timestep_embedder.linear_1", "time_in.out_layer": "time_text_embed.timestep_embedder.linear_2",
+           "vector_in.in_layer": "time_text_embed.text_embedder.linear_1", "vector_in.out_layer": "time_text_embed.text_embedder.linear_2",
+           "guidance_in.in_layer": "time_text_embed.guidance_embedder.linear_1", "guidance_in.out_layer": "time_text_embed.guidance_embedder.linear_2",
+           "txt_in": "context_embedder", "img_in": "x_embedder", "final_layer.linear": "proj_out", "final_layer.adaLN_modulation.1": "norm_out.linear"}
+    stem, leaf = name.rsplit(".", 1)
+    if stem in top:
+        return [(f"{top[stem]}.{leaf}", arr)]
+    m = re.match(r"double_blocks\.(\d+)\.(img|txt)_(mod\.lin|attn\.qkv|attn\.proj|attn\.norm\.query_norm|attn\.norm\.key_norm|mlp\.0|mlp\.2)\.(weight|bias|scale)$", name)
+    if m:
+        i, side, member, leaf = m.groups()
+        img = side == "img"
+        pre = f"transformer_blocks.{i}."
+        if member == "mod.lin":
+            return [(pre + ("norm1" if img else "norm1_context") + f".linear.{leaf}", arr)]
+        if member == "attn.qkv":
+            names = ["to_q", "to_k", "to_v"] if img else ["add_q_proj", "add_k_proj", "add_v_proj"]
+            return [(pre + f"attn.{n}.{leaf}", part) for n, part in zip(names, np.split(arr, 3, axis=0))]
+        if member == "attn.proj":
+            return [(pre + "attn." + ("to_out.0" if img else "to_add_out") + f".{leaf}", arr)]
+        if member.startswith("attn.norm"):
+            return [(pre + "attn.norm_" + ("" if img else "added_") + ("q" if "query" in member else "k") + ".weight", arr)]
+        ff = "ff" if img else "ff_context"
+        return [(pre + (f"{ff}.net.0.proj" if member == "mlp.0" else f"{ff}.net.2") + f".{leaf}", arr)]
+    m = re.match(r"single_blocks\.(\d+)\.(modulation\.lin|linear1|linear2|norm\.query_norm|norm\.key_norm)\.(weight|bias|scale)$", name)
+    assert m, name
+    i, member, leaf = m.groups()
+    pre = f"single_transformer_blocks.{i}."
+    if member == "modulation.lin":
+        return [(pre + f"norm.linear.{leaf}", arr)]
+    if member == "linear1":
+        parts = np.split(arr, [hidden, 2 * hidden, 3 * hidden], axis=0)   # q, k, v, mlp (unequal sizes)
+        return [(pre + f"{n}.{leaf}", part) for n, part in zip(["attn.to_q", "attn.to_k", "attn.to_v", "proj_mlp"], parts)]
+    if member == "linear2":
+        return [(pre + f"proj_out.{leaf}", arr)]
+    return [(pre + "attn.norm_" + ("q" if "query" in member else "k") + ".weight", arr)]
+
+
+@pytest.mark.parametrize("which", ["SD35_TINY", "FLUX_TINY"])
+def test_diffusers_dit_checkpoint_loads_bit_identically(sd, oracle, tmp_path, which):
+    """A diffusers-format transformer file (separate to_q / to_k / to_v [/ proj_mlp] Linears, 'transformer.' component prefix) loads into the
+    fused original-dialect parameters: every tensor name converts, the parts are stacked in order, and the forward is bit-identical to the
+    engine the file was written from.  f16 matrices and f32 vectors, as the engine stores them."""
+    from safetensors.numpy import save_file
+
+    model = getattr(sd, which)
+    src = sd.Engine(model=model, backend=oracle, weight_seed=11)
+    names = [n for n in src.tensor_names() if n.startswith(MDM)]
+    hidden = None
+    if which == "FLUX_TINY":
+        hidden = src.get_tensor(MDM + "single_blocks.0.linear2.weight").shape[0]
+    foreign, n_parts = {}, 0
+    for name in names:
+        arr = src.get_tensor(name)
+        arr = arr.astype(np.float16 if src.tensor_info(name)[1] == sd.F16 else np.float32)
+        pieces = mmdit_to_diffusers(name[len(MDM):], arr) if which == "SD35_TINY" else flux_to_diffusers(name[len(MDM):], arr, hidden)
+        n_parts += len(pieces) - 1
+        for dn, part in pieces:
+            assert "transformer." + dn not in foreign
+            foreign["transformer." + dn] = np.ascontiguousarray(part)
+            assert src.convert_tensor_name("transformer." + dn).split(".")[0] == "model"
+    assert n_parts > 0
+    save_file(foreign, str(tmp_path / "dit.safetensors"))
+    e = sd.Engine(model=model, backend=oracle, weight_seed=99)
+    r = e.load_weights(tmp_path / "dit.safetensors")
+    assert r["loaded"] == len(names) and r["unused"] == 0, r
+    for name in names:
+        np.testing.assert_array_equal(e.get_tensor(name), src.get_tensor(name), err_msg=name)
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((1, 16, 8, 8)).astype(np.float32)
+    t = np.array([0.6 if which == "FLUX_TINY" else 600.0], np.float32)
+    ctx = rng.standard_normal((1, 12, 96)).astype(np.float32)
+    y = rng.standard_normal((1, 64)).astype(np.float32)
+    np.testing.assert_array_equal(e.unet_forward(x, t, ctx, y), src.unet_forward(x, t, ctx, y))
+
+
 @pytest.mark.parametrize("raw,want", SD1_CASES)
 def test_sd1_names(e15, raw, want):
     assert e15.convert_tensor_name(raw) == want

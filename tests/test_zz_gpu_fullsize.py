@@ -325,7 +325,14 @@ def test_real_width_flux_blocks_vs_oracle(sd, oracle, gpu, wtype, tol):
     y = rng.standard_normal((1, 768)).astype(np.float32)
     wt = getattr(sd, wtype)
     ref = sd.Engine(model=sd.FLUX_WIDE1, backend=oracle, wtype=wt, flash_attn=False).unet_forward(x, t, c, y)   # exact-softmax chain
+    before = sd.backend_stats() if ON_GPU else None
     out = sd.Engine(model=sd.FLUX_WIDE1, backend=gpu, wtype=wt, flash_attn=True).unet_forward(x, t, c, y)
     err = rel_l2(out, ref)
     print(f"real-width FLUX blocks {wtype}: rel-L2 vs oracle {err:.3e}")
     assert np.isfinite(out).all() and err < tol
+    if before is not None and wtype == "Q4_0" and not os.environ.get("SDCPP_BACKEND_OPTS"):
+        st = sd.backend_stats()
+        # the 77-token text stream (txt_in, txt qkv / proj / mlp) runs on k_qgemm16 and the one-row modulation / embedder Linears on k_qgemv:
+        # raw q4_0 blocks, no f16 weight image for any of them
+        assert st["qgemm16_linears"] - before["qgemm16_linears"] >= 4, st
+        assert st["qgemv_linears"] - before["qgemv_linears"] >= 3, st
