@@ -1,7 +1,8 @@
 #!/usr/bin/env python
-"""k_qgemm16 (raw q8_0 / q4_0 blocks, in-register dequant on the way into the MFMA units) against the f16-weight-image GEMM on the text-stream
-Linear shapes of FLUX / SD3.5 / T5: time per launch (HIP events around each dispatch, all families summed so the image path's pack + split-K
-passes count) and the weight-stream rate.  Finds the row count where the image path takes over (option qgemm16_max_rows)."""
+"""Quantised Linears (q8_0 / q4_0 GGUF blocks) on the three paths the planner can take, per row count, on the text-stream / modulation shapes of
+FLUX and SD3.5:  raw-gemv = k_qgemv / k_qgemv_rows (<= 16 rows, VALU, one launch);  raw-mfma = k_qgemm16 (raw blocks dequantised in registers into
+MFMA fragments);  image = f16 weight image + k_gemm16.  Time = HIP events around each dispatch summed over ALL kernel families of the graph (so
+pack / split-K passes count), with the split per family.  This is the measurement behind the planner's defaults (qgemv_max_rows, qgemm16_max_rows)."""
 import sys
 from pathlib import Path
 
@@ -17,6 +18,8 @@ sd.load_mi355x_backend()
 L = sd.lib()
 rng = np.random.default_rng(0)
 REPS = 5
+MODES = {"raw-gemv": dict(qgemv=1, qgemv_max_rows=16, qgemm16_max_rows=0), "raw-mfma": dict(qgemv=1, qgemv_max_rows=2, qgemm16_max_rows=4096),
+         "image": dict(qgemv=0, qgemv_max_rows=16, qgemm16_max_rows=0)}
 
 
 def rel_l2(a, b):
@@ -29,9 +32,11 @@ def case(rows, K, M, wtype):
     w = (rng.standard_normal((M, K)) / np.sqrt(K)).astype(np.float32)
     b = rng.standard_normal(M).astype(np.float32)
     res = {}
-    for mode in (1, 0):
-        sd.backend_set_option("qgemm16", mode)
-        sd.backend_set_option("qgemm16_max_rows", 4096)
+    for mode, opts in MODES.items():
+        if mode == "raw-gemv" and rows > 16:
+            continue
+        for k, v in opts.items():
+            sd.backend_set_option(k, v)
         with Graph("MI355X0") as g:
             node = L.ggml_add_inplace(g.ctx, L.ggml_mul_mat(g.ctx, g.weight(w, wtype), g.input(x)), g.weight(b, F32))
             out = g.run(node)
@@ -42,17 +47,19 @@ def case(rows, K, M, wtype):
                 L.ggml_backend_graph_compute(g.backend, gf)
             t = sd.kernel_timings()
             sd.kernel_timing_enable(0)
-        res[mode] = (out, sum(f["total_ms"] for f in t) / REPS * 1e3)
-    sd.backend_set_option("qgemm16", 1)
-    sd.backend_set_option("qgemm16_max_rows", 512)
+        split = " + ".join(f"{f['kernel'].split('(')[0].strip()[:14]} {f['total_ms'] / REPS * 1e3:.1f}" for f in t if f["total_ms"] > 0)
+        res[mode] = (out, sum(f["total_ms"] for f in t) / REPS * 1e3, split)
+    for k, v in MODES["raw-gemv"].items():
+        sd.backend_set_option(k, v)
     wb = M * K // 32 * (34 if wtype == Q8_0 else 18)
-    q_us, i_us = res[1][1], res[0][1]
-    print(f"{'q8_0' if wtype == Q8_0 else 'q4_0'} rows={rows:5d} K={K:5d} M={M:5d} | raw blocks {q_us:7.1f} us ({wb / q_us / 1e3:7.1f} GB/s of quantised weights, "
-          f"{2.0 * rows * K * M / q_us / 1e6:6.1f} TF) | f16 image {i_us:7.1f} us ({2.0 * M * K / i_us / 1e3:7.1f} GB/s of image) | rel {rel_l2(res[1][0], res[0][0]):.1e}", flush=True)
+    line = f"{'q8_0' if wtype == Q8_0 else 'q4_0'} rows={rows:4d} K={K:5d} M={M:5d} ({wb / 1e6:5.1f} MB quantised)"
+    for mode, (out, us, split) in res.items():
+        line += f" | {mode}: {us:6.1f} us [{split}] rel {rel_l2(out, res['image'][0]):.0e}"
+    print(line, flush=True)
 
 
-shapes = [(3072, 9216), (3072, 12288), (12288, 3072), (4096, 3072)]
+shapes = [(3072, 9216), (3072, 18432), (12288, 3072), (4096, 3072)]
 for wtype in (Q8_0, Q4_0):
     for K, M in shapes:
-        for rows in (4, 32, 77, 128, 256, 512, 1024, 2048):
+        for rows in (1, 2, 4, 8, 16, 32, 77, 256):
             case(rows, K, M, wtype)

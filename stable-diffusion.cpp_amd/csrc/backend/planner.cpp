@@ -1927,6 +1927,7 @@ void planner_set_option(const char* key, int value) {
     else if (!strcmp(key, "flash_grid")) flash_attn_set_grid(value);
     else if (!strcmp(key, "gemm16_bn64")) gemm16_set_bn64(value);
     else if (!strcmp(key, "qgemm16")) g_opt.qgemm16 = value;
+    else if (!strcmp(key, "qgemv_max_rows")) qgemv_set_max_rows(value);
     else if (!strcmp(key, "fgemv")) g_opt.fgemv = value;
     else if (!strcmp(key, "fgemv_max_rows")) fgemv_set_max_rows(value);
     else if (!strcmp(key, "qgemm16_max_rows")) qgemm16_set_max_rows(value);

@@ -1009,9 +1009,9 @@ int gemm16_split_k(int64_t rows, int64_t M, int64_t K) {
 //     as a bare LDS-read -> MFMA chain with nothing to overlap (0.7 us per 128x128x32 step whatever the ring depth, wave count or tile width,
 //     profiles/r02q_tile_sweep.txt), so the launch takes nt x 0.7 us; S slices cut the chain to nt / S steps and bring S x the workgroups.
 //     The last arriver applies the launch's full epilogue, so every output mode (head-major, f16 image, gate, residual) can split.
-static int g_g16_sk_inkernel = 1;  // option "splitk_inkernel": 0 = never combine in the launch
+static int g_g16_sk_inkernel = 0;  // option "splitk_inkernel": 1 = combine in the launch.  Default off: whole-model A/B on SD1.5 (profiles/r02r_*) 26.36 vs 25.95-26.13 ms of kernels per forward
 void gemm16_set_splitk_inkernel(int v) { g_g16_sk_inkernel = v; }
-static int g_g16_sk_in_target = 640;  // option "splitk_in_target": workgroups an in-launch split aims for
+static int g_g16_sk_in_target = 320;  // option "splitk_in_target": workgroups an in-launch split aims for
 void gemm16_set_splitk_in_target(int v) { g_g16_sk_in_target = v; }
 static bool g16_use_bn64(int64_t rows, int64_t M) {
     const int64_t c128 = ((rows + 127) / 128) * ((M + 127) / 128);

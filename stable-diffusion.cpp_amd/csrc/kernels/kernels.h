@@ -132,6 +132,7 @@ void launch_nchw_to_nhwc_f16(hipStream_t s, void* dst, const float* x, int64_t h
 
 // ---- qgemm.hip: q8_0 / q4_0 Linear with <= 4 activation rows: raw quantised blocks streamed once, in-register dequant ----------------
 bool qgemv_supported(int wtype, int64_t rows, int64_t K);
+void qgemv_set_max_rows(int v);
 size_t qgemv_workspace_bytes(int64_t rows, int64_t K);
 void launch_qgemv(hipStream_t s, float* dst, int64_t ldd, const float* x, int64_t xs, int64_t rows, const void* wraw, int wtype, int64_t K, int64_t M, void* ws,
                   const Epilogue& ep, float pre_scale, bool pre_silu = false);

@@ -206,13 +206,161 @@ __global__ __launch_bounds__(256) void k_qgemv(QGArgs g) {
     }
 }
 
+// k_qgemv_rows — the same raw-block stream for 3 .. 16 activation rows (modulation vectors / embedders of a DiT batch, SDXL label embedding at
+// batch > 1).  A block's 32 weights are decoded ONCE into registers (exact integers, the scale d applied to the block sum) and re-used by every
+// row; the rows live in LDS as f16 (R x 32 floats per lane do not fit in registers beyond two rows).  Rounding points as k_qgemv.  One launch:
+// no f16 pack of the rows, no weight image, no split-K pass (r02r: the MFMA paths need ~30 us for such a Linear, most of it launch chain).
+template <int QT, int R, int CPW>
+__global__ __launch_bounds__(256) void k_qgemv_rows(QGArgs g) {
+    constexpr int BLK  = QT == 8 ? 34 : 18;
+    constexpr int SEGB = 64 * BLK;
+    constexpr int NG   = (SEGB + 15) / 16;
+    constexpr int NLD  = (NG + 63) / 64;
+    constexpr int NDW  = QT == 8 ? 9 : 5;
+    __shared__ __attribute__((aligned(16))) char strip[4][NLD * 64 * 16 + 16];
+    extern __shared__ __attribute__((aligned(16))) char xlds[];  // [R][K] halfs, 16-byte chunk c of block b at chunk slot c ^ (b & 3)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    char* my       = strip[wave];
+    const int nblk = g.K / 32;
+    const int nseg = (nblk + 63) / 64;
+    const int col0 = (blockIdx.x * 4 + wave) * CPW;
+    for (int c8 = threadIdx.x; c8 < g.K / 8; c8 += 256) {  // all R rows of a chunk column in flight together
+        float4 a[R], b[R];
+#pragma unroll
+        for (int t = 0; t < R; ++t) {
+            const float* xr = g.x + (int64_t)(t < g.rows ? t : 0) * g.xs + c8 * 8;
+            a[t]            = *(const float4*)xr;
+            b[t]            = *(const float4*)(xr + 4);
+        }
+        const int blk = c8 >> 2, ch = c8 & 3;
+#pragma unroll
+        for (int t = 0; t < R; ++t) {
+            float v[8] = {a[t].x, a[t].y, a[t].z, a[t].w, b[t].x, b[t].y, b[t].z, b[t].w};
+            half8_t h;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float u = g.pre_silu ? act_apply<UN_SILU>(v[j]) : v[j];
+                h[j]          = (_Float16)(u * g.pre_scale);
+            }
+            *(half8_t*)(xlds + ((size_t)t * g.K + (size_t)blk * 32) * 2 + ((ch ^ (blk & 3)) << 4)) = h;
+        }
+    }
+    __syncthreads();
+    if (col0 >= g.M) return;
+    float acc[CPW][R];
+#pragma unroll
+    for (int c = 0; c < CPW; ++c)
+#pragma unroll
+        for (int t = 0; t < R; ++t) acc[c][t] = 0.f;
+    const uint32_t boff = (uint32_t)lane * BLK;
+    const uint32_t bal  = boff & ~3u;
+    const uint32_t bsh  = (boff & 2u) * 8u;
+    for (int seg = 0; seg < nseg; ++seg) {
+        const int blk      = seg * 64 + lane;
+        const bool have    = blk < nblk;
+        const int seg_blks = min(64, nblk - seg * 64);
+        const int seg_ng   = (seg_blks * BLK + 15) / 16;
+        const int64_t seg_byte = (int64_t)seg * SEGB;
+        uint4 gl[CPW][NLD];
+#pragma unroll
+        for (int c = 0; c < CPW; ++c) {
+            const int col    = min(col0 + c, g.M - 1);
+            const char* rowp = g.W + (int64_t)col * g.row_bytes + seg_byte;
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                const int gidx = i * 64 + lane;
+                gl[c][i]       = gidx < seg_ng ? *(const uint4*)(rowp + (int64_t)gidx * 16) : make_uint4(0, 0, 0, 0);
+            }
+        }
+        float wd[CPW][32];  // exact integers q (q8_0) / n - 8 (q4_0)
+        float dw[CPW];
+#pragma unroll
+        for (int c = 0; c < CPW; ++c) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) *(uint4*)(my + (i * 64 + lane) * 16) = gl[c][i];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            uint32_t raw[NDW];
+#pragma unroll
+            for (int j = 0; j < NDW; ++j) raw[j] = *(const uint32_t*)(my + bal + 4 * j);
+            uint32_t wq[NDW - 1];
+#pragma unroll
+            for (int j = 0; j + 1 < NDW; ++j) wq[j] = __builtin_amdgcn_alignbit(raw[j + 1], raw[j], bsh);
+            dw[c] = have ? (float)__builtin_bit_cast(_Float16, (uint16_t)(wq[0] & 0xFFFFu)) : 0.f;
+            constexpr int NQ = QT == 8 ? 8 : 4;
+#pragma unroll
+            for (int m = 0; m < NQ; ++m) {
+                const uint32_t hi = m + 1 < NDW - 1 ? wq[m + 1] : (raw[NDW - 1] >> bsh);
+                const uint32_t q  = __builtin_amdgcn_alignbit(hi, wq[m], 16);
+                if (QT == 8) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) wd[c][4 * m + j] = (float)(int)(int8_t)(q >> (8 * j));
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        wd[c][4 * m + j]      = (float)(int)((q >> (8 * j)) & 0xFu) - 8.f;
+                        wd[c][16 + 4 * m + j] = (float)(int)((q >> (8 * j + 4)) & 0xFu) - 8.f;
+                    }
+                }
+            }
+        }
+        const int bx = have ? blk : 0;
+#pragma unroll
+        for (int t = 0; t < R; ++t) {
+            const char* xb = xlds + ((size_t)t * g.K + (size_t)bx * 32) * 2;
+            float xv[32];
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) {
+                const half8_t h = *(const half8_t*)(xb + ((ch ^ (bx & 3)) << 4));
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xv[8 * ch + j] = (float)h[j];
+            }
+#pragma unroll
+            for (int c = 0; c < CPW; ++c) {
+                float sa = 0.f, sb = 0.f;
+#pragma unroll
+                for (int j = 0; j < 32; j += 2) {
+                    sa = fmaf(wd[c][j], xv[j], sa);
+                    sb = fmaf(wd[c][j + 1], xv[j + 1], sb);
+                }
+                acc[c][t] += dw[c] * (sa + sb);  // dw = 0 for lanes past the last block
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) {
+        const int col = col0 + c;
+        if (col >= g.M) break;
+        float mine = 0.f;
+#pragma unroll
+        for (int t = 0; t < R; ++t) {
+            const float v = wave_sum(acc[c][t]);
+            if (lane == t) mine = v;
+        }
+        if (lane < g.rows && lane < R) {
+            float o = mine * g.scale + (g.bias ? g.bias[col] : 0.f);
+            if (g.residual) o += g.residual[(int64_t)lane * g.ldd + col];
+            g.dst[(int64_t)lane * g.ldd + col] = o;
+        }
+    }
+}
+
+static int g_qgemv_max_rows = 16;  // option "qgemv_max_rows"
+void qgemv_set_max_rows(int v) { g_qgemv_max_rows = v > 16 ? 16 : (v < 1 ? 1 : v); }
+
 size_t qgemv_workspace_bytes(int64_t, int64_t) { return 0; }  // (the first version quantised the activations into a workspace)
 
 bool qgemv_supported(int wtype, int64_t rows, int64_t K) {
     // whole row segments are fetched with 16-byte loads: every row must start 16-byte aligned (34 * K/32 and 18 * K/32 are multiples of 16 iff
-    // K % 256 == 0).  Rows: the activation values of a block live in registers (32 per row) — one or two rows.  Above that the f16 weight
-    // image + MFMA GEMM take over: from ~32 rows on the contraction stops being a pure weight stream anyway.
-    return (wtype == 8 || wtype == 2) && rows >= 1 && rows <= 2 && K % 256 == 0 && K >= 256 && K <= 12288;  // activations staged as f16 in LDS: 2 rows x 12288 halfs = 48 KB
+    // K % 256 == 0).  One or two rows: k_qgemv (activation values of a block in registers);  3 .. 16 rows: k_qgemv_rows (rows in LDS as f16,
+    // up to 128 KB).  Above that the contraction belongs on the MFMA units.
+    if (!(wtype == 8 || wtype == 2) || rows < 1 || rows > g_qgemv_max_rows || K % 256 != 0 || K < 256) return false;
+    if (rows <= 2) return K <= 12288;  // 2 rows x 12288 halfs = 48 KB
+    const int64_t r = rows <= 4 ? 4 : rows <= 8 ? 8 : 16;
+    return r * K * 2 <= 128 * 1024;
 }
 
 // x: f32 rows (row stride xs floats, 16-byte aligned), multiplied by pre_scale before the f16 rounding (ggml_ext_linear's scale)
@@ -228,6 +376,34 @@ void launch_qgemv(hipStream_t s, float* dst, int64_t ldd, const float* x, int64_
     g.dst = dst; g.ldd = ldd;
     g.bias = ep.bias; g.residual = ep.residual; g.scale = ep.scale; g.pre_scale = pre_scale;
     g.K = (int)K; g.M = (int)M; g.rows = (int)rows; g.pre_silu = pre_silu ? 1 : 0;
+    if (rows > 2) {
+        constexpr int CPW2 = 2;
+        const unsigned grid2 = (unsigned)((M + 4 * CPW2 - 1) / (4 * CPW2));
+        const int r          = rows <= 4 ? 4 : rows <= 8 ? 8 : 16;
+        const size_t lds     = (size_t)r * K * 2;
+#define QGR_LAUNCH(QT_, R_)                                                                                                         \
+    do {                                                                                                                            \
+        static bool attr_dev_[64] = {false};                                                                                        \
+        int dev_ = 0;                                                                                                               \
+        (void)hipGetDevice(&dev_);                                                                                                  \
+        if (!attr_dev_[dev_ & 63]) {                                                                                                \
+            (void)hipFuncSetAttribute((const void*)k_qgemv_rows<QT_, R_, CPW2>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); \
+            attr_dev_[dev_ & 63] = true;                                                                                            \
+        }                                                                                                                           \
+        k_qgemv_rows<QT_, R_, CPW2><<<grid2, 256, lds, s>>>(g);                                                                     \
+    } while (0)
+        if (wtype == 8) {
+            if (r == 4) QGR_LAUNCH(8, 4);
+            else if (r == 8) QGR_LAUNCH(8, 8);
+            else QGR_LAUNCH(8, 16);
+        } else {
+            if (r == 4) QGR_LAUNCH(4, 4);
+            else if (r == 8) QGR_LAUNCH(4, 8);
+            else QGR_LAUNCH(4, 16);
+        }
+#undef QGR_LAUNCH
+        return;
+    }
     constexpr int CPW = 4;
     const unsigned grid = (unsigned)((M + 4 * CPW - 1) / (4 * CPW));
 #define QG_LAUNCH(QT_, R_) k_qgemv<QT_, R_, CPW><<<grid, 256, (size_t)(R_) * K * 2, s>>>(g)
@@ -240,7 +416,6 @@ void launch_qgemv(hipStream_t s, float* dst, int64_t ldd, const float* x, int64_
     }
 #undef QG_LAUNCH
 }
-
 
 // =====================================================================================================
 // k_qgemm16 — the same raw-block weight stream on the MATRIX CORES, for Linears with a few hundred activation rows (text-stream Linears of the
@@ -426,35 +601,35 @@ __global__ __launch_bounds__(256) void k_qgemm16(QG16Args g) {
                 const int row = rbase + (r & 3) + 8 * (r >> 2);
                 if (row < g.R) g.dst16[(int64_t)row * g.ldd16 + col] = (_Float16)act_apply<UN_GELU>(acc[rb][r] * g.scale + bias);
             }
-        } else if (mode == 2) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = rbase + (r & 3) + 8 * (r >> 2);
-                if (row < g.R) {
-                    const uint32_t img = (uint32_t)row / (uint32_t)g.gate_L;
-                    const int64_t o    = (int64_t)row * g.ldd + col;
-                    dst[o]             = (acc[rb][r] * g.scale + bias) * g.gate[(int64_t)img * g.M + col] + g.residual[o];
-                }
-            }
         } else {
+            // gate / residual operands of the 16 registers are fetched together from clamped rows (a predicated load per element made the
+            // compiler drain vmcnt each time: 16 dependent round trips per block)
+            float rv[16], gv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = min(rbase + (r & 3) + 8 * (r >> 2), g.R - 1);
+                rv[r]         = g.residual[(int64_t)row * g.ldd + col];
+                gv[r]         = mode == 2 ? g.gate[(int64_t)((uint32_t)row / (uint32_t)g.gate_L) * g.M + col] : 1.f;
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = rbase + (r & 3) + 8 * (r >> 2);
-                if (row < g.R) {
-                    const int64_t o = (int64_t)row * g.ldd + col;
-                    dst[o]          = acc[rb][r] * g.scale + bias + g.residual[o];
-                }
+                if (row < g.R) dst[(int64_t)row * g.ldd + col] = (acc[rb][r] * g.scale + bias) * gv[r] + rv[r];
             }
         }
     }
 }
 
-static int g_qg16_max_rows = 512;  // option "qgemm16_max_rows": Linears with more activation rows go to the f16 weight image + k_gemm16 (0 = never use k_qgemm16)
+// option "qgemm16_max_rows": Linears with 17 .. max_rows activation rows take k_qgemm16 (0 = never).  Default 0: on MI355X the f16-image GEMM measured
+// faster at every row count from 32 up (profiles/r02r_qgemm16_probe.txt: 3072 -> 9216 q8_0 at 77 rows 63 vs 33 us, at 512 rows 117 vs 67 us — from a few
+// dozen rows on the contraction is bound by latency / MFMA issue, not by the weight stream), and 288 GB of HBM hold the image.  The raw-block
+// stream wins where the weight bytes dominate: <= 16 rows, k_qgemv / k_qgemv_rows.  k_qgemm16 stays selectable for resident-quantised operation.
+static int g_qg16_max_rows = 0;
 void qgemm16_set_max_rows(int v) { g_qg16_max_rows = v; }
 
 bool qgemm16_supported(int wtype, int64_t rows, int64_t K, int64_t M) {
     // column pieces are fetched with 16-byte loads: rows of the weight must start 16-byte aligned (K % 256 == 0); 1-2 rows belong to k_qgemv
-    return (wtype == 8 || wtype == 2) && rows >= 3 && rows <= g_qg16_max_rows && K % 256 == 0 && K >= 256 && M >= 1 && M < (1ll << 30);
+    return (wtype == 8 || wtype == 2) && rows >= 3 && rows <= g_qg16_max_rows && K % 256 == 0 && K >= 256 && M >= 1 && M < (1ll << 30);  // (the planner asks qgemv_supported first)
 }
 
 // split-K slices for a launch (1 = none): plain outputs only (the reduce pass adds bias and residual)
@@ -529,65 +704,85 @@ struct FGArgs {
     int K, M, rows, pre_silu;
 };
 
-template <bool W16, int R, int CPW>
+// NIT = K steps of 512 whose weight loads are issued together (before the rows are even staged): the launch is ONE memory round trip deep for
+// K <= 512 NIT instead of one per step (r02r: 26 us per launch with dependent per-step loads — the old 4-launch path took as long)
+template <bool W16, int R, int CPW, int NIT>
 __global__ __launch_bounds__(256) void k_fgemv(FGArgs g) {
     using XT = typename std::conditional<W16, _Float16, float>::type;
+    typedef float f32x8_t __attribute__((ext_vector_type(8)));
+    using WV = typename std::conditional<W16, half8_t, f32x8_t>::type;  // 8 weights as loaded
     extern __shared__ __attribute__((aligned(16))) char fg_smem[];  // [R][K] XT
     XT* xl         = (XT*)fg_smem;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    for (int t = 0; t < R; ++t) {
-        const int tt    = t < g.rows ? t : 0;
-        const float* xr = g.x + (int64_t)tt * g.xs;
-        for (int c4 = threadIdx.x; c4 < g.K / 4; c4 += 256) {
-            float4 a = *(const float4*)(xr + c4 * 4);
+    const int col0 = (blockIdx.x * 4 + wave) * CPW;
+    const int64_t row_bytes = (int64_t)g.K * (W16 ? 2 : 4);
+    WV wv[NIT][CPW];
+    auto loadw = [&](int kbase) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int k = kbase + it * 512 + lane * 8;
+#pragma unroll
+            for (int c = 0; c < CPW; ++c) {
+                const int col = min(col0 + c, g.M - 1);
+                // unconditional load from a clamped address (a lane past the end re-reads the last 8 weights and multiplies them by zeros below):
+                // a predicated load makes the compiler drain vmcnt after every pair
+                const int kk = min(k, g.K - 8);
+                wv[it][c]    = *(const WV*)(g.W + (int64_t)col * row_bytes + (size_t)kk * (W16 ? 2 : 4));
+            }
+        }
+    };
+    loadw(0);
+    // rows -> LDS: all R loads of a column chunk are issued before the first is used (one row at a time was R dependent L2 round trips)
+    for (int c4 = threadIdx.x; c4 < g.K / 4; c4 += 256) {
+        float4 a[R];
+#pragma unroll
+        for (int t = 0; t < R; ++t) a[t] = *(const float4*)(g.x + (int64_t)(t < g.rows ? t : 0) * g.xs + c4 * 4);
+#pragma unroll
+        for (int t = 0; t < R; ++t) {
+            float4 v = a[t];
             if (g.pre_silu) {
-                a.x = act_apply<UN_SILU>(a.x); a.y = act_apply<UN_SILU>(a.y); a.z = act_apply<UN_SILU>(a.z); a.w = act_apply<UN_SILU>(a.w);
+                v.x = act_apply<UN_SILU>(v.x); v.y = act_apply<UN_SILU>(v.y); v.z = act_apply<UN_SILU>(v.z); v.w = act_apply<UN_SILU>(v.w);
             }
             XT* d = xl + (size_t)t * g.K + c4 * 4;
-            d[0] = (XT)a.x; d[1] = (XT)a.y; d[2] = (XT)a.z; d[3] = (XT)a.w;
+            d[0] = (XT)v.x; d[1] = (XT)v.y; d[2] = (XT)v.z; d[3] = (XT)v.w;
         }
     }
     __syncthreads();
-    const int col0 = (blockIdx.x * 4 + wave) * CPW;
     if (col0 >= g.M) return;
     float acc[CPW][R];
 #pragma unroll
     for (int c = 0; c < CPW; ++c)
 #pragma unroll
         for (int t = 0; t < R; ++t) acc[c][t] = 0.f;
-    const int64_t row_bytes = (int64_t)g.K * (W16 ? 2 : 4);
-    for (int k = lane * 8; k < g.K; k += 512) {  // 8 weights per lane and step: 16 B (f16) / 32 B (f32), a wave covers 512 consecutive k
-        float w[CPW][8];
+    for (int kbase = 0; kbase < g.K; kbase += NIT * 512) {
 #pragma unroll
-        for (int c = 0; c < CPW; ++c) {
-            const int col    = min(col0 + c, g.M - 1);
-            const char* rowp = g.W + (int64_t)col * row_bytes;
-            if (W16) {
-                const half8_t h = *(const half8_t*)(rowp + (size_t)k * 2);
+        for (int it = 0; it < NIT; ++it) {
+            const int k = kbase + it * 512 + lane * 8;
+            if (kbase + it * 512 < g.K) {  // wave-uniform; lanes past the end read their (clamped) rows and contribute zeros
+                const bool live = k < g.K;
+                const int kx    = live ? k : 0;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) w[c][j] = (float)h[j];
-            } else {
-                const float4 a = *(const float4*)(rowp + (size_t)k * 4), b = *(const float4*)(rowp + (size_t)k * 4 + 16);
-                w[c][0] = a.x; w[c][1] = a.y; w[c][2] = a.z; w[c][3] = a.w; w[c][4] = b.x; w[c][5] = b.y; w[c][6] = b.z; w[c][7] = b.w;
+                for (int t = 0; t < R; ++t) {
+                    float xv[8];
+                    if (W16) {
+                        half8_t h = *(const half8_t*)((const _Float16*)xl + (size_t)t * g.K + kx);
+                        if (!live) h = (half8_t){0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) xv[j] = (float)h[j];
+                    } else {
+                        float4 a = *(const float4*)((const float*)xl + (size_t)t * g.K + kx), b = *(const float4*)((const float*)xl + (size_t)t * g.K + kx + 4);
+                        if (!live) a = b = make_float4(0.f, 0.f, 0.f, 0.f);
+                        xv[0] = a.x; xv[1] = a.y; xv[2] = a.z; xv[3] = a.w; xv[4] = b.x; xv[5] = b.y; xv[6] = b.z; xv[7] = b.w;
+                    }
+#pragma unroll
+                    for (int c = 0; c < CPW; ++c)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc[c][t] = fmaf((float)wv[it][c][j], xv[j], acc[c][t]);
+                }
             }
         }
-#pragma unroll
-        for (int t = 0; t < R; ++t) {
-            float xv[8];
-            if (W16) {
-                const half8_t h = *(const half8_t*)((const _Float16*)xl + (size_t)t * g.K + k);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) xv[j] = (float)h[j];
-            } else {
-                const float4 a = *(const float4*)((const float*)xl + (size_t)t * g.K + k), b = *(const float4*)((const float*)xl + (size_t)t * g.K + k + 4);
-                xv[0] = a.x; xv[1] = a.y; xv[2] = a.z; xv[3] = a.w; xv[4] = b.x; xv[5] = b.y; xv[6] = b.z; xv[7] = b.w;
-            }
-#pragma unroll
-            for (int c = 0; c < CPW; ++c)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc[c][t] = fmaf(w[c][j], xv[j], acc[c][t]);
-        }
+        if (kbase + NIT * 512 < g.K) loadw(kbase + NIT * 512);
     }
 #pragma unroll
     for (int c = 0; c < CPW; ++c) {
@@ -625,7 +820,7 @@ void launch_fgemv(hipStream_t s, float* dst, int64_t ldd, const float* x, int64_
     g.W = (const char*)w; g.x = x; g.xs = xs; g.dst = dst; g.ldd = ldd;
     g.bias = ep.bias; g.residual = ep.residual; g.scale = ep.scale;
     g.K = (int)K; g.M = (int)M; g.rows = (int)rows; g.pre_silu = pre_silu ? 1 : 0;
-    constexpr int CPW = 2;
+    constexpr int CPW = 2, NIT = 3;  // 3 x 512 = the 1280-wide embedding in one round trip
     const unsigned grid = (unsigned)((M + 4 * CPW - 1) / (4 * CPW));
     const int r         = rows <= 2 ? 2 : rows <= 4 ? 4 : rows <= 8 ? 8 : 16;
     const size_t lds    = (size_t)r * K * esz;
@@ -636,10 +831,10 @@ void launch_fgemv(hipStream_t s, float* dst, int64_t ldd, const float* x, int64_
         (void)hipGetDevice(&dev_);                                                                                 \
         bool& attr_ = attr_dev_[dev_ & 63];                                                                        \
         if (!attr_) {                                                                                              \
-            (void)hipFuncSetAttribute((const void*)k_fgemv<W16_, R_, CPW>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
+            (void)hipFuncSetAttribute((const void*)k_fgemv<W16_, R_, CPW, NIT>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
             attr_ = true;                                                                                          \
         }                                                                                                          \
-        k_fgemv<W16_, R_, CPW><<<grid, 256, lds, s>>>(g);                                                          \
+        k_fgemv<W16_, R_, CPW, NIT><<<grid, 256, lds, s>>>(g);                                                          \
     } while (0)
     if (wtype == 1) {
         if (r == 2) FG_LAUNCH(true, 2);

@@ -24,6 +24,8 @@ from sdcpp_amd import shard
 if ON_GPU:
     sd.load_mi355x_backend()
     GPU = "MI355X0"
+    for kv in filter(None, os.environ.get("SDCPP_BACKEND_OPTS", "").split(",")):  # debugging aid, as in conftest.py
+        sd.backend_set_option(kv.split("=")[0].strip(), int(kv.split("=")[1]))
 else:
     sd.load_backend(ROOT / "oracle" / "_build" / "libggml-cpu-oracle.so")
     GPU = "CPU-oracle"

@@ -230,12 +230,15 @@ def test_conv_time_embedding_add_fused(sd, oracle, gpu, rng, N, C, OC, HW, split
 
 
 @pytest.mark.parametrize("wtype,tol", [(Q8_0, 1e-2), (Q4_0, 3e-2)])
-@pytest.mark.parametrize("tokens,K,M,res", [(1, 3072, 18432 // 8, False), (2, 256, 100, True), (2, 1024, 33, False), (1, 4096, 640, True), (1, 768, 96, False), (3, 768, 96, False)])
+@pytest.mark.parametrize("tokens,K,M,res", [(1, 3072, 18432 // 8, False), (2, 256, 100, True), (2, 1024, 33, False), (1, 4096, 640, True), (1, 768, 96, False), (3, 768, 96, False),
+                                            (4, 3072, 300, True), (5, 1024, 100, False), (8, 4096, 130, False), (9, 2048, 64, True), (16, 3072, 256, False),
+                                            (16, 4096, 66, True), (16, 8192, 64, False), (17, 768, 96, False)])
 def test_quantised_gemv_raw_blocks(sd, oracle, gpu, rng, wtype, tol, tokens, K, M, res):
-    """q8_0 / q4_0 Linear under one or two activation rows (DiT adaLN / modulation vectors, ResBlock embedding projections): k_qgemv streams
-    the RAW GGUF blocks and dequantises in registers — no f16 weight image is built.  Rounding points = the MFMA path's (f16 activations,
-    exact d * q weights, f32 accumulation), so the bars are those of test_linear_weight_gemm: <= 2e-3 vs the exact dequantised product,
-    1e-2 / 3e-2 vs the oracle (which quantises the activations to q8_0 like ggml-cpu).  3 rows: stays on the MFMA GEMM."""
+    """q8_0 / q4_0 Linear under 1 .. 16 activation rows (DiT adaLN / modulation vectors and embedders of a batch, ResBlock embedding projections):
+    k_qgemv (1-2 rows) / k_qgemv_rows (3-16 rows, rows staged in LDS) stream the RAW GGUF blocks and dequantise in registers — no f16 weight
+    image is built.  Rounding points = the MFMA path's (f16 activations, exact d * q weights, f32 accumulation), so the bars are those of
+    test_linear_weight_gemm: <= 2e-3 vs the exact dequantised product, 1e-2 / 3e-2 vs the oracle (which quantises the activations to q8_0
+    like ggml-cpu).  17 rows, or 16 rows x 8192 (256 KB of staged rows): the MFMA GEMM."""
     x = rng.standard_normal((tokens, K)).astype(np.float32)
     w = (rng.standard_normal((M, K)) / np.sqrt(K)).astype(np.float32)
     b = rng.standard_normal(M).astype(np.float32)
@@ -255,7 +258,7 @@ def test_quantised_gemv_raw_blocks(sd, oracle, gpu, rng, wtype, tol, tokens, K, 
     if before is not None and not os.environ.get("SDCPP_BACKEND_OPTS"):
         st = sd.backend_stats()
         taken = st["qgemv_linears"] - before["qgemv_linears"]
-        assert taken == (1 if tokens <= 2 else 0)
+        assert taken == (1 if tokens <= 16 and (tokens <= 2 or (4 if tokens <= 4 else 8 if tokens <= 8 else 16) * K * 2 <= 128 * 1024) else 0)
         if taken:
             assert st["swizzled_weight_bytes"] == before["swizzled_weight_bytes"]   # no f16 image was built for this weight
             # same Linear through the MFMA GEMM (f16 weight image): the two kernels must agree far inside the quantisation bars
@@ -268,14 +271,24 @@ def test_quantised_gemv_raw_blocks(sd, oracle, gpu, rng, wtype, tol, tokens, K, 
             assert rel_l2(out, alt) < 5e-4
 
 
+@pytest.fixture()
+def qgemm16_on(sd):
+    """k_qgemm16 is selectable, not the default (the f16-image GEMM measured faster from 17 rows up, profiles/r02r_qgemm16_probe.txt)"""
+    if _on_gpu():
+        sd.backend_set_option("qgemm16_max_rows", 512)
+    yield
+    if _on_gpu():
+        sd.backend_set_option("qgemm16_max_rows", 0)
+
+
 @pytest.mark.parametrize("wtype,tol", [(Q8_0, 1e-2), (Q4_0, 3e-2)])
-@pytest.mark.parametrize("tokens,K,M,res", [(3, 768, 96, False), (33, 256, 100, True), (77, 768, 320, False), (64, 1024, 640, True), (130, 3072, 1152, True),
+@pytest.mark.parametrize("tokens,K,M,res", [(17, 768, 96, False), (33, 256, 100, True), (77, 768, 320, False), (64, 1024, 640, True), (130, 3072, 1152, True),
                                             (300, 1280, 320, False), (512, 4096, 200, False), (257, 12288, 128, True), (600, 768, 96, False)])
-def test_quantised_mfma_gemm_raw_blocks(sd, oracle, gpu, rng, wtype, tol, tokens, K, M, res):
-    """q8_0 / q4_0 Linear under 3 .. 512 activation rows (text-stream Linears of the DiTs, text encoders): k_qgemm16 streams the RAW GGUF blocks,
-    dequantises them in registers into MFMA B fragments (f16(d * q), bit-identical to what the f16 weight image would hold) and never builds
-    that image.  Bars as for test_linear_weight_gemm; against the same Linear on the f16-image GEMM only the f32 summation order differs.
-    600 rows: above qgemm16_max_rows, stays on the image path."""
+def test_quantised_mfma_gemm_raw_blocks(sd, oracle, gpu, rng, qgemm16_on, wtype, tol, tokens, K, M, res):
+    """q8_0 / q4_0 Linear under 17 .. 512 activation rows (text-stream Linears of the DiTs, text encoders) with option qgemm16_max_rows = 512:
+    k_qgemm16 streams the RAW GGUF blocks, dequantises them in registers into MFMA B fragments (f16(d * q), bit-identical to what the f16
+    weight image would hold) and never builds that image.  Bars as for test_linear_weight_gemm; against the same Linear on the f16-image GEMM
+    only the f32 summation order differs.  600 rows: above qgemm16_max_rows, stays on the image path."""
     x = rng.standard_normal((tokens, K)).astype(np.float32)
     w = (rng.standard_normal((M, K)) / np.sqrt(K)).astype(np.float32)
     b = rng.standard_normal(M).astype(np.float32)
@@ -376,7 +389,7 @@ def test_quantised_gemv_with_deferred_silu(sd, oracle, gpu, rng, wtype):
 
 
 @pytest.mark.parametrize("wtype", [Q8_0, Q4_0])
-def test_quantised_mlp_gelu_chain_raw_blocks(sd, oracle, gpu, rng, wtype):
+def test_quantised_mlp_gelu_chain_raw_blocks(sd, oracle, gpu, rng, qgemm16_on, wtype):
     """Mlp (block.hpp:249-258) with quantised weights on a short token run: fc1 -> GELU is written by k_qgemm16 as the f16 operand image of
     fc2, fc2 (+bias, +residual) reads it — both Linears on raw blocks."""
     tokens, C, Hd = 154, 256, 1024
