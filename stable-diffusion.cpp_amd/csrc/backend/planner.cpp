@@ -591,7 +591,10 @@ void plan_linear(Builder& B, int i, hipStream_t s, std::vector<int>& chain) {
     const ggml_tensor* xsrc    = psi != B.presilu.end() ? psi->second : x;
     const bool simple_rows     = x->nb[0] == 4 && (x->ne[2] == 1 || x->nb[2] == x->nb[1] * (size_t)x->ne[1]) && (x->ne[3] == 1 || x->nb[3] == x->nb[2] * (size_t)x->ne[2]) &&
                              aligned16(xsrc->data) && x->nb[1] % 16 == 0 && xsrc->nb[1] == x->nb[1];
-    const bool plain_epi       = hm_d == 0 && !ep.gate && gelu_out < 0 && geglu_out < 0;
+    // a tensor a fused producer wrote ONLY as an f16 operand image (GEGLU / GELU epilogues, LayerNorm -> f16, attention output: their f32 graph
+    // tensor is never materialised when all consumers are Linears) has no rows for the streaming kernels to read
+    const bool x_f32_live      = B.packed.find(strip_reshape(x)) == B.packed.end() && B.packed.find(strip_reshape(xsrc)) == B.packed.end();
+    const bool plain_epi       = hm_d == 0 && !ep.gate && gelu_out < 0 && geglu_out < 0 && x_f32_live;
     // the chain's output must not land on rows the kernel is still reading (the deferred SiLU's source may have been released by the allocator)
     const ggml_tensor* lastt   = gi.node(last);
     const bool src_safe        = xsrc == x || !overlaps(lastt->data, ggml_abi_nbytes(lastt), xsrc->data, ggml_abi_nbytes(xsrc));
@@ -1609,6 +1612,7 @@ bool build_plan(Planner* P, Plan* plan, const ggml_cgraph* g, hipStream_t s) {
                 const ggml_tensor* src = n->src[0];
                 const int c            = gi.sole(i);
                 if (g_opt.fusion && (g_opt.fgemv || g_opt.qgemv) && ggml_abi_get_unary_op(n) == GGML_UNARY_OP_SILU && c == i + 1 && is_f32(src) && contig(src) && contig(n) &&
+                    B.packed.find(strip_reshape(src)) == B.packed.end() &&
                     !(n->flags & GGML_TENSOR_FLAG_OUTPUT) && gi.node(c)->op == GGML_OP_MUL_MAT && gi.node(c)->src[1] == n && linear_fast_ok(gi.node(c))) {
                     const ggml_tensor* w = gi.node(c)->src[0];
                     const int64_t rows   = n->ne[1] * n->ne[2] * n->ne[3];

@@ -348,7 +348,10 @@ __global__ __launch_bounds__(256) void k_qgemv_rows(QGArgs g) {
     }
 }
 
-static int g_qgemv_max_rows = 16;  // option "qgemv_max_rows"
+// option "qgemv_max_rows" (<= 16).  Default 4: k_qgemv_rows is VALU work proportional to the row count and holds R x K halfs of LDS per workgroup;
+// on the DiT modulation / text-stream shapes it beats the f16-image GEMM path up to 4 rows (3072 -> 9216 q8_0: 24 vs 31 us, 4096 -> 3072: 14 vs 29 us)
+// and loses from 8 rows on (36 vs 28 us, 16 rows 89 vs 33 us) — profiles/r02s_qgemm_paths_probe.txt
+static int g_qgemv_max_rows = 4;
 void qgemv_set_max_rows(int v) { g_qgemv_max_rows = v > 16 ? 16 : (v < 1 ? 1 : v); }
 
 size_t qgemv_workspace_bytes(int64_t, int64_t) { return 0; }  // (the first version quantised the activations into a workspace)

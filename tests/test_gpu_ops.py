@@ -233,7 +233,8 @@ def test_conv_time_embedding_add_fused(sd, oracle, gpu, rng, N, C, OC, HW, split
 @pytest.mark.parametrize("tokens,K,M,res", [(1, 3072, 18432 // 8, False), (2, 256, 100, True), (2, 1024, 33, False), (1, 4096, 640, True), (1, 768, 96, False), (3, 768, 96, False),
                                             (4, 3072, 300, True), (5, 1024, 100, False), (8, 4096, 130, False), (9, 2048, 64, True), (16, 3072, 256, False),
                                             (16, 4096, 66, True), (16, 8192, 64, False), (17, 768, 96, False)])
-def test_quantised_gemv_raw_blocks(sd, oracle, gpu, rng, wtype, tol, tokens, K, M, res):
+@pytest.mark.parametrize("QGEMV_ROWS", [4, 16])   # 4 = the default policy, 16 = the kernel's range (option qgemv_max_rows)
+def test_quantised_gemv_raw_blocks(sd, oracle, gpu, rng, wtype, tol, tokens, K, M, res, QGEMV_ROWS):
     """q8_0 / q4_0 Linear under 1 .. 16 activation rows (DiT adaLN / modulation vectors and embedders of a batch, ResBlock embedding projections):
     k_qgemv (1-2 rows) / k_qgemv_rows (3-16 rows, rows staged in LDS) stream the RAW GGUF blocks and dequantise in registers — no f16 weight
     image is built.  Rounding points = the MFMA path's (f16 activations, exact d * q weights, f32 accumulation), so the bars are those of
@@ -248,8 +249,16 @@ def test_quantised_gemv_raw_blocks(sd, oracle, gpu, rng, wtype, tol, tokens, K, 
         y = L.ggml_add_inplace(g.ctx, L.ggml_mul_mat(g.ctx, g.weight(w, wtype), g.input(x)), g.weight(b, F32))
         return L.ggml_add(g.ctx, y, g.input(r)) if res else y
 
+    if QGEMV_ROWS != 4 and (tokens <= 4 or not _on_gpu()):
+        pytest.skip("same path as the default policy")
     before = sd.backend_stats() if _on_gpu() else None
-    ref, out = run_both(sd, oracle, gpu, build)
+    if _on_gpu():
+        sd.backend_set_option("qgemv_max_rows", QGEMV_ROWS)
+    try:
+        ref, out = run_both(sd, oracle, gpu, build)
+    finally:
+        if _on_gpu():
+            sd.backend_set_option("qgemv_max_rows", 4)
     assert np.isfinite(out).all()
     assert rel_l2(out, ref) < tol
     exact = x.astype(np.float64) @ dequant(w, wtype).astype(np.float64).T + b + (r if res else 0)
@@ -258,7 +267,7 @@ def test_quantised_gemv_raw_blocks(sd, oracle, gpu, rng, wtype, tol, tokens, K, 
     if before is not None and not os.environ.get("SDCPP_BACKEND_OPTS"):
         st = sd.backend_stats()
         taken = st["qgemv_linears"] - before["qgemv_linears"]
-        assert taken == (1 if tokens <= 16 and (tokens <= 2 or (4 if tokens <= 4 else 8 if tokens <= 8 else 16) * K * 2 <= 128 * 1024) else 0)
+        assert taken == (1 if tokens <= QGEMV_ROWS and (tokens <= 2 or (4 if tokens <= 4 else 8 if tokens <= 8 else 16) * K * 2 <= 128 * 1024) else 0)
         if taken:
             assert st["swizzled_weight_bytes"] == before["swizzled_weight_bytes"]   # no f16 image was built for this weight
             # same Linear through the MFMA GEMM (f16 weight image): the two kernels must agree far inside the quantisation bars
@@ -349,8 +358,12 @@ def test_few_row_linear_weight_stream(sd, oracle, gpu, rng, wtype, rows, K, M, r
     assert rel_l2(out, ref) < (2e-4 if wtype == F16 else (1e-5 if taken and on_stream else 2e-3))
     if before is not None and not os.environ.get("SDCPP_BACKEND_OPTS"):
         st = sd.backend_stats()
-        assert st["fgemv_linears"] - before["fgemv_linears"] == (1 if taken else 0)
-        assert st["fused_presilu"] - before["fused_presilu"] == (1 if taken and silu else 0)
+        # (silu + residual: the allocator may place the result on the rows the deferred SiLU would still have to read; the planner then runs
+        # the SiLU and the GEMM path — correct, just not the streaming kernel)
+        took = st["fgemv_linears"] - before["fgemv_linears"]
+        assert took == (1 if taken else 0) or (taken and silu and res and took == 0)
+        assert st["fused_presilu"] - before["fused_presilu"] == (1 if took and silu else 0)
+        taken = bool(took)
         if taken:
             assert st["swizzled_weight_bytes"] == before["swizzled_weight_bytes"]   # no weight image, no pack, no split-K pass
             assert st["kernels_planned"] - before["kernels_planned"] == 1
@@ -663,7 +676,7 @@ def test_manual_attention_chain(sd, oracle, gpu, rng, d, Lq, Lk, HN):
         assert sd.backend_stats()["gemm_attention"] - before["gemm_attention"] == 1
 
 
-@pytest.mark.parametrize("tokens,K,M", [(16, 1280, 1280), (1000, 5120, 200), (130, 2560, 96)])
+@pytest.mark.parametrize("tokens,K,M", [(24, 1280, 1280), (1000, 5120, 200), (130, 2560, 96)])   # (<= 16 rows: k_fgemv, no split)
 def test_linear_split_k(sd, oracle, gpu, rng, tokens, K, M):
     """deep-K GEMMs over few output tiles run split-K (slabs + fixed-order reduce with bias + residual)"""
     x = rng.standard_normal((tokens, K)).astype(np.float32)
