@@ -192,6 +192,8 @@ def main():
         roofline.update({"achieved": round(achieved, 2), "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "kernel": kt["kernel"],
                          "launches": kt["launches"], "avg_launch_us": round(kt["total_ms"] * 1e3 / kt["launches"], 2),
                          "avg_launch_gflop": round(kt["total_flops"] / kt["launches"] / 1e9, 2),
+                         # algorithmic HBM bytes of the same launches: NHWC f16 input image + weight image + f32 output (+ residual), each once
+                         "avg_launch_algorithmic_bytes": round(kt["total_bytes"] / kt["launches"]),
                          "share_of_step_time": round(kt["total_ms"] / (dt * 1e3), 4),
                          "timing": "hipEventElapsedTime around each launch on the launch stream, inside the timed region"})
         tf = ROOT / "profiles" / "r02_pmc_traffic.json"
@@ -292,6 +294,8 @@ def kernel_families(sd, trajectory, step):
             ach, peak, unit = f["total_bytes"] / sec / 1e9, HBM_PEAK_GBS, "GB/s"
         rows.append({"name": f["kernel"], "bound": f["bound"], "launches_per_step": round(f["launches"] / n, 1), "ms_per_step": round(f["total_ms"] / n, 3),
                      "share_of_step_time": round(f["total_ms"] / tot, 4), "achieved": round(ach, 1), "peak": peak, "unit": unit, "frac": round(ach / peak, 4)})
+        if f["bound"] == "mfma" and f["total_bytes"] > 0:  # contraction families: also the algorithmic-byte rate (operands once, output once) vs HBM
+            rows[-1]["algorithmic_gbs"] = round(f["total_bytes"] / sec / 1e9, 1)
     return rows
 
 

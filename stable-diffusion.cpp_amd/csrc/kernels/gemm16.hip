@@ -912,13 +912,13 @@ static int g16_pick_tile(int64_t rows, int64_t M, bool geglu, bool conv, int spl
 }
 
 template <int BN_, bool CONV_>
-static void g16_launch(hipStream_t s, G16Args& g, int64_t rows, double flops) {
+static void g16_launch(hipStream_t s, G16Args& g, int64_t rows, double flops, double bytes) {  // bytes: algorithmic HBM bytes (operand images read once + output written once [+ residual])
     const unsigned ny = g.split_k > 1 ? (unsigned)g.split_k : 1u;
     if (BN_ == 128 && g_g16_variant == 3 && !g.sk_cnt) {
         const int tile = g16_pick_tile(rows, g.C, g.geglu_inner > 0, CONV_, g.split_k > 1 ? g.split_k : 0, g.nt);  // the GEGLU pairing is laid out for 128-column tiles
         if (tile != G16_T128) {
             const int64_t rt256 = (rows + 255) / 256;
-            KScope ks_(s, CONV_ ? KF_CONV_T256 : KF_LINEAR, flops, 0.0);
+            KScope ks_(s, CONV_ ? KF_CONV_T256 : KF_LINEAR, flops, bytes);
             if (tile == G16_T320) {
                 g.ncol_tiles = (int)((g.C + 319) / 320);
 #ifdef MI355X_EXPERIMENTS
@@ -954,7 +954,7 @@ static void g16_launch(hipStream_t s, G16Args& g, int64_t rows, double flops) {
         }
     }
     const dim3 grid((unsigned)(((rows + 127) / 128) * g.ncol_tiles), ny);
-    KScope ks_(s, CONV_ ? KF_CONV_T128 : KF_LINEAR, flops, 0.0);
+    KScope ks_(s, CONV_ ? KF_CONV_T128 : KF_LINEAR, flops, bytes);
     if (g_g16_variant == 0)
         k_gemm16<128, BN_, CONV_, 64, 2, 2, 2><<<grid, 256, 0, s>>>(g);
     else if (g_g16_variant == 2)
@@ -1178,13 +1178,15 @@ void launch_gemm16_linear(hipStream_t s, float* dst, void* dst16, int64_t ldd16,
     // 64-column tiles: narrow outputs, and small grids (<= 128 tiles of 128x128 on 256 CUs: the cross-attention K/V projections of the 77-token
     // context, the time-embedding Linears) where twice the workgroups matter more than the tile's arithmetic intensity (r02q: 1232x768->768 36 -> 21 us)
     const bool bn64 = g16_use_bn64(rows, M);
+    // algorithmic bytes: A image + weight image once, output once (f32 or f16), residual once
+    const double lin_bytes = (double)rows * rup64(K, 64) * 2.0 + (double)rup64(K, 64) * rup64(M, 128) * 2.0 + (double)rows * M * (dst16 ? 2.0 : 4.0) + (e.residual ? (double)rows * M * 4.0 : 0.0);
     if (g16_trace()) fprintf(stderr, "G16 linear rows=%lld K=%lld M=%lld res=%d hm=%d f16out=%d\n", (long long)rows, (long long)K, (long long)M, e.residual ? 1 : 0, hm_d, dst16 ? 1 : 0);
     if (bn64) {
         g.ncol_tiles = (int)((M + 63) / 64);
-        g16_launch<64, false>(s, g, rows, 2.0 * rows * K * M);
+        g16_launch<64, false>(s, g, rows, 2.0 * rows * K * M, lin_bytes);
     } else {
         g.ncol_tiles = (int)((M + 127) / 128);
-        g16_launch<128, false>(s, g, rows, 2.0 * rows * K * M);
+        g16_launch<128, false>(s, g, rows, 2.0 * rows * K * M, lin_bytes);
     }
     if (S > 1 && !inker) launch_splitk_reduce(s, dst, splitk_ws, S, rows * M, e.bias, 1, M, e.residual);
 }
@@ -1206,7 +1208,7 @@ void launch_gemm16_linear_geglu(hipStream_t s, void* dst16, const void* a16, int
     g.ep          = G16Epi{bias, nullptr, 1.f};
     g.ncol_tiles  = (int)((M + 127) / 128);
     if (g16_trace()) fprintf(stderr, "G16 linear rows=%lld K=%lld M=%lld res=0 hm=0 f16out=1 geglu=1\n", (long long)rows, (long long)K, (long long)M);
-    g16_launch<128, false>(s, g, rows, 2.0 * rows * K * M);
+    g16_launch<128, false>(s, g, rows, 2.0 * rows * K * M, (double)rows * rup64(K, 64) * 2.0 + (double)rup64(K, 64) * rup64(M, 128) * 2.0 + (double)rows * (M / 2) * 2.0);
 }
 
 void launch_gemm16_conv(hipStream_t s, float* dst, const void* x16_nhwc, const void* wswz, int64_t W, int64_t H, int64_t IC, int64_t N, int64_t OC, int ksize,
@@ -1251,15 +1253,17 @@ void launch_gemm16_conv(hipStream_t s, float* dst, const void* x16_nhwc, const v
         }
     }
     const bool bn64 = OC <= 64;
+    // algorithmic bytes: the NHWC f16 input image once, the weight image once, the f32 output once (+ residual once)
+    const double conv_bytes = (double)N * H * W * g.ICp * 2.0 + (double)g.ICp * ksize * ksize * rup64(OC, 128) * 2.0 + (double)g.R * OC * 4.0 * (e.residual ? 2.0 : 1.0);
     if (g16_trace())
         fprintf(stderr, "G16 conv rows=%lld K=%lld M=%lld res=%d ks=%d s=%d ups=%d hw=%lldx%lld ic=%lld\n", (long long)g.R, (long long)g.ICp * ksize * ksize, (long long)OC,
                 e.residual ? 1 : 0, ksize, stride, g.UPS, (long long)W, (long long)H, (long long)IC);
     if (bn64) {
         g.ncol_tiles = (int)((OC + 63) / 64);
-        g16_launch<64, true>(s, g, g.R, 2.0 * g.R * IC * ksize * ksize * OC);
+        g16_launch<64, true>(s, g, g.R, 2.0 * g.R * IC * ksize * ksize * OC, conv_bytes);
     } else {
         g.ncol_tiles = (int)((OC + 127) / 128);
-        g16_launch<128, true>(s, g, g.R, 2.0 * g.R * IC * ksize * ksize * OC);
+        g16_launch<128, true>(s, g, g.R, 2.0 * g.R * IC * ksize * ksize * OC, conv_bytes);
     }
     if (S > 1 && !inker) launch_splitk_reduce(s, dst, splitk_ws, S, g.R * OC, e.bias, g.OHOW, OC, e.residual, e.chan_add);
 }
