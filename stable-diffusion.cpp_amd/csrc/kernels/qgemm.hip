@@ -26,6 +26,31 @@
 
 namespace mi355x {
 
+// Sum NV per-lane partial values over the 64 lanes of a wave with NV - 1 + (6 - log2 NV) cross-lane exchanges instead of 6 NV: every halving
+// step sends the half of the values the partner lane keeps (lanes with bit o set keep the upper half).  Afterwards value index
+// (lane >> (6 - log2 NV)) is complete in every lane of its group.  (k_fgemv's epilogue did 32 butterfly sums = 192 dependent ds_bpermute
+// round trips: a third of its 32 us, profiles/r02u_kernel_stats.csv.)
+template <int NV>
+__device__ __forceinline__ float wave_sum_transpose(float (&v)[NV], int lane) {
+    static_assert(NV >= 1 && NV <= 32 && (NV & (NV - 1)) == 0, "NV must be a power of two <= 32");
+    constexpr int LOG = NV == 1 ? 0 : NV == 2 ? 1 : NV == 4 ? 2 : NV == 8 ? 3 : NV == 16 ? 4 : 5;
+#pragma unroll
+    for (int st = 0; st < LOG; ++st) {
+        const int n = NV >> st, o = 32 >> st;
+        const bool up = (lane & o) != 0;
+#pragma unroll
+        for (int i = 0; i < n / 2; ++i) {
+            const float send = up ? v[i] : v[i + n / 2];
+            const float keep = up ? v[i + n / 2] : v[i];
+            v[i]             = keep + __shfl_xor(send, o, 64);
+        }
+    }
+    float r = v[0];
+#pragma unroll
+    for (int o = 32 >> LOG; o > 0; o >>= 1) r += __shfl_xor(r, o, 64);
+    return r;
+}
+
 struct QGArgs {
     const char* W;       // raw quantised rows
     int64_t row_bytes;
@@ -330,20 +355,20 @@ __global__ __launch_bounds__(256) void k_qgemv_rows(QGArgs g) {
             }
         }
     }
+    {
+        constexpr int NV  = CPW * R;  // value index c * R + t
+        constexpr int GRP = 64 / NV;  // lanes per finished value
+        float v[NV];
 #pragma unroll
-    for (int c = 0; c < CPW; ++c) {
-        const int col = col0 + c;
-        if (col >= g.M) break;
-        float mine = 0.f;
+        for (int c = 0; c < CPW; ++c)
 #pragma unroll
-        for (int t = 0; t < R; ++t) {
-            const float v = wave_sum(acc[c][t]);
-            if (lane == t) mine = v;
-        }
-        if (lane < g.rows && lane < R) {
-            float o = mine * g.scale + (g.bias ? g.bias[col] : 0.f);
-            if (g.residual) o += g.residual[(int64_t)lane * g.ldd + col];
-            g.dst[(int64_t)lane * g.ldd + col] = o;
+            for (int t = 0; t < R; ++t) v[c * R + t] = acc[c][t];
+        const float tot = wave_sum_transpose<NV>(v, lane);
+        const int idx = lane / GRP, c = idx / R, t = idx - c * R, col = col0 + c;
+        if ((lane & (GRP - 1)) == 0 && t < g.rows && col < g.M) {
+            float o = tot * g.scale + (g.bias ? g.bias[col] : 0.f);
+            if (g.residual) o += g.residual[(int64_t)t * g.ldd + col];
+            g.dst[(int64_t)t * g.ldd + col] = o;
         }
     }
 }
@@ -787,20 +812,20 @@ __global__ __launch_bounds__(256) void k_fgemv(FGArgs g) {
         }
         if (kbase + NIT * 512 < g.K) loadw(kbase + NIT * 512);
     }
+    {
+        constexpr int NV  = CPW * R;  // value index c * R + t
+        constexpr int GRP = 64 / NV;  // lanes per finished value
+        float v[NV];
 #pragma unroll
-    for (int c = 0; c < CPW; ++c) {
-        const int col = col0 + c;
-        if (col >= g.M) break;  // wave-uniform
-        float mine = 0.f;
+        for (int c = 0; c < CPW; ++c)
 #pragma unroll
-        for (int t = 0; t < R; ++t) {
-            const float v = wave_sum(acc[c][t]);
-            if (lane == t) mine = v;
-        }
-        if (lane < g.rows && lane < R) {
-            float o = mine * g.scale + (g.bias ? g.bias[col] : 0.f);
-            if (g.residual) o += g.residual[(int64_t)lane * g.ldd + col];
-            g.dst[(int64_t)lane * g.ldd + col] = o;
+            for (int t = 0; t < R; ++t) v[c * R + t] = acc[c][t];
+        const float tot = wave_sum_transpose<NV>(v, lane);
+        const int idx = lane / GRP, c = idx / R, t = idx - c * R, col = col0 + c;
+        if ((lane & (GRP - 1)) == 0 && t < g.rows && col < g.M) {
+            float o = tot * g.scale + (g.bias ? g.bias[col] : 0.f);
+            if (g.residual) o += g.residual[(int64_t)t * g.ldd + col];
+            g.dst[(int64_t)t * g.ldd + col] = o;
         }
     }
 }
