@@ -732,14 +732,18 @@ struct FGArgs {
     int K, M, rows, pre_silu;
 };
 
-// NIT = K steps of 512 whose weight loads are issued together (before the rows are even staged): the launch is ONE memory round trip deep for
-// K <= 512 NIT instead of one per step (r02r: 26 us per launch with dependent per-step loads — the old 4-launch path took as long)
-template <bool W16, int R, int CPW, int NIT>
+// Shape of the code matters as much as the data flow here: the instruction cache starts cold at every launch and this kernel runs its code
+// about once, so a version fully unrolled over the rows (staging, FMAs and 32 wave reductions for 16 rows: ~30 KB of straight-line code)
+// took 6 us at 2 rows and 23 us at 16 rows whatever K and M were (profiles/r02v_fgemv_probe.txt) — instruction fetch, not work.  Now the rows are
+// walked four at a time by ROLLED loops (a ~3 KB body that stays in the cache), the weights of the wave's CPW columns stay in registers.
+//   NIT = K steps of 512 whose weight loads are issued together, before the rows are even staged: one memory round trip for K <= 512 NIT.
+template <bool W16, int CPW, int NIT>
 __global__ __launch_bounds__(256) void k_fgemv(FGArgs g) {
     using XT = typename std::conditional<W16, _Float16, float>::type;
     typedef float f32x8_t __attribute__((ext_vector_type(8)));
     using WV = typename std::conditional<W16, half8_t, f32x8_t>::type;  // 8 weights as loaded
-    extern __shared__ __attribute__((aligned(16))) char fg_smem[];  // [R][K] XT
+    constexpr int RQ = 4;  // rows per pass of the compute loop
+    extern __shared__ __attribute__((aligned(16))) char fg_smem[];  // [rows rounded up to RQ][K] XT
     XT* xl         = (XT*)fg_smem;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -761,67 +765,75 @@ __global__ __launch_bounds__(256) void k_fgemv(FGArgs g) {
         }
     };
     loadw(0);
-    // rows -> LDS: all R loads of a column chunk are issued before the first is used (one row at a time was R dependent L2 round trips)
-    for (int c4 = threadIdx.x; c4 < g.K / 4; c4 += 256) {
-        float4 a[R];
+    // rows -> LDS (SiLU applied, rounded to the operand type): flat float4 chunks, four loads in flight per thread and trip
+    {
+        const int kq = g.K / 4, rows_p = (g.rows + RQ - 1) / RQ * RQ, total = rows_p * kq;
+        const float inv_kq = 1.0f / (float)kq;
+        for (int base = threadIdx.x; base < total; base += 4 * 256) {
+            float4 a[4];
+            int off[4];
 #pragma unroll
-        for (int t = 0; t < R; ++t) a[t] = *(const float4*)(g.x + (int64_t)(t < g.rows ? t : 0) * g.xs + c4 * 4);
-#pragma unroll
-        for (int t = 0; t < R; ++t) {
-            float4 v = a[t];
-            if (g.pre_silu) {
-                v.x = act_apply<UN_SILU>(v.x); v.y = act_apply<UN_SILU>(v.y); v.z = act_apply<UN_SILU>(v.z); v.w = act_apply<UN_SILU>(v.w);
+            for (int j = 0; j < 4; ++j) {
+                const int idx = min(base + j * 256, total - 1);
+                int row       = (int)((float)idx * inv_kq);
+                row += (row + 1) * kq <= idx;  // float reciprocal: off by at most one
+                row -= row * kq > idx;
+                const int c4 = idx - row * kq;
+                off[j]       = row * g.K + c4 * 4;
+                a[j]         = *(const float4*)(g.x + (int64_t)min(row, g.rows - 1) * g.xs + c4 * 4);  // rows of the last partial quad: copies, never stored
             }
-            XT* d = xl + (size_t)t * g.K + c4 * 4;
-            d[0] = (XT)v.x; d[1] = (XT)v.y; d[2] = (XT)v.z; d[3] = (XT)v.w;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float4 v = a[j];
+                if (g.pre_silu) {
+                    v.x = act_apply<UN_SILU>(v.x); v.y = act_apply<UN_SILU>(v.y); v.z = act_apply<UN_SILU>(v.z); v.w = act_apply<UN_SILU>(v.w);
+                }
+                if (base + j * 256 < total) {
+                    XT* d = xl + off[j];
+                    d[0] = (XT)v.x; d[1] = (XT)v.y; d[2] = (XT)v.z; d[3] = (XT)v.w;
+                }
+            }
         }
     }
     __syncthreads();
     if (col0 >= g.M) return;
-    float acc[CPW][R];
+    for (int t0 = 0; t0 < g.rows; t0 += RQ) {
+        float acc[CPW * RQ];  // value index c * RQ + r
 #pragma unroll
-    for (int c = 0; c < CPW; ++c)
+        for (int i = 0; i < CPW * RQ; ++i) acc[i] = 0.f;
+        for (int kbase = 0; kbase < g.K; kbase += NIT * 512) {
+            if (kbase > 0) loadw(kbase);  // K > 512 NIT (rare): the weights are re-fetched per row quad from L2
 #pragma unroll
-        for (int t = 0; t < R; ++t) acc[c][t] = 0.f;
-    for (int kbase = 0; kbase < g.K; kbase += NIT * 512) {
+            for (int it = 0; it < NIT; ++it) {
+                const int k = kbase + it * 512 + lane * 8;
+                if (kbase + it * 512 < g.K) {  // wave-uniform; lanes past the end read clamped data and contribute zeros
+                    const bool live = k < g.K;
+                    const int kx    = live ? k : 0;
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int k = kbase + it * 512 + lane * 8;
-            if (kbase + it * 512 < g.K) {  // wave-uniform; lanes past the end read their (clamped) rows and contribute zeros
-                const bool live = k < g.K;
-                const int kx    = live ? k : 0;
+                    for (int r = 0; r < RQ; ++r) {
+                        float xv[8];
+                        if (W16) {
+                            half8_t h = *(const half8_t*)((const _Float16*)xl + (size_t)(t0 + r) * g.K + kx);
+                            if (!live) h = (half8_t){0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-                for (int t = 0; t < R; ++t) {
-                    float xv[8];
-                    if (W16) {
-                        half8_t h = *(const half8_t*)((const _Float16*)xl + (size_t)t * g.K + kx);
-                        if (!live) h = (half8_t){0, 0, 0, 0, 0, 0, 0, 0};
+                            for (int j = 0; j < 8; ++j) xv[j] = (float)h[j];
+                        } else {
+                            float4 a = *(const float4*)((const float*)xl + (size_t)(t0 + r) * g.K + kx), b = *(const float4*)((const float*)xl + (size_t)(t0 + r) * g.K + kx + 4);
+                            if (!live) a = b = make_float4(0.f, 0.f, 0.f, 0.f);
+                            xv[0] = a.x; xv[1] = a.y; xv[2] = a.z; xv[3] = a.w; xv[4] = b.x; xv[5] = b.y; xv[6] = b.z; xv[7] = b.w;
+                        }
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) xv[j] = (float)h[j];
-                    } else {
-                        float4 a = *(const float4*)((const float*)xl + (size_t)t * g.K + kx), b = *(const float4*)((const float*)xl + (size_t)t * g.K + kx + 4);
-                        if (!live) a = b = make_float4(0.f, 0.f, 0.f, 0.f);
-                        xv[0] = a.x; xv[1] = a.y; xv[2] = a.z; xv[3] = a.w; xv[4] = b.x; xv[5] = b.y; xv[6] = b.z; xv[7] = b.w;
+                        for (int c = 0; c < CPW; ++c)
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) acc[c * RQ + r] = fmaf((float)wv[it][c][j], xv[j], acc[c * RQ + r]);
                     }
-#pragma unroll
-                    for (int c = 0; c < CPW; ++c)
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) acc[c][t] = fmaf((float)wv[it][c][j], xv[j], acc[c][t]);
                 }
             }
         }
-        if (kbase + NIT * 512 < g.K) loadw(kbase + NIT * 512);
-    }
-    {
-        constexpr int NV  = CPW * R;  // value index c * R + t
-        constexpr int GRP = 64 / NV;  // lanes per finished value
-        float v[NV];
-#pragma unroll
-        for (int c = 0; c < CPW; ++c)
-#pragma unroll
-            for (int t = 0; t < R; ++t) v[c * R + t] = acc[c][t];
-        const float tot = wave_sum_transpose<NV>(v, lane);
-        const int idx = lane / GRP, c = idx / R, t = idx - c * R, col = col0 + c;
+        if (g.K > NIT * 512) loadw(0);
+        constexpr int NV = CPW * RQ, GRP = 64 / NV;
+        const float tot = wave_sum_transpose<NV>(acc, lane);
+        const int idx = lane / GRP, c = idx / RQ, t = t0 + idx - c * RQ, col = col0 + c;
         if ((lane & (GRP - 1)) == 0 && t < g.rows && col < g.M) {
             float o = tot * g.scale + (g.bias ? g.bias[col] : 0.f);
             if (g.residual) o += g.residual[(int64_t)t * g.ldd + col];
@@ -836,7 +848,7 @@ void fgemv_set_max_rows(int v) { g_fgemv_max_rows = v > 16 ? 16 : v; }
 // wtype: 0 = f32, 1 = f16 (ggml type ids)
 bool fgemv_supported(int wtype, int64_t rows, int64_t K) {
     if (!(wtype == 0 || wtype == 1) || rows < 1 || rows > g_fgemv_max_rows || K % 8 != 0 || K < 8) return false;
-    const int64_t r = rows <= 2 ? 2 : rows <= 4 ? 4 : rows <= 8 ? 8 : 16;
+    const int64_t r = (rows + 3) / 4 * 4;
     return r * K * (wtype == 1 ? 2 : 4) <= 96 * 1024;  // the staged rows live in LDS
 }
 
@@ -850,32 +862,23 @@ void launch_fgemv(hipStream_t s, float* dst, int64_t ldd, const float* x, int64_
     g.K = (int)K; g.M = (int)M; g.rows = (int)rows; g.pre_silu = pre_silu ? 1 : 0;
     constexpr int CPW = 2, NIT = 3;  // 3 x 512 = the 1280-wide embedding in one round trip
     const unsigned grid = (unsigned)((M + 4 * CPW - 1) / (4 * CPW));
-    const int r         = rows <= 2 ? 2 : rows <= 4 ? 4 : rows <= 8 ? 8 : 16;
-    const size_t lds    = (size_t)r * K * esz;
-#define FG_LAUNCH(W16_, R_)                                                                                        \
-    do {                                                                                                           \
-        static bool attr_dev_[64] = {false};                                                                       \
-        int dev_ = 0;                                                                                              \
-        (void)hipGetDevice(&dev_);                                                                                 \
-        bool& attr_ = attr_dev_[dev_ & 63];                                                                        \
-        if (!attr_) {                                                                                              \
-            (void)hipFuncSetAttribute((const void*)k_fgemv<W16_, R_, CPW, NIT>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
-            attr_ = true;                                                                                          \
-        }                                                                                                          \
-        k_fgemv<W16_, R_, CPW, NIT><<<grid, 256, lds, s>>>(g);                                                          \
-    } while (0)
+    const size_t lds    = (size_t)((rows + 3) / 4 * 4) * K * esz;
+    static bool attr_dev_[64][2] = {};
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
     if (wtype == 1) {
-        if (r == 2) FG_LAUNCH(true, 2);
-        else if (r == 4) FG_LAUNCH(true, 4);
-        else if (r == 8) FG_LAUNCH(true, 8);
-        else FG_LAUNCH(true, 16);
+        if (!attr_dev_[dev_ & 63][0]) {
+            (void)hipFuncSetAttribute((const void*)k_fgemv<true, CPW, NIT>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            attr_dev_[dev_ & 63][0] = true;
+        }
+        k_fgemv<true, CPW, NIT><<<grid, 256, lds, s>>>(g);
     } else {
-        if (r == 2) FG_LAUNCH(false, 2);
-        else if (r == 4) FG_LAUNCH(false, 4);
-        else if (r == 8) FG_LAUNCH(false, 8);
-        else FG_LAUNCH(false, 16);
+        if (!attr_dev_[dev_ & 63][1]) {
+            (void)hipFuncSetAttribute((const void*)k_fgemv<false, CPW, NIT>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            attr_dev_[dev_ & 63][1] = true;
+        }
+        k_fgemv<false, CPW, NIT><<<grid, 256, lds, s>>>(g);
     }
-#undef FG_LAUNCH
 }
 
 }  // namespace mi355x
