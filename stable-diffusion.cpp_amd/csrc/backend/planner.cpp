@@ -41,11 +41,11 @@ namespace {
 struct Stats {
     std::atomic<int64_t> graphs_computed{0}, plans_built{0}, nodes_seen{0}, kernels_planned{0}, kernels_launched{0}, fused_conv{0},
         fused_conv_bounced{0}, fused_linear{0}, fused_norm{0}, fused_geglu{0}, fused_attention{0}, generic_matmul{0}, swizzled_weight_bytes{0}, fused_linear_geglu{0}, split_k_gemms{0}, head_major_gemms{0}, fused_modulate{0}, fused_gate{0}, fused_gelu{0}, fused_rope{0}, fused_concat_heads{0},
-        graph_replays{0}, qgemv_linears{0}, fused_chan_add{0}, fused_proj_tokens{0}, gemm_attention{0}, fused_q16{0}, split_k_inlaunch{0}, qgemm16_linears{0}, fgemv_linears{0}, fused_presilu{0};
+        graph_replays{0}, qgemv_linears{0}, fused_chan_add{0}, fused_proj_tokens{0}, gemm_attention{0}, fused_q16{0}, split_k_inlaunch{0}, qgemm16_linears{0}, fgemv_linears{0}, fused_presilu{0}, fused_sibling_linears{0};
 } g_stats;
 
 struct Options {
-    std::atomic<int> fusion{1}, mfma_gemm{1}, hip_graph{0}, flash_pattern{1}, gemm16{1}, fuse_modulate{1}, fuse_gate{1}, fuse_gelu{1}, fuse_rope{1}, fuse_concat_heads{1}, qgemv{1}, fuse_chan_add{1}, fuse_proj_tokens{1}, fuse_q16{1}, qgemm16{1}, fgemv{1};
+    std::atomic<int> fusion{1}, mfma_gemm{1}, hip_graph{0}, flash_pattern{1}, gemm16{1}, fuse_modulate{1}, fuse_gate{1}, fuse_gelu{1}, fuse_rope{1}, fuse_concat_heads{1}, qgemv{1}, fuse_chan_add{1}, fuse_proj_tokens{1}, fuse_q16{1}, qgemm16{1}, fgemv{1}, fuse_siblings{1};
 } g_opt;
 
 using Step = std::function<void(hipStream_t)>;
@@ -243,7 +243,30 @@ struct Builder {
     std::unordered_map<const ggml_tensor*, const ggml_tensor*> presilu;  // deferred SiLU node in front of a few-row Linear -> its source (applied by k_fgemv / k_qgemv on load)
     std::map<int, std::vector<Step>> deferred;                       // steps to run once the walk reaches graph node <key>
     Builder(Planner* p, Plan* pl, const ggml_cgraph* g) : P(p), plan(pl), gi(g) {}
-    void emit(Step s) { plan->steps.push_back(std::move(s)); }
+    // sibling projections (q / k / v of one attention) planned together: while emit_redirect >= 0 every step a plan_* function emits is parked at that
+    // graph node instead of the current position; hm_grouping makes plan_linear hand its head-major GEMM over (hm_group) instead of emitting it
+    int emit_redirect = -1;
+    bool hm_grouping  = false;
+    struct HmLaunch {
+        int node, out_node;        // the MUL_MAT and the last node of its chain
+        float* dst;                // f32 head-major destination, or
+        void* dst16;               // f16 head-major destination (absolute), or
+        size_t dst16_off;          // ... an arena offset when dst16_arena
+        bool dst16_arena;
+        size_t a_off;
+        int64_t lda;
+        const void* swz;
+        int64_t tokens, K, M;
+        Epilogue ep;
+        int hd, hH, hL;
+    };
+    std::vector<HmLaunch> hm_group;
+    void emit(Step s) {
+        if (emit_redirect >= 0)
+            deferred[emit_redirect].push_back(std::move(s));
+        else
+            plan->steps.push_back(std::move(s));
+    }
     // A fused chain normally runs at the position of its FIRST node.  When one of its operands is produced by a node that sits between
     // the chain's nodes in graph order (the adaLN chunk CONTs of a DiT block are reached by the DFS through the gate / scale operand),
     // the kernel is emitted at the position of the chain's LAST node instead.
@@ -695,17 +718,24 @@ void plan_linear(Builder& B, int i, hipStream_t s, std::vector<int>& chain) {
                     qview  = c1;
                 }
             }
+            const bool groupable = B.hm_grouping && !ep.residual && !ep.gate && !ep.gelu && !ep.chan_add;
             if (qflash >= 0) {
                 const size_t qoff        = B.alloc((size_t)tokens * M * 2);
                 B.q16[gi.node(qview)]    = qoff;
                 g_stats.fused_q16++;
                 const Builder::Split sk = B.plan_split(tokens, M, K, false, false);
-                B.emit([=](hipStream_t st) { launch_gemm16_linear(st, nullptr, P->arena + qoff, 0, P->arena + off, ld, swz, tokens, K, M, M, ep, hd, hH, hL, sk.ws(P), sk.cnt(P), sk.S); });
+                if (groupable && sk.S <= 1)
+                    B.hm_group.push_back(Builder::HmLaunch{i, last, nullptr, nullptr, qoff, true, off, ld, swz, tokens, K, M, ep, hd, hH, hL});
+                else
+                    B.emit([=](hipStream_t st) { launch_gemm16_linear(st, nullptr, P->arena + qoff, 0, P->arena + off, ld, swz, tokens, K, M, M, ep, hd, hH, hL, sk.ws(P), sk.cnt(P), sk.S); });
             } else {
                 const Builder::Split sk = hL >= 32 ? B.plan_split(tokens, M, K, false, false) : Builder::Split();
-                B.emit([=](hipStream_t st) {
-                    launch_gemm16_linear(st, f16o ? nullptr : (float*)hdst, f16o ? hdst : nullptr, 0, P->arena + off, ld, swz, tokens, K, M, M, ep, hd, hH, hL, sk.ws(P), sk.cnt(P), sk.S);
-                });
+                if (groupable && sk.S <= 1)
+                    B.hm_group.push_back(Builder::HmLaunch{i, last, f16o ? nullptr : (float*)hdst, f16o ? hdst : nullptr, 0, false, off, ld, swz, tokens, K, M, ep, hd, hH, hL});
+                else
+                    B.emit([=](hipStream_t st) {
+                        launch_gemm16_linear(st, f16o ? nullptr : (float*)hdst, f16o ? hdst : nullptr, 0, P->arena + off, ld, swz, tokens, K, M, M, ep, hd, hH, hL, sk.ws(P), sk.cnt(P), sk.S);
+                    });
             }
         } else if (useq) {
             const int S        = ep.gate ? 1 : qgemm16_split_k(tokens, K, M);
@@ -720,6 +750,100 @@ void plan_linear(Builder& B, int i, hipStream_t s, std::vector<int>& chain) {
         }
     }
     g_stats.fused_linear++;
+}
+
+static Step hm_single_step(Planner* P, const Builder::HmLaunch& h) {
+    return [=](hipStream_t st) {
+        launch_gemm16_linear(st, h.dst, h.dst16_arena ? (void*)(P->arena + h.dst16_off) : h.dst16, 0, P->arena + h.a_off, h.lda, h.swz, h.tokens, h.K, h.M, h.M, h.ep, h.hd, h.hH, h.hL);
+    };
+}
+
+// every reader of node k (through no-op views) sits after graph position `pos` or inside `members`
+static bool read_only_after(const GInfo& gi, int k, int pos, const std::vector<int>& members) {
+    for (int c : gi.consumers[k]) {
+        bool in = false;
+        for (int m : members) in = in || m == c;
+        if (in) continue;
+        if (ggml_abi_op_is_noop(gi.node(c)->op)) {
+            if (!read_only_after(gi, c, pos, members)) return false;
+        } else if (c <= pos) {
+            return false;
+        }
+    }
+    return true;
+}
+
+// The head-major projection at node i was handed over instead of emitted (B.hm_group[0]).  Its siblings — the other projections of the same
+// attention reading the same activation (to_k / to_v next to to_q in a self-attention, to_v next to to_k in a cross-attention; block.hpp
+// CrossAttention) — are planned NOW, their own steps parked at their graph positions, and all head-major GEMMs that agree in shape run as ONE
+// launch (launch_gemm16_linear_multi) at the position of the group's last node: by then every member's output buffer is allocated, the shared
+// operand image is private to the arena, and nothing before that position reads a member's output.
+void plan_sibling_group(Builder& B, int i, hipStream_t s, std::vector<int>& chain) {
+    GInfo& gi            = B.gi;
+    Planner* P           = B.P;
+    const ggml_tensor* n = gi.node(i);
+    const ggml_tensor* x = n->src[1];
+    const ggml_tensor* w = n->src[0];
+    std::vector<int> members = chain;
+    int emit_pos = i;
+    for (int c : chain) emit_pos = std::max(emit_pos, c);
+    if (g_opt.fuse_siblings) {
+        std::vector<int> sib;  // (x may be a graph input, which has no consumer list: scan the nodes that follow — the projections of one attention sit close together)
+        for (int c = i + 1; c < gi.g->n_nodes && c < i + 64; ++c) {
+            const ggml_tensor* m = gi.node(c);
+            if (!gi.done[c] && m->op == GGML_OP_MUL_MAT && m->src[1] == x && m->src[0] != w && linear_fast_ok(m) && m->src[0]->type == w->type && m->src[0]->ne[0] == w->ne[0] &&
+                m->src[0]->ne[1] == w->ne[1])
+                sib.push_back(c);
+        }
+        for (int j : sib) {
+            if (B.hm_group.size() >= 4) break;
+            std::vector<int> cj;
+            B.emit_redirect = j;
+            plan_linear(B, j, s, cj);
+            B.emit_redirect = -1;
+            for (int c : cj) {
+                gi.done[c] = 1;
+                members.push_back(c);
+            }
+        }
+    }
+    B.hm_grouping = false;
+    const Builder::HmLaunch& h0 = B.hm_group[0];
+    bool fuse = B.hm_group.size() >= 2;
+    for (const auto& h : B.hm_group) {
+        fuse = fuse && h.a_off == h0.a_off && h.lda == h0.lda && h.tokens == h0.tokens && h.K == h0.K && h.M == h0.M && h.hd == h0.hd && h.hH == h0.hH && h.hL == h0.hL &&
+               h.ep.scale == h0.ep.scale;
+        emit_pos = std::max(emit_pos, h.out_node);
+    }
+    for (const auto& h : B.hm_group) fuse = fuse && read_only_after(gi, h.out_node, emit_pos, members);
+    if (!fuse) {  // every projection on its own, at its own position
+        for (const auto& h : B.hm_group) {
+            if (h.node == i)
+                B.emit(hm_single_step(P, h));
+            else
+                B.deferred[h.node].push_back(hm_single_step(P, h));
+        }
+        B.hm_group.clear();
+        return;
+    }
+    const std::vector<Builder::HmLaunch> grp = B.hm_group;
+    B.hm_group.clear();
+    g_stats.fused_sibling_linears += (int64_t)grp.size() - 1;
+    B.emit_at(emit_pos, i, [=](hipStream_t st) {
+        float* dst[4]       = {nullptr, nullptr, nullptr, nullptr};
+        void* dst16[4]      = {nullptr, nullptr, nullptr, nullptr};
+        const void* wswz[4] = {nullptr, nullptr, nullptr, nullptr};
+        const float* bias[4] = {nullptr, nullptr, nullptr, nullptr};
+        const int nn = (int)grp.size();
+        for (int k = 0; k < nn; ++k) {
+            dst[k]   = grp[k].dst;
+            dst16[k] = grp[k].dst16_arena ? (void*)(P->arena + grp[k].dst16_off) : grp[k].dst16;
+            wswz[k]  = grp[k].swz;
+            bias[k]  = grp[k].ep.bias;
+        }
+        launch_gemm16_linear_multi(st, nn, dst, dst16, P->arena + grp[0].a_off, grp[0].lda, wswz, grp[0].tokens, grp[0].K, grp[0].M, bias, grp[0].ep.scale, grp[0].hd, grp[0].hH,
+                                   grp[0].hL);
+    });
 }
 
 // IM2COL chain -> implicit GEMM conv.  Returns false if the pattern does not match.
@@ -1591,8 +1715,12 @@ bool build_plan(Planner* P, Plan* plan, const ggml_cgraph* g, hipStream_t s) {
             case GGML_OP_IM2COL: ok = plan_conv_chain(B, i, s, chain); break;
             case GGML_OP_MUL_MAT:
                 if (linear_fast_ok(n)) {
+                    B.hm_group.clear();
+                    B.hm_grouping = g_opt.fusion && g_opt.gemm16;
                     plan_linear(B, i, s, chain);
-                    ok = true;
+                    if (!B.hm_group.empty()) plan_sibling_group(B, i, s, chain);
+                    B.hm_grouping = false;
+                    ok            = true;
                 } else {
                     ok = plan_manual_attention(B, i, s, chain);
                 }
@@ -1910,6 +2038,7 @@ void planner_get_stats(ggml_backend_mi355x_stats* o) {
     o->qgemm16_linears       = g_stats.qgemm16_linears;
     o->fgemv_linears         = g_stats.fgemv_linears;
     o->fused_presilu         = g_stats.fused_presilu;
+    o->fused_sibling_linears = g_stats.fused_sibling_linears;
     o->fused_attention       = g_stats.fused_attention;
     o->generic_matmul        = g_stats.generic_matmul;
     o->swizzled_weight_bytes = g_stats.swizzled_weight_bytes;
@@ -1933,6 +2062,7 @@ void planner_set_option(const char* key, int value) {
     else if (!strcmp(key, "qgemm16")) g_opt.qgemm16 = value;
     else if (!strcmp(key, "qgemv_max_rows")) qgemv_set_max_rows(value);
     else if (!strcmp(key, "fgemv")) g_opt.fgemv = value;
+    else if (!strcmp(key, "fuse_siblings")) g_opt.fuse_siblings = value;
     else if (!strcmp(key, "fgemv_max_rows")) fgemv_set_max_rows(value);
     else if (!strcmp(key, "qgemm16_max_rows")) qgemm16_set_max_rows(value);
     else if (!strcmp(key, "splitk_inkernel")) gemm16_set_splitk_inkernel(value);

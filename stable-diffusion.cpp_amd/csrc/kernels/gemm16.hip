@@ -59,6 +59,13 @@ struct G16Args {
     // order), takes a ticket on sk_cnt[tile], and the LAST arriver sums all slices in slice order and runs the regular epilogue
     float* sk_slab;
     int* sk_cnt;
+    // sibling Linears sharing the A operand in ONE launch (rows mode): column tile t belongs to weight t / ncol_tiles; each weight has its own image,
+    // destination(s) and bias, everything else (shape, head-major parameters, scale) is common.  multi <= 1: off.
+    int multi;
+    const half8_t* Wm[4];
+    float* dstm[4];
+    _Float16* dst16m[4];
+    const float* biasm[4];
     // conv gather
     int H, Wd, ICp, OH, OW, S, pad, UPS, KS, icb_per_tap, tap_major;
     int64_t OHOW;
@@ -318,7 +325,17 @@ __global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g
         nt  = min(g.nt_slice, g.nt - kt0);
         if (!g.sk_cnt) g.dst += (int64_t)blockIdx.y * g.slab;
     }
-    const int row_tile = bid / g.ncol_tiles, col_tile = bid - row_tile * g.ncol_tiles;
+    const int nct_all  = g.multi > 1 ? g.ncol_tiles * g.multi : g.ncol_tiles;
+    const int row_tile = bid / nct_all;
+    int col_tile       = bid - row_tile * nct_all;
+    if (!CONV && g.multi > 1) {  // workgroup-uniform: pick this tile's weight, destination and bias
+        const int wi = col_tile / g.ncol_tiles;
+        col_tile -= wi * g.ncol_tiles;
+        g.W       = g.Wm[wi];
+        g.dst     = g.dstm[wi];
+        g.dst16   = g.dst16m[wi];
+        g.ep.bias = g.biasm[wi];
+    }
     const int64_t row0 = (int64_t)row_tile * BM;
     const int col0     = col_tile * BN;
 
@@ -870,7 +887,8 @@ static int g_g16_t320 = 1;  // option "gemm16_t320": 0 disables the pipelined 25
 void gemm16_set_t320(int v) { g_g16_t320 = v; }
 int gemm16_split_k(int64_t rows, int64_t M, int64_t K);
 static int g16_t320_split(int64_t rows, int64_t M, int64_t nt);
-static int g16_pick_tile(int64_t rows, int64_t M, bool geglu, bool conv, int split, int64_t nt) {
+// mul > 1: `mul` sibling weights of M columns each in one launch (divisibility per weight, tile counts over all of them)
+static int g16_pick_tile(int64_t rows, int64_t M, bool geglu, bool conv, int split, int64_t nt, int mul = 1) {
     if (g_g16_variant != 3) return G16_T128;
     const bool can160 = M % 160 == 0 && !geglu;
     // T320 (256x320, one workgroup per CU): the weight image is padded to 128 columns only, so M must be a multiple of 320; the GEGLU
@@ -882,22 +900,22 @@ static int g16_pick_tile(int64_t rows, int64_t M, bool geglu, bool conv, int spl
         if ((g_g16_force_tile == G16_T160 || g_g16_force_tile == G16_T160N) && !can160) return G16_T256;
         return g_g16_force_tile > G16_T256P ? G16_T128 : g_g16_force_tile;
     }
-    const int64_t rt256 = (rows + 255) / 256, c128 = ((rows + 127) / 128) * ((M + 127) / 128), c256 = rt256 * ((M + 127) / 128);
+    const int64_t rt256 = (rows + 255) / 256, c128 = ((rows + 127) / 128) * ((M + 127) / 128) * mul, c256 = rt256 * ((M + 127) / 128) * mul;
     if (g_g16_force_tile < 0 && !split && g_g16_t320 && !can320 && M % 256 == 0) {
         // T256P: the same pipelined loop on 256x256 tiles (N a multiple of 256 but not of 320: DiT Linears, the KL-VAE's 512 / 256-channel convs)
         // one workgroup per CU: pipeline fill, drain and epilogue of a workgroup overlap with nothing, so short-K GEMMs (SD1.5's GEGLU FF1,
         // K = 320 .. 1280: 10-40 stages) stay on the 2-workgroups-per-CU tiles (r02d: 264 -> 318 us); long-K Linears (DiT) take it
-        const int64_t c256p = rt256 * (M / 256), rounds = (c256p + 255) / 256;
+        const int64_t c256p = rt256 * (M / 256) * mul, rounds = (c256p + 255) / 256;
         if (nt >= 64 && c256p >= 192 && c256p * 4 >= rounds * 256 * 3) return G16_T256P;
     }
     if (split) {
         if (can320 && g16_t320_split(rows, M, nt) == split) return G16_T320;
     } else if (g_g16_t320 && can320) {
         // one workgroup per CU and 256 CUs: take it when the launch fills >= 75 % of its rounds
-        const int64_t c320 = rt256 * (M / 320), rounds = (c320 + 255) / 256;
+        const int64_t c320 = rt256 * (M / 320) * mul, rounds = (c320 + 255) / 256;
         if (nt >= (conv ? 16 : 32) && c320 >= 192 && c320 * 4 >= rounds * 256 * 3) return G16_T320;
     }
-    const int64_t c160 = can160 ? rt256 * (M / 160) : 0;
+    const int64_t c160 = can160 ? rt256 * (M / 160) * mul : 0;
     double best = (double)((c128 + 767) / 768) * 1.0;
     int tile    = G16_T128;
     // a partially filled T256 round (256..511 workgroups: some CUs host two, most one) runs ~1.2x a full round's time per workgroup
@@ -914,8 +932,9 @@ static int g16_pick_tile(int64_t rows, int64_t M, bool geglu, bool conv, int spl
 template <int BN_, bool CONV_>
 static void g16_launch(hipStream_t s, G16Args& g, int64_t rows, double flops, double bytes) {  // bytes: algorithmic HBM bytes (operand images read once + output written once [+ residual])
     const unsigned ny = g.split_k > 1 ? (unsigned)g.split_k : 1u;
+    const int mul     = (!CONV_ && g.multi > 1) ? g.multi : 1;  // sibling Linears in one launch: mul x the column tiles
     if (BN_ == 128 && g_g16_variant == 3 && !g.sk_cnt) {
-        const int tile = g16_pick_tile(rows, g.C, g.geglu_inner > 0, CONV_, g.split_k > 1 ? g.split_k : 0, g.nt);  // the GEGLU pairing is laid out for 128-column tiles
+        const int tile = g16_pick_tile(rows, g.C, g.geglu_inner > 0, CONV_, g.split_k > 1 ? g.split_k : 0, g.nt, mul);  // the GEGLU pairing is laid out for 128-column tiles
         if (tile != G16_T128) {
             const int64_t rt256 = (rows + 255) / 256;
             KScope ks_(s, CONV_ ? KF_CONV_T256 : KF_LINEAR, flops, bytes);
@@ -923,37 +942,37 @@ static void g16_launch(hipStream_t s, G16Args& g, int64_t rows, double flops, do
                 g.ncol_tiles = (int)((g.C + 319) / 320);
 #ifdef MI355X_EXPERIMENTS
                 if (g_g16_abl == 1) {
-                    k_gemm16<256, 320, CONV_, 32, 4, 4, 2, 2><<<dim3((unsigned)(rt256 * g.ncol_tiles), ny), 512, 0, s>>>(g);
+                    k_gemm16<256, 320, CONV_, 32, 4, 4, 2, 2><<<dim3((unsigned)(rt256 * g.ncol_tiles * mul), ny), 512, 0, s>>>(g);
                     return;
                 }
                 if (g_g16_abl == 2) {
-                    k_gemm16<256, 320, CONV_, 32, 4, 4, 2, 3><<<dim3((unsigned)(rt256 * g.ncol_tiles), ny), 512, 0, s>>>(g);
+                    k_gemm16<256, 320, CONV_, 32, 4, 4, 2, 3><<<dim3((unsigned)(rt256 * g.ncol_tiles * mul), ny), 512, 0, s>>>(g);
                     return;
                 }
                 if (g_g16_abl == 3) {  // A tiles fetched for tap 0 only (other taps: the zero page): the DMA volume of a kernel that keeps the input window in LDS
-                    k_gemm16<256, 320, CONV_, 32, 4, 4, 2, 4><<<dim3((unsigned)(rt256 * g.ncol_tiles), ny), 512, 0, s>>>(g);
+                    k_gemm16<256, 320, CONV_, 32, 4, 4, 2, 4><<<dim3((unsigned)(rt256 * g.ncol_tiles * mul), ny), 512, 0, s>>>(g);
                     return;
                 }
 #endif
-                k_gemm16<256, 320, CONV_, 32, 4, 4, 2, 1><<<dim3((unsigned)(rt256 * g.ncol_tiles), ny), 512, 0, s>>>(g);
+                k_gemm16<256, 320, CONV_, 32, 4, 4, 2, 1><<<dim3((unsigned)(rt256 * g.ncol_tiles * mul), ny), 512, 0, s>>>(g);
             } else if (tile == G16_T256P) {
                 g.ncol_tiles = (int)((g.C + 255) / 256);
-                k_gemm16<256, 256, CONV_, 32, 4, 4, 2, 1><<<dim3((unsigned)(rt256 * g.ncol_tiles), ny), 512, 0, s>>>(g);
+                k_gemm16<256, 256, CONV_, 32, 4, 4, 2, 1><<<dim3((unsigned)(rt256 * g.ncol_tiles * mul), ny), 512, 0, s>>>(g);
             } else if (tile == G16_T160) {
                 g.ncol_tiles = (int)(g.C / 160);
-                k_gemm16<256, 160, CONV_, 32, 3, 4, 1><<<dim3((unsigned)(rt256 * g.ncol_tiles), ny), 256, 0, s>>>(g);
+                k_gemm16<256, 160, CONV_, 32, 3, 4, 1><<<dim3((unsigned)(rt256 * g.ncol_tiles * mul), ny), 256, 0, s>>>(g);
             } else if (tile == G16_T160N) {
                 g.ncol_tiles = (int)(g.C / 160);
-                k_gemm16<256, 160, CONV_, 32, 3, 8, 1><<<dim3((unsigned)(rt256 * g.ncol_tiles), ny), 512, 0, s>>>(g);
+                k_gemm16<256, 160, CONV_, 32, 3, 8, 1><<<dim3((unsigned)(rt256 * g.ncol_tiles * mul), ny), 512, 0, s>>>(g);
             } else if (tile == G16_T256W) {
-                k_gemm16<256, 128, CONV_, 32, 3, 2, 2><<<dim3((unsigned)(rt256 * g.ncol_tiles), ny), 256, 0, s>>>(g);
+                k_gemm16<256, 128, CONV_, 32, 3, 2, 2><<<dim3((unsigned)(rt256 * g.ncol_tiles * mul), ny), 256, 0, s>>>(g);
             } else {
-                k_gemm16<256, 128, CONV_, 32, 3, 4, 2><<<dim3((unsigned)(rt256 * g.ncol_tiles), ny), 512, 0, s>>>(g);
+                k_gemm16<256, 128, CONV_, 32, 3, 4, 2><<<dim3((unsigned)(rt256 * g.ncol_tiles * mul), ny), 512, 0, s>>>(g);
             }
             return;
         }
     }
-    const dim3 grid((unsigned)(((rows + 127) / 128) * g.ncol_tiles), ny);
+    const dim3 grid((unsigned)(((rows + 127) / 128) * g.ncol_tiles * mul), ny);
     KScope ks_(s, CONV_ ? KF_CONV_T128 : KF_LINEAR, flops, bytes);
     if (g_g16_variant == 0)
         k_gemm16<128, BN_, CONV_, 64, 2, 2, 2><<<grid, 256, 0, s>>>(g);
@@ -1013,8 +1032,8 @@ static int g_g16_sk_inkernel = 0;  // option "splitk_inkernel": 1 = combine in t
 void gemm16_set_splitk_inkernel(int v) { g_g16_sk_inkernel = v; }
 static int g_g16_sk_in_target = 320;  // option "splitk_in_target": workgroups an in-launch split aims for
 void gemm16_set_splitk_in_target(int v) { g_g16_sk_in_target = v; }
-static bool g16_use_bn64(int64_t rows, int64_t M) {
-    const int64_t c128 = ((rows + 127) / 128) * ((M + 127) / 128);
+static bool g16_use_bn64(int64_t rows, int64_t M, int mul = 1) {
+    const int64_t c128 = ((rows + 127) / 128) * ((M + 127) / 128) * mul;
     return M <= 64 || (M % 64 == 0 && g16_bk32() && (g_g16_force_tile == G16_T128N64 || (g_g16_force_tile < 0 && g_g16_bn64 && c128 <= 128)));
 }
 G16SplitPlan gemm16_split_plan(int64_t rows, int64_t M, int64_t K, bool conv, bool plain_out) {
@@ -1189,6 +1208,53 @@ void launch_gemm16_linear(hipStream_t s, float* dst, void* dst16, int64_t ldd16,
         g16_launch<128, false>(s, g, rows, 2.0 * rows * K * M, lin_bytes);
     }
     if (S > 1 && !inker) launch_splitk_reduce(s, dst, splitk_ws, S, rows * M, e.bias, 1, M, e.residual);
+}
+
+// n (2..4) sibling Linears over the same f16 operand image in ONE launch (q / k / v projections of a self-attention, k / v of a cross-attention:
+// block.hpp CrossAttention): same rows, K, M, head-major parameters and scale; per weight its image, f32 and / or f16 destination and bias.  The
+// operand rows are fetched once per row tile (the column tiles of all weights run back to back on one XCD) and two or three ~25 us launch chains
+// become one.
+void launch_gemm16_linear_multi(hipStream_t s, int n, float* const* dst, void* const* dst16, const void* a16, int64_t lda, const void* const* wswz, int64_t rows,
+                               int64_t K, int64_t M, const float* const* bias, float scale, int hm_d, int hm_H, int hm_L) {
+    if (n < 2 || n > 4) {
+        fprintf(stderr, "ggml-mi355x: launch_gemm16_linear_multi takes 2..4 weights\n");
+        abort();
+    }
+    G16Args g{};
+    g.A     = (const _Float16*)a16;
+    g.lda   = lda;
+    const int64_t Kp = rup64(K, 64);
+    g.kfr   = Kp / 16;
+    g.ldd   = M;
+    g.ldd16 = 0;
+    g.hm_d  = hm_d;
+    g.hm_H  = hm_H;
+    g.hm_L  = hm_L;
+    g.R     = rows;
+    g.C     = M;
+    g.nt    = (int)(Kp / (g16_bk32() ? 32 : 64));
+    g.ep    = G16Epi{bias[0], nullptr, scale};
+    g.multi = n;
+    for (int i = 0; i < n; ++i) {
+        g.Wm[i]     = (const half8_t*)wswz[i];
+        g.dstm[i]   = dst[i];
+        g.dst16m[i] = (_Float16*)dst16[i];
+        g.biasm[i]  = bias[i];
+    }
+    g.W     = g.Wm[0];
+    g.dst   = g.dstm[0];
+    g.dst16 = g.dst16m[0];
+    double out_b = 0.0;
+    for (int i = 0; i < n; ++i) out_b += (double)rows * M * (dst16[i] ? 2.0 : 4.0);
+    const double bytes = (double)rows * Kp * 2.0 + (double)n * Kp * rup64(M, 128) * 2.0 + out_b;
+    if (g16_trace()) fprintf(stderr, "G16 linear x%d rows=%lld K=%lld M=%lld hm=%d\n", n, (long long)rows, (long long)K, (long long)M, hm_d);
+    if (g16_use_bn64(rows, M, n)) {
+        g.ncol_tiles = (int)((M + 63) / 64);
+        g16_launch<64, false>(s, g, rows, 2.0 * n * rows * K * M, bytes);
+    } else {
+        g.ncol_tiles = (int)((M + 127) / 128);
+        g16_launch<128, false>(s, g, rows, 2.0 * n * rows * K * M, bytes);
+    }
 }
 
 void launch_gemm16_linear_geglu(hipStream_t s, void* dst16, const void* a16, int64_t lda, const void* wswz_geglu, int64_t rows, int64_t K, int64_t M,

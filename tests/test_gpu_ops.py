@@ -652,6 +652,17 @@ def test_attention_block_flash_operands_from_projections(sd, oracle, gpu, rng, d
         after = sd.backend_stats()
         assert after["fused_q16"] - before["fused_q16"] == (1 if d % 8 == 0 else 0)
         assert after["fused_attention"] - before["fused_attention"] == 1
+        if not os.environ.get("SDCPP_BACKEND_OPTS"):
+            # the projections reading the same activation run as ONE launch: q / k / v of a self-attention, k / v of a cross-attention
+            assert after["fused_sibling_linears"] - before["fused_sibling_linears"] == (2 if c is x else 1)
+            sd.backend_set_option("fuse_siblings", 0)
+            try:
+                with Graph(gpu) as g2:
+                    alt = g2.run(build(g2, sd.lib()))
+            finally:
+                sd.backend_set_option("fuse_siblings", 1)
+            assert sd.backend_stats()["fused_sibling_linears"] == after["fused_sibling_linears"]
+            np.testing.assert_array_equal(out, alt[0])   # same k order per output element whatever the tile geometry: bit-identical
 
 
 @pytest.mark.parametrize("d,Lq,Lk,HN", [(40, 200, 200, 4), (80, 100, 77, 2), (160, 64, 64, 2),
