@@ -38,8 +38,6 @@ HIP_FLAGS = ["-std=c++17", "-O3", "-fPIC", "-fvisibility=hidden", f"--offload-ar
              f"-I{CSRC / 'backend'}", f"-I{CSRC / 'kernels'}", "-D__HIP_PLATFORM_AMD__"]
 if VARIANT == "exp":
     HIP_FLAGS.append("-DMI355X_EXPERIMENTS")
-if VARIANT == "nt":  # A/B: non-temporal conv output stores / residual loads (gemm16.hip st_out / ld_res)
-    HIP_FLAGS.append("-DMI355X_NT_CONV_OUT")
 ORACLE_FLAGS = ["-std=c++17", "-O3", "-fPIC", "-fvisibility=hidden", "-fopenmp", "-mavx2", "-mfma", "-mf16c",
                 "-Wall", f"-I{INCLUDE}"]
 

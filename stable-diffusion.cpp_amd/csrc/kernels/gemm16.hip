@@ -88,15 +88,6 @@ template <typename T>
 __device__ __forceinline__ void st_u(T* ubase, uint32_t lane_bytes, T v) { *(T*)((char*)ubase + lane_bytes) = v; }
 template <typename T>
 __device__ __forceinline__ T ld_u(const T* ubase, uint32_t lane_bytes) { return *(const T*)((const char*)ubase + lane_bytes); }
-// conv output / residual: written / read exactly once by this kernel.  MI355X_NT_CONV_OUT (experiment builds: A/B through SDCPP_BACKEND_LIB) marks
-// them non-temporal so that the 84 MB output stream of a 64x64-level conv does not push the input window and the weight image out of the 4 MB L2
-#if defined(MI355X_NT_CONV_OUT)
-__device__ __forceinline__ void st_out(float* ubase, uint32_t lane_bytes, float v) { __builtin_nontemporal_store(v, (float*)((char*)ubase + lane_bytes)); }
-__device__ __forceinline__ float ld_res(const float* ubase, uint32_t lane_bytes) { return __builtin_nontemporal_load((const float*)((const char*)ubase + lane_bytes)); }
-#else
-__device__ __forceinline__ void st_out(float* ubase, uint32_t lane_bytes, float v) { st_u(ubase, lane_bytes, v); }
-__device__ __forceinline__ float ld_res(const float* ubase, uint32_t lane_bytes) { return ld_u(ubase, lane_bytes); }
-#endif
 
 enum { EPI_F32 = 0, EPI_F32_RES = 1, EPI_F16 = 2, EPI_HM_F32 = 3, EPI_HM_F16 = 4, EPI_GENERIC = 5, EPI_F16_GELU = 6, EPI_F32_GATE = 7 };
 
@@ -276,13 +267,13 @@ __device__ __forceinline__ void epi_conv(const float16_t (&acc)[RB][CB], const G
                     const bool ok = MODE != 2 || cblk + ro + 4 * hi < g.C;
                     bv[r - r0]    = (pb && ok) ? ld_u(pb + ro, 16u * hi) : 0.f;
                     if (pc && ok) bv[r - r0] += ld_u(pc + ro, (4u * hi + dimg * (uint32_t)g.C) * 4u);
-                    rv[r - r0]    = ((MODE == 1 || (MODE == 2 && g.ep.residual)) && ok) ? ld_res(g.ep.residual + ub + (int64_t)ro * g.OHOW, le * 4u) : 0.f;
+                    rv[r - r0]    = ((MODE == 1 || (MODE == 2 && g.ep.residual)) && ok) ? ld_u(g.ep.residual + ub + (int64_t)ro * g.OHOW, le * 4u) : 0.f;
                 }
 #pragma unroll
                 for (int r = r0; r < r0 + 8; ++r) {
                     const int ro = (r & 3) + 8 * (r >> 2);
                     if (MODE == 2 && cblk + ro + 4 * hi >= g.C) continue;
-                    st_out(g.dst + ub + (int64_t)ro * g.OHOW, le * 4u, acc[rb][cb][r] * g.ep.scale + bv[r - r0] + rv[r - r0]);
+                    st_u(g.dst + ub + (int64_t)ro * g.OHOW, le * 4u, acc[rb][cb][r] * g.ep.scale + bv[r - r0] + rv[r - r0]);
                 }
             }
         }
