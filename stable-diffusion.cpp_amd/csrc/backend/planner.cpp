@@ -41,11 +41,11 @@ namespace {
 struct Stats {
     std::atomic<int64_t> graphs_computed{0}, plans_built{0}, nodes_seen{0}, kernels_planned{0}, kernels_launched{0}, fused_conv{0},
         fused_conv_bounced{0}, fused_linear{0}, fused_norm{0}, fused_geglu{0}, fused_attention{0}, generic_matmul{0}, swizzled_weight_bytes{0}, fused_linear_geglu{0}, split_k_gemms{0}, head_major_gemms{0}, fused_modulate{0}, fused_gate{0}, fused_gelu{0}, fused_rope{0}, fused_concat_heads{0},
-        graph_replays{0}, qgemv_linears{0}, fused_chan_add{0}, fused_proj_tokens{0}, gemm_attention{0}, fused_q16{0}, split_k_inlaunch{0}, qgemm16_linears{0}, fgemv_linears{0}, fused_presilu{0}, fused_sibling_linears{0};
+        graph_replays{0}, qgemv_linears{0}, fused_chan_add{0}, fused_proj_tokens{0}, gemm_attention{0}, fused_q16{0}, split_k_inlaunch{0}, qgemm16_linears{0}, fgemv_linears{0}, fused_presilu{0}, fused_sibling_linears{0}, hoisted_kv_linears{0};
 } g_stats;
 
 struct Options {
-    std::atomic<int> fusion{1}, mfma_gemm{1}, hip_graph{0}, flash_pattern{1}, gemm16{1}, fuse_modulate{1}, fuse_gate{1}, fuse_gelu{1}, fuse_rope{1}, fuse_concat_heads{1}, qgemv{1}, fuse_chan_add{1}, fuse_proj_tokens{1}, fuse_q16{1}, qgemm16{1}, fgemv{1}, fuse_siblings{1};
+    std::atomic<int> fusion{1}, mfma_gemm{1}, hip_graph{0}, flash_pattern{1}, gemm16{1}, fuse_modulate{1}, fuse_gate{1}, fuse_gelu{1}, fuse_rope{1}, fuse_concat_heads{1}, qgemv{1}, fuse_chan_add{1}, fuse_proj_tokens{1}, fuse_q16{1}, qgemm16{1}, fgemv{1}, fuse_siblings{1}, hoist_kv{1};
 } g_opt;
 
 using Step = std::function<void(hipStream_t)>;
@@ -261,6 +261,9 @@ struct Builder {
         int hd, hH, hL;
     };
     std::vector<HmLaunch> hm_group;
+    // f16 head-major K / V images of cross-attention projections computed ahead of their graph position (plan_hoisted_kv) live in the arena:
+    // CPY node -> arena offset; the FLASH_ATTN_EXT node reads them from there
+    std::unordered_map<const ggml_tensor*, size_t> moved;
     void emit(Step s) {
         if (emit_redirect >= 0)
             deferred[emit_redirect].push_back(std::move(s));
@@ -830,10 +833,10 @@ void plan_sibling_group(Builder& B, int i, hipStream_t s, std::vector<int>& chai
     B.hm_group.clear();
     g_stats.fused_sibling_linears += (int64_t)grp.size() - 1;
     B.emit_at(emit_pos, i, [=](hipStream_t st) {
-        float* dst[4]       = {nullptr, nullptr, nullptr, nullptr};
-        void* dst16[4]      = {nullptr, nullptr, nullptr, nullptr};
-        const void* wswz[4] = {nullptr, nullptr, nullptr, nullptr};
-        const float* bias[4] = {nullptr, nullptr, nullptr, nullptr};
+        float* dst[16]        = {};
+        void* dst16[16]       = {};
+        const void* wswz[16]  = {};
+        const float* bias[16] = {};
         const int nn = (int)grp.size();
         for (int k = 0; k < nn; ++k) {
             dst[k]   = grp[k].dst;
@@ -844,6 +847,98 @@ void plan_sibling_group(Builder& B, int i, hipStream_t s, std::vector<int>& chai
         launch_gemm16_linear_multi(st, nn, dst, dst16, P->arena + grp[0].a_off, grp[0].lda, wswz, grp[0].tokens, grp[0].K, grp[0].M, bias, grp[0].ep.scale, grp[0].hd, grp[0].hH,
                                    grp[0].hL);
     });
+}
+
+// Cross-attention K / V projections (block.hpp CrossAttention: to_k / to_v of the context) of ALL transformer blocks of one width read the same
+// tensor — the text context, known before the first block runs.  Each is a ~25 us latency-bound launch (1232 x 768 -> 320 ... 1280) and there are 32
+// of them in an SD1.5 forward, 140 in an SDXL forward.  Pre-pass: group them by (context, shape), run each group as multi-weight launches of up
+// to 16 weights at the graph position of the group's FIRST member, and keep the f16 head-major results in the arena (their graph buffers are not
+// allocated that early); the FLASH_ATTN_EXT nodes read them from there (Builder::moved).  Only contexts that are graph inputs or a REPEAT of one
+// are hoisted: nothing fused can decide later not to materialise their f32 rows.
+void plan_hoisted_kv(Builder& B, hipStream_t s) {
+    if (!g_opt.hoist_kv || !g_opt.fusion || !g_opt.gemm16 || !g_opt.fuse_siblings) return;
+    GInfo& gi  = B.gi;
+    Planner* P = B.P;
+    struct Key {
+        const ggml_tensor* x;
+        int wtype;
+        int64_t K, M, d, H, L;
+        bool operator<(const Key& o) const { return std::tie(x, wtype, K, M, d, H, L) < std::tie(o.x, o.wtype, o.K, o.M, o.d, o.H, o.L); }
+    };
+    std::map<Key, std::vector<int>> groups;
+    for (int j = 0; j < gi.g->n_nodes; ++j) {
+        const ggml_tensor* n = gi.node(j);
+        if (n->op != GGML_OP_MUL_MAT || !linear_fast_ok(n)) continue;
+        const ggml_tensor* x  = n->src[1];
+        const ggml_tensor* xr = strip_reshape(x);
+        if (!(gi.idx(xr) < 0 || xr->op == GGML_OP_REPEAT)) continue;
+        const int j1 = gi.sole(j);
+        const int j2 = (j1 >= 0 && gi.node(j1)->op == GGML_OP_RESHAPE) ? gi.sole(j1) : -1;
+        const int j3 = (j2 >= 0 && gi.node(j2)->op == GGML_OP_PERMUTE) ? gi.sole(j2) : -1;
+        const int j4 = (j3 >= 0 && gi.node(j3)->op == GGML_OP_CONT) ? gi.sole(j3) : -1;
+        const int j5 = (j4 >= 0 && gi.node(j4)->op == GGML_OP_RESHAPE) ? gi.sole(j4) : -1;
+        if (j5 < 0 || gi.node(j5)->op != GGML_OP_CPY || gi.node(j5)->type != GGML_TYPE_F16) continue;
+        const int jf = gi.sole(j5);
+        if (jf < 0 || gi.node(jf)->op != GGML_OP_FLASH_ATTN_EXT || !planner_supports_op(gi.node(jf))) continue;
+        const ggml_tensor* f = gi.node(jf);
+        if (!((f->src[1] == gi.node(j5)) != (f->src[2] == gi.node(j5))) || f->src[0] == gi.node(j5)) continue;  // exactly one of K, V
+        const ggml_tensor* r4 = gi.node(j1);
+        const ggml_tensor* w  = n->src[0];
+        groups[Key{x, (int)w->type, w->ne[0], w->ne[1], r4->ne[0], r4->ne[1], r4->ne[2]}].push_back(j);
+    }
+    for (auto& kv : groups) {
+        std::vector<int>& mem = kv.second;
+        if (mem.size() < 3) continue;  // a lone k / v pair is taken by plan_sibling_group
+        const int j0 = mem[0];
+        for (size_t c0 = 0; c0 < mem.size(); c0 += 16) {
+            const size_t c1 = std::min(mem.size(), c0 + 16);
+            if (c1 - c0 < 2) break;  // a single left-over member: planned in place by the main walk
+            B.hm_group.clear();
+            B.hm_grouping = true;
+            for (size_t m = c0; m < c1; ++m) {
+                const int j = mem[m];
+                std::vector<int> cj;
+                B.emit_redirect = j;  // whatever this member emits besides its (captured) GEMM stays at its own position; the first one packs the context
+                if (m == c0) B.emit_redirect = j0;
+                plan_linear(B, j, s, cj);
+                B.emit_redirect = -1;
+                for (int c : cj) gi.done[c] = 1;
+            }
+            B.hm_grouping = false;
+            std::vector<Builder::HmLaunch> grp = B.hm_group;
+            B.hm_group.clear();
+            bool ok = grp.size() >= 2;
+            for (const auto& h : grp)
+                ok = ok && h.dst16 && !h.dst && !h.dst16_arena && h.a_off == grp[0].a_off && h.lda == grp[0].lda && h.tokens == grp[0].tokens && h.K == grp[0].K && h.M == grp[0].M &&
+                     h.hd == grp[0].hd && h.hH == grp[0].hH && h.hL == grp[0].hL && h.ep.scale == grp[0].ep.scale;
+            if (!ok) {  // every captured projection on its own, at its own position, into its graph buffer
+                for (const auto& h : grp) B.deferred[h.node].push_back(hm_single_step(P, h));
+                continue;
+            }
+            for (auto& h : grp) {
+                h.dst16_off   = B.alloc((size_t)h.tokens * h.M * 2);
+                h.dst16_arena = true;
+                h.dst16       = nullptr;
+                B.moved[gi.node(h.out_node)] = h.dst16_off;
+            }
+            g_stats.hoisted_kv_linears += (int64_t)grp.size();
+            g_stats.fused_sibling_linears += (int64_t)grp.size() - 1;
+            B.deferred[j0].push_back([=](hipStream_t st) {
+                float* dst[16]        = {};
+                void* dst16[16]       = {};
+                const void* wswz[16]  = {};
+                const float* bias[16] = {};
+                const int nn = (int)grp.size();
+                for (int k = 0; k < nn; ++k) {
+                    dst16[k] = P->arena + grp[k].dst16_off;
+                    wswz[k]  = grp[k].swz;
+                    bias[k]  = grp[k].ep.bias;
+                }
+                launch_gemm16_linear_multi(st, nn, dst, dst16, P->arena + grp[0].a_off, grp[0].lda, wswz, grp[0].tokens, grp[0].K, grp[0].M, bias, grp[0].ep.scale, grp[0].hd,
+                                           grp[0].hH, grp[0].hL);
+            });
+        }
+    }
 }
 
 // IM2COL chain -> implicit GEMM conv.  Returns false if the pattern does not match.
@@ -1632,6 +1727,20 @@ bool plan_single(Builder& B, int i, hipStream_t s) {
                 if (q16) qq.data = PP->arena + q16off;
                 return qq;
             };
+            // K / V projected ahead of their graph position (plan_hoisted_kv): same shape and strides, the data sits in the arena
+            const auto kmv = B.moved.find(n->src[1]), vmv = B.moved.find(n->src[2]);
+            const bool kmoved = kmv != B.moved.end(), vmoved = vmv != B.moved.end();
+            const size_t koff = kmoved ? kmv->second : 0, voff = vmoved ? vmv->second : 0;
+            if (kmoved) k.data = nullptr;
+            if (vmoved) v.data = nullptr;
+            auto kfix = [=](View4 kk) {
+                if (kmoved) kk.data = PP->arena + koff;
+                return kk;
+            };
+            auto vfix = [=](View4 vv) {
+                if (vmoved) vv.data = PP->arena + voff;
+                return vv;
+            };
             // dst.ne = [dv, H, Lq, B]: element (d, q, h) at h*nb1 + q*nb2
             const int64_t nbq = (int64_t)n->nb[2], nbh = (int64_t)n->nb[1];
             FlashOut fo;
@@ -1664,7 +1773,7 @@ bool plan_single(Builder& B, int i, hipStream_t s) {
                                 f2.H     = (int)H;
                                 f2.dst16 = P->arena + off;
                                 f2.ld16  = ld;
-                                launch_flash_attn(st, f2, qfix(q), k, v, sc);
+                                launch_flash_attn(st, f2, qfix(q), kfix(k), vfix(v), sc);
                             });
                             B.packed[ct] = Packed{off, ld, false};
                         } else {
@@ -1676,7 +1785,7 @@ bool plan_single(Builder& B, int i, hipStream_t s) {
                                 f2.nb_q = C * 4;
                                 f2.nb_h = d * 4;
                                 f2.nb_n = Lq * C * 4;
-                                launch_flash_attn(st, f2, qfix(q), k, v, sc);
+                                launch_flash_attn(st, f2, qfix(q), kfix(k), vfix(v), sc);
                             });
                         }
                         gi.done[j1] = gi.done[j2] = 1;
@@ -1685,7 +1794,7 @@ bool plan_single(Builder& B, int i, hipStream_t s) {
                     }
                 }
             }
-            B.emit([=](hipStream_t st) { launch_flash_attn(st, fo, qfix(q), k, v, sc); });
+            B.emit([=](hipStream_t st) { launch_flash_attn(st, fo, qfix(q), kfix(k), vfix(v), sc); });
             g_stats.fused_attention++;
             return true;
         }
@@ -1697,6 +1806,7 @@ bool plan_single(Builder& B, int i, hipStream_t s) {
 bool build_plan(Planner* P, Plan* plan, const ggml_cgraph* g, hipStream_t s) {
     Builder B(P, plan, g);
     GInfo& gi = B.gi;
+    plan_hoisted_kv(B, s);
     for (int i = 0; i < g->n_nodes; ++i) {
         {
             auto it = B.deferred.find(i);
@@ -2039,6 +2149,7 @@ void planner_get_stats(ggml_backend_mi355x_stats* o) {
     o->fgemv_linears         = g_stats.fgemv_linears;
     o->fused_presilu         = g_stats.fused_presilu;
     o->fused_sibling_linears = g_stats.fused_sibling_linears;
+    o->hoisted_kv_linears    = g_stats.hoisted_kv_linears;
     o->fused_attention       = g_stats.fused_attention;
     o->generic_matmul        = g_stats.generic_matmul;
     o->swizzled_weight_bytes = g_stats.swizzled_weight_bytes;
@@ -2063,6 +2174,7 @@ void planner_set_option(const char* key, int value) {
     else if (!strcmp(key, "qgemv_max_rows")) qgemv_set_max_rows(value);
     else if (!strcmp(key, "fgemv")) g_opt.fgemv = value;
     else if (!strcmp(key, "fuse_siblings")) g_opt.fuse_siblings = value;
+    else if (!strcmp(key, "hoist_kv")) g_opt.hoist_kv = value;
     else if (!strcmp(key, "fgemv_max_rows")) fgemv_set_max_rows(value);
     else if (!strcmp(key, "qgemm16_max_rows")) qgemm16_set_max_rows(value);
     else if (!strcmp(key, "splitk_inkernel")) gemm16_set_splitk_inkernel(value);

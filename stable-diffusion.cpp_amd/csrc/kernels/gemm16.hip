@@ -62,10 +62,10 @@ struct G16Args {
     // sibling Linears sharing the A operand in ONE launch (rows mode): column tile t belongs to weight t / ncol_tiles; each weight has its own image,
     // destination(s) and bias, everything else (shape, head-major parameters, scale) is common.  multi <= 1: off.
     int multi;
-    const half8_t* Wm[4];
-    float* dstm[4];
-    _Float16* dst16m[4];
-    const float* biasm[4];
+    const half8_t* Wm[16];
+    float* dstm[16];
+    _Float16* dst16m[16];
+    const float* biasm[16];
     // conv gather
     int H, Wd, ICp, OH, OW, S, pad, UPS, KS, icb_per_tap, tap_major;
     int64_t OHOW;
@@ -333,7 +333,10 @@ __global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g
         col_tile -= wi * g.ncol_tiles;
         // static indices + scalar selects: indexing the kernel-argument struct with a run-time value makes the compiler copy ALL of it to
         // scratch memory (392 B per lane, +50 VGPRs in every Linear instantiation: r02y, Linear family 7.5 -> 11.6 ms)
-#define G16_PICK(F, A) g.F = wi == 1 ? g.A[1] : wi == 2 ? g.A[2] : wi == 3 ? g.A[3] : g.A[0]
+#define G16_PICK(F, A)                                                                                                                                    \
+    g.F = wi < 8 ? (wi < 4 ? (wi < 2 ? (wi == 0 ? g.A[0] : g.A[1]) : (wi == 2 ? g.A[2] : g.A[3])) : (wi < 6 ? (wi == 4 ? g.A[4] : g.A[5]) : (wi == 6 ? g.A[6] : g.A[7]))) \
+                 : (wi < 12 ? (wi < 10 ? (wi == 8 ? g.A[8] : g.A[9]) : (wi == 10 ? g.A[10] : g.A[11]))                                                       \
+                            : (wi < 14 ? (wi == 12 ? g.A[12] : g.A[13]) : (wi == 14 ? g.A[14] : g.A[15])))
         G16_PICK(W, Wm);
         G16_PICK(dst, dstm);
         G16_PICK(dst16, dst16m);
@@ -1214,14 +1217,14 @@ void launch_gemm16_linear(hipStream_t s, float* dst, void* dst16, int64_t ldd16,
     if (S > 1 && !inker) launch_splitk_reduce(s, dst, splitk_ws, S, rows * M, e.bias, 1, M, e.residual);
 }
 
-// n (2..4) sibling Linears over the same f16 operand image in ONE launch (q / k / v projections of a self-attention, k / v of a cross-attention:
+// n (2..16) sibling Linears over the same f16 operand image in ONE launch (q / k / v projections of a self-attention, k / v of a cross-attention:
 // block.hpp CrossAttention): same rows, K, M, head-major parameters and scale; per weight its image, f32 and / or f16 destination and bias.  The
 // operand rows are fetched once per row tile (the column tiles of all weights run back to back on one XCD) and two or three ~25 us launch chains
 // become one.
 void launch_gemm16_linear_multi(hipStream_t s, int n, float* const* dst, void* const* dst16, const void* a16, int64_t lda, const void* const* wswz, int64_t rows,
                                int64_t K, int64_t M, const float* const* bias, float scale, int hm_d, int hm_H, int hm_L) {
-    if (n < 2 || n > 4) {
-        fprintf(stderr, "ggml-mi355x: launch_gemm16_linear_multi takes 2..4 weights\n");
+    if (n < 2 || n > 16) {
+        fprintf(stderr, "ggml-mi355x: launch_gemm16_linear_multi takes 2..16 weights\n");
         abort();
     }
     G16Args g{};

@@ -97,7 +97,7 @@ void gemm16_set_variant(int v);  // 0: BK64x2 stages, 1: BK32x3 stages (default)
 // hm_d > 0: head-major store — element (row = n*hm_L + l, col = h*hm_d + dd) goes to ((n*hm_H + h)*hm_L + l)*hm_d + dd of dst (f32) / dst16 (f16)
 void launch_gemm16_linear(hipStream_t s, float* dst, void* dst16, int64_t ldd16, const void* a16, int64_t lda, const void* wswz, int64_t rows,
                           int64_t K, int64_t M, int64_t ldd, const Epilogue& ep, int hm_d = 0, int hm_H = 0, int hm_L = 0, float* splitk_ws = nullptr, int* splitk_cnt = nullptr, int splitk_S = 0);
-// n (2..4) sibling Linears over the same operand image in one launch; per weight: image, f32 and / or f16 destination (head-major when hm_d > 0), bias
+// n (2..16) sibling Linears over the same operand image in one launch; per weight: image, f32 and / or f16 destination (head-major when hm_d > 0), bias
 void launch_gemm16_linear_multi(hipStream_t s, int n, float* const* dst, void* const* dst16, const void* a16, int64_t lda, const void* const* wswz, int64_t rows,
                                int64_t K, int64_t M, const float* const* bias, float scale, int hm_d, int hm_H, int hm_L);
 // FF1 + GEGLU in one kernel (block.hpp:193-210): wswz built with geglu_inner = M/2; dst16[t][c] = (y[t][c] + b[c]) * gelu(y[t][inner + c] + b[inner + c]),

@@ -665,6 +665,56 @@ def test_attention_block_flash_operands_from_projections(sd, oracle, gpu, rng, d
             np.testing.assert_array_equal(out, alt[0])   # same k order per output element whatever the tile geometry: bit-identical
 
 
+@pytest.mark.parametrize("d,H,Lq,Lk,N,ctx,blocks", [(40, 8, 96, 77, 2, 768, 3), (64, 4, 130, 77, 1, 320, 9), (80, 2, 64, 40, 3, 128, 2)])
+def test_cross_attention_kv_of_all_blocks_hoisted(sd, oracle, gpu, rng, d, H, Lq, Lk, N, ctx, blocks):
+    """`blocks` cross-attention layers in sequence reading ONE text context (what a UNet forward does: block.hpp CrossAttention to_k / to_v of every
+    transformer block): all their K / V projections run as grouped multi-weight launches at the position of the first one, results kept in the
+    backend's arena and read from there by the FLASH_ATTN_EXT nodes.  9 blocks = 18 projections = two launches (16 + 2)."""
+    C = d * H
+    x = rng.standard_normal((N, Lq, C)).astype(np.float32)
+    c = rng.standard_normal((N, Lk, ctx)).astype(np.float32)
+    ws = [[(rng.standard_normal(sh) / np.sqrt(sh[1])).astype(np.float32) for sh in ((C, C), (C, ctx), (C, ctx), (C, C))] for _ in range(blocks)]
+    scale = 1.0 / np.sqrt(d)
+
+    def build(g, L):
+        h = g.input(x)
+        ci = g.input(c)
+
+        def heads(t, Lt, f16):
+            t = L.ggml_reshape_4d(g.ctx, t, d, H, Lt, N)
+            t = L.ggml_cont(g.ctx, L.ggml_permute(g.ctx, t, 0, 2, 1, 3))
+            t = L.ggml_reshape_3d(g.ctx, t, d, Lt, H * N)
+            return L.ggml_cast(g.ctx, t, F16) if f16 else t
+
+        for wq, wk, wv, wo in ws:
+            q = heads(L.ggml_mul_mat(g.ctx, g.weight(wq, F16), h), Lq, False)
+            k = heads(L.ggml_mul_mat(g.ctx, g.weight(wk, F16), ci), Lk, True)
+            v = heads(L.ggml_mul_mat(g.ctx, g.weight(wv, F16), ci), Lk, True)
+            a = L.ggml_flash_attn_ext(g.ctx, q, k, v, None, scale, 0.0, 0.0)
+            L.ggml_flash_attn_ext_set_prec(a, 10)
+            nb = sd_tensor_nb(a)
+            a = L.ggml_view_4d(g.ctx, a, d, H, Lq, N, nb[1], nb[2], nb[1] * H, 0)
+            a = L.ggml_cont(g.ctx, L.ggml_permute(g.ctx, a, 0, 1, 2, 3))
+            a = L.ggml_reshape_3d(g.ctx, a, C, Lq, N)
+            h = L.ggml_add(g.ctx, L.ggml_mul_mat(g.ctx, g.weight(wo, F16), a), h)
+        return h
+
+    before = sd.backend_stats() if _on_gpu() else None
+    ref, out = run_both(sd, oracle, gpu, build)
+    assert np.isfinite(out).all() and rel_l2(out, ref) < 1e-2      # the oracle's flash path accumulates V in f16
+    if before is not None and Lk >= 32 and not os.environ.get("SDCPP_BACKEND_OPTS"):
+        after = sd.backend_stats()
+        assert after["hoisted_kv_linears"] - before["hoisted_kv_linears"] == (2 * blocks if blocks >= 2 and 2 * blocks >= 3 else 0)
+        sd.backend_set_option("hoist_kv", 0)
+        try:
+            with Graph(gpu) as g2:
+                alt = g2.run(build(g2, sd.lib()))
+        finally:
+            sd.backend_set_option("hoist_kv", 1)
+        assert sd.backend_stats()["hoisted_kv_linears"] == after["hoisted_kv_linears"]
+        np.testing.assert_array_equal(out, alt)
+
+
 @pytest.mark.parametrize("d,Lq,Lk,HN", [(40, 200, 200, 4), (80, 100, 77, 2), (160, 64, 64, 2),
                                         # head dims beyond the flash kernel (KL-VAE mid attention: 1 head x 512): composed from MFMA GEMMs + f16 row softmax
                                         (512, 256, 256, 1), (192, 100, 80, 2), (512, 1024, 1024, 2)])
