@@ -878,8 +878,13 @@ void plan_hoisted_kv(Builder& B, hipStream_t s) {
         const int j4 = (j3 >= 0 && gi.node(j3)->op == GGML_OP_CONT) ? gi.sole(j3) : -1;
         const int j5 = (j4 >= 0 && gi.node(j4)->op == GGML_OP_RESHAPE) ? gi.sole(j4) : -1;
         if (j5 < 0 || gi.node(j5)->op != GGML_OP_CPY || gi.node(j5)->type != GGML_TYPE_F16) continue;
-        const int jf = gi.sole(j5);
-        if (jf < 0 || gi.node(jf)->op != GGML_OP_FLASH_ATTN_EXT || !planner_supports_op(gi.node(jf))) continue;
+        int jf = -1, nread = 0;  // (ggml_cast's CPY node lists itself as src[1]: not a reader)
+        for (int c : gi.consumers[j5])
+            if (c != j5) {
+                jf = c;
+                ++nread;
+            }
+        if (nread != 1 || (gi.node(j5)->flags & GGML_TENSOR_FLAG_OUTPUT) || gi.node(jf)->op != GGML_OP_FLASH_ATTN_EXT || !planner_supports_op(gi.node(jf))) continue;
         const ggml_tensor* f = gi.node(jf);
         if (!((f->src[1] == gi.node(j5)) != (f->src[2] == gi.node(j5))) || f->src[0] == gi.node(j5)) continue;  // exactly one of K, V
         const ggml_tensor* r4 = gi.node(j1);
