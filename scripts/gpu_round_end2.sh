@@ -11,6 +11,7 @@ python scripts/rocpd_stats.py $D/stats_results.db $D/kernel_stats.csv | head -14
 for c in FETCH_SIZE WRITE_SIZE; do
   ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --pmc $c --kernel-include-regex "k_gemm16|k_nchw_to_nhwc|k_layer_norm_f16|k_gn_stats|k_fgemv" -d $R/$D -o pmc_$c -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-sdxl --no-e2e --no-kernels > /dev/null 2> $R/$D/pmc_$c.log )
 done
+python scripts/pmc_traffic.py $D/pmc_FETCH_SIZE_results.db $D/pmc_WRITE_SIZE_results.db "k_gemm16<256, %, true" $D/pmc_traffic_conv256.json | grep -E "hbm_bytes|launches"
 python scripts/pmc_traffic.py $D/pmc_FETCH_SIZE_results.db $D/pmc_WRITE_SIZE_results.db "k_gemm16<256, 320, true" $D/pmc_traffic_t320_conv.json | grep -E "hbm_bytes|launches"
 python scripts/pmc_traffic.py $D/pmc_FETCH_SIZE_results.db $D/pmc_WRITE_SIZE_results.db "k_nchw_to_nhwc_f16" $D/pmc_traffic_nchw_to_nhwc.json | grep -E "hbm_bytes|launches"
 python scripts/pmc_traffic.py $D/pmc_FETCH_SIZE_results.db $D/pmc_WRITE_SIZE_results.db "k_layer_norm_f16" $D/pmc_traffic_layer_norm_f16.json | grep -E "hbm_bytes|launches"
