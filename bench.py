@@ -201,7 +201,7 @@ def main():
             try:
                 pm = json.loads(tf.read_text())
                 roofline["traffic"] = pm["hbm_bytes_per_launch"]
-                roofline["traffic_source"] = "profiles/r02_pmc_traffic.json (k_gemm16<256, 320, true, ...>, the 256x320 pipelined conv tile): " + pm.get("source", "")
+                roofline["traffic_source"] = "profiles/r02_pmc_traffic.json (kernels matching '" + pm.get("kernel", "") + "': the 256-row conv instantiations): " + pm.get("source", "")
             except (ValueError, KeyError):
                 pass
     roofline["whole_step_tflops"] = round(step_tflops, 2)  # all kernels + host graph build + uploads: 2*B*UNet-forward FLOPs / step wall time
