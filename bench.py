@@ -263,7 +263,8 @@ def main():
         out["cpu_baseline"] = cpu_baseline(sd, args, lat, ctx_dim)
     if rank == 0:
         st = sd.backend_stats()
-        out["backend"] = {k: st[k] for k in ("swizzled_weight_bytes", "qgemv_linears", "split_k_gemms", "fused_attention", "generic_matmul", "plans_built", "graph_replays")}
+        out["backend"] = {k: st[k] for k in ("swizzled_weight_bytes", "qgemv_linears", "fgemv_linears", "fused_presilu", "fused_sibling_linears", "hoisted_kv_linears",
+                                             "qgemm16_linears", "split_k_gemms", "fused_attention", "generic_matmul", "plans_built", "graph_replays")}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
