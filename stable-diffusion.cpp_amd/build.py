@@ -38,6 +38,8 @@ HIP_FLAGS = ["-std=c++17", "-O3", "-fPIC", "-fvisibility=hidden", f"--offload-ar
              f"-I{CSRC / 'backend'}", f"-I{CSRC / 'kernels'}", "-D__HIP_PLATFORM_AMD__"]
 if VARIANT == "exp":
     HIP_FLAGS.append("-DMI355X_EXPERIMENTS")
+if VARIANT.startswith("occ"):  # A/B: flash attention (d <= 64) compiled for occ4 / occ5 waves per SIMD (flash_attn.hip FA_OCC_SMALL)
+    HIP_FLAGS.append("-DFA_OCC_SMALL=" + VARIANT[3:4])
 ORACLE_FLAGS = ["-std=c++17", "-O3", "-fPIC", "-fvisibility=hidden", "-fopenmp", "-mavx2", "-mfma", "-mf16c",
                 "-Wall", f"-I{INCLUDE}"]
 

@@ -52,8 +52,18 @@ struct FAArgs {
 // MSLOT (d = 40 on the 48-wide tile, FAST): the running max rides in the first padded k-slot — Q[q][40] = -m_run[q], K[key][40] = 1 — so the MFMA
 // delivers scores already relative to the max and the 32 v_sub per lane per tile disappear from the VALU-bound loop (m_run is kept
 // f16-representable; any consistent offset is a valid softmax shift because numerator and row sum use the same P)
+// Waves per SIMD the register allocator aims for at head dims <= 64 (the second __launch_bounds__ argument is waves per SIMD, and it is what
+// decides the residency: with 3 the compiler spends 160 VGPRs and three workgroups share a CU — measured SQ_WAVE_CYCLES / SIMD cycles = 2.67, the
+// 16 workgroups per CU of the L = 4096 launch run as 3+3+3+3+3+1 — although the 31.7 KB of LDS would admit five).  Compiled for 4 the kernel
+// spills ~25 registers into the tile loop and is 20-27 % SLOWER (5.6-6.1 vs 4.6-4.8 ms per SD1.5 forward); running the softmax over two 32-key
+// halves (16 live score registers instead of 32) did not remove the spills and changed nothing at 3 (profiles/r03e_flash_occupancy.txt).
+// Getting to 4 waves per SIMD needs a hand-made register budget (index arrays recomputed per tile, V fragments not hoisted), not a flag.
+#ifndef FA_OCC_SMALL
+#define FA_OCC_SMALL 3
+#endif
+
 template <int DKP, int NDV, bool FAST, int ABL = 0, bool MSLOT = false>
-__global__ __launch_bounds__(256, DKP <= 64 ? 3 : (DKP <= 128 ? 2 : 1)) void k_flash_attn(FAArgs g) {
+__global__ __launch_bounds__(256, DKP <= 64 ? FA_OCC_SMALL : (DKP <= 128 ? 2 : 1)) void k_flash_attn(FAArgs g) {
     constexpr int KS   = DKP / 16;                       // MFMA k-steps over the head dim
     constexpr int KROW = DKP + 8;                        // K tile row stride (halfs)
     constexpr int DCH  = DKP / 8;                        // 8-wide d chunks per key
