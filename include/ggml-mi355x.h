@@ -107,8 +107,8 @@ GGML_MI355X_API int ggml_backend_mi355x_get_kernel_timings(struct ggml_backend_m
  * "splitk_mid" (0: two K slices for launches of 193..384 workgroups), "pinned_uploads" (0: set_tensor_async stages through pinned host memory so the call does
  * not wait for the stream);
  * few-row / quantised Linears: "fgemv" (1: f16 / f32 weights under <= 16 rows on the one-launch weight-streaming kernel, SiLU in front of it applied on
- * load), "fgemv_max_rows" (16), "qgemv" (1) / "qgemv_max_rows" (4, <= 16: raw q8_0 / q4_0 blocks streamed up to that many rows), "qgemm16_max_rows" (0:
- * raw-block MFMA GEMM for 17 .. n rows — the resident-quantised mode; the f16-image GEMM measured faster), "qgemm16" (1);
+ * load), "fgemv_max_rows" (16), "qgemv" (1) / "qgemv_max_rows" (4, <= 16: raw q8_0 / q4_0 blocks streamed up to that many rows), "qgemm16_max_rows" (512:
+ * raw-block MFMA GEMM up to n rows; 8192 = the resident-quantised mode, no f16 image for any quantised Linear), "qgemm16" (1);
  * launch grouping: "fuse_siblings" (1: q / k / v projections of one attention as one multi-weight launch), "hoist_kv" (1: cross-attention K / V
  * projections of all blocks grouped ahead of their graph position, results in the arena); "fuse_q16", "fuse_chan_add", "fuse_proj_tokens" (1);
  * "splitk_inkernel" (0: split-K combined by the last-arriving workgroup, 128-row tiles; measured slower) / "splitk_in_target" (320).

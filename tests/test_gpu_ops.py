@@ -282,19 +282,19 @@ def test_quantised_gemv_raw_blocks(sd, oracle, gpu, rng, wtype, tol, tokens, K, 
 
 @pytest.fixture()
 def qgemm16_on(sd):
-    """k_qgemm16 is selectable, not the default (the f16-image GEMM measured faster from 17 rows up, profiles/r02r_qgemm16_probe.txt)"""
+    """k_qgemm16 up to 512 rows (the default; set explicitly so the test does not depend on it)"""
     if _on_gpu():
         sd.backend_set_option("qgemm16_max_rows", 512)
     yield
     if _on_gpu():
-        sd.backend_set_option("qgemm16_max_rows", 0)
+        sd.backend_set_option("qgemm16_max_rows", 512)
 
 
 @pytest.mark.parametrize("wtype,tol", [(Q8_0, 1e-2), (Q4_0, 3e-2)])
 @pytest.mark.parametrize("tokens,K,M,res", [(17, 768, 96, False), (33, 256, 100, True), (77, 768, 320, False), (64, 1024, 640, True), (130, 3072, 1152, True),
                                             (300, 1280, 320, False), (512, 4096, 200, False), (257, 12288, 128, True), (600, 768, 96, False)])
 def test_quantised_mfma_gemm_raw_blocks(sd, oracle, gpu, rng, qgemm16_on, wtype, tol, tokens, K, M, res):
-    """q8_0 / q4_0 Linear under 17 .. 512 activation rows (text-stream Linears of the DiTs, text encoders) with option qgemm16_max_rows = 512:
+    """q8_0 / q4_0 Linear under 17 .. 512 activation rows (text-stream Linears of the DiTs, text encoders; option qgemm16_max_rows = 512, the default):
     k_qgemm16 streams the RAW GGUF blocks, dequantises them in registers into MFMA B fragments (f16(d * q), bit-identical to what the f16
     weight image would hold) and never builds that image.  Bars as for test_linear_weight_gemm; against the same Linear on the f16-image GEMM
     only the f32 summation order differs.  600 rows: above qgemm16_max_rows, stays on the image path."""
