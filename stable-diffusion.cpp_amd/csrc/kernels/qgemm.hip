@@ -651,8 +651,8 @@ __global__ __launch_bounds__(256) void k_qgemm16(QG16Args g) {
 // option "qgemm16_max_rows": Linears with 5 .. max_rows activation rows take k_qgemm16 (0 = never).  Default 512 = the text streams of the DiTs and the
 // text encoders.  Two measurements decide it: (1) the single-Linear probe with L2-warm weights (profiles/r02s_qgemm_paths_probe.txt) has the f16-image
 // GEMM 1.3-2.3x faster kernel-for-kernel (3072 -> 9216 q8_0 at 77 rows 48 vs 21 us, at 256 rows 68 vs 32 us); (2) inside FLUX.1-dev, where every
-// layer's weights arrive cold from HBM, the 152 text-stream Linears on raw q4_0 blocks cost nothing (127.8 vs 128.9 ms per step) and take 4.3 GB of
-// f16 images out of HBM (17.2 -> 12.9 GB; profiles/r03g_flux_resident_quantised.txt).  The 4096-token image stream stays on the f16 image: with
+// layer's weights arrive cold from HBM, the 152 text-stream Linears on raw q4_0 blocks cost 0.3 % of the step (125.1 / 125.0 vs 124.5 / 124.8 ms,
+// alternating runs on one box) and take 4.3 GB of f16 images out of HBM (17.2 -> 12.9 GB; profiles/r03g_flux_resident_quantised.txt).  The 4096-token image stream stays on the f16 image: with
 // qgemm16_max_rows = 8192 the step takes 167 ms (+30 %) for 26 MB of images instead of 12.9 GB — the resident-quantised mode, selectable.
 static int g_qg16_max_rows = 512;
 void qgemm16_set_max_rows(int v) { g_qg16_max_rows = v; }
