@@ -23,7 +23,9 @@ namespace sdmi {
 
 // dtypes the safetensors format names that ggml has no element type for: decoded to f32 at load time (the reference widens them the
 // same way before its own convert step — F8 -> F16, F64 -> F32, I64 -> I32: src/model_io/safetensors_io.cpp:79-99, src/model_loader.cpp:81-153)
-enum class SrcKind { NATIVE, F64, I64, F8_E4M3, F8_E5M2 };
+// Q4_1 / Q5_0 / Q5_1: GGUF block quantisations the graph never computes in (the engine's parameter types are f32 / f16 / bf16 / q8_0 / q4_0); they are
+// decoded to f32 at load time and re-encoded in the parameter's type, like convert_tensor does for every source type (src/model_loader.cpp:155-205)
+enum class SrcKind { NATIVE, F64, I64, F8_E4M3, F8_E5M2, Q4_1, Q5_0, Q5_1 };
 
 struct FileTensor {
     std::string name;
@@ -175,6 +177,47 @@ inline void decode_src_kind(SrcKind kind, const uint8_t* raw, int64_t n, float* 
         case SrcKind::F8_E5M2:
             for (int64_t i = 0; i < n; ++i) dst[i] = f8_e5m2_to_f32(raw[i]);
             break;
+        // ggml block layouts (32 weights per block; byte j of qs holds element j in its low and element j + 16 in its high nibble):
+        //   q4_1 {f16 d, f16 m, u8 qs[16]}            x = q * d + m
+        //   q5_0 {f16 d, u8 qh[4], u8 qs[16]}         x = ((q | bit5 << 4) - 16) * d, bit5 of element j = bit j of the little-endian u32 qh
+        //   q5_1 {f16 d, f16 m, u8 qh[4], u8 qs[16]}  x = (q | bit5 << 4) * d + m
+        case SrcKind::Q4_1:
+        case SrcKind::Q5_0:
+        case SrcKind::Q5_1: {
+            const int bs = kind == SrcKind::Q4_1 ? 20 : (kind == SrcKind::Q5_0 ? 22 : 24);
+            for (int64_t b = 0; b < n / 32; ++b) {
+                const uint8_t* p = raw + b * bs;
+                ggml_fp16_t dh, mh = 0;
+                memcpy(&dh, p, 2);
+                p += 2;
+                if (kind != SrcKind::Q5_0) {
+                    memcpy(&mh, p, 2);
+                    p += 2;
+                }
+                const float d = ggml_fp16_to_fp32(dh), m = kind != SrcKind::Q5_0 ? ggml_fp16_to_fp32(mh) : 0.f;
+                uint32_t qh = 0;
+                if (kind != SrcKind::Q4_1) {
+                    memcpy(&qh, p, 4);
+                    p += 4;
+                }
+                float* y = dst + b * 32;
+                for (int j = 0; j < 16; ++j) {
+                    int x0 = p[j] & 0x0F, x1 = p[j] >> 4;
+                    if (kind != SrcKind::Q4_1) {
+                        x0 |= (int)((qh >> j) & 1u) << 4;
+                        x1 |= (int)((qh >> (j + 16)) & 1u) << 4;
+                    }
+                    if (kind == SrcKind::Q5_0) {
+                        y[j]      = (float)(x0 - 16) * d;
+                        y[j + 16] = (float)(x1 - 16) * d;
+                    } else {
+                        y[j]      = (float)x0 * d + m;
+                        y[j + 16] = (float)x1 * d + m;
+                    }
+                }
+            }
+            break;
+        }
         default: break;
     }
 }
@@ -386,8 +429,29 @@ inline bool read_gguf(const std::string& path, ModelFile& mf) {
     fclose(f);
     std::vector<FileTensor> keep;
     for (auto& t : mf.tensors) {
+        const int ty = (int)t.type;  // ggml type ids: 3 = q4_1, 6 = q5_0, 7 = q5_1
+        if (ty == 3 || ty == 6 || ty == 7) {
+            const uint64_t bs = ty == 3 ? 20 : (ty == 6 ? 22 : 24);
+            uint64_t n        = 1;
+            bool dims_ok      = t.ne[0] > 0 && t.ne[0] % 32 == 0 && t.ne[0] < (1ll << 40);
+            for (int d = 0; d < 4 && dims_ok; ++d) {
+                dims_ok = t.ne[d] > 0 && n <= (1ull << 46) / (uint64_t)t.ne[d];
+                n *= (uint64_t)t.ne[d];
+            }
+            const uint64_t nb = dims_ok ? n / 32 * bs : 0;
+            if (!dims_ok || t.offset > fsize || data0 > fsize - t.offset || nb > fsize - t.offset - data0) {
+                mf.error = "tensor '" + t.name + "' has invalid dimensions or lies outside the file";
+                return false;
+            }
+            t.kind   = ty == 3 ? SrcKind::Q4_1 : (ty == 6 ? SrcKind::Q5_0 : SrcKind::Q5_1);
+            t.type   = GGML_TYPE_F32;  // what decode_src_kind delivers
+            t.nbytes = nb;
+            t.offset += data0;
+            keep.push_back(t);
+            continue;
+        }
         const bool known = t.type == GGML_TYPE_F32 || t.type == GGML_TYPE_F16 || t.type == GGML_TYPE_BF16 || t.type == GGML_TYPE_Q8_0 || t.type == GGML_TYPE_Q4_0;
-        if (!known) {  // other quantisations (Q4_1, Q5_x, K-quants ...): not decodable by this build — an ERROR if a declared parameter needs one
+        if (!known) {  // K-quants, IQ types, integer tensors: not decodable by this build — an ERROR if a declared parameter needs one
             mf.undecodable[t.name] = "ggml type " + std::to_string((int)t.type);
             continue;
         }

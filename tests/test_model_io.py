@@ -145,6 +145,71 @@ def test_gguf_load_f16_f32_q8_0(sd, oracle, tmp_path):
         np.testing.assert_allclose(got, val, rtol=0, atol=1e-7, err_msg=n)
 
 
+def _q4_1_q5_blocks(a, kind):
+    """Encoder for the test: f32 [n] (n % 32 == 0) -> raw q4_1 / q5_0 / q5_1 blocks (public ggml block layouts) and the values they decode to.
+    q4_1 {f16 d, f16 m, qs[16]}, q5_0 {f16 d, qh[4], qs[16]}, q5_1 {f16 d, f16 m, qh[4], qs[16]}; byte j of qs = element j (low nibble) and
+    j + 16 (high nibble); bit j of the little-endian u32 qh = fifth bit of element j."""
+    x = a.reshape(-1, 32).astype(np.float32)
+    levels = 15 if kind == "q4_1" else 31
+    raw, vals = b"", []
+    for row in x:
+        if kind == "q5_0":
+            amax = float(np.abs(row).max())
+            d = np.float16(amax / 15.0 if amax > 0 else 1.0)
+            q = np.clip(np.round(row / np.float32(d)) + 16, 0, 31).astype(np.int64)
+            dec = (q - 16).astype(np.float32) * np.float32(d)
+            head = np.array([d], np.float16).tobytes()
+        else:
+            lo, hi = float(row.min()), float(row.max())
+            d = np.float16((hi - lo) / levels if hi > lo else 1.0)
+            m = np.float16(lo)
+            q = np.clip(np.round((row - np.float32(m)) / np.float32(d)), 0, levels).astype(np.int64)
+            dec = q.astype(np.float32) * np.float32(d) + np.float32(m)
+            head = np.array([d, m], np.float16).tobytes()
+        qs = ((q[:16] & 0xF) | ((q[16:] & 0xF) << 4)).astype(np.uint8).tobytes()
+        qh = b""
+        if kind != "q4_1":
+            bits = sum(int((q[j] >> 4) & 1) << j for j in range(32))
+            qh = struct.pack("<I", bits)
+        raw += head + qh + qs
+        vals.append(dec)
+    return raw, np.concatenate(vals)
+
+
+@pytest.mark.parametrize("kind,gtype", [("q4_1", 3), ("q5_0", 6), ("q5_1", 7)])
+def test_gguf_q4_1_q5_blocks_are_decoded_at_load(sd, oracle, tmp_path, kind, gtype):
+    """GGUF checkpoints of the reference's users are often q4_1 / q5_0 / q5_1: the graph never computes in those types, the loader decodes them to
+    f32 and re-encodes in the parameter's type like the reference's convert_tensor (src/model_loader.cpp:155-205)."""
+    e = sd.Engine(model=sd.SD15_TINY, backend=oracle, wtype=sd.F16)
+    rng = np.random.default_rng(gtype)
+    names = ["model.diffusion_model.input_blocks.1.1.transformer_blocks.0.attn1.to_q.weight", "model.diffusion_model.time_embed.0.weight"]
+    tensors, want = [], {}
+    for n in names:
+        ne, pty, _ = e.tensor_info(n)
+        ne = [int(d) for d in ne]
+        while len(ne) > 1 and ne[-1] == 1:
+            ne = ne[:-1]
+        assert ne[0] % 32 == 0
+        a = (rng.standard_normal(int(np.prod(ne))) * 0.1).astype(np.float32)
+        raw, val = _q4_1_q5_blocks(a, kind)
+        tensors.append((n, gtype, ne, raw))
+        want[n] = (val, pty)
+    p = tmp_path / f"tiny_{kind}.gguf"
+    _write_gguf(p, tensors)
+    r = e.load_weights(p)
+    assert r["loaded"] == len(names) and r["unused"] == 0
+    for n, (val, pty) in want.items():
+        got = e.get_tensor(n).ravel()
+        if pty == sd.F16:
+            val = val.astype(np.float16).astype(np.float32)
+        np.testing.assert_allclose(got, val, rtol=0, atol=1e-7, err_msg=n)
+    # a truncated block stream is rejected, not over-read
+    bad = tmp_path / f"bad_{kind}.gguf"
+    _write_gguf(bad, [(names[0], gtype, [64, 1 << 30], b"\0" * 44)])
+    with pytest.raises(RuntimeError):
+        e.load_weights(bad)
+
+
 def test_bad_files_are_rejected(sd, oracle, tmp_path):
     e = sd.Engine(model=sd.SD15_TINY, backend=oracle)
     p = tmp_path / "junk.bin"
