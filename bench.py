@@ -24,8 +24,9 @@ The JSON line also carries
                 (events around ~800 launches per step would perturb the headline): contraction families against the MFMA peak,
                 layout / norm / elementwise families as algorithmic bytes (one read + one write of the activation) / time against
                 8 TB/s, each with its share of the step's kernel time.
-  sdxl:         the other model the metric names — SDXL UNet 1024x1024, q8_0 Linear + f16 conv, batch 1 per GPU (config 3's per-GPU
-                share), a few steps after the timed region: ms/step, it/s, whole-step fraction of the MFMA peak.
+  sdxl / flux / sd35: the other workloads BASELINE.json names (configs 3, 4, 5) on this GPU's share of each configuration, a few device-resident
+                sampler steps after the timed region: ms/step, it/s, whole-step fraction of the MFMA peak, the three heaviest kernel
+                families; sdxl also times the 1024x1024 VAE decode, so its sec_per_image is end to end (30 steps + decode).
   cpu_baseline: the CPU oracle (restatement of the reference ggml-cpu path) timed on this box's host cores on a bounded
                 sample of the same workload (rank 0, N = 1 only).
 """
@@ -48,6 +49,7 @@ if (os.cpu_count() or 1) > 32:
 
 # algorithmic work per unit: 2*M*N*K per Linear / conv, 4*Lq*Lk*H*d per attention
 UNET_FWD_TFLOP = {"sd15": 0.803, "sdxl": 6.761, "sd35": 29.60, "flux": 69.47}
+VAE_DECODE_TFLOP_1024 = 10.47  # KL-VAE decode 128x128 -> 1024x1024
 MFMA_PEAK_TFLOPS = 2500.0
 HBM_PEAK_GBS = 8000.0
 
@@ -74,12 +76,14 @@ def parse():
                     help="time K host-driven cond+uncond forward pairs (x up / eps down per step, the reference's boundary) instead of the "
                          "device-resident trajectory")
     ap.add_argument("--no-sdxl", action="store_true", help="skip the SDXL 1024x1024 sub-record")
+    ap.add_argument("--skip-legs", default="", help="comma list of sub-records to skip: sdxl,flux,sd35")
     ap.add_argument("--no-kernels", action="store_true", help="skip the per-kernel-family pass")
     return ap.parse_args()
 
 
 def main():
     args = parse()
+    args.skip_legs = set(filter(None, args.skip_legs.split(",")))
     args.device_sampler = not args.host_loop
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -254,11 +258,14 @@ def main():
         hl = (time.perf_counter() - t0) / 5
         out["host_loop"] = {"ms_per_step": round(hl * 1e3, 3), "it_per_s": round(B / hl, 2),
                             "note": "cond+uncond forward pair per step from host buffers (x H2D, eps D2H each step); CFG / Euler math on the host is outside this step"}
-    if rank == 0 and world == 1 and args.model == "sd15" and not args.no_sdxl:
-        try:
-            out["sdxl"] = sdxl_leg(sd, backend_name, args)
-        except Exception as exc:
-            out["sdxl"] = {"error": str(exc)[:200]}
+    if rank == 0 and world == 1 and args.model == "sd15":
+        for leg in ("sdxl", "flux", "sd35"):
+            if leg in args.skip_legs or (leg == "sdxl" and args.no_sdxl):
+                continue
+            try:
+                out[leg] = model_leg(sd, backend_name, args, leg)
+            except Exception as exc:
+                out[leg] = {"error": str(exc)[:200]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not dit:  # the CPU leg is defined for the headline UNet workloads
         out["cpu_baseline"] = cpu_baseline(sd, args, lat, ctx_dim)
     if rank == 0:
@@ -300,34 +307,107 @@ def kernel_families(sd, trajectory, step):
     return rows
 
 
-def sdxl_leg(sd, backend_name, args):
-    """SDXL UNet 1024x1024 (latent 128x128), q8_0 Linear + f16 conv weights, batch 1 per GPU, cond+uncond in one graph, device-resident
-    Euler-A steps (the 30-step convention of BASELINE.json config 3; a few steps are timed).  6.761 TFLOP per forward."""
+LEGS = {
+    # name: (model attr, weight type attr, latent, ctx tokens, ctx dim, y dim, latent channels, per-GPU batch, timed steps, sampler steps of the config, cfg, forwards per step)
+    "sdxl": ("SDXL", "Q8_0", 128, 77, 2048, 2816, 4, 1, 6, 30, 7.0, 2),       # config 3: batch 8 over 8 GPUs -> 1 image per GPU
+    "flux": ("FLUX_DEV", "Q4_0", 128, 256, 4096, 768, 16, 1, 3, 28, 1.0, 1),   # config 4: one GPU, cfg 1 (distilled guidance 3.5)
+    "sd35": ("SD35_LARGE", "BF16", 128, 154, 4096, 2048, 16, 2, 2, 28, 7.0, 2),  # config 5: batch 16 over 8 GPUs -> 2 images per GPU
+}
+
+
+def model_leg(sd, backend_name, args, name):
+    """The other workloads BASELINE.json names, on this GPU's share of the configuration, a few device-resident sampler steps after the timed
+    region (bounded: the default bench run must finish in minutes):
+      sdxl  SDXL UNet 1024x1024, q8_0 Linear + f16 conv, cfg 7 (cond+uncond in one graph), batch 1, Euler-A; plus the 1024x1024 VAE decode, so
+            that sec_per_image is the true end-to-end figure (30 steps + decode);
+      flux  FLUX.1-dev 1024x1024 (4096 + 256 tokens), q4_0, cfg 1, batch 1, Euler;
+      sd35  SD3.5-large 1024x1024 (4096 + 154 tokens), bf16, cfg 7, batch 2, Euler.
+    Each carries ms_per_step, it/s, the whole-step fraction of the MFMA peak and its three heaviest kernel families (HIP events)."""
     import torch
 
+    mattr, wattr, lat, ntok, cdim, ydim, ch, B, k, cfg_steps, cfg, nfwd = LEGS[name]
+    dit = name != "sdxl"
     t_init = time.perf_counter()
-    eng = sd.Engine(model=sd.SDXL, backend=backend_name, wtype=sd.Q8_0, flash_attn=not args.no_flash)
+    eng = sd.Engine(model=getattr(sd, mattr), backend=backend_name, wtype=getattr(sd, wattr), flash_attn=not args.no_flash)
     init_s = time.perf_counter() - t_init
     rng = np.random.default_rng(99)
-    cond = rng.standard_normal((1, 77, 2048)).astype(np.float32)
-    uncond = rng.standard_normal((1, 77, 2048)).astype(np.float32)
-    y = rng.standard_normal((1, 2816)).astype(np.float32)
-    kw = dict(width=1024, height=1024, cfg=7.0, seed=42, batch=1, device_batch=1, method=sd.EULER_A, cond_y=y, uncond_y=y, fuse_cfg=True, device_sampler=True)
-    eng.sample_latents(cond, uncond, steps=2, **kw)   # builds weight images + plan
+    cond = rng.standard_normal((1, ntok, cdim)).astype(np.float32)
+    uncond = rng.standard_normal((1, ntok, cdim)).astype(np.float32)
+    y = rng.standard_normal((1, ydim)).astype(np.float32)
+    kw = dict(width=lat * 8, height=lat * 8, cfg=cfg, seed=42, batch=B, device_batch=B, method=sd.EULER if dit else sd.EULER_A, cond_y=y, uncond_y=y,
+              fuse_cfg=True, device_sampler=True)
+    unc = None if nfwd == 1 else uncond
+    st0 = sd.backend_stats()
+    eng.sample_latents(cond, unc, steps=1, **kw)   # builds weight images + plan
     torch.cuda.synchronize()
-    k = 6
     t0 = time.perf_counter()
-    eng.sample_latents(cond, uncond, steps=k, **kw)
+    eng.sample_latents(cond, unc, steps=k, **kw)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / k * 1e3
-    tfl = 2 * UNET_FWD_TFLOP["sdxl"] / (ms / 1e3)
-    st = sd.backend_stats()
-    res = {"workload": "sdxl UNet 1024x1024, cfg 7 (cond+uncond in one graph), q8_0 Linear + f16 conv weights, batch 1/GPU, Euler-A step, device-resident",
-           "steps_timed": k, "ms_per_step": round(ms, 2), "it_per_s": round(1e3 / ms, 3), "sec_per_image_30_steps_denoise": round(30 * ms / 1e3, 3),
-           "whole_step_tflops": round(tfl, 1), "whole_step_frac": round(tfl / MFMA_PEAK_TFLOPS, 4), "engine_init_s": round(init_s, 1),
-           "swizzled_weight_bytes_total": st.get("swizzled_weight_bytes")}
+    tfl = nfwd * B * UNET_FWD_TFLOP[name] / (ms / 1e3)
+    res = {"workload": f"{name} 1024x1024, {'cfg 1 (one forward per step)' if nfwd == 1 else 'cfg 7 (cond+uncond in one graph)'}, {wattr.lower()} Linear weights, "
+                       f"batch {B}/GPU, {'Euler' if dit else 'Euler-A'} step, device-resident",
+           "steps_timed": k, "ms_per_step": round(ms, 2), "it_per_s": round(B * 1e3 / ms, 3), "whole_step_tflops": round(tfl, 1),
+           "whole_step_frac": round(tfl / MFMA_PEAK_TFLOPS, 4), "engine_init_s": round(init_s, 1)}
+    if not args.no_kernels:
+        sd.kernel_timing_enable(sd.KF_ALL)
+        eng.sample_latents(cond, unc, steps=1, **kw)
+        fams = sd.kernel_timings()
+        sd.kernel_timing_enable(0)
+        tot = sum(f["total_ms"] for f in fams) or 1.0
+        top = []
+        for f in sorted(fams, key=lambda f: -f["total_ms"])[:3]:
+            sec = f["total_ms"] * 1e-3
+            mf = f["bound"] == "mfma"
+            ach = (f["total_flops"] / sec / 1e12) if mf else (f["total_bytes"] / sec / 1e9)
+            top.append({"name": f["kernel"], "bound": f["bound"], "launches_per_step": f["launches"], "ms_per_step": round(f["total_ms"], 3),
+                        "share_of_step_time": round(f["total_ms"] / tot, 4), "achieved": round(ach, 1), "unit": "TFLOP/s" if mf else "GB/s",
+                        "frac": round(ach / (MFMA_PEAK_TFLOPS if mf else HBM_PEAK_GBS), 4)})
+        res["kernels"] = top
+        res["kernel_ms_per_step"] = round(tot, 2)
+    if name == "sdxl":   # the end-to-end half of the metric: 30 sampler steps + the 128x128 -> 1024x1024 VAE decode (10.47 TFLOP)
+        z = rng.standard_normal((B, ch, lat, lat)).astype(np.float32)
+        eng.vae_decode(z)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.vae_decode(z)
+        torch.cuda.synchronize()
+        dec = (time.perf_counter() - t0) * 1e3
+        res["vae_decode_ms"] = round(dec, 1)
+        res["vae_decode_frac"] = round(VAE_DECODE_TFLOP_1024 * B / (dec / 1e3) / MFMA_PEAK_TFLOPS, 4)
+        res["sec_per_image"] = round((cfg_steps * ms + dec) / 1e3 / B, 3)
+        res["sec_per_image_note"] = f"{cfg_steps} sampler steps x ms_per_step + VAE decode (host pixel conversion excluded), per image"
+    else:
+        res["sec_per_image_denoise"] = round(cfg_steps * ms / 1e3 / B, 3)
+    st1 = sd.backend_stats()
+    res["weight_image_bytes"] = st1["swizzled_weight_bytes"] - st0["swizzled_weight_bytes"]
     del eng
     return res
+
+
+def host_cpu_info():
+    """CPU model and core counts of the box ("core count stated"): /proc/cpuinfo, no subprocess needed."""
+    info = {"logical_cpus": os.cpu_count()}
+    try:
+        model, phys = None, set()
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model is None:
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                pid = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                cid = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if pid is not None and cid is not None:
+                    phys.add((pid, cid))
+                pid = cid = None
+        info["model"] = model
+        info["physical_cores"] = len(phys) or None
+        info["schedulable_cpus"] = len(os.sched_getaffinity(0))
+    except OSError:
+        pass
+    return info
 
 
 def cpu_baseline(sd, args, lat, ctx_dim):
@@ -339,6 +419,7 @@ def cpu_baseline(sd, args, lat, ctx_dim):
     sd.load_backend(oracle_so)
     olib = C.CDLL(str(oracle_so))
     cores = int(olib.oracle_num_threads())
+    host = host_cpu_info()
     model_id = {"sd15": sd.SD15, "sdxl": sd.SDXL, "sd15_tiny": sd.SD15_TINY, "sd35": sd.SD35_LARGE, "sd35_tiny": sd.SD35_TINY}[args.model]
     eng = sd.Engine(model=model_id, backend="CPU-oracle", wtype=sd.Q8_0 if args.model == "sdxl" else sd.F16, flash_attn=False)
     rng = np.random.default_rng(7)
@@ -355,7 +436,7 @@ def cpu_baseline(sd, args, lat, ctx_dim):
         if el > args.cpu_baseline_seconds or n >= 8:
             break
     fwd_s = el / n
-    return {"value": round(1.0 / (2 * fwd_s), 5), "unit": "it/s", "cores": cores, "kind": "port",
+    return {"value": round(1.0 / (2 * fwd_s), 5), "unit": "it/s", "cores": cores, "kind": "port", "host": host,
             "sample": f"{n} UNet forward(s) of 1 image ({args.model}, latent {lat}x{lat}) in {el:.1f}s; one it = 2 forwards (cfg 7)",
             "sec_per_forward": round(fwd_s, 3)}
 

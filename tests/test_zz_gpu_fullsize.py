@@ -245,23 +245,27 @@ def test_full_width_sd15_unet_vs_oracle(sd, oracle, gpu):
 
 
 @full
-def test_full_size_vae_decode_vs_oracle(sd, oracle, gpu):
-    """KL-VAE decode 64x64 -> 512x512 (auto_encoder_kl.hpp:444-492; mid attention 1 head x d 512 over 4096 positions)"""
+@pytest.mark.parametrize("lat", [64, 128])
+def test_full_size_vae_decode_vs_oracle(sd, oracle, gpu, lat):
+    """KL-VAE decode 64x64 -> 512x512 and 128x128 -> 1024x1024 (configs 3 / 5; auto_encoder_kl.hpp:444-492; mid attention 1 head x d 512 over
+    4096 / 16384 positions; 10.5 TFLOP and 537 MB feature maps at 1024x1024)"""
     rng = np.random.default_rng(502)
-    z = rng.standard_normal((1, 4, 64, 64)).astype(np.float32) * 0.18215 * 3
+    z = rng.standard_normal((1, 4, lat, lat)).astype(np.float32) * 0.18215 * 3
     ref = sd.Engine(model=sd.SD15, backend=oracle).vae_decode(z)
     out = sd.Engine(model=sd.SD15, backend=gpu).vae_decode(z)
-    assert out.shape == (1, 3, 512, 512) and np.isfinite(out).all()
+    assert out.shape == (1, 3, lat * 8, lat * 8) and np.isfinite(out).all()
     p = psnr(out, ref)
-    print(f"full-size VAE decode: PSNR vs oracle {p:.1f} dB, max abs diff {np.abs(out - ref).max():.2e}")
+    print(f"full-size VAE decode {lat * 8}x{lat * 8}: PSNR vs oracle {p:.1f} dB, max abs diff {np.abs(out - ref).max():.2e}")
     assert p > 35.0
 
 
 
 @full
-def test_full_width_sdxl_unet_q8_0_vs_oracle(sd, oracle, gpu):
+@pytest.mark.parametrize("lat", [128])
+def test_full_width_sdxl_unet_q8_0_vs_oracle(sd, oracle, gpu, lat):
     """SDXL UNet (unet.hpp:47-57: depth-2 / depth-10 transformers, Linear proj_in / proj_out, label_emb), q8_0 Linear weights + f16 conv
-    (BASELINE.json config 3), latent 64x64 (the oracle needs ~4x longer at 128x128; widths and depths are the real ones).
+    (BASELINE.json config 3) at the BENCHMARKED latent size 128x128 (1024x1024 pixels: 4096 / 1024 tokens per transformer level; rounds 1-2 ran
+    this test at 64x64 only).
 
     The oracle quantises the ACTIVATIONS of a q8_0 Linear to q8_0 blocks as ggml-cpu does; the GPU multiplies
     f16-rounded activations with the exactly dequantised weights.  Through 70 transformer blocks that activation-quantisation noise is
@@ -270,7 +274,7 @@ def test_full_width_sdxl_unet_q8_0_vs_oracle(sd, oracle, gpu):
     farther from the oracle's q8_0 path than that path is from the exact-weight one (+ 5e-3).  Attention reference = the oracle's
     exact-softmax chain (see the SD1.5 test)."""
     rng = np.random.default_rng(503)
-    x = rng.standard_normal((1, 4, 64, 64)).astype(np.float32)
+    x = rng.standard_normal((1, 4, lat, lat)).astype(np.float32)
     t = np.array([500.0], np.float32)
     c = rng.standard_normal((1, 77, 2048)).astype(np.float32)
     y = rng.standard_normal((1, 2816)).astype(np.float32)
@@ -290,18 +294,19 @@ def test_full_width_sdxl_unet_q8_0_vs_oracle(sd, oracle, gpu):
     for flash in (True, False):
         out = sd.Engine(model=sd.SDXL, backend=gpu, wtype=sd.Q8_0, flash_attn=flash).unet_forward(x, t, c, y)
         e_x, e_q = rel_l2(out, ref), rel_l2(out, ref_q8)
-        print(f"full-width SDXL UNet q8_0 flash={flash}: GPU vs oracle(dequantised weights) {e_x:.3e}, GPU vs oracle(q8_0 activations) {e_q:.3e}, "
+        print(f"full-width SDXL UNet q8_0 latent {lat} flash={flash}: GPU vs oracle(dequantised weights) {e_x:.3e}, GPU vs oracle(q8_0 activations) {e_q:.3e}, "
               f"oracle q8_0 vs oracle dequantised {spread:.3e}")
         assert np.isfinite(out).all() and e_x < 5e-3 and e_q < spread + 5e-3
 
 
 @full
-@pytest.mark.parametrize("wtype,tol", [("F16", 5e-3), ("BF16", 2e-2)])
-def test_real_width_sd35_joint_blocks_vs_oracle(sd, oracle, gpu, wtype, tol):
+@pytest.mark.parametrize("wtype,tol,lat", [("F16", 5e-3, 64), ("BF16", 2e-2, 64), ("BF16", 2e-2, 128)])
+def test_real_width_sd35_joint_blocks_vs_oracle(sd, oracle, gpu, wtype, tol, lat):
     """Two SD3.5-large joint blocks at the real width (hidden 2432, 38 heads x 64, rms qk-norm; the second block's context stream is
-    pre_only — mmdit.hpp:614-699, 803) between the real embedders and final layer: 1024 image + 154 context tokens."""
+    pre_only — mmdit.hpp:614-699, 803) between the real embedders and final layer: 1024 image + 154 context tokens, and (lat 128) the
+    BENCHMARKED sequence of config 5: 4096 image + 154 context tokens (flash attention over 4250 keys, d = 64, 38 heads)."""
     rng = np.random.default_rng(504)
-    x = rng.standard_normal((1, 16, 64, 64)).astype(np.float32)
+    x = rng.standard_normal((1, 16, lat, lat)).astype(np.float32)
     t = np.array([600.0], np.float32)
     c = rng.standard_normal((1, 154, 4096)).astype(np.float32)
     y = rng.standard_normal((1, 2048)).astype(np.float32)
@@ -309,19 +314,21 @@ def test_real_width_sd35_joint_blocks_vs_oracle(sd, oracle, gpu, wtype, tol):
     ref = sd.Engine(model=sd.SD35_WIDE2, backend=oracle, wtype=wt, flash_attn=False).unet_forward(x, t, c, y)   # exact-softmax chain
     out = sd.Engine(model=sd.SD35_WIDE2, backend=gpu, wtype=wt, flash_attn=True).unet_forward(x, t, c, y)
     err = rel_l2(out, ref)
-    print(f"real-width SD3.5 joint blocks {wtype}: rel-L2 vs oracle {err:.3e}")
+    print(f"real-width SD3.5 joint blocks {wtype} latent {lat}: rel-L2 vs oracle {err:.3e}")
     assert np.isfinite(out).all() and err < tol
 
 
 @full
-@pytest.mark.parametrize("wtype,tol", [("F16", 5e-3), ("Q4_0", 6e-2)])
-def test_real_width_flux_blocks_vs_oracle(sd, oracle, gpu, wtype, tol):
+@pytest.mark.parametrize("wtype,tol,lat,ntxt", [("F16", 5e-3, 64, 77), ("Q4_0", 6e-2, 64, 77), ("Q4_0", 6e-2, 128, 256)])
+def test_real_width_flux_blocks_vs_oracle(sd, oracle, gpu, wtype, tol, lat, ntxt):
     """One FLUX.1-dev double-stream and one single-stream block at the real width (hidden 3072, 24 heads x 128, RoPE axes 16/56/56,
-    fused qkv+mlp linear1 3072 -> 21504; flux.hpp:430-700): 1024 image + 77 text tokens (a ragged key count for the d = 128 attention)."""
+    fused qkv+mlp linear1 3072 -> 21504; flux.hpp:430-700): 1024 image + 77 text tokens (a ragged key count for the d = 128 attention), and
+    (lat 128, 256 text tokens) the BENCHMARKED sequence of config 4: 4096 + 256 tokens — flash attention d = 128 over 4352 keys, the rotary kernel on
+    4352 positions, 4352 x 3072 -> 21504 and 15360 -> 3072 GEMMs on q4_0 weights."""
     rng = np.random.default_rng(505)
-    x = rng.standard_normal((1, 16, 64, 64)).astype(np.float32)
+    x = rng.standard_normal((1, 16, lat, lat)).astype(np.float32)
     t = np.array([0.62], np.float32)
-    c = rng.standard_normal((1, 77, 4096)).astype(np.float32)
+    c = rng.standard_normal((1, ntxt, 4096)).astype(np.float32)
     y = rng.standard_normal((1, 768)).astype(np.float32)
     wt = getattr(sd, wtype)
     ref = sd.Engine(model=sd.FLUX_WIDE1, backend=oracle, wtype=wt, flash_attn=False).unet_forward(x, t, c, y)   # exact-softmax chain
@@ -330,7 +337,7 @@ def test_real_width_flux_blocks_vs_oracle(sd, oracle, gpu, wtype, tol):
         sd.backend_set_option("qgemm16_max_rows", 512)
     out = sd.Engine(model=sd.FLUX_WIDE1, backend=gpu, wtype=wt, flash_attn=True).unet_forward(x, t, c, y)
     err = rel_l2(out, ref)
-    print(f"real-width FLUX blocks {wtype}: rel-L2 vs oracle {err:.3e}")
+    print(f"real-width FLUX blocks {wtype} latent {lat} + {ntxt} text tokens: rel-L2 vs oracle {err:.3e}")
     assert np.isfinite(out).all() and err < tol
     if before is not None and wtype == "Q4_0" and not os.environ.get("SDCPP_BACKEND_OPTS"):
         st = sd.backend_stats()

@@ -1,0 +1,169 @@
+"""The north-star check, at FULL width and FULL length: SD1.5 UNet 512x512, batch 1, seed 42, 20 Euler-A steps, cfg 7
+-> KL-VAE decode -> uint8 pixels, MI355X engine against the CPU oracle (generate_image -> sample -> decode_first_stage,
+src/stable-diffusion.cpp:5597-5871, 2509-2926, 3062-3078; sample_euler_ancestral, src/runtime/denoiser.hpp:1513-1546).
+
+Three measurements, printed and bounded:
+  * teacher-forced: at every step the GPU evaluates the (cond, uncond) pair on the ORACLE's x_t — per-step eps rel-L2 (what one forward costs,
+    with no trajectory amplification);
+  * free-running: the GPU's own 20-step trajectory (the device-resident product path, sdm_generate_image) against the oracle's — rel-L2 of the
+    latent after every step (host-loop restatement below, same Philox streams) and of the final latent;
+  * pixels: PSNR of the decoded uint8 images (bar: >= 35 dB) and the largest absolute pixel difference.
+Then the batch-8 device batch of bench.py: image 7 of an 8-image GPU run (seed 42 + 7) against an independent batch-1 oracle trajectory.
+
+The sampler loop is restated here in numpy from the engine's own primitives (sd.get_sigmas, sd_sigma_to_t, sd.philox_randn) so that the per-step
+states are observable; the test first proves the restatement equals the engine's host loop on the GPU (same forwards -> same bits up to the
+f32 host arithmetic), then uses it to drive both backends.  The oracle needs ~3 s per full-width forward: ~2 min per trajectory.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ON_GPU = os.environ.get("SDCPP_GPU_TESTS_ON_ORACLE") != "1"
+full = pytest.mark.skipif(not ON_GPU, reason="full-width 20-step trajectories on both sides")
+
+STEPS, CFG, SEED = 20, 7.0, 42
+
+
+def rel_l2(a, b):
+    a = np.asarray(a, np.float64).ravel()
+    b = np.asarray(b, np.float64).ravel()
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
+def psnr_u8(a, b):
+    mse = float(np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2))
+    return 10 * np.log10(255.0 ** 2 / max(mse, 1e-12))
+
+
+def ancestral(sigma_from, sigma_to, eta=1.0):
+    """get_ancestral_step, denoiser.hpp:1447-1467 (f32 arithmetic)"""
+    f = np.float32
+    if eta <= 0:
+        return f(sigma_to), f(0)
+    fs, ts = f(sigma_from) * f(sigma_from), f(sigma_to) * f(sigma_to)
+    up = f(0)
+    if fs > 0:
+        term = ts * (fs - ts) / fs
+        up = min(f(sigma_to), f(eta) * np.sqrt(max(term, f(0)), dtype=np.float32))
+    down_sq = ts - up * up
+    return (np.sqrt(down_sq, dtype=np.float32) if down_sq > 0 else f(0)), f(up)
+
+
+class Trajectory:
+    """Euler-A with CFG on one image, one step at a time (engine.cpp sample_group == stable-diffusion.cpp:2625-2897 + denoiser.hpp:1513-1546)."""
+
+    def __init__(self, sd, seed, lat=64):
+        self.sd, self.seed, self.lat = sd, seed, lat
+        self.sigmas = sd.get_sigmas(STEPS)
+        self.per = 4 * lat * lat
+        self.offset = 0
+        self.x = (self.noise() * self.sigmas[0]).reshape(1, 4, lat, lat)
+
+    def noise(self):
+        n = self.sd.philox_randn(self.seed, self.offset, self.per)
+        self.offset += 1
+        return n
+
+    def inputs(self, i):
+        sigma = np.float32(self.sigmas[i])
+        c_in = np.float32(1.0) / np.sqrt(sigma * sigma + np.float32(1.0), dtype=np.float32)
+        t = np.float32(self.sd.lib().sd_sigma_to_t(float(sigma)))
+        return (self.x * c_in).astype(np.float32), np.array([t, t], np.float32)
+
+    def advance(self, i, eps_cond, eps_uncond):
+        sigma, sigma_to = np.float32(self.sigmas[i]), np.float32(self.sigmas[i + 1])
+        guided = eps_uncond + np.float32(CFG) * (eps_cond - eps_uncond)
+        denoised = guided * (-sigma) + self.x
+        if sigma_to == 0:
+            self.x = denoised
+            return
+        down, up = ancestral(sigma, sigma_to)
+        ratio = np.float32(down / sigma)
+        self.x = ratio * self.x + (np.float32(1.0) - ratio) * denoised
+        if up > 0:
+            self.x = self.x + self.noise().reshape(self.x.shape) * up
+
+
+def pair_forward(eng, xin, t2, c2):
+    out = eng.unet_forward(np.repeat(xin, 2, axis=0), t2, c2)
+    return out[0:1], out[1:2]
+
+
+@full
+def test_sd15_20_step_euler_a_pixels_vs_oracle(sd, oracle, gpu):
+    rng = np.random.default_rng(4242)
+    cond = rng.standard_normal((1, 77, 768)).astype(np.float32)
+    uncond = rng.standard_normal((1, 77, 768)).astype(np.float32)
+    c2 = np.concatenate([cond, uncond])
+    gpu_e = sd.Engine(model=sd.SD15, backend=gpu, flash_attn=True)
+    ref_e = sd.Engine(model=sd.SD15, backend=oracle, flash_attn=False)   # the oracle's exact-softmax chain (see test_zz_gpu_fullsize.py)
+
+    # 1. oracle trajectory, with the GPU teacher-forced at every step
+    tr_ref, tr_gpu = Trajectory(sd, SEED), Trajectory(sd, SEED)
+    tf_err, free_err = [], []
+    for i in range(STEPS):
+        xin, t2 = tr_ref.inputs(i)
+        rc, ru = pair_forward(ref_e, xin, t2, c2)
+        gc, gu = pair_forward(gpu_e, xin, t2, c2)                  # GPU on the ORACLE's x_t
+        tf_err.append(max(rel_l2(gc, rc), rel_l2(gu, ru)))
+        tr_ref.advance(i, rc, ru)
+        xg, tg = tr_gpu.inputs(i)                                   # GPU on its OWN x_t
+        tr_gpu.advance(i, *pair_forward(gpu_e, xg, tg, c2))
+        free_err.append(rel_l2(tr_gpu.x, tr_ref.x))
+    print("teacher-forced eps rel-L2 per step: " + " ".join(f"{e:.2e}" for e in tf_err))
+    print("free-running latent rel-L2 per step: " + " ".join(f"{e:.2e}" for e in free_err))
+    assert max(tf_err) < 5e-3, tf_err
+    assert free_err[-1] < 5e-2, free_err
+
+    # 2. the product path: device-resident 20-step trajectory inside sdm_generate_image / sd_sample_latents
+    lat_dev = gpu_e.sample_latents(cond, uncond, width=512, height=512, steps=STEPS, cfg=CFG, seed=SEED, batch=1, device_batch=1,
+                                   method=sd.EULER_A, fuse_cfg=True, device_sampler=True)
+    lat_host = gpu_e.sample_latents(cond, uncond, width=512, height=512, steps=STEPS, cfg=CFG, seed=SEED, batch=1, device_batch=1,
+                                    method=sd.EULER_A, fuse_cfg=True, device_sampler=False)
+    e_loop = rel_l2(lat_host, tr_gpu.x)
+    e_dev = rel_l2(lat_dev, tr_ref.x)
+    print(f"engine host loop vs numpy restatement (both on the GPU): {e_loop:.2e}; device-resident trajectory vs oracle: {e_dev:.2e}; "
+          f"device vs host loop: {rel_l2(lat_dev, lat_host):.2e}")
+    assert e_loop < 1e-4          # same forwards, f32 host arithmetic in a different summation association at most
+    assert e_dev < 5e-2
+
+    # 3. pixels: the GPU image (device sampler + VAE decode + uint8) against the oracle's decode of the oracle's latents
+    img_gpu = gpu_e.generate_image(cond, uncond, width=512, height=512, steps=STEPS, cfg=CFG, seed=SEED, batch=1, device_batch=1,
+                                   method=sd.EULER_A, fuse_cfg=True, device_sampler=True)[0]
+    rgb_ref = ref_e.vae_decode(tr_ref.x.astype(np.float32))[0]                        # [3, 512, 512] in [0, 1]
+    img_ref = np.clip(rgb_ref.transpose(1, 2, 0) * 255.0 + 0.5, 0, 255).astype(np.uint8)   # float_to_u8, preprocessing.hpp:27-35
+    p = psnr_u8(img_gpu, img_ref)
+    dmax = int(np.abs(img_gpu.astype(np.int32) - img_ref.astype(np.int32)).max())
+    print(f"20-step Euler-A 512x512 pixels: PSNR {p:.1f} dB, max abs pixel difference {dmax}/255, mean {float(np.abs(img_gpu.astype(np.int32) - img_ref).mean()):.3f}")
+    assert img_gpu.shape == (512, 512, 3) and p >= 35.0
+
+    # 4. the bench configuration: 8 images in one device batch; image 7 (seed 42 + 7) against its own batch-1 oracle trajectory
+    lat8 = gpu_e.sample_latents(cond, uncond, width=512, height=512, steps=STEPS, cfg=CFG, seed=SEED, batch=8, device_batch=8,
+                                method=sd.EULER_A, fuse_cfg=True, device_sampler=True)
+    e0 = rel_l2(lat8[0:1], tr_ref.x)
+    tr7 = Trajectory(sd, SEED + 7)
+    for i in range(STEPS):
+        xin, t2 = tr7.inputs(i)
+        tr7.advance(i, *pair_forward(ref_e, xin, t2, c2))
+    e7 = rel_l2(lat8[7:8], tr7.x)
+    print(f"batch-8 device trajectory vs batch-1 oracle trajectories: image 0 {e0:.2e}, image 7 {e7:.2e}")
+    assert e0 < 5e-2 and e7 < 5e-2
+
+
+def test_sampler_restatement_matches_engine_on_small_model(sd, oracle, gpu):
+    """The numpy Euler-A loop above against the engine's own host loop on the tiny model (fast enough for the self-check mode too): identical
+    forwards on one backend, so the latents agree to f32 rounding — this pins the restatement the full-width test relies on."""
+    rng = np.random.default_rng(77)
+    cond = rng.standard_normal((1, 77, 64)).astype(np.float32)
+    uncond = rng.standard_normal((1, 77, 64)).astype(np.float32)
+    e = sd.Engine(model=sd.SD15_TINY, backend=gpu)
+    tr = Trajectory(sd, SEED, lat=16)
+    c2 = np.concatenate([cond, uncond])
+    for i in range(STEPS):
+        xin, t2 = tr.inputs(i)
+        tr.advance(i, *pair_forward(e, xin, t2, c2))
+    ref = e.sample_latents(cond, uncond, width=128, height=128, steps=STEPS, cfg=CFG, seed=SEED, batch=1, method=sd.EULER_A, fuse_cfg=True)
+    assert rel_l2(tr.x, ref) < 1e-4
