@@ -1,0 +1,117 @@
+#!/usr/bin/env python
+"""Correctness + timing of the LDS-window 3x3 conv kernel (conv3w.hip; option conv3w = 1, the default) against the round-2 per-tap gather kernel
+(conv3w = 0) on the 3x3 / stride-1 conv shapes of the benchmarked configurations, with bias, residual and the per-(image, channel) embedding
+add.  Correctness: the two kernels against each other (same f16 operands, f32 accumulation: summation-order noise only) AND sampled output
+elements against float64 products on the f16-rounded operands.  Timing: HIP events around each dispatch (kernel_timing families conv 256 / 128 +
+split-K reduce)."""
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+import sdcpp_amd as sd
+from ggml_graph import F16, F32, Graph
+
+sd.load_mi355x_backend()
+L = sd.lib()
+rng = np.random.default_rng(0)
+REPS = 5
+FAMS = (1 << 0) | (1 << 1) | (1 << 14)
+
+
+def rel_l2(a, b):
+    a = np.asarray(a, np.float64).ravel(); b = np.asarray(b, np.float64).ravel()
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
+def conv(N, IC, OC, HW, res=False, emb=False, H=None):
+    H = H or HW
+    x = rng.standard_normal((N, IC, H, HW)).astype(np.float32)
+    w = (rng.standard_normal((OC, IC, 3, 3)) / np.sqrt(IC * 9)).astype(np.float32)
+    b = rng.standard_normal(OC).astype(np.float32)
+    r = rng.standard_normal((N, OC, H, HW)).astype(np.float32)
+    e_in = rng.standard_normal((N, 128)).astype(np.float32)
+    we = (rng.standard_normal((OC, 128)) / np.sqrt(128)).astype(np.float32)
+    flops = 2.0 * N * H * HW * OC * IC * 9
+
+    def build(g):
+        y = L.ggml_conv_2d(g.ctx, g.weight(w, F16), g.input(x), 1, 1, 1, 1, 1, 1)
+        y = L.ggml_add_inplace(g.ctx, y, L.ggml_reshape_4d(g.ctx, g.weight(b, F32), 1, 1, OC, 1))
+        if emb:
+            e = L.ggml_mul_mat(g.ctx, g.weight(we, F16), L.ggml_silu(g.ctx, g.input(e_in)))
+            y = L.ggml_add(g.ctx, y, L.ggml_reshape_4d(g.ctx, e, 1, 1, OC, N))
+        if res:
+            y = L.ggml_add(g.ctx, y, g.input(r))
+        return y
+
+    outs, line = [], f"conv3x3 N{N} {IC}->{OC} @{H}x{HW}{' +res' if res else ''}{' +emb' if emb else ''}"
+    line = f"{line:44s}"
+    used = []
+    for opt in (0, 1):
+        sd.backend_set_option("conv3w", opt)
+        st0 = sd.backend_stats()
+        with Graph("MI355X0") as g:
+            node = build(g)
+            out = g.run(node)
+            gf = L.ggml_new_graph_custom(g.ctx, 256, False)
+            L.ggml_build_forward_expand(gf, node)
+            sd.kernel_timing_enable(FAMS)
+            for _ in range(REPS):
+                L.ggml_backend_graph_compute(g.backend, gf)
+            t = sd.kernel_timings()
+            sd.kernel_timing_enable(0)
+            out2 = g.fetch(node)
+        used.append(sd.backend_stats()["window_convs"] - st0["window_convs"])
+        ms = sum(f["total_ms"] for f in t) / REPS
+        outs.append(out)
+        line += f" | conv3w={opt}: {ms*1e3:8.1f} us {flops/ms/1e9:7.1f} TF{'' if np.array_equal(out, out2) else ' RERUN-DIFF'}"
+    sd.backend_set_option("conv3w", 1)
+    # sampled exact products (bias + optional residual; the embedding add is checked through the variant comparison)
+    worst = 0.0
+    if not emb:
+        xp = np.pad(x.astype(np.float16), ((0, 0), (0, 0), (1, 1), (1, 1)))
+        w16 = w.astype(np.float16).astype(np.float64)
+        scale = float(np.abs(outs[1]).mean())
+        r2 = np.random.default_rng(5)
+        pts = [(r2.integers(N), r2.integers(OC), r2.integers(H), r2.integers(HW)) for _ in range(48)]
+        pts += [(N - 1, OC - 1, oh, ow) for oh in (0, H - 1) for ow in (0, HW - 1)] + [(0, 0, 0, 0), (N - 1, 0, H // 2, HW - 1), (0, OC - 1, H - 1, HW // 2)]
+        for (n, oc, oh, ow) in pts:
+            ref = float((xp[n, :, oh:oh + 3, ow:ow + 3].astype(np.float64) * w16[oc]).sum() + b[oc] + (r[n, oc, oh, ow] if res else 0.0))
+            worst = max(worst, abs(outs[1][n, oc, oh, ow] - ref) / max(scale, abs(ref)))
+    rel = rel_l2(outs[1], outs[0])
+    ok = rel < 3e-5 and worst < 1e-3 and np.isfinite(outs[1]).all()
+    print(line + f" | window kernel used: {used[1]} | vs gather kernel rel {rel:.1e}, sampled err {worst:.1e} {'ok' if ok else 'FAIL'}", flush=True)
+    return ok
+
+
+if __name__ == "__main__":
+    ok = True
+    # SD1.5, 8 images x (cond, uncond)
+    ok &= conv(16, 320, 320, 64)
+    ok &= conv(16, 320, 320, 64, res=True)
+    ok &= conv(16, 320, 320, 64, emb=True)
+    ok &= conv(16, 640, 320, 64)
+    ok &= conv(16, 960, 320, 64, emb=True)
+    ok &= conv(16, 640, 640, 32)
+    ok &= conv(16, 640, 640, 32, res=True)
+    ok &= conv(16, 320, 640, 32, emb=True)
+    ok &= conv(16, 1280, 640, 32)
+    ok &= conv(16, 1920, 640, 32, emb=True)
+    # SDXL, one image x (cond, uncond)
+    ok &= conv(2, 320, 320, 128)
+    ok &= conv(2, 960, 320, 128, res=True)
+    ok &= conv(2, 640, 640, 64)
+    ok &= conv(2, 1280, 1280, 32)
+    ok &= conv(2, 2560, 1280, 32, emb=True)
+    # KL-VAE decoder (256-column tiles)
+    ok &= conv(8, 512, 512, 64)
+    ok &= conv(1, 512, 512, 128)
+    ok &= conv(8, 512, 512, 128, res=True)
+    # odd cases: non-square maps, few images, one channel block pair
+    ok &= conv(3, 64, 320, 64, H=96)
+    ok &= conv(1, 320, 640, 32, H=64)
+    ok &= conv(1, 128, 256, 128, H=64)
+    print("ALL OK" if ok else "SOME FAILED")

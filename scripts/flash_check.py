@@ -1,0 +1,85 @@
+#!/usr/bin/env python
+"""Correctness + timing of the flash-attention kernel variants (option flash_qb2: 0 = one query block per wave, the round-2 kernel;
+1 = two query blocks per wave) on the attention shapes of the benchmarked configurations.  Correctness: sampled rows against the exact
+softmax(QK^T / sqrt(d)) V in float64 on the f16-rounded K and V, and the two variants against each other.  Timing: HIP events around each
+dispatch (kernel_timing family 3)."""
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+import sdcpp_amd as sd
+from ggml_graph import F16, Graph
+
+sd.load_mi355x_backend()
+L = sd.lib()
+rng = np.random.default_rng(0)
+REPS = 5
+OPTS = [("flash_qb2", 0), ("flash_qb2", 1)]
+if len(sys.argv) > 1:   # extra "key=value" option settings to time as further variants
+    OPTS += [tuple([kv.split("=")[0], int(kv.split("=")[1])]) for kv in sys.argv[1:]]
+
+
+def rel_l2(a, b):
+    a = np.asarray(a, np.float64).ravel(); b = np.asarray(b, np.float64).ravel()
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
+def case(label, d, Lq, Lk, HN):
+    q = rng.standard_normal((HN, Lq, d)).astype(np.float32)
+    k = rng.standard_normal((HN, Lk, d)).astype(np.float32)
+    v = rng.standard_normal((HN, Lk, d)).astype(np.float32)
+    sc = 1.0 / np.sqrt(d)
+    flops = 4.0 * Lq * Lk * d * HN
+    outs = []
+    line = f"{label:34s}"
+    for key, val in OPTS:
+        sd.backend_set_option("flash_qb2", 1)
+        sd.backend_set_option(key, val)
+        with Graph("MI355X0") as g:
+            node = L.ggml_flash_attn_ext(g.ctx, g.input(q), g.input(k, F16), g.input(v, F16), None, sc, 0.0, 0.0)
+            out = g.run(node)
+            gf = L.ggml_new_graph_custom(g.ctx, 64, False)
+            L.ggml_build_forward_expand(gf, node)
+            sd.kernel_timing_enable(1 << 3)
+            for _ in range(REPS):
+                L.ggml_backend_graph_compute(g.backend, gf)
+            t = sd.kernel_timings()
+            sd.kernel_timing_enable(0)
+            out2 = g.fetch(node)
+        ms = sum(f["total_ms"] for f in t) / REPS
+        outs.append(out)
+        line += f" | {key}={val}: {ms*1e3:8.1f} us {flops/ms/1e9:7.1f} TF{'' if np.array_equal(out, out2) else ' RERUN-DIFF'}"
+        sd.backend_set_option(key, 1 if key == "flash_qb2" else 0)
+    k16, v16 = k.astype(np.float16).astype(np.float64), v.astype(np.float16).astype(np.float64)
+    worst = 0.0
+    r2 = np.random.default_rng(1)
+    picks = [(r2.integers(HN), r2.integers(Lq)) for _ in range(24)] + [(HN - 1, Lq - 1), (0, 0), (HN - 1, max(0, Lq - 33)), (0, min(Lq - 1, 32))]
+    for o in outs:
+        for h, i in picks:
+            s = (k16[h] @ q[h, i].astype(np.float64)) * sc
+            p = np.exp(s - s.max())
+            ref = (p / p.sum()) @ v16[h]
+            worst = max(worst, float(np.abs(o[0, i, h] - ref).max() / max(1.0, np.abs(ref).max())))
+    ok = worst < 3e-3 and all(np.isfinite(o).all() for o in outs) and all(rel_l2(o, outs[0]) < 2e-3 for o in outs)
+    print(line + f" | worst sampled err {worst:.1e} variants rel {max(rel_l2(o, outs[0]) for o in outs):.1e} {'ok' if ok else 'FAIL'}", flush=True)
+    return ok
+
+
+if __name__ == "__main__":
+    ok = True
+    ok &= case("sd15 L0 self d40 L4096 HN128", 40, 4096, 4096, 128)
+    ok &= case("sd15 L0 cross d40 Lk77 HN128", 40, 4096, 77, 128)
+    ok &= case("sd15 L1 self d80 L1024 HN128", 80, 1024, 1024, 128)
+    ok &= case("sd15 L2 self d160 L256 HN128", 160, 256, 256, 128)
+    ok &= case("sdxl self d64 L4096 HN20", 64, 4096, 4096, 20)
+    ok &= case("sdxl self d64 L1024 HN40", 64, 1024, 1024, 40)
+    ok &= case("sdxl cross d64 Lk77 HN20", 64, 4096, 77, 20)
+    ok &= case("sd35 joint d64 L4250 HN76", 64, 4250, 4250, 76)
+    ok &= case("flux d128 L4352 HN24", 128, 4352, 4352, 24)
+    ok &= case("ragged d40 Lq1000 Lk333 HN64", 40, 1000, 333, 64)
+    ok &= case("ragged d64 Lq300 Lk200 HN256", 64, 300, 200, 256)
+    print("ALL OK" if ok else "SOME FAILED")

@@ -41,7 +41,7 @@ namespace {
 struct Stats {
     std::atomic<int64_t> graphs_computed{0}, plans_built{0}, nodes_seen{0}, kernels_planned{0}, kernels_launched{0}, fused_conv{0},
         fused_conv_bounced{0}, fused_linear{0}, fused_norm{0}, fused_geglu{0}, fused_attention{0}, generic_matmul{0}, swizzled_weight_bytes{0}, fused_linear_geglu{0}, split_k_gemms{0}, head_major_gemms{0}, fused_modulate{0}, fused_gate{0}, fused_gelu{0}, fused_rope{0}, fused_concat_heads{0},
-        graph_replays{0}, qgemv_linears{0}, fused_chan_add{0}, fused_proj_tokens{0}, gemm_attention{0}, fused_q16{0}, split_k_inlaunch{0}, qgemm16_linears{0}, fgemv_linears{0}, fused_presilu{0}, fused_sibling_linears{0}, hoisted_kv_linears{0};
+        graph_replays{0}, qgemv_linears{0}, fused_chan_add{0}, fused_proj_tokens{0}, gemm_attention{0}, fused_q16{0}, split_k_inlaunch{0}, qgemm16_linears{0}, fgemv_linears{0}, fused_presilu{0}, fused_sibling_linears{0}, hoisted_kv_linears{0}, window_convs{0};
 } g_stats;
 
 struct Options {
@@ -358,9 +358,10 @@ const void* get_swz_linear(Planner* P, const ggml_tensor* w, hipStream_t s, bool
     g_stats.swizzled_weight_bytes += (int64_t)bytes;
     return d;
 }
-const void* get_swz_conv(Planner* P, const ggml_tensor* w, hipStream_t s) {
+// kblk32: the (32-channel block, tap, channel) image of the LDS-window kernel (conv3w.hip)
+const void* get_swz_conv(Planner* P, const ggml_tensor* w, hipStream_t s, bool kblk32 = false) {
     const bool icb_major = g_opt.gemm16 != 0 && !gemm16_tap_major();
-    uint64_t key = fnv(fnv(1469598103934665603ull, &w->data, sizeof(w->data)), icb_major ? "D" : "C", 1);
+    uint64_t key = fnv(fnv(1469598103934665603ull, &w->data, sizeof(w->data)), kblk32 ? "W" : (icb_major ? "D" : "C"), 1);
     auto it      = P->swz.find(key);
     if (it != P->swz.end()) return it->second.swz;
     const int64_t KW = w->ne[0], KH = w->ne[1], IC = w->ne[2], OC = w->ne[3];
@@ -368,7 +369,7 @@ const void* get_swz_conv(Planner* P, const ggml_tensor* w, hipStream_t s) {
     const size_t bytes = wswz_bytes(OC, ICp * KW * KH);
     void* d            = nullptr;
     if (hipMalloc(&d, bytes) != hipSuccess) return nullptr;
-    launch_wswz_conv(s, d, w->data, KW, KH, IC, OC, icb_major);
+    launch_wswz_conv(s, d, w->data, KW, KH, IC, OC, kblk32 ? 32 : (icb_major ? 64 : 0));
     P->swz[key] = {d, bytes, w->data, ggml_abi_nbytes(w)};
     g_stats.swizzled_weight_bytes += (int64_t)bytes;
     return d;
@@ -1058,10 +1059,13 @@ bool plan_conv_chain(Builder& B, int i, hipStream_t s, std::vector<int>& chain) 
             }
         }
     }
-    const void* swz = get_swz_conv(B.P, ker, s);
-    if (!swz) return false;
     float* final_dst = (float*)gi.node(last)->data;
     const int ks = KW, st_ = s0, pd = p0;
+    // 3x3 / stride 1 on 32 / 64 / 128-wide maps: the LDS-window kernel (conv3w.hip), with its own weight image
+    const bool ups_in = B.ups.find(x) != B.ups.end();
+    const int w3S     = (g_opt.gemm16 && token_major_out < 0) ? conv3w_plan(x->ne[0], x->ne[1], IC, N, OC, ks, st_, ups_in) : 0;
+    const void* swz   = get_swz_conv(B.P, ker, s, w3S > 0);
+    if (!swz) return false;
     if (g_opt.gemm16) {
         // gen-2: the conv reads an f16 NHWC image from the private arena, so the graph allocator's recycling of the
         // conv input for the chain output is harmless (no bounce).  A deferred nearest-x2 UPSCALE becomes an index shift.
@@ -1094,6 +1098,14 @@ bool plan_conv_chain(Builder& B, int i, hipStream_t s, std::vector<int>& chain) 
             B.emit([=](hipStream_t st) { launch_gemm16_linear(st, tdst, nullptr, 0, P->arena + off, lda, swz, tokens, IC, OC, OC, ep); });
             g_stats.fused_conv++;
             g_stats.fused_proj_tokens++;
+            return true;
+        }
+        if (w3S > 0) {
+            const size_t wsoff = w3S > 1 ? B.alloc((size_t)w3S * opos * OC * 4) : 0;
+            if (w3S > 1) g_stats.split_k_gemms++;
+            B.emit_at(emit_node, i, [=](hipStream_t st) { launch_conv3w(st, final_dst, P->arena + off, swz, SW, SH, IC, N, OC, ep, w3S > 1 ? (float*)(P->arena + wsoff) : nullptr, w3S); });
+            g_stats.fused_conv++;
+            g_stats.window_convs++;
             return true;
         }
         const Builder::Split sk = B.plan_split(opos, OC, rup64(IC) * ks * ks, true, true);
@@ -2155,6 +2167,7 @@ void planner_get_stats(ggml_backend_mi355x_stats* o) {
     o->fused_presilu         = g_stats.fused_presilu;
     o->fused_sibling_linears = g_stats.fused_sibling_linears;
     o->hoisted_kv_linears    = g_stats.hoisted_kv_linears;
+    o->window_convs          = g_stats.window_convs;
     o->fused_attention       = g_stats.fused_attention;
     o->generic_matmul        = g_stats.generic_matmul;
     o->swizzled_weight_bytes = g_stats.swizzled_weight_bytes;
@@ -2174,6 +2187,9 @@ void planner_set_option(const char* key, int value) {
     else if (!strcmp(key, "qgemv")) g_opt.qgemv = value;
     else if (!strcmp(key, "fuse_q16")) g_opt.fuse_q16 = value;
     else if (!strcmp(key, "flash_grid")) flash_attn_set_grid(value);
+    else if (!strcmp(key, "flash_qb2")) flash_attn_set_qb2(value);
+    else if (!strcmp(key, "conv3w")) conv3w_set(value);
+    else if (!strcmp(key, "conv3w_min_blocks")) conv3w_set_min_blocks(value);
     else if (!strcmp(key, "gemm16_bn64")) gemm16_set_bn64(value);
     else if (!strcmp(key, "qgemm16")) g_opt.qgemm16 = value;
     else if (!strcmp(key, "qgemv_max_rows")) qgemv_set_max_rows(value);

@@ -17,6 +17,7 @@
 // BEFORE the MFMAs of tile t and written to LDS after the next barrier, so HBM/L2 latency hides under compute.
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "device_utils.h"
 #include "kernels.h"
@@ -62,8 +63,15 @@ struct FAArgs {
 #define FA_OCC_SMALL 3
 #endif
 
-template <int DKP, int NDV, bool FAST, int ABL = 0, bool MSLOT = false>
-__global__ __launch_bounds__(256, DKP <= 64 ? FA_OCC_SMALL : (DKP <= 128 ? 2 : 1)) void k_flash_attn(FAArgs g) {
+// QB = query blocks (32 rows each) per wave.  QB = 2 (FAST only; round 3): a wave owns 64 queries, a workgroup 256 — every K / V fragment read
+// from LDS, every staged K / V byte and every barrier then feeds TWO MFMAs instead of one, and the two blocks' QK^T -> softmax -> PV chains are
+// independent instruction streams the scheduler can interleave (the round-2 kernel was a single dependent chain per wave: MFMA pipe 27-30 % busy,
+// 42 % of the wave cycles waiting, profiles/r03c_pmc_flash.txt).  Costs 2x the accumulator / score registers: 2 waves per SIMD.
+template <int DKP, int NDV, bool FAST, int ABL = 0, bool MSLOT = false, int QB = 1>
+__global__ __launch_bounds__(256, QB == 2 ? (DKP <= 96 ? 2 : 1) : (DKP <= 64 ? FA_OCC_SMALL : (DKP <= 128 ? 2 : 1))) void k_flash_attn(FAArgs g) {
+    static_assert(QB == 1 || FAST, "two query blocks per wave: FAST staging only");
+    constexpr int QW   = 32 * QB;                        // queries per wave
+    constexpr int QWG  = 4 * QW;                         // queries per workgroup
     constexpr int KS   = DKP / 16;                       // MFMA k-steps over the head dim
     constexpr int KROW = DKP + 8;                        // K tile row stride (halfs)
     constexpr int DCH  = DKP / 8;                        // 8-wide d chunks per key
@@ -89,14 +97,14 @@ __global__ __launch_bounds__(256, DKP <= 64 ? FA_OCC_SMALL : (DKP <= 128 ? 2 : 1
         const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
         const int h = j % g.grp, unit = (j / g.grp) * 8 + xcd;
         if (unit >= g.units) return;
-        const int nrb = (g.Lq + 127) >> 7;
+        const int nrb = (g.Lq + QWG - 1) / QWG;
         hn = (unit / nrb) * g.grp + h;
         qb = unit % nrb;
     } else {
         hn = blockIdx.y;
         qb = blockIdx.x;
     }
-    const int q0   = qb * 128 + wave * 32;
+    const int q0   = qb * QWG + wave * QW;              // first query of this wave; query block b starts at q0 + 32 * b
     const int qi   = q0 + (lane & 31);
 
     // ---- Q fragments (B operand of S^T): lane holds Q[qi][ks*16 + hi*8 .. +8] as f16.
@@ -104,14 +112,15 @@ __global__ __launch_bounds__(256, DKP <= 64 ? FA_OCC_SMALL : (DKP <= 128 ? 2 : 1
     // coalesced float4 loads and handed to the lanes through LDS (the region aliases the K/V tiles, which are staged afterwards).  Per-lane
     // row reads (32 rows x 2 halves per instruction, 4 useful bytes of every 64-byte segment) cost ~1500 TA cycles per wave: at Lk = 77
     // (cross-attention, 2 tiles per workgroup) that was most of the kernel.
-    half8_t qf[KS];
+    half8_t qf[QB][KS];
     if (g.q_f16) {  // f16 head-major Q written by the projection GEMM for this launch (rows d-contiguous, 16-byte aligned, D % 8 == 0)
         constexpr int QROW = DKP + 4, C8 = DKP / 8;
-        const char* qblk = g.q + (int64_t)hn * g.q_nb2 + (int64_t)(qb * 128) * g.q_nb1;
-        for (int e = threadIdx.x; e < 128 * C8; e += 256) {
+        static_assert(QWG * QROW <= NBUF * TILE_H, "Q staging must fit the K/V tile buffers");
+        const char* qblk = g.q + (int64_t)hn * g.q_nb2 + (int64_t)(qb * QWG) * g.q_nb1;
+        for (int e = threadIdx.x; e < QWG * C8; e += 256) {
             const int row = e / C8, c8 = e - row * C8;
             half8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (qb * 128 + row < g.Lq && c8 * 8 < g.D) v = *(const half8_t*)(qblk + (int64_t)row * g.q_nb1 + c8 * 16);
+            if (qb * QWG + row < g.Lq && c8 * 8 < g.D) v = *(const half8_t*)(qblk + (int64_t)row * g.q_nb1 + c8 * 16);
             half4_t a, b;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -123,20 +132,22 @@ __global__ __launch_bounds__(256, DKP <= 64 ? FA_OCC_SMALL : (DKP <= 128 ? 2 : 1
         }
         __syncthreads();
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const _Float16* p = &smem[(wave * 32 + (lane & 31)) * QROW + ks * 16 + hi * 8];
-            const half4_t a = *(const half4_t*)p, b = *(const half4_t*)(p + 4);
-            qf[ks] = (half8_t){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-        }
+        for (int b = 0; b < QB; ++b)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const _Float16* p = &smem[(wave * QW + b * 32 + (lane & 31)) * QROW + ks * 16 + hi * 8];
+                const half4_t a = *(const half4_t*)p, c = *(const half4_t*)(p + 4);
+                qf[b][ks] = (half8_t){a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]};
+            }
         __syncthreads();
     } else if (g.q_vec) {
         constexpr int QROW = DKP + 4, C4 = DKP / 4;  // +4 halfs: 8-byte aligned rows, 2-way conflicts at worst on the one-time fragment reads
-        static_assert(128 * QROW <= NBUF * TILE_H, "Q staging must fit the K/V tile buffers");
-        const char* qblk = g.q + (int64_t)hn * g.q_nb2 + (int64_t)(qb * 128) * g.q_nb1;
-        for (int e = threadIdx.x; e < 128 * C4; e += 256) {
+        static_assert(QWG * QROW <= NBUF * TILE_H, "Q staging must fit the K/V tile buffers");
+        const char* qblk = g.q + (int64_t)hn * g.q_nb2 + (int64_t)(qb * QWG) * g.q_nb1;
+        for (int e = threadIdx.x; e < QWG * C4; e += 256) {
             const int row = e / C4, c4 = e - row * C4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (qb * 128 + row < g.Lq && c4 * 4 < g.D) v = *(const float4*)(qblk + (int64_t)row * g.q_nb1 + c4 * 16);
+            if (qb * QWG + row < g.Lq && c4 * 4 < g.D) v = *(const float4*)(qblk + (int64_t)row * g.q_nb1 + c4 * 16);
             half4_t h;
             h[0] = (_Float16)(v.x * g.scale_log2e);  // scores come out of the MFMA in log2 units
             h[1] = (_Float16)(v.y * g.scale_log2e);
@@ -146,28 +157,39 @@ __global__ __launch_bounds__(256, DKP <= 64 ? FA_OCC_SMALL : (DKP <= 128 ? 2 : 1
         }
         __syncthreads();
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const _Float16* p = &smem[(wave * 32 + (lane & 31)) * QROW + ks * 16 + hi * 8];
-            const half4_t a = *(const half4_t*)p, b = *(const half4_t*)(p + 4);
-            qf[ks] = (half8_t){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-        }
+        for (int b = 0; b < QB; ++b)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const _Float16* p = &smem[(wave * QW + b * 32 + (lane & 31)) * QROW + ks * 16 + hi * 8];
+                const half4_t a = *(const half4_t*)p, c = *(const half4_t*)(p + 4);
+                qf[b][ks] = (half8_t){a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]};
+            }
         __syncthreads();
     } else {
-        const float* qrow = (const float*)(g.q + (int64_t)min(qi, g.Lq - 1) * g.q_nb1 + (int64_t)hn * g.q_nb2);
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
+        for (int b = 0; b < QB; ++b) {
+            const int qib     = qi + 32 * b;
+            const float* qrow = (const float*)(g.q + (int64_t)min(qib, g.Lq - 1) * g.q_nb1 + (int64_t)hn * g.q_nb2);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int d = ks * 16 + hi * 8 + j;
-                qf[ks][j]   = (_Float16)((d < g.D && qi < g.Lq) ? qrow[d] * g.scale_log2e : 0.f);
+            for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int d  = ks * 16 + hi * 8 + j;
+                    qf[b][ks][j] = (_Float16)((d < g.D && qib < g.Lq) ? qrow[d] * g.scale_log2e : 0.f);
+                }
             }
         }
     }
 
-    float16_t o[NDV];
+    float16_t o[QB][NDV];
+    float m_run[QB], l_run[QB];
 #pragma unroll
-    for (int nb = 0; nb < NDV; ++nb) o[nb] = (float16_t){0};
-    float m_run = MSLOT ? 0.f : -INFINITY, l_run = 0.f;  // MSLOT: Q's max slot starts at 0 and the first tile always moves the max
+    for (int b = 0; b < QB; ++b) {
+#pragma unroll
+        for (int nb = 0; nb < NDV; ++nb) o[b][nb] = (float16_t){0};
+        m_run[b] = MSLOT ? 0.f : -INFINITY;  // MSLOT: Q's max slot starts at 0 and the first tile always moves the max
+        l_run[b] = 0.f;
+    }
 
     const char* kbase = g.k + (int64_t)hn * g.k_nb2;
     const char* vbase = g.v + (int64_t)hn * g.v_nb2;
@@ -280,7 +302,10 @@ __global__ __launch_bounds__(256, DKP <= 64 ? FA_OCC_SMALL : (DKP <= 128 ? 2 : 1
         __syncthreads();
     }
     int buf = 0;
-    for (int kt = 0; kt < g.Lk; kt += FA_KT) {
+    // one 64-key tile.  TAIL (keys beyond Lk masked) is a compile-time flag: the hot loop over full tiles carries no mask code and no branch that
+    // would cut its basic blocks; a ragged last tile runs the second instantiation once.
+    auto tile = [&](const int kt, auto tail_tag) {
+        constexpr bool TAIL = decltype(tail_tag)::value;
         if (FAST) {
             // tile kt sits in buffer buf (visible since the barrier that ended the previous iteration); the registers hold tile
             // kt+64: park it in the other buffer now, then fetch kt+128 — both overlap this tile's MFMAs
@@ -296,88 +321,119 @@ __global__ __launch_bounds__(256, DKP <= 64 ? FA_OCC_SMALL : (DKP <= 128 ? 2 : 1
         const _Float16* Kc = Ks + (FAST ? buf * TILE_H : 0);
         const _Float16* Vc = Vt + (FAST ? buf * TILE_H : 0);
 
-        // ---- S^T = K Q^T  (rows i = key, cols j = query)
-        float16_t s[2];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            s[kb] = (float16_t){0};
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const half8_t kf = *(const half8_t*)&Kc[(kb * 32 + (lane & 31)) * KROW + ks * 16 + hi * 8];
-                s[kb]            = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[kb], 0, 0, 0);
-            }
-        }
-        // ---- online softmax for query (lane & 31); this lane holds keys kb*32 + (r&3)+8*(r>>2)+4*hi.  The loop is VALU-bound at
-        // d = 40 (32 exps per lane per tile vs 14 MFMAs), so every instruction counts: scores arrive pre-scaled (Q carries
+        // ---- per query block: S^T = K Q^T (rows i = key, cols j = query) -> online softmax -> P packed to f16.  Block b+1's QK^T MFMAs are
+        // independent of block b's softmax VALU work, so the two streams overlap; only ONE block's 32 score registers are live at a time.
+        half8_t pa[QB][4];
+        constexpr bool SHARE_KF = QB == 2 && KS <= 3;
+        half8_t kf[2][KS <= 6 ? KS : 1];
+        // ---- online softmax for query (lane & 31) of each block; this lane holds keys kb*32 + (r&3)+8*(r>>2)+4*hi.  The loop is VALU-bound at
+        // d = 40 (32 exps per lane per tile and block vs 14 MFMAs), so every instruction counts: scores arrive pre-scaled (Q carries
         // scale*log2e), exp is the bare v_exp_f32, and the running max is DEFERRED — it only moves when a query's tile max exceeds
         // it by more than FA_THR (2^8: P <= 256 stays exact enough in f16 and far from its range), which makes the accumulator
-        // rescale (16 cross-lane fetches + 16*NDV multiplies) rare instead of per tile.
-        if (kt + FA_KT > g.Lk) {  // tail tile: mask keys >= Lk
+        // rescale (16 cross-lane fetches + 16*NDV multiplies) rare instead of per tile.  The vote uses each lane's OWN 32 keys (a row's max
+        // exceeds the bar iff one of its two halves does): the cross-half exchange happens only on the rare path.
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+        for (int b = 0; b < QB; ++b) {
+            float16_t s[2];
+            if constexpr (KS <= 6) {
+                // all K fragments of the tile are requested before the first MFMA (left to itself the compiler issued read -> wait -> MFMA
+                // one at a time through a single register set: the LDS latency sat in front of every MFMA).  SHARE_KF (two query blocks,
+                // d <= 48): the fragments stay in registers for the second block — no second read, and its MFMAs start without an LDS wait
+                if (!SHARE_KF || b == 0) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (kt + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= g.Lk) s[kb][r] = -INFINITY;
-        }
-        float tmax = s[0][0];
-        if (ABL != 1) {
+                    for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) tmax = __builtin_fmaxf(__builtin_fmaxf(tmax, s[0][r]), s[1][r]);  // v_max3_f32
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        }
-        if (MSLOT ? (kt == 0 || __any(tmax > FA_THR)) : (ABL != 1 && __any(tmax > m_run + FA_THR))) {
-            float alpha;
-            if constexpr (MSLOT) {
-                // the scores are relative to m_run already: move the max by delta (rounded so that the new max is an f16 value), re-base this tile
-                const float m_new = (float)(_Float16)(m_run + (kt == 0 ? tmax : fmaxf(tmax, 0.f)));
-                const float delta = m_new - m_run;
-                alpha             = __builtin_amdgcn_exp2f(-delta);
-                m_run             = m_new;
+                        for (int ks = 0; ks < KS; ++ks) kf[kb][ks] = *(const half8_t*)&Kc[(kb * 32 + (lane & 31)) * KROW + ks * 16 + hi * 8];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                s[0] = (float16_t){0};
+                s[1] = (float16_t){0};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb) s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kb][ks], qf[b][ks], s[kb], 0, 0, 0);
+            } else {  // d = 128, 160: the fragments of a whole tile do not fit next to the accumulators
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    s[kb] = (float16_t){0};
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        const half8_t kf = *(const half8_t*)&Kc[(kb * 32 + (lane & 31)) * KROW + ks * 16 + hi * 8];
+                        s[kb]            = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[b][ks], s[kb], 0, 0, 0);
+                    }
+                }
+            }
+            if (TAIL) {  // tail tile: mask keys >= Lk
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) s[kb][r] -= delta;
-                if (hi) qf[KS - 1][0] = (_Float16)(-m_new);  // d = 40: k-step 2, upper lane half, element 0
-            } else {
-                const float m_new = fmaxf(m_run, tmax);
-                alpha             = __builtin_amdgcn_exp2f(m_run - m_new);  // m_run = -inf on the first tile -> 0
-                m_run             = m_new;
+                    for (int r = 0; r < 16; ++r)
+                        if (kt + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= g.Lk) s[kb][r] = -INFINITY;
             }
-            l_run *= alpha;
-            // rescale O rows: row i of the accumulator belongs to query lane i -> fetch its alpha
+            float tmax = s[0][0];
+            if (ABL != 1) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row  = (r & 3) + 8 * (r >> 2) + 4 * hi;
-                const float ar = __shfl(alpha, row, 64);
+                for (int r = 0; r < 16; ++r) tmax = __builtin_fmaxf(__builtin_fmaxf(tmax, s[0][r]), s[1][r]);  // v_max3_f32
+            }
+            if (MSLOT ? (kt == 0 || __any(tmax > FA_THR)) : (ABL != 1 && __any(tmax > m_run[b] + FA_THR))) {
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+                float alpha;
+                if constexpr (MSLOT) {
+                    // the scores are relative to m_run already: move the max by delta (rounded so that the new max is an f16 value), re-base this
+                    // tile.  The new max is clamped to the finite f16 range: the slot holds -m as f16, and +-inf there would turn every later
+                    // score of the row into NaN; any consistent offset is a valid softmax shift
+                    const float m_new = fminf((float)(_Float16)fminf(m_run[b] + (kt == 0 ? tmax : fmaxf(tmax, 0.f)), 65504.f), 65504.f);
+                    const float delta = m_new - m_run[b];
+                    alpha             = __builtin_amdgcn_exp2f(-delta);
+                    m_run[b]          = m_new;
 #pragma unroll
-                for (int nb = 0; nb < NDV; ++nb) o[nb][r] *= ar;
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) s[kb][r] -= delta;
+                    if (hi) qf[b][KS - 1][0] = (_Float16)(-m_new);  // d = 40: k-step 2, upper lane half, element 0
+                } else {
+                    const float m_new = fmaxf(m_run[b], tmax);
+                    alpha             = __builtin_amdgcn_exp2f(m_run[b] - m_new);  // m_run = -inf on the first tile -> 0
+                    m_run[b]          = m_new;
+                }
+                l_run[b] *= alpha;
+                // rescale O rows: row i of the accumulator belongs to query lane i -> fetch its alpha
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row  = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    const float ar = __shfl(alpha, row, 64);
+#pragma unroll
+                    for (int nb = 0; nb < NDV; ++nb) o[b][nb][r] *= ar;
+                }
+            }
+            if (ABL != 1) {
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[kb][r] = __builtin_amdgcn_exp2f(MSLOT ? s[kb][r] : s[kb][r] - m_run[b]);
+            }
+            if (!has_ones) {
+                float psum = 0.f;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) psum += s[kb][r];
+                l_run[b] += psum;
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {  // P in f16, in the accumulator's own key order: the A operand of P V with no data movement
+                const int kb = t >> 1, rb = (t & 1) * 8;
+#pragma unroll
+                for (int j = 0; j < 8; j += 2) {  // v_cvt_pk_f16_f32
+                    const half2_t h2 = __builtin_convertvector((float2_t){s[kb][rb + j], s[kb][rb + j + 1]}, half2_t);
+                    pa[b][t][j]     = h2[0];
+                    pa[b][t][j + 1] = h2[1];
+                }
             }
         }
-        if (ABL != 1) {
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) s[kb][r] = __builtin_amdgcn_exp2f(MSLOT ? s[kb][r] : s[kb][r] - m_run);
-        }
-        if (!has_ones) {
-            float psum = 0.f;
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) psum += s[kb][r];
-            l_run += psum;
-        }
-        // ---- O += P V : 4 k-steps of 16 keys; k-slot order = accumulator key order (see header)
+        // ---- O += P V : 4 k-steps of 16 keys; k-slot order = accumulator key order (see header); every V fragment feeds the QB blocks
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const int kb = t >> 1, rb = (t & 1) * 8;
-            half8_t pa;
-#pragma unroll
-            for (int j = 0; j < 8; j += 2) {  // v_cvt_pk_f16_f32
-                const half2_t h2 = __builtin_convertvector((float2_t){s[kb][rb + j], s[kb][rb + j + 1]}, half2_t);
-                pa[j]     = h2[0];
-                pa[j + 1] = h2[1];
-            }
 #pragma unroll
             for (int nb = 0; nb < NDV; ++nb) {
                 const _Float16* vrow = &Vc[(nb * 32 + (lane & 31)) * FA_VTS + t * 16 + 4 * hi];
@@ -391,43 +447,52 @@ __global__ __launch_bounds__(256, DKP <= 64 ? FA_OCC_SMALL : (DKP <= 128 ? 2 : 1
                 vf[5] = v1[1];
                 vf[6] = v1[2];
                 vf[7] = v1[3];
-                o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa, vf, o[nb], 0, 0, 0);
+#pragma unroll
+                for (int b = 0; b < QB; ++b) o[b][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa[b][t], vf, o[b][nb], 0, 0, 0);
             }
         }
         if (FAST) {
             __syncthreads();  // tile kt+64 is complete in the other buffer; everybody is done reading this one
             if (ABL != 2) buf ^= 1;
         }
+    };
+    {
+        int kt = 0;
+        for (; kt + FA_KT <= g.Lk; kt += FA_KT) tile(kt, std::false_type{});
+        if (kt < g.Lk) tile(kt, std::true_type{});
     }
 
     // ---- finalise: divide by the row sum (both lane halves), write [d] contiguous
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv   = l_tot > 0.f ? 1.0f / l_tot : 0.f;
     const int nb_l = g.DV >> 5, lane_l = (g.DV & 31) + 32 * hi;  // has_ones: accumulator column DV holds the row sums
     const int hh = g.H > 0 ? hn % g.H : hn, nn = g.H > 0 ? hn / g.H : 0;  // wave-uniform
     char* obase          = g.dst ? (char*)g.dst + (int64_t)hh * g.dst_nb_h + (int64_t)nn * g.dst_nb_n : nullptr;
     _Float16* obase16    = g.dst16 ? g.dst16 + (int64_t)nn * g.Lq * g.ld16 + (int64_t)hh * g.DV : nullptr;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row  = (r & 3) + 8 * (r >> 2) + 4 * hi;
-        float ir = __shfl(inv, row, 64);
-        if (has_ones) {
-            float lsum = 0.f;
+    for (int b = 0; b < QB; ++b) {
+        const float l_tot = l_run[b] + __shfl_xor(l_run[b], 32, 64);
+        const float inv   = l_tot > 0.f ? 1.0f / l_tot : 0.f;
 #pragma unroll
-            for (int nb = 0; nb < NDV; ++nb)
-                if (nb == nb_l) lsum = o[nb][r];
-            lsum = __shfl(lsum, lane_l, 64);
-            ir   = lsum > 0.f ? 1.0f / lsum : 0.f;
-        }
-        const int q = q0 + row;
-        if (q >= g.Lq) continue;
+        for (int r = 0; r < 16; ++r) {
+            const int row  = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            float ir = __shfl(inv, row, 64);
+            if (has_ones) {
+                float lsum = 0.f;
 #pragma unroll
-        for (int nb = 0; nb < NDV; ++nb) {
-            const int d = nb * 32 + (lane & 31);
-            if (d >= g.DV) continue;
-            const float val = o[nb][r] * ir;
-            if (obase) *(float*)(obase + (int64_t)q * g.dst_nb_q + d * 4) = val;
-            if (obase16) obase16[(int64_t)q * g.ld16 + d] = (_Float16)val;
+                for (int nb = 0; nb < NDV; ++nb)
+                    if (nb == nb_l) lsum = o[b][nb][r];
+                lsum = __shfl(lsum, lane_l, 64);
+                ir   = lsum > 0.f ? 1.0f / lsum : 0.f;
+            }
+            const int q = q0 + 32 * b + row;
+            if (q >= g.Lq) continue;
+#pragma unroll
+            for (int nb = 0; nb < NDV; ++nb) {
+                const int d = nb * 32 + (lane & 31);
+                if (d >= g.DV) continue;
+                const float val = o[b][nb][r] * ir;
+                if (obase) *(float*)(obase + (int64_t)q * g.dst_nb_q + d * 4) = val;
+                if (obase16) obase16[(int64_t)q * g.ld16 + d] = (_Float16)val;
+            }
         }
     }
 }
@@ -443,6 +508,8 @@ static int g_flash_mslot = 1;  // option "flash_mslot": 0 = subtract the running
 void flash_attn_set_mslot(int v) { g_flash_mslot = v; }
 static int g_flash_grid = 1;  // option "flash_grid": 0 = plain (query block, head) grid (A/B measurements)
 void flash_attn_set_grid(int v) { g_flash_grid = v; }
+static int g_flash_qb2 = 1;  // option "flash_qb2": 0 = one query block per wave everywhere (the round-2 kernel; A/B measurements)
+void flash_attn_set_qb2(int v) { g_flash_qb2 = v; }
 
 void launch_flash_attn(hipStream_t s, const FlashOut& out, const View4& q, const View4& k, const View4& v, float scale) {
     KScope ks_(s, KF_FLASH, 4.0 * (double)q.ne[1] * (double)k.ne[1] * (double)q.ne[2] * (double)q.ne[0], 0.0);  // 4 * Lq * Lk * (H*N) * d
@@ -479,15 +546,19 @@ void launch_flash_attn(hipStream_t s, const FlashOut& out, const View4& q, const
         fprintf(stderr, "mi355x: flash attention: f16 Q must be d-contiguous, 16-byte aligned, d %% 8 == 0\n");
         abort();
     }
-    dim3 grid((unsigned)((g.Lq + 127) / 128), (unsigned)q.ne[2]);
+    const int D     = g.D;
+    const bool fast = g.vec_ok && g.kv_f16 && v.nb[0] == 2 && k.nb[0] == 2 && g.D == g.DV;
+    // two query blocks per wave (256 queries per workgroup) when the launch still gives every CU two workgroups' worth of work
+    const int64_t wg256 = ((int64_t)(g.Lq + 255) / 256) * q.ne[2];
+    const bool qb2      = g_flash_qb2 && fast && D <= 64 && g.Lq >= 192 && wg256 >= 256;  // d = 80, 96: 256 VGPRs do not hold two blocks without spills
+    const int QWG       = qb2 ? 256 : 128;
+    dim3 grid((unsigned)((g.Lq + QWG - 1) / QWG), (unsigned)q.ne[2]);
     g.grp = g.units = 0;
     if (g_flash_grid && out.H > 0 && q.ne[2] % out.H == 0) {
         g.grp   = out.H;
         g.units = (int)(q.ne[2] / out.H) * (int)grid.x;
         grid    = dim3((unsigned)(((g.units + 7) / 8) * 8 * g.grp), 1u);
     }
-    const int D     = g.D;
-    const bool fast = g.vec_ok && g.kv_f16 && v.nb[0] == 2 && k.nb[0] == 2 && g.D == g.DV;
 #define FA_CASE(DKP_, NDV_)                                           \
     do {                                                              \
         if (fast)                                                     \
@@ -505,6 +576,15 @@ void launch_flash_attn(hipStream_t s, const FlashOut& out, const View4& q, const
         return;
     }
 #endif
+    if (qb2) {
+        if (D == 40 && g_flash_mslot)
+            k_flash_attn<48, 2, true, 0, true, 2><<<grid, 256, 0, s>>>(g);
+        else if (D <= 48)
+            k_flash_attn<48, 2, true, 0, false, 2><<<grid, 256, 0, s>>>(g);
+        else
+            k_flash_attn<64, 2, true, 0, false, 2><<<grid, 256, 0, s>>>(g);
+        return;
+    }
     if (D == 40 && fast && g_flash_mslot)
         k_flash_attn<48, 2, true, 0, true><<<grid, 256, 0, s>>>(g);
     else if (D <= 48)

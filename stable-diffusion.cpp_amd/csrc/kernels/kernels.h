@@ -66,8 +66,9 @@ size_t wswz_bytes(int64_t R, int64_t K);
 // geglu_inner > 0: rows permuted so that every wave of a gemm16 column tile owns matching value / gate blocks (GEGLU epilogue)
 void launch_wswz_linear(hipStream_t s, void* dst, const void* src, int src_type, int64_t K, int64_t R, int64_t src_row_bytes, int64_t geglu_inner = 0);
 // conv weight [KW,KH,IC,OC] f16 -> rows OC, K index = tap*ICp + ic (ICp = IC padded to 32)
-void launch_wswz_conv(hipStream_t s, void* dst, const void* src, int64_t KW, int64_t KH, int64_t IC, int64_t OC, bool icb_major = false);
-// icb_major: K ordered (64-channel block, tap, channel) for gemm16.hip; false: (tap, channel) for the first-generation kernels
+void launch_wswz_conv(hipStream_t s, void* dst, const void* src, int64_t KW, int64_t KH, int64_t IC, int64_t OC, int kblk = 0);
+// kblk: K ordered (kblk-channel block, tap, channel): 64 for the per-tap gather kernels of gemm16.hip, 32 for the LDS-window kernel of conv3w.hip;
+// 0: (tap, channel)
 
 struct Epilogue {
     const float* bias     = nullptr;  // per output feature / channel
@@ -121,6 +122,13 @@ void gemm16_set_splitk_in_target(int v);
 // x16: f16 NHWC [N][H][W][ICp]; dst f32 NCHW [OW,OH,OC,N]
 void launch_gemm16_conv(hipStream_t s, float* dst, const void* x16_nhwc, const void* wswz, int64_t W, int64_t H, int64_t IC, int64_t N, int64_t OC,
                         int ksize, int stride, int pad, bool upscale2x, const Epilogue& ep, float* splitk_ws = nullptr, int* splitk_cnt = nullptr, int splitk_S = 0);
+// ---- conv3w.hip: 3x3 / stride-1 conv with the input window resident in LDS (weights in the kblk = 32 image)
+// K slices the window kernel would run this shape with (>= 1), or 0: the shape stays on launch_gemm16_conv
+int conv3w_plan(int64_t W, int64_t H, int64_t IC, int64_t N, int64_t OC, int ksize, int stride, bool upscale2x, int* bn_out = nullptr);
+void launch_conv3w(hipStream_t s, float* dst, const void* x16_nhwc, const void* wswz32, int64_t W, int64_t H, int64_t IC, int64_t N, int64_t OC, const Epilogue& ep,
+                   float* splitk_ws, int S);
+void conv3w_set(int v);  // option "conv3w"
+void conv3w_set_min_blocks(int v);  // option "conv3w_min_blocks"
 // producers of f16 operand images (row stride = K rounded up to 64, zero padded)
 // L > 0: rows are N runs of L rows, run n starting bs elements after run n-1 (a token slice of a [C, Lfull, N] tensor)
 void launch_pack_rows_f16(hipStream_t s, void* dst, const float* x, int64_t R, int64_t K, int64_t xs, int64_t L = 0, int64_t bs = 0);
@@ -175,6 +183,7 @@ struct FlashOut {
 void flash_attn_set_ablate(int v);
 #endif
 void flash_attn_set_grid(int v);   // option "flash_grid"
+void flash_attn_set_qb2(int v);    // option "flash_qb2": two query blocks per wave (default on)
 void flash_attn_set_mslot(int v);  // option "flash_mslot"
 void launch_flash_attn(hipStream_t s, const FlashOut& out, const View4& q, const View4& k, const View4& v, float scale);
 

@@ -64,7 +64,7 @@ void launch_wswz_linear(hipStream_t s, void* dst, const void* src, int src_type,
 
 // conv weight [KW,KH,IC,OC] f16 -> rows OC, k = tap*ICp + ic
 __global__ void k_wswz_conv(half8_t* __restrict__ dst, const __half* __restrict__ src, int KW, int KH, int64_t IC, int64_t OC, int64_t ICp, int64_t Kp,
-                            int64_t total, int icb_major) {
+                            int64_t total, int kblk) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int lane     = (int)(i & 63);
@@ -77,10 +77,10 @@ __global__ void k_wswz_conv(half8_t* __restrict__ dst, const __half* __restrict_
     for (int j = 0; j < 8; ++j) {
         const int64_t k = k0 + j;
         int64_t tap, ic;
-        if (icb_major) {  // gemm16: k = (icb * taps + tap) * 64 + ic % 64
-            const int64_t taps = (int64_t)KH * KW, kb = k / 64;
+        if (kblk > 0) {  // gemm16 / conv3w: k = (channel block * taps + tap) * kblk + ic % kblk
+            const int64_t taps = (int64_t)KH * KW, kb = k / kblk;
             tap = kb % taps;
-            ic  = (kb / taps) * 64 + k % 64;
+            ic  = (kb / taps) * kblk + k % kblk;
         } else {  // first-generation kernels: k = tap * ICp + ic
             tap = k / ICp;
             ic  = k % ICp;
@@ -94,10 +94,10 @@ __global__ void k_wswz_conv(half8_t* __restrict__ dst, const __half* __restrict_
     }
     dst[i] = v;
 }
-void launch_wswz_conv(hipStream_t s, void* dst, const void* src, int64_t KW, int64_t KH, int64_t IC, int64_t OC, bool icb_major) {
+void launch_wswz_conv(hipStream_t s, void* dst, const void* src, int64_t KW, int64_t KH, int64_t IC, int64_t OC, int kblk) {
     const int64_t ICp = rup(IC, 64), Kp = ICp * KW * KH, Rp = rup(OC, 128);
     const int64_t total = (Rp / 32) * (Kp / 16) * 64;
-    k_wswz_conv<<<(unsigned)((total + 255) / 256), 256, 0, s>>>((half8_t*)dst, (const __half*)src, (int)KW, (int)KH, IC, OC, ICp, Kp, total, icb_major ? 1 : 0);
+    k_wswz_conv<<<(unsigned)((total + 255) / 256), 256, 0, s>>>((half8_t*)dst, (const __half*)src, (int)KW, (int)KH, IC, OC, ICp, Kp, total, kblk);
 }
 
 }  // namespace mi355x
