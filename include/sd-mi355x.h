@@ -188,6 +188,15 @@ SD_API int sd_get_sigmas(int steps, float* out /* steps+1 */);                  
  * failure.  Nothing is copied to the host.  fn = NULL restores the single-device CFG pair. */
 typedef bool (*sd_pair_exchange_fn)(void* device_eps, int64_t count, void* stream, void* user);
 SD_API void sd_set_pair_exchange(sdm_ctx_t* ctx, sd_pair_exchange_fn fn, void* user, int branch);
+/* Native RCCL form of the exchange (csrc/host/rccl_exchange.cpp): librccl.so is loaded with dlopen, no torch involved.  Rank 0 of a pair makes the
+ * 128-byte unique id and ships it to its partner by any means (a file, a socket, torch.distributed in the tests); both create a 2-rank
+ * communicator bound to HIP device `device` and install it: the engine then issues ONE in-place ncclAllReduce(SUM, f32) of its eps buffer per
+ * sampler step on the backend stream (replaces the reference's host-side guidance.cpp:149-179 when cond and uncond run on two GPUs). */
+SD_API bool sd_rccl_get_unique_id(void* id128);
+SD_API void* sd_rccl_comm_create(int device, int nranks, int rank, const void* id128); /* NULL on failure (sd_rccl_last_error) */
+SD_API void sd_rccl_comm_destroy(void* comm);
+SD_API bool sd_set_pair_exchange_rccl(sdm_ctx_t* ctx, void* comm, int branch); /* comm = NULL removes the exchange */
+SD_API const char* sd_rccl_last_error(void);
 SD_API void sd_set_guidance(sdm_ctx_t* ctx, float guidance); /* FLUX distilled-guidance input (default 3.5, stable-diffusion.h guidance.distilled_guidance) */
 SD_API int sd_get_flux_sigmas(int steps, int image_seq_len, float* out /* steps+1 */); /* FluxScheduler, denoiser.hpp:726-782 */
 SD_API int sd_gen_flux_pe(int h, int w, int patch_size, int context_len, const int* axes_dim, int n_axes, float theta, float* out); /* Rope::gen_flux_pe; returns floats written */

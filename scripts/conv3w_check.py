@@ -100,6 +100,10 @@ if __name__ == "__main__":
     ok &= conv(16, 320, 640, 32, emb=True)
     ok &= conv(16, 1280, 640, 32)
     ok &= conv(16, 1920, 640, 32, emb=True)
+    ok &= conv(16, 1280, 1280, 16)
+    ok &= conv(16, 1280, 1280, 16, res=True)
+    ok &= conv(16, 2560, 1280, 16, emb=True)
+    ok &= conv(16, 1920, 1280, 16)
     # SDXL, one image x (cond, uncond)
     ok &= conv(2, 320, 320, 128)
     ok &= conv(2, 960, 320, 128, res=True)

@@ -254,6 +254,15 @@ def lib() -> C.CDLL:
     L.sd_set_guidance.restype = None
     L.sd_set_pair_exchange.argtypes = [C.c_void_p, PAIR_EXCHANGE_FN, C.c_void_p, C.c_int]
     L.sd_set_pair_exchange.restype = None
+    L.sd_rccl_get_unique_id.argtypes = [C.c_void_p]
+    L.sd_rccl_get_unique_id.restype = C.c_bool
+    L.sd_rccl_comm_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.sd_rccl_comm_create.restype = C.c_void_p
+    L.sd_rccl_comm_destroy.argtypes = [C.c_void_p]
+    L.sd_rccl_comm_destroy.restype = None
+    L.sd_set_pair_exchange_rccl.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.sd_set_pair_exchange_rccl.restype = C.c_bool
+    L.sd_rccl_last_error.restype = C.c_char_p
     L.sd_gen_flux_pe.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_float, C.c_void_p]
     L.sd_sigma_to_t.argtypes = [C.c_float]
     L.sd_sigma_to_t.restype = C.c_float
@@ -549,6 +558,12 @@ class Engine:
             self._pair_cb = PAIR_EXCHANGE_FN(cb)   # kept alive as long as it is installed
         lib().sd_set_pair_exchange(self._ctx, self._pair_cb, None, int(branch))
 
+    def set_pair_exchange_rccl(self, comm, branch: int = 0) -> None:
+        """The native form (csrc/host/rccl_exchange.cpp): one in-place ncclAllReduce per step on the backend stream, issued from C++ through a
+        communicator made by rccl_comm_create; comm = None removes it."""
+        if not lib().sd_set_pair_exchange_rccl(self._ctx, comm, int(branch)):
+            raise EngineError("sd_set_pair_exchange_rccl failed: " + lib().sd_rccl_last_error().decode())
+
     def set_tensor(self, name: str, value: np.ndarray) -> None:
         v = _f32(value).ravel()
         if not lib().sd_set_tensor_f32(self._ctx, name.encode(), _fptr(v), v.size):
@@ -647,6 +662,27 @@ def t5_relative_position_buckets(q_len: int, k_len: int) -> np.ndarray:
     out = np.empty(q_len * k_len, dtype=np.int32)
     lib().sd_t5_relative_position_buckets(q_len, k_len, out.ctypes.data_as(C.c_void_p))
     return out.reshape(q_len, k_len)
+
+
+def rccl_unique_id() -> bytes:
+    """ncclGetUniqueId through the host library (librccl.so loaded with dlopen): the 128 bytes rank 0 ships to its partner(s)."""
+    buf = C.create_string_buffer(128)
+    if not lib().sd_rccl_get_unique_id(buf):
+        raise EngineError("sd_rccl_get_unique_id failed: " + lib().sd_rccl_last_error().decode())
+    return buf.raw
+
+
+def rccl_comm_create(device: int, nranks: int, rank: int, unique_id: bytes):
+    """ncclCommInitRank on HIP device `device`; returns the opaque communicator for Engine.set_pair_exchange_rccl."""
+    assert len(unique_id) == 128
+    comm = lib().sd_rccl_comm_create(int(device), int(nranks), int(rank), C.create_string_buffer(unique_id, 128))
+    if not comm:
+        raise EngineError("sd_rccl_comm_create failed: " + lib().sd_rccl_last_error().decode())
+    return comm
+
+
+def rccl_comm_destroy(comm) -> None:
+    lib().sd_rccl_comm_destroy(comm)
 
 
 def philox_randn(seed: int, offset: int, n: int) -> np.ndarray:

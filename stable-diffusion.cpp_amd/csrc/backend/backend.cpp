@@ -26,12 +26,6 @@
 #include "ktime.h"
 #include "planner.h"
 
-namespace mi355x {  // kernels/gemm16.hip
-void gemm16_timing_enable(bool on);
-void gemm16_timing_read(int64_t* launches, double* ms, double* flops);
-const char* gemm16_timing_kernel_name();
-}  // namespace mi355x
-
 namespace mi355x {
 
 #define HIP_OK(expr)                                                                                          \

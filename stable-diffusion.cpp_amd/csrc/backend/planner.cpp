@@ -247,6 +247,7 @@ struct Builder {
     // graph node instead of the current position; hm_grouping makes plan_linear hand its head-major GEMM over (hm_group) instead of emitting it
     int emit_redirect = -1;
     bool hm_grouping  = false;
+    bool hm_hoisting  = false;  // plan_hoisted_kv pre-pass: a head-major GEMM must be CAPTURED (never split, never emitted at the redirected position)
     struct HmLaunch {
         int node, out_node;        // the MUL_MAT and the last node of its chain
         float* dst;                // f32 head-major destination, or
@@ -733,7 +734,7 @@ void plan_linear(Builder& B, int i, hipStream_t s, std::vector<int>& chain) {
                 else
                     B.emit([=](hipStream_t st) { launch_gemm16_linear(st, nullptr, P->arena + qoff, 0, P->arena + off, ld, swz, tokens, K, M, M, ep, hd, hH, hL, sk.ws(P), sk.cnt(P), sk.S); });
             } else {
-                const Builder::Split sk = hL >= 32 ? B.plan_split(tokens, M, K, false, false) : Builder::Split();
+                const Builder::Split sk = (hL >= 32 && !B.hm_hoisting) ? B.plan_split(tokens, M, K, false, false) : Builder::Split();
                 if (groupable && sk.S <= 1)
                     B.hm_group.push_back(Builder::HmLaunch{i, last, f16o ? nullptr : (float*)hdst, f16o ? hdst : nullptr, 0, false, off, ld, swz, tokens, K, M, ep, hd, hH, hL});
                 else
@@ -901,16 +902,23 @@ void plan_hoisted_kv(Builder& B, hipStream_t s) {
             if (c1 - c0 < 2) break;  // a single left-over member: planned in place by the main walk
             B.hm_group.clear();
             B.hm_grouping = true;
+            B.hm_hoisting = true;  // the projection GEMM is captured (S = 1): nothing that writes a graph buffer may run at the redirected position
             for (size_t m = c0; m < c1; ++m) {
                 const int j = mem[m];
                 std::vector<int> cj;
                 B.emit_redirect = j;  // whatever this member emits besides its (captured) GEMM stays at its own position; the first one packs the context
                 if (m == c0) B.emit_redirect = j0;
+                const size_t before = B.hm_group.size();
                 plan_linear(B, j, s, cj);
                 B.emit_redirect = -1;
+                if (B.hm_group.size() != before + 1) {  // cannot happen for a bias-only K / V projection: fail loudly rather than corrupt a live buffer
+                    fprintf(stderr, "[ggml-mi355x] plan_hoisted_kv: projection at node %d was not captured\n", j);
+                    abort();
+                }
                 for (int c : cj) gi.done[c] = 1;
             }
             B.hm_grouping = false;
+            B.hm_hoisting = false;
             std::vector<Builder::HmLaunch> grp = B.hm_group;
             B.hm_group.clear();
             bool ok = grp.size() >= 2;
@@ -2190,6 +2198,7 @@ void planner_set_option(const char* key, int value) {
     else if (!strcmp(key, "flash_qb2")) flash_attn_set_qb2(value);
     else if (!strcmp(key, "conv3w")) conv3w_set(value);
     else if (!strcmp(key, "conv3w_min_blocks")) conv3w_set_min_blocks(value);
+    else if (!strcmp(key, "conv3w_min_blocks_deep")) conv3w_set_min_blocks_deep(value);
     else if (!strcmp(key, "gemm16_bn64")) gemm16_set_bn64(value);
     else if (!strcmp(key, "qgemm16")) g_opt.qgemm16 = value;
     else if (!strcmp(key, "qgemv_max_rows")) qgemv_set_max_rows(value);

@@ -1,0 +1,148 @@
+// rccl_exchange.cpp — the CFG-pair reduction as a NATIVE collective: one in-place ncclAllReduce (SUM, f32) of the engine's eps buffer per sampler
+// step, enqueued on the backend's HIP stream.  RCCL is loaded at run time with dlopen (librccl.so ships with ROCm; the host library has no
+// link-time dependency on it and none on torch).  This is the C++ counterpart of shard.make_pair_exchange (which goes through torch.distributed)
+// — north_star keeps the host C++.
+//
+// What is exchanged (src/runtime/guidance.cpp:149-179: guided = uncond + s * (cond - uncond)): the cond rank holds s * eps_cond, the uncond rank
+// (1 - s) * eps_uncond, so the SUM over the two ranks of a pair is the guided prediction; both ranks then take the same Euler(-A) update.
+// One [N, C, H, W] f32 buffer per step (64 KB per SD1.5 image, 1 MB per DiT image) over a single xGMI link.
+#include <dlfcn.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+
+#include "sd-mi355x.h"
+
+namespace {
+
+struct NcclUniqueId {  // ncclUniqueId (nccl.h): 128 opaque bytes, passed BY VALUE to ncclCommInitRank
+    char internal[128];
+};
+typedef void* NcclComm;
+typedef int (*fn_get_unique_id)(NcclUniqueId*);
+typedef int (*fn_comm_init_rank)(NcclComm*, int, NcclUniqueId, int);
+typedef int (*fn_all_reduce)(const void*, void*, size_t, int /*ncclDataType_t*/, int /*ncclRedOp_t*/, NcclComm, void* /*hipStream_t*/);
+typedef int (*fn_comm_destroy)(NcclComm);
+typedef const char* (*fn_error_string)(int);
+typedef int (*fn_hip_set_device)(int);
+constexpr int NCCL_FLOAT32 = 7, NCCL_SUM = 0;  // nccl.h enum values (ncclFloat32, ncclSum)
+
+struct Api {
+    void* h = nullptr;
+    fn_get_unique_id get_unique_id   = nullptr;
+    fn_comm_init_rank comm_init_rank = nullptr;
+    fn_all_reduce all_reduce         = nullptr;
+    fn_comm_destroy comm_destroy     = nullptr;
+    fn_error_string error_string     = nullptr;
+    fn_hip_set_device hip_set_device = nullptr;
+    bool ok                          = false;
+};
+std::mutex g_mu;
+Api g_api;
+thread_local std::string g_err;
+
+bool load_api() {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_api.ok) return true;
+    // a copy already resident in the process (torch bundles one) wins: two RCCL / HIP runtimes in one process do not share device state
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    void* h = nullptr;
+    for (const char* n : names)
+        if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD)) != nullptr) break;
+    if (!h)
+        for (const char* n : names)
+            if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL)) != nullptr) break;
+    if (!h) {
+        g_err = std::string("librccl.so not found: ") + (dlerror() ? dlerror() : "");
+        return false;
+    }
+    g_api.h              = h;
+    g_api.get_unique_id  = (fn_get_unique_id)dlsym(h, "ncclGetUniqueId");
+    g_api.comm_init_rank = (fn_comm_init_rank)dlsym(h, "ncclCommInitRank");
+    g_api.all_reduce     = (fn_all_reduce)dlsym(h, "ncclAllReduce");
+    g_api.comm_destroy   = (fn_comm_destroy)dlsym(h, "ncclCommDestroy");
+    g_api.error_string   = (fn_error_string)dlsym(h, "ncclGetErrorString");
+    g_api.hip_set_device = (fn_hip_set_device)dlsym(RTLD_DEFAULT, "hipSetDevice");  // the HIP runtime the backend plug-in brought in
+    if (!g_api.hip_set_device) {  // plug-ins are loaded RTLD_LOCAL: ask the resident runtime by name (never load a second one)
+        for (const char* n : {"libamdhip64.so.7", "libamdhip64.so.6", "libamdhip64.so"}) {
+            if (void* hh = dlopen(n, RTLD_NOW | RTLD_NOLOAD)) {
+                g_api.hip_set_device = (fn_hip_set_device)dlsym(hh, "hipSetDevice");
+                if (g_api.hip_set_device) break;
+            }
+        }
+    }
+    if (!g_api.get_unique_id || !g_api.comm_init_rank || !g_api.all_reduce || !g_api.comm_destroy) {
+        g_err = "librccl.so lacks ncclGetUniqueId / ncclCommInitRank / ncclAllReduce / ncclCommDestroy";
+        return false;
+    }
+    g_api.ok = true;
+    return true;
+}
+
+std::string nccl_err(int r) { return g_api.error_string ? g_api.error_string(r) : ("ncclResult_t " + std::to_string(r)); }
+
+// sd_pair_exchange_fn: user = the communicator
+bool rccl_exchange(void* device_eps, int64_t count, void* stream, void* user) {
+    if (!user || !stream || !g_api.ok) {
+        g_err = "native pair exchange needs a communicator and the backend's HIP stream (host backends have none)";
+        return false;
+    }
+    const int r = g_api.all_reduce(device_eps, device_eps, (size_t)count, NCCL_FLOAT32, NCCL_SUM, (NcclComm)user, stream);
+    if (r != 0) {
+        g_err = "ncclAllReduce: " + nccl_err(r);
+        return false;
+    }
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* sd_rccl_last_error(void) { return g_err.c_str(); }
+
+bool sd_rccl_get_unique_id(void* id128) {
+    if (!id128 || !load_api()) return false;
+    NcclUniqueId id;
+    const int r = g_api.get_unique_id(&id);
+    if (r != 0) {
+        g_err = "ncclGetUniqueId: " + nccl_err(r);
+        return false;
+    }
+    memcpy(id128, id.internal, sizeof(id.internal));
+    return true;
+}
+
+void* sd_rccl_comm_create(int device, int nranks, int rank, const void* id128) {
+    if (!id128 || !load_api()) return nullptr;
+    if (device >= 0 && g_api.hip_set_device) (void)g_api.hip_set_device(device);  // the communicator binds to the calling thread's current device
+    NcclUniqueId id;
+    memcpy(id.internal, id128, sizeof(id.internal));
+    NcclComm comm = nullptr;
+    const int r   = g_api.comm_init_rank(&comm, nranks, id, rank);
+    if (r != 0) {
+        g_err = "ncclCommInitRank: " + nccl_err(r);
+        return nullptr;
+    }
+    return comm;
+}
+
+void sd_rccl_comm_destroy(void* comm) {
+    if (comm && g_api.ok) (void)g_api.comm_destroy((NcclComm)comm);
+}
+
+bool sd_set_pair_exchange_rccl(sdm_ctx_t* ctx, void* comm, int branch) {
+    if (!ctx) return false;
+    if (!comm) {
+        sd_set_pair_exchange(ctx, nullptr, nullptr, 0);
+        return true;
+    }
+    if (!load_api()) return false;
+    sd_set_pair_exchange(ctx, rccl_exchange, comm, branch);
+    return true;
+}
+
+}  // extern "C"

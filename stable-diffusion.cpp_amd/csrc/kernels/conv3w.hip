@@ -41,7 +41,8 @@ struct C3Geom {
     static constexpr int BSTAGE = NF * 1024;
     static constexpr int NST    = 4;
     static constexpr int LDS    = 2 * WBUF + NST * BSTAGE;
-    static constexpr int RB1    = TW >= 64 ? 32 * 64 : PITCH * 64;  // byte distance of the wave's second 32-position block inside the window
+    // byte distance of the wave's second 32-position block inside the window: 32 pixels on (TW >= 64), one row down (TW = 32), two rows down (TW = 16)
+    static constexpr int RB1    = TW >= 64 ? 32 * 64 : (32 / TW) * PITCH * 64;
     static_assert(WBYTES % 1024 == 0 && PITCH % 16 == 0 && NWPW <= 5 && LDS <= 160 * 1024, "window geometry");
 };
 
@@ -121,12 +122,13 @@ __global__ __launch_bounds__(512, 2) void k_conv3w(G16Args g) {
     // ---- fragment read addresses.  A: one register per (kw, k-step): window pixel (oyl + kh, xb + (lane & 31) + kw), kh and the second row block are
     // immediates; B: lane-linear fragments of the current ring slot
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    const int oyl = TW >= 64 ? (wr * 64) / TW : wr * 2;           // first window row (before + kh) of this wave's positions
-    const int xb  = TW >= 64 ? (wr * 64) % TW : 0;
+    // this lane's output position inside the window (before the tap shift): a 32-position MFMA block is half a row (TW >= 64), a row (32) or two rows (16)
+    const int oyl = (wr * 64) / TW + (TW < 32 ? (lane & 31) / TW : 0);
+    const int xb  = TW >= 64 ? (wr * 64) % TW + (lane & 31) : (lane & 31) % TW;
     uint32_t aw[3];  // k-step 0; k-step 1 reads the slot with bit 1 flipped: address ^ 32 (the window base is 1-KiB aligned)
 #pragma unroll
     for (int kw = 0; kw < 3; ++kw) {
-        const int x = xb + (lane & 31) + kw;
+        const int x = xb + kw;
         aw[kw]      = lds0 + (uint32_t)((oyl * PITCH + x) * 64 + ((hi ^ ((x >> 2) & 3)) << 4));
     }
     const uint32_t bad0 = lds0 + (uint32_t)(2 * WBUF + wc * CB * 2 * 1024 + lane * 16);
@@ -293,25 +295,32 @@ __global__ __launch_bounds__(512, 2) void k_conv3w(G16Args g) {
 // ---- host side ---------------------------------------------------------------------------------------------------------------
 static int g_conv3w = 1;  // option "conv3w": 0 = every conv on the round-2 per-tap gather kernel (A/B measurements)
 void conv3w_set(int v) { g_conv3w = v; }
-static int g_conv3w_min_blocks = 6;  // option "conv3w_min_blocks": 32-channel blocks (9 stages each) a K slice must keep
+static int g_conv3w_min_blocks = 8, g_conv3w_min_blocks_deep = 5;  // options "conv3w_min_blocks" / "conv3w_min_blocks_deep": 32-channel blocks (9 stages each) a K slice keeps
 void conv3w_set_min_blocks(int v) { g_conv3w_min_blocks = v > 0 ? v : 1; }
+void conv3w_set_min_blocks_deep(int v) { g_conv3w_min_blocks_deep = v > 0 ? v : 1; }
 
-// Shapes the window kernel takes: 3x3, stride 1, no fused upsample, image width 32 / 64 / 128 with whole tiles of 256 positions per image,
+// Shapes the window kernel takes: 3x3, stride 1, no fused upsample, image width 16 / 32 / 64 / 128 with whole tiles of 256 positions per image,
 // OC a multiple of the column tile (320 or 256), a launch that fills the chip (with K slices over the 32-channel blocks where the output
 // alone does not).  Returns the number of K slices (>= 1), or 0 when the shape stays on the round-2 kernel.
 int conv3w_plan(int64_t W, int64_t H, int64_t IC, int64_t N, int64_t OC, int ksize, int stride, bool upscale2x, int* bn_out) {
     if (!g_conv3w || ksize != 3 || stride != 1 || upscale2x) return 0;
-    if (!(W == 32 || W == 64 || W == 128) || (H * W) % 256 != 0 || IC < 64) return 0;
+    if (!(W == 16 || W == 32 || W == 64 || W == 128) || (H * W) % 256 != 0 || IC < 64) return 0;
     if (N * H * W * ((IC + 63) / 64 * 64) * 2 >= (1ll << 32)) return 0;  // the window DMA keeps 32-bit byte offsets into the NHWC image
     const int bn = OC % 320 == 0 ? 320 : (OC % 256 == 0 ? 256 : 0);
     if (!bn) return 0;
     const int64_t tiles = (H * W * N / 256) * (OC / bn);
     const int64_t nicb  = (IC + 63) / 64 * 2;
     int S = 1;
-    if (tiles < 192) {  // one workgroup per CU: split K until ~256 workgroups
+    if (tiles < 192) {
+        // one workgroup per CU and too few tiles: K slices over the 32-channel blocks.  Every slice writes a whole f32 slab and a reduce pass reads
+        // them all, so a slice must keep real work (measured against the round-2 kernel, profiles/r04b_conv3w_check.txt): >= 8 blocks (72 stages) per
+        // slice wins 10-15 %; 5 blocks per slice lose 8-12 % at 128 tiles (320 -> 640 @32x32 x 16, 320 -> 320 @128x128 x 2) but win 15 % where
+        // the round-2 kernel is weakest (<= 64 tiles x 4 slices: 640 -> 640 @64x64 x 2)
         S = (int)(256 / tiles);
         if (S > 8) S = 8;
-        while (S > 1 && (nicb / S < g_conv3w_min_blocks || (S - 1) * ((nicb + S - 1) / S) >= nicb)) --S;  // every slice keeps a minimum of blocks, none is empty
+        const int64_t minb = tiles <= 64 ? g_conv3w_min_blocks_deep : g_conv3w_min_blocks;
+        if (tiles <= 64 && S > 4) S = 4;
+        while (S > 1 && (nicb / S < minb || (S - 1) * ((nicb + S - 1) / S) >= nicb)) --S;  // every slice keeps a minimum of blocks, none is empty
         if (tiles * S < 128) return 0;
     } else {
         const int64_t rounds = (tiles + 255) / 256;
@@ -377,11 +386,13 @@ void launch_conv3w(hipStream_t s, float* dst, const void* x16_nhwc, const void* 
     {
         KScope ks_(s, KF_CONV_T256, 2.0 * g.R * IC * 9 * OC, bytes);
         if (bn == 320) {
-            if (W == 32) c3_launch<32, 320>(s, g, tiles, (unsigned)S);
+            if (W == 16) c3_launch<16, 320>(s, g, tiles, (unsigned)S);
+            else if (W == 32) c3_launch<32, 320>(s, g, tiles, (unsigned)S);
             else if (W == 64) c3_launch<64, 320>(s, g, tiles, (unsigned)S);
             else c3_launch<128, 320>(s, g, tiles, (unsigned)S);
         } else {
-            if (W == 32) c3_launch<32, 256>(s, g, tiles, (unsigned)S);
+            if (W == 16) c3_launch<16, 256>(s, g, tiles, (unsigned)S);
+            else if (W == 32) c3_launch<32, 256>(s, g, tiles, (unsigned)S);
             else if (W == 64) c3_launch<64, 256>(s, g, tiles, (unsigned)S);
             else c3_launch<128, 256>(s, g, tiles, (unsigned)S);
         }

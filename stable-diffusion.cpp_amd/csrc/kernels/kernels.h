@@ -129,6 +129,7 @@ void launch_conv3w(hipStream_t s, float* dst, const void* x16_nhwc, const void* 
                    float* splitk_ws, int S);
 void conv3w_set(int v);  // option "conv3w"
 void conv3w_set_min_blocks(int v);  // option "conv3w_min_blocks"
+void conv3w_set_min_blocks_deep(int v);  // option "conv3w_min_blocks_deep"
 // producers of f16 operand images (row stride = K rounded up to 64, zero padded)
 // L > 0: rows are N runs of L rows, run n starting bs elements after run n-1 (a token slice of a [C, Lfull, N] tensor)
 void launch_pack_rows_f16(hipStream_t s, void* dst, const float* x, int64_t R, int64_t K, int64_t xs, int64_t L = 0, int64_t bs = 0);

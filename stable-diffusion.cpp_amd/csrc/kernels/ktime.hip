@@ -13,7 +13,7 @@
 namespace mi355x {
 namespace {
 const char* const kNames[KF_COUNT] = {
-    "conv implicit-GEMM, 256-row tiles (k_gemm16<256,*,true,...>)",
+    "conv implicit-GEMM, 256-row tiles (k_conv3w<*,*> LDS-window kernel / k_gemm16<256,*,true,...>)",
     "conv implicit-GEMM, 128-row tiles (k_gemm16<128,*,true,...>)",
     "Linear MFMA GEMM (k_gemm16<*,*,false,...>)",
     "flash attention (k_flash_attn)",
@@ -41,54 +41,88 @@ struct Rec {
 };
 std::atomic<uint32_t> g_mask{0};
 std::mutex g_mu;
-std::vector<std::pair<hipEvent_t, hipEvent_t>> g_pool;
-std::vector<Rec> g_recs;
+// events belong to the device that was current when they were created: pool and records are kept PER DEVICE (several backend instances may live in
+// one process, shard.generate_multi_device), and the record list is capped (nobody may be reading while timing stays enabled)
+constexpr int KT_MAX_DEV   = 16;
+constexpr size_t KT_MAX_REC = 1u << 20;
+struct DevState {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+    std::vector<Rec> recs;
+};
+DevState g_dev[KT_MAX_DEV];
 }  // namespace
 
 void ktime_enable(uint32_t fam_mask) {
     std::lock_guard<std::mutex> lk(g_mu);
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (int d = 0; d < KT_MAX_DEV; ++d) {
+        if (g_dev[d].recs.empty()) continue;
+        (void)hipSetDevice(d);
+        (void)hipDeviceSynchronize();
+        g_dev[d].recs.clear();
+    }
+    (void)hipSetDevice(cur);
     (void)hipDeviceSynchronize();
-    g_recs.clear();
     g_mask.store(fam_mask, std::memory_order_relaxed);
 }
 bool ktime_on(int fam) { return (g_mask.load(std::memory_order_relaxed) >> fam) & 1u; }
 
 KScope::KScope(hipStream_t stream, int fam, double flops, double bytes) : s(stream) {
     if (!ktime_on(fam)) return;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= KT_MAX_DEV) return;
     std::lock_guard<std::mutex> lk(g_mu);
-    if (g_recs.size() == g_pool.size()) {
+    DevState& D = g_dev[dev];
+    if (D.recs.size() >= KT_MAX_REC) return;  // full: further launches go untimed until the next read
+    if (D.recs.size() == D.pool.size()) {
         hipEvent_t a = nullptr, b = nullptr;
         if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
-        g_pool.emplace_back(a, b);
+        D.pool.emplace_back(a, b);
     }
-    const auto& ev = g_pool[g_recs.size()];
-    g_recs.push_back({ev.first, ev.second, fam, flops, bytes});
+    const auto& ev = D.pool[D.recs.size()];
+    D.recs.push_back({ev.first, ev.second, fam, flops, bytes});
     (void)hipEventRecord(ev.first, s);
     e1 = ev.second;
 }
 
 int ktime_read(KFamTiming* out, int cap, int* fam_index) {
     std::lock_guard<std::mutex> lk(g_mu);
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    struct Done {
+        int fam;
+        double flops, bytes;
+        float ms;
+    };
+    std::vector<Done> g_recs;  // the finished launches of every device (elapsed times are read while the events' device is current)
+    for (int d = 0; d < KT_MAX_DEV; ++d) {
+        if (g_dev[d].recs.empty()) continue;
+        (void)hipSetDevice(d);
+        (void)hipDeviceSynchronize();
+        for (const Rec& r : g_dev[d].recs) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) g_recs.push_back({r.fam, r.flops, r.bytes, ms});
+        }
+        g_dev[d].recs.clear();
+    }
+    (void)hipSetDevice(cur);
     (void)hipDeviceSynchronize();
     KFamTiming acc[KF_COUNT];
     for (int f = 0; f < KF_COUNT; ++f) acc[f] = {kNames[f], kBound[f], 0, 0.0, 0.0, 0.0};
-    for (const Rec& r : g_recs) {
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) continue;
+    for (const Done& r : g_recs) {
         acc[r.fam].launches++;
-        acc[r.fam].total_ms += ms;
+        acc[r.fam].total_ms += r.ms;
         acc[r.fam].total_flops += r.flops;
         acc[r.fam].total_bytes += r.bytes;
     }
     // MI355X_KTIME_DUMP=<file>: append one line per distinct (family, flops, bytes) launch shape — which shapes a family's time sits in
     if (const char* path = getenv("MI355X_KTIME_DUMP")) {
         std::map<std::tuple<int, double, double>, std::pair<int64_t, double>> shapes;
-        for (const Rec& r : g_recs) {
-            float ms = 0.f;
-            if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) continue;
+        for (const Done& r : g_recs) {
             auto& a = shapes[{r.fam, r.flops, r.bytes}];
             a.first++;
-            a.second += ms;
+            a.second += r.ms;
         }
         if (FILE* fp = fopen(path, "a")) {
             fprintf(fp, "# family | launches | us/launch | total ms | GFLOP/launch | MB/launch | TFLOP/s | GB/s\n");
@@ -101,7 +135,6 @@ int ktime_read(KFamTiming* out, int cap, int* fam_index) {
             fclose(fp);
         }
     }
-    g_recs.clear();
     int n = 0;
     for (int f = 0; f < KF_COUNT && n < cap; ++f)
         if (acc[f].launches > 0) {

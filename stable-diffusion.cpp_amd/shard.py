@@ -59,15 +59,24 @@ def make_pair_exchange(dist, group=None):
     import torch
 
     def exchange(ptr: int, count: int, stream) -> bool:
-        if dist.get_backend(group) == "nccl":
+        # The MI355X engine hands over a DEVICE address together with its (non-null) stream; host backends (the CPU oracle in the gloo tests)
+        # pass host memory and no stream.  The branch follows the pointer, not the process group's backend (a gloo group with GPU
+        # engines used to read the device pointer as host memory).
+        if stream:
             dev = torch.device("cuda", torch.cuda.current_device())
             t = torch.as_tensor(_DeviceF32(ptr, count), device=dev)
-            if stream:
-                with torch.cuda.stream(torch.cuda.ExternalStream(int(stream), device=dev)):
+            ext = torch.cuda.ExternalStream(int(stream), device=dev)
+            if dist.get_backend(group) == "nccl":
+                with torch.cuda.stream(ext):
                     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-            else:
-                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-                torch.cuda.synchronize()
+            else:  # no device collective in this group: stage through host memory, ordered on the engine's stream
+                with torch.cuda.stream(ext):
+                    h = t.to("cpu", non_blocking=False)
+                    dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+                    t.copy_(h)
+                ext.synchronize()
+        elif dist.get_backend(group) == "nccl":
+            raise RuntimeError("pair exchange: a host buffer cannot be reduced over an nccl (RCCL) group")
         else:
             a = np.ctypeslib.as_array((ctypes.c_float * count).from_address(ptr))
             dist.all_reduce(torch.from_numpy(a), op=dist.ReduceOp.SUM, group=group)
