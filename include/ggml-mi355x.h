@@ -118,6 +118,9 @@ GGML_MI355X_API void ggml_backend_mi355x_set_option(const char* key, int value);
 /* the hipStream_t every graph of this backend instance is enqueued on (graph_compute_async, set/get_tensor_async): a caller that touches a
  * tensor's device memory between two graphs (the CFG-pair all-reduce, sd_set_pair_exchange) orders its work on this stream */
 GGML_MI355X_API void* ggml_backend_mi355x_get_stream(ggml_backend_t backend);
+/* path of the HIP runtime library this plug-in is bound to, and hipSetDevice through it (for companions that must share its streams: RCCL) */
+GGML_MI355X_API const char* ggml_backend_mi355x_hip_library(void);
+GGML_MI355X_API int ggml_backend_mi355x_set_device(int hip_device);
 
 #ifdef __cplusplus
 }

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""Correctness + timing of the flash-attention kernel variants (option flash_qb2: 0 = one query block per wave, the round-2 kernel;
-1 = two query blocks per wave) on the attention shapes of the benchmarked configurations.  Correctness: sampled rows against the exact
+"""Correctness + timing of the flash-attention kernel variants (options flash_pp / flash_qb2: the round-2 kernel with one query block per
+wave, two query blocks per wave, the 8-wave ping-pong kernel) on the attention shapes of the benchmarked configurations.  Correctness: sampled rows against the exact
 softmax(QK^T / sqrt(d)) V in float64 on the f16-rounded K and V, and the two variants against each other.  Timing: HIP events around each
 dispatch (kernel_timing family 3)."""
 import sys
@@ -18,9 +18,8 @@ sd.load_mi355x_backend()
 L = sd.lib()
 rng = np.random.default_rng(0)
 REPS = 5
-OPTS = [("flash_qb2", 0), ("flash_qb2", 1)]
-if len(sys.argv) > 1:   # extra "key=value" option settings to time as further variants
-    OPTS += [tuple([kv.split("=")[0], int(kv.split("=")[1])]) for kv in sys.argv[1:]]
+# variants: the round-2 kernel (one query block per wave), two query blocks per wave, the 8-wave ping-pong kernel (the default policy)
+VARIANTS = [("r2", {"flash_pp": 0, "flash_qb2": 0}), ("qb2", {"flash_pp": 0, "flash_qb2": 1}), ("pp", {"flash_pp": 1, "flash_qb2": 1})]
 
 
 def rel_l2(a, b):
@@ -36,9 +35,9 @@ def case(label, d, Lq, Lk, HN):
     flops = 4.0 * Lq * Lk * d * HN
     outs = []
     line = f"{label:34s}"
-    for key, val in OPTS:
-        sd.backend_set_option("flash_qb2", 1)
-        sd.backend_set_option(key, val)
+    for name, opts in VARIANTS:
+        for key, val in opts.items():
+            sd.backend_set_option(key, val)
         with Graph("MI355X0") as g:
             node = L.ggml_flash_attn_ext(g.ctx, g.input(q), g.input(k, F16), g.input(v, F16), None, sc, 0.0, 0.0)
             out = g.run(node)
@@ -52,8 +51,9 @@ def case(label, d, Lq, Lk, HN):
             out2 = g.fetch(node)
         ms = sum(f["total_ms"] for f in t) / REPS
         outs.append(out)
-        line += f" | {key}={val}: {ms*1e3:8.1f} us {flops/ms/1e9:7.1f} TF{'' if np.array_equal(out, out2) else ' RERUN-DIFF'}"
-        sd.backend_set_option(key, 1 if key == "flash_qb2" else 0)
+        line += f" | {name}: {ms*1e3:8.1f} us {flops/ms/1e9:7.1f} TF{'' if np.array_equal(out, out2) else ' RERUN-DIFF'}"
+    sd.backend_set_option("flash_pp", 1)
+    sd.backend_set_option("flash_qb2", 1)
     k16, v16 = k.astype(np.float16).astype(np.float64), v.astype(np.float16).astype(np.float64)
     worst = 0.0
     r2 = np.random.default_rng(1)

@@ -22,6 +22,8 @@
 
 #include "ggml-abi.h"
 #include "ggml-abi-check.h"  // static_asserts: every layout fact of ggml's headers this backend was written against
+#include <dlfcn.h>
+
 #include "ggml-mi355x.h"
 #include "ktime.h"
 #include "planner.h"
@@ -274,6 +276,8 @@ static void* reg_get_proc(ggml_backend_reg_t, const char* name) {
     if (strcmp(name, "ggml_backend_mi355x_get_kernel_timings") == 0) return (void*)ggml_backend_mi355x_get_kernel_timings;
     if (strcmp(name, "ggml_backend_mi355x_kernel_timing_enable_mask") == 0) return (void*)ggml_backend_mi355x_kernel_timing_enable_mask;
     if (strcmp(name, "ggml_backend_mi355x_get_stream") == 0) return (void*)ggml_backend_mi355x_get_stream;
+    if (strcmp(name, "ggml_backend_mi355x_hip_library") == 0) return (void*)ggml_backend_mi355x_hip_library;
+    if (strcmp(name, "ggml_backend_mi355x_set_device") == 0) return (void*)ggml_backend_mi355x_set_device;
     return nullptr;
 }
 
@@ -369,6 +373,17 @@ GGML_MI355X_API void ggml_backend_mi355x_kernel_timing_enable_mask(uint32_t fami
 GGML_MI355X_API void* ggml_backend_mi355x_get_stream(ggml_backend_t backend) {
     return backend ? (void*)((mi355x::BackendCtx*)backend->context)->stream : nullptr;
 }
+// The HIP runtime THIS plug-in is bound to (a process may hold a second copy, e.g. the one a torch wheel bundles): a companion library that
+// must share streams with the backend — RCCL for the native CFG-pair exchange — is loaded from the same directory.
+GGML_MI355X_API const char* ggml_backend_mi355x_hip_library(void) {
+    static std::string path;
+    if (path.empty()) {
+        Dl_info info;
+        if (dladdr((void*)&hipGetDeviceCount, &info) && info.dli_fname) path = info.dli_fname;
+    }
+    return path.c_str();
+}
+GGML_MI355X_API int ggml_backend_mi355x_set_device(int hip_device) { return hipSetDevice(hip_device) == hipSuccess ? 0 : -1; }
 GGML_MI355X_API int ggml_backend_mi355x_get_kernel_timings(struct ggml_backend_mi355x_kernel_timing* out, int capacity) {
     mi355x::KFamTiming t[mi355x::KF_COUNT];
     int fam[mi355x::KF_COUNT];

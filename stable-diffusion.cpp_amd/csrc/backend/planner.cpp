@@ -2196,6 +2196,7 @@ void planner_set_option(const char* key, int value) {
     else if (!strcmp(key, "fuse_q16")) g_opt.fuse_q16 = value;
     else if (!strcmp(key, "flash_grid")) flash_attn_set_grid(value);
     else if (!strcmp(key, "flash_qb2")) flash_attn_set_qb2(value);
+    else if (!strcmp(key, "flash_pp")) flash_attn_set_pp(value);
     else if (!strcmp(key, "conv3w")) conv3w_set(value);
     else if (!strcmp(key, "conv3w_min_blocks")) conv3w_set_min_blocks(value);
     else if (!strcmp(key, "conv3w_min_blocks_deep")) conv3w_set_min_blocks_deep(value);

@@ -1,6 +1,6 @@
 // rccl_exchange.cpp — the CFG-pair reduction as a NATIVE collective: one in-place ncclAllReduce (SUM, f32) of the engine's eps buffer per sampler
-// step, enqueued on the backend's HIP stream.  RCCL is loaded at run time with dlopen (librccl.so ships with ROCm; the host library has no
-// link-time dependency on it and none on torch).  This is the C++ counterpart of shard.make_pair_exchange (which goes through torch.distributed)
+// step, enqueued on the backend's HIP stream.  RCCL is loaded at run time with dlopen from the directory of the HIP runtime the backend plug-in
+// is bound to (librccl.so ships with ROCm; the host library has no link-time dependency on it and none on torch).  This is the C++ counterpart of shard.make_pair_exchange (which goes through torch.distributed)
 // — north_star keeps the host C++.
 //
 // What is exchanged (src/runtime/guidance.cpp:149-179: guided = uncond + s * (cond - uncond)): the cond rank holds s * eps_cond, the uncond rank
@@ -14,6 +14,7 @@
 #include <mutex>
 #include <string>
 
+#include "ggml.h"
 #include "sd-mi355x.h"
 
 namespace {
@@ -47,16 +48,25 @@ thread_local std::string g_err;
 bool load_api() {
     std::lock_guard<std::mutex> lk(g_mu);
     if (g_api.ok) return true;
-    // a copy already resident in the process (torch bundles one) wins: two RCCL / HIP runtimes in one process do not share device state
-    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    // RCCL must sit on the SAME HIP runtime as the backend plug-in (its streams are handed to ncclAllReduce); a process may hold a second
+    // runtime + RCCL pair (the copies a torch wheel bundles).  The plug-in tells which runtime it is bound to; RCCL is taken from that directory.
+    typedef const char* (*fn_hip_library)(void);
+    ggml_backend_reg_t reg = ggml_backend_reg_by_name("MI355X");
+    fn_hip_library hl      = reg ? (fn_hip_library)ggml_backend_reg_get_proc_address(reg, "ggml_backend_mi355x_hip_library") : nullptr;
+    g_api.hip_set_device   = reg ? (fn_hip_set_device)ggml_backend_reg_get_proc_address(reg, "ggml_backend_mi355x_set_device") : nullptr;
+    if (!hl) {
+        g_err = "the MI355X backend plug-in is not loaded (sd_load_backend first)";
+        return false;
+    }
+    std::string dir = hl();
+    const size_t sl = dir.rfind('/');
+    dir             = sl == std::string::npos ? std::string() : dir.substr(0, sl + 1);
     void* h = nullptr;
-    for (const char* n : names)
-        if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD)) != nullptr) break;
-    if (!h)
-        for (const char* n : names)
-            if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL)) != nullptr) break;
+    for (const char* n : {"librccl.so.1", "librccl.so"})
+        if ((h = dlopen((dir + n).c_str(), RTLD_NOW | RTLD_LOCAL)) != nullptr) break;
     if (!h) {
-        g_err = std::string("librccl.so not found: ") + (dlerror() ? dlerror() : "");
+        const char* e = dlerror();
+        g_err         = "librccl.so not found next to " + std::string(hl()) + ": " + (e ? e : "");
         return false;
     }
     g_api.h              = h;
@@ -65,15 +75,6 @@ bool load_api() {
     g_api.all_reduce     = (fn_all_reduce)dlsym(h, "ncclAllReduce");
     g_api.comm_destroy   = (fn_comm_destroy)dlsym(h, "ncclCommDestroy");
     g_api.error_string   = (fn_error_string)dlsym(h, "ncclGetErrorString");
-    g_api.hip_set_device = (fn_hip_set_device)dlsym(RTLD_DEFAULT, "hipSetDevice");  // the HIP runtime the backend plug-in brought in
-    if (!g_api.hip_set_device) {  // plug-ins are loaded RTLD_LOCAL: ask the resident runtime by name (never load a second one)
-        for (const char* n : {"libamdhip64.so.7", "libamdhip64.so.6", "libamdhip64.so"}) {
-            if (void* hh = dlopen(n, RTLD_NOW | RTLD_NOLOAD)) {
-                g_api.hip_set_device = (fn_hip_set_device)dlsym(hh, "hipSetDevice");
-                if (g_api.hip_set_device) break;
-            }
-        }
-    }
     if (!g_api.get_unique_id || !g_api.comm_init_rank || !g_api.all_reduce || !g_api.comm_destroy) {
         g_err = "librccl.so lacks ncclGetUniqueId / ncclCommInitRank / ncclAllReduce / ncclCommDestroy";
         return false;

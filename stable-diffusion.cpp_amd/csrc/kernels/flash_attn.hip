@@ -497,6 +497,369 @@ __global__ __launch_bounds__(256, QB == 2 ? (DKP <= 96 ? 2 : 1) : (DKP <= 64 ? F
     }
 }
 
+// =====================================================================================================================================
+// k_flash_pp — the PING-PONG kernel (round 3).  Why: in k_flash_attn every wave runs QK^T (MFMA) -> softmax (VALU) -> PV (MFMA) as one dependent
+// chain and all four waves of a workgroup move through those phases together; the counters (profiles/r03c_pmc_flash.txt) show the consequence:
+// matrix-pipe time + VALU time + LDS time add up to the whole kernel — the two pipes hardly ever work at the same moment.  Two query blocks per
+// wave (QB = 2 above) gave 6 %.  Here a workgroup has EIGHT waves = two groups of four (waves w and w + 4 share a SIMD) whose tile loops are
+// offset by half an iteration and kept there by the workgroup barrier: while group X issues the MFMAs of its tile (S(t) = K(t) Q^T and
+// O += P(t-1) V(t-1), back to back, operands in LDS / registers), group Y does its VALU half (softmax of S -> P, the staging of the next K / V
+// half-tiles, the next global loads), then they swap.  On every SIMD one wave feeds the matrix pipe while its partner feeds the VALU — by
+// construction, not by luck.  The PV product is software-pipelined one tile behind QK^T, so a wave's MFMA phase never waits for its own softmax.
+//
+//   phase p:   even p: X = MFMA(t = p/2),     Y = VALU(t = p/2 - 1)  (+ staging)        one s_barrier at the end of every phase
+//              odd  p: X = VALU(t = (p-1)/2), Y = MFMA(t = (p-1)/2)
+// Staging: the group in its VALU phase stages one HALF (X: keys 32..63, Y: keys 0..31) of K(p/2 + 1) and of V(p/2) from registers loaded two
+// phases earlier (T14 split), K and V double-buffered.  Life times (T = tile): K(T) is written in phases 2T-2, 2T-1 and read in 2T, 2T+1;
+// V(T) is written in 2T, 2T+1 and read in 2T+2, 2T+3; the buffer it replaces (T-2) was last read in phase 2T-1 resp. 2T-3.
+// Per query the arithmetic and its order are those of k_flash_attn (same MFMA shapes, deferred max, max slot, ones column): results are bit-identical.
+template <int DKP, int NDV, bool MSLOT>
+__global__ __launch_bounds__(512, 2) void k_flash_pp(FAArgs g) {
+    constexpr int KS     = DKP / 16;
+    constexpr int KROW   = DKP + 8;
+    constexpr int DCH    = DKP / 8;
+    constexpr int TILE_H = FA_KT * KROW + NDV * 32 * FA_VTS;
+    constexpr int NCHP   = (32 * DCH + 255) / 256;  // chunks per thread per staging phase (half a tile by 256 threads; K and V each)
+    constexpr int QWG    = 256;
+    __shared__ __attribute__((aligned(16))) _Float16 smem[2 * TILE_H];
+    _Float16* Ks = smem;
+    _Float16* Vt = smem + FA_KT * KROW;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp  = wave >> 2;  // 0: group X (MFMA in even phases), 1: group Y
+    const int hi   = lane >> 5;
+    const int tg   = threadIdx.x & 255;  // thread index inside its group (staging)
+    int hn, qb;
+    if (g.grp > 0) {
+        const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
+        const int h = j % g.grp, unit = (j / g.grp) * 8 + xcd;
+        if (unit >= g.units) return;
+        const int nrb = (g.Lq + QWG - 1) / QWG;
+        hn = (unit / nrb) * g.grp + h;
+        qb = unit % nrb;
+    } else {
+        hn = blockIdx.y;
+        qb = blockIdx.x;
+    }
+    const int q0 = qb * QWG + wave * 32;
+    const int qi = q0 + (lane & 31);
+
+    // ---- Q fragments (as k_flash_attn): f16 image or f32 rows through LDS, or per-lane reads
+    half8_t qf[KS];
+    if (g.q_f16 || g.q_vec) {
+        constexpr int QROW = DKP + 4;
+        static_assert(QWG * QROW <= 2 * TILE_H, "Q staging must fit the K/V tile buffers");
+        const char* qblk = g.q + (int64_t)hn * g.q_nb2 + (int64_t)(qb * QWG) * g.q_nb1;
+        if (g.q_f16) {
+            constexpr int C8 = DKP / 8;
+            for (int e = threadIdx.x; e < QWG * C8; e += 512) {
+                const int row = e / C8, c8 = e - row * C8;
+                half8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (qb * QWG + row < g.Lq && c8 * 8 < g.D) v = *(const half8_t*)(qblk + (int64_t)row * g.q_nb1 + c8 * 16);
+                half4_t a, b;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    a[j] = (_Float16)((float)v[j] * g.scale_log2e);
+                    b[j] = (_Float16)((float)v[4 + j] * g.scale_log2e);
+                }
+                *(half4_t*)&smem[row * QROW + c8 * 8]     = a;
+                *(half4_t*)&smem[row * QROW + c8 * 8 + 4] = b;
+            }
+        } else {
+            constexpr int C4 = DKP / 4;
+            for (int e = threadIdx.x; e < QWG * C4; e += 512) {
+                const int row = e / C4, c4 = e - row * C4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (qb * QWG + row < g.Lq && c4 * 4 < g.D) v = *(const float4*)(qblk + (int64_t)row * g.q_nb1 + c4 * 16);
+                half4_t h;
+                h[0] = (_Float16)(v.x * g.scale_log2e);
+                h[1] = (_Float16)(v.y * g.scale_log2e);
+                h[2] = (_Float16)(v.z * g.scale_log2e);
+                h[3] = (_Float16)(v.w * g.scale_log2e);
+                *(half4_t*)&smem[row * QROW + c4 * 4] = h;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const _Float16* p = &smem[(wave * 32 + (lane & 31)) * QROW + ks * 16 + hi * 8];
+            const half4_t a = *(const half4_t*)p, c = *(const half4_t*)(p + 4);
+            qf[ks] = (half8_t){a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]};
+        }
+        __syncthreads();
+    } else {
+        const float* qrow = (const float*)(g.q + (int64_t)min(qi, g.Lq - 1) * g.q_nb1 + (int64_t)hn * g.q_nb2);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int d = ks * 16 + hi * 8 + j;
+                qf[ks][j]   = (_Float16)((d < g.D && qi < g.Lq) ? qrow[d] * g.scale_log2e : 0.f);
+            }
+    }
+
+    float16_t o[NDV];
+#pragma unroll
+    for (int nb = 0; nb < NDV; ++nb) o[nb] = (float16_t){0};
+    float m_run = MSLOT ? 0.f : -INFINITY, l_run = 0.f;
+
+    const char* kbase = g.k + (int64_t)hn * g.k_nb2;
+    const char* vbase = g.v + (int64_t)hn * g.v_nb2;
+    const int nd8           = g.D / 8;
+    const bool has_ones     = g.DV < NDV * 32 && g.D == g.DV && g.D % 8 == 0;
+    const bool ones_in_tile = has_ones && g.DV < DKP;
+    const int NT            = (g.Lk + FA_KT - 1) / FA_KT;
+
+    // ---- staging of this group's half tiles: thread tg handles chunks e = tg + 256 c of the 32 keys [32 * half, 32 * half + 32)
+    const int half = grp == 0 ? 1 : 0;
+    half8_t kreg[NCHP], vreg[NCHP];
+    uint32_t koff[NCHP], voff[NCHP];
+    int kkey[NCHP], vkey_[NCHP];  // key inside the TILE, or FA_KT (never valid)
+    bool kone[NCHP], vone[NCHP], live[NCHP];
+#pragma unroll
+    for (int c = 0; c < NCHP; ++c) {
+        const int e   = tg + c * 256;
+        const int key = 32 * half + e / DCH, ch = e % DCH;
+        const int vkey = 32 * half + (e & 31), vch = e >> 5;
+        live[c]  = e < 32 * DCH;
+        koff[c]  = (uint32_t)key * (uint32_t)g.k_nb1 + (uint32_t)ch * 16u;
+        voff[c]  = (uint32_t)vkey * (uint32_t)g.v_nb1 + (uint32_t)vch * 16u;
+        kkey[c]  = (live[c] && ch < nd8) ? key : FA_KT;
+        kone[c]  = live[c] && ch == nd8;
+        vkey_[c] = (live[c] && vch < nd8) ? vkey : FA_KT;
+        vone[c]  = live[c] && ones_in_tile && vch == nd8;
+    }
+    // registers <- global: K half of tile tk, V half of tile tv (either may lie beyond the last tile: skipped)
+    auto gload = [&](int tk, int tv) {
+        if (tk < NT) {
+            const char* kb = kbase + (int64_t)tk * FA_KT * g.k_nb1;
+            const int left = g.Lk - tk * FA_KT;
+#pragma unroll
+            for (int c = 0; c < NCHP; ++c) {
+                half8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+                kreg[c]   = z;
+                if (kkey[c] < left) kreg[c] = *(const half8_t*)(kb + koff[c]);
+                if (MSLOT && kone[c]) kreg[c][0] = (_Float16)1.0f;
+            }
+        }
+        if (tv < NT) {
+            const char* vb = vbase + (int64_t)tv * FA_KT * g.v_nb1;
+            const int left = g.Lk - tv * FA_KT;
+#pragma unroll
+            for (int c = 0; c < NCHP; ++c) {
+                half8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+                vreg[c]   = z;
+                if (vkey_[c] < left) vreg[c] = *(const half8_t*)(vb + voff[c]);
+                if (vone[c]) vreg[c][0] = (_Float16)1.0f;
+            }
+        }
+    };
+    // LDS <- registers: the halves loaded by the last gload(tk, tv)
+    auto lstore = [&](int tk, int tv) {
+        if (tk < NT) {
+            _Float16* ks = Ks + (tk & 1) * TILE_H;
+#pragma unroll
+            for (int c = 0; c < NCHP; ++c)
+                if (live[c]) {
+                    const int e = tg + c * 256;
+                    *(half8_t*)&ks[(32 * half + e / DCH) * KROW + (e % DCH) * 8] = kreg[c];
+                }
+        }
+        if (tv < NT) {
+            _Float16* vt = Vt + (tv & 1) * TILE_H;
+#pragma unroll
+            for (int c = 0; c < NCHP; ++c)
+                if (live[c]) {
+                    const int e = tg + c * 256;
+                    const int vkey = 32 * half + (e & 31), vch = e >> 5;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) vt[(vch * 8 + j) * FA_VTS + vkey] = vreg[c][j];
+                }
+        }
+    };
+
+    // ---- prologue (all 512 threads): clear the never-staged V^T rows, the ones row where it sits beyond the staged rows, K(0) in full
+    for (int b = 0; b < 2; ++b)
+        for (int e = threadIdx.x; e < NDV * 32 * FA_VTS / 2; e += 512) ((uint32_t*)(Vt + b * TILE_H))[e] = 0u;
+    __syncthreads();
+    if (has_ones && !ones_in_tile && threadIdx.x < FA_KT * 2) Vt[(threadIdx.x >> 6) * TILE_H + g.DV * FA_VTS + (threadIdx.x & 63)] = (_Float16)1.0f;
+    for (int e = threadIdx.x; e < FA_KT * DCH; e += 512) {
+        const int key = e / DCH, ch = e - key * DCH;
+        half8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (key < g.Lk && ch < nd8) v = *(const half8_t*)(kbase + (int64_t)key * g.k_nb1 + ch * 16);
+        if (MSLOT && ch == nd8) v[0] = (_Float16)1.0f;
+        *(half8_t*)&Ks[key * KROW + ch * 8] = v;
+    }
+    gload(1, 0);  // what this group stages in its first VALU(-like) phase
+    __syncthreads();
+
+    // ---- the two phase bodies
+    float16_t s[2];
+    half8_t pa[4];
+    // MFMA phase of tile t: S = K(t) Q^T (do_qk) and O += P(t-1) V(t-1) (do_pv)
+    auto mphase = [&](int t, bool do_qk, bool do_pv) {
+        if (do_qk) {
+            const _Float16* Kc = Ks + (t & 1) * TILE_H;
+            if constexpr (KS <= 6) {
+                half8_t kf[2][KS];
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) kf[kb][ks] = *(const half8_t*)&Kc[(kb * 32 + (lane & 31)) * KROW + ks * 16 + hi * 8];
+                s[0] = (float16_t){0};
+                s[1] = (float16_t){0};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb) s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kb][ks], qf[ks], s[kb], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    s[kb] = (float16_t){0};
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        const half8_t kf = *(const half8_t*)&Kc[(kb * 32 + (lane & 31)) * KROW + ks * 16 + hi * 8];
+                        s[kb]            = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[kb], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (do_pv) {
+            const _Float16* Vc = Vt + ((t - 1) & 1) * TILE_H;
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                for (int nb = 0; nb < NDV; ++nb) {
+                    const _Float16* vrow = &Vc[(nb * 32 + (lane & 31)) * FA_VTS + tt * 16 + 4 * hi];
+                    const half4_t v0 = *(const half4_t*)vrow, v1 = *(const half4_t*)(vrow + 8);
+                    const half8_t vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    o[nb]            = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa[tt], vf, o[nb], 0, 0, 0);
+                }
+        }
+    };
+    // VALU phase of tile t: online softmax of S(t) -> P(t) in f16 (the A operand of the next PV), running max / sum, rare rescale of O
+    auto vphase = [&](int t) {
+        const int kt = t * FA_KT;
+        if (kt + FA_KT > g.Lk) {  // ragged last tile: mask keys >= Lk
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (kt + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= g.Lk) s[kb][r] = -INFINITY;
+        }
+        float tmax = s[0][0];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tmax = __builtin_fmaxf(__builtin_fmaxf(tmax, s[0][r]), s[1][r]);
+        if (MSLOT ? (t == 0 || __any(tmax > FA_THR)) : __any(tmax > m_run + FA_THR)) {
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            float alpha;
+            if constexpr (MSLOT) {
+                const float m_new = fminf((float)(_Float16)fminf(m_run + (t == 0 ? tmax : fmaxf(tmax, 0.f)), 65504.f), 65504.f);
+                const float delta = m_new - m_run;
+                alpha             = __builtin_amdgcn_exp2f(-delta);
+                m_run             = m_new;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[kb][r] -= delta;
+                if (hi) qf[KS - 1][0] = (_Float16)(-m_new);
+            } else {
+                const float m_new = fmaxf(m_run, tmax);
+                alpha             = __builtin_amdgcn_exp2f(m_run - m_new);
+                m_run             = m_new;
+            }
+            l_run *= alpha;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row  = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const float ar = __shfl(alpha, row, 64);
+#pragma unroll
+                for (int nb = 0; nb < NDV; ++nb) o[nb][r] *= ar;
+            }
+        }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kb][r] = __builtin_amdgcn_exp2f(MSLOT ? s[kb][r] : s[kb][r] - m_run);
+        if (!has_ones) {
+            float psum = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) psum += s[kb][r];
+            l_run += psum;
+        }
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            const int kb = tt >> 1, rb = (tt & 1) * 8;
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+                const half2_t h2 = __builtin_convertvector((float2_t){s[kb][rb + j], s[kb][rb + j + 1]}, half2_t);
+                pa[tt][j]     = h2[0];
+                pa[tt][j + 1] = h2[1];
+            }
+        }
+    };
+
+    // ---- the two group programs (2 NT barriers each; see the phase table above)
+    if (grp == 0) {
+        for (int t = 0; t < NT; ++t) {
+            mphase(t, true, t > 0);   // phase 2t
+            __syncthreads();
+            lstore(t + 1, t);         // phase 2t + 1: K(t+1), V(t) halves
+            gload(t + 2, t + 1);
+            vphase(t);
+            __syncthreads();
+        }
+        mphase(NT, false, true);      // phase 2 NT: the last PV
+    } else {
+        lstore(1, 0);                 // phase 0: staging only
+        gload(2, 1);
+        __syncthreads();
+        for (int t = 0; t < NT; ++t) {
+            mphase(t, true, t > 0);   // phase 2t + 1
+            __syncthreads();
+            lstore(t + 2, t + 1);     // phase 2t + 2
+            gload(t + 3, t + 2);
+            vphase(t);
+            if (t + 1 < NT) __syncthreads();
+        }
+        mphase(NT, false, true);      // phase 2 NT + 1
+    }
+
+    // ---- finalise (as k_flash_attn)
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv   = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    const int nb_l = g.DV >> 5, lane_l = (g.DV & 31) + 32 * hi;
+    const int hh = g.H > 0 ? hn % g.H : hn, nn = g.H > 0 ? hn / g.H : 0;
+    char* obase       = g.dst ? (char*)g.dst + (int64_t)hh * g.dst_nb_h + (int64_t)nn * g.dst_nb_n : nullptr;
+    _Float16* obase16 = g.dst16 ? g.dst16 + (int64_t)nn * g.Lq * g.ld16 + (int64_t)hh * g.DV : nullptr;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float ir      = __shfl(inv, row, 64);
+        if (has_ones) {
+            float lsum = 0.f;
+#pragma unroll
+            for (int nb = 0; nb < NDV; ++nb)
+                if (nb == nb_l) lsum = o[nb][r];
+            lsum = __shfl(lsum, lane_l, 64);
+            ir   = lsum > 0.f ? 1.0f / lsum : 0.f;
+        }
+        const int q = q0 + row;
+        if (q >= g.Lq) continue;
+#pragma unroll
+        for (int nb = 0; nb < NDV; ++nb) {
+            const int d = nb * 32 + (lane & 31);
+            if (d >= g.DV) continue;
+            const float val = o[nb][r] * ir;
+            if (obase) *(float*)(obase + (int64_t)q * g.dst_nb_q + d * 4) = val;
+            if (obase16) obase16[(int64_t)q * g.ld16 + d] = (_Float16)val;
+        }
+    }
+}
+
 bool flash_attn_supported(int64_t D, int64_t DV) { return D == DV && D >= 8 && D <= 160; }
 
 #ifdef MI355X_EXPERIMENTS  // wrong-result timing ablations: never part of the shipped library (build with -DMI355X_EXPERIMENTS)
@@ -510,6 +873,8 @@ static int g_flash_grid = 1;  // option "flash_grid": 0 = plain (query block, he
 void flash_attn_set_grid(int v) { g_flash_grid = v; }
 static int g_flash_qb2 = 1;  // option "flash_qb2": 0 = one query block per wave everywhere (the round-2 kernel; A/B measurements)
 void flash_attn_set_qb2(int v) { g_flash_qb2 = v; }
+static int g_flash_pp = 1;  // option "flash_pp": 0 = never the ping-pong kernel (A/B measurements)
+void flash_attn_set_pp(int v) { g_flash_pp = v; }
 
 void launch_flash_attn(hipStream_t s, const FlashOut& out, const View4& q, const View4& k, const View4& v, float scale) {
     KScope ks_(s, KF_FLASH, 4.0 * (double)q.ne[1] * (double)k.ne[1] * (double)q.ne[2] * (double)q.ne[0], 0.0);  // 4 * Lq * Lk * (H*N) * d
@@ -550,8 +915,9 @@ void launch_flash_attn(hipStream_t s, const FlashOut& out, const View4& q, const
     const bool fast = g.vec_ok && g.kv_f16 && v.nb[0] == 2 && k.nb[0] == 2 && g.D == g.DV;
     // two query blocks per wave (256 queries per workgroup) when the launch still gives every CU two workgroups' worth of work
     const int64_t wg256 = ((int64_t)(g.Lq + 255) / 256) * q.ne[2];
-    const bool qb2      = g_flash_qb2 && fast && D <= 64 && g.Lq >= 192 && wg256 >= 256;  // d = 80, 96: 256 VGPRs do not hold two blocks without spills
-    const int QWG       = qb2 ? 256 : 128;
+    const bool pp       = g_flash_pp && fast && D <= 128 && g.Lq >= 192 && wg256 >= 256;  // the ping-pong kernel: 8 waves = 256 queries per workgroup (d = 160 spills)
+    const bool qb2      = !pp && g_flash_qb2 && fast && D <= 64 && g.Lq >= 192 && wg256 >= 256;  // d = 80, 96: 256 VGPRs do not hold two blocks without spills
+    const int QWG       = (qb2 || pp) ? 256 : 128;
     dim3 grid((unsigned)((g.Lq + QWG - 1) / QWG), (unsigned)q.ne[2]);
     g.grp = g.units = 0;
     if (g_flash_grid && out.H > 0 && q.ne[2] % out.H == 0) {
@@ -576,6 +942,21 @@ void launch_flash_attn(hipStream_t s, const FlashOut& out, const View4& q, const
         return;
     }
 #endif
+    if (pp) {
+        if (D == 40 && g_flash_mslot)
+            k_flash_pp<48, 2, true><<<grid, 512, 0, s>>>(g);
+        else if (D <= 48)
+            k_flash_pp<48, 2, false><<<grid, 512, 0, s>>>(g);
+        else if (D <= 64)
+            k_flash_pp<64, 2, false><<<grid, 512, 0, s>>>(g);
+        else if (D <= 80)
+            k_flash_pp<80, 3, false><<<grid, 512, 0, s>>>(g);
+        else if (D <= 96)
+            k_flash_pp<96, 3, false><<<grid, 512, 0, s>>>(g);
+        else
+            k_flash_pp<128, 4, false><<<grid, 512, 0, s>>>(g);
+        return;
+    }
     if (qb2) {
         if (D == 40 && g_flash_mslot)
             k_flash_attn<48, 2, true, 0, true, 2><<<grid, 256, 0, s>>>(g);

@@ -119,6 +119,28 @@ def rccl_in_place():
         dist.destroy_process_group()
 
 
+def rccl_native():
+    """The C++ exchange (csrc/host/rccl_exchange.cpp: dlopen'ed librccl, ncclAllReduce on the backend stream, no torch.distributed) on a one-rank
+    communicator: the all-reduce is the identity, so the trajectory equals the one with a no-op exchange bit for bit — and the call count /
+    buffer are the engine's own."""
+    cond, uncond = conds(13)
+    eng = sd.Engine(model=sd.SD15_TINY, backend=GPU)
+
+    def noop(ptr, count, stream):
+        return True
+
+    a = shard.sample_cfg_pair_split(eng, cond, uncond, dist=None, rank_in_pair=0, batch=1, exchange=noop, **KW)
+    comm = sd.rccl_comm_create(0, 1, 0, sd.rccl_unique_id())
+    try:
+        eng.set_pair_exchange_rccl(comm, 0)
+        b = eng.sample_latents(cond, uncond, batch=1, device_batch=1, method=sd.EULER_A, device_sampler=True, **KW)
+    finally:
+        eng.set_pair_exchange_rccl(None)
+        sd.rccl_comm_destroy(comm)
+    np.testing.assert_array_equal(a, b)
+    assert np.isfinite(a).all() and float(np.abs(a).max()) > 0
+
+
 def multi_device():
     cond, uncond = conds(14)
     engines = [sd.Engine(model=sd.SD15_TINY, backend=GPU) for _ in range(2)]
@@ -129,5 +151,6 @@ def multi_device():
         assert rel_l2(res[b], ref[b]) < 2e-3
 
 
-{"pair_a": lambda: pair_split(True), "pair_e": lambda: pair_split(False), "rccl": rccl_in_place, "multi": multi_device}[sys.argv[1]]()
+{"pair_a": lambda: pair_split(True), "pair_e": lambda: pair_split(False), "rccl": rccl_in_place, "rccl_native": rccl_native,
+ "multi": multi_device}[sys.argv[1]]()
 print("OK")

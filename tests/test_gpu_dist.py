@@ -44,6 +44,14 @@ def test_cfg_pair_exchange_is_an_in_place_rccl_all_reduce(sd, gpu):
     _run("rccl")
 
 
+def test_cfg_pair_exchange_native_rccl_from_cpp(sd, gpu):
+    """sd_set_pair_exchange_rccl: the exchange issued from C++ (librccl.so loaded with dlopen next to the plug-in's HIP runtime, ncclAllReduce on the
+    backend stream; replaces guidance.cpp:149-179 when cond / uncond sit on two GPUs) — one-rank communicator, bit-identical to a no-op exchange."""
+    if os.environ.get("SDCPP_GPU_TESTS_ON_ORACLE"):
+        pytest.skip("RCCL needs the GPU")
+    _run("rccl_native")
+
+
 def test_one_process_two_backend_instances(sd, gpu):
     """shard.generate_multi_device: two contexts, each running its contiguous share of five images on its own thread, equal the single-context
     batch image by image."""
