@@ -2197,6 +2197,7 @@ void planner_set_option(const char* key, int value) {
     else if (!strcmp(key, "flash_grid")) flash_attn_set_grid(value);
     else if (!strcmp(key, "flash_qb2")) flash_attn_set_qb2(value);
     else if (!strcmp(key, "flash_pp")) flash_attn_set_pp(value);
+    else if (!strcmp(key, "flash_pp_min_tiles")) flash_attn_set_pp_min_tiles(value);
     else if (!strcmp(key, "conv3w")) conv3w_set(value);
     else if (!strcmp(key, "conv3w_min_blocks")) conv3w_set_min_blocks(value);
     else if (!strcmp(key, "conv3w_min_blocks_deep")) conv3w_set_min_blocks_deep(value);

@@ -509,8 +509,8 @@ __global__ __launch_bounds__(256, QB == 2 ? (DKP <= 96 ? 2 : 1) : (DKP <= 64 ? F
 //
 //   phase p:   even p: X = MFMA(t = p/2),     Y = VALU(t = p/2 - 1)  (+ staging)        one s_barrier at the end of every phase
 //              odd  p: X = VALU(t = (p-1)/2), Y = MFMA(t = (p-1)/2)
-// Staging: the group in its VALU phase stages one HALF (X: keys 32..63, Y: keys 0..31) of K(p/2 + 1) and of V(p/2) from registers loaded two
-// phases earlier (T14 split), K and V double-buffered.  Life times (T = tile): K(T) is written in phases 2T-2, 2T-1 and read in 2T, 2T+1;
+// Staging: the group in its VALU phase stages one HALF (X: keys 32..63, Y: keys 0..31) of K(p/2 + 1) and of V(p/2) from registers loaded FOUR
+// phases earlier (T14 split, two register sets), K and V double-buffered in LDS.  Life times (T = tile): K(T) is written in phases 2T-2, 2T-1 and read in 2T, 2T+1;
 // V(T) is written in 2T, 2T+1 and read in 2T+2, 2T+3; the buffer it replaces (T-2) was last read in phase 2T-1 resp. 2T-3.
 // Per query the arithmetic and its order are those of k_flash_attn (same MFMA shapes, deferred max, max slot, ones column): results are bit-identical.
 template <int DKP, int NDV, bool MSLOT>
@@ -613,7 +613,9 @@ __global__ __launch_bounds__(512, 2) void k_flash_pp(FAArgs g) {
 
     // ---- staging of this group's half tiles: thread tg handles chunks e = tg + 256 c of the 32 keys [32 * half, 32 * half + 32)
     const int half = grp == 0 ? 1 : 0;
-    half8_t kreg[NCHP], vreg[NCHP];
+    // two register sets: the loads of staging step n are consumed at step n + 2 = FOUR phases later (with one set / two phases the kernel waited for
+    // its global loads in every VALU phase: 68 % of the wave cycles parked, profiles/r04c_pmc_flash_pp.txt)
+    half8_t kregA[NCHP], vregA[NCHP], kregB[NCHP], vregB[NCHP];
     uint32_t koff[NCHP], voff[NCHP];
     int kkey[NCHP], vkey_[NCHP];  // key inside the TILE, or FA_KT (never valid)
     bool kone[NCHP], vone[NCHP], live[NCHP];
@@ -630,54 +632,64 @@ __global__ __launch_bounds__(512, 2) void k_flash_pp(FAArgs g) {
         vkey_[c] = (live[c] && vch < nd8) ? vkey : FA_KT;
         vone[c]  = live[c] && ones_in_tile && vch == nd8;
     }
-    // registers <- global: K half of tile tk, V half of tile tv (either may lie beyond the last tile: skipped)
-    auto gload = [&](int tk, int tv) {
-        if (tk < NT) {
-            const char* kb = kbase + (int64_t)tk * FA_KT * g.k_nb1;
-            const int left = g.Lk - tk * FA_KT;
-#pragma unroll
-            for (int c = 0; c < NCHP; ++c) {
-                half8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
-                kreg[c]   = z;
-                if (kkey[c] < left) kreg[c] = *(const half8_t*)(kb + koff[c]);
-                if (MSLOT && kone[c]) kreg[c][0] = (_Float16)1.0f;
-            }
-        }
-        if (tv < NT) {
-            const char* vb = vbase + (int64_t)tv * FA_KT * g.v_nb1;
-            const int left = g.Lk - tv * FA_KT;
-#pragma unroll
-            for (int c = 0; c < NCHP; ++c) {
-                half8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
-                vreg[c]   = z;
-                if (vkey_[c] < left) vreg[c] = *(const half8_t*)(vb + voff[c]);
-                if (vone[c]) vreg[c][0] = (_Float16)1.0f;
-            }
-        }
-    };
-    // LDS <- registers: the halves loaded by the last gload(tk, tv)
-    auto lstore = [&](int tk, int tv) {
-        if (tk < NT) {
-            _Float16* ks = Ks + (tk & 1) * TILE_H;
-#pragma unroll
-            for (int c = 0; c < NCHP; ++c)
-                if (live[c]) {
-                    const int e = tg + c * 256;
-                    *(half8_t*)&ks[(32 * half + e / DCH) * KROW + (e % DCH) * 8] = kreg[c];
-                }
-        }
-        if (tv < NT) {
-            _Float16* vt = Vt + (tv & 1) * TILE_H;
-#pragma unroll
-            for (int c = 0; c < NCHP; ++c)
-                if (live[c]) {
-                    const int e = tg + c * 256;
-                    const int vkey = 32 * half + (e & 31), vch = e >> 5;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) vt[(vch * 8 + j) * FA_VTS + vkey] = vreg[c][j];
-                }
-        }
-    };
+    // registers <- global: K half of tile tk, V half of tile tv (either may lie beyond the last tile: skipped); LDS <- registers.  Macros over the
+    // NAMED register sets: passing the arrays to a lambda by reference put them in scratch memory.
+#define FPP_GLOAD(KR_, VR_, TK_, TV_)                                                                \
+    do {                                                                                             \
+        const int tk_ = (TK_), tv_ = (TV_);                                                          \
+        if (tk_ < NT) {                                                                              \
+            const char* kb_ = kbase + (int64_t)tk_ * FA_KT * g.k_nb1;                                \
+            const int left_ = g.Lk - tk_ * FA_KT;                                                    \
+            _Pragma("unroll") for (int c = 0; c < NCHP; ++c) {                                       \
+                half8_t z_ = {0, 0, 0, 0, 0, 0, 0, 0};                                               \
+                KR_[c]     = z_;                                                                     \
+                if (kkey[c] < left_) KR_[c] = *(const half8_t*)(kb_ + koff[c]);                      \
+                if (MSLOT && kone[c]) KR_[c][0] = (_Float16)1.0f;                                    \
+            }                                                                                        \
+        }                                                                                            \
+        if (tv_ < NT) {                                                                              \
+            const char* vb_ = vbase + (int64_t)tv_ * FA_KT * g.v_nb1;                                \
+            const int left_ = g.Lk - tv_ * FA_KT;                                                    \
+            _Pragma("unroll") for (int c = 0; c < NCHP; ++c) {                                       \
+                half8_t z_ = {0, 0, 0, 0, 0, 0, 0, 0};                                               \
+                VR_[c]     = z_;                                                                     \
+                if (vkey_[c] < left_) VR_[c] = *(const half8_t*)(vb_ + voff[c]);                     \
+                if (vone[c]) VR_[c][0] = (_Float16)1.0f;                                             \
+            }                                                                                        \
+        }                                                                                            \
+    } while (0)
+#define FPP_LSTORE(KR_, VR_, TK_, TV_)                                                               \
+    do {                                                                                             \
+        const int tk_ = (TK_), tv_ = (TV_);                                                          \
+        if (tk_ < NT) {                                                                              \
+            _Float16* ks_ = Ks + (tk_ & 1) * TILE_H;                                                 \
+            _Pragma("unroll") for (int c = 0; c < NCHP; ++c) if (live[c]) {                          \
+                const int e_ = tg + c * 256;                                                         \
+                *(half8_t*)&ks_[(32 * half + e_ / DCH) * KROW + (e_ % DCH) * 8] = KR_[c];            \
+            }                                                                                        \
+        }                                                                                            \
+        if (tv_ < NT) {                                                                              \
+            _Float16* vt_ = Vt + (tv_ & 1) * TILE_H;                                                 \
+            _Pragma("unroll") for (int c = 0; c < NCHP; ++c) if (live[c]) {                          \
+                const int e_ = tg + c * 256;                                                         \
+                const int vk_ = 32 * half + (e_ & 31), vc_ = e_ >> 5;                                \
+                _Pragma("unroll") for (int j = 0; j < 8; ++j) vt_[(vc_ * 8 + j) * FA_VTS + vk_] = VR_[c][j]; \
+            }                                                                                        \
+        }                                                                                            \
+    } while (0)
+    // staging step n of this group (n = 0, 1, ...): the halves of K(n + 1) and V(n) go to LDS from the set loaded two steps ago, which is then
+    // re-loaded for step n + 2
+#define FPP_STAGE(N_)                                  \
+    do {                                               \
+        const int n_ = (N_);                           \
+        if (n_ & 1) {                                  \
+            FPP_LSTORE(kregB, vregB, n_ + 1, n_);      \
+            FPP_GLOAD(kregB, vregB, n_ + 3, n_ + 2);   \
+        } else {                                       \
+            FPP_LSTORE(kregA, vregA, n_ + 1, n_);      \
+            FPP_GLOAD(kregA, vregA, n_ + 3, n_ + 2);   \
+        }                                              \
+    } while (0)
 
     // ---- prologue (all 512 threads): clear the never-staged V^T rows, the ones row where it sits beyond the staged rows, K(0) in full
     for (int b = 0; b < 2; ++b)
@@ -691,7 +703,8 @@ __global__ __launch_bounds__(512, 2) void k_flash_pp(FAArgs g) {
         if (MSLOT && ch == nd8) v[0] = (_Float16)1.0f;
         *(half8_t*)&Ks[key * KROW + ch * 8] = v;
     }
-    gload(1, 0);  // what this group stages in its first VALU(-like) phase
+    FPP_GLOAD(kregA, vregA, 1, 0);  // what this group stages in its first two VALU(-like) phases
+    FPP_GLOAD(kregB, vregB, 2, 1);
     __syncthreads();
 
     // ---- the two phase bodies
@@ -807,21 +820,18 @@ __global__ __launch_bounds__(512, 2) void k_flash_pp(FAArgs g) {
         for (int t = 0; t < NT; ++t) {
             mphase(t, true, t > 0);   // phase 2t
             __syncthreads();
-            lstore(t + 1, t);         // phase 2t + 1: K(t+1), V(t) halves
-            gload(t + 2, t + 1);
+            FPP_STAGE(t);             // phase 2t + 1: K(t+1), V(t) halves
             vphase(t);
             __syncthreads();
         }
         mphase(NT, false, true);      // phase 2 NT: the last PV
     } else {
-        lstore(1, 0);                 // phase 0: staging only
-        gload(2, 1);
+        FPP_STAGE(0);                 // phase 0: staging only
         __syncthreads();
         for (int t = 0; t < NT; ++t) {
             mphase(t, true, t > 0);   // phase 2t + 1
             __syncthreads();
-            lstore(t + 2, t + 1);     // phase 2t + 2
-            gload(t + 3, t + 2);
+            FPP_STAGE(t + 1);         // phase 2t + 2: K(t+2), V(t+1) halves
             vphase(t);
             if (t + 1 < NT) __syncthreads();
         }
@@ -875,6 +885,8 @@ static int g_flash_qb2 = 1;  // option "flash_qb2": 0 = one query block per wave
 void flash_attn_set_qb2(int v) { g_flash_qb2 = v; }
 static int g_flash_pp = 1;  // option "flash_pp": 0 = never the ping-pong kernel (A/B measurements)
 void flash_attn_set_pp(int v) { g_flash_pp = v; }
+static int g_flash_pp_min_tiles = 4;  // option "flash_pp_min_tiles": key tiles (64 keys) from which the ping-pong pipeline has a steady state worth its prologue
+void flash_attn_set_pp_min_tiles(int v) { g_flash_pp_min_tiles = v; }
 
 void launch_flash_attn(hipStream_t s, const FlashOut& out, const View4& q, const View4& k, const View4& v, float scale) {
     KScope ks_(s, KF_FLASH, 4.0 * (double)q.ne[1] * (double)k.ne[1] * (double)q.ne[2] * (double)q.ne[0], 0.0);  // 4 * Lq * Lk * (H*N) * d
@@ -915,8 +927,11 @@ void launch_flash_attn(hipStream_t s, const FlashOut& out, const View4& q, const
     const bool fast = g.vec_ok && g.kv_f16 && v.nb[0] == 2 && k.nb[0] == 2 && g.D == g.DV;
     // two query blocks per wave (256 queries per workgroup) when the launch still gives every CU two workgroups' worth of work
     const int64_t wg256 = ((int64_t)(g.Lq + 255) / 256) * q.ne[2];
-    const bool pp       = g_flash_pp && fast && D <= 128 && g.Lq >= 192 && wg256 >= 256;  // the ping-pong kernel: 8 waves = 256 queries per workgroup (d = 160 spills)
-    const bool qb2      = !pp && g_flash_qb2 && fast && D <= 64 && g.Lq >= 192 && wg256 >= 256;  // d = 80, 96: 256 VGPRs do not hold two blocks without spills
+    const int NT        = (g.Lk + FA_KT - 1) / FA_KT;
+    // the ping-pong kernel (8 waves = 256 queries per workgroup, one workgroup per CU): long key loops on grids that fill their rounds
+    // (320 workgroups on 256 CUs run as two rounds: SDXL's 4096-token level at batch 1 stays on the 4-wave kernel); d = 160 spills
+    const bool pp       = g_flash_pp && fast && D <= 128 && NT >= g_flash_pp_min_tiles && g.Lq >= 192 && wg256 >= 256 && wg256 * 5 >= ((wg256 + 255) / 256) * 256 * 4;
+    const bool qb2      = !pp && g_flash_qb2 && fast && D <= 48 && NT >= 4 && g.Lq >= 192 && wg256 >= 512;  // two query blocks per wave: d = 40 only (d = 64 measured slower, d >= 80 spills)
     const int QWG       = (qb2 || pp) ? 256 : 128;
     dim3 grid((unsigned)((g.Lq + QWG - 1) / QWG), (unsigned)q.ne[2]);
     g.grp = g.units = 0;
