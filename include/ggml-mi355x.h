@@ -83,6 +83,7 @@ struct ggml_backend_mi355x_stats {
     int64_t fused_sibling_linears; /* head-major projection GEMMs saved by running the q / k / v (or k / v) Linears of one attention as ONE launch over the shared operand */
     int64_t hoisted_kv_linears;  /* cross-attention K / V projections of the text context computed in grouped launches ahead of their graph position (results in the arena) */
     int64_t window_convs;        /* 3x3 convs planned on the LDS-window kernel (conv3w.hip) */
+    int64_t hoisted_emb_linears; /* per-ResBlock SiLU(emb) -> Linear projections computed by one grouped weight-streaming launch ahead of their graph position */
 };
 GGML_MI355X_API void ggml_backend_mi355x_get_stats(struct ggml_backend_mi355x_stats* out);
 /* live per-kernel-family timing (bench.py's roofline legs): while a family's bit is enabled, every dispatch of that family is bracketed by

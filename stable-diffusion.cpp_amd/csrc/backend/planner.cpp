@@ -41,11 +41,11 @@ namespace {
 struct Stats {
     std::atomic<int64_t> graphs_computed{0}, plans_built{0}, nodes_seen{0}, kernels_planned{0}, kernels_launched{0}, fused_conv{0},
         fused_conv_bounced{0}, fused_linear{0}, fused_norm{0}, fused_geglu{0}, fused_attention{0}, generic_matmul{0}, swizzled_weight_bytes{0}, fused_linear_geglu{0}, split_k_gemms{0}, head_major_gemms{0}, fused_modulate{0}, fused_gate{0}, fused_gelu{0}, fused_rope{0}, fused_concat_heads{0},
-        graph_replays{0}, qgemv_linears{0}, fused_chan_add{0}, fused_proj_tokens{0}, gemm_attention{0}, fused_q16{0}, split_k_inlaunch{0}, qgemm16_linears{0}, fgemv_linears{0}, fused_presilu{0}, fused_sibling_linears{0}, hoisted_kv_linears{0}, window_convs{0};
+        graph_replays{0}, qgemv_linears{0}, fused_chan_add{0}, fused_proj_tokens{0}, gemm_attention{0}, fused_q16{0}, split_k_inlaunch{0}, qgemm16_linears{0}, fgemv_linears{0}, fused_presilu{0}, fused_sibling_linears{0}, hoisted_kv_linears{0}, window_convs{0}, hoisted_emb_linears{0};
 } g_stats;
 
 struct Options {
-    std::atomic<int> fusion{1}, mfma_gemm{1}, hip_graph{0}, flash_pattern{1}, gemm16{1}, fuse_modulate{1}, fuse_gate{1}, fuse_gelu{1}, fuse_rope{1}, fuse_concat_heads{1}, qgemv{1}, fuse_chan_add{1}, fuse_proj_tokens{1}, fuse_q16{1}, qgemm16{1}, fgemv{1}, fuse_siblings{1}, hoist_kv{1};
+    std::atomic<int> fusion{1}, mfma_gemm{1}, hip_graph{0}, flash_pattern{1}, gemm16{1}, fuse_modulate{1}, fuse_gate{1}, fuse_gelu{1}, fuse_rope{1}, fuse_concat_heads{1}, qgemv{1}, fuse_chan_add{1}, fuse_proj_tokens{1}, fuse_q16{1}, qgemm16{1}, fgemv{1}, fuse_siblings{1}, hoist_kv{1}, hoist_emb{1};
 } g_opt;
 
 using Step = std::function<void(hipStream_t)>;
@@ -265,6 +265,13 @@ struct Builder {
     // f16 head-major K / V images of cross-attention projections computed ahead of their graph position (plan_hoisted_kv) live in the arena:
     // CPY node -> arena offset; the FLASH_ATTN_EXT node reads them from there
     std::unordered_map<const ggml_tensor*, size_t> moved;
+    // per-ResBlock embedding projections computed by ONE grouped launch ahead of their graph position (plan_hoisted_emb): the projection's output
+    // node (the bias ADD) -> {arena offset of its first column, floats between images}
+    struct MovedEmb {
+        size_t off;
+        int64_t ld, M, N;
+    };
+    std::unordered_map<const ggml_tensor*, MovedEmb> moved_emb;
     void emit(Step s) {
         if (emit_redirect >= 0)
             deferred[emit_redirect].push_back(std::move(s));
@@ -955,6 +962,134 @@ void plan_hoisted_kv(Builder& B, hipStream_t s) {
     }
 }
 
+// ResBlock embedding projections (block.hpp:126-160: emb_out = Linear(SiLU(emb)), one per ResBlock, added per (image, channel) to the first conv's
+// output).  All of them read ONE tensor, the time embedding, known before the first block runs; each is a ~20-25 us weight-streaming launch (22 per
+// SD1.5 forward: 0.45-0.65 ms per step, 1-2 % of the HBM rate, profiles/r04a_bench_round3_start.jsonl).  Pre-pass: their weight rows (and biases)
+// are concatenated ONCE into a private image — rows of a [M][K] weight are independent, so the concatenation is a set of device copies — and
+// one k_fgemv / k_qgemv launch at the position of the first member computes every projection; the results stay in the arena ([N][sum M], the
+// conv epilogues read their column range with the row stride sum M).  A member whose consumer turns out not to be a fused conv gets its
+// columns copied into its graph buffer instead (plan_single ADD / plan_conv_chain fallback).
+struct EmbMember {
+    int silu, mm, add;  // node indices: UNARY SILU, MUL_MAT, bias ADD
+    int64_t M;
+};
+void plan_hoisted_emb(Builder& B, hipStream_t s) {
+    if (!g_opt.hoist_emb || !g_opt.fusion || !g_opt.gemm16 || !g_opt.fuse_chan_add) return;
+    GInfo& gi  = B.gi;
+    Planner* P = B.P;
+    struct Key {
+        const ggml_tensor* e;
+        int wtype;
+        int64_t K, rows;
+        bool operator<(const Key& o) const { return std::tie(e, wtype, K, rows) < std::tie(o.e, o.wtype, o.K, o.rows); }
+    };
+    std::map<Key, std::vector<EmbMember>> groups;
+    for (int j = 0; j < gi.g->n_nodes; ++j) {
+        const ggml_tensor* n = gi.node(j);
+        if (n->op != GGML_OP_MUL_MAT || !linear_fast_ok(n)) continue;
+        const ggml_tensor* w = n->src[0];
+        const ggml_tensor* x = n->src[1];
+        const int is = gi.idx(x);
+        if (is < 0 || x->op != GGML_OP_UNARY || ggml_abi_get_unary_op(x) != GGML_UNARY_OP_SILU || gi.sole(is) != j || !contig(x) || !is_f32(x)) continue;
+        const ggml_tensor* e = x->src[0];
+        if (!e || !is_f32(e) || !contig(e) || e->ne[2] != 1 || e->ne[3] != 1 || !aligned16(e->data) || (x->flags & GGML_TENSOR_FLAG_OUTPUT)) continue;
+        const int64_t K = w->ne[0], M = w->ne[1], rows = x->ne[1];
+        if (x->ne[2] != 1 || x->ne[3] != 1 || !aligned16(w->data) || w->nb[1] != ggml_abi_row_size(w->type, K)) continue;
+        const bool fg = g_opt.fgemv && fgemv_supported((int)w->type, rows, K);
+        const bool qg = g_opt.qgemv && qgemv_supported((int)w->type, rows, K);
+        if (!fg && !qg) continue;
+        // -> ADD bias (in place) -> RESHAPE [1,1,M,N] -> ADD(conv output, .)
+        const int ja = gi.sole(j);
+        if (ja < 0 || gi.node(ja)->op != GGML_OP_ADD || gi.node(ja)->src[0] != n || !bias_like_row(gi.node(ja)->src[1], M) || gi.node(ja)->data != n->data ||
+            !is_static_weight(gi.node(ja)->src[1]) || (gi.node(ja)->flags & GGML_TENSOR_FLAG_OUTPUT))
+            continue;
+        int jr = gi.sole(ja);
+        if (jr < 0 || gi.node(jr)->op != GGML_OP_RESHAPE) continue;
+        const ggml_tensor* r = gi.node(jr);
+        if (!(r->ne[0] == 1 && r->ne[1] == 1 && r->ne[2] == M && r->ne[3] == rows)) continue;
+        const int jc = gi.sole(jr);
+        if (jc < 0 || gi.node(jc)->op != GGML_OP_ADD || gi.node(jc)->src[1] != r) continue;
+        if (gi.idx(e) > j) continue;  // the embedding must exist before the group's first member
+        groups[Key{e, (int)w->type, K, rows}].push_back(EmbMember{is, j, ja, M});
+    }
+    for (auto& kv : groups) {
+        std::vector<EmbMember>& mem = kv.second;
+        if (mem.size() < 3) continue;
+        const Key& k       = kv.first;
+        int64_t Mtot       = 0;
+        for (const auto& m : mem) Mtot += m.M;
+        const size_t rowb  = ggml_abi_row_size((ggml_type)k.wtype, k.K);
+        // the concatenated weight + bias image (cached like a swizzled weight; dropped with them when any weight is rewritten)
+        uint64_t key = 1469598103934665603ull;
+        for (const auto& m : mem) {
+            const void* wp = gi.node(m.mm)->src[0]->data;
+            key            = fnv(key, &wp, sizeof(wp));
+        }
+        key = fnv(key, "E", 1);
+        char* cat = nullptr;
+        auto it   = P->swz.find(key);
+        const size_t wbytes = (size_t)Mtot * rowb, bbytes = (size_t)Mtot * 4;
+        if (it != P->swz.end()) {
+            cat = (char*)it->second.swz;
+        } else {
+            void* d = nullptr;
+            if (hipMalloc(&d, wbytes + bbytes + 256) != hipSuccess) continue;
+            cat        = (char*)d;
+            size_t wo = 0, bo = 0;
+            for (const auto& m : mem) {
+                const ggml_tensor* w = gi.node(m.mm)->src[0];
+                const ggml_tensor* b = gi.node(m.add)->src[1];
+                (void)hipMemcpyAsync(cat + wo, w->data, (size_t)m.M * rowb, hipMemcpyDeviceToDevice, s);
+                (void)hipMemcpyAsync(cat + wbytes + bo, b->data, (size_t)m.M * 4, hipMemcpyDeviceToDevice, s);
+                wo += (size_t)m.M * rowb;
+                bo += (size_t)m.M * 4;
+            }
+            P->swz[key] = {d, wbytes + bbytes + 256, nullptr, (size_t)-1};  // src range "everything": dropped on any weight rewrite / buffer free
+            g_stats.swizzled_weight_bytes += (int64_t)(wbytes + bbytes);
+        }
+        const size_t ooff = B.alloc((size_t)k.rows * Mtot * 4);
+        int64_t col       = 0;
+        int first         = gi.g->n_nodes;
+        for (const auto& m : mem) {
+            B.moved_emb[gi.node(m.add)] = Builder::MovedEmb{ooff + (size_t)col * 4, Mtot, m.M, k.rows};
+            col += m.M;
+            first = std::min(first, m.silu);
+            gi.done[m.silu] = gi.done[m.mm] = gi.done[m.add] = 1;
+        }
+        const float* ex   = (const float*)k.e->data;
+        const int64_t xs  = (int64_t)k.e->nb[1] / 4, rows = k.rows, K = k.K;
+        const int wt      = k.wtype;
+        const bool use_q  = !(g_opt.fgemv && fgemv_supported(wt, rows, K));
+        const size_t wsoff = use_q ? B.alloc(qgemv_workspace_bytes(rows, K)) : 0;
+        const char* catp  = cat;
+        B.deferred[first].push_back([=](hipStream_t st) {
+            Epilogue ep;
+            ep.bias    = (const float*)(catp + wbytes);
+            float* out = (float*)(P->arena + ooff);
+            if (use_q)
+                launch_qgemv(st, out, Mtot, ex, xs, rows, catp, wt, K, Mtot, P->arena + wsoff, ep, 1.0f, true);
+            else
+                launch_fgemv(st, out, Mtot, ex, xs, rows, catp, wt, K, Mtot, ep, true);
+        });
+        g_stats.hoisted_emb_linears += (int64_t)mem.size();
+        g_stats.fused_linear += (int64_t)mem.size();
+        g_stats.fused_presilu += (int64_t)mem.size();
+    }
+}
+
+// a hoisted embedding projection whose consumer is NOT a fused conv epilogue: copy its columns from the grouped output into its graph buffer
+static void emit_moved_emb_copy(Builder& B, const ggml_tensor* e_add) {
+    auto it = B.moved_emb.find(e_add);
+    if (it == B.moved_emb.end()) return;
+    const Builder::MovedEmb me = it->second;
+    Planner* P                 = B.P;
+    float* dst                 = (float*)e_add->data;
+    B.emit([=](hipStream_t st) {
+        (void)hipMemcpy2DAsync(dst, (size_t)me.M * 4, P->arena + me.off, (size_t)me.ld * 4, (size_t)me.M * 4, (size_t)me.N, hipMemcpyDeviceToDevice, st);
+    });
+    B.moved_emb.erase(it);  // from here on the graph tensor itself is valid
+}
+
 // IM2COL chain -> implicit GEMM conv.  Returns false if the pattern does not match.
 bool plan_conv_chain(Builder& B, int i, hipStream_t s, std::vector<int>& chain) {
     GInfo& gi              = B.gi;
@@ -1025,6 +1160,8 @@ bool plan_conv_chain(Builder& B, int i, hipStream_t s, std::vector<int>& chain) 
     // ADD's position instead (its input is the private f16 image in the arena, which no graph node can overwrite in between)
     const size_t ob = ggml_abi_nbytes(out);
     int emit_node = i;
+    bool emb_arena = false;  // the chan_add operand lives in the arena (plan_hoisted_emb)
+    size_t emb_off = 0;
     if (g_opt.fuse_chan_add && g_opt.gemm16 && token_major_out < 0) {
         const int r = gi.sole(last);
         if (r >= 0 && gi.node(r)->op == GGML_OP_ADD && gi.node(r)->src[0] == gi.node(last)) {
@@ -1049,6 +1186,13 @@ bool plan_conv_chain(Builder& B, int i, hipStream_t s, std::vector<int>& chain) 
                     last      = r;
                     emit_node = r;
                     g_stats.fused_chan_add++;
+                    const auto me = B.moved_emb.find(eroot);
+                    if (me != B.moved_emb.end()) {  // computed by the grouped launch: read it from the arena (address resolved at launch time)
+                        emb_arena  = true;
+                        emb_off    = me->second.off;
+                        ep.chan_ld = me->second.ld;
+                        ep.chan_add = nullptr;
+                    }
                 }
             }
         }
@@ -1111,13 +1255,21 @@ bool plan_conv_chain(Builder& B, int i, hipStream_t s, std::vector<int>& chain) 
         if (w3S > 0) {
             const size_t wsoff = w3S > 1 ? B.alloc((size_t)w3S * opos * OC * 4) : 0;
             if (w3S > 1) g_stats.split_k_gemms++;
-            B.emit_at(emit_node, i, [=](hipStream_t st) { launch_conv3w(st, final_dst, P->arena + off, swz, SW, SH, IC, N, OC, ep, w3S > 1 ? (float*)(P->arena + wsoff) : nullptr, w3S); });
+            B.emit_at(emit_node, i, [=](hipStream_t st) {
+                Epilogue e2 = ep;
+                if (emb_arena) e2.chan_add = (const float*)(P->arena + emb_off);
+                launch_conv3w(st, final_dst, P->arena + off, swz, SW, SH, IC, N, OC, e2, w3S > 1 ? (float*)(P->arena + wsoff) : nullptr, w3S);
+            });
             g_stats.fused_conv++;
             g_stats.window_convs++;
             return true;
         }
         const Builder::Split sk = B.plan_split(opos, OC, rup64(IC) * ks * ks, true, true);
-        B.emit_at(emit_node, i, [=](hipStream_t st) { launch_gemm16_conv(st, final_dst, P->arena + off, swz, SW, SH, IC, N, OC, ks, st_, pd, upscale, ep, sk.ws(P), sk.cnt(P), sk.S); });
+        B.emit_at(emit_node, i, [=](hipStream_t st) {
+            Epilogue e2 = ep;
+            if (emb_arena) e2.chan_add = (const float*)(P->arena + emb_off);
+            launch_gemm16_conv(st, final_dst, P->arena + off, swz, SW, SH, IC, N, OC, ks, st_, pd, upscale, e2, sk.ws(P), sk.cnt(P), sk.S);
+        });
         g_stats.fused_conv++;
         return true;
     }
@@ -1601,6 +1753,8 @@ bool plan_single(Builder& B, int i, hipStream_t s) {
         case GGML_OP_SUB:
         case GGML_OP_MUL:
         case GGML_OP_DIV: {
+            for (int q = 0; q < 2; ++q)  // an operand that only exists in the grouped embedding output: materialise its graph tensor first
+                if (n->src[q]) emit_moved_emb_copy(B, strip_reshape(n->src[q]));
             const BinOp op = n->op == GGML_OP_ADD ? BIN_ADD : n->op == GGML_OP_SUB ? BIN_SUB : n->op == GGML_OP_MUL ? BIN_MUL : BIN_DIV;
             View4 a = view_of(n->src[0]), b = view_of(n->src[1]);
             View4 d = view_of(n);
@@ -1832,6 +1986,7 @@ bool build_plan(Planner* P, Plan* plan, const ggml_cgraph* g, hipStream_t s) {
     Builder B(P, plan, g);
     GInfo& gi = B.gi;
     plan_hoisted_kv(B, s);
+    plan_hoisted_emb(B, s);
     for (int i = 0; i < g->n_nodes; ++i) {
         {
             auto it = B.deferred.find(i);
@@ -2176,6 +2331,7 @@ void planner_get_stats(ggml_backend_mi355x_stats* o) {
     o->fused_sibling_linears = g_stats.fused_sibling_linears;
     o->hoisted_kv_linears    = g_stats.hoisted_kv_linears;
     o->window_convs          = g_stats.window_convs;
+    o->hoisted_emb_linears   = g_stats.hoisted_emb_linears;
     o->fused_attention       = g_stats.fused_attention;
     o->generic_matmul        = g_stats.generic_matmul;
     o->swizzled_weight_bytes = g_stats.swizzled_weight_bytes;
@@ -2199,6 +2355,7 @@ void planner_set_option(const char* key, int value) {
     else if (!strcmp(key, "flash_pp")) flash_attn_set_pp(value);
     else if (!strcmp(key, "flash_pp_min_tiles")) flash_attn_set_pp_min_tiles(value);
     else if (!strcmp(key, "conv3w")) conv3w_set(value);
+    else if (!strcmp(key, "hoist_emb")) g_opt.hoist_emb = value;
     else if (!strcmp(key, "conv3w_min_blocks")) conv3w_set_min_blocks(value);
     else if (!strcmp(key, "conv3w_min_blocks_deep")) conv3w_set_min_blocks_deep(value);
     else if (!strcmp(key, "gemm16_bn64")) gemm16_set_bn64(value);

@@ -338,7 +338,7 @@ static void c3_launch(hipStream_t s, const G16Args& g, unsigned tiles, unsigned 
 // zero page shared with gemm16.hip
 const _Float16* gemm16_zero_page();
 void launch_splitk_reduce_conv(hipStream_t s, float* dst, const float* ws, int S, int64_t n, const float* bias, int64_t inner, int64_t C, const float* residual,
-                               const float* chan_add);
+                               const float* chan_add, int64_t chan_ld);
 
 void launch_conv3w(hipStream_t s, float* dst, const void* x16_nhwc, const void* wswz32, int64_t W, int64_t H, int64_t IC, int64_t N, int64_t OC, const Epilogue& e,
                    float* splitk_ws, int S) {
@@ -371,6 +371,7 @@ void launch_conv3w(hipStream_t s, float* dst, const void* x16_nhwc, const void* 
     g.zero = gemm16_zero_page();
     g.ep   = G16Epi{e.bias, e.residual, e.scale};
     g.ep.chan_add = e.chan_add;
+    g.ep.chan_ld  = (int)e.chan_ld;
     g.ncol_tiles  = (int)(OC / bn);
     if (S > 1 && splitk_ws) {
         g.split_k  = S;
@@ -397,7 +398,7 @@ void launch_conv3w(hipStream_t s, float* dst, const void* x16_nhwc, const void* 
             else c3_launch<128, 256>(s, g, tiles, (unsigned)S);
         }
     }
-    if (S > 1) launch_splitk_reduce_conv(s, dst, splitk_ws, S, g.R * OC, e.bias, g.OHOW, OC, e.residual, e.chan_add);
+    if (S > 1) launch_splitk_reduce_conv(s, dst, splitk_ws, S, g.R * OC, e.bias, g.OHOW, OC, e.residual, e.chan_add, e.chan_ld);
 }
 
 }  // namespace mi355x

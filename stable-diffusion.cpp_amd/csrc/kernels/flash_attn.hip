@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256, QB == 2 ? (DKP <= 96 ? 2 : 1) : (DKP <= 64 ? F
     // lanes run along keys so the 8 transposing 2-byte LDS writes of a chunk are bank-contiguous (the (e / DCH, e % DCH) mapping
     // put a wave's 64 lanes on ~12 banks: 31 % of all LDS cycles were conflict cycles).
     // per-thread chunk coordinates are tile-invariant: 32-bit byte offsets against a wave-uniform tile base (SGPR base + VGPR offset loads)
-    uint32_t koff[NCH], voff[NCH];
+    uint32_t koff[NCH], voff[NCH];  // always a readable address: lanes / chunks that fetch nothing point at the tile's first bytes and are zeroed by lstore
     bool kone[NCH];             // MSLOT: this chunk starts at d = D (the max slot)
     int kkey[NCH], vkey_[NCH];  // key index inside the tile, or FA_KT (never valid) for chunks this thread does not fetch
 #pragma unroll
@@ -214,39 +214,46 @@ __global__ __launch_bounds__(256, QB == 2 ? (DKP <= 96 ? 2 : 1) : (DKP <= 64 ? F
         const int e   = threadIdx.x + c * 256;
         const int key = e / DCH, ch = e - key * DCH;
         const int vkey = e & (FA_KT - 1), vch = e >> 6;
-        koff[c]  = (uint32_t)key * (uint32_t)g.k_nb1 + (uint32_t)ch * 16u;
-        voff[c]  = (uint32_t)vkey * (uint32_t)g.v_nb1 + (uint32_t)vch * 16u;
         kkey[c]  = (e < FA_KT * DCH && ch < nd8) ? key : FA_KT;
         kone[c]  = e < FA_KT * DCH && ch == nd8;
         vkey_[c] = (e < FA_KT * DCH && vch < nd8) ? vkey : FA_KT;
+        koff[c]  = kkey[c] < FA_KT ? (uint32_t)key * (uint32_t)g.k_nb1 + (uint32_t)ch * 16u : 0u;
+        voff[c]  = vkey_[c] < FA_KT ? (uint32_t)vkey * (uint32_t)g.v_nb1 + (uint32_t)vch * 16u : 0u;
     }
+    // registers <- global.  BUFFER loads: uniform descriptor (one head's K / V rows, num_records = Lk rows: keys beyond Lk read as zeros for
+    // free), per-lane 32-bit offsets that never change, the tile offset in an SGPR — no per-tile address arithmetic and NOTHING touches the
+    // destination registers before lstore.  History (disassembly, round 3): with "zero, then flat load where valid" every load was preceded by an
+    // s_waitcnt vmcnt(0) (the zeroing v_mov / the 64-bit address computed INTO the destination registers needs their previous load retired, and
+    // the counter cannot tell loads apart), so the 2 NCH loads of a tile paid their latencies one after the other, and inserting the constant
+    // 1s right behind the loads added another wait each — the register prefetch hid nothing.
+    const auto rsK = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, (int)min((int64_t)g.Lk * g.k_nb1, (int64_t)0x7fffffff), 0x00020000);
+    const auto rsV = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, (int)min((int64_t)g.Lk * g.v_nb1, (int64_t)0x7fffffff), 0x00020000);
     auto gload = [&](int kt) {
-        const char* kb = kbase + (int64_t)kt * g.k_nb1;  // wave-uniform
-        const char* vb = vbase + (int64_t)kt * g.v_nb1;
-        const int left = min(g.Lk - kt, FA_KT);           // valid keys in this tile
+        const int sk = kt * (int)g.k_nb1, sv = kt * (int)g.v_nb1;  // wave-uniform tile offsets
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
-            half8_t zk = {0, 0, 0, 0, 0, 0, 0, 0};
-            kreg[c] = zk;
-            vreg[c] = zk;
-            if (kkey[c] < left) kreg[c] = *(const half8_t*)(kb + koff[c]);
-            if (MSLOT && kone[c]) kreg[c][0] = (_Float16)1.0f;  // K[key][D] = 1 (keys beyond Lk are masked after the MFMA)
-            if (vkey_[c] < left) vreg[c] = *(const half8_t*)(vb + voff[c]);
-            if (ones_in_tile && ((threadIdx.x + c * 256) >> 6) == nd8) vreg[c][0] = (_Float16)1.0f;  // V^T row DV = 1: PV accumulates the row sums
+            kreg[c] = __builtin_bit_cast(half8_t, __builtin_amdgcn_raw_buffer_load_b128(rsK, (int)koff[c], sk, 0));
+            vreg[c] = __builtin_bit_cast(half8_t, __builtin_amdgcn_raw_buffer_load_b128(rsV, (int)voff[c], sv, 0));
         }
     };
-    auto lstore = [&](int buf) {
+    // LDS <- registers (tile starting at key kt): zero what is not real data, insert the constant 1s of the max slot / ones row
+    auto lstore = [&](int buf, int kt) {
         _Float16* ks = Ks + buf * TILE_H;
         _Float16* vt = Vt + buf * TILE_H;
+        const int left = g.Lk - kt;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int e = threadIdx.x + c * 256;
             if (e < FA_KT * DCH) {
                 const int key = e / DCH, ch = e - key * DCH;
                 const int vkey = e & (FA_KT - 1), vch = e >> 6;
-                *(half8_t*)&ks[key * KROW + ch * 8] = kreg[c];
+                const half8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+                half8_t kv = kkey[c] < left ? kreg[c] : z, vv = vkey_[c] < left ? vreg[c] : z;
+                if (MSLOT && kone[c]) kv[0] = (_Float16)1.0f;                   // K[key][D] = 1 (keys beyond Lk are masked after the MFMA)
+                if (ones_in_tile && vch == nd8) vv[0] = (_Float16)1.0f;         // V^T row DV = 1: PV accumulates the row sums
+                *(half8_t*)&ks[key * KROW + ch * 8] = kv;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) vt[(vch * 8 + j) * FA_VTS + vkey] = vreg[c][j];
+                for (int j = 0; j < 8; ++j) vt[(vch * 8 + j) * FA_VTS + vkey] = vv[j];
             }
         }
     };
@@ -297,7 +304,7 @@ __global__ __launch_bounds__(256, QB == 2 ? (DKP <= 96 ? 2 : 1) : (DKP <= 64 ? F
     if (FAST) {
         gload(0);
         __syncthreads();  // the clears above
-        lstore(0);
+        lstore(0, 0);
         if (FA_KT < g.Lk) gload(FA_KT);
         __syncthreads();
     }
@@ -310,7 +317,7 @@ __global__ __launch_bounds__(256, QB == 2 ? (DKP <= 96 ? 2 : 1) : (DKP <= 64 ? F
             // tile kt sits in buffer buf (visible since the barrier that ended the previous iteration); the registers hold tile
             // kt+64: park it in the other buffer now, then fetch kt+128 — both overlap this tile's MFMAs
             if (ABL != 2) {
-                if (kt + FA_KT < g.Lk) lstore(buf ^ 1);
+                if (kt + FA_KT < g.Lk) lstore(buf ^ 1, kt + FA_KT);
                 if (kt + 2 * FA_KT < g.Lk) gload(kt + 2 * FA_KT);
             }
         } else {
@@ -615,8 +622,10 @@ __global__ __launch_bounds__(512, 2) void k_flash_pp(FAArgs g) {
     const int half = grp == 0 ? 1 : 0;
     // two register sets: the loads of staging step n are consumed at step n + 2 = FOUR phases later (with one set / two phases the kernel waited for
     // its global loads in every VALU phase: 68 % of the wave cycles parked, profiles/r04c_pmc_flash_pp.txt)
-    half8_t kregA[NCHP], vregA[NCHP], kregB[NCHP], vregB[NCHP];
-    uint32_t koff[NCHP], voff[NCHP];
+    // (d >= 80: one set, two phases ahead — a second set does not fit the 256 registers next to the accumulators)
+    constexpr int NSET = DKP <= 64 ? 2 : 1;
+    half8_t kregA[NCHP], vregA[NCHP], kregB[NSET == 2 ? NCHP : 1], vregB[NSET == 2 ? NCHP : 1];
+    uint32_t koff[NCHP], voff[NCHP];  // offsets are always readable addresses (dummies: the tile's first bytes, zeroed at the store)
     int kkey[NCHP], vkey_[NCHP];  // key inside the TILE, or FA_KT (never valid)
     bool kone[NCHP], vone[NCHP], live[NCHP];
 #pragma unroll
@@ -625,70 +634,78 @@ __global__ __launch_bounds__(512, 2) void k_flash_pp(FAArgs g) {
         const int key = 32 * half + e / DCH, ch = e % DCH;
         const int vkey = 32 * half + (e & 31), vch = e >> 5;
         live[c]  = e < 32 * DCH;
-        koff[c]  = (uint32_t)key * (uint32_t)g.k_nb1 + (uint32_t)ch * 16u;
-        voff[c]  = (uint32_t)vkey * (uint32_t)g.v_nb1 + (uint32_t)vch * 16u;
         kkey[c]  = (live[c] && ch < nd8) ? key : FA_KT;
         kone[c]  = live[c] && ch == nd8;
         vkey_[c] = (live[c] && vch < nd8) ? vkey : FA_KT;
         vone[c]  = live[c] && ones_in_tile && vch == nd8;
+        koff[c]  = kkey[c] < FA_KT ? (uint32_t)key * (uint32_t)g.k_nb1 + (uint32_t)ch * 16u : 0u;
+        voff[c]  = vkey_[c] < FA_KT ? (uint32_t)vkey * (uint32_t)g.v_nb1 + (uint32_t)vch * 16u : 0u;
     }
-    // registers <- global: K half of tile tk, V half of tile tv (either may lie beyond the last tile: skipped); LDS <- registers.  Macros over the
+    const auto rsK = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, (int)min((int64_t)g.Lk * g.k_nb1, (int64_t)0x7fffffff), 0x00020000);
+    const auto rsV = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, (int)min((int64_t)g.Lk * g.v_nb1, (int64_t)0x7fffffff), 0x00020000);
+    // registers <- global: K half of tile tk, V half of tile tv (either may lie beyond the last tile: skipped); LDS <- registers (which also inserts the
+    // constant 1s of the max slot / ones row: touching a loaded register earlier would put a vmcnt(0) wait right behind its load).  Macros over the
     // NAMED register sets: passing the arrays to a lambda by reference put them in scratch memory.
 #define FPP_GLOAD(KR_, VR_, TK_, TV_)                                                                \
-    do {                                                                                             \
+    do { /* buffer loads: uniform descriptor, constant per-lane offsets, tile offset in an SGPR (see gload in k_flash_attn) */ \
         const int tk_ = (TK_), tv_ = (TV_);                                                          \
         if (tk_ < NT) {                                                                              \
-            const char* kb_ = kbase + (int64_t)tk_ * FA_KT * g.k_nb1;                                \
-            const int left_ = g.Lk - tk_ * FA_KT;                                                    \
-            _Pragma("unroll") for (int c = 0; c < NCHP; ++c) {                                       \
-                half8_t z_ = {0, 0, 0, 0, 0, 0, 0, 0};                                               \
-                KR_[c]     = z_;                                                                     \
-                if (kkey[c] < left_) KR_[c] = *(const half8_t*)(kb_ + koff[c]);                      \
-                if (MSLOT && kone[c]) KR_[c][0] = (_Float16)1.0f;                                    \
-            }                                                                                        \
+            const int so_ = tk_ * FA_KT * (int)g.k_nb1;                                              \
+            _Pragma("unroll") for (int c = 0; c < NCHP; ++c)                                         \
+                KR_[c] = __builtin_bit_cast(half8_t, __builtin_amdgcn_raw_buffer_load_b128(rsK, (int)koff[c], so_, 0)); \
         }                                                                                            \
         if (tv_ < NT) {                                                                              \
-            const char* vb_ = vbase + (int64_t)tv_ * FA_KT * g.v_nb1;                                \
-            const int left_ = g.Lk - tv_ * FA_KT;                                                    \
-            _Pragma("unroll") for (int c = 0; c < NCHP; ++c) {                                       \
-                half8_t z_ = {0, 0, 0, 0, 0, 0, 0, 0};                                               \
-                VR_[c]     = z_;                                                                     \
-                if (vkey_[c] < left_) VR_[c] = *(const half8_t*)(vb_ + voff[c]);                     \
-                if (vone[c]) VR_[c][0] = (_Float16)1.0f;                                             \
-            }                                                                                        \
+            const int so_ = tv_ * FA_KT * (int)g.v_nb1;                                              \
+            _Pragma("unroll") for (int c = 0; c < NCHP; ++c)                                         \
+                VR_[c] = __builtin_bit_cast(half8_t, __builtin_amdgcn_raw_buffer_load_b128(rsV, (int)voff[c], so_, 0)); \
         }                                                                                            \
     } while (0)
 #define FPP_LSTORE(KR_, VR_, TK_, TV_)                                                               \
     do {                                                                                             \
         const int tk_ = (TK_), tv_ = (TV_);                                                          \
+        const half8_t z_ = {0, 0, 0, 0, 0, 0, 0, 0};                                                 \
         if (tk_ < NT) {                                                                              \
             _Float16* ks_ = Ks + (tk_ & 1) * TILE_H;                                                 \
+            const int left_ = g.Lk - tk_ * FA_KT;                                                    \
             _Pragma("unroll") for (int c = 0; c < NCHP; ++c) if (live[c]) {                          \
                 const int e_ = tg + c * 256;                                                         \
-                *(half8_t*)&ks_[(32 * half + e_ / DCH) * KROW + (e_ % DCH) * 8] = KR_[c];            \
+                half8_t kv_  = kkey[c] < left_ ? KR_[c] : z_;                                        \
+                if (MSLOT && kone[c]) kv_[0] = (_Float16)1.0f; /* the max slot: K[key][D] = 1 */     \
+                *(half8_t*)&ks_[(32 * half + e_ / DCH) * KROW + (e_ % DCH) * 8] = kv_;               \
             }                                                                                        \
         }                                                                                            \
         if (tv_ < NT) {                                                                              \
             _Float16* vt_ = Vt + (tv_ & 1) * TILE_H;                                                 \
+            const int left_ = g.Lk - tv_ * FA_KT;                                                    \
             _Pragma("unroll") for (int c = 0; c < NCHP; ++c) if (live[c]) {                          \
                 const int e_ = tg + c * 256;                                                         \
                 const int vk_ = 32 * half + (e_ & 31), vc_ = e_ >> 5;                                \
-                _Pragma("unroll") for (int j = 0; j < 8; ++j) vt_[(vc_ * 8 + j) * FA_VTS + vk_] = VR_[c][j]; \
+                half8_t vv_   = vkey_[c] < left_ ? VR_[c] : z_;                                      \
+                if (vone[c]) vv_[0] = (_Float16)1.0f; /* the ones row: PV accumulates the row sums */ \
+                _Pragma("unroll") for (int j = 0; j < 8; ++j) vt_[(vc_ * 8 + j) * FA_VTS + vk_] = vv_[j]; \
             }                                                                                        \
         }                                                                                            \
     } while (0)
     // staging step n of this group (n = 0, 1, ...): the halves of K(n + 1) and V(n) go to LDS from the set loaded two steps ago, which is then
     // re-loaded for step n + 2
-#define FPP_STAGE(N_)                                  \
-    do {                                               \
-        const int n_ = (N_);                           \
-        if (n_ & 1) {                                  \
-            FPP_LSTORE(kregB, vregB, n_ + 1, n_);      \
-            FPP_GLOAD(kregB, vregB, n_ + 3, n_ + 2);   \
-        } else {                                       \
-            FPP_LSTORE(kregA, vregA, n_ + 1, n_);      \
-            FPP_GLOAD(kregA, vregA, n_ + 3, n_ + 2);   \
-        }                                              \
+    // The set is chosen at COMPILE time (the tile loops below are unrolled by two): a run-time choice made the compiler merge the two sets through
+    // register copies, i.e. wait for the fresh loads on the spot.  With one set (NSET == 1) both macros use set A, two phases ahead.
+#define FPP_STAGE_A(N_)                                                    \
+    do {                                                                   \
+        const int n_ = (N_);                                               \
+        FPP_LSTORE(kregA, vregA, n_ + 1, n_);                              \
+        FPP_GLOAD(kregA, vregA, n_ + 1 + NSET, n_ + NSET);                 \
+    } while (0)
+#define FPP_STAGE_B(N_)                                                    \
+    do {                                                                   \
+        const int n_ = (N_);                                               \
+        if constexpr (NSET == 1) {                                         \
+            FPP_LSTORE(kregA, vregA, n_ + 1, n_);                          \
+            FPP_GLOAD(kregA, vregA, n_ + 2, n_ + 1);                       \
+        } else {                                                           \
+            FPP_LSTORE(kregB, vregB, n_ + 1, n_);                          \
+            FPP_GLOAD(kregB, vregB, n_ + 3, n_ + 2);                       \
+        }                                                                  \
     } while (0)
 
     // ---- prologue (all 512 threads): clear the never-staged V^T rows, the ones row where it sits beyond the staged rows, K(0) in full
@@ -703,8 +720,8 @@ __global__ __launch_bounds__(512, 2) void k_flash_pp(FAArgs g) {
         if (MSLOT && ch == nd8) v[0] = (_Float16)1.0f;
         *(half8_t*)&Ks[key * KROW + ch * 8] = v;
     }
-    FPP_GLOAD(kregA, vregA, 1, 0);  // what this group stages in its first two VALU(-like) phases
-    FPP_GLOAD(kregB, vregB, 2, 1);
+    FPP_GLOAD(kregA, vregA, 1, 0);  // what this group stages in its first (two) VALU(-like) phase(s)
+    if constexpr (NSET == 2) FPP_GLOAD(kregB, vregB, 2, 1);
     __syncthreads();
 
     // ---- the two phase bodies
@@ -815,28 +832,57 @@ __global__ __launch_bounds__(512, 2) void k_flash_pp(FAArgs g) {
         }
     };
 
-    // ---- the two group programs (2 NT barriers each; see the phase table above)
+    // ---- the two group programs (2 NT barriers each; see the phase table above).  The phase barrier waits for this wave's LDS traffic only:
+    // __syncthreads() also drains vmcnt, i.e. it waited for the global loads issued a moment earlier for a LATER phase — every VALU phase then
+    // lasted one L2 round trip (phases of ~2300 cycles instead of ~700, 69 % of the wave cycles parked: profiles/r04d_pmc_flash_pp.txt)
+#define FPP_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
     if (grp == 0) {
-        for (int t = 0; t < NT; ++t) {
+        int t = 0;
+        for (; t + 1 < NT; t += 2) {
             mphase(t, true, t > 0);   // phase 2t
-            __syncthreads();
-            FPP_STAGE(t);             // phase 2t + 1: K(t+1), V(t) halves
+            FPP_BARRIER();
+            FPP_STAGE_A(t);           // phase 2t + 1: K(t+1), V(t) halves (staging step n = t: even -> set A)
             vphase(t);
-            __syncthreads();
+            FPP_BARRIER();
+            mphase(t + 1, true, true);
+            FPP_BARRIER();
+            FPP_STAGE_B(t + 1);
+            vphase(t + 1);
+            FPP_BARRIER();
+        }
+        if (t < NT) {
+            mphase(t, true, t > 0);
+            FPP_BARRIER();
+            FPP_STAGE_A(t);
+            vphase(t);
+            FPP_BARRIER();
         }
         mphase(NT, false, true);      // phase 2 NT: the last PV
     } else {
-        FPP_STAGE(0);                 // phase 0: staging only
-        __syncthreads();
-        for (int t = 0; t < NT; ++t) {
+        FPP_STAGE_A(0);               // phase 0: staging only (step n = 0)
+        FPP_BARRIER();
+        int t = 0;
+        for (; t + 1 < NT; t += 2) {
             mphase(t, true, t > 0);   // phase 2t + 1
-            __syncthreads();
-            FPP_STAGE(t + 1);         // phase 2t + 2: K(t+2), V(t+1) halves
+            FPP_BARRIER();
+            FPP_STAGE_B(t + 1);       // phase 2t + 2: K(t+2), V(t+1) halves (step n = t + 1: odd -> set B)
             vphase(t);
-            if (t + 1 < NT) __syncthreads();
+            FPP_BARRIER();
+            mphase(t + 1, true, true);
+            FPP_BARRIER();
+            FPP_STAGE_A(t + 2);
+            vphase(t + 1);
+            if (t + 2 < NT) FPP_BARRIER();
+        }
+        if (t < NT) {
+            mphase(t, true, t > 0);
+            FPP_BARRIER();
+            FPP_STAGE_B(t + 1);
+            vphase(t);
         }
         mphase(NT, false, true);      // phase 2 NT + 1
     }
+#undef FPP_BARRIER
 
     // ---- finalise (as k_flash_attn)
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);

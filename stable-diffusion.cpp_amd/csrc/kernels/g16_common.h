@@ -13,6 +13,7 @@ struct G16Epi {  // dst = acc * scale + bias (+ residual); DiT variants: (acc*sc
     int gate_L        = 0;        // rows per image (>= 32)
     int gelu          = 0;        // f16-only output: tanh-GELU before rounding (Mlp fc1 -> fc2, block.hpp:249-258)
     const float* chan_add = nullptr;  // conv only: [N][OC] value added per (image, channel) — the ResBlock's time-embedding ADD (block.hpp:150-160)
+    int chan_ld           = 0;        // floats between images of chan_add (0 = C)
 };
 
 struct G16Args {
@@ -232,7 +233,8 @@ __device__ __forceinline__ void epi_conv(const float16_t (&acc)[RB][CB], const G
             if (cblk >= g.C) continue;
             const int64_t ub = ((int64_t)img0 * g.C + cblk) * g.OHOW;  // uniform
             const float* pb  = g.ep.bias ? g.ep.bias + cblk : nullptr;
-            const float* pc  = g.ep.chan_add ? g.ep.chan_add + (int64_t)img0 * g.C + cblk : nullptr;  // + dimg * C per lane
+            const uint32_t cld = g.ep.chan_ld ? (uint32_t)g.ep.chan_ld : (uint32_t)g.C;  // floats between the images of chan_add
+            const float* pc  = g.ep.chan_add ? g.ep.chan_add + (int64_t)img0 * cld + cblk : nullptr;  // + dimg * cld per lane
             // loads first (bias, residual), then the stores: dst may BE the residual, so the compiler cannot batch them itself
 #pragma unroll
             for (int r0 = 0; r0 < 16; r0 += 8) {
@@ -242,7 +244,7 @@ __device__ __forceinline__ void epi_conv(const float16_t (&acc)[RB][CB], const G
                     const int ro  = (r & 3) + 8 * (r >> 2);
                     const bool ok = MODE != 2 || cblk + ro + 4 * hi < g.C;
                     bv[r - r0]    = (pb && ok) ? ld_u(pb + ro, 16u * hi) : 0.f;
-                    if (pc && ok) bv[r - r0] += ld_u(pc + ro, (4u * hi + dimg * (uint32_t)g.C) * 4u);
+                    if (pc && ok) bv[r - r0] += ld_u(pc + ro, (4u * hi + dimg * cld) * 4u);
                     rv[r - r0]    = ((MODE == 1 || (MODE == 2 && g.ep.residual)) && ok) ? ld_u(g.ep.residual + ub + (int64_t)ro * g.OHOW, le * 4u) : 0.f;
                 }
 #pragma unroll

@@ -825,7 +825,7 @@ G16SplitPlan gemm16_split_plan(int64_t rows, int64_t M, int64_t K, bool conv, bo
 // dst[i] = sum_s slab_s[i] + bias[(i / inner) % C] + residual[i];  4 elements per thread (n % 4 == 0, and inner % 4 == 0 or inner == 1 with C % 4 == 0)
 template <bool V4>
 __global__ void k_splitk_reduce(float* __restrict__ dst, const float* __restrict__ ws, int S, int64_t slab, int64_t n, const float* __restrict__ bias,
-                                int64_t inner, int C, const float* residual, const float* __restrict__ chan_add) {
+                                int64_t inner, int C, const float* residual, const float* __restrict__ chan_add, int64_t chan_ld) {
     constexpr int W   = V4 ? 4 : 1;
     const int64_t i   = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * W;
     if (i >= n) return;
@@ -851,11 +851,14 @@ __global__ void k_splitk_reduce(float* __restrict__ dst, const float* __restrict
         }
     }
     if (chan_add) {  // conv output [OHOW][C][N]: element i belongs to (image, channel) pair i / OHOW
-        if (inner == 1) {  // 1x1 feature maps: consecutive elements are consecutive channels
+        // (image, channel) pair pc = i / inner = n * C + c sits at chan_add[n * chan_ld + c]
+        if (inner == 1) {  // 1x1 feature maps: consecutive elements are consecutive channels (C % 4 == 0 on the vector path: no image boundary inside)
+            const int64_t nimg = i / C;
 #pragma unroll
-            for (int j = 0; j < W; ++j) v[j] += chan_add[i + j];
+            for (int j = 0; j < W; ++j) v[j] += chan_add[nimg * chan_ld + (i - nimg * C) + j];
         } else {
-            const float b = chan_add[i / inner];
+            const int64_t pc = i / inner, nimg = pc / C;
+            const float b    = chan_add[nimg * chan_ld + (pc - nimg * C)];
 #pragma unroll
             for (int j = 0; j < W; ++j) v[j] += b;
         }
@@ -868,13 +871,14 @@ __global__ void k_splitk_reduce(float* __restrict__ dst, const float* __restrict
     for (int j = 0; j < W; ++j) dst[i + j] = v[j];
 }
 static void launch_splitk_reduce(hipStream_t s, float* dst, const float* ws, int S, int64_t n, const float* bias, int64_t inner, int64_t C, const float* residual,
-                                 const float* chan_add = nullptr) {
+                                 const float* chan_add = nullptr, int64_t chan_ld = 0) {
+    if (chan_ld <= 0) chan_ld = C;
     KScope ks_(s, KF_SPLITK, 0.0, (double)n * 4.0 * (S + 1));
     const bool v4 = n % 4 == 0 && (inner % 4 == 0 || (inner == 1 && C % 4 == 0)) && (((uintptr_t)dst | (uintptr_t)ws | (uintptr_t)residual) & 15) == 0;
     if (v4)
-        k_splitk_reduce<true><<<(unsigned)((n / 4 + 255) / 256), 256, 0, s>>>(dst, ws, S, n, n, bias, inner, (int)C, residual, chan_add);
+        k_splitk_reduce<true><<<(unsigned)((n / 4 + 255) / 256), 256, 0, s>>>(dst, ws, S, n, n, bias, inner, (int)C, residual, chan_add, chan_ld);
     else
-        k_splitk_reduce<false><<<(unsigned)((n + 255) / 256), 256, 0, s>>>(dst, ws, S, n, n, bias, inner, (int)C, residual, chan_add);
+        k_splitk_reduce<false><<<(unsigned)((n + 255) / 256), 256, 0, s>>>(dst, ws, S, n, n, bias, inner, (int)C, residual, chan_add, chan_ld);
 }
 
 void splitk_reduce_rows(hipStream_t s, float* dst, const float* ws, int S, int64_t n, const float* bias, int64_t C, const float* residual) {
@@ -898,8 +902,8 @@ static const _Float16* zero_page() {
 void gemm16_init() { (void)zero_page(); }
 const _Float16* gemm16_zero_page() { return zero_page(); }
 void launch_splitk_reduce_conv(hipStream_t s, float* dst, const float* ws, int S, int64_t n, const float* bias, int64_t inner, int64_t C, const float* residual,
-                               const float* chan_add) {
-    launch_splitk_reduce(s, dst, ws, S, n, bias, inner, C, residual, chan_add);
+                               const float* chan_add, int64_t chan_ld) {
+    launch_splitk_reduce(s, dst, ws, S, n, bias, inner, C, residual, chan_add, chan_ld);
 }
 
 // GGML_MI355X_TRACE=1: one stderr line per launch (shape), in launch order — joined with a rocprofv3 kernel trace by scripts/shape_stats.py
@@ -1066,6 +1070,7 @@ void launch_gemm16_conv(hipStream_t s, float* dst, const void* x16_nhwc, const v
     g16_check_epi(e);
     g.ep   = G16Epi{e.bias, e.residual, e.scale};
     g.ep.chan_add = e.chan_add;
+    g.ep.chan_ld  = (int)e.chan_ld;
     const bool inker = splitk_ws && splitk_cnt != nullptr && splitk_S > 1;
     const int S      = inker ? splitk_S : (splitk_ws ? gemm16_split_k(g.R, OC, (int64_t)g.ICp * ksize * ksize) : 1);
     if (S > 1) {
@@ -1093,7 +1098,7 @@ void launch_gemm16_conv(hipStream_t s, float* dst, const void* x16_nhwc, const v
         g.ncol_tiles = (int)((OC + 127) / 128);
         g16_launch<128, true>(s, g, g.R, 2.0 * g.R * IC * ksize * ksize * OC, conv_bytes);
     }
-    if (S > 1 && !inker) launch_splitk_reduce(s, dst, splitk_ws, S, g.R * OC, e.bias, g.OHOW, OC, e.residual, e.chan_add);
+    if (S > 1 && !inker) launch_splitk_reduce(s, dst, splitk_ws, S, g.R * OC, e.bias, g.OHOW, OC, e.residual, e.chan_add, e.chan_ld);
 }
 
 // =====================================================================================================

@@ -74,6 +74,7 @@ struct Epilogue {
     const float* bias     = nullptr;  // per output feature / channel
     const float* residual = nullptr;  // same layout as dst (added after bias)
     const float* chan_add = nullptr;  // conv only: per (oc, n) value added (time-embedding broadcast), [OC, N]
+    int64_t chan_ld       = 0;        // floats between the images of chan_add (0 = OC: the graph tensor; > OC: a column range of a grouped projection's output)
     float scale           = 1.0f;     // applied to the accumulator before bias
     int act               = -1;       // UnOp applied last, or -1
     // gemm16 linear only (DiT blocks):
