@@ -729,6 +729,46 @@ __global__ __launch_bounds__(512, 2) void k_flash_pp(FAArgs g) {
     half8_t pa[4];
     // MFMA phase of tile t: S = K(t) Q^T (do_qk) and O += P(t-1) V(t-1) (do_pv)
     auto mphase = [&](int t, bool do_qk, bool do_pv) {
+        if constexpr (DKP <= 64) {
+            // ALL LDS fragment reads of the phase (K for QK^T, V^T for PV) are requested before the first MFMA: the wave has nothing else to do in this
+            // phase, so a read issued between MFMAs is a read whose latency the matrix pipe waits for (phases of ~1400 cycles against 450 cycles
+            // of MFMA work, profiles/r04e_pmc_flash_pp.txt)
+            half8_t kf[2][KS], vf[4][NDV];
+            if (do_qk) {
+                const _Float16* Kc = Ks + (t & 1) * TILE_H;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) kf[kb][ks] = *(const half8_t*)&Kc[(kb * 32 + (lane & 31)) * KROW + ks * 16 + hi * 8];
+            }
+            if (do_pv) {
+                const _Float16* Vc = Vt + ((t - 1) & 1) * TILE_H;
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                    for (int nb = 0; nb < NDV; ++nb) {
+                        const _Float16* vrow = &Vc[(nb * 32 + (lane & 31)) * FA_VTS + tt * 16 + 4 * hi];
+                        const half4_t v0 = *(const half4_t*)vrow, v1 = *(const half4_t*)(vrow + 8);
+                        vf[tt][nb]       = (half8_t){v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (do_pv) {  // P(t-1) has been in registers since the last VALU phase: these MFMAs wait for V fragments only
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                    for (int nb = 0; nb < NDV; ++nb) o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa[tt], vf[tt][nb], o[nb], 0, 0, 0);
+            }
+            if (do_qk) {
+                s[0] = (float16_t){0};
+                s[1] = (float16_t){0};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb) s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kb][ks], qf[ks], s[kb], 0, 0, 0);
+            }
+            return;
+        }
         if (do_qk) {
             const _Float16* Kc = Ks + (t & 1) * TILE_H;
             if constexpr (KS <= 6) {
@@ -835,7 +875,13 @@ __global__ __launch_bounds__(512, 2) void k_flash_pp(FAArgs g) {
     // ---- the two group programs (2 NT barriers each; see the phase table above).  The phase barrier waits for this wave's LDS traffic only:
     // __syncthreads() also drains vmcnt, i.e. it waited for the global loads issued a moment earlier for a LATER phase — every VALU phase then
     // lasted one L2 round trip (phases of ~2300 cycles instead of ~700, 69 % of the wave cycles parked: profiles/r04d_pmc_flash_pp.txt)
-#define FPP_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+    // (sched_barrier on both sides: the asm only orders MEMORY operations — without them the compiler moved most of a phase's MFMAs behind the barrier)
+#define FPP_BARRIER()                                                         \
+    do {                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                    \
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       \
+        __builtin_amdgcn_sched_barrier(0);                                    \
+    } while (0)
     if (grp == 0) {
         int t = 0;
         for (; t + 1 < NT; t += 2) {
