@@ -19,7 +19,7 @@ L = sd.lib()
 rng = np.random.default_rng(0)
 REPS = 5
 # variants: the round-2 kernel (one query block per wave), two query blocks per wave, the 8-wave ping-pong kernel (the default policy)
-VARIANTS = [("r2", {"flash_pp": 0, "flash_qb2": 0}), ("qb2", {"flash_pp": 0, "flash_qb2": 1}), ("pp", {"flash_pp": 1, "flash_qb2": 1})]
+VARIANTS = [("r2", {"flash_pp": 0, "flash_qb2": 0}), ("qb2", {"flash_pp": 0, "flash_qb2": 1}), ("pp", {"flash_pp": 2, "flash_qb2": 1})]
 
 
 def rel_l2(a, b):

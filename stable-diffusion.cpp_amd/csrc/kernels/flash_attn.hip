@@ -1020,9 +1020,14 @@ void launch_flash_attn(hipStream_t s, const FlashOut& out, const View4& q, const
     // two query blocks per wave (256 queries per workgroup) when the launch still gives every CU two workgroups' worth of work
     const int64_t wg256 = ((int64_t)(g.Lq + 255) / 256) * q.ne[2];
     const int NT        = (g.Lk + FA_KT - 1) / FA_KT;
-    // the ping-pong kernel (8 waves = 256 queries per workgroup, one workgroup per CU): long key loops on grids that fill their rounds
-    // (320 workgroups on 256 CUs run as two rounds: SDXL's 4096-token level at batch 1 stays on the 4-wave kernel); d = 160 spills
-    const bool pp       = g_flash_pp && fast && D <= 128 && NT >= g_flash_pp_min_tiles && g.Lq >= 192 && wg256 >= 256 && wg256 * 5 >= ((wg256 + 255) / 256) * 256 * 4;
+    // the ping-pong kernel (8 waves = 256 queries per workgroup, one workgroup per CU): long key loops on grids that fill their rounds.  Measured
+    // (profiles/r04f_flash_variants.txt, HIP events, one box): it wins at d = 80 (90.6 vs 97.6 us at L = 1024), ties at d = 128 and LOSES at
+    // d <= 64 (d = 40, L = 4096: 814 vs 657 us for two query blocks per wave) — the counters show matrix-pipe time + VALU time + LDS time still
+    // adding up to the kernel time although the two groups are in opposite phases by construction: on this part a SIMD does not overlap one
+    // wave's MFMAs with its partner's VALU stream the way the phase picture assumes, so the extra barriers are pure cost.  Policy: d in (64, 96]
+    // only (option flash_pp = 2 forces it wherever it is legal, for A/B runs)
+    const bool pp_ok    = fast && D <= 128 && NT >= g_flash_pp_min_tiles && g.Lq >= 192 && wg256 >= 256 && wg256 * 5 >= ((wg256 + 255) / 256) * 256 * 4;
+    const bool pp       = pp_ok && (g_flash_pp == 2 || (g_flash_pp == 1 && D > 64 && D <= 96));
     const bool qb2      = !pp && g_flash_qb2 && fast && D <= 48 && NT >= 4 && g.Lq >= 192 && wg256 >= 512;  // two query blocks per wave: d = 40 only (d = 64 measured slower, d >= 80 spills)
     const int QWG       = (qb2 || pp) ? 256 : 128;
     dim3 grid((unsigned)((g.Lq + QWG - 1) / QWG), (unsigned)q.ne[2]);
