@@ -200,12 +200,12 @@ def main():
                          "avg_launch_algorithmic_bytes": round(kt["total_bytes"] / kt["launches"]),
                          "share_of_step_time": round(kt["total_ms"] / (dt * 1e3), 4),
                          "timing": "hipEventElapsedTime around each launch on the launch stream, inside the timed region"})
-        tf = ROOT / "profiles" / "r02_pmc_traffic.json"
+        tf = ROOT / "profiles" / "r04_pmc_traffic_conv256.json"   # PMC passes over THIS kernel family on the current code (scripts/gpu_round_end3.sh)
         if tf.exists() and args.model == "sd15" and B == 8 and fuse:
             try:
                 pm = json.loads(tf.read_text())
                 roofline["traffic"] = pm["hbm_bytes_per_launch"]
-                roofline["traffic_source"] = "profiles/r02_pmc_traffic.json (kernels matching '" + pm.get("kernel", "") + "': the 256-row conv instantiations): " + pm.get("source", "")
+                roofline["traffic_source"] = "profiles/r04_pmc_traffic_conv256.json (kernels matching '" + pm.get("kernel", "") + "', " + str(pm.get("launches_fetch_pass")) + " launches): " + pm.get("source", "")
             except (ValueError, KeyError):
                 pass
     roofline["whole_step_tflops"] = round(step_tflops, 2)  # all kernels + host graph build + uploads: 2*B*UNet-forward FLOPs / step wall time

@@ -84,6 +84,7 @@ struct ggml_backend_mi355x_stats {
     int64_t hoisted_kv_linears;  /* cross-attention K / V projections of the text context computed in grouped launches ahead of their graph position (results in the arena) */
     int64_t window_convs;        /* 3x3 convs planned on the LDS-window kernel (conv3w.hip) */
     int64_t hoisted_emb_linears; /* per-ResBlock SiLU(emb) -> Linear projections computed by one grouped weight-streaming launch ahead of their graph position */
+    int64_t fused_rows16;        /* Linear (+bias, +residual) read only by a 1x1 conv (SpatialTransformer proj_out): written as the conv's f16 operand rows */
 };
 GGML_MI355X_API void ggml_backend_mi355x_get_stats(struct ggml_backend_mi355x_stats* out);
 /* live per-kernel-family timing (bench.py's roofline legs): while a family's bit is enabled, every dispatch of that family is bracketed by
@@ -113,7 +114,13 @@ GGML_MI355X_API int ggml_backend_mi355x_get_kernel_timings(struct ggml_backend_m
  * raw-block MFMA GEMM up to n rows; 8192 = the resident-quantised mode, no f16 image for any quantised Linear), "qgemm16" (1);
  * launch grouping: "fuse_siblings" (1: q / k / v projections of one attention as one multi-weight launch), "hoist_kv" (1: cross-attention K / V
  * projections of all blocks grouped ahead of their graph position, results in the arena); "fuse_q16", "fuse_chan_add", "fuse_proj_tokens" (1);
- * "splitk_inkernel" (0: split-K combined by the last-arriving workgroup, 128-row tiles; measured slower) / "splitk_in_target" (320).
+ * "hoist_emb" (1: the per-ResBlock SiLU(emb) -> Linear projections as one grouped weight-streaming launch), "fuse_rows16" (0: a Linear read only by a
+ * 1x1 conv writes the conv's f16 operand rows; measured slightly slower on SD1.5);
+ * "splitk_inkernel" (0: split-K combined by the last-arriving workgroup, 128-row tiles; measured slower) / "splitk_in_target" (320);
+ * conv: "conv3w" (1: 3x3 / stride-1 convs on 16..128-wide maps on the LDS-window kernel), "conv3w_min_blocks" (8) / "conv3w_min_blocks_deep" (5:
+ * least 32-channel blocks per K slice when the window kernel splits K);
+ * flash attention: "flash_qb2" (1: two query blocks per wave for d <= 48), "flash_pp" (0; 1 = the 8-wave ping-pong kernel for 64 < d <= 96,
+ * 2 = wherever it is legal: measured slower or equal, kept for A/B runs), "flash_pp_min_tiles" (4).
  * Wrong-result timing ablations exist only in builds with -DMI355X_EXPERIMENTS ("flash_ablate"). */
 GGML_MI355X_API void ggml_backend_mi355x_set_option(const char* key, int value);
 /* the hipStream_t every graph of this backend instance is enqueued on (graph_compute_async, set/get_tensor_async): a caller that touches a

@@ -4,7 +4,7 @@ MI355X_MICROARCH.md 'rocprofv3 PMC slots').  Units/corrections per that guide's 
 units of 1024 B (rocprofv3 FETCH_SIZE/WRITE_SIZE = request count * 64 B / 1024), and on gfx950 FETCH_SIZE tallies the 128-B
 requests of wide coalesced streaming reads (16 B/lane, global_load and LDS-DMA alike — exactly this kernel's loads) at 64 B, so it
 is DOUBLED; WRITE_SIZE is uncalibrated and reported as is.
-usage: pmc_traffic.py <fetch.db> <write.db> <kernel substring> <out.json>"""
+usage: pmc_traffic.py <fetch.db> <write.db> <kernel substring[|substring...]> <out.json>"""
 import json
 import sqlite3
 import sys
@@ -12,7 +12,9 @@ import sys
 
 def per_launch(db, counter, pat):
     con = sqlite3.connect(db)
-    rows = list(con.execute("select dispatch_id, sum(counter_value) from pmc_events where counter_name = ? and name like ? group by dispatch_id", (counter, f"%{pat}%")))
+    pats = pat.split("|")   # several kernel-name patterns (SQL LIKE) may form one family: "k_conv3w|k_gemm16<256, %, true"
+    where = " or ".join("name like ?" for _ in pats)
+    rows = list(con.execute(f"select dispatch_id, sum(counter_value) from pmc_events where counter_name = ? and ({where}) group by dispatch_id", (counter, *[f"%{q}%" for q in pats])))
     vals = [v for _, v in rows]
     return (sum(vals) / len(vals) if vals else None), len(vals)
 

@@ -41,11 +41,11 @@ namespace {
 struct Stats {
     std::atomic<int64_t> graphs_computed{0}, plans_built{0}, nodes_seen{0}, kernels_planned{0}, kernels_launched{0}, fused_conv{0},
         fused_conv_bounced{0}, fused_linear{0}, fused_norm{0}, fused_geglu{0}, fused_attention{0}, generic_matmul{0}, swizzled_weight_bytes{0}, fused_linear_geglu{0}, split_k_gemms{0}, head_major_gemms{0}, fused_modulate{0}, fused_gate{0}, fused_gelu{0}, fused_rope{0}, fused_concat_heads{0},
-        graph_replays{0}, qgemv_linears{0}, fused_chan_add{0}, fused_proj_tokens{0}, gemm_attention{0}, fused_q16{0}, split_k_inlaunch{0}, qgemm16_linears{0}, fgemv_linears{0}, fused_presilu{0}, fused_sibling_linears{0}, hoisted_kv_linears{0}, window_convs{0}, hoisted_emb_linears{0};
+        graph_replays{0}, qgemv_linears{0}, fused_chan_add{0}, fused_proj_tokens{0}, gemm_attention{0}, fused_q16{0}, split_k_inlaunch{0}, qgemm16_linears{0}, fgemv_linears{0}, fused_presilu{0}, fused_sibling_linears{0}, hoisted_kv_linears{0}, window_convs{0}, hoisted_emb_linears{0}, fused_rows16{0};
 } g_stats;
 
 struct Options {
-    std::atomic<int> fusion{1}, mfma_gemm{1}, hip_graph{0}, flash_pattern{1}, gemm16{1}, fuse_modulate{1}, fuse_gate{1}, fuse_gelu{1}, fuse_rope{1}, fuse_concat_heads{1}, qgemv{1}, fuse_chan_add{1}, fuse_proj_tokens{1}, fuse_q16{1}, qgemm16{1}, fgemv{1}, fuse_siblings{1}, hoist_kv{1}, hoist_emb{1};
+    std::atomic<int> fusion{1}, mfma_gemm{1}, hip_graph{0}, flash_pattern{1}, gemm16{1}, fuse_modulate{1}, fuse_gate{1}, fuse_gelu{1}, fuse_rope{1}, fuse_concat_heads{1}, qgemv{1}, fuse_chan_add{1}, fuse_proj_tokens{1}, fuse_q16{1}, qgemm16{1}, fgemv{1}, fuse_siblings{1}, hoist_kv{1}, hoist_emb{1}, fuse_rows16{0};
 } g_opt;
 
 using Step = std::function<void(hipStream_t)>;
@@ -470,6 +470,43 @@ bool linear_fast_ok(const ggml_tensor* n) {
     return true;
 }
 
+// CONT node i = CONT(PERMUTE(1,0,2,3)(t)) of a token-major tensor t [C, HW, N] feeding RESHAPE [W,H,C,N] -> the IM2COL of a fusable 1x1 conv
+// (SpatialTransformer proj_out, block.hpp:566-572) and nothing else.  On success *rs_out = the last RESHAPE (the conv's input tensor).
+static bool tokens_to_conv_match(const GInfo& gi, int i, int* rs_out) {
+    const ggml_tensor* n = gi.node(i);
+    if (!g_opt.fuse_proj_tokens || !g_opt.gemm16 || !g_opt.fusion || n->op != GGML_OP_CONT || !is_f32(n) || !contig(n) || (n->flags & GGML_TENSOR_FLAG_OUTPUT)) return false;
+    const ggml_tensor* pm = n->src[0];
+    if (!pm || pm->op != GGML_OP_PERMUTE) return false;
+    const int32_t* pa = pm->op_params;
+    if (!(pa[0] == 1 && pa[1] == 0 && pa[2] == 2 && pa[3] == 3)) return false;
+    const ggml_tensor* t = pm->src[0];  // [C, HW, N(, 1)] token-major
+    if (!t || !is_f32(t) || !contig(t) || t->ne[3] != 1 || t->ne[0] % 4 != 0 || !aligned16(t->data)) return false;
+    const int64_t C = t->ne[0], HW = t->ne[1], N = t->ne[2];
+    int j = gi.sole(i);
+    int rs = -1;
+    while (j >= 0 && gi.node(j)->op == GGML_OP_RESHAPE) {
+        rs = j;
+        j  = gi.sole(j);
+    }
+    if (rs < 0 || j < 0 || gi.node(j)->op != GGML_OP_IM2COL || gi.node(j)->src[1] != gi.node(rs) || !conv_im2col_fast_ok(gi, j)) return false;
+    const ggml_tensor* xr  = gi.node(rs);
+    const ggml_tensor* ker = gi.node(j)->src[0];
+    if (ker->ne[0] != 1 || ker->ne[1] != 1 || ker->ne[2] != C || xr->ne[2] != C || xr->ne[3] != N || xr->ne[0] * xr->ne[1] != HW) return false;
+    if (!gi.only_noops_between(i, j, {i})) return false;
+    *rs_out = rs;
+    return true;
+}
+// node `last` (a token-major [C, HW, N] tensor) is read ONLY by such a CONT(PERMUTE) -> 1x1 conv chain: its f32 value is never needed, the
+// producing GEMM may write the conv's f16 operand rows instead
+static bool only_consumer_is_tokens_to_conv(const GInfo& gi, int last) {
+    const ggml_tensor* t = gi.node(last);
+    if ((t->flags & GGML_TENSOR_FLAG_OUTPUT) || gi.consumers[last].size() != 1) return false;
+    const int jp = gi.consumers[last][0];
+    if (gi.node(jp)->op != GGML_OP_PERMUTE || gi.node(jp)->src[0] != t || (gi.node(jp)->flags & GGML_TENSOR_FLAG_OUTPUT) || gi.consumers[jp].size() != 1) return false;
+    int rs = -1;
+    return tokens_to_conv_match(gi, gi.consumers[jp][0], &rs);
+}
+
 void plan_linear(Builder& B, int i, hipStream_t s, std::vector<int>& chain) {
     GInfo& gi            = B.gi;
     const ggml_tensor* n = gi.node(i);
@@ -756,6 +793,16 @@ void plan_linear(Builder& B, int i, hipStream_t s, std::vector<int>& chain) {
                 launch_qgemm16(st, dst, nullptr, 0, P->arena + off, ld, tokens, wraw, wt, K, M, ep, S > 1 ? (float*)(P->arena + wsoff) : nullptr, S);
             });
             g_stats.qgemm16_linears++;
+        } else if (g_opt.fuse_rows16 && !ep.gate && emit_node == i && M % 64 == 0 && x->ne[3] == 1 && only_consumer_is_tokens_to_conv(gi, last)) {
+            // FF2 (+bias, +residual) of a SpatialTransformer whose result only proj_out reads (block.hpp:566-572): write the 1x1 conv's f16 operand
+            // rows directly — no f32 tensor, no pack pass (the conv rounds its input to f16 anyway: same rounding point).  Option fuse_rows16,
+            // default OFF: on the SD1.5 bench forward it measured 23.34 vs 23.21 ms per step (profiles/r04h_ab_rows16.txt) — the f32 tensor the
+            // pack pass re-reads sits in the 256 MB Infinity Cache, while the f16 epilogue stores 64-byte row segments
+            const size_t ooff       = B.alloc((size_t)tokens * M * 2);
+            const Builder::Split sk = B.plan_split(tokens, M, K, false, false);
+            B.emit([=](hipStream_t st) { launch_gemm16_linear(st, nullptr, P->arena + ooff, M, P->arena + off, ld, swz, tokens, K, M, M, ep, 0, 0, 0, sk.ws(P), sk.cnt(P), sk.S); });
+            B.packed[gi.node(last)] = Packed{ooff, M, false};
+            g_stats.fused_rows16++;
         } else {
             const Builder::Split sk = B.plan_split(tokens, M, K, false, !ep.gate);
             B.emit_at(emit_node, i, [=](hipStream_t st) { launch_gemm16_linear(st, dst, nullptr, 0, P->arena + off, ld, swz, tokens, K, M, M, ep, 0, 0, 0, sk.ws(P), sk.cnt(P), sk.S); });
@@ -1280,36 +1327,26 @@ bool plan_conv_chain(Builder& B, int i, hipStream_t s, std::vector<int>& chain) 
 // NHWC f16 operand image [N][HW][Cp] is exactly the token rows rounded to f16: pack it straight from the token tensor and drop the
 // transposing copy (its f32 output is read by nothing else).
 bool plan_tokens_to_conv(Builder& B, int i, hipStream_t, std::vector<int>& chain) {
-    GInfo& gi            = B.gi;
-    const ggml_tensor* n = gi.node(i);
-    if (!g_opt.fuse_proj_tokens || !g_opt.gemm16 || !g_opt.fusion || !is_f32(n) || !contig(n) || (n->flags & GGML_TENSOR_FLAG_OUTPUT)) return false;
-    const ggml_tensor* pm = n->src[0];
-    if (!pm || pm->op != GGML_OP_PERMUTE) return false;
-    const int32_t* pa = pm->op_params;
-    if (!(pa[0] == 1 && pa[1] == 0 && pa[2] == 2 && pa[3] == 3)) return false;
-    const ggml_tensor* t = pm->src[0];  // [C, HW, N(, 1)] token-major
-    if (!t || !is_f32(t) || !contig(t) || t->ne[3] != 1 || t->ne[0] % 4 != 0 || !aligned16(t->data)) return false;
+    GInfo& gi = B.gi;
+    int rs    = -1;
+    if (!tokens_to_conv_match(gi, i, &rs)) return false;
+    const ggml_tensor* t  = gi.node(i)->src[0]->src[0];
+    const ggml_tensor* xr = gi.node(rs);
     const int64_t C = t->ne[0], HW = t->ne[1], N = t->ne[2];
-    // sole consumer chain: RESHAPE [W,H,C,N] -> IM2COL of a fusable 1x1 conv
-    int j = gi.sole(i);
-    int rs = -1;
-    while (j >= 0 && gi.node(j)->op == GGML_OP_RESHAPE) {
-        rs = j;
-        j  = gi.sole(j);
+    chain = {i};
+    g_stats.fused_proj_tokens++;
+    // the producing Linear already wrote these rows as an f16 image (plan_linear: residual epilogue -> f16 rows): the conv reads it as it is
+    const auto pr = B.packed.find(t);
+    if (pr != B.packed.end() && !pr->second.nhwc && pr->second.ld == rup64(C)) {
+        B.packed[xr] = Packed{pr->second.off, pr->second.ld, true};
+        return true;
     }
-    if (rs < 0 || j < 0 || gi.node(j)->op != GGML_OP_IM2COL || gi.node(j)->src[1] != gi.node(rs) || !conv_im2col_fast_ok(gi, j)) return false;
-    const ggml_tensor* xr  = gi.node(rs);
-    const ggml_tensor* ker = gi.node(j)->src[0];
-    if (ker->ne[0] != 1 || ker->ne[1] != 1 || ker->ne[2] != C || xr->ne[2] != C || xr->ne[3] != N || xr->ne[0] * xr->ne[1] != HW) return false;
-    if (!gi.only_noops_between(i, j, {i})) return false;
     Packed pk{B.alloc((size_t)N * HW * rup64(C) * 2), rup64(C), true};
     Planner* P       = B.P;
     const size_t off = pk.off;
     const float* tp  = (const float*)t->data;
     B.emit([=](hipStream_t st) { launch_pack_rows_f16(st, P->arena + off, tp, N * HW, C, C); });
     B.packed[xr] = pk;
-    chain        = {i};
-    g_stats.fused_proj_tokens++;
     return true;
 }
 
@@ -2332,6 +2369,7 @@ void planner_get_stats(ggml_backend_mi355x_stats* o) {
     o->hoisted_kv_linears    = g_stats.hoisted_kv_linears;
     o->window_convs          = g_stats.window_convs;
     o->hoisted_emb_linears   = g_stats.hoisted_emb_linears;
+    o->fused_rows16          = g_stats.fused_rows16;
     o->fused_attention       = g_stats.fused_attention;
     o->generic_matmul        = g_stats.generic_matmul;
     o->swizzled_weight_bytes = g_stats.swizzled_weight_bytes;
@@ -2356,6 +2394,7 @@ void planner_set_option(const char* key, int value) {
     else if (!strcmp(key, "flash_pp_min_tiles")) flash_attn_set_pp_min_tiles(value);
     else if (!strcmp(key, "conv3w")) conv3w_set(value);
     else if (!strcmp(key, "hoist_emb")) g_opt.hoist_emb = value;
+    else if (!strcmp(key, "fuse_rows16")) g_opt.fuse_rows16 = value;
     else if (!strcmp(key, "conv3w_min_blocks")) conv3w_set_min_blocks(value);
     else if (!strcmp(key, "conv3w_min_blocks_deep")) conv3w_set_min_blocks_deep(value);
     else if (!strcmp(key, "gemm16_bn64")) gemm16_set_bn64(value);

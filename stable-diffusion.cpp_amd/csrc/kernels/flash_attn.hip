@@ -975,7 +975,7 @@ static int g_flash_grid = 1;  // option "flash_grid": 0 = plain (query block, he
 void flash_attn_set_grid(int v) { g_flash_grid = v; }
 static int g_flash_qb2 = 1;  // option "flash_qb2": 0 = one query block per wave everywhere (the round-2 kernel; A/B measurements)
 void flash_attn_set_qb2(int v) { g_flash_qb2 = v; }
-static int g_flash_pp = 1;  // option "flash_pp": 0 = never the ping-pong kernel (A/B measurements)
+static int g_flash_pp = 0;  // option "flash_pp": 0 (default) = never the ping-pong kernel, 1 = for 64 < d <= 96, 2 = wherever it is legal (A/B measurements)
 void flash_attn_set_pp(int v) { g_flash_pp = v; }
 static int g_flash_pp_min_tiles = 4;  // option "flash_pp_min_tiles": key tiles (64 keys) from which the ping-pong pipeline has a steady state worth its prologue
 void flash_attn_set_pp_min_tiles(int v) { g_flash_pp_min_tiles = v; }
@@ -1024,8 +1024,9 @@ void launch_flash_attn(hipStream_t s, const FlashOut& out, const View4& q, const
     // (profiles/r04f_flash_variants.txt, HIP events, one box): it wins at d = 80 (90.6 vs 97.6 us at L = 1024), ties at d = 128 and LOSES at
     // d <= 64 (d = 40, L = 4096: 814 vs 657 us for two query blocks per wave) — the counters show matrix-pipe time + VALU time + LDS time still
     // adding up to the kernel time although the two groups are in opposite phases by construction: on this part a SIMD does not overlap one
-    // wave's MFMAs with its partner's VALU stream the way the phase picture assumes, so the extra barriers are pure cost.  Policy: d in (64, 96]
-    // only (option flash_pp = 2 forces it wherever it is legal, for A/B runs)
+    // wave's MFMAs with its partner's VALU stream the way the phase picture assumes, so the extra barriers are pure cost.  Inside the SD1.5 forward
+    // even the d = 80 win does not survive (profiles/r04g_ab_flash_pp.txt: step 25.70 ms without it, 25.87 with it for d = 80, 26.60 everywhere):
+    // default OFF; flash_pp = 1 takes it for d in (64, 96], 2 wherever it is legal (A/B runs)
     const bool pp_ok    = fast && D <= 128 && NT >= g_flash_pp_min_tiles && g.Lq >= 192 && wg256 >= 256 && wg256 * 5 >= ((wg256 + 255) / 256) * 256 * 4;
     const bool pp       = pp_ok && (g_flash_pp == 2 || (g_flash_pp == 1 && D > 64 && D <= 96));
     const bool qb2      = !pp && g_flash_qb2 && fast && D <= 48 && NT >= 4 && g.Lq >= 192 && wg256 >= 512;  // two query blocks per wave: d = 40 only (d = 64 measured slower, d >= 80 spills)

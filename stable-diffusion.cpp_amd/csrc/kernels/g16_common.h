@@ -48,6 +48,9 @@ struct G16Args {
     int64_t OHOW;
     const _Float16* zero;
     G16Epi ep;
+#ifdef MI355X_EXPERIMENTS
+    int abl;  // option "gemm16_abl" (wrong-result timing ablations): 5 = GEGLU epilogue without the GELU arithmetic, 6 = epilogue without its stores, 7 = no main loop
+#endif
 };
 
 #define GLDS16(gptr, ldsptr) \
@@ -66,7 +69,7 @@ __device__ __forceinline__ void st_u(T* ubase, uint32_t lane_bytes, T v) { *(T*)
 template <typename T>
 __device__ __forceinline__ T ld_u(const T* ubase, uint32_t lane_bytes) { return *(const T*)((const char*)ubase + lane_bytes); }
 
-enum { EPI_F32 = 0, EPI_F32_RES = 1, EPI_F16 = 2, EPI_HM_F32 = 3, EPI_HM_F16 = 4, EPI_GENERIC = 5, EPI_F16_GELU = 6, EPI_F32_GATE = 7 };
+enum { EPI_F32 = 0, EPI_F32_RES = 1, EPI_F16 = 2, EPI_HM_F32 = 3, EPI_HM_F16 = 4, EPI_GENERIC = 5, EPI_F16_GELU = 6, EPI_F32_GATE = 7, EPI_F16_RES = 8 };
 
 // FF1 + GEGLU: the weight image is laid out (k_wswz_linear, geglu_inner > 0) so that inside every 128-column tile the 32-column blocks
 // are [value w0 | gate w0 | value w1 | gate w1]: a wave's even column block holds 32 value columns, the next odd one the matching gates
@@ -92,6 +95,17 @@ __device__ __forceinline__ void epi_geglu(const float16_t (&acc)[RB][CB], const 
                 const int ro = (r & 3) + 8 * (r >> 2);
                 if (ro >= nvl) continue;
                 const float xv = acc[rb][2 * p][r] * g.ep.scale + bx, gv = acc[rb][2 * p + 1][r] * g.ep.scale + bg;
+#ifdef MI355X_EXPERIMENTS
+                if (g.abl == 5) {
+                    st_u(ub + (int64_t)ro * g.ldd16, lb, (_Float16)(xv * gv));
+                    continue;
+                }
+                if (g.abl == 6) {
+                    const float y = xv * act_apply<UN_GELU>(gv);
+                    if (y == 123456.789f) st_u(ub + (int64_t)ro * g.ldd16, lb, (_Float16)y);
+                    continue;
+                }
+#endif
                 st_u(ub + (int64_t)ro * g.ldd16, lb, (_Float16)(xv * act_apply<UN_GELU>(gv)));
             }
         }
@@ -105,7 +119,7 @@ __device__ __forceinline__ void epi_linear(const float16_t (&acc)[RB][CB], const
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
         const int64_t base_row = row0 + wr * (RB * 32) + rb * 32;  // wave-uniform
-        if ((MODE == EPI_GENERIC || MODE == EPI_F16 || MODE == EPI_F16_GELU || MODE == EPI_F32_GATE) && base_row >= g.R) continue;
+        if ((MODE == EPI_GENERIC || MODE == EPI_F16 || MODE == EPI_F16_GELU || MODE == EPI_F16_RES || MODE == EPI_F32_GATE) && base_row >= g.R) continue;
         uint32_t hm_n0 = 0, hm_l0 = 0;
         if (MODE == EPI_HM_F32 || MODE == EPI_HM_F16) {
             if (base_row >= g.R) continue;
@@ -143,6 +157,27 @@ __device__ __forceinline__ void epi_linear(const float16_t (&acc)[RB][CB], const
                     float v = acc[rb][cb][r] * g.ep.scale + bias;
                     if (MODE == EPI_F16_GELU) v = act_apply<UN_GELU>(v);
                     st_u(ub + (int64_t)ro * g.ldd16, lb, (_Float16)v);
+                }
+            } else if (MODE == EPI_F16_RES) {
+                // f16 rows of acc + bias + residual (f32 rows, ldd): the result is read only as a GEMM / 1x1-conv operand image
+                _Float16* ub      = g.dst16 + base_row * g.ldd16 + cblk;
+                const float* ur   = g.ep.residual + base_row * g.ldd + cblk;
+                const uint32_t lb = (uint32_t)(lc + 4 * hi * (int)g.ldd16) * 2u, lr = (uint32_t)(lc + 4 * hi * (int)g.ldd) * 4u;
+                const int nvl     = (int)(g.R - base_row < 32 ? g.R - base_row : 32) - 4 * hi;
+#pragma unroll
+                for (int r0 = 0; r0 < 16; r0 += 8) {
+                    float rv[8];
+#pragma unroll
+                    for (int r = r0; r < r0 + 8; ++r) {
+                        const int ro = (r & 3) + 8 * (r >> 2);
+                        rv[r - r0]   = ro < nvl ? ld_u(ur + (int64_t)ro * g.ldd, lr) : 0.f;
+                    }
+#pragma unroll
+                    for (int r = r0; r < r0 + 8; ++r) {
+                        const int ro = (r & 3) + 8 * (r >> 2);
+                        if (ro >= nvl) continue;
+                        st_u(ub + (int64_t)ro * g.ldd16, lb, (_Float16)(acc[rb][cb][r] * g.ep.scale + bias + rv[r - r0]));
+                    }
                 }
             } else if (MODE == EPI_F32_GATE) {
                 // x + (acc + bias) * gate[image][col]: the 32 rows of a block cross at most one image boundary (gate_L >= 32)
@@ -206,6 +241,36 @@ __device__ __forceinline__ void epi_linear(const float16_t (&acc)[RB][CB], const
                 }
             }
         }
+    }
+}
+
+// the Linear epilogue of one workgroup tile: ONE compact variant, chosen from launch- / workgroup-uniform conditions
+template <int BM, int RB, int CB>
+__device__ __forceinline__ void epi_dispatch_linear(const float16_t (&acc)[RB][CB], const G16Args& g, int64_t row0, int col0, int wr, int wc, int lane) {
+    const bool full = row0 + BM <= g.R;
+    if (CB % 2 == 0 && g.geglu_inner > 0) {
+        if constexpr (CB % 2 == 0) epi_geglu(acc, g, row0, col0, wr, wc, lane);
+    } else if (g.hm_d > 0 && g.hm_L >= 32 && !g.ep.residual && (g.dst != nullptr) != (g.dst16 != nullptr)) {
+        if (g.dst16)
+            epi_linear<EPI_HM_F16>(acc, g, row0, col0, wr, wc, lane);
+        else
+            epi_linear<EPI_HM_F32>(acc, g, row0, col0, wr, wc, lane);
+    } else if (g.ep.gate) {
+        epi_linear<EPI_F32_GATE>(acc, g, row0, col0, wr, wc, lane);
+    } else if (full && g.hm_d == 0 && g.dst && !g.dst16) {
+        if (g.ep.residual)
+            epi_linear<EPI_F32_RES>(acc, g, row0, col0, wr, wc, lane);
+        else
+            epi_linear<EPI_F32>(acc, g, row0, col0, wr, wc, lane);
+    } else if (g.hm_d == 0 && g.dst16 && !g.dst && g.ep.residual && !g.ep.gelu) {
+        epi_linear<EPI_F16_RES>(acc, g, row0, col0, wr, wc, lane);
+    } else if (g.hm_d == 0 && g.dst16 && !g.dst && !g.ep.residual) {
+        if (g.ep.gelu)
+            epi_linear<EPI_F16_GELU>(acc, g, row0, col0, wr, wc, lane);
+        else
+            epi_linear<EPI_F16>(acc, g, row0, col0, wr, wc, lane);
+    } else {
+        epi_linear<EPI_GENERIC>(acc, g, row0, col0, wr, wc, lane);
     }
 }
 

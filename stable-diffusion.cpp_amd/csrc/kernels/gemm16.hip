@@ -70,6 +70,9 @@ __global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g
     }
     // split-K: this workgroup accumulates K tiles [kt0, kt0 + nt) and stores raw partial sums into its slab
     int kt0 = 0, nt = g.nt;
+#ifdef MI355X_EXPERIMENTS
+    if (g.abl == 7) nt = PIPE ? 4 : 1;  // timing ablation: (almost) no main loop, the launch's fixed cost + epilogue
+#endif
     if (g.split_k > 1) {
         kt0 = blockIdx.y * g.nt_slice;
         nt  = min(g.nt_slice, g.nt - kt0);
@@ -570,30 +573,7 @@ __global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g
 
     // ---- epilogue: one compact variant per workgroup (all conditions are launch- or workgroup-uniform)
     if (!CONV) {
-        const bool full  = row0 + BM <= g.R;
-        const bool plain = full;
-        if (CB % 2 == 0 && g.geglu_inner > 0) {
-            if constexpr (CB % 2 == 0) epi_geglu(acc, g, row0, col0, wr, wc, lane);
-        } else if (g.hm_d > 0 && g.hm_L >= 32 && !g.ep.residual && (g.dst != nullptr) != (g.dst16 != nullptr)) {
-            if (g.dst16)
-                epi_linear<EPI_HM_F16>(acc, g, row0, col0, wr, wc, lane);
-            else
-                epi_linear<EPI_HM_F32>(acc, g, row0, col0, wr, wc, lane);
-        } else if (g.ep.gate) {
-            epi_linear<EPI_F32_GATE>(acc, g, row0, col0, wr, wc, lane);
-        } else if (plain && g.hm_d == 0 && g.dst && !g.dst16) {
-            if (g.ep.residual)
-                epi_linear<EPI_F32_RES>(acc, g, row0, col0, wr, wc, lane);
-            else
-                epi_linear<EPI_F32>(acc, g, row0, col0, wr, wc, lane);
-        } else if (g.hm_d == 0 && g.dst16 && !g.dst && !g.ep.residual) {
-            if (g.ep.gelu)
-                epi_linear<EPI_F16_GELU>(acc, g, row0, col0, wr, wc, lane);
-            else
-                epi_linear<EPI_F16>(acc, g, row0, col0, wr, wc, lane);
-        } else {
-            epi_linear<EPI_GENERIC>(acc, g, row0, col0, wr, wc, lane);
-        }
+        epi_dispatch_linear<BM>(acc, g, row0, col0, wr, wc, lane);
     } else {
         const bool fullc = col0 + BN <= g.C;
         if (fullc) {
@@ -941,6 +921,9 @@ void launch_gemm16_linear(hipStream_t s, float* dst, void* dst16, int64_t ldd16,
     g.C     = M;
     g.nt    = (int)(Kp / (g16_bk32() ? 32 : 64));
     g16_check_epi(e);
+#ifdef MI355X_EXPERIMENTS
+    g.abl = g_g16_abl;
+#endif
     g.ep    = {e.bias, e.residual, e.scale, e.gate, e.gate_L, e.gelu};
     if ((e.gate && (!e.residual || e.gate_L < 32 || !dst || dst16 || hm_d > 0 || rows >= (1ll << 31))) || (e.gelu && (dst || !dst16 || e.residual || hm_d > 0))) {
         fprintf(stderr, "ggml-mi355x: invalid gated / gelu gemm16 epilogue request\n");
@@ -1039,6 +1022,9 @@ void launch_gemm16_linear_geglu(hipStream_t s, void* dst16, const void* a16, int
     g.nt          = (int)(Kp / (g16_bk32() ? 32 : 64));
     g.ep          = G16Epi{bias, nullptr, 1.f};
     g.ncol_tiles  = (int)((M + 127) / 128);
+#ifdef MI355X_EXPERIMENTS
+    g.abl = g_g16_abl;
+#endif
     if (g16_trace()) fprintf(stderr, "G16 linear rows=%lld K=%lld M=%lld res=0 hm=0 f16out=1 geglu=1\n", (long long)rows, (long long)K, (long long)M);
     g16_launch<128, false>(s, g, rows, 2.0 * rows * K * M, (double)rows * rup64(K, 64) * 2.0 + (double)rup64(K, 64) * rup64(M, 128) * 2.0 + (double)rows * (M / 2) * 2.0);
 }

@@ -198,6 +198,53 @@ def test_spatial_transformer_projections_as_token_gemms(sd, oracle, gpu, rng, N,
         assert sd.backend_stats()["fused_proj_tokens"] - before["fused_proj_tokens"] == 2
 
 
+@pytest.mark.parametrize("N,C,K,H,W", [(2, 320, 1280, 16, 16), (3, 64, 256, 5, 7), (1, 128, 512, 9, 9), (2, 96, 384, 8, 8)])
+def test_ff2_residual_written_as_proj_out_operand_rows(sd, oracle, gpu, rng, N, C, K, H, W):
+    """Tail of a SpatialTransformer (block.hpp:560-577): FF2 Linear (+bias) + residual -> CONT(PERMUTE(1,0,2,3)) -> RESHAPE -> proj_out conv1x1
+    (+bias) + x.  The FF2 result is read only by the 1x1 conv, which rounds its input to f16: the GEMM epilogue writes acc + bias + residual
+    as the conv's f16 operand rows (no f32 tensor, no pack pass).  C = 96 (not a multiple of 64) keeps the f32 + pack path."""
+    x = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    t_in = rng.standard_normal((N, H * W, K)).astype(np.float32)
+    t_res = rng.standard_normal((N, H * W, C)).astype(np.float32)
+    w2 = (rng.standard_normal((C, K)) / np.sqrt(K)).astype(np.float32)
+    b2 = rng.standard_normal(C).astype(np.float32)
+    w_out = (rng.standard_normal((C, C, 1, 1)) / np.sqrt(C)).astype(np.float32)
+    b_out = rng.standard_normal(C).astype(np.float32)
+
+    def build(g, L):
+        xin = g.input(x)
+        res = g.input(t_res)
+        t = L.ggml_mul_mat(g.ctx, g.weight(w2, F16), g.input(t_in))
+        t = L.ggml_add_inplace(g.ctx, t, g.weight(b2, F32))
+        t = L.ggml_add(g.ctx, t, res)
+        y = L.ggml_cont(g.ctx, L.ggml_permute(g.ctx, t, 1, 0, 2, 3))
+        y = L.ggml_reshape_4d(g.ctx, y, W, H, C, N)
+        y = L.ggml_conv_2d(g.ctx, g.weight(w_out, F16), y, 1, 1, 0, 0, 1, 1)
+        y = L.ggml_add_inplace(g.ctx, y, L.ggml_reshape_4d(g.ctx, g.weight(b_out, F32), 1, 1, C, 1))
+        return L.ggml_add(g.ctx, y, xin)
+
+    before = sd.backend_stats() if _on_gpu() else None
+    if _on_gpu():
+        sd.backend_set_option("fuse_rows16", 1)   # off by default (measured slightly slower inside SD1.5); the path must stay correct
+    try:
+        ref, out = run_both(sd, oracle, gpu, build)
+    finally:
+        if _on_gpu():
+            sd.backend_set_option("fuse_rows16", 0)
+    assert out.shape == (N, C, H, W) and np.isfinite(out).all()
+    assert rel_l2(out, ref) < 3e-4
+    # exact: f16-rounded operands at the reference's rounding points (FF2 input and weight, then the conv's input and weight), f64 sums
+    h = t_in.astype(np.float16).astype(np.float64) @ w2.astype(np.float16).astype(np.float64).T + b2 + t_res
+    h16 = h.astype(np.float32).astype(np.float16).astype(np.float64)
+    y = h16 @ w_out.reshape(C, C).astype(np.float16).astype(np.float64).T + b_out
+    exact = y.reshape(N, H, W, C).transpose(0, 3, 1, 2) + x
+    assert rel_l2(out, exact) < 3e-4
+    if before is not None and not os.environ.get("SDCPP_BACKEND_OPTS"):
+        st = sd.backend_stats()
+        assert st["fused_rows16"] - before["fused_rows16"] == (1 if C % 64 == 0 else 0)
+        assert st["fused_proj_tokens"] - before["fused_proj_tokens"] == 1
+
+
 @pytest.mark.parametrize("N,C,OC,HW,split", [(2, 64, 320, 16, False), (3, 320, 96, 12, False), (2, 1280, 1280, 8, True), (2, 128, 128, 1, True), (1, 128, 64, 2, True),
                                               (5, 32, 32, 3, False)])
 def test_conv_time_embedding_add_fused(sd, oracle, gpu, rng, N, C, OC, HW, split):
