@@ -41,11 +41,11 @@ namespace {
 struct Stats {
     std::atomic<int64_t> graphs_computed{0}, plans_built{0}, nodes_seen{0}, kernels_planned{0}, kernels_launched{0}, fused_conv{0},
         fused_conv_bounced{0}, fused_linear{0}, fused_norm{0}, fused_geglu{0}, fused_attention{0}, generic_matmul{0}, swizzled_weight_bytes{0}, fused_linear_geglu{0}, split_k_gemms{0}, head_major_gemms{0}, fused_modulate{0}, fused_gate{0}, fused_gelu{0}, fused_rope{0}, fused_concat_heads{0},
-        graph_replays{0}, qgemv_linears{0}, fused_chan_add{0}, fused_proj_tokens{0}, gemm_attention{0}, fused_q16{0}, split_k_inlaunch{0}, qgemm16_linears{0}, fgemv_linears{0}, fused_presilu{0}, fused_sibling_linears{0}, hoisted_kv_linears{0}, window_convs{0}, hoisted_emb_linears{0}, fused_rows16{0};
+        graph_replays{0}, qgemv_linears{0}, fused_chan_add{0}, fused_proj_tokens{0}, gemm_attention{0}, fused_q16{0}, split_k_inlaunch{0}, qgemm16_linears{0}, fgemv_linears{0}, fused_presilu{0}, fused_sibling_linears{0}, hoisted_kv_linears{0}, window_convs{0}, hoisted_emb_linears{0}, fused_rows16{0}, fused_cat_rows16{0};
 } g_stats;
 
 struct Options {
-    std::atomic<int> fusion{1}, mfma_gemm{1}, hip_graph{0}, flash_pattern{1}, gemm16{1}, fuse_modulate{1}, fuse_gate{1}, fuse_gelu{1}, fuse_rope{1}, fuse_concat_heads{1}, qgemv{1}, fuse_chan_add{1}, fuse_proj_tokens{1}, fuse_q16{1}, qgemm16{1}, fgemv{1}, fuse_siblings{1}, hoist_kv{1}, hoist_emb{1}, fuse_rows16{0};
+    std::atomic<int> fusion{1}, mfma_gemm{1}, hip_graph{0}, flash_pattern{1}, gemm16{1}, fuse_modulate{1}, fuse_gate{1}, fuse_gelu{1}, fuse_rope{1}, fuse_concat_heads{1}, qgemv{1}, fuse_chan_add{1}, fuse_proj_tokens{1}, fuse_q16{1}, qgemm16{1}, fgemv{1}, fuse_siblings{1}, hoist_kv{1}, hoist_emb{1}, fuse_rows16{0}, fuse_cat_rows16{1};
 } g_opt;
 
 using Step = std::function<void(hipStream_t)>;
@@ -272,6 +272,21 @@ struct Builder {
         int64_t ld, M, N;
     };
     std::unordered_map<const ggml_tensor*, MovedEmb> moved_emb;
+    // CONCAT along the feature dimension read only by Linears (FLUX single block: concat(attn, gelu(mlp)) -> linear2, flux.hpp:594-700): the
+    // Linear's f16 operand image is assembled directly (plan_cat_rows16).  cat16: CONCAT node -> image and which parts a producer has written;
+    // cat16_part: a producer's tensor (the flash node's output CONT, the CONT in front of an in-place GELU) -> the columns it may write
+    struct Cat16 {
+        size_t off;
+        int64_t ld;
+        bool written[2];
+    };
+    struct Cat16Part {
+        size_t off;   // of the image
+        int64_t ld, col;
+        int cat, part;
+    };
+    std::unordered_map<int, Cat16> cat16;
+    std::unordered_map<const ggml_tensor*, Cat16Part> cat16_part;
     void emit(Step s) {
         if (emit_redirect >= 0)
             deferred[emit_redirect].push_back(std::move(s));
@@ -1976,7 +1991,21 @@ bool plan_single(Builder& B, int i, hipStream_t s) {
                         (int64_t)vw->nb[1] == (int64_t)n->nb[1] && (int64_t)vw->nb[2] == (int64_t)n->nb[2] && (int64_t)vw->nb[3] == (int64_t)n->nb[1] * H &&
                         gi.only_noops_between(i, j2, chain)) {
                         const int64_t C = d * H;
-                        if (all_consumers_gemm16(gi, j2, false)) {
+                        const auto cpart = B.cat16_part.find(ct);
+                        if (cpart != B.cat16_part.end() && C % 8 == 0) {
+                            // the output is one column range of a Linear's operand image (plan_cat_rows16): store it there as f16, nothing else reads it
+                            const Builder::Cat16Part pt = cpart->second;
+                            Planner* P                  = B.P;
+                            const size_t o              = pt.off + (size_t)pt.col * 2;
+                            B.emit([=](hipStream_t st) {
+                                FlashOut f2;
+                                f2.H     = (int)H;
+                                f2.dst16 = P->arena + o;
+                                f2.ld16  = pt.ld;
+                                launch_flash_attn(st, f2, qfix(q), kfix(k), vfix(v), sc);
+                            });
+                            B.cat16[pt.cat].written[pt.part] = true;
+                        } else if (all_consumers_gemm16(gi, j2, false)) {
                             // every reader is a weight GEMM (to_out): emit only the f16 operand image [tok][C]
                             Planner* P       = B.P;
                             const size_t off = B.alloc((size_t)Nimg * Lq * rup64(C) * 2);
@@ -2019,11 +2048,57 @@ bool plan_single(Builder& B, int i, hipStream_t s) {
     }
 }
 
+// the only non-view reader of node k, looking through RESHAPE views; -1 if there are several or k is a graph output
+static int sole_through_reshape(const GInfo& gi, int k) {
+    int j = gi.sole(k);
+    while (j >= 0 && gi.node(j)->op == GGML_OP_RESHAPE) j = gi.sole(j);
+    return j;
+}
+
+// CONCAT(a, b) along dimension 0 whose readers are all weight GEMMs (FLUX single block, flux.hpp:594-700: linear2(concat(attn, gelu(mlp)))): the
+// f32 concatenation is never built — the Linear's f16 operand image [rows][Ka + Kb] is allocated here and filled column range by column range.
+// A part whose producer can write f16 itself is registered in cat16_part (the flash node stores its output there; gelu(CONT(strided view)) becomes
+// ONE strided read -> GELU -> f16 pass); any other part is packed from its f32 tensor when the walk reaches the CONCAT node.
+void plan_cat_rows16(Builder& B) {
+    GInfo& gi = B.gi;
+    if (!g_opt.fusion || !g_opt.gemm16 || !g_opt.fuse_cat_rows16) return;
+    for (int i = 0; i < gi.g->n_nodes; ++i) {
+        const ggml_tensor* n = gi.node(i);
+        if (n->op != GGML_OP_CONCAT || n->op_params[0] != 0 || !is_f32(n) || !contig(n) || n->ne[3] != 1 || (n->flags & GGML_TENSOR_FLAG_OUTPUT)) continue;
+        const ggml_tensor *a = n->src[0], *b = n->src[1];
+        if (!is_f32(a) || !is_f32(b) || !contig(a) || !contig(b) || !aligned16(a->data) || !aligned16(b->data)) continue;
+        const int64_t Ka = a->ne[0], Kb = b->ne[0], rows = n->ne[1] * n->ne[2];
+        if (Ka % 8 != 0 || Kb % 8 != 0 || (Ka + Kb) % 64 != 0 || rows < 1) continue;
+        if (!all_consumers_gemm16(gi, i, false)) continue;
+        const int64_t ld = Ka + Kb;
+        const size_t off = B.alloc((size_t)rows * ld * 2);
+        B.cat16[i]       = Builder::Cat16{off, ld, {false, false}};
+        for (int p = 0; p < 2; ++p) {
+            const ggml_tensor* src = strip_reshape(n->src[p]);
+            const int is           = gi.idx(src);
+            if (is < 0 || sole_through_reshape(gi, is) != i) continue;
+            const int64_t col = p ? Ka : 0;
+            if (src->op == GGML_OP_CONT && src->src[0] && src->src[0]->op == GGML_OP_VIEW && src->src[0]->src[0] && src->src[0]->src[0]->op == GGML_OP_FLASH_ATTN_EXT) {
+                B.cat16_part[src] = Builder::Cat16Part{off, ld, col, i, p};  // taken (or not) by the flash node's output fusion
+            } else if (src->op == GGML_OP_UNARY && ggml_abi_get_unary_op(src) == GGML_UNARY_OP_GELU && src->src[0] && src->src[0]->op == GGML_OP_CONT &&
+                       src->data == src->src[0]->data) {
+                const ggml_tensor* cc = src->src[0];
+                const ggml_tensor* v  = cc->src[0];
+                const int ic          = gi.idx(cc);
+                if (ic >= 0 && gi.sole(ic) == is && v && is_f32(v) && v->nb[0] == 4 && v->ne[3] == 1 && (v->ne[2] == 1 || v->nb[2] == v->nb[1] * (size_t)v->ne[1]) &&
+                    v->nb[1] % 16 == 0 && aligned16(v->data) && v->ne[0] == (p ? Kb : Ka) && v->ne[1] * v->ne[2] == rows && !(cc->flags & GGML_TENSOR_FLAG_OUTPUT))
+                    B.cat16_part[cc] = Builder::Cat16Part{off, ld, col, i, p};  // taken when the walk reaches the CONT
+            }
+        }
+    }
+}
+
 bool build_plan(Planner* P, Plan* plan, const ggml_cgraph* g, hipStream_t s) {
     Builder B(P, plan, g);
     GInfo& gi = B.gi;
     plan_hoisted_kv(B, s);
     plan_hoisted_emb(B, s);
+    plan_cat_rows16(B);
     for (int i = 0; i < g->n_nodes; ++i) {
         {
             auto it = B.deferred.find(i);
@@ -2055,12 +2130,53 @@ bool build_plan(Planner* P, Plan* plan, const ggml_cgraph* g, hipStream_t s) {
             case GGML_OP_GROUP_NORM: ok = plan_group_norm(B, i, s, chain); break;
             case GGML_OP_NORM:
             case GGML_OP_RMS_NORM: ok = plan_layer_norm(B, i, s, chain); break;
-            case GGML_OP_CONCAT: ok = plan_concat_heads(B, i, s, chain); break;
-            case GGML_OP_CONT:
+            case GGML_OP_CONCAT: {
+                const auto ci = B.cat16.find(i);
+                if (ci != B.cat16.end()) {  // operand image of the Linears behind this concat: pack whatever its producers did not write themselves
+                    const Builder::Cat16 ct = ci->second;
+                    Planner* PP             = P;
+                    int64_t col             = 0;
+                    for (int p = 0; p < 2; ++p) {
+                        const ggml_tensor* sp = n->src[p];
+                        const int64_t Kp_     = sp->ne[0], rows = n->ne[1] * n->ne[2];
+                        if (!ct.written[p]) {
+                            const float* xp  = (const float*)sp->data;
+                            const size_t o   = ct.off + (size_t)col * 2;
+                            const int64_t ld = ct.ld;
+                            B.emit([=](hipStream_t st) { launch_pack_cols_f16(st, PP->arena + o, ld, xp, rows, Kp_, Kp_, false); });
+                        }
+                        col += Kp_;
+                    }
+                    B.packed[n] = Packed{ct.off, ct.ld, false};
+                    chain       = {i};
+                    ok          = true;
+                    g_stats.fused_cat_rows16++;
+                    break;
+                }
+                ok = plan_concat_heads(B, i, s, chain);
+                break;
+            }
+            case GGML_OP_CONT: {
+                const auto cp = B.cat16_part.find(n);
+                if (cp != B.cat16_part.end() && n->src[0] && n->src[0]->op == GGML_OP_VIEW && gi.sole(i) >= 0 && gi.node(gi.sole(i))->op == GGML_OP_UNARY) {
+                    // gelu(CONT(strided view)) as one pass: strided f32 rows -> GELU -> f16 columns of the operand image
+                    const Builder::Cat16Part pt = cp->second;
+                    const ggml_tensor* v        = n->src[0];
+                    Planner* PP                 = P;
+                    const float* xp             = (const float*)v->data;
+                    const int64_t rows = v->ne[1] * v->ne[2], K = v->ne[0], xs = (int64_t)v->nb[1] / 4;
+                    const size_t o     = pt.off + (size_t)pt.col * 2;
+                    B.emit([=](hipStream_t st) { launch_pack_cols_f16(st, PP->arena + o, pt.ld, xp, rows, K, xs, true); });
+                    B.cat16[pt.cat].written[pt.part] = true;
+                    chain = {i, gi.sole(i)};
+                    ok    = true;
+                    break;
+                }
                 ok = plan_geglu(B, i, s, chain);
                 if (!ok) ok = plan_rope(B, i, s, chain);
                 if (!ok) ok = plan_tokens_to_conv(B, i, s, chain);
                 break;
+            }
             case GGML_OP_UNARY: {
                 // SiLU feeding only the NEXT node, a Linear with a handful of rows (ResBlock emb_layers, time_embed.2, the DiT vector embedders):
                 // applied by the weight-streaming kernel while it stages the rows (plan_linear); adjacency keeps the source rows alive
@@ -2370,6 +2486,7 @@ void planner_get_stats(ggml_backend_mi355x_stats* o) {
     o->window_convs          = g_stats.window_convs;
     o->hoisted_emb_linears   = g_stats.hoisted_emb_linears;
     o->fused_rows16          = g_stats.fused_rows16;
+    o->fused_cat_rows16      = g_stats.fused_cat_rows16;
     o->fused_attention       = g_stats.fused_attention;
     o->generic_matmul        = g_stats.generic_matmul;
     o->swizzled_weight_bytes = g_stats.swizzled_weight_bytes;
@@ -2395,6 +2512,7 @@ void planner_set_option(const char* key, int value) {
     else if (!strcmp(key, "conv3w")) conv3w_set(value);
     else if (!strcmp(key, "hoist_emb")) g_opt.hoist_emb = value;
     else if (!strcmp(key, "fuse_rows16")) g_opt.fuse_rows16 = value;
+    else if (!strcmp(key, "fuse_cat_rows16")) g_opt.fuse_cat_rows16 = value;
     else if (!strcmp(key, "conv3w_min_blocks")) conv3w_set_min_blocks(value);
     else if (!strcmp(key, "conv3w_min_blocks_deep")) conv3w_set_min_blocks_deep(value);
     else if (!strcmp(key, "gemm16_bn64")) gemm16_set_bn64(value);

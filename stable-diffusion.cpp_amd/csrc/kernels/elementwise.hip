@@ -378,6 +378,49 @@ void launch_concat_heads(hipStream_t s, void* out, bool out_f16, const float* a,
         k_concat_heads<float><<<grid_for(n4, 256), 256, 0, s>>>((float*)out, a, b, (int)(d / 4), (int)H, La, Lb, N, n4);
 }
 
+// joint-attention operand assembly (MMDiT: DitSelfAttention::pre_attention mmdit.hpp:299-366 + block_mixing :614-668 + ggml_ext_attention_ext):
+// for ONE of q / k / v of both streams: the stream's columns of its fused qkv projection [rows][xs] -> per-head RMSNorm * w (q / k with qk-norm;
+// w == nullptr: none) -> token concat (context rows first) -> head-major [d, Lt, H, N] as f32 or f16.  Replaces split_qkv's permuted copy, the
+// strided norms, their weight MULs and the concat / permute / cast passes.  G lanes per head (d = 4 G), a head's 4 G floats are one contiguous run.
+template <typename TD, int G>
+__global__ void k_joint_heads(TD* __restrict__ out, const float* __restrict__ a, const float* __restrict__ b, int64_t xsa, int64_t xsb, const float* __restrict__ wa,
+                              const float* __restrict__ wb, float eps, int H, int64_t La, int64_t Lb, int64_t ngroups) {
+    const int j      = threadIdx.x % G;
+    const int64_t Lt = La + Lb;
+    for (int64_t gi = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / G; gi < ngroups; gi += (int64_t)gridDim.x * blockDim.x / G) {
+        const int h     = (int)(gi % H);
+        const int64_t t = gi / H, l = t % Lt, n = t / Lt;
+        const bool fst  = l < La;
+        const float* src = fst ? a + (n * La + l) * xsa : b + (n * Lb + (l - La)) * xsb;
+        float4 v         = *(const float4*)(src + h * (4 * G) + 4 * j);
+        const float* w   = fst ? wa : wb;
+        if (w) {
+            float ss = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+#pragma unroll
+            for (int m = G / 2; m >= 1; m >>= 1) ss += __shfl_xor(ss, m, G);
+            const float sc  = 1.0f / sqrtf(ss / (float)(4 * G) + eps);
+            const float4 ww = ((const float4*)w)[j];
+            v.x = v.x * sc * ww.x; v.y = v.y * sc * ww.y; v.z = v.z * sc * ww.z; v.w = v.w * sc * ww.w;
+        }
+        TD r[4] = {cvt<TD>(v.x), cvt<TD>(v.y), cvt<TD>(v.z), cvt<TD>(v.w)};
+        ((vec_t<TD, 4>*)out)[((n * H + h) * Lt + l) * G + j] = *(vec_t<TD, 4>*)r;
+    }
+}
+bool joint_heads_supported(int64_t d) { return d == 64 || d == 128; }
+void launch_joint_heads(hipStream_t s, void* out, bool out_f16, const float* a, int64_t xsa, const float* wa, const float* b, int64_t xsb, const float* wb, float eps,
+                        int64_t d, int64_t H, int64_t La, int64_t Lb, int64_t N) {
+    KScope ks_(s, KF_CONCAT, 0.0, (double)d * H * (La + Lb) * N * (4.0 + (out_f16 ? 2.0 : 4.0)));
+    const int64_t ng = H * (La + Lb) * N, nthr = ng * (d / 4);
+    const unsigned grid = grid_for(nthr, 256);
+#define JH(TD_, G_) k_joint_heads<TD_, G_><<<grid, 256, 0, s>>>((TD_*)out, a, b, xsa, xsb, wa, wb, eps, (int)H, La, Lb, ng)
+    if (d == 64) {
+        if (out_f16) JH(__half, 16); else JH(float, 16);
+    } else {
+        if (out_f16) JH(__half, 32); else JH(float, 32);
+    }
+#undef JH
+}
+
 // ---------------------------------------------------------------------------------------- concat / repeat / upscale / pad
 struct Idx4 {
     int64_t ne[4], nb[4];

@@ -1123,6 +1123,39 @@ void launch_pack_rows_f16(hipStream_t s, void* dst, const float* x, int64_t R, i
     k_pack_rows_f16<<<(unsigned)blocks, 256, 0, s>>>((_Float16*)dst, x, R, (int)K, Kp, xs, L, bs);
 }
 
+// f32 rows [R][K] (row stride xs floats) -> columns [0, K) of f16 rows with stride ld halfs (dst already points at the first column): one part of an
+// operand image that several producers fill side by side (concat along the feature dimension feeding a Linear).  GELU = 1: tanh-GELU first
+// (FLUX single block, flux.hpp:594-700: gelu(mlp) next to the attention output in linear2's operand).  K % 8 == 0, 16-byte aligned rows.
+template <int GELU>
+__global__ void k_pack_cols_f16(_Float16* __restrict__ dst, int64_t ld, const float* __restrict__ x, int64_t R, int K, int64_t xs) {
+    const int K8     = K / 8;
+    const int64_t n8 = R * K8;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / K8;
+        const int k0    = (int)(i - r * K8) * 8;
+        float4 a = *(const float4*)(x + r * xs + k0), b = *(const float4*)(x + r * xs + k0 + 4);
+        if (GELU) {
+            a.x = act_apply<UN_GELU>(a.x); a.y = act_apply<UN_GELU>(a.y); a.z = act_apply<UN_GELU>(a.z); a.w = act_apply<UN_GELU>(a.w);
+            b.x = act_apply<UN_GELU>(b.x); b.y = act_apply<UN_GELU>(b.y); b.z = act_apply<UN_GELU>(b.z); b.w = act_apply<UN_GELU>(b.w);
+        }
+        half8_t h;
+        h[0] = (_Float16)a.x; h[1] = (_Float16)a.y; h[2] = (_Float16)a.z; h[3] = (_Float16)a.w;
+        h[4] = (_Float16)b.x; h[5] = (_Float16)b.y; h[6] = (_Float16)b.z; h[7] = (_Float16)b.w;
+        *(half8_t*)(dst + r * ld + k0) = h;
+    }
+}
+void launch_pack_cols_f16(hipStream_t s, void* dst, int64_t ld, const float* x, int64_t R, int64_t K, int64_t xs, bool gelu) {
+    KScope ks_(s, KF_PACK_F16, 0.0, (double)R * K * 6.0);
+    const int64_t n8 = R * (K / 8);
+    int64_t blocks   = (n8 + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    if (blocks < 1) return;
+    if (gelu)
+        k_pack_cols_f16<1><<<(unsigned)blocks, 256, 0, s>>>((_Float16*)dst, ld, x, R, (int)K, xs);
+    else
+        k_pack_cols_f16<0><<<(unsigned)blocks, 256, 0, s>>>((_Float16*)dst, ld, x, R, (int)K, xs);
+}
+
 // LayerNorm / RMSNorm (+affine) writing the f16 operand image: one wave per row
 // mod_L > 0: adaLN modulate (mmdit.hpp:368-380) — w and b are per-image [images][ne0] tables and the affine is norm * (1 + w) + b
 __global__ __launch_bounds__(256) void k_layer_norm_f16(_Float16* __restrict__ dst, const float* __restrict__ x, int ne0, int Kp, int64_t nrows, int64_t xs,

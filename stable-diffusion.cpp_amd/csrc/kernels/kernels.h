@@ -29,6 +29,11 @@ void launch_concat(hipStream_t s, const View4& dst, const View4& a, const View4&
 void launch_repeat(hipStream_t s, const View4& dst, const View4& src);
 // a [d*H, La, N], b [d*H, Lb, N] f32 contiguous -> out [d, La+Lb, H, N] (f32 or f16): token concat + head-major permute (+ cast) in one pass
 void launch_concat_heads(hipStream_t s, void* out, bool out_f16, const float* a, const float* b, int64_t d, int64_t H, int64_t La, int64_t Lb, int64_t N);
+// one of q / k / v of a joint attention: both streams' columns of their fused qkv projections (row strides xsa / xsb floats) -> optional per-head
+// RMSNorm * w -> token concat (a first) -> head-major [d, La + Lb, H, N], f32 or f16 (elementwise.hip k_joint_heads); d = 64 or 128
+bool joint_heads_supported(int64_t d);
+void launch_joint_heads(hipStream_t s, void* out, bool out_f16, const float* a, int64_t xsa, const float* wa, const float* b, int64_t xsb, const float* wb, float eps,
+                        int64_t d, int64_t H, int64_t La, int64_t Lb, int64_t N);
 // interleaved rotary embedding: x [d, H, L, N] (d contiguous, other dims strided), pe [2,2,d/2,L] -> out [d, L, H*N] contiguous
 void launch_rope_pairs(hipStream_t s, float* out, const View4& x, const float* pe);
 void launch_upscale_nearest(hipStream_t s, const View4& dst, const View4& src);
@@ -134,6 +139,8 @@ void conv3w_set_min_blocks_deep(int v);  // option "conv3w_min_blocks_deep"
 // producers of f16 operand images (row stride = K rounded up to 64, zero padded)
 // L > 0: rows are N runs of L rows, run n starting bs elements after run n-1 (a token slice of a [C, Lfull, N] tensor)
 void launch_pack_rows_f16(hipStream_t s, void* dst, const float* x, int64_t R, int64_t K, int64_t xs, int64_t L = 0, int64_t bs = 0);
+// f32 rows -> K columns of f16 rows with stride ld (one part of an operand image filled by several producers), optional tanh-GELU; K % 8 == 0
+void launch_pack_cols_f16(hipStream_t s, void* dst, int64_t ld, const float* x, int64_t R, int64_t K, int64_t xs, bool gelu);
 // mod_L > 0: w, b are per-image [rows / mod_L][ne0] adaLN tables and the affine is norm * (1 + w) + b (DiT modulate)
 void launch_layer_norm_f16(hipStream_t s, void* dst, const float* x, int64_t ne0, int64_t nrows, int64_t x_stride, float eps, const float* w,
                            const float* b, bool rms, int64_t mod_L = 0);

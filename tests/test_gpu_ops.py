@@ -198,6 +198,64 @@ def test_spatial_transformer_projections_as_token_gemms(sd, oracle, gpu, rng, N,
         assert sd.backend_stats()["fused_proj_tokens"] - before["fused_proj_tokens"] == 2
 
 
+@pytest.mark.parametrize("d,H,L,M,flash", [(64, 2, 200, 384, True), (128, 1, 77, 128, True), (64, 3, 130, 320, False), (40, 2, 96, 112, True)])
+def test_single_block_tail_concat_assembled_as_operand_image(sd, oracle, gpu, rng, d, H, L, M, flash):
+    """FLUX single block tail (flux.hpp:594-700): t = linear1(x) -> q / k / v per-head views + mlp view; attn = flash(q, k, v) -> VIEW -> CONT;
+    out = linear2(concat(attn, gelu(CONT(mlp view)), 0)).  The f32 concatenation is never built: linear2's f16 operand image [L][C + M] is
+    filled by the flash kernel (columns 0 .. C) and by one strided-read -> GELU -> f16 pass (columns C ..).  flash = False feeds a plain f32
+    tensor as the first part (packed at the CONCAT node); d = 40, M = 112: (C + M) % 64 != 0 keeps the unfused path."""
+    C = d * H
+    x = rng.standard_normal((1, L, 96)).astype(np.float32)
+    w1 = (rng.standard_normal((3 * C + M, 96)) / np.sqrt(96)).astype(np.float32)
+    b1 = (rng.standard_normal(3 * C + M) * 0.1).astype(np.float32)
+    w2 = (rng.standard_normal((C, C + M)) / np.sqrt(C + M)).astype(np.float32)
+    b2 = rng.standard_normal(C).astype(np.float32)
+    a_in = rng.standard_normal((1, L, C)).astype(np.float32)
+    scale = 1.0 / np.sqrt(d)
+
+    def build(g, L_):
+        t = L_.ggml_mul_mat(g.ctx, g.weight(w1, F16), g.input(x))
+        t = L_.ggml_add_inplace(g.ctx, t, g.weight(b1, F32))                       # [3C + M, L, 1]
+        nb = sd_tensor_nb(t)
+        if flash:
+            def part(i, f16):
+                p = L_.ggml_view_4d(g.ctx, t, d, H, L, 1, 4 * d, nb[1], nb[2], 4 * C * i)
+                p = L_.ggml_cont(g.ctx, L_.ggml_permute(g.ctx, p, 0, 2, 1, 3))      # [d, L, H, 1]
+                p = L_.ggml_reshape_3d(g.ctx, p, d, L, H)
+                return L_.ggml_cast(g.ctx, p, F16) if f16 else p
+            a = L_.ggml_flash_attn_ext(g.ctx, part(0, False), part(1, True), part(2, True), None, scale, 0.0, 0.0)
+            L_.ggml_flash_attn_ext_set_prec(a, 10)
+            na = sd_tensor_nb(a)
+            a = L_.ggml_view_4d(g.ctx, a, d, H, L, 1, na[1], na[2], na[1] * H, 0)
+            a = L_.ggml_cont(g.ctx, L_.ggml_permute(g.ctx, a, 0, 1, 2, 3))
+            a = L_.ggml_reshape_3d(g.ctx, a, C, L, 1)
+        else:
+            a = g.input(a_in)
+        m = L_.ggml_view_3d(g.ctx, t, M, L, 1, nb[1], nb[2], 4 * 3 * C)
+        m = L_.ggml_gelu_inplace(g.ctx, L_.ggml_cont(g.ctx, m))
+        y = L_.ggml_mul_mat(g.ctx, g.weight(w2, F16), L_.ggml_concat(g.ctx, a, m, 0))
+        return L_.ggml_add_inplace(g.ctx, y, g.weight(b2, F32))
+
+    before = sd.backend_stats() if _on_gpu() else None
+    ref, out = run_both(sd, oracle, gpu, build)
+    assert np.isfinite(out).all()
+    assert rel_l2(out, ref) < 1e-2      # the oracle's flash path accumulates V in f16, its GELU goes through the f16 table
+    # exact chain in float64 on the f16-rounded operands at the reference's rounding points
+    f16 = lambda v: np.asarray(v, np.float32).astype(np.float16).astype(np.float64)
+    t = f16(x[0]) @ f16(w1).T + b1
+    if flash:
+        q, k, v = (t[:, i * C:(i + 1) * C].reshape(L, H, d).transpose(1, 0, 2) for i in range(3))
+        att = _attn_exact(q, f16(k), f16(v), scale).transpose(1, 0, 2).reshape(L, C)
+    else:
+        att = a_in[0].astype(np.float64)
+    u = t[:, 3 * C:]
+    gel = 0.5 * u * (1.0 + np.tanh(np.sqrt(2.0 / np.pi) * (u + 0.044715 * u ** 3)))
+    exact = f16(np.concatenate([att, gel], 1)) @ f16(w2).T + b2
+    assert rel_l2(out.reshape(L, C), exact) < 2e-3
+    if before is not None and not os.environ.get("SDCPP_BACKEND_OPTS"):
+        assert sd.backend_stats()["fused_cat_rows16"] - before["fused_cat_rows16"] == (1 if (C + M) % 64 == 0 else 0)
+
+
 @pytest.mark.parametrize("N,C,K,H,W", [(2, 320, 1280, 16, 16), (3, 64, 256, 5, 7), (1, 128, 512, 9, 9), (2, 96, 384, 8, 8)])
 def test_ff2_residual_written_as_proj_out_operand_rows(sd, oracle, gpu, rng, N, C, K, H, W):
     """Tail of a SpatialTransformer (block.hpp:560-577): FF2 Linear (+bias) + residual -> CONT(PERMUTE(1,0,2,3)) -> RESHAPE -> proj_out conv1x1
