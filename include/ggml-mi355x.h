@@ -85,6 +85,7 @@ struct ggml_backend_mi355x_stats {
     int64_t window_convs;        /* 3x3 convs planned on the LDS-window kernel (conv3w.hip) */
     int64_t hoisted_emb_linears; /* per-ResBlock SiLU(emb) -> Linear projections computed by one grouped weight-streaming launch ahead of their graph position */
     int64_t fused_rows16;        /* Linear (+bias, +residual) read only by a 1x1 conv (SpatialTransformer proj_out): written as the conv's f16 operand rows */
+    int64_t fused_joint_qkv;     /* MMDiT streams whose fused qkv projection feeds the joint attention through k_joint_heads (no split copy, no separate norms / concats) */
     int64_t fused_cat_rows16;    /* CONCAT along the feature dimension read only by Linears: their f16 operand image assembled directly (FLUX single block) */
 };
 GGML_MI355X_API void ggml_backend_mi355x_get_stats(struct ggml_backend_mi355x_stats* out);
@@ -115,7 +116,8 @@ GGML_MI355X_API int ggml_backend_mi355x_get_kernel_timings(struct ggml_backend_m
  * raw-block MFMA GEMM up to n rows; 8192 = the resident-quantised mode, no f16 image for any quantised Linear), "qgemm16" (1);
  * launch grouping: "fuse_siblings" (1: q / k / v projections of one attention as one multi-weight launch), "hoist_kv" (1: cross-attention K / V
  * projections of all blocks grouped ahead of their graph position, results in the arena); "fuse_q16", "fuse_chan_add", "fuse_proj_tokens" (1);
- * "hoist_emb" (1: the per-ResBlock SiLU(emb) -> Linear projections as one grouped weight-streaming launch), "fuse_cat_rows16" (1: concat(a, b) along features feeding only Linears is assembled as their f16
+ * "hoist_emb" (1: the per-ResBlock SiLU(emb) -> Linear projections as one grouped weight-streaming launch), "fuse_joint_qkv" (1: MMDiT joint attention — qkv projections into arena scratch, split / per-head RMSNorm / token
+ * concat / head-major cast as one pass per operand), "fuse_cat_rows16" (1: concat(a, b) along features feeding only Linears is assembled as their f16
  * operand image — flash output and gelu(strided view) write their columns themselves), "fuse_rows16" (0: a Linear read only by a
  * 1x1 conv writes the conv's f16 operand rows; measured slightly slower on SD1.5);
  * "splitk_inkernel" (0: split-K combined by the last-arriving workgroup, 128-row tiles; measured slower) / "splitk_in_target" (320);

@@ -41,11 +41,11 @@ namespace {
 struct Stats {
     std::atomic<int64_t> graphs_computed{0}, plans_built{0}, nodes_seen{0}, kernels_planned{0}, kernels_launched{0}, fused_conv{0},
         fused_conv_bounced{0}, fused_linear{0}, fused_norm{0}, fused_geglu{0}, fused_attention{0}, generic_matmul{0}, swizzled_weight_bytes{0}, fused_linear_geglu{0}, split_k_gemms{0}, head_major_gemms{0}, fused_modulate{0}, fused_gate{0}, fused_gelu{0}, fused_rope{0}, fused_concat_heads{0},
-        graph_replays{0}, qgemv_linears{0}, fused_chan_add{0}, fused_proj_tokens{0}, gemm_attention{0}, fused_q16{0}, split_k_inlaunch{0}, qgemm16_linears{0}, fgemv_linears{0}, fused_presilu{0}, fused_sibling_linears{0}, hoisted_kv_linears{0}, window_convs{0}, hoisted_emb_linears{0}, fused_rows16{0}, fused_cat_rows16{0};
+        graph_replays{0}, qgemv_linears{0}, fused_chan_add{0}, fused_proj_tokens{0}, gemm_attention{0}, fused_q16{0}, split_k_inlaunch{0}, qgemm16_linears{0}, fgemv_linears{0}, fused_presilu{0}, fused_sibling_linears{0}, hoisted_kv_linears{0}, window_convs{0}, hoisted_emb_linears{0}, fused_rows16{0}, fused_cat_rows16{0}, fused_joint_qkv{0};
 } g_stats;
 
 struct Options {
-    std::atomic<int> fusion{1}, mfma_gemm{1}, hip_graph{0}, flash_pattern{1}, gemm16{1}, fuse_modulate{1}, fuse_gate{1}, fuse_gelu{1}, fuse_rope{1}, fuse_concat_heads{1}, qgemv{1}, fuse_chan_add{1}, fuse_proj_tokens{1}, fuse_q16{1}, qgemm16{1}, fgemv{1}, fuse_siblings{1}, hoist_kv{1}, hoist_emb{1}, fuse_rows16{0}, fuse_cat_rows16{1};
+    std::atomic<int> fusion{1}, mfma_gemm{1}, hip_graph{0}, flash_pattern{1}, gemm16{1}, fuse_modulate{1}, fuse_gate{1}, fuse_gelu{1}, fuse_rope{1}, fuse_concat_heads{1}, qgemv{1}, fuse_chan_add{1}, fuse_proj_tokens{1}, fuse_q16{1}, qgemm16{1}, fgemv{1}, fuse_siblings{1}, hoist_kv{1}, hoist_emb{1}, fuse_rows16{0}, fuse_cat_rows16{1}, fuse_joint_qkv{1};
 } g_opt;
 
 using Step = std::function<void(hipStream_t)>;
@@ -287,6 +287,31 @@ struct Builder {
     };
     std::unordered_map<int, Cat16> cat16;
     std::unordered_map<const ggml_tensor*, Cat16Part> cat16_part;
+    // joint attention of the MMDiT (plan_joint_qkv): the fused qkv projections of both streams write into arena scratch (lin_redirect: the
+    // Linear's output node -> arena offset), and each of the q / k / v token CONCATs becomes ONE pass from there to the flash operand (jqkv)
+    struct JPart {
+        size_t off = 0;       // arena offset of this stream's first column of q / k / v
+        int64_t xs = 0;       // floats between its rows
+        const float* w = nullptr;  // per-head RMSNorm weight (nullptr: no norm)
+        float eps = 0.f;
+    };
+    struct JCat {
+        JPart part[2];
+        int d = 0, H = 0, last = -1;
+        bool f16 = false;
+        std::vector<int> chain;
+    };
+    std::unordered_map<int, JCat> jqkv;
+    std::unordered_map<const ggml_tensor*, size_t> lin_redirect;
+    // arena scratch shared by all blocks of a plan (one stream: a block's launches finish with it before the next block's producer overwrites it)
+    std::unordered_map<int, std::pair<size_t, size_t>> scratch_slots;
+    size_t scratch(int key, size_t bytes) {
+        auto it = scratch_slots.find(key);
+        if (it != scratch_slots.end() && it->second.second >= bytes) return it->second.first;
+        const size_t off   = alloc(bytes);
+        scratch_slots[key] = {off, bytes};
+        return off;
+    }
     void emit(Step s) {
         if (emit_redirect >= 0)
             deferred[emit_redirect].push_back(std::move(s));
@@ -681,7 +706,11 @@ void plan_linear(Builder& B, int i, hipStream_t s, std::vector<int>& chain) {
     // a tensor a fused producer wrote ONLY as an f16 operand image (GEGLU / GELU epilogues, LayerNorm -> f16, attention output: their f32 graph
     // tensor is never materialised when all consumers are Linears) has no rows for the streaming kernels to read
     const bool x_f32_live      = B.packed.find(strip_reshape(x)) == B.packed.end() && B.packed.find(strip_reshape(xsrc)) == B.packed.end();
-    const bool plain_epi       = hm_d == 0 && !ep.gate && gelu_out < 0 && geglu_out < 0 && x_f32_live;
+    // the output goes to arena scratch instead of the graph buffer (plan_joint_qkv): only the two GEMM paths below honour that
+    const auto rdi         = B.lin_redirect.find(gi.node(last));
+    const bool redir       = rdi != B.lin_redirect.end();
+    const size_t redir_off = redir ? rdi->second : 0;
+    const bool plain_epi       = hm_d == 0 && !ep.gate && gelu_out < 0 && geglu_out < 0 && x_f32_live && !redir;
     // the chain's output must not land on rows the kernel is still reading (the deferred SiLU's source may have been released by the allocator)
     const ggml_tensor* lastt   = gi.node(last);
     const bool src_safe        = xsrc == x || !overlaps(lastt->data, ggml_abi_nbytes(lastt), xsrc->data, ggml_abi_nbytes(xsrc));
@@ -805,7 +834,7 @@ void plan_linear(Builder& B, int i, hipStream_t s, std::vector<int>& chain) {
             const int S        = ep.gate ? 1 : qgemm16_split_k(tokens, K, M);
             const size_t wsoff = S > 1 ? B.alloc((size_t)S * tokens * M * 4) : 0;
             B.emit_at(emit_node, i, [=](hipStream_t st) {
-                launch_qgemm16(st, dst, nullptr, 0, P->arena + off, ld, tokens, wraw, wt, K, M, ep, S > 1 ? (float*)(P->arena + wsoff) : nullptr, S);
+                launch_qgemm16(st, redir ? (float*)(P->arena + redir_off) : dst, nullptr, 0, P->arena + off, ld, tokens, wraw, wt, K, M, ep, S > 1 ? (float*)(P->arena + wsoff) : nullptr, S);
             });
             g_stats.qgemm16_linears++;
         } else if (g_opt.fuse_rows16 && !ep.gate && emit_node == i && M % 64 == 0 && x->ne[3] == 1 && only_consumer_is_tokens_to_conv(gi, last)) {
@@ -820,7 +849,9 @@ void plan_linear(Builder& B, int i, hipStream_t s, std::vector<int>& chain) {
             g_stats.fused_rows16++;
         } else {
             const Builder::Split sk = B.plan_split(tokens, M, K, false, !ep.gate);
-            B.emit_at(emit_node, i, [=](hipStream_t st) { launch_gemm16_linear(st, dst, nullptr, 0, P->arena + off, ld, swz, tokens, K, M, M, ep, 0, 0, 0, sk.ws(P), sk.cnt(P), sk.S); });
+            B.emit_at(emit_node, i, [=](hipStream_t st) {
+                launch_gemm16_linear(st, redir ? (float*)(P->arena + redir_off) : dst, nullptr, 0, P->arena + off, ld, swz, tokens, K, M, M, ep, 0, 0, 0, sk.ws(P), sk.cnt(P), sk.S);
+            });
         }
     }
     g_stats.fused_linear++;
@@ -2093,12 +2124,210 @@ void plan_cat_rows16(Builder& B) {
     }
 }
 
+// the forward half of plan_concat_heads' pattern: CONCAT(dim 1) -> RESHAPE [d,H,Lt,N] -> PERMUTE(0,2,1,3) -> CONT [-> RESHAPE -> CPY f16]
+static bool concat_heads_forward(const GInfo& gi, int i, int* d_out, int* H_out, int* last_out, bool* f16_out, std::vector<int>* chain) {
+    const ggml_tensor* n = gi.node(i);
+    if (n->op != GGML_OP_CONCAT || n->op_params[0] != 1 || !is_f32(n) || n->ne[3] != 1) return false;
+    const int64_t C = n->ne[0], Lt = n->ne[1], N = n->ne[2];
+    const int j1 = gi.sole(i);
+    const int j2 = (j1 >= 0 && gi.node(j1)->op == GGML_OP_RESHAPE) ? gi.sole(j1) : -1;
+    const int j3 = (j2 >= 0 && gi.node(j2)->op == GGML_OP_PERMUTE) ? gi.sole(j2) : -1;
+    if (j3 < 0 || gi.node(j3)->op != GGML_OP_CONT || !is_f32(gi.node(j3)) || !contig(gi.node(j3))) return false;
+    const ggml_tensor* r4 = gi.node(j1);
+    const int32_t* ax     = gi.node(j2)->op_params;
+    const int64_t d = r4->ne[0], H = r4->ne[1];
+    if (!(ax[0] == 0 && ax[1] == 2 && ax[2] == 1 && ax[3] == 3) || d * H != C || r4->ne[2] != Lt || r4->ne[3] != N) return false;
+    *chain    = {i, j1, j2, j3};
+    *last_out = j3;
+    *f16_out  = false;
+    const int j4 = gi.sole(j3);
+    const int j5 = (j4 >= 0 && gi.node(j4)->op == GGML_OP_RESHAPE) ? gi.sole(j4) : -1;
+    if (j5 >= 0 && gi.node(j5)->op == GGML_OP_CPY && gi.node(j5)->type == GGML_TYPE_F16 && gi.node(j5)->src[0] == gi.node(j4) && contig(gi.node(j5))) {
+        chain->push_back(j4);
+        chain->push_back(j5);
+        *last_out = j5;
+        *f16_out  = true;
+    }
+    if ((gi.node(*last_out)->flags & GGML_TENSOR_FLAG_OUTPUT) || ((uintptr_t)gi.node(*last_out)->data & 15)) return false;
+    *d_out = (int)d;
+    *H_out = (int)H;
+    return true;
+}
+
+// MMDiT joint attention (mmdit.hpp:299-366 pre_attention, :614-668 block_mixing; ggml_extend.hpp:1253-1263 split_qkv, :1349-1485 attention):
+//   per stream  T = Linear_qkv(x) [3C, L, N] -> RESHAPE [C,3,L,N] -> PERMUTE(0,3,1,2) -> CONT S -> 3 VIEWs
+//               q, k: VIEW -> RESHAPE [d,H,L,N] -> RMS_NORM -> MUL(w[d]) -> RESHAPE [C,L,N]        (qk-norm; absent in SD3-medium)   v: VIEW
+//   joint       CONCAT(ctx, x, dim 1) -> RESHAPE -> PERMUTE(0,2,1,3) -> CONT [-> RESHAPE -> CPY f16] -> FLASH_ATTN_EXT
+// Per joint attention that is a permuted copy of both projections, four strided norms, four weight MULs and three concat + permute (+ cast)
+// passes.  Here: both projections write into arena scratch (never recycled by the graph allocator, so the operands can be read at the CONCATs'
+// positions), S / RMS_NORM / MUL are not executed, and each CONCAT becomes ONE k_joint_heads pass from the scratch rows to the flash operand
+// (Q as an f16 image when only the flash node reads it).  All-or-nothing per stream: every reader of T has to be inside the pattern.
+void plan_joint_qkv(Builder& B) {
+    GInfo& gi = B.gi;
+    if (!g_opt.fusion || !g_opt.gemm16 || !g_opt.fuse_concat_heads || !g_opt.fuse_joint_qkv) return;
+    struct VChain {
+        int cat = -1, part = -1;
+        const float* w = nullptr;
+        float eps = 0.f;
+        std::vector<int> skip;
+    };
+    struct Stream {
+        int iT = -1, iS = -1;
+        int64_t C = 0, rows = 0;
+        VChain v[3];
+        bool alive = true;
+    };
+    std::vector<Stream> streams;
+    for (int is = 0; is < gi.g->n_nodes; ++is) {
+        const ggml_tensor* S = gi.node(is);
+        if (S->op != GGML_OP_CONT || !is_f32(S) || !contig(S) || (S->flags & GGML_TENSOR_FLAG_OUTPUT) || !S->src[0] || S->src[0]->op != GGML_OP_PERMUTE) continue;
+        const ggml_tensor* pm = S->src[0];
+        const int32_t* pa     = pm->op_params;
+        if (!(pa[0] == 0 && pa[1] == 3 && pa[2] == 1 && pa[3] == 2)) continue;
+        const ggml_tensor* r1 = pm->src[0];
+        if (!r1 || r1->op != GGML_OP_RESHAPE || r1->ne[1] != 3) continue;
+        const ggml_tensor* T = strip_reshape(r1);
+        const int iT         = gi.idx(T);
+        const int64_t C      = r1->ne[0];
+        if (iT < 0 || !is_f32(T) || !contig(T) || T->ne[0] != 3 * C || T->ne[3] != 1 || C % 4 != 0 || !aligned16(T->data)) continue;
+        // T must come out of a weight GEMM (MUL_MAT [+ bias ADD in place]) and be read by nothing but S
+        const bool from_mm = T->op == GGML_OP_MUL_MAT || (T->op == GGML_OP_ADD && T->src[0] && strip_reshape(T->src[0])->op == GGML_OP_MUL_MAT && T->data == strip_reshape(T->src[0])->data);
+        const ggml_tensor* mm = T->op == GGML_OP_MUL_MAT ? T : (from_mm ? strip_reshape(T->src[0]) : nullptr);
+        if (!from_mm || !mm || !linear_fast_ok(mm)) continue;
+        {
+            int j = gi.sole(iT);
+            while (j >= 0 && (gi.node(j)->op == GGML_OP_RESHAPE || gi.node(j)->op == GGML_OP_PERMUTE)) j = gi.sole(j);
+            if (j != is) continue;
+        }
+        if (gi.consumers[is].size() != 3) continue;
+        Stream st;
+        st.iT   = iT;
+        st.iS   = is;
+        st.C    = C;
+        st.rows = T->ne[1] * T->ne[2];
+        bool ok = true;
+        bool seen[3] = {false, false, false};
+        for (int iv : gi.consumers[is]) {
+            const ggml_tensor* v = gi.node(iv);
+            if (v->op != GGML_OP_VIEW || v->ne[0] != C || v->ne[1] != S->ne[1] || v->ne[2] != S->ne[2] || v->ne[3] != 1 || v->nb[1] != S->nb[1] || v->nb[2] != S->nb[2] || S->nb[3] == 0) {
+                ok = false;
+                break;
+            }
+            const ptrdiff_t delta = (const char*)v->data - (const char*)S->data;
+            const int which       = (delta >= 0 && delta % (ptrdiff_t)S->nb[3] == 0) ? (int)(delta / (ptrdiff_t)S->nb[3]) : -1;
+            if (which < 0 || which > 2 || seen[which]) {
+                ok = false;
+                break;
+            }
+            seen[which] = true;
+            VChain vc;
+            int j    = gi.sole(iv);
+            int from = iv;
+            if (j >= 0 && gi.node(j)->op == GGML_OP_RESHAPE) {  // qk-norm branch
+                const int jn = gi.sole(j);
+                const int jm = (jn >= 0 && gi.node(jn)->op == GGML_OP_RMS_NORM && gi.node(jn)->src[0] == gi.node(j)) ? gi.sole(jn) : -1;
+                if (jm < 0 || gi.node(jm)->op != GGML_OP_MUL || gi.node(jm)->src[0] != gi.node(jn)) {
+                    ok = false;
+                    break;
+                }
+                const ggml_tensor* r2 = gi.node(j);
+                const ggml_tensor* w  = gi.node(jm)->src[1];
+                if (!is_f32(w) || !contig(w) || w->ne[0] != r2->ne[0] || ggml_abi_nelements(w) != r2->ne[0] || !is_static_weight(w) || !aligned16(w->data) ||
+                    r2->ne[0] * r2->ne[1] != C || !joint_heads_supported(r2->ne[0])) {
+                    ok = false;
+                    break;
+                }
+                const int jr = gi.sole(jm);
+                if (jr < 0 || gi.node(jr)->op != GGML_OP_RESHAPE || gi.node(jr)->ne[0] != C) {
+                    ok = false;
+                    break;
+                }
+                vc.w    = (const float*)w->data;
+                vc.eps  = ggml_abi_op_param_f32(gi.node(jn), 0);
+                vc.skip = {jn, jm};
+                from    = jr;
+                j       = gi.sole(jr);
+            }
+            if (j < 0 || gi.node(j)->op != GGML_OP_CONCAT || gi.node(j)->op_params[0] != 1) {
+                ok = false;
+                break;
+            }
+            vc.cat  = j;
+            vc.part = gi.node(j)->src[0] == gi.node(from) ? 0 : (gi.node(j)->src[1] == gi.node(from) ? 1 : -1);
+            if (vc.part < 0 || gi.node(j)->src[0] == gi.node(j)->src[1]) {
+                ok = false;
+                break;
+            }
+            st.v[which] = vc;
+        }
+        if (ok && seen[0] && seen[1] && seen[2]) streams.push_back(st);
+    }
+    if (streams.empty()) return;
+    // a CONCAT is fusable when BOTH parts come from candidate streams and its forward chain matches; drop streams until that holds for all their CONCATs
+    struct CatInfo {
+        int d = 0, H = 0, last = -1;
+        bool f16 = false, fwd = false;
+        std::vector<int> chain;
+    };
+    std::unordered_map<int, CatInfo> cats;
+    for (bool changed = true; changed;) {
+        changed = false;
+        std::unordered_map<int, int> cover;  // concat -> bit mask of covered parts
+        for (const Stream& st : streams)
+            if (st.alive)
+                for (int q = 0; q < 3; ++q) cover[st.v[q].cat] |= 1 << st.v[q].part;
+        for (Stream& st : streams) {
+            if (!st.alive) continue;
+            for (int q = 0; q < 3 && st.alive; ++q) {
+                const int c = st.v[q].cat;
+                auto ci     = cats.find(c);
+                if (ci == cats.end()) {
+                    CatInfo info;
+                    info.fwd = concat_heads_forward(gi, c, &info.d, &info.H, &info.last, &info.f16, &info.chain);
+                    ci       = cats.emplace(c, info).first;
+                }
+                const bool norm = st.v[q].w != nullptr;
+                if (cover[c] != 3 || !ci->second.fwd || (int64_t)ci->second.d * ci->second.H != st.C || ci->second.d % 4 != 0 || !joint_heads_supported(ci->second.d) ||
+                    (norm && ci->second.d != (int)(st.C / ci->second.H))) {
+                    st.alive = false;
+                    changed  = true;
+                }
+            }
+        }
+    }
+    for (const Stream& st : streams) {
+        if (!st.alive) continue;
+        const int part      = st.v[0].part;  // context = 0, x = 1: the two projections of one block are live together, the blocks run one after another
+        if (st.v[1].part != part || st.v[2].part != part) continue;
+        const size_t toff = B.scratch(0x4a51 + part, (size_t)st.rows * 3 * st.C * 4);
+        B.lin_redirect[gi.node(st.iT)] = toff;
+        gi.done[st.iS] = 1;
+        for (int q = 0; q < 3; ++q) {
+            for (int k : st.v[q].skip) gi.done[k] = 1;
+            const CatInfo& ci = cats[st.v[q].cat];
+            Builder::JCat& jc = B.jqkv[st.v[q].cat];
+            jc.d     = ci.d;
+            jc.H     = ci.H;
+            jc.last  = ci.last;
+            jc.f16   = ci.f16;
+            jc.chain = ci.chain;
+            Builder::JPart& jp = jc.part[part];
+            jp.off = toff + (size_t)q * st.C * 4;
+            jp.xs  = 3 * st.C;
+            jp.w   = st.v[q].w;
+            jp.eps = st.v[q].eps;
+        }
+        g_stats.fused_joint_qkv++;
+    }
+}
+
 bool build_plan(Planner* P, Plan* plan, const ggml_cgraph* g, hipStream_t s) {
     Builder B(P, plan, g);
     GInfo& gi = B.gi;
     plan_hoisted_kv(B, s);
     plan_hoisted_emb(B, s);
     plan_cat_rows16(B);
+    plan_joint_qkv(B);
     for (int i = 0; i < g->n_nodes; ++i) {
         {
             auto it = B.deferred.find(i);
@@ -2151,6 +2380,38 @@ bool build_plan(Planner* P, Plan* plan, const ggml_cgraph* g, hipStream_t s) {
                     chain       = {i};
                     ok          = true;
                     g_stats.fused_cat_rows16++;
+                    break;
+                }
+                const auto jq = B.jqkv.find(i);
+                if (jq != B.jqkv.end()) {  // q / k / v of a joint attention: scratch rows of both projections -> the flash operand, one pass
+                    const Builder::JCat jc = jq->second;
+                    Planner* PP            = P;
+                    const int64_t La = n->src[0]->ne[1], Lb = n->src[1]->ne[1], Nimg = n->ne[2];
+                    void* outp = gi.node(jc.last)->data;
+                    bool f16   = jc.f16;
+                    size_t qoff = 0;
+                    bool q16    = false;
+                    if (!f16 && g_opt.fuse_q16 && jc.d % 8 == 0) {  // Q read only by a FLASH_ATTN_EXT node: an f16 image in arena scratch
+                        const int c1 = gi.sole(jc.last);
+                        const int c2 = (c1 >= 0 && gi.node(c1)->op == GGML_OP_RESHAPE) ? gi.sole(c1) : -1;
+                        if (c2 >= 0 && gi.node(c2)->op == GGML_OP_FLASH_ATTN_EXT && gi.node(c2)->src[0] == gi.node(c1) && !gi.node(c2)->src[3] && contig(gi.node(c1)) &&
+                            gi.node(c1)->ne[0] == jc.d && flash_attn_supported(jc.d, gi.node(c2)->src[2]->ne[0])) {
+                            qoff = B.scratch(0x4a60, (size_t)jc.d * jc.H * (La + Lb) * Nimg * 2);
+                            B.q16[gi.node(c1)] = qoff;
+                            q16 = f16 = true;
+                            g_stats.fused_q16++;
+                        }
+                    }
+                    const Builder::JPart pa = jc.part[0], pb = jc.part[1];
+                    const float eps = pa.w ? pa.eps : pb.eps;
+                    const int d = jc.d, H = jc.H;
+                    B.emit_at(jc.last, i, [=](hipStream_t st) {
+                        launch_joint_heads(st, q16 ? (void*)(PP->arena + qoff) : outp, f16, (const float*)(PP->arena + pa.off), pa.xs, pa.w, (const float*)(PP->arena + pb.off), pb.xs,
+                                           pb.w, eps, d, H, La, Lb, Nimg);
+                    });
+                    chain = jc.chain;
+                    ok    = true;
+                    g_stats.fused_concat_heads++;
                     break;
                 }
                 ok = plan_concat_heads(B, i, s, chain);
@@ -2487,6 +2748,7 @@ void planner_get_stats(ggml_backend_mi355x_stats* o) {
     o->hoisted_emb_linears   = g_stats.hoisted_emb_linears;
     o->fused_rows16          = g_stats.fused_rows16;
     o->fused_cat_rows16      = g_stats.fused_cat_rows16;
+    o->fused_joint_qkv       = g_stats.fused_joint_qkv;
     o->fused_attention       = g_stats.fused_attention;
     o->generic_matmul        = g_stats.generic_matmul;
     o->swizzled_weight_bytes = g_stats.swizzled_weight_bytes;
@@ -2513,6 +2775,7 @@ void planner_set_option(const char* key, int value) {
     else if (!strcmp(key, "hoist_emb")) g_opt.hoist_emb = value;
     else if (!strcmp(key, "fuse_rows16")) g_opt.fuse_rows16 = value;
     else if (!strcmp(key, "fuse_cat_rows16")) g_opt.fuse_cat_rows16 = value;
+    else if (!strcmp(key, "fuse_joint_qkv")) g_opt.fuse_joint_qkv = value;
     else if (!strcmp(key, "conv3w_min_blocks")) conv3w_set_min_blocks(value);
     else if (!strcmp(key, "conv3w_min_blocks_deep")) conv3w_set_min_blocks_deep(value);
     else if (!strcmp(key, "gemm16_bn64")) gemm16_set_bn64(value);
