@@ -303,6 +303,13 @@ struct Builder {
     };
     std::unordered_map<int, JCat> jqkv;
     std::unordered_map<const ggml_tensor*, size_t> lin_redirect;
+    // FLUX attentions (plan_flux_qkv): sources of the q / k rotary passes (keyed by the rope chain's first CONT) and of the v head-major passes
+    // (keyed by the CONT of PERMUTE(v)); part[1] is unused (Lb == 0) in the single blocks
+    struct RopeSrc {
+        JPart part[2];
+        int64_t La = 0, Lb = 0;
+    };
+    std::unordered_map<int, RopeSrc> rope_src, v_src;
     // arena scratch shared by all blocks of a plan (one stream: a block's launches finish with it before the next block's producer overwrites it)
     std::unordered_map<int, std::pair<size_t, size_t>> scratch_slots;
     size_t scratch(int key, size_t bytes) {
@@ -1599,10 +1606,16 @@ bool plan_concat_heads(Builder& B, int i, hipStream_t, std::vector<int>& chain) 
 //   c1 = CONT(PERMUTE(x,0,2,1,3)) -> RESHAPE [2,d/2,L,HN] -> xc = CONT(PERMUTE(.,3,0,1,2)) -> {VIEW half 0, VIEW half 1} -> RESHAPE [1,..] -> REPEAT [2,..]
 //   pec = CONT(PERMUTE(pe,3,0,1,2)) -> {VIEW 0, VIEW 1};  out = ADD_inplace(MUL(rep0, pe0), MUL(rep1, pe1)) [-> RESHAPE [d, L, HN]]
 // => one kernel reading x and the ORIGINAL pe.  It runs at the ADD's position (its output buffer only exists from there on); x must be intact.
-bool plan_rope(Builder& B, int i, hipStream_t, std::vector<int>& chain) {
-    GInfo& gi             = B.gi;
+struct RopeMatch {
+    const ggml_tensor* x  = nullptr;  // [d, H, L, N], d contiguous
+    const ggml_tensor* pe = nullptr;  // [2, 2, d/2, L]
+    int add               = -1;       // the chain's last node: its buffer holds the rotated [d, L, H*N] tensor
+    std::vector<int> chain;
+};
+// the 8-node apply_rope chain starting at c1 = CONT(PERMUTE(x, 0,2,1,3)) (see plan_rope); pure pattern match, nothing is emitted
+static bool match_rope(const GInfo& gi, int i, RopeMatch& rm) {
     const ggml_tensor* c1 = gi.node(i);
-    if (!g_opt.fusion || !g_opt.fuse_rope || c1->op != GGML_OP_CONT || !is_f32(c1) || !contig(c1)) return false;
+    if (!g_opt.fusion || c1->op != GGML_OP_CONT || !is_f32(c1) || !contig(c1)) return false;
     const ggml_tensor* p1 = c1->src[0];
     if (!p1 || p1->op != GGML_OP_PERMUTE) return false;
     const int32_t* a1 = p1->op_params;
@@ -1663,16 +1676,71 @@ bool plan_rope(Builder& B, int i, hipStream_t, std::vector<int>& chain) {
     const int add = gi.sole(mul[0]);
     if (add < 0 || add != gi.sole(mul[1]) || gi.node(add)->op != GGML_OP_ADD || !contig(gi.node(add)) || (gi.node(add)->flags & GGML_TENSOR_FLAG_OUTPUT)) return false;
     c2.push_back(add);
-    // nothing outside the chain may run between its first and last node that overwrites x (it is read at the ADD's position)
-    const int first = *std::min_element(c2.begin(), c2.end());
-    if (B.clobbered_between(first, add, x->data, ggml_abi_nbytes(x), c2)) return false;
-    // every chain node except the ADD must be consumed inside the chain only (checked through sole()/size above), and none may be a graph output
     for (int k : c2)
         if (k != add && (gi.node(k)->flags & GGML_TENSOR_FLAG_OUTPUT)) return false;
-    chain        = c2;
+    rm.x     = x;
+    rm.pe    = pe;
+    rm.add   = add;
+    rm.chain = c2;
+    return true;
+}
+
+bool plan_rope(Builder& B, int i, hipStream_t, std::vector<int>& chain) {
+    GInfo& gi = B.gi;
+    RopeMatch rm;
+    if (!match_rope(gi, i, rm)) return false;
+    const ggml_tensor* x = rm.x;
+    const int add        = rm.add;
+    const auto rs        = B.rope_src.find(i);
+    if (rs != B.rope_src.end()) {
+        // q / k of a FLUX attention (plan_flux_qkv): projection rows in arena scratch -> per-head RMSNorm * w -> [token concat] -> rotary -> the
+        // flash operand (f16 when only the flash node / its f16 cast reads it), one pass
+        const Builder::RopeSrc src = rs->second;
+        Planner* P                 = B.P;
+        const float* pep           = (const float*)rm.pe->data;
+        const int64_t d = x->ne[0], H = x->ne[1], N = x->ne[3];
+        std::vector<int> c2 = rm.chain;
+        void* outp  = gi.node(add)->data;
+        bool f16    = false, q16 = false;
+        size_t qoff = 0;
+        int j       = gi.sole(add);
+        int via     = add;
+        while (j >= 0 && gi.node(j)->op == GGML_OP_RESHAPE) {
+            via = j;
+            j   = gi.sole(j);
+        }
+        if (j >= 0 && gi.node(j)->op == GGML_OP_CPY && gi.node(j)->type == GGML_TYPE_F16 && gi.node(j)->src[0] == gi.node(via) && contig(gi.node(j)) &&
+            !(gi.node(j)->flags & GGML_TENSOR_FLAG_OUTPUT) && aligned16(gi.node(j)->data)) {
+            outp = gi.node(j)->data;  // K: straight into the f16 cast's buffer
+            f16  = true;
+            c2.push_back(j);
+        } else if (j >= 0 && g_opt.fuse_q16 && gi.node(j)->op == GGML_OP_FLASH_ATTN_EXT && gi.node(j)->src[0] == gi.node(via) && !gi.node(j)->src[3] && contig(gi.node(via)) &&
+                   gi.node(via)->ne[0] == d && d % 8 == 0 && flash_attn_supported(d, gi.node(j)->src[2]->ne[0])) {
+            qoff = B.scratch(0x4a61, (size_t)ggml_abi_nelements(x) * 2);  // Q: an f16 image in arena scratch
+            B.q16[gi.node(via)] = qoff;
+            f16 = q16 = true;
+            g_stats.fused_q16++;
+        }
+        const int last = f16 && !q16 ? c2.back() : add;
+        const Builder::JPart pa = src.part[0], pb = src.part[1];
+        const int64_t La = src.La, Lb = src.Lb;
+        const float eps  = pa.eps;
+        B.emit_at(last, i, [=](hipStream_t st) {
+            launch_joint_heads(st, q16 ? (void*)(P->arena + qoff) : outp, f16, (const float*)(P->arena + pa.off), pa.xs, pa.w, Lb > 0 ? (const float*)(P->arena + pb.off) : nullptr, pb.xs,
+                               pb.w, eps, d, H, La, Lb, N, pep);
+        });
+        chain = c2;
+        g_stats.fused_rope++;
+        return true;
+    }
+    if (!g_opt.fusion || !g_opt.fuse_rope) return false;
+    // nothing outside the chain may run between its first and last node that overwrites x (it is read at the ADD's position)
+    const int first = *std::min_element(rm.chain.begin(), rm.chain.end());
+    if (B.clobbered_between(first, add, x->data, ggml_abi_nbytes(x), rm.chain)) return false;
+    chain        = rm.chain;
     View4 xv     = view_of(x);
     float* out   = (float*)gi.node(add)->data;
-    const float* pep = (const float*)pe->data;
+    const float* pep = (const float*)rm.pe->data;
     B.emit_at(add, i, [=](hipStream_t st) { launch_rope_pairs(st, out, xv, pep); });
     g_stats.fused_rope++;
     return true;
@@ -2321,6 +2389,176 @@ void plan_joint_qkv(Builder& B) {
     }
 }
 
+// FLUX attentions (flux.hpp:263-315 SelfAttention::pre_attention, :430-592 DoubleStreamBlock, :594-700 SingleStreamBlock; rope.hpp:966-1025):
+//   T = Linear(x) [3C (+ mlp), L, N];  q, k: VIEW [d,H,L,N] of T -> RMS_NORM -> MUL(w[d]) [-> CONCAT(txt, img, dim 2)] -> apply_rope (8 nodes) -> flash Q / CPY f16 -> flash K
+//   v: VIEW [d,H,L,N] of T [-> CONCAT(dim 2)] -> PERMUTE(0,2,1,3) -> CONT -> RESHAPE -> CPY f16 -> flash V;   single blocks: mlp VIEW [M,L,N] -> CONT -> GELU
+// When EVERY reader of T is one of these, T goes to arena scratch (lin_redirect) and each operand becomes one k_joint_heads pass from the
+// projection rows to the flash operand (norm, token concat, rotary, f16 in one go); the mlp part is the strided GELU pass of plan_cat_rows16.
+void plan_flux_qkv(Builder& B) {
+    GInfo& gi = B.gi;
+    if (!g_opt.fusion || !g_opt.gemm16 || !g_opt.fuse_rope || !g_opt.fuse_joint_qkv) return;
+    struct Use {
+        int kind = 0;  // 1 = q / k (rope), 2 = v, 3 = mlp
+        int anchor = -1, part = 0, cat = -1;
+        int64_t col = 0;  // first float of the view inside a row of T
+        const float* w = nullptr;
+        float eps = 0.f;
+        std::vector<int> skip;
+    };
+    struct Cand {
+        int iT = -1;
+        int64_t W = 0, L = 0, N = 0;
+        std::vector<Use> uses;
+        bool alive = true;
+    };
+    std::vector<Cand> cands;
+    for (int iT = 0; iT < gi.g->n_nodes; ++iT) {
+        const ggml_tensor* T = gi.node(iT);
+        if (!is_f32(T) || !contig(T) || T->ne[3] != 1 || (T->flags & GGML_TENSOR_FLAG_OUTPUT) || !aligned16(T->data) || gi.consumers[iT].size() < 3) continue;
+        const bool from_mm = T->op == GGML_OP_MUL_MAT || (T->op == GGML_OP_ADD && T->src[0] && strip_reshape(T->src[0])->op == GGML_OP_MUL_MAT && T->data == strip_reshape(T->src[0])->data);
+        const ggml_tensor* mm = T->op == GGML_OP_MUL_MAT ? T : (from_mm ? strip_reshape(T->src[0]) : nullptr);
+        if (!from_mm || !mm || !linear_fast_ok(mm) || B.lin_redirect.count(T)) continue;
+        Cand c;
+        c.iT = iT;
+        c.W  = T->ne[0];
+        c.L  = T->ne[1];
+        c.N  = T->ne[2];
+        bool ok = true;
+        for (int iv : gi.consumers[iT]) {
+            const ggml_tensor* v = gi.node(iv);
+            if (v->op != GGML_OP_VIEW || !is_f32(v) || v->nb[0] != 4) {
+                ok = false;
+                break;
+            }
+            const ptrdiff_t delta = (const char*)v->data - (const char*)T->data;
+            if (delta < 0 || delta >= (ptrdiff_t)T->nb[1] || delta % 16 != 0) {
+                ok = false;
+                break;
+            }
+            Use u;
+            u.col = delta / 4;
+            if (v->ne[3] == 1 && v->ne[1] == c.L && v->ne[2] == c.N && v->nb[1] == T->nb[1] && v->nb[2] == T->nb[2]) {  // [M, L, N] rows: the mlp part
+                const int jc = gi.sole(iv);
+                if (jc < 0 || gi.node(jc)->op != GGML_OP_CONT || !B.cat16_part.count(gi.node(jc))) {
+                    ok = false;
+                    break;
+                }
+                u.kind   = 3;
+                u.anchor = jc;
+                c.uses.push_back(u);
+                continue;
+            }
+            const int64_t d = v->ne[0], H = v->ne[1];
+            if (!(v->ne[2] == c.L && v->ne[3] == c.N && v->nb[1] == (size_t)d * 4 && v->nb[2] == T->nb[1] && (c.N == 1 || v->nb[3] == T->nb[2]) && joint_heads_supported(d) &&
+                  u.col + d * H <= c.W)) {
+                ok = false;
+                break;
+            }
+            int j    = gi.sole(iv);
+            int from = iv;
+            if (j >= 0 && gi.node(j)->op == GGML_OP_RMS_NORM && gi.node(j)->src[0] == v) {
+                const int jn = j, jm = gi.sole(jn);
+                if (jm < 0 || gi.node(jm)->op != GGML_OP_MUL || gi.node(jm)->src[0] != gi.node(jn)) {
+                    ok = false;
+                    break;
+                }
+                const ggml_tensor* w = gi.node(jm)->src[1];
+                if (!is_f32(w) || !contig(w) || w->ne[0] != d || ggml_abi_nelements(w) != d || !is_static_weight(w) || !aligned16(w->data)) {
+                    ok = false;
+                    break;
+                }
+                u.kind = 1;
+                u.w    = (const float*)w->data;
+                u.eps  = ggml_abi_op_param_f32(gi.node(jn), 0);
+                u.skip = {jn, jm};
+                from   = jm;
+                j      = gi.sole(jm);
+            } else {
+                u.kind = 2;
+            }
+            if (j >= 0 && gi.node(j)->op == GGML_OP_CONCAT && gi.node(j)->op_params[0] == 2 && gi.node(j)->src[0] != gi.node(j)->src[1]) {
+                u.cat  = j;
+                u.part = gi.node(j)->src[0] == gi.node(from) ? 0 : (gi.node(j)->src[1] == gi.node(from) ? 1 : -1);
+                if (u.part < 0 || !contig(gi.node(j))) {
+                    ok = false;
+                    break;
+                }
+                u.skip.push_back(j);
+                from = j;
+                j    = gi.sole(j);
+            }
+            // X = node(from) [d, H, Lt, N] -> PERMUTE(0,2,1,3) -> CONT
+            const int jc = (j >= 0 && gi.node(j)->op == GGML_OP_PERMUTE && gi.node(j)->src[0] == gi.node(from)) ? gi.sole(j) : -1;
+            if (jc < 0 || gi.node(jc)->op != GGML_OP_CONT || !is_f32(gi.node(jc)) || !contig(gi.node(jc))) {
+                ok = false;
+                break;
+            }
+            const int32_t* ax = gi.node(j)->op_params;
+            if (!(ax[0] == 0 && ax[1] == 2 && ax[2] == 1 && ax[3] == 3)) {
+                ok = false;
+                break;
+            }
+            u.anchor = jc;
+            if (u.kind == 1) {
+                RopeMatch rm;
+                if (!match_rope(gi, jc, rm) || rm.x != gi.node(from)) {
+                    ok = false;
+                    break;
+                }
+            } else {  // v: CONT -> RESHAPE -> CPY f16
+                const int jr = gi.sole(jc);
+                const int jy = (jr >= 0 && gi.node(jr)->op == GGML_OP_RESHAPE) ? gi.sole(jr) : -1;
+                if (jy < 0 || gi.node(jy)->op != GGML_OP_CPY || gi.node(jy)->type != GGML_TYPE_F16 || gi.node(jy)->src[0] != gi.node(jr) || !contig(gi.node(jy)) ||
+                    (gi.node(jy)->flags & GGML_TENSOR_FLAG_OUTPUT) || !aligned16(gi.node(jy)->data)) {
+                    ok = false;
+                    break;
+                }
+            }
+            c.uses.push_back(u);
+        }
+        if (ok && !c.uses.empty()) cands.push_back(c);
+    }
+    if (cands.empty()) return;
+    // anchors fed through a CONCAT need both parts from accepted candidates
+    for (bool changed = true; changed;) {
+        changed = false;
+        std::unordered_map<int, int> cover;
+        for (const Cand& c : cands)
+            if (c.alive)
+                for (const Use& u : c.uses)
+                    if (u.kind != 3) cover[u.anchor] |= 1 << u.part;
+        for (Cand& c : cands) {
+            if (!c.alive) continue;
+            for (const Use& u : c.uses)
+                if (u.kind != 3 && cover[u.anchor] != (u.cat >= 0 ? 3 : 1)) {
+                    c.alive = false;
+                    changed = true;
+                    break;
+                }
+        }
+    }
+    for (const Cand& c : cands) {
+        if (!c.alive) continue;
+        int role = 2;  // 0 / 1: first / second stream of a double block, 2: single block
+        for (const Use& u : c.uses)
+            if (u.kind != 3 && u.cat >= 0) role = u.part;
+        const size_t toff = B.scratch(0x4a70 + role, (size_t)c.W * c.L * c.N * 4);
+        B.lin_redirect[gi.node(c.iT)] = toff;
+        for (const Use& u : c.uses) {
+            for (int k : u.skip) gi.done[k] = 1;
+            if (u.kind == 3) continue;
+            Builder::RopeSrc& rs = (u.kind == 1 ? B.rope_src : B.v_src)[u.anchor];
+            Builder::JPart& jp   = rs.part[u.part];
+            jp.off = toff + (size_t)u.col * 4;
+            jp.xs  = c.W;
+            jp.w   = u.w;
+            jp.eps = u.eps;
+            (u.part == 0 ? rs.La : rs.Lb) = c.L;
+        }
+        g_stats.fused_joint_qkv++;
+    }
+}
+
 bool build_plan(Planner* P, Plan* plan, const ggml_cgraph* g, hipStream_t s) {
     Builder B(P, plan, g);
     GInfo& gi = B.gi;
@@ -2328,6 +2566,7 @@ bool build_plan(Planner* P, Plan* plan, const ggml_cgraph* g, hipStream_t s) {
     plan_hoisted_emb(B, s);
     plan_cat_rows16(B);
     plan_joint_qkv(B);
+    plan_flux_qkv(B);
     for (int i = 0; i < g->n_nodes; ++i) {
         {
             auto it = B.deferred.find(i);
@@ -2427,10 +2666,35 @@ bool build_plan(Planner* P, Plan* plan, const ggml_cgraph* g, hipStream_t s) {
                     const float* xp             = (const float*)v->data;
                     const int64_t rows = v->ne[1] * v->ne[2], K = v->ne[0], xs = (int64_t)v->nb[1] / 4;
                     const size_t o     = pt.off + (size_t)pt.col * 2;
-                    B.emit([=](hipStream_t st) { launch_pack_cols_f16(st, PP->arena + o, pt.ld, xp, rows, K, xs, true); });
+                    // the viewed projection may live in arena scratch (plan_flux_qkv)
+                    // (the VIEW's src[0] is the projection's output node — the in-place bias ADD; its view_src is the MUL_MAT underneath, same bytes)
+                    const ggml_tensor* root = v->src[0] && B.lin_redirect.count(v->src[0]) ? v->src[0] : (v->view_src ? v->view_src : v->src[0]);
+                    const auto rd           = root ? B.lin_redirect.find(root) : B.lin_redirect.end();
+                    const bool redir        = rd != B.lin_redirect.end();
+                    const size_t roff       = redir ? rd->second + (size_t)((const char*)v->data - (const char*)root->data) : 0;
+                    B.emit([=](hipStream_t st) { launch_pack_cols_f16(st, PP->arena + o, pt.ld, redir ? (const float*)(PP->arena + roff) : xp, rows, K, xs, true); });
                     B.cat16[pt.cat].written[pt.part] = true;
                     chain = {i, gi.sole(i)};
                     ok    = true;
+                    break;
+                }
+                const auto vs = B.v_src.find(i);
+                if (vs != B.v_src.end()) {  // v of a FLUX attention: projection rows in arena scratch -> [token concat] -> head-major f16, one pass
+                    const Builder::RopeSrc src = vs->second;
+                    const int jr = gi.sole(i), jy = gi.sole(jr);
+                    Planner* PP  = P;
+                    void* outp   = gi.node(jy)->data;
+                    const ggml_tensor* xt = n->src[0]->src[0];  // [d, H, Lt, N]
+                    const int64_t d = xt->ne[0], H = xt->ne[1], Nimg = xt->ne[3];
+                    const Builder::JPart pa = src.part[0], pb = src.part[1];
+                    const int64_t La = src.La, Lb = src.Lb;
+                    B.emit_at(jy, i, [=](hipStream_t st) {
+                        launch_joint_heads(st, outp, true, (const float*)(PP->arena + pa.off), pa.xs, nullptr, Lb > 0 ? (const float*)(PP->arena + pb.off) : nullptr, pb.xs, nullptr, 0.f, d, H,
+                                           La, Lb, Nimg, nullptr);
+                    });
+                    chain = {i, jr, jy};
+                    ok    = true;
+                    g_stats.fused_concat_heads++;
                     break;
                 }
                 ok = plan_geglu(B, i, s, chain);

@@ -384,14 +384,14 @@ void launch_concat_heads(hipStream_t s, void* out, bool out_f16, const float* a,
 // strided norms, their weight MULs and the concat / permute / cast passes.  G lanes per head (d = 4 G), a head's 4 G floats are one contiguous run.
 template <typename TD, int G>
 __global__ void k_joint_heads(TD* __restrict__ out, const float* __restrict__ a, const float* __restrict__ b, int64_t xsa, int64_t xsb, const float* __restrict__ wa,
-                              const float* __restrict__ wb, float eps, int H, int64_t La, int64_t Lb, int64_t ngroups) {
+                              const float* __restrict__ wb, float eps, int H, int64_t La, int64_t Lb, int64_t ngroups, const float* __restrict__ pe) {
     const int j      = threadIdx.x % G;
     const int64_t Lt = La + Lb;
     for (int64_t gi = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / G; gi < ngroups; gi += (int64_t)gridDim.x * blockDim.x / G) {
         const int h     = (int)(gi % H);
         const int64_t t = gi / H, l = t % Lt, n = t / Lt;
         const bool fst  = l < La;
-        const float* src = fst ? a + (n * La + l) * xsa : b + (n * Lb + (l - La)) * xsb;
+        const float* src = fst ? a + (n * La + l) * xsa : b + (n * Lb + (l - La)) * xsb;  // (Lb == 0: one stream, b is never read)
         float4 v         = *(const float4*)(src + h * (4 * G) + 4 * j);
         const float* w   = fst ? wa : wb;
         if (w) {
@@ -402,17 +402,25 @@ __global__ void k_joint_heads(TD* __restrict__ out, const float* __restrict__ a,
             const float4 ww = ((const float4*)w)[j];
             v.x = v.x * sc * ww.x; v.y = v.y * sc * ww.y; v.z = v.z * sc * ww.z; v.w = v.w * sc * ww.w;
         }
+        if (pe) {  // rotary embedding of the pairs (4j, 4j+1), (4j+2, 4j+3) at joint position l: Rope::apply_rope (rope.hpp:966-1004), pe [2,2,d/2,Lt]
+            const float4 m0 = *(const float4*)(pe + (l * (2 * G) + 2 * j) * 4), m1 = *(const float4*)(pe + (l * (2 * G) + 2 * j + 1) * 4);
+            const float4 u  = v;
+            v.x = u.x * m0.x + u.y * m0.y;
+            v.y = u.x * m0.z + u.y * m0.w;
+            v.z = u.z * m1.x + u.w * m1.y;
+            v.w = u.z * m1.z + u.w * m1.w;
+        }
         TD r[4] = {cvt<TD>(v.x), cvt<TD>(v.y), cvt<TD>(v.z), cvt<TD>(v.w)};
         ((vec_t<TD, 4>*)out)[((n * H + h) * Lt + l) * G + j] = *(vec_t<TD, 4>*)r;
     }
 }
 bool joint_heads_supported(int64_t d) { return d == 64 || d == 128; }
 void launch_joint_heads(hipStream_t s, void* out, bool out_f16, const float* a, int64_t xsa, const float* wa, const float* b, int64_t xsb, const float* wb, float eps,
-                        int64_t d, int64_t H, int64_t La, int64_t Lb, int64_t N) {
+                        int64_t d, int64_t H, int64_t La, int64_t Lb, int64_t N, const float* pe) {
     KScope ks_(s, KF_CONCAT, 0.0, (double)d * H * (La + Lb) * N * (4.0 + (out_f16 ? 2.0 : 4.0)));
     const int64_t ng = H * (La + Lb) * N, nthr = ng * (d / 4);
     const unsigned grid = grid_for(nthr, 256);
-#define JH(TD_, G_) k_joint_heads<TD_, G_><<<grid, 256, 0, s>>>((TD_*)out, a, b, xsa, xsb, wa, wb, eps, (int)H, La, Lb, ng)
+#define JH(TD_, G_) k_joint_heads<TD_, G_><<<grid, 256, 0, s>>>((TD_*)out, a, b, xsa, xsb, wa, wb, eps, (int)H, La, Lb, ng, pe)
     if (d == 64) {
         if (out_f16) JH(__half, 16); else JH(float, 16);
     } else {

@@ -33,7 +33,7 @@ void launch_concat_heads(hipStream_t s, void* out, bool out_f16, const float* a,
 // RMSNorm * w -> token concat (a first) -> head-major [d, La + Lb, H, N], f32 or f16 (elementwise.hip k_joint_heads); d = 64 or 128
 bool joint_heads_supported(int64_t d);
 void launch_joint_heads(hipStream_t s, void* out, bool out_f16, const float* a, int64_t xsa, const float* wa, const float* b, int64_t xsb, const float* wb, float eps,
-                        int64_t d, int64_t H, int64_t La, int64_t Lb, int64_t N);
+                        int64_t d, int64_t H, int64_t La, int64_t Lb, int64_t N, const float* pe = nullptr);  // pe: rotary table [2,2,d/2,La+Lb] applied after the norm (FLUX)
 // interleaved rotary embedding: x [d, H, L, N] (d contiguous, other dims strided), pe [2,2,d/2,L] -> out [d, L, H*N] contiguous
 void launch_rope_pairs(hipStream_t s, float* out, const View4& x, const float* pe);
 void launch_upscale_nearest(hipStream_t s, const View4& dst, const View4& src);
