@@ -369,7 +369,7 @@ struct Builder {
         G16SplitPlan sp = gemm16_split_plan(rows, M, K, conv, plain_out);
         if (sp.S > 1 && sp.inkernel && cnt_used + (size_t)sp.tiles > CNT_CAP) {  // counter block full: the slab + reduce pass where it applies
             sp.inkernel = false;
-            sp.S        = plain_out ? gemm16_split_k(rows, M, K) : 1;
+            sp.S        = plain_out ? gemm16_split_k(rows, M, K, conv) : 1;
             sp.ws_bytes = (size_t)sp.S * rows * M * 4;
         }
         if (sp.S <= 1) return r;
@@ -631,7 +631,7 @@ void plan_linear(Builder& B, int i, hipStream_t s, std::vector<int>& chain) {
     int emit_node = i;  // graph position at which the GEMM itself is launched (operand packing always happens at i)
     // DiT gate (mmdit.hpp:540-551): Linear -> MUL(., gate[M,1,N]) -> ADD(x, .): dst = x + (acc + bias) * gate
     if (g_opt.fusion && g_opt.gemm16 && g_opt.fuse_gate && hm_d == 0 && !ep.residual && x->ne[3] == 1 && x->ne[1] >= 32 && tokens < (1ll << 31) &&
-        gemm16_split_k(tokens, M, K) == 1) {  // split-K launches keep the plain epilogue (the slab reduce applies bias only)
+        gemm16_split_k(tokens, M, K, false) == 1) {  // split-K launches keep the plain epilogue (the slab reduce applies bias only)
         const int jm = gi.sole(last);
         const ggml_tensor* mt = jm >= 0 ? gi.node(jm) : nullptr;
         if (mt && mt->op == GGML_OP_MUL && mt->src[0] == gi.node(last)) {
@@ -3029,6 +3029,7 @@ void planner_set_option(const char* key, int value) {
     else if (!strcmp(key, "gemm16_abl")) gemm16_set_abl(value);
 #endif
     else if (!strcmp(key, "gemm16_t320")) gemm16_set_t320(value);
+    else if (!strcmp(key, "t320_linear_max_split")) gemm16_set_t320_linear_max_split(value);
     else if (!strcmp(key, "qgemv")) g_opt.qgemv = value;
     else if (!strcmp(key, "fuse_q16")) g_opt.fuse_q16 = value;
     else if (!strcmp(key, "flash_grid")) flash_attn_set_grid(value);

@@ -622,8 +622,8 @@ static int g_g16_bn64 = 1;  // option "gemm16_bn64": 0 = 64-column tiles only fo
 void gemm16_set_bn64(int v) { g_g16_bn64 = v; }
 static int g_g16_t320 = 1;  // option "gemm16_t320": 0 disables the pipelined 256x320 tile in the per-shape choice (A/B measurements)
 void gemm16_set_t320(int v) { g_g16_t320 = v; }
-int gemm16_split_k(int64_t rows, int64_t M, int64_t K);
-static int g16_t320_split(int64_t rows, int64_t M, int64_t nt);
+int gemm16_split_k(int64_t rows, int64_t M, int64_t K, bool conv);
+static int g16_t320_split(int64_t rows, int64_t M, int64_t nt, bool conv);
 // mul > 1: `mul` sibling weights of M columns each in one launch (divisibility per weight, tile counts over all of them)
 static int g16_pick_tile(int64_t rows, int64_t M, bool geglu, bool conv, int split, int64_t nt, int mul = 1) {
     if (g_g16_variant != 3) return G16_T128;
@@ -646,7 +646,7 @@ static int g16_pick_tile(int64_t rows, int64_t M, bool geglu, bool conv, int spl
         if (nt >= 64 && c256p >= 192 && c256p * 4 >= rounds * 256 * 3) return G16_T256P;
     }
     if (split) {
-        if (can320 && g16_t320_split(rows, M, nt) == split) return G16_T320;
+        if (can320 && g16_t320_split(rows, M, nt, conv) == split) return G16_T320;
     } else if (g_g16_t320 && can320) {
         // one workgroup per CU and 256 CUs: take it when the launch fills >= 75 % of its rounds
         const int64_t c320 = rt256 * (M / 320) * mul, rounds = (c320 + 255) / 256;
@@ -727,14 +727,20 @@ static int g_g16_splitk_target = 384;  // option "splitk_target": workgroups a s
 void gemm16_set_splitk_target(int v) { g_g16_splitk_target = v; }
 static int g_g16_splitk_mid = 0;
 void gemm16_set_splitk_mid(int v) { g_g16_splitk_mid = v; }
+static int g_g16_t320_linear_max_split = 4;  // option "t320_linear_max_split"
+void gemm16_set_t320_linear_max_split(int v) { g_g16_t320_linear_max_split = v; }
 // K slices for the pipelined 256x320 tile when the output alone does not fill the chip (one workgroup per CU: 256 slots): the 32x32 and
 // 16x16 UNet levels give 128 / 64 tiles.  0 = not applicable.  At least 20 stages per slice (4 of them are pipeline fill).
-static int g16_t320_split(int64_t rows, int64_t M, int64_t nt) {
+static int g16_t320_split(int64_t rows, int64_t M, int64_t nt, bool conv) {
     if (!g_g16_t320 || g_g16_variant != 3 || M % 320 != 0 || (g_g16_force_tile >= 0 && g_g16_force_tile != G16_T320)) return 0;
     const int64_t c320 = ((rows + 255) / 256) * (M / 320);
     if (c320 >= 192 || c320 < 8) return 0;
     int64_t S = 256 / c320;
     if (S > 16) S = 16;
+    // Linears (K <= 5120) with few row tiles: more than four slices means the slab traffic (S f32 outputs written, read again by the reduce pass)
+    // outweighs the deeper pipeline — SDXL's 2048-token FF2 / projections: 8 slices -> 128-row tiles with 2 slices, 35.1 -> 33.7 ms of kernels
+    // per pair forward (profiles/r04q_sdxl_splitk.txt)
+    if (!conv && S > g_g16_t320_linear_max_split) return 0;
     // every slice writes a whole f32 slab and the reduce pass reads them all: worth it only when a slice still carries real work
     // (profiles/r02d_t320_tile_check.txt: K/S = 2880 wins 10-45 %, K/S = 1280 loses 25 %); the 8x8 level (<= 2048 rows) has no good
     // alternative and takes shorter slices
@@ -742,11 +748,11 @@ static int g16_t320_split(int64_t rows, int64_t M, int64_t nt) {
     while (S > 1 && nt / S < min_stages) --S;
     return (S >= 2 && c320 * S >= 128) ? (int)S : 0;
 }
-int gemm16_split_k(int64_t rows, int64_t M, int64_t K) {
+int gemm16_split_k(int64_t rows, int64_t M, int64_t K, bool conv) {
     if (!g16_bk32()) return 1;
     const int64_t wgs = ((rows + 127) / 128) * ((M + 127) / 128);
     const int64_t nt  = rup64(K, 64) / 32;
-    if (const int s320 = g16_t320_split(rows, M, nt)) return s320;
+    if (const int s320 = g16_t320_split(rows, M, nt, conv)) return s320;
     if (wgs > g_g16_splitk_target / 2) {
         // option "splitk_mid" (experiment, default 0): 193..384 workgroups over 768 resident slots leave most CUs with one or two
         // workgroups (the 16x16 UNet level: 320 tiles, K = 11520..23040 at ~520 TFLOP/s); two K slices double the workgroups in flight
@@ -777,7 +783,7 @@ G16SplitPlan gemm16_split_plan(int64_t rows, int64_t M, int64_t K, bool conv, bo
     G16SplitPlan r{1, false, 0, 0};
     const int64_t nt = rup64(K, 64) / (g16_bk32() ? 32 : 64);
     if (!g16_bk32()) return r;
-    if (g16_t320_split(rows, M, nt) == 0 && g_g16_sk_inkernel && g_g16_variant == 3 && g_g16_force_tile < 0) {
+    if (g16_t320_split(rows, M, nt, conv) == 0 && g_g16_sk_inkernel && g_g16_variant == 3 && g_g16_force_tile < 0) {
         const int bn        = (conv ? M <= 64 : g16_use_bn64(rows, M)) ? 64 : 128;
         const int64_t tiles = ((rows + 127) / 128) * ((M + bn - 1) / bn);
         // only grids the 128-row tile would get anyway (g16_pick_tile moves to 256-row tiles from 256 of them on)
@@ -796,7 +802,7 @@ G16SplitPlan gemm16_split_plan(int64_t rows, int64_t M, int64_t K, bool conv, bo
         }
     }
     if (plain_out) {
-        r.S = gemm16_split_k(rows, M, K);
+        r.S = gemm16_split_k(rows, M, K, conv);
         if (r.S > 1) r.ws_bytes = (size_t)r.S * rows * M * 4;
     }
     return r;
@@ -930,7 +936,7 @@ void launch_gemm16_linear(hipStream_t s, float* dst, void* dst16, int64_t ldd16,
         abort();
     }
     const bool inker = splitk_ws && splitk_cnt != nullptr && splitk_S > 1;
-    const int S      = inker ? splitk_S : ((splitk_ws && dst && !dst16 && hm_d == 0 && ldd == M && !e.gate) ? gemm16_split_k(rows, M, K) : 1);
+    const int S      = inker ? splitk_S : ((splitk_ws && dst && !dst16 && hm_d == 0 && ldd == M && !e.gate) ? gemm16_split_k(rows, M, K, false) : 1);
     if (S > 1) {
         g.split_k  = S;
         g.nt_slice = (g.nt + S - 1) / S;
@@ -1058,7 +1064,7 @@ void launch_gemm16_conv(hipStream_t s, float* dst, const void* x16_nhwc, const v
     g.ep.chan_add = e.chan_add;
     g.ep.chan_ld  = (int)e.chan_ld;
     const bool inker = splitk_ws && splitk_cnt != nullptr && splitk_S > 1;
-    const int S      = inker ? splitk_S : (splitk_ws ? gemm16_split_k(g.R, OC, (int64_t)g.ICp * ksize * ksize) : 1);
+    const int S      = inker ? splitk_S : (splitk_ws ? gemm16_split_k(g.R, OC, (int64_t)g.ICp * ksize * ksize, true) : 1);
     if (S > 1) {
         g.split_k  = S;
         g.nt_slice = (g.nt + S - 1) / S;

@@ -112,7 +112,8 @@ void launch_gemm16_linear_multi(hipStream_t s, int n, float* const* dst, void* c
 void launch_gemm16_linear_geglu(hipStream_t s, void* dst16, const void* a16, int64_t lda, const void* wswz_geglu, int64_t rows, int64_t K, int64_t M,
                                 const float* bias);
 // split-K factor the launchers will use when given a workspace of factor * rows * M floats (1 = no split)
-int gemm16_split_k(int64_t rows, int64_t M, int64_t K);
+int gemm16_split_k(int64_t rows, int64_t M, int64_t K, bool conv);
+void gemm16_set_t320_linear_max_split(int v);  // option "t320_linear_max_split" (4): most K slices a Linear takes on the 256x320 tile
 // the split a launch of this shape should take: S slices; inkernel = combined by the last-arriving workgroup of every output tile (the launcher
 // then needs `tiles` zeroed int counters and ws_bytes of slab space, and applies the full epilogue itself), else slabs + k_splitk_reduce (only
 // for plain f32 outputs: plain_out).  S = 1: no split.
