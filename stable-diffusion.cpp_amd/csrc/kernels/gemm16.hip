@@ -711,6 +711,9 @@ static void g16_launch(hipStream_t s, G16Args& g, int64_t rows, double flops, do
     }
     const dim3 grid((unsigned)(((rows + 127) / 128) * g.ncol_tiles * mul), ny);
     KScope ks_(s, CONV_ ? KF_CONV_T128 : KF_LINEAR, flops, bytes);
+    // (measured and rejected: the hand-pipelined loop of the 256x320 tile instantiated for a 128x128 tile — 2 waves of 64x128, 4 stages, two
+    // workgroups per CU — for launches resident in one round: SDXL pair forward 33.6 -> 35.0 ms, SD1.5 step 23.55 -> 23.79 ms; one wave per SIMD
+    // hides less than the plain loop's four: profiles/r04s_t128p_rejected_*.txt)
     if (g_g16_variant == 0)
         k_gemm16<128, BN_, CONV_, 64, 2, 2, 2><<<grid, 256, 0, s>>>(g);
     else if (g_g16_variant == 2)
