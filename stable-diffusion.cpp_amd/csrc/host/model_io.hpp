@@ -304,6 +304,10 @@ inline bool read_safetensors(const std::string& path, ModelFile& mf) {
                 }
                 (void)c.eat(',');
             }
+            if (shape.size() == 5) {  // the reference folds the two outermost (torch-order) dims of a 5-D tensor: safetensors_io.cpp:277-283
+                shape[1] *= shape[0];
+                shape.erase(shape.begin());
+            }
             if (!known) {
                 mf.undecodable[key] = dtype;
             } else if (shape.size() <= 4 && b >= 0 && e >= b && base + (uint64_t)e <= fsize) {
@@ -326,7 +330,7 @@ inline bool read_safetensors(const std::string& path, ModelFile& mf) {
                 t.nbytes = (uint64_t)(e - b);
                 if (nel > 0) mf.tensors.push_back(t);
             } else {
-                mf.error = "bad shape / data_offsets for tensor '" + key + "'";
+                mf.error = (shape.size() > 4 ? "invalid tensor '" : "bad shape / data_offsets for tensor '") + key + "'";  // > 5 dims: safetensors_io.cpp:265-268
                 return false;
             }
         }

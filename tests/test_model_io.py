@@ -233,6 +233,43 @@ def _e4m3_decode_np(b):
     return np.where(s == 1, -v, v).astype(np.float32)
 
 
+def test_safetensors_5d_tensors_fold_their_outer_dims(sd, oracle, tmp_path):
+    """safetensors_io.cpp:265-283: a 5-D tensor is accepted with its two outermost (torch-order) dims folded into one; more than five
+    dims is the reference's 'invalid tensor' error.  A 4-D conv weight written as [2, OC/2, IC, KH, KW] must load as the same bytes, and an
+    undeclared 5-D tensor (a bundled 3-D conv) must not stop the file from loading."""
+    e = sd.Engine(model=sd.SD15_TINY, backend=oracle)
+    names = _names(e)
+    rng = np.random.default_rng(11)
+    tensors, want, folded = {}, {}, 0
+    for n in names:
+        ne, ty, _ = e.tensor_info(n)
+        shape = tuple(int(d) for d in reversed(ne))
+        while len(shape) > 1 and shape[0] == 1:
+            shape = shape[1:]
+        a = (rng.standard_normal(shape) * 0.05).astype(np.float32)
+        want[n] = a
+        if len(shape) == 4 and shape[0] % 2 == 0 and folded < 6:
+            a = a.reshape((2, shape[0] // 2) + shape[1:])
+            folded += 1
+        tensors[n] = ("F32", a)
+    assert folded == 6
+    tensors["bundled.conv3d.weight"] = ("F32", np.zeros((2, 3, 2, 2, 2), np.float32))
+    p = tmp_path / "tiny5d.safetensors"
+    _write_safetensors(p, tensors)
+    assert e.load_weights(p) == {"loaded": len(names), "missing": 0, "unused": 1}
+    for n in names[::9]:
+        _, ty, _ = e.tensor_info(n)
+        ref = want[n].ravel()
+        if ty == sd.F16:
+            ref = ref.astype(np.float16).astype(np.float32)
+        np.testing.assert_array_equal(e.get_tensor(n).ravel(), ref, err_msg=n)
+    tensors["six.dims"] = ("F32", np.zeros((1, 1, 2, 1, 1, 2), np.float32))
+    p6 = tmp_path / "tiny6d.safetensors"
+    _write_safetensors(p6, tensors)
+    with pytest.raises(Exception, match="invalid tensor"):
+        e.load_weights(p6)
+
+
 def test_safetensors_wide_and_8bit_dtypes_are_converted(sd, oracle, tmp_path):
     """F64 / I64 / F8_E4M3 / F8_E5M2 payloads are widened to f32 and then converted to the parameter's type, as the reference does
     (safetensors_io.cpp:79-99, model_loader.cpp:81-153) — round-1 advice: they used to be dropped silently."""
