@@ -18,8 +18,10 @@ sd.load_mi355x_backend()
 L = sd.lib()
 rng = np.random.default_rng(0)
 REPS = 5
-# variants: the round-2 kernel (one query block per wave), two query blocks per wave, the 8-wave ping-pong kernel (the default policy)
-VARIANTS = [("r2", {"flash_pp": 0, "flash_qb2": 0}), ("qb2", {"flash_pp": 0, "flash_qb2": 1}), ("pp", {"flash_pp": 2, "flash_qb2": 1})]
+# variants: a warm-up column (the first variant of a case runs on cold clocks), the round-2 kernel (one query block per wave), two query blocks
+# per wave, each with and without the fragment prefetch (flash_vpf); the ping-pong kernel of earlier runs is still reachable with flash_pp = 2
+VARIANTS = [("warm", {"flash_qb2": 0, "flash_vpf": 0}), ("r2", {"flash_qb2": 0, "flash_vpf": 0}), ("qb2", {"flash_qb2": 1, "flash_vpf": 0}),
+            ("vpf", {"flash_qb2": 0, "flash_vpf": 31}), ("qb2+vpf", {"flash_qb2": 1, "flash_vpf": 31})]
 
 
 def rel_l2(a, b):
@@ -52,8 +54,9 @@ def case(label, d, Lq, Lk, HN):
         ms = sum(f["total_ms"] for f in t) / REPS
         outs.append(out)
         line += f" | {name}: {ms*1e3:8.1f} us {flops/ms/1e9:7.1f} TF{'' if np.array_equal(out, out2) else ' RERUN-DIFF'}"
-    sd.backend_set_option("flash_pp", 1)
+    sd.backend_set_option("flash_pp", 0)
     sd.backend_set_option("flash_qb2", 1)
+    sd.backend_set_option("flash_vpf", 31)
     k16, v16 = k.astype(np.float16).astype(np.float64), v.astype(np.float16).astype(np.float64)
     worst = 0.0
     r2 = np.random.default_rng(1)

@@ -67,8 +67,16 @@ struct FAArgs {
 // from LDS, every staged K / V byte and every barrier then feeds TWO MFMAs instead of one, and the two blocks' QK^T -> softmax -> PV chains are
 // independent instruction streams the scheduler can interleave (the round-2 kernel was a single dependent chain per wave: MFMA pipe 27-30 % busy,
 // 42 % of the wave cycles waiting, profiles/r03c_pmc_flash.txt).  Costs 2x the accumulator / score registers: 2 waves per SIMD.
-template <int DKP, int NDV, bool FAST, int ABL = 0, bool MSLOT = false, int QB = 1>
-__global__ __launch_bounds__(256, QB == 2 ? (DKP <= 96 ? 2 : 1) : (DKP <= 64 ? FA_OCC_SMALL : (DKP <= 128 ? 2 : 1))) void k_flash_attn(FAArgs g) {
+// VPF: fragment reads issued AHEAD of the MFMAs that use them — the first V fragments of a tile before its softmax VALU work, the rest
+// four fragments ahead inside the PV loop; for d >= 128 the K fragments of QK^T in groups of four, one group ahead.  Left to the compiler every
+// MFMA (pair) was preceded by its own ds_read + s_waitcnt lgkmcnt: the LDS latency (~100 cycles) sat in front of each of the 16-32 MFMAs of a tile.
+// Measured (profiles/r04z_flash_vpf.txt, one box, alternating variants): d = 128, L = 4352: 409 -> 387 us; d = 64, L = 4250: 598 -> 553; d = 64,
+// L = 4096: 154 -> 148; d = 80: 99.5 -> 96.0; d = 40 with two query blocks: 641 -> 637.  Option "flash_vpf" (bit per head-dim class) for A/B runs.
+// (Also measured, rejected and removed: a software-pipelined tile loop computing S(t+1) = K(t+1) Q^T inside the exponentials of tile t — one
+// scheduling region, MFMAs and VALU interleaved by sched_group_barrier, bit-identical results: 15-25 % SLOWER at d <= 64 (second score register set:
+// 3 -> 2 waves per SIMD), equal at d = 128: profiles/r04x_flash_sp_rejected.txt.)
+template <int DKP, int NDV, bool FAST, int ABL = 0, bool MSLOT = false, int QB = 1, bool VPF = false>
+__global__ __launch_bounds__(256, QB == 2 ? (DKP <= 96 ? 2 : 1) : (DKP <= 64 ? (VPF ? 2 : FA_OCC_SMALL) : (DKP <= 128 ? 2 : 1))) void k_flash_attn(FAArgs g) {
     static_assert(QB == 1 || FAST, "two query blocks per wave: FAST staging only");
     constexpr int QW   = 32 * QB;                        // queries per wave
     constexpr int QWG  = 4 * QW;                         // queries per workgroup
@@ -331,6 +339,7 @@ __global__ __launch_bounds__(256, QB == 2 ? (DKP <= 96 ? 2 : 1) : (DKP <= 64 ? F
         // ---- per query block: S^T = K Q^T (rows i = key, cols j = query) -> online softmax -> P packed to f16.  Block b+1's QK^T MFMAs are
         // independent of block b's softmax VALU work, so the two streams overlap; only ONE block's 32 score registers are live at a time.
         half8_t pa[QB][4];
+        half4_t vq0[4], vq1[4];  // VPF: ring of four V fragments (two 8-byte halves each)
         constexpr bool SHARE_KF = QB == 2 && KS <= 3;
         half8_t kf[2][KS <= 6 ? KS : 1];
         // ---- online softmax for query (lane & 31) of each block; this lane holds keys kb*32 + (r&3)+8*(r>>2)+4*hi.  The loop is VALU-bound at
@@ -359,6 +368,42 @@ __global__ __launch_bounds__(256, QB == 2 ? (DKP <= 96 ? 2 : 1) : (DKP <= 64 ? F
                 for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
                     for (int kb = 0; kb < 2; ++kb) s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kb][ks], qf[b][ks], s[kb], 0, 0, 0);
+            } else if constexpr (VPF && KS == 8) {
+                // d = 128: groups of four fragments, the next group's reads in flight during the current group's MFMAs
+                constexpr int NG = 2 * KS / 4;  // groups over (kb, ks)
+                half8_t ka[4], kbq[4];
+                auto rdg = [&](half8_t (&dst)[4], int gi) {
+                    const int kb = (gi * 4) / KS, ks0 = (gi * 4) % KS;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) dst[j] = *(const half8_t*)&Kc[(kb * 32 + (lane & 31)) * KROW + (ks0 + j) * 16 + hi * 8];
+                };
+                s[0] = (float16_t){0};
+                s[1] = (float16_t){0};
+                rdg(ka, 0);
+#pragma unroll
+                for (int gi = 0; gi < NG; gi += 2) {
+                    rdg(kbq, gi + 1);
+                    {
+                        const int kb = (gi * 4) / KS, ks0 = (gi * 4) % KS;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka[j], qf[b][ks0 + j], s[kb], 0, 0, 0);
+                    }
+                    if (gi + 2 < NG) rdg(ka, gi + 2);
+                    {
+                        const int kb = ((gi + 1) * 4) / KS, ks0 = ((gi + 1) * 4) % KS;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kbq[j], qf[b][ks0 + j], s[kb], 0, 0, 0);
+                    }
+                }
+                static_assert(NG == 4, "the issue pattern below is written for KS = 8");
+                // issue order: the reads of groups 0 and 1, then MFMAs of group g followed by the reads of group g + 2
+                __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
             } else {  // d = 128, 160: the fragments of a whole tile do not fit next to the accumulators
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb) {
@@ -376,6 +421,16 @@ __global__ __launch_bounds__(256, QB == 2 ? (DKP <= 96 ? 2 : 1) : (DKP <= 64 ? F
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
                         if (kt + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= g.Lk) s[kb][r] = -INFINITY;
+            }
+            if (VPF && b == QB - 1) {  // the first four V fragments of this tile: in flight during the (last block's) softmax
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int t = i / NDV, nb = i % NDV;
+                    const _Float16* vrow = &Vc[(nb * 32 + (lane & 31)) * FA_VTS + t * 16 + 4 * hi];
+                    vq0[i] = *(const half4_t*)vrow;
+                    vq1[i] = *(const half4_t*)(vrow + 8);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
             float tmax = s[0][0];
             if (ABL != 1) {
@@ -439,6 +494,28 @@ __global__ __launch_bounds__(256, QB == 2 ? (DKP <= 96 ? 2 : 1) : (DKP <= 64 ? F
             }
         }
         // ---- O += P V : 4 k-steps of 16 keys; k-slot order = accumulator key order (see header); every V fragment feeds the QB blocks
+        if constexpr (VPF) {
+            constexpr int NFR = 4 * NDV;
+#pragma unroll
+            for (int i = 0; i < NFR; ++i) {
+                const int t = i / NDV, nb = i % NDV;
+                const half4_t v0 = vq0[i & 3], v1 = vq1[i & 3];
+                const half8_t vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+                for (int b = 0; b < QB; ++b) o[b][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa[b][t], vf, o[b][nb], 0, 0, 0);
+                if (i + 4 < NFR) {
+                    const int t2 = (i + 4) / NDV, nb2 = (i + 4) % NDV;
+                    const _Float16* vrow = &Vc[(nb2 * 32 + (lane & 31)) * FA_VTS + t2 * 16 + 4 * hi];
+                    vq0[i & 3] = *(const half4_t*)vrow;
+                    vq1[i & 3] = *(const half4_t*)(vrow + 8);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NFR; ++i) {  // the fragment's MFMA(s), then the two reads that refill its ring slot
+                __builtin_amdgcn_sched_group_barrier(0x008, QB, 0);
+                if (i + 4 < NFR) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            }
+        } else
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
 #pragma unroll
@@ -977,6 +1054,8 @@ static int g_flash_qb2 = 1;  // option "flash_qb2": 0 = one query block per wave
 void flash_attn_set_qb2(int v) { g_flash_qb2 = v; }
 static int g_flash_pp = 0;  // option "flash_pp": 0 (default) = never the ping-pong kernel, 1 = for 64 < d <= 96, 2 = wherever it is legal (A/B measurements)
 void flash_attn_set_pp(int v) { g_flash_pp = v; }
+static int g_flash_vpf = 31;  // option "flash_vpf": head-dim classes (1: d <= 48, 2: <= 64, 4: <= 96, 8: <= 128, 16: above) whose kernel prefetches its fragments
+void flash_attn_set_vpf(int v) { g_flash_vpf = v; }
 static int g_flash_pp_min_tiles = 4;  // option "flash_pp_min_tiles": key tiles (64 keys) from which the ping-pong pipeline has a steady state worth its prologue
 void flash_attn_set_pp_min_tiles(int v) { g_flash_pp_min_tiles = v; }
 
@@ -1038,12 +1117,14 @@ void launch_flash_attn(hipStream_t s, const FlashOut& out, const View4& q, const
         g.units = (int)(q.ne[2] / out.H) * (int)grid.x;
         grid    = dim3((unsigned)(((g.units + 7) / 8) * 8 * g.grp), 1u);
     }
-#define FA_CASE(DKP_, NDV_)                                           \
-    do {                                                              \
-        if (fast)                                                     \
-            k_flash_attn<DKP_, NDV_, true><<<grid, 256, 0, s>>>(g);   \
-        else                                                          \
-            k_flash_attn<DKP_, NDV_, false><<<grid, 256, 0, s>>>(g);  \
+#define FA_CASE(DKP_, NDV_)                                                                \
+    do {                                                                                   \
+        if (fast && (g_flash_vpf & (DKP_ <= 48 ? 1 : DKP_ <= 64 ? 2 : DKP_ <= 96 ? 4 : DKP_ <= 128 ? 8 : 16)))  \
+            k_flash_attn<DKP_, NDV_, true, 0, false, 1, true><<<grid, 256, 0, s>>>(g);     \
+        else if (fast)                                                                     \
+            k_flash_attn<DKP_, NDV_, true><<<grid, 256, 0, s>>>(g);                        \
+        else                                                                               \
+            k_flash_attn<DKP_, NDV_, false><<<grid, 256, 0, s>>>(g);                       \
     } while (0)
 #ifdef MI355X_EXPERIMENTS
     if (D <= 48 && fast && g_flash_ablate == 1) {
@@ -1070,6 +1151,13 @@ void launch_flash_attn(hipStream_t s, const FlashOut& out, const View4& q, const
             k_flash_pp<128, 4, false><<<grid, 512, 0, s>>>(g);
         return;
     }
+    if (qb2 && (g_flash_vpf & 1)) {
+        if (D == 40 && g_flash_mslot)
+            k_flash_attn<48, 2, true, 0, true, 2, true><<<grid, 256, 0, s>>>(g);
+        else
+            k_flash_attn<48, 2, true, 0, false, 2, true><<<grid, 256, 0, s>>>(g);
+        return;
+    }
     if (qb2) {
         if (D == 40 && g_flash_mslot)
             k_flash_attn<48, 2, true, 0, true, 2><<<grid, 256, 0, s>>>(g);
@@ -1079,7 +1167,9 @@ void launch_flash_attn(hipStream_t s, const FlashOut& out, const View4& q, const
             k_flash_attn<64, 2, true, 0, false, 2><<<grid, 256, 0, s>>>(g);
         return;
     }
-    if (D == 40 && fast && g_flash_mslot)
+    if (D == 40 && fast && g_flash_mslot && (g_flash_vpf & 1))
+        k_flash_attn<48, 2, true, 0, true, 1, true><<<grid, 256, 0, s>>>(g);
+    else if (D == 40 && fast && g_flash_mslot)
         k_flash_attn<48, 2, true, 0, true><<<grid, 256, 0, s>>>(g);
     else if (D <= 48)
         FA_CASE(48, 2);
