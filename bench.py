@@ -206,6 +206,8 @@ def main():
                 pm = json.loads(tf.read_text())
                 roofline["traffic"] = pm["hbm_bytes_per_launch"]
                 roofline["traffic_source"] = "profiles/r04_pmc_traffic_conv256.json (kernels matching '" + pm.get("kernel", "") + "', " + str(pm.get("launches_fetch_pass")) + " launches): " + pm.get("source", "")
+                if pm.get("note"):
+                    roofline["traffic_note"] = pm["note"]
             except (ValueError, KeyError):
                 pass
     roofline["whole_step_tflops"] = round(step_tflops, 2)  # all kernels + host graph build + uploads: 2*B*UNet-forward FLOPs / step wall time
