@@ -86,6 +86,7 @@ struct ggml_backend_mi355x_stats {
     int64_t hoisted_emb_linears; /* per-ResBlock SiLU(emb) -> Linear projections computed by one grouped weight-streaming launch ahead of their graph position */
     int64_t fused_rows16;        /* Linear (+bias, +residual) read only by a 1x1 conv (SpatialTransformer proj_out): written as the conv's f16 operand rows */
     int64_t fused_joint_qkv;     /* MMDiT streams whose fused qkv projection feeds the joint attention through k_joint_heads (no split copy, no separate norms / concats) */
+    int64_t jit_images;          /* quantised Linears planned with a just-in-time f16 image (option jit_qimages: no cached image, rebuilt in front of every launch) */
     int64_t fused_cat_rows16;    /* CONCAT along the feature dimension read only by Linears: their f16 operand image assembled directly (FLUX single block) */
 };
 GGML_MI355X_API void ggml_backend_mi355x_get_stats(struct ggml_backend_mi355x_stats* out);

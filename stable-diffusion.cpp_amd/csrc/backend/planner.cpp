@@ -41,11 +41,11 @@ namespace {
 struct Stats {
     std::atomic<int64_t> graphs_computed{0}, plans_built{0}, nodes_seen{0}, kernels_planned{0}, kernels_launched{0}, fused_conv{0},
         fused_conv_bounced{0}, fused_linear{0}, fused_norm{0}, fused_geglu{0}, fused_attention{0}, generic_matmul{0}, swizzled_weight_bytes{0}, fused_linear_geglu{0}, split_k_gemms{0}, head_major_gemms{0}, fused_modulate{0}, fused_gate{0}, fused_gelu{0}, fused_rope{0}, fused_concat_heads{0},
-        graph_replays{0}, qgemv_linears{0}, fused_chan_add{0}, fused_proj_tokens{0}, gemm_attention{0}, fused_q16{0}, split_k_inlaunch{0}, qgemm16_linears{0}, fgemv_linears{0}, fused_presilu{0}, fused_sibling_linears{0}, hoisted_kv_linears{0}, window_convs{0}, hoisted_emb_linears{0}, fused_rows16{0}, fused_cat_rows16{0}, fused_joint_qkv{0};
+        graph_replays{0}, qgemv_linears{0}, fused_chan_add{0}, fused_proj_tokens{0}, gemm_attention{0}, fused_q16{0}, split_k_inlaunch{0}, qgemm16_linears{0}, fgemv_linears{0}, fused_presilu{0}, fused_sibling_linears{0}, hoisted_kv_linears{0}, window_convs{0}, hoisted_emb_linears{0}, fused_rows16{0}, fused_cat_rows16{0}, fused_joint_qkv{0}, jit_images{0};
 } g_stats;
 
 struct Options {
-    std::atomic<int> fusion{1}, mfma_gemm{1}, hip_graph{0}, flash_pattern{1}, gemm16{1}, fuse_modulate{1}, fuse_gate{1}, fuse_gelu{1}, fuse_rope{1}, fuse_concat_heads{1}, qgemv{1}, fuse_chan_add{1}, fuse_proj_tokens{1}, fuse_q16{1}, qgemm16{1}, fgemv{1}, fuse_siblings{1}, hoist_kv{1}, hoist_emb{1}, fuse_rows16{0}, fuse_cat_rows16{1}, fuse_joint_qkv{1};
+    std::atomic<int> fusion{1}, mfma_gemm{1}, hip_graph{0}, flash_pattern{1}, gemm16{1}, fuse_modulate{1}, fuse_gate{1}, fuse_gelu{1}, fuse_rope{1}, fuse_concat_heads{1}, qgemv{1}, fuse_chan_add{1}, fuse_proj_tokens{1}, fuse_q16{1}, qgemm16{1}, fgemv{1}, fuse_siblings{1}, hoist_kv{1}, hoist_emb{1}, fuse_rows16{0}, fuse_cat_rows16{1}, fuse_joint_qkv{1}, jit_qimages{0};
 } g_opt;
 
 using Step = std::function<void(hipStream_t)>;
@@ -79,6 +79,17 @@ struct Planner {
     // OFFSETS; the base is read at launch time, so growing the arena never invalidates a cached plan.
     char* arena       = nullptr;
     size_t arena_cap  = 0;
+    // just-in-time weight images (option jit_qimages): one device buffer per image size, shared by every quantised Linear of that size and kept
+    // for the planner's lifetime (stable addresses: plans capture them)
+    std::map<size_t, void*> jit_buf;
+    void* jit_buffer(size_t bytes) {
+        auto it = jit_buf.find(bytes);
+        if (it != jit_buf.end()) return it->second;
+        void* d = nullptr;
+        if (hipMalloc(&d, bytes) != hipSuccess) return nullptr;
+        jit_buf[bytes] = d;
+        return d;
+    }
 };
 
 namespace {
@@ -762,7 +773,19 @@ void plan_linear(Builder& B, int i, hipStream_t s, std::vector<int>& chain) {
     const bool useq  = g_opt.gemm16 && g_opt.qgemm16 && hm_d == 0 && geglu_out < 0 && qgemm16_supported((int)w->type, tokens, K, M);
     const void* wraw = w->data;
     const int wt     = (int)w->type;
-    const void* swz = useq ? nullptr : get_swz_linear(B.P, w, s, geglu_out >= 0);
+    // resident-quantised mode (option jit_qimages): a quantised weight above the raw-block kernels' row range gets NO cached f16 image — the image is
+    // rebuilt by k_wswz_q into a buffer shared by all weights of that size right in front of the GEMM (HBM keeps 0.56 / 1.06 B per weight instead
+    // of 2.56 / 3.06; the GEMM reads the fresh image out of the Infinity Cache).  Plain row order only (no GEGLU pairing), not for grouped launches.
+    const bool jit = !useq && g_opt.jit_qimages && g_opt.gemm16 && geglu_out < 0 && hm_d == 0 && !B.hm_hoisting && wswz_q_supported((int)w->type, K) &&
+                     (int64_t)w->nb[1] == (int64_t)ggml_abi_row_size(w->type, K) && aligned16(w->data);
+    const void* swz = useq ? nullptr : (jit ? B.P->jit_buffer(wswz_bytes(M, K)) : get_swz_linear(B.P, w, s, geglu_out >= 0));
+    if (jit && swz) {
+        void* jb          = const_cast<void*>(swz);
+        const void* wsrc  = w->data;
+        const int wty     = (int)w->type;
+        B.emit_at(emit_node, i, [=](hipStream_t st) { launch_wswz_q(st, jb, wsrc, wty, K, M); });
+        g_stats.jit_images++;
+    }
     float* dst      = (float*)gi.node(last)->data;
     const float* xp = (const float*)x->data;
     const int64_t xs = (int64_t)x->nb[1] / 4;
@@ -2787,6 +2810,7 @@ void planner_destroy(Planner* p) {
         planner_clear_locked(p);
     }
     for (auto& kv : p->swz) (void)hipFree(kv.second.swz);
+    for (auto& kv : p->jit_buf) (void)hipFree(kv.second);
     if (p->arena) (void)hipFree(p->arena);
     delete p;
 }
@@ -3013,6 +3037,7 @@ void planner_get_stats(ggml_backend_mi355x_stats* o) {
     o->fused_rows16          = g_stats.fused_rows16;
     o->fused_cat_rows16      = g_stats.fused_cat_rows16;
     o->fused_joint_qkv       = g_stats.fused_joint_qkv;
+    o->jit_images            = g_stats.jit_images;
     o->fused_attention       = g_stats.fused_attention;
     o->generic_matmul        = g_stats.generic_matmul;
     o->swizzled_weight_bytes = g_stats.swizzled_weight_bytes;
@@ -3042,6 +3067,7 @@ void planner_set_option(const char* key, int value) {
     else if (!strcmp(key, "fuse_rows16")) g_opt.fuse_rows16 = value;
     else if (!strcmp(key, "fuse_cat_rows16")) g_opt.fuse_cat_rows16 = value;
     else if (!strcmp(key, "fuse_joint_qkv")) g_opt.fuse_joint_qkv = value;
+    else if (!strcmp(key, "jit_qimages")) g_opt.jit_qimages = value;
     else if (!strcmp(key, "conv3w_min_blocks")) conv3w_set_min_blocks(value);
     else if (!strcmp(key, "conv3w_min_blocks_deep")) conv3w_set_min_blocks_deep(value);
     else if (!strcmp(key, "gemm16_bn64")) gemm16_set_bn64(value);

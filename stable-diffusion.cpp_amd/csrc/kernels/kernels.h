@@ -169,6 +169,9 @@ void launch_fgemv(hipStream_t s, float* dst, int64_t ldd, const float* x, int64_
 // workspace of S * rows * M floats) only for plain outputs.
 bool qgemm16_supported(int wtype, int64_t rows, int64_t K, int64_t M);
 int qgemm16_split_k(int64_t rows, int64_t K, int64_t M);
+// raw q8_0 / q4_0 rows -> the f16 MFMA weight image of k_gemm16 (plain row order), fast enough to run in front of every launch (planner option jit_qimages)
+bool wswz_q_supported(int wtype, int64_t K);
+void launch_wswz_q(hipStream_t s, void* dst, const void* wraw, int wtype, int64_t K, int64_t R);
 void qgemm16_set_max_rows(int v);
 void launch_qgemm16(hipStream_t s, float* dst, void* dst16, int64_t ldd16, const void* a16, int64_t lda, int64_t rows, const void* wraw, int wtype, int64_t K,
                     int64_t M, const Epilogue& ep, float* splitk_ws = nullptr, int splitk_S = 1);

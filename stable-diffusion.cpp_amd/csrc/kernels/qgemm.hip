@@ -648,6 +648,92 @@ __global__ __launch_bounds__(256) void k_qgemm16(QG16Args g) {
     }
 }
 
+// =====================================================================================================
+// k_wswz_q — raw q8_0 / q4_0 rows -> the f16 MFMA weight image of k_gemm16 ([rows/32][K/16][64 lanes][8 halfs], wgemm.hip), FAST: this is the
+// "just-in-time image" of the resident-quantised mode (planner option jit_qimages): HBM keeps only the raw GGUF blocks, a Linear's f16 image
+// is rebuilt into a shared scratch right in front of its GEMM and read back out of the 256 MB Infinity Cache, never kept.
+// One wave per (32 weight rows, 256 k): the 32 contiguous 272 / 144-byte pieces are fetched with coalesced 16-byte loads into a per-wave LDS strip
+// (as k_qgemm16 does), every lane then decodes the blocks of ITS row into the two fragments of each block — same byte -> f16 trick, same
+// f16(d * q) values as wload() in wgemm.hip, bit for bit — and the wave writes 1 KiB per fragment.
+template <int QT>
+__global__ __launch_bounds__(256) void k_wswz_q(half8_t* __restrict__ dst, const char* __restrict__ W, int64_t row_bytes, int64_t R, int64_t kfr) {
+    constexpr int BLK = QT == 8 ? 34 : 18;
+    constexpr int SEG = 8;
+    constexpr int CS  = SEG * BLK;
+    constexpr int NGC = CS / 16;
+    constexpr int NGW = 32 * NGC;
+    constexpr int NLW = (NGW + 63) / 64;
+    __shared__ __attribute__((aligned(16))) char Wsm[4][32 * CS];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = lane & 31, hi = lane >> 5;
+    char* Ws         = Wsm[wave];
+    const int64_t rb = (int64_t)blockIdx.x * 4 + wave;  // 32-row block of the image
+    const int seg    = blockIdx.y;
+#pragma unroll
+    for (int i = 0; i < NLW; ++i) {
+        const int idx = i * 64 + lane;
+        if (idx < NGW) {
+            const int col    = idx / NGC, gr = idx - col * NGC;
+            const int64_t rr = min(rb * 32 + col, R - 1);
+            *(u32x4_t*)(Ws + idx * 16) = *(const u32x4_t*)(W + rr * row_bytes + (int64_t)seg * CS + gr * 16);
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0);  // this wave's strip only: no workgroup barrier needed (each wave reads what it wrote)
+    __builtin_amdgcn_wave_barrier();
+    const bool real = rb * 32 + n < R;  // rows that pad the image to a multiple of 128 are zero
+    half8_t* out    = dst + (rb * kfr + (int64_t)seg * 16) * 64 + lane;
+#pragma unroll
+    for (int b = 0; b < SEG; ++b) {
+        const char* blk  = Ws + n * CS + BLK * b;
+        const _Float16 d = real ? *(const _Float16*)blk : (_Float16)0.f;
+        const half2_t d2 = {d, d};
+        // this lane's quant bytes: q8_0 elements 8 hi .. 8 hi + 7 (fragment 2b) and 16 + 8 hi .. (fragment 2b + 1); q4_0 bytes 8 hi .. 8 hi + 7,
+        // whose low nibbles are elements 8 hi + i (fragment 2b) and whose high nibbles are elements 16 + 8 hi + i (fragment 2b + 1)
+        uint32_t qa[2], qb[2];
+        auto rd8 = [&](const char* qp, uint32_t (&q)[2]) {
+            if ((((BLK * b + 2) & 2) == 0)) {  // compile-time after unrolling (CS and the run offsets are multiples of 4)
+                q[0] = *(const uint32_t*)qp;
+                q[1] = *(const uint32_t*)(qp + 4);
+            } else {
+                const uint32_t r0 = *(const uint32_t*)(qp - 2), r1 = *(const uint32_t*)(qp + 2), r2 = *(const uint32_t*)(qp + 6);
+                q[0] = __builtin_amdgcn_alignbit(r1, r0, 16);
+                q[1] = __builtin_amdgcn_alignbit(r2, r1, 16);
+            }
+        };
+        uint32_t f0[4], f1[4];
+        if constexpr (QT == 8) {
+            rd8(blk + 2 + 8 * hi, qa);
+            rd8(blk + 2 + 16 + 8 * hi, qb);
+            const half2_t off = {(_Float16)1152.f, (_Float16)1152.f};
+            qg_deq4(qa[0] ^ 0x80808080u, off, d2, f0[0], f0[1]);
+            qg_deq4(qa[1] ^ 0x80808080u, off, d2, f0[2], f0[3]);
+            qg_deq4(qb[0] ^ 0x80808080u, off, d2, f1[0], f1[1]);
+            qg_deq4(qb[1] ^ 0x80808080u, off, d2, f1[2], f1[3]);
+        } else {
+            rd8(blk + 2 + 8 * hi, qa);
+            const half2_t off = {(_Float16)1032.f, (_Float16)1032.f};
+            qg_deq4(qa[0] & 0x0F0F0F0Fu, off, d2, f0[0], f0[1]);
+            qg_deq4(qa[1] & 0x0F0F0F0Fu, off, d2, f0[2], f0[3]);
+            qg_deq4((qa[0] >> 4) & 0x0F0F0F0Fu, off, d2, f1[0], f1[1]);
+            qg_deq4((qa[1] >> 4) & 0x0F0F0F0Fu, off, d2, f1[2], f1[3]);
+        }
+        out[(2 * b) * 64]     = __builtin_bit_cast(half8_t, (u32x4_t){f0[0], f0[1], f0[2], f0[3]});
+        out[(2 * b + 1) * 64] = __builtin_bit_cast(half8_t, (u32x4_t){f1[0], f1[1], f1[2], f1[3]});
+    }
+}
+bool wswz_q_supported(int wtype, int64_t K) { return (wtype == 8 || wtype == 2) && K % 256 == 0 && K >= 256; }
+// dst: image of wswz_bytes(R, K) bytes (rows padded to 128); plain (not GEGLU-paired) row order
+void launch_wswz_q(hipStream_t s, void* dst, const void* wraw, int wtype, int64_t K, int64_t R) {
+    const int64_t Rp = (R + 127) / 128 * 128, nblk = K / 32;
+    KScope ks_(s, KF_PACK_F16, 0.0, (double)R * nblk * (wtype == 8 ? 34 : 18) + (double)Rp * K * 2.0);
+    const dim3 grid((unsigned)(Rp / 128), (unsigned)(K / 256));
+    if (wtype == 8)
+        k_wswz_q<8><<<grid, 256, 0, s>>>((half8_t*)dst, (const char*)wraw, nblk * 34, R, K / 16);
+    else
+        k_wswz_q<4><<<grid, 256, 0, s>>>((half8_t*)dst, (const char*)wraw, nblk * 18, R, K / 16);
+}
+
 // option "qgemm16_max_rows": Linears with 5 .. max_rows activation rows take k_qgemm16 (0 = never).  Default 512 = the text streams of the DiTs and the
 // text encoders.  Two measurements decide it: (1) the single-Linear probe with L2-warm weights (profiles/r02s_qgemm_paths_probe.txt) has the f16-image
 // GEMM 1.3-2.3x faster kernel-for-kernel (3072 -> 9216 q8_0 at 77 rows 48 vs 21 us, at 256 rows 68 vs 32 us); (2) inside FLUX.1-dev, where every

@@ -198,6 +198,38 @@ def test_spatial_transformer_projections_as_token_gemms(sd, oracle, gpu, rng, N,
         assert sd.backend_stats()["fused_proj_tokens"] - before["fused_proj_tokens"] == 2
 
 
+@pytest.mark.parametrize("qname", ["Q8_0", "Q4_0"])
+@pytest.mark.parametrize("tokens,K,M", [(640, 512, 384), (1030, 256, 200), (2048, 3072, 640)])
+def test_quantised_linear_just_in_time_image(sd, oracle, gpu, rng, qname, tokens, K, M):
+    """Resident-quantised mode (option jit_qimages): above the raw-block kernels' row range a q8_0 / q4_0 Linear keeps no f16 weight image — k_wswz_q
+    rebuilds it from the raw GGUF blocks into a shared buffer in front of the GEMM.  The rebuilt image must equal the cached one bit for bit
+    (same f16(d * q) values), so the two modes give IDENTICAL outputs; M = 200 exercises the zero rows that pad the image to 128."""
+    if not _on_gpu():
+        pytest.skip("planner option of the MI355X backend")
+    wtype = Q8_0 if qname == "Q8_0" else Q4_0
+    x = rng.standard_normal((tokens, K)).astype(np.float32)
+    w = (rng.standard_normal((M, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(M).astype(np.float32)
+
+    def build(g, L):
+        y = L.ggml_mul_mat(g.ctx, g.weight(w, wtype), g.input(x))
+        return L.ggml_add_inplace(g.ctx, y, g.weight(b, F32))
+
+    outs = []
+    for jit in (0, 1):
+        sd.backend_set_option("jit_qimages", jit)
+        before = sd.backend_stats()["jit_images"]
+        try:
+            with Graph(gpu) as g:
+                outs.append(g.run(build(g, sd.lib())))
+        finally:
+            sd.backend_set_option("jit_qimages", 0)
+        assert sd.backend_stats()["jit_images"] - before == jit
+    assert np.array_equal(outs[0], outs[1])
+    exact = x.astype(np.float16).astype(np.float64) @ dequant(w, wtype).astype(np.float64).T + b
+    assert rel_l2(outs[1].reshape(tokens, M), exact) < 2e-3
+
+
 @pytest.mark.parametrize("d,H,L,M,flash", [(64, 2, 200, 384, True), (128, 1, 77, 128, True), (64, 3, 130, 320, False), (40, 2, 96, 112, True)])
 def test_single_block_tail_concat_assembled_as_operand_image(sd, oracle, gpu, rng, d, H, L, M, flash):
     """FLUX single block tail (flux.hpp:594-700): t = linear1(x) -> q / k / v per-head views + mlp view; attn = flash(q, k, v) -> VIEW -> CONT;
