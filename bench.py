@@ -273,7 +273,7 @@ def main():
     if rank == 0:
         st = sd.backend_stats()
         out["backend"] = {k: st[k] for k in ("swizzled_weight_bytes", "qgemv_linears", "fgemv_linears", "fused_presilu", "fused_sibling_linears", "hoisted_kv_linears",
-                                             "qgemm16_linears", "split_k_gemms", "fused_attention", "generic_matmul", "plans_built", "graph_replays")}
+                                             "qgemm16_linears", "jit_images", "split_k_gemms", "fused_attention", "generic_matmul", "plans_built", "graph_replays")}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -382,7 +382,8 @@ def model_leg(sd, backend_name, args, name):
     else:
         res["sec_per_image_denoise"] = round(cfg_steps * ms / 1e3 / B, 3)
     st1 = sd.backend_stats()
-    res["weight_image_bytes"] = st1["swizzled_weight_bytes"] - st0["swizzled_weight_bytes"]
+    res["weight_image_bytes"] = st1["swizzled_weight_bytes"] - st0["swizzled_weight_bytes"]   # f16 images kept resident (cached) for this model
+    res["jit_image_linears"] = st1["jit_images"] - st0["jit_images"]   # quantised Linears planned WITHOUT a resident image (rebuilt per launch, option jit_qimages)
     del eng
     return res
 

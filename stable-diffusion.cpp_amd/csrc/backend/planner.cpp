@@ -45,7 +45,7 @@ struct Stats {
 } g_stats;
 
 struct Options {
-    std::atomic<int> fusion{1}, mfma_gemm{1}, hip_graph{0}, flash_pattern{1}, gemm16{1}, fuse_modulate{1}, fuse_gate{1}, fuse_gelu{1}, fuse_rope{1}, fuse_concat_heads{1}, qgemv{1}, fuse_chan_add{1}, fuse_proj_tokens{1}, fuse_q16{1}, qgemm16{1}, fgemv{1}, fuse_siblings{1}, hoist_kv{1}, hoist_emb{1}, fuse_rows16{0}, fuse_cat_rows16{1}, fuse_joint_qkv{1}, jit_qimages{0};
+    std::atomic<int> fusion{1}, mfma_gemm{1}, hip_graph{0}, flash_pattern{1}, gemm16{1}, fuse_modulate{1}, fuse_gate{1}, fuse_gelu{1}, fuse_rope{1}, fuse_concat_heads{1}, qgemv{1}, fuse_chan_add{1}, fuse_proj_tokens{1}, fuse_q16{1}, qgemm16{1}, fgemv{1}, fuse_siblings{1}, hoist_kv{1}, hoist_emb{1}, fuse_rows16{0}, fuse_cat_rows16{1}, fuse_joint_qkv{1}, jit_qimages{4096};
 } g_opt;
 
 using Step = std::function<void(hipStream_t)>;
@@ -773,10 +773,10 @@ void plan_linear(Builder& B, int i, hipStream_t s, std::vector<int>& chain) {
     const bool useq  = g_opt.gemm16 && g_opt.qgemm16 && hm_d == 0 && geglu_out < 0 && qgemm16_supported((int)w->type, tokens, K, M);
     const void* wraw = w->data;
     const int wt     = (int)w->type;
-    // resident-quantised mode (option jit_qimages): a quantised weight above the raw-block kernels' row range gets NO cached f16 image — the image is
+    // resident-quantised weights (option jit_qimages = least activation rows, default 4096; 1 = always, 0 = never): such a Linear gets NO cached f16 image — the image is
     // rebuilt by k_wswz_q into a buffer shared by all weights of that size right in front of the GEMM (HBM keeps 0.56 / 1.06 B per weight instead
     // of 2.56 / 3.06; the GEMM reads the fresh image out of the Infinity Cache).  Plain row order only (no GEGLU pairing), not for grouped launches.
-    const bool jit = !useq && g_opt.jit_qimages && g_opt.gemm16 && geglu_out < 0 && hm_d == 0 && !B.hm_hoisting && wswz_q_supported((int)w->type, K) &&
+    const bool jit = !useq && g_opt.jit_qimages > 0 && tokens >= g_opt.jit_qimages && g_opt.gemm16 && geglu_out < 0 && hm_d == 0 && !B.hm_hoisting && wswz_q_supported((int)w->type, K) &&
                      (int64_t)w->nb[1] == (int64_t)ggml_abi_row_size(w->type, K) && aligned16(w->data);
     const void* swz = useq ? nullptr : (jit ? B.P->jit_buffer(wswz_bytes(M, K)) : get_swz_linear(B.P, w, s, geglu_out >= 0));
     if (jit && swz) {

@@ -223,7 +223,7 @@ def test_quantised_linear_just_in_time_image(sd, oracle, gpu, rng, qname, tokens
             with Graph(gpu) as g:
                 outs.append(g.run(build(g, sd.lib())))
         finally:
-            sd.backend_set_option("jit_qimages", 0)
+            sd.backend_set_option("jit_qimages", 4096)   # the default
         assert sd.backend_stats()["jit_images"] - before == jit
     assert np.array_equal(outs[0], outs[1])
     exact = x.astype(np.float16).astype(np.float64) @ dequant(w, wtype).astype(np.float64).T + b
