@@ -61,6 +61,7 @@ enum sd_model_family_t {
     SD_MODEL_FLUX_TINY  = 7, /* same topology: 2 + 2 blocks, hidden 128, 4 heads, axes 8/12/12 */
     SD_MODEL_SD35_WIDE2 = 8, /* SD3.5-large's real width (hidden 2432, 38 heads x 64), 2 joint blocks — full-width block parity tests */
     SD_MODEL_FLUX_WIDE1 = 9, /* FLUX.1-dev's real width (hidden 3072, 24 heads x 128), 1 double + 1 single block — same purpose */
+    SD_MODEL_SD3M_TINY  = 10, /* SD3-medium's topology at test size: MMDiT WITHOUT qk-norm and without MMDiT-X blocks (mmdit.hpp:299-366 with qk_norm = "") */
 };
 
 /* numeric values = enum ggml_type (stable-diffusion.h:98-143) */

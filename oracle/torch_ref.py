@@ -248,6 +248,7 @@ MMDIT_CFG = {
     # name: (depth, hidden, patch, in_ch, out_ch, pos_embed_max_size, d_self, qk_rms)
     "SD35_LARGE": (38, 2432, 2, 16, 16, 192, -1, True),
     "SD35_TINY": (3, 192, 2, 16, 16, 24, 0, True),
+    "SD3M_TINY": (3, 192, 2, 16, 16, 24, -1, False),   # SD3-medium's variant: no qk-norm, no MMDiT-X block
 }
 
 

@@ -26,7 +26,7 @@ F32, F16, Q4_0, Q8_0, I32, BF16 = 0, 1, 2, 8, 26, 30
 TYPE_SIZE = {F32: 4, F16: 2, BF16: 2, I32: 4}
 
 # sd_model_family_t
-SD15, SDXL, SD15_TINY, SDXL_TINY, SD35_LARGE, SD35_TINY, FLUX_DEV, FLUX_TINY, SD35_WIDE2, FLUX_WIDE1 = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
+SD15, SDXL, SD15_TINY, SDXL_TINY, SD35_LARGE, SD35_TINY, FLUX_DEV, FLUX_TINY, SD35_WIDE2, FLUX_WIDE1, SD3M_TINY = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
 # sd_pair_exchange_fn (include/sd-mi355x.h): (device address of the f32 eps buffer, element count, hipStream_t, user) -> ok
 PAIR_EXCHANGE_FN = C.CFUNCTYPE(C.c_bool, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p)
 EULER, EULER_A, SAMPLE_METHOD_DEFAULT = 0, 1, 2   # DEFAULT: Euler for the DiT families, Euler-A otherwise (sd_get_default_sample_method)
@@ -630,7 +630,7 @@ class Engine:
                        method=SAMPLE_METHOD_DEFAULT, eta=float("inf"), cond_y=None, uncond_y=None, fuse_cfg=False, device_sampler=False) -> np.ndarray:
         p, keep = self._gen_params(cond, uncond, width, height, steps, cfg, seed, batch, device_batch, method, eta, cond_y, uncond_y, fuse_cfg,
                                    device_sampler)
-        ch = 16 if self.model in (SD35_LARGE, SD35_TINY, FLUX_DEV, FLUX_TINY, SD35_WIDE2, FLUX_WIDE1) else 4
+        ch = 16 if self.model in (SD35_LARGE, SD35_TINY, FLUX_DEV, FLUX_TINY, SD35_WIDE2, FLUX_WIDE1, SD3M_TINY) else 4
         out = np.empty((batch, ch, height // 8, width // 8), dtype=np.float32)
         if not lib().sd_sample_latents(self._ctx, C.byref(p), _fptr(out)):
             raise EngineError("sd_sample_latents failed: " + lib().sd_last_error().decode())

@@ -2314,30 +2314,37 @@ void plan_joint_qkv(Builder& B) {
             VChain vc;
             int j    = gi.sole(iv);
             int from = iv;
-            if (j >= 0 && gi.node(j)->op == GGML_OP_RESHAPE) {  // qk-norm branch
-                const int jn = gi.sole(j);
-                const int jm = (jn >= 0 && gi.node(jn)->op == GGML_OP_RMS_NORM && gi.node(jn)->src[0] == gi.node(j)) ? gi.sole(jn) : -1;
+            while (j >= 0 && gi.node(j)->op == GGML_OP_RESHAPE) {  // [d,H,L,N] and back to [C,L,N] (pre_attention reshapes with or without the norm)
+                from = j;
+                j    = gi.sole(j);
+            }
+            if (j >= 0 && gi.node(j)->op == GGML_OP_RMS_NORM) {  // qk-norm branch: RESHAPE [d,H,L,N] -> RMS_NORM -> MUL(w[d]) -> RESHAPE [C,L,N]
+                const int jn = j;
+                const int jm = gi.node(jn)->src[0] == gi.node(from) ? gi.sole(jn) : -1;
                 if (jm < 0 || gi.node(jm)->op != GGML_OP_MUL || gi.node(jm)->src[0] != gi.node(jn)) {
                     ok = false;
                     break;
                 }
-                const ggml_tensor* r2 = gi.node(j);
+                const ggml_tensor* r2 = gi.node(from);
                 const ggml_tensor* w  = gi.node(jm)->src[1];
                 if (!is_f32(w) || !contig(w) || w->ne[0] != r2->ne[0] || ggml_abi_nelements(w) != r2->ne[0] || !is_static_weight(w) || !aligned16(w->data) ||
                     r2->ne[0] * r2->ne[1] != C || !joint_heads_supported(r2->ne[0])) {
                     ok = false;
                     break;
                 }
-                const int jr = gi.sole(jm);
-                if (jr < 0 || gi.node(jr)->op != GGML_OP_RESHAPE || gi.node(jr)->ne[0] != C) {
-                    ok = false;
-                    break;
-                }
                 vc.w    = (const float*)w->data;
                 vc.eps  = ggml_abi_op_param_f32(gi.node(jn), 0);
                 vc.skip = {jn, jm};
-                from    = jr;
-                j       = gi.sole(jr);
+                from    = jm;
+                j       = gi.sole(jm);
+                while (j >= 0 && gi.node(j)->op == GGML_OP_RESHAPE) {
+                    from = j;
+                    j    = gi.sole(j);
+                }
+                if (gi.node(from)->ne[0] != C) {
+                    ok = false;
+                    break;
+                }
             }
             if (j < 0 || gi.node(j)->op != GGML_OP_CONCAT || gi.node(j)->op_params[0] != 1) {
                 ok = false;

@@ -447,8 +447,8 @@ sdm_ctx_t* sdm_new_ctx(const sdm_ctx_params_t* params) {
     const bool xl   = params->model == SD_MODEL_SDXL || params->model == SD_MODEL_SDXL_TINY;
     const bool tiny = params->model == SD_MODEL_SD15_TINY || params->model == SD_MODEL_SDXL_TINY;
     const bool flux     = params->model == SD_MODEL_FLUX_DEV || params->model == SD_MODEL_FLUX_TINY || params->model == SD_MODEL_FLUX_WIDE1;
-    const bool dit      = params->model == SD_MODEL_SD35_LARGE || params->model == SD_MODEL_SD35_TINY || params->model == SD_MODEL_SD35_WIDE2 || flux;
-    const bool dit_tiny = params->model == SD_MODEL_SD35_TINY || params->model == SD_MODEL_FLUX_TINY;
+    const bool dit      = params->model == SD_MODEL_SD35_LARGE || params->model == SD_MODEL_SD35_TINY || params->model == SD_MODEL_SD35_WIDE2 || params->model == SD_MODEL_SD3M_TINY || flux;
+    const bool dit_tiny = params->model == SD_MODEL_SD35_TINY || params->model == SD_MODEL_FLUX_TINY || params->model == SD_MODEL_SD3M_TINY;
     UNetConfig ucfg = tiny ? UNetConfig::tiny(xl) : (xl ? UNetConfig::sdxl_base() : UNetConfig::sd15());
     VaeConfig vcfg  = (tiny || dit_tiny) ? VaeConfig::tiny() : (xl ? VaeConfig::sdxl() : VaeConfig::sd15());
     if (tiny && xl) vcfg.scale_factor = 0.13025f;
@@ -468,7 +468,7 @@ sdm_ctx_t* sdm_new_ctx(const sdm_ctx_params_t* params) {
         ctx->flux.init(ctx->unet_runner.ps, "model.diffusion_model.", dit_tiny ? FluxConfig::tiny() : (params->model == SD_MODEL_FLUX_WIDE1 ? FluxConfig::flux_wide1() : FluxConfig::flux_dev()));
     } else if (dit) {
         ctx->unet_runner.graph_size = 10240 * 8;  // MMDIT_GRAPH_SIZE (mmdit.hpp:14) x our batch headroom
-        ctx->mmdit.init(ctx->unet_runner.ps, "model.diffusion_model.", dit_tiny ? MMDiTConfig::tiny() : (params->model == SD_MODEL_SD35_WIDE2 ? MMDiTConfig::sd35_wide2() : MMDiTConfig::sd35_large()));
+        ctx->mmdit.init(ctx->unet_runner.ps, "model.diffusion_model.", dit_tiny ? (params->model == SD_MODEL_SD3M_TINY ? MMDiTConfig::tiny_medium() : MMDiTConfig::tiny()) : (params->model == SD_MODEL_SD35_WIDE2 ? MMDiTConfig::sd35_wide2() : MMDiTConfig::sd35_large()));
     } else
         ctx->unet.init(ctx->unet_runner.ps, "model.diffusion_model.", ucfg);  // prefix: stable-diffusion.cpp:1337
     ctx->pair_runner.backend       = backend;
@@ -739,7 +739,7 @@ static bool ensure_text_encoders(sdm_ctx_t* ctx) {
     if (ctx->te) return true;
     std::unique_ptr<sdm_ctx_t::TextEncoders> te(new sdm_ctx_t::TextEncoders());
     const int m     = (int)ctx->params.model;
-    const bool tiny = m == SD_MODEL_SD15_TINY || m == SD_MODEL_SDXL_TINY || m == SD_MODEL_SD35_TINY || m == SD_MODEL_FLUX_TINY;
+    const bool tiny = m == SD_MODEL_SD15_TINY || m == SD_MODEL_SDXL_TINY || m == SD_MODEL_SD35_TINY || m == SD_MODEL_FLUX_TINY || m == SD_MODEL_SD3M_TINY;
     ConditionerSpec& sp = te->spec;
     ClipTextConfig lc, gc;
     T5Config tc;
@@ -757,7 +757,7 @@ static bool ensure_text_encoders(sdm_ctx_t* ctx) {
         gp         = "cond_stage_model.1.transformer.text_model.";
         sp.adm_dim = ctx->unet.cfg.adm_in_channels;
         sp.ts_dim  = tiny ? 8 : 256;
-    } else if (m == SD_MODEL_SD35_LARGE || m == SD_MODEL_SD35_TINY || m == SD_MODEL_SD35_WIDE2) {
+    } else if (m == SD_MODEL_SD35_LARGE || m == SD_MODEL_SD35_TINY || m == SD_MODEL_SD35_WIDE2 || m == SD_MODEL_SD3M_TINY) {
         sp.family = CondFamily::SD3;
         sp.has_g = sp.has_t5 = true;
         lc = tiny ? ClipTextConfig::tiny(24, 2, 0, false, false) : ClipTextConfig::vit_l(false);

@@ -405,6 +405,13 @@ struct MMDiTConfig {
         c.d_self             = 0;
         return c;
     }
+    // SD3-medium's variant at test size: no qk-norm (the q / k parts of the fused projection go to the attention as they are), no MMDiT-X block
+    static MMDiTConfig tiny_medium() {
+        MMDiTConfig c = tiny();
+        c.qk_rms      = false;
+        c.d_self      = -1;
+        return c;
+    }
 };
 
 // mmdit.hpp:299-366

@@ -114,6 +114,29 @@ def test_mmdit_forward_parity(sd, oracle, gpu, flash, wtype):
     np.testing.assert_array_equal(out, gpu_e.unet_forward(x, t, ctx, y))
 
 
+def test_mmdit_without_qk_norm_forward_parity(sd, oracle, gpu):
+    """SD3-medium's MMDiT variant (no qk-norm: the q / k parts of the fused qkv projection reach the joint attention without the per-head
+    RMSNorm, mmdit.hpp:299-366 with qk_norm empty; no MMDiT-X block): the joint-attention operand pass runs with no norm weight on either
+    stream — every projection goes through the arena-scratch redirect (plan_joint_qkv)."""
+    rng = np.random.default_rng(19)
+    x = rng.standard_normal((2, 16, 16, 12)).astype(np.float32)
+    t = np.array([640.0, 333.0], dtype=np.float32)
+    ctx = rng.standard_normal((1, 77, 96)).astype(np.float32)
+    y = rng.standard_normal((1, 64)).astype(np.float32)
+    ref = sd.Engine(model=sd.SD3M_TINY, backend=oracle, flash_attn=True).unet_forward(x, t, ctx, y)
+    gpu_e = sd.Engine(model=sd.SD3M_TINY, backend=gpu, flash_attn=True)
+    on_gpu = gpu != oracle
+    before = sd.backend_stats() if on_gpu else None
+    out = gpu_e.unet_forward(x, t, ctx, y)
+    err = rel_l2(out, ref)
+    print(f"SD3M_TINY (no qk-norm): rel-L2 {err:.3e}")
+    assert np.isfinite(out).all() and err < 5e-3
+    if on_gpu and not os.environ.get("SDCPP_BACKEND_OPTS"):
+        st = sd.backend_stats()
+        assert st["fused_joint_qkv"] - before["fused_joint_qkv"] == 6   # both streams of the three joint blocks
+    np.testing.assert_array_equal(out, gpu_e.unet_forward(x, t, ctx, y))
+
+
 def test_mmdit_flow_trajectory_and_vae_parity(sd, oracle, gpu):
     rng = np.random.default_rng(18)
     cond, uncond = (rng.standard_normal((1, 40, 96)).astype(np.float32) for _ in range(2))

@@ -153,6 +153,19 @@ def test_mmdit_graph_vs_torch(sd, oracle, eng35, H, W):
     assert rel_l2(ef.unet_forward(x, t, ctx, y), b) < 5e-3
 
 
+def test_mmdit_without_qk_norm_graph_vs_torch(sd, oracle):
+    """SD3-medium's variant of the builder (no qk-norm, no MMDiT-X block) against the independent torch fp32 restatement."""
+    rng = np.random.default_rng(12)
+    e = sd.Engine(model=sd.SD3M_TINY, backend=oracle)
+    x = rng.standard_normal((2, 16, 10, 8)).astype(np.float32)
+    t = np.array([420.0, 77.0], dtype=np.float32)
+    ctx = rng.standard_normal((2, 20, 96)).astype(np.float32)
+    y = rng.standard_normal((2, 64)).astype(np.float32)
+    a = e.unet_forward(x, t, ctx, y)
+    b = torch_ref.mmdit_forward(e, "SD3M_TINY", x, t, ctx, y)
+    assert a.shape == b.shape and rel_l2(a, b) < 3e-3
+
+
 def test_mmdit_batched_and_broadcast_conditioning(sd, oracle, eng35):
     rng = np.random.default_rng(11)
     x = rng.standard_normal((3, 16, 8, 8)).astype(np.float32)
