@@ -319,6 +319,26 @@ def test_real_width_sd35_joint_blocks_vs_oracle(sd, oracle, gpu, wtype, tol, lat
 
 
 @full
+def test_real_width_flux_blocks_batch_of_two(sd, oracle, gpu):
+    """The FLUX q / k / v operand passes (plan_flux_qkv: projection rows in arena scratch -> per-head RMSNorm -> txt + img token concat -> rotary ->
+    head-major f16) with TWO images in the batch: rows of image 1 follow image 0's in every projection, the joint sequence restarts per image."""
+    rng = np.random.default_rng(506)
+    x = rng.standard_normal((2, 16, 32, 32)).astype(np.float32)
+    t = np.array([0.62, 0.31], np.float32)
+    c = rng.standard_normal((2, 77, 4096)).astype(np.float32)
+    y = rng.standard_normal((2, 768)).astype(np.float32)
+    ref = sd.Engine(model=sd.FLUX_WIDE1, backend=oracle, wtype=sd.F16, flash_attn=False).unet_forward(x, t, c, y)
+    before = sd.backend_stats() if ON_GPU else None
+    out = sd.Engine(model=sd.FLUX_WIDE1, backend=gpu, wtype=sd.F16, flash_attn=True).unet_forward(x, t, c, y)
+    err = rel_l2(out, ref)
+    print(f"real-width FLUX blocks, batch 2: rel-L2 vs oracle {err:.3e}; image 1 alone {rel_l2(out[1], ref[1]):.3e}")
+    assert np.isfinite(out).all() and err < 5e-3 and rel_l2(out[1], ref[1]) < 5e-3
+    if before is not None and not os.environ.get("SDCPP_BACKEND_OPTS"):
+        st = sd.backend_stats()
+        assert st["fused_joint_qkv"] - before["fused_joint_qkv"] == 3, st   # txt and img projection of the double block, linear1 of the single block
+
+
+@full
 @pytest.mark.parametrize("wtype,tol,lat,ntxt", [("F16", 5e-3, 64, 77), ("Q4_0", 6e-2, 64, 77), ("Q4_0", 6e-2, 128, 256)])
 def test_real_width_flux_blocks_vs_oracle(sd, oracle, gpu, wtype, tol, lat, ntxt):
     """One FLUX.1-dev double-stream and one single-stream block at the real width (hidden 3072, 24 heads x 128, RoPE axes 16/56/56,
