@@ -1,7 +1,9 @@
-"""Lane-level restatements (NumPy) of two pieces of device logic that are easy to get wrong and cannot run on the CPU box:
+"""Lane-level restatements (NumPy) of pieces of device logic that are easy to get wrong and cannot run on the CPU box:
   * k_qgemm16's in-register dequantisation (csrc/kernels/qgemm.hip): which strip bytes a lane of v_mfma_f32_32x32x16_f16 picks for its B fragment,
     the 2-byte-phase realignment, the v_perm / 0x6400 integer->f16 trick and the k order inside a block that the A fragment has to follow;
   * wave_sum_transpose: the halving cross-lane reduction of the few-row kernels and which lane ends up owning which value.
+  * k_wswz_q: the just-in-time f16 weight image built from raw q8_0 / q4_0 blocks (which bytes a lane turns into which fragment);
+  * k_joint_heads: the DiT attention-operand pass (group / lane indexing, butterfly RMSNorm, rotary pairs, head-major destination).
 They pin the index arithmetic the GPU parity tests (tests/test_gpu_ops.py::test_quantised_mfma_gemm_raw_blocks, test_few_row_linear_weight_stream)
 then confirm on hardware."""
 import numpy as np
@@ -104,3 +106,115 @@ def test_wave_sum_transpose_lane_ownership(nv):
     tot = orig.sum(0)
     for lane in range(64):
         assert abs(r[lane] - tot[lane // grp]) < 1e-9  # value index (lane / GRP) is complete in every lane of its group
+
+
+@pytest.mark.parametrize("qt", [8, 4])
+def test_wswz_q_image_fragments_in_natural_k_order(qt):
+    """k_wswz_q (csrc/kernels/qgemm.hip): the just-in-time weight image built from raw q8_0 / q4_0 blocks.  The image is k_gemm16's operand
+    [rows/32][K/16][64 lanes][8 halfs] in NATURAL k order: lane (n = lane % 32, hi = lane / 32) of fragment kb holds W[rb*32 + n][kb*16 + hi*8 .. +8].
+    Per block b of a 256-k segment a lane writes fragment 2b from the low byte run / low nibbles and fragment 2b+1 from the high run / high nibbles:
+    this pins which raw bytes that is (it differs from k_qgemm16's permuted in-block order for q8_0)."""
+    rng = np.random.default_rng(100 + qt)
+    BLK, SEG = (34, 8) if qt == 8 else (18, 8)
+    CS = SEG * BLK
+    strip = np.zeros(32 * CS, dtype=np.uint8)
+    wref = np.zeros((32, 256), dtype=np.float32)
+    for n in range(32):
+        for b in range(SEG):
+            d = np.float16(rng.uniform(0.01, 0.1))
+            o = n * CS + BLK * b
+            strip[o:o + 2] = np.array([d], dtype=np.float16).view(np.uint8)
+            if qt == 8:
+                q = rng.integers(-128, 128, 32).astype(np.int8)
+                strip[o + 2:o + 34] = q.view(np.uint8)
+                wref[n, 32 * b:32 * b + 32] = (np.float32(d) * q.astype(np.float32)).astype(np.float16)
+            else:
+                nib = rng.integers(0, 16, 32).astype(np.uint8)
+                strip[o + 2:o + 18] = nib[:16] | (nib[16:] << 4)
+                wref[n, 32 * b:32 * b + 32] = (np.float32(d) * (nib.astype(np.float32) - 8)).astype(np.float16)
+
+    def rd32(off):
+        assert off % 4 == 0, "LDS dword reads must be aligned"
+        return int(strip[off:off + 4].view(np.uint32)[0])
+
+    def rd8(qp, ph):   # eight bytes at qp: two dwords, realigned with v_alignbit when the run starts 2 bytes into a dword
+        if ph == 0:
+            return [rd32(qp), rd32(qp + 4)]
+        r = [rd32(qp - 2), rd32(qp + 2), rd32(qp + 6)]
+        return [(((r[1] << 32) | r[0]) >> 16) & 0xFFFFFFFF, (((r[2] << 32) | r[1]) >> 16) & 0xFFFFFFFF]
+
+    image = np.zeros((16, 64, 8), dtype=np.float32)   # the 16 fragments of this segment for one 32-row block
+    for b in range(SEG):
+        ph = (BLK * b + 2) & 2
+        for lane in range(64):
+            n, hi = lane & 31, lane >> 5
+            blk = n * CS + BLK * b
+            d = strip[blk:blk + 2].view(np.float16)[0]
+            if qt == 8:
+                qa, qb = rd8(blk + 2 + 8 * hi, ph), rd8(blk + 2 + 16 + 8 * hi, ph)
+                f0 = deq4(qa[0] ^ 0x80808080, 1152, d) + deq4(qa[1] ^ 0x80808080, 1152, d)
+                f1 = deq4(qb[0] ^ 0x80808080, 1152, d) + deq4(qb[1] ^ 0x80808080, 1152, d)
+            else:
+                qa = rd8(blk + 2 + 8 * hi, ph)
+                f0 = deq4(qa[0] & 0x0F0F0F0F, 1032, d) + deq4(qa[1] & 0x0F0F0F0F, 1032, d)
+                f1 = deq4((qa[0] >> 4) & 0x0F0F0F0F, 1032, d) + deq4((qa[1] >> 4) & 0x0F0F0F0F, 1032, d)
+            image[2 * b, lane] = np.array(f0, dtype=np.float32)
+            image[2 * b + 1, lane] = np.array(f1, dtype=np.float32)
+    # the image definition of wgemm.hip (k_wswz_linear): fragment kb, lane -> W[n][kb * 16 + hi * 8 + j]
+    for kb in range(16):
+        for lane in range(64):
+            n, hi = lane & 31, lane >> 5
+            np.testing.assert_array_equal(image[kb, lane], wref[n, kb * 16 + hi * 8:kb * 16 + hi * 8 + 8])
+
+
+@pytest.mark.parametrize("d,H,La,Lb,N,norm,rope", [(64, 3, 5, 9, 2, True, False), (128, 2, 4, 6, 1, True, True), (64, 2, 0 + 7, 0, 2, False, False), (128, 1, 3, 5, 2, False, True)])
+def test_joint_heads_indexing_norm_and_rotary(d, H, La, Lb, N, norm, rope):
+    """k_joint_heads (csrc/kernels/elementwise.hip): group gi of d/4 lanes handles head h = gi % H of joint token l = (gi / H) % Lt of image
+    n = gi / (H Lt); lane j owns elements 4j .. 4j+3; source row = the stream's projection row (n L + l') at column h d of the q / k / v
+    slice; per-head RMSNorm through a xor butterfly over the group; rotary on the pairs (4j, 4j+1), (4j+2, 4j+3) with the table entry of
+    joint position l; destination [d, Lt, H, N] head-major.  Checked against the node-by-node definition (split / norm / concat / rope / permute)."""
+    rng = np.random.default_rng(d + H)
+    C, Lt, G = d * H, La + Lb, d // 4
+    xs_a, xs_b = 3 * C, 3 * C + 64          # row strides of the two projections (the second one as in FLUX's linear1: extra columns)
+    col = C                                  # the k slice
+    Ta = rng.standard_normal((N * max(La, 1), xs_a)).astype(np.float32)
+    Tb = rng.standard_normal((N * max(Lb, 1), xs_b)).astype(np.float32)
+    wa = rng.standard_normal(d).astype(np.float32)
+    wb = rng.standard_normal(d).astype(np.float32)
+    eps = 1e-6
+    ang = rng.uniform(0, 6.28, (Lt, d // 2))
+    pe = np.stack([np.stack([np.cos(ang), -np.sin(ang)], -1), np.stack([np.sin(ang), np.cos(ang)], -1)], -2).astype(np.float32)   # [Lt, d/2, 2, 2]
+    out = np.zeros((N, H, Lt, d), dtype=np.float32)
+    for gi in range(H * Lt * N):
+        h, t = gi % H, gi // H
+        l, n = t % Lt, t // Lt
+        first = l < La
+        row = Ta[n * La + l] if first else Tb[n * Lb + (l - La)]
+        v = row[col + h * d:col + (h + 1) * d].copy().reshape(G, 4)           # lane j holds v[j]
+        w = wa if first else wb
+        if norm:
+            ss = (v * v).sum(1)                                                 # per-lane partial
+            m = G // 2
+            while m >= 1:                                                        # xor butterfly: every lane ends with the group total
+                ss = ss + ss[np.arange(G) ^ m]
+                m //= 2
+            sc = np.float32(1.0) / np.sqrt(ss / np.float32(d) + np.float32(eps))
+            v = v * sc[:, None] * w.reshape(G, 4)
+        if rope:
+            for j in range(G):
+                m0, m1 = pe[l, 2 * j], pe[l, 2 * j + 1]
+                x0, x1, x2, x3 = v[j]
+                v[j] = [x0 * m0[0, 0] + x1 * m0[0, 1], x0 * m0[1, 0] + x1 * m0[1, 1], x2 * m1[0, 0] + x3 * m1[0, 1], x2 * m1[1, 0] + x3 * m1[1, 1]]
+        out.reshape(-1, 4)[((n * H + h) * Lt + l) * G:((n * H + h) * Lt + l + 1) * G] = v
+    # definition, node by node
+    def stream(T, L, xs, w):
+        x = T[:, col:col + C].reshape(N, L, H, d) if L else np.zeros((N, 0, H, d), np.float32)
+        if norm and L:
+            x = x / np.sqrt((x.astype(np.float64) ** 2).mean(-1, keepdims=True) + eps) * w
+        return x
+    x = np.concatenate([stream(Ta, La, xs_a, wa), stream(Tb, Lb, xs_b, wb)], 1)      # [N, Lt, H, d]
+    if rope:
+        xp = x.reshape(N, Lt, H, d // 2, 2)
+        x = np.einsum("lpij,nlhpj->nlhpi", pe.astype(np.float64), xp).reshape(N, Lt, H, d)
+    ref = np.transpose(x, (0, 2, 1, 3))                                                   # [N, H, Lt, d] = ggml [d, Lt, H, N]
+    np.testing.assert_allclose(out, ref, rtol=2e-5, atol=2e-5)
