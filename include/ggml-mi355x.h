@@ -88,6 +88,7 @@ struct ggml_backend_mi355x_stats {
     int64_t fused_joint_qkv;     /* MMDiT streams whose fused qkv projection feeds the joint attention through k_joint_heads (no split copy, no separate norms / concats) */
     int64_t jit_images;          /* quantised Linears planned with a just-in-time f16 image (option jit_qimages: no cached image, rebuilt in front of every launch) */
     int64_t fused_cat_rows16;    /* CONCAT along the feature dimension read only by Linears: their f16 operand image assembled directly (FLUX single block) */
+    int64_t fused_gn_stats;      /* split-K convs whose slab reduce also writes the statistics of the GroupNorm that reads the result (k_splitk_reduce_gn) */
 };
 GGML_MI355X_API void ggml_backend_mi355x_get_stats(struct ggml_backend_mi355x_stats* out);
 /* live per-kernel-family timing (bench.py's roofline legs): while a family's bit is enabled, every dispatch of that family is bracketed by
@@ -119,7 +120,8 @@ GGML_MI355X_API int ggml_backend_mi355x_get_kernel_timings(struct ggml_backend_m
  * projections of all blocks grouped ahead of their graph position, results in the arena); "fuse_q16", "fuse_chan_add", "fuse_proj_tokens" (1);
  * "hoist_emb" (1: the per-ResBlock SiLU(emb) -> Linear projections as one grouped weight-streaming launch), "fuse_joint_qkv" (1: MMDiT joint attention — qkv projections into arena scratch, split / per-head RMSNorm / token
  * concat / head-major cast as one pass per operand), "fuse_cat_rows16" (1: concat(a, b) along features feeding only Linears is assembled as their f16
- * operand image — flash output and gelu(strided view) write their columns themselves), "fuse_rows16" (0: a Linear read only by a
+ * operand image — flash output and gelu(strided view) write their columns themselves), "fuse_gn_stats" (1: the slab reduce of a split-K conv
+ * also computes the statistics of the GroupNorm that reads its result), "fuse_rows16" (0: a Linear read only by a
  * 1x1 conv writes the conv's f16 operand rows; measured slightly slower on SD1.5);
  * "splitk_inkernel" (0: split-K combined by the last-arriving workgroup, 128-row tiles; measured slower) / "splitk_in_target" (320);
  * conv: "conv3w" (1: 3x3 / stride-1 convs on 16..128-wide maps on the LDS-window kernel), "conv3w_min_blocks" (8) / "conv3w_min_blocks_deep" (5:

@@ -41,11 +41,11 @@ namespace {
 struct Stats {
     std::atomic<int64_t> graphs_computed{0}, plans_built{0}, nodes_seen{0}, kernels_planned{0}, kernels_launched{0}, fused_conv{0},
         fused_conv_bounced{0}, fused_linear{0}, fused_norm{0}, fused_geglu{0}, fused_attention{0}, generic_matmul{0}, swizzled_weight_bytes{0}, fused_linear_geglu{0}, split_k_gemms{0}, head_major_gemms{0}, fused_modulate{0}, fused_gate{0}, fused_gelu{0}, fused_rope{0}, fused_concat_heads{0},
-        graph_replays{0}, qgemv_linears{0}, fused_chan_add{0}, fused_proj_tokens{0}, gemm_attention{0}, fused_q16{0}, split_k_inlaunch{0}, qgemm16_linears{0}, fgemv_linears{0}, fused_presilu{0}, fused_sibling_linears{0}, hoisted_kv_linears{0}, window_convs{0}, hoisted_emb_linears{0}, fused_rows16{0}, fused_cat_rows16{0}, fused_joint_qkv{0}, jit_images{0};
+        graph_replays{0}, qgemv_linears{0}, fused_chan_add{0}, fused_proj_tokens{0}, gemm_attention{0}, fused_q16{0}, split_k_inlaunch{0}, qgemm16_linears{0}, fgemv_linears{0}, fused_presilu{0}, fused_sibling_linears{0}, hoisted_kv_linears{0}, window_convs{0}, hoisted_emb_linears{0}, fused_rows16{0}, fused_cat_rows16{0}, fused_joint_qkv{0}, jit_images{0}, fused_gn_stats{0};
 } g_stats;
 
 struct Options {
-    std::atomic<int> fusion{1}, mfma_gemm{1}, hip_graph{0}, flash_pattern{1}, gemm16{1}, fuse_modulate{1}, fuse_gate{1}, fuse_gelu{1}, fuse_rope{1}, fuse_concat_heads{1}, qgemv{1}, fuse_chan_add{1}, fuse_proj_tokens{1}, fuse_q16{1}, qgemm16{1}, fgemv{1}, fuse_siblings{1}, hoist_kv{1}, hoist_emb{1}, fuse_rows16{0}, fuse_cat_rows16{1}, fuse_joint_qkv{1}, jit_qimages{4096};
+    std::atomic<int> fusion{1}, mfma_gemm{1}, hip_graph{0}, flash_pattern{1}, gemm16{1}, fuse_modulate{1}, fuse_gate{1}, fuse_gelu{1}, fuse_rope{1}, fuse_concat_heads{1}, qgemv{1}, fuse_chan_add{1}, fuse_proj_tokens{1}, fuse_q16{1}, qgemm16{1}, fgemv{1}, fuse_siblings{1}, hoist_kv{1}, hoist_emb{1}, fuse_rows16{0}, fuse_cat_rows16{1}, fuse_joint_qkv{1}, jit_qimages{4096}, fuse_gn_stats{1};
 } g_opt;
 
 using Step = std::function<void(hipStream_t)>;
@@ -283,6 +283,15 @@ struct Builder {
         int64_t ld, M, N;
     };
     std::unordered_map<const ggml_tensor*, MovedEmb> moved_emb;
+    // split-K conv output -> GroupNorm tables its slab reduce already wrote (plan_conv_chain look-ahead; plan_group_norm skips its statistics pass
+    // when weight / bias / groups / eps agree)
+    struct GnPre {
+        size_t off;
+        const float *w, *b;
+        int groups;
+        float eps;
+    };
+    std::unordered_map<const ggml_tensor*, GnPre> gn_pre;
     // CONCAT along the feature dimension read only by Linears (FLUX single block: concat(attn, gelu(mlp)) -> linear2, flux.hpp:594-700): the
     // Linear's f16 operand image is assembled directly (plan_cat_rows16).  cat16: CONCAT node -> image and which parts a producer has written;
     // cat16_part: a producer's tensor (the flash node's output CONT, the CONT in front of an in-place GELU) -> the columns it may write
@@ -1336,6 +1345,39 @@ bool plan_conv_chain(Builder& B, int i, hipStream_t s, std::vector<int>& chain) 
     }
     float* final_dst = (float*)gi.node(last)->data;
     const int ks = KW, st_ = s0, pd = p0;
+    // look-ahead: a GroupNorm (-> MUL w -> ADD b) that reads this chain's result.  When the conv runs split-K, the slab reduce pass computes its
+    // statistics while it writes the values (k_splitk_reduce_gn)
+    Builder::GnPre gnp{0, nullptr, nullptr, 0, 0.f};
+    if (g_opt.fuse_gn_stats && g_opt.gemm16 && token_major_out < 0) {
+        const ggml_tensor* res = gi.node(last);
+        for (int k : gi.consumers[last]) {
+            if (gnp.groups) break;
+            const ggml_tensor* g = gi.node(k);
+            if (g->op != GGML_OP_GROUP_NORM || g->src[0] != res || gi.done[k]) continue;
+            const int j1 = gi.sole(k);
+            if (j1 < 0 || gi.node(j1)->op != GGML_OP_MUL || gi.node(j1)->src[0] != g || !bias_like_chan(gi.node(j1)->src[1], OC)) break;
+            const int j2 = gi.sole(j1);
+            if (j2 < 0 || gi.node(j2)->op != GGML_OP_ADD || gi.node(j2)->src[0] != gi.node(j1) || !bias_like_chan(gi.node(j2)->src[1], OC)) break;
+            const int64_t ohw = res->ne[0] * res->ne[1];
+            if (!splitk_reduce_gn_supported(ohw, OC, N, g->op_params[0])) break;
+            gnp = Builder::GnPre{0, (const float*)gi.node(j1)->src[1]->data, (const float*)gi.node(j2)->src[1]->data, g->op_params[0], ggml_abi_op_param_f32(g, 1)};
+        }
+    }
+    auto gn_register = [&](int S) -> bool {  // called once the split factor is known
+        if (S <= 1 || !gnp.groups) return false;
+        gnp.off                    = B.alloc((size_t)N * OC * 4 * 2);
+        B.gn_pre[gi.node(last)]    = gnp;
+        g_stats.fused_gn_stats++;
+        return true;
+    };
+    auto gn_fill = [](Epilogue& e, const Builder::GnPre& g, char* arena, int64_t nc) {
+        e.gn_scale  = (float*)(arena + g.off);
+        e.gn_shift  = e.gn_scale + nc;
+        e.gn_w      = g.w;
+        e.gn_b      = g.b;
+        e.gn_groups = g.groups;
+        e.gn_eps    = g.eps;
+    };
     // 3x3 / stride 1 on 32 / 64 / 128-wide maps: the LDS-window kernel (conv3w.hip), with its own weight image
     const bool ups_in = B.ups.find(x) != B.ups.end();
     const int w3S     = (g_opt.gemm16 && token_major_out < 0) ? conv3w_plan(x->ne[0], x->ne[1], IC, N, OC, ks, st_, ups_in) : 0;
@@ -1378,9 +1420,11 @@ bool plan_conv_chain(Builder& B, int i, hipStream_t s, std::vector<int>& chain) 
         if (w3S > 0) {
             const size_t wsoff = w3S > 1 ? B.alloc((size_t)w3S * opos * OC * 4) : 0;
             if (w3S > 1) g_stats.split_k_gemms++;
+            const bool gn_on = gn_register(w3S);
             B.emit_at(emit_node, i, [=](hipStream_t st) {
                 Epilogue e2 = ep;
                 if (emb_arena) e2.chan_add = (const float*)(P->arena + emb_off);
+                if (gn_on) gn_fill(e2, gnp, P->arena, N * OC);
                 launch_conv3w(st, final_dst, P->arena + off, swz, SW, SH, IC, N, OC, e2, w3S > 1 ? (float*)(P->arena + wsoff) : nullptr, w3S);
             });
             g_stats.fused_conv++;
@@ -1388,9 +1432,11 @@ bool plan_conv_chain(Builder& B, int i, hipStream_t s, std::vector<int>& chain) 
             return true;
         }
         const Builder::Split sk = B.plan_split(opos, OC, rup64(IC) * ks * ks, true, true);
+        const bool gn_on        = sk.inkernel ? false : gn_register(sk.S);
         B.emit_at(emit_node, i, [=](hipStream_t st) {
             Epilogue e2 = ep;
             if (emb_arena) e2.chan_add = (const float*)(P->arena + emb_off);
+            if (gn_on) gn_fill(e2, gnp, P->arena, N * OC);
             launch_gemm16_conv(st, final_dst, P->arena + off, swz, SW, SH, IC, N, OC, ks, st_, pd, upscale, e2, sk.ws(P), sk.cnt(P), sk.S);
         });
         g_stats.fused_conv++;
@@ -1467,12 +1513,15 @@ bool plan_group_norm(Builder& B, int i, hipStream_t, std::vector<int>& chain) {
         // gen-2: every reader is an implicit-GEMM conv -> statistics kernel + one transposing apply kernel that writes the
         // f16 NHWC operand image straight into the arena; the f32 NCHW result is never materialised.
         Planner* P          = B.P;
-        const size_t so     = B.alloc((size_t)N * C * 4 * 2);
+        // statistics already written by the split-K reduce of the conv that produced x (plan_conv_chain look-ahead)?
+        const auto pre      = B.gn_pre.find(x);
+        const bool have     = pre != B.gn_pre.end() && pre->second.w == w && pre->second.b == b && pre->second.groups == groups && pre->second.eps == eps;
+        const size_t so     = have ? pre->second.off : B.alloc((size_t)N * C * 4 * 2);
         const size_t off    = B.alloc((size_t)N * hw * rup64(C) * 2);
         B.emit([=](hipStream_t st) {
             float* sc = (float*)(P->arena + so);
             float* sh = sc + N * C;
-            launch_gn_stats(st, sc, sh, xp, hw, C, N, groups, eps, w, b);
+            if (!have) launch_gn_stats(st, sc, sh, xp, hw, C, N, groups, eps, w, b);
             launch_nchw_to_nhwc_f16(st, P->arena + off, xp, hw, C, N, sc, sh, silu);
         });
         g_stats.kernels_planned++;
@@ -3045,6 +3094,7 @@ void planner_get_stats(ggml_backend_mi355x_stats* o) {
     o->fused_cat_rows16      = g_stats.fused_cat_rows16;
     o->fused_joint_qkv       = g_stats.fused_joint_qkv;
     o->jit_images            = g_stats.jit_images;
+    o->fused_gn_stats        = g_stats.fused_gn_stats;
     o->fused_attention       = g_stats.fused_attention;
     o->generic_matmul        = g_stats.generic_matmul;
     o->swizzled_weight_bytes = g_stats.swizzled_weight_bytes;
@@ -3073,6 +3123,7 @@ void planner_set_option(const char* key, int value) {
     else if (!strcmp(key, "hoist_emb")) g_opt.hoist_emb = value;
     else if (!strcmp(key, "fuse_rows16")) g_opt.fuse_rows16 = value;
     else if (!strcmp(key, "fuse_cat_rows16")) g_opt.fuse_cat_rows16 = value;
+    else if (!strcmp(key, "fuse_gn_stats")) g_opt.fuse_gn_stats = value;
     else if (!strcmp(key, "fuse_joint_qkv")) g_opt.fuse_joint_qkv = value;
     else if (!strcmp(key, "jit_qimages")) g_opt.jit_qimages = value;
     else if (!strcmp(key, "conv3w_min_blocks")) conv3w_set_min_blocks(value);

@@ -337,6 +337,7 @@ static void c3_launch(hipStream_t s, const G16Args& g, unsigned tiles, unsigned 
 
 // zero page shared with gemm16.hip
 const _Float16* gemm16_zero_page();
+void launch_splitk_reduce_conv_gn(hipStream_t s, float* dst, const float* ws, int S, int64_t hw, int64_t C, int64_t N, const Epilogue& e);
 void launch_splitk_reduce_conv(hipStream_t s, float* dst, const float* ws, int S, int64_t n, const float* bias, int64_t inner, int64_t C, const float* residual,
                                const float* chan_add, int64_t chan_ld);
 
@@ -398,7 +399,7 @@ void launch_conv3w(hipStream_t s, float* dst, const void* x16_nhwc, const void* 
             else c3_launch<128, 256>(s, g, tiles, (unsigned)S);
         }
     }
-    if (S > 1) launch_splitk_reduce_conv(s, dst, splitk_ws, S, g.R * OC, e.bias, g.OHOW, OC, e.residual, e.chan_add, e.chan_ld);
+    if (S > 1) launch_splitk_reduce_conv_gn(s, dst, splitk_ws, S, g.OHOW, OC, N, e);
 }
 
 }  // namespace mi355x

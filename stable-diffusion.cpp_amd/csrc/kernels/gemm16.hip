@@ -859,6 +859,92 @@ __global__ void k_splitk_reduce(float* __restrict__ dst, const float* __restrict
 #pragma unroll
     for (int j = 0; j < W; ++j) dst[i + j] = v[j];
 }
+// Slab reduce of a split-K conv FUSED with the statistics of the GroupNorm that reads the result next: one workgroup per (image, group) — the
+// group's cpg * hw outputs are one contiguous NCHW run — sums the S slabs in slice order, adds bias / embedding / residual exactly as
+// k_splitk_reduce does (same operation order: identical values), stores them, and keeps them in registers for the two-pass mean / variance of
+// k_gn_stats_reg (same per-thread order, same block reductions), then writes the per-(image, channel) affine.  Saves the GroupNorm
+// statistics pass (one more read of the tensor) and its launch for every split conv that feeds a GroupNorm.
+template <int NT, int NV>
+__global__ __launch_bounds__(NT) void k_splitk_reduce_gn(float* __restrict__ dst, const float* __restrict__ ws, int S, int64_t slab, int64_t hw, int C, int groups, int cpg,
+                                                         const float* __restrict__ bias, const float* residual, const float* __restrict__ chan_add, int64_t chan_ld, float eps,
+                                                         const float* __restrict__ gw, const float* __restrict__ gb, float* __restrict__ scale, float* __restrict__ shift) {
+    __shared__ float scratch[2 * (NT / 64)];
+    const int gidx = blockIdx.x % groups, n = blockIdx.x / groups;
+    const int c0   = gidx * cpg;
+    const int64_t cnt = (int64_t)cpg * hw, base = ((int64_t)n * C + c0) * hw, n4 = cnt / 4;
+    float4 v[NV];
+    float s = 0.f, dummy = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int64_t i4 = threadIdx.x + (int64_t)NT * j;
+        v[j]             = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i4 < n4) {
+            const int64_t e = i4 * 4, i = base + e;
+            float4 a        = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int sl = 0; sl < S; ++sl) {
+                const float4 t = *(const float4*)(ws + sl * slab + i);
+                a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+            }
+            const int c = c0 + (int)(e / hw);  // hw % 4 == 0: the four elements share their channel
+            if (bias) {
+                const float b = bias[c];
+                a.x += b; a.y += b; a.z += b; a.w += b;
+            }
+            if (chan_add) {
+                const float b = chan_add[(int64_t)n * chan_ld + c];
+                a.x += b; a.y += b; a.z += b; a.w += b;
+            }
+            if (residual) {
+                const float4 r = *(const float4*)(residual + i);
+                a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w;
+            }
+            *(float4*)(dst + i) = a;
+            v[j]                = a;
+        }
+        s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+    }
+    block_sum2<NT / 64>(s, dummy, scratch);
+    const float mean = s / (float)cnt;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        if (threadIdx.x + (int64_t)NT * j < n4) {
+            const float a = v[j].x - mean, bb = v[j].y - mean, c = v[j].z - mean, d = v[j].w - mean;
+            q += (a * a + bb * bb) + (c * c + d * d);
+        }
+    }
+    dummy = 0.f;
+    block_sum2<NT / 64>(q, dummy, scratch);
+    const float rstd = rsqrtf(q / (float)cnt + eps);
+    for (int c = c0 + threadIdx.x; c < c0 + cpg; c += NT) {
+        const float sc            = (gw ? gw[c] : 1.f) * rstd;
+        scale[(int64_t)n * C + c] = sc;
+        shift[(int64_t)n * C + c] = (gb ? gb[c] : 0.f) - mean * sc;
+    }
+}
+// true when the fused pass serves this launch: whole groups on the vector path that fit the register-resident variants, and at least one workgroup
+// per CU — the pass has ONE workgroup per (image, group), and with fewer it loses more on the slab sums than the statistics pass costs (SDXL's
+// batch-1 cfg pair, 64 workgroups: reduce 2.79 -> 3.48 ms against 0.27 ms of statistics saved, profiles/r04G_*)
+bool splitk_reduce_gn_supported(int64_t hw, int64_t C, int64_t N, int groups) {
+    if (groups <= 0 || C % groups != 0 || hw % 4 != 0 || N * groups < 256) return false;
+    return (C / groups) * hw <= 4 * 1024 * 16;
+}
+static void launch_splitk_reduce_gn(hipStream_t s, float* dst, const float* ws, int S, int64_t hw, int64_t C, int64_t N, const Epilogue& e) {
+    const int groups = e.gn_groups, cpg = (int)(C / groups);
+    const int64_t cnt = (int64_t)cpg * hw, n = hw * C * N;
+    const int64_t chan_ld = e.chan_ld > 0 ? e.chan_ld : C;
+    KScope ks_(s, KF_SPLITK, 0.0, (double)n * 4.0 * (S + 1 + (e.residual ? 1 : 0)));
+    const unsigned grid = (unsigned)(N * groups);
+#define SKGN(NT_, NV_) k_splitk_reduce_gn<NT_, NV_><<<grid, NT_, 0, s>>>(dst, ws, S, n, hw, (int)C, groups, cpg, e.bias, e.residual, e.chan_add, chan_ld, e.gn_eps, e.gn_w, e.gn_b, e.gn_scale, e.gn_shift)
+    if (cnt <= 4 * 256 * 4)  // the same variant choice as launch_gn_stats: same summation order, same statistics
+        SKGN(256, 4);
+    else if (cnt <= 4 * 1024 * 4)
+        SKGN(1024, 4);
+    else
+        SKGN(1024, 16);
+#undef SKGN
+}
+
 static void launch_splitk_reduce(hipStream_t s, float* dst, const float* ws, int S, int64_t n, const float* bias, int64_t inner, int64_t C, const float* residual,
                                  const float* chan_add = nullptr, int64_t chan_ld = 0) {
     if (chan_ld <= 0) chan_ld = C;
@@ -893,6 +979,13 @@ const _Float16* gemm16_zero_page() { return zero_page(); }
 void launch_splitk_reduce_conv(hipStream_t s, float* dst, const float* ws, int S, int64_t n, const float* bias, int64_t inner, int64_t C, const float* residual,
                                const float* chan_add, int64_t chan_ld) {
     launch_splitk_reduce(s, dst, ws, S, n, bias, inner, C, residual, chan_add, chan_ld);
+}
+// the same with the statistics of the GroupNorm that reads the output next (e.gn_*); falls back to the plain pass when the shape is not served
+void launch_splitk_reduce_conv_gn(hipStream_t s, float* dst, const float* ws, int S, int64_t hw, int64_t C, int64_t N, const Epilogue& e) {
+    if (e.gn_scale && (((uintptr_t)dst | (uintptr_t)ws | (uintptr_t)e.residual) & 15) == 0 && splitk_reduce_gn_supported(hw, C, N, e.gn_groups))
+        launch_splitk_reduce_gn(s, dst, ws, S, hw, C, N, e);
+    else
+        launch_splitk_reduce(s, dst, ws, S, hw * C * N, e.bias, hw, C, e.residual, e.chan_add, e.chan_ld);
 }
 
 // GGML_MI355X_TRACE=1: one stderr line per launch (shape), in launch order — joined with a rocprofv3 kernel trace by scripts/shape_stats.py
@@ -1093,7 +1186,12 @@ void launch_gemm16_conv(hipStream_t s, float* dst, const void* x16_nhwc, const v
         g.ncol_tiles = (int)((OC + 127) / 128);
         g16_launch<128, true>(s, g, g.R, 2.0 * g.R * IC * ksize * ksize * OC, conv_bytes);
     }
-    if (S > 1 && !inker) launch_splitk_reduce(s, dst, splitk_ws, S, g.R * OC, e.bias, g.OHOW, OC, e.residual, e.chan_add, e.chan_ld);
+    if (S > 1 && !inker) {
+        if (e.gn_scale && (((uintptr_t)dst | (uintptr_t)splitk_ws | (uintptr_t)e.residual) & 15) == 0 && splitk_reduce_gn_supported(g.OHOW, OC, N, e.gn_groups))
+            launch_splitk_reduce_gn(s, dst, splitk_ws, S, g.OHOW, OC, N, e);
+        else
+            launch_splitk_reduce(s, dst, splitk_ws, S, g.R * OC, e.bias, g.OHOW, OC, e.residual, e.chan_add, e.chan_ld);
+    }
 }
 
 // =====================================================================================================

@@ -82,6 +82,14 @@ struct Epilogue {
     int64_t chan_ld       = 0;        // floats between the images of chan_add (0 = OC: the graph tensor; > OC: a column range of a grouped projection's output)
     float scale           = 1.0f;     // applied to the accumulator before bias
     int act               = -1;       // UnOp applied last, or -1
+    // conv only, split-K launches only: the GroupNorm that reads this output next (planner look-ahead) — the slab reduce pass then also computes the
+    // group statistics of the values it writes and stores the per-(image, channel) affine y = x * gn_scale + gn_shift (k_splitk_reduce_gn)
+    float* gn_scale       = nullptr;
+    float* gn_shift       = nullptr;
+    const float* gn_w     = nullptr;
+    const float* gn_b     = nullptr;
+    int gn_groups         = 0;
+    float gn_eps          = 0.f;
     // gemm16 linear only (DiT blocks):
     const float* gate     = nullptr;  // [images][M]: dst = (acc*scale + bias) * gate[row / gate_L][col] + residual
     int gate_L            = 0;        // rows per image
@@ -113,6 +121,7 @@ void launch_gemm16_linear_geglu(hipStream_t s, void* dst16, const void* a16, int
                                 const float* bias);
 // split-K factor the launchers will use when given a workspace of factor * rows * M floats (1 = no split)
 int gemm16_split_k(int64_t rows, int64_t M, int64_t K, bool conv);
+bool splitk_reduce_gn_supported(int64_t hw, int64_t C, int64_t N, int groups);  // the slab reduce of a split conv can also produce the next GroupNorm's statistics
 void gemm16_set_t320_linear_max_split(int v);  // option "t320_linear_max_split" (4): most K slices a Linear takes on the 256x320 tile
 // the split a launch of this shape should take: S slices; inkernel = combined by the last-arriving workgroup of every output tile (the launcher
 // then needs `tiles` zeroed int counters and ws_bytes of slab space, and applies the full epilogue itself), else slabs + k_splitk_reduce (only

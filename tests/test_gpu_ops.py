@@ -915,6 +915,42 @@ def test_conv2d_split_k(sd, oracle, gpu, rng, N, IC, OC, H, W, ks, stride):
         assert sd.backend_stats()["split_k_gemms"] == before["split_k_gemms"] + 1
 
 
+@pytest.mark.parametrize("N,C,H,W,res", [(8, 256, 8, 8, True), (8, 320, 16, 16, False), (8, 1280, 16, 16, True), (8, 640, 32, 32, True), (2, 256, 8, 8, True)])
+def test_split_conv_reduce_writes_group_norm_statistics(sd, oracle, gpu, rng, N, C, H, W, res):
+    """ResBlock seam (block.hpp:126-179 -> next block's norm): a split-K 3x3 conv (+bias, +residual) whose result is read by GroupNorm -> affine -> SiLU -> conv
+    AND by a later ADD.  The slab reduce pass writes the values and the GroupNorm's per-(image, channel) affine (k_splitk_reduce_gn: register-resident
+    groups of 512 / 2560 / 10240 / 20480 values), so both the conv values and the normalised branch are checked.  With fewer than 256 (image, group)
+    pairs the planner keeps the separate statistics pass (last case)."""
+    x = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    r = (rng.standard_normal((N, C, H, W)) + 0.7).astype(np.float32)
+    w = (rng.standard_normal((C, C, 3, 3)) / np.sqrt(C * 9)).astype(np.float32)
+    b = rng.standard_normal(C).astype(np.float32)
+    gw = (1 + 0.1 * rng.standard_normal(C)).astype(np.float32)
+    gb = rng.standard_normal(C).astype(np.float32)
+    w2 = (rng.standard_normal((C, C, 1, 1)) / np.sqrt(C)).astype(np.float32)
+
+    def build(g, L):
+        h = L.ggml_conv_2d(g.ctx, g.weight(w, F16), g.input(x), 1, 1, 1, 1, 1, 1)
+        h = L.ggml_add_inplace(g.ctx, h, L.ggml_reshape_4d(g.ctx, g.weight(b, F32), 1, 1, C, 1))
+        if res:
+            h = L.ggml_add(g.ctx, h, g.input(r))
+        t = L.ggml_group_norm(g.ctx, h, 32, 1e-6)
+        t = L.ggml_mul_inplace(g.ctx, t, L.ggml_reshape_4d(g.ctx, g.weight(gw, F32), 1, 1, C, 1))
+        t = L.ggml_add_inplace(g.ctx, t, L.ggml_reshape_4d(g.ctx, g.weight(gb, F32), 1, 1, C, 1))
+        t = L.ggml_silu_inplace(g.ctx, t)
+        t = L.ggml_conv_2d(g.ctx, g.weight(w2, F16), t, 1, 1, 0, 0, 1, 1)
+        return L.ggml_add(g.ctx, t, h)
+
+    before = sd.backend_stats() if _on_gpu() else None
+    ref, out = run_both(sd, oracle, gpu, build)
+    assert out.shape == (N, C, H, W) and np.isfinite(out).all()
+    assert rel_l2(out, ref) < 3e-4
+    if before is not None and not os.environ.get("SDCPP_BACKEND_OPTS"):
+        st = sd.backend_stats()
+        assert st["split_k_gemms"] - before["split_k_gemms"] >= 1
+        assert st["fused_gn_stats"] - before["fused_gn_stats"] == (1 if N * 32 >= 256 else 0)
+
+
 @pytest.mark.parametrize("d,H,L_,N,K,f16", [(40, 8, 77, 3, 768, True), (40, 8, 77, 3, 768, False), (80, 4, 200, 2, 320, True), (64, 2, 24, 5, 128, False),
                                             (160, 2, 64, 2, 320, True), (40, 2, 300, 1, 64, False)])
 def test_projection_head_major_chain(sd, oracle, gpu, rng, d, H, L_, N, K, f16):
