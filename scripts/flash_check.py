@@ -20,8 +20,12 @@ rng = np.random.default_rng(0)
 REPS = 5
 # variants: a warm-up column (the first variant of a case runs on cold clocks), the round-2 kernel (one query block per wave), two query blocks
 # per wave, each with and without the fragment prefetch (flash_vpf); the ping-pong kernel of earlier runs is still reachable with flash_pp = 2
+sd.backend_set_option("flash_vtr", 0)  # the round-3 variants below are all on the transposed V tile
 VARIANTS = [("warm", {"flash_qb2": 0, "flash_vpf": 0}), ("r2", {"flash_qb2": 0, "flash_vpf": 0}), ("qb2", {"flash_qb2": 1, "flash_vpf": 0}),
             ("vpf", {"flash_qb2": 0, "flash_vpf": 31}), ("qb2+vpf", {"flash_qb2": 1, "flash_vpf": 31})]
+if len(sys.argv) > 1 and sys.argv[1] == "vtr":  # default kernels against the row-major V tile / transposing LDS read (flash_vtr), alternating
+    base, vtr = {"flash_qb2": 1, "flash_vpf": 31, "flash_vtr": 0}, {"flash_qb2": 1, "flash_vpf": 31, "flash_vtr": 31}
+    VARIANTS = [("warm", base), ("base", base), ("vtr", vtr), ("base", base), ("vtr", vtr)]
 
 
 def rel_l2(a, b):

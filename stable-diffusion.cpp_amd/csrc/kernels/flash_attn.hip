@@ -75,9 +75,31 @@ struct FAArgs {
 // (Also measured, rejected and removed: a software-pipelined tile loop computing S(t+1) = K(t+1) Q^T inside the exponentials of tile t — one
 // scheduling region, MFMAs and VALU interleaved by sched_group_barrier, bit-identical results: 15-25 % SLOWER at d <= 64 (second score register set:
 // 3 -> 2 waves per SIMD), equal at d = 128: profiles/r04x_flash_sp_rejected.txt.)
-template <int DKP, int NDV, bool FAST, int ABL = 0, bool MSLOT = false, int QB = 1, bool VPF = false>
+// VTR (FAST only; option "flash_vtr"): V tiles stay ROW-MAJOR [key][dv] in LDS — staged with the same coalesced 16-byte loads and 16-byte LDS
+// writes as K — and the PV B-fragments are fetched with the gfx950 transposing read (ds_read_b64_tr_b16), instead of transposing in the staging
+// pass (8 two-byte LDS writes per chunk: at d = 128 that is 32 ds_write_b16 per thread per tile next to 32 MFMAs, fed by loads that touch 64
+// different rows per instruction).  The read (cdna_hip_programming.md, LDS): inside each 16-lane group, lane i supplies the address of 4
+// consecutive halfs; result element j of lane l is half (l & 3) of the 8 bytes addressed by lane 4 j + ((l & 15) >> 2) of the same group.  With
+// lane i pointing at V[k0 + (i >> 2)][n0 + 4 (i & 3) ..], lane l receives V[k0 + j][n0 + (l & 15)], j = 0..3: four consecutive keys of one
+// output column — half a B fragment (the other half is the same read 8 keys further on).
+typedef short fa_short4_t __attribute__((__vector_size__(4 * sizeof(short))));
+__device__ __forceinline__ half4_t lds_read_tr16(const _Float16* p) {
+    const fa_short4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) fa_short4_t*)p);
+    return __builtin_bit_cast(half4_t, v);
+}
+// row stride (halfs) of the row-major V tile: a 32-lane half of the transposing read covers 4 keys x 32 columns (64 bytes per key), so rows
+// 16 dwords apart modulo the 64 banks never collide
+constexpr int fa_vtr_stride(int ndv) {
+    int dw = ndv * 16;
+    if (dw % 64 != 16 && dw % 64 != 48) dw += 16;
+    return dw * 2;
+}
+template <int DKP, int NDV, bool FAST, int ABL = 0, bool MSLOT = false, int QB = 1, bool VPF = false, bool VTR = false>
 __global__ __launch_bounds__(256, QB == 2 ? (DKP <= 96 ? 2 : 1) : (DKP <= 64 ? (VPF ? 2 : FA_OCC_SMALL) : (DKP <= 128 ? 2 : 1))) void k_flash_attn(FAArgs g) {
     static_assert(QB == 1 || FAST, "two query blocks per wave: FAST staging only");
+    static_assert(!VTR || FAST, "row-major V tiles: FAST staging only");
+    constexpr int VRS  = fa_vtr_stride(NDV);             // VTR: V tile row stride (halfs)
+    constexpr int VT_H = VTR ? FA_KT * VRS : NDV * 32 * FA_VTS;  // halfs of one V tile
     constexpr int QW   = 32 * QB;                        // queries per wave
     constexpr int QWG  = 4 * QW;                         // queries per workgroup
     constexpr int KS   = DKP / 16;                       // MFMA k-steps over the head dim
@@ -86,7 +108,7 @@ __global__ __launch_bounds__(256, QB == 2 ? (DKP <= 96 ? 2 : 1) : (DKP <= 64 ? (
     constexpr int NCH  = FAST ? (FA_KT * DCH + 255) / 256 : 1;  // prefetched chunks per thread (K and V each)
     // FAST: two K/V tile buffers — tile t+1 is written while tile t is read, ONE barrier per tile (waves were parked at the two
     // barriers of the single-buffer loop 47 % of their cycles, profiles/r01g_pmc_flash.txt)
-    constexpr int TILE_H = FA_KT * KROW + NDV * 32 * FA_VTS;  // halfs per tile buffer
+    constexpr int TILE_H = FA_KT * KROW + VT_H;  // halfs per tile buffer
     constexpr int NBUF   = FAST ? 2 : 1;
     __shared__ __attribute__((aligned(16))) _Float16 smem[NBUF * TILE_H];
     _Float16* Ks = smem;
@@ -221,7 +243,7 @@ __global__ __launch_bounds__(256, QB == 2 ? (DKP <= 96 ? 2 : 1) : (DKP <= 64 ? (
     for (int c = 0; c < NCH; ++c) {
         const int e   = threadIdx.x + c * 256;
         const int key = e / DCH, ch = e - key * DCH;
-        const int vkey = e & (FA_KT - 1), vch = e >> 6;
+        const int vkey = VTR ? key : (e & (FA_KT - 1)), vch = VTR ? ch : (e >> 6);
         kkey[c]  = (e < FA_KT * DCH && ch < nd8) ? key : FA_KT;
         kone[c]  = e < FA_KT * DCH && ch == nd8;
         vkey_[c] = (e < FA_KT * DCH && vch < nd8) ? vkey : FA_KT;
@@ -254,14 +276,18 @@ __global__ __launch_bounds__(256, QB == 2 ? (DKP <= 96 ? 2 : 1) : (DKP <= 64 ? (
             const int e = threadIdx.x + c * 256;
             if (e < FA_KT * DCH) {
                 const int key = e / DCH, ch = e - key * DCH;
-                const int vkey = e & (FA_KT - 1), vch = e >> 6;
+                const int vkey = VTR ? key : (e & (FA_KT - 1)), vch = VTR ? ch : (e >> 6);
                 const half8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
                 half8_t kv = kkey[c] < left ? kreg[c] : z, vv = vkey_[c] < left ? vreg[c] : z;
                 if (MSLOT && kone[c]) kv[0] = (_Float16)1.0f;                   // K[key][D] = 1 (keys beyond Lk are masked after the MFMA)
                 if (ones_in_tile && vch == nd8) vv[0] = (_Float16)1.0f;         // V^T row DV = 1: PV accumulates the row sums
                 *(half8_t*)&ks[key * KROW + ch * 8] = kv;
+                if constexpr (VTR) {
+                    *(half8_t*)&vt[vkey * VRS + vch * 8] = vv;
+                } else {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) vt[(vch * 8 + j) * FA_VTS + vkey] = vv[j];
+                    for (int j = 0; j < 8; ++j) vt[(vch * 8 + j) * FA_VTS + vkey] = vv[j];
+                }
             }
         }
     };
@@ -304,10 +330,10 @@ __global__ __launch_bounds__(256, QB == 2 ? (DKP <= 96 ? 2 : 1) : (DKP <= 64 ? (
     // padded V^T rows (d >= DKP) are never staged: clear them once so the masked output columns stay finite
 #pragma unroll
     for (int b = 0; b < NBUF; ++b)
-        for (int e = threadIdx.x; e < NDV * 32 * FA_VTS / 2; e += 256) ((uint32_t*)(Vt + b * TILE_H))[e] = 0u;
+        for (int e = threadIdx.x; e < VT_H / 2; e += 256) ((uint32_t*)(Vt + b * TILE_H))[e] = 0u;
     if (has_ones && !ones_in_tile) {
         __syncthreads();
-        if (threadIdx.x < FA_KT * NBUF) Vt[(threadIdx.x >> 6) * TILE_H + g.DV * FA_VTS + (threadIdx.x & 63)] = (_Float16)1.0f;
+        if (threadIdx.x < FA_KT * NBUF) Vt[(threadIdx.x >> 6) * TILE_H + (VTR ? (threadIdx.x & 63) * VRS + g.DV : g.DV * FA_VTS + (threadIdx.x & 63))] = (_Float16)1.0f;
     }
     if (FAST) {
         gload(0);
@@ -340,6 +366,19 @@ __global__ __launch_bounds__(256, QB == 2 ? (DKP <= 96 ? 2 : 1) : (DKP <= 64 ? (
         // independent of block b's softmax VALU work, so the two streams overlap; only ONE block's 32 score registers are live at a time.
         half8_t pa[QB][4];
         half4_t vq0[4], vq1[4];  // VPF: ring of four V fragments (two 8-byte halves each)
+        // B fragment (16 keys of k-step t, output columns nb * 32 + (lane & 31)) as two 4-key halves: keys t*16 + 4 hi .. and the same 8 further on
+        const int vtr_lane = (4 * hi + ((lane & 15) >> 2)) * VRS + ((lane >> 4) & 1) * 16 + 4 * (lane & 3);
+        auto vread = [&](int t, int nb, half4_t& a, half4_t& c) {
+            if constexpr (VTR) {
+                const _Float16* p = Vc + vtr_lane + t * 16 * VRS + nb * 32;
+                a = lds_read_tr16(p);
+                c = lds_read_tr16(p + 8 * VRS);
+            } else {
+                const _Float16* vrow = &Vc[(nb * 32 + (lane & 31)) * FA_VTS + t * 16 + 4 * hi];
+                a = *(const half4_t*)vrow;
+                c = *(const half4_t*)(vrow + 8);
+            }
+        };
         constexpr bool SHARE_KF = QB == 2 && KS <= 3;
         half8_t kf[2][KS <= 6 ? KS : 1];
         // ---- online softmax for query (lane & 31) of each block; this lane holds keys kb*32 + (r&3)+8*(r>>2)+4*hi.  The loop is VALU-bound at
@@ -425,10 +464,7 @@ __global__ __launch_bounds__(256, QB == 2 ? (DKP <= 96 ? 2 : 1) : (DKP <= 64 ? (
             if (VPF && b == QB - 1) {  // the first four V fragments of this tile: in flight during the (last block's) softmax
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int t = i / NDV, nb = i % NDV;
-                    const _Float16* vrow = &Vc[(nb * 32 + (lane & 31)) * FA_VTS + t * 16 + 4 * hi];
-                    vq0[i] = *(const half4_t*)vrow;
-                    vq1[i] = *(const half4_t*)(vrow + 8);
+                    vread(i / NDV, i % NDV, vq0[i], vq1[i]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -503,12 +539,7 @@ __global__ __launch_bounds__(256, QB == 2 ? (DKP <= 96 ? 2 : 1) : (DKP <= 64 ? (
                 const half8_t vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
 #pragma unroll
                 for (int b = 0; b < QB; ++b) o[b][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa[b][t], vf, o[b][nb], 0, 0, 0);
-                if (i + 4 < NFR) {
-                    const int t2 = (i + 4) / NDV, nb2 = (i + 4) % NDV;
-                    const _Float16* vrow = &Vc[(nb2 * 32 + (lane & 31)) * FA_VTS + t2 * 16 + 4 * hi];
-                    vq0[i & 3] = *(const half4_t*)vrow;
-                    vq1[i & 3] = *(const half4_t*)(vrow + 8);
-                }
+                if (i + 4 < NFR) vread((i + 4) / NDV, (i + 4) % NDV, vq0[i & 3], vq1[i & 3]);
             }
 #pragma unroll
             for (int i = 0; i < NFR; ++i) {  // the fragment's MFMA(s), then the two reads that refill its ring slot
@@ -520,8 +551,8 @@ __global__ __launch_bounds__(256, QB == 2 ? (DKP <= 96 ? 2 : 1) : (DKP <= 64 ? (
         for (int t = 0; t < 4; ++t) {
 #pragma unroll
             for (int nb = 0; nb < NDV; ++nb) {
-                const _Float16* vrow = &Vc[(nb * 32 + (lane & 31)) * FA_VTS + t * 16 + 4 * hi];
-                const half4_t v0 = *(const half4_t*)vrow, v1 = *(const half4_t*)(vrow + 8);
+                half4_t v0, v1;
+                vread(t, nb, v0, v1);
                 half8_t vf;
                 vf[0] = v0[0];
                 vf[1] = v0[1];
@@ -1056,6 +1087,8 @@ static int g_flash_pp = 0;  // option "flash_pp": 0 (default) = never the ping-p
 void flash_attn_set_pp(int v) { g_flash_pp = v; }
 static int g_flash_vpf = 31;  // option "flash_vpf": head-dim classes (1: d <= 48, 2: <= 64, 4: <= 96, 8: <= 128, 16: above) whose kernel prefetches its fragments
 void flash_attn_set_vpf(int v) { g_flash_vpf = v; }
+static int g_flash_vtr = 31;  // option "flash_vtr": head-dim classes (bits as flash_vpf) whose prefetching kernel keeps V row-major in LDS and reads it with ds_read_b64_tr_b16 (0 = the transposed tile of rounds 1-3)
+void flash_attn_set_vtr(int v) { g_flash_vtr = v; }
 static int g_flash_pp_min_tiles = 4;  // option "flash_pp_min_tiles": key tiles (64 keys) from which the ping-pong pipeline has a steady state worth its prologue
 void flash_attn_set_pp_min_tiles(int v) { g_flash_pp_min_tiles = v; }
 
@@ -1119,7 +1152,10 @@ void launch_flash_attn(hipStream_t s, const FlashOut& out, const View4& q, const
     }
 #define FA_CASE(DKP_, NDV_)                                                                \
     do {                                                                                   \
-        if (fast && (g_flash_vpf & (DKP_ <= 48 ? 1 : DKP_ <= 64 ? 2 : DKP_ <= 96 ? 4 : DKP_ <= 128 ? 8 : 16)))  \
+        constexpr int cls_ = DKP_ <= 48 ? 1 : DKP_ <= 64 ? 2 : DKP_ <= 96 ? 4 : DKP_ <= 128 ? 8 : 16;  \
+        if (fast && (g_flash_vpf & cls_) && (g_flash_vtr & cls_))                          \
+            k_flash_attn<DKP_, NDV_, true, 0, false, 1, true, true><<<grid, 256, 0, s>>>(g);  \
+        else if (fast && (g_flash_vpf & cls_))                                             \
             k_flash_attn<DKP_, NDV_, true, 0, false, 1, true><<<grid, 256, 0, s>>>(g);     \
         else if (fast)                                                                     \
             k_flash_attn<DKP_, NDV_, true><<<grid, 256, 0, s>>>(g);                        \
@@ -1151,6 +1187,13 @@ void launch_flash_attn(hipStream_t s, const FlashOut& out, const View4& q, const
             k_flash_pp<128, 4, false><<<grid, 512, 0, s>>>(g);
         return;
     }
+    if (qb2 && (g_flash_vpf & 1) && (g_flash_vtr & 1)) {
+        if (D == 40 && g_flash_mslot)
+            k_flash_attn<48, 2, true, 0, true, 2, true, true><<<grid, 256, 0, s>>>(g);
+        else
+            k_flash_attn<48, 2, true, 0, false, 2, true, true><<<grid, 256, 0, s>>>(g);
+        return;
+    }
     if (qb2 && (g_flash_vpf & 1)) {
         if (D == 40 && g_flash_mslot)
             k_flash_attn<48, 2, true, 0, true, 2, true><<<grid, 256, 0, s>>>(g);
@@ -1167,7 +1210,9 @@ void launch_flash_attn(hipStream_t s, const FlashOut& out, const View4& q, const
             k_flash_attn<64, 2, true, 0, false, 2><<<grid, 256, 0, s>>>(g);
         return;
     }
-    if (D == 40 && fast && g_flash_mslot && (g_flash_vpf & 1))
+    if (D == 40 && fast && g_flash_mslot && (g_flash_vpf & 1) && (g_flash_vtr & 1))
+        k_flash_attn<48, 2, true, 0, true, 1, true, true><<<grid, 256, 0, s>>>(g);
+    else if (D == 40 && fast && g_flash_mslot && (g_flash_vpf & 1))
         k_flash_attn<48, 2, true, 0, true, 1, true><<<grid, 256, 0, s>>>(g);
     else if (D == 40 && fast && g_flash_mslot)
         k_flash_attn<48, 2, true, 0, true><<<grid, 256, 0, s>>>(g);

@@ -218,3 +218,48 @@ def test_joint_heads_indexing_norm_and_rotary(d, H, La, Lb, N, norm, rope):
         x = np.einsum("lpij,nlhpj->nlhpi", pe.astype(np.float64), xp).reshape(N, Lt, H, d)
     ref = np.transpose(x, (0, 2, 1, 3))                                                   # [N, H, Lt, d] = ggml [d, Lt, H, N]
     np.testing.assert_allclose(out, ref, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("ndv,dkp", [(2, 48), (2, 64), (3, 80), (4, 128), (5, 160)])
+def test_flash_row_major_v_tile_transposing_read_fragments(ndv, dkp):
+    """k_flash_attn<..., VTR>: V tiles stay row-major [key][dv] in LDS and the PV B-fragments come from ds_read_b64_tr_b16.  Model of the read
+    (cdna_hip_programming.md, LDS section): inside each 16-lane group, result element j of lane l is half (l & 3) of the 8 bytes addressed by lane
+    4 j + ((l & 15) >> 2).  With the kernel's per-lane addresses every lane must receive, for k-step t and column block nb, the keys
+    t*16 + {4 hi .. 4 hi + 3} and the same 8 further on, of output column nb*32 + (lane & 31) — the fragment the transposed-tile path reads —
+    and a 32-lane half of one read must touch every LDS bank at most once."""
+    dw = ndv * 16
+    if dw % 64 not in (16, 48):
+        dw += 16
+    VRS = dw * 2
+    rng = np.random.default_rng(ndv)
+    V = rng.standard_normal((64, VRS)).astype(np.float16)
+    flat = V.reshape(-1)
+    lanes = np.arange(64)
+    hi = lanes >> 5
+    lane_off = (4 * hi + ((lanes & 15) >> 2)) * VRS + ((lanes >> 4) & 1) * 16 + 4 * (lanes & 3)
+
+    def tr16(addr):  # addr: per-lane element offsets
+        out = np.zeros((64, 4), np.float16)
+        for l in range(64):
+            g16 = l & ~15
+            for j in range(4):
+                src = g16 + 4 * j + ((l & 15) >> 2)
+                out[l, j] = flat[addr[src] + (l & 3)]
+        return out
+
+    for t in range(4):
+        for nb in range(ndv):
+            a = tr16(lane_off + t * 16 * VRS + nb * 32)
+            c = tr16(lane_off + (t * 16 + 8) * VRS + nb * 32)
+            for l in range(64):
+                col = nb * 32 + (l & 31)
+                k0 = t * 16 + 4 * (l >> 5)
+                np.testing.assert_array_equal(a[l], V[k0:k0 + 4, col])
+                np.testing.assert_array_equal(c[l], V[k0 + 8:k0 + 12, col])
+            for half in range(2):  # bank = (byte address / 4) % 64, 8 bytes per lane
+                banks = []
+                for l in range(32 * half, 32 * half + 32):
+                    b = ((lane_off[l] + t * 16 * VRS + nb * 32) * 2 // 4) % 64
+                    banks += [b, (b + 1) % 64]
+                assert len(set(banks)) == 64
+    assert dkp <= ndv * 32 and (64 * VRS * 2) % 16 == 0
