@@ -127,6 +127,7 @@ GGML_MI355X_API int ggml_backend_mi355x_get_kernel_timings(struct ggml_backend_m
  * conv: "conv3w" (1: 3x3 / stride-1 convs on 16..128-wide maps on the LDS-window kernel), "conv3w_min_blocks" (8) / "conv3w_min_blocks_deep" (5:
  * least 32-channel blocks per K slice when the window kernel splits K);
  * flash attention: "flash_vtr" (31: bit per head-dim class — V tiles row-major in LDS, fragments by ds_read_b64_tr_b16; 0 = transposing staging pass),
+ * "flash_ovl" (1: the two-block d = 40 kernel issues one block's softmax inside the other block's MFMAs; 2: also the other d <= 48 launches; 0: off),
  * "flash_qb2" (1: two query blocks per wave for d <= 48), "flash_pp" (0; 1 = the 8-wave ping-pong kernel for 64 < d <= 96,
  * 2 = wherever it is legal: measured slower or equal, kept for A/B runs), "flash_pp_min_tiles" (4).
  * Wrong-result timing ablations exist only in builds with -DMI355X_EXPERIMENTS ("flash_ablate"). */

@@ -26,6 +26,11 @@ VARIANTS = [("warm", {"flash_qb2": 0, "flash_vpf": 0}), ("r2", {"flash_qb2": 0, 
 if len(sys.argv) > 1 and sys.argv[1] == "vtr":  # default kernels against the row-major V tile / transposing LDS read (flash_vtr), alternating
     base, vtr = {"flash_qb2": 1, "flash_vpf": 31, "flash_vtr": 0}, {"flash_qb2": 1, "flash_vpf": 31, "flash_vtr": 31}
     VARIANTS = [("warm", base), ("base", base), ("vtr", vtr), ("base", base), ("vtr", vtr)]
+if len(sys.argv) > 1 and sys.argv[1] == "ovl":  # default kernels against the overlapped issue order of the two-block d <= 48 kernel (flash_ovl)
+    base, ovl = {"flash_ovl": 0}, {"flash_ovl": 1}
+    sd.backend_set_option("flash_vtr", 31)
+    VARIANTS = [("warm", base), ("base", base), ("ovl", ovl), ("base", base), ("ovl", ovl)]
+ONLY = sys.argv[2] if len(sys.argv) > 2 else ""  # substring filter on the case labels
 
 
 def rel_l2(a, b):
@@ -34,6 +39,8 @@ def rel_l2(a, b):
 
 
 def case(label, d, Lq, Lk, HN):
+    if ONLY and ONLY not in label:
+        return True
     q = rng.standard_normal((HN, Lq, d)).astype(np.float32)
     k = rng.standard_normal((HN, Lk, d)).astype(np.float32)
     v = rng.standard_normal((HN, Lk, d)).astype(np.float32)
@@ -61,6 +68,7 @@ def case(label, d, Lq, Lk, HN):
     sd.backend_set_option("flash_pp", 0)
     sd.backend_set_option("flash_qb2", 1)
     sd.backend_set_option("flash_vpf", 31)
+    sd.backend_set_option("flash_ovl", 0)
     k16, v16 = k.astype(np.float16).astype(np.float64), v.astype(np.float16).astype(np.float64)
     worst = 0.0
     r2 = np.random.default_rng(1)
@@ -87,6 +95,7 @@ if __name__ == "__main__":
     ok &= case("sdxl cross d64 Lk77 HN20", 64, 4096, 77, 20)
     ok &= case("sd35 joint d64 L4250 HN76", 64, 4250, 4250, 76)
     ok &= case("flux d128 L4352 HN24", 128, 4352, 4352, 24)
+    ok &= case("tail d40 L2048 Lk1000 HN128", 40, 2048, 1000, 128)
     ok &= case("ragged d40 Lq1000 Lk333 HN64", 40, 1000, 333, 64)
     ok &= case("ragged d64 Lq300 Lk200 HN256", 64, 300, 200, 256)
     print("ALL OK" if ok else "SOME FAILED")

@@ -94,9 +94,19 @@ constexpr int fa_vtr_stride(int ndv) {
     if (dw % 64 != 16 && dw % 64 != 48) dw += 16;
     return dw * 2;
 }
-template <int DKP, int NDV, bool FAST, int ABL = 0, bool MSLOT = false, int QB = 1, bool VPF = false, bool VTR = false>
+// OVL (two query blocks, d <= 48, VPF; option "flash_ovl"): the tile is issued so that one block's softmax VALU work sits in the issue gaps of the OTHER block's MFMAs, inside one scheduling
+// region each:   QK(b0) | max(b0) | { QK(b1) || exp, cvt (b0) } | max(b1) | { PV(b0) || exp, cvt (b1) } | PV(b1)
+// (a 32x32x16 MFMA occupies its SIMD's matrix pipe for 32 cycles and hides up to ~5 single-issue VALU / LDS instructions of the same wave in that
+// gap, MI355X_MICROARCH.md; the default stream runs QK -> softmax -> QK -> softmax -> PV as separate phases: 28 MFMAs = 900 cycles and ~160 VALU
+// of a tile one after the other).  Same arithmetic per query in the same order: bit-identical results.  Costs: both blocks' score registers are
+// live during region A, and the tile's eight V fragments stay in registers for the second P V pass.  Measured (profiles/r04L_flash_ovl.txt, alternating
+// variants, bit-identical outputs): d = 40, L = 4096: 601 -> 582 us; Lq = 2048, Lk = 1000 (ragged last tile): 111 -> 105 us.  The gain is small because
+// the kernel is bound by its instruction ISSUE (one v_exp_f32 per score), not by the order: a SIMD spends ~4 cycles per issued instruction whichever
+// wave it comes from, so what overlap can win is only the matrix pipe's own 32-cycle occupancy.
+template <int DKP, int NDV, bool FAST, int ABL = 0, bool MSLOT = false, int QB = 1, bool VPF = false, bool VTR = false, bool OVL = false>
 __global__ __launch_bounds__(256, QB == 2 ? (DKP <= 96 ? 2 : 1) : (DKP <= 64 ? (VPF ? 2 : FA_OCC_SMALL) : (DKP <= 128 ? 2 : 1))) void k_flash_attn(FAArgs g) {
     static_assert(QB == 1 || FAST, "two query blocks per wave: FAST staging only");
+    static_assert(!OVL || (QB == 2 && DKP == 48 && NDV == 2 && VPF && FAST && ABL == 0), "overlapped issue order: the two-block d <= 48 kernel only");
     static_assert(!VTR || FAST, "row-major V tiles: FAST staging only");
     constexpr int VRS  = fa_vtr_stride(NDV);             // VTR: V tile row stride (halfs)
     constexpr int VT_H = VTR ? FA_KT * VRS : NDV * 32 * FA_VTS;  // halfs of one V tile
@@ -230,7 +240,9 @@ __global__ __launch_bounds__(256, QB == 2 ? (DKP <= 96 ? 2 : 1) : (DKP <= 64 ? (
     // Row sums for free: when the head dim leaves a padded output column (DV < NDV*32; d = 40, 80: yes, d = 64, 128, 160: no), row DV
     // of V^T is set to ones and column DV of the PV accumulator becomes sum_k P[q][k] — in the same f16-rounded P the numerator
     // uses — instead of 32 VALU adds per lane per tile.  (FAST staging needs D % 8 == 0 for the row to sit at a chunk start.)
-    const bool has_ones     = g.DV < NDV * 32 && g.D == g.DV && (!FAST || g.D % 8 == 0);
+    // (OVL: the FAST d <= 48 launch always has the column — D = DV, D % 8 == 0 and D < 64 are dispatch conditions — and a compile-time constant
+    // keeps the tile body free of the branch that would cut its scheduling regions)
+    const bool has_ones     = OVL ? true : (g.DV < NDV * 32 && g.D == g.DV && (!FAST || g.D % 8 == 0));
     const bool ones_in_tile = has_ones && g.DV < DKP;  // the row is (re)written by the per-tile staging; else set once below
     // K chunks: thread e -> (key = e / DCH, chunk = e % DCH): row-major 16-byte LDS writes.  V chunks: (key = e % 64, chunk = e / 64):
     // lanes run along keys so the 8 transposing 2-byte LDS writes of a chunk are bank-contiguous (the (e / DCH, e % DCH) mapping
@@ -387,6 +399,118 @@ __global__ __launch_bounds__(256, QB == 2 ? (DKP <= 96 ? 2 : 1) : (DKP <= 64 ? (
         // it by more than FA_THR (2^8: P <= 256 stays exact enough in f16 and far from its range), which makes the accumulator
         // rescale (16 cross-lane fetches + 16*NDV multiplies) rare instead of per tile.  The vote uses each lane's OWN 32 keys (a row's max
         // exceeds the bar iff one of its two halves does): the cross-half exchange happens only on the rare path.
+        if constexpr (OVL) {
+            float16_t s0[2], s1[2];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) kf[kb][ks] = *(const half8_t*)&Kc[(kb * 32 + (lane & 31)) * KROW + ks * 16 + hi * 8];
+            __builtin_amdgcn_sched_barrier(0);
+            auto qk = [&](const int b, float16_t (&sc)[2]) {
+                sc[0] = (float16_t){0};
+                sc[1] = (float16_t){0};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb) sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kb][ks], qf[b][ks], sc[kb], 0, 0, 0);
+            };
+            auto tailmask = [&](float16_t (&sc)[2]) {
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (kt + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= g.Lk) sc[kb][r] = -INFINITY;
+            };
+            // tile max and the (rare) move of the running max — the code of the default path, on one block's scores
+            auto maxrare = [&](const int b, float16_t (&sc)[2]) {
+                float tmax = sc[0][0];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tmax = __builtin_fmaxf(__builtin_fmaxf(tmax, sc[0][r]), sc[1][r]);
+                if (MSLOT ? (kt == 0 || __any(tmax > FA_THR)) : __any(tmax > m_run[b] + FA_THR)) {
+                    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+                    float alpha;
+                    if constexpr (MSLOT) {
+                        const float m_new = fminf((float)(_Float16)fminf(m_run[b] + (kt == 0 ? tmax : fmaxf(tmax, 0.f)), 65504.f), 65504.f);
+                        const float delta = m_new - m_run[b];
+                        alpha             = __builtin_amdgcn_exp2f(-delta);
+                        m_run[b]          = m_new;
+#pragma unroll
+                        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) sc[kb][r] -= delta;
+                        if (hi) qf[b][KS - 1][0] = (_Float16)(-m_new);
+                    } else {
+                        const float m_new = fmaxf(m_run[b], tmax);
+                        alpha             = __builtin_amdgcn_exp2f(m_run[b] - m_new);
+                        m_run[b]          = m_new;
+                    }
+                    l_run[b] *= alpha;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row  = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        const float ar = __shfl(alpha, row, 64);
+#pragma unroll
+                        for (int nb = 0; nb < NDV; ++nb) o[b][nb][r] *= ar;
+                    }
+                }
+            };
+            auto expcvt = [&](const int b, float16_t (&sc)[2]) {
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sc[kb][r] = __builtin_amdgcn_exp2f(MSLOT ? sc[kb][r] : sc[kb][r] - m_run[b]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int kb = t >> 1, rb = (t & 1) * 8;
+#pragma unroll
+                    for (int j = 0; j < 8; j += 2) {
+                        const half2_t h2 = __builtin_convertvector((float2_t){sc[kb][rb + j], sc[kb][rb + j + 1]}, half2_t);
+                        pa[b][t][j]     = h2[0];
+                        pa[b][t][j + 1] = h2[1];
+                    }
+                }
+            };
+            qk(0, s0);
+            if (TAIL) tailmask(s0);
+            maxrare(0, s0);
+            // ---- region A: QK^T of block 1, the exponentials / f16 packing of block 0 in its gaps
+            qk(1, s1);
+            expcvt(0, s0);
+            // pin block 0's P here: left alone, the compiler sinks the (side-effect-free) exponentials down to their first user, the P V region
+#pragma unroll
+            for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(pa[0][t]));
+#pragma unroll
+            for (int i = 0; i < 2 * KS; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x400, 6, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+            }
+            if (TAIL) tailmask(s1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) vread(i / NDV, i % NDV, vq0[i], vq1[i]);  // in flight during block 1's max chain
+            __builtin_amdgcn_sched_barrier(0);
+            maxrare(1, s1);
+            // ---- regions B + C: P V of block 0 with block 1's exponentials in its gaps, then P V of block 1 (the fragment ring runs through both)
+            expcvt(1, s1);
+            constexpr int NFR = 4 * NDV;
+#pragma unroll
+            for (int k = 0; k < 2 * NFR; ++k) {
+                const int b = k / NFR, i = k % NFR, t = i / NDV, nb = i % NDV;
+                const half4_t v0 = vq0[k & 3], v1 = vq1[k & 3];
+                const half8_t vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                o[b][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa[b][t], vf, o[b][nb], 0, 0, 0);
+                if (k + 4 < 2 * NFR) vread(((k + 4) % NFR) / NDV, ((k + 4) % NFR) % NDV, vq0[k & 3], vq1[k & 3]);
+            }
+#pragma unroll
+            for (int k = 0; k < 2 * NFR; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (k < NFR) {
+                    __builtin_amdgcn_sched_group_barrier(0x400, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                }
+                if (k + 4 < 2 * NFR) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            }
+        } else {
 #pragma unroll
         for (int b = 0; b < QB; ++b) {
             float16_t s[2];
@@ -566,6 +690,7 @@ __global__ __launch_bounds__(256, QB == 2 ? (DKP <= 96 ? 2 : 1) : (DKP <= 64 ? (
                 for (int b = 0; b < QB; ++b) o[b][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa[b][t], vf, o[b][nb], 0, 0, 0);
             }
         }
+        }  // !OVL
         if (FAST) {
             __syncthreads();  // tile kt+64 is complete in the other buffer; everybody is done reading this one
             if (ABL != 2) buf ^= 1;
@@ -1089,6 +1214,8 @@ static int g_flash_vpf = 31;  // option "flash_vpf": head-dim classes (1: d <= 4
 void flash_attn_set_vpf(int v) { g_flash_vpf = v; }
 static int g_flash_vtr = 31;  // option "flash_vtr": head-dim classes (bits as flash_vpf) whose prefetching kernel keeps V row-major in LDS and reads it with ds_read_b64_tr_b16 (0 = the transposed tile of rounds 1-3)
 void flash_attn_set_vtr(int v) { g_flash_vtr = v; }
+static int g_flash_ovl = 1;  // option "flash_ovl": 1 = the two-block d = 40 kernel with one block's softmax issued inside the other block's MFMAs; 2 = also the other d <= 48 launches (that variant has not run on a GPU yet); 0 = phase-by-phase order
+void flash_attn_set_ovl(int v) { g_flash_ovl = v; }
 static int g_flash_pp_min_tiles = 4;  // option "flash_pp_min_tiles": key tiles (64 keys) from which the ping-pong pipeline has a steady state worth its prologue
 void flash_attn_set_pp_min_tiles(int v) { g_flash_pp_min_tiles = v; }
 
@@ -1185,6 +1312,14 @@ void launch_flash_attn(hipStream_t s, const FlashOut& out, const View4& q, const
             k_flash_pp<96, 3, false><<<grid, 512, 0, s>>>(g);
         else
             k_flash_pp<128, 4, false><<<grid, 512, 0, s>>>(g);
+        return;
+    }
+    if (qb2 && (g_flash_vpf & 1) && (g_flash_vtr & 1) && g_flash_ovl && D == 40 && g_flash_mslot) {
+        k_flash_attn<48, 2, true, 0, true, 2, true, true, true><<<grid, 256, 0, s>>>(g);
+        return;
+    }
+    if (qb2 && (g_flash_vpf & 1) && (g_flash_vtr & 1) && g_flash_ovl >= 2) {
+        k_flash_attn<48, 2, true, 0, false, 2, true, true, true><<<grid, 256, 0, s>>>(g);
         return;
     }
     if (qb2 && (g_flash_vpf & 1) && (g_flash_vtr & 1)) {
