@@ -30,6 +30,14 @@ if len(sys.argv) > 1 and sys.argv[1] == "ovl":  # default kernels against the ov
     base, ovl = {"flash_ovl": 0}, {"flash_ovl": 1}
     sd.backend_set_option("flash_vtr", 31)
     VARIANTS = [("warm", base), ("base", base), ("ovl", ovl), ("base", base), ("ovl", ovl)]
+if len(sys.argv) > 1 and sys.argv[1] == "nsel":  # select-free staging (flash_nsel; compiled at the end of round 3, never run): d = 40 two-block, d = 64, d = 128
+    base, ns = {"flash_nsel": 0}, {"flash_nsel": 1}
+    sd.backend_set_option("flash_vtr", 31)
+    VARIANTS = [("warm", base), ("base", base), ("nsel", ns), ("base", base), ("nsel", ns)]
+if len(sys.argv) > 1 and sys.argv[1] == "ovl2":  # the overlapped order in the d <= 48 launches without the max slot (flash_ovl = 2, never run): use with d = 32 / 48 cases
+    base, o2 = {"flash_ovl": 1}, {"flash_ovl": 2}
+    sd.backend_set_option("flash_vtr", 31)
+    VARIANTS = [("warm", base), ("base", base), ("ovl2", o2), ("base", base), ("ovl2", o2)]
 ONLY = sys.argv[2] if len(sys.argv) > 2 else ""  # substring filter on the case labels
 
 
@@ -68,7 +76,8 @@ def case(label, d, Lq, Lk, HN):
     sd.backend_set_option("flash_pp", 0)
     sd.backend_set_option("flash_qb2", 1)
     sd.backend_set_option("flash_vpf", 31)
-    sd.backend_set_option("flash_ovl", 0)
+    sd.backend_set_option("flash_ovl", 1)
+    sd.backend_set_option("flash_nsel", 0)
     k16, v16 = k.astype(np.float16).astype(np.float64), v.astype(np.float16).astype(np.float64)
     worst = 0.0
     r2 = np.random.default_rng(1)
@@ -96,6 +105,9 @@ if __name__ == "__main__":
     ok &= case("sd35 joint d64 L4250 HN76", 64, 4250, 4250, 76)
     ok &= case("flux d128 L4352 HN24", 128, 4352, 4352, 24)
     ok &= case("tail d40 L2048 Lk1000 HN128", 40, 2048, 1000, 128)
+    ok &= case("d48 L2048 Lk2048 HN128", 48, 2048, 2048, 128)
+    ok &= case("d32 L2048 Lk1000 HN128", 32, 2048, 1000, 128)
+    ok &= case("tail d128 L2048 Lk1000 HN48", 128, 2048, 1000, 48)
     ok &= case("ragged d40 Lq1000 Lk333 HN64", 40, 1000, 333, 64)
     ok &= case("ragged d64 Lq300 Lk200 HN256", 64, 300, 200, 256)
     print("ALL OK" if ok else "SOME FAILED")

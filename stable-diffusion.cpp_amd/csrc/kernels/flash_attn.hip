@@ -103,10 +103,16 @@ constexpr int fa_vtr_stride(int ndv) {
 // variants, bit-identical outputs): d = 40, L = 4096: 601 -> 582 us; Lq = 2048, Lk = 1000 (ragged last tile): 111 -> 105 us.  The gain is small because
 // the kernel is bound by its instruction ISSUE (one v_exp_f32 per score), not by the order: a SIMD spends ~4 cycles per issued instruction whichever
 // wave it comes from, so what overlap can win is only the matrix pipe's own 32-cycle occupancy.
-template <int DKP, int NDV, bool FAST, int ABL = 0, bool MSLOT = false, int QB = 1, bool VPF = false, bool VTR = false, bool OVL = false>
+// NSEL (FAST; option "flash_nsel", EXPERIMENT compiled at the end of round 3 with no GPU time left — default off until it has run): staging without
+// per-element selects.  The default lstore zeroes every chunk that is not real data with v_cndmask (4 per 16-byte chunk, K and V: 32 VALU per
+// thread per tile at d = 128, in a loop that is VALU-issue bound).  Here chunks that fetch nothing (the padding chunk of d = 40 / 80 rows) point their
+// buffer offset beyond num_records, so the load itself returns zeros, and full tiles (every key < Lk; a wave-uniform test) are stored as loaded;
+// only the ragged last tile takes the select path.
+template <int DKP, int NDV, bool FAST, int ABL = 0, bool MSLOT = false, int QB = 1, bool VPF = false, bool VTR = false, bool OVL = false, bool NSEL = false>
 __global__ __launch_bounds__(256, QB == 2 ? (DKP <= 96 ? 2 : 1) : (DKP <= 64 ? (VPF ? 2 : FA_OCC_SMALL) : (DKP <= 128 ? 2 : 1))) void k_flash_attn(FAArgs g) {
     static_assert(QB == 1 || FAST, "two query blocks per wave: FAST staging only");
     static_assert(!OVL || (QB == 2 && DKP == 48 && NDV == 2 && VPF && FAST && ABL == 0), "overlapped issue order: the two-block d <= 48 kernel only");
+    static_assert(!NSEL || FAST, "select-free staging: FAST staging only");
     static_assert(!VTR || FAST, "row-major V tiles: FAST staging only");
     constexpr int VRS  = fa_vtr_stride(NDV);             // VTR: V tile row stride (halfs)
     constexpr int VT_H = VTR ? FA_KT * VRS : NDV * 32 * FA_VTS;  // halfs of one V tile
@@ -259,8 +265,8 @@ __global__ __launch_bounds__(256, QB == 2 ? (DKP <= 96 ? 2 : 1) : (DKP <= 64 ? (
         kkey[c]  = (e < FA_KT * DCH && ch < nd8) ? key : FA_KT;
         kone[c]  = e < FA_KT * DCH && ch == nd8;
         vkey_[c] = (e < FA_KT * DCH && vch < nd8) ? vkey : FA_KT;
-        koff[c]  = kkey[c] < FA_KT ? (uint32_t)key * (uint32_t)g.k_nb1 + (uint32_t)ch * 16u : 0u;
-        voff[c]  = vkey_[c] < FA_KT ? (uint32_t)vkey * (uint32_t)g.v_nb1 + (uint32_t)vch * 16u : 0u;
+        koff[c]  = kkey[c] < FA_KT ? (uint32_t)key * (uint32_t)g.k_nb1 + (uint32_t)ch * 16u : (NSEL ? 0x7fffff00u : 0u);  // NSEL: out of range -> zeros
+        voff[c]  = vkey_[c] < FA_KT ? (uint32_t)vkey * (uint32_t)g.v_nb1 + (uint32_t)vch * 16u : (NSEL ? 0x7fffff00u : 0u);
     }
     // registers <- global.  BUFFER loads: uniform descriptor (one head's K / V rows, num_records = Lk rows: keys beyond Lk read as zeros for
     // free), per-lane 32-bit offsets that never change, the tile offset in an SGPR — no per-tile address arithmetic and NOTHING touches the
@@ -283,6 +289,25 @@ __global__ __launch_bounds__(256, QB == 2 ? (DKP <= 96 ? 2 : 1) : (DKP <= 64 ? (
         _Float16* ks = Ks + buf * TILE_H;
         _Float16* vt = Vt + buf * TILE_H;
         const int left = g.Lk - kt;
+        if constexpr (NSEL) {
+            if (left >= FA_KT) {  // wave-uniform: a full tile is stored as loaded (padding chunks were read as zeros by the range check)
+                asm volatile("" ::: "memory");  // keeps this a branch: if-converted, the two paths merge back into per-element selects
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    const int e = threadIdx.x + c * 256;
+                    if (e < FA_KT * DCH) {
+                        const int key = e / DCH, ch = e - key * DCH;
+                        half8_t kv = kreg[c], vv = vreg[c];
+                        if (MSLOT && kone[c]) kv[0] = (_Float16)1.0f;
+                        if (ones_in_tile && ch == nd8) vv[0] = (_Float16)1.0f;
+                        *(half8_t*)&ks[key * KROW + ch * 8] = kv;
+                        static_assert(!NSEL || VTR, "select-free staging is written for the row-major V tile");
+                        *(half8_t*)&vt[key * VRS + ch * 8] = vv;
+                    }
+                }
+                return;
+            }
+        }
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int e = threadIdx.x + c * 256;
@@ -1216,6 +1241,8 @@ static int g_flash_vtr = 31;  // option "flash_vtr": head-dim classes (bits as f
 void flash_attn_set_vtr(int v) { g_flash_vtr = v; }
 static int g_flash_ovl = 1;  // option "flash_ovl": 1 = the two-block d = 40 kernel with one block's softmax issued inside the other block's MFMAs; 2 = also the other d <= 48 launches (that variant has not run on a GPU yet); 0 = phase-by-phase order
 void flash_attn_set_ovl(int v) { g_flash_ovl = v; }
+static int g_flash_nsel = 0;  // option "flash_nsel": 1 = select-free staging in the d = 40 two-block, d = 64 and d = 128 kernels (experiment, has not run on a GPU yet)
+void flash_attn_set_nsel(int v) { g_flash_nsel = v; }
 static int g_flash_pp_min_tiles = 4;  // option "flash_pp_min_tiles": key tiles (64 keys) from which the ping-pong pipeline has a steady state worth its prologue
 void flash_attn_set_pp_min_tiles(int v) { g_flash_pp_min_tiles = v; }
 
@@ -1315,7 +1342,17 @@ void launch_flash_attn(hipStream_t s, const FlashOut& out, const View4& q, const
         return;
     }
     if (qb2 && (g_flash_vpf & 1) && (g_flash_vtr & 1) && g_flash_ovl && D == 40 && g_flash_mslot) {
-        k_flash_attn<48, 2, true, 0, true, 2, true, true, true><<<grid, 256, 0, s>>>(g);
+        if (g_flash_nsel)
+            k_flash_attn<48, 2, true, 0, true, 2, true, true, true, true><<<grid, 256, 0, s>>>(g);
+        else
+            k_flash_attn<48, 2, true, 0, true, 2, true, true, true><<<grid, 256, 0, s>>>(g);
+        return;
+    }
+    if (g_flash_nsel && !qb2 && fast && (D == 64 || D == 128) && (g_flash_vpf & (D == 64 ? 2 : 8)) && (g_flash_vtr & (D == 64 ? 2 : 8))) {
+        if (D == 64)
+            k_flash_attn<64, 2, true, 0, false, 1, true, true, false, true><<<grid, 256, 0, s>>>(g);
+        else
+            k_flash_attn<128, 4, true, 0, false, 1, true, true, false, true><<<grid, 256, 0, s>>>(g);
         return;
     }
     if (qb2 && (g_flash_vpf & 1) && (g_flash_vtr & 1) && g_flash_ovl >= 2) {
