@@ -35,7 +35,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "nsel":  # select-free staging (flash_ns
     sd.backend_set_option("flash_vtr", 31)
     VARIANTS = [("warm", base), ("base", base), ("nsel", ns), ("base", base), ("nsel", ns)]
 if len(sys.argv) > 1 and sys.argv[1] == "ovl2":  # the overlapped order in the d <= 48 launches without the max slot (flash_ovl = 2, never run): use with d = 32 / 48 cases
-    base, o2 = {"flash_ovl": 1}, {"flash_ovl": 2}
+    base, o2 = {"flash_ovl": 1, "flash_qb2": 2}, {"flash_ovl": 2, "flash_qb2": 2}
     sd.backend_set_option("flash_vtr", 31)
     VARIANTS = [("warm", base), ("base", base), ("ovl2", o2), ("base", base), ("ovl2", o2)]
 ONLY = sys.argv[2] if len(sys.argv) > 2 else ""  # substring filter on the case labels
