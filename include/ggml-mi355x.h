@@ -128,7 +128,8 @@ GGML_MI355X_API int ggml_backend_mi355x_get_kernel_timings(struct ggml_backend_m
  * least 32-channel blocks per K slice when the window kernel splits K);
  * flash attention: "flash_vtr" (31: bit per head-dim class — V tiles row-major in LDS, fragments by ds_read_b64_tr_b16; 0 = transposing staging pass),
  * "flash_ovl" (1: the two-block d = 40 kernel issues one block's softmax inside the other block's MFMAs; 2: also the other d <= 48 launches; 0: off),
- * "flash_nsel" (0; 1 = select-free K / V staging — experiment that has not run on a GPU yet),
+ * "flash_nsel" (0; 1 = select-free K / V staging — experiment that has not run on a GPU yet), "flash_short" (0; 1 = register-resident K / V
+ * kernel for Lk <= 96, d <= 64 — experiment that has not run on a GPU yet),
  * "flash_qb2" (1: two query blocks per wave for d <= 48), "flash_pp" (0; 1 = the 8-wave ping-pong kernel for 64 < d <= 96,
  * 2 = wherever it is legal: measured slower or equal, kept for A/B runs), "flash_pp_min_tiles" (4).
  * Wrong-result timing ablations exist only in builds with -DMI355X_EXPERIMENTS ("flash_ablate"). */

@@ -38,6 +38,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "ovl2":  # the overlapped order in the d
     base, o2 = {"flash_ovl": 1, "flash_qb2": 2}, {"flash_ovl": 2, "flash_qb2": 2}
     sd.backend_set_option("flash_vtr", 31)
     VARIANTS = [("warm", base), ("base", base), ("ovl2", o2), ("base", base), ("ovl2", o2)]
+if len(sys.argv) > 1 and sys.argv[1] == "short":  # k_flash_short (K / V register-resident, Lk <= 96, d <= 64; never run): use with the Lk77 cases
+    base, sh = {"flash_short": 0}, {"flash_short": 1}
+    sd.backend_set_option("flash_vtr", 31)
+    VARIANTS = [("warm", base), ("base", base), ("short", sh), ("base", base), ("short", sh)]
 ONLY = sys.argv[2] if len(sys.argv) > 2 else ""  # substring filter on the case labels
 
 
@@ -78,6 +82,7 @@ def case(label, d, Lq, Lk, HN):
     sd.backend_set_option("flash_vpf", 31)
     sd.backend_set_option("flash_ovl", 1)
     sd.backend_set_option("flash_nsel", 0)
+    sd.backend_set_option("flash_short", 0)
     k16, v16 = k.astype(np.float16).astype(np.float64), v.astype(np.float16).astype(np.float64)
     worst = 0.0
     r2 = np.random.default_rng(1)
@@ -108,6 +113,9 @@ if __name__ == "__main__":
     ok &= case("d48 L2048 Lk2048 HN128", 48, 2048, 2048, 128)
     ok &= case("d32 L2048 Lk1000 HN128", 32, 2048, 1000, 128)
     ok &= case("tail d128 L2048 Lk1000 HN48", 128, 2048, 1000, 48)
+    ok &= case("short d40 Lq1000 Lk77 HN16", 40, 1000, 77, 16)
+    ok &= case("short d64 Lq333 Lk96 HN40", 64, 333, 96, 40)
+    ok &= case("short d16 Lq4096 Lk1 HN8", 16, 4096, 1, 8)
     ok &= case("ragged d40 Lq1000 Lk333 HN64", 40, 1000, 333, 64)
     ok &= case("ragged d64 Lq300 Lk200 HN256", 64, 300, 200, 256)
     print("ALL OK" if ok else "SOME FAILED")

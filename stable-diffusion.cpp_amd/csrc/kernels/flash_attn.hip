@@ -15,6 +15,7 @@
 // and reading V with the same permutation.
 // Staging is split (cdna_hip_programming.md T14): the 16-byte global loads of tile t+1 are issued into registers
 // BEFORE the MFMAs of tile t and written to LDS after the next barrier, so HBM/L2 latency hides under compute.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
@@ -44,6 +45,7 @@ struct FAArgs {
     int q_vec;   // Q rows are f32 d-contiguous, 16-byte aligned, D % 4 == 0 -> coalesced float4 staging through LDS
     int vec_ok;  // K and V rows are d-contiguous, 16-byte aligned, D % 8 == 0 -> 128-bit staging loads
     float scale_log2e;
+    int qi;      // k_flash_short: 32-query blocks per wave
 };
 
 // FAST: K and V are f16, d-contiguous and 16-byte aligned (the FLASH_ATTN_EXT node as the reference builds it) -> 128-bit
@@ -763,6 +765,156 @@ __global__ __launch_bounds__(256, QB == 2 ? (DKP <= 96 ? 2 : 1) : (DKP <= 64 ? (
 }
 
 // =====================================================================================================================================
+// k_flash_short — attention onto a SHORT key sequence (Lk <= 96: the 77 text tokens every SD1.x / SDXL cross-attention reads), d <= 64.
+// EXPERIMENT written at the end of round 3 with no GPU time left: option "flash_short", default 0, has not run on a GPU yet
+// (scripts/flash_check.py short is its first call).
+// Why: the tile kernel spends a cross-attention launch on fixed costs — per 128 queries one workgroup stages Q through LDS, stages two K / V tiles
+// (the second holds 13 valid keys), and passes five barriers for 28 MFMAs: 80 us per SD1.5 launch at the 64x64 level (16 launches per step) for
+// 126 MB of traffic, i.e. 1.6 TB/s.  Here the whole K and V of one head live in REGISTERS: a workgroup stages the <= 96 keys once (K row-major,
+// V row-major for the transposing read), every wave pulls all its MFMA fragments (3 key blocks x KS K fragments, 6 k-steps x NDV V fragments) and
+// then walks g.qi blocks of 32 queries with no LDS access and no barrier: Q fragments straight from global memory (16 bytes per lane), one-pass
+// softmax (all keys are present: true row max, no running state), P as the A operand in the accumulator's key order as in k_flash_attn.
+template <int DKP, int NDV>
+__global__ __launch_bounds__(256, 2) void k_flash_short(FAArgs g) {
+    constexpr int KS   = DKP / 16;
+    constexpr int KROW = DKP + 8;
+    constexpr int DCH  = DKP / 8;
+    constexpr int NKB  = 3;             // key blocks of 32
+    constexpr int NKT  = 2 * NKB;       // P V k-steps of 16 keys
+    constexpr int NK   = 32 * NKB;      // keys held
+    constexpr int VRS  = fa_vtr_stride(NDV);
+    constexpr int VCH  = NDV * 4;       // 8-wide chunks per V row (all columns of the accumulator, zero beyond D)
+    __shared__ __attribute__((aligned(16))) _Float16 Ks[NK * KROW];
+    __shared__ __attribute__((aligned(16))) _Float16 Vs[NK * VRS];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int hi   = lane >> 5;
+    const int hn   = blockIdx.y;
+    const char* kbase = g.k + (int64_t)hn * g.k_nb2;
+    const char* vbase = g.v + (int64_t)hn * g.v_nb2;
+    const half8_t z8  = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int e = threadIdx.x; e < NK * DCH; e += 256) {
+        const int key = e / DCH, ch = e - key * DCH;
+        half8_t kv    = z8;
+        if (key < g.Lk && ch * 8 < g.D) kv = *(const half8_t*)(kbase + (int64_t)key * g.k_nb1 + ch * 16);
+        *(half8_t*)&Ks[key * KROW + ch * 8] = kv;
+    }
+    for (int e = threadIdx.x; e < NK * VCH; e += 256) {
+        const int key = e / VCH, ch = e - key * VCH;
+        half8_t vv    = z8;  // rows beyond Lk and columns beyond D are zeros: their P is 0, their products must stay finite
+        if (key < g.Lk && ch * 8 < g.DV) vv = *(const half8_t*)(vbase + (int64_t)key * g.v_nb1 + ch * 16);
+        *(half8_t*)&Vs[key * VRS + ch * 8] = vv;
+    }
+    __syncthreads();
+    half8_t kf[NKB][KS], vf[NKT][NDV];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) kf[kb][ks] = *(const half8_t*)&Ks[(kb * 32 + (lane & 31)) * KROW + ks * 16 + hi * 8];
+    const int vtr_lane = (4 * hi + ((lane & 15) >> 2)) * VRS + ((lane >> 4) & 1) * 16 + 4 * (lane & 3);
+#pragma unroll
+    for (int t = 0; t < NKT; ++t)
+#pragma unroll
+        for (int nb = 0; nb < NDV; ++nb) {
+            const _Float16* p = Vs + vtr_lane + t * 16 * VRS + nb * 32;
+            const half4_t a = lds_read_tr16(p), c = lds_read_tr16(p + 8 * VRS);
+            vf[t][nb] = (half8_t){a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]};
+        }
+
+    const int hh = g.H > 0 ? hn % g.H : hn, nn = g.H > 0 ? hn / g.H : 0;
+    char* obase       = g.dst ? (char*)g.dst + (int64_t)hh * g.dst_nb_h + (int64_t)nn * g.dst_nb_n : nullptr;
+    _Float16* obase16 = g.dst16 ? g.dst16 + (int64_t)nn * g.Lq * g.ld16 + (int64_t)hh * g.DV : nullptr;
+    const char* qhead = g.q + (int64_t)hn * g.q_nb2;
+    const int qwg     = 128 * g.qi;  // queries per workgroup
+    for (int it = 0; it < g.qi; ++it) {
+        const int q0 = blockIdx.x * qwg + (it * 4 + wave) * 32;  // wave-uniform
+        if (q0 >= g.Lq) break;
+        const int qi = min(q0 + (lane & 31), g.Lq - 1);
+        // ---- Q fragments (B operand of S^T = K Q^T): Q[qi][ks*16 + hi*8 .. +8], scaled by scale * log2(e), f16 — the values k_flash_attn stages
+        half8_t qf[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int d0 = ks * 16 + hi * 8;
+            float f[8]   = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (d0 < g.D) {
+                if (g.q_f16) {
+                    const half8_t v = *(const half8_t*)(qhead + (int64_t)qi * g.q_nb1 + d0 * 2);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) f[j] = (float)v[j];
+                } else {
+                    const float4 a = *(const float4*)(qhead + (int64_t)qi * g.q_nb1 + d0 * 4);
+                    const float4 c = *(const float4*)(qhead + (int64_t)qi * g.q_nb1 + d0 * 4 + 16);
+                    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w;
+                    f[4] = c.x; f[5] = c.y; f[6] = c.z; f[7] = c.w;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) qf[ks][j] = (_Float16)(f[j] * g.scale_log2e);
+        }
+        float16_t sc[NKB];
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) sc[kb] = (float16_t){0};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kb][ks], qf[ks], sc[kb], 0, 0, 0);
+        // this lane: query (lane & 31), keys kb*32 + (r&3) + 8*(r>>2) + 4*hi
+        float m = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= g.Lk) sc[kb][r] = -INFINITY;
+                m = fmaxf(m, sc[kb][r]);
+            }
+        m = fmaxf(m, __shfl_xor(m, 32, 64));  // key 0 is always present: finite
+        float psum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                sc[kb][r] = __builtin_amdgcn_exp2f(sc[kb][r] - m);
+                psum += sc[kb][r];
+            }
+        half8_t pa[NKT];
+#pragma unroll
+        for (int t = 0; t < NKT; ++t) {
+            const int kb = t >> 1, rb = (t & 1) * 8;
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+                const half2_t h2 = __builtin_convertvector((float2_t){sc[kb][rb + j], sc[kb][rb + j + 1]}, half2_t);
+                pa[t][j]     = h2[0];
+                pa[t][j + 1] = h2[1];
+            }
+        }
+        float16_t o[NDV];
+#pragma unroll
+        for (int nb = 0; nb < NDV; ++nb) o[nb] = (float16_t){0};
+#pragma unroll
+        for (int t = 0; t < NKT; ++t)
+#pragma unroll
+            for (int nb = 0; nb < NDV; ++nb) o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa[t], vf[t][nb], o[nb], 0, 0, 0);
+        const float l_tot = psum + __shfl_xor(psum, 32, 64);
+        const float inv   = 1.0f / l_tot;  // >= 1 term equal to 1
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row  = (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const float ir = __shfl(inv, row, 64);
+            const int q    = q0 + row;
+            if (q >= g.Lq) continue;
+#pragma unroll
+            for (int nb = 0; nb < NDV; ++nb) {
+                const int d = nb * 32 + (lane & 31);
+                if (d >= g.DV) continue;
+                const float val = o[nb][r] * ir;
+                if (obase) *(float*)(obase + (int64_t)q * g.dst_nb_q + d * 4) = val;
+                if (obase16) obase16[(int64_t)q * g.ld16 + d] = (_Float16)val;
+            }
+        }
+    }
+}
+
+// =====================================================================================================================================
 // k_flash_pp — the PING-PONG kernel (round 3).  Why: in k_flash_attn every wave runs QK^T (MFMA) -> softmax (VALU) -> PV (MFMA) as one dependent
 // chain and all four waves of a workgroup move through those phases together; the counters (profiles/r03c_pmc_flash.txt) show the consequence:
 // matrix-pipe time + VALU time + LDS time add up to the whole kernel — the two pipes hardly ever work at the same moment.  Two query blocks per
@@ -1243,12 +1395,15 @@ static int g_flash_ovl = 1;  // option "flash_ovl": 1 = the two-block d = 40 ker
 void flash_attn_set_ovl(int v) { g_flash_ovl = v; }
 static int g_flash_nsel = 0;  // option "flash_nsel": 1 = select-free staging in the d = 40 two-block, d = 64 and d = 128 kernels (experiment, has not run on a GPU yet)
 void flash_attn_set_nsel(int v) { g_flash_nsel = v; }
+static int g_flash_short = 0;  // option "flash_short": 1 = k_flash_short for Lk <= 96, d <= 64 (experiment, has not run on a GPU yet)
+void flash_attn_set_short(int v) { g_flash_short = v; }
 static int g_flash_pp_min_tiles = 4;  // option "flash_pp_min_tiles": key tiles (64 keys) from which the ping-pong pipeline has a steady state worth its prologue
 void flash_attn_set_pp_min_tiles(int v) { g_flash_pp_min_tiles = v; }
 
 void launch_flash_attn(hipStream_t s, const FlashOut& out, const View4& q, const View4& k, const View4& v, float scale) {
     KScope ks_(s, KF_FLASH, 4.0 * (double)q.ne[1] * (double)k.ne[1] * (double)q.ne[2] * (double)q.ne[0], 0.0);  // 4 * Lq * Lk * (H*N) * d
     FAArgs g;
+    g.qi = 0;
     g.q = (const char*)q.data;
     g.k = (const char*)k.data;
     g.v = (const char*)v.data;
@@ -1283,6 +1438,18 @@ void launch_flash_attn(hipStream_t s, const FlashOut& out, const View4& q, const
     }
     const int D     = g.D;
     const bool fast = g.vec_ok && g.kv_f16 && v.nb[0] == 2 && k.nb[0] == 2 && g.D == g.DV;
+    if (g_flash_short && fast && D <= 64 && g.Lk <= 96 && g.Lk >= 1 && (g.q_f16 || g.q_vec) && g.D % 8 == 0) {
+        // blocks of 32 queries per wave: enough to amortise the K / V fragment set-up, few enough to leave every CU >= 2 rounds of workgroups
+        const int64_t nblk = (int64_t)((g.Lq + 31) / 32) * q.ne[2];
+        g.qi  = (int)std::max<int64_t>(1, std::min<int64_t>(8, nblk / 4096));
+        g.grp = g.units = 0;
+        dim3 gs((unsigned)((g.Lq + 128 * g.qi - 1) / (128 * g.qi)), (unsigned)q.ne[2]);
+        if (D <= 48)
+            k_flash_short<48, 2><<<gs, 256, 0, s>>>(g);
+        else
+            k_flash_short<64, 2><<<gs, 256, 0, s>>>(g);
+        return;
+    }
     // two query blocks per wave (256 queries per workgroup) when the launch still gives every CU two workgroups' worth of work
     const int64_t wg256 = ((int64_t)(g.Lq + 255) / 256) * q.ne[2];
     const int NT        = (g.Lk + FA_KT - 1) / FA_KT;

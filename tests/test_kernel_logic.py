@@ -263,3 +263,113 @@ def test_flash_row_major_v_tile_transposing_read_fragments(ndv, dkp):
                     banks += [b, (b + 1) % 64]
                 assert len(set(banks)) == 64
     assert dkp <= ndv * 32 and (64 * VRS * 2) % 16 == 0
+
+
+def _mfma_32x32x16(A, B, C):
+    """v_mfma_f32_32x32x16_f16 on per-lane registers: A[l][j] = a[i = l & 31][k = 8 (l >> 5) + j], B[l][j] = b[k = 8 (l >> 5) + j][n = l & 31],
+    C[l][r] = c[i = (r & 3) + 8 (r >> 2) + 4 (l >> 5)][n = l & 31] (the layouts every MFMA kernel of this repo is written against)."""
+    a = np.zeros((32, 16), np.float64)
+    b = np.zeros((16, 32), np.float64)
+    for l in range(64):
+        for j in range(8):
+            a[l & 31, 8 * (l >> 5) + j] = A[l, j]
+            b[8 * (l >> 5) + j, l & 31] = B[l, j]
+    d = a @ b
+    out = C.copy()
+    for l in range(64):
+        for r in range(16):
+            out[l, r] += d[(r & 3) + 8 * (r >> 2) + 4 * (l >> 5), l & 31]
+    return out
+
+
+@pytest.mark.parametrize("d,Lq,Lk", [(40, 70, 77), (64, 33, 96), (16, 64, 1)])
+def test_flash_short_register_resident_kv_indexing(d, Lq, Lk):
+    """k_flash_short (attention onto <= 96 keys with the whole K / V in registers): the kernel's staging, fragment addresses, key mask, P packing
+    and output mapping, replayed lane by lane with the MFMA register layouts, must reproduce softmax(Q K^T / sqrt(d)) V."""
+    DKP = 48 if d <= 48 else 64
+    NDV, KS, KROW, NKB, NKT = 2, DKP // 16, DKP + 8, 3, 6
+    VRS = 96  # fa_vtr_stride(2)
+    rng = np.random.default_rng(d + Lk)
+    q = rng.standard_normal((Lq, d)).astype(np.float32)
+    k = rng.standard_normal((Lk, d)).astype(np.float16)
+    v = rng.standard_normal((Lk, d)).astype(np.float16)
+    scale = 1.0 / np.sqrt(d)
+    Ks = np.zeros(96 * KROW, np.float16)
+    Vs = np.zeros(96 * VRS, np.float16)
+    for e in range(96 * (DKP // 8)):
+        key, ch = divmod(e, DKP // 8)
+        if key < Lk and ch * 8 < d:
+            Ks[key * KROW + ch * 8: key * KROW + ch * 8 + 8] = k[key, ch * 8: ch * 8 + 8]
+    for e in range(96 * NDV * 4):
+        key, ch = divmod(e, NDV * 4)
+        if key < Lk and ch * 8 < d:
+            Vs[key * VRS + ch * 8: key * VRS + ch * 8 + 8] = v[key, ch * 8: ch * 8 + 8]
+    lanes = np.arange(64)
+    hi = lanes >> 5
+    kf = np.zeros((NKB, KS, 64, 8), np.float16)
+    for kb in range(NKB):
+        for ks in range(KS):
+            for l in range(64):
+                o = (kb * 32 + (l & 31)) * KROW + ks * 16 + hi[l] * 8
+                kf[kb, ks, l] = Ks[o:o + 8]
+    vtr_lane = (4 * hi + ((lanes & 15) >> 2)) * VRS + ((lanes >> 4) & 1) * 16 + 4 * (lanes & 3)
+
+    def tr16(addr):
+        out = np.zeros((64, 4), np.float16)
+        for l in range(64):
+            g16 = l & ~15
+            for j in range(4):
+                out[l, j] = Vs[addr[g16 + 4 * j + ((l & 15) >> 2)] + (l & 3)]
+        return out
+
+    vf = np.zeros((NKT, NDV, 64, 8), np.float16)
+    for t in range(NKT):
+        for nb in range(NDV):
+            p = vtr_lane + t * 16 * VRS + nb * 32
+            vf[t, nb, :, :4] = tr16(p)
+            vf[t, nb, :, 4:] = tr16(p + 8 * VRS)
+    out = np.full((Lq, d), np.nan, np.float32)
+    for q0 in range(0, Lq, 32):
+        qi = np.minimum(q0 + (lanes & 31), Lq - 1)
+        sc = np.zeros((NKB, 64, 16))
+        for ks in range(KS):
+            qf = np.zeros((64, 8), np.float16)
+            for l in range(64):
+                d0 = ks * 16 + hi[l] * 8
+                if d0 < d:
+                    qf[l] = (q[qi[l], d0:d0 + 8] * np.float32(scale * 1.4426950408889634)).astype(np.float16)
+            for kb in range(NKB):
+                sc[kb] = _mfma_32x32x16(kf[kb, ks].astype(np.float64), qf.astype(np.float64), sc[kb])
+        m = np.full(64, -np.inf)
+        for kb in range(NKB):
+            for r in range(16):
+                key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi
+                sc[kb][key >= Lk, r] = -np.inf
+                m = np.maximum(m, sc[kb][:, r])
+        m = np.maximum(m, m[lanes ^ 32])
+        psum = np.zeros(64)
+        for kb in range(NKB):
+            sc[kb] = np.exp2(sc[kb] - m[:, None])
+            psum += sc[kb].sum(1)
+        o = np.zeros((NDV, 64, 16))
+        for t in range(NKT):
+            kb, rb = t >> 1, (t & 1) * 8
+            pa = sc[kb][:, rb:rb + 8].astype(np.float16).astype(np.float64)
+            for nb in range(NDV):
+                o[nb] = _mfma_32x32x16(pa, vf[t, nb].astype(np.float64), o[nb])
+        inv = 1.0 / (psum + psum[lanes ^ 32])
+        for l in range(64):
+            for r in range(16):
+                row = (r & 3) + 8 * (r >> 2) + 4 * hi[l]
+                qq = q0 + row
+                if qq >= Lq:
+                    continue
+                for nb in range(NDV):
+                    dd = nb * 32 + (l & 31)
+                    if dd < d:
+                        out[qq, dd] = o[nb][l, r] * inv[row]
+    s = (q.astype(np.float64) @ k.astype(np.float64).T) * scale
+    p = np.exp(s - s.max(1, keepdims=True))
+    ref = (p / p.sum(1, keepdims=True)) @ v.astype(np.float64)
+    assert np.isfinite(out).all()
+    assert np.abs(out - ref).max() < 3e-3 * max(1.0, np.abs(ref).max())
