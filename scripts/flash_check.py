@@ -115,7 +115,7 @@ if __name__ == "__main__":
     ok &= case("tail d128 L2048 Lk1000 HN48", 128, 2048, 1000, 48)
     ok &= case("short d40 Lq1000 Lk77 HN16", 40, 1000, 77, 16)
     ok &= case("short d64 Lq333 Lk96 HN40", 64, 333, 96, 40)
-    ok &= case("short d16 Lq4096 Lk1 HN8", 16, 4096, 1, 8)
+    ok &= case("short d16 Lq4000 Lk65 HN8", 16, 4000, 65, 8)
     ok &= case("ragged d40 Lq1000 Lk333 HN64", 40, 1000, 333, 64)
     ok &= case("ragged d64 Lq300 Lk200 HN256", 64, 300, 200, 256)
     print("ALL OK" if ok else "SOME FAILED")

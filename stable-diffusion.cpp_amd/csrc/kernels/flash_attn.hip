@@ -765,17 +765,21 @@ __global__ __launch_bounds__(256, QB == 2 ? (DKP <= 96 ? 2 : 1) : (DKP <= 64 ? (
 }
 
 // =====================================================================================================================================
-// k_flash_short — attention onto a SHORT key sequence (Lk <= 96: the 77 text tokens every SD1.x / SDXL cross-attention reads), d <= 64.
+// k_flash_short — attention onto a SHORT key sequence (64 < Lk <= 96: the 77 text tokens every SD1.x / SDXL cross-attention reads), d <= 64.
 // EXPERIMENT written at the end of round 3 with no GPU time left: option "flash_short", default 0, has not run on a GPU yet
-// (scripts/flash_check.py short is its first call).
+// (scripts/flash_check.py short is its first call; its index logic is replayed lane by lane in tests/test_kernel_logic.py).
 // Why: the tile kernel spends a cross-attention launch on fixed costs — per 128 queries one workgroup stages Q through LDS, stages two K / V tiles
-// (the second holds 13 valid keys), and passes five barriers for 28 MFMAs: 80 us per SD1.5 launch at the 64x64 level (16 launches per step) for
-// 126 MB of traffic, i.e. 1.6 TB/s.  Here the whole K and V of one head live in REGISTERS: a workgroup stages the <= 96 keys once (K row-major,
-// V row-major for the transposing read), every wave pulls all its MFMA fragments (3 key blocks x KS K fragments, 6 k-steps x NDV V fragments) and
-// then walks g.qi blocks of 32 queries with no LDS access and no barrier: Q fragments straight from global memory (16 bytes per lane), one-pass
-// softmax (all keys are present: true row max, no running state), P as the A operand in the accumulator's key order as in k_flash_attn.
-template <int DKP, int NDV>
+// (the second holds 13 valid keys) and passes five barriers for 28 MFMAs: 80 us per SD1.5 launch at the 64x64 level (16 launches per step) for
+// 126 MB of traffic, i.e. 1.6 TB/s.  Here the whole K and V of one head live in REGISTERS: a workgroup stages the keys once (K row-major and
+// already multiplied by scale * log2(e), V row-major for the transposing read), every wave pulls all its MFMA fragments (3 key blocks x KS K
+// fragments, 6 k-steps x 2 V fragments) and then walks g.qi blocks of 32 queries with no LDS access and no barrier.  The block loop is written
+// for instruction count (these kernels are issue-bound): Q fragments are 16-byte buffer loads used as they arrive (the scale sits in K), the key
+// mask is the initial value of the last block's accumulator, the softmax is one pass (all keys present: true row max), P is normalised before it
+// is packed (each lane owns one query's scores: no cross-lane fetch of 1 / sum), and the output goes out through buffer stores whose address is a
+// loop-invariant per-lane offset (out of range for padded columns: dropped by the hardware) plus a wave-uniform row offset in an SGPR.
+template <int DKP, bool QF16, bool OUT16>
 __global__ __launch_bounds__(256, 2) void k_flash_short(FAArgs g) {
+    constexpr int NDV  = 2;
     constexpr int KS   = DKP / 16;
     constexpr int KROW = DKP + 8;
     constexpr int DCH  = DKP / 8;
@@ -784,6 +788,7 @@ __global__ __launch_bounds__(256, 2) void k_flash_short(FAArgs g) {
     constexpr int NK   = 32 * NKB;      // keys held
     constexpr int VRS  = fa_vtr_stride(NDV);
     constexpr int VCH  = NDV * 4;       // 8-wide chunks per V row (all columns of the accumulator, zero beyond D)
+    constexpr uint32_t OOR = 0x7fffff00u;  // a per-lane buffer offset beyond every num_records: loads return 0, stores are dropped
     __shared__ __attribute__((aligned(16))) _Float16 Ks[NK * KROW];
     __shared__ __attribute__((aligned(16))) _Float16 Vs[NK * VRS];
     const int lane = threadIdx.x & 63;
@@ -796,7 +801,11 @@ __global__ __launch_bounds__(256, 2) void k_flash_short(FAArgs g) {
     for (int e = threadIdx.x; e < NK * DCH; e += 256) {
         const int key = e / DCH, ch = e - key * DCH;
         half8_t kv    = z8;
-        if (key < g.Lk && ch * 8 < g.D) kv = *(const half8_t*)(kbase + (int64_t)key * g.k_nb1 + ch * 16);
+        if (key < g.Lk && ch * 8 < g.D) {
+            kv = *(const half8_t*)(kbase + (int64_t)key * g.k_nb1 + ch * 16);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) kv[j] = (_Float16)((float)kv[j] * g.scale_log2e);  // scores come out of the MFMA in log2 units
+        }
         *(half8_t*)&Ks[key * KROW + ch * 8] = kv;
     }
     for (int e = threadIdx.x; e < NK * VCH; e += 256) {
@@ -820,54 +829,72 @@ __global__ __launch_bounds__(256, 2) void k_flash_short(FAArgs g) {
             const half4_t a = lds_read_tr16(p), c = lds_read_tr16(p + 8 * VRS);
             vf[t][nb] = (half8_t){a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]};
         }
+    // this lane holds query (lane & 31) and, of key block kb, the keys kb*32 + (r&3) + 8*(r>>2) + 4*hi.  Keys >= Lk exist in the last block only
+    // (64 < Lk <= 96): -inf as the accumulator's initial value masks them without an instruction in the loop
+    float16_t negc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) negc[r] = (64 + (r & 3) + 8 * (r >> 2) + 4 * hi >= g.Lk) ? -INFINITY : 0.f;
 
-    const int hh = g.H > 0 ? hn % g.H : hn, nn = g.H > 0 ? hn / g.H : 0;
-    char* obase       = g.dst ? (char*)g.dst + (int64_t)hh * g.dst_nb_h + (int64_t)nn * g.dst_nb_n : nullptr;
-    _Float16* obase16 = g.dst16 ? g.dst16 + (int64_t)nn * g.Lq * g.ld16 + (int64_t)hh * g.DV : nullptr;
+    // ---- loop-invariant addressing
+    constexpr int QES = QF16 ? 2 : 4;
     const char* qhead = g.q + (int64_t)hn * g.q_nb2;
-    const int qwg     = 128 * g.qi;  // queries per workgroup
+    const auto rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)qhead, 0, (int)min((int64_t)(g.Lq - 1) * g.q_nb1 + (int64_t)g.D * QES, (int64_t)0x7ffffff0), 0x00020000);
+    const int hh = g.H > 0 ? hn % g.H : hn, nn = g.H > 0 ? hn / g.H : 0;
+    char* obytes;
+    int64_t ostride;
+    if (OUT16) {
+        obytes  = (char*)(g.dst16 + (int64_t)nn * g.Lq * g.ld16 + (int64_t)hh * g.DV);
+        ostride = g.ld16 * 2;
+    } else {
+        obytes  = (char*)g.dst + (int64_t)hh * g.dst_nb_h + (int64_t)nn * g.dst_nb_n;
+        ostride = g.dst_nb_q;
+    }
+    constexpr int OES = OUT16 ? 2 : 4;
+    const auto rsO = __builtin_amdgcn_make_buffer_rsrc((void*)obytes, 0, (int)min((int64_t)(g.Lq - 1) * ostride + (int64_t)g.DV * OES, (int64_t)0x7ffffff0), 0x00020000);
+    uint32_t ovoff[NDV];  // row 4*hi of a block, column nb*32 + (lane & 31); padded columns point out of range
+#pragma unroll
+    for (int nb = 0; nb < NDV; ++nb) {
+        const int d = nb * 32 + (lane & 31);
+        ovoff[nb]   = d < g.DV ? (uint32_t)(4 * hi) * (uint32_t)ostride + (uint32_t)d * OES : OOR;
+    }
+    const int qwg = 128 * g.qi;  // queries per workgroup
     for (int it = 0; it < g.qi; ++it) {
         const int q0 = blockIdx.x * qwg + (it * 4 + wave) * 32;  // wave-uniform
         if (q0 >= g.Lq) break;
-        const int qi = min(q0 + (lane & 31), g.Lq - 1);
-        // ---- Q fragments (B operand of S^T = K Q^T): Q[qi][ks*16 + hi*8 .. +8], scaled by scale * log2(e), f16 — the values k_flash_attn stages
+        const bool full  = q0 + 32 <= g.Lq;
+        const int rowl   = min(lane & 31, g.Lq - 1 - q0);  // a ragged last block reads its last valid row again (those results are not stored)
+        const int soffq  = q0 * (int)g.q_nb1;
+        // ---- Q fragments (B operand of S^T = K Q^T): Q[q][ks*16 + hi*8 .. +8] as f16, chunks beyond D read as zeros (offset out of range)
         half8_t qf[KS];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const int d0 = ks * 16 + hi * 8;
-            float f[8]   = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if (d0 < g.D) {
-                if (g.q_f16) {
-                    const half8_t v = *(const half8_t*)(qhead + (int64_t)qi * g.q_nb1 + d0 * 2);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) f[j] = (float)v[j];
-                } else {
-                    const float4 a = *(const float4*)(qhead + (int64_t)qi * g.q_nb1 + d0 * 4);
-                    const float4 c = *(const float4*)(qhead + (int64_t)qi * g.q_nb1 + d0 * 4 + 16);
-                    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w;
-                    f[4] = c.x; f[5] = c.y; f[6] = c.z; f[7] = c.w;
-                }
+            const int d0        = ks * 16 + hi * 8;
+            const uint32_t voff = d0 < g.D ? (uint32_t)rowl * (uint32_t)g.q_nb1 + (uint32_t)d0 * QES : OOR;
+            if constexpr (QF16) {
+                qf[ks] = __builtin_bit_cast(half8_t, __builtin_amdgcn_raw_buffer_load_b128(rsQ, (int)voff, soffq, 0));
+            } else {
+                const float4 a = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsQ, (int)voff, soffq, 0));
+                const float4 c = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsQ, (int)(voff == OOR ? OOR : voff + 16u), soffq, 0));
+                const half2_t h0 = __builtin_convertvector((float2_t){a.x, a.y}, half2_t), h1 = __builtin_convertvector((float2_t){a.z, a.w}, half2_t);
+                const half2_t h2 = __builtin_convertvector((float2_t){c.x, c.y}, half2_t), h3 = __builtin_convertvector((float2_t){c.z, c.w}, half2_t);
+                qf[ks] = (half8_t){h0[0], h0[1], h1[0], h1[1], h2[0], h2[1], h3[0], h3[1]};
             }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) qf[ks][j] = (_Float16)(f[j] * g.scale_log2e);
         }
         float16_t sc[NKB];
-#pragma unroll
-        for (int kb = 0; kb < NKB; ++kb) sc[kb] = (float16_t){0};
+        sc[0] = (float16_t){0};
+        sc[1] = (float16_t){0};
+        sc[2] = negc;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb) sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kb][ks], qf[ks], sc[kb], 0, 0, 0);
-        // this lane: query (lane & 31), keys kb*32 + (r&3) + 8*(r>>2) + 4*hi
-        float m = -INFINITY;
+        float m = sc[0][0];  // key 0 (block 0, r = 0) is never masked for hi = 0; the other half's partial max is merged below
 #pragma unroll
-        for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                if (kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= g.Lk) sc[kb][r] = -INFINITY;
-                m = fmaxf(m, sc[kb][r]);
-            }
-        m = fmaxf(m, __shfl_xor(m, 32, 64));  // key 0 is always present: finite
+        for (int r = 0; r < 16; ++r) {
+            m = __builtin_fmaxf(__builtin_fmaxf(m, sc[0][r]), sc[1][r]);  // v_max3_f32
+            m = __builtin_fmaxf(m, sc[2][r]);
+        }
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
         float psum = 0.f;
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb)
@@ -876,13 +903,14 @@ __global__ __launch_bounds__(256, 2) void k_flash_short(FAArgs g) {
                 sc[kb][r] = __builtin_amdgcn_exp2f(sc[kb][r] - m);
                 psum += sc[kb][r];
             }
+        const float inv = 1.0f / (psum + __shfl_xor(psum, 32, 64));  // >= one term equal to 1
         half8_t pa[NKT];
 #pragma unroll
         for (int t = 0; t < NKT; ++t) {
             const int kb = t >> 1, rb = (t & 1) * 8;
 #pragma unroll
             for (int j = 0; j < 8; j += 2) {
-                const half2_t h2 = __builtin_convertvector((float2_t){sc[kb][rb + j], sc[kb][rb + j + 1]}, half2_t);
+                const half2_t h2 = __builtin_convertvector((float2_t){sc[kb][rb + j] * inv, sc[kb][rb + j + 1] * inv}, half2_t);
                 pa[t][j]     = h2[0];
                 pa[t][j + 1] = h2[1];
             }
@@ -894,22 +922,24 @@ __global__ __launch_bounds__(256, 2) void k_flash_short(FAArgs g) {
         for (int t = 0; t < NKT; ++t)
 #pragma unroll
             for (int nb = 0; nb < NDV; ++nb) o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa[t], vf[t][nb], o[nb], 0, 0, 0);
-        const float l_tot = psum + __shfl_xor(psum, 32, 64);
-        const float inv   = 1.0f / l_tot;  // >= 1 term equal to 1
+        // ---- rows (r&3) + 8*(r>>2) + 4*hi of the block, column nb*32 + (lane & 31)
+        auto put = [&](const int r, const int nb, const uint32_t vo) {
+            const int soff = (q0 + (r & 3) + 8 * (r >> 2)) * (int)ostride;  // wave-uniform
+            if constexpr (OUT16)
+                __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(short, (_Float16)o[nb][r]), rsO, (int)vo, soff, 0);
+            else
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, o[nb][r]), rsO, (int)vo, soff, 0);
+        };
+        if (full) {  // wave-uniform: every row of the block exists
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row  = (r & 3) + 8 * (r >> 2) + 4 * hi;
-            const float ir = __shfl(inv, row, 64);
-            const int q    = q0 + row;
-            if (q >= g.Lq) continue;
+            for (int r = 0; r < 16; ++r)
 #pragma unroll
-            for (int nb = 0; nb < NDV; ++nb) {
-                const int d = nb * 32 + (lane & 31);
-                if (d >= g.DV) continue;
-                const float val = o[nb][r] * ir;
-                if (obase) *(float*)(obase + (int64_t)q * g.dst_nb_q + d * 4) = val;
-                if (obase16) obase16[(int64_t)q * g.ld16 + d] = (_Float16)val;
-            }
+                for (int nb = 0; nb < NDV; ++nb) put(r, nb, ovoff[nb]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int nb = 0; nb < NDV; ++nb) put(r, nb, q0 + (r & 3) + 8 * (r >> 2) + 4 * hi < g.Lq ? ovoff[nb] : OOR);
         }
     }
 }
@@ -1438,16 +1468,29 @@ void launch_flash_attn(hipStream_t s, const FlashOut& out, const View4& q, const
     }
     const int D     = g.D;
     const bool fast = g.vec_ok && g.kv_f16 && v.nb[0] == 2 && k.nb[0] == 2 && g.D == g.DV;
-    if (g_flash_short && fast && D <= 64 && g.Lk <= 96 && g.Lk >= 1 && (g.q_f16 || g.q_vec) && g.D % 8 == 0) {
+    if (g_flash_short && fast && D <= 64 && g.Lk <= 96 && g.Lk > 64 && (g.q_f16 || g.q_vec) && g.D % 8 == 0 && (g.dst != nullptr) != (g.dst16 != nullptr) &&
+        (int64_t)g.Lq * std::max<int64_t>(g.q_nb1, g.dst16 ? g.ld16 * 2 : dst_nb_q) < (int64_t)0x7ff00000) {
         // blocks of 32 queries per wave: enough to amortise the K / V fragment set-up, few enough to leave every CU >= 2 rounds of workgroups
         const int64_t nblk = (int64_t)((g.Lq + 31) / 32) * q.ne[2];
         g.qi  = (int)std::max<int64_t>(1, std::min<int64_t>(8, nblk / 4096));
         g.grp = g.units = 0;
         dim3 gs((unsigned)((g.Lq + 128 * g.qi - 1) / (128 * g.qi)), (unsigned)q.ne[2]);
+#define FS_CASE(DKP_)                                                          \
+    do {                                                                       \
+        if (g.q_f16 && g.dst16)                                                \
+            k_flash_short<DKP_, true, true><<<gs, 256, 0, s>>>(g);             \
+        else if (g.q_f16)                                                      \
+            k_flash_short<DKP_, true, false><<<gs, 256, 0, s>>>(g);            \
+        else if (g.dst16)                                                      \
+            k_flash_short<DKP_, false, true><<<gs, 256, 0, s>>>(g);            \
+        else                                                                   \
+            k_flash_short<DKP_, false, false><<<gs, 256, 0, s>>>(g);           \
+    } while (0)
         if (D <= 48)
-            k_flash_short<48, 2><<<gs, 256, 0, s>>>(g);
+            FS_CASE(48);
         else
-            k_flash_short<64, 2><<<gs, 256, 0, s>>>(g);
+            FS_CASE(64);
+#undef FS_CASE
         return;
     }
     // two query blocks per wave (256 queries per workgroup) when the launch still gives every CU two workgroups' worth of work

@@ -282,10 +282,11 @@ def _mfma_32x32x16(A, B, C):
     return out
 
 
-@pytest.mark.parametrize("d,Lq,Lk", [(40, 70, 77), (64, 33, 96), (16, 64, 1)])
+@pytest.mark.parametrize("d,Lq,Lk", [(40, 70, 77), (64, 33, 96), (16, 64, 65)])
 def test_flash_short_register_resident_kv_indexing(d, Lq, Lk):
-    """k_flash_short (attention onto <= 96 keys with the whole K / V in registers): the kernel's staging, fragment addresses, key mask, P packing
-    and output mapping, replayed lane by lane with the MFMA register layouts, must reproduce softmax(Q K^T / sqrt(d)) V."""
+    """k_flash_short (attention onto 65..96 keys with the whole K / V in registers): the kernel's staging (K carries the scale), fragment
+    addresses, key mask as accumulator init, one-pass softmax with P normalised before packing, and output mapping, replayed lane by lane with
+    the MFMA register layouts, must reproduce softmax(Q K^T / sqrt(d)) V."""
     DKP = 48 if d <= 48 else 64
     NDV, KS, KROW, NKB, NKT = 2, DKP // 16, DKP + 8, 3, 6
     VRS = 96  # fa_vtr_stride(2)
@@ -298,8 +299,8 @@ def test_flash_short_register_resident_kv_indexing(d, Lq, Lk):
     Vs = np.zeros(96 * VRS, np.float16)
     for e in range(96 * (DKP // 8)):
         key, ch = divmod(e, DKP // 8)
-        if key < Lk and ch * 8 < d:
-            Ks[key * KROW + ch * 8: key * KROW + ch * 8 + 8] = k[key, ch * 8: ch * 8 + 8]
+        if key < Lk and ch * 8 < d:  # K carries scale * log2(e)
+            Ks[key * KROW + ch * 8: key * KROW + ch * 8 + 8] = (k[key, ch * 8: ch * 8 + 8].astype(np.float32) * np.float32(scale * 1.4426950408889634)).astype(np.float16)
     for e in range(96 * NDV * 4):
         key, ch = divmod(e, NDV * 4)
         if key < Lk and ch * 8 < d:
@@ -328,46 +329,48 @@ def test_flash_short_register_resident_kv_indexing(d, Lq, Lk):
             p = vtr_lane + t * 16 * VRS + nb * 32
             vf[t, nb, :, :4] = tr16(p)
             vf[t, nb, :, 4:] = tr16(p + 8 * VRS)
+    negc = np.zeros((64, 16))  # key mask of the last block = the accumulator's initial value
+    for r in range(16):
+        negc[64 + (r & 3) + 8 * (r >> 2) + 4 * hi >= Lk, r] = -np.inf
     out = np.full((Lq, d), np.nan, np.float32)
-    for q0 in range(0, Lq, 32):
-        qi = np.minimum(q0 + (lanes & 31), Lq - 1)
-        sc = np.zeros((NKB, 64, 16))
-        for ks in range(KS):
-            qf = np.zeros((64, 8), np.float16)
-            for l in range(64):
-                d0 = ks * 16 + hi[l] * 8
-                if d0 < d:
-                    qf[l] = (q[qi[l], d0:d0 + 8] * np.float32(scale * 1.4426950408889634)).astype(np.float16)
+    with np.errstate(invalid="ignore"):
+        for q0 in range(0, Lq, 32):
+            rowl = np.minimum(lanes & 31, Lq - 1 - q0)
+            sc = np.zeros((NKB, 64, 16))
+            sc[2] = negc
+            for ks in range(KS):
+                qf = np.zeros((64, 8), np.float16)
+                for l in range(64):
+                    d0 = ks * 16 + hi[l] * 8
+                    if d0 < d:
+                        qf[l] = q[q0 + rowl[l], d0:d0 + 8].astype(np.float16)
+                for kb in range(NKB):
+                    sc[kb] = _mfma_32x32x16(kf[kb, ks].astype(np.float64), qf.astype(np.float64), sc[kb])
+            m = sc[0][:, 0].copy()
             for kb in range(NKB):
-                sc[kb] = _mfma_32x32x16(kf[kb, ks].astype(np.float64), qf.astype(np.float64), sc[kb])
-        m = np.full(64, -np.inf)
-        for kb in range(NKB):
-            for r in range(16):
-                key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi
-                sc[kb][key >= Lk, r] = -np.inf
-                m = np.maximum(m, sc[kb][:, r])
-        m = np.maximum(m, m[lanes ^ 32])
-        psum = np.zeros(64)
-        for kb in range(NKB):
-            sc[kb] = np.exp2(sc[kb] - m[:, None])
-            psum += sc[kb].sum(1)
-        o = np.zeros((NDV, 64, 16))
-        for t in range(NKT):
-            kb, rb = t >> 1, (t & 1) * 8
-            pa = sc[kb][:, rb:rb + 8].astype(np.float16).astype(np.float64)
-            for nb in range(NDV):
-                o[nb] = _mfma_32x32x16(pa, vf[t, nb].astype(np.float64), o[nb])
-        inv = 1.0 / (psum + psum[lanes ^ 32])
-        for l in range(64):
-            for r in range(16):
-                row = (r & 3) + 8 * (r >> 2) + 4 * hi[l]
-                qq = q0 + row
-                if qq >= Lq:
-                    continue
+                m = np.maximum(m, sc[kb].max(1))
+            m = np.maximum(m, m[lanes ^ 32])
+            psum = np.zeros(64)
+            for kb in range(NKB):
+                sc[kb] = np.exp2(sc[kb] - m[:, None])
+                psum += sc[kb].sum(1)
+            inv = 1.0 / (psum + psum[lanes ^ 32])
+            o = np.zeros((NDV, 64, 16))
+            for t in range(NKT):
+                kb, rb = t >> 1, (t & 1) * 8
+                pa = (sc[kb][:, rb:rb + 8] * inv[:, None]).astype(np.float16).astype(np.float64)  # each lane owns ONE query's scores
                 for nb in range(NDV):
-                    dd = nb * 32 + (l & 31)
-                    if dd < d:
-                        out[qq, dd] = o[nb][l, r] * inv[row]
+                    o[nb] = _mfma_32x32x16(pa, vf[t, nb].astype(np.float64), o[nb])
+            full = q0 + 32 <= Lq
+            for l in range(64):
+                for r in range(16):
+                    qq = q0 + (r & 3) + 8 * (r >> 2) + 4 * hi[l]
+                    if not full and qq >= Lq:
+                        continue
+                    for nb in range(NDV):
+                        dd = nb * 32 + (l & 31)
+                        if dd < d:
+                            out[qq, dd] = o[nb][l, r]
     s = (q.astype(np.float64) @ k.astype(np.float64).T) * scale
     p = np.exp(s - s.max(1, keepdims=True))
     ref = (p / p.sum(1, keepdims=True)) @ v.astype(np.float64)
