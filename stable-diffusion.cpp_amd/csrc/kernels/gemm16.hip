@@ -1521,8 +1521,7 @@ void launch_gn_stats(hipStream_t s, float* scale, float* shift, const float* x, 
     KScope ks_(s, KF_GN_STATS, 0.0, (double)hw * C * N * 4.0);  // algorithmic: ONE read of the activation
     const int cpg       = (int)((C + groups - 1) / groups);
     const int64_t cnt   = (int64_t)cpg * hw;
-    const bool full_grp = C % groups == 0 || true;  // the last group may be short: the kernels bound it by c1
-    const bool v4       = hw % 4 == 0 && (((uintptr_t)x) & 15) == 0 && full_grp;
+    const bool v4       = hw % 4 == 0 && (((uintptr_t)x) & 15) == 0;  // (a short last group is fine: the kernels bound it by c1)
     const unsigned grid = (unsigned)(N * groups);
     if (v4 && cnt <= 4 * 256 * 4)
         k_gn_stats_reg<256, 4><<<grid, 256, 0, s>>>(scale, shift, x, hw, (int)C, groups, cpg, eps, w, b);
