@@ -126,6 +126,7 @@ GGML_MI355X_API int ggml_backend_mi355x_get_kernel_timings(struct ggml_backend_m
  * "splitk_inkernel" (0: split-K combined by the last-arriving workgroup, 128-row tiles; measured slower) / "splitk_in_target" (320);
  * conv: "conv3w" (1: 3x3 / stride-1 convs on 16..128-wide maps on the LDS-window kernel), "conv3w_min_blocks" (8) / "conv3w_min_blocks_deep" (5:
  * least 32-channel blocks per K slice when the window kernel splits K);
+ * "gemm16_swp" (0; 1 = the 256-row Linear tiles with the accumulator transposed, 16-byte epilogue accesses — experiment that has not run on a GPU yet);
  * flash attention: "flash_vtr" (31: bit per head-dim class — V tiles row-major in LDS, fragments by ds_read_b64_tr_b16; 0 = transposing staging pass),
  * "flash_ovl" (1: the two-block d = 40 kernel issues one block's softmax inside the other block's MFMAs; 2: also the other d <= 48 launches; 0: off),
  * "flash_nsel" (0; 1 = select-free K / V staging — experiment that has not run on a GPU yet), "flash_short" (0; 1 = register-resident K / V

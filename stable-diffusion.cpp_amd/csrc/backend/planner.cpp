@@ -3122,6 +3122,7 @@ void planner_set_option(const char* key, int value) {
     else if (!strcmp(key, "flash_ovl")) flash_attn_set_ovl(value);
     else if (!strcmp(key, "flash_nsel")) flash_attn_set_nsel(value);
     else if (!strcmp(key, "flash_short")) flash_attn_set_short(value);
+    else if (!strcmp(key, "gemm16_swp")) gemm16_set_swp(value);
     else if (!strcmp(key, "flash_pp_min_tiles")) flash_attn_set_pp_min_tiles(value);
     else if (!strcmp(key, "conv3w")) conv3w_set(value);
     else if (!strcmp(key, "hoist_emb")) g_opt.hoist_emb = value;

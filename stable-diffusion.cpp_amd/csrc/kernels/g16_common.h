@@ -274,6 +274,93 @@ __device__ __forceinline__ void epi_dispatch_linear(const float16_t (&acc)[RB][C
     }
 }
 
+// ---- SWP (option "gemm16_swp", EXPERIMENT written at the end of round 3 with no GPU time left; default off, has not run on a GPU yet) ----
+// The Linear kernels of the big-token tiles instantiated with the MFMA operands swapped (as the conv path does): a 32x32 accumulator block then
+// holds D^T — lane = ROW (lane & 31) of the block, register r = COLUMN (r&3) + 8*(r>>2) + 4*hi — so a lane owns four CONSECUTIVE output features
+// of one token per register quad: bias, residual and result move as 16-byte (f32) / 8-byte (f16) accesses, one per four elements, and a ragged
+// last row tile is a per-lane predicate.  The D[row][col] layout needs one 4-byte (2-byte) access per element: at K = 320 the 160-element epilogue
+// of a wave issues more instructions than its 100-MFMA main loop.  What it costs: an access instruction touches 32 rows x 32
+// bytes instead of 2 rows x 128 bytes — whether the L2 merges the four quads of a 128-byte line is what the first GPU run has to show.
+// Serves: f32 (+bias, +residual), f16 rows (+GELU), GEGLU.  Everything else stays on the D[row][col] kernels (host-side choice, g16_swp_ok).
+enum { SWP_F32 = 0, SWP_F16 = 1, SWP_GEGLU = 2 };
+template <int MODE, int RB, int CB>
+__device__ __forceinline__ void epi_linear_swp(const float16_t (&acc)[RB][CB], const G16Args& g, int64_t row0, int col0, int wr, int wc, int lane) {
+    const int hi = lane >> 5, lr = lane & 31;
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        const int64_t row = row0 + wr * (RB * 32) + rb * 32 + lr;  // this lane's token
+        if (row >= g.R) continue;
+        if constexpr (MODE == SWP_GEGLU) {
+            static_assert(MODE != SWP_GEGLU || CB % 2 == 0, "GEGLU pairing needs an even number of column blocks per wave");
+#pragma unroll
+            for (int p = 0; p < CB / 2; ++p) {
+                const int gb  = col0 / 32 + wc * CB + 2 * p;                  // global 32-column block of the value half (see epi_geglu)
+                const int oc0 = ((gb >> 2) * 2 + ((gb & 3) >> 1)) * 32;      // first output column of this pair
+                if (oc0 >= g.geglu_inner) continue;
+                _Float16* orow = g.dst16 + row * g.ldd16 + oc0 + 4 * hi;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float4 bx = make_float4(0.f, 0.f, 0.f, 0.f), bg = bx;
+                    if (g.ep.bias) {
+                        bx = *(const float4*)(g.ep.bias + oc0 + 8 * q + 4 * hi);
+                        bg = *(const float4*)(g.ep.bias + g.geglu_inner + oc0 + 8 * q + 4 * hi);
+                    }
+                    const float bxs[4] = {bx.x, bx.y, bx.z, bx.w}, bgs[4] = {bg.x, bg.y, bg.z, bg.w};
+                    half4_t h;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float xv = acc[rb][2 * p][4 * q + j] * g.ep.scale + bxs[j], gv = acc[rb][2 * p + 1][4 * q + j] * g.ep.scale + bgs[j];
+                        h[j]           = (_Float16)(xv * act_apply<UN_GELU>(gv));
+                    }
+                    *(half4_t*)(orow + 8 * q) = h;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                const int cblk = col0 + (wc * CB + cb) * 32;
+                if (cblk >= g.C) continue;  // whole blocks only: C % 32 == 0 is a launch precondition
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c = cblk + 8 * q + 4 * hi;
+                    float4 b    = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (g.ep.bias) b = *(const float4*)(g.ep.bias + c);
+                    const float bs[4] = {b.x, b.y, b.z, b.w};
+                    if constexpr (MODE == SWP_F32) {
+                        float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (g.ep.residual) rv = *(const float4*)(g.ep.residual + row * g.ldd + c);  // the same lane stores these four elements below
+                        float4 o;
+                        o.x = acc[rb][cb][4 * q] * g.ep.scale + bs[0] + rv.x;
+                        o.y = acc[rb][cb][4 * q + 1] * g.ep.scale + bs[1] + rv.y;
+                        o.z = acc[rb][cb][4 * q + 2] * g.ep.scale + bs[2] + rv.z;
+                        o.w = acc[rb][cb][4 * q + 3] * g.ep.scale + bs[3] + rv.w;
+                        *(float4*)(g.dst + row * g.ldd + c) = o;
+                    } else {
+                        half4_t h;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            float v = acc[rb][cb][4 * q + j] * g.ep.scale + bs[j];
+                            if (g.ep.gelu) v = act_apply<UN_GELU>(v);
+                            h[j] = (_Float16)v;
+                        }
+                        *(half4_t*)(g.dst16 + row * g.ldd16 + c) = h;
+                    }
+                }
+            }
+        }
+    }
+}
+template <int RB, int CB>
+__device__ __forceinline__ void epi_dispatch_linear_swp(const float16_t (&acc)[RB][CB], const G16Args& g, int64_t row0, int col0, int wr, int wc, int lane) {
+    if (g.geglu_inner > 0) {
+        if constexpr (CB % 2 == 0) epi_linear_swp<SWP_GEGLU>(acc, g, row0, col0, wr, wc, lane);
+    } else if (g.dst16) {
+        epi_linear_swp<SWP_F16>(acc, g, row0, col0, wr, wc, lane);
+    } else {
+        epi_linear_swp<SWP_F32>(acc, g, row0, col0, wr, wc, lane);
+    }
+}
+
 // conv (D[oc][pos]): register r holds output channel ro(r) + 4*hi of the block, lanes run along output positions.
 // MODE 0: bias only, 1: + residual, 2: generic (ragged channel block)
 template <int MODE, int RB, int CB>

@@ -38,8 +38,9 @@ namespace mi355x {
 // the barrier both publishes stage kt+1 (each wave waited for its own DMA pieces first) and frees slot kt for the DMA of stage kt+4,
 // with two further stages (72 KB) in flight across it.  FLOP per DMA byte is 1.45x the 256x160 tile's (the LDS-DMA stream, ~23 B/clk/CU,
 // is what bounds these kernels: profiles/r02a_gemm_ablation_kernel_stats.csv).
-template <int BM, int BN, bool CONV, int BK, int NST, int WR, int WC, int PIPE = 0>
+template <int BM, int BN, bool CONV, int BK, int NST, int WR, int WC, int PIPE = 0, bool SWP = false>
 __global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g) {
+    static_assert(!SWP || !CONV, "SWP: the Linear kernels with the accumulator transposed (g16_common.h, epi_linear_swp)");
     constexpr int NW  = WR * WC;
     constexpr int RB  = BM / WR / 32;  // 32-row blocks per wave
     constexpr int CB  = BN / WC / 32;  // 32-col blocks per wave
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g
             for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
                 for (int cb = 0; cb < CB; ++cb) {
-                    if (CONV)
+                    if (CONV || SWP)
                         acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[cb], af[rb], acc[rb][cb], 0, 0, 0);  // D[oc][pos]
                     else
                         acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[rb], bf[cb], acc[rb][cb], 0, 0, 0);  // D[row][col]
@@ -316,7 +317,7 @@ __global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g
                 asm volatile("" ::"v"(a), "v"(b));
                 return;
             }
-            if (CONV)
+            if (CONV || SWP)
                 acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b, a, acc[rb][cb], 0, 0, 0);  // D[oc][pos]
             else
                 acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[rb][cb], 0, 0, 0);  // D[row][col]
@@ -572,7 +573,9 @@ __global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g
     }
 
     // ---- epilogue: one compact variant per workgroup (all conditions are launch- or workgroup-uniform)
-    if (!CONV) {
+    if constexpr (SWP) {
+        epi_dispatch_linear_swp(acc, g, row0, col0, wr, wc, lane);
+    } else if (!CONV) {
         epi_dispatch_linear<BM>(acc, g, row0, col0, wr, wc, lane);
     } else {
         const bool fullc = col0 + BN <= g.C;
@@ -666,6 +669,18 @@ static int g16_pick_tile(int64_t rows, int64_t M, bool geglu, bool conv, int spl
     return tile;
 }
 
+static int g_g16_swp = 0;  // option "gemm16_swp": 1 = big-token Linear tiles with the accumulator transposed (16-byte epilogue accesses; experiment, has not run on a GPU yet)
+void gemm16_set_swp(int v) { g_g16_swp = v; }
+// can this launch's epilogue run on the transposed accumulator?  (f32 +bias +residual | f16 rows (+GELU) | GEGLU; whole 32-column blocks; vector alignment)
+static bool g16_swp_ok(const G16Args& g) {
+    if (!g_g16_swp || g.split_k > 1 || g.multi > 1 || g.hm_d > 0 || g.ep.gate || g.C % 32 != 0) return false;
+    auto al = [](const void* p, int a) { return (((uintptr_t)p) & (uintptr_t)(a - 1)) == 0; };
+    if (g.ep.bias && !al(g.ep.bias, 16)) return false;
+    if (g.geglu_inner > 0) return g.dst16 && !g.dst && !g.ep.residual && g.geglu_inner % 32 == 0 && g.ldd16 % 4 == 0 && al(g.dst16, 8);
+    if (g.dst16) return !g.dst && !g.ep.residual && g.ldd16 % 4 == 0 && al(g.dst16, 8);
+    return g.dst && !g.ep.gelu && g.ldd % 4 == 0 && al(g.dst, 16) && (!g.ep.residual || al(g.ep.residual, 16));
+}
+
 template <int BN_, bool CONV_>
 static void g16_launch(hipStream_t s, G16Args& g, int64_t rows, double flops, double bytes) {  // bytes: algorithmic HBM bytes (operand images read once + output written once [+ residual])
     const unsigned ny = g.split_k > 1 ? (unsigned)g.split_k : 1u;
@@ -691,15 +706,33 @@ static void g16_launch(hipStream_t s, G16Args& g, int64_t rows, double flops, do
                     return;
                 }
 #endif
+                if constexpr (!CONV_) {
+                    if (g16_swp_ok(g)) {
+                        k_gemm16<256, 320, false, 32, 4, 4, 2, 1, true><<<dim3((unsigned)(rt256 * g.ncol_tiles * mul), ny), 512, 0, s>>>(g);
+                        return;
+                    }
+                }
                 k_gemm16<256, 320, CONV_, 32, 4, 4, 2, 1><<<dim3((unsigned)(rt256 * g.ncol_tiles * mul), ny), 512, 0, s>>>(g);
             } else if (tile == G16_T256P) {
                 g.ncol_tiles = (int)((g.C + 255) / 256);
+                if constexpr (!CONV_) {
+                    if (g16_swp_ok(g)) {
+                        k_gemm16<256, 256, false, 32, 4, 4, 2, 1, true><<<dim3((unsigned)(rt256 * g.ncol_tiles * mul), ny), 512, 0, s>>>(g);
+                        return;
+                    }
+                }
                 k_gemm16<256, 256, CONV_, 32, 4, 4, 2, 1><<<dim3((unsigned)(rt256 * g.ncol_tiles * mul), ny), 512, 0, s>>>(g);
             } else if (tile == G16_T160) {
                 g.ncol_tiles = (int)(g.C / 160);
                 k_gemm16<256, 160, CONV_, 32, 3, 4, 1><<<dim3((unsigned)(rt256 * g.ncol_tiles * mul), ny), 256, 0, s>>>(g);
             } else if (tile == G16_T160N) {
                 g.ncol_tiles = (int)(g.C / 160);
+                if constexpr (!CONV_) {
+                    if (g16_swp_ok(g) && g.geglu_inner == 0) {  // 160-column tiles: five column blocks per wave, no GEGLU pairing
+                        k_gemm16<256, 160, false, 32, 3, 8, 1, 0, true><<<dim3((unsigned)(rt256 * g.ncol_tiles * mul), ny), 512, 0, s>>>(g);
+                        return;
+                    }
+                }
                 k_gemm16<256, 160, CONV_, 32, 3, 8, 1><<<dim3((unsigned)(rt256 * g.ncol_tiles * mul), ny), 512, 0, s>>>(g);
             } else if (tile == G16_T256W) {
                 k_gemm16<256, 128, CONV_, 32, 3, 2, 2><<<dim3((unsigned)(rt256 * g.ncol_tiles * mul), ny), 256, 0, s>>>(g);

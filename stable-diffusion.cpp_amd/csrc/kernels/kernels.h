@@ -211,7 +211,8 @@ void flash_attn_set_vpf(int v);
 void flash_attn_set_vtr(int v);
 void flash_attn_set_ovl(int v);
 void flash_attn_set_nsel(int v);
-void flash_attn_set_short(int v);  // 1: register-resident K / V kernel for Lk <= 96, d <= 64 (experiment)  // 1: select-free K / V staging (experiment)  // 1: overlapped issue order in the two-block d <= 48 kernel (experiment)  // bit per head-dim class: row-major V tiles read with the transposing LDS read    // option "flash_vpf": bit mask of head-dim classes whose kernel issues its LDS fragment reads ahead of the MFMAs
+void flash_attn_set_short(int v);
+void gemm16_set_swp(int v);  // 1: transposed-accumulator epilogue for the big-token Linear tiles (experiment)  // 1: register-resident K / V kernel for Lk <= 96, d <= 64 (experiment)  // 1: select-free K / V staging (experiment)  // 1: overlapped issue order in the two-block d <= 48 kernel (experiment)  // bit per head-dim class: row-major V tiles read with the transposing LDS read    // option "flash_vpf": bit mask of head-dim classes whose kernel issues its LDS fragment reads ahead of the MFMAs
 void flash_attn_set_pp_min_tiles(int v);  // option "flash_pp_min_tiles"
 void flash_attn_set_mslot(int v);  // option "flash_mslot"
 void launch_flash_attn(hipStream_t s, const FlashOut& out, const View4& q, const View4& k, const View4& v, float scale);
