@@ -89,6 +89,8 @@ struct ggml_backend_mi355x_stats {
     int64_t jit_images;          /* quantised Linears planned with a just-in-time f16 image (option jit_qimages: no cached image, rebuilt in front of every launch) */
     int64_t fused_cat_rows16;    /* CONCAT along the feature dimension read only by Linears: their f16 operand image assembled directly (FLUX single block) */
     int64_t fused_gn_stats;      /* split-K convs whose slab reduce also writes the statistics of the GroupNorm that reads the result (k_splitk_reduce_gn) */
+    int64_t fused_ln_reduce;     /* split-K Linears whose slab reduce also writes the f16 operand image of the LayerNorm that reads the result (k_splitk_reduce_ln) */
+    int64_t redirect_fallbacks;  /* graphs planned a second time without the joint-qkv pre-passes because a redirected projection was not taken by its Linear */
 };
 GGML_MI355X_API void ggml_backend_mi355x_get_stats(struct ggml_backend_mi355x_stats* out);
 /* live per-kernel-family timing (bench.py's roofline legs): while a family's bit is enabled, every dispatch of that family is bracketed by
@@ -126,11 +128,13 @@ GGML_MI355X_API int ggml_backend_mi355x_get_kernel_timings(struct ggml_backend_m
  * "splitk_inkernel" (0: split-K combined by the last-arriving workgroup, 128-row tiles; measured slower) / "splitk_in_target" (320);
  * conv: "conv3w" (1: 3x3 / stride-1 convs on 16..128-wide maps on the LDS-window kernel), "conv3w_min_blocks" (8) / "conv3w_min_blocks_deep" (5:
  * least 32-channel blocks per K slice when the window kernel splits K);
- * "gemm16_swp" (0; 1 = the 256-row Linear tiles with the accumulator transposed, 16-byte epilogue accesses — experiment that has not run on a GPU yet);
+ * "gemm16_swp" (0; 1 = the 256-row Linear tiles with the accumulator transposed, 16-byte epilogue accesses: correct, measured 1 % slower per SD1.5 step);
+ * "fuse_ln_reduce" (1: the slab reduce of a split-K Linear also writes the f16 operand image of the LayerNorm that reads its result),
+ * "ln_r4" (LayerNorm -> f16 image with four rows per wave);
  * flash attention: "flash_vtr" (31: bit per head-dim class — V tiles row-major in LDS, fragments by ds_read_b64_tr_b16; 0 = transposing staging pass),
  * "flash_ovl" (1: the two-block d = 40 kernel issues one block's softmax inside the other block's MFMAs; 2: also the other d <= 48 launches; 0: off),
- * "flash_nsel" (0; 1 = select-free K / V staging — experiment that has not run on a GPU yet), "flash_short" (0; 1 = register-resident K / V
- * kernel for Lk <= 96, d <= 64 — experiment that has not run on a GPU yet),
+ * "flash_nsel" (1: select-free K / V staging, bit-identical; 0 = per-chunk selects), "flash_short" (2: register-resident K / V kernel for the
+ * 77-token cross-attentions, 64 < Lk <= 96 and d <= 64, with the next block's Q rows prefetched; 1 = without the prefetch; 0 = the tile kernel),
  * "flash_qb2" (1: two query blocks per wave for d <= 48), "flash_pp" (0; 1 = the 8-wave ping-pong kernel for 64 < d <= 96,
  * 2 = wherever it is legal: measured slower or equal, kept for A/B runs), "flash_pp_min_tiles" (4).
  * Wrong-result timing ablations exist only in builds with -DMI355X_EXPERIMENTS ("flash_ablate"). */
@@ -141,6 +145,7 @@ GGML_MI355X_API void* ggml_backend_mi355x_get_stream(ggml_backend_t backend);
 /* path of the HIP runtime library this plug-in is bound to, and hipSetDevice through it (for companions that must share its streams: RCCL) */
 GGML_MI355X_API const char* ggml_backend_mi355x_hip_library(void);
 GGML_MI355X_API int ggml_backend_mi355x_set_device(int hip_device);
+GGML_MI355X_API int ggml_backend_mi355x_get_device(void); /* the calling thread's current HIP device of the plug-in's runtime, -1 on error */
 
 #ifdef __cplusplus
 }

@@ -39,9 +39,9 @@ if len(sys.argv) > 1 and sys.argv[1] == "ovl2":  # the overlapped order in the d
     sd.backend_set_option("flash_vtr", 31)
     VARIANTS = [("warm", base), ("base", base), ("ovl2", o2), ("base", base), ("ovl2", o2)]
 if len(sys.argv) > 1 and sys.argv[1] == "short":  # k_flash_short (K / V register-resident, Lk <= 96, d <= 64; never run): use with the Lk77 cases
-    base, sh = {"flash_short": 0}, {"flash_short": 1}
+    base, sh, sp = {"flash_short": 0}, {"flash_short": 1}, {"flash_short": 2}  # 2 = with the next block's Q rows prefetched
     sd.backend_set_option("flash_vtr", 31)
-    VARIANTS = [("warm", base), ("base", base), ("short", sh), ("base", base), ("short", sh)]
+    VARIANTS = [("warm", base), ("base", base), ("short", sh), ("short+pf", sp), ("base", base), ("short", sh), ("short+pf", sp)]
 ONLY = sys.argv[2] if len(sys.argv) > 2 else ""  # substring filter on the case labels
 
 

@@ -278,6 +278,7 @@ static void* reg_get_proc(ggml_backend_reg_t, const char* name) {
     if (strcmp(name, "ggml_backend_mi355x_get_stream") == 0) return (void*)ggml_backend_mi355x_get_stream;
     if (strcmp(name, "ggml_backend_mi355x_hip_library") == 0) return (void*)ggml_backend_mi355x_hip_library;
     if (strcmp(name, "ggml_backend_mi355x_set_device") == 0) return (void*)ggml_backend_mi355x_set_device;
+    if (strcmp(name, "ggml_backend_mi355x_get_device") == 0) return (void*)ggml_backend_mi355x_get_device;
     return nullptr;
 }
 
@@ -384,6 +385,10 @@ GGML_MI355X_API const char* ggml_backend_mi355x_hip_library(void) {
     return path.c_str();
 }
 GGML_MI355X_API int ggml_backend_mi355x_set_device(int hip_device) { return hipSetDevice(hip_device) == hipSuccess ? 0 : -1; }
+GGML_MI355X_API int ggml_backend_mi355x_get_device(void) {
+    int d = -1;
+    return hipGetDevice(&d) == hipSuccess ? d : -1;
+}
 GGML_MI355X_API int ggml_backend_mi355x_get_kernel_timings(struct ggml_backend_mi355x_kernel_timing* out, int capacity) {
     mi355x::KFamTiming t[mi355x::KF_COUNT];
     int fam[mi355x::KF_COUNT];

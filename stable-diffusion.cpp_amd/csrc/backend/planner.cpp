@@ -30,6 +30,7 @@
 #include <algorithm>
 #include <map>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 #include "kernels.h"
@@ -41,11 +42,11 @@ namespace {
 struct Stats {
     std::atomic<int64_t> graphs_computed{0}, plans_built{0}, nodes_seen{0}, kernels_planned{0}, kernels_launched{0}, fused_conv{0},
         fused_conv_bounced{0}, fused_linear{0}, fused_norm{0}, fused_geglu{0}, fused_attention{0}, generic_matmul{0}, swizzled_weight_bytes{0}, fused_linear_geglu{0}, split_k_gemms{0}, head_major_gemms{0}, fused_modulate{0}, fused_gate{0}, fused_gelu{0}, fused_rope{0}, fused_concat_heads{0},
-        graph_replays{0}, qgemv_linears{0}, fused_chan_add{0}, fused_proj_tokens{0}, gemm_attention{0}, fused_q16{0}, split_k_inlaunch{0}, qgemm16_linears{0}, fgemv_linears{0}, fused_presilu{0}, fused_sibling_linears{0}, hoisted_kv_linears{0}, window_convs{0}, hoisted_emb_linears{0}, fused_rows16{0}, fused_cat_rows16{0}, fused_joint_qkv{0}, jit_images{0}, fused_gn_stats{0};
+        graph_replays{0}, qgemv_linears{0}, fused_chan_add{0}, fused_proj_tokens{0}, gemm_attention{0}, fused_q16{0}, split_k_inlaunch{0}, qgemm16_linears{0}, fgemv_linears{0}, fused_presilu{0}, fused_sibling_linears{0}, hoisted_kv_linears{0}, window_convs{0}, hoisted_emb_linears{0}, fused_rows16{0}, fused_cat_rows16{0}, fused_joint_qkv{0}, jit_images{0}, fused_gn_stats{0}, redirect_fallbacks{0}, fused_ln_reduce{0};
 } g_stats;
 
 struct Options {
-    std::atomic<int> fusion{1}, mfma_gemm{1}, hip_graph{0}, flash_pattern{1}, gemm16{1}, fuse_modulate{1}, fuse_gate{1}, fuse_gelu{1}, fuse_rope{1}, fuse_concat_heads{1}, qgemv{1}, fuse_chan_add{1}, fuse_proj_tokens{1}, fuse_q16{1}, qgemm16{1}, fgemv{1}, fuse_siblings{1}, hoist_kv{1}, hoist_emb{1}, fuse_rows16{0}, fuse_cat_rows16{1}, fuse_joint_qkv{1}, jit_qimages{4096}, fuse_gn_stats{1};
+    std::atomic<int> fusion{1}, mfma_gemm{1}, hip_graph{0}, flash_pattern{1}, gemm16{1}, fuse_modulate{1}, fuse_gate{1}, fuse_gelu{1}, fuse_rope{1}, fuse_concat_heads{1}, qgemv{1}, fuse_chan_add{1}, fuse_proj_tokens{1}, fuse_q16{1}, qgemm16{1}, fgemv{1}, fuse_siblings{1}, hoist_kv{1}, hoist_emb{1}, fuse_rows16{0}, fuse_cat_rows16{1}, fuse_joint_qkv{1}, jit_qimages{4096}, fuse_gn_stats{1}, fuse_ln_reduce{1};
 } g_opt;
 
 using Step = std::function<void(hipStream_t)>;
@@ -292,6 +293,14 @@ struct Builder {
         float eps;
     };
     std::unordered_map<const ggml_tensor*, GnPre> gn_pre;
+    // split-K Linear output -> f16 operand image of the LayerNorm that reads it, already written by the slab reduce (plan_linear look-ahead;
+    // plan_layer_norm skips its launch when weight / bias / eps agree)
+    struct LnPre {
+        size_t off;
+        const float *w, *b;
+        float eps;
+    };
+    std::unordered_map<const ggml_tensor*, LnPre> ln_pre;
     // CONCAT along the feature dimension read only by Linears (FLUX single block: concat(attn, gelu(mlp)) -> linear2, flux.hpp:594-700): the
     // Linear's f16 operand image is assembled directly (plan_cat_rows16).  cat16: CONCAT node -> image and which parts a producer has written;
     // cat16_part: a producer's tensor (the flash node's output CONT, the CONT in front of an in-place GELU) -> the columns it may write
@@ -323,6 +332,10 @@ struct Builder {
     };
     std::unordered_map<int, JCat> jqkv;
     std::unordered_map<const ggml_tensor*, size_t> lin_redirect;
+    // the redirected tensors whose GEMM really wrote the scratch (plan_linear): build_plan checks that every redirect was taken — a projection
+    // whose bias ADD was not fused, or whose chain ended on a later node, would leave the readers of the scratch with garbage
+    std::unordered_set<const ggml_tensor*> redirect_taken;
+    bool no_redirect = false;  // second attempt of build_plan after such a mismatch: plan_joint_qkv / plan_flux_qkv stay off
     // FLUX attentions (plan_flux_qkv): sources of the q / k rotary passes (keyed by the rope chain's first CONT) and of the v head-major passes
     // (keyed by the CONT of PERMUTE(v)); part[1] is unused (Lb == 0) in the single blocks
     struct RopeSrc {
@@ -875,6 +888,7 @@ void plan_linear(Builder& B, int i, hipStream_t s, std::vector<int>& chain) {
             B.emit_at(emit_node, i, [=](hipStream_t st) {
                 launch_qgemm16(st, redir ? (float*)(P->arena + redir_off) : dst, nullptr, 0, P->arena + off, ld, tokens, wraw, wt, K, M, ep, S > 1 ? (float*)(P->arena + wsoff) : nullptr, S);
             });
+            if (redir) B.redirect_taken.insert(gi.node(last));
             g_stats.qgemm16_linears++;
         } else if (g_opt.fuse_rows16 && !ep.gate && emit_node == i && M % 64 == 0 && x->ne[3] == 1 && only_consumer_is_tokens_to_conv(gi, last)) {
             // FF2 (+bias, +residual) of a SpatialTransformer whose result only proj_out reads (block.hpp:566-572): write the 1x1 conv's f16 operand
@@ -888,9 +902,47 @@ void plan_linear(Builder& B, int i, hipStream_t s, std::vector<int>& chain) {
             g_stats.fused_rows16++;
         } else {
             const Builder::Split sk = B.plan_split(tokens, M, K, false, !ep.gate);
+            // look-ahead: this output -> NORM -> MUL w -> ADD b read only by weight GEMMs (the next LayerNorm of a transformer block).  When the
+            // Linear runs split-K with the slab reduce pass, that pass also writes the LayerNorm's f16 operand image (k_splitk_reduce_ln)
+            bool ln_on       = false;
+            size_t ln_off    = 0;
+            const float *lnw = nullptr, *lnb = nullptr;
+            float lneps      = 0.f;
+            if (g_opt.fuse_ln_reduce && g_opt.fusion && sk.S > 1 && !sk.inkernel && !redir && !ep.gate && emit_node == i && hm_d == 0 && splitk_reduce_ln_supported(tokens, M) &&
+                !(gi.node(last)->flags & GGML_TENSOR_FLAG_OUTPUT)) {
+                const ggml_tensor* res = gi.node(last);
+                for (int k : gi.consumers[last]) {
+                    const ggml_tensor* nn = gi.node(k);
+                    if (nn->op != GGML_OP_NORM || nn->src[0] != res || gi.done[k] || !is_f32(nn) || !contig(nn) || !contig(res) || nn->ne[0] != M) continue;
+                    const int j1 = gi.sole(k);
+                    if (j1 < 0 || gi.node(j1)->op != GGML_OP_MUL || gi.node(j1)->src[0] != nn || !bias_like_row(gi.node(j1)->src[1], M) || gi.node(j1)->data != nn->data) break;
+                    const int j2 = gi.sole(j1);
+                    if (j2 < 0 || gi.node(j2)->op != GGML_OP_ADD || gi.node(j2)->src[0] != gi.node(j1) || !bias_like_row(gi.node(j2)->src[1], M) || gi.node(j2)->data != nn->data) break;
+                    std::vector<int> lc{k, j1, j2};
+                    if (!gi.only_noops_between(k, j1, lc) || !gi.only_noops_between(j1, j2, lc) || !all_consumers_gemm16(gi, j2, false)) break;
+                    lnw = (const float*)gi.node(j1)->src[1]->data;
+                    lnb = (const float*)gi.node(j2)->src[1]->data;
+                    // the reduce pass moves 16 bytes per lane: decided here with the addresses the launch will see
+                    if (!aligned16(dst) || !aligned16(ep.residual) || !aligned16(ep.bias) || !aligned16(lnw) || !aligned16(lnb)) break;
+                    lneps  = ggml_abi_op_param_f32(nn, 0);
+                    ln_off = B.alloc((size_t)tokens * rup64(M) * 2);
+                    ln_on  = true;
+                    B.ln_pre[res] = Builder::LnPre{ln_off, lnw, lnb, lneps};
+                    g_stats.fused_ln_reduce++;
+                    break;
+                }
+            }
             B.emit_at(emit_node, i, [=](hipStream_t st) {
-                launch_gemm16_linear(st, redir ? (float*)(P->arena + redir_off) : dst, nullptr, 0, P->arena + off, ld, swz, tokens, K, M, M, ep, 0, 0, 0, sk.ws(P), sk.cnt(P), sk.S);
+                Epilogue e2 = ep;
+                if (ln_on) {
+                    e2.ln_dst16 = P->arena + ln_off;
+                    e2.ln_w     = lnw;
+                    e2.ln_b     = lnb;
+                    e2.ln_eps   = lneps;
+                }
+                launch_gemm16_linear(st, redir ? (float*)(P->arena + redir_off) : dst, nullptr, 0, P->arena + off, ld, swz, tokens, K, M, M, e2, 0, 0, 0, sk.ws(P), sk.cnt(P), sk.S);
             });
+            if (redir) B.redirect_taken.insert(gi.node(last));
         }
     }
     g_stats.fused_linear++;
@@ -1330,7 +1382,7 @@ bool plan_conv_chain(Builder& B, int i, hipStream_t s, std::vector<int>& chain) 
         }
     }
     // -> ADD residual (same shape, either operand order), only when it directly follows
-    if (!ep.chan_add && token_major_out < 0) {
+    if (!ep.chan_add && !emb_arena && token_major_out < 0) {  // emb_arena: a hoisted embedding add is a chan_add whose pointer is resolved at launch
         int r = gi.sole(last);
         if (r >= 0 && !gi.done[r] && gi.node(r)->op == GGML_OP_ADD && gi.only_noops_between(last, r, chain)) {
             const ggml_tensor* a     = gi.node(r);
@@ -1365,6 +1417,9 @@ bool plan_conv_chain(Builder& B, int i, hipStream_t s, std::vector<int>& chain) 
     }
     auto gn_register = [&](int S) -> bool {  // called once the split factor is known
         if (S <= 1 || !gnp.groups) return false;
+        // k_splitk_reduce_gn moves 16 bytes per lane: decided HERE, with the addresses the launch will see, so that plan_group_norm never skips a
+        // statistics pass the reduce then does not run (slabs come from B.alloc, 256-byte aligned)
+        if ((((uintptr_t)final_dst | (uintptr_t)ep.residual) & 15) != 0) return false;
         gnp.off                    = B.alloc((size_t)N * OC * 4 * 2);
         B.gn_pre[gi.node(last)]    = gnp;
         g_stats.fused_gn_stats++;
@@ -1621,6 +1676,12 @@ bool plan_layer_norm(Builder& B, int i, hipStream_t, std::vector<int>& chain) {
     }
     if (C % 4 == 0 && xs % 4 == 0 && aligned16(xp) && (!w || aligned16(w)) && (!b || aligned16(b)) && all_consumers_gemm16(gi, last, false)) {
         // gen-2: all readers are weight GEMMs (q/k/v or FF projections) -> write the f16 operand image only
+        const auto lp = B.ln_pre.find(x);
+        if (lp != B.ln_pre.end() && !rms && lp->second.w == w && lp->second.b == b && lp->second.eps == eps && xs == C) {  // written by the split-K reduce of the producing Linear
+            B.packed[gi.node(last)] = Packed{lp->second.off, rup64(C), false};
+            g_stats.fused_norm++;
+            return true;
+        }
         Planner* P       = B.P;
         const size_t off = B.alloc((size_t)rows * rup64(C) * 2);
         B.emit([=](hipStream_t st) { launch_layer_norm_f16(st, P->arena + off, xp, C, rows, xs, eps, w, b, rms); });
@@ -2304,11 +2365,12 @@ static bool concat_heads_forward(const GInfo& gi, int i, int* d_out, int* H_out,
 // (Q as an f16 image when only the flash node reads it).  All-or-nothing per stream: every reader of T has to be inside the pattern.
 void plan_joint_qkv(Builder& B) {
     GInfo& gi = B.gi;
-    if (!g_opt.fusion || !g_opt.gemm16 || !g_opt.fuse_concat_heads || !g_opt.fuse_joint_qkv) return;
+    if (!g_opt.fusion || !g_opt.gemm16 || !g_opt.fuse_concat_heads || !g_opt.fuse_joint_qkv || B.no_redirect) return;
     struct VChain {
         int cat = -1, part = -1;
         const float* w = nullptr;
         float eps = 0.f;
+        int64_t nd = 0;  // width of the per-head RMSNorm (its ne[0]): must be the attention's head dim
         std::vector<int> skip;
     };
     struct Stream {
@@ -2383,6 +2445,7 @@ void plan_joint_qkv(Builder& B) {
                 }
                 vc.w    = (const float*)w->data;
                 vc.eps  = ggml_abi_op_param_f32(gi.node(jn), 0);
+                vc.nd   = r2->ne[0];
                 vc.skip = {jn, jm};
                 from    = jm;
                 j       = gi.sole(jm);
@@ -2435,7 +2498,7 @@ void plan_joint_qkv(Builder& B) {
                 }
                 const bool norm = st.v[q].w != nullptr;
                 if (cover[c] != 3 || !ci->second.fwd || (int64_t)ci->second.d * ci->second.H != st.C || ci->second.d % 4 != 0 || !joint_heads_supported(ci->second.d) ||
-                    (norm && ci->second.d != (int)(st.C / ci->second.H))) {
+                    (norm && (int64_t)ci->second.d != st.v[q].nd)) {
                     st.alive = false;
                     changed  = true;
                 }
@@ -2475,7 +2538,7 @@ void plan_joint_qkv(Builder& B) {
 // projection rows to the flash operand (norm, token concat, rotary, f16 in one go); the mlp part is the strided GELU pass of plan_cat_rows16.
 void plan_flux_qkv(Builder& B) {
     GInfo& gi = B.gi;
-    if (!g_opt.fusion || !g_opt.gemm16 || !g_opt.fuse_rope || !g_opt.fuse_joint_qkv) return;
+    if (!g_opt.fusion || !g_opt.gemm16 || !g_opt.fuse_rope || !g_opt.fuse_joint_qkv || B.no_redirect) return;
     struct Use {
         int kind = 0;  // 1 = q / k (rope), 2 = v, 3 = mlp
         int anchor = -1, part = 0, cat = -1;
@@ -2638,8 +2701,9 @@ void plan_flux_qkv(Builder& B) {
     }
 }
 
-bool build_plan(Planner* P, Plan* plan, const ggml_cgraph* g, hipStream_t s) {
+bool build_plan(Planner* P, Plan* plan, const ggml_cgraph* g, hipStream_t s, bool no_redirect = false) {
     Builder B(P, plan, g);
+    B.no_redirect = no_redirect;
     GInfo& gi = B.gi;
     plan_hoisted_kv(B, s);
     plan_hoisted_emb(B, s);
@@ -2824,6 +2888,16 @@ bool build_plan(Planner* P, Plan* plan, const ggml_cgraph* g, hipStream_t s) {
         }
         gi.done[i] = 1;
     }
+    for (const auto& kv : B.lin_redirect)
+        if (!B.redirect_taken.count(kv.first)) {
+            // a projection the qkv pre-passes sent to arena scratch was not written there (its chain did not end on the redirected node): plan the
+            // graph again without those pre-passes rather than let the attention operands read scratch nobody filled
+            if (no_redirect) return false;
+            fprintf(stderr, "[ggml-mi355x] qkv redirect of node '%s' not taken by its Linear: planning without the joint-qkv pre-passes\n", kv.first->name);
+            *plan = Plan{};
+            g_stats.redirect_fallbacks++;
+            return build_plan(P, plan, g, s, true);
+        }
     if (B.cnt_used > 0) {  // tile counters of the in-launch split-K combines: zero before the first launch of every run
         Planner* PP          = P;
         const size_t coff    = B.cnt_off, cbytes = B.cnt_used * sizeof(int);
@@ -3095,6 +3169,8 @@ void planner_get_stats(ggml_backend_mi355x_stats* o) {
     o->fused_joint_qkv       = g_stats.fused_joint_qkv;
     o->jit_images            = g_stats.jit_images;
     o->fused_gn_stats        = g_stats.fused_gn_stats;
+    o->fused_ln_reduce       = g_stats.fused_ln_reduce;
+    o->redirect_fallbacks    = g_stats.redirect_fallbacks;
     o->fused_attention       = g_stats.fused_attention;
     o->generic_matmul        = g_stats.generic_matmul;
     o->swizzled_weight_bytes = g_stats.swizzled_weight_bytes;
@@ -3123,6 +3199,7 @@ void planner_set_option(const char* key, int value) {
     else if (!strcmp(key, "flash_nsel")) flash_attn_set_nsel(value);
     else if (!strcmp(key, "flash_short")) flash_attn_set_short(value);
     else if (!strcmp(key, "gemm16_swp")) gemm16_set_swp(value);
+    else if (!strcmp(key, "ln_r4")) gemm16_set_ln_r4(value);
     else if (!strcmp(key, "flash_pp_min_tiles")) flash_attn_set_pp_min_tiles(value);
     else if (!strcmp(key, "conv3w")) conv3w_set(value);
     else if (!strcmp(key, "hoist_emb")) g_opt.hoist_emb = value;
@@ -3130,6 +3207,7 @@ void planner_set_option(const char* key, int value) {
     else if (!strcmp(key, "fuse_cat_rows16")) g_opt.fuse_cat_rows16 = value;
     else if (!strcmp(key, "fuse_gn_stats")) g_opt.fuse_gn_stats = value;
     else if (!strcmp(key, "fuse_joint_qkv")) g_opt.fuse_joint_qkv = value;
+    else if (!strcmp(key, "fuse_ln_reduce")) g_opt.fuse_ln_reduce = value;
     else if (!strcmp(key, "jit_qimages")) g_opt.jit_qimages = value;
     else if (!strcmp(key, "conv3w_min_blocks")) conv3w_set_min_blocks(value);
     else if (!strcmp(key, "conv3w_min_blocks_deep")) conv3w_set_min_blocks_deep(value);

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <set>
 #include <string>
 
 #include "ggml.h"
@@ -29,6 +30,7 @@ typedef int (*fn_all_reduce)(const void*, void*, size_t, int /*ncclDataType_t*/,
 typedef int (*fn_comm_destroy)(NcclComm);
 typedef const char* (*fn_error_string)(int);
 typedef int (*fn_hip_set_device)(int);
+typedef int (*fn_hip_get_device)(void);
 constexpr int NCCL_FLOAT32 = 7, NCCL_SUM = 0;  // nccl.h enum values (ncclFloat32, ncclSum)
 
 struct Api {
@@ -39,21 +41,38 @@ struct Api {
     fn_comm_destroy comm_destroy     = nullptr;
     fn_error_string error_string     = nullptr;
     fn_hip_set_device hip_set_device = nullptr;
+    fn_hip_get_device hip_get_device = nullptr;
     bool ok                          = false;
+    bool failed                      = false;  // a load attempt found no usable library: not repeated (the answer cannot change inside one process)
 };
 std::mutex g_mu;
 Api g_api;
-thread_local std::string g_err;
+// the last error of ANY thread (a host typically creates the communicator on one thread and asks for the error on another); sd_rccl_last_error
+// hands out a per-thread copy so the pointer it returns stays valid while other threads fail
+std::mutex g_err_mu;
+std::string g_err_text;
+struct ErrSink {
+    ErrSink& operator=(const std::string& s) {
+        std::lock_guard<std::mutex> lk(g_err_mu);
+        g_err_text = s;
+        return *this;
+    }
+} g_err;
+// communicators created here and not yet destroyed: the exchange callback refuses a communicator that is no longer in this set, so a context that
+// still has a destroyed communicator installed fails its next step with an error instead of calling into freed RCCL state
+std::set<void*> g_live;
 
 bool load_api() {
     std::lock_guard<std::mutex> lk(g_mu);
     if (g_api.ok) return true;
+    if (g_api.failed) return false;
     // RCCL must sit on the SAME HIP runtime as the backend plug-in (its streams are handed to ncclAllReduce); a process may hold a second
     // runtime + RCCL pair (the copies a torch wheel bundles).  The plug-in tells which runtime it is bound to; RCCL is taken from that directory.
     typedef const char* (*fn_hip_library)(void);
     ggml_backend_reg_t reg = ggml_backend_reg_by_name("MI355X");
     fn_hip_library hl      = reg ? (fn_hip_library)ggml_backend_reg_get_proc_address(reg, "ggml_backend_mi355x_hip_library") : nullptr;
     g_api.hip_set_device   = reg ? (fn_hip_set_device)ggml_backend_reg_get_proc_address(reg, "ggml_backend_mi355x_set_device") : nullptr;
+    g_api.hip_get_device   = reg ? (fn_hip_get_device)ggml_backend_reg_get_proc_address(reg, "ggml_backend_mi355x_get_device") : nullptr;
     if (!hl) {
         g_err = "the MI355X backend plug-in is not loaded (sd_load_backend first)";
         return false;
@@ -67,6 +86,7 @@ bool load_api() {
     if (!h) {
         const char* e = dlerror();
         g_err         = "librccl.so not found next to " + std::string(hl()) + ": " + (e ? e : "");
+        g_api.failed  = true;
         return false;
     }
     g_api.h              = h;
@@ -77,6 +97,9 @@ bool load_api() {
     g_api.error_string   = (fn_error_string)dlsym(h, "ncclGetErrorString");
     if (!g_api.get_unique_id || !g_api.comm_init_rank || !g_api.all_reduce || !g_api.comm_destroy) {
         g_err = "librccl.so lacks ncclGetUniqueId / ncclCommInitRank / ncclAllReduce / ncclCommDestroy";
+        dlclose(h);
+        g_api        = Api{};
+        g_api.failed = true;
         return false;
     }
     g_api.ok = true;
@@ -91,6 +114,13 @@ bool rccl_exchange(void* device_eps, int64_t count, void* stream, void* user) {
         g_err = "native pair exchange needs a communicator and the backend's HIP stream (host backends have none)";
         return false;
     }
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (!g_live.count(user)) {
+            g_err = "native pair exchange: the installed communicator was destroyed (sd_set_pair_exchange_rccl(ctx, NULL, 0) before sd_rccl_comm_destroy)";
+            return false;
+        }
+    }
     const int r = g_api.all_reduce(device_eps, device_eps, (size_t)count, NCCL_FLOAT32, NCCL_SUM, (NcclComm)user, stream);
     if (r != 0) {
         g_err = "ncclAllReduce: " + nccl_err(r);
@@ -103,7 +133,12 @@ bool rccl_exchange(void* device_eps, int64_t count, void* stream, void* user) {
 
 extern "C" {
 
-const char* sd_rccl_last_error(void) { return g_err.c_str(); }
+const char* sd_rccl_last_error(void) {
+    static thread_local std::string copy;
+    std::lock_guard<std::mutex> lk(g_err_mu);
+    copy = g_err_text;
+    return copy.c_str();
+}
 
 bool sd_rccl_get_unique_id(void* id128) {
     if (!id128 || !load_api()) return false;
@@ -119,20 +154,32 @@ bool sd_rccl_get_unique_id(void* id128) {
 
 void* sd_rccl_comm_create(int device, int nranks, int rank, const void* id128) {
     if (!id128 || !load_api()) return nullptr;
-    if (device >= 0 && g_api.hip_set_device) (void)g_api.hip_set_device(device);  // the communicator binds to the calling thread's current device
+    // the communicator binds to the calling thread's current device: switch for the call only, the caller's device is put back
+    const int prev = (device >= 0 && g_api.hip_get_device) ? g_api.hip_get_device() : -1;
+    if (device >= 0 && g_api.hip_set_device) (void)g_api.hip_set_device(device);
     NcclUniqueId id;
     memcpy(id.internal, id128, sizeof(id.internal));
     NcclComm comm = nullptr;
     const int r   = g_api.comm_init_rank(&comm, nranks, id, rank);
+    if (prev >= 0 && prev != device && g_api.hip_set_device) (void)g_api.hip_set_device(prev);
     if (r != 0) {
         g_err = "ncclCommInitRank: " + nccl_err(r);
         return nullptr;
     }
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_live.insert(comm);
     return comm;
 }
 
+// Order of teardown: remove the exchange from every context that uses the communicator (sd_set_pair_exchange_rccl(ctx, NULL, 0)), then destroy it.
+// A context that still has it installed does not crash afterwards — its next sampler step fails with an error (rccl_exchange checks g_live).
 void sd_rccl_comm_destroy(void* comm) {
-    if (comm && g_api.ok) (void)g_api.comm_destroy((NcclComm)comm);
+    if (!comm) return;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (!g_api.ok || !g_live.erase(comm)) return;  // not one of ours (or already destroyed): nothing to do
+    }
+    (void)g_api.comm_destroy((NcclComm)comm);
 }
 
 bool sd_set_pair_exchange_rccl(sdm_ctx_t* ctx, void* comm, int branch) {

@@ -105,7 +105,7 @@ constexpr int fa_vtr_stride(int ndv) {
 // variants, bit-identical outputs): d = 40, L = 4096: 601 -> 582 us; Lq = 2048, Lk = 1000 (ragged last tile): 111 -> 105 us.  The gain is small because
 // the kernel is bound by its instruction ISSUE (one v_exp_f32 per score), not by the order: a SIMD spends ~4 cycles per issued instruction whichever
 // wave it comes from, so what overlap can win is only the matrix pipe's own 32-cycle occupancy.
-// NSEL (FAST; option "flash_nsel", EXPERIMENT compiled at the end of round 3 with no GPU time left — default off until it has run): staging without
+// NSEL (FAST; option "flash_nsel", default on since round 4): staging without
 // per-element selects.  The default lstore zeroes every chunk that is not real data with v_cndmask (4 per 16-byte chunk, K and V: 32 VALU per
 // thread per tile at d = 128, in a loop that is VALU-issue bound).  Here chunks that fetch nothing (the padding chunk of d = 40 / 80 rows) point their
 // buffer offset beyond num_records, so the load itself returns zeros, and full tiles (every key < Lk; a wave-uniform test) are stored as loaded;
@@ -766,8 +766,10 @@ __global__ __launch_bounds__(256, QB == 2 ? (DKP <= 96 ? 2 : 1) : (DKP <= 64 ? (
 
 // =====================================================================================================================================
 // k_flash_short — attention onto a SHORT key sequence (64 < Lk <= 96: the 77 text tokens every SD1.x / SDXL cross-attention reads), d <= 64.
-// EXPERIMENT written at the end of round 3 with no GPU time left: option "flash_short", default 0, has not run on a GPU yet
-// (scripts/flash_check.py short is its first call; its index logic is replayed lane by lane in tests/test_kernel_logic.py).
+// Written at the end of round 3, first run in round 4 (scripts/flash_check.py short; index logic replayed lane by lane in tests/test_kernel_logic.py):
+// SD1.5 64x64-level cross-attention 81 -> 40 us, SDXL's 20.2 -> 16.6 us, SD1.5 step -1 % (profiles/r05a_flash_short.txt).  Its first GPU run
+// returned garbage: the output stores sat behind a lambda taking the accumulator register index as an argument, and hipcc (ROCm 7.2) stored
+// element 0 sixteen times — the stores are plain unrolled loops now.
 // Why: the tile kernel spends a cross-attention launch on fixed costs — per 128 queries one workgroup stages Q through LDS, stages two K / V tiles
 // (the second holds 13 valid keys) and passes five barriers for 28 MFMAs: 80 us per SD1.5 launch at the 64x64 level (16 launches per step) for
 // 126 MB of traffic, i.e. 1.6 TB/s.  Here the whole K and V of one head live in REGISTERS: a workgroup stages the keys once (K row-major and
@@ -777,7 +779,10 @@ __global__ __launch_bounds__(256, QB == 2 ? (DKP <= 96 ? 2 : 1) : (DKP <= 64 ? (
 // mask is the initial value of the last block's accumulator, the softmax is one pass (all keys present: true row max), P is normalised before it
 // is packed (each lane owns one query's scores: no cross-lane fetch of 1 / sum), and the output goes out through buffer stores whose address is a
 // loop-invariant per-lane offset (out of range for padded columns: dropped by the hardware) plus a wave-uniform row offset in an SGPR.
-template <int DKP, bool QF16, bool OUT16>
+// PF (option flash_short = 2): the Q fragments of block it + 1 are requested before block it's MFMAs — a wave runs its blocks one after the other with
+// one other wave on its SIMD, so without it every block starts with an exposed global-load latency.
+typedef unsigned int fa_u32x4_t __attribute__((__vector_size__(4 * sizeof(unsigned int))));
+template <int DKP, bool QF16, bool OUT16, bool PF = false>
 __global__ __launch_bounds__(256, 2) void k_flash_short(FAArgs g) {
     constexpr int NDV  = 2;
     constexpr int KS   = DKP / 16;
@@ -858,27 +863,50 @@ __global__ __launch_bounds__(256, 2) void k_flash_short(FAArgs g) {
         ovoff[nb]   = d < g.DV ? (uint32_t)(4 * hi) * (uint32_t)ostride + (uint32_t)d * OES : OOR;
     }
     const int qwg = 128 * g.qi;  // queries per workgroup
+    // raw Q registers of one block: Q[q][ks*16 + hi*8 .. +8], chunks beyond D read as zeros (offset out of range); a ragged last block reads its
+    // last valid row again (those results are not stored)
+    constexpr int NQR = QF16 ? KS : 2 * KS;
+    fa_u32x4_t qraw[NQR];
+#define FS_LOADQ(Q0_)                                                                                                                   \
+    {                                                                                                                                   \
+        const int rowl_  = min(lane & 31, g.Lq - 1 - (Q0_));                                                                            \
+        const int soffq_ = (Q0_) * (int)g.q_nb1;                                                                                        \
+        _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                                                             \
+            const int d0        = ks * 16 + hi * 8;                                                                                     \
+            const uint32_t voff = d0 < g.D ? (uint32_t)rowl_ * (uint32_t)g.q_nb1 + (uint32_t)d0 * QES : OOR;                            \
+            if constexpr (QF16) {                                                                                                       \
+                qraw[ks] = __builtin_amdgcn_raw_buffer_load_b128(rsQ, (int)voff, soffq_, 0);                                            \
+            } else {                                                                                                                    \
+                qraw[2 * ks]     = __builtin_amdgcn_raw_buffer_load_b128(rsQ, (int)voff, soffq_, 0);                                    \
+                qraw[2 * ks + 1] = __builtin_amdgcn_raw_buffer_load_b128(rsQ, (int)(voff == OOR ? OOR : voff + 16u), soffq_, 0);        \
+            }                                                                                                                           \
+        }                                                                                                                               \
+    }
+    if constexpr (PF) {
+        const int q00 = blockIdx.x * qwg + wave * 32;
+        if (q00 < g.Lq) FS_LOADQ(q00)
+    }
     for (int it = 0; it < g.qi; ++it) {
         const int q0 = blockIdx.x * qwg + (it * 4 + wave) * 32;  // wave-uniform
         if (q0 >= g.Lq) break;
         const bool full  = q0 + 32 <= g.Lq;
-        const int rowl   = min(lane & 31, g.Lq - 1 - q0);  // a ragged last block reads its last valid row again (those results are not stored)
-        const int soffq  = q0 * (int)g.q_nb1;
-        // ---- Q fragments (B operand of S^T = K Q^T): Q[q][ks*16 + hi*8 .. +8] as f16, chunks beyond D read as zeros (offset out of range)
+        if constexpr (!PF) FS_LOADQ(q0)
+        // ---- Q fragments (B operand of S^T = K Q^T) as f16
         half8_t qf[KS];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const int d0        = ks * 16 + hi * 8;
-            const uint32_t voff = d0 < g.D ? (uint32_t)rowl * (uint32_t)g.q_nb1 + (uint32_t)d0 * QES : OOR;
             if constexpr (QF16) {
-                qf[ks] = __builtin_bit_cast(half8_t, __builtin_amdgcn_raw_buffer_load_b128(rsQ, (int)voff, soffq, 0));
+                qf[ks] = __builtin_bit_cast(half8_t, qraw[ks]);
             } else {
-                const float4 a = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsQ, (int)voff, soffq, 0));
-                const float4 c = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsQ, (int)(voff == OOR ? OOR : voff + 16u), soffq, 0));
+                const float4 a = __builtin_bit_cast(float4, qraw[2 * ks]), c = __builtin_bit_cast(float4, qraw[2 * ks + 1]);
                 const half2_t h0 = __builtin_convertvector((float2_t){a.x, a.y}, half2_t), h1 = __builtin_convertvector((float2_t){a.z, a.w}, half2_t);
                 const half2_t h2 = __builtin_convertvector((float2_t){c.x, c.y}, half2_t), h3 = __builtin_convertvector((float2_t){c.z, c.w}, half2_t);
                 qf[ks] = (half8_t){h0[0], h0[1], h1[0], h1[1], h2[0], h2[1], h3[0], h3[1]};
             }
+        }
+        if constexpr (PF) {  // the next block's rows: in flight during this block's MFMAs, softmax and stores
+            const int q1 = q0 + 128;
+            if (it + 1 < g.qi && q1 < g.Lq) FS_LOADQ(q1)
         }
         float16_t sc[NKB];
         sc[0] = (float16_t){0};
@@ -922,26 +950,29 @@ __global__ __launch_bounds__(256, 2) void k_flash_short(FAArgs g) {
         for (int t = 0; t < NKT; ++t)
 #pragma unroll
             for (int nb = 0; nb < NDV; ++nb) o[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pa[t], vf[t][nb], o[nb], 0, 0, 0);
-        // ---- rows (r&3) + 8*(r>>2) + 4*hi of the block, column nb*32 + (lane & 31)
-        auto put = [&](const int r, const int nb, const uint32_t vo) {
-            const int soff = (q0 + (r & 3) + 8 * (r >> 2)) * (int)ostride;  // wave-uniform
-            if constexpr (OUT16)
-                __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(short, (_Float16)o[nb][r]), rsO, (int)vo, soff, 0);
-            else
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, o[nb][r]), rsO, (int)vo, soff, 0);
-        };
-        if (full) {  // wave-uniform: every row of the block exists
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-#pragma unroll
-                for (int nb = 0; nb < NDV; ++nb) put(r, nb, ovoff[nb]);
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-#pragma unroll
-                for (int nb = 0; nb < NDV; ++nb) put(r, nb, q0 + (r & 3) + 8 * (r >> 2) + 4 * hi < g.Lq ? ovoff[nb] : OOR);
-        }
+        // ---- rows (r&3) + 8*(r>>2) + 4*hi of the block, column nb*32 + (lane & 31).  Written as plain unrolled loops: behind a lambda taking the
+        // register index as a run-time argument hipcc (ROCm 7.2) stored element 0 of the accumulator sixteen times (seen in the ISA, found on the GPU)
+#define FS_PUT(VO_)                                                                                                             \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                                                \
+        const int ro   = (r & 3) + 8 * (r >> 2);                                                                                    \
+        const int soff = (q0 + ro) * (int)ostride; /* wave-uniform */                                                               \
+        _Pragma("unroll") for (int nb = 0; nb < NDV; ++nb) {                                                                        \
+            const uint32_t vo = (VO_);                                                                                              \
+            const float val   = o[nb][r];                                                                                           \
+            if constexpr (OUT16)                                                                                                    \
+                __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(short, (_Float16)val), rsO, (int)vo, soff, 0);             \
+            else                                                                                                                    \
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, val), rsO, (int)vo, soff, 0);                         \
+        }                                                                                                                           \
     }
+        if (full) {  // wave-uniform: every row of the block exists
+            FS_PUT(ovoff[nb])
+        } else {
+            FS_PUT(q0 + ro + 4 * hi < g.Lq ? ovoff[nb] : OOR)
+        }
+#undef FS_PUT
+    }
+#undef FS_LOADQ
 }
 
 // =====================================================================================================================================
@@ -1423,9 +1454,9 @@ static int g_flash_vtr = 31;  // option "flash_vtr": head-dim classes (bits as f
 void flash_attn_set_vtr(int v) { g_flash_vtr = v; }
 static int g_flash_ovl = 1;  // option "flash_ovl": 1 = the two-block d = 40 kernel with one block's softmax issued inside the other block's MFMAs; 2 = also the other d <= 48 launches (that variant has not run on a GPU yet); 0 = phase-by-phase order
 void flash_attn_set_ovl(int v) { g_flash_ovl = v; }
-static int g_flash_nsel = 0;  // option "flash_nsel": 1 = select-free staging in the d = 40 two-block, d = 64 and d = 128 kernels (experiment, has not run on a GPU yet)
+static int g_flash_nsel = 1;  // option "flash_nsel": 1 = select-free staging in the d = 40 two-block, d = 64 and d = 128 kernels (round 4: bit-identical, d = 128 346 -> 326 us, SD1.5 step -0.6 %; profiles/r05a_*)
 void flash_attn_set_nsel(int v) { g_flash_nsel = v; }
-static int g_flash_short = 0;  // option "flash_short": 1 = k_flash_short for Lk <= 96, d <= 64 (experiment, has not run on a GPU yet)
+static int g_flash_short = 2;  // option "flash_short": k_flash_short for 64 < Lk <= 96, d <= 64 (the 77-token cross-attentions): 1 = on, 2 = with the next block's Q rows prefetched (default; round 4: 81 -> 40 us per SD1.5 64x64-level launch), 0 = the tile kernel
 void flash_attn_set_short(int v) { g_flash_short = v; }
 static int g_flash_pp_min_tiles = 4;  // option "flash_pp_min_tiles": key tiles (64 keys) from which the ping-pong pipeline has a steady state worth its prologue
 void flash_attn_set_pp_min_tiles(int v) { g_flash_pp_min_tiles = v; }
@@ -1475,21 +1506,28 @@ void launch_flash_attn(hipStream_t s, const FlashOut& out, const View4& q, const
         g.qi  = (int)std::max<int64_t>(1, std::min<int64_t>(8, nblk / 4096));
         g.grp = g.units = 0;
         dim3 gs((unsigned)((g.Lq + 128 * g.qi - 1) / (128 * g.qi)), (unsigned)q.ne[2]);
-#define FS_CASE(DKP_)                                                          \
+#define FS_CASE(DKP_, PF_)                                                     \
     do {                                                                       \
         if (g.q_f16 && g.dst16)                                                \
-            k_flash_short<DKP_, true, true><<<gs, 256, 0, s>>>(g);             \
+            k_flash_short<DKP_, true, true, PF_><<<gs, 256, 0, s>>>(g);        \
         else if (g.q_f16)                                                      \
-            k_flash_short<DKP_, true, false><<<gs, 256, 0, s>>>(g);            \
+            k_flash_short<DKP_, true, false, PF_><<<gs, 256, 0, s>>>(g);       \
         else if (g.dst16)                                                      \
-            k_flash_short<DKP_, false, true><<<gs, 256, 0, s>>>(g);            \
+            k_flash_short<DKP_, false, true, PF_><<<gs, 256, 0, s>>>(g);       \
         else                                                                   \
-            k_flash_short<DKP_, false, false><<<gs, 256, 0, s>>>(g);           \
+            k_flash_short<DKP_, false, false, PF_><<<gs, 256, 0, s>>>(g);      \
     } while (0)
-        if (D <= 48)
-            FS_CASE(48);
-        else
-            FS_CASE(64);
+        if (g_flash_short >= 2) {
+            if (D <= 48)
+                FS_CASE(48, true);
+            else
+                FS_CASE(64, true);
+        } else {
+            if (D <= 48)
+                FS_CASE(48, false);
+            else
+                FS_CASE(64, false);
+        }
 #undef FS_CASE
         return;
     }

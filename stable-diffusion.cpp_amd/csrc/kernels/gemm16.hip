@@ -989,6 +989,97 @@ static void launch_splitk_reduce(hipStream_t s, float* dst, const float* ws, int
         k_splitk_reduce<false><<<(unsigned)((n + 255) / 256), 256, 0, s>>>(dst, ws, S, n, n, bias, inner, (int)C, residual, chan_add, chan_ld);
 }
 
+// Slab reduce of a split-K Linear FUSED with the LayerNorm that reads the result next (Epilogue::ln_*): a 16-lane group owns one row (four rows
+// per wave, NV float4 per lane, M <= 64 * NV), sums the S slabs in slice order, adds bias and residual in the order of k_splitk_reduce (identical
+// values), stores the f32 row and normalises it from registers exactly as k_layer_norm_f16_r4 does.  Saves the LayerNorm launch and its read of
+// the tensor: at SDXL's 32x32 level (2048 rows) these are 10 us launches of which there are three per transformer block.
+template <int NV>
+__global__ __launch_bounds__(256) void k_splitk_reduce_ln(float* __restrict__ dst, const float* __restrict__ ws, int S, int64_t slab, int64_t nrows, int M, int Kp,
+                                                          const float* __restrict__ bias, const float* residual, _Float16* __restrict__ dst16, float eps,
+                                                          const float* __restrict__ w, const float* __restrict__ b) {
+    const int sub     = threadIdx.x & 15;
+    const int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool live   = row < nrows;
+    const int64_t rr  = live ? row : nrows - 1;
+    const int n4      = M / 4;
+    float4 v[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < S; ++s) {
+        const float4* p = (const float4*)(ws + s * slab + rr * M);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = sub + 16 * j;
+            if (i < n4) {
+                const float4 t = p[i];
+                v[j].x += t.x; v[j].y += t.y; v[j].z += t.z; v[j].w += t.w;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int i = sub + 16 * j;
+        if (i >= n4) continue;
+        if (bias) { const float4 t = ((const float4*)bias)[i]; v[j].x += t.x; v[j].y += t.y; v[j].z += t.z; v[j].w += t.w; }
+        if (residual) { const float4 t = ((const float4*)(residual + rr * M))[i]; v[j].x += t.x; v[j].y += t.y; v[j].z += t.z; v[j].w += t.w; }
+        if (live) ((float4*)(dst + row * M))[i] = v[j];
+    }
+    auto sum16 = [](float t) {
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+        return t;
+    };
+    float sm = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) sm += (v[j].x + v[j].y) + (v[j].z + v[j].w);  // slots beyond n4 hold zeros
+    const float mean = sum16(sm) / (float)M;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        if (sub + 16 * j < n4) {
+            const float a = v[j].x - mean, bb = v[j].y - mean, c = v[j].z - mean, d = v[j].w - mean;
+            q += (a * a + bb * bb) + (c * c + d * d);
+        }
+    }
+    const float rstd = rsqrtf(sum16(q) / (float)M + eps);
+    if (!live) return;
+    _Float16* yr = dst16 + row * Kp;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int i = sub + 16 * j;
+        if (i >= Kp / 4) continue;
+        half4_t h = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+        if (i < n4) {
+            float4 t = v[j];
+            t.x = (t.x - mean) * rstd; t.y = (t.y - mean) * rstd; t.z = (t.z - mean) * rstd; t.w = (t.w - mean) * rstd;
+            if (w) { const float4 ww = ((const float4*)w)[i]; t.x *= ww.x; t.y *= ww.y; t.z *= ww.z; t.w *= ww.w; }
+            if (b) { const float4 bb = ((const float4*)b)[i]; t.x += bb.x; t.y += bb.y; t.z += bb.z; t.w += bb.w; }
+            h[0] = (_Float16)t.x; h[1] = (_Float16)t.y; h[2] = (_Float16)t.z; h[3] = (_Float16)t.w;
+        }
+        *(half4_t*)(yr + i * 4) = h;
+    }
+}
+bool splitk_reduce_ln_supported(int64_t rows, int64_t M) { return M % 4 == 0 && rup64(M, 64) <= 1280 && rows >= 64; }
+static void launch_splitk_reduce_ln(hipStream_t s, float* dst, const float* ws, int S, int64_t rows, int64_t M, const Epilogue& e) {
+    if (!splitk_reduce_ln_supported(rows, M) || ((((uintptr_t)dst | (uintptr_t)ws | (uintptr_t)e.residual | (uintptr_t)e.bias | (uintptr_t)e.ln_w | (uintptr_t)e.ln_b)) & 15) != 0) {
+        // the planner registered this LayerNorm as done (plan_linear look-ahead checks the same conditions with the same addresses)
+        fprintf(stderr, "ggml-mi355x: split-K reduce asked for a LayerNorm image on a shape / alignment it does not serve\n");
+        abort();
+    }
+    const int Kp = (int)rup64(M, 64);
+    // algorithmic bytes: the slabs + residual in, the f32 tensor and the f16 image out
+    KScope ks_(s, KF_SPLITK, 0.0, (double)rows * M * 4.0 * (S + 1 + (e.residual ? 1 : 0)) + (double)rows * Kp * 2.0);
+    const unsigned grid = (unsigned)((rows + 15) / 16);
+#define SKLN(NV_) k_splitk_reduce_ln<NV_><<<grid, 256, 0, s>>>(dst, ws, S, rows * M, rows, (int)M, Kp, e.bias, e.residual, (_Float16*)e.ln_dst16, e.ln_eps, e.ln_w, e.ln_b)
+    if (Kp <= 64 * 5)
+        SKLN(5);
+    else if (Kp <= 64 * 10)
+        SKLN(10);
+    else
+        SKLN(20);
+#undef SKLN
+}
+
 void splitk_reduce_rows(hipStream_t s, float* dst, const float* ws, int S, int64_t n, const float* bias, int64_t C, const float* residual) {
     launch_splitk_reduce(s, dst, ws, S, n, bias, 1, C, residual);
 }
@@ -1009,13 +1100,21 @@ static const _Float16* zero_page() {
 
 void gemm16_init() { (void)zero_page(); }
 const _Float16* gemm16_zero_page() { return zero_page(); }
+// The planner sets e.gn_* only after checking shape AND alignment with the launch's own addresses (plan_conv_chain::gn_register) and then drops
+// the GroupNorm's statistics pass; a launch that cannot honour that would leave the scale / shift tables unwritten — stop instead of going on.
+[[noreturn]] static void g16_gn_contract_violation() {
+    fprintf(stderr, "ggml-mi355x: split-K reduce asked for GroupNorm statistics on a shape / alignment it does not serve\n");
+    abort();
+}
 void launch_splitk_reduce_conv(hipStream_t s, float* dst, const float* ws, int S, int64_t n, const float* bias, int64_t inner, int64_t C, const float* residual,
                                const float* chan_add, int64_t chan_ld) {
     launch_splitk_reduce(s, dst, ws, S, n, bias, inner, C, residual, chan_add, chan_ld);
 }
 // the same with the statistics of the GroupNorm that reads the output next (e.gn_*); falls back to the plain pass when the shape is not served
 void launch_splitk_reduce_conv_gn(hipStream_t s, float* dst, const float* ws, int S, int64_t hw, int64_t C, int64_t N, const Epilogue& e) {
-    if (e.gn_scale && (((uintptr_t)dst | (uintptr_t)ws | (uintptr_t)e.residual) & 15) == 0 && splitk_reduce_gn_supported(hw, C, N, e.gn_groups))
+    const bool gn_ok = (((uintptr_t)dst | (uintptr_t)ws | (uintptr_t)e.residual) & 15) == 0 && splitk_reduce_gn_supported(hw, C, N, e.gn_groups);
+    if (e.gn_scale && !gn_ok) g16_gn_contract_violation();
+    if (e.gn_scale)
         launch_splitk_reduce_gn(s, dst, ws, S, hw, C, N, e);
     else
         launch_splitk_reduce(s, dst, ws, S, hw * C * N, e.bias, hw, C, e.residual, e.chan_add, e.chan_ld);
@@ -1091,7 +1190,16 @@ void launch_gemm16_linear(hipStream_t s, float* dst, void* dst16, int64_t ldd16,
         g.ncol_tiles = (int)((M + 127) / 128);
         g16_launch<128, false>(s, g, rows, 2.0 * rows * K * M, lin_bytes);
     }
-    if (S > 1 && !inker) launch_splitk_reduce(s, dst, splitk_ws, S, rows * M, e.bias, 1, M, e.residual);
+    if (e.ln_dst16 && !(S > 1 && !inker)) {
+        fprintf(stderr, "ggml-mi355x: a LayerNorm image was asked of a Linear that does not run the split-K reduce pass\n");
+        abort();
+    }
+    if (S > 1 && !inker) {
+        if (e.ln_dst16)
+            launch_splitk_reduce_ln(s, dst, splitk_ws, S, rows, M, e);
+        else
+            launch_splitk_reduce(s, dst, splitk_ws, S, rows * M, e.bias, 1, M, e.residual);
+    }
 }
 
 // n (2..16) sibling Linears over the same f16 operand image in ONE launch (q / k / v projections of a self-attention, k / v of a cross-attention:
@@ -1220,7 +1328,9 @@ void launch_gemm16_conv(hipStream_t s, float* dst, const void* x16_nhwc, const v
         g16_launch<128, true>(s, g, g.R, 2.0 * g.R * IC * ksize * ksize * OC, conv_bytes);
     }
     if (S > 1 && !inker) {
-        if (e.gn_scale && (((uintptr_t)dst | (uintptr_t)splitk_ws | (uintptr_t)e.residual) & 15) == 0 && splitk_reduce_gn_supported(g.OHOW, OC, N, e.gn_groups))
+        const bool gn_ok = (((uintptr_t)dst | (uintptr_t)splitk_ws | (uintptr_t)e.residual) & 15) == 0 && splitk_reduce_gn_supported(g.OHOW, OC, N, e.gn_groups);
+        if (e.gn_scale && !gn_ok) g16_gn_contract_violation();
+        if (e.gn_scale)
             launch_splitk_reduce_gn(s, dst, splitk_ws, S, g.OHOW, OC, N, e);
         else
             launch_splitk_reduce(s, dst, splitk_ws, S, g.R * OC, e.bias, g.OHOW, OC, e.residual, e.chan_add, e.chan_ld);
@@ -1392,12 +1502,85 @@ __global__ __launch_bounds__(256) void k_layer_norm_f16_reg(_Float16* __restrict
         *(half4_t*)(yr + i * 4) = h;
     }
 }
+// four rows per wave: a 16-lane group keeps its row in NV float4 registers per lane (ne0 <= 64 * NV).  Against the one-row-per-wave kernel above
+// (C = 320: 80 float4 over 64 lanes = two load instructions of which the second is three quarters empty, 1.25 KB in flight per wave) every lane
+// of every load carries data, a wave has 4 rows = 5 KB in flight, and the two reductions take 4 shuffle steps instead of 6.
+template <int NV>
+__global__ __launch_bounds__(256) void k_layer_norm_f16_r4(_Float16* __restrict__ dst, const float* __restrict__ x, int ne0, int Kp, int64_t nrows, int64_t xs,
+                                                           float eps, const float* __restrict__ w, const float* __restrict__ b, int rms, int64_t mod_L) {
+    const int sub     = threadIdx.x & 15;
+    const int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool live   = row < nrows;  // dead groups keep running: the shuffles below are wave-wide
+    const int64_t rr  = live ? row : nrows - 1;
+    const float wadd  = mod_L > 0 ? 1.f : 0.f;
+    if (mod_L > 0) {
+        w += (rr / mod_L) * ne0;
+        b += (rr / mod_L) * ne0;
+    }
+    const float4* xr = (const float4*)(x + rr * xs);
+    const int n4     = ne0 / 4;
+    float4 v[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int i = sub + 16 * j;
+        v[j]        = i < n4 ? xr[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    auto sum16 = [](float t) {
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+        return t;
+    };
+    float mean = 0.f;
+    if (!rms) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+        mean = sum16(s) / (float)ne0;
+    }
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        if (sub + 16 * j < n4) {
+            const float a = v[j].x - mean, bb = v[j].y - mean, c = v[j].z - mean, d = v[j].w - mean;
+            q += (a * a + bb * bb) + (c * c + d * d);
+        }
+    }
+    const float rstd = rsqrtf(sum16(q) / (float)ne0 + eps);
+    if (!live) return;
+    _Float16* yr = dst + row * Kp;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int i = sub + 16 * j;
+        if (i >= Kp / 4) continue;
+        half4_t h = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+        if (i < n4) {
+            float4 t = v[j];
+            t.x = (t.x - mean) * rstd; t.y = (t.y - mean) * rstd; t.z = (t.z - mean) * rstd; t.w = (t.w - mean) * rstd;
+            if (w) { const float4 ww = ((const float4*)w)[i]; t.x *= ww.x + wadd; t.y *= ww.y + wadd; t.z *= ww.z + wadd; t.w *= ww.w + wadd; }
+            if (b) { const float4 bb = ((const float4*)b)[i]; t.x += bb.x; t.y += bb.y; t.z += bb.z; t.w += bb.w; }
+            h[0] = (_Float16)t.x; h[1] = (_Float16)t.y; h[2] = (_Float16)t.z; h[3] = (_Float16)t.w;
+        }
+        *(half4_t*)(yr + i * 4) = h;
+    }
+}
+static int g_ln_r4 = 0;  // option "ln_r4" (round 4 experiment)
+void gemm16_set_ln_r4(int v) { g_ln_r4 = v; }
 void launch_layer_norm_f16(hipStream_t s, void* dst, const float* x, int64_t ne0, int64_t nrows, int64_t xs, float eps, const float* w, const float* b, bool rms,
                            int64_t mod_L) {
     KScope ks_(s, KF_LN_F16, 0.0, (double)nrows * ne0 * 4.0 + (double)nrows * rup64(ne0, 64) * 2.0);
     const int Kp = (int)rup64(ne0, 64);
-    const unsigned grid = (unsigned)((nrows + 3) / 4);
 #define LN16_ARGS (_Float16*)dst, x, (int)ne0, Kp, nrows, xs, eps, w, b, rms ? 1 : 0, mod_L
+    if (g_ln_r4 && Kp <= 1280 && nrows >= 64) {
+        const unsigned g4 = (unsigned)((nrows + 15) / 16);
+        if (Kp <= 64 * 5)
+            k_layer_norm_f16_r4<5><<<g4, 256, 0, s>>>(LN16_ARGS);
+        else if (Kp <= 64 * 10)
+            k_layer_norm_f16_r4<10><<<g4, 256, 0, s>>>(LN16_ARGS);
+        else
+            k_layer_norm_f16_r4<20><<<g4, 256, 0, s>>>(LN16_ARGS);
+        return;
+    }
+    const unsigned grid = (unsigned)((nrows + 3) / 4);
     if (Kp <= 256 * 2)
         k_layer_norm_f16_reg<2><<<grid, 256, 0, s>>>(LN16_ARGS);
     else if (Kp <= 256 * 5)

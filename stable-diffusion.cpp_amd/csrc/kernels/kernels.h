@@ -90,6 +90,13 @@ struct Epilogue {
     const float* gn_b     = nullptr;
     int gn_groups         = 0;
     float gn_eps          = 0.f;
+    // Linear only, split-K launches with the slab reduce pass only: the LayerNorm (-> MUL w -> ADD b) that reads this output next and feeds only
+    // weight GEMMs (planner look-ahead, plan_linear) — the reduce pass keeps each finished row in registers and also writes that LayerNorm's
+    // f16 operand image (k_splitk_reduce_ln): no second read of the tensor, no second launch
+    void* ln_dst16        = nullptr;  // [rows][rup64(M)] halfs
+    const float* ln_w     = nullptr;
+    const float* ln_b     = nullptr;
+    float ln_eps          = 0.f;
     // gemm16 linear only (DiT blocks):
     const float* gate     = nullptr;  // [images][M]: dst = (acc*scale + bias) * gate[row / gate_L][col] + residual
     int gate_L            = 0;        // rows per image
@@ -121,7 +128,8 @@ void launch_gemm16_linear_geglu(hipStream_t s, void* dst16, const void* a16, int
                                 const float* bias);
 // split-K factor the launchers will use when given a workspace of factor * rows * M floats (1 = no split)
 int gemm16_split_k(int64_t rows, int64_t M, int64_t K, bool conv);
-bool splitk_reduce_gn_supported(int64_t hw, int64_t C, int64_t N, int groups);  // the slab reduce of a split conv can also produce the next GroupNorm's statistics
+bool splitk_reduce_gn_supported(int64_t hw, int64_t C, int64_t N, int groups);
+bool splitk_reduce_ln_supported(int64_t rows, int64_t M);  // the slab reduce of a split Linear can also write the next LayerNorm's f16 operand image  // the slab reduce of a split conv can also produce the next GroupNorm's statistics
 void gemm16_set_t320_linear_max_split(int v);  // option "t320_linear_max_split" (4): most K slices a Linear takes on the 256x320 tile
 // the split a launch of this shape should take: S slices; inkernel = combined by the last-arriving workgroup of every output tile (the launcher
 // then needs `tiles` zeroed int counters and ws_bytes of slab space, and applies the full epilogue itself), else slabs + k_splitk_reduce (only
@@ -205,14 +213,15 @@ struct FlashOut {
 void flash_attn_set_ablate(int v);
 #endif
 void flash_attn_set_grid(int v);   // option "flash_grid"
-void flash_attn_set_qb2(int v);    // option "flash_qb2": two query blocks per wave (default on)
-void flash_attn_set_pp(int v);     // option "flash_pp": the 8-wave ping-pong kernel (default on)
-void flash_attn_set_vpf(int v);
-void flash_attn_set_vtr(int v);
-void flash_attn_set_ovl(int v);
-void flash_attn_set_nsel(int v);
-void flash_attn_set_short(int v);
-void gemm16_set_swp(int v);  // 1: transposed-accumulator epilogue for the big-token Linear tiles (experiment)  // 1: register-resident K / V kernel for Lk <= 96, d <= 64 (experiment)  // 1: select-free K / V staging (experiment)  // 1: overlapped issue order in the two-block d <= 48 kernel (experiment)  // bit per head-dim class: row-major V tiles read with the transposing LDS read    // option "flash_vpf": bit mask of head-dim classes whose kernel issues its LDS fragment reads ahead of the MFMAs
+void flash_attn_set_qb2(int v);    // option "flash_qb2": 1 = two query blocks per wave for the d = 40 max-slot launches (default), 2 = for every d <= 48 launch, 0 = off
+void flash_attn_set_pp(int v);     // option "flash_pp": the 8-wave ping-pong kernel (default 0: measured slower; 1 = d in (64, 96], 2 = wherever legal)
+void flash_attn_set_vpf(int v);    // option "flash_vpf": bit mask of head-dim classes (1: d <= 48, 2: <= 64, 4: <= 96, 8: <= 128, 16: above) whose kernel issues its LDS fragment reads ahead of the MFMAs
+void flash_attn_set_vtr(int v);    // option "flash_vtr": same bits: row-major V tiles read with the transposing LDS read (ds_read_b64_tr_b16)
+void flash_attn_set_ovl(int v);    // option "flash_ovl": 1 = overlapped issue order in the two-block d = 40 kernel (default), 2 = also the other d <= 48 two-block launches, 0 = phase by phase
+void flash_attn_set_nsel(int v);   // option "flash_nsel": 1 = select-free K / V staging in the d = 40 two-block, d = 64 and d = 128 kernels (default since round 4: bit-identical, -3..6 % per launch)
+void flash_attn_set_short(int v);  // option "flash_short": k_flash_short (K / V register-resident) for 64 < Lk <= 96, d <= 64: 0 = off, 1 = on, 2 = with the next block's Q prefetched (default)
+void gemm16_set_swp(int v);        // option "gemm16_swp": 1 = transposed-accumulator epilogue for the big-token Linear tiles (measured round 4: correct, 1 % slower per step; default 0)
+void gemm16_set_ln_r4(int v);      // option "ln_r4": 1 = LayerNorm -> f16 image with four rows per wave (16 lanes per row) for rows of <= 1280 floats
 void flash_attn_set_pp_min_tiles(int v);  // option "flash_pp_min_tiles"
 void flash_attn_set_mslot(int v);  // option "flash_mslot"
 void launch_flash_attn(hipStream_t s, const FlashOut& out, const View4& q, const View4& k, const View4& v, float scale);

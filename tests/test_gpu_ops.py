@@ -951,6 +951,43 @@ def test_split_conv_reduce_writes_group_norm_statistics(sd, oracle, gpu, rng, N,
         assert st["fused_gn_stats"] - before["fused_gn_stats"] == (1 if N * 32 >= 256 else 0)
 
 
+@pytest.mark.parametrize("tokens,K,M,res", [(2048, 5120, 1280, True), (2048, 1280, 1280, True), (1000, 2560, 640, True), (2048, 1280, 320, False)])
+def test_split_linear_reduce_writes_layer_norm_image(sd, oracle, gpu, rng, tokens, K, M, res):
+    """Transformer-block seam (block.hpp BasicTransformerBlock: x = x + attn(norm1(x)); norm2(x) -> ...): a split-K Linear (+bias, +residual) whose result
+    is read by LayerNorm -> affine feeding only a weight GEMM AND by a later ADD.  The slab reduce pass writes the f32 rows and the LayerNorm's f16
+    operand image (k_splitk_reduce_ln); both branches are checked (SDXL's 2048-token level: to_out / FF2 -> the next LayerNorm)."""
+    x = rng.standard_normal((tokens, K)).astype(np.float32)
+    r = (rng.standard_normal((tokens, M)) + 0.5).astype(np.float32)
+    w = (rng.standard_normal((M, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(M).astype(np.float32)
+    lw = (1 + 0.1 * rng.standard_normal(M)).astype(np.float32)
+    lb = rng.standard_normal(M).astype(np.float32)
+    w2 = (rng.standard_normal((M, M)) / np.sqrt(M)).astype(np.float32)
+
+    def build(g, L):
+        h = L.ggml_mul_mat(g.ctx, g.weight(w, F16), g.input(x))
+        h = L.ggml_add_inplace(g.ctx, h, g.weight(b, F32))
+        if res:
+            h = L.ggml_add(g.ctx, h, g.input(r))
+        t = L.ggml_norm(g.ctx, h, 1e-5)
+        t = L.ggml_mul_inplace(g.ctx, t, g.weight(lw, F32))
+        t = L.ggml_add_inplace(g.ctx, t, g.weight(lb, F32))
+        t = L.ggml_mul_mat(g.ctx, g.weight(w2, F16), t)
+        return L.ggml_add(g.ctx, t, h)
+
+    before = sd.backend_stats() if _on_gpu() else None
+    ref, out = run_both(sd, oracle, gpu, build)
+    assert out.shape[-2:] == (tokens, M) and np.isfinite(out).all()
+    assert rel_l2(out, ref) < 3e-4
+    if before is not None and not os.environ.get("SDCPP_BACKEND_OPTS"):
+        st = sd.backend_stats()
+        split = st["split_k_gemms"] - before["split_k_gemms"] + st["split_k_inlaunch"] - before["split_k_inlaunch"]
+        # the fusion is taken exactly when the first Linear runs split-K with the slab reduce pass
+        assert st["fused_ln_reduce"] - before["fused_ln_reduce"] in ((0, 1) if split else (0,))
+        if tokens == 2048 and K >= 1280 and M == 1280:
+            assert st["fused_ln_reduce"] - before["fused_ln_reduce"] == 1  # the SDXL shapes the fusion exists for
+
+
 @pytest.mark.parametrize("d,H,L_,N,K,f16", [(40, 8, 77, 3, 768, True), (40, 8, 77, 3, 768, False), (80, 4, 200, 2, 320, True), (64, 2, 24, 5, 128, False),
                                             (160, 2, 64, 2, 320, True), (40, 2, 300, 1, 64, False)])
 def test_projection_head_major_chain(sd, oracle, gpu, rng, d, H, L_, N, K, f16):
