@@ -129,8 +129,7 @@ GGML_MI355X_API int ggml_backend_mi355x_get_kernel_timings(struct ggml_backend_m
  * conv: "conv3w" (1: 3x3 / stride-1 convs on 16..128-wide maps on the LDS-window kernel), "conv3w_min_blocks" (8) / "conv3w_min_blocks_deep" (5:
  * least 32-channel blocks per K slice when the window kernel splits K);
  * "gemm16_swp" (0; 1 = the 256-row Linear tiles with the accumulator transposed, 16-byte epilogue accesses: correct, measured 1 % slower per SD1.5 step);
- * "fuse_ln_reduce" (1: the slab reduce of a split-K Linear also writes the f16 operand image of the LayerNorm that reads its result),
- * "ln_r4" (LayerNorm -> f16 image with four rows per wave);
+ * "fuse_ln_reduce" (1: the slab reduce of a split-K Linear also writes the f16 operand image of the LayerNorm that reads its result);
  * flash attention: "flash_vtr" (31: bit per head-dim class — V tiles row-major in LDS, fragments by ds_read_b64_tr_b16; 0 = transposing staging pass),
  * "flash_ovl" (1: the two-block d = 40 kernel issues one block's softmax inside the other block's MFMAs; 2: also the other d <= 48 launches; 0: off),
  * "flash_nsel" (1: select-free K / V staging, bit-identical; 0 = per-chunk selects), "flash_short" (2: register-resident K / V kernel for the

@@ -151,7 +151,12 @@ SD_API bool sd_get_tensor(sdm_ctx_t* ctx, const char* name, void* dst, size_t nb
 SD_API bool sd_get_tensor_f32(sdm_ctx_t* ctx, const char* name, float* dst, int64_t nelem);  /* dequantised */
 SD_API bool sd_set_tensor_f32(sdm_ctx_t* ctx, const char* name, const float* src, int64_t nelem); /* converts per stored type */
 
-/* ---- checkpoint files: safetensors (F32/F16/BF16) and GGUF v2/v3 (F32/F16/BF16/Q8_0/Q4_0) ----
+/* ---- checkpoint files, told apart by their first bytes:
+ *   safetensors          F32 / F16 / BF16 native; F64 / I64 / F8_E4M3 / F8_E5M2 widened at load
+ *   GGUF v2 / v3         F32 / F16 / BF16 / Q8_0 / Q4_0 native; Q4_1 / Q5_0 / Q5_1 / Q2_K / Q3_K / Q4_K / Q5_K / Q6_K / IQ4_NL decoded at load
+ *   PyTorch checkpoints  torch.save's zip container (.ckpt / .pt / .pth / .bin, PyTorch >= 1.6) and the legacy stream: float / half / bfloat16 /
+ *                        double / long storages of contiguous tensors, found in the root dictionary and the dictionaries nested in it ("state_dict");
+ *                        the pickle is interpreted, never executed (csrc/host/torch_ckpt_io.hpp)
  * Every parameter the model declares that the file names (original-LDM / sd.cpp GGUF names, e.g. "model.diffusion_model.input_blocks.0.0.weight")
  * is converted file dtype -> f32 -> the parameter's type (ModelLoader convert_tensor, src/model_loader.cpp:155-205) and uploaded.
  * Returns the number of parameters loaded, -1 on error (sd_last_error); *n_missing = declared but absent, *n_unused = in the file but unknown. */

@@ -908,7 +908,7 @@ void plan_linear(Builder& B, int i, hipStream_t s, std::vector<int>& chain) {
             size_t ln_off    = 0;
             const float *lnw = nullptr, *lnb = nullptr;
             float lneps      = 0.f;
-            if (g_opt.fuse_ln_reduce && g_opt.fusion && sk.S > 1 && !sk.inkernel && !redir && !ep.gate && emit_node == i && hm_d == 0 && splitk_reduce_ln_supported(tokens, M) &&
+            if (g_opt.fuse_ln_reduce && g_opt.fusion && sk.S > 1 && sk.S <= 4 && !sk.inkernel && !redir && !ep.gate && emit_node == i && hm_d == 0 && splitk_reduce_ln_supported(tokens, M) &&
                 !(gi.node(last)->flags & GGML_TENSOR_FLAG_OUTPUT)) {
                 const ggml_tensor* res = gi.node(last);
                 for (int k : gi.consumers[last]) {
@@ -3199,7 +3199,6 @@ void planner_set_option(const char* key, int value) {
     else if (!strcmp(key, "flash_nsel")) flash_attn_set_nsel(value);
     else if (!strcmp(key, "flash_short")) flash_attn_set_short(value);
     else if (!strcmp(key, "gemm16_swp")) gemm16_set_swp(value);
-    else if (!strcmp(key, "ln_r4")) gemm16_set_ln_r4(value);
     else if (!strcmp(key, "flash_pp_min_tiles")) flash_attn_set_pp_min_tiles(value);
     else if (!strcmp(key, "conv3w")) conv3w_set(value);
     else if (!strcmp(key, "hoist_emb")) g_opt.hoist_emb = value;

@@ -31,6 +31,7 @@
 #include "conditioner.hpp"
 #include "sampler.hpp"
 #include "model_io.hpp"
+#include "torch_ckpt_io.hpp"
 #include "name_conversion.hpp"
 #include "sd-mi355x.h"
 

@@ -25,7 +25,25 @@ namespace sdmi {
 // same way before its own convert step — F8 -> F16, F64 -> F32, I64 -> I32: src/model_io/safetensors_io.cpp:79-99, src/model_loader.cpp:81-153)
 // Q4_1 / Q5_0 / Q5_1: GGUF block quantisations the graph never computes in (the engine's parameter types are f32 / f16 / bf16 / q8_0 / q4_0); they are
 // decoded to f32 at load time and re-encoded in the parameter's type, like convert_tensor does for every source type (src/model_loader.cpp:155-205)
-enum class SrcKind { NATIVE, F64, I64, F8_E4M3, F8_E5M2, Q4_1, Q5_0, Q5_1 };
+// K-quants (Q2_K .. Q6_K: super-blocks of 256 weights with 4- / 6-bit sub-block scales — the q2_k / q3_k / q4_k FLUX and SD3.5 files docs/flux.md:36-38
+// points its users at) and IQ4_NL (32 weights, non-linear 4-bit code book) take the same route: decoded to f32 at load, re-encoded in the parameter's type.
+enum class SrcKind { NATIVE, F64, I64, F8_E4M3, F8_E5M2, Q4_1, Q5_0, Q5_1, Q2_K, Q3_K, Q4_K, Q5_K, Q6_K, IQ4_NL };
+
+// ggml type id -> (kind, weights per block, bytes per block) of the block formats decoded at load time; false for every other type
+inline bool gguf_decoded_kind(int ggml_type_id, SrcKind& kind, int& blck, int& bytes) {
+    switch (ggml_type_id) {
+        case 3: kind = SrcKind::Q4_1, blck = 32, bytes = 20; return true;
+        case 6: kind = SrcKind::Q5_0, blck = 32, bytes = 22; return true;
+        case 7: kind = SrcKind::Q5_1, blck = 32, bytes = 24; return true;
+        case 10: kind = SrcKind::Q2_K, blck = 256, bytes = 84; return true;
+        case 11: kind = SrcKind::Q3_K, blck = 256, bytes = 110; return true;
+        case 12: kind = SrcKind::Q4_K, blck = 256, bytes = 144; return true;
+        case 13: kind = SrcKind::Q5_K, blck = 256, bytes = 176; return true;
+        case 14: kind = SrcKind::Q6_K, blck = 256, bytes = 210; return true;
+        case 20: kind = SrcKind::IQ4_NL, blck = 32, bytes = 18; return true;
+        default: return false;
+    }
+}
 
 struct FileTensor {
     std::string name;
@@ -214,6 +232,134 @@ inline void decode_src_kind(SrcKind kind, const uint8_t* raw, int64_t n, float* 
                         y[j]      = (float)x0 * d + m;
                         y[j + 16] = (float)x1 * d + m;
                     }
+                }
+            }
+            break;
+        }
+        // ---- K-quants (ggml-common.h block_q{2,3,4,5,6}_K; QK_K = 256; all fields little-endian).  Values follow upstream's dequantize_row_q*_K.
+        //   q2_K {u8 scales[16] (low nibble: scale, high nibble: min, per 16 weights); u8 qs[64] (2 bits per weight); f16 d; f16 dmin}
+        //        x = d * sc * q - dmin * mn.  Weight order: per 128-weight half, bit pairs 0..3 of qs[0..31]: pair s covers weights 32 s .. 32 s + 31
+        case SrcKind::Q2_K:
+            for (int64_t blk = 0; blk < n / 256; ++blk) {
+                const uint8_t* p  = raw + blk * 84;
+                const uint8_t* sc = p;
+                const uint8_t* q  = p + 16;
+                ggml_fp16_t dh, mh;
+                memcpy(&dh, p + 80, 2);
+                memcpy(&mh, p + 82, 2);
+                const float d = ggml_fp16_to_fp32(dh), dmin = ggml_fp16_to_fp32(mh);
+                float* y = dst + blk * 256;
+                int is   = 0;
+                for (int half = 0; half < 2; ++half, q += 32)
+                    for (int shift = 0; shift < 8; shift += 2)
+                        for (int part = 0; part < 2; ++part, ++is) {
+                            const float dl = d * (float)(sc[is] & 0xF), ml = dmin * (float)(sc[is] >> 4);
+                            for (int l = 0; l < 16; ++l) *y++ = dl * (float)((q[l + 16 * part] >> shift) & 3) - ml;
+                        }
+            }
+            break;
+        //   q3_K {u8 hmask[32] (bit b of hmask[l]: high bit of weight 32 b + l); u8 qs[64] (low 2 bits, order as q2_K); u8 scales[12] (16 six-bit scales:
+        //        low 4 bits in bytes 0..7 (nibbles), high 2 bits in bytes 8..11); f16 d}     x = d * (scale - 32) * (q2 - (hbit ? 0 : 4))
+        case SrcKind::Q3_K:
+            for (int64_t blk = 0; blk < n / 256; ++blk) {
+                const uint8_t* p  = raw + blk * 110;
+                const uint8_t* hm = p;
+                const uint8_t* q  = p + 32;
+                const uint8_t* s8 = p + 96;
+                ggml_fp16_t dh;
+                memcpy(&dh, p + 108, 2);
+                const float d = ggml_fp16_to_fp32(dh);
+                int scales[16];
+                for (int j = 0; j < 16; ++j) {
+                    const int lo = j < 8 ? (s8[j] & 0xF) : (s8[j - 8] >> 4);
+                    const int hi = (s8[8 + (j & 3)] >> (2 * (j >> 2))) & 3;
+                    scales[j]    = (lo | (hi << 4)) - 32;
+                }
+                float* y  = dst + blk * 256;
+                int is    = 0;
+                uint8_t m = 1;
+                for (int half = 0; half < 2; ++half, q += 32)
+                    for (int shift = 0; shift < 8; shift += 2, m = (uint8_t)(m << 1))
+                        for (int part = 0; part < 2; ++part, ++is) {
+                            const float dl = d * (float)scales[is];
+                            for (int l = 0; l < 16; ++l) {
+                                const int k = l + 16 * part;
+                                *y++        = dl * (float)((int)((q[k] >> shift) & 3) - ((hm[k] & m) ? 0 : 4));
+                            }
+                        }
+            }
+            break;
+        //   q4_K {f16 d; f16 dmin; u8 scales[12] (8 six-bit scales + 8 six-bit mins, get_scale_min_k4); u8 qs[128]}: per 64 weights, 32 low nibbles then 32 high
+        //   q5_K {f16 d; f16 dmin; u8 scales[12]; u8 qh[32] (bit 2 g + 0 / 1 of qh[l]: fifth bit of the low / high nibble weight l of group g); u8 qs[128]}
+        //        x = d * sc * q - dmin * mn
+        case SrcKind::Q4_K:
+        case SrcKind::Q5_K: {
+            const bool five = kind == SrcKind::Q5_K;
+            const int bs    = five ? 176 : 144;
+            for (int64_t blk = 0; blk < n / 256; ++blk) {
+                const uint8_t* p  = raw + blk * bs;
+                ggml_fp16_t dh, mh;
+                memcpy(&dh, p, 2);
+                memcpy(&mh, p + 2, 2);
+                const float d = ggml_fp16_to_fp32(dh), dmin = ggml_fp16_to_fp32(mh);
+                const uint8_t* s12 = p + 4;
+                const uint8_t* qh  = p + 16;
+                const uint8_t* q   = p + (five ? 48 : 16);
+                float* y = dst + blk * 256;
+                for (int g = 0; g < 4; ++g, q += 32)
+                    for (int part = 0; part < 2; ++part) {
+                        const int j = 2 * g + part;
+                        int sc, mn;
+                        if (j < 4) {
+                            sc = s12[j] & 63;
+                            mn = s12[j + 4] & 63;
+                        } else {
+                            sc = (s12[j + 4] & 0xF) | ((s12[j - 4] >> 6) << 4);
+                            mn = (s12[j + 4] >> 4) | ((s12[j] >> 6) << 4);
+                        }
+                        const float dl = d * (float)sc, ml = dmin * (float)mn;
+                        for (int l = 0; l < 32; ++l) {
+                            int v = part ? (q[l] >> 4) : (q[l] & 0xF);
+                            if (five && ((qh[l] >> j) & 1)) v += 16;
+                            *y++ = dl * (float)v - ml;
+                        }
+                    }
+            }
+            break;
+        }
+        //   q6_K {u8 ql[128]; u8 qh[64]; i8 scales[16] (per 16 weights); f16 d}: per 128-weight half, weight l + 32 c (c = 0..3) has its low 4 bits in
+        //        ql[l + 32 (c & 1)] (low nibble for c < 2, high nibble otherwise) and its high 2 bits at bits 2 c of qh[l];  x = d * scale * (q - 32)
+        case SrcKind::Q6_K:
+            for (int64_t blk = 0; blk < n / 256; ++blk) {
+                const uint8_t* p  = raw + blk * 210;
+                const uint8_t* ql = p;
+                const uint8_t* qh = p + 128;
+                const int8_t* sc  = (const int8_t*)(p + 192);
+                ggml_fp16_t dh;
+                memcpy(&dh, p + 208, 2);
+                const float d = ggml_fp16_to_fp32(dh);
+                float* y = dst + blk * 256;
+                for (int half = 0; half < 2; ++half, y += 128, ql += 64, qh += 32, sc += 8)
+                    for (int l = 0; l < 32; ++l)
+                        for (int c = 0; c < 4; ++c) {
+                            const int lo = (c < 2) ? (ql[l + 32 * (c & 1)] & 0xF) : (ql[l + 32 * (c & 1)] >> 4);
+                            const int q6 = (lo | (((qh[l] >> (2 * c)) & 3) << 4)) - 32;
+                            y[l + 32 * c] = d * (float)sc[l / 16 + 2 * c] * (float)q6;
+                        }
+            }
+            break;
+        //   iq4_nl {f16 d; u8 qs[16]}: x = d * kvalues[q], element j in the low nibble of byte j, element j + 16 in the high nibble
+        case SrcKind::IQ4_NL: {
+            static const int8_t kv[16] = {-127, -104, -83, -65, -49, -35, -22, -10, 1, 13, 25, 38, 53, 69, 89, 113};
+            for (int64_t blk = 0; blk < n / 32; ++blk) {
+                const uint8_t* p = raw + blk * 18;
+                ggml_fp16_t dh;
+                memcpy(&dh, p, 2);
+                const float d = ggml_fp16_to_fp32(dh);
+                float* y = dst + blk * 32;
+                for (int j = 0; j < 16; ++j) {
+                    y[j]      = d * (float)kv[p[2 + j] & 0xF];
+                    y[j + 16] = d * (float)kv[p[2 + j] >> 4];
                 }
             }
             break;
@@ -433,21 +579,23 @@ inline bool read_gguf(const std::string& path, ModelFile& mf) {
     fclose(f);
     std::vector<FileTensor> keep;
     for (auto& t : mf.tensors) {
-        const int ty = (int)t.type;  // ggml type ids: 3 = q4_1, 6 = q5_0, 7 = q5_1
-        if (ty == 3 || ty == 6 || ty == 7) {
-            const uint64_t bs = ty == 3 ? 20 : (ty == 6 ? 22 : 24);
+        const int ty = (int)t.type;
+        SrcKind dk;
+        int dblck = 0, dbytes = 0;
+        if (gguf_decoded_kind(ty, dk, dblck, dbytes)) {  // q4_1 / q5_0 / q5_1 / K-quants / iq4_nl: decoded to f32 when the tensor is read
+            const uint64_t bs = (uint64_t)dbytes;
             uint64_t n        = 1;
-            bool dims_ok      = t.ne[0] > 0 && t.ne[0] % 32 == 0 && t.ne[0] < (1ll << 40);
+            bool dims_ok      = t.ne[0] > 0 && t.ne[0] % dblck == 0 && t.ne[0] < (1ll << 40);
             for (int d = 0; d < 4 && dims_ok; ++d) {
                 dims_ok = t.ne[d] > 0 && n <= (1ull << 46) / (uint64_t)t.ne[d];
                 n *= (uint64_t)t.ne[d];
             }
-            const uint64_t nb = dims_ok ? n / 32 * bs : 0;
+            const uint64_t nb = dims_ok ? n / (uint64_t)dblck * bs : 0;
             if (!dims_ok || t.offset > fsize || data0 > fsize - t.offset || nb > fsize - t.offset - data0) {
                 mf.error = "tensor '" + t.name + "' has invalid dimensions or lies outside the file";
                 return false;
             }
-            t.kind   = ty == 3 ? SrcKind::Q4_1 : (ty == 6 ? SrcKind::Q5_0 : SrcKind::Q5_1);
+            t.kind   = dk;
             t.type   = GGML_TYPE_F32;  // what decode_src_kind delivers
             t.nbytes = nb;
             t.offset += data0;
@@ -455,7 +603,7 @@ inline bool read_gguf(const std::string& path, ModelFile& mf) {
             continue;
         }
         const bool known = t.type == GGML_TYPE_F32 || t.type == GGML_TYPE_F16 || t.type == GGML_TYPE_BF16 || t.type == GGML_TYPE_Q8_0 || t.type == GGML_TYPE_Q4_0;
-        if (!known) {  // K-quants, IQ types, integer tensors: not decodable by this build — an ERROR if a declared parameter needs one
+        if (!known) {  // IQ types other than iq4_nl, ternary / MX types, integer tensors: not decodable by this build — an ERROR if a declared parameter needs one
             mf.undecodable[t.name] = "ggml type " + std::to_string((int)t.type);
             continue;
         }
@@ -480,6 +628,8 @@ inline bool read_gguf(const std::string& path, ModelFile& mf) {
     return true;
 }
 
+inline bool read_torch_zip(const std::string& path, ModelFile& mf);     // torch_ckpt_io.hpp
+inline bool read_torch_legacy(const std::string& path, ModelFile& mf);  // torch_ckpt_io.hpp
 inline bool read_model_file(const std::string& path, ModelFile& mf) {
     FILE* f = fopen(path.c_str(), "rb");
     if (!f) {
@@ -490,6 +640,8 @@ inline bool read_model_file(const std::string& path, ModelFile& mf) {
     const size_t n = fread(magic, 1, 4, f);
     fclose(f);
     if (n == 4 && memcmp(magic, "GGUF", 4) == 0) return read_gguf(path, mf);
+    if (n == 4 && memcmp(magic, "PK\x03\x04", 4) == 0) return read_torch_zip(path, mf);             // torch.save since PyTorch 1.6 (.ckpt / .pt / .pth / .bin)
+    if (n == 4 && (unsigned char)magic[0] == 0x80 && magic[1] == 2 && (unsigned char)magic[2] == 0x8a) return read_torch_legacy(path, mf);  // older torch.save: PROTO 2, LONG1 magic
     return read_safetensors(path, mf);
 }
 

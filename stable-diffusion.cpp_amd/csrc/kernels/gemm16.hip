@@ -989,94 +989,108 @@ static void launch_splitk_reduce(hipStream_t s, float* dst, const float* ws, int
         k_splitk_reduce<false><<<(unsigned)((n + 255) / 256), 256, 0, s>>>(dst, ws, S, n, n, bias, inner, (int)C, residual, chan_add, chan_ld);
 }
 
-// Slab reduce of a split-K Linear FUSED with the LayerNorm that reads the result next (Epilogue::ln_*): a 16-lane group owns one row (four rows
-// per wave, NV float4 per lane, M <= 64 * NV), sums the S slabs in slice order, adds bias and residual in the order of k_splitk_reduce (identical
-// values), stores the f32 row and normalises it from registers exactly as k_layer_norm_f16_r4 does.  Saves the LayerNorm launch and its read of
-// the tensor: at SDXL's 32x32 level (2048 rows) these are 10 us launches of which there are three per transformer block.
-template <int NV>
-__global__ __launch_bounds__(256) void k_splitk_reduce_ln(float* __restrict__ dst, const float* __restrict__ ws, int S, int64_t slab, int64_t nrows, int M, int Kp,
+// Slab reduce of a split-K Linear FUSED with the LayerNorm that reads the result next (Epilogue::ln_*): one wave per row (NV float4 per lane,
+// M <= 256 * NV), S <= 4 slabs summed in slice order, bias and residual added in the order of k_splitk_reduce (identical values), the f32 row
+// stored, then normalised from registers exactly as k_layer_norm_f16_reg does (same per-lane order, same wave reductions: identical image).
+// Saves the LayerNorm launch and its read of the tensor: at SDXL's 32x32 level (2048 rows) both passes are ~11 us launches bound by their latency
+// chain, three pairs per transformer block.  (First version, round 4: four rows per wave on 16-lane groups — 128 workgroups for 2048 rows and
+// 100 dependent loads per lane: 45 us per launch instead of 11.7 + 10.6, profiles/r05b_*; the standalone LayerNorm in that layout was also
+// slower, 2.28 -> 4.55 ms per SDXL forward, and was removed.)
+template <int NV, int S>
+__global__ __launch_bounds__(256) void k_splitk_reduce_ln(float* __restrict__ dst, const float* __restrict__ ws, int64_t slab, int64_t nrows, int M, int Kp,
                                                           const float* __restrict__ bias, const float* residual, _Float16* __restrict__ dst16, float eps,
                                                           const float* __restrict__ w, const float* __restrict__ b) {
-    const int sub     = threadIdx.x & 15;
-    const int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
-    const bool live   = row < nrows;
-    const int64_t rr  = live ? row : nrows - 1;
-    const int n4      = M / 4;
-    float4 v[NV];
+    const int lane    = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= nrows) return;
+    const int n4 = M / 4;
+    float4 v[NV], t[S][NV], r[NV];
+    // every load of the row is issued before the first add
 #pragma unroll
-    for (int j = 0; j < NV; ++j) v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int s = 0; s < S; ++s) {
-        const float4* p = (const float4*)(ws + s * slab + rr * M);
+        const float4* p = (const float4*)(ws + s * slab + row * M);
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            const int i = sub + 16 * j;
-            if (i < n4) {
-                const float4 t = p[i];
-                v[j].x += t.x; v[j].y += t.y; v[j].z += t.z; v[j].w += t.w;
-            }
+            const int i = lane + 64 * j;
+            t[s][j]     = i < n4 ? p[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
-        const int i = sub + 16 * j;
-        if (i >= n4) continue;
-        if (bias) { const float4 t = ((const float4*)bias)[i]; v[j].x += t.x; v[j].y += t.y; v[j].z += t.z; v[j].w += t.w; }
-        if (residual) { const float4 t = ((const float4*)(residual + rr * M))[i]; v[j].x += t.x; v[j].y += t.y; v[j].z += t.z; v[j].w += t.w; }
-        if (live) ((float4*)(dst + row * M))[i] = v[j];
+        const int i = lane + 64 * j;
+        r[j]        = (residual && i < n4) ? ((const float4*)(residual + row * M))[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    auto sum16 = [](float t) {
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
-        return t;
-    };
+    for (int j = 0; j < NV; ++j) {
+        const int i = lane + 64 * j;
+        v[j]        = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            v[j].x += t[s][j].x; v[j].y += t[s][j].y; v[j].z += t[s][j].z; v[j].w += t[s][j].w;
+        }
+        if (i >= n4) continue;
+        if (bias) { const float4 bb = ((const float4*)bias)[i]; v[j].x += bb.x; v[j].y += bb.y; v[j].z += bb.z; v[j].w += bb.w; }
+        if (residual) { v[j].x += r[j].x; v[j].y += r[j].y; v[j].z += r[j].z; v[j].w += r[j].w; }
+        ((float4*)(dst + row * M))[i] = v[j];
+    }
     float sm = 0.f;
 #pragma unroll
     for (int j = 0; j < NV; ++j) sm += (v[j].x + v[j].y) + (v[j].z + v[j].w);  // slots beyond n4 hold zeros
-    const float mean = sum16(sm) / (float)M;
+    const float mean = wave_sum(sm) / (float)M;
     float q = 0.f;
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
-        if (sub + 16 * j < n4) {
+        if (lane + 64 * j < n4) {
             const float a = v[j].x - mean, bb = v[j].y - mean, c = v[j].z - mean, d = v[j].w - mean;
             q += (a * a + bb * bb) + (c * c + d * d);
         }
     }
-    const float rstd = rsqrtf(sum16(q) / (float)M + eps);
-    if (!live) return;
+    const float rstd = rsqrtf(wave_sum(q) / (float)M + eps);
     _Float16* yr = dst16 + row * Kp;
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
-        const int i = sub + 16 * j;
+        const int i = lane + 64 * j;
         if (i >= Kp / 4) continue;
         half4_t h = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
         if (i < n4) {
-            float4 t = v[j];
-            t.x = (t.x - mean) * rstd; t.y = (t.y - mean) * rstd; t.z = (t.z - mean) * rstd; t.w = (t.w - mean) * rstd;
-            if (w) { const float4 ww = ((const float4*)w)[i]; t.x *= ww.x; t.y *= ww.y; t.z *= ww.z; t.w *= ww.w; }
-            if (b) { const float4 bb = ((const float4*)b)[i]; t.x += bb.x; t.y += bb.y; t.z += bb.z; t.w += bb.w; }
-            h[0] = (_Float16)t.x; h[1] = (_Float16)t.y; h[2] = (_Float16)t.z; h[3] = (_Float16)t.w;
+            float4 x = v[j];
+            x.x = (x.x - mean) * rstd; x.y = (x.y - mean) * rstd; x.z = (x.z - mean) * rstd; x.w = (x.w - mean) * rstd;
+            if (w) { const float4 ww = ((const float4*)w)[i]; x.x *= ww.x; x.y *= ww.y; x.z *= ww.z; x.w *= ww.w; }
+            if (b) { const float4 bb = ((const float4*)b)[i]; x.x += bb.x; x.y += bb.y; x.z += bb.z; x.w += bb.w; }
+            h[0] = (_Float16)x.x; h[1] = (_Float16)x.y; h[2] = (_Float16)x.z; h[3] = (_Float16)x.w;
         }
         *(half4_t*)(yr + i * 4) = h;
     }
 }
 bool splitk_reduce_ln_supported(int64_t rows, int64_t M) { return M % 4 == 0 && rup64(M, 64) <= 1280 && rows >= 64; }
 static void launch_splitk_reduce_ln(hipStream_t s, float* dst, const float* ws, int S, int64_t rows, int64_t M, const Epilogue& e) {
-    if (!splitk_reduce_ln_supported(rows, M) || ((((uintptr_t)dst | (uintptr_t)ws | (uintptr_t)e.residual | (uintptr_t)e.bias | (uintptr_t)e.ln_w | (uintptr_t)e.ln_b)) & 15) != 0) {
+    if (!splitk_reduce_ln_supported(rows, M) || S < 2 || S > 4 ||
+        ((((uintptr_t)dst | (uintptr_t)ws | (uintptr_t)e.residual | (uintptr_t)e.bias | (uintptr_t)e.ln_w | (uintptr_t)e.ln_b)) & 15) != 0) {
         // the planner registered this LayerNorm as done (plan_linear look-ahead checks the same conditions with the same addresses)
-        fprintf(stderr, "ggml-mi355x: split-K reduce asked for a LayerNorm image on a shape / alignment it does not serve\n");
+        fprintf(stderr, "ggml-mi355x: split-K reduce asked for a LayerNorm image on a shape / slice count / alignment it does not serve\n");
         abort();
     }
     const int Kp = (int)rup64(M, 64);
     // algorithmic bytes: the slabs + residual in, the f32 tensor and the f16 image out
     KScope ks_(s, KF_SPLITK, 0.0, (double)rows * M * 4.0 * (S + 1 + (e.residual ? 1 : 0)) + (double)rows * Kp * 2.0);
-    const unsigned grid = (unsigned)((rows + 15) / 16);
-#define SKLN(NV_) k_splitk_reduce_ln<NV_><<<grid, 256, 0, s>>>(dst, ws, S, rows * M, rows, (int)M, Kp, e.bias, e.residual, (_Float16*)e.ln_dst16, e.ln_eps, e.ln_w, e.ln_b)
-    if (Kp <= 64 * 5)
-        SKLN(5);
-    else if (Kp <= 64 * 10)
-        SKLN(10);
+    const unsigned grid = (unsigned)((rows + 3) / 4);
+#define SKLN(NV_, S_) k_splitk_reduce_ln<NV_, S_><<<grid, 256, 0, s>>>(dst, ws, rows * M, rows, (int)M, Kp, e.bias, e.residual, (_Float16*)e.ln_dst16, e.ln_eps, e.ln_w, e.ln_b)
+#define SKLN_S(NV_)             \
+    do {                        \
+        if (S == 2)             \
+            SKLN(NV_, 2);       \
+        else if (S == 3)        \
+            SKLN(NV_, 3);       \
+        else                    \
+            SKLN(NV_, 4);       \
+    } while (0)
+    if (Kp <= 256 * 2)
+        SKLN_S(2);
+    else if (Kp <= 256 * 3)
+        SKLN_S(3);
     else
-        SKLN(20);
+        SKLN_S(5);
+#undef SKLN_S
 #undef SKLN
 }
 
@@ -1502,84 +1516,11 @@ __global__ __launch_bounds__(256) void k_layer_norm_f16_reg(_Float16* __restrict
         *(half4_t*)(yr + i * 4) = h;
     }
 }
-// four rows per wave: a 16-lane group keeps its row in NV float4 registers per lane (ne0 <= 64 * NV).  Against the one-row-per-wave kernel above
-// (C = 320: 80 float4 over 64 lanes = two load instructions of which the second is three quarters empty, 1.25 KB in flight per wave) every lane
-// of every load carries data, a wave has 4 rows = 5 KB in flight, and the two reductions take 4 shuffle steps instead of 6.
-template <int NV>
-__global__ __launch_bounds__(256) void k_layer_norm_f16_r4(_Float16* __restrict__ dst, const float* __restrict__ x, int ne0, int Kp, int64_t nrows, int64_t xs,
-                                                           float eps, const float* __restrict__ w, const float* __restrict__ b, int rms, int64_t mod_L) {
-    const int sub     = threadIdx.x & 15;
-    const int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
-    const bool live   = row < nrows;  // dead groups keep running: the shuffles below are wave-wide
-    const int64_t rr  = live ? row : nrows - 1;
-    const float wadd  = mod_L > 0 ? 1.f : 0.f;
-    if (mod_L > 0) {
-        w += (rr / mod_L) * ne0;
-        b += (rr / mod_L) * ne0;
-    }
-    const float4* xr = (const float4*)(x + rr * xs);
-    const int n4     = ne0 / 4;
-    float4 v[NV];
-#pragma unroll
-    for (int j = 0; j < NV; ++j) {
-        const int i = sub + 16 * j;
-        v[j]        = i < n4 ? xr[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    auto sum16 = [](float t) {
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
-        return t;
-    };
-    float mean = 0.f;
-    if (!rms) {
-        float s = 0.f;
-#pragma unroll
-        for (int j = 0; j < NV; ++j) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
-        mean = sum16(s) / (float)ne0;
-    }
-    float q = 0.f;
-#pragma unroll
-    for (int j = 0; j < NV; ++j) {
-        if (sub + 16 * j < n4) {
-            const float a = v[j].x - mean, bb = v[j].y - mean, c = v[j].z - mean, d = v[j].w - mean;
-            q += (a * a + bb * bb) + (c * c + d * d);
-        }
-    }
-    const float rstd = rsqrtf(sum16(q) / (float)ne0 + eps);
-    if (!live) return;
-    _Float16* yr = dst + row * Kp;
-#pragma unroll
-    for (int j = 0; j < NV; ++j) {
-        const int i = sub + 16 * j;
-        if (i >= Kp / 4) continue;
-        half4_t h = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
-        if (i < n4) {
-            float4 t = v[j];
-            t.x = (t.x - mean) * rstd; t.y = (t.y - mean) * rstd; t.z = (t.z - mean) * rstd; t.w = (t.w - mean) * rstd;
-            if (w) { const float4 ww = ((const float4*)w)[i]; t.x *= ww.x + wadd; t.y *= ww.y + wadd; t.z *= ww.z + wadd; t.w *= ww.w + wadd; }
-            if (b) { const float4 bb = ((const float4*)b)[i]; t.x += bb.x; t.y += bb.y; t.z += bb.z; t.w += bb.w; }
-            h[0] = (_Float16)t.x; h[1] = (_Float16)t.y; h[2] = (_Float16)t.z; h[3] = (_Float16)t.w;
-        }
-        *(half4_t*)(yr + i * 4) = h;
-    }
-}
-static int g_ln_r4 = 0;  // option "ln_r4" (round 4 experiment)
-void gemm16_set_ln_r4(int v) { g_ln_r4 = v; }
 void launch_layer_norm_f16(hipStream_t s, void* dst, const float* x, int64_t ne0, int64_t nrows, int64_t xs, float eps, const float* w, const float* b, bool rms,
                            int64_t mod_L) {
     KScope ks_(s, KF_LN_F16, 0.0, (double)nrows * ne0 * 4.0 + (double)nrows * rup64(ne0, 64) * 2.0);
     const int Kp = (int)rup64(ne0, 64);
 #define LN16_ARGS (_Float16*)dst, x, (int)ne0, Kp, nrows, xs, eps, w, b, rms ? 1 : 0, mod_L
-    if (g_ln_r4 && Kp <= 1280 && nrows >= 64) {
-        const unsigned g4 = (unsigned)((nrows + 15) / 16);
-        if (Kp <= 64 * 5)
-            k_layer_norm_f16_r4<5><<<g4, 256, 0, s>>>(LN16_ARGS);
-        else if (Kp <= 64 * 10)
-            k_layer_norm_f16_r4<10><<<g4, 256, 0, s>>>(LN16_ARGS);
-        else
-            k_layer_norm_f16_r4<20><<<g4, 256, 0, s>>>(LN16_ARGS);
-        return;
-    }
     const unsigned grid = (unsigned)((nrows + 3) / 4);
     if (Kp <= 256 * 2)
         k_layer_norm_f16_reg<2><<<grid, 256, 0, s>>>(LN16_ARGS);

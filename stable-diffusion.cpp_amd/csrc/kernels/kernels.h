@@ -221,7 +221,6 @@ void flash_attn_set_ovl(int v);    // option "flash_ovl": 1 = overlapped issue o
 void flash_attn_set_nsel(int v);   // option "flash_nsel": 1 = select-free K / V staging in the d = 40 two-block, d = 64 and d = 128 kernels (default since round 4: bit-identical, -3..6 % per launch)
 void flash_attn_set_short(int v);  // option "flash_short": k_flash_short (K / V register-resident) for 64 < Lk <= 96, d <= 64: 0 = off, 1 = on, 2 = with the next block's Q prefetched (default)
 void gemm16_set_swp(int v);        // option "gemm16_swp": 1 = transposed-accumulator epilogue for the big-token Linear tiles (measured round 4: correct, 1 % slower per step; default 0)
-void gemm16_set_ln_r4(int v);      // option "ln_r4": 1 = LayerNorm -> f16 image with four rows per wave (16 lanes per row) for rows of <= 1280 floats
 void flash_attn_set_pp_min_tiles(int v);  // option "flash_pp_min_tiles"
 void flash_attn_set_mslot(int v);  // option "flash_mslot"
 void launch_flash_attn(hipStream_t s, const FlashOut& out, const View4& q, const View4& k, const View4& v, float scale);

@@ -210,6 +210,113 @@ def test_gguf_q4_1_q5_blocks_are_decoded_at_load(sd, oracle, tmp_path, kind, gty
         e.load_weights(bad)
 
 
+def _rand_f16(rng, n, lo=0.002, hi=0.05):
+    return (rng.uniform(lo, hi, n) * rng.choice([-1.0, 1.0], n)).astype(np.float16)
+
+
+def _kquant_random_blocks(rng, kind, nblk):
+    """Random VALID super-blocks of a K-quant (every bit pattern of the integer fields is legal; the f16 scales are finite) and the values they decode
+    to, computed here in vectorised numpy from the public block layouts (ggml-common.h) the way gguf-py's quants.py does — independent of the scalar
+    loops in model_io.hpp, which follow ggml-quants.c dequantize_row_q*_K."""
+    if kind == "q2_K":  # {u8 scales[16]; u8 qs[64]; f16 d; f16 dmin}
+        scales = rng.integers(0, 256, (nblk, 16), dtype=np.uint8)
+        qs = rng.integers(0, 256, (nblk, 64), dtype=np.uint8)
+        d, dmin = _rand_f16(rng, nblk), _rand_f16(rng, nblk)
+        raw = b"".join(scales[i].tobytes() + qs[i].tobytes() + d[i].tobytes() + dmin[i].tobytes() for i in range(nblk))
+        dl = d.astype(np.float32)[:, None] * (scales & 0xF).astype(np.float32)          # [nblk, 16]
+        ml = dmin.astype(np.float32)[:, None] * (scales >> 4).astype(np.float32)
+        q = (qs.reshape(nblk, 2, 1, 32) >> np.array([0, 2, 4, 6], np.uint8).reshape(1, 1, 4, 1)) & 3   # [nblk, half, shift, 32]
+        q = q.reshape(nblk, 16, 16).astype(np.float32)                                   # 16 groups of 16 in output order
+        val = dl[:, :, None] * q - ml[:, :, None]
+    elif kind == "q3_K":  # {u8 hmask[32]; u8 qs[64]; u8 scales[12]; f16 d}
+        hmask = rng.integers(0, 256, (nblk, 32), dtype=np.uint8)
+        qs = rng.integers(0, 256, (nblk, 64), dtype=np.uint8)
+        sc12 = rng.integers(0, 256, (nblk, 12), dtype=np.uint8)
+        d = _rand_f16(rng, nblk)
+        raw = b"".join(hmask[i].tobytes() + qs[i].tobytes() + sc12[i].tobytes() + d[i].tobytes() for i in range(nblk))
+        lo = np.concatenate([sc12[:, :8] & 0xF, sc12[:, :8] >> 4], axis=1)               # 16 low nibbles
+        hi = np.stack([(sc12[:, 8:12] >> s) & 3 for s in (0, 2, 4, 6)], axis=1).reshape(nblk, 16)
+        scales = (lo | (hi << 4)).astype(np.int32) - 32
+        q = (qs.reshape(nblk, 2, 1, 32) >> np.array([0, 2, 4, 6], np.uint8).reshape(1, 1, 4, 1)) & 3
+        q = q.reshape(nblk, 8, 32).astype(np.int32)                                      # 8 runs of 32 weights
+        hb = ((hmask[:, None, :] >> np.arange(8, dtype=np.uint8).reshape(1, 8, 1)) & 1).astype(np.int32)
+        q = q - 4 * (1 - hb)
+        val = d.astype(np.float32)[:, None, None] * scales.reshape(nblk, 16, 1).astype(np.float32) * q.reshape(nblk, 16, 16).astype(np.float32)
+    elif kind in ("q4_K", "q5_K"):  # {f16 d; f16 dmin; u8 scales[12]; [u8 qh[32];] u8 qs[128]}
+        sc12 = rng.integers(0, 256, (nblk, 12), dtype=np.uint8)
+        qs = rng.integers(0, 256, (nblk, 128), dtype=np.uint8)
+        qh = rng.integers(0, 256, (nblk, 32), dtype=np.uint8)
+        d, dmin = _rand_f16(rng, nblk), _rand_f16(rng, nblk)
+        raw = b"".join(d[i].tobytes() + dmin[i].tobytes() + sc12[i].tobytes() + (qh[i].tobytes() if kind == "q5_K" else b"") + qs[i].tobytes() for i in range(nblk))
+        sc = np.concatenate([sc12[:, 0:4] & 63, (sc12[:, 8:12] & 0xF) | ((sc12[:, 0:4] >> 6) << 4)], axis=1).astype(np.float32)
+        mn = np.concatenate([sc12[:, 4:8] & 63, (sc12[:, 8:12] >> 4) | ((sc12[:, 4:8] >> 6) << 4)], axis=1).astype(np.float32)
+        q4 = qs.reshape(nblk, 4, 32)
+        q = np.stack([q4 & 0xF, q4 >> 4], axis=2).reshape(nblk, 8, 32).astype(np.int32)  # group g: low nibbles then high nibbles
+        if kind == "q5_K":
+            q = q + 16 * ((qh[:, None, :] >> np.arange(8, dtype=np.uint8).reshape(1, 8, 1)) & 1).astype(np.int32)
+        val = d.astype(np.float32)[:, None, None] * sc[:, :, None] * q.astype(np.float32) - dmin.astype(np.float32)[:, None, None] * mn[:, :, None]
+    elif kind == "q6_K":  # {u8 ql[128]; u8 qh[64]; i8 scales[16]; f16 d}
+        ql = rng.integers(0, 256, (nblk, 128), dtype=np.uint8)
+        qh = rng.integers(0, 256, (nblk, 64), dtype=np.uint8)
+        sc = rng.integers(-128, 128, (nblk, 16), dtype=np.int8)
+        d = _rand_f16(rng, nblk, 0.0005, 0.004)
+        raw = b"".join(ql[i].tobytes() + qh[i].tobytes() + sc[i].tobytes() + d[i].tobytes() for i in range(nblk))
+        l2 = ql.reshape(nblk, 2, 2, 32)                                                  # [half][l32 block 0/1][l]
+        lo = np.stack([l2[:, :, 0] & 0xF, l2[:, :, 1] & 0xF, l2[:, :, 0] >> 4, l2[:, :, 1] >> 4], axis=2)  # [nblk, half, c, 32]
+        h2 = qh.reshape(nblk, 2, 1, 32)
+        hi = (h2 >> np.array([0, 2, 4, 6], np.uint8).reshape(1, 1, 4, 1)) & 3
+        q = (lo | (hi << 4)).astype(np.int32) - 32                                       # weight half*128 + 32 c + l
+        s = sc.reshape(nblk, 2, 4, 2).astype(np.float32)                                 # scale index half*8 + 2 c + l // 16
+        s = np.repeat(s, 16, axis=3)                                                     # [nblk, half, c, 32]
+        val = (d.astype(np.float32)[:, None, None, None] * s) * q.astype(np.float32)
+    else:  # iq4_nl {f16 d; u8 qs[16]}
+        kv = np.array([-127, -104, -83, -65, -49, -35, -22, -10, 1, 13, 25, 38, 53, 69, 89, 113], np.float32)
+        qs = rng.integers(0, 256, (nblk, 16), dtype=np.uint8)
+        d = _rand_f16(rng, nblk, 0.0002, 0.002)
+        raw = b"".join(d[i].tobytes() + qs[i].tobytes() for i in range(nblk))
+        val = d.astype(np.float32)[:, None] * np.concatenate([kv[qs & 0xF], kv[qs >> 4]], axis=1)
+    return raw, val.astype(np.float32).reshape(-1)
+
+
+@pytest.mark.parametrize("kind,gtype,blck,bytes_", [("q2_K", 10, 256, 84), ("q3_K", 11, 256, 110), ("q4_K", 12, 256, 144), ("q5_K", 13, 256, 176),
+                                                     ("q6_K", 14, 256, 210), ("iq4_nl", 20, 32, 18)])
+def test_gguf_k_quants_are_decoded_at_load(sd, oracle, tmp_path, kind, gtype, blck, bytes_):
+    """The q2_k / q3_k / q4_k / q5_k / q6_k GGUF files the reference's docs point FLUX / SD3.5 users at (docs/flux.md:36-38): 256-weight super-blocks,
+    decoded to f32 at load and re-encoded in the parameter's type like convert_tensor does for every source type (src/model_loader.cpp:155-205)."""
+    e = sd.Engine(model=sd.SD15_TINY, backend=oracle, wtype=sd.F16)
+    rng = np.random.default_rng(100 + gtype)
+    names = ["model.diffusion_model.input_blocks.4.1.transformer_blocks.0.ff.net.2.weight",   # [256, 64]  f16 parameter
+             "model.diffusion_model.input_blocks.7.1.transformer_blocks.0.ff.net.0.proj.bias"]  # [1024]     f32 parameter
+    tensors, want = [], {}
+    for n in names:
+        ne, pty, _ = e.tensor_info(n)
+        ne = [int(d) for d in ne]
+        while len(ne) > 1 and ne[-1] == 1:
+            ne = ne[:-1]
+        assert ne[0] % blck == 0
+        raw, val = _kquant_random_blocks(rng, kind, int(np.prod(ne)) // blck)
+        assert len(raw) == int(np.prod(ne)) // blck * bytes_
+        tensors.append((n, gtype, ne, raw))
+        want[n] = (val, pty)
+    p = tmp_path / f"tiny_{kind}.gguf"
+    _write_gguf(p, tensors)
+    r = e.load_weights(p)
+    assert r["loaded"] == len(names) and r["unused"] == 0
+    for n, (val, pty) in want.items():
+        got = e.get_tensor(n).ravel()
+        if pty == sd.F16:
+            val = val.astype(np.float16).astype(np.float32)
+        # f32 parameters: bit-equal up to the last ulp of the two multiplication orders; f16 parameters: a value on a rounding tie may land one f16 step away
+        np.testing.assert_allclose(got, val, rtol=1e-3 if pty == sd.F16 else 2e-7, atol=1e-7, err_msg=n)
+    # a truncated block stream is rejected, not over-read; a row that is not a whole number of blocks too
+    _write_gguf(tmp_path / "bad1.gguf", [(names[0], gtype, [256, 1 << 30], b"\0" * 300)])
+    with pytest.raises(RuntimeError):
+        e.load_weights(tmp_path / "bad1.gguf")
+    _write_gguf(tmp_path / "bad2.gguf", [(names[0], gtype, [blck + 8, 64], b"\0" * (bytes_ * 80))])
+    with pytest.raises(RuntimeError):
+        e.load_weights(tmp_path / "bad2.gguf")
+
+
 def test_bad_files_are_rejected(sd, oracle, tmp_path):
     e = sd.Engine(model=sd.SD15_TINY, backend=oracle)
     p = tmp_path / "junk.bin"
@@ -310,13 +417,111 @@ def test_malformed_headers_are_rejected_not_overread(sd, oracle, tmp_path):
     # ... while an undecodable tensor the model does NOT declare is just unused
     _write_safetensors(tmp_path / "i8b.safetensors", {"unrelated.flag": ("BOOL", np.zeros((3,), np.uint8)), name: ("F32", np.ones((n,), np.float32))})
     assert e.load_weights(tmp_path / "i8b.safetensors")["loaded"] == 1
-    # 3. GGUF: K-quant type on a declared tensor; ne0 not a whole number of blocks; a dimension that overflows; data past the end of the file
+    # 3. GGUF: a type this build does not decode (iq2_xxs = 16; the K-quants and iq4_nl ARE decoded) on a declared tensor; ne0 not a whole number
+    #    of blocks; a dimension that overflows; data past the end of the file
     wname = "model.diffusion_model.time_embed.0.weight"
     ne = [int(d) for d in e.tensor_info(wname)[0][:2]]
-    _write_gguf(tmp_path / "q4k.gguf", [(wname, 12, ne, b"\0" * 64)])
+    _write_gguf(tmp_path / "q4k.gguf", [(wname, 16, ne, b"\0" * 64)])
     with pytest.raises(sd.EngineError, match="cannot decode"):
         e.load_weights(tmp_path / "q4k.gguf")
     for bad_ne, raw in (([33, 4], b"\0" * 34 * 8), ([32, 2**62], b"\0" * 34), ([32, 2**20], b"\0" * 34)):
         _write_gguf(tmp_path / "bad.gguf", [(wname, sd.Q8_0, bad_ne, raw)])
         with pytest.raises(sd.EngineError, match="invalid dimensions|outside the file"):
             e.load_weights(tmp_path / "bad.gguf")
+
+
+# ---- PyTorch checkpoints (.ckpt / .pt): files written by torch.save itself — the format's own reference implementation ------------------------------
+def _tiny_state(e, rng, names):
+    """{name: np array in torch order} for the given parameters of the tiny engine"""
+    out = {}
+    for n in names:
+        ne, _, _ = e.tensor_info(n)
+        shape = [int(d) for d in ne]
+        while len(shape) > 1 and shape[-1] == 1:
+            shape = shape[:-1]
+        out[n] = (rng.standard_normal(shape[::-1]) * 0.1).astype(np.float32)
+    return out
+
+
+_CKPT_NAMES = ["model.diffusion_model.input_blocks.1.1.transformer_blocks.0.attn1.to_q.weight", "model.diffusion_model.time_embed.0.weight",
+               "model.diffusion_model.input_blocks.0.0.weight", "model.diffusion_model.input_blocks.0.0.bias", "model.diffusion_model.out.0.weight"]
+
+
+@pytest.mark.parametrize("legacy", [False, True])
+@pytest.mark.parametrize("wrap", ["bare", "lightning"])
+def test_torch_checkpoint_load(sd, oracle, tmp_path, legacy, wrap):
+    """torch.save'd checkpoints (the zip container of PyTorch >= 1.6 and the legacy stream, src/model_io/torch_zip_io.cpp / torch_legacy_io.cpp /
+    pickle_io.cpp): a bare state dict and a pytorch-lightning style {"epoch", "global_step", "state_dict": OrderedDict, "optimizer_states": [...]}
+    with f32 / f16 / bf16 / f64 tensors, a view into a shared storage (non-zero storage offset), an int64 step counter the model does not
+    declare, and an optimizer state holding tensors under names that are not parameters.  Loaded through sd_load_weights and compared tensor by tensor."""
+    import collections
+    import torch
+    e = sd.Engine(model=sd.SD15_TINY, backend=oracle, wtype=sd.F16)
+    rng = np.random.default_rng(7)
+    st = _tiny_state(e, rng, _CKPT_NAMES)
+    sdict = collections.OrderedDict()
+    dts = [torch.float32, torch.float16, torch.bfloat16, torch.float64, torch.float32]
+    want = {}
+    for (n, a), dt in zip(st.items(), dts):
+        t = torch.from_numpy(a).to(dt)
+        sdict[n] = t
+        want[n] = t.to(torch.float32).numpy()
+    # a view: two parameters over ONE storage, the second at a non-zero element offset
+    n0, n1 = _CKPT_NAMES[3], "model.diffusion_model.input_blocks.1.0.in_layers.0.bias"
+    c0 = st[n0].size
+    c1 = int(np.prod([int(d) for d in e.tensor_info(n1)[0]]))
+    shared = torch.from_numpy((rng.standard_normal(c0 + c1) * 0.1).astype(np.float32))
+    sdict[n0], sdict[n1] = shared[:c0], shared[c0:]
+    want[n0], want[n1] = shared[:c0].numpy(), shared[c0:].numpy()
+    sdict["model.diffusion_model.some_counter"] = torch.tensor([3], dtype=torch.int64)  # not a parameter: ignored
+    obj = sdict
+    if wrap == "lightning":
+        obj = {"epoch": 6, "global_step": 470000, "pytorch-lightning_version": "1.4.2", "state_dict": sdict, "lr": 1e-4, "flag": True, "none": None,
+               "optimizer_states": [{"state": {0: {"exp_avg": torch.zeros(3, 5), "step": 17}}, "param_groups": [{"lr": 1e-4, "betas": (0.9, 0.999)}]}],
+               "callbacks": {"ckpt": {"best": torch.tensor(0.25)}}}
+    p = tmp_path / ("m_legacy.ckpt" if legacy else "m.ckpt")
+    torch.save(obj, p, _use_new_zipfile_serialization=not legacy)
+    r = e.load_weights(p)
+    assert r["loaded"] == len(want), r
+    for n, val in want.items():
+        got = e.get_tensor(n)
+        _, pty, _ = e.tensor_info(n)
+        ref = val.reshape(got.shape)
+        if pty == sd.F16:
+            ref = ref.astype(np.float16).astype(np.float32)
+        np.testing.assert_array_equal(got, ref, err_msg=n)
+
+
+def test_torch_checkpoint_rejects_what_it_cannot_read(sd, oracle, tmp_path):
+    """Non-contiguous tensors are not offered to the loader (a declared parameter stored transposed is reported missing, never read with the wrong
+    layout); an integer storage on a declared parameter is an error; truncated archives and pickles are rejected, not over-read."""
+    import torch
+    e = sd.Engine(model=sd.SD15_TINY, backend=oracle, wtype=sd.F16)
+    rng = np.random.default_rng(8)
+    name = _CKPT_NAMES[1]
+    a = _tiny_state(e, rng, [name])[name]
+    good = tmp_path / "good.ckpt"
+    torch.save({name: torch.from_numpy(a)}, good)
+    assert e.load_weights(good)["loaded"] == 1
+    # transposed view: same storage, strides swapped
+    tt = torch.from_numpy(np.ascontiguousarray(a.T)).t()
+    assert tt.shape == a.shape and not tt.is_contiguous()
+    torch.save({name: tt}, tmp_path / "nc.ckpt")
+    with pytest.raises(sd.EngineError):
+        e.load_weights(tmp_path / "nc.ckpt")  # nothing loadable in the file
+    torch.save({name: torch.from_numpy(a).to(torch.int32)}, tmp_path / "int.ckpt")
+    with pytest.raises(sd.EngineError, match="cannot decode"):
+        e.load_weights(tmp_path / "int.ckpt")
+    raw = good.read_bytes()
+    for cut in (len(raw) - 10, len(raw) // 2, 40):
+        (tmp_path / "cut.ckpt").write_bytes(raw[:cut])
+        with pytest.raises(sd.EngineError):
+            e.load_weights(tmp_path / "cut.ckpt")
+    # a storage entry shorter than the pickle says: corrupt the element count of the shape inside data.pkl is hard to do portably — instead point the
+    # central directory's size of the storage entry below the tensor's byte count
+    legacy = tmp_path / "leg.ckpt"
+    torch.save({name: torch.from_numpy(a)}, legacy, _use_new_zipfile_serialization=False)
+    lraw = legacy.read_bytes()
+    (tmp_path / "legcut.ckpt").write_bytes(lraw[: len(lraw) - a.nbytes // 2])
+    with pytest.raises(sd.EngineError):
+        e.load_weights(tmp_path / "legcut.ckpt")
