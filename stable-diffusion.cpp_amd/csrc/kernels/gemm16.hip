@@ -819,7 +819,8 @@ G16SplitPlan gemm16_split_plan(int64_t rows, int64_t M, int64_t K, bool conv, bo
     G16SplitPlan r{1, false, 0, 0};
     const int64_t nt = rup64(K, 64) / (g16_bk32() ? 32 : 64);
     if (!g16_bk32()) return r;
-    if (g16_t320_split(rows, M, nt, conv) == 0 && g_g16_sk_inkernel && g_g16_variant == 3 && g_g16_force_tile < 0) {
+    // splitk_inkernel = 2: only launches whose output mode the slab reduce cannot serve (head-major / f16 / gated epilogues)
+    if (g16_t320_split(rows, M, nt, conv) == 0 && (g_g16_sk_inkernel == 1 || (g_g16_sk_inkernel == 2 && !plain_out)) && g_g16_variant == 3 && g_g16_force_tile < 0) {
         const int bn        = (conv ? M <= 64 : g16_use_bn64(rows, M)) ? 64 : 128;
         const int64_t tiles = ((rows + 127) / 128) * ((M + bn - 1) / bn);
         // only grids the 128-row tile would get anyway (g16_pick_tile moves to 256-row tiles from 256 of them on)

@@ -108,3 +108,51 @@ def test_gguf_quantised_blocks_into_gpu_buffers(sd, oracle, gpu, tmp_path, qname
     err = rel_l2(out, ref)
     print(f"UNet forward on {qname} blocks loaded from a GGUF file: GPU vs oracle rel-L2 {err:.3e}")
     assert np.isfinite(out).all() and err < tol
+
+
+def test_torch_checkpoint_and_k_quant_gguf_into_gpu_buffers(sd, oracle, gpu, tmp_path):
+    """A whole tiny model as a torch.save checkpoint (Lightning-style wrapper, f16 / f32 / bf16 tensors) into MI355X buffers, then two of its Linear
+    weights overwritten from a GGUF file holding q4_K / q6_K super-blocks (decoded at load, model_io.hpp): read back and run through a UNet forward
+    against the oracle engine loaded from the same two files."""
+    import collections
+    import torch
+    from test_model_io import _kquant_random_blocks
+    e_gpu = sd.Engine(model=sd.SD15_TINY, backend=gpu)
+    e_ref = sd.Engine(model=sd.SD15_TINY, backend=oracle)
+    names = _names(e_gpu)
+    rng = np.random.default_rng(33)
+    sdict, want = collections.OrderedDict(), {}
+    for i, n in enumerate(names):
+        shape, _ = _shape(e_gpu, n)
+        fan = max(1, int(np.prod(shape[1:])) if len(shape) > 1 else 1)
+        a = (rng.standard_normal(shape) / np.sqrt(fan)).astype(np.float32) if len(shape) > 1 else (rng.standard_normal(shape) * 0.1 + (1.0 if n.endswith("norm.weight") else 0.0)).astype(np.float32)
+        t = torch.from_numpy(a).to((torch.float32, torch.float16, torch.bfloat16)[i % 3])
+        sdict[n], want[n] = t, t.to(torch.float32).numpy()
+    p = tmp_path / "tiny.ckpt"
+    torch.save({"global_step": 1, "state_dict": sdict, "optimizer_states": [{"state": {0: {"exp_avg": torch.zeros(4, 4)}}}]}, p)
+    kq = [("model.diffusion_model.input_blocks.4.1.transformer_blocks.0.ff.net.2.weight", "q4_K", 12), ("model.diffusion_model.input_blocks.5.1.transformer_blocks.0.ff.net.2.weight", "q6_K", 14)]
+    gg = []
+    for n, kind, gtype in kq:
+        ne = [int(d) for d in e_gpu.tensor_info(n)[0][:2]]
+        raw, val = _kquant_random_blocks(rng, kind, ne[0] * ne[1] // 256)
+        gg.append((n, gtype, ne, raw))
+        want[n] = val.reshape(ne[1], ne[0])
+    _write_gguf(tmp_path / "kq.gguf", gg)
+    for e in (e_gpu, e_ref):
+        assert e.load_weights(p) == {"loaded": len(names), "missing": 0, "unused": 0}
+        assert e.load_weights(tmp_path / "kq.gguf")["loaded"] == 2
+    for n in names[::9] + [k[0] for k in kq]:
+        _, ty = _shape(e_gpu, n)
+        ref = want[n].ravel()
+        if ty == sd.F16:
+            np.testing.assert_allclose(e_gpu.get_tensor(n).ravel(), ref.astype(np.float16).astype(np.float32), rtol=1e-3, atol=1e-7, err_msg=n)
+        else:
+            np.testing.assert_allclose(e_gpu.get_tensor(n).ravel(), ref, rtol=2e-7, atol=1e-7, err_msg=n)
+        np.testing.assert_array_equal(e_gpu.get_tensor(n), e_ref.get_tensor(n), err_msg=n)  # both engines hold the same converted bytes
+    x = rng.standard_normal((2, 4, 16, 16)).astype(np.float32)
+    ctx = rng.standard_normal((1, 77, 64)).astype(np.float32)
+    t = np.array([500.0, 500.0], np.float32)
+    out, ref = e_gpu.unet_forward(x, t, ctx), e_ref.unet_forward(x, t, ctx)
+    err = rel_l2(out, ref)
+    print(f"UNet forward on weights from a torch checkpoint + K-quant GGUF: GPU vs oracle rel-L2 {err:.3e}")
+    assert np.isfinite(out).all() and err < 5e-3
