@@ -200,12 +200,14 @@ def main():
                          "avg_launch_algorithmic_bytes": round(kt["total_bytes"] / kt["launches"]),
                          "share_of_step_time": round(kt["total_ms"] / (dt * 1e3), 4),
                          "timing": "hipEventElapsedTime around each launch on the launch stream, inside the timed region"})
-        tf = ROOT / "profiles" / "r04_pmc_traffic_conv256.json"   # PMC passes over THIS kernel family on the current code (scripts/gpu_round_end3.sh)
+        # PMC passes over THIS kernel family (scripts/gpu_round_end3.sh); the newest committed set: profiles/r<round><call>_pmc_traffic_conv256.json
+        tfs = sorted((ROOT / "profiles").glob("r[0-9][0-9][a-zA-Z]_pmc_traffic_conv256.json"))
+        tf = tfs[-1] if tfs else ROOT / "profiles" / "r04_pmc_traffic_conv256.json"
         if tf.exists() and args.model == "sd15" and B == 8 and fuse:
             try:
                 pm = json.loads(tf.read_text())
                 roofline["traffic"] = pm["hbm_bytes_per_launch"]
-                roofline["traffic_source"] = "profiles/r04_pmc_traffic_conv256.json (kernels matching '" + pm.get("kernel", "") + "', " + str(pm.get("launches_fetch_pass")) + " launches): " + pm.get("source", "")
+                roofline["traffic_source"] = "profiles/" + tf.name + " (kernels matching '" + pm.get("kernel", "") + "', " + str(pm.get("launches_fetch_pass")) + " launches): " + pm.get("source", "")
                 if pm.get("note"):
                     roofline["traffic_note"] = pm["note"]
             except (ValueError, KeyError):
