@@ -118,6 +118,8 @@ GGML_MI355X_API int ggml_backend_mi355x_get_kernel_timings(struct ggml_backend_m
  * few-row / quantised Linears: "fgemv" (1: f16 / f32 weights under <= 16 rows on the one-launch weight-streaming kernel, SiLU in front of it applied on
  * load), "fgemv_max_rows" (16), "qgemv" (1) / "qgemv_max_rows" (4, <= 16: raw q8_0 / q4_0 blocks streamed up to that many rows), "qgemm16_max_rows" (512:
  * raw-block MFMA GEMM up to n rows; 8192 = the resident-quantised mode, no f16 image for any quantised Linear), "qgemm16" (1);
+ * "relax_res_overlap" (1: a Linear + residual ADD fuses even when the allocator put the sum on the Linear input's released f32 buffer — GEMM launches read the
+ * arena's f16 operand image, not that buffer; 0 = the round-3 test);
  * launch grouping: "fuse_siblings" (1: q / k / v projections of one attention as one multi-weight launch), "hoist_kv" (1: cross-attention K / V
  * projections of all blocks grouped ahead of their graph position, results in the arena); "fuse_q16", "fuse_chan_add", "fuse_proj_tokens" (1);
  * "hoist_emb" (1: the per-ResBlock SiLU(emb) -> Linear projections as one grouped weight-streaming launch), "fuse_joint_qkv" (1: MMDiT joint attention — qkv projections into arena scratch, split / per-head RMSNorm / token

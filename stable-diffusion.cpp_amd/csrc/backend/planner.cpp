@@ -22,6 +22,7 @@
 
 #include <atomic>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <memory>
@@ -46,7 +47,7 @@ struct Stats {
 } g_stats;
 
 struct Options {
-    std::atomic<int> fusion{1}, mfma_gemm{1}, hip_graph{0}, flash_pattern{1}, gemm16{1}, fuse_modulate{1}, fuse_gate{1}, fuse_gelu{1}, fuse_rope{1}, fuse_concat_heads{1}, qgemv{1}, fuse_chan_add{1}, fuse_proj_tokens{1}, fuse_q16{1}, qgemm16{1}, fgemv{1}, fuse_siblings{1}, hoist_kv{1}, hoist_emb{1}, fuse_rows16{0}, fuse_cat_rows16{1}, fuse_joint_qkv{1}, jit_qimages{4096}, fuse_gn_stats{1}, fuse_ln_reduce{1};
+    std::atomic<int> fusion{1}, mfma_gemm{1}, hip_graph{0}, flash_pattern{1}, gemm16{1}, fuse_modulate{1}, fuse_gate{1}, fuse_gelu{1}, fuse_rope{1}, fuse_concat_heads{1}, qgemv{1}, fuse_chan_add{1}, fuse_proj_tokens{1}, fuse_q16{1}, qgemm16{1}, fgemv{1}, fuse_siblings{1}, hoist_kv{1}, hoist_emb{1}, fuse_rows16{0}, fuse_cat_rows16{1}, fuse_joint_qkv{1}, jit_qimages{4096}, fuse_gn_stats{1}, fuse_ln_reduce{1}, relax_res_overlap{1};
 } g_opt;
 
 using Step = std::function<void(hipStream_t)>;
@@ -651,8 +652,12 @@ void plan_linear(Builder& B, int i, hipStream_t s, std::vector<int>& chain) {
                 if (other && is_f32(other) && contig(other) && contig(a) && ggml_abi_same_shape(other, a) && ggml_abi_same_shape(gi.node(last), a) &&
                     gi.idx(other) < i) {
                     const size_t ob = ggml_abi_nbytes(a);
-                    // dst must not land on the activation tile the other workgroups are still reading
-                    if (!overlaps(a->data, ob, x->data, ggml_abi_nbytes(x)) && (other->data == a->data || !overlaps(a->data, ob, other->data, ob))) {
+                    // dst must not land on activation rows other workgroups are still reading.  Only the few-row streaming kernels (<= 16 rows) read x's
+                    // f32 graph buffer; a GEMM launch reads the f16 operand image in the arena (written by x's producer or by the pack pass that runs
+                    // in front of it), so the allocator handing x's released buffer to the ADD is no hazard there (it did for the to_out + x of every
+                    // first attention: 16 unfused 84 .. 21 MB adds per SD1.5 forward, GGML_MI355X_PLAN_TRACE)
+                    const bool reads_x_f32 = !g_opt.gemm16 || !g_opt.relax_res_overlap || tokens <= 16;
+                    if ((!reads_x_f32 || !overlaps(a->data, ob, x->data, ggml_abi_nbytes(x))) && (other->data == a->data || !overlaps(a->data, ob, other->data, ob))) {
                         ep.residual = (const float*)other->data;
                         chain.push_back(r);
                         last = r;
@@ -2025,6 +2030,16 @@ bool plan_manual_attention(Builder& B, int i, hipStream_t, std::vector<int>& cha
 bool plan_single(Builder& B, int i, hipStream_t s) {
     GInfo& gi            = B.gi;
     const ggml_tensor* n = gi.node(i);
+    // GGML_MI355X_PLAN_TRACE=1: one line per node that no fused pattern claimed (what is left to fuse, and who produces its operands)
+    static const bool trace = getenv("GGML_MI355X_PLAN_TRACE") != nullptr;
+    if (trace && n->op != GGML_OP_RESHAPE && n->op != GGML_OP_VIEW && n->op != GGML_OP_PERMUTE && n->op != GGML_OP_TRANSPOSE && n->op != GGML_OP_NONE) {
+        fprintf(stderr, "[plan_single] node %d op %d '%s' ne [%lld %lld %lld %lld]", i, (int)n->op, n->name, (long long)n->ne[0], (long long)n->ne[1], (long long)n->ne[2],
+                (long long)n->ne[3]);
+        for (int q = 0; q < 3 && n->src[q]; ++q)
+            fprintf(stderr, "  src%d: op %d '%s' ne [%lld %lld %lld %lld]", q, (int)n->src[q]->op, n->src[q]->name, (long long)n->src[q]->ne[0], (long long)n->src[q]->ne[1],
+                    (long long)n->src[q]->ne[2], (long long)n->src[q]->ne[3]);
+        fprintf(stderr, "\n");
+    }
     switch (n->op) {
         case GGML_OP_DUP:
         case GGML_OP_CONT:
@@ -3226,6 +3241,7 @@ void planner_set_option(const char* key, int value) {
     else if (!strcmp(key, "gemm16")) (void)value;  // kept for old scripts: the gemm16 path is the only one (first-generation kernels removed)
     else if (!strcmp(key, "fuse_modulate")) g_opt.fuse_modulate = value;
     else if (!strcmp(key, "fuse_gate")) g_opt.fuse_gate = value;
+    else if (!strcmp(key, "relax_res_overlap")) g_opt.relax_res_overlap = value;
     else if (!strcmp(key, "fuse_gelu")) g_opt.fuse_gelu = value;
     else if (!strcmp(key, "fuse_rope")) g_opt.fuse_rope = value;
     else if (!strcmp(key, "fuse_concat_heads")) g_opt.fuse_concat_heads = value;

@@ -443,6 +443,7 @@ def test_graph_cache_replays_same_shapes_and_rebuilds_on_change(sd, oracle):
     np.testing.assert_array_equal(e.unet_forward(xs[1], ts[1], ctx, y), outs[1])
 
 
+@pytest.mark.gpu  # no GPU work, but 1.6 TFLOP of CPU arithmetic: seconds on the GPU box's host cores, > 15 minutes in an 8-core build container
 @pytest.mark.parametrize("name,latent,ctx_dim,adm", [("SD15", 64, 768, 0), ("SDXL", 32, 2048, 2816)])
 def test_full_width_unet_graph_vs_torch(sd, oracle, name, latent, ctx_dim, adm):
     """The independent leg at the REAL widths (VERDICT r2 weak point 1: the torch restatement used to run at tiny width only): the SD1.5 UNet at its
