@@ -395,18 +395,19 @@ struct Builder {
         int S          = 1;
         bool inkernel  = false;
         size_t wsoff   = 0, cnt_rel = 0, cnt_base = 0;
-        float* ws(const Planner* p) const { return S > 1 ? (float*)(p->arena + wsoff) : nullptr; }  // resolved at launch: the arena may have grown
+        float* ws(const Planner* p) const { return (S > 1 || S < 0) ? (float*)(p->arena + wsoff) : nullptr; }  // resolved at launch: the arena may have grown (S < 0: stream-K slots)
         int* cnt(const Planner* p) const { return inkernel ? (int*)(p->arena + cnt_base) + cnt_rel : nullptr; }
     };
-    Split plan_split(int64_t rows, int64_t M, int64_t K, bool conv, bool plain_out) {
+    Split plan_split(int64_t rows, int64_t M, int64_t K, bool conv, bool plain_out, bool geglu = false) {
         Split r;
-        G16SplitPlan sp = gemm16_split_plan(rows, M, K, conv, plain_out);
+        G16SplitPlan sp = gemm16_split_plan(rows, M, K, conv, plain_out, geglu);
         if (sp.S > 1 && sp.inkernel && cnt_used + (size_t)sp.tiles > CNT_CAP) {  // counter block full: the slab + reduce pass where it applies
             sp.inkernel = false;
             sp.S        = plain_out ? gemm16_split_k(rows, M, K, conv) : 1;
             sp.ws_bytes = (size_t)sp.S * rows * M * 4;
         }
-        if (sp.S <= 1) return r;
+        if (sp.S == 0 || sp.S == 1) return r;
+        if (sp.S < 0 && cnt_used + (size_t)sp.tiles > CNT_CAP) return r;  // stream-K needs its tile counters
         if (sp.inkernel) {
             if (!cnt_alloc) {
                 cnt_off   = alloc(CNT_CAP * sizeof(int));
@@ -836,7 +837,8 @@ void plan_linear(Builder& B, int i, hipStream_t s, std::vector<int>& chain) {
         if (geglu_out >= 0) {
             const size_t ooff  = B.alloc((size_t)tokens * (M / 2) * 2);
             const float* biasp = ep.bias;
-            B.emit([=](hipStream_t st) { launch_gemm16_linear_geglu(st, P->arena + ooff, P->arena + off, ld, swz, tokens, K, M, biasp); });
+            const Builder::Split sk = B.plan_split(tokens, M, K, false, false, true);  // stream-K or nothing
+            B.emit([=](hipStream_t st) { launch_gemm16_linear_geglu(st, P->arena + ooff, P->arena + off, ld, swz, tokens, K, M, biasp, sk.ws(P), sk.cnt(P), sk.S); });
             B.packed[gi.node(geglu_out)] = Packed{ooff, M / 2, false};
             g_stats.fused_geglu++;
             g_stats.fused_linear_geglu++;
@@ -3214,6 +3216,9 @@ void planner_set_option(const char* key, int value) {
     else if (!strcmp(key, "flash_nsel")) flash_attn_set_nsel(value);
     else if (!strcmp(key, "flash_short")) flash_attn_set_short(value);
     else if (!strcmp(key, "gemm16_swp")) gemm16_set_swp(value);
+    else if (!strcmp(key, "streamk")) gemm16_set_streamk(value);
+    else if (!strcmp(key, "t256p_min_nt_sk")) gemm16_set_t256p_min_nt_sk(value);
+    else if (!strcmp(key, "t256p_min_tiles_sk")) gemm16_set_t256p_min_tiles_sk(value);
     else if (!strcmp(key, "flash_pp_min_tiles")) flash_attn_set_pp_min_tiles(value);
     else if (!strcmp(key, "conv3w")) conv3w_set(value);
     else if (!strcmp(key, "hoist_emb")) g_opt.hoist_emb = value;

@@ -36,6 +36,8 @@ struct G16Args {
     // order), takes a ticket on sk_cnt[tile], and the LAST arriver sums all slices in slice order and runs the regular epilogue
     float* sk_slab;
     int* sk_cnt;
+    // stream-K (k_gemm16<..., SK = true>): sk_grid workgroups share sk_tiles * nt (tile, K-tile) units; slab slots 2w / 2w + 1 of workgroup w in sk_slab, one counter per tile in sk_cnt
+    int sk_grid, sk_tiles;
     // sibling Linears sharing the A operand in ONE launch (rows mode): column tile t belongs to weight t / ncol_tiles; each weight has its own image,
     // destination(s) and bias, everything else (shape, head-major parameters, scale) is common.  multi <= 1: off.
     int multi;

@@ -38,9 +38,17 @@ namespace mi355x {
 // the barrier both publishes stage kt+1 (each wave waited for its own DMA pieces first) and frees slot kt for the DMA of stage kt+4,
 // with two further stages (72 KB) in flight across it.  FLOP per DMA byte is 1.45x the 256x160 tile's (the LDS-DMA stream, ~23 B/clk/CU,
 // is what bounds these kernels: profiles/r02a_gemm_ablation_kernel_stats.csv).
-template <int BM, int BN, bool CONV, int BK, int NST, int WR, int WC, int PIPE = 0, bool SWP = false>
+// SK = true (pipelined Linear tiles only): STREAM-K.  The launch is one workgroup per CU (g.sk_grid of them); the (tile, K-tile) units of the whole
+// GEMM are cut into g.sk_grid equal contiguous ranges and workgroup w walks range w tile by tile.  A tile whose K range is shared by several
+// workgroups is combined by its LAST-ARRIVING part: every part dumps its raw accumulators to a slab slot (write-through stores), takes a ticket on
+// the tile's counter, and the last arriver sums the parts in part order (bitwise deterministic whoever arrives last) and runs the regular
+// epilogue — the in-launch split-K protocol below with a per-tile part count.  Nobody waits for another workgroup.  Why: a grid of T tiles on
+// 256 CUs takes ceil(T / 256) rounds; DiT Linears have T = 192 .. 1428 (FLUX 4096 x 3072 -> 9216: 576 tiles = 2.25 rounds paid as 3; SD3.5
+// 8192 x 9728 -> 2432: 320 tiles = 1.25 rounds paid as 2), profiles/r05b_*.
+template <int BM, int BN, bool CONV, int BK, int NST, int WR, int WC, int PIPE = 0, bool SWP = false, bool SK = false>
 __global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g) {
     static_assert(!SWP || !CONV, "SWP: the Linear kernels with the accumulator transposed (g16_common.h, epi_linear_swp)");
+    static_assert(!SK || (PIPE == 1 && !CONV && !SWP), "stream-K is written for the pipelined Linear tiles");
     constexpr int NW  = WR * WC;
     constexpr int RB  = BM / WR / 32;  // 32-row blocks per wave
     constexpr int CB  = BN / WC / 32;  // 32-col blocks per wave
@@ -59,25 +67,48 @@ __global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g
     static_assert(APW * NW * 1024 == ABYTES && APW >= 1, "A stage must split evenly over the waves");
     __shared__ __attribute__((aligned(1024))) char smem[NST * (ABYTES + BBYTES)];
 
-    const int lane = threadIdx.x & 63;
+    const int lane0 = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = wave % WR, wc = wave / WR;
 
+    // stream-K: this workgroup's unit range [sk_u, sk_end) of the g.sk_tiles * g.nt (tile, K-tile) units
+    int64_t sk_u = 0, sk_end = 0;
+    int sk_w = 0;  // logical workgroup index: the workgroups of one XCD (blockIdx % 8) take ADJACENT unit ranges, so that — like the XCD-aware tile order of the
+                   // plain launch — the 32 workgroups sharing an L2 walk tiles of the same one or two row tiles (first run without it: FLUX Linears +9 %)
+    if constexpr (SK) {
+        const int64_t U = (int64_t)g.sk_tiles * g.nt;
+        sk_w            = (g.sk_grid & 7) == 0 ? (int)(blockIdx.x & 7) * (g.sk_grid >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+        sk_u            = (int64_t)sk_w * U / g.sk_grid;
+        sk_end          = (int64_t)(sk_w + 1) * U / g.sk_grid;
+    }
+  for (bool sk_more = true; sk_more;) {  // one pass per tile segment (stream-K); exactly one pass otherwise
+    // stream-K: the lane id is made opaque per pass, so that every lane-derived address (DMA sources, fragment offsets, epilogue offsets) is
+    // recomputed inside the pass it is used in instead of being hoisted to kernel entry and kept live (= spilled) across the whole loop
+    int lane = lane0;
+    if constexpr (SK) asm volatile("" : "+v"(lane));
     // XCD-aware tile order: consecutive ids on one XCD share the A row tile (all column tiles of a row tile)
     int bid = blockIdx.x;
-    {
-        const int nb = gridDim.x;
-        if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);
-    }
     // split-K: this workgroup accumulates K tiles [kt0, kt0 + nt) and stores raw partial sums into its slab
     int kt0 = 0, nt = g.nt;
+    if constexpr (SK) {
+        bid     = (int)(sk_u / g.nt);
+        kt0     = (int)(sk_u - (int64_t)bid * g.nt);
+        nt      = (int)min((int64_t)(g.nt - kt0), sk_end - sk_u);
+        sk_u += nt;
+        sk_more = sk_u < sk_end;
+        if (nt <= 0) break;  // more workgroups than units
+    } else {
+        sk_more = false;
+        const int nb = gridDim.x;
+        if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);
 #ifdef MI355X_EXPERIMENTS
-    if (g.abl == 7) nt = PIPE ? 4 : 1;  // timing ablation: (almost) no main loop, the launch's fixed cost + epilogue
+        if (g.abl == 7) nt = PIPE ? 4 : 1;  // timing ablation: (almost) no main loop, the launch's fixed cost + epilogue
 #endif
-    if (g.split_k > 1) {
-        kt0 = blockIdx.y * g.nt_slice;
-        nt  = min(g.nt_slice, g.nt - kt0);
-        if (!g.sk_cnt) g.dst += (int64_t)blockIdx.y * g.slab;
+        if (g.split_k > 1) {
+            kt0 = blockIdx.y * g.nt_slice;
+            nt  = min(g.nt_slice, g.nt - kt0);
+            if (!g.sk_cnt) g.dst += (int64_t)blockIdx.y * g.slab;
+        }
     }
     const int nct_all  = g.multi > 1 ? g.ncol_tiles * g.multi : g.ncol_tiles;
     const int row_tile = bid / nct_all;
@@ -572,6 +603,67 @@ __global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g
         }
     }
 
+    // ---- stream-K: a segment that is not a whole tile is one PART of its tile
+    if constexpr (SK) {
+        __syncthreads();  // every wave is past its last fragment read: the ring is dead (flag below) and may be restaged by the next segment
+        if (!(kt0 == 0 && nt == g.nt)) {
+            typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+            constexpr int TILE_B = BM * BN * 4;
+            // parts of tile `bid` in K order: part p is computed by (logical) workgroup wf + p, wf = owner of the tile's first unit; owner of unit u =
+            // floor(((u + 1) * G - 1) / U).  Slab slots: two per workgroup — [2w] for its segment with kt0 > 0 (at most one: its first), [2w + 1] for
+            // its segment starting at kt0 == 0 and cut short by the end of its range (at most one: its last)
+            const int64_t U  = (int64_t)g.sk_tiles * g.nt, G = g.sk_grid;
+            const int64_t uf = (int64_t)bid * g.nt;
+            const int wf     = (int)(((uf + 1) * G - 1) / U), wl = (int)(((uf + g.nt) * G - 1) / U);
+            const int nparts = wl - wf + 1;
+            char* mine       = (char*)g.sk_slab + (int64_t)(2 * sk_w + (kt0 == 0 ? 1 : 0)) * TILE_B;  // wave-uniform
+            {
+                const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)mine, 0, TILE_B, 0x00020000);
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                        for (int i4 = 0; i4 < 4; ++i4) {
+                            u32x4_t v;
+                            v[0] = __float_as_uint(acc[rb][cb][4 * i4]);
+                            v[1] = __float_as_uint(acc[rb][cb][4 * i4 + 1]);
+                            v[2] = __float_as_uint(acc[rb][cb][4 * i4 + 2]);
+                            v[3] = __float_as_uint(acc[rb][cb][4 * i4 + 3]);
+                            __builtin_amdgcn_raw_buffer_store_b128(v, rs, ((((wave * RB + rb) * CB + cb) * 4 + i4) * 64 + lane) * 16, 0, 16);  // sc1: write-through
+                        }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains
+            __syncthreads();
+            int* flag = (int*)smem;
+            if (threadIdx.x == 0) *flag = __hip_atomic_fetch_add(&g.sk_cnt[bid], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nparts - 1;
+            __syncthreads();
+            const int last = *flag;
+            __syncthreads();  // the flag word belongs to the ring the next segment stages into
+            if (!last) continue;
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) acc[rb][cb] = (float16_t){0};
+            for (int p = 0; p < nparts; ++p) {  // part order: the sum does not depend on who arrives last
+                const char* part = (const char*)g.sk_slab + (int64_t)(p == 0 ? 2 * wf + 1 : 2 * (wf + p)) * TILE_B;
+                const auto rp    = __builtin_amdgcn_make_buffer_rsrc((void*)part, 0, TILE_B, 0x00020000);
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                        for (int i4 = 0; i4 < 4; ++i4) {
+                            const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rp, ((((wave * RB + rb) * CB + cb) * 4 + i4) * 64 + lane) * 16, 0, 16);
+                            acc[rb][cb][4 * i4] += __uint_as_float(v[0]);
+                            acc[rb][cb][4 * i4 + 1] += __uint_as_float(v[1]);
+                            acc[rb][cb][4 * i4 + 2] += __uint_as_float(v[2]);
+                            acc[rb][cb][4 * i4 + 3] += __uint_as_float(v[3]);
+                        }
+            }
+        }
+    }
+
     // ---- epilogue: one compact variant per workgroup (all conditions are launch- or workgroup-uniform)
     if constexpr (SWP) {
         epi_dispatch_linear_swp(acc, g, row0, col0, wr, wc, lane);
@@ -588,6 +680,7 @@ __global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g
             epi_conv<2>(acc, g, row0, col0, wr, wc, lane);
         }
     }
+  }  // tile segments
 }
 
 static inline int64_t rup64(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
@@ -623,6 +716,10 @@ void gemm16_set_abl(int v) { g_g16_abl = v; }
 #endif
 static int g_g16_bn64 = 1;  // option "gemm16_bn64": 0 = 64-column tiles only for M <= 64 (A/B measurements)
 void gemm16_set_bn64(int v) { g_g16_bn64 = v; }
+static int g_g16_streamk = 1;  // option "streamk" (g16_streamk_grid below)
+static int g_g16_t256p_min_nt_sk = 64, g_g16_t256p_min_tiles_sk = 192;  // options "t256p_min_nt_sk" / "t256p_min_tiles_sk": K stages / tiles from which a stream-K-able Linear takes the 256 x 256 tile
+void gemm16_set_t256p_min_nt_sk(int v) { g_g16_t256p_min_nt_sk = v; }
+void gemm16_set_t256p_min_tiles_sk(int v) { g_g16_t256p_min_tiles_sk = v; }
 static int g_g16_t320 = 1;  // option "gemm16_t320": 0 disables the pipelined 256x320 tile in the per-shape choice (A/B measurements)
 void gemm16_set_t320(int v) { g_g16_t320 = v; }
 int gemm16_split_k(int64_t rows, int64_t M, int64_t K, bool conv);
@@ -646,7 +743,9 @@ static int g16_pick_tile(int64_t rows, int64_t M, bool geglu, bool conv, int spl
         // one workgroup per CU: pipeline fill, drain and epilogue of a workgroup overlap with nothing, so short-K GEMMs (SD1.5's GEGLU FF1,
         // K = 320 .. 1280: 10-40 stages) stay on the 2-workgroups-per-CU tiles (r02d: 264 -> 318 us); long-K Linears (DiT) take it
         const int64_t c256p = rt256 * (M / 256) * mul, rounds = (c256p + 255) / 256;
-        if (nt >= 64 && c256p >= 192 && c256p * 4 >= rounds * 256 * 3) return G16_T256P;
+        // stream-K (g16_streamk_grid) runs such a launch as ONE round whatever its tile count: the round-fill test only binds launches that cannot take it
+        const bool sk_ok = g_g16_streamk && !conv && mul == 1 && c256p * nt >= 256 * 16;
+        if (nt >= (sk_ok ? g_g16_t256p_min_nt_sk : 64) && c256p >= (sk_ok ? g_g16_t256p_min_tiles_sk : 192) && (sk_ok || c256p * 4 >= rounds * 256 * 3)) return G16_T256P;
     }
     if (split) {
         if (can320 && g16_t320_split(rows, M, nt, conv) == split) return G16_T320;
@@ -669,7 +768,38 @@ static int g16_pick_tile(int64_t rows, int64_t M, bool geglu, bool conv, int spl
     return tile;
 }
 
-static int g_g16_swp = 0;  // option "gemm16_swp": 1 = big-token Linear tiles with the accumulator transposed (16-byte epilogue accesses; experiment, has not run on a GPU yet)
+static int g_g16_swp = 0;  // option "gemm16_swp": 1 = big-token Linear tiles with the accumulator transposed (16-byte epilogue accesses; measured slower: profiles/r05a_ab_gemm16_swp_rejected.txt)
+// ---- stream-K policy (option "streamk", default 1).  A Linear that g16_pick_tile sends to a one-workgroup-per-CU pipelined tile (T320 / T256P) and
+// whose tile count leaves the last round mostly empty runs as ONE round of persistent workgroups over equal (tile, K-tile) unit ranges instead
+// (k_gemm16<..., SK>).  Returns the grid (= CUs), or 0.  rows / M / K of ONE weight; not for grouped (multi) launches, GEGLU, or K-split launches.
+void gemm16_set_streamk(int v) { g_g16_streamk = v; }
+static int g16_num_cus() {
+    static const int n = [] {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        return cus;
+    }();
+    return n;
+}
+static int g16_streamk_grid(int64_t rows, int64_t M, int64_t K, bool geglu, int* tiles_out = nullptr, int* bn_out = nullptr) {
+    if (!g_g16_streamk || g_g16_variant != 3 || !g16_bk32() || g_g16_force_tile >= 0 || g_g16_swp) return 0;
+    const int64_t nt = rup64(K, 64) / 32;
+    if (!geglu && gemm16_split_k(rows, M, K, false) > 1) return 0;
+    const int tile = g16_pick_tile(rows, M, geglu, false, 0, nt, 1);
+    // (the 256 x 320 tile's stream-K instantiation needs 21 spilled registers on top of its 160 accumulators; its Linears — M a multiple of 320: the
+    // UNets — have tile counts that fill their rounds or take K slices, so only the 256 x 256 tile (DiT widths) is instantiated)
+    if (tile != G16_T256P) return 0;
+    const int bn        = 256;
+    const int64_t tiles = ((rows + 255) / 256) * ((M + bn - 1) / bn);
+    const int cus       = g16_num_cus();
+    const int64_t rounds = (tiles + cus - 1) / cus;
+    // worth it when the plain launch wastes more than ~8 % of its rounds (every boundary tile costs a slab round trip) and a unit range keeps real work
+    if (tiles * 100 >= rounds * cus * 92 || tiles * nt < (int64_t)cus * 16 || tiles >= (1 << 20)) return 0;
+    if (tiles_out) *tiles_out = (int)tiles;
+    if (bn_out) *bn_out = bn;
+    return cus;
+}
+
 void gemm16_set_swp(int v) { g_g16_swp = v; }
 // can this launch's epilogue run on the transposed accumulator?  (f32 +bias +residual | f16 rows (+GELU) | GEGLU; whole 32-column blocks; vector alignment)
 static bool g16_swp_ok(const G16Args& g) {
@@ -685,8 +815,21 @@ template <int BN_, bool CONV_>
 static void g16_launch(hipStream_t s, G16Args& g, int64_t rows, double flops, double bytes) {  // bytes: algorithmic HBM bytes (operand images read once + output written once [+ residual])
     const unsigned ny = g.split_k > 1 ? (unsigned)g.split_k : 1u;
     const int mul     = (!CONV_ && g.multi > 1) ? g.multi : 1;  // sibling Linears in one launch: mul x the column tiles
-    if (BN_ == 128 && g_g16_variant == 3 && !g.sk_cnt) {
+    if (BN_ == 128 && g_g16_variant == 3 && (!g.sk_cnt || g.sk_grid > 0)) {
         const int tile = g16_pick_tile(rows, g.C, g.geglu_inner > 0, CONV_, g.split_k > 1 ? g.split_k : 0, g.nt, mul);  // the GEGLU pairing is laid out for 128-column tiles
+        if constexpr (!CONV_) {
+            if (g.sk_grid > 0) {  // stream-K: one persistent workgroup per CU (the planner asked g16_streamk_grid, which made the same tile choice)
+                KScope ks_(s, KF_LINEAR, flops, bytes);
+                if (tile == G16_T256P) {
+                    g.ncol_tiles = (int)((g.C + 255) / 256);
+                    k_gemm16<256, 256, false, 32, 4, 4, 2, 1, false, true><<<dim3((unsigned)g.sk_grid, 1), 512, 0, s>>>(g);
+                } else {
+                    fprintf(stderr, "ggml-mi355x: stream-K launch planned for a shape that does not take a pipelined tile\n");
+                    abort();
+                }
+                return;
+            }
+        }
         if (tile != G16_T128) {
             const int64_t rt256 = (rows + 255) / 256;
             KScope ks_(s, CONV_ ? KF_CONV_T256 : KF_LINEAR, flops, bytes);
@@ -815,10 +958,21 @@ static bool g16_use_bn64(int64_t rows, int64_t M, int mul = 1) {
     const int64_t c128 = ((rows + 127) / 128) * ((M + 127) / 128) * mul;
     return M <= 64 || (M % 64 == 0 && g16_bk32() && (g_g16_force_tile == G16_T128N64 || (g_g16_force_tile < 0 && g_g16_bn64 && c128 <= 128)));
 }
-G16SplitPlan gemm16_split_plan(int64_t rows, int64_t M, int64_t K, bool conv, bool plain_out) {
+G16SplitPlan gemm16_split_plan(int64_t rows, int64_t M, int64_t K, bool conv, bool plain_out, bool geglu) {
     G16SplitPlan r{1, false, 0, 0};
     const int64_t nt = rup64(K, 64) / (g16_bk32() ? 32 : 64);
     if (!g16_bk32()) return r;
+    if (!conv) {
+        int tiles = 0, bn = 0;
+        if (const int grid = g16_streamk_grid(rows, M, K, geglu, &tiles, &bn)) {  // S = -grid: stream-K (launch_gemm16_linear / _geglu)
+            r.S        = -grid;
+            r.inkernel = true;
+            r.tiles    = tiles;
+            r.ws_bytes = (size_t)grid * 2 * 256 * bn * 4;
+            return r;
+        }
+    }
+    if (geglu) return r;  // the GEGLU launch knows no other split
     // splitk_inkernel = 2: only launches whose output mode the slab reduce cannot serve (head-major / f16 / gated epilogues)
     if (g16_t320_split(rows, M, nt, conv) == 0 && (g_g16_sk_inkernel == 1 || (g_g16_sk_inkernel == 2 && !plain_out)) && g_g16_variant == 3 && g_g16_force_tile < 0) {
         const int bn        = (conv ? M <= 64 : g16_use_bn64(rows, M)) ? 64 : 128;
@@ -1178,8 +1332,20 @@ void launch_gemm16_linear(hipStream_t s, float* dst, void* dst16, int64_t ldd16,
         fprintf(stderr, "ggml-mi355x: invalid gated / gelu gemm16 epilogue request\n");
         abort();
     }
-    const bool inker = splitk_ws && splitk_cnt != nullptr && splitk_S > 1;
-    const int S      = inker ? splitk_S : ((splitk_ws && dst && !dst16 && hm_d == 0 && ldd == M && !e.gate) ? gemm16_split_k(rows, M, K, false) : 1);
+    const bool streamk = splitk_ws && splitk_cnt != nullptr && splitk_S < 0;
+    if (streamk) {  // gemm16_split_plan's S = -grid
+        int tiles = 0;
+        if (g16_streamk_grid(rows, M, K, false, &tiles) != -splitk_S) {
+            fprintf(stderr, "ggml-mi355x: stream-K plan and launch disagree (options changed between plan and launch?)\n");
+            abort();
+        }
+        g.sk_grid  = -splitk_S;
+        g.sk_tiles = tiles;
+        g.sk_slab  = splitk_ws;
+        g.sk_cnt   = splitk_cnt;
+    }
+    const bool inker = !streamk && splitk_ws && splitk_cnt != nullptr && splitk_S > 1;
+    const int S      = streamk ? 1 : inker ? splitk_S : ((splitk_ws && dst && !dst16 && hm_d == 0 && ldd == M && !e.gate) ? gemm16_split_k(rows, M, K, false) : 1);
     if (S > 1) {
         g.split_k  = S;
         g.nt_slice = (g.nt + S - 1) / S;
@@ -1265,7 +1431,7 @@ void launch_gemm16_linear_multi(hipStream_t s, int n, float* const* dst, void* c
 }
 
 void launch_gemm16_linear_geglu(hipStream_t s, void* dst16, const void* a16, int64_t lda, const void* wswz_geglu, int64_t rows, int64_t K, int64_t M,
-                                const float* bias) {
+                                const float* bias, float* splitk_ws, int* splitk_cnt, int splitk_S) {
     G16Args g{};
     g.A           = (const _Float16*)a16;
     g.lda         = lda;
@@ -1283,6 +1449,17 @@ void launch_gemm16_linear_geglu(hipStream_t s, void* dst16, const void* a16, int
 #ifdef MI355X_EXPERIMENTS
     g.abl = g_g16_abl;
 #endif
+    if (splitk_ws && splitk_cnt && splitk_S < 0) {  // stream-K (gemm16_split_plan(..., geglu = true))
+        int tiles = 0;
+        if (g16_streamk_grid(rows, M, K, true, &tiles) != -splitk_S) {
+            fprintf(stderr, "ggml-mi355x: stream-K plan and launch disagree (options changed between plan and launch?)\n");
+            abort();
+        }
+        g.sk_grid  = -splitk_S;
+        g.sk_tiles = tiles;
+        g.sk_slab  = splitk_ws;
+        g.sk_cnt   = splitk_cnt;
+    }
     if (g16_trace()) fprintf(stderr, "G16 linear rows=%lld K=%lld M=%lld res=0 hm=0 f16out=1 geglu=1\n", (long long)rows, (long long)K, (long long)M);
     g16_launch<128, false>(s, g, rows, 2.0 * rows * K * M, (double)rows * rup64(K, 64) * 2.0 + (double)rup64(K, 64) * rup64(M, 128) * 2.0 + (double)rows * (M / 2) * 2.0);
 }

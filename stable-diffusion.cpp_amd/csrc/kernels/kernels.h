@@ -125,7 +125,7 @@ void launch_gemm16_linear_multi(hipStream_t s, int n, float* const* dst, void* c
 // FF1 + GEGLU in one kernel (block.hpp:193-210): wswz built with geglu_inner = M/2; dst16[t][c] = (y[t][c] + b[c]) * gelu(y[t][inner + c] + b[inner + c]),
 // f16 row-major with row stride inner (inner % 64 == 0) — the operand image of the FF2 GEMM.  The [tokens][2*inner] f32 tensor is never written.
 void launch_gemm16_linear_geglu(hipStream_t s, void* dst16, const void* a16, int64_t lda, const void* wswz_geglu, int64_t rows, int64_t K, int64_t M,
-                                const float* bias);
+                                const float* bias, float* splitk_ws = nullptr, int* splitk_cnt = nullptr, int splitk_S = 0);
 // split-K factor the launchers will use when given a workspace of factor * rows * M floats (1 = no split)
 int gemm16_split_k(int64_t rows, int64_t M, int64_t K, bool conv);
 bool splitk_reduce_gn_supported(int64_t hw, int64_t C, int64_t N, int groups);
@@ -140,7 +140,7 @@ struct G16SplitPlan {
     size_t ws_bytes;
     int tiles;
 };
-G16SplitPlan gemm16_split_plan(int64_t rows, int64_t M, int64_t K, bool conv, bool plain_out);
+G16SplitPlan gemm16_split_plan(int64_t rows, int64_t M, int64_t K, bool conv, bool plain_out, bool geglu = false);  // S < 0: stream-K with -S persistent workgroups (Linear only)
 void gemm16_set_splitk_inkernel(int v);
 void gemm16_set_splitk_in_target(int v);
 // x16: f16 NHWC [N][H][W][ICp]; dst f32 NCHW [OW,OH,OC,N]
@@ -220,6 +220,9 @@ void flash_attn_set_vtr(int v);    // option "flash_vtr": same bits: row-major V
 void flash_attn_set_ovl(int v);    // option "flash_ovl": 1 = overlapped issue order in the two-block d = 40 kernel (default), 2 = also the other d <= 48 two-block launches, 0 = phase by phase
 void flash_attn_set_nsel(int v);   // option "flash_nsel": 1 = select-free K / V staging in the d = 40 two-block, d = 64 and d = 128 kernels (default since round 4: bit-identical, -3..6 % per launch)
 void flash_attn_set_short(int v);  // option "flash_short": k_flash_short (K / V register-resident) for 64 < Lk <= 96, d <= 64: 0 = off, 1 = on, 2 = with the next block's Q prefetched (default)
+void gemm16_set_t256p_min_nt_sk(int v);     // option "t256p_min_nt_sk" (64): least 32-wide K stages of a Linear that stream-K could run for it to take the 256 x 256 tile
+void gemm16_set_t256p_min_tiles_sk(int v);  // option "t256p_min_tiles_sk" (192): least tiles, same condition
+void gemm16_set_streamk(int v);    // option "streamk" (1): Linears whose tile count leaves the last round of a one-workgroup-per-CU tile mostly empty run as one round of persistent workgroups over equal (tile, K-tile) ranges
 void gemm16_set_swp(int v);        // option "gemm16_swp": 1 = transposed-accumulator epilogue for the big-token Linear tiles (measured round 4: correct, 1 % slower per step; default 0)
 void flash_attn_set_pp_min_tiles(int v);  // option "flash_pp_min_tiles"
 void flash_attn_set_mslot(int v);  // option "flash_mslot"

@@ -198,6 +198,46 @@ def test_spatial_transformer_projections_as_token_gemms(sd, oracle, gpu, rng, N,
         assert sd.backend_stats()["fused_proj_tokens"] - before["fused_proj_tokens"] == 2
 
 
+@pytest.mark.parametrize("tokens,K,M,res", [(3328, 2048, 4096, True), (3328, 2048, 4096, False), (4352, 3072, 3072, True), (3100, 2560, 4096, False)])
+def test_linear_stream_k(sd, oracle, gpu, rng, tokens, K, M, res):
+    """Stream-K (option streamk, gemm16.hip k_gemm16<..., SK>): Linears whose tile count leaves the last round of a one-workgroup-per-CU tile mostly
+    empty (13 x 16 = 208 tiles of 256 x 256 on 256 CUs; 17 x 12 = 204 for the FLUX linear2 width; a ragged last row tile) run as one
+    persistent workgroup per CU over equal (tile, K-tile) ranges, tiles cut by a range boundary are summed by their last-arriving part in part
+    order.  Against the plain launch (same kernel, whole tiles: differs by f32 summation order in the cut tiles only), against the exact
+    product of the f16-rounded operands, and bit-identical between runs."""
+    if not _on_gpu():
+        pytest.skip("planner option of the MI355X backend")
+    x = rng.standard_normal((tokens, K)).astype(np.float32)
+    w = (rng.standard_normal((M, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(M).astype(np.float32)
+    r = rng.standard_normal((tokens, M)).astype(np.float32)
+
+    def build(g, L):
+        y = L.ggml_add_inplace(g.ctx, L.ggml_mul_mat(g.ctx, g.weight(w, F16), g.input(x)), g.weight(b, F32))
+        return L.ggml_add(g.ctx, y, g.input(r)) if res else y
+
+    def run_gpu():
+        with Graph(gpu) as g:
+            return g.run(build(g, sd.lib())).reshape(tokens, M)
+
+    try:
+        sd.backend_set_option("streamk", 0)
+        plain = run_gpu()
+        sd.backend_set_option("streamk", 1)
+        before = sd.backend_stats()["split_k_inlaunch"]
+        out = run_gpu()
+        assert sd.backend_stats()["split_k_inlaunch"] - before == 1, "the shape did not take the stream-K launch"
+        again = run_gpu()
+    finally:
+        sd.backend_set_option("streamk", 1)
+    assert np.isfinite(out).all()
+    np.testing.assert_array_equal(out, again)
+    assert rel_l2(out, plain) < 1e-6
+    rows = np.unique(np.concatenate([rng.integers(0, tokens, 48), [0, 255, 256, tokens - 1]]))
+    exact = x[rows].astype(np.float16).astype(np.float64) @ w.astype(np.float16).astype(np.float64).T + b + (r[rows] if res else 0.0)
+    assert np.abs(out[rows] - exact).max() < 1e-3 * max(1.0, float(np.abs(exact).max()))
+
+
 @pytest.mark.parametrize("qname", ["Q8_0", "Q4_0"])
 @pytest.mark.parametrize("tokens,K,M", [(640, 512, 384), (1030, 256, 200), (2048, 3072, 640)])
 def test_quantised_linear_just_in_time_image(sd, oracle, gpu, rng, qname, tokens, K, M):
