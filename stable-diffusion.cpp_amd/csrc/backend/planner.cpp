@@ -47,7 +47,7 @@ struct Stats {
 } g_stats;
 
 struct Options {
-    std::atomic<int> fusion{1}, mfma_gemm{1}, hip_graph{0}, flash_pattern{1}, gemm16{1}, fuse_modulate{1}, fuse_gate{1}, fuse_gelu{1}, fuse_rope{1}, fuse_concat_heads{1}, qgemv{1}, fuse_chan_add{1}, fuse_proj_tokens{1}, fuse_q16{1}, qgemm16{1}, fgemv{1}, fuse_siblings{1}, hoist_kv{1}, hoist_emb{1}, fuse_rows16{0}, fuse_cat_rows16{1}, fuse_joint_qkv{1}, jit_qimages{4096}, fuse_gn_stats{1}, fuse_ln_reduce{1}, relax_res_overlap{1};
+    std::atomic<int> fusion{1}, mfma_gemm{1}, hip_graph{0}, flash_pattern{1}, gemm16{1}, fuse_modulate{1}, fuse_gate{1}, fuse_gelu{1}, fuse_rope{1}, fuse_concat_heads{1}, qgemv{1}, fuse_chan_add{1}, fuse_proj_tokens{1}, fuse_q16{1}, qgemm16{1}, fgemv{1}, fuse_siblings{1}, hoist_kv{1}, hoist_emb{1}, fuse_rows16{0}, fuse_cat_rows16{1}, fuse_joint_qkv{1}, jit_qimages{4096}, fuse_gn_stats{1}, fuse_ln_reduce{1}, relax_res_overlap{1}, fuse_split_gelu{1};
 } g_opt;
 
 using Step = std::function<void(hipStream_t)>;
@@ -317,6 +317,8 @@ struct Builder {
     };
     std::unordered_map<int, Cat16> cat16;
     std::unordered_map<const ggml_tensor*, Cat16Part> cat16_part;
+    // CONT nodes of cat16_part whose columns the PRODUCING Linear's epilogue already wrote as gelu -> f16 (Epilogue::split_col): CONT and GELU are not executed
+    std::unordered_set<const ggml_tensor*> cat16_by_linear;
     // joint attention of the MMDiT (plan_joint_qkv): the fused qkv projections of both streams write into arena scratch (lin_redirect: the
     // Linear's output node -> arena offset), and each of the q / k / v token CONCATs becomes ONE pass from there to the flash operand (jqkv)
     struct JPart {
@@ -435,15 +437,17 @@ inline const ggml_tensor* strip_reshape(const ggml_tensor* t) {
 // ---------------------------------------------------------------------------------------------------
 // swizzled weights
 // ---------------------------------------------------------------------------------------------------
-const void* get_swz_linear(Planner* P, const ggml_tensor* w, hipStream_t s, bool geglu_pairs = false) {
-    uint64_t key = fnv(fnv(1469598103934665603ull, &w->data, sizeof(w->data)), geglu_pairs ? "G" : "L", 1);
+// geglu: 0 = plain row order, 1 = GEGLU 128-column pairing, 2 = GEGLU 16-column interleave (gemm16_geglu_mode)
+const void* get_swz_linear(Planner* P, const ggml_tensor* w, hipStream_t s, int geglu = 0) {
+    const bool geglu_pairs = geglu == 1;
+    uint64_t key = fnv(fnv(1469598103934665603ull, &w->data, sizeof(w->data)), geglu == 2 ? "H" : geglu_pairs ? "G" : "L", 1);
     auto it      = P->swz.find(key);
     if (it != P->swz.end()) return it->second.swz;
     const int64_t K = w->ne[0], R = w->ne[1];
     const size_t bytes = wswz_bytes(R, K);
     void* d            = nullptr;
     if (hipMalloc(&d, bytes) != hipSuccess) return nullptr;
-    launch_wswz_linear(s, d, w->data, (int)w->type, K, R, (int64_t)w->nb[1], geglu_pairs ? R / 2 : 0);
+    launch_wswz_linear(s, d, w->data, (int)w->type, K, R, (int64_t)w->nb[1], geglu == 2 ? -(R / 2) : geglu_pairs ? R / 2 : 0);
     P->swz[key] = {d, bytes, w->data, ggml_abi_nbytes(w)};
     g_stats.swizzled_weight_bytes += (int64_t)bytes;
     return d;
@@ -806,7 +810,8 @@ void plan_linear(Builder& B, int i, hipStream_t s, std::vector<int>& chain) {
     // of 2.56 / 3.06; the GEMM reads the fresh image out of the Infinity Cache).  Plain row order only (no GEGLU pairing), not for grouped launches.
     const bool jit = !useq && g_opt.jit_qimages > 0 && tokens >= g_opt.jit_qimages && g_opt.gemm16 && geglu_out < 0 && hm_d == 0 && !B.hm_hoisting && wswz_q_supported((int)w->type, K) &&
                      (int64_t)w->nb[1] == (int64_t)ggml_abi_row_size(w->type, K) && aligned16(w->data);
-    const void* swz = useq ? nullptr : (jit ? B.P->jit_buffer(wswz_bytes(M, K)) : get_swz_linear(B.P, w, s, geglu_out >= 0));
+    const int geglu_mode = geglu_out >= 0 ? gemm16_geglu_mode(tokens, M, K) : 0;
+    const void* swz = useq ? nullptr : (jit ? B.P->jit_buffer(wswz_bytes(M, K)) : get_swz_linear(B.P, w, s, geglu_mode));
     if (jit && swz) {
         void* jb          = const_cast<void*>(swz);
         const void* wsrc  = w->data;
@@ -838,7 +843,7 @@ void plan_linear(Builder& B, int i, hipStream_t s, std::vector<int>& chain) {
             const size_t ooff  = B.alloc((size_t)tokens * (M / 2) * 2);
             const float* biasp = ep.bias;
             const Builder::Split sk = B.plan_split(tokens, M, K, false, false, true);  // stream-K or nothing
-            B.emit([=](hipStream_t st) { launch_gemm16_linear_geglu(st, P->arena + ooff, P->arena + off, ld, swz, tokens, K, M, biasp, sk.ws(P), sk.cnt(P), sk.S); });
+            B.emit([=](hipStream_t st) { launch_gemm16_linear_geglu(st, P->arena + ooff, P->arena + off, ld, swz, tokens, K, M, biasp, sk.ws(P), sk.cnt(P), sk.S, geglu_mode); });
             B.packed[gi.node(geglu_out)] = Packed{ooff, M / 2, false};
             g_stats.fused_geglu++;
             g_stats.fused_linear_geglu++;
@@ -939,8 +944,40 @@ void plan_linear(Builder& B, int i, hipStream_t s, std::vector<int>& chain) {
                     break;
                 }
             }
+            // look-ahead (FLUX single block, flux.hpp:594-700: linear1 = [q k v | mlp], linear2(concat(attn, gelu(mlp)))): the tail columns of this
+            // output are read ONLY through VIEW -> CONT -> GELU into linear2's f16 operand image (plan_cat_rows16 registered that CONT): the GEMM's
+            // epilogue stores gelu(.) as f16 straight into the image for those column tiles and never writes their f32 values
+            bool split_on = false;
+            int64_t split_c0 = 0, split_ld = 0;
+            size_t split_off = 0;
+            if (g_opt.fusion && g_opt.fuse_cat_rows16 && g_opt.fuse_split_gelu && sk.S <= 1 && !ln_on && !ep.gate && !ep.residual && hm_d == 0 && emit_node == i && !useq && gemm16_split_col_supported(tokens, M, K)) {
+                const ggml_tensor* T = gi.node(last);
+                for (int c : gi.consumers[last]) {
+                    const ggml_tensor* v = gi.node(c);
+                    if (v->op != GGML_OP_VIEW || v->nb[0] != 4 || v->nb[1] != T->nb[1] || v->ne[1] * v->ne[2] * v->ne[3] != tokens) continue;
+                    const int jc = gi.sole(c);
+                    if (jc < 0 || gi.node(jc)->op != GGML_OP_CONT) continue;
+                    const auto cp = B.cat16_part.find(gi.node(jc));
+                    if (cp == B.cat16_part.end()) continue;
+                    const int64_t c0 = (int64_t)((const char*)v->data - (const char*)T->data) / 4;
+                    if (c0 <= 0 || c0 % 256 != 0 || c0 + v->ne[0] != M || cp->second.ld % 8 != 0 || cp->second.col % 8 != 0) continue;
+                    split_on  = true;
+                    split_c0  = c0;
+                    split_ld  = cp->second.ld;
+                    split_off = cp->second.off + (size_t)cp->second.col * 2;
+                    B.cat16[cp->second.cat].written[cp->second.part] = true;
+                    B.cat16_by_linear.insert(gi.node(jc));
+                    g_stats.fused_gelu++;
+                    break;
+                }
+            }
             B.emit_at(emit_node, i, [=](hipStream_t st) {
                 Epilogue e2 = ep;
+                if (split_on) {
+                    e2.split_col   = split_c0;
+                    e2.split_dst16 = P->arena + split_off;
+                    e2.split_ldd16 = split_ld;
+                }
                 if (ln_on) {
                     e2.ln_dst16 = P->arena + ln_off;
                     e2.ln_w     = lnw;
@@ -2818,6 +2855,11 @@ bool build_plan(Planner* P, Plan* plan, const ggml_cgraph* g, hipStream_t s, boo
             }
             case GGML_OP_CONT: {
                 const auto cp = B.cat16_part.find(n);
+                if (cp != B.cat16_part.end() && B.cat16_by_linear.count(n) && gi.sole(i) >= 0 && gi.node(gi.sole(i))->op == GGML_OP_UNARY) {
+                    chain = {i, gi.sole(i)};  // the producing Linear's epilogue wrote gelu(.) into the image already
+                    ok    = true;
+                    break;
+                }
                 if (cp != B.cat16_part.end() && n->src[0] && n->src[0]->op == GGML_OP_VIEW && gi.sole(i) >= 0 && gi.node(gi.sole(i))->op == GGML_OP_UNARY) {
                     // gelu(CONT(strided view)) as one pass: strided f32 rows -> GELU -> f16 columns of the operand image
                     const Builder::Cat16Part pt = cp->second;
@@ -3217,6 +3259,8 @@ void planner_set_option(const char* key, int value) {
     else if (!strcmp(key, "flash_short")) flash_attn_set_short(value);
     else if (!strcmp(key, "gemm16_swp")) gemm16_set_swp(value);
     else if (!strcmp(key, "streamk")) gemm16_set_streamk(value);
+    else if (!strcmp(key, "geglu16")) gemm16_set_geglu16(value);
+    else if (!strcmp(key, "conv3w_prio")) conv3w_set_prio(value);
     else if (!strcmp(key, "t256p_min_nt_sk")) gemm16_set_t256p_min_nt_sk(value);
     else if (!strcmp(key, "t256p_min_tiles_sk")) gemm16_set_t256p_min_tiles_sk(value);
     else if (!strcmp(key, "flash_pp_min_tiles")) flash_attn_set_pp_min_tiles(value);
@@ -3238,6 +3282,7 @@ void planner_set_option(const char* key, int value) {
     else if (!strcmp(key, "hoist_kv")) g_opt.hoist_kv = value;
     else if (!strcmp(key, "fgemv_max_rows")) fgemv_set_max_rows(value);
     else if (!strcmp(key, "qgemm16_max_rows")) qgemm16_set_max_rows(value);
+    else if (!strcmp(key, "qgemm16_rb")) qgemm16_set_rb(value);
     else if (!strcmp(key, "splitk_inkernel")) gemm16_set_splitk_inkernel(value);
     else if (!strcmp(key, "splitk_in_target")) gemm16_set_splitk_in_target(value);
     else if (!strcmp(key, "flash_mslot")) flash_attn_set_mslot(value);
@@ -3247,6 +3292,7 @@ void planner_set_option(const char* key, int value) {
     else if (!strcmp(key, "fuse_modulate")) g_opt.fuse_modulate = value;
     else if (!strcmp(key, "fuse_gate")) g_opt.fuse_gate = value;
     else if (!strcmp(key, "relax_res_overlap")) g_opt.relax_res_overlap = value;
+    else if (!strcmp(key, "fuse_split_gelu")) g_opt.fuse_split_gelu = value;
     else if (!strcmp(key, "fuse_gelu")) g_opt.fuse_gelu = value;
     else if (!strcmp(key, "fuse_rope")) g_opt.fuse_rope = value;
     else if (!strcmp(key, "fuse_concat_heads")) g_opt.fuse_concat_heads = value;

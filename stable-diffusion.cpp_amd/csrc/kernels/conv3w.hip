@@ -49,7 +49,11 @@ struct C3Geom {
 #define C3_RD(DST_, ADDR_, OFF_) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST_) : "v"(ADDR_), "n"(OFF_))
 #define C3_TIE(X_) asm volatile("" : "+v"(X_))
 
-template <int TW, int BN>
+// PRIO: wave priority around the MFMA groups — 0: none, 1: s_setprio 1 around every MFMA pair, 2: s_setprio 1 from the first MFMA of a k-step to its
+// last, 3 (default): static, the second-dispatched half of the workgroup (waves 4..7) runs at priority 1 (MI355X_MICROARCH.md, two waves per SIMD,
+// item 4).  Measured on the SD1.5 step (profiles/r05d_ab_conv3w_prio.txt): 119.3 / 120.0 / 119.5 / 118.6 us per launch for 0 / 1 / 2 / 3 — the loop is not
+// bound by which of a SIMD's two waves issues first; the static form is kept for its 0.6 %.  Option "conv3w_prio" = 0 selects the plain kernel (A/B).
+template <int TW, int BN, int PRIO = 3>
 __global__ __launch_bounds__(512, 2) void k_conv3w(G16Args g) {
     using G = C3Geom<TW, BN>;
     constexpr int CB = G::CB, CL = CB - 2, PITCH = G::PITCH, NWPW = G::NWPW, WBUF = G::WBUF, BSTAGE = G::BSTAGE, NF = G::NF, RB1 = G::RB1;
@@ -60,6 +64,9 @@ __global__ __launch_bounds__(512, 2) void k_conv3w(G16Args g) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = wave & 3, wc = wave >> 2;
     const int hi = lane >> 5;
+    if constexpr (PRIO == 3) {
+        if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+    }
 
     int bid = blockIdx.x;
     {
@@ -163,36 +170,48 @@ __global__ __launch_bounds__(512, 2) void k_conv3w(G16Args g) {
         C3_RD(HNXT[0], bn_, ((CB - 2) * 2 + (KSN_)) * 1024);                                                         \
         C3_RD(HNXT[1], bn_, ((CB - 1) * 2 + (KSN_)) * 1024);                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
+        C3_PRIO_UP(1); C3_PRIO_UP(2);                                                                                \
         mma(0, 0, ACUR[0], BL[0]);                                                                                   \
         mma(1, 0, ACUR[1], BL[0]);                                                                                   \
+        C3_PRIO_DN(1);                                                                                               \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
         C3_RD(BL[0], bn_, (0 * 2 + (KSN_)) * 1024);                                                                  \
         HOOK_(0, __VA_ARGS__);                                                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
+        C3_PRIO_UP(1);                                                                                               \
         mma(0, 1, ACUR[0], BL[1]);                                                                                   \
         mma(1, 1, ACUR[1], BL[1]);                                                                                   \
+        C3_PRIO_DN(1);                                                                                               \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
         C3_RD(BL[1], bn_, (1 * 2 + (KSN_)) * 1024);                                                                  \
         HOOK_(1, __VA_ARGS__);                                                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
         if constexpr (CL > 2) {                                                                                      \
+            C3_PRIO_UP(1);                                                                                           \
             mma(0, 2, ACUR[0], BL[CL - 1]);                                                                          \
             mma(1, 2, ACUR[1], BL[CL - 1]);                                                                          \
+            C3_PRIO_DN(1);                                                                                           \
             __builtin_amdgcn_sched_barrier(0);                                                                       \
             C3_RD(BL[CL - 1], bn_, (2 * 2 + (KSN_)) * 1024);                                                         \
             __builtin_amdgcn_sched_barrier(0);                                                                       \
         }                                                                                                            \
         HOOK_(2, __VA_ARGS__);                                                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
+        C3_PRIO_UP(1);                                                                                               \
         mma(0, CB - 2, ACUR[0], HCUR[0]);                                                                            \
         mma(1, CB - 2, ACUR[1], HCUR[0]);                                                                            \
+        C3_PRIO_DN(1);                                                                                               \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
         HOOK_(3, __VA_ARGS__);                                                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
+        C3_PRIO_UP(1);                                                                                               \
         mma(0, CB - 1, ACUR[0], HCUR[1]);                                                                            \
         mma(1, CB - 1, ACUR[1], HCUR[1]);                                                                            \
+        C3_PRIO_DN(1); C3_PRIO_DN(2);                                                                                \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
     } while (0)
+#define C3_PRIO_UP(P_) do { if constexpr (PRIO == (P_)) __builtin_amdgcn_s_setprio(1); } while (0)
+#define C3_PRIO_DN(P_) do { if constexpr (PRIO == (P_)) __builtin_amdgcn_s_setprio(0); } while (0)
 #define C3_TIE_FRAGS(AS_, HS_)                                                                                       \
     do {                                                                                                             \
         C3_TIE(AS_[0]);                                                                                              \
@@ -293,6 +312,8 @@ __global__ __launch_bounds__(512, 2) void k_conv3w(G16Args g) {
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------------
+static int g_conv3w_prio = 3;  // option "conv3w_prio": 0 = the kernel without the static wave priority (320-column tiles on 16 / 32 / 64-wide maps; A/B runs)
+void conv3w_set_prio(int v) { g_conv3w_prio = v; }
 static int g_conv3w = 1;  // option "conv3w": 0 = every conv on the round-2 per-tap gather kernel (A/B measurements)
 void conv3w_set(int v) { g_conv3w = v; }
 static int g_conv3w_min_blocks = 8, g_conv3w_min_blocks_deep = 5;  // options "conv3w_min_blocks" / "conv3w_min_blocks_deep": 32-channel blocks (9 stages each) a K slice keeps
@@ -332,6 +353,9 @@ int conv3w_plan(int64_t W, int64_t H, int64_t IC, int64_t N, int64_t OC, int ksi
 
 template <int TW, int BN>
 static void c3_launch(hipStream_t s, const G16Args& g, unsigned tiles, unsigned ny) {
+    if constexpr (BN == 320 && TW <= 64) {
+        if (g_conv3w_prio == 0) return (void)k_conv3w<TW, BN, 0><<<dim3(tiles, ny), 512, 0, s>>>(g);
+    }
     k_conv3w<TW, BN><<<dim3(tiles, ny), 512, 0, s>>>(g);
 }
 

@@ -25,6 +25,7 @@ struct G16Args {
     _Float16* dst16;   // optional f16 row-major copy of the output (rows mode), row stride ldd16 halfs
     int64_t ldd, ldd16;
     int geglu_inner;       // > 0: GEGLU epilogue (weights in the paired order of k_wswz_linear), f16 output [rows][geglu_inner]
+    int geglu16;           // with geglu_inner > 0: the weight image is in the 16-column interleave (k_wswz_linear, geglu_inner < 0) -> epi_geglu16 (any tile geometry)
     int hm_d, hm_H, hm_L;  // head-major store (rows mode): element (row = n*L + l, col = h*d + dd) -> ((n*H + h)*L + l)*d + dd
     int64_t R, C;
     int nt;            // K tiles (BK each)
@@ -38,6 +39,10 @@ struct G16Args {
     int* sk_cnt;
     // stream-K (k_gemm16<..., SK = true>): sk_grid workgroups share sk_tiles * nt (tile, K-tile) units; slab slots 2w / 2w + 1 of workgroup w in sk_slab, one counter per tile in sk_cnt
     int sk_grid, sk_tiles;
+    // column tiles with col0 >= split_col (> 0) store gelu(acc * scale + bias) as f16 rows into split_dst16 (pointer pre-offset so that the GLOBAL column indexes it) instead of the f32 output
+    int split_col;
+    _Float16* split_dst16;
+    int64_t split_ldd16;
     // sibling Linears sharing the A operand in ONE launch (rows mode): column tile t belongs to weight t / ncol_tiles; each weight has its own image,
     // destination(s) and bias, everything else (shape, head-major parameters, scale) is common.  multi <= 1: off.
     int multi;
@@ -109,6 +114,38 @@ __device__ __forceinline__ void epi_geglu(const float16_t (&acc)[RB][CB], const 
                 }
 #endif
                 st_u(ub + (int64_t)ro * g.ldd16, lb, (_Float16)(xv * act_apply<UN_GELU>(gv)));
+            }
+        }
+    }
+}
+
+// FF1 + GEGLU for ANY tile geometry (an odd number of column blocks per wave: the 256 x 160 and 256 x 320 tiles): the weight image interleaves value and
+// gate at 16 columns — columns 0..15 of every 32-column block are the values of outputs 16 b .. 16 b + 15, columns 16..31 their gates — so value and gate
+// of one output sit in lanes l and l ^ 16 of the same accumulator register.  ONE v_permlane16_swap per register pair (j, j + 8) brings them together:
+// swap(vdst = acc[j + 8], src = acc[j]) exchanges vdst's lanes 16..31 with src's lanes 0..15 (and 48..63 with 32..47): afterwards vdst = {values of
+// register j + 8 | values of register j} and src = {gates of j + 8 | gates of j} by lane half — lanes 0..15 finish the row of register j + 8, lanes
+// 16..31 the row of register j, 16 consecutive outputs each (32-byte row segments).  Same arithmetic per output as epi_geglu.
+template <int RB, int CB>
+__device__ __forceinline__ void epi_geglu16(const float16_t (&acc)[RB][CB], const G16Args& g, int64_t row0, int col0, int wr, int wc, int lane) {
+    const int hi = lane >> 5, l16 = lane & 15, up = (lane >> 4) & 1;
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+        const int oc0 = (col0 / 32 + wc * CB + cb) * 16;  // first output of this column block
+        if (oc0 >= g.geglu_inner) continue;
+        const float bx = g.ep.bias ? g.ep.bias[oc0 + l16] : 0.f, bg = g.ep.bias ? g.ep.bias[g.geglu_inner + oc0 + l16] : 0.f;
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            const int64_t base_row = row0 + wr * (RB * 32) + rb * 32;
+            if (base_row >= g.R) continue;
+            const int nv      = (int)(g.R - base_row < 32 ? g.R - base_row : 32);
+            _Float16* ub      = g.dst16 + base_row * g.ldd16 + oc0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[rb][cb][j + 8]), __float_as_uint(acc[rb][cb][j]), false, false);
+                const float xv = __uint_as_float(sw[0]) * g.ep.scale + bx, gv = __uint_as_float(sw[1]) * g.ep.scale + bg;
+                const int r  = up ? j : j + 8;                      // the register this lane finishes
+                const int ro = (r & 3) + 8 * (r >> 2) + 4 * hi;     // its row inside the block
+                if (ro < nv) ub[(int64_t)ro * g.ldd16 + l16] = (_Float16)(xv * act_apply<UN_GELU>(gv));
             }
         }
     }
@@ -250,7 +287,9 @@ __device__ __forceinline__ void epi_linear(const float16_t (&acc)[RB][CB], const
 template <int BM, int RB, int CB>
 __device__ __forceinline__ void epi_dispatch_linear(const float16_t (&acc)[RB][CB], const G16Args& g, int64_t row0, int col0, int wr, int wc, int lane) {
     const bool full = row0 + BM <= g.R;
-    if (CB % 2 == 0 && g.geglu_inner > 0) {
+    if (g.geglu_inner > 0 && g.geglu16) {
+        epi_geglu16(acc, g, row0, col0, wr, wc, lane);
+    } else if (CB % 2 == 0 && g.geglu_inner > 0) {
         if constexpr (CB % 2 == 0) epi_geglu(acc, g, row0, col0, wr, wc, lane);
     } else if (g.hm_d > 0 && g.hm_L >= 32 && !g.ep.residual && (g.dst != nullptr) != (g.dst16 != nullptr)) {
         if (g.dst16)

@@ -668,6 +668,17 @@ __global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g
     if constexpr (SWP) {
         epi_dispatch_linear_swp(acc, g, row0, col0, wr, wc, lane);
     } else if (!CONV) {
+        // column-range epilogue (Epilogue::split_col): this tile belongs to the f32 output or to the f16 gelu tensor.  Compiled into the pipelined
+        // 256 x 256 tile only (the epilogue code exists twice there): gemm16_split_col_supported tells the planner which launches take that tile
+        if (PIPE == 1 && BN == 256 && g.split_col > 0) {
+            const bool hi_part = col0 >= g.split_col;
+            G16Args gs   = g;  // (a workgroup-uniform copy: the stream-K loop must see the launch's own fields again in its next pass)
+            gs.dst       = hi_part ? nullptr : g.dst;
+            gs.dst16     = hi_part ? g.split_dst16 : nullptr;
+            gs.ldd16     = hi_part ? g.split_ldd16 : 0;
+            gs.ep.gelu   = hi_part ? 1 : 0;
+            epi_dispatch_linear<BM>(acc, gs, row0, col0, wr, wc, lane);
+        } else
         epi_dispatch_linear<BM>(acc, g, row0, col0, wr, wc, lane);
     } else {
         const bool fullc = col0 + BN <= g.C;
@@ -716,7 +727,7 @@ void gemm16_set_abl(int v) { g_g16_abl = v; }
 #endif
 static int g_g16_bn64 = 1;  // option "gemm16_bn64": 0 = 64-column tiles only for M <= 64 (A/B measurements)
 void gemm16_set_bn64(int v) { g_g16_bn64 = v; }
-static int g_g16_streamk = 1;  // option "streamk" (g16_streamk_grid below)
+static int g_g16_streamk = 0;  // option "streamk" (g16_streamk_grid below): 0 (default) = off — measured neutral to slightly negative on the FLUX forward even restricted to launches of two rounds or more (profiles/r05e_family_flux_split_gelu_streamk.txt); 1 = that policy; 2 = every candidate
 static int g_g16_t256p_min_nt_sk = 64, g_g16_t256p_min_tiles_sk = 192;  // options "t256p_min_nt_sk" / "t256p_min_tiles_sk": K stages / tiles from which a stream-K-able Linear takes the 256 x 256 tile
 void gemm16_set_t256p_min_nt_sk(int v) { g_g16_t256p_min_nt_sk = v; }
 void gemm16_set_t256p_min_tiles_sk(int v) { g_g16_t256p_min_tiles_sk = v; }
@@ -725,12 +736,14 @@ void gemm16_set_t320(int v) { g_g16_t320 = v; }
 int gemm16_split_k(int64_t rows, int64_t M, int64_t K, bool conv);
 static int g16_t320_split(int64_t rows, int64_t M, int64_t nt, bool conv);
 // mul > 1: `mul` sibling weights of M columns each in one launch (divisibility per weight, tile counts over all of them)
-static int g16_pick_tile(int64_t rows, int64_t M, bool geglu, bool conv, int split, int64_t nt, int mul = 1) {
+// geglu: 0 = plain Linear, 1 = GEGLU launch on the paired weight image (128-column pairing: tiles with an even number of column blocks per wave
+// only), 2 = GEGLU launch on the 16-column interleave (epi_geglu16: any tile)
+static int g16_pick_tile(int64_t rows, int64_t M, int geglu, bool conv, int split, int64_t nt, int mul = 1) {
     if (g_g16_variant != 3) return G16_T128;
-    const bool can160 = M % 160 == 0 && !geglu;
+    const bool can160 = M % 160 == 0 && geglu != 1;
     // T320 (256x320, one workgroup per CU): the weight image is padded to 128 columns only, so M must be a multiple of 320; the GEGLU
     // pairing is laid out for 128-column tiles
-    const bool can320 = M % 320 == 0 && !geglu;
+    const bool can320 = M % 320 == 0 && geglu != 1;
     if (g_g16_force_tile >= 0) {
         if (g_g16_force_tile == G16_T320) return can320 ? G16_T320 : G16_T256;
         if (g_g16_force_tile == G16_T256P) return M % 256 == 0 ? G16_T256P : G16_T256;
@@ -744,7 +757,7 @@ static int g16_pick_tile(int64_t rows, int64_t M, bool geglu, bool conv, int spl
         // K = 320 .. 1280: 10-40 stages) stay on the 2-workgroups-per-CU tiles (r02d: 264 -> 318 us); long-K Linears (DiT) take it
         const int64_t c256p = rt256 * (M / 256) * mul, rounds = (c256p + 255) / 256;
         // stream-K (g16_streamk_grid) runs such a launch as ONE round whatever its tile count: the round-fill test only binds launches that cannot take it
-        const bool sk_ok = g_g16_streamk && !conv && mul == 1 && c256p * nt >= 256 * 16;
+        const bool sk_ok = g_g16_streamk >= 2 && !conv && mul == 1 && c256p * nt >= 256 * 16;  // (default policy: stream-K never widens the tile choice)
         if (nt >= (sk_ok ? g_g16_t256p_min_nt_sk : 64) && c256p >= (sk_ok ? g_g16_t256p_min_tiles_sk : 192) && (sk_ok || c256p * 4 >= rounds * 256 * 3)) return G16_T256P;
     }
     if (split) {
@@ -768,6 +781,9 @@ static int g16_pick_tile(int64_t rows, int64_t M, bool geglu, bool conv, int spl
     return tile;
 }
 
+bool gemm16_split_col_supported(int64_t rows, int64_t M, int64_t K);
+int gemm16_geglu_mode(int64_t rows, int64_t M, int64_t K);
+static bool g16_use_bn64(int64_t rows, int64_t M, int mul);
 static int g_g16_swp = 0;  // option "gemm16_swp": 1 = big-token Linear tiles with the accumulator transposed (16-byte epilogue accesses; measured slower: profiles/r05a_ab_gemm16_swp_rejected.txt)
 // ---- stream-K policy (option "streamk", default 1).  A Linear that g16_pick_tile sends to a one-workgroup-per-CU pipelined tile (T320 / T256P) and
 // whose tile count leaves the last round mostly empty runs as ONE round of persistent workgroups over equal (tile, K-tile) unit ranges instead
@@ -785,7 +801,7 @@ static int g16_streamk_grid(int64_t rows, int64_t M, int64_t K, bool geglu, int*
     if (!g_g16_streamk || g_g16_variant != 3 || !g16_bk32() || g_g16_force_tile >= 0 || g_g16_swp) return 0;
     const int64_t nt = rup64(K, 64) / 32;
     if (!geglu && gemm16_split_k(rows, M, K, false) > 1) return 0;
-    const int tile = g16_pick_tile(rows, M, geglu, false, 0, nt, 1);
+    const int tile = g16_pick_tile(rows, M, geglu ? gemm16_geglu_mode(rows, M, K) : 0, false, 0, nt, 1);
     // (the 256 x 320 tile's stream-K instantiation needs 21 spilled registers on top of its 160 accumulators; its Linears — M a multiple of 320: the
     // UNets — have tile counts that fill their rounds or take K slices, so only the 256 x 256 tile (DiT widths) is instantiated)
     if (tile != G16_T256P) return 0;
@@ -793,8 +809,14 @@ static int g16_streamk_grid(int64_t rows, int64_t M, int64_t K, bool geglu, int*
     const int64_t tiles = ((rows + 255) / 256) * ((M + bn - 1) / bn);
     const int cus       = g16_num_cus();
     const int64_t rounds = (tiles + cus - 1) / cus;
-    // worth it when the plain launch wastes more than ~8 % of its rounds (every boundary tile costs a slab round trip) and a unit range keeps real work
-    if (tiles * 100 >= rounds * cus * 92 || tiles * nt < (int64_t)cus * 16 || tiles >= (1 << 20)) return 0;
+    // Measured (FLUX.1-dev shapes, profiles/r05c_streamk_*.txt): every range boundary cuts a tile, so all workgroups dump and combine 256 KB slabs at the SAME
+    // time at the end of their ranges.  With at least two full rounds of work behind it that costs less than the empty part of the last round when
+    // that part is large (4096 x 3072 -> 9216: 576 tiles = 2.25 rounds, 271 -> 255 us); it loses when the last round is nearly full (1428 tiles = 5.58
+    // rounds: +1.5 %) and loses badly when the whole launch is one partial round, where EVERY tile is cut (192 tiles: 123 -> 153 us, 204 tiles,
+    // K = 15360: 412 -> 457 us).  Hence: two rounds or more, and at least 15 % of the rounds empty (option "streamk" = 2: every candidate, for A/B runs).
+    if (tiles * nt < (int64_t)cus * 16 || tiles >= (1 << 20)) return 0;
+    if (g_g16_streamk == 1 && (rounds < 2 || tiles * 100 >= rounds * cus * 85)) return 0;
+    if (g_g16_streamk >= 2 && tiles * 100 >= rounds * cus * 92) return 0;
     if (tiles_out) *tiles_out = (int)tiles;
     if (bn_out) *bn_out = bn;
     return cus;
@@ -811,12 +833,32 @@ static bool g16_swp_ok(const G16Args& g) {
     return g.dst && !g.ep.gelu && g.ldd % 4 == 0 && al(g.dst, 16) && (!g.ep.residual || al(g.ep.residual, 16));
 }
 
+// weight image layout of a GEGLU FF1 of this shape (M = 2 * inner columns): 2 = 16-column interleave (the launch takes a tile with an odd number of
+// column blocks per wave: 256 x 160 / 256 x 320), 1 = 128-column pairing.  Option "geglu16" (1): 0 = always pairing (round-3 behaviour)
+static int g_g16_geglu16 = 1;
+void gemm16_set_geglu16(int v) { g_g16_geglu16 = v; }
+int gemm16_geglu_mode(int64_t rows, int64_t M, int64_t K) {
+    if (!g_g16_geglu16 || g_g16_variant != 3 || !g16_bk32() || g_g16_force_tile >= 0 || (M / 2) % 16 != 0) return 1;
+    const int tile = g16_pick_tile(rows, M, 2, false, 0, rup64(K, 64) / 32, 1);
+    return (tile == G16_T160 || tile == G16_T160N || tile == G16_T320) ? 2 : 1;
+}
+// a Linear of this shape runs on the pipelined 256 x 256 tile without K slices: the launches that may carry Epilogue::split_col
+bool gemm16_split_col_supported(int64_t rows, int64_t M, int64_t K) {
+    if (g_g16_variant != 3 || !g16_bk32() || g_g16_swp || M % 256 != 0 || M % 160 == 0 || g16_use_bn64(rows, M, 1)) return false;
+    const int64_t nt = rup64(K, 64) / 32;
+    return gemm16_split_k(rows, M, K, false) == 1 && g16_pick_tile(rows, M, false, false, 0, nt, 1) == G16_T256P;
+}
+
 template <int BN_, bool CONV_>
 static void g16_launch(hipStream_t s, G16Args& g, int64_t rows, double flops, double bytes) {  // bytes: algorithmic HBM bytes (operand images read once + output written once [+ residual])
     const unsigned ny = g.split_k > 1 ? (unsigned)g.split_k : 1u;
     const int mul     = (!CONV_ && g.multi > 1) ? g.multi : 1;  // sibling Linears in one launch: mul x the column tiles
     if (BN_ == 128 && g_g16_variant == 3 && (!g.sk_cnt || g.sk_grid > 0)) {
-        const int tile = g16_pick_tile(rows, g.C, g.geglu_inner > 0, CONV_, g.split_k > 1 ? g.split_k : 0, g.nt, mul);  // the GEGLU pairing is laid out for 128-column tiles
+        const int tile = g16_pick_tile(rows, g.C, g.geglu_inner > 0 ? (g.geglu16 ? 2 : 1) : 0, CONV_, g.split_k > 1 ? g.split_k : 0, g.nt, mul);  // the GEGLU pairing is laid out for 128-column tiles
+        if (g.geglu_inner > 0 && g.geglu16 && tile != G16_T160 && tile != G16_T160N && tile != G16_T320) {
+            fprintf(stderr, "ggml-mi355x: GEGLU launch planned on the 16-column interleave, but its tile takes the paired image\n");
+            abort();
+        }
         if constexpr (!CONV_) {
             if (g.sk_grid > 0) {  // stream-K: one persistent workgroup per CU (the planner asked g16_streamk_grid, which made the same tile choice)
                 KScope ks_(s, KF_LINEAR, flops, bytes);
@@ -954,7 +996,7 @@ static int g_g16_sk_inkernel = 0;  // option "splitk_inkernel": 1 = combine in t
 void gemm16_set_splitk_inkernel(int v) { g_g16_sk_inkernel = v; }
 static int g_g16_sk_in_target = 320;  // option "splitk_in_target": workgroups an in-launch split aims for
 void gemm16_set_splitk_in_target(int v) { g_g16_sk_in_target = v; }
-static bool g16_use_bn64(int64_t rows, int64_t M, int mul = 1) {
+static bool g16_use_bn64(int64_t rows, int64_t M, int mul) {
     const int64_t c128 = ((rows + 127) / 128) * ((M + 127) / 128) * mul;
     return M <= 64 || (M % 64 == 0 && g16_bk32() && (g_g16_force_tile == G16_T128N64 || (g_g16_force_tile < 0 && g_g16_bn64 && c128 <= 128)));
 }
@@ -975,7 +1017,7 @@ G16SplitPlan gemm16_split_plan(int64_t rows, int64_t M, int64_t K, bool conv, bo
     if (geglu) return r;  // the GEGLU launch knows no other split
     // splitk_inkernel = 2: only launches whose output mode the slab reduce cannot serve (head-major / f16 / gated epilogues)
     if (g16_t320_split(rows, M, nt, conv) == 0 && (g_g16_sk_inkernel == 1 || (g_g16_sk_inkernel == 2 && !plain_out)) && g_g16_variant == 3 && g_g16_force_tile < 0) {
-        const int bn        = (conv ? M <= 64 : g16_use_bn64(rows, M)) ? 64 : 128;
+        const int bn        = (conv ? M <= 64 : g16_use_bn64(rows, M, 1)) ? 64 : 128;
         const int64_t tiles = ((rows + 127) / 128) * ((M + bn - 1) / bn);
         // only grids the 128-row tile would get anyway (g16_pick_tile moves to 256-row tiles from 256 of them on)
         const int64_t c256 = ((rows + 255) / 256) * ((M + 127) / 128);
@@ -1328,6 +1370,15 @@ void launch_gemm16_linear(hipStream_t s, float* dst, void* dst16, int64_t ldd16,
     g.abl = g_g16_abl;
 #endif
     g.ep    = {e.bias, e.residual, e.scale, e.gate, e.gate_L, e.gelu};
+    if (e.split_col > 0) {
+        if (!gemm16_split_col_supported(rows, M, K) || !dst || dst16 || hm_d > 0 || e.gate || e.gelu || e.residual || !e.split_dst16 || e.split_col % 256 != 0 || e.split_col >= M || M % 160 == 0 || (splitk_ws && splitk_S > 1)) {
+            fprintf(stderr, "ggml-mi355x: invalid column-range epilogue request (split_col)\n");
+            abort();
+        }
+        g.split_col   = (int)e.split_col;
+        g.split_dst16 = (_Float16*)e.split_dst16 - e.split_col;  // indexed by the global column
+        g.split_ldd16 = e.split_ldd16;
+    }
     if ((e.gate && (!e.residual || e.gate_L < 32 || !dst || dst16 || hm_d > 0 || rows >= (1ll << 31))) || (e.gelu && (dst || !dst16 || e.residual || hm_d > 0))) {
         fprintf(stderr, "ggml-mi355x: invalid gated / gelu gemm16 epilogue request\n");
         abort();
@@ -1345,7 +1396,7 @@ void launch_gemm16_linear(hipStream_t s, float* dst, void* dst16, int64_t ldd16,
         g.sk_cnt   = splitk_cnt;
     }
     const bool inker = !streamk && splitk_ws && splitk_cnt != nullptr && splitk_S > 1;
-    const int S      = streamk ? 1 : inker ? splitk_S : ((splitk_ws && dst && !dst16 && hm_d == 0 && ldd == M && !e.gate) ? gemm16_split_k(rows, M, K, false) : 1);
+    const int S      = (streamk || e.split_col > 0) ? 1 : inker ? splitk_S : ((splitk_ws && dst && !dst16 && hm_d == 0 && ldd == M && !e.gate) ? gemm16_split_k(rows, M, K, false) : 1);
     if (S > 1) {
         g.split_k  = S;
         g.nt_slice = (g.nt + S - 1) / S;
@@ -1360,7 +1411,7 @@ void launch_gemm16_linear(hipStream_t s, float* dst, void* dst16, int64_t ldd16,
     }
     // 64-column tiles: narrow outputs, and small grids (<= 128 tiles of 128x128 on 256 CUs: the cross-attention K/V projections of the 77-token
     // context, the time-embedding Linears) where twice the workgroups matter more than the tile's arithmetic intensity (r02q: 1232x768->768 36 -> 21 us)
-    const bool bn64 = g16_use_bn64(rows, M);
+    const bool bn64 = g16_use_bn64(rows, M, 1);
     // algorithmic bytes: A image + weight image once, output once (f32 or f16), residual once
     const double lin_bytes = (double)rows * rup64(K, 64) * 2.0 + (double)rup64(K, 64) * rup64(M, 128) * 2.0 + (double)rows * M * (dst16 ? 2.0 : 4.0) + (e.residual ? (double)rows * M * 4.0 : 0.0);
     if (g16_trace()) fprintf(stderr, "G16 linear rows=%lld K=%lld M=%lld res=%d hm=%d f16out=%d\n", (long long)rows, (long long)K, (long long)M, e.residual ? 1 : 0, hm_d, dst16 ? 1 : 0);
@@ -1431,7 +1482,7 @@ void launch_gemm16_linear_multi(hipStream_t s, int n, float* const* dst, void* c
 }
 
 void launch_gemm16_linear_geglu(hipStream_t s, void* dst16, const void* a16, int64_t lda, const void* wswz_geglu, int64_t rows, int64_t K, int64_t M,
-                                const float* bias, float* splitk_ws, int* splitk_cnt, int splitk_S) {
+                                const float* bias, float* splitk_ws, int* splitk_cnt, int splitk_S, int geglu_mode) {
     G16Args g{};
     g.A           = (const _Float16*)a16;
     g.lda         = lda;
@@ -1440,6 +1491,7 @@ void launch_gemm16_linear_geglu(hipStream_t s, void* dst16, const void* a16, int
     g.kfr         = Kp / 16;
     g.dst16       = (_Float16*)dst16;
     g.geglu_inner = (int)(M / 2);
+    g.geglu16     = geglu_mode == 2 ? 1 : 0;  // the layout the planner built the weight image in (gemm16_geglu_mode)
     g.ldd16       = M / 2;
     g.R           = rows;
     g.C           = M;

@@ -101,6 +101,13 @@ struct Epilogue {
     const float* gate     = nullptr;  // [images][M]: dst = (acc*scale + bias) * gate[row / gate_L][col] + residual
     int gate_L            = 0;        // rows per image
     int gelu              = 0;        // f16-only output: tanh-GELU applied before rounding
+    // gemm16 linear only, plain f32 output launches: the column tiles at or beyond split_col do not write the f32 output — they store
+    // gelu(acc * scale + bias) as f16 into another tensor: element (row, col) at split_dst16[row * split_ldd16 + (col - split_col)].  FLUX single
+    // block (flux.hpp:594-700): linear1 = [q k v | mlp]; the mlp columns are read only as gelu(mlp) inside linear2's operand image.  split_col must be
+    // a multiple of 256 and of the launch's column tile.
+    int64_t split_col     = 0;
+    void* split_dst16     = nullptr;
+    int64_t split_ldd16   = 0;
 };
 // ---- gemm16.hip: second-generation contraction, both operands f16 via LDS-DMA -------------------------------
 // a16: f16 row-major [rows][lda] (K contiguous, padded to 64); output f32 [rows][ldd] and/or f16 [rows][ldd16]
@@ -125,7 +132,10 @@ void launch_gemm16_linear_multi(hipStream_t s, int n, float* const* dst, void* c
 // FF1 + GEGLU in one kernel (block.hpp:193-210): wswz built with geglu_inner = M/2; dst16[t][c] = (y[t][c] + b[c]) * gelu(y[t][inner + c] + b[inner + c]),
 // f16 row-major with row stride inner (inner % 64 == 0) — the operand image of the FF2 GEMM.  The [tokens][2*inner] f32 tensor is never written.
 void launch_gemm16_linear_geglu(hipStream_t s, void* dst16, const void* a16, int64_t lda, const void* wswz_geglu, int64_t rows, int64_t K, int64_t M,
-                                const float* bias, float* splitk_ws = nullptr, int* splitk_cnt = nullptr, int splitk_S = 0);
+                                const float* bias, float* splitk_ws = nullptr, int* splitk_cnt = nullptr, int splitk_S = 0, int geglu_mode = 1);
+// layout of the weight image a GEGLU FF1 of this shape needs: 1 = 128-column value / gate pairing, 2 = 16-column interleave (launch_wswz_linear geglu_inner < 0)
+int gemm16_geglu_mode(int64_t rows, int64_t M, int64_t K);
+void gemm16_set_geglu16(int v);  // option "geglu16" (1)
 // split-K factor the launchers will use when given a workspace of factor * rows * M floats (1 = no split)
 int gemm16_split_k(int64_t rows, int64_t M, int64_t K, bool conv);
 bool splitk_reduce_gn_supported(int64_t hw, int64_t C, int64_t N, int groups);
@@ -151,6 +161,8 @@ void launch_gemm16_conv(hipStream_t s, float* dst, const void* x16_nhwc, const v
 int conv3w_plan(int64_t W, int64_t H, int64_t IC, int64_t N, int64_t OC, int ksize, int stride, bool upscale2x, int* bn_out = nullptr);
 void launch_conv3w(hipStream_t s, float* dst, const void* x16_nhwc, const void* wswz32, int64_t W, int64_t H, int64_t IC, int64_t N, int64_t OC, const Epilogue& ep,
                    float* splitk_ws, int S);
+void qgemm16_set_rb(int v);   // option "qgemm16_rb" (3): row blocks per k_qgemm16 tile (1 / 2 / 4 forced; 3 = 64-row tiles for small grids; 0 = by row count only)
+void conv3w_set_prio(int v);  // option "conv3w_prio" (3): static wave priority of the second half of a k_conv3w workgroup; 0 = without (A/B)
 void conv3w_set(int v);  // option "conv3w"
 void conv3w_set_min_blocks(int v);  // option "conv3w_min_blocks"
 void conv3w_set_min_blocks_deep(int v);  // option "conv3w_min_blocks_deep"
@@ -222,7 +234,8 @@ void flash_attn_set_nsel(int v);   // option "flash_nsel": 1 = select-free K / V
 void flash_attn_set_short(int v);  // option "flash_short": k_flash_short (K / V register-resident) for 64 < Lk <= 96, d <= 64: 0 = off, 1 = on, 2 = with the next block's Q prefetched (default)
 void gemm16_set_t256p_min_nt_sk(int v);     // option "t256p_min_nt_sk" (64): least 32-wide K stages of a Linear that stream-K could run for it to take the 256 x 256 tile
 void gemm16_set_t256p_min_tiles_sk(int v);  // option "t256p_min_tiles_sk" (192): least tiles, same condition
-void gemm16_set_streamk(int v);    // option "streamk" (1): Linears whose tile count leaves the last round of a one-workgroup-per-CU tile mostly empty run as one round of persistent workgroups over equal (tile, K-tile) ranges
+bool gemm16_split_col_supported(int64_t rows, int64_t M, int64_t K);  // a Linear of this shape may carry Epilogue::split_col (it takes the pipelined 256 x 256 tile, no K slices)
+void gemm16_set_streamk(int v);    // option "streamk" (0; 1 = launches of two rounds or more, 2 = every candidate): Linears whose tile count leaves the last round of a one-workgroup-per-CU tile mostly empty run as one round of persistent workgroups over equal (tile, K-tile) ranges
 void gemm16_set_swp(int v);        // option "gemm16_swp": 1 = transposed-accumulator epilogue for the big-token Linear tiles (measured round 4: correct, 1 % slower per step; default 0)
 void flash_attn_set_pp_min_tiles(int v);  // option "flash_pp_min_tiles"
 void flash_attn_set_mslot(int v);  // option "flash_mslot"

@@ -742,6 +742,8 @@ void launch_wswz_q(hipStream_t s, void* dst, const void* wraw, int wtype, int64_
 // qgemm16_max_rows = 8192 the step takes 167 ms (+30 %) for 26 MB of images instead of 12.9 GB — the resident-quantised mode, selectable.
 static int g_qg16_max_rows = 512;
 void qgemm16_set_max_rows(int v) { g_qg16_max_rows = v; }
+static int g_qg16_rb = 3;  // option "qgemm16_rb": 32-row blocks per workgroup tile (1 / 2 / 4 forced); 0 = by row count only; 3 (default) = by row count, 64-row tiles for small grids (FLUX text stream: 7.0 -> 6.1 ms per forward, profiles/r05d_family_flux_qgemm16_rb.txt)
+void qgemm16_set_rb(int v) { g_qg16_rb = v; }
 
 bool qgemm16_supported(int wtype, int64_t rows, int64_t K, int64_t M) {
     // column pieces are fetched with 16-byte loads: rows of the weight must start 16-byte aligned (K % 256 == 0); 1-2 rows belong to k_qgemv
@@ -782,7 +784,11 @@ void launch_qgemm16(hipStream_t s, float* dst, void* dst16, int64_t ldd16, const
         fprintf(stderr, "ggml-mi355x: invalid k_qgemm16 epilogue request\n");
         abort();
     }
-    const int rb    = rows <= 32 ? 1 : rows <= 64 ? 2 : 4;
+    // 128-row tiles re-use a dequantised B fragment four times, but a launch of few tiles (256 text tokens x 3072 -> 12288: 2 x 96 workgroups of four
+    // waves = one wave per SIMD on 3/4 of the CUs) cannot hide its load -> LDS -> dequantise -> MFMA chain: 64-row tiles double the workgroups in flight
+    int rb          = rows <= 32 ? 1 : rows <= 64 ? 2 : 4;
+    if (g_qg16_rb == 1 || g_qg16_rb == 2 || g_qg16_rb == 4) rb = rows <= 32 ? 1 : (rows <= 64 && g_qg16_rb > 2) ? 2 : g_qg16_rb;
+    else if (g_qg16_rb == 3 && rb == 4 && ((rows + 127) / 128) * ((M + 127) / 128) * S < 512) rb = 2;  // 3 = auto: 64-row tiles while the grid stays under two workgroups per CU
     const dim3 grid((unsigned)((rows + rb * 32 - 1) / (rb * 32)), (unsigned)((M + 127) / 128), (unsigned)S);
 #define QG16_LAUNCH(QT_, RB_) k_qgemm16<QT_, RB_><<<grid, 256, 0, s>>>(g)
     if (wtype == 8) {

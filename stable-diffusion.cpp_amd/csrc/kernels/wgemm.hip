@@ -30,6 +30,7 @@ __device__ __forceinline__ float wload(const char* row, int type, int64_t k) {
 }
 
 // one thread per (fragment, lane): writes 8 halfs
+// geglu_inner < 0: the 16-column interleave of -geglu_inner outputs (below);
 // geglu_inner > 0: GEGLU pairing (gemm16.hip EPI_GEGLU) — 32-row block rb of the image holds, for column tile t = rb/4 and q = rb%4
 // (wave column wc = q/2, block cb = q%2), rows cb*inner + (2t + wc)*32 + r of the source: each wave then owns a value block (cb = 0)
 // and the gate block of the same 32 output columns (cb = 1).
@@ -45,6 +46,11 @@ __global__ void k_wswz_linear(half8_t* __restrict__ dst, const char* __restrict_
         const int64_t t = rb >> 2, q = rb & 3;
         row = (q & 1) * geglu_inner + (2 * t + (q >> 1)) * 32 + (lane & 31);
         if ((2 * t + (q >> 1)) * 32 >= geglu_inner) row = R;  // beyond the last pair: zero rows
+    } else if (geglu_inner < 0) {
+        // 16-column interleave (gemm16.hip epi_geglu16, any tile geometry): 32-row block rb of the image holds the value rows of outputs
+        // 16 rb .. 16 rb + 15 in its rows 0..15 and their gate rows in rows 16..31
+        const int64_t inner = -geglu_inner, out = rb * 16 + (lane & 15);
+        row = out < inner ? ((lane & 16) ? inner : 0) + out : R;
     }
     const int64_t k0  = kb * 16 + (lane >> 5) * 8;
     half8_t v;

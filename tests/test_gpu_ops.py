@@ -223,7 +223,7 @@ def test_linear_stream_k(sd, oracle, gpu, rng, tokens, K, M, res):
     try:
         sd.backend_set_option("streamk", 0)
         plain = run_gpu()
-        sd.backend_set_option("streamk", 1)
+        sd.backend_set_option("streamk", 2)  # every candidate shape (the default policy, 1, takes launches of two rounds or more only)
         before = sd.backend_stats()["split_k_inlaunch"]
         out = run_gpu()
         assert sd.backend_stats()["split_k_inlaunch"] - before == 1, "the shape did not take the stream-K launch"
@@ -1055,11 +1055,13 @@ def test_projection_head_major_chain(sd, oracle, gpu, rng, d, H, L_, N, K, f16):
         assert sd.backend_stats()["head_major_gemms"] == before["head_major_gemms"] + (1 if L_ >= 32 else 0)
 
 
-@pytest.mark.parametrize("tokens,dim,inner", [(100, 64, 128), (300, 320, 1280), (77, 128, 192)])
+@pytest.mark.parametrize("tokens,dim,inner", [(100, 64, 128), (300, 320, 1280), (77, 128, 192), (2048, 1280, 5120), (2000, 1280, 5120), (33000, 320, 1280)])
 def test_feed_forward_geglu_fused(sd, oracle, gpu, rng, tokens, dim, inner):
     """FeedForward (block.hpp:193-247): Linear(dim, 2*inner) -> GEGLU -> Linear(inner, dim) + residual.  When 2*inner % 128 == 0 the
     first GEMM computes value and gate columns side by side and writes the f16 operand of the second one (no [tokens][2*inner]
-    tensor); inner = 192 exercises the unfused fallback."""
+    tensor); inner = 192 exercises the unfused fallback.  2048 / 2000 x 1280 -> 10240 (the SDXL 32x32-level FF1, full and with a ragged last row
+    tile) takes the 256 x 320 tile with the weight image in the 16-column value / gate interleave (epi_geglu16: one v_permlane16_swap per
+    register pair); 33000 x 320 the 256 x 128 tile with the 128-column pairing at a ragged row count."""
     x = rng.standard_normal((1, tokens, dim)).astype(np.float32)
     w1 = (rng.standard_normal((2 * inner, dim)) / np.sqrt(dim)).astype(np.float32)
     b1 = rng.standard_normal(2 * inner).astype(np.float32)
