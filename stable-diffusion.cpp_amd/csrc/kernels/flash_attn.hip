@@ -113,6 +113,8 @@ constexpr int fa_vtr_stride(int ndv) {
 template <int DKP, int NDV, bool FAST, int ABL = 0, bool MSLOT = false, int QB = 1, bool VPF = false, bool VTR = false, bool OVL = false, bool NSEL = false>
 __global__ __launch_bounds__(256, QB == 2 ? (DKP <= 96 ? 2 : 1) : (DKP <= 64 ? (VPF ? 2 : FA_OCC_SMALL) : (DKP <= 128 ? 2 : 1))) void k_flash_attn(FAArgs g) {
     static_assert(QB == 1 || FAST, "two query blocks per wave: FAST staging only");
+    static_assert(!MSLOT || DKP == 48 || DKP == 80, "max slot: d = 40 on the 48-wide tile, d = 64 on the 80-wide tile");
+    constexpr int MS_HI = DKP == 48 ? 1 : 0;  // lane half holding element d = D of the last k-step (the max slot)
     static_assert(!OVL || (QB == 2 && DKP == 48 && NDV == 2 && VPF && FAST && ABL == 0), "overlapped issue order: the two-block d <= 48 kernel only");
     static_assert(!NSEL || FAST, "select-free staging: FAST staging only");
     static_assert(!VTR || FAST, "row-major V tiles: FAST staging only");
@@ -639,7 +641,7 @@ __global__ __launch_bounds__(256, QB == 2 ? (DKP <= 96 ? 2 : 1) : (DKP <= 64 ? (
                     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) s[kb][r] -= delta;
-                    if (hi) qf[b][KS - 1][0] = (_Float16)(-m_new);  // d = 40: k-step 2, upper lane half, element 0
+                    if (hi == MS_HI) qf[b][KS - 1][0] = (_Float16)(-m_new);  // d = 40: k-step 2, upper lane half, element 0; d = 64 on the 80-wide tile: k-step 4, lower half
                 } else {
                     const float m_new = fmaxf(m_run[b], tmax);
                     alpha             = __builtin_amdgcn_exp2f(m_run[b] - m_new);  // m_run = -inf on the first tile -> 0
@@ -1440,6 +1442,8 @@ static int g_flash_ablate = 0;
 void flash_attn_set_ablate(int v) { g_flash_ablate = v; }
 #endif
 
+static int g_flash_mslot64 = 0;  // option "flash_mslot64" (launch_flash_attn)
+void flash_attn_set_mslot64(int v) { g_flash_mslot64 = v; }
 static int g_flash_mslot = 1;  // option "flash_mslot": 0 = subtract the running max on the VALU (A/B measurements)
 void flash_attn_set_mslot(int v) { g_flash_mslot = v; }
 static int g_flash_grid = 1;  // option "flash_grid": 0 = plain (query block, head) grid (A/B measurements)
@@ -1599,6 +1603,18 @@ void launch_flash_attn(hipStream_t s, const FlashOut& out, const View4& q, const
         return;
     }
     if (g_flash_nsel && !qb2 && fast && (D == 64 || D == 128) && (g_flash_vpf & (D == 64 ? 2 : 8)) && (g_flash_vtr & (D == 64 ? 2 : 8))) {
+        // d = 64 is bound by instruction ISSUE (issue port 99.5 % busy, matrix pipe 40 %: profiles/r05g_pmc_sq_flash.txt).  Measured and REJECTED (round 4,
+        // profiles/r05h_flash_mslot64_rejected.txt; -DMI355X_EXPERIMENTS builds keep it behind option "flash_mslot64"): trading matrix work for VALU work — the
+        // running max in a fifth k-step (80-wide tile: +2 MFMAs per tile, -32 v_sub per lane) is 25-27 % SLOWER (L = 4096: 139 -> 175 us; L = 4250: 534 ->
+        // 630-660 us), with the row sums in a ones column of a third V block on top (+4 MFMAs, -32 v_add) 30 % slower: once more, matrix-pipe time and VALU
+        // time ADD on this part; the d = 40 max slot pays only because its k-step and its V column were padding anyway
+#ifdef MI355X_EXPERIMENTS
+        if (D == 64 && g_flash_mslot64 == 1)
+            k_flash_attn<80, 2, true, 0, true, 1, true, true, false, true><<<grid, 256, 0, s>>>(g);
+        else if (D == 64 && g_flash_mslot64 == 2)
+            k_flash_attn<80, 3, true, 0, true, 1, true, true, false, true><<<grid, 256, 0, s>>>(g);
+        else
+#endif
         if (D == 64)
             k_flash_attn<64, 2, true, 0, false, 1, true, true, false, true><<<grid, 256, 0, s>>>(g);
         else

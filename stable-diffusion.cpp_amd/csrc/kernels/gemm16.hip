@@ -765,7 +765,10 @@ static int g16_pick_tile(int64_t rows, int64_t M, int geglu, bool conv, int spli
     } else if (g_g16_t320 && can320) {
         // one workgroup per CU and 256 CUs: take it when the launch fills >= 75 % of its rounds
         const int64_t c320 = rt256 * (M / 320) * mul, rounds = (c320 + 255) / 256;
-        if (nt >= (conv ? 16 : 32) && c320 >= 192 && c320 * 4 >= rounds * 256 * 3) return G16_T320;
+        // GEGLU launches (16-column interleave): a single round only — the heavier epilogue of a one-workgroup-per-CU tile overlaps with nothing, and from two
+        // rounds on the 256 x 128 tile (two workgroups per CU) wins: 4096 x 1280 -> 10240 (512 tiles) 187.9 vs 191.5 us for FF1 + FF2, against 121.7 ->
+        // 113.0 us at 2048 rows (256 tiles = SDXL's 32 x 32 level), profiles/r05f_ff_probe_geglu16.txt
+        if (nt >= (conv ? 16 : 32) && c320 >= 192 && c320 * 4 >= rounds * 256 * 3 && (geglu != 2 || rounds == 1)) return G16_T320;
     }
     const int64_t c160 = can160 ? rt256 * (M / 160) * mul : 0;
     double best = (double)((c128 + 767) / 768) * 1.0;
@@ -996,9 +999,11 @@ static int g_g16_sk_inkernel = 0;  // option "splitk_inkernel": 1 = combine in t
 void gemm16_set_splitk_inkernel(int v) { g_g16_sk_inkernel = v; }
 static int g_g16_sk_in_target = 320;  // option "splitk_in_target": workgroups an in-launch split aims for
 void gemm16_set_splitk_in_target(int v) { g_g16_sk_in_target = v; }
+static int g_g16_bn64_max = 128;  // option "bn64_max_tiles": 64-column tiles for launches of up to this many 128 x 128 tiles
+void gemm16_set_bn64_max(int v) { g_g16_bn64_max = v; }
 static bool g16_use_bn64(int64_t rows, int64_t M, int mul) {
     const int64_t c128 = ((rows + 127) / 128) * ((M + 127) / 128) * mul;
-    return M <= 64 || (M % 64 == 0 && g16_bk32() && (g_g16_force_tile == G16_T128N64 || (g_g16_force_tile < 0 && g_g16_bn64 && c128 <= 128)));
+    return M <= 64 || (M % 64 == 0 && g16_bk32() && (g_g16_force_tile == G16_T128N64 || (g_g16_force_tile < 0 && g_g16_bn64 && c128 <= g_g16_bn64_max)));
 }
 G16SplitPlan gemm16_split_plan(int64_t rows, int64_t M, int64_t K, bool conv, bool plain_out, bool geglu) {
     G16SplitPlan r{1, false, 0, 0};

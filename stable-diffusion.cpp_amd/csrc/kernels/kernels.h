@@ -135,6 +135,7 @@ void launch_gemm16_linear_geglu(hipStream_t s, void* dst16, const void* a16, int
                                 const float* bias, float* splitk_ws = nullptr, int* splitk_cnt = nullptr, int splitk_S = 0, int geglu_mode = 1);
 // layout of the weight image a GEGLU FF1 of this shape needs: 1 = 128-column value / gate pairing, 2 = 16-column interleave (launch_wswz_linear geglu_inner < 0)
 int gemm16_geglu_mode(int64_t rows, int64_t M, int64_t K);
+void gemm16_set_bn64_max(int v);  // option "bn64_max_tiles" (128)
 void gemm16_set_geglu16(int v);  // option "geglu16" (1)
 // split-K factor the launchers will use when given a workspace of factor * rows * M floats (1 = no split)
 int gemm16_split_k(int64_t rows, int64_t M, int64_t K, bool conv);
@@ -238,6 +239,7 @@ bool gemm16_split_col_supported(int64_t rows, int64_t M, int64_t K);  // a Linea
 void gemm16_set_streamk(int v);    // option "streamk" (0; 1 = launches of two rounds or more, 2 = every candidate): Linears whose tile count leaves the last round of a one-workgroup-per-CU tile mostly empty run as one round of persistent workgroups over equal (tile, K-tile) ranges
 void gemm16_set_swp(int v);        // option "gemm16_swp": 1 = transposed-accumulator epilogue for the big-token Linear tiles (measured round 4: correct, 1 % slower per step; default 0)
 void flash_attn_set_pp_min_tiles(int v);  // option "flash_pp_min_tiles"
+void flash_attn_set_mslot64(int v);  // option "flash_mslot64" (0): d = 64 launches with the running max in a padded k-slot (1) and the row sums in a ones column of V (2)
 void flash_attn_set_mslot(int v);  // option "flash_mslot"
 void launch_flash_attn(hipStream_t s, const FlashOut& out, const View4& q, const View4& k, const View4& v, float scale);
 
