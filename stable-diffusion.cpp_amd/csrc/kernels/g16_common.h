@@ -38,7 +38,7 @@ struct G16Args {
     float* sk_slab;
     int* sk_cnt;
     // stream-K (k_gemm16<..., SK = true>): sk_grid workgroups share sk_tiles * nt (tile, K-tile) units; slab slots 2w / 2w + 1 of workgroup w in sk_slab, one counter per tile in sk_cnt
-    int sk_grid, sk_tiles;
+    int sk_grid, sk_tiles, sk_dp;  // sk_dp: tiles [0, sk_dp) stay whole (sk_dp / sk_grid per workgroup), tiles [sk_dp, sk_tiles) are cut over K (0: every tile may be cut)
     // column tiles with col0 >= split_col (> 0) store gelu(acc * scale + bias) as f16 rows into split_dst16 (pointer pre-offset so that the GLOBAL column indexes it) instead of the f32 output
     int split_col;
     _Float16* split_dst16;

@@ -75,11 +75,18 @@ __global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g
     int64_t sk_u = 0, sk_end = 0;
     int sk_w = 0;  // logical workgroup index: the workgroups of one XCD (blockIdx % 8) take ADJACENT unit ranges, so that — like the XCD-aware tile order of the
                    // plain launch — the 32 workgroups sharing an L2 walk tiles of the same one or two row tiles (first run without it: FLUX Linears +9 %)
+    int dp_t = 0, dp_end = 0;  // hybrid: whole tiles [dp_t, dp_end) of this workgroup, walked AFTER its share of the cut tiles
     if constexpr (SK) {
-        const int64_t U = (int64_t)g.sk_tiles * g.nt;
+        // tiles [0, sk_dp) are whole tiles, sk_dp / sk_grid per workgroup (data-parallel rounds); tiles [sk_dp, sk_tiles) — the part that does not fill a
+        // round — are cut over K into equal unit ranges and come FIRST: their slab traffic then overlaps the whole-tile work of the other workgroups
+        // instead of arriving as one burst at the end of the launch (sk_dp = 0: pure stream-K)
+        const int64_t U = (int64_t)(g.sk_tiles - g.sk_dp) * g.nt;
         sk_w            = (g.sk_grid & 7) == 0 ? (int)(blockIdx.x & 7) * (g.sk_grid >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
         sk_u            = (int64_t)sk_w * U / g.sk_grid;
         sk_end          = (int64_t)(sk_w + 1) * U / g.sk_grid;
+        const int per   = g.sk_dp / g.sk_grid;
+        dp_t            = sk_w * per;
+        dp_end          = dp_t + per;
     }
   for (bool sk_more = true; sk_more;) {  // one pass per tile segment (stream-K); exactly one pass otherwise
     // stream-K: the lane id is made opaque per pass, so that every lane-derived address (DMA sources, fragment offsets, epilogue offsets) is
@@ -91,12 +98,18 @@ __global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g
     // split-K: this workgroup accumulates K tiles [kt0, kt0 + nt) and stores raw partial sums into its slab
     int kt0 = 0, nt = g.nt;
     if constexpr (SK) {
-        bid     = (int)(sk_u / g.nt);
-        kt0     = (int)(sk_u - (int64_t)bid * g.nt);
-        nt      = (int)min((int64_t)(g.nt - kt0), sk_end - sk_u);
-        sk_u += nt;
-        sk_more = sk_u < sk_end;
-        if (nt <= 0) break;  // more workgroups than units
+        if (sk_u < sk_end) {
+            const int rt = (int)(sk_u / g.nt);  // tile inside the cut part
+            bid          = g.sk_dp + rt;
+            kt0          = (int)(sk_u - (int64_t)rt * g.nt);
+            nt           = (int)min((int64_t)(g.nt - kt0), sk_end - sk_u);
+            sk_u += nt;
+        } else if (dp_t < dp_end) {
+            bid = dp_t++;
+        } else {
+            break;  // more workgroups than units
+        }
+        sk_more = sk_u < sk_end || dp_t < dp_end;
     } else {
         sk_more = false;
         const int nb = gridDim.x;
@@ -612,8 +625,8 @@ __global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g
             // parts of tile `bid` in K order: part p is computed by (logical) workgroup wf + p, wf = owner of the tile's first unit; owner of unit u =
             // floor(((u + 1) * G - 1) / U).  Slab slots: two per workgroup — [2w] for its segment with kt0 > 0 (at most one: its first), [2w + 1] for
             // its segment starting at kt0 == 0 and cut short by the end of its range (at most one: its last)
-            const int64_t U  = (int64_t)g.sk_tiles * g.nt, G = g.sk_grid;
-            const int64_t uf = (int64_t)bid * g.nt;
+            const int64_t U  = (int64_t)(g.sk_tiles - g.sk_dp) * g.nt, G = g.sk_grid;
+            const int64_t uf = (int64_t)(bid - g.sk_dp) * g.nt;
             const int wf     = (int)(((uf + 1) * G - 1) / U), wl = (int)(((uf + g.nt) * G - 1) / U);
             const int nparts = wl - wf + 1;
             char* mine       = (char*)g.sk_slab + (int64_t)(2 * sk_w + (kt0 == 0 ? 1 : 0)) * TILE_B;  // wave-uniform
@@ -636,7 +649,7 @@ __global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains
             __syncthreads();
             int* flag = (int*)smem;
-            if (threadIdx.x == 0) *flag = __hip_atomic_fetch_add(&g.sk_cnt[bid], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nparts - 1;
+            if (threadIdx.x == 0) *flag = __hip_atomic_fetch_add(&g.sk_cnt[bid - g.sk_dp], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nparts - 1;
             __syncthreads();
             const int last = *flag;
             __syncthreads();  // the flag word belongs to the ring the next segment stages into
@@ -757,7 +770,7 @@ static int g16_pick_tile(int64_t rows, int64_t M, int geglu, bool conv, int spli
         // K = 320 .. 1280: 10-40 stages) stay on the 2-workgroups-per-CU tiles (r02d: 264 -> 318 us); long-K Linears (DiT) take it
         const int64_t c256p = rt256 * (M / 256) * mul, rounds = (c256p + 255) / 256;
         // stream-K (g16_streamk_grid) runs such a launch as ONE round whatever its tile count: the round-fill test only binds launches that cannot take it
-        const bool sk_ok = g_g16_streamk >= 2 && !conv && mul == 1 && c256p * nt >= 256 * 16;  // (default policy: stream-K never widens the tile choice)
+        const bool sk_ok = g_g16_streamk == 2 && !conv && mul == 1 && c256p * nt >= 256 * 16;  // (default policy: stream-K never widens the tile choice)
         if (nt >= (sk_ok ? g_g16_t256p_min_nt_sk : 64) && c256p >= (sk_ok ? g_g16_t256p_min_tiles_sk : 192) && (sk_ok || c256p * 4 >= rounds * 256 * 3)) return G16_T256P;
     }
     if (split) {
@@ -800,7 +813,7 @@ static int g16_num_cus() {
     }();
     return n;
 }
-static int g16_streamk_grid(int64_t rows, int64_t M, int64_t K, bool geglu, int* tiles_out = nullptr, int* bn_out = nullptr) {
+static int g16_streamk_grid(int64_t rows, int64_t M, int64_t K, bool geglu, int* tiles_out = nullptr, int* bn_out = nullptr, int* dp_out = nullptr) {
     if (!g_g16_streamk || g_g16_variant != 3 || !g16_bk32() || g_g16_force_tile >= 0 || g_g16_swp) return 0;
     const int64_t nt = rup64(K, 64) / 32;
     if (!geglu && gemm16_split_k(rows, M, K, false) > 1) return 0;
@@ -819,7 +832,16 @@ static int g16_streamk_grid(int64_t rows, int64_t M, int64_t K, bool geglu, int*
     // K = 15360: 412 -> 457 us).  Hence: two rounds or more, and at least 15 % of the rounds empty (option "streamk" = 2: every candidate, for A/B runs).
     if (tiles * nt < (int64_t)cus * 16 || tiles >= (1 << 20)) return 0;
     if (g_g16_streamk == 1 && (rounds < 2 || tiles * 100 >= rounds * cus * 85)) return 0;
-    if (g_g16_streamk >= 2 && tiles * 100 >= rounds * cus * 92) return 0;
+    if (g_g16_streamk == 2 && tiles * 100 >= rounds * cus * 92) return 0;
+    // 3 = HYBRID: the full rounds stay whole tiles (sk_dp of them), only the tiles of the partial last round are cut — over all workgroups, before anything else.
+    // Worth it when that round is at most 3/4 full and a workgroup's share of it is still a pipeline's worth of K stages
+    int64_t dp = 0;
+    if (g_g16_streamk == 3) {
+        dp = (tiles / cus) * cus;
+        const int64_t rem = tiles - dp;
+        if (dp == 0 || rem == 0 || rem * 4 > (int64_t)cus * 3 || rem * nt < (int64_t)cus * 12) return 0;
+    }
+    if (dp_out) *dp_out = (int)dp;
     if (tiles_out) *tiles_out = (int)tiles;
     if (bn_out) *bn_out = bn;
     return cus;
@@ -1390,13 +1412,14 @@ void launch_gemm16_linear(hipStream_t s, float* dst, void* dst16, int64_t ldd16,
     }
     const bool streamk = splitk_ws && splitk_cnt != nullptr && splitk_S < 0;
     if (streamk) {  // gemm16_split_plan's S = -grid
-        int tiles = 0;
-        if (g16_streamk_grid(rows, M, K, false, &tiles) != -splitk_S) {
+        int tiles = 0, dp = 0;
+        if (g16_streamk_grid(rows, M, K, false, &tiles, nullptr, &dp) != -splitk_S) {
             fprintf(stderr, "ggml-mi355x: stream-K plan and launch disagree (options changed between plan and launch?)\n");
             abort();
         }
         g.sk_grid  = -splitk_S;
         g.sk_tiles = tiles;
+        g.sk_dp    = dp;
         g.sk_slab  = splitk_ws;
         g.sk_cnt   = splitk_cnt;
     }
@@ -1507,13 +1530,14 @@ void launch_gemm16_linear_geglu(hipStream_t s, void* dst16, const void* a16, int
     g.abl = g_g16_abl;
 #endif
     if (splitk_ws && splitk_cnt && splitk_S < 0) {  // stream-K (gemm16_split_plan(..., geglu = true))
-        int tiles = 0;
-        if (g16_streamk_grid(rows, M, K, true, &tiles) != -splitk_S) {
+        int tiles = 0, dp = 0;
+        if (g16_streamk_grid(rows, M, K, true, &tiles, nullptr, &dp) != -splitk_S) {
             fprintf(stderr, "ggml-mi355x: stream-K plan and launch disagree (options changed between plan and launch?)\n");
             abort();
         }
         g.sk_grid  = -splitk_S;
         g.sk_tiles = tiles;
+        g.sk_dp    = dp;
         g.sk_slab  = splitk_ws;
         g.sk_cnt   = splitk_cnt;
     }

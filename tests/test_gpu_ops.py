@@ -198,8 +198,9 @@ def test_spatial_transformer_projections_as_token_gemms(sd, oracle, gpu, rng, N,
         assert sd.backend_stats()["fused_proj_tokens"] - before["fused_proj_tokens"] == 2
 
 
-@pytest.mark.parametrize("tokens,K,M,res", [(3328, 2048, 4096, True), (3328, 2048, 4096, False), (4352, 3072, 3072, True), (3100, 2560, 4096, False)])
-def test_linear_stream_k(sd, oracle, gpu, rng, tokens, K, M, res):
+@pytest.mark.parametrize("tokens,K,M,res,mode", [(3328, 2048, 4096, True, 2), (3328, 2048, 4096, False, 2), (4352, 3072, 3072, True, 2), (3100, 2560, 4096, False, 2),
+                                                 (4352, 3072, 6144, True, 3), (4200, 2048, 9216, False, 3)])
+def test_linear_stream_k(sd, oracle, gpu, rng, tokens, K, M, res, mode):
     """Stream-K (option streamk, gemm16.hip k_gemm16<..., SK>): Linears whose tile count leaves the last round of a one-workgroup-per-CU tile mostly
     empty (13 x 16 = 208 tiles of 256 x 256 on 256 CUs; 17 x 12 = 204 for the FLUX linear2 width; a ragged last row tile) run as one
     persistent workgroup per CU over equal (tile, K-tile) ranges, tiles cut by a range boundary are summed by their last-arriving part in part
@@ -223,7 +224,8 @@ def test_linear_stream_k(sd, oracle, gpu, rng, tokens, K, M, res):
     try:
         sd.backend_set_option("streamk", 0)
         plain = run_gpu()
-        sd.backend_set_option("streamk", 2)  # every candidate shape (the default policy, 1, takes launches of two rounds or more only)
+        sd.backend_set_option("streamk", mode)  # 2 = every candidate shape cut over all tiles; 3 = hybrid: whole tiles for the full rounds (17 x 24 = 408 and 17 x 36 = 612
+        #                                          tiles of 256 x 256: one / two rounds of 256), the rest cut over K among all workgroups and computed first
         before = sd.backend_stats()["split_k_inlaunch"]
         out = run_gpu()
         assert sd.backend_stats()["split_k_inlaunch"] - before == 1, "the shape did not take the stream-K launch"
