@@ -91,6 +91,7 @@ struct ggml_backend_mi355x_stats {
     int64_t fused_gn_stats;      /* split-K convs whose slab reduce also writes the statistics of the GroupNorm that reads the result (k_splitk_reduce_gn) */
     int64_t fused_ln_reduce;     /* split-K Linears whose slab reduce also writes the f16 operand image of the LayerNorm that reads the result (k_splitk_reduce_ln) */
     int64_t redirect_fallbacks;  /* graphs planned a second time without the joint-qkv pre-passes because a redirected projection was not taken by its Linear */
+    int64_t fused_concat_gn;     /* skip-connection CONCATs never materialised: GroupNorm statistics / apply (and the skip conv's operand cast) read the two sources (plan_concat_gn) */
 };
 GGML_MI355X_API void ggml_backend_mi355x_get_stats(struct ggml_backend_mi355x_stats* out);
 /* live per-kernel-family timing (bench.py's roofline legs): while a family's bit is enabled, every dispatch of that family is bracketed by
@@ -118,6 +119,9 @@ GGML_MI355X_API int ggml_backend_mi355x_get_kernel_timings(struct ggml_backend_m
  * few-row / quantised Linears: "fgemv" (1: f16 / f32 weights under <= 16 rows on the one-launch weight-streaming kernel, SiLU in front of it applied on
  * load), "fgemv_max_rows" (16), "qgemv" (1) / "qgemv_max_rows" (4, <= 16: raw q8_0 / q4_0 blocks streamed up to that many rows), "qgemm16_max_rows" (512:
  * raw-block MFMA GEMM up to n rows; 8192 = the resident-quantised mode, no f16 image for any quantised Linear), "qgemm16" (1);
+ * "fuse_concat_gn" (1: UNet skip-connection CONCAT read only by a GroupNorm chain (+ the skip 1x1 conv) is never built, option 0 = the concat pass),
+ * "fuse_split_gelu" (1: FLUX linear1 writes gelu(mlp) as f16 into linear2's operand image), "geglu16" (1: GEGLU FF1 on the 256 x 320 tile through the 16-column
+ * value / gate interleave), "streamk" (0; 1 / 2 / 3: stream-K policies for the pipelined 256 x 256 Linear tile), "qgemm16_rb" (3), "conv3w_prio" (3);
  * "relax_res_overlap" (1: a Linear + residual ADD fuses even when the allocator put the sum on the Linear input's released f32 buffer — GEMM launches read the
  * arena's f16 operand image, not that buffer; 0 = the round-3 test);
  * launch grouping: "fuse_siblings" (1: q / k / v projections of one attention as one multi-weight launch), "hoist_kv" (1: cross-attention K / V

@@ -43,11 +43,11 @@ namespace {
 struct Stats {
     std::atomic<int64_t> graphs_computed{0}, plans_built{0}, nodes_seen{0}, kernels_planned{0}, kernels_launched{0}, fused_conv{0},
         fused_conv_bounced{0}, fused_linear{0}, fused_norm{0}, fused_geglu{0}, fused_attention{0}, generic_matmul{0}, swizzled_weight_bytes{0}, fused_linear_geglu{0}, split_k_gemms{0}, head_major_gemms{0}, fused_modulate{0}, fused_gate{0}, fused_gelu{0}, fused_rope{0}, fused_concat_heads{0},
-        graph_replays{0}, qgemv_linears{0}, fused_chan_add{0}, fused_proj_tokens{0}, gemm_attention{0}, fused_q16{0}, split_k_inlaunch{0}, qgemm16_linears{0}, fgemv_linears{0}, fused_presilu{0}, fused_sibling_linears{0}, hoisted_kv_linears{0}, window_convs{0}, hoisted_emb_linears{0}, fused_rows16{0}, fused_cat_rows16{0}, fused_joint_qkv{0}, jit_images{0}, fused_gn_stats{0}, redirect_fallbacks{0}, fused_ln_reduce{0};
+        graph_replays{0}, qgemv_linears{0}, fused_chan_add{0}, fused_proj_tokens{0}, gemm_attention{0}, fused_q16{0}, split_k_inlaunch{0}, qgemm16_linears{0}, fgemv_linears{0}, fused_presilu{0}, fused_sibling_linears{0}, hoisted_kv_linears{0}, window_convs{0}, hoisted_emb_linears{0}, fused_rows16{0}, fused_cat_rows16{0}, fused_joint_qkv{0}, jit_images{0}, fused_gn_stats{0}, redirect_fallbacks{0}, fused_ln_reduce{0}, fused_concat_gn{0};
 } g_stats;
 
 struct Options {
-    std::atomic<int> fusion{1}, mfma_gemm{1}, hip_graph{0}, flash_pattern{1}, gemm16{1}, fuse_modulate{1}, fuse_gate{1}, fuse_gelu{1}, fuse_rope{1}, fuse_concat_heads{1}, qgemv{1}, fuse_chan_add{1}, fuse_proj_tokens{1}, fuse_q16{1}, qgemm16{1}, fgemv{1}, fuse_siblings{1}, hoist_kv{1}, hoist_emb{1}, fuse_rows16{0}, fuse_cat_rows16{1}, fuse_joint_qkv{1}, jit_qimages{4096}, fuse_gn_stats{1}, fuse_ln_reduce{1}, relax_res_overlap{1}, fuse_split_gelu{1};
+    std::atomic<int> fusion{1}, mfma_gemm{1}, hip_graph{0}, flash_pattern{1}, gemm16{1}, fuse_modulate{1}, fuse_gate{1}, fuse_gelu{1}, fuse_rope{1}, fuse_concat_heads{1}, qgemv{1}, fuse_chan_add{1}, fuse_proj_tokens{1}, fuse_q16{1}, qgemm16{1}, fgemv{1}, fuse_siblings{1}, hoist_kv{1}, hoist_emb{1}, fuse_rows16{0}, fuse_cat_rows16{1}, fuse_joint_qkv{1}, jit_qimages{4096}, fuse_gn_stats{1}, fuse_ln_reduce{1}, relax_res_overlap{1}, fuse_split_gelu{1}, fuse_concat_gn{1};
 } g_opt;
 
 using Step = std::function<void(hipStream_t)>;
@@ -1633,6 +1633,73 @@ bool plan_group_norm(Builder& B, int i, hipStream_t, std::vector<int>& chain) {
     return true;
 }
 
+// UNet skip connection (unet.hpp:702, block.hpp:126-179): CONCAT(h, skip; channels) read ONLY by the next ResBlock's GROUP_NORM -> MUL w -> ADD b -> SiLU chain
+// (feeding implicit-GEMM convs) and, optionally, by the skip 1x1 conv.  The f32 concatenation is never built: at the CONCAT's position the GroupNorm statistics
+// are taken over the two sources, and ONE transposing pass reads the two sources once and writes the f16 NHWC operand of the GroupNorm'ed conv and — when the
+// skip conv is there — the plain f16 NHWC operand of that conv.  Both sources are alive at that position and only arena memory is written, so the
+// graph allocator's later re-use of their buffers is no hazard.  Saves the concat pass (read + write of the concatenated tensor) and one further read.
+bool plan_concat_gn(Builder& B, int i, hipStream_t, std::vector<int>& chain) {
+    GInfo& gi            = B.gi;
+    const ggml_tensor* n = gi.node(i);
+    if (!g_opt.fusion || !g_opt.gemm16 || !g_opt.fuse_concat_gn || n->op != GGML_OP_CONCAT || n->op_params[0] != 2 || !is_f32(n) || !contig(n) || (n->flags & GGML_TENSOR_FLAG_OUTPUT)) return false;
+    const ggml_tensor *a = n->src[0], *b = n->src[1];
+    if (!is_f32(a) || !is_f32(b) || !contig(a) || !contig(b) || a->ne[0] != n->ne[0] || a->ne[1] != n->ne[1] || a->ne[3] != n->ne[3] || b->ne[0] != n->ne[0] || b->ne[1] != n->ne[1] ||
+        b->ne[3] != n->ne[3] || a->ne[2] + b->ne[2] != n->ne[2])
+        return false;
+    const int64_t hw = n->ne[0] * n->ne[1], C = n->ne[2], C1 = a->ne[2], N = n->ne[3];
+    // consumers: exactly one GROUP_NORM chain, at most one other reader which must be a conv's IM2COL / CONV_2D (it finds its operand in B.packed)
+    int jg = -1, jc = -1;
+    for (int c : gi.consumers[i]) {
+        const ggml_tensor* t = gi.node(c);
+        if (t->op == GGML_OP_GROUP_NORM && t->src[0] == n && jg < 0)
+            jg = c;
+        else if ((t->op == GGML_OP_IM2COL || t->op == GGML_OP_CONV_2D) && t->src[1] == n && jc < 0)
+            jc = c;
+        else
+            return false;
+    }
+    if (jg < 0) return false;
+    const ggml_tensor* gn = gi.node(jg);
+    const int groups      = gn->op_params[0];
+    const float eps       = ggml_abi_op_param_f32(gn, 1);
+    if (!contig(gn) || !gn_two_source_supported((const float*)a->data, (const float*)b->data, hw, C, C1, groups)) return false;
+    const int j1 = gi.sole(jg);
+    if (j1 < 0 || gi.node(j1)->op != GGML_OP_MUL || gi.node(j1)->src[0] != gn || !bias_like_chan(gi.node(j1)->src[1], C) || gi.node(j1)->data != gn->data) return false;
+    const int j2 = gi.sole(j1);
+    if (j2 < 0 || gi.node(j2)->op != GGML_OP_ADD || gi.node(j2)->src[0] != gi.node(j1) || !bias_like_chan(gi.node(j2)->src[1], C) || gi.node(j2)->data != gn->data) return false;
+    int last  = j2;
+    bool silu = false;
+    const int j3 = gi.sole(j2);
+    if (j3 >= 0 && gi.node(j3)->op == GGML_OP_UNARY && ggml_abi_get_unary_op(gi.node(j3)) == GGML_UNARY_OP_SILU && gi.node(j3)->data == gn->data) {
+        silu = true;
+        last = j3;
+    }
+    if (!all_consumers_gemm16(gi, last, true)) return false;
+    for (int k : {jg, j1, j2, j3})
+        if (k >= 0 && k <= last && gi.done[k]) return false;
+    const float* w  = (const float*)gi.node(j1)->src[1]->data;
+    const float* bb = (const float*)gi.node(j2)->src[1]->data;
+    Planner* P       = B.P;
+    const size_t so  = B.alloc((size_t)N * C * 4 * 2);
+    const size_t off = B.alloc((size_t)N * hw * rup64(C) * 2);
+    const size_t roff = jc >= 0 ? B.alloc((size_t)N * hw * rup64(C) * 2) : 0;
+    const float *ap = (const float*)a->data, *bp = (const float*)b->data;
+    const bool raw  = jc >= 0;
+    B.emit([=](hipStream_t st) {
+        float* sc = (float*)(P->arena + so);
+        float* sh = sc + N * C;
+        launch_gn_stats(st, sc, sh, ap, hw, C, N, groups, eps, w, bb, bp, C1);
+        launch_nchw_to_nhwc_f16(st, P->arena + off, ap, hw, C, N, sc, sh, silu, bp, C1, raw ? (void*)(P->arena + roff) : nullptr);
+    });
+    B.packed[gi.node(last)] = Packed{off, rup64(C), true};
+    if (raw) B.packed[n] = Packed{roff, rup64(C), true};
+    chain = {i, jg, j1, j2};
+    if (silu) chain.push_back(j3);
+    g_stats.fused_norm++;
+    g_stats.fused_concat_gn++;
+    return true;
+}
+
 // NORM / RMS_NORM -> MUL(w[C]) [-> ADD(b[C])]
 bool plan_layer_norm(Builder& B, int i, hipStream_t, std::vector<int>& chain) {
     GInfo& gi            = B.gi;
@@ -2796,6 +2863,10 @@ bool build_plan(Planner* P, Plan* plan, const ggml_cgraph* g, hipStream_t s, boo
             case GGML_OP_NORM:
             case GGML_OP_RMS_NORM: ok = plan_layer_norm(B, i, s, chain); break;
             case GGML_OP_CONCAT: {
+                if (plan_concat_gn(B, i, s, chain)) {
+                    ok = true;
+                    break;
+                }
                 const auto ci = B.cat16.find(i);
                 if (ci != B.cat16.end()) {  // operand image of the Linears behind this concat: pack whatever its producers did not write themselves
                     const Builder::Cat16 ct = ci->second;
@@ -3230,6 +3301,7 @@ void planner_get_stats(ggml_backend_mi355x_stats* o) {
     o->fused_gn_stats        = g_stats.fused_gn_stats;
     o->fused_ln_reduce       = g_stats.fused_ln_reduce;
     o->redirect_fallbacks    = g_stats.redirect_fallbacks;
+    o->fused_concat_gn       = g_stats.fused_concat_gn;
     o->fused_attention       = g_stats.fused_attention;
     o->generic_matmul        = g_stats.generic_matmul;
     o->swizzled_weight_bytes = g_stats.swizzled_weight_bytes;
@@ -3295,6 +3367,7 @@ void planner_set_option(const char* key, int value) {
     else if (!strcmp(key, "fuse_gate")) g_opt.fuse_gate = value;
     else if (!strcmp(key, "relax_res_overlap")) g_opt.relax_res_overlap = value;
     else if (!strcmp(key, "fuse_split_gelu")) g_opt.fuse_split_gelu = value;
+    else if (!strcmp(key, "fuse_concat_gn")) g_opt.fuse_concat_gn = value;
     else if (!strcmp(key, "fuse_gelu")) g_opt.fuse_gelu = value;
     else if (!strcmp(key, "fuse_rope")) g_opt.fuse_rope = value;
     else if (!strcmp(key, "fuse_concat_heads")) g_opt.fuse_concat_heads = value;

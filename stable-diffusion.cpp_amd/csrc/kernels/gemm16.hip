@@ -1862,24 +1862,34 @@ __global__ __launch_bounds__(NT) void k_gn_stats(float* __restrict__ scale, floa
         shift[(int64_t)n * C + c] = (b ? b[c] : 0.f) - mean * sc;
     }
 }
+// TWO-SOURCE form of the statistics / apply kernels (round 4): the activation is the channel concatenation [x (C1 channels) | x2 (C - C1 channels)] of two NCHW
+// tensors that is never materialised (UNet skip connections: CONCAT(h, skip) read only by a GroupNorm and by the skip 1x1 conv, unet.hpp:702).  Float4 i4 of the
+// (image n, channels c0..) slab: hw % 4 == 0, so the four elements share their channel and their source.  x2 == nullptr: the single contiguous tensor.
+__device__ __forceinline__ float4 gn_ld4(const float* __restrict__ x, const float* __restrict__ x2, int C1, int C, int n, int c0, int64_t hw, int64_t i4) {
+    if (!x2) return ((const float4*)(x + ((int64_t)n * C + c0) * hw))[i4];
+    const int64_t e  = i4 * 4;
+    const int ch     = c0 + (int)(e / hw);
+    const int64_t of = e - (int64_t)(ch - c0) * hw;
+    const float* p   = ch < C1 ? x + ((int64_t)n * C1 + ch) * hw : x2 + ((int64_t)n * (C - C1) + (ch - C1)) * hw;
+    return *(const float4*)(p + of);
+}
 // register-resident variant: one (image, group) slab of up to 4 * NT * NV floats is read ONCE into NV float4 registers per thread
 // (the kernel above reads it twice: mean, then centred sum of squares); same per-thread order, same block reductions
 template <int NT, int NV>
 __global__ __launch_bounds__(NT) void k_gn_stats_reg(float* __restrict__ scale, float* __restrict__ shift, const float* __restrict__ x, int64_t hw, int C, int groups,
-                                                     int cpg, float eps, const float* __restrict__ w, const float* __restrict__ b) {
+                                                     int cpg, float eps, const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ x2 = nullptr, int C1 = 0) {
     __shared__ float scratch[2 * (NT / 64)];
     const int gidx = blockIdx.x % groups, n = blockIdx.x / groups;
     const int c0 = gidx * cpg, c1 = min(c0 + cpg, C);
     if (c0 >= c1) return;
     const int64_t cnt = (int64_t)(c1 - c0) * hw;
-    const float4* xs  = (const float4*)(x + ((int64_t)n * C + c0) * hw);
     const int64_t n4  = cnt / 4;
     float4 v[NV];
     float s = 0.f, dummy = 0.f;
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         const int64_t i = threadIdx.x + (int64_t)NT * j;
-        v[j]            = i < n4 ? xs[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[j]            = i < n4 ? gn_ld4(x, x2, C1, C, n, c0, hw, i) : make_float4(0.f, 0.f, 0.f, 0.f);
         s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
     }
     block_sum2<NT / 64>(s, dummy, scratch);
@@ -1906,17 +1916,16 @@ __global__ __launch_bounds__(NT) void k_gn_stats_reg(float* __restrict__ scale, 
 // the group; the two-pass kernel reads every byte twice and ran at 2.7 TB/s algorithmic)
 template <int NT>
 __global__ __launch_bounds__(NT) void k_gn_stats_1pass(float* __restrict__ scale, float* __restrict__ shift, const float* __restrict__ x, int64_t hw, int C, int groups,
-                                                       int cpg, float eps, const float* __restrict__ w, const float* __restrict__ b) {
+                                                       int cpg, float eps, const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ x2 = nullptr, int C1 = 0) {
     __shared__ float scratch[2 * (NT / 64)];
     const int gidx = blockIdx.x % groups, n = blockIdx.x / groups;
     const int c0 = gidx * cpg, c1 = min(c0 + cpg, C);
     if (c0 >= c1) return;
     const int64_t cnt = (int64_t)(c1 - c0) * hw;
-    const float* xs   = x + ((int64_t)n * C + c0) * hw;
-    const float K     = xs[0];
+    const float K     = gn_ld4(x, x2, C1, C, n, c0, hw, 0).x;
     float s1 = 0.f, s2 = 0.f;
     for (int64_t i = threadIdx.x; i < cnt / 4; i += NT) {
-        const float4 v = ((const float4*)xs)[i];
+        const float4 v = gn_ld4(x, x2, C1, C, n, c0, hw, i);
         const float a = v.x - K, bb = v.y - K, c = v.z - K, d = v.w - K;
         s1 += (a + bb) + (c + d);
         s2 += (a * a + bb * bb) + (c * c + d * d);
@@ -1932,21 +1941,30 @@ __global__ __launch_bounds__(NT) void k_gn_stats_1pass(float* __restrict__ scale
         shift[(int64_t)n * C + c] = (b ? b[c] : 0.f) - mean * sc;
     }
 }
+// x2 != nullptr: statistics of the channel concatenation [x (C1 channels) | x2] (gn_two_source_supported)
+bool gn_two_source_supported(const float* x, const float* x2, int64_t hw, int64_t C, int64_t C1, int groups) {
+    const int64_t cnt = ((C + groups - 1) / groups) * hw;
+    return hw % 4 == 0 && ((((uintptr_t)x) | ((uintptr_t)x2)) & 15) == 0 && C1 > 0 && C1 < C && (cnt <= 4 * 1024 * 16 || cnt >= 16384) && C * hw < (1ll << 31);
+}
 void launch_gn_stats(hipStream_t s, float* scale, float* shift, const float* x, int64_t hw, int64_t C, int64_t N, int groups, float eps, const float* w,
-                     const float* b) {
+                     const float* b, const float* x2, int64_t C1) {
     KScope ks_(s, KF_GN_STATS, 0.0, (double)hw * C * N * 4.0);  // algorithmic: ONE read of the activation
     const int cpg       = (int)((C + groups - 1) / groups);
     const int64_t cnt   = (int64_t)cpg * hw;
-    const bool v4       = hw % 4 == 0 && (((uintptr_t)x) & 15) == 0;  // (a short last group is fine: the kernels bound it by c1)
+    const bool v4       = hw % 4 == 0 && ((((uintptr_t)x) | ((uintptr_t)x2)) & 15) == 0;  // (a short last group is fine: the kernels bound it by c1)
     const unsigned grid = (unsigned)(N * groups);
+    if (x2 && !gn_two_source_supported(x, x2, hw, C, C1, groups)) {
+        fprintf(stderr, "ggml-mi355x: two-source GroupNorm statistics asked for a shape they do not take\n");
+        abort();
+    }
     if (v4 && cnt <= 4 * 256 * 4)
-        k_gn_stats_reg<256, 4><<<grid, 256, 0, s>>>(scale, shift, x, hw, (int)C, groups, cpg, eps, w, b);
+        k_gn_stats_reg<256, 4><<<grid, 256, 0, s>>>(scale, shift, x, hw, (int)C, groups, cpg, eps, w, b, x2, (int)C1);
     else if (v4 && cnt <= 4 * 1024 * 4)
-        k_gn_stats_reg<1024, 4><<<grid, 1024, 0, s>>>(scale, shift, x, hw, (int)C, groups, cpg, eps, w, b);
+        k_gn_stats_reg<1024, 4><<<grid, 1024, 0, s>>>(scale, shift, x, hw, (int)C, groups, cpg, eps, w, b, x2, (int)C1);
     else if (v4 && cnt <= 4 * 1024 * 16)
-        k_gn_stats_reg<1024, 16><<<grid, 1024, 0, s>>>(scale, shift, x, hw, (int)C, groups, cpg, eps, w, b);
+        k_gn_stats_reg<1024, 16><<<grid, 1024, 0, s>>>(scale, shift, x, hw, (int)C, groups, cpg, eps, w, b, x2, (int)C1);
     else if (v4 && cnt >= 16384)
-        k_gn_stats_1pass<1024><<<grid, 1024, 0, s>>>(scale, shift, x, hw, (int)C, groups, cpg, eps, w, b);
+        k_gn_stats_1pass<1024><<<grid, 1024, 0, s>>>(scale, shift, x, hw, (int)C, groups, cpg, eps, w, b, x2, (int)C1);
     else if (cnt >= 16384)
         k_gn_stats<1024><<<grid, 1024, 0, s>>>(scale, shift, x, hw, (int)C, groups, cpg, eps, w, b);
     else
@@ -1983,11 +2001,17 @@ __global__ __launch_bounds__(256) void k_nchw_to_nhwc_f16(_Float16* __restrict__
 // consecutive positions — two float4 loads (256-byte row segments per 16 lanes), affine + SiLU, four half2 LDS stores (row stride 33
 // dwords: 2-way conflicts at most).  Store: a thread owns one position x 8 channels — one 16-byte store (128-byte rows per 8 lanes).
 __global__ __launch_bounds__(256) void k_nchw_to_nhwc_f16_v4(_Float16* __restrict__ dst, const float* __restrict__ x, int64_t hw, int C, int Cp,
-                                                             const float* __restrict__ scale, const float* __restrict__ shift, int silu) {
+                                                             const float* __restrict__ scale, const float* __restrict__ shift, int silu,
+                                                             const float* __restrict__ x2 = nullptr, int C1 = 0, _Float16* __restrict__ dst_raw = nullptr) {
     __shared__ uint32_t tile[64][33];  // [position][channel pair] half2
+    __shared__ uint32_t tile_raw[64][33];  // dst_raw != nullptr: the same values WITHOUT affine / SiLU (the image the skip 1x1 conv reads)
     const int n  = blockIdx.z;
     const int p0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
-    const float* xn = x + (int64_t)n * C * hw;
+    // channel row pointer: one tensor, or the concatenation [x (C1 channels) | x2 (C - C1)] (gn_ld4)
+    auto rowp = [&](int c) -> const float* {
+        if (!x2) return x + ((int64_t)n * C + c) * hw;
+        return c < C1 ? x + ((int64_t)n * C1 + c) * hw : x2 + ((int64_t)n * (C - C1) + (c - C1)) * hw;
+    };
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         const int item = threadIdx.x + 256 * k;  // 32 channel pairs x 16 position quads
@@ -1995,10 +2019,17 @@ __global__ __launch_bounds__(256) void k_nchw_to_nhwc_f16_v4(_Float16* __restric
         const int c = c0 + 2 * cp, p = p0 + pq;
         float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
         if (p < hw) {
-            if (c < C) va = *(const float4*)(xn + (int64_t)c * hw + p);
-            if (c + 1 < C) vb = *(const float4*)(xn + (int64_t)(c + 1) * hw + p);
+            if (c < C) va = *(const float4*)(rowp(c) + p);
+            if (c + 1 < C) vb = *(const float4*)(rowp(c + 1) + p);
         }
         float a[4] = {va.x, va.y, va.z, va.w}, bq[4] = {vb.x, vb.y, vb.z, vb.w};
+        if (dst_raw) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const _Float16 hu = (_Float16)(c < C ? a[i] : 0.f), hv = (_Float16)(c + 1 < C ? bq[i] : 0.f);
+                tile_raw[pq + i][cp] = (uint32_t)__builtin_bit_cast(uint16_t, hu) | ((uint32_t)__builtin_bit_cast(uint16_t, hv) << 16);
+            }
+        }
         if (scale) {
             const float sa = c < C ? scale[(int64_t)n * C + c] : 0.f, ha = c < C ? shift[(int64_t)n * C + c] : 0.f;
             const float sb = c + 1 < C ? scale[(int64_t)n * C + c + 1] : 0.f, hb = c + 1 < C ? shift[(int64_t)n * C + c + 1] : 0.f;
@@ -2035,15 +2066,31 @@ __global__ __launch_bounds__(256) void k_nchw_to_nhwc_f16_v4(_Float16* __restric
             o.z = tile[pos][cg + 2];
             o.w = tile[pos][cg + 3];
             *(uint4*)(dn + (int64_t)p * Cp + c) = o;
+            if (dst_raw) {
+                uint4 r;
+                r.x = tile_raw[pos][cg];
+                r.y = tile_raw[pos][cg + 1];
+                r.z = tile_raw[pos][cg + 2];
+                r.w = tile_raw[pos][cg + 3];
+                *(uint4*)(dst_raw + (int64_t)n * hw * Cp + (int64_t)p * Cp + c) = r;
+            }
         }
     }
 }
-void launch_nchw_to_nhwc_f16(hipStream_t s, void* dst, const float* x, int64_t hw, int64_t C, int64_t N, const float* scale, const float* shift, bool silu) {
-    KScope ks_(s, KF_NCHW_NHWC, 0.0, (double)hw * C * N * 4.0 + (double)hw * rup64(C, 64) * N * 2.0);
+// x2 != nullptr: the source is the channel concatenation [x (C1 channels) | x2 (C - C1)] (both NCHW, never materialised);  dst_raw != nullptr: a second
+// image of the same values without affine / SiLU (one read of the sources for the GroupNorm'ed conv operand AND the skip 1x1 conv's operand)
+void launch_nchw_to_nhwc_f16(hipStream_t s, void* dst, const float* x, int64_t hw, int64_t C, int64_t N, const float* scale, const float* shift, bool silu,
+                             const float* x2, int64_t C1, void* dst_raw) {
+    KScope ks_(s, KF_NCHW_NHWC, 0.0, (double)hw * C * N * 4.0 + (double)hw * rup64(C, 64) * N * 2.0 * (dst_raw ? 2.0 : 1.0));
     const int Cp = (int)rup64(C, 64);
     dim3 grid((unsigned)((hw + 63) / 64), (unsigned)(Cp / 64), (unsigned)N);
-    if (hw % 4 == 0 && ((((uintptr_t)x) | ((uintptr_t)dst)) & 15) == 0)
-        k_nchw_to_nhwc_f16_v4<<<grid, 256, 0, s>>>((_Float16*)dst, x, hw, (int)C, Cp, scale, shift, silu ? 1 : 0);
+    const bool v4 = hw % 4 == 0 && ((((uintptr_t)x) | ((uintptr_t)dst) | ((uintptr_t)x2) | ((uintptr_t)dst_raw)) & 15) == 0;
+    if ((x2 || dst_raw) && !v4) {
+        fprintf(stderr, "ggml-mi355x: two-source / two-output NCHW -> NHWC pass needs hw %% 4 == 0 and 16-byte aligned tensors\n");
+        abort();
+    }
+    if (v4)
+        k_nchw_to_nhwc_f16_v4<<<grid, 256, 0, s>>>((_Float16*)dst, x, hw, (int)C, Cp, scale, shift, silu ? 1 : 0, x2, (int)C1, (_Float16*)dst_raw);
     else
         k_nchw_to_nhwc_f16<<<grid, 256, 0, s>>>((_Float16*)dst, x, hw, (int)C, Cp, scale, shift, silu ? 1 : 0);
 }

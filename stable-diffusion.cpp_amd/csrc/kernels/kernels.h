@@ -176,10 +176,13 @@ void launch_pack_cols_f16(hipStream_t s, void* dst, int64_t ld, const float* x, 
 void launch_layer_norm_f16(hipStream_t s, void* dst, const float* x, int64_t ne0, int64_t nrows, int64_t x_stride, float eps, const float* w,
                            const float* b, bool rms, int64_t mod_L = 0);
 void launch_geglu_f16(hipStream_t s, void* dst, const float* x, int64_t tokens, int64_t inner, int64_t x_stride);
+// x2 != nullptr (both launchers): the activation is the channel concatenation [x (C1 channels) | x2 (C - C1 channels)] of two NCHW tensors, never materialised
+// (UNet skip connections); dst_raw != nullptr: a second NHWC image of the same values without affine / SiLU
+bool gn_two_source_supported(const float* x, const float* x2, int64_t hw, int64_t C, int64_t C1, int groups);
 void launch_gn_stats(hipStream_t s, float* scale, float* shift, const float* x, int64_t hw, int64_t C, int64_t N, int groups, float eps,
-                     const float* w, const float* b);
+                     const float* w, const float* b, const float* x2 = nullptr, int64_t C1 = 0);
 void launch_nchw_to_nhwc_f16(hipStream_t s, void* dst, const float* x, int64_t hw, int64_t C, int64_t N, const float* scale, const float* shift,
-                             bool silu);
+                             bool silu, const float* x2 = nullptr, int64_t C1 = 0, void* dst_raw = nullptr);
 
 // ---- qgemm.hip: q8_0 / q4_0 Linear with <= 4 activation rows: raw quantised blocks streamed once, in-register dequant ----------------
 bool qgemv_supported(int wtype, int64_t rows, int64_t K);

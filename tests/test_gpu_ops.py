@@ -123,6 +123,37 @@ def test_group_norm_into_conv_large_groups(sd, oracle, gpu, rng, shape, mean):
     assert np.isfinite(out).all() and rel_l2(out, ref) < 3e-4
 
 
+@pytest.mark.parametrize("N,Ca,Cb,HW,mean", [(2, 64, 32, 16, 1.5), (2, 320, 320, 64, -0.5), (1, 640, 320, 32, 0.2), (3, 128, 64, 8, 0.0)])
+def test_skip_concat_group_norm_two_sources(sd, oracle, gpu, rng, N, Ca, Cb, HW, mean):
+    """UNet skip connection (unet.hpp:702 + block.hpp:126-179): h = CONCAT(h, skip; channels); ResBlock(h) = conv3x3(SiLU(GN(h) w + b)) ... + conv1x1(h).  The
+    concatenation is never built: GroupNorm statistics and ONE transposing pass read the two sources and write both convs' f16 NHWC operands (plan_concat_gn).
+    Ca = 64 with 3 channels per group and Ca = 640 with 30: groups straddle the two sources; the sources carry different means."""
+    C = Ca + Cb
+    a = (rng.standard_normal((N, Ca, HW, HW)) * 1.3 + mean).astype(np.float32)
+    b = (rng.standard_normal((N, Cb, HW, HW)) * 0.7 - mean).astype(np.float32)
+    w = (1 + 0.1 * rng.standard_normal(C)).astype(np.float32)
+    bb = rng.standard_normal(C).astype(np.float32)
+    OC = 64
+    wc = (rng.standard_normal((OC, C, 3, 3)) / np.sqrt(C * 9)).astype(np.float32)
+    ws = (rng.standard_normal((OC, C, 1, 1)) / np.sqrt(C)).astype(np.float32)
+
+    def build(g, L):
+        h = L.ggml_concat(g.ctx, g.input(a), g.input(b), 2)
+        t = L.ggml_group_norm(g.ctx, h, 32, 1e-6)
+        t = L.ggml_mul_inplace(g.ctx, t, L.ggml_reshape_4d(g.ctx, g.weight(w, F32), 1, 1, C, 1))
+        t = L.ggml_add_inplace(g.ctx, t, L.ggml_reshape_4d(g.ctx, g.weight(bb, F32), 1, 1, C, 1))
+        t = L.ggml_silu_inplace(g.ctx, t)
+        y = L.ggml_conv_2d(g.ctx, g.weight(wc, F16), t, 1, 1, 1, 1, 1, 1)
+        sk = L.ggml_conv_2d(g.ctx, g.weight(ws, F16), h, 1, 1, 0, 0, 1, 1)
+        return L.ggml_add(g.ctx, y, sk)
+
+    before = sd.backend_stats() if _on_gpu() else None
+    ref, out = run_both(sd, oracle, gpu, build)
+    assert np.isfinite(out).all() and rel_l2(out, ref) < 3e-4
+    if before is not None and not os.environ.get("SDCPP_BACKEND_OPTS"):
+        assert sd.backend_stats()["fused_concat_gn"] - before["fused_concat_gn"] == 1
+
+
 @pytest.mark.parametrize("C,rows", [(320, 64), (1280, 17), (77, 5), (3072, 8)])
 def test_layer_norm_chain(sd, oracle, gpu, rng, C, rows):
     x = (rng.standard_normal((rows, C)) * 2 + 1).astype(np.float32)
