@@ -212,6 +212,9 @@ def main():
                     roofline["traffic_note"] = pm["note"]
             except (ValueError, KeyError):
                 pass
+    # what the nominal-peak fraction contains (SQ-level PMC over the dominant launch in isolation, committed profile — not measured in this run)
+    roofline["pmc_dominant_launch"] = {"kernel": "k_conv3w<64,320> (3x3, 320 -> 320 @64x64, 16 images)", "sustained_clock_ghz": 1.61, "matrix_pipe_busy": 0.69,
+                                       "waves_parked_frac": 0.30, "lds_bank_conflicts": 0, "source": "profiles/r05b_pmc_sq_gemm_kernels.txt (rocprofv3 --pmc, three passes)"}
     roofline["whole_step_tflops"] = round(step_tflops, 2)  # all kernels + host graph build + uploads: 2*B*UNet-forward FLOPs / step wall time
     roofline["whole_step_frac"] = round(step_tflops / MFMA_PEAK_TFLOPS, 4)
     if timing and rank == 0 and not args.no_kernels:
