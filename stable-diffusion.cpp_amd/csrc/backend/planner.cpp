@@ -1647,14 +1647,14 @@ bool plan_concat_gn(Builder& B, int i, hipStream_t, std::vector<int>& chain) {
         b->ne[3] != n->ne[3] || a->ne[2] + b->ne[2] != n->ne[2])
         return false;
     const int64_t hw = n->ne[0] * n->ne[1], C = n->ne[2], C1 = a->ne[2], N = n->ne[3];
-    // consumers: exactly one GROUP_NORM chain, at most one other reader which must be a conv's IM2COL / CONV_2D (it finds its operand in B.packed)
+    // consumers: exactly one GROUP_NORM chain, at most one other reader which must be the IM2COL of a conv chain the implicit-GEMM kernels take
     int jg = -1, jc = -1;
     for (int c : gi.consumers[i]) {
         const ggml_tensor* t = gi.node(c);
         if (t->op == GGML_OP_GROUP_NORM && t->src[0] == n && jg < 0)
             jg = c;
-        else if ((t->op == GGML_OP_IM2COL || t->op == GGML_OP_CONV_2D) && t->src[1] == n && jc < 0)
-            jc = c;
+        else if (t->op == GGML_OP_IM2COL && t->src[1] == n && jc < 0 && conv_im2col_fast_ok(gi, c))
+            jc = c;  // a conv chain that runs on the implicit-GEMM kernels: it takes its operand from B.packed and never reads the f32 tensor
         else
             return false;
     }
