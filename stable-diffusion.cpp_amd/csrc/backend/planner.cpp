@@ -47,7 +47,7 @@ struct Stats {
 } g_stats;
 
 struct Options {
-    std::atomic<int> fusion{1}, mfma_gemm{1}, hip_graph{0}, flash_pattern{1}, gemm16{1}, fuse_modulate{1}, fuse_gate{1}, fuse_gelu{1}, fuse_rope{1}, fuse_concat_heads{1}, qgemv{1}, fuse_chan_add{1}, fuse_proj_tokens{1}, fuse_q16{1}, qgemm16{1}, fgemv{1}, fuse_siblings{1}, hoist_kv{1}, hoist_emb{1}, fuse_rows16{0}, fuse_cat_rows16{1}, fuse_joint_qkv{1}, jit_qimages{4096}, fuse_gn_stats{1}, fuse_ln_reduce{1}, relax_res_overlap{1}, fuse_split_gelu{1}, fuse_concat_gn{1};
+    std::atomic<int> fusion{1}, mfma_gemm{1}, hip_graph{0}, flash_pattern{1}, gemm16{1}, fuse_modulate{1}, fuse_gate{1}, fuse_gelu{1}, fuse_rope{1}, fuse_concat_heads{1}, qgemv{1}, fuse_chan_add{1}, fuse_proj_tokens{1}, fuse_q16{1}, qgemm16{1}, fgemv{1}, fuse_siblings{1}, hoist_kv{1}, hoist_emb{1}, fuse_rows16{0}, fuse_cat_rows16{1}, fuse_joint_qkv{1}, jit_qimages{4096}, fuse_gn_stats{1}, fuse_ln_reduce{1}, relax_res_overlap{1}, fuse_split_gelu{1}, fuse_concat_gn{1}, fuse_gn_tokens{1};
 } g_opt;
 
 using Step = std::function<void(hipStream_t)>;
@@ -1608,6 +1608,42 @@ bool plan_group_norm(Builder& B, int i, hipStream_t, std::vector<int>& chain) {
     }
     float* dst      = (float*)n->data;
     const float* xp = (const float*)x->data;
+    // SpatialTransformer with Linear projections (SDXL, block.hpp:548-566): norm(x) -> PERMUTE(1,2,0,3) -> CONT -> RESHAPE [C, W*H, N] -> proj_in Linear.  The NHWC
+    // f16 image the apply pass writes IS that Linear's operand image ([N * W*H tokens][rup64(C)]): no f32 GroupNorm kernel, no transposing copy, no pack pass
+    int tok_cont = -1;
+    if (g_opt.fusion && g_opt.fuse_gn_tokens && w && !silu) {
+        const int jp = gi.sole(last);
+        const ggml_tensor* pt = jp >= 0 ? gi.node(jp) : nullptr;
+        if (pt && pt->op == GGML_OP_PERMUTE && pt->src[0] == gi.node(last) && pt->op_params[0] == 1 && pt->op_params[1] == 2 && pt->op_params[2] == 0 && pt->op_params[3] == 3) {
+            const int jc = gi.sole(jp);
+            const ggml_tensor* ct = jc >= 0 ? gi.node(jc) : nullptr;
+            if (ct && ct->op == GGML_OP_CONT && ct->src[0] == pt && is_f32(ct) && contig(ct) && ct->ne[0] == C && !(ct->flags & GGML_TENSOR_FLAG_OUTPUT) && all_consumers_gemm16(gi, jc, false)) {
+                std::vector<int> c2 = chain;
+                c2.push_back(jp);
+                c2.push_back(jc);
+                if (gi.only_noops_between(last, jc, c2)) tok_cont = jc;
+            }
+        }
+    }
+    if (tok_cont >= 0) {
+        Planner* P       = B.P;
+        const auto pre   = B.gn_pre.find(x);
+        const bool have  = pre != B.gn_pre.end() && pre->second.w == w && pre->second.b == b && pre->second.groups == groups && pre->second.eps == eps;
+        const size_t so  = have ? pre->second.off : B.alloc((size_t)N * C * 4 * 2);
+        const size_t off = B.alloc((size_t)N * hw * rup64(C) * 2);
+        B.emit([=](hipStream_t st) {
+            float* sc = (float*)(P->arena + so);
+            float* sh = sc + N * C;
+            if (!have) launch_gn_stats(st, sc, sh, xp, hw, C, N, groups, eps, w, b);
+            launch_nchw_to_nhwc_f16(st, P->arena + off, xp, hw, C, N, sc, sh, false);
+        });
+        chain.push_back(gi.sole(last));
+        chain.push_back(tok_cont);
+        B.packed[gi.node(tok_cont)] = Packed{off, rup64(C), false};
+        g_stats.fused_norm++;
+        g_stats.fused_proj_tokens++;
+        return true;
+    }
     if (w && all_consumers_gemm16(gi, last, true)) {
         // gen-2: every reader is an implicit-GEMM conv -> statistics kernel + one transposing apply kernel that writes the
         // f16 NHWC operand image straight into the arena; the f32 NCHW result is never materialised.
@@ -3368,6 +3404,7 @@ void planner_set_option(const char* key, int value) {
     else if (!strcmp(key, "relax_res_overlap")) g_opt.relax_res_overlap = value;
     else if (!strcmp(key, "fuse_split_gelu")) g_opt.fuse_split_gelu = value;
     else if (!strcmp(key, "fuse_concat_gn")) g_opt.fuse_concat_gn = value;
+    else if (!strcmp(key, "fuse_gn_tokens")) g_opt.fuse_gn_tokens = value;
     else if (!strcmp(key, "fuse_gelu")) g_opt.fuse_gelu = value;
     else if (!strcmp(key, "fuse_rope")) g_opt.fuse_rope = value;
     else if (!strcmp(key, "fuse_concat_heads")) g_opt.fuse_concat_heads = value;

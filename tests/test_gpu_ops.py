@@ -123,6 +123,32 @@ def test_group_norm_into_conv_large_groups(sd, oracle, gpu, rng, shape, mean):
     assert np.isfinite(out).all() and rel_l2(out, ref) < 3e-4
 
 
+@pytest.mark.parametrize("N,C,inner,H,W", [(2, 640, 640, 16, 16), (1, 64, 96, 5, 8), (2, 1280, 1280, 32, 32)])
+def test_group_norm_into_token_linear(sd, oracle, gpu, rng, N, C, inner, H, W):
+    """SpatialTransformer with Linear projections (SDXL, block.hpp:548-566): GroupNorm (+affine) -> PERMUTE(1,2,0,3) -> CONT -> RESHAPE [C, W*H, N] -> proj_in Linear.
+    The GroupNorm apply pass writes the Linear's f16 operand image: no f32 norm kernel, no transposing copy, no pack pass."""
+    x = (rng.standard_normal((N, C, H, W)) * 1.2 + 0.4).astype(np.float32)
+    w = (1 + 0.1 * rng.standard_normal(C)).astype(np.float32)
+    b = rng.standard_normal(C).astype(np.float32)
+    wl = (rng.standard_normal((inner, C)) / np.sqrt(C)).astype(np.float32)
+    bl = rng.standard_normal(inner).astype(np.float32)
+
+    def build(g, L):
+        t = L.ggml_group_norm(g.ctx, g.input(x), 32, 1e-6)
+        t = L.ggml_mul_inplace(g.ctx, t, L.ggml_reshape_4d(g.ctx, g.weight(w, F32), 1, 1, C, 1))
+        t = L.ggml_add_inplace(g.ctx, t, L.ggml_reshape_4d(g.ctx, g.weight(b, F32), 1, 1, C, 1))
+        t = L.ggml_cont(g.ctx, L.ggml_permute(g.ctx, t, 1, 2, 0, 3))
+        t = L.ggml_reshape_3d(g.ctx, t, C, W * H, N)
+        y = L.ggml_mul_mat(g.ctx, g.weight(wl, F16), t)
+        return L.ggml_add_inplace(g.ctx, y, g.weight(bl, F32))
+
+    before = sd.backend_stats() if _on_gpu() else None
+    ref, out = run_both(sd, oracle, gpu, build)
+    assert np.isfinite(out).all() and rel_l2(out, ref) < 3e-4
+    if before is not None and not os.environ.get("SDCPP_BACKEND_OPTS") and H * W % 4 == 0:
+        assert sd.backend_stats()["fused_proj_tokens"] - before["fused_proj_tokens"] == 1
+
+
 @pytest.mark.parametrize("N,Ca,Cb,HW,mean", [(2, 64, 32, 16, 1.5), (2, 320, 320, 64, -0.5), (1, 640, 320, 32, 0.2), (3, 128, 64, 8, 0.0)])
 def test_skip_concat_group_norm_two_sources(sd, oracle, gpu, rng, N, Ca, Cb, HW, mean):
     """UNet skip connection (unet.hpp:702 + block.hpp:126-179): h = CONCAT(h, skip; channels); ResBlock(h) = conv3x3(SiLU(GN(h) w + b)) ... + conv1x1(h).  The
