@@ -119,6 +119,7 @@ GGML_MI355X_API int ggml_backend_mi355x_get_kernel_timings(struct ggml_backend_m
  * few-row / quantised Linears: "fgemv" (1: f16 / f32 weights under <= 16 rows on the one-launch weight-streaming kernel, SiLU in front of it applied on
  * load), "fgemv_max_rows" (16), "qgemv" (1) / "qgemv_max_rows" (4, <= 16: raw q8_0 / q4_0 blocks streamed up to that many rows), "qgemm16_max_rows" (512:
  * raw-block MFMA GEMM up to n rows; 8192 = the resident-quantised mode, no f16 image for any quantised Linear), "qgemm16" (1);
+ * "fuse_linear_nchw" (1: Linear proj_out -> PERMUTE -> CONT -> RESHAPE -> ADD x_in of such a SpatialTransformer runs as a 1x1 implicit-GEMM conv over the token rows: NCHW + bias + residual epilogue),
  * "fuse_gn_tokens" (1: GroupNorm -> PERMUTE -> CONT -> Linear proj_in of a SpatialTransformer with Linear projections (SDXL): the GroupNorm apply pass writes the Linear's f16 operand image),
  * "fuse_concat_gn" (1: UNet skip-connection CONCAT read only by a GroupNorm chain (+ the skip 1x1 conv) is never built, option 0 = the concat pass),
  * "fuse_split_gelu" (1: FLUX linear1 writes gelu(mlp) as f16 into linear2's operand image), "geglu16" (1: GEGLU FF1 on the 256 x 320 tile through the 16-column

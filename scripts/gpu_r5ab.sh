@@ -1,0 +1,10 @@
+#!/bin/bash
+# round 4, call AB: Linear proj_out -> NCHW + residual as a 1x1 implicit-GEMM conv (SDXL SpatialTransformer): op test, SDXL model tests, family A/B
+cd "$GRAFT_REPO_ROOT" || exit 1
+mkdir -p gpurun_out
+export PYTHONUNBUFFERED=1 TMPDIR=/tmp
+( timeout 300 python -m pytest tests/test_gpu_ops.py -m gpu -q -x -k "token_linear or group_norm_into_token or spatial or linear_weight" ) > gpurun_out/r5ab_tests_ops.log 2>&1; echo "rc=$?" >> gpurun_out/r5ab_tests_ops.log
+( timeout 400 python -m pytest tests/test_gpu_model.py tests/test_zz_gpu_fullsize.py -m gpu -q -x -k "sdxl or unet or mmdit or flux" ) > gpurun_out/r5ab_tests_models.log 2>&1; echo "rc=$?" >> gpurun_out/r5ab_tests_models.log
+rm -f gpurun_out/r5ab_family_sdxl.txt
+for rep in 1 2; do for o in "fuse_linear_nchw=0" "fuse_linear_nchw=1"; do echo "#### sdxl $o" >> gpurun_out/r5ab_family_sdxl.txt; timeout 300 python scripts/family_times.py sdxl $o 2>&1 | head -18 >> gpurun_out/r5ab_family_sdxl.txt; done; done
+tail -n 3 gpurun_out/r5ab_tests_ops.log gpurun_out/r5ab_tests_models.log; grep "####\|==\|copies\|binary\|Linear\|conv implicit-GEMM, 2" gpurun_out/r5ab_family_sdxl.txt

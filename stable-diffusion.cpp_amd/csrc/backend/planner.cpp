@@ -47,7 +47,7 @@ struct Stats {
 } g_stats;
 
 struct Options {
-    std::atomic<int> fusion{1}, mfma_gemm{1}, hip_graph{0}, flash_pattern{1}, gemm16{1}, fuse_modulate{1}, fuse_gate{1}, fuse_gelu{1}, fuse_rope{1}, fuse_concat_heads{1}, qgemv{1}, fuse_chan_add{1}, fuse_proj_tokens{1}, fuse_q16{1}, qgemm16{1}, fgemv{1}, fuse_siblings{1}, hoist_kv{1}, hoist_emb{1}, fuse_rows16{0}, fuse_cat_rows16{1}, fuse_joint_qkv{1}, jit_qimages{4096}, fuse_gn_stats{1}, fuse_ln_reduce{1}, relax_res_overlap{1}, fuse_split_gelu{1}, fuse_concat_gn{1}, fuse_gn_tokens{1};
+    std::atomic<int> fusion{1}, mfma_gemm{1}, hip_graph{0}, flash_pattern{1}, gemm16{1}, fuse_modulate{1}, fuse_gate{1}, fuse_gelu{1}, fuse_rope{1}, fuse_concat_heads{1}, qgemv{1}, fuse_chan_add{1}, fuse_proj_tokens{1}, fuse_q16{1}, qgemm16{1}, fgemv{1}, fuse_siblings{1}, hoist_kv{1}, hoist_emb{1}, fuse_rows16{0}, fuse_cat_rows16{1}, fuse_joint_qkv{1}, jit_qimages{4096}, fuse_gn_stats{1}, fuse_ln_reduce{1}, relax_res_overlap{1}, fuse_split_gelu{1}, fuse_concat_gn{1}, fuse_gn_tokens{1}, fuse_linear_nchw{1};
 } g_opt;
 
 using Step = std::function<void(hipStream_t)>;
@@ -671,6 +671,45 @@ void plan_linear(Builder& B, int i, hipStream_t s, std::vector<int>& chain) {
             }
         }
     }
+    // SpatialTransformer proj_out as a Linear (SDXL, block.hpp:566-572): Linear (+bias) -> PERMUTE(1,0,2,3) -> CONT -> RESHAPE [W,H,M,N] -> ADD(., x_in).  The GEMM
+    // runs as a 1x1 implicit-GEMM conv over the token rows (its NHWC operand image IS the row image, the Linear's weight image IS the 1x1 conv image): the
+    // D[oc][pos] epilogue writes NCHW with bias and the x_in residual — no transposing copy, no separate add
+    int nchw_add = -1;
+    const float* nchw_res = nullptr;
+    int64_t nchw_HW = 0, nchw_N = 0;
+    if (g_opt.fusion && g_opt.gemm16 && g_opt.fuse_proj_tokens && g_opt.fuse_linear_nchw && hm_d == 0 && !ep.residual && last != i && tokens > 16 && n->ne[3] == 1 && x->ne[3] == 1) {
+        const int jp = gi.sole(last);
+        const ggml_tensor* pt = jp >= 0 ? gi.node(jp) : nullptr;
+        if (pt && pt->op == GGML_OP_PERMUTE && pt->src[0] == gi.node(last) && pt->op_params[0] == 1 && pt->op_params[1] == 0 && pt->op_params[2] == 2 && pt->op_params[3] == 3) {
+            const int jc = gi.sole(jp);
+            if (jc >= 0 && gi.node(jc)->op == GGML_OP_CONT && gi.node(jc)->src[0] == pt && is_f32(gi.node(jc)) && contig(gi.node(jc))) {
+                std::vector<int> c2 = chain;
+                c2.push_back(jp);
+                c2.push_back(jc);
+                int via = jc, j = gi.sole(jc);
+                while (j >= 0 && gi.node(j)->op == GGML_OP_RESHAPE) {
+                    c2.push_back(j);
+                    via = j;
+                    j   = gi.sole(j);
+                }
+                const ggml_tensor* a = j >= 0 ? gi.node(j) : nullptr;
+                if (a && via != jc && a->op == GGML_OP_ADD && !gi.done[j] && is_f32(a) && contig(a)) {
+                    const ggml_tensor* other = a->src[0] == gi.node(via) ? a->src[1] : (a->src[1] == gi.node(via) ? a->src[0] : nullptr);
+                    const int64_t HWt = n->ne[1], Nimg = n->ne[2];
+                    if (other && is_f32(other) && contig(other) && ggml_abi_same_shape(other, a) && a->ne[2] == M && a->ne[3] == Nimg && a->ne[0] * a->ne[1] == HWt && gi.idx(other) < i &&
+                        (other->data == a->data || !overlaps(a->data, ggml_abi_nbytes(a), other->data, ggml_abi_nbytes(other))) && aligned16(a->data) && aligned16(other->data) &&
+                        gi.only_noops_between(last, j, c2)) {
+                        c2.push_back(j);
+                        chain    = c2;
+                        nchw_add = j;
+                        nchw_res = (const float*)other->data;
+                        nchw_HW  = HWt;
+                        nchw_N   = Nimg;
+                    }
+                }
+            }
+        }
+    }
     int emit_node = i;  // graph position at which the GEMM itself is launched (operand packing always happens at i)
     // DiT gate (mmdit.hpp:540-551): Linear -> MUL(., gate[M,1,N]) -> ADD(x, .): dst = x + (acc + bias) * gate
     if (g_opt.fusion && g_opt.gemm16 && g_opt.fuse_gate && hm_d == 0 && !ep.residual && x->ne[3] == 1 && x->ne[1] >= 32 && tokens < (1ll << 31) &&
@@ -839,6 +878,23 @@ void plan_linear(Builder& B, int i, hipStream_t s, std::vector<int>& chain) {
         Planner* P       = B.P;
         const size_t off = it->second.off;
         const int64_t ld = it->second.ld;
+        if (nchw_add >= 0 && !useq && swz && ld == rup64(K) && geglu_out < 0 && gelu_out < 0 && !ep.gate && !redir) {
+            float* ndst             = (float*)gi.node(nchw_add)->data;
+            const int64_t HWt = nchw_HW, Nimg = nchw_N;
+            const float* resp       = nchw_res;
+            const Builder::Split sk = B.plan_split(tokens, M, rup64(K), true, true);
+            B.emit_at(emit_node, i, [=](hipStream_t st) {
+                Epilogue e2 = ep;
+                e2.residual = resp;
+                launch_gemm16_conv(st, ndst, P->arena + off, swz, HWt, 1, K, Nimg, M, 1, 1, 0, false, e2, sk.ws(P), sk.cnt(P), sk.S);
+            });
+            g_stats.fused_linear++;
+            g_stats.fused_proj_tokens++;
+            return;
+        }
+        if (nchw_add >= 0) {  // the chain was extended for nothing: give the nodes behind the bias back to the walk
+            while (!chain.empty() && chain.back() != last) chain.pop_back();
+        }
         if (geglu_out >= 0) {
             const size_t ooff  = B.alloc((size_t)tokens * (M / 2) * 2);
             const float* biasp = ep.bias;
@@ -3405,6 +3461,7 @@ void planner_set_option(const char* key, int value) {
     else if (!strcmp(key, "fuse_split_gelu")) g_opt.fuse_split_gelu = value;
     else if (!strcmp(key, "fuse_concat_gn")) g_opt.fuse_concat_gn = value;
     else if (!strcmp(key, "fuse_gn_tokens")) g_opt.fuse_gn_tokens = value;
+    else if (!strcmp(key, "fuse_linear_nchw")) g_opt.fuse_linear_nchw = value;
     else if (!strcmp(key, "fuse_gelu")) g_opt.fuse_gelu = value;
     else if (!strcmp(key, "fuse_rope")) g_opt.fuse_rope = value;
     else if (!strcmp(key, "fuse_concat_heads")) g_opt.fuse_concat_heads = value;

@@ -149,6 +149,30 @@ def test_group_norm_into_token_linear(sd, oracle, gpu, rng, N, C, inner, H, W):
         assert sd.backend_stats()["fused_proj_tokens"] - before["fused_proj_tokens"] == 1
 
 
+@pytest.mark.parametrize("N,C,inner,H,W", [(2, 640, 640, 32, 32), (1, 64, 96, 5, 8), (2, 1280, 1280, 16, 16), (3, 320, 320, 8, 8)])
+def test_token_linear_into_nchw_residual(sd, oracle, gpu, rng, N, C, inner, H, W):
+    """SpatialTransformer with Linear projections, the way out (SDXL, block.hpp:566-572): proj_out Linear (+bias) on tokens -> PERMUTE(1,0,2,3) -> CONT -> RESHAPE
+    [W,H,C,N] -> ADD(., x_in).  Runs as ONE 1x1 implicit-GEMM conv over the token rows with the NCHW + bias + residual epilogue: no transposing copy, no add."""
+    t = rng.standard_normal((N, H * W, inner)).astype(np.float32)
+    xin = rng.standard_normal((N, C, H, W)).astype(np.float32)
+    wl = (rng.standard_normal((C, inner)) / np.sqrt(inner)).astype(np.float32)
+    bl = rng.standard_normal(C).astype(np.float32)
+
+    def build(g, L):
+        y = L.ggml_mul_mat(g.ctx, g.weight(wl, F16), g.input(t))
+        y = L.ggml_add_inplace(g.ctx, y, g.weight(bl, F32))
+        y = L.ggml_cont(g.ctx, L.ggml_permute(g.ctx, y, 1, 0, 2, 3))
+        y = L.ggml_reshape_4d(g.ctx, y, W, H, C, N)
+        return L.ggml_add(g.ctx, y, g.input(xin))
+
+    before = sd.backend_stats() if _on_gpu() else None
+    ref, out = run_both(sd, oracle, gpu, build)
+    assert out.shape == (N, C, H, W) and np.isfinite(out).all()
+    assert rel_l2(out, ref) < 3e-4
+    if before is not None and not os.environ.get("SDCPP_BACKEND_OPTS"):
+        assert sd.backend_stats()["fused_proj_tokens"] - before["fused_proj_tokens"] == 1
+
+
 @pytest.mark.parametrize("N,Ca,Cb,HW,mean", [(2, 64, 32, 16, 1.5), (2, 320, 320, 64, -0.5), (1, 640, 320, 32, 0.2), (3, 128, 64, 8, 0.0)])
 def test_skip_concat_group_norm_two_sources(sd, oracle, gpu, rng, N, Ca, Cb, HW, mean):
     """UNet skip connection (unet.hpp:702 + block.hpp:126-179): h = CONCAT(h, skip; channels); ResBlock(h) = conv3x3(SiLU(GN(h) w + b)) ... + conv1x1(h).  The
