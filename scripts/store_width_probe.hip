@@ -119,23 +119,10 @@ int main() {
         const size_t bytes = (size_t)rows * ld * 2;
         for (int cols : {64, 128}) {
             const int nblk = cols / 32;
-            // one workgroup per (row tile, column tile): emulate by launching row tiles x column tiles with out offset folded into blockIdx
-            auto run = [&](int which) {
-                const int ctiles = ld / cols;
-                float ms = time_ms([&] {
-                    for (int ct = 0; ct < 1; ++ct) {
-                        if (which == 0) k_store_mfma16<<<rows / 256 * ctiles, 512>>>((_Float16*)buf, ld / ctiles * ctiles == ld ? cols : ld, nblk, 1.f);
-                    }
-                });
-                return ms;
-            };
-            (void)run;
             // simpler and closer to the kernel: the output is a [rows * ctiles][cols] matrix with ld = cols (contiguous tiles) for variant A, and the real strided layout for variant B
             for (int strided = 0; strided < 2; ++strided) {
                 const int ctiles = ld / cols;
                 const int l      = strided ? ld : cols;
-                auto off = [&](int) { return 0; };
-                (void)off;
                 float t0 = time_ms([&] {
                     if (!strided) k_store_mfma16<<<rows / 256 * ctiles, 512>>>((_Float16*)buf, l, nblk, 1.f);
                     else for (int ct = 0; ct < ctiles; ++ct) k_store_mfma16<<<rows / 256, 512>>>((_Float16*)buf + ct * cols, l, nblk, 1.f);

@@ -1456,7 +1456,7 @@ static int g_flash_vpf = 31;  // option "flash_vpf": head-dim classes (1: d <= 4
 void flash_attn_set_vpf(int v) { g_flash_vpf = v; }
 static int g_flash_vtr = 31;  // option "flash_vtr": head-dim classes (bits as flash_vpf) whose prefetching kernel keeps V row-major in LDS and reads it with ds_read_b64_tr_b16 (0 = the transposed tile of rounds 1-3)
 void flash_attn_set_vtr(int v) { g_flash_vtr = v; }
-static int g_flash_ovl = 1;  // option "flash_ovl": 1 = the two-block d = 40 kernel with one block's softmax issued inside the other block's MFMAs; 2 = also the other d <= 48 launches (that variant has not run on a GPU yet); 0 = phase-by-phase order
+static int g_flash_ovl = 1;  // option "flash_ovl": 1 = the two-block d = 40 kernel with one block's softmax issued inside the other block's MFMAs; 2 = also the other d <= 48 launches (shapes no supported model has; checked by scripts/flash_check.py ovl2 only); 0 = phase-by-phase order
 void flash_attn_set_ovl(int v) { g_flash_ovl = v; }
 static int g_flash_nsel = 1;  // option "flash_nsel": 1 = select-free staging in the d = 40 two-block, d = 64 and d = 128 kernels (round 4: bit-identical, d = 128 346 -> 326 us, SD1.5 step -0.6 %; profiles/r05a_*)
 void flash_attn_set_nsel(int v) { g_flash_nsel = v; }

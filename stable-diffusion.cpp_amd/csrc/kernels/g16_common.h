@@ -315,13 +315,15 @@ __device__ __forceinline__ void epi_dispatch_linear(const float16_t (&acc)[RB][C
     }
 }
 
-// ---- SWP (option "gemm16_swp", EXPERIMENT written at the end of round 3 with no GPU time left; default off, has not run on a GPU yet) ----
+// ---- SWP (option "gemm16_swp"; default off.  Round 4 ran it: correct — 98 Linear / GEGLU / model tests with it forced on — and 1.4 % SLOWER per SD1.5 step,
+// 23.24 -> 23.56 ms, profiles/r05a_ab_gemm16_swp_rejected.txt: an access instruction that touches 32 rows x 32 bytes costs more than four that touch 2 rows x 128
+// bytes, and narrow stores are not what bounds these epilogues, profiles/r05b_store_width_probe.txt) ----
 // The Linear kernels of the big-token tiles instantiated with the MFMA operands swapped (as the conv path does): a 32x32 accumulator block then
 // holds D^T — lane = ROW (lane & 31) of the block, register r = COLUMN (r&3) + 8*(r>>2) + 4*hi — so a lane owns four CONSECUTIVE output features
 // of one token per register quad: bias, residual and result move as 16-byte (f32) / 8-byte (f16) accesses, one per four elements, and a ragged
 // last row tile is a per-lane predicate.  The D[row][col] layout needs one 4-byte (2-byte) access per element: at K = 320 the 160-element epilogue
 // of a wave issues more instructions than its 100-MFMA main loop.  What it costs: an access instruction touches 32 rows x 32
-// bytes instead of 2 rows x 128 bytes — whether the L2 merges the four quads of a 128-byte line is what the first GPU run has to show.
+// bytes instead of 2 rows x 128 bytes — and that is what the GPU run charged for (above).
 // Serves: f32 (+bias, +residual), f16 rows (+GELU), GEGLU.  Everything else stays on the D[row][col] kernels (host-side choice, g16_swp_ok).
 enum { SWP_F32 = 0, SWP_F16 = 1, SWP_GEGLU = 2 };
 template <int MODE, int RB, int CB>

@@ -4,6 +4,8 @@
   * wave_sum_transpose: the halving cross-lane reduction of the few-row kernels and which lane ends up owning which value.
   * k_wswz_q: the just-in-time f16 weight image built from raw q8_0 / q4_0 blocks (which bytes a lane turns into which fragment);
   * k_joint_heads: the DiT attention-operand pass (group / lane indexing, butterfly RMSNorm, rotary pairs, head-major destination).
+  * round 4: epi_geglu16's value / gate pairing by v_permlane16_swap on the 16-column-interleaved FF1 weight image; gn_ld4's float4 indexing of a never-built
+    channel concatenation; the unit ranges, part owners and slab slots of the stream-K kernel.
 They pin the index arithmetic the GPU parity tests (tests/test_gpu_ops.py::test_quantised_mfma_gemm_raw_blocks, test_few_row_linear_weight_stream)
 then confirm on hardware."""
 import numpy as np
@@ -376,3 +378,140 @@ def test_flash_short_register_resident_kv_indexing(d, Lq, Lk):
     ref = (p / p.sum(1, keepdims=True)) @ v.astype(np.float64)
     assert np.isfinite(out).all()
     assert np.abs(out - ref).max() < 3e-3 * max(1.0, np.abs(ref).max())
+
+
+# ---- round 4 ------------------------------------------------------------------------------------------------------------------------
+def permlane16_swap(vdst: np.ndarray, src: np.ndarray):
+    """v_permlane16_swap_b32 on 64-lane registers: lanes 16..31 of vdst <-> lanes 0..15 of src, lanes 48..63 of vdst <-> lanes 32..47 of src"""
+    d, s = vdst.copy(), src.copy()
+    for base in (0, 32):
+        d[base + 16:base + 32], s[base:base + 16] = src[base:base + 16].copy(), vdst[base + 16:base + 32].copy()
+    return d, s
+
+
+@pytest.mark.parametrize("inner,cb_per_wave", [(160, 5), (64, 2), (80, 5)])
+def test_geglu16_interleaved_image_and_lane_pairing(inner, cb_per_wave):
+    """epi_geglu16 (g16_common.h) + k_wswz_linear(geglu_inner < 0) (wgemm.hip): the FF1 weight image interleaves value and gate at 16 columns, a 32x32
+    accumulator block then holds value(o) in lane l and gate(o) in lane l ^ 16 of the same register, and ONE permlane16_swap per register pair (j, j + 8)
+    brings them together: every (row, output) of the block must be finished exactly once, by the lane the store address is computed for, from
+    the matching value / gate pair."""
+    rng = np.random.default_rng(inner)
+    R = 2 * inner
+    nblk = (R + 31) // 32
+    # image column (= weight row of the image) -> source row: block b, lane-row w: out = 16 b + (w & 15); source = out (w < 16) or inner + out; beyond inner: zero row
+    src_row = np.full(nblk * 32, -1)
+    for rb in range(nblk):
+        for w in range(32):
+            out = rb * 16 + (w & 15)
+            if out < inner:
+                src_row[rb * 32 + w] = (inner if (w & 16) else 0) + out
+    assert sorted(r for r in src_row if r >= 0) == list(range(R))           # every value and gate row appears exactly once
+    # a "GEMM" whose output column c is the image column c: y[row][c] = f(row, src_row[c]) — use distinct numbers per (row, source row)
+    rows = 32
+    full = rng.standard_normal((rows, R)).astype(np.float32)               # full[row][source row]: value columns [0, inner), gate columns [inner, 2 inner)
+    done = np.zeros((rows, inner), dtype=int)
+    got_v = np.zeros((rows, inner), np.float32)
+    got_g = np.zeros((rows, inner), np.float32)
+    for cb in range(cb_per_wave):                                           # the column blocks of one wave (col0 = 0, wc = 0)
+        oc0 = cb * 16
+        if oc0 >= inner:
+            continue
+        # accumulator block in the D[row][col] layout: register r of lane (hi, lc) holds row (r & 3) + 8 (r >> 2) + 4 hi, column 32 cb + lc
+        acc = np.zeros((16, 64), np.float32)
+        for lane in range(64):
+            hi, lc = lane >> 5, lane & 31
+            sr = src_row[cb * 32 + lc]
+            for r in range(16):
+                row = (r & 3) + 8 * (r >> 2) + 4 * hi
+                acc[r, lane] = full[row, sr] if sr >= 0 else 0.0
+        for j in range(8):
+            v, g = permlane16_swap(acc[j + 8], acc[j])                      # sw[0], sw[1] of the kernel
+            for lane in range(64):
+                hi, l16, up = lane >> 5, lane & 15, (lane >> 4) & 1
+                r = j if up else j + 8
+                row = (r & 3) + 8 * (r >> 2) + 4 * hi
+                o = oc0 + l16
+                done[row, o] += 1
+                got_v[row, o], got_g[row, o] = v[lane], g[lane]
+    covered = min(inner, cb_per_wave * 16)
+    assert (done[:, :covered] == 1).all() and (done[:, covered:] == 0).all()
+    np.testing.assert_array_equal(got_v[:, :covered], full[:, :covered])
+    np.testing.assert_array_equal(got_g[:, :covered], full[:, inner:inner + covered])
+
+
+@pytest.mark.parametrize("C1,C2,hw,groups", [(64, 32, 16, 32), (640, 320, 64, 32), (320, 320, 256, 32), (128, 64, 4, 32)])
+def test_group_norm_two_source_float4_indexing(C1, C2, hw, groups):
+    """gn_ld4 (gemm16.hip): float4 i4 of the (image n, channels c0..) slab of the NEVER-BUILT concatenation [x (C1 channels) | x2 (C2)] — hw % 4 == 0, so the
+    four elements share their channel and their source; groups may straddle the two sources (C1 not a multiple of the group width)."""
+    rng = np.random.default_rng(C1 + hw)
+    N, C = 2, C1 + C2
+    a = rng.standard_normal((N, C1, hw)).astype(np.float32)
+    b = rng.standard_normal((N, C2, hw)).astype(np.float32)
+    cat = np.concatenate([a, b], axis=1)
+    cpg = (C + groups - 1) // groups
+
+    def gn_ld4(n, c0, i4):
+        e = i4 * 4
+        ch = c0 + e // hw
+        of = e - (ch - c0) * hw
+        src = a[n, ch] if ch < C1 else b[n, ch - C1]
+        return src[of:of + 4]
+
+    for n in range(N):
+        for gidx in range(groups):
+            c0, c1 = gidx * cpg, min(gidx * cpg + cpg, C)
+            if c0 >= c1:
+                continue
+            flat = cat[n, c0:c1].reshape(-1)
+            for i4 in rng.integers(0, flat.size // 4, 16):
+                np.testing.assert_array_equal(gn_ld4(n, c0, int(i4)), flat[4 * i4:4 * i4 + 4])
+
+
+@pytest.mark.parametrize("T,NT,G,hybrid", [(208, 64, 256, False), (204, 96, 256, False), (576, 96, 256, False), (408, 96, 256, True), (612, 64, 256, True),
+                                           (1428, 96, 256, True), (5, 7, 8, False), (19, 5, 8, True)])
+def test_stream_k_unit_ranges_parts_and_slab_slots(T, NT, G, hybrid):
+    """k_gemm16<..., SK> (gemm16.hip): the (tile, K-tile) units of the cut part are split into G equal contiguous ranges; a tile cut by a range boundary is a
+    list of parts in K order, part p computed by (logical) workgroup wf + p with wf = owner of the tile's first unit = floor(((u + 1) G - 1) / U); a workgroup
+    dumps a part with kt0 > 0 into slab slot 2 w and a part starting at kt0 == 0 into slot 2 w + 1.  Checked here: every unit is covered exactly once, the owner
+    formula agrees with the ranges, the slots a reducer reads are the slots the parts were written to and no slot is used twice; hybrid: full rounds stay
+    whole tiles, G per round, contiguous per workgroup."""
+    dp = (T // G) * G if hybrid else 0
+    Tr = T - dp
+    U = Tr * NT
+    cover = np.zeros((T, NT), dtype=int)
+    slot_of = {}      # (tile, part index) -> slot written
+    used = set()
+    for w in range(G):
+        u, end = w * U // G, (w + 1) * U // G
+        partials = 0
+        while u < end:
+            rt = u // NT
+            kt0 = u - rt * NT
+            nt = min(NT - kt0, end - u)
+            cover[dp + rt, kt0:kt0 + nt] += 1
+            if not (kt0 == 0 and nt == NT):
+                uf = rt * NT
+                wf, wl = ((uf + 1) * G - 1) // U, ((uf + NT) * G - 1) // U
+                assert wf <= w <= wl
+                slot = 2 * w + (1 if kt0 == 0 else 0)
+                assert slot not in used
+                used.add(slot)
+                slot_of[(rt, w - wf)] = slot
+                partials += 1
+            u += nt
+        assert partials <= 2
+        per = dp // G
+        for t in range(w * per, w * per + per):
+            cover[t, :] += 1
+    assert (cover == 1).all()
+    # the reducer of tile rt reads part p from slot (p == 0 ? 2 wf + 1 : 2 (wf + p))
+    for rt in range(Tr):
+        uf = rt * NT
+        if U == 0:
+            break
+        wf, wl = ((uf + 1) * G - 1) // U, ((uf + NT) * G - 1) // U
+        if wl == wf:
+            assert (rt, 0) not in slot_of     # a whole tile: no slab traffic
+            continue
+        for p in range(wl - wf + 1):
+            assert slot_of[(rt, p)] == (2 * wf + 1 if p == 0 else 2 * (wf + p))
