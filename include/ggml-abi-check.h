@@ -51,6 +51,28 @@ GGML_ABI_ASSERT(offsetof(struct ggml_cgraph, order) == 80 && offsetof(struct ggm
 GGML_ABI_ASSERT(GGML_TYPE_F32 == 0 && GGML_TYPE_F16 == 1 && GGML_TYPE_Q4_0 == 2 && GGML_TYPE_Q8_0 == 8 && GGML_TYPE_I32 == 26 && GGML_TYPE_BF16 == 30,
                 "ggml_type numbering");
 
+/* enum ggml_op / ggml_unary_op: the numbers a PREBUILT libggml-mi355x.so was compiled with (include/ggml-abi.h's recollection of upstream).  The
+ * prebuilt plug-in does not trust them at run time — ggml_backend_init() rebuilds its op tables from the host's ggml_op_name() /
+ * ggml_unary_op_name() (csrc/backend/backend.cpp: resolve_host_enums; reference call sites src/core/ggml_extend_backend.cpp:302-320, 466-509) —
+ * so a fork that inserts ops is translated, not mis-dispatched.  When this header is included after a REAL ggml.h these asserts tell the maintainer
+ * whether that translation is the identity for this checkout; define GGML_ABI_CHECK_SKIP_OP_NUMBERS to rebuild against a fork with shifted numbers
+ * (the rebuilt plug-in then uses the fork's constants directly). */
+#ifndef GGML_ABI_CHECK_SKIP_OP_NUMBERS
+GGML_ABI_ASSERT(GGML_OP_NONE == 0 && GGML_OP_DUP == 1 && GGML_OP_ADD == 2 && GGML_OP_SUB == 6 && GGML_OP_MUL == 7 && GGML_OP_DIV == 8, "ggml_op numbering: arithmetic");
+GGML_ABI_ASSERT(GGML_OP_REPEAT == 20 && GGML_OP_CONCAT == 22 && GGML_OP_NORM == 24 && GGML_OP_RMS_NORM == 25 && GGML_OP_GROUP_NORM == 27,
+                "ggml_op numbering: repeat / concat / norms");
+GGML_ABI_ASSERT(GGML_OP_MUL_MAT == 29 && GGML_OP_SCALE == 32 && GGML_OP_CPY == 34 && GGML_OP_CONT == 35 && GGML_OP_RESHAPE == 36 && GGML_OP_VIEW == 37 &&
+                    GGML_OP_PERMUTE == 38 && GGML_OP_TRANSPOSE == 39 && GGML_OP_GET_ROWS == 40,
+                "ggml_op numbering: mul_mat .. get_rows");
+GGML_ABI_ASSERT(GGML_OP_SOFT_MAX == 46 && GGML_OP_IM2COL == 52 && GGML_OP_CONV_2D == 55 && GGML_OP_UPSCALE == 62 && GGML_OP_PAD == 63 &&
+                    GGML_OP_TIMESTEP_EMBEDDING == 67 && GGML_OP_FLASH_ATTN_EXT == 73 && GGML_OP_UNARY == 85,
+                "ggml_op numbering: soft_max .. unary");
+GGML_ABI_ASSERT(GGML_UNARY_OP_NEG == 2 && GGML_UNARY_OP_TANH == 4 && GGML_UNARY_OP_RELU == 6 && GGML_UNARY_OP_SIGMOID == 7 && GGML_UNARY_OP_GELU == 8 &&
+                    GGML_UNARY_OP_GELU_QUICK == 9 && GGML_UNARY_OP_SILU == 10 && GGML_UNARY_OP_EXP == 13,
+                "ggml_unary_op numbering");
+#endif
+GGML_ABI_ASSERT(GGML_OP_COUNT < 255 && GGML_UNARY_OP_COUNT < 255, "the by-name translation tables are indexed by a byte");
+
 /* plug-in vtables: the entry points the reference calls must sit where upstream puts them (ggml-backend-impl.h, API version 2) */
 GGML_ABI_ASSERT(GGML_BACKEND_API_VERSION == 2, "backend API version");
 GGML_ABI_ASSERT(offsetof(struct ggml_backend, iface) == 8, "ggml_backend.iface");

@@ -102,6 +102,10 @@ enum ggml_op {
     GGML_OP_ADD,
     GGML_OP_ADD_ID,
     GGML_OP_ADD1,
+#ifdef GGML_ABI_TEST_SHIFTED_ENUMS /* TESTS ONLY: a host "fork" with two ops inserted mid-enum (tests/test_abi.py::test_op_enum_remap); never defined for the plug-in */
+    GGML_OP_FORK_EXTRA_A,
+    GGML_OP_FORK_EXTRA_B,
+#endif
     GGML_OP_ACC,
     GGML_OP_SUB,
     GGML_OP_MUL,
@@ -200,6 +204,9 @@ enum ggml_unary_op {
     GGML_UNARY_OP_SGN,
     GGML_UNARY_OP_NEG,
     GGML_UNARY_OP_STEP,
+#ifdef GGML_ABI_TEST_SHIFTED_ENUMS
+    GGML_UNARY_OP_FORK_EXTRA,
+#endif
     GGML_UNARY_OP_TANH,
     GGML_UNARY_OP_ELU,
     GGML_UNARY_OP_RELU,

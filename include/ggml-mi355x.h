@@ -94,6 +94,16 @@ struct ggml_backend_mi355x_stats {
     int64_t fused_concat_gn;     /* skip-connection CONCATs never materialised: GroupNorm statistics / apply (and the skip conv's operand cast) read the two sources (plan_concat_gn) */
 };
 GGML_MI355X_API void ggml_backend_mi355x_get_stats(struct ggml_backend_mi355x_stats* out);
+/* Host enum numbering, resolved BY NAME.  The numeric values of `enum ggml_op` / `enum ggml_unary_op` in ggml-abi.h are a recollection of upstream, and
+ * the reference links a fork that adds ops (src/core/ggml_extend.hpp:1059,1088,3492): ggml_backend_init() looks up the host's ggml_op_name /
+ * ggml_unary_op_name / ggml_type_name (dlsym over the loaded objects) and rebuilds the planner's op tables from the names; type numbers (part of the
+ * GGUF file format) are verified.  A host that lacks a needed name, names two numbers alike, or numbers a type differently gets ZERO devices and the
+ * reason on stderr and in ggml_backend_mi355x_enum_status().  A host that hides those functions can call ggml_backend_mi355x_resolve_enums() itself
+ * BEFORE ggml_backend_init(); returns 0, or -1 with the tables unchanged.  get_enum_maps: host number -> ggml-abi.h number (GGML_OP_COUNT /
+ * GGML_UNARY_OP_COUNT = unknown to this backend), 256 entries each. */
+GGML_MI355X_API int ggml_backend_mi355x_resolve_enums(const char* (*op_name)(int), const char* (*unary_op_name)(int), const char* (*type_name)(int));
+GGML_MI355X_API const char* ggml_backend_mi355x_enum_status(void);
+GGML_MI355X_API void ggml_backend_mi355x_get_enum_maps(uint8_t* ops256, uint8_t* unary256);
 /* live per-kernel-family timing (bench.py's roofline legs): while a family's bit is enabled, every dispatch of that family is bracketed by
  * HIP events recorded on the launch stream.  get_* synchronise the device, return the totals since enable / the last get_, and reset.
  * Family indices (bit positions of `family_mask`): 0 conv 256-row tiles, 1 conv 128-row tiles, 2 Linear GEMM, 3 flash attention,

@@ -18,7 +18,7 @@ import numpy as np
 PKG_DIR = Path(__file__).resolve().parent
 ROOT = PKG_DIR.parent
 LIB_DIR = PKG_DIR / "lib"
-HOST_LIB = LIB_DIR / "libsdcpp-host.so"
+HOST_LIB = Path(os.environ.get("SDCPP_HOST_LIB", str(LIB_DIR / "libsdcpp-host.so")))  # override: tests/test_abi.py runs the "forked enum" host build
 BACKEND_LIB = Path(os.environ.get("SDCPP_BACKEND_LIB", str(LIB_DIR / "libggml-mi355x.so")))  # override: experiment builds (build.py SDCPP_BUILD_VARIANT)
 
 # ggml_type numeric values (include/ggml-abi.h)

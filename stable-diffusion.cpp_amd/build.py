@@ -64,9 +64,9 @@ def _deps_hash(src: Path, flags: list[str], extra_dirs: list[Path]) -> str:
     return h.hexdigest()
 
 
-def _compile(compiler: str, src: Path, flags: list[str], hdr_dirs: list[Path]) -> Path:
+def _compile(compiler: str, src: Path, flags: list[str], hdr_dirs: list[Path], tag: str = "") -> Path:
     OBJ.mkdir(exist_ok=True)
-    obj = OBJ / (src.parent.name + "_" + src.name + ".o")
+    obj = OBJ / (tag + src.parent.name + "_" + src.name + ".o")
     stamp = obj.with_suffix(".o.sha1")
     digest = _deps_hash(src, [compiler] + flags, hdr_dirs)
     if obj.exists() and stamp.exists() and stamp.read_text() == digest:
@@ -92,6 +92,19 @@ def build_host(pool) -> Path:
     hdrs = [CSRC / "ggml", CSRC / "host", INCLUDE]
     objs = list(pool.map(lambda s: _compile(CXX, s, HOST_FLAGS, hdrs), srcs))
     out = LIB / "libsdcpp-host.so"
+    _link(CXX, objs, out, ["-ldl", "-pthread"])
+    return out
+
+
+def build_host_opshift(pool) -> Path:
+    """TEST FIXTURE (tests/test_abi.py::test_op_enum_remap, tests/test_gpu_abi_remap.py): the same host built as a ggml "fork" whose op / unary-op
+    enums have extra entries inserted mid-table (-DGGML_ABI_TEST_SHIFTED_ENUMS, include/ggml-abi.h).  The plug-in is NOT rebuilt: it has to find the
+    shifted numbering through the host's ggml_op_name() at ggml_backend_init()."""
+    srcs = sorted((CSRC / "ggml").glob("*.cpp")) + sorted((CSRC / "host").glob("*.cpp"))
+    hdrs = [CSRC / "ggml", CSRC / "host", INCLUDE]
+    flags = HOST_FLAGS + ["-DGGML_ABI_TEST_SHIFTED_ENUMS"]
+    objs = list(pool.map(lambda s: _compile(CXX, s, flags, hdrs, tag="opshift_"), srcs))
+    out = LIB / "libsdcpp-host-opshift.so"
     _link(CXX, objs, out, ["-ldl", "-pthread"])
     return out
 
@@ -123,6 +136,7 @@ def build_all(verbose: bool = True) -> dict[str, Path]:
             "host": pool.submit(build_host, pool),
             "backend": pool.submit(build_backend, pool),
             "oracle": pool.submit(build_oracle, pool),
+            "host_opshift": pool.submit(build_host_opshift, pool),
         }
         out = {k: f.result() for k, f in futs.items()}
     if verbose:

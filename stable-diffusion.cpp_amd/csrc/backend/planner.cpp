@@ -38,6 +38,108 @@
 
 namespace mi355x {
 
+// ---------------------------------------------------------------------------------------------------
+// op-number translation (VERDICT r4 task 4).  The numeric values of `enum ggml_op` / `enum ggml_unary_op` in include/ggml-abi.h are a
+// RECOLLECTION of upstream ggml; the reference builds against a fork that adds ops (src/core/ggml_extend.hpp:1059,1088,3492) and a fork
+// may insert them mid-enum.  Every read of a host tensor's op in this file goes through xop() / xunary(): host number -> the number
+// this file was written against.  The tables start as the identity and are rebuilt BY NAME at ggml_backend_init() when the host process
+// exports ggml_op_name / ggml_unary_op_name (every libggml-base does): planner_build_op_maps().  A host op this backend does not know
+// maps to GGML_OP_COUNT (never supported, never matched by a pattern).
+// ---------------------------------------------------------------------------------------------------
+static uint8_t g_opmap[256];
+static uint8_t g_unmap[256];
+static bool g_opmap_init = [] {
+    for (int i = 0; i < 256; ++i) {
+        g_opmap[i] = (uint8_t)(i < GGML_OP_COUNT ? i : GGML_OP_COUNT);
+        g_unmap[i] = (uint8_t)(i < GGML_UNARY_OP_COUNT ? i : GGML_UNARY_OP_COUNT);
+    }
+    return true;
+}();
+static inline enum ggml_op xop(const ggml_tensor* t) { return (enum ggml_op)g_opmap[(unsigned)t->op & 255u]; }
+static inline enum ggml_unary_op xunary(const ggml_tensor* t) { return (enum ggml_unary_op)g_unmap[(unsigned)t->op_params[0] & 255u]; }
+
+namespace {
+// the names upstream ggml gives the ops / unary ops the planner dispatches on (GGML_OP_NAME / GGML_UNARY_OP_NAME tables)
+struct NameNum {
+    const char* name;
+    int num;
+};
+const NameNum kNeededOps[] = {
+    {"NONE", GGML_OP_NONE}, {"DUP", GGML_OP_DUP}, {"ADD", GGML_OP_ADD}, {"SUB", GGML_OP_SUB}, {"MUL", GGML_OP_MUL}, {"DIV", GGML_OP_DIV},
+    {"REPEAT", GGML_OP_REPEAT}, {"CONCAT", GGML_OP_CONCAT}, {"NORM", GGML_OP_NORM}, {"RMS_NORM", GGML_OP_RMS_NORM}, {"GROUP_NORM", GGML_OP_GROUP_NORM},
+    {"MUL_MAT", GGML_OP_MUL_MAT}, {"SCALE", GGML_OP_SCALE}, {"CPY", GGML_OP_CPY}, {"CONT", GGML_OP_CONT}, {"RESHAPE", GGML_OP_RESHAPE},
+    {"VIEW", GGML_OP_VIEW}, {"PERMUTE", GGML_OP_PERMUTE}, {"TRANSPOSE", GGML_OP_TRANSPOSE}, {"GET_ROWS", GGML_OP_GET_ROWS},
+    {"SOFT_MAX", GGML_OP_SOFT_MAX}, {"IM2COL", GGML_OP_IM2COL}, {"CONV_2D", GGML_OP_CONV_2D}, {"UPSCALE", GGML_OP_UPSCALE}, {"PAD", GGML_OP_PAD},
+    {"TIMESTEP_EMBEDDING", GGML_OP_TIMESTEP_EMBEDDING}, {"FLASH_ATTN_EXT", GGML_OP_FLASH_ATTN_EXT}, {"UNARY", GGML_OP_UNARY},
+};
+const NameNum kNeededUnary[] = {
+    {"NEG", GGML_UNARY_OP_NEG}, {"TANH", GGML_UNARY_OP_TANH}, {"RELU", GGML_UNARY_OP_RELU}, {"SIGMOID", GGML_UNARY_OP_SIGMOID},
+    {"GELU", GGML_UNARY_OP_GELU}, {"GELU_QUICK", GGML_UNARY_OP_GELU_QUICK}, {"SILU", GGML_UNARY_OP_SILU}, {"EXP", GGML_UNARY_OP_EXP},
+};
+const NameNum kNeededTypes[] = {
+    {"f32", GGML_TYPE_F32}, {"f16", GGML_TYPE_F16}, {"q4_0", GGML_TYPE_Q4_0}, {"q8_0", GGML_TYPE_Q8_0}, {"i32", GGML_TYPE_I32}, {"bf16", GGML_TYPE_BF16},
+};
+
+// scans host numbers 0 .. until every needed name has been seen (never past the largest needed op: the host's name table is not indexed beyond what
+// any compatible ggml defines); cap = hard stop for a host that lacks a needed name
+bool build_map(const char* (*name_of)(int), const NameNum* need, int n_need, int cap, int unknown, uint8_t* table, char* err, size_t err_len, const char* what) {
+    uint8_t out[256];
+    for (int i = 0; i < 256; ++i) out[i] = (uint8_t)unknown;
+    std::vector<int> found(n_need, -1);
+    int left = n_need;
+    for (int h = 0; h < cap && left > 0; ++h) {
+        const char* nm = name_of(h);
+        if (!nm) break;
+        for (int k = 0; k < n_need; ++k)
+            if (!strcmp(nm, need[k].name)) {
+                if (found[k] >= 0) {
+                    snprintf(err, err_len, "host %s numbers %d and %d are both named '%s'", what, found[k], h, nm);
+                    return false;
+                }
+                found[k] = h;
+                out[h]   = (uint8_t)need[k].num;
+                --left;
+            }
+    }
+    for (int k = 0; k < n_need; ++k)
+        if (found[k] < 0) {
+            snprintf(err, err_len, "host has no %s named '%s' among its first %d", what, need[k].name, cap);
+            return false;
+        }
+    memcpy(table, out, 256);
+    return true;
+}
+}  // namespace
+
+bool planner_build_op_maps(const char* (*op_name)(int), const char* (*unary_name)(int), const char* (*type_name)(int), char* err, size_t err_len) {
+    uint8_t ops[256], un[256];
+    if (err && err_len) err[0] = 0;
+    char local[256];
+    if (!err) {
+        err     = local;
+        err_len = sizeof(local);
+    }
+    if (op_name && !build_map(op_name, kNeededOps, (int)(sizeof(kNeededOps) / sizeof(kNeededOps[0])), 200, GGML_OP_COUNT, ops, err, err_len, "op")) return false;
+    if (unary_name && !build_map(unary_name, kNeededUnary, (int)(sizeof(kNeededUnary) / sizeof(kNeededUnary[0])), 64, GGML_UNARY_OP_COUNT, un, err, err_len, "unary op")) return false;
+    if (type_name) {
+        // type numbers are part of the GGUF file format and cannot drift without breaking every model file: verified, not remapped
+        for (const NameNum& t : kNeededTypes) {
+            const char* nm = type_name(t.num);
+            if (!nm || strcmp(nm, t.name)) {
+                snprintf(err, err_len, "host ggml_type %d is named '%s', this backend was written against '%s'", t.num, nm ? nm : "(null)", t.name);
+                return false;
+            }
+        }
+    }
+    if (op_name) memcpy(g_opmap, ops, 256);
+    if (unary_name) memcpy(g_unmap, un, 256);
+    return true;
+}
+void planner_get_op_maps(uint8_t* ops256, uint8_t* unary256) {
+    if (ops256) memcpy(ops256, g_opmap, 256);
+    if (unary256) memcpy(unary256, g_unmap, 256);
+}
+
 namespace {
 
 struct Stats {
@@ -230,7 +332,7 @@ struct GInfo {
     // true when every node strictly between a and b is a view op or already claimed by the current chain
     bool only_noops_between(int a, int b, const std::vector<int>& chain) const {
         for (int k = a + 1; k < b; ++k) {
-            if (ggml_abi_op_is_noop(node(k)->op)) continue;
+            if (ggml_abi_op_is_noop(xop(node(k)))) continue;
             bool in_chain = false;
             for (int c : chain) in_chain = in_chain || (c == k);
             if (!in_chain) return false;
@@ -374,7 +476,7 @@ struct Builder {
     bool clobbered_between(int a, int b, const void* p, size_t n, const std::vector<int>& chain) const {
         for (int k = a + 1; k <= b; ++k) {
             const ggml_tensor* t = gi.node(k);
-            if (ggml_abi_op_is_noop(t->op)) continue;
+            if (ggml_abi_op_is_noop(xop(t))) continue;
             bool in_chain = false;
             for (int c : chain) in_chain = in_chain || (c == k);
             if (in_chain) continue;
@@ -430,7 +532,7 @@ struct Builder {
 
 inline int64_t rup64(int64_t a) { return (a + 63) / 64 * 64; }
 inline const ggml_tensor* strip_reshape(const ggml_tensor* t) {
-    while (t && t->op == GGML_OP_RESHAPE && t->src[0]) t = t->src[0];
+    while (t && xop(t) == GGML_OP_RESHAPE && t->src[0]) t = t->src[0];
     return t;
 }
 
@@ -487,7 +589,7 @@ bool bias_like_row(const ggml_tensor* b, int64_t M) {  // [M] f32
 // is node i an IM2COL that plan_conv_chain will turn into an MFMA implicit-GEMM conv?
 bool conv_im2col_fast_ok(const GInfo& gi, int i) {
     const ggml_tensor* im = gi.node(i);
-    if (im->op != GGML_OP_IM2COL || !g_opt.mfma_gemm || !g_opt.fusion) return false;
+    if (xop(im) != GGML_OP_IM2COL || !g_opt.mfma_gemm || !g_opt.fusion) return false;
     const ggml_tensor* ker = im->src[0];
     const ggml_tensor* x   = im->src[1];
     const int32_t* p       = im->op_params;
@@ -498,15 +600,15 @@ bool conv_im2col_fast_ok(const GInfo& gi, int i) {
     if (KW != KH || p[0] != p[1] || p[2] != p[3]) return false;
     if (!((KW == 3 && p[2] == 1 && (p[0] == 1 || p[0] == 2)) || (KW == 1 && p[2] == 0 && p[0] == 1))) return false;
     int j1 = gi.sole(i);
-    if (j1 < 0 || gi.node(j1)->op != GGML_OP_RESHAPE) return false;
+    if (j1 < 0 || xop(gi.node(j1)) != GGML_OP_RESHAPE) return false;
     int j2 = gi.sole(j1);
-    if (j2 < 0 || gi.node(j2)->op != GGML_OP_MUL_MAT || gi.node(j2)->src[0] != gi.node(j1)) return false;
+    if (j2 < 0 || xop(gi.node(j2)) != GGML_OP_MUL_MAT || gi.node(j2)->src[0] != gi.node(j1)) return false;
     int j3 = gi.sole(j2);
-    if (j3 < 0 || gi.node(j3)->op != GGML_OP_RESHAPE) return false;
+    if (j3 < 0 || xop(gi.node(j3)) != GGML_OP_RESHAPE) return false;
     int j4 = gi.sole(j3);
-    if (j4 < 0 || gi.node(j4)->op != GGML_OP_PERMUTE) return false;
+    if (j4 < 0 || xop(gi.node(j4)) != GGML_OP_PERMUTE) return false;
     int j5 = gi.sole(j4);
-    return j5 >= 0 && gi.node(j5)->op == GGML_OP_CONT;
+    return j5 >= 0 && xop(gi.node(j5)) == GGML_OP_CONT;
 }
 bool linear_fast_ok(const ggml_tensor* n);
 // every consumer of node i (looking through RESHAPE views) is a gen-2 GEMM that reads the f16 image
@@ -522,15 +624,15 @@ bool all_consumers_gemm16(const GInfo& gi, int i, bool want_conv) {
         if (gi.consumers[k].empty() && k != i) return false;
         for (int c : gi.consumers[k]) {
             const ggml_tensor* cn = gi.node(c);
-            if (cn->op == GGML_OP_RESHAPE) {
+            if (xop(cn) == GGML_OP_RESHAPE) {
                 if ((cn->flags & GGML_TENSOR_FLAG_OUTPUT)) return false;
                 work.push_back(c);
                 continue;
             }
             if (want_conv) {
-                if (!(cn->op == GGML_OP_IM2COL && cn->src[1] == gi.node(k) && conv_im2col_fast_ok(gi, c))) return false;
+                if (!(xop(cn) == GGML_OP_IM2COL && cn->src[1] == gi.node(k) && conv_im2col_fast_ok(gi, c))) return false;
             } else {
-                if (!(cn->op == GGML_OP_MUL_MAT && strip_reshape(cn->src[1]) == t && linear_fast_ok(cn))) return false;
+                if (!(xop(cn) == GGML_OP_MUL_MAT && strip_reshape(cn->src[1]) == t && linear_fast_ok(cn))) return false;
             }
             ++n_real;
         }
@@ -560,9 +662,9 @@ bool linear_fast_ok(const ggml_tensor* n) {
 // (SpatialTransformer proj_out, block.hpp:566-572) and nothing else.  On success *rs_out = the last RESHAPE (the conv's input tensor).
 static bool tokens_to_conv_match(const GInfo& gi, int i, int* rs_out) {
     const ggml_tensor* n = gi.node(i);
-    if (!g_opt.fuse_proj_tokens || !g_opt.gemm16 || !g_opt.fusion || n->op != GGML_OP_CONT || !is_f32(n) || !contig(n) || (n->flags & GGML_TENSOR_FLAG_OUTPUT)) return false;
+    if (!g_opt.fuse_proj_tokens || !g_opt.gemm16 || !g_opt.fusion || xop(n) != GGML_OP_CONT || !is_f32(n) || !contig(n) || (n->flags & GGML_TENSOR_FLAG_OUTPUT)) return false;
     const ggml_tensor* pm = n->src[0];
-    if (!pm || pm->op != GGML_OP_PERMUTE) return false;
+    if (!pm || xop(pm) != GGML_OP_PERMUTE) return false;
     const int32_t* pa = pm->op_params;
     if (!(pa[0] == 1 && pa[1] == 0 && pa[2] == 2 && pa[3] == 3)) return false;
     const ggml_tensor* t = pm->src[0];  // [C, HW, N(, 1)] token-major
@@ -570,11 +672,11 @@ static bool tokens_to_conv_match(const GInfo& gi, int i, int* rs_out) {
     const int64_t C = t->ne[0], HW = t->ne[1], N = t->ne[2];
     int j = gi.sole(i);
     int rs = -1;
-    while (j >= 0 && gi.node(j)->op == GGML_OP_RESHAPE) {
+    while (j >= 0 && xop(gi.node(j)) == GGML_OP_RESHAPE) {
         rs = j;
         j  = gi.sole(j);
     }
-    if (rs < 0 || j < 0 || gi.node(j)->op != GGML_OP_IM2COL || gi.node(j)->src[1] != gi.node(rs) || !conv_im2col_fast_ok(gi, j)) return false;
+    if (rs < 0 || j < 0 || xop(gi.node(j)) != GGML_OP_IM2COL || gi.node(j)->src[1] != gi.node(rs) || !conv_im2col_fast_ok(gi, j)) return false;
     const ggml_tensor* xr  = gi.node(rs);
     const ggml_tensor* ker = gi.node(j)->src[0];
     if (ker->ne[0] != 1 || ker->ne[1] != 1 || ker->ne[2] != C || xr->ne[2] != C || xr->ne[3] != N || xr->ne[0] * xr->ne[1] != HW) return false;
@@ -588,7 +690,7 @@ static bool only_consumer_is_tokens_to_conv(const GInfo& gi, int last) {
     const ggml_tensor* t = gi.node(last);
     if ((t->flags & GGML_TENSOR_FLAG_OUTPUT) || gi.consumers[last].size() != 1) return false;
     const int jp = gi.consumers[last][0];
-    if (gi.node(jp)->op != GGML_OP_PERMUTE || gi.node(jp)->src[0] != t || (gi.node(jp)->flags & GGML_TENSOR_FLAG_OUTPUT) || gi.consumers[jp].size() != 1) return false;
+    if (xop(gi.node(jp)) != GGML_OP_PERMUTE || gi.node(jp)->src[0] != t || (gi.node(jp)->flags & GGML_TENSOR_FLAG_OUTPUT) || gi.consumers[jp].size() != 1) return false;
     int rs = -1;
     return tokens_to_conv_match(gi, gi.consumers[jp][0], &rs);
 }
@@ -608,9 +710,9 @@ void plan_linear(Builder& B, int i, hipStream_t s, std::vector<int>& chain) {
     bool hm_f16 = false;
     if (g_opt.fusion && g_opt.gemm16) {
         const int j1 = gi.sole(i);
-        const int j2 = (j1 >= 0 && gi.node(j1)->op == GGML_OP_RESHAPE) ? gi.sole(j1) : -1;
-        const int j3 = (j2 >= 0 && gi.node(j2)->op == GGML_OP_PERMUTE) ? gi.sole(j2) : -1;
-        if (j3 >= 0 && gi.node(j3)->op == GGML_OP_CONT && is_f32(gi.node(j3)) && contig(gi.node(j3))) {
+        const int j2 = (j1 >= 0 && xop(gi.node(j1)) == GGML_OP_RESHAPE) ? gi.sole(j1) : -1;
+        const int j3 = (j2 >= 0 && xop(gi.node(j2)) == GGML_OP_PERMUTE) ? gi.sole(j2) : -1;
+        if (j3 >= 0 && xop(gi.node(j3)) == GGML_OP_CONT && is_f32(gi.node(j3)) && contig(gi.node(j3))) {
             const ggml_tensor* r4 = gi.node(j1);
             const int32_t* ax    = gi.node(j2)->op_params;
             const int64_t d = r4->ne[0], H = r4->ne[1], L = r4->ne[2], Nimg = r4->ne[3];
@@ -619,8 +721,8 @@ void plan_linear(Builder& B, int i, hipStream_t s, std::vector<int>& chain) {
                 std::vector<int> c2{i, j1, j2, j3};
                 int lastn = j3;
                 const int j4 = gi.sole(j3);
-                const int j5 = (j4 >= 0 && gi.node(j4)->op == GGML_OP_RESHAPE) ? gi.sole(j4) : -1;
-                if (j5 >= 0 && gi.node(j5)->op == GGML_OP_CPY && gi.node(j5)->type == GGML_TYPE_F16 && gi.node(j5)->src[0] == gi.node(j4) && contig(gi.node(j5))) {
+                const int j5 = (j4 >= 0 && xop(gi.node(j4)) == GGML_OP_RESHAPE) ? gi.sole(j4) : -1;
+                if (j5 >= 0 && xop(gi.node(j5)) == GGML_OP_CPY && gi.node(j5)->type == GGML_TYPE_F16 && gi.node(j5)->src[0] == gi.node(j4) && contig(gi.node(j5))) {
                     c2.push_back(j4);
                     c2.push_back(j5);
                     lastn  = j5;
@@ -640,18 +742,18 @@ void plan_linear(Builder& B, int i, hipStream_t s, std::vector<int>& chain) {
         // [RESHAPE] -> ADD bias
         int j = gi.sole(last);
         int via = last;
-        while (j >= 0 && gi.node(j)->op == GGML_OP_RESHAPE) {
+        while (j >= 0 && xop(gi.node(j)) == GGML_OP_RESHAPE) {
             via = j;
             j   = gi.sole(j);
         }
-        if (j >= 0 && gi.node(j)->op == GGML_OP_ADD && gi.node(j)->src[0] == gi.node(via) && bias_like_row(gi.node(j)->src[1], M) &&
+        if (j >= 0 && xop(gi.node(j)) == GGML_OP_ADD && gi.node(j)->src[0] == gi.node(via) && bias_like_row(gi.node(j)->src[1], M) &&
             gi.node(j)->data == n->data && gi.only_noops_between(i, j, chain)) {
             ep.bias = (const float*)gi.node(j)->src[1]->data;
             chain.push_back(j);
             last = j;
             // -> ADD residual (either operand order), same shape, contiguous
             int r = gi.sole(last);
-            if (r >= 0 && !gi.done[r] && gi.node(r)->op == GGML_OP_ADD && gi.only_noops_between(last, r, chain)) {
+            if (r >= 0 && !gi.done[r] && xop(gi.node(r)) == GGML_OP_ADD && gi.only_noops_between(last, r, chain)) {
                 const ggml_tensor* a = gi.node(r);
                 const ggml_tensor* other = a->src[0] == gi.node(last) ? a->src[1] : (a->src[1] == gi.node(last) ? a->src[0] : nullptr);
                 if (other && is_f32(other) && contig(other) && contig(a) && ggml_abi_same_shape(other, a) && ggml_abi_same_shape(gi.node(last), a) &&
@@ -680,20 +782,20 @@ void plan_linear(Builder& B, int i, hipStream_t s, std::vector<int>& chain) {
     if (g_opt.fusion && g_opt.gemm16 && g_opt.fuse_proj_tokens && g_opt.fuse_linear_nchw && hm_d == 0 && !ep.residual && last != i && tokens > 16 && n->ne[3] == 1 && x->ne[3] == 1) {
         const int jp = gi.sole(last);
         const ggml_tensor* pt = jp >= 0 ? gi.node(jp) : nullptr;
-        if (pt && pt->op == GGML_OP_PERMUTE && pt->src[0] == gi.node(last) && pt->op_params[0] == 1 && pt->op_params[1] == 0 && pt->op_params[2] == 2 && pt->op_params[3] == 3) {
+        if (pt && xop(pt) == GGML_OP_PERMUTE && pt->src[0] == gi.node(last) && pt->op_params[0] == 1 && pt->op_params[1] == 0 && pt->op_params[2] == 2 && pt->op_params[3] == 3) {
             const int jc = gi.sole(jp);
-            if (jc >= 0 && gi.node(jc)->op == GGML_OP_CONT && gi.node(jc)->src[0] == pt && is_f32(gi.node(jc)) && contig(gi.node(jc))) {
+            if (jc >= 0 && xop(gi.node(jc)) == GGML_OP_CONT && gi.node(jc)->src[0] == pt && is_f32(gi.node(jc)) && contig(gi.node(jc))) {
                 std::vector<int> c2 = chain;
                 c2.push_back(jp);
                 c2.push_back(jc);
                 int via = jc, j = gi.sole(jc);
-                while (j >= 0 && gi.node(j)->op == GGML_OP_RESHAPE) {
+                while (j >= 0 && xop(gi.node(j)) == GGML_OP_RESHAPE) {
                     c2.push_back(j);
                     via = j;
                     j   = gi.sole(j);
                 }
                 const ggml_tensor* a = j >= 0 ? gi.node(j) : nullptr;
-                if (a && via != jc && a->op == GGML_OP_ADD && !gi.done[j] && is_f32(a) && contig(a)) {
+                if (a && via != jc && xop(a) == GGML_OP_ADD && !gi.done[j] && is_f32(a) && contig(a)) {
                     const ggml_tensor* other = a->src[0] == gi.node(via) ? a->src[1] : (a->src[1] == gi.node(via) ? a->src[0] : nullptr);
                     const int64_t HWt = n->ne[1], Nimg = n->ne[2];
                     if (other && is_f32(other) && contig(other) && ggml_abi_same_shape(other, a) && a->ne[2] == M && a->ne[3] == Nimg && a->ne[0] * a->ne[1] == HWt && gi.idx(other) < i &&
@@ -716,11 +818,11 @@ void plan_linear(Builder& B, int i, hipStream_t s, std::vector<int>& chain) {
         gemm16_split_k(tokens, M, K, false) == 1) {  // split-K launches keep the plain epilogue (the slab reduce applies bias only)
         const int jm = gi.sole(last);
         const ggml_tensor* mt = jm >= 0 ? gi.node(jm) : nullptr;
-        if (mt && mt->op == GGML_OP_MUL && mt->src[0] == gi.node(last)) {
+        if (mt && xop(mt) == GGML_OP_MUL && mt->src[0] == gi.node(last)) {
             const ggml_tensor* gv = mt->src[1];
             const int jr          = gi.sole(jm);
             const ggml_tensor* a  = jr >= 0 ? gi.node(jr) : nullptr;
-            if (is_f32(gv) && contig(gv) && gv->ne[0] == M && gv->ne[1] == 1 && gv->ne[2] == x->ne[2] && gv->ne[3] == 1 && a && a->op == GGML_OP_ADD) {
+            if (is_f32(gv) && contig(gv) && gv->ne[0] == M && gv->ne[1] == 1 && gv->ne[2] == x->ne[2] && gv->ne[3] == 1 && a && xop(a) == GGML_OP_ADD) {
                 const ggml_tensor* other = a->src[1] == mt ? a->src[0] : (a->src[0] == mt ? a->src[1] : nullptr);
                 const size_t ob          = ggml_abi_nbytes(a);
                 std::vector<int> c2 = chain;
@@ -746,7 +848,7 @@ void plan_linear(Builder& B, int i, hipStream_t s, std::vector<int>& chain) {
     int gelu_out = -1;
     if (g_opt.fusion && g_opt.gemm16 && g_opt.fuse_gelu && hm_d == 0 && !ep.residual && !ep.gate) {
         const int ju = gi.sole(last);
-        if (ju >= 0 && gi.node(ju)->op == GGML_OP_UNARY && ggml_abi_get_unary_op(gi.node(ju)) == GGML_UNARY_OP_GELU && gi.node(ju)->src[0] == gi.node(last) &&
+        if (ju >= 0 && xop(gi.node(ju)) == GGML_OP_UNARY && xunary(gi.node(ju)) == GGML_UNARY_OP_GELU && gi.node(ju)->src[0] == gi.node(last) &&
             contig(gi.node(ju)) && M % 64 == 0 && all_consumers_gemm16(gi, ju, false)) {
             std::vector<int> c2 = chain;
             c2.push_back(ju);
@@ -767,16 +869,16 @@ void plan_linear(Builder& B, int i, hipStream_t s, std::vector<int>& chain) {
         for (int c : gi.consumers[last]) {
             const ggml_tensor* v = gi.node(c);
             const ggml_tensor* root = X->view_src ? X->view_src : X;  // the in-place bias ADD is itself a view of the MUL_MAT output
-            if (v->op != GGML_OP_VIEW || (v->view_src != X && v->view_src != root) || v->ne[0] != inner || v->nb[1] != X->nb[1] || v->nb[2] != X->nb[2] || v->nb[3] != X->nb[3] ||
+            if (xop(v) != GGML_OP_VIEW || (v->view_src != X && v->view_src != root) || v->ne[0] != inner || v->nb[1] != X->nb[1] || v->nb[2] != X->nb[2] || v->nb[3] != X->nb[3] ||
                 v->ne[1] != X->ne[1] || v->ne[2] != X->ne[2] || v->ne[3] != X->ne[3])
                 continue;
             if (v->data == X->data) vlo = c;
             if ((const char*)v->data == (const char*)X->data + inner * 4) vhi = c;
         }
         const int jc = vhi >= 0 ? gi.sole(vhi) : -1;
-        const int jg = (jc >= 0 && gi.node(jc)->op == GGML_OP_CONT && gi.node(jc)->src[0] == gi.node(vhi)) ? gi.sole(jc) : -1;
-        const int jm = (jg >= 0 && gi.node(jg)->op == GGML_OP_UNARY && ggml_abi_get_unary_op(gi.node(jg)) == GGML_UNARY_OP_GELU) ? gi.sole(jg) : -1;
-        if (vlo >= 0 && jm >= 0 && gi.node(jm)->op == GGML_OP_MUL && gi.node(jm)->src[0] == gi.node(vlo) && gi.node(jm)->src[1] == gi.node(jg) &&
+        const int jg = (jc >= 0 && xop(gi.node(jc)) == GGML_OP_CONT && gi.node(jc)->src[0] == gi.node(vhi)) ? gi.sole(jc) : -1;
+        const int jm = (jg >= 0 && xop(gi.node(jg)) == GGML_OP_UNARY && xunary(gi.node(jg)) == GGML_UNARY_OP_GELU) ? gi.sole(jg) : -1;
+        if (vlo >= 0 && jm >= 0 && xop(gi.node(jm)) == GGML_OP_MUL && gi.node(jm)->src[0] == gi.node(vlo) && gi.node(jm)->src[1] == gi.node(jg) &&
             gi.sole(vlo) == jm && !(X->flags & GGML_TENSOR_FLAG_OUTPUT) && all_consumers_gemm16(gi, jm, false)) {
             std::vector<int> c2 = chain;
             for (int c : {vlo, vhi, jc, jg, jm}) c2.push_back(c);
@@ -924,8 +1026,8 @@ void plan_linear(Builder& B, int i, hipStream_t s, std::vector<int>& chain) {
             int qflash = -1, qview = -1;
             if (!f16o && g_opt.fuse_q16 && hd % 8 == 0) {
                 const int c1 = gi.sole(last);
-                const int c2 = (c1 >= 0 && gi.node(c1)->op == GGML_OP_RESHAPE) ? gi.sole(c1) : -1;
-                if (c2 >= 0 && gi.node(c2)->op == GGML_OP_FLASH_ATTN_EXT && gi.node(c2)->src[0] == gi.node(c1) && !gi.node(c2)->src[3] && contig(gi.node(c1)) &&
+                const int c2 = (c1 >= 0 && xop(gi.node(c1)) == GGML_OP_RESHAPE) ? gi.sole(c1) : -1;
+                if (c2 >= 0 && xop(gi.node(c2)) == GGML_OP_FLASH_ATTN_EXT && gi.node(c2)->src[0] == gi.node(c1) && !gi.node(c2)->src[3] && contig(gi.node(c1)) &&
                     gi.node(c1)->ne[0] == hd && flash_attn_supported(hd, gi.node(c2)->src[2]->ne[0])) {
                     qflash = c2;
                     qview  = c1;
@@ -981,11 +1083,11 @@ void plan_linear(Builder& B, int i, hipStream_t s, std::vector<int>& chain) {
                 const ggml_tensor* res = gi.node(last);
                 for (int k : gi.consumers[last]) {
                     const ggml_tensor* nn = gi.node(k);
-                    if (nn->op != GGML_OP_NORM || nn->src[0] != res || gi.done[k] || !is_f32(nn) || !contig(nn) || !contig(res) || nn->ne[0] != M) continue;
+                    if (xop(nn) != GGML_OP_NORM || nn->src[0] != res || gi.done[k] || !is_f32(nn) || !contig(nn) || !contig(res) || nn->ne[0] != M) continue;
                     const int j1 = gi.sole(k);
-                    if (j1 < 0 || gi.node(j1)->op != GGML_OP_MUL || gi.node(j1)->src[0] != nn || !bias_like_row(gi.node(j1)->src[1], M) || gi.node(j1)->data != nn->data) break;
+                    if (j1 < 0 || xop(gi.node(j1)) != GGML_OP_MUL || gi.node(j1)->src[0] != nn || !bias_like_row(gi.node(j1)->src[1], M) || gi.node(j1)->data != nn->data) break;
                     const int j2 = gi.sole(j1);
-                    if (j2 < 0 || gi.node(j2)->op != GGML_OP_ADD || gi.node(j2)->src[0] != gi.node(j1) || !bias_like_row(gi.node(j2)->src[1], M) || gi.node(j2)->data != nn->data) break;
+                    if (j2 < 0 || xop(gi.node(j2)) != GGML_OP_ADD || gi.node(j2)->src[0] != gi.node(j1) || !bias_like_row(gi.node(j2)->src[1], M) || gi.node(j2)->data != nn->data) break;
                     std::vector<int> lc{k, j1, j2};
                     if (!gi.only_noops_between(k, j1, lc) || !gi.only_noops_between(j1, j2, lc) || !all_consumers_gemm16(gi, j2, false)) break;
                     lnw = (const float*)gi.node(j1)->src[1]->data;
@@ -1010,9 +1112,9 @@ void plan_linear(Builder& B, int i, hipStream_t s, std::vector<int>& chain) {
                 const ggml_tensor* T = gi.node(last);
                 for (int c : gi.consumers[last]) {
                     const ggml_tensor* v = gi.node(c);
-                    if (v->op != GGML_OP_VIEW || v->nb[0] != 4 || v->nb[1] != T->nb[1] || v->ne[1] * v->ne[2] * v->ne[3] != tokens) continue;
+                    if (xop(v) != GGML_OP_VIEW || v->nb[0] != 4 || v->nb[1] != T->nb[1] || v->ne[1] * v->ne[2] * v->ne[3] != tokens) continue;
                     const int jc = gi.sole(c);
-                    if (jc < 0 || gi.node(jc)->op != GGML_OP_CONT) continue;
+                    if (jc < 0 || xop(gi.node(jc)) != GGML_OP_CONT) continue;
                     const auto cp = B.cat16_part.find(gi.node(jc));
                     if (cp == B.cat16_part.end()) continue;
                     const int64_t c0 = (int64_t)((const char*)v->data - (const char*)T->data) / 4;
@@ -1060,7 +1162,7 @@ static bool read_only_after(const GInfo& gi, int k, int pos, const std::vector<i
         bool in = false;
         for (int m : members) in = in || m == c;
         if (in) continue;
-        if (ggml_abi_op_is_noop(gi.node(c)->op)) {
+        if (ggml_abi_op_is_noop(xop(gi.node(c)))) {
             if (!read_only_after(gi, c, pos, members)) return false;
         } else if (c <= pos) {
             return false;
@@ -1087,7 +1189,7 @@ void plan_sibling_group(Builder& B, int i, hipStream_t s, std::vector<int>& chai
         std::vector<int> sib;  // (x may be a graph input, which has no consumer list: scan the nodes that follow — the projections of one attention sit close together)
         for (int c = i + 1; c < gi.g->n_nodes && c < i + 64; ++c) {
             const ggml_tensor* m = gi.node(c);
-            if (!gi.done[c] && m->op == GGML_OP_MUL_MAT && m->src[1] == x && m->src[0] != w && linear_fast_ok(m) && m->src[0]->type == w->type && m->src[0]->ne[0] == w->ne[0] &&
+            if (!gi.done[c] && xop(m) == GGML_OP_MUL_MAT && m->src[1] == x && m->src[0] != w && linear_fast_ok(m) && m->src[0]->type == w->type && m->src[0]->ne[0] == w->ne[0] &&
                 m->src[0]->ne[1] == w->ne[1])
                 sib.push_back(c);
         }
@@ -1161,23 +1263,23 @@ void plan_hoisted_kv(Builder& B, hipStream_t s) {
     std::map<Key, std::vector<int>> groups;
     for (int j = 0; j < gi.g->n_nodes; ++j) {
         const ggml_tensor* n = gi.node(j);
-        if (n->op != GGML_OP_MUL_MAT || !linear_fast_ok(n)) continue;
+        if (xop(n) != GGML_OP_MUL_MAT || !linear_fast_ok(n)) continue;
         const ggml_tensor* x  = n->src[1];
         const ggml_tensor* xr = strip_reshape(x);
-        if (!(gi.idx(xr) < 0 || xr->op == GGML_OP_REPEAT)) continue;
+        if (!(gi.idx(xr) < 0 || xop(xr) == GGML_OP_REPEAT)) continue;
         const int j1 = gi.sole(j);
-        const int j2 = (j1 >= 0 && gi.node(j1)->op == GGML_OP_RESHAPE) ? gi.sole(j1) : -1;
-        const int j3 = (j2 >= 0 && gi.node(j2)->op == GGML_OP_PERMUTE) ? gi.sole(j2) : -1;
-        const int j4 = (j3 >= 0 && gi.node(j3)->op == GGML_OP_CONT) ? gi.sole(j3) : -1;
-        const int j5 = (j4 >= 0 && gi.node(j4)->op == GGML_OP_RESHAPE) ? gi.sole(j4) : -1;
-        if (j5 < 0 || gi.node(j5)->op != GGML_OP_CPY || gi.node(j5)->type != GGML_TYPE_F16) continue;
+        const int j2 = (j1 >= 0 && xop(gi.node(j1)) == GGML_OP_RESHAPE) ? gi.sole(j1) : -1;
+        const int j3 = (j2 >= 0 && xop(gi.node(j2)) == GGML_OP_PERMUTE) ? gi.sole(j2) : -1;
+        const int j4 = (j3 >= 0 && xop(gi.node(j3)) == GGML_OP_CONT) ? gi.sole(j3) : -1;
+        const int j5 = (j4 >= 0 && xop(gi.node(j4)) == GGML_OP_RESHAPE) ? gi.sole(j4) : -1;
+        if (j5 < 0 || xop(gi.node(j5)) != GGML_OP_CPY || gi.node(j5)->type != GGML_TYPE_F16) continue;
         int jf = -1, nread = 0;  // (ggml_cast's CPY node lists itself as src[1]: not a reader)
         for (int c : gi.consumers[j5])
             if (c != j5) {
                 jf = c;
                 ++nread;
             }
-        if (nread != 1 || (gi.node(j5)->flags & GGML_TENSOR_FLAG_OUTPUT) || gi.node(jf)->op != GGML_OP_FLASH_ATTN_EXT || !planner_supports_op(gi.node(jf))) continue;
+        if (nread != 1 || (gi.node(j5)->flags & GGML_TENSOR_FLAG_OUTPUT) || xop(gi.node(jf)) != GGML_OP_FLASH_ATTN_EXT || !planner_supports_op(gi.node(jf))) continue;
         const ggml_tensor* f = gi.node(jf);
         if (!((f->src[1] == gi.node(j5)) != (f->src[2] == gi.node(j5))) || f->src[0] == gi.node(j5)) continue;  // exactly one of K, V
         const ggml_tensor* r4 = gi.node(j1);
@@ -1270,11 +1372,11 @@ void plan_hoisted_emb(Builder& B, hipStream_t s) {
     std::map<Key, std::vector<EmbMember>> groups;
     for (int j = 0; j < gi.g->n_nodes; ++j) {
         const ggml_tensor* n = gi.node(j);
-        if (n->op != GGML_OP_MUL_MAT || !linear_fast_ok(n)) continue;
+        if (xop(n) != GGML_OP_MUL_MAT || !linear_fast_ok(n)) continue;
         const ggml_tensor* w = n->src[0];
         const ggml_tensor* x = n->src[1];
         const int is = gi.idx(x);
-        if (is < 0 || x->op != GGML_OP_UNARY || ggml_abi_get_unary_op(x) != GGML_UNARY_OP_SILU || gi.sole(is) != j || !contig(x) || !is_f32(x)) continue;
+        if (is < 0 || xop(x) != GGML_OP_UNARY || xunary(x) != GGML_UNARY_OP_SILU || gi.sole(is) != j || !contig(x) || !is_f32(x)) continue;
         const ggml_tensor* e = x->src[0];
         if (!e || !is_f32(e) || !contig(e) || e->ne[2] != 1 || e->ne[3] != 1 || !aligned16(e->data) || (x->flags & GGML_TENSOR_FLAG_OUTPUT)) continue;
         const int64_t K = w->ne[0], M = w->ne[1], rows = x->ne[1];
@@ -1284,15 +1386,15 @@ void plan_hoisted_emb(Builder& B, hipStream_t s) {
         if (!fg && !qg) continue;
         // -> ADD bias (in place) -> RESHAPE [1,1,M,N] -> ADD(conv output, .)
         const int ja = gi.sole(j);
-        if (ja < 0 || gi.node(ja)->op != GGML_OP_ADD || gi.node(ja)->src[0] != n || !bias_like_row(gi.node(ja)->src[1], M) || gi.node(ja)->data != n->data ||
+        if (ja < 0 || xop(gi.node(ja)) != GGML_OP_ADD || gi.node(ja)->src[0] != n || !bias_like_row(gi.node(ja)->src[1], M) || gi.node(ja)->data != n->data ||
             !is_static_weight(gi.node(ja)->src[1]) || (gi.node(ja)->flags & GGML_TENSOR_FLAG_OUTPUT))
             continue;
         int jr = gi.sole(ja);
-        if (jr < 0 || gi.node(jr)->op != GGML_OP_RESHAPE) continue;
+        if (jr < 0 || xop(gi.node(jr)) != GGML_OP_RESHAPE) continue;
         const ggml_tensor* r = gi.node(jr);
         if (!(r->ne[0] == 1 && r->ne[1] == 1 && r->ne[2] == M && r->ne[3] == rows)) continue;
         const int jc = gi.sole(jr);
-        if (jc < 0 || gi.node(jc)->op != GGML_OP_ADD || gi.node(jc)->src[1] != r) continue;
+        if (jc < 0 || xop(gi.node(jc)) != GGML_OP_ADD || gi.node(jc)->src[1] != r) continue;
         if (gi.idx(e) > j) continue;  // the embedding must exist before the group's first member
         groups[Key{e, (int)w->type, K, rows}].push_back(EmbMember{is, j, ja, M});
     }
@@ -1392,18 +1494,18 @@ bool plan_conv_chain(Builder& B, int i, hipStream_t s, std::vector<int>& chain) 
     const int64_t IC = ker->ne[2], OC = ker->ne[3], N = x->ne[3];
     // RESHAPE -> MUL_MAT -> RESHAPE -> PERMUTE -> CONT
     int j1 = gi.sole(i);
-    if (j1 < 0 || gi.node(j1)->op != GGML_OP_RESHAPE) return false;
+    if (j1 < 0 || xop(gi.node(j1)) != GGML_OP_RESHAPE) return false;
     int j2 = gi.sole(j1);
-    if (j2 < 0 || gi.node(j2)->op != GGML_OP_MUL_MAT || gi.node(j2)->src[0] != gi.node(j1)) return false;
+    if (j2 < 0 || xop(gi.node(j2)) != GGML_OP_MUL_MAT || gi.node(j2)->src[0] != gi.node(j1)) return false;
     if (root_of(gi.node(j2)->src[1]) != root_of(ker)) return false;
     int j3 = gi.sole(j2);
-    if (j3 < 0 || gi.node(j3)->op != GGML_OP_RESHAPE) return false;
+    if (j3 < 0 || xop(gi.node(j3)) != GGML_OP_RESHAPE) return false;
     int j4 = gi.sole(j3);
-    if (j4 < 0 || gi.node(j4)->op != GGML_OP_PERMUTE) return false;
+    if (j4 < 0 || xop(gi.node(j4)) != GGML_OP_PERMUTE) return false;
     const int32_t* ax = gi.node(j4)->op_params;
     if (!(ax[0] == 0 && ax[1] == 1 && ax[2] == 3 && ax[3] == 2)) return false;
     int j5 = gi.sole(j4);
-    if (j5 < 0 || gi.node(j5)->op != GGML_OP_CONT) return false;
+    if (j5 < 0 || xop(gi.node(j5)) != GGML_OP_CONT) return false;
     chain = {i, j1, j2, j3, j4, j5};
     if (!gi.only_noops_between(i, j5, chain)) return false;
     const ggml_tensor* out = gi.node(j5);  // [OW,OH,OC,N]
@@ -1413,7 +1515,7 @@ bool plan_conv_chain(Builder& B, int i, hipStream_t s, std::vector<int>& chain) 
     int last = j5;
     // -> ADD bias [1,1,OC,1]
     int j6 = gi.sole(last);
-    if (j6 >= 0 && gi.node(j6)->op == GGML_OP_ADD && gi.node(j6)->src[0] == gi.node(last) && bias_like_chan(gi.node(j6)->src[1], OC) &&
+    if (j6 >= 0 && xop(gi.node(j6)) == GGML_OP_ADD && gi.node(j6)->src[0] == gi.node(last) && bias_like_chan(gi.node(j6)->src[1], OC) &&
         gi.node(j6)->data == out->data && gi.only_noops_between(last, j6, chain)) {
         ep.bias = (const float*)gi.node(j6)->src[1]->data;
         chain.push_back(j6);
@@ -1425,8 +1527,8 @@ bool plan_conv_chain(Builder& B, int i, hipStream_t s, std::vector<int>& chain) 
     int token_major_out = -1;
     if (g_opt.fuse_proj_tokens && g_opt.gemm16 && KW == 1 && s0 == 1 && B.ups.find(x) == B.ups.end()) {
         const int jp = gi.sole(last);
-        const int jc = (jp >= 0 && gi.node(jp)->op == GGML_OP_PERMUTE && gi.node(jp)->src[0] == gi.node(last)) ? gi.sole(jp) : -1;
-        if (jc >= 0 && gi.node(jc)->op == GGML_OP_CONT && gi.node(jc)->src[0] == gi.node(jp) && is_f32(gi.node(jc)) && contig(gi.node(jc))) {
+        const int jc = (jp >= 0 && xop(gi.node(jp)) == GGML_OP_PERMUTE && gi.node(jp)->src[0] == gi.node(last)) ? gi.sole(jp) : -1;
+        if (jc >= 0 && xop(gi.node(jc)) == GGML_OP_CONT && gi.node(jc)->src[0] == gi.node(jp) && is_f32(gi.node(jc)) && contig(gi.node(jc))) {
             const int32_t* pa = gi.node(jp)->op_params;
             std::vector<int> c2 = chain;
             c2.push_back(jp);
@@ -1448,19 +1550,19 @@ bool plan_conv_chain(Builder& B, int i, hipStream_t s, std::vector<int>& chain) 
     size_t emb_off = 0;
     if (g_opt.fuse_chan_add && g_opt.gemm16 && token_major_out < 0) {
         const int r = gi.sole(last);
-        if (r >= 0 && gi.node(r)->op == GGML_OP_ADD && gi.node(r)->src[0] == gi.node(last)) {
+        if (r >= 0 && xop(gi.node(r)) == GGML_OP_ADD && gi.node(r)->src[0] == gi.node(last)) {
             const ggml_tensor* a = gi.node(r);
             const ggml_tensor* e = a->src[1];
             // only the embedding Linear's output (MUL_MAT [+ bias ADD]) qualifies: on 1x1 feature maps EVERY [1,1,OC,N] tensor has this shape —
             // e.g. the ResBlock's skip operand, which the skip conv's own chain claims as its residual (two chains claiming one ADD)
             const ggml_tensor* eroot = strip_reshape(e);
-            const bool from_linear   = eroot->op == GGML_OP_MUL_MAT || (eroot->op == GGML_OP_ADD && eroot->src[0] && strip_reshape(eroot->src[0])->op == GGML_OP_MUL_MAT);
+            const bool from_linear   = xop(eroot) == GGML_OP_MUL_MAT || (xop(eroot) == GGML_OP_ADD && eroot->src[0] && xop(strip_reshape(eroot->src[0])) == GGML_OP_MUL_MAT);
             if (!gi.done[r] && from_linear && is_f32(e) && contig(e) && contig(a) && e->ne[0] == 1 && e->ne[1] == 1 && e->ne[2] == OC && e->ne[3] == N && N > 0 &&
                 ggml_abi_same_shape(out, a) && gi.idx(eroot) < r && !(gi.node(last)->flags & GGML_TENSOR_FLAG_OUTPUT)) {
                 bool ok = true;  // nothing between the chain and the ADD may touch the ADD's output range
                 for (int k = last + 1; k < r && ok; ++k) {
                     const ggml_tensor* t = gi.node(k);
-                    if (ggml_abi_op_is_noop(t->op)) continue;
+                    if (ggml_abi_op_is_noop(xop(t))) continue;
                     for (int q = 0; q < GGML_MAX_SRC && t->src[q]; ++q)
                         for (int c : chain) ok = ok && t->src[q] != gi.node(c);
                 }
@@ -1484,7 +1586,7 @@ bool plan_conv_chain(Builder& B, int i, hipStream_t s, std::vector<int>& chain) 
     // -> ADD residual (same shape, either operand order), only when it directly follows
     if (!ep.chan_add && !emb_arena && token_major_out < 0) {  // emb_arena: a hoisted embedding add is a chan_add whose pointer is resolved at launch
         int r = gi.sole(last);
-        if (r >= 0 && !gi.done[r] && gi.node(r)->op == GGML_OP_ADD && gi.only_noops_between(last, r, chain)) {
+        if (r >= 0 && !gi.done[r] && xop(gi.node(r)) == GGML_OP_ADD && gi.only_noops_between(last, r, chain)) {
             const ggml_tensor* a     = gi.node(r);
             const ggml_tensor* other = a->src[0] == gi.node(last) ? a->src[1] : (a->src[1] == gi.node(last) ? a->src[0] : nullptr);
             if (other && is_f32(other) && contig(other) && contig(a) && ggml_abi_same_shape(other, a) && ggml_abi_same_shape(out, a) && gi.idx(other) < i &&
@@ -1505,11 +1607,11 @@ bool plan_conv_chain(Builder& B, int i, hipStream_t s, std::vector<int>& chain) 
         for (int k : gi.consumers[last]) {
             if (gnp.groups) break;
             const ggml_tensor* g = gi.node(k);
-            if (g->op != GGML_OP_GROUP_NORM || g->src[0] != res || gi.done[k]) continue;
+            if (xop(g) != GGML_OP_GROUP_NORM || g->src[0] != res || gi.done[k]) continue;
             const int j1 = gi.sole(k);
-            if (j1 < 0 || gi.node(j1)->op != GGML_OP_MUL || gi.node(j1)->src[0] != g || !bias_like_chan(gi.node(j1)->src[1], OC)) break;
+            if (j1 < 0 || xop(gi.node(j1)) != GGML_OP_MUL || gi.node(j1)->src[0] != g || !bias_like_chan(gi.node(j1)->src[1], OC)) break;
             const int j2 = gi.sole(j1);
-            if (j2 < 0 || gi.node(j2)->op != GGML_OP_ADD || gi.node(j2)->src[0] != gi.node(j1) || !bias_like_chan(gi.node(j2)->src[1], OC)) break;
+            if (j2 < 0 || xop(gi.node(j2)) != GGML_OP_ADD || gi.node(j2)->src[0] != gi.node(j1) || !bias_like_chan(gi.node(j2)->src[1], OC)) break;
             const int64_t ohw = res->ne[0] * res->ne[1];
             if (!splitk_reduce_gn_supported(ohw, OC, N, g->op_params[0])) break;
             gnp = Builder::GnPre{0, (const float*)gi.node(j1)->src[1]->data, (const float*)gi.node(j2)->src[1]->data, g->op_params[0], ggml_abi_op_param_f32(g, 1)};
@@ -1642,10 +1744,10 @@ bool plan_group_norm(Builder& B, int i, hipStream_t, std::vector<int>& chain) {
     int last = i;
     if (g_opt.fusion) {
         int j1 = gi.sole(i);
-        if (j1 >= 0 && gi.node(j1)->op == GGML_OP_MUL && gi.node(j1)->src[0] == n && bias_like_chan(gi.node(j1)->src[1], C) && gi.node(j1)->data == n->data &&
+        if (j1 >= 0 && xop(gi.node(j1)) == GGML_OP_MUL && gi.node(j1)->src[0] == n && bias_like_chan(gi.node(j1)->src[1], C) && gi.node(j1)->data == n->data &&
             gi.only_noops_between(i, j1, chain)) {
             int j2 = gi.sole(j1);
-            if (j2 >= 0 && gi.node(j2)->op == GGML_OP_ADD && gi.node(j2)->src[0] == gi.node(j1) && bias_like_chan(gi.node(j2)->src[1], C) &&
+            if (j2 >= 0 && xop(gi.node(j2)) == GGML_OP_ADD && gi.node(j2)->src[0] == gi.node(j1) && bias_like_chan(gi.node(j2)->src[1], C) &&
                 gi.node(j2)->data == n->data && gi.only_noops_between(j1, j2, chain)) {
                 w = (const float*)gi.node(j1)->src[1]->data;
                 b = (const float*)gi.node(j2)->src[1]->data;
@@ -1653,7 +1755,7 @@ bool plan_group_norm(Builder& B, int i, hipStream_t, std::vector<int>& chain) {
                 chain.push_back(j2);
                 last   = j2;
                 int j3 = gi.sole(j2);
-                if (j3 >= 0 && gi.node(j3)->op == GGML_OP_UNARY && ggml_abi_get_unary_op(gi.node(j3)) == GGML_UNARY_OP_SILU && gi.node(j3)->data == n->data &&
+                if (j3 >= 0 && xop(gi.node(j3)) == GGML_OP_UNARY && xunary(gi.node(j3)) == GGML_UNARY_OP_SILU && gi.node(j3)->data == n->data &&
                     gi.only_noops_between(j2, j3, chain)) {
                     silu = true;
                     chain.push_back(j3);
@@ -1670,10 +1772,10 @@ bool plan_group_norm(Builder& B, int i, hipStream_t, std::vector<int>& chain) {
     if (g_opt.fusion && g_opt.fuse_gn_tokens && w && !silu) {
         const int jp = gi.sole(last);
         const ggml_tensor* pt = jp >= 0 ? gi.node(jp) : nullptr;
-        if (pt && pt->op == GGML_OP_PERMUTE && pt->src[0] == gi.node(last) && pt->op_params[0] == 1 && pt->op_params[1] == 2 && pt->op_params[2] == 0 && pt->op_params[3] == 3) {
+        if (pt && xop(pt) == GGML_OP_PERMUTE && pt->src[0] == gi.node(last) && pt->op_params[0] == 1 && pt->op_params[1] == 2 && pt->op_params[2] == 0 && pt->op_params[3] == 3) {
             const int jc = gi.sole(jp);
             const ggml_tensor* ct = jc >= 0 ? gi.node(jc) : nullptr;
-            if (ct && ct->op == GGML_OP_CONT && ct->src[0] == pt && is_f32(ct) && contig(ct) && ct->ne[0] == C && !(ct->flags & GGML_TENSOR_FLAG_OUTPUT) && all_consumers_gemm16(gi, jc, false)) {
+            if (ct && xop(ct) == GGML_OP_CONT && ct->src[0] == pt && is_f32(ct) && contig(ct) && ct->ne[0] == C && !(ct->flags & GGML_TENSOR_FLAG_OUTPUT) && all_consumers_gemm16(gi, jc, false)) {
                 std::vector<int> c2 = chain;
                 c2.push_back(jp);
                 c2.push_back(jc);
@@ -1733,7 +1835,7 @@ bool plan_group_norm(Builder& B, int i, hipStream_t, std::vector<int>& chain) {
 bool plan_concat_gn(Builder& B, int i, hipStream_t, std::vector<int>& chain) {
     GInfo& gi            = B.gi;
     const ggml_tensor* n = gi.node(i);
-    if (!g_opt.fusion || !g_opt.gemm16 || !g_opt.fuse_concat_gn || n->op != GGML_OP_CONCAT || n->op_params[0] != 2 || !is_f32(n) || !contig(n) || (n->flags & GGML_TENSOR_FLAG_OUTPUT)) return false;
+    if (!g_opt.fusion || !g_opt.gemm16 || !g_opt.fuse_concat_gn || xop(n) != GGML_OP_CONCAT || n->op_params[0] != 2 || !is_f32(n) || !contig(n) || (n->flags & GGML_TENSOR_FLAG_OUTPUT)) return false;
     const ggml_tensor *a = n->src[0], *b = n->src[1];
     if (!is_f32(a) || !is_f32(b) || !contig(a) || !contig(b) || a->ne[0] != n->ne[0] || a->ne[1] != n->ne[1] || a->ne[3] != n->ne[3] || b->ne[0] != n->ne[0] || b->ne[1] != n->ne[1] ||
         b->ne[3] != n->ne[3] || a->ne[2] + b->ne[2] != n->ne[2])
@@ -1743,9 +1845,9 @@ bool plan_concat_gn(Builder& B, int i, hipStream_t, std::vector<int>& chain) {
     int jg = -1, jc = -1;
     for (int c : gi.consumers[i]) {
         const ggml_tensor* t = gi.node(c);
-        if (t->op == GGML_OP_GROUP_NORM && t->src[0] == n && jg < 0)
+        if (xop(t) == GGML_OP_GROUP_NORM && t->src[0] == n && jg < 0)
             jg = c;
-        else if (t->op == GGML_OP_IM2COL && t->src[1] == n && jc < 0 && conv_im2col_fast_ok(gi, c))
+        else if (xop(t) == GGML_OP_IM2COL && t->src[1] == n && jc < 0 && conv_im2col_fast_ok(gi, c))
             jc = c;  // a conv chain that runs on the implicit-GEMM kernels: it takes its operand from B.packed and never reads the f32 tensor
         else
             return false;
@@ -1756,13 +1858,13 @@ bool plan_concat_gn(Builder& B, int i, hipStream_t, std::vector<int>& chain) {
     const float eps       = ggml_abi_op_param_f32(gn, 1);
     if (!contig(gn) || !gn_two_source_supported((const float*)a->data, (const float*)b->data, hw, C, C1, groups)) return false;
     const int j1 = gi.sole(jg);
-    if (j1 < 0 || gi.node(j1)->op != GGML_OP_MUL || gi.node(j1)->src[0] != gn || !bias_like_chan(gi.node(j1)->src[1], C) || gi.node(j1)->data != gn->data) return false;
+    if (j1 < 0 || xop(gi.node(j1)) != GGML_OP_MUL || gi.node(j1)->src[0] != gn || !bias_like_chan(gi.node(j1)->src[1], C) || gi.node(j1)->data != gn->data) return false;
     const int j2 = gi.sole(j1);
-    if (j2 < 0 || gi.node(j2)->op != GGML_OP_ADD || gi.node(j2)->src[0] != gi.node(j1) || !bias_like_chan(gi.node(j2)->src[1], C) || gi.node(j2)->data != gn->data) return false;
+    if (j2 < 0 || xop(gi.node(j2)) != GGML_OP_ADD || gi.node(j2)->src[0] != gi.node(j1) || !bias_like_chan(gi.node(j2)->src[1], C) || gi.node(j2)->data != gn->data) return false;
     int last  = j2;
     bool silu = false;
     const int j3 = gi.sole(j2);
-    if (j3 >= 0 && gi.node(j3)->op == GGML_OP_UNARY && ggml_abi_get_unary_op(gi.node(j3)) == GGML_UNARY_OP_SILU && gi.node(j3)->data == gn->data) {
+    if (j3 >= 0 && xop(gi.node(j3)) == GGML_OP_UNARY && xunary(gi.node(j3)) == GGML_UNARY_OP_SILU && gi.node(j3)->data == gn->data) {
         silu = true;
         last = j3;
     }
@@ -1806,12 +1908,12 @@ bool plan_layer_norm(Builder& B, int i, hipStream_t, std::vector<int>& chain) {
             if (x->nb[d] % 4 != 0 || n->nb[d] % 4 != 0) return false;
         View4 xv = view_of(x), dv = view_of(n);
         const float eps4 = ggml_abi_op_param_f32(n, 0);
-        const bool rms4  = n->op == GGML_OP_RMS_NORM;
+        const bool rms4  = xop(n) == GGML_OP_RMS_NORM;
         B.emit([=](hipStream_t st) { launch_layer_norm_4d(st, (float*)dv.data, (const float*)xv.data, xv.ne, xv.nb, dv.nb, eps4, nullptr, nullptr, rms4); });
         chain.push_back(i);
         return true;
     }
-    const bool rms   = n->op == GGML_OP_RMS_NORM;
+    const bool rms   = xop(n) == GGML_OP_RMS_NORM;
     const float eps  = ggml_abi_op_param_f32(n, 0);
     const int64_t C = x->ne[0], rows = x->ne[1] * x->ne[2] * x->ne[3];
     const float *w = nullptr, *b = nullptr;
@@ -1819,13 +1921,13 @@ bool plan_layer_norm(Builder& B, int i, hipStream_t, std::vector<int>& chain) {
     int last = i;
     if (g_opt.fusion) {
         int j1 = gi.sole(i);
-        if (j1 >= 0 && gi.node(j1)->op == GGML_OP_MUL && gi.node(j1)->src[0] == n && bias_like_row(gi.node(j1)->src[1], C) && gi.node(j1)->data == n->data &&
+        if (j1 >= 0 && xop(gi.node(j1)) == GGML_OP_MUL && gi.node(j1)->src[0] == n && bias_like_row(gi.node(j1)->src[1], C) && gi.node(j1)->data == n->data &&
             gi.only_noops_between(i, j1, chain)) {
             w = (const float*)gi.node(j1)->src[1]->data;
             chain.push_back(j1);
             last   = j1;
             int j2 = gi.sole(j1);
-            if (j2 >= 0 && gi.node(j2)->op == GGML_OP_ADD && gi.node(j2)->src[0] == gi.node(j1) && bias_like_row(gi.node(j2)->src[1], C) &&
+            if (j2 >= 0 && xop(gi.node(j2)) == GGML_OP_ADD && gi.node(j2)->src[0] == gi.node(j1) && bias_like_row(gi.node(j2)->src[1], C) &&
                 gi.node(j2)->data == n->data && gi.only_noops_between(j1, j2, chain)) {
                 b = (const float*)gi.node(j2)->src[1]->data;
                 chain.push_back(j2);
@@ -1842,14 +1944,14 @@ bool plan_layer_norm(Builder& B, int i, hipStream_t, std::vector<int>& chain) {
         int jm = -1, ja = -1;
         for (int c : gi.consumers[i]) {
             const ggml_tensor* t = gi.node(c);
-            if (t->op == GGML_OP_MUL && t->src[0] == n) jm = c;
-            if (t->op == GGML_OP_ADD && t->src[0] == n) ja = c;
+            if (xop(t) == GGML_OP_MUL && t->src[0] == n) jm = c;
+            if (xop(t) == GGML_OP_ADD && t->src[0] == n) ja = c;
         }
         auto mod_vec = [&](const ggml_tensor* v) {  // [C, 1, N] contiguous f32
             return v && is_f32(v) && contig(v) && v->ne[0] == C && v->ne[1] == 1 && v->ne[2] == n->ne[2] && v->ne[3] == 1 && aligned16(v->data);
         };
         const int js = (jm >= 0 && ja >= 0 && gi.node(ja)->src[1] == gi.node(jm) && gi.sole(jm) == ja) ? gi.sole(ja) : -1;
-        if (js >= 0 && gi.node(js)->op == GGML_OP_ADD && gi.node(js)->src[0] == gi.node(ja) && mod_vec(gi.node(jm)->src[1]) && mod_vec(gi.node(js)->src[1]) &&
+        if (js >= 0 && xop(gi.node(js)) == GGML_OP_ADD && gi.node(js)->src[0] == gi.node(ja) && mod_vec(gi.node(jm)->src[1]) && mod_vec(gi.node(js)->src[1]) &&
             all_consumers_gemm16(gi, js, false)) {
             std::vector<int> c2{i, jm, ja, js};
             const ggml_tensor* sc_t = gi.node(jm)->src[1];
@@ -1902,14 +2004,14 @@ bool plan_layer_norm(Builder& B, int i, hipStream_t, std::vector<int>& chain) {
 bool plan_concat_heads(Builder& B, int i, hipStream_t, std::vector<int>& chain) {
     GInfo& gi            = B.gi;
     const ggml_tensor* n = gi.node(i);
-    if (!g_opt.fusion || !g_opt.fuse_concat_heads || n->op != GGML_OP_CONCAT || n->op_params[0] != 1 || !is_f32(n) || n->ne[3] != 1) return false;
+    if (!g_opt.fusion || !g_opt.fuse_concat_heads || xop(n) != GGML_OP_CONCAT || n->op_params[0] != 1 || !is_f32(n) || n->ne[3] != 1) return false;
     const ggml_tensor *a = n->src[0], *b = n->src[1];
     if (!is_f32(a) || !is_f32(b) || !contig(a) || !contig(b) || ((uintptr_t)a->data & 15) || ((uintptr_t)b->data & 15)) return false;
     const int64_t C = n->ne[0], Lt = n->ne[1], N = n->ne[2];
     const int j1 = gi.sole(i);
-    const int j2 = (j1 >= 0 && gi.node(j1)->op == GGML_OP_RESHAPE) ? gi.sole(j1) : -1;
-    const int j3 = (j2 >= 0 && gi.node(j2)->op == GGML_OP_PERMUTE) ? gi.sole(j2) : -1;
-    if (j3 < 0 || gi.node(j3)->op != GGML_OP_CONT || !is_f32(gi.node(j3)) || !contig(gi.node(j3))) return false;
+    const int j2 = (j1 >= 0 && xop(gi.node(j1)) == GGML_OP_RESHAPE) ? gi.sole(j1) : -1;
+    const int j3 = (j2 >= 0 && xop(gi.node(j2)) == GGML_OP_PERMUTE) ? gi.sole(j2) : -1;
+    if (j3 < 0 || xop(gi.node(j3)) != GGML_OP_CONT || !is_f32(gi.node(j3)) || !contig(gi.node(j3))) return false;
     const ggml_tensor* r4 = gi.node(j1);
     const int32_t* ax     = gi.node(j2)->op_params;
     const int64_t d = r4->ne[0], H = r4->ne[1];
@@ -1918,8 +2020,8 @@ bool plan_concat_heads(Builder& B, int i, hipStream_t, std::vector<int>& chain) 
     int last = j3;
     bool f16 = false;
     const int j4 = gi.sole(j3);
-    const int j5 = (j4 >= 0 && gi.node(j4)->op == GGML_OP_RESHAPE) ? gi.sole(j4) : -1;
-    if (j5 >= 0 && gi.node(j5)->op == GGML_OP_CPY && gi.node(j5)->type == GGML_TYPE_F16 && gi.node(j5)->src[0] == gi.node(j4) && contig(gi.node(j5))) {
+    const int j5 = (j4 >= 0 && xop(gi.node(j4)) == GGML_OP_RESHAPE) ? gi.sole(j4) : -1;
+    if (j5 >= 0 && xop(gi.node(j5)) == GGML_OP_CPY && gi.node(j5)->type == GGML_TYPE_F16 && gi.node(j5)->src[0] == gi.node(j4) && contig(gi.node(j5))) {
         c2.push_back(j4);
         c2.push_back(j5);
         last = j5;
@@ -1951,9 +2053,9 @@ struct RopeMatch {
 // the 8-node apply_rope chain starting at c1 = CONT(PERMUTE(x, 0,2,1,3)) (see plan_rope); pure pattern match, nothing is emitted
 static bool match_rope(const GInfo& gi, int i, RopeMatch& rm) {
     const ggml_tensor* c1 = gi.node(i);
-    if (!g_opt.fusion || c1->op != GGML_OP_CONT || !is_f32(c1) || !contig(c1)) return false;
+    if (!g_opt.fusion || xop(c1) != GGML_OP_CONT || !is_f32(c1) || !contig(c1)) return false;
     const ggml_tensor* p1 = c1->src[0];
-    if (!p1 || p1->op != GGML_OP_PERMUTE) return false;
+    if (!p1 || xop(p1) != GGML_OP_PERMUTE) return false;
     const int32_t* a1 = p1->op_params;
     if (!(a1[0] == 0 && a1[1] == 2 && a1[2] == 1 && a1[3] == 3)) return false;
     const ggml_tensor* x = p1->src[0];
@@ -1961,7 +2063,7 @@ static bool match_rope(const GInfo& gi, int i, RopeMatch& rm) {
     const int64_t d = x->ne[0], H = x->ne[1], L = x->ne[2], N = x->ne[3];
     auto sole_op = [&](int k, int op) {
         const int j = k >= 0 ? gi.sole(k) : -1;
-        return (j >= 0 && (int)gi.node(j)->op == op) ? j : -1;
+        return (j >= 0 && (int)xop(gi.node(j)) == op) ? j : -1;
     };
     const int r1 = sole_op(i, GGML_OP_RESHAPE);
     const int p2 = sole_op(r1, GGML_OP_PERMUTE);
@@ -1977,7 +2079,7 @@ static bool match_rope(const GInfo& gi, int i, RopeMatch& rm) {
     const ggml_tensor* pec = nullptr;
     for (int v : gi.consumers[xc]) {
         const ggml_tensor* vt = gi.node(v);
-        if (vt->op != GGML_OP_VIEW || vt->view_src != xct) return false;
+        if (xop(vt) != GGML_OP_VIEW || vt->view_src != xct) return false;
         const size_t half = xct->nb[2] * xct->ne[2];
         const int which   = (const char*)vt->data == (const char*)xct->data ? 0 : ((const char*)vt->data == (const char*)xct->data + half ? 1 : -1);
         if (which < 0 || vt->ne[0] != d / 2 || vt->ne[1] != L || vt->ne[2] != H * N) return false;
@@ -1989,7 +2091,7 @@ static bool match_rope(const GInfo& gi, int i, RopeMatch& rm) {
         if (!(rpt->ne[0] == 2 && rpt->ne[1] == d / 2 && rpt->ne[2] == L && rpt->ne[3] == H * N)) return false;
         // pe operand: VIEW (half `which`) of CONT(PERMUTE(pe, 3,0,1,2))
         const ggml_tensor* pv = gi.node(m)->src[1];
-        if (!pv || pv->op != GGML_OP_VIEW || !pv->view_src || pv->view_src->op != GGML_OP_CONT) return false;
+        if (!pv || xop(pv) != GGML_OP_VIEW || !pv->view_src || xop(pv->view_src) != GGML_OP_CONT) return false;
         const ggml_tensor* pc = pv->view_src;
         if (pec && pec != pc) return false;
         pec               = pc;
@@ -2000,7 +2102,7 @@ static bool match_rope(const GInfo& gi, int i, RopeMatch& rm) {
     }
     if (mul[0] < 0 || mul[1] < 0 || !pec) return false;
     const ggml_tensor* pp = pec->src[0];
-    if (!pp || pp->op != GGML_OP_PERMUTE) return false;
+    if (!pp || xop(pp) != GGML_OP_PERMUTE) return false;
     const int32_t* a3     = pp->op_params;
     const ggml_tensor* pe = pp->src[0];
     if (!(a3[0] == 3 && a3[1] == 0 && a3[2] == 1 && a3[3] == 2) || !pe || !is_f32(pe) || !contig(pe) || pe->ne[0] != 2 || pe->ne[1] != 2 || pe->ne[2] != d / 2 ||
@@ -2010,7 +2112,7 @@ static bool match_rope(const GInfo& gi, int i, RopeMatch& rm) {
     if (ipec < 0 || gi.consumers[ipec].size() != 2) return false;  // only this chain's two views read the permuted table
     c2.push_back(ipec);
     const int add = gi.sole(mul[0]);
-    if (add < 0 || add != gi.sole(mul[1]) || gi.node(add)->op != GGML_OP_ADD || !contig(gi.node(add)) || (gi.node(add)->flags & GGML_TENSOR_FLAG_OUTPUT)) return false;
+    if (add < 0 || add != gi.sole(mul[1]) || xop(gi.node(add)) != GGML_OP_ADD || !contig(gi.node(add)) || (gi.node(add)->flags & GGML_TENSOR_FLAG_OUTPUT)) return false;
     c2.push_back(add);
     for (int k : c2)
         if (k != add && (gi.node(k)->flags & GGML_TENSOR_FLAG_OUTPUT)) return false;
@@ -2041,16 +2143,16 @@ bool plan_rope(Builder& B, int i, hipStream_t, std::vector<int>& chain) {
         size_t qoff = 0;
         int j       = gi.sole(add);
         int via     = add;
-        while (j >= 0 && gi.node(j)->op == GGML_OP_RESHAPE) {
+        while (j >= 0 && xop(gi.node(j)) == GGML_OP_RESHAPE) {
             via = j;
             j   = gi.sole(j);
         }
-        if (j >= 0 && gi.node(j)->op == GGML_OP_CPY && gi.node(j)->type == GGML_TYPE_F16 && gi.node(j)->src[0] == gi.node(via) && contig(gi.node(j)) &&
+        if (j >= 0 && xop(gi.node(j)) == GGML_OP_CPY && gi.node(j)->type == GGML_TYPE_F16 && gi.node(j)->src[0] == gi.node(via) && contig(gi.node(j)) &&
             !(gi.node(j)->flags & GGML_TENSOR_FLAG_OUTPUT) && aligned16(gi.node(j)->data)) {
             outp = gi.node(j)->data;  // K: straight into the f16 cast's buffer
             f16  = true;
             c2.push_back(j);
-        } else if (j >= 0 && g_opt.fuse_q16 && gi.node(j)->op == GGML_OP_FLASH_ATTN_EXT && gi.node(j)->src[0] == gi.node(via) && !gi.node(j)->src[3] && contig(gi.node(via)) &&
+        } else if (j >= 0 && g_opt.fuse_q16 && xop(gi.node(j)) == GGML_OP_FLASH_ATTN_EXT && gi.node(j)->src[0] == gi.node(via) && !gi.node(j)->src[3] && contig(gi.node(via)) &&
                    gi.node(via)->ne[0] == d && d % 8 == 0 && flash_attn_supported(d, gi.node(j)->src[2]->ne[0])) {
             qoff = B.scratch(0x4a61, (size_t)ggml_abi_nelements(x) * 2);  // Q: an f16 image in arena scratch
             B.q16[gi.node(via)] = qoff;
@@ -2086,18 +2188,18 @@ bool plan_rope(Builder& B, int i, hipStream_t, std::vector<int>& chain) {
 bool plan_geglu(Builder& B, int i, hipStream_t, std::vector<int>& chain) {
     GInfo& gi            = B.gi;
     const ggml_tensor* c = gi.node(i);
-    if (!g_opt.fusion || c->op != GGML_OP_CONT) return false;
+    if (!g_opt.fusion || xop(c) != GGML_OP_CONT) return false;
     const ggml_tensor* vhi = c->src[0];
-    if (!vhi || vhi->op != GGML_OP_VIEW || !vhi->view_src || !is_f32(c)) return false;
+    if (!vhi || xop(vhi) != GGML_OP_VIEW || !vhi->view_src || !is_f32(c)) return false;
     const ggml_tensor* X = vhi->view_src;
     const int64_t inner  = vhi->ne[0];
     if (!is_f32(X) || !contig(X) || X->ne[0] != 2 * inner || inner % 4 != 0) return false;
     if ((const char*)vhi->data != (const char*)X->data + inner * 4) return false;
     if (vhi->nb[1] != X->nb[1] || vhi->nb[2] != X->nb[2] || vhi->nb[3] != X->nb[3]) return false;
     int j1 = gi.sole(i);
-    if (j1 < 0 || gi.node(j1)->op != GGML_OP_UNARY || ggml_abi_get_unary_op(gi.node(j1)) != GGML_UNARY_OP_GELU || gi.node(j1)->src[0] != c) return false;
+    if (j1 < 0 || xop(gi.node(j1)) != GGML_OP_UNARY || xunary(gi.node(j1)) != GGML_UNARY_OP_GELU || gi.node(j1)->src[0] != c) return false;
     int j2 = gi.sole(j1);
-    if (j2 < 0 || gi.node(j2)->op != GGML_OP_MUL || gi.node(j2)->src[1] != gi.node(j1)) return false;
+    if (j2 < 0 || xop(gi.node(j2)) != GGML_OP_MUL || gi.node(j2)->src[1] != gi.node(j1)) return false;
     const ggml_tensor* vlo = gi.node(j2)->src[0];
     if (!vlo || vlo->view_src != X || vlo->data != X->data || vlo->ne[0] != inner || vlo->nb[1] != X->nb[1]) return false;
     chain = {i, j1, j2};
@@ -2133,12 +2235,12 @@ bool plan_manual_attention(Builder& B, int i, hipStream_t, std::vector<int>& cha
     if (!is_f32(k) || !is_f32(q) || is_static_weight(k) || k->nb[0] != 4 || q->nb[0] != 4) return false;
     if (k->ne[3] != 1 || q->ne[3] != 1 || k->ne[2] != q->ne[2]) return false;
     int j1 = gi.sole(i);
-    if (j1 < 0 || gi.node(j1)->op != GGML_OP_SCALE || gi.node(j1)->src[0] != kq || ggml_abi_op_param_f32(gi.node(j1), 1) != 0.f) return false;
+    if (j1 < 0 || xop(gi.node(j1)) != GGML_OP_SCALE || gi.node(j1)->src[0] != kq || ggml_abi_op_param_f32(gi.node(j1), 1) != 0.f) return false;
     int j2 = gi.sole(j1);
-    if (j2 < 0 || gi.node(j2)->op != GGML_OP_SOFT_MAX || gi.node(j2)->src[0] != gi.node(j1) || gi.node(j2)->src[1] != nullptr) return false;
+    if (j2 < 0 || xop(gi.node(j2)) != GGML_OP_SOFT_MAX || gi.node(j2)->src[0] != gi.node(j1) || gi.node(j2)->src[1] != nullptr) return false;
     if (ggml_abi_op_param_f32(gi.node(j2), 0) != 1.0f || ggml_abi_op_param_f32(gi.node(j2), 1) != 0.0f) return false;
     int j3 = gi.sole(j2);
-    if (j3 < 0 || gi.node(j3)->op != GGML_OP_MUL_MAT || gi.node(j3)->src[1] != gi.node(j2)) return false;
+    if (j3 < 0 || xop(gi.node(j3)) != GGML_OP_MUL_MAT || gi.node(j3)->src[1] != gi.node(j2)) return false;
     const ggml_tensor* vt  = gi.node(j3)->src[0];  // [Lk, dv, HN]
     const ggml_tensor* out = gi.node(j3);          // [dv, Lq, HN]
     if (!is_f32(vt) || is_static_weight(vt) || vt->nb[0] != 4 || vt->ne[3] != 1 || vt->ne[2] != q->ne[2] || vt->ne[0] != k->ne[1]) return false;
@@ -2230,15 +2332,15 @@ bool plan_single(Builder& B, int i, hipStream_t s) {
     const ggml_tensor* n = gi.node(i);
     // GGML_MI355X_PLAN_TRACE=1: one line per node that no fused pattern claimed (what is left to fuse, and who produces its operands)
     static const bool trace = getenv("GGML_MI355X_PLAN_TRACE") != nullptr;
-    if (trace && n->op != GGML_OP_RESHAPE && n->op != GGML_OP_VIEW && n->op != GGML_OP_PERMUTE && n->op != GGML_OP_TRANSPOSE && n->op != GGML_OP_NONE) {
-        fprintf(stderr, "[plan_single] node %d op %d '%s' ne [%lld %lld %lld %lld]", i, (int)n->op, n->name, (long long)n->ne[0], (long long)n->ne[1], (long long)n->ne[2],
+    if (trace && xop(n) != GGML_OP_RESHAPE && xop(n) != GGML_OP_VIEW && xop(n) != GGML_OP_PERMUTE && xop(n) != GGML_OP_TRANSPOSE && xop(n) != GGML_OP_NONE) {
+        fprintf(stderr, "[plan_single] node %d op %d '%s' ne [%lld %lld %lld %lld]", i, (int)xop(n), n->name, (long long)n->ne[0], (long long)n->ne[1], (long long)n->ne[2],
                 (long long)n->ne[3]);
         for (int q = 0; q < 3 && n->src[q]; ++q)
-            fprintf(stderr, "  src%d: op %d '%s' ne [%lld %lld %lld %lld]", q, (int)n->src[q]->op, n->src[q]->name, (long long)n->src[q]->ne[0], (long long)n->src[q]->ne[1],
+            fprintf(stderr, "  src%d: op %d '%s' ne [%lld %lld %lld %lld]", q, (int)xop(n->src[q]), n->src[q]->name, (long long)n->src[q]->ne[0], (long long)n->src[q]->ne[1],
                     (long long)n->src[q]->ne[2], (long long)n->src[q]->ne[3]);
         fprintf(stderr, "\n");
     }
-    switch (n->op) {
+    switch (xop(n)) {
         case GGML_OP_DUP:
         case GGML_OP_CONT:
         case GGML_OP_CPY: {
@@ -2252,7 +2354,7 @@ bool plan_single(Builder& B, int i, hipStream_t s) {
         case GGML_OP_DIV: {
             for (int q = 0; q < 2; ++q)  // an operand that only exists in the grouped embedding output: materialise its graph tensor first
                 if (n->src[q]) emit_moved_emb_copy(B, strip_reshape(n->src[q]));
-            const BinOp op = n->op == GGML_OP_ADD ? BIN_ADD : n->op == GGML_OP_SUB ? BIN_SUB : n->op == GGML_OP_MUL ? BIN_MUL : BIN_DIV;
+            const BinOp op = xop(n) == GGML_OP_ADD ? BIN_ADD : xop(n) == GGML_OP_SUB ? BIN_SUB : xop(n) == GGML_OP_MUL ? BIN_MUL : BIN_DIV;
             View4 a = view_of(n->src[0]), b = view_of(n->src[1]);
             View4 d = view_of(n);
             B.emit([=](hipStream_t st) { launch_binary(st, op, (void*)d.data, d.nb, a, b); });
@@ -2268,7 +2370,7 @@ bool plan_single(Builder& B, int i, hipStream_t s) {
         }
         case GGML_OP_UNARY: {
             UnOp u;
-            switch (ggml_abi_get_unary_op(n)) {
+            switch (xunary(n)) {
                 case GGML_UNARY_OP_SILU: u = UN_SILU; break;
                 case GGML_UNARY_OP_GELU: u = UN_GELU; break;
                 case GGML_UNARY_OP_GELU_QUICK: u = UN_GELU_QUICK; break;
@@ -2426,8 +2528,8 @@ bool plan_single(Builder& B, int i, hipStream_t s) {
             // -> VIEW [d,H,Lq,N] -> CONT [C,Lq,N] (ggml_extend.hpp:1446-1455, 1481-1482): write the final layout directly
             if (g_opt.fusion) {
                 const int j1 = gi.sole(i);
-                const int j2 = (j1 >= 0 && gi.node(j1)->op == GGML_OP_VIEW) ? gi.sole(j1) : -1;
-                if (j2 >= 0 && gi.node(j2)->op == GGML_OP_CONT && gi.node(j2)->src[0] == gi.node(j1) && is_f32(gi.node(j2)) && contig(gi.node(j2))) {
+                const int j2 = (j1 >= 0 && xop(gi.node(j1)) == GGML_OP_VIEW) ? gi.sole(j1) : -1;
+                if (j2 >= 0 && xop(gi.node(j2)) == GGML_OP_CONT && gi.node(j2)->src[0] == gi.node(j1) && is_f32(gi.node(j2)) && contig(gi.node(j2))) {
                     const ggml_tensor* vw = gi.node(j1);   // ne = [d, H, Lq, N]
                     const ggml_tensor* ct = gi.node(j2);
                     std::vector<int> chain{i, j1, j2};
@@ -2496,7 +2598,7 @@ bool plan_single(Builder& B, int i, hipStream_t s) {
 // the only non-view reader of node k, looking through RESHAPE views; -1 if there are several or k is a graph output
 static int sole_through_reshape(const GInfo& gi, int k) {
     int j = gi.sole(k);
-    while (j >= 0 && gi.node(j)->op == GGML_OP_RESHAPE) j = gi.sole(j);
+    while (j >= 0 && xop(gi.node(j)) == GGML_OP_RESHAPE) j = gi.sole(j);
     return j;
 }
 
@@ -2509,7 +2611,7 @@ void plan_cat_rows16(Builder& B) {
     if (!g_opt.fusion || !g_opt.gemm16 || !g_opt.fuse_cat_rows16) return;
     for (int i = 0; i < gi.g->n_nodes; ++i) {
         const ggml_tensor* n = gi.node(i);
-        if (n->op != GGML_OP_CONCAT || n->op_params[0] != 0 || !is_f32(n) || !contig(n) || n->ne[3] != 1 || (n->flags & GGML_TENSOR_FLAG_OUTPUT)) continue;
+        if (xop(n) != GGML_OP_CONCAT || n->op_params[0] != 0 || !is_f32(n) || !contig(n) || n->ne[3] != 1 || (n->flags & GGML_TENSOR_FLAG_OUTPUT)) continue;
         const ggml_tensor *a = n->src[0], *b = n->src[1];
         if (!is_f32(a) || !is_f32(b) || !contig(a) || !contig(b) || !aligned16(a->data) || !aligned16(b->data)) continue;
         const int64_t Ka = a->ne[0], Kb = b->ne[0], rows = n->ne[1] * n->ne[2];
@@ -2523,9 +2625,9 @@ void plan_cat_rows16(Builder& B) {
             const int is           = gi.idx(src);
             if (is < 0 || sole_through_reshape(gi, is) != i) continue;
             const int64_t col = p ? Ka : 0;
-            if (src->op == GGML_OP_CONT && src->src[0] && src->src[0]->op == GGML_OP_VIEW && src->src[0]->src[0] && src->src[0]->src[0]->op == GGML_OP_FLASH_ATTN_EXT) {
+            if (xop(src) == GGML_OP_CONT && src->src[0] && xop(src->src[0]) == GGML_OP_VIEW && src->src[0]->src[0] && xop(src->src[0]->src[0]) == GGML_OP_FLASH_ATTN_EXT) {
                 B.cat16_part[src] = Builder::Cat16Part{off, ld, col, i, p};  // taken (or not) by the flash node's output fusion
-            } else if (src->op == GGML_OP_UNARY && ggml_abi_get_unary_op(src) == GGML_UNARY_OP_GELU && src->src[0] && src->src[0]->op == GGML_OP_CONT &&
+            } else if (xop(src) == GGML_OP_UNARY && xunary(src) == GGML_UNARY_OP_GELU && src->src[0] && xop(src->src[0]) == GGML_OP_CONT &&
                        src->data == src->src[0]->data) {
                 const ggml_tensor* cc = src->src[0];
                 const ggml_tensor* v  = cc->src[0];
@@ -2541,12 +2643,12 @@ void plan_cat_rows16(Builder& B) {
 // the forward half of plan_concat_heads' pattern: CONCAT(dim 1) -> RESHAPE [d,H,Lt,N] -> PERMUTE(0,2,1,3) -> CONT [-> RESHAPE -> CPY f16]
 static bool concat_heads_forward(const GInfo& gi, int i, int* d_out, int* H_out, int* last_out, bool* f16_out, std::vector<int>* chain) {
     const ggml_tensor* n = gi.node(i);
-    if (n->op != GGML_OP_CONCAT || n->op_params[0] != 1 || !is_f32(n) || n->ne[3] != 1) return false;
+    if (xop(n) != GGML_OP_CONCAT || n->op_params[0] != 1 || !is_f32(n) || n->ne[3] != 1) return false;
     const int64_t C = n->ne[0], Lt = n->ne[1], N = n->ne[2];
     const int j1 = gi.sole(i);
-    const int j2 = (j1 >= 0 && gi.node(j1)->op == GGML_OP_RESHAPE) ? gi.sole(j1) : -1;
-    const int j3 = (j2 >= 0 && gi.node(j2)->op == GGML_OP_PERMUTE) ? gi.sole(j2) : -1;
-    if (j3 < 0 || gi.node(j3)->op != GGML_OP_CONT || !is_f32(gi.node(j3)) || !contig(gi.node(j3))) return false;
+    const int j2 = (j1 >= 0 && xop(gi.node(j1)) == GGML_OP_RESHAPE) ? gi.sole(j1) : -1;
+    const int j3 = (j2 >= 0 && xop(gi.node(j2)) == GGML_OP_PERMUTE) ? gi.sole(j2) : -1;
+    if (j3 < 0 || xop(gi.node(j3)) != GGML_OP_CONT || !is_f32(gi.node(j3)) || !contig(gi.node(j3))) return false;
     const ggml_tensor* r4 = gi.node(j1);
     const int32_t* ax     = gi.node(j2)->op_params;
     const int64_t d = r4->ne[0], H = r4->ne[1];
@@ -2555,8 +2657,8 @@ static bool concat_heads_forward(const GInfo& gi, int i, int* d_out, int* H_out,
     *last_out = j3;
     *f16_out  = false;
     const int j4 = gi.sole(j3);
-    const int j5 = (j4 >= 0 && gi.node(j4)->op == GGML_OP_RESHAPE) ? gi.sole(j4) : -1;
-    if (j5 >= 0 && gi.node(j5)->op == GGML_OP_CPY && gi.node(j5)->type == GGML_TYPE_F16 && gi.node(j5)->src[0] == gi.node(j4) && contig(gi.node(j5))) {
+    const int j5 = (j4 >= 0 && xop(gi.node(j4)) == GGML_OP_RESHAPE) ? gi.sole(j4) : -1;
+    if (j5 >= 0 && xop(gi.node(j5)) == GGML_OP_CPY && gi.node(j5)->type == GGML_TYPE_F16 && gi.node(j5)->src[0] == gi.node(j4) && contig(gi.node(j5))) {
         chain->push_back(j4);
         chain->push_back(j5);
         *last_out = j5;
@@ -2595,23 +2697,23 @@ void plan_joint_qkv(Builder& B) {
     std::vector<Stream> streams;
     for (int is = 0; is < gi.g->n_nodes; ++is) {
         const ggml_tensor* S = gi.node(is);
-        if (S->op != GGML_OP_CONT || !is_f32(S) || !contig(S) || (S->flags & GGML_TENSOR_FLAG_OUTPUT) || !S->src[0] || S->src[0]->op != GGML_OP_PERMUTE) continue;
+        if (xop(S) != GGML_OP_CONT || !is_f32(S) || !contig(S) || (S->flags & GGML_TENSOR_FLAG_OUTPUT) || !S->src[0] || xop(S->src[0]) != GGML_OP_PERMUTE) continue;
         const ggml_tensor* pm = S->src[0];
         const int32_t* pa     = pm->op_params;
         if (!(pa[0] == 0 && pa[1] == 3 && pa[2] == 1 && pa[3] == 2)) continue;
         const ggml_tensor* r1 = pm->src[0];
-        if (!r1 || r1->op != GGML_OP_RESHAPE || r1->ne[1] != 3) continue;
+        if (!r1 || xop(r1) != GGML_OP_RESHAPE || r1->ne[1] != 3) continue;
         const ggml_tensor* T = strip_reshape(r1);
         const int iT         = gi.idx(T);
         const int64_t C      = r1->ne[0];
         if (iT < 0 || !is_f32(T) || !contig(T) || T->ne[0] != 3 * C || T->ne[3] != 1 || C % 4 != 0 || !aligned16(T->data)) continue;
         // T must come out of a weight GEMM (MUL_MAT [+ bias ADD in place]) and be read by nothing but S
-        const bool from_mm = T->op == GGML_OP_MUL_MAT || (T->op == GGML_OP_ADD && T->src[0] && strip_reshape(T->src[0])->op == GGML_OP_MUL_MAT && T->data == strip_reshape(T->src[0])->data);
-        const ggml_tensor* mm = T->op == GGML_OP_MUL_MAT ? T : (from_mm ? strip_reshape(T->src[0]) : nullptr);
+        const bool from_mm = xop(T) == GGML_OP_MUL_MAT || (xop(T) == GGML_OP_ADD && T->src[0] && xop(strip_reshape(T->src[0])) == GGML_OP_MUL_MAT && T->data == strip_reshape(T->src[0])->data);
+        const ggml_tensor* mm = xop(T) == GGML_OP_MUL_MAT ? T : (from_mm ? strip_reshape(T->src[0]) : nullptr);
         if (!from_mm || !mm || !linear_fast_ok(mm)) continue;
         {
             int j = gi.sole(iT);
-            while (j >= 0 && (gi.node(j)->op == GGML_OP_RESHAPE || gi.node(j)->op == GGML_OP_PERMUTE)) j = gi.sole(j);
+            while (j >= 0 && (xop(gi.node(j)) == GGML_OP_RESHAPE || xop(gi.node(j)) == GGML_OP_PERMUTE)) j = gi.sole(j);
             if (j != is) continue;
         }
         if (gi.consumers[is].size() != 3) continue;
@@ -2624,7 +2726,7 @@ void plan_joint_qkv(Builder& B) {
         bool seen[3] = {false, false, false};
         for (int iv : gi.consumers[is]) {
             const ggml_tensor* v = gi.node(iv);
-            if (v->op != GGML_OP_VIEW || v->ne[0] != C || v->ne[1] != S->ne[1] || v->ne[2] != S->ne[2] || v->ne[3] != 1 || v->nb[1] != S->nb[1] || v->nb[2] != S->nb[2] || S->nb[3] == 0) {
+            if (xop(v) != GGML_OP_VIEW || v->ne[0] != C || v->ne[1] != S->ne[1] || v->ne[2] != S->ne[2] || v->ne[3] != 1 || v->nb[1] != S->nb[1] || v->nb[2] != S->nb[2] || S->nb[3] == 0) {
                 ok = false;
                 break;
             }
@@ -2638,14 +2740,14 @@ void plan_joint_qkv(Builder& B) {
             VChain vc;
             int j    = gi.sole(iv);
             int from = iv;
-            while (j >= 0 && gi.node(j)->op == GGML_OP_RESHAPE) {  // [d,H,L,N] and back to [C,L,N] (pre_attention reshapes with or without the norm)
+            while (j >= 0 && xop(gi.node(j)) == GGML_OP_RESHAPE) {  // [d,H,L,N] and back to [C,L,N] (pre_attention reshapes with or without the norm)
                 from = j;
                 j    = gi.sole(j);
             }
-            if (j >= 0 && gi.node(j)->op == GGML_OP_RMS_NORM) {  // qk-norm branch: RESHAPE [d,H,L,N] -> RMS_NORM -> MUL(w[d]) -> RESHAPE [C,L,N]
+            if (j >= 0 && xop(gi.node(j)) == GGML_OP_RMS_NORM) {  // qk-norm branch: RESHAPE [d,H,L,N] -> RMS_NORM -> MUL(w[d]) -> RESHAPE [C,L,N]
                 const int jn = j;
                 const int jm = gi.node(jn)->src[0] == gi.node(from) ? gi.sole(jn) : -1;
-                if (jm < 0 || gi.node(jm)->op != GGML_OP_MUL || gi.node(jm)->src[0] != gi.node(jn)) {
+                if (jm < 0 || xop(gi.node(jm)) != GGML_OP_MUL || gi.node(jm)->src[0] != gi.node(jn)) {
                     ok = false;
                     break;
                 }
@@ -2662,7 +2764,7 @@ void plan_joint_qkv(Builder& B) {
                 vc.skip = {jn, jm};
                 from    = jm;
                 j       = gi.sole(jm);
-                while (j >= 0 && gi.node(j)->op == GGML_OP_RESHAPE) {
+                while (j >= 0 && xop(gi.node(j)) == GGML_OP_RESHAPE) {
                     from = j;
                     j    = gi.sole(j);
                 }
@@ -2671,7 +2773,7 @@ void plan_joint_qkv(Builder& B) {
                     break;
                 }
             }
-            if (j < 0 || gi.node(j)->op != GGML_OP_CONCAT || gi.node(j)->op_params[0] != 1) {
+            if (j < 0 || xop(gi.node(j)) != GGML_OP_CONCAT || gi.node(j)->op_params[0] != 1) {
                 ok = false;
                 break;
             }
@@ -2770,8 +2872,8 @@ void plan_flux_qkv(Builder& B) {
     for (int iT = 0; iT < gi.g->n_nodes; ++iT) {
         const ggml_tensor* T = gi.node(iT);
         if (!is_f32(T) || !contig(T) || T->ne[3] != 1 || (T->flags & GGML_TENSOR_FLAG_OUTPUT) || !aligned16(T->data) || gi.consumers[iT].size() < 3) continue;
-        const bool from_mm = T->op == GGML_OP_MUL_MAT || (T->op == GGML_OP_ADD && T->src[0] && strip_reshape(T->src[0])->op == GGML_OP_MUL_MAT && T->data == strip_reshape(T->src[0])->data);
-        const ggml_tensor* mm = T->op == GGML_OP_MUL_MAT ? T : (from_mm ? strip_reshape(T->src[0]) : nullptr);
+        const bool from_mm = xop(T) == GGML_OP_MUL_MAT || (xop(T) == GGML_OP_ADD && T->src[0] && xop(strip_reshape(T->src[0])) == GGML_OP_MUL_MAT && T->data == strip_reshape(T->src[0])->data);
+        const ggml_tensor* mm = xop(T) == GGML_OP_MUL_MAT ? T : (from_mm ? strip_reshape(T->src[0]) : nullptr);
         if (!from_mm || !mm || !linear_fast_ok(mm) || B.lin_redirect.count(T)) continue;
         Cand c;
         c.iT = iT;
@@ -2781,7 +2883,7 @@ void plan_flux_qkv(Builder& B) {
         bool ok = true;
         for (int iv : gi.consumers[iT]) {
             const ggml_tensor* v = gi.node(iv);
-            if (v->op != GGML_OP_VIEW || !is_f32(v) || v->nb[0] != 4) {
+            if (xop(v) != GGML_OP_VIEW || !is_f32(v) || v->nb[0] != 4) {
                 ok = false;
                 break;
             }
@@ -2794,7 +2896,7 @@ void plan_flux_qkv(Builder& B) {
             u.col = delta / 4;
             if (v->ne[3] == 1 && v->ne[1] == c.L && v->ne[2] == c.N && v->nb[1] == T->nb[1] && v->nb[2] == T->nb[2]) {  // [M, L, N] rows: the mlp part
                 const int jc = gi.sole(iv);
-                if (jc < 0 || gi.node(jc)->op != GGML_OP_CONT || !B.cat16_part.count(gi.node(jc))) {
+                if (jc < 0 || xop(gi.node(jc)) != GGML_OP_CONT || !B.cat16_part.count(gi.node(jc))) {
                     ok = false;
                     break;
                 }
@@ -2811,9 +2913,9 @@ void plan_flux_qkv(Builder& B) {
             }
             int j    = gi.sole(iv);
             int from = iv;
-            if (j >= 0 && gi.node(j)->op == GGML_OP_RMS_NORM && gi.node(j)->src[0] == v) {
+            if (j >= 0 && xop(gi.node(j)) == GGML_OP_RMS_NORM && gi.node(j)->src[0] == v) {
                 const int jn = j, jm = gi.sole(jn);
-                if (jm < 0 || gi.node(jm)->op != GGML_OP_MUL || gi.node(jm)->src[0] != gi.node(jn)) {
+                if (jm < 0 || xop(gi.node(jm)) != GGML_OP_MUL || gi.node(jm)->src[0] != gi.node(jn)) {
                     ok = false;
                     break;
                 }
@@ -2831,7 +2933,7 @@ void plan_flux_qkv(Builder& B) {
             } else {
                 u.kind = 2;
             }
-            if (j >= 0 && gi.node(j)->op == GGML_OP_CONCAT && gi.node(j)->op_params[0] == 2 && gi.node(j)->src[0] != gi.node(j)->src[1]) {
+            if (j >= 0 && xop(gi.node(j)) == GGML_OP_CONCAT && gi.node(j)->op_params[0] == 2 && gi.node(j)->src[0] != gi.node(j)->src[1]) {
                 u.cat  = j;
                 u.part = gi.node(j)->src[0] == gi.node(from) ? 0 : (gi.node(j)->src[1] == gi.node(from) ? 1 : -1);
                 if (u.part < 0 || !contig(gi.node(j))) {
@@ -2843,8 +2945,8 @@ void plan_flux_qkv(Builder& B) {
                 j    = gi.sole(j);
             }
             // X = node(from) [d, H, Lt, N] -> PERMUTE(0,2,1,3) -> CONT
-            const int jc = (j >= 0 && gi.node(j)->op == GGML_OP_PERMUTE && gi.node(j)->src[0] == gi.node(from)) ? gi.sole(j) : -1;
-            if (jc < 0 || gi.node(jc)->op != GGML_OP_CONT || !is_f32(gi.node(jc)) || !contig(gi.node(jc))) {
+            const int jc = (j >= 0 && xop(gi.node(j)) == GGML_OP_PERMUTE && gi.node(j)->src[0] == gi.node(from)) ? gi.sole(j) : -1;
+            if (jc < 0 || xop(gi.node(jc)) != GGML_OP_CONT || !is_f32(gi.node(jc)) || !contig(gi.node(jc))) {
                 ok = false;
                 break;
             }
@@ -2862,8 +2964,8 @@ void plan_flux_qkv(Builder& B) {
                 }
             } else {  // v: CONT -> RESHAPE -> CPY f16
                 const int jr = gi.sole(jc);
-                const int jy = (jr >= 0 && gi.node(jr)->op == GGML_OP_RESHAPE) ? gi.sole(jr) : -1;
-                if (jy < 0 || gi.node(jy)->op != GGML_OP_CPY || gi.node(jy)->type != GGML_TYPE_F16 || gi.node(jy)->src[0] != gi.node(jr) || !contig(gi.node(jy)) ||
+                const int jy = (jr >= 0 && xop(gi.node(jr)) == GGML_OP_RESHAPE) ? gi.sole(jr) : -1;
+                if (jy < 0 || xop(gi.node(jy)) != GGML_OP_CPY || gi.node(jy)->type != GGML_TYPE_F16 || gi.node(jy)->src[0] != gi.node(jr) || !contig(gi.node(jy)) ||
                     (gi.node(jy)->flags & GGML_TENSOR_FLAG_OUTPUT) || !aligned16(gi.node(jy)->data)) {
                     ok = false;
                     break;
@@ -2933,11 +3035,11 @@ bool build_plan(Planner* P, Plan* plan, const ggml_cgraph* g, hipStream_t s, boo
         }
         if (gi.done[i]) continue;
         const ggml_tensor* n = gi.node(i);
-        if (ggml_abi_op_is_noop(n->op)) continue;
+        if (ggml_abi_op_is_noop(xop(n))) continue;
         if (ggml_abi_nelements(n) == 0) continue;
         std::vector<int> chain;
         bool ok = false;
-        switch (n->op) {
+        switch (xop(n)) {
             case GGML_OP_IM2COL: ok = plan_conv_chain(B, i, s, chain); break;
             case GGML_OP_MUL_MAT:
                 if (linear_fast_ok(n)) {
@@ -2992,8 +3094,8 @@ bool build_plan(Planner* P, Plan* plan, const ggml_cgraph* g, hipStream_t s, boo
                     bool q16    = false;
                     if (!f16 && g_opt.fuse_q16 && jc.d % 8 == 0) {  // Q read only by a FLASH_ATTN_EXT node: an f16 image in arena scratch
                         const int c1 = gi.sole(jc.last);
-                        const int c2 = (c1 >= 0 && gi.node(c1)->op == GGML_OP_RESHAPE) ? gi.sole(c1) : -1;
-                        if (c2 >= 0 && gi.node(c2)->op == GGML_OP_FLASH_ATTN_EXT && gi.node(c2)->src[0] == gi.node(c1) && !gi.node(c2)->src[3] && contig(gi.node(c1)) &&
+                        const int c2 = (c1 >= 0 && xop(gi.node(c1)) == GGML_OP_RESHAPE) ? gi.sole(c1) : -1;
+                        if (c2 >= 0 && xop(gi.node(c2)) == GGML_OP_FLASH_ATTN_EXT && gi.node(c2)->src[0] == gi.node(c1) && !gi.node(c2)->src[3] && contig(gi.node(c1)) &&
                             gi.node(c1)->ne[0] == jc.d && flash_attn_supported(jc.d, gi.node(c2)->src[2]->ne[0])) {
                             qoff = B.scratch(0x4a60, (size_t)jc.d * jc.H * (La + Lb) * Nimg * 2);
                             B.q16[gi.node(c1)] = qoff;
@@ -3018,12 +3120,12 @@ bool build_plan(Planner* P, Plan* plan, const ggml_cgraph* g, hipStream_t s, boo
             }
             case GGML_OP_CONT: {
                 const auto cp = B.cat16_part.find(n);
-                if (cp != B.cat16_part.end() && B.cat16_by_linear.count(n) && gi.sole(i) >= 0 && gi.node(gi.sole(i))->op == GGML_OP_UNARY) {
+                if (cp != B.cat16_part.end() && B.cat16_by_linear.count(n) && gi.sole(i) >= 0 && xop(gi.node(gi.sole(i))) == GGML_OP_UNARY) {
                     chain = {i, gi.sole(i)};  // the producing Linear's epilogue wrote gelu(.) into the image already
                     ok    = true;
                     break;
                 }
-                if (cp != B.cat16_part.end() && n->src[0] && n->src[0]->op == GGML_OP_VIEW && gi.sole(i) >= 0 && gi.node(gi.sole(i))->op == GGML_OP_UNARY) {
+                if (cp != B.cat16_part.end() && n->src[0] && xop(n->src[0]) == GGML_OP_VIEW && gi.sole(i) >= 0 && xop(gi.node(gi.sole(i))) == GGML_OP_UNARY) {
                     // gelu(CONT(strided view)) as one pass: strided f32 rows -> GELU -> f16 columns of the operand image
                     const Builder::Cat16Part pt = cp->second;
                     const ggml_tensor* v        = n->src[0];
@@ -3072,9 +3174,9 @@ bool build_plan(Planner* P, Plan* plan, const ggml_cgraph* g, hipStream_t s, boo
                 // applied by the weight-streaming kernel while it stages the rows (plan_linear); adjacency keeps the source rows alive
                 const ggml_tensor* src = n->src[0];
                 const int c            = gi.sole(i);
-                if (g_opt.fusion && (g_opt.fgemv || g_opt.qgemv) && ggml_abi_get_unary_op(n) == GGML_UNARY_OP_SILU && c == i + 1 && is_f32(src) && contig(src) && contig(n) &&
+                if (g_opt.fusion && (g_opt.fgemv || g_opt.qgemv) && xunary(n) == GGML_UNARY_OP_SILU && c == i + 1 && is_f32(src) && contig(src) && contig(n) &&
                     B.packed.find(strip_reshape(src)) == B.packed.end() &&
-                    !(n->flags & GGML_TENSOR_FLAG_OUTPUT) && gi.node(c)->op == GGML_OP_MUL_MAT && gi.node(c)->src[1] == n && linear_fast_ok(gi.node(c))) {
+                    !(n->flags & GGML_TENSOR_FLAG_OUTPUT) && xop(gi.node(c)) == GGML_OP_MUL_MAT && gi.node(c)->src[1] == n && linear_fast_ok(gi.node(c))) {
                     const ggml_tensor* w = gi.node(c)->src[0];
                     const int64_t rows   = n->ne[1] * n->ne[2] * n->ne[3];
                     if ((g_opt.fgemv && fgemv_supported((int)w->type, rows, w->ne[0])) || (g_opt.qgemv && qgemv_supported((int)w->type, rows, w->ne[0]))) {
@@ -3090,7 +3192,7 @@ bool build_plan(Planner* P, Plan* plan, const ggml_cgraph* g, hipStream_t s, boo
                 const ggml_tensor* src = n->src[0];
                 const int c            = gi.sole(i);
                 if (g_opt.gemm16 && n->op_params[0] == GGML_SCALE_MODE_NEAREST && is_f32(src) && contig(src) && n->ne[0] == 2 * src->ne[0] &&
-                    n->ne[1] == 2 * src->ne[1] && n->ne[2] == src->ne[2] && n->ne[3] == src->ne[3] && c >= 0 && gi.node(c)->op == GGML_OP_IM2COL &&
+                    n->ne[1] == 2 * src->ne[1] && n->ne[2] == src->ne[2] && n->ne[3] == src->ne[3] && c >= 0 && xop(gi.node(c)) == GGML_OP_IM2COL &&
                     gi.node(c)->src[1] == n && conv_im2col_fast_ok(gi, c) && gi.node(c)->src[0]->ne[0] == 3 && gi.node(c)->op_params[0] == 1) {
                     B.ups[n] = src;
                     chain    = {i};
@@ -3105,7 +3207,7 @@ bool build_plan(Planner* P, Plan* plan, const ggml_cgraph* g, hipStream_t s, boo
             continue;
         }
         if (!planner_supports_op(n) || !plan_single(B, i, s)) {
-            fprintf(stderr, "[ggml-mi355x] unsupported node %d: op=%d type=%d name=%s\n", i, (int)n->op, (int)n->type, n->name);
+            fprintf(stderr, "[ggml-mi355x] unsupported node %d: op=%d type=%d name=%s\n", i, (int)xop(n), (int)n->type, n->name);
             return false;
         }
         gi.done[i] = 1;
@@ -3263,7 +3365,7 @@ enum ggml_status planner_compute(Planner* p, ggml_cgraph* g, hipStream_t stream)
 
 bool planner_supports_op(const ggml_tensor* n) {
     auto f32c = [](const ggml_tensor* t) { return t && t->type == GGML_TYPE_F32; };
-    switch (n->op) {
+    switch (xop(n)) {
         case GGML_OP_NONE:
         case GGML_OP_RESHAPE:
         case GGML_OP_VIEW:
@@ -3288,7 +3390,7 @@ bool planner_supports_op(const ggml_tensor* n) {
         case GGML_OP_SCALE:
             return f32c(n) && f32c(n->src[0]) && ggml_abi_is_contiguous(n) && ggml_abi_is_contiguous(n->src[0]);
         case GGML_OP_UNARY:
-            switch (ggml_abi_get_unary_op(n)) {
+            switch (xunary(n)) {
                 case GGML_UNARY_OP_SILU:
                 case GGML_UNARY_OP_GELU:
                 case GGML_UNARY_OP_GELU_QUICK:
@@ -3330,7 +3432,7 @@ bool planner_supports_op(const ggml_tensor* n) {
         case GGML_OP_REPEAT:
         case GGML_OP_UPSCALE:
         case GGML_OP_PAD:
-            if (n->op == GGML_OP_UPSCALE && n->op_params[0] != GGML_SCALE_MODE_NEAREST) return false;
+            if (xop(n) == GGML_OP_UPSCALE && n->op_params[0] != GGML_SCALE_MODE_NEAREST) return false;
             return f32c(n) && f32c(n->src[0]);
         case GGML_OP_GET_ROWS: {
             const ggml_tensor *a = n->src[0], *b = n->src[1];

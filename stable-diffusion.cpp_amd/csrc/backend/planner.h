@@ -16,5 +16,9 @@ bool planner_supports_op(const ggml_tensor* op);
 void planner_forget_range(const void* ptr, size_t size);
 void planner_get_stats(ggml_backend_mi355x_stats* out);
 void planner_set_option(const char* key, int value);
+// host op / unary-op numbers -> the numbers of include/ggml-abi.h, rebuilt from the host's name functions (NULL: that table is left alone);
+// type numbers are verified, not remapped.  false + message: a needed name is missing / duplicated / a type is numbered differently (tables unchanged).
+bool planner_build_op_maps(const char* (*op_name)(int), const char* (*unary_name)(int), const char* (*type_name)(int), char* err, size_t err_len);
+void planner_get_op_maps(uint8_t* ops256, uint8_t* unary256);
 
 }  // namespace mi355x

@@ -138,6 +138,27 @@ const char* ggml_op_name(enum ggml_op op) {
     }
 }
 
+const char* ggml_unary_op_name(enum ggml_unary_op op) {
+    switch (op) {
+        case GGML_UNARY_OP_ABS: return "ABS";
+        case GGML_UNARY_OP_SGN: return "SGN";
+        case GGML_UNARY_OP_NEG: return "NEG";
+        case GGML_UNARY_OP_STEP: return "STEP";
+        case GGML_UNARY_OP_TANH: return "TANH";
+        case GGML_UNARY_OP_ELU: return "ELU";
+        case GGML_UNARY_OP_RELU: return "RELU";
+        case GGML_UNARY_OP_SIGMOID: return "SIGMOID";
+        case GGML_UNARY_OP_GELU: return "GELU";
+        case GGML_UNARY_OP_GELU_QUICK: return "GELU_QUICK";
+        case GGML_UNARY_OP_SILU: return "SILU";
+        case GGML_UNARY_OP_HARDSWISH: return "HARDSWISH";
+        case GGML_UNARY_OP_HARDSIGMOID: return "HARDSIGMOID";
+        case GGML_UNARY_OP_EXP: return "EXP";
+        case GGML_UNARY_OP_GELU_ERF: return "GELU_ERF";
+        default: return "UNARY?";
+    }
+}
+
 const char* ggml_op_desc(const ggml_tensor* t) {
     if (t->op == GGML_OP_UNARY) {
         switch (ggml_abi_get_unary_op(t)) {

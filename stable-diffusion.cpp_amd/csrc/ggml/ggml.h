@@ -57,6 +57,7 @@ GGML_API size_t ggml_row_size(enum ggml_type type, int64_t ne);
 GGML_API size_t ggml_element_size(const struct ggml_tensor* tensor);
 GGML_API const char* ggml_type_name(enum ggml_type type);
 GGML_API const char* ggml_op_name(enum ggml_op op);
+GGML_API const char* ggml_unary_op_name(enum ggml_unary_op op);
 GGML_API const char* ggml_op_desc(const struct ggml_tensor* t);
 GGML_API const char* ggml_status_to_string(enum ggml_status status);
 GGML_API bool ggml_is_quantized(enum ggml_type type);

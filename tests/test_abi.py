@@ -60,3 +60,120 @@ def test_engine_refuses_to_run_without_the_hip_backend(sd):
         pass
     with pytest.raises(sd.EngineError):
         sd.Engine(model=sd.SD15_TINY)  # default backend = MI355X0
+
+
+# ---------------------------------------------------------------- enum numbering resolved by name (VERDICT r4 task 4)
+_REMAP_PROBE = r"""
+import ctypes as C, json, os, sys
+host = C.CDLL(os.environ["HOST"], mode=C.RTLD_GLOBAL)       # the host process links its libggml first ...
+be = C.CDLL(os.environ["BACKEND"])                          # ... then dlopen()s the plug-in (ggml_backend_load)
+be.ggml_backend_init.restype = C.c_void_p
+be.ggml_backend_mi355x_enum_status.restype = C.c_char_p
+host.ggml_op_name.restype = C.c_char_p
+host.ggml_unary_op_name.restype = C.c_char_p
+assert be.ggml_backend_init()
+ops = (C.c_uint8 * 256)(); un = (C.c_uint8 * 256)()
+be.ggml_backend_mi355x_get_enum_maps(ops, un)
+print(json.dumps({"status": be.ggml_backend_mi355x_enum_status().decode(), "ops": list(ops), "unary": list(un),
+                  "op_names": [(host.ggml_op_name(i) or b"").decode() for i in range(100)],
+                  "unary_names": [(host.ggml_unary_op_name(i) or b"").decode() for i in range(20)]}))
+"""
+
+
+def _remap_probe(sd, host_so):
+    import json
+    import os
+    import sys
+
+    env = dict(os.environ, HOST=str(host_so), BACKEND=str(sd.BACKEND_LIB))
+    r = subprocess.run([sys.executable, "-c", _REMAP_PROBE], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def _abi_enum(name: str) -> dict:
+    """enum values of include/ggml-abi.h as the PLUG-IN was compiled (GGML_ABI_TEST_SHIFTED_ENUMS undefined)."""
+    txt = (ROOT / "include" / "ggml-abi.h").read_text()
+    body = re.search(r"enum " + name + r"\s*\{(.*?)\};", txt, re.S).group(1)
+    body = re.sub(r"#ifdef GGML_ABI_TEST_SHIFTED_ENUMS.*?#endif", "", body, flags=re.S)
+    body = re.sub(r"/\*.*?\*/|//[^\n]*", "", body, flags=re.S)
+    out, nxt = {}, 0
+    for item in filter(None, (x.strip() for x in body.split(","))):
+        if "=" in item:
+            k, v = (y.strip() for y in item.split("="))
+            nxt = int(v, 0) if v.lstrip("-").isdigit() or v.startswith("0x") else out[v]
+            item = k
+        out[item] = nxt
+        nxt += 1
+    return out
+
+
+def test_op_enum_identity_on_the_matching_host(sd):
+    got = _remap_probe(sd, sd.LIB_DIR / "libsdcpp-host.so")
+    assert "translated by name" in got["status"], got["status"]
+    ops = _abi_enum("ggml_op")
+    for k in ("GGML_OP_ADD", "GGML_OP_MUL_MAT", "GGML_OP_IM2COL", "GGML_OP_FLASH_ATTN_EXT", "GGML_OP_UNARY", "GGML_OP_GROUP_NORM"):
+        assert got["ops"][ops[k]] == ops[k]
+
+
+def test_op_enum_remap(sd):
+    """A host "fork" with two ops and one unary op inserted mid-enum (libsdcpp-host-opshift.so, build.py): the UNCHANGED plug-in must translate the
+    shifted numbers back by name.  The GPU leg (tests/test_gpu_abi_remap.py) then runs the same graph through both hosts."""
+    shifted = sd.LIB_DIR / "libsdcpp-host-opshift.so"
+    assert shifted.exists(), "build.py did not build the shifted-enum host fixture"
+    got = _remap_probe(sd, shifted)
+    assert "translated by name" in got["status"], got["status"]
+    ops, un = _abi_enum("ggml_op"), _abi_enum("ggml_unary_op")
+    names = got["op_names"]
+    moved = 0
+    for abi_name, abi_num in ops.items():
+        nm = abi_name[len("GGML_OP_"):]
+        if nm not in names or abi_name == "GGML_OP_COUNT":
+            continue
+        host_num = names.index(nm)
+        mapped = got["ops"][host_num]
+        if mapped != ops["GGML_OP_COUNT"]:  # an op the planner dispatches on
+            assert mapped == abi_num, (nm, host_num, mapped, abi_num)
+            moved += host_num != abi_num
+    assert moved >= 20  # everything after ADD1 moved by two
+    for nm in ("MUL_MAT", "IM2COL", "FLASH_ATTN_EXT", "UNARY", "CONT", "GROUP_NORM", "SOFT_MAX"):
+        assert names.index(nm) == ops["GGML_OP_" + nm] + 2 and got["ops"][names.index(nm)] == ops["GGML_OP_" + nm]
+    # the fork's own ops are unknown to the backend: never supported, never pattern-matched
+    assert got["ops"][ops["GGML_OP_ACC"]] == ops["GGML_OP_COUNT"] and got["ops"][ops["GGML_OP_ACC"] + 1] == ops["GGML_OP_COUNT"]
+    un_names = got["unary_names"]
+    for nm in ("TANH", "GELU", "SILU", "EXP"):
+        assert un_names.index(nm) == un["GGML_UNARY_OP_" + nm] + 1 and got["unary"][un_names.index(nm)] == un["GGML_UNARY_OP_" + nm]
+    assert got["unary"][un["GGML_UNARY_OP_NEG"]] == un["GGML_UNARY_OP_NEG"]  # before the insertion point: unmoved
+
+
+def test_op_enum_mismatch_registers_no_device(sd):
+    """Duplicate / missing names and a renumbered tensor type are refused (tables unchanged, reason reported)."""
+    be = C.CDLL(str(sd.BACKEND_LIB))
+    be.ggml_backend_mi355x_enum_status.restype = C.c_char_p
+    keep = {}
+
+    def FN(f):  # const char* (*)(int) whose strings outlive the call
+        def g(i):
+            v = f(i)
+            if v is None:
+                return None
+            return C.cast(keep.setdefault(v, C.create_string_buffer(v)), C.c_void_p).value
+
+        cb = C.CFUNCTYPE(C.c_void_p, C.c_int)(g)
+        keep[id(cb)] = cb
+        return cb
+
+    before = (C.c_uint8 * 256)()
+    be.ggml_backend_mi355x_get_enum_maps(before, None)
+    dup = FN(lambda i: b"ADD")  # every number is called ADD
+    assert be.ggml_backend_mi355x_resolve_enums(dup, None, None) == -1
+    assert b"both named 'ADD'" in be.ggml_backend_mi355x_enum_status()
+    few = FN(lambda i: [b"NONE", b"DUP", b"ADD"][i] if i < 3 else None)  # a host without MUL_MAT
+    assert be.ggml_backend_mi355x_resolve_enums(few, None, None) == -1
+    assert b"no op named" in be.ggml_backend_mi355x_enum_status()
+    types = FN(lambda i: {0: b"f32", 1: b"f16", 2: b"q8_0"}.get(i, b"?"))  # type 2 is not q4_0
+    assert be.ggml_backend_mi355x_resolve_enums(None, None, types) == -1
+    assert b"ggml_type 2" in be.ggml_backend_mi355x_enum_status()
+    after = (C.c_uint8 * 256)()
+    be.ggml_backend_mi355x_get_enum_maps(after, None)
+    assert list(before) == list(after)
