@@ -2,7 +2,9 @@
 """bench.py — denoise-loop throughput of the MI355X engine on BASELINE.json's metric.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+  N > 1 without a launcher around it: the script re-executes itself as N ranks under torch.distributed.run (one process per GPU, RCCL); launched by
+  `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` it is one of those ranks.  WORLD_SIZE != N is an error, and `n_gpus` in
+  the line is the number of ranks that took part in the closing all-reduce, not the number asked for.
 
 A "step" is one sampler iteration of the hot path over one batch of synthetic input.  Default (device-resident trajectory, SURVEY.md
 section 8 f4): the latents stay in HBM for the whole timed region and every step is ONE graph — x*c_in, the cond AND uncond UNet forwards
@@ -17,18 +19,23 @@ collective => weak scaling: per-GPU batch fixed.
 The JSON line also carries
   roofline:     headline = the dominant kernel family (implicit-GEMM conv, 256-row tiles): achieved = sum of the launches' algorithmic
                 FLOPs (2 * output positions * IC*KH*KW * OC) / sum of their durations, measured live with HIP events recorded on the
-                backend's launch stream around every dispatch INSIDE the timed region, vs the dense f16 MFMA peak (2.5 PFLOP/s,
-                MI355X_MICROARCH.md).  traffic = HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/
-                (FETCH_SIZE doubled per the guide's gfx950 correction + WRITE_SIZE), or null.
+                backend's launch stream around every dispatch, vs the dense f16 MFMA peak (2.5 PFLOP/s, MI355X_MICROARCH.md).  The timed
+                region replays the step's hipGraph (the product default since round 5); events inside a captured graph cannot be read back,
+                so the SAME K steps run once more eagerly right after it with the events on (roofline.timing, eager_ms_per_step);
+                --hip-graph 0 times eager launches and records the events inside the timed region itself.
+                traffic = HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE doubled per the guide's
+                gfx950 correction + WRITE_SIZE) with traffic_commit = the version of that file, or null: never measured in this process.
                 roofline.kernels[] = EVERY kernel family of the step, timed the same way in a short extra pass after the timed region
                 (events around ~800 launches per step would perturb the headline): contraction families against the MFMA peak,
                 layout / norm / elementwise families as algorithmic bytes (one read + one write of the activation) / time against
                 8 TB/s, each with its share of the step's kernel time.
   sdxl / flux / sd35: the other workloads BASELINE.json names (configs 3, 4, 5) on this GPU's share of each configuration, a few device-resident
                 sampler steps after the timed region: ms/step, it/s, whole-step fraction of the MFMA peak, the three heaviest kernel
-                families; sdxl also times the 1024x1024 VAE decode, so its sec_per_image is end to end (30 steps + decode).
+                families; sdxl's sec_per_image is one TIMED sdm_generate_image call (30 steps + 1024x1024 VAE decode + u8 pixels).
+  sdxl_b8:      config 3 at its one-GPU point: the whole batch of 8 SDXL images on this GPU (3 timed steps + one timed generate_image).
   cpu_baseline: the CPU oracle (restatement of the reference ggml-cpu path) timed on this box's host cores on a bounded
-                sample of the same workload (rank 0, N = 1 only).
+                sample of the same workload (rank 0, N = 1 only), with the oracle's default team (<= 16 threads) and with every
+                schedulable CPU; value = the faster.
 """
 from __future__ import annotations
 
@@ -62,7 +69,7 @@ def parse():
     ap.add_argument("--model", default="sd15", choices=["sd15", "sdxl", "sd15_tiny", "sd35", "sd35_tiny", "flux", "flux_tiny"])
     ap.add_argument("--batch", type=int, default=8, help="images per GPU (device batch)")
     ap.add_argument("--no-flash", action="store_true")
-    ap.add_argument("--hip-graph", type=int, default=0)
+    ap.add_argument("--hip-graph", type=int, default=1, help="hipGraph replay of the step's plan (the product default); 0 = eager launches")
     ap.add_argument("--g16-variant", type=int, default=-1, help="gemm16 pipeline variant (A/B measurements)")
     ap.add_argument("--no-fuse-cfg", action="store_true", help="run cond and uncond as two graph computes (the reference's way)")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
@@ -78,43 +85,90 @@ def parse():
     ap.add_argument("--no-sdxl", action="store_true", help="skip the SDXL 1024x1024 sub-record")
     ap.add_argument("--skip-legs", default="", help="comma list of sub-records to skip: sdxl,flux,sd35")
     ap.add_argument("--no-kernels", action="store_true", help="skip the per-kernel-family pass")
+    ap.add_argument("--selftest-cpu", action="store_true",
+                    help="HARNESS SELF-CHECK, not a measurement: run the launch / sharding / reduction logic of this script on the CPU oracle backend "
+                         "with gloo and the tiny UNet (tests/test_dist_shard.py::test_bench_gpus_2_launches_two_ranks)")
     return ap.parse_args()
+
+
+def _file_version(path: Path) -> str:
+    """Commit that last touched a committed profile (git checkout) or the sha1 of its bytes (the GPU box's snapshot has no .git)."""
+    import hashlib
+    import subprocess
+    try:
+        h = subprocess.run(["git", "log", "-1", "--format=%h", "--", str(path)], cwd=ROOT, capture_output=True, text=True, timeout=20).stdout.strip()
+        if h:
+            return "git:" + h
+    except (OSError, subprocess.SubprocessError):
+        pass
+    return "sha1:" + hashlib.sha1(path.read_bytes()).hexdigest()[:12]
+
+
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: re-run this command line as N ranks (one process per GPU) under torch.distributed.run —
+    the way the driver launches N > 1 itself.  Returns the launcher's exit code; rank 0's JSON line passes through on stdout."""
+    import socket
+    import subprocess
+
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           str(Path(__file__).resolve())] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
     args.skip_legs = set(filter(None, args.skip_legs.split(",")))
     args.device_sampler = not args.host_loop
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} (or run `python bench.py --gpus N` and let it launch itself)")
     import torch
     import torch.distributed as dist
 
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the product has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
     import sdcpp_amd as sd
 
-    sd.load_mi355x_backend()
+    selftest = args.selftest_cpu
+    if selftest:
+        # harness self-check on a CPU-only box: same launch / shard / reduce code, the oracle backend instead of the GPU, gloo instead of RCCL
+        args.model, args.no_cpu_baseline, args.no_e2e, args.no_kernels, args.hip_graph = "sd15_tiny", True, True, True, 0
+        args.batch = min(args.batch, 2)
+        sd.load_backend(ROOT / "oracle" / "_build" / "libggml-cpu-oracle.so")
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo")
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (the product has no CPU fallback)")
+        if local_rank >= torch.cuda.device_count():
+            raise SystemExit(f"bench.py: rank {rank} has no GPU of its own (local_rank {local_rank}, {torch.cuda.device_count()} visible): one process per GPU")
+        torch.cuda.set_device(local_rank)
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        sd.load_mi355x_backend()
     L = sd.lib()
     model_id = {"sd15": sd.SD15, "sdxl": sd.SDXL, "sd15_tiny": sd.SD15_TINY, "sd35": sd.SD35_LARGE, "sd35_tiny": sd.SD35_TINY,
                 "flux": sd.FLUX_DEV, "flux_tiny": sd.FLUX_TINY}[args.model]
-    backend_name = f"MI355X{local_rank if local_rank < len([d for d in sd.devices() if d.startswith('MI355X')]) else 0}"
+    backend_name = "CPU-oracle" if selftest else f"MI355X{local_rank}"   # one process per GPU: this rank's own device, never a shared one
     flux = args.model.startswith("flux")
     dit = args.model.startswith("sd35") or flux
     wtype = sd.Q8_0 if args.model == "sdxl" else (sd.Q4_0 if flux else (sd.BF16 if dit else sd.F16))   # BASELINE.json configs 3 / 4 / 5
     eng = sd.Engine(model=model_id, backend=backend_name, wtype=wtype, flash_attn=not args.no_flash)
-    sd.backend_set_option("hip_graph", args.hip_graph)
-    if args.g16_variant >= 0:
-        sd.backend_set_option("gemm16_variant", args.g16_variant)
-    for kv in args.backend_opt:
-        k, v = kv.split("=")
-        sd.backend_set_option(k.strip(), int(v))
+    if not selftest:
+        sd.backend_set_option("hip_graph", args.hip_graph)
+        if args.g16_variant >= 0:
+            sd.backend_set_option("gemm16_variant", args.g16_variant)
+        for kv in args.backend_opt:
+            k, v = kv.split("=")
+            sd.backend_set_option(k.strip(), int(v))
 
     rng = np.random.default_rng(1234 + rank)
     tiny = args.model == "sd15_tiny"
@@ -146,11 +200,15 @@ def main():
             eng.unet_forward(x, t, cond, y)
             eng.unet_forward(x, t, uncond, y)
 
+    def dev_sync():
+        if not selftest:
+            torch.cuda.synchronize()
+
     def barrier():
-        torch.cuda.synchronize()
+        dev_sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        dev_sync()
 
     def trajectory(k):
         # k sampler iterations on the device batch: x*c_in, cond+uncond forward, CFG, Euler(-A) update per step, no host crossing in between
@@ -164,8 +222,12 @@ def main():
         for _ in range(args.warmup):
             step()
     barrier()
-    timing = args.hip_graph == 0  # events cannot be recorded inside a captured graph replay
-    if timing:
+    # Eager launches (hip_graph 0): the dominant family's HIP events are recorded INSIDE the timed region.  hipGraph replay (the product default): events
+    # recorded inside a captured graph cannot be read back on this runtime (scripts/graph_event_probe.hip), so the timed region runs untouched and the
+    # same K steps are repeated eagerly right after it with the events on (roofline.timing says which; eager_ms_per_step is that pass's wall time).
+    timing = not selftest
+    timing_live = timing and args.hip_graph == 0
+    if timing_live:
         sd.kernel_timing_enable(True)
     t0 = time.perf_counter()
     if args.device_sampler:
@@ -175,16 +237,33 @@ def main():
             step()
     barrier()
     dt = time.perf_counter() - t0
-    kt = sd.kernel_timing() if timing else None
-    if timing:
+    kt = sd.kernel_timing() if timing_live else None
+    if timing_live:
+        sd.kernel_timing_enable(False)
+    eager_ms = None
+    if timing and not timing_live:
+        sd.kernel_timing_enable(True)   # plans run eagerly while a family is being timed
+        barrier()
+        t1 = time.perf_counter()
+        if args.device_sampler:
+            trajectory(args.steps)
+        else:
+            for _ in range(args.steps):
+                step()
+        barrier()
+        eager_ms = (time.perf_counter() - t1) / args.steps * 1e3
+        kt = sd.kernel_timing()
         sd.kernel_timing_enable(False)
     per_rank_ms = [round(dt / args.steps * 1e3, 3)]
+    rccl_ranks = 1
     if world > 1:
-        tt = torch.zeros(world, device="cuda", dtype=torch.float64)
+        tt = torch.zeros(world + 1, device="cpu" if selftest else "cuda", dtype=torch.float64)
         tt[rank] = dt
+        tt[world] = 1.0   # one per rank that reached the reduction: n_gpus is what actually ran, not what was asked for
         dist.all_reduce(tt, op=dist.ReduceOp.SUM)
-        per_rank_ms = [round(float(v) / args.steps * 1e3, 3) for v in tt.tolist()]   # stragglers show up here
-        dt = float(tt.max().item())
+        per_rank_ms = [round(float(v) / args.steps * 1e3, 3) for v in tt[:world].tolist()]   # stragglers show up here
+        dt = float(tt[:world].max().item())
+        rccl_ranks = int(round(float(tt[world].item())))
     ms_per_step = dt / args.steps * 1e3
     its = B * world * args.steps / dt
 
@@ -199,7 +278,12 @@ def main():
                          # algorithmic HBM bytes of the same launches: NHWC f16 input image + weight image + f32 output (+ residual), each once
                          "avg_launch_algorithmic_bytes": round(kt["total_bytes"] / kt["launches"]),
                          "share_of_step_time": round(kt["total_ms"] / (dt * 1e3), 4),
-                         "timing": "hipEventElapsedTime around each launch on the launch stream, inside the timed region"})
+                         "timing": ("hipEventElapsedTime around each launch on the launch stream, inside the timed region" if timing_live else
+                                    "hipEventElapsedTime around each launch on the launch stream, over the same K steps repeated EAGERLY right after the timed "
+                                    "region (the timed region replays a hipGraph; events inside a captured graph cannot be read back)")})
+        if eager_ms is not None:
+            roofline["eager_ms_per_step"] = round(eager_ms, 3)
+            roofline["share_of_step_time"] = round(kt["total_ms"] / (eager_ms * args.steps), 4)
         # PMC passes over THIS kernel family (scripts/gpu_round_end3.sh); the newest committed set: profiles/r<round><call>_pmc_traffic_conv256.json
         tfs = sorted((ROOT / "profiles").glob("r[0-9][0-9][a-zA-Z]_pmc_traffic_conv256.json"))
         tf = tfs[-1] if tfs else ROOT / "profiles" / "r04_pmc_traffic_conv256.json"
@@ -207,23 +291,23 @@ def main():
             try:
                 pm = json.loads(tf.read_text())
                 roofline["traffic"] = pm["hbm_bytes_per_launch"]
+                roofline["traffic_measured_in_this_run"] = False  # rocprofv3 --pmc cannot run inside this process: a committed profile of the same command
+                roofline["traffic_commit"] = _file_version(tf)
                 roofline["traffic_source"] = "profiles/" + tf.name + " (kernels matching '" + pm.get("kernel", "") + "', " + str(pm.get("launches_fetch_pass")) + " launches): " + pm.get("source", "")
                 if pm.get("note"):
                     roofline["traffic_note"] = pm["note"]
             except (ValueError, KeyError):
                 pass
-    # what the nominal-peak fraction contains (SQ-level PMC over the dominant launch in isolation, committed profile — not measured in this run)
-    roofline["pmc_dominant_launch"] = {"kernel": "k_conv3w<64,320> (3x3, 320 -> 320 @64x64, 16 images)", "sustained_clock_ghz": 1.61, "matrix_pipe_busy": 0.69,
-                                       "waves_parked_frac": 0.30, "lds_bank_conflicts": 0, "source": "profiles/r05b_pmc_sq_gemm_kernels.txt (rocprofv3 --pmc, three passes)"}
     roofline["whole_step_tflops"] = round(step_tflops, 2)  # all kernels + host graph build + uploads: 2*B*UNet-forward FLOPs / step wall time
     roofline["whole_step_frac"] = round(step_tflops / MFMA_PEAK_TFLOPS, 4)
     if timing and rank == 0 and not args.no_kernels:
         roofline["kernels"] = kernel_families(sd, trajectory if args.device_sampler else None, step)
     out = {
-        "metric": "denoise it/s (image-iterations/s: cond+uncond UNet forwards per image per step)",
+        "metric": ("SELFTEST on the CPU oracle (harness check, NOT a measurement) — " if selftest else "") + "denoise it/s (image-iterations/s: cond+uncond UNet forwards per image per step)",
         "value": round(its, 3),
         "unit": "it/s",
-        "n_gpus": world,
+        "n_gpus": rccl_ranks,
+        "rccl_ranks": rccl_ranks,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3),
@@ -233,6 +317,7 @@ def main():
         "vs_baseline": None,
         "dtype": "f16",
         "data": "synthetic",
+        "devices": [backend_name] if world == 1 else f"one process per GPU: rank r drives MI355X<r> ({world} ranks)",
         "config": {"workload": f"{args.model} {'MMDiT' if dit else 'UNet'} {lat*8}x{lat*8}, {'cfg 1 (distilled guidance 3.5, one forward per step)' if flux else 'cfg 7 (cond+uncond)'}, {'q8_0 Linear + f16 conv' if args.model == 'sdxl' else ('q4_0' if flux else ('bf16' if dit else 'f16'))} weights, batch {B}/GPU, Euler-A step",
                    "global_batch": B * world, "flash_attn": not args.no_flash, "hip_graph": args.hip_graph,
                    "cfg_pair_in_one_graph": fuse, "device_resident_sampler": bool(args.device_sampler),
@@ -254,7 +339,7 @@ def main():
                           "vae_decode_ms": round(st["last_decode_ms"], 1)}
         except Exception as exc:  # the headline line must survive a failure of the extra leg
             out["e2e"] = {"error": str(exc)[:200]}
-    if rank == 0 and world == 1 and args.device_sampler:
+    if rank == 0 and world == 1 and args.device_sampler and not selftest:
         # the PCIe-inclusive rate of the reference's boundary (host buffers in and out every step), for DESIGN.md — never the headline
         step()
         torch.cuda.synchronize()
@@ -266,7 +351,7 @@ def main():
         out["host_loop"] = {"ms_per_step": round(hl * 1e3, 3), "it_per_s": round(B / hl, 2),
                             "note": "cond+uncond forward pair per step from host buffers (x H2D, eps D2H each step); CFG / Euler math on the host is outside this step"}
     if rank == 0 and world == 1 and args.model == "sd15":
-        for leg in ("sdxl", "flux", "sd35"):
+        for leg in ("sdxl", "flux", "sd35", "sdxl_b8"):
             if leg in args.skip_legs or (leg == "sdxl" and args.no_sdxl):
                 continue
             try:
@@ -275,7 +360,9 @@ def main():
                 out[leg] = {"error": str(exc)[:200]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not dit:  # the CPU leg is defined for the headline UNet workloads
         out["cpu_baseline"] = cpu_baseline(sd, args, lat, ctx_dim)
-    if rank == 0:
+    if rank == 0 and selftest:
+        print(json.dumps(out), flush=True)
+    elif rank == 0:
         st = sd.backend_stats()
         out["backend"] = {k: st[k] for k in ("swizzled_weight_bytes", "qgemv_linears", "fgemv_linears", "fused_presilu", "fused_sibling_linears", "hoisted_kv_linears",
                                              "qgemm16_linears", "jit_images", "split_k_gemms", "fused_attention", "generic_matmul", "plans_built", "graph_replays")}
@@ -319,6 +406,7 @@ LEGS = {
     "sdxl": ("SDXL", "Q8_0", 128, 77, 2048, 2816, 4, 1, 6, 30, 7.0, 2),       # config 3: batch 8 over 8 GPUs -> 1 image per GPU
     "flux": ("FLUX_DEV", "Q4_0", 128, 256, 4096, 768, 16, 1, 3, 28, 1.0, 1),   # config 4: one GPU, cfg 1 (distilled guidance 3.5)
     "sd35": ("SD35_LARGE", "BF16", 128, 154, 4096, 2048, 16, 2, 2, 28, 7.0, 2),  # config 5: batch 16 over 8 GPUs -> 2 images per GPU
+    "sdxl_b8": ("SDXL", "Q8_0", 128, 77, 2048, 2816, 4, 8, 3, 30, 7.0, 2),    # config 3 at its ONE-GPU point: the whole batch of 8 on one MI355X
 }
 
 
@@ -333,7 +421,7 @@ def model_leg(sd, backend_name, args, name):
     import torch
 
     mattr, wattr, lat, ntok, cdim, ydim, ch, B, k, cfg_steps, cfg, nfwd = LEGS[name]
-    dit = name != "sdxl"
+    dit = not name.startswith("sdxl")
     t_init = time.perf_counter()
     eng = sd.Engine(model=getattr(sd, mattr), backend=backend_name, wtype=getattr(sd, wattr), flash_attn=not args.no_flash)
     init_s = time.perf_counter() - t_init
@@ -351,8 +439,8 @@ def model_leg(sd, backend_name, args, name):
     eng.sample_latents(cond, unc, steps=k, **kw)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / k * 1e3
-    tfl = nfwd * B * UNET_FWD_TFLOP[name] / (ms / 1e3)
-    res = {"workload": f"{name} 1024x1024, {'cfg 1 (one forward per step)' if nfwd == 1 else 'cfg 7 (cond+uncond in one graph)'}, {wattr.lower()} Linear weights, "
+    tfl = nfwd * B * UNET_FWD_TFLOP[name.split("_")[0]] / (ms / 1e3)
+    res = {"workload": f"{name.split('_')[0]} 1024x1024, {'cfg 1 (one forward per step)' if nfwd == 1 else 'cfg 7 (cond+uncond in one graph)'}, {wattr.lower()} Linear weights, "
                        f"batch {B}/GPU, {'Euler' if dit else 'Euler-A'} step, device-resident",
            "steps_timed": k, "ms_per_step": round(ms, 2), "it_per_s": round(B * 1e3 / ms, 3), "whole_step_tflops": round(tfl, 1),
            "whole_step_frac": round(tfl / MFMA_PEAK_TFLOPS, 4), "engine_init_s": round(init_s, 1)}
@@ -372,9 +460,11 @@ def model_leg(sd, backend_name, args, name):
                         "frac": round(ach / (MFMA_PEAK_TFLOPS if mf else HBM_PEAK_GBS), 4)})
         res["kernels"] = top
         res["kernel_ms_per_step"] = round(tot, 2)
-    if name == "sdxl":   # the end-to-end half of the metric: 30 sampler steps + the 128x128 -> 1024x1024 VAE decode (10.47 TFLOP)
+    if name.startswith("sdxl"):
+        # the end-to-end half of the metric, TIMED (VERDICT r4 missing #3): one sdm_generate_image call = noise -> 30 Euler-A steps (cond + uncond, cfg 7) ->
+        # 128x128 -> 1024x1024 VAE decode (10.47 TFLOP per image; Conv2d scale 1/32 like the reference without --vae) -> u8 pixels on the host
         z = rng.standard_normal((B, ch, lat, lat)).astype(np.float32)
-        eng.vae_decode(z)
+        eng.vae_decode(z)   # untimed: builds the VAE weight images and plan
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         eng.vae_decode(z)
@@ -382,8 +472,14 @@ def model_leg(sd, backend_name, args, name):
         dec = (time.perf_counter() - t0) * 1e3
         res["vae_decode_ms"] = round(dec, 1)
         res["vae_decode_frac"] = round(VAE_DECODE_TFLOP_1024 * B / (dec / 1e3) / MFMA_PEAK_TFLOPS, 4)
-        res["sec_per_image"] = round((cfg_steps * ms + dec) / 1e3 / B, 3)
-        res["sec_per_image_note"] = f"{cfg_steps} sampler steps x ms_per_step + VAE decode (host pixel conversion excluded), per image"
+        t0 = time.perf_counter()
+        img = eng.generate_image(cond, uncond, steps=cfg_steps, **kw)
+        e2e = time.perf_counter() - t0
+        st = eng.stats()
+        assert img.shape == (B, lat * 8, lat * 8, 3)
+        res["sec_per_image"] = round(e2e / B, 4)
+        res["e2e"] = {"timed": True, "batch": B, "steps": cfg_steps, "wall_s": round(e2e, 3), "sample_ms": round(st["last_sample_ms"], 1),
+                      "vae_decode_ms": round(st["last_decode_ms"], 1), "note": "one sdm_generate_image call: noise, sampler steps, VAE decode, u8 conversion"}
     else:
         res["sec_per_image_denoise"] = round(cfg_steps * ms / 1e3 / B, 3)
     st1 = sd.backend_stats()
@@ -435,18 +531,34 @@ def cpu_baseline(sd, args, lat, ctx_dim):
     t = np.full((1,), 500.0, dtype=np.float32)
     ctx = rng.standard_normal((1, 77, ctx_dim)).astype(np.float32)
     y = rng.standard_normal((1, 2816)).astype(np.float32) if args.model == "sdxl" else None
-    n = 0
-    t0 = time.perf_counter()
-    while True:
-        eng.unet_forward(x, t, ctx, y)
-        n += 1
-        el = time.perf_counter() - t0
-        if el > args.cpu_baseline_seconds or n >= 8:
-            break
-    fwd_s = el / n
-    return {"value": round(1.0 / (2 * fwd_s), 5), "unit": "it/s", "cores": cores, "kind": "port", "host": host,
-            "sample": f"{n} UNet forward(s) of 1 image ({args.model}, latent {lat}x{lat}) in {el:.1f}s; one it = 2 forwards (cfg 7)",
-            "sec_per_forward": round(fwd_s, 3)}
+    olib.oracle_set_num_threads.restype = C.c_int
+
+    def timed(budget_s):
+        n = 0
+        t0 = time.perf_counter()
+        while True:
+            eng.unet_forward(x, t, ctx, y)
+            n += 1
+            el = time.perf_counter() - t0
+            if el > budget_s or n >= 8:
+                return n, el
+
+    # two team sizes: the oracle's default (<= 16 threads: the team the parity tests use) and every CPU this process may be
+    # scheduled on (affinity mask and cgroup quota).  `value` / `cores` = the faster of the two; both are listed.
+    runs = []
+    n, el = timed(args.cpu_baseline_seconds / 2)
+    runs.append({"cores": cores, "it_per_s": round(n / (2 * el), 5), "sec_per_forward": round(el / n, 3), "forwards": n})
+    all_cpus = int(olib.oracle_set_num_threads(0))
+    if all_cpus > cores:
+        eng.unet_forward(x, t, ctx, y)  # untimed: the bigger team's threads start
+        n2, el2 = timed(args.cpu_baseline_seconds / 2)
+        runs.append({"cores": all_cpus, "it_per_s": round(n2 / (2 * el2), 5), "sec_per_forward": round(el2 / n2, 3), "forwards": n2})
+    olib.oracle_set_num_threads(cores)
+    best = max(runs, key=lambda r: r["it_per_s"])
+    return {"value": best["it_per_s"], "unit": "it/s", "cores": best["cores"], "kind": "port", "host": host, "team_sizes": runs,
+            "sample": f"{best['forwards']} UNet forward(s) of 1 image ({args.model}, latent {lat}x{lat}) on {best['cores']} threads; one it = 2 forwards (cfg 7); "
+                      f"`cores` are schedulable hardware threads (the OpenMP team size), the host has {host.get('physical_cores')} physical cores",
+            "sec_per_forward": best["sec_per_forward"]}
 
 
 if __name__ == "__main__":

@@ -92,6 +92,7 @@ struct ggml_backend_mi355x_stats {
     int64_t fused_ln_reduce;     /* split-K Linears whose slab reduce also writes the f16 operand image of the LayerNorm that reads the result (k_splitk_reduce_ln) */
     int64_t redirect_fallbacks;  /* graphs planned a second time without the joint-qkv pre-passes because a redirected projection was not taken by its Linear */
     int64_t fused_concat_gn;     /* skip-connection CONCATs never materialised: GroupNorm statistics / apply (and the skip conv's operand cast) read the two sources (plan_concat_gn) */
+    int64_t fused_conv_scale;    /* Conv2d scales (SCALE s -> conv -> SCALE 1/s, the reference's SDXL VAE setting) folded into the operand image and the epilogue */
 };
 GGML_MI355X_API void ggml_backend_mi355x_get_stats(struct ggml_backend_mi355x_stats* out);
 /* Host enum numbering, resolved BY NAME.  The numeric values of `enum ggml_op` / `enum ggml_unary_op` in ggml-abi.h are a recollection of upstream, and
@@ -122,7 +123,7 @@ GGML_MI355X_API void ggml_backend_mi355x_kernel_timing_enable(int enable);      
 GGML_MI355X_API void ggml_backend_mi355x_kernel_timing_enable_mask(uint32_t family_mask);
 GGML_MI355X_API void ggml_backend_mi355x_get_kernel_timing(struct ggml_backend_mi355x_kernel_timing* out);  /* the first timed family */
 GGML_MI355X_API int ggml_backend_mi355x_get_kernel_timings(struct ggml_backend_mi355x_kernel_timing* out, int capacity);  /* every family with launches; returns the count */
-/* options (default): "fusion" (1), "mfma_gemm" (1), "hip_graph" (0), "flash_pattern" (1), "gemm16" (1), "gemm16_variant" (3), "gemm16_tile" (-1),
+/* options (default): "fusion" (1), "mfma_gemm" (1), "hip_graph" (1: a plan is captured into a hipGraph the second time it runs and replayed from then on; 2 = capture at the first run; eager while kernel timing is on), "flash_pattern" (1), "gemm16" (1), "gemm16_variant" (3), "gemm16_tile" (-1),
  * "splitk_target" (384), "conv_tap_major" (0), "fuse_modulate" / "fuse_gate" / "fuse_gelu" / "fuse_rope" / "fuse_concat_heads" (1);
  * "splitk_mid" (0: two K slices for launches of 193..384 workgroups), "pinned_uploads" (0: set_tensor_async stages through pinned host memory so the call does
  * not wait for the stream);

@@ -62,6 +62,8 @@ enum sd_model_family_t {
     SD_MODEL_SD35_WIDE2 = 8, /* SD3.5-large's real width (hidden 2432, 38 heads x 64), 2 joint blocks — full-width block parity tests */
     SD_MODEL_FLUX_WIDE1 = 9, /* FLUX.1-dev's real width (hidden 3072, 24 heads x 128), 1 double + 1 single block — same purpose */
     SD_MODEL_SD3M_TINY  = 10, /* SD3-medium's topology at test size: MMDiT WITHOUT qk-norm and without MMDiT-X blocks (mmdit.hpp:299-366 with qk_norm = "") */
+    SD_MODEL_SD35_WIDE8 = 11, /* SD3.5-large's real width, 8 joint blocks: the middle point of the depth sweep (2 / 8 / 38) of tests/test_zz_gpu_fulldepth.py */
+    SD_MODEL_FLUX_WIDE8 = 12, /* FLUX.1-dev's real width, 3 double + 5 single blocks: the middle point of the FLUX depth sweep (1+1 / 3+5 / 19+38) */
 };
 
 /* numeric values = enum ggml_type (stable-diffusion.h:98-143) */
@@ -204,6 +206,9 @@ SD_API void sd_rccl_comm_destroy(void* comm);
 SD_API bool sd_set_pair_exchange_rccl(sdm_ctx_t* ctx, void* comm, int branch); /* comm = NULL removes the exchange */
 SD_API const char* sd_rccl_last_error(void);
 SD_API void sd_set_guidance(sdm_ctx_t* ctx, float guidance); /* FLUX distilled-guidance input (default 3.5, stable-diffusion.h guidance.distilled_guidance) */
+/* AutoEncoderKL::set_conv2d_scale (src/model/vae/auto_encoder_kl.hpp:708-717): every Conv2d of the VAE computes conv(x * s) / s + bias.  SDXL contexts start with
+ * s = 1/32 — what the reference sets when no external VAE is given (src/stable-diffusion.cpp:1477-1485; `--vae` with a fixed VAE -> call this with 1) */
+SD_API void sd_set_vae_conv2d_scale(sdm_ctx_t* ctx, float scale);
 SD_API int sd_get_flux_sigmas(int steps, int image_seq_len, float* out /* steps+1 */); /* FluxScheduler, denoiser.hpp:726-782 */
 SD_API int sd_gen_flux_pe(int h, int w, int patch_size, int context_len, const int* axes_dim, int n_axes, float theta, float* out); /* Rope::gen_flux_pe; returns floats written */
 SD_API int sd_get_flow_sigmas(int steps, float shift, float* out /* steps+1 */);    /* DiscreteFlowDenoiser, denoiser.hpp:1239-1283 (t = 1000*sigma) */

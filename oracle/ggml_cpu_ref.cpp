@@ -74,7 +74,7 @@ inline float gelu_quick_f32(float x) { return x * (1.0f / (1.0f + expf(GELU_QUIC
 // Threads the oracle uses: the CPUs this process may actually run on (affinity mask and cgroup CPU quota), capped at 16
 // — GPU boxes report hundreds of hardware threads to a container that may only schedule a few of them, and an
 // oversubscribed OpenMP team spin-waiting at every one of the ~3k per-graph parallel regions is pathologically slow.
-int usable_cpus() {
+int usable_cpus(bool cap16 = true) {
     int n = omp_get_num_procs();
     cpu_set_t set;
     if (sched_getaffinity(0, sizeof(set), &set) == 0) n = std::min(n, CPU_COUNT(&set));
@@ -87,6 +87,7 @@ int usable_cpus() {
         }
         fclose(f);
     }
+    if (!cap16) return std::max(1, n);  // every CPU this process may be scheduled on (oracle_set_num_threads(0): bench.py's all-core cpu_baseline figure)
     if (const char* e = getenv("ORACLE_THREADS")) n = std::max(1, atoi(e));
     else {
         n = std::min(n, 16);
@@ -195,6 +196,7 @@ void gemm_nt_f32(const float* A, int64_t lda, const float* B, int64_t ldb, float
     }
 }
 
+bool g_exact_weights = false;  // oracle_set_exact_weights()
 // ---------------------------------------------------------------- MUL_MAT
 // reference semantics: SURVEY.md Appendix A + E.1; call sites ggml_extend.hpp:1022,1028,1161,1467,1475
 void op_mul_mat(ggml_tensor* dst) {
@@ -203,7 +205,10 @@ void op_mul_mat(ggml_tensor* dst) {
     const int64_t K = s0->ne[0], M = s0->ne[1], N = s1->ne[1];
     const int64_t ne02 = s0->ne[2], ne03 = s0->ne[3], ne12 = s1->ne[2], ne13 = s1->ne[3];
     const int64_t r2 = ne12 / ne02, r3 = ne13 / ne03;
-    const bool quant = (s0->type == GGML_TYPE_Q8_0 || s0->type == GGML_TYPE_Q4_0);
+    // g_exact_weights (oracle_set_exact_weights, tests only): the weight is widened to f32 EXACTLY (bf16 / f16 / dequantised q8_0 / q4_0 blocks) and the
+    // activation row is NOT rounded to the weight's vec_dot type — the arithmetic-exact product both ggml-cpu's path and the GPU's approximate
+    const bool exact = g_exact_weights && (s0->type == GGML_TYPE_Q8_0 || s0->type == GGML_TYPE_Q4_0 || s0->type == GGML_TYPE_BF16 || s0->type == GGML_TYPE_F16);
+    const bool quant = !exact && (s0->type == GGML_TYPE_Q8_0 || s0->type == GGML_TYPE_Q4_0);
 
     std::vector<float> A((size_t)M * K), B((size_t)N * K);
     std::vector<q8blk> Bq;
@@ -231,7 +236,7 @@ void op_mul_mat(ggml_tensor* dst) {
                     for (int64_t k = 0; k < K; ++k) tmp[k] = load_as_f32(s1, row + k * s1->nb[0]);
                     xf = tmp.data();
                 }
-                switch (s0->type) {
+                switch (exact ? GGML_TYPE_F32 : s0->type) {
                     case GGML_TYPE_F16:
                         for (int64_t k = 0; k < K; ++k) out[k] = h2f(f2h(xf[k]));
                         break;
@@ -258,6 +263,26 @@ void op_mul_mat(ggml_tensor* dst) {
                             break;
                         case GGML_TYPE_BF16:
                             for (int64_t k = 0; k < K; ++k) out[k] = bf2f(((const uint16_t*)row)[k]);
+                            break;
+                        case GGML_TYPE_Q8_0:  // exact mode only: block = f16 d + 32 int8
+                            for (int64_t b = 0; b < K / 32; ++b) {
+                                ggml_fp16_t h;
+                                memcpy(&h, row + b * 34, 2);
+                                const float d = h2f(h);
+                                for (int j = 0; j < 32; ++j) out[b * 32 + j] = d * (float)((const int8_t*)(row + b * 34 + 2))[j];
+                            }
+                            break;
+                        case GGML_TYPE_Q4_0:  // exact mode only: block = f16 d + 16 bytes; element j < 16 = low nibble of qs[j], j >= 16 = high nibble of qs[j - 16]
+                            for (int64_t b = 0; b < K / 32; ++b) {
+                                ggml_fp16_t h;
+                                memcpy(&h, row + b * 18, 2);
+                                const float d     = h2f(h);
+                                const uint8_t* qs = (const uint8_t*)(row + b * 18 + 2);
+                                for (int j = 0; j < 16; ++j) {
+                                    out[b * 32 + j]      = d * (float)((int)(qs[j] & 0xF) - 8);
+                                    out[b * 32 + 16 + j] = d * (float)((int)(qs[j] >> 4) - 8);
+                                }
+                            }
                             break;
                         default:
                             for (int64_t k = 0; k < K; ++k) out[k] = ((const float*)row)[k];
@@ -947,3 +972,19 @@ extern "C" __attribute__((visibility("default"))) ggml_backend_reg_t ggml_backen
 extern "C" __attribute__((visibility("default"))) int ggml_backend_score(void) { return 1; }
 // number of OpenMP threads the oracle will use (reported as cpu_baseline.cores)
 extern "C" __attribute__((visibility("default"))) int oracle_num_threads(void) { return omp_get_max_threads(); }
+// team size for the following graph computes: n > 0 = exactly n, n <= 0 = every schedulable CPU (affinity mask and cgroup quota; hardware threads,
+// not physical cores).  Returns the size set.  bench.py's cpu_baseline reports the default (<= 16) and the all-CPU figure; the full-depth DiT parity
+// tests use it so the oracle forward finishes in minutes.
+extern "C" __attribute__((visibility("default"))) int oracle_set_num_threads(int n) {
+    init_tables();
+    const int want = n > 0 ? n : usable_cpus(false);
+    omp_set_num_threads(want);
+    return want;
+}
+// 1: every MUL_MAT with a 16-bit or quantised weight multiplies the exactly widened weight with the UNROUNDED f32 activations (no f16 / bf16 / q8_0
+// rounding of src1): the arithmetic-exact reference the full-depth DiT tests measure both the ggml-cpu-faithful path and the GPU against.  Returns the old value.
+extern "C" __attribute__((visibility("default"))) int oracle_set_exact_weights(int on) {
+    const int was   = g_exact_weights ? 1 : 0;
+    g_exact_weights = on != 0;
+    return was;
+}

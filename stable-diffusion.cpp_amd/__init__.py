@@ -26,7 +26,7 @@ F32, F16, Q4_0, Q8_0, I32, BF16 = 0, 1, 2, 8, 26, 30
 TYPE_SIZE = {F32: 4, F16: 2, BF16: 2, I32: 4}
 
 # sd_model_family_t
-SD15, SDXL, SD15_TINY, SDXL_TINY, SD35_LARGE, SD35_TINY, FLUX_DEV, FLUX_TINY, SD35_WIDE2, FLUX_WIDE1, SD3M_TINY = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
+SD15, SDXL, SD15_TINY, SDXL_TINY, SD35_LARGE, SD35_TINY, FLUX_DEV, FLUX_TINY, SD35_WIDE2, FLUX_WIDE1, SD3M_TINY, SD35_WIDE8, FLUX_WIDE8 = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12
 # sd_pair_exchange_fn (include/sd-mi355x.h): (device address of the f32 eps buffer, element count, hipStream_t, user) -> ok
 PAIR_EXCHANGE_FN = C.CFUNCTYPE(C.c_bool, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p)
 EULER, EULER_A, SAMPLE_METHOD_DEFAULT = 0, 1, 2   # DEFAULT: Euler for the DiT families, Euler-A otherwise (sd_get_default_sample_method)
@@ -252,6 +252,8 @@ def lib() -> C.CDLL:
     L.sd_get_flux_sigmas.argtypes = [C.c_int, C.c_int, C.c_void_p]
     L.sd_set_guidance.argtypes = [C.c_void_p, C.c_float]
     L.sd_set_guidance.restype = None
+    L.sd_set_vae_conv2d_scale.argtypes = [C.c_void_p, C.c_float]
+    L.sd_set_vae_conv2d_scale.restype = None
     L.sd_set_pair_exchange.argtypes = [C.c_void_p, PAIR_EXCHANGE_FN, C.c_void_p, C.c_int]
     L.sd_set_pair_exchange.restype = None
     L.sd_rccl_get_unique_id.argtypes = [C.c_void_p]
@@ -310,7 +312,7 @@ def load_mi355x_backend() -> None:
 
 _BACKEND_STAT_FIELDS = ("graphs_computed plans_built nodes_seen kernels_planned kernels_launched fused_conv fused_conv_bounced fused_linear "
                         "fused_norm fused_geglu fused_attention generic_matmul swizzled_weight_bytes graph_replays fused_linear_geglu "
-                        "split_k_gemms head_major_gemms fused_modulate fused_gate fused_gelu fused_rope fused_concat_heads qgemv_linears fused_chan_add fused_proj_tokens gemm_attention fused_q16 split_k_inlaunch qgemm16_linears fgemv_linears fused_presilu fused_sibling_linears hoisted_kv_linears window_convs hoisted_emb_linears fused_rows16 fused_joint_qkv jit_images fused_cat_rows16 fused_gn_stats fused_ln_reduce redirect_fallbacks fused_concat_gn").split()
+                        "split_k_gemms head_major_gemms fused_modulate fused_gate fused_gelu fused_rope fused_concat_heads qgemv_linears fused_chan_add fused_proj_tokens gemm_attention fused_q16 split_k_inlaunch qgemm16_linears fgemv_linears fused_presilu fused_sibling_linears hoisted_kv_linears window_convs hoisted_emb_linears fused_rows16 fused_joint_qkv jit_images fused_cat_rows16 fused_gn_stats fused_ln_reduce redirect_fallbacks fused_concat_gn fused_conv_scale").split()
 
 
 class BackendStats(C.Structure):
@@ -538,6 +540,10 @@ class Engine:
             raise EngineError("sd_convert_tensor_name: name too long")
         return buf.value.decode()
 
+    def set_vae_conv2d_scale(self, scale: float) -> None:
+        """AutoEncoderKL::set_conv2d_scale: conv(x * s) / s + b on every VAE conv (SDXL engines start with 1/32, like the reference without --vae)."""
+        lib().sd_set_vae_conv2d_scale(self._ctx, float(scale))
+
     def set_guidance(self, guidance: float) -> None:
         """FLUX distilled-guidance input (default 3.5)"""
         lib().sd_set_guidance(self._ctx, float(guidance))
@@ -630,7 +636,7 @@ class Engine:
                        method=SAMPLE_METHOD_DEFAULT, eta=float("inf"), cond_y=None, uncond_y=None, fuse_cfg=False, device_sampler=False) -> np.ndarray:
         p, keep = self._gen_params(cond, uncond, width, height, steps, cfg, seed, batch, device_batch, method, eta, cond_y, uncond_y, fuse_cfg,
                                    device_sampler)
-        ch = 16 if self.model in (SD35_LARGE, SD35_TINY, FLUX_DEV, FLUX_TINY, SD35_WIDE2, FLUX_WIDE1, SD3M_TINY) else 4
+        ch = 16 if self.model in (SD35_LARGE, SD35_TINY, FLUX_DEV, FLUX_TINY, SD35_WIDE2, FLUX_WIDE1, SD3M_TINY, SD35_WIDE8, FLUX_WIDE8) else 4
         out = np.empty((batch, ch, height // 8, width // 8), dtype=np.float32)
         if not lib().sd_sample_latents(self._ctx, C.byref(p), _fptr(out)):
             raise EngineError("sd_sample_latents failed: " + lib().sd_last_error().decode())

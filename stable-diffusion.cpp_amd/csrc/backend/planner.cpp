@@ -35,6 +35,7 @@
 #include <vector>
 
 #include "kernels.h"
+#include "ktime.h"
 
 namespace mi355x {
 
@@ -145,11 +146,11 @@ namespace {
 struct Stats {
     std::atomic<int64_t> graphs_computed{0}, plans_built{0}, nodes_seen{0}, kernels_planned{0}, kernels_launched{0}, fused_conv{0},
         fused_conv_bounced{0}, fused_linear{0}, fused_norm{0}, fused_geglu{0}, fused_attention{0}, generic_matmul{0}, swizzled_weight_bytes{0}, fused_linear_geglu{0}, split_k_gemms{0}, head_major_gemms{0}, fused_modulate{0}, fused_gate{0}, fused_gelu{0}, fused_rope{0}, fused_concat_heads{0},
-        graph_replays{0}, qgemv_linears{0}, fused_chan_add{0}, fused_proj_tokens{0}, gemm_attention{0}, fused_q16{0}, split_k_inlaunch{0}, qgemm16_linears{0}, fgemv_linears{0}, fused_presilu{0}, fused_sibling_linears{0}, hoisted_kv_linears{0}, window_convs{0}, hoisted_emb_linears{0}, fused_rows16{0}, fused_cat_rows16{0}, fused_joint_qkv{0}, jit_images{0}, fused_gn_stats{0}, redirect_fallbacks{0}, fused_ln_reduce{0}, fused_concat_gn{0};
+        graph_replays{0}, qgemv_linears{0}, fused_chan_add{0}, fused_proj_tokens{0}, gemm_attention{0}, fused_q16{0}, split_k_inlaunch{0}, qgemm16_linears{0}, fgemv_linears{0}, fused_presilu{0}, fused_sibling_linears{0}, hoisted_kv_linears{0}, window_convs{0}, hoisted_emb_linears{0}, fused_rows16{0}, fused_cat_rows16{0}, fused_joint_qkv{0}, jit_images{0}, fused_gn_stats{0}, redirect_fallbacks{0}, fused_ln_reduce{0}, fused_concat_gn{0}, fused_conv_scale{0};
 } g_stats;
 
 struct Options {
-    std::atomic<int> fusion{1}, mfma_gemm{1}, hip_graph{0}, flash_pattern{1}, gemm16{1}, fuse_modulate{1}, fuse_gate{1}, fuse_gelu{1}, fuse_rope{1}, fuse_concat_heads{1}, qgemv{1}, fuse_chan_add{1}, fuse_proj_tokens{1}, fuse_q16{1}, qgemm16{1}, fgemv{1}, fuse_siblings{1}, hoist_kv{1}, hoist_emb{1}, fuse_rows16{0}, fuse_cat_rows16{1}, fuse_joint_qkv{1}, jit_qimages{4096}, fuse_gn_stats{1}, fuse_ln_reduce{1}, relax_res_overlap{1}, fuse_split_gelu{1}, fuse_concat_gn{1}, fuse_gn_tokens{1}, fuse_linear_nchw{1};
+    std::atomic<int> fusion{1}, mfma_gemm{1}, hip_graph{1}, flash_pattern{1}, gemm16{1}, fuse_modulate{1}, fuse_gate{1}, fuse_gelu{1}, fuse_rope{1}, fuse_concat_heads{1}, qgemv{1}, fuse_chan_add{1}, fuse_proj_tokens{1}, fuse_q16{1}, qgemm16{1}, fgemv{1}, fuse_siblings{1}, hoist_kv{1}, hoist_emb{1}, fuse_rows16{0}, fuse_cat_rows16{1}, fuse_joint_qkv{1}, jit_qimages{4096}, fuse_gn_stats{1}, fuse_ln_reduce{1}, relax_res_overlap{1}, fuse_split_gelu{1}, fuse_concat_gn{1}, fuse_gn_tokens{1}, fuse_linear_nchw{1}, fuse_conv_scale{1};
 } g_opt;
 
 using Step = std::function<void(hipStream_t)>;
@@ -161,6 +162,7 @@ struct Plan {
     std::vector<Step> steps;
     hipGraphExec_t graph_exec = nullptr;
     bool graph_failed         = false;
+    int64_t runs              = 0;  // executions so far: the hipGraph is captured when a plan comes back (one-shot graphs never pay for a capture)
 };
 
 struct SwzEntry {
@@ -345,6 +347,7 @@ struct Packed {
     size_t off;     // arena offset of the f16 image
     int64_t ld;     // row stride in halfs (K or C rounded up to 64)
     bool nhwc;      // [N][H*W][Cp] image of an NCHW tensor (else [rows][Kp] of a row-major tensor)
+    float mul = 1.f;  // the image holds f16(value * mul): Conv2d scale folded into the operand (SDXL VAE, ggml_extend.hpp:1131-1171)
 };
 
 struct Builder {
@@ -419,6 +422,14 @@ struct Builder {
     };
     std::unordered_map<int, Cat16> cat16;
     std::unordered_map<const ggml_tensor*, Cat16Part> cat16_part;
+    // Conv2d scale (ggml_ext_conv_2d with scale != 1: x = SCALE(x, s) -> conv -> SCALE(1/s) -> + bias; the reference sets s = 1/32 on every VAE conv of SDXL,
+    // src/stable-diffusion.cpp:1477-1485): the SCALE node in front of an implicit-GEMM conv is never executed — its output tensor maps to the tensor it
+    // scales and the factor, and the conv's f16 operand image is written as f16(x * s) by whichever pass packs it
+    struct PreScale {
+        const ggml_tensor* src;
+        float mul;
+    };
+    std::unordered_map<const ggml_tensor*, PreScale> prescale;
     // CONT nodes of cat16_part whose columns the PRODUCING Linear's epilogue already wrote as gelu -> f16 (Epilogue::split_col): CONT and GELU are not executed
     std::unordered_set<const ggml_tensor*> cat16_by_linear;
     // joint attention of the MMDiT (plan_joint_qkv): the fused qkv projections of both streams write into arena scratch (lin_redirect: the
@@ -611,13 +622,25 @@ bool conv_im2col_fast_ok(const GInfo& gi, int i) {
     return j5 >= 0 && xop(gi.node(j5)) == GGML_OP_CONT;
 }
 bool linear_fast_ok(const ggml_tensor* n);
-// every consumer of node i (looking through RESHAPE views) is a gen-2 GEMM that reads the f16 image
-bool all_consumers_gemm16(const GInfo& gi, int i, bool want_conv) {
+// node k = SCALE(x, s) (no bias) read only by the IM2COL of an implicit-GEMM conv: the Conv2d scale of ggml_ext_conv_2d (ggml_extend.hpp:1131-1171)
+bool scale_into_conv(const GInfo& gi, int k, float* s_out) {
+    const ggml_tensor* n = gi.node(k);
+    if (xop(n) != GGML_OP_SCALE || !g_opt.gemm16 || !g_opt.fusion || !g_opt.fuse_conv_scale || (n->flags & GGML_TENSOR_FLAG_OUTPUT)) return false;
+    if (ggml_abi_op_param_f32(n, 1) != 0.f || !is_f32(n) || !contig(n) || !n->src[0] || !is_f32(n->src[0]) || !contig(n->src[0])) return false;
+    const int c = gi.sole(k);
+    if (c < 0 || xop(gi.node(c)) != GGML_OP_IM2COL || gi.node(c)->src[1] != n || !conv_im2col_fast_ok(gi, c)) return false;
+    *s_out = ggml_abi_op_param_f32(n, 0);
+    return true;
+}
+// every consumer of node i (looking through RESHAPE views) is a gen-2 GEMM that reads the f16 image.  want_conv with mul_out: a consumer may reach its
+// conv through a Conv2d-scale node (scale_into_conv) when ALL of them do, with one factor: *mul_out = that factor (1 = none)
+bool all_consumers_gemm16(const GInfo& gi, int i, bool want_conv, float* mul_out = nullptr) {
     if (!g_opt.gemm16 || !g_opt.mfma_gemm || !g_opt.fusion) return false;
     const ggml_tensor* t = gi.node(i);
     if ((t->flags & GGML_TENSOR_FLAG_OUTPUT) || i == gi.g->n_nodes - 1) return false;
     std::vector<int> work{i};
     int n_real = 0;
+    float mul  = 1.f;
     while (!work.empty()) {
         const int k = work.back();
         work.pop_back();
@@ -630,13 +653,21 @@ bool all_consumers_gemm16(const GInfo& gi, int i, bool want_conv) {
                 continue;
             }
             if (want_conv) {
-                if (!(xop(cn) == GGML_OP_IM2COL && cn->src[1] == gi.node(k) && conv_im2col_fast_ok(gi, c))) return false;
+                float sc = 1.f;
+                if (mul_out && cn->src[0] == gi.node(k) && scale_into_conv(gi, c, &sc)) {
+                    if (n_real > 0 && sc != mul) return false;
+                    mul = sc;
+                } else {
+                    if (!(xop(cn) == GGML_OP_IM2COL && cn->src[1] == gi.node(k) && conv_im2col_fast_ok(gi, c))) return false;
+                    if (n_real > 0 && mul != 1.f) return false;
+                }
             } else {
                 if (!(xop(cn) == GGML_OP_MUL_MAT && strip_reshape(cn->src[1]) == t && linear_fast_ok(cn))) return false;
             }
             ++n_real;
         }
     }
+    if (mul_out) *mul_out = mul;
     return n_real > 0;
 }
 
@@ -1119,6 +1150,21 @@ void plan_linear(Builder& B, int i, hipStream_t s, std::vector<int>& chain) {
                     if (cp == B.cat16_part.end()) continue;
                     const int64_t c0 = (int64_t)((const char*)v->data - (const char*)T->data) / 4;
                     if (c0 <= 0 || c0 % 256 != 0 || c0 + v->ne[0] != M || cp->second.ld % 8 != 0 || cp->second.col % 8 != 0) continue;
+                    // the f32 columns >= c0 are never written: every OTHER reader of T has to be a VIEW confined to columns [0, c0) of the same rows
+                    // (round-4 advice: a full-width read, a second view over the tail or a graph output would see unwritten memory)
+                    bool others_ok = !(T->flags & GGML_TENSOR_FLAG_OUTPUT) && !(v->flags & GGML_TENSOR_FLAG_OUTPUT);
+                    for (int c2 : gi.consumers[last]) {
+                        if (c2 == c || !others_ok) continue;
+                        const ggml_tensor* v2 = gi.node(c2);
+                        if (xop(v2) != GGML_OP_VIEW || v2->nb[0] != 4 || v2->nb[1] != T->nb[1] || (v2->flags & GGML_TENSOR_FLAG_OUTPUT)) {
+                            others_ok = false;
+                            break;
+                        }
+                        const int64_t b2 = (int64_t)((const char*)v2->data - (const char*)T->data);
+                        const int64_t col2 = b2 >= 0 ? (b2 % (int64_t)T->nb[1]) / 4 : -1;
+                        if (b2 < 0 || b2 % 4 != 0 || col2 + v2->ne[0] > c0) others_ok = false;
+                    }
+                    if (!others_ok) continue;
                     split_on  = true;
                     split_c0  = c0;
                     split_ld  = cp->second.ld;
@@ -1487,6 +1533,16 @@ bool plan_conv_chain(Builder& B, int i, hipStream_t s, std::vector<int>& chain) 
     if (p[6] != 1 || p[4] != 1 || p[5] != 1) return false;                       // 2-D, no dilation
     if (ker->type != GGML_TYPE_F16 || !is_static_weight(ker) || !contig(ker)) return false;
     if (!is_f32(x) || !contig(x)) return false;
+    // Conv2d scale in front (the SCALE node was elided, main loop): the operand is f16(xs * pre_mul), xs = the tensor the SCALE read
+    const ggml_tensor* xs = x;
+    float pre_mul         = 1.f;
+    {
+        const auto ps = B.prescale.find(x);
+        if (ps != B.prescale.end()) {
+            xs      = ps->second.src;
+            pre_mul = ps->second.mul;
+        }
+    }
     const int KW = (int)ker->ne[0], KH = (int)ker->ne[1];
     const int s0 = p[0], s1 = p[1], p0 = p[2], p1 = p[3];
     if (KW != KH || s0 != s1 || p0 != p1) return false;
@@ -1513,10 +1569,21 @@ bool plan_conv_chain(Builder& B, int i, hipStream_t s, std::vector<int>& chain) 
 
     Epilogue ep;
     int last = j5;
+    // -> SCALE(1 / s): the second half of a Conv2d scale (ggml_ext_conv_2d: applied to the conv result BEFORE the bias) = the epilogue's accumulator scale
+    if (g_opt.fuse_conv_scale && g_opt.gemm16) {
+        const int jS = gi.sole(last);
+        if (jS >= 0 && xop(gi.node(jS)) == GGML_OP_SCALE && gi.node(jS)->src[0] == gi.node(last) && ggml_abi_op_param_f32(gi.node(jS), 1) == 0.f && is_f32(gi.node(jS)) &&
+            contig(gi.node(jS)) && !(gi.node(last)->flags & GGML_TENSOR_FLAG_OUTPUT) && gi.only_noops_between(last, jS, chain)) {
+            ep.scale = ggml_abi_op_param_f32(gi.node(jS), 0);
+            chain.push_back(jS);
+            last = jS;
+            g_stats.fused_conv_scale++;
+        }
+    }
     // -> ADD bias [1,1,OC,1]
     int j6 = gi.sole(last);
     if (j6 >= 0 && xop(gi.node(j6)) == GGML_OP_ADD && gi.node(j6)->src[0] == gi.node(last) && bias_like_chan(gi.node(j6)->src[1], OC) &&
-        gi.node(j6)->data == out->data && gi.only_noops_between(last, j6, chain)) {
+        gi.node(j6)->data == gi.node(last)->data && gi.only_noops_between(last, j6, chain)) {
         ep.bias = (const float*)gi.node(j6)->src[1]->data;
         chain.push_back(j6);
         last = j6;
@@ -1525,7 +1592,7 @@ bool plan_conv_chain(Builder& B, int i, hipStream_t s, std::vector<int>& chain) 
     // token-major [OC, W*H, N] the transformer blocks read.  A 1x1 conv IS a token GEMM: rows = positions of the NHWC operand image,
     // columns = output channels — run it in Linear mode and write the CONT's layout directly (no NCHW tensor, no transpose pass).
     int token_major_out = -1;
-    if (g_opt.fuse_proj_tokens && g_opt.gemm16 && KW == 1 && s0 == 1 && B.ups.find(x) == B.ups.end()) {
+    if (g_opt.fuse_proj_tokens && g_opt.gemm16 && KW == 1 && s0 == 1 && B.ups.find(xs) == B.ups.end()) {
         const int jp = gi.sole(last);
         const int jc = (jp >= 0 && xop(gi.node(jp)) == GGML_OP_PERMUTE && gi.node(jp)->src[0] == gi.node(last)) ? gi.sole(jp) : -1;
         if (jc >= 0 && xop(gi.node(jc)) == GGML_OP_CONT && gi.node(jc)->src[0] == gi.node(jp) && is_f32(gi.node(jc)) && contig(gi.node(jc))) {
@@ -1636,28 +1703,32 @@ bool plan_conv_chain(Builder& B, int i, hipStream_t s, std::vector<int>& chain) 
         e.gn_eps    = g.eps;
     };
     // 3x3 / stride 1 on 32 / 64 / 128-wide maps: the LDS-window kernel (conv3w.hip), with its own weight image
-    const bool ups_in = B.ups.find(x) != B.ups.end();
+    const bool ups_in = B.ups.find(xs) != B.ups.end();
     const int w3S     = (g_opt.gemm16 && token_major_out < 0) ? conv3w_plan(x->ne[0], x->ne[1], IC, N, OC, ks, st_, ups_in) : 0;
     const void* swz   = get_swz_conv(B.P, ker, s, w3S > 0);
     if (!swz) return false;
     if (g_opt.gemm16) {
         // gen-2: the conv reads an f16 NHWC image from the private arena, so the graph allocator's recycling of the
         // conv input for the chain output is harmless (no bounce).  A deferred nearest-x2 UPSCALE becomes an index shift.
-        const ggml_tensor* src = x;
+        const ggml_tensor* src = xs;
         bool upscale           = false;
-        auto ui                = B.ups.find(x);
+        auto ui                = B.ups.find(xs);
         if (ui != B.ups.end()) {
             src     = ui->second;
             upscale = true;
         }
         const int64_t SW = src->ne[0], SH = src->ne[1];
         auto it = B.packed.find(src);
+        if (it != B.packed.end() && it->second.nhwc && it->second.mul != pre_mul) {
+            fprintf(stderr, "[ggml-mi355x] plan_conv_chain: operand image of node %d was written with factor %g, the conv wants %g\n", i, it->second.mul, pre_mul);
+            return false;
+        }
         if (it == B.packed.end() || !it->second.nhwc) {
-            Packed pk{B.alloc((size_t)N * SW * SH * rup64(IC) * 2), rup64(IC), true};
+            Packed pk{B.alloc((size_t)N * SW * SH * rup64(IC) * 2), rup64(IC), true, pre_mul};
             Planner* P       = B.P;
             const size_t off = pk.off;
             const float* sp  = (const float*)src->data;
-            B.emit([=](hipStream_t st) { launch_nchw_to_nhwc_f16(st, P->arena + off, sp, SW * SH, IC, N, nullptr, nullptr, false); });
+            B.emit([=](hipStream_t st) { launch_nchw_to_nhwc_f16(st, P->arena + off, sp, SW * SH, IC, N, nullptr, nullptr, false, nullptr, 0, nullptr, pre_mul); });
             B.packed[src] = pk;
             it            = B.packed.find(src);
         }
@@ -1802,7 +1873,8 @@ bool plan_group_norm(Builder& B, int i, hipStream_t, std::vector<int>& chain) {
         g_stats.fused_proj_tokens++;
         return true;
     }
-    if (w && all_consumers_gemm16(gi, last, true)) {
+    float conv_mul = 1.f;
+    if (w && all_consumers_gemm16(gi, last, true, &conv_mul)) {
         // gen-2: every reader is an implicit-GEMM conv -> statistics kernel + one transposing apply kernel that writes the
         // f16 NHWC operand image straight into the arena; the f32 NCHW result is never materialised.
         Planner* P          = B.P;
@@ -1815,10 +1887,10 @@ bool plan_group_norm(Builder& B, int i, hipStream_t, std::vector<int>& chain) {
             float* sc = (float*)(P->arena + so);
             float* sh = sc + N * C;
             if (!have) launch_gn_stats(st, sc, sh, xp, hw, C, N, groups, eps, w, b);
-            launch_nchw_to_nhwc_f16(st, P->arena + off, xp, hw, C, N, sc, sh, silu);
+            launch_nchw_to_nhwc_f16(st, P->arena + off, xp, hw, C, N, sc, sh, silu, nullptr, 0, nullptr, conv_mul);
         });
         g_stats.kernels_planned++;
-        B.packed[gi.node(last)] = Packed{off, rup64(C), true};
+        B.packed[gi.node(last)] = Packed{off, rup64(C), true, conv_mul};
         g_stats.fused_norm++;
         return true;
     }
@@ -3187,10 +3259,47 @@ bool build_plan(Planner* P, Plan* plan, const ggml_cgraph* g, hipStream_t s, boo
                 }
                 break;
             }
+            case GGML_OP_SCALE: {
+                // Conv2d scale in front of an implicit-GEMM conv: never executed.  The operand image is packed HERE (the source is alive at this position)
+                // unless its producer already wrote it (GroupNorm apply pass, with the factor)
+                float cs = 1.f;
+                if (!scale_into_conv(gi, i, &cs)) break;
+                const ggml_tensor* xs0 = n->src[0];
+                const ggml_tensor* src = xs0;
+                const auto ui          = B.ups.find(xs0);
+                if (ui != B.ups.end()) src = ui->second;
+                const auto it = B.packed.find(src);
+                if (it != B.packed.end() && it->second.nhwc && it->second.mul != cs) break;  // an image with another factor: run the SCALE as a plain node
+                if (it == B.packed.end() || !it->second.nhwc) {
+                    const int64_t SW = src->ne[0], SH = src->ne[1], IC = src->ne[2], N = src->ne[3];
+                    Packed pk{B.alloc((size_t)N * SW * SH * rup64(IC) * 2), rup64(IC), true, cs};
+                    Planner* PP      = P;
+                    const size_t off = pk.off;
+                    const float* sp  = (const float*)src->data;
+                    B.emit([=](hipStream_t st) { launch_nchw_to_nhwc_f16(st, PP->arena + off, sp, SW * SH, IC, N, nullptr, nullptr, false, nullptr, 0, nullptr, cs); });
+                    B.packed[src] = pk;
+                }
+                B.prescale[n] = Builder::PreScale{xs0, cs};
+                chain         = {i};
+                ok            = true;
+                break;
+            }
             case GGML_OP_UPSCALE: {
                 // nearest x2 feeding only an implicit-GEMM conv (UpSampleBlock, block.hpp:57-64): fold into the conv's gather
                 const ggml_tensor* src = n->src[0];
-                const int c            = gi.sole(i);
+                int c                  = gi.sole(i);
+                float cs               = 1.f;
+                if (c >= 0 && scale_into_conv(gi, c, &cs)) c = gi.sole(c);  // UPSCALE -> Conv2d scale -> conv (SDXL VAE)
+                else cs = 1.f;
+                if (cs != 1.f) {
+                    if (g_opt.gemm16 && n->op_params[0] == GGML_SCALE_MODE_NEAREST && is_f32(src) && contig(src) && n->ne[0] == 2 * src->ne[0] && n->ne[1] == 2 * src->ne[1] &&
+                        n->ne[2] == src->ne[2] && n->ne[3] == src->ne[3] && gi.node(c)->src[0]->ne[0] == 3 && gi.node(c)->op_params[0] == 1) {
+                        B.ups[n] = src;
+                        chain    = {i};
+                        ok       = true;
+                    }
+                    break;
+                }
                 if (g_opt.gemm16 && n->op_params[0] == GGML_SCALE_MODE_NEAREST && is_f32(src) && contig(src) && n->ne[0] == 2 * src->ne[0] &&
                     n->ne[1] == 2 * src->ne[1] && n->ne[2] == src->ne[2] && n->ne[3] == src->ne[3] && c >= 0 && xop(gi.node(c)) == GGML_OP_IM2COL &&
                     gi.node(c)->src[1] == n && conv_im2col_fast_ok(gi, c) && gi.node(c)->src[0]->ne[0] == 3 && gi.node(c)->op_params[0] == 1) {
@@ -3327,7 +3436,11 @@ enum ggml_status planner_compute(Planner* p, ggml_cgraph* g, hipStream_t stream)
                 kv.second->graph_exec = nullptr;
             }
     }
-    if (g_opt.hip_graph && !plan->graph_failed) {
+    // hipGraph replay (option hip_graph, default ON since round 5: -2.2 % on the SD1.5 step, profiles/r04C_ab_hip_graph.txt).  A plan is captured the
+    // SECOND time it runs — the first run is eager, so graphs computed once (tests, a one-off VAE decode) pay nothing — and runs eagerly whenever the
+    // per-launch kernel timing is on (events recorded inside a captured graph cannot be read back on this runtime, scripts/graph_event_probe.hip).
+    const bool replay_ok = g_opt.hip_graph && !plan->graph_failed && !ktime_any() && (plan->runs++ >= 1 || g_opt.hip_graph >= 2);
+    if (replay_ok) {
         if (!plan->graph_exec) {
             hipGraph_t hg = nullptr;
             if (hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
@@ -3496,6 +3609,7 @@ void planner_get_stats(ggml_backend_mi355x_stats* o) {
     o->fused_ln_reduce       = g_stats.fused_ln_reduce;
     o->redirect_fallbacks    = g_stats.redirect_fallbacks;
     o->fused_concat_gn       = g_stats.fused_concat_gn;
+    o->fused_conv_scale      = g_stats.fused_conv_scale;
     o->fused_attention       = g_stats.fused_attention;
     o->generic_matmul        = g_stats.generic_matmul;
     o->swizzled_weight_bytes = g_stats.swizzled_weight_bytes;
@@ -3564,6 +3678,7 @@ void planner_set_option(const char* key, int value) {
     else if (!strcmp(key, "fuse_concat_gn")) g_opt.fuse_concat_gn = value;
     else if (!strcmp(key, "fuse_gn_tokens")) g_opt.fuse_gn_tokens = value;
     else if (!strcmp(key, "fuse_linear_nchw")) g_opt.fuse_linear_nchw = value;
+    else if (!strcmp(key, "fuse_conv_scale")) g_opt.fuse_conv_scale = value;
     else if (!strcmp(key, "fuse_gelu")) g_opt.fuse_gelu = value;
     else if (!strcmp(key, "fuse_rope")) g_opt.fuse_rope = value;
     else if (!strcmp(key, "fuse_concat_heads")) g_opt.fuse_concat_heads = value;

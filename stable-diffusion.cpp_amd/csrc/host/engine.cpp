@@ -301,6 +301,7 @@ struct sdm_ctx_t {
     FluxModel flux;
     bool is_dit = false, is_flux = false;
     float guidance = 3.5f;
+    float vae_conv2d_scale = 1.f;  // AutoEncoderKL::set_conv2d_scale (1/32 for SDXL, as the reference sets it without an external VAE)
     FluxFlowDenoiser flux_denoiser;
     VaeDecoder vae;
     CompVisDenoiser denoiser;
@@ -447,8 +448,8 @@ sdm_ctx_t* sdm_new_ctx(const sdm_ctx_params_t* params) {
 
     const bool xl   = params->model == SD_MODEL_SDXL || params->model == SD_MODEL_SDXL_TINY;
     const bool tiny = params->model == SD_MODEL_SD15_TINY || params->model == SD_MODEL_SDXL_TINY;
-    const bool flux     = params->model == SD_MODEL_FLUX_DEV || params->model == SD_MODEL_FLUX_TINY || params->model == SD_MODEL_FLUX_WIDE1;
-    const bool dit      = params->model == SD_MODEL_SD35_LARGE || params->model == SD_MODEL_SD35_TINY || params->model == SD_MODEL_SD35_WIDE2 || params->model == SD_MODEL_SD3M_TINY || flux;
+    const bool flux     = params->model == SD_MODEL_FLUX_DEV || params->model == SD_MODEL_FLUX_TINY || params->model == SD_MODEL_FLUX_WIDE1 || params->model == SD_MODEL_FLUX_WIDE8;
+    const bool dit      = params->model == SD_MODEL_SD35_LARGE || params->model == SD_MODEL_SD35_TINY || params->model == SD_MODEL_SD35_WIDE2 || params->model == SD_MODEL_SD35_WIDE8 || params->model == SD_MODEL_SD3M_TINY || flux;
     const bool dit_tiny = params->model == SD_MODEL_SD35_TINY || params->model == SD_MODEL_FLUX_TINY || params->model == SD_MODEL_SD3M_TINY;
     UNetConfig ucfg = tiny ? UNetConfig::tiny(xl) : (xl ? UNetConfig::sdxl_base() : UNetConfig::sd15());
     VaeConfig vcfg  = (tiny || dit_tiny) ? VaeConfig::tiny() : (xl ? VaeConfig::sdxl() : VaeConfig::sd15());
@@ -466,10 +467,10 @@ sdm_ctx_t* sdm_new_ctx(const sdm_ctx_params_t* params) {
     ctx->is_flux                    = flux;
     if (flux) {
         ctx->unet_runner.graph_size = 32768 * 4;  // FLUX_GRAPH_SIZE headroom
-        ctx->flux.init(ctx->unet_runner.ps, "model.diffusion_model.", dit_tiny ? FluxConfig::tiny() : (params->model == SD_MODEL_FLUX_WIDE1 ? FluxConfig::flux_wide1() : FluxConfig::flux_dev()));
+        ctx->flux.init(ctx->unet_runner.ps, "model.diffusion_model.", dit_tiny ? FluxConfig::tiny() : (params->model == SD_MODEL_FLUX_WIDE1 ? FluxConfig::flux_wide1() : (params->model == SD_MODEL_FLUX_WIDE8 ? FluxConfig::flux_wide8() : FluxConfig::flux_dev())));
     } else if (dit) {
         ctx->unet_runner.graph_size = 10240 * 8;  // MMDIT_GRAPH_SIZE (mmdit.hpp:14) x our batch headroom
-        ctx->mmdit.init(ctx->unet_runner.ps, "model.diffusion_model.", dit_tiny ? (params->model == SD_MODEL_SD3M_TINY ? MMDiTConfig::tiny_medium() : MMDiTConfig::tiny()) : (params->model == SD_MODEL_SD35_WIDE2 ? MMDiTConfig::sd35_wide2() : MMDiTConfig::sd35_large()));
+        ctx->mmdit.init(ctx->unet_runner.ps, "model.diffusion_model.", dit_tiny ? (params->model == SD_MODEL_SD3M_TINY ? MMDiTConfig::tiny_medium() : MMDiTConfig::tiny()) : (params->model == SD_MODEL_SD35_WIDE2 ? MMDiTConfig::sd35_wide2() : (params->model == SD_MODEL_SD35_WIDE8 ? MMDiTConfig::sd35_wide8() : MMDiTConfig::sd35_large())));
     } else
         ctx->unet.init(ctx->unet_runner.ps, "model.diffusion_model.", ucfg);  // prefix: stable-diffusion.cpp:1337
     ctx->pair_runner.backend       = backend;
@@ -478,6 +479,10 @@ sdm_ctx_t* sdm_new_ctx(const sdm_ctx_params_t* params) {
     ctx->vae_runner.ps.linear_type = GGML_TYPE_F16;
     ctx->vae_runner.graph_size     = 20480;
     ctx->vae.init(ctx->vae_runner.ps, "first_stage_model.", vcfg);  // prefix: stable-diffusion.cpp:1472
+    if (xl) {  // SDXL without an external VAE: Conv2d scale 1/32 on every VAE conv (src/stable-diffusion.cpp:1477-1485)
+        ctx->vae_conv2d_scale = 1.f / 32.f;
+        ctx->vae.set_conv2d_scale(ctx->vae_conv2d_scale);
+    }
 
     if (!ctx->unet_runner.alloc_weights(params->weight_seed) || !ctx->vae_runner.alloc_weights(params->weight_seed)) {
         set_error("weight buffer allocation failed");
@@ -758,7 +763,7 @@ static bool ensure_text_encoders(sdm_ctx_t* ctx) {
         gp         = "cond_stage_model.1.transformer.text_model.";
         sp.adm_dim = ctx->unet.cfg.adm_in_channels;
         sp.ts_dim  = tiny ? 8 : 256;
-    } else if (m == SD_MODEL_SD35_LARGE || m == SD_MODEL_SD35_TINY || m == SD_MODEL_SD35_WIDE2 || m == SD_MODEL_SD3M_TINY) {
+    } else if (m == SD_MODEL_SD35_LARGE || m == SD_MODEL_SD35_TINY || m == SD_MODEL_SD35_WIDE2 || m == SD_MODEL_SD35_WIDE8 || m == SD_MODEL_SD3M_TINY) {
         sp.family = CondFamily::SD3;
         sp.has_g = sp.has_t5 = true;
         lc = tiny ? ClipTextConfig::tiny(24, 2, 0, false, false) : ClipTextConfig::vit_l(false);
@@ -1068,7 +1073,7 @@ bool sd_vae_decode(sdm_ctx_t* ctx, const float* latents, int w, int h, int c, in
     const size_t on = (size_t)w * 8 * h * 8 * 3 * n;
     const double t0 = now_ms();
     char sig[64];
-    snprintf(sig, sizeof(sig), "vae %d %d %d %d", w, h, c, n);
+    snprintf(sig, sizeof(sig), "vae %d %d %d %d s%g", w, h, c, n, (double)ctx->vae_conv2d_scale);
     if (!r.compute(build, out_rgb, on * sizeof(float), sig, {z.data()})) return false;
     parallel_chunks(on, [&](size_t b, size_t e) {  // scale_tensor_to_0_1, vae.hpp:24-30
         for (size_t i = b; i < e; ++i) {
@@ -1519,6 +1524,11 @@ int sd_get_sigmas(int steps, float* out) {
     return (int)s.size();
 }
 void sd_set_guidance(sdm_ctx_t* ctx, float guidance) { ctx->guidance = guidance; }
+void sd_set_vae_conv2d_scale(sdm_ctx_t* ctx, float scale) {
+    if (!ctx || !(scale > 0.f)) return;
+    ctx->vae_conv2d_scale = scale;
+    ctx->vae.set_conv2d_scale(scale);
+}
 void sd_set_pair_exchange(sdm_ctx_t* ctx, sd_pair_exchange_fn fn, void* user, int branch) {
     ctx->pair_fn     = fn;
     ctx->pair_user   = user;

@@ -335,6 +335,22 @@ struct VaeDecoder {
         conv_out.init(ps, d + "conv_out.", block_in, cfg.out_ch, 3, 1, 1);
     }
 
+    // AutoEncoderKL::set_conv2d_scale (auto_encoder_kl.hpp:708-717): every Conv2d block of the autoencoder gets the factor (the reference sets 1/32 for SDXL
+    // when no external VAE is given, src/stable-diffusion.cpp:1477-1485: the f16 im2col of ggml-cpu overflows on the SDXL VAE's activations otherwise)
+    void set_conv2d_scale(float s) {
+        std::vector<Conv2d*> all{&post_quant, &conv_in, &conv_out, &mid1.conv1, &mid1.conv2, &mid1.nin, &mid2.conv1, &mid2.conv2, &mid2.nin,
+                                 &mid_attn.q, &mid_attn.k, &mid_attn.v, &mid_attn.proj_out};
+        for (auto& u : ups) {
+            for (auto& b : u.blocks) {
+                all.push_back(&b.conv1);
+                all.push_back(&b.conv2);
+                all.push_back(&b.nin);
+            }
+            if (u.upsample) all.push_back(u.upsample.get());
+        }
+        for (Conv2d* cv : all) cv->scale = s;
+    }
+
     // AutoEncoderKLModel::decode + Decoder::forward
     ggml_tensor* forward(GraphCtx& g, ggml_tensor* z) const {
         ggml_context* c = g.ctx;
@@ -390,6 +406,12 @@ struct MMDiTConfig {
     static MMDiTConfig sd35_wide2() {
         MMDiTConfig c = sd35_large();
         c.depth       = 2;
+        c.num_heads   = 38;
+        return c;
+    }
+    static MMDiTConfig sd35_wide8() {  // 8 joint blocks at the real width (depth sweep of the full-depth parity test)
+        MMDiTConfig c = sd35_large();
+        c.depth       = 8;
         c.num_heads   = 38;
         return c;
     }
@@ -639,6 +661,12 @@ struct FluxConfig {  // flux.hpp:28-60
         FluxConfig c;
         c.depth               = 1;
         c.depth_single_blocks = 1;
+        return c;
+    }
+    static FluxConfig flux_wide8() {  // 3 double + 5 single blocks at the real width (depth sweep of the full-depth parity test)
+        FluxConfig c;
+        c.depth               = 3;
+        c.depth_single_blocks = 5;
         return c;
     }
     static FluxConfig tiny() {

@@ -11,6 +11,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <condition_variable>
+#include <map>
 #include <mutex>
 #include <set>
 #include <string>
@@ -61,6 +63,8 @@ struct ErrSink {
 // communicators created here and not yet destroyed: the exchange callback refuses a communicator that is no longer in this set, so a context that
 // still has a destroyed communicator installed fails its next step with an error instead of calling into freed RCCL state
 std::set<void*> g_live;
+std::map<void*, int> g_inflight;  // communicator -> all-reduce calls currently enqueueing on it (destroy waits for zero)
+std::condition_variable g_idle;
 
 bool load_api() {
     std::lock_guard<std::mutex> lk(g_mu);
@@ -120,8 +124,16 @@ bool rccl_exchange(void* device_eps, int64_t count, void* stream, void* user) {
             g_err = "native pair exchange: the installed communicator was destroyed (sd_set_pair_exchange_rccl(ctx, NULL, 0) before sd_rccl_comm_destroy)";
             return false;
         }
+        ++g_inflight[user];  // held across the enqueue: sd_rccl_comm_destroy waits for it (round-4 advice: the check alone left a window)
     }
     const int r = g_api.all_reduce(device_eps, device_eps, (size_t)count, NCCL_FLOAT32, NCCL_SUM, (NcclComm)user, stream);
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (--g_inflight[user] == 0) {
+            g_inflight.erase(user);
+            g_idle.notify_all();
+        }
+    }
     if (r != 0) {
         g_err = "ncclAllReduce: " + nccl_err(r);
         return false;
@@ -156,7 +168,10 @@ void* sd_rccl_comm_create(int device, int nranks, int rank, const void* id128) {
     if (!id128 || !load_api()) return nullptr;
     // the communicator binds to the calling thread's current device: switch for the call only, the caller's device is put back
     const int prev = (device >= 0 && g_api.hip_get_device) ? g_api.hip_get_device() : -1;
-    if (device >= 0 && g_api.hip_set_device) (void)g_api.hip_set_device(device);
+    if (device >= 0 && g_api.hip_set_device && g_api.hip_set_device(device) != 0) {
+        g_err = "hipSetDevice(" + std::to_string(device) + ") failed: the communicator would bind to the wrong device";
+        return nullptr;
+    }
     NcclUniqueId id;
     memcpy(id.internal, id128, sizeof(id.internal));
     NcclComm comm = nullptr;
@@ -176,8 +191,9 @@ void* sd_rccl_comm_create(int device, int nranks, int rank, const void* id128) {
 void sd_rccl_comm_destroy(void* comm) {
     if (!comm) return;
     {
-        std::lock_guard<std::mutex> lk(g_mu);
-        if (!g_api.ok || !g_live.erase(comm)) return;  // not one of ours (or already destroyed): nothing to do
+        std::unique_lock<std::mutex> lk(g_mu);
+        if (!g_api.ok || !g_live.erase(comm)) return;  // not one of ours (or already destroyed): nothing to do; new exchanges are refused from here on
+        g_idle.wait(lk, [&] { return g_inflight.find(comm) == g_inflight.end(); });  // an all-reduce being enqueued on another thread finishes first
     }
     (void)g_api.comm_destroy((NcclComm)comm);
 }

@@ -380,9 +380,14 @@ inline bool pkl_tensor_entry(const std::string& name, const PklValue& t, uint64_
     ft.type   = t.type;
     ft.kind   = t.src;
     uint64_t nelem = 1;
+    for (int64_t d : t.shape)
+        if (d == 0) {  // a zero-element tensor (torch.zeros(0, 4)): the reference accepts the file and carries no data for it (pickle_io.cpp: has_zero_dimension)
+            mf.undecodable[name] = "a zero-element tensor";
+            return true;
+        }
     for (int64_t d : t.shape) {
-        if (d <= 0 || nelem > (1ull << 46) / (uint64_t)d) {
-            mf.error = "tensor '" + name + "' has an empty or overflowing shape";
+        if (d < 0 || nelem > (1ull << 46) / (uint64_t)d) {
+            mf.error = "tensor '" + name + "' has a negative or overflowing shape";
             return false;
         }
         nelem *= (uint64_t)d;

@@ -801,7 +801,7 @@ bool gemm16_split_col_supported(int64_t rows, int64_t M, int64_t K);
 int gemm16_geglu_mode(int64_t rows, int64_t M, int64_t K);
 static bool g16_use_bn64(int64_t rows, int64_t M, int mul);
 static int g_g16_swp = 0;  // option "gemm16_swp": 1 = big-token Linear tiles with the accumulator transposed (16-byte epilogue accesses; measured slower: profiles/r05a_ab_gemm16_swp_rejected.txt)
-// ---- stream-K policy (option "streamk", default 1).  A Linear that g16_pick_tile sends to a one-workgroup-per-CU pipelined tile (T320 / T256P) and
+// ---- stream-K policy (option "streamk", default 0 = off: measured 2.8 % slower, profiles/r05i_*).  A Linear that g16_pick_tile sends to a one-workgroup-per-CU pipelined tile (T320 / T256P) and
 // whose tile count leaves the last round mostly empty runs as ONE round of persistent workgroups over equal (tile, K-tile) unit ranges instead
 // (k_gemm16<..., SK>).  Returns the grid (= CUs), or 0.  rows / M / K of ONE weight; not for grouped (multi) launches, GEGLU, or K-split launches.
 void gemm16_set_streamk(int v) { g_g16_streamk = v; }
@@ -1974,7 +1974,7 @@ void launch_gn_stats(hipStream_t s, float* scale, float* shift, const float* x, 
 // f32 NCHW [hw][C][N] -> f16 NHWC [N][hw][Cp] with optional per-(n,c) affine (GroupNorm apply) and SiLU.
 // 64 channels x 64 positions per workgroup through an LDS transpose: coalesced 256-B reads along hw, 128-B writes along c.
 __global__ __launch_bounds__(256) void k_nchw_to_nhwc_f16(_Float16* __restrict__ dst, const float* __restrict__ x, int64_t hw, int C, int Cp,
-                                                          const float* __restrict__ scale, const float* __restrict__ shift, int silu) {
+                                                          const float* __restrict__ scale, const float* __restrict__ shift, int silu, float post_mul) {
     __shared__ float tile[64][65];
     const int n  = blockIdx.z;
     const int p0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
@@ -1987,6 +1987,7 @@ __global__ __launch_bounds__(256) void k_nchw_to_nhwc_f16(_Float16* __restrict__
             v = xn[(int64_t)c * hw + p];
             if (scale) v = v * scale[(int64_t)n * C + c] + shift[(int64_t)n * C + c];
             if (silu) v = act_apply<UN_SILU>(v);
+            v *= post_mul;
         }
         tile[j][tx] = v;
     }
@@ -2002,7 +2003,8 @@ __global__ __launch_bounds__(256) void k_nchw_to_nhwc_f16(_Float16* __restrict__
 // dwords: 2-way conflicts at most).  Store: a thread owns one position x 8 channels — one 16-byte store (128-byte rows per 8 lanes).
 __global__ __launch_bounds__(256) void k_nchw_to_nhwc_f16_v4(_Float16* __restrict__ dst, const float* __restrict__ x, int64_t hw, int C, int Cp,
                                                              const float* __restrict__ scale, const float* __restrict__ shift, int silu,
-                                                             const float* __restrict__ x2 = nullptr, int C1 = 0, _Float16* __restrict__ dst_raw = nullptr) {
+                                                             const float* __restrict__ x2 = nullptr, int C1 = 0, _Float16* __restrict__ dst_raw = nullptr,
+                                                             float post_mul = 1.f) {
     __shared__ uint32_t tile[64][33];  // [position][channel pair] half2
     __shared__ uint32_t tile_raw[64][33];  // dst_raw != nullptr: the same values WITHOUT affine / SiLU (the image the skip 1x1 conv reads)
     const int n  = blockIdx.z;
@@ -2046,6 +2048,8 @@ __global__ __launch_bounds__(256) void k_nchw_to_nhwc_f16_v4(_Float16* __restric
                 u = act_apply<UN_SILU>(u);
                 v = act_apply<UN_SILU>(v);
             }
+            u *= post_mul;  // Conv2d scale (ggml_ext_conv_2d: x = scale(x, s) before the f16 im2col) folded into the operand image
+            v *= post_mul;
             if (c >= C) u = 0.f;       // padded channels of the operand image are zeros
             if (c + 1 >= C) v = 0.f;
             const _Float16 hu = (_Float16)u, hv = (_Float16)v;
@@ -2080,7 +2084,7 @@ __global__ __launch_bounds__(256) void k_nchw_to_nhwc_f16_v4(_Float16* __restric
 // x2 != nullptr: the source is the channel concatenation [x (C1 channels) | x2 (C - C1)] (both NCHW, never materialised);  dst_raw != nullptr: a second
 // image of the same values without affine / SiLU (one read of the sources for the GroupNorm'ed conv operand AND the skip 1x1 conv's operand)
 void launch_nchw_to_nhwc_f16(hipStream_t s, void* dst, const float* x, int64_t hw, int64_t C, int64_t N, const float* scale, const float* shift, bool silu,
-                             const float* x2, int64_t C1, void* dst_raw) {
+                             const float* x2, int64_t C1, void* dst_raw, float post_mul) {
     KScope ks_(s, KF_NCHW_NHWC, 0.0, (double)hw * C * N * 4.0 + (double)hw * rup64(C, 64) * N * 2.0 * (dst_raw ? 2.0 : 1.0));
     const int Cp = (int)rup64(C, 64);
     dim3 grid((unsigned)((hw + 63) / 64), (unsigned)(Cp / 64), (unsigned)N);
@@ -2090,9 +2094,9 @@ void launch_nchw_to_nhwc_f16(hipStream_t s, void* dst, const float* x, int64_t h
         abort();
     }
     if (v4)
-        k_nchw_to_nhwc_f16_v4<<<grid, 256, 0, s>>>((_Float16*)dst, x, hw, (int)C, Cp, scale, shift, silu ? 1 : 0, x2, (int)C1, (_Float16*)dst_raw);
+        k_nchw_to_nhwc_f16_v4<<<grid, 256, 0, s>>>((_Float16*)dst, x, hw, (int)C, Cp, scale, shift, silu ? 1 : 0, x2, (int)C1, (_Float16*)dst_raw, post_mul);
     else
-        k_nchw_to_nhwc_f16<<<grid, 256, 0, s>>>((_Float16*)dst, x, hw, (int)C, Cp, scale, shift, silu ? 1 : 0);
+        k_nchw_to_nhwc_f16<<<grid, 256, 0, s>>>((_Float16*)dst, x, hw, (int)C, Cp, scale, shift, silu ? 1 : 0, post_mul);
 }
 
 }  // namespace mi355x

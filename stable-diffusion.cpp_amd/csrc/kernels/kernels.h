@@ -182,7 +182,7 @@ bool gn_two_source_supported(const float* x, const float* x2, int64_t hw, int64_
 void launch_gn_stats(hipStream_t s, float* scale, float* shift, const float* x, int64_t hw, int64_t C, int64_t N, int groups, float eps,
                      const float* w, const float* b, const float* x2 = nullptr, int64_t C1 = 0);
 void launch_nchw_to_nhwc_f16(hipStream_t s, void* dst, const float* x, int64_t hw, int64_t C, int64_t N, const float* scale, const float* shift,
-                             bool silu, const float* x2 = nullptr, int64_t C1 = 0, void* dst_raw = nullptr);
+                             bool silu, const float* x2 = nullptr, int64_t C1 = 0, void* dst_raw = nullptr, float post_mul = 1.f);  // post_mul: after affine / SiLU (Conv2d scale)
 
 // ---- qgemm.hip: q8_0 / q4_0 Linear with <= 4 activation rows: raw quantised blocks streamed once, in-register dequant ----------------
 bool qgemv_supported(int wtype, int64_t rows, int64_t K);

@@ -39,6 +39,7 @@ struct KFamTiming {
 
 void ktime_enable(uint32_t fam_mask);  // resets the accumulators
 bool ktime_on(int fam);
+bool ktime_any();  // any family enabled: plans run eagerly (events cannot be read back from inside a captured hipGraph)
 int ktime_read(KFamTiming* out, int cap, int* fam_index = nullptr);  // synchronises the device; returns the families with launches > 0; resets
 
 struct KScope {

@@ -66,6 +66,7 @@ void ktime_enable(uint32_t fam_mask) {
     (void)hipDeviceSynchronize();
     g_mask.store(fam_mask, std::memory_order_relaxed);
 }
+bool ktime_any() { return g_mask.load(std::memory_order_relaxed) != 0; }
 bool ktime_on(int fam) { return (g_mask.load(std::memory_order_relaxed) >> fam) & 1u; }
 
 KScope::KScope(hipStream_t stream, int fam, double flops, double bytes) : s(stream) {

@@ -66,6 +66,29 @@ def test_vae_decode_parity(sd, oracle, gpu):
     assert psnr > 35.0
 
 
+def test_vae_decode_with_conv2d_scale_parity(sd, oracle, gpu):
+    """SDXL engines run the VAE with Conv2d scale 1/32 like the reference without --vae (src/stable-diffusion.cpp:1477-1485): SCALE -> conv -> SCALE 1/s ->
+    bias; the MI355X backend folds both SCALE nodes away (operand image x s, epilogue x 1/s).  Odd width: the 4-byte pack kernel; 2 images."""
+    rng = np.random.default_rng(81)
+    for shape in ((2, 4, 16, 16), (1, 4, 9, 7)):
+        z = rng.standard_normal(shape).astype(np.float32) * 0.13025 * 3
+        ref = sd.Engine(model=sd.SDXL_TINY, backend=oracle).vae_decode(z)
+        e = sd.Engine(model=sd.SDXL_TINY, backend=gpu)
+        st0 = sd.backend_stats() if gpu != oracle else None
+        out = e.vae_decode(z)
+        mse = float(np.mean((out.astype(np.float64) - ref) ** 2))
+        psnr = 10 * np.log10(1.0 / max(mse, 1e-20))
+        print(f"VAE decode {shape} with Conv2d scale 1/32: PSNR {psnr:.1f} dB")
+        assert np.isfinite(out).all() and psnr > 35.0
+        if st0 is not None and not os.environ.get("SDCPP_BACKEND_OPTS"):
+            st1 = sd.backend_stats()
+            assert st1["fused_conv_scale"] - st0["fused_conv_scale"] == st1["fused_conv"] - st0["fused_conv"] > 20
+        e.set_vae_conv2d_scale(1.0)   # --vae with a fixed VAE: plain convs
+        plain = e.vae_decode(z)
+        assert float(np.abs(plain - out).max()) < 2e-2
+        np.testing.assert_array_equal(out.shape, plain.shape)
+
+
 def test_sampler_trajectory_parity(sd, oracle, gpu):
     """4-step Euler-A with CFG 7, two images in one device batch vs the oracle's independent batch-1 runs."""
     rng = np.random.default_rng(9)

@@ -312,7 +312,7 @@ def test_linear_stream_k(sd, oracle, gpu, rng, tokens, K, M, res, mode):
         assert sd.backend_stats()["split_k_inlaunch"] - before == 1, "the shape did not take the stream-K launch"
         again = run_gpu()
     finally:
-        sd.backend_set_option("streamk", 1)
+        sd.backend_set_option("streamk", 0)
     assert np.isfinite(out).all()
     np.testing.assert_array_equal(out, again)
     assert rel_l2(out, plain) < 1e-6

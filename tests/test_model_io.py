@@ -525,3 +525,25 @@ def test_torch_checkpoint_rejects_what_it_cannot_read(sd, oracle, tmp_path):
     (tmp_path / "legcut.ckpt").write_bytes(lraw[: len(lraw) - a.nbytes // 2])
     with pytest.raises(sd.EngineError):
         e.load_weights(tmp_path / "legcut.ckpt")
+
+
+@pytest.mark.parametrize("legacy", [False, True])
+def test_torch_checkpoint_with_a_zero_element_tensor_loads(sd, oracle, tmp_path, legacy):
+    """Round-4 advice: torch.save({..., 'empty': torch.zeros(0, 4)}) — the reference accepts such files (pickle_io.cpp: has_zero_dimension);
+    a zero-element tensor next to good ones must not abort the load (it carries no data: listed as unused)."""
+    import torch
+    e = sd.Engine(model=sd.SD15_TINY, backend=oracle, wtype=sd.F16)
+    rng = np.random.default_rng(9)
+    names = _CKPT_NAMES[:2]
+    st = _tiny_state(e, rng, names)
+    obj = {"state_dict": {**{k: torch.from_numpy(v) for k, v in st.items()}, "empty": torch.zeros(0, 4), "also.empty": torch.zeros(3, 0, 2)}}
+    p = tmp_path / "z.ckpt"
+    torch.save(obj, p, _use_new_zipfile_serialization=not legacy)
+    r = e.load_weights(p)
+    assert r["loaded"] == len(names), r
+    for n, val in st.items():
+        got = e.get_tensor(n)
+        ref = val.reshape(got.shape)
+        if e.tensor_info(n)[1] == sd.F16:
+            ref = ref.astype(np.float16).astype(np.float32)
+        np.testing.assert_array_equal(got, ref, err_msg=n)
