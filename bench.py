@@ -509,6 +509,11 @@ def host_cpu_info():
         info["model"] = model
         info["physical_cores"] = len(phys) or None
         info["schedulable_cpus"] = len(os.sched_getaffinity(0))
+        try:   # the container's CPU-time quota: what actually bounds an OpenMP team here (the GPU boxes of this pool: 16 CPUs of a 256-thread host)
+            quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            info["cgroup_cpu_quota"] = None if quota == "max" else round(int(quota) / int(period), 2)
+        except (OSError, ValueError):
+            info["cgroup_cpu_quota"] = None
     except OSError:
         pass
     return info
@@ -548,7 +553,7 @@ def cpu_baseline(sd, args, lat, ctx_dim):
     runs = []
     n, el = timed(args.cpu_baseline_seconds / 2)
     runs.append({"cores": cores, "it_per_s": round(n / (2 * el), 5), "sec_per_forward": round(el / n, 3), "forwards": n})
-    all_cpus = int(olib.oracle_set_num_threads(0))
+    all_cpus = int(olib.oracle_set_num_threads(0))   # affinity mask AND the cgroup CPU quota: threads beyond the quota only time-slice
     if all_cpus > cores:
         eng.unet_forward(x, t, ctx, y)  # untimed: the bigger team's threads start
         n2, el2 = timed(args.cpu_baseline_seconds / 2)
@@ -557,7 +562,8 @@ def cpu_baseline(sd, args, lat, ctx_dim):
     best = max(runs, key=lambda r: r["it_per_s"])
     return {"value": best["it_per_s"], "unit": "it/s", "cores": best["cores"], "kind": "port", "host": host, "team_sizes": runs,
             "sample": f"{best['forwards']} UNet forward(s) of 1 image ({args.model}, latent {lat}x{lat}) on {best['cores']} threads; one it = 2 forwards (cfg 7); "
-                      f"`cores` are schedulable hardware threads (the OpenMP team size), the host has {host.get('physical_cores')} physical cores",
+                      f"`cores` = the OpenMP team = every CPU this container may use ({all_cpus}: affinity mask and cgroup quota "
+                      f"{host.get('cgroup_cpu_quota')}) of a host with {host.get('physical_cores')} physical cores",
             "sec_per_forward": best["sec_per_forward"]}
 
 

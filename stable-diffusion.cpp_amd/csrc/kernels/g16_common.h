@@ -28,6 +28,8 @@ struct G16Args {
     int geglu16;           // with geglu_inner > 0: the weight image is in the 16-column interleave (k_wswz_linear, geglu_inner < 0) -> epi_geglu16 (any tile geometry)
     int hm_d, hm_H, hm_L;  // head-major store (rows mode): element (row = n*L + l, col = h*d + dd) -> ((n*H + h)*L + l)*d + dd
     int64_t R, C;
+    int64_t row_base;  // rows mode: this launch's tiles start at row row_base (a multiple of 256) of the R rows — the second launch of a row-split Linear (g16_launch: tail rows on smaller tiles)
+    int wblk_lim;      // > 0: 32-column blocks the weight image holds (columns padded to 128): tiles wider than the padding (256-column tiles on M % 256 == 128) fetch block wblk_lim - 1 instead of reading past the image
     int nt;            // K tiles (BK each)
     int ncol_tiles;
     int split_k;       // > 1: blockIdx.y = K slice; slice s accumulates K tiles [s*nt_slice, ...) into dst + s*slab (raw partial sums)

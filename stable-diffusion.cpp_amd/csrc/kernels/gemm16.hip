@@ -141,7 +141,7 @@ __global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g
         G16_PICK(ep.bias, biasm);
 #undef G16_PICK
     }
-    const int64_t row0 = (int64_t)row_tile * BM;
+    const int64_t row0 = (CONV ? 0 : g.row_base) + (int64_t)row_tile * BM;
     const int col0     = col_tile * BN;
 
     // XOR permutation of the k-slots of LDS row r (conflict-free ds_read_b128 over 16 consecutive rows)
@@ -191,7 +191,9 @@ __global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g
         const int f  = q * NW + wave;
         const int fs = f < NF ? f : NF - 1;
         const int cb = fs / KSTEPS, ks = fs % KSTEPS;
-        wsrc[q]      = g.W + ((int64_t)(col0 / 32 + cb) * g.kfr + ks) * 64 + lane;
+        int wb       = col0 / 32 + cb;
+        if (!CONV && g.wblk_lim > 0 && wb >= g.wblk_lim) wb = g.wblk_lim - 1;  // column blocks past the padded image: any valid block (their outputs are masked by col < C)
+        wsrc[q]      = g.W + ((int64_t)wb * g.kfr + ks) * 64 + lane;
         wdst[q]      = fs * 1024;
     }
     const bool w_short = WEXTRA != 0 && wave >= WEXTRA;  // this wave issues one W fragment fewer per stage
@@ -751,6 +753,31 @@ static int g16_t320_split(int64_t rows, int64_t M, int64_t nt, bool conv);
 // mul > 1: `mul` sibling weights of M columns each in one launch (divisibility per weight, tile counts over all of them)
 // geglu: 0 = plain Linear, 1 = GEGLU launch on the paired weight image (128-column pairing: tiles with an even number of column blocks per wave
 // only), 2 = GEGLU launch on the 16-column interleave (epi_geglu16: any tile)
+// option "t256p_pad" (round 5): the pipelined 256 x 256 tile also for Linears whose width is a multiple of 128 but not of 256 (SD3.5-large: 2432 = 9.5 tiles,
+// 7296 = 28.5): the last column tile is half empty (its weight fetches are clamped to the image, its outputs masked), at most 6 % of the launch
+static int g_g16_t256p_pad = 1;
+void gemm16_set_t256p_pad(int v) { g_g16_t256p_pad = v; }
+// option "tail_split" (round 5): a 256 x 256-tile Linear whose tile count leaves the last of its >= 2 rounds mostly empty runs as TWO launches split by rows:
+// whole rounds of 256 x 256 tiles, then the remaining rows on the small tiles (g16_tail_rows).  No slab traffic, no reduction — unlike stream-K.
+static int g_g16_tail_split = 1;
+void gemm16_set_tail_split(int v) { g_g16_tail_split = v; }
+static bool g16_pad256_ok(int64_t M, int geglu, bool conv, int mul) {
+    return g_g16_t256p_pad && !conv && mul == 1 && geglu == 0 && M % 128 == 0 && M % 256 != 0 && M >= 2048;  // >= 2048: the empty half tile is <= 6 % of the columns
+}
+// row tiles (256 rows) the main launch of a row-split Linear takes; 0 = one launch.  Unit of the estimate: one round of 256 x 256 tiles on 256 CUs
+static int g16_num_cus();
+static int g16_tail_rows(int64_t rows, int64_t M) {
+    if (!g_g16_tail_split) return 0;
+    const int64_t ncol = (M + 255) / 256, rt = (rows + 255) / 256, T = rt * ncol, full = T / g16_num_cus(), rem = T % g16_num_cus();
+    if (full < 1 || rem == 0) return 0;
+    const int64_t rtm = full * g16_num_cus() / ncol;
+    if (rtm <= 0 || rtm >= rt) return 0;
+    const int64_t tail_rows = rows - rtm * 256, tail_wgs = ((tail_rows + 127) / 128) * ((M + 127) / 128);
+    // tail on 128 x 128 tiles (3 workgroups per CU at most): one per CU ~ half a big tile's time, two ~ 0.75, a full round of three ~ 1.25
+    const double tail_cost = tail_wgs <= 256 ? 0.5 : (tail_wgs <= 512 ? 0.75 : 1.25 * (double)((tail_wgs + 767) / 768));
+    const double main_cost = (double)((rtm * ncol + g16_num_cus() - 1) / g16_num_cus());
+    return (main_cost + tail_cost < (double)(full + 1) * 0.95) ? (int)rtm : 0;
+}
 static int g16_pick_tile(int64_t rows, int64_t M, int geglu, bool conv, int split, int64_t nt, int mul = 1) {
     if (g_g16_variant != 3) return G16_T128;
     const bool can160 = M % 160 == 0 && geglu != 1;
@@ -764,11 +791,13 @@ static int g16_pick_tile(int64_t rows, int64_t M, int geglu, bool conv, int spli
         return g_g16_force_tile > G16_T256P ? G16_T128 : g_g16_force_tile;
     }
     const int64_t rt256 = (rows + 255) / 256, c128 = ((rows + 127) / 128) * ((M + 127) / 128) * mul, c256 = rt256 * ((M + 127) / 128) * mul;
-    if (g_g16_force_tile < 0 && !split && g_g16_t320 && !can320 && M % 256 == 0) {
+    if (g_g16_force_tile < 0 && !split && g_g16_t320 && !can320 && (M % 256 == 0 || g16_pad256_ok(M, geglu, conv, mul))) {
         // T256P: the same pipelined loop on 256x256 tiles (N a multiple of 256 but not of 320: DiT Linears, the KL-VAE's 512 / 256-channel convs)
         // one workgroup per CU: pipeline fill, drain and epilogue of a workgroup overlap with nothing, so short-K GEMMs (SD1.5's GEGLU FF1,
         // K = 320 .. 1280: 10-40 stages) stay on the 2-workgroups-per-CU tiles (r02d: 264 -> 318 us); long-K Linears (DiT) take it
-        const int64_t c256p = rt256 * (M / 256) * mul, rounds = (c256p + 255) / 256;
+        const int64_t c256p = rt256 * ((M + 255) / 256) * mul;
+        int64_t rounds      = (c256p + 255) / 256;
+        if (!conv && mul == 1 && geglu == 0 && g16_tail_rows(rows, M) > 0) rounds = c256p / 256;  // the partial round goes to the tail launch: the fill test sees whole rounds
         // stream-K (g16_streamk_grid) runs such a launch as ONE round whatever its tile count: the round-fill test only binds launches that cannot take it
         const bool sk_ok = g_g16_streamk == 2 && !conv && mul == 1 && c256p * nt >= 256 * 16;  // (default policy: stream-K never widens the tile choice)
         if (nt >= (sk_ok ? g_g16_t256p_min_nt_sk : 64) && c256p >= (sk_ok ? g_g16_t256p_min_tiles_sk : 192) && (sk_ok || c256p * 4 >= rounds * 256 * 3)) return G16_T256P;
@@ -897,6 +926,23 @@ static void g16_launch(hipStream_t s, G16Args& g, int64_t rows, double flops, do
                 return;
             }
         }
+        if constexpr (!CONV_) {
+            const int rtm = (tile == G16_T256P && ny == 1 && mul == 1 && g.geglu_inner == 0 && !g.sk_cnt) ? g16_tail_rows(rows, g.C) : 0;
+            if (rtm > 0) {
+                // row split: whole rounds of 256 x 256 tiles, then the remaining rows on whatever tile their shape picks (epilogue indices are absolute rows)
+                const double fm = (double)((int64_t)rtm * 256) / (double)rows;
+                G16Args t       = g;
+                t.row_base      = g.row_base + (int64_t)rtm * 256;
+                {
+                    KScope ks_(s, KF_LINEAR, flops * fm, bytes * fm);
+                    g.ncol_tiles = (int)((g.C + 255) / 256);
+                    if (g.C % 256 != 0) g.wblk_lim = (int)(rup64(g.C, 128) / 32);
+                    k_gemm16<256, 256, false, 32, 4, 4, 2, 1><<<dim3((unsigned)(rtm * g.ncol_tiles), 1), 512, 0, s>>>(g);
+                }
+                g16_launch<BN_, CONV_>(s, t, rows - (int64_t)rtm * 256, flops * (1.0 - fm), bytes * (1.0 - fm));
+                return;
+            }
+        }
         if (tile != G16_T128) {
             const int64_t rt256 = (rows + 255) / 256;
             KScope ks_(s, CONV_ ? KF_CONV_T256 : KF_LINEAR, flops, bytes);
@@ -926,6 +972,7 @@ static void g16_launch(hipStream_t s, G16Args& g, int64_t rows, double flops, do
             } else if (tile == G16_T256P) {
                 g.ncol_tiles = (int)((g.C + 255) / 256);
                 if constexpr (!CONV_) {
+                    if (g.C % 256 != 0) g.wblk_lim = (int)(rup64(g.C, 128) / 32);
                     if (g16_swp_ok(g)) {
                         k_gemm16<256, 256, false, 32, 4, 4, 2, 1, true><<<dim3((unsigned)(rt256 * g.ncol_tiles * mul), ny), 512, 0, s>>>(g);
                         return;

@@ -121,6 +121,8 @@ void gemm16_set_tile(int t);     // -1: per-shape choice; 0..5: force T128 / T25
 void gemm16_set_abl(int v);
 #endif
 void gemm16_set_t320(int v);
+void gemm16_set_t256p_pad(int v);   // option "t256p_pad" (1): 256 x 256 pipelined tile for Linear widths that are multiples of 128 only (last column tile half empty)
+void gemm16_set_tail_split(int v);  // option "tail_split" (1): row-split launches (whole rounds of 256 x 256 tiles + the remaining rows on small tiles)
 void gemm16_set_bn64(int v);     // 0: never choose the pipelined 256x320 tile
 void gemm16_set_variant(int v);  // 0: BK64x2 stages, 1: BK32x3 stages (default), 2: BK64x3 stages
 // hm_d > 0: head-major store — element (row = n*hm_L + l, col = h*hm_d + dd) goes to ((n*hm_H + h)*hm_L + l)*hm_d + dd of dst (f32) / dst16 (f16)

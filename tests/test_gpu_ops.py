@@ -321,6 +321,49 @@ def test_linear_stream_k(sd, oracle, gpu, rng, tokens, K, M, res, mode):
     assert np.abs(out[rows] - exact).max() < 1e-3 * max(1.0, float(np.abs(exact).max()))
 
 
+@pytest.mark.parametrize("tokens,K,M,res", [(4352, 2048, 12288, True), (8192, 2048, 2432, True), (4096, 2048, 7296, False), (8500, 2304, 9728, False), (4300, 2048, 9216, True)])
+def test_linear_row_split_and_padded_256_tiles(sd, oracle, gpu, rng, tokens, K, M, res):
+    """Round 5 tile policy of the DiT Linears (gemm16.hip g16_tail_rows / g16_pad256_ok):
+      tail_split  17 x 48 = 816 tiles of 256 x 256 are 3.19 rounds on 256 CUs, paid as 4 — the launch runs as 768 whole tiles (rows 0..4095) plus the last 256 rows on
+                  small tiles (second launch, row_base); no slab, no reduction;
+      t256p_pad   widths that are multiples of 128 only (SD3.5: 2432, 7296) take the pipelined 256 x 256 tile, the last column tile half empty.
+    Against the same Linear with both options off (same products, tile geometry only), against the exact product of the f16-rounded operands on sampled rows
+    (first / last row of the main part, first row of the tail, last row; columns of the half-empty tile included), bit-identical between runs."""
+    if not _on_gpu():
+        pytest.skip("tile policy of the MI355X backend")
+    x = rng.standard_normal((tokens, K)).astype(np.float32)
+    w = (rng.standard_normal((M, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(M).astype(np.float32)
+    r = rng.standard_normal((tokens, M)).astype(np.float32)
+
+    def build(g, L):
+        y = L.ggml_add_inplace(g.ctx, L.ggml_mul_mat(g.ctx, g.weight(w, F16), g.input(x)), g.weight(b, F32))
+        return L.ggml_add(g.ctx, y, g.input(r)) if res else y
+
+    def run_gpu():
+        with Graph(gpu) as g:
+            return g.run(build(g, sd.lib())).reshape(tokens, M)
+
+    try:
+        sd.backend_set_option("tail_split", 0)
+        sd.backend_set_option("t256p_pad", 0)
+        plain = run_gpu()
+        sd.backend_set_option("tail_split", 1)
+        sd.backend_set_option("t256p_pad", 1)
+        out = run_gpu()
+        again = run_gpu()
+    finally:
+        sd.backend_set_option("tail_split", 1)
+        sd.backend_set_option("t256p_pad", 1)
+    assert np.isfinite(out).all()
+    np.testing.assert_array_equal(out, again)
+    assert rel_l2(out, plain) < 1e-6
+    edges = [0, 255, 256, tokens - 1] + [k * 256 + d for k in range(1, (tokens + 255) // 256) for d in (-1, 0)]
+    rows = np.unique(np.concatenate([rng.integers(0, tokens, 48), [e for e in edges if 0 <= e < tokens]]))
+    exact = x[rows].astype(np.float16).astype(np.float64) @ w.astype(np.float16).astype(np.float64).T + b + (r[rows] if res else 0.0)
+    assert np.abs(out[rows] - exact).max() < 1e-3 * max(1.0, float(np.abs(exact).max()))
+
+
 @pytest.mark.parametrize("qname", ["Q8_0", "Q4_0"])
 @pytest.mark.parametrize("tokens,K,M", [(640, 512, 384), (1030, 256, 200), (2048, 3072, 640)])
 def test_quantised_linear_just_in_time_image(sd, oracle, gpu, rng, qname, tokens, K, M):

@@ -515,3 +515,60 @@ def test_stream_k_unit_ranges_parts_and_slab_slots(T, NT, G, hybrid):
             continue
         for p in range(wl - wf + 1):
             assert slot_of[(rt, p)] == (2 * wf + 1 if p == 0 else 2 * (wf + p))
+
+
+# ---- round 5: row-split launches (gemm16.hip g16_tail_rows) and the clamped weight fetch of half-empty 256-column tiles (wblk_lim) -------------------
+def tail_rows(rows, M, cus=256):
+    """restatement of g16_tail_rows: row tiles (256 rows) of the main launch, 0 = one launch"""
+    ncol, rt = (M + 255) // 256, (rows + 255) // 256
+    T = rt * ncol
+    full, rem = T // cus, T % cus
+    if full < 1 or rem == 0:
+        return 0
+    rtm = full * cus // ncol
+    if rtm <= 0 or rtm >= rt:
+        return 0
+    tail = rows - rtm * 256
+    wgs = ((tail + 127) // 128) * ((M + 127) // 128)
+    tail_cost = 0.5 if wgs <= 256 else (0.75 if wgs <= 512 else 1.25 * ((wgs + 767) // 768))
+    main_cost = (rtm * ncol + cus - 1) // cus
+    return rtm if main_cost + tail_cost < (full + 1) * 0.95 else 0
+
+
+@pytest.mark.parametrize("rows,M,expect_split", [(4352, 12288, True), (4352, 9216, True), (4352, 21504, False), (4352, 3072, False), (8192, 2432, True),
+                                                 (8500, 9728, True), (4096, 12288, False), (65536, 320, False), (300, 4096, False)])
+def test_row_split_covers_every_row_exactly_once(rows, M, expect_split):
+    rtm = tail_rows(rows, M)
+    assert (rtm > 0) == expect_split, (rows, M, rtm)
+    if not rtm:
+        return
+    ncol = (M + 255) // 256
+    # main launch: row tiles [0, rtm) x every column tile, whole rounds at most; tail launch: row_base = rtm * 256, rows - row_base rows on ITS tile size
+    assert rtm * ncol <= (((rows + 255) // 256) * ncol // 256) * 256
+    row_base = rtm * 256
+    covered = np.zeros(rows, dtype=np.int32)
+    for t in range(rtm):
+        covered[t * 256:min(rows, (t + 1) * 256)] += 1
+    for bm in (128, 256):   # whatever tile the tail picks: row0 = row_base + tile * BM, rows >= R are masked by the epilogue
+        c2 = covered.copy()
+        for t in range((rows - row_base + bm - 1) // bm):
+            r0 = row_base + t * bm
+            c2[r0:min(rows, r0 + bm)] += 1
+        assert (c2 == 1).all()
+    # a nested split of the tail would start at row_base again: the recursion passes the remaining rows and the accumulated base
+    assert row_base % 256 == 0 and 0 < rows - row_base < rows
+
+
+@pytest.mark.parametrize("M", [2432, 7296, 2176, 3200])
+def test_half_empty_column_tile_fetches_stay_inside_the_weight_image(M):
+    """the weight image holds rup128(M) columns = rup128(M) / 32 fragment blocks; a 256-column tile asks for blocks col0/32 .. col0/32 + 7: the blocks at or
+    beyond the limit are clamped to the last block of the image (their outputs are masked by col < M)"""
+    lim = ((M + 127) // 128 * 128) // 32
+    ncol = (M + 255) // 256
+    for ct in range(ncol):
+        for cb in range(8):
+            wb = ct * 8 + cb
+            wbc = min(wb, lim - 1) if M % 256 else wb
+            assert 0 <= wbc < lim
+            if wb * 32 < M:
+                assert wbc == wb   # every block that holds real columns is fetched from its own place

@@ -28,6 +28,10 @@ pytestmark = pytest.mark.gpu
 ROOT = Path(__file__).resolve().parent.parent
 ON_GPU = os.environ.get("SDCPP_GPU_TESTS_ON_ORACLE") != "1"
 full = pytest.mark.skipif(os.environ.get("SDCPP_SKIP_FULLDEPTH") == "1", reason="SDCPP_SKIP_FULLDEPTH=1")
+# The ggml-cpu-faithful oracle forward at FULL depth doubles the oracle time of this file (the GPU boxes give a container 16 CPUs: a 38-block SD3.5 forward
+# is ~1.5 min of oracle, a FLUX forward ~4 min).  Default: the faithful leg runs at the middle depth (3+5 FLUX blocks) and the full depth is held to the
+# exact reference; SDCPP_FULLDEPTH_FAITHFUL=1 adds the faithful forward at full depth (run once per round by the builder: profiles/r06*_fulldepth.txt).
+FAITHFUL_AT_FULL_DEPTH = os.environ.get("SDCPP_FULLDEPTH_FAITHFUL") == "1" or not ON_GPU
 
 
 def rel_l2(a, b):
@@ -86,7 +90,9 @@ def sweep(sd, oracle, gpu, name, models, wtype, args, full_bar):
     print(f"{name} error growth (GPU vs exact): " + "  ".join(f"{l}: {x:.2e}" for l, x, _, _ in rows))
     label, e_x, e_f, spread = rows[-1]
     assert e_x <= full_bar, (label, e_x)
-    assert e_f <= spread + 5e-3, (label, e_f, spread)
+    for label, e_x, e_f, spread in rows:
+        if e_f == e_f:   # the faithful leg ran at this depth
+            assert e_f <= spread + 5e-3, (label, e_f, spread)
     return rows
 
 
@@ -97,7 +103,7 @@ def test_sd35_large_full_depth_vs_oracle(sd, oracle, gpu):
     t = np.array([600.0], np.float32)
     c = rng.standard_normal((1, 154, 4096)).astype(np.float32)
     y = rng.standard_normal((1, 2048)).astype(np.float32)
-    models = [("2", sd.SD35_WIDE2, False), ("8", sd.SD35_WIDE8, False), ("38", sd.SD35_LARGE, True)]
+    models = [("2", sd.SD35_WIDE2, False), ("8", sd.SD35_WIDE8, False), ("38", sd.SD35_LARGE, FAITHFUL_AT_FULL_DEPTH)]
     if not ON_GPU:   # harness self-check on a CPU-only box: the shallow point only
         models = [("2", sd.SD35_WIDE2, True)]
         x = x[:, :, :32, :32]
@@ -111,7 +117,7 @@ def test_flux_dev_full_depth_vs_oracle(sd, oracle, gpu):
     t = np.array([0.62], np.float32)
     c = rng.standard_normal((1, 256, 4096)).astype(np.float32)
     y = rng.standard_normal((1, 768)).astype(np.float32)
-    models = [("1+1", sd.FLUX_WIDE1, False), ("3+5", sd.FLUX_WIDE8, False), ("19+38", sd.FLUX_DEV, True)]
+    models = [("1+1", sd.FLUX_WIDE1, False), ("3+5", sd.FLUX_WIDE8, True), ("19+38", sd.FLUX_DEV, FAITHFUL_AT_FULL_DEPTH)]
     if not ON_GPU:
         models = [("1+1", sd.FLUX_WIDE1, True)]
         x = x[:, :, :32, :32]
