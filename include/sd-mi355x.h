@@ -206,6 +206,14 @@ SD_API void sd_rccl_comm_destroy(void* comm);
 SD_API bool sd_set_pair_exchange_rccl(sdm_ctx_t* ctx, void* comm, int branch); /* comm = NULL removes the exchange */
 SD_API const char* sd_rccl_last_error(void);
 SD_API void sd_set_guidance(sdm_ctx_t* ctx, float guidance); /* FLUX distilled-guidance input (default 3.5, stable-diffusion.h guidance.distilled_guidance) */
+/* the host sampler's classifier-free-guidance combine on n floats: out = uncond + scale * (cond - uncond), three separately rounded f32 operations like
+ * sd::guidance::ClassifierFreeGuidance::forward on sd::Tensor<float> (src/runtime/guidance.cpp:171) — bit-exact against that code compiled into oracle/_ref */
+SD_API void sd_cfg_combine(const float* cond, const float* uncond, int64_t n, float scale, float* out);
+/* the host sampler loop (sigma ladder, initial noise, scalings / timestep per step, ancestral step, update, Philox noise order) on one image of n floats with
+ * a synthetic model, denoised = x / (1 + sigma) + 0.01 * sigma: family 0 CompVis (SD1.x / SDXL), 1 discrete flow (SD3.x), 2 FLUX flow; method = sdm_sample_method_t;
+ * eta INFINITY = the method's default; aux: optional 5 floats per step (c_skip, c_out, c_in, t, sigma).  Returns the ladder length, -1 on bad arguments.  For the
+ * bit-exact tests against the reference's src/runtime/denoiser.hpp compiled into oracle/_ref (tests/test_host_logic.py). */
+SD_API int sd_sample_synthetic(int family, int steps, int image_seq_len, int64_t n, uint64_t seed, int method, float eta, float* out, float* aux);
 /* AutoEncoderKL::set_conv2d_scale (src/model/vae/auto_encoder_kl.hpp:708-717): every Conv2d of the VAE computes conv(x * s) / s + bias.  SDXL contexts start with
  * s = 1/32 — what the reference sets when no external VAE is given (src/stable-diffusion.cpp:1477-1485; `--vae` with a fixed VAE -> call this with 1) */
 SD_API void sd_set_vae_conv2d_scale(sdm_ctx_t* ctx, float scale);

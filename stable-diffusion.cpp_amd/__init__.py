@@ -691,6 +691,18 @@ def rccl_comm_destroy(comm) -> None:
     lib().sd_rccl_comm_destroy(comm)
 
 
+def cfg_combine(cond: np.ndarray, uncond: np.ndarray, scale: float) -> np.ndarray:
+    """The host sampler's CFG combine (sd_cfg_combine): uncond + scale * (cond - uncond), each operation rounded to f32."""
+    c, u = _f32(cond).ravel(), _f32(uncond).ravel()
+    assert c.size == u.size
+    out = np.empty_like(c)
+    L = lib()
+    L.sd_cfg_combine.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p]
+    L.sd_cfg_combine.restype = None
+    L.sd_cfg_combine(c.ctypes.data, u.ctypes.data, c.size, float(scale), out.ctypes.data)
+    return out.reshape(np.shape(cond))
+
+
 def philox_randn(seed: int, offset: int, n: int) -> np.ndarray:
     out = np.empty(n, dtype=np.float32)
     lib().sd_philox_randn(seed, offset, n, _fptr(out))
@@ -702,6 +714,18 @@ def philox_uint32(seed: int, offset: int, n: int) -> np.ndarray:
     out = np.empty((n, 4), dtype=np.uint32)
     lib().sd_philox_uint32(seed, offset, n, out.ctypes.data_as(C.c_void_p))
     return out
+
+
+def sample_synthetic(family: int, steps: int, n: int, seed: int, method: int = EULER_A, eta: float = float("inf"), image_seq_len: int = 0):
+    """The host sampler loop on one image of n floats with a synthetic model (sd_sample_synthetic): returns (latents, aux[steps, 5] = c_skip, c_out, c_in, t, sigma)."""
+    L = lib()
+    L.sd_sample_synthetic.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int64, C.c_uint64, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
+    L.sd_sample_synthetic.restype = C.c_int
+    out, aux = np.empty(n, np.float32), np.zeros((steps, 5), np.float32)
+    k = L.sd_sample_synthetic(family, steps, image_seq_len, n, seed, method, eta, out.ctypes.data, aux.ctypes.data)
+    if k != steps + 1:
+        raise EngineError(f"sd_sample_synthetic returned {k}")
+    return out, aux
 
 
 def get_sigmas(steps: int) -> np.ndarray:

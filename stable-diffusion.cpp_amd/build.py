@@ -130,6 +130,16 @@ def build_oracle(pool) -> Path:
     return out
 
 
+def build_oracle_ref(pool):
+    """oracle/_ref: the parts of the REFERENCE that compile from their own few sources where they lie (oracle/Makefile: PhiloxRNG, the CFG combine of
+    src/runtime/guidance.cpp) — only where /root/reference exists (this container); the GPU box uses the prebuilt files that travel with the snapshot."""
+    ref = Path(os.environ.get("SD_REFERENCE", "/root/reference"))
+    if not (ref / "src" / "runtime" / "guidance.cpp").exists():
+        return None
+    _run(["make", "-C", str(ORACLE), "ref", f"REF={ref}"])
+    return ORACLE / "_ref"
+
+
 def build_all(verbose: bool = True) -> dict[str, Path]:
     with cf.ThreadPoolExecutor(max_workers=os.cpu_count() or 4) as pool:
         futs = {
@@ -137,8 +147,9 @@ def build_all(verbose: bool = True) -> dict[str, Path]:
             "backend": pool.submit(build_backend, pool),
             "oracle": pool.submit(build_oracle, pool),
             "host_opshift": pool.submit(build_host_opshift, pool),
+            "oracle_ref": pool.submit(build_oracle_ref, pool),
         }
-        out = {k: f.result() for k, f in futs.items()}
+        out = {k: f.result() for k, f in futs.items() if f.result() is not None}
     if verbose:
         for k, v in out.items():
             print(f"[build] {k}: {v.relative_to(ROOT)}")

@@ -1178,7 +1178,7 @@ static bool sample_group(sdm_ctx_t* ctx, const sdm_img_gen_params_t* p, int b0, 
                 memcpy(&uncond_out[b * per], &o2[(2 * b + 1) * per], per * sizeof(float));
             }
             for (size_t k = 0; k < x.size(); ++k) {
-                const float guided = uncond_out[k] + sp.txt_cfg * (cond_out[k] - uncond_out[k]);
+                const float guided = cfg_guided(cond_out[k], uncond_out[k], sp.txt_cfg);
                 denoised[k]        = guided * c_out + x[k] * c_skip;
             }
         } else if (!run(p->cond, cond_out.data())) {
@@ -1186,37 +1186,19 @@ static bool sample_group(sdm_ctx_t* ctx, const sdm_img_gen_params_t* p, int b0, 
         } else if (use_cfg) {
             if (!run(p->uncond, uncond_out.data())) return false;
             for (size_t k = 0; k < x.size(); ++k) {  // guidance.cpp:171 ; stable-diffusion.cpp:2876
-                const float guided = uncond_out[k] + sp.txt_cfg * (cond_out[k] - uncond_out[k]);
+                const float guided = cfg_guided(cond_out[k], uncond_out[k], sp.txt_cfg);
                 denoised[k]        = guided * c_out + x[k] * c_skip;
             }
         } else {
             for (size_t k = 0; k < x.size(); ++k) denoised[k] = cond_out[k] * c_out + x[k] * c_skip;
         }
-        if (method == SDM_EULER_A_SAMPLE_METHOD) {  // denoiser.hpp:1513-1546
-            if (sigma_to == 0.f) {
-                x = denoised;
-            } else if (eta == 0.f) {
-                const float ratio = sigma_to / sigma;
-                for (size_t k = 0; k < x.size(); ++k) x[k] = ratio * x[k] + (float)((1.0 - ratio) * denoised[k]);
-            } else {
-                const float ratio = sigma_down / sigma;
-                for (size_t k = 0; k < x.size(); ++k) x[k] = ratio * x[k] + (1.0f - ratio) * denoised[k];
-                if (sigma_up > 0.f) {
-                    noise_job.get();
-                    if (ctx->is_dit)
-                        for (size_t k = 0; k < x.size(); ++k) x[k] *= alpha_scale;  // denoiser.hpp:1537-1539
-                    for (int b = 0; b < nb; ++b) {
-                        const std::vector<float>& nz = step_noise[b];
-                        for (size_t k = 0; k < per; ++k) x[b * per + k] += nz[k] * sigma_up;
-                    }
-                }
-            }
-        } else {  // sample_euler, denoiser.hpp:1582-1597
-            for (size_t k = 0; k < x.size(); ++k) {
-                const float d = (x[k] - denoised[k]) / sigma;
-                x[k] += d * (sigma_to - sigma);
-            }
-        }
+        // the update itself: sample_euler_ancestral / sample_euler (sampler.hpp: sampler_update — the function tests hold bit-for-bit against the reference's
+        // own src/runtime/denoiser.hpp compiled into oracle/_ref)
+        sampler_update(x.data(), denoised.data(), per, nb, method == SDM_EULER_A_SAMPLE_METHOD, ctx->is_dit, sigma, sigma_to, eta, sigma_down, sigma_up, alpha_scale,
+                       [&](int b) -> const float* {
+                           if (noise_job.valid()) noise_job.get();
+                           return step_noise[b].data();
+                       });
     }
     memcpy(out, x.data(), x.size() * sizeof(float));
     return true;
@@ -1524,6 +1506,54 @@ int sd_get_sigmas(int steps, float* out) {
     return (int)s.size();
 }
 void sd_set_guidance(sdm_ctx_t* ctx, float guidance) { ctx->guidance = guidance; }
+// the host sampler's CFG combine on n floats (cfg_guided, sampler.hpp) — exported so that tests can hold it bit-for-bit against the reference's own
+// ClassifierFreeGuidance::forward compiled into oracle/_ref (src/runtime/guidance.cpp:149-179)
+// The host sampler's loop — sigma ladder, initial noise, per-step scalings / timestep, ancestral step, update, Philox noise order — on ONE image of n floats
+// with a SYNTHETIC model in place of the network: denoised = x * (1 / (1 + sigma)) + 0.01 * sigma  (plain f32 arithmetic the reference-side wrapper
+// oracle/ref_denoiser_wrap.cpp states identically).  family: 0 = CompVis (SD1.x / SDXL), 1 = discrete flow (SD3.x, shift 3), 2 = FLUX flow; method: the
+// sdm_sample_method_t value; eta: INFINITY = the method's default.  aux (optional, 5 floats per step): c_skip, c_out, c_in, t, sigma — what the loop fed the model.
+// Tests only (tests/test_host_logic.py: bit-for-bit against the reference's src/runtime/denoiser.hpp compiled into oracle/_ref).
+int sd_sample_synthetic(int family, int steps, int image_seq_len, int64_t n, uint64_t seed, int method, float eta, float* out, float* aux) {
+    if (steps < 1 || n < 1 || family < 0 || family > 2) return -1;
+    CompVisDenoiser cv;
+    DiscreteFlowDenoiser fl;
+    FluxFlowDenoiser fx;
+    const bool flow = family != 0;
+    if (eta == INFINITY) eta = method == SDM_EULER_A_SAMPLE_METHOD ? 1.0f : 0.0f;
+    const std::vector<float> sigmas = family == 0 ? cv.get_sigmas((uint32_t)steps) : (family == 1 ? fl.get_sigmas((uint32_t)steps) : fx.get_sigmas((uint32_t)steps, image_seq_len));
+    PhiloxRNG rng(seed);
+    std::vector<float> x = rng.randn((uint32_t)n), den((size_t)n), nz;
+    for (int64_t k = 0; k < n; ++k) x[k] = 0.0f + x[k] * sigmas[0];
+    for (int i = 0; i + 1 < (int)sigmas.size(); ++i) {
+        const float sigma = sigmas[i], sigma_to = sigmas[i + 1];
+        float c_skip, c_out, c_in;
+        if (family == 0) cv.scalings(sigma, c_skip, c_out, c_in);
+        else if (family == 1) fl.scalings(sigma, c_skip, c_out, c_in);
+        else fx.scalings(sigma, c_skip, c_out, c_in);
+        const float t = family == 0 ? cv.sigma_to_t(sigma) : (family == 1 ? fl.sigma_to_t(sigma) : sigma);
+        if (aux) {
+            float* a = aux + 5 * i;
+            a[0] = c_skip, a[1] = c_out, a[2] = c_in, a[3] = t, a[4] = sigma;
+        }
+        const float g = 1.0f / (1.0f + sigma), h = 0.01f * sigma;
+        for (int64_t k = 0; k < n; ++k) den[k] = x[k] * g + h;
+        float sigma_down = 0.f, sigma_up = 0.f, alpha_scale = 1.f;
+        if (method == SDM_EULER_A_SAMPLE_METHOD && sigma_to != 0.f && eta != 0.f) {
+            if (flow) ancestral_step_flow(sigma, sigma_to, eta, sigma_down, sigma_up, alpha_scale);
+            else ancestral_step(sigma, sigma_to, eta, sigma_down, sigma_up);
+        }
+        sampler_update(x.data(), den.data(), (size_t)n, 1, method == SDM_EULER_A_SAMPLE_METHOD, flow, sigma, sigma_to, eta, sigma_down, sigma_up, alpha_scale,
+                       [&](int) -> const float* {
+                           nz = rng.randn((uint32_t)n);
+                           return nz.data();
+                       });
+    }
+    memcpy(out, x.data(), sizeof(float) * (size_t)n);
+    return (int)sigmas.size();
+}
+void sd_cfg_combine(const float* cond, const float* uncond, int64_t n, float scale, float* out) {
+    for (int64_t k = 0; k < n; ++k) out[k] = cfg_guided(cond[k], uncond[k], scale);
+}
 void sd_set_vae_conv2d_scale(sdm_ctx_t* ctx, float scale) {
     if (!ctx || !(scale > 0.f)) return;
     ctx->vae_conv2d_scale = scale;

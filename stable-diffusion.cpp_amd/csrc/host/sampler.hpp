@@ -214,3 +214,50 @@ inline void ancestral_step_flow(float sigma_from, float sigma_to, float eta, flo
 }
 
 }  // namespace sdmi
+
+// classifier-free guidance on one element — sd::guidance::ClassifierFreeGuidance::forward, src/runtime/guidance.cpp:171: pred_uncond + guidance_scale *
+// (pred_cond - pred_uncond) on sd::Tensor<float>, i.e. THREE separately rounded f32 operations (difference, scaled difference, sum).  The host library is
+// built without FMA contraction (build.py HOST_FLAGS: baseline x86-64), and the volatile steps keep it that way under any flags: bit-exact against the
+// reference's own code (tests/test_host_logic.py::test_cfg_combine_bit_exact_vs_reference).
+inline float cfg_guided(float cond, float uncond, float scale) {
+    volatile float d = cond - uncond;
+    volatile float s = scale * d;
+    return uncond + s;
+}
+
+// One sampler update on `nb` images of `per` floats each — the arithmetic of the reference's sd::Tensor<float> expressions, operation by operation (every
+// tensor operator rounds to f32; scalars are cast to float before they meet the tensor, src/core/tensor.hpp:612-618, 750-760):
+//   Euler-A  (sample_euler_ancestral, src/runtime/denoiser.hpp:1513-1546):  sigma_to == 0: x = denoised;
+//            eta == 0: x = r*x + (1 - r)*denoised with r = sigma_to / sigma;  else r = sigma_down / sigma, the same blend, then (sigma_up > 0)
+//            [flow denoisers: x *= alpha_scale], x += noise * sigma_up
+//   Euler    (sample_euler, :1582-1597):  d = (x - denoised) / sigma;  x += d * (sigma_to - sigma)
+// noise(b) returns image b's `per` ancestral-noise floats (asked for only when sigma_up > 0).  The host library is built for baseline x86-64 (no FMA
+// contraction); tests/test_host_logic.py holds whole trajectories of this function bit-for-bit against the reference's own code (oracle/_ref).
+template <class NoiseFn>
+inline void sampler_update(float* x, const float* denoised, size_t per, int nb, bool euler_a, bool flow, float sigma, float sigma_to, float eta, float sigma_down,
+                           float sigma_up, float alpha_scale, NoiseFn&& noise) {
+    const size_t n = per * (size_t)nb;
+    if (!euler_a) {
+        const float ds = sigma_to - sigma;
+        for (size_t k = 0; k < n; ++k) {
+            const float d = (x[k] - denoised[k]) / sigma;
+            x[k] += d * ds;
+        }
+        return;
+    }
+    if (sigma_to == 0.f) {
+        for (size_t k = 0; k < n; ++k) x[k] = denoised[k];
+        return;
+    }
+    const float ratio = (eta == 0.f ? sigma_to : sigma_down) / sigma;
+    const float one_m = 1.0f - ratio;  // eta == 0: the reference writes (1.0 - ratio) in double and casts the scalar to float: the same value
+    for (size_t k = 0; k < n; ++k) x[k] = ratio * x[k] + one_m * denoised[k];
+    if (eta != 0.f && sigma_up > 0.f) {
+        if (flow)
+            for (size_t k = 0; k < n; ++k) x[k] *= alpha_scale;
+        for (int b = 0; b < nb; ++b) {
+            const float* nz = noise(b);
+            for (size_t k = 0; k < per; ++k) x[(size_t)b * per + k] += nz[k] * sigma_up;
+        }
+    }
+}
