@@ -4,6 +4,7 @@
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
+struct ggml_tensor;
 enum ggml_type { GGML_TYPE_F32 = 0, GGML_TYPE_F16 = 1, GGML_TYPE_COUNT = 64 };
 size_t ggml_type_size(enum ggml_type t);
 int64_t ggml_blck_size(enum ggml_type t);

@@ -126,6 +126,12 @@ inline std::string vae_diffusers_to_ldm(const std::string& name, const NameDiale
         return t;
     };
     if (p[1] == "conv_norm_out") return side + "norm_out." + join_from(p, 2);
+    // an LDM-layout name whose attention members are spelled the diffusers way (mid.attn_1.to_q / to_k / to_v / to_out.0): the reference rewrites those whenever
+    // the result holds "mid.attn_1." (vae_extra_conversion_map, src/name_conversion.cpp:957-996) — found by the table test against its own code (round 5)
+    if (p[1] == "mid" && p[2] == "attn_1" && p.size() >= 5) {
+        if (p[3] == "to_out" && p.size() >= 6 && p[4] == "0") return side + "mid.attn_1.proj_out." + join_from(p, 5);
+        if (p[3] == "to_q" || p[3] == "to_k" || p[3] == "to_v") return side + "mid.attn_1." + vae_attn_member(p[3]) + "." + join_from(p, 4);
+    }
     if (p[1] == "mid_block" && p.size() >= 5 && is_index(p[3])) {
         if (p[2] == "resnets") return side + "mid.block_" + std::to_string(std::stoi(p[3]) + 1) + "." + resnet_tail(4);
         if (p[2] == "attentions") {
