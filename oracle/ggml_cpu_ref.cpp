@@ -183,8 +183,65 @@ static inline void gemm_nt_2x4(const float* a0, const float* a1, const float* b0
     for (int a = 0; a < 2; ++a)
         for (int b = 0; b < 4; ++b) out[a][b] = hsum8(acc[a][b]) + tail[a][b];
 }
+// AVX-512 hosts (the GPU boxes' EPYC 9575F, this container's Xeon): a 4 x 4 block on 16-lane FMA chains — what ggml-cpu's vec_dot does there
+// (GGML_F32_EPR = 16).  Per-element arithmetic: 16 strided partial sums over k, a tree reduction, the scalar fma tail (K % 16).  It differs from the AVX2
+// block above by summation order only (~1e-7 relative); chosen at run time, ORACLE_NO_AVX512=1 forces the AVX2 block.  ~2-3x the AVX2 block's rate: the
+// whole-model oracle forwards of the full-width / full-depth GPU tests are what the GPU suite's wall time consists of.
+__attribute__((target("avx512f"))) static inline void gemm_nt_4x4_avx512(const float* const (&a)[4], const float* const (&b)[4], int64_t K, float (&out)[4][4]) {
+    __m512 acc[4][4];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) acc[i][j] = _mm512_setzero_ps();
+    int64_t k = 0;
+    for (; k + 16 <= K; k += 16) {
+        const __m512 va0 = _mm512_loadu_ps(a[0] + k), va1 = _mm512_loadu_ps(a[1] + k), va2 = _mm512_loadu_ps(a[2] + k), va3 = _mm512_loadu_ps(a[3] + k);
+        for (int j = 0; j < 4; ++j) {
+            const __m512 vb = _mm512_loadu_ps(b[j] + k);
+            acc[0][j]       = _mm512_fmadd_ps(va0, vb, acc[0][j]);
+            acc[1][j]       = _mm512_fmadd_ps(va1, vb, acc[1][j]);
+            acc[2][j]       = _mm512_fmadd_ps(va2, vb, acc[2][j]);
+            acc[3][j]       = _mm512_fmadd_ps(va3, vb, acc[3][j]);
+        }
+    }
+    float tail[4][4] = {{0}};
+    for (; k < K; ++k)
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) tail[i][j] = fmaf(a[i][k], b[j][k], tail[i][j]);
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) out[i][j] = _mm512_reduce_add_ps(acc[i][j]) + tail[i][j];
+}
+__attribute__((target("avx512f"))) static void gemm_nt_f32_avx512(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc_n, int64_t M, int64_t N, int64_t K) {
+    const int64_t groups = (N + 3) / 4;
+    const int nth        = std::max(1, omp_get_max_threads());
+    int64_t per          = groups / ((int64_t)nth * 4);
+    per                  = std::max<int64_t>(1, std::min<int64_t>(per, K <= 4096 ? 12 : (K <= 8192 ? 6 : 3)));
+    const int64_t NB = per * 4, nchunks = (N + NB - 1) / NB;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t ch = 0; ch < nchunks; ++ch) {
+        const int64_t nbeg = ch * NB, nend = std::min(N, nbeg + NB);
+        for (int64_t m0 = 0; m0 < M; m0 += 4) {
+            const int64_t mm   = std::min<int64_t>(4, M - m0);
+            const float* const a[4] = {A + m0 * lda, A + (m0 + (mm > 1 ? 1 : 0)) * lda, A + (m0 + (mm > 2 ? 2 : 0)) * lda, A + (m0 + (mm > 3 ? 3 : 0)) * lda};
+            for (int64_t n0 = nbeg; n0 < nend; n0 += 4) {
+                const int64_t nn   = std::min<int64_t>(4, N - n0);
+                const float* const b[4] = {B + n0 * ldb, B + (n0 + (nn > 1 ? 1 : 0)) * ldb, B + (n0 + (nn > 2 ? 2 : 0)) * ldb, B + (n0 + (nn > 3 ? 3 : 0)) * ldb};
+                float out[4][4];
+                gemm_nt_4x4_avx512(a, b, K, out);
+                for (int i = 0; i < mm; ++i)
+                    for (int j = 0; j < nn; ++j) C[(n0 + j) * ldc_n + m0 + i] = out[i][j];
+            }
+        }
+    }
+}
+static bool oracle_use_avx512() {
+    static const bool on = __builtin_cpu_supports("avx512f") && !getenv("ORACLE_NO_AVX512");
+    return on;
+}
 void gemm_nt_f32(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc_n, int64_t M, int64_t N, int64_t K) {
     // C element (m, n) stored at C[n*ldc_n + m]  (ggml dst layout: ne0 = M contiguous)
+    if (oracle_use_avx512()) {
+        gemm_nt_f32_avx512(A, lda, B, ldb, C, ldc_n, M, N, K);
+        return;
+    }
     // Schedule (round 5; results bit-identical to the round-1 loop, which walked all of A once per FOUR rows of B and ran at DRAM speed): a thread takes a
     // chunk of NB rows of B (kept in its L2 / L3 slice), walks the rows of A in pairs ONCE per chunk and reuses each pair (L1-resident) for every group of
     // four B rows of the chunk.  ~3x faster on the whole-model oracle forwards the full-depth parity tests run.

@@ -759,7 +759,7 @@ static int g_g16_t256p_pad = 1;
 void gemm16_set_t256p_pad(int v) { g_g16_t256p_pad = v; }
 // option "tail_split" (round 5): a 256 x 256-tile Linear whose tile count leaves the last of its >= 2 rounds mostly empty runs as TWO launches split by rows:
 // whole rounds of 256 x 256 tiles, then the remaining rows on the small tiles (g16_tail_rows).  No slab traffic, no reduction — unlike stream-K.
-static int g_g16_tail_split = 1;
+static int g_g16_tail_split = 0;  // default OFF: measured neutral on FLUX (57.64 vs 57.67 ms of Linear kernels per forward) and SD3.5 (58.23 vs 58.17), profiles/r06b_ab_*_tail_split.txt
 void gemm16_set_tail_split(int v) { g_g16_tail_split = v; }
 static bool g16_pad256_ok(int64_t M, int geglu, bool conv, int mul) {
     return g_g16_t256p_pad && !conv && mul == 1 && geglu == 0 && M % 128 == 0 && M % 256 != 0 && M >= 2048;  // >= 2048: the empty half tile is <= 6 % of the columns
