@@ -184,7 +184,7 @@ static inline void gemm_nt_2x4(const float* a0, const float* a1, const float* b0
         for (int b = 0; b < 4; ++b) out[a][b] = hsum8(acc[a][b]) + tail[a][b];
 }
 // AVX-512 hosts (the GPU boxes' EPYC 9575F, this container's Xeon): a 4 x 4 block on 16-lane FMA chains — what ggml-cpu's vec_dot does there
-// (GGML_F32_EPR = 16).  Per-element arithmetic: 16 strided partial sums over k, a tree reduction, the scalar fma tail (K % 16).  It differs from the AVX2
+// (GGML_F32_EPR = 16).  Per-element arithmetic: 16 strided partial sums over k (the last K % 16 elements in one masked step), a tree reduction.  It differs from the AVX2
 // block above by summation order only (~1e-7 relative); chosen at run time, ORACLE_NO_AVX512=1 forces the AVX2 block.  ~2-3x the AVX2 block's rate: the
 // whole-model oracle forwards of the full-width / full-depth GPU tests are what the GPU suite's wall time consists of.
 __attribute__((target("avx512f"))) static inline void gemm_nt_4x4_avx512(const float* const (&a)[4], const float* const (&b)[4], int64_t K, float (&out)[4][4]) {
@@ -202,12 +202,19 @@ __attribute__((target("avx512f"))) static inline void gemm_nt_4x4_avx512(const f
             acc[3][j]       = _mm512_fmadd_ps(va3, vb, acc[3][j]);
         }
     }
-    float tail[4][4] = {{0}};
-    for (; k < K; ++k)
-        for (int i = 0; i < 4; ++i)
-            for (int j = 0; j < 4; ++j) tail[i][j] = fmaf(a[i][k], b[j][k], tail[i][j]);
+    if (k < K) {  // the last K % 16 elements: one masked step on the same lane chains (attention's K = d_head = 40 would otherwise run 128 scalar fmas per block)
+        const __mmask16 m = (__mmask16)((1u << (K - k)) - 1u);
+        const __m512 va0 = _mm512_maskz_loadu_ps(m, a[0] + k), va1 = _mm512_maskz_loadu_ps(m, a[1] + k), va2 = _mm512_maskz_loadu_ps(m, a[2] + k), va3 = _mm512_maskz_loadu_ps(m, a[3] + k);
+        for (int j = 0; j < 4; ++j) {
+            const __m512 vb = _mm512_maskz_loadu_ps(m, b[j] + k);
+            acc[0][j]       = _mm512_fmadd_ps(va0, vb, acc[0][j]);
+            acc[1][j]       = _mm512_fmadd_ps(va1, vb, acc[1][j]);
+            acc[2][j]       = _mm512_fmadd_ps(va2, vb, acc[2][j]);
+            acc[3][j]       = _mm512_fmadd_ps(va3, vb, acc[3][j]);
+        }
+    }
     for (int i = 0; i < 4; ++i)
-        for (int j = 0; j < 4; ++j) out[i][j] = _mm512_reduce_add_ps(acc[i][j]) + tail[i][j];
+        for (int j = 0; j < 4; ++j) out[i][j] = _mm512_reduce_add_ps(acc[i][j]);
 }
 __attribute__((target("avx512f"))) static void gemm_nt_f32_avx512(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc_n, int64_t M, int64_t N, int64_t K) {
     const int64_t groups = (N + 3) / 4;
@@ -972,9 +979,21 @@ void be_free(ggml_backend_t b) { delete b; }
 void be_sync(ggml_backend_t) {}
 enum ggml_status be_graph_compute(ggml_backend_t, ggml_cgraph* g) {
     init_tables();
+    static const bool prof = getenv("ORACLE_PROFILE") != nullptr;  // per-op wall time of every graph, printed to stderr (where does an oracle forward spend its time?)
+    double t_op[GGML_OP_COUNT + 1] = {0};
     for (int i = 0; i < g->n_nodes; ++i) {
+        const double t0 = prof ? omp_get_wtime() : 0.0;
         enum ggml_status st = compute_node(g->nodes[i]);
         if (st != GGML_STATUS_SUCCESS) return st;
+        if (prof) t_op[std::min<int>((int)g->nodes[i]->op, GGML_OP_COUNT)] += omp_get_wtime() - t0;
+    }
+    if (prof) {
+        double tot = 0;
+        for (double v : t_op) tot += v;
+        fprintf(stderr, "[oracle profile] %d nodes, %.3f s:", g->n_nodes, tot);
+        for (int o = 0; o <= GGML_OP_COUNT; ++o)
+            if (t_op[o] > 0.01 * tot) fprintf(stderr, " op%d %.3f", o, t_op[o]);
+        fprintf(stderr, "\n");
     }
     return GGML_STATUS_SUCCESS;
 }

@@ -68,11 +68,8 @@ __global__ __launch_bounds__(512, 2) void k_conv3w(G16Args g) {
         if (wave >= 4) __builtin_amdgcn_s_setprio(1);
     }
 
-    int bid = blockIdx.x;
-    {
-        const int nb = gridDim.x;
-        if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);  // XCD-aware: consecutive tiles of one XCD share rows / halos
-    }
+    int bid, kslice;
+    g16_wg_order(g, g.ncol_tiles, bid, kslice);  // default: XCD-aware, consecutive tiles of one XCD share rows / halos; weight-heavy launches: weight-major
     const int row_tile = bid / g.ncol_tiles;
     const int col_tile = bid - row_tile * g.ncol_tiles;
     const int64_t row0 = (int64_t)row_tile * 256;
@@ -81,9 +78,9 @@ __global__ __launch_bounds__(512, 2) void k_conv3w(G16Args g) {
     // K range of this workgroup: 32-channel blocks [icb0, icb0 + nicb)
     int icb0 = 0, nicb = g.nt;  // g.nt = number of 32-channel blocks for this kernel
     if (g.split_k > 1) {
-        icb0 = blockIdx.y * g.nt_slice;
+        icb0 = kslice * g.nt_slice;
         nicb = min(g.nt_slice, g.nt - icb0);
-        g.dst += (int64_t)blockIdx.y * g.slab;
+        g.dst += (int64_t)kslice * g.slab;
     }
 
     // ---- tile position: image n, first row oy0 (TW == image width: a tile is TR full rows)
@@ -408,6 +405,7 @@ void launch_conv3w(hipStream_t s, float* dst, const void* x16_nhwc, const void* 
         S = 1;
     }
     const unsigned tiles = (unsigned)((g.R / 256) * g.ncol_tiles);
+    g.worder             = gemm16_worder_rows(g, tiles, (unsigned)S);  // 16x16-level 1280-channel convs: 29.5 .. 59 MB of weights against 10.5 MB of image
     const double bytes   = (double)N * H * W * g.ICp * 2.0 + (double)g.ICp * 9 * ((OC + 127) / 128 * 128) * 2.0 + (double)g.R * OC * 4.0 * (e.residual ? 2.0 : 1.0);
     {
         KScope ks_(s, KF_CONV_T256, 2.0 * g.R * IC * 9 * OC, bytes);

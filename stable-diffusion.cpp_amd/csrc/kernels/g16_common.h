@@ -29,6 +29,11 @@ struct G16Args {
     int hm_d, hm_H, hm_L;  // head-major store (rows mode): element (row = n*L + l, col = h*d + dd) -> ((n*H + h)*L + l)*d + dd
     int64_t R, C;
     int64_t row_base;  // rows mode: this launch's tiles start at row row_base (a multiple of 256) of the R rows — the second launch of a row-split Linear (g16_launch: tail rows on smaller tiles)
+    int worder;        // > 0: WEIGHT-MAJOR workgroup order, value = row tiles of the launch (g16_wg_order).  Launches whose weight bytes dominate their activation
+                       // bytes (the 8x8 / 16x16 UNet levels: 29.5 .. 59 MB of weights against 2.6 .. 10.5 MB of NHWC image, K cut into slices) keep every
+                       // (column tile, K slice) weight chunk on ONE XCD — its row tiles run back to back there and re-read the chunk from that XCD's L2 — instead
+                       // of the default order (consecutive ids of one XCD share the A rows), under which every XCD fetched every weight chunk:
+                       // 297 MB fetched per launch for 29.5 MB of weights (profiles/r06c_pmc_conv256_by_shape.txt)
     int wblk_lim;      // > 0: 32-column blocks the weight image holds (columns padded to 128): tiles wider than the padding (256-column tiles on M % 256 == 128) fetch block wblk_lim - 1 instead of reading past the image
     int nt;            // K tiles (BK each)
     int ncol_tiles;
@@ -61,6 +66,28 @@ struct G16Args {
     int abl;  // option "gemm16_abl" (wrong-result timing ablations): 5 = GEGLU epilogue without the GELU arithmetic, 6 = epilogue without its stores, 7 = no main loop
 #endif
 };
+
+// host side (gemm16.hip): row tiles for G16Args::worder when a conv launch of gx x ny workgroups should run weight-major, else 0 (option "conv_wmajor")
+int gemm16_worder_rows(const G16Args& g, unsigned gx, unsigned ny);
+void gemm16_set_conv_wmajor(int v);
+// workgroup -> (tile id, K slice).  Default: XCD-aware tile order over blockIdx.x (consecutive ids on one XCD share the A row tile), slice = blockIdx.y.
+// Weight-major (g.worder = row tiles; needs gridDim.x % 8 == 0 and (column tiles x slices) % 8 == 0, checked by the launcher): workgroup L = y * gridDim.x + x
+// runs on XCD L % 8; XCD k takes the (column tile, slice) pairs p = k, k + 8, ... and walks the row tiles of one pair back to back.
+__device__ __forceinline__ void g16_wg_order(const G16Args& g, int ncol_all, int& bid, int& kslice) {
+    if (g.worder > 0) {
+        const int L  = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x;
+        const int k  = L & 7, j = L >> 3;
+        const int pl = j / g.worder, r = j - pl * g.worder;
+        const int p  = pl * 8 + k;
+        kslice       = p / ncol_all;
+        bid          = r * ncol_all + (p - kslice * ncol_all);
+        return;
+    }
+    const int nb = gridDim.x;
+    bid          = blockIdx.x;
+    if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);
+    kslice = blockIdx.y;
+}
 
 #define GLDS16(gptr, ldsptr) \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr), (__attribute__((address_space(3))) void*)(ldsptr), 16, 0, 0)

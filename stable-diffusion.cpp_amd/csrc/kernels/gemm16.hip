@@ -94,7 +94,7 @@ __global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g
     int lane = lane0;
     if constexpr (SK) asm volatile("" : "+v"(lane));
     // XCD-aware tile order: consecutive ids on one XCD share the A row tile (all column tiles of a row tile)
-    int bid = blockIdx.x;
+    int bid = blockIdx.x, kslice = blockIdx.y;
     // split-K: this workgroup accumulates K tiles [kt0, kt0 + nt) and stores raw partial sums into its slab
     int kt0 = 0, nt = g.nt;
     if constexpr (SK) {
@@ -112,15 +112,14 @@ __global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g
         sk_more = sk_u < sk_end || dp_t < dp_end;
     } else {
         sk_more = false;
-        const int nb = gridDim.x;
-        if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);
+        g16_wg_order(g, g.multi > 1 ? g.ncol_tiles * g.multi : g.ncol_tiles, bid, kslice);
 #ifdef MI355X_EXPERIMENTS
         if (g.abl == 7) nt = PIPE ? 4 : 1;  // timing ablation: (almost) no main loop, the launch's fixed cost + epilogue
 #endif
         if (g.split_k > 1) {
-            kt0 = blockIdx.y * g.nt_slice;
+            kt0 = kslice * g.nt_slice;
             nt  = min(g.nt_slice, g.nt - kt0);
-            if (!g.sk_cnt) g.dst += (int64_t)blockIdx.y * g.slab;
+            if (!g.sk_cnt) g.dst += (int64_t)kslice * g.slab;
         }
     }
     const int nct_all  = g.multi > 1 ? g.ncol_tiles * g.multi : g.ncol_tiles;
@@ -578,7 +577,7 @@ __global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g
         constexpr int TILE_B = BM * BN * 4;
         char* slab0          = (char*)g.sk_slab + (int64_t)bid * g.split_k * TILE_B;  // wave-uniform
         const auto rs        = __builtin_amdgcn_make_buffer_rsrc((void*)slab0, 0, g.split_k * TILE_B, 0x00020000);
-        const int mine       = (int)blockIdx.y * TILE_B;
+        const int mine       = kslice * TILE_B;
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
@@ -903,6 +902,20 @@ bool gemm16_split_col_supported(int64_t rows, int64_t M, int64_t K) {
     return gemm16_split_k(rows, M, K, false) == 1 && g16_pick_tile(rows, M, false, false, 0, nt, 1) == G16_T256P;
 }
 
+// option "conv_wmajor" (round 5, default 1): conv launches whose weight image is at least twice their NHWC input image run in weight-major workgroup order
+// (G16Args::worder, g16_wg_order).  0 = the A-major order everywhere (A/B measurements).
+static int g_g16_conv_wmajor = 1;
+void gemm16_set_conv_wmajor(int v) { g_g16_conv_wmajor = v; }
+int gemm16_worder_rows(const G16Args& g, unsigned gx, unsigned ny) {
+    if (!g_g16_conv_wmajor || g.KS == 0 || g.ncol_tiles <= 0 || g.multi > 1 || g.sk_grid > 0) return 0;
+    if (gx % 8 != 0 || gx % (unsigned)g.ncol_tiles != 0 || ((unsigned)g.ncol_tiles * ny) % 8 != 0) return 0;
+    const int nrow = (int)(gx / (unsigned)g.ncol_tiles);
+    if (nrow < 2) return 0;  // one row tile: nothing shares a weight chunk
+    const int64_t imgs = g.OHOW > 0 ? g.R / g.OHOW : 1;
+    const double act   = (double)imgs * g.H * g.Wd * g.ICp * 2.0;
+    const double wts   = (double)g.ICp * g.KS * g.KS * (double)rup64(g.C, 128) * 2.0;
+    return wts >= 2.0 * act ? nrow : 0;
+}
 template <int BN_, bool CONV_>
 static void g16_launch(hipStream_t s, G16Args& g, int64_t rows, double flops, double bytes) {  // bytes: algorithmic HBM bytes (operand images read once + output written once [+ residual])
     const unsigned ny = g.split_k > 1 ? (unsigned)g.split_k : 1u;
@@ -946,6 +959,11 @@ static void g16_launch(hipStream_t s, G16Args& g, int64_t rows, double flops, do
         if (tile != G16_T128) {
             const int64_t rt256 = (rows + 255) / 256;
             KScope ks_(s, CONV_ ? KF_CONV_T256 : KF_LINEAR, flops, bytes);
+            if constexpr (CONV_) {  // weight-heavy convs (8x8 / 16x16 UNet levels): weight-major workgroup order
+                G16Args t    = g;
+                t.ncol_tiles = tile == G16_T320 ? (int)((g.C + 319) / 320) : (tile == G16_T256P ? (int)((g.C + 255) / 256) : ((tile == G16_T160 || tile == G16_T160N) ? (int)(g.C / 160) : g.ncol_tiles));
+                g.worder     = gemm16_worder_rows(t, (unsigned)(rt256 * t.ncol_tiles * mul), ny);
+            }
             if (tile == G16_T320) {
                 g.ncol_tiles = (int)((g.C + 319) / 320);
 #ifdef MI355X_EXPERIMENTS

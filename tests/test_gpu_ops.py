@@ -1081,6 +1081,43 @@ def test_conv2d_split_k(sd, oracle, gpu, rng, N, IC, OC, H, W, ks, stride):
         assert sd.backend_stats()["split_k_gemms"] == before["split_k_gemms"] + 1
 
 
+@pytest.mark.parametrize("N,IC,OC,HW", [(16, 1280, 1280, 16), (16, 1280, 1280, 8), (16, 2560, 1280, 16), (16, 2560, 1280, 8), (8, 1280, 1280, 16), (16, 1920, 640, 16)])
+def test_conv2d_weight_major_workgroup_order(sd, oracle, gpu, rng, N, IC, OC, HW):
+    """Round 5 (g16_common.h g16_wg_order, option conv_wmajor): the 8x8 / 16x16-level 3x3 convs of the benchmarked SD1.5 batch (16 images; 29.5 .. 59 MB of weights
+    against 2.6 .. 21 MB of NHWC image, K cut into 4 .. 16 slices) run their workgroups weight-major — every (column tile, K slice) weight chunk on one XCD.  Every
+    (tile, slice) computes what it computed before and the slab reduce sums in slice order, so the result is BIT-IDENTICAL to the default order; also against the
+    oracle.  Both kernels that take such shapes: k_conv3w<16> (16-wide maps) and the implicit-GEMM k_gemm16<256, 320, true> (8-wide maps)."""
+    x = rng.standard_normal((N, IC, HW, HW)).astype(np.float32)
+    w = (rng.standard_normal((OC, IC, 3, 3)) / np.sqrt(IC * 9)).astype(np.float32)
+    b = rng.standard_normal(OC).astype(np.float32)
+    r = rng.standard_normal((N, OC, HW, HW)).astype(np.float32)
+
+    def build(g, L):
+        y = L.ggml_conv_2d(g.ctx, g.weight(w, F16), g.input(x), 1, 1, 1, 1, 1, 1)
+        y = L.ggml_add_inplace(g.ctx, y, L.ggml_reshape_4d(g.ctx, g.weight(b, F32), 1, 1, OC, 1))
+        return L.ggml_add(g.ctx, y, g.input(r))
+
+    if not _on_gpu():
+        pytest.skip("workgroup order of the MI355X kernels")
+    with Graph(oracle) as g:
+        ref = g.run(build(g, sd.lib()))
+
+    def run_gpu():
+        with Graph(gpu) as g:
+            return g.run(build(g, sd.lib()))
+
+    try:
+        sd.backend_set_option("conv_wmajor", 0)
+        plain = run_gpu()
+        sd.backend_set_option("conv_wmajor", 1)
+        out = run_gpu()
+    finally:
+        sd.backend_set_option("conv_wmajor", 1)
+    assert np.isfinite(out).all()
+    np.testing.assert_array_equal(out, plain)
+    assert rel_l2(out, ref) < 2e-4
+
+
 @pytest.mark.parametrize("N,C,H,W,res", [(8, 256, 8, 8, True), (8, 320, 16, 16, False), (8, 1280, 16, 16, True), (8, 640, 32, 32, True), (2, 256, 8, 8, True)])
 def test_split_conv_reduce_writes_group_norm_statistics(sd, oracle, gpu, rng, N, C, H, W, res):
     """ResBlock seam (block.hpp:126-179 -> next block's norm): a split-K 3x3 conv (+bias, +residual) whose result is read by GroupNorm -> affine -> SiLU -> conv

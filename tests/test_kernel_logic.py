@@ -572,3 +572,47 @@ def test_half_empty_column_tile_fetches_stay_inside_the_weight_image(M):
             assert 0 <= wbc < lim
             if wb * 32 < M:
                 assert wbc == wb   # every block that holds real columns is fetched from its own place
+
+
+# ---- round 5: weight-major workgroup order (g16_common.h g16_wg_order) -----------------------------------------------------------------------------------
+def wg_order(x, y, gx, ncol, worder):
+    """restatement of g16_wg_order: workgroup (x, y) of a gx x S grid -> (tile id, K slice)"""
+    if worder > 0:
+        L = y * gx + x
+        k, j = L & 7, L >> 3
+        pl, r = divmod(j, worder)
+        p = pl * 8 + k
+        ks, ct = divmod(p, ncol)
+        return r * ncol + ct, ks
+    bid = (x & 7) * (gx >> 3) + (x >> 3) if gx % 8 == 0 else x
+    return bid, y
+
+
+@pytest.mark.parametrize("nrow,ncol,S", [(4, 4, 16), (16, 4, 4), (16, 4, 8), (4, 8, 2), (2, 4, 2), (8, 8, 1), (16, 8, 3)])
+def test_weight_major_order_is_a_bijection_and_keeps_a_weight_chunk_on_one_xcd(nrow, ncol, S):
+    """8x8 / 16x16-level convs (4 x 4 tiles x 16 slices; 16 x 4 tiles x 4 slices): every (tile, slice) is computed exactly once, every (column tile, slice)
+    weight chunk is touched by ONE XCD only (workgroup L = y * gx + x runs on XCD L % 8), and its row tiles are consecutive in that XCD's dispatch order."""
+    gx = nrow * ncol
+    assert gx % 8 == 0 and (ncol * S) % 8 == 0   # the launcher's conditions (gemm16_worder_rows)
+    seen, xcd_of, order = set(), {}, {}
+    for y in range(S):
+        for x in range(gx):
+            bid, ks = wg_order(x, y, gx, ncol, nrow)
+            assert 0 <= bid < gx and 0 <= ks < S
+            assert (bid, ks) not in seen
+            seen.add((bid, ks))
+            L = y * gx + x
+            chunk = (bid % ncol, ks)
+            assert xcd_of.setdefault(chunk, L % 8) == L % 8
+            order.setdefault(chunk, []).append(L >> 3)
+    assert len(seen) == gx * S
+    for chunk, js in order.items():
+        js = sorted(js)
+        assert js == list(range(js[0], js[0] + nrow))   # back to back on that XCD
+    # the default order, for contrast: a weight chunk is fetched by several XCDs
+    xcds = {}
+    for y in range(S):
+        for x in range(gx):
+            bid, ks = wg_order(x, y, gx, ncol, 0)
+            xcds.setdefault((bid % ncol, ks), set()).add((y * gx + x) % 8)
+    assert max(len(v) for v in xcds.values()) > 1 or nrow * ncol <= 8
