@@ -3629,6 +3629,7 @@ void planner_set_option(const char* key, int value) {
     else if (!strcmp(key, "t256p_pad")) gemm16_set_t256p_pad(value);
     else if (!strcmp(key, "tail_split")) gemm16_set_tail_split(value);
     else if (!strcmp(key, "conv_wmajor")) gemm16_set_conv_wmajor(value);
+    else if (!strcmp(key, "ln16_rows")) gemm16_set_ln16_rows(value);
     else if (!strcmp(key, "t320_linear_max_split")) gemm16_set_t320_linear_max_split(value);
     else if (!strcmp(key, "qgemv")) g_opt.qgemv = value;
     else if (!strcmp(key, "fuse_q16")) g_opt.fuse_q16 = value;

@@ -1840,12 +1840,90 @@ __global__ __launch_bounds__(256) void k_layer_norm_f16_reg(_Float16* __restrict
         *(half4_t*)(yr + i * 4) = h;
     }
 }
+// R rows per wave (round 5): the loads of all R rows are issued before the first reduction, so a wave keeps R x 1.25 .. 5 KB in flight instead of one row's —
+// k_layer_norm_f16 ran at 40 % of the HBM peak with traffic = algorithmic bytes (profiles/r05a_pmc_traffic_layer_norm_f16.json): latency, not bytes.  The arithmetic
+// of a row is the single-row kernel's, statement for statement (bit-identical outputs).  MEASURED SLOWER and left off (option "ln16_rows" = 4 selects it): see g_ln16_rows.
+template <int NV, int R>
+__global__ __launch_bounds__(256) void k_layer_norm_f16_rows(_Float16* __restrict__ dst, const float* __restrict__ x, int ne0, int Kp, int64_t nrows, int64_t xs,
+                                                             float eps, const float* __restrict__ w, const float* __restrict__ b, int rms, int64_t mod_L) {
+    const int lane     = threadIdx.x & 63;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+    if (row0 >= nrows) return;
+    const float wadd = mod_L > 0 ? 1.f : 0.f;
+    const int n4     = ne0 / 4;
+    float4 v[R][NV];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t row = row0 + r < nrows ? row0 + r : nrows - 1;  // a ragged last group re-reads the last row (its stores are masked below)
+        const float4* xr  = (const float4*)(x + row * xs);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = lane + 64 * j;
+            v[r][j]     = i < n4 ? xr[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    float mean[R], rstd[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        mean[r] = 0.f;
+        if (!rms) {
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) s += (v[r][j].x + v[r][j].y) + (v[r][j].z + v[r][j].w);
+            mean[r] = wave_sum(s) / (float)ne0;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            if (lane + 64 * j < n4) {
+                const float a = v[r][j].x - mean[r], bb = v[r][j].y - mean[r], c = v[r][j].z - mean[r], d = v[r][j].w - mean[r];
+                q += (a * a + bb * bb) + (c * c + d * d);
+            }
+        }
+        rstd[r] = rsqrtf(wave_sum(q) / (float)ne0 + eps);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t row = row0 + r;
+        if (row >= nrows) break;
+        const float* wr = w;
+        const float* br = b;
+        if (mod_L > 0) {
+            wr = w + (row / mod_L) * ne0;
+            br = b + (row / mod_L) * ne0;
+        }
+        _Float16* yr = dst + row * Kp;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = lane + 64 * j;
+            if (i >= Kp / 4) continue;
+            half4_t h = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+            if (i < n4) {
+                float4 t = v[r][j];
+                t.x = (t.x - mean[r]) * rstd[r]; t.y = (t.y - mean[r]) * rstd[r]; t.z = (t.z - mean[r]) * rstd[r]; t.w = (t.w - mean[r]) * rstd[r];
+                if (wr) { const float4 ww = ((const float4*)wr)[i]; t.x *= ww.x + wadd; t.y *= ww.y + wadd; t.z *= ww.z + wadd; t.w *= ww.w + wadd; }
+                if (br) { const float4 bb = ((const float4*)br)[i]; t.x += bb.x; t.y += bb.y; t.z += bb.z; t.w += bb.w; }
+                h[0] = (_Float16)t.x; h[1] = (_Float16)t.y; h[2] = (_Float16)t.z; h[3] = (_Float16)t.w;
+            }
+            *(half4_t*)(yr + i * 4) = h;
+        }
+    }
+}
+static int g_ln16_rows = 1;  // option "ln16_rows": rows per wave of the register-resident LayerNorm -> f16 image kernel.  Default 1 = the single-row kernel: the multi-row form (4) measured SLOWER — SD1.5 family 0.963 -> 1.032 ms, SDXL 0.343 -> 0.381 ms, step 21.98 -> 22.08 ms (profiles/r06e_*): fewer, fatter waves hide less than many thin ones here
+void gemm16_set_ln16_rows(int v) { g_ln16_rows = v; }
 void launch_layer_norm_f16(hipStream_t s, void* dst, const float* x, int64_t ne0, int64_t nrows, int64_t xs, float eps, const float* w, const float* b, bool rms,
                            int64_t mod_L) {
     KScope ks_(s, KF_LN_F16, 0.0, (double)nrows * ne0 * 4.0 + (double)nrows * rup64(ne0, 64) * 2.0);
     const int Kp = (int)rup64(ne0, 64);
 #define LN16_ARGS (_Float16*)dst, x, (int)ne0, Kp, nrows, xs, eps, w, b, rms ? 1 : 0, mod_L
     const unsigned grid = (unsigned)((nrows + 3) / 4);
+    if (g_ln16_rows > 1 && nrows >= 4096 && ne0 % 4 == 0) {  // enough rows to fill the chip with multi-row waves
+        if (Kp <= 256 * 2) return (void)k_layer_norm_f16_rows<2, 4><<<(unsigned)((nrows + 15) / 16), 256, 0, s>>>(LN16_ARGS);
+        if (Kp <= 256 * 5) return (void)k_layer_norm_f16_rows<5, 2><<<(unsigned)((nrows + 7) / 8), 256, 0, s>>>(LN16_ARGS);
+    }
     if (Kp <= 256 * 2)
         k_layer_norm_f16_reg<2><<<grid, 256, 0, s>>>(LN16_ARGS);
     else if (Kp <= 256 * 5)

@@ -123,6 +123,7 @@ void gemm16_set_abl(int v);
 void gemm16_set_t320(int v);
 void gemm16_set_t256p_pad(int v);   // option "t256p_pad" (1): 256 x 256 pipelined tile for Linear widths that are multiples of 128 only (last column tile half empty)
 void gemm16_set_conv_wmajor(int v);  // option "conv_wmajor" (1): weight-major workgroup order for convs whose weight image is >= 2x their input image
+void gemm16_set_ln16_rows(int v);    // option "ln16_rows" (4): rows per wave of the LayerNorm -> f16 operand image kernel for rows of <= 1280 values
 void gemm16_set_tail_split(int v);  // option "tail_split" (1): row-split launches (whole rounds of 256 x 256 tiles + the remaining rows on small tiles)
 void gemm16_set_bn64(int v);     // 0: never choose the pipelined 256x320 tile
 void gemm16_set_variant(int v);  // 0: BK64x2 stages, 1: BK32x3 stages (default), 2: BK64x3 stages

@@ -221,6 +221,35 @@ def test_layer_norm_chain(sd, oracle, gpu, rng, C, rows):
     assert np.abs(out - ref).max() < 3e-5
 
 
+@pytest.mark.parametrize("C,rows,rms", [(320, 4101, False), (640, 16384, False), (1280, 4096, False), (300, 5000, False), (64, 4200, True), (1280, 4099, True)])
+def test_layer_norm_into_linear_operand_image_multi_row_waves(sd, oracle, gpu, rng, C, rows, rms):
+    """Round 5 (gemm16.hip k_layer_norm_f16_rows, option ln16_rows): LayerNorm / RMSNorm (+ affine) feeding a Linear writes the GEMM's f16 operand image; with >= 4096
+    rows of <= 1280 values a wave handles 4 (C <= 512) or 2 rows with all loads in flight before the first reduction.  Per-row arithmetic is the single-row
+    kernel's: bit-identical to the default single-row kernel (ragged row counts included); also against the oracle.  Measured slower, so off by default."""
+    x = (rng.standard_normal((rows, C)) * 2 + 1).astype(np.float32)
+    w = rng.standard_normal(C).astype(np.float32)
+    b = rng.standard_normal(C).astype(np.float32)
+    wl = (rng.standard_normal((96, C)) / np.sqrt(C)).astype(np.float32)
+
+    def build(g, L):
+        t = (L.ggml_rms_norm if rms else L.ggml_norm)(g.ctx, g.input(x), 1e-5)
+        t = L.ggml_mul_inplace(g.ctx, t, g.weight(w, F32))
+        if not rms:
+            t = L.ggml_add_inplace(g.ctx, t, g.weight(b, F32))
+        return L.ggml_mul_mat(g.ctx, g.weight(wl, F16), t)
+
+    ref, out = run_both(sd, oracle, gpu, build)
+    assert rel_l2(out, ref) < 3e-4
+    if _on_gpu():
+        try:
+            sd.backend_set_option("ln16_rows", 4)   # the multi-row kernel (measured slower, off by default: profiles/r06e_*)
+            with Graph(gpu) as g:
+                multi = g.run(build(g, sd.lib()))
+        finally:
+            sd.backend_set_option("ln16_rows", 1)
+        np.testing.assert_array_equal(out, multi)
+
+
 def test_soft_max(sd, oracle, gpu, rng):
     x = (rng.standard_normal((3, 4, 50, 77)) * 4).astype(np.float32)
     ref, out = run_both(sd, oracle, gpu, lambda g, L: L.ggml_soft_max(g.ctx, g.input(x)))
