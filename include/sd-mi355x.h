@@ -209,6 +209,9 @@ SD_API void sd_set_guidance(sdm_ctx_t* ctx, float guidance); /* FLUX distilled-g
 /* the host sampler's classifier-free-guidance combine on n floats: out = uncond + scale * (cond - uncond), three separately rounded f32 operations like
  * sd::guidance::ClassifierFreeGuidance::forward on sd::Tensor<float> (src/runtime/guidance.cpp:171) — bit-exact against that code compiled into oracle/_ref */
 SD_API void sd_cfg_combine(const float* cond, const float* uncond, int64_t n, float scale, float* out);
+/* the pixel stage of sdm_generate_image on caller memory: planar CHW floats in [0, 1] -> interleaved RGB bytes (src/runtime/preprocessing.hpp:27-60); for the
+ * bit-exact test against that header compiled into oracle/_ref */
+SD_API void sd_planar_rgb_to_u8(const float* chw, int width, int height, uint8_t* out);
 /* the host sampler loop (sigma ladder, initial noise, scalings / timestep per step, ancestral step, update, Philox noise order) on one image of n floats with
  * a synthetic model, denoised = x / (1 + sigma) + 0.01 * sigma: family 0 CompVis (SD1.x / SDXL), 1 discrete flow (SD3.x), 2 FLUX flow; method = sdm_sample_method_t;
  * eta INFINITY = the method's default; aux: optional 5 floats per step (c_skip, c_out, c_in, t, sigma).  Returns the ladder length, -1 on bad arguments.  For the

@@ -15,6 +15,7 @@
 
 #include "core/rng_philox.hpp"
 #include "runtime/denoiser.hpp"
+#include "runtime/preprocessing.hpp"
 
 // util.cpp / ggml symbols the headers declare and these paths never call
 KeyValueArgs parse_key_value_args(const char*, const char*) { return {}; }
@@ -23,6 +24,7 @@ bool parse_strict_float(const std::string&, float&) { return false; }
 bool parse_strict_bool(const std::string&, bool&) { return false; }
 bool parse_strict_int(const std::string&, int&) { return false; }
 void log_printf(sd_log_level_t, const char*, int, const char*, ...) {}
+float sd_image_get_f32(sd_image_t, int64_t, int64_t, int64_t, bool) { return 0.f; }  // named by preprocessing.hpp's image -> tensor helpers, which nothing here calls
 size_t ggml_type_size(enum ggml_type) { return 4; }
 int64_t ggml_blck_size(enum ggml_type) { return 1; }
 const char* ggml_type_name(enum ggml_type) { return "stub"; }
@@ -98,4 +100,10 @@ REF_API int ref_sample_synthetic(int family, int steps, int image_seq_len, int64
     if (r.numel() != n) return -1;
     std::memcpy(out, r.data(), sizeof(float) * (size_t)n);
     return (int)sigmas.size();
+}
+// the pixel stage: planar CHW floats -> interleaved RGB bytes — preprocessing_tensor_frame_to_sd_image (src/runtime/preprocessing.hpp:37-60, float_to_u8 :27-35), what
+// tensor_to_sd_image (src/core/util.cpp:678-693) calls on the decoded image
+REF_API void ref_planar_rgb_to_u8(const float* chw, int width, int height, uint8_t* out) {
+    sd::Tensor<float> t({width, height, 3, 1}, std::vector<float>(chw, chw + (size_t)width * height * 3));
+    preprocessing_tensor_frame_to_sd_image(t, 0, out);
 }

@@ -716,6 +716,18 @@ def philox_uint32(seed: int, offset: int, n: int) -> np.ndarray:
     return out
 
 
+def planar_rgb_to_u8(chw: np.ndarray) -> np.ndarray:
+    """The pixel stage of sdm_generate_image on caller memory (sd_planar_rgb_to_u8): [3, H, W] floats -> [H, W, 3] bytes."""
+    x = np.ascontiguousarray(chw, dtype=np.float32)
+    _, h, w = x.shape
+    out = np.empty((h, w, 3), np.uint8)
+    L = lib()
+    L.sd_planar_rgb_to_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.sd_planar_rgb_to_u8.restype = None
+    L.sd_planar_rgb_to_u8(x.ctypes.data, w, h, out.ctypes.data)
+    return out
+
+
 def sample_synthetic(family: int, steps: int, n: int, seed: int, method: int = EULER_A, eta: float = float("inf"), image_seq_len: int = 0):
     """The host sampler loop on one image of n floats with a synthetic model (sd_sample_synthetic): returns (latents, aux[steps, 5] = c_skip, c_out, c_in, t, sigma)."""
     L = lib()

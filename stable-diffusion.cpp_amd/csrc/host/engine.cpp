@@ -1444,6 +1444,19 @@ static inline uint8_t float_to_u8(float v) {  // preprocessing.hpp:27-35
     return (uint8_t)(v * 255.0f + 0.5f);
 }
 
+// planar CHW floats in [0, 1] -> interleaved RGB bytes (preprocessing_tensor_frame_to_sd_image, src/runtime/preprocessing.hpp:37-60)
+static void planar_rgb_to_u8(const float* f, size_t pix, uint8_t* d) {
+    parallel_chunks(pix, [&](size_t i0, size_t i1) {
+        for (size_t i = i0; i < i1; ++i) {
+            d[i * 3 + 0] = float_to_u8(f[i]);
+            d[i * 3 + 1] = float_to_u8(f[pix + i]);
+            d[i * 3 + 2] = float_to_u8(f[2 * pix + i]);
+        }
+    });
+}
+// the same conversion on caller memory — tests only (bit-exact against the reference's preprocessing.hpp compiled into oracle/_ref)
+void sd_planar_rgb_to_u8(const float* chw, int width, int height, uint8_t* out) { planar_rgb_to_u8(chw, (size_t)width * height, out); }
+
 bool sdm_generate_image(sdm_ctx_t* ctx, const sdm_img_gen_params_t* p, sdm_image_t** images_out, int* num_images_out) {
     const int W = p->width / 8, H = p->height / 8, C = ctx->in_channels();
     const size_t per = (size_t)W * H * C;
@@ -1471,13 +1484,7 @@ bool sdm_generate_image(sdm_ctx_t* ctx, const sdm_img_gen_params_t* p, sdm_image
         imgs[b].data    = (uint8_t*)malloc(pix * 3);
         const float* f  = rgb.data() + (size_t)b * pix * 3;
         uint8_t* d      = imgs[b].data;
-        parallel_chunks(pix, [&](size_t i0, size_t i1) {  // planar CHW -> interleaved RGB (preprocessing.hpp:52-60)
-            for (size_t i = i0; i < i1; ++i) {
-                d[i * 3 + 0] = float_to_u8(f[i]);
-                d[i * 3 + 1] = float_to_u8(f[pix + i]);
-                d[i * 3 + 2] = float_to_u8(f[2 * pix + i]);
-            }
-        });
+        planar_rgb_to_u8(f, pix, d);
     }
     *images_out     = imgs;
     *num_images_out = p->batch_count;
