@@ -3112,7 +3112,15 @@ bool build_plan(Planner* P, Plan* plan, const ggml_cgraph* g, hipStream_t s, boo
         std::vector<int> chain;
         bool ok = false;
         switch (xop(n)) {
-            case GGML_OP_IM2COL: ok = plan_conv_chain(B, i, s, chain); break;
+            case GGML_OP_IM2COL:
+                ok = plan_conv_chain(B, i, s, chain);
+                if (!ok && n->src[1] && (B.prescale.count(n->src[1]) || B.ups.count(n->src[1]))) {
+                    // the node in front (a Conv2d scale / a nearest-x2 upsample) was elided on the promise that this chain fuses: its tensor was never written.
+                    // Fail the graph loudly rather than convolve unwritten memory (conv_im2col_fast_ok and plan_conv_chain must agree; this is the backstop)
+                    fprintf(stderr, "[ggml-mi355x] node %d: conv chain behind an elided SCALE / UPSCALE did not fuse\n", i);
+                    return false;
+                }
+                break;
             case GGML_OP_MUL_MAT:
                 if (linear_fast_ok(n)) {
                     B.hm_group.clear();
