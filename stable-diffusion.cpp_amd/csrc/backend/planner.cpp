@@ -654,7 +654,7 @@ bool all_consumers_gemm16(const GInfo& gi, int i, bool want_conv, float* mul_out
             }
             if (want_conv) {
                 float sc = 1.f;
-                if (mul_out && cn->src[0] == gi.node(k) && scale_into_conv(gi, c, &sc)) {
+                if (mul_out && k == i && cn->src[0] == gi.node(k) && scale_into_conv(gi, c, &sc)) {  // k == i: the SCALE reads the tensor itself (the image is keyed by it), not a RESHAPE of it
                     if (n_real > 0 && sc != mul) return false;
                     mul = sc;
                 } else {
