@@ -147,6 +147,10 @@ GGML_MI355X_API int ggml_backend_mi355x_get_kernel_timings(struct ggml_backend_m
  * "splitk_inkernel" (0: split-K combined by the last-arriving workgroup, 128-row tiles; measured slower) / "splitk_in_target" (320);
  * conv: "conv3w" (1: 3x3 / stride-1 convs on 16..128-wide maps on the LDS-window kernel), "conv3w_min_blocks" (8) / "conv3w_min_blocks_deep" (5:
  * least 32-channel blocks per K slice when the window kernel splits K);
+ * round 5: "fuse_conv_scale" (1: Conv2d scale — SCALE s -> conv -> SCALE 1/s, the reference's SDXL VAE setting — folded into the operand image and the epilogue),
+ * "conv_wmajor" (1: weight-major workgroup order for convs whose weight image is >= 2x their input image: every (column tile, K slice) weight chunk on one XCD),
+ * "t256p_pad" (1: the pipelined 256 x 256 Linear tile also for widths that are multiples of 128 only), "tail_split" (0: row-split launches — whole rounds of 256 x 256
+ * tiles + the remaining rows on small tiles; measured neutral), "ln16_rows" (1; 4 = four rows per wave in the LayerNorm -> f16 image kernel: measured slower);
  * "gemm16_swp" (0; 1 = the 256-row Linear tiles with the accumulator transposed, 16-byte epilogue accesses: correct, measured 1 % slower per SD1.5 step);
  * "fuse_ln_reduce" (1: the slab reduce of a split-K Linear also writes the f16 operand image of the LayerNorm that reads its result);
  * flash attention: "flash_vtr" (31: bit per head-dim class — V tiles row-major in LDS, fragments by ds_read_b64_tr_b16; 0 = transposing staging pass),
