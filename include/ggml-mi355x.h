@@ -93,6 +93,8 @@ struct ggml_backend_mi355x_stats {
     int64_t redirect_fallbacks;  /* graphs planned a second time without the joint-qkv pre-passes because a redirected projection was not taken by its Linear */
     int64_t fused_concat_gn;     /* skip-connection CONCATs never materialised: GroupNorm statistics / apply (and the skip conv's operand cast) read the two sources (plan_concat_gn) */
     int64_t fused_conv_scale;    /* Conv2d scales (SCALE s -> conv -> SCALE 1/s, the reference's SDXL VAE setting) folded into the operand image and the epilogue */
+    int64_t view_graphs;         /* plans built for SUB-GRAPH VIEWS (sd_ggml_graph_view, src/core/ggml_extend_backend.cpp:449-463: leafs NULL / size 0) */
+    int64_t view_external_nodes; /* nodes of those slices treated as read outside the slice (parent use_counts > readers inside, the slice's last node and its sources) */
 };
 GGML_MI355X_API void ggml_backend_mi355x_get_stats(struct ggml_backend_mi355x_stats* out);
 /* Host enum numbering, resolved BY NAME.  The numeric values of `enum ggml_op` / `enum ggml_unary_op` in ggml-abi.h are a recollection of upstream, and

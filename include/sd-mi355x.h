@@ -225,6 +225,20 @@ SD_API int sd_gen_flux_pe(int h, int w, int patch_size, int context_len, const i
 SD_API int sd_get_flow_sigmas(int steps, float shift, float* out /* steps+1 */);    /* DiscreteFlowDenoiser, denoiser.hpp:1239-1283 (t = 1000*sigma) */
 SD_API float sd_sigma_to_t(float sigma);                                             /* denoiser.hpp:1140-1165 */
 
+/* Node-by-node evaluation hook: the reference's sd_graph_eval_callback_t / sd_set_backend_eval_callback (include/stable-diffusion.h:442-447; used by the
+ * imatrix collector, src/runtime/imatrix.cpp:39-100,180).  With a callback installed every graph a context computes goes through
+ * sdm_backend_graph_compute_with_eval_callback, which restates sd_backend_graph_compute_with_eval_callback (src/core/ggml_extend_backend.cpp:466-509)
+ * statement for statement: the callback is asked about every node (ask = true); the graph is cut BEHIND each node it wants, the slice is handed to the
+ * backend as a SUB-GRAPH VIEW built exactly like sd_ggml_graph_view (:449-463: nodes + i0, n_leafs 0, leafs NULL, size 0, uid 0, the PARENT's use_counts /
+ * visited_hash_set), computed async + synchronised, then the callback sees the node again (ask = false) and may read it and its sources; returning false
+ * stops the graph (GGML_STATUS_ABORTED).  The sdm_ prefix keeps the names apart from the reference's own symbols. */
+struct ggml_tensor;
+struct ggml_cgraph;
+struct ggml_backend;
+typedef bool (*sdm_graph_eval_callback_t)(struct ggml_tensor* t, bool ask, void* user_data);
+SD_API void sdm_set_backend_eval_callback(sdm_graph_eval_callback_t cb, void* user_data);
+SD_API int sdm_backend_graph_compute_with_eval_callback(struct ggml_backend* backend, struct ggml_cgraph* gf, sdm_graph_eval_callback_t cb, void* user_data); /* enum ggml_status */
+
 /* ---- timing / introspection ---- */
 typedef struct {
     double last_sample_ms;  /* denoise loop wall time of the last sd_sample_latents / sdm_generate_image */

@@ -29,6 +29,8 @@ TYPE_SIZE = {F32: 4, F16: 2, BF16: 2, I32: 4}
 SD15, SDXL, SD15_TINY, SDXL_TINY, SD35_LARGE, SD35_TINY, FLUX_DEV, FLUX_TINY, SD35_WIDE2, FLUX_WIDE1, SD3M_TINY, SD35_WIDE8, FLUX_WIDE8 = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12
 # sd_pair_exchange_fn (include/sd-mi355x.h): (device address of the f32 eps buffer, element count, hipStream_t, user) -> ok
 PAIR_EXCHANGE_FN = C.CFUNCTYPE(C.c_bool, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p)
+# sdm_graph_eval_callback_t (include/sd-mi355x.h; the reference's sd_graph_eval_callback_t, include/stable-diffusion.h:442): (tensor, ask, user) -> bool
+EVAL_CALLBACK_FN = C.CFUNCTYPE(C.c_bool, C.c_void_p, C.c_bool, C.c_void_p)
 EULER, EULER_A, SAMPLE_METHOD_DEFAULT = 0, 1, 2   # DEFAULT: Euler for the DiT families, Euler-A otherwise (sd_get_default_sample_method)
 
 
@@ -283,6 +285,10 @@ def lib() -> C.CDLL:
     L.sd_get_learned_condition.argtypes = [C.c_void_p, C.POINTER(SdTokenList), C.POINTER(SdTokenList), C.POINTER(SdTokenList), C.c_int, C.c_int, C.c_int,
                                            C.c_bool, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
     L.sd_get_learned_condition.restype = C.c_bool
+    L.sdm_set_backend_eval_callback.argtypes = [EVAL_CALLBACK_FN, C.c_void_p]
+    L.sdm_set_backend_eval_callback.restype = None
+    L.sdm_backend_graph_compute_with_eval_callback.argtypes = [C.c_void_p, C.c_void_p, EVAL_CALLBACK_FN, C.c_void_p]
+    L.sdm_backend_graph_compute_with_eval_callback.restype = C.c_int
     _lib = L
     return L
 
@@ -312,7 +318,7 @@ def load_mi355x_backend() -> None:
 
 _BACKEND_STAT_FIELDS = ("graphs_computed plans_built nodes_seen kernels_planned kernels_launched fused_conv fused_conv_bounced fused_linear "
                         "fused_norm fused_geglu fused_attention generic_matmul swizzled_weight_bytes graph_replays fused_linear_geglu "
-                        "split_k_gemms head_major_gemms fused_modulate fused_gate fused_gelu fused_rope fused_concat_heads qgemv_linears fused_chan_add fused_proj_tokens gemm_attention fused_q16 split_k_inlaunch qgemm16_linears fgemv_linears fused_presilu fused_sibling_linears hoisted_kv_linears window_convs hoisted_emb_linears fused_rows16 fused_joint_qkv jit_images fused_cat_rows16 fused_gn_stats fused_ln_reduce redirect_fallbacks fused_concat_gn fused_conv_scale").split()
+                        "split_k_gemms head_major_gemms fused_modulate fused_gate fused_gelu fused_rope fused_concat_heads qgemv_linears fused_chan_add fused_proj_tokens gemm_attention fused_q16 split_k_inlaunch qgemm16_linears fgemv_linears fused_presilu fused_sibling_linears hoisted_kv_linears window_convs hoisted_emb_linears fused_rows16 fused_joint_qkv jit_images fused_cat_rows16 fused_gn_stats fused_ln_reduce redirect_fallbacks fused_concat_gn fused_conv_scale view_graphs view_external_nodes").split()
 
 
 class BackendStats(C.Structure):
@@ -661,6 +667,91 @@ class Engine:
         s = SdStats()
         lib().sd_get_stats(self._ctx, C.byref(s))
         return {f[0]: getattr(s, f[0]) for f in SdStats._fields_}
+
+
+def op_number(name: str) -> int:
+    """The host's numeric value of ggml op `name` (resolved through ggml_op_name like the plug-in does at init)."""
+    L = lib()
+    L.ggml_op_name.argtypes = [C.c_int]
+    L.ggml_op_name.restype = C.c_char_p
+    for i in range(200):
+        nm = L.ggml_op_name(i)
+        if nm is None:
+            break
+        if nm.decode() == name:
+            return i
+    raise EngineError(f"host has no ggml op named {name}")
+
+
+class EvalTrace:
+    """Node-by-node evaluation of every graph the engines compute while the context manager is active (sdm_set_backend_eval_callback: the reference's
+    sd_set_backend_eval_callback / imatrix pattern, src/runtime/imatrix.cpp:39-100).  `want(index, tensor_struct)` decides which nodes the graph is cut
+    behind; each wanted node is downloaded after its slice ran (f32 / f16 tensors; `with_src1` also downloads src[1] of a MUL_MAT, what the imatrix
+    collector reads).  records: list of (node index, op, name, value, src1 value or None) in evaluation order; `stop_after` makes the callback return false
+    after that many records (-> GGML_STATUS_ABORTED)."""
+
+    def __init__(self, want, with_src1: bool = True, stop_after: int | None = None, mul_mat_op: int | None = None):
+        self.want, self.with_src1, self.stop_after, self.mul_mat_op = want, with_src1, stop_after, mul_mat_op
+        self.records, self.asked, self.graphs = [], 0, 0
+        self._index, self._reset = -1, True
+        if self.mul_mat_op is None:
+            self.mul_mat_op = op_number("MUL_MAT")
+        self._cb = EVAL_CALLBACK_FN(self._call)
+
+    def _fetch(self, tptr):
+        """f32 / f16 tensor -> float32 numpy [ne3, ne2, ne1, ne0]; a strided view is read out of the (contiguous) tensor it aliases."""
+        L = lib()
+        ts = C.cast(tptr, C.POINTER(GgmlTensor)).contents
+        if ts.type not in (F32, F16) or not ts.data:
+            return None
+        dt = np.float32 if ts.type == F32 else np.float16
+        esz = TYPE_SIZE[ts.type]
+        shape = [int(ts.ne[i]) for i in range(3, -1, -1)]
+        strides = [int(ts.nb[i]) for i in range(3, -1, -1)]
+
+        def contiguous(t):
+            return t.nb[0] == TYPE_SIZE.get(t.type, 0) and all(t.nb[i] == t.nb[i - 1] * t.ne[i - 1] for i in range(1, 4))
+
+        if contiguous(ts):
+            out = np.empty(shape, dtype=dt)
+            L.ggml_backend_tensor_get(tptr, out.ctypes.data_as(C.c_void_p), 0, out.nbytes)
+            return out.astype(np.float32)
+        if not ts.view_src:
+            return None
+        root = C.cast(ts.view_src, C.POINTER(GgmlTensor)).contents
+        if not contiguous(root) or not root.data:
+            return None
+        raw = np.empty(int(L.ggml_nbytes(ts.view_src)), dtype=np.uint8)
+        L.ggml_backend_tensor_get(ts.view_src, raw.ctypes.data_as(C.c_void_p), 0, raw.nbytes)
+        off = int(ts.data) - int(root.data)
+        last = off + sum((n - 1) * st for n, st in zip(shape, strides)) + esz
+        if off < 0 or last > raw.nbytes:
+            return None
+        return np.lib.stride_tricks.as_strided(raw[off:].view(dt) if (raw.nbytes - off) % esz == 0 else raw[off:off + (raw.nbytes - off) // esz * esz].view(dt),
+                                               shape=shape, strides=strides).astype(np.float32)
+
+    def _call(self, tptr, ask, _user):
+        ts = C.cast(tptr, C.POINTER(GgmlTensor)).contents
+        if ask:
+            if self._reset:  # the node after a graph's final result starts the next graph
+                self._index, self._reset = -1, False
+                self.graphs += 1
+            self._index += 1
+            self.asked += 1
+            self._reset = ts.name == b"ggml_runner_final_result_tensor"
+            return bool(self.want(self._index, ts))
+        src1 = None
+        if self.with_src1 and self.mul_mat_op is not None and ts.op == self.mul_mat_op and ts.src[1]:
+            src1 = self._fetch(ts.src[1])
+        self.records.append((self._index, int(ts.op), ts.name.decode(errors="replace"), self._fetch(tptr), src1))
+        return not (self.stop_after is not None and len(self.records) >= self.stop_after)
+
+    def __enter__(self):
+        lib().sdm_set_backend_eval_callback(self._cb, None)
+        return self
+
+    def __exit__(self, *a):
+        lib().sdm_set_backend_eval_callback(EVAL_CALLBACK_FN(), None)
 
 
 def t5_relative_position_buckets(q_len: int, k_len: int) -> np.ndarray:

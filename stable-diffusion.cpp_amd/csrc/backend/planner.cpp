@@ -146,11 +146,11 @@ namespace {
 struct Stats {
     std::atomic<int64_t> graphs_computed{0}, plans_built{0}, nodes_seen{0}, kernels_planned{0}, kernels_launched{0}, fused_conv{0},
         fused_conv_bounced{0}, fused_linear{0}, fused_norm{0}, fused_geglu{0}, fused_attention{0}, generic_matmul{0}, swizzled_weight_bytes{0}, fused_linear_geglu{0}, split_k_gemms{0}, head_major_gemms{0}, fused_modulate{0}, fused_gate{0}, fused_gelu{0}, fused_rope{0}, fused_concat_heads{0},
-        graph_replays{0}, qgemv_linears{0}, fused_chan_add{0}, fused_proj_tokens{0}, gemm_attention{0}, fused_q16{0}, split_k_inlaunch{0}, qgemm16_linears{0}, fgemv_linears{0}, fused_presilu{0}, fused_sibling_linears{0}, hoisted_kv_linears{0}, window_convs{0}, hoisted_emb_linears{0}, fused_rows16{0}, fused_cat_rows16{0}, fused_joint_qkv{0}, jit_images{0}, fused_gn_stats{0}, redirect_fallbacks{0}, fused_ln_reduce{0}, fused_concat_gn{0}, fused_conv_scale{0};
+        graph_replays{0}, qgemv_linears{0}, fused_chan_add{0}, fused_proj_tokens{0}, gemm_attention{0}, fused_q16{0}, split_k_inlaunch{0}, qgemm16_linears{0}, fgemv_linears{0}, fused_presilu{0}, fused_sibling_linears{0}, hoisted_kv_linears{0}, window_convs{0}, hoisted_emb_linears{0}, fused_rows16{0}, fused_cat_rows16{0}, fused_joint_qkv{0}, jit_images{0}, fused_gn_stats{0}, redirect_fallbacks{0}, fused_ln_reduce{0}, fused_concat_gn{0}, fused_conv_scale{0}, view_graphs{0}, view_external_nodes{0};
 } g_stats;
 
 struct Options {
-    std::atomic<int> fusion{1}, mfma_gemm{1}, hip_graph{1}, flash_pattern{1}, gemm16{1}, fuse_modulate{1}, fuse_gate{1}, fuse_gelu{1}, fuse_rope{1}, fuse_concat_heads{1}, qgemv{1}, fuse_chan_add{1}, fuse_proj_tokens{1}, fuse_q16{1}, qgemm16{1}, fgemv{1}, fuse_siblings{1}, hoist_kv{1}, hoist_emb{1}, fuse_rows16{0}, fuse_cat_rows16{1}, fuse_joint_qkv{1}, jit_qimages{4096}, fuse_gn_stats{1}, fuse_ln_reduce{1}, relax_res_overlap{1}, fuse_split_gelu{1}, fuse_concat_gn{1}, fuse_gn_tokens{1}, fuse_linear_nchw{1}, fuse_conv_scale{1};
+    std::atomic<int> fusion{1}, mfma_gemm{1}, hip_graph{1}, flash_pattern{1}, gemm16{1}, fuse_modulate{1}, fuse_gate{1}, fuse_gelu{1}, fuse_rope{1}, fuse_concat_heads{1}, qgemv{1}, fuse_chan_add{1}, fuse_proj_tokens{1}, fuse_q16{1}, qgemm16{1}, fgemv{1}, fuse_siblings{1}, hoist_kv{1}, hoist_emb{1}, fuse_rows16{0}, fuse_cat_rows16{1}, fuse_joint_qkv{1}, jit_qimages{4096}, fuse_gn_stats{1}, fuse_ln_reduce{1}, relax_res_overlap{1}, fuse_split_gelu{1}, fuse_concat_gn{1}, fuse_gn_tokens{1}, fuse_linear_nchw{1}, fuse_conv_scale{1}, ignore_use_counts{0};
 } g_opt;
 
 using Step = std::function<void(hipStream_t)>;
@@ -251,6 +251,69 @@ static inline uint64_t mix_words(uint64_t h, const void* p, size_t n) {
     return h;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// SUB-GRAPH VIEWS.  The reference's node-by-node evaluation (sd_backend_graph_compute_with_eval_callback, src/core/ggml_extend_backend.cpp:466-509; the
+// imatrix collector, src/runtime/imatrix.cpp) hands graph_compute SLICES of a graph: sd_ggml_graph_view (:449-463) = { size 0, nodes + i0, n_leafs 0,
+// leafs NULL, uid 0, and the PARENT's use_counts / visited_hash_set } — ggml_backend_sched builds its splits the same way (ggml_graph_view).  A slice is
+// not closed: a node with no reader inside it may be read by a later slice or by the host's callback.  Every "never materialised" decision in this file
+// asks GInfo for a node's consumers, so an open slice is made safe in ONE place: a node that is (or may be) needed outside the slice gets a phantom
+// consumer no pattern matches (GInfo::node(n_nodes), op = unsupported) — its f32 tensor is then written like any tensor with an unknown reader.
+//   externally needed  =  the parent's use count of the tensor (ggml_hash_find over visited_hash_set: hash = address >> 4, linear probing, `used` bitset;
+//                         use_counts[slot] = source slots referring to it, upstream ggml_visit_parents) exceeds its readers inside the slice,
+//                         or the count cannot be read (no table / not found: assume needed);
+//                      +  the slice's LAST node — the tensor the callback asked for — and that node's sources (imatrix reads src[1] of each MUL_MAT);
+//                      +  through RESHAPE / VIEW / PERMUTE / TRANSPOSE: a needed view makes the tensor it aliases needed.
+// ---------------------------------------------------------------------------------------------------
+inline bool graph_is_view(const ggml_cgraph* g) { return g->leafs == nullptr || g->size == 0; }
+int parent_use_count(const ggml_cgraph* g, const ggml_tensor* t) {  // -1: unknown
+    const ggml_hash_set& hs = g->visited_hash_set;
+    if (!g->use_counts || !hs.keys || !hs.used || hs.size == 0 || g_opt.ignore_use_counts) return -1;
+    const size_t h = ((size_t)(uintptr_t)t >> 4) % hs.size;
+    size_t i       = h;
+    while ((hs.used[i >> 5] >> (i & 31)) & 1u) {
+        if (hs.keys[i] == t) return (int)g->use_counts[i];
+        i = (i + 1) % hs.size;
+        if (i == h) break;
+    }
+    return -1;
+}
+// ext[i] = 1: node i of the view may be read outside it
+void view_external_nodes(const ggml_cgraph* g, std::vector<char>& ext) {
+    const int n = g->n_nodes;
+    ext.assign((size_t)n, 0);
+    std::unordered_map<const ggml_tensor*, int> index;
+    index.reserve((size_t)n * 2);
+    for (int i = 0; i < n; ++i) index[g->nodes[i]] = i;
+    std::vector<int> inside((size_t)n, 0);
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < GGML_MAX_SRC; ++j) {
+            const ggml_tensor* sj = g->nodes[i]->src[j];
+            if (!sj) continue;
+            const auto it = index.find(sj);
+            if (it != index.end()) inside[it->second]++;
+        }
+    for (int i = 0; i < n; ++i) {
+        const int uc = parent_use_count(g, g->nodes[i]);
+        ext[i]       = (uc < 0 || uc > inside[i]) ? 1 : 0;
+    }
+    if (n > 0) {
+        ext[n - 1] = 1;
+        for (int j = 0; j < GGML_MAX_SRC; ++j) {
+            const ggml_tensor* sj = g->nodes[n - 1]->src[j];
+            const auto it         = sj ? index.find(sj) : index.end();
+            if (it != index.end()) ext[it->second] = 1;
+        }
+    }
+    for (int i = n - 1; i >= 0; --i) {
+        const ggml_tensor* t = g->nodes[i];
+        if (!ext[i] || !ggml_abi_op_is_noop(xop(t))) continue;
+        for (const ggml_tensor* a : {(const ggml_tensor*)t->src[0], (const ggml_tensor*)t->view_src}) {
+            const auto it = a ? index.find(a) : index.end();
+            if (it != index.end()) ext[it->second] = 1;
+        }
+    }
+}
+
 // Two independently mixed 64-bit hashes in one pass: `key` indexes the plan cache, `check` is stored in the plan and compared on a hit
 // (round-1 advice: a cached launch list holds raw device addresses — replaying the wrong one corrupts results silently).  Everything a
 // fusion decision reads is hashed: per node op / type / flags / shape / strides / params / address, per source its address, type,
@@ -278,9 +341,12 @@ static inline void mix2(uint64_t& a, uint64_t& b, const void* p, size_t n) {
 GraphKey graph_key(const ggml_cgraph* g) {
     uint64_t h = 1469598103934665603ull, k = 0x165667B19E3779F9ull;
     mix2(h, k, &g->n_nodes, sizeof(g->n_nodes));
+    std::vector<char> ext;
+    const bool view = graph_is_view(g);
+    if (view) view_external_nodes(g, ext);  // a slice's plan depends on which of its nodes are needed outside it
     for (int i = 0; i < g->n_nodes; ++i) {
         const ggml_tensor* n = g->nodes[i];
-        const int32_t head[4] = {(int32_t)n->op, (int32_t)n->type, n->flags & GGML_TENSOR_FLAG_OUTPUT, i};
+        const int32_t head[4] = {(int32_t)n->op, (int32_t)n->type, (n->flags & GGML_TENSOR_FLAG_OUTPUT) | (view ? 0x40000000 | (ext[i] ? 0x20000000 : 0) : 0), i};
         mix2(h, k, head, sizeof(head));
         mix2(h, k, n->ne, sizeof(n->ne));
         mix2(h, k, n->nb, sizeof(n->nb));
@@ -308,7 +374,21 @@ struct GInfo {
     std::vector<std::vector<int>> consumers;
     std::vector<char> done;
 
-    explicit GInfo(const ggml_cgraph* gr) : g(gr), consumers(gr->n_nodes), done(gr->n_nodes, 0) {
+    ggml_tensor phantom;  // node(n_nodes): the reader outside a sub-graph view (see SUB-GRAPH VIEWS above); an op no pattern matches, no sources, no data
+    bool is_view = false;
+    int n_external = 0;
+
+    // consumers / done have one slot more than the graph has nodes: index n_nodes is the phantom (always "done", read by nobody)
+    explicit GInfo(const ggml_cgraph* gr) : g(gr), consumers(gr->n_nodes + 1), done(gr->n_nodes + 1, 0) {
+        memset(&phantom, 0, sizeof(phantom));
+        phantom.op = (enum ggml_op)255;
+        for (int h = 255; h >= 0; --h)  // a host op number this backend maps to "unsupported" (255 unless a host names 256 ops)
+            if (g_opmap[h] == GGML_OP_COUNT) {
+                phantom.op = (enum ggml_op)h;
+                break;
+            }
+        snprintf(phantom.name, sizeof(phantom.name), "(reader outside the view)");
+        done[g->n_nodes] = 1;
         for (int i = 0; i < g->n_nodes; ++i) index[g->nodes[i]] = i;
         for (int i = 0; i < g->n_nodes; ++i) {
             const ggml_tensor* n = g->nodes[i];
@@ -318,8 +398,18 @@ struct GInfo {
                 if (it != index.end()) consumers[it->second].push_back(i);
             }
         }
+        is_view = graph_is_view(g);
+        if (is_view) {
+            std::vector<char> ext;
+            view_external_nodes(g, ext);
+            for (int i = 0; i < g->n_nodes; ++i)
+                if (ext[i]) {
+                    consumers[i].push_back(g->n_nodes);
+                    ++n_external;
+                }
+        }
     }
-    const ggml_tensor* node(int i) const { return g->nodes[i]; }
+    const ggml_tensor* node(int i) const { return i == g->n_nodes ? &phantom : g->nodes[i]; }
     int idx(const ggml_tensor* t) const {
         auto it = index.find(t);
         return it == index.end() ? -1 : it->second;
@@ -3346,6 +3436,10 @@ bool build_plan(Planner* P, Plan* plan, const ggml_cgraph* g, hipStream_t s, boo
     }
     plan->n_nodes      = g->n_nodes;
     plan->arena_needed = B.arena_off;
+    if (gi.is_view) {
+        g_stats.view_graphs++;
+        g_stats.view_external_nodes += gi.n_external;
+    }
     g_stats.plans_built++;
     g_stats.nodes_seen += g->n_nodes;
     g_stats.kernels_planned += (int64_t)plan->steps.size();
@@ -3618,6 +3712,8 @@ void planner_get_stats(ggml_backend_mi355x_stats* o) {
     o->redirect_fallbacks    = g_stats.redirect_fallbacks;
     o->fused_concat_gn       = g_stats.fused_concat_gn;
     o->fused_conv_scale      = g_stats.fused_conv_scale;
+    o->view_graphs           = g_stats.view_graphs;
+    o->view_external_nodes   = g_stats.view_external_nodes;
     o->fused_attention       = g_stats.fused_attention;
     o->generic_matmul        = g_stats.generic_matmul;
     o->swizzled_weight_bytes = g_stats.swizzled_weight_bytes;
@@ -3691,6 +3787,7 @@ void planner_set_option(const char* key, int value) {
     else if (!strcmp(key, "fuse_gn_tokens")) g_opt.fuse_gn_tokens = value;
     else if (!strcmp(key, "fuse_linear_nchw")) g_opt.fuse_linear_nchw = value;
     else if (!strcmp(key, "fuse_conv_scale")) g_opt.fuse_conv_scale = value;
+    else if (!strcmp(key, "ignore_use_counts")) g_opt.ignore_use_counts = value;  // test hook: a host whose sub-graph views carry no use_counts table
     else if (!strcmp(key, "fuse_gelu")) g_opt.fuse_gelu = value;
     else if (!strcmp(key, "fuse_rope")) g_opt.fuse_rope = value;
     else if (!strcmp(key, "fuse_concat_heads")) g_opt.fuse_concat_heads = value;

@@ -10,7 +10,6 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <unordered_set>
 #include <vector>
 
 extern "C" void ggml_abort(const char* file, int line, const char* fmt, ...) {
@@ -24,11 +23,45 @@ extern "C" void ggml_abort(const char* file, int line, const char* fmt, ...) {
     abort();
 }
 
+// The visited set is upstream's open-addressing ggml_hash_set (keys + a used bitset, hash = address >> 4, linear probing) and use_counts[slot] counts
+// how often the tensor in that slot is a source of a visited tensor: both are part of struct ggml_cgraph and are what a backend handed a SUB-GRAPH VIEW
+// (sd_ggml_graph_view, src/core/ggml_extend_backend.cpp:449-463: nodes + i0, leafs = NULL, the PARENT's use_counts / visited_hash_set) has to read to
+// tell whether a node of the slice is still needed outside it.
 struct graph_storage {
     ggml_cgraph g;  // must be first: the cgraph pointer handed to backends is the storage pointer
-    std::unordered_set<ggml_tensor*> visited;
-    std::vector<ggml_tensor*> nodes, leafs;
+    std::vector<ggml_tensor*> nodes, leafs, keys;
+    std::vector<uint32_t> used;
+    std::vector<int32_t> use_counts;
 };
+
+static size_t hash_size_for(size_t min_sz) {  // a prime >= min_sz (upstream picks from a table of primes; any size works for a reader)
+    size_t n = min_sz | 1;
+    for (;; n += 2) {
+        bool prime = n > 2;
+        for (size_t d = 3; d * d <= n && prime; d += 2) prime = n % d != 0;
+        if (prime) return n;
+    }
+}
+static inline size_t hash_slot(const ggml_hash_set& hs, const ggml_tensor* key) {  // slot holding key, or the free slot where it belongs
+    const size_t h = ((size_t)(uintptr_t)key >> 4) % hs.size;
+    size_t i       = h;
+    while ((hs.used[i >> 5] >> (i & 31) & 1u) && hs.keys[i] != key) {
+        i = (i + 1) % hs.size;
+        GGML_ASSERT(i != h && "graph hash set full");
+    }
+    return i;
+}
+static inline bool hash_has(const ggml_hash_set& hs, size_t slot) { return (hs.used[slot >> 5] >> (slot & 31)) & 1u; }
+// true when key was not in the set yet
+static inline bool hash_insert(graph_storage* gs, ggml_tensor* key) {
+    ggml_hash_set& hs = gs->g.visited_hash_set;
+    const size_t i    = hash_slot(hs, key);
+    if (hash_has(hs, i)) return false;
+    hs.used[i >> 5] |= 1u << (i & 31);
+    hs.keys[i]             = key;
+    gs->g.use_counts[i]    = 0;
+    return true;
+}
 
 struct ggml_context {
     bool no_alloc;
@@ -812,6 +845,12 @@ ggml_cgraph* ggml_new_graph_custom(ggml_context* ctx, size_t size, bool) {
     gs->g.nodes = gs->nodes.data();
     gs->g.leafs = gs->leafs.data();
     gs->g.order = GGML_CGRAPH_EVAL_ORDER_LEFT_TO_RIGHT;
+    const size_t hsz = hash_size_for(size * 2);
+    gs->keys.assign(hsz, nullptr);
+    gs->used.assign((hsz + 31) / 32, 0u);
+    gs->use_counts.assign(hsz, 0);
+    gs->g.visited_hash_set = ggml_hash_set{hsz, gs->used.data(), gs->keys.data()};
+    gs->g.use_counts       = gs->use_counts.data();
     static uint64_t uid = 0;
     gs->g.uid           = ++uid;
     static_assert(offsetof(graph_storage, g) == 0, "cgraph must be first");
@@ -826,17 +865,15 @@ static void visit_parents(graph_storage* gs, ggml_tensor* node) {
         ggml_tensor* t;
         int next;
     };
-    if (gs->visited.count(node)) return;
+    if (!hash_insert(gs, node)) return;
     std::vector<frame> stack;
-    gs->visited.insert(node);
     stack.push_back({node, 0});
     while (!stack.empty()) {
         frame& f = stack.back();
         bool pushed = false;
         while (f.next < GGML_MAX_SRC) {
             ggml_tensor* s = f.t->src[f.next++];
-            if (s && !gs->visited.count(s)) {
-                gs->visited.insert(s);
+            if (s && hash_insert(gs, s)) {
                 stack.push_back({s, 0});
                 pushed = true;
                 break;
@@ -846,6 +883,8 @@ static void visit_parents(graph_storage* gs, ggml_tensor* node) {
         ggml_tensor* t = stack.back().t;
         stack.pop_back();
         ggml_cgraph* g = &gs->g;
+        for (int k = 0; k < GGML_MAX_SRC; ++k)  // one use per source slot, counted once per visited tensor (upstream ggml_visit_parents)
+            if (t->src[k]) g->use_counts[hash_slot(g->visited_hash_set, t->src[k])]++;
         if (t->op == GGML_OP_NONE && !(t->flags & GGML_TENSOR_FLAG_PARAM)) {
             GGML_ASSERT(g->n_leafs < g->size);
             if (t->name[0] == 0) snprintf(t->name, sizeof(t->name), "leaf_%d", g->n_leafs);

@@ -228,6 +228,7 @@ GGML_API void ggml_backend_tensor_copy(struct ggml_tensor* src, struct ggml_tens
         if (!(x)) ggml_abort(__FILE__, __LINE__, "GGML_ASSERT(%s) failed", #x);        \
     } while (0)
 GGML_API void ggml_abort(const char* file, int line, const char* fmt, ...) __attribute__((noreturn));
+#define GGML_ABORT(...) ggml_abort(__FILE__, __LINE__, __VA_ARGS__)
 
 #ifdef __cplusplus
 }

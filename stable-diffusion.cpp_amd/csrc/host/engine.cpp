@@ -101,6 +101,61 @@ static void fill_normal(float* dst, int64_t n, uint64_t seed, float mean, float 
 }
 
 // ---------------------------------------------------------------------------------------------------
+// node-by-node evaluation hook (include/sd-mi355x.h): restates src/core/ggml_extend_backend.cpp:449-509 and src/core/util.cpp:638-668
+// ---------------------------------------------------------------------------------------------------
+static sdm_graph_eval_callback_t g_eval_cb = nullptr;
+static void* g_eval_cb_data                = nullptr;
+
+static ggml_cgraph graph_view(ggml_cgraph* parent, int i0, int i1) {  // sd_ggml_graph_view
+    ggml_cgraph v;
+    v.size             = 0;
+    v.n_nodes          = i1 - i0;
+    v.n_leafs          = 0;
+    v.nodes            = parent->nodes + i0;
+    v.grads            = nullptr;
+    v.grad_accs        = nullptr;
+    v.leafs            = nullptr;
+    v.use_counts       = parent->use_counts;
+    v.visited_hash_set = parent->visited_hash_set;
+    v.order            = parent->order;
+    v.uid              = 0;
+    return v;
+}
+
+extern "C" void sdm_set_backend_eval_callback(sdm_graph_eval_callback_t cb, void* user_data) {
+    g_eval_cb      = cb;
+    g_eval_cb_data = user_data;
+}
+
+extern "C" int sdm_backend_graph_compute_with_eval_callback(ggml_backend* backend, ggml_cgraph* gf, sdm_graph_eval_callback_t cb, void* user_data) {
+    if (cb == nullptr) return (int)ggml_backend_graph_compute(backend, gf);
+    enum ggml_status status = GGML_STATUS_SUCCESS;
+    const int n_nodes       = ggml_graph_n_nodes(gf);
+    bool stopped            = false;
+    for (int j0 = 0; j0 < n_nodes; ++j0) {
+        ggml_tensor* t = ggml_graph_node(gf, j0);
+        bool need      = cb(t, true, user_data);
+        int j1         = j0;
+        while (!need && j1 < n_nodes - 1) {
+            t    = ggml_graph_node(gf, ++j1);
+            need = cb(t, true, user_data);
+        }
+        ggml_cgraph gv = graph_view(gf, j0, j1 + 1);
+        status         = ggml_backend_graph_compute_async(backend, &gv);
+        if (status != GGML_STATUS_SUCCESS) break;
+        ggml_backend_synchronize(backend);
+        if (need && !cb(t, false, user_data)) {
+            stopped = true;
+            break;
+        }
+        j0 = j1;
+    }
+    ggml_backend_synchronize(backend);
+    if (stopped && status == GGML_STATUS_SUCCESS) status = GGML_STATUS_ABORTED;
+    return (int)status;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Runner: weights residency + per-call graph lifecycle
 // ---------------------------------------------------------------------------------------------------
 struct HostInput {
@@ -264,7 +319,10 @@ struct Runner {
             else
                 ggml_backend_tensor_set(in.t, in.data, 0, in.nbytes);
         }
-        const enum ggml_status st = async ? ggml_backend_graph_compute_async(backend, gf) : ggml_backend_graph_compute(backend, gf);
+        // GGMLRunner::compute routes through the eval-callback variant whenever a callback is installed (ggml_extend.hpp:2857-2860)
+        const enum ggml_status st = g_eval_cb ? (enum ggml_status)sdm_backend_graph_compute_with_eval_callback(backend, gf, g_eval_cb, g_eval_cb_data)
+                                    : async   ? ggml_backend_graph_compute_async(backend, gf)
+                                              : ggml_backend_graph_compute(backend, gf);
         if (st != GGML_STATUS_SUCCESS) {
             set_error(std::string("graph compute failed: ") + ggml_status_to_string(st));
             if (keep)
