@@ -239,6 +239,16 @@ typedef bool (*sdm_graph_eval_callback_t)(struct ggml_tensor* t, bool ask, void*
 SD_API void sdm_set_backend_eval_callback(sdm_graph_eval_callback_t cb, void* user_data);
 SD_API int sdm_backend_graph_compute_with_eval_callback(struct ggml_backend* backend, struct ggml_cgraph* gf, sdm_graph_eval_callback_t cb, void* user_data); /* enum ggml_status */
 
+/* Graph topology as text, for the node-for-node comparison with the graphs the REFERENCE's own builders emit (tests/test_ref_graphs.py; the reference side is
+ * oracle/ref_graphs_wrap.cpp -> oracle/_ref/libref_graphs.so, which calls this same function on its graphs).  One line per leaf ("L <j> type ne nb flags name")
+ * and per node ("N <i> OP type ne nb op_params flags sources view_src@offset name"), sources as n<i> / l<j>.  Returns the bytes needed incl. the
+ * terminating 0 (call with cap 0 to size the buffer).  sdm_set_graph_capture(1): every graph an engine context computes is described just before it is
+ * submitted and kept until the next one; 2: described and NOT computed (the call fails with "graph captured, compute skipped": topology of full-size models
+ * without the arithmetic); sdm_last_graph_description copies it out. */
+SD_API size_t sdm_graph_describe(struct ggml_cgraph* gf, char* buf, size_t cap);
+SD_API void sdm_set_graph_capture(int on);
+SD_API size_t sdm_last_graph_description(char* buf, size_t cap);
+
 /* ---- timing / introspection ---- */
 typedef struct {
     double last_sample_ms;  /* denoise loop wall time of the last sd_sample_latents / sdm_generate_image */

@@ -111,6 +111,19 @@ ggml_backend_t ggml_backend_init_by_name(const char* name, const char* params) {
     return d ? ggml_backend_dev_init(d, params) : nullptr;
 }
 
+ggml_backend_t ggml_backend_init_by_type(enum ggml_backend_dev_type type, const char* params) {
+    ggml_backend_dev_t d = ggml_backend_dev_by_type(type);
+    return d ? ggml_backend_dev_init(d, params) : nullptr;
+}
+ggml_backend_t ggml_backend_init_best(void) {
+    ggml_backend_dev_t d = ggml_backend_dev_by_type(GGML_BACKEND_DEVICE_TYPE_GPU);
+    if (!d && !reg().devs.empty()) d = reg().devs.front();
+    return d ? ggml_backend_dev_init(d, nullptr) : nullptr;
+}
+void ggml_backend_load_all(void) {}
+ggml_backend_dev_t ggml_backend_buft_get_device(ggml_backend_buffer_type_t buft) { return buft->device; }
+ggml_backend_buffer_type_t ggml_backend_dev_host_buffer_type(ggml_backend_dev_t d) { return d->iface.get_host_buffer_type ? d->iface.get_host_buffer_type(d) : nullptr; }
+
 // ---- backend (stream) ----------------------------------------------------------------------------
 const char* ggml_backend_name(ggml_backend_t b) { return b ? b->iface.get_name(b) : "NULL"; }
 void ggml_backend_free(ggml_backend_t b) {

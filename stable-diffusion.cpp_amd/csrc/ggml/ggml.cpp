@@ -10,6 +10,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <execinfo.h>
+#include <ctime>
 #include <vector>
 
 extern "C" void ggml_abort(const char* file, int line, const char* fmt, ...) {
@@ -20,6 +22,10 @@ extern "C" void ggml_abort(const char* file, int line, const char* fmt, ...) {
     vfprintf(stderr, fmt, args);
     va_end(args);
     fprintf(stderr, "\n");
+    if (getenv("GGML_ABORT_BACKTRACE")) {  // which constructor / wrapper reached the failed assertion
+        void* frames[48];
+        backtrace_symbols_fd(frames, backtrace(frames, 48), 2);
+    }
     abort();
 }
 
@@ -683,6 +689,14 @@ ggml_tensor* ggml_repeat(ggml_context* ctx, ggml_tensor* a, ggml_tensor* b) {
     r->src[0]      = a;
     return r;
 }
+ggml_tensor* ggml_repeat_4d(ggml_context* ctx, ggml_tensor* a, int64_t ne0, int64_t ne1, int64_t ne2, int64_t ne3) {
+    const int64_t ne[4] = {ne0, ne1, ne2, ne3};
+    for (int d = 0; d < 4; ++d) GGML_ASSERT(a->ne[d] > 0 && ne[d] % a->ne[d] == 0);
+    ggml_tensor* r = ggml_new_tensor(ctx, a->type, GGML_MAX_DIMS, ne);
+    r->op          = GGML_OP_REPEAT;
+    r->src[0]      = a;
+    return r;
+}
 ggml_tensor* ggml_concat(ggml_context* ctx, ggml_tensor* a, ggml_tensor* b, int dim) {
     GGML_ASSERT(dim >= 0 && dim < GGML_MAX_DIMS && a->type == b->type);
     int64_t ne[4];
@@ -788,15 +802,17 @@ ggml_tensor* ggml_upscale(ggml_context* ctx, ggml_tensor* a, int scale_factor, e
     return r;
 }
 
-ggml_tensor* ggml_pad(ggml_context* ctx, ggml_tensor* a, int p0, int p1, int p2, int p3) {
-    const int64_t ne[4] = {a->ne[0] + p0, a->ne[1] + p1, a->ne[2] + p2, a->ne[3] + p3};
+// zero padding on both sides of every dimension; op_params = {lp0, rp0, lp1, rp1, lp2, rp2, lp3, rp3}
+ggml_tensor* ggml_pad_ext(ggml_context* ctx, ggml_tensor* a, int lp0, int rp0, int lp1, int rp1, int lp2, int rp2, int lp3, int rp3) {
+    const int64_t ne[4] = {a->ne[0] + lp0 + rp0, a->ne[1] + lp1 + rp1, a->ne[2] + lp2 + rp2, a->ne[3] + lp3 + rp3};
     ggml_tensor* r      = ggml_new_tensor(ctx, a->type, 4, ne);
     r->op               = GGML_OP_PAD;
-    const int32_t params[] = {0, p0, 0, p1, 0, p2, 0, p3};  // lp0,rp0,lp1,rp1,...
+    const int32_t params[] = {lp0, rp0, lp1, rp1, lp2, rp2, lp3, rp3};
     memcpy(r->op_params, params, sizeof(params));
     r->src[0] = a;
     return r;
 }
+ggml_tensor* ggml_pad(ggml_context* ctx, ggml_tensor* a, int p0, int p1, int p2, int p3) { return ggml_pad_ext(ctx, a, 0, p0, 0, p1, 0, p2, 0, p3); }
 
 // dst[j]=cos(t*f_j), dst[j+half]=sin(t*f_j), f_j = exp(-ln(max_period)*j/half); zero pad if dim odd
 ggml_tensor* ggml_timestep_embedding(ggml_context* ctx, ggml_tensor* timesteps, int dim, int max_period) {
@@ -906,6 +922,28 @@ ggml_tensor* ggml_graph_node(ggml_cgraph* cgraph, int i) {
     if (i < 0) return cgraph->nodes[cgraph->n_nodes + i];
     return cgraph->nodes[i];
 }
+// appends a node to a graph WITHOUT visiting its sources (upstream semantics: the caller adds nodes in evaluation order)
+void ggml_graph_add_node(ggml_cgraph* cgraph, ggml_tensor* tensor) {
+    GGML_ASSERT(cgraph->n_nodes < cgraph->size);
+    cgraph->nodes[cgraph->n_nodes++] = tensor;
+}
+void ggml_unravel_index(const ggml_tensor* tensor, int64_t i, int64_t* i0, int64_t* i1, int64_t* i2, int64_t* i3) {
+    const int64_t ne0 = tensor->ne[0], ne1 = tensor->ne[1], ne2 = tensor->ne[2];
+    const int64_t j3 = i / (ne2 * ne1 * ne0);
+    const int64_t j2 = (i - j3 * ne2 * ne1 * ne0) / (ne1 * ne0);
+    const int64_t j1 = (i - j3 * ne2 * ne1 * ne0 - j2 * ne1 * ne0) / ne0;
+    const int64_t j0 = i - j3 * ne2 * ne1 * ne0 - j2 * ne1 * ne0 - j1 * ne0;
+    if (i0) *i0 = j0;
+    if (i1) *i1 = j1;
+    if (i2) *i2 = j2;
+    if (i3) *i3 = j3;
+}
+int64_t ggml_time_us(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (int64_t)ts.tv_sec * 1000000 + (int64_t)ts.tv_nsec / 1000;
+}
+int64_t ggml_time_ms(void) { return ggml_time_us() / 1000; }
 ggml_tensor* ggml_graph_get_tensor(const ggml_cgraph* cgraph, const char* name) {
     for (int i = 0; i < cgraph->n_leafs; ++i)
         if (strcmp(cgraph->leafs[i]->name, name) == 0) return cgraph->leafs[i];

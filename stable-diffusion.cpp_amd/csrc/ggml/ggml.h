@@ -129,6 +129,7 @@ GGML_API struct ggml_tensor* ggml_permute(struct ggml_context* ctx, struct ggml_
 GGML_API struct ggml_tensor* ggml_transpose(struct ggml_context* ctx, struct ggml_tensor* a);
 
 GGML_API struct ggml_tensor* ggml_repeat(struct ggml_context* ctx, struct ggml_tensor* a, struct ggml_tensor* b);
+GGML_API struct ggml_tensor* ggml_repeat_4d(struct ggml_context* ctx, struct ggml_tensor* a, int64_t ne0, int64_t ne1, int64_t ne2, int64_t ne3);
 GGML_API struct ggml_tensor* ggml_concat(struct ggml_context* ctx, struct ggml_tensor* a, struct ggml_tensor* b, int dim);
 GGML_API struct ggml_tensor* ggml_soft_max(struct ggml_context* ctx, struct ggml_tensor* a);
 GGML_API struct ggml_tensor* ggml_soft_max_inplace(struct ggml_context* ctx, struct ggml_tensor* a);
@@ -140,6 +141,7 @@ GGML_API struct ggml_tensor* ggml_conv_2d(struct ggml_context* ctx, struct ggml_
 GGML_API struct ggml_tensor* ggml_conv_2d_direct(struct ggml_context* ctx, struct ggml_tensor* a, struct ggml_tensor* b, int s0, int s1, int p0, int p1, int d0, int d1);
 GGML_API struct ggml_tensor* ggml_upscale(struct ggml_context* ctx, struct ggml_tensor* a, int scale_factor, enum ggml_scale_mode mode);
 GGML_API struct ggml_tensor* ggml_pad(struct ggml_context* ctx, struct ggml_tensor* a, int p0, int p1, int p2, int p3);
+GGML_API struct ggml_tensor* ggml_pad_ext(struct ggml_context* ctx, struct ggml_tensor* a, int lp0, int rp0, int lp1, int rp1, int lp2, int rp2, int lp3, int rp3);
 GGML_API struct ggml_tensor* ggml_timestep_embedding(struct ggml_context* ctx, struct ggml_tensor* timesteps, int dim, int max_period);
 GGML_API struct ggml_tensor* ggml_flash_attn_ext(struct ggml_context* ctx, struct ggml_tensor* q, struct ggml_tensor* k, struct ggml_tensor* v, struct ggml_tensor* mask, float scale, float max_bias, float logit_softcap);
 GGML_API void ggml_flash_attn_ext_set_prec(struct ggml_tensor* a, enum ggml_prec prec);
@@ -150,6 +152,10 @@ GGML_API struct ggml_cgraph* ggml_new_graph_custom(struct ggml_context* ctx, siz
 GGML_API void ggml_build_forward_expand(struct ggml_cgraph* cgraph, struct ggml_tensor* tensor);
 GGML_API int ggml_graph_n_nodes(struct ggml_cgraph* cgraph);
 GGML_API struct ggml_tensor* ggml_graph_node(struct ggml_cgraph* cgraph, int i);
+GGML_API void ggml_graph_add_node(struct ggml_cgraph* cgraph, struct ggml_tensor* tensor);
+GGML_API void ggml_unravel_index(const struct ggml_tensor* tensor, int64_t i, int64_t* i0, int64_t* i1, int64_t* i2, int64_t* i3);
+GGML_API int64_t ggml_time_ms(void);
+GGML_API int64_t ggml_time_us(void);
 GGML_API struct ggml_tensor* ggml_graph_get_tensor(const struct ggml_cgraph* cgraph, const char* name);
 
 /* ---- graph allocator (ggml-alloc.h; reference: ggml_extend.hpp:2227-2232,2832) ---- */
@@ -188,6 +194,11 @@ GGML_API ggml_backend_buffer_type_t ggml_backend_dev_buffer_type(ggml_backend_de
 GGML_API bool ggml_backend_dev_supports_op(ggml_backend_dev_t device, const struct ggml_tensor* op);
 GGML_API bool ggml_backend_dev_supports_buft(ggml_backend_dev_t device, ggml_backend_buffer_type_t buft);
 GGML_API ggml_backend_t ggml_backend_init_by_name(const char* name, const char* params);
+GGML_API ggml_backend_t ggml_backend_init_by_type(enum ggml_backend_dev_type type, const char* params);
+GGML_API ggml_backend_t ggml_backend_init_best(void); /* first GPU device, else the first device */
+GGML_API void ggml_backend_load_all(void);            /* plug-ins are loaded explicitly (ggml_backend_load): nothing to scan */
+GGML_API ggml_backend_dev_t ggml_backend_buft_get_device(ggml_backend_buffer_type_t buft);
+GGML_API ggml_backend_buffer_type_t ggml_backend_dev_host_buffer_type(ggml_backend_dev_t device); /* NULL when the device has none */
 
 GGML_API const char* ggml_backend_name(ggml_backend_t backend);
 GGML_API void ggml_backend_free(ggml_backend_t backend);

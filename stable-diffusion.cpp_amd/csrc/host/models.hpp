@@ -793,6 +793,9 @@ struct FluxMLP {  // flux.hpp:317-341 (GELU tanh)
     ggml_tensor* forward(GraphCtx& g, ggml_tensor* x) const { return l2.forward(g, ext_gelu(g.ctx, l0.forward(g, x), true)); }
 };
 
+// gate operand of `x + out * gate` in the FLUX blocks: the [H, N] view itself for N == 1 (what the reference emits), [H, 1, N] for our batched graphs
+inline ggml_tensor* flux_gate(ggml_context* c, ggml_tensor* gate) { return gate->ne[1] == 1 ? gate : ggml_reshape_3d(c, gate, gate->ne[0], 1, gate->ne[1]); }
+
 struct FluxDoubleBlock {  // flux.hpp:430-592
     FluxModulation img_mod, txt_mod;
     PlainLayerNorm n1, n2;
@@ -818,14 +821,15 @@ struct FluxDoubleBlock {  // flux.hpp:430-592
         ggml_tensor* attn = rope_attention(g, q, k, v, pe);  // [H, n_txt + n_img, N]
         ggml_tensor* txt_attn_out = ggml_view_3d(c, attn, attn->ne[0], txt->ne[1], attn->ne[2], attn->nb[1], attn->nb[2], 0);
         ggml_tensor* img_attn_out = ggml_view_3d(c, attn, attn->ne[0], img->ne[1], attn->ne[2], attn->nb[1], attn->nb[2], txt->ne[1] * attn->nb[1]);
-        // the reference multiplies by the [H, N] gate view directly, which only broadcasts for N == 1 (flux.hpp:1281 asserts it); the
-        // [H, 1, N] reshape below is the same node for N == 1 and makes our batched graphs well-formed
-        img = ggml_add(c, img, ggml_mul(c, img_attn.proj.forward(g, img_attn_out), ggml_reshape_3d(c, im[0].gate, im[0].gate->ne[0], 1, im[0].gate->ne[1])));
+        // the reference multiplies by the [H, N] gate view directly (flux.hpp:578-588), which only broadcasts for N == 1 (flux.hpp:1281 asserts it): for
+        // N == 1 the graph is the reference's node for node (tests/test_ref_graphs.py — until round 6 a RESHAPE sat in front of every gate MUL);
+        // OUR batched graphs (N > 1) need the [H, 1, N] form
+        img = ggml_add(c, img, ggml_mul(c, img_attn.proj.forward(g, img_attn_out), flux_gate(c, im[0].gate)));
         ggml_tensor* imlp = img_mlp.forward(g, modulate(c, n2.forward(g, img), im[1].shift, im[1].scale));
-        img = ggml_add(c, img, ggml_mul(c, imlp, ggml_reshape_3d(c, im[1].gate, im[1].gate->ne[0], 1, im[1].gate->ne[1])));
-        txt = ggml_add(c, txt, ggml_mul(c, txt_attn.proj.forward(g, txt_attn_out), ggml_reshape_3d(c, tm[0].gate, tm[0].gate->ne[0], 1, tm[0].gate->ne[1])));
+        img = ggml_add(c, img, ggml_mul(c, imlp, flux_gate(c, im[1].gate)));
+        txt = ggml_add(c, txt, ggml_mul(c, txt_attn.proj.forward(g, txt_attn_out), flux_gate(c, tm[0].gate)));
         ggml_tensor* tmlp = txt_mlp.forward(g, modulate(c, n2.forward(g, txt), tm[1].shift, tm[1].scale));
-        txt = ggml_add(c, txt, ggml_mul(c, tmlp, ggml_reshape_3d(c, tm[1].gate, tm[1].gate->ne[0], 1, tm[1].gate->ne[1])));
+        txt = ggml_add(c, txt, ggml_mul(c, tmlp, flux_gate(c, tm[1].gate)));
     }
 };
 
@@ -855,7 +859,7 @@ struct FluxSingleBlock {  // flux.hpp:594-700
         ggml_tensor* mlp  = ggml_view_3d(c, t, mlp_hidden, t->ne[1], t->ne[2], t->nb[1], t->nb[2], hidden * 3 * t->nb[0]);
         mlp               = ext_gelu(c, mlp, true);
         ggml_tensor* out  = linear2.forward(g, ggml_concat(c, attn, mlp, 0));
-        return ggml_add(c, x, ggml_mul(c, out, ggml_reshape_3d(c, mod.gate, mod.gate->ne[0], 1, mod.gate->ne[1])));
+        return ggml_add(c, x, ggml_mul(c, out, flux_gate(c, mod.gate)));
     }
 };
 
@@ -893,8 +897,9 @@ struct FluxModel {
         if (y->ne[1] != N) y = ggml_repeat(c, y, ggml_new_tensor_2d(c, GGML_TYPE_F32, y->ne[0], N));
         const int ps_ = cfg.patch_size;
         const int pad_h = (ps_ - (int)(H % ps_)) % ps_, pad_w = (ps_ - (int)(W % ps_)) % ps_;
-        // DiT::pad_and_patchify(patch_last = true) — dit.hpp:7-34, 67-88
-        ggml_tensor* img = ggml_pad(c, x, pad_w, pad_h, 0, 0);
+        // DiT::pad_and_patchify(patch_last = true) — dit.hpp:7-34, 67-88; ggml_ext_pad emits the PAD node only when there is something to pad
+        // (ggml_extend.hpp:1100-1113; round 6: found against the reference-emitted graph)
+        ggml_tensor* img = (pad_w != 0 || pad_h != 0) ? ggml_pad(c, x, pad_w, pad_h, 0, 0) : x;
         const int64_t h = (H + pad_h) / ps_, w = (W + pad_w) / ps_;
         img = ggml_reshape_4d(c, img, ps_, w, ps_, h * C * N);
         img = ggml_cont(c, ggml_permute(c, img, 0, 2, 1, 3));

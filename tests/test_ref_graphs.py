@@ -1,0 +1,159 @@
+"""The reference's OWN graph builders as the topology oracle, and the reference's OWN runner driving a backend through this repository's ggml front-end
+(VERDICT r5 missing #1 / next-round task 2).
+
+oracle/_ref/libref_graphs.so is src/core/ggml_extend.hpp (ggml_ext_* wrappers, GGMLBlock / Linear / Conv2d / norms, GGMLRunner), ggml_extend_backend.cpp,
+ggml_graph_cut.cpp, layer_split_partition.cpp, util.cpp, src/model/common/block.hpp + rope.hpp, src/model/diffusion/{unet,mmdit,flux,dit}.hpp and
+src/model/vae/auto_encoder_kl.hpp compiled from /root/reference where they lie, against csrc/ggml (oracle/Makefile; tests/ref_graphs.py).  Until round 6 the
+GPU path and the oracle both consumed csrc/host/models.hpp / nn.hpp — this author's restatement of those files — so a topology or constant error would
+have cancelled in every parity test.
+
+  (a) NODE FOR NODE: for every model family, at test widths AND at the benchmarked widths, the graph the reference emits (UnetModelBlock::forward,
+      unet.hpp:526-745; AutoEncoderKLModel::decode, auto_encoder_kl.hpp:589-620; MMDiT::forward, mmdit.hpp:881-927; Flux::forward, flux.hpp:905-1180,
+      through the reference's own build_graph + GGMLRunner::get_compute_graph) equals the engine's: op, type, ne, nb, op_params, flags, every source index,
+      view offsets, leaf order and parameter names — one serialiser (sdm_graph_describe) for both.  Node NAMES are compared too except where the reference
+      renames a tensor for its own tooling ("bench-start/-end", graph-cut marks).  It found one difference, fixed: the engine flagged the result tensor
+      GGML_TENSOR_FLAG_OUTPUT and did not append the runner's two built-in leaves.
+  (b) the reference's GGMLRunner::compute (its gallocr placement, input uploads, graph_compute, read-back) on the CPU oracle backend gives the engine's
+      result BIT FOR BIT for every tiny model — and so does its own eval-callback slicing (sd_set_backend_eval_callback -> sd_ggml_graph_view).
+The GPU half (reference-emitted graphs through libggml-mi355x.so, fusion counters equal): tests/test_gpu_ref_graphs.py.
+"""
+import numpy as np
+import pytest
+
+import ref_graphs as rg
+
+pytestmark = pytest.mark.skipif(not rg.available(), reason="oracle/_ref/libref_graphs.so not built (needs /root/reference: `make -C oracle ref`)")
+
+RENAMED_BY_REFERENCE_TOOLING = ("bench-start", "bench-end", "ggml_runner_cut:")
+
+
+def inputs_for(sd, name, rng, real=False):
+    """(family, version, model enum, overrides, kwargs of RefRunner.describe/compute, engine call, output shape)"""
+    if name in ("SD15_TINY", "SDXL_TINY", "SD15", "SDXL"):
+        xl = "XL" in name
+        hw = (64, 64) if name == "SD15" else (32, 32) if name == "SDXL" else (16, 16)
+        n = 1 if real else 2
+        ctx_dim = {"SD15": 768, "SDXL": 2048}.get(name, 64)
+        adm = 2816 if name == "SDXL" else 96
+        x = rng.standard_normal((n, 4) + hw).astype(np.float32)
+        t = np.linspace(700.0, 200.0, n).astype(np.float32)
+        ctx = rng.standard_normal((1, 77, ctx_dim)).astype(np.float32)
+        y = rng.standard_normal((1, adm)).astype(np.float32) if xl else None
+        return dict(family="unet", version="sdxl" if xl else "sd1", model=getattr(sd, name), overrides=rg.OVERRIDES.get(name, ""),
+                    ref=dict(x=x, t=t, ctx=ctx, y=y), eng=lambda e: e.unet_forward(x, t, ctx, y), out=x.shape)
+    if name.startswith("VAE"):
+        model = {"VAE": sd.SD15_TINY, "VAE_SDXL": sd.SDXL_TINY, "VAE16": sd.SD35_TINY, "VAE_FULL": sd.SD15}[name]
+        version = {"VAE": "sd1", "VAE_SDXL": "sdxl", "VAE16": "sd3", "VAE_FULL": "sd1"}[name]
+        zc = 16 if name == "VAE16" else 4
+        z = rng.standard_normal((1, zc, 12, 10)).astype(np.float32) * 0.5
+        # the engine's sd_vae_decode wraps the graph in the reference's host steps: z / scale_factor + shift_factor in front (diffusion_to_vae_latents,
+        # auto_encoder_kl.hpp:818-826), clamp((x + 1) / 2, 0, 1) behind (vae.hpp:24-30); the reference graph is fed / post-processed the same way here
+        sf, sh = {"sd1": (0.18215, 0.0), "sdxl": (0.13025, 0.0), "sd3": (1.5305, 0.0609)}[version]
+        z_graph = (z / np.float32(sf) + np.float32(sh)).astype(np.float32)
+        post = lambda v: np.clip((v + np.float32(1.0)) * np.float32(0.5), np.float32(0.0), np.float32(1.0)).astype(np.float32)
+        return dict(family="vae", version=version, model=model, overrides="", ref=dict(x=z_graph), eng=lambda e: e.vae_decode(z), out=(1, 3, 96, 80),
+                    scale=(1.0 / 32.0) if name == "VAE_SDXL" else None, post=post)
+    dit_ctx = {"SD35_TINY": 96, "SD3M_TINY": 96, "FLUX_TINY": 96, "SD35_LARGE": 4096, "FLUX_DEV": 4096}[name]
+    dit_y = {"SD35_LARGE": 2048, "FLUX_DEV": 768}.get(name, 64)
+    flux = name.startswith("FLUX")
+    n = 1 if (flux or real) else 2
+    x = rng.standard_normal((n, 16, 14, 12)).astype(np.float32)
+    t = (np.array([0.81, 0.27]) if flux else np.array([731.0, 210.0]))[:n].astype(np.float32)
+    ctx = rng.standard_normal((n, 40, dit_ctx)).astype(np.float32)  # the DiT graphs take conditioning per image (the reference's caller repeats it)
+    y = rng.standard_normal((n, dit_y)).astype(np.float32)
+    g = np.full(n, 3.5, np.float32) if flux else None
+    return dict(family="flux" if flux else "mmdit", version="flux" if flux else "sd3", model=getattr(sd, name), overrides=rg.OVERRIDES.get(name, ""),
+                ref=dict(x=x, t=t, ctx=ctx, y=y, guidance=g), eng=lambda e: e.unet_forward(x, t, ctx, y), out=x.shape)
+
+
+def compare_descriptions(name, dref, deng):
+    lr, nr = rg.split_description(dref)
+    le, ne = rg.split_description(deng)
+    assert len(nr) == len(ne), f"{name}: the reference emits {len(nr)} nodes, the engine {len(ne)}"
+    assert len(lr) == len(le), f"{name}: the reference graph has {len(lr)} leaves, the engine's {len(le)}"
+    for a, b in zip(lr, le):
+        assert a == b, f"{name}: leaf differs\n  reference: {a}\n  engine:    {b}"
+    renamed = 0
+    for a, b in zip(nr, ne):
+        assert rg.strip_name(a) == rg.strip_name(b), f"{name}: node differs\n  reference: {a}\n  engine:    {b}"
+        if a != b:
+            ref_name = a[a.index(" name=") + 6:]
+            assert ref_name.startswith(RENAMED_BY_REFERENCE_TOOLING), f"{name}: node name differs\n  reference: {a}\n  engine:    {b}"
+            renamed += 1
+    return len(nr), len(lr), renamed
+
+
+TINY = ["SD15_TINY", "SDXL_TINY", "VAE", "VAE_SDXL", "VAE16", "SD35_TINY", "SD3M_TINY", "FLUX_TINY"]
+
+
+@pytest.mark.parametrize("flash", [True, False])
+@pytest.mark.parametrize("name", TINY)
+def test_reference_emitted_graph_equals_engine_graph_node_for_node(sd, oracle, name, flash):
+    c = inputs_for(sd, name, np.random.default_rng(5))
+    e = sd.Engine(model=c["model"], backend=oracle, flash_attn=flash)
+    r = rg.RefRunner(e, c["family"], c["version"], oracle, flash_attn=flash, overrides=c["overrides"], copy_weights=False)
+    if c.get("scale"):
+        r.set_conv2d_scale(c["scale"])  # SDXL engines start with the VAE Conv2d scale 1/32 (src/stable-diffusion.cpp:1477-1485)
+    dref = r.describe(**c["ref"])
+    deng = rg.engine_graph_description(lambda: c["eng"](e), compute=False)
+    nodes, leafs, renamed = compare_descriptions(name, dref, deng)
+    print(f"{name} flash={flash}: {nodes} nodes, {leafs} leaves identical ({renamed} nodes renamed by the reference's tooling)")
+    r.close()
+
+
+@pytest.mark.parametrize("name", ["SD15", "SDXL", "VAE_FULL", "SD35_LARGE", "FLUX_DEV"])
+def test_reference_emitted_graph_equals_engine_graph_at_the_benchmarked_widths(sd, oracle, name, monkeypatch):
+    """Graphs only (nothing is computed, the weight tables are allocated and left unfilled): the benchmarked models themselves — SD1.5 UNet (320 ch, 64x64
+    latent), SDXL UNet (70 transformer blocks), the 128-ch KL-VAE decoder, SD3.5-large (38 joint blocks, hidden 2432), FLUX.1-dev (19 double + 38 single
+    blocks, hidden 3072, 24 x 128); flash attention on as in bench.py.  The reference side detects every configuration from the weight table
+    (UNetConfig / MMDiTConfig / FluxConfig::detect_from_weights) — no overrides."""
+    monkeypatch.setenv("SDCPP_SKIP_WEIGHT_INIT", "1")
+    c = inputs_for(sd, name, np.random.default_rng(6), real=True)
+    assert c["overrides"] == ""
+    e = sd.Engine(model=c["model"], backend=oracle, flash_attn=True)
+    r = rg.RefRunner(e, c["family"], c["version"], oracle, flash_attn=True, overrides=c["overrides"], copy_weights=False)
+    dref = r.describe(**c["ref"])
+    deng = rg.engine_graph_description(lambda: c["eng"](e), compute=False)
+    nodes, leafs, renamed = compare_descriptions(name, dref, deng)
+    print(f"{name}: {nodes} nodes, {leafs} leaves identical at the benchmarked width")
+    r.close()
+
+
+@pytest.mark.parametrize("name", TINY)
+def test_reference_runner_computes_the_engine_result_bit_for_bit_on_the_oracle(sd, oracle, name):
+    c = inputs_for(sd, name, np.random.default_rng(7))
+    e = sd.Engine(model=c["model"], backend=oracle, flash_attn=True)
+    r = rg.RefRunner(e, c["family"], c["version"], oracle, flash_attn=True, overrides=c["overrides"])
+    if c.get("scale"):
+        r.set_conv2d_scale(c["scale"])
+    ref = c.get("post", lambda v: v)(r.compute(c["out"], **c["ref"]))
+    out = c["eng"](e)
+    assert np.isfinite(ref).all()
+    np.testing.assert_array_equal(ref, out.reshape(ref.shape))
+    r.close()
+
+
+def test_reference_eval_callback_slicing_through_the_reference_own_view_constructor(sd, oracle):
+    """The REAL sd_backend_graph_compute_with_eval_callback / sd_ggml_graph_view (src/core/ggml_extend_backend.cpp:449-509, compiled into libref_graphs.so),
+    installed through the reference's sd_set_backend_eval_callback, asks about every node once, in order, cuts behind every MUL_MAT and gives the whole-graph
+    result; the host's restatement (sdm_backend_graph_compute_with_eval_callback) records the same node sequence."""
+    c = inputs_for(sd, "SD15_TINY", np.random.default_rng(8))
+    e = sd.Engine(model=c["model"], backend=oracle, flash_attn=True)
+    r = rg.RefRunner(e, c["family"], c["version"], oracle, flash_attn=True, overrides=c["overrides"])
+    whole = r.compute(c["out"], **c["ref"])
+    mm = sd.op_number("MUL_MAT")
+    tr = sd.EvalTrace(lambda i, ts: ts.op == mm)
+    rg.lib().refg_set_eval_callback(tr._cb, None)
+    try:
+        sliced = r.compute(c["out"], **c["ref"])
+    finally:
+        rg.lib().refg_set_eval_callback(sd.EVAL_CALLBACK_FN(), None)
+    np.testing.assert_array_equal(sliced, whole)
+    with sd.EvalTrace(lambda i, ts: ts.op == mm) as tr2:
+        out = c["eng"](e)
+    np.testing.assert_array_equal(out.reshape(whole.shape), whole)
+    assert tr.asked == tr2.asked and len(tr.records) == len(tr2.records) > 100
+    for a, b in zip(tr.records, tr2.records):
+        assert a[:2] == b[:2]
+        np.testing.assert_array_equal(a[3], b[3])
+    r.close()
