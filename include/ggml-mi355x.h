@@ -94,6 +94,7 @@ struct ggml_backend_mi355x_stats {
     int64_t fused_concat_gn;     /* skip-connection CONCATs never materialised: GroupNorm statistics / apply (and the skip conv's operand cast) read the two sources (plan_concat_gn) */
     int64_t fused_conv_scale;    /* Conv2d scales (SCALE s -> conv -> SCALE 1/s, the reference's SDXL VAE setting) folded into the operand image and the epilogue */
     int64_t view_graphs;         /* plans built for SUB-GRAPH VIEWS (sd_ggml_graph_view, src/core/ggml_extend_backend.cpp:449-463: leafs NULL / size 0) */
+    int64_t plans_evicted;       /* cached plans (with their captured hipGraph) dropped by the LRU bound of the plan cache (option plan_cache_cap, default 512) */
     int64_t view_external_nodes; /* nodes of those slices treated as read outside the slice (parent use_counts > readers inside, the slice's last node and its sources) */
 };
 GGML_MI355X_API void ggml_backend_mi355x_get_stats(struct ggml_backend_mi355x_stats* out);
@@ -163,6 +164,17 @@ GGML_MI355X_API int ggml_backend_mi355x_get_kernel_timings(struct ggml_backend_m
  * 2 = wherever it is legal: measured slower or equal, kept for A/B runs), "flash_pp_min_tiles" (4).
  * Wrong-result timing ablations exist only in builds with -DMI355X_EXPERIMENTS ("flash_ablate"). */
 GGML_MI355X_API void ggml_backend_mi355x_set_option(const char* key, int value);
+/* What the calling thread's current device delivers, measured in about a second (csrc/kernels/calib.hip): an MFMA loop from registers (f16, 32x32x16: the
+ * matrix pipe's ceiling at the clock the chip sustains under it, and that clock), a float4 copy and a read-only pass over 1 GiB.  bench.py reports them as
+ * roofline.measured_peaks next to the vendor peaks, so that runs on boxes of different speed can be compared.  Returns 0, or -1 on failure. */
+struct ggml_backend_mi355x_calibration {
+    float mfma_f16_tflops; /* dense f16 MFMA, TFLOP/s */
+    float mfma_clock_mhz;  /* shader clock during the MFMA loop */
+    float copy_tbs;        /* (read + write bytes) / time of a float4 copy, TB/s */
+    float read_tbs;        /* read-only pass, TB/s */
+    int compute_units;
+};
+GGML_MI355X_API int ggml_backend_mi355x_calibrate(struct ggml_backend_mi355x_calibration* out);
 /* the hipStream_t every graph of this backend instance is enqueued on (graph_compute_async, set/get_tensor_async): a caller that touches a
  * tensor's device memory between two graphs (the CFG-pair all-reduce, sd_set_pair_exchange) orders its work on this stream */
 GGML_MI355X_API void* ggml_backend_mi355x_get_stream(ggml_backend_t backend);

@@ -219,7 +219,8 @@ SD_API void sd_planar_rgb_to_u8(const float* chw, int width, int height, uint8_t
 SD_API int sd_sample_synthetic(int family, int steps, int image_seq_len, int64_t n, uint64_t seed, int method, float eta, float* out, float* aux);
 /* AutoEncoderKL::set_conv2d_scale (src/model/vae/auto_encoder_kl.hpp:708-717): every Conv2d of the VAE computes conv(x * s) / s + bias.  SDXL contexts start with
  * s = 1/32 — what the reference sets when no external VAE is given (src/stable-diffusion.cpp:1477-1485; `--vae` with a fixed VAE -> call this with 1) */
-SD_API void sd_set_vae_conv2d_scale(sdm_ctx_t* ctx, float scale);
+SD_API bool sd_set_vae_conv2d_scale(sdm_ctx_t* ctx, float scale); /* false (sd_last_error) for a non-finite or non-positive scale; loading a file under the
+                                                                     "first_stage_model" prefix (= --vae) resets an SDXL context to scale 1 like the reference */
 SD_API int sd_get_flux_sigmas(int steps, int image_seq_len, float* out /* steps+1 */); /* FluxScheduler, denoiser.hpp:726-782 */
 SD_API int sd_gen_flux_pe(int h, int w, int patch_size, int context_len, const int* axes_dim, int n_axes, float theta, float* out); /* Rope::gen_flux_pe; returns floats written */
 SD_API int sd_get_flow_sigmas(int steps, float shift, float* out /* steps+1 */);    /* DiscreteFlowDenoiser, denoiser.hpp:1239-1283 (t = 1000*sigma) */

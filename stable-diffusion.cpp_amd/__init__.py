@@ -255,7 +255,7 @@ def lib() -> C.CDLL:
     L.sd_set_guidance.argtypes = [C.c_void_p, C.c_float]
     L.sd_set_guidance.restype = None
     L.sd_set_vae_conv2d_scale.argtypes = [C.c_void_p, C.c_float]
-    L.sd_set_vae_conv2d_scale.restype = None
+    L.sd_set_vae_conv2d_scale.restype = C.c_bool
     L.sd_set_pair_exchange.argtypes = [C.c_void_p, PAIR_EXCHANGE_FN, C.c_void_p, C.c_int]
     L.sd_set_pair_exchange.restype = None
     L.sd_rccl_get_unique_id.argtypes = [C.c_void_p]
@@ -318,7 +318,7 @@ def load_mi355x_backend() -> None:
 
 _BACKEND_STAT_FIELDS = ("graphs_computed plans_built nodes_seen kernels_planned kernels_launched fused_conv fused_conv_bounced fused_linear "
                         "fused_norm fused_geglu fused_attention generic_matmul swizzled_weight_bytes graph_replays fused_linear_geglu "
-                        "split_k_gemms head_major_gemms fused_modulate fused_gate fused_gelu fused_rope fused_concat_heads qgemv_linears fused_chan_add fused_proj_tokens gemm_attention fused_q16 split_k_inlaunch qgemm16_linears fgemv_linears fused_presilu fused_sibling_linears hoisted_kv_linears window_convs hoisted_emb_linears fused_rows16 fused_joint_qkv jit_images fused_cat_rows16 fused_gn_stats fused_ln_reduce redirect_fallbacks fused_concat_gn fused_conv_scale view_graphs view_external_nodes").split()
+                        "split_k_gemms head_major_gemms fused_modulate fused_gate fused_gelu fused_rope fused_concat_heads qgemv_linears fused_chan_add fused_proj_tokens gemm_attention fused_q16 split_k_inlaunch qgemm16_linears fgemv_linears fused_presilu fused_sibling_linears hoisted_kv_linears window_convs hoisted_emb_linears fused_rows16 fused_joint_qkv jit_images fused_cat_rows16 fused_gn_stats fused_ln_reduce redirect_fallbacks fused_concat_gn fused_conv_scale view_graphs plans_evicted view_external_nodes").split()
 
 
 class BackendStats(C.Structure):
@@ -383,6 +383,22 @@ def kernel_timing() -> dict:
     """The first timed family (the dominant kernel when only that one is enabled)."""
     t = kernel_timings()
     return t[0] if t else {"kernel": "(no timed launches)", "family": -1, "bound": "mfma", "launches": 0, "total_ms": 0.0, "total_flops": 0.0, "total_bytes": 0.0}
+
+
+class Calibration(C.Structure):
+    """struct ggml_backend_mi355x_calibration (include/ggml-mi355x.h)"""
+    _fields_ = [("mfma_f16_tflops", C.c_float), ("mfma_clock_mhz", C.c_float), ("copy_tbs", C.c_float), ("read_tbs", C.c_float), ("compute_units", C.c_int)]
+
+
+def calibrate() -> dict | None:
+    """What the current device delivers (MFMA loop, float4 copy / read, clock under MFMA load): csrc/kernels/calib.hip."""
+    b = _backend()
+    b.ggml_backend_mi355x_calibrate.argtypes = [C.POINTER(Calibration)]
+    c = Calibration()
+    if b.ggml_backend_mi355x_calibrate(C.byref(c)) != 0:
+        return None
+    return {"mfma_f16_tflops": round(c.mfma_f16_tflops, 1), "mfma_clock_mhz": round(c.mfma_clock_mhz, 1), "copy_tbs": round(c.copy_tbs, 3), "read_tbs": round(c.read_tbs, 3),
+            "compute_units": c.compute_units}
 
 
 def backend_set_option(key: str, value: int) -> None:
@@ -548,7 +564,8 @@ class Engine:
 
     def set_vae_conv2d_scale(self, scale: float) -> None:
         """AutoEncoderKL::set_conv2d_scale: conv(x * s) / s + b on every VAE conv (SDXL engines start with 1/32, like the reference without --vae)."""
-        lib().sd_set_vae_conv2d_scale(self._ctx, float(scale))
+        if not lib().sd_set_vae_conv2d_scale(self._ctx, float(scale)):
+            raise EngineError(lib().sd_last_error().decode())
 
     def set_guidance(self, guidance: float) -> None:
         """FLUX distilled-guidance input (default 3.5)"""

@@ -28,6 +28,7 @@
 #include "ggml-mi355x.h"
 #include "ktime.h"
 #include "planner.h"
+#include "kernels.h"
 
 namespace mi355x {
 
@@ -101,6 +102,10 @@ static ggml_backend_buffer_t buft_alloc(ggml_backend_buffer_type_t t, size_t siz
         (void)hipGetLastError();
         return nullptr;  // host turns this into "alloc failed" (ggml_extend.hpp:2232-2236)
     }
+    // GGML_MI355X_POISON=1 (debugging): every byte a kernel may read before anything wrote it is a NaN pattern — an uninitialised read shows up as NaN in the
+    // result instead of depending on what the allocator handed back (round 6: the FLUX graphs' results depended on the buffer's previous contents)
+    static const bool poison = getenv("GGML_MI355X_POISON") != nullptr;
+    if (poison) (void)hipMemset(p, 0xFF, size > 0 ? size : 256);
     ggml_backend_buffer* b = new ggml_backend_buffer();
     memset(b, 0, sizeof(*b));
     b->iface.free_buffer   = buf_free;
@@ -411,6 +416,16 @@ GGML_MI355X_API int ggml_backend_mi355x_get_device_count(void) {
     return (int)mi355x::g_devices.size();
 }
 GGML_MI355X_API void ggml_backend_mi355x_get_stats(struct ggml_backend_mi355x_stats* out) { mi355x::planner_get_stats(out); }
+GGML_MI355X_API int ggml_backend_mi355x_calibrate(struct ggml_backend_mi355x_calibration* out) {
+    mi355x::CalibrationResult r;
+    if (!out || !mi355x::calibrate_device(nullptr, &r)) return -1;
+    out->mfma_f16_tflops = r.mfma_f16_tflops;
+    out->mfma_clock_mhz  = r.mfma_clock_mhz;
+    out->copy_tbs        = r.copy_tbs;
+    out->read_tbs        = r.read_tbs;
+    out->compute_units   = r.compute_units;
+    return 0;
+}
 // explicit form of the by-name enum resolution (a host that does not export the name functions globally, and the ABI tests): returns 0 and installs
 // the translation, or -1 (tables unchanged; the reason is in ggml_backend_mi355x_enum_status()).  NULL arguments leave that table alone.
 GGML_MI355X_API int ggml_backend_mi355x_resolve_enums(const char* (*op_name)(int), const char* (*unary_op_name)(int), const char* (*type_name)(int)) {

@@ -81,16 +81,27 @@ const NameNum kNeededTypes[] = {
     {"f32", GGML_TYPE_F32}, {"f16", GGML_TYPE_F16}, {"q4_0", GGML_TYPE_Q4_0}, {"q8_0", GGML_TYPE_Q8_0}, {"i32", GGML_TYPE_I32}, {"bf16", GGML_TYPE_BF16},
 };
 
-// scans host numbers 0 .. until every needed name has been seen (never past the largest needed op: the host's name table is not indexed beyond what
-// any compatible ggml defines); cap = hard stop for a host that lacks a needed name
-bool build_map(const char* (*name_of)(int), const NameNum* need, int n_need, int cap, int unknown, uint8_t* table, char* err, size_t err_len, const char* what) {
+// Scans host numbers 0, 1, ... and stops at the first name that cannot be an op name.  Upstream's ggml_op_name(op) is GGML_OP_NAME[op] with no bounds
+// check, so asking beyond the host's table reads whatever follows it (round-5 advice: a host lacking one needed name was read up to number 199 and
+// strcmp ran on garbage).  Op / unary-op names are upper-case identifiers ([A-Z0-9_]+, at most 32 characters); what follows GGML_OP_NAME in upstream is
+// GGML_OP_SYMBOL ("none", "x", "x+y", ...), so the scan ends exactly at the table's end there, and at the first NULL / non-identifier anywhere else;
+// it also stops as soon as every name it looks for has been seen.  `optional` names (ops a host may predate: CONV_2D, unary EXP) stay "unknown" when missing.
+bool plausible_op_name(const char* nm) {
+    if (!nm) return false;
+    int n = 0;
+    for (; nm[n] && n <= 32; ++n)
+        if (!((nm[n] >= 'A' && nm[n] <= 'Z') || (nm[n] >= '0' && nm[n] <= '9') || nm[n] == '_')) return false;
+    return n > 0 && n <= 32;
+}
+bool build_map(const char* (*name_of)(int), const NameNum* need, int n_need, int cap, int unknown, uint8_t* table, char* err, size_t err_len, const char* what,
+               const char* const* optional = nullptr, int n_optional = 0) {
     uint8_t out[256];
     for (int i = 0; i < 256; ++i) out[i] = (uint8_t)unknown;
     std::vector<int> found(n_need, -1);
     int left = n_need;
     for (int h = 0; h < cap && left > 0; ++h) {
         const char* nm = name_of(h);
-        if (!nm) break;
+        if (!plausible_op_name(nm)) break;
         for (int k = 0; k < n_need; ++k)
             if (!strcmp(nm, need[k].name)) {
                 if (found[k] >= 0) {
@@ -104,7 +115,10 @@ bool build_map(const char* (*name_of)(int), const NameNum* need, int n_need, int
     }
     for (int k = 0; k < n_need; ++k)
         if (found[k] < 0) {
-            snprintf(err, err_len, "host has no %s named '%s' among its first %d", what, need[k].name, cap);
+            bool opt = false;
+            for (int o = 0; o < n_optional; ++o) opt = opt || !strcmp(optional[o], need[k].name);
+            if (opt) continue;  // the host never emits it; a graph that did would see "unsupported"
+            snprintf(err, err_len, "host has no %s named '%s'", what, need[k].name);
             return false;
         }
     memcpy(table, out, 256);
@@ -120,8 +134,11 @@ bool planner_build_op_maps(const char* (*op_name)(int), const char* (*unary_name
         err     = local;
         err_len = sizeof(local);
     }
-    if (op_name && !build_map(op_name, kNeededOps, (int)(sizeof(kNeededOps) / sizeof(kNeededOps[0])), 200, GGML_OP_COUNT, ops, err, err_len, "op")) return false;
-    if (unary_name && !build_map(unary_name, kNeededUnary, (int)(sizeof(kNeededUnary) / sizeof(kNeededUnary[0])), 64, GGML_UNARY_OP_COUNT, un, err, err_len, "unary op")) return false;
+    static const char* const kOptionalOps[]   = {"CONV_2D"};
+    static const char* const kOptionalUnary[] = {"EXP"};
+    if (op_name && !build_map(op_name, kNeededOps, (int)(sizeof(kNeededOps) / sizeof(kNeededOps[0])), 200, GGML_OP_COUNT, ops, err, err_len, "op", kOptionalOps, 1)) return false;
+    if (unary_name && !build_map(unary_name, kNeededUnary, (int)(sizeof(kNeededUnary) / sizeof(kNeededUnary[0])), 64, GGML_UNARY_OP_COUNT, un, err, err_len, "unary op", kOptionalUnary, 1))
+        return false;
     if (type_name) {
         // type numbers are part of the GGUF file format and cannot drift without breaking every model file: verified, not remapped
         for (const NameNum& t : kNeededTypes) {
@@ -146,11 +163,11 @@ namespace {
 struct Stats {
     std::atomic<int64_t> graphs_computed{0}, plans_built{0}, nodes_seen{0}, kernels_planned{0}, kernels_launched{0}, fused_conv{0},
         fused_conv_bounced{0}, fused_linear{0}, fused_norm{0}, fused_geglu{0}, fused_attention{0}, generic_matmul{0}, swizzled_weight_bytes{0}, fused_linear_geglu{0}, split_k_gemms{0}, head_major_gemms{0}, fused_modulate{0}, fused_gate{0}, fused_gelu{0}, fused_rope{0}, fused_concat_heads{0},
-        graph_replays{0}, qgemv_linears{0}, fused_chan_add{0}, fused_proj_tokens{0}, gemm_attention{0}, fused_q16{0}, split_k_inlaunch{0}, qgemm16_linears{0}, fgemv_linears{0}, fused_presilu{0}, fused_sibling_linears{0}, hoisted_kv_linears{0}, window_convs{0}, hoisted_emb_linears{0}, fused_rows16{0}, fused_cat_rows16{0}, fused_joint_qkv{0}, jit_images{0}, fused_gn_stats{0}, redirect_fallbacks{0}, fused_ln_reduce{0}, fused_concat_gn{0}, fused_conv_scale{0}, view_graphs{0}, view_external_nodes{0};
+        graph_replays{0}, qgemv_linears{0}, fused_chan_add{0}, fused_proj_tokens{0}, gemm_attention{0}, fused_q16{0}, split_k_inlaunch{0}, qgemm16_linears{0}, fgemv_linears{0}, fused_presilu{0}, fused_sibling_linears{0}, hoisted_kv_linears{0}, window_convs{0}, hoisted_emb_linears{0}, fused_rows16{0}, fused_cat_rows16{0}, fused_joint_qkv{0}, jit_images{0}, fused_gn_stats{0}, redirect_fallbacks{0}, fused_ln_reduce{0}, fused_concat_gn{0}, fused_conv_scale{0}, view_graphs{0}, view_external_nodes{0}, plans_evicted{0};
 } g_stats;
 
 struct Options {
-    std::atomic<int> fusion{1}, mfma_gemm{1}, hip_graph{1}, flash_pattern{1}, gemm16{1}, fuse_modulate{1}, fuse_gate{1}, fuse_gelu{1}, fuse_rope{1}, fuse_concat_heads{1}, qgemv{1}, fuse_chan_add{1}, fuse_proj_tokens{1}, fuse_q16{1}, qgemm16{1}, fgemv{1}, fuse_siblings{1}, hoist_kv{1}, hoist_emb{1}, fuse_rows16{0}, fuse_cat_rows16{1}, fuse_joint_qkv{1}, jit_qimages{4096}, fuse_gn_stats{1}, fuse_ln_reduce{1}, relax_res_overlap{1}, fuse_split_gelu{1}, fuse_concat_gn{1}, fuse_gn_tokens{1}, fuse_linear_nchw{1}, fuse_conv_scale{1}, ignore_use_counts{0};
+    std::atomic<int> fusion{1}, mfma_gemm{1}, hip_graph{1}, flash_pattern{1}, gemm16{1}, fuse_modulate{1}, fuse_gate{1}, fuse_gelu{1}, fuse_rope{1}, fuse_concat_heads{1}, qgemv{1}, fuse_chan_add{1}, fuse_proj_tokens{1}, fuse_q16{1}, qgemm16{1}, fgemv{1}, fuse_siblings{1}, hoist_kv{1}, hoist_emb{1}, fuse_rows16{0}, fuse_cat_rows16{1}, fuse_joint_qkv{1}, jit_qimages{4096}, fuse_gn_stats{1}, fuse_ln_reduce{1}, relax_res_overlap{1}, fuse_split_gelu{1}, fuse_concat_gn{1}, fuse_gn_tokens{1}, fuse_linear_nchw{1}, fuse_conv_scale{1}, ignore_use_counts{0}, plan_cache_cap{512};
 } g_opt;
 
 using Step = std::function<void(hipStream_t)>;
@@ -163,6 +180,7 @@ struct Plan {
     hipGraphExec_t graph_exec = nullptr;
     bool graph_failed         = false;
     int64_t runs              = 0;  // executions so far: the hipGraph is captured when a plan comes back (one-shot graphs never pay for a capture)
+    uint64_t last_use         = 0;  // Planner::tick at the last execution: the plan cache evicts the least recently used entry beyond plan_cache_cap
 };
 
 struct SwzEntry {
@@ -179,6 +197,7 @@ std::vector<Planner*> g_planners;
 
 struct Planner {
     int device;
+    uint64_t tick = 0;
     std::unordered_map<uint64_t, std::unique_ptr<Plan>> plans;
     std::unordered_map<uint64_t, SwzEntry> swz;  // key: hash(src ptr, kind)
     // private operand arena: f16 activation images + GroupNorm affine tables of the plan being executed.  Plans hold
@@ -2341,7 +2360,21 @@ bool plan_rope(Builder& B, int i, hipStream_t, std::vector<int>& chain) {
     View4 xv     = view_of(x);
     float* out   = (float*)gi.node(add)->data;
     const float* pep = (const float*)rm.pe->data;
-    B.emit_at(add, i, [=](hipStream_t st) { launch_rope_pairs(st, out, xv, pep); });
+    // x is dead after the chain's first node, so the graph allocator may have put the chain's result on top of it — and the kernel reads x as [d, H, L, N]
+    // while it writes the result as [d, L, H N]: one thread would overwrite pairs another thread has yet to read.  (Round 6: this was a real race — the
+    // FLUX test model's result changed from run to run once a second backend instance on the device shifted the kernel's timing; found when the
+    // reference-emitted graphs were compared bit for bit with the engine's, tests/test_gpu_ref_graphs.py.)  On overlap the result goes through arena scratch.
+    const size_t out_bytes = ggml_abi_nbytes(gi.node(add));
+    if (overlaps(out, out_bytes, x->data, ggml_abi_nbytes(x)) || overlaps(out, out_bytes, rm.pe->data, ggml_abi_nbytes(rm.pe))) {
+        Planner* P       = B.P;
+        const size_t off = B.scratch(0x4a62, out_bytes);
+        B.emit_at(add, i, [=](hipStream_t st) {
+            launch_rope_pairs(st, (float*)(P->arena + off), xv, pep);
+            (void)hipMemcpyAsync(out, P->arena + off, out_bytes, hipMemcpyDeviceToDevice, st);
+        });
+    } else {
+        B.emit_at(add, i, [=](hipStream_t st) { launch_rope_pairs(st, out, xv, pep); });
+    }
     g_stats.fused_rope++;
     return true;
 }
@@ -3367,7 +3400,16 @@ bool build_plan(Planner* P, Plan* plan, const ggml_cgraph* g, hipStream_t s, boo
                 const auto ui          = B.ups.find(xs0);
                 if (ui != B.ups.end()) src = ui->second;
                 const auto it = B.packed.find(src);
-                if (it != B.packed.end() && it->second.nhwc && it->second.mul != cs) break;  // an image with another factor: run the SCALE as a plain node
+                if (it != B.packed.end() && it->second.nhwc && it->second.mul != cs) {
+                    // an image with another factor exists: the SCALE would have to run as a plain node — which reads the f32 tensor of its source.  That
+                    // tensor does not exist when the source was elided (a deferred UPSCALE) or written only as an operand image (round-5 advice): fail
+                    // the graph loudly instead of scaling unwritten memory.  (Unreachable today: every VAE conv shares one factor.)
+                    if (B.ups.count(xs0) || B.prescale.count(xs0)) {
+                        fprintf(stderr, "[ggml-mi355x] node %d: Conv2d scale %g behind an elided node whose operand image carries factor %g\n", i, (double)cs, (double)it->second.mul);
+                        return false;
+                    }
+                    break;
+                }
                 if (it == B.packed.end() || !it->second.nhwc) {
                     const int64_t SW = src->ne[0], SH = src->ne[1], IC = src->ne[2], N = src->ne[3];
                     Packed pk{B.alloc((size_t)N * SW * SH * rup64(IC) * 2), rup64(IC), true, cs};
@@ -3517,7 +3559,23 @@ enum ggml_status planner_compute(Planner* p, ggml_cgraph* g, hipStream_t stream)
         np->check     = gk.check;
         plan          = np.get();
         p->plans[key] = std::move(np);
+        // bounded cache (round-5 advice: every plan that ran twice kept a hipGraphExec for ever — varying shapes, context lengths, VAE scales or
+        // eval-callback slicings grew it without limit): beyond plan_cache_cap entries the least recently used plan goes, with its captured graph
+        const size_t cap = (size_t)std::max(2, g_opt.plan_cache_cap.load());
+        while (p->plans.size() > cap) {
+            auto victim = p->plans.end();
+            for (auto pi = p->plans.begin(); pi != p->plans.end(); ++pi)
+                if (pi->second.get() != plan && (victim == p->plans.end() || pi->second->last_use < victim->second->last_use)) victim = pi;
+            if (victim == p->plans.end()) break;
+            if (victim->second->graph_exec) {
+                (void)hipStreamSynchronize(stream);  // a replay of the victim may still be in flight on this stream
+                (void)hipGraphExecDestroy(victim->second->graph_exec);
+            }
+            p->plans.erase(victim);
+            g_stats.plans_evicted++;
+        }
     }
+    plan->last_use = ++p->tick;
     if (plan->arena_needed > p->arena_cap) {
         // grow the operand arena (plans keep offsets, so only captured hipGraphs must be dropped)
         (void)hipStreamSynchronize(stream);
@@ -3532,6 +3590,8 @@ enum ggml_status planner_compute(Planner* p, ggml_cgraph* g, hipStream_t stream)
         }
         p->arena     = (char*)np;
         p->arena_cap = want;
+        static const bool poison = getenv("GGML_MI355X_POISON") != nullptr;  // see backend.cpp: unwritten arena bytes read as NaN
+        if (poison) (void)hipMemset(np, 0xFF, want);
         for (auto& kv : p->plans)
             if (kv.second->graph_exec) {
                 (void)hipGraphExecDestroy(kv.second->graph_exec);
@@ -3563,6 +3623,10 @@ enum ggml_status planner_compute(Planner* p, ggml_cgraph* g, hipStream_t stream)
             if (hipGraphLaunch(plan->graph_exec, stream) == hipSuccess) {
                 g_stats.graph_replays++;
                 g_stats.kernels_launched += (int64_t)plan->steps.size();
+                if (hipPeekAtLastError() != hipSuccess) {  // a sticky error from an earlier launch surfaces here as it does on the eager path
+                    fprintf(stderr, "[ggml-mi355x] error pending after graph replay: %s\n", hipGetErrorString(hipGetLastError()));
+                    return GGML_STATUS_FAILED;
+                }
                 return GGML_STATUS_SUCCESS;
             }
             plan->graph_failed = true;
@@ -3714,6 +3778,7 @@ void planner_get_stats(ggml_backend_mi355x_stats* o) {
     o->fused_conv_scale      = g_stats.fused_conv_scale;
     o->view_graphs           = g_stats.view_graphs;
     o->view_external_nodes   = g_stats.view_external_nodes;
+    o->plans_evicted         = g_stats.plans_evicted;
     o->fused_attention       = g_stats.fused_attention;
     o->generic_matmul        = g_stats.generic_matmul;
     o->swizzled_weight_bytes = g_stats.swizzled_weight_bytes;
@@ -3787,6 +3852,7 @@ void planner_set_option(const char* key, int value) {
     else if (!strcmp(key, "fuse_gn_tokens")) g_opt.fuse_gn_tokens = value;
     else if (!strcmp(key, "fuse_linear_nchw")) g_opt.fuse_linear_nchw = value;
     else if (!strcmp(key, "fuse_conv_scale")) g_opt.fuse_conv_scale = value;
+    else if (!strcmp(key, "plan_cache_cap")) g_opt.plan_cache_cap = value;  // plans (and captured hipGraphs) kept per backend instance, LRU beyond that (default 512)
     else if (!strcmp(key, "ignore_use_counts")) g_opt.ignore_use_counts = value;  // test hook: a host whose sub-graph views carry no use_counts table
     else if (!strcmp(key, "fuse_gelu")) g_opt.fuse_gelu = value;
     else if (!strcmp(key, "fuse_rope")) g_opt.fuse_rope = value;

@@ -143,21 +143,48 @@ const char* ggml_type_name(enum ggml_type type) {
     }
 }
 
+// every op of the enum has its name, like upstream's GGML_OP_NAME table (the plug-in resolves the numbers it needs BY NAME and ends its scan at the first
+// string that is not an op name, planner.cpp build_map)
 const char* ggml_op_name(enum ggml_op op) {
     switch (op) {
         case GGML_OP_NONE: return "NONE";
         case GGML_OP_DUP: return "DUP";
         case GGML_OP_ADD: return "ADD";
+        case GGML_OP_ADD_ID: return "ADD_ID";
+        case GGML_OP_ADD1: return "ADD1";
+#ifdef GGML_ABI_TEST_SHIFTED_ENUMS
+        case GGML_OP_FORK_EXTRA_A: return "FORK_EXTRA_A";
+        case GGML_OP_FORK_EXTRA_B: return "FORK_EXTRA_B";
+#endif
+        case GGML_OP_ACC: return "ACC";
         case GGML_OP_SUB: return "SUB";
         case GGML_OP_MUL: return "MUL";
         case GGML_OP_DIV: return "DIV";
+        case GGML_OP_SQR: return "SQR";
+        case GGML_OP_SQRT: return "SQRT";
+        case GGML_OP_LOG: return "LOG";
+        case GGML_OP_SIN: return "SIN";
+        case GGML_OP_COS: return "COS";
+        case GGML_OP_SUM: return "SUM";
+        case GGML_OP_SUM_ROWS: return "SUM_ROWS";
+        case GGML_OP_CUMSUM: return "CUMSUM";
+        case GGML_OP_MEAN: return "MEAN";
+        case GGML_OP_ARGMAX: return "ARGMAX";
+        case GGML_OP_COUNT_EQUAL: return "COUNT_EQUAL";
         case GGML_OP_REPEAT: return "REPEAT";
+        case GGML_OP_REPEAT_BACK: return "REPEAT_BACK";
         case GGML_OP_CONCAT: return "CONCAT";
+        case GGML_OP_SILU_BACK: return "SILU_BACK";
         case GGML_OP_NORM: return "NORM";
         case GGML_OP_RMS_NORM: return "RMS_NORM";
+        case GGML_OP_RMS_NORM_BACK: return "RMS_NORM_BACK";
         case GGML_OP_GROUP_NORM: return "GROUP_NORM";
+        case GGML_OP_L2_NORM: return "L2_NORM";
         case GGML_OP_MUL_MAT: return "MUL_MAT";
+        case GGML_OP_MUL_MAT_ID: return "MUL_MAT_ID";
+        case GGML_OP_OUT_PROD: return "OUT_PROD";
         case GGML_OP_SCALE: return "SCALE";
+        case GGML_OP_SET: return "SET";
         case GGML_OP_CPY: return "CPY";
         case GGML_OP_CONT: return "CONT";
         case GGML_OP_RESHAPE: return "RESHAPE";
@@ -165,15 +192,61 @@ const char* ggml_op_name(enum ggml_op op) {
         case GGML_OP_PERMUTE: return "PERMUTE";
         case GGML_OP_TRANSPOSE: return "TRANSPOSE";
         case GGML_OP_GET_ROWS: return "GET_ROWS";
+        case GGML_OP_GET_ROWS_BACK: return "GET_ROWS_BACK";
+        case GGML_OP_SET_ROWS: return "SET_ROWS";
+        case GGML_OP_DIAG: return "DIAG";
+        case GGML_OP_DIAG_MASK_INF: return "DIAG_MASK_INF";
+        case GGML_OP_DIAG_MASK_ZERO: return "DIAG_MASK_ZERO";
         case GGML_OP_SOFT_MAX: return "SOFT_MAX";
+        case GGML_OP_SOFT_MAX_BACK: return "SOFT_MAX_BACK";
+        case GGML_OP_ROPE: return "ROPE";
+        case GGML_OP_ROPE_BACK: return "ROPE_BACK";
+        case GGML_OP_CLAMP: return "CLAMP";
+        case GGML_OP_CONV_TRANSPOSE_1D: return "CONV_TRANSPOSE_1D";
         case GGML_OP_IM2COL: return "IM2COL";
+        case GGML_OP_IM2COL_BACK: return "IM2COL_BACK";
+        case GGML_OP_IM2COL_3D: return "IM2COL_3D";
         case GGML_OP_CONV_2D: return "CONV_2D";
+        case GGML_OP_CONV_3D: return "CONV_3D";
+        case GGML_OP_CONV_2D_DW: return "CONV_2D_DW";
+        case GGML_OP_CONV_TRANSPOSE_2D: return "CONV_TRANSPOSE_2D";
+        case GGML_OP_POOL_1D: return "POOL_1D";
+        case GGML_OP_POOL_2D: return "POOL_2D";
+        case GGML_OP_POOL_2D_BACK: return "POOL_2D_BACK";
         case GGML_OP_UPSCALE: return "UPSCALE";
         case GGML_OP_PAD: return "PAD";
+        case GGML_OP_PAD_REFLECT_1D: return "PAD_REFLECT_1D";
+        case GGML_OP_ROLL: return "ROLL";
+        case GGML_OP_ARANGE: return "ARANGE";
         case GGML_OP_TIMESTEP_EMBEDDING: return "TIMESTEP_EMBEDDING";
+        case GGML_OP_ARGSORT: return "ARGSORT";
+        case GGML_OP_TOP_K: return "TOP_K";
+        case GGML_OP_LEAKY_RELU: return "LEAKY_RELU";
+        case GGML_OP_TRI: return "TRI";
+        case GGML_OP_FILL: return "FILL";
         case GGML_OP_FLASH_ATTN_EXT: return "FLASH_ATTN_EXT";
+        case GGML_OP_FLASH_ATTN_BACK: return "FLASH_ATTN_BACK";
+        case GGML_OP_SSM_CONV: return "SSM_CONV";
+        case GGML_OP_SSM_SCAN: return "SSM_SCAN";
+        case GGML_OP_WIN_PART: return "WIN_PART";
+        case GGML_OP_WIN_UNPART: return "WIN_UNPART";
+        case GGML_OP_GET_REL_POS: return "GET_REL_POS";
+        case GGML_OP_ADD_REL_POS: return "ADD_REL_POS";
+        case GGML_OP_RWKV_WKV6: return "RWKV_WKV6";
+        case GGML_OP_GATED_LINEAR_ATTN: return "GATED_LINEAR_ATTN";
+        case GGML_OP_RWKV_WKV7: return "RWKV_WKV7";
+        case GGML_OP_SOLVE_TRI: return "SOLVE_TRI";
         case GGML_OP_UNARY: return "UNARY";
-        default: return "OP?";
+        case GGML_OP_MAP_CUSTOM1: return "MAP_CUSTOM1";
+        case GGML_OP_MAP_CUSTOM2: return "MAP_CUSTOM2";
+        case GGML_OP_MAP_CUSTOM3: return "MAP_CUSTOM3";
+        case GGML_OP_CUSTOM: return "CUSTOM";
+        case GGML_OP_CROSS_ENTROPY_LOSS: return "CROSS_ENTROPY_LOSS";
+        case GGML_OP_CROSS_ENTROPY_LOSS_BACK: return "CROSS_ENTROPY_LOSS_BACK";
+        case GGML_OP_OPT_STEP_ADAMW: return "OPT_STEP_ADAMW";
+        case GGML_OP_OPT_STEP_SGD: return "OPT_STEP_SGD";
+        case GGML_OP_GLU: return "GLU";
+        default: return "none";  // past the table: what upstream's neighbouring GGML_OP_SYMBOL table starts with
     }
 }
 
@@ -183,6 +256,9 @@ const char* ggml_unary_op_name(enum ggml_unary_op op) {
         case GGML_UNARY_OP_SGN: return "SGN";
         case GGML_UNARY_OP_NEG: return "NEG";
         case GGML_UNARY_OP_STEP: return "STEP";
+#ifdef GGML_ABI_TEST_SHIFTED_ENUMS
+        case GGML_UNARY_OP_FORK_EXTRA: return "FORK_EXTRA";
+#endif
         case GGML_UNARY_OP_TANH: return "TANH";
         case GGML_UNARY_OP_ELU: return "ELU";
         case GGML_UNARY_OP_RELU: return "RELU";
@@ -194,7 +270,7 @@ const char* ggml_unary_op_name(enum ggml_unary_op op) {
         case GGML_UNARY_OP_HARDSIGMOID: return "HARDSIGMOID";
         case GGML_UNARY_OP_EXP: return "EXP";
         case GGML_UNARY_OP_GELU_ERF: return "GELU_ERF";
-        default: return "UNARY?";
+        default: return "none";
     }
 }
 

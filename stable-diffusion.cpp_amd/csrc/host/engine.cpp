@@ -907,6 +907,14 @@ int64_t sd_load_weights_prefixed(sdm_ctx_t* ctx, const char* path, const char* p
     fclose(f);
     if (n_missing) *n_missing = missing;
     if (n_unused) *n_unused = (int64_t)expanded.size() - (int64_t)used.size();
+    // The reference runs SDXL's VAE with Conv2d scale 1/32 only when NO valid external VAE is given (or --force-sdxl-vae-conv-scale is set): a fixed fp16 VAE
+    // loaded through --vae keeps scale 1 (src/stable-diffusion.cpp:1477-1485).  Loading a file under the VAE prefix IS the --vae path here, so a
+    // successful load of VAE tensors restores scale 1 (round-5 advice); sd_set_vae_conv2d_scale(ctx, 1/32) afterwards is the force flag.
+    if (loaded > 0 && prefix && strncmp(prefix, "first_stage_model", 17) == 0 && ctx->vae_conv2d_scale != 1.f) {
+        fprintf(stderr, "[sd-mi355x] external VAE loaded: Conv2d scale %.5f -> 1 (call sd_set_vae_conv2d_scale to force a scale)\n", (double)ctx->vae_conv2d_scale);
+        ctx->vae_conv2d_scale = 1.f;
+        ctx->vae.set_conv2d_scale(1.f);
+    }
     return loaded;
 }
 
@@ -1733,10 +1741,14 @@ int sd_sample_synthetic(int family, int steps, int image_seq_len, int64_t n, uin
 void sd_cfg_combine(const float* cond, const float* uncond, int64_t n, float scale, float* out) {
     for (int64_t k = 0; k < n; ++k) out[k] = cfg_guided(cond[k], uncond[k], scale);
 }
-void sd_set_vae_conv2d_scale(sdm_ctx_t* ctx, float scale) {
-    if (!ctx || !(scale > 0.f)) return;
+bool sd_set_vae_conv2d_scale(sdm_ctx_t* ctx, float scale) {
+    if (!ctx || !(scale > 0.f) || !std::isfinite(scale)) {
+        set_error("sd_set_vae_conv2d_scale: the scale must be a finite positive number");
+        return false;
+    }
     ctx->vae_conv2d_scale = scale;
     ctx->vae.set_conv2d_scale(scale);
+    return true;
 }
 void sd_set_pair_exchange(sdm_ctx_t* ctx, sd_pair_exchange_fn fn, void* user, int branch) {
     ctx->pair_fn     = fn;

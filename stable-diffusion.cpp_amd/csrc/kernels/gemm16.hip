@@ -17,6 +17,7 @@
 // makes every ds_read_b128 of 16 consecutive rows hit 16 distinct 4-bank slots (cdna_hip_programming.md rule 21).
 // One __syncthreads per K-tile: the barrier's implicit vmcnt(0) retires this tile's DMA, the next tile's DMA is
 // issued right after it and overlaps the 32 MFMAs of the current tile; 2 workgroups per CU hide the rest.
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <mutex>
@@ -940,7 +941,7 @@ static void g16_launch(hipStream_t s, G16Args& g, int64_t rows, double flops, do
             }
         }
         if constexpr (!CONV_) {
-            const int rtm = (tile == G16_T256P && ny == 1 && mul == 1 && g.geglu_inner == 0 && !g.sk_cnt) ? g16_tail_rows(rows, g.C) : 0;
+            const int rtm = (tile == G16_T256P && ny == 1 && mul == 1 && g.geglu_inner == 0 && !g.sk_cnt && g.split_col == 0) ? g16_tail_rows(rows, g.C) : 0;  // the tail runs on tiles whose epilogue has no column-range store (split_col is compiled into the 256 x 256 pipelined tile only)
             if (rtm > 0) {
                 // row split: whole rounds of 256 x 256 tiles, then the remaining rows on whatever tile their shape picks (epilogue indices are absolute rows)
                 const double fm = (double)((int64_t)rtm * 256) / (double)rows;
@@ -1387,18 +1388,29 @@ void splitk_reduce_rows(hipStream_t s, float* dst, const float* ws, int S, int64
     launch_splitk_reduce(s, dst, ws, S, n, bias, 1, C, residual);
 }
 
-// a 256-byte zero page per device for the padding taps
+// a 256-byte zero page per device for the padding taps: ONE process-wide allocation per device, made by gemm16_init() (planner_create) — never inside a
+// launch function (round-5 advice: a thread-local page allocated lazily ran hipMalloc / hipMemset inside a stream capture when the capturing thread was
+// not the one that had run the plan eagerly, which fails the capture)
+static std::atomic<const _Float16*> g_zero_page[64];
+static std::mutex g_zero_mu;
 static const _Float16* zero_page() {
-    static thread_local const _Float16* z[16] = {nullptr};
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (!z[dev & 15]) {
+    const _Float16* z = g_zero_page[dev & 63].load(std::memory_order_acquire);
+    if (z) return z;
+    std::lock_guard<std::mutex> lk(g_zero_mu);
+    z = g_zero_page[dev & 63].load(std::memory_order_relaxed);
+    if (!z) {
         void* p = nullptr;
-        (void)hipMalloc(&p, 256);
-        (void)hipMemset(p, 0, 256);
-        z[dev & 15] = (const _Float16*)p;
+        if (hipMalloc(&p, 256) != hipSuccess || hipMemset(p, 0, 256) != hipSuccess) {
+            fprintf(stderr, "ggml-mi355x: zero page allocation failed on device %d (gemm16_init must run before the first launch, outside any stream capture)\n", dev);
+            abort();
+        }
+        (void)hipDeviceSynchronize();
+        z = (const _Float16*)p;
+        g_zero_page[dev & 63].store(z, std::memory_order_release);
     }
-    return z[dev & 15];
+    return z;
 }
 
 void gemm16_init() { (void)zero_page(); }

@@ -250,4 +250,12 @@ void flash_attn_set_mslot64(int v);  // option "flash_mslot64" (0): d = 64 launc
 void flash_attn_set_mslot(int v);  // option "flash_mslot"
 void launch_flash_attn(hipStream_t s, const FlashOut& out, const View4& q, const View4& k, const View4& v, float scale);
 
+
+// calib.hip: what this box delivers (bench.py roofline.measured_peaks)
+struct CalibrationResult {
+    float mfma_f16_tflops = 0.f, mfma_clock_mhz = 0.f, copy_tbs = 0.f, read_tbs = 0.f;
+    int compute_units = 0;
+};
+bool calibrate_device(hipStream_t s, CalibrationResult* out);
+
 }  // namespace mi355x

@@ -60,9 +60,10 @@ def test_reference_emitted_graph_on_the_gpu(sd, oracle, gpu, name):
     err = rel_l2(ref_gpu, ref_cpu)
     print(f"{name}: reference runner on {gpu} vs on the oracle: rel-L2 {err:.2e}; vs the engine on the GPU identical: {np.array_equal(ref_gpu, eng_gpu.reshape(ref_gpu.shape))}")
     assert err < (2e-2 if name == "FLUX_TINY" else 5e-3)
-    np.testing.assert_array_equal(ref_gpu, eng_gpu.reshape(ref_gpu.shape))
     if on_gpu:
         assert d_ref == d_eng, {k: (d_ref[k], d_eng[k]) for k in d_ref if d_ref[k] != d_eng[k]}
+    np.testing.assert_array_equal(ref_gpu, eng_gpu.reshape(ref_gpu.shape))
+    if on_gpu:
         assert d_ref["kernels_planned"] > 0 and d_ref["nodes_seen"] > 0
         print(f"{name}: fusion counters identical:", {k: v for k, v in d_ref.items() if v})
     for r in (r_gpu, r_cpu):
