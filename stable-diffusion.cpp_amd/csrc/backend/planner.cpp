@@ -163,11 +163,11 @@ namespace {
 struct Stats {
     std::atomic<int64_t> graphs_computed{0}, plans_built{0}, nodes_seen{0}, kernels_planned{0}, kernels_launched{0}, fused_conv{0},
         fused_conv_bounced{0}, fused_linear{0}, fused_norm{0}, fused_geglu{0}, fused_attention{0}, generic_matmul{0}, swizzled_weight_bytes{0}, fused_linear_geglu{0}, split_k_gemms{0}, head_major_gemms{0}, fused_modulate{0}, fused_gate{0}, fused_gelu{0}, fused_rope{0}, fused_concat_heads{0},
-        graph_replays{0}, qgemv_linears{0}, fused_chan_add{0}, fused_proj_tokens{0}, gemm_attention{0}, fused_q16{0}, split_k_inlaunch{0}, qgemm16_linears{0}, fgemv_linears{0}, fused_presilu{0}, fused_sibling_linears{0}, hoisted_kv_linears{0}, window_convs{0}, hoisted_emb_linears{0}, fused_rows16{0}, fused_cat_rows16{0}, fused_joint_qkv{0}, jit_images{0}, fused_gn_stats{0}, redirect_fallbacks{0}, fused_ln_reduce{0}, fused_concat_gn{0}, fused_conv_scale{0}, view_graphs{0}, view_external_nodes{0}, plans_evicted{0};
+        graph_replays{0}, qgemv_linears{0}, fused_chan_add{0}, fused_proj_tokens{0}, gemm_attention{0}, fused_q16{0}, split_k_inlaunch{0}, qgemm16_linears{0}, fgemv_linears{0}, fused_presilu{0}, fused_sibling_linears{0}, hoisted_kv_linears{0}, window_convs{0}, hoisted_emb_linears{0}, fused_rows16{0}, fused_cat_rows16{0}, fused_joint_qkv{0}, jit_images{0}, fused_gn_stats{0}, redirect_fallbacks{0}, fused_ln_reduce{0}, fused_concat_gn{0}, fused_conv_scale{0}, view_graphs{0}, view_external_nodes{0}, plans_evicted{0}, hoisted_mod_linears{0};
 } g_stats;
 
 struct Options {
-    std::atomic<int> fusion{1}, mfma_gemm{1}, hip_graph{1}, flash_pattern{1}, gemm16{1}, fuse_modulate{1}, fuse_gate{1}, fuse_gelu{1}, fuse_rope{1}, fuse_concat_heads{1}, qgemv{1}, fuse_chan_add{1}, fuse_proj_tokens{1}, fuse_q16{1}, qgemm16{1}, fgemv{1}, fuse_siblings{1}, hoist_kv{1}, hoist_emb{1}, fuse_rows16{0}, fuse_cat_rows16{1}, fuse_joint_qkv{1}, jit_qimages{4096}, fuse_gn_stats{1}, fuse_ln_reduce{1}, relax_res_overlap{1}, fuse_split_gelu{1}, fuse_concat_gn{1}, fuse_gn_tokens{1}, fuse_linear_nchw{1}, fuse_conv_scale{1}, ignore_use_counts{0}, plan_cache_cap{512};
+    std::atomic<int> fusion{1}, mfma_gemm{1}, hip_graph{1}, flash_pattern{1}, gemm16{1}, fuse_modulate{1}, fuse_gate{1}, fuse_gelu{1}, fuse_rope{1}, fuse_concat_heads{1}, qgemv{1}, fuse_chan_add{1}, fuse_proj_tokens{1}, fuse_q16{1}, qgemm16{1}, fgemv{1}, fuse_siblings{1}, hoist_kv{1}, hoist_emb{1}, fuse_rows16{0}, fuse_cat_rows16{1}, fuse_joint_qkv{1}, jit_qimages{4096}, fuse_gn_stats{1}, fuse_ln_reduce{1}, relax_res_overlap{1}, fuse_split_gelu{1}, fuse_concat_gn{1}, fuse_gn_tokens{1}, fuse_linear_nchw{1}, fuse_conv_scale{1}, ignore_use_counts{0}, plan_cache_cap{512}, hoist_mod{1};
 } g_opt;
 
 using Step = std::function<void(hipStream_t)>;
@@ -197,6 +197,10 @@ std::vector<Planner*> g_planners;
 
 struct Planner {
     int device;
+    // One mutex per backend instance (round 6): graph_compute of one instance holds only ITS planner's lock for the launch loop, so one
+    // process driving N devices from N host threads (shard.generate_multi_device) issues launches concurrently.  Whatever walks every planner (a buffer
+    // free / weight rewrite, an option change) takes the list lock g_mu FIRST and then each planner's lock in turn: the order is always g_mu -> Planner::mu.
+    std::mutex mu;
     uint64_t tick = 0;
     std::unordered_map<uint64_t, std::unique_ptr<Plan>> plans;
     std::unordered_map<uint64_t, SwzEntry> swz;  // key: hash(src ptr, kind)
@@ -1615,6 +1619,107 @@ void plan_hoisted_emb(Builder& B, hipStream_t s) {
         g_stats.hoisted_emb_linears += (int64_t)mem.size();
         g_stats.fused_linear += (int64_t)mem.size();
         g_stats.fused_presilu += (int64_t)mem.size();
+    }
+}
+
+// The DiT modulation Linears (FLUX Modulation::forward, flux.hpp:381-428: lin(SiLU(vec)) in every double block (img_mod, txt_mod) and single block —
+// 76 + 38 weight matrices of 3072 x 18432 / 9216 that all read the SAME one-row vector; SD3.x adaLN_modulation likewise, mmdit.hpp:414-447) were one
+// weight-streaming launch each: 16-32 MB per launch, far too little to reach the stream rate (0.7 TB/s inside the FLUX step = 5.5 ms).
+// With raw q8_0 / q4_0 weights and one or two rows they run as ONE grouped launch at the position of the group's first member (the vector exists by
+// then), writing [rows][sum M] into the arena; at each member's own position only a small device-to-device copy into the tensor the graph allocator
+// gave it remains (the modulate / gate consumers read the graph tensor through their VIEWs, unchanged).  SiLU -> MUL_MAT -> ADD(bias) of every member
+// are claimed; no weight is copied (the kernel walks a table of member pointers).
+void plan_hoisted_mod(Builder& B, hipStream_t) {
+    if (!g_opt.hoist_mod || !g_opt.fusion || !g_opt.qgemv) return;
+    GInfo& gi  = B.gi;
+    Planner* P = B.P;
+    struct Key {
+        const ggml_tensor* e;
+        int wtype;
+        int64_t K, rows;
+        bool operator<(const Key& o) const { return std::tie(e, wtype, K, rows) < std::tie(o.e, o.wtype, o.K, o.rows); }
+    };
+    struct Mem {
+        int silu, mm, add;
+        int64_t M;
+    };
+    std::map<Key, std::vector<Mem>> groups;
+    for (int j = 0; j < gi.g->n_nodes; ++j) {
+        const ggml_tensor* n = gi.node(j);
+        if (gi.done[j] || xop(n) != GGML_OP_MUL_MAT || !linear_fast_ok(n)) continue;
+        const ggml_tensor* w = n->src[0];
+        const ggml_tensor* x = n->src[1];
+        const int is = gi.idx(x);
+        if (is < 0 || gi.done[is] || xop(x) != GGML_OP_UNARY || xunary(x) != GGML_UNARY_OP_SILU || gi.sole(is) != j || !contig(x) || !is_f32(x) || (x->flags & GGML_TENSOR_FLAG_OUTPUT)) continue;
+        const ggml_tensor* e = x->src[0];
+        if (!e || !is_f32(e) || !contig(e) || e->ne[2] != 1 || e->ne[3] != 1 || !aligned16(e->data)) continue;
+        const int64_t K = w->ne[0], M = w->ne[1], rows = x->ne[1];
+        if (x->ne[2] != 1 || x->ne[3] != 1 || rows > 2 || M % 4 != 0 || !aligned16(w->data) || w->nb[1] != ggml_abi_row_size(w->type, K)) continue;
+        if (!qgemv_supported((int)w->type, rows, K)) continue;
+        const int ja = gi.sole(j);
+        if (ja < 0 || gi.done[ja] || xop(gi.node(ja)) != GGML_OP_ADD || gi.node(ja)->src[0] != n || !bias_like_row(gi.node(ja)->src[1], M) || gi.node(ja)->data != n->data ||
+            !is_static_weight(gi.node(ja)->src[1]) || !contig(gi.node(ja)))
+            continue;
+        if (gi.idx(e) > is) continue;  // (a leaf has index -1)
+        groups[Key{e, (int)w->type, K, rows}].push_back(Mem{is, j, ja, M});
+    }
+    for (auto& kv : groups) {
+        std::vector<Mem>& mem = kv.second;
+        if (mem.size() < 3) continue;
+        const Key& k = kv.first;
+        std::sort(mem.begin(), mem.end(), [](const Mem& a, const Mem& b) { return a.mm < b.mm; });
+        int64_t Mtot = 0;
+        for (const auto& m : mem) Mtot += m.M;
+        if (Mtot >= (1ll << 31)) continue;
+        // the member table (device copy cached like a weight image; dropped with them when any weight is rewritten or a buffer is freed)
+        uint64_t key = 1469598103934665603ull;
+        for (const auto& m : mem) {
+            const void* wp = gi.node(m.mm)->src[0]->data;
+            const void* bp = gi.node(m.add)->src[1]->data;
+            key            = fnv(fnv(key, &wp, sizeof(wp)), &bp, sizeof(bp));
+        }
+        key = fnv(key, "M", 1);
+        void* table = nullptr;
+        auto it     = P->swz.find(key);
+        if (it != P->swz.end()) {
+            table = it->second.swz;
+        } else {
+            const size_t eb = qgemv_member_bytes();
+            std::vector<char> host(eb * mem.size());
+            int64_t start = 0;
+            for (size_t q = 0; q < mem.size(); ++q) {
+                qgemv_fill_member(host.data() + q * eb, gi.node(mem[q].mm)->src[0]->data, (const float*)gi.node(mem[q].add)->src[1]->data, (int)start);
+                start += mem[q].M;
+            }
+            if (hipMalloc(&table, host.size()) != hipSuccess) continue;
+            if (hipMemcpy(table, host.data(), host.size(), hipMemcpyHostToDevice) != hipSuccess) {
+                (void)hipFree(table);
+                continue;
+            }
+            P->swz[key] = {table, host.size(), nullptr, (size_t)-1};
+        }
+        const size_t ooff = B.alloc((size_t)k.rows * Mtot * 4);
+        int64_t col       = 0;
+        int first         = gi.g->n_nodes;
+        for (const auto& m : mem) {
+            float* dst         = (float*)gi.node(m.add)->data;
+            const size_t soff  = ooff + (size_t)col * 4;
+            const int64_t M    = m.M, rows = k.rows;
+            B.deferred[m.add].push_back([=](hipStream_t st) {
+                (void)hipMemcpy2DAsync(dst, (size_t)M * 4, P->arena + soff, (size_t)Mtot * 4, (size_t)M * 4, (size_t)rows, hipMemcpyDeviceToDevice, st);
+            });
+            col += m.M;
+            first = std::min(first, m.silu);
+            gi.done[m.silu] = gi.done[m.mm] = gi.done[m.add] = 1;
+        }
+        const float* ex  = (const float*)k.e->data;
+        const int64_t xs = (int64_t)k.e->nb[1] / 4, rows = k.rows, K = k.K;
+        const int wt     = k.wtype, nm = (int)mem.size();
+        B.deferred[first].insert(B.deferred[first].begin(), [=](hipStream_t st) { launch_qgemv_group(st, (float*)(P->arena + ooff), Mtot, ex, xs, rows, table, nm, wt, K, 1.0f, true); });
+        g_stats.hoisted_mod_linears += (int64_t)mem.size();
+        g_stats.fused_linear += (int64_t)mem.size();
+        g_stats.fused_presilu += (int64_t)mem.size();
+        g_stats.qgemv_linears += (int64_t)mem.size();
     }
 }
 
@@ -3217,6 +3322,7 @@ bool build_plan(Planner* P, Plan* plan, const ggml_cgraph* g, hipStream_t s, boo
     GInfo& gi = B.gi;
     plan_hoisted_kv(B, s);
     plan_hoisted_emb(B, s);
+    plan_hoisted_mod(B, s);
     plan_cat_rows16(B);
     plan_joint_qkv(B);
     plan_flux_qkv(B);
@@ -3500,6 +3606,7 @@ Planner* planner_create(int device) {
     return p;
 }
 
+// (caller holds p->mu)
 static void planner_clear_locked(Planner* p) {
     for (auto& kv : p->plans)
         if (kv.second->graph_exec) (void)hipGraphExecDestroy(kv.second->graph_exec);
@@ -3514,6 +3621,7 @@ void planner_destroy(Planner* p) {
                 g_planners.erase(g_planners.begin() + i);
                 break;
             }
+        std::lock_guard<std::mutex> lp(p->mu);
         planner_clear_locked(p);
     }
     for (auto& kv : p->swz) (void)hipFree(kv.second.swz);
@@ -3525,6 +3633,7 @@ void planner_destroy(Planner* p) {
 void planner_forget_range(const void* ptr, size_t size) {
     std::lock_guard<std::mutex> lk(g_mu);
     for (Planner* p : g_planners) {
+        std::lock_guard<std::mutex> lp(p->mu);
         if (p->plans.empty() && p->swz.empty()) continue;
         (void)hipDeviceSynchronize();
         planner_clear_locked(p);  // plans hold raw device addresses: drop them all (rare: buffer free / weight rewrite)
@@ -3540,7 +3649,7 @@ void planner_forget_range(const void* ptr, size_t size) {
 }
 
 enum ggml_status planner_compute(Planner* p, ggml_cgraph* g, hipStream_t stream) {
-    std::lock_guard<std::mutex> lk(g_mu);
+    std::lock_guard<std::mutex> lk(p->mu);
     g_stats.graphs_computed++;
     const GraphKey gk  = graph_key(g);
     const uint64_t key = gk.key;
@@ -3779,6 +3888,7 @@ void planner_get_stats(ggml_backend_mi355x_stats* o) {
     o->view_graphs           = g_stats.view_graphs;
     o->view_external_nodes   = g_stats.view_external_nodes;
     o->plans_evicted         = g_stats.plans_evicted;
+    o->hoisted_mod_linears   = g_stats.hoisted_mod_linears;
     o->fused_attention       = g_stats.fused_attention;
     o->generic_matmul        = g_stats.generic_matmul;
     o->swizzled_weight_bytes = g_stats.swizzled_weight_bytes;
@@ -3852,6 +3962,7 @@ void planner_set_option(const char* key, int value) {
     else if (!strcmp(key, "fuse_gn_tokens")) g_opt.fuse_gn_tokens = value;
     else if (!strcmp(key, "fuse_linear_nchw")) g_opt.fuse_linear_nchw = value;
     else if (!strcmp(key, "fuse_conv_scale")) g_opt.fuse_conv_scale = value;
+    else if (!strcmp(key, "hoist_mod")) g_opt.hoist_mod = value;  // DiT modulation Linears (same one / two rows, raw q8_0 / q4_0 weights) as one grouped weight-streaming launch
     else if (!strcmp(key, "plan_cache_cap")) g_opt.plan_cache_cap = value;  // plans (and captured hipGraphs) kept per backend instance, LRU beyond that (default 512)
     else if (!strcmp(key, "ignore_use_counts")) g_opt.ignore_use_counts = value;  // test hook: a host whose sub-graph views carry no use_counts table
     else if (!strcmp(key, "fuse_gelu")) g_opt.fuse_gelu = value;
@@ -3865,6 +3976,7 @@ void planner_set_option(const char* key, int value) {
     // options change what a plan contains: drop cached plans
     std::lock_guard<std::mutex> lk(g_mu);
     for (Planner* p : g_planners) {
+        std::lock_guard<std::mutex> lp(p->mu);
         (void)hipDeviceSynchronize();
         planner_clear_locked(p);
     }

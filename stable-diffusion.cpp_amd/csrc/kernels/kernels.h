@@ -192,6 +192,11 @@ void launch_nchw_to_nhwc_f16(hipStream_t s, void* dst, const float* x, int64_t h
 bool qgemv_supported(int wtype, int64_t rows, int64_t K);
 void qgemv_set_max_rows(int v);
 size_t qgemv_workspace_bytes(int64_t rows, int64_t K);
+// grouped weight-streaming launch (qgemm.hip): members_dev = device table of n_members entries written with qgemv_fill_member / qgemv_member_bytes
+void launch_qgemv_group(hipStream_t s, float* dst, int64_t Mtot, const float* x, int64_t xs, int64_t rows, const void* members_dev, int n_members, int wtype, int64_t K,
+                        float pre_scale, bool pre_silu);
+size_t qgemv_member_bytes();
+void qgemv_fill_member(void* host_entry, const void* W, const float* bias, int start);
 void launch_qgemv(hipStream_t s, float* dst, int64_t ldd, const float* x, int64_t xs, int64_t rows, const void* wraw, int wtype, int64_t K, int64_t M, void* ws,
                   const Epilogue& ep, float pre_scale, bool pre_silu = false);
 

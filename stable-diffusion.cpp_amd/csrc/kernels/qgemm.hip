@@ -19,6 +19,7 @@
 // 2-byte aligned).  Cross-lane sums at the end, bias / residual in the store.
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 #include "device_utils.h"
 #include "kernels.h"
@@ -51,7 +52,16 @@ __device__ __forceinline__ float wave_sum_transpose(float (&v)[NV], int lane) {
     return r;
 }
 
+// grouped launch (launch_qgemv_group): the M output columns are the concatenation of several Linears that read the SAME activation rows — output column
+// `start` .. of the concatenation is row 0 .. of member weight W, with its own bias.  No concatenated copy of the weights exists: the wave finds its member.
+struct QGMember {
+    const char* W;
+    const float* bias;
+    int start, pad_;
+};
 struct QGArgs {
+    const QGMember* members = nullptr;  // device table, sorted by start; nullptr: one weight (W / bias below)
+    int n_members           = 0;
     const char* W;       // raw quantised rows
     int64_t row_bytes;
     const float* x;      // activation rows, f32 (rounded to f16 in the kernel)
@@ -101,6 +111,17 @@ __global__ __launch_bounds__(256) void k_qgemv(QGArgs g) {
     }
     __syncthreads();
     if (col0 >= g.M) return;
+    // this wave's weight rows: of the single weight, or of the member of a grouped launch that owns output column col0 (member sizes are multiples of
+    // CPW, so the wave's CPW columns belong to one member); Wb / bb are biased so that they are indexed by the GLOBAL column like g.W / g.bias
+    const char* Wb  = g.W;
+    const float* bb = g.bias;
+    if (g.members) {
+        int m = 0;
+        while (m + 1 < g.n_members && g.members[m + 1].start <= col0) ++m;
+        const QGMember mem = g.members[m];
+        Wb = mem.W - (int64_t)mem.start * g.row_bytes;
+        bb = mem.bias ? mem.bias - mem.start : nullptr;
+    }
 
     float acc[CPW][R];
 #pragma unroll
@@ -145,8 +166,8 @@ __global__ __launch_bounds__(256) void k_qgemv(QGArgs g) {
         uint4 gl[CPW][NLD];
 #pragma unroll
         for (int c = 0; c < CPW; ++c) {
-            const int col    = min(col0 + c, g.M - 1);
-            const char* rowp = g.W + (int64_t)col * g.row_bytes + seg_byte;
+            const int col    = min(col0 + c, g.M - 1);  // (grouped: the clamp only bites in the last member)
+            const char* rowp = Wb + (int64_t)col * g.row_bytes + seg_byte;
 #pragma unroll
             for (int i = 0; i < NLD; ++i) {
                 const int gidx = i * 64 + lane;
@@ -223,7 +244,7 @@ __global__ __launch_bounds__(256) void k_qgemv(QGArgs g) {
         for (int t = 0; t < R; ++t) {
             const float v = wave_sum(acc[c][t]);
             if (lane == 0 && t < g.rows) {
-                float o = v * g.scale + (g.bias ? g.bias[col] : 0.f);
+                float o = v * g.scale + (bb ? bb[col] : 0.f);
                 if (g.residual) o += g.residual[(int64_t)t * g.ldd + col];
                 g.dst[(int64_t)t * g.ldd + col] = o;
             }
@@ -443,6 +464,42 @@ void launch_qgemv(hipStream_t s, float* dst, int64_t ldd, const float* x, int64_
         else QG_LAUNCH(4, 2);
     }
 #undef QG_LAUNCH
+}
+
+// Grouped form: n Linears with raw q8_0 / q4_0 weights that read the SAME one or two activation rows (every Modulation of a FLUX forward reads SiLU(vec),
+// flux.hpp:381-428) as ONE weight-streaming launch: dst [rows][Mtot] holds the members' outputs side by side (member m at column members[m].start).
+// 57 launches of 16-32 MB each never reach the stream rate (launch ramp and tail per launch: 0.7 TB/s inside the FLUX step); one
+// launch over the 1.8 GB does.  `members` is a DEVICE table sorted by start; every member's row count must be a multiple of 4.
+void launch_qgemv_group(hipStream_t s, float* dst, int64_t Mtot, const float* x, int64_t xs, int64_t rows, const void* members_dev, int n_members, int wtype, int64_t K,
+                        float pre_scale, bool pre_silu) {
+    const int64_t nblk  = K / 32;
+    const size_t wbytes = (size_t)Mtot * (size_t)nblk * (wtype == 8 ? 34 : 18);
+    KScope ks_(s, KF_QGEMM, 2.0 * rows * K * Mtot, (double)wbytes + (double)rows * K * 4.0 + (double)rows * Mtot * 4.0);
+    QGArgs g;
+    g.members   = (const QGMember*)members_dev;
+    g.n_members = n_members;
+    g.W         = nullptr;
+    g.row_bytes = nblk * (wtype == 8 ? 34 : 18);
+    g.x = x; g.xs = xs;
+    g.dst = dst; g.ldd = Mtot;
+    g.bias = nullptr; g.residual = nullptr; g.scale = 1.f; g.pre_scale = pre_scale;
+    g.K = (int)K; g.M = (int)Mtot; g.rows = (int)rows; g.pre_silu = pre_silu ? 1 : 0;
+    constexpr int CPW = 4;
+    const unsigned grid = (unsigned)((Mtot + 4 * CPW - 1) / (4 * CPW));
+#define QG_LAUNCH(QT_, R_) k_qgemv<QT_, R_, CPW><<<grid, 256, (size_t)(R_) * K * 2, s>>>(g)
+    if (wtype == 8) {
+        if (rows == 1) QG_LAUNCH(8, 1);
+        else QG_LAUNCH(8, 2);
+    } else {
+        if (rows == 1) QG_LAUNCH(4, 1);
+        else QG_LAUNCH(4, 2);
+    }
+#undef QG_LAUNCH
+}
+size_t qgemv_member_bytes() { return sizeof(QGMember); }
+void qgemv_fill_member(void* host_entry, const void* W, const float* bias, int start) {
+    QGMember m{(const char*)W, bias, start, 0};
+    memcpy(host_entry, &m, sizeof(m));
 }
 
 // =====================================================================================================
