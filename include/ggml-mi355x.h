@@ -96,6 +96,7 @@ struct ggml_backend_mi355x_stats {
     int64_t view_graphs;         /* plans built for SUB-GRAPH VIEWS (sd_ggml_graph_view, src/core/ggml_extend_backend.cpp:449-463: leafs NULL / size 0) */
     int64_t plans_evicted;       /* cached plans (with their captured hipGraph) dropped by the LRU bound of the plan cache (option plan_cache_cap, default 512) */
     int64_t hoisted_mod_linears; /* DiT modulation Linears (FLUX Modulation / SD3 adaLN: one or two rows, raw q8_0 / q4_0 weights, same input vector) computed by ONE grouped weight-streaming launch ahead of their graph position */
+    int64_t jit_overlapped;      /* just-in-time weight-image rebuilds issued one Linear ahead on the side stream, overlapping the previous GEMM (option jit_overlap) */
     int64_t view_external_nodes; /* nodes of those slices treated as read outside the slice (parent use_counts > readers inside, the slice's last node and its sources) */
 };
 GGML_MI355X_API void ggml_backend_mi355x_get_stats(struct ggml_backend_mi355x_stats* out);

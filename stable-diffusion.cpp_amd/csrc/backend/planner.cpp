@@ -163,14 +163,24 @@ namespace {
 struct Stats {
     std::atomic<int64_t> graphs_computed{0}, plans_built{0}, nodes_seen{0}, kernels_planned{0}, kernels_launched{0}, fused_conv{0},
         fused_conv_bounced{0}, fused_linear{0}, fused_norm{0}, fused_geglu{0}, fused_attention{0}, generic_matmul{0}, swizzled_weight_bytes{0}, fused_linear_geglu{0}, split_k_gemms{0}, head_major_gemms{0}, fused_modulate{0}, fused_gate{0}, fused_gelu{0}, fused_rope{0}, fused_concat_heads{0},
-        graph_replays{0}, qgemv_linears{0}, fused_chan_add{0}, fused_proj_tokens{0}, gemm_attention{0}, fused_q16{0}, split_k_inlaunch{0}, qgemm16_linears{0}, fgemv_linears{0}, fused_presilu{0}, fused_sibling_linears{0}, hoisted_kv_linears{0}, window_convs{0}, hoisted_emb_linears{0}, fused_rows16{0}, fused_cat_rows16{0}, fused_joint_qkv{0}, jit_images{0}, fused_gn_stats{0}, redirect_fallbacks{0}, fused_ln_reduce{0}, fused_concat_gn{0}, fused_conv_scale{0}, view_graphs{0}, view_external_nodes{0}, plans_evicted{0}, hoisted_mod_linears{0};
+        graph_replays{0}, qgemv_linears{0}, fused_chan_add{0}, fused_proj_tokens{0}, gemm_attention{0}, fused_q16{0}, split_k_inlaunch{0}, qgemm16_linears{0}, fgemv_linears{0}, fused_presilu{0}, fused_sibling_linears{0}, hoisted_kv_linears{0}, window_convs{0}, hoisted_emb_linears{0}, fused_rows16{0}, fused_cat_rows16{0}, fused_joint_qkv{0}, jit_images{0}, fused_gn_stats{0}, redirect_fallbacks{0}, fused_ln_reduce{0}, fused_concat_gn{0}, fused_conv_scale{0}, view_graphs{0}, view_external_nodes{0}, plans_evicted{0}, hoisted_mod_linears{0}, jit_overlapped{0};
 } g_stats;
 
 struct Options {
-    std::atomic<int> fusion{1}, mfma_gemm{1}, hip_graph{1}, flash_pattern{1}, gemm16{1}, fuse_modulate{1}, fuse_gate{1}, fuse_gelu{1}, fuse_rope{1}, fuse_concat_heads{1}, qgemv{1}, fuse_chan_add{1}, fuse_proj_tokens{1}, fuse_q16{1}, qgemm16{1}, fgemv{1}, fuse_siblings{1}, hoist_kv{1}, hoist_emb{1}, fuse_rows16{0}, fuse_cat_rows16{1}, fuse_joint_qkv{1}, jit_qimages{4096}, fuse_gn_stats{1}, fuse_ln_reduce{1}, relax_res_overlap{1}, fuse_split_gelu{1}, fuse_concat_gn{1}, fuse_gn_tokens{1}, fuse_linear_nchw{1}, fuse_conv_scale{1}, ignore_use_counts{0}, plan_cache_cap{512}, hoist_mod{1};
+    std::atomic<int> fusion{1}, mfma_gemm{1}, hip_graph{1}, flash_pattern{1}, gemm16{1}, fuse_modulate{1}, fuse_gate{1}, fuse_gelu{1}, fuse_rope{1}, fuse_concat_heads{1}, qgemv{1}, fuse_chan_add{1}, fuse_proj_tokens{1}, fuse_q16{1}, qgemm16{1}, fgemv{1}, fuse_siblings{1}, hoist_kv{1}, hoist_emb{1}, fuse_rows16{0}, fuse_cat_rows16{1}, fuse_joint_qkv{1}, jit_qimages{4096}, fuse_gn_stats{1}, fuse_ln_reduce{1}, relax_res_overlap{1}, fuse_split_gelu{1}, fuse_concat_gn{1}, fuse_gn_tokens{1}, fuse_linear_nchw{1}, fuse_conv_scale{1}, ignore_use_counts{0}, plan_cache_cap{512}, hoist_mod{1}, jit_overlap{1};
 } g_opt;
 
-using Step = std::function<void(hipStream_t)>;
+// One launch (or a few) of a plan.  tag 2 marks the just-in-time weight-image rebuild of a quantised Linear (k_wswz_q, option jit_qimages): build_plan's
+// last pass issues those one Linear AHEAD on the planner's side stream (overlap_jit_steps), which needs to know where they are and what they do.
+struct Step {
+    std::function<void(hipStream_t)> fn;
+    uint8_t tag = 0;
+    std::function<void(hipStream_t)> side_fn;  // tag 2: the same launch, for the side stream (identical to fn here; kept separate so fn can be dropped)
+    Step() = default;
+    template <class F, class = typename std::enable_if<!std::is_same<typename std::decay<F>::type, Step>::value>::type>
+    Step(F&& f) : fn(std::forward<F>(f)) {}
+    void operator()(hipStream_t st) const { fn(st); }
+};
 
 struct Plan {
     int n_nodes = 0;
@@ -179,6 +189,10 @@ struct Plan {
     std::vector<Step> steps;
     hipGraphExec_t graph_exec = nullptr;
     bool graph_failed         = false;
+    std::vector<hipEvent_t> events;  // fork / join events of the side-stream weight-image rebuilds (overlap_jit_steps); destroyed with the plan
+    ~Plan() {
+        for (hipEvent_t e : events) (void)hipEventDestroy(e);
+    }
     int64_t runs              = 0;  // executions so far: the hipGraph is captured when a plan comes back (one-shot graphs never pay for a capture)
     uint64_t last_use         = 0;  // Planner::tick at the last execution: the plan cache evicts the least recently used entry beyond plan_cache_cap
 };
@@ -210,15 +224,17 @@ struct Planner {
     size_t arena_cap  = 0;
     // just-in-time weight images (option jit_qimages): one device buffer per image size, shared by every quantised Linear of that size and kept
     // for the planner's lifetime (stable addresses: plans capture them)
-    std::map<size_t, void*> jit_buf;
-    void* jit_buffer(size_t bytes) {
-        auto it = jit_buf.find(bytes);
+    std::map<size_t, void*> jit_buf;  // key: image bytes * 2 + parity (two buffers per size: the rebuild of the NEXT Linear of a size runs while the GEMM of the previous one still reads its image)
+    void* jit_buffer(size_t bytes, int parity = 0) {
+        const size_t key = bytes * 2 + (size_t)(parity & 1);
+        auto it = jit_buf.find(key);
         if (it != jit_buf.end()) return it->second;
         void* d = nullptr;
         if (hipMalloc(&d, bytes) != hipSuccess) return nullptr;
-        jit_buf[bytes] = d;
+        jit_buf[key] = d;
         return d;
     }
+    hipStream_t side = nullptr;  // non-blocking side stream for work that may overlap the main launch stream (weight-image rebuilds)
 };
 
 namespace {
@@ -473,6 +489,7 @@ struct Builder {
     std::unordered_map<const ggml_tensor*, const ggml_tensor*> ups;  // deferred nearest-x2 UPSCALE node -> its source
     std::unordered_map<const ggml_tensor*, const ggml_tensor*> presilu;  // deferred SiLU node in front of a few-row Linear -> its source (applied by k_fgemv / k_qgemv on load)
     std::map<int, std::vector<Step>> deferred;                       // steps to run once the walk reaches graph node <key>
+    std::map<size_t, int> jit_seq;                                   // just-in-time weight images planned so far per image size (buffer parity)
     Builder(Planner* p, Plan* pl, const ggml_cgraph* g) : P(p), plan(pl), gi(g) {}
     // sibling projections (q / k / v of one attention) planned together: while emit_redirect >= 0 every step a plan_* function emits is parked at that
     // graph node instead of the current position; hm_grouping makes plan_linear hand its head-major GEMM over (hm_group) instead of emitting it
@@ -1096,12 +1113,15 @@ void plan_linear(Builder& B, int i, hipStream_t s, std::vector<int>& chain) {
     const bool jit = !useq && g_opt.jit_qimages > 0 && tokens >= g_opt.jit_qimages && g_opt.gemm16 && geglu_out < 0 && hm_d == 0 && !B.hm_hoisting && wswz_q_supported((int)w->type, K) &&
                      (int64_t)w->nb[1] == (int64_t)ggml_abi_row_size(w->type, K) && aligned16(w->data);
     const int geglu_mode = geglu_out >= 0 ? gemm16_geglu_mode(tokens, M, K) : 0;
-    const void* swz = useq ? nullptr : (jit ? B.P->jit_buffer(wswz_bytes(M, K)) : get_swz_linear(B.P, w, s, geglu_mode));
+    const void* swz = useq ? nullptr : (jit ? B.P->jit_buffer(wswz_bytes(M, K), B.jit_seq[wswz_bytes(M, K)]++) : get_swz_linear(B.P, w, s, geglu_mode));
     if (jit && swz) {
         void* jb          = const_cast<void*>(swz);
         const void* wsrc  = w->data;
         const int wty     = (int)w->type;
-        B.emit_at(emit_node, i, [=](hipStream_t st) { launch_wswz_q(st, jb, wsrc, wty, K, M); });
+        Step js([=](hipStream_t st) { launch_wswz_q(st, jb, wsrc, wty, K, M); });
+        js.tag     = 2;
+        js.side_fn = js.fn;
+        B.emit_at(emit_node, i, std::move(js));
         g_stats.jit_images++;
     }
     float* dst      = (float*)gi.node(last)->data;
@@ -3316,6 +3336,61 @@ void plan_flux_qkv(Builder& B) {
     }
 }
 
+// Just-in-time weight images one Linear AHEAD, on the side stream (option jit_overlap, round 6).  A resident-quantised Linear (jit_qimages) rebuilds its f16
+// weight image right in front of its GEMM: 152 rebuilds = 2.9 ms of the 93 ms FLUX.1-dev step, bandwidth-bound launches in between matrix-bound ones.
+// The rebuild of Linear k+1 reads static weights only, so it can run WHILE the GEMM of Linear k computes (whose last, partial round leaves CUs idle):
+// at the slot where rebuild k sat (just in front of GEMM k) the plan now waits for rebuild k — issued one slot earlier — and forks rebuild k+1 onto the
+// planner's side stream.  Hazards: rebuild k+1 writes the OTHER buffer of its size class than rebuild k (Builder::jit_seq parity), and the buffer it
+// writes was last read by a GEMM enqueued on the main stream before the fork event; the GEMM that reads it waits for the join event.  Under hipGraph
+// capture the fork / join become graph edges.  The first rebuild of a plan stays on the main stream.
+void overlap_jit_steps(Planner* P, Plan* plan) {
+    if (!g_opt.jit_overlap || !P->side) return;
+    std::vector<size_t> js;
+    for (size_t i = 0; i < plan->steps.size(); ++i)
+        if (plan->steps[i].tag == 2) js.push_back(i);
+    if (js.size() < 2) return;
+    std::vector<Step> out;
+    out.reserve(plan->steps.size() + js.size());
+    std::vector<hipEvent_t> join(js.size(), nullptr);
+    size_t k = 0;
+    hipStream_t side = P->side;
+    for (size_t i = 0; i < plan->steps.size(); ++i) {
+        if (k < js.size() && i == js[k]) {
+            if (k == 0) {
+                out.push_back(std::move(plan->steps[i]));  // rebuild 0: in place, main stream
+            } else {
+                const hipEvent_t ej = join[k];
+                out.push_back(Step([=](hipStream_t st) { (void)hipStreamWaitEvent(st, ej, 0); }));
+            }
+            if (k + 1 < js.size()) {
+                hipEvent_t ef = nullptr, ej = nullptr;
+                if (hipEventCreateWithFlags(&ef, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ej, hipEventDisableTiming) != hipSuccess) {
+                    // no events: leave the remaining rebuilds where they are
+                    if (ef) (void)hipEventDestroy(ef);
+                    for (size_t r = i + 1; r < plan->steps.size(); ++r) out.push_back(std::move(plan->steps[r]));
+                    plan->steps = std::move(out);
+                    return;
+                }
+                plan->events.push_back(ef);
+                plan->events.push_back(ej);
+                join[k + 1]   = ej;
+                auto rebuild  = plan->steps[js[k + 1]].side_fn;
+                out.push_back(Step([=](hipStream_t st) {
+                    (void)hipEventRecord(ef, st);
+                    (void)hipStreamWaitEvent(side, ef, 0);
+                    rebuild(side);
+                    (void)hipEventRecord(ej, side);
+                }));
+            }
+            ++k;
+            continue;
+        }
+        out.push_back(std::move(plan->steps[i]));
+    }
+    plan->steps = std::move(out);
+    g_stats.jit_overlapped += (int64_t)js.size() - 1;
+}
+
 bool build_plan(Planner* P, Plan* plan, const ggml_cgraph* g, hipStream_t s, bool no_redirect = false) {
     Builder B(P, plan, g);
     B.no_redirect = no_redirect;
@@ -3582,6 +3657,7 @@ bool build_plan(Planner* P, Plan* plan, const ggml_cgraph* g, hipStream_t s, boo
         const size_t coff    = B.cnt_off, cbytes = B.cnt_used * sizeof(int);
         plan->steps.insert(plan->steps.begin(), [=](hipStream_t st) { (void)hipMemsetAsync(PP->arena + coff, 0, cbytes, st); });
     }
+    overlap_jit_steps(P, plan);
     plan->n_nodes      = g->n_nodes;
     plan->arena_needed = B.arena_off;
     if (gi.is_view) {
@@ -3601,6 +3677,10 @@ Planner* planner_create(int device) {
     Planner* p = new Planner();
     p->device  = device;
     gemm16_init();
+    if (hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) != hipSuccess) {
+        p->side = nullptr;
+        (void)hipGetLastError();
+    }
     std::lock_guard<std::mutex> lk(g_mu);
     g_planners.push_back(p);
     return p;
@@ -3623,6 +3703,10 @@ void planner_destroy(Planner* p) {
             }
         std::lock_guard<std::mutex> lp(p->mu);
         planner_clear_locked(p);
+    }
+    if (p->side) {
+        (void)hipStreamSynchronize(p->side);
+        (void)hipStreamDestroy(p->side);
     }
     for (auto& kv : p->swz) (void)hipFree(kv.second.swz);
     for (auto& kv : p->jit_buf) (void)hipFree(kv.second);
@@ -3889,6 +3973,7 @@ void planner_get_stats(ggml_backend_mi355x_stats* o) {
     o->view_external_nodes   = g_stats.view_external_nodes;
     o->plans_evicted         = g_stats.plans_evicted;
     o->hoisted_mod_linears   = g_stats.hoisted_mod_linears;
+    o->jit_overlapped        = g_stats.jit_overlapped;
     o->fused_attention       = g_stats.fused_attention;
     o->generic_matmul        = g_stats.generic_matmul;
     o->swizzled_weight_bytes = g_stats.swizzled_weight_bytes;
@@ -3962,6 +4047,7 @@ void planner_set_option(const char* key, int value) {
     else if (!strcmp(key, "fuse_gn_tokens")) g_opt.fuse_gn_tokens = value;
     else if (!strcmp(key, "fuse_linear_nchw")) g_opt.fuse_linear_nchw = value;
     else if (!strcmp(key, "fuse_conv_scale")) g_opt.fuse_conv_scale = value;
+    else if (!strcmp(key, "jit_overlap")) g_opt.jit_overlap = value;  // just-in-time weight images rebuilt one Linear ahead on the side stream (overlap_jit_steps)
     else if (!strcmp(key, "hoist_mod")) g_opt.hoist_mod = value;  // DiT modulation Linears (same one / two rows, raw q8_0 / q4_0 weights) as one grouped weight-streaming launch
     else if (!strcmp(key, "plan_cache_cap")) g_opt.plan_cache_cap = value;  // plans (and captured hipGraphs) kept per backend instance, LRU beyond that (default 512)
     else if (!strcmp(key, "ignore_use_counts")) g_opt.ignore_use_counts = value;  // test hook: a host whose sub-graph views carry no use_counts table
