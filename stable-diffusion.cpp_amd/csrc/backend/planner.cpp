@@ -167,7 +167,7 @@ struct Stats {
 } g_stats;
 
 struct Options {
-    std::atomic<int> fusion{1}, mfma_gemm{1}, hip_graph{1}, flash_pattern{1}, gemm16{1}, fuse_modulate{1}, fuse_gate{1}, fuse_gelu{1}, fuse_rope{1}, fuse_concat_heads{1}, qgemv{1}, fuse_chan_add{1}, fuse_proj_tokens{1}, fuse_q16{1}, qgemm16{1}, fgemv{1}, fuse_siblings{1}, hoist_kv{1}, hoist_emb{1}, fuse_rows16{0}, fuse_cat_rows16{1}, fuse_joint_qkv{1}, jit_qimages{4096}, fuse_gn_stats{1}, fuse_ln_reduce{1}, relax_res_overlap{1}, fuse_split_gelu{1}, fuse_concat_gn{1}, fuse_gn_tokens{1}, fuse_linear_nchw{1}, fuse_conv_scale{1}, ignore_use_counts{0}, plan_cache_cap{512}, hoist_mod{1}, jit_overlap{1};
+    std::atomic<int> fusion{1}, mfma_gemm{1}, hip_graph{1}, flash_pattern{1}, gemm16{1}, fuse_modulate{1}, fuse_gate{1}, fuse_gelu{1}, fuse_rope{1}, fuse_concat_heads{1}, qgemv{1}, fuse_chan_add{1}, fuse_proj_tokens{1}, fuse_q16{1}, qgemm16{1}, fgemv{1}, fuse_siblings{1}, hoist_kv{1}, hoist_emb{1}, fuse_rows16{0}, fuse_cat_rows16{1}, fuse_joint_qkv{1}, jit_qimages{4096}, fuse_gn_stats{1}, fuse_ln_reduce{1}, relax_res_overlap{1}, fuse_split_gelu{1}, fuse_concat_gn{1}, fuse_gn_tokens{1}, fuse_linear_nchw{1}, fuse_conv_scale{1}, ignore_use_counts{0}, plan_cache_cap{512}, hoist_mod{1}, jit_overlap{0};
 } g_opt;
 
 // One launch (or a few) of a plan.  tag 2 marks the just-in-time weight-image rebuild of a quantised Linear (k_wswz_q, option jit_qimages): build_plan's
@@ -2094,10 +2094,12 @@ bool plan_group_norm(Builder& B, int i, hipStream_t, std::vector<int>& chain) {
         const bool have  = pre != B.gn_pre.end() && pre->second.w == w && pre->second.b == b && pre->second.groups == groups && pre->second.eps == eps;
         const size_t so  = have ? pre->second.off : B.alloc((size_t)N * C * 4 * 2);
         const size_t off = B.alloc((size_t)N * hw * rup64(C) * 2);
+        const int gsp    = have ? 0 : gn_stats_split(hw, C, N, groups);  // few large slabs: several workgroups per (image, group), partial sums in arena scratch
+        const size_t po  = gsp ? B.alloc((size_t)N * groups * gsp * 2 * 4) : 0;
         B.emit([=](hipStream_t st) {
             float* sc = (float*)(P->arena + so);
             float* sh = sc + N * C;
-            if (!have) launch_gn_stats(st, sc, sh, xp, hw, C, N, groups, eps, w, b);
+            if (!have) launch_gn_stats(st, sc, sh, xp, hw, C, N, groups, eps, w, b, nullptr, 0, gsp ? (float*)(P->arena + po) : nullptr);
             launch_nchw_to_nhwc_f16(st, P->arena + off, xp, hw, C, N, sc, sh, false);
         });
         chain.push_back(gi.sole(last));
@@ -2117,10 +2119,12 @@ bool plan_group_norm(Builder& B, int i, hipStream_t, std::vector<int>& chain) {
         const bool have     = pre != B.gn_pre.end() && pre->second.w == w && pre->second.b == b && pre->second.groups == groups && pre->second.eps == eps;
         const size_t so     = have ? pre->second.off : B.alloc((size_t)N * C * 4 * 2);
         const size_t off    = B.alloc((size_t)N * hw * rup64(C) * 2);
+        const int gsp       = have ? 0 : gn_stats_split(hw, C, N, groups);
+        const size_t po     = gsp ? B.alloc((size_t)N * groups * gsp * 2 * 4) : 0;
         B.emit([=](hipStream_t st) {
             float* sc = (float*)(P->arena + so);
             float* sh = sc + N * C;
-            if (!have) launch_gn_stats(st, sc, sh, xp, hw, C, N, groups, eps, w, b);
+            if (!have) launch_gn_stats(st, sc, sh, xp, hw, C, N, groups, eps, w, b, nullptr, 0, gsp ? (float*)(P->arena + po) : nullptr);
             launch_nchw_to_nhwc_f16(st, P->arena + off, xp, hw, C, N, sc, sh, silu, nullptr, 0, nullptr, conv_mul);
         });
         g_stats.kernels_planned++;
@@ -3343,6 +3347,11 @@ void plan_flux_qkv(Builder& B) {
 // planner's side stream.  Hazards: rebuild k+1 writes the OTHER buffer of its size class than rebuild k (Builder::jit_seq parity), and the buffer it
 // writes was last read by a GEMM enqueued on the main stream before the fork event; the GEMM that reads it waits for the join event.  Under hipGraph
 // capture the fork / join become graph edges.  The first rebuild of a plan stays on the main stream.
+// MEASURED AND REJECTED as a default (profiles/r07h_ab_jit_overlap.txt): FLUX.1-dev 89.97 -> 92.58 ms per step (+2.9 %), SDXL batch 8 135.57 -> 135.98, results
+// bit-identical.  The rebuild does run concurrently — and takes 11.5 ms of kernel time per step instead of 6.9 while slowing the GEMM it shares the CUs and
+// the HBM / Infinity-Cache path with: the 256 x 256 GEMM tile owns its CU (144 KB of LDS, two waves per SIMD at 256 registers), so the rebuild's
+// workgroups only get CUs the GEMM's last round has left, arriving as a burst of 75 MB of writes exactly when the next GEMM wants its first tiles.
+// The option stays (default 0) so the number can be re-measured.
 void overlap_jit_steps(Planner* P, Plan* plan) {
     if (!g_opt.jit_overlap || !P->side) return;
     std::vector<size_t> js;
@@ -4059,6 +4068,7 @@ void planner_set_option(const char* key, int value) {
     else if (!strcmp(key, "gemm16_tile")) gemm16_set_tile(value);
     else if (!strcmp(key, "splitk_mid")) gemm16_set_splitk_mid(value);
     else if (!strcmp(key, "splitk_target")) gemm16_set_splitk_target(value);
+    else if (!strcmp(key, "gn_split_min")) gemm16_set_gn_split_min(value);
     // options change what a plan contains: drop cached plans
     std::lock_guard<std::mutex> lk(g_mu);
     for (Planner* p : g_planners) {

@@ -2096,18 +2096,87 @@ __global__ __launch_bounds__(NT) void k_gn_stats_1pass(float* __restrict__ scale
         shift[(int64_t)n * C + c] = (b ? b[c] : 0.f) - mean * sc;
     }
 }
+// FEW (image, group) slabs, each large (the KL-VAE at batch 1: 32 slabs of 16.8 MB at the 512 x 512 x 128 level; SDXL's first UNet level at batch 1):
+// one workgroup per slab leaves 7/8 of the chip idle — 30 launches = 8.0 ms of the 25 ms 1024 x 1024 decode at 0.9 TB/s (profiles/r07i_vae_families.txt).
+// Here P workgroups share a slab: each sums its contiguous part relative to the slab's first element K (same shifted-data form as k_gn_stats_1pass)
+// into part[(slab * P + p) * 2 + {0, 1}]; k_gn_stats_final adds the P partial pairs in a fixed order (bitwise deterministic) and writes scale / shift.
+template <int NT>
+__global__ __launch_bounds__(NT) void k_gn_stats_part(float* __restrict__ part, const float* __restrict__ x, int64_t hw, int C, int groups, int cpg, int P) {
+    __shared__ float scratch[2 * (NT / 64)];
+    const int p = blockIdx.x % P, slab = blockIdx.x / P;
+    const int gidx = slab % groups, n = slab / groups;
+    const int c0 = gidx * cpg, c1 = min(c0 + cpg, C);
+    if (c0 >= c1) return;
+    const int64_t n4 = (int64_t)(c1 - c0) * hw / 4;
+    const float4* xs = (const float4*)(x + ((int64_t)n * C + c0) * hw);
+    const float K    = ((const float*)xs)[0];
+    const int64_t i0 = n4 * p / P, i1 = n4 * (p + 1) / P;
+    float s1 = 0.f, s2 = 0.f;
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += NT) {
+        const float4 v = xs[i];
+        const float a = v.x - K, bb = v.y - K, c = v.z - K, d = v.w - K;
+        s1 += (a + bb) + (c + d);
+        s2 += (a * a + bb * bb) + (c * c + d * d);
+    }
+    block_sum2<NT / 64>(s1, s2, scratch);
+    if (threadIdx.x == 0) {
+        part[(int64_t)blockIdx.x * 2]     = s1;
+        part[(int64_t)blockIdx.x * 2 + 1] = s2;
+    }
+}
+__global__ __launch_bounds__(64) void k_gn_stats_final(float* __restrict__ scale, float* __restrict__ shift, const float* __restrict__ part, const float* __restrict__ x,
+                                                       int64_t hw, int C, int groups, int cpg, int P, float eps, const float* __restrict__ w, const float* __restrict__ b) {
+    const int slab = blockIdx.x, gidx = slab % groups, n = slab / groups;
+    const int c0 = gidx * cpg, c1 = min(c0 + cpg, C);
+    if (c0 >= c1) return;
+    const int64_t cnt = (int64_t)(c1 - c0) * hw;
+    float s1 = 0.f, s2 = 0.f;
+    for (int p = 0; p < P; ++p) {  // every lane the same fixed order
+        s1 += part[((int64_t)slab * P + p) * 2];
+        s2 += part[((int64_t)slab * P + p) * 2 + 1];
+    }
+    const float K    = x[((int64_t)n * C + c0) * hw];
+    const float m1   = s1 / (float)cnt;
+    const float mean = K + m1;
+    const float var  = fmaxf(s2 / (float)cnt - m1 * m1, 0.f);
+    const float rstd = rsqrtf(var + eps);
+    for (int c = c0 + threadIdx.x; c < c1; c += 64) {
+        const float sc            = (w ? w[c] : 1.f) * rstd;
+        scale[(int64_t)n * C + c] = sc;
+        shift[(int64_t)n * C + c] = (b ? b[c] : 0.f) - mean * sc;
+    }
+}
+static int64_t g_gn_split_min = 1 << 16;  // option "gn_split_min": least floats per (image, group) slab for the shared-slab form (0 turns it off: 1 << 62)
+void gemm16_set_gn_split_min(int v) { g_gn_split_min = v <= 0 ? (1ll << 62) : (int64_t)v; }
+// workgroups per slab for that form (0: the one-workgroup-per-slab kernels); the caller provides N * groups * P * 2 floats of scratch
+int gn_stats_split(int64_t hw, int64_t C, int64_t N, int groups) {
+    const int64_t cpg = (C + groups - 1) / groups, cnt = cpg * hw, slabs = N * groups;
+    if (hw % 4 != 0 || C % groups != 0 || cnt < g_gn_split_min || slabs >= 128) return 0;  // from 256 KB per slab on, fewer than 128 slabs
+    int64_t P = 512 / slabs;
+    if (P > 32) P = 32;
+    while (P > 1 && cnt / 4 / P < 2048) P /= 2;  // at least 32 KB per workgroup
+    return P >= 2 ? (int)P : 0;
+}
+
 // x2 != nullptr: statistics of the channel concatenation [x (C1 channels) | x2] (gn_two_source_supported)
 bool gn_two_source_supported(const float* x, const float* x2, int64_t hw, int64_t C, int64_t C1, int groups) {
     const int64_t cnt = ((C + groups - 1) / groups) * hw;
     return hw % 4 == 0 && ((((uintptr_t)x) | ((uintptr_t)x2)) & 15) == 0 && C1 > 0 && C1 < C && (cnt <= 4 * 1024 * 16 || cnt >= 16384) && C * hw < (1ll << 31);
 }
 void launch_gn_stats(hipStream_t s, float* scale, float* shift, const float* x, int64_t hw, int64_t C, int64_t N, int groups, float eps, const float* w,
-                     const float* b, const float* x2, int64_t C1) {
+                     const float* b, const float* x2, int64_t C1, float* part) {
     KScope ks_(s, KF_GN_STATS, 0.0, (double)hw * C * N * 4.0);  // algorithmic: ONE read of the activation
     const int cpg       = (int)((C + groups - 1) / groups);
     const int64_t cnt   = (int64_t)cpg * hw;
     const bool v4       = hw % 4 == 0 && ((((uintptr_t)x) | ((uintptr_t)x2)) & 15) == 0;  // (a short last group is fine: the kernels bound it by c1)
     const unsigned grid = (unsigned)(N * groups);
+    if (part && !x2 && v4) {
+        if (const int P = gn_stats_split(hw, C, N, groups)) {
+            k_gn_stats_part<1024><<<grid * (unsigned)P, 1024, 0, s>>>(part, x, hw, (int)C, groups, cpg, P);
+            k_gn_stats_final<<<grid, 64, 0, s>>>(scale, shift, part, x, hw, (int)C, groups, cpg, P, eps, w, b);
+            return;
+        }
+    }
     if (x2 && !gn_two_source_supported(x, x2, hw, C, C1, groups)) {
         fprintf(stderr, "ggml-mi355x: two-source GroupNorm statistics asked for a shape they do not take\n");
         abort();

@@ -183,8 +183,11 @@ void launch_geglu_f16(hipStream_t s, void* dst, const float* x, int64_t tokens, 
 // x2 != nullptr (both launchers): the activation is the channel concatenation [x (C1 channels) | x2 (C - C1 channels)] of two NCHW tensors, never materialised
 // (UNet skip connections); dst_raw != nullptr: a second NHWC image of the same values without affine / SiLU
 bool gn_two_source_supported(const float* x, const float* x2, int64_t hw, int64_t C, int64_t C1, int groups);
+// part: optional scratch of N * groups * gn_stats_split(...) * 2 floats — with it, few large (image, group) slabs are shared by several workgroups
 void launch_gn_stats(hipStream_t s, float* scale, float* shift, const float* x, int64_t hw, int64_t C, int64_t N, int groups, float eps,
-                     const float* w, const float* b, const float* x2 = nullptr, int64_t C1 = 0);
+                     const float* w, const float* b, const float* x2 = nullptr, int64_t C1 = 0, float* part = nullptr);
+int gn_stats_split(int64_t hw, int64_t C, int64_t N, int groups);
+void gemm16_set_gn_split_min(int v);  // option "gn_split_min" (65536 floats): least slab size for it; 0 = never  // workgroups per slab the split form would use (0: not used for this shape)
 void launch_nchw_to_nhwc_f16(hipStream_t s, void* dst, const float* x, int64_t hw, int64_t C, int64_t N, const float* scale, const float* shift,
                              bool silu, const float* x2 = nullptr, int64_t C1 = 0, void* dst_raw = nullptr, float post_mul = 1.f);  // post_mul: after affine / SiLU (Conv2d scale)
 
