@@ -88,6 +88,27 @@ def test_full_width_sd15_unet_through_the_reference_runner_on_the_gpu(sd, oracle
     r.close()
 
 
+def test_full_width_sdxl_unet_q8_0_through_the_reference_runner_on_the_gpu(sd, oracle, gpu):
+    """BASELINE.json config 3's model — the SDXL UNet, 70 transformer blocks, q8_0 Linear weights + f16 conv kernels, 1024x1024 (128x128 latent), cond + uncond — built,
+    placed and submitted by the reference's own runner: bit-identical to the engine's forward, same fusion counters (the raw-block kernels, sibling / hoisted
+    launches and split-K decisions the bench numbers rest on are taken for the reference-emitted graph too)."""
+    rng = np.random.default_rng(15)
+    x = np.repeat(rng.standard_normal((1, 4, 128, 128)).astype(np.float32), 2, axis=0)
+    t = np.array([600.0, 600.0], np.float32)
+    ctx = rng.standard_normal((2, 77, 2048)).astype(np.float32)
+    y = rng.standard_normal((2, 2816)).astype(np.float32)
+    e = sd.Engine(model=sd.SDXL, backend=gpu, flash_attn=True, wtype=sd.Q8_0)
+    r = rg.RefRunner(e, "unet", "sdxl", gpu, flash_attn=True)
+    ref, d_ref = _delta(sd, lambda: r.compute(x.shape, x=x, t=t, ctx=ctx, y=y), gpu != oracle)
+    out, d_eng = _delta(sd, lambda: e.unet_forward(x, t, ctx, y), gpu != oracle)
+    assert np.isfinite(ref).all()
+    if gpu != oracle:
+        assert d_ref == d_eng, {k: (d_ref[k], d_eng[k]) for k in d_ref if d_ref[k] != d_eng[k]}
+        print("SDXL UNet q8_0 through the reference runner: fusion counters", {k: v for k, v in d_ref.items() if v})
+    np.testing.assert_array_equal(ref, out)
+    r.close()
+
+
 @pytest.mark.parametrize("name", ["SD15_TINY", "SD35_TINY", "FLUX_TINY"])
 def test_reference_real_eval_callback_slicing_on_the_gpu(sd, oracle, gpu, name):
     c = inputs_for(sd, name, np.random.default_rng(14))

@@ -101,6 +101,28 @@ def test_reference_emitted_graph_equals_engine_graph_node_for_node(sd, oracle, n
     r.close()
 
 
+@pytest.mark.parametrize("name,wtype", [("SDXL_TINY", "Q8_0"), ("SD15_TINY", "Q4_0"), ("SD35_TINY", "BF16"), ("SD35_TINY", "Q8_0"), ("FLUX_TINY", "Q4_0"), ("FLUX_TINY", "Q8_0")])
+def test_reference_parameter_types_under_quantised_checkpoints(sd, oracle, name, wtype):
+    """The reference decides every parameter's ggml type in `init_params`: the checkpoint's type, EXCEPT Linears it forces to F32 (`force_f32`: MMDiT
+    t / y / context embedders and final layer, mmdit.hpp:258-283, 733, 795), weights whose row length is no multiple of the block size (ggml_extend.hpp:3422-3425),
+    conv kernels (always F16, :3602) and biases / norm weights (F32).  With the engine's tensor table as the checkpoint, the reference-built graph must have the
+    engine's leaf TYPES and byte strides (the node-for-node comparison covers them), and compute the same result bit for bit."""
+    c = inputs_for(sd, name, np.random.default_rng(9))
+    e = sd.Engine(model=c["model"], backend=oracle, flash_attn=True, wtype=getattr(sd, wtype))
+    r = rg.RefRunner(e, c["family"], c["version"], oracle, flash_attn=True, overrides=c["overrides"])
+    dref = r.describe(**c["ref"])
+    deng = rg.engine_graph_description(lambda: c["eng"](e), compute=False)
+    nodes, leafs, _ = compare_descriptions(name, dref, deng)
+    kinds = {}
+    for line in rg.split_description(deng)[0]:
+        kinds[line.split()[2]] = kinds.get(line.split()[2], 0) + 1
+    print(f"{name} {wtype}: {nodes} nodes, leaf types {kinds}")
+    assert wtype.lower() in kinds and kinds[wtype.lower()] >= 8
+    ref = r.compute(c["out"], **c["ref"])
+    np.testing.assert_array_equal(ref, c["eng"](e).reshape(ref.shape))
+    r.close()
+
+
 @pytest.mark.parametrize("name", ["SD15", "SDXL", "VAE_FULL", "SD35_LARGE", "FLUX_DEV"])
 def test_reference_emitted_graph_equals_engine_graph_at_the_benchmarked_widths(sd, oracle, name, monkeypatch):
     """Graphs only (nothing is computed, the weight tables are allocated and left unfilled): the benchmarked models themselves — SD1.5 UNet (320 ch, 64x64
