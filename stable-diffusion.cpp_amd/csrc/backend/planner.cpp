@@ -163,7 +163,7 @@ namespace {
 struct Stats {
     std::atomic<int64_t> graphs_computed{0}, plans_built{0}, nodes_seen{0}, kernels_planned{0}, kernels_launched{0}, fused_conv{0},
         fused_conv_bounced{0}, fused_linear{0}, fused_norm{0}, fused_geglu{0}, fused_attention{0}, generic_matmul{0}, swizzled_weight_bytes{0}, fused_linear_geglu{0}, split_k_gemms{0}, head_major_gemms{0}, fused_modulate{0}, fused_gate{0}, fused_gelu{0}, fused_rope{0}, fused_concat_heads{0},
-        graph_replays{0}, qgemv_linears{0}, fused_chan_add{0}, fused_proj_tokens{0}, gemm_attention{0}, fused_q16{0}, split_k_inlaunch{0}, qgemm16_linears{0}, fgemv_linears{0}, fused_presilu{0}, fused_sibling_linears{0}, hoisted_kv_linears{0}, window_convs{0}, hoisted_emb_linears{0}, fused_rows16{0}, fused_cat_rows16{0}, fused_joint_qkv{0}, jit_images{0}, fused_gn_stats{0}, redirect_fallbacks{0}, fused_ln_reduce{0}, fused_concat_gn{0}, fused_conv_scale{0}, view_graphs{0}, view_external_nodes{0}, plans_evicted{0}, hoisted_mod_linears{0}, jit_overlapped{0};
+        graph_replays{0}, qgemv_linears{0}, fused_chan_add{0}, fused_proj_tokens{0}, gemm_attention{0}, fused_q16{0}, split_k_inlaunch{0}, qgemm16_linears{0}, fgemv_linears{0}, fused_presilu{0}, fused_sibling_linears{0}, hoisted_kv_linears{0}, window_convs{0}, hoisted_emb_linears{0}, fused_rows16{0}, fused_cat_rows16{0}, fused_joint_qkv{0}, jit_images{0}, fused_gn_stats{0}, redirect_fallbacks{0}, fused_ln_reduce{0}, fused_concat_gn{0}, fused_conv_scale{0}, view_graphs{0}, view_external_nodes{0}, plans_evicted{0}, hoisted_mod_linears{0}, jit_overlapped{0}, qinloop_linears{0};
 } g_stats;
 
 struct Options {
@@ -1110,10 +1110,20 @@ void plan_linear(Builder& B, int i, hipStream_t s, std::vector<int>& chain) {
     // resident-quantised weights (option jit_qimages = least activation rows, default 4096; 1 = always, 0 = never): such a Linear gets NO cached f16 image — the image is
     // rebuilt by k_wswz_q into a buffer shared by all weights of that size right in front of the GEMM (HBM keeps 0.56 / 1.06 B per weight instead
     // of 2.56 / 3.06; the GEMM reads the fresh image out of the Infinity Cache).  Plain row order only (no GEGLU pairing), not for grouped launches.
-    const bool jit = !useq && g_opt.jit_qimages > 0 && tokens >= g_opt.jit_qimages && g_opt.gemm16 && geglu_out < 0 && hm_d == 0 && !B.hm_hoisting && wswz_q_supported((int)w->type, K) &&
+    // ... and above that range (round 6): the pipelined 256 x 256 GEMM tile itself takes the raw blocks — fetched by LDS-DMA into a raw ring, dequantised once per
+    // workgroup into the B stage its MFMA fragments are read from (k_gemm16<..., QT>, gemm16.hip) — wherever the launch takes that tile anyway.  No f16 image exists
+    // for such a weight, cached or rebuilt.  Bitwise the image path's result.  Option qinloop_min_rows (0 = off).
+    const bool qin = !useq && g_opt.gemm16 && geglu_out < 0 && hm_d == 0 && !B.hm_hoisting && nchw_add < 0 && (wt == 8 || wt == 2) &&
+                     (int64_t)w->nb[1] == (int64_t)ggml_abi_row_size(w->type, K) && aligned16(w->data) && gemm16_qinloop_supported(wt, tokens, M, K, 1, 1);
+    if (qin) {
+        ep.qtype      = wt;
+        ep.qrow_bytes = (int64_t)w->nb[1];
+        g_stats.qinloop_linears++;
+    }
+    const bool jit = !useq && !qin && g_opt.jit_qimages > 0 && tokens >= g_opt.jit_qimages && g_opt.gemm16 && geglu_out < 0 && hm_d == 0 && !B.hm_hoisting && wswz_q_supported((int)w->type, K) &&
                      (int64_t)w->nb[1] == (int64_t)ggml_abi_row_size(w->type, K) && aligned16(w->data);
     const int geglu_mode = geglu_out >= 0 ? gemm16_geglu_mode(tokens, M, K) : 0;
-    const void* swz = useq ? nullptr : (jit ? B.P->jit_buffer(wswz_bytes(M, K), B.jit_seq[wswz_bytes(M, K)]++) : get_swz_linear(B.P, w, s, geglu_mode));
+    const void* swz = useq ? nullptr : qin ? w->data : (jit ? B.P->jit_buffer(wswz_bytes(M, K), B.jit_seq[wswz_bytes(M, K)]++) : get_swz_linear(B.P, w, s, geglu_mode));
     if (jit && swz) {
         void* jb          = const_cast<void*>(swz);
         const void* wsrc  = w->data;
@@ -3983,6 +3993,7 @@ void planner_get_stats(ggml_backend_mi355x_stats* o) {
     o->plans_evicted         = g_stats.plans_evicted;
     o->hoisted_mod_linears   = g_stats.hoisted_mod_linears;
     o->jit_overlapped        = g_stats.jit_overlapped;
+    o->qinloop_linears       = g_stats.qinloop_linears;
     o->fused_attention       = g_stats.fused_attention;
     o->generic_matmul        = g_stats.generic_matmul;
     o->swizzled_weight_bytes = g_stats.swizzled_weight_bytes;
@@ -4030,6 +4041,7 @@ void planner_set_option(const char* key, int value) {
     else if (!strcmp(key, "fuse_joint_qkv")) g_opt.fuse_joint_qkv = value;
     else if (!strcmp(key, "fuse_ln_reduce")) g_opt.fuse_ln_reduce = value;
     else if (!strcmp(key, "jit_qimages")) g_opt.jit_qimages = value;
+    else if (!strcmp(key, "qinloop_min_rows")) gemm16_set_qinloop_min_rows(value);
     else if (!strcmp(key, "conv3w_min_blocks")) conv3w_set_min_blocks(value);
     else if (!strcmp(key, "conv3w_min_blocks_deep")) conv3w_set_min_blocks_deep(value);
     else if (!strcmp(key, "gemm16_bn64")) gemm16_set_bn64(value);

@@ -46,10 +46,24 @@ namespace mi355x {
 // epilogue — the in-launch split-K protocol below with a per-tile part count.  Nobody waits for another workgroup.  Why: a grid of T tiles on
 // 256 CUs takes ceil(T / 256) rounds; DiT Linears have T = 192 .. 1428 (FLUX 4096 x 3072 -> 9216: 576 tiles = 2.25 rounds paid as 3; SD3.5
 // 8192 x 9728 -> 2432: 320 tiles = 1.25 rounds paid as 2), profiles/r05b_*.
-template <int BM, int BN, bool CONV, int BK, int NST, int WR, int WC, int PIPE = 0, bool SWP = false, bool SK = false>
+// QT = 8 / 4 (pipelined 256 x 256 Linear tile only): the weight operand is NOT an f16 image — g.W points at the RAW GGUF q8_0 / q4_0 rows and the blocks are
+// dequantised inside the main loop, once per workgroup, into the B stage the MFMA fragments are read from (DESIGN.md section 3.2 "in-loop dequantisation"):
+//   * raw ring: the 2-block piece (68 / 36 B) of each of the tile's 256 weight rows that covers TWO K stages is fetched by LDS-DMA into one of three raw slots —
+//     4 / 2 16-byte pieces per row [row][64 / 32 B] (piece order XOR-permuted per row on the DMA source so that the 16-byte reads below are conflict-free)
+//     plus one 16-byte piece holding the LAST 16 bytes of the pair [row][16 B]: every fetched byte belongs to the row, nothing is read past a row's end;
+//   * B stages: TWO f16 slots in the fragment order of the weight image; thread (column c = tid & 255, half h = tid >> 8) reads its 16 quants + the block
+//     scale out of the raw slot (two ds_read_b128 + one ds_read_b32), converts them with the v_perm / v_pk_add / v_pk_mul sequence of k_qgemm16 — f16(d * q),
+//     bit-identical to the value the f16 image holds — and stores the two 16-byte fragment rows with ds_write_b128;
+//   * schedule (iteration kt computes stage kt): raw ds_reads for stage kt + 2 are issued in the first k-step (they return under the existing lgkmcnt(0) in
+//     front of the barrier), the conversion runs in the MFMA shadow of the second k-step and its ds_writes land in the B slot stage kt just left; the raw
+//     chunk of stages kt + 6 / kt + 7 is issued every even iteration behind the A pieces of stage kt + 4.  The LDS-DMA queue retires in order, so ONE counted
+//     wait per iteration — vmcnt(2 A + 2 A + raw pieces) — covers both the A stage and the raw chunk that the next barrier publishes.
+// The result is bitwise the same as the image path's on the same tile (same operand values, same summation order).
+template <int BM, int BN, bool CONV, int BK, int NST, int WR, int WC, int PIPE = 0, bool SWP = false, bool SK = false, int QT = 0>
 __global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g) {
     static_assert(!SWP || !CONV, "SWP: the Linear kernels with the accumulator transposed (g16_common.h, epi_linear_swp)");
     static_assert(!SK || (PIPE == 1 && !CONV && !SWP), "stream-K is written for the pipelined Linear tiles");
+    static_assert(QT == 0 || ((QT == 8 || QT == 4) && PIPE == 1 && !CONV && !SWP && !SK && BM == 256 && BN == 256 && WR * WC == 8), "in-loop dequantisation: pipelined 256 x 256 Linear tile");
     constexpr int NW  = WR * WC;
     constexpr int RB  = BM / WR / 32;  // 32-row blocks per wave
     constexpr int CB  = BN / WC / 32;  // 32-col blocks per wave
@@ -66,7 +80,20 @@ __global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g
     constexpr int BBYTES = NF * 1024;
     constexpr int NPT    = APW + WPW;                  // LDS-DMA instructions per wave per stage (waves >= WEXTRA: one fewer when WEXTRA != 0)
     static_assert(APW * NW * 1024 == ABYTES && APW >= 1, "A stage must split evenly over the waves");
-    __shared__ __attribute__((aligned(1024))) char smem[NST * (ABYTES + BBYTES)];
+    // in-loop dequantisation (QT): A ring (NST slots) | two f16 B slots | three raw slots
+    constexpr int QBLK  = QT == 8 ? 34 : 18;            // bytes of a quantised block (32 weights)
+    constexpr int QPB   = QT == 8 ? 64 : 32;            // bytes per row of the raw slot's piece region (whole 16-byte pieces of the 2-block pair)
+    constexpr int QNP   = QPB / 16;                     // ... pieces per row
+    constexpr int QTOFF = 2 * QBLK - 16;                // source offset of the tail piece (the last 16 bytes of the pair)
+    constexpr int QRAWB = BN * (QPB + 16);              // bytes of a raw slot
+    constexpr int QNRAW = 3;
+    constexpr int QPI   = QT ? BN * QNP / (NW * 64) : 0;  // piece-region LDS-DMA instructions per wave and chunk (2 / 1), + 1 for the tail region
+    constexpr int QRQ   = QPI + 1;
+    constexpr int QB0   = NST * ABYTES;                 // first B slot
+    constexpr int QR0   = QB0 + 2 * BBYTES;             // first raw slot
+    constexpr int SMEMB = QT ? QR0 + QNRAW * QRAWB : NST * (ABYTES + BBYTES);
+    static_assert(SMEMB <= 160 * 1024, "LDS budget");
+    __shared__ __attribute__((aligned(1024))) char smem[SMEMB];
 
     const int lane0 = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -193,7 +220,7 @@ __global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g
         const int cb = fs / KSTEPS, ks = fs % KSTEPS;
         int wb       = col0 / 32 + cb;
         if (!CONV && g.wblk_lim > 0 && wb >= g.wblk_lim) wb = g.wblk_lim - 1;  // column blocks past the padded image: any valid block (their outputs are masked by col < C)
-        wsrc[q]      = g.W + ((int64_t)wb * g.kfr + ks) * 64 + lane;
+        wsrc[q]      = QT ? g.W : g.W + ((int64_t)wb * g.kfr + ks) * 64 + lane;  // (QT: g.W points at raw quantised rows, fetched by the loop further down)
         wdst[q]      = fs * 1024;
     }
     const bool w_short = WEXTRA != 0 && wave >= WEXTRA;  // this wave issues one W fragment fewer per stage
@@ -497,10 +524,237 @@ __global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g
         }                                                                                                                          \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                         \
     } while (0)
+        if constexpr (QT != 0) {
+            // ================= in-loop dequantisation (see the header comment of this kernel) =================
+            typedef uint32_t qu32x4_t __attribute__((ext_vector_type(4)));
+            typedef _Float16 qhalf2_t __attribute__((ext_vector_type(2)));
+            const int tid = (int)threadIdx.x;
+            const int qc  = tid & 255;  // conversion pass: this thread's weight row (column of the tile) ...
+            const int qh  = wave >> 2;  // ... and its half of the block's 32 weights (wave-uniform)
+            auto qf = [](int c) { return QT == 8 ? ((c >> 2) & 3) : ((c >> 3) & 1); };  // physical piece slot of logical piece p of raw row c: p ^ qf(c)
+            const char* qsrc[QPI];
+#pragma unroll
+            for (int r = 0; r < QPI; ++r) {
+                const int idx = r * (NW * 64) + tid, col = idx / QNP, pp = idx % QNP;
+                qsrc[r]       = (const char*)g.W + (int64_t)(col0 + col) * g.qrow_bytes + ((pp ^ qf(col)) << 4);
+            }
+            const char* qsrcT = (const char*)g.W + (int64_t)(col0 + wave * 32 + (lane & 31)) * g.qrow_bytes + QTOFF;
+            // byte offsets of this thread's raw reads inside a raw slot, per block of the pair ([0] / [1]): two 16-byte pieces (A, B) and the dword holding the scale (D)
+            uint32_t qoA[2], qoB[2], qoD[2];
+            {
+                const int f = qf(qc);
+                auto pc = [&](int p) { return (uint32_t)(qc * QPB + ((p ^ f) << 4)); };
+                const uint32_t T = (uint32_t)(BN * QPB + qc * 16);
+                if constexpr (QT == 8) {
+                    qoA[0] = qh ? pc(1) : pc(0);
+                    qoB[0] = qh ? pc(2) : pc(1);
+                    qoD[0] = pc(0);
+                    qoA[1] = qh ? T : pc(2);
+                    qoB[1] = qh ? T : pc(3);
+                    qoD[1] = pc(2);
+                } else {
+                    qoA[0] = pc(0);
+                    qoB[0] = pc(1);
+                    qoD[0] = pc(0);
+                    qoA[1] = T;
+                    qoB[1] = T;
+                    qoD[1] = pc(1);
+                }
+            }
+            const uint32_t qraw0 = lds0 + (uint32_t)QR0;
+            const uint32_t qwB   = lds0 + (uint32_t)(QB0 + ((qc >> 5) * KSTEPS + qh) * 1024 + (qc & 31) * 16);  // first fragment row this thread writes (second: + 512)
+            const uint32_t badq  = lds0 + (uint32_t)(QB0 + (wc * CB * KSTEPS) * 1024 + lane * 16);
+            const int qnch       = nt >> 1;          // 2-stage chunks of this K range (kt0 and nt are even: launcher precondition)
+            const int64_t qch0   = (int64_t)(kt0 >> 1) * (2 * QBLK);
+            qu32x4_t RA, RB;
+            uint32_t RD;
+            auto q_issue_raw_piece = [&](int i, int ch, int slot) {  // LDS-DMA piece i (< QPI: piece region, QPI: tail region) of chunk ch into raw slot `slot`
+                const int cc      = ch < qnch ? ch : qnch - 1;  // past the end: a harmless re-fetch of the last chunk (keeps the per-iteration DMA count constant)
+                const int64_t off = qch0 + (int64_t)cc * (2 * QBLK);
+                char* rb          = smem + QR0 + slot * QRAWB;
+                if (i < QPI) {
+                    GLDS16(qsrc[i < QPI ? i : 0] + off, rb + (i * (NW * 64) + wave * 64) * 16);
+                } else {
+                    if (lane < 32) GLDS16(qsrcT + off, rb + BN * QPB + wave * 512);
+                }
+            };
+            auto q_issue_a = [&](int q, int ktabs, int slot) { GLDS16(asrc[q] + (int64_t)ktabs * BK, smem + slot * ABYTES + (wave * APW + q) * 1024); };
+            // registers -> the 16 quant bytes (Qv) and the block scale of block B_ of the pair
+            auto q_extract = [&](int b, uint32_t (&Qv)[4], qhalf2_t& d2) {
+                uint32_t dbits;
+                if (b == 0) {
+                    Qv[0] = __builtin_amdgcn_alignbit(RA[1], RA[0], 16);
+                    Qv[1] = __builtin_amdgcn_alignbit(RA[2], RA[1], 16);
+                    Qv[2] = __builtin_amdgcn_alignbit(RA[3], RA[2], 16);
+                    Qv[3] = __builtin_amdgcn_alignbit(RB[0], RA[3], 16);
+                    dbits = ((QT == 8 && qh) ? RD : RA[0]) & 0xffffu;
+                } else if (QT == 8 && !qh) {
+                    Qv[0] = RA[1];
+                    Qv[1] = RA[2];
+                    Qv[2] = RA[3];
+                    Qv[3] = RB[0];
+                    dbits = RA[0] >> 16;
+                } else {
+                    Qv[0] = RA[0];
+                    Qv[1] = RA[1];
+                    Qv[2] = RA[2];
+                    Qv[3] = RA[3];
+                    dbits = RD >> 16;
+                }
+                if constexpr (QT == 4) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) Qv[i] = (qh ? Qv[i] >> 4 : Qv[i]) & 0x0F0F0F0Fu;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) Qv[i] ^= 0x80808080u;
+                }
+                const _Float16 d = __builtin_bit_cast(_Float16, (uint16_t)dbits);
+                d2               = (qhalf2_t){d, d};
+            };
+            // four bytes -> two half2 {1024 + b0, 1024 + b1}, {1024 + b2, 1024 + b3} (exponent byte 0x64), minus 1152 / 1032 = the exact integer, times d: f16(d * q)
+            auto q_deq4 = [&](uint32_t u, qhalf2_t d2, uint32_t& o01, uint32_t& o23) {
+                const qhalf2_t off = {(_Float16)(QT == 8 ? 1152.f : 1032.f), (_Float16)(QT == 8 ? 1152.f : 1032.f)};
+                const uint32_t p01 = __builtin_amdgcn_perm(0x64646464u, u, 0x04010400u);
+                const uint32_t p23 = __builtin_amdgcn_perm(0x64646464u, u, 0x04030402u);
+                o01                = __builtin_bit_cast(uint32_t, (__builtin_bit_cast(qhalf2_t, p01) - off) * d2);
+                o23                = __builtin_bit_cast(uint32_t, (__builtin_bit_cast(qhalf2_t, p23) - off) * d2);
+            };
+#define G16Q_RAW_READ(B_, RBASE_)                                                                                      \
+    do {                                                                                                             \
+        asm volatile("ds_read_b128 %0, %1" : "=v"(RA) : "v"((RBASE_) + qoA[B_]));                                    \
+        asm volatile("ds_read_b128 %0, %1" : "=v"(RB) : "v"((RBASE_) + qoB[B_]));                                    \
+        asm volatile("ds_read_b32 %0, %1" : "=v"(RD) : "v"((RBASE_) + qoD[B_]));                                     \
+    } while (0)
+#define G16Q_WRITE(SLOT_)                                                                                             \
+    do {                                                                                                             \
+        const qu32x4_t w0_ = {O[0], O[1], O[2], O[3]}, w1_ = {O[4], O[5], O[6], O[7]};                               \
+        asm volatile("ds_write_b128 %0, %1" ::"v"(qwB + (uint32_t)((SLOT_) * BBYTES)), "v"(w0_) : "memory");           \
+        asm volatile("ds_write_b128 %0, %1 offset:512" ::"v"(qwB + (uint32_t)((SLOT_) * BBYTES)), "v"(w1_) : "memory"); \
+    } while (0)
+            // ---- fill: raw chunks 0 .. 2 and A stages 0 .. 3, in the order the steady state would have issued them
+            q_issue_raw_piece(0, 0, 0);
+            if constexpr (QPI > 1) q_issue_raw_piece(1, 0, 0);
+            q_issue_raw_piece(QPI, 0, 0);
+#pragma unroll
+            for (int q = 0; q < APW; ++q) q_issue_a(q, kt0 + 0, 0);
+            q_issue_raw_piece(0, 1, 1);
+            if constexpr (QPI > 1) q_issue_raw_piece(1, 1, 1);
+            q_issue_raw_piece(QPI, 1, 1);
+#pragma unroll
+            for (int q = 0; q < APW; ++q) q_issue_a(q, kt0 + 1, 1);
+#pragma unroll
+            for (int q = 0; q < APW; ++q) q_issue_a(q, kt0 + 2, 2);
+            q_issue_raw_piece(0, 2, 2);
+            if constexpr (QPI > 1) q_issue_raw_piece(1, 2, 2);
+            q_issue_raw_piece(QPI, 2, 2);
+#pragma unroll
+            for (int q = 0; q < APW; ++q) q_issue_a(q, kt0 + 3, 3);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * QRQ + 4 * APW) : "memory");  // raw chunk 0 landed
+            asm volatile("s_barrier" ::: "memory");
+            {   // B stages 0 and 1 (both blocks of chunk 0), outside the pipeline
+                uint32_t Qv[4], O[8];
+                qhalf2_t d2;
+                G16Q_RAW_READ(0, qraw0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                G16_TIE(RA);
+                G16_TIE(RB);
+                G16_TIE(RD);
+                q_extract(0, Qv, d2);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) q_deq4(Qv[i], d2, O[2 * i], O[2 * i + 1]);
+                G16Q_WRITE(0);
+                G16Q_RAW_READ(1, qraw0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                G16_TIE(RA);
+                G16_TIE(RB);
+                G16_TIE(RD);
+                q_extract(1, Qv, d2);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) q_deq4(Qv[i], d2, O[2 * i], O[2 * i + 1]);
+                G16Q_WRITE(1);
+            }
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(QRQ + 3 * APW) : "memory");  // A stage 0 and raw chunk 1 landed; this thread's B writes done
+            asm volatile("s_barrier" ::: "memory");
+            G16_RD(A0[0], aad0, 0);
+            G16_RD(A0[1], aad0, 2048);
+            G16_RD(BL[0], badq, (0 * KSTEPS) * 1024);
+            G16_RD(BL[1], badq, (1 * KSTEPS) * 1024);
+            if constexpr (CL > 2) G16_RD(BL[CL - 1], badq, (2 * KSTEPS) * 1024);
+            G16_RD(BH0[0], badq, ((CB - 2) * KSTEPS) * 1024);
+            G16_RD(BH0[1], badq, ((CB - 1) * KSTEPS) * 1024);
+            int buf = 0, kt = 0, rs = 0;  // rs: raw slot of chunk kt / 2
+            // first k-step of iteration kt: the raw bytes of stage kt + 2 (block qb_ of chunk kt / 2 + 1) into registers
+#define G16Q_RD_HOOK(I_)                                                                                              \
+    do {                                                                                                             \
+        if ((I_) == 0 && qmode_ != 2) G16Q_RAW_READ(qb_, qraw0 + (uint32_t)((rs == QNRAW - 1 ? 0 : rs + 1) * QRAWB)); \
+    } while (0)
+            // second k-step: LDS-DMA of A stage kt + 4 (+ raw chunk kt / 2 + 3 when kt is even) and the conversion of stage kt + 2 into B slot qb_
+#define G16Q_DQ_HOOK(I_)                                                                                              \
+    do {                                                                                                             \
+        if (qmode_ == 0 && (I_) < APW) q_issue_a((I_), kt0 + kt + NST, fbuf);                                        \
+        if (qmode_ == 0 && qb_ == 0 && (I_) >= 2 && (I_) - 2 < QRQ) q_issue_raw_piece((I_) - 2 < QPI ? (I_) - 2 : QPI, (kt >> 1) + QNRAW, rs); \
+        if (qmode_ != 2) {                                                                                           \
+            if ((I_) == 0) q_extract(qb_, Qv, qd2);                                                                  \
+            if ((I_) == 1) {                                                                                         \
+                q_deq4(Qv[0], qd2, O[0], O[1]);                                                                      \
+                q_deq4(Qv[1], qd2, O[2], O[3]);                                                                      \
+            }                                                                                                        \
+            if ((I_) == 2) {                                                                                         \
+                q_deq4(Qv[2], qd2, O[4], O[5]);                                                                      \
+                q_deq4(Qv[3], qd2, O[6], O[7]);                                                                      \
+            }                                                                                                        \
+            if ((I_) == 3) G16Q_WRITE(qb_);                                                                          \
+        }                                                                                                            \
+    } while (0)
+            static_assert(APW == 2 && QRQ <= 3, "hook slots: two A pieces, then up to three raw pieces");
+#define G16Q_ITER(B_, MODE_, W_)                                                                                      \
+    do {                                                                                                             \
+        constexpr int qb_ = (B_), qmode_ = (MODE_);                                                                  \
+        const uint32_t sa = (uint32_t)buf * ABYTES;                                                                  \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                           \
+        G16_TIE_FRAGS(A0, BH0);                                                                                      \
+        G16_KSTEP_H(A0, A1, BH0, BH1, aad1 + sa, badq + (uint32_t)(qb_ * BBYTES), 1, G16Q_RD_HOOK);                   \
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(W_) : "memory");                                         \
+        G16_TIE_FRAGS(A1, BH1);                                                                                      \
+        if (qmode_ != 2) {                                                                                           \
+            G16_TIE(RA);                                                                                             \
+            G16_TIE(RB);                                                                                             \
+            G16_TIE(RD);                                                                                             \
+        }                                                                                                            \
+        asm volatile("s_barrier" ::: "memory");                                                                      \
+        const int fbuf = buf;                                                                                        \
+        (void)fbuf;                                                                                                  \
+        buf               = buf == NST - 1 ? 0 : buf + 1;                                                            \
+        const uint32_t sn = (uint32_t)buf * ABYTES;                                                                  \
+        uint32_t Qv[4], O[8];                                                                                        \
+        qhalf2_t qd2;                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        G16_KSTEP_H(A1, A0, BH1, BH0, aad0 + sn, badq + (uint32_t)((1 - qb_) * BBYTES), 0, G16Q_DQ_HOOK);             \
+        ++kt;                                                                                                        \
+    } while (0)
+            // steady state, two iterations per pass (the block of the pair is a compile-time constant): kt even, kt + NST + 1 < nt
+            for (; kt + NST < nt;) {
+                G16Q_ITER(0, 0, 2 * APW + QRQ);
+                G16Q_ITER(1, 0, 2 * APW + QRQ);
+                rs = rs == QNRAW - 1 ? 0 : rs + 1;
+            }
+            // drain: stages nt - 4 .. nt - 1; the first two iterations still convert stages nt - 2 / nt - 1
+            G16Q_ITER(0, 1, 2 * APW + QRQ);
+            G16Q_ITER(1, 1, APW + QRQ);
+            G16Q_ITER(0, 2, 0);
+            G16Q_ITER(1, 2, 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#undef G16Q_ITER
+#undef G16Q_DQ_HOOK
+#undef G16Q_RD_HOOK
+#undef G16Q_WRITE
+#undef G16Q_RAW_READ
+        } else {
         if (WEXTRA != 0 && w_short)
             G16_PIPE_LOOP(NPT - 1);
         else
             G16_PIPE_LOOP(NPT);
+        }
 #undef G16_PIPE_LOOP
 #undef G16_DMA_HOOK
 #undef G16_TIE_FRAGS
@@ -896,6 +1150,18 @@ int gemm16_geglu_mode(int64_t rows, int64_t M, int64_t K) {
     const int tile = g16_pick_tile(rows, M, 2, false, 0, rup64(K, 64) / 32, 1);
     return (tile == G16_T160 || tile == G16_T160N || tile == G16_T320) ? 2 : 1;
 }
+// in-loop dequantisation (k_gemm16<..., QT>): shapes whose launch takes the pipelined 256 x 256 tile anyway, whole column tiles, an even number (>= 6) of K stages
+// per K slice, weight rows that start 4-byte aligned (K / 32 even: K % 64 == 0).  Option "qinloop_min_rows" (default 513 = right above k_qgemm16's range; 0 = off)
+static int g_g16_qinloop_min_rows = 513;
+void gemm16_set_qinloop_min_rows(int v) { g_g16_qinloop_min_rows = v; }
+bool gemm16_qinloop_supported(int wtype, int64_t rows, int64_t M, int64_t K, int mul, int split) {
+    if (g_g16_qinloop_min_rows <= 0 || rows < g_g16_qinloop_min_rows || (wtype != 8 && wtype != 2)) return false;
+    if (g_g16_variant != 3 || !g16_bk32() || g_g16_swp || g_g16_force_tile >= 0 || g_g16_streamk) return false;
+    if (M % 256 != 0 || K % 64 != 0 || K < 192 || g16_use_bn64(rows, M, mul)) return false;
+    const int64_t nt = K / 32;
+    if (split > 1 || gemm16_split_k(rows, M, K, false) > 1) return false;  // (K slices: not yet)
+    return g16_pick_tile(rows, M, 0, false, 0, nt, mul) == G16_T256P;
+}
 // a Linear of this shape runs on the pipelined 256 x 256 tile without K slices: the launches that may carry Epilogue::split_col
 bool gemm16_split_col_supported(int64_t rows, int64_t M, int64_t K) {
     if (g_g16_variant != 3 || !g16_bk32() || g_g16_swp || M % 256 != 0 || M % 160 == 0 || g16_use_bn64(rows, M, 1)) return false;
@@ -923,6 +1189,10 @@ static void g16_launch(hipStream_t s, G16Args& g, int64_t rows, double flops, do
     const int mul     = (!CONV_ && g.multi > 1) ? g.multi : 1;  // sibling Linears in one launch: mul x the column tiles
     if (BN_ == 128 && g_g16_variant == 3 && (!g.sk_cnt || g.sk_grid > 0)) {
         const int tile = g16_pick_tile(rows, g.C, g.geglu_inner > 0 ? (g.geglu16 ? 2 : 1) : 0, CONV_, g.split_k > 1 ? g.split_k : 0, g.nt, mul);  // the GEGLU pairing is laid out for 128-column tiles
+        if (g.qt && (tile != G16_T256P || g.sk_grid > 0 || g.C % 256 != 0 || g.nt < 6 || (g.nt & 1) || (g.split_k > 1 && ((g.nt_slice & 1) || g.nt_slice < 6 || g.nt - (g.split_k - 1) * g.nt_slice < 6)))) {
+            fprintf(stderr, "ggml-mi355x: in-loop dequantisation planned for a launch that does not take the pipelined 256 x 256 tile (tile %d, rows %lld, M %lld, K stages %d)\n", tile, (long long)rows, (long long)g.C, g.nt);
+            abort();
+        }
         if (g.geglu_inner > 0 && g.geglu16 && tile != G16_T160 && tile != G16_T160N && tile != G16_T320) {
             fprintf(stderr, "ggml-mi355x: GEGLU launch planned on the 16-column interleave, but its tile takes the paired image\n");
             abort();
@@ -941,7 +1211,7 @@ static void g16_launch(hipStream_t s, G16Args& g, int64_t rows, double flops, do
             }
         }
         if constexpr (!CONV_) {
-            const int rtm = (tile == G16_T256P && ny == 1 && mul == 1 && g.geglu_inner == 0 && !g.sk_cnt && g.split_col == 0) ? g16_tail_rows(rows, g.C) : 0;  // the tail runs on tiles whose epilogue has no column-range store (split_col is compiled into the 256 x 256 pipelined tile only)
+            const int rtm = (tile == G16_T256P && ny == 1 && mul == 1 && g.geglu_inner == 0 && !g.sk_cnt && g.split_col == 0 && !g.qt) ? g16_tail_rows(rows, g.C) : 0;  // the tail runs on tiles whose epilogue has no column-range store (split_col is compiled into the 256 x 256 pipelined tile only)
             if (rtm > 0) {
                 // row split: whole rounds of 256 x 256 tiles, then the remaining rows on whatever tile their shape picks (epilogue indices are absolute rows)
                 const double fm = (double)((int64_t)rtm * 256) / (double)rows;
@@ -991,6 +1261,14 @@ static void g16_launch(hipStream_t s, G16Args& g, int64_t rows, double flops, do
             } else if (tile == G16_T256P) {
                 g.ncol_tiles = (int)((g.C + 255) / 256);
                 if constexpr (!CONV_) {
+                    if (g.qt) {  // raw quantised rows, dequantised in the main loop
+                        const dim3 grid((unsigned)(rt256 * g.ncol_tiles * mul), ny);
+                        if (g.qt == 8)
+                            k_gemm16<256, 256, false, 32, 4, 4, 2, 1, false, false, 8><<<grid, 512, 0, s>>>(g);
+                        else
+                            k_gemm16<256, 256, false, 32, 4, 4, 2, 1, false, false, 4><<<grid, 512, 0, s>>>(g);
+                        return;
+                    }
                     if (g.C % 256 != 0) g.wblk_lim = (int)(rup64(g.C, 128) / 32);
                     if (g16_swp_ok(g)) {
                         k_gemm16<256, 256, false, 32, 4, 4, 2, 1, true><<<dim3((unsigned)(rt256 * g.ncol_tiles * mul), ny), 512, 0, s>>>(g);
@@ -1474,6 +1752,14 @@ void launch_gemm16_linear(hipStream_t s, float* dst, void* dst16, int64_t ldd16,
     g.abl = g_g16_abl;
 #endif
     g.ep    = {e.bias, e.residual, e.scale, e.gate, e.gate_L, e.gelu};
+    if (e.qtype) {
+        g.qt         = e.qtype == 8 ? 8 : 4;
+        g.qrow_bytes = e.qrow_bytes;
+        if ((e.qtype != 8 && e.qtype != 2) || e.qrow_bytes % 4 != 0 || ((uintptr_t)wswz & 15) != 0 || K % 64 != 0) {
+            fprintf(stderr, "ggml-mi355x: invalid in-loop dequantisation request (type %d, row bytes %lld)\n", e.qtype, (long long)e.qrow_bytes);
+            abort();
+        }
+    }
     if (e.split_col > 0) {
         if (!gemm16_split_col_supported(rows, M, K) || !dst || dst16 || hm_d > 0 || e.gate || e.gelu || e.residual || !e.split_dst16 || e.split_col % 256 != 0 || e.split_col >= M || M % 160 == 0 || (splitk_ws && splitk_S > 1)) {
             fprintf(stderr, "ggml-mi355x: invalid column-range epilogue request (split_col)\n");

@@ -108,10 +108,18 @@ struct Epilogue {
     int64_t split_col     = 0;
     void* split_dst16     = nullptr;
     int64_t split_ldd16   = 0;
+    // gemm16 linear only: the weight pointer(s) handed to the launch are NOT f16 images but the RAW GGUF rows of a q8_0 (qtype 8) / q4_0 (qtype 2) tensor,
+    // qrow_bytes apart; the blocks are dequantised inside the GEMM's main loop (k_gemm16<..., QT>).  Only for launches gemm16_qinloop_supported accepts.
+    int qtype             = 0;
+    int64_t qrow_bytes    = 0;
 };
 // ---- gemm16.hip: second-generation contraction, both operands f16 via LDS-DMA -------------------------------
 // a16: f16 row-major [rows][lda] (K contiguous, padded to 64); output f32 [rows][ldd] and/or f16 [rows][ldd16]
 void gemm16_init();
+// a Linear of this shape over raw q8_0 (wtype 8) / q4_0 (wtype 2) rows runs on the pipelined 256 x 256 tile with the blocks dequantised in the main loop:
+// no f16 weight image, resident or rebuilt (mul: sibling weights in one launch; split: the launch's K slices, <= 1 = none)
+bool gemm16_qinloop_supported(int wtype, int64_t rows, int64_t M, int64_t K, int mul, int split);
+void gemm16_set_qinloop_min_rows(int v);
 void gemm16_set_tap_major(int v);  // A/B: conv K order (tap, channel block) instead of (channel block, tap)
 int gemm16_tap_major();
 void gemm16_set_splitk_target(int v);

@@ -425,6 +425,65 @@ def test_quantised_linear_just_in_time_image(sd, oracle, gpu, rng, qname, tokens
     assert rel_l2(outs[1].reshape(tokens, M), exact) < 2e-3
 
 
+@pytest.mark.parametrize("qname", ["Q8_0", "Q4_0"])
+@pytest.mark.parametrize("tokens,K,M,epi", [(4096, 2048, 3072, "bias"), (4352, 3072, 3072, "res"), (4000, 2304, 3072, "gelu"), (6200, 2048, 2048, "bias"),
+                                            (4096, 2048, 3072, "gate")])
+def test_quantised_linear_dequantised_in_the_gemm_main_loop(sd, oracle, gpu, rng, qname, tokens, K, M, epi):
+    """In-loop dequantisation (k_gemm16<..., QT>, option qinloop_min_rows): above k_qgemm16's row range a q8_0 / q4_0 Linear whose launch takes the pipelined
+    256 x 256 tile reads the RAW GGUF blocks — LDS-DMA into a raw ring, dequantised once per workgroup into the B stage of the MFMA loop — and keeps no f16
+    weight image, cached or rebuilt.  Same operand values (f16(d * q)) and the same summation order as the image path on the same tile: the two outputs must be
+    IDENTICAL; ragged last row tiles (4000, 6200, 4352 rows), K stages 64 / 72 / 96, epilogues bias / residual / GELU -> f16 operand image / DiT gate."""
+    if not _on_gpu():
+        pytest.skip("planner option of the MI355X backend")
+    wtype = Q8_0 if qname == "Q8_0" else Q4_0
+    x = rng.standard_normal((tokens, K)).astype(np.float32)
+    w = (rng.standard_normal((M, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(M).astype(np.float32)
+    r = rng.standard_normal((tokens, M)).astype(np.float32)
+    gt = rng.standard_normal((1, M)).astype(np.float32)
+    w2 = (rng.standard_normal((256, M)) / np.sqrt(M)).astype(np.float32)
+
+    def build(g, L):
+        xin0 = g.input(x.reshape(1, tokens, K)) if epi == "gate" else g.input(x)
+        y = L.ggml_add_inplace(g.ctx, L.ggml_mul_mat(g.ctx, g.weight(w, wtype), xin0), g.weight(b, F32))
+        if epi == "res":
+            y = L.ggml_add(g.ctx, y, g.input(r))
+        elif epi == "gelu":   # fc1 -> GELU -> fc2 (f16 weights): fc1's epilogue writes fc2's operand image
+            y = L.ggml_mul_mat(g.ctx, g.weight(w2, F16), L.ggml_gelu_inplace(g.ctx, y))
+        elif epi == "gate":   # x + (Linear) * gate
+            y = L.ggml_add(g.ctx, g.input(r.reshape(1, tokens, M)), L.ggml_mul(g.ctx, y, g.input(gt.reshape(1, 1, M))))
+        return y
+
+    outs = []
+    for qin in (0, 513):
+        sd.backend_set_option("qinloop_min_rows", qin)
+        before = sd.backend_stats()["qinloop_linears"]
+        try:
+            with Graph(gpu) as g:
+                outs.append(g.run(build(g, sd.lib())))
+            with Graph(gpu) as g:
+                again = g.run(build(g, sd.lib()))
+        finally:
+            sd.backend_set_option("qinloop_min_rows", 513)   # the default
+        assert sd.backend_stats()["qinloop_linears"] - before == (2 if qin else 0)
+        assert np.array_equal(outs[-1], again)
+    assert np.isfinite(outs[1]).all()
+    assert np.array_equal(outs[0], outs[1])
+    rows = np.unique(np.concatenate([rng.integers(0, tokens, 40), [0, 255, 256, tokens - 1]]))
+    lin = x[rows].astype(np.float16).astype(np.float64) @ dequant(w, wtype).astype(np.float64).T + b
+    if epi == "res":
+        exact = lin + r[rows]
+    elif epi == "gate":
+        exact = r[rows] + lin * gt
+    elif epi == "gelu":
+        gl = 0.5 * lin * (1.0 + np.tanh(np.sqrt(2.0 / np.pi) * (lin + 0.044715 * lin ** 3)))
+        exact = gl.astype(np.float16).astype(np.float64) @ w2.astype(np.float16).astype(np.float64).T
+    else:
+        exact = lin
+    got = outs[1].reshape(tokens, -1)[rows]
+    assert np.abs(got - exact).max() < 3e-3 * max(1.0, float(np.abs(exact).max()))
+
+
 @pytest.mark.parametrize("d,H,L,M,flash", [(64, 2, 200, 384, True), (128, 1, 77, 128, True), (64, 3, 130, 320, False), (40, 2, 96, 112, True)])
 def test_single_block_tail_concat_assembled_as_operand_image(sd, oracle, gpu, rng, d, H, L, M, flash):
     """FLUX single block tail (flux.hpp:594-700): t = linear1(x) -> q / k / v per-head views + mlp view; attn = flash(q, k, v) -> VIEW -> CONT;
