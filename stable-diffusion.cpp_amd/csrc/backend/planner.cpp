@@ -4052,6 +4052,7 @@ void planner_set_option(const char* key, int value) {
     else if (!strcmp(key, "hoist_kv")) g_opt.hoist_kv = value;
     else if (!strcmp(key, "fgemv_max_rows")) fgemv_set_max_rows(value);
     else if (!strcmp(key, "qgemm16_max_rows")) qgemm16_set_max_rows(value);
+    else if (!strcmp(key, "qgemm16_pf")) qgemm16_set_pf(value);
     else if (!strcmp(key, "qgemm16_rb")) qgemm16_set_rb(value);
     else if (!strcmp(key, "splitk_inkernel")) gemm16_set_splitk_inkernel(value);
     else if (!strcmp(key, "splitk_in_target")) gemm16_set_splitk_in_target(value);

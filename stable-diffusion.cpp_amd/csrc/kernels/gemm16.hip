@@ -539,26 +539,30 @@ __global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g
                 qsrc[r]       = (const char*)g.W + (int64_t)(col0 + col) * g.qrow_bytes + ((pp ^ qf(col)) << 4);
             }
             const char* qsrcT = (const char*)g.W + (int64_t)(col0 + wave * 32 + (lane & 31)) * g.qrow_bytes + QTOFF;
-            // byte offsets of this thread's raw reads inside a raw slot, per block of the pair ([0] / [1]): two 16-byte pieces (A, B) and the dword holding the scale (D)
+            // byte offsets of this thread's raw reads inside a raw slot, per block of the pair ([0] / [1]): ONE 16-byte piece (A), the dword that follows the
+            // piece's bytes in the row (B: the fifth dword of a 2-byte-misaligned run) and the dword holding the block scale (D).  A thread needs 16 quant bytes +
+            // the scale, 18 bytes: it reads 20 (24 for the second half of a q8_0 pair's first block, whose scale sits 18 bytes ahead of its quants)
             uint32_t qoA[2], qoB[2], qoD[2];
             {
                 const int f = qf(qc);
                 auto pc = [&](int p) { return (uint32_t)(qc * QPB + ((p ^ f) << 4)); };
                 const uint32_t T = (uint32_t)(BN * QPB + qc * 16);
                 if constexpr (QT == 8) {
-                    qoA[0] = qh ? pc(1) : pc(0);
-                    qoB[0] = qh ? pc(2) : pc(1);
-                    qoD[0] = pc(0);
-                    qoA[1] = qh ? T : pc(2);
-                    qoB[1] = qh ? T : pc(3);
-                    qoD[1] = pc(2);
+                    // block 0: scale at bytes 0-1, quants 2..33; block 1: scale at 34-35, quants 36..67 (the tail piece holds bytes 52..67)
+                    qoA[0] = qh ? pc(1) : pc(0);   // bytes 16..31 | 0..15
+                    qoB[0] = qh ? pc(2) : pc(1);   // dword at 32 | 16
+                    qoD[0] = pc(0);                // scale: low half of the dword at 0
+                    qoA[1] = qh ? T : pc(2);       // bytes 52..67 | 32..47
+                    qoB[1] = pc(3);                // (h = 0) dword at 48
+                    qoD[1] = pc(2);                // scale: high half of the dword at 32
                 } else {
-                    qoA[0] = pc(0);
-                    qoB[0] = pc(1);
+                    // block 0: scale at 0-1, nibble bytes 2..17; block 1: scale at 18-19, nibble bytes 20..35 (= the tail piece)
+                    qoA[0] = pc(0);                // bytes 0..15
+                    qoB[0] = pc(1);                // dword at 16
                     qoD[0] = pc(0);
-                    qoA[1] = T;
-                    qoB[1] = T;
-                    qoD[1] = pc(1);
+                    qoA[1] = T;                    // bytes 20..35
+                    qoB[1] = pc(1);
+                    qoD[1] = pc(1);                // scale: high half of the dword at 16
                 }
             }
             const uint32_t qraw0 = lds0 + (uint32_t)QR0;
@@ -566,8 +570,8 @@ __global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g
             const uint32_t badq  = lds0 + (uint32_t)(QB0 + (wc * CB * KSTEPS) * 1024 + lane * 16);
             const int qnch       = nt >> 1;          // 2-stage chunks of this K range (kt0 and nt are even: launcher precondition)
             const int64_t qch0   = (int64_t)(kt0 >> 1) * (2 * QBLK);
-            qu32x4_t RA, RB;
-            uint32_t RD;
+            qu32x4_t RA;
+            uint32_t RB = 0, RD = 0;
             auto q_issue_raw_piece = [&](int i, int ch, int slot) {  // LDS-DMA piece i (< QPI: piece region, QPI: tail region) of chunk ch into raw slot `slot`
                 const int cc      = ch < qnch ? ch : qnch - 1;  // past the end: a harmless re-fetch of the last chunk (keeps the per-iteration DMA count constant)
                 const int64_t off = qch0 + (int64_t)cc * (2 * QBLK);
@@ -580,19 +584,19 @@ __global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g
             };
             auto q_issue_a = [&](int q, int ktabs, int slot) { GLDS16(asrc[q] + (int64_t)ktabs * BK, smem + slot * ABYTES + (wave * APW + q) * 1024); };
             // registers -> the 16 quant bytes (Qv) and the block scale of block B_ of the pair
-            auto q_extract = [&](int b, uint32_t (&Qv)[4], qhalf2_t& d2) {
-                uint32_t dbits;
-                if (b == 0) {
+            // part 1: the 16 quant bytes of block b out of the raw registers (realigned when the run starts 2 bytes into a dword) + the scale's 16 bits
+            auto q_extract1 = [&](int b, uint32_t (&Qv)[4], uint32_t& dbits) {
+                if (b == 0) {  // the run starts 2 bytes into RA (scale or a neighbour's quants in front of it)
                     Qv[0] = __builtin_amdgcn_alignbit(RA[1], RA[0], 16);
                     Qv[1] = __builtin_amdgcn_alignbit(RA[2], RA[1], 16);
                     Qv[2] = __builtin_amdgcn_alignbit(RA[3], RA[2], 16);
-                    Qv[3] = __builtin_amdgcn_alignbit(RB[0], RA[3], 16);
+                    Qv[3] = __builtin_amdgcn_alignbit(RB, RA[3], 16);
                     dbits = ((QT == 8 && qh) ? RD : RA[0]) & 0xffffu;
                 } else if (QT == 8 && !qh) {
                     Qv[0] = RA[1];
                     Qv[1] = RA[2];
                     Qv[2] = RA[3];
-                    Qv[3] = RB[0];
+                    Qv[3] = RB;
                     dbits = RA[0] >> 16;
                 } else {
                     Qv[0] = RA[0];
@@ -601,6 +605,9 @@ __global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g
                     Qv[3] = RA[3];
                     dbits = RD >> 16;
                 }
+            };
+            // part 2: nibble select (q4_0: this thread's half of the block is the low or the high nibbles) / sign flip (q8_0: u = q + 128), scale as half2
+            auto q_extract2 = [&](uint32_t (&Qv)[4], uint32_t dbits, qhalf2_t& d2) {
                 if constexpr (QT == 4) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) Qv[i] = (qh ? Qv[i] >> 4 : Qv[i]) & 0x0F0F0F0Fu;
@@ -611,6 +618,11 @@ __global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g
                 const _Float16 d = __builtin_bit_cast(_Float16, (uint16_t)dbits);
                 d2               = (qhalf2_t){d, d};
             };
+            auto q_extract = [&](int b, uint32_t (&Qv)[4], qhalf2_t& d2) {
+                uint32_t dbits;
+                q_extract1(b, Qv, dbits);
+                q_extract2(Qv, dbits, d2);
+            };
             // four bytes -> two half2 {1024 + b0, 1024 + b1}, {1024 + b2, 1024 + b3} (exponent byte 0x64), minus 1152 / 1032 = the exact integer, times d: f16(d * q)
             auto q_deq4 = [&](uint32_t u, qhalf2_t d2, uint32_t& o01, uint32_t& o23) {
                 const qhalf2_t off = {(_Float16)(QT == 8 ? 1152.f : 1032.f), (_Float16)(QT == 8 ? 1152.f : 1032.f)};
@@ -619,17 +631,17 @@ __global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g
                 o01                = __builtin_bit_cast(uint32_t, (__builtin_bit_cast(qhalf2_t, p01) - off) * d2);
                 o23                = __builtin_bit_cast(uint32_t, (__builtin_bit_cast(qhalf2_t, p23) - off) * d2);
             };
+    // (which of the three reads a (type, block, half) combination needs is a compile-time / wave-uniform fact: see the offset table above)
 #define G16Q_RAW_READ(B_, RBASE_)                                                                                      \
     do {                                                                                                             \
         asm volatile("ds_read_b128 %0, %1" : "=v"(RA) : "v"((RBASE_) + qoA[B_]));                                    \
-        asm volatile("ds_read_b128 %0, %1" : "=v"(RB) : "v"((RBASE_) + qoB[B_]));                                    \
-        asm volatile("ds_read_b32 %0, %1" : "=v"(RD) : "v"((RBASE_) + qoD[B_]));                                     \
+        if (((B_) == 0) || (QT == 8 && !qh)) asm volatile("ds_read_b32 %0, %1" : "=v"(RB) : "v"((RBASE_) + qoB[B_])); \
+        if ((QT == 4 && (B_) == 1) || (QT == 8 && qh)) asm volatile("ds_read_b32 %0, %1" : "=v"(RD) : "v"((RBASE_) + qoD[B_])); \
     } while (0)
-#define G16Q_WRITE(SLOT_)                                                                                             \
+#define G16Q_WRITE(SLOT_, HALF_)                                                                                      \
     do {                                                                                                             \
-        const qu32x4_t w0_ = {O[0], O[1], O[2], O[3]}, w1_ = {O[4], O[5], O[6], O[7]};                               \
-        asm volatile("ds_write_b128 %0, %1" ::"v"(qwB + (uint32_t)((SLOT_) * BBYTES)), "v"(w0_) : "memory");           \
-        asm volatile("ds_write_b128 %0, %1 offset:512" ::"v"(qwB + (uint32_t)((SLOT_) * BBYTES)), "v"(w1_) : "memory"); \
+        const qu32x4_t w_ = {O[4 * (HALF_)], O[4 * (HALF_) + 1], O[4 * (HALF_) + 2], O[4 * (HALF_) + 3]};           \
+        asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(qwB + (uint32_t)((SLOT_) * BBYTES)), "v"(w_), "n"(512 * (HALF_)) : "memory"); \
     } while (0)
             // ---- fill: raw chunks 0 .. 2 and A stages 0 .. 3, in the order the steady state would have issued them
             q_issue_raw_piece(0, 0, 0);
@@ -651,27 +663,31 @@ __global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g
             for (int q = 0; q < APW; ++q) q_issue_a(q, kt0 + 3, 3);
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * QRQ + 4 * APW) : "memory");  // raw chunk 0 landed
             asm volatile("s_barrier" ::: "memory");
-            {   // B stages 0 and 1 (both blocks of chunk 0), outside the pipeline
-                uint32_t Qv[4], O[8];
-                qhalf2_t d2;
+            // conversion state carried from the second k-step of an iteration (which converts the first 8 weights of stage kt + 2) to the first k-step of the
+            // next one (which converts the other 8): the last two quant dwords and the scale
+            uint32_t Qv[4], qdbits = 0;
+            qhalf2_t qd2;
+            {   // B stage 0 (block 0 of chunk 0) and the first half of B stage 1, outside the pipeline
+                uint32_t O[8];
                 G16Q_RAW_READ(0, qraw0);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 G16_TIE(RA);
                 G16_TIE(RB);
                 G16_TIE(RD);
-                q_extract(0, Qv, d2);
+                q_extract(0, Qv, qd2);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) q_deq4(Qv[i], d2, O[2 * i], O[2 * i + 1]);
-                G16Q_WRITE(0);
+                for (int i = 0; i < 4; ++i) q_deq4(Qv[i], qd2, O[2 * i], O[2 * i + 1]);
+                G16Q_WRITE(0, 0);
+                G16Q_WRITE(0, 1);
                 G16Q_RAW_READ(1, qraw0);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 G16_TIE(RA);
                 G16_TIE(RB);
                 G16_TIE(RD);
-                q_extract(1, Qv, d2);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) q_deq4(Qv[i], d2, O[2 * i], O[2 * i + 1]);
-                G16Q_WRITE(1);
+                q_extract(1, Qv, qd2);
+                q_deq4(Qv[0], qd2, O[0], O[1]);
+                q_deq4(Qv[1], qd2, O[2], O[3]);
+                G16Q_WRITE(1, 0);
             }
             asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(QRQ + 3 * APW) : "memory");  // A stage 0 and raw chunk 1 landed; this thread's B writes done
             asm volatile("s_barrier" ::: "memory");
@@ -683,40 +699,74 @@ __global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g
             G16_RD(BH0[0], badq, ((CB - 2) * KSTEPS) * 1024);
             G16_RD(BH0[1], badq, ((CB - 1) * KSTEPS) * 1024);
             int buf = 0, kt = 0, rs = 0;  // rs: raw slot of chunk kt / 2
-            // first k-step of iteration kt: the raw bytes of stage kt + 2 (block qb_ of chunk kt / 2 + 1) into registers
+            // first k-step of iteration kt: the raw bytes of stage kt + 2 (block qb_ of chunk kt / 2 + 1) into registers; the second 8 weights of stage kt + 1
+            // (started by the previous iteration) converted and stored into B slot 1 - qb_ — the barrier of this iteration publishes that stage
+#define G16Q_PIN2(A_, B_)                                                                                             \
+    do {                                                                                                             \
+        G16_TIE(A_);                                                                                                 \
+        G16_TIE(B_);                                                                                                 \
+    } while (0)
+    // (every slice of the conversion is pinned to its hook by passing its results through an empty asm volatile: left alone, the compiler sinks the
+    // side-effect-free VALU work down to its first use and the whole conversion runs in one lump in front of the ds_write)
 #define G16Q_RD_HOOK(I_)                                                                                              \
     do {                                                                                                             \
-        if ((I_) == 0 && qmode_ != 2) G16Q_RAW_READ(qb_, qraw0 + (uint32_t)((rs == QNRAW - 1 ? 0 : rs + 1) * QRAWB)); \
-    } while (0)
-            // second k-step: LDS-DMA of A stage kt + 4 (+ raw chunk kt / 2 + 3 when kt is even) and the conversion of stage kt + 2 into B slot qb_
-#define G16Q_DQ_HOOK(I_)                                                                                              \
-    do {                                                                                                             \
-        if (qmode_ == 0 && (I_) < APW) q_issue_a((I_), kt0 + kt + NST, fbuf);                                        \
-        if (qmode_ == 0 && qb_ == 0 && (I_) >= 2 && (I_) - 2 < QRQ) q_issue_raw_piece((I_) - 2 < QPI ? (I_) - 2 : QPI, (kt >> 1) + QNRAW, rs); \
-        if (qmode_ != 2) {                                                                                           \
-            if ((I_) == 0) q_extract(qb_, Qv, qd2);                                                                  \
+        if ((I_) == 0 && qconv_) G16Q_RAW_READ(qb_, qraw0 + (uint32_t)((rs == QNRAW - 1 ? 0 : rs + 1) * QRAWB));      \
+        if (qfin_) {                                                                                                 \
             if ((I_) == 1) {                                                                                         \
-                q_deq4(Qv[0], qd2, O[0], O[1]);                                                                      \
-                q_deq4(Qv[1], qd2, O[2], O[3]);                                                                      \
+                q_deq4(Qv[2], qd2, O[4], O[5]);                                                                      \
+                G16Q_PIN2(O[4], O[5]);                                                                               \
             }                                                                                                        \
             if ((I_) == 2) {                                                                                         \
-                q_deq4(Qv[2], qd2, O[4], O[5]);                                                                      \
                 q_deq4(Qv[3], qd2, O[6], O[7]);                                                                      \
+                G16Q_PIN2(O[6], O[7]);                                                                               \
             }                                                                                                        \
-            if ((I_) == 3) G16Q_WRITE(qb_);                                                                          \
+            if ((I_) == 3) G16Q_WRITE(1 - qb_, 1);                                                                   \
+        }                                                                                                            \
+    } while (0)
+            // second k-step: LDS-DMA of A stage kt + 4 (+ raw chunk kt / 2 + 3 when kt is even); the first 8 weights of stage kt + 2 into B slot qb_
+#define G16Q_DQ_HOOK(I_)                                                                                              \
+    do {                                                                                                             \
+        if (qdma_ && (I_) < APW) q_issue_a((I_), kt0 + kt + NST, fbuf);                                              \
+        if (qdma_ && qb_ == 0 && (I_) >= 2 && (I_) - 2 < QRQ) q_issue_raw_piece((I_) - 2 < QPI ? (I_) - 2 : QPI, (kt >> 1) + QNRAW, rs); \
+        if (qconv_) {                                                                                                \
+            if ((I_) == 0) {                                                                                         \
+                q_extract1(qb_, Qv, qdbits);                                                                         \
+                G16Q_PIN2(Qv[0], Qv[1]);                                                                             \
+                G16Q_PIN2(Qv[2], Qv[3]);                                                                             \
+                G16_TIE(qdbits);                                                                                     \
+            }                                                                                                        \
+            if ((I_) == 1) {                                                                                         \
+                q_extract2(Qv, qdbits, qd2);                                                                         \
+                G16Q_PIN2(Qv[0], Qv[1]);                                                                             \
+                G16Q_PIN2(Qv[2], Qv[3]);                                                                             \
+                G16_TIE(qd2);                                                                                        \
+            }                                                                                                        \
+            if ((I_) == 2) {                                                                                         \
+                q_deq4(Qv[0], qd2, O[0], O[1]);                                                                      \
+                G16Q_PIN2(O[0], O[1]);                                                                               \
+            }                                                                                                        \
+            if ((I_) == 3) {                                                                                         \
+                q_deq4(Qv[1], qd2, O[2], O[3]);                                                                      \
+                G16Q_PIN2(O[2], O[3]);                                                                               \
+            }                                                                                                        \
+            if ((I_) == 4) G16Q_WRITE(qb_, 0);                                                                       \
         }                                                                                                            \
     } while (0)
             static_assert(APW == 2 && QRQ <= 3, "hook slots: two A pieces, then up to three raw pieces");
-#define G16Q_ITER(B_, MODE_, W_)                                                                                      \
+            // DMA_: issue LDS-DMA (steady state); CONV_: start the conversion of stage kt + 2; FIN_: finish the conversion of stage kt + 1; W_: LDS-DMA instructions
+            // that may stay in flight across the barrier
+#define G16Q_ITER(B_, DMA_, CONV_, FIN_, W_)                                                                          \
     do {                                                                                                             \
-        constexpr int qb_ = (B_), qmode_ = (MODE_);                                                                  \
+        constexpr int qb_ = (B_);                                                                                    \
+        constexpr bool qdma_ = (DMA_), qconv_ = (CONV_), qfin_ = (FIN_);                                             \
         const uint32_t sa = (uint32_t)buf * ABYTES;                                                                  \
+        uint32_t O[8];                                                                                               \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                           \
         G16_TIE_FRAGS(A0, BH0);                                                                                      \
         G16_KSTEP_H(A0, A1, BH0, BH1, aad1 + sa, badq + (uint32_t)(qb_ * BBYTES), 1, G16Q_RD_HOOK);                   \
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(W_) : "memory");                                         \
         G16_TIE_FRAGS(A1, BH1);                                                                                      \
-        if (qmode_ != 2) {                                                                                           \
+        if (qconv_) {                                                                                                \
             G16_TIE(RA);                                                                                             \
             G16_TIE(RB);                                                                                             \
             G16_TIE(RD);                                                                                             \
@@ -726,26 +776,25 @@ __global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g
         (void)fbuf;                                                                                                  \
         buf               = buf == NST - 1 ? 0 : buf + 1;                                                            \
         const uint32_t sn = (uint32_t)buf * ABYTES;                                                                  \
-        uint32_t Qv[4], O[8];                                                                                        \
-        qhalf2_t qd2;                                                                                                \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
         G16_KSTEP_H(A1, A0, BH1, BH0, aad0 + sn, badq + (uint32_t)((1 - qb_) * BBYTES), 0, G16Q_DQ_HOOK);             \
         ++kt;                                                                                                        \
     } while (0)
             // steady state, two iterations per pass (the block of the pair is a compile-time constant): kt even, kt + NST + 1 < nt
             for (; kt + NST < nt;) {
-                G16Q_ITER(0, 0, 2 * APW + QRQ);
-                G16Q_ITER(1, 0, 2 * APW + QRQ);
+                G16Q_ITER(0, true, true, true, 2 * APW + QRQ);
+                G16Q_ITER(1, true, true, true, 2 * APW + QRQ);
                 rs = rs == QNRAW - 1 ? 0 : rs + 1;
             }
-            // drain: stages nt - 4 .. nt - 1; the first two iterations still convert stages nt - 2 / nt - 1
-            G16Q_ITER(0, 1, 2 * APW + QRQ);
-            G16Q_ITER(1, 1, APW + QRQ);
-            G16Q_ITER(0, 2, 0);
-            G16Q_ITER(1, 2, 0);
+            // drain: stages nt - 4 .. nt - 1; the first two iterations still start the conversion of stages nt - 2 / nt - 1
+            G16Q_ITER(0, false, true, true, 2 * APW + QRQ);
+            G16Q_ITER(1, false, true, true, APW + QRQ);
+            G16Q_ITER(0, false, false, true, 0);
+            G16Q_ITER(1, false, false, false, 0);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #undef G16Q_ITER
 #undef G16Q_DQ_HOOK
+#undef G16Q_PIN2
 #undef G16Q_RD_HOOK
 #undef G16Q_WRITE
 #undef G16Q_RAW_READ

@@ -226,6 +226,7 @@ int qgemm16_split_k(int64_t rows, int64_t K, int64_t M);
 bool wswz_q_supported(int wtype, int64_t K);
 void launch_wswz_q(hipStream_t s, void* dst, const void* wraw, int wtype, int64_t K, int64_t R);
 void qgemm16_set_max_rows(int v);
+void qgemm16_set_pf(int v);  // segments of global loads in flight in k_qgemm16 (1 / 2)
 void launch_qgemm16(hipStream_t s, float* dst, void* dst16, int64_t ldd16, const void* a16, int64_t lda, int64_t rows, const void* wraw, int wtype, int64_t K,
                     int64_t M, const Epilogue& ep, float* splitk_ws = nullptr, int splitk_S = 1);
 // dst[i] = sum_s ws[s * n + i] + bias[i % C] + residual[i] (gemm16.hip's k_splitk_reduce on a row-major [rows][C] output)

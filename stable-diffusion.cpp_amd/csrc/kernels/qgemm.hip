@@ -553,7 +553,10 @@ __device__ __forceinline__ void qg_deq4(uint32_t u, half2_t off, half2_t d2, uin
     o23                = __builtin_bit_cast(uint32_t, h23);
 }
 
-template <int QT, int RB>
+// PF = 2 (round 6): TWO segments of global loads in flight (two register sets, loop unrolled by two).  With one set a workgroup's K loop was a chain of
+// nseg x (HBM round trip -> LDS -> dequantise -> MFMA) with ~0.3 us of arithmetic per link: FLUX's 256-token text-stream Linears ran at 0.27 TB/s of weight bytes
+// (58 us per launch, 76 launches = 4.4 ms of the step)
+template <int QT, int RB, int PF = 1>
 __global__ __launch_bounds__(256) void k_qgemm16(QG16Args g) {
     constexpr int BLK = QT == 8 ? 34 : 18;
     constexpr int SEG = 8;               // blocks per K segment (256 weights)
@@ -583,6 +586,37 @@ __global__ __launch_bounds__(256) void k_qgemm16(QG16Args g) {
         for (int i = 0; i < 16; ++i) acc[rb][i] = 0.f;
 
     u32x4_t wreg[NLW], areg[NLA];
+    u32x4_t wreg2[PF > 1 ? NLW : 1], areg2[PF > 1 ? NLA : 1];  // second register set (PF = 2)
+    auto fetch_into = [&](int seg, u32x4_t* wr, u32x4_t* ar) {
+#pragma unroll
+        for (int i = 0; i < NLW; ++i) {
+            const int idx = i * 64 + lane;
+            const int col = idx / NGC, gr = idx - col * NGC;
+            const int cc  = min(colw + col, g.M - 1);
+            wr[i]         = (u32x4_t){0, 0, 0, 0};
+            if (idx < NGW) wr[i] = *(const u32x4_t*)(g.W + (int64_t)cc * g.row_bytes + (int64_t)seg * CS + gr * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < NLA; ++i) {
+            const int idx     = i * 256 + (int)threadIdx.x;
+            const int row     = idx >> 5, gr = idx & 31;
+            const int64_t grw = row0 + row;
+            ar[i]             = (u32x4_t){0, 0, 0, 0};
+            if (grw < g.R) ar[i] = *(const u32x4_t*)(g.A + grw * g.lda + (int64_t)seg * 256 + gr * 8);
+        }
+    };
+    auto stash = [&](const u32x4_t* wr, const u32x4_t* ar) {  // registers -> LDS (between two workgroup barriers)
+#pragma unroll
+        for (int i = 0; i < NLW; ++i) {
+            const int idx = i * 64 + lane;
+            if (idx < NGW) *(u32x4_t*)(Ws + idx * 16) = wr[i];  // strip = [column][piece bytes]: idx * 16 = col * CS + gr * 16
+        }
+#pragma unroll
+        for (int i = 0; i < NLA; ++i) {
+            const int idx = i * 256 + (int)threadIdx.x;
+            *(u32x4_t*)(As + (idx >> 5) * AS + (idx & 31) * 16) = ar[i];
+        }
+    };
     auto fetch = [&](int seg) {
 #pragma unroll
         for (int i = 0; i < NLW; ++i) {
@@ -601,21 +635,7 @@ __global__ __launch_bounds__(256) void k_qgemm16(QG16Args g) {
             if (grw < g.R) areg[i] = *(const u32x4_t*)(g.A + grw * g.lda + (int64_t)seg * 256 + gr * 8);
         }
     };
-    if (seg0 < seg1) fetch(seg0);
-    for (int seg = seg0; seg < seg1; ++seg) {
-        __syncthreads();  // every wave is done reading the previous segment
-#pragma unroll
-        for (int i = 0; i < NLW; ++i) {
-            const int idx = i * 64 + lane;
-            if (idx < NGW) *(u32x4_t*)(Ws + idx * 16) = wreg[i];  // strip = [column][piece bytes]: idx * 16 = col * CS + gr * 16
-        }
-#pragma unroll
-        for (int i = 0; i < NLA; ++i) {
-            const int idx = i * 256 + (int)threadIdx.x;
-            *(u32x4_t*)(As + (idx >> 5) * AS + (idx & 31) * 16) = areg[i];
-        }
-        __syncthreads();
-        if (seg + 1 < seg1) fetch(seg + 1);  // in flight during the MFMAs below
+    auto compute_seg = [&]() {
 #pragma unroll
         for (int b = 0; b < SEG; ++b) {
             const char* blk  = Ws + n * CS + BLK * b;
@@ -662,6 +682,32 @@ __global__ __launch_bounds__(256) void k_qgemm16(QG16Args g) {
             for (int rb = 0; rb < RB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af0[rb], bf0, acc[rb], 0, 0, 0);
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af1[rb], bf1, acc[rb], 0, 0, 0);
+        }
+    };
+    if constexpr (PF > 1) {
+        if (seg0 < seg1) fetch_into(seg0, wreg, areg);
+        if (seg0 + 1 < seg1) fetch_into(seg0 + 1, wreg2, areg2);
+        for (int seg = seg0; seg < seg1; seg += 2) {
+            __syncthreads();  // every wave is done reading the previous segment
+            stash(wreg, areg);
+            __syncthreads();
+            if (seg + 2 < seg1) fetch_into(seg + 2, wreg, areg);  // two segments in flight during the MFMAs below
+            compute_seg();
+            if (seg + 1 >= seg1) break;
+            __syncthreads();
+            stash(wreg2, areg2);
+            __syncthreads();
+            if (seg + 3 < seg1) fetch_into(seg + 3, wreg2, areg2);
+            compute_seg();
+        }
+    } else {
+        if (seg0 < seg1) fetch(seg0);
+        for (int seg = seg0; seg < seg1; ++seg) {
+            __syncthreads();  // every wave is done reading the previous segment
+            stash(wreg, areg);
+            __syncthreads();
+            if (seg + 1 < seg1) fetch(seg + 1);  // in flight during the MFMAs below
+            compute_seg();
         }
     }
     // ---- store: register r of a 32x32 block holds row (r & 3) + 8 (r >> 2) + 4 kg, lanes run along columns
@@ -799,6 +845,8 @@ void launch_wswz_q(hipStream_t s, void* dst, const void* wraw, int wtype, int64_
 // qgemm16_max_rows = 8192 the step takes 167 ms (+30 %) for 26 MB of images instead of 12.9 GB — the resident-quantised mode, selectable.
 static int g_qg16_max_rows = 512;
 void qgemm16_set_max_rows(int v) { g_qg16_max_rows = v; }
+static int g_qg16_pf = 1;  // option "qgemm16_pf": segments of global loads in flight per workgroup.  2 measured SLOWER on the FLUX text stream (few-row family 4.87 -> 6.53 ms per forward, gpurun_out/r08e): the chain is bound by the single wave per SIMD walking LDS read -> dequantise -> MFMA, not by the HBM round trip
+void qgemm16_set_pf(int v) { g_qg16_pf = v; }
 static int g_qg16_rb = 3;  // option "qgemm16_rb": 32-row blocks per workgroup tile (1 / 2 / 4 forced); 0 = by row count only; 3 (default) = by row count, 64-row tiles for small grids (FLUX text stream: 7.0 -> 6.1 ms per forward, profiles/r05d_family_flux_qgemm16_rb.txt)
 void qgemm16_set_rb(int v) { g_qg16_rb = v; }
 
@@ -847,7 +895,15 @@ void launch_qgemm16(hipStream_t s, float* dst, void* dst16, int64_t ldd16, const
     if (g_qg16_rb == 1 || g_qg16_rb == 2 || g_qg16_rb == 4) rb = rows <= 32 ? 1 : (rows <= 64 && g_qg16_rb > 2) ? 2 : g_qg16_rb;
     else if (g_qg16_rb == 3 && rb == 4 && ((rows + 127) / 128) * ((M + 127) / 128) * S < 512) rb = 2;  // 3 = auto: 64-row tiles while the grid stays under two workgroups per CU
     const dim3 grid((unsigned)((rows + rb * 32 - 1) / (rb * 32)), (unsigned)((M + 127) / 128), (unsigned)S);
-#define QG16_LAUNCH(QT_, RB_) k_qgemm16<QT_, RB_><<<grid, 256, 0, s>>>(g)
+    // two segments in flight (PF = 2) whenever a workgroup walks at least four segments and the register sets fit (RB <= 2: 64-row tiles; option "qgemm16_pf")
+    const bool pf2 = g_qg16_pf >= 2 && rb <= 2 && g.nseg_slice >= 4;
+#define QG16_LAUNCH(QT_, RB_)                                         \
+    do {                                                              \
+        if (pf2 && (RB_) <= 2)                                        \
+            k_qgemm16<QT_, ((RB_) <= 2 ? (RB_) : 2), 2><<<grid, 256, 0, s>>>(g); \
+        else                                                          \
+            k_qgemm16<QT_, RB_, 1><<<grid, 256, 0, s>>>(g);           \
+    } while (0)
     if (wtype == 8) {
         if (rb == 1) QG16_LAUNCH(8, 1);
         else if (rb == 2) QG16_LAUNCH(8, 2);
