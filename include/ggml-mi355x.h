@@ -158,6 +158,9 @@ GGML_MI355X_API int ggml_backend_mi355x_get_kernel_timings(struct ggml_backend_m
  * "t256p_pad" (1: the pipelined 256 x 256 Linear tile also for widths that are multiples of 128 only), "tail_split" (0: row-split launches — whole rounds of 256 x 256
  * tiles + the remaining rows on small tiles; measured neutral), "ln16_rows" (1; 4 = four rows per wave in the LayerNorm -> f16 image kernel: measured slower);
  * "gemm16_swp" (0; 1 = the 256-row Linear tiles with the accumulator transposed, 16-byte epilogue accesses: correct, measured 1 % slower per SD1.5 step);
+ * round 6: "qinloop_min_rows" (513: q8_0 / q4_0 Linears with at least that many activation rows whose launch takes the pipelined 256 x 256 tile read the RAW GGUF blocks and
+ * dequantise them inside the GEMM's main loop — no f16 weight image, cached or rebuilt; 0 = off: cached image, or "jit_qimages" rebuild), "qgemm16_pf" (1; 2 = two
+ * segments of loads in flight in k_qgemm16: measured slower), "hoist_mod" (1), "jit_overlap" (0), "plan_cache_cap" (512), "gn_split_min" (65536);
  * "fuse_ln_reduce" (1: the slab reduce of a split-K Linear also writes the f16 operand image of the LayerNorm that reads its result);
  * flash attention: "flash_vtr" (31: bit per head-dim class — V tiles row-major in LDS, fragments by ds_read_b64_tr_b16; 0 = transposing staging pass),
  * "flash_ovl" (1: the two-block d = 40 kernel issues one block's softmax inside the other block's MFMAs; 2: also the other d <= 48 launches; 0: off),
