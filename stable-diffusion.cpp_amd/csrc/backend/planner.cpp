@@ -4042,6 +4042,7 @@ void planner_set_option(const char* key, int value) {
     else if (!strcmp(key, "fuse_ln_reduce")) g_opt.fuse_ln_reduce = value;
     else if (!strcmp(key, "jit_qimages")) g_opt.jit_qimages = value;
     else if (!strcmp(key, "qinloop_min_rows")) gemm16_set_qinloop_min_rows(value);
+    else if (!strcmp(key, "gemm16_t192p")) gemm16_set_t192p(value);
     else if (!strcmp(key, "conv3w_min_blocks")) conv3w_set_min_blocks(value);
     else if (!strcmp(key, "conv3w_min_blocks_deep")) conv3w_set_min_blocks_deep(value);
     else if (!strcmp(key, "gemm16_bn64")) gemm16_set_bn64(value);

@@ -63,7 +63,7 @@ template <int BM, int BN, bool CONV, int BK, int NST, int WR, int WC, int PIPE =
 __global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g) {
     static_assert(!SWP || !CONV, "SWP: the Linear kernels with the accumulator transposed (g16_common.h, epi_linear_swp)");
     static_assert(!SK || (PIPE == 1 && !CONV && !SWP), "stream-K is written for the pipelined Linear tiles");
-    static_assert(QT == 0 || ((QT == 8 || QT == 4) && PIPE == 1 && !CONV && !SWP && !SK && BM == 256 && BN == 256 && WR * WC == 8), "in-loop dequantisation: pipelined 256 x 256 Linear tile");
+    static_assert(QT == 0 || ((QT == 8 || QT == 4) && PIPE == 1 && !CONV && !SWP && !SK && BM == 256 && (BN == 256 || BN == 192) && WR * WC == 8), "in-loop dequantisation: pipelined 256 x 256 / 256 x 192 Linear tiles");
     constexpr int NW  = WR * WC;
     constexpr int RB  = BM / WR / 32;  // 32-row blocks per wave
     constexpr int CB  = BN / WC / 32;  // 32-col blocks per wave
@@ -85,9 +85,10 @@ __global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g
     constexpr int QPB   = QT == 8 ? 64 : 32;            // bytes per row of the raw slot's piece region (whole 16-byte pieces of the 2-block pair)
     constexpr int QNP   = QPB / 16;                     // ... pieces per row
     constexpr int QTOFF = 2 * QBLK - 16;                // source offset of the tail piece (the last 16 bytes of the pair)
-    constexpr int QRAWB = BN * (QPB + 16);              // bytes of a raw slot
+    constexpr int QVC   = 256;                          // columns a raw slot is laid out for: the 192-column tile fetches 64 clamped duplicates (every wave issues the same number of LDS-DMA instructions)
+    constexpr int QRAWB = QVC * (QPB + 16);             // bytes of a raw slot
     constexpr int QNRAW = 3;
-    constexpr int QPI   = QT ? BN * QNP / (NW * 64) : 0;  // piece-region LDS-DMA instructions per wave and chunk (2 / 1), + 1 for the tail region
+    constexpr int QPI   = QT ? QVC * QNP / (NW * 64) : 0;  // piece-region LDS-DMA instructions per wave and chunk (2 / 1), + 1 for the tail region
     constexpr int QRQ   = QPI + 1;
     constexpr int QB0   = NST * ABYTES;                 // first B slot
     constexpr int QR0   = QB0 + 2 * BBYTES;             // first raw slot
@@ -415,10 +416,12 @@ __global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g
         G16_RD(BL[0], bn_, (0 * KSTEPS + (KSN_)) * 1024);                                                            \
         HOOK_(0);                                                                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
-        mma(0, 1, ACUR[0], BL[1]);                                                                                   \
-        mma(1, 1, ACUR[1], BL[1]);                                                                                   \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-        G16_RD(BL[1], bn_, (1 * KSTEPS + (KSN_)) * 1024);                                                            \
+        if constexpr (CL > 1) {                                                                                      \
+            mma(0, 1, ACUR[0], BL[CL > 1 ? 1 : 0]);                                                                  \
+            mma(1, 1, ACUR[1], BL[CL > 1 ? 1 : 0]);                                                                  \
+            __builtin_amdgcn_sched_barrier(0);                                                                       \
+            G16_RD(BL[CL > 1 ? 1 : 0], bn_, (1 * KSTEPS + (KSN_)) * 1024);                                           \
+        }                                                                                                            \
         HOOK_(1);                                                                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
         if constexpr (CL > 2) {                                                                                      \
@@ -478,7 +481,7 @@ __global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g
         G16_RD(A0[0], aad0, 0);                                                                                                    \
         G16_RD(A0[1], aad0, 2048);                                                                                                 \
         G16_RD(BL[0], bad, (0 * KSTEPS) * 1024);                                                                                   \
-        G16_RD(BL[1], bad, (1 * KSTEPS) * 1024);                                                                                   \
+        if constexpr (CL > 1) G16_RD(BL[CL > 1 ? 1 : 0], bad, (1 * KSTEPS) * 1024);                                                \
         if constexpr (CL > 2) G16_RD(BL[CL - 1], bad, (2 * KSTEPS) * 1024);                                                        \
         G16_RD(BH0[0], bad, ((CB - 2) * KSTEPS) * 1024);                                                                           \
         G16_RD(BH0[1], bad, ((CB - 1) * KSTEPS) * 1024);                                                                           \
@@ -529,16 +532,19 @@ __global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g
             typedef uint32_t qu32x4_t __attribute__((ext_vector_type(4)));
             typedef _Float16 qhalf2_t __attribute__((ext_vector_type(2)));
             const int tid = (int)threadIdx.x;
-            const int qc  = tid & 255;  // conversion pass: this thread's weight row (column of the tile) ...
-            const int qh  = wave >> 2;  // ... and its half of the block's 32 weights (wave-uniform)
+            constexpr int QWH = BN / 64;               // waves per half of the conversion pass (4; 3 on the 192-column tile, whose last two waves convert nothing)
+            const int qh      = wave / QWH;            // conversion pass: this thread's half of the block's 32 weights (wave-uniform) ...
+            const int qc      = (tid - qh * BN) & 255; // ... and its weight row (column of the tile)
+            const bool qact   = wave < 2 * QWH;
             auto qf = [](int c) { return QT == 8 ? ((c >> 2) & 3) : ((c >> 3) & 1); };  // physical piece slot of logical piece p of raw row c: p ^ qf(c)
             const char* qsrc[QPI];
 #pragma unroll
             for (int r = 0; r < QPI; ++r) {
                 const int idx = r * (NW * 64) + tid, col = idx / QNP, pp = idx % QNP;
-                qsrc[r]       = (const char*)g.W + (int64_t)(col0 + col) * g.qrow_bytes + ((pp ^ qf(col)) << 4);
+                qsrc[r]       = (const char*)g.W + (int64_t)(col0 + (col < BN ? col : BN - 1)) * g.qrow_bytes + ((pp ^ qf(col)) << 4);
             }
-            const char* qsrcT = (const char*)g.W + (int64_t)(col0 + wave * 32 + (lane & 31)) * g.qrow_bytes + QTOFF;
+            const int qtc     = wave * 32 + (lane & 31);
+            const char* qsrcT = (const char*)g.W + (int64_t)(col0 + (qtc < BN ? qtc : BN - 1)) * g.qrow_bytes + QTOFF;
             // byte offsets of this thread's raw reads inside a raw slot, per block of the pair ([0] / [1]): ONE 16-byte piece (A), the dword that follows the
             // piece's bytes in the row (B: the fifth dword of a 2-byte-misaligned run) and the dword holding the block scale (D).  A thread needs 16 quant bytes +
             // the scale, 18 bytes: it reads 20 (24 for the second half of a q8_0 pair's first block, whose scale sits 18 bytes ahead of its quants)
@@ -546,7 +552,7 @@ __global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g
             {
                 const int f = qf(qc);
                 auto pc = [&](int p) { return (uint32_t)(qc * QPB + ((p ^ f) << 4)); };
-                const uint32_t T = (uint32_t)(BN * QPB + qc * 16);
+                const uint32_t T = (uint32_t)(QVC * QPB + qc * 16);
                 if constexpr (QT == 8) {
                     // block 0: scale at bytes 0-1, quants 2..33; block 1: scale at 34-35, quants 36..67 (the tail piece holds bytes 52..67)
                     qoA[0] = qh ? pc(1) : pc(0);   // bytes 16..31 | 0..15
@@ -579,7 +585,7 @@ __global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g
                 if (i < QPI) {
                     GLDS16(qsrc[i < QPI ? i : 0] + off, rb + (i * (NW * 64) + wave * 64) * 16);
                 } else {
-                    if (lane < 32) GLDS16(qsrcT + off, rb + BN * QPB + wave * 512);
+                    if (lane < 32) GLDS16(qsrcT + off, rb + QVC * QPB + wave * 512);
                 }
             };
             auto q_issue_a = [&](int q, int ktabs, int slot) { GLDS16(asrc[q] + (int64_t)ktabs * BK, smem + slot * ABYTES + (wave * APW + q) * 1024); };
@@ -667,7 +673,7 @@ __global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g
             // next one (which converts the other 8): the last two quant dwords and the scale
             uint32_t Qv[4], qdbits = 0;
             qhalf2_t qd2;
-            {   // B stage 0 (block 0 of chunk 0) and the first half of B stage 1, outside the pipeline
+            if (qact) {   // B stage 0 (block 0 of chunk 0) and the first half of B stage 1, outside the pipeline
                 uint32_t O[8];
                 G16Q_RAW_READ(0, qraw0);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -694,7 +700,7 @@ __global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g
             G16_RD(A0[0], aad0, 0);
             G16_RD(A0[1], aad0, 2048);
             G16_RD(BL[0], badq, (0 * KSTEPS) * 1024);
-            G16_RD(BL[1], badq, (1 * KSTEPS) * 1024);
+            if constexpr (CL > 1) G16_RD(BL[CL > 1 ? 1 : 0], badq, (1 * KSTEPS) * 1024);
             if constexpr (CL > 2) G16_RD(BL[CL - 1], badq, (2 * KSTEPS) * 1024);
             G16_RD(BH0[0], badq, ((CB - 2) * KSTEPS) * 1024);
             G16_RD(BH0[1], badq, ((CB - 1) * KSTEPS) * 1024);
@@ -710,8 +716,8 @@ __global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g
     // side-effect-free VALU work down to its first use and the whole conversion runs in one lump in front of the ds_write)
 #define G16Q_RD_HOOK(I_)                                                                                              \
     do {                                                                                                             \
-        if ((I_) == 0 && qconv_) G16Q_RAW_READ(qb_, qraw0 + (uint32_t)((rs == QNRAW - 1 ? 0 : rs + 1) * QRAWB));      \
-        if (qfin_) {                                                                                                 \
+        if ((I_) == 0 && qconv_ && qact) G16Q_RAW_READ(qb_, qraw0 + (uint32_t)((rs == QNRAW - 1 ? 0 : rs + 1) * QRAWB)); \
+        if (qfin_ && qact) {                                                                                         \
             if ((I_) == 1) {                                                                                         \
                 q_deq4(Qv[2], qd2, O[4], O[5]);                                                                      \
                 G16Q_PIN2(O[4], O[5]);                                                                               \
@@ -728,7 +734,7 @@ __global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g
     do {                                                                                                             \
         if (qdma_ && (I_) < APW) q_issue_a((I_), kt0 + kt + NST, fbuf);                                              \
         if (qdma_ && qb_ == 0 && (I_) >= 2 && (I_) - 2 < QRQ) q_issue_raw_piece((I_) - 2 < QPI ? (I_) - 2 : QPI, (kt >> 1) + QNRAW, rs); \
-        if (qconv_) {                                                                                                \
+        if (qconv_ && qact) {                                                                                        \
             if ((I_) == 0) {                                                                                         \
                 q_extract1(qb_, Qv, qdbits);                                                                         \
                 G16Q_PIN2(Qv[0], Qv[1]);                                                                             \
@@ -1032,7 +1038,7 @@ static inline bool g16_bk32() { return g_g16_variant == 1 || g_g16_variant == 3;
 //   T160   256x160, 4 waves of 64x160  (78 KB, 2/CU)                 — outputs that are multiples of 160 but not of 128 (SD1.5's 320):
 //                                                                       no padded columns, 2 column tiles instead of 3
 //   T160N  256x160, 8 waves of 32x160  (78 KB, 2/CU)                 — T160 with twice the waves in flight (experiment)
-enum { G16_T128 = 0, G16_T256 = 1, G16_T256W = 2, G16_T160 = 3, G16_T160N = 4, G16_T320 = 5, G16_T256P = 6, G16_T128N64 = 7 };
+enum { G16_T128 = 0, G16_T256 = 1, G16_T256W = 2, G16_T160 = 3, G16_T160N = 4, G16_T320 = 5, G16_T256P = 6, G16_T128N64 = 7, G16_T192P = 8 };  // T192P: the pipelined loop on 256 x 192 tiles (Linears only)
 static int g_g16_force_tile = -1;  // option "gemm16_tile": force one configuration (A/B measurements); -1 = choose per shape
 void gemm16_set_tile(int t) { g_g16_force_tile = t; }
 // Per-shape choice.  Measured on SD1.5 batch 16 (profiles/r01e_tile_configs.txt): a launch takes ceil(workgroups / resident slots)
@@ -1058,6 +1064,8 @@ static int g16_t320_split(int64_t rows, int64_t M, int64_t nt, bool conv);
 // only), 2 = GEGLU launch on the 16-column interleave (epi_geglu16: any tile)
 // option "t256p_pad" (round 5): the pipelined 256 x 256 tile also for Linears whose width is a multiple of 128 but not of 256 (SD3.5-large: 2432 = 9.5 tiles,
 // 7296 = 28.5): the last column tile is half empty (its weight fetches are clamped to the image, its outputs masked), at most 6 % of the launch
+static int g_g16_t192p = 1;  // option "gemm16_t192p": 0 = never take the 256 x 192 tile by itself
+void gemm16_set_t192p(int v) { g_g16_t192p = v; }
 static int g_g16_t256p_pad = 1;
 void gemm16_set_t256p_pad(int v) { g_g16_t256p_pad = v; }
 // option "tail_split" (round 5): a 256 x 256-tile Linear whose tile count leaves the last of its >= 2 rounds mostly empty runs as TWO launches split by rows:
@@ -1090,6 +1098,7 @@ static int g16_pick_tile(int64_t rows, int64_t M, int geglu, bool conv, int spli
     if (g_g16_force_tile >= 0) {
         if (g_g16_force_tile == G16_T320) return can320 ? G16_T320 : G16_T256;
         if (g_g16_force_tile == G16_T256P) return M % 256 == 0 ? G16_T256P : G16_T256;
+        if (g_g16_force_tile == G16_T192P) return (M % 192 == 0 && !conv && geglu == 0 && !split) ? G16_T192P : G16_T256;
         if ((g_g16_force_tile == G16_T160 || g_g16_force_tile == G16_T160N) && !can160) return G16_T256;
         return g_g16_force_tile > G16_T256P ? G16_T128 : g_g16_force_tile;
     }
@@ -1103,7 +1112,16 @@ static int g16_pick_tile(int64_t rows, int64_t M, int geglu, bool conv, int spli
         if (!conv && mul == 1 && geglu == 0 && g16_tail_rows(rows, M) > 0) rounds = c256p / 256;  // the partial round goes to the tail launch: the fill test sees whole rounds
         // stream-K (g16_streamk_grid) runs such a launch as ONE round whatever its tile count: the round-fill test only binds launches that cannot take it
         const bool sk_ok = g_g16_streamk == 2 && !conv && mul == 1 && c256p * nt >= 256 * 16;  // (default policy: stream-K never widens the tile choice)
-        if (nt >= (sk_ok ? g_g16_t256p_min_nt_sk : 64) && c256p >= (sk_ok ? g_g16_t256p_min_tiles_sk : 192) && (sk_ok || c256p * 4 >= rounds * 256 * 3)) return G16_T256P;
+        if (nt >= (sk_ok ? g_g16_t256p_min_nt_sk : 64) && c256p >= (sk_ok ? g_g16_t256p_min_tiles_sk : 192) && (sk_ok || c256p * 4 >= rounds * 256 * 3)) {
+            // 256 x 192 tiles (round 6) where they quantise better on the chip: FLUX's 4096-row img stream has 192 (-> 3072) / 576 (-> 9216) tiles of 256 x 256 = one / three
+            // rounds on 256 CUs of which a quarter is idle; 256 / 768 tiles of 256 x 192 fill them.  A round of the narrower tile costs ~0.8 of a 256 x 256 round
+            // (gpurun_out/r08g: 88.7 -> 80.6, 309.7 -> 280.5, 259.0 -> 228.3 us; equal round counts lose: -> 12288 292.6 vs 299.7 us)
+            if (g_g16_t192p && !conv && mul == 1 && geglu == 0 && M % 192 == 0 && !sk_ok) {
+                const int64_t c192 = rt256 * (M / 192), r192 = (c192 + 255) / 256;
+                if ((double)r192 * 0.80 < (double)rounds * 0.97) return G16_T192P;
+            }
+            return G16_T256P;
+        }
     }
     if (split) {
         if (can320 && g16_t320_split(rows, M, nt, conv) == split) return G16_T320;
@@ -1206,10 +1224,11 @@ void gemm16_set_qinloop_min_rows(int v) { g_g16_qinloop_min_rows = v; }
 bool gemm16_qinloop_supported(int wtype, int64_t rows, int64_t M, int64_t K, int mul, int split) {
     if (g_g16_qinloop_min_rows <= 0 || rows < g_g16_qinloop_min_rows || (wtype != 8 && wtype != 2)) return false;
     if (g_g16_variant != 3 || !g16_bk32() || g_g16_swp || g_g16_force_tile >= 0 || g_g16_streamk) return false;
-    if (M % 256 != 0 || K % 64 != 0 || K < 192 || g16_use_bn64(rows, M, mul)) return false;
+    if (K % 64 != 0 || K < 192 || g16_use_bn64(rows, M, mul)) return false;
     const int64_t nt = K / 32;
     if (split > 1 || gemm16_split_k(rows, M, K, false) > 1) return false;  // (K slices: not yet)
-    return g16_pick_tile(rows, M, 0, false, 0, nt, mul) == G16_T256P;
+    const int tile = g16_pick_tile(rows, M, 0, false, 0, nt, mul);
+    return (tile == G16_T256P && M % 256 == 0) || (tile == G16_T192P && M % 192 == 0);
 }
 // a Linear of this shape runs on the pipelined 256 x 256 tile without K slices: the launches that may carry Epilogue::split_col
 bool gemm16_split_col_supported(int64_t rows, int64_t M, int64_t K) {
@@ -1238,7 +1257,7 @@ static void g16_launch(hipStream_t s, G16Args& g, int64_t rows, double flops, do
     const int mul     = (!CONV_ && g.multi > 1) ? g.multi : 1;  // sibling Linears in one launch: mul x the column tiles
     if (BN_ == 128 && g_g16_variant == 3 && (!g.sk_cnt || g.sk_grid > 0)) {
         const int tile = g16_pick_tile(rows, g.C, g.geglu_inner > 0 ? (g.geglu16 ? 2 : 1) : 0, CONV_, g.split_k > 1 ? g.split_k : 0, g.nt, mul);  // the GEGLU pairing is laid out for 128-column tiles
-        if (g.qt && (tile != G16_T256P || g.sk_grid > 0 || g.C % 256 != 0 || g.nt < 6 || (g.nt & 1) || (g.split_k > 1 && ((g.nt_slice & 1) || g.nt_slice < 6 || g.nt - (g.split_k - 1) * g.nt_slice < 6)))) {
+        if (g.qt && ((tile != G16_T256P && tile != G16_T192P) || g.sk_grid > 0 || g.C % (tile == G16_T192P ? 192 : 256) != 0 || g.nt < 6 || (g.nt & 1) || (g.split_k > 1 && ((g.nt_slice & 1) || g.nt_slice < 6 || g.nt - (g.split_k - 1) * g.nt_slice < 6)))) {
             fprintf(stderr, "ggml-mi355x: in-loop dequantisation planned for a launch that does not take the pipelined 256 x 256 tile (tile %d, rows %lld, M %lld, K stages %d)\n", tile, (long long)rows, (long long)g.C, g.nt);
             abort();
         }
@@ -1325,6 +1344,17 @@ static void g16_launch(hipStream_t s, G16Args& g, int64_t rows, double flops, do
                     }
                 }
                 k_gemm16<256, 256, CONV_, 32, 4, 4, 2, 1><<<dim3((unsigned)(rt256 * g.ncol_tiles * mul), ny), 512, 0, s>>>(g);
+            } else if (tile == G16_T192P) {
+                g.ncol_tiles = (int)(g.C / 192);
+                if constexpr (!CONV_) {
+                    const dim3 grid((unsigned)(rt256 * g.ncol_tiles * mul), ny);
+                    if (g.qt == 8)
+                        k_gemm16<256, 192, false, 32, 4, 4, 2, 1, false, false, 8><<<grid, 512, 0, s>>>(g);
+                    else if (g.qt)
+                        k_gemm16<256, 192, false, 32, 4, 4, 2, 1, false, false, 4><<<grid, 512, 0, s>>>(g);
+                    else
+                        k_gemm16<256, 192, false, 32, 4, 4, 2, 1><<<grid, 512, 0, s>>>(g);
+                }
             } else if (tile == G16_T160) {
                 g.ncol_tiles = (int)(g.C / 160);
                 k_gemm16<256, 160, CONV_, 32, 3, 4, 1><<<dim3((unsigned)(rt256 * g.ncol_tiles * mul), ny), 256, 0, s>>>(g);

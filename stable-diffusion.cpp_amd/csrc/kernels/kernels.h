@@ -120,6 +120,7 @@ void gemm16_init();
 // no f16 weight image, resident or rebuilt (mul: sibling weights in one launch; split: the launch's K slices, <= 1 = none)
 bool gemm16_qinloop_supported(int wtype, int64_t rows, int64_t M, int64_t K, int mul, int split);
 void gemm16_set_qinloop_min_rows(int v);
+void gemm16_set_t192p(int v);  // 0: the per-shape choice never takes the pipelined 256 x 192 tile
 void gemm16_set_tap_major(int v);  // A/B: conv K order (tap, channel block) instead of (channel block, tap)
 int gemm16_tap_major();
 void gemm16_set_splitk_target(int v);
