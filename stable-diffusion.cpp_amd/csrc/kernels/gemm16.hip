@@ -541,10 +541,11 @@ __global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g
 #pragma unroll
             for (int r = 0; r < QPI; ++r) {
                 const int idx = r * (NW * 64) + tid, col = idx / QNP, pp = idx % QNP;
-                qsrc[r]       = (const char*)g.W + (int64_t)(col0 + (col < BN ? col : BN - 1)) * g.qrow_bytes + ((pp ^ qf(col)) << 4);
+                const int64_t wr_ = min((int64_t)col0 + (col < BN ? col : BN - 1), g.C - 1);  // (a ragged last column tile re-fetches the last weight row: those outputs are masked)
+                qsrc[r]       = (const char*)g.W + wr_ * g.qrow_bytes + ((pp ^ qf(col)) << 4);
             }
             const int qtc     = wave * 32 + (lane & 31);
-            const char* qsrcT = (const char*)g.W + (int64_t)(col0 + (qtc < BN ? qtc : BN - 1)) * g.qrow_bytes + QTOFF;
+            const char* qsrcT = (const char*)g.W + min((int64_t)col0 + (qtc < BN ? qtc : BN - 1), g.C - 1) * g.qrow_bytes + QTOFF;
             // byte offsets of this thread's raw reads inside a raw slot, per block of the pair ([0] / [1]): ONE 16-byte piece (A), the dword that follows the
             // piece's bytes in the row (B: the fifth dword of a 2-byte-misaligned run) and the dword holding the block scale (D).  A thread needs 16 quant bytes +
             // the scale, 18 bytes: it reads 20 (24 for the second half of a q8_0 pair's first block, whose scale sits 18 bytes ahead of its quants)
@@ -1098,7 +1099,7 @@ static int g16_pick_tile(int64_t rows, int64_t M, int geglu, bool conv, int spli
     if (g_g16_force_tile >= 0) {
         if (g_g16_force_tile == G16_T320) return can320 ? G16_T320 : G16_T256;
         if (g_g16_force_tile == G16_T256P) return M % 256 == 0 ? G16_T256P : G16_T256;
-        if (g_g16_force_tile == G16_T192P) return (M % 192 == 0 && !conv && geglu == 0 && !split) ? G16_T192P : G16_T256;
+        if (g_g16_force_tile == G16_T192P) return ((M % 192 == 0 || (M % 64 == 0 && M >= 2048)) && !conv && geglu == 0 && !split) ? G16_T192P : G16_T256;
         if ((g_g16_force_tile == G16_T160 || g_g16_force_tile == G16_T160N) && !can160) return G16_T256;
         return g_g16_force_tile > G16_T256P ? G16_T128 : g_g16_force_tile;
     }
@@ -1112,16 +1113,19 @@ static int g16_pick_tile(int64_t rows, int64_t M, int geglu, bool conv, int spli
         if (!conv && mul == 1 && geglu == 0 && g16_tail_rows(rows, M) > 0) rounds = c256p / 256;  // the partial round goes to the tail launch: the fill test sees whole rounds
         // stream-K (g16_streamk_grid) runs such a launch as ONE round whatever its tile count: the round-fill test only binds launches that cannot take it
         const bool sk_ok = g_g16_streamk == 2 && !conv && mul == 1 && c256p * nt >= 256 * 16;  // (default policy: stream-K never widens the tile choice)
-        if (nt >= (sk_ok ? g_g16_t256p_min_nt_sk : 64) && c256p >= (sk_ok ? g_g16_t256p_min_tiles_sk : 192) && (sk_ok || c256p * 4 >= rounds * 256 * 3)) {
-            // 256 x 192 tiles (round 6) where they quantise better on the chip: FLUX's 4096-row img stream has 192 (-> 3072) / 576 (-> 9216) tiles of 256 x 256 = one / three
-            // rounds on 256 CUs of which a quarter is idle; 256 / 768 tiles of 256 x 192 fill them.  A round of the narrower tile costs ~0.8 of a 256 x 256 round
-            // (gpurun_out/r08g: 88.7 -> 80.6, 309.7 -> 280.5, 259.0 -> 228.3 us; equal round counts lose: -> 12288 292.6 vs 299.7 us)
-            if (g_g16_t192p && !conv && mul == 1 && geglu == 0 && M % 192 == 0 && !sk_ok) {
-                const int64_t c192 = rt256 * (M / 192), r192 = (c192 + 255) / 256;
-                if ((double)r192 * 0.80 < (double)rounds * 0.97) return G16_T192P;
-            }
-            return G16_T256P;
+        const bool ok256 = nt >= (sk_ok ? g_g16_t256p_min_nt_sk : 64) && c256p >= (sk_ok ? g_g16_t256p_min_tiles_sk : 192) && (sk_ok || c256p * 4 >= rounds * 256 * 3);
+        // 256 x 192 tiles (round 6) where they quantise better on the chip: FLUX's 4096-row img stream has 192 (-> 3072) / 576 (-> 9216) tiles of 256 x 256 = one / three
+        // rounds on 256 CUs of which a quarter is idle; 256 / 768 tiles of 256 x 192 fill them.  A round of the narrower tile costs ~0.8 of a 256 x 256 round
+        // (gpurun_out/r08g: 88.7 -> 80.6, 309.7 -> 280.5, 259.0 -> 228.3 us; equal round counts lose: -> 12288 292.6 vs 299.7 us).
+        // Widths that are not multiples of 192 (SD3.5-large: 2432 = 12.67 tiles, 9728 = 50.67) take it like the padded 256 x 256 tile does: the last column tile's weight
+        // fetches are clamped to the image, its outputs masked — at most 6 % of the launch from 2048 columns on.  Same fill rule as the 256 x 256 tile (>= 192 tiles,
+        // rounds at least 3/4 full); where only the narrower tile passes it (SD3.5: 8500 x 2432 = 340 tiles of 256 x 256 = 1.33 rounds, 442 of 256 x 192 = 1.73) it is taken
+        if (g_g16_t192p && !conv && mul == 1 && geglu == 0 && (M % 192 == 0 || (g_g16_t256p_pad && M % 64 == 0 && M >= 2048)) && !sk_ok && nt >= 64) {
+            const int64_t c192 = rt256 * ((M + 191) / 192), r192 = (c192 + 255) / 256;
+            const bool ok192   = c192 >= 192 && c192 * 4 >= r192 * 256 * 3;
+            if (ok192 && (!ok256 || (double)r192 * 0.80 < (double)rounds * 0.97)) return G16_T192P;
         }
+        if (ok256) return G16_T256P;
     }
     if (split) {
         if (can320 && g16_t320_split(rows, M, nt, conv) == split) return G16_T320;
@@ -1228,7 +1232,7 @@ bool gemm16_qinloop_supported(int wtype, int64_t rows, int64_t M, int64_t K, int
     const int64_t nt = K / 32;
     if (split > 1 || gemm16_split_k(rows, M, K, false) > 1) return false;  // (K slices: not yet)
     const int tile = g16_pick_tile(rows, M, 0, false, 0, nt, mul);
-    return (tile == G16_T256P && M % 256 == 0) || (tile == G16_T192P && M % 192 == 0);
+    return (tile == G16_T256P || tile == G16_T192P) && M % 64 == 0;  // (ragged last column tiles re-fetch the last weight row)
 }
 // a Linear of this shape runs on the pipelined 256 x 256 tile without K slices: the launches that may carry Epilogue::split_col
 bool gemm16_split_col_supported(int64_t rows, int64_t M, int64_t K) {
@@ -1257,7 +1261,7 @@ static void g16_launch(hipStream_t s, G16Args& g, int64_t rows, double flops, do
     const int mul     = (!CONV_ && g.multi > 1) ? g.multi : 1;  // sibling Linears in one launch: mul x the column tiles
     if (BN_ == 128 && g_g16_variant == 3 && (!g.sk_cnt || g.sk_grid > 0)) {
         const int tile = g16_pick_tile(rows, g.C, g.geglu_inner > 0 ? (g.geglu16 ? 2 : 1) : 0, CONV_, g.split_k > 1 ? g.split_k : 0, g.nt, mul);  // the GEGLU pairing is laid out for 128-column tiles
-        if (g.qt && ((tile != G16_T256P && tile != G16_T192P) || g.sk_grid > 0 || g.C % (tile == G16_T192P ? 192 : 256) != 0 || g.nt < 6 || (g.nt & 1) || (g.split_k > 1 && ((g.nt_slice & 1) || g.nt_slice < 6 || g.nt - (g.split_k - 1) * g.nt_slice < 6)))) {
+        if (g.qt && ((tile != G16_T256P && tile != G16_T192P) || g.sk_grid > 0 || g.C % 64 != 0 || g.nt < 6 || (g.nt & 1) || (g.split_k > 1 && ((g.nt_slice & 1) || g.nt_slice < 6 || g.nt - (g.split_k - 1) * g.nt_slice < 6)))) {
             fprintf(stderr, "ggml-mi355x: in-loop dequantisation planned for a launch that does not take the pipelined 256 x 256 tile (tile %d, rows %lld, M %lld, K stages %d)\n", tile, (long long)rows, (long long)g.C, g.nt);
             abort();
         }
@@ -1345,7 +1349,8 @@ static void g16_launch(hipStream_t s, G16Args& g, int64_t rows, double flops, do
                 }
                 k_gemm16<256, 256, CONV_, 32, 4, 4, 2, 1><<<dim3((unsigned)(rt256 * g.ncol_tiles * mul), ny), 512, 0, s>>>(g);
             } else if (tile == G16_T192P) {
-                g.ncol_tiles = (int)(g.C / 192);
+                g.ncol_tiles = (int)((g.C + 191) / 192);
+                if (g.C % 192 != 0) g.wblk_lim = (int)(rup64(g.C, 128) / 32);
                 if constexpr (!CONV_) {
                     const dim3 grid((unsigned)(rt256 * g.ncol_tiles * mul), ny);
                     if (g.qt == 8)
