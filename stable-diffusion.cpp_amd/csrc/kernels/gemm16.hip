@@ -1255,12 +1255,14 @@ int gemm16_worder_rows(const G16Args& g, unsigned gx, unsigned ny) {
     const double wts   = (double)g.ICp * g.KS * g.KS * (double)rup64(g.C, 128) * 2.0;
     return wts >= 2.0 * act ? nrow : 0;
 }
+static bool g16_trace();
 template <int BN_, bool CONV_>
 static void g16_launch(hipStream_t s, G16Args& g, int64_t rows, double flops, double bytes) {  // bytes: algorithmic HBM bytes (operand images read once + output written once [+ residual])
     const unsigned ny = g.split_k > 1 ? (unsigned)g.split_k : 1u;
     const int mul     = (!CONV_ && g.multi > 1) ? g.multi : 1;  // sibling Linears in one launch: mul x the column tiles
     if (BN_ == 128 && g_g16_variant == 3 && (!g.sk_cnt || g.sk_grid > 0)) {
         const int tile = g16_pick_tile(rows, g.C, g.geglu_inner > 0 ? (g.geglu16 ? 2 : 1) : 0, CONV_, g.split_k > 1 ? g.split_k : 0, g.nt, mul);  // the GEGLU pairing is laid out for 128-column tiles
+        if (g16_trace()) fprintf(stderr, "G16 tile %d rows=%lld C=%lld nt=%d split=%d mul=%d qt=%d\n", tile, (long long)rows, (long long)g.C, g.nt, g.split_k, mul, g.qt);
         if (g.qt && ((tile != G16_T256P && tile != G16_T192P) || g.sk_grid > 0 || g.C % 64 != 0 || g.nt < 6 || (g.nt & 1) || (g.split_k > 1 && ((g.nt_slice & 1) || g.nt_slice < 6 || g.nt - (g.split_k - 1) * g.nt_slice < 6)))) {
             fprintf(stderr, "ggml-mi355x: in-loop dequantisation planned for a launch that does not take the pipelined 256 x 256 tile (tile %d, rows %lld, M %lld, K stages %d)\n", tile, (long long)rows, (long long)g.C, g.nt);
             abort();
