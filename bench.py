@@ -212,8 +212,8 @@ def main():
 
     def trajectory(k):
         # k sampler iterations on the device batch: x*c_in, cond+uncond forward, CFG, Euler(-A) update per step, no host crossing in between
-        eng.sample_latents(cond, None if flux else uncond, width=lat * 8, height=lat * 8, steps=k, cfg=1.0 if flux else 7.0, seed=42, batch=B,
-                           device_batch=B, method=sd.EULER if dit else sd.EULER_A, cond_y=y, uncond_y=y, fuse_cfg=True, device_sampler=True)
+        return eng.sample_latents(cond, None if flux else uncond, width=lat * 8, height=lat * 8, steps=k, cfg=1.0 if flux else 7.0, seed=42, batch=B,
+                                  device_batch=B, method=sd.EULER if dit else sd.EULER_A, cond_y=y, uncond_y=y, fuse_cfg=True, device_sampler=True)
 
     if args.device_sampler:
         if args.warmup > 0:
@@ -231,12 +231,14 @@ def main():
         sd.kernel_timing_enable(True)
     t0 = time.perf_counter()
     if args.device_sampler:
-        trajectory(args.steps)
+        timed_latents = trajectory(args.steps)
     else:
         for _ in range(args.steps):
             step()
     barrier()
     dt = time.perf_counter() - t0
+    if args.device_sampler and not np.isfinite(timed_latents).all():   # a timing on NaN data is not a measurement
+        raise RuntimeError(f"bench: the latents sampled in the timed region are not finite ({int((~np.isfinite(timed_latents)).sum())} of {timed_latents.size} values)")
     kt = sd.kernel_timing() if timing_live else None
     if timing_live:
         sd.kernel_timing_enable(False)
@@ -537,9 +539,12 @@ def model_leg(sd, backend_name, args, name):
     eng.sample_latents(cond, unc, steps=1, **kw)   # builds weight images + plan
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    eng.sample_latents(cond, unc, steps=k, **kw)
+    lat_out = eng.sample_latents(cond, unc, steps=k, **kw)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / k * 1e3
+    # a timing on NaN data is not a measurement (round 6 found the batch >= 2 DiT legs of earlier rounds running on NaNs: an operand-aliasing race in a fusion)
+    if not np.isfinite(lat_out).all():
+        raise RuntimeError(f"bench leg {name}: the sampled latents are not finite ({int((~np.isfinite(lat_out)).sum())} of {lat_out.size} values)")
     tfl = nfwd * B * UNET_FWD_TFLOP[name.split("_")[0]] / (ms / 1e3)
     res = {"workload": f"{name.split('_')[0]} 1024x1024, {'cfg 1 (one forward per step)' if nfwd == 1 else 'cfg 7 (cond+uncond in one graph)'}, {wattr.lower()} Linear weights, "
                        f"batch {B}/GPU, {'Euler' if dit else 'Euler-A'} step, device-resident",

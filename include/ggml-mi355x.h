@@ -99,6 +99,7 @@ struct ggml_backend_mi355x_stats {
     int64_t jit_overlapped;      /* just-in-time weight-image rebuilds issued one Linear ahead on the side stream, overlapping the previous GEMM (option jit_overlap) */
     int64_t view_external_nodes; /* nodes of those slices treated as read outside the slice (parent use_counts > readers inside, the slice's last node and its sources) */
     int64_t qinloop_linears;     /* q8_0 / q4_0 Linears above k_qgemm16's row range planned on the pipelined 256 x 256 tile with the raw GGUF blocks dequantised INSIDE the main loop (k_gemm16<..., QT>): no f16 weight image, resident or rebuilt */
+    int64_t flash_out_alias;     /* FLASH_ATTN_EXT -> VIEW -> CONT chains NOT written by the flash kernel itself because the graph allocator gave the CONT the block of a Q / K / V operand (the node runs plain, the CONT as a copy) */
 };
 GGML_MI355X_API void ggml_backend_mi355x_get_stats(struct ggml_backend_mi355x_stats* out);
 /* Host enum numbering, resolved BY NAME.  The numeric values of `enum ggml_op` / `enum ggml_unary_op` in ggml-abi.h are a recollection of upstream, and

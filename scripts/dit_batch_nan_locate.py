@@ -46,6 +46,24 @@ with sd.EvalTrace(note) as tr0:
 nn = tr0.asked
 print("nodes", nn, flush=True)
 lo, hi = 0, nn - 1
+if len(sys.argv) > 5 and sys.argv[5] == "sets":
+    for spec in sys.argv[6:]:
+        cuts = set(int(v) for v in spec.split(","))
+        with sd.EvalTrace(lambda i, ts: i in cuts, with_src1=False) as tr:
+            o2 = eng.unet_forward(x, t, ctx, y)
+        rec = [(i, None if v is None else bool(np.isfinite(v).all())) for (i, op, name, v, _s) in tr.records]
+        for (i, op, name, v, _s) in tr.records:
+            if v is not None and not np.isfinite(v).all():
+                bad = ~np.isfinite(v)
+                print(f"   node {i} shape {v.shape}: non-finite {int(bad.sum())} of {v.size}")
+                for ax in range(v.ndim):
+                    other = tuple(a for a in range(v.ndim) if a != ax)
+                    cnt = bad.sum(axis=other)
+                    nz = np.nonzero(cnt)[0]
+                    print(f"      axis {ax} (len {v.shape[ax]}): indices with bad values: {len(nz)}; first {nz[:12].tolist()} last {nz[-6:].tolist()}; counts at those {cnt[nz[:6]].tolist()}")
+                break
+        print(f"cuts {sorted(cuts)}: final finite {bool(np.isfinite(o2).all())}; records (node, finite) {rec}", flush=True)
+    sys.exit(0)
 if len(sys.argv) > 5 and sys.argv[5] == "single":
     # ONE cut at a time: which cuts make the final result finite (a fusion across that node is the culprit), and where is the recorded node itself bad
     res = []

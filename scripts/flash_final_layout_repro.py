@@ -24,7 +24,7 @@ def exact(q, k, v, scale):
     return np.einsum("hqk,hkd->hqd", p, v.astype(np.float64))
 
 
-def case(d, H, N, Lq, Lk, fused=True):
+def case(d, H, N, Lq, Lk, fused=True, reshape=False):
     HN = H * N
     q = rng.standard_normal((HN, Lq, d)).astype(np.float32)
     k = rng.standard_normal((HN, Lk, d)).astype(np.float32)
@@ -37,6 +37,8 @@ def case(d, H, N, Lq, Lk, fused=True):
         ts = tensor_struct(o)
         vw = L.ggml_view_4d(g.ctx, o, d, H, Lq, N, int(ts.nb[1]), int(ts.nb[2]), int(ts.nb[1]) * H, 0)
         ct = L.ggml_cont(g.ctx, vw)   # [d, H, Lq, N]
+        if reshape:
+            ct = L.ggml_reshape_3d(g.ctx, ct, d * H, Lq, N)
         out = g.run(ct)
     sd.backend_set_option("fusion", 1)
     ex = exact(q, k.astype(np.float16).astype(np.float32), v.astype(np.float16).astype(np.float32), scale).reshape(N, H, Lq, d).transpose(0, 2, 1, 3)   # [N, Lq, H, d]
@@ -44,8 +46,8 @@ def case(d, H, N, Lq, Lk, fused=True):
     fin = np.isfinite(got)
     err = float(np.linalg.norm(np.where(fin, got, 0) - ex) / np.linalg.norm(ex))
     per = [(int((~fin[n]).sum()), float(np.linalg.norm(np.where(fin[n], got[n], 0) - ex[n]) / np.linalg.norm(ex[n]))) for n in range(N)]
-    print(f"d {d} H {H} N {N} Lq {Lq} Lk {Lk} fused {fused}: non-finite {int((~fin).sum())} of {got.size}, rel-L2 {err:.2e}, per image (non-finite, rel-L2) {per}", flush=True)
+    print(f"d {d} H {H} N {N} Lq {Lq} Lk {Lk} fused {fused} reshape {reshape}: non-finite {int((~fin).sum())} of {got.size}, rel-L2 {err:.2e}, per image (non-finite, rel-L2) {per}", flush=True)
 
 
-for a in ((64, 38, 2, 1178, 1178), (64, 38, 1, 1178, 1178), (64, 38, 2, 410, 410), (64, 4, 2, 1178, 1178), (64, 38, 2, 1024, 1024), (64, 38, 2, 1152, 1152), (128, 24, 2, 1280, 1280), (64, 38, 2, 1178, 1178, False)):
+for a in ((64, 38, 2, 1178, 1178, True, True), (64, 38, 1, 1178, 1178, True, True), (64, 38, 2, 410, 410, True, True), (64, 4, 2, 300, 300, True, True), (64, 38, 2, 1178, 1178, True, False)):
     case(*a)

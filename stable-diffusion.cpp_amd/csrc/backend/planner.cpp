@@ -163,7 +163,7 @@ namespace {
 struct Stats {
     std::atomic<int64_t> graphs_computed{0}, plans_built{0}, nodes_seen{0}, kernels_planned{0}, kernels_launched{0}, fused_conv{0},
         fused_conv_bounced{0}, fused_linear{0}, fused_norm{0}, fused_geglu{0}, fused_attention{0}, generic_matmul{0}, swizzled_weight_bytes{0}, fused_linear_geglu{0}, split_k_gemms{0}, head_major_gemms{0}, fused_modulate{0}, fused_gate{0}, fused_gelu{0}, fused_rope{0}, fused_concat_heads{0},
-        graph_replays{0}, qgemv_linears{0}, fused_chan_add{0}, fused_proj_tokens{0}, gemm_attention{0}, fused_q16{0}, split_k_inlaunch{0}, qgemm16_linears{0}, fgemv_linears{0}, fused_presilu{0}, fused_sibling_linears{0}, hoisted_kv_linears{0}, window_convs{0}, hoisted_emb_linears{0}, fused_rows16{0}, fused_cat_rows16{0}, fused_joint_qkv{0}, jit_images{0}, fused_gn_stats{0}, redirect_fallbacks{0}, fused_ln_reduce{0}, fused_concat_gn{0}, fused_conv_scale{0}, view_graphs{0}, view_external_nodes{0}, plans_evicted{0}, hoisted_mod_linears{0}, jit_overlapped{0}, qinloop_linears{0};
+        graph_replays{0}, qgemv_linears{0}, fused_chan_add{0}, fused_proj_tokens{0}, gemm_attention{0}, fused_q16{0}, split_k_inlaunch{0}, qgemm16_linears{0}, fgemv_linears{0}, fused_presilu{0}, fused_sibling_linears{0}, hoisted_kv_linears{0}, window_convs{0}, hoisted_emb_linears{0}, fused_rows16{0}, fused_cat_rows16{0}, fused_joint_qkv{0}, jit_images{0}, fused_gn_stats{0}, redirect_fallbacks{0}, fused_ln_reduce{0}, fused_concat_gn{0}, fused_conv_scale{0}, view_graphs{0}, view_external_nodes{0}, plans_evicted{0}, hoisted_mod_linears{0}, jit_overlapped{0}, qinloop_linears{0}, flash_out_alias{0};
 } g_stats;
 
 struct Options {
@@ -243,6 +243,21 @@ inline bool overlaps(const void* a, size_t an, const void* b, size_t bn) {
     const char* pa = (const char*)a;
     const char* pb = (const char*)b;
     return pa < pb + bn && pb < pa + an;
+}
+
+// FLASH_ATTN_EXT -> VIEW -> CONT written by the flash kernel itself: does the CONT's block share memory with an operand the kernel reads from the GRAPH buffer?
+// (Q as an f16 arena image / K, V moved to the arena by the hoisting pre-pass are not in the graph buffer.)  The allocator recycles the block of a tensor whose last
+// reader is the flash node for the next allocation of that size — which is this CONT.
+bool flash_out_aliases_operand(const ggml_tensor* ct, const ggml_tensor* fa, bool q_in_arena, bool k_in_arena, bool v_in_arena) {
+    const size_t on = ggml_abi_nbytes(ct);
+    const bool skip[3] = {q_in_arena, k_in_arena, v_in_arena};
+    for (int j = 0; j < 3; ++j) {
+        const ggml_tensor* o = fa->src[j];
+        if (!o || skip[j]) continue;
+        const ggml_tensor* root = o->view_src ? o->view_src : o;  // a view's bytes lie inside the tensor it aliases: test that whole block
+        if (overlaps(ct->data, on, root->data, ggml_abi_nbytes(root)) || overlaps(ct->data, on, o->data, ggml_abi_nbytes(o))) return true;
+    }
+    return false;
 }
 
 View4 view_of(const ggml_tensor* t) {
@@ -2873,6 +2888,10 @@ bool plan_single(Builder& B, int i, hipStream_t s) {
                         gi.only_noops_between(i, j2, chain)) {
                         const int64_t C = d * H;
                         const auto cpart = B.cat16_part.find(ct);
+                        if (getenv("GGML_MI355X_PLAN_TRACE"))
+                            fprintf(stderr, "[plan flash] node %d of %d (view %d): d %lld H %lld Lq %lld N %lld -> %s; q16 %d kmoved %d vmoved %d; cont %p q %p k %p v %p\n", i, gi.g->n_nodes, (int)gi.is_view,
+                                    (long long)d, (long long)H, (long long)Lq, (long long)Nimg, cpart != B.cat16_part.end() && C % 8 == 0 ? "cat16 column range" : all_consumers_gemm16(gi, j2, false) ? "f16 operand image" : "f32 final layout",
+                                    (int)q16, (int)kmoved, (int)vmoved, ct->data, n->src[0]->data, n->src[1]->data, n->src[2]->data);
                         if (cpart != B.cat16_part.end() && C % 8 == 0) {
                             // the output is one column range of a Linear's operand image (plan_cat_rows16): store it there as f16, nothing else reads it
                             const Builder::Cat16Part pt = cpart->second;
@@ -2902,7 +2921,7 @@ bool plan_single(Builder& B, int i, hipStream_t s) {
                                 launch_flash_attn(st, f2, qfix(q), kfix(k), vfix(v), sc);
                             });
                             B.packed[ct] = Packed{off, ld, false};
-                        } else {
+                        } else if (!flash_out_aliases_operand(ct, n, q16, kmoved, vmoved)) {
                             float* cdst = (float*)ct->data;
                             B.emit([=](hipStream_t st) {
                                 FlashOut f2;
@@ -2913,6 +2932,14 @@ bool plan_single(Builder& B, int i, hipStream_t s) {
                                 f2.nb_n = Lq * C * 4;
                                 launch_flash_attn(st, f2, qfix(q), kfix(k), vfix(v), sc);
                             });
+                        } else {
+                            // the graph allocator handed the CONT the block of a Q / K / V operand that dies at the flash node (found at SD3.5-large batch 2, where the
+                            // CONT got V's block: every output was NaN): writing the final layout from inside the kernel would overwrite operand rows other
+                            // workgroups still read.  The node's own output never aliases its operands: run it plain, VIEW -> CONT as a copy
+                            g_stats.flash_out_alias++;
+                            B.emit([=](hipStream_t st) { launch_flash_attn(st, fo, qfix(q), kfix(k), vfix(v), sc); });
+                            g_stats.fused_attention++;
+                            return true;
                         }
                         gi.done[j1] = gi.done[j2] = 1;
                         g_stats.fused_attention++;
@@ -3994,6 +4021,7 @@ void planner_get_stats(ggml_backend_mi355x_stats* o) {
     o->hoisted_mod_linears   = g_stats.hoisted_mod_linears;
     o->jit_overlapped        = g_stats.jit_overlapped;
     o->qinloop_linears       = g_stats.qinloop_linears;
+    o->flash_out_alias       = g_stats.flash_out_alias;
     o->fused_attention       = g_stats.fused_attention;
     o->generic_matmul        = g_stats.generic_matmul;
     o->swizzled_weight_bytes = g_stats.swizzled_weight_bytes;

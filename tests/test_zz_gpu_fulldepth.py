@@ -123,3 +123,37 @@ def test_flux_dev_full_depth_vs_oracle(sd, oracle, gpu):
         x = x[:, :, :32, :32]
         c = c[:, :64]
     sweep(sd, oracle, gpu, "FLUX.1-dev q4_0, 4096+256 tokens", models, sd.Q4_0, (x, t, c, y), 2e-2)
+
+
+@full
+@pytest.mark.parametrize("name", ["SD35_WIDE2", "FLUX_WIDE1"])
+def test_full_width_dit_at_batch_two_vs_oracle(sd, oracle, gpu, name):
+    """Batch 2 / 4 at full width (round 6).  Every full-size DiT test ran ONE image; at batch 2 with >= 1024 tokens the graph allocator gives the CONT that ends
+    FLASH_ATTN_EXT -> VIEW -> CONT the block of the attention's V operand (dead after the flash node), and the flash kernel — which writes that CONT's final layout
+    itself — overwrote V rows other workgroups were still reading: EVERY output of SD3.5-large / FLUX.1-dev was NaN from batch 2 on (the bench's sd35 leg ran on NaN
+    data).  The fusion now checks the CONT against the operands it reads from the graph buffer (flash_out_aliases_operand) and runs the node plain where they share
+    memory.  Two full-width blocks, 1024 image tokens, batches 2 and 4, against the exact oracle; the batch-2 SD3.5 case must take the guarded path."""
+    rng = np.random.default_rng(603)
+    flux = name.startswith("FLUX")
+    lat = 64 if ON_GPU else 16
+    ntok, ydim = (256, 768) if flux else (154, 2048)
+    wtype = sd.Q4_0 if flux else sd.BF16
+    for n in ((2, 4) if ON_GPU else (2,)):
+        x = rng.standard_normal((n, 16, lat, lat)).astype(np.float32)
+        t = np.linspace(0.3, 0.8, n).astype(np.float32) if flux else np.linspace(200.0, 800.0, n).astype(np.float32)
+        c = rng.standard_normal((n, ntok if ON_GPU else 32, 4096)).astype(np.float32)
+        y = rng.standard_normal((n, ydim)).astype(np.float32)
+        exact, t_x, _ = oracle_forward(sd, oracle, getattr(sd, name), wtype, (x, t, c, y), exact=True)
+        before = sd.backend_stats()["flash_out_alias"] if ON_GPU else 0
+        e = sd.Engine(model=getattr(sd, name), backend=gpu, wtype=wtype, flash_attn=True)
+        out = e.unet_forward(x, t, c, y)
+        again = e.unet_forward(x, t, c, y)
+        del e
+        alias = sd.backend_stats()["flash_out_alias"] - before if ON_GPU else 0
+        assert np.isfinite(out).all(), f"{name} batch {n}: {int((~np.isfinite(out)).sum())} non-finite outputs"
+        assert np.array_equal(out, again)
+        err = rel_l2(out, exact)
+        print(f"{name} batch {n}, {lat * lat // 4} + {c.shape[1]} tokens: GPU vs exact {err:.3e} (oracle {t_x:.0f} s); flash outputs kept off an aliased operand: {alias}")
+        assert err < 2e-2
+        for i in range(n):   # no image may be worse than the batch as a whole by much (a per-image addressing slip would show here)
+            assert rel_l2(out[i], exact[i]) < 2e-2
