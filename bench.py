@@ -382,7 +382,7 @@ def main():
     elif rank == 0:
         st = sd.backend_stats()
         out["backend"] = {k: st[k] for k in ("swizzled_weight_bytes", "qgemv_linears", "fgemv_linears", "fused_presilu", "fused_sibling_linears", "hoisted_kv_linears",
-                                             "qgemm16_linears", "jit_images", "qinloop_linears", "split_k_gemms", "fused_attention", "generic_matmul", "plans_built", "graph_replays")}
+                                             "qgemm16_linears", "jit_images", "qinloop_linears", "flash_out_alias", "flash_slice_images", "split_k_gemms", "fused_attention", "generic_matmul", "plans_built", "graph_replays")}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -590,6 +590,7 @@ def model_leg(sd, backend_name, args, name):
     res["weight_image_bytes"] = st1["swizzled_weight_bytes"] - st0["swizzled_weight_bytes"]   # f16 images kept resident (cached) for this model
     res["jit_image_linears"] = st1["jit_images"] - st0["jit_images"]   # quantised Linears planned WITHOUT a resident image (rebuilt per launch, option jit_qimages)
     res["inloop_dequant_linears"] = st1["qinloop_linears"] - st0["qinloop_linears"]   # ... and those whose GEMM reads the raw GGUF blocks and dequantises them in its main loop (no image at all)
+    res["flash_out_alias"] = st1["flash_out_alias"] - st0["flash_out_alias"]   # attention outputs NOT written in their final layout by the flash kernel because the allocator gave that buffer an operand's block
     res["raw_block_few_row_linears"] = (st1["qgemm16_linears"] - st0["qgemm16_linears"]) + (st1["qgemv_linears"] - st0["qgemv_linears"])   # k_qgemm16 / k_qgemv plans (<= 512 rows)
     del eng
     return res

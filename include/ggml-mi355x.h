@@ -100,6 +100,7 @@ struct ggml_backend_mi355x_stats {
     int64_t view_external_nodes; /* nodes of those slices treated as read outside the slice (parent use_counts > readers inside, the slice's last node and its sources) */
     int64_t qinloop_linears;     /* q8_0 / q4_0 Linears above k_qgemm16's row range planned on the pipelined 256 x 256 tile with the raw GGUF blocks dequantised INSIDE the main loop (k_gemm16<..., QT>): no f16 weight image, resident or rebuilt */
     int64_t flash_out_alias;     /* FLASH_ATTN_EXT -> VIEW -> CONT chains NOT written by the flash kernel itself because the graph allocator gave the CONT the block of a Q / K / V operand (the node runs plain, the CONT as a copy) */
+    int64_t flash_slice_images;  /* token-slice views of an attention output registered on the flash kernel's f16 operand image (their Linears read runs of rows out of it: no f32 tensor, no pack pass) */
 };
 GGML_MI355X_API void ggml_backend_mi355x_get_stats(struct ggml_backend_mi355x_stats* out);
 /* Host enum numbering, resolved BY NAME.  The numeric values of `enum ggml_op` / `enum ggml_unary_op` in ggml-abi.h are a recollection of upstream, and
@@ -161,7 +162,7 @@ GGML_MI355X_API int ggml_backend_mi355x_get_kernel_timings(struct ggml_backend_m
  * "gemm16_swp" (0; 1 = the 256-row Linear tiles with the accumulator transposed, 16-byte epilogue accesses: correct, measured 1 % slower per SD1.5 step);
  * round 6: "qinloop_min_rows" (513: q8_0 / q4_0 Linears with at least that many activation rows whose launch takes the pipelined 256 x 256 tile read the RAW GGUF blocks and
  * dequantise them inside the GEMM's main loop — no f16 weight image, cached or rebuilt; 0 = off: cached image, or "jit_qimages" rebuild), "qgemm16_pf" (1; 2 = two
- * segments of loads in flight in k_qgemm16: measured slower), "hoist_mod" (1), "jit_overlap" (0), "plan_cache_cap" (512), "gn_split_min" (65536);
+ * segments of loads in flight in k_qgemm16: measured slower), "fuse_flash_slices" (1: the proj Linears of an MMDiT / FLUX double block read their token slices out of the flash kernel's f16 image), "gemm16_t192p" (1: the pipelined 256 x 192 Linear tile where it quantises better on 256 CUs), "hoist_mod" (1), "jit_overlap" (0), "plan_cache_cap" (512), "gn_split_min" (65536);
  * "fuse_ln_reduce" (1: the slab reduce of a split-K Linear also writes the f16 operand image of the LayerNorm that reads its result);
  * flash attention: "flash_vtr" (31: bit per head-dim class — V tiles row-major in LDS, fragments by ds_read_b64_tr_b16; 0 = transposing staging pass),
  * "flash_ovl" (1: the two-block d = 40 kernel issues one block's softmax inside the other block's MFMAs; 2: also the other d <= 48 launches; 0: off),

@@ -25,3 +25,5 @@ y = rng.standard_normal((n, ydim)).astype(np.float32)
 eng = sd.Engine(model=getattr(sd, mattr), backend="MI355X0", wtype=getattr(sd, wattr), flash_attn=True)
 out = eng.unet_forward(x, t, ctx, y)
 print(f"{mattr} latent {lat} batch {n}: finite {bool(np.isfinite(out).all())}", flush=True)
+st = sd.backend_stats()
+print({k: st[k] for k in ("flash_slice_images", "flash_out_alias", "fused_attention", "qinloop_linears", "qgemm16_linears")}, flush=True)

@@ -318,7 +318,7 @@ def load_mi355x_backend() -> None:
 
 _BACKEND_STAT_FIELDS = ("graphs_computed plans_built nodes_seen kernels_planned kernels_launched fused_conv fused_conv_bounced fused_linear "
                         "fused_norm fused_geglu fused_attention generic_matmul swizzled_weight_bytes graph_replays fused_linear_geglu "
-                        "split_k_gemms head_major_gemms fused_modulate fused_gate fused_gelu fused_rope fused_concat_heads qgemv_linears fused_chan_add fused_proj_tokens gemm_attention fused_q16 split_k_inlaunch qgemm16_linears fgemv_linears fused_presilu fused_sibling_linears hoisted_kv_linears window_convs hoisted_emb_linears fused_rows16 fused_joint_qkv jit_images fused_cat_rows16 fused_gn_stats fused_ln_reduce redirect_fallbacks fused_concat_gn fused_conv_scale view_graphs plans_evicted hoisted_mod_linears jit_overlapped view_external_nodes qinloop_linears flash_out_alias").split()
+                        "split_k_gemms head_major_gemms fused_modulate fused_gate fused_gelu fused_rope fused_concat_heads qgemv_linears fused_chan_add fused_proj_tokens gemm_attention fused_q16 split_k_inlaunch qgemm16_linears fgemv_linears fused_presilu fused_sibling_linears hoisted_kv_linears window_convs hoisted_emb_linears fused_rows16 fused_joint_qkv jit_images fused_cat_rows16 fused_gn_stats fused_ln_reduce redirect_fallbacks fused_concat_gn fused_conv_scale view_graphs plans_evicted hoisted_mod_linears jit_overlapped view_external_nodes qinloop_linears flash_out_alias flash_slice_images").split()
 
 
 class BackendStats(C.Structure):

@@ -163,11 +163,11 @@ namespace {
 struct Stats {
     std::atomic<int64_t> graphs_computed{0}, plans_built{0}, nodes_seen{0}, kernels_planned{0}, kernels_launched{0}, fused_conv{0},
         fused_conv_bounced{0}, fused_linear{0}, fused_norm{0}, fused_geglu{0}, fused_attention{0}, generic_matmul{0}, swizzled_weight_bytes{0}, fused_linear_geglu{0}, split_k_gemms{0}, head_major_gemms{0}, fused_modulate{0}, fused_gate{0}, fused_gelu{0}, fused_rope{0}, fused_concat_heads{0},
-        graph_replays{0}, qgemv_linears{0}, fused_chan_add{0}, fused_proj_tokens{0}, gemm_attention{0}, fused_q16{0}, split_k_inlaunch{0}, qgemm16_linears{0}, fgemv_linears{0}, fused_presilu{0}, fused_sibling_linears{0}, hoisted_kv_linears{0}, window_convs{0}, hoisted_emb_linears{0}, fused_rows16{0}, fused_cat_rows16{0}, fused_joint_qkv{0}, jit_images{0}, fused_gn_stats{0}, redirect_fallbacks{0}, fused_ln_reduce{0}, fused_concat_gn{0}, fused_conv_scale{0}, view_graphs{0}, view_external_nodes{0}, plans_evicted{0}, hoisted_mod_linears{0}, jit_overlapped{0}, qinloop_linears{0}, flash_out_alias{0};
+        graph_replays{0}, qgemv_linears{0}, fused_chan_add{0}, fused_proj_tokens{0}, gemm_attention{0}, fused_q16{0}, split_k_inlaunch{0}, qgemm16_linears{0}, fgemv_linears{0}, fused_presilu{0}, fused_sibling_linears{0}, hoisted_kv_linears{0}, window_convs{0}, hoisted_emb_linears{0}, fused_rows16{0}, fused_cat_rows16{0}, fused_joint_qkv{0}, jit_images{0}, fused_gn_stats{0}, redirect_fallbacks{0}, fused_ln_reduce{0}, fused_concat_gn{0}, fused_conv_scale{0}, view_graphs{0}, view_external_nodes{0}, plans_evicted{0}, hoisted_mod_linears{0}, jit_overlapped{0}, qinloop_linears{0}, flash_out_alias{0}, flash_slice_images{0};
 } g_stats;
 
 struct Options {
-    std::atomic<int> fusion{1}, mfma_gemm{1}, hip_graph{1}, flash_pattern{1}, gemm16{1}, fuse_modulate{1}, fuse_gate{1}, fuse_gelu{1}, fuse_rope{1}, fuse_concat_heads{1}, qgemv{1}, fuse_chan_add{1}, fuse_proj_tokens{1}, fuse_q16{1}, qgemm16{1}, fgemv{1}, fuse_siblings{1}, hoist_kv{1}, hoist_emb{1}, fuse_rows16{0}, fuse_cat_rows16{1}, fuse_joint_qkv{1}, jit_qimages{4096}, fuse_gn_stats{1}, fuse_ln_reduce{1}, relax_res_overlap{1}, fuse_split_gelu{1}, fuse_concat_gn{1}, fuse_gn_tokens{1}, fuse_linear_nchw{1}, fuse_conv_scale{1}, ignore_use_counts{0}, plan_cache_cap{512}, hoist_mod{1}, jit_overlap{0};
+    std::atomic<int> fusion{1}, mfma_gemm{1}, hip_graph{1}, flash_pattern{1}, gemm16{1}, fuse_modulate{1}, fuse_gate{1}, fuse_gelu{1}, fuse_rope{1}, fuse_concat_heads{1}, qgemv{1}, fuse_chan_add{1}, fuse_proj_tokens{1}, fuse_q16{1}, qgemm16{1}, fgemv{1}, fuse_siblings{1}, hoist_kv{1}, hoist_emb{1}, fuse_rows16{0}, fuse_cat_rows16{1}, fuse_joint_qkv{1}, jit_qimages{4096}, fuse_gn_stats{1}, fuse_ln_reduce{1}, relax_res_overlap{1}, fuse_split_gelu{1}, fuse_concat_gn{1}, fuse_gn_tokens{1}, fuse_linear_nchw{1}, fuse_conv_scale{1}, ignore_use_counts{0}, plan_cache_cap{512}, hoist_mod{1}, jit_overlap{0}, fuse_flash_slices{1};
 } g_opt;
 
 // One launch (or a few) of a plan.  tag 2 marks the just-in-time weight-image rebuild of a quantised Linear (k_wswz_q, option jit_qimages): build_plan's
@@ -492,6 +492,9 @@ struct Packed {
     int64_t ld;     // row stride in halfs (K or C rounded up to 64)
     bool nhwc;      // [N][H*W][Cp] image of an NCHW tensor (else [rows][Kp] of a row-major tensor)
     float mul = 1.f;  // the image holds f16(value * mul): Conv2d scale folded into the operand (SDXL VAE, ggml_extend.hpp:1131-1171)
+    // rows in runs: row r of the tensor is image row (r / runL) * runS + r % runL from `off` on — a token slice [C, L, N] of an attention output whose image holds
+    // all Lq tokens of each of the N images (runL = L, runS = Lq; off addresses the slice's first row).  0: consecutive rows
+    int64_t runL = 0, runS = 0;
 };
 
 struct Builder {
@@ -834,6 +837,55 @@ bool linear_fast_ok(const ggml_tensor* n) {
     return true;
 }
 
+// The CONT [d, H, Lq, N] that ends FLASH_ATTN_EXT -> VIEW -> CONT (node j2) is read only through RESHAPE [C, Lq, N] -> VIEWs that each take a row range
+// [row0, row0 + L) of every image at full width, and every such VIEW feeds only gen-2 weight GEMMs (to_out of the context / x streams of an MMDiT block, the txt /
+// img proj of a FLUX double block).  Direct MUL_MAT readers of the RESHAPE are fine too (all_consumers_gemm16's case, registered by the caller).
+struct FlashSlice {
+    const ggml_tensor* view;
+    int64_t row0, L;
+};
+bool flash_out_token_slices(const GInfo& gi, int j2, int64_t C, int64_t Lq, int64_t N, std::vector<FlashSlice>& out) {
+    out.clear();
+    if (!g_opt.gemm16 || !g_opt.mfma_gemm || !g_opt.fusion || !g_opt.fuse_flash_slices || C % 8 != 0) return false;
+    const ggml_tensor* ct = gi.node(j2);
+    if ((ct->flags & GGML_TENSOR_FLAG_OUTPUT) || j2 == gi.g->n_nodes - 1) return false;
+    std::vector<int> work{j2};
+    int n_real = 0;
+    while (!work.empty()) {
+        const int k = work.back();
+        work.pop_back();
+        if (gi.consumers[k].empty()) return false;
+        for (int c : gi.consumers[k]) {
+            const ggml_tensor* cn = gi.node(c);
+            if (cn->flags & GGML_TENSOR_FLAG_OUTPUT) return false;
+            if (xop(cn) == GGML_OP_RESHAPE) {
+                work.push_back(c);
+                continue;
+            }
+            // the [d, H, Lq, N] VIEW of the node's output (ggml_extend.hpp:1446-1455) when it is not followed by a CONT (one image: already contiguous): same bytes
+            if (xop(cn) == GGML_OP_VIEW && cn->data == ct->data && contig(cn) && ggml_abi_nelements(cn) == ggml_abi_nelements(ct) && is_f32(cn)) {
+                work.push_back(c);
+                continue;
+            }
+            if (xop(cn) == GGML_OP_MUL_MAT && strip_reshape(cn->src[1]) == ct && linear_fast_ok(cn)) {
+                ++n_real;
+                continue;
+            }
+            if (xop(cn) != GGML_OP_VIEW || !is_f32(cn) || cn->ne[0] != C || cn->nb[0] != 4 || (int64_t)cn->nb[1] != C * 4 || cn->ne[2] != N || cn->ne[3] != 1 ||
+                (N > 1 && (int64_t)cn->nb[2] != Lq * C * 4))
+                return false;
+            const int64_t byte0 = (const char*)cn->data - (const char*)ct->data;
+            if (byte0 < 0 || byte0 % (C * 4) != 0) return false;
+            const int64_t row0 = byte0 / (C * 4);
+            if (row0 + cn->ne[1] > Lq || cn->ne[1] < 1) return false;
+            if (!all_consumers_gemm16(gi, c, false)) return false;
+            out.push_back(FlashSlice{cn, row0, cn->ne[1]});
+            ++n_real;
+        }
+    }
+    return n_real > 0 && !out.empty();
+}
+
 // CONT node i = CONT(PERMUTE(1,0,2,3)(t)) of a token-major tensor t [C, HW, N] feeding RESHAPE [W,H,C,N] -> the IM2COL of a fusable 1x1 conv
 // (SpatialTransformer proj_out, block.hpp:566-572) and nothing else.  On success *rs_out = the last RESHAPE (the conv's input tensor).
 static bool tokens_to_conv_match(const GInfo& gi, int i, int* rs_out) {
@@ -1167,8 +1219,25 @@ void plan_linear(Builder& B, int i, hipStream_t s, std::vector<int>& chain) {
             if (it->second.nhwc) it->second = pk;
         }
         Planner* P       = B.P;
-        const size_t off = it->second.off;
+        size_t off       = it->second.off;
         const int64_t ld = it->second.ld;
+        if (it->second.runL > 0) {
+            // the rows sit in runs inside a wider f16 image (a token slice of an attention output, plan_single FLASH_ATTN_EXT): the plain Linear launches take the
+            // run geometry; launches that cannot (grouped head-major projections, GEGLU, the NCHW epilogue) get the rows gathered into an image of their own first
+            const int64_t rL = it->second.runL, rS = it->second.runS;
+            if (geglu_out >= 0 || hm_d > 0 || nchw_add >= 0) {
+                const size_t goff = B.alloc((size_t)tokens * ld * 2), soff = off;
+                const int64_t nrun = tokens / rL;
+                B.emit([=](hipStream_t st) {
+                    for (int64_t r = 0; r < nrun; ++r)
+                        (void)hipMemcpyAsync(P->arena + goff + (size_t)(r * rL * ld * 2), P->arena + soff + (size_t)(r * rS * ld * 2), (size_t)(rL * ld * 2), hipMemcpyDeviceToDevice, st);
+                });
+                off = goff;
+            } else {
+                ep.a_run_L = rL;
+                ep.a_run_S = rS;
+            }
+        }
         if (nchw_add >= 0 && !useq && swz && ld == rup64(K) && geglu_out < 0 && gelu_out < 0 && !ep.gate && !redir) {
             float* ndst             = (float*)gi.node(nchw_add)->data;
             const int64_t HWt = nchw_HW, Nimg = nchw_N;
@@ -2905,11 +2974,23 @@ bool plan_single(Builder& B, int i, hipStream_t s) {
                                 launch_flash_attn(st, f2, qfix(q), kfix(k), vfix(v), sc);
                             });
                             B.cat16[pt.cat].written[pt.part] = true;
-                        } else if (all_consumers_gemm16(gi, j2, false)) {
-                            // every reader is a weight GEMM (to_out): emit only the f16 operand image [tok][C]
+                        } else if (std::vector<FlashSlice> slices; all_consumers_gemm16(gi, j2, false) || flash_out_token_slices(gi, j2, C, Lq, Nimg, slices)) {
+                            // every reader is a weight GEMM (to_out) — directly, or through token slices of the [C, Lq, N] tensor (MMDiT block_mixing, mmdit.hpp:651-667;
+                            // FLUX double blocks: the txt / img rows of the joint attention go to two proj Linears): emit only the f16 operand image [tok][C]; a slice's
+                            // Linear reads its rows out of it (runs of L rows, Lq apart: Epilogue::a_run_L / a_run_S) — no f32 tensor, no pack pass, and the image lives
+                            // in the arena, where it cannot alias an operand
                             Planner* P       = B.P;
                             const size_t off = B.alloc((size_t)Nimg * Lq * rup64(C) * 2);
                             const int64_t ld = rup64(C);
+                            for (const FlashSlice& fs : slices) {
+                                Packed pk{off + (size_t)fs.row0 * (size_t)ld * 2, ld, false};
+                                if (Nimg > 1 && fs.L != Lq) {
+                                    pk.runL = fs.L;
+                                    pk.runS = Lq;
+                                }
+                                B.packed[fs.view] = pk;
+                                g_stats.flash_slice_images++;
+                            }
                             if (ld != C) {  // zero the K padding once per launch
                                 B.emit([=](hipStream_t st) { (void)hipMemsetAsync(P->arena + off, 0, (size_t)Nimg * Lq * ld * 2, st); });
                             }
@@ -2945,6 +3026,32 @@ bool plan_single(Builder& B, int i, hipStream_t s) {
                         g_stats.fused_attention++;
                         return true;
                     }
+                }
+            }
+            // one image: the node's own [d, H, Lq] output IS the token-major [C, Lq] tensor (ggml_ext_attention_ext reshapes it without a CONT; FLUX at batch 1).  Read
+            // only through token slices feeding weight GEMMs (flux.hpp:560-575: txt_attn_out / img_attn_out -> proj): the f16 operand image again, no f32 tensor
+            if (g_opt.fusion && n->ne[3] == 1 && contig(n) && !(n->flags & GGML_TENSOR_FLAG_OUTPUT)) {
+                const int64_t d = n->ne[0], HN = n->ne[1], Lq = n->ne[2], C = d * HN;
+                std::vector<FlashSlice> slices;
+                if (flash_out_token_slices(gi, i, C, Lq, 1, slices)) {
+                    Planner* P       = B.P;
+                    const int64_t ld = rup64(C);
+                    const size_t off = B.alloc((size_t)Lq * ld * 2);
+                    if (ld != C) B.emit([=](hipStream_t st) { (void)hipMemsetAsync(P->arena + off, 0, (size_t)Lq * ld * 2, st); });
+                    B.emit([=](hipStream_t st) {
+                        FlashOut f2;
+                        f2.H     = (int)HN;
+                        f2.dst16 = P->arena + off;
+                        f2.ld16  = ld;
+                        launch_flash_attn(st, f2, qfix(q), kfix(k), vfix(v), sc);
+                    });
+                    for (const FlashSlice& fs : slices) {
+                        B.packed[fs.view] = Packed{off + (size_t)fs.row0 * (size_t)ld * 2, ld, false};
+                        g_stats.flash_slice_images++;
+                    }
+                    B.packed[n] = Packed{off, ld, false};  // (a Linear reading all rows through a RESHAPE)
+                    g_stats.fused_attention++;
+                    return true;
                 }
             }
             B.emit([=](hipStream_t st) { launch_flash_attn(st, fo, qfix(q), kfix(k), vfix(v), sc); });
@@ -4022,6 +4129,7 @@ void planner_get_stats(ggml_backend_mi355x_stats* o) {
     o->jit_overlapped        = g_stats.jit_overlapped;
     o->qinloop_linears       = g_stats.qinloop_linears;
     o->flash_out_alias       = g_stats.flash_out_alias;
+    o->flash_slice_images    = g_stats.flash_slice_images;
     o->fused_attention       = g_stats.fused_attention;
     o->generic_matmul        = g_stats.generic_matmul;
     o->swizzled_weight_bytes = g_stats.swizzled_weight_bytes;
@@ -4070,6 +4178,7 @@ void planner_set_option(const char* key, int value) {
     else if (!strcmp(key, "fuse_ln_reduce")) g_opt.fuse_ln_reduce = value;
     else if (!strcmp(key, "jit_qimages")) g_opt.jit_qimages = value;
     else if (!strcmp(key, "qinloop_min_rows")) gemm16_set_qinloop_min_rows(value);
+    else if (!strcmp(key, "fuse_flash_slices")) g_opt.fuse_flash_slices = value;
     else if (!strcmp(key, "gemm16_t192p")) gemm16_set_t192p(value);
     else if (!strcmp(key, "conv3w_min_blocks")) conv3w_set_min_blocks(value);
     else if (!strcmp(key, "conv3w_min_blocks_deep")) conv3w_set_min_blocks_deep(value);

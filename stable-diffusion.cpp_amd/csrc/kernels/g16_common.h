@@ -34,6 +34,7 @@ struct G16Args {
                        // (column tile, K slice) weight chunk on ONE XCD — its row tiles run back to back there and re-read the chunk from that XCD's L2 — instead
                        // of the default order (consecutive ids of one XCD share the A rows), under which every XCD fetched every weight chunk:
                        // 297 MB fetched per launch for 29.5 MB of weights (profiles/r06c_pmc_conv256_by_shape.txt)
+    int a_runL, a_runS;  // > 0 (rows mode): A rows come in runs — row r is image row (r / a_runL) * a_runS + r % a_runL (Epilogue::a_run_L / a_run_S)
     int qt;            // 8 / 4: W points at RAW GGUF q8_0 / q4_0 rows (qrow_bytes apart), dequantised inside the main loop (k_gemm16<..., QT>: pipelined 256 x 256 tile only); 0: f16 weight image
     int64_t qrow_bytes;
     int wblk_lim;      // > 0: 32-column blocks the weight image holds (columns padded to 128): tiles wider than the padding (256-column tiles on M % 256 == 128) fetch block wblk_lim - 1 instead of reading past the image

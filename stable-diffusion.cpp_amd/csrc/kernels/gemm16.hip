@@ -187,6 +187,7 @@ __global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g
         int64_t row  = row0 + r;
         if (!CONV) {
             if (row >= g.R) row = g.R - 1;
+            if (g.a_runL > 0) row = (int64_t)((uint32_t)row / (uint32_t)g.a_runL) * g.a_runS + (uint32_t)row % (uint32_t)g.a_runL;  // rows in runs (token slices of a wider image)
             asrc[q] = g.A + row * g.lda + ls * 8;
         } else {
             // all per-position address work happens ONCE here; the K loop only adds a wave-uniform tap offset
@@ -1838,6 +1839,14 @@ void launch_gemm16_linear(hipStream_t s, float* dst, void* dst16, int64_t ldd16,
     g.abl = g_g16_abl;
 #endif
     g.ep    = {e.bias, e.residual, e.scale, e.gate, e.gate_L, e.gelu};
+    if (e.a_run_L > 0 && e.a_run_S != e.a_run_L) {
+        if (rows >= (1ll << 31) || e.a_run_S >= (1ll << 31) || rows % e.a_run_L != 0) {
+            fprintf(stderr, "ggml-mi355x: invalid operand-run request (rows %lld, run %lld, stride %lld)\n", (long long)rows, (long long)e.a_run_L, (long long)e.a_run_S);
+            abort();
+        }
+        g.a_runL = (int)e.a_run_L;
+        g.a_runS = (int)e.a_run_S;
+    }
     if (e.qtype) {
         g.qt         = e.qtype == 8 ? 8 : 4;
         g.qrow_bytes = e.qrow_bytes;

@@ -112,6 +112,11 @@ struct Epilogue {
     // qrow_bytes apart; the blocks are dequantised inside the GEMM's main loop (k_gemm16<..., QT>).  Only for launches gemm16_qinloop_supported accepts.
     int qtype             = 0;
     int64_t qrow_bytes    = 0;
+    // gemm16 / qgemm16 linear only: the f16 operand image holds the rows in RUNS — row r of the Linear is image row (r / a_run_L) * a_run_S + r % a_run_L (the pointer
+    // handed to the launch addresses row 0).  A token slice [C, L, N] of an attention output whose f16 image the flash kernel wrote for all (Lq > L) tokens of each of
+    // the N images (MMDiT block_mixing, mmdit.hpp:651-667): a_run_L = L, a_run_S = Lq.  0 = rows are consecutive.
+    int64_t a_run_L       = 0;
+    int64_t a_run_S       = 0;
 };
 // ---- gemm16.hip: second-generation contraction, both operands f16 via LDS-DMA -------------------------------
 // a16: f16 row-major [rows][lda] (K contiguous, padded to 64); output f32 [rows][ldd] and/or f16 [rows][ldd16]

@@ -538,6 +538,7 @@ struct QG16Args {
     int R, M;
     int nseg, nseg_slice;
     int64_t slab;  // > 0: split-K, slice z writes acc * scale to dst + z * slab (bias / residual are added by the reduce pass)
+    int a_runL, a_runS;  // > 0: A rows in runs (Epilogue::a_run_L / a_run_S)
 };
 
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
@@ -587,6 +588,9 @@ __global__ __launch_bounds__(256) void k_qgemm16(QG16Args g) {
 
     u32x4_t wreg[NLW], areg[NLA];
     u32x4_t wreg2[PF > 1 ? NLW : 1], areg2[PF > 1 ? NLA : 1];  // second register set (PF = 2)
+    auto a_phys = [&](int64_t r) -> int64_t {  // rows in runs (token slices of a wider operand image)
+        return g.a_runL > 0 ? (int64_t)((uint32_t)r / (uint32_t)g.a_runL) * g.a_runS + (uint32_t)r % (uint32_t)g.a_runL : r;
+    };
     auto fetch_into = [&](int seg, u32x4_t* wr, u32x4_t* ar) {
 #pragma unroll
         for (int i = 0; i < NLW; ++i) {
@@ -602,7 +606,7 @@ __global__ __launch_bounds__(256) void k_qgemm16(QG16Args g) {
             const int row     = idx >> 5, gr = idx & 31;
             const int64_t grw = row0 + row;
             ar[i]             = (u32x4_t){0, 0, 0, 0};
-            if (grw < g.R) ar[i] = *(const u32x4_t*)(g.A + grw * g.lda + (int64_t)seg * 256 + gr * 8);
+            if (grw < g.R) ar[i] = *(const u32x4_t*)(g.A + a_phys(grw) * g.lda + (int64_t)seg * 256 + gr * 8);
         }
     };
     auto stash = [&](const u32x4_t* wr, const u32x4_t* ar) {  // registers -> LDS (between two workgroup barriers)
@@ -632,7 +636,7 @@ __global__ __launch_bounds__(256) void k_qgemm16(QG16Args g) {
             const int row     = idx >> 5, gr = idx & 31;
             const int64_t grw = row0 + row;
             areg[i]           = (u32x4_t){0, 0, 0, 0};
-            if (grw < g.R) areg[i] = *(const u32x4_t*)(g.A + grw * g.lda + (int64_t)seg * 256 + gr * 8);
+            if (grw < g.R) areg[i] = *(const u32x4_t*)(g.A + a_phys(grw) * g.lda + (int64_t)seg * 256 + gr * 8);
         }
     };
     auto compute_seg = [&]() {
@@ -878,6 +882,10 @@ void launch_qgemm16(hipStream_t s, float* dst, void* dst16, int64_t ldd16, const
     g.dst = dst; g.ldd = M; g.dst16 = (_Float16*)dst16; g.ldd16 = ldd16;
     g.bias = ep.bias; g.residual = ep.residual; g.gate = ep.gate; g.gate_L = ep.gate_L > 0 ? ep.gate_L : 1; g.gelu = ep.gelu; g.scale = ep.scale;
     g.R = (int)rows; g.M = (int)M;
+    if (ep.a_run_L > 0 && ep.a_run_S != ep.a_run_L) {
+        g.a_runL = (int)ep.a_run_L;
+        g.a_runS = (int)ep.a_run_S;
+    }
     g.nseg = (int)(K / 256);
     const int S = (splitk_ws && splitk_S > 1 && !ep.gate && !ep.gelu && dst) ? splitk_S : 1;
     g.nseg_slice = (g.nseg + S - 1) / S;
