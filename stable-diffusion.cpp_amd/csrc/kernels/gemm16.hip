@@ -457,8 +457,8 @@ __global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g
     } while (0)
 #define G16_DMA_HOOK(I_)                                                                                             \
     do {                                                                                                             \
-        if (PIPE != 3 && (I_) < NPT) stage_piece((I_), kt0 + kt + NST, fbuf, c_tap, c_kh, c_kw, c_icb, c_sub);      \
-        if (PIPE != 3 && (I_) == 4 && NPT > 5) {                                                                     \
+        if (PIPE != 3 && PIPE != 5 && PIPE != 6 && (I_) < NPT) stage_piece((I_), kt0 + kt + NST, fbuf, c_tap, c_kh, c_kw, c_icb, c_sub);      \
+        if (PIPE != 3 && PIPE != 5 && PIPE != 6 && (I_) == 4 && NPT > 5) {                                                                     \
             _Pragma("unroll") for (int e_ = 5; e_ < NPT; ++e_) stage_piece(e_, kt0 + kt + NST, fbuf, c_tap, c_kh, c_kw, c_icb, c_sub); \
         }                                                                                                            \
     } while (0)
@@ -490,14 +490,14 @@ __global__ __launch_bounds__(WR * WC * 64, PIPE ? 2 : 2) void k_gemm16(G16Args g
         /* steady state: stages kt+1 .. kt+3 exist and stage kt+4 is issued — nothing in the body is conditional */               \
         for (; kt + NST < nt; ++kt) {                                                                                              \
             const uint32_t so = (uint32_t)buf * STAGE;                                                                             \
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                     \
+            if constexpr (PIPE != 6) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                            \
             G16_TIE_FRAGS(A0, BH0);                                                                                                \
             G16_KSTEP(A0, A1, BH0, BH1, aad1 + so, bad + so, 1);                                                                   \
             /* this wave's pieces of stage kt+1 have landed (two younger stages stay in flight) and all its fragment reads of       \
                stage kt are complete; the barrier then makes stage kt+1 readable and this slot refillable for everyone */           \
-            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * (NP_)) : "memory");                                            \
+            if constexpr (PIPE != 6) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * (NP_)) : "memory");                   \
             G16_TIE_FRAGS(A1, BH1);                                                                                                \
-            asm volatile("s_barrier" ::: "memory");                                                                                \
+            if constexpr (PIPE != 5 && PIPE != 6) asm volatile("s_barrier" ::: "memory");                                          \
             /* the slot just freed takes stage kt+4: its NPT LDS-DMA pieces are issued one per MFMA group of this k-step */         \
             const int fbuf    = buf;                                                                                               \
             buf               = buf == NST - 1 ? 0 : buf + 1;                                                                      \
@@ -1345,6 +1345,24 @@ static void g16_launch(hipStream_t s, G16Args& g, int64_t rows, double flops, do
                         return;
                     }
                     if (g.C % 256 != 0) g.wblk_lim = (int)(rup64(g.C, 128) / 32);
+#ifdef MI355X_EXPERIMENTS
+                    if (g_g16_abl == 1) {  // timing ablations of the pipelined 256 x 256 Linear tile (scripts/gemm_ablation.py linear): no MFMAs / no DMA after the fill
+                        k_gemm16<256, 256, false, 32, 4, 4, 2, 2><<<dim3((unsigned)(rt256 * g.ncol_tiles * mul), ny), 512, 0, s>>>(g);
+                        return;
+                    }
+                    if (g_g16_abl == 2) {
+                        k_gemm16<256, 256, false, 32, 4, 4, 2, 3><<<dim3((unsigned)(rt256 * g.ncol_tiles * mul), ny), 512, 0, s>>>(g);
+                        return;
+                    }
+                    if (g_g16_abl == 5) {  // ... and no barrier in the steady loop
+                        k_gemm16<256, 256, false, 32, 4, 4, 2, 5><<<dim3((unsigned)(rt256 * g.ncol_tiles * mul), ny), 512, 0, s>>>(g);
+                        return;
+                    }
+                    if (g_g16_abl == 6) {  // ... and no LDS waits either: the bare issue stream of fragment reads and MFMAs
+                        k_gemm16<256, 256, false, 32, 4, 4, 2, 6><<<dim3((unsigned)(rt256 * g.ncol_tiles * mul), ny), 512, 0, s>>>(g);
+                        return;
+                    }
+#endif
                     if (g16_swp_ok(g)) {
                         k_gemm16<256, 256, false, 32, 4, 4, 2, 1, true><<<dim3((unsigned)(rt256 * g.ncol_tiles * mul), ny), 512, 0, s>>>(g);
                         return;
