@@ -49,6 +49,59 @@ from pathlib import Path
 
 import numpy as np
 
+
+class SclkSampler:
+    """Shader clock and socket power of GPU 0 while a region runs: a thread asks librocm_smi64 (what `rocm-smi --showclocks --showpower` prints) every 50 ms —
+    rsmi_dev_gpu_clk_freq_get(RSMI_CLK_TYPE_SYS): frequency[current], rsmi_dev_current_socket_power_get.  The timed region is a C call that releases the GIL.
+    Reports nothing where the library or the calls are missing."""
+
+    class _Freqs(C.Structure):
+        _fields_ = [("has_deep_sleep", C.c_bool), ("num_supported", C.c_uint32), ("current", C.c_uint32), ("frequency", C.c_uint64 * 33)]
+
+    def __init__(self):
+        self.mhz, self.watts, self._stop, self._t, self.lib = [], [], False, None, None
+        try:
+            lib = C.CDLL("librocm_smi64.so")
+            if lib.rsmi_init(C.c_uint64(0)) == 0:
+                self.lib = lib
+        except OSError:
+            pass
+
+    def _run(self):
+        f, pw = self._Freqs(), C.c_uint64(0)
+        while not self._stop:
+            try:
+                if self.lib.rsmi_dev_gpu_clk_freq_get(C.c_uint32(0), C.c_int(0), C.byref(f)) == 0 and f.current < 33:
+                    self.mhz.append(int(f.frequency[f.current] // 1000000))
+                if self.lib.rsmi_dev_current_socket_power_get(C.c_uint32(0), C.byref(pw)) == 0:
+                    self.watts.append(pw.value / 1e6)
+            except (AttributeError, OSError):
+                break
+            time.sleep(0.05)
+
+    def __enter__(self):
+        import threading
+        if self.lib is not None:
+            self._t = threading.Thread(target=self._run, daemon=True)
+            self._t.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop = True
+        if self._t:
+            self._t.join(timeout=1.0)
+
+    def summary(self):
+        if not self.mhz and not self.watts:
+            return None
+        r = {"samples": max(len(self.mhz), len(self.watts))}
+        if self.mhz:
+            r["sclk_mhz_median"] = int(np.median(self.mhz))
+            r["sclk_mhz_min"] = int(min(self.mhz))
+        if self.watts:
+            r["socket_power_w_median"] = round(float(np.median(self.watts)), 0)
+        return r
+
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 if (os.cpu_count() or 1) > 32:
@@ -229,13 +282,15 @@ def main():
     timing_live = timing and args.hip_graph == 0
     if timing_live:
         sd.kernel_timing_enable(True)
+    sclk = SclkSampler()
     t0 = time.perf_counter()
-    if args.device_sampler:
-        timed_latents = trajectory(args.steps)
-    else:
-        for _ in range(args.steps):
-            step()
-    barrier()
+    with sclk:
+        if args.device_sampler:
+            timed_latents = trajectory(args.steps)
+        else:
+            for _ in range(args.steps):
+                step()
+        barrier()
     dt = time.perf_counter() - t0
     if args.device_sampler and not np.isfinite(timed_latents).all():   # a timing on NaN data is not a measurement
         raise RuntimeError(f"bench: the latents sampled in the timed region are not finite ({int((~np.isfinite(timed_latents)).sum())} of {timed_latents.size} values)")
@@ -310,6 +365,12 @@ def main():
             if roofline.get("achieved"):
                 roofline["frac_of_measured_mfma"] = round(roofline["achieved"] / cal["mfma_f16_tflops"], 4)
             roofline["value_per_measured_mfma_pflops"] = round(its / (cal["mfma_f16_tflops"] / 1e3), 2)   # it/s per measured PFLOP/s: the box-independent form of `value`
+        ss = sclk.summary()
+        if ss:   # the clock the chip actually held during the timed steps (power-capped: the nominal MFMA peak assumes 2.4 GHz)
+            ss["mfma_peak_at_that_clock_tflops"] = round(MFMA_PEAK_TFLOPS * ss["sclk_mhz_median"] / 2400.0, 1) if "sclk_mhz_median" in ss else None
+            if ss.get("mfma_peak_at_that_clock_tflops") and roofline.get("achieved"):
+                ss["dominant_family_frac_of_that"] = round(roofline["achieved"] / ss["mfma_peak_at_that_clock_tflops"], 4)
+            roofline["sustained_clock"] = ss
     roofline["whole_step_tflops"] = round(step_tflops, 2)  # all kernels + host graph build + uploads: 2*B*UNet-forward FLOPs / step wall time
     roofline["whole_step_frac"] = round(step_tflops / MFMA_PEAK_TFLOPS, 4)
     if timing and rank == 0 and not args.no_kernels:
