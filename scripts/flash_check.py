@@ -46,6 +46,17 @@ if len(sys.argv) > 1 and sys.argv[1] == "mslot64":  # d = 64: running max in a p
     base, m1, m2 = {"flash_mslot64": 0, "flash_nsel": 1}, {"flash_mslot64": 1, "flash_nsel": 1}, {"flash_mslot64": 2, "flash_nsel": 1}
     sd.backend_set_option("flash_vtr", 31)
     VARIANTS = [("warm", base), ("base", base), ("mslot", m1), ("mslot+ones", m2), ("base", base), ("mslot", m1), ("mslot+ones", m2)]
+if len(sys.argv) > 1 and sys.argv[1] == "pk":  # round 6: max subtraction / row sums as packed f32 operations (flash_pk) and, at d = 64, two query blocks per wave on top (flash_qb64)
+    base, pk, q64 = {"flash_pk": 0, "flash_qb64": 0}, {"flash_pk": 1, "flash_qb64": 0}, {"flash_pk": 0, "flash_qb64": 1}
+    sd.backend_set_option("flash_vtr", 31)
+    sd.backend_set_option("flash_nsel", 1)
+    VARIANTS = [("warm", base), ("base", base), ("pk", pk), ("qb64", q64), ("base", base), ("pk", pk), ("qb64", q64)]
+if len(sys.argv) > 1 and sys.argv[1] == "sm":  # round 6: softmax arithmetic variants of the d = 64 / d = 128 one-block kernels (flash_sm: 2 = accumulator-initialised max, 4 = v_dot2 row sums) and two query blocks per wave at d = 64
+    base = {"flash_pk": 0, "flash_qb64": 0, "flash_sm": 0}
+    VARIANTS = [("warm", base), ("base", base), ("sm2", dict(base, flash_sm=2)), ("sm4", dict(base, flash_sm=4)), ("sm6", dict(base, flash_sm=6)), ("qb64", dict(base, flash_qb64=1)),
+                ("base", base), ("sm2", dict(base, flash_sm=2)), ("sm4", dict(base, flash_sm=4)), ("sm6", dict(base, flash_sm=6)), ("qb64", dict(base, flash_qb64=1))]
+    sd.backend_set_option("flash_vtr", 31)
+    sd.backend_set_option("flash_nsel", 1)
 ONLY = sys.argv[2] if len(sys.argv) > 2 else ""  # substring filter on the case labels
 
 
@@ -85,7 +96,10 @@ def case(label, d, Lq, Lk, HN):
     sd.backend_set_option("flash_qb2", 1)
     sd.backend_set_option("flash_vpf", 31)
     sd.backend_set_option("flash_ovl", 1)
-    sd.backend_set_option("flash_nsel", 0)
+    sd.backend_set_option("flash_nsel", 1 if (len(sys.argv) > 1 and sys.argv[1] in ("pk", "sm")) else 0)
+    sd.backend_set_option("flash_sm", 0)
+    sd.backend_set_option("flash_pk", 0)
+    sd.backend_set_option("flash_qb64", 0)
     sd.backend_set_option("flash_short", 0)
     sd.backend_set_option("flash_mslot64", 0)
     k16, v16 = k.astype(np.float16).astype(np.float64), v.astype(np.float16).astype(np.float64)
@@ -112,6 +126,8 @@ if __name__ == "__main__":
     ok &= case("sdxl self d64 L4096 HN20", 64, 4096, 4096, 20)
     ok &= case("sdxl self d64 L1024 HN40", 64, 1024, 1024, 40)
     ok &= case("sdxl cross d64 Lk77 HN20", 64, 4096, 77, 20)
+    ok &= case("sdxl b8 self d64 L4096 HN160", 64, 4096, 4096, 160)
+    ok &= case("sdxl b8 self d64 L1024 HN320", 64, 1024, 1024, 320)
     ok &= case("sd35 joint d64 L4250 HN76", 64, 4250, 4250, 76)
     ok &= case("flux d128 L4352 HN24", 128, 4352, 4352, 24)
     ok &= case("tail d40 L2048 Lk1000 HN128", 40, 2048, 1000, 128)

@@ -4160,6 +4160,9 @@ void planner_set_option(const char* key, int value) {
     else if (!strcmp(key, "flash_vtr")) flash_attn_set_vtr(value);
     else if (!strcmp(key, "flash_ovl")) flash_attn_set_ovl(value);
     else if (!strcmp(key, "flash_nsel")) flash_attn_set_nsel(value);
+    else if (!strcmp(key, "flash_pk")) flash_attn_set_pk(value);
+    else if (!strcmp(key, "flash_sm")) flash_attn_set_sm(value);
+    else if (!strcmp(key, "flash_qb64")) flash_attn_set_qb64(value);
     else if (!strcmp(key, "flash_short")) flash_attn_set_short(value);
     else if (!strcmp(key, "gemm16_swp")) gemm16_set_swp(value);
     else if (!strcmp(key, "streamk")) gemm16_set_streamk(value);

@@ -110,13 +110,25 @@ constexpr int fa_vtr_stride(int ndv) {
 // thread per tile at d = 128, in a loop that is VALU-issue bound).  Here chunks that fetch nothing (the padding chunk of d = 40 / 80 rows) point their
 // buffer offset beyond num_records, so the load itself returns zeros, and full tiles (every key < Lk; a wave-uniform test) are stored as loaded;
 // only the ragged last tile takes the select path.
-template <int DKP, int NDV, bool FAST, int ABL = 0, bool MSLOT = false, int QB = 1, bool VPF = false, bool VTR = false, bool OVL = false, bool NSEL = false>
+// PK (round 6; option "flash_pk"; launches whose kernel subtracts the running max / adds the row sums on the VALU, i.e. every head dim but the d = 40 max-slot kernel):
+// those two passes over the 32 scores of a lane as PACKED f32 operations (v_pk_add_f32: two scores per issued instruction) — 33 v_sub + 34 v_add per
+// tile become 16 + 17 in a loop that is bound by instruction issue (d = 64: 165 non-MFMA VALU instructions per 64-key tile next to 16 MFMAs before, 133 with it).
+// The row sum is accumulated as two interleaved partial sums (even / odd score registers): the same terms in another association than the serial chain.
+// Measured SLOWER (profiles/r09a_flash_pk_rejected.txt: d = 64 138 -> 144 us, d = 128 329 -> 345 us): a v_pk_add_f32 is not cheaper than the two v_add_f32 it replaces here.
+// SM = softmax arithmetic variant bits: 1 = PK; 2 = MINIT (one query block per wave): the QK^T accumulator is INITIALISED with -m_run (sixteen registers holding the
+// lane's query's -m, rewritten only when the running max moves), so the scores leave the MFMA relative to the max — the d = 40 max slot's effect without a k-slot — and the
+// 32 v_sub per tile disappear; 4 = DOT2: the row sum from the f16-rounded P (the values the numerator uses) with v_dot2_f32_f16 against (1, 1): 16 instead of 32 additions.
+template <int DKP, int NDV, bool FAST, int ABL = 0, bool MSLOT = false, int QB = 1, bool VPF = false, bool VTR = false, bool OVL = false, bool NSEL = false, int SM = 0>
 __global__ __launch_bounds__(256, QB == 2 ? (DKP <= 96 ? 2 : 1) : (DKP <= 64 ? (VPF ? 2 : FA_OCC_SMALL) : (DKP <= 128 ? 2 : 1))) void k_flash_attn(FAArgs g) {
     static_assert(QB == 1 || FAST, "two query blocks per wave: FAST staging only");
     static_assert(!MSLOT || DKP == 48 || DKP == 80, "max slot: d = 40 on the 48-wide tile, d = 64 on the 80-wide tile");
     constexpr int MS_HI = DKP == 48 ? 1 : 0;  // lane half holding element d = D of the last k-step (the max slot)
     static_assert(!OVL || (QB == 2 && DKP == 48 && NDV == 2 && VPF && FAST && ABL == 0), "overlapped issue order: the two-block d <= 48 kernel only");
     static_assert(!NSEL || FAST, "select-free staging: FAST staging only");
+    constexpr bool PK = (SM & 1) != 0, MINIT = (SM & 2) != 0, DOT2 = (SM & 4) != 0;
+    static_assert(!(MINIT || DOT2) || (!OVL && !MSLOT && ABL == 0), "MINIT / DOT2: the phase-by-phase kernels without the max slot");
+    static_assert(!MINIT || (QB == 1 && DKP / 16 <= 6), "MINIT: sixteen more registers per query block — one block per wave only; written for the whole-tile fragment path (d <= 96)");
+    constexpr bool REL = MSLOT || MINIT;  // scores leave the MFMA relative to the running max
     static_assert(!VTR || FAST, "row-major V tiles: FAST staging only");
     constexpr int VRS  = fa_vtr_stride(NDV);             // VTR: V tile row stride (halfs)
     constexpr int VT_H = VTR ? FA_KT * VRS : NDV * 32 * FA_VTS;  // halfs of one V tile
@@ -237,9 +249,13 @@ __global__ __launch_bounds__(256, QB == 2 ? (DKP <= 96 ? 2 : 1) : (DKP <= 64 ? (
     for (int b = 0; b < QB; ++b) {
 #pragma unroll
         for (int nb = 0; nb < NDV; ++nb) o[b][nb] = (float16_t){0};
-        m_run[b] = MSLOT ? 0.f : -INFINITY;  // MSLOT: Q's max slot starts at 0 and the first tile always moves the max
+        m_run[b] = REL ? 0.f : -INFINITY;  // MSLOT: Q's max slot starts at 0 and the first tile always moves the max
         l_run[b] = 0.f;
     }
+
+    float16_t negm[MINIT ? QB : 1];  // MINIT: -m_run of this lane's query in all sixteen registers (the C operand of the first QK^T MFMA of each key block)
+#pragma unroll
+    for (int b = 0; b < (MINIT ? QB : 1); ++b) negm[b] = (float16_t){0};
 
     const char* kbase = g.k + (int64_t)hn * g.k_nb2;
     const char* vbase = g.v + (int64_t)hn * g.v_nb2;
@@ -278,6 +294,15 @@ __global__ __launch_bounds__(256, QB == 2 ? (DKP <= 96 ? 2 : 1) : (DKP <= 64 ? (
     // s_waitcnt vmcnt(0) (the zeroing v_mov / the 64-bit address computed INTO the destination registers needs their previous load retired, and
     // the counter cannot tell loads apart), so the 2 NCH loads of a tile paid their latencies one after the other, and inserting the constant
     // 1s right behind the loads added another wait each — the register prefetch hid nothing.
+    // (the descriptors' words are wave-uniform by construction; said explicitly, because under SGPR pressure — the two-block d = 64 instantiation — the compiler kept them in
+    // VGPRs and wrapped every tile's loads in waterfall loops)
+    auto uni_ptr = [](const char* p) {
+        const uint64_t u = (uint64_t)(uintptr_t)p;
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u), hi_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32));
+        return (const char*)(uintptr_t)(((uint64_t)hi_ << 32) | lo);
+    };
+    kbase = uni_ptr(kbase);
+    vbase = uni_ptr(vbase);
     const auto rsK = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, (int)min((int64_t)g.Lk * g.k_nb1, (int64_t)0x7fffffff), 0x00020000);
     const auto rsV = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, (int)min((int64_t)g.Lk * g.v_nb1, (int64_t)0x7fffffff), 0x00020000);
     auto gload = [&](int kt) {
@@ -420,7 +445,7 @@ __global__ __launch_bounds__(256, QB == 2 ? (DKP <= 96 ? 2 : 1) : (DKP <= 64 ? (
                 c = *(const half4_t*)(vrow + 8);
             }
         };
-        constexpr bool SHARE_KF = QB == 2 && KS <= 3;
+        constexpr bool SHARE_KF = QB == 2 && KS <= 4;
         half8_t kf[2][KS <= 6 ? KS : 1];
         // ---- online softmax for query (lane & 31) of each block; this lane holds keys kb*32 + (r&3)+8*(r>>2)+4*hi.  The loop is VALU-bound at
         // d = 40 (32 exps per lane per tile and block vs 14 MFMAs), so every instruction counts: scores arrive pre-scaled (Q carries
@@ -554,10 +579,17 @@ __global__ __launch_bounds__(256, QB == 2 ? (DKP <= 96 ? 2 : 1) : (DKP <= 64 ? (
                         for (int ks = 0; ks < KS; ++ks) kf[kb][ks] = *(const half8_t*)&Kc[(kb * 32 + (lane & 31)) * KROW + ks * 16 + hi * 8];
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                s[0] = (float16_t){0};
-                s[1] = (float16_t){0};
+                if constexpr (MINIT) {
+                    // D = A B + C with C = the -m_run registers and D = the score registers: written as the instruction itself, because the builtin ties D to C and
+                    // the compiler then copies the sixteen registers first (24 moves per tile: most of what the 32 subtractions cost)
+                    asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(s[0]) : "v"(kf[0][0]), "v"(qf[b][0]), "v"(negm[b]));
+                    asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(s[1]) : "v"(kf[1][0]), "v"(qf[b][0]), "v"(negm[b]));
+                } else {
+                    s[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0][0], qf[b][0], (float16_t){0}, 0, 0, 0);
+                    s[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[1][0], qf[b][0], (float16_t){0}, 0, 0, 0);
+                }
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks)
+                for (int ks = 1; ks < KS; ++ks)
 #pragma unroll
                     for (int kb = 0; kb < 2; ++kb) s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kb][ks], qf[b][ks], s[kb], 0, 0, 0);
             } else if constexpr (VPF && KS == 8) {
@@ -626,10 +658,22 @@ __global__ __launch_bounds__(256, QB == 2 ? (DKP <= 96 ? 2 : 1) : (DKP <= 64 ? (
 #pragma unroll
                 for (int r = 0; r < 16; ++r) tmax = __builtin_fmaxf(__builtin_fmaxf(tmax, s[0][r]), s[1][r]);  // v_max3_f32
             }
-            if (MSLOT ? (kt == 0 || __any(tmax > FA_THR)) : (ABL != 1 && __any(tmax > m_run[b] + FA_THR))) {
+            if (REL ? (kt == 0 || __any(tmax > FA_THR)) : (ABL != 1 && __any(tmax > m_run[b] + FA_THR))) {
                 tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
                 float alpha;
-                if constexpr (MSLOT) {
+                if constexpr (MINIT) {
+                    // as the max slot below, without its f16 constraint: -m enters the MFMA as an f32 accumulator value
+                    const float m_new = m_run[b] + (kt == 0 ? tmax : fmaxf(tmax, 0.f));
+                    const float delta = m_new - m_run[b];
+                    alpha             = kt == 0 ? 0.f : __builtin_amdgcn_exp2f(-delta);  // (first tile: O and l are zero)
+                    m_run[b]          = m_new;
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) s[kb][r] -= delta;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) negm[MINIT ? b : 0][r] = -m_new;
+                } else if constexpr (MSLOT) {
                     // the scores are relative to m_run already: move the max by delta (rounded so that the new max is an f16 value), re-base this
                     // tile.  The new max is clamped to the finite f16 range: the slot holds -m as f16, and +-inf there would turn every later
                     // score of the row into NaN; any consistent offset is a valid softmax shift
@@ -658,18 +702,42 @@ __global__ __launch_bounds__(256, QB == 2 ? (DKP <= 96 ? 2 : 1) : (DKP <= 64 ? (
                 }
             }
             if (ABL != 1) {
+                if constexpr (PK && !REL) {
+                    const float2_t mm = {m_run[b], m_run[b]};
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
+                    for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) s[kb][r] = __builtin_amdgcn_exp2f(MSLOT ? s[kb][r] : s[kb][r] - m_run[b]);
+                        for (int r = 0; r < 16; r += 2) {  // v_pk_add_f32 (neg): two scores per instruction
+                            const float2_t d2 = (float2_t){s[kb][r], s[kb][r + 1]} - mm;
+                            s[kb][r]          = __builtin_amdgcn_exp2f(d2[0]);
+                            s[kb][r + 1]      = __builtin_amdgcn_exp2f(d2[1]);
+                        }
+                } else {
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) s[kb][r] = __builtin_amdgcn_exp2f(REL ? s[kb][r] : s[kb][r] - m_run[b]);
+                }
             }
-            if (!has_ones) {
-                float psum = 0.f;
+            if (!has_ones && !DOT2) {
+                if constexpr (PK) {
+                    // two independent chains (a dependent v_pk_add_f32 needs a wait state after its producer: a single chain is issued with an s_nop per link)
+                    float2_t pa2 = {s[0][0], s[0][1]}, pb2 = {s[1][0], s[1][1]};
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
+                    for (int r = 2; r < 16; r += 2) {
+                        pa2 += (float2_t){s[0][r], s[0][r + 1]};
+                        pb2 += (float2_t){s[1][r], s[1][r + 1]};
+                    }
+                    pa2 += pb2;
+                    l_run[b] += pa2[0] + pa2[1];
+                } else {
+                    float psum = 0.f;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) psum += s[kb][r];
-                l_run[b] += psum;
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) psum += s[kb][r];
+                    l_run[b] += psum;
+                }
             }
 #pragma unroll
             for (int t = 0; t < 4; ++t) {  // P in f16, in the accumulator's own key order: the A operand of P V with no data movement
@@ -679,6 +747,17 @@ __global__ __launch_bounds__(256, QB == 2 ? (DKP <= 96 ? 2 : 1) : (DKP <= 64 ? (
                     const half2_t h2 = __builtin_convertvector((float2_t){s[kb][rb + j], s[kb][rb + j + 1]}, half2_t);
                     pa[b][t][j]     = h2[0];
                     pa[b][t][j + 1] = h2[1];
+                }
+            }
+            if constexpr (DOT2) {
+                if (!has_ones) {  // four independent chains of v_dot2_f32_f16 over the packed P
+                    const half2_t one2 = {(_Float16)1.0f, (_Float16)1.0f};
+                    float ps4[4]       = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int j = 0; j < 8; j += 2) ps4[j >> 1] = __builtin_amdgcn_fdot2((half2_t){pa[b][t][j], pa[b][t][j + 1]}, one2, ps4[j >> 1], false);
+                    l_run[b] += (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
                 }
             }
         }
@@ -1114,6 +1193,15 @@ __global__ __launch_bounds__(512, 2) void k_flash_pp(FAArgs g) {
         koff[c]  = kkey[c] < FA_KT ? (uint32_t)key * (uint32_t)g.k_nb1 + (uint32_t)ch * 16u : 0u;
         voff[c]  = vkey_[c] < FA_KT ? (uint32_t)vkey * (uint32_t)g.v_nb1 + (uint32_t)vch * 16u : 0u;
     }
+    // (the descriptors' words are wave-uniform by construction; said explicitly, because under SGPR pressure — the two-block d = 64 instantiation — the compiler kept them in
+    // VGPRs and wrapped every tile's loads in waterfall loops)
+    auto uni_ptr = [](const char* p) {
+        const uint64_t u = (uint64_t)(uintptr_t)p;
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u), hi_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32));
+        return (const char*)(uintptr_t)(((uint64_t)hi_ << 32) | lo);
+    };
+    kbase = uni_ptr(kbase);
+    vbase = uni_ptr(vbase);
     const auto rsK = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, (int)min((int64_t)g.Lk * g.k_nb1, (int64_t)0x7fffffff), 0x00020000);
     const auto rsV = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, (int)min((int64_t)g.Lk * g.v_nb1, (int64_t)0x7fffffff), 0x00020000);
     // registers <- global: K half of tile tk, V half of tile tv (either may lie beyond the last tile: skipped); LDS <- registers (which also inserts the
@@ -1462,6 +1550,12 @@ static int g_flash_nsel = 1;  // option "flash_nsel": 1 = select-free staging in
 void flash_attn_set_nsel(int v) { g_flash_nsel = v; }
 static int g_flash_short = 2;  // option "flash_short": k_flash_short for 64 < Lk <= 96, d <= 64 (the 77-token cross-attentions): 1 = on, 2 = with the next block's Q rows prefetched (default; round 4: 81 -> 40 us per SD1.5 64x64-level launch), 0 = the tile kernel
 void flash_attn_set_short(int v) { g_flash_short = v; }
+static int g_flash_pk = 0;  // option "flash_pk": 1 = max subtraction and row sums as packed f32 operations in the d = 64 / d = 128 kernels (k_flash_attn PK; measured SLOWER: profiles/r09a_flash_pk_rejected.txt), 0 = scalar
+void flash_attn_set_pk(int v) { g_flash_pk = v; }
+static int g_flash_sm = 0;  // option "flash_sm": softmax arithmetic variant of the d = 64 / d = 128 one-block kernels (k_flash_attn SM bits: 2 = MINIT, 4 = DOT2, 6 = both); flash_pk = 1 is bit 1
+void flash_attn_set_sm(int v) { g_flash_sm = v; }
+static int g_flash_qb64 = 0;  // option "flash_qb64": N > 0 = two query blocks per wave also at d = 64 when the launch has at least N workgroups of 256 queries (prefetching row-major-V kernel); 0 = off
+void flash_attn_set_qb64(int v) { g_flash_qb64 = v; }
 static int g_flash_pp_min_tiles = 4;  // option "flash_pp_min_tiles": key tiles (64 keys) from which the ping-pong pipeline has a steady state worth its prologue
 void flash_attn_set_pp_min_tiles(int v) { g_flash_pp_min_tiles = v; }
 
@@ -1550,7 +1644,9 @@ void launch_flash_attn(hipStream_t s, const FlashOut& out, const View4& q, const
     // two query blocks per wave: d = 40 only (d = 64 measured slower, d >= 80 spills).  Other head dims <= 48 on grids this large occur in none of the
     // supported models and no test reaches them, so by default they stay on the one-block kernels every test runs; flash_qb2 = 2 sends them here too
     const bool qb2      = !pp && g_flash_qb2 && fast && D <= 48 && (g_flash_qb2 >= 2 || (D == 40 && g_flash_mslot)) && NT >= 4 && g.Lq >= 192 && wg256 >= 512;
-    const int QWG       = (qb2 || pp) ? 256 : 128;
+    // d = 64 (round 6): the same two-block structure on the prefetching row-major-V kernel, where the launch leaves enough workgroups of 256 queries
+    const bool qb64     = !pp && g_flash_qb64 > 0 && fast && D == 64 && g_flash_nsel && (g_flash_vpf & 2) && (g_flash_vtr & 2) && NT >= 4 && g.Lq >= 192 && wg256 >= g_flash_qb64;
+    const int QWG       = (qb2 || pp || qb64) ? 256 : 128;
     dim3 grid((unsigned)((g.Lq + QWG - 1) / QWG), (unsigned)q.ne[2]);
     g.grp = g.units = 0;
     if (g_flash_grid && out.H > 0 && q.ne[2] % out.H == 0) {
@@ -1602,7 +1698,7 @@ void launch_flash_attn(hipStream_t s, const FlashOut& out, const View4& q, const
             k_flash_attn<48, 2, true, 0, true, 2, true, true, true><<<grid, 256, 0, s>>>(g);
         return;
     }
-    if (g_flash_nsel && !qb2 && fast && (D == 64 || D == 128) && (g_flash_vpf & (D == 64 ? 2 : 8)) && (g_flash_vtr & (D == 64 ? 2 : 8))) {
+    if (g_flash_nsel && !qb2 && !pp && fast && (D == 64 || D == 128) && (g_flash_vpf & (D == 64 ? 2 : 8)) && (g_flash_vtr & (D == 64 ? 2 : 8))) {
         // d = 64 is bound by instruction ISSUE (issue port 99.5 % busy, matrix pipe 40 %: profiles/r05g_pmc_sq_flash.txt).  Measured and REJECTED (round 4,
         // profiles/r05h_flash_mslot64_rejected.txt; -DMI355X_EXPERIMENTS builds keep it behind option "flash_mslot64"): trading matrix work for VALU work — the
         // running max in a fifth k-step (80-wide tile: +2 MFMAs per tile, -32 v_sub per lane) is 25-27 % SLOWER (L = 4096: 139 -> 175 us; L = 4250: 534 ->
@@ -1615,8 +1711,24 @@ void launch_flash_attn(hipStream_t s, const FlashOut& out, const View4& q, const
             k_flash_attn<80, 3, true, 0, true, 1, true, true, false, true><<<grid, 256, 0, s>>>(g);
         else
 #endif
-        if (D == 64)
+        if (D == 64 && qb64 && g_flash_pk)
+            k_flash_attn<64, 2, true, 0, false, 2, true, true, false, true, 1><<<grid, 256, 0, s>>>(g);
+        else if (D == 64 && qb64)
+            k_flash_attn<64, 2, true, 0, false, 2, true, true, false, true><<<grid, 256, 0, s>>>(g);
+        else if (D == 64 && g_flash_pk)
+            k_flash_attn<64, 2, true, 0, false, 1, true, true, false, true, 1><<<grid, 256, 0, s>>>(g);
+        else if (D == 64 && g_flash_sm == 2)
+            k_flash_attn<64, 2, true, 0, false, 1, true, true, false, true, 2><<<grid, 256, 0, s>>>(g);
+        else if (D == 64 && g_flash_sm == 4)
+            k_flash_attn<64, 2, true, 0, false, 1, true, true, false, true, 4><<<grid, 256, 0, s>>>(g);
+        else if (D == 64 && g_flash_sm == 6)
+            k_flash_attn<64, 2, true, 0, false, 1, true, true, false, true, 6><<<grid, 256, 0, s>>>(g);
+        else if (D == 64)
             k_flash_attn<64, 2, true, 0, false, 1, true, true, false, true><<<grid, 256, 0, s>>>(g);
+        else if (g_flash_pk)
+            k_flash_attn<128, 4, true, 0, false, 1, true, true, false, true, 1><<<grid, 256, 0, s>>>(g);
+        else if (g_flash_sm & 4)
+            k_flash_attn<128, 4, true, 0, false, 1, true, true, false, true, 4><<<grid, 256, 0, s>>>(g);
         else
             k_flash_attn<128, 4, true, 0, false, 1, true, true, false, true><<<grid, 256, 0, s>>>(g);
         return;

@@ -262,6 +262,9 @@ void flash_attn_set_vpf(int v);    // option "flash_vpf": bit mask of head-dim c
 void flash_attn_set_vtr(int v);    // option "flash_vtr": same bits: row-major V tiles read with the transposing LDS read (ds_read_b64_tr_b16)
 void flash_attn_set_ovl(int v);    // option "flash_ovl": 1 = overlapped issue order in the two-block d = 40 kernel (default), 2 = also the other d <= 48 two-block launches, 0 = phase by phase
 void flash_attn_set_nsel(int v);   // option "flash_nsel": 1 = select-free K / V staging in the d = 40 two-block, d = 64 and d = 128 kernels (default since round 4: bit-identical, -3..6 % per launch)
+void flash_attn_set_sm(int v);     // option "flash_sm": softmax arithmetic variant of the d = 64 / d = 128 one-block kernels (2 = accumulator-initialised max, 4 = v_dot2 row sums, 6 = both)
+void flash_attn_set_pk(int v);     // option "flash_pk": 1 = running-max subtraction and row sums as packed f32 operations (two scores per instruction; measured slower); 0 = scalar (default)
+void flash_attn_set_qb64(int v);   // option "flash_qb64": N > 0 = two query blocks per wave at d = 64 for launches with at least N workgroups of 256 queries; 0 = off
 void flash_attn_set_short(int v);  // option "flash_short": k_flash_short (K / V register-resident) for 64 < Lk <= 96, d <= 64: 0 = off, 1 = on, 2 = with the next block's Q prefetched (default)
 void gemm16_set_t256p_min_nt_sk(int v);     // option "t256p_min_nt_sk" (64): least 32-wide K stages of a Linear that stream-K could run for it to take the 256 x 256 tile
 void gemm16_set_t256p_min_tiles_sk(int v);  // option "t256p_min_tiles_sk" (192): least tiles, same condition
