@@ -77,8 +77,21 @@ enum sdm_type_t {
 
 /* SDM_SAMPLE_METHOD_COUNT = "the family's default" like the reference's SAMPLE_METHOD_COUNT (sd_get_default_sample_method,
  * stable-diffusion.cpp:3965-3975): Euler for the DiT families (SD3.5, FLUX), Euler-A otherwise */
-enum sdm_sample_method_t { SDM_EULER_SAMPLE_METHOD = 0, SDM_EULER_A_SAMPLE_METHOD = 1, SDM_SAMPLE_METHOD_COUNT = 2 };
-enum sdm_scheduler_t { SDM_DISCRETE_SCHEDULER = 0 };
+/* Numeric values = the reference's sample_method_t / scheduler_t (include/stable-diffusion.h:38-83), so integers a host already holds keep their meaning.  Implemented
+ * (host-side math, bit-for-bit against src/runtime/denoiser.hpp compiled from the reference: tests/test_host_logic.py): methods 0 ... 10; schedulers DISCRETE, KARRAS,
+ * EXPONENTIAL, AYS, SGM_UNIFORM, SIMPLE, SMOOTHSTEP, KL_OPTIMAL, LCM and FLUX.  Any other value makes sdm_generate_image / sdm_sample_latents fail with an error message
+ * (sd_last_error) instead of silently sampling something else.  SDM_SCHEDULER_COUNT = "the default for this model and method" (sd_get_default_scheduler,
+ * stable-diffusion.cpp:3977-3998): LCM for the LCM method, SIMPLE for DDIM trailing, FLUX for FLUX, DISCRETE otherwise.  Euler / Euler-A (and DDIM trailing, which the
+ * reference runs as Euler-A) take the device-resident sampler; the multi-stage and multi-step methods run the host loop around the device forward. */
+enum sdm_sample_method_t {
+    SDM_EULER_SAMPLE_METHOD = 0, SDM_EULER_A_SAMPLE_METHOD = 1, SDM_HEUN_SAMPLE_METHOD = 2, SDM_DPM2_SAMPLE_METHOD = 3, SDM_DPMPP2S_A_SAMPLE_METHOD = 4,
+    SDM_DPMPP2M_SAMPLE_METHOD = 5, SDM_DPMPP2Mv2_SAMPLE_METHOD = 6, SDM_IPNDM_SAMPLE_METHOD = 7, SDM_IPNDM_V_SAMPLE_METHOD = 8, SDM_LCM_SAMPLE_METHOD = 9,
+    SDM_DDIM_TRAILING_SAMPLE_METHOD = 10, SDM_SAMPLE_METHOD_COUNT = 21
+};
+enum sdm_scheduler_t {
+    SDM_DISCRETE_SCHEDULER = 0, SDM_KARRAS_SCHEDULER = 1, SDM_EXPONENTIAL_SCHEDULER = 2, SDM_AYS_SCHEDULER = 3, SDM_GITS_SCHEDULER = 4, SDM_SGM_UNIFORM_SCHEDULER = 5,
+    SDM_SIMPLE_SCHEDULER = 6, SDM_SMOOTHSTEP_SCHEDULER = 7, SDM_KL_OPTIMAL_SCHEDULER = 8, SDM_LCM_SCHEDULER = 9, SDM_FLUX_SCHEDULER = 14, SDM_SCHEDULER_COUNT = 16
+};
 
 typedef struct {
     const char* backend;        /* ggml device name, case-insensitive; NULL -> "MI355X0" (stable-diffusion.h:232) */
@@ -217,6 +230,12 @@ SD_API void sd_planar_rgb_to_u8(const float* chw, int width, int height, uint8_t
  * eta INFINITY = the method's default; aux: optional 5 floats per step (c_skip, c_out, c_in, t, sigma).  Returns the ladder length, -1 on bad arguments.  For the
  * bit-exact tests against the reference's src/runtime/denoiser.hpp compiled into oracle/_ref (tests/test_host_logic.py). */
 SD_API int sd_sample_synthetic(int family, int steps, int image_seq_len, int64_t n, uint64_t seed, int method, float eta, float* out, float* aux);
+/* the same with a scheduler (sdm_scheduler_t; SDM_SCHEDULER_COUNT = the default) and any implemented method; aux receives 5 floats per MODEL CALL in call order (at most aux_calls
+ * of them); returns the number of model calls, or -1 */
+SD_API int sd_sample_synthetic2(int family, int steps, int image_seq_len, int64_t n, uint64_t seed, int method, int scheduler, float eta, float* out, float* aux, int aux_calls);
+/* sigma ladder of a denoiser family (0 CompVis SD1.x, 1 discrete flow, 2 FLUX flow, 3 CompVis with the SDXL Align-Your-Steps table) under a scheduler; shift <= 0: the family's default;
+ * returns the count (steps + 1) or -1 for a scheduler that is not implemented */
+SD_API int sd_get_sigmas_sched(int family, int scheduler, int steps, int image_seq_len, float shift, float* out);
 /* AutoEncoderKL::set_conv2d_scale (src/model/vae/auto_encoder_kl.hpp:708-717): every Conv2d of the VAE computes conv(x * s) / s + bias.  SDXL contexts start with
  * s = 1/32 — what the reference sets when no external VAE is given (src/stable-diffusion.cpp:1477-1485; `--vae` with a fixed VAE -> call this with 1) */
 SD_API bool sd_set_vae_conv2d_scale(sdm_ctx_t* ctx, float scale); /* false (sd_last_error) for a non-finite or non-positive scale; loading a file under the

@@ -107,3 +107,52 @@ REF_API void ref_planar_rgb_to_u8(const float* chw, int width, int height, uint8
     sd::Tensor<float> t({width, height, 3, 1}, std::vector<float>(chw, chw + (size_t)width * height * 3));
     preprocessing_tensor_frame_to_sd_image(t, 0, out);
 }
+
+// ---- round 6: every scheduler / sampler the product implements (sdm_scheduler_t / sdm_sample_method_t carry the reference's numeric values) ----
+namespace {
+std::shared_ptr<Denoiser> make_denoiser_shift(int family, float shift) {
+    auto d = make_denoiser(family == 3 ? 0 : family);
+    if (shift > 0.f)
+        if (auto f = std::dynamic_pointer_cast<DiscreteFlowDenoiser>(d)) f->set_shift(shift);
+    return d;
+}
+// family 3 = the CompVis denoiser under VERSION_SDXL (only the Align-Your-Steps scheduler looks at the version); FLUX.1-dev's flow shift is 1.15 (stable-diffusion.cpp:1822-1827)
+SDVersion version_of4(int family) { return family == 3 ? VERSION_SDXL : version_of(family); }
+float default_shift(int family) { return family == 2 ? 1.15f : 0.f; }
+}  // namespace
+
+REF_API int ref_get_sigmas_sched(int family, int scheduler, int steps, int image_seq_len, float shift, float* out) {
+    auto d = make_denoiser_shift(family, shift > 0.f ? shift : default_shift(family));
+    const std::vector<float> s = d->get_sigmas((uint32_t)steps, image_seq_len, (scheduler_t)scheduler, version_of4(family));
+    std::memcpy(out, s.data(), sizeof(float) * s.size());
+    return (int)s.size();
+}
+// sample_k_diffusion under any method / scheduler on the synthetic model; aux: 5 floats per MODEL CALL in call order (at most aux_calls); returns the number of model calls
+REF_API int ref_sample_synthetic2(int family, int steps, int image_seq_len, int64_t n, uint64_t seed, int method, int scheduler, float eta, float* out, float* aux, int aux_calls) {
+    auto d = make_denoiser_shift(family, default_shift(family));
+    const std::vector<float> sigmas = d->get_sigmas((uint32_t)steps, image_seq_len, (scheduler_t)scheduler, version_of4(family));
+    auto rng = std::make_shared<PhiloxRNG>();
+    rng->manual_seed(seed);
+    sd::Tensor<float> noise  = sd::Tensor<float>::randn({n}, rng);
+    sd::Tensor<float> latent = sd::Tensor<float>::zeros({n});
+    sd::Tensor<float> x      = d->noise_scaling(sigmas[0], noise, latent);
+    int calls = 0;
+    denoise_cb_t model = [&](const sd::Tensor<float>& xin, float sigma, int) {
+        if (aux && calls < aux_calls) {
+            const std::vector<float> sc = d->get_scalings(sigma);
+            float* a = aux + 5 * (size_t)calls;
+            a[0] = sc[0], a[1] = sc[1], a[2] = sc[2], a[3] = d->sigma_to_t(sigma), a[4] = sigma;
+        }
+        ++calls;
+        sd::guidance::GuiderOutput o;
+        o.pred        = sd::Tensor<float>({n});
+        const float g = 1.0f / (1.0f + sigma), h = 0.01f * sigma;
+        for (int64_t k = 0; k < n; ++k) o.pred.data()[k] = xin.data()[k] * g + h;
+        return o;
+    };
+    const bool flow = family == 1 || family == 2;
+    sd::Tensor<float> r = sample_k_diffusion((sample_method_t)method, model, std::move(x), sigmas, rng, eta, flow, nullptr);
+    if (r.numel() != n) return -1;
+    std::memcpy(out, r.data(), sizeof(float) * (size_t)n);
+    return calls;
+}

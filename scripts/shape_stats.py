@@ -10,7 +10,7 @@ import sys
 db, log = sys.argv[1], sys.argv[2]
 con = sqlite3.connect(db)
 kern = [(n, (e - s) / 1e3) for n, s, e in con.execute("select name, start, end from kernels where name like '%k_gemm16%' order by start")]
-lines = [l.strip() for l in open(log, errors="ignore") if l.startswith("G16 ")]
+lines = [l.strip() for l in open(log, errors="ignore") if l.startswith("G16 ") and not l.startswith("G16 tile")]  # ("G16 tile": the tile-choice line of the same launch)
 print(f"{len(kern)} dispatches, {len(lines)} trace lines")
 n = min(len(kern), len(lines))
 agg = collections.OrderedDict()

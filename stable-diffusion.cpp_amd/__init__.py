@@ -31,7 +31,11 @@ SD15, SDXL, SD15_TINY, SDXL_TINY, SD35_LARGE, SD35_TINY, FLUX_DEV, FLUX_TINY, SD
 PAIR_EXCHANGE_FN = C.CFUNCTYPE(C.c_bool, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p)
 # sdm_graph_eval_callback_t (include/sd-mi355x.h; the reference's sd_graph_eval_callback_t, include/stable-diffusion.h:442): (tensor, ask, user) -> bool
 EVAL_CALLBACK_FN = C.CFUNCTYPE(C.c_bool, C.c_void_p, C.c_bool, C.c_void_p)
-EULER, EULER_A, SAMPLE_METHOD_DEFAULT = 0, 1, 2   # DEFAULT: Euler for the DiT families, Euler-A otherwise (sd_get_default_sample_method)
+# sdm_sample_method_t / sdm_scheduler_t (include/sd-mi355x.h): the reference's numeric values (include/stable-diffusion.h:38-83)
+EULER, EULER_A, HEUN, DPM2, DPMPP2S_A, DPMPP2M, DPMPP2Mv2, IPNDM, IPNDM_V, LCM, DDIM_TRAILING = range(11)
+SAMPLE_METHOD_DEFAULT = 21   # Euler for the DiT families, Euler-A otherwise (sd_get_default_sample_method)
+SCHED_DISCRETE, SCHED_KARRAS, SCHED_EXPONENTIAL, SCHED_AYS, SCHED_GITS, SCHED_SGM_UNIFORM, SCHED_SIMPLE, SCHED_SMOOTHSTEP, SCHED_KL_OPTIMAL, SCHED_LCM = range(10)
+SCHED_FLUX, SCHEDULER_DEFAULT = 14, 16   # DEFAULT: LCM for the LCM method, SIMPLE for DDIM trailing, FLUX for FLUX, DISCRETE otherwise (sd_get_default_scheduler)
 
 
 class EngineError(RuntimeError):
@@ -624,7 +628,7 @@ class Engine:
         return out
 
     def _gen_params(self, cond, uncond, width, height, steps, cfg, seed, batch, device_batch, method, eta, cond_y=None, uncond_y=None,
-                    fuse_cfg=False, device_sampler=False):
+                    fuse_cfg=False, device_sampler=False, scheduler=SCHEDULER_DEFAULT):
         p = SdImgGenParams()
         lib().sdm_img_gen_params_init(C.byref(p))
         keep = []
@@ -647,6 +651,7 @@ class Engine:
         p.sample_params.txt_cfg = cfg
         p.sample_params.sample_steps = steps
         p.sample_params.sample_method = method
+        p.sample_params.scheduler = scheduler
         p.sample_params.eta = eta
         p.seed = seed
         p.batch_count = batch
@@ -656,9 +661,10 @@ class Engine:
         return p, keep
 
     def sample_latents(self, cond, uncond=None, width=512, height=512, steps=20, cfg=7.0, seed=42, batch=1, device_batch=0,
-                       method=SAMPLE_METHOD_DEFAULT, eta=float("inf"), cond_y=None, uncond_y=None, fuse_cfg=False, device_sampler=False) -> np.ndarray:
+                       method=SAMPLE_METHOD_DEFAULT, eta=float("inf"), cond_y=None, uncond_y=None, fuse_cfg=False, device_sampler=False,
+                       scheduler=SCHEDULER_DEFAULT) -> np.ndarray:
         p, keep = self._gen_params(cond, uncond, width, height, steps, cfg, seed, batch, device_batch, method, eta, cond_y, uncond_y, fuse_cfg,
-                                   device_sampler)
+                                   device_sampler, scheduler)
         ch = 16 if self.model in (SD35_LARGE, SD35_TINY, FLUX_DEV, FLUX_TINY, SD35_WIDE2, FLUX_WIDE1, SD3M_TINY, SD35_WIDE8, FLUX_WIDE8) else 4
         out = np.empty((batch, ch, height // 8, width // 8), dtype=np.float32)
         if not lib().sd_sample_latents(self._ctx, C.byref(p), _fptr(out)):
@@ -666,10 +672,11 @@ class Engine:
         return out
 
     def generate_image(self, cond, uncond=None, width=512, height=512, steps=20, cfg=7.0, seed=42, batch=1, device_batch=0,
-                       method=SAMPLE_METHOD_DEFAULT, eta=float("inf"), cond_y=None, uncond_y=None, fuse_cfg=False, device_sampler=False) -> np.ndarray:
+                       method=SAMPLE_METHOD_DEFAULT, eta=float("inf"), cond_y=None, uncond_y=None, fuse_cfg=False, device_sampler=False,
+                       scheduler=SCHEDULER_DEFAULT) -> np.ndarray:
         """-> uint8 [batch, H, W, 3]"""
         p, keep = self._gen_params(cond, uncond, width, height, steps, cfg, seed, batch, device_batch, method, eta, cond_y, uncond_y, fuse_cfg,
-                                   device_sampler)
+                                   device_sampler, scheduler)
         imgs = C.POINTER(SdImage)()
         n = C.c_int()
         if not lib().sdm_generate_image(self._ctx, C.byref(p), C.byref(imgs), C.byref(n)):
@@ -846,6 +853,30 @@ def sample_synthetic(family: int, steps: int, n: int, seed: int, method: int = E
     if k != steps + 1:
         raise EngineError(f"sd_sample_synthetic returned {k}")
     return out, aux
+
+
+def sample_synthetic2(family: int, steps: int, n: int, seed: int, method: int, scheduler: int = SCHEDULER_DEFAULT, eta: float = float("inf"), image_seq_len: int = 0):
+    """sd_sample_synthetic2: any implemented method / scheduler; returns (latents, aux[calls, 5] = c_skip, c_out, c_in, t, sigma per model call in call order)."""
+    L = lib()
+    L.sd_sample_synthetic2.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int64, C.c_uint64, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_int]
+    L.sd_sample_synthetic2.restype = C.c_int
+    out, aux = np.empty(n, np.float32), np.zeros((2 * steps, 5), np.float32)
+    k = L.sd_sample_synthetic2(family, steps, image_seq_len, n, seed, method, scheduler, eta, out.ctypes.data, aux.ctypes.data, 2 * steps)
+    if k < 1:
+        raise EngineError(f"sd_sample_synthetic2 returned {k}")
+    return out, aux[:k]
+
+
+def get_sigmas_sched(family: int, scheduler: int, steps: int, image_seq_len: int = 0, shift: float = 0.0) -> np.ndarray:
+    """sd_get_sigmas_sched: the ladder of a denoiser family (0 CompVis SD1.x, 1 discrete flow, 2 FLUX flow, 3 CompVis + SDXL AYS table) under sdm_scheduler_t `scheduler`."""
+    L = lib()
+    L.sd_get_sigmas_sched.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]
+    L.sd_get_sigmas_sched.restype = C.c_int
+    out = np.empty(steps + 2, np.float32)
+    k = L.sd_get_sigmas_sched(family, scheduler, steps, image_seq_len, shift, out.ctypes.data)
+    if k < 0:
+        raise EngineError(f"sd_get_sigmas_sched: scheduler {scheduler} is not implemented")
+    return out[:k].copy()
 
 
 def get_sigmas(steps: int) -> np.ndarray:

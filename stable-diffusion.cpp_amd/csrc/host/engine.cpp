@@ -480,8 +480,14 @@ struct sdm_ctx_t {
     DiscreteFlowDenoiser flow_denoiser;
     int in_channels() const { return is_flux ? 16 : (is_dit ? (int)mmdit.cfg.in_channels : unet.cfg.in_channels); }
     int out_channels() const { return is_flux ? 16 : (is_dit ? (int)mmdit.cfg.out_channels : unet.cfg.out_channels); }
-    std::vector<float> get_sigmas(uint32_t n, int image_seq_len) const {
-        return is_flux ? flux_denoiser.get_sigmas(n, image_seq_len) : (is_dit ? flow_denoiser.get_sigmas(n) : denoiser.get_sigmas(n));
+    // Denoiser::get_sigmas (denoiser.hpp:1046-1123): the scheduler sees this family's sigma_min / sigma_max / t_to_sigma.  sched = SCHED_COUNT: the family's own ladder
+    std::vector<float> get_sigmas(uint32_t n, int image_seq_len, int sched = SCHED_COUNT) const {
+        if (sched == SCHED_COUNT) sched = is_flux ? SCHED_FLUX : SCHED_DISCRETE;
+        if (sched == SCHED_FLUX) return flux_denoiser.get_sigmas(n, image_seq_len);  // FluxScheduler needs only the sequence length
+        if (is_flux) return scheduler_sigmas(sched, n, flux_denoiser.sigma_min(), flux_denoiser.sigma_max(), [&](float t) { return flux_denoiser.t_to_sigma(t); }, -1);
+        if (is_dit) return scheduler_sigmas(sched, n, flow_denoiser.sigma_min(), flow_denoiser.sigma_max(), [&](float t) { return flow_denoiser.t_to_sigma(t); }, -1);
+        const int ays = (params.model == SD_MODEL_SD15 || params.model == SD_MODEL_SD15_TINY) ? 0 : 1;  // AYSScheduler picks its table by version (denoiser.hpp:186-200)
+        return scheduler_sigmas(sched, n, denoiser.sigma_min(), denoiser.sigma_max(), [&](float t) { return denoiser.t_to_sigma(t); }, ays);
     }
     void scalings(float sigma, float& c_skip, float& c_out, float& c_in) const {
         if (is_flux)
@@ -566,7 +572,7 @@ void sdm_ctx_params_init(sdm_ctx_params_t* p) {
 void sdm_sample_params_init(sdm_sample_params_t* p) {  // stable-diffusion.cpp:3650-3667
     memset(p, 0, sizeof(*p));
     p->txt_cfg       = 7.0f;
-    p->scheduler     = SDM_DISCRETE_SCHEDULER;
+    p->scheduler     = SDM_SCHEDULER_COUNT;  // resolved per model and method at sampling time (sd_get_default_scheduler)
     p->sample_method = SDM_SAMPLE_METHOD_COUNT;  // resolved per family at sampling time (sd_get_default_sample_method)
     p->sample_steps  = 20;
     p->eta           = INFINITY;
@@ -1271,58 +1277,51 @@ static int resolve_sample_method(const sdm_ctx_t* ctx, int m) {
     if (m == SDM_SAMPLE_METHOD_COUNT) return ctx->is_dit ? SDM_EULER_SAMPLE_METHOD : SDM_EULER_A_SAMPLE_METHOD;
     return m;
 }
-static bool sample_group(sdm_ctx_t* ctx, const sdm_img_gen_params_t* p, int b0, int nb, float* out) {
-    const int W = p->width / 8, H = p->height / 8, C = ctx->in_channels();
-    const size_t per = (size_t)W * H * C;
-    const sdm_sample_params_t& sp = p->sample_params;
-    const int method = resolve_sample_method(ctx, sp.sample_method);
-    float eta        = sp.eta;
-    if (eta == INFINITY) eta = method == SDM_EULER_A_SAMPLE_METHOD ? 1.0f : 0.0f;  // resolve_eta, stable-diffusion.cpp:4024-4049
-    const std::vector<float> sigmas = ctx->get_sigmas(sp.sample_steps, W * H);  // image_seq_len = latent pixels (stable-diffusion.cpp:2983-2986)
-    const int steps                 = (int)sigmas.size() - 1;
-
-    // per-image RNG: seed+b; initial noise consumes offset 0 (stable-diffusion.cpp:5678-5683; rng == sampler_rng :886-889)
-    std::vector<PhiloxRNG> rngs;
-    std::vector<float> x(per * nb);
-    for (int b = 0; b < nb; ++b) rngs.emplace_back((uint64_t)(p->seed + b0 + b));
-    parallel_chunks((size_t)nb, [&](size_t i0, size_t i1) {
-        for (size_t b = i0; b < i1; ++b) {
-            std::vector<float> noise = rngs[b].randn((uint32_t)per);
-            for (size_t i = 0; i < per; ++i) x[b * per + i] = 0.0f + noise[i] * sigmas[0];  // noise_scaling, denoiser.hpp:1174-1179
-        }
-    }, 2);
-    const bool use_cfg = sp.txt_cfg != 1.0f && p->uncond.c_crossattn != nullptr;
-    std::vector<float> noised(per * nb), cond_out(per * nb), uncond_out(per * nb), denoised(per * nb), ts(nb);
-    std::vector<std::vector<float>> step_noise(nb);
+// resolve_scheduler / sd_get_default_scheduler (stable-diffusion.cpp:3977-3998, 4015-4022)
+static int resolve_scheduler(const sdm_ctx_t* ctx, int scheduler, int method) {
+    if (scheduler != SDM_SCHEDULER_COUNT) return scheduler;
+    if (method == SDM_LCM_SAMPLE_METHOD) return SDM_LCM_SCHEDULER;
+    if (method == SDM_DDIM_TRAILING_SAMPLE_METHOD) return SDM_SIMPLE_SCHEDULER;
+    return ctx->is_flux ? SDM_FLUX_SCHEDULER : SDM_DISCRETE_SCHEDULER;
+}
+// method / scheduler / eta of one call, resolved as generate_image does (resolve_sample_method, resolve_scheduler, resolve_eta: stable-diffusion.cpp:4006-4049).  DDIM trailing IS
+// Euler-A on the reference (sample_k_diffusion, denoiser.hpp:2843-2845) with its own eta / scheduler defaults: `method` comes back as Euler-A for it.
+static bool resolve_sampling(const sdm_ctx_t* ctx, const sdm_sample_params_t& sp, int& method, int& scheduler, float& eta) {
+    method    = resolve_sample_method(ctx, sp.sample_method);
+    scheduler = resolve_scheduler(ctx, sp.scheduler, method);
+    if (!sample_method_supported(method)) {
+        set_error("sample method " + std::to_string(method) + " is not implemented (sdm_sample_method_t: 0 ... 10)");
+        return false;
+    }
+    if (!scheduler_supported(scheduler)) {
+        set_error("scheduler " + std::to_string(scheduler) + " is not implemented (sdm_scheduler_t)");
+        return false;
+    }
+    eta = sp.eta == INFINITY ? default_eta(method) : sp.eta;
+    if (method == SDM_DDIM_TRAILING_SAMPLE_METHOD) method = SDM_EULER_A_SAMPLE_METHOD;
+    return true;
+}
+// One denoiser call of the host loop — the reference's `denoise` lambda (stable-diffusion.cpp:2620-2926) on nb images: scalings and timestep of sigma, x * c_in, the model
+// forward(s) (the cond / uncond pair in ONE graph when the conditionings allow it), classifier-free guidance, pred * c_out + x * c_skip.
+struct HostDenoise {
+    sdm_ctx_t* ctx;
+    const sdm_img_gen_params_t* p;
+    int W, H, C, nb;
+    size_t per;
+    bool use_cfg;
+    std::vector<float> noised, cond_out, uncond_out, ts;
     std::vector<float> x2, o2, t2, c2, y2;  // staging of the fused (cond, uncond) pair
-
-    for (int i = 0; i < steps; ++i) {
-        const float sigma = sigmas[i], sigma_to = sigmas[i + 1];
+    HostDenoise(sdm_ctx_t* ctx_, const sdm_img_gen_params_t* p_, int W_, int H_, int C_, int nb_)
+        : ctx(ctx_), p(p_), W(W_), H(H_), C(C_), nb(nb_), per((size_t)W_ * H_ * C_), use_cfg(p_->sample_params.txt_cfg != 1.0f && p_->uncond.c_crossattn != nullptr),
+          noised(per * nb_), cond_out(per * nb_), uncond_out(per * nb_), ts(nb_) {}
+    bool operator()(const float* x, float sigma, float* denoised) {
+        const sdm_sample_params_t& sp = p->sample_params;
+        const size_t n = per * (size_t)nb;
         float c_skip, c_out, c_in;
         ctx->scalings(sigma, c_skip, c_out, c_in);
         const float t = ctx->sigma_to_t(sigma);
         for (int b = 0; b < nb; ++b) ts[b] = t;
-        for (size_t k = 0; k < x.size(); ++k) noised[k] = x[k] * c_in;  // stable-diffusion.cpp:2662
-        // The ancestral noise of this step depends on the sigma ladder only, not on the model output: draw it (host Philox, 0.7 ms per
-        // SD1.5 image) on a helper thread WHILE the device runs the forward, instead of after it.  Same per-image streams, same order.
-        float sigma_down = 0.f, sigma_up = 0.f, alpha_scale = 1.f;
-        std::future<void> noise_job;
-        if (method == SDM_EULER_A_SAMPLE_METHOD && sigma_to != 0.f && eta != 0.f) {
-            if (ctx->is_dit)  // flow denoisers (SD3.5, FLUX): get_ancestral_step(..., is_flow_denoiser), denoiser.hpp:1501-1511
-                ancestral_step_flow(sigma, sigma_to, eta, sigma_down, sigma_up, alpha_scale);
-            else
-                ancestral_step(sigma, sigma_to, eta, sigma_down, sigma_up);
-            if (sigma_up > 0.f)
-                noise_job = std::async(std::launch::async, [&]() {
-                    for (int b = 0; b < nb; ++b) step_noise[b] = rngs[b].randn((uint32_t)per);
-                });
-        }
-        struct JoinNoise {  // an early return must not leave the helper writing into dead stack frames
-            std::future<void>& f;
-            ~JoinNoise() {
-                if (f.valid()) f.wait();
-            }
-        } join_noise{noise_job};
+        for (size_t k = 0; k < n; ++k) noised[k] = x[k] * c_in;  // stable-diffusion.cpp:2662
         auto run = [&](const sd_condition_t& cd, float* dst) {
             return sd_unet_forward(ctx, noised.data(), W, H, C, nb, ts.data(), cd.c_crossattn, cd.ctx_dim, cd.n_tokens, 1,
                                    cd.c_vector, cd.vector_dim, 1, dst);
@@ -1332,7 +1331,7 @@ static bool sample_group(sdm_ctx_t* ctx, const sdm_img_gen_params_t* p, int b0, 
             // tiled over the 2*nb images by the graph's ggml_repeat (dst[i] = src[i % 2])
             const size_t cn  = (size_t)p->cond.ctx_dim * p->cond.n_tokens;
             const bool has_y = p->cond.c_vector && p->uncond.c_vector;
-            if (x2.empty()) {  // first step: the pair's conditioning is the same for every step, the staging buffers are reused
+            if (x2.empty()) {  // first call: the pair's conditioning is the same for every step, the staging buffers are reused
                 x2.resize(2 * per * nb);
                 o2.resize(2 * per * nb);
                 t2.resize(2 * nb);
@@ -1357,7 +1356,7 @@ static bool sample_group(sdm_ctx_t* ctx, const sdm_img_gen_params_t* p, int b0, 
                 memcpy(&cond_out[b * per], &o2[(2 * b) * per], per * sizeof(float));
                 memcpy(&uncond_out[b * per], &o2[(2 * b + 1) * per], per * sizeof(float));
             }
-            for (size_t k = 0; k < x.size(); ++k) {
+            for (size_t k = 0; k < n; ++k) {
                 const float guided = cfg_guided(cond_out[k], uncond_out[k], sp.txt_cfg);
                 denoised[k]        = guided * c_out + x[k] * c_skip;
             }
@@ -1365,13 +1364,82 @@ static bool sample_group(sdm_ctx_t* ctx, const sdm_img_gen_params_t* p, int b0, 
             return false;
         } else if (use_cfg) {
             if (!run(p->uncond, uncond_out.data())) return false;
-            for (size_t k = 0; k < x.size(); ++k) {  // guidance.cpp:171 ; stable-diffusion.cpp:2876
+            for (size_t k = 0; k < n; ++k) {  // guidance.cpp:171 ; stable-diffusion.cpp:2876
                 const float guided = cfg_guided(cond_out[k], uncond_out[k], sp.txt_cfg);
                 denoised[k]        = guided * c_out + x[k] * c_skip;
             }
         } else {
-            for (size_t k = 0; k < x.size(); ++k) denoised[k] = cond_out[k] * c_out + x[k] * c_skip;
+            for (size_t k = 0; k < n; ++k) denoised[k] = cond_out[k] * c_out + x[k] * c_skip;
         }
+        return true;
+    }
+};
+static bool sample_group(sdm_ctx_t* ctx, const sdm_img_gen_params_t* p, int b0, int nb, float* out) {
+    const int W = p->width / 8, H = p->height / 8, C = ctx->in_channels();
+    const size_t per = (size_t)W * H * C;
+    const sdm_sample_params_t& sp = p->sample_params;
+    int method, scheduler;
+    float eta;
+    if (!resolve_sampling(ctx, sp, method, scheduler, eta)) return false;
+    const std::vector<float> sigmas = ctx->get_sigmas(sp.sample_steps, W * H, scheduler);  // image_seq_len = latent pixels (stable-diffusion.cpp:2983-2986)
+    const int steps                 = (int)sigmas.size() - 1;
+    if (steps < 1) {
+        set_error("the scheduler returned no sigma ladder for " + std::to_string(sp.sample_steps) + " steps");
+        return false;
+    }
+
+    // per-image RNG: seed+b; initial noise consumes offset 0 (stable-diffusion.cpp:5678-5683; rng == sampler_rng :886-889)
+    std::vector<PhiloxRNG> rngs;
+    std::vector<float> x(per * nb);
+    for (int b = 0; b < nb; ++b) rngs.emplace_back((uint64_t)(p->seed + b0 + b));
+    parallel_chunks((size_t)nb, [&](size_t i0, size_t i1) {
+        for (size_t b = i0; b < i1; ++b) {
+            std::vector<float> noise = rngs[b].randn((uint32_t)per);
+            for (size_t i = 0; i < per; ++i) x[b * per + i] = 0.0f + noise[i] * sigmas[0];  // noise_scaling, denoiser.hpp:1174-1179
+        }
+    }, 2);
+    HostDenoise denoise(ctx, p, W, H, C, nb);
+    std::vector<float> denoised(per * nb);
+    std::vector<std::vector<float>> step_noise(nb);
+
+    if (method != SDM_EULER_SAMPLE_METHOD && method != SDM_EULER_A_SAMPLE_METHOD) {
+        // the multi-stage / multi-step samplers (sampler.hpp: run_sampler_generic): per-image Philox streams, one draw of `per` normals per image and request
+        const bool ok = run_sampler_generic(method, [&](const float* xin, float sigma, float* den) { return denoise(xin, sigma, den); }, x, sigmas,
+                                            [&](float* dst) {
+                                                for (int b = 0; b < nb; ++b) {
+                                                    const std::vector<float> nz = rngs[b].randn((uint32_t)per);
+                                                    memcpy(dst + (size_t)b * per, nz.data(), per * sizeof(float));
+                                                }
+                                            },
+                                            eta, ctx->is_dit);
+        if (!ok) return false;
+        memcpy(out, x.data(), x.size() * sizeof(float));
+        return true;
+    }
+
+    for (int i = 0; i < steps; ++i) {
+        const float sigma = sigmas[i], sigma_to = sigmas[i + 1];
+        // The ancestral noise of this step depends on the sigma ladder only, not on the model output: draw it (host Philox, 0.7 ms per
+        // SD1.5 image) on a helper thread WHILE the device runs the forward, instead of after it.  Same per-image streams, same order.
+        float sigma_down = 0.f, sigma_up = 0.f, alpha_scale = 1.f;
+        std::future<void> noise_job;
+        if (method == SDM_EULER_A_SAMPLE_METHOD && sigma_to != 0.f && eta != 0.f) {
+            if (ctx->is_dit)  // flow denoisers (SD3.5, FLUX): get_ancestral_step(..., is_flow_denoiser), denoiser.hpp:1501-1511
+                ancestral_step_flow(sigma, sigma_to, eta, sigma_down, sigma_up, alpha_scale);
+            else
+                ancestral_step(sigma, sigma_to, eta, sigma_down, sigma_up);
+            if (sigma_up > 0.f)
+                noise_job = std::async(std::launch::async, [&]() {
+                    for (int b = 0; b < nb; ++b) step_noise[b] = rngs[b].randn((uint32_t)per);
+                });
+        }
+        struct JoinNoise {  // an early return must not leave the helper writing into dead stack frames
+            std::future<void>& f;
+            ~JoinNoise() {
+                if (f.valid()) f.wait();
+            }
+        } join_noise{noise_job};
+        if (!denoise(x.data(), sigma, denoised.data())) return false;
         // the update itself: sample_euler_ancestral / sample_euler (sampler.hpp: sampler_update — the function tests hold bit-for-bit against the reference's
         // own src/runtime/denoiser.hpp compiled into oracle/_ref)
         sampler_update(x.data(), denoised.data(), per, nb, method == SDM_EULER_A_SAMPLE_METHOD, ctx->is_dit, sigma, sigma_to, eta, sigma_down, sigma_up, alpha_scale,
@@ -1401,13 +1469,21 @@ static bool sample_group_device(sdm_ctx_t* ctx, const sdm_img_gen_params_t* p, i
     const bool has_y   = p->cond.c_vector != nullptr;
     if (use_cfg && (p->cond.ctx_dim != p->uncond.ctx_dim || p->cond.n_tokens != p->uncond.n_tokens || has_y != (p->uncond.c_vector != nullptr))) return true;
     if (ctx->out_channels() != C) return true;  // learned-sigma heads are not sampled this way
+    int method, scheduler;
+    float eta;
+    if (!resolve_sampling(ctx, sp, method, scheduler, eta)) {
+        *handled = true;  // (the error is set: the host loop would refuse the same parameters)
+        return false;
+    }
+    if (method != SDM_EULER_SAMPLE_METHOD && method != SDM_EULER_A_SAMPLE_METHOD) return true;  // multi-stage / multi-step samplers: the host loop around the device forward
     *handled = true;
     const size_t per = (size_t)W * H * C;
-    const int method = resolve_sample_method(ctx, sp.sample_method);
-    float eta        = sp.eta;
-    if (eta == INFINITY) eta = method == SDM_EULER_A_SAMPLE_METHOD ? 1.0f : 0.0f;
-    const std::vector<float> sigmas = ctx->get_sigmas(sp.sample_steps, W * H);
+    const std::vector<float> sigmas = ctx->get_sigmas(sp.sample_steps, W * H, scheduler);
     const int steps                 = (int)sigmas.size() - 1;
+    if (steps < 1) {
+        set_error("the scheduler returned no sigma ladder for " + std::to_string(sp.sample_steps) + " steps");
+        return false;
+    }
     const bool euler_a              = method == SDM_EULER_A_SAMPLE_METHOD;
     const bool flow                 = ctx->is_dit;  // flow denoiser: ancestral steps rescale x by alpha_scale before the noise (denoiser.hpp:1536-1541)
 
@@ -1737,6 +1813,86 @@ int sd_sample_synthetic(int family, int steps, int image_seq_len, int64_t n, uin
     }
     memcpy(out, x.data(), sizeof(float) * (size_t)n);
     return (int)sigmas.size();
+}
+// sd_sample_synthetic with a scheduler and every implemented method (the loop sample_group runs, on the synthetic model); aux: 5 floats per model call, in call order
+int sd_sample_synthetic2(int family, int steps, int image_seq_len, int64_t n, uint64_t seed, int method, int scheduler, float eta, float* out, float* aux, int aux_calls) {
+    if (steps < 1 || n < 1 || family < 0 || family > 3 || !sample_method_supported(method)) return -1;
+    CompVisDenoiser cv;
+    DiscreteFlowDenoiser fl;
+    FluxFlowDenoiser fx;
+    const int fam   = family == 3 ? 0 : family;
+    const bool flow = fam != 0;
+    if (scheduler == SDM_SCHEDULER_COUNT) scheduler = method == SM_LCM ? SCHED_LCM : (method == SM_DDIM_TRAILING ? SCHED_SIMPLE : (fam == 2 ? SCHED_FLUX : SCHED_DISCRETE));
+    if (!scheduler_supported(scheduler)) return -1;
+    if (eta == INFINITY) eta = default_eta(method);
+    if (method == SM_DDIM_TRAILING) method = SM_EULER_A;
+    std::vector<float> sigmas((size_t)steps + 2);
+    const int ns = sd_get_sigmas_sched(family, scheduler, steps, image_seq_len, 0.f, sigmas.data());
+    if (ns < 2) return -1;
+    sigmas.resize((size_t)ns);
+    PhiloxRNG rng(seed);
+    std::vector<float> x = rng.randn((uint32_t)n);
+    for (int64_t k = 0; k < n; ++k) x[k] = 0.0f + x[k] * sigmas[0];
+    int calls  = 0;
+    auto model = [&](const float* xin, float sigma, float* den) {
+        float c_skip, c_out, c_in;
+        if (fam == 0) cv.scalings(sigma, c_skip, c_out, c_in);
+        else if (fam == 1) fl.scalings(sigma, c_skip, c_out, c_in);
+        else fx.scalings(sigma, c_skip, c_out, c_in);
+        const float t = fam == 0 ? cv.sigma_to_t(sigma) : (fam == 1 ? fl.sigma_to_t(sigma) : sigma);
+        if (aux && calls < aux_calls) {
+            float* a = aux + 5 * (size_t)calls;
+            a[0] = c_skip, a[1] = c_out, a[2] = c_in, a[3] = t, a[4] = sigma;
+        }
+        ++calls;
+        const float g = 1.0f / (1.0f + sigma), h = 0.01f * sigma;
+        for (int64_t k = 0; k < n; ++k) den[k] = xin[k] * g + h;
+        return true;
+    };
+    if (method == SM_EULER || method == SM_EULER_A) {
+        std::vector<float> den((size_t)n), nz;
+        for (int i = 0; i + 1 < (int)sigmas.size(); ++i) {
+            const float sigma = sigmas[i], sigma_to = sigmas[i + 1];
+            model(x.data(), sigma, den.data());
+            float sigma_down = 0.f, sigma_up = 0.f, alpha_scale = 1.f;
+            if (method == SM_EULER_A && sigma_to != 0.f && eta != 0.f) {
+                if (flow) ancestral_step_flow(sigma, sigma_to, eta, sigma_down, sigma_up, alpha_scale);
+                else ancestral_step(sigma, sigma_to, eta, sigma_down, sigma_up);
+            }
+            sampler_update(x.data(), den.data(), (size_t)n, 1, method == SM_EULER_A, flow, sigma, sigma_to, eta, sigma_down, sigma_up, alpha_scale, [&](int) -> const float* {
+                nz = rng.randn((uint32_t)n);
+                return nz.data();
+            });
+        }
+    } else if (!run_sampler_generic(method, model, x, sigmas, [&](float* dst) {
+                   const std::vector<float> nz = rng.randn((uint32_t)n);
+                   memcpy(dst, nz.data(), sizeof(float) * (size_t)n);
+               }, eta, flow)) {
+        return -1;
+    }
+    memcpy(out, x.data(), sizeof(float) * (size_t)n);
+    return calls;
+}
+int sd_get_sigmas_sched(int family, int scheduler, int steps, int image_seq_len, float shift, float* out) {
+    if (family < 0 || family > 3 || steps < 0 || !scheduler_supported(scheduler)) return -1;
+    std::vector<float> s;
+    if (scheduler == SCHED_FLUX) {
+        FluxFlowDenoiser d;
+        s = d.get_sigmas((uint32_t)steps, image_seq_len);
+    } else if (family == 0 || family == 3) {
+        static const CompVisDenoiser d;
+        s = scheduler_sigmas(scheduler, (uint32_t)steps, d.sigma_min(), d.sigma_max(), [&](float t) { return d.t_to_sigma(t); }, family == 3 ? 1 : 0);
+    } else if (family == 1) {
+        DiscreteFlowDenoiser d;
+        if (shift > 0.f) d.shift = shift;
+        s = scheduler_sigmas(scheduler, (uint32_t)steps, d.sigma_min(), d.sigma_max(), [&](float t) { return d.t_to_sigma(t); }, -1);
+    } else {
+        FluxFlowDenoiser d;
+        if (shift > 0.f) d.shift = shift;
+        s = scheduler_sigmas(scheduler, (uint32_t)steps, d.sigma_min(), d.sigma_max(), [&](float t) { return d.t_to_sigma(t); }, -1);
+    }
+    memcpy(out, s.data(), s.size() * sizeof(float));
+    return (int)s.size();
 }
 void sd_cfg_combine(const float* cond, const float* uncond, int64_t n, float scale, float* out) {
     for (int64_t k = 0; k < n; ++k) out[k] = cfg_guided(cond[k], uncond[k], scale);

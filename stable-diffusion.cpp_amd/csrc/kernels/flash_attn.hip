@@ -119,7 +119,7 @@ constexpr int fa_vtr_stride(int ndv) {
 // lane's query's -m, rewritten only when the running max moves), so the scores leave the MFMA relative to the max — the d = 40 max slot's effect without a k-slot — and the
 // 32 v_sub per tile disappear; 4 = DOT2: the row sum from the f16-rounded P (the values the numerator uses) with v_dot2_f32_f16 against (1, 1): 16 instead of 32 additions.
 template <int DKP, int NDV, bool FAST, int ABL = 0, bool MSLOT = false, int QB = 1, bool VPF = false, bool VTR = false, bool OVL = false, bool NSEL = false, int SM = 0>
-__global__ __launch_bounds__(256, QB == 2 ? (DKP <= 96 ? 2 : 1) : (DKP <= 64 ? (VPF ? 2 : FA_OCC_SMALL) : (DKP <= 128 ? 2 : 1))) void k_flash_attn(FAArgs g) {
+__global__ __launch_bounds__(256, QB == 2 ? (DKP <= 96 ? 2 : 1) : (DKP <= 64 ? ((VPF && !(SM & 2)) ? 2 : FA_OCC_SMALL) : (DKP <= 128 ? 2 : 1))) void k_flash_attn(FAArgs g) {
     static_assert(QB == 1 || FAST, "two query blocks per wave: FAST staging only");
     static_assert(!MSLOT || DKP == 48 || DKP == 80, "max slot: d = 40 on the 48-wide tile, d = 64 on the 80-wide tile");
     constexpr int MS_HI = DKP == 48 ? 1 : 0;  // lane half holding element d = D of the last k-step (the max slot)

@@ -107,6 +107,99 @@ def test_euler_a_trajectory_vs_numpy_restatement(sd, oracle, eng15):
     assert rel_l2(out, x) < 1e-4
 
 
+def test_more_samplers_through_the_engine(sd, oracle, eng15):
+    """Round-6 widening of row a2 at the ENGINE level (the arithmetic of every method is pinned bit for bit against the reference in test_host_logic.py): the host loop's
+    generic path drives the real model — DPM++ 2M and Heun under the Karras ladder against numpy restatements (k-diffusion's formulas) calling the same UNet; two model calls
+    per step but the last for the two-stage methods; the device-sampler flag falls back to the host loop for them with the same bits; per-image Philox streams in a batch
+    (LCM, DPM++ 2S a); DDIM trailing == Euler-A at eta 0 on the simple ladder; values that are not implemented are refused with a message."""
+    rng = np.random.default_rng(41)
+    cond = rng.standard_normal((1, 77, 64)).astype(np.float32)
+    uncond = rng.standard_normal((1, 77, 64)).astype(np.float32)
+    steps, cfg, seed = 4, 5.0, 17
+    kw = dict(width=128, height=128, steps=steps, cfg=cfg, seed=seed, batch=1)
+    sig = sd.get_sigmas_sched(0, sd.SCHED_KARRAS, steps)
+    from test_host_logic import philox_randn_np
+
+    def denoise(x, s):
+        s = np.float32(s)
+        c_in = np.float32(1.0) / np.sqrt(s * s + np.float32(1.0))
+        t = np.array([sd.lib().sd_sigma_to_t(float(s))], dtype=np.float32)
+        ec, eu = eng15.unet_forward(x * c_in, t, cond), eng15.unet_forward(x * c_in, t, uncond)
+        return (eu + np.float32(cfg) * (ec - eu)) * (-s) + x
+
+    x0 = (philox_randn_np(seed, 0, 4 * 16 * 16) * sig[0]).astype(np.float32).reshape(1, 4, 16, 16)
+    # DPM++ 2M (k-diffusion sample_dpmpp_2m)
+    x, old = x0.copy(), None
+    for i in range(steps):
+        den = denoise(x, sig[i])
+        t, t_next = -np.log(np.float64(sig[i])), (-np.log(np.float64(sig[i + 1])) if sig[i + 1] > 0 else np.inf)
+        h = t_next - t
+        if old is None or sig[i + 1] == 0:
+            x = (sig[i + 1] / sig[i]) * x - np.expm1(-h) * den
+        else:
+            r = (t - (-np.log(np.float64(sig[i - 1])))) / h
+            x = (sig[i + 1] / sig[i]) * x - np.expm1(-h) * ((1 + 1 / (2 * r)) * den - (1 / (2 * r)) * old)
+        old = den
+    calls0 = eng15.stats()["unet_calls"]
+    out = eng15.sample_latents(cond, uncond, method=sd.DPMPP2M, scheduler=sd.SCHED_KARRAS, **kw)
+    assert eng15.stats()["unet_calls"] - calls0 == 2 * steps          # cond + uncond per step
+    assert rel_l2(out, x) < 2e-4
+    # Heun (k-diffusion sample_heun)
+    x = x0.copy()
+    for i in range(steps):
+        den = denoise(x, sig[i])
+        d, dt = (x - den) / sig[i], sig[i + 1] - sig[i]
+        if sig[i + 1] == 0:
+            x = x + d * dt
+        else:
+            x2 = x + d * dt
+            d2 = (x2 - denoise(x2, sig[i + 1])) / sig[i + 1]
+            x = x + (d + d2) / 2 * dt
+    calls0 = eng15.stats()["unet_calls"]
+    out = eng15.sample_latents(cond, uncond, method=sd.HEUN, scheduler=sd.SCHED_KARRAS, fuse_cfg=True, **kw)
+    assert eng15.stats()["unet_calls"] - calls0 == 2 * steps - 1      # the pair in one graph; no second stage on the last step
+    assert rel_l2(out, x) < 2e-4
+    np.testing.assert_array_equal(eng15.sample_latents(cond, uncond, method=sd.HEUN, scheduler=sd.SCHED_KARRAS, fuse_cfg=True, device_sampler=True, **kw), out)
+    # a batch draws each image's noise from its own stream (seed + b): image b of the batch == the single image with that seed
+    for m in (sd.LCM, sd.DPMPP2S_A):
+        kb = dict(kw, batch=3, device_batch=3, method=m, fuse_cfg=True)
+        full = eng15.sample_latents(cond, uncond, **kb)
+        assert np.isfinite(full).all() and full.std() > 0
+        one = eng15.sample_latents(cond, uncond, **dict(kb, batch=1, device_batch=1, seed=seed + 2))
+        assert rel_l2(full[2:3], one) < 1e-5
+    # DDIM trailing is Euler-A with eta 0 on the simple ladder (sample_k_diffusion, denoiser.hpp:2843-2845; defaults stable-diffusion.cpp:3987-3988, 4031)
+    np.testing.assert_array_equal(eng15.sample_latents(cond, uncond, method=sd.DDIM_TRAILING, **kw),
+                                  eng15.sample_latents(cond, uncond, method=sd.EULER_A, eta=0.0, scheduler=sd.SCHED_SIMPLE, **kw))
+    np.testing.assert_array_equal(eng15.sample_latents(cond, uncond, method=sd.DDIM_TRAILING, device_sampler=True, fuse_cfg=True, **kw),
+                                  eng15.sample_latents(cond, uncond, method=sd.EULER_A, eta=0.0, scheduler=sd.SCHED_SIMPLE, device_sampler=True, fuse_cfg=True, **kw))
+    # not implemented -> an error, never another sampler / ladder
+    for bad in (dict(method=11), dict(method=20), dict(scheduler=4), dict(scheduler=15)):
+        for dev in (False, True):
+            with pytest.raises(sd.EngineError, match="not implemented"):
+                eng15.sample_latents(cond, uncond, device_sampler=dev, fuse_cfg=True, **dict(kw, **bad))
+
+
+def test_more_samplers_on_the_flow_families(sd, oracle, eng35):
+    """The flow variants through the engine (SD3.5 tiny): DPM++ 2S ancestral takes sample_dpmpp_2s_ancestral_flow (first step at sigma 1: ONE model call), LCM rescales by
+    1 - sigma before the noise; every implemented method returns finite latents that differ from method to method; the default scheduler stays the discrete flow ladder."""
+    rng = np.random.default_rng(43)
+    cond = rng.standard_normal((1, 40, 96)).astype(np.float32)
+    y = rng.standard_normal((1, 64)).astype(np.float32)
+    kw = dict(width=64, height=64, steps=4, cfg=1.0, seed=5, batch=1, cond_y=y)
+    outs = {}
+    for m in range(11):
+        calls0 = eng35.stats()["unet_calls"]
+        outs[m] = eng35.sample_latents(cond, None, method=m, **kw)
+        calls = eng35.stats()["unet_calls"] - calls0
+        assert np.isfinite(outs[m]).all(), m
+        assert calls == {sd.HEUN: 7, sd.DPM2: 7, sd.DPMPP2S_A: 6}.get(m, 4), (m, calls)   # 2S a (flow): sigma_0 = 1 -> first step reuses its one call; last step is Euler
+    keys = sorted(outs)
+    for i, a in enumerate(keys):
+        for b in keys[i + 1:]:
+            same = np.array_equal(outs[a], outs[b])
+            assert same == ((a, b) in {(sd.EULER, sd.EULER_A)} and False), (a, b)
+
+
 def test_generate_image_end_to_end(sd, oracle, eng15):
     rng = np.random.default_rng(5)
     cond = rng.standard_normal((1, 77, 64)).astype(np.float32)
