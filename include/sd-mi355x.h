@@ -78,19 +78,23 @@ enum sdm_type_t {
 /* SDM_SAMPLE_METHOD_COUNT = "the family's default" like the reference's SAMPLE_METHOD_COUNT (sd_get_default_sample_method,
  * stable-diffusion.cpp:3965-3975): Euler for the DiT families (SD3.5, FLUX), Euler-A otherwise */
 /* Numeric values = the reference's sample_method_t / scheduler_t (include/stable-diffusion.h:38-83), so integers a host already holds keep their meaning.  Implemented
- * (host-side math, bit-for-bit against src/runtime/denoiser.hpp compiled from the reference: tests/test_host_logic.py): methods 0 ... 10; schedulers DISCRETE, KARRAS,
- * EXPONENTIAL, AYS, SGM_UNIFORM, SIMPLE, SMOOTHSTEP, KL_OPTIMAL, LCM and FLUX.  Any other value makes sdm_generate_image / sdm_sample_latents fail with an error message
+ * (host-side math, bit-for-bit against src/runtime/denoiser.hpp compiled from the reference: tests/test_host_logic.py): EVERY method sample_k_diffusion dispatches, 0 ... 20 (the `extra_sample_args` knobs of LMS / Euler GE / LCM
+ * at their defaults); schedulers DISCRETE, KARRAS, EXPONENTIAL, AYS, GITS, SGM_UNIFORM, SIMPLE, SMOOTHSTEP, KL_OPTIMAL, LCM, BONG_TANGENT, BETA (alpha = beta = 0.6) and FLUX — every
+ * scheduler_t value but the default ladders of model families outside this engine (LTX2 = 11, LOGIT_NORMAL = 12, FLUX2 = 13).  Any other value makes sdm_generate_image / sdm_sample_latents fail with an error message
  * (sd_last_error) instead of silently sampling something else.  SDM_SCHEDULER_COUNT = "the default for this model and method" (sd_get_default_scheduler,
- * stable-diffusion.cpp:3977-3998): LCM for the LCM method, SIMPLE for DDIM trailing, FLUX for FLUX, DISCRETE otherwise.  Euler / Euler-A (and DDIM trailing, which the
+ * stable-diffusion.cpp:3977-3998): LCM for the LCM and TCD methods, SIMPLE for DDIM trailing, FLUX for FLUX, DISCRETE otherwise.  Euler / Euler-A (and DDIM trailing, which the
  * reference runs as Euler-A) take the device-resident sampler; the multi-stage and multi-step methods run the host loop around the device forward. */
 enum sdm_sample_method_t {
     SDM_EULER_SAMPLE_METHOD = 0, SDM_EULER_A_SAMPLE_METHOD = 1, SDM_HEUN_SAMPLE_METHOD = 2, SDM_DPM2_SAMPLE_METHOD = 3, SDM_DPMPP2S_A_SAMPLE_METHOD = 4,
     SDM_DPMPP2M_SAMPLE_METHOD = 5, SDM_DPMPP2Mv2_SAMPLE_METHOD = 6, SDM_IPNDM_SAMPLE_METHOD = 7, SDM_IPNDM_V_SAMPLE_METHOD = 8, SDM_LCM_SAMPLE_METHOD = 9,
-    SDM_DDIM_TRAILING_SAMPLE_METHOD = 10, SDM_SAMPLE_METHOD_COUNT = 21
+    SDM_DDIM_TRAILING_SAMPLE_METHOD = 10, SDM_TCD_SAMPLE_METHOD = 11, SDM_RES_MULTISTEP_SAMPLE_METHOD = 12, SDM_RES_2S_SAMPLE_METHOD = 13, SDM_ER_SDE_SAMPLE_METHOD = 14,
+    SDM_EULER_CFG_PP_SAMPLE_METHOD = 15, SDM_EULER_A_CFG_PP_SAMPLE_METHOD = 16, SDM_EULER_GE_SAMPLE_METHOD = 17, SDM_DPMPP2M_SDE_SAMPLE_METHOD = 18,
+    SDM_DPMPP2M_SDE_BT_SAMPLE_METHOD = 19, SDM_LMS_SAMPLE_METHOD = 20, SDM_SAMPLE_METHOD_COUNT = 21
 };
 enum sdm_scheduler_t {
     SDM_DISCRETE_SCHEDULER = 0, SDM_KARRAS_SCHEDULER = 1, SDM_EXPONENTIAL_SCHEDULER = 2, SDM_AYS_SCHEDULER = 3, SDM_GITS_SCHEDULER = 4, SDM_SGM_UNIFORM_SCHEDULER = 5,
-    SDM_SIMPLE_SCHEDULER = 6, SDM_SMOOTHSTEP_SCHEDULER = 7, SDM_KL_OPTIMAL_SCHEDULER = 8, SDM_LCM_SCHEDULER = 9, SDM_FLUX_SCHEDULER = 14, SDM_SCHEDULER_COUNT = 16
+    SDM_SIMPLE_SCHEDULER = 6, SDM_SMOOTHSTEP_SCHEDULER = 7, SDM_KL_OPTIMAL_SCHEDULER = 8, SDM_LCM_SCHEDULER = 9, SDM_BONG_TANGENT_SCHEDULER = 10, SDM_FLUX_SCHEDULER = 14,
+    SDM_BETA_SCHEDULER = 15, SDM_SCHEDULER_COUNT = 16
 };
 
 typedef struct {

@@ -148,6 +148,11 @@ REF_API int ref_sample_synthetic2(int family, int steps, int image_seq_len, int6
         o.pred        = sd::Tensor<float>({n});
         const float g = 1.0f / (1.0f + sigma), h = 0.01f * sigma;
         for (int64_t k = 0; k < n; ++k) o.pred.data()[k] = xin.data()[k] * g + h;
+        if (method == EULER_CFG_PP_SAMPLE_METHOD || method == EULER_A_CFG_PP_SAMPLE_METHOD) {  // the synthetic model's unconditional prediction
+            o.pred_uncond  = sd::Tensor<float>({n});
+            const float gu = 0.9f / (1.0f + sigma), hu = -0.02f * sigma;
+            for (int64_t k = 0; k < n; ++k) o.pred_uncond.data()[k] = xin.data()[k] * gu + hu;
+        }
         return o;
     };
     const bool flow = family == 1 || family == 2;

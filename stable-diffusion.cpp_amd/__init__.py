@@ -33,9 +33,10 @@ PAIR_EXCHANGE_FN = C.CFUNCTYPE(C.c_bool, C.c_void_p, C.c_int64, C.c_void_p, C.c_
 EVAL_CALLBACK_FN = C.CFUNCTYPE(C.c_bool, C.c_void_p, C.c_bool, C.c_void_p)
 # sdm_sample_method_t / sdm_scheduler_t (include/sd-mi355x.h): the reference's numeric values (include/stable-diffusion.h:38-83)
 EULER, EULER_A, HEUN, DPM2, DPMPP2S_A, DPMPP2M, DPMPP2Mv2, IPNDM, IPNDM_V, LCM, DDIM_TRAILING = range(11)
+TCD, RES_MULTISTEP, RES_2S, ER_SDE, EULER_CFG_PP, EULER_A_CFG_PP, EULER_GE, DPMPP2M_SDE, DPMPP2M_SDE_BT, LMS = range(11, 21)
 SAMPLE_METHOD_DEFAULT = 21   # Euler for the DiT families, Euler-A otherwise (sd_get_default_sample_method)
 SCHED_DISCRETE, SCHED_KARRAS, SCHED_EXPONENTIAL, SCHED_AYS, SCHED_GITS, SCHED_SGM_UNIFORM, SCHED_SIMPLE, SCHED_SMOOTHSTEP, SCHED_KL_OPTIMAL, SCHED_LCM = range(10)
-SCHED_FLUX, SCHEDULER_DEFAULT = 14, 16   # DEFAULT: LCM for the LCM method, SIMPLE for DDIM trailing, FLUX for FLUX, DISCRETE otherwise (sd_get_default_scheduler)
+SCHED_BONG_TANGENT, SCHED_FLUX, SCHED_BETA, SCHEDULER_DEFAULT = 10, 14, 15, 16   # DEFAULT: LCM for the LCM method, SIMPLE for DDIM trailing, FLUX for FLUX, DISCRETE otherwise (sd_get_default_scheduler)
 
 
 class EngineError(RuntimeError):
@@ -862,7 +863,7 @@ def sample_synthetic2(family: int, steps: int, n: int, seed: int, method: int, s
     L.sd_sample_synthetic2.restype = C.c_int
     out, aux = np.empty(n, np.float32), np.zeros((2 * steps, 5), np.float32)
     k = L.sd_sample_synthetic2(family, steps, image_seq_len, n, seed, method, scheduler, eta, out.ctypes.data, aux.ctypes.data, 2 * steps)
-    if k < 1:
+    if k < 0:   # (0 model calls: DPM++ 2M SDE BT on a one-sigma ladder returns the noise as it is, like the reference)
         raise EngineError(f"sd_sample_synthetic2 returned {k}")
     return out, aux[:k]
 

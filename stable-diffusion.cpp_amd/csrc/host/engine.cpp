@@ -1280,7 +1280,7 @@ static int resolve_sample_method(const sdm_ctx_t* ctx, int m) {
 // resolve_scheduler / sd_get_default_scheduler (stable-diffusion.cpp:3977-3998, 4015-4022)
 static int resolve_scheduler(const sdm_ctx_t* ctx, int scheduler, int method) {
     if (scheduler != SDM_SCHEDULER_COUNT) return scheduler;
-    if (method == SDM_LCM_SAMPLE_METHOD) return SDM_LCM_SCHEDULER;
+    if (method == SDM_LCM_SAMPLE_METHOD || method == SDM_TCD_SAMPLE_METHOD) return SDM_LCM_SCHEDULER;
     if (method == SDM_DDIM_TRAILING_SAMPLE_METHOD) return SDM_SIMPLE_SCHEDULER;
     return ctx->is_flux ? SDM_FLUX_SCHEDULER : SDM_DISCRETE_SCHEDULER;
 }
@@ -1290,7 +1290,7 @@ static bool resolve_sampling(const sdm_ctx_t* ctx, const sdm_sample_params_t& sp
     method    = resolve_sample_method(ctx, sp.sample_method);
     scheduler = resolve_scheduler(ctx, sp.scheduler, method);
     if (!sample_method_supported(method)) {
-        set_error("sample method " + std::to_string(method) + " is not implemented (sdm_sample_method_t: 0 ... 10)");
+        set_error("sample method " + std::to_string(method) + " is not implemented (sdm_sample_method_t: 0 ... 20)");
         return false;
     }
     if (!scheduler_supported(scheduler)) {
@@ -1314,7 +1314,9 @@ struct HostDenoise {
     HostDenoise(sdm_ctx_t* ctx_, const sdm_img_gen_params_t* p_, int W_, int H_, int C_, int nb_)
         : ctx(ctx_), p(p_), W(W_), H(H_), C(C_), nb(nb_), per((size_t)W_ * H_ * C_), use_cfg(p_->sample_params.txt_cfg != 1.0f && p_->uncond.c_crossattn != nullptr),
           noised(per * nb_), cond_out(per * nb_), uncond_out(per * nb_), ts(nb_) {}
-    bool operator()(const float* x, float sigma, float* denoised) {
+    // denoised_uncond (the CFG++ methods): GuiderOutput::pred_uncond = base_uncond * c_out + x * c_skip with the unconditional forward — or the conditional one when there is
+    // no guidance pair (stable-diffusion.cpp:2877-2884)
+    bool operator()(const float* x, float sigma, float* denoised, float* denoised_uncond = nullptr) {
         const sdm_sample_params_t& sp = p->sample_params;
         const size_t n = per * (size_t)nb;
         float c_skip, c_out, c_in;
@@ -1371,6 +1373,10 @@ struct HostDenoise {
         } else {
             for (size_t k = 0; k < n; ++k) denoised[k] = cond_out[k] * c_out + x[k] * c_skip;
         }
+        if (denoised_uncond) {
+            const float* base = use_cfg ? uncond_out.data() : cond_out.data();
+            for (size_t k = 0; k < n; ++k) denoised_uncond[k] = base[k] * c_out + x[k] * c_skip;
+        }
         return true;
     }
 };
@@ -1404,14 +1410,18 @@ static bool sample_group(sdm_ctx_t* ctx, const sdm_img_gen_params_t* p, int b0, 
 
     if (method != SDM_EULER_SAMPLE_METHOD && method != SDM_EULER_A_SAMPLE_METHOD) {
         // the multi-stage / multi-step samplers (sampler.hpp: run_sampler_generic): per-image Philox streams, one draw of `per` normals per image and request
-        const bool ok = run_sampler_generic(method, [&](const float* xin, float sigma, float* den) { return denoise(xin, sigma, den); }, x, sigmas,
+        const bool ok = run_sampler_generic(method, [&](const float* xin, float sigma, float* den, float* unc) { return denoise(xin, sigma, den, unc); }, x, sigmas,
                                             [&](float* dst) {
                                                 for (int b = 0; b < nb; ++b) {
                                                     const std::vector<float> nz = rngs[b].randn((uint32_t)per);
                                                     memcpy(dst + (size_t)b * per, nz.data(), per * sizeof(float));
                                                 }
                                             },
-                                            eta, ctx->is_dit);
+                                            eta, ctx->is_dit, nb,
+                                            [&](int b, uint32_t cnt, float* dst) {
+                                                const std::vector<float> nz = rngs[b].randn(cnt);
+                                                memcpy(dst, nz.data(), cnt * sizeof(float));
+                                            });
         if (!ok) return false;
         memcpy(out, x.data(), x.size() * sizeof(float));
         return true;
@@ -1822,7 +1832,7 @@ int sd_sample_synthetic2(int family, int steps, int image_seq_len, int64_t n, ui
     FluxFlowDenoiser fx;
     const int fam   = family == 3 ? 0 : family;
     const bool flow = fam != 0;
-    if (scheduler == SDM_SCHEDULER_COUNT) scheduler = method == SM_LCM ? SCHED_LCM : (method == SM_DDIM_TRAILING ? SCHED_SIMPLE : (fam == 2 ? SCHED_FLUX : SCHED_DISCRETE));
+    if (scheduler == SDM_SCHEDULER_COUNT) scheduler = (method == SM_LCM || method == SM_TCD) ? SCHED_LCM : (method == SM_DDIM_TRAILING ? SCHED_SIMPLE : (fam == 2 ? SCHED_FLUX : SCHED_DISCRETE));
     if (!scheduler_supported(scheduler)) return -1;
     if (eta == INFINITY) eta = default_eta(method);
     if (method == SM_DDIM_TRAILING) method = SM_EULER_A;
@@ -1834,7 +1844,7 @@ int sd_sample_synthetic2(int family, int steps, int image_seq_len, int64_t n, ui
     std::vector<float> x = rng.randn((uint32_t)n);
     for (int64_t k = 0; k < n; ++k) x[k] = 0.0f + x[k] * sigmas[0];
     int calls  = 0;
-    auto model = [&](const float* xin, float sigma, float* den) {
+    auto model = [&](const float* xin, float sigma, float* den, float* unc) {
         float c_skip, c_out, c_in;
         if (fam == 0) cv.scalings(sigma, c_skip, c_out, c_in);
         else if (fam == 1) fl.scalings(sigma, c_skip, c_out, c_in);
@@ -1847,13 +1857,17 @@ int sd_sample_synthetic2(int family, int steps, int image_seq_len, int64_t n, ui
         ++calls;
         const float g = 1.0f / (1.0f + sigma), h = 0.01f * sigma;
         for (int64_t k = 0; k < n; ++k) den[k] = xin[k] * g + h;
+        if (unc) {  // the synthetic model's unconditional prediction (the CFG++ methods)
+            const float gu = 0.9f / (1.0f + sigma), hu = -0.02f * sigma;
+            for (int64_t k = 0; k < n; ++k) unc[k] = xin[k] * gu + hu;
+        }
         return true;
     };
     if (method == SM_EULER || method == SM_EULER_A) {
         std::vector<float> den((size_t)n), nz;
         for (int i = 0; i + 1 < (int)sigmas.size(); ++i) {
             const float sigma = sigmas[i], sigma_to = sigmas[i + 1];
-            model(x.data(), sigma, den.data());
+            model(x.data(), sigma, den.data(), nullptr);
             float sigma_down = 0.f, sigma_up = 0.f, alpha_scale = 1.f;
             if (method == SM_EULER_A && sigma_to != 0.f && eta != 0.f) {
                 if (flow) ancestral_step_flow(sigma, sigma_to, eta, sigma_down, sigma_up, alpha_scale);
@@ -1867,7 +1881,10 @@ int sd_sample_synthetic2(int family, int steps, int image_seq_len, int64_t n, ui
     } else if (!run_sampler_generic(method, model, x, sigmas, [&](float* dst) {
                    const std::vector<float> nz = rng.randn((uint32_t)n);
                    memcpy(dst, nz.data(), sizeof(float) * (size_t)n);
-               }, eta, flow)) {
+               }, eta, flow, 1, [&](int, uint32_t cnt, float* dst) {
+                   const std::vector<float> nz = rng.randn(cnt);
+                   memcpy(dst, nz.data(), sizeof(float) * cnt);
+               })) {
         return -1;
     }
     memcpy(out, x.data(), sizeof(float) * (size_t)n);

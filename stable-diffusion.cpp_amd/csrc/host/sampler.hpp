@@ -4,6 +4,11 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstring>
+#include <functional>
+#include <limits>
+#include <map>
+#include <random>
 #include <vector>
 
 namespace sdmi {
@@ -199,7 +204,121 @@ enum : int {
 };
 inline bool scheduler_supported(int s) {
     return s == SCHED_DISCRETE || s == SCHED_KARRAS || s == SCHED_EXPONENTIAL || s == SCHED_AYS || s == SCHED_SGM_UNIFORM || s == SCHED_SIMPLE || s == SCHED_SMOOTHSTEP ||
-           s == SCHED_KL_OPTIMAL || s == SCHED_LCM || s == SCHED_FLUX;
+           s == SCHED_KL_OPTIMAL || s == SCHED_LCM || s == SCHED_FLUX || s == SCHED_GITS || s == SCHED_BONG_TANGENT || s == SCHED_BETA;
+}
+// (not implemented: LTX2, logit-normal and FLUX.2 — the default ladders of model families outside this engine: LTX video, Ideogram, FLUX.2; include/sd-mi355x.h)
+
+// BetaScheduler's quantile function (denoiser.hpp:308-463) with its default alpha = beta = 0.6: regularised incomplete beta by Lentz's continued fraction, Newton steps
+struct BetaQuantile {
+    static double log_beta(double a, double b) { return std::lgamma(a) + std::lgamma(b) - std::lgamma(a + b); }
+    static double incbeta(double x, double a, double b) {
+        if (x <= 0.0) return 0.0;
+        if (x >= 1.0) return 1.0;
+        const int max_iter = 200;
+        const double epsilon = 3.0e-7, tiny = 1e-30;
+        const double qab = a + b, qap = a + 1.0, qam = a - 1.0;
+        double c = 1.0, d = 1.0 - qab * x / qap;
+        if (std::abs(d) < tiny) d = tiny;
+        d        = 1.0 / d;
+        double h = d;
+        for (int m = 1; m <= max_iter; m++) {
+            const int m2 = 2 * m;
+            double aa    = m * (b - m) * x / ((qam + m2) * (a + m2));
+            d            = 1.0 + aa * d;
+            if (std::abs(d) < tiny) d = tiny;
+            c = 1.0 + aa / c;
+            if (std::abs(c) < tiny) c = tiny;
+            d = 1.0 / d;
+            h *= d * c;
+            aa = -(a + m) * (qab + m) * x / ((a + m2) * (qap + m2));
+            d  = 1.0 + aa * d;
+            if (std::abs(d) < tiny) d = tiny;
+            c = 1.0 + aa / c;
+            if (std::abs(c) < tiny) c = tiny;
+            d                = 1.0 / d;
+            const double del = d * c;
+            h *= del;
+            if (std::abs(del - 1.0) < epsilon) break;
+        }
+        return std::exp(a * std::log(x) + b * std::log(1.0 - x) - log_beta(a, b)) / a * h;
+    }
+    static double cdf(double x, double a, double b) {
+        if (x == 0.0) return 0.0;
+        if (x == 1.0) return 1.0;
+        if (x < (a + 1.0) / (a + b + 2.0)) return incbeta(x, a, b);
+        return 1.0 - incbeta(1.0 - x, b, a);
+    }
+    static double ppf(double u, double a, double b, int max_iter = 30) {
+        double x = 0.5;
+        for (int i = 0; i < max_iter; i++) {
+            const double f = cdf(x, a, b) - u;
+            if (std::abs(f) < 1e-10) break;
+            const double df = std::exp((a - 1.0) * std::log(x) + (b - 1.0) * std::log(1.0 - x) - log_beta(a, b));
+            x -= f / df;
+            if (x <= 0.0) x = 1e-10;
+            if (x >= 1.0) x = 1.0 - 1e-10;
+        }
+        return x;
+    }
+};
+// BongTangentScheduler::get_bong_tangent_sigmas — denoiser.hpp:525-558
+inline std::vector<float> bong_tangent_sigmas(int steps, float slope, float pivot, float start, float end) {
+    const float kPi = 3.14159265358979323846f;
+    std::vector<float> sigmas;
+    if (steps <= 0) return sigmas;
+    const float smax   = ((2.0f / kPi) * atanf(-slope * (0.0f - pivot)) + 1.0f) * 0.5f;
+    const float smin   = ((2.0f / kPi) * atanf(-slope * ((float)(steps - 1) - pivot)) + 1.0f) * 0.5f;
+    const float srange = smax - smin, sscale = start - end;
+    if (fabsf(srange) < 1e-8f) {
+        if (steps == 1) return {start};
+        for (int i = 0; i < steps; ++i) {
+            const float t = (float)i / (float)(steps - 1);
+            sigmas.push_back(start + (end - start) * t);
+        }
+        return sigmas;
+    }
+    const float inv_srange = 1.0f / srange;
+    for (int x = 0; x < steps; ++x) {
+        const float v = ((2.0f / kPi) * atanf(-slope * ((float)x - pivot)) + 1.0f) * 0.5f;
+        sigmas.push_back(((v - smin) * inv_srange) * sscale + end);
+    }
+    return sigmas;
+}
+// GITS (https://github.com/zju-pi/diff-sampler, "gits-main"): the published noise ladders for coefficient 1.20 — the one GITSScheduler always selects (denoiser.hpp:220-247:
+// coeff is fixed at 1.20f -> index 8 of GITS_NOISE) — for 2 ... 20 steps, row n - 2 holding n + 1 sigmas
+inline const float* gits_noise_1_20(uint32_t n) {
+    static const float T[] = {
+        14.61464119f, 0.803307f, 0.02916753f,
+        14.61464119f, 1.56271636f, 0.52423614f, 0.02916753f,
+        14.61464119f, 2.36326075f, 0.92192322f, 0.36617002f, 0.02916753f,
+        14.61464119f, 2.84484982f, 1.24153244f, 0.59516323f, 0.25053367f, 0.02916753f,
+        14.61464119f, 5.85520077f, 2.05039096f, 0.95350921f, 0.45573691f, 0.17026083f, 0.02916753f,
+        14.61464119f, 5.85520077f, 2.45070267f, 1.24153244f, 0.64427125f, 0.29807833f, 0.09824532f, 0.02916753f,
+        14.61464119f, 5.85520077f, 2.45070267f, 1.36964464f, 0.803307f, 0.45573691f, 0.25053367f, 0.09824532f, 0.02916753f,
+        14.61464119f, 5.85520077f, 2.84484982f, 1.61558151f, 0.95350921f, 0.59516323f, 0.36617002f, 0.19894916f, 0.09824532f, 0.02916753f,
+        14.61464119f, 5.85520077f, 2.84484982f, 1.67050016f, 1.08895338f, 0.74807048f, 0.50118381f, 0.32104823f, 0.19894916f, 0.09824532f, 0.02916753f,
+        14.61464119f, 5.85520077f, 2.95596409f, 1.84880662f, 1.24153244f, 0.83188516f, 0.59516323f, 0.41087446f, 0.27464288f, 0.17026083f, 0.09824532f, 0.02916753f,
+        14.61464119f, 5.85520077f, 3.07277966f, 1.98035145f, 1.36964464f, 0.95350921f, 0.69515091f, 0.50118381f, 0.36617002f, 0.25053367f, 0.17026083f, 0.09824532f, 0.02916753f,
+        14.61464119f, 6.77309084f, 3.46139455f, 2.36326075f, 1.56271636f, 1.08895338f, 0.803307f, 0.59516323f, 0.45573691f, 0.34370604f, 0.25053367f, 0.17026083f, 0.09824532f,
+        0.02916753f,
+        14.61464119f, 6.77309084f, 3.46139455f, 2.45070267f, 1.61558151f, 1.162866f, 0.86115354f, 0.64427125f, 0.50118381f, 0.38853383f, 0.29807833f, 0.22545385f, 0.17026083f,
+        0.09824532f, 0.02916753f,
+        14.61464119f, 7.49001646f, 4.65472794f, 3.07277966f, 2.12350607f, 1.51179266f, 1.08895338f, 0.83188516f, 0.64427125f, 0.50118381f, 0.38853383f, 0.29807833f, 0.22545385f,
+        0.17026083f, 0.09824532f, 0.02916753f,
+        14.61464119f, 7.49001646f, 4.65472794f, 3.07277966f, 2.12350607f, 1.51179266f, 1.08895338f, 0.83188516f, 0.64427125f, 0.50118381f, 0.41087446f, 0.32104823f, 0.25053367f,
+        0.19894916f, 0.13792117f, 0.09824532f, 0.02916753f,
+        14.61464119f, 7.49001646f, 4.65472794f, 3.07277966f, 2.12350607f, 1.51179266f, 1.08895338f, 0.83188516f, 0.64427125f, 0.50118381f, 0.41087446f, 0.34370604f, 0.27464288f,
+        0.22545385f, 0.17026083f, 0.13792117f, 0.09824532f, 0.02916753f,
+        14.61464119f, 7.49001646f, 4.65472794f, 3.07277966f, 2.19988537f, 1.61558151f, 1.20157266f, 0.92192322f, 0.72133851f, 0.57119018f, 0.45573691f, 0.36617002f, 0.29807833f,
+        0.25053367f, 0.19894916f, 0.17026083f, 0.13792117f, 0.09824532f, 0.02916753f,
+        14.61464119f, 7.49001646f, 4.65472794f, 3.07277966f, 2.19988537f, 1.61558151f, 1.24153244f, 0.95350921f, 0.74807048f, 0.59516323f, 0.4783645f, 0.38853383f, 0.32104823f,
+        0.27464288f, 0.22545385f, 0.19894916f, 0.17026083f, 0.13792117f, 0.09824532f, 0.02916753f,
+        14.61464119f, 7.49001646f, 4.65472794f, 3.07277966f, 2.19988537f, 1.61558151f, 1.24153244f, 0.95350921f, 0.74807048f, 0.59516323f, 0.50118381f, 0.41087446f, 0.34370604f,
+        0.29807833f, 0.25053367f, 0.22545385f, 0.19894916f, 0.17026083f, 0.13792117f, 0.09824532f, 0.02916753f};
+    static_assert(sizeof(T) / sizeof(T[0]) == 228, "19 ladders of 3 ... 21 sigmas");
+    size_t off = 0;
+    for (uint32_t k = 2; k < n; ++k) off += k + 1;
+    return T + off;
 }
 // linear_space — denoiser.hpp:122-135 (a running sum, not start + i * inc)
 inline std::vector<float> linear_space(float start, float end, size_t num_points) {
@@ -248,6 +367,59 @@ inline std::vector<float> scheduler_sigmas(int sched, uint32_t n, float sigma_mi
             const float max_inv_rho = (float)pow((double)sigma_max, (double)(1.f / rho));
             for (uint32_t i = 0; i < n; ++i) r[i] = (float)pow((double)(max_inv_rho + (float)i / ((float)n - 1.f) * (min_inv_rho - max_inv_rho)), (double)rho);
             r[n] = 0.f;
+            return r;
+        }
+        case SCHED_GITS: {  // denoiser.hpp:220-247 (n < 2 indexes in front of the table there: no ladder here)
+            if (sigma_max <= 0.0f || n < 2) return r;
+            if (n <= 20) {
+                const float* row = gits_noise_1_20(n);
+                r.assign(row, row + n + 1);
+            } else {
+                const float* last = gits_noise_1_20(20);
+                r                 = log_linear_interpolation(std::vector<float>(last, last + 21), n + 1);
+            }
+            r[n] = 0.0f;
+            return r;
+        }
+        case SCHED_BETA: {  // denoiser.hpp:434-462, alpha = beta = 0.6 (no extra sample args); repeated timesteps are dropped: the ladder may be SHORTER than n + 1
+            if (n == 0) return r;
+            if (n == 1) return {t_to_sigma((float)t_max), 0.f};
+            int last_t = -1;
+            for (uint32_t i = 0; i < n; i++) {
+                const double u      = 1.0 - static_cast<double>(i) / static_cast<double>(n);
+                const double t_cont = BetaQuantile::ppf(u, 0.6, 0.6) * t_max;
+                const int t         = static_cast<int>(std::lround(t_cont));
+                if (t != last_t) {
+                    r.push_back(t_to_sigma(static_cast<float>(t)));
+                    last_t = t;
+                }
+            }
+            r.push_back(0.f);
+            return r;
+        }
+        case SCHED_BONG_TANGENT: {  // denoiser.hpp:560-608
+            if (n == 0) return r;
+            const float start = sigma_max, end = sigma_min, middle = sigma_min + (sigma_max - sigma_min) * 0.5f;
+            const float pivot_1 = 0.6f, pivot_2 = 0.6f;
+            float slope_1 = 0.2f, slope_2 = 0.2f;
+            const int steps = static_cast<int>(n) + 2;
+            const int midpoint  = static_cast<int>(((float)steps * pivot_1 + (float)steps * pivot_2) * 0.5f);
+            const int pivot_1_i = static_cast<int>((float)steps * pivot_1), pivot_2_i = static_cast<int>((float)steps * pivot_2);
+            const float slope_scale = (float)steps / 40.0f;
+            slope_1 = slope_1 / slope_scale;
+            slope_2 = slope_2 / slope_scale;
+            const int stage_2_len = steps - midpoint, stage_1_len = steps - stage_2_len;
+            std::vector<float> s1       = bong_tangent_sigmas(stage_1_len, slope_1, (float)pivot_1_i, start, middle);
+            const std::vector<float> s2 = bong_tangent_sigmas(stage_2_len, slope_2, (float)(pivot_2_i - stage_1_len), middle, end);
+            if (!s1.empty()) s1.pop_back();
+            r.insert(r.end(), s1.begin(), s1.end());
+            r.insert(r.end(), s2.begin(), s2.end());
+            if (r.size() < n + 1) {
+                while (r.size() < n + 1) r.push_back(end);
+            } else if (r.size() > n + 1) {
+                r.resize(n + 1);
+            }
+            r[n] = 0.0f;
             return r;
         }
         case SCHED_EXPONENTIAL: {  // denoiser.hpp:56-76
@@ -372,31 +544,126 @@ inline void ancestral_step_flow(float sigma_from, float sigma_to, float eta, flo
 // compiled into oracle/_ref on whole trajectories (tests/test_host_logic.py::test_more_samplers_bit_exact_vs_reference).
 enum : int {
     SM_EULER = 0, SM_EULER_A = 1, SM_HEUN = 2, SM_DPM2 = 3, SM_DPMPP2S_A = 4, SM_DPMPP2M = 5, SM_DPMPP2Mv2 = 6, SM_IPNDM = 7, SM_IPNDM_V = 8, SM_LCM = 9, SM_DDIM_TRAILING = 10,
-    SM_COUNT = 21
+    SM_TCD = 11, SM_RES_MULTISTEP = 12, SM_RES_2S = 13, SM_ER_SDE = 14, SM_EULER_CFG_PP = 15, SM_EULER_A_CFG_PP = 16, SM_EULER_GE = 17, SM_DPMPP2M_SDE = 18,
+    SM_DPMPP2M_SDE_BT = 19, SM_LMS = 20, SM_COUNT = 21
 };
-inline bool sample_method_supported(int m) { return m >= SM_EULER && m <= SM_DDIM_TRAILING; }
+inline bool sample_method_supported(int m) { return m >= SM_EULER && m < SM_COUNT; }
+// the CFG++ methods step along the UNCONDITIONAL prediction: the model callback is asked for it (GuiderOutput::pred_uncond, stable-diffusion.cpp:2877-2884)
+inline bool sample_method_needs_uncond(int m) { return m == SM_EULER_CFG_PP || m == SM_EULER_A_CFG_PP; }
 // resolve_eta — src/stable-diffusion.cpp:4024-4049
-inline float default_eta(int method) { return (method == SM_EULER_A || method == SM_DPMPP2S_A) ? 1.0f : 0.0f; }
+inline float default_eta(int method) {
+    switch (method) {
+        case SM_EULER_A: case SM_DPMPP2S_A: case SM_ER_SDE: case SM_EULER_A_CFG_PP: case SM_DPMPP2M_SDE: case SM_DPMPP2M_SDE_BT: return 1.0f;
+        default: return 0.0f;
+    }
+}
 
-// model(x, sigma, denoised) -> false on failure; randn(out): one N(0,1) draw per element of x from the sampler's RNG stream(s) (sd::Tensor<float>::randn_like(x, rng))
+// get_ancestral_step(sigma_from, sigma_to, eta, is_flow_denoiser) — denoiser.hpp:1501-1511
+inline void ancestral_step3(float sigma_from, float sigma_to, float eta, bool flow, float& sigma_down, float& sigma_up, float& alpha_scale) {
+    if (flow) {
+        ancestral_step_flow(sigma_from, sigma_to, eta, sigma_down, sigma_up, alpha_scale);
+    } else {
+        ancestral_step(sigma_from, sigma_to, eta, sigma_down, sigma_up);
+        alpha_scale = 1.0f;
+    }
+}
+
+// STDDefaultRNG (src/core/rng.hpp:14-33): std::default_random_engine seeded with the low 32 bits, a FRESH std::normal_distribution<float> per call — the generator the
+// reference's Brownian tree draws from.  (Both sides are libstdc++ here; the stream is that library's minstd_rand0 + Marsaglia polar method.)
+inline std::vector<float> std_default_randn(uint64_t seed, size_t n) {
+    std::default_random_engine generator;
+    generator.seed((unsigned int)seed);
+    std::normal_distribution<float> distribution(0.0f, 1.0f);
+    std::vector<float> r;
+    r.reserve(n);
+    for (size_t i = 0; i < n; ++i) r.push_back(distribution(generator));
+    return r;
+}
+
+// BrownianTreeNoiseSampler (src/runtime/denoiser.hpp:1909-1993): deterministic Brownian increments over [sigma_min, sigma_max] for ONE image of n floats
+struct BrownianTree {
+    static constexpr int kMaxDepth = 24;
+    double t_min, t_max;
+    size_t n;
+    uint64_t root_seed;
+    std::vector<float> w_at_tmax;
+    std::map<double, std::vector<float>> cache;
+    static uint64_t mix64(uint64_t v, uint64_t salt) {
+        uint64_t z = v + salt;
+        z          = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+        z          = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+        return z ^ (z >> 31);
+    }
+    BrownianTree(size_t n_, double sigma_min, double sigma_max, uint64_t seed) : t_min(sigma_min), t_max(sigma_max), n(n_), root_seed(mix64(seed, 0x9E3779B97F4A7C15ULL)) {
+        w_at_tmax     = std_default_randn(mix64(seed, 0xBF58476D1CE4E5B9ULL), n);
+        const float f = std::sqrt(static_cast<float>(t_max - t_min));
+        for (float& v : w_at_tmax) v *= f;
+    }
+    double clamp(double t) const { return std::min(std::max(t, t_min), t_max); }
+    std::vector<float> bridge(double a, double c, const std::vector<float>& w_a, const std::vector<float>& w_c, double t, uint64_t node_seed, int depth) const {
+        std::vector<float> r(n);
+        if (depth <= 0 || c - a < 1e-9) {
+            const float alpha = (c > a) ? static_cast<float>((t - a) / (c - a)) : 0.5f;
+            const float om    = 1.0f - alpha;
+            for (size_t k = 0; k < n; ++k) r[k] = om * w_a[k] + alpha * w_c[k];
+            return r;
+        }
+        const double m = 0.5 * (a + c);
+        const float sd = static_cast<float>(std::sqrt((c - m) * (m - a) / (c - a)));
+        const std::vector<float> z = std_default_randn(node_seed, n);
+        for (size_t k = 0; k < n; ++k) r[k] = 0.5f * (w_a[k] + w_c[k]) + sd * z[k];
+        if (t == m) return r;
+        if (t < m) return bridge(a, m, w_a, r, t, mix64(node_seed, 1), depth - 1);
+        return bridge(m, c, r, w_c, t, mix64(node_seed, 2), depth - 1);
+    }
+    const std::vector<float>& w(double t) {
+        auto it = cache.find(t);
+        if (it != cache.end()) return it->second;
+        const std::vector<float> zero(n, 0.0f);
+        return cache.emplace(t, bridge(t_min, t_max, zero, w_at_tmax, t, root_seed, kMaxDepth)).first->second;
+    }
+    // unit-variance noise of the interval [sigma_a, sigma_b] into out
+    void operator()(double sigma_a, double sigma_b, float* out) {
+        const double a = clamp(std::min(sigma_a, sigma_b)), b = clamp(std::max(sigma_a, sigma_b));
+        const std::vector<float> wb = w(b);  // (copy: the second lookup may rehash nothing — std::map keeps references valid — but keeps the reference's evaluation order w(b), w(a))
+        const std::vector<float>& wa = w(a);
+        const float span = static_cast<float>(std::max(std::abs(sigma_b - sigma_a), 1e-12));
+        const float f    = 1.0f / std::sqrt(span);
+        for (size_t k = 0; k < n; ++k) out[k] = (wb[k] - wa[k]) * f;
+    }
+};
+
+// model(x, sigma, denoised, denoised_uncond) -> false on failure (denoised_uncond: nullptr unless the method steps along the unconditional prediction — the CFG++ methods);
+// randn(out): one N(0,1) draw per element of x from the sampler's RNG stream(s) (sd::Tensor<float>::randn_like(x, rng));
+// draw(b, count, out): `count` normals from image b's stream (rng->randn(count): the Brownian-tree seed of DPM++ 2M SDE BT); nb images of x.size() / nb floats each
 template <class ModelFn, class RandnFn>
-inline bool run_sampler_generic(int method, ModelFn&& model, std::vector<float>& x, const std::vector<float>& sigmas, RandnFn&& randn, float eta, bool flow) {
+inline bool run_sampler_generic(int method, ModelFn&& model, std::vector<float>& x, const std::vector<float>& sigmas_in, RandnFn&& randn, float eta, bool flow, int nb = 1,
+                                const std::function<void(int, uint32_t, float*)>& draw = nullptr) {
     const size_t n  = x.size();
+    std::vector<float> sigmas = sigmas_in;
     const int steps = (int)sigmas.size() - 1;
     std::vector<float> den(n), x2(n), den2(n), d(n), nz;
+    auto phi1_fn = [](float t) -> float {
+        if (fabsf(t) < 1e-6f) return 1.0f + t * 0.5f + (t * t) / 6.0f;
+        return (expf(t) - 1.0f) / t;
+    };
+    auto phi2_fn = [&](float t) -> float {
+        if (fabsf(t) < 1e-6f) return 0.5f + t / 6.0f + (t * t) / 24.0f;
+        return (phi1_fn(t) - 1.0f) / t;
+    };
     auto t_fn     = [](float sigma) -> float { return (float)(-log((double)sigma)); };
     auto sigma_fn = [](float t) -> float { return (float)exp((double)-t); };
     switch (method) {
         case SM_HEUN:
             for (int i = 0; i < steps; ++i) {
-                if (!model(x.data(), sigmas[i], den.data())) return false;
+                if (!model(x.data(), sigmas[i], den.data(), nullptr)) return false;
                 const float dt = sigmas[i + 1] - sigmas[i];
                 for (size_t k = 0; k < n; ++k) d[k] = (x[k] - den[k]) / sigmas[i];
                 if (sigmas[i + 1] == 0) {
                     for (size_t k = 0; k < n; ++k) x[k] += d[k] * dt;
                 } else {
                     for (size_t k = 0; k < n; ++k) x2[k] = x[k] + d[k] * dt;
-                    if (!model(x2.data(), sigmas[i + 1], den2.data())) return false;
+                    if (!model(x2.data(), sigmas[i + 1], den2.data(), nullptr)) return false;
                     for (size_t k = 0; k < n; ++k) {
                         const float d2 = (x2[k] - den2[k]) / sigmas[i + 1];
                         const float dm = (d[k] + d2) / 2.0f;
@@ -407,7 +674,7 @@ inline bool run_sampler_generic(int method, ModelFn&& model, std::vector<float>&
             return true;
         case SM_DPM2:
             for (int i = 0; i < steps; ++i) {
-                if (!model(x.data(), sigmas[i], den.data())) return false;
+                if (!model(x.data(), sigmas[i], den.data(), nullptr)) return false;
                 for (size_t k = 0; k < n; ++k) d[k] = (x[k] - den[k]) / sigmas[i];
                 if (sigmas[i + 1] == 0) {
                     const float dt = sigmas[i + 1] - sigmas[i];
@@ -416,7 +683,7 @@ inline bool run_sampler_generic(int method, ModelFn&& model, std::vector<float>&
                     const float sigma_mid = (float)exp(0.5f * (log((double)sigmas[i]) + log((double)sigmas[i + 1])));
                     const float dt_1 = sigma_mid - sigmas[i], dt_2 = sigmas[i + 1] - sigmas[i];
                     for (size_t k = 0; k < n; ++k) x2[k] = x[k] + d[k] * dt_1;
-                    if (!model(x2.data(), sigma_mid, den2.data())) return false;
+                    if (!model(x2.data(), sigma_mid, den2.data(), nullptr)) return false;
                     for (size_t k = 0; k < n; ++k) {
                         const float d2 = (x2[k] - den2[k]) / sigma_mid;
                         x[k] += d2 * dt_2;
@@ -427,7 +694,7 @@ inline bool run_sampler_generic(int method, ModelFn&& model, std::vector<float>&
         case SM_DPMPP2S_A:
             if (!flow) {
                 for (int i = 0; i < steps; ++i) {
-                    if (!model(x.data(), sigmas[i], den.data())) return false;
+                    if (!model(x.data(), sigmas[i], den.data(), nullptr)) return false;
                     float sigma_down, sigma_up;
                     ancestral_step(sigmas[i], sigmas[i + 1], eta, sigma_down, sigma_up);
                     if (sigma_down == 0) {
@@ -436,7 +703,7 @@ inline bool run_sampler_generic(int method, ModelFn&& model, std::vector<float>&
                         const float t = t_fn(sigmas[i]), t_next = t_fn(sigma_down), h = t_next - t, s = t + 0.5f * h, sigma_s = sigma_fn(s);
                         const float a1 = sigma_s / sigma_fn(t), b1 = (float)(exp((double)(-h * 0.5f)) - 1);
                         for (size_t k = 0; k < n; ++k) x2[k] = a1 * x[k] - b1 * den[k];
-                        if (!model(x2.data(), sigma_s, den2.data())) return false;
+                        if (!model(x2.data(), sigma_s, den2.data(), nullptr)) return false;
                         const float a2 = sigma_fn(t_next) / sigma_fn(t), b2 = (float)(exp((double)-h) - 1);
                         for (size_t k = 0; k < n; ++k) x[k] = a2 * x[k] - b2 * den2[k];
                     }
@@ -451,7 +718,7 @@ inline bool run_sampler_generic(int method, ModelFn&& model, std::vector<float>&
             for (int i = 0; i < steps; ++i) {  // sample_dpmpp_2s_ancestral_flow, denoiser.hpp:1697-1789
                 const float sigma = sigmas[i], sigma_to = sigmas[i + 1];
                 const bool opt_first_step = (1.0 - (double)sigma < 1e-6);
-                if (!model(x.data(), sigma, den.data())) return false;
+                if (!model(x.data(), sigma, den.data(), nullptr)) return false;
                 if (sigma_to == 0.0f) {
                     x = den;
                     continue;
@@ -463,7 +730,7 @@ inline bool run_sampler_generic(int method, ModelFn&& model, std::vector<float>&
                     const float exp_s = std::sqrt(((1 - sigma) / sigma) * ((1 - sigma_down) / sigma_down));
                     const float sigma_s = 1.0f / (exp_s + 1.0f), ratio = sigma_s / sigma, omr = 1.0f - ratio;
                     for (size_t k = 0; k < n; ++k) x2[k] = (x[k] * ratio) + (den[k] * omr);
-                    if (!model(x2.data(), sigma_s, den2.data())) return false;
+                    if (!model(x2.data(), sigma_s, den2.data(), nullptr)) return false;
                     D_i = den2.data();
                 }
                 const float rd = sigma_down / sigma, omrd = 1.0f - rd;
@@ -479,7 +746,7 @@ inline bool run_sampler_generic(int method, ModelFn&& model, std::vector<float>&
         case SM_DPMPP2Mv2: {
             std::vector<float> old = x;
             for (int i = 0; i < steps; ++i) {
-                if (!model(x.data(), sigmas[i], den.data())) return false;
+                if (!model(x.data(), sigmas[i], den.data(), nullptr)) return false;
                 const float t = t_fn(sigmas[i]), t_next = t_fn(sigmas[i + 1]), h = t_next - t, a = sigmas[i + 1] / sigmas[i];
                 if (i == 0 || sigmas[i + 1] == 0) {
                     const float b = (float)(exp((double)-h) - 1.f);
@@ -512,7 +779,7 @@ inline bool run_sampler_generic(int method, ModelFn&& model, std::vector<float>&
             std::vector<std::vector<float>> hist;
             for (int i = 0; i < steps; ++i) {
                 const float sigma = sigmas[i], sigma_next = sigmas[i + 1];
-                if (!model(x.data(), sigma, den.data())) return false;
+                if (!model(x.data(), sigma, den.data(), nullptr)) return false;
                 std::vector<float> dc(n);
                 for (size_t k = 0; k < n; ++k) dc[k] = (x[k] - den[k]) / sigma;
                 const int order = std::min(max_order, i + 1);
@@ -545,7 +812,7 @@ inline bool run_sampler_generic(int method, ModelFn&& model, std::vector<float>&
         }
         case SM_LCM:
             for (int i = 0; i < steps; ++i) {
-                if (!model(x.data(), sigmas[i], den.data())) return false;
+                if (!model(x.data(), sigmas[i], den.data(), nullptr)) return false;
                 x = den;
                 if (sigmas[i + 1] > 0) {
                     if (flow) {
@@ -561,6 +828,373 @@ inline bool run_sampler_generic(int method, ModelFn&& model, std::vector<float>&
                 }
             }
             return true;
+        case SM_DPMPP2M_SDE:      // sample_dpmpp_2m_sde, denoiser.hpp:1861-1907 (std::log / exp / expm1 / sqrt on floats: the float overloads)
+        case SM_DPMPP2M_SDE_BT: {  // sample_dpmpp_2m_sde_bt, denoiser.hpp:1995-2057: the same update with Brownian-tree noise (one tree per image, seeded from its stream)
+            std::vector<BrownianTree> trees;
+            const size_t per = n / (size_t)(nb > 0 ? nb : 1);
+            if (method == SM_DPMPP2M_SDE_BT) {
+                double sigma_max = 0.0, sigma_min = std::numeric_limits<double>::infinity();
+                for (float s : sigmas)
+                    if (s > 0.0f) {
+                        sigma_max = std::max(sigma_max, static_cast<double>(s));
+                        sigma_min = std::min(sigma_min, static_cast<double>(s));
+                    }
+                if (sigma_max <= sigma_min) return true;  // (the reference returns x as it is)
+                if (!draw) return false;
+                for (int b = 0; b < nb; ++b) {
+                    float two[2];
+                    draw(b, 2, two);
+                    uint64_t tree_seed = 0;
+                    memcpy(&tree_seed, two, sizeof(tree_seed));
+                    trees.emplace_back(per, sigma_min, sigma_max, tree_seed);
+                }
+            }
+            std::vector<float> old;
+            bool have_old = false;
+            float h_last  = 0.f;
+            for (int i = 0; i < steps; ++i) {
+                if (!model(x.data(), sigmas[i], den.data(), nullptr)) return false;
+                if (sigmas[i + 1] == 0.f) {
+                    x = den;
+                } else {
+                    const float t = -logf(sigmas[i]), s = -logf(sigmas[i + 1]), h = s - t, eta_h = eta * h;
+                    const float a = sigmas[i + 1] / sigmas[i] * expf(-eta_h);
+                    const float b = -expm1f(-h - eta_h);
+                    for (size_t k = 0; k < n; ++k) x[k] = a * x[k] + b * den[k];
+                    if (have_old) {
+                        const float r = h_last / h, c = 0.5f * b / r;
+                        for (size_t k = 0; k < n; ++k) x[k] += c * (den[k] - old[k]);
+                    }
+                    if (eta > 0.f) {
+                        nz.resize(n);
+                        if (method == SM_DPMPP2M_SDE_BT)
+                            for (int b2 = 0; b2 < nb; ++b2) trees[(size_t)b2]((double)sigmas[i], (double)sigmas[i + 1], nz.data() + (size_t)b2 * per);
+                        else
+                            randn(nz.data());
+                        const float f = sigmas[i + 1] * sqrtf(-expm1f(-2.f * eta_h));
+                        for (size_t k = 0; k < n; ++k) x[k] += nz[k] * f;
+                    }
+                    h_last = h;
+                }
+                old      = den;
+                have_old = true;
+            }
+            return true;
+        }
+        case SM_RES_MULTISTEP: {  // sample_res_multistep, denoiser.hpp:2230-2306
+            std::vector<float> old = x;
+            bool have_old_sigma  = false;
+            float old_sigma_down = 0.0f;
+            for (int i = 0; i < steps; ++i) {
+                if (!model(x.data(), sigmas[i], den.data(), nullptr)) return false;
+                const float sigma_from = sigmas[i], sigma_to = sigmas[i + 1];
+                float sigma_down, sigma_up, alpha_scale;
+                ancestral_step3(sigma_from, sigma_to, eta, flow, sigma_down, sigma_up, alpha_scale);
+                if (sigma_down == 0.0f || !have_old_sigma) {
+                    const float dt = sigma_down - sigma_from;
+                    for (size_t k = 0; k < n; ++k) x[k] += ((x[k] - den[k]) / sigma_from) * dt;
+                } else {
+                    const float t = -logf(sigma_from), t_old = -logf(old_sigma_down), t_next = -logf(sigma_down), t_prev = -logf(sigmas[i - 1]);
+                    const float h = t_next - t, c2 = (t_prev - t_old) / h;
+                    const float phi1_val = phi1_fn(-h), phi2_val = phi2_fn(-h);
+                    float b1 = phi1_val - phi2_val / c2, b2 = phi2_val / c2;
+                    if (!std::isfinite(b1)) b1 = 0.0f;
+                    if (!std::isfinite(b2)) b2 = 0.0f;
+                    const float sh = expf(-h);
+                    for (size_t k = 0; k < n; ++k) {
+                        const float in = b1 * den[k] + b2 * old[k];
+                        x[k]           = sh * x[k] + h * in;
+                    }
+                }
+                if (sigma_to > 0.0f && sigma_up > 0.0f) {
+                    if (flow)
+                        for (size_t k = 0; k < n; ++k) x[k] *= alpha_scale;
+                    nz.resize(n);
+                    randn(nz.data());
+                    for (size_t k = 0; k < n; ++k) x[k] += nz[k] * sigma_up;
+                }
+                old            = den;
+                old_sigma_down = sigma_down;
+                have_old_sigma = true;
+            }
+            return true;
+        }
+        case SM_RES_2S: {  // sample_res_2s, denoiser.hpp:2308-2378
+            const float c2 = 0.5f;
+            std::vector<float> x0(n), eps1(n);
+            for (int i = 0; i < steps; ++i) {
+                const float sigma_from = sigmas[i], sigma_to = sigmas[i + 1];
+                if (!model(x.data(), sigma_from, den.data(), nullptr)) return false;
+                float sigma_down, sigma_up, alpha_scale;
+                ancestral_step3(sigma_from, sigma_to, eta, flow, sigma_down, sigma_up, alpha_scale);
+                x0 = x;
+                if (sigma_down == 0.0f || sigma_from == 0.0f) {
+                    x = den;
+                } else {
+                    const float t = -logf(sigma_from), t_next = -logf(sigma_down), h = t_next - t;
+                    const float a21 = c2 * phi1_fn(-h * c2), phi1_val = phi1_fn(-h), phi2_val = phi2_fn(-h);
+                    const float b2 = phi2_val / c2, b1 = phi1_val - b2;
+                    const float sigma_c2 = expf(-(t + h * c2)), ha = h * a21;
+                    for (size_t k = 0; k < n; ++k) {
+                        eps1[k] = den[k] - x0[k];
+                        x2[k]   = x0[k] + eps1[k] * ha;
+                    }
+                    if (!model(x2.data(), sigma_c2, den2.data(), nullptr)) return false;
+                    for (size_t k = 0; k < n; ++k) {
+                        const float eps2 = den2[k] - x0[k];
+                        const float in   = b1 * eps1[k] + b2 * eps2;
+                        x[k]             = x0[k] + h * in;
+                    }
+                }
+                if (sigma_to > 0.0f && sigma_up > 0.0f) {
+                    if (flow)
+                        for (size_t k = 0; k < n; ++k) x[k] *= alpha_scale;
+                    nz.resize(n);
+                    randn(nz.data());
+                    for (size_t k = 0; k < n; ++k) x[k] += nz[k] * sigma_up;
+                }
+            }
+            return true;
+        }
+        case SM_ER_SDE: {  // sample_er_sde, denoiser.hpp:2380-2513
+            constexpr int max_stage = 3, num_integration_points = 200;
+            constexpr float num_integration_points_f = 200.0f;
+            const float s_noise = eta;
+            auto flow_sigma = [](float sigma) -> float {
+                sigma = std::max(sigma, 1e-6f);
+                sigma = std::min(sigma, 1.0f - 1e-4f);
+                return sigma;
+            };
+            auto to_lambda = [&](float sigma) -> float {
+                if (flow) {
+                    sigma = flow_sigma(sigma);
+                    return sigma / std::max(1.0f - sigma, 1e-6f);
+                }
+                return std::max(sigma, 1e-6f);
+            };
+            auto to_alpha = [&](float sigma) -> float {
+                if (flow) {
+                    sigma = flow_sigma(sigma);
+                    return 1.0f - sigma;
+                }
+                return 1.0f;
+            };
+            auto noise_scaler = [](float v) -> float {
+                v = std::max(v, 0.0f);
+                return v * (expf(powf(v, 0.3f)) + 10.0f);
+            };
+            if (flow)
+                for (size_t i = 0; i + 1 < sigmas.size(); ++i)
+                    if (sigmas[i] > 1.0f) sigmas[i] = flow_sigma(sigmas[i]);
+            std::vector<float> er_lambdas(sigmas.size(), 0.0f);
+            for (size_t i = 0; i < sigmas.size(); ++i) er_lambdas[i] = to_lambda(sigmas[i]);
+            std::vector<float> old = x, old_d = x, den_d(n);
+            bool have_old = false, have_old_d = false;
+            for (int i = 0; i < steps; ++i) {
+                if (!model(x.data(), sigmas[i], den.data(), nullptr)) return false;
+                const int stage_used = std::min(max_stage, i + 1);
+                if (sigmas[i + 1] == 0.0f) {
+                    x = den;
+                } else {
+                    const float er_lambda_s = er_lambdas[i], er_lambda_t = er_lambdas[i + 1];
+                    const float alpha_s = to_alpha(sigmas[i]), alpha_t = to_alpha(sigmas[i + 1]);
+                    const float scaled_s = noise_scaler(er_lambda_s), scaled_t = noise_scaler(er_lambda_t);
+                    const float r_alpha = alpha_s > 0.0f ? alpha_t / alpha_s : 0.0f;
+                    const float r       = scaled_s > 0.0f ? scaled_t / scaled_s : 0.0f;
+                    const float cx = r_alpha * r, cd = alpha_t * (1.0f - r);
+                    for (size_t k = 0; k < n; ++k) x[k] = cx * x[k] + cd * den[k];
+                    if (stage_used >= 2 && have_old) {
+                        const float dt = er_lambda_t - er_lambda_s;
+                        const float lambda_step_size = -dt / num_integration_points_f;
+                        float s = 0.0f, s_u = 0.0f;
+                        for (int p = 0; p < num_integration_points; ++p) {
+                            const float lambda_pos = er_lambda_t + p * lambda_step_size;
+                            const float scaled_pos = noise_scaler(lambda_pos);
+                            if (scaled_pos <= 0.0f) continue;
+                            s += 1.0f / scaled_pos;
+                            if (stage_used >= 3 && have_old_d) s_u += (lambda_pos - er_lambda_s) / scaled_pos;
+                        }
+                        s *= lambda_step_size;
+                        const float denom_d = er_lambda_s - er_lambdas[i - 1];
+                        if (std::fabs(denom_d) > 1e-12f) {
+                            const float coeff_d = alpha_t * (dt + s * scaled_t);
+                            for (size_t k = 0; k < n; ++k) {
+                                den_d[k] = (den[k] - old[k]) / denom_d;
+                                x[k] += coeff_d * den_d[k];
+                            }
+                            if (stage_used >= 3 && have_old_d) {
+                                const float denom_u = (er_lambda_s - er_lambdas[i - 2]) * 0.5f;
+                                if (std::fabs(denom_u) > 1e-12f) {
+                                    s_u *= lambda_step_size;
+                                    const float coeff_u = alpha_t * (0.5f * dt * dt + s_u * scaled_t);
+                                    for (size_t k = 0; k < n; ++k) {
+                                        const float den_u = (den_d[k] - old_d[k]) / denom_u;
+                                        x[k] += coeff_u * den_u;
+                                    }
+                                }
+                            }
+                            old_d      = den_d;
+                            have_old_d = true;
+                        }
+                    }
+                    const float noise_scale_sq = er_lambda_t * er_lambda_t - er_lambda_s * er_lambda_s * r * r;
+                    if (s_noise > 0.0f && noise_scale_sq > 0.0f) {
+                        const float noise_scale = alpha_t * std::sqrt(std::max(noise_scale_sq, 0.0f));
+                        nz.resize(n);
+                        randn(nz.data());
+                        for (size_t k = 0; k < n; ++k) x[k] += nz[k] * noise_scale;
+                    }
+                }
+                old      = den;
+                have_old = true;
+            }
+            return true;
+        }
+        case SM_TCD: {  // sample_tcd, denoiser.hpp:2515-2579
+            const float beta_start = 0.00085f, beta_end = 0.0120f;
+            std::vector<double> alphas_cumprod(TIMESTEPS), compvis_sigmas(TIMESTEPS);
+            for (int i = 0; i < TIMESTEPS; i++) {
+                // (mixed types as the reference writes them: the float base is promoted by std::pow(float, int), the running product is double)
+                alphas_cumprod[i] = (i == 0 ? 1.0f : alphas_cumprod[i - 1]) *
+                                    (1.0f - std::pow(sqrtf(beta_start) + (sqrtf(beta_end) - sqrtf(beta_start)) * ((float)i / (TIMESTEPS - 1)), 2));
+                compvis_sigmas[i] = std::sqrt((1 - alphas_cumprod[i]) / alphas_cumprod[i]);
+            }
+            auto get_timestep_from_sigma = [&](float s) -> int {
+                auto it = std::lower_bound(compvis_sigmas.begin(), compvis_sigmas.end(), s);
+                if (it == compvis_sigmas.begin()) return 0;
+                if (it == compvis_sigmas.end()) return TIMESTEPS - 1;
+                const int idx_high = static_cast<int>(std::distance(compvis_sigmas.begin(), it)), idx_low = idx_high - 1;
+                if (std::abs(compvis_sigmas[idx_high] - s) < std::abs(compvis_sigmas[idx_low] - s)) return idx_high;
+                return idx_low;
+            };
+            for (int i = 0; i < steps; ++i) {
+                const float sigma_to    = sigmas[i + 1];
+                const int prev_timestep = get_timestep_from_sigma(sigma_to);
+                const int timestep_s    = (int)floor((1 - eta) * prev_timestep);
+                const float sigma       = sigmas[i];
+                if (!model(x.data(), sigma, den.data(), nullptr)) return false;
+                const float alpha_prod_t_prev = 1.0f / (sigma_to * sigma_to + 1.0f);
+                const float alpha_prod_s      = static_cast<float>(alphas_cumprod[timestep_s]);
+                const float beta_prod_s       = 1.0f - alpha_prod_s;
+                const float c1 = std::sqrt(alpha_prod_s / alpha_prod_t_prev), c2 = std::sqrt(beta_prod_s / alpha_prod_t_prev);
+                for (size_t k = 0; k < n; ++k) {
+                    const float dk = (x[k] - den[k]) / sigma;
+                    x[k]           = c1 * den[k] + c2 * dk;
+                }
+                if (eta > 0 && sigma_to > 0.0f) {
+                    const float c3 = std::sqrt(alpha_prod_t_prev / alpha_prod_s), c4 = std::sqrt(1.0f / alpha_prod_t_prev - 1.0f / alpha_prod_s);
+                    nz.resize(n);
+                    randn(nz.data());
+                    for (size_t k = 0; k < n; ++k) x[k] = c3 * x[k] + c4 * nz[k];
+                }
+            }
+            return true;
+        }
+        case SM_LMS: {  // sample_lms, denoiser.hpp:2581-2685 with its defaults (no extra sample args): 1000 divisions, order 4, history shift 1
+            const int divisions = 1000, shift = 1;
+            const int max_order = std::min(4, steps);
+            auto coeff = [&](const int order, const int m, const int j) -> float {
+                const float a = sigmas[m], dx = (sigmas[m + 1] - a) / divisions, s = sigmas[m - j];
+                const float b0 = a + 0.5f * dx;
+                float sum = 0.0f;
+                for (int h = 0; h < divisions; h++) {
+                    const float b = h * dx + b0;
+                    float prod    = 1.0f;
+                    for (int k = 0; k < j; k++) {
+                        const float t = sigmas[m - k];
+                        prod *= (b - t) / (s - t);
+                    }
+                    for (int k = j + 1; k < order; k++) {
+                        const float t = sigmas[m - k];
+                        prod *= (b - t) / (s - t);
+                    }
+                    sum += prod;
+                }
+                return sum * dx;
+            };
+            std::vector<float> lms_coeff((size_t)std::max(max_order, 1));
+            std::vector<std::vector<float>> hist;
+            for (int i = 0; i < steps; ++i) {
+                const float sigma = sigmas[i];
+                if (!model(x.data(), sigma, den.data(), nullptr)) return false;
+                const int order = std::min(max_order, i + 1);
+                for (int c = 0; c < order; c++) lms_coeff[(size_t)c] = coeff(order, i, c);
+                std::vector<float> d_cur(n);
+                for (size_t k = 0; k < n; ++k) {
+                    d_cur[k] = (x[k] - den[k]) / sigma;
+                    x[k] += d_cur[k] * lms_coeff[0];
+                }
+                if (max_order > 1) {
+                    const int hist_size_p1 = (int)hist.size() + 1;
+                    if (i) {
+                        const int hist_max = (int)hist.size() - 1;
+                        for (int c = 2; c <= order; c++) {
+                            const std::vector<float>& hc = hist[(size_t)std::min(hist_max, hist_size_p1 - c + shift)];
+                            const float lc               = lms_coeff[(size_t)c - 1];
+                            for (size_t k = 0; k < n; ++k) x[k] += hc[k] * lc;
+                        }
+                    }
+                    if (hist_size_p1 == max_order) hist.erase(hist.begin());
+                    hist.push_back(std::move(d_cur));
+                }
+            }
+            return true;
+        }
+        case SM_EULER_CFG_PP:      // sample_euler_cfg_pp, denoiser.hpp:2687-2705
+        case SM_EULER_A_CFG_PP: {  // sample_euler_ancestral_cfg_pp, denoiser.hpp:2707-2733 (the two-value get_ancestral_step: no flow variant)
+            std::vector<float> unc(n);
+            for (int i = 0; i < steps; ++i) {
+                const float sigma = sigmas[i];
+                if (!model(x.data(), sigma, den.data(), unc.data())) return false;
+                float to = sigmas[i + 1], sigma_up = 0.f;
+                if (method == SM_EULER_A_CFG_PP) ancestral_step(sigmas[i], sigmas[i + 1], eta, to, sigma_up);
+                for (size_t k = 0; k < n; ++k) {
+                    const float dk = (x[k] - unc[k]) / sigma;
+                    x[k]           = den[k] + dk * to;
+                }
+                if (method == SM_EULER_A_CFG_PP && sigmas[i + 1] > 0) {
+                    nz.resize(n);
+                    randn(nz.data());
+                    for (size_t k = 0; k < n; ++k) x[k] += nz[k] * sigma_up;
+                }
+            }
+            return true;
+        }
+        case SM_EULER_GE: {  // sample_gradient_estimation, denoiser.hpp:2736-2792 with gamma = 2 (no extra sample args)
+            const float ge_gamma = 2.0f, omg = 1.0f - ge_gamma;
+            std::vector<float> old_d;
+            bool has_old_d = false;
+            for (int i = 0; i < steps; ++i) {
+                const float sigma = sigmas[i], sigma_to = sigmas[i + 1];
+                if (!model(x.data(), sigma, den.data(), nullptr)) return false;
+                if (sigma_to == 0.f) {
+                    x = den;
+                } else {
+                    float sigma_down, sigma_up, alpha_scale;
+                    ancestral_step3(sigma, sigma_to, eta, flow, sigma_down, sigma_up, alpha_scale);
+                    const float dt = sigma_down - sigma;
+                    for (size_t k = 0; k < n; ++k) d[k] = (x[k] - den[k]) / sigma;
+                    if (has_old_d) {
+                        for (size_t k = 0; k < n; ++k) {
+                            const float d_bar = d[k] * ge_gamma + old_d[k] * omg;
+                            x[k] += d_bar * dt;
+                        }
+                    } else {
+                        for (size_t k = 0; k < n; ++k) x[k] += d[k] * dt;
+                    }
+                    old_d     = d;
+                    has_old_d = true;
+                    if (sigma_up > 0.f) {
+                        if (flow)
+                            for (size_t k = 0; k < n; ++k) x[k] *= alpha_scale;
+                        nz.resize(n);
+                        randn(nz.data());
+                        for (size_t k = 0; k < n; ++k) x[k] += nz[k] * sigma_up;
+                    }
+                }
+            }
+            return true;
+        }
         default:
             return false;
     }

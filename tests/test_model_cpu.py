@@ -160,6 +160,18 @@ def test_more_samplers_through_the_engine(sd, oracle, eng15):
     assert eng15.stats()["unet_calls"] - calls0 == 2 * steps - 1      # the pair in one graph; no second stage on the last step
     assert rel_l2(out, x) < 2e-4
     np.testing.assert_array_equal(eng15.sample_latents(cond, uncond, method=sd.HEUN, scheduler=sd.SCHED_KARRAS, fuse_cfg=True, device_sampler=True, **kw), out)
+    # Euler CFG++ (sample_euler_cfg_pp): the step direction comes from the UNCONDITIONAL denoised prediction, the landing point from the guided one
+    x = x0.copy()
+    for i in range(steps):
+        s = np.float32(sig[i])
+        c_in = np.float32(1.0) / np.sqrt(s * s + np.float32(1.0))
+        t = np.array([sd.lib().sd_sigma_to_t(float(s))], dtype=np.float32)
+        ec, eu = eng15.unet_forward(x * c_in, t, cond), eng15.unet_forward(x * c_in, t, uncond)
+        den, unc = (eu + np.float32(cfg) * (ec - eu)) * (-s) + x, eu * (-s) + x
+        x = den + (x - unc) / s * sig[i + 1]
+    for fuse in (False, True):
+        out = eng15.sample_latents(cond, uncond, method=sd.EULER_CFG_PP, scheduler=sd.SCHED_KARRAS, fuse_cfg=fuse, **kw)
+        assert rel_l2(out, x) < 2e-4
     # a batch draws each image's noise from its own stream (seed + b): image b of the batch == the single image with that seed
     for m in (sd.LCM, sd.DPMPP2S_A):
         kb = dict(kw, batch=3, device_batch=3, method=m, fuse_cfg=True)
@@ -173,7 +185,7 @@ def test_more_samplers_through_the_engine(sd, oracle, eng15):
     np.testing.assert_array_equal(eng15.sample_latents(cond, uncond, method=sd.DDIM_TRAILING, device_sampler=True, fuse_cfg=True, **kw),
                                   eng15.sample_latents(cond, uncond, method=sd.EULER_A, eta=0.0, scheduler=sd.SCHED_SIMPLE, device_sampler=True, fuse_cfg=True, **kw))
     # not implemented -> an error, never another sampler / ladder
-    for bad in (dict(method=11), dict(method=20), dict(scheduler=4), dict(scheduler=15)):
+    for bad in (dict(method=22), dict(method=-1), dict(scheduler=11), dict(scheduler=13)):
         for dev in (False, True):
             with pytest.raises(sd.EngineError, match="not implemented"):
                 eng15.sample_latents(cond, uncond, device_sampler=dev, fuse_cfg=True, **dict(kw, **bad))
@@ -187,12 +199,13 @@ def test_more_samplers_on_the_flow_families(sd, oracle, eng35):
     y = rng.standard_normal((1, 64)).astype(np.float32)
     kw = dict(width=64, height=64, steps=4, cfg=1.0, seed=5, batch=1, cond_y=y)
     outs = {}
-    for m in range(11):
+    for m in range(21):
         calls0 = eng35.stats()["unet_calls"]
         outs[m] = eng35.sample_latents(cond, None, method=m, **kw)
         calls = eng35.stats()["unet_calls"] - calls0
         assert np.isfinite(outs[m]).all(), m
-        assert calls == {sd.HEUN: 7, sd.DPM2: 7, sd.DPMPP2S_A: 6}.get(m, 4), (m, calls)   # 2S a (flow): sigma_0 = 1 -> first step reuses its one call; last step is Euler
+        # 2S a (flow): sigma_0 = 1 -> first step reuses its one call; last step is Euler.  RES 2S: two stages per step but the last
+        assert calls == {sd.HEUN: 7, sd.DPM2: 7, sd.DPMPP2S_A: 6, sd.RES_2S: 7}.get(m, 4), (m, calls)
     keys = sorted(outs)
     for i, a in enumerate(keys):
         for b in keys[i + 1:]:
