@@ -104,6 +104,25 @@ def test_sampler_trajectory_parity(sd, oracle, gpu):
     assert err < 2e-2
 
 
+@pytest.mark.parametrize("method,scheduler", [("DPMPP2M", "SCHED_KARRAS"), ("HEUN", "SCHED_KARRAS"), ("RES_2S", "SCHED_BETA"), ("EULER_A_CFG_PP", "SCHED_GITS"),
+                                              ("LMS", "SCHED_BONG_TANGENT"), ("DPMPP2M_SDE_BT", "SCHEDULER_DEFAULT"), ("TCD", "SCHEDULER_DEFAULT")])
+def test_more_samplers_trajectory_parity(sd, oracle, gpu, method, scheduler):
+    """The multi-stage / multi-step samplers run the host loop (bit-exact against the reference's sample_k_diffusion on the CPU: tests/test_host_logic.py) around the DEVICE
+    forward: 5-step trajectories with CFG 5, two images in one device batch, the cond / uncond pair in one graph, against the oracle backend's batch-1 runs — two-stage methods
+    (second model call at an intermediate sigma), history methods, the CFG++ update that needs the unconditional prediction, the Brownian-tree noise."""
+    rng = np.random.default_rng(19)
+    cond = rng.standard_normal((1, 77, 64)).astype(np.float32)
+    uncond = rng.standard_normal((1, 77, 64)).astype(np.float32)
+    kw = dict(width=128, height=128, steps=5, cfg=5.0, method=getattr(sd, method), scheduler=getattr(sd, scheduler))
+    gpu_e = sd.Engine(model=sd.SD15_TINY, backend=gpu)
+    out = gpu_e.sample_latents(cond, uncond, batch=2, device_batch=2, seed=11, fuse_cfg=True, device_sampler=True, **kw)   # (device_sampler: falls back to the host loop)
+    ref_e = sd.Engine(model=sd.SD15_TINY, backend=oracle)
+    ref = np.concatenate([ref_e.sample_latents(cond, uncond, batch=1, seed=11 + b, **kw) for b in range(2)])
+    err = rel_l2(out, ref)
+    print(f"{method} / {scheduler}: trajectory rel-L2 {err:.3e}")
+    assert np.isfinite(out).all() and err < 2e-2
+
+
 @pytest.mark.parametrize("flash,wtype", [(False, "F16"), (True, "F16"), (True, "BF16")])
 def test_mmdit_forward_parity(sd, oracle, gpu, flash, wtype):
     """SD3.5 MMDiT (tiny width, same topology incl. one MMDiT-X block; odd latent size exercises pad + crop) — SURVEY.md row a11.
