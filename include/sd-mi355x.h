@@ -195,6 +195,11 @@ SD_API bool sd_unet_forward(sdm_ctx_t* ctx, const float* x, int w, int h, int c,
                             const float* y, int64_t y_dim, int64_t y_n, float* out);
 /* VAE decode_first_stage (stable-diffusion.cpp:3062-3078): latents [w,h,zc,n] (diffusion scale) -> rgb f32 [8w,8h,3,n] in [0,1] */
 SD_API bool sd_vae_decode(sdm_ctx_t* ctx, const float* latents, int w, int h, int c, int n, float* out_rgb);
+/* TAESD, the tiny autoencoder's decoder (src/model/vae/tae.hpp:123-183, 732-792; the reference's `--taesd`): the same latents -> rgb f32 [8w,8h,3,n], NOT clamped (the graph's
+ * output is the image; the u8 stage clamps).  The module (parameters "tae.decoder.layers.<i>. ...", 4 latent channels, 16 for the DiT families) is made on first use;
+ * sd_load_weights_prefixed(ctx, file, "tae.") loads a taesd checkpoint into it.  sd_use_tae(ctx, true): sdm_generate_image decodes with it instead of the KL-VAE. */
+SD_API bool sd_tae_decode(sdm_ctx_t* ctx, const float* latents, int w, int h, int c, int n, float* out_rgb);
+SD_API bool sd_use_tae(sdm_ctx_t* ctx, bool on);
 /* sample(): init noise (Philox seed+b) -> Euler(-A) loop with CFG -> final latents [w,h,c,batch_count] */
 SD_API bool sd_sample_latents(sdm_ctx_t* ctx, const sdm_img_gen_params_t* p, float* out_latents);
 /* sdm_generate_image: sample + decode + uint8 RGB.  Caller frees with sdm_free_images (library callocs). */

@@ -30,6 +30,7 @@
 
 #include "model/diffusion/unet.hpp"
 #include "model/vae/auto_encoder_kl.hpp"
+#include "model/vae/tae.hpp"
 #include "model/diffusion/dit.hpp"
 #include "model/diffusion/mmdit.hpp"
 #include "model/diffusion/flux.hpp"
@@ -190,6 +191,19 @@ struct VaeH : public Handle, public AutoEncoderKL {
     using GGMLRunner::free_compute_ctx;
 };
 
+// TAESD (round 6): the reference makes it with the lookup prefix "decoder.layers" and names its parameters under "tae" (stable-diffusion.cpp:1417-1422, tae.hpp:744, 753)
+struct TaeH : public Handle, public TinyImageAutoEncoder {
+    TaeH(ggml_backend_t be, SDVersion v, std::shared_ptr<ResidentWeights> w) : TinyImageAutoEncoder(be, g_storage, "decoder.layers", /*decoder_only*/ true, v, w) {
+        weights = w;
+        std::map<std::string, ggml_tensor*> m;
+        TinyImageAutoEncoder::get_param_tensors(m);
+        list_params(m);
+    }
+    ggml_context* params_context() override { return params_ctx; }
+    using GGMLRunner::prepare_compute_graph;
+    using GGMLRunner::free_compute_ctx;
+};
+
 sd::Tensor<float> tensor_of(const float* data, const int64_t* ne, int n_dims) {
     if (!data || n_dims <= 0) return {};
     std::vector<int64_t> shape(ne, ne + n_dims);
@@ -216,7 +230,7 @@ REF_API void refg_storage_add(const char* name, int type, int n_dims, const int6
     g_storage[name] = ts;
 }
 
-// family: 0 UNet, 1 KL-VAE decoder, 2 MMDiT, 3 FLUX.  overrides: "key=value;key=a,b,c" applied on top of the detected configuration ("" / NULL: none)
+// family: 0 UNet, 1 KL-VAE decoder, 2 MMDiT, 3 FLUX, 4 TAESD decoder.  overrides: "key=value;key=a,b,c" applied on top of the detected configuration ("" / NULL: none)
 REF_API void* refg_new(int family, const char* version, void* backend, const char* prefix, int flash_attn, const char* overrides) {
     auto w  = std::make_shared<ResidentWeights>();
     auto ov = parse_overrides(overrides);
@@ -241,6 +255,11 @@ REF_API void* refg_new(int family, const char* version, void* backend, const cha
         }
         case 3: {
             auto* p = new FluxH(be, prefix, ov, w);
+            h = p, r = p;
+            break;
+        }
+        case 4: {
+            auto* p = new TaeH(be, version_of(version), w);
             h = p, r = p;
             break;
         }
@@ -312,6 +331,13 @@ REF_API int64_t refg_run(void* hp, int describe_only, const float* x, const int6
             if (!describe_only) result = p->Flux::FluxRunner::compute(1, X, T, C, {}, Y, G);
             break;
         }
+        case 4: {
+            auto* p   = static_cast<TaeH*>(h);
+            r         = p;
+            get_graph = [&, p]() { return p->build_graph(X, true); };
+            if (!describe_only) result = p->_compute(1, X, true);
+            break;
+        }
     }
     if (describe_only) {
         ggml_cgraph* gf = nullptr;
@@ -321,6 +347,7 @@ REF_API int64_t refg_run(void* hp, int describe_only, const float* x, const int6
             case 1: ok = static_cast<VaeH*>(h)->prepare_compute_graph(get_graph, &gf); break;
             case 2: ok = static_cast<MMDiTH*>(h)->prepare_compute_graph(get_graph, &gf); break;
             case 3: ok = static_cast<FluxH*>(h)->prepare_compute_graph(get_graph, &gf); break;
+            case 4: ok = static_cast<TaeH*>(h)->prepare_compute_graph(get_graph, &gf); break;
         }
         if (!ok || !gf) return -1;
         const size_t need = sdm_graph_describe(gf, nullptr, 0);
@@ -333,6 +360,7 @@ REF_API int64_t refg_run(void* hp, int describe_only, const float* x, const int6
             case 1: static_cast<VaeH*>(h)->free_compute_ctx(); break;
             case 2: static_cast<MMDiTH*>(h)->free_compute_ctx(); break;
             case 3: static_cast<FluxH*>(h)->free_compute_ctx(); break;
+            case 4: static_cast<TaeH*>(h)->free_compute_ctx(); break;
         }
         return n_nodes;
     }

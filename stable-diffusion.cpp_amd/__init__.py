@@ -628,6 +628,26 @@ class Engine:
             raise EngineError("sd_vae_decode failed: " + lib().sd_last_error().decode())
         return out
 
+    def tae_decode(self, latents: np.ndarray) -> np.ndarray:
+        """sd_tae_decode — TAESD (src/model/vae/tae.hpp): latents [N,C,h,w] (diffusion scale, unscaled) -> rgb [N,3,8h,8w], not clamped."""
+        z = _f32(latents)
+        n, c, h, w = z.shape
+        out = np.empty((n, 3, h * 8, w * 8), dtype=np.float32)
+        L = lib()
+        L.sd_tae_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.sd_tae_decode.restype = C.c_bool
+        if not L.sd_tae_decode(self._ctx, _fptr(z), w, h, c, n, _fptr(out)):
+            raise EngineError("sd_tae_decode failed: " + L.sd_last_error().decode())
+        return out
+
+    def use_tae(self, on: bool = True):
+        """sd_use_tae: generate_image decodes with TAESD instead of the KL-VAE (the reference's --taesd without --taesd-preview-only)."""
+        L = lib()
+        L.sd_use_tae.argtypes = [C.c_void_p, C.c_bool]
+        L.sd_use_tae.restype = C.c_bool
+        if not L.sd_use_tae(self._ctx, bool(on)):
+            raise EngineError("sd_use_tae failed: " + L.sd_last_error().decode())
+
     def _gen_params(self, cond, uncond, width, height, steps, cfg, seed, batch, device_batch, method, eta, cond_y=None, uncond_y=None,
                     fuse_cfg=False, device_sampler=False, scheduler=SCHEDULER_DEFAULT):
         p = SdImgGenParams()

@@ -605,6 +605,8 @@ ggml_tensor* ggml_gelu_quick_inplace(ggml_context* ctx, ggml_tensor* a) { return
 ggml_tensor* ggml_sigmoid(ggml_context* ctx, ggml_tensor* a) { return unary_impl(ctx, a, GGML_UNARY_OP_SIGMOID, false); }
 ggml_tensor* ggml_tanh(ggml_context* ctx, ggml_tensor* a) { return unary_impl(ctx, a, GGML_UNARY_OP_TANH, false); }
 ggml_tensor* ggml_relu(ggml_context* ctx, ggml_tensor* a) { return unary_impl(ctx, a, GGML_UNARY_OP_RELU, false); }
+ggml_tensor* ggml_tanh_inplace(ggml_context* ctx, ggml_tensor* a) { return unary_impl(ctx, a, GGML_UNARY_OP_TANH, true); }
+ggml_tensor* ggml_relu_inplace(ggml_context* ctx, ggml_tensor* a) { return unary_impl(ctx, a, GGML_UNARY_OP_RELU, true); }
 
 ggml_tensor* ggml_norm(ggml_context* ctx, ggml_tensor* a, float eps) {
     ggml_tensor* r = ggml_dup_tensor(ctx, a);

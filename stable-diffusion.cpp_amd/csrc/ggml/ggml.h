@@ -105,6 +105,8 @@ GGML_API struct ggml_tensor* ggml_gelu_quick_inplace(struct ggml_context* ctx, s
 GGML_API struct ggml_tensor* ggml_sigmoid(struct ggml_context* ctx, struct ggml_tensor* a);
 GGML_API struct ggml_tensor* ggml_tanh(struct ggml_context* ctx, struct ggml_tensor* a);
 GGML_API struct ggml_tensor* ggml_relu(struct ggml_context* ctx, struct ggml_tensor* a);
+GGML_API struct ggml_tensor* ggml_tanh_inplace(struct ggml_context* ctx, struct ggml_tensor* a);
+GGML_API struct ggml_tensor* ggml_relu_inplace(struct ggml_context* ctx, struct ggml_tensor* a);
 
 GGML_API struct ggml_tensor* ggml_norm(struct ggml_context* ctx, struct ggml_tensor* a, float eps);
 GGML_API struct ggml_tensor* ggml_rms_norm(struct ggml_context* ctx, struct ggml_tensor* a, float eps);

@@ -529,8 +529,13 @@ struct sdm_ctx_t {
     std::vector<float> pe_cache;  // FLUX rotary table of the last (h, w, n_tokens)
     int pe_h = 0, pe_w = 0;
     int64_t pe_tokens = 0;
+    // TAESD (tae.hpp): the tiny decoder next to the KL-VAE, made on first use (sd_tae_decode / sd_use_tae) like the reference makes it when a taesd file is given
+    Runner tae_runner;
+    TaeDecoder tae;
+    bool tae_ready = false, tae_for_images = false;
     std::vector<Runner*> runners() {
         std::vector<Runner*> v{&unet_runner, &vae_runner};
+        if (tae_ready) v.push_back(&tae_runner);
         if (te) {
             if (te->spec.has_l) v.push_back(&te->l_runner);
             if (te->spec.has_g) v.push_back(&te->g_runner);
@@ -1271,6 +1276,56 @@ bool sd_vae_decode(sdm_ctx_t* ctx, const float* latents, int w, int h, int c, in
     return true;
 }
 
+// ---- TAESD decode ------------------------------------------------------
+// TinyImageAutoEncoder (src/model/vae/tae.hpp:732-792; made at stable-diffusion.cpp:1407-1424 with the weights of `--taesd`, file prefix "tae."): parameters
+// "tae.decoder.layers.<i>. ...", z_channels 16 for the DiT families.  Weights: synthetic like every other module until sd_load_weights_prefixed(ctx, file, "tae.") fills them.
+static bool ensure_tae(sdm_ctx_t* ctx) {
+    if (ctx->tae_ready) return true;
+    Runner& r       = ctx->tae_runner;
+    r.backend       = ctx->backend;
+    r.ps.linear_type = GGML_TYPE_F16;
+    r.graph_size    = 2048;
+    ctx->tae.init(r.ps, "tae.decoder.layers.", ctx->is_dit ? 16 : 4);
+    if (!r.alloc_weights(ctx->params.weight_seed)) {
+        set_error("TAESD weight buffer allocation failed");
+        return false;
+    }
+    for (auto& sp : r.ps.specs) ctx->all_tensors.push_back({sp.name, sp.tensor});
+    ctx->stats.weight_bytes += ggml_backend_buffer_get_size(r.weights);
+    ctx->tae_ready = true;
+    return true;
+}
+// decode_first_stage with the tiny autoencoder: the diffusion latents enter as they are (diffusion_to_vae_latents is the identity, tae.hpp:763-765), the graph's output IS the
+// image (scale_input = false, tae.hpp:745: no (x + 1) / 2, no clamp — the u8 conversion clamps); latents [w,h,zc,n] -> rgb f32 [8w,8h,3,n]
+bool sd_tae_decode(sdm_ctx_t* ctx, const float* latents, int w, int h, int c, int n, float* out_rgb) {
+    if (!ensure_tae(ctx)) return false;
+    if (c != (int)ctx->tae.z_channels) {
+        set_error("sd_tae_decode: the latents have " + std::to_string(c) + " channels, this model's TAESD takes " + std::to_string(ctx->tae.z_channels));
+        return false;
+    }
+    Runner& r  = ctx->tae_runner;
+    auto build = [&](GraphCtx& g, std::vector<HostInput>& in) {
+        g.conv_direct   = ctx->params.diffusion_conv_direct;
+        ggml_tensor* tz = ggml_new_tensor_4d(g.ctx, GGML_TYPE_F32, w, h, c, n);
+        ggml_set_input(tz);
+        in.push_back({tz, latents, ggml_nbytes(tz)});
+        return ctx->tae.forward(g, tz);
+    };
+    const size_t on = (size_t)w * 8 * h * 8 * 3 * n;
+    const double t0 = now_ms();
+    char sig[64];
+    snprintf(sig, sizeof(sig), "tae %d %d %d %d", w, h, c, n);
+    if (!r.compute(build, out_rgb, on * sizeof(float), sig, {latents})) return false;
+    ctx->stats.last_decode_ms = now_ms() - t0;
+    return true;
+}
+// the reference decodes with TAESD instead of the KL-VAE when a taesd file is given and it is not for previews only (stable-diffusion.cpp:1496-1516): sdm_generate_image's switch
+bool sd_use_tae(sdm_ctx_t* ctx, bool on) {
+    if (on && !ensure_tae(ctx)) return false;
+    ctx->tae_for_images = on;
+    return true;
+}
+
 // ---- sample(): the denoise loop -------------------------------------------------------------------
 // resolve_sample_method / sd_get_default_sample_method (stable-diffusion.cpp:3965-3975, 4006-4013): DiT families default to plain Euler
 static int resolve_sample_method(const sdm_ctx_t* ctx, int m) {
@@ -1736,7 +1791,7 @@ bool sdm_generate_image(sdm_ctx_t* ctx, const sdm_img_gen_params_t* p, sdm_image
     double dec_ms   = 0;
     for (int b0 = 0; b0 < p->batch_count; b0 += group) {
         const int nb = std::min(group, p->batch_count - b0);
-        if (!sd_vae_decode(ctx, latents.data() + b0 * per, W, H, C, nb, rgb.data() + (size_t)b0 * pix * 3)) {
+        if (!(ctx->tae_for_images ? sd_tae_decode : sd_vae_decode)(ctx, latents.data() + b0 * per, W, H, C, nb, rgb.data() + (size_t)b0 * pix * 3)) {
             sdm_free_images(imgs, p->batch_count);
             return false;
         }

@@ -375,6 +375,65 @@ struct VaeDecoder {
     }
 };
 
+// ---- TAESD: the tiny autoencoder's decoder (SURVEY.md section 8 row f4 "TAESD ... adjacent graphs") — src/model/vae/tae.hpp:15-76 (TAEBlock), :123-183 (TinyDecoder),
+// :686-730 (TAESD), :732-792 (TinyImageAutoEncoder: latents enter unscaled, the output is the image in [0, 1] as it leaves the graph).  64 channels throughout:
+// tanh(z / 3) * 3 -> conv -> ReLU -> 3 x [3 blocks, nearest x2, bias-free conv] -> block -> conv to RGB.  Sequential indices as the checkpoint keys have them.
+struct TaeBlock {
+    Conv2d c0, c2, c4;
+    void init(ParamStore& ps, const std::string& prefix, int64_t ch) {
+        c0.init(ps, prefix + "conv.0.", ch, ch, 3, 1, 1);
+        c2.init(ps, prefix + "conv.2.", ch, ch, 3, 1, 1);
+        c4.init(ps, prefix + "conv.4.", ch, ch, 3, 1, 1);
+    }
+    ggml_tensor* forward(GraphCtx& g, ggml_tensor* x) const {
+        ggml_context* c = g.ctx;
+        ggml_tensor* h  = c0.forward(g, x);
+        h               = ggml_relu_inplace(c, h);
+        h               = c2.forward(g, h);
+        h               = ggml_relu_inplace(c, h);
+        h               = c4.forward(g, h);
+        h               = ggml_add(c, h, x);
+        return ggml_relu_inplace(c, h);
+    }
+};
+struct TaeDecoder {
+    static constexpr int kChannels = 64, kBlocks = 3;
+    int64_t z_channels = 4;
+    // layer index -> what sits there (tae.hpp:130-158): 0 conv, 1 ReLU, 2-4 blocks, 5 upsample, 6 conv, 7-9 blocks, 10 upsample, 11 conv, 12-14 blocks, 15 upsample, 16 conv,
+    // 17 block, 18 conv
+    Conv2d conv_in, conv_out, up_conv[3];
+    TaeBlock blocks[3 * kBlocks + 1];
+    void init(ParamStore& ps, const std::string& prefix, int64_t zc) {
+        z_channels = zc;
+        int index  = 0, nb = 0;
+        conv_in.init(ps, prefix + std::to_string(index++) + ".", zc, kChannels, 3, 1, 1);
+        index++;  // ReLU
+        for (int stage = 0; stage < 3; ++stage) {
+            for (int i = 0; i < kBlocks; ++i) blocks[nb++].init(ps, prefix + std::to_string(index++) + ".", kChannels);
+            index++;  // Upsample
+            up_conv[stage].init(ps, prefix + std::to_string(index++) + ".", kChannels, kChannels, 3, 1, 1, /*bias*/ false);
+        }
+        blocks[nb++].init(ps, prefix + std::to_string(index++) + ".", kChannels);
+        conv_out.init(ps, prefix + std::to_string(index++) + ".", kChannels, 3, 3, 1, 1);
+    }
+    ggml_tensor* forward(GraphCtx& g, ggml_tensor* z) const {
+        ggml_context* c = g.ctx;
+        ggml_tensor* h  = ext_scale(c, z, 1.0f / 3.0f);
+        h               = ggml_tanh_inplace(c, h);
+        h               = ext_scale(c, h, 3.0f);
+        h               = conv_in.forward(g, h);
+        h               = ggml_relu_inplace(c, h);
+        int nb          = 0;
+        for (int stage = 0; stage < 3; ++stage) {
+            for (int i = 0; i < kBlocks; ++i) h = blocks[nb++].forward(g, h);
+            h = ggml_upscale(c, h, 2, GGML_SCALE_MODE_NEAREST);
+            h = up_conv[stage].forward(g, h);
+        }
+        h = blocks[nb++].forward(g, h);
+        return conv_out.forward(g, h);
+    }
+};
+
 // =====================================================================================================
 // MMDiT (SD3 / SD3.5) — src/model/diffusion/mmdit.hpp
 // =====================================================================================================

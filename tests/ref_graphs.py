@@ -13,7 +13,7 @@ import numpy as np
 import sdcpp_amd as sd
 
 LIB = Path(__file__).resolve().parent.parent / "oracle" / "_ref" / "libref_graphs.so"
-FAMILY = {"unet": 0, "vae": 1, "mmdit": 2, "flux": 3}
+FAMILY = {"unet": 0, "vae": 1, "mmdit": 2, "flux": 3, "tae": 4}
 _lib = None
 
 

@@ -89,6 +89,21 @@ def test_vae_decode_with_conv2d_scale_parity(sd, oracle, gpu):
         np.testing.assert_array_equal(out.shape, plain.shape)
 
 
+@pytest.mark.parametrize("model_name,zc,hw,n", [("SD15_TINY", 4, (12, 10), 3), ("SD15_TINY", 4, (64, 64), 2), ("SD35_TINY", 16, (128, 128), 1)])
+def test_taesd_decode_parity(sd, oracle, gpu, model_name, zc, hw, n):
+    """TAESD's decoder (src/model/vae/tae.hpp:123-183) through the C ABI on the GPU against the oracle backend: a ragged small latent, the
+    512 x 512 and the 16-channel 1024 x 1024 decode (64-channel 3x3 convs + ReLU up to 1024 x 1024 feature maps).  The output is unclamped: compared as it leaves the graph."""
+    rng = np.random.default_rng(23)
+    z = (rng.standard_normal((n, zc) + hw) * 1.5).astype(np.float32)
+    ref = sd.Engine(model=getattr(sd, model_name), backend=oracle).tae_decode(z)
+    g = sd.Engine(model=getattr(sd, model_name), backend=gpu)
+    out = g.tae_decode(z)
+    err = rel_l2(out, ref)
+    print(f"TAESD {model_name} {hw} x{n}: rel-L2 {err:.3e}, decode {g.stats()['last_decode_ms']:.2f} ms")
+    assert np.isfinite(out).all() and err < 3e-3
+    np.testing.assert_array_equal(g.tae_decode(z), out)   # plan cache / hipGraph replay
+
+
 def test_sampler_trajectory_parity(sd, oracle, gpu):
     """4-step Euler-A with CFG 7, two images in one device batch vs the oracle's independent batch-1 runs."""
     rng = np.random.default_rng(9)

@@ -44,6 +44,7 @@ def test_reference_emitted_graph_on_the_gpu(sd, oracle, gpu, name):
     c = inputs_for(sd, name, np.random.default_rng(11))
     post = c.get("post", lambda v: v)
     e_gpu = sd.Engine(model=c["model"], backend=gpu, flash_attn=True)
+    c.get("prepare", lambda e_: None)(e_gpu)
     r_gpu = rg.RefRunner(e_gpu, c["family"], c["version"], gpu, flash_attn=True, overrides=c["overrides"])
     r_cpu = rg.RefRunner(e_gpu, c["family"], c["version"], oracle, flash_attn=True, overrides=c["overrides"])
     for r in (r_gpu, r_cpu):

@@ -63,6 +63,70 @@ def test_vae_graph_vs_torch(sd, oracle, eng15):
     assert np.abs(a - b).max() < 5e-3
 
 
+def _taesd_decode_torch(e, z):
+    """Independent fp32 restatement of TAESD's TinyDecoder (the published taesd.py layout the reference follows, src/model/vae/tae.hpp:123-183) on the engine's weights:
+    clamp-by-tanh, conv + ReLU, 3 x [3 residual blocks, nearest x2, bias-free conv], block, conv to RGB.  Conv operands rounded to f16 like the graph's im2col + MUL_MAT."""
+    import torch
+    import torch.nn.functional as F
+
+    def h16(t):
+        return t.half().float()
+
+    def conv(x, i, sub="", bias=True):
+        w = torch.from_numpy(e.get_tensor(f"tae.decoder.layers.{i}.{sub}weight").astype(np.float32))
+        b = torch.from_numpy(e.get_tensor(f"tae.decoder.layers.{i}.{sub}bias")) if bias else None
+        return F.conv2d(h16(x), h16(w), b, padding=1)
+
+    def block(x, i):
+        h = F.relu(conv(x, i, "conv.0."))
+        h = F.relu(conv(h, i, "conv.2."))
+        return F.relu(conv(h, i, "conv.4.") + x)
+
+    x = torch.tanh(torch.from_numpy(z) / 3.0) * 3.0
+    x = F.relu(conv(x, 0))
+    i = 2
+    for _ in range(3):
+        for _ in range(3):
+            x = block(x, i)
+            i += 1
+        x = F.interpolate(x, scale_factor=2, mode="nearest")
+        i += 1
+        x = conv(x, i, bias=False)
+        i += 1
+    x = block(x, i)
+    return conv(x, i + 1).numpy()
+
+
+@pytest.mark.parametrize("model_name,zc", [("SD15_TINY", 4), ("SD35_TINY", 16)])
+def test_taesd_decoder_vs_torch(sd, oracle, model_name, zc):
+    """SURVEY.md section 8 row f4 (TAESD, the adjacent decode graph): sd_tae_decode on the oracle backend against an independent PyTorch fp32 restatement of the same layers on
+    the same (synthetic) weights; the parameter table carries the checkpoint's names ("tae." + the sequential taesd indices); two images in one graph == two graphs; the
+    generate_image switch (sd_use_tae) hands the u8 stage the TAESD image."""
+    e = sd.Engine(model=getattr(sd, model_name), backend=oracle)
+    rng = np.random.default_rng(21)
+    z = (rng.standard_normal((2, zc, 12, 10)) * 2.0).astype(np.float32)
+    out = e.tae_decode(z)
+    assert out.shape == (2, 3, 96, 80) and np.isfinite(out).all()
+    names = [n for n in e.tensor_names() if n.startswith("tae.")]
+    assert len(names) == 2 + 10 * 6 + 3 + 2 and "tae.decoder.layers.6.weight" in names and "tae.decoder.layers.6.bias" not in names and "tae.decoder.layers.18.bias" in names
+    assert e.tensor_info("tae.decoder.layers.0.weight")[0][:4] == [3, 3, zc, 64]
+    ref = _taesd_decode_torch(e, z)
+    assert rel_l2(out, ref) < 2e-3
+    np.testing.assert_array_equal(e.tae_decode(z[1:2]), out[1:2])
+    with pytest.raises(sd.EngineError, match="channels"):
+        e.tae_decode(z[:, :3])
+    if zc == 4:
+        cond = rng.standard_normal((1, 77, 64)).astype(np.float32)
+        kw = dict(width=64, height=64, steps=2, cfg=1.0, seed=3, batch=1)
+        lat = e.sample_latents(cond, None, **kw)
+        e.use_tae(True)
+        img = e.generate_image(cond, None, **kw)
+        e.use_tae(False)
+        want = np.clip(e.tae_decode(lat), 0, 1)[0].transpose(1, 2, 0)
+        assert img.shape == (1, 64, 64, 3) and np.abs(img[0].astype(np.float32) - want * 255.0).max() <= 0.5 + 1e-3
+        assert not np.array_equal(img, e.generate_image(cond, None, **kw))   # the KL-VAE again
+
+
 def test_batched_graph_equals_independent_runs(sd, oracle, eng15):
     rng = np.random.default_rng(3)
     x = rng.standard_normal((3, 4, 16, 16)).astype(np.float32)

@@ -53,6 +53,11 @@ def inputs_for(sd, name, rng, real=False):
         post = lambda v: np.clip((v + np.float32(1.0)) * np.float32(0.5), np.float32(0.0), np.float32(1.0)).astype(np.float32)
         return dict(family="vae", version=version, model=model, overrides="", ref=dict(x=z_graph), eng=lambda e: e.vae_decode(z), out=(1, 3, 96, 80),
                     scale=(1.0 / 32.0) if name == "VAE_SDXL" else None, post=post)
+    if name.startswith("TAE"):
+        # TAESD (tae.hpp): the engine makes the module on first use; latents enter unscaled, the graph's output is the image
+        model, version, zc = {"TAE": (sd.SD15_TINY, "sd1", 4), "TAE16": (sd.SD35_TINY, "sd3", 16)}[name]
+        z = (rng.standard_normal((1 if real else 2, zc, 12, 10)) * 2.0).astype(np.float32)
+        return dict(family="tae", version=version, model=model, overrides="", ref=dict(x=z), eng=lambda e: e.tae_decode(z), out=(z.shape[0], 3, 96, 80), prepare=lambda e: (e.use_tae(True), e.use_tae(False)))
     dit_ctx = {"SD35_TINY": 96, "SD3M_TINY": 96, "FLUX_TINY": 96, "SD35_LARGE": 4096, "FLUX_DEV": 4096}[name]
     dit_y = {"SD35_LARGE": 2048, "FLUX_DEV": 768}.get(name, 64)
     flux = name.startswith("FLUX")
@@ -83,7 +88,7 @@ def compare_descriptions(name, dref, deng):
     return len(nr), len(lr), renamed
 
 
-TINY = ["SD15_TINY", "SDXL_TINY", "VAE", "VAE_SDXL", "VAE16", "SD35_TINY", "SD3M_TINY", "FLUX_TINY"]
+TINY = ["SD15_TINY", "SDXL_TINY", "VAE", "VAE_SDXL", "VAE16", "SD35_TINY", "SD3M_TINY", "FLUX_TINY", "TAE", "TAE16"]
 
 
 @pytest.mark.parametrize("flash", [True, False])
@@ -91,6 +96,7 @@ TINY = ["SD15_TINY", "SDXL_TINY", "VAE", "VAE_SDXL", "VAE16", "SD35_TINY", "SD3M
 def test_reference_emitted_graph_equals_engine_graph_node_for_node(sd, oracle, name, flash):
     c = inputs_for(sd, name, np.random.default_rng(5))
     e = sd.Engine(model=c["model"], backend=oracle, flash_attn=flash)
+    c.get("prepare", lambda e_: None)(e)
     r = rg.RefRunner(e, c["family"], c["version"], oracle, flash_attn=flash, overrides=c["overrides"], copy_weights=False)
     if c.get("scale"):
         r.set_conv2d_scale(c["scale"])  # SDXL engines start with the VAE Conv2d scale 1/32 (src/stable-diffusion.cpp:1477-1485)
@@ -145,6 +151,7 @@ def test_reference_emitted_graph_equals_engine_graph_at_the_benchmarked_widths(s
 def test_reference_runner_computes_the_engine_result_bit_for_bit_on_the_oracle(sd, oracle, name):
     c = inputs_for(sd, name, np.random.default_rng(7))
     e = sd.Engine(model=c["model"], backend=oracle, flash_attn=True)
+    c.get("prepare", lambda e_: None)(e)
     r = rg.RefRunner(e, c["family"], c["version"], oracle, flash_attn=True, overrides=c["overrides"])
     if c.get("scale"):
         r.set_conv2d_scale(c["scale"])
