@@ -138,6 +138,10 @@ typedef struct {
     bool device_sampler;        /* OUR extension: the whole iteration — x*c_in, model pair, CFG combine, Euler(-A) update —
                                    is one graph per step on latents that stay in a backend buffer; nothing crosses back to the host until
                                    the last step (the reference's three crossings per model call: stable-diffusion.cpp:2636-2664, 2855-2896) */
+    const float* init_latent;   /* img2img (stable-diffusion.h init_image, already encoded: sd_vae_encode): diffusion latents [w/8, h/8, C] shared by the batch like the
+                                   reference's one init image; the trajectory starts from noise_scaling(sigma_0, noise, init_latent) (denoiser.hpp:1181-1186, 1274-1279);
+                                   NULL = txt2img */
+    float strength;             /* with init_latent: < 1 keeps the last t_enc + 2 sigmas of the ladder, t_enc = (int)(steps * strength) (stable-diffusion.cpp:4940-4980); 0.75 default */
 } sdm_img_gen_params_t;
 
 typedef struct {
@@ -195,6 +199,10 @@ SD_API bool sd_unet_forward(sdm_ctx_t* ctx, const float* x, int w, int h, int c,
                             const float* y, int64_t y_dim, int64_t y_n, float* out);
 /* VAE decode_first_stage (stable-diffusion.cpp:3062-3078): latents [w,h,zc,n] (diffusion scale) -> rgb f32 [8w,8h,3,n] in [0,1] */
 SD_API bool sd_vae_decode(sdm_ctx_t* ctx, const float* latents, int w, int h, int c, int n, float* out_rgb);
+/* VAE encode — encode_first_stage (stable-diffusion.cpp:3042-3060): rgb f32 planar [w,h,3,n] in [0,1] -> diffusion latents [w/8,h/8,zc,n], SAMPLED from the encoder's diagonal
+ * Gaussian with Philox(seed) like the reference (auto_encoder_kl.hpp:750-759) and scaled to the diffusion model's range; moments_out (optional) receives the graph's output
+ * [w/8,h/8,2*zc,n] (mean | log-variance).  The encoder ("first_stage_model.encoder. ...", "first_stage_model.quant_conv. ...") is made on first use. */
+SD_API bool sd_vae_encode(sdm_ctx_t* ctx, const float* rgb, int w, int h, int n, uint64_t seed, float* out_latents, float* moments_out);
 /* TAESD, the tiny autoencoder's decoder (src/model/vae/tae.hpp:123-183, 732-792; the reference's `--taesd`): the same latents -> rgb f32 [8w,8h,3,n], NOT clamped (the graph's
  * output is the image; the u8 stage clamps).  The module (parameters "tae.decoder.layers.<i>. ...", 4 latent channels, 16 for the DiT families) is made on first use;
  * sd_load_weights_prefixed(ctx, file, "tae.") loads a taesd checkpoint into it.  sd_use_tae(ctx, true): sdm_generate_image decodes with it instead of the KL-VAE. */

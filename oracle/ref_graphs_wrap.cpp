@@ -180,7 +180,8 @@ struct FluxH : public Handle, public Flux::FluxRunner {
 };
 
 struct VaeH : public Handle, public AutoEncoderKL {
-    VaeH(ggml_backend_t be, const std::string& prefix, SDVersion v, std::shared_ptr<ResidentWeights> w) : AutoEncoderKL(be, g_storage, prefix, /*decode_only*/ true, false, v, w) {
+    VaeH(ggml_backend_t be, const std::string& prefix, SDVersion v, std::shared_ptr<ResidentWeights> w, bool with_encoder = false)
+        : AutoEncoderKL(be, g_storage, prefix, /*decode_only*/ !with_encoder, false, v, w) {
         weights = w;
         std::map<std::string, ggml_tensor*> m;
         AutoEncoderKL::get_param_tensors(m);
@@ -230,7 +231,7 @@ REF_API void refg_storage_add(const char* name, int type, int n_dims, const int6
     g_storage[name] = ts;
 }
 
-// family: 0 UNet, 1 KL-VAE decoder, 2 MMDiT, 3 FLUX, 4 TAESD decoder.  overrides: "key=value;key=a,b,c" applied on top of the detected configuration ("" / NULL: none)
+// family: 0 UNet, 1 KL-VAE decoder, 2 MMDiT, 3 FLUX, 4 TAESD decoder, 5 KL-VAE with its encoder (encode graph).  overrides: "key=value;key=a,b,c" applied on top of the detected configuration ("" / NULL: none)
 REF_API void* refg_new(int family, const char* version, void* backend, const char* prefix, int flash_attn, const char* overrides) {
     auto w  = std::make_shared<ResidentWeights>();
     auto ov = parse_overrides(overrides);
@@ -263,6 +264,11 @@ REF_API void* refg_new(int family, const char* version, void* backend, const cha
             h = p, r = p;
             break;
         }
+        case 5: {  // the whole autoencoder (decode_only = false): the ENCODE graph is what refg_run builds
+            auto* p = new VaeH(be, prefix, version_of(version), w, true);
+            h = p, r = p;
+            break;
+        }
         default: return nullptr;
     }
     h->family  = family;
@@ -285,7 +291,7 @@ REF_API int refg_alloc_params(void* hp) {
 }
 REF_API void refg_set_conv2d_scale(void* hp, float scale) {
     Handle* h = (Handle*)hp;
-    if (h->family == 1) static_cast<VaeH*>(h)->set_conv2d_scale(scale);
+    if (h->family == 1 || h->family == 5) static_cast<VaeH*>(h)->set_conv2d_scale(scale);
 }
 
 // Inputs as the reference's sd::Tensor<float> (shape = ggml ne order): x [W,H,C,N], timesteps [N], context [dim, L, Nc], y [dim, Ny], guidance [N] (FLUX).
@@ -338,6 +344,13 @@ REF_API int64_t refg_run(void* hp, int describe_only, const float* x, const int6
             if (!describe_only) result = p->_compute(1, X, true);
             break;
         }
+        case 5: {
+            auto* p   = static_cast<VaeH*>(h);
+            r         = p;
+            get_graph = [&, p]() { return p->build_graph(X, false); };
+            if (!describe_only) result = p->_compute(1, X, false);
+            break;
+        }
     }
     if (describe_only) {
         ggml_cgraph* gf = nullptr;
@@ -348,6 +361,7 @@ REF_API int64_t refg_run(void* hp, int describe_only, const float* x, const int6
             case 2: ok = static_cast<MMDiTH*>(h)->prepare_compute_graph(get_graph, &gf); break;
             case 3: ok = static_cast<FluxH*>(h)->prepare_compute_graph(get_graph, &gf); break;
             case 4: ok = static_cast<TaeH*>(h)->prepare_compute_graph(get_graph, &gf); break;
+            case 5: ok = static_cast<VaeH*>(h)->prepare_compute_graph(get_graph, &gf); break;
         }
         if (!ok || !gf) return -1;
         const size_t need = sdm_graph_describe(gf, nullptr, 0);
@@ -361,6 +375,7 @@ REF_API int64_t refg_run(void* hp, int describe_only, const float* x, const int6
             case 2: static_cast<MMDiTH*>(h)->free_compute_ctx(); break;
             case 3: static_cast<FluxH*>(h)->free_compute_ctx(); break;
             case 4: static_cast<TaeH*>(h)->free_compute_ctx(); break;
+            case 5: static_cast<VaeH*>(h)->free_compute_ctx(); break;
         }
         return n_nodes;
     }

@@ -241,6 +241,26 @@ def vae_decode(engine, latents, scale_factor=0.18215, ch_mult=(1, 2, 4, 4)):
     return ((h + 1.0) * 0.5).clamp(0.0, 1.0).numpy()  # vae.hpp:24-30
 
 
+def vae_encode_moments(engine, rgb, ch_mult=(1, 2, 4, 4), num_res_blocks=2, use_quant=True):
+    """VAE::encode's graph — Encoder::forward + quant_conv (auto_encoder_kl.hpp:276-366, 637-664), ldm's Encoder written from its definition: x * 2 - 1, conv_in,
+    per level 2 ResnetBlocks + (pad right / bottom by one, 3x3 stride-2 conv), mid block / attention / block, GroupNorm + SiLU + conv_out -> moments (mean | logvar)."""
+    w = Weights(engine, "first_stage_model.")
+    e = w.sub("encoder.")
+    h = conv(e.sub("conv_in."), torch.as_tensor(rgb, dtype=torch.float32) * 2.0 - 1.0, padding=1)
+    for i in range(len(ch_mult)):
+        for j in range(num_res_blocks):
+            h = vae_resnet(e.sub(f"down.{i}.block.{j}."), h)
+        if i != len(ch_mult) - 1:
+            h = conv(e.sub(f"down.{i}.downsample.conv."), F.pad(h, (0, 1, 0, 1)), stride=2)
+    h = vae_resnet(e.sub("mid.block_1."), h)
+    h = vae_attn(e.sub("mid.attn_1."), h)
+    h = vae_resnet(e.sub("mid.block_2."), h)
+    h = conv(e.sub("conv_out."), F.silu(group_norm(e.sub("norm_out."), h)), padding=1)
+    if use_quant:
+        h = conv(w.sub("quant_conv."), h)
+    return h.numpy()
+
+
 # =====================================================================================================
 # MMDiT (SD3 / SD3.5) — src/model/diffusion/mmdit.hpp, written from the model's mathematical definition
 # =====================================================================================================

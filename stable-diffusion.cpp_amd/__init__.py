@@ -93,7 +93,8 @@ class SdCondition(C.Structure):
 class SdImgGenParams(C.Structure):
     _fields_ = [("cond", SdCondition), ("uncond", SdCondition), ("width", C.c_int), ("height", C.c_int),
                 ("sample_params", SdSampleParams), ("seed", C.c_int64), ("batch_count", C.c_int),
-                ("device_batch", C.c_int), ("decode", C.c_bool), ("fuse_cfg_pair", C.c_bool), ("device_sampler", C.c_bool)]
+                ("device_batch", C.c_int), ("decode", C.c_bool), ("fuse_cfg_pair", C.c_bool), ("device_sampler", C.c_bool),
+                ("init_latent", C.c_void_p), ("strength", C.c_float)]
 
 
 class SdTokenList(C.Structure):
@@ -628,6 +629,21 @@ class Engine:
             raise EngineError("sd_vae_decode failed: " + lib().sd_last_error().decode())
         return out
 
+    def vae_encode(self, rgb: np.ndarray, seed: int = 42, return_moments: bool = False):
+        """sd_vae_encode: rgb [N,3,H,W] in [0,1] -> diffusion latents [N,zc,H/8,W/8] sampled with Philox(seed) (+ the moments [N,2*zc,H/8,W/8] the graph produced)."""
+        x = _f32(rgb)
+        n, c, h, w = x.shape
+        assert c == 3
+        zc = 16 if self.model in (SD35_LARGE, SD35_TINY, FLUX_DEV, FLUX_TINY, SD35_WIDE2, FLUX_WIDE1, SD3M_TINY, SD35_WIDE8, FLUX_WIDE8) else 4
+        out = np.empty((n, zc, h // 8, w // 8), dtype=np.float32)
+        mom = np.empty((n, 2 * zc, h // 8, w // 8), dtype=np.float32)
+        L = lib()
+        L.sd_vae_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p]
+        L.sd_vae_encode.restype = C.c_bool
+        if not L.sd_vae_encode(self._ctx, _fptr(x), w, h, n, seed, _fptr(out), _fptr(mom)):
+            raise EngineError("sd_vae_encode failed: " + L.sd_last_error().decode())
+        return (out, mom) if return_moments else out
+
     def tae_decode(self, latents: np.ndarray) -> np.ndarray:
         """sd_tae_decode — TAESD (src/model/vae/tae.hpp): latents [N,C,h,w] (diffusion scale, unscaled) -> rgb [N,3,8h,8w], not clamped."""
         z = _f32(latents)
@@ -649,7 +665,7 @@ class Engine:
             raise EngineError("sd_use_tae failed: " + L.sd_last_error().decode())
 
     def _gen_params(self, cond, uncond, width, height, steps, cfg, seed, batch, device_batch, method, eta, cond_y=None, uncond_y=None,
-                    fuse_cfg=False, device_sampler=False, scheduler=SCHEDULER_DEFAULT):
+                    fuse_cfg=False, device_sampler=False, scheduler=SCHEDULER_DEFAULT, init_latent=None, strength=0.75):
         p = SdImgGenParams()
         lib().sdm_img_gen_params_init(C.byref(p))
         keep = []
@@ -679,13 +695,19 @@ class Engine:
         p.device_batch = device_batch
         p.fuse_cfg_pair = fuse_cfg
         p.device_sampler = device_sampler
+        if init_latent is not None:
+            il = _f32(init_latent)
+            keep.append(il)
+            p.init_latent = il.ctypes.data_as(C.c_void_p)
+            p.strength = strength
         return p, keep
 
     def sample_latents(self, cond, uncond=None, width=512, height=512, steps=20, cfg=7.0, seed=42, batch=1, device_batch=0,
                        method=SAMPLE_METHOD_DEFAULT, eta=float("inf"), cond_y=None, uncond_y=None, fuse_cfg=False, device_sampler=False,
-                       scheduler=SCHEDULER_DEFAULT) -> np.ndarray:
+                       scheduler=SCHEDULER_DEFAULT, init_latent=None, strength=0.75) -> np.ndarray:
+        """init_latent [C,h/8,w/8] (+ strength): img2img — the trajectory starts from the noised init latent, (int)(steps * strength) steps before the end of the ladder."""
         p, keep = self._gen_params(cond, uncond, width, height, steps, cfg, seed, batch, device_batch, method, eta, cond_y, uncond_y, fuse_cfg,
-                                   device_sampler, scheduler)
+                                   device_sampler, scheduler, init_latent, strength)
         ch = 16 if self.model in (SD35_LARGE, SD35_TINY, FLUX_DEV, FLUX_TINY, SD35_WIDE2, FLUX_WIDE1, SD3M_TINY, SD35_WIDE8, FLUX_WIDE8) else 4
         out = np.empty((batch, ch, height // 8, width // 8), dtype=np.float32)
         if not lib().sd_sample_latents(self._ctx, C.byref(p), _fptr(out)):
@@ -694,10 +716,10 @@ class Engine:
 
     def generate_image(self, cond, uncond=None, width=512, height=512, steps=20, cfg=7.0, seed=42, batch=1, device_batch=0,
                        method=SAMPLE_METHOD_DEFAULT, eta=float("inf"), cond_y=None, uncond_y=None, fuse_cfg=False, device_sampler=False,
-                       scheduler=SCHEDULER_DEFAULT) -> np.ndarray:
+                       scheduler=SCHEDULER_DEFAULT, init_latent=None, strength=0.75) -> np.ndarray:
         """-> uint8 [batch, H, W, 3]"""
         p, keep = self._gen_params(cond, uncond, width, height, steps, cfg, seed, batch, device_batch, method, eta, cond_y, uncond_y, fuse_cfg,
-                                   device_sampler, scheduler)
+                                   device_sampler, scheduler, init_latent, strength)
         imgs = C.POINTER(SdImage)()
         n = C.c_int()
         if not lib().sdm_generate_image(self._ctx, C.byref(p), C.byref(imgs), C.byref(n)):

@@ -529,6 +529,10 @@ struct sdm_ctx_t {
     std::vector<float> pe_cache;  // FLUX rotary table of the last (h, w, n_tokens)
     int pe_h = 0, pe_w = 0;
     int64_t pe_tokens = 0;
+    // KL-VAE encoder (auto_encoder_kl.hpp:276-366), made on first sd_vae_encode: the reference builds it unless vae_decode_only is set (stable-diffusion.cpp:1467-1474)
+    Runner vae_enc_runner;
+    VaeEncoder vae_enc;
+    bool vae_enc_ready = false;
     // TAESD (tae.hpp): the tiny decoder next to the KL-VAE, made on first use (sd_tae_decode / sd_use_tae) like the reference makes it when a taesd file is given
     Runner tae_runner;
     TaeDecoder tae;
@@ -536,6 +540,7 @@ struct sdm_ctx_t {
     std::vector<Runner*> runners() {
         std::vector<Runner*> v{&unet_runner, &vae_runner};
         if (tae_ready) v.push_back(&tae_runner);
+        if (vae_enc_ready) v.push_back(&vae_enc_runner);
         if (te) {
             if (te->spec.has_l) v.push_back(&te->l_runner);
             if (te->spec.has_g) v.push_back(&te->g_runner);
@@ -590,6 +595,7 @@ void sdm_img_gen_params_init(sdm_img_gen_params_t* p) {  // stable-diffusion.cpp
     p->seed        = 42;
     p->batch_count = 1;
     p->decode      = true;
+    p->strength    = 0.75f;  // stable-diffusion.cpp:3718 (read only with an init latent)
 }
 
 // locate libggml-mi355x.so next to this library (the GGML_BACKEND_DL convention:
@@ -925,6 +931,7 @@ int64_t sd_load_weights_prefixed(sdm_ctx_t* ctx, const char* path, const char* p
         fprintf(stderr, "[sd-mi355x] external VAE loaded: Conv2d scale %.5f -> 1 (call sd_set_vae_conv2d_scale to force a scale)\n", (double)ctx->vae_conv2d_scale);
         ctx->vae_conv2d_scale = 1.f;
         ctx->vae.set_conv2d_scale(1.f);
+        if (ctx->vae_enc_ready) ctx->vae_enc.set_conv2d_scale(1.f);
     }
     return loaded;
 }
@@ -1276,6 +1283,66 @@ bool sd_vae_decode(sdm_ctx_t* ctx, const float* latents, int w, int h, int c, in
     return true;
 }
 
+// ---- VAE encode (the data format in front of the path: pixels -> the init latent of img2img) -------------
+static bool ensure_vae_encoder(sdm_ctx_t* ctx) {
+    if (ctx->vae_enc_ready) return true;
+    Runner& r        = ctx->vae_enc_runner;
+    r.backend        = ctx->backend;
+    r.ps.linear_type = GGML_TYPE_F16;
+    r.graph_size     = 20480;
+    ctx->vae_enc.init(r.ps, "first_stage_model.", ctx->vae.cfg);
+    ctx->vae_enc.set_conv2d_scale(ctx->vae_conv2d_scale);  // AutoEncoderKL::set_conv2d_scale reaches every Conv2d of the autoencoder, encoder included
+    if (!r.alloc_weights(ctx->params.weight_seed)) {
+        set_error("VAE encoder weight buffer allocation failed");
+        return false;
+    }
+    for (auto& sp : r.ps.specs) ctx->all_tensors.push_back({sp.name, sp.tensor});
+    ctx->stats.weight_bytes += ggml_backend_buffer_get_size(r.weights);
+    ctx->vae_enc_ready = true;
+    return true;
+}
+// encode_first_stage (stable-diffusion.cpp:3042-3060) = VAE::encode (vae.hpp:112-168: x * 2 - 1, the encoder graph -> moments), gaussian_latent_sample
+// (auto_encoder_kl.hpp:750-759: mean + exp(0.5 * clamp(logvar, -30, 20)) * randn from the context RNG — seeded with the request's seed, offset 0, stable-diffusion.cpp:5630),
+// vae_to_diffusion_latents ((z - shift) * scale, :830-838).  rgb: planar f32 [w, h, 3, n] in [0, 1]; w, h multiples of 8; out: [w/8, h/8, zc, n].
+// moments_out (optional, 2 * zc channels): what left the graph.
+bool sd_vae_encode(sdm_ctx_t* ctx, const float* rgb, int w, int h, int n, uint64_t seed, float* out_latents, float* moments_out) {
+    if (w < 8 || h < 8 || w % 8 || h % 8 || n < 1) {
+        set_error("sd_vae_encode: width and height must be positive multiples of 8");
+        return false;
+    }
+    if (!ensure_vae_encoder(ctx)) return false;
+    Runner& r       = ctx->vae_enc_runner;
+    const size_t ni = (size_t)w * h * 3 * n;
+    std::vector<float> x(ni);
+    for (size_t i = 0; i < ni; ++i) x[i] = rgb[i] * 2.0f - 1.0f;  // scale_tensor_to_minus1_1, vae.hpp:17-22
+    const int zc = (int)ctx->vae.cfg.z_channels, lw = w / 8, lh = h / 8;
+    auto build = [&](GraphCtx& g, std::vector<HostInput>& in) {
+        g.flash_attn    = ctx->params.diffusion_flash_attn;
+        g.conv_direct   = ctx->params.diffusion_conv_direct;
+        ggml_tensor* tx = ggml_new_tensor_4d(g.ctx, GGML_TYPE_F32, w, h, 3, n);
+        ggml_set_input(tx);
+        in.push_back({tx, x.data(), ggml_nbytes(tx)});
+        return ctx->vae_enc.forward(g, tx);
+    };
+    const size_t plane = (size_t)lw * lh, per = plane * zc;
+    std::vector<float> moments(2 * per * n);
+    char sig[64];
+    snprintf(sig, sizeof(sig), "vae-enc %d %d %d s%g", w, h, n, (double)ctx->vae_conv2d_scale);
+    if (!r.compute(build, moments.data(), moments.size() * sizeof(float), sig, {x.data()})) return false;
+    if (moments_out) memcpy(moments_out, moments.data(), moments.size() * sizeof(float));
+    PhiloxRNG rng(seed);
+    const std::vector<float> noise = rng.randn((uint32_t)(per * n));  // randn_like(mean): one draw over the whole [lw, lh, zc, n] tensor
+    const float sf = ctx->vae.cfg.scale_factor, sh = ctx->vae.cfg.shift_factor;
+    for (int b = 0; b < n; ++b)
+        for (size_t i = 0; i < per; ++i) {
+            const float mean = moments[(size_t)b * 2 * per + i], logvar = moments[(size_t)b * 2 * per + per + i];
+            const float stddev = std::exp(0.5f * std::max(-30.0f, std::min(20.0f, logvar)));
+            const float z      = mean + stddev * noise[(size_t)b * per + i];
+            out_latents[(size_t)b * per + i] = (z - sh) * sf;
+        }
+    return true;
+}
+
 // ---- TAESD decode ------------------------------------------------------
 // TinyImageAutoEncoder (src/model/vae/tae.hpp:732-792; made at stable-diffusion.cpp:1407-1424 with the weights of `--taesd`, file prefix "tae."): parameters
 // "tae.decoder.layers.<i>. ...", z_channels 16 for the DiT families.  Weights: synthetic like every other module until sd_load_weights_prefixed(ctx, file, "tae.") fills them.
@@ -1435,6 +1502,29 @@ struct HostDenoise {
         return true;
     }
 };
+// img2img (stable-diffusion.cpp:4924-4980): with an init latent and strength < 1 the trajectory starts t_enc = steps * strength steps before the end of the ladder
+static std::vector<float> call_sigmas(const sdm_ctx_t* ctx, const sdm_img_gen_params_t* p, int image_seq_len, int scheduler) {
+    std::vector<float> sigmas = ctx->get_sigmas(p->sample_params.sample_steps, image_seq_len, scheduler);
+    if (p->init_latent && p->strength < 1.f && !sigmas.empty()) {
+        const int sample_steps = p->sample_params.sample_steps;
+        size_t t_enc           = static_cast<size_t>(sample_steps * p->strength);
+        if (t_enc == static_cast<size_t>(sample_steps)) t_enc--;
+        const int64_t first = (int64_t)sample_steps - (int64_t)t_enc - 1;
+        if (first > 0 && first < (int64_t)sigmas.size()) sigmas.erase(sigmas.begin(), sigmas.begin() + first);  // (a ladder shorter than steps + 1 — beta scheduler — keeps at least its last pair)
+    }
+    return sigmas;
+}
+// Denoiser::noise_scaling (denoiser.hpp:1181-1186 CompVis: latent + noise * sigma; :1274-1279 flow: latent * (1 - sigma) + noise * sigma); latent NULL = zeros (txt2img)
+static inline void noise_scaling(float* x, const float* noise, const float* latent, size_t n, float sigma, bool flow) {
+    if (!latent) {
+        for (size_t i = 0; i < n; ++i) x[i] = 0.0f + noise[i] * sigma;
+    } else if (flow) {
+        const float om = 1.0f - sigma;
+        for (size_t i = 0; i < n; ++i) x[i] = latent[i] * om + noise[i] * sigma;
+    } else {
+        for (size_t i = 0; i < n; ++i) x[i] = latent[i] + noise[i] * sigma;
+    }
+}
 static bool sample_group(sdm_ctx_t* ctx, const sdm_img_gen_params_t* p, int b0, int nb, float* out) {
     const int W = p->width / 8, H = p->height / 8, C = ctx->in_channels();
     const size_t per = (size_t)W * H * C;
@@ -1442,7 +1532,7 @@ static bool sample_group(sdm_ctx_t* ctx, const sdm_img_gen_params_t* p, int b0, 
     int method, scheduler;
     float eta;
     if (!resolve_sampling(ctx, sp, method, scheduler, eta)) return false;
-    const std::vector<float> sigmas = ctx->get_sigmas(sp.sample_steps, W * H, scheduler);  // image_seq_len = latent pixels (stable-diffusion.cpp:2983-2986)
+    const std::vector<float> sigmas = call_sigmas(ctx, p, W * H, scheduler);  // image_seq_len = latent pixels (stable-diffusion.cpp:2983-2986)
     const int steps                 = (int)sigmas.size() - 1;
     if (steps < 1) {
         set_error("the scheduler returned no sigma ladder for " + std::to_string(sp.sample_steps) + " steps");
@@ -1456,7 +1546,7 @@ static bool sample_group(sdm_ctx_t* ctx, const sdm_img_gen_params_t* p, int b0, 
     parallel_chunks((size_t)nb, [&](size_t i0, size_t i1) {
         for (size_t b = i0; b < i1; ++b) {
             std::vector<float> noise = rngs[b].randn((uint32_t)per);
-            for (size_t i = 0; i < per; ++i) x[b * per + i] = 0.0f + noise[i] * sigmas[0];  // noise_scaling, denoiser.hpp:1174-1179
+            noise_scaling(&x[b * per], noise.data(), p->init_latent, per, sigmas[0], ctx->is_dit);
         }
     }, 2);
     HostDenoise denoise(ctx, p, W, H, C, nb);
@@ -1543,7 +1633,7 @@ static bool sample_group_device(sdm_ctx_t* ctx, const sdm_img_gen_params_t* p, i
     if (method != SDM_EULER_SAMPLE_METHOD && method != SDM_EULER_A_SAMPLE_METHOD) return true;  // multi-stage / multi-step samplers: the host loop around the device forward
     *handled = true;
     const size_t per = (size_t)W * H * C;
-    const std::vector<float> sigmas = ctx->get_sigmas(sp.sample_steps, W * H, scheduler);
+    const std::vector<float> sigmas = call_sigmas(ctx, p, W * H, scheduler);
     const int steps                 = (int)sigmas.size() - 1;
     if (steps < 1) {
         set_error("the scheduler returned no sigma ladder for " + std::to_string(sp.sample_steps) + " steps");
@@ -1580,7 +1670,7 @@ static bool sample_group_device(sdm_ctx_t* ctx, const sdm_img_gen_params_t* p, i
     parallel_chunks((size_t)nb, [&](size_t i0, size_t i1) {
         for (size_t b = i0; b < i1; ++b) {
             std::vector<float> nz = rngs[b].randn((uint32_t)per);
-            for (size_t i = 0; i < per; ++i) x[b * per + i] = 0.0f + nz[i] * sigmas[0];
+            noise_scaling(&x[b * per], nz.data(), p->init_latent, per, sigmas[0], ctx->is_dit);
         }
     }, 2);
     ggml_backend_tensor_set_async(ctx->backend, st.x, x.data(), 0, x.size() * sizeof(float));
@@ -1976,6 +2066,7 @@ bool sd_set_vae_conv2d_scale(sdm_ctx_t* ctx, float scale) {
     }
     ctx->vae_conv2d_scale = scale;
     ctx->vae.set_conv2d_scale(scale);
+    if (ctx->vae_enc_ready) ctx->vae_enc.set_conv2d_scale(scale);
     return true;
 }
 void sd_set_pair_exchange(sdm_ctx_t* ctx, sd_pair_exchange_fn fn, void* user, int branch) {

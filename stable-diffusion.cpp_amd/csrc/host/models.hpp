@@ -375,6 +375,81 @@ struct VaeDecoder {
     }
 };
 
+// ---- KL-VAE encoder — src/model/vae/auto_encoder_kl.hpp:276-366 (Encoder), :637-664 (AutoEncoderKLModel::encode: + quant_conv), DownSampleBlock with vae_downsample
+// (src/model/common/block.hpp:10-41: pad right / bottom by one, 3x3 stride-2 conv without padding).  Output: the moments [w/8, h/8, 2 * z_channels, N] (mean | log-variance).
+struct VaeEncoder {
+    VaeConfig cfg;
+    Conv2d conv_in, conv_out, quant;
+    VaeResnetBlock mid1, mid2;
+    VaeAttnBlock mid_attn;
+    struct Down {
+        std::vector<VaeResnetBlock> blocks;
+        std::unique_ptr<Conv2d> downsample;
+    };
+    std::vector<Down> downs;
+    GroupNorm32 norm_out;
+
+    void init(ParamStore& ps, const std::string& prefix, const VaeConfig& c) {
+        cfg                 = c;
+        const int nr        = (int)cfg.ch_mult.size();
+        const std::string e = prefix + "encoder.";
+        conv_in.init(ps, e + "conv_in.", 3, cfg.ch, 3, 1, 1);
+        int block_in = cfg.ch;
+        downs.resize(nr);
+        for (int i = 0; i < nr; ++i) {
+            block_in            = i == 0 ? cfg.ch : cfg.ch * cfg.ch_mult[i - 1];
+            const int block_out = cfg.ch * cfg.ch_mult[i];
+            downs[i].blocks.resize(cfg.num_res_blocks);
+            for (int j = 0; j < cfg.num_res_blocks; ++j) {
+                downs[i].blocks[j].init(ps, e + "down." + std::to_string(i) + ".block." + std::to_string(j) + ".", block_in, block_out);
+                block_in = block_out;
+            }
+            if (i != nr - 1) {
+                downs[i].downsample = std::make_unique<Conv2d>();
+                downs[i].downsample->init(ps, e + "down." + std::to_string(i) + ".downsample.conv.", block_in, block_in, 3, 2, 0);
+            }
+        }
+        mid1.init(ps, e + "mid.block_1.", block_in, block_in);
+        mid_attn.init(ps, e + "mid.attn_1.", block_in);
+        mid2.init(ps, e + "mid.block_2.", block_in, block_in);
+        norm_out.init(ps, e + "norm_out.", block_in);
+        conv_out.init(ps, e + "conv_out.", block_in, 2 * cfg.z_channels, 3, 1, 1);
+        if (cfg.use_quant) quant.init(ps, prefix + "quant_conv.", 2 * cfg.z_channels, 2 * cfg.z_channels, 1);
+    }
+    void set_conv2d_scale(float s) {
+        std::vector<Conv2d*> all{&conv_in, &conv_out, &quant, &mid1.conv1, &mid1.conv2, &mid1.nin, &mid2.conv1, &mid2.conv2, &mid2.nin,
+                                 &mid_attn.q, &mid_attn.k, &mid_attn.v, &mid_attn.proj_out};
+        for (auto& d : downs) {
+            for (auto& b : d.blocks) {
+                all.push_back(&b.conv1);
+                all.push_back(&b.conv2);
+                all.push_back(&b.nin);
+            }
+            if (d.downsample) all.push_back(d.downsample.get());
+        }
+        for (Conv2d* cv : all) cv->scale = s;
+    }
+    ggml_tensor* forward(GraphCtx& g, ggml_tensor* x) const {
+        ggml_context* c = g.ctx;
+        ggml_tensor* h  = conv_in.forward(g, x);
+        for (auto& d : downs) {
+            for (auto& b : d.blocks) h = b.forward(g, h);
+            if (d.downsample) {
+                h = ggml_pad_ext(c, h, 0, 1, 0, 1, 0, 0, 0, 0);  // ggml_ext_pad(x, 1, 1): right / bottom
+                h = d.downsample->forward(g, h);
+            }
+        }
+        h = mid1.forward(g, h);
+        h = mid_attn.forward(g, h);
+        h = mid2.forward(g, h);
+        h = norm_out.forward(g, h);
+        h = ggml_silu_inplace(c, h);
+        h = conv_out.forward(g, h);
+        if (cfg.use_quant) h = quant.forward(g, h);
+        return h;
+    }
+};
+
 // ---- TAESD: the tiny autoencoder's decoder (SURVEY.md section 8 row f4 "TAESD ... adjacent graphs") — src/model/vae/tae.hpp:15-76 (TAEBlock), :123-183 (TinyDecoder),
 // :686-730 (TAESD), :732-792 (TinyImageAutoEncoder: latents enter unscaled, the output is the image in [0, 1] as it leaves the graph).  64 channels throughout:
 // tanh(z / 3) * 3 -> conv -> ReLU -> 3 x [3 blocks, nearest x2, bias-free conv] -> block -> conv to RGB.  Sequential indices as the checkpoint keys have them.

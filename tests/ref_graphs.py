@@ -13,7 +13,7 @@ import numpy as np
 import sdcpp_amd as sd
 
 LIB = Path(__file__).resolve().parent.parent / "oracle" / "_ref" / "libref_graphs.so"
-FAMILY = {"unet": 0, "vae": 1, "mmdit": 2, "flux": 3, "tae": 4}
+FAMILY = {"unet": 0, "vae": 1, "mmdit": 2, "flux": 3, "tae": 4, "vae_enc": 5}
 _lib = None
 
 
@@ -77,7 +77,7 @@ class RefRunner:
     def __init__(self, engine, family: str, version: str, device: str, flash_attn: bool = False, overrides: str = "", copy_weights: bool = True):
         L, H = lib(), sd.lib()
         self.L, self.H, self.engine, self.family = L, H, engine, family
-        prefix = "first_stage_model" if family == "vae" else "model.diffusion_model"
+        prefix = "first_stage_model" if family in ("vae", "vae_enc") else "model.diffusion_model"
         L.refg_storage_clear()
         for name in engine.tensor_names():
             ne, gtype, _ = engine.tensor_info(name)

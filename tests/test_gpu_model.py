@@ -104,6 +104,28 @@ def test_taesd_decode_parity(sd, oracle, gpu, model_name, zc, hw, n):
     np.testing.assert_array_equal(g.tae_decode(z), out)   # plan cache / hipGraph replay
 
 
+@pytest.mark.parametrize("model_name,hw,n", [("SD15_TINY", (128, 64), 2), ("SDXL_TINY", (128, 128), 1), ("SD35_TINY", (64, 96), 1)])
+def test_vae_encode_and_img2img_parity(sd, oracle, gpu, model_name, hw, n):
+    """sd_vae_encode (pad + stride-2 downsample convs, ragged sizes, the SDXL Conv2d scale, the 16-channel encoder) and an img2img trajectory started from its latent, GPU vs
+    the oracle backend."""
+    rng = np.random.default_rng(29)
+    img = rng.random((n, 3) + hw).astype(np.float32)
+    dit = model_name.startswith("SD35")
+    cond = rng.standard_normal((1, 40, 96) if dit else (1, 77, 64)).astype(np.float32)
+    y = rng.standard_normal((1, 64 if dit else 96)).astype(np.float32) if model_name != "SD15_TINY" else None
+    res = []
+    for be in (oracle, gpu):
+        e = sd.Engine(model=getattr(sd, model_name), backend=be)
+        lat, mom = e.vae_encode(img, seed=5, return_moments=True)
+        traj = e.sample_latents(cond, cond * 0.5, width=hw[1], height=hw[0], steps=6, cfg=3.0, seed=8, batch=1, cond_y=y, uncond_y=y, init_latent=lat[0], strength=0.5,
+                                fuse_cfg=True, device_sampler=True)
+        res.append((lat, mom, traj))
+    (lat_r, mom_r, tr_r), (lat_g, mom_g, tr_g) = res
+    print(f"VAE encode {model_name} {hw} x{n}: moments rel-L2 {rel_l2(mom_g, mom_r):.2e}; img2img trajectory from its own latent {rel_l2(tr_g, tr_r):.2e}")
+    assert np.isfinite(mom_g).all() and rel_l2(mom_g, mom_r) < 5e-3 and rel_l2(lat_g, lat_r) < 5e-3
+    assert np.isfinite(tr_g).all() and rel_l2(tr_g, tr_r) < 2e-2
+
+
 def test_sampler_trajectory_parity(sd, oracle, gpu):
     """4-step Euler-A with CFG 7, two images in one device batch vs the oracle's independent batch-1 runs."""
     rng = np.random.default_rng(9)

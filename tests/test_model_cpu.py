@@ -63,6 +63,57 @@ def test_vae_graph_vs_torch(sd, oracle, eng15):
     assert np.abs(a - b).max() < 5e-3
 
 
+def test_vae_encoder_and_img2img(sd, oracle, eng15):
+    """The data format in front of the path (round 6): sd_vae_encode — the KL-VAE encoder graph against the PyTorch fp32 restatement on the same weights; the latent is
+    mean + exp(0.5 * clamp(logvar, -30, 20)) * Philox(seed) noise, shifted / scaled to the diffusion range (gaussian_latent_sample + vae_to_diffusion_latents,
+    auto_encoder_kl.hpp:750-759, 830-838) — and img2img through the sampler: the trajectory starts from noise_scaling(sigma_0, noise, init_latent) on the ladder's last
+    (int)(steps * strength) + 2 sigmas (stable-diffusion.cpp:4940-4980), on the host loop and on the device-resident sampler alike."""
+    from test_host_logic import philox_randn_np
+    rng = np.random.default_rng(31)
+    img = rng.random((2, 3, 64, 48)).astype(np.float32)
+    lat, mom = eng15.vae_encode(img, seed=9, return_moments=True)
+    assert lat.shape == (2, 4, 8, 6) and mom.shape == (2, 8, 8, 6)
+    ref = torch_ref.vae_encode_moments(eng15, img)
+    assert rel_l2(mom, ref) < 2e-3
+    mean, logvar = mom[:, :4], mom[:, 4:]
+    noise = philox_randn_np(9, 0, lat.size).reshape(lat.shape)
+    want = (mean + np.exp(np.float32(0.5) * np.clip(logvar, -30, 20)) * noise) * np.float32(0.18215)
+    assert rel_l2(lat, want) < 1e-6
+    np.testing.assert_array_equal(eng15.vae_encode(img[1:2], seed=9, return_moments=True)[1], mom[1:2])
+    assert any(n.startswith("first_stage_model.encoder.down.2.downsample.conv.") for n in eng15.tensor_names()) and "first_stage_model.quant_conv.weight" in eng15.tensor_names()
+    with pytest.raises(sd.EngineError, match="multiples of 8"):
+        eng15.vae_encode(img[:, :, :63])
+    # img2img
+    cond = rng.standard_normal((1, 77, 64)).astype(np.float32)
+    uncond = rng.standard_normal((1, 77, 64)).astype(np.float32)
+    init = eng15.vae_encode(rng.random((1, 3, 128, 128)).astype(np.float32), seed=4)[0]
+    steps, strength, cfg, seed = 10, 0.45, 4.0, 21
+    kw = dict(width=128, height=128, steps=steps, cfg=cfg, seed=seed, batch=1, method=sd.EULER)
+    sig = sd.get_sigmas(steps)[steps - int(steps * strength) - 1:]
+    assert len(sig) == 6   # t_enc + 1 = 5 steps (the reference slices from steps - t_enc - 1)
+    x = (init[None] + philox_randn_np(seed, 0, init.size).reshape(init.shape)[None] * sig[0]).astype(np.float32)
+    for i in range(len(sig) - 1):
+        s = np.float32(sig[i])
+        c_in = np.float32(1.0) / np.sqrt(s * s + np.float32(1.0))
+        t = np.array([sd.lib().sd_sigma_to_t(float(s))], dtype=np.float32)
+        ec, eu = eng15.unet_forward(x * c_in, t, cond), eng15.unet_forward(x * c_in, t, uncond)
+        den = (eu + np.float32(cfg) * (ec - eu)) * (-s) + x
+        x = x + (x - den) / s * (sig[i + 1] - s)
+    calls0 = eng15.stats()["unet_calls"]
+    out = eng15.sample_latents(cond, uncond, init_latent=init, strength=strength, **kw)
+    assert eng15.stats()["unet_calls"] - calls0 == 2 * 5
+    assert rel_l2(out, x) < 2e-4
+    np.testing.assert_array_equal(eng15.sample_latents(cond, uncond, init_latent=init, strength=strength, fuse_cfg=True, device_sampler=True, **kw),
+                                  eng15.sample_latents(cond, uncond, init_latent=init, strength=strength, fuse_cfg=True, **kw))
+    # a batch shares the init latent, every image has its own noise; strength 1 keeps the whole ladder; a zero latent at strength 1 is txt2img
+    two = eng15.sample_latents(cond, uncond, init_latent=init, strength=strength, **dict(kw, batch=2, device_batch=2, fuse_cfg=True))
+    np.testing.assert_allclose(two[0], eng15.sample_latents(cond, uncond, init_latent=init, strength=strength, fuse_cfg=True, **kw)[0], rtol=0, atol=1e-5)
+    assert not np.array_equal(two[0], two[1])
+    np.testing.assert_array_equal(eng15.sample_latents(cond, uncond, init_latent=np.zeros_like(init), strength=1.0, **kw), eng15.sample_latents(cond, uncond, **kw))
+    img8 = eng15.generate_image(cond, uncond, init_latent=init, strength=0.3, **kw)
+    assert img8.shape == (1, 128, 128, 3)
+
+
 def _taesd_decode_torch(e, z):
     """Independent fp32 restatement of TAESD's TinyDecoder (the published taesd.py layout the reference follows, src/model/vae/tae.hpp:123-183) on the engine's weights:
     clamp-by-tanh, conv + ReLU, 3 x [3 residual blocks, nearest x2, bias-free conv], block, conv to RGB.  Conv operands rounded to f16 like the graph's im2col + MUL_MAT."""
@@ -275,6 +326,31 @@ def test_more_samplers_on_the_flow_families(sd, oracle, eng35):
         for b in keys[i + 1:]:
             same = np.array_equal(outs[a], outs[b])
             assert same == ((a, b) in {(sd.EULER, sd.EULER_A)} and False), (a, b)
+
+
+def test_img2img_on_the_flow_family(sd, oracle, eng35):
+    """img2img on a flow denoiser (SD3.5 tiny): DiscreteFlowDenoiser::noise_scaling is latent * (1 - sigma) + noise * sigma (denoiser.hpp:1274-1279); one Euler step from
+    the sliced ladder restated in numpy; the device-resident sampler gives the host loop's bits; the 16-channel encoder feeds it."""
+    from test_host_logic import philox_randn_np
+    rng = np.random.default_rng(37)
+    cond = rng.standard_normal((1, 40, 96)).astype(np.float32)
+    y = rng.standard_normal((1, 64)).astype(np.float32)
+    init = eng35.vae_encode(rng.random((1, 3, 64, 64)).astype(np.float32), seed=2)[0]
+    assert init.shape == (16, 8, 8)
+    steps, strength, seed = 8, 0.2, 6            # t_enc = 1 -> the last three sigmas, two steps
+    kw = dict(width=64, height=64, steps=steps, cfg=1.0, seed=seed, batch=1, cond_y=y, method=sd.EULER, init_latent=init, strength=strength)
+    sig = sd.get_sigmas_sched(1, sd.SCHED_DISCRETE, steps)[steps - int(steps * strength) - 1:]
+    assert len(sig) == 3
+    s0 = np.float32(sig[0])
+    x = (init[None] * (np.float32(1.0) - s0) + philox_randn_np(seed, 0, init.size).reshape(init.shape)[None] * s0).astype(np.float32)
+    for i in range(2):
+        s = np.float32(sig[i])
+        t = np.array([s * np.float32(1000.0)], dtype=np.float32)
+        den = eng35.unet_forward(x, t, cond, y) * (-s) + x      # flow scalings: c_in 1, c_out -sigma, c_skip 1
+        x = x + (x - den) / s * (sig[i + 1] - s)
+    out = eng35.sample_latents(cond, None, **kw)
+    assert rel_l2(out, x) < 2e-4
+    np.testing.assert_array_equal(eng35.sample_latents(cond, None, device_sampler=True, **kw), out)
 
 
 def test_generate_image_end_to_end(sd, oracle, eng15):

@@ -41,7 +41,7 @@ def inputs_for(sd, name, rng, real=False):
         y = rng.standard_normal((1, adm)).astype(np.float32) if xl else None
         return dict(family="unet", version="sdxl" if xl else "sd1", model=getattr(sd, name), overrides=rg.OVERRIDES.get(name, ""),
                     ref=dict(x=x, t=t, ctx=ctx, y=y), eng=lambda e: e.unet_forward(x, t, ctx, y), out=x.shape)
-    if name.startswith("VAE"):
+    if name.startswith("VAE") and not name.startswith("VAE_ENC"):
         model = {"VAE": sd.SD15_TINY, "VAE_SDXL": sd.SDXL_TINY, "VAE16": sd.SD35_TINY, "VAE_FULL": sd.SD15}[name]
         version = {"VAE": "sd1", "VAE_SDXL": "sdxl", "VAE16": "sd3", "VAE_FULL": "sd1"}[name]
         zc = 16 if name == "VAE16" else 4
@@ -53,6 +53,22 @@ def inputs_for(sd, name, rng, real=False):
         post = lambda v: np.clip((v + np.float32(1.0)) * np.float32(0.5), np.float32(0.0), np.float32(1.0)).astype(np.float32)
         return dict(family="vae", version=version, model=model, overrides="", ref=dict(x=z_graph), eng=lambda e: e.vae_decode(z), out=(1, 3, 96, 80),
                     scale=(1.0 / 32.0) if name == "VAE_SDXL" else None, post=post)
+    if name.startswith("VAE_ENC"):
+        # the encode graph (Encoder::forward + quant_conv, auto_encoder_kl.hpp:276-366, 637-664): the engine's sd_vae_encode feeds x * 2 - 1 (vae.hpp:17-22) and
+        # hands back the moments as they leave the graph; the encoder module is made on first use.  The reference infers only the DECODER's width from the weight
+        # table (auto_encoder_kl.hpp:519-536) — its encoder always has ch = 128 — so these cases run the real-width autoencoders (SD1.5's, SD3.5's 16-channel one)
+        model, version, zc = {"VAE_ENC": (sd.SD15, "sd1", 4), "VAE_ENC_SCALED": (sd.SD15, "sd1", 4), "VAE_ENC16": (sd.SD35_WIDE2, "sd3", 16)}[name]
+        img = rng.random((1, 3, 48, 40)).astype(np.float32)
+        x_graph = (img * np.float32(2.0) - np.float32(1.0)).astype(np.float32)
+        scale = (1.0 / 32.0) if name == "VAE_ENC_SCALED" else None
+
+        def prepare(e):
+            e.vae_encode(np.zeros((1, 3, 8, 8), np.float32))
+            if scale:
+                e.set_vae_conv2d_scale(scale)
+
+        return dict(family="vae_enc", version=version, model=model, overrides="", ref=dict(x=x_graph), eng=lambda e: e.vae_encode(img, return_moments=True)[1],
+                    out=(1, 2 * zc, 6, 5), scale=scale, prepare=prepare)
     if name.startswith("TAE"):
         # TAESD (tae.hpp): the engine makes the module on first use; latents enter unscaled, the graph's output is the image
         model, version, zc = {"TAE": (sd.SD15_TINY, "sd1", 4), "TAE16": (sd.SD35_TINY, "sd3", 16)}[name]
@@ -88,7 +104,7 @@ def compare_descriptions(name, dref, deng):
     return len(nr), len(lr), renamed
 
 
-TINY = ["SD15_TINY", "SDXL_TINY", "VAE", "VAE_SDXL", "VAE16", "SD35_TINY", "SD3M_TINY", "FLUX_TINY", "TAE", "TAE16"]
+TINY = ["SD15_TINY", "SDXL_TINY", "VAE", "VAE_SDXL", "VAE16", "SD35_TINY", "SD3M_TINY", "FLUX_TINY", "TAE", "TAE16", "VAE_ENC", "VAE_ENC_SCALED", "VAE_ENC16"]
 
 
 @pytest.mark.parametrize("flash", [True, False])

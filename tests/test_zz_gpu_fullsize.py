@@ -260,6 +260,26 @@ def test_full_size_vae_decode_vs_oracle(sd, oracle, gpu, lat):
 
 
 @full
+@pytest.mark.parametrize("model_name,px,scale", [("SD15", 512, None), ("SD15", 256, 1.0 / 32.0), ("SD35_WIDE2", 256, None)])
+def test_full_size_vae_encode_vs_oracle(sd, oracle, gpu, model_name, px, scale):
+    """KL-VAE ENCODE at the real width (ch 128; auto_encoder_kl.hpp:276-366, 637-664): 512 x 512 -> the 64 x 64 moments SD1.5's img2img starts from (3x3 convs on 512 x 512 x 128
+    feature maps, the pad + stride-2 downsamples, d = 512 mid attention over 4096 positions), with the Conv2d scale the reference gives SDXL, and the 16-channel encoder."""
+    rng = np.random.default_rng(505)
+    img = rng.random((1, 3, px, px)).astype(np.float32)
+    outs = []
+    for be in (oracle, gpu):
+        e = sd.Engine(model=getattr(sd, model_name), backend=be)
+        if scale:
+            e.vae_encode(np.zeros((1, 3, 8, 8), np.float32))
+            e.set_vae_conv2d_scale(scale)
+        outs.append(e.vae_encode(img, seed=3, return_moments=True))
+    (lat_r, mom_r), (lat_g, mom_g) = outs
+    err = rel_l2(mom_g, mom_r)
+    print(f"full-size VAE encode {model_name} {px}x{px} scale {scale}: moments rel-L2 vs oracle {err:.2e}, latents {rel_l2(lat_g, lat_r):.2e}")
+    assert np.isfinite(mom_g).all() and err < 5e-3 and rel_l2(lat_g, lat_r) < 5e-3
+
+
+@full
 @pytest.mark.parametrize("model_name,lat", [("SD35_WIDE2", 128), ("FLUX_WIDE1", 64)])
 def test_full_size_16_channel_vae_decode_vs_oracle(sd, oracle, gpu, model_name, lat):
     """The 16-channel KL-VAE of the DiT families at full width (ch 128, no post_quant_conv; auto_encoder_kl.hpp:548-556, 589-620, scale / shift factors
