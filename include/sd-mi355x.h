@@ -97,6 +97,9 @@ enum sdm_scheduler_t {
     SDM_BETA_SCHEDULER = 15, SDM_SCHEDULER_COUNT = 16
 };
 
+/* prediction_t of the reference (include/stable-diffusion.h), the two UNet parameterisations: sd_set_prediction */
+enum sdm_prediction_t { SDM_EPS_PRED = 0, SDM_V_PRED = 1 };
+
 typedef struct {
     const char* backend;        /* ggml device name, case-insensitive; NULL -> "MI355X0" (stable-diffusion.h:232) */
     enum sd_model_family_t model;
@@ -114,6 +117,9 @@ typedef struct {
     enum sdm_sample_method_t sample_method;
     int sample_steps;
     float eta;                  /* INFINITY -> 1.0 for Euler-A (stable-diffusion.cpp:4024-4049) */
+    const float* custom_sigmas; /* sd_sample_params_t::custom_sigmas: count > 1 replaces the scheduler's ladder as it is (last value normally 0) */
+    int custom_sigmas_count;
+    float flow_shift;           /* flow families: the time shift of DiscreteFlowDenoiser (set_flow_shift, stable-diffusion.cpp:3106-3115); INFINITY = the default (SD3.x 3.0, FLUX.1-dev 1.15) */
 } sdm_sample_params_t;
 
 /* SDCondition (conditioner.hpp:18-34): c_crossattn [ctx_dim, n_tokens], c_vector [adm] (SDXL) */
@@ -141,6 +147,8 @@ typedef struct {
     const float* init_latent;   /* img2img (stable-diffusion.h init_image, already encoded: sd_vae_encode): diffusion latents [w/8, h/8, C] shared by the batch like the
                                    reference's one init image; the trajectory starts from noise_scaling(sigma_0, noise, init_latent) (denoiser.hpp:1181-1186, 1274-1279);
                                    NULL = txt2img */
+    const float* denoise_mask;  /* inpainting (stable-diffusion.h mask_image, at latent resolution): [w/8, h/8] f32, 1 = repaint, 0 = keep; with init_latent every denoised
+                                   prediction becomes denoised * mask + init_latent * (1 - mask) (stable-diffusion.cpp:2888-2890); NULL = none */
     float strength;             /* with init_latent: < 1 keeps the last t_enc + 2 sigmas of the ladder, t_enc = (int)(steps * strength) (stable-diffusion.cpp:4940-4980); 0.75 default */
 } sdm_img_gen_params_t;
 
@@ -203,6 +211,8 @@ SD_API bool sd_vae_decode(sdm_ctx_t* ctx, const float* latents, int w, int h, in
  * Gaussian with Philox(seed) like the reference (auto_encoder_kl.hpp:750-759) and scaled to the diffusion model's range; moments_out (optional) receives the graph's output
  * [w/8,h/8,2*zc,n] (mean | log-variance).  The encoder ("first_stage_model.encoder. ...", "first_stage_model.quant_conv. ...") is made on first use. */
 SD_API bool sd_vae_encode(sdm_ctx_t* ctx, const float* rgb, int w, int h, int n, uint64_t seed, float* out_latents, float* moments_out);
+/* sd_ctx_params_t::prediction: SDM_V_PRED switches the UNet families to CompVisVDenoiser's scalings (denoiser.hpp:1198-1205) in the host loop and the device-resident sampler */
+SD_API bool sd_set_prediction(sdm_ctx_t* ctx, int prediction);
 /* TAESD, the tiny autoencoder's decoder (src/model/vae/tae.hpp:123-183, 732-792; the reference's `--taesd`): the same latents -> rgb f32 [8w,8h,3,n], NOT clamped (the graph's
  * output is the image; the u8 stage clamps).  The module (parameters "tae.decoder.layers.<i>. ...", 4 latent channels, 16 for the DiT families) is made on first use;
  * sd_load_weights_prefixed(ctx, file, "tae.") loads a taesd checkpoint into it.  sd_use_tae(ctx, true): sdm_generate_image decodes with it instead of the KL-VAE. */

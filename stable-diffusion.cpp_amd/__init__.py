@@ -82,7 +82,7 @@ class SdCtxParams(C.Structure):
 
 class SdSampleParams(C.Structure):
     _fields_ = [("txt_cfg", C.c_float), ("scheduler", C.c_int), ("sample_method", C.c_int),
-                ("sample_steps", C.c_int), ("eta", C.c_float)]
+                ("sample_steps", C.c_int), ("eta", C.c_float), ("custom_sigmas", C.c_void_p), ("custom_sigmas_count", C.c_int), ("flow_shift", C.c_float)]
 
 
 class SdCondition(C.Structure):
@@ -94,7 +94,7 @@ class SdImgGenParams(C.Structure):
     _fields_ = [("cond", SdCondition), ("uncond", SdCondition), ("width", C.c_int), ("height", C.c_int),
                 ("sample_params", SdSampleParams), ("seed", C.c_int64), ("batch_count", C.c_int),
                 ("device_batch", C.c_int), ("decode", C.c_bool), ("fuse_cfg_pair", C.c_bool), ("device_sampler", C.c_bool),
-                ("init_latent", C.c_void_p), ("strength", C.c_float)]
+                ("init_latent", C.c_void_p), ("denoise_mask", C.c_void_p), ("strength", C.c_float)]
 
 
 class SdTokenList(C.Structure):
@@ -656,6 +656,14 @@ class Engine:
             raise EngineError("sd_tae_decode failed: " + L.sd_last_error().decode())
         return out
 
+    def set_prediction(self, prediction: int):
+        """sd_set_prediction: 0 = eps (default), 1 = v-prediction (CompVisVDenoiser's scalings)."""
+        L = lib()
+        L.sd_set_prediction.argtypes = [C.c_void_p, C.c_int]
+        L.sd_set_prediction.restype = C.c_bool
+        if not L.sd_set_prediction(self._ctx, int(prediction)):
+            raise EngineError("sd_set_prediction failed: " + L.sd_last_error().decode())
+
     def use_tae(self, on: bool = True):
         """sd_use_tae: generate_image decodes with TAESD instead of the KL-VAE (the reference's --taesd without --taesd-preview-only)."""
         L = lib()
@@ -665,7 +673,7 @@ class Engine:
             raise EngineError("sd_use_tae failed: " + L.sd_last_error().decode())
 
     def _gen_params(self, cond, uncond, width, height, steps, cfg, seed, batch, device_batch, method, eta, cond_y=None, uncond_y=None,
-                    fuse_cfg=False, device_sampler=False, scheduler=SCHEDULER_DEFAULT, init_latent=None, strength=0.75):
+                    fuse_cfg=False, device_sampler=False, scheduler=SCHEDULER_DEFAULT, init_latent=None, strength=0.75, custom_sigmas=None, flow_shift=None, denoise_mask=None):
         p = SdImgGenParams()
         lib().sdm_img_gen_params_init(C.byref(p))
         keep = []
@@ -695,19 +703,32 @@ class Engine:
         p.device_batch = device_batch
         p.fuse_cfg_pair = fuse_cfg
         p.device_sampler = device_sampler
+        if custom_sigmas is not None:
+            cs = _f32(custom_sigmas)
+            keep.append(cs)
+            p.sample_params.custom_sigmas = cs.ctypes.data_as(C.c_void_p)
+            p.sample_params.custom_sigmas_count = cs.size
+        if flow_shift is not None:
+            p.sample_params.flow_shift = flow_shift
         if init_latent is not None:
             il = _f32(init_latent)
             keep.append(il)
             p.init_latent = il.ctypes.data_as(C.c_void_p)
             p.strength = strength
+            if denoise_mask is not None:
+                dm = _f32(denoise_mask)
+                assert dm.shape == il.shape[-2:]
+                keep.append(dm)
+                p.denoise_mask = dm.ctypes.data_as(C.c_void_p)
         return p, keep
 
     def sample_latents(self, cond, uncond=None, width=512, height=512, steps=20, cfg=7.0, seed=42, batch=1, device_batch=0,
                        method=SAMPLE_METHOD_DEFAULT, eta=float("inf"), cond_y=None, uncond_y=None, fuse_cfg=False, device_sampler=False,
-                       scheduler=SCHEDULER_DEFAULT, init_latent=None, strength=0.75) -> np.ndarray:
-        """init_latent [C,h/8,w/8] (+ strength): img2img — the trajectory starts from the noised init latent, (int)(steps * strength) steps before the end of the ladder."""
+                       scheduler=SCHEDULER_DEFAULT, init_latent=None, strength=0.75, custom_sigmas=None, flow_shift=None, denoise_mask=None) -> np.ndarray:
+        """init_latent [C,h/8,w/8] (+ strength): img2img — the trajectory starts from the noised init latent, (int)(steps * strength) steps before the end of the ladder;
+        custom_sigmas: the ladder to use instead of the scheduler's; flow_shift: the flow families' time shift."""
         p, keep = self._gen_params(cond, uncond, width, height, steps, cfg, seed, batch, device_batch, method, eta, cond_y, uncond_y, fuse_cfg,
-                                   device_sampler, scheduler, init_latent, strength)
+                                   device_sampler, scheduler, init_latent, strength, custom_sigmas, flow_shift, denoise_mask)
         ch = 16 if self.model in (SD35_LARGE, SD35_TINY, FLUX_DEV, FLUX_TINY, SD35_WIDE2, FLUX_WIDE1, SD3M_TINY, SD35_WIDE8, FLUX_WIDE8) else 4
         out = np.empty((batch, ch, height // 8, width // 8), dtype=np.float32)
         if not lib().sd_sample_latents(self._ctx, C.byref(p), _fptr(out)):

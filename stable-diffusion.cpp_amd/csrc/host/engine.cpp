@@ -494,9 +494,15 @@ struct sdm_ctx_t {
             flux_denoiser.scalings(sigma, c_skip, c_out, c_in);
         else if (is_dit)
             flow_denoiser.scalings(sigma, c_skip, c_out, c_in);
-        else
+        else if (prediction == SDM_V_PRED) {  // CompVisVDenoiser::get_scalings (denoiser.hpp:1198-1205), sigma_data = 1
+            const float sigma_data = 1.0f;
+            c_skip = sigma_data * sigma_data / (sigma * sigma + sigma_data * sigma_data);
+            c_out  = -sigma * sigma_data / std::sqrt(sigma * sigma + sigma_data * sigma_data);
+            c_in   = 1.0f / std::sqrt(sigma * sigma + sigma_data * sigma_data);
+        } else
             denoiser.scalings(sigma, c_skip, c_out, c_in);
     }
+    int prediction = SDM_EPS_PRED;  // sd_ctx_params_t::prediction (stable-diffusion.h): the UNet families' parameterisation
     float sigma_to_t(float sigma) const { return is_flux ? sigma : (is_dit ? flow_denoiser.sigma_to_t(sigma) : denoiser.sigma_to_t(sigma)); }
     sd_stats_t stats{};
     std::vector<std::pair<std::string, ggml_tensor*>> all_tensors;
@@ -586,6 +592,7 @@ void sdm_sample_params_init(sdm_sample_params_t* p) {  // stable-diffusion.cpp:3
     p->sample_method = SDM_SAMPLE_METHOD_COUNT;  // resolved per family at sampling time (sd_get_default_sample_method)
     p->sample_steps  = 20;
     p->eta           = INFINITY;
+    p->flow_shift    = INFINITY;  // the family's default (stable-diffusion.cpp:3665, 3106-3115)
 }
 void sdm_img_gen_params_init(sdm_img_gen_params_t* p) {  // stable-diffusion.cpp:3710-3731
     memset(p, 0, sizeof(*p));
@@ -1387,6 +1394,20 @@ bool sd_tae_decode(sdm_ctx_t* ctx, const float* latents, int w, int h, int c, in
     return true;
 }
 // the reference decodes with TAESD instead of the KL-VAE when a taesd file is given and it is not for previews only (stable-diffusion.cpp:1496-1516): sdm_generate_image's switch
+// sd_ctx_params_t::prediction (stable-diffusion.h prediction_t; resolved at stable-diffusion.cpp:1760-1790): v-prediction UNets (SD2.x 768-v, v-pred SDXL fine-tunes) use
+// CompVisVDenoiser's scalings; the flow families have one parameterisation each
+bool sd_set_prediction(sdm_ctx_t* ctx, int prediction) {
+    if (prediction != SDM_EPS_PRED && prediction != SDM_V_PRED) {
+        set_error("sd_set_prediction: only SDM_EPS_PRED and SDM_V_PRED are implemented");
+        return false;
+    }
+    if (ctx->is_dit && prediction != SDM_EPS_PRED) {
+        set_error("sd_set_prediction: the flow families (SD3.x, FLUX) have a fixed parameterisation");
+        return false;
+    }
+    ctx->prediction = prediction;
+    return true;
+}
 bool sd_use_tae(sdm_ctx_t* ctx, bool on) {
     if (on && !ensure_tae(ctx)) return false;
     ctx->tae_for_images = on;
@@ -1499,14 +1520,36 @@ struct HostDenoise {
             const float* base = use_cfg ? uncond_out.data() : cond_out.data();
             for (size_t k = 0; k < n; ++k) denoised_uncond[k] = base[k] * c_out + x[k] * c_skip;
         }
+        if (p->denoise_mask && p->init_latent) {  // inpainting: denoised * mask + init_latent * (1 - mask), the mask broadcast over channels and images (stable-diffusion.cpp:2888-2890)
+            const size_t plane = (size_t)W * H;
+            for (int b = 0; b < nb; ++b)
+                for (int c = 0; c < C; ++c) {
+                    float* d        = denoised + (size_t)b * per + (size_t)c * plane;
+                    const float* il = p->init_latent + (size_t)c * plane;
+                    for (size_t k = 0; k < plane; ++k) {
+                        const float m = p->denoise_mask[k];
+                        d[k]          = d[k] * m + il[k] * (1.0f - m);
+                    }
+                }
+        }
         return true;
     }
 };
 // img2img (stable-diffusion.cpp:4924-4980): with an init latent and strength < 1 the trajectory starts t_enc = steps * strength steps before the end of the ladder
-static std::vector<float> call_sigmas(const sdm_ctx_t* ctx, const sdm_img_gen_params_t* p, int image_seq_len, int scheduler) {
-    std::vector<float> sigmas = ctx->get_sigmas(p->sample_params.sample_steps, image_seq_len, scheduler);
+static std::vector<float> call_sigmas(sdm_ctx_t* ctx, const sdm_img_gen_params_t* p, int image_seq_len, int scheduler) {
+    // set_flow_shift (stable-diffusion.cpp:3106-3115): the request's shift, or the family default (SD3.x 3.0, FLUX.1-dev 1.15), on the flow denoisers
+    const float fs = p->sample_params.flow_shift;
+    ctx->flow_denoiser.shift = (std::isfinite(fs) && fs > 0.f) ? fs : 3.0f;
+    ctx->flux_denoiser.shift = (std::isfinite(fs) && fs > 0.f) ? fs : 1.15f;
+    // custom sigmas replace the scheduler's ladder as they are (stable-diffusion.cpp:4337-4349)
+    std::vector<float> sigmas = (p->sample_params.custom_sigmas && p->sample_params.custom_sigmas_count > 1)
+                                    ? std::vector<float>(p->sample_params.custom_sigmas, p->sample_params.custom_sigmas + p->sample_params.custom_sigmas_count)
+                                    : ctx->get_sigmas(p->sample_params.sample_steps, image_seq_len, scheduler);
     if (p->init_latent && p->strength < 1.f && !sigmas.empty()) {
-        const int sample_steps = p->sample_params.sample_steps;
+        // (custom sigmas set sample_steps to their count - 1 first, stable-diffusion.cpp:4337-4345; a scheduler that returned fewer sigmas than steps + 1 — beta — likewise here)
+        const int sample_steps = std::min(p->sample_params.sample_steps, (int)sigmas.size() - 1) < p->sample_params.sample_steps || p->sample_params.custom_sigmas_count > 1
+                                     ? (int)sigmas.size() - 1
+                                     : p->sample_params.sample_steps;
         size_t t_enc           = static_cast<size_t>(sample_steps * p->strength);
         if (t_enc == static_cast<size_t>(sample_steps)) t_enc--;
         const int64_t first = (int64_t)sample_steps - (int64_t)t_enc - 1;
@@ -1631,6 +1674,7 @@ static bool sample_group_device(sdm_ctx_t* ctx, const sdm_img_gen_params_t* p, i
         return false;
     }
     if (method != SDM_EULER_SAMPLE_METHOD && method != SDM_EULER_A_SAMPLE_METHOD) return true;  // multi-stage / multi-step samplers: the host loop around the device forward
+    if (p->denoise_mask && p->init_latent) return true;  // the inpainting blend lives in the host loop's denoise call
     *handled = true;
     const size_t per = (size_t)W * H * C;
     const std::vector<float> sigmas = call_sigmas(ctx, p, W * H, scheduler);

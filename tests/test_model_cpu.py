@@ -353,6 +353,85 @@ def test_img2img_on_the_flow_family(sd, oracle, eng35):
     np.testing.assert_array_equal(eng35.sample_latents(cond, None, device_sampler=True, **kw), out)
 
 
+def test_custom_sigmas_flow_shift_and_v_prediction(sd, oracle, eng15, eng35):
+    """The remaining knobs of sd_sample_params_t / sd_ctx_params_t on the denoise path: custom_sigmas replace the scheduler's ladder as they are; flow_shift is the flow
+    denoiser's time shift (set_flow_shift, stable-diffusion.cpp:3106-3115); prediction = V switches the UNet families to CompVisVDenoiser's scalings
+    (denoiser.hpp:1198-1205) on the host loop and the device-resident sampler alike."""
+    from test_host_logic import philox_randn_np
+    rng = np.random.default_rng(47)
+    cond = rng.standard_normal((1, 77, 64)).astype(np.float32)
+    uncond = rng.standard_normal((1, 77, 64)).astype(np.float32)
+    kw = dict(width=64, height=64, steps=5, cfg=3.0, seed=13, batch=1)
+    karras = sd.get_sigmas_sched(0, sd.SCHED_KARRAS, 5)
+    np.testing.assert_array_equal(eng15.sample_latents(cond, uncond, custom_sigmas=karras, **kw), eng15.sample_latents(cond, uncond, scheduler=sd.SCHED_KARRAS, **kw))
+    short = eng15.sample_latents(cond, uncond, custom_sigmas=karras[2:], **kw)              # 3 steps whatever `steps` says
+    calls0 = eng15.stats()["unet_calls"]
+    np.testing.assert_array_equal(eng15.sample_latents(cond, uncond, custom_sigmas=karras[2:], **dict(kw, steps=20)), short)
+    assert eng15.stats()["unet_calls"] - calls0 == 2 * 3
+    # flow shift
+    c35 = rng.standard_normal((1, 40, 96)).astype(np.float32)
+    y = rng.standard_normal((1, 64)).astype(np.float32)
+    k35 = dict(width=64, height=64, steps=4, cfg=1.0, seed=5, batch=1, cond_y=y)
+    base = eng35.sample_latents(c35, None, **k35)
+    np.testing.assert_array_equal(eng35.sample_latents(c35, None, flow_shift=3.0, **k35), base)
+    shifted = eng35.sample_latents(c35, None, flow_shift=1.7, **k35)
+    np.testing.assert_array_equal(shifted, eng35.sample_latents(c35, None, custom_sigmas=sd.get_sigmas_sched(1, sd.SCHED_DISCRETE, 4, shift=1.7), **k35))
+    assert not np.array_equal(shifted, base)
+    np.testing.assert_array_equal(eng35.sample_latents(c35, None, **k35), base)            # the default is back without the field
+    # v-prediction
+    e = sd.Engine(model=sd.SD15_TINY, backend=oracle)
+    eps_out = e.sample_latents(cond, uncond, method=sd.EULER, **kw)
+    e.set_prediction(1)
+    sig = sd.get_sigmas(5)
+    x = (philox_randn_np(13, 0, 4 * 8 * 8) * sig[0]).astype(np.float32).reshape(1, 4, 8, 8)
+    for i in range(5):
+        s = np.float32(sig[i])
+        den_ = s * s + np.float32(1.0)
+        c_skip, c_out, c_in = np.float32(1.0) / den_, -s / np.sqrt(den_), np.float32(1.0) / np.sqrt(den_)
+        t = np.array([sd.lib().sd_sigma_to_t(float(s))], dtype=np.float32)
+        ec, eu = e.unet_forward(x * c_in, t, cond), e.unet_forward(x * c_in, t, uncond)
+        den = (eu + np.float32(3.0) * (ec - eu)) * c_out + x * c_skip
+        x = x + (x - den) / s * (sig[i + 1] - s)
+    v_out = e.sample_latents(cond, uncond, method=sd.EULER, **kw)
+    assert rel_l2(v_out, x) < 2e-4 and not np.array_equal(v_out, eps_out)
+    np.testing.assert_array_equal(e.sample_latents(cond, uncond, method=sd.EULER, fuse_cfg=True, device_sampler=True, **kw), e.sample_latents(cond, uncond, method=sd.EULER, fuse_cfg=True, **kw))
+    e.set_prediction(0)
+    np.testing.assert_array_equal(e.sample_latents(cond, uncond, method=sd.EULER, **kw), eps_out)
+    with pytest.raises(sd.EngineError):
+        e.set_prediction(2)
+    with pytest.raises(sd.EngineError, match="flow"):
+        eng35.set_prediction(1)
+
+
+def test_inpainting_denoise_mask(sd, oracle, eng15):
+    """denoise_mask (the reference's mask_image at latent resolution): every denoised prediction becomes denoised * mask + init_latent * (1 - mask)
+    (stable-diffusion.cpp:2888-2890).  With plain Euler the last step lands on the blended prediction: kept pixels come back as the init latent exactly (to rounding), the
+    repainted ones differ; an all-ones mask is img2img; the device-sampler flag falls back to the host loop; numpy restatement of the whole trajectory."""
+    from test_host_logic import philox_randn_np
+    rng = np.random.default_rng(53)
+    cond = rng.standard_normal((1, 77, 64)).astype(np.float32)
+    init = rng.standard_normal((4, 8, 8)).astype(np.float32)
+    mask = np.zeros((8, 8), np.float32)
+    mask[2:6, 3:7] = 1.0
+    mask[0, 0] = 0.5
+    kw = dict(width=64, height=64, steps=6, cfg=1.0, seed=3, batch=1, method=sd.EULER, init_latent=init, strength=0.6)
+    out = eng15.sample_latents(cond, None, denoise_mask=mask, **kw)[0]
+    keep = mask == 0
+    assert np.abs(out[:, keep] - init[:, keep]).max() < 1e-5 and np.abs(out[:, mask == 1] - init[:, mask == 1]).max() > 1e-2
+    np.testing.assert_array_equal(eng15.sample_latents(cond, None, denoise_mask=np.ones_like(mask), **kw), eng15.sample_latents(cond, None, **kw))
+    np.testing.assert_array_equal(eng15.sample_latents(cond, None, denoise_mask=mask, device_sampler=True, **kw)[0], out)
+    sig = sd.get_sigmas(6)[6 - int(6 * 0.6) - 1:]
+    x = (init[None] + philox_randn_np(3, 0, init.size).reshape(init.shape)[None] * sig[0]).astype(np.float32)
+    for i in range(len(sig) - 1):
+        s = np.float32(sig[i])
+        c_in = np.float32(1.0) / np.sqrt(s * s + np.float32(1.0))
+        t = np.array([sd.lib().sd_sigma_to_t(float(s))], dtype=np.float32)
+        den = eng15.unet_forward(x * c_in, t, cond) * (-s) + x
+        den = den * mask + init[None] * (np.float32(1.0) - mask)
+        x = x + (x - den) / s * (sig[i + 1] - s)
+    assert rel_l2(out, x[0]) < 2e-4
+
+
 def test_generate_image_end_to_end(sd, oracle, eng15):
     rng = np.random.default_rng(5)
     cond = rng.standard_normal((1, 77, 64)).astype(np.float32)

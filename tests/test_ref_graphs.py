@@ -110,6 +110,8 @@ TINY = ["SD15_TINY", "SDXL_TINY", "VAE", "VAE_SDXL", "VAE16", "SD35_TINY", "SD3M
 @pytest.mark.parametrize("flash", [True, False])
 @pytest.mark.parametrize("name", TINY)
 def test_reference_emitted_graph_equals_engine_graph_node_for_node(sd, oracle, name, flash):
+    if name in ("VAE_ENC_SCALED", "VAE_ENC16") and not flash:
+        pytest.skip("real-width engines (seconds of weight initialisation each): the manual-attention variant of the encode graph is covered by VAE_ENC")
     c = inputs_for(sd, name, np.random.default_rng(5))
     e = sd.Engine(model=c["model"], backend=oracle, flash_attn=flash)
     c.get("prepare", lambda e_: None)(e)
@@ -165,6 +167,8 @@ def test_reference_emitted_graph_equals_engine_graph_at_the_benchmarked_widths(s
 
 @pytest.mark.parametrize("name", TINY)
 def test_reference_runner_computes_the_engine_result_bit_for_bit_on_the_oracle(sd, oracle, name):
+    if name == "VAE_ENC_SCALED":
+        pytest.skip("real-width engine: the scaled encode graph is compared node for node above and computed on the GPU (tests/test_gpu_ref_graphs.py)")
     c = inputs_for(sd, name, np.random.default_rng(7))
     e = sd.Engine(model=c["model"], backend=oracle, flash_attn=True)
     c.get("prepare", lambda e_: None)(e)
