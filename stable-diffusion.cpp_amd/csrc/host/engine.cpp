@@ -744,6 +744,8 @@ bool sd_set_tensor_f32(sdm_ctx_t* ctx, const char* name, const float* src, int64
 // file dtype -> f32 -> the parameter's ggml type (convert_tensor, model_loader.cpp:155-205) and ggml_backend_tensor_set it.
 // Returns the number of parameters loaded, or -1 on a file / shape error; tensors the file does not name keep their current values.
 static bool ensure_text_encoders(sdm_ctx_t* ctx);
+static bool ensure_vae_encoder(sdm_ctx_t* ctx);
+static bool ensure_tae(sdm_ctx_t* ctx);
 
 static NameDialect name_dialect(const sdm_ctx_t* ctx) {
     NameDialect d;
@@ -783,11 +785,13 @@ int64_t sd_load_weights_prefixed(sdm_ctx_t* ctx, const char* path, const char* p
     const NameDialect dialect = name_dialect(ctx);
     std::vector<FileTensor> expanded;
     expanded.reserve(mf.tensors.size());
-    bool names_te = false;
+    bool names_te = false, names_enc = false, names_tae = false;
     for (const FileTensor& t : mf.tensors) {
         FileTensor c = t;
         c.name       = canonical_tensor_name(prefix ? std::string(prefix) + t.name : t.name, dialect);
         names_te     = names_te || c.name.rfind("cond_stage_model.", 0) == 0 || c.name.rfind("text_encoders.", 0) == 0;
+        names_enc    = names_enc || c.name.rfind("first_stage_model.encoder.", 0) == 0;
+        names_tae    = names_tae || c.name.rfind("tae.decoder.layers.", 0) == 0;
         const std::vector<std::string> qkv = split_in_proj_names(c.name);
         const int outer                    = c.n_dims >= 2 ? 1 : 0;  // the fused dimension: rows of the weight, elements of the bias
         if (!qkv.empty() && c.ne[outer] % 3 == 0 && (outer == 1 || !ggml_is_quantized(c.type))) {
@@ -808,6 +812,9 @@ int64_t sd_load_weights_prefixed(sdm_ctx_t* ctx, const char* path, const char* p
     std::map<std::string, std::string> undecodable;  // canonical name -> dtype the readers could not decode
     for (auto& kv : mf.undecodable) undecodable[canonical_tensor_name(prefix ? std::string(prefix) + kv.first : kv.first, dialect)] = kv.second;
     if (names_te && !ensure_text_encoders(ctx)) return -1;  // like the conditioners' tensor_storage_map probes (conditioner.hpp:630-651)
+    // a checkpoint that carries the VAE encoder / a taesd file: the modules made on first use are made now, so their tensors are loaded instead of reported unused
+    if (names_enc && !ensure_vae_encoder(ctx)) return -1;
+    if (names_tae && !ensure_tae(ctx)) return -1;
     FILE* f = fopen(path, "rb");
     if (!f) {
         set_error(std::string("cannot open ") + path);

@@ -110,6 +110,38 @@ def test_safetensors_load_converts_and_runs(sd, oracle, tmp_path):
     assert np.abs(e2.unet_forward(x, np.array([100.0], np.float32), ctx) - y1).max() > 1e-3
 
 
+def test_taesd_file_and_vae_encoder_tensors_make_their_modules(sd, oracle, tmp_path):
+    """A taesd checkpoint (names "decoder.layers.<i>. ...", loaded under the prefix "tae." like the reference's --taesd, stable-diffusion.cpp:798-803) and a VAE file that
+    carries the encoder: the modules the engine makes on first use are made by the load, their tensors are filled (not reported unused) and the graphs use them."""
+    e = sd.Engine(model=sd.SD15_TINY, backend=oracle)
+    probe = sd.Engine(model=sd.SD15_TINY, backend=oracle)
+    probe.use_tae(True)
+    probe.vae_encode(np.zeros((1, 3, 8, 8), np.float32))
+    rng = np.random.default_rng(4)
+    tae, enc = {}, {}
+    for n in _names(probe):
+        if not (n.startswith("tae.") or n.startswith("first_stage_model.encoder.") or n.startswith("first_stage_model.quant_conv.")):
+            continue
+        ne, ty, _ = probe.tensor_info(n)
+        shape = tuple(int(d) for d in reversed(ne))
+        while len(shape) > 1 and shape[0] == 1:
+            shape = shape[1:]
+        a = (rng.standard_normal(shape) * 0.05).astype(np.float16)
+        (tae if n.startswith("tae.") else enc)[n[4:] if n.startswith("tae.") else n] = ("F16", a)
+    assert not any(n.startswith("tae.") or ".encoder." in n for n in _names(e))
+    _write_safetensors(tmp_path / "taesd.safetensors", tae)
+    _write_safetensors(tmp_path / "vae_enc.safetensors", enc)
+    r = e.load_weights(tmp_path / "taesd.safetensors", prefix="tae.")
+    assert r["loaded"] == len(tae) and r["unused"] == 0
+    r = e.load_weights(tmp_path / "vae_enc.safetensors")
+    assert r["loaded"] == len(enc) and r["unused"] == 0
+    np.testing.assert_array_equal(e.get_tensor("tae.decoder.layers.0.weight").ravel(), tae["decoder.layers.0.weight"][1].astype(np.float32).ravel())
+    z = rng.standard_normal((1, 4, 4, 4)).astype(np.float32)
+    assert np.abs(e.tae_decode(z) - probe.tae_decode(z)).max() > 1e-4
+    img = rng.random((1, 3, 16, 16)).astype(np.float32)
+    assert np.abs(e.vae_encode(img, return_moments=True)[1] - probe.vae_encode(img, return_moments=True)[1]).max() > 1e-4
+
+
 def test_gguf_load_f16_f32_q8_0(sd, oracle, tmp_path):
     e = sd.Engine(model=sd.SD15_TINY, backend=oracle, wtype=sd.Q8_0)
     rng = np.random.default_rng(4)
