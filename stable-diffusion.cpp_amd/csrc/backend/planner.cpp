@@ -167,7 +167,7 @@ struct Stats {
 } g_stats;
 
 struct Options {
-    std::atomic<int> fusion{1}, mfma_gemm{1}, hip_graph{1}, flash_pattern{1}, gemm16{1}, fuse_modulate{1}, fuse_gate{1}, fuse_gelu{1}, fuse_rope{1}, fuse_concat_heads{1}, qgemv{1}, fuse_chan_add{1}, fuse_proj_tokens{1}, fuse_q16{1}, qgemm16{1}, fgemv{1}, fuse_siblings{1}, hoist_kv{1}, hoist_emb{1}, fuse_rows16{0}, fuse_cat_rows16{1}, fuse_joint_qkv{1}, jit_qimages{4096}, fuse_gn_stats{1}, fuse_ln_reduce{1}, relax_res_overlap{1}, fuse_split_gelu{1}, fuse_concat_gn{1}, fuse_gn_tokens{1}, fuse_linear_nchw{1}, fuse_conv_scale{1}, ignore_use_counts{0}, plan_cache_cap{512}, hoist_mod{1}, jit_overlap{0}, fuse_flash_slices{1};
+    std::atomic<int> fusion{1}, mfma_gemm{1}, hip_graph{1}, flash_pattern{1}, gemm16{1}, fuse_modulate{1}, fuse_gate{1}, fuse_gelu{1}, fuse_rope{1}, fuse_concat_heads{1}, qgemv{1}, fuse_chan_add{1}, fuse_proj_tokens{1}, fuse_q16{1}, qgemm16{1}, fgemv{1}, fuse_siblings{1}, hoist_kv{1}, hoist_emb{1}, fuse_rows16{0}, fuse_cat_rows16{1}, fuse_joint_qkv{1}, jit_qimages{4096}, fuse_gn_stats{1}, fuse_ln_reduce{1}, relax_res_overlap{1}, fuse_split_gelu{1}, fuse_concat_gn{1}, fuse_gn_tokens{1}, fuse_linear_nchw{1}, fuse_conv_scale{1}, ignore_use_counts{0}, plan_cache_cap{512}, hoist_mod{1}, jit_overlap{0}, fuse_flash_slices{1}, fuse_act_pack{1};
 } g_opt;
 
 // One launch (or a few) of a plan.  tag 2 marks the just-in-time weight-image rebuild of a quantised Linear (k_wswz_q, option jit_qimages): build_plan's
@@ -2802,6 +2802,19 @@ bool plan_single(Builder& B, int i, hipStream_t s) {
             const int64_t nel = ggml_abi_nelements(n);
             float* dst        = (float*)n->data;
             const float* src  = (const float*)n->src[0]->data;
+            // ReLU / SiLU read ONLY by implicit-GEMM convs (TAESD's conv -> ReLU -> conv chains, tae.hpp:15-76; option fuse_act_pack): the activation is applied while
+            // the convs' f16 NHWC operand image is written — no unary launch, the (in-place) f32 result is never written
+            float conv_mul = 1.f;
+            if (g_opt.fuse_act_pack && (u == UN_RELU || u == UN_SILU) && is_f32(n) && contig(n) && is_f32(n->src[0]) && contig(n->src[0]) && n->ne[2] >= 1 &&
+                all_consumers_gemm16(gi, i, true, &conv_mul)) {
+                Planner* P       = B.P;
+                const int64_t hw = n->ne[0] * n->ne[1], C = n->ne[2], N = n->ne[3];
+                const size_t off = B.alloc((size_t)N * hw * rup64(C) * 2);
+                const int act    = u == UN_SILU ? 1 : 2;
+                B.emit([=](hipStream_t st) { launch_nchw_to_nhwc_f16(st, P->arena + off, src, hw, C, N, nullptr, nullptr, act, nullptr, 0, nullptr, conv_mul); });
+                B.packed[n] = Packed{off, rup64(C), true, conv_mul};
+                return true;
+            }
             B.emit([=](hipStream_t st) { launch_unary(st, u, dst, src, nel); });
             return true;
         }
@@ -4211,6 +4224,7 @@ void planner_set_option(const char* key, int value) {
     else if (!strcmp(key, "fuse_linear_nchw")) g_opt.fuse_linear_nchw = value;
     else if (!strcmp(key, "fuse_conv_scale")) g_opt.fuse_conv_scale = value;
     else if (!strcmp(key, "jit_overlap")) g_opt.jit_overlap = value;  // just-in-time weight images rebuilt one Linear ahead on the side stream (overlap_jit_steps)
+    else if (!strcmp(key, "fuse_act_pack")) g_opt.fuse_act_pack = value;  // ReLU / SiLU read only by convs: applied while their operand image is packed
     else if (!strcmp(key, "hoist_mod")) g_opt.hoist_mod = value;  // DiT modulation Linears (same one / two rows, raw q8_0 / q4_0 weights) as one grouped weight-streaming launch
     else if (!strcmp(key, "plan_cache_cap")) g_opt.plan_cache_cap = value;  // plans (and captured hipGraphs) kept per backend instance, LRU beyond that (default 512)
     else if (!strcmp(key, "ignore_use_counts")) g_opt.ignore_use_counts = value;  // test hook: a host whose sub-graph views carry no use_counts table

@@ -2609,7 +2609,8 @@ __global__ __launch_bounds__(256) void k_nchw_to_nhwc_f16(_Float16* __restrict__
         if (c < C && p < hw) {
             v = xn[(int64_t)c * hw + p];
             if (scale) v = v * scale[(int64_t)n * C + c] + shift[(int64_t)n * C + c];
-            if (silu) v = act_apply<UN_SILU>(v);
+            if (silu == 1) v = act_apply<UN_SILU>(v);
+            else if (silu == 2) v = act_apply<UN_RELU>(v);
             v *= post_mul;
         }
         tile[j][tx] = v;
@@ -2667,9 +2668,12 @@ __global__ __launch_bounds__(256) void k_nchw_to_nhwc_f16_v4(_Float16* __restric
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float u = a[i], v = bq[i];
-            if (silu) {
+            if (silu == 1) {
                 u = act_apply<UN_SILU>(u);
                 v = act_apply<UN_SILU>(v);
+            } else if (silu == 2) {  // ReLU in front of a conv (TAESD, tae.hpp:15-76)
+                u = act_apply<UN_RELU>(u);
+                v = act_apply<UN_RELU>(v);
             }
             u *= post_mul;  // Conv2d scale (ggml_ext_conv_2d: x = scale(x, s) before the f16 im2col) folded into the operand image
             v *= post_mul;
@@ -2706,7 +2710,7 @@ __global__ __launch_bounds__(256) void k_nchw_to_nhwc_f16_v4(_Float16* __restric
 }
 // x2 != nullptr: the source is the channel concatenation [x (C1 channels) | x2 (C - C1)] (both NCHW, never materialised);  dst_raw != nullptr: a second
 // image of the same values without affine / SiLU (one read of the sources for the GroupNorm'ed conv operand AND the skip 1x1 conv's operand)
-void launch_nchw_to_nhwc_f16(hipStream_t s, void* dst, const float* x, int64_t hw, int64_t C, int64_t N, const float* scale, const float* shift, bool silu,
+void launch_nchw_to_nhwc_f16(hipStream_t s, void* dst, const float* x, int64_t hw, int64_t C, int64_t N, const float* scale, const float* shift, int silu,
                              const float* x2, int64_t C1, void* dst_raw, float post_mul) {
     KScope ks_(s, KF_NCHW_NHWC, 0.0, (double)hw * C * N * 4.0 + (double)hw * rup64(C, 64) * N * 2.0 * (dst_raw ? 2.0 : 1.0));
     const int Cp = (int)rup64(C, 64);
@@ -2717,9 +2721,9 @@ void launch_nchw_to_nhwc_f16(hipStream_t s, void* dst, const float* x, int64_t h
         abort();
     }
     if (v4)
-        k_nchw_to_nhwc_f16_v4<<<grid, 256, 0, s>>>((_Float16*)dst, x, hw, (int)C, Cp, scale, shift, silu ? 1 : 0, x2, (int)C1, (_Float16*)dst_raw, post_mul);
+        k_nchw_to_nhwc_f16_v4<<<grid, 256, 0, s>>>((_Float16*)dst, x, hw, (int)C, Cp, scale, shift, silu, x2, (int)C1, (_Float16*)dst_raw, post_mul);
     else
-        k_nchw_to_nhwc_f16<<<grid, 256, 0, s>>>((_Float16*)dst, x, hw, (int)C, Cp, scale, shift, silu ? 1 : 0, post_mul);
+        k_nchw_to_nhwc_f16<<<grid, 256, 0, s>>>((_Float16*)dst, x, hw, (int)C, Cp, scale, shift, silu, post_mul);
 }
 
 }  // namespace mi355x

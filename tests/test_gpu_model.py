@@ -126,6 +126,32 @@ def test_vae_encode_and_img2img_parity(sd, oracle, gpu, model_name, hw, n):
     assert np.isfinite(tr_g).all() and rel_l2(tr_g, tr_r) < 2e-2
 
 
+def test_activation_folded_into_the_conv_operand_image(sd, oracle, gpu):
+    """conv -> ReLU -> conv (TAESD's blocks): a ReLU read only by convs is applied while their f16 NHWC operand image is written (option fuse_act_pack) — 20 unary
+    launches fewer per decode, the in-place f32 result never written, bit-identical to the unfused plan."""
+    if gpu == oracle:
+        pytest.skip("planner behaviour of the MI355X backend")
+    rng = np.random.default_rng(27)
+    z = (rng.standard_normal((2, 4, 24, 20)) * 1.5).astype(np.float32)
+    e = sd.Engine(model=sd.SD15_TINY, backend=gpu)
+
+    def run():
+        s0 = sd.backend_stats()
+        out = e.tae_decode(z)
+        s1 = sd.backend_stats()
+        return out, s1["kernels_planned"] - s0["kernels_planned"]
+
+    try:
+        sd.backend_set_option("fuse_act_pack", 0)
+        plain, k_plain = run()
+    finally:
+        sd.backend_set_option("fuse_act_pack", 1)
+    fused, k_fused = run()
+    print(f"TAESD decode: {k_plain} kernels unfused, {k_fused} with the activation folded into the operand image")
+    np.testing.assert_array_equal(fused, plain)
+    assert k_plain - k_fused > 0
+
+
 def test_sampler_trajectory_parity(sd, oracle, gpu):
     """4-step Euler-A with CFG 7, two images in one device batch vs the oracle's independent batch-1 runs."""
     rng = np.random.default_rng(9)
