@@ -2815,6 +2815,27 @@ bool plan_single(Builder& B, int i, hipStream_t s) {
                 B.packed[n] = Packed{off, rup64(C), true, conv_mul};
                 return true;
             }
+            // ... and read by convs AND others (a TAESD block's output: the next block's first conv and its residual ADD): one pass writes the f32 result (in place)
+            // and the convs' operand image — the separate pack pass's second read of the tensor disappears
+            if (g_opt.fuse_act_pack && (u == UN_RELU || u == UN_SILU) && is_f32(n) && contig(n) && is_f32(n->src[0]) && contig(n->src[0]) && n->ne[3] >= 1 && !gi.consumers[i].empty() &&
+                g_opt.gemm16 && g_opt.mfma_gemm && g_opt.fusion) {
+                bool conv_reader = false, scaled = false;
+                for (int c : gi.consumers[i]) {
+                    const ggml_tensor* cn = gi.node(c);
+                    if (xop(cn) == GGML_OP_IM2COL && cn->src[1] == n && conv_im2col_fast_ok(gi, c)) conv_reader = true;
+                    float sc = 1.f;
+                    if (cn->src[0] == n && scale_into_conv(gi, c, &sc)) scaled = true;  // (a Conv2d scale in front of a reader: its image carries another factor)
+                }
+                if (conv_reader && !scaled) {
+                    Planner* P       = B.P;
+                    const int64_t hw = n->ne[0] * n->ne[1], C = n->ne[2], N = n->ne[3];
+                    const size_t off = B.alloc((size_t)N * hw * rup64(C) * 2);
+                    const int act    = u == UN_SILU ? 1 : 2;
+                    B.emit([=](hipStream_t st) { launch_nchw_to_nhwc_f16(st, P->arena + off, src, hw, C, N, nullptr, nullptr, act, nullptr, 0, nullptr, 1.f, dst); });
+                    B.packed[n] = Packed{off, rup64(C), true, 1.f};
+                    return true;
+                }
+            }
             B.emit([=](hipStream_t st) { launch_unary(st, u, dst, src, nel); });
             return true;
         }

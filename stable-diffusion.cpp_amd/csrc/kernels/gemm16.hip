@@ -2597,7 +2597,7 @@ void launch_gn_stats(hipStream_t s, float* scale, float* shift, const float* x, 
 // f32 NCHW [hw][C][N] -> f16 NHWC [N][hw][Cp] with optional per-(n,c) affine (GroupNorm apply) and SiLU.
 // 64 channels x 64 positions per workgroup through an LDS transpose: coalesced 256-B reads along hw, 128-B writes along c.
 __global__ __launch_bounds__(256) void k_nchw_to_nhwc_f16(_Float16* __restrict__ dst, const float* __restrict__ x, int64_t hw, int C, int Cp,
-                                                          const float* __restrict__ scale, const float* __restrict__ shift, int silu, float post_mul) {
+                                                          const float* __restrict__ scale, const float* __restrict__ shift, int silu, float post_mul, float* dst_f32) {
     __shared__ float tile[64][65];
     const int n  = blockIdx.z;
     const int p0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
@@ -2611,6 +2611,7 @@ __global__ __launch_bounds__(256) void k_nchw_to_nhwc_f16(_Float16* __restrict__
             if (scale) v = v * scale[(int64_t)n * C + c] + shift[(int64_t)n * C + c];
             if (silu == 1) v = act_apply<UN_SILU>(v);
             else if (silu == 2) v = act_apply<UN_RELU>(v);
+            if (dst_f32) dst_f32[((int64_t)n * C + c) * hw + p] = v;  // (x may alias dst_f32: every element is read and written by the same thread)
             v *= post_mul;
         }
         tile[j][tx] = v;
@@ -2628,7 +2629,7 @@ __global__ __launch_bounds__(256) void k_nchw_to_nhwc_f16(_Float16* __restrict__
 __global__ __launch_bounds__(256) void k_nchw_to_nhwc_f16_v4(_Float16* __restrict__ dst, const float* __restrict__ x, int64_t hw, int C, int Cp,
                                                              const float* __restrict__ scale, const float* __restrict__ shift, int silu,
                                                              const float* __restrict__ x2 = nullptr, int C1 = 0, _Float16* __restrict__ dst_raw = nullptr,
-                                                             float post_mul = 1.f) {
+                                                             float post_mul = 1.f, float* dst_f32 = nullptr) {
     __shared__ uint32_t tile[64][33];  // [position][channel pair] half2
     __shared__ uint32_t tile_raw[64][33];  // dst_raw != nullptr: the same values WITHOUT affine / SiLU (the image the skip 1x1 conv reads)
     const int n  = blockIdx.z;
@@ -2675,12 +2676,17 @@ __global__ __launch_bounds__(256) void k_nchw_to_nhwc_f16_v4(_Float16* __restric
                 u = act_apply<UN_RELU>(u);
                 v = act_apply<UN_RELU>(v);
             }
+            a[i] = u, bq[i] = v;  // (kept for the f32 write-back below)
             u *= post_mul;  // Conv2d scale (ggml_ext_conv_2d: x = scale(x, s) before the f16 im2col) folded into the operand image
             v *= post_mul;
             if (c >= C) u = 0.f;       // padded channels of the operand image are zeros
             if (c + 1 >= C) v = 0.f;
             const _Float16 hu = (_Float16)u, hv = (_Float16)v;
             tile[pq + i][cp] = (uint32_t)__builtin_bit_cast(uint16_t, hu) | ((uint32_t)__builtin_bit_cast(uint16_t, hv) << 16);
+        }
+        if (dst_f32 && p < hw) {  // the activated values as f32 NCHW too (in place over x: this thread read exactly these eight floats)
+            if (c < C) *(float4*)(dst_f32 + ((int64_t)n * C + c) * hw + p) = make_float4(a[0], a[1], a[2], a[3]);
+            if (c + 1 < C) *(float4*)(dst_f32 + ((int64_t)n * C + c + 1) * hw + p) = make_float4(bq[0], bq[1], bq[2], bq[3]);
         }
     }
     __syncthreads();
@@ -2711,19 +2717,23 @@ __global__ __launch_bounds__(256) void k_nchw_to_nhwc_f16_v4(_Float16* __restric
 // x2 != nullptr: the source is the channel concatenation [x (C1 channels) | x2 (C - C1)] (both NCHW, never materialised);  dst_raw != nullptr: a second
 // image of the same values without affine / SiLU (one read of the sources for the GroupNorm'ed conv operand AND the skip 1x1 conv's operand)
 void launch_nchw_to_nhwc_f16(hipStream_t s, void* dst, const float* x, int64_t hw, int64_t C, int64_t N, const float* scale, const float* shift, int silu,
-                             const float* x2, int64_t C1, void* dst_raw, float post_mul) {
-    KScope ks_(s, KF_NCHW_NHWC, 0.0, (double)hw * C * N * 4.0 + (double)hw * rup64(C, 64) * N * 2.0 * (dst_raw ? 2.0 : 1.0));
+                             const float* x2, int64_t C1, void* dst_raw, float post_mul, float* dst_f32) {
+    KScope ks_(s, KF_NCHW_NHWC, 0.0, (double)hw * C * N * 4.0 * (dst_f32 ? 2.0 : 1.0) + (double)hw * rup64(C, 64) * N * 2.0 * (dst_raw ? 2.0 : 1.0));
+    if (dst_f32 && x2) {
+        fprintf(stderr, "ggml-mi355x: NCHW -> NHWC pass with an f32 write-back takes one source\n");
+        abort();
+    }
     const int Cp = (int)rup64(C, 64);
     dim3 grid((unsigned)((hw + 63) / 64), (unsigned)(Cp / 64), (unsigned)N);
-    const bool v4 = hw % 4 == 0 && ((((uintptr_t)x) | ((uintptr_t)dst) | ((uintptr_t)x2) | ((uintptr_t)dst_raw)) & 15) == 0;
+    const bool v4 = hw % 4 == 0 && ((((uintptr_t)x) | ((uintptr_t)dst) | ((uintptr_t)x2) | ((uintptr_t)dst_raw) | ((uintptr_t)dst_f32)) & 15) == 0;
     if ((x2 || dst_raw) && !v4) {
         fprintf(stderr, "ggml-mi355x: two-source / two-output NCHW -> NHWC pass needs hw %% 4 == 0 and 16-byte aligned tensors\n");
         abort();
     }
     if (v4)
-        k_nchw_to_nhwc_f16_v4<<<grid, 256, 0, s>>>((_Float16*)dst, x, hw, (int)C, Cp, scale, shift, silu, x2, (int)C1, (_Float16*)dst_raw, post_mul);
+        k_nchw_to_nhwc_f16_v4<<<grid, 256, 0, s>>>((_Float16*)dst, x, hw, (int)C, Cp, scale, shift, silu, x2, (int)C1, (_Float16*)dst_raw, post_mul, dst_f32);
     else
-        k_nchw_to_nhwc_f16<<<grid, 256, 0, s>>>((_Float16*)dst, x, hw, (int)C, Cp, scale, shift, silu, post_mul);
+        k_nchw_to_nhwc_f16<<<grid, 256, 0, s>>>((_Float16*)dst, x, hw, (int)C, Cp, scale, shift, silu, post_mul, dst_f32);
 }
 
 }  // namespace mi355x

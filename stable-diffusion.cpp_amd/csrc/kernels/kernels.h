@@ -203,7 +203,7 @@ void launch_gn_stats(hipStream_t s, float* scale, float* shift, const float* x, 
 int gn_stats_split(int64_t hw, int64_t C, int64_t N, int groups);
 void gemm16_set_gn_split_min(int v);  // option "gn_split_min" (65536 floats): least slab size for it; 0 = never  // workgroups per slab the split form would use (0: not used for this shape)
 void launch_nchw_to_nhwc_f16(hipStream_t s, void* dst, const float* x, int64_t hw, int64_t C, int64_t N, const float* scale, const float* shift,
-                             int act, const float* x2 = nullptr, int64_t C1 = 0, void* dst_raw = nullptr, float post_mul = 1.f);  // act: 0 none, 1 SiLU, 2 ReLU (after the affine); post_mul: after affine / activation (Conv2d scale)
+                             int act, const float* x2 = nullptr, int64_t C1 = 0, void* dst_raw = nullptr, float post_mul = 1.f, float* dst_f32 = nullptr);  // act: 0 none, 1 SiLU, 2 ReLU (after the affine); post_mul: after affine / activation (Conv2d scale); dst_f32: the activated values also as f32 NCHW (may be x itself: the in-place unary), single source only
 
 // ---- qgemm.hip: q8_0 / q4_0 Linear with <= 4 activation rows: raw quantised blocks streamed once, in-register dequant ----------------
 bool qgemv_supported(int wtype, int64_t rows, int64_t K);
