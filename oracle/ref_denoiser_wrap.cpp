@@ -31,8 +31,8 @@ const char* ggml_type_name(enum ggml_type) { return "stub"; }
 
 namespace {
 std::shared_ptr<Denoiser> make_denoiser(int family) {
-    if (family == 0) {
-        auto d = std::make_shared<CompVisDenoiser>();
+    if (family == 0 || family == 4) {  // 4 (round 6): the v-prediction parameterisation, CompVisVDenoiser (denoiser.hpp:1198-1205), over the same sigma table
+        std::shared_ptr<CompVisDenoiser> d = family == 4 ? std::make_shared<CompVisVDenoiser>() : std::make_shared<CompVisDenoiser>();
         // restated: calculate_alphas_cumprod (src/stable-diffusion.cpp:173-186) + the table fill (:671-680)
         const float ls_sqrt = sqrtf(0.00085f), le_sqrt = sqrtf(0.0120f), amount = le_sqrt - ls_sqrt;
         float product = 1.0f;
@@ -47,7 +47,7 @@ std::shared_ptr<Denoiser> make_denoiser(int family) {
     if (family == 1) return std::make_shared<DiscreteFlowDenoiser>(3.0f);  // SD3.x: shift 3 (stable-diffusion.cpp, sd3 default flow shift)
     return std::make_shared<FluxFlowDenoiser>();
 }
-SDVersion version_of(int family) { return family == 0 ? VERSION_SD1 : (family == 1 ? VERSION_SD3 : VERSION_FLUX); }
+SDVersion version_of(int family) { return (family == 0 || family == 4) ? VERSION_SD1 : (family == 1 ? VERSION_SD3 : VERSION_FLUX); }
 scheduler_t scheduler_of(int family) { return family == 2 ? FLUX_SCHEDULER : DISCRETE_SCHEDULER; }  // sd_get_default_scheduler, src/stable-diffusion.cpp:3977-3998
 }  // namespace
 
@@ -111,7 +111,7 @@ REF_API void ref_planar_rgb_to_u8(const float* chw, int width, int height, uint8
 // ---- round 6: every scheduler / sampler the product implements (sdm_scheduler_t / sdm_sample_method_t carry the reference's numeric values) ----
 namespace {
 std::shared_ptr<Denoiser> make_denoiser_shift(int family, float shift) {
-    auto d = make_denoiser(family == 3 ? 0 : family);
+    auto d = make_denoiser(family == 3 ? 0 : family);  // (4 passes through: CompVisVDenoiser)
     if (shift > 0.f)
         if (auto f = std::dynamic_pointer_cast<DiscreteFlowDenoiser>(d)) f->set_shift(shift);
     return d;

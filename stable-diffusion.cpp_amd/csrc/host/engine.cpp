@@ -2022,11 +2022,11 @@ int sd_sample_synthetic(int family, int steps, int image_seq_len, int64_t n, uin
 }
 // sd_sample_synthetic with a scheduler and every implemented method (the loop sample_group runs, on the synthetic model); aux: 5 floats per model call, in call order
 int sd_sample_synthetic2(int family, int steps, int image_seq_len, int64_t n, uint64_t seed, int method, int scheduler, float eta, float* out, float* aux, int aux_calls) {
-    if (steps < 1 || n < 1 || family < 0 || family > 3 || !sample_method_supported(method)) return -1;
+    if (steps < 1 || n < 1 || family < 0 || family > 4 || !sample_method_supported(method)) return -1;  // family 4: CompVis with the v-prediction scalings
     CompVisDenoiser cv;
     DiscreteFlowDenoiser fl;
     FluxFlowDenoiser fx;
-    const int fam   = family == 3 ? 0 : family;
+    const int fam   = (family == 3 || family == 4) ? 0 : family;
     const bool flow = fam != 0;
     if (scheduler == SDM_SCHEDULER_COUNT) scheduler = (method == SM_LCM || method == SM_TCD) ? SCHED_LCM : (method == SM_DDIM_TRAILING ? SCHED_SIMPLE : (fam == 2 ? SCHED_FLUX : SCHED_DISCRETE));
     if (!scheduler_supported(scheduler)) return -1;
@@ -2042,7 +2042,12 @@ int sd_sample_synthetic2(int family, int steps, int image_seq_len, int64_t n, ui
     int calls  = 0;
     auto model = [&](const float* xin, float sigma, float* den, float* unc) {
         float c_skip, c_out, c_in;
-        if (fam == 0) cv.scalings(sigma, c_skip, c_out, c_in);
+        if (family == 4) {  // CompVisVDenoiser::get_scalings, sigma_data = 1 (the expressions sdm_ctx_t::scalings uses for SDM_V_PRED)
+            const float sigma_data = 1.0f;
+            c_skip = sigma_data * sigma_data / (sigma * sigma + sigma_data * sigma_data);
+            c_out  = -sigma * sigma_data / std::sqrt(sigma * sigma + sigma_data * sigma_data);
+            c_in   = 1.0f / std::sqrt(sigma * sigma + sigma_data * sigma_data);
+        } else if (fam == 0) cv.scalings(sigma, c_skip, c_out, c_in);
         else if (fam == 1) fl.scalings(sigma, c_skip, c_out, c_in);
         else fx.scalings(sigma, c_skip, c_out, c_in);
         const float t = fam == 0 ? cv.sigma_to_t(sigma) : (fam == 1 ? fl.sigma_to_t(sigma) : sigma);
@@ -2087,12 +2092,12 @@ int sd_sample_synthetic2(int family, int steps, int image_seq_len, int64_t n, ui
     return calls;
 }
 int sd_get_sigmas_sched(int family, int scheduler, int steps, int image_seq_len, float shift, float* out) {
-    if (family < 0 || family > 3 || steps < 0 || !scheduler_supported(scheduler)) return -1;
+    if (family < 0 || family > 4 || steps < 0 || !scheduler_supported(scheduler)) return -1;
     std::vector<float> s;
     if (scheduler == SCHED_FLUX) {
         FluxFlowDenoiser d;
         s = d.get_sigmas((uint32_t)steps, image_seq_len);
-    } else if (family == 0 || family == 3) {
+    } else if (family == 0 || family == 3 || family == 4) {
         static const CompVisDenoiser d;
         s = scheduler_sigmas(scheduler, (uint32_t)steps, d.sigma_min(), d.sigma_max(), [&](float t) { return d.t_to_sigma(t); }, family == 3 ? 1 : 0);
     } else if (family == 1) {
