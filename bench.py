@@ -639,6 +639,16 @@ def model_leg(sd, backend_name, args, name):
     dec = (time.perf_counter() - t0) * 1e3
     res["vae_decode_ms"] = round(dec, 1)
     res["vae_decode_frac"] = round(VAE_DECODE_TFLOP_1024 * B / (dec / 1e3) / MFMA_PEAK_TFLOPS, 4)
+    try:  # the tiny autoencoder's decode of the same latents (the reference's --taesd; reported beside the KL-VAE decode, not part of sec_per_image)
+        eng.tae_decode(z)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.tae_decode(z)
+        torch.cuda.synchronize()
+        res["taesd_decode_ms"] = round((time.perf_counter() - t0) * 1e3, 2)
+    except Exception as ex:  # never let the side measurement take the leg down
+        res["taesd_decode_ms"] = None
+        res["taesd_error"] = str(ex)[:200]
     t0 = time.perf_counter()
     img = eng.generate_image(cond, unc, steps=cfg_steps, **kw)
     e2e = time.perf_counter() - t0
