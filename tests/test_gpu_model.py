@@ -149,7 +149,7 @@ def test_activation_folded_into_the_conv_operand_image(sd, oracle, gpu):
     fused, k_fused = run()
     print(f"TAESD decode: {k_plain} kernels unfused, {k_fused} with the activation folded into the operand image")
     np.testing.assert_array_equal(fused, plain)
-    assert k_plain - k_fused > 0
+    assert k_plain - k_fused == 28   # 20 ReLUs read only by convs lose their launch, 8 more (read by a conv and the residual ADD) merge with the pack pass
 
 
 def test_sampler_trajectory_parity(sd, oracle, gpu):
