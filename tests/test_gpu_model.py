@@ -89,7 +89,7 @@ def test_vae_decode_with_conv2d_scale_parity(sd, oracle, gpu):
         np.testing.assert_array_equal(out.shape, plain.shape)
 
 
-@pytest.mark.parametrize("model_name,zc,hw,n", [("SD15_TINY", 4, (12, 10), 3), ("SD15_TINY", 4, (64, 64), 2), ("SD35_TINY", 16, (128, 128), 1)])
+@pytest.mark.parametrize("model_name,zc,hw,n", [("SD15_TINY", 4, (12, 10), 3), ("SD15_TINY", 4, (9, 7), 2), ("SD15_TINY", 4, (64, 64), 2), ("SD35_TINY", 16, (128, 128), 1)])
 def test_taesd_decode_parity(sd, oracle, gpu, model_name, zc, hw, n):
     """TAESD's decoder (src/model/vae/tae.hpp:123-183) through the C ABI on the GPU against the oracle backend: a ragged small latent, the
     512 x 512 and the 16-channel 1024 x 1024 decode (64-channel 3x3 convs + ReLU up to 1024 x 1024 feature maps).  The output is unclamped: compared as it leaves the graph."""
