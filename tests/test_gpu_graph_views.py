@@ -48,6 +48,12 @@ def _case(sd, name):
     if name == "VAE_SCALED":  # SDXL: Conv2d scale 1/32, SCALE nodes folded into the conv (both must survive a cut between SCALE and IM2COL)
         z = rng.standard_normal((1, 4, 12, 10)).astype(np.float32) * 0.5
         return sd.SDXL_TINY, lambda e: e.vae_decode(z)
+    if name == "TAE":  # TAESD's conv -> ReLU -> conv chains: the ReLUs folded into the operand-image pack must survive a cut between the ReLU and its conv
+        z = rng.standard_normal((2, 4, 12, 10)).astype(np.float32) * 1.5
+        return sd.SD15_TINY, lambda e: e.tae_decode(z)
+    if name == "VAE_ENC":  # the encode graph: PAD + stride-2 downsample convs
+        img = rng.random((1, 3, 48, 40)).astype(np.float32)
+        return sd.SD15_TINY, lambda e: e.vae_encode(img, return_moments=True)[1]
     x = rng.standard_normal((2, 16, 14, 12)).astype(np.float32)
     ctx = rng.standard_normal((1, 40, 96)).astype(np.float32)
     y = rng.standard_normal((1, 64)).astype(np.float32)
@@ -58,7 +64,7 @@ def _case(sd, name):
     return getattr(sd, name), lambda e: e.unet_forward(x, t, ctx, y)
 
 
-CASES = ["SD15_TINY", "SDXL_TINY", "VAE", "VAE_SCALED", "SD35_TINY", "FLUX_TINY"]
+CASES = ["SD15_TINY", "SDXL_TINY", "VAE", "VAE_SCALED", "SD35_TINY", "FLUX_TINY", "TAE", "VAE_ENC"]
 
 
 def _traced(sd, engine, run, want):
