@@ -119,6 +119,9 @@ typedef struct {
     float eta;                  /* INFINITY -> 1.0 for Euler-A (stable-diffusion.cpp:4024-4049) */
     const float* custom_sigmas; /* sd_sample_params_t::custom_sigmas: count > 1 replaces the scheduler's ladder as it is (last value normally 0) */
     int custom_sigmas_count;
+    const int* slg_layers;      /* skip-layer guidance (sd_slg_params_t; SD3.x): joint blocks left out of one more conditional forward per step inside the window */
+    int slg_layer_count;        /* (slg_layer_start, slg_layer_end) x the ladder length; guided += (cond - skip) * slg_scale (guidance.cpp:296-340).  scale 0 = off */
+    float slg_layer_start, slg_layer_end, slg_scale;
     float flow_shift;           /* flow families: the time shift of DiscreteFlowDenoiser (set_flow_shift, stable-diffusion.cpp:3106-3115); INFINITY = the default (SD3.x 3.0, FLUX.1-dev 1.15) */
 } sdm_sample_params_t;
 
@@ -205,6 +208,9 @@ SD_API bool sd_convert_tensor_name(sdm_ctx_t* ctx, const char* name, char* out, 
 SD_API bool sd_unet_forward(sdm_ctx_t* ctx, const float* x, int w, int h, int c, int n, const float* timesteps,
                             const float* context, int64_t ctx_dim, int64_t n_tokens, int64_t ctx_n,
                             const float* y, int64_t y_dim, int64_t y_n, float* out);
+/* the same forward WITHOUT the listed joint blocks — MMDiT::forward's skip_layers (mmdit.hpp:854-866), the extra evaluation of skip-layer guidance; MMDiT family only */
+SD_API bool sd_unet_forward_skip_layers(sdm_ctx_t* ctx, const float* x, int w, int h, int c, int n, const float* timesteps, const float* context, int64_t ctx_dim,
+                                        int64_t n_tokens, int64_t ctx_n, const float* y, int64_t y_dim, int64_t y_n, const int* skip_layers, int n_skip, float* out);
 /* VAE decode_first_stage (stable-diffusion.cpp:3062-3078): latents [w,h,zc,n] (diffusion scale) -> rgb f32 [8w,8h,3,n] in [0,1] */
 SD_API bool sd_vae_decode(sdm_ctx_t* ctx, const float* latents, int w, int h, int c, int n, float* out_rgb);
 /* VAE encode — encode_first_stage (stable-diffusion.cpp:3042-3060): rgb f32 planar [w,h,3,n] in [0,1] -> diffusion latents [w/8,h/8,zc,n], SAMPLED from the encoder's diagonal

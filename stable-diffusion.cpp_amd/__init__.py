@@ -82,7 +82,9 @@ class SdCtxParams(C.Structure):
 
 class SdSampleParams(C.Structure):
     _fields_ = [("txt_cfg", C.c_float), ("scheduler", C.c_int), ("sample_method", C.c_int),
-                ("sample_steps", C.c_int), ("eta", C.c_float), ("custom_sigmas", C.c_void_p), ("custom_sigmas_count", C.c_int), ("flow_shift", C.c_float)]
+                ("sample_steps", C.c_int), ("eta", C.c_float), ("custom_sigmas", C.c_void_p), ("custom_sigmas_count", C.c_int),
+                ("slg_layers", C.c_void_p), ("slg_layer_count", C.c_int), ("slg_layer_start", C.c_float), ("slg_layer_end", C.c_float), ("slg_scale", C.c_float),
+                ("flow_shift", C.c_float)]
 
 
 class SdCondition(C.Structure):
@@ -620,6 +622,21 @@ class Engine:
             raise EngineError("sd_unet_forward failed: " + lib().sd_last_error().decode())
         return out
 
+    def unet_forward_skip_layers(self, x, timesteps, context, y, skip_layers) -> np.ndarray:
+        """sd_unet_forward_skip_layers: the MMDiT forward without the listed joint blocks (skip-layer guidance's extra evaluation)."""
+        x, t, ctxt, yy = _f32(x), _f32(timesteps), _f32(context), (None if y is None else _f32(y))
+        n, c, h, w = x.shape
+        out = np.empty_like(x)
+        sk = np.ascontiguousarray(skip_layers, dtype=np.int32)
+        L = lib()
+        L.sd_unet_forward_skip_layers.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p,
+                                                  C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]
+        L.sd_unet_forward_skip_layers.restype = C.c_bool
+        if not L.sd_unet_forward_skip_layers(self._ctx, _fptr(x), w, h, c, n, _fptr(t), _fptr(ctxt), ctxt.shape[2], ctxt.shape[1], ctxt.shape[0], _fptr(yy),
+                                             0 if yy is None else yy.shape[1], 0 if yy is None else yy.shape[0], sk.ctypes.data_as(C.c_void_p), sk.size, _fptr(out)):
+            raise EngineError("sd_unet_forward_skip_layers failed: " + L.sd_last_error().decode())
+        return out
+
     def vae_decode(self, latents: np.ndarray) -> np.ndarray:
         """latents [N,C,h,w] (diffusion scale) -> rgb [N,3,8h,8w] in [0,1]."""
         z = _f32(latents)
@@ -673,7 +690,7 @@ class Engine:
             raise EngineError("sd_use_tae failed: " + L.sd_last_error().decode())
 
     def _gen_params(self, cond, uncond, width, height, steps, cfg, seed, batch, device_batch, method, eta, cond_y=None, uncond_y=None,
-                    fuse_cfg=False, device_sampler=False, scheduler=SCHEDULER_DEFAULT, init_latent=None, strength=0.75, custom_sigmas=None, flow_shift=None, denoise_mask=None):
+                    fuse_cfg=False, device_sampler=False, scheduler=SCHEDULER_DEFAULT, init_latent=None, strength=0.75, custom_sigmas=None, flow_shift=None, denoise_mask=None, slg=None):
         p = SdImgGenParams()
         lib().sdm_img_gen_params_init(C.byref(p))
         keep = []
@@ -710,6 +727,14 @@ class Engine:
             p.sample_params.custom_sigmas_count = cs.size
         if flow_shift is not None:
             p.sample_params.flow_shift = flow_shift
+        if slg is not None:   # (layers, scale[, start, end])
+            ly = np.ascontiguousarray(slg[0], dtype=np.int32)
+            keep.append(ly)
+            p.sample_params.slg_layers = ly.ctypes.data_as(C.c_void_p)
+            p.sample_params.slg_layer_count = ly.size
+            p.sample_params.slg_scale = slg[1]
+            if len(slg) > 2:
+                p.sample_params.slg_layer_start, p.sample_params.slg_layer_end = slg[2], slg[3]
         if init_latent is not None:
             il = _f32(init_latent)
             keep.append(il)
@@ -724,11 +749,11 @@ class Engine:
 
     def sample_latents(self, cond, uncond=None, width=512, height=512, steps=20, cfg=7.0, seed=42, batch=1, device_batch=0,
                        method=SAMPLE_METHOD_DEFAULT, eta=float("inf"), cond_y=None, uncond_y=None, fuse_cfg=False, device_sampler=False,
-                       scheduler=SCHEDULER_DEFAULT, init_latent=None, strength=0.75, custom_sigmas=None, flow_shift=None, denoise_mask=None) -> np.ndarray:
+                       scheduler=SCHEDULER_DEFAULT, init_latent=None, strength=0.75, custom_sigmas=None, flow_shift=None, denoise_mask=None, slg=None) -> np.ndarray:
         """init_latent [C,h/8,w/8] (+ strength): img2img — the trajectory starts from the noised init latent, (int)(steps * strength) steps before the end of the ladder;
         custom_sigmas: the ladder to use instead of the scheduler's; flow_shift: the flow families' time shift."""
         p, keep = self._gen_params(cond, uncond, width, height, steps, cfg, seed, batch, device_batch, method, eta, cond_y, uncond_y, fuse_cfg,
-                                   device_sampler, scheduler, init_latent, strength, custom_sigmas, flow_shift, denoise_mask)
+                                   device_sampler, scheduler, init_latent, strength, custom_sigmas, flow_shift, denoise_mask, slg)
         ch = 16 if self.model in (SD35_LARGE, SD35_TINY, FLUX_DEV, FLUX_TINY, SD35_WIDE2, FLUX_WIDE1, SD3M_TINY, SD35_WIDE8, FLUX_WIDE8) else 4
         out = np.empty((batch, ch, height // 8, width // 8), dtype=np.float32)
         if not lib().sd_sample_latents(self._ctx, C.byref(p), _fptr(out)):

@@ -593,6 +593,8 @@ void sdm_sample_params_init(sdm_sample_params_t* p) {  // stable-diffusion.cpp:3
     p->sample_steps  = 20;
     p->eta           = INFINITY;
     p->flow_shift    = INFINITY;  // the family's default (stable-diffusion.cpp:3665, 3106-3115)
+    p->slg_layer_start = 0.01f;   // stable-diffusion.cpp:3655-3658
+    p->slg_layer_end   = 0.2f;
 }
 void sdm_img_gen_params_init(sdm_img_gen_params_t* p) {  // stable-diffusion.cpp:3710-3731
     memset(p, 0, sizeof(*p));
@@ -1240,20 +1242,26 @@ static ggml_tensor* build_model_call(sdm_ctx_t* ctx, GraphCtx& g, std::vector<Ho
     return ctx->is_dit ? ctx->mmdit.forward(g, tx, tt, tc, ty) : ctx->unet.forward(g, tx, tt, tc, ty);
 }
 
-bool sd_unet_forward(sdm_ctx_t* ctx, const float* x, int w, int h, int c, int n, const float* timesteps, const float* context,
-                     int64_t ctx_dim, int64_t n_tokens, int64_t ctx_n, const float* y, int64_t y_dim, int64_t y_n, float* out) {
+// skip: the joint blocks a skip-layer-guidance forward leaves out (MMDiT only; NULL / empty = the whole model)
+static bool unet_forward_skip(sdm_ctx_t* ctx, const float* x, int w, int h, int c, int n, const float* timesteps, const float* context, int64_t ctx_dim, int64_t n_tokens,
+                              int64_t ctx_n, const float* y, int64_t y_dim, int64_t y_n, float* out, const std::vector<int>* skip) {
     Runner& r = ctx->unet_runner;
     ModelSideInputs si;
     if (!prepare_side_inputs(ctx, w, h, n, n_tokens, y != nullptr, si)) return false;
+    if (skip && skip->empty()) skip = nullptr;
     auto build = [&](GraphCtx& g, std::vector<HostInput>& in) {
         ggml_tensor* tx = ggml_new_tensor_4d(g.ctx, GGML_TYPE_F32, w, h, c, n);
         ggml_set_input(tx);
         in.push_back({tx, x, ggml_nbytes(tx)});
+        g.skip_layers = skip;
         return build_model_call(ctx, g, in, tx, n, timesteps, context, ctx_dim, n_tokens, ctx_n, y, y_dim, y_n, si);
     };
-    char sig[160];
-    snprintf(sig, sizeof(sig), "fwd %d %d %d %d %lld %lld %lld %lld %lld %d", w, h, c, n, (long long)ctx_dim, (long long)n_tokens, (long long)ctx_n,
-             (long long)(y ? y_dim : -1), (long long)y_n, (int)ctx->is_flux);
+    char sig[256];
+    int so = snprintf(sig, sizeof(sig), "fwd %d %d %d %d %lld %lld %lld %lld %lld %d", w, h, c, n, (long long)ctx_dim, (long long)n_tokens, (long long)ctx_n,
+                      (long long)(y ? y_dim : -1), (long long)y_n, (int)ctx->is_flux);
+    if (skip)
+        for (int l : *skip)
+            if (so < (int)sizeof(sig) - 8) so += snprintf(sig + so, sizeof(sig) - so, " s%d", l);
     std::vector<const void*> ptrs{x, timesteps, context};
     if (y) ptrs.push_back(y);
     if (ctx->is_flux) {
@@ -1265,6 +1273,21 @@ bool sd_unet_forward(sdm_ctx_t* ctx, const float* x, int w, int h, int c, int n,
     ctx->stats.graph_nodes = r.last_nodes;
     if (r.galloc) ctx->stats.compute_buffer_bytes = ggml_gallocr_get_buffer_size(r.galloc, 0);
     return ok;
+}
+bool sd_unet_forward(sdm_ctx_t* ctx, const float* x, int w, int h, int c, int n, const float* timesteps, const float* context,
+                     int64_t ctx_dim, int64_t n_tokens, int64_t ctx_n, const float* y, int64_t y_dim, int64_t y_n, float* out) {
+    return unet_forward_skip(ctx, x, w, h, c, n, timesteps, context, ctx_dim, n_tokens, ctx_n, y, y_dim, y_n, out, nullptr);
+}
+
+// the same forward without the listed MMDiT joint blocks (MMDiT::forward's skip_layers, mmdit.hpp:854-866): what skip-layer guidance evaluates
+bool sd_unet_forward_skip_layers(sdm_ctx_t* ctx, const float* x, int w, int h, int c, int n, const float* timesteps, const float* context, int64_t ctx_dim, int64_t n_tokens,
+                                 int64_t ctx_n, const float* y, int64_t y_dim, int64_t y_n, const int* skip_layers, int n_skip, float* out) {
+    if (!ctx->is_dit || ctx->is_flux) {
+        set_error("sd_unet_forward_skip_layers: skip layers exist for the MMDiT family only");
+        return false;
+    }
+    const std::vector<int> skip(skip_layers, skip_layers + (n_skip > 0 ? n_skip : 0));
+    return unet_forward_skip(ctx, x, w, h, c, n, timesteps, context, ctx_dim, n_tokens, ctx_n, y, y_dim, y_n, out, &skip);
 }
 
 // ---- VAE decode ---------------------------------------------------------------------------------
@@ -1459,14 +1482,17 @@ struct HostDenoise {
     int W, H, C, nb;
     size_t per;
     bool use_cfg;
-    std::vector<float> noised, cond_out, uncond_out, ts;
+    std::vector<float> noised, cond_out, uncond_out, ts, skip_out;
+    int n_sigmas = 0;  // sigmas.size() of the trajectory (GuidanceInput::schedule_size)
     std::vector<float> x2, o2, t2, c2, y2;  // staging of the fused (cond, uncond) pair
     HostDenoise(sdm_ctx_t* ctx_, const sdm_img_gen_params_t* p_, int W_, int H_, int C_, int nb_)
         : ctx(ctx_), p(p_), W(W_), H(H_), C(C_), nb(nb_), per((size_t)W_ * H_ * C_), use_cfg(p_->sample_params.txt_cfg != 1.0f && p_->uncond.c_crossattn != nullptr),
           noised(per * nb_), cond_out(per * nb_), uncond_out(per * nb_), ts(nb_) {}
     // denoised_uncond (the CFG++ methods): GuiderOutput::pred_uncond = base_uncond * c_out + x * c_skip with the unconditional forward — or the conditional one when there is
     // no guidance pair (stable-diffusion.cpp:2877-2884)
-    bool operator()(const float* x, float sigma, float* denoised, float* denoised_uncond = nullptr) {
+    // step: the sampler's step index of this call (sample_k_diffusion hands the denoise callback i + 1, negated for the first stage of the two-stage methods): what
+    // SkipLayerGuidance::is_enabled_for_step looks at (guidance.cpp:306-314)
+    bool operator()(const float* x, float sigma, float* denoised, float* denoised_uncond = nullptr, int step = 0) {
         const sdm_sample_params_t& sp = p->sample_params;
         const size_t n = per * (size_t)nb;
         float c_skip, c_out, c_in;
@@ -1508,21 +1534,35 @@ struct HostDenoise {
                 memcpy(&cond_out[b * per], &o2[(2 * b) * per], per * sizeof(float));
                 memcpy(&uncond_out[b * per], &o2[(2 * b + 1) * per], per * sizeof(float));
             }
-            for (size_t k = 0; k < n; ++k) {
-                const float guided = cfg_guided(cond_out[k], uncond_out[k], sp.txt_cfg);
-                denoised[k]        = guided * c_out + x[k] * c_skip;
-            }
+            for (size_t k = 0; k < n; ++k) denoised[k] = cfg_guided(cond_out[k], uncond_out[k], sp.txt_cfg);
         } else if (!run(p->cond, cond_out.data())) {
             return false;
         } else if (use_cfg) {
             if (!run(p->uncond, uncond_out.data())) return false;
-            for (size_t k = 0; k < n; ++k) {  // guidance.cpp:171 ; stable-diffusion.cpp:2876
-                const float guided = cfg_guided(cond_out[k], uncond_out[k], sp.txt_cfg);
-                denoised[k]        = guided * c_out + x[k] * c_skip;
-            }
+            for (size_t k = 0; k < n; ++k) denoised[k] = cfg_guided(cond_out[k], uncond_out[k], sp.txt_cfg);  // guidance.cpp:171
         } else {
-            for (size_t k = 0; k < n; ++k) denoised[k] = cond_out[k] * c_out + x[k] * c_skip;
+            for (size_t k = 0; k < n; ++k) denoised[k] = cond_out[k];
         }
+        // skip-layer guidance (SkipLayerGuidance, guidance.cpp:296-340; stable-diffusion.cpp:2593-2611, 2860-2871): inside the step window one more conditional forward
+        // WITHOUT the listed joint blocks; guided += (cond - skip) * scale.  DiT families only (the reference warns and ignores it elsewhere)
+        if (ctx->is_dit && !ctx->is_flux && sp.slg_scale != 0.0f && sp.slg_layers && sp.slg_layer_count > 0) {
+            const size_t schedule_size = (size_t)n_sigmas;
+            const int start_step = static_cast<int>(sp.slg_layer_start * static_cast<float>(schedule_size));
+            const int stop_step  = static_cast<int>(sp.slg_layer_end * static_cast<float>(schedule_size));
+            if (schedule_size != 0 && step > start_step && step < stop_step) {
+                const std::vector<int> skip(sp.slg_layers, sp.slg_layers + sp.slg_layer_count);
+                skip_out.resize(n);
+                if (!unet_forward_skip(ctx, noised.data(), W, H, C, nb, ts.data(), p->cond.c_crossattn, p->cond.ctx_dim, p->cond.n_tokens, 1, p->cond.c_vector, p->cond.vector_dim, 1,
+                                       skip_out.data(), &skip))
+                    return false;
+                for (size_t k = 0; k < n; ++k) {
+                    volatile float d = cond_out[k] - skip_out[k];  // (three separately rounded operations, like cfg_guided)
+                    volatile float sc = d * sp.slg_scale;
+                    denoised[k] += sc;
+                }
+            }
+        }
+        for (size_t k = 0; k < n; ++k) denoised[k] = denoised[k] * c_out + x[k] * c_skip;  // stable-diffusion.cpp:2876
         if (denoised_uncond) {
             const float* base = use_cfg ? uncond_out.data() : cond_out.data();
             for (size_t k = 0; k < n; ++k) denoised_uncond[k] = base[k] * c_out + x[k] * c_skip;
@@ -1600,12 +1640,13 @@ static bool sample_group(sdm_ctx_t* ctx, const sdm_img_gen_params_t* p, int b0, 
         }
     }, 2);
     HostDenoise denoise(ctx, p, W, H, C, nb);
+    denoise.n_sigmas = (int)sigmas.size();
     std::vector<float> denoised(per * nb);
     std::vector<std::vector<float>> step_noise(nb);
 
     if (method != SDM_EULER_SAMPLE_METHOD && method != SDM_EULER_A_SAMPLE_METHOD) {
         // the multi-stage / multi-step samplers (sampler.hpp: run_sampler_generic): per-image Philox streams, one draw of `per` normals per image and request
-        const bool ok = run_sampler_generic(method, [&](const float* xin, float sigma, float* den, float* unc) { return denoise(xin, sigma, den, unc); }, x, sigmas,
+        const bool ok = run_sampler_generic(method, [&](const float* xin, float sigma, float* den, float* unc, int step) { return denoise(xin, sigma, den, unc, step); }, x, sigmas,
                                             [&](float* dst) {
                                                 for (int b = 0; b < nb; ++b) {
                                                     const std::vector<float> nz = rngs[b].randn((uint32_t)per);
@@ -1644,7 +1685,7 @@ static bool sample_group(sdm_ctx_t* ctx, const sdm_img_gen_params_t* p, int b0, 
                 if (f.valid()) f.wait();
             }
         } join_noise{noise_job};
-        if (!denoise(x.data(), sigma, denoised.data())) return false;
+        if (!denoise(x.data(), sigma, denoised.data(), nullptr, i + 1)) return false;
         // the update itself: sample_euler_ancestral / sample_euler (sampler.hpp: sampler_update — the function tests hold bit-for-bit against the reference's
         // own src/runtime/denoiser.hpp compiled into oracle/_ref)
         sampler_update(x.data(), denoised.data(), per, nb, method == SDM_EULER_A_SAMPLE_METHOD, ctx->is_dit, sigma, sigma_to, eta, sigma_down, sigma_up, alpha_scale,
@@ -1682,6 +1723,7 @@ static bool sample_group_device(sdm_ctx_t* ctx, const sdm_img_gen_params_t* p, i
     }
     if (method != SDM_EULER_SAMPLE_METHOD && method != SDM_EULER_A_SAMPLE_METHOD) return true;  // multi-stage / multi-step samplers: the host loop around the device forward
     if (p->denoise_mask && p->init_latent) return true;  // the inpainting blend lives in the host loop's denoise call
+    if (sp.slg_scale != 0.0f && sp.slg_layers && sp.slg_layer_count > 0 && ctx->is_dit && !ctx->is_flux) return true;  // skip-layer guidance: a third forward inside a step window
     *handled = true;
     const size_t per = (size_t)W * H * C;
     const std::vector<float> sigmas = call_sigmas(ctx, p, W * H, scheduler);
@@ -2040,7 +2082,7 @@ int sd_sample_synthetic2(int family, int steps, int image_seq_len, int64_t n, ui
     std::vector<float> x = rng.randn((uint32_t)n);
     for (int64_t k = 0; k < n; ++k) x[k] = 0.0f + x[k] * sigmas[0];
     int calls  = 0;
-    auto model = [&](const float* xin, float sigma, float* den, float* unc) {
+    auto model = [&](const float* xin, float sigma, float* den, float* unc, int /*step*/) {
         float c_skip, c_out, c_in;
         if (family == 4) {  // CompVisVDenoiser::get_scalings, sigma_data = 1 (the expressions sdm_ctx_t::scalings uses for SDM_V_PRED)
             const float sigma_data = 1.0f;
@@ -2068,7 +2110,7 @@ int sd_sample_synthetic2(int family, int steps, int image_seq_len, int64_t n, ui
         std::vector<float> den((size_t)n), nz;
         for (int i = 0; i + 1 < (int)sigmas.size(); ++i) {
             const float sigma = sigmas[i], sigma_to = sigmas[i + 1];
-            model(x.data(), sigma, den.data(), nullptr);
+            model(x.data(), sigma, den.data(), nullptr, i + 1);
             float sigma_down = 0.f, sigma_up = 0.f, alpha_scale = 1.f;
             if (method == SM_EULER_A && sigma_to != 0.f && eta != 0.f) {
                 if (flow) ancestral_step_flow(sigma, sigma_to, eta, sigma_down, sigma_up, alpha_scale);

@@ -752,7 +752,11 @@ struct MMDiTModel {
             cv              = ggml_add(c, cv, ye);
         }
         if (context != nullptr) context = context_embedder.forward(g, context);
-        for (auto& jb : blocks) block_mixing(g, jb, context, x, cv);
+        for (size_t bi = 0; bi < blocks.size(); ++bi) {
+            // skip-layer guidance (mmdit.hpp:862-865): the listed joint blocks are left out of this forward
+            if (g.skip_layers && std::find(g.skip_layers->begin(), g.skip_layers->end(), (int)bi) != g.skip_layers->end()) continue;
+            block_mixing(g, blocks[bi], context, x, cv);
+        }
 
         // FinalLayer — mmdit.hpp:725-757
         auto mv = ext_chunk(c, final_adaLN.forward(g, ggml_silu(c, cv)), 2, 0, true);

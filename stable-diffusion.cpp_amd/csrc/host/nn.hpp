@@ -59,6 +59,7 @@ struct GraphCtx {
     ggml_backend_t backend = nullptr;
     bool flash_attn        = false;  // sdm_ctx_params_t.diffusion_flash_attn
     bool conv_direct       = false;  // sdm_ctx_params_t.diffusion_conv_direct
+    const std::vector<int>* skip_layers = nullptr;  // skip-layer guidance: joint blocks the MMDiT forward leaves out (mmdit.hpp:854-866)
 };
 
 // ---- ggml_ext_* wrappers (node-for-node) --------------------------------------------------------

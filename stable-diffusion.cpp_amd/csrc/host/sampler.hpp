@@ -656,14 +656,14 @@ inline bool run_sampler_generic(int method, ModelFn&& model, std::vector<float>&
     switch (method) {
         case SM_HEUN:
             for (int i = 0; i < steps; ++i) {
-                if (!model(x.data(), sigmas[i], den.data(), nullptr)) return false;
+                if (!model(x.data(), sigmas[i], den.data(), nullptr, -(i + 1))) return false;
                 const float dt = sigmas[i + 1] - sigmas[i];
                 for (size_t k = 0; k < n; ++k) d[k] = (x[k] - den[k]) / sigmas[i];
                 if (sigmas[i + 1] == 0) {
                     for (size_t k = 0; k < n; ++k) x[k] += d[k] * dt;
                 } else {
                     for (size_t k = 0; k < n; ++k) x2[k] = x[k] + d[k] * dt;
-                    if (!model(x2.data(), sigmas[i + 1], den2.data(), nullptr)) return false;
+                    if (!model(x2.data(), sigmas[i + 1], den2.data(), nullptr, i + 1)) return false;
                     for (size_t k = 0; k < n; ++k) {
                         const float d2 = (x2[k] - den2[k]) / sigmas[i + 1];
                         const float dm = (d[k] + d2) / 2.0f;
@@ -674,7 +674,7 @@ inline bool run_sampler_generic(int method, ModelFn&& model, std::vector<float>&
             return true;
         case SM_DPM2:
             for (int i = 0; i < steps; ++i) {
-                if (!model(x.data(), sigmas[i], den.data(), nullptr)) return false;
+                if (!model(x.data(), sigmas[i], den.data(), nullptr, -(i + 1))) return false;
                 for (size_t k = 0; k < n; ++k) d[k] = (x[k] - den[k]) / sigmas[i];
                 if (sigmas[i + 1] == 0) {
                     const float dt = sigmas[i + 1] - sigmas[i];
@@ -683,7 +683,7 @@ inline bool run_sampler_generic(int method, ModelFn&& model, std::vector<float>&
                     const float sigma_mid = (float)exp(0.5f * (log((double)sigmas[i]) + log((double)sigmas[i + 1])));
                     const float dt_1 = sigma_mid - sigmas[i], dt_2 = sigmas[i + 1] - sigmas[i];
                     for (size_t k = 0; k < n; ++k) x2[k] = x[k] + d[k] * dt_1;
-                    if (!model(x2.data(), sigma_mid, den2.data(), nullptr)) return false;
+                    if (!model(x2.data(), sigma_mid, den2.data(), nullptr, i + 1)) return false;
                     for (size_t k = 0; k < n; ++k) {
                         const float d2 = (x2[k] - den2[k]) / sigma_mid;
                         x[k] += d2 * dt_2;
@@ -694,7 +694,7 @@ inline bool run_sampler_generic(int method, ModelFn&& model, std::vector<float>&
         case SM_DPMPP2S_A:
             if (!flow) {
                 for (int i = 0; i < steps; ++i) {
-                    if (!model(x.data(), sigmas[i], den.data(), nullptr)) return false;
+                    if (!model(x.data(), sigmas[i], den.data(), nullptr, -(i + 1))) return false;
                     float sigma_down, sigma_up;
                     ancestral_step(sigmas[i], sigmas[i + 1], eta, sigma_down, sigma_up);
                     if (sigma_down == 0) {
@@ -703,7 +703,7 @@ inline bool run_sampler_generic(int method, ModelFn&& model, std::vector<float>&
                         const float t = t_fn(sigmas[i]), t_next = t_fn(sigma_down), h = t_next - t, s = t + 0.5f * h, sigma_s = sigma_fn(s);
                         const float a1 = sigma_s / sigma_fn(t), b1 = (float)(exp((double)(-h * 0.5f)) - 1);
                         for (size_t k = 0; k < n; ++k) x2[k] = a1 * x[k] - b1 * den[k];
-                        if (!model(x2.data(), sigma_s, den2.data(), nullptr)) return false;
+                        if (!model(x2.data(), sigma_s, den2.data(), nullptr, i + 1)) return false;
                         const float a2 = sigma_fn(t_next) / sigma_fn(t), b2 = (float)(exp((double)-h) - 1);
                         for (size_t k = 0; k < n; ++k) x[k] = a2 * x[k] - b2 * den2[k];
                     }
@@ -718,7 +718,7 @@ inline bool run_sampler_generic(int method, ModelFn&& model, std::vector<float>&
             for (int i = 0; i < steps; ++i) {  // sample_dpmpp_2s_ancestral_flow, denoiser.hpp:1697-1789
                 const float sigma = sigmas[i], sigma_to = sigmas[i + 1];
                 const bool opt_first_step = (1.0 - (double)sigma < 1e-6);
-                if (!model(x.data(), sigma, den.data(), nullptr)) return false;
+                if (!model(x.data(), sigma, den.data(), nullptr, (opt_first_step ? 1 : -1) * (i + 1))) return false;
                 if (sigma_to == 0.0f) {
                     x = den;
                     continue;
@@ -730,7 +730,7 @@ inline bool run_sampler_generic(int method, ModelFn&& model, std::vector<float>&
                     const float exp_s = std::sqrt(((1 - sigma) / sigma) * ((1 - sigma_down) / sigma_down));
                     const float sigma_s = 1.0f / (exp_s + 1.0f), ratio = sigma_s / sigma, omr = 1.0f - ratio;
                     for (size_t k = 0; k < n; ++k) x2[k] = (x[k] * ratio) + (den[k] * omr);
-                    if (!model(x2.data(), sigma_s, den2.data(), nullptr)) return false;
+                    if (!model(x2.data(), sigma_s, den2.data(), nullptr, i + 1)) return false;
                     D_i = den2.data();
                 }
                 const float rd = sigma_down / sigma, omrd = 1.0f - rd;
@@ -746,7 +746,7 @@ inline bool run_sampler_generic(int method, ModelFn&& model, std::vector<float>&
         case SM_DPMPP2Mv2: {
             std::vector<float> old = x;
             for (int i = 0; i < steps; ++i) {
-                if (!model(x.data(), sigmas[i], den.data(), nullptr)) return false;
+                if (!model(x.data(), sigmas[i], den.data(), nullptr, i + 1)) return false;
                 const float t = t_fn(sigmas[i]), t_next = t_fn(sigmas[i + 1]), h = t_next - t, a = sigmas[i + 1] / sigmas[i];
                 if (i == 0 || sigmas[i + 1] == 0) {
                     const float b = (float)(exp((double)-h) - 1.f);
@@ -779,7 +779,7 @@ inline bool run_sampler_generic(int method, ModelFn&& model, std::vector<float>&
             std::vector<std::vector<float>> hist;
             for (int i = 0; i < steps; ++i) {
                 const float sigma = sigmas[i], sigma_next = sigmas[i + 1];
-                if (!model(x.data(), sigma, den.data(), nullptr)) return false;
+                if (!model(x.data(), sigma, den.data(), nullptr, i + 1)) return false;
                 std::vector<float> dc(n);
                 for (size_t k = 0; k < n; ++k) dc[k] = (x[k] - den[k]) / sigma;
                 const int order = std::min(max_order, i + 1);
@@ -812,7 +812,7 @@ inline bool run_sampler_generic(int method, ModelFn&& model, std::vector<float>&
         }
         case SM_LCM:
             for (int i = 0; i < steps; ++i) {
-                if (!model(x.data(), sigmas[i], den.data(), nullptr)) return false;
+                if (!model(x.data(), sigmas[i], den.data(), nullptr, i + 1)) return false;
                 x = den;
                 if (sigmas[i + 1] > 0) {
                     if (flow) {
@@ -853,7 +853,7 @@ inline bool run_sampler_generic(int method, ModelFn&& model, std::vector<float>&
             bool have_old = false;
             float h_last  = 0.f;
             for (int i = 0; i < steps; ++i) {
-                if (!model(x.data(), sigmas[i], den.data(), nullptr)) return false;
+                if (!model(x.data(), sigmas[i], den.data(), nullptr, i + 1)) return false;
                 if (sigmas[i + 1] == 0.f) {
                     x = den;
                 } else {
@@ -886,7 +886,7 @@ inline bool run_sampler_generic(int method, ModelFn&& model, std::vector<float>&
             bool have_old_sigma  = false;
             float old_sigma_down = 0.0f;
             for (int i = 0; i < steps; ++i) {
-                if (!model(x.data(), sigmas[i], den.data(), nullptr)) return false;
+                if (!model(x.data(), sigmas[i], den.data(), nullptr, i + 1)) return false;
                 const float sigma_from = sigmas[i], sigma_to = sigmas[i + 1];
                 float sigma_down, sigma_up, alpha_scale;
                 ancestral_step3(sigma_from, sigma_to, eta, flow, sigma_down, sigma_up, alpha_scale);
@@ -924,7 +924,7 @@ inline bool run_sampler_generic(int method, ModelFn&& model, std::vector<float>&
             std::vector<float> x0(n), eps1(n);
             for (int i = 0; i < steps; ++i) {
                 const float sigma_from = sigmas[i], sigma_to = sigmas[i + 1];
-                if (!model(x.data(), sigma_from, den.data(), nullptr)) return false;
+                if (!model(x.data(), sigma_from, den.data(), nullptr, -(i + 1))) return false;
                 float sigma_down, sigma_up, alpha_scale;
                 ancestral_step3(sigma_from, sigma_to, eta, flow, sigma_down, sigma_up, alpha_scale);
                 x0 = x;
@@ -939,7 +939,7 @@ inline bool run_sampler_generic(int method, ModelFn&& model, std::vector<float>&
                         eps1[k] = den[k] - x0[k];
                         x2[k]   = x0[k] + eps1[k] * ha;
                     }
-                    if (!model(x2.data(), sigma_c2, den2.data(), nullptr)) return false;
+                    if (!model(x2.data(), sigma_c2, den2.data(), nullptr, i + 1)) return false;
                     for (size_t k = 0; k < n; ++k) {
                         const float eps2 = den2[k] - x0[k];
                         const float in   = b1 * eps1[k] + b2 * eps2;
@@ -991,7 +991,7 @@ inline bool run_sampler_generic(int method, ModelFn&& model, std::vector<float>&
             std::vector<float> old = x, old_d = x, den_d(n);
             bool have_old = false, have_old_d = false;
             for (int i = 0; i < steps; ++i) {
-                if (!model(x.data(), sigmas[i], den.data(), nullptr)) return false;
+                if (!model(x.data(), sigmas[i], den.data(), nullptr, i + 1)) return false;
                 const int stage_used = std::min(max_stage, i + 1);
                 if (sigmas[i + 1] == 0.0f) {
                     x = den;
@@ -1072,7 +1072,7 @@ inline bool run_sampler_generic(int method, ModelFn&& model, std::vector<float>&
                 const int prev_timestep = get_timestep_from_sigma(sigma_to);
                 const int timestep_s    = (int)floor((1 - eta) * prev_timestep);
                 const float sigma       = sigmas[i];
-                if (!model(x.data(), sigma, den.data(), nullptr)) return false;
+                if (!model(x.data(), sigma, den.data(), nullptr, i + 1)) return false;
                 const float alpha_prod_t_prev = 1.0f / (sigma_to * sigma_to + 1.0f);
                 const float alpha_prod_s      = static_cast<float>(alphas_cumprod[timestep_s]);
                 const float beta_prod_s       = 1.0f - alpha_prod_s;
@@ -1116,7 +1116,7 @@ inline bool run_sampler_generic(int method, ModelFn&& model, std::vector<float>&
             std::vector<std::vector<float>> hist;
             for (int i = 0; i < steps; ++i) {
                 const float sigma = sigmas[i];
-                if (!model(x.data(), sigma, den.data(), nullptr)) return false;
+                if (!model(x.data(), sigma, den.data(), nullptr, i + 1)) return false;
                 const int order = std::min(max_order, i + 1);
                 for (int c = 0; c < order; c++) lms_coeff[(size_t)c] = coeff(order, i, c);
                 std::vector<float> d_cur(n);
@@ -1145,7 +1145,7 @@ inline bool run_sampler_generic(int method, ModelFn&& model, std::vector<float>&
             std::vector<float> unc(n);
             for (int i = 0; i < steps; ++i) {
                 const float sigma = sigmas[i];
-                if (!model(x.data(), sigma, den.data(), unc.data())) return false;
+                if (!model(x.data(), sigma, den.data(), unc.data(), i + 1)) return false;
                 float to = sigmas[i + 1], sigma_up = 0.f;
                 if (method == SM_EULER_A_CFG_PP) ancestral_step(sigmas[i], sigmas[i + 1], eta, to, sigma_up);
                 for (size_t k = 0; k < n; ++k) {
@@ -1166,7 +1166,7 @@ inline bool run_sampler_generic(int method, ModelFn&& model, std::vector<float>&
             bool has_old_d = false;
             for (int i = 0; i < steps; ++i) {
                 const float sigma = sigmas[i], sigma_to = sigmas[i + 1];
-                if (!model(x.data(), sigma, den.data(), nullptr)) return false;
+                if (!model(x.data(), sigma, den.data(), nullptr, i + 1)) return false;
                 if (sigma_to == 0.f) {
                     x = den;
                 } else {

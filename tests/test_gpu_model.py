@@ -152,6 +152,26 @@ def test_activation_folded_into_the_conv_operand_image(sd, oracle, gpu):
     assert k_plain - k_fused == 28   # 20 ReLUs read only by convs lose their launch, 8 more (read by a conv and the residual ADD) merge with the pack pass
 
 
+def test_skip_layer_guidance_parity(sd, oracle, gpu):
+    """Skip-layer guidance on the GPU (SD3.5 tiny, CFG 3 + SLG on joint block 1 in a three-step window): the MMDiT forward without a block is its own graph / plan; trajectory and
+    the skip forward alone against the oracle backend."""
+    rng = np.random.default_rng(61)
+    cond = rng.standard_normal((1, 40, 96)).astype(np.float32)
+    uncond = rng.standard_normal((1, 40, 96)).astype(np.float32)
+    y = rng.standard_normal((1, 64)).astype(np.float32)
+    x = rng.standard_normal((2, 16, 14, 12)).astype(np.float32)
+    t = np.array([731.0, 210.0], dtype=np.float32)
+    kw = dict(width=64, height=96, steps=6, cfg=3.0, seed=8, batch=2, device_batch=2, cond_y=y, uncond_y=y, method=sd.EULER, fuse_cfg=True, slg=([1], 2.5, 0.2, 0.8))
+    res = []
+    for be in (oracle, gpu):
+        e = sd.Engine(model=sd.SD35_TINY, backend=be, flash_attn=True)
+        res.append((e.unet_forward_skip_layers(x, t, np.repeat(cond, 2, 0), np.repeat(y, 2, 0), [0, 2]), e.sample_latents(cond, uncond, **kw)))
+    (f_r, tr_r), (f_g, tr_g) = res
+    print(f"SLG: forward without blocks 0 and 2 rel-L2 {rel_l2(f_g, f_r):.2e}; CFG + SLG trajectory {rel_l2(tr_g, tr_r):.2e}")
+    assert np.isfinite(f_g).all() and rel_l2(f_g, f_r) < 5e-3
+    assert np.isfinite(tr_g).all() and rel_l2(tr_g, tr_r) < 2e-2
+
+
 def test_sampler_trajectory_parity(sd, oracle, gpu):
     """4-step Euler-A with CFG 7, two images in one device batch vs the oracle's independent batch-1 runs."""
     rng = np.random.default_rng(9)

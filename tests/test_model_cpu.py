@@ -432,6 +432,53 @@ def test_inpainting_denoise_mask(sd, oracle, eng15):
     assert rel_l2(out, x[0]) < 2e-4
 
 
+def test_skip_layer_guidance(sd, oracle, eng35, eng15):
+    """Skip-layer guidance (sd_slg_params_t; SkipLayerGuidance, guidance.cpp:296-340; MMDiT::forward's skip_layers, mmdit.hpp:854-866): inside the step window
+    (start, end) x len(sigmas) the denoise call runs the conditional branch once more WITHOUT the listed joint blocks and adds (cond - skip) * scale to the guided prediction.
+    Numpy restatement of a CFG + SLG Euler trajectory on the engine's own forwards; call counts; the forward without blocks is a smaller graph; scale 0 / an empty window / a
+    UNet model leave the trajectory untouched; the device-sampler flag falls back to the host loop."""
+    from test_host_logic import philox_randn_np
+    rng = np.random.default_rng(59)
+    cond = rng.standard_normal((1, 40, 96)).astype(np.float32)
+    uncond = rng.standard_normal((1, 40, 96)).astype(np.float32)
+    y = rng.standard_normal((1, 64)).astype(np.float32)
+    steps, cfg, seed, scale, layers = 6, 3.0, 8, 2.5, [1]
+    kw = dict(width=64, height=64, steps=steps, cfg=cfg, seed=seed, batch=1, cond_y=y, uncond_y=y, method=sd.EULER)
+    sig = sd.get_sigmas_sched(1, sd.SCHED_DISCRETE, steps)
+    start, end = 0.2, 0.8                      # window: step > int(0.2 * 7) = 1 and step < int(0.8 * 7) = 5  ->  steps 2, 3, 4 (1-based)
+    x = (philox_randn_np(seed, 0, 16 * 8 * 8) * sig[0]).astype(np.float32).reshape(1, 16, 8, 8)
+    n_slg = 0
+    for i in range(steps):
+        s = np.float32(sig[i])
+        t = np.array([s * np.float32(1000.0)], dtype=np.float32)
+        ec, eu = eng35.unet_forward(x, t, cond, y), eng35.unet_forward(x, t, uncond, y)
+        g = eu + np.float32(cfg) * (ec - eu)
+        if 1 < i + 1 < 5:
+            g = g + (ec - eng35.unet_forward_skip_layers(x, t, cond, y, layers)) * np.float32(scale)
+            n_slg += 1
+        den = g * (-s) + x
+        x = x + (x - den) / s * (sig[i + 1] - s)
+    assert n_slg == 3
+    nodes_full = eng35.stats()["graph_nodes"]
+    eng35.unet_forward_skip_layers(x, np.array([500.0], np.float32), cond, y, layers)
+    assert eng35.stats()["graph_nodes"] < nodes_full
+    calls0 = eng35.stats()["unet_calls"]
+    out = eng35.sample_latents(cond, uncond, slg=(layers, scale, start, end), **kw)
+    assert eng35.stats()["unet_calls"] - calls0 == 2 * steps + 3
+    assert rel_l2(out, x) < 2e-4
+    plain = eng35.sample_latents(cond, uncond, **kw)
+    assert not np.array_equal(out, plain)
+    np.testing.assert_array_equal(eng35.sample_latents(cond, uncond, slg=(layers, 0.0, start, end), **kw), plain)
+    np.testing.assert_array_equal(eng35.sample_latents(cond, uncond, slg=(layers, scale, 0.5, 0.5), **kw), plain)
+    np.testing.assert_array_equal(eng35.sample_latents(cond, uncond, slg=(layers, scale, start, end), fuse_cfg=True, device_sampler=True, **kw),
+                                  eng35.sample_latents(cond, uncond, slg=(layers, scale, start, end), fuse_cfg=True, **kw))
+    c15 = rng.standard_normal((1, 77, 64)).astype(np.float32)
+    k15 = dict(width=64, height=64, steps=3, cfg=1.0, seed=2, batch=1)
+    np.testing.assert_array_equal(eng15.sample_latents(c15, None, slg=([1], 2.0, 0.0, 1.0), **k15), eng15.sample_latents(c15, None, **k15))   # "SLG is incompatible with this model type"
+    with pytest.raises(sd.EngineError, match="MMDiT"):
+        eng15.unet_forward_skip_layers(np.zeros((1, 4, 8, 8), np.float32), np.array([1.0], np.float32), c15, None, [0])
+
+
 def test_generate_image_end_to_end(sd, oracle, eng15):
     rng = np.random.default_rng(5)
     cond = rng.standard_normal((1, 77, 64)).astype(np.float32)
