@@ -211,36 +211,34 @@ inline bool scheduler_supported(int s) {
 // BetaScheduler's quantile function (denoiser.hpp:308-463) with its default alpha = beta = 0.6: regularised incomplete beta by Lentz's continued fraction, Newton steps
 struct BetaQuantile {
     static double log_beta(double a, double b) { return std::lgamma(a) + std::lgamma(b) - std::lgamma(a + b); }
+    // I_x(a, b) by the modified Lentz evaluation of its continued fraction: every partial numerator `term` updates the pair (D, C) and contributes the factor D * C;
+    // numerators alternate between the even form m (b - m) x / ((a + 2m - 1)(a + 2m)) and the odd form -(a + m)(a + b + m) x / ((a + 2m)(a + 2m + 1)).  Operation order as
+    // the reference evaluates it (the ladders are compared bit for bit).
     static double incbeta(double x, double a, double b) {
         if (x <= 0.0) return 0.0;
         if (x >= 1.0) return 1.0;
-        const int max_iter = 200;
-        const double epsilon = 3.0e-7, tiny = 1e-30;
-        const double qab = a + b, qap = a + 1.0, qam = a - 1.0;
-        double c = 1.0, d = 1.0 - qab * x / qap;
-        if (std::abs(d) < tiny) d = tiny;
-        d        = 1.0 / d;
-        double h = d;
-        for (int m = 1; m <= max_iter; m++) {
+        const double tiny = 1e-30, tol = 3.0e-7;
+        const double apb = a + b, ap1 = a + 1.0, am1 = a - 1.0;
+        double C = 1.0, D = 1.0 - apb * x / ap1;
+        if (std::abs(D) < tiny) D = tiny;
+        D          = 1.0 / D;
+        double frac = D;
+        auto factor = [&](double term) {
+            D = 1.0 + term * D;
+            if (std::abs(D) < tiny) D = tiny;
+            C = 1.0 + term / C;
+            if (std::abs(C) < tiny) C = tiny;
+            D = 1.0 / D;
+            return D * C;
+        };
+        for (int m = 1; m <= 200; m++) {
             const int m2 = 2 * m;
-            double aa    = m * (b - m) * x / ((qam + m2) * (a + m2));
-            d            = 1.0 + aa * d;
-            if (std::abs(d) < tiny) d = tiny;
-            c = 1.0 + aa / c;
-            if (std::abs(c) < tiny) c = tiny;
-            d = 1.0 / d;
-            h *= d * c;
-            aa = -(a + m) * (qab + m) * x / ((a + m2) * (qap + m2));
-            d  = 1.0 + aa * d;
-            if (std::abs(d) < tiny) d = tiny;
-            c = 1.0 + aa / c;
-            if (std::abs(c) < tiny) c = tiny;
-            d                = 1.0 / d;
-            const double del = d * c;
-            h *= del;
-            if (std::abs(del - 1.0) < epsilon) break;
+            frac *= factor(m * (b - m) * x / ((am1 + m2) * (a + m2)));
+            const double last = factor(-(a + m) * (apb + m) * x / ((a + m2) * (ap1 + m2)));
+            frac *= last;
+            if (std::abs(last - 1.0) < tol) break;
         }
-        return std::exp(a * std::log(x) + b * std::log(1.0 - x) - log_beta(a, b)) / a * h;
+        return std::exp(a * std::log(x) + b * std::log(1.0 - x) - log_beta(a, b)) / a * frac;
     }
     static double cdf(double x, double a, double b) {
         if (x == 0.0) return 0.0;
