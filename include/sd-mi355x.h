@@ -32,7 +32,10 @@
  *   generate_image                      :493-496 -> sdm_generate_image (batch_count images, seeds seed+b)
  *   free_sd_images                      :595-597 -> sdm_free_images
  *   sd_*_params_init                             -> sdm_*_params_init
- *   sd_set_backend_eval_callback        :442-447 -> (sub-graph views are honoured by the backend)
+ *   sd_set_backend_eval_callback        :442-447 -> sdm_set_backend_eval_callback (sub-graph views are honoured by the backend)
+ *   sd_img_gen_params_t::init_image / mask_image / strength -> sdm_img_gen_params_t::init_latent (sd_vae_encode) / denoise_mask / strength
+ *   sd_sample_params_t::custom_sigmas / flow_shift / guidance.slg -> the same fields of sdm_sample_params_t (slg_*)
+ *   sd_ctx_params_t::prediction / taesd_path     -> sd_set_prediction / sd_use_tae + sd_load_weights_prefixed(ctx, file, "tae.")
  * Names without a reference counterpart (sd_unet_forward, sd_vae_decode, sd_load_backend, ...) keep the plain `sd_` prefix.
  */
 #ifndef SD_MI355X_H
