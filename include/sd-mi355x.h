@@ -125,6 +125,8 @@ typedef struct {
     const int* slg_layers;      /* skip-layer guidance (sd_slg_params_t; SD3.x): joint blocks left out of one more conditional forward per step inside the window */
     int slg_layer_count;        /* (slg_layer_start, slg_layer_end) x the ladder length; guided += (cond - skip) * slg_scale (guidance.cpp:296-340).  scale 0 = off */
     float slg_layer_start, slg_layer_end, slg_scale;
+    int shifted_timestep;       /* sd_sample_params_t::shifted_timestep (timestep-shifted distilled UNets): > 0: the model sees round(t * shifted_timestep / 1000) and that
+                                   timestep's output scalings (prepare_sample_timesteps / adjust_sample_step_scalings, stable-diffusion.cpp:2411-2457); 0 = off */
     float flow_shift;           /* flow families: the time shift of DiscreteFlowDenoiser (set_flow_shift, stable-diffusion.cpp:3106-3115); INFINITY = the default (SD3.x 3.0, FLUX.1-dev 1.15) */
 } sdm_sample_params_t;
 

@@ -1474,6 +1474,24 @@ static bool resolve_sampling(const sdm_ctx_t* ctx, const sdm_sample_params_t& sp
     if (method == SDM_DDIM_TRAILING_SAMPLE_METHOD) method = SDM_EULER_A_SAMPLE_METHOD;
     return true;
 }
+// scalings and timestep of one model call: Denoiser::get_scalings + sigma_to_t, and — sd_sample_params_t::shifted_timestep > 0 (timestep-shifted distilled UNets) —
+// prepare_sample_timesteps / adjust_sample_step_scalings (stable-diffusion.cpp:2411-2457): the model sees round(t * shift / 1000) and the output scalings of THAT timestep's sigma
+static void step_scalings(const sdm_ctx_t* ctx, const sdm_sample_params_t& sp, float sigma, float& c_skip, float& c_out, float& c_in, float& t) {
+    ctx->scalings(sigma, c_skip, c_out, c_in);
+    t = ctx->sigma_to_t(sigma);
+    if (sp.shifted_timestep > 0 && !ctx->is_dit) {
+        const float shifted_t_float = t * (float(sp.shifted_timestep) / float(TIMESTEPS));
+        int64_t shifted_t           = static_cast<int64_t>(roundf(shifted_t_float));
+        shifted_t                   = std::max((int64_t)0, std::min((int64_t)(TIMESTEPS - 1), shifted_t));
+        t                           = (float)shifted_t;
+        const int64_t idx           = static_cast<int64_t>(roundf(t));
+        const float shifted_sigma   = ctx->denoiser.t_to_sigma((float)idx);
+        float s_skip, s_out, s_in;
+        ctx->scalings(shifted_sigma, s_skip, s_out, s_in);
+        c_skip = s_skip * c_in / s_in;
+        c_out  = s_out;
+    }
+}
 // One denoiser call of the host loop — the reference's `denoise` lambda (stable-diffusion.cpp:2620-2926) on nb images: scalings and timestep of sigma, x * c_in, the model
 // forward(s) (the cond / uncond pair in ONE graph when the conditionings allow it), classifier-free guidance, pred * c_out + x * c_skip.
 struct HostDenoise {
@@ -1495,9 +1513,8 @@ struct HostDenoise {
     bool operator()(const float* x, float sigma, float* denoised, float* denoised_uncond = nullptr, int step = 0) {
         const sdm_sample_params_t& sp = p->sample_params;
         const size_t n = per * (size_t)nb;
-        float c_skip, c_out, c_in;
-        ctx->scalings(sigma, c_skip, c_out, c_in);
-        const float t = ctx->sigma_to_t(sigma);
+        float c_skip, c_out, c_in, t;
+        step_scalings(ctx, sp, sigma, c_skip, c_out, c_in, t);
         for (int b = 0; b < nb; ++b) ts[b] = t;
         for (size_t k = 0; k < n; ++k) noised[k] = x[k] * c_in;  // stable-diffusion.cpp:2662
         auto run = [&](const sd_condition_t& cd, float* dst) {
@@ -1807,9 +1824,9 @@ static bool sample_group_device(sdm_ctx_t* ctx, const sdm_img_gen_params_t* p, i
 
     for (int i = 0; i < steps; ++i) {
         const float sigma = sigmas[i], sigma_to = sigmas[i + 1];
-        float c_skip, c_out, c_in;
-        ctx->scalings(sigma, c_skip, c_out, c_in);
-        std::fill(ts.begin(), ts.end(), ctx->sigma_to_t(sigma));
+        float c_skip, c_out, c_in, t_model;
+        step_scalings(ctx, sp, sigma, c_skip, c_out, c_in, t_model);
+        std::fill(ts.begin(), ts.end(), t_model);
         // scalars of this step: {c_in, cfg scale, c_out, c_skip, a, b, noise gain, alpha}; Euler-A: x' = (a*x + b*denoised) [* alpha on flow models] + gain*noise;
         // Euler: x' = x + ((x - denoised) / a) * b with a = sigma, b = sigma_to - sigma
         float sc[8] = {c_in, pair ? (ctx->pair_branch == 0 ? sp.txt_cfg : 1.0f - sp.txt_cfg) : sp.txt_cfg, c_out, c_skip, 0.f, 0.f, 0.f, 1.f};

@@ -401,6 +401,22 @@ def test_custom_sigmas_flow_shift_and_v_prediction(sd, oracle, eng15, eng35):
         e.set_prediction(2)
     with pytest.raises(sd.EngineError, match="flow"):
         eng35.set_prediction(1)
+    # shifted_timestep (prepare_sample_timesteps / adjust_sample_step_scalings, stable-diffusion.cpp:2411-2457): the model sees round(t * 250 / 1000), the output scalings are
+    # those of that timestep's sigma and c_skip = shifted c_skip * c_in / shifted c_in
+    x = (philox_randn_np(13, 0, 4 * 8 * 8) * sig[0]).astype(np.float32).reshape(1, 4, 8, 8)
+    for i in range(5):
+        s = np.float32(sig[i])
+        c_in = np.float32(1.0) / np.sqrt(s * s + np.float32(1.0))
+        ts = np.float32(np.clip(np.round(np.float32(sd.lib().sd_sigma_to_t(float(s))) * np.float32(250.0 / 1000.0)), 0, 999))
+        ss = np.float32(sd.get_sigmas_sched(0, sd.SCHED_DISCRETE, 1000)[999 - int(ts)])      # t_to_sigma of an integer timestep = the 1000-step discrete ladder's entry
+        c_skip = np.float32(1.0) * c_in / (np.float32(1.0) / np.sqrt(ss * ss + np.float32(1.0)))
+        ec, eu = e.unet_forward(x * c_in, np.array([ts], np.float32), cond), e.unet_forward(x * c_in, np.array([ts], np.float32), uncond)
+        den = (eu + np.float32(3.0) * (ec - eu)) * (-ss) + x * c_skip
+        x = x + (x - den) / s * (sig[i + 1] - s)
+    sh = e.sample_latents(cond, uncond, method=sd.EULER, shifted_timestep=250, **kw)
+    assert rel_l2(sh, x) < 2e-4 and not np.array_equal(sh, eps_out)
+    np.testing.assert_array_equal(e.sample_latents(cond, uncond, method=sd.EULER, shifted_timestep=250, fuse_cfg=True, device_sampler=True, **kw),
+                                  e.sample_latents(cond, uncond, method=sd.EULER, shifted_timestep=250, fuse_cfg=True, **kw))
 
 
 def test_inpainting_denoise_mask(sd, oracle, eng15):
