@@ -125,6 +125,9 @@ typedef struct {
     const int* slg_layers;      /* skip-layer guidance (sd_slg_params_t; SD3.x): joint blocks left out of one more conditional forward per step inside the window */
     int slg_layer_count;        /* (slg_layer_start, slg_layer_end) x the ladder length; guided += (cond - skip) * slg_scale (guidance.cpp:296-340).  scale 0 = off */
     float slg_layer_start, slg_layer_end, slg_scale;
+    float apg_eta, apg_momentum, apg_norm_threshold, apg_norm_threshold_smoothing; /* adaptive projected guidance (the reference's extra_sample_args apg_eta / apg_momentum /
+                                   apg_norm_threshold / apg_norm_threshold_smoothing; AdaptiveProjectedGuidance, guidance.cpp:209-294) in place of plain CFG on the
+                                   (cond, uncond) pair; neutral values (1, 0, 0, 0) = off */
     int shifted_timestep;       /* sd_sample_params_t::shifted_timestep (timestep-shifted distilled UNets): > 0: the model sees round(t * shifted_timestep / 1000) and that
                                    timestep's output scalings (prepare_sample_timesteps / adjust_sample_step_scalings, stable-diffusion.cpp:2411-2457); 0 = off */
     float flow_shift;           /* flow families: the time shift of DiscreteFlowDenoiser (set_flow_shift, stable-diffusion.cpp:3106-3115); INFINITY = the default (SD3.x 3.0, FLUX.1-dev 1.15) */
@@ -274,6 +277,9 @@ SD_API int sd_sample_synthetic2(int family, int steps, int image_seq_len, int64_
 /* sigma ladder of a denoiser family (0 CompVis SD1.x, 1 discrete flow, 2 FLUX flow, 3 CompVis with the SDXL Align-Your-Steps table) under a scheduler; shift <= 0: the family's default;
  * returns the count (steps + 1) or -1 for a scheduler that is not implemented */
 SD_API int sd_get_sigmas_sched(int family, int scheduler, int steps, int image_seq_len, float shift, float* out);
+/* adaptive projected guidance over `steps` successive calls on one image of n floats (cond / uncond / out: [steps][n]); for the bit-exact test against guidance.cpp */
+SD_API void sd_apg_sequence(const float* cond, const float* uncond, int64_t n, int steps, float scale, float eta, float momentum, float norm_threshold,
+                            float norm_threshold_smoothing, float* out);
 /* AutoEncoderKL::set_conv2d_scale (src/model/vae/auto_encoder_kl.hpp:708-717): every Conv2d of the VAE computes conv(x * s) / s + bias.  SDXL contexts start with
  * s = 1/32 — what the reference sets when no external VAE is given (src/stable-diffusion.cpp:1477-1485; `--vae` with a fixed VAE -> call this with 1) */
 SD_API bool sd_set_vae_conv2d_scale(sdm_ctx_t* ctx, float scale); /* false (sd_last_error) for a non-finite or non-positive scale; loading a file under the

@@ -38,3 +38,26 @@ extern "C" __attribute__((visibility("default"))) int ref_cfg_combine(const floa
     std::memcpy(out, o.pred.data(), sizeof(float) * (size_t)n);
     return 0;
 }
+
+// AdaptiveProjectedGuidance::forward (guidance.cpp:181-294) over `steps` successive calls of ONE guider object (the momentum buffer lives in it): cond / uncond / out are
+// [steps][n]; returns 0, -1 on a size mismatch
+extern "C" __attribute__((visibility("default"))) int ref_apg_sequence(const float* cond, const float* uncond, int64_t n, int steps, float guidance_scale, float eta, float momentum,
+                                                                       float norm_threshold, float norm_threshold_smoothing, float* out) {
+    sd::guidance::AdaptiveProjectedGuidanceParams prm;
+    prm.eta                      = eta;
+    prm.momentum                 = momentum;
+    prm.norm_threshold           = norm_threshold;
+    prm.norm_threshold_smoothing = norm_threshold_smoothing;
+    sd::guidance::AdaptiveProjectedGuidance g(guidance_scale, 1.0f, prm);
+    for (int s = 0; s < steps; ++s) {
+        sd::Tensor<float> c({n}, std::vector<float>(cond + (size_t)s * n, cond + (size_t)(s + 1) * n));
+        sd::Tensor<float> u({n}, std::vector<float>(uncond + (size_t)s * n, uncond + (size_t)(s + 1) * n));
+        sd::guidance::GuidanceInput in;
+        in.pred_cond   = &c;
+        in.pred_uncond = &u;
+        const sd::guidance::GuiderOutput o = g.forward(in, sd::guidance::GuiderOutput{});
+        if (o.pred.numel() != n) return -1;
+        std::memcpy(out + (size_t)s * n, o.pred.data(), sizeof(float) * (size_t)n);
+    }
+    return 0;
+}

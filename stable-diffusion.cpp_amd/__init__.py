@@ -84,6 +84,7 @@ class SdSampleParams(C.Structure):
     _fields_ = [("txt_cfg", C.c_float), ("scheduler", C.c_int), ("sample_method", C.c_int),
                 ("sample_steps", C.c_int), ("eta", C.c_float), ("custom_sigmas", C.c_void_p), ("custom_sigmas_count", C.c_int),
                 ("slg_layers", C.c_void_p), ("slg_layer_count", C.c_int), ("slg_layer_start", C.c_float), ("slg_layer_end", C.c_float), ("slg_scale", C.c_float),
+                ("apg_eta", C.c_float), ("apg_momentum", C.c_float), ("apg_norm_threshold", C.c_float), ("apg_norm_threshold_smoothing", C.c_float),
                 ("shifted_timestep", C.c_int), ("flow_shift", C.c_float)]
 
 
@@ -690,7 +691,7 @@ class Engine:
             raise EngineError("sd_use_tae failed: " + L.sd_last_error().decode())
 
     def _gen_params(self, cond, uncond, width, height, steps, cfg, seed, batch, device_batch, method, eta, cond_y=None, uncond_y=None,
-                    fuse_cfg=False, device_sampler=False, scheduler=SCHEDULER_DEFAULT, init_latent=None, strength=0.75, custom_sigmas=None, flow_shift=None, denoise_mask=None, slg=None, shifted_timestep=0):
+                    fuse_cfg=False, device_sampler=False, scheduler=SCHEDULER_DEFAULT, init_latent=None, strength=0.75, custom_sigmas=None, flow_shift=None, denoise_mask=None, slg=None, shifted_timestep=0, apg=None):
         p = SdImgGenParams()
         lib().sdm_img_gen_params_init(C.byref(p))
         keep = []
@@ -726,6 +727,8 @@ class Engine:
             p.sample_params.custom_sigmas = cs.ctypes.data_as(C.c_void_p)
             p.sample_params.custom_sigmas_count = cs.size
         p.sample_params.shifted_timestep = shifted_timestep
+        if apg is not None:   # (eta, momentum, norm_threshold, norm_threshold_smoothing)
+            p.sample_params.apg_eta, p.sample_params.apg_momentum, p.sample_params.apg_norm_threshold, p.sample_params.apg_norm_threshold_smoothing = apg
         if flow_shift is not None:
             p.sample_params.flow_shift = flow_shift
         if slg is not None:   # (layers, scale[, start, end])
@@ -750,11 +753,11 @@ class Engine:
 
     def sample_latents(self, cond, uncond=None, width=512, height=512, steps=20, cfg=7.0, seed=42, batch=1, device_batch=0,
                        method=SAMPLE_METHOD_DEFAULT, eta=float("inf"), cond_y=None, uncond_y=None, fuse_cfg=False, device_sampler=False,
-                       scheduler=SCHEDULER_DEFAULT, init_latent=None, strength=0.75, custom_sigmas=None, flow_shift=None, denoise_mask=None, slg=None, shifted_timestep=0) -> np.ndarray:
+                       scheduler=SCHEDULER_DEFAULT, init_latent=None, strength=0.75, custom_sigmas=None, flow_shift=None, denoise_mask=None, slg=None, shifted_timestep=0, apg=None) -> np.ndarray:
         """init_latent [C,h/8,w/8] (+ strength): img2img — the trajectory starts from the noised init latent, (int)(steps * strength) steps before the end of the ladder;
         custom_sigmas: the ladder to use instead of the scheduler's; flow_shift: the flow families' time shift."""
         p, keep = self._gen_params(cond, uncond, width, height, steps, cfg, seed, batch, device_batch, method, eta, cond_y, uncond_y, fuse_cfg,
-                                   device_sampler, scheduler, init_latent, strength, custom_sigmas, flow_shift, denoise_mask, slg, shifted_timestep)
+                                   device_sampler, scheduler, init_latent, strength, custom_sigmas, flow_shift, denoise_mask, slg, shifted_timestep, apg)
         ch = 16 if self.model in (SD35_LARGE, SD35_TINY, FLUX_DEV, FLUX_TINY, SD35_WIDE2, FLUX_WIDE1, SD3M_TINY, SD35_WIDE8, FLUX_WIDE8) else 4
         out = np.empty((batch, ch, height // 8, width // 8), dtype=np.float32)
         if not lib().sd_sample_latents(self._ctx, C.byref(p), _fptr(out)):
@@ -967,6 +970,17 @@ def get_sigmas_sched(family: int, scheduler: int, steps: int, image_seq_len: int
     if k < 0:
         raise EngineError(f"sd_get_sigmas_sched: scheduler {scheduler} is not implemented")
     return out[:k].copy()
+
+
+def apg_sequence(cond: np.ndarray, uncond: np.ndarray, scale: float, eta: float, momentum: float, norm_threshold: float, smoothing: float) -> np.ndarray:
+    """sd_apg_sequence: adaptive projected guidance over successive calls ([steps, n] arrays) of one image."""
+    c, u = _f32(cond), _f32(uncond)
+    out = np.empty_like(c)
+    L = lib()
+    L.sd_apg_sequence.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]
+    L.sd_apg_sequence.restype = None
+    L.sd_apg_sequence(c.ctypes.data, u.ctypes.data, c.shape[1], c.shape[0], scale, eta, momentum, norm_threshold, smoothing, out.ctypes.data)
+    return out
 
 
 def get_sigmas(steps: int) -> np.ndarray:

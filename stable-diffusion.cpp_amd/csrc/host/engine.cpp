@@ -593,6 +593,7 @@ void sdm_sample_params_init(sdm_sample_params_t* p) {  // stable-diffusion.cpp:3
     p->sample_steps  = 20;
     p->eta           = INFINITY;
     p->flow_shift    = INFINITY;  // the family's default (stable-diffusion.cpp:3665, 3106-3115)
+    p->apg_eta         = 1.0f;    // AdaptiveProjectedGuidanceParams defaults (guidance.h:21-26): all neutral = plain classifier-free guidance
     p->slg_layer_start = 0.01f;   // stable-diffusion.cpp:3655-3658
     p->slg_layer_end   = 0.2f;
 }
@@ -1502,6 +1503,7 @@ struct HostDenoise {
     bool use_cfg;
     std::vector<float> noised, cond_out, uncond_out, ts, skip_out;
     int n_sigmas = 0;  // sigmas.size() of the trajectory (GuidanceInput::schedule_size)
+    std::vector<std::vector<float>> apg_momentum;  // adaptive projected guidance: one momentum buffer per image
     std::vector<float> x2, o2, t2, c2, y2;  // staging of the fused (cond, uncond) pair
     HostDenoise(sdm_ctx_t* ctx_, const sdm_img_gen_params_t* p_, int W_, int H_, int C_, int nb_)
         : ctx(ctx_), p(p_), W(W_), H(H_), C(C_), nb(nb_), per((size_t)W_ * H_ * C_), use_cfg(p_->sample_params.txt_cfg != 1.0f && p_->uncond.c_crossattn != nullptr),
@@ -1520,6 +1522,17 @@ struct HostDenoise {
         auto run = [&](const sd_condition_t& cd, float* dst) {
             return sd_unet_forward(ctx, noised.data(), W, H, C, nb, ts.data(), cd.c_crossattn, cd.ctx_dim, cd.n_tokens, 1,
                                    cd.c_vector, cd.vector_dim, 1, dst);
+        };
+        // the primary guidance of the (cond, uncond) pair: classifier-free (guidance.cpp:171) or, with any apg_* parameter set, adaptive projected guidance per image
+        // (guidance.cpp:209-294; the momentum buffer lives as long as the trajectory, like the reference's guider object)
+        auto guide = [&](float* dst) {
+            const ApgParams apg{sp.apg_eta, sp.apg_momentum, sp.apg_norm_threshold, sp.apg_norm_threshold_smoothing};
+            if (apg.enabled()) {
+                if (apg_momentum.size() != (size_t)nb) apg_momentum.assign((size_t)nb, std::vector<float>());
+                for (int b = 0; b < nb; ++b) apg_guided(&cond_out[(size_t)b * per], &uncond_out[(size_t)b * per], per, sp.txt_cfg, apg, apg_momentum[(size_t)b], dst + (size_t)b * per);
+            } else {
+                for (size_t k = 0; k < n; ++k) dst[k] = cfg_guided(cond_out[k], uncond_out[k], sp.txt_cfg);
+            }
         };
         if (use_cfg && p->fuse_cfg_pair && p->cond.ctx_dim == p->uncond.ctx_dim && p->cond.n_tokens == p->uncond.n_tokens) {
             // one graph for the cond/uncond pair: images interleaved (b cond, b uncond, ...); context/y have batch 2 and are
@@ -1551,12 +1564,12 @@ struct HostDenoise {
                 memcpy(&cond_out[b * per], &o2[(2 * b) * per], per * sizeof(float));
                 memcpy(&uncond_out[b * per], &o2[(2 * b + 1) * per], per * sizeof(float));
             }
-            for (size_t k = 0; k < n; ++k) denoised[k] = cfg_guided(cond_out[k], uncond_out[k], sp.txt_cfg);
+            guide(denoised);
         } else if (!run(p->cond, cond_out.data())) {
             return false;
         } else if (use_cfg) {
             if (!run(p->uncond, uncond_out.data())) return false;
-            for (size_t k = 0; k < n; ++k) denoised[k] = cfg_guided(cond_out[k], uncond_out[k], sp.txt_cfg);  // guidance.cpp:171
+            guide(denoised);
         } else {
             for (size_t k = 0; k < n; ++k) denoised[k] = cond_out[k];
         }
@@ -1740,6 +1753,7 @@ static bool sample_group_device(sdm_ctx_t* ctx, const sdm_img_gen_params_t* p, i
     }
     if (method != SDM_EULER_SAMPLE_METHOD && method != SDM_EULER_A_SAMPLE_METHOD) return true;  // multi-stage / multi-step samplers: the host loop around the device forward
     if (p->denoise_mask && p->init_latent) return true;  // the inpainting blend lives in the host loop's denoise call
+    if (ApgParams{sp.apg_eta, sp.apg_momentum, sp.apg_norm_threshold, sp.apg_norm_threshold_smoothing}.enabled()) return true;  // adaptive projected guidance: norms and a momentum buffer on the host
     if (sp.slg_scale != 0.0f && sp.slg_layers && sp.slg_layer_count > 0 && ctx->is_dit && !ctx->is_flux) return true;  // skip-layer guidance: a third forward inside a step window
     *handled = true;
     const size_t per = (size_t)W * H * C;
@@ -2170,6 +2184,12 @@ int sd_get_sigmas_sched(int family, int scheduler, int steps, int image_seq_len,
     }
     memcpy(out, s.data(), s.size() * sizeof(float));
     return (int)s.size();
+}
+// adaptive projected guidance over `steps` successive denoise calls of one image (momentum carried), for the bit-exact test against the reference's guidance.cpp
+void sd_apg_sequence(const float* cond, const float* uncond, int64_t n, int steps, float scale, float eta, float momentum, float norm_threshold, float norm_threshold_smoothing, float* out) {
+    const ApgParams prm{eta, momentum, norm_threshold, norm_threshold_smoothing};
+    std::vector<float> buf;
+    for (int s = 0; s < steps; ++s) apg_guided(cond + (size_t)s * n, uncond + (size_t)s * n, (size_t)n, scale, prm, buf, out + (size_t)s * n);
 }
 void sd_cfg_combine(const float* cond, const float* uncond, int64_t n, float scale, float* out) {
     for (int64_t k = 0; k < n; ++k) out[k] = cfg_guided(cond[k], uncond[k], scale);

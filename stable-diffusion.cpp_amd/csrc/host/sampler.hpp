@@ -1210,6 +1210,61 @@ inline float cfg_guided(float cond, float uncond, float scale) {
     return uncond + s;
 }
 
+// AdaptiveProjectedGuidance::forward for the (cond, uncond) pair of ONE image of n floats — src/runtime/guidance.cpp:209-294: the guidance delta cond - uncond with momentum
+// (the buffer is carried by the caller from step to step), rescaled to a norm threshold (norm measured at SDXL's standard resolution), its component parallel to cond
+// scaled by eta; pred = cond + (scale - 1) * delta.  sd::Tensor<float>::sum accumulates in double and rounds once (tensor.hpp:340-347).  scale == 1: the reference returns cond.
+struct ApgParams {
+    float eta = 1.0f, momentum = 0.0f, norm_threshold = 0.0f, norm_threshold_smoothing = 0.0f;
+    bool enabled() const { return eta != 1.0f || momentum != 0.0f || norm_threshold > 0.0f; }  // is_adaptive_projected_guidance_enabled, guidance.cpp:18-20
+};
+inline void apg_guided(const float* cond, const float* uncond, size_t n, float scale, const ApgParams& prm, std::vector<float>& momentum_buffer, float* out) {
+    std::vector<float> deltas(n);
+    for (size_t k = 0; k < n; ++k) deltas[k] = cond[k] - uncond[k];
+    if (prm.momentum != 0.0f) {
+        if (momentum_buffer.size() != n) momentum_buffer.assign(n, 0.0f);
+        for (size_t k = 0; k < n; ++k) deltas[k] += prm.momentum * momentum_buffer[k];
+        momentum_buffer = deltas;
+    }
+    auto sum_prod = [&](const float* a, const float* b) {
+        double total = 0.0;
+        for (size_t k = 0; k < n; ++k) {
+            const float pr = a[k] * b[k];
+            total += static_cast<double>(pr);
+        }
+        return static_cast<float>(total);
+    };
+    float diff_norm        = 0.0f;
+    const int standard_res = 2 * 1024 / 8;
+    if (prm.norm_threshold > 0.0f) diff_norm = std::sqrt(sum_prod(deltas.data(), deltas.data())) * standard_res / std::sqrt(static_cast<float>(n));
+    float factor = 1.0f;
+    if (prm.norm_threshold > 0.0f && diff_norm > 0.0f) {
+        if (prm.norm_threshold_smoothing <= 0.0f) {
+            factor = std::min(1.0f, prm.norm_threshold / diff_norm);
+        } else {
+            const float x = prm.norm_threshold / diff_norm;
+            factor        = x / std::pow(1.0f + std::pow(x, 1.0f / prm.norm_threshold_smoothing), prm.norm_threshold_smoothing);
+        }
+    }
+    for (size_t k = 0; k < n; ++k) deltas[k] *= factor;
+    if (prm.eta != 1.0f) {
+        const float cond_norm_sq = sum_prod(cond, cond);
+        if (cond_norm_sq != 0.0f) {
+            const float projection_scale = sum_prod(cond, deltas.data()) / cond_norm_sq;
+            const float em1              = prm.eta - 1.0f;
+            for (size_t k = 0; k < n; ++k) {
+                const float pc = projection_scale * cond[k];
+                deltas[k] += em1 * pc;
+            }
+        }
+    }
+    if (scale != 1.0f) {
+        const float sm1 = scale - 1.0f;
+        for (size_t k = 0; k < n; ++k) out[k] = cond[k] + sm1 * deltas[k];
+    } else {
+        for (size_t k = 0; k < n; ++k) out[k] = cond[k];
+    }
+}
+
 // One sampler update on `nb` images of `per` floats each — the arithmetic of the reference's sd::Tensor<float> expressions, operation by operation (every
 // tensor operator rounds to f32; scalars are cast to float before they meet the tensor, src/core/tensor.hpp:612-618, 750-760):
 //   Euler-A  (sample_euler_ancestral, src/runtime/denoiser.hpp:1513-1546):  sigma_to == 0: x = denoised;

@@ -495,6 +495,37 @@ def test_skip_layer_guidance(sd, oracle, eng35, eng15):
         eng15.unet_forward_skip_layers(np.zeros((1, 4, 8, 8), np.float32), np.array([1.0], np.float32), c15, None, [0])
 
 
+def test_adaptive_projected_guidance_through_the_engine(sd, oracle, eng15):
+    """apg_* on the denoise call (the arithmetic is pinned bit for bit against the reference's guidance.cpp in test_host_logic.py): an Euler trajectory restated in numpy with
+    the pinned apg_sequence as the guider (momentum carried from step to step, one buffer per image); neutral parameters are plain CFG; the device-sampler flag falls back."""
+    from test_host_logic import philox_randn_np
+    rng = np.random.default_rng(67)
+    cond = rng.standard_normal((1, 77, 64)).astype(np.float32)
+    uncond = rng.standard_normal((1, 77, 64)).astype(np.float32)
+    steps, cfg, seed, apg = 4, 6.0, 31, (0.3, -0.5, 12.0, 0.0)
+    kw = dict(width=64, height=64, steps=steps, cfg=cfg, seed=seed, batch=1, method=sd.EULER)
+    sig = sd.get_sigmas(steps)
+    x = (philox_randn_np(seed, 0, 4 * 8 * 8) * sig[0]).astype(np.float32).reshape(1, 4, 8, 8)
+    conds, unconds = [], []
+    for i in range(steps):
+        s = np.float32(sig[i])
+        c_in = np.float32(1.0) / np.sqrt(s * s + np.float32(1.0))
+        t = np.array([sd.lib().sd_sigma_to_t(float(s))], dtype=np.float32)
+        conds.append(eng15.unet_forward(x * c_in, t, cond).ravel())
+        unconds.append(eng15.unet_forward(x * c_in, t, uncond).ravel())
+        g = sd.apg_sequence(np.stack(conds), np.stack(unconds), cfg, *apg)[-1].reshape(x.shape)   # the whole history: the momentum buffer is rebuilt call by call
+        den = g * (-s) + x
+        x = x + (x - den) / s * (sig[i + 1] - s)
+    out = eng15.sample_latents(cond, uncond, apg=apg, **kw)
+    assert rel_l2(out, x) < 2e-4
+    plain = eng15.sample_latents(cond, uncond, **kw)
+    assert not np.array_equal(out, plain)
+    np.testing.assert_array_equal(eng15.sample_latents(cond, uncond, apg=(1.0, 0.0, 0.0, 0.0), **kw), plain)
+    np.testing.assert_array_equal(eng15.sample_latents(cond, uncond, apg=apg, fuse_cfg=True, device_sampler=True, **kw), eng15.sample_latents(cond, uncond, apg=apg, fuse_cfg=True, **kw))
+    two = eng15.sample_latents(cond, uncond, apg=apg, fuse_cfg=True, **dict(kw, batch=2, device_batch=2))
+    np.testing.assert_allclose(two[0], eng15.sample_latents(cond, uncond, apg=apg, fuse_cfg=True, **kw)[0], rtol=0, atol=1e-5)
+
+
 def test_generate_image_end_to_end(sd, oracle, eng15):
     rng = np.random.default_rng(5)
     cond = rng.standard_normal((1, 77, 64)).astype(np.float32)
